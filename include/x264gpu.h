@@ -1,0 +1,155 @@
+/* include/x264gpu.h — boundary B3: thin C ABI between the host encoder (behind x264_encoder_encode,
+ * reference call site codec.c:1693) and the hand-written HIP kernels for gfx950.
+ *
+ * Plain C: pointers + sizes only, no C++/torch types.  All `d_` pointers are device (HBM) pointers,
+ * `stream` is a hipStream_t passed as void* (NULL = default stream).  Every function returns 0 on
+ * success or a negative X264GPU_E* code; there is NO CPU fallback — without a GPU the calls fail.
+ *
+ * Each entry point names the libx264 internal it replaces — libx264 itself is not
+ * in the reference tree, so the citation is the reference call site plus the upstream location.
+ */
+#ifndef X264GPU_H
+#define X264GPU_H
+#include <stdint.h>
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define X264GPU_ABI_VERSION 1
+enum { X264GPU_OK = 0, X264GPU_EINVAL = -1, X264GPU_EHIP = -2, X264GPU_ENOMEM = -3, X264GPU_ENODEV = -4 };
+
+/* ------------------------------------------------------------------------------------------------
+ * runtime / memory (so C callers and ctypes tests need nothing but this library)
+ * ---------------------------------------------------------------------------------------------- */
+int  x264gpu_abi_version(void);
+int  x264gpu_device_count(void);               /* 0 when no GPU is visible */
+int  x264gpu_set_device(int dev);
+const char *x264gpu_last_error(void);
+int  x264gpu_malloc(void **d_ptr, size_t bytes);
+int  x264gpu_free(void *d_ptr);
+int  x264gpu_memcpy_h2d(void *d_dst, const void *h_src, size_t bytes, void *stream);
+int  x264gpu_memcpy_d2h(void *h_dst, const void *d_src, size_t bytes, void *stream);
+int  x264gpu_memset(void *d_dst, int value, size_t bytes, void *stream);
+int  x264gpu_stream_sync(void *stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Tier 1 — DSP primitives in batch form (the "checkasm" surface: same device code the frame
+ * pipeline uses, exposed so every primitive is parity-tested against oracle/ in isolation).
+ * Block arrays are tightly packed: block i of a WxH batch starts at base + i*W*H, row stride W.
+ * ---------------------------------------------------------------------------------------------- */
+/* A2/A3: pixel_sad_WxH, pixel_satd_WxH, pixel_sa8d_{8x8,16x16}, pixel_ssd, pixel_var
+ * ([x264-upstream] common/pixel.c).  metric: 0 SAD, 1 SATD, 2 SA8D, 3 SSD.  W,H in {4,8,16}. */
+int x264gpu_pixel_metric(int metric, const uint8_t *d_a, const uint8_t *d_b, int n, int w, int h,
+                         int32_t *d_out, void *stream);
+/* pixel_var_{16x16,8x8}: out[i] = sum | (sqr << 32) */
+int x264gpu_pixel_var(const uint8_t *d_a, int n, int w, int h, uint64_t *d_out, void *stream);
+
+/* A6/A7/A8: sub4x4_dct -> quant_4x4 -> (levels out) -> dequant_4x4 -> add4x4_idct, per 4x4 block
+ * ([x264-upstream] common/dct.c, common/quant.c).  enc/pred: n blocks of 4x4 u8.  Outputs (any may be
+ * NULL): coef = forward transform, levels = quantised (raster order), recon = reconstructed pixels.
+ * list: 0 intra-luma 1 inter-luma 2 intra-chroma 3 inter-chroma (deadzone lists). */
+int x264gpu_dctq4x4(const uint8_t *d_enc, const uint8_t *d_pred, int n, int qp, int list,
+                    int16_t *d_coef, int16_t *d_levels, uint8_t *d_recon, void *stream);
+/* 8x8 transform path: sub8x8_dct8 -> quant_8x8 -> dequant_8x8 -> add8x8_idct8.  list: 0 intra 1 inter */
+int x264gpu_dctq8x8(const uint8_t *d_enc, const uint8_t *d_pred, int n, int qp, int list,
+                    int16_t *d_coef, int16_t *d_levels, uint8_t *d_recon, void *stream);
+
+/* A5: intra predictors ([x264-upstream] common/predict.c; H.264 8.3).  d_plane is a reconstructed
+ * plane (stride bytes); block i sits at pixel (xy[2i], xy[2i+1]); out = n tightly packed predictions.
+ * kind: 0 = 16x16 luma, 1 = 8x8 chroma, 2 = 4x4 luma.  avail: X264O_AVAIL_* style bits (4x4 only). */
+int x264gpu_intra_predict(int kind, const uint8_t *d_plane, int stride, const int32_t *d_xy,
+                          const int32_t *d_mode, const int32_t *d_avail, int n, uint8_t *d_out, void *stream);
+
+/* A4: hpel_filter + border expansion ([x264-upstream] common/mc.c hpel_filter, common/frame.c
+ * x264_frame_filter / frame_expand_border).  d_planes = 4 contiguous padded planes (full,H,V,HV), each
+ * plane_bytes apart; pointers address the padded origin; sample (0,0) is at pad*stride+pad.
+ * Reads plane 0 interior (w x h), writes all of planes 1..3 and the border of plane 0. */
+int x264gpu_hpel_filter(uint8_t *d_planes, size_t plane_bytes, int stride, int w, int h, int pad, void *stream);
+/* A1: frame_init_lowres_core ([x264-upstream] common/mc.c): 4 half-res planes, dst stride ds */
+int x264gpu_lowres(const uint8_t *d_src, int ss, int w, int h, uint8_t *d_dst, size_t plane_bytes, int ds,
+                   void *stream);
+/* A10: mc_luma / get_ref and mc_chroma ([x264-upstream] common/mc.c).  Block i of size w x h at
+ * (xy[2i],xy[2i+1]) with quarter-pel mv (mv[2i],mv[2i+1]); luma reads the 4 padded planes, chroma
+ * reads a padded NV12 plane (d_ref addresses sample (0,0)) and writes U then V blocks. */
+int x264gpu_mc_luma(const uint8_t *d_planes00, size_t plane_bytes, int stride, const int32_t *d_xy,
+                    const int32_t *d_mv, int n, int w, int h, uint8_t *d_out, void *stream);
+int x264gpu_mc_chroma(const uint8_t *d_nv12_00, int stride, const int32_t *d_xy, const int32_t *d_mv,
+                      int n, int w, int h, uint8_t *d_out, void *stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Tier 2 — frame pipeline: the hot path of x264_encoder_encode for a batch of independent
+ * closed-GOP streams (one launch covers `streams` frames of identical geometry).
+ * ---------------------------------------------------------------------------------------------- */
+enum { X264GPU_MB_I4x4 = 0, X264GPU_MB_I16x16 = 2, X264GPU_MB_P_L0 = 4, X264GPU_MB_P_8x8 = 5,
+       X264GPU_MB_P_SKIP = 6 };
+enum { X264GPU_SLICE_P = 0, X264GPU_SLICE_B = 1, X264GPU_SLICE_I = 2 };
+
+/* per-macroblock decision record written by the GPU, consumed by the host entropy coder (64 B) */
+typedef struct x264gpu_mb {
+    uint8_t  type;          /* X264GPU_MB_* */
+    uint8_t  i16_mode;      /* intra 16x16 prediction mode (I_PRED_16x16_*, real modes 0..3) */
+    uint8_t  chroma_mode;   /* intra chroma prediction mode 0..3 */
+    uint8_t  qp;            /* luma qp used for this macroblock */
+    uint8_t  cbp_luma;      /* bit i = 8x8 block i has coded coefficients */
+    uint8_t  cbp_chroma;    /* 0 none, 1 DC only, 2 DC+AC */
+    uint8_t  partition;     /* 0 16x16, 1 16x8, 2 8x16, 3 8x8 (P only) */
+    int8_t   ref[4];        /* reference index per 8x8 */
+    uint8_t  i4_mode[16];   /* intra 4x4 modes, x264 block order (zigzag-of-8x8) */
+    int16_t  mv[4][2];      /* quarter-pel motion vector per 8x8 (x,y) */
+    uint32_t nnz;           /* bit b (0..15 luma blk order, 16..19 U, 20..23 V, 24 lumaDC, 25 U DC, 26 V DC) */
+    int32_t  cost;          /* analysis cost of the chosen mode (diagnostic) */
+    uint8_t  pad[9];
+} x264gpu_mb;
+
+/* quantised levels per macroblock, scan (zigzag) order, int16:
+ *   [0..255]   16 luma 4x4 blocks x 16 (x264 block order; for I16x16 index 0 of each block is unused/0)
+ *   [256..271] luma DC (I16x16 only)
+ *   [272..279] chroma DC: U[4], V[4]
+ *   [280..407] chroma AC: 8 blocks x 16 (index 0 of each unused/0)
+ *   [408..415] padding   -> 416 int16 = 832 bytes */
+#define X264GPU_MB_LEVELS 416
+#define X264GPU_LV_LUMA 0
+#define X264GPU_LV_LUMA_DC 256
+#define X264GPU_LV_CHROMA_DC 272
+#define X264GPU_LV_CHROMA_AC 280
+
+typedef struct x264gpu_encoder x264gpu_encoder;  /* opaque: owns the device-resident DPB + work buffers */
+
+typedef struct x264gpu_config {
+    int width, height;        /* luma picture size (even) */
+    int streams;              /* independent streams/closed GOPs encoded in lock-step */
+    int refs;                 /* reference frames for P (round 1: 1) */
+    int qp_i, qp_p;           /* constant QPs (X264_RC_CQP path, codec.c:1498-1502) */
+    int me_range;             /* --merange (16) */
+    int subme;                /* --subme level (round 1 honours 0..7 search depth) */
+    int deblock;              /* 1 = in-loop filter on */
+    int deblock_alpha, deblock_beta; /* --deblock a:b offsets */
+    int chroma_qp_offset;
+    int deadzone_inter, deadzone_intra;
+    int dct_decimate;
+    int partitions;           /* bit0 p8x8 (16x8/8x16/8x8), bit1 i4x4 */
+} x264gpu_config;
+
+int  x264gpu_encoder_create(x264gpu_encoder **enc, const x264gpu_config *cfg);
+void x264gpu_encoder_destroy(x264gpu_encoder *enc);
+/* sizes of the per-frame outputs for ONE stream */
+int  x264gpu_encoder_mb_count(const x264gpu_encoder *enc);
+/* Encode one frame per stream.  d_i420: `streams` tightly packed I420 pictures (W*H*3/2 each) already
+ * resident in HBM.  slice_type: X264GPU_SLICE_I (IDR, resets the DPB) or X264GPU_SLICE_P.
+ * Outputs stay on the device: d_mb [streams][mb_count] records, d_levels [streams][mb_count][416].
+ * Replaces (for the slice types supported) x264_frame_copy_picture, x264_macroblock_analyse,
+ * x264_macroblock_encode, x264_frame_deblock_row, x264_frame_filter of [x264-upstream]. */
+int  x264gpu_encode_frames(x264gpu_encoder *enc, const uint8_t *d_i420, int slice_type,
+                           x264gpu_mb *d_mb, int16_t *d_levels, void *stream);
+/* copy the reconstructed (deblocked) picture of `stream_idx` out as I420 (for parity tests / PSNR) */
+int  x264gpu_encoder_get_recon(x264gpu_encoder *enc, int stream_idx, uint8_t *d_i420_out, void *stream);
+/* timing hook for bench.py: average device time per named stage of the last call (ms), 0 if unknown */
+int  x264gpu_encoder_stage_count(void);
+const char *x264gpu_encoder_stage_name(int i);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,130 @@
+"""ctypes view of oracle/liboracle.so — the CPU checker.  Imported by tests/, smoke() and bench.py's
+cpu_baseline leg only; the product (x264vfw_amd/) never touches it."""
+import ctypes as C
+import os
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+_so = os.path.join(ROOT, "oracle", "liboracle.so")
+if not os.path.exists(_so):
+    import subprocess
+    subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "oracle")])
+L = C.CDLL(_so)
+
+u8p = np.ctypeslib.ndpointer(dtype=np.uint8, flags="C_CONTIGUOUS")
+i16p = np.ctypeslib.ndpointer(dtype=np.int16, flags="C_CONTIGUOUS")
+i32p = np.ctypeslib.ndpointer(dtype=np.int32, flags="C_CONTIGUOUS")
+_i = C.c_int
+
+
+def _sig(name, res, args):
+    f = getattr(L, name)
+    f.restype, f.argtypes = res, args
+    return f
+
+
+for _n in ("x264o_sad", "x264o_ssd", "x264o_satd", "x264o_sa8d"):
+    _sig(_n, _i, [C.c_void_p, _i, C.c_void_p, _i, _i, _i])
+_sig("x264o_var", C.c_uint64, [C.c_void_p, _i, _i, _i])
+_sig("x264o_hadamard_ac", C.c_uint64, [C.c_void_p, _i, _i, _i])
+_sig("x264o_sub4x4_dct", None, [i16p, C.c_void_p, _i, C.c_void_p, _i])
+_sig("x264o_add4x4_idct", None, [C.c_void_p, _i, i16p])
+_sig("x264o_sub8x8_dct8", None, [i16p, C.c_void_p, _i, C.c_void_p, _i])
+_sig("x264o_add8x8_idct8", None, [C.c_void_p, _i, i16p])
+_sig("x264o_dct4x4dc", None, [i16p])
+_sig("x264o_idct4x4dc", None, [i16p])
+_sig("x264o_dct2x2dc", None, [i16p])
+
+
+class QuantTables(C.Structure):
+    _fields_ = [("quant4_mf", (C.c_uint16 * 16) * 52 * 4), ("quant4_bias", (C.c_uint16 * 16) * 52 * 4),
+                ("dequant4_mf", (C.c_int32 * 16) * 6), ("quant8_mf", (C.c_uint16 * 64) * 52 * 2),
+                ("quant8_bias", (C.c_uint16 * 64) * 52 * 2), ("dequant8_mf", (C.c_int32 * 64) * 6)]
+
+
+_sig("x264o_quant_init", None, [C.POINTER(QuantTables), _i, _i])
+_sig("x264o_quant_4x4", _i, [i16p, C.c_void_p, C.c_void_p])
+_sig("x264o_quant_8x8", _i, [i16p, C.c_void_p, C.c_void_p])
+_sig("x264o_quant_4x4_dc", _i, [i16p, _i, _i])
+_sig("x264o_quant_2x2_dc", _i, [i16p, _i, _i])
+_sig("x264o_dequant_4x4", None, [i16p, C.c_void_p, _i])
+_sig("x264o_dequant_8x8", None, [i16p, C.c_void_p, _i])
+_sig("x264o_dequant_4x4_dc", None, [i16p, C.c_void_p, _i])
+_sig("x264o_dequant_2x2_dc", None, [i16p, i16p, C.c_void_p, _i])
+_sig("x264o_decimate_score", _i, [i16p, _i])
+_sig("x264o_predict_16x16", None, [C.c_void_p, _i, C.c_void_p, _i, _i])
+_sig("x264o_predict_8x8c", None, [C.c_void_p, _i, C.c_void_p, _i, _i])
+_sig("x264o_predict_4x4", None, [C.c_void_p, _i, C.c_void_p, _i, _i, _i])
+_sig("x264o_predict_8x8_filter", None, [C.c_void_p, _i, C.c_void_p, _i])
+_sig("x264o_predict_8x8", None, [C.c_void_p, _i, C.c_void_p, _i])
+_sig("x264o_frame_filter", None, [C.POINTER(C.c_void_p), _i, _i, _i, _i])
+_sig("x264o_frame_init_lowres", None, [C.c_void_p, _i, _i, _i, C.POINTER(C.c_void_p), _i])
+_sig("x264o_mc_luma", None, [C.c_void_p, _i, C.POINTER(C.c_void_p), _i, _i, _i, _i, _i, _i, _i])
+_sig("x264o_mc_chroma", None, [C.c_void_p, C.c_void_p, _i, C.c_void_p, _i, _i, _i, _i, _i, _i, _i])
+_sig("x264o_deblock_luma_edge", None, [C.c_void_p, _i, _i, _i, _i, _i, _i, _i])
+_sig("x264o_deblock_chroma_edge", None, [C.c_void_p, _i, _i, _i, _i, _i, _i, _i])
+
+_QT = {}
+
+
+def quant_tables(dz_inter=21, dz_intra=11):
+    key = (dz_inter, dz_intra)
+    if key not in _QT:
+        t = QuantTables()
+        L.x264o_quant_init(C.byref(t), dz_inter, dz_intra)
+        _QT[key] = t
+    return _QT[key]
+
+
+def ptr(a, off=0):
+    """address of element `off` (flat index) of a contiguous numpy array"""
+    return a.ctypes.data + off * a.itemsize
+
+
+def metric(name, a, b):
+    """a, b: (n, h, w) uint8 -> int32[n]"""
+    f = getattr(L, "x264o_" + name)
+    n, h, w = a.shape
+    out = np.empty(n, np.int32)
+    for i in range(n):
+        out[i] = f(ptr(a, i * h * w), w, ptr(b, i * h * w), w, w, h)
+    return out
+
+
+def dctq4x4(enc, pred, qp, lst):
+    """enc,pred: (n,4,4) u8 -> coef, levels (raster), recon"""
+    t = quant_tables()
+    n = enc.shape[0]
+    coef = np.zeros((n, 16), np.int16)
+    lev = np.zeros((n, 16), np.int16)
+    rec = pred.copy()
+    mf = C.addressof(t.quant4_mf[lst][qp])
+    bias = C.addressof(t.quant4_bias[lst][qp])
+    for i in range(n):
+        d = np.zeros(16, np.int16)
+        L.x264o_sub4x4_dct(d, ptr(enc, i * 16), 4, ptr(pred, i * 16), 4)
+        coef[i] = d
+        L.x264o_quant_4x4(d, mf, bias)
+        lev[i] = d
+        L.x264o_dequant_4x4(d, C.addressof(t.dequant4_mf), qp)
+        L.x264o_add4x4_idct(ptr(rec, i * 16), 4, d)
+    return coef, lev, rec
+
+
+def make_padded_planes(img, pad):
+    """img (h,w) u8 -> planes (4, h+2p, stride) with plane 0 interior = img; returns (planes, stride)"""
+    h, w = img.shape
+    stride = (w + 2 * pad + 63) // 64 * 64
+    planes = np.zeros((4, h + 2 * pad, stride), np.uint8)
+    planes[0, pad:pad + h, pad:pad + w] = img
+    return planes, stride
+
+
+def frame_filter(planes, stride, w, h, pad):
+    arr = (C.c_void_p * 4)(*[ptr(planes, (k * planes.shape[1] + pad) * stride + pad) for k in range(4)])
+    L.x264o_frame_filter(arr, stride, w, h, pad)
+
+
+def plane_ptrs(planes, stride, pad):
+    return (C.c_void_p * 4)(*[ptr(planes, (k * planes.shape[1] + pad) * stride + pad) for k in range(4)])

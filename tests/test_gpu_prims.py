@@ -1,0 +1,144 @@
+"""-m gpu: Tier-1 primitives of libx264gpu.so vs the CPU oracle, bit-exact, through the C ABI."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import oracle_lib as O
+
+pytestmark = pytest.mark.gpu
+
+
+def dev(a):
+    import torch
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+def blocks(rng, n, h, w, kind):
+    if kind == "rand":
+        return rng.integers(0, 256, (n, h, w), dtype=np.uint8)
+    if kind == "extreme":
+        return rng.choice(np.array([0, 255], np.uint8), (n, h, w))
+    base = rng.integers(0, 256, (n, 1, 1))
+    return np.clip(base + rng.integers(-6, 7, (n, h, w)), 0, 255).astype(np.uint8)
+
+
+@pytest.mark.parametrize("metric,name", [(0, "sad"), (1, "satd"), (2, "sa8d"), (3, "ssd")])
+@pytest.mark.parametrize("w,h", [(16, 16), (16, 8), (8, 16), (8, 8), (8, 4), (4, 8), (4, 4)])
+def test_pixel_metric(gpu, metric, name, w, h):
+    import torch
+    if name == "sa8d" and (w, h) not in ((16, 16), (8, 8)):
+        pytest.skip("sa8d is defined for 8x8 and 16x16")
+    rng = np.random.default_rng(1000 * metric + 16 * w + h)
+    for kind in ("rand", "extreme", "smooth"):
+        n = 257
+        a, b = blocks(rng, n, h, w, kind), blocks(rng, n, h, w, kind)
+        da, db = dev(a), dev(b)
+        out = torch.empty(n, dtype=torch.int32, device="cuda")
+        gpu.check(gpu.x264gpu_pixel_metric(metric, da.data_ptr(), db.data_ptr(), n, w, h, out.data_ptr(), None))
+        np.testing.assert_array_equal(out.cpu().numpy(), O.metric(name, a, b), err_msg=f"{name} {w}x{h} {kind}")
+
+
+@pytest.mark.parametrize("w,h", [(16, 16), (8, 8), (8, 16)])
+def test_pixel_var(gpu, w, h):
+    import torch
+    rng = np.random.default_rng(7)
+    n = 130
+    a = blocks(rng, n, h, w, "rand")
+    out = torch.empty(n, dtype=torch.int64, device="cuda")
+    gpu.check(gpu.x264gpu_pixel_var(dev(a).data_ptr(), n, w, h, out.data_ptr(), None))
+    ref = np.array([O.L.x264o_var(O.ptr(a, i * w * h), w, w, h) for i in range(n)], np.uint64)
+    np.testing.assert_array_equal(out.cpu().numpy().view(np.uint64), ref)
+
+
+@pytest.mark.parametrize("qp", [0, 5, 12, 23, 24, 26, 35, 36, 37, 51])
+@pytest.mark.parametrize("lst", [0, 1, 2, 3])
+def test_dctq4x4(gpu, qp, lst):
+    import torch
+    rng = np.random.default_rng(qp * 4 + lst)
+    n = 1000
+    enc = np.concatenate([blocks(rng, n // 2, 4, 4, "rand"), blocks(rng, n // 2, 4, 4, "smooth")])
+    pred = np.concatenate([blocks(rng, n // 2, 4, 4, "smooth"), blocks(rng, n // 2, 4, 4, "extreme")])
+    coef = torch.empty((n, 16), dtype=torch.int16, device="cuda")
+    lev = torch.empty_like(coef)
+    rec = torch.empty((n, 16), dtype=torch.uint8, device="cuda")
+    gpu.check(gpu.x264gpu_dctq4x4(dev(enc).data_ptr(), dev(pred).data_ptr(), n, qp, lst, coef.data_ptr(),
+                                  lev.data_ptr(), rec.data_ptr(), None))
+    rc, rl, rr = O.dctq4x4(enc, pred, qp, lst)
+    np.testing.assert_array_equal(coef.cpu().numpy(), rc)
+    np.testing.assert_array_equal(lev.cpu().numpy(), rl)
+    np.testing.assert_array_equal(rec.cpu().numpy().reshape(n, 4, 4), rr)
+
+
+@pytest.mark.parametrize("w,h", [(64, 48), (100, 36), (352, 288)])
+def test_hpel_filter(gpu, w, h):
+    rng = np.random.default_rng(w + h)
+    pad = 32
+    img = rng.integers(0, 256, (h, w), dtype=np.uint8)
+    planes, stride = O.make_padded_planes(img, pad)
+    ref = planes.copy()
+    O.frame_filter(ref, stride, w, h, pad)
+    d = dev(planes)
+    pb = planes.shape[1] * stride
+    gpu.check(gpu.x264gpu_hpel_filter(d.data_ptr(), pb, stride, w, h, pad, None))
+    got = d.cpu().numpy()
+    for k in range(4):
+        np.testing.assert_array_equal(got[k, :, :w + 2 * pad], ref[k, :, :w + 2 * pad], err_msg=f"plane {k}")
+
+
+@pytest.mark.parametrize("w,h", [(64, 48), (98, 34), (352, 288)])
+def test_lowres(gpu, w, h):
+    import torch
+    rng = np.random.default_rng(w * h)
+    img = rng.integers(0, 256, (h, w), dtype=np.uint8)
+    ds = (w // 2 + 31) // 32 * 32
+    ref = np.zeros((4, h // 2, ds), np.uint8)
+    arr = (C.c_void_p * 4)(*[O.ptr(ref, k * (h // 2) * ds) for k in range(4)])
+    O.L.x264o_frame_init_lowres(O.ptr(img), w, w, h, arr, ds)
+    out = torch.zeros((4, h // 2, ds), dtype=torch.uint8, device="cuda")
+    gpu.check(gpu.x264gpu_lowres(dev(img).data_ptr(), w, w, h, out.data_ptr(), (h // 2) * ds, ds, None))
+    np.testing.assert_array_equal(out.cpu().numpy(), ref)
+
+
+def test_mc_luma_chroma(gpu):
+    import torch
+    rng = np.random.default_rng(99)
+    w, h, pad = 96, 64, 32
+    img = rng.integers(0, 256, (h, w), dtype=np.uint8)
+    planes, stride = O.make_padded_planes(img, pad)
+    O.frame_filter(planes, stride, w, h, pad)
+    d = dev(planes)
+    pb = planes.shape[1] * stride
+    p00 = d.data_ptr() + pad * stride + pad
+    pp = O.plane_ptrs(planes, stride, pad)
+    for bw, bh in ((16, 16), (16, 8), (8, 16), (8, 8), (8, 4), (4, 8), (4, 4)):
+        n = 300
+        xy = np.stack([rng.integers(0, w - bw + 1, n), rng.integers(0, h - bh + 1, n)], 1).astype(np.int32)
+        mv = rng.integers(-4 * 20, 4 * 20, (n, 2)).astype(np.int32)
+        mv[:16] = [[i & 3, i >> 2] for i in range(16)]
+        out = torch.empty((n, bh, bw), dtype=torch.uint8, device="cuda")
+        gpu.check(gpu.x264gpu_mc_luma(p00, pb, stride, dev(xy).data_ptr(), dev(mv).data_ptr(), n, bw, bh,
+                                      out.data_ptr(), None))
+        ref = np.empty((n, bh, bw), np.uint8)
+        for i in range(n):
+            O.L.x264o_mc_luma(O.ptr(ref, i * bw * bh), bw, pp, stride, int(xy[i, 0]), int(xy[i, 1]),
+                              int(mv[i, 0]), int(mv[i, 1]), bw, bh)
+        np.testing.assert_array_equal(out.cpu().numpy(), ref, err_msg=f"mc_luma {bw}x{bh}")
+    # chroma: padded NV12 plane, 16 px of padding (32 bytes each side)
+    cw, ch, cpad = w // 2, h // 2, 16
+    cs = (2 * cw + 4 * cpad + 63) // 64 * 64
+    nv = rng.integers(0, 256, (ch + 2 * cpad, cs), dtype=np.uint8)
+    dnv = dev(nv)
+    org = cpad * cs + 2 * cpad
+    for bw, bh in ((8, 8), (8, 4), (4, 8), (4, 4)):
+        n = 300
+        xy = np.stack([rng.integers(0, cw - bw + 1, n), rng.integers(0, ch - bh + 1, n)], 1).astype(np.int32)
+        mv = rng.integers(-8 * 10, 8 * 10, (n, 2)).astype(np.int32)
+        out = torch.empty((n, 2, bh, bw), dtype=torch.uint8, device="cuda")
+        gpu.check(gpu.x264gpu_mc_chroma(dnv.data_ptr() + org, cs, dev(xy).data_ptr(), dev(mv).data_ptr(), n, bw, bh,
+                                        out.data_ptr(), None))
+        ref = np.empty((n, 2, bh, bw), np.uint8)
+        for i in range(n):
+            O.L.x264o_mc_chroma(O.ptr(ref, i * 2 * bw * bh), O.ptr(ref, i * 2 * bw * bh + bw * bh), bw,
+                                O.ptr(nv, org), cs, int(xy[i, 0]), int(xy[i, 1]), int(mv[i, 0]), int(mv[i, 1]), bw, bh)
+        np.testing.assert_array_equal(out.cpu().numpy(), ref, err_msg=f"mc_chroma {bw}x{bh}")

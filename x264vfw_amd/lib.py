@@ -1,0 +1,91 @@
+"""ctypes binding of libx264gpu.so (include/x264gpu.h).  Fails loudly when the library is missing."""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libx264gpu.so")
+
+
+class X264GpuError(RuntimeError):
+    pass
+
+
+def _load():
+    if not os.path.exists(LIB_PATH):
+        raise X264GpuError(
+            f"{LIB_PATH} not built — run `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(there is no CPU fallback for the HIP hot path)")
+    return C.CDLL(LIB_PATH)
+
+
+_lib = _load()
+_vp, _i, _sz = C.c_void_p, C.c_int, C.c_size_t
+
+
+class MbRecord(C.Structure):
+    """Mirror of struct x264gpu_mb (64 bytes)."""
+    _fields_ = [("type", C.c_uint8), ("i16_mode", C.c_uint8), ("chroma_mode", C.c_uint8), ("qp", C.c_uint8),
+                ("cbp_luma", C.c_uint8), ("cbp_chroma", C.c_uint8), ("partition", C.c_uint8),
+                ("ref", C.c_int8 * 4), ("i4_mode", C.c_uint8 * 16), ("mv", (C.c_int16 * 2) * 4),
+                ("nnz", C.c_uint32), ("cost", C.c_int32), ("pad", C.c_uint8 * 9)]
+
+
+class Config(C.Structure):
+    """Mirror of struct x264gpu_config."""
+    _fields_ = [(n, C.c_int) for n in (
+        "width", "height", "streams", "refs", "qp_i", "qp_p", "me_range", "subme", "deblock",
+        "deblock_alpha", "deblock_beta", "chroma_qp_offset", "deadzone_inter", "deadzone_intra",
+        "dct_decimate", "partitions")]
+
+
+MB_LEVELS = 416
+
+_SIGS = {
+    "x264gpu_abi_version": (_i, []),
+    "x264gpu_device_count": (_i, []),
+    "x264gpu_set_device": (_i, [_i]),
+    "x264gpu_last_error": (C.c_char_p, []),
+    "x264gpu_malloc": (_i, [C.POINTER(_vp), _sz]),
+    "x264gpu_free": (_i, [_vp]),
+    "x264gpu_memcpy_h2d": (_i, [_vp, _vp, _sz, _vp]),
+    "x264gpu_memcpy_d2h": (_i, [_vp, _vp, _sz, _vp]),
+    "x264gpu_memset": (_i, [_vp, _i, _sz, _vp]),
+    "x264gpu_stream_sync": (_i, [_vp]),
+    "x264gpu_pixel_metric": (_i, [_i, _vp, _vp, _i, _i, _i, _vp, _vp]),
+    "x264gpu_pixel_var": (_i, [_vp, _i, _i, _i, _vp, _vp]),
+    "x264gpu_dctq4x4": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp]),
+    "x264gpu_dctq8x8": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp]),
+    "x264gpu_intra_predict": (_i, [_i, _vp, _i, _vp, _vp, _vp, _i, _vp, _vp]),
+    "x264gpu_hpel_filter": (_i, [_vp, _sz, _i, _i, _i, _i, _vp]),
+    "x264gpu_lowres": (_i, [_vp, _i, _i, _i, _vp, _sz, _i, _vp]),
+    "x264gpu_mc_luma": (_i, [_vp, _sz, _i, _vp, _vp, _i, _i, _i, _vp, _vp]),
+    "x264gpu_mc_chroma": (_i, [_vp, _i, _vp, _vp, _i, _i, _i, _vp, _vp]),
+    "x264gpu_encoder_create": (_i, [C.POINTER(_vp), C.POINTER(Config)]),
+    "x264gpu_encoder_destroy": (None, [_vp]),
+    "x264gpu_encoder_mb_count": (_i, [_vp]),
+    "x264gpu_encode_frames": (_i, [_vp, _vp, _i, _vp, _vp, _vp]),
+    "x264gpu_encoder_get_recon": (_i, [_vp, _i, _vp, _vp]),
+    "x264gpu_encoder_stage_count": (_i, []),
+    "x264gpu_encoder_stage_name": (C.c_char_p, [_i]),
+}
+
+EXPORTS = tuple(_SIGS)
+_missing = []
+for _name, (_res, _args) in _SIGS.items():
+    try:
+        _fn = getattr(_lib, _name)
+    except AttributeError:
+        _missing.append(_name)
+        continue
+    _fn.restype, _fn.argtypes = _res, _args
+if _missing:
+    raise X264GpuError(f"libx264gpu.so lacks symbols declared in include/x264gpu.h: {_missing}")
+
+
+def check(rc, what="x264gpu call"):
+    if rc != 0:
+        raise X264GpuError(f"{what} failed ({rc}): {_lib.x264gpu_last_error().decode()}")
+
+
+def __getattr__(name):
+    return getattr(_lib, name)
