@@ -128,3 +128,66 @@ def frame_filter(planes, stride, w, h, pad):
 
 def plane_ptrs(planes, stride, pad):
     return (C.c_void_p * 4)(*[ptr(planes, (k * planes.shape[1] + pad) * stride + pad) for k in range(4)])
+
+
+# ---- frame pipeline (oracle/encoder.c) ----
+import sys
+sys.path.insert(0, ROOT)
+from x264vfw_amd.lib import Config, MbRecord, MB_LEVELS  # noqa: E402  (plain ctypes structs, no GPU needed)
+
+_sig("x264o_encoder_create", C.c_void_p, [C.POINTER(Config)])
+_sig("x264o_encoder_destroy", None, [C.c_void_p])
+_sig("x264o_encoder_mb_count", _i, [C.c_void_p])
+_sig("x264o_encoder_encode", _i, [C.c_void_p, C.c_void_p, _i, C.c_void_p, C.c_void_p])
+_sig("x264o_encoder_get_recon", None, [C.c_void_p, C.c_void_p])
+_sig("x264o_encoder_ref_plane", C.c_void_p, [C.c_void_p, _i, C.POINTER(_i), C.POINTER(_i)])
+_sig("x264o_lambda", _i, [_i])
+
+MB_DTYPE = np.dtype([("type", "u1"), ("i16_mode", "u1"), ("chroma_mode", "u1"), ("qp", "u1"), ("cbp_luma", "u1"),
+                     ("cbp_chroma", "u1"), ("partition", "u1"), ("ref", "i1", 4), ("i4_mode", "u1", 16),
+                     ("_p0", "u1"), ("mv", "<i2", (4, 2)), ("nnz", "<u4"), ("cost", "<i4"), ("pad", "u1", 9),
+                     ("_p1", "u1", 3)])
+assert MB_DTYPE.itemsize == 64 == C.sizeof(MbRecord)
+
+
+def default_config(width, height, streams=1, **kw):
+    c = Config(width=width, height=height, streams=streams, refs=1, qp_i=20, qp_p=23, me_range=16, subme=7,
+               deblock=1, deblock_alpha=0, deblock_beta=0, chroma_qp_offset=0, deadzone_inter=21,
+               deadzone_intra=11, dct_decimate=1, partitions=2)
+    for k, v in kw.items():
+        setattr(c, k, v)
+    return c
+
+
+class OracleEncoder:
+    def __init__(self, cfg):
+        self.cfg = cfg
+        self.h = L.x264o_encoder_create(C.byref(cfg))
+        self.n = L.x264o_encoder_mb_count(self.h)
+
+    def encode(self, i420, slice_type):
+        mbs = np.zeros(self.n, MB_DTYPE)
+        lv = np.zeros((self.n, MB_LEVELS), np.int16)
+        i420 = np.ascontiguousarray(i420, np.uint8)
+        rc = L.x264o_encoder_encode(self.h, ptr(i420), slice_type, ptr(mbs), ptr(lv))
+        assert rc == 0
+        return mbs, lv
+
+    def recon(self):
+        w, h = self.cfg.width, self.cfg.height
+        out = np.zeros(w * h * 3 // 2, np.uint8)
+        L.x264o_encoder_get_recon(self.h, ptr(out))
+        return out
+
+    def ref_plane(self, k):
+        s, r = _i(), _i()
+        p = L.x264o_encoder_ref_plane(self.h, k, C.byref(s), C.byref(r))
+        return np.ctypeslib.as_array(C.cast(p, C.POINTER(C.c_uint8)), (r.value, s.value)).copy()
+
+    def close(self):
+        if self.h:
+            L.x264o_encoder_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        self.close()

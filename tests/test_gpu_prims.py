@@ -46,7 +46,8 @@ def test_pixel_var(gpu, w, h):
     n = 130
     a = blocks(rng, n, h, w, "rand")
     out = torch.empty(n, dtype=torch.int64, device="cuda")
-    gpu.check(gpu.x264gpu_pixel_var(dev(a).data_ptr(), n, w, h, out.data_ptr(), None))
+    da = dev(a)
+    gpu.check(gpu.x264gpu_pixel_var(da.data_ptr(), n, w, h, out.data_ptr(), None))
     ref = np.array([O.L.x264o_var(O.ptr(a, i * w * h), w, w, h) for i in range(n)], np.uint64)
     np.testing.assert_array_equal(out.cpu().numpy().view(np.uint64), ref)
 
@@ -62,7 +63,8 @@ def test_dctq4x4(gpu, qp, lst):
     coef = torch.empty((n, 16), dtype=torch.int16, device="cuda")
     lev = torch.empty_like(coef)
     rec = torch.empty((n, 16), dtype=torch.uint8, device="cuda")
-    gpu.check(gpu.x264gpu_dctq4x4(dev(enc).data_ptr(), dev(pred).data_ptr(), n, qp, lst, coef.data_ptr(),
+    denc, dpred = dev(enc), dev(pred)   # keep alive: freed temporaries would alias in the caching allocator
+    gpu.check(gpu.x264gpu_dctq4x4(denc.data_ptr(), dpred.data_ptr(), n, qp, lst, coef.data_ptr(),
                                   lev.data_ptr(), rec.data_ptr(), None))
     rc, rl, rr = O.dctq4x4(enc, pred, qp, lst)
     np.testing.assert_array_equal(coef.cpu().numpy(), rc)
@@ -96,7 +98,8 @@ def test_lowres(gpu, w, h):
     arr = (C.c_void_p * 4)(*[O.ptr(ref, k * (h // 2) * ds) for k in range(4)])
     O.L.x264o_frame_init_lowres(O.ptr(img), w, w, h, arr, ds)
     out = torch.zeros((4, h // 2, ds), dtype=torch.uint8, device="cuda")
-    gpu.check(gpu.x264gpu_lowres(dev(img).data_ptr(), w, w, h, out.data_ptr(), (h // 2) * ds, ds, None))
+    dimg = dev(img)
+    gpu.check(gpu.x264gpu_lowres(dimg.data_ptr(), w, w, h, out.data_ptr(), (h // 2) * ds, ds, None))
     np.testing.assert_array_equal(out.cpu().numpy(), ref)
 
 
@@ -117,7 +120,8 @@ def test_mc_luma_chroma(gpu):
         mv = rng.integers(-4 * 20, 4 * 20, (n, 2)).astype(np.int32)
         mv[:16] = [[i & 3, i >> 2] for i in range(16)]
         out = torch.empty((n, bh, bw), dtype=torch.uint8, device="cuda")
-        gpu.check(gpu.x264gpu_mc_luma(p00, pb, stride, dev(xy).data_ptr(), dev(mv).data_ptr(), n, bw, bh,
+        dxy, dmv = dev(xy), dev(mv)
+        gpu.check(gpu.x264gpu_mc_luma(p00, pb, stride, dxy.data_ptr(), dmv.data_ptr(), n, bw, bh,
                                       out.data_ptr(), None))
         ref = np.empty((n, bh, bw), np.uint8)
         for i in range(n):
@@ -135,7 +139,8 @@ def test_mc_luma_chroma(gpu):
         xy = np.stack([rng.integers(0, cw - bw + 1, n), rng.integers(0, ch - bh + 1, n)], 1).astype(np.int32)
         mv = rng.integers(-8 * 10, 8 * 10, (n, 2)).astype(np.int32)
         out = torch.empty((n, 2, bh, bw), dtype=torch.uint8, device="cuda")
-        gpu.check(gpu.x264gpu_mc_chroma(dnv.data_ptr() + org, cs, dev(xy).data_ptr(), dev(mv).data_ptr(), n, bw, bh,
+        dxy, dmv = dev(xy), dev(mv)
+        gpu.check(gpu.x264gpu_mc_chroma(dnv.data_ptr() + org, cs, dxy.data_ptr(), dmv.data_ptr(), n, bw, bh,
                                         out.data_ptr(), None))
         ref = np.empty((n, 2, bh, bw), np.uint8)
         for i in range(n):
