@@ -100,7 +100,7 @@ typedef struct x264gpu_mb {
     int16_t  mv[4][2];      /* quarter-pel motion vector per 8x8 (x,y) */
     uint32_t nnz;           /* bit b (0..15 luma blk order, 16..19 U, 20..23 V, 24 lumaDC, 25 U DC, 26 V DC) */
     int32_t  cost;          /* analysis cost of the chosen mode (diagnostic) */
-    uint8_t  pad[9];
+    int32_t  aux[3];        /* diagnostics: [0] best inter cost, [1] intra-16x16 source estimate (P slices) */
 } x264gpu_mb;
 
 /* quantised levels per macroblock, scan (zigzag) order, int16:

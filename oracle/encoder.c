@@ -42,6 +42,7 @@ typedef struct x264o_encoder {
     uint16_t *cost_mv[52];       /* lambda-scaled mv bit costs per qp, centred at MVCOST_HALF */
     x264o_quant_tables qt;
     int have_ref;
+    int slice_type;              /* slice being encoded */
 } x264o_encoder;
 
 static int clampi(int v, int lo, int hi) { return v < lo ? lo : v > hi ? hi : v; }
@@ -361,6 +362,7 @@ static void analyse_p_mb(x264o_encoder *e, int mbx, int mby, x264gpu_mb *mb)
     int icost = intra16_estimate(e, mbx, mby, lambda);
     memset(mb, 0, sizeof(*mb));
     mb->qp = (uint8_t)qp;
+    mb->aux[0] = m.cost; mb->aux[1] = icost;
     if (icost < m.cost) {
         mb->type = X264GPU_MB_I16x16;   /* provisional: real intra analysis happens in the intra stage */
         mb->cost = icost;
@@ -426,9 +428,11 @@ static void intra_mb(x264o_encoder *e, int mbx, int mby, int qp, x264gpu_mb *mbs
     pixel *rec = luma_plane(e, e->cur, 0) + (size_t)mby * 16 * e->rs + mbx * 16;
     int left = mbx > 0, top = mby > 0;
     pixel pred[256];
+    int aux0 = mb->aux[0], aux1 = mb->aux[1];     /* keep the P-slice analysis diagnostics */
     memset(mb, 0, sizeof(*mb));
     memset(lv, 0, X264GPU_MB_LEVELS * sizeof(int16_t));
     mb->qp = (uint8_t)qp;
+    if (e->slice_type == X264GPU_SLICE_P) { mb->aux[0] = aux0; mb->aux[1] = aux1; }
     for (int k = 0; k < 4; k++) mb->ref[k] = -1;
     /* --- intra 16x16 mode decision (SATD + lambda*ue(mode)); order V,H,DC,P, first-best wins --- */
     int modes[4], n = 0, best16 = 1 << 28, mode16 = 0;
@@ -636,6 +640,7 @@ int x264o_encoder_encode(x264o_encoder *e, const uint8_t *i420, int slice_type, 
 {
     int n = e->mbw * e->mbh;
     if (slice_type == X264GPU_SLICE_P && !e->have_ref) return -1;
+    e->slice_type = slice_type;
     ingest(e, i420);
     if (slice_type == X264GPU_SLICE_I) {
         for (int i = 0; i < n; i++) { e->reff[1][i] = -1; e->mvf[1][i][0] = e->mvf[1][i][1] = 0; }

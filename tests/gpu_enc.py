@@ -1,0 +1,49 @@
+"""Python mirror of the Tier-2 C ABI (include/x264gpu.h x264gpu_encoder_*): thin, no logic of its own."""
+import ctypes as C
+
+import numpy as np
+
+import oracle_lib as O
+from x264vfw_amd import lib
+from x264vfw_amd.lib import MB_LEVELS
+
+
+class GpuEncoder:
+    def __init__(self, cfg):
+        import torch
+        self.torch = torch
+        self.cfg = cfg
+        self.h = C.c_void_p()
+        lib.check(lib.x264gpu_encoder_create(C.byref(self.h), C.byref(cfg)), "encoder_create")
+        self.n = lib.x264gpu_encoder_mb_count(self.h)
+        self.S = cfg.streams
+        self.d_mb = torch.zeros((self.S, self.n, 64), dtype=torch.uint8, device="cuda")
+        self.d_lv = torch.zeros((self.S, self.n, MB_LEVELS), dtype=torch.int16, device="cuda")
+
+    def encode(self, frames, slice_type):
+        """frames: list (one per stream) of I420 uint8 arrays -> (mb records [S,n], levels [S,n,416])"""
+        t = self.torch
+        d_in = t.from_numpy(np.stack(frames)).cuda()
+        lib.check(lib.x264gpu_encode_frames(self.h, d_in.data_ptr(), slice_type, self.d_mb.data_ptr(),
+                                            self.d_lv.data_ptr(), None), "encode_frames")
+        t.cuda.synchronize()
+        mb = self.d_mb.cpu().numpy().view(O.MB_DTYPE).reshape(self.S, self.n)
+        return mb, self.d_lv.cpu().numpy()
+
+    def recon(self, s=0):
+        t = self.torch
+        w, h = self.cfg.width, self.cfg.height
+        out = t.zeros(w * h * 3 // 2, dtype=t.uint8, device="cuda")
+        lib.check(lib.x264gpu_encoder_get_recon(self.h, s, out.data_ptr(), None), "get_recon")
+        return out.cpu().numpy()
+
+    def close(self):
+        if self.h:
+            lib.x264gpu_encoder_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -145,8 +145,7 @@ _sig("x264o_lambda", _i, [_i])
 
 MB_DTYPE = np.dtype([("type", "u1"), ("i16_mode", "u1"), ("chroma_mode", "u1"), ("qp", "u1"), ("cbp_luma", "u1"),
                      ("cbp_chroma", "u1"), ("partition", "u1"), ("ref", "i1", 4), ("i4_mode", "u1", 16),
-                     ("_p0", "u1"), ("mv", "<i2", (4, 2)), ("nnz", "<u4"), ("cost", "<i4"), ("pad", "u1", 9),
-                     ("_p1", "u1", 3)])
+                     ("_p0", "u1"), ("mv", "<i2", (4, 2)), ("nnz", "<u4"), ("cost", "<i4"), ("aux", "<i4", 3)])
 assert MB_DTYPE.itemsize == 64 == C.sizeof(MbRecord)
 
 

@@ -14,7 +14,7 @@ def synth_frames(width, height, nframes, seed=0x264, scene_len=97):
                          pos=[(int(rng.integers(0, width)), int(rng.integers(0, height))) for _ in vel],
                          base=int(rng.integers(60, 160)))
         t = n % scene_len
-        y = (scene["base"] + (xx * 60 // width if scene["g"] & 1 else 0) + (yy * 50 // height if scene["g"] & 2 else 20)).astype(np.int32)
+        y = (scene["base"] + (xx * 60 // width if scene["g"] & 1 else 0 * xx) + (yy * 50 // height if scene["g"] & 2 else 20)).astype(np.int32)
         u = np.full((height // 2, width // 2), 118 + 5 * scene["g"], np.int32)
         v = np.full((height // 2, width // 2), 134 - 4 * scene["g"], np.int32)
         for (vx, vy), tex, (px, py) in zip(vel, scene["tex"], scene["pos"]):

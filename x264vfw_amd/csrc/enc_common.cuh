@@ -1,0 +1,166 @@
+// enc_common.cuh — device-side view of one lock-step batch of streams (frame pipeline, Tier 2).
+#pragma once
+#include "common.cuh"
+#include "mc.cuh"
+#include "intra.cuh"
+
+namespace x264gpu {
+
+constexpr int PAD = 32;    // luma padding of reference planes (samples)
+constexpr int CPAD = 16;   // chroma padding (chroma samples; 2*CPAD bytes in NV12)
+constexpr int MVCOST_HALF = 32768;
+
+// Everything a pipeline kernel needs, passed by value.  All per-stream buffers are [streams][...] with
+// the per-stream byte strides below, so blockIdx.y (or the workgroup index) selects the stream.
+struct EncK {
+    int w, h;                 // picture size
+    int mbw, mbh, nmb;        // macroblock grid
+    int cw, ch;               // coded size (multiples of 16)
+    int fs, rs;               // fenc stride, reference-plane stride (bytes)
+    size_t fency_bytes, fencuv_bytes;        // per stream
+    size_t plane_bytes, luma_bytes;          // one padded plane; 4 planes
+    size_t cplane_bytes;                     // padded NV12 plane
+    const uint8_t *i420;      // [streams] tightly packed input pictures
+    uint8_t *fenc_y, *fenc_uv;
+    uint8_t *rec_luma, *rec_chroma;          // DPB slot being reconstructed
+    const uint8_t *ref_luma, *ref_chroma;    // DPB slot used as reference
+    const int16_t *mvf_prev; int16_t *mvf_cur;     // [streams][nmb][2]
+    const int8_t *reff_prev; int8_t *reff_cur;     // [streams][nmb]
+    const uint16_t *cost_mv;  // 2*MVCOST_HALF entries for the slice qp
+    x264gpu_mb *mb;           // [streams][nmb]
+    int16_t *levels;          // [streams][nmb][416]
+    int qp, lambda, qpc;
+    int me_range, subme, dct_decimate, partitions, chroma_qp_offset;
+    int slice_type;
+    int alpha_off, beta_off;  // deblock offsets (already *2)
+    Q4 q_luma_intra, q_luma_inter, q_chroma_intra, q_chroma_inter;
+};
+
+__device__ __forceinline__ const uint8_t *ref_plane00(const EncK &k, int s)
+{
+    return k.ref_luma + (size_t)s * k.luma_bytes + (size_t)PAD * k.rs + PAD;
+}
+__device__ __forceinline__ uint8_t *rec_plane00(const EncK &k, int s)
+{
+    return k.rec_luma + (size_t)s * k.luma_bytes + (size_t)PAD * k.rs + PAD;
+}
+__device__ __forceinline__ const uint8_t *ref_chroma00(const EncK &k, int s)
+{
+    return k.ref_chroma + (size_t)s * k.cplane_bytes + (size_t)CPAD * k.rs + 2 * CPAD;
+}
+__device__ __forceinline__ uint8_t *rec_chroma00(const EncK &k, int s)
+{
+    return k.rec_chroma + (size_t)s * k.cplane_bytes + (size_t)CPAD * k.rs + 2 * CPAD;
+}
+
+static __device__ const uint8_t d_chroma_qp_table[52] = {
+    0,  1,  2,  3,  4,  5,  6,  7,  8,  9,  10, 11, 12, 13, 14, 15, 16, 17,
+    18, 19, 20, 21, 22, 23, 24, 25, 26, 27, 28, 29, 29, 30, 31, 32, 32, 33,
+    34, 34, 35, 35, 36, 36, 37, 37, 37, 38, 38, 38, 39, 39, 39, 39 };
+__device__ __forceinline__ int chroma_qp_dev(int q) { return d_chroma_qp_table[q < 0 ? 0 : q > 51 ? 51 : q]; }
+
+__device__ __forceinline__ int bs_size_ue(int v)
+{
+    return 2 * (31 - __builtin_clz(v + 1)) + 1;
+}
+
+// ---- shared residual coders (used by the inter and the intra kernels) ------------------------------
+
+// scatter this lane's 4 levels (natural layout: row j, columns 0..3) to scan order in `dst[16]`
+__device__ __forceinline__ void store_levels_scan(int16_t *dst, const int v[4], int j)
+{
+#pragma unroll
+    for (int c = 0; c < 4; c++) dst[zigzag4_inv(j * 4 + c)] = (int16_t)v[c];
+}
+__device__ __forceinline__ unsigned scan_mask(const int v[4], int j)
+{
+    unsigned m = 0;
+#pragma unroll
+    for (int c = 0; c < 4; c++) m |= (v[c] != 0 ? 1u : 0u) << zigzag4_inv(j * 4 + c);
+    return m;
+}
+__device__ __forceinline__ bool any_big(const int v[4])
+{
+    return (abs(v[0]) > 1) | (abs(v[1]) > 1) | (abs(v[2]) > 1) | (abs(v[3]) > 1);
+}
+
+// gather 4 chroma samples of one plane (c = 0 U, 1 V) from 8 interleaved NV12 bytes
+__device__ __forceinline__ uint32_t nv12_pick(uint32_t lo, uint32_t hi, int c)
+{
+    lo >>= 8 * c; hi >>= 8 * c;
+    return (lo & 0xff) | ((lo >> 8) & 0xff00) | ((hi & 0xff) << 16) | ((hi << 8) & 0xff000000u);
+}
+
+// Chroma residual of one macroblock.  Lanes 0..31 active: plane c = lane>>4 (one DPP row per plane),
+// 4x4 block i = (lane>>2)&3, row j = lane&3.  enc/pred are this lane's 4 samples (packed).  Returns the
+// reconstructed 4 samples; writes levels + updates nnz / cbp via the out-params (valid on every lane).
+__device__ __forceinline__ uint32_t chroma_residual(uint32_t enc, uint32_t pred, const Q4 &q, bool inter, bool decimate,
+                                                    int lane, int16_t *lv, unsigned &nnz_bits, int &cbp_chroma)
+{
+    const int c = (lane >> 4) & 1, i = (lane >> 2) & 3, j = lane & 3;
+    const bool act = lane < 32;
+    int e[4], p[4], v[4];
+    unpack4(enc, e); unpack4(pred, p);
+#pragma unroll
+    for (int t = 0; t < 4; t++) v[t] = act ? e[t] - p[t] : 0;
+    dct4_quad(v, lane);
+    // DC of each block sits at (row 0, col 0): collect the plane's four DCs on every lane of the plane
+    int dcs[4];
+#pragma unroll
+    for (int b = 0; b < 4; b++) dcs[b] = __shfl(v[0], (lane & 48) + 4 * b);
+    if (j == 0) v[0] = 0;
+    quant4_row(v, q, j);
+    unsigned mask = quad_or((int)scan_mask(v, j));
+    int big = quad_or(any_big(v) ? 1 : 0);
+    bool nz = mask != 0;
+    int score = 0;
+    if (inter && decimate) {
+        int s = nz ? (big ? 9 : decimate_from_mask(mask, 1)) : 0;
+        score = row16_sum(j == 0 ? s : 0);
+    }
+    bool plane_ac = row16_or(nz ? 1 : 0) != 0;
+    if (plane_ac && inter && decimate && score < 7) plane_ac = false;
+    // 2x2 DC Hadamard + quant (every lane of the plane redundantly)
+    int f[4];
+    { int a = dcs[0] + dcs[1], b = dcs[0] - dcs[1], cc = dcs[2] + dcs[3], d = dcs[2] - dcs[3];
+      f[0] = a + cc; f[1] = b + d; f[2] = a - cc; f[3] = b - d; }
+    int ldc[4], nzdc = 0;
+#pragma unroll
+    for (int b = 0; b < 4; b++) { ldc[b] = quant_one(f[b], q.mf[0] >> 1, q.bias[0] << 1); nzdc |= ldc[b]; }
+    int dq[4] = { 0, 0, 0, 0 };
+    if (nzdc) {
+        int a = ldc[0] + ldc[1], b = ldc[0] - ldc[1], cc = ldc[2] + ldc[3], d = ldc[2] - ldc[3];
+        int g[4] = { a + cc, b + d, a - cc, b - d };
+        int ls = q.dq[0] << (q.qp / 6);
+#pragma unroll
+        for (int b2 = 0; b2 < 4; b2++) dq[b2] = (g[b2] * ls) >> 5;
+    }
+    const bool keep = plane_ac && nz;
+    if (act) {
+        int16_t *l = lv + X264GPU_LV_CHROMA_AC + (c * 4 + i) * 16;
+        int z[4] = { 0, 0, 0, 0 };
+        store_levels_scan(l, keep ? v : z, j);
+        if (i == 0 && j == 0)
+#pragma unroll
+            for (int b = 0; b < 4; b++) lv[X264GPU_LV_CHROMA_DC + c * 4 + b] = (int16_t)ldc[b];
+    }
+    if (keep) dequant4_row(v, q, j);
+    else { v[0] = v[1] = v[2] = v[3] = 0; }
+    if (j == 0) v[0] = dq[i];
+    idct4_quad(v, lane);
+#pragma unroll
+    for (int t = 0; t < 4; t++) v[t] += p[t];
+    // flags: ballot over one lane per block
+    unsigned long long bal = __ballot(act && keep && j == 0);
+    unsigned long long bdc = __ballot(act && nzdc != 0 && i == 0 && j == 0);
+    unsigned bits = 0;
+#pragma unroll
+    for (int b = 0; b < 8; b++) bits |= (unsigned)((bal >> (4 * b)) & 1) << (16 + b);
+    bits |= (unsigned)(bdc & 1) << 25;
+    bits |= (unsigned)((bdc >> 16) & 1) << 26;
+    nnz_bits |= bits;
+    cbp_chroma = (bits & 0x00ff0000u) ? 2 : (bits & 0x06000000u) ? 1 : 0;
+    return pack4_clip(v);
+}
+
+}  // namespace x264gpu

@@ -1,0 +1,188 @@
+// encoder.hip — Tier-2 frame pipeline of include/x264gpu.h: host-side orchestration of the HIP
+// kernels that replace the per-frame work of x264_encoder_encode() (reference call site
+// codec.c:1693) for a lock-step batch of independent closed-GOP streams.
+//
+// Stage order per call (all on the caller's HIP stream, no host synchronisation, graph-capturable):
+//   ingest -> [P: analyse (ME) -> encode_inter] -> intra wavefront -> deblock wavefront ->
+//   half-pel planes + border expansion.   Device-resident DPB: two slots of {4 padded luma planes,
+//   padded NV12 chroma} per stream; the MV field of the previous frame feeds the next frame's ME.
+#include "enc_common.cuh"
+#include "k_analyse.cuh"
+#include "k_encode.cuh"
+#include "k_intra.cuh"
+#include "k_deblock.cuh"
+#include <math.h>
+#include <string.h>
+#include <new>
+
+namespace x264gpu {
+int launch_hpel_filter(uint8_t *planes, size_t plane_bytes, int stride, int w, int h, int pad, hipStream_t st);
+}
+using namespace x264gpu;
+
+struct x264gpu_encoder {
+    x264gpu_config cfg;
+    EncK k;                       // template of the kernel argument block (pointers refreshed per call)
+    uint8_t *fenc_y = nullptr, *fenc_uv = nullptr;
+    uint8_t *luma[2] = { nullptr, nullptr }, *chroma[2] = { nullptr, nullptr };
+    int16_t *mvf[2] = { nullptr, nullptr };
+    int8_t *reff[2] = { nullptr, nullptr };
+    uint16_t *cost_mv[52] = {};
+    int cur = 0, have_ref = 0;
+};
+
+static const char *const kStageNames[] = { "ingest", "analyse_p", "encode_inter", "intra", "deblock", "hpel_filter" };
+
+static int build_cost_mv(x264gpu_encoder *e, int qp)
+{
+    if (e->cost_mv[qp]) return X264GPU_OK;
+    // lambda * (2*log2(|mvd|+1) + 0.718 + (mvd != 0)) + 0.5 in float, saturated to u16 (x264's cost_mv)
+    uint16_t *h = new (std::nothrow) uint16_t[2 * MVCOST_HALF];
+    if (!h) return set_err(X264GPU_ENOMEM, "cost_mv host", hipSuccess);
+    const int lambda = lambda_of(qp);
+    for (int i = 0; i < MVCOST_HALF; i++) {
+        float bits = log2f((float)(i + 1)) * 2.0f + 0.718f + (i ? 1.0f : 0.0f);
+        int c = (int)((float)lambda * bits + 0.5f);
+        if (c > 65535) c = 65535;
+        h[MVCOST_HALF + i] = (uint16_t)c;
+        h[MVCOST_HALF - i] = (uint16_t)c;
+    }
+    h[0] = h[1];
+    hipError_t er = hipMalloc((void **)&e->cost_mv[qp], 2 * MVCOST_HALF * sizeof(uint16_t));
+    if (er == hipSuccess) er = hipMemcpy(e->cost_mv[qp], h, 2 * MVCOST_HALF * sizeof(uint16_t), hipMemcpyHostToDevice);
+    delete[] h;
+    if (er != hipSuccess) return set_err(X264GPU_EHIP, "cost_mv upload", er);
+    return X264GPU_OK;
+}
+
+extern "C" {
+
+int x264gpu_encoder_create(x264gpu_encoder **out, const x264gpu_config *cfg)
+{
+    ARG_TRY(out && cfg);
+    ARG_TRY(cfg->width >= 16 && cfg->height >= 16 && !(cfg->width & 1) && !(cfg->height & 1) && cfg->streams >= 1);
+    ARG_TRY(cfg->qp_i >= 0 && cfg->qp_i <= 51 && cfg->qp_p >= 0 && cfg->qp_p <= 51 && cfg->refs == 1);
+    ARG_TRY(cfg->width <= 4096 && cfg->height <= 2304 && cfg->me_range >= 4 && cfg->me_range <= 16);
+    x264gpu_encoder *e = new (std::nothrow) x264gpu_encoder();
+    if (!e) return set_err(X264GPU_ENOMEM, "encoder", hipSuccess);
+    e->cfg = *cfg;
+    EncK &k = e->k;
+    memset(&k, 0, sizeof(k));
+    k.w = cfg->width; k.h = cfg->height;
+    k.mbw = (k.w + 15) / 16; k.mbh = (k.h + 15) / 16; k.nmb = k.mbw * k.mbh;
+    k.cw = k.mbw * 16; k.ch = k.mbh * 16;
+    k.fs = (k.cw + 63) / 64 * 64;
+    k.rs = (k.cw + 2 * PAD + 63) / 64 * 64;
+    k.fency_bytes = (size_t)k.fs * k.ch;
+    k.fencuv_bytes = (size_t)k.fs * k.ch / 2;
+    k.plane_bytes = (size_t)k.rs * (k.ch + 2 * PAD);
+    k.luma_bytes = 4 * k.plane_bytes;
+    k.cplane_bytes = (size_t)k.rs * (k.ch / 2 + 2 * CPAD);
+    k.me_range = cfg->me_range; k.subme = cfg->subme; k.dct_decimate = cfg->dct_decimate;
+    k.partitions = cfg->partitions; k.chroma_qp_offset = cfg->chroma_qp_offset;
+    k.alpha_off = cfg->deblock_alpha * 2; k.beta_off = cfg->deblock_beta * 2;
+    const size_t S = (size_t)cfg->streams;
+    hipError_t er = hipSuccess;
+    auto alloc = [&](void **p, size_t n, int fill) {
+        if (er != hipSuccess) return;
+        er = hipMalloc(p, n);
+        if (er == hipSuccess) er = hipMemset(*p, fill, n);
+    };
+    alloc((void **)&e->fenc_y, S * k.fency_bytes, 0);
+    alloc((void **)&e->fenc_uv, S * k.fencuv_bytes, 0);
+    for (int i = 0; i < 2; i++) {
+        alloc((void **)&e->luma[i], S * k.luma_bytes, 0);
+        alloc((void **)&e->chroma[i], S * k.cplane_bytes, 0);
+        alloc((void **)&e->mvf[i], S * k.nmb * 2 * sizeof(int16_t), 0);
+        alloc((void **)&e->reff[i], S * k.nmb, 0xff);
+    }
+    if (er != hipSuccess) { x264gpu_encoder_destroy(e); return set_err(er == hipErrorOutOfMemory ? X264GPU_ENOMEM : X264GPU_EHIP, "encoder buffers", er); }
+    int rc = build_cost_mv(e, cfg->qp_p);
+    if (rc) { x264gpu_encoder_destroy(e); return rc; }
+    *out = e;
+    return X264GPU_OK;
+}
+
+void x264gpu_encoder_destroy(x264gpu_encoder *e)
+{
+    if (!e) return;
+    (void)hipFree(e->fenc_y); (void)hipFree(e->fenc_uv);
+    for (int i = 0; i < 2; i++) { (void)hipFree(e->luma[i]); (void)hipFree(e->chroma[i]); (void)hipFree(e->mvf[i]); (void)hipFree(e->reff[i]); }
+    for (int q = 0; q < 52; q++) (void)hipFree(e->cost_mv[q]);
+    delete e;
+}
+
+int x264gpu_encoder_mb_count(const x264gpu_encoder *e) { return e ? e->k.nmb : 0; }
+int x264gpu_encoder_stage_count(void) { return (int)(sizeof(kStageNames) / sizeof(kStageNames[0])); }
+const char *x264gpu_encoder_stage_name(int i) { return i >= 0 && i < x264gpu_encoder_stage_count() ? kStageNames[i] : ""; }
+
+int x264gpu_encode_frames(x264gpu_encoder *e, const uint8_t *d_i420, int slice_type, x264gpu_mb *d_mb,
+                          int16_t *d_levels, void *stream)
+{
+    ARG_TRY(e && d_i420 && d_mb && d_levels);
+    ARG_TRY(slice_type == X264GPU_SLICE_I || slice_type == X264GPU_SLICE_P);
+    ARG_TRY(slice_type == X264GPU_SLICE_I || e->have_ref);
+    hipStream_t st = (hipStream_t)stream;
+    const int S = e->cfg.streams;
+    EncK k = e->k;
+    const int qp = slice_type == X264GPU_SLICE_I ? e->cfg.qp_i : e->cfg.qp_p;
+    k.i420 = d_i420; k.fenc_y = e->fenc_y; k.fenc_uv = e->fenc_uv;
+    k.rec_luma = e->luma[e->cur]; k.rec_chroma = e->chroma[e->cur];
+    k.ref_luma = e->luma[e->cur ^ 1]; k.ref_chroma = e->chroma[e->cur ^ 1];
+    k.mvf_prev = e->mvf[0]; k.mvf_cur = e->mvf[1]; k.reff_prev = e->reff[0]; k.reff_cur = e->reff[1];
+    k.cost_mv = e->cost_mv[e->cfg.qp_p];
+    k.mb = d_mb; k.levels = d_levels;
+    k.qp = qp; k.lambda = lambda_of(qp); k.qpc = chroma_qp_of(qp, e->cfg.chroma_qp_offset);
+    k.slice_type = slice_type;
+    QuantCfg qc; qc.deadzone_inter = e->cfg.deadzone_inter; qc.deadzone_intra = e->cfg.deadzone_intra;
+    k.q_luma_intra = make_q4(qp, 0, qc); k.q_luma_inter = make_q4(qp, 1, qc);
+    k.q_chroma_intra = make_q4(k.qpc, 2, qc); k.q_chroma_inter = make_q4(k.qpc, 3, qc);
+
+    hipLaunchKernelGGL(k_ingest, dim3((k.cw / 4 + 255) / 256, k.ch, S), dim3(256), 0, st, k);
+    if (slice_type == X264GPU_SLICE_P) {
+        hipLaunchKernelGGL(k_analyse_p, dim3((k.nmb + 3) / 4, S), dim3(256), 0, st, k);
+        hipLaunchKernelGGL(k_encode_inter, dim3((k.nmb + 3) / 4, S), dim3(256), 0, st, k);
+    } else {
+        HIP_TRY(hipMemsetAsync(e->reff[1], 0xff, (size_t)S * k.nmb, st));
+        HIP_TRY(hipMemsetAsync(e->mvf[1], 0, (size_t)S * k.nmb * 2 * sizeof(int16_t), st));
+    }
+    hipLaunchKernelGGL(k_intra, dim3(S), dim3(1024), 0, st, k);
+    if (e->cfg.deblock) hipLaunchKernelGGL(k_deblock, dim3(S), dim3(1024), 0, st, k);
+    for (int s = 0; s < S; s++)
+        launch_hpel_filter(e->luma[e->cur] + (size_t)s * k.luma_bytes, k.plane_bytes, k.rs, k.cw, k.ch, PAD, st);
+    hipLaunchKernelGGL(k_chroma_border, dim3((k.cw / 2 + 2 * CPAD + 255) / 256, k.ch / 2 + 2 * CPAD, S), dim3(256), 0, st, k);
+    HIP_TRY(hipGetLastError());
+    e->cur ^= 1;
+    { int16_t *t = e->mvf[0]; e->mvf[0] = e->mvf[1]; e->mvf[1] = t; }
+    { int8_t *t = e->reff[0]; e->reff[0] = e->reff[1]; e->reff[1] = t; }
+    e->have_ref = 1;
+    return X264GPU_OK;
+}
+
+}  // extern "C"
+
+// crop + de-interleave the newest reference into I420 (parity tests, PSNR)
+__global__ __launch_bounds__(256) void k_get_recon(const uint8_t *__restrict__ luma00, const uint8_t *__restrict__ chroma00,
+                                                   int rs, int w, int h, uint8_t *__restrict__ out)
+{
+    const int x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y;
+    if (x >= w) return;
+    out[(size_t)y * w + x] = luma00[(size_t)y * rs + x];
+    if (y < h / 2 && x < w / 2) {
+        uint8_t *u = out + (size_t)w * h, *v = u + (size_t)(w / 2) * (h / 2);
+        u[(size_t)y * (w / 2) + x] = chroma00[(size_t)y * rs + 2 * x];
+        v[(size_t)y * (w / 2) + x] = chroma00[(size_t)y * rs + 2 * x + 1];
+    }
+}
+
+extern "C" int x264gpu_encoder_get_recon(x264gpu_encoder *e, int stream_idx, uint8_t *d_out, void *stream)
+{
+    ARG_TRY(e && d_out && stream_idx >= 0 && stream_idx < e->cfg.streams && e->have_ref);
+    const EncK &k = e->k;
+    const int slot = e->cur ^ 1;
+    const uint8_t *l = e->luma[slot] + (size_t)stream_idx * k.luma_bytes + (size_t)PAD * k.rs + PAD;
+    const uint8_t *c = e->chroma[slot] + (size_t)stream_idx * k.cplane_bytes + (size_t)CPAD * k.rs + 2 * CPAD;
+    hipLaunchKernelGGL(k_get_recon, dim3((k.w + 255) / 256, k.h), dim3(256), 0, (hipStream_t)stream, l, c, k.rs, k.w, k.h, d_out);
+    HIP_TRY(hipGetLastError());
+    return X264GPU_OK;
+}

@@ -1,0 +1,275 @@
+// k_analyse.cuh — P-frame macroblock analysis: motion estimation SAD/SATD pyramid (A2/A3) + the
+// intra-vs-inter estimate.  One wavefront per macroblock, four macroblocks per workgroup.
+//
+//   full-pel:  the reference search window (50 rows x 64 B, centred on the best start predictor) is
+//              staged in LDS with coalesced 8-byte loads; candidates are evaluated four at a time,
+//              lane = (candidate, row): 16 pixels per lane via v_alignbyte + v_sad_u8, 16-lane DPP row
+//              reduction, then a packed (cost<<3|tag) wave min replaying x264's first-best tie-breaks.
+//   sub-pel:   half-pel diamond on SAD, quarter-pel diamond on SATD; samples come straight from the four
+//              half-pel planes in HBM/L2 (mc_luma_row4), SATD in the Z layout (quad = 4x4 block).
+// Restates oracle/encoder.c me_search_16x16 / intra16_estimate / analyse_p_mb bit-exactly.
+#pragma once
+#include "enc_common.cuh"
+
+namespace x264gpu {
+
+constexpr int WIN_ROWS = 50, WIN_COLS = 64, WIN_STRIDE = 68, WIN_R = 17;
+
+__device__ __forceinline__ int clampi(int v, int lo, int hi) { return v < lo ? lo : v > hi ? hi : v; }
+__device__ __forceinline__ int median3(int a, int b, int c)
+{
+    int mn = min(a, b), mx = max(a, b);
+    return c < mn ? mn : c > mx ? mx : c;
+}
+
+// SAD of one 16-pixel row held in cr[4] against 16 bytes at (row base `wrow`, byte offset xoff) in LDS
+__device__ __forceinline__ int sad_row16_lds(const uint8_t *wrow, int xoff, const uint32_t cr[4])
+{
+    const uint32_t *w = (const uint32_t *)(wrow + (xoff & ~3));
+    const int sh = xoff & 3;
+    uint32_t w0 = w[0], w1 = w[1], w2 = w[2], w3 = w[3], w4 = w[4];
+    unsigned s = 0;
+    s = __builtin_amdgcn_sad_u8(__builtin_amdgcn_alignbyte(w1, w0, sh), cr[0], s);
+    s = __builtin_amdgcn_sad_u8(__builtin_amdgcn_alignbyte(w2, w1, sh), cr[1], s);
+    s = __builtin_amdgcn_sad_u8(__builtin_amdgcn_alignbyte(w3, w2, sh), cr[2], s);
+    s = __builtin_amdgcn_sad_u8(__builtin_amdgcn_alignbyte(w4, w3, sh), cr[3], s);
+    return (int)s;
+}
+__device__ __forceinline__ int sad_row16_global(const uint8_t *p, const uint32_t cr[4])
+{
+    unsigned s = 0;
+#pragma unroll
+    for (int i = 0; i < 4; i++) s = __builtin_amdgcn_sad_u8(load_u32_unaligned(p + 4 * i), cr[i], s);
+    return (int)s;
+}
+
+__device__ __forceinline__ int hex_dx(int i) { return (int)((0x01343101u >> (4 * i)) & 15) - 2; }
+__device__ __forceinline__ int hex_dy(int i) { return (int)((0x20024420u >> (4 * i)) & 15) - 2; }
+__device__ __forceinline__ int sq_dx(int k) { return (int)((0x22002011u >> (4 * (k - 1))) & 15) - 1; }  // k = 1..8
+__device__ __forceinline__ int sq_dy(int k) { return (int)((0x20201120u >> (4 * (k - 1))) & 15) - 1; }
+
+__global__ __launch_bounds__(256) void k_analyse_p(EncK k)
+{
+    __shared__ __attribute__((aligned(16))) uint8_t s_win[4][WIN_ROWS * WIN_STRIDE];
+    __shared__ uint8_t s_nb[4][NB_SIZE];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int mbi = blockIdx.x * 4 + wave, s = blockIdx.y;
+    if (mbi >= k.nmb) return;                       // wave-uniform; no block-wide barriers below
+    const int mbx = mbi % k.mbw, mby = mbi / k.mbw;
+    uint8_t *win = s_win[wave];
+    uint8_t *nb = s_nb[wave];
+
+    const uint8_t *fenc = k.fenc_y + (size_t)s * k.fency_bytes + (size_t)mby * 16 * k.fs + mbx * 16;
+    const uint8_t *p00 = ref_plane00(k, s);
+    const int px = mbx * 16, py = mby * 16;        // macroblock position in the picture
+
+    // current macroblock in both lane mappings
+    const int r = lane & 15, cnd = lane >> 4;       // (candidate, row) mapping
+    uint32_t cr[4];
+    { const uint4 v = *(const uint4 *)(fenc + (size_t)r * k.fs); cr[0] = v.x; cr[1] = v.y; cr[2] = v.z; cr[3] = v.w; }
+    const int zx = z_x0(lane), zy = z_y(lane);      // Z mapping
+    const uint32_t cz = *(const uint32_t *)(fenc + (size_t)zy * k.fs + zx);
+
+    // ---- motion vector limits (oracle mv_limits) ----
+    const int vrange = 512 * 4;
+    int smin0 = 4 * (-16 * mbx - 24), smax0 = 4 * (16 * (k.mbw - mbx - 1) + 24);
+    int smin1 = clampi(4 * (-16 * mby - 24), -vrange, vrange - 1), smax1 = clampi(4 * (16 * (k.mbh - mby - 1) + 24), -vrange, vrange - 1);
+    const int fmin0 = (smin0 >> 2) + 6, fmax0 = (smax0 >> 2) - 6, fmin1 = (smin1 >> 2) + 6, fmax1 = (smax1 >> 2) - 6;
+
+    // ---- predictor from the previous frame's MV field (oracle prev_mvp) ----
+    const int16_t *mvf = k.mvf_prev + (size_t)s * k.nmb * 2;
+    const int8_t *rf = k.reff_prev + (size_t)s * k.nmb;
+    int mvp0, mvp1;
+    {
+        int a0 = 0, a1 = 0, b0 = 0, b1 = 0, c0 = 0, c1 = 0;
+        const bool ia = mbx > 0, ib = mby > 0, ic = mby > 0 && mbx + 1 < k.mbw;
+        if (ia) { int i = mbi - 1; if (rf[i] >= 0) { a0 = mvf[2 * i]; a1 = mvf[2 * i + 1]; } }
+        if (ib) { int i = mbi - k.mbw; if (rf[i] >= 0) { b0 = mvf[2 * i]; b1 = mvf[2 * i + 1]; } }
+        if (ic) { int i = mbi - k.mbw + 1; if (rf[i] >= 0) { c0 = mvf[2 * i]; c1 = mvf[2 * i + 1]; } }
+        else if (mby > 0 && mbx > 0) { int i = mbi - k.mbw - 1; if (rf[i] >= 0) { c0 = mvf[2 * i]; c1 = mvf[2 * i + 1]; } }
+        if (!ib && ia) { mvp0 = a0; mvp1 = a1; }
+        else { mvp0 = median3(a0, b0, c0); mvp1 = median3(a1, b1, c1); }
+    }
+    const uint16_t *cmx = k.cost_mv + MVCOST_HALF - mvp0, *cmy = k.cost_mv + MVCOST_HALF - mvp1;
+
+    // ---- start candidates: predictor, zero, co-located (lane groups 0..2 evaluate one each) ----
+    int bmx, bmy, bcost;
+    {
+        int cx[3], cy[3];
+        cx[0] = clampi((mvp0 + 2) >> 2, fmin0, fmax0); cy[0] = clampi((mvp1 + 2) >> 2, fmin1, fmax1);
+        cx[1] = clampi(0, fmin0, fmax0); cy[1] = clampi(0, fmin1, fmax1);
+        const bool has_col = rf[mbi] >= 0;
+        cx[2] = has_col ? clampi((mvf[2 * mbi] + 2) >> 2, fmin0, fmax0) : 0;
+        cy[2] = has_col ? clampi((mvf[2 * mbi + 1] + 2) >> 2, fmin1, fmax1) : 0;
+        const int c = cnd < 3 ? cnd : 0;
+        const int mx = c == 0 ? cx[0] : c == 1 ? cx[1] : cx[2], my = c == 0 ? cy[0] : c == 1 ? cy[1] : cy[2];
+        int sad = sad_row16_global(p00 + (long)(py + my + r) * k.rs + px + mx, cr);
+        sad = row16_sum(sad);
+        unsigned key = 0xffffffffu;
+        if (cnd < 2 || (cnd == 2 && has_col)) key = ((unsigned)(sad + cmx[mx * 4] + cmy[my * 4]) << 3) | (unsigned)cnd;
+        key = wave_min_u32(key);
+        const int best = key & 7;
+        bcost = (int)(key >> 3);
+        bmx = best == 0 ? cx[0] : best == 1 ? cx[1] : cx[2];
+        bmy = best == 0 ? cy[0] : best == 1 ? cy[1] : cy[2];
+    }
+
+    // ---- stage the search window in LDS ----
+    int wx0 = (px + bmx - WIN_R) & ~7, wy0 = py + bmy - WIN_R;
+    wx0 = clampi(wx0, -PAD, k.cw + PAD - WIN_COLS);
+    wy0 = clampi(wy0, -PAD, k.ch + PAD - WIN_ROWS);
+    for (int i = lane; i < WIN_ROWS * 8; i += 64) {
+        const int row = i >> 3, col = (i & 7) * 8;
+        const uint2 v = *(const uint2 *)(p00 + (long)(wy0 + row) * k.rs + wx0 + col);
+        uint32_t *d = (uint32_t *)(win + row * WIN_STRIDE + col);
+        d[0] = v.x; d[1] = v.y;
+    }
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_s_waitcnt(0xc07f);
+
+    // cost of full-pel candidate (mx,my) for this lane's row; valid after row16_sum on the 16-lane group
+#define FPEL_KEY(mx, my, tag) \
+    (((unsigned)(row16_sum(sad_row16_lds(win + (py + (my) + r - wy0) * WIN_STRIDE, px + (mx) - wx0, cr)) + cmx[(mx) * 4] + cmy[(my) * 4]) << 3) | (unsigned)(tag))
+
+    // ---- hexagon search ----
+    {
+        unsigned key = (unsigned)bcost << 3;
+        // first ring: hex2[1..6], tags 2..7 (two passes of four lane groups)
+        {
+            int i = 1 + cnd;                                   // hex2 index 1..4
+            unsigned kk = FPEL_KEY(bmx + hex_dx(i), bmy + hex_dy(i), i + 1);
+            key = min(key, wave_min_u32(kk));
+            i = 5 + (cnd & 1);                                 // hex2 index 5..6
+            kk = FPEL_KEY(bmx + hex_dx(i), bmy + hex_dy(i), i + 1);
+            if (cnd >= 2) kk = 0xffffffffu;
+            key = min(key, wave_min_u32(kk));
+        }
+        if (key & 7) {
+            int dir = (int)(key & 7) - 2;
+            bmx += hex_dx(dir + 1); bmy += hex_dy(dir + 1);
+            for (int it = (k.me_range >> 1) - 1; it > 0 && bmx >= fmin0 && bmx <= fmax0 && bmy >= fmin1 && bmy <= fmax1; it--) {
+                key &= ~7u;
+                const int c = cnd < 3 ? cnd : 0;
+                unsigned kk = FPEL_KEY(bmx + hex_dx(dir + c), bmy + hex_dy(dir + c), c + 1);
+                if (cnd >= 3) kk = 0xffffffffu;
+                key = min(key, wave_min_u32(kk));
+                if (!(key & 7)) break;
+                dir += (int)(key & 7) - 2;
+                dir = dir < 0 ? 5 : dir > 5 ? 0 : dir;         // mod6m1
+                bmx += hex_dx(dir + 1); bmy += hex_dy(dir + 1);
+            }
+        }
+        bcost = (int)(key >> 3);
+        // square refine: square1[1..8]; first strictly-better candidate in order wins
+        unsigned sk = ((unsigned)bcost << 4);
+        {
+            int q = 1 + cnd;
+            unsigned kk = (FPEL_KEY(bmx + sq_dx(q), bmy + sq_dy(q), 0) << 1) | (unsigned)q;
+            sk = min(sk, wave_min_u32(kk));
+            q = 5 + cnd;
+            kk = (FPEL_KEY(bmx + sq_dx(q), bmy + sq_dy(q), 0) << 1) | (unsigned)q;
+            sk = min(sk, wave_min_u32(kk));
+        }
+        const int bd = sk & 15;
+        bcost = (int)(sk >> 4);
+        if (bd) { bmx += sq_dx(bd); bmy += sq_dy(bd); }
+    }
+#undef FPEL_KEY
+
+    // ---- sub-pel refinement ----
+    int mx = bmx * 4, my = bmy * 4;
+    const size_t pb = k.plane_bytes;
+    if (k.subme >= 2) {
+        const int sub = min(k.subme, 11);
+        const int hp_it = sub < 6 ? 1 : sub < 8 ? 2 : 4;
+        const int qp_it = sub < 4 ? 0 : sub == 4 ? 1 : sub < 8 ? 2 : 10;
+        // half-pel diamond, SAD, lane = (candidate, row): (0,-2) (0,2) (-2,0) (2,0)
+        for (int it = hp_it; it > 0; it--) {
+            const int cx = mx + (cnd == 2 ? -2 : cnd == 3 ? 2 : 0), cy = my + (cnd == 0 ? -2 : cnd == 1 ? 2 : 0);
+            unsigned sd = 0;
+#pragma unroll
+            for (int i = 0; i < 4; i++) sd = __builtin_amdgcn_sad_u8(mc_luma_row4(p00, pb, k.rs, px + 4 * i, py + r, cx, cy), cr[i], sd);
+            unsigned key = ((unsigned)(row16_sum((int)sd) + cmx[cx] + cmy[cy]) << 2) | (unsigned)cnd;
+            key = wave_min_u32(key);
+            if ((int)(key >> 2) < bcost) {
+                const int b = key & 3;
+                bcost = (int)(key >> 2);
+                mx += b == 2 ? -2 : b == 3 ? 2 : 0; my += b == 0 ? -2 : b == 1 ? 2 : 0;
+            } else break;
+        }
+        // SATD at the best half-pel position
+        {
+            int e[4], p[4], d[4];
+            unpack4(cz, e); unpack4(mc_luma_row4(p00, pb, k.rs, px + zx, py + zy, mx, my), p);
+#pragma unroll
+            for (int i = 0; i < 4; i++) d[i] = e[i] - p[i];
+            bcost = (wave_sum(satd_quad_partial(d, lane)) >> 1) + cmx[mx] + cmy[my];
+        }
+        // quarter-pel diamond, SATD: (0,-1) (0,1) (-1,0) (1,0), never stepping straight back
+        int bdir = -1;
+        for (int it = qp_it; it > 0; it--) {
+            if (my <= smin1 || my >= smax1 || mx <= smin0 || mx >= smax0) break;
+            const int odir = bdir, omx = mx, omy = my;
+            for (int q = 0; q < 4; q++) {
+                if ((q ^ 1) == odir) continue;
+                const int cx = omx + (q == 2 ? -1 : q == 3 ? 1 : 0), cy = omy + (q == 0 ? -1 : q == 1 ? 1 : 0);
+                int e[4], p[4], d[4];
+                unpack4(cz, e); unpack4(mc_luma_row4(p00, pb, k.rs, px + zx, py + zy, cx, cy), p);
+#pragma unroll
+                for (int i = 0; i < 4; i++) d[i] = e[i] - p[i];
+                const int c = (wave_sum(satd_quad_partial(d, lane)) >> 1) + cmx[cx] + cmy[cy];
+                if (c < bcost) { bcost = c; mx = cx; my = cy; bdir = q; }
+            }
+            if (mx == omx && my == omy) break;
+        }
+    }
+
+    // ---- intra 16x16 estimate on source neighbours (oracle intra16_estimate) ----
+    const bool left = mbx > 0, top = mby > 0;
+    if (lane < 25) nb[NB_TOP - 1 + lane] = (top && (lane > 0 || left)) ? fenc[-(long)k.fs - 1 + lane] : 128;   // tl + top[0..23]
+    if (lane < 16) nb[NB_LEFT + lane] = left ? fenc[(long)lane * k.fs - 1] : 128;
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_s_waitcnt(0xc07f);
+    int icost = 1 << 28;
+    {
+        const Pred16 pp = pred16_setup(nb, lane);
+        int modes[4], n = 0;
+        if (left && top) { modes[0] = PRED16_V; modes[1] = PRED16_H; modes[2] = PRED16_DC; modes[3] = PRED16_P; n = 4; }
+        else if (left) { modes[0] = PRED16_H; modes[1] = PRED16_DC_LEFT; n = 2; }
+        else if (top) { modes[0] = PRED16_V; modes[1] = PRED16_DC_TOP; n = 2; }
+        else { modes[0] = PRED16_DC_128; n = 1; }
+        for (int i = 0; i < n; i++) {
+            const int m = modes[i], sig = m > PRED16_P ? PRED16_DC : m;
+            int e[4], p[4], d[4];
+            unpack4(cz, e); unpack4(pred16_row4(nb, pp, m, zx, zy), p);
+#pragma unroll
+            for (int t = 0; t < 4; t++) d[t] = e[t] - p[t];
+            const int c = (wave_sum(satd_quad_partial(d, lane)) >> 1) + k.lambda * bs_size_ue(sig);
+            icost = min(icost, c);
+        }
+    }
+
+    // ---- record ----
+    if (lane == 0) {
+        x264gpu_mb *mb = k.mb + (size_t)s * k.nmb + mbi;
+        x264gpu_mb rec;
+        __builtin_memset(&rec, 0, sizeof(rec));
+        rec.qp = (uint8_t)k.qp;
+        rec.aux[0] = bcost; rec.aux[1] = icost;
+        int16_t *mo = k.mvf_cur + ((size_t)s * k.nmb + mbi) * 2;
+        if (icost < bcost) {
+            rec.type = X264GPU_MB_I16x16;
+            rec.cost = icost;
+            for (int i = 0; i < 4; i++) rec.ref[i] = -1;
+            k.reff_cur[(size_t)s * k.nmb + mbi] = -1; mo[0] = 0; mo[1] = 0;
+        } else {
+            rec.type = X264GPU_MB_P_L0;
+            rec.cost = bcost;
+            for (int i = 0; i < 4; i++) { rec.mv[i][0] = (int16_t)mx; rec.mv[i][1] = (int16_t)my; rec.ref[i] = 0; }
+            k.reff_cur[(size_t)s * k.nmb + mbi] = 0; mo[0] = (int16_t)mx; mo[1] = (int16_t)my;
+        }
+        *mb = rec;
+    }
+}
+
+}  // namespace x264gpu

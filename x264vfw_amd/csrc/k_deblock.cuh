@@ -1,0 +1,213 @@
+// k_deblock.cuh — in-loop deblocking filter (A9; H.264 8.7) as a 2-D wavefront.  The normative
+// macroblock order (left, top and top-right neighbours first) makes this a d = x + 2y wavefront; as in
+// k_intra one 1024-thread workgroup per stream walks the diagonals with workgroup barriers.  Each
+// wavefront stages its macroblock (+4 rows / 4 columns of neighbours) in LDS, runs the four vertical
+// then four horizontal edges there (luma on lanes 0..15, chroma on lanes 16..31 in the same step), and
+// writes back only the samples the standard lets this macroblock modify.
+// Restates oracle/encoder.c deblock_frame + oracle/deblock.c bit-exactly.
+#pragma once
+#include "enc_common.cuh"
+
+namespace x264gpu {
+
+static __device__ const uint8_t d_alpha_table[52] = {
+    0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 4, 4, 5, 6, 7, 8, 9, 10, 12, 13,
+    15, 17, 20, 22, 25, 28, 32, 36, 40, 45, 50, 56, 63, 71, 80, 90, 101, 113, 127, 144, 162, 182, 203, 226, 255, 255 };
+static __device__ const uint8_t d_beta_table[52] = {
+    0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 2, 2, 2, 3, 3, 3, 3, 4, 4, 4,
+    6, 6, 7, 7, 8, 8, 9, 9, 10, 10, 11, 11, 12, 12, 13, 13, 14, 14, 15, 15, 16, 16, 17, 17, 18, 18 };
+static __device__ const uint8_t d_tc0_table[52][3] = {
+    { 0, 0, 0 }, { 0, 0, 0 }, { 0, 0, 0 }, { 0, 0, 0 }, { 0, 0, 0 }, { 0, 0, 0 }, { 0, 0, 0 }, { 0, 0, 0 },
+    { 0, 0, 0 }, { 0, 0, 0 }, { 0, 0, 0 }, { 0, 0, 0 }, { 0, 0, 0 }, { 0, 0, 0 }, { 0, 0, 0 }, { 0, 0, 0 },
+    { 0, 0, 0 }, { 0, 0, 1 }, { 0, 0, 1 }, { 0, 0, 1 }, { 0, 0, 1 }, { 0, 1, 1 }, { 0, 1, 1 }, { 1, 1, 1 },
+    { 1, 1, 1 }, { 1, 1, 1 }, { 1, 1, 1 }, { 1, 1, 2 }, { 1, 1, 2 }, { 1, 1, 2 }, { 1, 1, 2 }, { 1, 2, 3 },
+    { 1, 2, 3 }, { 2, 2, 3 }, { 2, 2, 4 }, { 2, 3, 4 }, { 2, 3, 4 }, { 3, 3, 5 }, { 3, 4, 6 }, { 3, 4, 6 },
+    { 4, 5, 7 }, { 4, 5, 8 }, { 4, 6, 9 }, { 5, 7, 10 }, { 6, 8, 11 }, { 6, 8, 13 }, { 7, 10, 14 }, { 8, 11, 16 },
+    { 9, 12, 18 }, { 10, 13, 20 }, { 11, 15, 23 }, { 13, 17, 25 } };
+
+constexpr int DL_STRIDE = 24;                  // luma tile: rows -4..15, cols -4..15
+constexpr int DL_ORG = 4 * DL_STRIDE + 4;
+constexpr int DL_SIZE = 20 * DL_STRIDE;
+constexpr int DC_STRIDE = 24;                  // chroma NV12 tile: rows -2..7, bytes -4..15
+constexpr int DC_ORG = 2 * DC_STRIDE + 4;
+constexpr int DC_SIZE = 10 * DC_STRIDE;
+
+struct DeblockLds { uint8_t lt[16][DL_SIZE]; uint8_t ct[16][DC_SIZE]; };
+
+__device__ __forceinline__ bool mb_is_intra(int type) { return type == X264GPU_MB_I4x4 || type == X264GPU_MB_I16x16; }
+
+// boundary strength between 4x4 block (pbx,pby) of P and (qbx,qby) of Q (oracle edge_bs)
+__device__ __forceinline__ int edge_bs(const x264gpu_mb *P, int pbx, int pby, const x264gpu_mb *Q, int qbx, int qby, bool mb_edge)
+{
+    if (mb_is_intra(P->type) || mb_is_intra(Q->type)) return mb_edge ? 4 : 3;
+    const int pn = (P->nnz >> (((pby >> 1) * 2 + (pbx >> 1)) * 4 + (pby & 1) * 2 + (pbx & 1))) & 1;
+    const int qn = (Q->nnz >> (((qby >> 1) * 2 + (qbx >> 1)) * 4 + (qby & 1) * 2 + (qbx & 1))) & 1;
+    if (pn || qn) return 2;
+    const int pi = (pby >> 1) * 2 + (pbx >> 1), qi = (qby >> 1) * 2 + (qbx >> 1);
+    if (P->ref[pi] != Q->ref[qi]) return 1;
+    if (abs(P->mv[pi][0] - Q->mv[qi][0]) >= 4 || abs(P->mv[pi][1] - Q->mv[qi][1]) >= 4) return 1;
+    return 0;
+}
+
+// one luma line across an edge; pix -> q0, xs = byte step across the edge (oracle x264o_deblock_luma_edge)
+__device__ __forceinline__ void filter_luma_line(uint8_t *pix, int xs, int alpha, int beta, int tc0, int bs)
+{
+    const int p2 = pix[-3 * xs], p1 = pix[-2 * xs], p0 = pix[-xs], q0 = pix[0], q1 = pix[xs], q2 = pix[2 * xs];
+    if (abs(p0 - q0) >= alpha || abs(p1 - p0) >= beta || abs(q1 - q0) >= beta) return;
+    const int ap = abs(p2 - p0), aq = abs(q2 - q0);
+    if (bs < 4) {
+        const int tc = tc0 + (ap < beta) + (aq < beta);
+        const int delta = min(max((((q0 - p0) << 2) + (p1 - q1) + 4) >> 3, -tc), tc);
+        if (ap < beta) pix[-2 * xs] = (uint8_t)(p1 + min(max((p2 + ((p0 + q0 + 1) >> 1) - (p1 << 1)) >> 1, -tc0), tc0));
+        if (aq < beta) pix[xs] = (uint8_t)(q1 + min(max((q2 + ((p0 + q0 + 1) >> 1) - (q1 << 1)) >> 1, -tc0), tc0));
+        pix[-xs] = (uint8_t)clip_u8(p0 + delta);
+        pix[0] = (uint8_t)clip_u8(q0 - delta);
+    } else {
+        const bool strong = abs(p0 - q0) < ((alpha >> 2) + 2);
+        if (ap < beta && strong) {
+            const int p3 = pix[-4 * xs];
+            pix[-xs] = (uint8_t)((p2 + 2 * p1 + 2 * p0 + 2 * q0 + q1 + 4) >> 3);
+            pix[-2 * xs] = (uint8_t)((p2 + p1 + p0 + q0 + 2) >> 2);
+            pix[-3 * xs] = (uint8_t)((2 * p3 + 3 * p2 + p1 + p0 + q0 + 4) >> 3);
+        } else
+            pix[-xs] = (uint8_t)((2 * p1 + p0 + q1 + 2) >> 2);
+        if (aq < beta && strong) {
+            const int q3 = pix[3 * xs];
+            pix[0] = (uint8_t)((p1 + 2 * p0 + 2 * q0 + 2 * q1 + q2 + 4) >> 3);
+            pix[xs] = (uint8_t)((p0 + q0 + q1 + q2 + 2) >> 2);
+            pix[2 * xs] = (uint8_t)((2 * q3 + 3 * q2 + q1 + q0 + p0 + 4) >> 3);
+        } else
+            pix[0] = (uint8_t)((2 * q1 + q0 + p1 + 2) >> 2);
+    }
+}
+
+__device__ __forceinline__ void filter_chroma_line(uint8_t *pix, int xs, int alpha, int beta, int tc0, int bs)
+{
+    const int p1 = pix[-2 * xs], p0 = pix[-xs], q0 = pix[0], q1 = pix[xs];
+    if (abs(p0 - q0) >= alpha || abs(p1 - p0) >= beta || abs(q1 - q0) >= beta) return;
+    if (bs < 4) {
+        const int tc = tc0 + 1;
+        const int delta = min(max((((q0 - p0) << 2) + (p1 - q1) + 4) >> 3, -tc), tc);
+        pix[-xs] = (uint8_t)clip_u8(p0 + delta);
+        pix[0] = (uint8_t)clip_u8(q0 - delta);
+    } else {
+        pix[-xs] = (uint8_t)((2 * p1 + p0 + q1 + 2) >> 2);
+        pix[0] = (uint8_t)((2 * q1 + q0 + p1 + 2) >> 2);
+    }
+}
+
+__device__ void deblock_mb_wave(const EncK &k, DeblockLds &L, int wave, int lane, int s, int mbx, int mby)
+{
+    uint8_t *lt = L.lt[wave] + DL_ORG, *ct = L.ct[wave] + DC_ORG;
+    const x264gpu_mb *mbs = k.mb + (size_t)s * k.nmb;
+    const x264gpu_mb *Q = mbs + mby * k.mbw + mbx;
+    uint8_t *Y = rec_plane00(k, s) + (size_t)(mby * 16) * k.rs + mbx * 16;
+    uint8_t *UV = rec_chroma00(k, s) + (size_t)(mby * 8) * k.rs + mbx * 16;
+
+    // ---- stage the neighbourhood in LDS ----
+    for (int i = lane; i < 20 * 5; i += 64) {
+        const int r = i / 5 - 4, c = (i % 5) * 4 - 4;
+        *(uint32_t *)(lt + r * DL_STRIDE + c) = *(const uint32_t *)(Y + (long)r * k.rs + c);
+    }
+    if (lane < 50) {
+        const int r = lane / 5 - 2, c = (lane % 5) * 4 - 4;
+        *(uint32_t *)(ct + r * DC_STRIDE + c) = *(const uint32_t *)(UV + (long)r * k.rs + c);
+    }
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_s_waitcnt(0xc07f);
+
+    const int qpq = Q->qp, qpcq = chroma_qp_dev(qpq + k.chroma_qp_offset);
+    for (int dir = 0; dir < 2; dir++)
+        for (int edge = 0; edge < 4; edge++) {
+            const x264gpu_mb *P = Q;
+            if (edge == 0) {
+                if (dir == 0) { if (mbx == 0) continue; P = Q - 1; }
+                else { if (mby == 0) continue; P = Q - k.mbw; }
+            }
+            const int qpp = P->qp;
+            const int qpav = (qpp + qpq + 1) >> 1, qpcav = (chroma_qp_dev(qpp + k.chroma_qp_offset) + qpcq + 1) >> 1;
+            const int ia = min(max(qpav + k.alpha_off, 0), 51), ib = min(max(qpav + k.beta_off, 0), 51);
+            const int ica = min(max(qpcav + k.alpha_off, 0), 51), icb = min(max(qpcav + k.beta_off, 0), 51);
+            if (lane < 16) {
+                const int seg = lane >> 2;
+                const int qbx = dir == 0 ? edge : seg, qby = dir == 0 ? seg : edge;
+                const int pbx = dir == 0 ? (edge + 3) & 3 : seg, pby = dir == 0 ? seg : (edge + 3) & 3;
+                const int bs = edge_bs(P, pbx, pby, Q, qbx, qby, edge == 0);
+                if (bs) {
+                    const int tc0 = bs < 4 ? d_tc0_table[ia][bs - 1] : 0;
+                    uint8_t *pix = dir == 0 ? lt + lane * DL_STRIDE + edge * 4 : lt + edge * 4 * DL_STRIDE + lane;
+                    filter_luma_line(pix, dir == 0 ? 1 : DL_STRIDE, d_alpha_table[ia], d_beta_table[ib], tc0, bs);
+                }
+            } else if (lane < 32 && !(edge & 1)) {
+                const int t = lane - 16;           // vertical edge: chroma row 0..7 (U and V); horizontal: byte column 0..15
+                if (dir == 0 && t < 8) {
+                    const int seg = t >> 1;
+                    const int bs = edge_bs(P, (edge + 3) & 3, seg, Q, edge, seg, edge == 0);
+                    if (bs) {
+                        const int tc0 = bs < 4 ? d_tc0_table[ica][bs - 1] : 0;
+                        uint8_t *pix = ct + t * DC_STRIDE + edge * 4;      // chroma x = edge*2 -> byte edge*4
+                        filter_chroma_line(pix, 2, d_alpha_table[ica], d_beta_table[icb], tc0, bs);
+                        filter_chroma_line(pix + 1, 2, d_alpha_table[ica], d_beta_table[icb], tc0, bs);
+                    }
+                } else if (dir == 1) {
+                    const int seg = t >> 2;
+                    const int bs = edge_bs(P, seg, (edge + 3) & 3, Q, seg, edge, edge == 0);
+                    if (bs) {
+                        const int tc0 = bs < 4 ? d_tc0_table[ica][bs - 1] : 0;
+                        uint8_t *pix = ct + (edge * 2) * DC_STRIDE + t;     // chroma y = edge*2
+                        filter_chroma_line(pix, DC_STRIDE, d_alpha_table[ica], d_beta_table[icb], tc0, bs);
+                    }
+                }
+            }
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_s_waitcnt(0xc07f);
+        }
+
+    // ---- write back exactly what this macroblock may have modified ----
+    {   // own luma 16x16: 64 dwords
+        const int r = lane >> 2, c = (lane & 3) * 4;
+        *(uint32_t *)(Y + (long)r * k.rs + c) = *(const uint32_t *)(lt + r * DL_STRIDE + c);
+    }
+    if (mbx > 0 && lane < 16) *(uint32_t *)(Y + (long)lane * k.rs - 4) = *(const uint32_t *)(lt + lane * DL_STRIDE - 4);
+    if (mby > 0 && lane >= 16 && lane < 28) {
+        const int i = lane - 16, r = -3 + i / 4, c = (i & 3) * 4;
+        *(uint32_t *)(Y + (long)r * k.rs + c) = *(const uint32_t *)(lt + r * DL_STRIDE + c);
+    }
+    if (lane >= 32) {   // own chroma 8 rows x 16 bytes: 32 dwords
+        const int i = lane - 32, r = i >> 2, c = (i & 3) * 4;
+        *(uint32_t *)(UV + (long)r * k.rs + c) = *(const uint32_t *)(ct + r * DC_STRIDE + c);
+    }
+    __builtin_amdgcn_wave_barrier();
+    if (mbx > 0 && lane < 8) *(uint32_t *)(UV + (long)lane * k.rs - 4) = *(const uint32_t *)(ct + lane * DC_STRIDE - 4);
+    if (mby > 0 && lane >= 8 && lane < 16) {
+        const int i = lane - 8, r = -2 + (i >> 2), c = (i & 3) * 4;
+        *(uint32_t *)(UV + (long)r * k.rs + c) = *(const uint32_t *)(ct + r * DC_STRIDE + c);
+    }
+}
+
+__global__ __launch_bounds__(1024) void k_deblock(EncK k)
+{
+    __shared__ __attribute__((aligned(16))) DeblockLds L;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, s = blockIdx.x;
+    const int ndiag = k.mbw + 2 * (k.mbh - 1);
+    for (int d = 0; d < ndiag; d++) {
+        const int ymin = max(0, (d - (k.mbw - 1) + 1) >> 1), ymax = min(k.mbh - 1, d >> 1);
+        for (int i = ymin + wave; i <= ymax; i += 16) deblock_mb_wave(k, L, wave, lane, s, d - 2 * i, i);
+        __syncthreads();
+    }
+}
+
+// chroma border expansion of the padded NV12 reference (frame_expand_border for the chroma plane)
+__global__ __launch_bounds__(256) void k_chroma_border(EncK k)
+{
+    const int s = blockIdx.z;
+    const int cw = k.cw / 2, chh = k.ch / 2;
+    const int x = blockIdx.x * 256 + threadIdx.x - CPAD, y = blockIdx.y - CPAD;   // chroma sample coords
+    if (x >= cw + CPAD) return;
+    if (x >= 0 && x < cw && y >= 0 && y < chh) return;
+    uint8_t *uv = rec_chroma00(k, s);
+    const int sx = min(max(x, 0), cw - 1), sy = min(max(y, 0), chh - 1);
+    *(uint16_t *)(uv + (long)y * k.rs + 2 * x) = *(const uint16_t *)(uv + (long)sy * k.rs + 2 * sx);
+}
+
+}  // namespace x264gpu

@@ -1,0 +1,113 @@
+// k_encode.cuh — macroblock encode kernels: motion compensation + 4x4 integer DCT + deadzone quant +
+// decimation + dequant + iDCT + reconstruction (A6/A7/A8/A10) for inter macroblocks, and the
+// reconstructed-neighbour intra stage (A5) run as a 2-D wavefront by one workgroup per stream.
+// Restates oracle/encoder.c encode_inter_mb / intra_mb bit-exactly.
+#pragma once
+#include "enc_common.cuh"
+
+namespace x264gpu {
+
+// ------------------------------------------------------------------------------------------------
+// stage 0: ingest I420 -> MB-aligned luma + NV12 chroma with edge replication (A1)
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_ingest(EncK k)
+{
+    const int s = blockIdx.z;
+    const int x = (blockIdx.x * 256 + threadIdx.x) * 4, y = blockIdx.y;
+    if (x >= k.cw) return;
+    const uint8_t *src = k.i420 + (size_t)s * ((size_t)k.w * k.h * 3 / 2);
+    const uint8_t *sy = src + (size_t)min(y, k.h - 1) * k.w;
+    int v[4];
+#pragma unroll
+    for (int i = 0; i < 4; i++) v[i] = sy[min(x + i, k.w - 1)];
+    *(uint32_t *)(k.fenc_y + (size_t)s * k.fency_bytes + (size_t)y * k.fs + x) = pack4(v);
+    if (y < k.ch / 2) {
+        // 4 output bytes = 2 chroma samples (U,V interleaved)
+        const int cwid = k.w / 2, chgt = k.h / 2;
+        const uint8_t *su = src + (size_t)k.w * k.h + (size_t)min(y, chgt - 1) * cwid, *sv = su + (size_t)cwid * chgt;
+        int c0 = min(x / 2, cwid - 1), c1 = min(x / 2 + 1, cwid - 1);
+        int u[4] = { su[c0], sv[c0], su[c1], sv[c1] };
+        *(uint32_t *)(k.fenc_uv + (size_t)s * k.fencuv_bytes + (size_t)y * k.fs + x) = pack4(u);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// stage 2: inter macroblock encode, one wavefront per macroblock (Z layout)
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_encode_inter(EncK k)
+{
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int mbi = blockIdx.x * 4 + wave, s = blockIdx.y;
+    if (mbi >= k.nmb) return;
+    x264gpu_mb *mbp = k.mb + (size_t)s * k.nmb + mbi;
+    if (mbp->type != X264GPU_MB_P_L0) return;       // wave-uniform
+    const int mbx = mbi % k.mbw, mby = mbi / k.mbw, px = mbx * 16, py = mby * 16;
+    const int mvx = mbp->mv[0][0], mvy = mbp->mv[0][1];
+    int16_t *lv = k.levels + ((size_t)s * k.nmb + mbi) * X264GPU_MB_LEVELS;
+    const uint8_t *fenc = k.fenc_y + (size_t)s * k.fency_bytes + (size_t)py * k.fs + px;
+    const int j = lane & 3, blk = lane >> 2, zx = z_x0(lane), zy = z_y(lane);
+
+    // ---- luma ----
+    const uint32_t pred = mc_luma_row4(ref_plane00(k, s), k.plane_bytes, k.rs, px + zx, py + zy, mvx, mvy);
+    const uint32_t enc = *(const uint32_t *)(fenc + (size_t)zy * k.fs + zx);
+    int e[4], p[4], v[4];
+    unpack4(enc, e); unpack4(pred, p);
+#pragma unroll
+    for (int i = 0; i < 4; i++) v[i] = e[i] - p[i];
+    dct4_quad(v, lane);
+    quant4_row(v, k.q_luma_inter, j);
+    const unsigned mask = (unsigned)quad_or((int)scan_mask(v, j));
+    const bool nz = mask != 0;
+    bool keep = nz;
+    if (k.dct_decimate) {
+        const int big = quad_or(any_big(v) ? 1 : 0);
+        const int sc = nz ? (big ? 9 : decimate_from_mask(mask, 0)) : 0;
+        const int score8 = row16_sum(j == 0 ? sc : 0);                  // per 8x8 (= DPP row)
+        bool any8 = row16_or(nz ? 1 : 0) != 0;
+        if (any8 && score8 < 4) any8 = false;
+        const int mbscore = wave_sum(((lane & 15) == 0 && any8) ? score8 : 0);
+        keep = nz && any8 && mbscore >= 6;
+    }
+    { int z[4] = { 0, 0, 0, 0 }; store_levels_scan(lv + blk * 16, keep ? v : z, j); }
+    if (!keep) v[0] = v[1] = v[2] = v[3] = 0;
+    dequant4_row(v, k.q_luma_inter, j);
+    idct4_quad(v, lane);
+#pragma unroll
+    for (int i = 0; i < 4; i++) v[i] += p[i];
+    *(uint32_t *)(rec_plane00(k, s) + (size_t)(py + zy) * k.rs + px + zx) = pack4_clip(v);
+    const unsigned long long bal = __ballot(keep && j == 0);
+    unsigned nnz = 0;
+#pragma unroll
+    for (int b = 0; b < 16; b++) nnz |= (unsigned)((bal >> (4 * b)) & 1) << b;
+    int cbp_luma = 0;
+#pragma unroll
+    for (int i8 = 0; i8 < 4; i8++) cbp_luma |= ((nnz >> (4 * i8)) & 15) ? 1 << i8 : 0;
+
+    // ---- chroma (lanes 0..31: plane = lane>>4, block = (lane>>2)&3) ----
+    const int c = (lane >> 4) & 1, ci = (lane >> 2) & 3, cx0 = (ci & 1) * 4, cyy = (ci >> 1) * 4 + j;
+    uint32_t pu, pv;
+    mc_chroma_row4(ref_chroma00(k, s), k.rs, mbx * 8 + cx0, mby * 8 + cyy, mvx, mvy, pu, pv);
+    const uint8_t *fuv = k.fenc_uv + (size_t)s * k.fencuv_bytes + (size_t)(mby * 8 + cyy) * k.fs + px + 2 * cx0;
+    const uint2 fe = *(const uint2 *)fuv;
+    const uint32_t cenc = nv12_pick(fe.x, fe.y, c), cpred = c ? pv : pu;
+    int cbp_chroma = 0;
+    const uint32_t crec = chroma_residual(cenc, cpred, k.q_chroma_inter, true, k.dct_decimate != 0, lane, lv, nnz, cbp_chroma);
+    // interleave U (lanes 0..15) with V (lanes 16..31) and store 8 NV12 bytes from the U lanes
+    const uint32_t other = (uint32_t)__shfl_xor((int)crec, 16);
+    if (lane < 16) {
+        const uint32_t u = crec, w = other;
+        uint2 o;
+        o.x = (u & 0xff) | ((w & 0xff) << 8) | ((u & 0xff00) << 8) | ((w & 0xff00) << 16);
+        o.y = ((u >> 16) & 0xff) | (((w >> 16) & 0xff) << 8) | ((u >> 24) << 16) | ((w >> 24) << 24);
+        *(uint2 *)(rec_chroma00(k, s) + (size_t)(mby * 8 + cyy) * k.rs + px + 2 * cx0) = o;
+    }
+    if (lane >= 32 && lane < 40) lv[X264GPU_LV_LUMA_DC + (lane - 32) * 2] = 0, lv[X264GPU_LV_LUMA_DC + (lane - 32) * 2 + 1] = 0;
+    if (lane >= 40 && lane < 44) lv[408 + (lane - 40) * 2] = 0, lv[408 + (lane - 40) * 2 + 1] = 0;
+    if (lane == 0) {
+        mbp->nnz = nnz;
+        mbp->cbp_luma = (uint8_t)cbp_luma;
+        mbp->cbp_chroma = (uint8_t)cbp_chroma;
+    }
+}
+
+}  // namespace x264gpu

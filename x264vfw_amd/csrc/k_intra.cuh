@@ -1,0 +1,294 @@
+// k_intra.cuh — intra macroblock analysis + encode on reconstructed neighbours (A5 + A6-A8), run as a
+// 2-D wavefront: ONE 1024-thread workgroup per stream walks the anti-diagonals d = x + 2y; its 16
+// wavefronts take the macroblocks of a diagonal, a workgroup barrier separates diagonals (no
+// inter-workgroup hand-off, so no agent-scope fences are needed).  Intra 4x4 evaluates the nine modes
+// of a block in parallel: one quad of lanes per mode (table-driven predictors, intra.cuh).
+// Restates oracle/encoder.c intra_mb bit-exactly.
+#pragma once
+#include "enc_common.cuh"
+
+namespace x264gpu {
+
+constexpr int IT_STRIDE = 32;                 // luma tile stride (bytes)
+constexpr int IT_ORG = IT_STRIDE + 4;         // offset of sample (0,0): row -1 and columns -4..-1 precede it
+constexpr int IT_SIZE = 17 * IT_STRIDE + 8;
+
+struct IntraLds {
+    uint8_t tile[16][IT_SIZE];
+    uint8_t nb[16][NB_SIZE];
+    uint8_t U[16][U_SIZE];
+    uint8_t cnb[16][2][CNB_SIZE];
+    uint8_t modes[16][16];
+    uint8_t tab[9 * 16];
+};
+
+__device__ __forceinline__ int blkidx_of(int bx, int by) { return ((by >> 1) * 2 + (bx >> 1)) * 4 + (by & 1) * 2 + (bx & 1); }
+
+// neighbour availability of 4x4 block b (oracle i4_avail)
+__device__ __forceinline__ int i4_avail(int mbx, int mby, int mbw, int b)
+{
+    const int bx = z_bx(b), by = z_by(b);
+    int a = 0;
+    if (bx > 0 || mbx > 0) a |= AVAIL_LEFT;
+    if (by > 0 || mby > 0) a |= AVAIL_TOP;
+    if ((bx > 0 || mbx > 0) && (by > 0 || mby > 0)) a |= AVAIL_TOPLEFT;
+    if (by == 0) { if (mby > 0 && (bx < 3 || mbx + 1 < mbw)) a |= AVAIL_TOPRIGHT; }
+    else if (bx < 3 && blkidx_of(bx + 1, by - 1) < b) a |= AVAIL_TOPRIGHT;
+    return a;
+}
+
+// predicted intra 4x4 mode (8.3.1.1; oracle i4_pred_mode)
+__device__ __forceinline__ int i4_pred_mode(const x264gpu_mb *mbs, int mbw, int mbx, int mby, int b, const uint8_t *cur)
+{
+    const int bx = z_bx(b), by = z_by(b);
+    int ma, mb_;
+    if (bx > 0) ma = cur[blkidx_of(bx - 1, by)];
+    else if (mbx > 0) { const x264gpu_mb *n = mbs + mby * mbw + mbx - 1; ma = n->type == X264GPU_MB_I4x4 ? n->i4_mode[blkidx_of(3, by)] : 2; }
+    else return 2;
+    if (by > 0) mb_ = cur[blkidx_of(bx, by - 1)];
+    else if (mby > 0) { const x264gpu_mb *n = mbs + (mby - 1) * mbw + mbx; mb_ = n->type == X264GPU_MB_I4x4 ? n->i4_mode[blkidx_of(bx, 3)] : 2; }
+    else return 2;
+    return min(ma, mb_);
+}
+
+__device__ void intra_mb_wave(const EncK &k, IntraLds &L, int wave, int lane, int s, int mbx, int mby)
+{
+    uint8_t *tile = L.tile[wave] + IT_ORG;     // sample (0,0)
+    uint8_t *nb = L.nb[wave];
+    uint8_t *U = L.U[wave];
+    uint8_t *m4 = L.modes[wave];
+    const int mbi = mby * k.mbw + mbx, px = mbx * 16, py = mby * 16;
+    x264gpu_mb *mbs = k.mb + (size_t)s * k.nmb;
+    int16_t *lv = k.levels + ((size_t)s * k.nmb + mbi) * X264GPU_MB_LEVELS;
+    const uint8_t *fenc = k.fenc_y + (size_t)s * k.fency_bytes + (size_t)py * k.fs + px;
+    uint8_t *rec = rec_plane00(k, s) + (size_t)py * k.rs + px;
+    const bool left = mbx > 0, top = mby > 0, topright = top && mbx + 1 < k.mbw;
+    const int j = lane & 3, zx = z_x0(lane), zy = z_y(lane);
+    const int qp = k.qp, lambda = k.lambda;
+
+    // ---- neighbours: row -1 (x = -1..19) and column -1 into the tile; nb[] for the 16x16 predictors ----
+    if (lane < 21) {
+        const int x = lane - 1;
+        const bool ok = top && (x >= 0 || left) && (x < 16 || topright);
+        const uint8_t v = ok ? rec[-(long)k.rs + x] : 128;
+        tile[-IT_STRIDE + x] = v;
+        nb[NB_TOP + x] = v;                    // x = -1 lands on NB_TL
+    } else if (lane >= 32 && lane < 48) {
+        const int y = lane - 32;
+        const uint8_t v = left ? rec[(long)y * k.rs - 1] : 128;
+        tile[y * IT_STRIDE - 1] = v;
+        nb[NB_LEFT + y] = v;
+    }
+    const uint32_t cz = *(const uint32_t *)(fenc + (size_t)zy * k.fs + zx);
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_s_waitcnt(0xc07f);
+
+    // ---- intra 16x16 mode decision ----
+    const Pred16 pp = pred16_setup(nb, lane);
+    int best16 = 1 << 28, mode16 = 0;
+    {
+        int modes[4], n;
+        if (left && top) { modes[0] = PRED16_V; modes[1] = PRED16_H; modes[2] = PRED16_DC; modes[3] = PRED16_P; n = 4; }
+        else if (left) { modes[0] = PRED16_H; modes[1] = PRED16_DC_LEFT; n = 2; }
+        else if (top) { modes[0] = PRED16_V; modes[1] = PRED16_DC_TOP; n = 2; }
+        else { modes[0] = PRED16_DC_128; n = 1; }
+        for (int i = 0; i < n; i++) {
+            const int m = modes[i], sig = m > PRED16_P ? PRED16_DC : m;
+            int e[4], p[4], d[4];
+            unpack4(cz, e); unpack4(pred16_row4(nb, pp, m, zx, zy), p);
+#pragma unroll
+            for (int t = 0; t < 4; t++) d[t] = e[t] - p[t];
+            const int c = (wave_sum(satd_quad_partial(d, lane)) >> 1) + lambda * bs_size_ue(sig);
+            if (c < best16) { best16 = c; mode16 = m; }
+        }
+    }
+
+    // ---- intra 4x4: nine modes per block in parallel, blocks in coding order ----
+    bool use_i4 = false;
+    unsigned nnz = 0;
+    int cost4 = 0;
+    if (k.partitions & 2) {
+        cost4 = lambda * (24 + 16);
+        for (int b = 0; b < 16; b++) {
+            const int bx = z_bx(b), by = z_by(b);
+            const int avail = i4_avail(mbx, mby, k.mbw, b);
+            const int pm = i4_pred_mode(mbs, k.mbw, mbx, mby, b, m4);
+            uint8_t *bt = tile + by * 4 * IT_STRIDE + bx * 4;
+            pred4_build_u(U, bt, IT_STRIDE, avail, lane);
+            const int m = lane >> 2;
+            const bool ok = m < 9 && pred4_mode_ok(m, avail);
+            const uint32_t pr = pred4_row4(U, L.tab, m < 9 ? m : 8, j);
+            const uint32_t en = (uint32_t)__shfl((int)cz, b * 4 + j);
+            int e[4], p[4], d[4];
+            unpack4(en, e); unpack4(pr, p);
+#pragma unroll
+            for (int t = 0; t < 4; t++) d[t] = e[t] - p[t];
+            const int sat = quad_sum(satd_quad_partial(d, lane)) >> 1;
+            unsigned key = ok ? (((unsigned)(sat + (m == pm ? 0 : 3 * lambda)) << 4) | (unsigned)m) : 0xffffffffu;
+            key = wave_min_u32(key);
+            const int bm = key & 15;
+            cost4 += (int)(key >> 4);
+            if (lane == 0) m4[b] = (uint8_t)bm;
+            // encode the block with the winning prediction (every quad does the same work)
+            const uint32_t bp = (uint32_t)__shfl((int)pr, bm * 4 + j);
+            int v[4];
+            unpack4(bp, p);
+#pragma unroll
+            for (int t = 0; t < 4; t++) v[t] = e[t] - p[t];
+            dct4_quad(v, lane);
+            quant4_row(v, k.q_luma_intra, j);
+            const bool nz = quad_or((v[0] | v[1] | v[2] | v[3]) != 0 ? 1 : 0) != 0;
+            if (lane < 4) store_levels_scan(lv + b * 16, v, j);
+            dequant4_row(v, k.q_luma_intra, j);
+            idct4_quad(v, lane);
+#pragma unroll
+            for (int t = 0; t < 4; t++) v[t] += p[t];
+            if (lane < 4) *(uint32_t *)(bt + j * IT_STRIDE) = pack4_clip(v);
+            if (nz) nnz |= 1u << b;
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_s_waitcnt(0xc07f);
+        }
+        use_i4 = cost4 < best16;
+    }
+
+    x264gpu_mb recd;
+    __builtin_memset(&recd, 0, sizeof(recd));
+    recd.qp = (uint8_t)qp;
+    for (int i = 0; i < 4; i++) recd.ref[i] = -1;
+    if (k.slice_type == X264GPU_SLICE_P) { recd.aux[0] = mbs[mbi].aux[0]; recd.aux[1] = mbs[mbi].aux[1]; }
+
+    if (use_i4) {
+        recd.type = X264GPU_MB_I4x4;
+        recd.cost = cost4;
+        for (int b = 0; b < 16; b++) recd.i4_mode[b] = m4[b];
+        recd.nnz = nnz;
+        for (int i8 = 0; i8 < 4; i8++) if ((nnz >> (4 * i8)) & 15) recd.cbp_luma |= 1 << i8;
+        // reconstructed luma: tile -> frame
+        *(uint32_t *)(rec + (size_t)zy * k.rs + zx) = *(const uint32_t *)(tile + zy * IT_STRIDE + zx);
+        if (lane < 16) lv[X264GPU_LV_LUMA_DC + lane] = 0;
+    } else {
+        // ---- x264_mb_encode_i16x16 ----
+        recd.type = X264GPU_MB_I16x16;
+        recd.cost = best16;
+        recd.i16_mode = (uint8_t)(mode16 > PRED16_P ? PRED16_DC : mode16);
+        int e[4], p[4], v[4];
+        unpack4(cz, e); unpack4(pred16_row4(nb, pp, mode16, zx, zy), p);
+#pragma unroll
+        for (int t = 0; t < 4; t++) v[t] = e[t] - p[t];
+        dct4_quad(v, lane);
+        const int dcv = v[0];                      // meaningful on j == 0 lanes
+        if (j == 0) v[0] = 0;
+        quant4_row(v, k.q_luma_intra, j);
+        const bool nz = quad_or((v[0] | v[1] | v[2] | v[3]) != 0 ? 1 : 0) != 0;
+        store_levels_scan(lv + (lane >> 2) * 16, v, j);
+        dequant4_row(v, k.q_luma_intra, j);
+        const unsigned long long bal = __ballot(nz && j == 0);
+        unsigned acn = 0;
+#pragma unroll
+        for (int b = 0; b < 16; b++) acn |= (unsigned)((bal >> (4 * b)) & 1) << b;
+        // DC matrix in natural layout on every quad: lane row r = j, register c -> block (bx=c, by=r)
+        int dc[4];
+#pragma unroll
+        for (int c = 0; c < 4; c++) dc[c] = __shfl(dcv, 4 * blkidx_of(c, j));
+        had4x4_quad(dc, lane);
+#pragma unroll
+        for (int c = 0; c < 4; c++) dc[c] = quant_one((dc[c] + 1) >> 1, k.q_luma_intra.mf[0] >> 1, k.q_luma_intra.bias[0] << 1);
+        const bool nzdc = quad_or((dc[0] | dc[1] | dc[2] | dc[3]) != 0 ? 1 : 0) != 0;
+        if (lane < 4) store_levels_scan(lv + X264GPU_LV_LUMA_DC, dc, j);
+        had4x4_quad(dc, lane);
+        {
+            const int ls = k.q_luma_intra.dq[0], qb = qp / 6 - 6;
+#pragma unroll
+            for (int c = 0; c < 4; c++) dc[c] = dequant_one(dc[c], ls, qb);
+        }
+        // hand each block its DC: the value lives in register bx of quad-lane by
+        {
+            const int b = lane >> 2, bx = z_bx(b), by = z_by(b);
+            int t0 = __shfl(dc[0], by), t1 = __shfl(dc[1], by), t2 = __shfl(dc[2], by), t3 = __shfl(dc[3], by);
+            const int mine = bx == 0 ? t0 : bx == 1 ? t1 : bx == 2 ? t2 : t3;
+            if (j == 0) v[0] = nzdc ? mine : 0;
+        }
+        idct4_quad(v, lane);
+#pragma unroll
+        for (int t = 0; t < 4; t++) v[t] += p[t];
+        *(uint32_t *)(rec + (size_t)zy * k.rs + zx) = pack4_clip(v);
+        recd.nnz = acn | (nzdc ? 1u << 24 : 0);
+        recd.cbp_luma = acn ? 15 : 0;
+    }
+    if (lane >= 16 && lane < 24) lv[408 + lane - 16] = 0;
+
+    // ---- chroma: mode decision + encode (lanes 0..31; plane = lane>>4) ----
+    {
+        const int c = (lane >> 4) & 1, ci = (lane >> 2) & 3, cx0 = (ci & 1) * 4, cyy = (ci >> 1) * 4 + j;
+        uint8_t *cnb = L.cnb[wave][c];
+        uint8_t *ruv = rec_chroma00(k, s) + (size_t)(mby * 8) * k.rs + px;
+        // neighbour ring of both planes: lanes 0..8 top (x=-1..7) and 9..16 left, per plane on its own DPP row
+        {
+            const int t = lane & 15, pl = (lane >> 4) & 1;
+            if (lane < 32) {
+                if (t < 9) { const int x = t - 1; L.cnb[wave][pl][CNB_TOP + x] = (top && (x >= 0 || left)) ? ruv[-(long)k.rs + 2 * x + pl] : 128; }
+            } else {
+                const int y = t & 7, pl2 = (t >> 3) & 1;
+                if (lane < 48) L.cnb[wave][pl2][CNB_LEFT + y] = left ? ruv[(long)y * k.rs - 2 + pl2] : 128;
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_s_waitcnt(0xc07f);
+        const PredC pc = predc_setup(cnb);
+        const uint8_t *fuv = k.fenc_uv + (size_t)s * k.fencuv_bytes + (size_t)(mby * 8 + cyy) * k.fs + px + 2 * cx0;
+        const uint2 fe = *(const uint2 *)fuv;
+        const uint32_t cenc = nv12_pick(fe.x, fe.y, c);
+        int modes[4], n;
+        if (left && top) { modes[0] = PREDC_DC; modes[1] = PREDC_H; modes[2] = PREDC_V; modes[3] = PREDC_P; n = 4; }
+        else if (left) { modes[0] = PREDC_DC_LEFT; modes[1] = PREDC_H; n = 2; }
+        else if (top) { modes[0] = PREDC_DC_TOP; modes[1] = PREDC_V; n = 2; }
+        else { modes[0] = PREDC_DC_128; n = 1; }
+        int bestc = 1 << 28, bestm = 0;
+        for (int i = 0; i < n; i++) {
+            const int m = modes[i], sig = m > PREDC_P ? PREDC_DC : m;
+            int e[4], p[4], d[4];
+            unpack4(cenc, e); unpack4(predc_row4(cnb, pc, m, ci, j), p);
+#pragma unroll
+            for (int t = 0; t < 4; t++) d[t] = lane < 32 ? e[t] - p[t] : 0;
+            const int cst = (wave_sum(satd_quad_partial(d, lane)) >> 1) + lambda * bs_size_ue(sig);
+            if (cst < bestc) { bestc = cst; bestm = m; }
+        }
+        recd.chroma_mode = (uint8_t)(bestm > PREDC_P ? PREDC_DC : bestm);
+        const uint32_t cpred = predc_row4(cnb, pc, bestm, ci, j);
+        int cbp_chroma = 0;
+        unsigned nn = recd.nnz;
+        const uint32_t crec = chroma_residual(cenc, cpred, k.q_chroma_intra, false, false, lane, lv, nn, cbp_chroma);
+        recd.nnz = nn;
+        recd.cbp_chroma = (uint8_t)cbp_chroma;
+        const uint32_t other = (uint32_t)__shfl_xor((int)crec, 16);
+        if (lane < 16) {
+            const uint32_t u = crec, w = other;
+            uint2 o;
+            o.x = (u & 0xff) | ((w & 0xff) << 8) | ((u & 0xff00) << 8) | ((w & 0xff00) << 16);
+            o.y = ((u >> 16) & 0xff) | (((w >> 16) & 0xff) << 8) | ((u >> 24) << 16) | ((w >> 24) << 24);
+            *(uint2 *)(ruv + (size_t)cyy * k.rs + 2 * cx0) = o;
+        }
+    }
+    if (lane == 0) mbs[mbi] = recd;
+}
+
+__global__ __launch_bounds__(1024) void k_intra(EncK k)
+{
+    __shared__ __attribute__((aligned(16))) IntraLds L;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, s = blockIdx.x;
+    for (int i = threadIdx.x; i < 9 * 16; i += 1024) L.tab[i] = ((const uint8_t *)c_pred4_table.t)[i];
+    __syncthreads();
+    const x264gpu_mb *mbs = k.mb + (size_t)s * k.nmb;
+    const int ndiag = k.mbw + 2 * (k.mbh - 1);
+    for (int d = 0; d < ndiag; d++) {
+        const int ymin = max(0, (d - (k.mbw - 1) + 1) >> 1), ymax = min(k.mbh - 1, d >> 1);
+        for (int i = ymin + wave; i <= ymax; i += 16) {
+            const int mby = i, mbx = d - 2 * i;
+            if (k.slice_type == X264GPU_SLICE_I || mbs[mby * k.mbw + mbx].type != X264GPU_MB_P_L0)
+                intra_mb_wave(k, L, wave, lane, s, mbx, mby);
+        }
+        __syncthreads();
+    }
+}
+
+}  // namespace x264gpu

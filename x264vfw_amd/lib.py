@@ -11,6 +11,13 @@ class X264GpuError(RuntimeError):
 
 
 def _load():
+    # One HIP runtime per process: PyTorch bundles its own libamdhip64.so.7.  Importing torch first makes
+    # the loader bind libx264gpu.so's NEEDED libamdhip64.so.7 to that already-loaded copy; the other order
+    # leaves two runtimes in the process and whichever initialises second sees no device.
+    try:
+        import torch  # noqa: F401  (plumbing only: device buffers, streams)
+    except ImportError:
+        pass
     if not os.path.exists(LIB_PATH):
         raise X264GpuError(
             f"{LIB_PATH} not built — run `python -c 'import __graft_entry__ as g; g.build()'` "
@@ -26,8 +33,8 @@ class MbRecord(C.Structure):
     """Mirror of struct x264gpu_mb (64 bytes)."""
     _fields_ = [("type", C.c_uint8), ("i16_mode", C.c_uint8), ("chroma_mode", C.c_uint8), ("qp", C.c_uint8),
                 ("cbp_luma", C.c_uint8), ("cbp_chroma", C.c_uint8), ("partition", C.c_uint8),
-                ("ref", C.c_int8 * 4), ("i4_mode", C.c_uint8 * 16), ("mv", (C.c_int16 * 2) * 4),
-                ("nnz", C.c_uint32), ("cost", C.c_int32), ("pad", C.c_uint8 * 9)]
+                ("ref", C.c_int8 * 4), ("i4_mode", C.c_uint8 * 16),                ("_p0", C.c_uint8), ("mv", (C.c_int16 * 2) * 4),
+                ("nnz", C.c_uint32), ("cost", C.c_int32), ("aux", C.c_int32 * 3)]
 
 
 class Config(C.Structure):
