@@ -1,0 +1,204 @@
+#!/usr/bin/env python3
+"""bench.py — 1080p yuv420p frames/sec of the MI355X encode hot path (BASELINE.json metric).
+
+  python bench.py [--gpus N] [--steps K] [--warmup W]        (N>1 is launched by torch.distributed.run)
+
+A *step* is one lock-step pass of the hot path over one batch of synthetic input: every one of the
+`--streams` independent closed-GOP streams on this GPU advances by one frame (ingest -> ME/analysis ->
+DCT/quant/recon -> intra wavefront -> deblock wavefront -> half-pel planes), through the C ABI
+x264gpu_encode_frames() of libx264gpu.so.  Inputs are resident in HBM before the timed region.  The
+timed K steps start on an IDR boundary and contain the I/P mix of closed GOPs with --keyint (60).
+Frames of different streams/GOPs are independent (config 5 of BASELINE.json), so N GPUs shard streams
+one set per GPU with no collective in the data path ("scaling": "weak").
+
+Rank 0 prints ONE JSON line with `roofline` (dominant kernel, HIP-event timed inside the timed region)
+and `cpu_baseline` (the oracle restatement on one host core, bounded sample).
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0   # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+
+def synth_batch(torch, streams, frames, w, h, seed, device):
+    """[frames, streams, w*h*3/2] uint8 I420 on the device: gradient + 3 moving textured rectangles +
+    per-pixel noise, generated with torch ops (plumbing only)."""
+    g = torch.Generator(device=device)
+    g.manual_seed(seed)
+    yy = torch.arange(h, device=device).view(h, 1)
+    xx = torch.arange(w, device=device).view(1, w)
+    out = torch.empty((frames, streams, w * h * 3 // 2), dtype=torch.uint8, device=device)
+    vel = ((3, 1), (-2, 2), (5, -3))
+    for s in range(streams):
+        base = 90 + 7 * (s % 8)
+        grad = (base + xx * 60 // w + yy * 50 // h).to(torch.int16)
+        tex = [torch.randint(0, 256, (h // 3, w // 3), generator=g, device=device, dtype=torch.int16) for _ in vel]
+        pos = [(int(torch.randint(0, w, (1,), generator=g, device=device)), int(torch.randint(0, h, (1,), generator=g, device=device))) for _ in vel]
+        for n in range(frames):
+            y = grad.clone()
+            u = torch.full((h // 2, w // 2), 118, dtype=torch.int16, device=device)
+            v = torch.full((h // 2, w // 2), 134, dtype=torch.int16, device=device)
+            for (vx, vy), t, (px, py) in zip(vel, tex, pos):
+                th, tw = t.shape
+                ys = (torch.arange(th, device=device) + py + vy * n) % h
+                xs = (torch.arange(tw, device=device) + px + vx * n) % w
+                y[ys.view(-1, 1), xs.view(1, -1)] = 40 + t * 150 // 255
+                u[(ys[::2] // 2).view(-1, 1), (xs[::2] // 2).view(1, -1)] = 100 + t[::2, ::2] * 40 // 255
+                v[(ys[::2] // 2).view(-1, 1), (xs[::2] // 2).view(1, -1)] = 150 - t[::2, ::2] * 40 // 255
+            y = (y + torch.randint(-4, 5, y.shape, generator=g, device=device, dtype=torch.int16)).clamp_(16, 235)
+            u = (u + torch.randint(-2, 3, u.shape, generator=g, device=device, dtype=torch.int16)).clamp_(16, 240)
+            v = (v + torch.randint(-2, 3, v.shape, generator=g, device=device, dtype=torch.int16)).clamp_(16, 240)
+            out[n, s] = torch.cat([y.reshape(-1), u.reshape(-1), v.reshape(-1)]).to(torch.uint8)
+    return out
+
+
+def cpu_baseline(w, h, nframes, keyint):
+    """oracle/ (CPU restatement, one core) on a bounded sample of the same workload — the checker timed as
+    a baseline, never the product."""
+    import numpy as np
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_lib as O
+    from synth import synth_frames
+    frames = synth_frames(w, h, nframes, seed=0x264, scene_len=10 ** 9)
+    enc = O.OracleEncoder(O.default_config(w, h))
+    t0 = time.perf_counter()
+    for i, f in enumerate(frames):
+        enc.encode(np.ascontiguousarray(f), 2 if i % keyint == 0 else 0)
+    dt = time.perf_counter() - t0
+    enc.close()
+    return nframes / dt, dt
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=60)
+    ap.add_argument("--warmup", type=int, default=4)
+    ap.add_argument("--width", type=int, default=1920)
+    ap.add_argument("--height", type=int, default=1080)
+    ap.add_argument("--streams", type=int, default=16, help="independent closed-GOP streams per GPU (lock-step batch)")
+    ap.add_argument("--groups", type=int, default=2, help="stream groups on separate HIP streams (stage overlap)")
+    ap.add_argument("--keyint", type=int, default=60)
+    ap.add_argument("--qp", type=int, default=23)
+    ap.add_argument("--cpu-frames", type=int, default=12, help="frames of the CPU-baseline sample (0 = skip)")
+    args = ap.parse_args()
+
+    import torch
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the HIP hot path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    from x264vfw_amd import lib
+    from x264vfw_amd.lib import Config, MB_LEVELS
+
+    W, H, S, G = args.width, args.height, args.streams, max(1, min(args.groups, args.streams))
+    K, Wu = args.steps, args.warmup
+    per = [S // G + (1 if i < S % G else 0) for i in range(G)]
+    qp_i, qp_p = max(0, args.qp - 3), args.qp      # CQP ladder: ipratio 1.4 ~ -3 (x264 CQP convention)
+
+    # ---- inputs resident in HBM: warmup frames + K timed frames per stream ----
+    nfr = Wu + K
+    data = [synth_batch(torch, per[g], nfr, W, H, 0x264 + 1000 * rank + 17 * g, dev) for g in range(G)]
+    encs, hs, mbs, lvs, streams = [], [], [], [], []
+    for g in range(G):
+        cfg = Config(width=W, height=H, streams=per[g], refs=1, qp_i=qp_i, qp_p=qp_p, me_range=16, subme=7, deblock=1,
+                     deblock_alpha=0, deblock_beta=0, chroma_qp_offset=0, deadzone_inter=21, deadzone_intra=11,
+                     dct_decimate=1, partitions=2)
+        h = C.c_void_p()
+        lib.check(lib.x264gpu_encoder_create(C.byref(h), C.byref(cfg)), "encoder_create")
+        n = lib.x264gpu_encoder_mb_count(h)
+        hs.append(h)
+        mbs.append(torch.empty((per[g], n, 64), dtype=torch.uint8, device=dev))
+        lvs.append(torch.empty((per[g], n, MB_LEVELS), dtype=torch.int16, device=dev))
+        streams.append(torch.cuda.Stream(device=dev))
+
+    def step(i, first_of_gop):
+        st = 2 if first_of_gop else 0
+        for g in range(G):
+            lib.check(lib.x264gpu_encode_frames(hs[g], data[g][i].data_ptr(), st, mbs[g].data_ptr(), lvs[g].data_ptr(),
+                                                streams[g].cuda_stream), "encode_frames")
+
+    def sync():
+        torch.cuda.synchronize(dev)
+        if dist is not None:
+            dist.barrier()
+
+    for i in range(Wu):
+        step(i, i == 0)
+    sync()
+    for g in range(G):
+        lib.check(lib.x264gpu_encoder_profile_begin(hs[g], K), "profile_begin")
+    sync()
+    t0 = time.perf_counter()
+    for i in range(K):
+        step(Wu + i, i % args.keyint == 0)
+    sync()
+    dt = time.perf_counter() - t0
+
+    nst = lib.x264gpu_encoder_stage_count()
+    names = [lib.x264gpu_encoder_stage_name(i).decode() for i in range(nst)]
+    ms = [0.0] * nst
+    cnt = [0] * nst
+    for g in range(G):
+        a, b = (C.c_double * nst)(), (C.c_int * nst)()
+        lib.check(lib.x264gpu_encoder_profile_end(hs[g], streams[g].cuda_stream, a, b), "profile_end")
+        for i in range(nst):
+            ms[i] += a[i]
+            cnt[i] += b[i]
+    if dist is not None:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    frames_total = S * K * world
+    fps = frames_total / dt
+    # ---- roofline of the dominant kernel (largest summed device time on this rank) ----
+    Sb = 1.5 * W * H
+    # algorithmic HBM bytes per frame and stage (DESIGN.md "kernels"): planes each stage must read/write once
+    alg = {"ingest": 2 * Sb, "analyse_p": 2 * W * H, "encode_inter": 3 * Sb, "intra": 2 * Sb, "deblock": 2 * Sb,
+           "hpel_filter": 4 * W * H + 0.5 * W * H}
+    dom = max(range(nst), key=lambda i: ms[i])
+    frames_per_launch = S / G            # every launch of a group covers its streams (one frame each)
+    avg_ms = ms[dom] / max(cnt[dom], 1)
+    achieved = alg[names[dom]] * frames_per_launch / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
+    roof = {"bound": "hbm", "kernel": names[dom], "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
+            "avg_launch_ms": round(avg_ms, 4),
+            "stage_ms_per_step": {names[i]: round(ms[i] / K / G, 4) for i in range(nst)}}
+    out = {"metric": "1080p yuv420p frames/sec at preset=medium (I/P subset, CQP), hot path on MI355X",
+           "value": round(fps, 2), "unit": "frames/s", "n_gpus": world, "steps": K, "warmup": Wu,
+           "ms_per_step": round(dt / K * 1e3, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+           "dtype": "u8", "data": "synthetic",
+           "config": {"workload": f"{W}x{H} yuv420p, {S} closed-GOP streams/GPU x {K} frames, keyint {args.keyint}, "
+                                  f"CQP {qp_i}/{qp_p}, me hex merange 16 subme 7, i16x16+i4x4, p16x16, ref 1, deblock 0:0",
+                      "streams_per_gpu": S, "stream_groups": G, "frames_per_step": S * world},
+           "roofline": roof}
+    if rank == 0:
+        if args.cpu_frames > 0:
+            cfps, cdt = cpu_baseline(W, H, args.cpu_frames, args.keyint)
+            out["cpu_baseline"] = {"value": round(cfps, 3), "unit": "frames/s", "cores": 1, "kind": "port",
+                                   "sample": f"{args.cpu_frames} frames {W}x{H} (1 I + {args.cpu_frames - 1} P), oracle/encoder.c single thread, {cdt:.1f} s"}
+        print(json.dumps(out), flush=True)
+    for h in hs:
+        lib.x264gpu_encoder_destroy(h)
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -145,9 +145,13 @@ int  x264gpu_encode_frames(x264gpu_encoder *enc, const uint8_t *d_i420, int slic
                            x264gpu_mb *d_mb, int16_t *d_levels, void *stream);
 /* copy the reconstructed (deblocked) picture of `stream_idx` out as I420 (for parity tests / PSNR) */
 int  x264gpu_encoder_get_recon(x264gpu_encoder *enc, int stream_idx, uint8_t *d_i420_out, void *stream);
-/* timing hook for bench.py: average device time per named stage of the last call (ms), 0 if unknown */
+/* Per-stage device timing for bench.py (HIP events on the caller's stream, no host sync in the timed
+ * region): profile_begin arms up to max_calls encode_frames calls; profile_end synchronises the stream
+ * and returns, per stage, the summed milliseconds and the number of launches that ran. */
 int  x264gpu_encoder_stage_count(void);
 const char *x264gpu_encoder_stage_name(int i);
+int  x264gpu_encoder_profile_begin(x264gpu_encoder *enc, int max_calls);
+int  x264gpu_encoder_profile_end(x264gpu_encoder *enc, void *stream, double *ms_sum, int *launches);
 
 #ifdef __cplusplus
 }

@@ -29,7 +29,12 @@ struct x264gpu_encoder {
     int8_t *reff[2] = { nullptr, nullptr };
     uint16_t *cost_mv[52] = {};
     int cur = 0, have_ref = 0;
+    // optional per-stage profiling: (NSTAGE+1) events per armed call
+    hipEvent_t *ev = nullptr;
+    int *ev_mask = nullptr;       // per call: bit i = stage i ran
+    int prof_calls = 0, prof_cap = 0;
 };
+enum { NSTAGE = 6 };
 
 static const char *const kStageNames[] = { "ingest", "analyse_p", "encode_inter", "intra", "deblock", "hpel_filter" };
 
@@ -103,9 +108,49 @@ int x264gpu_encoder_create(x264gpu_encoder **out, const x264gpu_config *cfg)
     return X264GPU_OK;
 }
 
+static void profile_free(x264gpu_encoder *e)
+{
+    if (e->ev) {
+        for (int i = 0; i < e->prof_cap * (NSTAGE + 1); i++) (void)hipEventDestroy(e->ev[i]);
+        delete[] e->ev; delete[] e->ev_mask;
+    }
+    e->ev = nullptr; e->ev_mask = nullptr; e->prof_cap = e->prof_calls = 0;
+}
+
+int x264gpu_encoder_profile_begin(x264gpu_encoder *e, int max_calls)
+{
+    ARG_TRY(e && max_calls > 0 && max_calls <= 100000);
+    profile_free(e);
+    e->ev = new (std::nothrow) hipEvent_t[(size_t)max_calls * (NSTAGE + 1)];
+    e->ev_mask = new (std::nothrow) int[max_calls];
+    if (!e->ev || !e->ev_mask) return set_err(X264GPU_ENOMEM, "profile events", hipSuccess);
+    for (int i = 0; i < max_calls * (NSTAGE + 1); i++) HIP_TRY(hipEventCreate(&e->ev[i]));
+    e->prof_cap = max_calls;
+    return X264GPU_OK;
+}
+
+int x264gpu_encoder_profile_end(x264gpu_encoder *e, void *stream, double *ms_sum, int *launches)
+{
+    ARG_TRY(e && ms_sum && launches);
+    HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
+    for (int i = 0; i < NSTAGE; i++) { ms_sum[i] = 0; launches[i] = 0; }
+    for (int c = 0; c < e->prof_calls; c++) {
+        hipEvent_t *ev = e->ev + (size_t)c * (NSTAGE + 1);
+        for (int i = 0; i < NSTAGE; i++) {
+            if (!(e->ev_mask[c] >> i & 1)) continue;
+            float ms = 0;
+            HIP_TRY(hipEventElapsedTime(&ms, ev[i], ev[i + 1]));
+            ms_sum[i] += ms; launches[i]++;
+        }
+    }
+    profile_free(e);
+    return X264GPU_OK;
+}
+
 void x264gpu_encoder_destroy(x264gpu_encoder *e)
 {
     if (!e) return;
+    profile_free(e);
     (void)hipFree(e->fenc_y); (void)hipFree(e->fenc_uv);
     for (int i = 0; i < 2; i++) { (void)hipFree(e->luma[i]); (void)hipFree(e->chroma[i]); (void)hipFree(e->mvf[i]); (void)hipFree(e->reff[i]); }
     for (int q = 0; q < 52; q++) (void)hipFree(e->cost_mv[q]);
@@ -138,19 +183,37 @@ int x264gpu_encode_frames(x264gpu_encoder *e, const uint8_t *d_i420, int slice_t
     k.q_luma_intra = make_q4(qp, 0, qc); k.q_luma_inter = make_q4(qp, 1, qc);
     k.q_chroma_intra = make_q4(k.qpc, 2, qc); k.q_chroma_inter = make_q4(k.qpc, 3, qc);
 
+    hipEvent_t *ev = nullptr;
+    int mask = 0;
+    if (e->ev && e->prof_calls < e->prof_cap) ev = e->ev + (size_t)e->prof_calls * (NSTAGE + 1);
+#define STAGE_MARK(i) do { if (ev) { HIP_TRY(hipEventRecord(ev[i], st)); } } while (0)
+    STAGE_MARK(0);
     hipLaunchKernelGGL(k_ingest, dim3((k.cw / 4 + 255) / 256, k.ch, S), dim3(256), 0, st, k);
+    mask |= 1;
+    STAGE_MARK(1);
     if (slice_type == X264GPU_SLICE_P) {
         hipLaunchKernelGGL(k_analyse_p, dim3((k.nmb + 3) / 4, S), dim3(256), 0, st, k);
+        STAGE_MARK(2);
         hipLaunchKernelGGL(k_encode_inter, dim3((k.nmb + 3) / 4, S), dim3(256), 0, st, k);
+        mask |= 2 | 4;
     } else {
         HIP_TRY(hipMemsetAsync(e->reff[1], 0xff, (size_t)S * k.nmb, st));
         HIP_TRY(hipMemsetAsync(e->mvf[1], 0, (size_t)S * k.nmb * 2 * sizeof(int16_t), st));
+        STAGE_MARK(2);
     }
+    STAGE_MARK(3);
     hipLaunchKernelGGL(k_intra, dim3(S), dim3(1024), 0, st, k);
-    if (e->cfg.deblock) hipLaunchKernelGGL(k_deblock, dim3(S), dim3(1024), 0, st, k);
+    mask |= 8;
+    STAGE_MARK(4);
+    if (e->cfg.deblock) { hipLaunchKernelGGL(k_deblock, dim3(S), dim3(1024), 0, st, k); mask |= 16; }
+    STAGE_MARK(5);
     for (int s = 0; s < S; s++)
         launch_hpel_filter(e->luma[e->cur] + (size_t)s * k.luma_bytes, k.plane_bytes, k.rs, k.cw, k.ch, PAD, st);
     hipLaunchKernelGGL(k_chroma_border, dim3((k.cw / 2 + 2 * CPAD + 255) / 256, k.ch / 2 + 2 * CPAD, S), dim3(256), 0, st, k);
+    mask |= 32;
+    STAGE_MARK(6);
+#undef STAGE_MARK
+    if (ev) e->ev_mask[e->prof_calls++] = mask;
     HIP_TRY(hipGetLastError());
     e->cur ^= 1;
     { int16_t *t = e->mvf[0]; e->mvf[0] = e->mvf[1]; e->mvf[1] = t; }
