@@ -91,9 +91,8 @@ def main():
     args = ap.parse_args()
 
     import torch
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
+    from x264vfw_amd import shard
+    rank, local_rank, world = shard.env_rank_world()
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the HIP hot path has no CPU fallback")
     torch.cuda.set_device(local_rank)
@@ -106,14 +105,16 @@ def main():
     from x264vfw_amd import lib
     from x264vfw_amd.lib import Config, MB_LEVELS
 
-    W, H, S, G = args.width, args.height, args.streams, max(1, min(args.groups, args.streams))
+    W, H, S = args.width, args.height, args.streams
     K, Wu = args.steps, args.warmup
-    per = [S // G + (1 if i < S % G else 0) for i in range(G)]
+    per = shard.split_groups(S, args.groups)
+    G = len(per)
+    gids = shard.stream_ids(rank, world, S)          # global stream ids of this rank (seeds only)
     qp_i, qp_p = max(0, args.qp - 3), args.qp      # CQP ladder: ipratio 1.4 ~ -3 (x264 CQP convention)
 
     # ---- inputs resident in HBM: warmup frames + K timed frames per stream ----
     nfr = Wu + K
-    data = [synth_batch(torch, per[g], nfr, W, H, 0x264 + 1000 * rank + 17 * g, dev) for g in range(G)]
+    data = [synth_batch(torch, per[g], nfr, W, H, shard.stream_seed(0x264, gids[sum(per[:g])]), dev) for g in range(G)]
     encs, hs, mbs, lvs, streams = [], [], [], [], []
     for g in range(G):
         cfg = Config(width=W, height=H, streams=per[g], refs=1, qp_i=qp_i, qp_p=qp_p, me_range=16, subme=7, deblock=1,
@@ -160,13 +161,8 @@ def main():
         for i in range(nst):
             ms[i] += a[i]
             cnt[i] += b[i]
-    if dist is not None:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
-
-    frames_total = S * K * world
-    fps = frames_total / dt
+    dt = shard.max_over_ranks(dt, dist, dev)
+    fps = shard.aggregate_fps(S, K, world, dt)
     # ---- roofline of the dominant kernel (largest summed device time on this rank) ----
     Sb = 1.5 * W * H
     # algorithmic HBM bytes per frame and stage (DESIGN.md "kernels"): planes each stage must read/write once

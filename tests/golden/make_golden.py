@@ -1,0 +1,65 @@
+#!/usr/bin/env python3
+"""Regenerates tests/golden/*.json|npz from the CPU oracle (oracle/liboracle.so).
+
+The reference tree has no tests, fixtures or golden vectors for this path and its
+implementation (libx264) is not in /root/reference, so nothing can be captured from the reference itself:
+these fixtures pin the oracle (which tests/test_oracle_spec.py pins to ITU-T H.264) so that a later edit of
+either the oracle or the HIP path that changes results is caught on both the CPU and the GPU box.
+Run from the repo root:  python tests/golden/make_golden.py
+"""
+import hashlib
+import json
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.dirname(HERE))
+import oracle_lib as O  # noqa: E402
+from synth import synth_frames  # noqa: E402
+
+CASES = [("p176x144", 176, 144, 5, {}), ("p208x120_q30", 208, 120, 3, dict(qp_i=27, qp_p=30)),
+         ("p64x48_nodeblock", 64, 48, 3, dict(deblock=0))]
+
+
+def sha(a):
+    return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+
+
+def pipeline_case(w, h, n, kw):
+    enc = O.OracleEncoder(O.default_config(w, h, **kw))
+    out = []
+    for i, f in enumerate(synth_frames(w, h, n, seed=w * 7 + h)):
+        mbs, lv = enc.encode(f, 2 if i == 0 else 0)
+        out.append({"mb": sha(mbs.view(np.uint8)), "levels": sha(lv), "recon": sha(enc.recon()),
+                    "types": np.bincount(mbs["type"], minlength=7).tolist(), "nonzero_levels": int((lv != 0).sum())})
+    enc.close()
+    return out
+
+
+def prim_vectors():
+    rng = np.random.default_rng(0x264)
+    a = rng.integers(0, 256, (32, 16, 16), dtype=np.uint8)
+    b = np.clip(a.astype(int) + rng.integers(-20, 21, a.shape), 0, 255).astype(np.uint8)
+    d = {"a": a, "b": b}
+    for m in ("sad", "satd", "sa8d", "ssd"):
+        d[m + "_16x16"] = O.metric(m, a, b)
+    a8, b8 = np.ascontiguousarray(a[:, :8, :8]), np.ascontiguousarray(b[:, :8, :8])
+    for m in ("sad", "satd", "sa8d"):
+        d[m + "_8x8"] = O.metric(m, a8, b8)
+    enc = np.ascontiguousarray(a[:, :4, :4])
+    pred = np.ascontiguousarray(b[:, 4:8, 4:8])
+    for qp in (0, 23, 37, 51):
+        for lst in (0, 1):
+            c, l, r = O.dctq4x4(enc, pred, qp, lst)
+            d[f"coef_q{qp}_l{lst}"], d[f"lev_q{qp}_l{lst}"], d[f"rec_q{qp}_l{lst}"] = c, l, r
+    d["enc4"], d["pred4"] = enc, pred
+    return d
+
+
+if __name__ == "__main__":
+    js = {name: {"w": w, "h": h, "frames": n, "cfg": kw, "per_frame": pipeline_case(w, h, n, kw)} for name, w, h, n, kw in CASES}
+    json.dump(js, open(os.path.join(HERE, "oracle_pipeline.json"), "w"), indent=1)
+    np.savez_compressed(os.path.join(HERE, "prim_vectors.npz"), **prim_vectors())
+    print("golden fixtures written")

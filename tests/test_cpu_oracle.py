@@ -1,0 +1,102 @@
+"""CPU: the oracle against the committed golden fixtures (tests/golden, made by make_golden.py), sanity
+of the oracle encoder, and the C-ABI export surface of libx264gpu.so (no compute calls without a GPU)."""
+import hashlib
+import json
+import os
+import re
+
+import numpy as np
+import pytest
+
+import oracle_lib as O
+from synth import psnr, synth_frames
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def sha(a):
+    return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+
+
+def test_prim_golden_vectors():
+    g = np.load(os.path.join(GOLD, "prim_vectors.npz"))
+    a, b = g["a"], g["b"]
+    for m in ("sad", "satd", "sa8d", "ssd"):
+        np.testing.assert_array_equal(O.metric(m, a, b), g[m + "_16x16"])
+    a8, b8 = np.ascontiguousarray(a[:, :8, :8]), np.ascontiguousarray(b[:, :8, :8])
+    for m in ("sad", "satd", "sa8d"):
+        np.testing.assert_array_equal(O.metric(m, a8, b8), g[m + "_8x8"])
+    for qp in (0, 23, 37, 51):
+        for lst in (0, 1):
+            c, l, r = O.dctq4x4(g["enc4"], g["pred4"], qp, lst)
+            np.testing.assert_array_equal(c, g[f"coef_q{qp}_l{lst}"])
+            np.testing.assert_array_equal(l, g[f"lev_q{qp}_l{lst}"])
+            np.testing.assert_array_equal(r, g[f"rec_q{qp}_l{lst}"])
+
+
+@pytest.mark.parametrize("case", ["p176x144", "p208x120_q30", "p64x48_nodeblock"])
+def test_pipeline_golden(case):
+    js = json.load(open(os.path.join(GOLD, "oracle_pipeline.json")))[case]
+    w, h = js["w"], js["h"]
+    enc = O.OracleEncoder(O.default_config(w, h, **js["cfg"]))
+    for i, (f, exp) in enumerate(zip(synth_frames(w, h, js["frames"], seed=w * 7 + h), js["per_frame"])):
+        mbs, lv = enc.encode(f, 2 if i == 0 else 0)
+        assert sha(mbs.view(np.uint8)) == exp["mb"], f"frame {i} records"
+        assert sha(lv) == exp["levels"], f"frame {i} levels"
+        assert sha(enc.recon()) == exp["recon"], f"frame {i} recon"
+
+
+def test_oracle_encoder_quality_and_monotonic_qp():
+    w, h = 176, 144
+    frames = synth_frames(w, h, 4, seed=3)
+    res = {}
+    for qp in (18, 28, 38):
+        enc = O.OracleEncoder(O.default_config(w, h, qp_i=qp - 3, qp_p=qp))
+        ps, nz = [], 0
+        for i, f in enumerate(frames):
+            mbs, lv = enc.encode(f, 2 if i == 0 else 0)
+            ps.append(psnr(enc.recon()[:w * h], f[:w * h]))
+            nz += int((lv != 0).sum())
+        res[qp] = (min(ps), nz)
+    assert res[18][0] > res[28][0] > res[38][0] > 24.0
+    assert res[18][1] > res[28][1] > res[38][1]
+
+
+def test_oracle_static_scene_goes_inter_zero_mv():
+    """edge case: identical frames -> P frame is all inter with zero motion and no residual"""
+    w, h = 96, 64
+    f = synth_frames(w, h, 1, seed=5)[0]
+    enc = O.OracleEncoder(O.default_config(w, h, qp_i=20, qp_p=30))
+    enc.encode(f, 2)
+    rec_i = enc.recon()
+    mbs, lv = enc.encode(rec_i, 0)       # feed the reconstruction back: perfectly predictable
+    assert (mbs["type"] == 4).all() and (mbs["mv"] == 0).all() and not lv.any()
+
+
+def test_abi_exports_every_declared_symbol():
+    """include/x264gpu.h is the contract: every function it declares is exported by libx264gpu.so"""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    hdr = open(os.path.join(root, "include", "x264gpu.h")).read()
+    declared = set(re.findall(r"\b(x264gpu_[a-z0-9_]+)\s*\(", hdr))
+    from x264vfw_amd import lib
+    assert declared, "no declarations parsed"
+    missing = sorted(d for d in declared if d not in lib.EXPORTS)
+    assert not missing, f"declared in x264gpu.h but not bound: {missing}"
+    import ctypes
+    so = ctypes.CDLL(lib.LIB_PATH)
+    for name in declared:
+        assert hasattr(so, name), f"{name} not exported by libx264gpu.so"
+    assert lib.x264gpu_abi_version() == 1
+
+
+def test_no_gpu_means_loud_failure():
+    """without a device the product reports it; there is no CPU fallback to fall into"""
+    import torch
+    from x264vfw_amd import lib
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    assert lib.x264gpu_device_count() == 0
+    import ctypes as C
+    h = C.c_void_p()
+    cfg = O.default_config(64, 48)
+    assert lib.x264gpu_encoder_create(C.byref(h), C.byref(cfg)) != 0
