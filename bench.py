@@ -185,6 +185,9 @@ def main():
                       "streams_per_gpu": S, "stream_groups": G, "frames_per_step": S * world},
            "roofline": roof}
     if rank == 0:
+        import numpy as np
+        types = np.bincount(mbs[0].cpu().numpy()[:, :, 0].reshape(-1), minlength=7)
+        out["config"]["mb_types_last_step"] = {"I4x4": int(types[0]), "I16x16": int(types[2]), "P16x16": int(types[4])}
         if args.cpu_frames > 0:
             cfps, cdt = cpu_baseline(W, H, args.cpu_frames, args.keyint)
             out["cpu_baseline"] = {"value": round(cfps, 3), "unit": "frames/s", "cores": 1, "kind": "port",

@@ -151,6 +151,9 @@ int  x264gpu_encoder_get_recon(x264gpu_encoder *enc, int stream_idx, uint8_t *d_
 int  x264gpu_encoder_stage_count(void);
 const char *x264gpu_encoder_stage_name(int i);
 int  x264gpu_encoder_profile_begin(x264gpu_encoder *enc, int max_calls);
+/* diagnostics (NULL = off, the default): d_counters = [streams][16 waves][16] uint64 cycle counters written by the
+ * wavefront kernels: {intra wait, work, MBs, total, deblock wait, work, MBs, total, 5 intra section sums, 3 spare} */
+int  x264gpu_encoder_set_debug(x264gpu_encoder *enc, void *d_counters);
 int  x264gpu_encoder_profile_end(x264gpu_encoder *enc, void *stream, double *ms_sum, int *launches);
 
 #ifdef __cplusplus

@@ -488,6 +488,7 @@ static void intra_mb(x264o_encoder *e, int mbx, int mby, int qp, x264gpu_mb *mbs
                 x264o_add4x4_idct(r, e->rs, d);
                 nnz4 |= 1u << b;
             } else memset(lv4 + b * 16, 0, 32);
+            if (cost4 >= best16) break;          /* early termination: i4x4 can no longer beat i16x16 */
         }
         if (cost4 < best16) {
             use_i4 = 1;

@@ -34,6 +34,7 @@ struct EncK {
     int slice_type;
     int alpha_off, beta_off;  // deblock offsets (already *2)
     Q4 q_luma_intra, q_luma_inter, q_chroma_intra, q_chroma_inter;
+    unsigned long long *dbg;  // optional diagnostics (NULL in production): per (stream, wave) cycle counters
 };
 
 __device__ __forceinline__ const uint8_t *ref_plane00(const EncK &k, int s)
@@ -67,17 +68,23 @@ __device__ __forceinline__ int bs_size_ue(int v)
 // ---- shared residual coders (used by the inter and the intra kernels) ------------------------------
 
 // scatter this lane's 4 levels (natural layout: row j, columns 0..3) to scan order in `dst[16]`
+// scan (zigzag) index of the four coefficients a lane holds in natural layout (row j, columns 0..3),
+// packed one nibble each: row 0 -> {0,1,5,6}, row 1 -> {2,4,7,12}, row 2 -> {3,8,11,13}, row 3 -> {9,10,14,15}
+__device__ __forceinline__ unsigned scan_nibbles(int j)
+{
+    return j == 0 ? 0x6510u : j == 1 ? 0xC742u : j == 2 ? 0xDB83u : 0xFEA9u;
+}
 __device__ __forceinline__ void store_levels_scan(int16_t *dst, const int v[4], int j)
 {
-#pragma unroll
-    for (int c = 0; c < 4; c++) dst[zigzag4_inv(j * 4 + c)] = (int16_t)v[c];
+    const unsigned z = scan_nibbles(j);
+    dst[z & 15] = (int16_t)v[0]; dst[(z >> 4) & 15] = (int16_t)v[1];
+    dst[(z >> 8) & 15] = (int16_t)v[2]; dst[z >> 12] = (int16_t)v[3];
 }
 __device__ __forceinline__ unsigned scan_mask(const int v[4], int j)
 {
-    unsigned m = 0;
-#pragma unroll
-    for (int c = 0; c < 4; c++) m |= (v[c] != 0 ? 1u : 0u) << zigzag4_inv(j * 4 + c);
-    return m;
+    const unsigned z = scan_nibbles(j);
+    return ((v[0] != 0 ? 1u : 0u) << (z & 15)) | ((v[1] != 0 ? 1u : 0u) << ((z >> 4) & 15)) |
+           ((v[2] != 0 ? 1u : 0u) << ((z >> 8) & 15)) | ((v[3] != 0 ? 1u : 0u) << (z >> 12));
 }
 __device__ __forceinline__ bool any_big(const int v[4])
 {

@@ -16,7 +16,8 @@
 #include <new>
 
 namespace x264gpu {
-int launch_hpel_filter(uint8_t *planes, size_t plane_bytes, int stride, int w, int h, int pad, hipStream_t st);
+int launch_hpel_filter(uint8_t *planes, size_t plane_bytes, int stride, int w, int h, int pad, int batch,
+                       size_t batch_bytes, hipStream_t st);
 }
 using namespace x264gpu;
 
@@ -29,6 +30,7 @@ struct x264gpu_encoder {
     int8_t *reff[2] = { nullptr, nullptr };
     uint16_t *cost_mv[52] = {};
     int cur = 0, have_ref = 0;
+    unsigned long long *dbg = nullptr;   // diagnostics buffer set by x264gpu_encoder_set_debug
     // optional per-stage profiling: (NSTAGE+1) events per armed call
     hipEvent_t *ev = nullptr;
     int *ev_mask = nullptr;       // per call: bit i = stage i ran
@@ -158,6 +160,7 @@ void x264gpu_encoder_destroy(x264gpu_encoder *e)
 }
 
 int x264gpu_encoder_mb_count(const x264gpu_encoder *e) { return e ? e->k.nmb : 0; }
+int x264gpu_encoder_set_debug(x264gpu_encoder *e, void *d_counters) { ARG_TRY(e); e->dbg = (unsigned long long *)d_counters; return X264GPU_OK; }
 int x264gpu_encoder_stage_count(void) { return (int)(sizeof(kStageNames) / sizeof(kStageNames[0])); }
 const char *x264gpu_encoder_stage_name(int i) { return i >= 0 && i < x264gpu_encoder_stage_count() ? kStageNames[i] : ""; }
 
@@ -179,6 +182,7 @@ int x264gpu_encode_frames(x264gpu_encoder *e, const uint8_t *d_i420, int slice_t
     k.mb = d_mb; k.levels = d_levels;
     k.qp = qp; k.lambda = lambda_of(qp); k.qpc = chroma_qp_of(qp, e->cfg.chroma_qp_offset);
     k.slice_type = slice_type;
+    k.dbg = e->dbg;
     QuantCfg qc; qc.deadzone_inter = e->cfg.deadzone_inter; qc.deadzone_intra = e->cfg.deadzone_intra;
     k.q_luma_intra = make_q4(qp, 0, qc); k.q_luma_inter = make_q4(qp, 1, qc);
     k.q_chroma_intra = make_q4(k.qpc, 2, qc); k.q_chroma_inter = make_q4(k.qpc, 3, qc);
@@ -207,8 +211,7 @@ int x264gpu_encode_frames(x264gpu_encoder *e, const uint8_t *d_i420, int slice_t
     STAGE_MARK(4);
     if (e->cfg.deblock) { hipLaunchKernelGGL(k_deblock, dim3(S), dim3(1024), 0, st, k); mask |= 16; }
     STAGE_MARK(5);
-    for (int s = 0; s < S; s++)
-        launch_hpel_filter(e->luma[e->cur] + (size_t)s * k.luma_bytes, k.plane_bytes, k.rs, k.cw, k.ch, PAD, st);
+    launch_hpel_filter(e->luma[e->cur], k.plane_bytes, k.rs, k.cw, k.ch, PAD, S, k.luma_bytes, st);
     hipLaunchKernelGGL(k_chroma_border, dim3((k.cw / 2 + 2 * CPAD + 255) / 256, k.ch / 2 + 2 * CPAD, S), dim3(256), 0, st, k);
     mask |= 32;
     STAGE_MARK(6);

@@ -13,9 +13,10 @@ __device__ __forceinline__ int tap6(int a, int b, int c, int d, int e, int f) { 
 
 // planes: padded origin of plane 0; sample (0,0) at pad*stride+pad.  One 256-thread block per 64x16 tile
 // of the PADDED plane; source reads are clamped to the picture (== edge replication, oracle/mc.c).
-__global__ __launch_bounds__(256) void k_hpel_filter(uint8_t *__restrict__ planes, size_t plane_bytes, int stride,
-                                                     int w, int h, int pad)
+__global__ __launch_bounds__(256) void k_hpel_filter(uint8_t *__restrict__ planes0, size_t plane_bytes, int stride,
+                                                     int w, int h, int pad, size_t batch_bytes)
 {
+    uint8_t *__restrict__ planes = planes0 + (size_t)blockIdx.z * batch_bytes;   // blockIdx.z = stream
     __shared__ uint8_t s[HP_SH][HP_SW];
     __shared__ int16_t vi[HP_TH][HP_SW];
     const int t = threadIdx.x;
@@ -81,10 +82,11 @@ __global__ __launch_bounds__(256) void k_lowres(const uint8_t *__restrict__ src,
 }  // namespace
 
 namespace x264gpu {
-int launch_hpel_filter(uint8_t *planes, size_t plane_bytes, int stride, int w, int h, int pad, hipStream_t st)
+int launch_hpel_filter(uint8_t *planes, size_t plane_bytes, int stride, int w, int h, int pad, int batch,
+                       size_t batch_bytes, hipStream_t st)
 {
-    dim3 grid((w + 2 * pad + HP_TW - 1) / HP_TW, (h + 2 * pad + HP_TH - 1) / HP_TH);
-    hipLaunchKernelGGL(k_hpel_filter, grid, dim3(256), 0, st, planes, plane_bytes, stride, w, h, pad);
+    dim3 grid((w + 2 * pad + HP_TW - 1) / HP_TW, (h + 2 * pad + HP_TH - 1) / HP_TH, batch);
+    hipLaunchKernelGGL(k_hpel_filter, grid, dim3(256), 0, st, planes, plane_bytes, stride, w, h, pad, batch_bytes);
     return 0;
 }
 }  // namespace x264gpu
@@ -95,7 +97,7 @@ int x264gpu_hpel_filter(uint8_t *d_planes, size_t plane_bytes, int stride, int w
 {
     ARG_TRY(d_planes && w > 0 && h > 0 && pad >= 8 && (stride % 4) == 0 && stride >= w + 2 * pad && ((w + 2 * pad) % 4) == 0);
     ARG_TRY(plane_bytes >= (size_t)stride * (h + 2 * pad) && (plane_bytes % 4) == 0 && (pad % 4) == 0);
-    launch_hpel_filter(d_planes, plane_bytes, stride, w, h, pad, (hipStream_t)stream);
+    launch_hpel_filter(d_planes, plane_bytes, stride, w, h, pad, 1, 0, (hipStream_t)stream);
     HIP_TRY(hipGetLastError());
     return X264GPU_OK;
 }

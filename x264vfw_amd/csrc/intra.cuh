@@ -103,14 +103,15 @@ __device__ __forceinline__ bool pred4_mode_ok(int mode, int avail)
     }
 }
 
-// Build U[] for the 4x4 block whose top-left sample is tile[ty][tx]; `tile` is an LDS image with stride
-// ts whose row -1 / column -1 hold the neighbours.  All 64 lanes call; lanes 0..14 do the work.
+// Build U[] for the 4x4 block whose top-left sample is `blk` inside an LDS tile of stride ts whose row -1 /
+// column -1 hold the neighbours.  All 64 lanes call.  Lane k (0..14) fetches e[k-1]; the 2- and 3-tap
+// filters come from DPP row shifts of that register (no LDS round trip); lane 15 computes the DC value.
 __device__ __forceinline__ void pred4_build_u(uint8_t *U, const uint8_t *blk, int ts, int avail, int lane)
 {
-    // e[k], k=-1..13
+    int v = 0;
     if (lane < 15) {
-        int k = lane - 1, v;
-        int kk = k < 0 ? 0 : k > 12 ? 12 : k;
+        const int k = lane - 1;
+        const int kk = k < 0 ? 0 : k > 12 ? 12 : k;
         if (kk <= 3) v = blk[(3 - kk) * ts - 1];                       // left column, bottom -> top
         else if (kk == 4) v = blk[-ts - 1];                           // corner
         else {
@@ -118,29 +119,30 @@ __device__ __forceinline__ void pred4_build_u(uint8_t *U, const uint8_t *blk, in
             if (x > 3 && !(avail & AVAIL_TOPRIGHT)) x = 3;            // replicate top[3] (8.3.1.2)
             v = blk[-ts + x];
         }
-        U[lane] = (uint8_t)v;
+    } else if (lane == 15) {
+        const uint32_t t = *(const uint32_t *)(blk - ts);
+        const int st = (int)__builtin_amdgcn_sad_u8(t, 0u, 0u);
+        const int sl = blk[-1] + blk[ts - 1] + blk[2 * ts - 1] + blk[3 * ts - 1];
+        const bool l = avail & AVAIL_LEFT, tp = avail & AVAIL_TOP;
+        v = l && tp ? (st + sl + 4) >> 3 : l ? (sl + 2) >> 2 : tp ? (st + 2) >> 2 : 128;
     }
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_s_waitcnt(0xc07f);   // lgkmcnt(0): LDS writes above visible to the reads below
-    if (lane < 13) {
-        int a = U[U_E + lane - 1], b = U[U_E + lane], c = U[U_E + lane + 1];
-        U[U_F2 + lane] = (uint8_t)((b + c + 1) >> 1);
-        U[U_F3 + lane] = (uint8_t)((a + 2 * b + c + 2) >> 2);
-    } else if (lane == 13) {
-        int st = U[U_E + 5] + U[U_E + 6] + U[U_E + 7] + U[U_E + 8];
-        int sl = U[U_E + 0] + U[U_E + 1] + U[U_E + 2] + U[U_E + 3];
-        const bool l = avail & AVAIL_LEFT, t = avail & AVAIL_TOP;
-        U[U_DC] = (uint8_t)(l && t ? (st + sl + 4) >> 3 : l ? (sl + 2) >> 2 : t ? (st + 2) >> 2 : 128);
+    const int lo = dpp<0x111>(v);     // row_shr:1  -> value of lane-1  (e[k-1])
+    const int hi = dpp<0x101>(v);     // row_shl:1  -> value of lane+1  (e[k+1])
+    if (lane < 15) U[lane] = (uint8_t)v;
+    else if (lane == 15) U[U_DC] = (uint8_t)v;
+    if (lane >= 1 && lane <= 13) {
+        U[U_F2 + lane - 1] = (uint8_t)((v + hi + 1) >> 1);
+        U[U_F3 + lane - 1] = (uint8_t)((lo + 2 * v + hi + 2) >> 2);
     }
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_s_waitcnt(0xc07f);
 }
 
-// predicted row j (4 pixels) of the block for `mode` (0..8), from U[] and the index table in LDS
-__device__ __forceinline__ uint32_t pred4_row4(const uint8_t *U, const uint8_t *tab /* [9][16] in LDS */, int mode, int j)
+// predicted row (4 pixels) from U[] given this lane's four table indices packed in t4
+__device__ __forceinline__ uint32_t pred4_row4(const uint8_t *U, uint32_t t4)
 {
-    const uint8_t *t = tab + mode * 16 + j * 4;
-    return (uint32_t)U[t[0]] | ((uint32_t)U[t[1]] << 8) | ((uint32_t)U[t[2]] << 16) | ((uint32_t)U[t[3]] << 24);
+    return (uint32_t)U[t4 & 0xff] | ((uint32_t)U[(t4 >> 8) & 0xff] << 8) | ((uint32_t)U[(t4 >> 16) & 0xff] << 16) |
+           ((uint32_t)U[t4 >> 24] << 24);
 }
 
 // ---- chroma 8x8 (per plane neighbour array of 17 bytes: [0]=tl, [1..8]=top, [9..16]=left)

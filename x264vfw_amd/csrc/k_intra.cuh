@@ -19,7 +19,9 @@ struct IntraLds {
     uint8_t U[16][U_SIZE];
     uint8_t cnb[16][2][CNB_SIZE];
     uint8_t modes[16][16];
-    uint8_t tab[9 * 16];
+    uint8_t nmodes[16][8];      // neighbour macroblocks' edge modes: [0..3] left column (by 0..3), [4..7] top row (bx 0..3)
+    int progress[160];
+    unsigned long long sect[16][8];   // diagnostics: per-wave section cycle accumulators
 };
 
 __device__ __forceinline__ int blkidx_of(int bx, int by) { return ((by >> 1) * 2 + (bx >> 1)) * 4 + (by & 1) * 2 + (bx & 1); }
@@ -38,20 +40,20 @@ __device__ __forceinline__ int i4_avail(int mbx, int mby, int mbw, int b)
 }
 
 // predicted intra 4x4 mode (8.3.1.1; oracle i4_pred_mode)
-__device__ __forceinline__ int i4_pred_mode(const x264gpu_mb *mbs, int mbw, int mbx, int mby, int b, const uint8_t *cur)
+__device__ __forceinline__ int i4_pred_mode(const uint8_t *nm, int mbx, int mby, int b, const uint8_t *cur)
 {
     const int bx = z_bx(b), by = z_by(b);
     int ma, mb_;
     if (bx > 0) ma = cur[blkidx_of(bx - 1, by)];
-    else if (mbx > 0) { const x264gpu_mb *n = mbs + mby * mbw + mbx - 1; ma = n->type == X264GPU_MB_I4x4 ? n->i4_mode[blkidx_of(3, by)] : 2; }
+    else if (mbx > 0) ma = nm[by];
     else return 2;
     if (by > 0) mb_ = cur[blkidx_of(bx, by - 1)];
-    else if (mby > 0) { const x264gpu_mb *n = mbs + (mby - 1) * mbw + mbx; mb_ = n->type == X264GPU_MB_I4x4 ? n->i4_mode[blkidx_of(bx, 3)] : 2; }
+    else if (mby > 0) mb_ = nm[4 + bx];
     else return 2;
     return min(ma, mb_);
 }
 
-__device__ void intra_mb_wave(const EncK &k, IntraLds &L, int wave, int lane, int s, int mbx, int mby)
+__device__ void intra_mb_wave(const EncK &k, IntraLds &L, int wave, int lane, int s, int mbx, int mby, uint32_t t4)
 {
     uint8_t *tile = L.tile[wave] + IT_ORG;     // sample (0,0)
     uint8_t *nb = L.nb[wave];
@@ -65,6 +67,8 @@ __device__ void intra_mb_wave(const EncK &k, IntraLds &L, int wave, int lane, in
     const bool left = mbx > 0, top = mby > 0, topright = top && mbx + 1 < k.mbw;
     const int j = lane & 3, zx = z_x0(lane), zy = z_y(lane);
     const int qp = k.qp, lambda = k.lambda;
+    unsigned long long ts0 = k.dbg ? clock64() : 0;
+#define SECT(i) do { if (k.dbg) { unsigned long long t_ = clock64(); if (lane == 0) L.sect[wave][i] += t_ - ts0; ts0 = t_; } } while (0)
 
     // ---- neighbours: row -1 (x = -1..19) and column -1 into the tile; nb[] for the 16x16 predictors ----
     if (lane < 21) {
@@ -79,10 +83,19 @@ __device__ void intra_mb_wave(const EncK &k, IntraLds &L, int wave, int lane, in
         tile[y * IT_STRIDE - 1] = v;
         nb[NB_LEFT + y] = v;
     }
+    // edge modes of the left / top macroblocks (DC unless that macroblock is I4x4), fetched once
+    if (lane >= 48 && lane < 56) {
+        const int i = lane - 48;
+        int m = 2;
+        if (i < 4 && left) { const x264gpu_mb *n = mbs + mbi - 1; if (n->type == X264GPU_MB_I4x4) m = n->i4_mode[blkidx_of(3, i)]; }
+        if (i >= 4 && top) { const x264gpu_mb *n = mbs + mbi - k.mbw; if (n->type == X264GPU_MB_I4x4) m = n->i4_mode[blkidx_of(i - 4, 3)]; }
+        L.nmodes[wave][i] = (uint8_t)m;
+    }
     const uint32_t cz = *(const uint32_t *)(fenc + (size_t)zy * k.fs + zx);
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_s_waitcnt(0xc07f);
 
+    SECT(0);
     // ---- intra 16x16 mode decision ----
     const Pred16 pp = pred16_setup(nb, lane);
     int best16 = 1 << 28, mode16 = 0;
@@ -103,6 +116,7 @@ __device__ void intra_mb_wave(const EncK &k, IntraLds &L, int wave, int lane, in
         }
     }
 
+    SECT(1);
     // ---- intra 4x4: nine modes per block in parallel, blocks in coding order ----
     bool use_i4 = false;
     unsigned nnz = 0;
@@ -112,12 +126,12 @@ __device__ void intra_mb_wave(const EncK &k, IntraLds &L, int wave, int lane, in
         for (int b = 0; b < 16; b++) {
             const int bx = z_bx(b), by = z_by(b);
             const int avail = i4_avail(mbx, mby, k.mbw, b);
-            const int pm = i4_pred_mode(mbs, k.mbw, mbx, mby, b, m4);
+            const int pm = i4_pred_mode(L.nmodes[wave], mbx, mby, b, m4);
             uint8_t *bt = tile + by * 4 * IT_STRIDE + bx * 4;
             pred4_build_u(U, bt, IT_STRIDE, avail, lane);
             const int m = lane >> 2;
             const bool ok = m < 9 && pred4_mode_ok(m, avail);
-            const uint32_t pr = pred4_row4(U, L.tab, m < 9 ? m : 8, j);
+            const uint32_t pr = pred4_row4(U, t4);
             const uint32_t en = (uint32_t)__shfl((int)cz, b * 4 + j);
             int e[4], p[4], d[4];
             unpack4(en, e); unpack4(pr, p);
@@ -147,10 +161,12 @@ __device__ void intra_mb_wave(const EncK &k, IntraLds &L, int wave, int lane, in
             if (nz) nnz |= 1u << b;
             __builtin_amdgcn_wave_barrier();
             __builtin_amdgcn_s_waitcnt(0xc07f);
+            if (cost4 >= best16) break;            // intra 4x4 can no longer win (costs only grow)
         }
         use_i4 = cost4 < best16;
     }
 
+    SECT(2);
     x264gpu_mb recd;
     __builtin_memset(&recd, 0, sizeof(recd));
     recd.qp = (uint8_t)qp;
@@ -216,6 +232,7 @@ __device__ void intra_mb_wave(const EncK &k, IntraLds &L, int wave, int lane, in
         recd.cbp_luma = acn ? 15 : 0;
     }
     if (lane >= 16 && lane < 24) lv[408 + lane - 16] = 0;
+    SECT(3);
 
     // ---- chroma: mode decision + encode (lanes 0..31; plane = lane>>4) ----
     {
@@ -269,25 +286,55 @@ __device__ void intra_mb_wave(const EncK &k, IntraLds &L, int wave, int lane, in
             *(uint2 *)(ruv + (size_t)cyy * k.rs + 2 * cx0) = o;
         }
     }
+    SECT(4);
     if (lane == 0) mbs[mbi] = recd;
+#undef SECT
 }
 
 __global__ __launch_bounds__(1024) void k_intra(EncK k)
 {
     __shared__ __attribute__((aligned(16))) IntraLds L;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, s = blockIdx.x;
-    for (int i = threadIdx.x; i < 9 * 16; i += 1024) L.tab[i] = ((const uint8_t *)c_pred4_table.t)[i];
+    // this lane's four table entries for (mode = lane>>2, row = lane&3); lanes of modes >= 9 are idle
+    const uint32_t t4 = (lane >> 2) < 9 ? ((const uint32_t *)c_pred4_table.t)[lane] : 0x01010101u * U_DC;
+    for (int i = threadIdx.x; i < 160; i += 1024) L.progress[i] = 0;
+    if (threadIdx.x < 128) ((unsigned long long *)L.sect)[threadIdx.x] = 0;
     __syncthreads();
     const x264gpu_mb *mbs = k.mb + (size_t)s * k.nmb;
-    const int ndiag = k.mbw + 2 * (k.mbh - 1);
-    for (int d = 0; d < ndiag; d++) {
-        const int ymin = max(0, (d - (k.mbw - 1) + 1) >> 1), ymax = min(k.mbh - 1, d >> 1);
-        for (int i = ymin + wave; i <= ymax; i += 16) {
-            const int mby = i, mbx = d - 2 * i;
-            if (k.slice_type == X264GPU_SLICE_I || mbs[mby * k.mbw + mbx].type != X264GPU_MB_P_L0)
-                intra_mb_wave(k, L, wave, lane, s, mbx, mby);
+    volatile int *progress = L.progress;
+    unsigned long long t_wait = 0, t_work = 0, n_mb = 0, t_begin = k.dbg ? clock64() : 0;
+    // wave w owns macroblock rows w, w+16, ...; an intra macroblock at x needs row-1 complete up to x+1
+    // (top-right neighbour).  Inter macroblocks were reconstructed by k_encode_inter and are skipped.
+    for (int row = wave; row < k.mbh; row += 16) {
+        for (int x0 = 0; x0 < k.mbw; x0 += 64) {
+            bool is_intra = false;
+            if (x0 + lane < k.mbw) is_intra = k.slice_type == X264GPU_SLICE_I || mbs[row * k.mbw + x0 + lane].type != X264GPU_MB_P_L0;
+            unsigned long long todo = __ballot(is_intra);
+            const int chunk_end = min(x0 + 64, k.mbw);
+            // everything left of the next intra macroblock of this row is already reconstructed
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            if (lane == 0) progress[row] = todo ? x0 + __builtin_ctzll(todo) : chunk_end;
+            while (todo) {
+                const int x = x0 + __builtin_ctzll(todo);
+                todo &= todo - 1;
+                const unsigned long long t0 = k.dbg ? clock64() : 0;
+                if (row > 0) {
+                    const int need = min(x + 2, k.mbw);
+                    while (progress[row - 1] < need) __builtin_amdgcn_s_sleep(2);
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+                }
+                const unsigned long long t1 = k.dbg ? clock64() : 0;
+                intra_mb_wave(k, L, wave, lane, s, x, row, t4);
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                if (k.dbg) { const unsigned long long t2 = clock64(); t_wait += t1 - t0; t_work += t2 - t1; n_mb++; }
+                if (lane == 0) progress[row] = todo ? x0 + __builtin_ctzll(todo) : chunk_end;
+            }
         }
-        __syncthreads();
+    }
+    if (k.dbg && lane == 0) {
+        unsigned long long *d = k.dbg + ((size_t)s * 16 + wave) * 16;
+        d[0] = t_wait; d[1] = t_work; d[2] = n_mb; d[3] = clock64() - t_begin;
+        for (int i = 0; i < 5; i++) d[8 + i] = L.sect[wave][i];
     }
 }
 

@@ -75,6 +75,7 @@ _SIGS = {
     "x264gpu_encoder_stage_count": (_i, []),
     "x264gpu_encoder_stage_name": (C.c_char_p, [_i]),
     "x264gpu_encoder_profile_begin": (_i, [_vp, _i]),
+    "x264gpu_encoder_set_debug": (_i, [_vp, _vp]),
     "x264gpu_encoder_profile_end": (_i, [_vp, _vp, C.POINTER(C.c_double), C.POINTER(_i)]),
 }
 
