@@ -1,0 +1,558 @@
+// oracle/h264dec.cpp — minimal H.264 decoder for the syntax subset the host entropy coder emits
+// (TEST INFRASTRUCTURE ONLY; see x264o.h).  Closes the loop: bitstream -> pictures must equal the encoder's
+// reconstruction bit for bit, which checks the slice/macroblock syntax (7.3.3-7.3.5), CAVLC (9.2), motion
+// vector and intra-mode prediction (8.3.1.1, 8.4.1) and boundary strengths (8.7.2.1) independently of the
+// encoder-side code paths.  Sample reconstruction reuses the oracle's spec-pinned DSP (predict, dequant,
+// inverse transforms, interpolation, edge filters).  Subset: Baseline-style streams — CAVLC, frame MBs,
+// I (I4x4/I16x16) and P (P_L0_16x16, P_Skip, intra) slices, one slice per picture, poc type 2, one ref.
+#include "x264o.h"
+#include "../x264vfw_amd/host/cavlc_tables.hpp"
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+#include <vector>
+
+using namespace x264host;
+
+namespace {
+
+struct BitReader {
+    const uint8_t *p; size_t n; size_t pos = 0;          // pos in bits
+    int get1() { if (pos >= n * 8) { err = true; return 0; } int b = (p[pos >> 3] >> (7 - (pos & 7))) & 1; pos++; return b; }
+    uint32_t get(int k) { uint32_t v = 0; while (k--) v = (v << 1) | get1(); return v; }
+    uint32_t ue() { int z = 0; while (!get1() && z < 32 && !err) z++; return z ? ((1u << z) - 1 + get(z)) : 0; }
+    int se() { uint32_t k = ue(); return (k & 1) ? (int)((k + 1) >> 1) : -(int)(k >> 1); }
+    bool more_rbsp_data() const
+    {
+        // true unless only the rbsp_trailing_bits remain
+        if (pos >= n * 8) return false;
+        size_t last = n;
+        while (last > 0 && p[last - 1] == 0) last--;
+        if (!last) return false;
+        int b = 0;
+        while (!((p[last - 1] >> b) & 1)) b++;
+        size_t stop = (last - 1) * 8 + (7 - b);       // bit position of the stop bit
+        return pos < stop;
+    }
+    bool err = false;
+};
+
+const uint8_t kBlkX[16] = { 0, 1, 0, 1, 2, 3, 2, 3, 0, 1, 0, 1, 2, 3, 2, 3 };
+const uint8_t kBlkY[16] = { 0, 0, 1, 1, 0, 0, 1, 1, 2, 2, 3, 3, 2, 2, 3, 3 };
+const uint8_t kIdxOf[4][4] = { { 0, 1, 4, 5 }, { 2, 3, 6, 7 }, { 8, 9, 12, 13 }, { 10, 11, 14, 15 } };
+
+struct MbInfo {
+    int intra, i16, skip;
+    int mvx, mvy, ref;       // ref -1 for intra
+    int qp;
+    uint8_t i4mode[16];
+    uint8_t tc[24];          // total_coeff per block (for nC)
+    uint32_t nz;             // luma blocks with coefficients (deblock bS 2): bit per block idx
+};
+
+struct Decoder {
+    int mbw = 0, mbh = 0, width = 0, height = 0, crop_r = 0, crop_b = 0;
+    int log2_max_frame_num = 4, poc_type = 2;
+    int pic_init_qp = 26, chroma_qp_offset = 0, deblock_ctrl = 1, num_ref_default = 1;
+    int stride = 0, pad = 32, cpad = 16;
+    size_t plane_bytes = 0, cplane_bytes = 0;
+    std::vector<pixel> luma[2], chroma[2];
+    int cur = 0;
+    std::vector<MbInfo> mb;
+    bool have_sps = false, have_pps = false;
+    std::vector<std::vector<uint8_t>> frames;
+    x264o_quant_tables qt;
+
+    pixel *Y(int slot, int k = 0) { return luma[slot].data() + k * plane_bytes + (size_t)pad * stride + pad; }
+    pixel *UV(int slot) { return chroma[slot].data() + (size_t)cpad * stride + 2 * cpad; }
+
+    void alloc()
+    {
+        stride = (mbw * 16 + 2 * pad + 63) / 64 * 64;
+        plane_bytes = (size_t)stride * (mbh * 16 + 2 * pad);
+        cplane_bytes = (size_t)stride * (mbh * 8 + 2 * cpad);
+        for (int s = 0; s < 2; s++) { luma[s].assign(4 * plane_bytes, 0); chroma[s].assign(cplane_bytes, 0); }
+        mb.assign((size_t)mbw * mbh, MbInfo());
+        x264o_quant_init(&qt, 21, 11);
+    }
+};
+
+int clampi(int v, int lo, int hi) { return v < lo ? lo : v > hi ? hi : v; }
+
+// ---- CAVLC parsing ----
+int read_vlc(BitReader &br, const uint8_t *len, const uint8_t *bits, int n)
+{
+    // incremental prefix match (tables are prefix-free)
+    uint32_t code = 0;
+    for (int l = 1; l <= 16; l++) {
+        code = (code << 1) | br.get1();
+        for (int i = 0; i < n; i++) if (len[i] == l && bits[i] == code) return i;
+    }
+    br.err = true;
+    return 0;
+}
+
+// returns total_coeff; coefficients (scan order) written to out[0..max-1]
+int residual_block(BitReader &br, int16_t *out, int maxn, int nC)
+{
+    memset(out, 0, sizeof(int16_t) * maxn);
+    int tok = nC < 0 ? read_vlc(br, chroma_dc_coeff_token_len, chroma_dc_coeff_token_bits, 20)
+                     : read_vlc(br, coeff_token_len[nC < 2 ? 0 : nC < 4 ? 1 : nC < 8 ? 2 : 3], coeff_token_bits[nC < 2 ? 0 : nC < 4 ? 1 : nC < 8 ? 2 : 3], 68);
+    int total = tok >> 2, t1 = tok & 3;
+    if (!total) return 0;
+    int level[16];
+    int suffix_len = total > 10 && t1 < 3 ? 1 : 0;
+    for (int i = 0; i < total; i++) {
+        if (i < t1) { level[i] = br.get1() ? -1 : 1; continue; }
+        int prefix = 0;
+        while (!br.get1() && prefix < 32 && !br.err) prefix++;
+        int size = prefix == 14 && suffix_len == 0 ? 4 : prefix >= 15 ? prefix - 3 : suffix_len;
+        int code = ((prefix < 15 ? prefix : 15) << suffix_len) + (size ? (int)br.get(size) : 0);
+        if (prefix >= 15 && suffix_len == 0) code += 15;
+        if (prefix >= 16) code += (1 << (prefix - 3)) - 4096;
+        if (i == t1 && t1 < 3) code += 2;
+        level[i] = (code & 1) ? (-code - 1) >> 1 : (code + 2) >> 1;
+        if (suffix_len == 0) suffix_len = 1;
+        if (abs(level[i]) > (3 << (suffix_len - 1)) && suffix_len < 6) suffix_len++;
+    }
+    int zeros = 0;
+    if (total < maxn) {
+        if (nC < 0) zeros = read_vlc(br, chroma_dc_total_zeros_len[total - 1], chroma_dc_total_zeros_bits[total - 1], 4);
+        else zeros = read_vlc(br, total_zeros_len[total - 1], total_zeros_bits[total - 1], 16);
+    }
+    int pos = total + zeros - 1;               // position of the highest-frequency coefficient
+    int left = zeros;
+    for (int i = 0; i < total; i++) {
+        if (pos < 0 || pos >= maxn) { br.err = true; return total; }
+        out[pos] = (int16_t)level[i];
+        int run = 0;
+        if (i < total - 1 && left > 0) { int t = (left < 7 ? left : 7) - 1; run = read_vlc(br, run_before_len[t], run_before_bits[t], 16); left -= run; }
+        else if (i == total - 1) run = left;
+        pos -= run + 1;
+    }
+    return total;
+}
+
+struct SliceDec {
+    Decoder &d;
+    BitReader &br;
+    int slice_type, qp, disable_deblock, alpha_off, beta_off;
+
+    int nc_luma(int mbx, int mby, int blk)
+    {
+        int bx = kBlkX[blk], by = kBlkY[blk], na = -1, nb = -1;
+        if (bx > 0) na = d.mb[mby * d.mbw + mbx].tc[kIdxOf[by][bx - 1]];
+        else if (mbx > 0) na = d.mb[mby * d.mbw + mbx - 1].tc[kIdxOf[by][3]];
+        if (by > 0) nb = d.mb[mby * d.mbw + mbx].tc[kIdxOf[by - 1][bx]];
+        else if (mby > 0) nb = d.mb[(mby - 1) * d.mbw + mbx].tc[kIdxOf[3][bx]];
+        return na >= 0 && nb >= 0 ? (na + nb + 1) >> 1 : na >= 0 ? na : nb >= 0 ? nb : 0;
+    }
+    int nc_chroma(int mbx, int mby, int c, int i)
+    {
+        int bx = i & 1, by = i >> 1, na = -1, nb = -1, base = 16 + c * 4;
+        if (bx > 0) na = d.mb[mby * d.mbw + mbx].tc[base + by * 2];
+        else if (mbx > 0) na = d.mb[mby * d.mbw + mbx - 1].tc[base + by * 2 + 1];
+        if (by > 0) nb = d.mb[mby * d.mbw + mbx].tc[base + bx];
+        else if (mby > 0) nb = d.mb[(mby - 1) * d.mbw + mbx].tc[base + 2 + bx];
+        return na >= 0 && nb >= 0 ? (na + nb + 1) >> 1 : na >= 0 ? na : nb >= 0 ? nb : 0;
+    }
+
+    struct Nb { bool avail; int ref, mvx, mvy; };
+    Nb nb(int x, int y, int cur_idx)
+    {
+        Nb n = { false, -1, 0, 0 };
+        if (x < 0 || y < 0 || x >= d.mbw || y >= d.mbh) return n;
+        int i = y * d.mbw + x;
+        if (i >= cur_idx) return n;
+        n.avail = true;
+        const MbInfo &m = d.mb[i];
+        if (!m.intra) { n.ref = m.ref; n.mvx = m.mvx; n.mvy = m.mvy; }
+        return n;
+    }
+    void mvp(int mbx, int mby, int ref, int &px, int &py)
+    {
+        int ci = mby * d.mbw + mbx;
+        Nb a = nb(mbx - 1, mby, ci), b = nb(mbx, mby - 1, ci), c = nb(mbx + 1, mby - 1, ci);
+        if (!c.avail) c = nb(mbx - 1, mby - 1, ci);
+        if (!b.avail && !c.avail && a.avail) { b = a; c = a; }
+        int cnt = (a.ref == ref) + (b.ref == ref) + (c.ref == ref);
+        if (cnt == 1) { const Nb &s = a.ref == ref ? a : b.ref == ref ? b : c; px = s.mvx; py = s.mvy; return; }
+        auto med = [](int x, int y, int z) { return x > y ? (y > z ? y : x > z ? z : x) : (x > z ? x : y > z ? z : y); };
+        px = med(a.mvx, b.mvx, c.mvx); py = med(a.mvy, b.mvy, c.mvy);
+    }
+    void skip_mv(int mbx, int mby, int &px, int &py)
+    {
+        int ci = mby * d.mbw + mbx;
+        Nb a = nb(mbx - 1, mby, ci), b = nb(mbx, mby - 1, ci);
+        if (!a.avail || !b.avail || (a.ref == 0 && !a.mvx && !a.mvy) || (b.ref == 0 && !b.mvx && !b.mvy)) { px = py = 0; return; }
+        mvp(mbx, mby, 0, px, py);
+    }
+
+    void inter_pred(int mbx, int mby, int mvx, int mvy)
+    {
+        int ref = d.cur ^ 1;
+        pixel *planes[4] = { d.Y(ref, 0), d.Y(ref, 1), d.Y(ref, 2), d.Y(ref, 3) };
+        x264o_mc_luma(d.Y(d.cur) + (size_t)mby * 16 * d.stride + mbx * 16, d.stride, planes, d.stride, mbx * 16, mby * 16, mvx, mvy, 16, 16);
+        pixel pu[64], pv[64];
+        x264o_mc_chroma(pu, pv, 8, d.UV(ref), d.stride, mbx * 8, mby * 8, mvx, mvy, 8, 8);
+        pixel *uv = d.UV(d.cur) + (size_t)mby * 8 * d.stride + mbx * 16;
+        for (int y = 0; y < 8; y++) for (int x = 0; x < 8; x++) { uv[y * d.stride + 2 * x] = pu[y * 8 + x]; uv[y * d.stride + 2 * x + 1] = pv[y * 8 + x]; }
+    }
+
+    void chroma_residual(int mbx, int mby, int cbp_chroma, MbInfo &m, int qpc)
+    {
+        int16_t dc[2][4] = { { 0 } }, ac[2][4][16];
+        memset(ac, 0, sizeof(ac));
+        if (cbp_chroma) for (int c = 0; c < 2; c++) residual_block(br, dc[c], 4, -1);
+        if (cbp_chroma == 2)
+            for (int c = 0; c < 2; c++)
+                for (int i = 0; i < 4; i++) m.tc[16 + c * 4 + i] = (uint8_t)residual_block(br, ac[c][i] + 1, 15, nc_chroma(mbx, mby, c, i));
+        pixel *uv = d.UV(d.cur) + (size_t)mby * 8 * d.stride + mbx * 16;
+        for (int c = 0; c < 2; c++) {
+            dctcoef dq[4];
+            x264o_dequant_2x2_dc(dq, dc[c], d.qt.dequant4_mf, qpc);
+            pixel p[64];
+            for (int y = 0; y < 8; y++) for (int x = 0; x < 8; x++) p[y * 8 + x] = uv[y * d.stride + 2 * x + c];
+            for (int i = 0; i < 4; i++) {
+                dctcoef blk[16];
+                for (int k = 0; k < 16; k++) blk[x264o_zigzag4[k]] = ac[c][i][k];
+                x264o_dequant_4x4(blk, d.qt.dequant4_mf, qpc);
+                blk[0] = dq[i];
+                x264o_add4x4_idct(p + (i >> 1) * 32 + (i & 1) * 4, 8, blk);
+            }
+            for (int y = 0; y < 8; y++) for (int x = 0; x < 8; x++) uv[y * d.stride + 2 * x + c] = p[y * 8 + x];
+        }
+    }
+
+    int i4_avail(int mbx, int mby, int b)
+    {
+        int bx = kBlkX[b], by = kBlkY[b], a = 0;
+        if (bx > 0 || mbx > 0) a |= X264O_AVAIL_LEFT;
+        if (by > 0 || mby > 0) a |= X264O_AVAIL_TOP;
+        if ((bx > 0 || mbx > 0) && (by > 0 || mby > 0)) a |= X264O_AVAIL_TOPLEFT;
+        if (by == 0) { if (mby > 0 && (bx < 3 || mbx + 1 < d.mbw)) a |= X264O_AVAIL_TOPRIGHT; }
+        else if (bx < 3 && kIdxOf[by - 1][bx + 1] < b) a |= X264O_AVAIL_TOPRIGHT;
+        return a;
+    }
+    int pred_i4(int mbx, int mby, int b, const MbInfo &cur)
+    {
+        int bx = kBlkX[b], by = kBlkY[b], ma, mb_;
+        if (bx > 0) ma = cur.i4mode[kIdxOf[by][bx - 1]];
+        else if (mbx > 0) { const MbInfo &n = d.mb[mby * d.mbw + mbx - 1]; ma = n.intra && !n.i16 ? n.i4mode[kIdxOf[by][3]] : 2; }
+        else return 2;
+        if (by > 0) mb_ = cur.i4mode[kIdxOf[by - 1][bx]];
+        else if (mby > 0) { const MbInfo &n = d.mb[(mby - 1) * d.mbw + mbx]; mb_ = n.intra && !n.i16 ? n.i4mode[kIdxOf[3][bx]] : 2; }
+        else return 2;
+        return ma < mb_ ? ma : mb_;
+    }
+
+    void intra_mb(int mbx, int mby, int mbtype /* I-slice numbering */, MbInfo &m)
+    {
+        pixel *rec = d.Y(d.cur) + (size_t)mby * 16 * d.stride + mbx * 16;
+        int left = mbx > 0, top = mby > 0;
+        m.intra = 1; m.ref = -1; m.mvx = m.mvy = 0;
+        int cbp_luma = 0, cbp_chroma = 0, i16mode = 0;
+        if (mbtype == 0) {
+            m.i16 = 0;
+            for (int b = 0; b < 16; b++) {
+                int pm = pred_i4(mbx, mby, b, m);
+                if (br.get1()) m.i4mode[b] = (uint8_t)pm;
+                else { int r = (int)br.get(3); m.i4mode[b] = (uint8_t)(r < pm ? r : r + 1); }
+            }
+        } else {
+            m.i16 = 1;
+            int t = mbtype - 1;
+            i16mode = t & 3; cbp_chroma = (t >> 2) % 3; cbp_luma = t >= 12 ? 15 : 0;
+            memset(m.i4mode, 2, 16);
+        }
+        int chroma_mode = (int)br.ue();
+        if (!m.i16) {
+            int code = (int)br.ue(), cbp = -1;
+            for (int i = 0; i < 48; i++) if (cbp_to_golomb_intra[i] == code) cbp = i;
+            if (cbp < 0) { br.err = true; return; }
+            cbp_luma = cbp & 15; cbp_chroma = cbp >> 4;
+        }
+        if (m.i16 || cbp_luma || cbp_chroma) qp += br.se();
+        m.qp = qp;
+        int qpc = x264o_chroma_qp[clampi(qp + d.chroma_qp_offset, 0, 51)];
+        if (m.i16) {
+            int16_t dcl[16], acl[16][16];
+            memset(acl, 0, sizeof(acl));
+            residual_block(br, dcl, 16, nc_luma(mbx, mby, 0));
+            for (int i8 = 0; i8 < 4; i8++)
+                if (cbp_luma >> i8 & 1)
+                    for (int k = 0; k < 4; k++) { int b = i8 * 4 + k; m.tc[b] = (uint8_t)residual_block(br, acl[b] + 1, 15, nc_luma(mbx, mby, b)); }
+            int mode = i16mode;
+            if (mode == I_PRED_16x16_DC) mode = left && top ? I_PRED_16x16_DC : left ? I_PRED_16x16_DC_LEFT : top ? I_PRED_16x16_DC_TOP : I_PRED_16x16_DC_128;
+            pixel pred[256];
+            x264o_predict_16x16(pred, 16, rec, d.stride, mode);
+            for (int y = 0; y < 16; y++) memcpy(rec + y * d.stride, pred + y * 16, 16);
+            dctcoef dc[16];
+            for (int k = 0; k < 16; k++) dc[x264o_zigzag4[k]] = dcl[k];
+            x264o_idct4x4dc(dc);
+            x264o_dequant_4x4_dc(dc, d.qt.dequant4_mf, qp);
+            for (int b = 0; b < 16; b++) {
+                dctcoef blk[16];
+                for (int k = 0; k < 16; k++) blk[x264o_zigzag4[k]] = acl[b][k];
+                x264o_dequant_4x4(blk, d.qt.dequant4_mf, qp);
+                blk[0] = dc[kBlkY[b] * 4 + kBlkX[b]];
+                x264o_add4x4_idct(rec + kBlkY[b] * 4 * d.stride + kBlkX[b] * 4, d.stride, blk);
+            }
+        } else {
+            for (int b = 0; b < 16; b++) {
+                int16_t l[16];
+                memset(l, 0, sizeof(l));
+                if (cbp_luma >> (b >> 2) & 1) m.tc[b] = (uint8_t)residual_block(br, l, 16, nc_luma(mbx, mby, b));
+                int avail = i4_avail(mbx, mby, b), mode = m.i4mode[b];
+                if (mode == I_PRED_4x4_DC) {
+                    int l_ = avail & X264O_AVAIL_LEFT, t_ = avail & X264O_AVAIL_TOP;
+                    mode = l_ && t_ ? I_PRED_4x4_DC : l_ ? I_PRED_4x4_DC_LEFT : t_ ? I_PRED_4x4_DC_TOP : I_PRED_4x4_DC_128;
+                }
+                pixel *r = rec + kBlkY[b] * 4 * d.stride + kBlkX[b] * 4, p4[16];
+                x264o_predict_4x4(p4, 4, r, d.stride, mode, avail);
+                for (int y = 0; y < 4; y++) memcpy(r + y * d.stride, p4 + y * 4, 4);
+                dctcoef blk[16];
+                for (int k = 0; k < 16; k++) blk[x264o_zigzag4[k]] = l[k];
+                x264o_dequant_4x4(blk, d.qt.dequant4_mf, qp);
+                x264o_add4x4_idct(r, d.stride, blk);
+                if (m.tc[b]) m.nz |= 1u << b;
+            }
+        }
+        // chroma prediction
+        pixel *uv = d.UV(d.cur) + (size_t)mby * 8 * d.stride + mbx * 16;
+        int cmode = chroma_mode;
+        if (cmode == I_PRED_CHROMA_DC) cmode = left && top ? I_PRED_CHROMA_DC : left ? I_PRED_CHROMA_DC_LEFT : top ? I_PRED_CHROMA_DC_TOP : I_PRED_CHROMA_DC_128;
+        for (int c = 0; c < 2; c++) {
+            pixel ring[81], out[64];
+            memset(ring, 128, sizeof(ring));
+            for (int y = -1; y < 8; y++)
+                for (int x = -1; x < 8; x++) {
+                    if ((y >= 0 && x >= 0) || (y < 0 && !top) || (x < 0 && !left)) continue;
+                    ring[(y + 1) * 9 + x + 1] = uv[y * d.stride + 2 * x + c];
+                }
+            x264o_predict_8x8c(out, 8, ring + 10, 9, cmode);
+            for (int y = 0; y < 8; y++) for (int x = 0; x < 8; x++) uv[y * d.stride + 2 * x + c] = out[y * 8 + x];
+        }
+        chroma_residual(mbx, mby, cbp_chroma, m, qpc);
+    }
+
+    void inter_mb(int mbx, int mby, MbInfo &m)
+    {
+        m.intra = 0; m.i16 = 0; memset(m.i4mode, 2, 16);
+        int ref = d.num_ref_default > 1 ? (d.num_ref_default == 2 ? !br.get1() : (int)br.ue()) : 0;
+        int px, py;
+        mvp(mbx, mby, ref, px, py);
+        m.ref = ref; m.mvx = px + br.se(); m.mvy = py + br.se();
+        int code = (int)br.ue(), cbp = -1;
+        for (int i = 0; i < 48; i++) if (cbp_to_golomb_inter[i] == code) cbp = i;
+        if (cbp < 0) { br.err = true; return; }
+        if (cbp) qp += br.se();
+        m.qp = qp;
+        inter_pred(mbx, mby, m.mvx, m.mvy);
+        pixel *rec = d.Y(d.cur) + (size_t)mby * 16 * d.stride + mbx * 16;
+        for (int b = 0; b < 16; b++) {
+            if (!(cbp >> (b >> 2) & 1)) continue;
+            int16_t l[16];
+            m.tc[b] = (uint8_t)residual_block(br, l, 16, nc_luma(mbx, mby, b));
+            if (m.tc[b]) m.nz |= 1u << b;
+            dctcoef blk[16];
+            for (int k = 0; k < 16; k++) blk[x264o_zigzag4[k]] = l[k];
+            x264o_dequant_4x4(blk, d.qt.dequant4_mf, qp);
+            x264o_add4x4_idct(rec + kBlkY[b] * 4 * d.stride + kBlkX[b] * 4, d.stride, blk);
+        }
+        chroma_residual(mbx, mby, cbp >> 4, m, x264o_chroma_qp[clampi(qp + d.chroma_qp_offset, 0, 51)]);
+    }
+
+    void run()
+    {
+        int n = d.mbw * d.mbh, i = 0;
+        for (auto &m : d.mb) m = MbInfo();
+        while (i < n && !br.err) {
+            if (slice_type == 0) {
+                int run = (int)br.ue();
+                while (run-- && i < n) {
+                    MbInfo &m = d.mb[i];
+                    int mbx = i % d.mbw, mby = i / d.mbw, px, py;
+                    skip_mv(mbx, mby, px, py);
+                    m.intra = 0; m.skip = 1; m.ref = 0; m.mvx = px; m.mvy = py; m.qp = qp; memset(m.i4mode, 2, 16);
+                    inter_pred(mbx, mby, px, py);
+                    i++;
+                }
+                if (i >= n || !br.more_rbsp_data()) break;
+            }
+            MbInfo &m = d.mb[i];
+            int mbx = i % d.mbw, mby = i / d.mbw;
+            int t = (int)br.ue();
+            if (slice_type == 0) { if (t == 0) inter_mb(mbx, mby, m); else if (t >= 5) intra_mb(mbx, mby, t - 5, m); else br.err = true; }
+            else intra_mb(mbx, mby, t, m);
+            i++;
+        }
+    }
+
+    // ---- deblocking (8.7), written from the clause; filters come from oracle/deblock.c ----
+    int bs_of(const MbInfo &p, int pb, const MbInfo &q, int qb, bool mbedge)
+    {
+        if (p.intra || q.intra) return mbedge ? 4 : 3;
+        if ((p.nz >> pb & 1) || (q.nz >> qb & 1)) return 2;
+        if (p.ref != q.ref) return 1;
+        return abs(p.mvx - q.mvx) >= 4 || abs(p.mvy - q.mvy) >= 4;
+    }
+    void deblock()
+    {
+        if (disable_deblock == 1) return;
+        pixel *Yp = d.Y(d.cur), *UVp = d.UV(d.cur);
+        for (int mby = 0; mby < d.mbh; mby++)
+            for (int mbx = 0; mbx < d.mbw; mbx++) {
+                const MbInfo &q = d.mb[mby * d.mbw + mbx];
+                for (int vert = 1; vert >= 0; vert--)            // vertical edges first
+                    for (int e = 0; e < 4; e++) {
+                        const MbInfo *p = &q;
+                        if (e == 0) {
+                            if (vert) { if (!mbx) continue; p = &d.mb[mby * d.mbw + mbx - 1]; }
+                            else { if (!mby) continue; p = &d.mb[(mby - 1) * d.mbw + mbx]; }
+                        }
+                        int qpav = (p->qp + q.qp + 1) >> 1;
+                        int qpcav = (x264o_chroma_qp[clampi(p->qp + d.chroma_qp_offset, 0, 51)] + x264o_chroma_qp[clampi(q.qp + d.chroma_qp_offset, 0, 51)] + 1) >> 1;
+                        int ia = clampi(qpav + alpha_off, 0, 51), ib = clampi(qpav + beta_off, 0, 51);
+                        int ica = clampi(qpcav + alpha_off, 0, 51), icb = clampi(qpcav + beta_off, 0, 51);
+                        for (int k = 0; k < 4; k++) {
+                            int qb = vert ? kIdxOf[k][e] : kIdxOf[e][k];
+                            int pb = vert ? kIdxOf[k][(e + 3) & 3] : kIdxOf[(e + 3) & 3][k];
+                            int bs = bs_of(*p, pb, q, qb, e == 0);
+                            if (!bs) continue;
+                            int x = mbx * 16 + (vert ? e * 4 : k * 4), y = mby * 16 + (vert ? k * 4 : e * 4);
+                            int tc0 = bs < 4 ? x264o_tc0_table[ia][bs - 1] : 0;
+                            if (vert) x264o_deblock_luma_edge(Yp + (size_t)y * d.stride + x, 1, d.stride, 4, x264o_alpha_table[ia], x264o_beta_table[ib], tc0, bs);
+                            else x264o_deblock_luma_edge(Yp + (size_t)y * d.stride + x, d.stride, 1, 4, x264o_alpha_table[ia], x264o_beta_table[ib], tc0, bs);
+                            if (e & 1) continue;
+                            int ctc0 = bs < 4 ? x264o_tc0_table[ica][bs - 1] : 0;
+                            for (int c = 0; c < 2; c++) {
+                                pixel *pc = UVp + (size_t)(y / 2) * d.stride + 2 * (x / 2) + c;
+                                if (vert) x264o_deblock_chroma_edge(pc, 2, d.stride, 2, x264o_alpha_table[ica], x264o_beta_table[icb], ctc0, bs);
+                                else x264o_deblock_chroma_edge(pc, d.stride, 2, 2, x264o_alpha_table[ica], x264o_beta_table[icb], ctc0, bs);
+                            }
+                        }
+                    }
+            }
+    }
+};
+
+void finish_picture(Decoder &d)
+{
+    // output (cropped I420), then make the picture a reference: half-pel planes + borders
+    int w = d.width, h = d.height;
+    std::vector<uint8_t> f((size_t)w * h * 3 / 2);
+    for (int y = 0; y < h; y++) memcpy(&f[(size_t)y * w], d.Y(d.cur) + (size_t)y * d.stride, w);
+    uint8_t *u = &f[(size_t)w * h], *v = u + (size_t)(w / 2) * (h / 2);
+    const pixel *uv = d.UV(d.cur);
+    for (int y = 0; y < h / 2; y++) for (int x = 0; x < w / 2; x++) { u[y * (w / 2) + x] = uv[(size_t)y * d.stride + 2 * x]; v[y * (w / 2) + x] = uv[(size_t)y * d.stride + 2 * x + 1]; }
+    d.frames.push_back(std::move(f));
+    pixel *planes[4] = { d.Y(d.cur, 0), d.Y(d.cur, 1), d.Y(d.cur, 2), d.Y(d.cur, 3) };
+    x264o_frame_filter(planes, d.stride, d.mbw * 16, d.mbh * 16, d.pad);
+    pixel *c = d.UV(d.cur);
+    int cw = d.mbw * 8, ch = d.mbh * 8;
+    for (int y = -d.cpad; y < ch + d.cpad; y++)
+        for (int x = -d.cpad; x < cw + d.cpad; x++)
+            if (x < 0 || x >= cw || y < 0 || y >= ch) {
+                int sx = clampi(x, 0, cw - 1), sy = clampi(y, 0, ch - 1);
+                c[(size_t)y * d.stride + 2 * x] = c[(size_t)sy * d.stride + 2 * sx];
+                c[(size_t)y * d.stride + 2 * x + 1] = c[(size_t)sy * d.stride + 2 * sx + 1];
+            }
+    d.cur ^= 1;
+}
+
+bool decode_nal(Decoder &d, const uint8_t *nal, size_t n)
+{
+    if (n < 2) return true;
+    int type = nal[0] & 31;
+    std::vector<uint8_t> rbsp;
+    for (size_t i = 1; i < n; i++) {
+        if (i >= 2 && nal[i] == 3 && nal[i - 1] == 0 && nal[i - 2] == 0) continue;   // emulation_prevention_three_byte
+        rbsp.push_back(nal[i]);
+    }
+    BitReader br{ rbsp.data(), rbsp.size() };
+    if (type == 7) {
+        int profile = (int)br.get(8); br.get(8); br.get(8); br.ue();
+        if (profile >= 100) return false;
+        d.log2_max_frame_num = (int)br.ue() + 4;
+        d.poc_type = (int)br.ue();
+        if (d.poc_type != 2) return false;
+        br.ue(); br.get1();
+        d.mbw = (int)br.ue() + 1; d.mbh = (int)br.ue() + 1;
+        if (!br.get1()) return false;                       // frame_mbs_only
+        br.get1();
+        d.crop_r = d.crop_b = 0;
+        if (br.get1()) { br.ue(); d.crop_r = 2 * (int)br.ue(); br.ue(); d.crop_b = 2 * (int)br.ue(); }
+        d.width = d.mbw * 16 - d.crop_r; d.height = d.mbh * 16 - d.crop_b;
+        d.alloc();
+        d.have_sps = !br.err;
+        return d.have_sps;
+    }
+    if (type == 8) {
+        br.ue(); br.ue();
+        if (br.get1()) return false;                        // CABAC not supported by this checker
+        br.get1(); if (br.ue()) return false;
+        d.num_ref_default = (int)br.ue() + 1; br.ue();
+        if (br.get1() || br.get(2)) return false;           // weighted prediction
+        d.pic_init_qp = 26 + br.se(); br.se();
+        d.chroma_qp_offset = br.se();
+        d.deblock_ctrl = br.get1();
+        if (br.get1()) return false;                        // constrained intra
+        br.get1();
+        d.have_pps = !br.err;
+        return d.have_pps;
+    }
+    if (type == 1 || type == 5) {
+        if (!d.have_sps || !d.have_pps) return false;
+        if (br.ue() != 0) return false;                     // first_mb_in_slice
+        int st = (int)br.ue() % 5;
+        if (st != 0 && st != 2) return false;
+        br.ue();
+        br.get(d.log2_max_frame_num);
+        if (type == 5) br.ue();
+        if (st == 0) {
+            if (br.get1()) return false;                    // num_ref_idx override
+            if (br.get1()) return false;                    // list modification
+        }
+        if ((nal[0] >> 5) & 3) { if (type == 5) { br.get1(); br.get1(); } else if (br.get1()) return false; }
+        int qp = d.pic_init_qp + br.se();
+        int disable = 0, a = 0, b = 0;
+        if (d.deblock_ctrl) { disable = (int)br.ue(); if (disable != 1) { a = 2 * br.se(); b = 2 * br.se(); } }
+        SliceDec sd{ d, br, st, qp, disable, a, b };
+        sd.run();
+        if (br.err) return false;
+        sd.deblock();
+        finish_picture(d);
+        return true;
+    }
+    return true;     // SEI, AUD, ... ignored
+}
+
+}  // namespace
+
+extern "C" {
+
+// Decodes an Annex-B stream.  Returns the number of pictures, or -1 on a syntax error / unsupported
+// feature.  Pictures are written back to back (cropped I420) into `out` if it is large enough.
+int x264o_h264_decode(const uint8_t *data, size_t n, uint8_t *out, size_t out_cap, int *width, int *height)
+{
+    Decoder d;
+    size_t i = 0;
+    auto is_start = [&](size_t k) { return k + 2 < n && data[k] == 0 && data[k + 1] == 0 && data[k + 2] == 1; };
+    while (i < n && !is_start(i)) i++;
+    while (i < n) {
+        size_t s = i + 3, e = s;
+        while (e < n && !is_start(e)) e++;
+        size_t end = e;
+        while (end > s && data[end - 1] == 0 && e < n) end--;       // trailing_zero_8bits / 4-byte start codes
+        if (!decode_nal(d, data + s, end - s)) return -1;
+        i = e;
+    }
+    if (width) *width = d.width;
+    if (height) *height = d.height;
+    size_t fsz = (size_t)d.width * d.height * 3 / 2, off = 0;
+    for (auto &f : d.frames) { if (off + fsz <= out_cap) memcpy(out + off, f.data(), fsz); off += fsz; }
+    return (int)d.frames.size();
+}
+
+}

@@ -14,7 +14,7 @@ def pytest_configure(config):
     # the oracle is test infrastructure: (re)build it on demand, it is plain C and takes seconds
     so = os.path.join(ROOT, "oracle", "liboracle.so")
     srcs = [os.path.join(ROOT, "oracle", f) for f in os.listdir(os.path.join(ROOT, "oracle"))
-            if f.endswith((".c", ".h"))]
+            if f.endswith((".c", ".h", ".cpp"))]
     if not os.path.exists(so) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in srcs):
         subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "oracle")])
 

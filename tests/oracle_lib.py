@@ -190,3 +190,20 @@ class OracleEncoder:
 
     def __del__(self):
         self.close()
+
+
+# ---- bitstream checker (oracle/h264dec.cpp) ----
+_sig("x264o_h264_decode", _i, [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.POINTER(_i), C.POINTER(_i)])
+
+
+def h264_decode(stream, max_frames, w, h):
+    """Annex-B bytes -> list of I420 frames (or raises on a syntax error / unsupported feature)"""
+    data = np.frombuffer(bytes(stream), np.uint8)
+    out = np.zeros(max_frames * w * h * 3 // 2, np.uint8)
+    ww, hh = _i(), _i()
+    n = L.x264o_h264_decode(ptr(data), len(data), ptr(out), out.nbytes, C.byref(ww), C.byref(hh))
+    if n < 0:
+        raise ValueError("bitstream rejected by the checker decoder")
+    assert (ww.value, hh.value) == (w, h), (ww.value, hh.value)
+    fs = w * h * 3 // 2
+    return [out[i * fs:(i + 1) * fs].copy() for i in range(min(n, max_frames))]

@@ -1,0 +1,108 @@
+"""-m gpu: the drop-in boundary B1 end to end — x264_param_default_preset -> x264_encoder_open ->
+x264_encoder_encode loop (the exact call sequence of codec.c:1463,1623,1693,1848-1857) on the MI355X path,
+bitstream checked by the decoder and against the bitstream the oracle's records produce."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import host_lib as HL
+import oracle_lib as O
+from synth import synth_frames
+
+pytestmark = pytest.mark.gpu
+H = HL.H
+
+
+def open_encoder(w, h, opts):
+    p = HL.Param()
+    assert H.x264_param_default_preset(C.byref(p), b"medium", None) == 0
+    p.i_width, p.i_height, p.i_csp = w, h, HL.X264_CSP_I420
+    p.i_fps_num, p.i_fps_den = 25, 1
+    p.i_log_level = -1
+    for k, v in opts.items():
+        assert H.x264_param_parse(C.byref(p), k.encode(), None if v is None else str(v).encode()) == 0, k
+    p.b_vfr_input = 0
+    p.b_annexb, p.b_repeat_headers = 1, 1                              # VfW mode (codec.c:1611-1615)
+    assert H.x264_param_apply_profile(C.byref(p), b"baseline") == 0
+    h_ = H.x264_encoder_open_157(C.byref(p))
+    assert h_, "x264_encoder_open failed"
+    eff = HL.Param()
+    H.x264_encoder_parameters(h_, C.byref(eff))
+    return h_, eff
+
+
+def encode_all(h_, w, h, frames):
+    pic, out = HL.Picture(), HL.Picture()
+    assert H.x264_picture_alloc(C.byref(pic), HL.X264_CSP_I420, w, h) == 0
+    stream, info, recons = b"", [], []
+    for i, f in enumerate(frames):
+        C.memmove(pic.img.plane[0], f.ctypes.data, f.size)              # planes are contiguous in x264_picture_alloc
+        pic.i_pts = i
+        nal, n = C.POINTER(HL.Nal)(), C.c_int()
+        size = H.x264_encoder_encode(h_, C.byref(nal), C.byref(n), C.byref(pic), C.byref(out))
+        assert size > 0
+        # all NALs of a call are contiguous from nal[0].p_payload (relied on at codec.c:1703,1719)
+        assert sum(nal[k].i_payload for k in range(n.value)) == size
+        for k in range(1, n.value):
+            assert C.addressof(nal[k].p_payload.contents) == C.addressof(nal[k - 1].p_payload.contents) + nal[k - 1].i_payload
+        stream += C.string_at(nal[0].p_payload, size)
+        info.append((out.i_type, out.b_keyframe, out.i_pts, [nal[k].i_type for k in range(n.value)]))
+        rec = np.zeros(w * h * 3 // 2, np.uint8)
+        assert H.x264host_get_recon(h_, rec.ctypes.data) == 0
+        recons.append(rec)
+    assert H.x264_encoder_delayed_frames(h_) == 0
+    assert H.x264_encoder_encode(h_, C.byref(nal), C.byref(n), None, C.byref(out)) == 0   # flush: nothing delayed
+    H.x264_picture_clean(C.byref(pic))
+    return stream, info, recons
+
+
+@pytest.mark.parametrize("w,h,opts", [(176, 144, {"qp": 26, "keyint": 4}), (352, 288, {"qp": 30, "keyint": 250}),
+                                       (208, 120, {"qp": 22, "keyint": 3, "no-deblock": None})])
+def test_encode_api_closed_loop(gpu, w, h, opts):
+    nfr = 7
+    frames = synth_frames(w, h, nfr, seed=w + 3 * h)
+    h_, eff = open_encoder(w, h, opts)
+    assert (eff.i_bframe, eff.i_frame_reference, eff.b_cabac, eff.rc.i_rc_method) == (0, 1, 0, HL.X264_RC_CQP)   # effective params
+    stream, info, recons = encode_all(h_, w, h, frames)
+    H.x264_encoder_close(h_)
+    keyint = opts["keyint"]
+    for i, (typ, key, pts, nal_types) in enumerate(info):
+        idr = i % keyint == 0
+        assert key == int(idr) and pts == i and typ == (1 if idr else 3)
+        assert nal_types[-1] == (5 if idr else 1)
+        if idr:
+            assert nal_types[:2] == [7, 8]                                # SPS/PPS before each keyframe (codec.c:1614)
+    dec = O.h264_decode(stream, nfr, w, h)
+    assert len(dec) == nfr
+    for i in range(nfr):
+        np.testing.assert_array_equal(dec[i], recons[i], err_msg=f"decoded picture {i} != encoder reconstruction")
+
+
+def test_bitstream_equals_oracle_path(gpu):
+    """same records -> same bytes: the GPU path's slice NALs equal the ones coded from the oracle's records"""
+    w, h, nfr, qp = 176, 144, 5, 27
+    frames = synth_frames(w, h, nfr, seed=99)
+    h_, eff = open_encoder(w, h, {"qp": qp, "keyint": 250})
+    stream, info, _ = encode_all(h_, w, h, frames)
+    H.x264_encoder_close(h_)
+    qp_i = max(1, int(qp - 6.0 * np.log2(1.4) + 0.5))
+    enc = O.OracleEncoder(O.default_config(w, h, qp_i=qp_i, qp_p=qp))
+    ref = b""
+    for i, f in enumerate(frames):
+        mbs, lv = enc.encode(f, 2 if i == 0 else 0)
+        ref += HL.write_slice(11, 9, 2 if i == 0 else 0, qp_i if i == 0 else qp, qp, i, 8, int(i == 0), 0, 0, mbs, lv)[0]
+    def slice_nals(b):
+        import re
+        return [n.rstrip(b"\x00") if False else n for n in re.split(b"\x00\x00\x00\x01|\x00\x00\x01", b) if n and (n[0] & 31) in (1, 5)]
+    assert slice_nals(stream) == slice_nals(ref)
+
+
+def test_headers_call(gpu):
+    h_, _ = open_encoder(64, 48, {"qp": 30})
+    nal, n = C.POINTER(HL.Nal)(), C.c_int()
+    size = H.x264_encoder_headers(h_, C.byref(nal), C.byref(n))
+    assert n.value == 3 and [nal[k].i_type for k in range(3)] == [7, 8, 6] and size == sum(nal[k].i_payload for k in range(3))
+    for k in range(3):                                                       # 4-byte prefix each (output/raw.c:41-47)
+        assert bytes(nal[k].p_payload[0:4]) == b"\x00\x00\x00\x01"
+    H.x264_encoder_close(h_)

@@ -1,0 +1,177 @@
+"""CPU: the host side of the drop-in (boundary B1) without a GPU — x264_param_* semantics as the driver uses
+them (codec.c:1463,1349,1581,1584), parameter sets, and the CAVLC entropy coder closed-loop against the
+checker decoder, fed with macroblock records from the oracle encoder."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import host_lib as HL
+import oracle_lib as O
+from synth import synth_frames
+
+H = HL.H
+
+
+def preset(name=None, tune=None):
+    p = HL.Param()
+    rc = H.x264_param_default_preset(C.byref(p), name.encode() if name else None, tune.encode() if tune else None)
+    return rc, p
+
+
+def test_defaults_are_medium():
+    """values the help text prints from x264_param_default (config.c:1544-1692)"""
+    rc, p = preset()
+    assert rc == 0
+    assert (p.i_keyint_max, p.i_scenecut_threshold, p.i_bframe, p.i_bframe_adaptive, p.i_frame_reference) == (250, 40, 3, 1, 3)
+    assert (p.b_cabac, p.b_deblocking_filter, p.analyse.i_me_method, p.analyse.i_me_range, p.analyse.i_subpel_refine) == (1, 1, 1, 16, 7)
+    assert (p.analyse.i_trellis, p.analyse.b_transform_8x8, p.analyse.i_weighted_pred, p.rc.i_lookahead) == (1, 1, 2, 40)
+    assert abs(p.rc.f_rf_constant - 23.0) < 1e-6 and p.rc.i_rc_method == HL.X264_RC_CRF and p.rc.b_mb_tree == 1
+    assert (p.analyse.i_luma_deadzone[0], p.analyse.i_luma_deadzone[1]) == (21, 11)
+
+
+def test_presets_follow_the_reference_table():
+    """config.c:1460-1498"""
+    _, u = preset("ultrafast")
+    assert (u.analyse.b_transform_8x8, u.rc.i_aq_mode, u.i_bframe, u.b_cabac, u.b_deblocking_filter, u.rc.b_mb_tree) == (0, 0, 0, 0, 0, 0)
+    assert (u.analyse.i_me_method, u.analyse.inter, u.i_frame_reference, u.analyse.i_subpel_refine, u.analyse.i_weighted_pred) == (0, 0, 1, 0, 0)
+    _, s = preset("slow")
+    assert (s.analyse.i_direct_mv_pred, s.rc.i_lookahead, s.i_frame_reference, s.analyse.i_subpel_refine, s.analyse.i_trellis) == (3, 50, 5, 8, 2)
+    _, v = preset("veryslow")
+    assert (v.i_bframe, v.analyse.i_me_method, v.analyse.i_me_range, v.i_frame_reference, v.analyse.i_subpel_refine) == (8, 2, 24, 16, 10)
+    assert preset("5")[0] == 0 and preset("nosuch")[0] < 0                 # numeric presets; unknown name -> <0 (codec.c:1463)
+    _, z = preset("medium", "zerolatency")
+    assert (z.i_bframe, z.rc.i_lookahead, z.rc.b_mb_tree) == (0, 0, 0)
+    _, f = preset(None, "fastdecode,zerolatency")                          # comma separated (codec.c:1433-1445)
+    assert (f.b_cabac, f.b_deblocking_filter, f.i_bframe) == (0, 0, 0)
+    assert preset(None, "film,grain")[0] < 0                               # one psy tuning at a time
+    assert preset(None, "nonsense")[0] < 0
+
+
+def test_param_parse_names_values_and_errors():
+    """return codes relied on at codec.c:1357-1361"""
+    _, p = preset()
+    P = lambda n, v=None: H.x264_param_parse(C.byref(p), n.encode(), v.encode() if v is not None else None)
+    assert P("ref", "5") == 0 and p.i_frame_reference == 5
+    assert P("no-cabac") == 0 and p.b_cabac == 0
+    assert P("cabac") == 0 and p.b_cabac == 1
+    assert P("qp", "30") == 0 and p.rc.i_rc_method == HL.X264_RC_CQP and p.rc.i_qp_constant == 30
+    assert P("crf", "18.5") == 0 and abs(p.rc.f_rf_constant - 18.5) < 1e-6
+    assert P("deblock", "-1:2") == 0 and (p.i_deblocking_filter_alphac0, p.i_deblocking_filter_beta) == (-1, 2)
+    assert P("no-deblock") == 0 and p.b_deblocking_filter == 0
+    assert P("me", "umh") == 0 and p.analyse.i_me_method == 2
+    assert P("partitions", "p8x8,i4x4") == 0 and p.analyse.inter == (0x10 | 0x1)
+    assert P("keyint", "infinite") == 0 and p.i_keyint_max == 1 << 30
+    assert P("fps", "30000/1001") == 0 and (p.i_fps_num, p.i_fps_den) == (30000, 1001)
+    assert P("sar", "4:3") == 0 and (p.vui.i_sar_width, p.vui.i_sar_height) == (4, 3)
+    assert P("level", "4.1") == 0 and p.i_level_idc == 41
+    assert P("psy-rd", "0.5:0.2") == 0 and abs(p.analyse.f_psy_rd - 0.5) < 1e-6
+    assert P("threads", "1") == 0 and P("cpu-independent") == 0 and P("stitchable") == 0
+    assert P("this-is-not-an-option", "1") == HL.X264_PARAM_BAD_NAME
+    assert P("ref", "abc") == HL.X264_PARAM_BAD_VALUE
+    assert P("me", "warp") == HL.X264_PARAM_BAD_VALUE
+    assert P("ref") == HL.X264_PARAM_BAD_VALUE                              # missing argument
+
+
+def test_profile_and_fastfirstpass():
+    _, p = preset()
+    assert H.x264_param_apply_profile(C.byref(p), None) == 0 and p.b_cabac == 1          # NULL = no restriction (codec.c:1584)
+    assert H.x264_param_apply_profile(C.byref(p), b"baseline") == 0
+    assert (p.b_cabac, p.i_bframe, p.analyse.b_transform_8x8, p.analyse.i_weighted_pred) == (0, 0, 0, 0)
+    assert H.x264_param_apply_profile(C.byref(p), b"nope") < 0
+    _, q = preset()
+    q.rc.b_stat_write = 1
+    H.x264_param_apply_fastfirstpass(C.byref(q))                                           # config.c:1535-1538
+    assert (q.i_frame_reference, q.analyse.b_transform_8x8, q.analyse.inter, q.analyse.i_me_method, q.analyse.i_subpel_refine, q.analyse.i_trellis) == (1, 0, 0, 0, 2, 0)
+
+
+def test_levels_table_and_picture_alloc():
+    idcs = [l.level_idc for l in HL.LEVELS]
+    assert idcs[-1] == 0 and 40 in idcs and 62 in idcs                      # 0-terminated, up to 6.2 (codec.c:87-89,1596)
+    l40 = [l for l in HL.LEVELS if l.level_idc == 40][0]
+    assert l40.dpb == 32768 and l40.frame_size == 8192                      # dpb in macroblocks, compared with mbs*refs
+    pic = HL.Picture()
+    H.x264_picture_clean(C.byref(pic))                                       # safe on a zeroed struct (codec.c:1872)
+    assert H.x264_picture_alloc(C.byref(pic), HL.X264_CSP_I420, 64, 48) == 0
+    assert pic.img.i_plane == 3 and list(pic.img.i_stride)[:3] == [64, 32, 32]
+    H.x264_picture_clean(C.byref(pic))
+    assert H.x264_picture_alloc(C.byref(pic), 0x7f, 64, 48) < 0
+
+
+def test_open_without_gpu_fails_loudly():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    _, p = preset()
+    p.i_width, p.i_height = 64, 48
+    assert not H.x264_encoder_open_157(C.byref(p))
+
+
+@pytest.mark.parametrize("w,h,kw", [(64, 48, {}), (176, 144, {}), (176, 144, dict(qp_i=36, qp_p=40)), (208, 120, dict(deblock=0)),
+                                     (96, 80, dict(qp_i=8, qp_p=10)), (64, 64, dict(partitions=0))])
+def test_cavlc_closed_loop(w, h, kw):
+    """oracle records -> host CAVLC -> checker decoder == oracle reconstruction, I and P pictures"""
+    nfr = 4
+    frames = synth_frames(w, h, nfr, seed=11 * w + h)
+    cfg = O.default_config(w, h, **kw)
+    enc = O.OracleEncoder(cfg)
+    mbw, mbh = (w + 15) // 16, (h + 15) // 16
+    stream = HL.write_headers(w, h, pic_init_qp=cfg.qp_p)
+    recons, skipped = [], 0
+    for i, f in enumerate(frames):
+        idr = i == 0
+        mbs, lv = enc.encode(f, 2 if idr else 0)
+        s, sk = HL.write_slice(mbw, mbh, 2 if idr else 0, cfg.qp_i if idr else cfg.qp_p, cfg.qp_p, i, 8, int(idr), 0,
+                               0 if cfg.deblock else 1, mbs, lv)
+        stream += s
+        skipped += sk
+        recons.append(enc.recon())
+    dec = O.h264_decode(stream, nfr, w, h)
+    assert len(dec) == nfr
+    for i in range(nfr):
+        np.testing.assert_array_equal(dec[i], recons[i], err_msg=f"picture {i}")
+
+
+def test_cavlc_static_sequence_uses_skip():
+    w, h = 96, 64
+    f = synth_frames(w, h, 1, seed=5)[0]
+    cfg = O.default_config(w, h, qp_i=20, qp_p=30)
+    enc = O.OracleEncoder(cfg)
+    mbs, lv = enc.encode(f, 2)
+    stream = HL.write_headers(w, h, pic_init_qp=30) + HL.write_slice(6, 4, 2, 20, 30, 0, 8, 1, 0, 0, mbs, lv)[0]
+    rec = enc.recon()
+    mbs, lv = enc.encode(rec, 0)
+    s, sk = HL.write_slice(6, 4, 0, 30, 30, 1, 8, 0, 0, 0, mbs, lv)
+    assert sk == 24 and len(s) < 16                                          # every macroblock is P_Skip
+    dec = O.h264_decode(stream + s, 2, w, h)
+    np.testing.assert_array_equal(dec[1], enc.recon())
+
+
+def test_cavlc_tables_are_prefix_codes():
+    """structural check of Tables 9-5/9-7/9-8/9-9/9-10 as typed in cavlc_tables.hpp"""
+    import re
+    from fractions import Fraction
+    import os
+    src = open(os.path.join(HL.ROOT, "x264vfw_amd", "host", "cavlc_tables.hpp")).read()
+
+    def arr(name):
+        body = re.search(name + r"\[[^\]]*\](?:\[[^\]]*\])?\s*=\s*\{(.*?)\};", src, re.S).group(1)
+        rows = re.findall(r"\{([^{}]*)\}", body) or [body]
+        return [[int(x) for x in r.replace("\n", " ").split(",") if x.strip()] for r in rows]
+
+    def check(lens, bits, complete):
+        codes = [format(b, "0%db" % l) for l, b in zip(lens, bits) if l > 0]
+        assert len(set(codes)) == len(codes)
+        assert not any(a != b and b.startswith(a) for a in codes for b in codes)
+        k = sum(Fraction(1, 2 ** len(c)) for c in codes)
+        assert k == 1 if complete else k < 1
+    for t in range(4):
+        check(arr("coeff_token_len")[t], arr("coeff_token_bits")[t], False)
+    check(arr("chroma_dc_coeff_token_len")[0], arr("chroma_dc_coeff_token_bits")[0], True)
+    for t in range(15):
+        check(arr("total_zeros_len")[t], arr("total_zeros_bits")[t], t > 0)
+    for t in range(3):
+        check(arr("chroma_dc_total_zeros_len")[t][:4 - t], arr("chroma_dc_total_zeros_bits")[t][:4 - t], True)
+    for t in range(7):
+        check(arr("run_before_len")[t], arr("run_before_bits")[t], t < 6)
+    assert sorted(arr("cbp_to_golomb_intra")[0]) == list(range(48)) == sorted(arr("cbp_to_golomb_inter")[0])

@@ -1,0 +1,315 @@
+// encoder.cpp — x264_encoder_* API (boundary B1) over the MI355X hot path (boundary B3, libx264gpu.so).
+//   x264_encoder_open        codec.c:1623    x264_encoder_parameters  codec.c:1630
+//   x264_encoder_headers     codec.c:1650    x264_encoder_encode      codec.c:1693
+//   x264_encoder_delayed_frames codec.c:1848 x264_encoder_close       codec.c:1857
+// Contracts kept: NULL / negative on failure, diagnostics only through pf_log, all NALs of a
+// call contiguous from nal[0].p_payload, buffers valid until the next call, param strings copied at open,
+// pic_out->{i_type,b_keyframe,i_pts,i_dts} filled.  No CPU fallback: open fails without a GPU.
+#include "host.hpp"
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <string>
+
+using namespace x264host;
+
+struct x264_t {
+    x264_param_t param;
+    std::string stat_in, stat_out;
+    x264gpu_encoder *gpu = nullptr;
+    int mbw = 0, mbh = 0, nmb = 0;
+    int qp_i = 23, qp_p = 23, pic_init_qp = 26;
+    int keyint = 250;
+    int log2_max_frame_num = 8;
+    int level_idc = 40, profile_idc = 66;
+    int frame_no = 0;            // frames submitted
+    int frames_since_idr = 0;
+    int frame_num = 0;
+    int idr_pic_id = 0;
+    int sei_sent = 0;
+    uint8_t *d_in = nullptr;
+    x264gpu_mb *d_mb = nullptr;
+    int16_t *d_lv = nullptr;
+    std::vector<uint8_t> h_in;
+    std::vector<x264gpu_mb> h_mb;
+    std::vector<int16_t> h_lv;
+    std::vector<uint8_t> out;            // bitstream of the current call
+    std::vector<x264_nal_t> nals;
+    std::vector<size_t> nal_off;
+    SliceStats last_stats = { 0 };
+};
+
+static void xlog(const x264_param_t *p, int level, const char *fmt, ...)
+{
+    if (!p->pf_log || level > p->i_log_level) return;
+    va_list ap;
+    va_start(ap, fmt);
+    p->pf_log(p->p_log_private, level, fmt, ap);
+    va_end(ap);
+}
+
+static int clampi(int v, int lo, int hi) { return v < lo ? lo : v > hi ? hi : v; }
+
+static int pick_level(const x264_param_t *p, int mbs, int refs)
+{
+    double fps = p->i_fps_den ? (double)p->i_fps_num / p->i_fps_den : 25.0;
+    for (int i = 0; x264_levels[i].level_idc; i++) {
+        const x264_level_t &l = x264_levels[i];
+        if (l.level_idc == 9) continue;
+        if (l.frame_size >= mbs && l.mbps >= (int)(mbs * fps) && l.dpb >= mbs * refs) return l.level_idc;
+    }
+    return 62;
+}
+
+static const char kSeiText[] = "x264vfw-mi355x hot path r1 - H.264/MPEG-4 AVC codec - options: cavlc ip hex subme7 ref1 cqp";
+
+static SpsParams make_sps(const x264_t *h)
+{
+    const x264_param_t &p = h->param;
+    SpsParams s = {};
+    s.profile_idc = h->profile_idc; s.level_idc = h->level_idc; s.sps_id = p.i_sps_id;
+    s.mbw = h->mbw; s.mbh = h->mbh; s.crop_right = h->mbw * 16 - p.i_width; s.crop_bottom = h->mbh * 16 - p.i_height;
+    s.num_ref_frames = 1; s.log2_max_frame_num = h->log2_max_frame_num;
+    s.sar_w = p.vui.i_sar_width; s.sar_h = p.vui.i_sar_height; s.fullrange = p.vui.b_fullrange;
+    s.colorprim = p.vui.i_colorprim; s.transfer = p.vui.i_transfer; s.colmatrix = p.vui.i_colmatrix;
+    s.overscan = p.vui.i_overscan; s.vidformat = p.vui.i_vidformat;
+    s.num_units_in_tick = p.i_timebase_num; s.time_scale = p.i_timebase_den * 2;
+    s.constraint_set0 = h->profile_idc == 66; s.constraint_set1 = h->profile_idc <= 77;
+    return s;
+}
+static PpsParams make_pps(const x264_t *h)
+{
+    PpsParams pp = { h->param.i_sps_id, h->param.i_sps_id, 0, 1, h->pic_init_qp, h->param.analyse.i_chroma_qp_offset };
+    return pp;
+}
+// appends SPS, PPS (and optionally the version SEI) to h->out, recording NAL offsets and types
+static void emit_sets(x264_t *h, std::vector<int> &types, bool sei)
+{
+    const bool annexb = h->param.b_annexb != 0;
+    h->nal_off.push_back(h->out.size()); types.push_back(7);
+    write_sps(h->out, make_sps(h), annexb);
+    h->nal_off.push_back(h->out.size()); types.push_back(8);
+    write_pps(h->out, make_pps(h), annexb);
+    if (sei) {
+        h->nal_off.push_back(h->out.size()); types.push_back(6);
+        write_sei_version(h->out, kSeiText, annexb);
+    }
+}
+
+extern "C" {
+
+x264_t *x264_encoder_open(x264_param_t *param)
+{
+    if (!param) return nullptr;
+    if (param->i_width < 16 || param->i_height < 16 || (param->i_width & 1) || (param->i_height & 1)) {
+        xlog(param, X264_LOG_ERROR, "invalid width x height (%dx%d)\n", param->i_width, param->i_height);
+        return nullptr;
+    }
+    if ((param->i_csp & X264_CSP_MASK) != X264_CSP_I420) { xlog(param, X264_LOG_ERROR, "only i420 input is supported\n"); return nullptr; }
+    if (x264gpu_device_count() < 1) { xlog(param, X264_LOG_ERROR, "no MI355X device visible (there is no CPU fallback)\n"); return nullptr; }
+    x264_t *h = new x264_t();
+    h->param = *param;
+    x264_param_t &p = h->param;
+    if (p.rc.psz_stat_in) { h->stat_in = p.rc.psz_stat_in; p.rc.psz_stat_in = &h->stat_in[0]; }     // codec.c:1386 stack buffers
+    if (p.rc.psz_stat_out) { h->stat_out = p.rc.psz_stat_out; p.rc.psz_stat_out = &h->stat_out[0]; }
+    h->mbw = (p.i_width + 15) / 16; h->mbh = (p.i_height + 15) / 16; h->nmb = h->mbw * h->mbh;
+    if (!p.i_timebase_num || !p.i_timebase_den) { p.i_timebase_num = p.i_fps_den; p.i_timebase_den = p.i_fps_num; }
+
+    // ---- effective parameters: what this round's pipeline implements (reported back via encoder_parameters) ----
+    if (p.i_bframe) { xlog(&p, X264_LOG_WARNING, "B-frames are not implemented in the MI355X path yet: bframes 0\n"); p.i_bframe = 0; }
+    if (p.i_frame_reference != 1) { xlog(&p, X264_LOG_INFO, "ref %d -> 1 (single reference this round)\n", p.i_frame_reference); p.i_frame_reference = 1; }
+    if (p.b_cabac) { xlog(&p, X264_LOG_WARNING, "CABAC is not implemented yet: using CAVLC\n"); p.b_cabac = 0; }
+    p.analyse.b_transform_8x8 = 0; p.analyse.i_weighted_pred = X264_WEIGHTP_NONE; p.analyse.b_weighted_bipred = 0;
+    p.analyse.inter &= X264_ANALYSE_I4x4; p.analyse.intra &= X264_ANALYSE_I4x4;
+    p.analyse.i_trellis = 0; p.rc.b_mb_tree = 0; p.rc.i_aq_mode = X264_AQ_NONE; p.rc.i_lookahead = 0; p.i_scenecut_threshold = 0;
+    p.analyse.i_me_method = X264_ME_HEX; p.analyse.i_me_range = clampi(p.analyse.i_me_range, 4, 16);
+    p.analyse.i_subpel_refine = clampi(p.analyse.i_subpel_refine, 0, 7);
+    p.b_interlaced = 0; p.i_slice_count = 1; p.i_threads = 1;
+    if (p.i_keyint_max <= 0) p.i_keyint_max = 1;
+    h->keyint = p.i_keyint_max;
+    // rate control: constant QP only (X264_RC_CQP, codec.c:1498-1502); CRF/ABR map to their nominal quantiser
+    int qp = p.rc.i_rc_method == X264_RC_CQP ? p.rc.i_qp_constant : p.rc.i_rc_method == X264_RC_CRF ? (int)(p.rc.f_rf_constant + 0.5f) : 26;
+    if (p.rc.i_rc_method != X264_RC_CQP) xlog(&p, X264_LOG_WARNING, "rate control other than CQP is not implemented yet: constant qp %d\n", qp);
+    if (qp < 1) { xlog(&p, X264_LOG_WARNING, "lossless is not supported: qp 1\n"); qp = 1; }
+    p.rc.i_rc_method = X264_RC_CQP; p.rc.i_qp_constant = clampi(qp, 1, 51);
+    h->qp_p = p.rc.i_qp_constant;
+    h->qp_i = clampi((int)(h->qp_p - 6.0 * log2(p.rc.f_ip_factor > 0 ? p.rc.f_ip_factor : 1.0) + 0.5), 1, 51);
+    h->pic_init_qp = clampi(h->qp_p, 0, 51);
+    h->profile_idc = 66;
+    h->level_idc = p.i_level_idc > 0 ? p.i_level_idc : pick_level(&p, h->nmb, 1);
+    p.i_level_idc = h->level_idc;
+    h->log2_max_frame_num = 4;
+    while ((1 << h->log2_max_frame_num) <= (h->keyint < 65536 ? h->keyint : 65535) && h->log2_max_frame_num < 16) h->log2_max_frame_num++;
+
+    x264gpu_config cfg = {};
+    cfg.width = p.i_width; cfg.height = p.i_height; cfg.streams = 1; cfg.refs = 1;
+    cfg.qp_i = h->qp_i; cfg.qp_p = h->qp_p; cfg.me_range = p.analyse.i_me_range; cfg.subme = p.analyse.i_subpel_refine;
+    cfg.deblock = p.b_deblocking_filter; cfg.deblock_alpha = p.i_deblocking_filter_alphac0; cfg.deblock_beta = p.i_deblocking_filter_beta;
+    cfg.chroma_qp_offset = p.analyse.i_chroma_qp_offset;
+    cfg.deadzone_inter = p.analyse.i_luma_deadzone[0]; cfg.deadzone_intra = p.analyse.i_luma_deadzone[1];
+    cfg.dct_decimate = p.analyse.b_dct_decimate;
+    cfg.partitions = (p.analyse.intra & X264_ANALYSE_I4x4) ? 2 : 0;
+    size_t insz = (size_t)p.i_width * p.i_height * 3 / 2;
+    if (x264gpu_encoder_create(&h->gpu, &cfg) != X264GPU_OK ||
+        x264gpu_malloc((void **)&h->d_in, insz) != X264GPU_OK ||
+        x264gpu_malloc((void **)&h->d_mb, (size_t)h->nmb * sizeof(x264gpu_mb)) != X264GPU_OK ||
+        x264gpu_malloc((void **)&h->d_lv, (size_t)h->nmb * X264GPU_MB_LEVELS * sizeof(int16_t)) != X264GPU_OK) {
+        xlog(&p, X264_LOG_ERROR, "GPU encoder setup failed: %s\n", x264gpu_last_error());
+        x264_encoder_close(h);
+        return nullptr;
+    }
+    h->h_in.resize(insz); h->h_mb.resize(h->nmb); h->h_lv.resize((size_t)h->nmb * X264GPU_MB_LEVELS);
+    xlog(&p, X264_LOG_INFO, "MI355X hot path: %dx%d, %d MBs, CQP I:%d P:%d, keyint %d, level %d\n", p.i_width, p.i_height, h->nmb,
+         h->qp_i, h->qp_p, h->keyint, h->level_idc);
+    return h;
+}
+
+void x264_encoder_parameters(x264_t *h, x264_param_t *param) { if (h && param) *param = h->param; }
+
+static void publish_nals(x264_t *h, x264_nal_t **pp_nal, int *pi_nal, const std::vector<int> &types)
+{
+    h->nals.resize(h->nal_off.size());
+    for (size_t i = 0; i < h->nal_off.size(); i++) {
+        x264_nal_t &n = h->nals[i];
+        memset(&n, 0, sizeof(n));
+        size_t end = i + 1 < h->nal_off.size() ? h->nal_off[i + 1] : h->out.size();
+        n.p_payload = h->out.data() + h->nal_off[i];
+        n.i_payload = (int)(end - h->nal_off[i]);
+        n.i_type = types[i];
+        n.i_ref_idc = types[i] == 6 ? 0 : types[i] == 1 ? 2 : 3;
+        n.b_long_startcode = 1;
+    }
+    *pp_nal = h->nals.data();
+    *pi_nal = (int)h->nals.size();
+}
+
+int x264_encoder_headers(x264_t *h, x264_nal_t **pp_nal, int *pi_nal)
+{
+    if (!h || !pp_nal || !pi_nal) return -1;
+    h->out.clear(); h->nal_off.clear();
+    std::vector<int> types;
+    emit_sets(h, types, true);               // nal[0]=SPS nal[1]=PPS nal[2]=SEI (output/raw.c:41-47)
+    publish_nals(h, pp_nal, pi_nal, types);
+    return (int)h->out.size();
+}
+
+int x264_encoder_encode(x264_t *h, x264_nal_t **pp_nal, int *pi_nal, x264_picture_t *pic_in, x264_picture_t *pic_out)
+{
+    if (!h || !pp_nal || !pi_nal) return -1;
+    *pi_nal = 0; *pp_nal = nullptr;
+    if (!pic_in) return 0;                       // flush: nothing is ever delayed (no B-frames, no lookahead)
+    const x264_param_t &p = h->param;
+    const int w = p.i_width, ht = p.i_height;
+    if ((pic_in->img.i_csp & X264_CSP_MASK) != X264_CSP_I420 || pic_in->img.i_plane < 3) {
+        xlog(&p, X264_LOG_ERROR, "x264_encoder_encode: input picture must be I420\n");
+        return -1;
+    }
+    // ---- frame copy-in: three strided planes -> one tightly packed I420 buffer -> HBM (replaces x264_frame_copy_picture) ----
+    uint8_t *dst = h->h_in.data();
+    for (int pl = 0; pl < 3; pl++) {
+        int pw = pl ? w / 2 : w, ph = pl ? ht / 2 : ht;
+        const uint8_t *src = pic_in->img.plane[pl];
+        for (int y = 0; y < ph; y++, dst += pw, src += pic_in->img.i_stride[pl]) memcpy(dst, src, pw);
+    }
+    bool idr = h->frames_since_idr == 0 || h->frames_since_idr >= h->keyint || pic_in->i_type == X264_TYPE_IDR || pic_in->i_type == X264_TYPE_KEYFRAME;
+    if (idr) { h->frames_since_idr = 0; h->frame_num = 0; }
+    int st = idr ? X264GPU_SLICE_I : X264GPU_SLICE_P;
+    if (x264gpu_memcpy_h2d(h->d_in, h->h_in.data(), h->h_in.size(), nullptr) != X264GPU_OK ||
+        x264gpu_encode_frames(h->gpu, h->d_in, st, h->d_mb, h->d_lv, nullptr) != X264GPU_OK ||
+        x264gpu_memcpy_d2h(h->h_mb.data(), h->d_mb, h->h_mb.size() * sizeof(x264gpu_mb), nullptr) != X264GPU_OK ||
+        x264gpu_memcpy_d2h(h->h_lv.data(), h->d_lv, h->h_lv.size() * sizeof(int16_t), nullptr) != X264GPU_OK) {
+        xlog(&p, X264_LOG_ERROR, "x264_encoder_encode: GPU hot path failed: %s\n", x264gpu_last_error());
+        return -1;
+    }
+    // ---- host: headers + entropy coding ----
+    h->out.clear(); h->nal_off.clear();
+    std::vector<int> types;
+    if (idr && p.b_repeat_headers) {
+        emit_sets(h, types, !h->sei_sent);
+        h->sei_sent = 1;
+    }
+    SliceParams sp = {};
+    sp.mbw = h->mbw; sp.mbh = h->mbh; sp.slice_type = st; sp.qp = idr ? h->qp_i : h->qp_p; sp.pic_init_qp = h->pic_init_qp;
+    sp.frame_num = h->frame_num; sp.log2_max_frame_num = h->log2_max_frame_num;
+    sp.idr = idr; sp.idr_pic_id = h->idr_pic_id; sp.nal_ref_idc = idr ? 3 : 2; sp.pps_id = p.i_sps_id; sp.num_ref = 1;
+    sp.disable_deblock_idc = p.b_deblocking_filter ? 0 : 1;
+    sp.alpha_off_div2 = p.i_deblocking_filter_alphac0; sp.beta_off_div2 = p.i_deblocking_filter_beta;
+    h->nal_off.push_back(h->out.size()); types.push_back(idr ? 5 : 1);
+    h->last_stats.skip = 0;
+    write_slice(h->out, sp, h->h_mb.data(), h->h_lv.data(), p.b_annexb != 0, h->nal_off.size() == 1, &h->last_stats);
+    publish_nals(h, pp_nal, pi_nal, types);
+    if (pic_out) {
+        x264_picture_init(pic_out);
+        pic_out->i_type = idr ? X264_TYPE_IDR : X264_TYPE_P;
+        pic_out->b_keyframe = idr;
+        pic_out->i_pts = pic_in->i_pts; pic_out->i_dts = pic_in->i_pts;
+        pic_out->img = pic_in->img;
+    }
+    if (idr) h->idr_pic_id = (h->idr_pic_id + 1) & 0xffff;
+    h->frame_num = (h->frame_num + 1) & ((1 << h->log2_max_frame_num) - 1);
+    h->frames_since_idr++;
+    h->frame_no++;
+    return (int)h->out.size();
+}
+
+int x264_encoder_delayed_frames(x264_t *h) { (void)h; return 0; }
+
+void x264_encoder_close(x264_t *h)
+{
+    if (!h) return;
+    if (h->gpu) x264gpu_encoder_destroy(h->gpu);
+    if (h->d_in) x264gpu_free(h->d_in);
+    if (h->d_mb) x264gpu_free(h->d_mb);
+    if (h->d_lv) x264gpu_free(h->d_lv);
+    delete h;
+}
+
+/* test/diagnostic hooks (not part of the x264 API): entropy-code caller-supplied records, fetch the GPU recon */
+int x264host_write_slice(int mbw, int mbh, int slice_type, int qp, int pic_init_qp, int frame_num, int log2_max_frame_num,
+                         int idr, int idr_pic_id, int disable_deblock_idc, const x264gpu_mb *mbs, const int16_t *levels,
+                         uint8_t *out, int cap, int *skipped)
+{
+    SliceParams sp = {};
+    sp.mbw = mbw; sp.mbh = mbh; sp.slice_type = slice_type; sp.qp = qp; sp.pic_init_qp = pic_init_qp; sp.frame_num = frame_num;
+    sp.log2_max_frame_num = log2_max_frame_num; sp.idr = idr; sp.idr_pic_id = idr_pic_id; sp.nal_ref_idc = idr ? 3 : 2; sp.num_ref = 1;
+    sp.disable_deblock_idc = disable_deblock_idc;
+    std::vector<uint8_t> v;
+    SliceStats stt = { 0 };
+    write_slice(v, sp, mbs, levels, true, true, &stt);
+    if (skipped) *skipped = stt.skip;
+    if ((int)v.size() > cap) return -1;
+    memcpy(out, v.data(), v.size());
+    return (int)v.size();
+}
+
+int x264host_write_headers(int width, int height, int level_idc, int log2_max_frame_num, int pic_init_qp, int chroma_qp_offset,
+                           uint32_t num_units_in_tick, uint32_t time_scale, uint8_t *out, int cap)
+{
+    SpsParams s = {};
+    s.profile_idc = 66; s.level_idc = level_idc; s.mbw = (width + 15) / 16; s.mbh = (height + 15) / 16;
+    s.crop_right = s.mbw * 16 - width; s.crop_bottom = s.mbh * 16 - height; s.num_ref_frames = 1; s.log2_max_frame_num = log2_max_frame_num;
+    s.fullrange = 0; s.colorprim = 2; s.transfer = 2; s.colmatrix = 2; s.vidformat = 5;
+    s.num_units_in_tick = num_units_in_tick; s.time_scale = time_scale; s.constraint_set0 = 1; s.constraint_set1 = 1;
+    std::vector<uint8_t> v;
+    write_sps(v, s, true);
+    PpsParams pp = { 0, 0, 0, 1, pic_init_qp, chroma_qp_offset };
+    write_pps(v, pp, true);
+    if ((int)v.size() > cap) return -1;
+    memcpy(out, v.data(), v.size());
+    return (int)v.size();
+}
+
+int x264host_get_recon(x264_t *h, uint8_t *i420_out)
+{
+    if (!h || !h->gpu) return -1;
+    size_t n = (size_t)h->param.i_width * h->param.i_height * 3 / 2;
+    uint8_t *d = nullptr;
+    if (x264gpu_malloc((void **)&d, n) != X264GPU_OK) return -1;
+    int rc = x264gpu_encoder_get_recon(h->gpu, 0, d, nullptr);
+    if (rc == X264GPU_OK) rc = x264gpu_memcpy_d2h(i420_out, d, n, nullptr);
+    x264gpu_free(d);
+    return rc;
+}
+
+}  /* extern "C" */

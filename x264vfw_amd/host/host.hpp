@@ -1,0 +1,39 @@
+// host.hpp — internal declarations of the host-side encoder shell (boundary B1 behind include/x264.h).
+#pragma once
+#include "../../include/x264.h"
+#include "../../include/x264gpu.h"
+#include "bitstream.hpp"
+#include <vector>
+
+namespace x264host {
+
+struct SliceParams {
+    int mbw, mbh;
+    int slice_type;          // X264GPU_SLICE_I / _P
+    int qp, pic_init_qp;
+    int frame_num, log2_max_frame_num;
+    int idr, idr_pic_id, nal_ref_idc;
+    int pps_id;
+    int num_ref;
+    int disable_deblock_idc, alpha_off_div2, beta_off_div2;
+};
+struct SliceStats { int skip; };
+
+struct SpsParams {
+    int profile_idc, level_idc, sps_id;
+    int mbw, mbh, crop_right, crop_bottom;       // crop in luma samples
+    int num_ref_frames, log2_max_frame_num;
+    int sar_w, sar_h, fullrange, colorprim, transfer, colmatrix, overscan, vidformat;
+    uint32_t num_units_in_tick, time_scale;
+    int constraint_set0, constraint_set1;
+};
+struct PpsParams { int pps_id, sps_id, cabac, num_ref, pic_init_qp, chroma_qp_offset; };
+
+void write_sps(std::vector<uint8_t> &out, const SpsParams &s, bool annexb);
+void write_pps(std::vector<uint8_t> &out, const PpsParams &p, bool annexb);
+void write_sei_version(std::vector<uint8_t> &out, const char *text, bool annexb);
+void write_slice_header(BitWriter &bw, const SliceParams &p);
+void write_slice(std::vector<uint8_t> &out, const SliceParams &p, const x264gpu_mb *mbs, const int16_t *levels,
+                 bool annexb, bool long_startcode, SliceStats *stats);
+
+}  // namespace x264host

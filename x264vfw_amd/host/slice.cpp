@@ -1,0 +1,270 @@
+// slice.cpp — host-side entropy coding of one slice from the GPU's macroblock records + levels
+// (north star: "CABAC/entropy left on the host").  CAVLC (ITU-T H.264 7.3.4, 7.3.5, 9.2); plays the role
+// of [x264-upstream] encoder/cavlc.c + the slice header of encoder/encoder.c behind x264_encoder_encode
+// (reference call site codec.c:1693).  Motion-vector differences and P_Skip are derived here from the
+// true H.264 predictors (8.4.1.1, 8.4.1.3), because the GPU analysis ran without raster-order neighbours.
+#include "host.hpp"
+#include "cavlc_tables.hpp"
+#include <stdlib.h>
+
+namespace x264host {
+
+namespace {
+
+const uint8_t kBlkX[16] = { 0, 1, 0, 1, 2, 3, 2, 3, 0, 1, 0, 1, 2, 3, 2, 3 };
+const uint8_t kBlkY[16] = { 0, 0, 1, 1, 0, 0, 1, 1, 2, 2, 3, 3, 2, 2, 3, 3 };
+const uint8_t kIdxOf[4][4] = { { 0, 1, 4, 5 }, { 2, 3, 6, 7 }, { 8, 9, 12, 13 }, { 10, 11, 14, 15 } };  // [by][bx]
+
+inline bool is_intra(const x264gpu_mb &m) { return m.type == X264GPU_MB_I4x4 || m.type == X264GPU_MB_I16x16; }
+
+struct SliceCtx {
+    const SliceParams &p;
+    const x264gpu_mb *mbs;
+    const int16_t *levels;
+    BitWriter &bw;
+    std::vector<uint8_t> tc;      // total_coeff per block: [mb][24] (16 luma by block index, 4 U, 4 V); skip/absent = 0
+    std::vector<uint8_t> coded;   // 1 once the macroblock has been written (availability inside the slice)
+    std::vector<uint8_t> skipped;
+    SliceStats *stats;
+
+    int mbw() const { return p.mbw; }
+
+    // ---- nC for coeff_token (9.2.1): average of left (A) and top (B) block totals ----
+    int nc_luma(int mbx, int mby, int blk) const
+    {
+        int bx = kBlkX[blk], by = kBlkY[blk], na = -1, nb = -1;
+        if (bx > 0) na = tc[(size_t)(mby * mbw() + mbx) * 24 + kIdxOf[by][bx - 1]];
+        else if (mbx > 0) na = tc[(size_t)(mby * mbw() + mbx - 1) * 24 + kIdxOf[by][3]];
+        if (by > 0) nb = tc[(size_t)(mby * mbw() + mbx) * 24 + kIdxOf[by - 1][bx]];
+        else if (mby > 0) nb = tc[(size_t)((mby - 1) * mbw() + mbx) * 24 + kIdxOf[3][bx]];
+        if (na >= 0 && nb >= 0) return (na + nb + 1) >> 1;
+        return na >= 0 ? na : nb >= 0 ? nb : 0;
+    }
+    int nc_chroma(int mbx, int mby, int c, int i) const
+    {
+        int bx = i & 1, by = i >> 1, na = -1, nb = -1, base = 16 + c * 4;
+        if (bx > 0) na = tc[(size_t)(mby * mbw() + mbx) * 24 + base + by * 2];
+        else if (mbx > 0) na = tc[(size_t)(mby * mbw() + mbx - 1) * 24 + base + by * 2 + 1];
+        if (by > 0) nb = tc[(size_t)(mby * mbw() + mbx) * 24 + base + bx];
+        else if (mby > 0) nb = tc[(size_t)((mby - 1) * mbw() + mbx) * 24 + base + 2 + bx];
+        if (na >= 0 && nb >= 0) return (na + nb + 1) >> 1;
+        return na >= 0 ? na : nb >= 0 ? nb : 0;
+    }
+
+    // ---- residual_block_cavlc (7.3.5.3.2 / 9.2): l[0..n-1] in scan order; nC = -1 selects chroma DC ----
+    int residual_block(const int16_t *l, int n, int nC)
+    {
+        int idx[16], total = 0;
+        for (int i = 0; i < n; i++) if (l[i]) idx[total++] = i;      // ascending frequency
+        int t1 = 0;
+        for (int k = total - 1; k >= 0 && t1 < 3; k--) { if (abs(l[idx[k]]) == 1) t1++; else break; }
+        if (nC < 0) bw.put(chroma_dc_coeff_token_bits[4 * total + t1], chroma_dc_coeff_token_len[4 * total + t1]);
+        else {
+            int tab = nC < 2 ? 0 : nC < 4 ? 1 : nC < 8 ? 2 : 3;
+            bw.put(coeff_token_bits[tab][4 * total + t1], coeff_token_len[tab][4 * total + t1]);
+        }
+        if (!total) return 0;
+        for (int k = 0; k < t1; k++) bw.put1(l[idx[total - 1 - k]] < 0);
+        int suffix_len = total > 10 && t1 < 3 ? 1 : 0;
+        for (int k = total - 1 - t1; k >= 0; k--) {
+            int level = l[idx[k]];
+            int code = level > 0 ? 2 * level - 2 : -2 * level - 1;          // levelCode (9.2.2.1)
+            if (k == total - 1 - t1 && t1 < 3) code -= 2;
+            write_level(code, suffix_len);
+            if (suffix_len == 0) suffix_len = 1;
+            if (abs(level) > (3 << (suffix_len - 1)) && suffix_len < 6) suffix_len++;
+        }
+        if (total < n) {
+            int zeros = idx[total - 1] + 1 - total;                         // total_zeros
+            if (nC < 0) bw.put(chroma_dc_total_zeros_bits[total - 1][zeros], chroma_dc_total_zeros_len[total - 1][zeros]);
+            else bw.put(total_zeros_bits[total - 1][zeros], total_zeros_len[total - 1][zeros]);
+            int left = zeros;
+            for (int k = total - 1; k > 0 && left > 0; k--) {
+                int run = idx[k] - idx[k - 1] - 1;
+                int t = (left < 7 ? left : 7) - 1;
+                bw.put(run_before_bits[t][run], run_before_len[t][run]);
+                left -= run;
+            }
+        }
+        return total;
+    }
+    void write_level(int code, int suffix_len)
+    {
+        // level_prefix / level_suffix (9.2.2.1), including the escape forms
+        if (suffix_len == 0) {
+            if (code < 14) { bw.put(1, code + 1); return; }
+            if (code < 30) { bw.put(1, 15); bw.put((uint32_t)(code - 14), 4); return; }
+            code -= 30;                       // prefix 15: levelCode = 30 + suffix (12 bits)
+        } else {
+            if ((code >> suffix_len) < 15) { bw.put(1, (code >> suffix_len) + 1); bw.put((uint32_t)(code & ((1 << suffix_len) - 1)), suffix_len); return; }
+            code -= 15 << suffix_len;         // prefix 15: 12-bit suffix
+        }
+        if (code < 4096) { bw.put(1, 16); bw.put((uint32_t)code, 12); return; }
+        // prefix >= 16 (only reachable at very low QP): suffix size prefix-3, offset (1<<(prefix-3)) - 4096
+        code -= 4096;
+        int prefix = 16;
+        while (code >= (1 << (prefix - 3))) { code -= 1 << (prefix - 3); prefix++; }
+        bw.put(0, prefix); bw.put1(1);
+        bw.put((uint32_t)code, prefix - 3);
+    }
+
+    // ---- motion vector prediction (8.4.1.3) for a 16x16 partition with refIdx 0 ----
+    struct Nb { bool avail; int ref; int mvx, mvy; };
+    Nb neighbour(int mbx, int mby) const
+    {
+        Nb n = { false, -1, 0, 0 };
+        if (mbx < 0 || mby < 0 || mbx >= p.mbw || mby >= p.mbh) return n;
+        int i = mby * p.mbw + mbx;
+        if (!coded[i]) return n;
+        n.avail = true;
+        const x264gpu_mb &m = mbs[i];
+        if (!is_intra(m)) { n.ref = m.ref[0]; n.mvx = m.mv[0][0]; n.mvy = m.mv[0][1]; }
+        return n;
+    }
+    void mvp16x16(int mbx, int mby, int ref, int &px, int &py) const
+    {
+        Nb a = neighbour(mbx - 1, mby), b = neighbour(mbx, mby - 1), c = neighbour(mbx + 1, mby - 1);
+        if (!c.avail) c = neighbour(mbx - 1, mby - 1);
+        if (!b.avail && !c.avail && a.avail) { b = a; c = a; }
+        int na = a.ref == ref, nb = b.ref == ref, nc = c.ref == ref;
+        if (na + nb + nc == 1) {
+            const Nb &s = na ? a : nb ? b : c;
+            px = s.mvx; py = s.mvy;
+            return;
+        }
+        auto med = [](int x, int y, int z) { int mn = x < y ? x : y, mx = x < y ? y : x; return z < mn ? mn : z > mx ? mx : z; };
+        px = med(a.mvx, b.mvx, c.mvx); py = med(a.mvy, b.mvy, c.mvy);
+    }
+    void pskip_mv(int mbx, int mby, int &px, int &py) const
+    {
+        Nb a = neighbour(mbx - 1, mby), b = neighbour(mbx, mby - 1);
+        if (!a.avail || !b.avail || (a.ref == 0 && a.mvx == 0 && a.mvy == 0) || (b.ref == 0 && b.mvx == 0 && b.mvy == 0)) { px = py = 0; return; }
+        mvp16x16(mbx, mby, 0, px, py);
+    }
+
+    // predicted intra 4x4 mode (8.3.1.1)
+    int pred_i4_mode(int mbx, int mby, int blk) const
+    {
+        int bx = kBlkX[blk], by = kBlkY[blk], ma, mb;
+        const x264gpu_mb &cur = mbs[mby * p.mbw + mbx];
+        if (bx > 0) ma = cur.i4_mode[kIdxOf[by][bx - 1]];
+        else if (mbx > 0) { const x264gpu_mb &n = mbs[mby * p.mbw + mbx - 1]; ma = n.type == X264GPU_MB_I4x4 ? n.i4_mode[kIdxOf[by][3]] : 2; }
+        else return 2;
+        if (by > 0) mb = cur.i4_mode[kIdxOf[by - 1][bx]];
+        else if (mby > 0) { const x264gpu_mb &n = mbs[(mby - 1) * p.mbw + mbx]; mb = n.type == X264GPU_MB_I4x4 ? n.i4_mode[kIdxOf[3][bx]] : 2; }
+        else return 2;
+        return ma < mb ? ma : mb;
+    }
+
+    void write_residual(int mbx, int mby, const x264gpu_mb &m, const int16_t *lv)
+    {
+        uint8_t *t = &tc[(size_t)(mby * p.mbw + mbx) * 24];
+        if (m.type == X264GPU_MB_I16x16) residual_block(lv + X264GPU_LV_LUMA_DC, 16, nc_luma(mbx, mby, 0));
+        for (int i8 = 0; i8 < 4; i8++) {
+            if (!(m.cbp_luma >> i8 & 1)) continue;
+            for (int k = 0; k < 4; k++) {
+                int b = i8 * 4 + k;
+                if (m.type == X264GPU_MB_I16x16) t[b] = (uint8_t)residual_block(lv + b * 16 + 1, 15, nc_luma(mbx, mby, b));
+                else t[b] = (uint8_t)residual_block(lv + b * 16, 16, nc_luma(mbx, mby, b));
+            }
+        }
+        if (m.cbp_chroma) {
+            for (int c = 0; c < 2; c++) residual_block(lv + X264GPU_LV_CHROMA_DC + c * 4, 4, -1);
+            if (m.cbp_chroma == 2)
+                for (int c = 0; c < 2; c++)
+                    for (int i = 0; i < 4; i++)
+                        t[16 + c * 4 + i] = (uint8_t)residual_block(lv + X264GPU_LV_CHROMA_AC + (c * 4 + i) * 16 + 1, 15, nc_chroma(mbx, mby, c, i));
+        }
+    }
+
+    void write_mb_intra(int mbx, int mby, const x264gpu_mb &m, const int16_t *lv, int type_offset)
+    {
+        if (m.type == X264GPU_MB_I4x4) {
+            bw.ue(type_offset + 0);
+            for (int b = 0; b < 16; b++) {
+                int pm = pred_i4_mode(mbx, mby, b), mode = m.i4_mode[b];
+                if (mode == pm) bw.put1(1);
+                else { bw.put1(0); bw.put((uint32_t)(mode < pm ? mode : mode - 1), 3); }
+            }
+            bw.ue(m.chroma_mode);
+            bw.ue(cbp_to_golomb_intra[m.cbp_luma | (m.cbp_chroma << 4)]);
+            if (m.cbp_luma || m.cbp_chroma) bw.se(0);            // mb_qp_delta (constant QP)
+        } else {
+            bw.ue(type_offset + 1 + m.i16_mode + 4 * m.cbp_chroma + (m.cbp_luma ? 12 : 0));
+            bw.ue(m.chroma_mode);
+            bw.se(0);                                            // mb_qp_delta always present for Intra16x16
+        }
+        write_residual(mbx, mby, m, lv);
+    }
+
+    void run()
+    {
+        int skip_run = 0;
+        for (int mby = 0; mby < p.mbh; mby++)
+            for (int mbx = 0; mbx < p.mbw; mbx++) {
+                int i = mby * p.mbw + mbx;
+                const x264gpu_mb &m = mbs[i];
+                const int16_t *lv = levels + (size_t)i * X264GPU_MB_LEVELS;
+                if (p.slice_type == X264GPU_SLICE_I) write_mb_intra(mbx, mby, m, lv, 0);
+                else if (is_intra(m)) { bw.ue(skip_run); skip_run = 0; write_mb_intra(mbx, mby, m, lv, 5); }
+                else {
+                    int px, py;
+                    bool skip = false;
+                    if (m.partition == 0 && m.ref[0] == 0 && !m.cbp_luma && !m.cbp_chroma) {
+                        pskip_mv(mbx, mby, px, py);
+                        skip = px == m.mv[0][0] && py == m.mv[0][1];
+                    }
+                    if (skip) { skip_run++; skipped[i] = 1; if (stats) stats->skip++; }
+                    else {
+                        bw.ue(skip_run); skip_run = 0;
+                        bw.ue(0);                                            // P_L0_16x16
+                        if (p.num_ref > 1) bw.te(p.num_ref - 1, m.ref[0]);
+                        mvp16x16(mbx, mby, m.ref[0], px, py);
+                        bw.se(m.mv[0][0] - px); bw.se(m.mv[0][1] - py);
+                        bw.ue(cbp_to_golomb_inter[m.cbp_luma | (m.cbp_chroma << 4)]);
+                        if (m.cbp_luma || m.cbp_chroma) bw.se(0);
+                        write_residual(mbx, mby, m, lv);
+                    }
+                }
+                coded[i] = 1;
+            }
+        if (skip_run) bw.ue(skip_run);
+    }
+};
+
+}  // namespace
+
+void write_slice_header(BitWriter &bw, const SliceParams &p)
+{
+    bw.ue(0);                                                   // first_mb_in_slice
+    bw.ue((p.slice_type == X264GPU_SLICE_I ? 2 : 0) + 5);       // slice_type (+5: all slices of the picture alike)
+    bw.ue(p.pps_id);
+    bw.put((uint32_t)p.frame_num & ((1u << p.log2_max_frame_num) - 1), p.log2_max_frame_num);
+    if (p.idr) bw.ue(p.idr_pic_id);
+    // pic_order_cnt_type 2: nothing to send
+    if (p.slice_type != X264GPU_SLICE_I) {
+        bw.put1(0);                                             // num_ref_idx_active_override_flag
+        bw.put1(0);                                             // ref_pic_list_modification_flag_l0
+    }
+    if (p.nal_ref_idc) {
+        if (p.idr) { bw.put1(0); bw.put1(0); }                  // no_output_of_prior_pics, long_term_reference
+        else bw.put1(0);                                        // adaptive_ref_pic_marking_mode_flag
+    }
+    bw.se(p.qp - p.pic_init_qp);                                // slice_qp_delta
+    bw.ue(p.disable_deblock_idc);
+    if (p.disable_deblock_idc != 1) { bw.se(p.alpha_off_div2); bw.se(p.beta_off_div2); }
+}
+
+void write_slice(std::vector<uint8_t> &out, const SliceParams &p, const x264gpu_mb *mbs, const int16_t *levels,
+                 bool annexb, bool long_startcode, SliceStats *stats)
+{
+    BitWriter bw;
+    write_slice_header(bw, p);
+    size_t n = (size_t)p.mbw * p.mbh;
+    SliceCtx ctx{ p, mbs, levels, bw, std::vector<uint8_t>(n * 24, 0), std::vector<uint8_t>(n, 0), std::vector<uint8_t>(n, 0), stats };
+    ctx.run();
+    bw.trailing();
+    append_nal(out, p.nal_ref_idc, p.idr ? 5 : 1, bw.bytes(), annexb, long_startcode);
+}
+
+}  // namespace x264host
