@@ -112,3 +112,75 @@ def write_slice(mbw, mbh, slice_type, qp, pic_init_qp, frame_num, log2_max_frame
                                disable_deblock, mbs.ctypes.data, lv.ctypes.data, buf.ctypes.data, buf.size, C.byref(sk))
     assert n > 0
     return bytes(buf[:n]), sk.value
+
+
+# ---- boundary B2: VfW driver shell (include/vfw_shim.h) ----
+DWORD, LONG, WORD = C.c_uint32, C.c_int32, C.c_uint16
+
+
+class BITMAPINFOHEADER(C.Structure):
+    _fields_ = [("biSize", DWORD), ("biWidth", LONG), ("biHeight", LONG), ("biPlanes", WORD), ("biBitCount", WORD),
+                ("biCompression", DWORD), ("biSizeImage", DWORD), ("biXPelsPerMeter", LONG), ("biYPelsPerMeter", LONG),
+                ("biClrUsed", DWORD), ("biClrImportant", DWORD)]
+
+
+class BITMAPINFO(C.Structure):
+    _fields_ = [("bmiHeader", BITMAPINFOHEADER), ("bmiColors", DWORD * 1)]
+
+
+class ICOPEN(C.Structure):
+    _fields_ = [("dwSize", DWORD), ("fccType", DWORD), ("fccHandler", DWORD), ("dwVersion", DWORD), ("dwFlags", DWORD),
+                ("dwError", C.c_ssize_t), ("pV1Reserved", C.c_void_p), ("pV2Reserved", C.c_void_p), ("dnDevNode", DWORD)]
+
+
+class ICINFO(C.Structure):
+    _fields_ = [("dwSize", DWORD), ("fccType", DWORD), ("fccHandler", DWORD), ("dwFlags", DWORD), ("dwVersion", DWORD),
+                ("dwVersionICM", DWORD), ("szName", C.c_uint16 * 16), ("szDescription", C.c_uint16 * 128), ("szDriver", C.c_uint16 * 128)]
+
+
+class ICCOMPRESS(C.Structure):
+    _fields_ = [("dwFlags", DWORD), ("lpbiOutput", C.POINTER(BITMAPINFOHEADER)), ("lpOutput", C.c_void_p),
+                ("lpbiInput", C.POINTER(BITMAPINFOHEADER)), ("lpInput", C.c_void_p), ("lpckid", C.POINTER(DWORD)),
+                ("lpdwFlags", C.POINTER(DWORD)), ("lFrameNum", LONG), ("dwFrameSize", DWORD), ("dwQuality", DWORD),
+                ("lpbiPrev", C.POINTER(BITMAPINFOHEADER)), ("lpPrev", C.c_void_p)]
+
+
+class ICCOMPRESSFRAMES(C.Structure):
+    _fields_ = [("dwFlags", DWORD), ("lpbiOutput", C.POINTER(BITMAPINFOHEADER)), ("lOutput", C.c_ssize_t),
+                ("lpbiInput", C.POINTER(BITMAPINFOHEADER)), ("lInput", C.c_ssize_t), ("lStartFrame", LONG), ("lFrameCount", LONG),
+                ("lQuality", LONG), ("lDataRate", LONG), ("lKeyRate", LONG), ("dwRate", DWORD), ("dwScale", DWORD),
+                ("dwOverheadPerFrame", DWORD), ("dwReserved2", DWORD), ("GetData", C.c_void_p), ("PutData", C.c_void_p)]
+
+
+class VfwConfig(C.Structure):
+    _fields_ = [(n, _i) for n in ("i_format_version", "i_preset", "i_tuning", "i_profile", "i_level", "b_fastdecode", "b_zerolatency",
+                                  "i_encoding_type", "i_qp", "i_rf_constant", "i_passbitrate", "i_pass", "i_fourcc", "i_log_level",
+                                  "b_psnr", "b_ssim", "b_no_asm", "i_sar_width", "i_sar_height")] + [("extra_cmdline", C.c_char * 4096)]
+
+
+_sig("DriverProc", C.c_ssize_t, [C.c_size_t, C.c_void_p, C.c_uint, C.c_ssize_t, C.c_ssize_t])
+_sig("x264vfw_shim_log", C.c_char_p, [C.c_size_t])
+
+
+def fourcc(s):
+    return s[0] | (s[1] << 8) | (s[2] << 16) | (s[3] << 24)
+
+
+DRV_LOAD, DRV_OPEN, DRV_CLOSE, DRV_FREE, DRV_CONFIGURE, DRV_QUERYCONFIGURE, DRV_USER = 1, 3, 4, 6, 7, 8, 0x4000
+ICM_GETSTATE, ICM_SETSTATE, ICM_GETINFO = 0x5000, 0x5001, 0x5002
+ICM_COMPRESS_GET_FORMAT, ICM_COMPRESS_GET_SIZE, ICM_COMPRESS_QUERY, ICM_COMPRESS_BEGIN, ICM_COMPRESS, ICM_COMPRESS_END = (
+    0x4004, 0x4005, 0x4006, 0x4007, 0x4008, 0x4009)
+ICM_DECOMPRESS_QUERY, ICM_COMPRESS_FRAMES_INFO = 0x400b, 0x4046
+ICERR_OK, ICERR_UNSUPPORTED, ICERR_BADFORMAT, ICERR_BADSIZE, ICERR_ERROR = 0, -1, -2, -7, -100
+AVIIF_KEYFRAME = 0x10
+
+
+def addr(x):
+    return C.addressof(x)
+
+
+def bmi(w, h, four, bits=12):
+    b = BITMAPINFO()
+    b.bmiHeader.biSize, b.bmiHeader.biWidth, b.bmiHeader.biHeight = C.sizeof(BITMAPINFOHEADER), w, h
+    b.bmiHeader.biPlanes, b.bmiHeader.biBitCount, b.bmiHeader.biCompression = 1, bits, fourcc(four)
+    return b

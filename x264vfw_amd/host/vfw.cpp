@@ -1,0 +1,373 @@
+// vfw.cpp — boundary B2: Linux re-host of the x264vfw driver shell for the compress path.
+//   DriverProc                 driverproc.c:89-301     message dispatch, DRV_OPEN returns the CODEC* as id
+//   compress_get_format/_get_size/_query   codec.c:581-652
+//   compress_begin             codec.c:1381-1684       CONFIG + extra cmdline -> x264_param_t -> x264_encoder_open
+//   compress / encode_frame    codec.c:1686-1835       ICCOMPRESS in, contiguous NALs out, AVIIF_KEYFRAME
+//   compress_end / frames_info codec.c:1838-1894
+// Same message set, return conventions and sticky-error behaviour; the Windows-only parts (registry, dialogs,
+// log window, VirtualDub hack, file muxers, decoder) are out of scope.
+#include "host.hpp"
+#include "../../include/vfw_shim.h"
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <string>
+#include <vector>
+
+namespace {
+
+const DWORD kFourccOut[] = { mmioFOURCC('H', '2', '6', '4'), mmioFOURCC('h', '2', '6', '4'), mmioFOURCC('X', '2', '6', '4'),
+                             mmioFOURCC('x', '2', '6', '4'), mmioFOURCC('A', 'V', 'C', '1'), mmioFOURCC('a', 'v', 'c', '1'),
+                             mmioFOURCC('V', 'S', 'S', 'H') };                                       /* codec.c:112-121 */
+const char *const kPresets[] = { "ultrafast", "superfast", "veryfast", "faster", "fast", "medium", "slow", "slower", "veryslow", "placebo" };
+const char *const kTunes[] = { "", "film", "animation", "grain", "stillimage", "psnr", "ssim" };
+const char *const kProfiles[] = { "", "baseline", "main", "high" };
+const int kLevels[] = { -1, 10, 9, 11, 12, 13, 20, 21, 22, 30, 31, 32, 40, 41, 42, 50, 51, 52, 60, 61, 62 };
+
+enum { CSP_NONE = 0, CSP_I420, CSP_YV12 };
+
+struct CODEC {                          /* x264vfw.h:187-252, compress-side members */
+    x264_t *h;
+    X264VFW_CONFIG config;
+    int b_encoder_error;
+    BITMAPINFOHEADER *prev_lpbiOutput;
+    DWORD prev_output_biSizeImage;
+    int b_check_size;
+    int i_frame_remain, i_frame_total;
+    uint32_t i_fps_num, i_fps_den;
+    x264_picture_t conv_pic;
+    int b_user_ref;
+    std::string log;
+};
+
+void config_defaults(X264VFW_CONFIG *c)
+{
+    memset(c, 0, sizeof(*c));
+    c->i_format_version = X264VFW_FORMAT_VERSION;
+    c->i_preset = 5;                    /* medium (config.c:96) */
+    c->i_level = 0;                     /* auto */
+    c->i_encoding_type = 2;             /* single pass CRF after the GordianKnot remap (config.c:205-228,256) */
+    c->i_qp = 23; c->i_rf_constant = 230; c->i_passbitrate = 800; c->i_pass = 1;
+    c->i_log_level = 2;                 /* warning */
+    c->i_sar_width = c->i_sar_height = 1;
+}
+
+void log_cb(void *priv, int level, const char *fmt, va_list ap)
+{
+    CODEC *codec = (CODEC *)priv;
+    char buf[1024];
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    if (codec) codec->log += buf;
+    if (level <= X264_LOG_ERROR) fputs(buf, stderr);
+}
+void vlog(CODEC *codec, int level, const char *fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    log_cb(codec, level, fmt, ap);
+    va_end(ap);
+}
+
+int get_csp(const BITMAPINFOHEADER *hdr)          /* codec.c:187-231; packed/RGB inputs are next-row f1 */
+{
+    DWORD f = hdr->biCompression;
+    if (f == mmioFOURCC('I', '4', '2', '0') || f == mmioFOURCC('I', 'Y', 'U', 'V')) return CSP_I420;
+    if (f == mmioFOURCC('Y', 'V', '1', '2')) return CSP_YV12;
+    return CSP_NONE;
+}
+bool supported_fourcc(DWORD f) { for (DWORD k : kFourccOut) if (k == f) return true; return false; }
+
+LRESULT compress_get_size(BITMAPINFO *out)        /* codec.c:618-621 */
+{
+    return ((out->bmiHeader.biWidth + 15) & ~15) * ((out->bmiHeader.biHeight + 31) & ~31) * 3 + 4096;
+}
+
+LRESULT compress_get_format(CODEC *codec, BITMAPINFO *in, BITMAPINFO *out)
+{
+    if (!out) return sizeof(BITMAPINFOHEADER);
+    BITMAPINFOHEADER *ih = &in->bmiHeader, *oh = &out->bmiHeader;
+    if (get_csp(ih) == CSP_NONE) return ICERR_BADFORMAT;
+    int w = ih->biWidth, h = abs(ih->biHeight);
+    if (w <= 0 || h <= 0 || (w % 2) || (h % 2)) return ICERR_BADFORMAT;
+    memset(oh, 0, sizeof(*oh));
+    oh->biSize = sizeof(*oh); oh->biWidth = w; oh->biHeight = h; oh->biPlanes = 1; oh->biBitCount = 24;
+    int fi = codec->config.i_fourcc;
+    oh->biCompression = kFourccOut[fi >= 0 && fi < 7 ? fi : 0];
+    oh->biSizeImage = (DWORD)compress_get_size(out);
+    return ICERR_OK;
+}
+
+LRESULT compress_query(CODEC *codec, BITMAPINFO *in, BITMAPINFO *out)
+{
+    BITMAPINFOHEADER *ih = &in->bmiHeader;
+    if (get_csp(ih) == CSP_NONE) return ICERR_BADFORMAT;
+    int w = ih->biWidth, h = abs(ih->biHeight);
+    if (w <= 0 || h <= 0 || (w % 2) || (h % 2)) return ICERR_BADFORMAT;
+    if (!out) return ICERR_OK;
+    if (w != out->bmiHeader.biWidth || h != out->bmiHeader.biHeight) return ICERR_BADFORMAT;
+    if (!supported_fourcc(out->bmiHeader.biCompression)) return ICERR_BADFORMAT;
+    return ICERR_OK;
+}
+
+LRESULT compress_end(CODEC *codec)
+{
+    if (codec->h) {
+        x264_encoder_close(codec->h);            /* nothing is ever delayed on this path (no B-frames) */
+        codec->h = nullptr;
+    }
+    x264_picture_clean(&codec->conv_pic);
+    memset(&codec->conv_pic, 0, sizeof(codec->conv_pic));
+    codec->b_encoder_error = 0;
+    return ICERR_OK;
+}
+
+// split the extra command line like codec.c:1169-1223 (whitespace separated, double quotes group)
+std::vector<std::string> split_cmdline(const char *s)
+{
+    std::vector<std::string> out;
+    std::string cur;
+    bool in_q = false, have = false;
+    for (; *s; s++) {
+        if (*s == '"') { in_q = !in_q; have = true; }
+        else if (!in_q && (*s == ' ' || *s == '\t' || *s == '\r' || *s == '\n')) { if (have) { out.push_back(cur); cur.clear(); have = false; } }
+        else { cur += *s; have = true; }
+    }
+    if (have) out.push_back(cur);
+    return out;
+}
+
+bool option_takes_value(const std::string &name)
+{
+    static const char *const flags[] = { "fast-firstpass", "slow-firstpass", "no-b-adapt", "open-gop", "bluray-compat", "intra-refresh",
+        "no-scenecut", "nf", "no-deblock", "interlaced", "no-interlaced", "tff", "bff", "constrained-intra", "cabac", "no-cabac", "asm", "no-asm",
+        "weightb", "no-weightb", "psy", "no-psy", "mixed-refs", "no-mixed-refs", "chroma-me", "no-chroma-me", "8x8dct", "no-8x8dct",
+        "fast-pskip", "no-fast-pskip", "dct-decimate", "no-dct-decimate", "mbtree", "no-mbtree", "sliced-threads", "no-sliced-threads",
+        "thread-input", "deterministic", "non-deterministic", "cpu-independent", "psnr", "no-psnr", "ssim", "no-ssim", "quiet", "verbose",
+        "progress", "no-progress", "aud", "no-aud", "force-cfr", "pic-struct", "fake-interlaced", "stitchable", "filler", "vd-hack", "no-output",
+        "stdout", "stdin", "dts-compress", 0 };
+    for (int i = 0; flags[i]; i++) if (name == flags[i]) return false;
+    return true;
+}
+
+LRESULT compress_begin(CODEC *codec, BITMAPINFO *in, BITMAPINFO *out)
+{
+    X264VFW_CONFIG *cfg = &codec->config;
+    compress_end(codec);                                                    /* destroy previous handle (codec.c:1394) */
+    codec->log.clear();
+    if (compress_query(codec, in, out) != ICERR_OK) {
+        vlog(codec, X264_LOG_ERROR, "incompatible input/output frame format (encode)\n");
+        codec->b_encoder_error = 1;
+        return ICERR_BADFORMAT;
+    }
+    codec->b_check_size = out->bmiHeader.biSizeImage != 0;
+    codec->b_user_ref = 0;
+    codec->i_frame_remain = codec->i_frame_total ? codec->i_frame_total : -1;
+
+    const char *preset = cfg->i_preset >= 0 && cfg->i_preset < 10 ? kPresets[cfg->i_preset] : nullptr;
+    const char *profile = cfg->i_profile > 0 && cfg->i_profile < 4 ? kProfiles[cfg->i_profile] : nullptr;
+    std::string tune = cfg->i_tuning > 0 && cfg->i_tuning < 7 ? kTunes[cfg->i_tuning] : "";
+    if (cfg->b_fastdecode) tune += tune.empty() ? "fastdecode" : ",fastdecode";
+    if (cfg->b_zerolatency) tune += tune.empty() ? "zerolatency" : ",zerolatency";
+    std::vector<std::string> argv = split_cmdline(cfg->extra_cmdline);
+    std::string preset_s = preset ? preset : "", profile_s = profile ? profile : "";
+    for (size_t i = 0; i + 1 < argv.size(); i++) {                          /* presets first (parse_preset_tune, codec.c:1198-1223) */
+        if (argv[i] == "--preset") preset_s = argv[i + 1];
+        if (argv[i] == "--tune") tune = argv[i + 1];
+    }
+    x264_param_t param;
+    if (x264_param_default_preset(&param, preset_s.empty() ? nullptr : preset_s.c_str(), tune.empty() ? nullptr : tune.c_str()) < 0) {
+        vlog(codec, X264_LOG_ERROR, "x264_param_default_preset failed\n");
+        goto fail;
+    }
+    param.i_width = in->bmiHeader.biWidth;
+    param.i_height = abs(in->bmiHeader.biHeight);
+    param.i_csp = X264_CSP_I420;
+    param.i_frame_total = codec->i_frame_total;
+    if (codec->i_fps_num > 0 && codec->i_fps_den > 0) { param.i_fps_num = codec->i_fps_num; param.i_fps_den = codec->i_fps_den; }
+    param.i_level_idc = cfg->i_level >= 0 && cfg->i_level < (int)(sizeof(kLevels) / sizeof(kLevels[0])) ? kLevels[cfg->i_level] : -1;
+    param.rc.b_stat_write = param.rc.b_stat_read = 0;
+    switch (cfg->i_encoding_type) {                                         /* codec.c:1490-1533 */
+    case 0: param.rc.i_rc_method = X264_RC_CQP; param.rc.i_qp_constant = 0; break;
+    case 1: param.rc.i_rc_method = X264_RC_CQP; param.rc.i_qp_constant = cfg->i_qp; break;
+    case 2: param.rc.i_rc_method = X264_RC_CRF; param.rc.f_rf_constant = (float)cfg->i_rf_constant * 0.1f; break;
+    case 3: case 4: param.rc.i_rc_method = X264_RC_ABR; param.rc.i_bitrate = cfg->i_passbitrate; break;
+    default: goto fail;
+    }
+    param.vui.i_sar_width = cfg->i_sar_width; param.vui.i_sar_height = cfg->i_sar_height;
+    param.pf_log = log_cb; param.p_log_private = codec; param.i_log_level = cfg->i_log_level - 1;
+    param.analyse.b_psnr = cfg->i_encoding_type > 0 && cfg->i_log_level >= 3 && cfg->b_psnr;
+    param.analyse.b_ssim = cfg->i_encoding_type > 0 && cfg->i_log_level >= 3 && cfg->b_ssim;
+    param.cpu = cfg->b_no_asm ? 0 : param.cpu;
+    for (size_t i = 0; i < argv.size(); i++) {                              /* parse_cmdline (codec.c:1225-1378) */
+        const std::string &a = argv[i];
+        if (a.size() < 3 || a[0] != '-' || a[1] != '-') { vlog(codec, X264_LOG_ERROR, "unknown option or absent argument: '%s'\n", a.c_str()); goto fail; }
+        std::string name = a.substr(2), value;
+        bool has_value = false;
+        size_t eq = name.find('=');
+        if (eq != std::string::npos) { value = name.substr(eq + 1); name = name.substr(0, eq); has_value = true; }
+        else if (option_takes_value(name) && i + 1 < argv.size()) { value = argv[++i]; has_value = true; }
+        if (name == "preset" || name == "tune") continue;
+        if (name == "profile") { profile_s = value; continue; }
+        if (name == "ref") codec->b_user_ref = 1;
+        if (name == "quiet") { param.i_log_level = X264_LOG_NONE; continue; }
+        if (name == "output" || name == "muxer" || name == "vd-hack" || name == "no-output" || name == "dts-compress") {
+            vlog(codec, X264_LOG_WARNING, "not supported option: '%s'\n", a.c_str());
+            continue;
+        }
+        int rc = x264_param_parse(&param, name.c_str(), has_value ? value.c_str() : nullptr);
+        if (rc == X264_PARAM_BAD_NAME) { vlog(codec, X264_LOG_ERROR, "unknown option: '%s'\n", a.c_str()); goto fail; }
+        if (rc == X264_PARAM_BAD_VALUE) { vlog(codec, X264_LOG_ERROR, "invalid argument: '%s' = '%s'\n", a.c_str(), value.c_str()); goto fail; }
+    }
+    param.b_vfr_input = 0;                                                  /* VFW supports only CFR (codec.c:1567-1569) */
+    param.i_timebase_num = param.i_fps_den; param.i_timebase_den = param.i_fps_num;
+    param.vui.b_fullrange = param.vui.b_fullrange == 1;
+    if (param.vui.i_colmatrix < 0) param.vui.i_colmatrix = 2;
+    if (x264_param_apply_profile(&param, profile_s.empty() ? nullptr : profile_s.c_str()) < 0) {
+        vlog(codec, X264_LOG_ERROR, "x264_param_apply_profile failed\n");
+        goto fail;
+    }
+    if (!codec->b_user_ref) {                                               /* level-based ref clamp (codec.c:1592-1606) */
+        int mbs = ((param.i_width + 15) >> 4) * ((param.i_height + 15) >> 4);
+        for (int i = 0; x264_levels[i].level_idc != 0; i++)
+            if (param.i_level_idc == x264_levels[i].level_idc) {
+                while (mbs * param.i_frame_reference > x264_levels[i].dpb && param.i_frame_reference > 1) param.i_frame_reference--;
+                break;
+            }
+    }
+    param.b_annexb = 1; param.b_repeat_headers = 1;                         /* VFW needs SPS/PPS before each keyframe */
+    codec->h = x264_encoder_open(&param);
+    if (!codec->h) { vlog(codec, X264_LOG_ERROR, "x264_encoder_open failed\n"); goto fail; }
+    x264_encoder_parameters(codec->h, &param);
+    if (x264_picture_alloc(&codec->conv_pic, param.i_csp, param.i_width, param.i_height) < 0) {
+        vlog(codec, X264_LOG_ERROR, "x264_picture_alloc failed\n");
+        goto fail;
+    }
+    return ICERR_OK;
+fail:
+    codec->b_encoder_error = 1;
+    compress_end(codec);
+    codec->b_encoder_error = 1;
+    return ICERR_ERROR;
+}
+
+int encode_frame(CODEC *codec, x264_picture_t *pic, x264_picture_t *pic_out, uint8_t *buf, DWORD buf_size, int *got_picture)
+{
+    x264_nal_t *nal;
+    int i_nal;
+    *got_picture = 0;
+    int size = x264_encoder_encode(codec->h, &nal, &i_nal, pic, pic_out);
+    if (size < 0) { vlog(codec, X264_LOG_ERROR, "x264_encoder_encode failed\n"); return -1; }
+    if (size) {
+        *got_picture = 1;
+        if (buf) {
+            if ((DWORD)size > buf_size && codec->b_check_size) {
+                vlog(codec, X264_LOG_ERROR, "output frame buffer too small (size %d / needed %d)\n", (int)buf_size, size);
+                return -1;
+            }
+            memcpy(buf, nal[0].p_payload, size);                            /* NALs are contiguous from nal[0] */
+        } else
+            size = 0;
+    }
+    return size;
+}
+
+LRESULT compress(CODEC *codec, ICCOMPRESS *icc)
+{
+    if (!codec->h || codec->b_encoder_error) return ICERR_ERROR;
+    BITMAPINFOHEADER *inhdr = icc->lpbiInput, *outhdr = icc->lpbiOutput;
+    x264_picture_t pic_out;
+    int got_picture, i_out;
+    /* "buggy apps" workaround (codec.c:1743-1753) */
+    if (codec->prev_lpbiOutput == outhdr && outhdr->biSizeImage < codec->prev_output_biSizeImage) outhdr->biSizeImage = codec->prev_output_biSizeImage;
+    codec->prev_lpbiOutput = outhdr;
+    codec->prev_output_biSizeImage = outhdr->biSizeImage;
+    if (codec->i_frame_remain) {
+        if (codec->i_frame_remain != -1) codec->i_frame_remain--;
+        int csp = get_csp(inhdr), w = inhdr->biWidth, h = abs(inhdr->biHeight);
+        if (csp == CSP_NONE) { vlog(codec, X264_LOG_ERROR, "unknown input frame colorspace\n"); codec->b_encoder_error = 1; return ICERR_BADFORMAT; }
+        /* x264vfw_img_fill (codec.c:304-379) + i420_to_i420 / yv12 swap (csp.c:409-412): plane pointers over the caller's buffer */
+        const uint8_t *y = (const uint8_t *)icc->lpInput, *c0 = y + (size_t)w * h, *c1 = c0 + (size_t)(w / 2) * (h / 2);
+        const uint8_t *u = csp == CSP_YV12 ? c1 : c0, *v = csp == CSP_YV12 ? c0 : c1;
+        memcpy(codec->conv_pic.img.plane[0], y, (size_t)w * h);
+        memcpy(codec->conv_pic.img.plane[1], u, (size_t)(w / 2) * (h / 2));
+        memcpy(codec->conv_pic.img.plane[2], v, (size_t)(w / 2) * (h / 2));
+        i_out = encode_frame(codec, &codec->conv_pic, &pic_out, (uint8_t *)icc->lpOutput, outhdr->biSizeImage, &got_picture);
+        codec->conv_pic.i_pts++;
+    } else
+        i_out = encode_frame(codec, nullptr, &pic_out, (uint8_t *)icc->lpOutput, outhdr->biSizeImage, &got_picture);
+    if (i_out < 0) { codec->b_encoder_error = 1; return ICERR_ERROR; }
+    *icc->lpdwFlags = got_picture && pic_out.b_keyframe ? AVIIF_KEYFRAME : 0;
+    outhdr->biSizeImage = i_out;
+    return ICERR_OK;
+}
+
+}  // namespace
+
+extern "C" LRESULT DriverProc(DWORD_PTR dwDriverId, HDRVR hDriver, UINT uMsg, LPARAM lParam1, LPARAM lParam2)
+{
+    CODEC *codec = (CODEC *)dwDriverId;
+    switch (uMsg) {
+    case DRV_LOAD: case DRV_FREE: return DRV_OK;
+    case DRV_OPEN: {
+        ICOPEN *icopen = (ICOPEN *)lParam2;
+        if (icopen && icopen->fccType != ICTYPE_VIDEO) return 0;
+        codec = new (std::nothrow) CODEC();
+        if (!codec) { if (icopen) icopen->dwError = ICERR_MEMORY; return 0; }
+        codec->h = nullptr; codec->b_encoder_error = 0; codec->prev_lpbiOutput = nullptr; codec->prev_output_biSizeImage = 0;
+        memset(&codec->conv_pic, 0, sizeof(codec->conv_pic));
+        config_defaults(&codec->config);
+        codec->i_frame_total = 0; codec->i_fps_num = codec->i_fps_den = 0;
+        if (icopen) icopen->dwError = ICERR_OK;
+        return (LRESULT)codec;
+    }
+    case DRV_CLOSE:
+        compress_end(codec);                     /* compress_end doesn't always get called by hosts (driverproc.c:131-139) */
+        delete codec;
+        return DRV_OK;
+    case DRV_QUERYCONFIGURE: return 0;
+    case DRV_CONFIGURE: return DRV_CANCEL;
+    case ICM_GETSTATE:
+        if (!lParam1) return sizeof(X264VFW_CONFIG);
+        if ((size_t)lParam2 != sizeof(X264VFW_CONFIG)) return ICERR_BADSIZE;
+        memcpy((void *)lParam1, &codec->config, sizeof(X264VFW_CONFIG));
+        ((X264VFW_CONFIG *)lParam1)->i_format_version = X264VFW_FORMAT_VERSION;
+        return ICERR_OK;
+    case ICM_SETSTATE:
+        if (!lParam1) { config_defaults(&codec->config); return 0; }
+        if ((size_t)lParam2 != sizeof(X264VFW_CONFIG) || ((X264VFW_CONFIG *)lParam1)->i_format_version != X264VFW_FORMAT_VERSION) return 0;
+        memcpy(&codec->config, (void *)lParam1, sizeof(X264VFW_CONFIG));
+        return sizeof(X264VFW_CONFIG);
+    case ICM_GETINFO: {
+        ICINFO *ii = (ICINFO *)lParam1;
+        if ((size_t)lParam2 < sizeof(ICINFO)) return 0;
+        memset(ii, 0, sizeof(*ii));
+        ii->dwSize = sizeof(ICINFO); ii->fccType = ICTYPE_VIDEO; ii->fccHandler = mmioFOURCC('X', '2', '6', '4');
+        ii->dwFlags = VIDCF_COMPRESSFRAMES | VIDCF_FASTTEMPORALC; ii->dwVersion = 0; ii->dwVersionICM = ICVERSION;
+        const char *nm = "x264vfw", *ds = "x264vfw - H.264/MPEG-4 AVC codec";
+        for (int i = 0; nm[i] && i < 15; i++) ii->szName[i] = (uint16_t)nm[i];
+        for (int i = 0; ds[i] && i < 127; i++) ii->szDescription[i] = (uint16_t)ds[i];
+        return sizeof(ICINFO);
+    }
+    case ICM_CONFIGURE: case ICM_ABOUT: return ICERR_OK;       /* dialogs are out of scope; lParam1 == -1 is the capability query */
+    case ICM_GET: return lParam1 ? ICERR_OK : 0;
+    case ICM_SET: return 0;
+    case ICM_COMPRESS_GET_FORMAT: return compress_get_format(codec, (BITMAPINFO *)lParam1, (BITMAPINFO *)lParam2);
+    case ICM_COMPRESS_GET_SIZE: return compress_get_size((BITMAPINFO *)lParam2);
+    case ICM_COMPRESS_QUERY: return compress_query(codec, (BITMAPINFO *)lParam1, (BITMAPINFO *)lParam2);
+    case ICM_COMPRESS_BEGIN: return compress_begin(codec, (BITMAPINFO *)lParam1, (BITMAPINFO *)lParam2);
+    case ICM_COMPRESS: return compress(codec, (ICCOMPRESS *)lParam1);
+    case ICM_COMPRESS_END:
+        codec->i_frame_total = 0; codec->i_fps_num = codec->i_fps_den = 0;
+        return compress_end(codec);
+    case ICM_COMPRESS_FRAMES_INFO: {
+        ICCOMPRESSFRAMES *icf = (ICCOMPRESSFRAMES *)lParam1;
+        codec->i_frame_total = icf->lFrameCount; codec->i_fps_num = icf->dwRate; codec->i_fps_den = icf->dwScale;
+        return ICERR_OK;
+    }
+    default:
+        return uMsg < DRV_USER ? 0 /* DefDriverProc */ : ICERR_UNSUPPORTED;
+    }
+}
+
+/* test hook: the driver's log text of the last session (the Windows build shows it in a list box) */
+extern "C" const char *x264vfw_shim_log(DWORD_PTR dwDriverId) { return dwDriverId ? ((CODEC *)dwDriverId)->log.c_str() : ""; }
