@@ -207,3 +207,21 @@ def h264_decode(stream, max_frames, w, h):
     assert (ww.value, hh.value) == (w, h), (ww.value, hh.value)
     fs = w * h * 3 // 2
     return [out[i * fs:(i + 1) * fs].copy() for i in range(min(n, max_frames))]
+
+
+def dctq8x8(enc, pred, qp, lst):
+    """enc,pred: (n,8,8) u8 -> coef, levels (raster), recon — the 8x8 transform path"""
+    t = quant_tables()
+    n = enc.shape[0]
+    coef = np.zeros((n, 64), np.int16)
+    lev = np.zeros((n, 64), np.int16)
+    rec = pred.copy()
+    for i in range(n):
+        d = np.zeros(64, np.int16)
+        L.x264o_sub8x8_dct8(d, ptr(enc, i * 64), 8, ptr(pred, i * 64), 8)
+        coef[i] = d
+        L.x264o_quant_8x8(d, C.addressof(t.quant8_mf[lst][qp]), C.addressof(t.quant8_bias[lst][qp]))
+        lev[i] = d
+        L.x264o_dequant_8x8(d, C.addressof(t.dequant8_mf), qp)
+        L.x264o_add8x8_idct8(ptr(rec, i * 64), 8, d)
+    return coef, lev, rec

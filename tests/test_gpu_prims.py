@@ -147,3 +147,64 @@ def test_mc_luma_chroma(gpu):
             O.L.x264o_mc_chroma(O.ptr(ref, i * 2 * bw * bh), O.ptr(ref, i * 2 * bw * bh + bw * bh), bw,
                                 O.ptr(nv, org), cs, int(xy[i, 0]), int(xy[i, 1]), int(mv[i, 0]), int(mv[i, 1]), bw, bh)
         np.testing.assert_array_equal(out.cpu().numpy(), ref, err_msg=f"mc_chroma {bw}x{bh}")
+
+
+@pytest.mark.parametrize("qp", [0, 7, 23, 35, 36, 42, 51])
+@pytest.mark.parametrize("lst", [0, 1])
+def test_dctq8x8(gpu, qp, lst):
+    import torch
+    rng = np.random.default_rng(800 + qp * 2 + lst)
+    n = 333
+    enc = np.concatenate([blocks(rng, n - 100, 8, 8, "rand"), blocks(rng, 100, 8, 8, "smooth")])
+    pred = np.concatenate([blocks(rng, n - 100, 8, 8, "smooth"), blocks(rng, 100, 8, 8, "extreme")])
+    coef = torch.empty((n, 64), dtype=torch.int16, device="cuda")
+    lev = torch.empty_like(coef)
+    rec = torch.empty((n, 64), dtype=torch.uint8, device="cuda")
+    denc, dpred = dev(enc), dev(pred)
+    gpu.check(gpu.x264gpu_dctq8x8(denc.data_ptr(), dpred.data_ptr(), n, qp, lst, coef.data_ptr(), lev.data_ptr(), rec.data_ptr(), None))
+    rc, rl, rr = O.dctq8x8(enc, pred, qp, lst)
+    np.testing.assert_array_equal(coef.cpu().numpy(), rc)
+    np.testing.assert_array_equal(lev.cpu().numpy(), rl)
+    np.testing.assert_array_equal(rec.cpu().numpy().reshape(n, 8, 8), rr)
+
+
+def test_intra_predictors(gpu):
+    import torch
+    rng = np.random.default_rng(4242)
+    W = H = 96
+    plane = rng.integers(0, 256, (H, W), dtype=np.uint8)
+    dplane = dev(plane)
+    for kind, size, nmodes, fn in ((0, 16, 7, O.L.x264o_predict_16x16), (1, 8, 7, O.L.x264o_predict_8x8c)):
+        n = 200
+        xy = rng.integers(8, W - size - 8, (n, 2)).astype(np.int32)
+        mode = rng.integers(0, nmodes, n).astype(np.int32)
+        avail = np.zeros(n, np.int32)
+        out = torch.empty((n, size, size), dtype=torch.uint8, device="cuda")
+        dxy, dmode, dav = dev(xy), dev(mode), dev(avail)
+        gpu.check(gpu.x264gpu_intra_predict(kind, dplane.data_ptr(), W, dxy.data_ptr(), dmode.data_ptr(), dav.data_ptr(), n, out.data_ptr(), None))
+        ref = np.zeros((n, size, size), np.uint8)
+        for i in range(n):
+            fn(O.ptr(ref, i * size * size), size, O.ptr(plane, int(xy[i, 1]) * W + int(xy[i, 0])), W, int(mode[i]))
+        np.testing.assert_array_equal(out.cpu().numpy(), ref, err_msg=f"kind {kind}")
+    # 4x4: the nine modes with every legal availability combination
+    n = 600
+    xy = rng.integers(8, W - 16, (n, 2)).astype(np.int32)
+    mode = rng.integers(0, 9, n).astype(np.int32)
+    avail = rng.integers(0, 16, n).astype(np.int32)
+    for i in range(n):
+        m, a = int(mode[i]), int(avail[i])
+        need = {0: 2, 1: 1, 2: 0, 3: 2, 4: 11, 5: 11, 6: 11, 7: 2, 8: 1}[m]
+        avail[i] = a | need
+        if not avail[i] & 2:
+            avail[i] &= ~4
+    out = torch.empty((n, 4, 4), dtype=torch.uint8, device="cuda")
+    dxy, dmode, dav = dev(xy), dev(mode), dev(avail)
+    gpu.check(gpu.x264gpu_intra_predict(2, dplane.data_ptr(), W, dxy.data_ptr(), dmode.data_ptr(), dav.data_ptr(), n, out.data_ptr(), None))
+    ref = np.zeros((n, 4, 4), np.uint8)
+    for i in range(n):
+        m, a = int(mode[i]), int(avail[i])
+        real = m
+        if m == 2:
+            real = 2 if (a & 1 and a & 2) else 9 if a & 1 else 10 if a & 2 else 11
+        O.L.x264o_predict_4x4(O.ptr(ref, i * 16), 4, O.ptr(plane, int(xy[i, 1]) * W + int(xy[i, 0])), W, real, a)
+    np.testing.assert_array_equal(out.cpu().numpy(), ref)

@@ -1,0 +1,198 @@
+// prim2_kernels.hip — Tier-1 primitives, part 2: the 8x8 transform path (A6-A8: sub8x8_dct8, quant_8x8,
+// dequant_8x8, add8x8_idct8) and the intra predictors (A5) as batch kernels.
+//
+// 8x8 layout: lane = (block, row) — 8 lanes own one 8x8 block, each lane holds one row of 8 samples in
+// registers.  Row transforms are in-lane 8-point butterflies; column transforms run after an 8x8 transpose
+// across the 8 lanes (three exchange stages: DPP quad_perm for lane^1 / lane^2, a cross-lane shuffle for
+// lane^4).  Quantiser tables have six position classes (normAdjust8x8); each lane keeps the four it needs.
+#include "common.cuh"
+#include "intra.cuh"
+
+using namespace x264gpu;
+
+namespace {
+
+struct Q8 { int mf[6], bias[6], dq[6], qp; };
+
+Q8 make_q8(int qp, int list, const QuantCfg &c = QuantCfg())
+{
+    static const int qs[6][6] = { { 13107, 11428, 20972, 12222, 16777, 15481 }, { 11916, 10826, 19174, 11058, 14980, 14290 },
+                                  { 10082, 8943, 15978, 9675, 12710, 11985 },   { 9362, 8228, 14913, 8931, 11984, 11259 },
+                                  { 8192, 7346, 13159, 7740, 10486, 9777 },     { 7282, 6428, 11570, 6830, 9118, 8640 } };
+    static const int ds[6][6] = { { 20, 18, 32, 19, 25, 24 }, { 22, 19, 35, 21, 28, 26 }, { 26, 23, 42, 24, 33, 31 },
+                                  { 28, 25, 45, 26, 35, 33 }, { 32, 28, 51, 30, 40, 38 }, { 36, 32, 58, 34, 46, 43 } };
+    const int dz = list == 0 ? 32 - c.deadzone_intra : 32 - c.deadzone_inter;
+    Q8 q;
+    q.qp = qp;
+    const int sh = qp / 6;
+    for (int k = 0; k < 6; k++) {
+        int base = qs[qp % 6][k];
+        int mf = sh <= 0 ? base : (base + (1 << (sh - 1))) >> sh;
+        int b = ((dz << 10) + (mf >> 1)) / mf, cap = (1 << 15) / mf;
+        q.mf[k] = mf; q.bias[k] = b < cap ? b : cap; q.dq[k] = ds[qp % 6][k] * 16;
+    }
+    return q;
+}
+
+__device__ __forceinline__ void fwd8_1d(int s[8])
+{
+    const int s07 = s[0] + s[7], s16 = s[1] + s[6], s25 = s[2] + s[5], s34 = s[3] + s[4];
+    const int d07 = s[0] - s[7], d16 = s[1] - s[6], d25 = s[2] - s[5], d34 = s[3] - s[4];
+    const int a0 = s07 + s34, a1 = s16 + s25, a2 = s07 - s34, a3 = s16 - s25;
+    const int a4 = d16 + d25 + (d07 + (d07 >> 1));
+    const int a5 = d07 - d34 - (d25 + (d25 >> 1));
+    const int a6 = d07 + d34 - (d16 + (d16 >> 1));
+    const int a7 = d16 - d25 + (d34 + (d34 >> 1));
+    s[0] = a0 + a1; s[1] = a4 + (a7 >> 2); s[2] = a2 + (a3 >> 1); s[3] = a5 + (a6 >> 2);
+    s[4] = a0 - a1; s[5] = a6 - (a5 >> 2); s[6] = (a2 >> 1) - a3; s[7] = (a4 >> 2) - a7;
+}
+__device__ __forceinline__ void inv8_1d(int s[8])
+{
+    const int a0 = s[0] + s[4], a2 = s[0] - s[4], a4 = (s[2] >> 1) - s[6], a6 = (s[6] >> 1) + s[2];
+    const int b0 = a0 + a6, b2 = a2 + a4, b4 = a2 - a4, b6 = a0 - a6;
+    const int a1 = -s[3] + s[5] - s[7] - (s[7] >> 1);
+    const int a3 = s[1] + s[7] - s[3] - (s[3] >> 1);
+    const int a5 = -s[1] + s[7] + s[5] + (s[5] >> 1);
+    const int a7 = s[3] + s[5] + s[1] + (s[1] >> 1);
+    const int b1 = (a7 >> 2) + a1, b3 = a3 + (a5 >> 2), b5 = (a3 >> 2) - a5, b7 = a7 - (a1 >> 2);
+    s[0] = b0 + b7; s[1] = b2 + b5; s[2] = b4 + b3; s[3] = b6 + b1;
+    s[4] = b6 - b1; s[5] = b4 - b3; s[6] = b2 - b5; s[7] = b0 - b7;
+}
+// (lane r, reg c) -> (lane c, reg r) within each group of 8 lanes
+__device__ __forceinline__ void transpose8(int v[8], int lane)
+{
+#pragma unroll
+    for (int s = 1; s < 8; s <<= 1) {
+        const bool hi = lane & s;
+#pragma unroll
+        for (int r = 0; r < 8; r++) {
+            if (r & s) continue;
+            const int send = hi ? v[r] : v[r | s];
+            const int recv = s == 1 ? dpp<DPP_XOR1>(send) : s == 2 ? dpp<DPP_XOR2>(send) : __shfl_xor(send, 4);
+            if (hi) v[r] = recv; else v[r | s] = recv;
+        }
+    }
+}
+__device__ __forceinline__ int class8(int r, int c)
+{
+    // normAdjust8x8 class of position (r,c): [r&3][c&3] -> { {0,3,4,3}, {3,1,5,1}, {4,5,2,5}, {3,1,5,1} }
+    const unsigned long long tab = 0x1513525415133430ull;   // nibble (r&3)*4 + (c&3)
+    return (int)((tab >> (((r & 3) * 4 + (c & 3)) * 4)) & 15);
+}
+
+__global__ __launch_bounds__(256) void k_dctq8x8(const uint8_t *__restrict__ enc, const uint8_t *__restrict__ pred, int n, Q8 q,
+                                                 int16_t *__restrict__ coef, int16_t *__restrict__ levels, uint8_t *__restrict__ recon)
+{
+    const int lane = threadIdx.x & 63;
+    const int blk = (blockIdx.x * 4 + (threadIdx.x >> 6)) * 8 + (lane >> 3), row = lane & 7;
+    const bool valid = blk < n;
+    uint2 pe = make_uint2(0, 0), pp = make_uint2(0, 0);
+    if (valid) { pe = *(const uint2 *)(enc + (size_t)blk * 64 + row * 8); pp = *(const uint2 *)(pred + (size_t)blk * 64 + row * 8); }
+    int e[8], p[8], v[8];
+    unpack4(pe.x, e); unpack4(pe.y, e + 4); unpack4(pp.x, p); unpack4(pp.y, p + 4);
+#pragma unroll
+    for (int i = 0; i < 8; i++) v[i] = e[i] - p[i];
+    fwd8_1d(v); transpose8(v, lane); fwd8_1d(v); transpose8(v, lane);       // natural layout: lane = row, reg = col
+    if (coef && valid)
+#pragma unroll
+        for (int i = 0; i < 8; i++) coef[(size_t)blk * 64 + row * 8 + i] = (int16_t)v[i];
+    int mf[4], bs[4], dq[4];
+#pragma unroll
+    for (int c = 0; c < 4; c++) { const int k = class8(row, c); mf[c] = q.mf[k]; bs[c] = q.bias[k]; dq[c] = q.dq[k]; }
+#pragma unroll
+    for (int i = 0; i < 8; i++) v[i] = quant_one(v[i], mf[i & 3], bs[i & 3]);
+    if (levels && valid)
+#pragma unroll
+        for (int i = 0; i < 8; i++) levels[(size_t)blk * 64 + row * 8 + i] = (int16_t)v[i];
+    const int qb = q.qp / 6 - 6;
+#pragma unroll
+    for (int i = 0; i < 8; i++) v[i] = dequant_one(v[i], dq[i & 3], qb);
+    inv8_1d(v); transpose8(v, lane); inv8_1d(v); transpose8(v, lane);       // 8.5.13: rows first, then columns
+#pragma unroll
+    for (int i = 0; i < 8; i++) v[i] = ((v[i] + 32) >> 6) + p[i];
+    if (recon && valid) {
+        uint2 o;
+        o.x = pack4_clip(v); o.y = pack4_clip(v + 4);
+        *(uint2 *)(recon + (size_t)blk * 64 + row * 8) = o;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// intra predictors: one wavefront per block; neighbours staged in per-wave LDS exactly as in k_intra
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_intra_predict(int kind, const uint8_t *__restrict__ plane, int stride,
+                                                       const int32_t *__restrict__ xy, const int32_t *__restrict__ mode,
+                                                       const int32_t *__restrict__ avail, int n, uint8_t *__restrict__ out)
+{
+    __shared__ uint8_t s_nb[4][NB_SIZE];
+    __shared__ __attribute__((aligned(4))) uint8_t s_tile[4][5 * 16];
+    __shared__ uint8_t s_u[4][U_SIZE];
+    __shared__ uint8_t s_cnb[4][CNB_SIZE];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int idx = blockIdx.x * 4 + wave;
+    if (idx >= n) return;
+    const uint8_t *blk = plane + (size_t)xy[2 * idx + 1] * stride + xy[2 * idx];
+    const int m = mode[idx];
+    if (kind == 0) {
+        uint8_t *nb = s_nb[wave];
+        if (lane < 17) nb[NB_TOP - 1 + lane] = blk[-(long)stride - 1 + lane];
+        else if (lane >= 32 && lane < 48) nb[NB_LEFT + lane - 32] = blk[(long)(lane - 32) * stride - 1];
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_s_waitcnt(0xc07f);
+        const Pred16 pp = pred16_setup(nb, lane);
+        const int x0 = (lane & 3) * 4, y = lane >> 2;
+        *(uint32_t *)(out + (size_t)idx * 256 + y * 16 + x0) = pred16_row4(nb, pp, m, x0, y);
+    } else if (kind == 1) {
+        uint8_t *nb = s_cnb[wave];
+        if (lane < 9) nb[CNB_TOP - 1 + lane] = blk[-(long)stride - 1 + lane];
+        else if (lane >= 16 && lane < 24) nb[CNB_LEFT + lane - 16] = blk[(long)(lane - 16) * stride - 1];
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_s_waitcnt(0xc07f);
+        const PredC pc = predc_setup(nb);
+        if (lane < 16) {
+            const int i = lane >> 2, j = lane & 3;
+            *(uint32_t *)(out + (size_t)idx * 64 + ((i >> 1) * 4 + j) * 8 + (i & 1) * 4) = predc_row4(nb, pc, m, i, j);
+        }
+    } else {
+        // 4x4: tile rows -1..3, columns -1..7 at offset (row+1)*16 + 4 + col
+        uint8_t *tile = s_tile[wave] + 16 + 4;
+        const int av = avail[idx];
+        if (lane < 9) tile[-16 - 1 + lane] = blk[-(long)stride - 1 + lane];
+        else if (lane >= 16 && lane < 20) tile[(lane - 16) * 16 - 1] = blk[(long)(lane - 16) * stride - 1];
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_s_waitcnt(0xc07f);
+        pred4_build_u(s_u[wave], tile, 16, av, lane);
+        // DC variants (modes 9..11 of the oracle) are selected by availability inside pred4_build_u: mode 2
+        const int mm = m > 8 ? 2 : m;
+        if (lane < 4) {
+            const uint32_t t4 = ((const uint32_t *)c_pred4_table.t)[mm * 4 + lane];
+            *(uint32_t *)(out + (size_t)idx * 16 + lane * 4) = pred4_row4(s_u[wave], t4);
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" {
+
+int x264gpu_dctq8x8(const uint8_t *d_enc, const uint8_t *d_pred, int n, int qp, int list, int16_t *d_coef, int16_t *d_levels,
+                    uint8_t *d_recon, void *stream)
+{
+    ARG_TRY(n >= 0 && d_enc && d_pred && qp >= 0 && qp <= 51 && (list == 0 || list == 1));
+    if (!n) return X264GPU_OK;
+    hipLaunchKernelGGL(k_dctq8x8, dim3((n + 31) / 32), dim3(256), 0, (hipStream_t)stream, d_enc, d_pred, n, make_q8(qp, list), d_coef, d_levels, d_recon);
+    HIP_TRY(hipGetLastError());
+    return X264GPU_OK;
+}
+
+int x264gpu_intra_predict(int kind, const uint8_t *d_plane, int stride, const int32_t *d_xy, const int32_t *d_mode,
+                          const int32_t *d_avail, int n, uint8_t *d_out, void *stream)
+{
+    ARG_TRY(kind >= 0 && kind <= 2 && d_plane && d_xy && d_mode && d_out && n >= 0 && (kind != 2 || d_avail));
+    if (!n) return X264GPU_OK;
+    hipLaunchKernelGGL(k_intra_predict, dim3((n + 3) / 4), dim3(256), 0, (hipStream_t)stream, kind, d_plane, stride, d_xy, d_mode, d_avail, n, d_out);
+    HIP_TRY(hipGetLastError());
+    return X264GPU_OK;
+}
+
+}  // extern "C"
