@@ -83,7 +83,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=4)
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--height", type=int, default=1080)
-    ap.add_argument("--streams", type=int, default=16, help="independent closed-GOP streams per GPU (lock-step batch)")
+    ap.add_argument("--streams", type=int, default=256, help="independent closed-GOP streams per GPU (lock-step batch)")
     ap.add_argument("--groups", type=int, default=2, help="stream groups on separate HIP streams (stage overlap)")
     ap.add_argument("--keyint", type=int, default=60)
     ap.add_argument("--qp", type=int, default=23)
@@ -119,7 +119,7 @@ def main():
     for g in range(G):
         cfg = Config(width=W, height=H, streams=per[g], refs=1, qp_i=qp_i, qp_p=qp_p, me_range=16, subme=7, deblock=1,
                      deblock_alpha=0, deblock_beta=0, chroma_qp_offset=0, deadzone_inter=21, deadzone_intra=11,
-                     dct_decimate=1, partitions=2)
+                     dct_decimate=1, partitions=3)
         h = C.c_void_p()
         lib.check(lib.x264gpu_encoder_create(C.byref(h), C.byref(cfg)), "encoder_create")
         n = lib.x264gpu_encoder_mb_count(h)
@@ -181,13 +181,13 @@ def main():
            "ms_per_step": round(dt / K * 1e3, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
            "dtype": "u8", "data": "synthetic",
            "config": {"workload": f"{W}x{H} yuv420p, {S} closed-GOP streams/GPU x {K} frames, keyint {args.keyint}, "
-                                  f"CQP {qp_i}/{qp_p}, me hex merange 16 subme 7, i16x16+i4x4, p16x16, ref 1, deblock 0:0",
+                                  f"CQP {qp_i}/{qp_p}, me hex merange 16 subme 7, partitions p8x8(16x8,8x16,8x8)+i4x4, ref 1, deblock 0:0",
                       "streams_per_gpu": S, "stream_groups": G, "frames_per_step": S * world},
            "roofline": roof}
     if rank == 0:
         import numpy as np
         types = np.bincount(mbs[0].cpu().numpy()[:, :, 0].reshape(-1), minlength=7)
-        out["config"]["mb_types_last_step"] = {"I4x4": int(types[0]), "I16x16": int(types[2]), "P16x16": int(types[4])}
+        out["config"]["mb_types_last_step"] = {"I4x4": int(types[0]), "I16x16": int(types[2]), "P16x16/16x8/8x16": int(types[4]), "P8x8": int(types[5])}
         if args.cpu_frames > 0:
             cfps, cdt = cpu_baseline(W, H, args.cpu_frames, args.keyint)
             out["cpu_baseline"] = {"value": round(cfps, 3), "unit": "frames/s", "cores": 1, "kind": "port",

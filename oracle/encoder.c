@@ -241,30 +241,26 @@ static const int8_t hex2[8][2] = { { -1, -2 }, { -2, 0 }, { -1, 2 }, { 1, 2 }, {
 static const int8_t square1[9][2] = { { 0, 0 }, { 0, -1 }, { 0, 1 }, { -1, 0 }, { 1, 0 }, { -1, -1 }, { -1, 1 }, { 1, -1 }, { 1, 1 } };
 static const int8_t mod6m1[8] = { 5, 0, 1, 2, 3, 4, 5, 0 };
 
-static me_result me_search_16x16(x264o_encoder *e, int mbx, int mby, int qp)
+/* Generic block search: w x h block at offset (ox,oy) inside macroblock (mbx,mby).  Start candidates are
+ * tried in order (first-best wins), then hexagon + square full-pel search on SAD and the sub-pel diamonds
+ * (half-pel on SAD, quarter-pel on SATD) — x264_me_search_ref + refine_subpel.  mvp = cost predictor. */
+static me_result me_search_block(x264o_encoder *e, int mbx, int mby, int ox, int oy, int w, int h, int qp,
+                                 const int mvp[2], const int (*cand)[2], int ncand)
 {
-    const pixel *fenc = e->fenc_y + (size_t)mby * 16 * e->fs + mbx * 16;
+    const pixel *fenc = e->fenc_y + (size_t)(mby * 16 + oy) * e->fs + mbx * 16 + ox;
     int ref = e->cur ^ 1;
     pixel *planes[4] = { luma_plane(e, ref, 0), luma_plane(e, ref, 1), luma_plane(e, ref, 2), luma_plane(e, ref, 3) };
-    const pixel *full = planes[0] + (size_t)mby * 16 * e->rs + mbx * 16;
+    const pixel *full = planes[0] + (size_t)(mby * 16 + oy) * e->rs + mbx * 16 + ox;
     const uint16_t *cm = cost_mv_for(e, qp);
-    int smin[2], smax[2], fmin[2], fmax[2], mvp[2];
+    int smin[2], smax[2], fmin[2], fmax[2];
     mv_limits(e, mbx, mby, smin, smax, fmin, fmax);
-    prev_mvp(e, mbx, mby, mvp);
     const uint16_t *cmx = cm - mvp[0], *cmy = cm - mvp[1];
-#define FPEL_COST(mx, my) (x264o_sad(fenc, e->fs, full + (my) * e->rs + (mx), e->rs, 16, 16) + cmx[(mx) * 4] + cmy[(my) * 4])
-    /* start candidates, in priority order: predictor, zero, co-located previous-frame MV */
-    int cand[3][2], ncand = 0, mi = mby * e->mbw + mbx;
-    cand[ncand][0] = clampi((mvp[0] + 2) >> 2, fmin[0], fmax[0]); cand[ncand][1] = clampi((mvp[1] + 2) >> 2, fmin[1], fmax[1]); ncand++;
-    cand[ncand][0] = clampi(0, fmin[0], fmax[0]); cand[ncand][1] = clampi(0, fmin[1], fmax[1]); ncand++;
-    if (e->reff[0][mi] >= 0) {
-        cand[ncand][0] = clampi((e->mvf[0][mi][0] + 2) >> 2, fmin[0], fmax[0]);
-        cand[ncand][1] = clampi((e->mvf[0][mi][1] + 2) >> 2, fmin[1], fmax[1]); ncand++;
-    }
+#define FPEL_COST(mx, my) (x264o_sad(fenc, e->fs, full + (my) * e->rs + (mx), e->rs, w, h) + cmx[(mx) * 4] + cmy[(my) * 4])
     int bmx = 0, bmy = 0, bcost = 1 << 28;
     for (int i = 0; i < ncand; i++) {
-        int c = FPEL_COST(cand[i][0], cand[i][1]);
-        if (c < bcost) { bcost = c; bmx = cand[i][0]; bmy = cand[i][1]; }
+        int cx = clampi(cand[i][0], fmin[0], fmax[0]), cy = clampi(cand[i][1], fmin[1], fmax[1]);
+        int c = FPEL_COST(cx, cy);
+        if (c < bcost) { bcost = c; bmx = cx; bmy = cy; }
     }
     /* hexagon search (radius 2), then 3x3 square refine; first-best wins ties, centre wins over all */
     {
@@ -308,14 +304,14 @@ static me_result me_search_16x16(x264o_encoder *e, int mbx, int mby, int qp)
             int omx = mx, omy = my;
             for (int k = 0; k < 4; k++) {
                 int cx = omx + dia[k][0], cy = omy + dia[k][1];
-                x264o_mc_luma(pred, 16, planes, e->rs, mbx * 16, mby * 16, cx, cy, 16, 16);
-                int c = x264o_sad(fenc, e->fs, pred, 16, 16, 16) + cmx[cx] + cmy[cy];
+                x264o_mc_luma(pred, 16, planes, e->rs, mbx * 16 + ox, mby * 16 + oy, cx, cy, w, h);
+                int c = x264o_sad(fenc, e->fs, pred, 16, w, h) + cmx[cx] + cmy[cy];
                 if (c < bcost) { bcost = c; mx = cx; my = cy; }
             }
             if (mx == omx && my == omy) break;
         }
-        x264o_mc_luma(pred, 16, planes, e->rs, mbx * 16, mby * 16, mx, my, 16, 16);
-        bcost = x264o_satd(fenc, e->fs, pred, 16, 16, 16) + cmx[mx] + cmy[my];
+        x264o_mc_luma(pred, 16, planes, e->rs, mbx * 16 + ox, mby * 16 + oy, mx, my, w, h);
+        bcost = x264o_satd(fenc, e->fs, pred, 16, w, h) + cmx[mx] + cmy[my];
         int bdir = -1;
         static const int8_t qd[4][2] = { { 0, -1 }, { 0, 1 }, { -1, 0 }, { 1, 0 } };
         for (int it = iters[sub][1]; it > 0; it--) {
@@ -324,8 +320,8 @@ static me_result me_search_16x16(x264o_encoder *e, int mbx, int mby, int qp)
             for (int k = 0; k < 4; k++) {
                 if ((k ^ 1) == odir) continue;     /* do not step back to where we came from */
                 int cx = omx + qd[k][0], cy = omy + qd[k][1];
-                x264o_mc_luma(pred, 16, planes, e->rs, mbx * 16, mby * 16, cx, cy, 16, 16);
-                int c = x264o_satd(fenc, e->fs, pred, 16, 16, 16) + cmx[cx] + cmy[cy];
+                x264o_mc_luma(pred, 16, planes, e->rs, mbx * 16 + ox, mby * 16 + oy, cx, cy, w, h);
+                int c = x264o_satd(fenc, e->fs, pred, 16, w, h) + cmx[cx] + cmy[cy];
                 if (c < bcost) { bcost = c; mx = cx; my = cy; bdir = k; }
             }
             if (mx == omx && my == omy) break;
@@ -333,6 +329,17 @@ static me_result me_search_16x16(x264o_encoder *e, int mbx, int mby, int qp)
     }
     me_result r = { mx, my, bcost };
     return r;
+}
+
+static me_result me_search_16x16(x264o_encoder *e, int mbx, int mby, int qp, int mvp[2])
+{
+    /* start candidates, in priority order: predictor, zero, co-located previous-frame MV */
+    int cand[3][2], ncand = 0, mi = mby * e->mbw + mbx;
+    prev_mvp(e, mbx, mby, mvp);
+    cand[ncand][0] = (mvp[0] + 2) >> 2; cand[ncand][1] = (mvp[1] + 2) >> 2; ncand++;
+    cand[ncand][0] = 0; cand[ncand][1] = 0; ncand++;
+    if (e->reff[0][mi] >= 0) { cand[ncand][0] = (e->mvf[0][mi][0] + 2) >> 2; cand[ncand][1] = (e->mvf[0][mi][1] + 2) >> 2; ncand++; }
+    return me_search_block(e, mbx, mby, 0, 0, 16, 16, qp, mvp, (const int (*)[2])cand, ncand);
 }
 
 /* intra 16x16 SATD estimate on SOURCE neighbours (lookahead-style; decides intra vs inter in P) */
@@ -355,23 +362,55 @@ static int intra16_estimate(x264o_encoder *e, int mbx, int mby, int lambda)
     return best;
 }
 
+/* Partition shapes of a P macroblock (D_16x16, D_16x8, D_8x16, D_8x8): block list per shape as
+ * {ox, oy, w, h, first 8x8 index, second 8x8 index or -1} */
+static const int8_t part_geom[4][4][6] = {
+    { { 0, 0, 16, 16, 0, -1 } },
+    { { 0, 0, 16, 8, 0, 1 }, { 0, 8, 16, 8, 2, 3 } },
+    { { 0, 0, 8, 16, 0, 2 }, { 8, 0, 8, 16, 1, 3 } },
+    { { 0, 0, 8, 8, 0, -1 }, { 8, 0, 8, 8, 1, -1 }, { 0, 8, 8, 8, 2, -1 }, { 8, 8, 8, 8, 3, -1 } } };
+static const int8_t part_count[4] = { 1, 2, 2, 4 };
+/* macroblock-type overhead in bits beyond P_L0_16x16: ue(1)/ue(2) = 3 bits, P_8x8 = ue(3) + 4 x ue(0) */
+static const int8_t part_extra_bits[4] = { 0, 2, 2, 8 };
+
 static void analyse_p_mb(x264o_encoder *e, int mbx, int mby, x264gpu_mb *mb)
 {
-    int qp = e->cfg.qp_p, lambda = x264o_lambda(qp), mi = mby * e->mbw + mbx;
-    me_result m = me_search_16x16(e, mbx, mby, qp);
+    int qp = e->cfg.qp_p, lambda = x264o_lambda(qp), mi = mby * e->mbw + mbx, mvp[2];
+    me_result m = me_search_16x16(e, mbx, mby, qp, mvp);
+    int best_cost = m.cost, best_shape = 0;
+    int best_mv[4][2] = { { m.mvx, m.mvy }, { m.mvx, m.mvy }, { m.mvx, m.mvy }, { m.mvx, m.mvy } };
+    if (e->cfg.partitions & 1) {
+        /* sub-partition searches start from the 16x16 vector; 16x8 / 8x16 only when 8x8 beats 16x16 */
+        int c0[1][2] = { { (m.mvx + 2) >> 2, (m.mvy + 2) >> 2 } };
+        static const int order[3] = { 3, 1, 2 };
+        for (int oi = 0; oi < 3; oi++) {
+            int shape = order[oi], cost = lambda * part_extra_bits[shape], mv[4][2];
+            if (oi > 0 && best_shape == 0) break;
+            for (int p = 0; p < part_count[shape]; p++) {
+                const int8_t *g = part_geom[shape][p];
+                me_result r = me_search_block(e, mbx, mby, g[0], g[1], g[2], g[3], qp, mvp, (const int (*)[2])c0, 1);
+                cost += r.cost;
+                mv[g[4]][0] = r.mvx; mv[g[4]][1] = r.mvy;
+                if (g[5] >= 0) { mv[g[5]][0] = r.mvx; mv[g[5]][1] = r.mvy; }
+            }
+            if (cost < best_cost) { best_cost = cost; best_shape = shape; memcpy(best_mv, mv, sizeof(mv)); }
+        }
+    }
     int icost = intra16_estimate(e, mbx, mby, lambda);
     memset(mb, 0, sizeof(*mb));
     mb->qp = (uint8_t)qp;
-    mb->aux[0] = m.cost; mb->aux[1] = icost;
-    if (icost < m.cost) {
+    mb->aux[0] = best_cost; mb->aux[1] = icost; mb->aux[2] = m.cost;
+    /* the field used as next frame's predictor always carries the 16x16 vector */
+    if (icost < best_cost) {
         mb->type = X264GPU_MB_I16x16;   /* provisional: real intra analysis happens in the intra stage */
         mb->cost = icost;
         e->reff[1][mi] = -1; e->mvf[1][mi][0] = e->mvf[1][mi][1] = 0;
         for (int k = 0; k < 4; k++) mb->ref[k] = -1;
     } else {
-        mb->type = X264GPU_MB_P_L0;
-        mb->cost = m.cost;
-        for (int k = 0; k < 4; k++) { mb->mv[k][0] = (int16_t)m.mvx; mb->mv[k][1] = (int16_t)m.mvy; mb->ref[k] = 0; }
+        mb->type = best_shape == 3 ? X264GPU_MB_P_8x8 : X264GPU_MB_P_L0;
+        mb->partition = (uint8_t)best_shape;
+        mb->cost = best_cost;
+        for (int k = 0; k < 4; k++) { mb->mv[k][0] = (int16_t)best_mv[k][0]; mb->mv[k][1] = (int16_t)best_mv[k][1]; mb->ref[k] = 0; }
         e->reff[1][mi] = 0; e->mvf[1][mi][0] = (int16_t)m.mvx; e->mvf[1][mi][1] = (int16_t)m.mvy;
     }
 }
@@ -383,9 +422,13 @@ static void encode_inter_mb(x264o_encoder *e, int mbx, int mby, x264gpu_mb *mb, 
     pixel *planes[4] = { luma_plane(e, ref, 0), luma_plane(e, ref, 1), luma_plane(e, ref, 2), luma_plane(e, ref, 3) };
     pixel *rec = luma_plane(e, e->cur, 0) + (size_t)mby * 16 * e->rs + mbx * 16;
     pixel *rec_uv = chroma_plane(e, e->cur) + (size_t)mby * 8 * e->rs + mbx * 16;
-    x264o_mc_luma(rec, e->rs, planes, e->rs, mbx * 16, mby * 16, mb->mv[0][0], mb->mv[0][1], 16, 16);
     pixel pu[64], pv[64];
-    x264o_mc_chroma(pu, pv, 8, chroma_plane(e, ref), e->rs, mbx * 8, mby * 8, mb->mv[0][0], mb->mv[0][1], 8, 8);
+    for (int k = 0; k < 4; k++) {      /* motion compensation per 8x8 quadrant (covers 16x16 / 16x8 / 8x16 / 8x8) */
+        int ox = (k & 1) * 8, oy = (k >> 1) * 8;
+        x264o_mc_luma(rec + oy * e->rs + ox, e->rs, planes, e->rs, mbx * 16 + ox, mby * 16 + oy, mb->mv[k][0], mb->mv[k][1], 8, 8);
+        x264o_mc_chroma(pu + (oy / 2) * 8 + ox / 2, pv + (oy / 2) * 8 + ox / 2, 8, chroma_plane(e, ref), e->rs, mbx * 8 + ox / 2, mby * 8 + oy / 2,
+                        mb->mv[k][0], mb->mv[k][1], 4, 4);
+    }
     for (int y = 0; y < 8; y++)
         for (int x = 0; x < 8; x++) { rec_uv[y * e->rs + 2 * x] = pu[y * 8 + x]; rec_uv[y * e->rs + 2 * x + 1] = pv[y * 8 + x]; }
     memset(lv, 0, X264GPU_MB_LEVELS * sizeof(int16_t));
@@ -428,11 +471,11 @@ static void intra_mb(x264o_encoder *e, int mbx, int mby, int qp, x264gpu_mb *mbs
     pixel *rec = luma_plane(e, e->cur, 0) + (size_t)mby * 16 * e->rs + mbx * 16;
     int left = mbx > 0, top = mby > 0;
     pixel pred[256];
-    int aux0 = mb->aux[0], aux1 = mb->aux[1];     /* keep the P-slice analysis diagnostics */
+    int aux0 = mb->aux[0], aux1 = mb->aux[1], aux2 = mb->aux[2];     /* keep the P-slice analysis diagnostics */
     memset(mb, 0, sizeof(*mb));
     memset(lv, 0, X264GPU_MB_LEVELS * sizeof(int16_t));
     mb->qp = (uint8_t)qp;
-    if (e->slice_type == X264GPU_SLICE_P) { mb->aux[0] = aux0; mb->aux[1] = aux1; }
+    if (e->slice_type == X264GPU_SLICE_P) { mb->aux[0] = aux0; mb->aux[1] = aux1; mb->aux[2] = aux2; }
     for (int k = 0; k < 4; k++) mb->ref[k] = -1;
     /* --- intra 16x16 mode decision (SATD + lambda*ue(mode)); order V,H,DC,P, first-best wins --- */
     int modes[4], n = 0, best16 = 1 << 28, mode16 = 0;
@@ -654,12 +697,12 @@ int x264o_encoder_encode(x264o_encoder *e, const uint8_t *i420, int slice_type, 
         for (int mby = 0; mby < e->mbh; mby++)
             for (int mbx = 0; mbx < e->mbw; mbx++) {
                 x264gpu_mb *mb = &mbs[mby * e->mbw + mbx];
-                if (mb->type == X264GPU_MB_P_L0) encode_inter_mb(e, mbx, mby, mb, levels + (size_t)(mby * e->mbw + mbx) * X264GPU_MB_LEVELS);
+                if (mb->type == X264GPU_MB_P_L0 || mb->type == X264GPU_MB_P_8x8) encode_inter_mb(e, mbx, mby, mb, levels + (size_t)(mby * e->mbw + mbx) * X264GPU_MB_LEVELS);
             }
         for (int mby = 0; mby < e->mbh; mby++)
             for (int mbx = 0; mbx < e->mbw; mbx++) {
                 x264gpu_mb *mb = &mbs[mby * e->mbw + mbx];
-                if (mb->type != X264GPU_MB_P_L0) intra_mb(e, mbx, mby, e->cfg.qp_p, mbs, levels + (size_t)(mby * e->mbw + mbx) * X264GPU_MB_LEVELS);
+                if (mb->type != X264GPU_MB_P_L0 && mb->type != X264GPU_MB_P_8x8) intra_mb(e, mbx, mby, e->cfg.qp_p, mbs, levels + (size_t)(mby * e->mbw + mbx) * X264GPU_MB_LEVELS);
             }
     }
     if (e->cfg.deblock) deblock_frame(e, mbs);

@@ -8,6 +8,7 @@
 #include "x264o.h"
 #include "../x264vfw_amd/host/cavlc_tables.hpp"
 #include <stdint.h>
+#include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 #include <vector>
@@ -43,7 +44,7 @@ const uint8_t kIdxOf[4][4] = { { 0, 1, 4, 5 }, { 2, 3, 6, 7 }, { 8, 9, 12, 13 },
 
 struct MbInfo {
     int intra, i16, skip;
-    int mvx, mvy, ref;       // ref -1 for intra
+    int mv8[4][2], ref8[4];  // motion per 8x8 block; ref -1 for intra
     int qp;
     uint8_t i4mode[16];
     uint8_t tc[24];          // total_coeff per block (for nC)
@@ -158,22 +159,27 @@ struct SliceDec {
     }
 
     struct Nb { bool avail; int ref, mvx, mvy; };
-    Nb nb(int x, int y, int cur_idx)
+    int cur_idx = 0, known8 = 0;     // current macroblock; mask of its 8x8 blocks with decoded motion
+    Nb blk8(int gx, int gy)
     {
         Nb n = { false, -1, 0, 0 };
-        if (x < 0 || y < 0 || x >= d.mbw || y >= d.mbh) return n;
-        int i = y * d.mbw + x;
-        if (i >= cur_idx) return n;
+        if (gx < 0 || gy < 0 || gx >= 2 * d.mbw || gy >= 2 * d.mbh) return n;
+        int i = (gy >> 1) * d.mbw + (gx >> 1), k = (gy & 1) * 2 + (gx & 1);
+        if (i > cur_idx || (i == cur_idx && !(known8 >> k & 1))) return n;
         n.avail = true;
         const MbInfo &m = d.mb[i];
-        if (!m.intra) { n.ref = m.ref; n.mvx = m.mvx; n.mvy = m.mvy; }
+        if (!m.intra) { n.ref = m.ref8[k]; n.mvx = m.mv8[k][0]; n.mvy = m.mv8[k][1]; }
         return n;
     }
-    void mvp(int mbx, int mby, int ref, int &px, int &py)
+    // 8.4.1.3: gx,gy = first 8x8 block of the partition, w8 its width in 8x8 units; shape 1 = 16x8, 2 = 8x16
+    void mvp(int gx, int gy, int w8, int shape, int part, int ref, int &px, int &py)
     {
-        int ci = mby * d.mbw + mbx;
-        Nb a = nb(mbx - 1, mby, ci), b = nb(mbx, mby - 1, ci), c = nb(mbx + 1, mby - 1, ci);
-        if (!c.avail) c = nb(mbx - 1, mby - 1, ci);
+        Nb a = blk8(gx - 1, gy), b = blk8(gx, gy - 1), c = blk8(gx + w8, gy - 1);
+        if (!c.avail) c = blk8(gx - 1, gy - 1);
+        if (shape == 1 && part == 0 && b.ref == ref) { px = b.mvx; py = b.mvy; return; }
+        if (shape == 1 && part == 1 && a.ref == ref) { px = a.mvx; py = a.mvy; return; }
+        if (shape == 2 && part == 0 && a.ref == ref) { px = a.mvx; py = a.mvy; return; }
+        if (shape == 2 && part == 1 && c.ref == ref) { px = c.mvx; py = c.mvy; return; }
         if (!b.avail && !c.avail && a.avail) { b = a; c = a; }
         int cnt = (a.ref == ref) + (b.ref == ref) + (c.ref == ref);
         if (cnt == 1) { const Nb &s = a.ref == ref ? a : b.ref == ref ? b : c; px = s.mvx; py = s.mvy; return; }
@@ -182,19 +188,23 @@ struct SliceDec {
     }
     void skip_mv(int mbx, int mby, int &px, int &py)
     {
-        int ci = mby * d.mbw + mbx;
-        Nb a = nb(mbx - 1, mby, ci), b = nb(mbx, mby - 1, ci);
+        Nb a = blk8(2 * mbx - 1, 2 * mby), b = blk8(2 * mbx, 2 * mby - 1);
         if (!a.avail || !b.avail || (a.ref == 0 && !a.mvx && !a.mvy) || (b.ref == 0 && !b.mvx && !b.mvy)) { px = py = 0; return; }
-        mvp(mbx, mby, 0, px, py);
+        mvp(2 * mbx, 2 * mby, 2, 0, 0, 0, px, py);
     }
 
-    void inter_pred(int mbx, int mby, int mvx, int mvy)
+    void inter_pred(int mbx, int mby, const MbInfo &m)
     {
         int ref = d.cur ^ 1;
         pixel *planes[4] = { d.Y(ref, 0), d.Y(ref, 1), d.Y(ref, 2), d.Y(ref, 3) };
-        x264o_mc_luma(d.Y(d.cur) + (size_t)mby * 16 * d.stride + mbx * 16, d.stride, planes, d.stride, mbx * 16, mby * 16, mvx, mvy, 16, 16);
         pixel pu[64], pv[64];
-        x264o_mc_chroma(pu, pv, 8, d.UV(ref), d.stride, mbx * 8, mby * 8, mvx, mvy, 8, 8);
+        for (int k = 0; k < 4; k++) {
+            int ox = (k & 1) * 8, oy = (k >> 1) * 8;
+            x264o_mc_luma(d.Y(d.cur) + (size_t)(mby * 16 + oy) * d.stride + mbx * 16 + ox, d.stride, planes, d.stride, mbx * 16 + ox, mby * 16 + oy,
+                          m.mv8[k][0], m.mv8[k][1], 8, 8);
+            x264o_mc_chroma(pu + (oy / 2) * 8 + ox / 2, pv + (oy / 2) * 8 + ox / 2, 8, d.UV(ref), d.stride, mbx * 8 + ox / 2, mby * 8 + oy / 2,
+                            m.mv8[k][0], m.mv8[k][1], 4, 4);
+        }
         pixel *uv = d.UV(d.cur) + (size_t)mby * 8 * d.stride + mbx * 16;
         for (int y = 0; y < 8; y++) for (int x = 0; x < 8; x++) { uv[y * d.stride + 2 * x] = pu[y * 8 + x]; uv[y * d.stride + 2 * x + 1] = pv[y * 8 + x]; }
     }
@@ -250,7 +260,7 @@ struct SliceDec {
     {
         pixel *rec = d.Y(d.cur) + (size_t)mby * 16 * d.stride + mbx * 16;
         int left = mbx > 0, top = mby > 0;
-        m.intra = 1; m.ref = -1; m.mvx = m.mvy = 0;
+        m.intra = 1; for (int k = 0; k < 4; k++) { m.ref8[k] = -1; m.mv8[k][0] = m.mv8[k][1] = 0; }
         int cbp_luma = 0, cbp_chroma = 0, i16mode = 0;
         if (mbtype == 0) {
             m.i16 = 0;
@@ -336,19 +346,33 @@ struct SliceDec {
         chroma_residual(mbx, mby, cbp_chroma, m, qpc);
     }
 
-    void inter_mb(int mbx, int mby, MbInfo &m)
+    void inter_mb(int mbx, int mby, int shape, MbInfo &m)
     {
+        static const int8_t geom[4][4][4] = { { { 0, 0, 2, 2 } }, { { 0, 0, 2, 1 }, { 0, 1, 2, 1 } }, { { 0, 0, 1, 2 }, { 1, 0, 1, 2 } },
+                                              { { 0, 0, 1, 1 }, { 1, 0, 1, 1 }, { 0, 1, 1, 1 }, { 1, 1, 1, 1 } } };
         m.intra = 0; m.i16 = 0; memset(m.i4mode, 2, 16);
-        int ref = d.num_ref_default > 1 ? (d.num_ref_default == 2 ? !br.get1() : (int)br.ue()) : 0;
-        int px, py;
-        mvp(mbx, mby, ref, px, py);
-        m.ref = ref; m.mvx = px + br.se(); m.mvy = py + br.se();
+        int nparts = shape == 0 ? 1 : shape == 3 ? 4 : 2, refs[4] = { 0, 0, 0, 0 };
+        if (shape == 3) for (int k = 0; k < 4; k++) if (br.ue() != 0) { br.err = true; return; }     // only P_L0_8x8 sub-macroblocks
+        if (d.num_ref_default > 1) for (int k = 0; k < nparts; k++) refs[k] = d.num_ref_default == 2 ? !br.get1() : (int)br.ue();
+        for (int k = 0; k < nparts; k++) {
+            const int8_t *g = geom[shape][k];
+            int px, py;
+            mvp(2 * mbx + g[0], 2 * mby + g[1], g[2], shape, k, refs[k], px, py);
+            int mvx = px + br.se(), mvy = py + br.se();
+            if (getenv("X264O_DEC_DEBUG")) fprintf(stderr, "mb %d,%d shape %d part %d mvp %d,%d mv %d,%d\n", mbx, mby, shape, k, px, py, mvx, mvy);
+            for (int yy = g[1]; yy < g[1] + g[3]; yy++)
+                for (int xx = g[0]; xx < g[0] + g[2]; xx++) {
+                    int b8 = yy * 2 + xx;
+                    m.ref8[b8] = refs[k]; m.mv8[b8][0] = mvx; m.mv8[b8][1] = mvy;
+                    known8 |= 1 << b8;
+                }
+        }
         int code = (int)br.ue(), cbp = -1;
         for (int i = 0; i < 48; i++) if (cbp_to_golomb_inter[i] == code) cbp = i;
         if (cbp < 0) { br.err = true; return; }
         if (cbp) qp += br.se();
         m.qp = qp;
-        inter_pred(mbx, mby, m.mvx, m.mvy);
+        inter_pred(mbx, mby, m);
         pixel *rec = d.Y(d.cur) + (size_t)mby * 16 * d.stride + mbx * 16;
         for (int b = 0; b < 16; b++) {
             if (!(cbp >> (b >> 2) & 1)) continue;
@@ -373,9 +397,11 @@ struct SliceDec {
                 while (run-- && i < n) {
                     MbInfo &m = d.mb[i];
                     int mbx = i % d.mbw, mby = i / d.mbw, px, py;
+                    cur_idx = i; known8 = 0;
                     skip_mv(mbx, mby, px, py);
-                    m.intra = 0; m.skip = 1; m.ref = 0; m.mvx = px; m.mvy = py; m.qp = qp; memset(m.i4mode, 2, 16);
-                    inter_pred(mbx, mby, px, py);
+                    m.intra = 0; m.skip = 1; m.qp = qp; memset(m.i4mode, 2, 16);
+                    for (int k = 0; k < 4; k++) { m.ref8[k] = 0; m.mv8[k][0] = px; m.mv8[k][1] = py; }
+                    inter_pred(mbx, mby, m);
                     i++;
                 }
                 if (i >= n || !br.more_rbsp_data()) break;
@@ -383,7 +409,8 @@ struct SliceDec {
             MbInfo &m = d.mb[i];
             int mbx = i % d.mbw, mby = i / d.mbw;
             int t = (int)br.ue();
-            if (slice_type == 0) { if (t == 0) inter_mb(mbx, mby, m); else if (t >= 5) intra_mb(mbx, mby, t - 5, m); else br.err = true; }
+            cur_idx = i; known8 = 0;
+            if (slice_type == 0) { if (t <= 3) inter_mb(mbx, mby, t, m); else if (t >= 5) intra_mb(mbx, mby, t - 5, m); else br.err = true; }
             else intra_mb(mbx, mby, t, m);
             i++;
         }
@@ -394,8 +421,9 @@ struct SliceDec {
     {
         if (p.intra || q.intra) return mbedge ? 4 : 3;
         if ((p.nz >> pb & 1) || (q.nz >> qb & 1)) return 2;
-        if (p.ref != q.ref) return 1;
-        return abs(p.mvx - q.mvx) >= 4 || abs(p.mvy - q.mvy) >= 4;
+        int p8 = pb >> 2, q8 = qb >> 2;           // block index / 4 = 8x8 quadrant in H.264 block order
+        if (p.ref8[p8] != q.ref8[q8]) return 1;
+        return abs(p.mv8[p8][0] - q.mv8[q8][0]) >= 4 || abs(p.mv8[p8][1] - q.mv8[q8][1]) >= 4;
     }
     void deblock()
     {

@@ -8,7 +8,7 @@ from synth import synth_frames
 
 pytestmark = pytest.mark.gpu
 
-FIELDS = ("aux", "type", "i16_mode", "chroma_mode", "qp", "cbp_luma", "cbp_chroma", "partition", "ref", "i4_mode", "mv",
+FIELDS = ("aux", "type", "partition", "i16_mode", "chroma_mode", "qp", "cbp_luma", "cbp_chroma", "ref", "i4_mode", "mv",
           "nnz", "cost")
 
 
@@ -41,6 +41,10 @@ def compare(tag, mbw, g_mb, o_mb, g_lv, o_lv, g_rec, o_rec):
     (176, 144, 3, dict(qp_i=35, qp_p=38)),
     (176, 144, 3, dict(qp_i=10, qp_p=12, subme=2)),
     (208, 120, 3, dict(subme=5)),      # height not a multiple of 16
+    (176, 144, 4, dict(partitions=3)),                       # P16x8 / P8x16 / P8x8 search
+    (352, 288, 3, dict(partitions=3, qp_i=28, qp_p=31)),
+    (208, 120, 3, dict(partitions=1, subme=4, dct_decimate=0)),
+    (64, 48, 3, dict(partitions=3, subme=1)),
 ])
 def test_pipeline_bitexact(gpu, w, h, nfr, kw):
     from gpu_enc import GpuEncoder

@@ -108,7 +108,9 @@ def test_open_without_gpu_fails_loudly():
 
 
 @pytest.mark.parametrize("w,h,kw", [(64, 48, {}), (176, 144, {}), (176, 144, dict(qp_i=36, qp_p=40)), (208, 120, dict(deblock=0)),
-                                     (96, 80, dict(qp_i=8, qp_p=10)), (64, 64, dict(partitions=0))])
+                                     (96, 80, dict(qp_i=8, qp_p=10)), (64, 64, dict(partitions=0)),
+                                     (176, 144, dict(partitions=3)), (352, 288, dict(partitions=3, qp_i=30, qp_p=33)),
+                                     (208, 120, dict(partitions=1, subme=4))])
 def test_cavlc_closed_loop(w, h, kw):
     """oracle records -> host CAVLC -> checker decoder == oracle reconstruction, I and P pictures"""
     nfr = 4

@@ -48,10 +48,121 @@ __device__ __forceinline__ int hex_dy(int i) { return (int)((0x20024420u >> (4 *
 __device__ __forceinline__ int sq_dx(int k) { return (int)((0x22002011u >> (4 * (k - 1))) & 15) - 1; }  // k = 1..8
 __device__ __forceinline__ int sq_dy(int k) { return (int)((0x20201120u >> (4 * (k - 1))) & 15) - 1; }
 
+// ------------------------------------------------------------------------------------------------
+// Sub-partition search (P16x8 / P8x16 / P8x8) in the Z layout: every partition of a shape is searched at
+// the same time, each on its own lanes (an 8x8 block is one DPP row of 16 lanes), with lane-private motion
+// state and predicated updates, so the wave runs ONE instruction stream for 2 or 4 independent hexagon /
+// square / half-pel / quarter-pel searches.  Restates oracle me_search_block for the partitions of a shape.
+// ------------------------------------------------------------------------------------------------
+struct PartCtx {
+    const uint8_t *win; int wx0, wy0;          // LDS search window (full-pel plane) and its picture origin
+    const uint16_t *cx, *cy;                   // LDS slices of the mv-cost table, index = qpel mv - cbase + 96
+    int cbx, cby;                              // qpel mv at slice centre
+    const uint8_t *p00; size_t pb; int rs;     // half-pel planes
+    int px, py, zx, zy; uint32_t cz;           // macroblock position, lane position, lane's 4 source pixels
+    int fmin0, fmax0, fmin1, fmax1, smin0, smax0, smin1, smax1;
+    int me_range, hp_it, qp_it, lane;
+};
+__device__ __forceinline__ int part_sum(int v, int shape)
+{
+    int r = row16_sum(v);
+    if (shape == 1) r += __shfl_xor(r, 16);
+    else if (shape == 2) r += __shfl_xor(r, 32);
+    return r;
+}
+__device__ __forceinline__ int pc_mvcost(const PartCtx &c, int qx, int qy) { return c.cx[qx - c.cbx + 96] + c.cy[qy - c.cby + 96]; }
+__device__ __forceinline__ int pc_fpel_cost(const PartCtx &c, int fx, int fy, int shape)
+{
+    const int off = (c.py + c.zy + fy - c.wy0) * WIN_STRIDE + (c.px + c.zx + fx - c.wx0);
+    const uint32_t *w = (const uint32_t *)(c.win + (off & ~3));
+    const uint32_t ref = __builtin_amdgcn_alignbyte(w[1], w[0], off & 3);
+    return part_sum(sad4(ref, c.cz), shape) + pc_mvcost(c, fx * 4, fy * 4);
+}
+// returns the partition cost (uniform over the partition's lanes) and this lane's partition mv (qpel)
+__device__ int search_shape(const PartCtx &c, int shape, int c0x, int c0y, int &out_mx, int &out_my)
+{
+    int bx = c0x, by = c0y;
+    unsigned key = (unsigned)pc_fpel_cost(c, bx, by, shape) << 3;
+    for (int i = 1; i <= 6; i++) key = min(key, ((unsigned)pc_fpel_cost(c, bx + hex_dx(i), by + hex_dy(i), shape) << 3) | (unsigned)(i + 1));
+    bool running = (key & 7) != 0;
+    int dir = running ? (int)(key & 7) - 2 : 0;
+    if (running) { bx += hex_dx(dir + 1); by += hex_dy(dir + 1); }
+    for (int it = (c.me_range >> 1) - 1; it > 0; it--) {
+        if (!__any(running)) break;
+        running = running && bx >= c.fmin0 && bx <= c.fmax0 && by >= c.fmin1 && by <= c.fmax1;
+        unsigned k2 = key & ~7u;
+        for (int t = 0; t < 3; t++) k2 = min(k2, ((unsigned)pc_fpel_cost(c, bx + hex_dx(dir + t), by + hex_dy(dir + t), shape) << 3) | (unsigned)(t + 1));
+        if (running) {
+            key = k2;
+            if (!(key & 7)) running = false;
+            else {
+                dir += (int)(key & 7) - 2;
+                dir = dir < 0 ? 5 : dir > 5 ? 0 : dir;
+                bx += hex_dx(dir + 1); by += hex_dy(dir + 1);
+            }
+        }
+    }
+    int bcost = (int)(key >> 3);
+    {
+        unsigned sk = (unsigned)bcost << 4;
+        for (int q = 1; q <= 8; q++) sk = min(sk, ((unsigned)pc_fpel_cost(c, bx + sq_dx(q), by + sq_dy(q), shape) << 4) | (unsigned)q);
+        const int bd = sk & 15;
+        bcost = (int)(sk >> 4);
+        if (bd) { bx += sq_dx(bd); by += sq_dy(bd); }
+    }
+    int mx = bx * 4, my = by * 4;
+    if (c.hp_it > 0) {
+        int e[4];
+        unpack4(c.cz, e);
+        bool hp_run = true;
+        for (int it = c.hp_it; it > 0; it--) {
+            if (!__any(hp_run)) break;
+            unsigned kk = 0xffffffffu;
+            for (int q = 0; q < 4; q++) {
+                const int cxq = mx + (q == 2 ? -2 : q == 3 ? 2 : 0), cyq = my + (q == 0 ? -2 : q == 1 ? 2 : 0);
+                const int cst = part_sum(sad4(mc_luma_row4(c.p00, c.pb, c.rs, c.px + c.zx, c.py + c.zy, cxq, cyq), c.cz), shape) + pc_mvcost(c, cxq, cyq);
+                kk = min(kk, ((unsigned)cst << 2) | (unsigned)q);
+            }
+            if (hp_run && (int)(kk >> 2) < bcost) {
+                const int b = kk & 3;
+                bcost = (int)(kk >> 2);
+                mx += b == 2 ? -2 : b == 3 ? 2 : 0; my += b == 0 ? -2 : b == 1 ? 2 : 0;
+            } else hp_run = false;
+        }
+        {
+            int p[4], d[4];
+            unpack4(mc_luma_row4(c.p00, c.pb, c.rs, c.px + c.zx, c.py + c.zy, mx, my), p);
+#pragma unroll
+            for (int i = 0; i < 4; i++) d[i] = e[i] - p[i];
+            bcost = (part_sum(satd_quad_partial(d, c.lane), shape) >> 1) + pc_mvcost(c, mx, my);
+        }
+        int bdir = -1;
+        bool qp_run = true;
+        for (int it = c.qp_it; it > 0; it--) {
+            if (!__any(qp_run)) break;
+            qp_run = qp_run && !(my <= c.smin1 || my >= c.smax1 || mx <= c.smin0 || mx >= c.smax0);
+            const int odir = bdir, omx = mx, omy = my;
+            for (int q = 0; q < 4; q++) {
+                const int cxq = omx + (q == 2 ? -1 : q == 3 ? 1 : 0), cyq = omy + (q == 0 ? -1 : q == 1 ? 1 : 0);
+                int p[4], d[4];
+                unpack4(mc_luma_row4(c.p00, c.pb, c.rs, c.px + c.zx, c.py + c.zy, cxq, cyq), p);
+#pragma unroll
+                for (int i = 0; i < 4; i++) d[i] = e[i] - p[i];
+                const int cst = (part_sum(satd_quad_partial(d, c.lane), shape) >> 1) + pc_mvcost(c, cxq, cyq);
+                if (qp_run && (q ^ 1) != odir && cst < bcost) { bcost = cst; mx = cxq; my = cyq; bdir = q; }
+            }
+            if (mx == omx && my == omy) qp_run = false;
+        }
+    }
+    out_mx = mx; out_my = my;
+    return bcost;
+}
+
 __global__ __launch_bounds__(256) void k_analyse_p(EncK k)
 {
     __shared__ __attribute__((aligned(16))) uint8_t s_win[4][WIN_ROWS * WIN_STRIDE];
     __shared__ uint8_t s_nb[4][NB_SIZE];
+    __shared__ uint16_t s_cost[4][2][192];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int mbi = blockIdx.x * 4 + wave, s = blockIdx.y;
     if (mbi >= k.nmb) return;                       // wave-uniform; no block-wide barriers below
@@ -224,6 +335,48 @@ __global__ __launch_bounds__(256) void k_analyse_p(EncK k)
         }
     }
 
+    // ---- sub-partitions (oracle analyse_p_mb): 8x8 first, 16x8 / 8x16 only if 8x8 beat 16x16 ----
+    const int cost16 = bcost;
+    int best_cost = bcost, best_shape = 0;
+    int lmx = mx, lmy = my;                         // this lane's 8x8 block's motion vector (lane>>4 = 8x8 index)
+    if (k.partitions & 1) {
+        const int c0x = clampi((mx + 2) >> 2, fmin0, fmax0), c0y = clampi((my + 2) >> 2, fmin1, fmax1);
+        int pwx0 = clampi((px + c0x - WIN_R) & ~7, -PAD, k.cw + PAD - WIN_COLS), pwy0 = clampi(py + c0y - WIN_R, -PAD, k.ch + PAD - WIN_ROWS);
+        __builtin_amdgcn_wave_barrier();
+        for (int i = lane; i < WIN_ROWS * 8; i += 64) {
+            const int row = i >> 3, col = (i & 7) * 8;
+            const uint2 v = *(const uint2 *)(p00 + (long)(pwy0 + row) * k.rs + pwx0 + col);
+            uint32_t *d = (uint32_t *)(win + row * WIN_STRIDE + col);
+            d[0] = v.x; d[1] = v.y;
+        }
+        for (int i = lane; i < 192; i += 64) {
+            s_cost[wave][0][i] = cmx[c0x * 4 + i - 96];
+            s_cost[wave][1][i] = cmy[c0y * 4 + i - 96];
+        }
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_s_waitcnt(0xc07f);
+        PartCtx pc;
+        pc.win = win; pc.wx0 = pwx0; pc.wy0 = pwy0; pc.cx = s_cost[wave][0]; pc.cy = s_cost[wave][1]; pc.cbx = c0x * 4; pc.cby = c0y * 4;
+        pc.p00 = p00; pc.pb = k.plane_bytes; pc.rs = k.rs; pc.px = px; pc.py = py; pc.zx = zx; pc.zy = zy; pc.cz = cz;
+        pc.fmin0 = fmin0; pc.fmax0 = fmax0; pc.fmin1 = fmin1; pc.fmax1 = fmax1; pc.smin0 = smin0; pc.smax0 = smax0; pc.smin1 = smin1; pc.smax1 = smax1;
+        pc.me_range = k.me_range; pc.lane = lane;
+        const int sub = min(k.subme, 11);
+        pc.hp_it = sub < 2 ? 0 : sub < 6 ? 1 : sub < 8 ? 2 : 4;
+        pc.qp_it = sub < 4 ? 0 : sub == 4 ? 1 : sub < 8 ? 2 : 10;
+        for (int oi = 0; oi < 3; oi++) {
+            const int shape = oi == 0 ? 3 : oi;
+            if (oi > 0 && best_shape == 0) break;
+            int smx, smy;
+            const int pcost = search_shape(pc, shape, c0x, c0y, smx, smy);
+            int total = k.lambda * (shape == 3 ? 8 : 2);
+            if (shape == 3) total += __builtin_amdgcn_readlane(pcost, 0) + __builtin_amdgcn_readlane(pcost, 16) + __builtin_amdgcn_readlane(pcost, 32) + __builtin_amdgcn_readlane(pcost, 48);
+            else if (shape == 1) total += __builtin_amdgcn_readlane(pcost, 0) + __builtin_amdgcn_readlane(pcost, 32);
+            else total += __builtin_amdgcn_readlane(pcost, 0) + __builtin_amdgcn_readlane(pcost, 16);
+            if (total < best_cost) { best_cost = total; best_shape = shape; lmx = smx; lmy = smy; }
+        }
+    }
+    bcost = best_cost;
+
     // ---- intra 16x16 estimate on source neighbours (oracle intra16_estimate) ----
     const bool left = mbx > 0, top = mby > 0;
     if (lane < 25) nb[NB_TOP - 1 + lane] = (top && (lane > 0 || left)) ? fenc[-(long)k.fs - 1 + lane] : 128;   // tl + top[0..23]
@@ -250,12 +403,16 @@ __global__ __launch_bounds__(256) void k_analyse_p(EncK k)
     }
 
     // ---- record ----
+    const int m0x = __builtin_amdgcn_readlane(lmx, 0), m0y = __builtin_amdgcn_readlane(lmy, 0);
+    const int m1x = __builtin_amdgcn_readlane(lmx, 16), m1y = __builtin_amdgcn_readlane(lmy, 16);
+    const int m2x = __builtin_amdgcn_readlane(lmx, 32), m2y = __builtin_amdgcn_readlane(lmy, 32);
+    const int m3x = __builtin_amdgcn_readlane(lmx, 48), m3y = __builtin_amdgcn_readlane(lmy, 48);
     if (lane == 0) {
         x264gpu_mb *mb = k.mb + (size_t)s * k.nmb + mbi;
         x264gpu_mb rec;
         __builtin_memset(&rec, 0, sizeof(rec));
         rec.qp = (uint8_t)k.qp;
-        rec.aux[0] = bcost; rec.aux[1] = icost;
+        rec.aux[0] = bcost; rec.aux[1] = icost; rec.aux[2] = cost16;
         int16_t *mo = k.mvf_cur + ((size_t)s * k.nmb + mbi) * 2;
         if (icost < bcost) {
             rec.type = X264GPU_MB_I16x16;
@@ -263,10 +420,13 @@ __global__ __launch_bounds__(256) void k_analyse_p(EncK k)
             for (int i = 0; i < 4; i++) rec.ref[i] = -1;
             k.reff_cur[(size_t)s * k.nmb + mbi] = -1; mo[0] = 0; mo[1] = 0;
         } else {
-            rec.type = X264GPU_MB_P_L0;
+            rec.type = best_shape == 3 ? X264GPU_MB_P_8x8 : X264GPU_MB_P_L0;
+            rec.partition = (uint8_t)best_shape;
             rec.cost = bcost;
-            for (int i = 0; i < 4; i++) { rec.mv[i][0] = (int16_t)mx; rec.mv[i][1] = (int16_t)my; rec.ref[i] = 0; }
-            k.reff_cur[(size_t)s * k.nmb + mbi] = 0; mo[0] = (int16_t)mx; mo[1] = (int16_t)my;
+            rec.mv[0][0] = (int16_t)m0x; rec.mv[0][1] = (int16_t)m0y; rec.mv[1][0] = (int16_t)m1x; rec.mv[1][1] = (int16_t)m1y;
+            rec.mv[2][0] = (int16_t)m2x; rec.mv[2][1] = (int16_t)m2y; rec.mv[3][0] = (int16_t)m3x; rec.mv[3][1] = (int16_t)m3y;
+            for (int i = 0; i < 4; i++) rec.ref[i] = 0;
+            k.reff_cur[(size_t)s * k.nmb + mbi] = 0; mo[0] = (int16_t)mx; mo[1] = (int16_t)my;     // field carries the 16x16 vector
         }
         *mb = rec;
     }

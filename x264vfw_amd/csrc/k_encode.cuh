@@ -40,9 +40,9 @@ __global__ __launch_bounds__(256) void k_encode_inter(EncK k)
     const int mbi = blockIdx.x * 4 + wave, s = blockIdx.y;
     if (mbi >= k.nmb) return;
     x264gpu_mb *mbp = k.mb + (size_t)s * k.nmb + mbi;
-    if (mbp->type != X264GPU_MB_P_L0) return;       // wave-uniform
+    if (mbp->type != X264GPU_MB_P_L0 && mbp->type != X264GPU_MB_P_8x8) return;       // wave-uniform
     const int mbx = mbi % k.mbw, mby = mbi / k.mbw, px = mbx * 16, py = mby * 16;
-    const int mvx = mbp->mv[0][0], mvy = mbp->mv[0][1];
+    const int mvx = mbp->mv[lane >> 4][0], mvy = mbp->mv[lane >> 4][1];     // luma: lane>>4 = 8x8 block (partition motion)
     int16_t *lv = k.levels + ((size_t)s * k.nmb + mbi) * X264GPU_MB_LEVELS;
     const uint8_t *fenc = k.fenc_y + (size_t)s * k.fency_bytes + (size_t)py * k.fs + px;
     const int j = lane & 3, blk = lane >> 2, zx = z_x0(lane), zy = z_y(lane);
@@ -86,7 +86,7 @@ __global__ __launch_bounds__(256) void k_encode_inter(EncK k)
     // ---- chroma (lanes 0..31: plane = lane>>4, block = (lane>>2)&3) ----
     const int c = (lane >> 4) & 1, ci = (lane >> 2) & 3, cx0 = (ci & 1) * 4, cyy = (ci >> 1) * 4 + j;
     uint32_t pu, pv;
-    mc_chroma_row4(ref_chroma00(k, s), k.rs, mbx * 8 + cx0, mby * 8 + cyy, mvx, mvy, pu, pv);
+    mc_chroma_row4(ref_chroma00(k, s), k.rs, mbx * 8 + cx0, mby * 8 + cyy, mbp->mv[ci][0], mbp->mv[ci][1], pu, pv);   // chroma 4x4 block ci <-> luma 8x8 ci
     const uint8_t *fuv = k.fenc_uv + (size_t)s * k.fencuv_bytes + (size_t)(mby * 8 + cyy) * k.fs + px + 2 * cx0;
     const uint2 fe = *(const uint2 *)fuv;
     const uint32_t cenc = nv12_pick(fe.x, fe.y, c), cpred = c ? pv : pu;

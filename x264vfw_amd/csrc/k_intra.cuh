@@ -171,7 +171,7 @@ __device__ void intra_mb_wave(const EncK &k, IntraLds &L, int wave, int lane, in
     __builtin_memset(&recd, 0, sizeof(recd));
     recd.qp = (uint8_t)qp;
     for (int i = 0; i < 4; i++) recd.ref[i] = -1;
-    if (k.slice_type == X264GPU_SLICE_P) { recd.aux[0] = mbs[mbi].aux[0]; recd.aux[1] = mbs[mbi].aux[1]; }
+    if (k.slice_type == X264GPU_SLICE_P) { recd.aux[0] = mbs[mbi].aux[0]; recd.aux[1] = mbs[mbi].aux[1]; recd.aux[2] = mbs[mbi].aux[2]; }
 
     if (use_i4) {
         recd.type = X264GPU_MB_I4x4;
@@ -308,7 +308,7 @@ __global__ __launch_bounds__(1024) void k_intra(EncK k)
     for (int row = wave; row < k.mbh; row += 16) {
         for (int x0 = 0; x0 < k.mbw; x0 += 64) {
             bool is_intra = false;
-            if (x0 + lane < k.mbw) is_intra = k.slice_type == X264GPU_SLICE_I || mbs[row * k.mbw + x0 + lane].type != X264GPU_MB_P_L0;
+            if (x0 + lane < k.mbw) { const int t = mbs[row * k.mbw + x0 + lane].type; is_intra = k.slice_type == X264GPU_SLICE_I || (t != X264GPU_MB_P_L0 && t != X264GPU_MB_P_8x8); }
             unsigned long long todo = __ballot(is_intra);
             const int chunk_end = min(x0 + 64, k.mbw);
             // everything left of the next intra macroblock of this row is already reconstructed

@@ -108,23 +108,37 @@ struct SliceCtx {
         bw.put((uint32_t)code, prefix - 3);
     }
 
-    // ---- motion vector prediction (8.4.1.3) for a 16x16 partition with refIdx 0 ----
+    // ---- motion vector prediction (8.4.1.3) on an 8x8-granular motion cache (smallest partition is 8x8) ----
     struct Nb { bool avail; int ref; int mvx, mvy; };
-    Nb neighbour(int mbx, int mby) const
+    int cur_mb = 0;               // macroblock being coded
+    int done8 = 0;                // 8x8 blocks of the current macroblock whose motion is already known
+    Nb cur8[4];                   // motion of the current macroblock's 8x8 blocks (valid where done8 is set)
+    Nb block8(int gx, int gy) const
     {
         Nb n = { false, -1, 0, 0 };
-        if (mbx < 0 || mby < 0 || mbx >= p.mbw || mby >= p.mbh) return n;
-        int i = mby * p.mbw + mbx;
+        if (gx < 0 || gy < 0 || gx >= 2 * p.mbw || gy >= 2 * p.mbh) return n;
+        int i = (gy >> 1) * p.mbw + (gx >> 1), k = (gy & 1) * 2 + (gx & 1);
+        if (i == cur_mb) { if (done8 >> k & 1) return cur8[k]; return n; }
         if (!coded[i]) return n;
         n.avail = true;
         const x264gpu_mb &m = mbs[i];
-        if (!is_intra(m)) { n.ref = m.ref[0]; n.mvx = m.mv[0][0]; n.mvy = m.mv[0][1]; }
+        if (!is_intra(m)) { n.ref = m.ref[k]; n.mvx = m.mv[k][0]; n.mvy = m.mv[k][1]; }
         return n;
     }
-    void mvp16x16(int mbx, int mby, int ref, int &px, int &py) const
+    // partition = 8x8 blocks [bx8, bx8+w8) x [by8, by8+h8) of macroblock (mbx,mby); shape/part select the
+    // directional rules of 16x8 / 8x16 partitions
+    void mvp_part(int mbx, int mby, int bx8, int by8, int w8, int shape, int part, int ref, int &px, int &py) const
     {
-        Nb a = neighbour(mbx - 1, mby), b = neighbour(mbx, mby - 1), c = neighbour(mbx + 1, mby - 1);
-        if (!c.avail) c = neighbour(mbx - 1, mby - 1);
+        int gx = 2 * mbx + bx8, gy = 2 * mby + by8;
+        Nb a = block8(gx - 1, gy), b = block8(gx, gy - 1), c = block8(gx + w8, gy - 1);
+        if (!c.avail) c = block8(gx - 1, gy - 1);
+        if (shape == 1) {
+            if (part == 0 && b.ref == ref) { px = b.mvx; py = b.mvy; return; }
+            if (part == 1 && a.ref == ref) { px = a.mvx; py = a.mvy; return; }
+        } else if (shape == 2) {
+            if (part == 0 && a.ref == ref) { px = a.mvx; py = a.mvy; return; }
+            if (part == 1 && c.ref == ref) { px = c.mvx; py = c.mvy; return; }
+        }
         if (!b.avail && !c.avail && a.avail) { b = a; c = a; }
         int na = a.ref == ref, nb = b.ref == ref, nc = c.ref == ref;
         if (na + nb + nc == 1) {
@@ -137,9 +151,9 @@ struct SliceCtx {
     }
     void pskip_mv(int mbx, int mby, int &px, int &py) const
     {
-        Nb a = neighbour(mbx - 1, mby), b = neighbour(mbx, mby - 1);
+        Nb a = block8(2 * mbx - 1, 2 * mby), b = block8(2 * mbx, 2 * mby - 1);
         if (!a.avail || !b.avail || (a.ref == 0 && a.mvx == 0 && a.mvy == 0) || (b.ref == 0 && b.mvx == 0 && b.mvy == 0)) { px = py = 0; return; }
-        mvp16x16(mbx, mby, 0, px, py);
+        mvp_part(mbx, mby, 0, 0, 2, 0, 0, 0, px, py);
     }
 
     // predicted intra 4x4 mode (8.3.1.1)
@@ -210,17 +224,34 @@ struct SliceCtx {
                 else {
                     int px, py;
                     bool skip = false;
+                    cur_mb = i; done8 = 0;
                     if (m.partition == 0 && m.ref[0] == 0 && !m.cbp_luma && !m.cbp_chroma) {
                         pskip_mv(mbx, mby, px, py);
                         skip = px == m.mv[0][0] && py == m.mv[0][1];
                     }
                     if (skip) { skip_run++; skipped[i] = 1; if (stats) stats->skip++; }
                     else {
+                        // partition geometry in 8x8 units: {bx8, by8, w8, h8}
+                        static const int8_t geom[4][4][4] = { { { 0, 0, 2, 2 } }, { { 0, 0, 2, 1 }, { 0, 1, 2, 1 } },
+                                                              { { 0, 0, 1, 2 }, { 1, 0, 1, 2 } },
+                                                              { { 0, 0, 1, 1 }, { 1, 0, 1, 1 }, { 0, 1, 1, 1 }, { 1, 1, 1, 1 } } };
+                        const int nparts = m.partition == 0 ? 1 : m.partition == 3 ? 4 : 2;
                         bw.ue(skip_run); skip_run = 0;
-                        bw.ue(0);                                            // P_L0_16x16
-                        if (p.num_ref > 1) bw.te(p.num_ref - 1, m.ref[0]);
-                        mvp16x16(mbx, mby, m.ref[0], px, py);
-                        bw.se(m.mv[0][0] - px); bw.se(m.mv[0][1] - py);
+                        bw.ue(m.partition);                                  // P_L0_16x16 / P_L0_L0_16x8 / P_L0_L0_8x16 / P_8x8
+                        if (m.partition == 3) for (int k = 0; k < 4; k++) bw.ue(0);      // sub_mb_type P_L0_8x8
+                        if (p.num_ref > 1)
+                            for (int k = 0; k < nparts; k++) { const int8_t *g = geom[m.partition][k]; bw.te(p.num_ref - 1, m.ref[g[1] * 2 + g[0]]); }
+                        for (int k = 0; k < nparts; k++) {
+                            const int8_t *g = geom[m.partition][k];
+                            int b8 = g[1] * 2 + g[0];
+                            mvp_part(mbx, mby, g[0], g[1], g[2], m.partition, k, m.ref[b8], px, py);
+                            bw.se(m.mv[b8][0] - px); bw.se(m.mv[b8][1] - py);
+                            for (int yy = g[1]; yy < g[1] + g[3]; yy++)
+                                for (int xx = g[0]; xx < g[0] + g[2]; xx++) {
+                                    cur8[yy * 2 + xx] = Nb{ true, m.ref[b8], m.mv[b8][0], m.mv[b8][1] };
+                                    done8 |= 1 << (yy * 2 + xx);
+                                }
+                        }
                         bw.ue(cbp_to_golomb_inter[m.cbp_luma | (m.cbp_chroma << 4)]);
                         if (m.cbp_luma || m.cbp_chroma) bw.se(0);
                         write_residual(mbx, mby, m, lv);
