@@ -67,7 +67,7 @@ def cpu_baseline(w, h, nframes, keyint):
     import oracle_lib as O
     from synth import synth_frames
     frames = synth_frames(w, h, nframes, seed=0x264, scene_len=10 ** 9)
-    enc = O.OracleEncoder(O.default_config(w, h))
+    enc = O.OracleEncoder(O.default_config(w, h, refs=3, partitions=3))
     t0 = time.perf_counter()
     for i, f in enumerate(frames):
         enc.encode(np.ascontiguousarray(f), 2 if i % keyint == 0 else 0)
@@ -87,6 +87,7 @@ def main():
     ap.add_argument("--groups", type=int, default=2, help="stream groups on separate HIP streams (stage overlap)")
     ap.add_argument("--keyint", type=int, default=60)
     ap.add_argument("--qp", type=int, default=23)
+    ap.add_argument("--refs", type=int, default=3, help="reference frames (medium: 3)")
     ap.add_argument("--cpu-frames", type=int, default=12, help="frames of the CPU-baseline sample (0 = skip)")
     args = ap.parse_args()
 
@@ -117,7 +118,7 @@ def main():
     data = [synth_batch(torch, per[g], nfr, W, H, shard.stream_seed(0x264, gids[sum(per[:g])]), dev) for g in range(G)]
     encs, hs, mbs, lvs, streams = [], [], [], [], []
     for g in range(G):
-        cfg = Config(width=W, height=H, streams=per[g], refs=1, qp_i=qp_i, qp_p=qp_p, me_range=16, subme=7, deblock=1,
+        cfg = Config(width=W, height=H, streams=per[g], refs=args.refs, qp_i=qp_i, qp_p=qp_p, me_range=16, subme=7, deblock=1,
                      deblock_alpha=0, deblock_beta=0, chroma_qp_offset=0, deadzone_inter=21, deadzone_intra=11,
                      dct_decimate=1, partitions=3)
         h = C.c_void_p()
@@ -181,7 +182,7 @@ def main():
            "ms_per_step": round(dt / K * 1e3, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
            "dtype": "u8", "data": "synthetic",
            "config": {"workload": f"{W}x{H} yuv420p, {S} closed-GOP streams/GPU x {K} frames, keyint {args.keyint}, "
-                                  f"CQP {qp_i}/{qp_p}, me hex merange 16 subme 7, partitions p8x8(16x8,8x16,8x8)+i4x4, ref 1, deblock 0:0",
+                                  f"CQP {qp_i}/{qp_p}, me hex merange 16 subme 7, partitions p8x8(16x8,8x16,8x8)+i4x4, ref {args.refs}, deblock 0:0",
                       "streams_per_gpu": S, "stream_groups": G, "frames_per_step": S * world},
            "roofline": roof}
     if rank == 0:

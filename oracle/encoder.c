@@ -26,6 +26,7 @@
 #define PAD 32          /* luma padding of reference planes */
 #define CPAD 16         /* chroma padding (samples) */
 #define MVCOST_HALF 32768
+#define X264O_MAX_SLOTS 5     /* up to 4 reference frames + current */
 
 typedef struct x264o_encoder {
     x264gpu_config cfg;
@@ -34,8 +35,10 @@ typedef struct x264o_encoder {
     pixel *fenc_y, *fenc_uv;
     int rs;                      /* reference plane stride */
     size_t plane_bytes, cplane_bytes;
-    pixel *luma[2];              /* 4 padded planes each */
-    pixel *chroma[2];            /* padded NV12 */
+    pixel *luma[X264O_MAX_SLOTS];   /* DPB slots: 4 padded planes each (refs + the picture being built) */
+    pixel *chroma[X264O_MAX_SLOTS]; /* padded NV12 */
+    int slots;                   /* refs + 1 */
+    int nref;                    /* reference pictures usable by the current P slice */
     int cur;                     /* DPB slot being reconstructed */
     int16_t (*mvf[2])[2];        /* per-MB mv field: [0] previous frame, [1] current */
     int8_t *reff[2];             /* per-MB ref (-1 = intra) */
@@ -69,6 +72,8 @@ void x264o_build_cost_mv(uint16_t *tab /* 2*MVCOST_HALF entries */, int lambda)
     tab[0] = tab[1];
 }
 
+/* DPB slot of reference index r of the current P slice: r = 0 is the most recent picture */
+static int ref_slot(const x264o_encoder *e, int r) { return (e->cur - 1 - r + 2 * e->slots) % e->slots; }
 static pixel *luma_plane(x264o_encoder *e, int slot, int k) { return e->luma[slot] + k * e->plane_bytes + (size_t)PAD * e->rs + PAD; }
 static pixel *chroma_plane(x264o_encoder *e, int slot) { return e->chroma[slot] + (size_t)CPAD * e->rs + 2 * CPAD; }
 
@@ -84,9 +89,12 @@ x264o_encoder *x264o_encoder_create(const x264gpu_config *cfg)
     e->rs = (e->cw + 2 * PAD + 63) / 64 * 64;
     e->plane_bytes = (size_t)e->rs * (e->ch + 2 * PAD);
     e->cplane_bytes = (size_t)e->rs * (e->ch / 2 + 2 * CPAD);
-    for (int s = 0; s < 2; s++) {
+    e->slots = clampi(cfg->refs, 1, X264O_MAX_SLOTS - 1) + 1;
+    for (int s = 0; s < e->slots; s++) {
         e->luma[s] = calloc(4, e->plane_bytes);
         e->chroma[s] = calloc(1, e->cplane_bytes);
+    }
+    for (int s = 0; s < 2; s++) {
         e->mvf[s] = calloc((size_t)e->mbw * e->mbh, sizeof(int16_t[2]));
         e->reff[s] = malloc((size_t)e->mbw * e->mbh);
         memset(e->reff[s], -1, (size_t)e->mbw * e->mbh);
@@ -98,7 +106,8 @@ x264o_encoder *x264o_encoder_create(const x264gpu_config *cfg)
 void x264o_encoder_destroy(x264o_encoder *e)
 {
     if (!e) return;
-    for (int s = 0; s < 2; s++) { free(e->luma[s]); free(e->chroma[s]); free(e->mvf[s]); free(e->reff[s]); }
+    for (int s = 0; s < e->slots; s++) { free(e->luma[s]); free(e->chroma[s]); }
+    for (int s = 0; s < 2; s++) { free(e->mvf[s]); free(e->reff[s]); }
     for (int q = 0; q < 52; q++) free(e->cost_mv[q]);
     free(e->fenc_y); free(e->fenc_uv); free(e);
 }
@@ -244,11 +253,11 @@ static const int8_t mod6m1[8] = { 5, 0, 1, 2, 3, 4, 5, 0 };
 /* Generic block search: w x h block at offset (ox,oy) inside macroblock (mbx,mby).  Start candidates are
  * tried in order (first-best wins), then hexagon + square full-pel search on SAD and the sub-pel diamonds
  * (half-pel on SAD, quarter-pel on SATD) — x264_me_search_ref + refine_subpel.  mvp = cost predictor. */
-static me_result me_search_block(x264o_encoder *e, int mbx, int mby, int ox, int oy, int w, int h, int qp,
+static me_result me_search_block(x264o_encoder *e, int mbx, int mby, int ox, int oy, int w, int h, int qp, int refidx,
                                  const int mvp[2], const int (*cand)[2], int ncand)
 {
     const pixel *fenc = e->fenc_y + (size_t)(mby * 16 + oy) * e->fs + mbx * 16 + ox;
-    int ref = e->cur ^ 1;
+    int ref = ref_slot(e, refidx);
     pixel *planes[4] = { luma_plane(e, ref, 0), luma_plane(e, ref, 1), luma_plane(e, ref, 2), luma_plane(e, ref, 3) };
     const pixel *full = planes[0] + (size_t)(mby * 16 + oy) * e->rs + mbx * 16 + ox;
     const uint16_t *cm = cost_mv_for(e, qp);
@@ -331,7 +340,10 @@ static me_result me_search_block(x264o_encoder *e, int mbx, int mby, int ox, int
     return r;
 }
 
-static me_result me_search_16x16(x264o_encoder *e, int mbx, int mby, int qp, int mvp[2])
+/* bits of ref_idx te(v) for `nref` active references */
+static int ref_bits(int nref, int r) { return nref <= 1 ? 0 : nref == 2 ? 1 : bs_size_ue(r); }
+
+static me_result me_search_16x16(x264o_encoder *e, int mbx, int mby, int qp, int refidx, int mvp[2])
 {
     /* start candidates, in priority order: predictor, zero, co-located previous-frame MV */
     int cand[3][2], ncand = 0, mi = mby * e->mbw + mbx;
@@ -339,7 +351,7 @@ static me_result me_search_16x16(x264o_encoder *e, int mbx, int mby, int qp, int
     cand[ncand][0] = (mvp[0] + 2) >> 2; cand[ncand][1] = (mvp[1] + 2) >> 2; ncand++;
     cand[ncand][0] = 0; cand[ncand][1] = 0; ncand++;
     if (e->reff[0][mi] >= 0) { cand[ncand][0] = (e->mvf[0][mi][0] + 2) >> 2; cand[ncand][1] = (e->mvf[0][mi][1] + 2) >> 2; ncand++; }
-    return me_search_block(e, mbx, mby, 0, 0, 16, 16, qp, mvp, (const int (*)[2])cand, ncand);
+    return me_search_block(e, mbx, mby, 0, 0, 16, 16, qp, refidx, mvp, (const int (*)[2])cand, ncand);
 }
 
 /* intra 16x16 SATD estimate on SOURCE neighbours (lookahead-style; decides intra vs inter in P) */
@@ -376,19 +388,27 @@ static const int8_t part_extra_bits[4] = { 0, 2, 2, 8 };
 static void analyse_p_mb(x264o_encoder *e, int mbx, int mby, x264gpu_mb *mb)
 {
     int qp = e->cfg.qp_p, lambda = x264o_lambda(qp), mi = mby * e->mbw + mbx, mvp[2];
-    me_result m = me_search_16x16(e, mbx, mby, qp, mvp);
+    /* 16x16 search in every usable reference (most recent first); lower index wins ties */
+    me_result m = { 0, 0, 1 << 28 };
+    int bref = 0;
+    for (int r = 0; r < e->nref; r++) {
+        me_result t = me_search_16x16(e, mbx, mby, qp, r, mvp);
+        t.cost += lambda * ref_bits(e->nref, r);
+        if (t.cost < m.cost) { m = t; bref = r; }
+    }
     int best_cost = m.cost, best_shape = 0;
     int best_mv[4][2] = { { m.mvx, m.mvy }, { m.mvx, m.mvy }, { m.mvx, m.mvy }, { m.mvx, m.mvy } };
     if (e->cfg.partitions & 1) {
-        /* sub-partition searches start from the 16x16 vector; 16x8 / 8x16 only when 8x8 beats 16x16 */
+        /* sub-partition searches start from the 16x16 vector, in the 16x16 winner's reference (no mixed refs);
+         * 16x8 / 8x16 only when 8x8 beats 16x16 */
         int c0[1][2] = { { (m.mvx + 2) >> 2, (m.mvy + 2) >> 2 } };
         static const int order[3] = { 3, 1, 2 };
         for (int oi = 0; oi < 3; oi++) {
-            int shape = order[oi], cost = lambda * part_extra_bits[shape], mv[4][2];
+            int shape = order[oi], cost = lambda * (part_extra_bits[shape] + part_count[shape] * ref_bits(e->nref, bref)), mv[4][2];
             if (oi > 0 && best_shape == 0) break;
             for (int p = 0; p < part_count[shape]; p++) {
                 const int8_t *g = part_geom[shape][p];
-                me_result r = me_search_block(e, mbx, mby, g[0], g[1], g[2], g[3], qp, mvp, (const int (*)[2])c0, 1);
+                me_result r = me_search_block(e, mbx, mby, g[0], g[1], g[2], g[3], qp, bref, mvp, (const int (*)[2])c0, 1);
                 cost += r.cost;
                 mv[g[4]][0] = r.mvx; mv[g[4]][1] = r.mvy;
                 if (g[5] >= 0) { mv[g[5]][0] = r.mvx; mv[g[5]][1] = r.mvy; }
@@ -410,7 +430,7 @@ static void analyse_p_mb(x264o_encoder *e, int mbx, int mby, x264gpu_mb *mb)
         mb->type = best_shape == 3 ? X264GPU_MB_P_8x8 : X264GPU_MB_P_L0;
         mb->partition = (uint8_t)best_shape;
         mb->cost = best_cost;
-        for (int k = 0; k < 4; k++) { mb->mv[k][0] = (int16_t)best_mv[k][0]; mb->mv[k][1] = (int16_t)best_mv[k][1]; mb->ref[k] = 0; }
+        for (int k = 0; k < 4; k++) { mb->mv[k][0] = (int16_t)best_mv[k][0]; mb->mv[k][1] = (int16_t)best_mv[k][1]; mb->ref[k] = (int8_t)bref; }
         e->reff[1][mi] = 0; e->mvf[1][mi][0] = (int16_t)m.mvx; e->mvf[1][mi][1] = (int16_t)m.mvy;
     }
 }
@@ -418,7 +438,7 @@ static void analyse_p_mb(x264o_encoder *e, int mbx, int mby, x264gpu_mb *mb)
 /* ---- stage 2: inter macroblock encode (x264_macroblock_encode, P_L0 16x16) ---- */
 static void encode_inter_mb(x264o_encoder *e, int mbx, int mby, x264gpu_mb *mb, int16_t *lv)
 {
-    int ref = e->cur ^ 1, qp = mb->qp, qpc = x264o_chroma_qp[clampi(qp + e->cfg.chroma_qp_offset, 0, 51)];
+    int ref = ref_slot(e, mb->ref[0]), qp = mb->qp, qpc = x264o_chroma_qp[clampi(qp + e->cfg.chroma_qp_offset, 0, 51)];
     pixel *planes[4] = { luma_plane(e, ref, 0), luma_plane(e, ref, 1), luma_plane(e, ref, 2), luma_plane(e, ref, 3) };
     pixel *rec = luma_plane(e, e->cur, 0) + (size_t)mby * 16 * e->rs + mbx * 16;
     pixel *rec_uv = chroma_plane(e, e->cur) + (size_t)mby * 8 * e->rs + mbx * 16;
@@ -685,6 +705,8 @@ int x264o_encoder_encode(x264o_encoder *e, const uint8_t *i420, int slice_type, 
     int n = e->mbw * e->mbh;
     if (slice_type == X264GPU_SLICE_P && !e->have_ref) return -1;
     e->slice_type = slice_type;
+    if (slice_type == X264GPU_SLICE_I) e->have_ref = 0;      /* IDR: the DPB is emptied */
+    e->nref = e->have_ref < e->slots - 1 ? e->have_ref : e->slots - 1;
     ingest(e, i420);
     if (slice_type == X264GPU_SLICE_I) {
         for (int i = 0; i < n; i++) { e->reff[1][i] = -1; e->mvf[1][i][0] = e->mvf[1][i][1] = 0; }
@@ -708,17 +730,17 @@ int x264o_encoder_encode(x264o_encoder *e, const uint8_t *i420, int slice_type, 
     if (e->cfg.deblock) deblock_frame(e, mbs);
     filter_frame(e);
     /* rotate: the frame just built becomes the reference; its MV field becomes "previous" */
-    e->cur ^= 1;
+    e->cur = (e->cur + 1) % e->slots;
     { int16_t (*t)[2] = e->mvf[0]; e->mvf[0] = e->mvf[1]; e->mvf[1] = t; }
     { int8_t *t = e->reff[0]; e->reff[0] = e->reff[1]; e->reff[1] = t; }
-    e->have_ref = 1;
+    e->have_ref++;
     return 0;
 }
 
 /* reconstructed (deblocked) picture of the most recent frame, cropped to width x height, I420 */
 void x264o_encoder_get_recon(x264o_encoder *e, uint8_t *out)
 {
-    int w = e->cfg.width, h = e->cfg.height, slot = e->cur ^ 1;
+    int w = e->cfg.width, h = e->cfg.height, slot = (e->cur + e->slots - 1) % e->slots;
     const pixel *Y = luma_plane(e, slot, 0), *UV = chroma_plane(e, slot);
     for (int y = 0; y < h; y++) memcpy(out + (size_t)y * w, Y + (size_t)y * e->rs, w);
     uint8_t *u = out + (size_t)w * h, *v = u + (size_t)(w / 2) * (h / 2);
@@ -730,7 +752,8 @@ void x264o_encoder_get_recon(x264o_encoder *e, uint8_t *out)
 const uint8_t *x264o_encoder_ref_plane(x264o_encoder *e, int k, int *stride, int *rows)
 {
     *stride = e->rs;
-    if (k < 4) { *rows = e->ch + 2 * PAD; return e->luma[e->cur ^ 1] + k * e->plane_bytes; }
+    int last = (e->cur + e->slots - 1) % e->slots;
+    if (k < 4) { *rows = e->ch + 2 * PAD; return e->luma[last] + k * e->plane_bytes; }
     *rows = e->ch / 2 + 2 * CPAD;
-    return e->chroma[e->cur ^ 1];
+    return e->chroma[last];
 }

@@ -57,8 +57,9 @@ struct Decoder {
     int pic_init_qp = 26, chroma_qp_offset = 0, deblock_ctrl = 1, num_ref_default = 1;
     int stride = 0, pad = 32, cpad = 16;
     size_t plane_bytes = 0, cplane_bytes = 0;
-    std::vector<pixel> luma[2], chroma[2];
-    int cur = 0;
+    std::vector<pixel> luma[5], chroma[5];   // DPB slots: up to 4 references + the picture being decoded
+    int cur = 0, slots = 2, have = 0, num_ref_frames = 1, nref_active = 1;
+    int ref_slot(int r) const { return (cur - 1 - r + 2 * slots) % slots; }
     std::vector<MbInfo> mb;
     bool have_sps = false, have_pps = false;
     std::vector<std::vector<uint8_t>> frames;
@@ -72,7 +73,8 @@ struct Decoder {
         stride = (mbw * 16 + 2 * pad + 63) / 64 * 64;
         plane_bytes = (size_t)stride * (mbh * 16 + 2 * pad);
         cplane_bytes = (size_t)stride * (mbh * 8 + 2 * cpad);
-        for (int s = 0; s < 2; s++) { luma[s].assign(4 * plane_bytes, 0); chroma[s].assign(cplane_bytes, 0); }
+        slots = num_ref_frames + 1;
+        for (int s = 0; s < slots; s++) { luma[s].assign(4 * plane_bytes, 0); chroma[s].assign(cplane_bytes, 0); }
         mb.assign((size_t)mbw * mbh, MbInfo());
         x264o_quant_init(&qt, 21, 11);
     }
@@ -195,10 +197,10 @@ struct SliceDec {
 
     void inter_pred(int mbx, int mby, const MbInfo &m)
     {
-        int ref = d.cur ^ 1;
-        pixel *planes[4] = { d.Y(ref, 0), d.Y(ref, 1), d.Y(ref, 2), d.Y(ref, 3) };
         pixel pu[64], pv[64];
         for (int k = 0; k < 4; k++) {
+            int ref = d.ref_slot(m.ref8[k]);
+            pixel *planes[4] = { d.Y(ref, 0), d.Y(ref, 1), d.Y(ref, 2), d.Y(ref, 3) };
             int ox = (k & 1) * 8, oy = (k >> 1) * 8;
             x264o_mc_luma(d.Y(d.cur) + (size_t)(mby * 16 + oy) * d.stride + mbx * 16 + ox, d.stride, planes, d.stride, mbx * 16 + ox, mby * 16 + oy,
                           m.mv8[k][0], m.mv8[k][1], 8, 8);
@@ -353,7 +355,8 @@ struct SliceDec {
         m.intra = 0; m.i16 = 0; memset(m.i4mode, 2, 16);
         int nparts = shape == 0 ? 1 : shape == 3 ? 4 : 2, refs[4] = { 0, 0, 0, 0 };
         if (shape == 3) for (int k = 0; k < 4; k++) if (br.ue() != 0) { br.err = true; return; }     // only P_L0_8x8 sub-macroblocks
-        if (d.num_ref_default > 1) for (int k = 0; k < nparts; k++) refs[k] = d.num_ref_default == 2 ? !br.get1() : (int)br.ue();
+        if (d.nref_active > 1) for (int k = 0; k < nparts; k++) refs[k] = d.nref_active == 2 ? !br.get1() : (int)br.ue();
+        for (int k = 0; k < nparts; k++) if (refs[k] >= d.nref_active) { br.err = true; return; }
         for (int k = 0; k < nparts; k++) {
             const int8_t *g = geom[shape][k];
             int px, py;
@@ -486,7 +489,8 @@ void finish_picture(Decoder &d)
                 c[(size_t)y * d.stride + 2 * x] = c[(size_t)sy * d.stride + 2 * sx];
                 c[(size_t)y * d.stride + 2 * x + 1] = c[(size_t)sy * d.stride + 2 * sx + 1];
             }
-    d.cur ^= 1;
+    d.cur = (d.cur + 1) % d.slots;
+    d.have++;
 }
 
 bool decode_nal(Decoder &d, const uint8_t *nal, size_t n)
@@ -505,7 +509,8 @@ bool decode_nal(Decoder &d, const uint8_t *nal, size_t n)
         d.log2_max_frame_num = (int)br.ue() + 4;
         d.poc_type = (int)br.ue();
         if (d.poc_type != 2) return false;
-        br.ue(); br.get1();
+        d.num_ref_frames = (int)br.ue(); br.get1();
+        if (d.num_ref_frames < 1 || d.num_ref_frames > 4) return false;
         d.mbw = (int)br.ue() + 1; d.mbh = (int)br.ue() + 1;
         if (!br.get1()) return false;                       // frame_mbs_only
         br.get1();
@@ -538,9 +543,12 @@ bool decode_nal(Decoder &d, const uint8_t *nal, size_t n)
         br.ue();
         br.get(d.log2_max_frame_num);
         if (type == 5) br.ue();
+        if (type == 5) d.have = 0;                          // IDR empties the DPB
+        d.nref_active = d.num_ref_default;
         if (st == 0) {
-            if (br.get1()) return false;                    // num_ref_idx override
+            if (br.get1()) d.nref_active = (int)br.ue() + 1; // num_ref_idx_active_override_flag
             if (br.get1()) return false;                    // list modification
+            if (d.nref_active > d.have || d.nref_active > d.num_ref_frames) return false;   // refers to pictures not in the DPB
         }
         if ((nal[0] >> 5) & 3) { if (type == 5) { br.get1(); br.get1(); } else if (br.get1()) return false; }
         int qp = d.pic_init_qp + br.se();

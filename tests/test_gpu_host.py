@@ -58,12 +58,14 @@ def encode_all(h_, w, h, frames):
 
 
 @pytest.mark.parametrize("w,h,opts", [(176, 144, {"qp": 26, "keyint": 4}), (352, 288, {"qp": 30, "keyint": 250}),
-                                       (208, 120, {"qp": 22, "keyint": 3, "no-deblock": None})])
+                                       (208, 120, {"qp": 22, "keyint": 3, "no-deblock": None}),
+                                       (176, 144, {"qp": 28, "keyint": 250, "ref": 1, "partitions": "i4x4"})])
 def test_encode_api_closed_loop(gpu, w, h, opts):
     nfr = 7
     frames = synth_frames(w, h, nfr, seed=w + 3 * h)
     h_, eff = open_encoder(w, h, opts)
-    assert (eff.i_bframe, eff.i_frame_reference, eff.b_cabac, eff.rc.i_rc_method) == (0, 1, 0, HL.X264_RC_CQP)   # effective params
+    assert (eff.i_bframe, eff.b_cabac, eff.rc.i_rc_method) == (0, 0, HL.X264_RC_CQP)   # effective params
+    assert eff.i_frame_reference == int(opts.get("ref", 3))                         # medium: --ref 3
     stream, info, recons = encode_all(h_, w, h, frames)
     H.x264_encoder_close(h_)
     keyint = opts["keyint"]
@@ -87,11 +89,12 @@ def test_bitstream_equals_oracle_path(gpu):
     stream, info, _ = encode_all(h_, w, h, frames)
     H.x264_encoder_close(h_)
     qp_i = max(1, int(qp - 6.0 * np.log2(1.4) + 0.5))
-    enc = O.OracleEncoder(O.default_config(w, h, qp_i=qp_i, qp_p=qp, partitions=3))      # medium: p8x8 + i4x4
+    enc = O.OracleEncoder(O.default_config(w, h, qp_i=qp_i, qp_p=qp, partitions=3, refs=3))      # medium: p8x8 + i4x4, ref 3
     ref = b""
     for i, f in enumerate(frames):
         mbs, lv = enc.encode(f, 2 if i == 0 else 0)
-        ref += HL.write_slice(11, 9, 2 if i == 0 else 0, qp_i if i == 0 else qp, qp, i, 8, int(i == 0), 0, 0, mbs, lv)[0]
+        ref += HL.write_slice(11, 9, 2 if i == 0 else 0, qp_i if i == 0 else qp, qp, i, 8, int(i == 0), 0, 0, mbs, lv,
+                              num_ref=max(1, min(3, i)), num_ref_default=3)[0]
     def slice_nals(b):
         import re
         return [n.rstrip(b"\x00") if False else n for n in re.split(b"\x00\x00\x00\x01|\x00\x00\x01", b) if n and (n[0] & 31) in (1, 5)]

@@ -45,6 +45,9 @@ def compare(tag, mbw, g_mb, o_mb, g_lv, o_lv, g_rec, o_rec):
     (352, 288, 3, dict(partitions=3, qp_i=28, qp_p=31)),
     (208, 120, 3, dict(partitions=1, subme=4, dct_decimate=0)),
     (64, 48, 3, dict(partitions=3, subme=1)),
+    (176, 144, 7, dict(refs=3, partitions=3)),               # medium: --ref 3
+    (208, 120, 6, dict(refs=2)),
+    (96, 80, 7, dict(refs=4, partitions=1, qp_i=30, qp_p=33)),
 ])
 def test_pipeline_bitexact(gpu, w, h, nfr, kw):
     from gpu_enc import GpuEncoder
@@ -53,7 +56,7 @@ def test_pipeline_bitexact(gpu, w, h, nfr, kw):
     og, gg = O.OracleEncoder(cfg), GpuEncoder(cfg)
     mbw = (w + 15) // 16
     for i, f in enumerate(frames):
-        st = 2 if i == 0 else 0
+        st = 2 if i in (0, 5) else 0                        # a second IDR empties the DPB again
         o_mb, o_lv = og.encode(f, st)
         g_mb, g_lv = gg.encode([f], st)
         compare(f"{w}x{h} {kw} frame {i}", mbw, g_mb[0], o_mb, g_lv[0], o_lv, gg.recon(0), og.recon())

@@ -23,7 +23,8 @@ struct EncK {
     const uint8_t *i420;      // [streams] tightly packed input pictures
     uint8_t *fenc_y, *fenc_uv;
     uint8_t *rec_luma, *rec_chroma;          // DPB slot being reconstructed
-    const uint8_t *ref_luma, *ref_chroma;    // DPB slot used as reference
+    const uint8_t *ref_luma[4], *ref_chroma[4];   // DPB slots of reference index 0..nref-1 (0 = most recent)
+    int nref;                                // references usable by this P slice
     const int16_t *mvf_prev; int16_t *mvf_cur;     // [streams][nmb][2]
     const int8_t *reff_prev; int8_t *reff_cur;     // [streams][nmb]
     const uint16_t *cost_mv;  // 2*MVCOST_HALF entries for the slice qp
@@ -37,18 +38,20 @@ struct EncK {
     unsigned long long *dbg;  // optional diagnostics (NULL in production): per (stream, wave) cycle counters
 };
 
-__device__ __forceinline__ const uint8_t *ref_plane00(const EncK &k, int s)
+__device__ __forceinline__ const uint8_t *ref_plane00(const EncK &k, int s, int r)
 {
-    return k.ref_luma + (size_t)s * k.luma_bytes + (size_t)PAD * k.rs + PAD;
+    return k.ref_luma[r] + (size_t)s * k.luma_bytes + (size_t)PAD * k.rs + PAD;
 }
 __device__ __forceinline__ uint8_t *rec_plane00(const EncK &k, int s)
 {
     return k.rec_luma + (size_t)s * k.luma_bytes + (size_t)PAD * k.rs + PAD;
 }
-__device__ __forceinline__ const uint8_t *ref_chroma00(const EncK &k, int s)
+__device__ __forceinline__ const uint8_t *ref_chroma00(const EncK &k, int s, int r)
 {
-    return k.ref_chroma + (size_t)s * k.cplane_bytes + (size_t)CPAD * k.rs + 2 * CPAD;
+    return k.ref_chroma[r] + (size_t)s * k.cplane_bytes + (size_t)CPAD * k.rs + 2 * CPAD;
 }
+// bits of ref_idx te(v) with nref active references
+__device__ __forceinline__ int ref_bits(int nref, int r) { return nref <= 1 ? 0 : nref == 2 ? 1 : 2 * (31 - __builtin_clz(r + 1)) + 1; }
 __device__ __forceinline__ uint8_t *rec_chroma00(const EncK &k, int s)
 {
     return k.rec_chroma + (size_t)s * k.cplane_bytes + (size_t)CPAD * k.rs + 2 * CPAD;

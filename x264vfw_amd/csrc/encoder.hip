@@ -25,11 +25,12 @@ struct x264gpu_encoder {
     x264gpu_config cfg;
     EncK k;                       // template of the kernel argument block (pointers refreshed per call)
     uint8_t *fenc_y = nullptr, *fenc_uv = nullptr;
-    uint8_t *luma[2] = { nullptr, nullptr }, *chroma[2] = { nullptr, nullptr };
+    uint8_t *luma[5] = {}, *chroma[5] = {};      // DPB slots: refs + the picture being reconstructed
+    int slots = 2, have = 0;                     // have = pictures in the DPB since the last IDR
     int16_t *mvf[2] = { nullptr, nullptr };
     int8_t *reff[2] = { nullptr, nullptr };
     uint16_t *cost_mv[52] = {};
-    int cur = 0, have_ref = 0;
+    int cur = 0;
     unsigned long long *dbg = nullptr;   // diagnostics buffer set by x264gpu_encoder_set_debug
     // optional per-stage profiling: (NSTAGE+1) events per armed call
     hipEvent_t *ev = nullptr;
@@ -68,7 +69,7 @@ int x264gpu_encoder_create(x264gpu_encoder **out, const x264gpu_config *cfg)
 {
     ARG_TRY(out && cfg);
     ARG_TRY(cfg->width >= 16 && cfg->height >= 16 && !(cfg->width & 1) && !(cfg->height & 1) && cfg->streams >= 1);
-    ARG_TRY(cfg->qp_i >= 0 && cfg->qp_i <= 51 && cfg->qp_p >= 0 && cfg->qp_p <= 51 && cfg->refs == 1);
+    ARG_TRY(cfg->qp_i >= 0 && cfg->qp_i <= 51 && cfg->qp_p >= 0 && cfg->qp_p <= 51 && cfg->refs >= 1 && cfg->refs <= 4);
     ARG_TRY(cfg->width <= 4096 && cfg->height <= 2304 && cfg->me_range >= 4 && cfg->me_range <= 16);
     x264gpu_encoder *e = new (std::nothrow) x264gpu_encoder();
     if (!e) return set_err(X264GPU_ENOMEM, "encoder", hipSuccess);
@@ -97,9 +98,12 @@ int x264gpu_encoder_create(x264gpu_encoder **out, const x264gpu_config *cfg)
     };
     alloc((void **)&e->fenc_y, S * k.fency_bytes, 0);
     alloc((void **)&e->fenc_uv, S * k.fencuv_bytes, 0);
-    for (int i = 0; i < 2; i++) {
+    e->slots = cfg->refs + 1;
+    for (int i = 0; i < e->slots; i++) {
         alloc((void **)&e->luma[i], S * k.luma_bytes, 0);
         alloc((void **)&e->chroma[i], S * k.cplane_bytes, 0);
+    }
+    for (int i = 0; i < 2; i++) {
         alloc((void **)&e->mvf[i], S * k.nmb * 2 * sizeof(int16_t), 0);
         alloc((void **)&e->reff[i], S * k.nmb, 0xff);
     }
@@ -154,7 +158,8 @@ void x264gpu_encoder_destroy(x264gpu_encoder *e)
     if (!e) return;
     profile_free(e);
     (void)hipFree(e->fenc_y); (void)hipFree(e->fenc_uv);
-    for (int i = 0; i < 2; i++) { (void)hipFree(e->luma[i]); (void)hipFree(e->chroma[i]); (void)hipFree(e->mvf[i]); (void)hipFree(e->reff[i]); }
+    for (int i = 0; i < 5; i++) { (void)hipFree(e->luma[i]); (void)hipFree(e->chroma[i]); }
+    for (int i = 0; i < 2; i++) { (void)hipFree(e->mvf[i]); (void)hipFree(e->reff[i]); }
     for (int q = 0; q < 52; q++) (void)hipFree(e->cost_mv[q]);
     delete e;
 }
@@ -169,14 +174,19 @@ int x264gpu_encode_frames(x264gpu_encoder *e, const uint8_t *d_i420, int slice_t
 {
     ARG_TRY(e && d_i420 && d_mb && d_levels);
     ARG_TRY(slice_type == X264GPU_SLICE_I || slice_type == X264GPU_SLICE_P);
-    ARG_TRY(slice_type == X264GPU_SLICE_I || e->have_ref);
+    ARG_TRY(slice_type == X264GPU_SLICE_I || e->have > 0);
     hipStream_t st = (hipStream_t)stream;
     const int S = e->cfg.streams;
     EncK k = e->k;
     const int qp = slice_type == X264GPU_SLICE_I ? e->cfg.qp_i : e->cfg.qp_p;
     k.i420 = d_i420; k.fenc_y = e->fenc_y; k.fenc_uv = e->fenc_uv;
+    if (slice_type == X264GPU_SLICE_I) e->have = 0;                      // IDR empties the DPB
     k.rec_luma = e->luma[e->cur]; k.rec_chroma = e->chroma[e->cur];
-    k.ref_luma = e->luma[e->cur ^ 1]; k.ref_chroma = e->chroma[e->cur ^ 1];
+    k.nref = e->have < e->cfg.refs ? e->have : e->cfg.refs;
+    for (int r = 0; r < 4; r++) {
+        const int slot = (e->cur - 1 - (r < k.nref ? r : 0) + 2 * e->slots) % e->slots;
+        k.ref_luma[r] = e->luma[slot]; k.ref_chroma[r] = e->chroma[slot];
+    }
     k.mvf_prev = e->mvf[0]; k.mvf_cur = e->mvf[1]; k.reff_prev = e->reff[0]; k.reff_cur = e->reff[1];
     k.cost_mv = e->cost_mv[e->cfg.qp_p];
     k.mb = d_mb; k.levels = d_levels;
@@ -218,10 +228,10 @@ int x264gpu_encode_frames(x264gpu_encoder *e, const uint8_t *d_i420, int slice_t
 #undef STAGE_MARK
     if (ev) e->ev_mask[e->prof_calls++] = mask;
     HIP_TRY(hipGetLastError());
-    e->cur ^= 1;
+    e->cur = (e->cur + 1) % e->slots;
     { int16_t *t = e->mvf[0]; e->mvf[0] = e->mvf[1]; e->mvf[1] = t; }
     { int8_t *t = e->reff[0]; e->reff[0] = e->reff[1]; e->reff[1] = t; }
-    e->have_ref = 1;
+    e->have++;
     return X264GPU_OK;
 }
 
@@ -243,9 +253,9 @@ __global__ __launch_bounds__(256) void k_get_recon(const uint8_t *__restrict__ l
 
 extern "C" int x264gpu_encoder_get_recon(x264gpu_encoder *e, int stream_idx, uint8_t *d_out, void *stream)
 {
-    ARG_TRY(e && d_out && stream_idx >= 0 && stream_idx < e->cfg.streams && e->have_ref);
+    ARG_TRY(e && d_out && stream_idx >= 0 && stream_idx < e->cfg.streams && e->have > 0);
     const EncK &k = e->k;
-    const int slot = e->cur ^ 1;
+    const int slot = (e->cur + e->slots - 1) % e->slots;
     const uint8_t *l = e->luma[slot] + (size_t)stream_idx * k.luma_bytes + (size_t)PAD * k.rs + PAD;
     const uint8_t *c = e->chroma[slot] + (size_t)stream_idx * k.cplane_bytes + (size_t)CPAD * k.rs + 2 * CPAD;
     hipLaunchKernelGGL(k_get_recon, dim3((k.w + 255) / 256, k.h), dim3(256), 0, (hipStream_t)stream, l, c, k.rs, k.w, k.h, d_out);

@@ -171,7 +171,6 @@ __global__ __launch_bounds__(256) void k_analyse_p(EncK k)
     uint8_t *nb = s_nb[wave];
 
     const uint8_t *fenc = k.fenc_y + (size_t)s * k.fency_bytes + (size_t)mby * 16 * k.fs + mbx * 16;
-    const uint8_t *p00 = ref_plane00(k, s);
     const int px = mbx * 16, py = mby * 16;        // macroblock position in the picture
 
     // current macroblock in both lane mappings
@@ -203,137 +202,148 @@ __global__ __launch_bounds__(256) void k_analyse_p(EncK k)
     }
     const uint16_t *cmx = k.cost_mv + MVCOST_HALF - mvp0, *cmy = k.cost_mv + MVCOST_HALF - mvp1;
 
-    // ---- start candidates: predictor, zero, co-located (lane groups 0..2 evaluate one each) ----
-    int bmx, bmy, bcost;
-    {
-        int cx[3], cy[3];
-        cx[0] = clampi((mvp0 + 2) >> 2, fmin0, fmax0); cy[0] = clampi((mvp1 + 2) >> 2, fmin1, fmax1);
-        cx[1] = clampi(0, fmin0, fmax0); cy[1] = clampi(0, fmin1, fmax1);
-        const bool has_col = rf[mbi] >= 0;
-        cx[2] = has_col ? clampi((mvf[2 * mbi] + 2) >> 2, fmin0, fmax0) : 0;
-        cy[2] = has_col ? clampi((mvf[2 * mbi + 1] + 2) >> 2, fmin1, fmax1) : 0;
-        const int c = cnd < 3 ? cnd : 0;
-        const int mx = c == 0 ? cx[0] : c == 1 ? cx[1] : cx[2], my = c == 0 ? cy[0] : c == 1 ? cy[1] : cy[2];
-        int sad = sad_row16_global(p00 + (long)(py + my + r) * k.rs + px + mx, cr);
-        sad = row16_sum(sad);
-        unsigned key = 0xffffffffu;
-        if (cnd < 2 || (cnd == 2 && has_col)) key = ((unsigned)(sad + cmx[mx * 4] + cmy[my * 4]) << 3) | (unsigned)cnd;
-        key = wave_min_u32(key);
-        const int best = key & 7;
-        bcost = (int)(key >> 3);
-        bmx = best == 0 ? cx[0] : best == 1 ? cx[1] : cx[2];
-        bmy = best == 0 ? cy[0] : best == 1 ? cy[1] : cy[2];
-    }
-
-    // ---- stage the search window in LDS ----
-    int wx0 = (px + bmx - WIN_R) & ~7, wy0 = py + bmy - WIN_R;
-    wx0 = clampi(wx0, -PAD, k.cw + PAD - WIN_COLS);
-    wy0 = clampi(wy0, -PAD, k.ch + PAD - WIN_ROWS);
-    for (int i = lane; i < WIN_ROWS * 8; i += 64) {
-        const int row = i >> 3, col = (i & 7) * 8;
-        const uint2 v = *(const uint2 *)(p00 + (long)(wy0 + row) * k.rs + wx0 + col);
-        uint32_t *d = (uint32_t *)(win + row * WIN_STRIDE + col);
-        d[0] = v.x; d[1] = v.y;
-    }
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_s_waitcnt(0xc07f);
-
-    // cost of full-pel candidate (mx,my) for this lane's row; valid after row16_sum on the 16-lane group
-#define FPEL_KEY(mx, my, tag) \
-    (((unsigned)(row16_sum(sad_row16_lds(win + (py + (my) + r - wy0) * WIN_STRIDE, px + (mx) - wx0, cr)) + cmx[(mx) * 4] + cmy[(my) * 4]) << 3) | (unsigned)(tag))
-
-    // ---- hexagon search ----
-    {
-        unsigned key = (unsigned)bcost << 3;
-        // first ring: hex2[1..6], tags 2..7 (two passes of four lane groups)
-        {
-            int i = 1 + cnd;                                   // hex2 index 1..4
-            unsigned kk = FPEL_KEY(bmx + hex_dx(i), bmy + hex_dy(i), i + 1);
-            key = min(key, wave_min_u32(kk));
-            i = 5 + (cnd & 1);                                 // hex2 index 5..6
-            kk = FPEL_KEY(bmx + hex_dx(i), bmy + hex_dy(i), i + 1);
-            if (cnd >= 2) kk = 0xffffffffu;
-            key = min(key, wave_min_u32(kk));
-        }
-        if (key & 7) {
-            int dir = (int)(key & 7) - 2;
-            bmx += hex_dx(dir + 1); bmy += hex_dy(dir + 1);
-            for (int it = (k.me_range >> 1) - 1; it > 0 && bmx >= fmin0 && bmx <= fmax0 && bmy >= fmin1 && bmy <= fmax1; it--) {
-                key &= ~7u;
-                const int c = cnd < 3 ? cnd : 0;
-                unsigned kk = FPEL_KEY(bmx + hex_dx(dir + c), bmy + hex_dy(dir + c), c + 1);
-                if (cnd >= 3) kk = 0xffffffffu;
-                key = min(key, wave_min_u32(kk));
-                if (!(key & 7)) break;
-                dir += (int)(key & 7) - 2;
-                dir = dir < 0 ? 5 : dir > 5 ? 0 : dir;         // mod6m1
-                bmx += hex_dx(dir + 1); bmy += hex_dy(dir + 1);
-            }
-        }
-        bcost = (int)(key >> 3);
-        // square refine: square1[1..8]; first strictly-better candidate in order wins
-        unsigned sk = ((unsigned)bcost << 4);
-        {
-            int q = 1 + cnd;
-            unsigned kk = (FPEL_KEY(bmx + sq_dx(q), bmy + sq_dy(q), 0) << 1) | (unsigned)q;
-            sk = min(sk, wave_min_u32(kk));
-            q = 5 + cnd;
-            kk = (FPEL_KEY(bmx + sq_dx(q), bmy + sq_dy(q), 0) << 1) | (unsigned)q;
-            sk = min(sk, wave_min_u32(kk));
-        }
-        const int bd = sk & 15;
-        bcost = (int)(sk >> 4);
-        if (bd) { bmx += sq_dx(bd); bmy += sq_dy(bd); }
-    }
-#undef FPEL_KEY
-
-    // ---- sub-pel refinement ----
-    int mx = bmx * 4, my = bmy * 4;
+    // ---- 16x16 search in every usable reference (oracle analyse_p_mb); lower index wins ties ----
     const size_t pb = k.plane_bytes;
-    if (k.subme >= 2) {
-        const int sub = min(k.subme, 11);
-        const int hp_it = sub < 6 ? 1 : sub < 8 ? 2 : 4;
-        const int qp_it = sub < 4 ? 0 : sub == 4 ? 1 : sub < 8 ? 2 : 10;
-        // half-pel diamond, SAD, lane = (candidate, row): (0,-2) (0,2) (-2,0) (2,0)
-        for (int it = hp_it; it > 0; it--) {
-            const int cx = mx + (cnd == 2 ? -2 : cnd == 3 ? 2 : 0), cy = my + (cnd == 0 ? -2 : cnd == 1 ? 2 : 0);
-            unsigned sd = 0;
-#pragma unroll
-            for (int i = 0; i < 4; i++) sd = __builtin_amdgcn_sad_u8(mc_luma_row4(p00, pb, k.rs, px + 4 * i, py + r, cx, cy), cr[i], sd);
-            unsigned key = ((unsigned)(row16_sum((int)sd) + cmx[cx] + cmy[cy]) << 2) | (unsigned)cnd;
-            key = wave_min_u32(key);
-            if ((int)(key >> 2) < bcost) {
-                const int b = key & 3;
-                bcost = (int)(key >> 2);
-                mx += b == 2 ? -2 : b == 3 ? 2 : 0; my += b == 0 ? -2 : b == 1 ? 2 : 0;
-            } else break;
-        }
-        // SATD at the best half-pel position
+    int best_mx = 0, best_my = 0, best16 = 1 << 28, bref = 0;
+    for (int r_ = 0; r_ < k.nref; r_++) {
+        const uint8_t *p00 = ref_plane00(k, s, r_);
+        // ---- start candidates: predictor, zero, co-located (lane groups 0..2 evaluate one each) ----
+        int bmx, bmy, bcost;
         {
-            int e[4], p[4], d[4];
-            unpack4(cz, e); unpack4(mc_luma_row4(p00, pb, k.rs, px + zx, py + zy, mx, my), p);
-#pragma unroll
-            for (int i = 0; i < 4; i++) d[i] = e[i] - p[i];
-            bcost = (wave_sum(satd_quad_partial(d, lane)) >> 1) + cmx[mx] + cmy[my];
+            int cx[3], cy[3];
+            cx[0] = clampi((mvp0 + 2) >> 2, fmin0, fmax0); cy[0] = clampi((mvp1 + 2) >> 2, fmin1, fmax1);
+            cx[1] = clampi(0, fmin0, fmax0); cy[1] = clampi(0, fmin1, fmax1);
+            const bool has_col = rf[mbi] >= 0;
+            cx[2] = has_col ? clampi((mvf[2 * mbi] + 2) >> 2, fmin0, fmax0) : 0;
+            cy[2] = has_col ? clampi((mvf[2 * mbi + 1] + 2) >> 2, fmin1, fmax1) : 0;
+            const int c = cnd < 3 ? cnd : 0;
+            const int mx = c == 0 ? cx[0] : c == 1 ? cx[1] : cx[2], my = c == 0 ? cy[0] : c == 1 ? cy[1] : cy[2];
+            int sad = sad_row16_global(p00 + (long)(py + my + r) * k.rs + px + mx, cr);
+            sad = row16_sum(sad);
+            unsigned key = 0xffffffffu;
+            if (cnd < 2 || (cnd == 2 && has_col)) key = ((unsigned)(sad + cmx[mx * 4] + cmy[my * 4]) << 3) | (unsigned)cnd;
+            key = wave_min_u32(key);
+            const int best = key & 7;
+            bcost = (int)(key >> 3);
+            bmx = best == 0 ? cx[0] : best == 1 ? cx[1] : cx[2];
+            bmy = best == 0 ? cy[0] : best == 1 ? cy[1] : cy[2];
         }
-        // quarter-pel diamond, SATD: (0,-1) (0,1) (-1,0) (1,0), never stepping straight back
-        int bdir = -1;
-        for (int it = qp_it; it > 0; it--) {
-            if (my <= smin1 || my >= smax1 || mx <= smin0 || mx >= smax0) break;
-            const int odir = bdir, omx = mx, omy = my;
-            for (int q = 0; q < 4; q++) {
-                if ((q ^ 1) == odir) continue;
-                const int cx = omx + (q == 2 ? -1 : q == 3 ? 1 : 0), cy = omy + (q == 0 ? -1 : q == 1 ? 1 : 0);
-                int e[4], p[4], d[4];
-                unpack4(cz, e); unpack4(mc_luma_row4(p00, pb, k.rs, px + zx, py + zy, cx, cy), p);
-#pragma unroll
-                for (int i = 0; i < 4; i++) d[i] = e[i] - p[i];
-                const int c = (wave_sum(satd_quad_partial(d, lane)) >> 1) + cmx[cx] + cmy[cy];
-                if (c < bcost) { bcost = c; mx = cx; my = cy; bdir = q; }
+
+        // ---- stage the search window in LDS ----
+        int wx0 = (px + bmx - WIN_R) & ~7, wy0 = py + bmy - WIN_R;
+        wx0 = clampi(wx0, -PAD, k.cw + PAD - WIN_COLS);
+        wy0 = clampi(wy0, -PAD, k.ch + PAD - WIN_ROWS);
+        for (int i = lane; i < WIN_ROWS * 8; i += 64) {
+            const int row = i >> 3, col = (i & 7) * 8;
+            const uint2 v = *(const uint2 *)(p00 + (long)(wy0 + row) * k.rs + wx0 + col);
+            uint32_t *d = (uint32_t *)(win + row * WIN_STRIDE + col);
+            d[0] = v.x; d[1] = v.y;
+        }
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_s_waitcnt(0xc07f);
+
+        // cost of full-pel candidate (mx,my) for this lane's row; valid after row16_sum on the 16-lane group
+    #define FPEL_KEY(mx, my, tag) \
+        (((unsigned)(row16_sum(sad_row16_lds(win + (py + (my) + r - wy0) * WIN_STRIDE, px + (mx) - wx0, cr)) + cmx[(mx) * 4] + cmy[(my) * 4]) << 3) | (unsigned)(tag))
+
+        // ---- hexagon search ----
+        {
+            unsigned key = (unsigned)bcost << 3;
+            // first ring: hex2[1..6], tags 2..7 (two passes of four lane groups)
+            {
+                int i = 1 + cnd;                                   // hex2 index 1..4
+                unsigned kk = FPEL_KEY(bmx + hex_dx(i), bmy + hex_dy(i), i + 1);
+                key = min(key, wave_min_u32(kk));
+                i = 5 + (cnd & 1);                                 // hex2 index 5..6
+                kk = FPEL_KEY(bmx + hex_dx(i), bmy + hex_dy(i), i + 1);
+                if (cnd >= 2) kk = 0xffffffffu;
+                key = min(key, wave_min_u32(kk));
             }
-            if (mx == omx && my == omy) break;
+            if (key & 7) {
+                int dir = (int)(key & 7) - 2;
+                bmx += hex_dx(dir + 1); bmy += hex_dy(dir + 1);
+                for (int it = (k.me_range >> 1) - 1; it > 0 && bmx >= fmin0 && bmx <= fmax0 && bmy >= fmin1 && bmy <= fmax1; it--) {
+                    key &= ~7u;
+                    const int c = cnd < 3 ? cnd : 0;
+                    unsigned kk = FPEL_KEY(bmx + hex_dx(dir + c), bmy + hex_dy(dir + c), c + 1);
+                    if (cnd >= 3) kk = 0xffffffffu;
+                    key = min(key, wave_min_u32(kk));
+                    if (!(key & 7)) break;
+                    dir += (int)(key & 7) - 2;
+                    dir = dir < 0 ? 5 : dir > 5 ? 0 : dir;         // mod6m1
+                    bmx += hex_dx(dir + 1); bmy += hex_dy(dir + 1);
+                }
+            }
+            bcost = (int)(key >> 3);
+            // square refine: square1[1..8]; first strictly-better candidate in order wins
+            unsigned sk = ((unsigned)bcost << 4);
+            {
+                int q = 1 + cnd;
+                unsigned kk = (FPEL_KEY(bmx + sq_dx(q), bmy + sq_dy(q), 0) << 1) | (unsigned)q;
+                sk = min(sk, wave_min_u32(kk));
+                q = 5 + cnd;
+                kk = (FPEL_KEY(bmx + sq_dx(q), bmy + sq_dy(q), 0) << 1) | (unsigned)q;
+                sk = min(sk, wave_min_u32(kk));
+            }
+            const int bd = sk & 15;
+            bcost = (int)(sk >> 4);
+            if (bd) { bmx += sq_dx(bd); bmy += sq_dy(bd); }
         }
+    #undef FPEL_KEY
+
+        // ---- sub-pel refinement ----
+        int mx = bmx * 4, my = bmy * 4;
+        if (k.subme >= 2) {
+            const int sub = min(k.subme, 11);
+            const int hp_it = sub < 6 ? 1 : sub < 8 ? 2 : 4;
+            const int qp_it = sub < 4 ? 0 : sub == 4 ? 1 : sub < 8 ? 2 : 10;
+            // half-pel diamond, SAD, lane = (candidate, row): (0,-2) (0,2) (-2,0) (2,0)
+            for (int it = hp_it; it > 0; it--) {
+                const int cx = mx + (cnd == 2 ? -2 : cnd == 3 ? 2 : 0), cy = my + (cnd == 0 ? -2 : cnd == 1 ? 2 : 0);
+                unsigned sd = 0;
+    #pragma unroll
+                for (int i = 0; i < 4; i++) sd = __builtin_amdgcn_sad_u8(mc_luma_row4(p00, pb, k.rs, px + 4 * i, py + r, cx, cy), cr[i], sd);
+                unsigned key = ((unsigned)(row16_sum((int)sd) + cmx[cx] + cmy[cy]) << 2) | (unsigned)cnd;
+                key = wave_min_u32(key);
+                if ((int)(key >> 2) < bcost) {
+                    const int b = key & 3;
+                    bcost = (int)(key >> 2);
+                    mx += b == 2 ? -2 : b == 3 ? 2 : 0; my += b == 0 ? -2 : b == 1 ? 2 : 0;
+                } else break;
+            }
+            // SATD at the best half-pel position
+            {
+                int e[4], p[4], d[4];
+                unpack4(cz, e); unpack4(mc_luma_row4(p00, pb, k.rs, px + zx, py + zy, mx, my), p);
+    #pragma unroll
+                for (int i = 0; i < 4; i++) d[i] = e[i] - p[i];
+                bcost = (wave_sum(satd_quad_partial(d, lane)) >> 1) + cmx[mx] + cmy[my];
+            }
+            // quarter-pel diamond, SATD: (0,-1) (0,1) (-1,0) (1,0), never stepping straight back
+            int bdir = -1;
+            for (int it = qp_it; it > 0; it--) {
+                if (my <= smin1 || my >= smax1 || mx <= smin0 || mx >= smax0) break;
+                const int odir = bdir, omx = mx, omy = my;
+                for (int q = 0; q < 4; q++) {
+                    if ((q ^ 1) == odir) continue;
+                    const int cx = omx + (q == 2 ? -1 : q == 3 ? 1 : 0), cy = omy + (q == 0 ? -1 : q == 1 ? 1 : 0);
+                    int e[4], p[4], d[4];
+                    unpack4(cz, e); unpack4(mc_luma_row4(p00, pb, k.rs, px + zx, py + zy, cx, cy), p);
+    #pragma unroll
+                    for (int i = 0; i < 4; i++) d[i] = e[i] - p[i];
+                    const int c = (wave_sum(satd_quad_partial(d, lane)) >> 1) + cmx[cx] + cmy[cy];
+                    if (c < bcost) { bcost = c; mx = cx; my = cy; bdir = q; }
+                }
+                if (mx == omx && my == omy) break;
+            }
+        }
+
+        bcost += k.lambda * ref_bits(k.nref, r_);
+        if (bcost < best16) { best16 = bcost; best_mx = mx; best_my = my; bref = r_; }
+        __builtin_amdgcn_wave_barrier();
     }
+    const uint8_t *p00 = ref_plane00(k, s, bref);
+    int mx = best_mx, my = best_my, bcost = best16;
 
     // ---- sub-partitions (oracle analyse_p_mb): 8x8 first, 16x8 / 8x16 only if 8x8 beat 16x16 ----
     const int cost16 = bcost;
@@ -368,7 +378,7 @@ __global__ __launch_bounds__(256) void k_analyse_p(EncK k)
             if (oi > 0 && best_shape == 0) break;
             int smx, smy;
             const int pcost = search_shape(pc, shape, c0x, c0y, smx, smy);
-            int total = k.lambda * (shape == 3 ? 8 : 2);
+            int total = k.lambda * ((shape == 3 ? 8 : 2) + (shape == 3 ? 4 : 2) * ref_bits(k.nref, bref));
             if (shape == 3) total += __builtin_amdgcn_readlane(pcost, 0) + __builtin_amdgcn_readlane(pcost, 16) + __builtin_amdgcn_readlane(pcost, 32) + __builtin_amdgcn_readlane(pcost, 48);
             else if (shape == 1) total += __builtin_amdgcn_readlane(pcost, 0) + __builtin_amdgcn_readlane(pcost, 32);
             else total += __builtin_amdgcn_readlane(pcost, 0) + __builtin_amdgcn_readlane(pcost, 16);
@@ -425,8 +435,8 @@ __global__ __launch_bounds__(256) void k_analyse_p(EncK k)
             rec.cost = bcost;
             rec.mv[0][0] = (int16_t)m0x; rec.mv[0][1] = (int16_t)m0y; rec.mv[1][0] = (int16_t)m1x; rec.mv[1][1] = (int16_t)m1y;
             rec.mv[2][0] = (int16_t)m2x; rec.mv[2][1] = (int16_t)m2y; rec.mv[3][0] = (int16_t)m3x; rec.mv[3][1] = (int16_t)m3y;
-            for (int i = 0; i < 4; i++) rec.ref[i] = 0;
-            k.reff_cur[(size_t)s * k.nmb + mbi] = 0; mo[0] = (int16_t)mx; mo[1] = (int16_t)my;     // field carries the 16x16 vector
+            for (int i = 0; i < 4; i++) rec.ref[i] = (int8_t)bref;
+            k.reff_cur[(size_t)s * k.nmb + mbi] = (int8_t)bref; mo[0] = (int16_t)mx; mo[1] = (int16_t)my;     // field carries the 16x16 vector
         }
         *mb = rec;
     }

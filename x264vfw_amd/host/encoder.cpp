@@ -70,7 +70,7 @@ static SpsParams make_sps(const x264_t *h)
     SpsParams s = {};
     s.profile_idc = h->profile_idc; s.level_idc = h->level_idc; s.sps_id = p.i_sps_id;
     s.mbw = h->mbw; s.mbh = h->mbh; s.crop_right = h->mbw * 16 - p.i_width; s.crop_bottom = h->mbh * 16 - p.i_height;
-    s.num_ref_frames = 1; s.log2_max_frame_num = h->log2_max_frame_num;
+    s.num_ref_frames = h->param.i_frame_reference; s.log2_max_frame_num = h->log2_max_frame_num;
     s.sar_w = p.vui.i_sar_width; s.sar_h = p.vui.i_sar_height; s.fullrange = p.vui.b_fullrange;
     s.colorprim = p.vui.i_colorprim; s.transfer = p.vui.i_transfer; s.colmatrix = p.vui.i_colmatrix;
     s.overscan = p.vui.i_overscan; s.vidformat = p.vui.i_vidformat;
@@ -80,7 +80,7 @@ static SpsParams make_sps(const x264_t *h)
 }
 static PpsParams make_pps(const x264_t *h)
 {
-    PpsParams pp = { h->param.i_sps_id, h->param.i_sps_id, 0, 1, h->pic_init_qp, h->param.analyse.i_chroma_qp_offset };
+    PpsParams pp = { h->param.i_sps_id, h->param.i_sps_id, 0, h->param.i_frame_reference, h->pic_init_qp, h->param.analyse.i_chroma_qp_offset };
     return pp;
 }
 // appends SPS, PPS (and optionally the version SEI) to h->out, recording NAL offsets and types
@@ -118,7 +118,9 @@ x264_t *x264_encoder_open(x264_param_t *param)
 
     // ---- effective parameters: what this round's pipeline implements (reported back via encoder_parameters) ----
     if (p.i_bframe) { xlog(&p, X264_LOG_WARNING, "B-frames are not implemented in the MI355X path yet: bframes 0\n"); p.i_bframe = 0; }
-    if (p.i_frame_reference != 1) { xlog(&p, X264_LOG_INFO, "ref %d -> 1 (single reference this round)\n", p.i_frame_reference); p.i_frame_reference = 1; }
+    if (p.i_frame_reference > 4) { xlog(&p, X264_LOG_INFO, "ref %d -> 4 (DPB of the MI355X path holds up to 4 references)\n", p.i_frame_reference); p.i_frame_reference = 4; }
+    if (p.i_frame_reference < 1) p.i_frame_reference = 1;
+    p.analyse.b_mixed_references = 0;
     if (p.b_cabac) { xlog(&p, X264_LOG_WARNING, "CABAC is not implemented yet: using CAVLC\n"); p.b_cabac = 0; }
     p.analyse.b_transform_8x8 = 0; p.analyse.i_weighted_pred = X264_WEIGHTP_NONE; p.analyse.b_weighted_bipred = 0;
     p.analyse.inter &= X264_ANALYSE_I4x4 | X264_ANALYSE_PSUB16x16; p.analyse.intra &= X264_ANALYSE_I4x4;
@@ -137,13 +139,13 @@ x264_t *x264_encoder_open(x264_param_t *param)
     h->qp_i = clampi((int)(h->qp_p - 6.0 * log2(p.rc.f_ip_factor > 0 ? p.rc.f_ip_factor : 1.0) + 0.5), 1, 51);
     h->pic_init_qp = clampi(h->qp_p, 0, 51);
     h->profile_idc = 66;
-    h->level_idc = p.i_level_idc > 0 ? p.i_level_idc : pick_level(&p, h->nmb, 1);
+    h->level_idc = p.i_level_idc > 0 ? p.i_level_idc : pick_level(&p, h->nmb, p.i_frame_reference);
     p.i_level_idc = h->level_idc;
     h->log2_max_frame_num = 4;
     while ((1 << h->log2_max_frame_num) <= (h->keyint < 65536 ? h->keyint : 65535) && h->log2_max_frame_num < 16) h->log2_max_frame_num++;
 
     x264gpu_config cfg = {};
-    cfg.width = p.i_width; cfg.height = p.i_height; cfg.streams = 1; cfg.refs = 1;
+    cfg.width = p.i_width; cfg.height = p.i_height; cfg.streams = 1; cfg.refs = p.i_frame_reference;
     cfg.qp_i = h->qp_i; cfg.qp_p = h->qp_p; cfg.me_range = p.analyse.i_me_range; cfg.subme = p.analyse.i_subpel_refine;
     cfg.deblock = p.b_deblocking_filter; cfg.deblock_alpha = p.i_deblocking_filter_alphac0; cfg.deblock_beta = p.i_deblocking_filter_beta;
     cfg.chroma_qp_offset = p.analyse.i_chroma_qp_offset;
@@ -232,7 +234,9 @@ int x264_encoder_encode(x264_t *h, x264_nal_t **pp_nal, int *pi_nal, x264_pictur
     SliceParams sp = {};
     sp.mbw = h->mbw; sp.mbh = h->mbh; sp.slice_type = st; sp.qp = idr ? h->qp_i : h->qp_p; sp.pic_init_qp = h->pic_init_qp;
     sp.frame_num = h->frame_num; sp.log2_max_frame_num = h->log2_max_frame_num;
-    sp.idr = idr; sp.idr_pic_id = h->idr_pic_id; sp.nal_ref_idc = idr ? 3 : 2; sp.pps_id = p.i_sps_id; sp.num_ref = 1;
+    sp.idr = idr; sp.idr_pic_id = h->idr_pic_id; sp.nal_ref_idc = idr ? 3 : 2; sp.pps_id = p.i_sps_id;
+    sp.num_ref_default = p.i_frame_reference;
+    sp.num_ref = h->frames_since_idr < p.i_frame_reference ? (h->frames_since_idr > 0 ? h->frames_since_idr : 1) : p.i_frame_reference;
     sp.disable_deblock_idc = p.b_deblocking_filter ? 0 : 1;
     sp.alpha_off_div2 = p.i_deblocking_filter_alphac0; sp.beta_off_div2 = p.i_deblocking_filter_beta;
     h->nal_off.push_back(h->out.size()); types.push_back(idr ? 5 : 1);
@@ -267,12 +271,13 @@ void x264_encoder_close(x264_t *h)
 
 /* test/diagnostic hooks (not part of the x264 API): entropy-code caller-supplied records, fetch the GPU recon */
 int x264host_write_slice(int mbw, int mbh, int slice_type, int qp, int pic_init_qp, int frame_num, int log2_max_frame_num,
-                         int idr, int idr_pic_id, int disable_deblock_idc, const x264gpu_mb *mbs, const int16_t *levels,
-                         uint8_t *out, int cap, int *skipped)
+                         int idr, int idr_pic_id, int disable_deblock_idc, int num_ref, int num_ref_default,
+                         const x264gpu_mb *mbs, const int16_t *levels, uint8_t *out, int cap, int *skipped)
 {
     SliceParams sp = {};
     sp.mbw = mbw; sp.mbh = mbh; sp.slice_type = slice_type; sp.qp = qp; sp.pic_init_qp = pic_init_qp; sp.frame_num = frame_num;
-    sp.log2_max_frame_num = log2_max_frame_num; sp.idr = idr; sp.idr_pic_id = idr_pic_id; sp.nal_ref_idc = idr ? 3 : 2; sp.num_ref = 1;
+    sp.log2_max_frame_num = log2_max_frame_num; sp.idr = idr; sp.idr_pic_id = idr_pic_id; sp.nal_ref_idc = idr ? 3 : 2;
+    sp.num_ref = num_ref; sp.num_ref_default = num_ref_default;
     sp.disable_deblock_idc = disable_deblock_idc;
     std::vector<uint8_t> v;
     SliceStats stt = { 0 };
@@ -284,16 +289,16 @@ int x264host_write_slice(int mbw, int mbh, int slice_type, int qp, int pic_init_
 }
 
 int x264host_write_headers(int width, int height, int level_idc, int log2_max_frame_num, int pic_init_qp, int chroma_qp_offset,
-                           uint32_t num_units_in_tick, uint32_t time_scale, uint8_t *out, int cap)
+                           uint32_t num_units_in_tick, uint32_t time_scale, int num_ref, uint8_t *out, int cap)
 {
     SpsParams s = {};
     s.profile_idc = 66; s.level_idc = level_idc; s.mbw = (width + 15) / 16; s.mbh = (height + 15) / 16;
-    s.crop_right = s.mbw * 16 - width; s.crop_bottom = s.mbh * 16 - height; s.num_ref_frames = 1; s.log2_max_frame_num = log2_max_frame_num;
+    s.crop_right = s.mbw * 16 - width; s.crop_bottom = s.mbh * 16 - height; s.num_ref_frames = num_ref; s.log2_max_frame_num = log2_max_frame_num;
     s.fullrange = 0; s.colorprim = 2; s.transfer = 2; s.colmatrix = 2; s.vidformat = 5;
     s.num_units_in_tick = num_units_in_tick; s.time_scale = time_scale; s.constraint_set0 = 1; s.constraint_set1 = 1;
     std::vector<uint8_t> v;
     write_sps(v, s, true);
-    PpsParams pp = { 0, 0, 0, 1, pic_init_qp, chroma_qp_offset };
+    PpsParams pp = { 0, 0, 0, num_ref, pic_init_qp, chroma_qp_offset };
     write_pps(v, pp, true);
     if ((int)v.size() > cap) return -1;
     memcpy(out, v.data(), v.size());

@@ -14,7 +14,8 @@ struct SliceParams {
     int frame_num, log2_max_frame_num;
     int idr, idr_pic_id, nal_ref_idc;
     int pps_id;
-    int num_ref;
+    int num_ref;             // active references of this slice (te() range)
+    int num_ref_default;     // PPS num_ref_idx_l0_default_active
     int disable_deblock_idc, alpha_off_div2, beta_off_div2;
 };
 struct SliceStats { int skip; };

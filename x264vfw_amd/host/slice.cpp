@@ -274,7 +274,9 @@ void write_slice_header(BitWriter &bw, const SliceParams &p)
     if (p.idr) bw.ue(p.idr_pic_id);
     // pic_order_cnt_type 2: nothing to send
     if (p.slice_type != X264GPU_SLICE_I) {
-        bw.put1(0);                                             // num_ref_idx_active_override_flag
+        const bool ovr = p.num_ref != p.num_ref_default;       // fewer pictures in the DPB than the PPS default
+        bw.put1(ovr);                                           // num_ref_idx_active_override_flag
+        if (ovr) bw.ue(p.num_ref - 1);
         bw.put1(0);                                             // ref_pic_list_modification_flag_l0
     }
     if (p.nal_ref_idc) {
