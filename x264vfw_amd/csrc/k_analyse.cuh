@@ -5,13 +5,18 @@
 //              staged in LDS with coalesced 8-byte loads; candidates are evaluated four at a time,
 //              lane = (candidate, row): 16 pixels per lane via v_alignbyte + v_sad_u8, 16-lane DPP row
 //              reduction, then a packed (cost<<3|tag) wave min replaying x264's first-best tie-breaks.
-//   sub-pel:   half-pel diamond on SAD, quarter-pel diamond on SATD; samples come straight from the four
-//              half-pel planes in HBM/L2 (mc_luma_row4), SATD in the Z layout (quad = 4x4 block).
+//   sub-pel:   half-pel diamond on SAD, quarter-pel diamond on SATD; the +-2 px neighbourhood of the full-pel
+//              winner in all four half-pel planes is staged in LDS once (sub_stage), SATD in the Z layout.
 // Restates oracle/encoder.c me_search_16x16 / intra16_estimate / analyse_p_mb bit-exactly.
 #pragma once
 #include "enc_common.cuh"
 
 namespace x264gpu {
+
+// occupancy the register allocator targets for k_analyse_p (waves per SIMD)
+#ifndef X264GPU_ANALYSE_WAVES
+#define X264GPU_ANALYSE_WAVES 4
+#endif
 
 constexpr int WIN_ROWS = 50, WIN_COLS = 64, WIN_STRIDE = 68, WIN_R = 17;
 
@@ -49,6 +54,86 @@ __device__ __forceinline__ int sq_dx(int k) { return (int)((0x22002011u >> (4 * 
 __device__ __forceinline__ int sq_dy(int k) { return (int)((0x20201120u >> (4 * (k - 1))) & 15) - 1; }
 
 // ------------------------------------------------------------------------------------------------
+// Sub-pel neighbourhood in LDS.  Once a full-pel vector is fixed, every sample the half-/quarter-pel
+// diamonds can touch lies within +-2 px of the displaced block, in one of the four half-pel planes.  The
+// lanes of a partition copy that neighbourhood ((h+4) rows x (w+4 rounded to dwords) of all four planes) to
+// LDS with one batch of independent aligned dword loads; the refinement then runs without touching HBM/L2.
+//   geometry: rows `rh`, row pitch 1<<rwl dwords, `ncol` dwords per row actually loaded, n = rh<<rwl dwords
+//   per plane; origin (x0,y0) in picture coordinates, x0 a multiple of 4.
+// ------------------------------------------------------------------------------------------------
+// M = margin in pixels: 2 covers subme <= 7 (2 half-pel + 3 quarter-pel steps), 5 covers the 4 + 10 steps of subme >= 8.
+template <int M> struct SubGeo {
+    static constexpr int DWORDS = M == 2 ? 768 : 2304;            // 4 parts x 4 planes x (8+2M) rows x pitch (8x8 is the largest)
+    static __device__ __forceinline__ int rwl(int w) { return M == 2 && w == 8 ? 2 : 3; }
+    static __device__ __forceinline__ int ncol(int w) { return (w + 2 * M + 6) >> 2; }
+    static __device__ __forceinline__ int rh(int h) { return h + 2 * M; }
+};
+template <int M>
+__device__ __forceinline__ void sub_stage(uint32_t *buf, const uint8_t *__restrict__ p00, size_t pb, int rs, int x0, int y0,
+                                          int rwl, int rh, int ncol, int li, int L)
+{
+    const int n = rh << rwl;
+    if (M == 2) {                                                    // n <= 3*L for every shape: 12 loads in flight, then 12 stores
+        uint32_t v[12];
+#pragma unroll
+        for (int pl = 0; pl < 4; pl++)
+#pragma unroll
+            for (int t = 0; t < 3; t++) {
+                const int i = li + t * L, row = i >> rwl, col = i & ((1 << rwl) - 1);
+                v[pl * 3 + t] = (i < n && col < ncol) ? *(const uint32_t *)(p00 + pl * pb + (long)(y0 + row) * rs + x0 + 4 * col) : 0u;
+            }
+#pragma unroll
+        for (int pl = 0; pl < 4; pl++)
+#pragma unroll
+            for (int t = 0; t < 3; t++) {
+                const int i = li + t * L;
+                if (i < n) buf[pl * n + i] = v[pl * 3 + t];
+            }
+    } else {
+        for (int i = li; i < n; i += L) {
+            const int row = i >> rwl, col = i & ((1 << rwl) - 1);
+            uint32_t v[4];
+#pragma unroll
+            for (int pl = 0; pl < 4; pl++) v[pl] = col < ncol ? *(const uint32_t *)(p00 + pl * pb + (long)(y0 + row) * rs + x0 + 4 * col) : 0u;
+#pragma unroll
+            for (int pl = 0; pl < 4; pl++) buf[pl * n + i] = v[pl];
+        }
+    }
+}
+__device__ __forceinline__ uint32_t lds_u32_at(const uint32_t *buf, int byte_off)
+{
+    const uint32_t *w = buf + (byte_off >> 2);
+    return __builtin_amdgcn_alignbyte(w[1], w[0], byte_off & 3);
+}
+// mc_luma_row4 on the staged neighbourhood: 4 pixels at picture position (x..x+3, y) displaced by (mvx,mvy) qpel
+__device__ __forceinline__ uint32_t sub_row4(const uint32_t *buf, int n, int rwl, int x0, int y0, int x, int y, int mvx, int mvy)
+{
+    const int idx = ((mvy & 3) << 2) | (mvx & 3);
+    const int pl0 = (kQpelPlane0Packed >> (2 * idx)) & 3, pl1 = (kQpelPlane1Packed >> (2 * idx)) & 3;
+    const int bx = x + (mvx >> 2) - x0, by = y + (mvy >> 2) - y0;
+    const uint32_t a = lds_u32_at(buf + pl0 * n, (((by + ((mvy & 3) == 3 ? 1 : 0)) << rwl) << 2) + bx);
+    const uint32_t b = lds_u32_at(buf + pl1 * n, ((by << rwl) << 2) + bx + ((mvx & 3) == 3 ? 1 : 0));
+    return (idx & 5) ? avg4_u8(a, b) : a;
+}
+// SAD of a 16-pixel row at a HALF-pel displacement (single plane, no averaging) against cr[4]
+__device__ __forceinline__ int sub_sad_row16_hpel(const uint32_t *buf, int n, int rwl, int x0, int y0, int x, int y, int mvx, int mvy,
+                                                  const uint32_t cr[4])
+{
+    const int idx = ((mvy & 3) << 2) | (mvx & 3);
+    const int pl0 = (kQpelPlane0Packed >> (2 * idx)) & 3;
+    const int off = (((y + (mvy >> 2) - y0) << rwl) << 2) + x + (mvx >> 2) - x0;
+    const uint32_t *w = buf + pl0 * n + (off >> 2);
+    const int sh = off & 3;
+    const uint32_t w0 = w[0], w1 = w[1], w2 = w[2], w3 = w[3], w4 = w[4];
+    unsigned sd = 0;
+    sd = __builtin_amdgcn_sad_u8(__builtin_amdgcn_alignbyte(w1, w0, sh), cr[0], sd);
+    sd = __builtin_amdgcn_sad_u8(__builtin_amdgcn_alignbyte(w2, w1, sh), cr[1], sd);
+    sd = __builtin_amdgcn_sad_u8(__builtin_amdgcn_alignbyte(w3, w2, sh), cr[2], sd);
+    sd = __builtin_amdgcn_sad_u8(__builtin_amdgcn_alignbyte(w4, w3, sh), cr[3], sd);
+    return (int)sd;
+}
+
+// ------------------------------------------------------------------------------------------------
 // Sub-partition search (P16x8 / P8x16 / P8x8) in the Z layout: every partition of a shape is searched at
 // the same time, each on its own lanes (an 8x8 block is one DPP row of 16 lanes), with lane-private motion
 // state and predicated updates, so the wave runs ONE instruction stream for 2 or 4 independent hexagon /
@@ -62,6 +147,7 @@ struct PartCtx {
     int px, py, zx, zy; uint32_t cz;           // macroblock position, lane position, lane's 4 source pixels
     int fmin0, fmax0, fmin1, fmax1, smin0, smax0, smin1, smax1;
     int me_range, hp_it, qp_it, lane;
+    uint32_t *sub;                             // LDS sub-pel neighbourhood buffer (SUB_DWORDS)
 };
 __device__ __forceinline__ int part_sum(int v, int shape)
 {
@@ -79,6 +165,7 @@ __device__ __forceinline__ int pc_fpel_cost(const PartCtx &c, int fx, int fy, in
     return part_sum(sad4(ref, c.cz), shape) + pc_mvcost(c, fx * 4, fy * 4);
 }
 // returns the partition cost (uniform over the partition's lanes) and this lane's partition mv (qpel)
+template <int M>
 __device__ int search_shape(const PartCtx &c, int shape, int c0x, int c0y, int &out_mx, int &out_my)
 {
     int bx = c0x, by = c0y;
@@ -114,13 +201,31 @@ __device__ int search_shape(const PartCtx &c, int shape, int c0x, int c0y, int &
     if (c.hp_it > 0) {
         int e[4];
         unpack4(c.cz, e);
+        // stage this partition's sub-pel neighbourhood (origin follows the partition's own full-pel vector)
+        const int pw = shape == 1 ? 16 : 8, ph_ = shape == 2 ? 16 : 8;
+        const int rwl = SubGeo<M>::rwl(pw), rh = SubGeo<M>::rh(ph_), ncol = SubGeo<M>::ncol(pw), sn = rh << rwl;
+        const int pi = shape == 3 ? c.lane >> 4 : shape == 1 ? c.lane >> 5 : (c.lane >> 4) & 1;
+        const int li = shape == 3 ? c.lane & 15 : shape == 1 ? c.lane & 31 : (c.lane & 15) | ((c.lane >> 5) << 4);
+        const int partx = shape == 1 ? 0 : (c.zx & 8), party = shape == 2 ? 0 : (c.zy & 8);
+        const int sx0 = (c.px + partx + bx - M) & ~3, sy0 = c.py + party + by - M;
+        uint32_t *sb = c.sub + pi * 4 * sn;
+        __builtin_amdgcn_wave_barrier();
+        sub_stage<M>(sb, c.p00, c.pb, c.rs, sx0, sy0, rwl, rh, ncol, li, shape == 3 ? 16 : 32);
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_s_waitcnt(0xc07f);
+    #define SUBPX(qx, qy) sub_row4(sb, sn, rwl, sx0, sy0, c.px + c.zx, c.py + c.zy, (qx), (qy))
         bool hp_run = true;
         for (int it = c.hp_it; it > 0; it--) {
             if (!__any(hp_run)) break;
             unsigned kk = 0xffffffffu;
+            uint32_t ph[4];
+#pragma unroll
+            for (int q = 0; q < 4; q++)
+                ph[q] = SUBPX(mx + (q == 2 ? -2 : q == 3 ? 2 : 0), my + (q == 0 ? -2 : q == 1 ? 2 : 0));
+#pragma unroll
             for (int q = 0; q < 4; q++) {
                 const int cxq = mx + (q == 2 ? -2 : q == 3 ? 2 : 0), cyq = my + (q == 0 ? -2 : q == 1 ? 2 : 0);
-                const int cst = part_sum(sad4(mc_luma_row4(c.p00, c.pb, c.rs, c.px + c.zx, c.py + c.zy, cxq, cyq), c.cz), shape) + pc_mvcost(c, cxq, cyq);
+                const int cst = part_sum(sad4(ph[q], c.cz), shape) + pc_mvcost(c, cxq, cyq);
                 kk = min(kk, ((unsigned)cst << 2) | (unsigned)q);
             }
             if (hp_run && (int)(kk >> 2) < bcost) {
@@ -131,7 +236,7 @@ __device__ int search_shape(const PartCtx &c, int shape, int c0x, int c0y, int &
         }
         {
             int p[4], d[4];
-            unpack4(mc_luma_row4(c.p00, c.pb, c.rs, c.px + c.zx, c.py + c.zy, mx, my), p);
+            unpack4(SUBPX(mx, my), p);
 #pragma unroll
             for (int i = 0; i < 4; i++) d[i] = e[i] - p[i];
             bcost = (part_sum(satd_quad_partial(d, c.lane), shape) >> 1) + pc_mvcost(c, mx, my);
@@ -142,10 +247,15 @@ __device__ int search_shape(const PartCtx &c, int shape, int c0x, int c0y, int &
             if (!__any(qp_run)) break;
             qp_run = qp_run && !(my <= c.smin1 || my >= c.smax1 || mx <= c.smin0 || mx >= c.smax0);
             const int odir = bdir, omx = mx, omy = my;
+            uint32_t pq[4];
+#pragma unroll
+            for (int q = 0; q < 4; q++)
+                pq[q] = SUBPX(omx + (q == 2 ? -1 : q == 3 ? 1 : 0), omy + (q == 0 ? -1 : q == 1 ? 1 : 0));
+#pragma unroll
             for (int q = 0; q < 4; q++) {
                 const int cxq = omx + (q == 2 ? -1 : q == 3 ? 1 : 0), cyq = omy + (q == 0 ? -1 : q == 1 ? 1 : 0);
                 int p[4], d[4];
-                unpack4(mc_luma_row4(c.p00, c.pb, c.rs, c.px + c.zx, c.py + c.zy, cxq, cyq), p);
+                unpack4(pq[q], p);
 #pragma unroll
                 for (int i = 0; i < 4; i++) d[i] = e[i] - p[i];
                 const int cst = (part_sum(satd_quad_partial(d, c.lane), shape) >> 1) + pc_mvcost(c, cxq, cyq);
@@ -153,16 +263,19 @@ __device__ int search_shape(const PartCtx &c, int shape, int c0x, int c0y, int &
             }
             if (mx == omx && my == omy) qp_run = false;
         }
+    #undef SUBPX
     }
     out_mx = mx; out_my = my;
     return bcost;
 }
 
-__global__ __launch_bounds__(256) void k_analyse_p(EncK k)
+template <int M>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(X264GPU_ANALYSE_WAVES, 8))) void k_analyse_p(EncK k)
 {
     __shared__ __attribute__((aligned(16))) uint8_t s_win[4][WIN_ROWS * WIN_STRIDE];
     __shared__ uint8_t s_nb[4][NB_SIZE];
     __shared__ uint16_t s_cost[4][2][192];
+    __shared__ uint32_t s_sub[4][SubGeo<M>::DWORDS];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int mbi = blockIdx.x * 4 + wave, s = blockIdx.y;
     if (mbi >= k.nmb) return;                       // wave-uniform; no block-wide barriers below
@@ -239,12 +352,20 @@ __global__ __launch_bounds__(256) void k_analyse_p(EncK k)
             uint32_t *d = (uint32_t *)(win + row * WIN_STRIDE + col);
             d[0] = v.x; d[1] = v.y;
         }
+        // mv-cost table slices around the start vector into LDS: every later cost lookup of this search is an
+        // LDS read instead of a dependent global load (hex moves <= 17 px, sub-pel <= 1 px: |delta| < 96 qpel)
+        const int cbx = bmx * 4, cby = bmy * 4;
+        for (int i = lane; i < 192; i += 64) {
+            s_cost[wave][0][i] = cmx[cbx + i - 96];
+            s_cost[wave][1][i] = cmy[cby + i - 96];
+        }
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_s_waitcnt(0xc07f);
+    #define MVC(qx, qy) ((int)s_cost[wave][0][(qx) - cbx + 96] + (int)s_cost[wave][1][(qy) - cby + 96])
 
         // cost of full-pel candidate (mx,my) for this lane's row; valid after row16_sum on the 16-lane group
     #define FPEL_KEY(mx, my, tag) \
-        (((unsigned)(row16_sum(sad_row16_lds(win + (py + (my) + r - wy0) * WIN_STRIDE, px + (mx) - wx0, cr)) + cmx[(mx) * 4] + cmy[(my) * 4]) << 3) | (unsigned)(tag))
+        (((unsigned)(row16_sum(sad_row16_lds(win + (py + (my) + r - wy0) * WIN_STRIDE, px + (mx) - wx0, cr)) + MVC((mx) * 4, (my) * 4)) << 3) | (unsigned)(tag))
 
         // ---- hexagon search ----
         {
@@ -297,13 +418,17 @@ __global__ __launch_bounds__(256) void k_analyse_p(EncK k)
             const int sub = min(k.subme, 11);
             const int hp_it = sub < 6 ? 1 : sub < 8 ? 2 : 4;
             const int qp_it = sub < 4 ? 0 : sub == 4 ? 1 : sub < 8 ? 2 : 10;
+            // the whole refinement reads the staged neighbourhood of the full-pel winner
+            uint32_t *sb = s_sub[wave];
+            const int sx0 = (px + bmx - M) & ~3, sy0 = py + bmy - M, rwl = 3, sn = SubGeo<M>::rh(16) << 3;
+            sub_stage<M>(sb, p00, pb, k.rs, sx0, sy0, rwl, SubGeo<M>::rh(16), SubGeo<M>::ncol(16), lane, 64);
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_s_waitcnt(0xc07f);
             // half-pel diamond, SAD, lane = (candidate, row): (0,-2) (0,2) (-2,0) (2,0)
             for (int it = hp_it; it > 0; it--) {
                 const int cx = mx + (cnd == 2 ? -2 : cnd == 3 ? 2 : 0), cy = my + (cnd == 0 ? -2 : cnd == 1 ? 2 : 0);
-                unsigned sd = 0;
-    #pragma unroll
-                for (int i = 0; i < 4; i++) sd = __builtin_amdgcn_sad_u8(mc_luma_row4(p00, pb, k.rs, px + 4 * i, py + r, cx, cy), cr[i], sd);
-                unsigned key = ((unsigned)(row16_sum((int)sd) + cmx[cx] + cmy[cy]) << 2) | (unsigned)cnd;
+                const int sd = sub_sad_row16_hpel(sb, sn, rwl, sx0, sy0, px, py + r, cx, cy, cr);
+                unsigned key = ((unsigned)(row16_sum(sd) + MVC(cx, cy)) << 2) | (unsigned)cnd;
                 key = wave_min_u32(key);
                 if ((int)(key >> 2) < bcost) {
                     const int b = key & 3;
@@ -314,30 +439,37 @@ __global__ __launch_bounds__(256) void k_analyse_p(EncK k)
             // SATD at the best half-pel position
             {
                 int e[4], p[4], d[4];
-                unpack4(cz, e); unpack4(mc_luma_row4(p00, pb, k.rs, px + zx, py + zy, mx, my), p);
+                unpack4(cz, e); unpack4(sub_row4(sb, sn, rwl, sx0, sy0, px + zx, py + zy, mx, my), p);
     #pragma unroll
                 for (int i = 0; i < 4; i++) d[i] = e[i] - p[i];
-                bcost = (wave_sum(satd_quad_partial(d, lane)) >> 1) + cmx[mx] + cmy[my];
+                bcost = (wave_sum(satd_quad_partial(d, lane)) >> 1) + MVC(mx, my);
             }
             // quarter-pel diamond, SATD: (0,-1) (0,1) (-1,0) (1,0), never stepping straight back
             int bdir = -1;
             for (int it = qp_it; it > 0; it--) {
                 if (my <= smin1 || my >= smax1 || mx <= smin0 || mx >= smax0) break;
                 const int odir = bdir, omx = mx, omy = my;
+                // fetch the four candidates' samples first (independent loads, one round trip), then evaluate in order
+                uint32_t pq[4];
+    #pragma unroll
+                for (int q = 0; q < 4; q++)
+                    pq[q] = sub_row4(sb, sn, rwl, sx0, sy0, px + zx, py + zy, omx + (q == 2 ? -1 : q == 3 ? 1 : 0), omy + (q == 0 ? -1 : q == 1 ? 1 : 0));
+    #pragma unroll
                 for (int q = 0; q < 4; q++) {
                     if ((q ^ 1) == odir) continue;
                     const int cx = omx + (q == 2 ? -1 : q == 3 ? 1 : 0), cy = omy + (q == 0 ? -1 : q == 1 ? 1 : 0);
                     int e[4], p[4], d[4];
-                    unpack4(cz, e); unpack4(mc_luma_row4(p00, pb, k.rs, px + zx, py + zy, cx, cy), p);
+                    unpack4(cz, e); unpack4(pq[q], p);
     #pragma unroll
                     for (int i = 0; i < 4; i++) d[i] = e[i] - p[i];
-                    const int c = (wave_sum(satd_quad_partial(d, lane)) >> 1) + cmx[cx] + cmy[cy];
+                    const int c = (wave_sum(satd_quad_partial(d, lane)) >> 1) + MVC(cx, cy);
                     if (c < bcost) { bcost = c; mx = cx; my = cy; bdir = q; }
                 }
                 if (mx == omx && my == omy) break;
             }
         }
 
+    #undef MVC
         bcost += k.lambda * ref_bits(k.nref, r_);
         if (bcost < best16) { best16 = bcost; best_mx = mx; best_my = my; bref = r_; }
         __builtin_amdgcn_wave_barrier();
@@ -369,7 +501,7 @@ __global__ __launch_bounds__(256) void k_analyse_p(EncK k)
         pc.win = win; pc.wx0 = pwx0; pc.wy0 = pwy0; pc.cx = s_cost[wave][0]; pc.cy = s_cost[wave][1]; pc.cbx = c0x * 4; pc.cby = c0y * 4;
         pc.p00 = p00; pc.pb = k.plane_bytes; pc.rs = k.rs; pc.px = px; pc.py = py; pc.zx = zx; pc.zy = zy; pc.cz = cz;
         pc.fmin0 = fmin0; pc.fmax0 = fmax0; pc.fmin1 = fmin1; pc.fmax1 = fmax1; pc.smin0 = smin0; pc.smax0 = smax0; pc.smin1 = smin1; pc.smax1 = smax1;
-        pc.me_range = k.me_range; pc.lane = lane;
+        pc.me_range = k.me_range; pc.lane = lane; pc.sub = s_sub[wave];
         const int sub = min(k.subme, 11);
         pc.hp_it = sub < 2 ? 0 : sub < 6 ? 1 : sub < 8 ? 2 : 4;
         pc.qp_it = sub < 4 ? 0 : sub == 4 ? 1 : sub < 8 ? 2 : 10;
@@ -377,7 +509,7 @@ __global__ __launch_bounds__(256) void k_analyse_p(EncK k)
             const int shape = oi == 0 ? 3 : oi;
             if (oi > 0 && best_shape == 0) break;
             int smx, smy;
-            const int pcost = search_shape(pc, shape, c0x, c0y, smx, smy);
+            const int pcost = search_shape<M>(pc, shape, c0x, c0y, smx, smy);
             int total = k.lambda * ((shape == 3 ? 8 : 2) + (shape == 3 ? 4 : 2) * ref_bits(k.nref, bref));
             if (shape == 3) total += __builtin_amdgcn_readlane(pcost, 0) + __builtin_amdgcn_readlane(pcost, 16) + __builtin_amdgcn_readlane(pcost, 32) + __builtin_amdgcn_readlane(pcost, 48);
             else if (shape == 1) total += __builtin_amdgcn_readlane(pcost, 0) + __builtin_amdgcn_readlane(pcost, 32);
