@@ -154,6 +154,60 @@ __device__ __forceinline__ int satd_quad_partial(const int d[4], int lane)
     return abs(t[0]) + abs(t[1]) + abs(t[2]) + abs(t[3]);
 }
 
+// ---- packed-16 SATD ------------------------------------------------------------------------------------
+// The 4x4 Hadamard of pixel differences never leaves 13 bits (16 * 255), so two coefficients share a VGPR
+// and v_pk_* instructions do two butterflies at once.  Two identities remove most of the rest:
+//   * any permutation of the four inputs of a 4-point Hadamard only permutes/negates its outputs, so the
+//     byte pairs (0,2) / (1,3) that one AND / one shift+AND extract can be used as they come;
+//   * |a+b| + |a-b| = 2*max(|a|,|b|), so the last horizontal stage is a max, and because a block's 16
+//     coefficients all have the parity of its pixel sum, sum|c| is even: the per-lane "half share" below
+//     summed over the quad IS the block's SATD (sum|c| >> 1), exactly.
+typedef short s16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ s16x2 as_s16x2(uint32_t v) { return __builtin_bit_cast(s16x2, v); }
+__device__ __forceinline__ uint32_t as_u32(s16x2 v) { return __builtin_bit_cast(uint32_t, v); }
+__device__ __forceinline__ s16x2 pk_even(uint32_t p) { return as_s16x2(p & 0x00ff00ffu); }          // (p0, p2)
+__device__ __forceinline__ s16x2 pk_odd(uint32_t p) { return as_s16x2((p >> 8) & 0x00ff00ffu); }    // (p1, p3)
+// per-lane vertical butterfly signs: +1 on the lane that adds, -1 on the lane that subtracts
+__device__ __forceinline__ s16x2 pk_sign(bool neg) { return as_s16x2(neg ? 0xffffffffu : 0x00010001u); }
+template <int CTRL>
+__device__ __forceinline__ s16x2 pk_bfly(s16x2 v, s16x2 sg)
+{
+    const s16x2 y = as_s16x2((uint32_t)dpp<CTRL>((int)as_u32(v)));
+    return v * sg + y;                                             // v_pk_mad_i16
+}
+// half share of sum|H4 (e - p) H4| for one 4x4 block: lane = one row (4 packed pixels), quad = block
+__device__ __forceinline__ int satd4_half_pk(s16x2 e_even, s16x2 e_odd, uint32_t p, s16x2 sg1, s16x2 sg2)
+{
+    const s16x2 da = e_even - pk_even(p), db = e_odd - pk_odd(p);
+    s16x2 u = da + db, v = da - db;                                // first horizontal stage
+    u = pk_bfly<DPP_XOR1>(u, sg1); v = pk_bfly<DPP_XOR1>(v, sg1);  // both vertical stages across the quad
+    u = pk_bfly<DPP_XOR2>(u, sg2); v = pk_bfly<DPP_XOR2>(v, sg2);
+    u = __builtin_elementwise_max(u, -u); v = __builtin_elementwise_max(v, -v);
+    const s16x2 m = __builtin_elementwise_max(u, as_s16x2(__builtin_amdgcn_alignbit(as_u32(u), as_u32(u), 16))) +
+                    __builtin_elementwise_max(v, as_s16x2(__builtin_amdgcn_alignbit(as_u32(v), as_u32(v), 16)));
+    return (int)(as_u32(m) & 0xffffu);
+}
+__device__ __forceinline__ int satd4_half(uint32_t e, uint32_t p, int lane)
+{
+    return satd4_half_pk(pk_even(e), pk_odd(e), p, pk_sign(lane & 1), pk_sign(lane & 2));
+}
+// lane = one 16-pixel row (4 dwords); the quad covers four 4x4 blocks side by side: half share of their SATDs
+__device__ __forceinline__ int satd16x4_half_pk(const uint32_t e[4], const uint32_t p[4], s16x2 sg1, s16x2 sg2)
+{
+    s16x2 acc = as_s16x2(0u);
+#pragma unroll
+    for (int b = 0; b < 4; b++) {
+        const s16x2 da = pk_even(e[b]) - pk_even(p[b]), db = pk_odd(e[b]) - pk_odd(p[b]);
+        s16x2 u = da + db, v = da - db;
+        u = pk_bfly<DPP_XOR1>(u, sg1); v = pk_bfly<DPP_XOR1>(v, sg1);
+        u = pk_bfly<DPP_XOR2>(u, sg2); v = pk_bfly<DPP_XOR2>(v, sg2);
+        u = __builtin_elementwise_max(u, -u); v = __builtin_elementwise_max(v, -v);
+        acc += __builtin_elementwise_max(u, as_s16x2(__builtin_amdgcn_alignbit(as_u32(u), as_u32(u), 16))) +
+               __builtin_elementwise_max(v, as_s16x2(__builtin_amdgcn_alignbit(as_u32(v), as_u32(v), 16)));   // <= 8 * 4080
+    }
+    return (int)(as_u32(acc) & 0xffffu);
+}
+
 // 2-D 4x4 Hadamard kept in registers (natural layout in, same layout out, unnormalised)
 __device__ __forceinline__ void hadamard4_quad(int t[4], int lane)
 {

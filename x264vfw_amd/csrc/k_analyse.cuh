@@ -115,6 +115,23 @@ __device__ __forceinline__ uint32_t sub_row4(const uint32_t *buf, int n, int rwl
     const uint32_t b = lds_u32_at(buf + pl1 * n, ((by << rwl) << 2) + bx + ((mvx & 3) == 3 ? 1 : 0));
     return (idx & 5) ? avg4_u8(a, b) : a;
 }
+// 16 pixels of row y at picture x..x+15 displaced by the quarter-pel vector (mvx,mvy): out[4] packed dwords
+__device__ __forceinline__ void sub_row16(const uint32_t *buf, int n, int rwl, int x0, int y0, int x, int y, int mvx, int mvy, uint32_t out[4])
+{
+    const int idx = ((mvy & 3) << 2) | (mvx & 3);
+    const int pl0 = (kQpelPlane0Packed >> (2 * idx)) & 3, pl1 = (kQpelPlane1Packed >> (2 * idx)) & 3;
+    const int bx = x + (mvx >> 2) - x0, by = y + (mvy >> 2) - y0;
+    const int o0 = (((by + ((mvy & 3) == 3 ? 1 : 0)) << rwl) << 2) + bx, o1 = ((by << rwl) << 2) + bx + ((mvx & 3) == 3 ? 1 : 0);
+    const uint32_t *wa = buf + pl0 * n + (o0 >> 2), *wb = buf + pl1 * n + (o1 >> 2);
+    uint32_t a[5], b[5];
+#pragma unroll
+    for (int i = 0; i < 5; i++) { a[i] = wa[i]; b[i] = wb[i]; }
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        const uint32_t pa = __builtin_amdgcn_alignbyte(a[i + 1], a[i], o0 & 3), pb_ = __builtin_amdgcn_alignbyte(b[i + 1], b[i], o1 & 3);
+        out[i] = (idx & 5) ? avg4_u8(pa, pb_) : pa;
+    }
+}
 // SAD of a 16-pixel row at a HALF-pel displacement (single plane, no averaging) against cr[4]
 __device__ __forceinline__ int sub_sad_row16_hpel(const uint32_t *buf, int n, int rwl, int x0, int y0, int x, int y, int mvx, int mvy,
                                                   const uint32_t cr[4])
@@ -199,8 +216,7 @@ __device__ int search_shape(const PartCtx &c, int shape, int c0x, int c0y, int &
     }
     int mx = bx * 4, my = by * 4;
     if (c.hp_it > 0) {
-        int e[4];
-        unpack4(c.cz, e);
+        const s16x2 ze = pk_even(c.cz), zo = pk_odd(c.cz), sg1 = pk_sign(c.lane & 1), sg2 = pk_sign(c.lane & 2);
         // stage this partition's sub-pel neighbourhood (origin follows the partition's own full-pel vector)
         const int pw = shape == 1 ? 16 : 8, ph_ = shape == 2 ? 16 : 8;
         const int rwl = SubGeo<M>::rwl(pw), rh = SubGeo<M>::rh(ph_), ncol = SubGeo<M>::ncol(pw), sn = rh << rwl;
@@ -235,11 +251,7 @@ __device__ int search_shape(const PartCtx &c, int shape, int c0x, int c0y, int &
             } else hp_run = false;
         }
         {
-            int p[4], d[4];
-            unpack4(SUBPX(mx, my), p);
-#pragma unroll
-            for (int i = 0; i < 4; i++) d[i] = e[i] - p[i];
-            bcost = (part_sum(satd_quad_partial(d, c.lane), shape) >> 1) + pc_mvcost(c, mx, my);
+            bcost = part_sum(satd4_half_pk(ze, zo, SUBPX(mx, my), sg1, sg2), shape) + pc_mvcost(c, mx, my);
         }
         int bdir = -1;
         bool qp_run = true;
@@ -254,11 +266,7 @@ __device__ int search_shape(const PartCtx &c, int shape, int c0x, int c0y, int &
 #pragma unroll
             for (int q = 0; q < 4; q++) {
                 const int cxq = omx + (q == 2 ? -1 : q == 3 ? 1 : 0), cyq = omy + (q == 0 ? -1 : q == 1 ? 1 : 0);
-                int p[4], d[4];
-                unpack4(pq[q], p);
-#pragma unroll
-                for (int i = 0; i < 4; i++) d[i] = e[i] - p[i];
-                const int cst = (part_sum(satd_quad_partial(d, c.lane), shape) >> 1) + pc_mvcost(c, cxq, cyq);
+                const int cst = part_sum(satd4_half_pk(ze, zo, pq[q], sg1, sg2), shape) + pc_mvcost(c, cxq, cyq);
                 if (qp_run && (q ^ 1) != odir && cst < bcost) { bcost = cst; mx = cxq; my = cyq; bdir = q; }
             }
             if (mx == omx && my == omy) qp_run = false;
@@ -438,34 +446,26 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(X264GPU_ANA
             }
             // SATD at the best half-pel position
             {
-                int e[4], p[4], d[4];
-                unpack4(cz, e); unpack4(sub_row4(sb, sn, rwl, sx0, sy0, px + zx, py + zy, mx, my), p);
-    #pragma unroll
-                for (int i = 0; i < 4; i++) d[i] = e[i] - p[i];
-                bcost = (wave_sum(satd_quad_partial(d, lane)) >> 1) + MVC(mx, my);
+                bcost = wave_sum(satd4_half(cz, sub_row4(sb, sn, rwl, sx0, sy0, px + zx, py + zy, mx, my), lane)) + MVC(mx, my);
             }
-            // quarter-pel diamond, SATD: (0,-1) (0,1) (-1,0) (1,0), never stepping straight back
+            // quarter-pel diamond, SATD: (0,-1) (0,1) (-1,0) (1,0), never stepping straight back.  The four
+            // candidates are independent, so they run at once in the (candidate, row) mapping: a quad of
+            // lanes = 4 rows x 16 columns = four 4x4 blocks (packed-16 Hadamard), a DPP row = one candidate.
+            // min over (cost<<2 | q) == x264's in-order "first strictly better" update.
             int bdir = -1;
+            const s16x2 sg1 = pk_sign(lane & 1), sg2 = pk_sign(lane & 2);
             for (int it = qp_it; it > 0; it--) {
                 if (my <= smin1 || my >= smax1 || mx <= smin0 || mx >= smax0) break;
-                const int odir = bdir, omx = mx, omy = my;
-                // fetch the four candidates' samples first (independent loads, one round trip), then evaluate in order
-                uint32_t pq[4];
-    #pragma unroll
-                for (int q = 0; q < 4; q++)
-                    pq[q] = sub_row4(sb, sn, rwl, sx0, sy0, px + zx, py + zy, omx + (q == 2 ? -1 : q == 3 ? 1 : 0), omy + (q == 0 ? -1 : q == 1 ? 1 : 0));
-    #pragma unroll
-                for (int q = 0; q < 4; q++) {
-                    if ((q ^ 1) == odir) continue;
-                    const int cx = omx + (q == 2 ? -1 : q == 3 ? 1 : 0), cy = omy + (q == 0 ? -1 : q == 1 ? 1 : 0);
-                    int e[4], p[4], d[4];
-                    unpack4(cz, e); unpack4(pq[q], p);
-    #pragma unroll
-                    for (int i = 0; i < 4; i++) d[i] = e[i] - p[i];
-                    const int c = (wave_sum(satd_quad_partial(d, lane)) >> 1) + MVC(cx, cy);
-                    if (c < bcost) { bcost = c; mx = cx; my = cy; bdir = q; }
-                }
-                if (mx == omx && my == omy) break;
+                const int cx = mx + (cnd == 2 ? -1 : cnd == 3 ? 1 : 0), cy = my + (cnd == 0 ? -1 : cnd == 1 ? 1 : 0);
+                uint32_t pr[4];
+                sub_row16(sb, sn, rwl, sx0, sy0, px, py + r, cx, cy, pr);
+                unsigned key = ((unsigned)(row16_sum(satd16x4_half_pk(cr, pr, sg1, sg2)) + MVC(cx, cy)) << 2) | (unsigned)cnd;
+                if ((cnd ^ 1) == bdir) key = 0xffffffffu;
+                key = wave_min_u32(key);
+                if ((int)(key >> 2) >= bcost) break;
+                bcost = (int)(key >> 2);
+                bdir = key & 3;
+                mx += bdir == 2 ? -1 : bdir == 3 ? 1 : 0; my += bdir == 0 ? -1 : bdir == 1 ? 1 : 0;
             }
         }
 
@@ -535,11 +535,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(X264GPU_ANA
         else { modes[0] = PRED16_DC_128; n = 1; }
         for (int i = 0; i < n; i++) {
             const int m = modes[i], sig = m > PRED16_P ? PRED16_DC : m;
-            int e[4], p[4], d[4];
-            unpack4(cz, e); unpack4(pred16_row4(nb, pp, m, zx, zy), p);
-#pragma unroll
-            for (int t = 0; t < 4; t++) d[t] = e[t] - p[t];
-            const int c = (wave_sum(satd_quad_partial(d, lane)) >> 1) + k.lambda * bs_size_ue(sig);
+            const int c = wave_sum(satd4_half(cz, pred16_row4(nb, pp, m, zx, zy), lane)) + k.lambda * bs_size_ue(sig);
             icost = min(icost, c);
         }
     }
