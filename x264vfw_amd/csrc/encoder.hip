@@ -207,8 +207,9 @@ int x264gpu_encode_frames(x264gpu_encoder *e, const uint8_t *d_i420, int slice_t
     STAGE_MARK(1);
     if (slice_type == X264GPU_SLICE_P) {
         // sub-pel neighbourhood margin: 2 px reaches every step of subme <= 7, subme >= 8 needs 5 px
-        if (k.subme >= 8) hipLaunchKernelGGL(k_analyse_p<5>, dim3((k.nmb + 3) / 4, S), dim3(256), 0, st, k);
-        else hipLaunchKernelGGL(k_analyse_p<2>, dim3((k.nmb + 3) / 4, S), dim3(256), 0, st, k);
+        const int me_blocks = (((k.nmb + 3) / 4 + 7) / 8) * 8;      // multiple of 8: XCD-contiguous mapping in the kernel
+        if (k.subme >= 8) hipLaunchKernelGGL(k_analyse_p<5>, dim3(me_blocks, S), dim3(256), 0, st, k);
+        else hipLaunchKernelGGL(k_analyse_p<2>, dim3(me_blocks, S), dim3(256), 0, st, k);
         STAGE_MARK(2);
         hipLaunchKernelGGL(k_encode_inter, dim3((k.nmb + 3) / 4, S), dim3(256), 0, st, k);
         mask |= 2 | 4;

@@ -285,7 +285,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(X264GPU_ANA
     __shared__ uint16_t s_cost[4][2][192];
     __shared__ uint32_t s_sub[4][SubGeo<M>::DWORDS];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int mbi = blockIdx.x * 4 + wave, s = blockIdx.y;
+    // Workgroups are dealt round-robin to the 8 XCDs (each with its own L2): give every XCD one contiguous
+    // eighth of the picture so the overlapping search windows of neighbouring macroblocks share an L2.
+    const int per_xcd = gridDim.x >> 3;
+    const int mbi = (((int)blockIdx.x & 7) * per_xcd + ((int)blockIdx.x >> 3)) * 4 + wave, s = blockIdx.y;
     if (mbi >= k.nmb) return;                       // wave-uniform; no block-wide barriers below
     const int mbx = mbi % k.mbw, mby = mbi / k.mbw;
     uint8_t *win = s_win[wave];
