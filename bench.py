@@ -59,6 +59,29 @@ def synth_batch(torch, streams, frames, w, h, seed, device):
     return out
 
 
+def pmc_evidence(stage, avg_launch_ms, frames_per_launch):
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 --pmc passes of this same
+    command (tools/profile_round.sh -> profiles/r01_pmc_per_launch.json; FETCH_SIZE and WRITE_SIZE collected in
+    separate passes, KB -> bytes, read side doubled as MI355X_MICROARCH.md prescribes for gfx950), plus the
+    VALU issue utilisation the same passes imply (the path is integer-VALU bound, not HBM bound).  PMC counters
+    cannot be read from inside an un-profiled run, so this is the profile's figure, valid only for the default
+    workload (128 frames per launch); anything else reports null."""
+    path = os.path.join(ROOT, "profiles", "r01_pmc_per_launch.json")
+    if not os.path.exists(path) or frames_per_launch != 128:
+        return None, None
+    tab = json.load(open(path))
+    key = [k for k in tab if ("k_" + stage) in k]
+    if not key or "hbm_bytes_per_launch_corrected" not in tab[key[0]]:
+        return None, None
+    t = tab[key[0]]
+    valu = None
+    if "SQ_INSTS_VALU" in t and avg_launch_ms > 0:
+        simds, clk = 256 * 4, 2.4e9                      # wave64 VALU op = 4 issue cycles on a SIMD16
+        valu = {"insts_per_launch": int(t["SQ_INSTS_VALU"]), "issue_util": round(t["SQ_INSTS_VALU"] * 4 / (simds * clk * avg_launch_ms * 1e-3), 3),
+                "source": "profiles/r01_pmc_per_launch.json"}
+    return int(t["hbm_bytes_per_launch_corrected"]), valu
+
+
 def cpu_baseline(w, h, nframes, keyint):
     """oracle/ (CPU restatement, one core) on a bounded sample of the same workload — the checker timed as
     a baseline, never the product."""
@@ -173,8 +196,9 @@ def main():
     frames_per_launch = S / G            # every launch of a group covers its streams (one frame each)
     avg_ms = ms[dom] / max(cnt[dom], 1)
     achieved = alg[names[dom]] * frames_per_launch / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
+    traffic, valu = pmc_evidence(names[dom], avg_ms, S // G)
     roof = {"bound": "hbm", "kernel": names[dom], "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
+            "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic, "valu": valu,
             "avg_launch_ms": round(avg_ms, 4),
             "stage_ms_per_step": {names[i]: round(ms[i] / K / G, 4) for i in range(nst)}}
     out = {"metric": "1080p yuv420p frames/sec at preset=medium (I/P subset, CQP), hot path on MI355X",
