@@ -82,7 +82,7 @@ int x264gpu_mc_chroma(const uint8_t *d_nv12_00, int stride, const int32_t *d_xy,
  * Tier 2 — frame pipeline: the hot path of x264_encoder_encode for a batch of independent
  * closed-GOP streams (one launch covers `streams` frames of identical geometry).
  * ---------------------------------------------------------------------------------------------- */
-enum { X264GPU_MB_I4x4 = 0, X264GPU_MB_I16x16 = 2, X264GPU_MB_P_L0 = 4, X264GPU_MB_P_8x8 = 5,
+enum { X264GPU_MB_I4x4 = 0, X264GPU_MB_I8x8 = 1, X264GPU_MB_I16x16 = 2, X264GPU_MB_P_L0 = 4, X264GPU_MB_P_8x8 = 5,
        X264GPU_MB_P_SKIP = 6 };
 enum { X264GPU_SLICE_P = 0, X264GPU_SLICE_B = 1, X264GPU_SLICE_I = 2 };
 
@@ -96,15 +96,18 @@ typedef struct x264gpu_mb {
     uint8_t  cbp_chroma;    /* 0 none, 1 DC only, 2 DC+AC */
     uint8_t  partition;     /* 0 16x16, 1 16x8, 2 8x16, 3 8x8 (P only) */
     int8_t   ref[4];        /* reference index per 8x8 */
-    uint8_t  i4_mode[16];   /* intra 4x4 modes, x264 block order (zigzag-of-8x8) */
+    uint8_t  i4_mode[16];   /* intra 4x4 modes, x264 block order (zigzag-of-8x8); I8x8: mode of 8x8 block i in [4i..4i+3] */
+    uint8_t  transform8x8;  /* transform_size_8x8_flag: luma residual uses the 8x8 transform (0 when cbp_luma == 0) */
     int16_t  mv[4][2];      /* quarter-pel motion vector per 8x8 (x,y) */
-    uint32_t nnz;           /* bit b (0..15 luma blk order, 16..19 U, 20..23 V, 24 lumaDC, 25 U DC, 26 V DC) */
+    uint32_t nnz;           /* bit b (0..15 luma blk order [transform8x8: of the interleaved 4x4s], 16..19 U, 20..23 V, 24 lumaDC, 25 U DC, 26 V DC) */
     int32_t  cost;          /* analysis cost of the chosen mode (diagnostic) */
     int32_t  aux[3];        /* diagnostics: [0] best inter cost, [1] intra-16x16 source estimate (P slices) */
 } x264gpu_mb;
 
 /* quantised levels per macroblock, scan (zigzag) order, int16:
- *   [0..255]   16 luma 4x4 blocks x 16 (x264 block order; for I16x16 index 0 of each block is unused/0)
+ *   [0..255]   16 luma 4x4 blocks x 16 (x264 block order; for I16x16 index 0 of each block is unused/0).
+ *              transform8x8: 8x8 block i occupies blocks 4i..4i+3 in CAVLC-interleaved form, i.e. level z of
+ *              the 8x8 zigzag sits at block 4i + (z & 3), index z >> 2 (x264 zigzag_interleave_8x8_cavlc)
  *   [256..271] luma DC (I16x16 only)
  *   [272..279] chroma DC: U[4], V[4]
  *   [280..407] chroma AC: 8 blocks x 16 (index 0 of each unused/0)
@@ -129,7 +132,8 @@ typedef struct x264gpu_config {
     int chroma_qp_offset;
     int deadzone_inter, deadzone_intra;
     int dct_decimate;
-    int partitions;           /* bit0 p8x8 (16x8/8x16/8x8), bit1 i4x4 */
+    int partitions;           /* bit0 p8x8 (16x8/8x16/8x8), bit1 i4x4, bit2 i8x8 (needs dct8x8) */
+    int dct8x8;               /* --8x8dct: adaptive 8x8 luma transform (High profile) */
 } x264gpu_config;
 
 int  x264gpu_encoder_create(x264gpu_encoder **enc, const x264gpu_config *cfg);

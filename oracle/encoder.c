@@ -162,9 +162,9 @@ static void encode_luma_inter(x264o_encoder *e, const pixel *fenc, pixel *rec, i
     int mbscore = 0;
     for (int i8 = 0; i8 < 4; i8++) {
         int any = nz[i8 * 4] | nz[i8 * 4 + 1] | nz[i8 * 4 + 2] | nz[i8 * 4 + 3];
+        if (any) mbscore += score8[i8];               /* every coded 8x8 counts towards the macroblock score, kept or not */
         if (any && e->cfg.dct_decimate && score8[i8] < 4) any = 0;
         if (!any) for (int k = 0; k < 4; k++) nz[i8 * 4 + k] = 0;
-        else mbscore += score8[i8];
     }
     if (e->cfg.dct_decimate && mbscore < 6) for (int b = 0; b < 16; b++) nz[b] = 0;
     for (int b = 0; b < 16; b++) {
@@ -173,6 +173,41 @@ static void encode_luma_inter(x264o_encoder *e, const pixel *fenc, pixel *rec, i
         x264o_add4x4_idct(rec + blk_y[b] * 4 * e->rs + blk_x[b] * 4, e->rs, d[b]);
         mb->nnz |= 1u << b;
         mb->cbp_luma |= 1 << (b >> 2);
+    }
+}
+
+/* inter luma with the 8x8 transform ([x264-upstream] encoder/macroblock.c x264_macroblock_encode, b_transform_8x8
+ * branch): sub16x16_dct8, quant_8x8, scan_8x8, decimate_score64 per 8x8 (kept when >= 4) and per MB (>= 6),
+ * dequant_8x8 + add8x8_idct8; levels leave in the CAVLC-interleaved 4x4 form (zigzag_interleave_8x8_cavlc). */
+static void encode_luma_inter8(x264o_encoder *e, const pixel *fenc, pixel *rec, int qp, x264gpu_mb *mb, int16_t *lv)
+{
+    dctcoef d[4][64];
+    int16_t scan[4][64];
+    int keep[4], mbscore = 0;
+    const uint16_t *mf = e->qt.quant8_mf[X264O_CQM_8PY][qp], *bias = e->qt.quant8_bias[X264O_CQM_8PY][qp];
+    for (int i8 = 0; i8 < 4; i8++) {
+        const pixel *f = fenc + (i8 >> 1) * 8 * e->fs + (i8 & 1) * 8;
+        pixel *r = rec + (i8 >> 1) * 8 * e->rs + (i8 & 1) * 8;
+        x264o_sub8x8_dct8(d[i8], f, e->fs, r, e->rs);
+        keep[i8] = x264o_quant_8x8(d[i8], mf, bias);
+        for (int k = 0; k < 64; k++) scan[i8][k] = d[i8][x264o_zigzag8[k]];
+        if (keep[i8] && e->cfg.dct_decimate) {
+            int sc = x264o_decimate_score(scan[i8], 64);
+            mbscore += sc;
+            if (sc < 4) keep[i8] = 0;
+        }
+    }
+    if (e->cfg.dct_decimate && mbscore < 6) keep[0] = keep[1] = keep[2] = keep[3] = 0;
+    for (int i8 = 0; i8 < 4; i8++) {
+        if (!keep[i8]) continue;            /* levels were zeroed by the caller */
+        for (int k = 0; k < 64; k++) {
+            int16_t v = scan[i8][k];
+            lv[(i8 * 4 + (k & 3)) * 16 + (k >> 2)] = v;
+            if (v) mb->nnz |= 1u << (i8 * 4 + (k & 3));
+        }
+        x264o_dequant_8x8(d[i8], e->qt.dequant8_mf, qp);
+        x264o_add8x8_idct8(rec + (i8 >> 1) * 8 * e->rs + (i8 & 1) * 8, e->rs, d[i8]);
+        mb->cbp_luma |= 1 << i8;
     }
 }
 
@@ -452,7 +487,13 @@ static void encode_inter_mb(x264o_encoder *e, int mbx, int mby, x264gpu_mb *mb, 
     for (int y = 0; y < 8; y++)
         for (int x = 0; x < 8; x++) { rec_uv[y * e->rs + 2 * x] = pu[y * 8 + x]; rec_uv[y * e->rs + 2 * x + 1] = pv[y * 8 + x]; }
     memset(lv, 0, X264GPU_MB_LEVELS * sizeof(int16_t));
-    encode_luma_inter(e, e->fenc_y + (size_t)mby * 16 * e->fs + mbx * 16, rec, qp, mb, lv);
+    const pixel *fenc = e->fenc_y + (size_t)mby * 16 * e->fs + mbx * 16;
+    /* transform size ([x264-upstream] analyse.c x264_mb_analyse_transform): SA8D vs SATD of the prediction error */
+    mb->transform8x8 = 0;
+    if (e->cfg.dct8x8) mb->transform8x8 = x264o_sa8d(fenc, e->fs, rec, e->rs, 16, 16) < x264o_satd(fenc, e->fs, rec, e->rs, 16, 16);
+    if (mb->transform8x8) encode_luma_inter8(e, fenc, rec, qp, mb, lv);
+    else encode_luma_inter(e, fenc, rec, qp, mb, lv);
+    if (!mb->cbp_luma) mb->transform8x8 = 0;      /* the flag is not transmitted without luma coefficients (macroblock_cache_save) */
     encode_chroma(e, e->fenc_uv + (size_t)mby * 8 * e->fs + mbx * 16, rec_uv, qpc, 1, mb, lv);
 }
 
@@ -626,9 +667,10 @@ static int blk_nnz(const x264gpu_mb *m, int bx, int by)
 {
     static const uint8_t idx_of[4][4] = { { 0, 1, 4, 5 }, { 2, 3, 6, 7 }, { 8, 9, 12, 13 }, { 10, 11, 14, 15 } };
     if (m->type == X264GPU_MB_I16x16) return 1;   /* intra: bS >= 3 anyway */
+    if (m->transform8x8) return (m->cbp_luma >> ((by >> 1) * 2 + (bx >> 1))) & 1;   /* 8.7.2.1: the 8x8 block containing the sample */
     return (m->nnz >> idx_of[by][bx]) & 1;
 }
-static int is_intra(const x264gpu_mb *m) { return m->type == X264GPU_MB_I4x4 || m->type == X264GPU_MB_I16x16; }
+static int is_intra(const x264gpu_mb *m) { return m->type == X264GPU_MB_I4x4 || m->type == X264GPU_MB_I8x8 || m->type == X264GPU_MB_I16x16; }
 
 static int edge_bs(const x264gpu_mb *p, int pbx, int pby, const x264gpu_mb *q, int qbx, int qby, int mb_edge)
 {
@@ -650,6 +692,7 @@ static void deblock_frame(x264o_encoder *e, const x264gpu_mb *mbs)
             for (int dir = 0; dir < 2; dir++)          /* 0: vertical edges (filter across x), 1: horizontal */
                 for (int edge = 0; edge < 4; edge++) {
                     const x264gpu_mb *p = q;
+                    if ((edge & 1) && q->transform8x8) continue;     /* no transform edge at 4-sample offsets */
                     if (edge == 0) {
                         if (dir == 0) { if (mbx == 0) continue; p = &mbs[mby * e->mbw + mbx - 1]; }
                         else { if (mby == 0) continue; p = &mbs[(mby - 1) * e->mbw + mbx]; }

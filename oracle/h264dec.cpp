@@ -44,6 +44,7 @@ const uint8_t kIdxOf[4][4] = { { 0, 1, 4, 5 }, { 2, 3, 6, 7 }, { 8, 9, 12, 13 },
 
 struct MbInfo {
     int intra, i16, skip;
+    int t8;                  // transform_size_8x8_flag (luma residual / Intra_8x8)
     int mv8[4][2], ref8[4];  // motion per 8x8 block; ref -1 for intra
     int qp;
     uint8_t i4mode[16];
@@ -54,7 +55,7 @@ struct MbInfo {
 struct Decoder {
     int mbw = 0, mbh = 0, width = 0, height = 0, crop_r = 0, crop_b = 0;
     int log2_max_frame_num = 4, poc_type = 2;
-    int pic_init_qp = 26, chroma_qp_offset = 0, deblock_ctrl = 1, num_ref_default = 1;
+    int pic_init_qp = 26, chroma_qp_offset = 0, deblock_ctrl = 1, num_ref_default = 1, transform8x8_mode = 0;
     int stride = 0, pad = 32, cpad = 16;
     size_t plane_bytes = 0, cplane_bytes = 0;
     std::vector<pixel> luma[5], chroma[5];   // DPB slots: up to 4 references + the picture being decoded
@@ -236,6 +237,26 @@ struct SliceDec {
         }
     }
 
+    // luma residual of one 8x8 block coded with the 8x8 transform: CAVLC carries it as four interleaved 4x4
+    // blocks (7.3.5.3.2: lumaLevel8x8[64*i8 + 4*i + k] = level4x4[i8*4+k][i]); adds the residual to `r`
+    void luma8x8_residual(int mbx, int mby, int i8, bool coded, MbInfo &m, pixel *r)
+    {
+        dctcoef c8[64];
+        memset(c8, 0, sizeof(c8));
+        bool any = false;
+        if (coded)
+            for (int k = 0; k < 4; k++) {
+                int16_t l[16];
+                int b = i8 * 4 + k;
+                m.tc[b] = (uint8_t)residual_block(br, l, 16, nc_luma(mbx, mby, b));
+                if (m.tc[b]) any = true;
+                for (int i = 0; i < 16; i++) c8[x264o_zigzag8[4 * i + k]] = l[i];
+            }
+        if (any) m.nz |= 0xfu << (4 * i8);           // 8.7.2.1: the 8x8 block containing the sample has coefficients
+        x264o_dequant_8x8(c8, d.qt.dequant8_mf, qp);
+        x264o_add8x8_idct8(r, d.stride, c8);
+    }
+
     int i4_avail(int mbx, int mby, int b)
     {
         int bx = kBlkX[b], by = kBlkY[b], a = 0;
@@ -266,6 +287,16 @@ struct SliceDec {
         int cbp_luma = 0, cbp_chroma = 0, i16mode = 0;
         if (mbtype == 0) {
             m.i16 = 0;
+            m.t8 = d.transform8x8_mode ? br.get1() : 0;
+            if (m.t8) {
+                // Intra8x8PredMode (8.3.2.1): predicted from the neighbouring 4x4 entries; stored replicated
+                for (int i8 = 0; i8 < 4; i8++) {
+                    int pm = pred_i4(mbx, mby, i8 * 4, m), mode;
+                    if (br.get1()) mode = pm;
+                    else { int r = (int)br.get(3); mode = r < pm ? r : r + 1; }
+                    memset(m.i4mode + i8 * 4, mode, 4);
+                }
+            } else
             for (int b = 0; b < 16; b++) {
                 int pm = pred_i4(mbx, mby, b, m);
                 if (br.get1()) m.i4mode[b] = (uint8_t)pm;
@@ -309,6 +340,24 @@ struct SliceDec {
                 x264o_dequant_4x4(blk, d.qt.dequant4_mf, qp);
                 blk[0] = dc[kBlkY[b] * 4 + kBlkX[b]];
                 x264o_add4x4_idct(rec + kBlkY[b] * 4 * d.stride + kBlkX[b] * 4, d.stride, blk);
+            }
+        } else if (m.t8) {
+            for (int i8 = 0; i8 < 4; i8++) {
+                int x8 = i8 & 1, y8 = i8 >> 1, avail = 0;
+                if (x8 || left) avail |= X264O_AVAIL_LEFT;
+                if (y8 || top) avail |= X264O_AVAIL_TOP;
+                if ((x8 || left) && (y8 || top)) avail |= X264O_AVAIL_TOPLEFT;
+                if (i8 == 0 ? top : i8 == 1 ? (top && mbx + 1 < d.mbw) : i8 == 2) avail |= X264O_AVAIL_TOPRIGHT;
+                int mode = m.i4mode[i8 * 4];
+                if (mode == I_PRED_4x4_DC) {
+                    int l_ = avail & X264O_AVAIL_LEFT, t_ = avail & X264O_AVAIL_TOP;
+                    mode = l_ && t_ ? I_PRED_4x4_DC : l_ ? I_PRED_4x4_DC_LEFT : t_ ? I_PRED_4x4_DC_TOP : I_PRED_4x4_DC_128;
+                }
+                pixel *r = rec + y8 * 8 * d.stride + x8 * 8, edge[33], p8[64];
+                x264o_predict_8x8_filter(r, d.stride, edge, avail);
+                x264o_predict_8x8(p8, 8, edge, mode);
+                for (int y = 0; y < 8; y++) memcpy(r + y * d.stride, p8 + y * 8, 8);
+                luma8x8_residual(mbx, mby, i8, cbp_luma >> i8 & 1, m, r);
             }
         } else {
             for (int b = 0; b < 16; b++) {
@@ -373,10 +422,15 @@ struct SliceDec {
         int code = (int)br.ue(), cbp = -1;
         for (int i = 0; i < 48; i++) if (cbp_to_golomb_inter[i] == code) cbp = i;
         if (cbp < 0) { br.err = true; return; }
+        m.t8 = (d.transform8x8_mode && (cbp & 15)) ? br.get1() : 0;      // all partitions are >= 8x8 in this subset
         if (cbp) qp += br.se();
         m.qp = qp;
         inter_pred(mbx, mby, m);
         pixel *rec = d.Y(d.cur) + (size_t)mby * 16 * d.stride + mbx * 16;
+        if (m.t8) {
+            for (int i8 = 0; i8 < 4; i8++)
+                if (cbp >> i8 & 1) luma8x8_residual(mbx, mby, i8, true, m, rec + (i8 >> 1) * 8 * d.stride + (i8 & 1) * 8);
+        } else
         for (int b = 0; b < 16; b++) {
             if (!(cbp >> (b >> 2) & 1)) continue;
             int16_t l[16];
@@ -438,6 +492,7 @@ struct SliceDec {
                 for (int vert = 1; vert >= 0; vert--)            // vertical edges first
                     for (int e = 0; e < 4; e++) {
                         const MbInfo *p = &q;
+                        if ((e & 1) && q.t8) continue;           // transform_size_8x8_flag: no luma edge at 4-sample offsets
                         if (e == 0) {
                             if (vert) { if (!mbx) continue; p = &d.mb[mby * d.mbw + mbx - 1]; }
                             else { if (!mby) continue; p = &d.mb[(mby - 1) * d.mbw + mbx]; }
@@ -505,7 +560,9 @@ bool decode_nal(Decoder &d, const uint8_t *nal, size_t n)
     BitReader br{ rbsp.data(), rbsp.size() };
     if (type == 7) {
         int profile = (int)br.get(8); br.get(8); br.get(8); br.ue();
-        if (profile >= 100) return false;
+        if (profile >= 100) {                               // High: 4:2:0, 8 bit, flat scaling lists only
+            if (br.ue() != 1 || br.ue() != 0 || br.ue() != 0 || br.get1() || br.get1()) return false;
+        }
         d.log2_max_frame_num = (int)br.ue() + 4;
         d.poc_type = (int)br.ue();
         if (d.poc_type != 2) return false;
@@ -532,6 +589,12 @@ bool decode_nal(Decoder &d, const uint8_t *nal, size_t n)
         d.deblock_ctrl = br.get1();
         if (br.get1()) return false;                        // constrained intra
         br.get1();
+        d.transform8x8_mode = 0;
+        if (br.more_rbsp_data()) {
+            d.transform8x8_mode = br.get1();
+            if (br.get1()) return false;                    // pic_scaling_matrix_present_flag
+            if (br.se() != d.chroma_qp_offset) return false; // second_chroma_qp_index_offset
+        }
         d.have_pps = !br.err;
         return d.have_pps;
     }

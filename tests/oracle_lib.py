@@ -145,14 +145,14 @@ _sig("x264o_lambda", _i, [_i])
 
 MB_DTYPE = np.dtype([("type", "u1"), ("i16_mode", "u1"), ("chroma_mode", "u1"), ("qp", "u1"), ("cbp_luma", "u1"),
                      ("cbp_chroma", "u1"), ("partition", "u1"), ("ref", "i1", 4), ("i4_mode", "u1", 16),
-                     ("_p0", "u1"), ("mv", "<i2", (4, 2)), ("nnz", "<u4"), ("cost", "<i4"), ("aux", "<i4", 3)])
+                     ("transform8x8", "u1"), ("mv", "<i2", (4, 2)), ("nnz", "<u4"), ("cost", "<i4"), ("aux", "<i4", 3)])
 assert MB_DTYPE.itemsize == 64 == C.sizeof(MbRecord)
 
 
 def default_config(width, height, streams=1, **kw):
     c = Config(width=width, height=height, streams=streams, refs=1, qp_i=20, qp_p=23, me_range=16, subme=7,
                deblock=1, deblock_alpha=0, deblock_beta=0, chroma_qp_offset=0, deadzone_inter=21,
-               deadzone_intra=11, dct_decimate=1, partitions=2)
+               deadzone_intra=11, dct_decimate=1, partitions=2, dct8x8=0)
     for k, v in kw.items():
         setattr(c, k, v)
     return c

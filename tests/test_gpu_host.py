@@ -14,7 +14,7 @@ pytestmark = pytest.mark.gpu
 H = HL.H
 
 
-def open_encoder(w, h, opts):
+def open_encoder(w, h, opts, profile=b"baseline"):
     p = HL.Param()
     assert H.x264_param_default_preset(C.byref(p), b"medium", None) == 0
     p.i_width, p.i_height, p.i_csp = w, h, HL.X264_CSP_I420
@@ -24,7 +24,7 @@ def open_encoder(w, h, opts):
         assert H.x264_param_parse(C.byref(p), k.encode(), None if v is None else str(v).encode()) == 0, k
     p.b_vfr_input = 0
     p.b_annexb, p.b_repeat_headers = 1, 1                              # VfW mode (codec.c:1611-1615)
-    assert H.x264_param_apply_profile(C.byref(p), b"baseline") == 0
+    assert H.x264_param_apply_profile(C.byref(p), profile) == 0
     h_ = H.x264_encoder_open_157(C.byref(p))
     assert h_, "x264_encoder_open failed"
     eff = HL.Param()
@@ -59,11 +59,16 @@ def encode_all(h_, w, h, frames):
 
 @pytest.mark.parametrize("w,h,opts", [(176, 144, {"qp": 26, "keyint": 4}), (352, 288, {"qp": 30, "keyint": 250}),
                                        (208, 120, {"qp": 22, "keyint": 3, "no-deblock": None}),
-                                       (176, 144, {"qp": 28, "keyint": 250, "ref": 1, "partitions": "i4x4"})])
+                                       (176, 144, {"qp": 28, "keyint": 250, "ref": 1, "partitions": "i4x4"}),
+                                       (176, 144, {"qp": 24, "keyint": 250, "_profile": b"high"}),      # 8x8dct: High profile stream
+                                       (352, 288, {"qp": 27, "keyint": 5, "_profile": b"high"})])
 def test_encode_api_closed_loop(gpu, w, h, opts):
     nfr = 7
     frames = synth_frames(w, h, nfr, seed=w + 3 * h)
-    h_, eff = open_encoder(w, h, opts)
+    opts = dict(opts)
+    profile = opts.pop("_profile", b"baseline")
+    h_, eff = open_encoder(w, h, opts, profile)
+    assert eff.analyse.b_transform_8x8 == int(profile == b"high")
     assert (eff.i_bframe, eff.b_cabac, eff.rc.i_rc_method) == (0, 0, HL.X264_RC_CQP)   # effective params
     assert eff.i_frame_reference == int(opts.get("ref", 3))                         # medium: --ref 3
     stream, info, recons = encode_all(h_, w, h, frames)
@@ -85,16 +90,16 @@ def test_bitstream_equals_oracle_path(gpu):
     """same records -> same bytes: the GPU path's slice NALs equal the ones coded from the oracle's records"""
     w, h, nfr, qp = 176, 144, 5, 27
     frames = synth_frames(w, h, nfr, seed=99)
-    h_, eff = open_encoder(w, h, {"qp": qp, "keyint": 250})
+    h_, eff = open_encoder(w, h, {"qp": qp, "keyint": 250}, b"high")
     stream, info, _ = encode_all(h_, w, h, frames)
     H.x264_encoder_close(h_)
     qp_i = max(1, int(qp - 6.0 * np.log2(1.4) + 0.5))
-    enc = O.OracleEncoder(O.default_config(w, h, qp_i=qp_i, qp_p=qp, partitions=3, refs=3))      # medium: p8x8 + i4x4, ref 3
+    enc = O.OracleEncoder(O.default_config(w, h, qp_i=qp_i, qp_p=qp, partitions=3, refs=3, dct8x8=1))      # medium: p8x8 + i4x4, ref 3, 8x8dct
     ref = b""
     for i, f in enumerate(frames):
         mbs, lv = enc.encode(f, 2 if i == 0 else 0)
         ref += HL.write_slice(11, 9, 2 if i == 0 else 0, qp_i if i == 0 else qp, qp, i, 8, int(i == 0), 0, 0, mbs, lv,
-                              num_ref=max(1, min(3, i)), num_ref_default=3)[0]
+                              num_ref=max(1, min(3, i)), num_ref_default=3, t8x8=1)[0]
     def slice_nals(b):
         import re
         return [n.rstrip(b"\x00") if False else n for n in re.split(b"\x00\x00\x00\x01|\x00\x00\x01", b) if n and (n[0] & 31) in (1, 5)]

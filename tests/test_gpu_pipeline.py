@@ -50,6 +50,9 @@ def compare(tag, mbw, g_mb, o_mb, g_lv, o_lv, g_rec, o_rec):
     (96, 80, 7, dict(refs=4, partitions=1, qp_i=30, qp_p=33)),
     (176, 144, 4, dict(subme=9, partitions=3, refs=2)),      # 4 half-pel + 10 quarter-pel steps: 5 px sub-pel neighbourhood
     (352, 288, 3, dict(subme=8, partitions=3, qp_i=30, qp_p=34)),
+    (176, 144, 4, dict(dct8x8=1)),                           # adaptive 8x8 transform on inter macroblocks
+    (352, 288, 4, dict(dct8x8=1, partitions=3, refs=2, qp_i=26, qp_p=28)),
+    (208, 120, 3, dict(dct8x8=1, qp_i=12, qp_p=14, dct_decimate=0)),
 ])
 def test_pipeline_bitexact(gpu, w, h, nfr, kw):
     from gpu_enc import GpuEncoder

@@ -111,7 +111,9 @@ def test_open_without_gpu_fails_loudly():
                                      (96, 80, dict(qp_i=8, qp_p=10)), (64, 64, dict(partitions=0)),
                                      (176, 144, dict(partitions=3)), (352, 288, dict(partitions=3, qp_i=30, qp_p=33)),
                                      (208, 120, dict(partitions=1, subme=4)), (176, 144, dict(refs=3, partitions=3)),
-                                     (96, 80, dict(refs=2)), (208, 120, dict(refs=4, partitions=3, qp_i=30, qp_p=32))])
+                                     (96, 80, dict(refs=2)), (208, 120, dict(refs=4, partitions=3, qp_i=30, qp_p=32)),
+                                     (176, 144, dict(dct8x8=1)), (352, 288, dict(dct8x8=1, partitions=3, refs=2, qp_i=26, qp_p=28)),
+                                     (208, 120, dict(dct8x8=1, qp_i=12, qp_p=14, dct_decimate=0))])
 def test_cavlc_closed_loop(w, h, kw):
     """oracle records -> host CAVLC -> checker decoder == oracle reconstruction, I and P pictures"""
     nfr = 7 if kw.get("refs", 1) > 1 else 4
@@ -119,13 +121,13 @@ def test_cavlc_closed_loop(w, h, kw):
     cfg = O.default_config(w, h, **kw)
     enc = O.OracleEncoder(cfg)
     mbw, mbh = (w + 15) // 16, (h + 15) // 16
-    stream = HL.write_headers(w, h, pic_init_qp=cfg.qp_p, num_ref=cfg.refs)
+    stream = HL.write_headers(w, h, pic_init_qp=cfg.qp_p, num_ref=cfg.refs, t8x8=cfg.dct8x8)
     recons, skipped = [], 0
     for i, f in enumerate(frames):
         idr = i == 0
         mbs, lv = enc.encode(f, 2 if idr else 0)
         s, sk = HL.write_slice(mbw, mbh, 2 if idr else 0, cfg.qp_i if idr else cfg.qp_p, cfg.qp_p, i, 8, int(idr), 0,
-                               0 if cfg.deblock else 1, mbs, lv, num_ref=max(1, min(cfg.refs, i)), num_ref_default=cfg.refs)
+                               0 if cfg.deblock else 1, mbs, lv, num_ref=max(1, min(cfg.refs, i)), num_ref_default=cfg.refs, t8x8=cfg.dct8x8)
         if cfg.refs > 1 and i >= 2:
             assert (mbs["ref"][mbs["type"] >= 4] >= 0).all()
         stream += s

@@ -5,6 +5,7 @@
 #include <stdio.h>
 #include "../../include/x264gpu.h"
 #include "dsp.cuh"
+#include "dsp8.cuh"
 
 namespace x264gpu {
 
@@ -41,6 +42,27 @@ inline Q4 make_q4(int qp, int list, const QuantCfg &c = QuantCfg())
         q.mf[k] = mf;
         q.bias[k] = b < cap ? b : cap;
         q.dq[k] = ds[qp % 6][k] * 16;
+    }
+    return q;
+}
+
+// 8x8 luma quantiser: six normAdjust8x8 position classes (list 0 intra, 1 inter)
+inline Q8 make_q8(int qp, int list, const QuantCfg &c = QuantCfg())
+{
+    static const int qs[6][6] = { { 13107, 11428, 20972, 12222, 16777, 15481 }, { 11916, 10826, 19174, 11058, 14980, 14290 },
+                                  { 10082, 8943, 15978, 9675, 12710, 11985 },   { 9362, 8228, 14913, 8931, 11984, 11259 },
+                                  { 8192, 7346, 13159, 7740, 10486, 9777 },     { 7282, 6428, 11570, 6830, 9118, 8640 } };
+    static const int ds[6][6] = { { 20, 18, 32, 19, 25, 24 }, { 22, 19, 35, 21, 28, 26 }, { 26, 23, 42, 24, 33, 31 },
+                                  { 28, 25, 45, 26, 35, 33 }, { 32, 28, 51, 30, 40, 38 }, { 36, 32, 58, 34, 46, 43 } };
+    const int dz = list == 0 ? 32 - c.deadzone_intra : 32 - c.deadzone_inter;
+    Q8 q;
+    q.qp = qp;
+    const int sh = qp / 6;
+    for (int k = 0; k < 6; k++) {
+        int base = qs[qp % 6][k];
+        int mf = sh <= 0 ? base : (base + (1 << (sh - 1))) >> sh;
+        int b = ((dz << 10) + (mf >> 1)) / mf, cap = (1 << 15) / mf;
+        q.mf[k] = mf; q.bias[k] = b < cap ? b : cap; q.dq[k] = ds[qp % 6][k] * 16;
     }
     return q;
 }

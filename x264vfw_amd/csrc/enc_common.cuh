@@ -35,6 +35,8 @@ struct EncK {
     int slice_type;
     int alpha_off, beta_off;  // deblock offsets (already *2)
     Q4 q_luma_intra, q_luma_inter, q_chroma_intra, q_chroma_inter;
+    Q8 q8_intra, q8_inter;    // 8x8 luma transform (dct8x8)
+    int dct8x8;
     unsigned long long *dbg;  // optional diagnostics (NULL in production): per (stream, wave) cycle counters
 };
 

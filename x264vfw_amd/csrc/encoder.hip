@@ -87,7 +87,7 @@ int x264gpu_encoder_create(x264gpu_encoder **out, const x264gpu_config *cfg)
     k.luma_bytes = 4 * k.plane_bytes;
     k.cplane_bytes = (size_t)k.rs * (k.ch / 2 + 2 * CPAD);
     k.me_range = cfg->me_range; k.subme = cfg->subme; k.dct_decimate = cfg->dct_decimate;
-    k.partitions = cfg->partitions; k.chroma_qp_offset = cfg->chroma_qp_offset;
+    k.partitions = cfg->partitions; k.chroma_qp_offset = cfg->chroma_qp_offset; k.dct8x8 = cfg->dct8x8;
     k.alpha_off = cfg->deblock_alpha * 2; k.beta_off = cfg->deblock_beta * 2;
     const size_t S = (size_t)cfg->streams;
     hipError_t er = hipSuccess;
@@ -196,6 +196,7 @@ int x264gpu_encode_frames(x264gpu_encoder *e, const uint8_t *d_i420, int slice_t
     QuantCfg qc; qc.deadzone_inter = e->cfg.deadzone_inter; qc.deadzone_intra = e->cfg.deadzone_intra;
     k.q_luma_intra = make_q4(qp, 0, qc); k.q_luma_inter = make_q4(qp, 1, qc);
     k.q_chroma_intra = make_q4(k.qpc, 2, qc); k.q_chroma_inter = make_q4(k.qpc, 3, qc);
+    k.q8_intra = make_q8(qp, 0, qc); k.q8_inter = make_q8(qp, 1, qc);
 
     hipEvent_t *ev = nullptr;
     int mask = 0;

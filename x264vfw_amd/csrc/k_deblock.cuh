@@ -41,14 +41,17 @@ struct DeblockLds {
     uint8_t alpha[52], beta[52], tc0[52][4], cqp[52];
 };
 
-__device__ __forceinline__ bool mb_is_intra(int type) { return type == X264GPU_MB_I4x4 || type == X264GPU_MB_I16x16; }
+__device__ __forceinline__ bool mb_is_intra(int type) { return type == X264GPU_MB_I4x4 || type == X264GPU_MB_I8x8 || type == X264GPU_MB_I16x16; }
 
 // boundary strength between 4x4 block (pbx,pby) of P and (qbx,qby) of Q (oracle edge_bs)
 __device__ __forceinline__ int edge_bs(const x264gpu_mb *P, int pbx, int pby, const x264gpu_mb *Q, int qbx, int qby, bool mb_edge)
 {
     if (mb_is_intra(P->type) || mb_is_intra(Q->type)) return mb_edge ? 4 : 3;
-    const int pn = (P->nnz >> (((pby >> 1) * 2 + (pbx >> 1)) * 4 + (pby & 1) * 2 + (pbx & 1))) & 1;
-    const int qn = (Q->nnz >> (((qby >> 1) * 2 + (qbx >> 1)) * 4 + (qby & 1) * 2 + (qbx & 1))) & 1;
+    // transform8x8: "the 8x8 block containing the sample" has coefficients (8.7.2.1) = its cbp_luma bit
+    const int pn = P->transform8x8 ? (P->cbp_luma >> ((pby >> 1) * 2 + (pbx >> 1))) & 1
+                                   : (P->nnz >> (((pby >> 1) * 2 + (pbx >> 1)) * 4 + (pby & 1) * 2 + (pbx & 1))) & 1;
+    const int qn = Q->transform8x8 ? (Q->cbp_luma >> ((qby >> 1) * 2 + (qbx >> 1))) & 1
+                                   : (Q->nnz >> (((qby >> 1) * 2 + (qbx >> 1)) * 4 + (qby & 1) * 2 + (qbx & 1))) & 1;
     if (pn || qn) return 2;
     const int pi = (pby >> 1) * 2 + (pbx >> 1), qi = (qby >> 1) * 2 + (qbx >> 1);
     if (P->ref[pi] != Q->ref[qi]) return 1;
@@ -146,6 +149,7 @@ __device__ void deblock_mb_wave(const EncK &k, DeblockLds &L, int wave, int lane
     for (int dir = 0; dir < 2; dir++)
         for (int edge = 0; edge < 4; edge++) {
             const x264gpu_mb *P = Q;
+            if ((edge & 1) && Q->transform8x8) continue;       // no transform edge at 4-sample offsets
             if (edge == 0) {
                 if (dir == 0) { if (mbx == 0) continue; P = &L.rec[wave][1]; }
                 else { if (mby == 0) continue; P = &L.rec[wave][2]; }

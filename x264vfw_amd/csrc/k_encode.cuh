@@ -51,6 +51,73 @@ __global__ __launch_bounds__(256) void k_encode_inter(EncK k)
     const int refidx = mbp->ref[0];                 // one reference per macroblock (no mixed refs)
     const uint32_t pred = mc_luma_row4(ref_plane00(k, s, refidx), k.plane_bytes, k.rs, px + zx, py + zy, mvx, mvy);
     const uint32_t enc = *(const uint32_t *)(fenc + (size_t)zy * k.fs + zx);
+    unsigned nnz = 0;
+    int cbp_luma = 0;
+    // transform size ([x264-upstream] analyse.c x264_mb_analyse_transform): SA8D vs SATD of the prediction error
+    bool t8 = false;
+    uint32_t elo = 0, ehi = 0, plo = 0, phi = 0;
+    if (k.dct8x8) {
+        z_to_r8(enc, lane, elo, ehi); z_to_r8(pred, lane, plo, phi);
+        const int h8 = sa8d_r8_half(elo, ehi, plo, phi, lane);
+        const int cost8 = (2 * wave_sum(lane < 32 ? h8 : 0) + 2) >> 2, cost4 = wave_sum(satd4_half(enc, pred, lane));
+        t8 = cost8 < cost4;
+    }
+    if (t8) {
+        // ---- 8x8 transform, R8 layout: lane = (8x8 block, row) on lanes 0..31 (upper half mirrors) ----
+        const int row = lane & 7, i8 = (lane >> 3) & 3;
+        int e[8], p[8], v[8];
+        unpack4(elo, e); unpack4(ehi, e + 4); unpack4(plo, p); unpack4(phi, p + 4);
+#pragma unroll
+        for (int i = 0; i < 8; i++) v[i] = e[i] - p[i];
+        fwd8_1d(v); transpose8(v, lane); fwd8_1d(v); transpose8(v, lane);
+        int mf[4], bs[4], dq[4];
+        q8_row(k.q8_inter, row, mf, bs, dq);
+        unsigned mlo = 0, mhi = 0, big = 0;
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+            v[i] = quant_one(v[i], mf[i & 3], bs[i & 3]);
+            const int z = c_zigzag8_inv[row * 8 + i];
+            if (v[i]) { if (z < 32) mlo |= 1u << z; else mhi |= 1u << (z - 32); }
+            big |= abs(v[i]) > 1 ? 1u : 0u;
+        }
+        mlo = group8_or(mlo); mhi = group8_or(mhi); big = group8_or(big);
+        const unsigned long long mask = ((unsigned long long)mhi << 32) | mlo;
+        bool keep = mask != 0;
+        if (k.dct_decimate) {
+            const int sc = keep ? (big ? 9 : decimate64_from_mask(mask)) : 0;
+            const int mbscore = __builtin_amdgcn_readlane(sc, 0) + __builtin_amdgcn_readlane(sc, 8) + __builtin_amdgcn_readlane(sc, 16) + __builtin_amdgcn_readlane(sc, 24);
+            keep = keep && sc >= 4 && mbscore >= 6;
+        }
+        // levels leave in the CAVLC-interleaved 4x4 form: scan index z -> block 4*i8 + (z & 3), position z >> 2
+        if (lane < 32) {
+#pragma unroll
+            for (int i = 0; i < 8; i++) {
+                const int z = c_zigzag8_inv[row * 8 + i];
+                lv[(i8 * 4 + (z & 3)) * 16 + (z >> 2)] = (int16_t)(keep ? v[i] : 0);
+            }
+        }
+        unsigned n4 = 0;
+#pragma unroll
+        for (int q = 0; q < 4; q++) n4 |= (mask & (0x1111111111111111ull << q)) ? 1u << q : 0u;
+        if (!keep) n4 = 0;
+#pragma unroll
+        for (int g = 0; g < 4; g++) {
+            const unsigned ng = (unsigned)__builtin_amdgcn_readlane((int)n4, g * 8);
+            nnz |= ng << (4 * g);
+            cbp_luma |= ng ? 1 << g : 0;
+        }
+        const int qb = k.q8_inter.qp / 6 - 6;
+#pragma unroll
+        for (int i = 0; i < 8; i++) v[i] = keep ? dequant_one(v[i], dq[i & 3], qb) : 0;
+        inv8_1d(v); transpose8(v, lane); inv8_1d(v); transpose8(v, lane);        // 8.5.13: rows first, then columns
+#pragma unroll
+        for (int i = 0; i < 8; i++) v[i] = ((v[i] + 32) >> 6) + p[i];
+        if (lane < 32) {
+            uint2 o;
+            o.x = pack4_clip(v); o.y = pack4_clip(v + 4);
+            *(uint2 *)(rec_plane00(k, s) + (size_t)(py + (i8 >> 1) * 8 + row) * k.rs + px + (i8 & 1) * 8) = o;
+        }
+    } else {
     int e[4], p[4], v[4];
     unpack4(enc, e); unpack4(pred, p);
 #pragma unroll
@@ -65,8 +132,8 @@ __global__ __launch_bounds__(256) void k_encode_inter(EncK k)
         const int sc = nz ? (big ? 9 : decimate_from_mask(mask, 0)) : 0;
         const int score8 = row16_sum(j == 0 ? sc : 0);                  // per 8x8 (= DPP row)
         bool any8 = row16_or(nz ? 1 : 0) != 0;
+        const int mbscore = wave_sum(((lane & 15) == 0 && any8) ? score8 : 0);   // every coded 8x8 counts, kept or not
         if (any8 && score8 < 4) any8 = false;
-        const int mbscore = wave_sum(((lane & 15) == 0 && any8) ? score8 : 0);
         keep = nz && any8 && mbscore >= 6;
     }
     { int z[4] = { 0, 0, 0, 0 }; store_levels_scan(lv + blk * 16, keep ? v : z, j); }
@@ -77,12 +144,11 @@ __global__ __launch_bounds__(256) void k_encode_inter(EncK k)
     for (int i = 0; i < 4; i++) v[i] += p[i];
     *(uint32_t *)(rec_plane00(k, s) + (size_t)(py + zy) * k.rs + px + zx) = pack4_clip(v);
     const unsigned long long bal = __ballot(keep && j == 0);
-    unsigned nnz = 0;
 #pragma unroll
     for (int b = 0; b < 16; b++) nnz |= (unsigned)((bal >> (4 * b)) & 1) << b;
-    int cbp_luma = 0;
 #pragma unroll
     for (int i8 = 0; i8 < 4; i8++) cbp_luma |= ((nnz >> (4 * i8)) & 15) ? 1 << i8 : 0;
+    }
 
     // ---- chroma (lanes 0..31: plane = lane>>4, block = (lane>>2)&3) ----
     const int c = (lane >> 4) & 1, ci = (lane >> 2) & 3, cx0 = (ci & 1) * 4, cyy = (ci >> 1) * 4 + j;
@@ -107,6 +173,7 @@ __global__ __launch_bounds__(256) void k_encode_inter(EncK k)
     if (lane == 0) {
         mbp->nnz = nnz;
         mbp->cbp_luma = (uint8_t)cbp_luma;
+        mbp->transform8x8 = (uint8_t)(t8 && cbp_luma);     // not transmitted without luma coefficients
         mbp->cbp_chroma = (uint8_t)cbp_chroma;
     }
 }

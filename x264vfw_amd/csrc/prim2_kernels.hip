@@ -7,78 +7,11 @@
 // lane^4).  Quantiser tables have six position classes (normAdjust8x8); each lane keeps the four it needs.
 #include "common.cuh"
 #include "intra.cuh"
+#include "dsp8.cuh"
 
 using namespace x264gpu;
 
 namespace {
-
-struct Q8 { int mf[6], bias[6], dq[6], qp; };
-
-Q8 make_q8(int qp, int list, const QuantCfg &c = QuantCfg())
-{
-    static const int qs[6][6] = { { 13107, 11428, 20972, 12222, 16777, 15481 }, { 11916, 10826, 19174, 11058, 14980, 14290 },
-                                  { 10082, 8943, 15978, 9675, 12710, 11985 },   { 9362, 8228, 14913, 8931, 11984, 11259 },
-                                  { 8192, 7346, 13159, 7740, 10486, 9777 },     { 7282, 6428, 11570, 6830, 9118, 8640 } };
-    static const int ds[6][6] = { { 20, 18, 32, 19, 25, 24 }, { 22, 19, 35, 21, 28, 26 }, { 26, 23, 42, 24, 33, 31 },
-                                  { 28, 25, 45, 26, 35, 33 }, { 32, 28, 51, 30, 40, 38 }, { 36, 32, 58, 34, 46, 43 } };
-    const int dz = list == 0 ? 32 - c.deadzone_intra : 32 - c.deadzone_inter;
-    Q8 q;
-    q.qp = qp;
-    const int sh = qp / 6;
-    for (int k = 0; k < 6; k++) {
-        int base = qs[qp % 6][k];
-        int mf = sh <= 0 ? base : (base + (1 << (sh - 1))) >> sh;
-        int b = ((dz << 10) + (mf >> 1)) / mf, cap = (1 << 15) / mf;
-        q.mf[k] = mf; q.bias[k] = b < cap ? b : cap; q.dq[k] = ds[qp % 6][k] * 16;
-    }
-    return q;
-}
-
-__device__ __forceinline__ void fwd8_1d(int s[8])
-{
-    const int s07 = s[0] + s[7], s16 = s[1] + s[6], s25 = s[2] + s[5], s34 = s[3] + s[4];
-    const int d07 = s[0] - s[7], d16 = s[1] - s[6], d25 = s[2] - s[5], d34 = s[3] - s[4];
-    const int a0 = s07 + s34, a1 = s16 + s25, a2 = s07 - s34, a3 = s16 - s25;
-    const int a4 = d16 + d25 + (d07 + (d07 >> 1));
-    const int a5 = d07 - d34 - (d25 + (d25 >> 1));
-    const int a6 = d07 + d34 - (d16 + (d16 >> 1));
-    const int a7 = d16 - d25 + (d34 + (d34 >> 1));
-    s[0] = a0 + a1; s[1] = a4 + (a7 >> 2); s[2] = a2 + (a3 >> 1); s[3] = a5 + (a6 >> 2);
-    s[4] = a0 - a1; s[5] = a6 - (a5 >> 2); s[6] = (a2 >> 1) - a3; s[7] = (a4 >> 2) - a7;
-}
-__device__ __forceinline__ void inv8_1d(int s[8])
-{
-    const int a0 = s[0] + s[4], a2 = s[0] - s[4], a4 = (s[2] >> 1) - s[6], a6 = (s[6] >> 1) + s[2];
-    const int b0 = a0 + a6, b2 = a2 + a4, b4 = a2 - a4, b6 = a0 - a6;
-    const int a1 = -s[3] + s[5] - s[7] - (s[7] >> 1);
-    const int a3 = s[1] + s[7] - s[3] - (s[3] >> 1);
-    const int a5 = -s[1] + s[7] + s[5] + (s[5] >> 1);
-    const int a7 = s[3] + s[5] + s[1] + (s[1] >> 1);
-    const int b1 = (a7 >> 2) + a1, b3 = a3 + (a5 >> 2), b5 = (a3 >> 2) - a5, b7 = a7 - (a1 >> 2);
-    s[0] = b0 + b7; s[1] = b2 + b5; s[2] = b4 + b3; s[3] = b6 + b1;
-    s[4] = b6 - b1; s[5] = b4 - b3; s[6] = b2 - b5; s[7] = b0 - b7;
-}
-// (lane r, reg c) -> (lane c, reg r) within each group of 8 lanes
-__device__ __forceinline__ void transpose8(int v[8], int lane)
-{
-#pragma unroll
-    for (int s = 1; s < 8; s <<= 1) {
-        const bool hi = lane & s;
-#pragma unroll
-        for (int r = 0; r < 8; r++) {
-            if (r & s) continue;
-            const int send = hi ? v[r] : v[r | s];
-            const int recv = s == 1 ? dpp<DPP_XOR1>(send) : s == 2 ? dpp<DPP_XOR2>(send) : __shfl_xor(send, 4);
-            if (hi) v[r] = recv; else v[r | s] = recv;
-        }
-    }
-}
-__device__ __forceinline__ int class8(int r, int c)
-{
-    // normAdjust8x8 class of position (r,c): [r&3][c&3] -> { {0,3,4,3}, {3,1,5,1}, {4,5,2,5}, {3,1,5,1} }
-    const unsigned long long tab = 0x1513525415133430ull;   // nibble (r&3)*4 + (c&3)
-    return (int)((tab >> (((r & 3) * 4 + (c & 3)) * 4)) & 15);
-}
 
 __global__ __launch_bounds__(256) void k_dctq8x8(const uint8_t *__restrict__ enc, const uint8_t *__restrict__ pred, int n, Q8 q,
                                                  int16_t *__restrict__ coef, int16_t *__restrict__ levels, uint8_t *__restrict__ recon)

@@ -80,7 +80,8 @@ static SpsParams make_sps(const x264_t *h)
 }
 static PpsParams make_pps(const x264_t *h)
 {
-    PpsParams pp = { h->param.i_sps_id, h->param.i_sps_id, 0, h->param.i_frame_reference, h->pic_init_qp, h->param.analyse.i_chroma_qp_offset };
+    PpsParams pp = { h->param.i_sps_id, h->param.i_sps_id, 0, h->param.i_frame_reference, h->pic_init_qp, h->param.analyse.i_chroma_qp_offset,
+                     h->param.analyse.b_transform_8x8 };
     return pp;
 }
 // appends SPS, PPS (and optionally the version SEI) to h->out, recording NAL offsets and types
@@ -122,7 +123,8 @@ x264_t *x264_encoder_open(x264_param_t *param)
     if (p.i_frame_reference < 1) p.i_frame_reference = 1;
     p.analyse.b_mixed_references = 0;
     if (p.b_cabac) { xlog(&p, X264_LOG_WARNING, "CABAC is not implemented yet: using CAVLC\n"); p.b_cabac = 0; }
-    p.analyse.b_transform_8x8 = 0; p.analyse.i_weighted_pred = X264_WEIGHTP_NONE; p.analyse.b_weighted_bipred = 0;
+    p.analyse.i_weighted_pred = X264_WEIGHTP_NONE; p.analyse.b_weighted_bipred = 0;
+    p.analyse.b_transform_8x8 = p.analyse.b_transform_8x8 != 0;
     p.analyse.inter &= X264_ANALYSE_I4x4 | X264_ANALYSE_PSUB16x16; p.analyse.intra &= X264_ANALYSE_I4x4;
     p.analyse.i_trellis = 0; p.rc.b_mb_tree = 0; p.rc.i_aq_mode = X264_AQ_NONE; p.rc.i_lookahead = 0; p.i_scenecut_threshold = 0;
     p.analyse.i_me_method = X264_ME_HEX; p.analyse.i_me_range = clampi(p.analyse.i_me_range, 4, 16);
@@ -138,7 +140,7 @@ x264_t *x264_encoder_open(x264_param_t *param)
     h->qp_p = p.rc.i_qp_constant;
     h->qp_i = clampi((int)(h->qp_p - 6.0 * log2(p.rc.f_ip_factor > 0 ? p.rc.f_ip_factor : 1.0) + 0.5), 1, 51);
     h->pic_init_qp = clampi(h->qp_p, 0, 51);
-    h->profile_idc = 66;
+    h->profile_idc = p.analyse.b_transform_8x8 ? 100 : 66;        // High only for the 8x8 transform; everything else is Baseline-compatible
     h->level_idc = p.i_level_idc > 0 ? p.i_level_idc : pick_level(&p, h->nmb, p.i_frame_reference);
     p.i_level_idc = h->level_idc;
     h->log2_max_frame_num = 4;
@@ -152,6 +154,7 @@ x264_t *x264_encoder_open(x264_param_t *param)
     cfg.deadzone_inter = p.analyse.i_luma_deadzone[0]; cfg.deadzone_intra = p.analyse.i_luma_deadzone[1];
     cfg.dct_decimate = p.analyse.b_dct_decimate;
     cfg.partitions = ((p.analyse.intra & X264_ANALYSE_I4x4) ? 2 : 0) | ((p.analyse.inter & X264_ANALYSE_PSUB16x16) ? 1 : 0);
+    cfg.dct8x8 = p.analyse.b_transform_8x8;
     size_t insz = (size_t)p.i_width * p.i_height * 3 / 2;
     if (x264gpu_encoder_create(&h->gpu, &cfg) != X264GPU_OK ||
         x264gpu_malloc((void **)&h->d_in, insz) != X264GPU_OK ||
@@ -239,6 +242,7 @@ int x264_encoder_encode(x264_t *h, x264_nal_t **pp_nal, int *pi_nal, x264_pictur
     sp.num_ref = h->frames_since_idr < p.i_frame_reference ? (h->frames_since_idr > 0 ? h->frames_since_idr : 1) : p.i_frame_reference;
     sp.disable_deblock_idc = p.b_deblocking_filter ? 0 : 1;
     sp.alpha_off_div2 = p.i_deblocking_filter_alphac0; sp.beta_off_div2 = p.i_deblocking_filter_beta;
+    sp.transform8x8_mode = p.analyse.b_transform_8x8;
     h->nal_off.push_back(h->out.size()); types.push_back(idr ? 5 : 1);
     h->last_stats.skip = 0;
     write_slice(h->out, sp, h->h_mb.data(), h->h_lv.data(), p.b_annexb != 0, h->nal_off.size() == 1, &h->last_stats);
@@ -271,14 +275,14 @@ void x264_encoder_close(x264_t *h)
 
 /* test/diagnostic hooks (not part of the x264 API): entropy-code caller-supplied records, fetch the GPU recon */
 int x264host_write_slice(int mbw, int mbh, int slice_type, int qp, int pic_init_qp, int frame_num, int log2_max_frame_num,
-                         int idr, int idr_pic_id, int disable_deblock_idc, int num_ref, int num_ref_default,
+                         int idr, int idr_pic_id, int disable_deblock_idc, int num_ref, int num_ref_default, int transform8x8_mode,
                          const x264gpu_mb *mbs, const int16_t *levels, uint8_t *out, int cap, int *skipped)
 {
     SliceParams sp = {};
     sp.mbw = mbw; sp.mbh = mbh; sp.slice_type = slice_type; sp.qp = qp; sp.pic_init_qp = pic_init_qp; sp.frame_num = frame_num;
     sp.log2_max_frame_num = log2_max_frame_num; sp.idr = idr; sp.idr_pic_id = idr_pic_id; sp.nal_ref_idc = idr ? 3 : 2;
     sp.num_ref = num_ref; sp.num_ref_default = num_ref_default;
-    sp.disable_deblock_idc = disable_deblock_idc;
+    sp.disable_deblock_idc = disable_deblock_idc; sp.transform8x8_mode = transform8x8_mode;
     std::vector<uint8_t> v;
     SliceStats stt = { 0 };
     write_slice(v, sp, mbs, levels, true, true, &stt);
@@ -289,16 +293,16 @@ int x264host_write_slice(int mbw, int mbh, int slice_type, int qp, int pic_init_
 }
 
 int x264host_write_headers(int width, int height, int level_idc, int log2_max_frame_num, int pic_init_qp, int chroma_qp_offset,
-                           uint32_t num_units_in_tick, uint32_t time_scale, int num_ref, uint8_t *out, int cap)
+                           uint32_t num_units_in_tick, uint32_t time_scale, int num_ref, int transform8x8_mode, uint8_t *out, int cap)
 {
     SpsParams s = {};
-    s.profile_idc = 66; s.level_idc = level_idc; s.mbw = (width + 15) / 16; s.mbh = (height + 15) / 16;
+    s.profile_idc = transform8x8_mode ? 100 : 66; s.level_idc = level_idc; s.mbw = (width + 15) / 16; s.mbh = (height + 15) / 16;
     s.crop_right = s.mbw * 16 - width; s.crop_bottom = s.mbh * 16 - height; s.num_ref_frames = num_ref; s.log2_max_frame_num = log2_max_frame_num;
     s.fullrange = 0; s.colorprim = 2; s.transfer = 2; s.colmatrix = 2; s.vidformat = 5;
-    s.num_units_in_tick = num_units_in_tick; s.time_scale = time_scale; s.constraint_set0 = 1; s.constraint_set1 = 1;
+    s.num_units_in_tick = num_units_in_tick; s.time_scale = time_scale; s.constraint_set0 = !transform8x8_mode; s.constraint_set1 = !transform8x8_mode;
     std::vector<uint8_t> v;
     write_sps(v, s, true);
-    PpsParams pp = { 0, 0, 0, num_ref, pic_init_qp, chroma_qp_offset };
+    PpsParams pp = { 0, 0, 0, num_ref, pic_init_qp, chroma_qp_offset, transform8x8_mode };
     write_pps(v, pp, true);
     if ((int)v.size() > cap) return -1;
     memcpy(out, v.data(), v.size());

@@ -17,6 +17,7 @@ struct SliceParams {
     int num_ref;             // active references of this slice (te() range)
     int num_ref_default;     // PPS num_ref_idx_l0_default_active
     int disable_deblock_idc, alpha_off_div2, beta_off_div2;
+    int transform8x8_mode;   // PPS transform_8x8_mode_flag
 };
 struct SliceStats { int skip; };
 
@@ -28,7 +29,7 @@ struct SpsParams {
     uint32_t num_units_in_tick, time_scale;
     int constraint_set0, constraint_set1;
 };
-struct PpsParams { int pps_id, sps_id, cabac, num_ref, pic_init_qp, chroma_qp_offset; };
+struct PpsParams { int pps_id, sps_id, cabac, num_ref, pic_init_qp, chroma_qp_offset, transform8x8_mode; };
 
 void write_sps(std::vector<uint8_t> &out, const SpsParams &s, bool annexb);
 void write_pps(std::vector<uint8_t> &out, const PpsParams &p, bool annexb);

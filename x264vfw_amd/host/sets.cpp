@@ -13,6 +13,12 @@ void write_sps(std::vector<uint8_t> &out, const SpsParams &s, bool annexb)
     bw.put1(s.constraint_set0); bw.put1(s.constraint_set1); bw.put(0, 6);      // constraint_set2..5 + reserved
     bw.put((uint32_t)s.level_idc, 8);
     bw.ue(s.sps_id);
+    if (s.profile_idc >= 100) {                 // High: 4:2:0, 8 bit, no transform bypass, flat scaling matrices
+        bw.ue(1);                               // chroma_format_idc
+        bw.ue(0); bw.ue(0);                     // bit_depth_luma_minus8, bit_depth_chroma_minus8
+        bw.put1(0);                             // qpprime_y_zero_transform_bypass_flag
+        bw.put1(0);                             // seq_scaling_matrix_present_flag
+    }
     bw.ue(s.log2_max_frame_num - 4);
     bw.ue(2);                                   // pic_order_cnt_type 2: output order == decoding order (no B frames)
     bw.ue(s.num_ref_frames);
@@ -86,6 +92,11 @@ void write_pps(std::vector<uint8_t> &out, const PpsParams &p, bool annexb)
     bw.put1(1);                                 // deblocking_filter_control_present_flag
     bw.put1(0);                                 // constrained_intra_pred_flag
     bw.put1(0);                                 // redundant_pic_cnt_present_flag
+    if (p.transform8x8_mode) {
+        bw.put1(1);                             // transform_8x8_mode_flag
+        bw.put1(0);                             // pic_scaling_matrix_present_flag
+        bw.se(p.chroma_qp_offset);              // second_chroma_qp_index_offset
+    }
     bw.trailing();
     append_nal(out, 3, 8, bw.bytes(), annexb, true);
 }

@@ -15,7 +15,7 @@ const uint8_t kBlkX[16] = { 0, 1, 0, 1, 2, 3, 2, 3, 0, 1, 0, 1, 2, 3, 2, 3 };
 const uint8_t kBlkY[16] = { 0, 0, 1, 1, 0, 0, 1, 1, 2, 2, 3, 3, 2, 2, 3, 3 };
 const uint8_t kIdxOf[4][4] = { { 0, 1, 4, 5 }, { 2, 3, 6, 7 }, { 8, 9, 12, 13 }, { 10, 11, 14, 15 } };  // [by][bx]
 
-inline bool is_intra(const x264gpu_mb &m) { return m.type == X264GPU_MB_I4x4 || m.type == X264GPU_MB_I16x16; }
+inline bool is_intra(const x264gpu_mb &m) { return m.type == X264GPU_MB_I4x4 || m.type == X264GPU_MB_I8x8 || m.type == X264GPU_MB_I16x16; }
 
 struct SliceCtx {
     const SliceParams &p;
@@ -162,10 +162,10 @@ struct SliceCtx {
         int bx = kBlkX[blk], by = kBlkY[blk], ma, mb;
         const x264gpu_mb &cur = mbs[mby * p.mbw + mbx];
         if (bx > 0) ma = cur.i4_mode[kIdxOf[by][bx - 1]];
-        else if (mbx > 0) { const x264gpu_mb &n = mbs[mby * p.mbw + mbx - 1]; ma = n.type == X264GPU_MB_I4x4 ? n.i4_mode[kIdxOf[by][3]] : 2; }
+        else if (mbx > 0) { const x264gpu_mb &n = mbs[mby * p.mbw + mbx - 1]; ma = (n.type == X264GPU_MB_I4x4 || n.type == X264GPU_MB_I8x8) ? n.i4_mode[kIdxOf[by][3]] : 2; }
         else return 2;
         if (by > 0) mb = cur.i4_mode[kIdxOf[by - 1][bx]];
-        else if (mby > 0) { const x264gpu_mb &n = mbs[(mby - 1) * p.mbw + mbx]; mb = n.type == X264GPU_MB_I4x4 ? n.i4_mode[kIdxOf[3][bx]] : 2; }
+        else if (mby > 0) { const x264gpu_mb &n = mbs[(mby - 1) * p.mbw + mbx]; mb = (n.type == X264GPU_MB_I4x4 || n.type == X264GPU_MB_I8x8) ? n.i4_mode[kIdxOf[3][bx]] : 2; }
         else return 2;
         return ma < mb ? ma : mb;
     }
@@ -193,8 +193,22 @@ struct SliceCtx {
 
     void write_mb_intra(int mbx, int mby, const x264gpu_mb &m, const int16_t *lv, int type_offset)
     {
-        if (m.type == X264GPU_MB_I4x4) {
+        if (m.type == X264GPU_MB_I8x8) {
+            // I_NxN with transform_size_8x8_flag = 1: four Intra8x8PredMode (8.3.2.1); modes are stored replicated over
+            // the 8x8's 4x4 entries, so the 4x4 predictor of its top-left block is exactly predIntra8x8PredMode
             bw.ue(type_offset + 0);
+            bw.put1(1);
+            for (int i8 = 0; i8 < 4; i8++) {
+                int pm = pred_i4_mode(mbx, mby, i8 * 4), mode = m.i4_mode[i8 * 4];
+                if (mode == pm) bw.put1(1);
+                else { bw.put1(0); bw.put((uint32_t)(mode < pm ? mode : mode - 1), 3); }
+            }
+            bw.ue(m.chroma_mode);
+            bw.ue(cbp_to_golomb_intra[m.cbp_luma | (m.cbp_chroma << 4)]);
+            if (m.cbp_luma || m.cbp_chroma) bw.se(0);
+        } else if (m.type == X264GPU_MB_I4x4) {
+            bw.ue(type_offset + 0);
+            if (p.transform8x8_mode) bw.put1(0);                 // transform_size_8x8_flag
             for (int b = 0; b < 16; b++) {
                 int pm = pred_i4_mode(mbx, mby, b), mode = m.i4_mode[b];
                 if (mode == pm) bw.put1(1);
@@ -253,6 +267,7 @@ struct SliceCtx {
                                 }
                         }
                         bw.ue(cbp_to_golomb_inter[m.cbp_luma | (m.cbp_chroma << 4)]);
+                        if (p.transform8x8_mode && m.cbp_luma) bw.put1(m.transform8x8);      // every partition here is >= 8x8
                         if (m.cbp_luma || m.cbp_chroma) bw.se(0);
                         write_residual(mbx, mby, m, lv);
                     }

@@ -33,7 +33,7 @@ class MbRecord(C.Structure):
     """Mirror of struct x264gpu_mb (64 bytes)."""
     _fields_ = [("type", C.c_uint8), ("i16_mode", C.c_uint8), ("chroma_mode", C.c_uint8), ("qp", C.c_uint8),
                 ("cbp_luma", C.c_uint8), ("cbp_chroma", C.c_uint8), ("partition", C.c_uint8),
-                ("ref", C.c_int8 * 4), ("i4_mode", C.c_uint8 * 16),                ("_p0", C.c_uint8), ("mv", (C.c_int16 * 2) * 4),
+                ("ref", C.c_int8 * 4), ("i4_mode", C.c_uint8 * 16),                ("transform8x8", C.c_uint8), ("mv", (C.c_int16 * 2) * 4),
                 ("nnz", C.c_uint32), ("cost", C.c_int32), ("aux", C.c_int32 * 3)]
 
 
@@ -42,7 +42,7 @@ class Config(C.Structure):
     _fields_ = [(n, C.c_int) for n in (
         "width", "height", "streams", "refs", "qp_i", "qp_p", "me_range", "subme", "deblock",
         "deblock_alpha", "deblock_beta", "chroma_qp_offset", "deadzone_inter", "deadzone_intra",
-        "dct_decimate", "partitions")]
+        "dct_decimate", "partitions", "dct8x8")]
 
 
 MB_LEVELS = 416
