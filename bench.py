@@ -90,7 +90,7 @@ def cpu_baseline(w, h, nframes, keyint):
     import oracle_lib as O
     from synth import synth_frames
     frames = synth_frames(w, h, nframes, seed=0x264, scene_len=10 ** 9)
-    enc = O.OracleEncoder(O.default_config(w, h, refs=3, partitions=3))
+    enc = O.OracleEncoder(O.default_config(w, h, refs=3, partitions=7, dct8x8=1))
     t0 = time.perf_counter()
     for i, f in enumerate(frames):
         enc.encode(np.ascontiguousarray(f), 2 if i % keyint == 0 else 0)
@@ -143,7 +143,7 @@ def main():
     for g in range(G):
         cfg = Config(width=W, height=H, streams=per[g], refs=args.refs, qp_i=qp_i, qp_p=qp_p, me_range=16, subme=7, deblock=1,
                      deblock_alpha=0, deblock_beta=0, chroma_qp_offset=0, deadzone_inter=21, deadzone_intra=11,
-                     dct_decimate=1, partitions=3)
+                     dct_decimate=1, partitions=7, dct8x8=1)
         h = C.c_void_p()
         lib.check(lib.x264gpu_encoder_create(C.byref(h), C.byref(cfg)), "encoder_create")
         n = lib.x264gpu_encoder_mb_count(h)
@@ -206,13 +206,13 @@ def main():
            "ms_per_step": round(dt / K * 1e3, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
            "dtype": "u8", "data": "synthetic",
            "config": {"workload": f"{W}x{H} yuv420p, {S} closed-GOP streams/GPU x {K} frames, keyint {args.keyint}, "
-                                  f"CQP {qp_i}/{qp_p}, me hex merange 16 subme 7, partitions p8x8(16x8,8x16,8x8)+i4x4, ref {args.refs}, deblock 0:0",
+                                  f"CQP {qp_i}/{qp_p}, me hex merange 16 subme 7, partitions p8x8(16x8,8x16,8x8)+i8x8+i4x4, 8x8dct, ref {args.refs}, deblock 0:0",
                       "streams_per_gpu": S, "stream_groups": G, "frames_per_step": S * world},
            "roofline": roof}
     if rank == 0:
         import numpy as np
         types = np.bincount(mbs[0].cpu().numpy()[:, :, 0].reshape(-1), minlength=7)
-        out["config"]["mb_types_last_step"] = {"I4x4": int(types[0]), "I16x16": int(types[2]), "P16x16/16x8/8x16": int(types[4]), "P8x8": int(types[5])}
+        out["config"]["mb_types_last_step"] = {"I4x4": int(types[0]), "I8x8": int(types[1]), "I16x16": int(types[2]), "P16x16/16x8/8x16": int(types[4]), "P8x8": int(types[5])}
         if args.cpu_frames > 0:
             cfps, cdt = cpu_baseline(W, H, args.cpu_frames, args.keyint)
             out["cpu_baseline"] = {"value": round(cfps, 3), "unit": "frames/s", "cores": 1, "kind": "port",

@@ -500,14 +500,16 @@ static void encode_inter_mb(x264o_encoder *e, int mbx, int mby, x264gpu_mb *mb, 
 /* ---- stage 3: intra macroblock analysis + encode with reconstructed neighbours ---- */
 static int i4_pred_mode(const x264gpu_mb *mbs, int mbw, int mbx, int mby, int b, const uint8_t *cur_modes)
 {
-    /* 8.3.1.1: min of left/top block modes; DC when a neighbour is absent; non-I4x4 neighbour MBs count as DC */
+    /* 8.3.1.1 / 8.3.2.1: min of left/top block modes; DC when a neighbour is absent; neighbour MBs that are not I_NxN
+     * count as DC.  I8x8 macroblocks store each 8x8 mode replicated over its four 4x4 entries, which makes the 4x4
+     * look-up of the top-left 4x4 of an 8x8 block exactly predIntra8x8PredMode (x264_mb_predict_intra4x4_mode(h, 4*idx)). */
     int bx = blk_x[b], by = blk_y[b], ma, mb_;
     static const uint8_t idx_of[4][4] = { { 0, 1, 4, 5 }, { 2, 3, 6, 7 }, { 8, 9, 12, 13 }, { 10, 11, 14, 15 } };
     if (bx > 0) ma = cur_modes[idx_of[by][bx - 1]];
-    else if (mbx > 0) { const x264gpu_mb *n = &mbs[mby * mbw + mbx - 1]; ma = n->type == X264GPU_MB_I4x4 ? n->i4_mode[idx_of[by][3]] : 2; }
+    else if (mbx > 0) { const x264gpu_mb *n = &mbs[mby * mbw + mbx - 1]; ma = (n->type == X264GPU_MB_I4x4 || n->type == X264GPU_MB_I8x8) ? n->i4_mode[idx_of[by][3]] : 2; }
     else return 2;
     if (by > 0) mb_ = cur_modes[idx_of[by - 1][bx]];
-    else if (mby > 0) { const x264gpu_mb *n = &mbs[(mby - 1) * mbw + mbx]; mb_ = n->type == X264GPU_MB_I4x4 ? n->i4_mode[idx_of[3][bx]] : 2; }
+    else if (mby > 0) { const x264gpu_mb *n = &mbs[(mby - 1) * mbw + mbx]; mb_ = (n->type == X264GPU_MB_I4x4 || n->type == X264GPU_MB_I8x8) ? n->i4_mode[idx_of[3][bx]] : 2; }
     else return 2;
     return ma < mb_ ? ma : mb_;
 }
@@ -552,7 +554,8 @@ static void intra_mb(x264o_encoder *e, int mbx, int mby, int qp, x264gpu_mb *mbs
     }
     /* --- intra 4x4: per block 9 modes on reconstructed neighbours, coded as we go --- */
     int use_i4 = 0;
-    if (e->cfg.partitions & 2) {
+    const int parts = (e->slice_type == X264GPU_SLICE_I && (e->cfg.partitions & 0x100)) ? (e->cfg.partitions >> 8) & 6 : e->cfg.partitions & 7;
+    if (parts & 2) {
         pixel save[256];
         for (int y = 0; y < 16; y++) memcpy(save + y * 16, rec + y * e->rs, 16);
         int cost4 = lambda * (24 + 16);
@@ -605,7 +608,81 @@ static void intra_mb(x264o_encoder *e, int mbx, int mby, int qp, x264gpu_mb *mbs
         } else
             for (int y = 0; y < 16; y++) memcpy(rec + y * e->rs, save + y * 16, 16);
     }
-    if (!use_i4) {
+    /* --- intra 8x8 ([x264-upstream] analyse.c x264_mb_analyse_intra, I8x8 branch + x264_mb_encode_i8x8): per 8x8 block
+     *     9 modes on the 1-2-1 filtered edge, cost = SA8D + 3*lambda unless the mode is the predicted one, base 4*lambda;
+     *     blocks are coded as we go.  x264 analyses 8x8 before 4x4; the outcome does not depend on the order (the early
+     *     terminations only reject candidates that lose the final strict-< comparison anyway), so it runs last here and
+     *     is selected only if strictly cheaper than the best of 16x16 / 4x4 — x264's COPY2_IF_LT order. --- */
+    int use_i8 = 0;
+    if ((parts & 4) && e->cfg.dct8x8) {
+        pixel save[256];
+        for (int y = 0; y < 16; y++) memcpy(save + y * 16, rec + y * e->rs, 16);
+        const int cur = use_i4 ? mb->cost : best16;
+        int cost8 = lambda * 4, done = 1;
+        uint8_t m8[16];
+        int16_t lv8[256];
+        uint32_t nnz8 = 0;
+        int cbp8 = 0;
+        memset(lv8, 0, sizeof(lv8));
+        memset(m8, 2, sizeof(m8));
+        const uint16_t *mf = e->qt.quant8_mf[X264O_CQM_8IY][qp], *bias = e->qt.quant8_bias[X264O_CQM_8IY][qp];
+        for (int i8 = 0; i8 < 4; i8++) {
+            int x8 = i8 & 1, y8 = i8 >> 1, avail = 0;
+            const pixel *f = fenc + y8 * 8 * e->fs + x8 * 8;
+            pixel *r = rec + y8 * 8 * e->rs + x8 * 8;
+            if (x8 || left) avail |= X264O_AVAIL_LEFT;
+            if (y8 || top) avail |= X264O_AVAIL_TOP;
+            if ((x8 || left) && (y8 || top)) avail |= X264O_AVAIL_TOPLEFT;
+            if (i8 == 0 ? top : i8 == 1 ? (top && mbx + 1 < e->mbw) : i8 == 2) avail |= X264O_AVAIL_TOPRIGHT;
+            int pm = i4_pred_mode(mbs, e->mbw, mbx, mby, i8 * 4, m8);
+            pixel edge[33], p8[64], bp[64];
+            x264o_predict_8x8_filter(r, e->rs, edge, avail);
+            int bestc = 1 << 28, bestm = 2;
+            for (int m = 0; m < 9; m++) {
+                int real = m;
+                int need_l = m == I_PRED_4x4_H || m == I_PRED_4x4_HU, need_t = m == I_PRED_4x4_V || m == I_PRED_4x4_DDL || m == I_PRED_4x4_VL;
+                int need_all = m == I_PRED_4x4_DDR || m == I_PRED_4x4_VR || m == I_PRED_4x4_HD;
+                if (need_l && !(avail & X264O_AVAIL_LEFT)) continue;
+                if (need_t && !(avail & X264O_AVAIL_TOP)) continue;
+                if (need_all && (avail & (X264O_AVAIL_LEFT | X264O_AVAIL_TOP | X264O_AVAIL_TOPLEFT)) != (X264O_AVAIL_LEFT | X264O_AVAIL_TOP | X264O_AVAIL_TOPLEFT)) continue;
+                if (m == I_PRED_4x4_DC) {
+                    int l = avail & X264O_AVAIL_LEFT, t = avail & X264O_AVAIL_TOP;
+                    real = l && t ? I_PRED_4x4_DC : l ? I_PRED_4x4_DC_LEFT : t ? I_PRED_4x4_DC_TOP : I_PRED_4x4_DC_128;
+                }
+                x264o_predict_8x8(p8, 8, edge, real);
+                int c = x264o_sa8d(f, e->fs, p8, 8, 8, 8) + (m == pm ? 0 : 3 * lambda);
+                if (c < bestc) { bestc = c; bestm = m; memcpy(bp, p8, 64); }
+            }
+            cost8 += bestc;
+            memset(m8 + i8 * 4, bestm, 4);
+            if (i8 < 3 && cost8 > cur) { done = 0; break; }     /* cannot win any more */
+            for (int y = 0; y < 8; y++) memcpy(r + y * e->rs, bp + y * 8, 8);
+            dctcoef d[64];
+            x264o_sub8x8_dct8(d, f, e->fs, r, e->rs);
+            if (x264o_quant_8x8(d, mf, bias)) {
+                for (int k = 0; k < 64; k++) {
+                    int16_t v = d[x264o_zigzag8[k]];
+                    lv8[(i8 * 4 + (k & 3)) * 16 + (k >> 2)] = v;
+                    if (v) nnz8 |= 1u << (i8 * 4 + (k & 3));
+                }
+                x264o_dequant_8x8(d, e->qt.dequant8_mf, qp);
+                x264o_add8x8_idct8(r, e->rs, d);
+                cbp8 |= 1 << i8;
+            }
+        }
+        if (done && cost8 < cur) {
+            use_i8 = 1; use_i4 = 0;
+            mb->type = X264GPU_MB_I8x8;
+            mb->cost = cost8;
+            mb->transform8x8 = 1;
+            memcpy(mb->i4_mode, m8, 16);
+            memcpy(lv, lv8, sizeof(lv8));
+            mb->nnz = nnz8;
+            mb->cbp_luma = (uint8_t)cbp8;
+        } else
+            for (int y = 0; y < 16; y++) memcpy(rec + y * e->rs, save + y * 16, 16);
+    }
+    if (!use_i4 && !use_i8) {
         /* x264_mb_encode_i16x16 */
         mb->type = X264GPU_MB_I16x16;
         mb->cost = best16;

@@ -53,6 +53,10 @@ def compare(tag, mbw, g_mb, o_mb, g_lv, o_lv, g_rec, o_rec):
     (176, 144, 4, dict(dct8x8=1)),                           # adaptive 8x8 transform on inter macroblocks
     (352, 288, 4, dict(dct8x8=1, partitions=3, refs=2, qp_i=26, qp_p=28)),
     (208, 120, 3, dict(dct8x8=1, qp_i=12, qp_p=14, dct_decimate=0)),
+    (176, 144, 4, dict(dct8x8=1, partitions=6)),             # Intra_8x8 next to Intra_4x4 / 16x16
+    (352, 288, 4, dict(dct8x8=1, partitions=7, refs=3, qp_i=28, qp_p=31)),   # the medium toolset of this round
+    (208, 120, 3, dict(dct8x8=1, partitions=4, qp_i=14, qp_p=16)),
+    (64, 48, 3, dict(dct8x8=1, partitions=7, qp_i=38, qp_p=40)),
 ])
 def test_pipeline_bitexact(gpu, w, h, nfr, kw):
     from gpu_enc import GpuEncoder

@@ -113,7 +113,9 @@ def test_open_without_gpu_fails_loudly():
                                      (208, 120, dict(partitions=1, subme=4)), (176, 144, dict(refs=3, partitions=3)),
                                      (96, 80, dict(refs=2)), (208, 120, dict(refs=4, partitions=3, qp_i=30, qp_p=32)),
                                      (176, 144, dict(dct8x8=1)), (352, 288, dict(dct8x8=1, partitions=3, refs=2, qp_i=26, qp_p=28)),
-                                     (208, 120, dict(dct8x8=1, qp_i=12, qp_p=14, dct_decimate=0))])
+                                     (208, 120, dict(dct8x8=1, qp_i=12, qp_p=14, dct_decimate=0)),
+                                     (176, 144, dict(dct8x8=1, partitions=6)), (352, 288, dict(dct8x8=1, partitions=7, refs=3, qp_i=28, qp_p=31)),
+                                     (208, 120, dict(dct8x8=1, partitions=4, qp_i=14, qp_p=16)), (64, 48, dict(dct8x8=1, partitions=7, qp_i=38, qp_p=40))])
 def test_cavlc_closed_loop(w, h, kw):
     """oracle records -> host CAVLC -> checker decoder == oracle reconstruction, I and P pictures"""
     nfr = 7 if kw.get("refs", 1) > 1 else 4

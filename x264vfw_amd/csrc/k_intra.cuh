@@ -6,6 +6,7 @@
 // Restates oracle/encoder.c intra_mb bit-exactly.
 #pragma once
 #include "enc_common.cuh"
+#include "intra8.cuh"
 
 namespace x264gpu {
 
@@ -19,6 +20,12 @@ struct IntraLds {
     uint8_t U[16][U_SIZE];
     uint8_t cnb[16][2][CNB_SIZE];
     uint8_t modes[16][16];
+    // Intra_8x8 works in its own tile / level buffer so the 4x4 candidate's results survive until the final choice
+    __attribute__((aligned(8))) uint8_t tile8[16][IT_SIZE];
+    __attribute__((aligned(8))) int16_t lv8[16][256];
+    uint8_t U8[16][U8_SIZE];
+    uint8_t modes8[16][16];
+    __attribute__((aligned(8))) uint8_t pred8tab[9 * 64];
     uint8_t nmodes[16][8];      // neighbour macroblocks' edge modes: [0..3] left column (by 0..3), [4..7] top row (bx 0..3)
     int progress[160];
     unsigned long long sect[16][8];   // diagnostics: per-wave section cycle accumulators
@@ -71,24 +78,27 @@ __device__ void intra_mb_wave(const EncK &k, IntraLds &L, int wave, int lane, in
 #define SECT(i) do { if (k.dbg) { unsigned long long t_ = clock64(); if (lane == 0) L.sect[wave][i] += t_ - ts0; ts0 = t_; } } while (0)
 
     // ---- neighbours: row -1 (x = -1..19) and column -1 into the tile; nb[] for the 16x16 predictors ----
-    if (lane < 21) {
+    uint8_t *tile8 = L.tile8[wave] + IT_ORG;
+    if (lane < 25) {                           // x = -1..23: the top-right 8 samples serve Intra_8x8 block 1
         const int x = lane - 1;
         const bool ok = top && (x >= 0 || left) && (x < 16 || topright);
         const uint8_t v = ok ? rec[-(long)k.rs + x] : 128;
         tile[-IT_STRIDE + x] = v;
-        nb[NB_TOP + x] = v;                    // x = -1 lands on NB_TL
+        tile8[-IT_STRIDE + x] = v;
+        if (lane < 21) nb[NB_TOP + x] = v;     // x = -1 lands on NB_TL
     } else if (lane >= 32 && lane < 48) {
         const int y = lane - 32;
         const uint8_t v = left ? rec[(long)y * k.rs - 1] : 128;
         tile[y * IT_STRIDE - 1] = v;
+        tile8[y * IT_STRIDE - 1] = v;
         nb[NB_LEFT + y] = v;
     }
-    // edge modes of the left / top macroblocks (DC unless that macroblock is I4x4), fetched once
+    // edge modes of the left / top macroblocks (DC unless that macroblock is I4x4 / I8x8), fetched once
     if (lane >= 48 && lane < 56) {
         const int i = lane - 48;
         int m = 2;
-        if (i < 4 && left) { const x264gpu_mb *n = mbs + mbi - 1; if (n->type == X264GPU_MB_I4x4) m = n->i4_mode[blkidx_of(3, i)]; }
-        if (i >= 4 && top) { const x264gpu_mb *n = mbs + mbi - k.mbw; if (n->type == X264GPU_MB_I4x4) m = n->i4_mode[blkidx_of(i - 4, 3)]; }
+        if (i < 4 && left) { const x264gpu_mb *n = mbs + mbi - 1; if (n->type == X264GPU_MB_I4x4 || n->type == X264GPU_MB_I8x8) m = n->i4_mode[blkidx_of(3, i)]; }
+        if (i >= 4 && top) { const x264gpu_mb *n = mbs + mbi - k.mbw; if (n->type == X264GPU_MB_I4x4 || n->type == X264GPU_MB_I8x8) m = n->i4_mode[blkidx_of(i - 4, 3)]; }
         L.nmodes[wave][i] = (uint8_t)m;
     }
     const uint32_t cz = *(const uint32_t *)(fenc + (size_t)zy * k.fs + zx);
@@ -166,6 +176,98 @@ __device__ void intra_mb_wave(const EncK &k, IntraLds &L, int wave, int lane, in
         use_i4 = cost4 < best16;
     }
 
+    // ---- intra 8x8 (oracle intra_mb, I8x8 branch): R8 layout, lane = (mode group, row); eight modes per pass, the
+    //      ninth (HU) in a second pass on group 0.  Candidate results stay in LDS (tile8 / lv8) until the final choice ----
+    bool use_i8 = false;
+    unsigned nnz8 = 0;
+    int cost8 = 0, cbp8 = 0;
+    if ((k.partitions & 4) && k.dct8x8) {
+        const int cur = use_i4 ? cost4 : best16;
+        uint8_t *m8 = L.modes8[wave], *U8 = L.U8[wave];
+        int16_t *lv8 = L.lv8[wave];
+        const int g = lane >> 3, r8 = lane & 7;
+        if (lane < 16) m8[lane] = 2;
+        cost8 = lambda * 4;
+        bool done = true;
+        for (int i8 = 0; i8 < 4; i8++) {
+            const int x8 = i8 & 1, y8 = i8 >> 1;
+            int avail = 0;
+            if (x8 || left) avail |= AVAIL_LEFT;
+            if (y8 || top) avail |= AVAIL_TOP;
+            if ((x8 || left) && (y8 || top)) avail |= AVAIL_TOPLEFT;
+            if (i8 == 0 ? top : i8 == 1 ? topright : i8 == 2) avail |= AVAIL_TOPRIGHT;
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_s_waitcnt(0xc07f);
+            const int pm = i4_pred_mode(L.nmodes[wave], mbx, mby, i8 * 4, m8);
+            uint8_t *bt = tile8 + y8 * 8 * IT_STRIDE + x8 * 8;
+            pred8_build_u(U8, bt, IT_STRIDE, avail, lane);
+            // source rows of this 8x8 block in R8 layout (every mode group gets a copy)
+            const int src = i8 * 16 + (r8 >> 2) * 8 + (r8 & 3);
+            const uint32_t elo = (uint32_t)__shfl((int)cz, src), ehi = (uint32_t)__shfl((int)cz, src + 4);
+            uint32_t p1lo, p1hi, p2lo, p2hi;
+            unsigned key;
+            {   // modes 0..7, one per group
+                pred8_row8(U8, L.pred8tab, g, r8, p1lo, p1hi);
+                int h = sa8d_r8_half(elo, ehi, p1lo, p1hi, lane);
+                h += dpp<DPP_XOR1>(h); h += dpp<DPP_XOR2>(h); h += __shfl_xor(h, 4);
+                const int c = ((2 * h + 2) >> 2) + (g == pm ? 0 : 3 * lambda);
+                key = pred4_mode_ok(g, avail) ? (((unsigned)c << 4) | (unsigned)g) : 0xffffffffu;
+            }
+            {   // mode 8 on group 0
+                pred8_row8(U8, L.pred8tab, 8, r8, p2lo, p2hi);
+                int h = sa8d_r8_half(elo, ehi, p2lo, p2hi, lane);
+                h += dpp<DPP_XOR1>(h); h += dpp<DPP_XOR2>(h); h += __shfl_xor(h, 4);
+                const int c = ((2 * h + 2) >> 2) + (8 == pm ? 0 : 3 * lambda);
+                const unsigned k2 = (g == 0 && pred4_mode_ok(8, avail)) ? (((unsigned)c << 4) | 8u) : 0xffffffffu;
+                key = min(key, k2);
+            }
+            key = wave_min_u32(key);
+            const int bm = key & 15;
+            cost8 += (int)(key >> 4);
+            if (lane < 4) m8[i8 * 4 + lane] = (uint8_t)bm;
+            if (i8 < 3 && cost8 > cur) { done = false; break; }      // cannot win any more
+            // winning prediction to every group, then encode (all groups do the same work; group 0 stores)
+            const uint32_t plo = bm == 8 ? (uint32_t)__shfl((int)p2lo, r8) : (uint32_t)__shfl((int)p1lo, bm * 8 + r8);
+            const uint32_t phi = bm == 8 ? (uint32_t)__shfl((int)p2hi, r8) : (uint32_t)__shfl((int)p1hi, bm * 8 + r8);
+            int e[8], p[8], v[8];
+            unpack4(elo, e); unpack4(ehi, e + 4); unpack4(plo, p); unpack4(phi, p + 4);
+#pragma unroll
+            for (int i = 0; i < 8; i++) v[i] = e[i] - p[i];
+            fwd8_1d(v); transpose8(v, lane); fwd8_1d(v); transpose8(v, lane);
+            int mf[4], bs[4], dq[4];
+            q8_row(k.q8_intra, r8, mf, bs, dq);
+            unsigned mlo = 0, mhi = 0;
+#pragma unroll
+            for (int i = 0; i < 8; i++) {
+                v[i] = quant_one(v[i], mf[i & 3], bs[i & 3]);
+                const int z = c_zigzag8_inv[r8 * 8 + i];
+                if (v[i]) { if (z < 32) mlo |= 1u << z; else mhi |= 1u << (z - 32); }
+                if (g == 0) lv8[(i8 * 4 + (z & 3)) * 16 + (z >> 2)] = (int16_t)v[i];
+            }
+            mlo = group8_or(mlo); mhi = group8_or(mhi);
+            const unsigned long long mask = ((unsigned long long)mhi << 32) | mlo;
+#pragma unroll
+            for (int q = 0; q < 4; q++) nnz8 |= (mask & (0x1111111111111111ull << q)) ? 1u << (i8 * 4 + q) : 0u;   // group 0's value is read below
+            if (mask) cbp8 |= 1 << i8;
+            const int qb = k.q8_intra.qp / 6 - 6;
+#pragma unroll
+            for (int i = 0; i < 8; i++) v[i] = dequant_one(v[i], dq[i & 3], qb);
+            inv8_1d(v); transpose8(v, lane); inv8_1d(v); transpose8(v, lane);
+#pragma unroll
+            for (int i = 0; i < 8; i++) v[i] = ((v[i] + 32) >> 6) + p[i];
+            if (g == 0) {
+                *(uint32_t *)(bt + r8 * IT_STRIDE) = pack4_clip(v);
+                *(uint32_t *)(bt + r8 * IT_STRIDE + 4) = pack4_clip(v + 4);
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_s_waitcnt(0xc07f);
+        nnz8 = (unsigned)__builtin_amdgcn_readfirstlane((int)nnz8);
+        cbp8 = __builtin_amdgcn_readfirstlane(cbp8);
+        use_i8 = done && cost8 < cur;
+        if (use_i8) use_i4 = false;
+    }
+
     SECT(2);
     x264gpu_mb recd;
     __builtin_memset(&recd, 0, sizeof(recd));
@@ -173,7 +275,17 @@ __device__ void intra_mb_wave(const EncK &k, IntraLds &L, int wave, int lane, in
     for (int i = 0; i < 4; i++) recd.ref[i] = -1;
     if (k.slice_type == X264GPU_SLICE_P) { recd.aux[0] = mbs[mbi].aux[0]; recd.aux[1] = mbs[mbi].aux[1]; recd.aux[2] = mbs[mbi].aux[2]; }
 
-    if (use_i4) {
+    if (use_i8) {
+        recd.type = X264GPU_MB_I8x8;
+        recd.cost = cost8;
+        recd.transform8x8 = 1;
+        for (int b = 0; b < 16; b++) recd.i4_mode[b] = L.modes8[wave][b];
+        recd.nnz = nnz8;
+        recd.cbp_luma = (uint8_t)cbp8;
+        *(uint32_t *)(rec + (size_t)zy * k.rs + zx) = *(const uint32_t *)(tile8 + zy * IT_STRIDE + zx);
+        *(uint2 *)(lv + lane * 4) = *(const uint2 *)(L.lv8[wave] + lane * 4);       // 256 luma levels, interleaved 4x4 form
+        if (lane < 16) lv[X264GPU_LV_LUMA_DC + lane] = 0;
+    } else if (use_i4) {
         recd.type = X264GPU_MB_I4x4;
         recd.cost = cost4;
         for (int b = 0; b < 16; b++) recd.i4_mode[b] = m4[b];
@@ -299,6 +411,7 @@ __global__ __launch_bounds__(1024) void k_intra(EncK k)
     const uint32_t t4 = (lane >> 2) < 9 ? ((const uint32_t *)c_pred4_table.t)[lane] : 0x01010101u * U_DC;
     for (int i = threadIdx.x; i < 160; i += 1024) L.progress[i] = 0;
     if (threadIdx.x < 128) ((unsigned long long *)L.sect)[threadIdx.x] = 0;
+    if (threadIdx.x < 144) ((uint32_t *)L.pred8tab)[threadIdx.x] = ((const uint32_t *)c_pred8_table)[threadIdx.x];
     __syncthreads();
     const x264gpu_mb *mbs = k.mb + (size_t)s * k.nmb;
     volatile int *progress = L.progress;

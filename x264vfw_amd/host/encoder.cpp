@@ -62,7 +62,7 @@ static int pick_level(const x264_param_t *p, int mbs, int refs)
     return 62;
 }
 
-static const char kSeiText[] = "x264vfw-mi355x hot path r1 - H.264/MPEG-4 AVC codec - options: cavlc ip p8x8 i4x4 hex ref1 cqp";
+static const char kSeiText[] = "x264vfw-mi355x hot path r1 - H.264/MPEG-4 AVC codec - options: cavlc ip p8x8 i4x4 i8x8 8x8dct hex ref<=4 cqp";
 
 static SpsParams make_sps(const x264_t *h)
 {
@@ -125,7 +125,8 @@ x264_t *x264_encoder_open(x264_param_t *param)
     if (p.b_cabac) { xlog(&p, X264_LOG_WARNING, "CABAC is not implemented yet: using CAVLC\n"); p.b_cabac = 0; }
     p.analyse.i_weighted_pred = X264_WEIGHTP_NONE; p.analyse.b_weighted_bipred = 0;
     p.analyse.b_transform_8x8 = p.analyse.b_transform_8x8 != 0;
-    p.analyse.inter &= X264_ANALYSE_I4x4 | X264_ANALYSE_PSUB16x16; p.analyse.intra &= X264_ANALYSE_I4x4;
+    p.analyse.inter &= X264_ANALYSE_I4x4 | X264_ANALYSE_I8x8 | X264_ANALYSE_PSUB16x16; p.analyse.intra &= X264_ANALYSE_I4x4 | X264_ANALYSE_I8x8;
+    if (!p.analyse.b_transform_8x8) { p.analyse.inter &= ~X264_ANALYSE_I8x8; p.analyse.intra &= ~X264_ANALYSE_I8x8; }   // as x264 validate_parameters
     p.analyse.i_trellis = 0; p.rc.b_mb_tree = 0; p.rc.i_aq_mode = X264_AQ_NONE; p.rc.i_lookahead = 0; p.i_scenecut_threshold = 0;
     p.analyse.i_me_method = X264_ME_HEX; p.analyse.i_me_range = clampi(p.analyse.i_me_range, 4, 16);
     p.analyse.i_subpel_refine = clampi(p.analyse.i_subpel_refine, 0, 7);
@@ -153,7 +154,9 @@ x264_t *x264_encoder_open(x264_param_t *param)
     cfg.chroma_qp_offset = p.analyse.i_chroma_qp_offset;
     cfg.deadzone_inter = p.analyse.i_luma_deadzone[0]; cfg.deadzone_intra = p.analyse.i_luma_deadzone[1];
     cfg.dct_decimate = p.analyse.b_dct_decimate;
-    cfg.partitions = ((p.analyse.intra & X264_ANALYSE_I4x4) ? 2 : 0) | ((p.analyse.inter & X264_ANALYSE_PSUB16x16) ? 1 : 0);
+    // P slices follow analyse.inter, I slices analyse.intra (bit8 marks the separate I-slice set)
+    cfg.partitions = ((p.analyse.inter & X264_ANALYSE_PSUB16x16) ? 1 : 0) | ((p.analyse.inter & X264_ANALYSE_I4x4) ? 2 : 0) | ((p.analyse.inter & X264_ANALYSE_I8x8) ? 4 : 0) |
+                     0x100 | ((p.analyse.intra & X264_ANALYSE_I4x4) ? 0x200 : 0) | ((p.analyse.intra & X264_ANALYSE_I8x8) ? 0x400 : 0);
     cfg.dct8x8 = p.analyse.b_transform_8x8;
     size_t insz = (size_t)p.i_width * p.i_height * 3 / 2;
     if (x264gpu_encoder_create(&h->gpu, &cfg) != X264GPU_OK ||
