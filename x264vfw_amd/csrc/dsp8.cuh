@@ -37,6 +37,13 @@ __device__ __forceinline__ void inv8_1d(int s[8])
     s[0] = b0 + b7; s[1] = b2 + b5; s[2] = b4 + b3; s[3] = b6 + b1;
     s[4] = b6 - b1; s[5] = b4 - b3; s[6] = b2 - b5; s[7] = b0 - b7;
 }
+// value of lane^4 (exchange between the two quads of an 8-lane group): row_shl:4 feeds lanes 0-3 / 8-11 of each DPP
+// row, row_shr:4 feeds lanes 4-7 / 12-15 (bank masks select which quads a DPP move writes)
+__device__ __forceinline__ int xor4(int v)
+{
+    int r = __builtin_amdgcn_update_dpp(0, v, 0x104, 0xf, 0x5, false);      // row_shl:4 -> lane i takes lane i+4
+    return __builtin_amdgcn_update_dpp(r, v, 0x114, 0xf, 0xa, false);       // row_shr:4 -> lane i takes lane i-4
+}
 // (lane r, reg c) -> (lane c, reg r) within each group of 8 lanes
 __device__ __forceinline__ void transpose8(int v[8], int lane)
 {
@@ -47,7 +54,7 @@ __device__ __forceinline__ void transpose8(int v[8], int lane)
         for (int r = 0; r < 8; r++) {
             if (r & s) continue;
             const int send = hi ? v[r] : v[r | s];
-            const int recv = s == 1 ? dpp<DPP_XOR1>(send) : s == 2 ? dpp<DPP_XOR2>(send) : __shfl_xor(send, 4);
+            const int recv = s == 1 ? dpp<DPP_XOR1>(send) : s == 2 ? dpp<DPP_XOR2>(send) : xor4(send);
             if (hi) v[r] = recv; else v[r | s] = recv;
         }
     }
@@ -75,7 +82,7 @@ __device__ __forceinline__ unsigned group8_or(unsigned v)
 {
     v |= (unsigned)dpp<DPP_XOR1>((int)v);
     v |= (unsigned)dpp<DPP_XOR2>((int)v);
-    v |= (unsigned)__shfl_xor((int)v, 4);
+    v |= (unsigned)xor4((int)v);
     return v;
 }
 // decimate_score64 from the scan-order nonzero mask (all levels known to be +-1): table {3 x4, 2 x8, 1 x20, 0..}
@@ -115,7 +122,7 @@ __device__ __forceinline__ int sa8d_r8_half(uint32_t elo, uint32_t ehi, uint32_t
     for (int i = 0; i < 4; i++) {
         s16x2 u = pk_bfly<DPP_XOR1>(t[i], sg1);
         u = pk_bfly<DPP_XOR2>(u, sg2);
-        u = u * sg4 + as_s16x2((uint32_t)__shfl_xor((int)as_u32(u), 4));
+        u = u * sg4 + as_s16x2((uint32_t)xor4((int)as_u32(u)));
         u = __builtin_elementwise_max(u, -u);
         const s16x2 m = __builtin_elementwise_max(u, as_s16x2(__builtin_amdgcn_alignbit(as_u32(u), as_u32(u), 16)));   // index bit 1
         acc += as_u32(m) & 0xffffu;

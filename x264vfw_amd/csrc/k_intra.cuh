@@ -127,62 +127,16 @@ __device__ void intra_mb_wave(const EncK &k, IntraLds &L, int wave, int lane, in
     }
 
     SECT(1);
-    // ---- intra 4x4: nine modes per block in parallel, blocks in coding order ----
-    bool use_i4 = false;
-    unsigned nnz = 0;
-    int cost4 = 0;
-    if (k.partitions & 2) {
-        cost4 = lambda * (24 + 16);
-        for (int b = 0; b < 16; b++) {
-            const int bx = z_bx(b), by = z_by(b);
-            const int avail = i4_avail(mbx, mby, k.mbw, b);
-            const int pm = i4_pred_mode(L.nmodes[wave], mbx, mby, b, m4);
-            uint8_t *bt = tile + by * 4 * IT_STRIDE + bx * 4;
-            pred4_build_u(U, bt, IT_STRIDE, avail, lane);
-            const int m = lane >> 2;
-            const bool ok = m < 9 && pred4_mode_ok(m, avail);
-            const uint32_t pr = pred4_row4(U, t4);
-            const uint32_t en = (uint32_t)__shfl((int)cz, b * 4 + j);
-            int e[4], p[4], d[4];
-            unpack4(en, e); unpack4(pr, p);
-#pragma unroll
-            for (int t = 0; t < 4; t++) d[t] = e[t] - p[t];
-            const int sat = quad_sum(satd_quad_partial(d, lane)) >> 1;
-            unsigned key = ok ? (((unsigned)(sat + (m == pm ? 0 : 3 * lambda)) << 4) | (unsigned)m) : 0xffffffffu;
-            key = wave_min_u32(key);
-            const int bm = key & 15;
-            cost4 += (int)(key >> 4);
-            if (lane == 0) m4[b] = (uint8_t)bm;
-            // encode the block with the winning prediction (every quad does the same work)
-            const uint32_t bp = (uint32_t)__shfl((int)pr, bm * 4 + j);
-            int v[4];
-            unpack4(bp, p);
-#pragma unroll
-            for (int t = 0; t < 4; t++) v[t] = e[t] - p[t];
-            dct4_quad(v, lane);
-            quant4_row(v, k.q_luma_intra, j);
-            const bool nz = quad_or((v[0] | v[1] | v[2] | v[3]) != 0 ? 1 : 0) != 0;
-            if (lane < 4) store_levels_scan(lv + b * 16, v, j);
-            dequant4_row(v, k.q_luma_intra, j);
-            idct4_quad(v, lane);
-#pragma unroll
-            for (int t = 0; t < 4; t++) v[t] += p[t];
-            if (lane < 4) *(uint32_t *)(bt + j * IT_STRIDE) = pack4_clip(v);
-            if (nz) nnz |= 1u << b;
-            __builtin_amdgcn_wave_barrier();
-            __builtin_amdgcn_s_waitcnt(0xc07f);
-            if (cost4 >= best16) break;            // intra 4x4 can no longer win (costs only grow)
-        }
-        use_i4 = cost4 < best16;
-    }
-
     // ---- intra 8x8 (oracle intra_mb, I8x8 branch): R8 layout, lane = (mode group, row); eight modes per pass, the
     //      ninth (HU) in a second pass on group 0.  Candidate results stay in LDS (tile8 / lv8) until the final choice ----
-    bool use_i8 = false;
+    // The final choice (16x16, then 4x4 if strictly cheaper, then 8x8 if strictly cheaper still: x264's COPY2_IF_LT chain)
+    // does not depend on the order of the two analyses; running 8x8 first lets the 16-block 4x4 loop stop as soon as it
+    // can no longer win.
+    bool use_i8 = false, i8_done = false;
     unsigned nnz8 = 0;
     int cost8 = 0, cbp8 = 0;
     if ((k.partitions & 4) && k.dct8x8) {
-        const int cur = use_i4 ? cost4 : best16;
+        const int cur = best16;
         uint8_t *m8 = L.modes8[wave], *U8 = L.U8[wave];
         int16_t *lv8 = L.lv8[wave];
         const int g = lane >> 3, r8 = lane & 7;
@@ -209,14 +163,14 @@ __device__ void intra_mb_wave(const EncK &k, IntraLds &L, int wave, int lane, in
             {   // modes 0..7, one per group
                 pred8_row8(U8, L.pred8tab, g, r8, p1lo, p1hi);
                 int h = sa8d_r8_half(elo, ehi, p1lo, p1hi, lane);
-                h += dpp<DPP_XOR1>(h); h += dpp<DPP_XOR2>(h); h += __shfl_xor(h, 4);
+                h += dpp<DPP_XOR1>(h); h += dpp<DPP_XOR2>(h); h += xor4(h);
                 const int c = ((2 * h + 2) >> 2) + (g == pm ? 0 : 3 * lambda);
                 key = pred4_mode_ok(g, avail) ? (((unsigned)c << 4) | (unsigned)g) : 0xffffffffu;
             }
             {   // mode 8 on group 0
                 pred8_row8(U8, L.pred8tab, 8, r8, p2lo, p2hi);
                 int h = sa8d_r8_half(elo, ehi, p2lo, p2hi, lane);
-                h += dpp<DPP_XOR1>(h); h += dpp<DPP_XOR2>(h); h += __shfl_xor(h, 4);
+                h += dpp<DPP_XOR1>(h); h += dpp<DPP_XOR2>(h); h += xor4(h);
                 const int c = ((2 * h + 2) >> 2) + (8 == pm ? 0 : 3 * lambda);
                 const unsigned k2 = (g == 0 && pred4_mode_ok(8, avail)) ? (((unsigned)c << 4) | 8u) : 0xffffffffu;
                 key = min(key, k2);
@@ -264,11 +218,63 @@ __device__ void intra_mb_wave(const EncK &k, IntraLds &L, int wave, int lane, in
         __builtin_amdgcn_s_waitcnt(0xc07f);
         nnz8 = (unsigned)__builtin_amdgcn_readfirstlane((int)nnz8);
         cbp8 = __builtin_amdgcn_readfirstlane(cbp8);
-        use_i8 = done && cost8 < cur;
-        if (use_i8) use_i4 = false;
+        i8_done = done;
     }
 
     SECT(2);
+    // ---- intra 4x4: nine modes per block in parallel, blocks in coding order ----
+    bool use_i4 = false;
+    const int thr8 = i8_done ? cost8 : (1 << 28);
+    unsigned nnz = 0;
+    int cost4 = 0;
+    if (k.partitions & 2) {
+        cost4 = lambda * (24 + 16);
+        for (int b = 0; b < 16; b++) {
+            const int bx = z_bx(b), by = z_by(b);
+            const int avail = i4_avail(mbx, mby, k.mbw, b);
+            const int pm = i4_pred_mode(L.nmodes[wave], mbx, mby, b, m4);
+            uint8_t *bt = tile + by * 4 * IT_STRIDE + bx * 4;
+            pred4_build_u(U, bt, IT_STRIDE, avail, lane);
+            const int m = lane >> 2;
+            const bool ok = m < 9 && pred4_mode_ok(m, avail);
+            const uint32_t pr = pred4_row4(U, t4);
+            const uint32_t en = (uint32_t)__shfl((int)cz, b * 4 + j);
+            int e[4], p[4], d[4];
+            unpack4(en, e); unpack4(pr, p);
+#pragma unroll
+            for (int t = 0; t < 4; t++) d[t] = e[t] - p[t];
+            const int sat = quad_sum(satd_quad_partial(d, lane)) >> 1;
+            unsigned key = ok ? (((unsigned)(sat + (m == pm ? 0 : 3 * lambda)) << 4) | (unsigned)m) : 0xffffffffu;
+            key = wave_min_u32(key);
+            const int bm = key & 15;
+            cost4 += (int)(key >> 4);
+            if (lane == 0) m4[b] = (uint8_t)bm;
+            // encode the block with the winning prediction (every quad does the same work)
+            const uint32_t bp = (uint32_t)__shfl((int)pr, bm * 4 + j);
+            int v[4];
+            unpack4(bp, p);
+#pragma unroll
+            for (int t = 0; t < 4; t++) v[t] = e[t] - p[t];
+            dct4_quad(v, lane);
+            quant4_row(v, k.q_luma_intra, j);
+            const bool nz = quad_or((v[0] | v[1] | v[2] | v[3]) != 0 ? 1 : 0) != 0;
+            if (lane < 4) store_levels_scan(lv + b * 16, v, j);
+            dequant4_row(v, k.q_luma_intra, j);
+            idct4_quad(v, lane);
+#pragma unroll
+            for (int t = 0; t < 4; t++) v[t] += p[t];
+            if (lane < 4) *(uint32_t *)(bt + j * IT_STRIDE) = pack4_clip(v);
+            if (nz) nnz |= 1u << b;
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_s_waitcnt(0xc07f);
+            if (cost4 >= best16 || cost4 > thr8) break;            // intra 4x4 can no longer win (costs only grow)
+        }
+        use_i4 = cost4 < best16 && cost4 <= thr8;
+    }
+    use_i8 = i8_done && cost8 < (use_i4 ? cost4 : best16);
+    if (use_i8) use_i4 = false;
+
+    SECT(3);
     x264gpu_mb recd;
     __builtin_memset(&recd, 0, sizeof(recd));
     recd.qp = (uint8_t)qp;
@@ -344,7 +350,7 @@ __device__ void intra_mb_wave(const EncK &k, IntraLds &L, int wave, int lane, in
         recd.cbp_luma = acn ? 15 : 0;
     }
     if (lane >= 16 && lane < 24) lv[408 + lane - 16] = 0;
-    SECT(3);
+    SECT(4);
 
     // ---- chroma: mode decision + encode (lanes 0..31; plane = lane>>4) ----
     {
@@ -398,7 +404,7 @@ __device__ void intra_mb_wave(const EncK &k, IntraLds &L, int wave, int lane, in
             *(uint2 *)(ruv + (size_t)cyy * k.rs + 2 * cx0) = o;
         }
     }
-    SECT(4);
+    SECT(5);
     if (lane == 0) mbs[mbi] = recd;
 #undef SECT
 }
@@ -447,7 +453,7 @@ __global__ __launch_bounds__(1024) void k_intra(EncK k)
     if (k.dbg && lane == 0) {
         unsigned long long *d = k.dbg + ((size_t)s * 16 + wave) * 16;
         d[0] = t_wait; d[1] = t_work; d[2] = n_mb; d[3] = clock64() - t_begin;
-        for (int i = 0; i < 5; i++) d[8 + i] = L.sect[wave][i];
+        for (int i = 0; i < 6; i++) d[8 + i] = L.sect[wave][i];
     }
 }
 
