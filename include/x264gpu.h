@@ -78,6 +78,22 @@ int x264gpu_mc_luma(const uint8_t *d_planes00, size_t plane_bytes, int stride, c
 int x264gpu_mc_chroma(const uint8_t *d_nv12_00, int stride, const int32_t *d_xy, const int32_t *d_mv,
                       int n, int w, int h, uint8_t *d_out, void *stream);
 
+/* ---- input colourspace conversion to I420 -----------------------------------------
+ * Replaces the x264vfw_csp_function_t table the driver installs for an I420 encoder (/root/reference/csp.c:436-487,
+ * called at codec.c:1799): plane copies (I420, YV12 with the U/V swap), YV16 / YV24 subsampling (csp.c:39-73),
+ * YUY2 / UYVY de-interleave (csp.c:155-205) and BGR / BGRA in 20-bit fixed point for BT.601/709 x TV/PC range
+ * (csp.c:252-388), each with the optional vertical flip.  csp ids are the driver's (csp.h:30-44). */
+enum { X264GPU_CSP_MASK = 0xff, X264GPU_CSP_I420 = 1, X264GPU_CSP_YV12 = 2, X264GPU_CSP_YV16 = 3, X264GPU_CSP_YV24 = 4,
+       X264GPU_CSP_NV12 = 5, X264GPU_CSP_YUYV = 6, X264GPU_CSP_UYVY = 7, X264GPU_CSP_BGR = 8, X264GPU_CSP_BGRA = 9,
+       X264GPU_CSP_VFLIP = 0x1000 };
+/* plane offsets / strides of a frame of `csp` held in one contiguous buffer (x264vfw_img_fill, codec.c:304-379);
+ * returns the buffer size in bytes, or -1 for an unknown csp */
+long x264gpu_csp_img_fill(int csp, int width, int height, long off[3], int stride[3]);
+/* device -> device conversion; width/height even; colmatrix709 / fullrange select the RGB matrix exactly as
+ * x264vfw_csp_init(i_colmatrix == 1, b_fullrange) does.  Packed formats use d_src[0] only. */
+int x264gpu_csp_to_i420(const uint8_t *const d_src[3], const int src_stride[3], int csp, int width, int height,
+                        int colmatrix709, int fullrange, uint8_t *const d_dst[3], const int dst_stride[3], void *stream);
+
 /* ------------------------------------------------------------------------------------------------
  * Tier 2 — frame pipeline: the hot path of x264_encoder_encode for a batch of independent
  * closed-GOP streams (one launch covers `streams` frames of identical geometry).

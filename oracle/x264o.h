@@ -119,6 +119,14 @@ extern const uint8_t x264o_tc0_table[52][3];
 void x264o_deblock_luma_edge(pixel *pix, int xstride, int ystride, int lines, int alpha, int beta, int tc0, int bs);
 void x264o_deblock_chroma_edge(pixel *pix, int xstride, int ystride, int lines, int alpha, int beta, int tc0, int bs);
 
+/* ---- input colourspace conversion to I420: /root/reference/csp.c (next-row f1) ---- */
+enum { X264O_CSP_MASK = 0xff, X264O_CSP_I420 = 1, X264O_CSP_YV12 = 2, X264O_CSP_YV16 = 3, X264O_CSP_YV24 = 4, X264O_CSP_NV12 = 5,
+       X264O_CSP_YUYV = 6, X264O_CSP_UYVY = 7, X264O_CSP_BGR = 8, X264O_CSP_BGRA = 9, X264O_CSP_VFLIP = 0x1000 };   /* csp.h:30-44 */
+void x264o_csp_rgb_coefs(int colmatrix709, int fullrange, uint32_t c[12]);
+long x264o_csp_img_fill(int csp, int width, int height, long off[3], int stride[3]);
+int  x264o_csp_to_i420(uint8_t *const dst[3], const int dstride[3], const uint8_t *const src[3], const int sstride[3],
+                       int csp, int w, int h, int colmatrix709, int fullrange);
+
 #ifdef __cplusplus
 }
 #endif

@@ -225,3 +225,29 @@ def dctq8x8(enc, pred, qp, lst):
         L.x264o_dequant_8x8(d, C.addressof(t.dequant8_mf), qp)
         L.x264o_add8x8_idct8(ptr(rec, i * 64), 8, d)
     return coef, lev, rec
+
+
+# ---- input colourspace conversion (oracle/csp.c <- /root/reference/csp.c) ----
+CSP = dict(I420=1, YV12=2, YV16=3, YV24=4, NV12=5, YUYV=6, UYVY=7, BGR=8, BGRA=9, VFLIP=0x1000)
+_sig("x264o_csp_img_fill", C.c_long, [_i, _i, _i, C.POINTER(C.c_long), C.POINTER(_i)])
+_sig("x264o_csp_to_i420", _i, [C.POINTER(C.c_void_p), C.POINTER(_i), C.POINTER(C.c_void_p), C.POINTER(_i), _i, _i, _i, _i, _i])
+_sig("x264o_csp_rgb_coefs", None, [_i, _i, C.POINTER(C.c_uint32)])
+
+
+def csp_img_fill(csp, w, h):
+    off, st = (C.c_long * 3)(), (_i * 3)()
+    n = L.x264o_csp_img_fill(csp, w, h, off, st)
+    return n, list(off), list(st)
+
+
+def csp_to_i420(buf, csp, w, h, colmatrix709=0, fullrange=0):
+    """buf: one contiguous frame laid out as x264vfw_img_fill does -> tight I420 (w*h*3/2 bytes)"""
+    buf = np.ascontiguousarray(buf, np.uint8)
+    n, off, st = csp_img_fill(csp, w, h)
+    assert n == buf.size, (n, buf.size)
+    out = np.zeros(w * h * 3 // 2, np.uint8)
+    src = (C.c_void_p * 3)(*[buf.ctypes.data + o for o in off])
+    dst = (C.c_void_p * 3)(out.ctypes.data, out.ctypes.data + w * h, out.ctypes.data + w * h + (w // 2) * (h // 2))
+    rc = L.x264o_csp_to_i420(dst, (_i * 3)(w, w // 2, w // 2), src, (_i * 3)(*st), csp, w, h, colmatrix709, fullrange)
+    assert rc == 0
+    return out
