@@ -75,3 +75,62 @@ def test_small_output_buffer_is_an_error(gpu):
     assert b"output frame buffer too small" in V.H.x264vfw_shim_log(cid)
     assert D(cid, None, V.ICM_COMPRESS, V.addr(icc), 0) == V.ICERR_ERROR     # sticky b_encoder_error
     D(cid, None, V.DRV_CLOSE, 0, 0)
+
+
+@pytest.mark.parametrize("fmt", ["YUY2", "UYVY", "YV16", "YV24", "RGB24", "RGB32", "RGB32_topdown"])
+def test_icm_compress_native_colourspaces(gpu, fmt):
+    """Packed / RGB / 4:2:2 / 4:4:4 inputs (codec.c:187-231): the shell uploads the native frame and converts on the device;
+    the stream must equal the one produced from the oracle-converted I420 picture (csp.c restated in oracle/csp.c)."""
+    w, h, nfr = 96, 80, 3
+    rng = np.random.default_rng(7)
+    CSP = O.CSP
+    four, bits, height, csp = {"YUY2": (b"YUY2", 16, h, CSP["YUYV"]), "UYVY": (b"UYVY", 16, h, CSP["UYVY"]), "YV16": (b"YV16", 16, h, CSP["YV16"]),
+                               "YV24": (b"YV24", 24, h, CSP["YV24"]), "RGB24": (None, 24, h, CSP["BGR"] | CSP["VFLIP"]),
+                               "RGB32": (None, 32, h, CSP["BGRA"] | CSP["VFLIP"]), "RGB32_topdown": (None, 32, -h, CSP["BGRA"])}[fmt]
+    # smooth-ish content so the encode is meaningful: low-pass noise
+    base = rng.integers(0, 256, (nfr, O.csp_img_fill(csp, w, h)[0]), dtype=np.uint8)
+    raws = [np.ascontiguousarray(b) for b in base]
+
+    def run(frames, fourcc, bitcount, hh):
+        ico = V.ICOPEN(fccType=V.fourcc(b"vidc"))
+        cid = D(0, None, V.DRV_OPEN, 0, V.addr(ico))
+        n = D(cid, None, V.ICM_GETSTATE, 0, 0)
+        cfg = V.VfwConfig()
+        D(cid, None, V.ICM_GETSTATE, V.addr(cfg), n)
+        cfg.i_encoding_type, cfg.i_qp, cfg.extra_cmdline = 1, 30, b"--keyint 250 --colormatrix bt709 --range pc"
+        assert D(cid, None, V.ICM_SETSTATE, V.addr(cfg), n) == n
+        inb, outb = V.bmi(w, hh, fourcc if fourcc else b"\x00\x00\x00\x00"), V.BITMAPINFO()
+        inb.bmiHeader.biBitCount = bitcount
+        assert D(cid, None, V.ICM_COMPRESS_GET_FORMAT, V.addr(inb), V.addr(outb)) == V.ICERR_OK
+        assert D(cid, None, V.ICM_COMPRESS_QUERY, V.addr(inb), V.addr(outb)) == V.ICERR_OK
+        assert D(cid, None, V.ICM_COMPRESS_BEGIN, V.addr(inb), V.addr(outb)) == V.ICERR_OK, V.H.x264vfw_shim_log(cid)
+        cap = outb.bmiHeader.biSizeImage
+        buf = C.create_string_buffer(cap)
+        stream = b""
+        for f in frames:
+            flags = V.DWORD(0)
+            outb.bmiHeader.biSizeImage = cap
+            icc = V.ICCOMPRESS(lpbiOutput=C.pointer(outb.bmiHeader), lpOutput=C.cast(buf, C.c_void_p), lpbiInput=C.pointer(inb.bmiHeader),
+                               lpInput=f.ctypes.data, lpdwFlags=C.pointer(flags))
+            assert D(cid, None, V.ICM_COMPRESS, V.addr(icc), C.sizeof(icc)) == V.ICERR_OK, V.H.x264vfw_shim_log(cid)
+            stream += buf.raw[:outb.bmiHeader.biSizeImage]
+        assert D(cid, None, V.ICM_COMPRESS_END, 0, 0) == V.ICERR_OK
+        assert D(cid, None, V.DRV_CLOSE, 0, 0) == 1
+        return stream
+
+    native = run(raws, four, bits, height)
+    converted = [np.ascontiguousarray(O.csp_to_i420(r, csp, w, h, 1, 1)) for r in raws]       # bt709, pc range as configured
+    via_i420 = run(converted, b"I420", 12, h)
+    assert native == via_i420
+    assert len(O.h264_decode(native, nfr, w, h)) == nfr
+
+
+def test_unsupported_input_is_badformat(gpu):
+    ico = V.ICOPEN(fccType=V.fourcc(b"vidc"))
+    cid = D(0, None, V.DRV_OPEN, 0, V.addr(ico))
+    inb, outb = V.bmi(64, 48, b"NV12"), V.BITMAPINFO()
+    assert D(cid, None, V.ICM_COMPRESS_QUERY, V.addr(inb), 0) == V.ICERR_BADFORMAT
+    inb = V.bmi(64, 48, b"\x00\x00\x00\x00")
+    inb.bmiHeader.biBitCount = 16                                            # RGB555/565 are not driver inputs (codec.c:218-226)
+    assert D(cid, None, V.ICM_COMPRESS_GET_FORMAT, V.addr(inb), V.addr(outb)) == V.ICERR_BADFORMAT
+    D(cid, None, V.DRV_CLOSE, 0, 0)

@@ -213,9 +213,12 @@ int x264_encoder_encode(x264_t *h, x264_nal_t **pp_nal, int *pi_nal, x264_pictur
         xlog(&p, X264_LOG_ERROR, "x264_encoder_encode: input picture must be I420\n");
         return -1;
     }
+    // Zero-copy input (x264gpu_host_input_i420): the caller (the VfW shell after the device-side colourspace conversion)
+    // already placed a tight I420 picture in the encoder's device staging buffer.
+    const bool resident = pic_in->img.plane[0] == h->d_in;
     // ---- frame copy-in: three strided planes -> one tightly packed I420 buffer -> HBM (replaces x264_frame_copy_picture) ----
     uint8_t *dst = h->h_in.data();
-    for (int pl = 0; pl < 3; pl++) {
+    for (int pl = 0; pl < 3 && !resident; pl++) {
         int pw = pl ? w / 2 : w, ph = pl ? ht / 2 : ht;
         const uint8_t *src = pic_in->img.plane[pl];
         for (int y = 0; y < ph; y++, dst += pw, src += pic_in->img.i_stride[pl]) memcpy(dst, src, pw);
@@ -223,7 +226,7 @@ int x264_encoder_encode(x264_t *h, x264_nal_t **pp_nal, int *pi_nal, x264_pictur
     bool idr = h->frames_since_idr == 0 || h->frames_since_idr >= h->keyint || pic_in->i_type == X264_TYPE_IDR || pic_in->i_type == X264_TYPE_KEYFRAME;
     if (idr) { h->frames_since_idr = 0; h->frame_num = 0; }
     int st = idr ? X264GPU_SLICE_I : X264GPU_SLICE_P;
-    if (x264gpu_memcpy_h2d(h->d_in, h->h_in.data(), h->h_in.size(), nullptr) != X264GPU_OK ||
+    if ((!resident && x264gpu_memcpy_h2d(h->d_in, h->h_in.data(), h->h_in.size(), nullptr) != X264GPU_OK) ||
         x264gpu_encode_frames(h->gpu, h->d_in, st, h->d_mb, h->d_lv, nullptr) != X264GPU_OK ||
         x264gpu_memcpy_d2h(h->h_mb.data(), h->d_mb, h->h_mb.size() * sizeof(x264gpu_mb), nullptr) != X264GPU_OK ||
         x264gpu_memcpy_d2h(h->h_lv.data(), h->d_lv, h->h_lv.size() * sizeof(int16_t), nullptr) != X264GPU_OK) {
@@ -311,6 +314,10 @@ int x264host_write_headers(int width, int height, int level_idc, int log2_max_fr
     memcpy(out, v.data(), v.size());
     return (int)v.size();
 }
+
+/* device pointer of the encoder's input staging buffer: a tight I420 picture (Y w*h, U, V).  A picture whose plane[0]
+ * equals this pointer is encoded in place, without the host copy-in and upload (used by the VfW shell, vfw.cpp). */
+uint8_t *x264gpu_host_input_i420(x264_t *h) { return h ? h->d_in : nullptr; }
 
 int x264host_get_recon(x264_t *h, uint8_t *i420_out)
 {

@@ -24,7 +24,8 @@ const char *const kTunes[] = { "", "film", "animation", "grain", "stillimage", "
 const char *const kProfiles[] = { "", "baseline", "main", "high" };
 const int kLevels[] = { -1, 10, 9, 11, 12, 13, 20, 21, 22, 30, 31, 32, 40, 41, 42, 50, 51, 52, 60, 61, 62 };
 
-enum { CSP_NONE = 0, CSP_I420, CSP_YV12 };
+extern "C" uint8_t *x264gpu_host_input_i420(x264_t *h);       /* host/encoder.cpp */
+enum { CSP_NONE = 0 };                                         /* the rest are the driver's ids: X264GPU_CSP_* (csp.h:30-44) */
 
 struct CODEC {                          /* x264vfw.h:187-252, compress-side members */
     x264_t *h;
@@ -37,6 +38,8 @@ struct CODEC {                          /* x264vfw.h:187-252, compress-side memb
     uint32_t i_fps_num, i_fps_den;
     x264_picture_t conv_pic;
     int b_user_ref;
+    uint8_t *d_raw; size_t raw_cap;     /* device copy of the caller's frame in its native colourspace */
+    int colmatrix709, fullrange;        /* x264vfw_csp_init arguments (codec.c:1570-1577,1672) */
     std::string log;
 };
 
@@ -68,12 +71,24 @@ void vlog(CODEC *codec, int level, const char *fmt, ...)
     va_end(ap);
 }
 
-int get_csp(const BITMAPINFOHEADER *hdr)          /* codec.c:187-231; packed/RGB inputs are next-row f1 */
+int get_csp(const BITMAPINFOHEADER *hdr)          /* codec.c:187-231 */
 {
-    DWORD f = hdr->biCompression;
-    if (f == mmioFOURCC('I', '4', '2', '0') || f == mmioFOURCC('I', 'Y', 'U', 'V')) return CSP_I420;
-    if (f == mmioFOURCC('Y', 'V', '1', '2')) return CSP_YV12;
-    return CSP_NONE;
+    /* For YUV the bitmap is always top-down regardless of the biHeight sign */
+    switch (hdr->biCompression) {
+    case mmioFOURCC('I', '4', '2', '0'): case mmioFOURCC('I', 'Y', 'U', 'V'): return X264GPU_CSP_I420;
+    case mmioFOURCC('Y', 'V', '1', '2'): return X264GPU_CSP_YV12;
+    case mmioFOURCC('Y', 'V', '1', '6'): return X264GPU_CSP_YV16;
+    case mmioFOURCC('Y', 'V', '2', '4'): return X264GPU_CSP_YV24;
+    case mmioFOURCC('Y', 'U', 'Y', 'V'): case mmioFOURCC('Y', 'U', 'Y', '2'): return X264GPU_CSP_YUYV;
+    case mmioFOURCC('U', 'Y', 'V', 'Y'): case mmioFOURCC('H', 'D', 'Y', 'C'): return X264GPU_CSP_UYVY;
+    case BI_RGB: {
+        const int vflip = hdr->biHeight < 0 ? 0 : X264GPU_CSP_VFLIP;      /* bottom-up DIB */
+        if (hdr->biBitCount == 24) return X264GPU_CSP_BGR | vflip;
+        if (hdr->biBitCount == 32) return X264GPU_CSP_BGRA | vflip;
+        return CSP_NONE;
+    }
+    default: return CSP_NONE;        /* NV12 input belongs to an NV12 encoder (csp.c:489-491), not built */
+    }
 }
 bool supported_fourcc(DWORD f) { for (DWORD k : kFourccOut) if (k == f) return true; return false; }
 
@@ -117,6 +132,7 @@ LRESULT compress_end(CODEC *codec)
     }
     x264_picture_clean(&codec->conv_pic);
     memset(&codec->conv_pic, 0, sizeof(codec->conv_pic));
+    if (codec->d_raw) { x264gpu_free(codec->d_raw); codec->d_raw = nullptr; codec->raw_cap = 0; }
     codec->b_encoder_error = 0;
     return ICERR_OK;
 }
@@ -210,6 +226,12 @@ LRESULT compress_begin(CODEC *codec, BITMAPINFO *in, BITMAPINFO *out)
         if (name == "profile") { profile_s = value; continue; }
         if (name == "ref") codec->b_user_ref = 1;
         if (name == "quiet") { param.i_log_level = X264_LOG_NONE; continue; }
+        if (name == "range") {                                              /* OPT_RANGE (codec.c:1322-1329): auto / tv / pc */
+            int r = value == "auto" ? -1 : value == "tv" ? 0 : value == "pc" ? 1 : -2;
+            if (r == -2) { vlog(codec, X264_LOG_ERROR, "unknown range '%s'\n", value.c_str()); goto fail; }
+            param.vui.b_fullrange = r;
+            continue;
+        }
         if (name == "output" || name == "muxer" || name == "vd-hack" || name == "no-output" || name == "dts-compress") {
             vlog(codec, X264_LOG_WARNING, "not supported option: '%s'\n", a.c_str());
             continue;
@@ -222,6 +244,7 @@ LRESULT compress_begin(CODEC *codec, BITMAPINFO *in, BITMAPINFO *out)
     param.i_timebase_num = param.i_fps_den; param.i_timebase_den = param.i_fps_num;
     param.vui.b_fullrange = param.vui.b_fullrange == 1;
     if (param.vui.i_colmatrix < 0) param.vui.i_colmatrix = 2;
+    codec->colmatrix709 = param.vui.i_colmatrix == 1; codec->fullrange = param.vui.b_fullrange;      /* x264vfw_csp_init (csp.c:452-485) */
     if (x264_param_apply_profile(&param, profile_s.empty() ? nullptr : profile_s.c_str()) < 0) {
         vlog(codec, X264_LOG_ERROR, "x264_param_apply_profile failed\n");
         goto fail;
@@ -285,13 +308,31 @@ LRESULT compress(CODEC *codec, ICCOMPRESS *icc)
         if (codec->i_frame_remain != -1) codec->i_frame_remain--;
         int csp = get_csp(inhdr), w = inhdr->biWidth, h = abs(inhdr->biHeight);
         if (csp == CSP_NONE) { vlog(codec, X264_LOG_ERROR, "unknown input frame colorspace\n"); codec->b_encoder_error = 1; return ICERR_BADFORMAT; }
-        /* x264vfw_img_fill (codec.c:304-379) + i420_to_i420 / yv12 swap (csp.c:409-412): plane pointers over the caller's buffer */
-        const uint8_t *y = (const uint8_t *)icc->lpInput, *c0 = y + (size_t)w * h, *c1 = c0 + (size_t)(w / 2) * (h / 2);
-        const uint8_t *u = csp == CSP_YV12 ? c1 : c0, *v = csp == CSP_YV12 ? c0 : c1;
-        memcpy(codec->conv_pic.img.plane[0], y, (size_t)w * h);
-        memcpy(codec->conv_pic.img.plane[1], u, (size_t)(w / 2) * (h / 2));
-        memcpy(codec->conv_pic.img.plane[2], v, (size_t)(w / 2) * (h / 2));
-        i_out = encode_frame(codec, &codec->conv_pic, &pic_out, (uint8_t *)icc->lpOutput, outhdr->biSizeImage, &got_picture);
+        /* x264vfw_img_fill (codec.c:304-379) over the caller's buffer, then csp.convert[] (codec.c:1774) — on the device:
+         * the native frame is uploaded once and converted straight into the encoder's I420 staging buffer */
+        long off[3]; int st[3];
+        const long n = x264gpu_csp_img_fill(csp, w, h, off, st);
+        if (n < 0) { vlog(codec, X264_LOG_ERROR, "unknown input frame colorspace\n"); codec->b_encoder_error = 1; return ICERR_BADFORMAT; }
+        if ((size_t)n > codec->raw_cap) {
+            if (codec->d_raw) x264gpu_free(codec->d_raw);
+            codec->d_raw = nullptr; codec->raw_cap = 0;
+            if (x264gpu_malloc((void **)&codec->d_raw, (size_t)n) != X264GPU_OK) { vlog(codec, X264_LOG_ERROR, "device allocation failed\n"); codec->b_encoder_error = 1; return ICERR_MEMORY; }
+            codec->raw_cap = (size_t)n;
+        }
+        uint8_t *d_i420 = x264gpu_host_input_i420(codec->h);
+        const uint8_t *src[3] = { codec->d_raw + off[0], codec->d_raw + off[1], codec->d_raw + off[2] };
+        uint8_t *dst[3] = { d_i420, d_i420 + (size_t)w * h, d_i420 + (size_t)w * h + (size_t)(w / 2) * (h / 2) };
+        const int dst_stride[3] = { w, w / 2, w / 2 };
+        if (x264gpu_memcpy_h2d(codec->d_raw, icc->lpInput, (size_t)n, nullptr) != X264GPU_OK ||
+            x264gpu_csp_to_i420(src, st, csp, w, h, codec->colmatrix709, codec->fullrange, dst, dst_stride, nullptr) != X264GPU_OK) {
+            vlog(codec, X264_LOG_ERROR, "colorspace conversion failed\n");
+            codec->b_encoder_error = 1;
+            return ICERR_ERROR;
+        }
+        x264_picture_t pic = codec->conv_pic;                 /* header fields (pts, type) of the running picture */
+        pic.img.i_csp = X264_CSP_I420; pic.img.i_plane = 3;
+        for (int k = 0; k < 3; k++) { pic.img.plane[k] = dst[k]; pic.img.i_stride[k] = dst_stride[k]; }
+        i_out = encode_frame(codec, &pic, &pic_out, (uint8_t *)icc->lpOutput, outhdr->biSizeImage, &got_picture);
         codec->conv_pic.i_pts++;
     } else
         i_out = encode_frame(codec, nullptr, &pic_out, (uint8_t *)icc->lpOutput, outhdr->biSizeImage, &got_picture);
@@ -314,6 +355,7 @@ extern "C" LRESULT DriverProc(DWORD_PTR dwDriverId, HDRVR hDriver, UINT uMsg, LP
         codec = new (std::nothrow) CODEC();
         if (!codec) { if (icopen) icopen->dwError = ICERR_MEMORY; return 0; }
         codec->h = nullptr; codec->b_encoder_error = 0; codec->prev_lpbiOutput = nullptr; codec->prev_output_biSizeImage = 0;
+        codec->d_raw = nullptr; codec->raw_cap = 0; codec->colmatrix709 = 0; codec->fullrange = 0;
         memset(&codec->conv_pic, 0, sizeof(codec->conv_pic));
         config_defaults(&codec->config);
         codec->i_frame_total = 0; codec->i_fps_num = codec->i_fps_den = 0;
