@@ -93,6 +93,11 @@ long x264gpu_csp_img_fill(int csp, int width, int height, long off[3], int strid
  * x264vfw_csp_init(i_colmatrix == 1, b_fullrange) does.  Packed formats use d_src[0] only. */
 int x264gpu_csp_to_i420(const uint8_t *const d_src[3], const int src_stride[3], int csp, int width, int height,
                         int colmatrix709, int fullrange, uint8_t *const d_dst[3], const int dst_stride[3], void *stream);
+/* the same for `frames` pictures of identical geometry laid out src_frame_bytes / dst_frame_bytes apart: one launch per
+ * plane group instead of one per picture (a 1080p picture is ~3 us of HBM time, launch overhead would dominate) */
+int x264gpu_csp_to_i420_batch(const uint8_t *const d_src[3], const int src_stride[3], size_t src_frame_bytes, int csp, int width,
+                              int height, int colmatrix709, int fullrange, uint8_t *const d_dst[3], const int dst_stride[3],
+                              size_t dst_frame_bytes, int frames, void *stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Tier 2 — frame pipeline: the hot path of x264_encoder_encode for a batch of independent

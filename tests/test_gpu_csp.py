@@ -55,3 +55,27 @@ def test_csp_rejects_unsupported(gpu):
     s = (C.c_int * 3)(16, 8, 8)
     assert lib.x264gpu_csp_to_i420(z, s, CSP["NV12"], 16, 8, 0, 0, z, s, None) != 0          # another encoder colourspace
     assert lib.x264gpu_csp_to_i420(z, s, CSP["I420"], 15, 8, 0, 0, z, s, None) != 0          # odd width
+
+
+@pytest.mark.parametrize("name", ["BGRA", "YUYV", "YV24"])
+def test_csp_batch(gpu, name):
+    """`frames` pictures per launch == the same pictures converted one by one"""
+    import torch
+    from x264vfw_amd import lib
+    w, h, nf = 66, 34, 5
+    csp = CSP[name] | CSP["VFLIP"]
+    n = O.csp_img_fill(csp, w, h)[0]
+    rng = np.random.default_rng(11)
+    buf = rng.integers(0, 256, (nf, n), dtype=np.uint8)
+    off, st = (C.c_long * 3)(), (C.c_int * 3)()
+    lib.x264gpu_csp_img_fill(csp, w, h, off, st)
+    d_src = torch.from_numpy(buf).cuda()
+    osz = w * h * 3 // 2
+    d_dst = torch.zeros((nf, osz), dtype=torch.uint8, device="cuda")
+    src = (C.c_void_p * 3)(*[d_src.data_ptr() + o for o in off])
+    dst = (C.c_void_p * 3)(d_dst.data_ptr(), d_dst.data_ptr() + w * h, d_dst.data_ptr() + w * h + (w // 2) * (h // 2))
+    lib.check(lib.x264gpu_csp_to_i420_batch(src, st, n, csp, w, h, 0, 1, dst, (C.c_int * 3)(w, w // 2, w // 2), osz, nf, None), "csp batch")
+    torch.cuda.synchronize()
+    got = d_dst.cpu().numpy()
+    for i in range(nf):
+        np.testing.assert_array_equal(got[i], O.csp_to_i420(buf[i], csp, w, h, 0, 1), err_msg=f"frame {i}")

@@ -14,6 +14,7 @@ struct CspArgs {
     const uint8_t *src[3]; long sstride[3];      // source planes (already flip-adjusted: first row + signed pitch)
     uint8_t *dst[3]; int dstride[3];
     int w, h;                                    // luma size (even)
+    long sframe, dframe;                         // byte distance between consecutive frames of a batch (blockIdx.z)
     uint32_t c[12];                              // RGB coefficients (oracle x264o_csp_rgb_coefs)
 };
 
@@ -26,10 +27,12 @@ __device__ __forceinline__ uint32_t avg4(uint32_t a, uint32_t b) { return (a | b
 
 // ---- plane copy / 2:1 vertical / 2:1 both (csp.c:28-74): thread = 16 output bytes of one row ----
 template <int MODE>
-__global__ __launch_bounds__(256) void k_csp_plane(uint8_t *__restrict__ dst, int ds, const uint8_t *__restrict__ src, long ss, int w, int h)
+__global__ __launch_bounds__(256) void k_csp_plane(uint8_t *__restrict__ dst, int ds, const uint8_t *__restrict__ src, long ss, int w, int h,
+                                                   long sframe, long dframe)
 {
     const int x = (blockIdx.x * 256 + threadIdx.x) * 16, y = blockIdx.y;
     if (x >= w) return;
+    dst += (long)blockIdx.z * dframe; src += (long)blockIdx.z * sframe;
     uint8_t *d = dst + (long)y * ds + x;
     const uint8_t *s = src + (long)y * (MODE == 0 ? 1 : 2) * ss + (MODE == 2 ? 2 * x : x);
     if (x + 16 <= w) {
@@ -65,9 +68,10 @@ __global__ __launch_bounds__(256) void k_csp_yuyv(CspArgs a)
 {
     const int x = (blockIdx.x * 256 + threadIdx.x) * 8, r = blockIdx.y * 2;
     if (x >= a.w) return;
-    const uint8_t *s0 = a.src[0] + (long)r * a.sstride[0] + 2 * x, *s1 = s0 + a.sstride[0];
-    uint8_t *y0 = a.dst[0] + (long)r * a.dstride[0] + x, *y1 = y0 + a.dstride[0];
-    uint8_t *u = a.dst[1] + (long)(r >> 1) * a.dstride[1] + (x >> 1), *v = a.dst[2] + (long)(r >> 1) * a.dstride[2] + (x >> 1);
+    const long fs = (long)blockIdx.z * a.sframe, fd = (long)blockIdx.z * a.dframe;
+    const uint8_t *s0 = a.src[0] + fs + (long)r * a.sstride[0] + 2 * x, *s1 = s0 + a.sstride[0];
+    uint8_t *y0 = a.dst[0] + fd + (long)r * a.dstride[0] + x, *y1 = y0 + a.dstride[0];
+    uint8_t *u = a.dst[1] + fd + (long)(r >> 1) * a.dstride[1] + (x >> 1), *v = a.dst[2] + fd + (long)(r >> 1) * a.dstride[2] + (x >> 1);
     if (x + 8 <= a.w) {
         uint32_t p0[4], p1[4];
 #pragma unroll
@@ -101,9 +105,10 @@ __global__ __launch_bounds__(256) void k_csp_bgr(CspArgs a)
 {
     const int x = (blockIdx.x * 256 + threadIdx.x) * 8, r = blockIdx.y * 2;
     if (x >= a.w) return;
-    const uint8_t *s0 = a.src[0] + (long)r * a.sstride[0] + (long)x * STEP, *s1 = s0 + a.sstride[0];
-    uint8_t *y0 = a.dst[0] + (long)r * a.dstride[0] + x, *y1 = y0 + a.dstride[0];
-    uint8_t *u = a.dst[1] + (long)(r >> 1) * a.dstride[1] + (x >> 1), *v = a.dst[2] + (long)(r >> 1) * a.dstride[2] + (x >> 1);
+    const long fs = (long)blockIdx.z * a.sframe, fd = (long)blockIdx.z * a.dframe;
+    const uint8_t *s0 = a.src[0] + fs + (long)r * a.sstride[0] + (long)x * STEP, *s1 = s0 + a.sstride[0];
+    uint8_t *y0 = a.dst[0] + fd + (long)r * a.dstride[0] + x, *y1 = y0 + a.dstride[0];
+    uint8_t *u = a.dst[1] + fd + (long)(r >> 1) * a.dstride[1] + (x >> 1), *v = a.dst[2] + fd + (long)(r >> 1) * a.dstride[2] + (x >> 1);
     const int n = min(8, a.w - x);
     uint32_t w0[8] = { 0, 0, 0, 0, 0, 0, 0, 0 }, w1[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };      // up to 32 source bytes per row
     if (n == 8) {
@@ -155,9 +160,9 @@ void rgb_coefs(int colmatrix709, int fullrange, uint32_t c[12])
 }
 
 template <int MODE>
-void launch_plane(uint8_t *dst, int ds, const uint8_t *src, long ss, int w, int h, hipStream_t st)
+void launch_plane(uint8_t *dst, int ds, const uint8_t *src, long ss, int w, int h, long sframe, long dframe, int frames, hipStream_t st)
 {
-    hipLaunchKernelGGL(k_csp_plane<MODE>, dim3((w + 4095) / 4096, h), dim3(256), 0, st, dst, ds, src, ss, w, h);
+    hipLaunchKernelGGL(k_csp_plane<MODE>, dim3((w + 4095) / 4096, h, frames), dim3(256), 0, st, dst, ds, src, ss, w, h, sframe, dframe);
 }
 
 }  // namespace
@@ -190,9 +195,12 @@ long x264gpu_csp_img_fill(int csp, int width, int height, long off[3], int strid
     }
 }
 
-int x264gpu_csp_to_i420(const uint8_t *const d_src[3], const int src_stride[3], int csp, int width, int height, int colmatrix709,
-                        int fullrange, uint8_t *const d_dst[3], const int dst_stride[3], void *stream)
+int x264gpu_csp_to_i420_batch(const uint8_t *const d_src[3], const int src_stride[3], size_t src_frame_bytes, int csp, int width, int height,
+                              int colmatrix709, int fullrange, uint8_t *const d_dst[3], const int dst_stride[3], size_t dst_frame_bytes,
+                              int frames, void *stream)
 {
+    ARG_TRY(frames >= 1 && frames <= 65535);
+    const long sframe = (long)src_frame_bytes, dframe = (long)dst_frame_bytes;
     ARG_TRY(d_src && src_stride && d_dst && dst_stride && d_src[0] && d_dst[0] && d_dst[1] && d_dst[2]);
     ARG_TRY(width > 0 && height > 0 && !(width & 1) && !(height & 1));
     const int id = csp & X264GPU_CSP_MASK, flip = (csp & X264GPU_CSP_VFLIP) != 0;
@@ -202,15 +210,15 @@ int x264gpu_csp_to_i420(const uint8_t *const d_src[3], const int src_stride[3], 
     case X264GPU_CSP_I420: case X264GPU_CSP_YV12: case X264GPU_CSP_YV16: case X264GPU_CSP_YV24: {
         ARG_TRY(d_src[1] && d_src[2]);
         const int swap = id != X264GPU_CSP_I420, vs = (id == X264GPU_CSP_YV16 || id == X264GPU_CSP_YV24) ? 2 : 1;
-        launch_plane<0>(d_dst[0], dst_stride[0], flip ? d_src[0] + (long)(h - 1) * src_stride[0] : d_src[0], flip ? -(long)src_stride[0] : src_stride[0], w, h, st);
+        launch_plane<0>(d_dst[0], dst_stride[0], flip ? d_src[0] + (long)(h - 1) * src_stride[0] : d_src[0], flip ? -(long)src_stride[0] : src_stride[0], w, h, sframe, dframe, frames, st);
         for (int p = 1; p <= 2; p++) {
             uint8_t *d = d_dst[swap ? 3 - p : p];
             const int ds = dst_stride[swap ? 3 - p : p];
             const long ss = flip ? -(long)src_stride[p] : src_stride[p];
             const uint8_t *s = flip ? d_src[p] + (long)(vs * ch - 1) * src_stride[p] : d_src[p];
-            if (id == X264GPU_CSP_YV16) launch_plane<1>(d, ds, s, ss, cw, ch, st);
-            else if (id == X264GPU_CSP_YV24) launch_plane<2>(d, ds, s, ss, cw, ch, st);
-            else launch_plane<0>(d, ds, s, ss, cw, ch, st);
+            if (id == X264GPU_CSP_YV16) launch_plane<1>(d, ds, s, ss, cw, ch, sframe, dframe, frames, st);
+            else if (id == X264GPU_CSP_YV24) launch_plane<2>(d, ds, s, ss, cw, ch, sframe, dframe, frames, st);
+            else launch_plane<0>(d, ds, s, ss, cw, ch, sframe, dframe, frames, st);
         }
         break;
     }
@@ -219,9 +227,9 @@ int x264gpu_csp_to_i420(const uint8_t *const d_src[3], const int src_stride[3], 
         a.src[0] = flip ? d_src[0] + (long)(h - 1) * src_stride[0] : d_src[0];
         a.sstride[0] = flip ? -(long)src_stride[0] : src_stride[0];
         for (int p = 0; p < 3; p++) { a.dst[p] = d_dst[p]; a.dstride[p] = dst_stride[p]; }
-        a.w = w; a.h = h;
+        a.w = w; a.h = h; a.sframe = sframe; a.dframe = dframe;
         rgb_coefs(colmatrix709, fullrange, a.c);
-        const dim3 grid((w + 2047) / 2048, ch), blk(256);
+        const dim3 grid((w + 2047) / 2048, ch, frames), blk(256);
         if (id == X264GPU_CSP_YUYV) hipLaunchKernelGGL(k_csp_yuyv<false>, grid, blk, 0, st, a);
         else if (id == X264GPU_CSP_UYVY) hipLaunchKernelGGL(k_csp_yuyv<true>, grid, blk, 0, st, a);
         else if (id == X264GPU_CSP_BGR) hipLaunchKernelGGL(k_csp_bgr<3>, grid, blk, 0, st, a);
@@ -233,6 +241,12 @@ int x264gpu_csp_to_i420(const uint8_t *const d_src[3], const int src_stride[3], 
     }
     HIP_TRY(hipGetLastError());
     return X264GPU_OK;
+}
+
+int x264gpu_csp_to_i420(const uint8_t *const d_src[3], const int src_stride[3], int csp, int width, int height, int colmatrix709,
+                        int fullrange, uint8_t *const d_dst[3], const int dst_stride[3], void *stream)
+{
+    return x264gpu_csp_to_i420_batch(d_src, src_stride, 0, csp, width, height, colmatrix709, fullrange, d_dst, dst_stride, 0, 1, stream);
 }
 
 }  // extern "C"

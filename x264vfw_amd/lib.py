@@ -69,6 +69,7 @@ _SIGS = {
     "x264gpu_mc_chroma": (_i, [_vp, _i, _vp, _vp, _i, _i, _i, _vp, _vp]),
     "x264gpu_csp_img_fill": (C.c_long, [_i, _i, _i, C.POINTER(C.c_long), C.POINTER(_i)]),
     "x264gpu_csp_to_i420": (_i, [C.POINTER(_vp), C.POINTER(_i), _i, _i, _i, _i, _i, C.POINTER(_vp), C.POINTER(_i), _vp]),
+    "x264gpu_csp_to_i420_batch": (_i, [C.POINTER(_vp), C.POINTER(_i), _sz, _i, _i, _i, _i, _i, C.POINTER(_vp), C.POINTER(_i), _sz, _i, _vp]),
     "x264gpu_encoder_create": (_i, [C.POINTER(_vp), C.POINTER(Config)]),
     "x264gpu_encoder_destroy": (None, [_vp]),
     "x264gpu_encoder_mb_count": (_i, [_vp]),
