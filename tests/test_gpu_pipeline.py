@@ -85,3 +85,40 @@ def test_pipeline_multistream(gpu):
         for s in range(S):
             o_mb, o_lv = ogs[s].encode(seqs[s][i], st)
             compare(f"stream {s} frame {i}", (w + 15) // 16, g_mb[s], o_mb, g_lv[s], o_lv, gg.recon(s), ogs[s].recon())
+
+
+@pytest.mark.parametrize("w,h,nfr,kw", [
+    (1280, 720, 3, dict(dct8x8=1, partitions=7, refs=3)),        # BASELINE.json configs[1]: 720p, medium toolset, bit-exact
+    (1920, 1080, 2, dict(dct8x8=1, partitions=7, refs=3)),       # configs[2] geometry: 1088 coded rows, cropped output
+])
+def test_pipeline_bitexact_full_size(gpu, w, h, nfr, kw):
+    """the headline geometries against the oracle (a few frames: the CPU oracle runs ~3 frames/s at 1080p)"""
+    from gpu_enc import GpuEncoder
+    frames = synth_frames(w, h, nfr, seed=w + h)
+    cfg = O.default_config(w, h, **kw)
+    og, gg = O.OracleEncoder(cfg), GpuEncoder(cfg)
+    mbw = (w + 15) // 16
+    for i, f in enumerate(frames):
+        st = 2 if i == 0 else 0
+        o_mb, o_lv = og.encode(f, st)
+        g_mb, g_lv = gg.encode([f], st)
+        compare(f"{w}x{h} frame {i}", mbw, g_mb[0], o_mb, g_lv[0], o_lv, gg.recon(0), og.recon())
+    og.close(); gg.close()
+
+
+def test_full_size_closed_loop_properties(gpu):
+    """1080p, many streams in lock-step: size-independent properties instead of the (slow) oracle —
+    every stream of a batch fed the same frames produces identical records/levels/recon (no cross-stream leakage),
+    and the reconstruction stays close to the source (PSNR) for every frame of a short GOP."""
+    from gpu_enc import GpuEncoder
+    from synth import psnr
+    w, h, S, nfr = 1920, 1080, 4, 4
+    frames = synth_frames(w, h, nfr, seed=77)
+    gg = GpuEncoder(O.default_config(w, h, streams=S, dct8x8=1, partitions=7, refs=3))
+    for i, f in enumerate(frames):
+        mb, lv = gg.encode([f] * S, 2 if i == 0 else 0)
+        for s in range(1, S):
+            assert np.array_equal(mb[s], mb[0]) and np.array_equal(lv[s], lv[0])
+            assert np.array_equal(gg.recon(s), gg.recon(0))
+        assert psnr(gg.recon(0)[:w * h], f[:w * h]) > 36.0
+    gg.close()
