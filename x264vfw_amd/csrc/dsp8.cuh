@@ -13,6 +13,21 @@ namespace x264gpu {
 
 struct Q8 { int mf[6], bias[6], dq[6], qp; };
 
+// 8-sample rows without pointer arithmetic on the register arrays (keeps them out of promoted-alloca LDS)
+__device__ __forceinline__ void unpack8(uint32_t lo, uint32_t hi, int v[8])
+{
+    v[0] = lo & 0xff; v[1] = (lo >> 8) & 0xff; v[2] = (lo >> 16) & 0xff; v[3] = lo >> 24;
+    v[4] = hi & 0xff; v[5] = (hi >> 8) & 0xff; v[6] = (hi >> 16) & 0xff; v[7] = hi >> 24;
+}
+__device__ __forceinline__ uint32_t pack4_clip8lo(const int v[8])
+{
+    return (uint32_t)clip_u8(v[0]) | ((uint32_t)clip_u8(v[1]) << 8) | ((uint32_t)clip_u8(v[2]) << 16) | ((uint32_t)clip_u8(v[3]) << 24);
+}
+__device__ __forceinline__ uint32_t pack4_clip8hi(const int v[8])
+{
+    return (uint32_t)clip_u8(v[4]) | ((uint32_t)clip_u8(v[5]) << 8) | ((uint32_t)clip_u8(v[6]) << 16) | ((uint32_t)clip_u8(v[7]) << 24);
+}
+
 __device__ __forceinline__ void fwd8_1d(int s[8])
 {
     const int s07 = s[0] + s[7], s16 = s[1] + s[6], s25 = s[2] + s[5], s34 = s[3] + s[4];
@@ -44,20 +59,27 @@ __device__ __forceinline__ int xor4(int v)
     int r = __builtin_amdgcn_update_dpp(0, v, 0x104, 0xf, 0x5, false);      // row_shl:4 -> lane i takes lane i+4
     return __builtin_amdgcn_update_dpp(r, v, 0x114, 0xf, 0xa, false);       // row_shr:4 -> lane i takes lane i-4
 }
-// (lane r, reg c) -> (lane c, reg r) within each group of 8 lanes
+// (lane r, reg c) -> (lane c, reg r) within each group of 8 lanes: three exchange stages.  The stage stride is a
+// template parameter so every register index is a compile-time constant (a runtime-indexed v[] would be demoted to
+// an LDS-backed array by the compiler, which is what the first version of this routine silently cost).
+template <int S>
+__device__ __forceinline__ void transpose8_stage(int v[8], int lane)
+{
+    const bool hi = lane & S;
+#pragma unroll
+    for (int r = 0; r < 8; r++) {
+        if (r & S) continue;
+        const int send = hi ? v[r] : v[r | S];
+        const int recv = S == 1 ? dpp<DPP_XOR1>(send) : S == 2 ? dpp<DPP_XOR2>(send) : xor4(send);
+        v[r] = hi ? recv : v[r];
+        v[r | S] = hi ? v[r | S] : recv;
+    }
+}
 __device__ __forceinline__ void transpose8(int v[8], int lane)
 {
-#pragma unroll
-    for (int s = 1; s < 8; s <<= 1) {
-        const bool hi = lane & s;
-#pragma unroll
-        for (int r = 0; r < 8; r++) {
-            if (r & s) continue;
-            const int send = hi ? v[r] : v[r | s];
-            const int recv = s == 1 ? dpp<DPP_XOR1>(send) : s == 2 ? dpp<DPP_XOR2>(send) : xor4(send);
-            if (hi) v[r] = recv; else v[r | s] = recv;
-        }
-    }
+    transpose8_stage<1>(v, lane);
+    transpose8_stage<2>(v, lane);
+    transpose8_stage<4>(v, lane);
 }
 __device__ __forceinline__ int class8(int r, int c)
 {

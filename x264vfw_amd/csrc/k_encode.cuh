@@ -66,7 +66,7 @@ __global__ __launch_bounds__(256) void k_encode_inter(EncK k)
         // ---- 8x8 transform, R8 layout: lane = (8x8 block, row) on lanes 0..31 (upper half mirrors) ----
         const int row = lane & 7, i8 = (lane >> 3) & 3;
         int e[8], p[8], v[8];
-        unpack4(elo, e); unpack4(ehi, e + 4); unpack4(plo, p); unpack4(phi, p + 4);
+        unpack8(elo, ehi, e); unpack8(plo, phi, p);
 #pragma unroll
         for (int i = 0; i < 8; i++) v[i] = e[i] - p[i];
         fwd8_1d(v); transpose8(v, lane); fwd8_1d(v); transpose8(v, lane);
@@ -114,7 +114,7 @@ __global__ __launch_bounds__(256) void k_encode_inter(EncK k)
         for (int i = 0; i < 8; i++) v[i] = ((v[i] + 32) >> 6) + p[i];
         if (lane < 32) {
             uint2 o;
-            o.x = pack4_clip(v); o.y = pack4_clip(v + 4);
+            o.x = pack4_clip8lo(v); o.y = pack4_clip8hi(v);
             *(uint2 *)(rec_plane00(k, s) + (size_t)(py + (i8 >> 1) * 8 + row) * k.rs + px + (i8 & 1) * 8) = o;
         }
     } else {

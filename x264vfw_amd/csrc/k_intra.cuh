@@ -184,7 +184,7 @@ __device__ void intra_mb_wave(const EncK &k, IntraLds &L, int wave, int lane, in
             const uint32_t plo = bm == 8 ? (uint32_t)__shfl((int)p2lo, r8) : (uint32_t)__shfl((int)p1lo, bm * 8 + r8);
             const uint32_t phi = bm == 8 ? (uint32_t)__shfl((int)p2hi, r8) : (uint32_t)__shfl((int)p1hi, bm * 8 + r8);
             int e[8], p[8], v[8];
-            unpack4(elo, e); unpack4(ehi, e + 4); unpack4(plo, p); unpack4(phi, p + 4);
+            unpack8(elo, ehi, e); unpack8(plo, phi, p);
 #pragma unroll
             for (int i = 0; i < 8; i++) v[i] = e[i] - p[i];
             fwd8_1d(v); transpose8(v, lane); fwd8_1d(v); transpose8(v, lane);
@@ -210,8 +210,8 @@ __device__ void intra_mb_wave(const EncK &k, IntraLds &L, int wave, int lane, in
 #pragma unroll
             for (int i = 0; i < 8; i++) v[i] = ((v[i] + 32) >> 6) + p[i];
             if (g == 0) {
-                *(uint32_t *)(bt + r8 * IT_STRIDE) = pack4_clip(v);
-                *(uint32_t *)(bt + r8 * IT_STRIDE + 4) = pack4_clip(v + 4);
+                *(uint32_t *)(bt + r8 * IT_STRIDE) = pack4_clip8lo(v);
+                *(uint32_t *)(bt + r8 * IT_STRIDE + 4) = pack4_clip8hi(v);
             }
         }
         __builtin_amdgcn_wave_barrier();

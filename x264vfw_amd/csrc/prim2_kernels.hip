@@ -22,7 +22,7 @@ __global__ __launch_bounds__(256) void k_dctq8x8(const uint8_t *__restrict__ enc
     uint2 pe = make_uint2(0, 0), pp = make_uint2(0, 0);
     if (valid) { pe = *(const uint2 *)(enc + (size_t)blk * 64 + row * 8); pp = *(const uint2 *)(pred + (size_t)blk * 64 + row * 8); }
     int e[8], p[8], v[8];
-    unpack4(pe.x, e); unpack4(pe.y, e + 4); unpack4(pp.x, p); unpack4(pp.y, p + 4);
+    unpack8(pe.x, pe.y, e); unpack8(pp.x, pp.y, p);
 #pragma unroll
     for (int i = 0; i < 8; i++) v[i] = e[i] - p[i];
     fwd8_1d(v); transpose8(v, lane); fwd8_1d(v); transpose8(v, lane);       // natural layout: lane = row, reg = col
@@ -45,7 +45,7 @@ __global__ __launch_bounds__(256) void k_dctq8x8(const uint8_t *__restrict__ enc
     for (int i = 0; i < 8; i++) v[i] = ((v[i] + 32) >> 6) + p[i];
     if (recon && valid) {
         uint2 o;
-        o.x = pack4_clip(v); o.y = pack4_clip(v + 4);
+        o.x = pack4_clip8lo(v); o.y = pack4_clip8hi(v);
         *(uint2 *)(recon + (size_t)blk * 64 + row * 8) = o;
     }
 }
