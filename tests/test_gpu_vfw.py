@@ -134,3 +134,49 @@ def test_unsupported_input_is_badformat(gpu):
     inb.bmiHeader.biBitCount = 16                                            # RGB555/565 are not driver inputs (codec.c:218-226)
     assert D(cid, None, V.ICM_COMPRESS_GET_FORMAT, V.addr(inb), V.addr(outb)) == V.ICERR_BADFORMAT
     D(cid, None, V.DRV_CLOSE, 0, 0)
+
+
+def test_raw_file_output(gpu, tmp_path):
+    """--output file.h264 (select_output -> raw_output, codec.c:1111-1164 / output/raw.c): frames go to the file as Annex-B,
+    ICM_COMPRESS hands the host application empty frames, and the file decodes to the same pictures as the buffer path."""
+    w, h, nfr = 96, 80, 4
+    frames = synth_frames(w, h, nfr, seed=5)
+    path = tmp_path / "out.h264"
+
+    def run(cmdline):
+        ico = V.ICOPEN(fccType=V.fourcc(b"vidc"))
+        cid = D(0, None, V.DRV_OPEN, 0, V.addr(ico))
+        n = D(cid, None, V.ICM_GETSTATE, 0, 0)
+        cfg = V.VfwConfig()
+        D(cid, None, V.ICM_GETSTATE, V.addr(cfg), n)
+        cfg.i_encoding_type, cfg.i_qp, cfg.extra_cmdline = 1, 28, cmdline
+        D(cid, None, V.ICM_SETSTATE, V.addr(cfg), n)
+        inb, outb = V.bmi(w, h, b"I420"), V.BITMAPINFO()
+        assert D(cid, None, V.ICM_COMPRESS_GET_FORMAT, V.addr(inb), V.addr(outb)) == V.ICERR_OK
+        rc = D(cid, None, V.ICM_COMPRESS_BEGIN, V.addr(inb), V.addr(outb))
+        if rc != V.ICERR_OK:
+            log = V.H.x264vfw_shim_log(cid)
+            D(cid, None, V.DRV_CLOSE, 0, 0)
+            return None, log
+        cap = outb.bmiHeader.biSizeImage
+        buf = C.create_string_buffer(cap)
+        stream, sizes = b"", []
+        for f in frames:
+            flags = V.DWORD(0)
+            outb.bmiHeader.biSizeImage = cap
+            icc = V.ICCOMPRESS(lpbiOutput=C.pointer(outb.bmiHeader), lpOutput=C.cast(buf, C.c_void_p), lpbiInput=C.pointer(inb.bmiHeader),
+                               lpInput=f.ctypes.data, lpdwFlags=C.pointer(flags))
+            assert D(cid, None, V.ICM_COMPRESS, V.addr(icc), C.sizeof(icc)) == V.ICERR_OK
+            sizes.append(outb.bmiHeader.biSizeImage)
+            stream += buf.raw[:outb.bmiHeader.biSizeImage]
+        assert D(cid, None, V.ICM_COMPRESS_END, 0, 0) == V.ICERR_OK
+        D(cid, None, V.DRV_CLOSE, 0, 0)
+        return stream, sizes
+
+    direct, sizes = run(b"--keyint 250")
+    assert all(s > 0 for s in sizes)
+    to_file, sizes = run(b"--keyint 250 --output " + str(path).encode())
+    assert to_file == b"" and sizes == [0] * nfr                             # codec.c:1708-1721: nothing reaches the VfW buffer
+    assert path.read_bytes() == direct
+    none, log = run(b"--output " + str(tmp_path / "x.mkv").encode())
+    assert none is None and b"output support" in log                         # other muxers are not built (next-row f3)

@@ -8,6 +8,7 @@
 // log window, VirtualDub hack, file muxers, decoder) are out of scope.
 #include "host.hpp"
 #include "../../include/vfw_shim.h"
+#include <ctype.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -40,6 +41,7 @@ struct CODEC {                          /* x264vfw.h:187-252, compress-side memb
     int b_user_ref;
     uint8_t *d_raw; size_t raw_cap;     /* device copy of the caller's frame in its native colourspace */
     int colmatrix709, fullrange;        /* x264vfw_csp_init arguments (codec.c:1570-1577,1672) */
+    FILE *cli_hout; int b_cli_output, b_no_output;   /* file output instead of the VfW buffer (codec.c:1111-1164,1609-1663; output/raw.c) */
     std::string log;
 };
 
@@ -133,6 +135,8 @@ LRESULT compress_end(CODEC *codec)
     x264_picture_clean(&codec->conv_pic);
     memset(&codec->conv_pic, 0, sizeof(codec->conv_pic));
     if (codec->d_raw) { x264gpu_free(codec->d_raw); codec->d_raw = nullptr; codec->raw_cap = 0; }
+    if (codec->cli_hout) { fclose(codec->cli_hout); codec->cli_hout = nullptr; }          /* raw_output.close_file (output/raw.c:60-66) */
+    codec->b_cli_output = 0;
     codec->b_encoder_error = 0;
     return ICERR_OK;
 }
@@ -186,6 +190,8 @@ LRESULT compress_begin(CODEC *codec, BITMAPINFO *in, BITMAPINFO *out)
     if (cfg->b_zerolatency) tune += tune.empty() ? "zerolatency" : ",zerolatency";
     std::vector<std::string> argv = split_cmdline(cfg->extra_cmdline);
     std::string preset_s = preset ? preset : "", profile_s = profile ? profile : "";
+    std::string out_file = "-", muxer = "auto";                                /* codec.c:1545-1546 */
+    codec->b_no_output = 0; codec->b_cli_output = 0;
     for (size_t i = 0; i + 1 < argv.size(); i++) {                          /* presets first (parse_preset_tune, codec.c:1198-1223) */
         if (argv[i] == "--preset") preset_s = argv[i + 1];
         if (argv[i] == "--tune") tune = argv[i + 1];
@@ -232,7 +238,10 @@ LRESULT compress_begin(CODEC *codec, BITMAPINFO *in, BITMAPINFO *out)
             param.vui.b_fullrange = r;
             continue;
         }
-        if (name == "output" || name == "muxer" || name == "vd-hack" || name == "no-output" || name == "dts-compress") {
+        if (name == "output") { out_file = value; continue; }                /* OPT_OUTPUT (codec.c:1261-1263) */
+        if (name == "muxer") { muxer = value; continue; }
+        if (name == "no-output") { codec->b_no_output = 1; continue; }
+        if (name == "vd-hack" || name == "dts-compress") {
             vlog(codec, X264_LOG_WARNING, "not supported option: '%s'\n", a.c_str());
             continue;
         }
@@ -258,6 +267,20 @@ LRESULT compress_begin(CODEC *codec, BITMAPINFO *in, BITMAPINFO *out)
             }
     }
     param.b_annexb = 1; param.b_repeat_headers = 1;                         /* VFW needs SPS/PPS before each keyframe */
+    if (out_file != "-") {                                                  /* select_output (codec.c:1111-1164) */
+        std::string ext = muxer;
+        if (muxer == "auto") { size_t dot = out_file.rfind('.'); ext = dot == std::string::npos ? "" : out_file.substr(dot + 1); }
+        for (char &ch : ext) ch = (char)tolower((unsigned char)ch);
+        if (ext == "mp4" || ext == "mkv" || ext == "flv" || ext == "avi") {
+            vlog(codec, X264_LOG_ERROR, "not compiled with %s output support (raw Annex-B only)\n", ext.c_str());
+            goto fail;
+        }
+        codec->b_cli_output = 1;                                            /* raw_output: Annex-B with in-band SPS/PPS */
+        if (!codec->b_no_output && !(codec->cli_hout = fopen(out_file.c_str(), "w+b"))) {
+            vlog(codec, X264_LOG_ERROR, "could not open output file: '%s'\n", out_file.c_str());
+            goto fail;
+        }
+    }
     codec->h = x264_encoder_open(&param);
     if (!codec->h) { vlog(codec, X264_LOG_ERROR, "x264_encoder_open failed\n"); goto fail; }
     x264_encoder_parameters(codec->h, &param);
@@ -282,7 +305,11 @@ int encode_frame(CODEC *codec, x264_picture_t *pic, x264_picture_t *pic_out, uin
     if (size < 0) { vlog(codec, X264_LOG_ERROR, "x264_encoder_encode failed\n"); return -1; }
     if (size) {
         *got_picture = 1;
-        if (buf) {
+        if (!codec->b_no_output && codec->b_cli_output && fwrite(nal[0].p_payload, size, 1, codec->cli_hout) != 1) {   /* raw_output.write_frame */
+            vlog(codec, X264_LOG_ERROR, "can't write frame to outfile\n");
+            return -1;
+        }
+        if (!(codec->b_no_output || codec->b_cli_output) && buf) {
             if ((DWORD)size > buf_size && codec->b_check_size) {
                 vlog(codec, X264_LOG_ERROR, "output frame buffer too small (size %d / needed %d)\n", (int)buf_size, size);
                 return -1;
@@ -356,6 +383,7 @@ extern "C" LRESULT DriverProc(DWORD_PTR dwDriverId, HDRVR hDriver, UINT uMsg, LP
         if (!codec) { if (icopen) icopen->dwError = ICERR_MEMORY; return 0; }
         codec->h = nullptr; codec->b_encoder_error = 0; codec->prev_lpbiOutput = nullptr; codec->prev_output_biSizeImage = 0;
         codec->d_raw = nullptr; codec->raw_cap = 0; codec->colmatrix709 = 0; codec->fullrange = 0;
+        codec->cli_hout = nullptr; codec->b_cli_output = 0; codec->b_no_output = 0;
         memset(&codec->conv_pic, 0, sizeof(codec->conv_pic));
         config_defaults(&codec->config);
         codec->i_frame_total = 0; codec->i_fps_num = codec->i_fps_den = 0;
