@@ -117,11 +117,7 @@ __device__ void intra_mb_wave(const EncK &k, IntraLds &L, int wave, int lane, in
         else { modes[0] = PRED16_DC_128; n = 1; }
         for (int i = 0; i < n; i++) {
             const int m = modes[i], sig = m > PRED16_P ? PRED16_DC : m;
-            int e[4], p[4], d[4];
-            unpack4(cz, e); unpack4(pred16_row4(nb, pp, m, zx, zy), p);
-#pragma unroll
-            for (int t = 0; t < 4; t++) d[t] = e[t] - p[t];
-            const int c = (wave_sum(satd_quad_partial(d, lane)) >> 1) + lambda * bs_size_ue(sig);
+            const int c = wave_sum(satd4_half(cz, pred16_row4(nb, pp, m, zx, zy), lane)) + lambda * bs_size_ue(sig);
             if (c < best16) { best16 = c; mode16 = m; }
         }
     }
@@ -239,11 +235,9 @@ __device__ void intra_mb_wave(const EncK &k, IntraLds &L, int wave, int lane, in
             const bool ok = m < 9 && pred4_mode_ok(m, avail);
             const uint32_t pr = pred4_row4(U, t4);
             const uint32_t en = (uint32_t)__shfl((int)cz, b * 4 + j);
-            int e[4], p[4], d[4];
-            unpack4(en, e); unpack4(pr, p);
-#pragma unroll
-            for (int t = 0; t < 4; t++) d[t] = e[t] - p[t];
-            const int sat = quad_sum(satd_quad_partial(d, lane)) >> 1;
+            int e[4], p[4];
+            unpack4(en, e);
+            const int sat = quad_sum(satd4_half(en, pr, lane));
             unsigned key = ok ? (((unsigned)(sat + (m == pm ? 0 : 3 * lambda)) << 4) | (unsigned)m) : 0xffffffffu;
             key = wave_min_u32(key);
             const int bm = key & 15;
@@ -381,11 +375,8 @@ __device__ void intra_mb_wave(const EncK &k, IntraLds &L, int wave, int lane, in
         int bestc = 1 << 28, bestm = 0;
         for (int i = 0; i < n; i++) {
             const int m = modes[i], sig = m > PREDC_P ? PREDC_DC : m;
-            int e[4], p[4], d[4];
-            unpack4(cenc, e); unpack4(predc_row4(cnb, pc, m, ci, j), p);
-#pragma unroll
-            for (int t = 0; t < 4; t++) d[t] = lane < 32 ? e[t] - p[t] : 0;
-            const int cst = (wave_sum(satd_quad_partial(d, lane)) >> 1) + lambda * bs_size_ue(sig);
+            const int hs = satd4_half(cenc, predc_row4(cnb, pc, m, ci, j), lane);
+            const int cst = wave_sum(lane < 32 ? hs : 0) + lambda * bs_size_ue(sig);
             if (cst < bestc) { bestc = cst; bestm = m; }
         }
         recd.chroma_mode = (uint8_t)(bestm > PREDC_P ? PREDC_DC : bestm);
