@@ -20,7 +20,9 @@ import oracle_lib as O  # noqa: E402
 from synth import synth_frames  # noqa: E402
 
 CASES = [("p176x144", 176, 144, 5, {}), ("p208x120_q30", 208, 120, 3, dict(qp_i=27, qp_p=30)),
-         ("p64x48_nodeblock", 64, 48, 3, dict(deblock=0))]
+         ("p64x48_nodeblock", 64, 48, 3, dict(deblock=0)),
+         ("p176x144_medium", 176, 144, 5, dict(refs=3, partitions=7, dct8x8=1)),
+         ("p208x120_i8x8_only", 208, 120, 3, dict(partitions=4, dct8x8=1, qp_i=24, qp_p=27))]
 
 
 def sha(a):
@@ -58,7 +60,22 @@ def prim_vectors():
     return d
 
 
+def csp_vectors():
+    """hashes of the colourspace-ingest oracle (oracle/csp.c) on seeded frames, every format x flip x matrix/range"""
+    out = {}
+    rng = np.random.default_rng(0xC59)
+    w, h = 48, 20
+    for name in ("I420", "YV12", "YV16", "YV24", "YUYV", "UYVY", "BGR", "BGRA"):
+        for flip in (0, 1):
+            csp = O.CSP[name] | (O.CSP["VFLIP"] if flip else 0)
+            buf = rng.integers(0, 256, O.csp_img_fill(csp, w, h)[0], dtype=np.uint8)
+            for mat, full in ([(0, 0)] if name not in ("BGR", "BGRA") else [(0, 0), (0, 1), (1, 0), (1, 1)]):
+                out[f"{name}_flip{flip}_m{mat}_r{full}"] = {"in": sha(buf), "out": sha(O.csp_to_i420(buf, csp, w, h, mat, full))}
+    return {"w": w, "h": h, "seed": 0xC59, "cases": out}
+
+
 if __name__ == "__main__":
+    json.dump(csp_vectors(), open(os.path.join(HERE, "oracle_csp.json"), "w"), indent=1)
     js = {name: {"w": w, "h": h, "frames": n, "cfg": kw, "per_frame": pipeline_case(w, h, n, kw)} for name, w, h, n, kw in CASES}
     json.dump(js, open(os.path.join(HERE, "oracle_pipeline.json"), "w"), indent=1)
     np.savez_compressed(os.path.join(HERE, "prim_vectors.npz"), **prim_vectors())

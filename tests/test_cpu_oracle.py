@@ -34,7 +34,7 @@ def test_prim_golden_vectors():
             np.testing.assert_array_equal(r, g[f"rec_q{qp}_l{lst}"])
 
 
-@pytest.mark.parametrize("case", ["p176x144", "p208x120_q30", "p64x48_nodeblock"])
+@pytest.mark.parametrize("case", ["p176x144", "p208x120_q30", "p64x48_nodeblock", "p176x144_medium", "p208x120_i8x8_only"])
 def test_pipeline_golden(case):
     js = json.load(open(os.path.join(GOLD, "oracle_pipeline.json")))[case]
     w, h = js["w"], js["h"]
@@ -44,6 +44,20 @@ def test_pipeline_golden(case):
         assert sha(mbs.view(np.uint8)) == exp["mb"], f"frame {i} records"
         assert sha(lv) == exp["levels"], f"frame {i} levels"
         assert sha(enc.recon()) == exp["recon"], f"frame {i} recon"
+
+
+def test_csp_golden():
+    """oracle/csp.c against the committed hashes (tests/golden/oracle_csp.json)"""
+    js = json.load(open(os.path.join(GOLD, "oracle_csp.json")))
+    rng = np.random.default_rng(js["seed"])
+    w, h = js["w"], js["h"]
+    for name in ("I420", "YV12", "YV16", "YV24", "YUYV", "UYVY", "BGR", "BGRA"):
+        for flip in (0, 1):
+            csp = O.CSP[name] | (O.CSP["VFLIP"] if flip else 0)
+            buf = rng.integers(0, 256, O.csp_img_fill(csp, w, h)[0], dtype=np.uint8)
+            for mat, full in ([(0, 0)] if name not in ("BGR", "BGRA") else [(0, 0), (0, 1), (1, 0), (1, 1)]):
+                exp = js["cases"][f"{name}_flip{flip}_m{mat}_r{full}"]
+                assert sha(buf) == exp["in"] and sha(O.csp_to_i420(buf, csp, w, h, mat, full)) == exp["out"], (name, flip, mat, full)
 
 
 def test_oracle_encoder_quality_and_monotonic_qp():
