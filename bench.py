@@ -173,7 +173,7 @@ def main():
     for g in range(G):
         cfg = Config(width=W, height=H, streams=per[g], refs=args.refs, qp_i=qp_i, qp_p=qp_p, me_range=16, subme=7, deblock=1,
                      deblock_alpha=0, deblock_beta=0, chroma_qp_offset=0, deadzone_inter=21, deadzone_intra=11,
-                     dct_decimate=1, partitions=7, dct8x8=1)
+                     dct_decimate=1, partitions=7, dct8x8=1, me_method=1)
         h = C.c_void_p()
         lib.check(lib.x264gpu_encoder_create(C.byref(h), C.byref(cfg)), "encoder_create")
         n = lib.x264gpu_encoder_mb_count(h)

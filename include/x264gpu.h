@@ -157,6 +157,7 @@ typedef struct x264gpu_config {
                                * same bits 1-2 unless bit8 is set, then bit9 = i4x4 and bit10 = i8x8 (x264 keeps separate
                                * analyse.intra / analyse.inter masks) */
     int dct8x8;               /* --8x8dct: adaptive 8x8 luma transform (High profile) */
+    int me_method;            /* --me: 0 dia (radius-1 diamond), 1 hex (hexagon + square refine); x264's X264_ME_DIA / X264_ME_HEX */
 } x264gpu_config;
 
 int  x264gpu_encoder_create(x264gpu_encoder **enc, const x264gpu_config *cfg);

@@ -306,6 +306,21 @@ static me_result me_search_block(x264o_encoder *e, int mbx, int mby, int ox, int
         int c = FPEL_COST(cx, cy);
         if (c < bcost) { bcost = c; bmx = cx; bmy = cy; }
     }
+    if (e->cfg.me_method == 0) {
+        /* X264_ME_DIA ([x264-upstream] encoder/me.c): radius-1 diamond, up to merange steps; order (0,-1) (0,1) (-1,0) (1,0),
+         * strictly-better wins, the centre wins ties; no square refine afterwards */
+        static const int8_t dia1[4][2] = { { 0, -1 }, { 0, 1 }, { -1, 0 }, { 1, 0 } };
+        int i = e->cfg.me_range;
+        do {
+            int best = -1;
+            for (int k = 0; k < 4; k++) {
+                int c = FPEL_COST(bmx + dia1[k][0], bmy + dia1[k][1]);
+                if (c < bcost) { bcost = c; best = k; }
+            }
+            if (best < 0) break;
+            bmx += dia1[best][0]; bmy += dia1[best][1];
+        } while (--i && bmx >= fmin[0] && bmx <= fmax[0] && bmy >= fmin[1] && bmy <= fmax[1]);
+    } else
     /* hexagon search (radius 2), then 3x3 square refine; first-best wins ties, centre wins over all */
     {
         int key = bcost << 3;

@@ -14,9 +14,9 @@ pytestmark = pytest.mark.gpu
 H = HL.H
 
 
-def open_encoder(w, h, opts, profile=b"baseline"):
+def open_encoder(w, h, opts, profile=b"baseline", preset=b"medium"):
     p = HL.Param()
-    assert H.x264_param_default_preset(C.byref(p), b"medium", None) == 0
+    assert H.x264_param_default_preset(C.byref(p), preset, None) == 0
     p.i_width, p.i_height, p.i_csp = w, h, HL.X264_CSP_I420
     p.i_fps_num, p.i_fps_den = 25, 1
     p.i_log_level = -1
@@ -24,7 +24,7 @@ def open_encoder(w, h, opts, profile=b"baseline"):
         assert H.x264_param_parse(C.byref(p), k.encode(), None if v is None else str(v).encode()) == 0, k
     p.b_vfr_input = 0
     p.b_annexb, p.b_repeat_headers = 1, 1                              # VfW mode (codec.c:1611-1615)
-    assert H.x264_param_apply_profile(C.byref(p), profile) == 0
+    assert H.x264_param_apply_profile(C.byref(p), profile) == 0        # profile None = no restriction
     h_ = H.x264_encoder_open_157(C.byref(p))
     assert h_, "x264_encoder_open failed"
     eff = HL.Param()
@@ -84,6 +84,32 @@ def test_encode_api_closed_loop(gpu, w, h, opts):
     assert len(dec) == nfr
     for i in range(nfr):
         np.testing.assert_array_equal(dec[i], recons[i], err_msg=f"decoded picture {i} != encoder reconstruction")
+
+
+def test_preset_ultrafast_is_fully_covered(gpu):
+    """preset ultrafast (config.c:1460-1466): every tool x264 uses there exists in this path — me dia, subme 0, ref 1,
+    no partitions, no 8x8dct, CAVLC, no deblock, no B-frames — so the effective parameters equal the requested ones and the
+    stream equals the one entropy-coded from the oracle's records."""
+    w, h, nfr, qp = 352, 288, 5, 26
+    frames = synth_frames(w, h, nfr, seed=352)
+    h_, eff = open_encoder(w, h, {"qp": qp, "keyint": 250}, None, b"ultrafast")
+    assert (eff.analyse.i_me_method, eff.analyse.i_subpel_refine, eff.i_frame_reference, eff.b_cabac, eff.i_bframe) == (0, 0, 1, 0, 0)
+    assert (eff.analyse.b_transform_8x8, eff.b_deblocking_filter, eff.analyse.inter & 0x10) == (0, 0, 0)
+    stream, info, recons = encode_all(h_, w, h, frames)
+    H.x264_encoder_close(h_)
+    qp_i = max(1, int(qp - 6.0 * np.log2(1.4) + 0.5))
+    enc = O.OracleEncoder(O.default_config(w, h, qp_i=qp_i, qp_p=qp, partitions=0x100, refs=1, me_method=0, subme=0, deblock=0))
+    ref = b""
+    for i, f in enumerate(frames):
+        mbs, lv = enc.encode(f, 2 if i == 0 else 0)
+        ref += HL.write_slice(22, 18, 2 if i == 0 else 0, qp_i if i == 0 else qp, qp, i, 8, int(i == 0), 0, 1, mbs, lv)[0]
+        np.testing.assert_array_equal(recons[i], enc.recon())
+    import re
+    nals = lambda b: [n for n in re.split(b"\x00\x00\x00\x01|\x00\x00\x01", b) if n and (n[0] & 31) in (1, 5)]
+    assert nals(stream) == nals(ref)
+    dec = O.h264_decode(stream, nfr, w, h)
+    for i in range(nfr):
+        np.testing.assert_array_equal(dec[i], recons[i])
 
 
 def test_bitstream_equals_oracle_path(gpu):

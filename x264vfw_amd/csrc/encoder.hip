@@ -71,6 +71,7 @@ int x264gpu_encoder_create(x264gpu_encoder **out, const x264gpu_config *cfg)
     ARG_TRY(cfg->width >= 16 && cfg->height >= 16 && !(cfg->width & 1) && !(cfg->height & 1) && cfg->streams >= 1);
     ARG_TRY(cfg->qp_i >= 0 && cfg->qp_i <= 51 && cfg->qp_p >= 0 && cfg->qp_p <= 51 && cfg->refs >= 1 && cfg->refs <= 4);
     ARG_TRY(cfg->width <= 4096 && cfg->height <= 2304 && cfg->me_range >= 4 && cfg->me_range <= 16);
+    ARG_TRY(cfg->me_method == 0 || cfg->me_method == 1);
     x264gpu_encoder *e = new (std::nothrow) x264gpu_encoder();
     if (!e) return set_err(X264GPU_ENOMEM, "encoder", hipSuccess);
     e->cfg = *cfg;
@@ -87,7 +88,7 @@ int x264gpu_encoder_create(x264gpu_encoder **out, const x264gpu_config *cfg)
     k.luma_bytes = 4 * k.plane_bytes;
     k.cplane_bytes = (size_t)k.rs * (k.ch / 2 + 2 * CPAD);
     k.me_range = cfg->me_range; k.subme = cfg->subme; k.dct_decimate = cfg->dct_decimate;
-    k.partitions = cfg->partitions; k.chroma_qp_offset = cfg->chroma_qp_offset; k.dct8x8 = cfg->dct8x8;
+    k.partitions = cfg->partitions; k.chroma_qp_offset = cfg->chroma_qp_offset; k.dct8x8 = cfg->dct8x8; k.me_method = cfg->me_method;
     k.alpha_off = cfg->deblock_alpha * 2; k.beta_off = cfg->deblock_beta * 2;
     const size_t S = (size_t)cfg->streams;
     hipError_t er = hipSuccess;

@@ -163,7 +163,7 @@ struct PartCtx {
     const uint8_t *p00; size_t pb; int rs;     // half-pel planes
     int px, py, zx, zy; uint32_t cz;           // macroblock position, lane position, lane's 4 source pixels
     int fmin0, fmax0, fmin1, fmax1, smin0, smax0, smin1, smax1;
-    int me_range, hp_it, qp_it, lane;
+    int me_range, me_method, hp_it, qp_it, lane;
     uint32_t *sub;                             // LDS sub-pel neighbourhood buffer (SUB_DWORDS)
 };
 __device__ __forceinline__ int part_sum(int v, int shape)
@@ -185,34 +185,54 @@ __device__ __forceinline__ int pc_fpel_cost(const PartCtx &c, int fx, int fy, in
 template <int M>
 __device__ int search_shape(const PartCtx &c, int shape, int c0x, int c0y, int &out_mx, int &out_my)
 {
-    int bx = c0x, by = c0y;
-    unsigned key = (unsigned)pc_fpel_cost(c, bx, by, shape) << 3;
-    for (int i = 1; i <= 6; i++) key = min(key, ((unsigned)pc_fpel_cost(c, bx + hex_dx(i), by + hex_dy(i), shape) << 3) | (unsigned)(i + 1));
-    bool running = (key & 7) != 0;
-    int dir = running ? (int)(key & 7) - 2 : 0;
-    if (running) { bx += hex_dx(dir + 1); by += hex_dy(dir + 1); }
-    for (int it = (c.me_range >> 1) - 1; it > 0; it--) {
-        if (!__any(running)) break;
-        running = running && bx >= c.fmin0 && bx <= c.fmax0 && by >= c.fmin1 && by <= c.fmax1;
-        unsigned k2 = key & ~7u;
-        for (int t = 0; t < 3; t++) k2 = min(k2, ((unsigned)pc_fpel_cost(c, bx + hex_dx(dir + t), by + hex_dy(dir + t), shape) << 3) | (unsigned)(t + 1));
-        if (running) {
-            key = k2;
-            if (!(key & 7)) running = false;
-            else {
-                dir += (int)(key & 7) - 2;
-                dir = dir < 0 ? 5 : dir > 5 ? 0 : dir;
-                bx += hex_dx(dir + 1); by += hex_dy(dir + 1);
+    int bx = c0x, by = c0y, bcost;
+    if (c.me_method == 0) {
+        // X264_ME_DIA: radius-1 diamond (0,-1) (0,1) (-1,0) (1,0), up to merange steps, centre wins ties, no square refine
+        bcost = pc_fpel_cost(c, bx, by, shape);
+        bool running = true;
+        for (int it = c.me_range; it > 0; it--) {
+            if (!__any(running)) break;
+            unsigned kk = 0xffffffffu;
+            for (int q = 0; q < 4; q++)
+                kk = min(kk, ((unsigned)pc_fpel_cost(c, bx + (q == 2 ? -1 : q == 3 ? 1 : 0), by + (q == 0 ? -1 : q == 1 ? 1 : 0), shape) << 2) | (unsigned)q);
+            if (running) {
+                if ((int)(kk >> 2) < bcost) {
+                    const int q = kk & 3;
+                    bcost = (int)(kk >> 2);
+                    bx += q == 2 ? -1 : q == 3 ? 1 : 0; by += q == 0 ? -1 : q == 1 ? 1 : 0;
+                    running = bx >= c.fmin0 && bx <= c.fmax0 && by >= c.fmin1 && by <= c.fmax1;
+                } else running = false;
             }
         }
-    }
-    int bcost = (int)(key >> 3);
-    {
-        unsigned sk = (unsigned)bcost << 4;
-        for (int q = 1; q <= 8; q++) sk = min(sk, ((unsigned)pc_fpel_cost(c, bx + sq_dx(q), by + sq_dy(q), shape) << 4) | (unsigned)q);
-        const int bd = sk & 15;
-        bcost = (int)(sk >> 4);
-        if (bd) { bx += sq_dx(bd); by += sq_dy(bd); }
+    } else {
+        unsigned key = (unsigned)pc_fpel_cost(c, bx, by, shape) << 3;
+        for (int i = 1; i <= 6; i++) key = min(key, ((unsigned)pc_fpel_cost(c, bx + hex_dx(i), by + hex_dy(i), shape) << 3) | (unsigned)(i + 1));
+        bool running = (key & 7) != 0;
+        int dir = running ? (int)(key & 7) - 2 : 0;
+        if (running) { bx += hex_dx(dir + 1); by += hex_dy(dir + 1); }
+        for (int it = (c.me_range >> 1) - 1; it > 0; it--) {
+            if (!__any(running)) break;
+            running = running && bx >= c.fmin0 && bx <= c.fmax0 && by >= c.fmin1 && by <= c.fmax1;
+            unsigned k2 = key & ~7u;
+            for (int t = 0; t < 3; t++) k2 = min(k2, ((unsigned)pc_fpel_cost(c, bx + hex_dx(dir + t), by + hex_dy(dir + t), shape) << 3) | (unsigned)(t + 1));
+            if (running) {
+                key = k2;
+                if (!(key & 7)) running = false;
+                else {
+                    dir += (int)(key & 7) - 2;
+                    dir = dir < 0 ? 5 : dir > 5 ? 0 : dir;
+                    bx += hex_dx(dir + 1); by += hex_dy(dir + 1);
+                }
+            }
+        }
+        bcost = (int)(key >> 3);
+        {
+            unsigned sk = (unsigned)bcost << 4;
+            for (int q = 1; q <= 8; q++) sk = min(sk, ((unsigned)pc_fpel_cost(c, bx + sq_dx(q), by + sq_dy(q), shape) << 4) | (unsigned)q);
+            const int bd = sk & 15;
+            bcost = (int)(sk >> 4);
+            if (bd) { bx += sq_dx(bd); by += sq_dy(bd); }
+        }
     }
     int mx = bx * 4, my = by * 4;
     if (c.hp_it > 0) {
@@ -378,6 +398,17 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(X264GPU_ANA
     #define FPEL_KEY(mx, my, tag) \
         (((unsigned)(row16_sum(sad_row16_lds(win + (py + (my) + r - wy0) * WIN_STRIDE, px + (mx) - wx0, cr)) + MVC((mx) * 4, (my) * 4)) << 3) | (unsigned)(tag))
 
+        if (k.me_method == 0) {
+            // ---- X264_ME_DIA: the four neighbours are exactly the four lane groups; centre wins ties ----
+            int it = k.me_range;
+            do {
+                const unsigned kk = wave_min_u32(((FPEL_KEY(bmx + (cnd == 2 ? -1 : cnd == 3 ? 1 : 0), bmy + (cnd == 0 ? -1 : cnd == 1 ? 1 : 0), 0) >> 3) << 2) | (unsigned)cnd);
+                if ((int)(kk >> 2) >= bcost) break;
+                const int q = kk & 3;
+                bcost = (int)(kk >> 2);
+                bmx += q == 2 ? -1 : q == 3 ? 1 : 0; bmy += q == 0 ? -1 : q == 1 ? 1 : 0;
+            } while (--it && bmx >= fmin0 && bmx <= fmax0 && bmy >= fmin1 && bmy <= fmax1);
+        } else
         // ---- hexagon search ----
         {
             unsigned key = (unsigned)bcost << 3;
@@ -504,7 +535,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(X264GPU_ANA
         pc.win = win; pc.wx0 = pwx0; pc.wy0 = pwy0; pc.cx = s_cost[wave][0]; pc.cy = s_cost[wave][1]; pc.cbx = c0x * 4; pc.cby = c0y * 4;
         pc.p00 = p00; pc.pb = k.plane_bytes; pc.rs = k.rs; pc.px = px; pc.py = py; pc.zx = zx; pc.zy = zy; pc.cz = cz;
         pc.fmin0 = fmin0; pc.fmax0 = fmax0; pc.fmin1 = fmin1; pc.fmax1 = fmax1; pc.smin0 = smin0; pc.smax0 = smax0; pc.smin1 = smin1; pc.smax1 = smax1;
-        pc.me_range = k.me_range; pc.lane = lane; pc.sub = s_sub[wave];
+        pc.me_range = k.me_range; pc.me_method = k.me_method; pc.lane = lane; pc.sub = s_sub[wave];
         const int sub = min(k.subme, 11);
         pc.hp_it = sub < 2 ? 0 : sub < 6 ? 1 : sub < 8 ? 2 : 4;
         pc.qp_it = sub < 4 ? 0 : sub == 4 ? 1 : sub < 8 ? 2 : 10;
