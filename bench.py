@@ -112,7 +112,7 @@ def csp_probe(torch, lib, dev, W, H, frames=64, iters=10):
             "achieved_GBps": round(gbs, 1), "frac_of_hbm_peak": round(gbs / HBM_PEAK_GBS, 4), "frames_per_s": round(frames / (ms * 1e-3), 1)}
 
 
-def cpu_baseline(w, h, nframes, keyint):
+def cpu_baseline(w, h, nframes, keyint, tools):
     """oracle/ (CPU restatement, one core) on a bounded sample of the same workload — the checker timed as
     a baseline, never the product."""
     import numpy as np
@@ -120,7 +120,7 @@ def cpu_baseline(w, h, nframes, keyint):
     import oracle_lib as O
     from synth import synth_frames
     frames = synth_frames(w, h, nframes, seed=0x264, scene_len=10 ** 9)
-    enc = O.OracleEncoder(O.default_config(w, h, refs=3, partitions=7, dct8x8=1))
+    enc = O.OracleEncoder(O.default_config(w, h, **tools))
     t0 = time.perf_counter()
     for i, f in enumerate(frames):
         enc.encode(np.ascontiguousarray(f), 2 if i % keyint == 0 else 0)
@@ -141,6 +141,8 @@ def main():
     ap.add_argument("--keyint", type=int, default=60)
     ap.add_argument("--qp", type=int, default=23)
     ap.add_argument("--refs", type=int, default=3, help="reference frames (medium: 3)")
+    ap.add_argument("--preset", default="medium", choices=["medium", "ultrafast", "slow"],
+                    help="toolset of the other BASELINE.json configs (default medium = the headline); slow runs hex instead of umh")
     ap.add_argument("--cpu-frames", type=int, default=12, help="frames of the CPU-baseline sample (0 = skip)")
     args = ap.parse_args()
 
@@ -166,14 +168,17 @@ def main():
     gids = shard.stream_ids(rank, world, S)          # global stream ids of this rank (seeds only)
     qp_i, qp_p = max(0, args.qp - 3), args.qp      # CQP ladder: ipratio 1.4 ~ -3 (x264 CQP convention)
 
+    # toolsets (config.c:1460-1498 preset deltas restricted to what the pipeline implements)
+    tools = {"medium": dict(refs=args.refs, subme=7, deblock=1, partitions=7, dct8x8=1, me_method=1),
+             "ultrafast": dict(refs=1, subme=0, deblock=0, partitions=0x100, dct8x8=0, me_method=0),
+             "slow": dict(refs=4, subme=9, deblock=1, partitions=7, dct8x8=1, me_method=1)}[args.preset]
     # ---- inputs resident in HBM: warmup frames + K timed frames per stream ----
     nfr = Wu + K
     data = [synth_batch(torch, per[g], nfr, W, H, shard.stream_seed(0x264, gids[sum(per[:g])]), dev) for g in range(G)]
     encs, hs, mbs, lvs, streams = [], [], [], [], []
     for g in range(G):
-        cfg = Config(width=W, height=H, streams=per[g], refs=args.refs, qp_i=qp_i, qp_p=qp_p, me_range=16, subme=7, deblock=1,
-                     deblock_alpha=0, deblock_beta=0, chroma_qp_offset=0, deadzone_inter=21, deadzone_intra=11,
-                     dct_decimate=1, partitions=7, dct8x8=1, me_method=1)
+        cfg = Config(width=W, height=H, streams=per[g], qp_i=qp_i, qp_p=qp_p, me_range=16, deblock_alpha=0, deblock_beta=0,
+                     chroma_qp_offset=0, deadzone_inter=21, deadzone_intra=11, dct_decimate=1, **tools)
         h = C.c_void_p()
         lib.check(lib.x264gpu_encoder_create(C.byref(h), C.byref(cfg)), "encoder_create")
         n = lib.x264gpu_encoder_mb_count(h)
@@ -236,7 +241,7 @@ def main():
            "ms_per_step": round(dt / K * 1e3, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
            "dtype": "u8", "data": "synthetic",
            "config": {"workload": f"{W}x{H} yuv420p, {S} closed-GOP streams/GPU x {K} frames, keyint {args.keyint}, "
-                                  f"CQP {qp_i}/{qp_p}, me hex merange 16 subme 7, partitions p8x8(16x8,8x16,8x8)+i8x8+i4x4, 8x8dct, ref {args.refs}, deblock 0:0",
+                                  f"CQP {qp_i}/{qp_p}, preset {args.preset} toolset: {tools}",
                       "streams_per_gpu": S, "stream_groups": G, "frames_per_step": S * world},
            "roofline": roof}
     if rank == 0:
@@ -245,7 +250,7 @@ def main():
         out["config"]["mb_types_last_step"] = {"I4x4": int(types[0]), "I8x8": int(types[1]), "I16x16": int(types[2]), "P16x16/16x8/8x16": int(types[4]), "P8x8": int(types[5])}
         out["csp_ingest"] = csp_probe(torch, lib, dev, W, H)
         if args.cpu_frames > 0:
-            cfps, cdt = cpu_baseline(W, H, args.cpu_frames, args.keyint)
+            cfps, cdt = cpu_baseline(W, H, args.cpu_frames, args.keyint, tools)
             out["cpu_baseline"] = {"value": round(cfps, 3), "unit": "frames/s", "cores": 1, "kind": "port",
                                    "sample": f"{args.cpu_frames} frames {W}x{H} (1 I + {args.cpu_frames - 1} P), oracle/encoder.c single thread, {cdt:.1f} s"}
         print(json.dumps(out), flush=True)
