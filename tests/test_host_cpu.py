@@ -184,3 +184,21 @@ def test_cavlc_tables_are_prefix_codes():
     for t in range(7):
         check(arr("run_before_len")[t], arr("run_before_bits")[t], t < 6)
     assert sorted(arr("cbp_to_golomb_intra")[0]) == list(range(48)) == sorted(arr("cbp_to_golomb_inter")[0])
+
+
+def test_host_abi_exports_every_declared_symbol():
+    """include/x264.h (B1), include/vfw_shim.h (B2) and include/x264gpu_host.h are contracts: every function they declare is
+    exported by libx264gpu_host.so (no compute calls here — there is no GPU on this box)"""
+    import os
+    import re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    declared = set()
+    for hdr, pat in (("x264.h", r"\b(x264_[a-z0-9_]+)\s*\("), ("vfw_shim.h", r"\b(DriverProc|x264vfw_[a-z0-9_]+)\s*\("),
+                     ("x264gpu_host.h", r"\b(x264gpu_host_[a-z0-9_]+|x264host_[a-z0-9_]+)\s*\(")):
+        text = open(os.path.join(root, "include", hdr)).read()
+        text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+        declared |= set(re.findall(pat, text))
+    declared.discard("x264_encoder_open")                       # a macro onto x264_encoder_open_<build> (codec.c:1623)
+    assert len(declared) > 15, declared
+    missing = [d for d in sorted(declared) if not hasattr(H, d)]
+    assert not missing, f"declared but not exported: {missing}"

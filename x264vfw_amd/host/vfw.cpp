@@ -25,7 +25,7 @@ const char *const kTunes[] = { "", "film", "animation", "grain", "stillimage", "
 const char *const kProfiles[] = { "", "baseline", "main", "high" };
 const int kLevels[] = { -1, 10, 9, 11, 12, 13, 20, 21, 22, 30, 31, 32, 40, 41, 42, 50, 51, 52, 60, 61, 62 };
 
-extern "C" uint8_t *x264gpu_host_input_i420(x264_t *h);       /* host/encoder.cpp */
+#include "../../include/x264gpu_host.h"
 enum { CSP_NONE = 0 };                                         /* the rest are the driver's ids: X264GPU_CSP_* (csp.h:30-44) */
 
 struct CODEC {                          /* x264vfw.h:187-252, compress-side members */
