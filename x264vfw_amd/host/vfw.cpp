@@ -8,6 +8,7 @@
 // log window, VirtualDub hack, file muxers, decoder) are out of scope.
 #include "host.hpp"
 #include "../../include/vfw_shim.h"
+#include "../../include/x264gpu_host.h"
 #include <ctype.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -25,7 +26,6 @@ const char *const kTunes[] = { "", "film", "animation", "grain", "stillimage", "
 const char *const kProfiles[] = { "", "baseline", "main", "high" };
 const int kLevels[] = { -1, 10, 9, 11, 12, 13, 20, 21, 22, 30, 31, 32, 40, 41, 42, 50, 51, 52, 60, 61, 62 };
 
-#include "../../include/x264gpu_host.h"
 enum { CSP_NONE = 0 };                                         /* the rest are the driver's ids: X264GPU_CSP_* (csp.h:30-44) */
 
 struct CODEC {                          /* x264vfw.h:187-252, compress-side members */
