@@ -69,10 +69,11 @@ __device__ __forceinline__ void transpose8_stage(int v[8], int lane)
 #pragma unroll
     for (int r = 0; r < 8; r++) {
         if (r & S) continue;
-        const int send = hi ? v[r] : v[r | S];
+        const int lo_v = v[r], hi_v = v[r | S];                 // values first: `c ? v[a] : v[b]` is an lvalue select (a pointer select)
+        const int send = hi ? lo_v : hi_v;
         const int recv = S == 1 ? dpp<DPP_XOR1>(send) : S == 2 ? dpp<DPP_XOR2>(send) : xor4(send);
-        v[r] = hi ? recv : v[r];
-        v[r | S] = hi ? v[r | S] : recv;
+        v[r] = hi ? recv : lo_v;
+        v[r | S] = hi ? hi_v : recv;
     }
 }
 __device__ __forceinline__ void transpose8(int v[8], int lane)

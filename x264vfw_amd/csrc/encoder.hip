@@ -9,7 +9,9 @@
 #include "enc_common.cuh"
 #include "k_analyse.cuh"
 #include "k_encode.cuh"
+#include <stdlib.h>
 #include "k_intra.cuh"
+#include "k_intra2.cuh"
 #include "k_deblock.cuh"
 #include <math.h>
 #include <string.h>
@@ -222,7 +224,10 @@ int x264gpu_encode_frames(x264gpu_encoder *e, const uint8_t *d_i420, int slice_t
         STAGE_MARK(2);
     }
     STAGE_MARK(3);
-    hipLaunchKernelGGL(k_intra, dim3(S), dim3(1024), 0, st, k);
+    // band kernel (four macroblock rows per wavefront); X264GPU_INTRA_V1=1 selects the row-per-wave predecessor for A/B runs
+    static const bool intra_v1 = getenv("X264GPU_INTRA_V1") != nullptr;
+    if (intra_v1) hipLaunchKernelGGL(k_intra, dim3(S), dim3(1024), 0, st, k);
+    else hipLaunchKernelGGL(k_intra2, dim3(S), dim3(I2_WAVES * 64), 0, st, k);
     mask |= 8;
     STAGE_MARK(4);
     if (e->cfg.deblock) { hipLaunchKernelGGL(k_deblock, dim3(S), dim3(1024), 0, st, k); mask |= 16; }
