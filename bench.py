@@ -136,7 +136,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=4)
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--height", type=int, default=1080)
-    ap.add_argument("--streams", type=int, default=256, help="independent closed-GOP streams per GPU (lock-step batch)")
+    ap.add_argument("--streams", type=int, default=512, help="independent closed-GOP streams per GPU (lock-step batch)")
     ap.add_argument("--groups", type=int, default=2, help="stream groups on separate HIP streams (stage overlap)")
     ap.add_argument("--keyint", type=int, default=60)
     ap.add_argument("--qp", type=int, default=23)

@@ -13,11 +13,14 @@
 //            phase C (per active slot, whole wave): final choice, record, Intra16x16 encode, chroma
 // Same results as k_intra / oracle intra_mb, bit-exact.
 #pragma once
+#ifndef X264GPU_I2_WAVES
+#define X264GPU_I2_WAVES 8           // wavefronts per workgroup (each owns bands w, w + WAVES, ...)
+#endif
 #include "k_intra.cuh"
 
 namespace x264gpu {
 
-constexpr int I2_WAVES = 16;               // wavefronts per workgroup
+constexpr int I2_WAVES = X264GPU_I2_WAVES;               // wavefronts per workgroup
 struct SlotLds {
     __attribute__((aligned(8))) uint8_t tile[IT_SIZE];
     __attribute__((aligned(8))) uint8_t tile8[IT_SIZE];
@@ -478,6 +481,7 @@ __global__ __launch_bounds__(I2_WAVES * 64) void k_intra2(EncK kk)
     const x264gpu_mb *mbs = k.mb + (size_t)s * k.nmb;
     volatile int *progress = L.progress;
     SlotLds *slots = L.slot[wave];
+    unsigned long long tA = 0, tB = 0, tC = 0, tW = 0, nstep = 0, nslot = 0, t_begin = k.dbg ? clock64() : 0;
     const int mbw = k.mbw, nbands = (k.mbh + 3) >> 2;
     for (int band = wave; band < nbands; band += I2_WAVES) {
         const int r0 = band * 4;
@@ -498,18 +502,27 @@ __global__ __launch_bounds__(I2_WAVES * 64) void k_intra2(EncK kk)
                 if (above >= need) act |= 1u << i;
             }
             if (all_done) break;
-            if (!act) { __builtin_amdgcn_s_sleep(2); continue; }
+            if (!act) { const unsigned long long w0 = k.dbg ? clock64() : 0; __builtin_amdgcn_s_sleep(2); if (k.dbg) tW += clock64() - w0; continue; }
+            const unsigned long long c0 = k.dbg ? clock64() : 0;
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
 #pragma unroll
             for (int i = 0; i < 4; i++) if (act >> i & 1) i2_phase_a(k, slots[i], lane, s, x[i], r0 + i);
+            const unsigned long long c1 = k.dbg ? clock64() : 0;
             i2_phase_b(k, L, slots, lane, s, act);
+            const unsigned long long c2 = k.dbg ? clock64() : 0;
 #pragma unroll
             for (int i = 0; i < 4; i++) if (act >> i & 1) i2_phase_c(k, slots[i], lane, s, x[i], r0 + i);
+            if (k.dbg) { const unsigned long long c3 = clock64(); tA += c1 - c0; tB += c2 - c1; tC += c3 - c2; nstep++; nslot += __builtin_popcount(act); }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
 #pragma unroll
             for (int i = 0; i < 4; i++) if (act >> i & 1) { x[i] = i2_next_intra(k, mbs, r0 + i, x[i] + 1, lane); cur[i] = x[i]; }
             if (lane < 4 && r0 + lane < k.mbh) progress[r0 + lane] = lane == 0 ? cur[0] : lane == 1 ? cur[1] : lane == 2 ? cur[2] : cur[3];
         }
+    }
+    if (k.dbg && lane == 0) {
+        unsigned long long *d = k.dbg + ((size_t)s * 16 + wave) * 16;   // [stream][16 wave slots][16]
+        d[0] = tW; d[1] = tA + tB + tC; d[2] = nslot; d[3] = clock64() - t_begin;
+        d[8] = tA; d[9] = tB; d[10] = tC; d[11] = nstep;
     }
 }
 
