@@ -65,11 +65,13 @@ def pmc_evidence(stage, avg_launch_ms, frames_per_launch):
     separate passes, KB -> bytes, read side doubled as MI355X_MICROARCH.md prescribes for gfx950), plus the
     VALU issue utilisation the same passes imply (the path is integer-VALU bound, not HBM bound).  PMC counters
     cannot be read from inside an un-profiled run, so this is the profile's figure, valid only for the default
-    workload (128 frames per launch); anything else reports null."""
+    workload (the profile records its frames per launch); anything else reports null."""
     path = os.path.join(ROOT, "profiles", "r01_pmc_per_launch.json")
-    if not os.path.exists(path) or frames_per_launch != 128:
+    if not os.path.exists(path):
         return None, None
     tab = json.load(open(path))
+    if tab.get("_workload", {}).get("frames_per_launch") != frames_per_launch:
+        return None, None
     key = [k for k in tab if ("k_" + stage) in k]
     if not key or "hbm_bytes_per_launch_corrected" not in tab[key[0]]:
         return None, None

@@ -35,8 +35,17 @@ def main():
         if "SQ_INSTS_VALU" in v and "SQ_WAVES" in v and v["SQ_WAVES"]:
             v["valu_per_wave"] = v["SQ_INSTS_VALU"] / v["SQ_WAVES"]
             v["cycles_per_wave"] = v["SQ_WAVE_CYCLES"] / v["SQ_WAVES"]
+    # frames one launch covers in the profiled command (bench.py default: streams / groups), so bench.py only quotes these
+    # figures for the same workload
+    try:
+        b = json.loads(open(os.path.join(out, "bench_under_rocprof.json")).read().strip().split("\n")[-1])
+        table["_workload"] = {"frames_per_launch": b["config"]["streams_per_gpu"] // b["config"]["stream_groups"], "config": b["config"]["workload"]}
+    except Exception as e:  # noqa: BLE001
+        table["_workload"] = {"frames_per_launch": None, "error": str(e)}
     json.dump(table, open(os.path.join(out, "pmc_per_launch.json"), "w"), indent=1, sort_keys=True)
     for k, v in sorted(table.items()):
+        if k.startswith("_"):
+            continue
         print(k, {c: ("%.4g" % x if isinstance(x, float) else x) for c, x in v.items() if c != "launches_profiled"})
 
 
