@@ -208,6 +208,7 @@ __device__ __forceinline__ void i2_phase_c(const EncK &k, SlotLds &S, int lane, 
     }
     if (lane >= 16 && lane < 24) lv[408 + lane - 16] = 0;
 
+    __builtin_amdgcn_sched_barrier(0);      // keep the scheduler from interleaving phases (it costs ~80 spilled VGPRs otherwise)
     // ---- chroma: mode decision + encode (lanes 0..31; plane = lane>>4) ----
     {
         const int c = (lane >> 4) & 1, ci = (lane >> 2) & 3, cx0 = (ci & 1) * 4, cyy = (ci >> 1) * 4 + j;
@@ -395,6 +396,7 @@ __device__ __forceinline__ void i2_phase_b(const EncK &k, Intra2Lds &L, SlotLds 
         __builtin_amdgcn_s_waitcnt(0xc07f);
     }
 
+    __builtin_amdgcn_sched_barrier(0);      // keep the scheduler from interleaving phases (it costs ~80 spilled VGPRs otherwise)
     // ================= Intra4x4: quad q of the slot evaluates modes q, q+4 (+ mode 8 on quad 0) =================
     int cost4 = 1 << 28;
     unsigned nnz4 = 0;
@@ -445,6 +447,7 @@ __device__ __forceinline__ void i2_phase_b(const EncK &k, Intra2Lds &L, SlotLds 
             if (!__any(act && cost4 < best16 && cost4 <= thr8)) break;   // no slot's Intra4x4 can win any more (costs only grow)
         }
     }
+    __builtin_amdgcn_sched_barrier(0);      // keep the scheduler from interleaving phases (it costs ~80 spilled VGPRs otherwise)
     if (l16 == 0) {
         S.info[SI_COST8] = cost8; S.info[SI_DONE8] = alive8 ? 1 : 0; S.info[SI_NNZ8] = (int)nnz8; S.info[SI_CBP8] = cbp8;
         S.info[SI_COST4] = cost4; S.info[SI_NNZ4] = (int)nnz4;
@@ -468,7 +471,10 @@ __device__ __forceinline__ int i2_next_intra(const EncK &k, const x264gpu_mb *mb
     return k.mbw;
 }
 
-__global__ __launch_bounds__(I2_WAVES * 64) void k_intra2(EncK kk)
+#ifndef X264GPU_I2_OCC
+#define X264GPU_I2_OCC 4          // waves per SIMD the register allocator targets (2 -> up to 256 VGPRs, 4 -> 128)
+#endif
+__global__ __launch_bounds__(I2_WAVES * 64) __attribute__((amdgpu_waves_per_eu(X264GPU_I2_OCC, 8))) void k_intra2(EncK kk)
 {
     __shared__ __attribute__((aligned(16))) Intra2Lds L;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, s = blockIdx.x;
@@ -506,12 +512,14 @@ __global__ __launch_bounds__(I2_WAVES * 64) void k_intra2(EncK kk)
             const unsigned long long c0 = k.dbg ? clock64() : 0;
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
 #pragma unroll
-            for (int i = 0; i < 4; i++) if (act >> i & 1) i2_phase_a(k, slots[i], lane, s, x[i], r0 + i);
+            for (int i = 0; i < 4; i++) if (act >> i & 1) { i2_phase_a(k, slots[i], lane, s, x[i], r0 + i); __builtin_amdgcn_sched_barrier(0); }
             const unsigned long long c1 = k.dbg ? clock64() : 0;
+            __builtin_amdgcn_sched_barrier(0);
             i2_phase_b(k, L, slots, lane, s, act);
+            __builtin_amdgcn_sched_barrier(0);
             const unsigned long long c2 = k.dbg ? clock64() : 0;
 #pragma unroll
-            for (int i = 0; i < 4; i++) if (act >> i & 1) i2_phase_c(k, slots[i], lane, s, x[i], r0 + i);
+            for (int i = 0; i < 4; i++) if (act >> i & 1) { __builtin_amdgcn_sched_barrier(0); i2_phase_c(k, slots[i], lane, s, x[i], r0 + i); }
             if (k.dbg) { const unsigned long long c3 = clock64(); tA += c1 - c0; tB += c2 - c1; tC += c3 - c2; nstep++; nslot += __builtin_popcount(act); }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
 #pragma unroll
