@@ -511,15 +511,17 @@ __global__ __launch_bounds__(I2_WAVES * 64) __attribute__((amdgpu_waves_per_eu(X
             if (!act) { const unsigned long long w0 = k.dbg ? clock64() : 0; __builtin_amdgcn_s_sleep(2); if (k.dbg) tW += clock64() - w0; continue; }
             const unsigned long long c0 = k.dbg ? clock64() : 0;
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-#pragma unroll
-            for (int i = 0; i < 4; i++) if (act >> i & 1) { i2_phase_a(k, slots[i], lane, s, x[i], r0 + i); __builtin_amdgcn_sched_barrier(0); }
+#pragma unroll 1
+            for (int i = 0; i < 4; i++)            // one copy of the phase code (instruction-cache footprint), slot chosen at run time
+                if (act >> i & 1) { i2_phase_a(k, slots[i], lane, s, i == 0 ? x[0] : i == 1 ? x[1] : i == 2 ? x[2] : x[3], r0 + i); __builtin_amdgcn_sched_barrier(0); }
             const unsigned long long c1 = k.dbg ? clock64() : 0;
             __builtin_amdgcn_sched_barrier(0);
             i2_phase_b(k, L, slots, lane, s, act);
             __builtin_amdgcn_sched_barrier(0);
             const unsigned long long c2 = k.dbg ? clock64() : 0;
-#pragma unroll
-            for (int i = 0; i < 4; i++) if (act >> i & 1) { __builtin_amdgcn_sched_barrier(0); i2_phase_c(k, slots[i], lane, s, x[i], r0 + i); }
+#pragma unroll 1
+            for (int i = 0; i < 4; i++)
+                if (act >> i & 1) { __builtin_amdgcn_sched_barrier(0); i2_phase_c(k, slots[i], lane, s, i == 0 ? x[0] : i == 1 ? x[1] : i == 2 ? x[2] : x[3], r0 + i); }
             if (k.dbg) { const unsigned long long c3 = clock64(); tA += c1 - c0; tB += c2 - c1; tC += c3 - c2; nstep++; nslot += __builtin_popcount(act); }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
 #pragma unroll
