@@ -289,7 +289,7 @@ static const int8_t mod6m1[8] = { 5, 0, 1, 2, 3, 4, 5, 0 };
  * tried in order (first-best wins), then hexagon + square full-pel search on SAD and the sub-pel diamonds
  * (half-pel on SAD, quarter-pel on SATD) — x264_me_search_ref + refine_subpel.  mvp = cost predictor. */
 static me_result me_search_block(x264o_encoder *e, int mbx, int mby, int ox, int oy, int w, int h, int qp, int refidx,
-                                 const int mvp[2], const int (*cand)[2], int ncand)
+                                 const int mvp[2], const int (*cand)[2], int ncand, int *halfpel_thresh)
 {
     const pixel *fenc = e->fenc_y + (size_t)(mby * 16 + oy) * e->fs + mbx * 16 + ox;
     int ref = ref_slot(e, refidx);
@@ -371,9 +371,16 @@ static me_result me_search_block(x264o_encoder *e, int mbx, int mby, int ox, int
         }
         x264o_mc_luma(pred, 16, planes, e->rs, mbx * 16 + ox, mby * 16 + oy, mx, my, w, h);
         bcost = x264o_satd(fenc, e->fs, pred, 16, w, h) + cmx[mx] + cmy[my];
+        /* early termination when examining several reference frames ([x264-upstream] me.c refine_subpel, p_halfpel_thresh):
+         * a reference whose half-pel SATD cost is more than 8/7 of the best one so far skips the quarter-pel diamond */
+        int skip_qpel = 0;
+        if (halfpel_thresh) {
+            if (((bcost * 7) >> 3) > *halfpel_thresh) skip_qpel = 1;
+            else if (bcost < *halfpel_thresh) *halfpel_thresh = bcost;
+        }
         int bdir = -1;
         static const int8_t qd[4][2] = { { 0, -1 }, { 0, 1 }, { -1, 0 }, { 1, 0 } };
-        for (int it = iters[sub][1]; it > 0; it--) {
+        for (int it = skip_qpel ? 0 : iters[sub][1]; it > 0; it--) {
             if (my <= smin[1] || my >= smax[1] || mx <= smin[0] || mx >= smax[0]) break;
             int odir = bdir, omx = mx, omy = my;
             for (int k = 0; k < 4; k++) {
@@ -393,7 +400,7 @@ static me_result me_search_block(x264o_encoder *e, int mbx, int mby, int ox, int
 /* bits of ref_idx te(v) for `nref` active references */
 static int ref_bits(int nref, int r) { return nref <= 1 ? 0 : nref == 2 ? 1 : bs_size_ue(r); }
 
-static me_result me_search_16x16(x264o_encoder *e, int mbx, int mby, int qp, int refidx, int mvp[2])
+static me_result me_search_16x16(x264o_encoder *e, int mbx, int mby, int qp, int refidx, int mvp[2], int *halfpel_thresh)
 {
     /* start candidates, in priority order: predictor, zero, co-located previous-frame MV */
     int cand[3][2], ncand = 0, mi = mby * e->mbw + mbx;
@@ -401,7 +408,7 @@ static me_result me_search_16x16(x264o_encoder *e, int mbx, int mby, int qp, int
     cand[ncand][0] = (mvp[0] + 2) >> 2; cand[ncand][1] = (mvp[1] + 2) >> 2; ncand++;
     cand[ncand][0] = 0; cand[ncand][1] = 0; ncand++;
     if (e->reff[0][mi] >= 0) { cand[ncand][0] = (e->mvf[0][mi][0] + 2) >> 2; cand[ncand][1] = (e->mvf[0][mi][1] + 2) >> 2; ncand++; }
-    return me_search_block(e, mbx, mby, 0, 0, 16, 16, qp, refidx, mvp, (const int (*)[2])cand, ncand);
+    return me_search_block(e, mbx, mby, 0, 0, 16, 16, qp, refidx, mvp, (const int (*)[2])cand, ncand, halfpel_thresh);
 }
 
 /* intra 16x16 SATD estimate on SOURCE neighbours (lookahead-style; decides intra vs inter in P) */
@@ -441,8 +448,9 @@ static void analyse_p_mb(x264o_encoder *e, int mbx, int mby, x264gpu_mb *mb)
     /* 16x16 search in every usable reference (most recent first); lower index wins ties */
     me_result m = { 0, 0, 1 << 28 };
     int bref = 0;
+    int halfpel_thresh = 1 << 28;          /* INT_MAX-like: shared by the references of this macroblock, only with more than one */
     for (int r = 0; r < e->nref; r++) {
-        me_result t = me_search_16x16(e, mbx, mby, qp, r, mvp);
+        me_result t = me_search_16x16(e, mbx, mby, qp, r, mvp, e->nref > 1 ? &halfpel_thresh : NULL);
         t.cost += lambda * ref_bits(e->nref, r);
         if (t.cost < m.cost) { m = t; bref = r; }
     }
@@ -458,7 +466,7 @@ static void analyse_p_mb(x264o_encoder *e, int mbx, int mby, x264gpu_mb *mb)
             if (oi > 0 && best_shape == 0) break;
             for (int p = 0; p < part_count[shape]; p++) {
                 const int8_t *g = part_geom[shape][p];
-                me_result r = me_search_block(e, mbx, mby, g[0], g[1], g[2], g[3], qp, bref, mvp, (const int (*)[2])c0, 1);
+                me_result r = me_search_block(e, mbx, mby, g[0], g[1], g[2], g[3], qp, bref, mvp, (const int (*)[2])c0, 1, NULL);
                 cost += r.cost;
                 mv[g[4]][0] = r.mvx; mv[g[4]][1] = r.mvy;
                 if (g[5] >= 0) { mv[g[5]][0] = r.mvx; mv[g[5]][1] = r.mvy; }

@@ -348,7 +348,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(X264GPU_ANA
 
     // ---- 16x16 search in every usable reference (oracle analyse_p_mb); lower index wins ties ----
     const size_t pb = k.plane_bytes;
-    int best_mx = 0, best_my = 0, best16 = 1 << 28, bref = 0;
+    int best_mx = 0, best_my = 0, best16 = 1 << 28, bref = 0, halfpel_thresh = 1 << 28;
     for (int r_ = 0; r_ < k.nref; r_++) {
         const uint8_t *p00 = ref_plane00(k, s, r_);
         // ---- start candidates: predictor, zero, co-located (lane groups 0..2 evaluate one each) ----
@@ -482,13 +482,20 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(X264GPU_ANA
             {
                 bcost = wave_sum(satd4_half(cz, sub_row4(sb, sn, rwl, sx0, sy0, px + zx, py + zy, mx, my), lane)) + MVC(mx, my);
             }
+            // early termination when examining several references (x264 refine_subpel, p_halfpel_thresh): a reference whose
+            // half-pel SATD cost exceeds 8/7 of the best so far skips its quarter-pel diamond
+            bool skip_qpel = false;
+            if (k.nref > 1) {
+                if (((bcost * 7) >> 3) > halfpel_thresh) skip_qpel = true;
+                else if (bcost < halfpel_thresh) halfpel_thresh = bcost;
+            }
             // quarter-pel diamond, SATD: (0,-1) (0,1) (-1,0) (1,0), never stepping straight back.  The four
             // candidates are independent, so they run at once in the (candidate, row) mapping: a quad of
             // lanes = 4 rows x 16 columns = four 4x4 blocks (packed-16 Hadamard), a DPP row = one candidate.
             // min over (cost<<2 | q) == x264's in-order "first strictly better" update.
             int bdir = -1;
             const s16x2 sg1 = pk_sign(lane & 1), sg2 = pk_sign(lane & 2);
-            for (int it = qp_it; it > 0; it--) {
+            for (int it = skip_qpel ? 0 : qp_it; it > 0; it--) {
                 if (my <= smin1 || my >= smax1 || mx <= smin0 || mx >= smax0) break;
                 const int cx = mx + (cnd == 2 ? -1 : cnd == 3 ? 1 : 0), cy = my + (cnd == 0 ? -1 : cnd == 1 ? 1 : 0);
                 uint32_t pr[4];
