@@ -125,3 +125,27 @@ def test_full_size_closed_loop_properties(gpu):
             assert np.array_equal(gg.recon(s), gg.recon(0))
         assert psnr(gg.recon(0)[:w * h], f[:w * h]) > 36.0
     gg.close()
+
+
+def test_many_streams_long_gop_deterministic(gpu):
+    """race / scheduling check for the wavefront kernels: 48 streams fed the SAME frames for a 24-frame GOP must stay
+    identical to each other frame by frame (records, levels, reconstruction), and stream 0 must equal the oracle on the
+    first frames.  Any ordering bug in the band / row hand-offs shows up as a stream that diverges."""
+    from gpu_enc import GpuEncoder
+    w, h, S, nfr = 352, 288, 48, 24
+    frames = synth_frames(w, h, nfr, seed=4242)
+    cfg = O.default_config(w, h, streams=S, dct8x8=1, partitions=7, refs=3)
+    gg, og = GpuEncoder(cfg), O.OracleEncoder(O.default_config(w, h, dct8x8=1, partitions=7, refs=3))
+    mbw = (w + 15) // 16
+    for i, f in enumerate(frames):
+        st = 2 if i == 0 else 0
+        mb, lv = gg.encode([f] * S, st)
+        same = [s for s in range(1, S) if not (np.array_equal(mb[s], mb[0]) and np.array_equal(lv[s], lv[0]))]
+        assert not same, f"frame {i}: streams {same[:8]} diverge from stream 0"
+        r0 = gg.recon(0)
+        for s in (1, S // 2, S - 1):
+            assert np.array_equal(gg.recon(s), r0), f"frame {i}: reconstruction of stream {s} differs"
+        if i < 6:
+            o_mb, o_lv = og.encode(f, st)
+            compare(f"frame {i}", mbw, mb[0], o_mb, lv[0], o_lv, r0, og.recon())
+    gg.close(); og.close()
