@@ -227,7 +227,8 @@ int x264gpu_encode_frames(x264gpu_encoder *e, const uint8_t *d_i420, int slice_t
     // band kernel (four macroblock rows per wavefront); X264GPU_INTRA_V1=1 selects the row-per-wave predecessor for A/B runs
     static const bool intra_v1 = getenv("X264GPU_INTRA_V1") != nullptr;
     if (intra_v1) hipLaunchKernelGGL(k_intra, dim3(S), dim3(1024), 0, st, k);
-    else hipLaunchKernelGGL(k_intra2, dim3(S), dim3(I2_WAVES * 64), 0, st, k);
+    else if (S >= 128) hipLaunchKernelGGL(k_intra2<I2_WAVES>, dim3(S), dim3(I2_WAVES * 64), 0, st, k);        // CUs are full: small workgroups, two per CU
+    else hipLaunchKernelGGL(k_intra2<I2_WAVES_FEW>, dim3(S), dim3(I2_WAVES_FEW * 64), 0, st, k);                  // few streams: all bands of a frame at once
     mask |= 8;
     STAGE_MARK(4);
     if (e->cfg.deblock) { hipLaunchKernelGGL(k_deblock, dim3(S), dim3(DB_WAVES * 64), 0, st, k); mask |= 16; }

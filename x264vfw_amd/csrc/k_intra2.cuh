@@ -20,7 +20,8 @@
 
 namespace x264gpu {
 
-constexpr int I2_WAVES = X264GPU_I2_WAVES;               // wavefronts per workgroup
+constexpr int I2_WAVES = X264GPU_I2_WAVES;               // wavefronts per workgroup for many-stream launches
+constexpr int I2_WAVES_FEW = 16;                         // ... and when few streams are in flight (latency over footprint)
 struct SlotLds {
     __attribute__((aligned(8))) uint8_t tile[IT_SIZE];
     __attribute__((aligned(8))) uint8_t tile8[IT_SIZE];
@@ -35,8 +36,9 @@ struct SlotLds {
     int info[12];                                       // see enum below
 };
 enum { SI_BEST16 = 0, SI_MODE16, SI_COST8, SI_DONE8, SI_NNZ8, SI_CBP8, SI_COST4, SI_NNZ4, SI_MBX, SI_MBY };
-struct Intra2Lds {
-    SlotLds slot[I2_WAVES][4];
+template <int NW>
+struct Intra2LdsT {
+    SlotLds slot[NW][4];
     __attribute__((aligned(8))) uint8_t pred8tab[9 * 64];
     __attribute__((aligned(4))) uint8_t pred4tab[9 * 16];
     int progress[160];
@@ -263,7 +265,8 @@ __device__ __forceinline__ void i2_phase_c(const EncK &k, SlotLds &S, int lane, 
 
 // ---- phase B: Intra8x8 then Intra4x4 of the four slots side by side -----------------------------------------------
 // lane = (slot, 16 lanes).  Values that are uniform inside a slot (costs, modes, availability) live in VGPRs here.
-__device__ __forceinline__ void i2_phase_b(const EncK &k, Intra2Lds &L, SlotLds *slots, int lane, int s, unsigned active)
+template <class LDS>
+__device__ __forceinline__ void i2_phase_b(const EncK &k, LDS &L, SlotLds *slots, int lane, int s, unsigned active)
 {
     const int sl = lane >> 4, l16 = lane & 15;
     SlotLds &S = slots[sl];
@@ -474,11 +477,12 @@ __device__ __forceinline__ int i2_next_intra(const EncK &k, const x264gpu_mb *mb
 #ifndef X264GPU_I2_OCC
 #define X264GPU_I2_OCC 4          // waves per SIMD the register allocator targets (2 -> up to 256 VGPRs, 4 -> 128)
 #endif
-__global__ __launch_bounds__(I2_WAVES * 64) __attribute__((amdgpu_waves_per_eu(X264GPU_I2_OCC, 8))) void k_intra2(EncK kk)
+template <int NW>
+__global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(X264GPU_I2_OCC, 8))) void k_intra2(EncK kk)
 {
-    __shared__ __attribute__((aligned(16))) Intra2Lds L;
+    __shared__ __attribute__((aligned(16))) Intra2LdsT<NW> L;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, s = blockIdx.x;
-    for (int i = threadIdx.x; i < 160; i += I2_WAVES * 64) L.progress[i] = 0;
+    for (int i = threadIdx.x; i < 160; i += NW * 64) L.progress[i] = 0;
     if (threadIdx.x < 144) ((uint32_t *)L.pred8tab)[threadIdx.x] = ((const uint32_t *)c_pred8_table)[threadIdx.x];
     if (threadIdx.x < 36) ((uint32_t *)L.pred4tab)[threadIdx.x] = ((const uint32_t *)c_pred4_table.t)[threadIdx.x];
     if (lane < 4 * 12) L.slot[wave][lane / 12].info[lane % 12] = 0;
@@ -489,7 +493,7 @@ __global__ __launch_bounds__(I2_WAVES * 64) __attribute__((amdgpu_waves_per_eu(X
     SlotLds *slots = L.slot[wave];
     unsigned long long tA = 0, tB = 0, tC = 0, tW = 0, nstep = 0, nslot = 0, t_begin = k.dbg ? clock64() : 0;
     const int mbw = k.mbw, nbands = (k.mbh + 3) >> 2;
-    for (int band = wave; band < nbands; band += I2_WAVES) {
+    for (int band = wave; band < nbands; band += NW) {
         const int r0 = band * 4;
         int x[4], cur[4];                      // next intra macroblock / macroblocks completed, per row of the band
 #pragma unroll
