@@ -31,6 +31,7 @@ int  x264gpu_malloc(void **d_ptr, size_t bytes);
 int  x264gpu_free(void *d_ptr);
 int  x264gpu_memcpy_h2d(void *d_dst, const void *h_src, size_t bytes, void *stream);
 int  x264gpu_memcpy_d2h(void *h_dst, const void *d_src, size_t bytes, void *stream);
+int  x264gpu_memcpy_d2d(void *d_dst, const void *d_src, size_t bytes, void *stream);   /* asynchronous on `stream` */
 int  x264gpu_memset(void *d_dst, int value, size_t bytes, void *stream);
 int  x264gpu_stream_sync(void *stream);
 

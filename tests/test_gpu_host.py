@@ -140,3 +140,41 @@ def test_headers_call(gpu):
     for k in range(3):                                                       # 4-byte prefix each (output/raw.c:41-47)
         assert bytes(nal[k].p_payload[0:4]) == b"\x00\x00\x00\x01"
     H.x264_encoder_close(h_)
+
+
+@pytest.mark.parametrize("w,h,nfr,keyint,threads", [(176, 144, 23, 4, 3), (96, 80, 17, 5, 4), (176, 144, 12, 4, 3), (64, 48, 9, 3, 8), (64, 48, 2, 6, 2)])
+def test_gop_parallel_equals_serial(gpu, w, h, nfr, keyint, threads):
+    """--threads G codes G closed GOPs in lock-step: the frames come out (G-1)*keyint calls late, in order, and the stream is
+    byte-identical to the serial encode (fixed keyint + CQP make the GOPs independent); flush drains the rest."""
+    frames = synth_frames(w, h, nfr, seed=31 * w + nfr)
+    opts = {"qp": 27, "keyint": keyint, "min-keyint": keyint}
+    h1, _ = open_encoder(w, h, opts, b"high")
+    serial, info1, _ = encode_all(h1, w, h, frames)
+    H.x264_encoder_close(h1)
+    hg, eff = open_encoder(w, h, dict(opts, threads=threads), b"high")
+    assert eff.i_threads == threads
+    pic, out = HL.Picture(), HL.Picture()
+    assert H.x264_picture_alloc(C.byref(pic), HL.X264_CSP_I420, w, h) == 0
+    nal, n = C.POINTER(HL.Nal)(), C.c_int()
+    stream, pts_out, calls_with_output = b"", [], 0
+    delay = (threads - 1) * keyint
+    for i, f in enumerate(frames):
+        for pl, (sz, off) in enumerate([(w * h, 0), (w * h // 4, w * h), (w * h // 4, w * h * 5 // 4)]):
+            C.memmove(pic.img.plane[pl], f[off:off + sz].ctypes.data, sz)
+        pic.i_pts = 100 + i
+        size = H.x264_encoder_encode(hg, C.byref(nal), C.byref(n), C.byref(pic), C.byref(out))
+        assert size >= 0
+        assert (size > 0) == (i >= delay), f"call {i}: size {size}, delay {delay}"
+        if size:
+            stream += C.string_at(nal[0].p_payload, size); pts_out.append(out.i_pts)
+        assert H.x264_encoder_delayed_frames(hg) == i + 1 - len(pts_out)
+    while H.x264_encoder_delayed_frames(hg):
+        size = H.x264_encoder_encode(hg, C.byref(nal), C.byref(n), None, C.byref(out))
+        assert size > 0
+        stream += C.string_at(nal[0].p_payload, size); pts_out.append(out.i_pts)
+    assert H.x264_encoder_encode(hg, C.byref(nal), C.byref(n), None, C.byref(out)) == 0
+    H.x264_encoder_close(hg)
+    H.x264_picture_clean(C.byref(pic))
+    assert pts_out == [100 + i for i in range(nfr)]
+    assert stream == serial
+    assert len(O.h264_decode(stream, nfr, w, h)) == nfr

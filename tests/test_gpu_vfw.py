@@ -178,5 +178,15 @@ def test_raw_file_output(gpu, tmp_path):
     to_file, sizes = run(b"--keyint 250 --output " + str(path).encode())
     assert to_file == b"" and sizes == [0] * nfr                             # codec.c:1708-1721: nothing reaches the VfW buffer
     assert path.read_bytes() == direct
+    # GOP-parallel coding (--threads 3): frames reach the file late and compress_end flushes the rest (codec.c:1842-1856);
+    # the file is byte-identical to the serial one
+    par_path = tmp_path / "par.h264"
+    run(b"--keyint 2 --min-keyint 2 --output " + str(path).encode())
+    serial_k2 = path.read_bytes()
+    to_file, sizes = run(b"--keyint 2 --min-keyint 2 --threads 3 --output " + str(par_path).encode())
+    assert to_file == b"" and par_path.read_bytes() == serial_k2
+    # without a file the VfW buffer cannot take late frames: threads falls back to 1 (same stream, no delay)
+    direct_t, sizes = run(b"--keyint 250 --threads 4")
+    assert direct_t == direct and all(s > 0 for s in sizes)
     none, log = run(b"--output " + str(tmp_path / "x.mkv").encode())
     assert none is None and b"output support" in log                         # other muxers are not built (next-row f3)

@@ -19,12 +19,14 @@ H = HL.H
 
 def main():
     w, h, n = 1920, 1080, int(sys.argv[1]) if len(sys.argv) > 1 else 60
+    threads = int(sys.argv[2]) if len(sys.argv) > 2 else 1              # --threads G: closed GOPs coded in lock-step
+    keyint = int(sys.argv[3]) if len(sys.argv) > 3 else 60
     frames = synth_frames(w, h, 8, seed=1)
     p = HL.Param()
     assert H.x264_param_default_preset(C.byref(p), b"medium", None) == 0
     p.i_width, p.i_height, p.i_csp = w, h, HL.X264_CSP_I420
     p.i_fps_num, p.i_fps_den, p.i_log_level = 25, 1, -1
-    for k, v in (("qp", "23"), ("keyint", "60")):
+    for k, v in (("qp", "23"), ("keyint", str(keyint)), ("threads", str(threads))):
         assert H.x264_param_parse(C.byref(p), k.encode(), v.encode()) == 0
     p.b_annexb, p.b_repeat_headers = 1, 1
     h_ = H.x264_encoder_open_157(C.byref(p))
@@ -34,21 +36,27 @@ def main():
     nal, nn = C.POINTER(HL.Nal)(), C.c_int()
     planes = [(w * h, 0), (w * h // 4, w * h), (w * h // 4, w * h * 5 // 4)]
     total, t_enc = 0, 0.0
-    for i in range(n + 4):
+    got = 0
+    t_start = time.perf_counter()
+    for i in range(n):
         f = frames[i % len(frames)]
         for pl, (sz, off) in enumerate(planes):
             C.memmove(pic.img.plane[pl], f[off:off + sz].ctypes.data, sz)
         pic.i_pts = i
-        t0 = time.perf_counter()
         size = H.x264_encoder_encode(h_, C.byref(nal), C.byref(nn), C.byref(pic), C.byref(out))
-        dt = time.perf_counter() - t0
+        assert size >= 0
+        got += size > 0
+        total += size
+    while H.x264_encoder_delayed_frames(h_):
+        size = H.x264_encoder_encode(h_, C.byref(nal), C.byref(nn), None, C.byref(out))
         assert size > 0
-        if i >= 4:
-            t_enc += dt
-            total += size
+        got += 1
+        total += size
+    t_enc = time.perf_counter() - t_start
     H.x264_encoder_close(h_)
-    print(f"B1 single stream 1080p medium toolset: {n / t_enc:.1f} frames/s ({1e3 * t_enc / n:.2f} ms/frame incl. upload, GPU, download, host CAVLC; "
-          f"{total / n / 1e3:.1f} kB/frame)")
+    assert got == n
+    print(f"B1 single stream 1080p medium toolset, threads {threads}, keyint {keyint}: {n / t_enc:.1f} frames/s ({1e3 * t_enc / n:.2f} ms/frame incl. "
+          f"host copy-in, upload, GPU, download, host CAVLC; {total / n / 1e3:.1f} kB/frame; {os.cpu_count()} host cores)")
 
 
 if __name__ == "__main__":

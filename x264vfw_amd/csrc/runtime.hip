@@ -47,6 +47,11 @@ int x264gpu_memcpy_d2h(void *h, const void *d, size_t n, void *stream)
     HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
     return X264GPU_OK;
 }
+int x264gpu_memcpy_d2d(void *dst, const void *src, size_t n, void *stream)
+{
+    HIP_TRY(hipMemcpyAsync(dst, src, n, hipMemcpyDeviceToDevice, (hipStream_t)stream));
+    return X264GPU_OK;
+}
 int x264gpu_memset(void *d, int v, size_t n, void *stream)
 {
     HIP_TRY(hipMemsetAsync(d, v, n, (hipStream_t)stream));

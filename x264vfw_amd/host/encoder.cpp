@@ -10,7 +10,9 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <deque>
 #include <string>
+#include <thread>
 
 using namespace x264host;
 
@@ -38,6 +40,19 @@ struct x264_t {
     std::vector<x264_nal_t> nals;
     std::vector<size_t> nal_off;
     SliceStats last_stats = { 0 };
+    // ---- GOP-parallel mode (--threads G > 1): G closed GOPs of the one stream are coded in lock-step on G stream slots of the
+    //      GPU encoder; frames come out in order, (G-1)*keyint calls late.  Fixed keyint + CQP make the GOPs independent, so
+    //      the bytes equal the serial encode's (tests/test_gpu_host.py::test_gop_parallel_equals_serial).
+    int G = 1;
+    uint8_t *d_ring = nullptr;           // device: [keyint positions][G slots] tight I420 pictures of the batch being gathered
+    long submitted = 0, emitted = 0;     // frames in / out
+    int next_pos = 0;                    // first position of the current batch not yet coded
+    bool flushed = false;                // the partly gathered batch has been coded (flush calls only drain after that)
+    struct Coded { std::vector<uint8_t> bytes; std::vector<size_t> off; std::vector<int> types; int idr; };
+    std::deque<Coded> ready;             // coded frames [emitted, emitted + ready.size())
+    std::deque<int64_t> pts;             // pts of frames not yet emitted
+    std::vector<Coded> slotbuf;          // G x keyint frames of the batch being coded (index slot * keyint + pos)
+    std::vector<uint8_t> slot_have;      // which of them are coded
 };
 
 static void xlog(const x264_param_t *p, int level, const char *fmt, ...)
@@ -131,7 +146,8 @@ x264_t *x264_encoder_open(x264_param_t *param)
     if (p.analyse.i_me_method > X264_ME_HEX) { xlog(&p, X264_LOG_WARNING, "me umh/esa/tesa are not implemented in the MI355X path yet: me hex\n"); p.analyse.i_me_method = X264_ME_HEX; }
     p.analyse.i_me_range = clampi(p.analyse.i_me_range, 4, 16);
     p.analyse.i_subpel_refine = clampi(p.analyse.i_subpel_refine, 0, 7);
-    p.b_interlaced = 0; p.i_slice_count = 1; p.i_threads = 1;
+    p.b_interlaced = 0; p.i_slice_count = 1;
+    p.i_threads = clampi(p.i_threads, 1, 64);                  // --threads G: GOPs coded in lock-step (1 = no delay)
     if (p.i_keyint_max <= 0) p.i_keyint_max = 1;
     h->keyint = p.i_keyint_max;
     // rate control: constant QP only (X264_RC_CQP, codec.c:1498-1502); CRF/ABR map to their nominal quantiser
@@ -149,7 +165,16 @@ x264_t *x264_encoder_open(x264_param_t *param)
     while ((1 << h->log2_max_frame_num) <= (h->keyint < 65536 ? h->keyint : 65535) && h->log2_max_frame_num < 16) h->log2_max_frame_num++;
 
     x264gpu_config cfg = {};
-    cfg.width = p.i_width; cfg.height = p.i_height; cfg.streams = 1; cfg.refs = p.i_frame_reference;
+    // GOP-parallel factor: bounded by the device ring (keyint x G pictures) staying under 24 GB
+    h->G = p.i_threads;
+    {
+        const double pic = (double)p.i_width * p.i_height * 1.5;
+        while (h->G > 1 && pic * h->keyint * h->G > 24e9) h->G--;
+        if (h->keyint >= (1 << 20)) h->G = 1;                  // "infinite" keyint: nothing to run in parallel
+        if (h->G != p.i_threads) xlog(&p, X264_LOG_INFO, "threads %d -> %d (GOP ring of keyint %d pictures)\n", p.i_threads, h->G, h->keyint);
+        p.i_threads = h->G;
+    }
+    cfg.width = p.i_width; cfg.height = p.i_height; cfg.streams = h->G; cfg.refs = p.i_frame_reference;
     cfg.qp_i = h->qp_i; cfg.qp_p = h->qp_p; cfg.me_range = p.analyse.i_me_range; cfg.subme = p.analyse.i_subpel_refine;
     cfg.deblock = p.b_deblocking_filter; cfg.deblock_alpha = p.i_deblocking_filter_alphac0; cfg.deblock_beta = p.i_deblocking_filter_beta;
     cfg.chroma_qp_offset = p.analyse.i_chroma_qp_offset;
@@ -163,13 +188,15 @@ x264_t *x264_encoder_open(x264_param_t *param)
     size_t insz = (size_t)p.i_width * p.i_height * 3 / 2;
     if (x264gpu_encoder_create(&h->gpu, &cfg) != X264GPU_OK ||
         x264gpu_malloc((void **)&h->d_in, insz) != X264GPU_OK ||
-        x264gpu_malloc((void **)&h->d_mb, (size_t)h->nmb * sizeof(x264gpu_mb)) != X264GPU_OK ||
-        x264gpu_malloc((void **)&h->d_lv, (size_t)h->nmb * X264GPU_MB_LEVELS * sizeof(int16_t)) != X264GPU_OK) {
+        x264gpu_malloc((void **)&h->d_mb, (size_t)h->G * h->nmb * sizeof(x264gpu_mb)) != X264GPU_OK ||
+        x264gpu_malloc((void **)&h->d_lv, (size_t)h->G * h->nmb * X264GPU_MB_LEVELS * sizeof(int16_t)) != X264GPU_OK ||
+        (h->G > 1 && x264gpu_malloc((void **)&h->d_ring, (size_t)h->G * h->keyint * insz) != X264GPU_OK)) {
         xlog(&p, X264_LOG_ERROR, "GPU encoder setup failed: %s\n", x264gpu_last_error());
         x264_encoder_close(h);
         return nullptr;
     }
-    h->h_in.resize(insz); h->h_mb.resize(h->nmb); h->h_lv.resize((size_t)h->nmb * X264GPU_MB_LEVELS);
+    h->h_in.resize(insz); h->h_mb.resize((size_t)h->G * h->nmb); h->h_lv.resize((size_t)h->G * h->nmb * X264GPU_MB_LEVELS);
+    if (h->G > 1) { h->slotbuf.resize((size_t)h->G * h->keyint); h->slot_have.assign((size_t)h->G * h->keyint, 0); }
     xlog(&p, X264_LOG_INFO, "MI355X hot path: %dx%d, %d MBs, CQP I:%d P:%d, keyint %d, level %d\n", p.i_width, p.i_height, h->nmb,
          h->qp_i, h->qp_p, h->keyint, h->level_idc);
     return h;
@@ -204,11 +231,132 @@ int x264_encoder_headers(x264_t *h, x264_nal_t **pp_nal, int *pi_nal)
     return (int)h->out.size();
 }
 
+// ---- GOP-parallel mode ------------------------------------------------------------------------------------------------
+// Frame i of the stream belongs to GOP g = i / keyint at position t = i % keyint; GOP g runs on slot g % G of batch g / G.
+// Pictures are uploaded into a position-major device ring, so the G pictures of one position are contiguous = one
+// x264gpu_encode_frames call.  A position is coded when the batch's last GOP delivers it (or at flush with the slots that
+// exist); the G slices are entropy-coded by a thread each.  Frames leave in stream order, one per call.
+static void code_position(x264_t *h, int batch, int t, int nslots_with_t)
+{
+    const x264_param_t &p = h->param;
+    const size_t insz = (size_t)p.i_width * p.i_height * 3 / 2;
+    const int st = t == 0 ? X264GPU_SLICE_I : X264GPU_SLICE_P, G = h->G;
+    if (x264gpu_encode_frames(h->gpu, h->d_ring + (size_t)t * G * insz, st, h->d_mb, h->d_lv, nullptr) != X264GPU_OK ||
+        x264gpu_memcpy_d2h(h->h_mb.data(), h->d_mb, (size_t)G * h->nmb * sizeof(x264gpu_mb), nullptr) != X264GPU_OK ||
+        x264gpu_memcpy_d2h(h->h_lv.data(), h->d_lv, (size_t)G * h->nmb * X264GPU_MB_LEVELS * sizeof(int16_t), nullptr) != X264GPU_OK) {
+        xlog(&p, X264_LOG_ERROR, "x264_encoder_encode: GPU hot path failed: %s\n", x264gpu_last_error());
+        return;
+    }
+    auto work = [&](int s) {
+        x264_t::Coded &c = h->slotbuf[(size_t)s * h->keyint + t];
+        c.bytes.clear(); c.off.clear(); c.types.clear();
+        c.idr = t == 0;
+        const long gop = (long)batch * G + s;
+        if (c.idr && p.b_repeat_headers) {
+            const bool annexb = p.b_annexb != 0;
+            c.off.push_back(c.bytes.size()); c.types.push_back(7); write_sps(c.bytes, make_sps(h), annexb);
+            c.off.push_back(c.bytes.size()); c.types.push_back(8); write_pps(c.bytes, make_pps(h), annexb);
+            if (gop == 0) { c.off.push_back(c.bytes.size()); c.types.push_back(6); write_sei_version(c.bytes, kSeiText, annexb); }
+        }
+        SliceParams sp = {};
+        sp.mbw = h->mbw; sp.mbh = h->mbh; sp.slice_type = st; sp.qp = c.idr ? h->qp_i : h->qp_p; sp.pic_init_qp = h->pic_init_qp;
+        sp.frame_num = t & ((1 << h->log2_max_frame_num) - 1); sp.log2_max_frame_num = h->log2_max_frame_num;
+        sp.idr = c.idr; sp.idr_pic_id = (int)(gop & 0xffff); sp.nal_ref_idc = c.idr ? 3 : 2; sp.pps_id = p.i_sps_id;
+        sp.num_ref_default = p.i_frame_reference;
+        sp.num_ref = t < p.i_frame_reference ? (t > 0 ? t : 1) : p.i_frame_reference;
+        sp.disable_deblock_idc = p.b_deblocking_filter ? 0 : 1;
+        sp.alpha_off_div2 = p.i_deblocking_filter_alphac0; sp.beta_off_div2 = p.i_deblocking_filter_beta;
+        sp.transform8x8_mode = p.analyse.b_transform_8x8;
+        c.off.push_back(c.bytes.size()); c.types.push_back(c.idr ? 5 : 1);
+        write_slice(c.bytes, sp, h->h_mb.data() + (size_t)s * h->nmb, h->h_lv.data() + (size_t)s * h->nmb * X264GPU_MB_LEVELS,
+                    p.b_annexb != 0, c.off.size() == 1, nullptr);
+        h->slot_have[(size_t)s * h->keyint + t] = 1;
+    };
+    const unsigned hw = std::thread::hardware_concurrency();
+    const int nthr = (int)(hw ? (hw < (unsigned)nslots_with_t ? hw : (unsigned)nslots_with_t) : 1);
+    if (nthr <= 1) { for (int s = 0; s < nslots_with_t; s++) work(s); return; }
+    std::vector<std::thread> pool;
+    for (int th = 0; th < nthr; th++) pool.emplace_back([&, th]() { for (int s = th; s < nslots_with_t; s += nthr) work(s); });
+    for (auto &th : pool) th.join();
+}
+
+// frames of the batch being gathered move to the ordered output queue once every earlier frame is there
+static void drain_batch(x264_t *h, long batch_first_frame, long frames_in_batch)
+{
+    const int K = h->keyint;
+    while ((long)(h->emitted + (long)h->ready.size()) < batch_first_frame + frames_in_batch) {
+        const long j = h->emitted + (long)h->ready.size() - batch_first_frame;     // index inside the batch
+        if (j < 0) break;
+        const size_t idx = (size_t)(j / K) * K + (size_t)(j % K);
+        if (!h->slot_have[idx]) break;
+        h->ready.push_back(std::move(h->slotbuf[idx]));
+        h->slot_have[idx] = 0;
+    }
+}
+
+static int encode_gop_parallel(x264_t *h, x264_nal_t **pp_nal, int *pi_nal, x264_picture_t *pic_in, x264_picture_t *pic_out, bool resident)
+{
+    const x264_param_t &p = h->param;
+    const int G = h->G, K = h->keyint;
+    const size_t insz = (size_t)p.i_width * p.i_height * 3 / 2;
+    const long per_batch = (long)G * K;
+    if (pic_in) {
+        if (h->flushed) { xlog(&p, X264_LOG_ERROR, "x264_encoder_encode: pictures after a flush are not supported in GOP-parallel mode\n"); return -1; }
+        const long i = h->submitted, b = i / per_batch, r = i % per_batch;
+        const int s = (int)(r / K), t = (int)(r % K);
+        // a new batch may only start gathering once the previous one is fully coded and drained into the output queue
+        uint8_t *dst = h->d_ring + ((size_t)t * G + s) * insz;
+        const void *src = resident ? (const void *)h->d_in : (const void *)h->h_in.data();
+        if ((resident ? x264gpu_memcpy_d2d(dst, src, insz, nullptr) : x264gpu_memcpy_h2d(dst, src, insz, nullptr)) != X264GPU_OK) {
+            xlog(&p, X264_LOG_ERROR, "x264_encoder_encode: upload failed: %s\n", x264gpu_last_error());
+            return -1;
+        }
+        h->pts.push_back(pic_in->i_pts);
+        h->submitted++;
+        if (s == G - 1) {                                      // the batch's last GOP delivers position t: every slot has it
+            code_position(h, (int)b, t, G);
+            h->next_pos = t + 1 == K ? 0 : t + 1;
+        }
+        drain_batch(h, b * per_batch, r + 1);
+    } else {
+        // flush: code what the partly gathered batch holds, position by position, with the slots that have that position
+        const long i = h->submitted, b = i == 0 ? 0 : (i - 1) / per_batch, r = i - b * per_batch;    // r frames in the last batch
+        if (!h->flushed && r > 0 && !(r == per_batch && h->next_pos == 0)) {
+            const int full = (int)(r / K), part = (int)(r % K);            // `full` complete GOPs, then `part` frames
+            for (int t = h->next_pos; t < K; t++) {
+                const int nslots = full + (t < part ? 1 : 0);
+                if (nslots <= 0) break;
+                code_position(h, (int)b, t, nslots);
+            }
+            h->next_pos = 0;
+        }
+        h->flushed = true;
+        drain_batch(h, b * per_batch, r);
+    }
+    if (h->ready.empty()) return 0;
+    // ---- emit frame h->emitted ----
+    x264_t::Coded c = std::move(h->ready.front());
+    h->ready.pop_front();
+    h->out = std::move(c.bytes);
+    h->nal_off = c.off;
+    publish_nals(h, pp_nal, pi_nal, c.types);
+    if (pic_out) {
+        x264_picture_init(pic_out);
+        pic_out->i_type = c.idr ? X264_TYPE_IDR : X264_TYPE_P;
+        pic_out->b_keyframe = c.idr;
+        pic_out->i_pts = h->pts.front(); pic_out->i_dts = h->pts.front();
+    }
+    h->pts.pop_front();
+    h->emitted++;
+    h->frame_no++;
+    return (int)h->out.size();
+}
+
 int x264_encoder_encode(x264_t *h, x264_nal_t **pp_nal, int *pi_nal, x264_picture_t *pic_in, x264_picture_t *pic_out)
 {
     if (!h || !pp_nal || !pi_nal) return -1;
     *pi_nal = 0; *pp_nal = nullptr;
-    if (!pic_in) return 0;                       // flush: nothing is ever delayed (no B-frames, no lookahead)
+    if (!pic_in) return h->G > 1 ? encode_gop_parallel(h, pp_nal, pi_nal, nullptr, pic_out, false) : 0;   // flush
     const x264_param_t &p = h->param;
     const int w = p.i_width, ht = p.i_height;
     if ((pic_in->img.i_csp & X264_CSP_MASK) != X264_CSP_I420 || pic_in->img.i_plane < 3) {
@@ -225,6 +373,7 @@ int x264_encoder_encode(x264_t *h, x264_nal_t **pp_nal, int *pi_nal, x264_pictur
         const uint8_t *src = pic_in->img.plane[pl];
         for (int y = 0; y < ph; y++, dst += pw, src += pic_in->img.i_stride[pl]) memcpy(dst, src, pw);
     }
+    if (h->G > 1) return encode_gop_parallel(h, pp_nal, pi_nal, pic_in, pic_out, resident);
     bool idr = h->frames_since_idr == 0 || h->frames_since_idr >= h->keyint || pic_in->i_type == X264_TYPE_IDR || pic_in->i_type == X264_TYPE_KEYFRAME;
     if (idr) { h->frames_since_idr = 0; h->frame_num = 0; }
     int st = idr ? X264GPU_SLICE_I : X264GPU_SLICE_P;
@@ -269,7 +418,7 @@ int x264_encoder_encode(x264_t *h, x264_nal_t **pp_nal, int *pi_nal, x264_pictur
     return (int)h->out.size();
 }
 
-int x264_encoder_delayed_frames(x264_t *h) { (void)h; return 0; }
+int x264_encoder_delayed_frames(x264_t *h) { return h && h->G > 1 ? (int)(h->submitted - h->emitted) : 0; }
 
 void x264_encoder_close(x264_t *h)
 {
@@ -278,6 +427,7 @@ void x264_encoder_close(x264_t *h)
     if (h->d_in) x264gpu_free(h->d_in);
     if (h->d_mb) x264gpu_free(h->d_mb);
     if (h->d_lv) x264gpu_free(h->d_lv);
+    if (h->d_ring) x264gpu_free(h->d_ring);
     delete h;
 }
 

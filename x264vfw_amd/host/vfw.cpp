@@ -126,10 +126,22 @@ LRESULT compress_query(CODEC *codec, BITMAPINFO *in, BITMAPINFO *out)
     return ICERR_OK;
 }
 
+int encode_frame(CODEC *codec, x264_picture_t *pic, x264_picture_t *pic_out, uint8_t *buf, DWORD buf_size, int *got_picture);
+
 LRESULT compress_end(CODEC *codec)
 {
     if (codec->h) {
-        x264_encoder_close(codec->h);            /* nothing is ever delayed on this path (no B-frames) */
+        if (!codec->b_encoder_error && codec->b_cli_output && x264_encoder_delayed_frames(codec->h)) {
+            /* flush delayed frames into the output file (codec.c:1842-1856; b_flush_delayed == file output here):
+             * GOP-parallel mode (--threads G) holds (G-1)*keyint frames back */
+            x264_picture_t pic_out;
+            int got_picture;
+            vlog(codec, X264_LOG_DEBUG, "flush delayed frames\n");
+            do {
+                if (encode_frame(codec, nullptr, &pic_out, nullptr, 0, &got_picture) < 0) break;
+            } while (x264_encoder_delayed_frames(codec->h));
+        }
+        x264_encoder_close(codec->h);
         codec->h = nullptr;
     }
     x264_picture_clean(&codec->conv_pic);
@@ -267,6 +279,12 @@ LRESULT compress_begin(CODEC *codec, BITMAPINFO *in, BITMAPINFO *out)
             }
     }
     param.b_annexb = 1; param.b_repeat_headers = 1;                         /* VFW needs SPS/PPS before each keyframe */
+    if (out_file == "-" && param.i_threads > 1) {
+        /* the VfW buffer cannot take late frames (the reference warns "few frames probably would be lost", codec.c:1800-1810);
+         * GOP-parallel coding is for file output, where compress_end flushes */
+        vlog(codec, X264_LOG_WARNING, "--threads %d needs --output <file> (frames would arrive late): threads 1\n", param.i_threads);
+        param.i_threads = 1;
+    }
     if (out_file != "-") {                                                  /* select_output (codec.c:1111-1164) */
         std::string ext = muxer;
         if (muxer == "auto") { size_t dot = out_file.rfind('.'); ext = dot == std::string::npos ? "" : out_file.substr(dot + 1); }

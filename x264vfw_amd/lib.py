@@ -56,6 +56,7 @@ _SIGS = {
     "x264gpu_free": (_i, [_vp]),
     "x264gpu_memcpy_h2d": (_i, [_vp, _vp, _sz, _vp]),
     "x264gpu_memcpy_d2h": (_i, [_vp, _vp, _sz, _vp]),
+    "x264gpu_memcpy_d2d": (_i, [_vp, _vp, _sz, _vp]),
     "x264gpu_memset": (_i, [_vp, _i, _sz, _vp]),
     "x264gpu_stream_sync": (_i, [_vp]),
     "x264gpu_pixel_metric": (_i, [_i, _vp, _vp, _i, _i, _i, _vp, _vp]),
