@@ -202,3 +202,35 @@ def test_host_abi_exports_every_declared_symbol():
     assert len(declared) > 15, declared
     missing = [d for d in sorted(declared) if not hasattr(H, d)]
     assert not missing, f"declared but not exported: {missing}"
+
+
+@pytest.mark.parametrize("seed", [21, 22, 23])
+def test_cavlc_closed_loop_random(seed):
+    """randomised closed loop on the CPU: oracle records -> host CAVLC -> checker decoder == oracle reconstruction, over random
+    sizes, quantisers 0..51 and toolset combinations (partitions, refs, 8x8 transform, Intra_8x8, dia/hex, deblock offsets)"""
+    import random
+    rnd = random.Random(seed)
+    for it in range(12):
+        w = max(16, 16 * rnd.randint(1, 9) - rnd.choice([0, 0, 2, 6, 14]))
+        h = max(16, 16 * rnd.randint(1, 7) - rnd.choice([0, 0, 2, 8, 12]))
+        dct = rnd.randint(0, 1)
+        kw = dict(refs=rnd.randint(1, 4), partitions=rnd.choice([0, 1, 2, 3, 4, 5, 6, 7]) if dct else rnd.choice([0, 1, 2, 3]), dct8x8=dct,
+                  subme=rnd.choice([0, 2, 5, 7]), me_method=rnd.randint(0, 1), qp_i=rnd.randint(0, 51), qp_p=rnd.randint(0, 51),
+                  deblock=rnd.randint(0, 1), dct_decimate=rnd.randint(0, 1), chroma_qp_offset=rnd.randint(-6, 6))
+        nfr = rnd.randint(2, 6)
+        frames = synth_frames(w, h, nfr, seed=rnd.randint(0, 10 ** 6))
+        cfg = O.default_config(w, h, **kw)
+        enc = O.OracleEncoder(cfg)
+        mbw, mbh = (w + 15) // 16, (h + 15) // 16
+        stream = HL.write_headers(w, h, pic_init_qp=cfg.qp_p, cqo=cfg.chroma_qp_offset, num_ref=cfg.refs, t8x8=cfg.dct8x8)
+        recons = []
+        for i, f in enumerate(frames):
+            idr = i == 0
+            mbs, lv = enc.encode(f, 2 if idr else 0)
+            stream += HL.write_slice(mbw, mbh, 2 if idr else 0, cfg.qp_i if idr else cfg.qp_p, cfg.qp_p, i, 8, int(idr), 0,
+                                     0 if cfg.deblock else 1, mbs, lv, num_ref=max(1, min(cfg.refs, i)), num_ref_default=cfg.refs, t8x8=cfg.dct8x8)[0]
+            recons.append(enc.recon())
+        dec = O.h264_decode(stream, nfr, w, h)
+        assert len(dec) == nfr, f"seed {seed} case {it}: {w}x{h} {kw}: decoder returned {len(dec)} pictures"
+        for i in range(nfr):
+            np.testing.assert_array_equal(dec[i], recons[i], err_msg=f"seed {seed} case {it}: {w}x{h} {kw} picture {i}")
