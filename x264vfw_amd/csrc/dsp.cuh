@@ -84,6 +84,15 @@ __device__ __forceinline__ unsigned wave_min_u32(unsigned v)
     return a < c ? a : c;
 }
 
+__device__ __forceinline__ unsigned row16_min_u32(unsigned v)      // min over a DPP row of quad-uniform values
+{
+    unsigned t;
+    t = (unsigned)dpp<DPP_ROW_HALF_MIRROR>((int)v); v = t < v ? t : v;
+    t = (unsigned)dpp<DPP_ROW_MIRROR>((int)v); v = t < v ? t : v;
+    return v;
+}
+
+
 // transpose a 4x4 tile held as 4 registers x 4 quad lanes (lane j, reg c) -> (lane c, reg j)
 __device__ __forceinline__ void quad_transpose(int v[4], int lane)
 {

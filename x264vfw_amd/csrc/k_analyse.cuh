@@ -151,10 +151,9 @@ __device__ __forceinline__ int sub_sad_row16_hpel(const uint32_t *buf, int n, in
 }
 
 // ------------------------------------------------------------------------------------------------
-// Sub-partition search (P16x8 / P8x16 / P8x8) in the Z layout: every partition of a shape is searched at
-// the same time, each on its own lanes (an 8x8 block is one DPP row of 16 lanes), with lane-private motion
-// state and predicated updates, so the wave runs ONE instruction stream for 2 or 4 independent hexagon /
-// square / half-pel / quarter-pel searches.  Restates oracle me_search_block for the partitions of a shape.
+// Sub-partition search (P16x8 / P8x16 / P8x8): every partition of a shape is searched at the same time, each on its own
+// lanes, with partition-private motion state and predicated updates, so the wave runs ONE instruction stream for 2 or 4
+// independent hexagon / square / half-pel / quarter-pel searches.  Restates oracle me_search_block for the partitions of a shape.
 // ------------------------------------------------------------------------------------------------
 struct PartCtx {
     const uint8_t *win; int wx0, wy0;          // LDS search window (full-pel plane) and its picture origin
@@ -165,36 +164,90 @@ struct PartCtx {
     int fmin0, fmax0, fmin1, fmax1, smin0, smax0, smin1, smax1;
     int me_range, me_method, hp_it, qp_it, lane;
     uint32_t *sub;                             // LDS sub-pel neighbourhood buffer (SUB_DWORDS)
+    const uint8_t *fenc; int fs;               // source macroblock (for the candidate-parallel 8x8 search)
 };
-__device__ __forceinline__ int part_sum(int v, int shape)
-{
-    int r = row16_sum(v);
-    if (shape == 1) r += __shfl_xor(r, 16);
-    else if (shape == 2) r += __shfl_xor(r, 32);
-    return r;
-}
 __device__ __forceinline__ int pc_mvcost(const PartCtx &c, int qx, int qy) { return c.cx[qx - c.cbx + 96] + c.cy[qy - c.cby + 96]; }
-__device__ __forceinline__ int pc_fpel_cost(const PartCtx &c, int fx, int fy, int shape)
+// ------------------------------------------------------------------------------------------------
+// Candidate-parallel partition search: the lanes of a partition split into four groups that evaluate four CANDIDATE vectors at
+// once; a lane holds 16 pixels of its partition per candidate (as in the 16x16 search).  Per-partition search state is uniform
+// over the partition's lanes.  Same arithmetic and tie-breaks as oracle me_search_block.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ int sad8_lds(const uint8_t *base, int off, uint32_t e0, uint32_t e1)
 {
-    const int off = (c.py + c.zy + fy - c.wy0) * WIN_STRIDE + (c.px + c.zx + fx - c.wx0);
-    const uint32_t *w = (const uint32_t *)(c.win + (off & ~3));
-    const uint32_t ref = __builtin_amdgcn_alignbyte(w[1], w[0], off & 3);
-    return part_sum(sad4(ref, c.cz), shape) + pc_mvcost(c, fx * 4, fy * 4);
+    const uint32_t *w = (const uint32_t *)(base + (off & ~3));
+    const int sh = off & 3;
+    const uint32_t w0 = w[0], w1 = w[1], w2 = w[2];
+    unsigned sd = __builtin_amdgcn_sad_u8(__builtin_amdgcn_alignbyte(w1, w0, sh), e0, 0u);
+    return (int)__builtin_amdgcn_sad_u8(__builtin_amdgcn_alignbyte(w2, w1, sh), e1, sd);
 }
-// returns the partition cost (uniform over the partition's lanes) and this lane's partition mv (qpel)
-template <int M>
-__device__ int search_shape(const PartCtx &c, int shape, int c0x, int c0y, int &out_mx, int &out_my)
+// 8 pixels of row y at picture x..x+7 displaced by the quarter-pel vector, from the staged sub-pel neighbourhood
+__device__ __forceinline__ void sub_row8(const uint32_t *buf, int n, int rwl, int x0, int y0, int x, int y, int mvx, int mvy, uint32_t out[2])
 {
+    const int idx = ((mvy & 3) << 2) | (mvx & 3);
+    const int pl0 = (kQpelPlane0Packed >> (2 * idx)) & 3, pl1 = (kQpelPlane1Packed >> (2 * idx)) & 3;
+    const int bx = x + (mvx >> 2) - x0, by = y + (mvy >> 2) - y0;
+    const int o0 = (((by + ((mvy & 3) == 3 ? 1 : 0)) << rwl) << 2) + bx, o1 = ((by << rwl) << 2) + bx + ((mvx & 3) == 3 ? 1 : 0);
+    const uint32_t *wa = buf + pl0 * n + (o0 >> 2), *wb = buf + pl1 * n + (o1 >> 2);
+    const uint32_t a0 = wa[0], a1 = wa[1], a2 = wa[2], b0 = wb[0], b1 = wb[1], b2 = wb[2];
+    const uint32_t pa0 = __builtin_amdgcn_alignbyte(a1, a0, o0 & 3), pa1 = __builtin_amdgcn_alignbyte(a2, a1, o0 & 3);
+    const uint32_t pb0 = __builtin_amdgcn_alignbyte(b1, b0, o1 & 3), pb1 = __builtin_amdgcn_alignbyte(b2, b1, o1 & 3);
+    out[0] = (idx & 5) ? avg4_u8(pa0, pb0) : pa0;
+    out[1] = (idx & 5) ? avg4_u8(pa1, pb1) : pa1;
+}
+// half share of the SATD of an 8x8 partition held as two rows x 8 pixels per lane (quad = the partition): 4x4 blocks are
+// (column half) x (lane pair); vertical butterflies: the two rows in the lane, then lane^1
+__device__ __forceinline__ int satd8x8_2rows_half(const uint32_t e0[2], const uint32_t e1[2], const uint32_t p0[2], const uint32_t p1[2], s16x2 sg1)
+{
+    s16x2 acc = as_s16x2(0u);
+#pragma unroll
+    for (int b = 0; b < 2; b++) {
+        const s16x2 da0 = pk_even(e0[b]) - pk_even(p0[b]), db0 = pk_odd(e0[b]) - pk_odd(p0[b]);
+        const s16x2 da1 = pk_even(e1[b]) - pk_even(p1[b]), db1 = pk_odd(e1[b]) - pk_odd(p1[b]);
+        const s16x2 u0 = da0 + db0, v0 = da0 - db0, u1 = da1 + db1, v1 = da1 - db1;
+        s16x2 t[4] = { u0 + u1, u0 - u1, v0 + v1, v0 - v1 };
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            s16x2 x = pk_bfly<DPP_XOR1>(t[i], sg1);
+            x = __builtin_elementwise_max(x, -x);
+            acc += __builtin_elementwise_max(x, as_s16x2(__builtin_amdgcn_alignbit(as_u32(x), as_u32(x), 16)));     // <= 8 * 4080
+        }
+    }
+    return (int)(as_u32(acc) & 0xffffu);
+}
+
+// SHAPE 3: four 8x8 partitions (one per DPP row, four lanes per candidate); 1: two 16x8; 2: two 8x16 (32 lanes per partition,
+// eight lanes per candidate).  A lane holds two 8-pixel segments of its partition: rows (2s, 2s+1) for the 8-wide shapes,
+// the left and right half of row s for 16x8.
+template <int M>
+__device__ int search_parts(const PartCtx &c, const int SHAPE, int c0x, int c0y, int &out_mx, int &out_my)
+{
+    const int GL = SHAPE == 3 ? 4 : 8;             // SHAPE is wave-uniform: one copy of the code serves the three shapes
+    const int lane = c.lane, part = SHAPE == 3 ? lane >> 4 : lane >> 5, cnd = SHAPE == 3 ? (lane >> 2) & 3 : (lane >> 3) & 3, sr = lane & (GL - 1);
+    const int ox = SHAPE == 3 ? (part & 1) * 8 : SHAPE == 2 ? part * 8 : 0, oy = SHAPE == 3 ? (part >> 1) * 8 : SHAPE == 1 ? part * 8 : 0;
+    const int y0 = oy + (SHAPE == 1 ? sr : 2 * sr), y1 = SHAPE == 1 ? y0 : y0 + 1, x1 = SHAPE == 1 ? 8 : 0;
+    uint32_t e0[2], e1[2];
+    { const uint2 a = *(const uint2 *)(c.fenc + (size_t)y0 * c.fs + ox), b = *(const uint2 *)(c.fenc + (size_t)y1 * c.fs + ox + x1);
+      e0[0] = a.x; e0[1] = a.y; e1[0] = b.x; e1[1] = b.y; }
+    const int wb0 = (c.py + y0 - c.wy0) * WIN_STRIDE + (c.px + ox - c.wx0), wb1 = (c.py + y1 - c.wy0) * WIN_STRIDE + (c.px + ox + x1 - c.wx0);
+    auto gsum = [&](int v) { v = quad_sum(v); const int w = xor4(v); return GL == 8 ? v + w : v; };  // over the candidate's lanes
+    auto cmin = [&](unsigned k) {                                                                        // over the four candidates of a partition
+        if (SHAPE == 3) return row16_min_u32(k);
+        unsigned t = (unsigned)__builtin_amdgcn_update_dpp(0, (int)k, 0x128, 0xf, 0xf, true);           // row_ror:8: the other group of this DPP row
+        k = t < k ? t : k;
+        t = (unsigned)__shfl_xor((int)k, 16);
+        return t < k ? t : k;
+    };
+    // candidate cost (uniform over the candidate's lanes): SAD of the partition at full-pel (fx,fy) + mv cost
+#define FPC(fx, fy) (gsum(sad8_lds(c.win, wb0 + (fy) * WIN_STRIDE + (fx), e0[0], e0[1]) + sad8_lds(c.win, wb1 + (fy) * WIN_STRIDE + (fx), e1[0], e1[1])) + \
+                     pc_mvcost(c, (fx) * 4, (fy) * 4))
     int bx = c0x, by = c0y, bcost;
     if (c.me_method == 0) {
-        // X264_ME_DIA: radius-1 diamond (0,-1) (0,1) (-1,0) (1,0), up to merange steps, centre wins ties, no square refine
-        bcost = pc_fpel_cost(c, bx, by, shape);
+        bcost = FPC(bx, by);
         bool running = true;
         for (int it = c.me_range; it > 0; it--) {
             if (!__any(running)) break;
-            unsigned kk = 0xffffffffu;
-            for (int q = 0; q < 4; q++)
-                kk = min(kk, ((unsigned)pc_fpel_cost(c, bx + (q == 2 ? -1 : q == 3 ? 1 : 0), by + (q == 0 ? -1 : q == 1 ? 1 : 0), shape) << 2) | (unsigned)q);
+            const int cx = bx + (cnd == 2 ? -1 : cnd == 3 ? 1 : 0), cy = by + (cnd == 0 ? -1 : cnd == 1 ? 1 : 0);
+            const unsigned kk = cmin(((unsigned)FPC(cx, cy) << 2) | (unsigned)cnd);
             if (running) {
                 if ((int)(kk >> 2) < bcost) {
                     const int q = kk & 3;
@@ -205,16 +258,26 @@ __device__ int search_shape(const PartCtx &c, int shape, int c0x, int c0y, int &
             }
         }
     } else {
-        unsigned key = (unsigned)pc_fpel_cost(c, bx, by, shape) << 3;
-        for (int i = 1; i <= 6; i++) key = min(key, ((unsigned)pc_fpel_cost(c, bx + hex_dx(i), by + hex_dy(i), shape) << 3) | (unsigned)(i + 1));
+        unsigned key = (unsigned)FPC(bx, by) << 3;
+        {   // first ring: hex2[1..6], tags 2..7, in two passes of four candidates
+            int i = 1 + cnd;
+            unsigned kk = ((unsigned)FPC(bx + hex_dx(i), by + hex_dy(i)) << 3) | (unsigned)(i + 1);
+            key = min(key, cmin(kk));
+            i = 5 + (cnd & 1);
+            kk = ((unsigned)FPC(bx + hex_dx(i), by + hex_dy(i)) << 3) | (unsigned)(i + 1);
+            if (cnd >= 2) kk = 0xffffffffu;
+            key = min(key, cmin(kk));
+        }
         bool running = (key & 7) != 0;
         int dir = running ? (int)(key & 7) - 2 : 0;
         if (running) { bx += hex_dx(dir + 1); by += hex_dy(dir + 1); }
         for (int it = (c.me_range >> 1) - 1; it > 0; it--) {
             if (!__any(running)) break;
             running = running && bx >= c.fmin0 && bx <= c.fmax0 && by >= c.fmin1 && by <= c.fmax1;
-            unsigned k2 = key & ~7u;
-            for (int t = 0; t < 3; t++) k2 = min(k2, ((unsigned)pc_fpel_cost(c, bx + hex_dx(dir + t), by + hex_dy(dir + t), shape) << 3) | (unsigned)(t + 1));
+            const int cc = cnd < 3 ? cnd : 0;
+            unsigned kk = ((unsigned)FPC(bx + hex_dx(dir + cc), by + hex_dy(dir + cc)) << 3) | (unsigned)(cc + 1);
+            if (cnd >= 3) kk = 0xffffffffu;
+            const unsigned k2 = min(key & ~7u, cmin(kk));
             if (running) {
                 key = k2;
                 if (!(key & 7)) running = false;
@@ -226,74 +289,83 @@ __device__ int search_shape(const PartCtx &c, int shape, int c0x, int c0y, int &
             }
         }
         bcost = (int)(key >> 3);
-        {
+        {   // square refine: square1[1..8], first strictly-better candidate in order wins
             unsigned sk = (unsigned)bcost << 4;
-            for (int q = 1; q <= 8; q++) sk = min(sk, ((unsigned)pc_fpel_cost(c, bx + sq_dx(q), by + sq_dy(q), shape) << 4) | (unsigned)q);
+            int q = 1 + cnd;
+            sk = min(sk, cmin(((unsigned)FPC(bx + sq_dx(q), by + sq_dy(q)) << 4) | (unsigned)q));
+            q = 5 + cnd;
+            sk = min(sk, cmin(((unsigned)FPC(bx + sq_dx(q), by + sq_dy(q)) << 4) | (unsigned)q));
             const int bd = sk & 15;
             bcost = (int)(sk >> 4);
             if (bd) { bx += sq_dx(bd); by += sq_dy(bd); }
         }
     }
+#undef FPC
     int mx = bx * 4, my = by * 4;
     if (c.hp_it > 0) {
-        const s16x2 ze = pk_even(c.cz), zo = pk_odd(c.cz), sg1 = pk_sign(c.lane & 1), sg2 = pk_sign(c.lane & 2);
-        // stage this partition's sub-pel neighbourhood (origin follows the partition's own full-pel vector)
-        const int pw = shape == 1 ? 16 : 8, ph_ = shape == 2 ? 16 : 8;
-        const int rwl = SubGeo<M>::rwl(pw), rh = SubGeo<M>::rh(ph_), ncol = SubGeo<M>::ncol(pw), sn = rh << rwl;
-        const int pi = shape == 3 ? c.lane >> 4 : shape == 1 ? c.lane >> 5 : (c.lane >> 4) & 1;
-        const int li = shape == 3 ? c.lane & 15 : shape == 1 ? c.lane & 31 : (c.lane & 15) | ((c.lane >> 5) << 4);
-        const int partx = shape == 1 ? 0 : (c.zx & 8), party = shape == 2 ? 0 : (c.zy & 8);
-        const int sx0 = (c.px + partx + bx - M) & ~3, sy0 = c.py + party + by - M;
-        uint32_t *sb = c.sub + pi * 4 * sn;
+        const s16x2 sg1 = pk_sign(lane & 1), sg2 = pk_sign(lane & 2);
+        const int PW = SHAPE == 1 ? 16 : 8, PH = SHAPE == 2 ? 16 : 8, L = SHAPE == 3 ? 16 : 32;
+        const int rwl = SubGeo<M>::rwl(PW), rh = SubGeo<M>::rh(PH), ncol = SubGeo<M>::ncol(PW), sn = rh << rwl;
+        const int sx0 = (c.px + ox + bx - M) & ~3, sy0 = c.py + oy + by - M;
+        uint32_t *sb = c.sub + part * 4 * sn;
         __builtin_amdgcn_wave_barrier();
-        sub_stage<M>(sb, c.p00, c.pb, c.rs, sx0, sy0, rwl, rh, ncol, li, shape == 3 ? 16 : 32);
+        sub_stage<M>(sb, c.p00, c.pb, c.rs, sx0, sy0, rwl, rh, ncol, lane & (L - 1), L);
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_s_waitcnt(0xc07f);
-    #define SUBPX(qx, qy) sub_row4(sb, sn, rwl, sx0, sy0, c.px + c.zx, c.py + c.zy, (qx), (qy))
+        const int X0 = c.px + ox, Y0 = c.py + y0, X1 = X0 + x1, Y1 = c.py + y1;
+        // SATD of the partition for the prediction segments p0 / p1 (half share per lane, summed over the candidate's lanes)
+        auto satd_part = [&](const uint32_t p0[2], const uint32_t p1[2]) {
+            if (SHAPE == 1) {
+                const uint32_t e[4] = { e0[0], e0[1], e1[0], e1[1] }, p[4] = { p0[0], p0[1], p1[0], p1[1] };
+                return gsum(satd16x4_half_pk(e, p, sg1, sg2));
+            }
+            return gsum(satd8x8_2rows_half(e0, e1, p0, p1, sg1));
+        };
         bool hp_run = true;
         for (int it = c.hp_it; it > 0; it--) {
             if (!__any(hp_run)) break;
-            unsigned kk = 0xffffffffu;
-            uint32_t ph[4];
-#pragma unroll
-            for (int q = 0; q < 4; q++)
-                ph[q] = SUBPX(mx + (q == 2 ? -2 : q == 3 ? 2 : 0), my + (q == 0 ? -2 : q == 1 ? 2 : 0));
-#pragma unroll
-            for (int q = 0; q < 4; q++) {
-                const int cxq = mx + (q == 2 ? -2 : q == 3 ? 2 : 0), cyq = my + (q == 0 ? -2 : q == 1 ? 2 : 0);
-                const int cst = part_sum(sad4(ph[q], c.cz), shape) + pc_mvcost(c, cxq, cyq);
-                kk = min(kk, ((unsigned)cst << 2) | (unsigned)q);
-            }
+            const int cx = mx + (cnd == 2 ? -2 : cnd == 3 ? 2 : 0), cy = my + (cnd == 0 ? -2 : cnd == 1 ? 2 : 0);
+            uint32_t p0[2], p1[2];
+            sub_row8(sb, sn, rwl, sx0, sy0, X0, Y0, cx, cy, p0);
+            sub_row8(sb, sn, rwl, sx0, sy0, X1, Y1, cx, cy, p1);
+            unsigned sd = __builtin_amdgcn_sad_u8(p0[0], e0[0], 0u);
+            sd = __builtin_amdgcn_sad_u8(p0[1], e0[1], sd); sd = __builtin_amdgcn_sad_u8(p1[0], e1[0], sd); sd = __builtin_amdgcn_sad_u8(p1[1], e1[1], sd);
+            const unsigned kk = cmin(((unsigned)(gsum((int)sd) + pc_mvcost(c, cx, cy)) << 2) | (unsigned)cnd);
             if (hp_run && (int)(kk >> 2) < bcost) {
                 const int b = kk & 3;
                 bcost = (int)(kk >> 2);
                 mx += b == 2 ? -2 : b == 3 ? 2 : 0; my += b == 0 ? -2 : b == 1 ? 2 : 0;
             } else hp_run = false;
         }
-        {
-            bcost = part_sum(satd4_half_pk(ze, zo, SUBPX(mx, my), sg1, sg2), shape) + pc_mvcost(c, mx, my);
+        {   // SATD at the best half-pel position (every candidate group computes the same value)
+            uint32_t p0[2], p1[2];
+            sub_row8(sb, sn, rwl, sx0, sy0, X0, Y0, mx, my, p0);
+            sub_row8(sb, sn, rwl, sx0, sy0, X1, Y1, mx, my, p1);
+            bcost = satd_part(p0, p1) + pc_mvcost(c, mx, my);
         }
         int bdir = -1;
         bool qp_run = true;
         for (int it = c.qp_it; it > 0; it--) {
             if (!__any(qp_run)) break;
             qp_run = qp_run && !(my <= c.smin1 || my >= c.smax1 || mx <= c.smin0 || mx >= c.smax0);
-            const int odir = bdir, omx = mx, omy = my;
-            uint32_t pq[4];
-#pragma unroll
-            for (int q = 0; q < 4; q++)
-                pq[q] = SUBPX(omx + (q == 2 ? -1 : q == 3 ? 1 : 0), omy + (q == 0 ? -1 : q == 1 ? 1 : 0));
-#pragma unroll
-            for (int q = 0; q < 4; q++) {
-                const int cxq = omx + (q == 2 ? -1 : q == 3 ? 1 : 0), cyq = omy + (q == 0 ? -1 : q == 1 ? 1 : 0);
-                const int cst = part_sum(satd4_half_pk(ze, zo, pq[q], sg1, sg2), shape) + pc_mvcost(c, cxq, cyq);
-                if (qp_run && (q ^ 1) != odir && cst < bcost) { bcost = cst; mx = cxq; my = cyq; bdir = q; }
-            }
-            if (mx == omx && my == omy) qp_run = false;
+            const int cx = mx + (cnd == 2 ? -1 : cnd == 3 ? 1 : 0), cy = my + (cnd == 0 ? -1 : cnd == 1 ? 1 : 0);
+            uint32_t p0[2], p1[2];
+            sub_row8(sb, sn, rwl, sx0, sy0, X0, Y0, cx, cy, p0);
+            sub_row8(sb, sn, rwl, sx0, sy0, X1, Y1, cx, cy, p1);
+            unsigned kk = ((unsigned)(satd_part(p0, p1) + pc_mvcost(c, cx, cy)) << 2) | (unsigned)cnd;
+            if ((cnd ^ 1) == bdir) kk = 0xffffffffu;
+            kk = cmin(kk);
+            if (qp_run && (int)(kk >> 2) < bcost) {
+                bcost = (int)(kk >> 2);
+                bdir = kk & 3;
+                mx += bdir == 2 ? -1 : bdir == 3 ? 1 : 0; my += bdir == 0 ? -1 : bdir == 1 ? 1 : 0;
+            } else qp_run = false;
         }
-    #undef SUBPX
     }
-    out_mx = mx; out_my = my;
+    if (SHAPE == 2) {       // 8x16: partition k owns lanes 32k.., but callers index vectors by 8x8 block (lane >> 4): blocks 1, 3 are partition 1
+        const int src = ((lane >> 4) & 1) * 32;
+        out_mx = __shfl(mx, src); out_my = __shfl(my, src);
+    } else { out_mx = mx; out_my = my; }
     return bcost;
 }
 
@@ -542,7 +614,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(X264GPU_ANA
         pc.win = win; pc.wx0 = pwx0; pc.wy0 = pwy0; pc.cx = s_cost[wave][0]; pc.cy = s_cost[wave][1]; pc.cbx = c0x * 4; pc.cby = c0y * 4;
         pc.p00 = p00; pc.pb = k.plane_bytes; pc.rs = k.rs; pc.px = px; pc.py = py; pc.zx = zx; pc.zy = zy; pc.cz = cz;
         pc.fmin0 = fmin0; pc.fmax0 = fmax0; pc.fmin1 = fmin1; pc.fmax1 = fmax1; pc.smin0 = smin0; pc.smax0 = smax0; pc.smin1 = smin1; pc.smax1 = smax1;
-        pc.me_range = k.me_range; pc.me_method = k.me_method; pc.lane = lane; pc.sub = s_sub[wave];
+        pc.me_range = k.me_range; pc.me_method = k.me_method; pc.lane = lane; pc.sub = s_sub[wave]; pc.fenc = fenc; pc.fs = k.fs;
         const int sub = min(k.subme, 11);
         pc.hp_it = sub < 2 ? 0 : sub < 6 ? 1 : sub < 8 ? 2 : 4;
         pc.qp_it = sub < 4 ? 0 : sub == 4 ? 1 : sub < 8 ? 2 : 10;
@@ -550,11 +622,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(X264GPU_ANA
             const int shape = oi == 0 ? 3 : oi;
             if (oi > 0 && best_shape == 0) break;
             int smx, smy;
-            const int pcost = search_shape<M>(pc, shape, c0x, c0y, smx, smy);
+            const int pcost = search_parts<M>(pc, shape, c0x, c0y, smx, smy);
             int total = k.lambda * ((shape == 3 ? 8 : 2) + (shape == 3 ? 4 : 2) * ref_bits(k.nref, bref));
             if (shape == 3) total += __builtin_amdgcn_readlane(pcost, 0) + __builtin_amdgcn_readlane(pcost, 16) + __builtin_amdgcn_readlane(pcost, 32) + __builtin_amdgcn_readlane(pcost, 48);
             else if (shape == 1) total += __builtin_amdgcn_readlane(pcost, 0) + __builtin_amdgcn_readlane(pcost, 32);
-            else total += __builtin_amdgcn_readlane(pcost, 0) + __builtin_amdgcn_readlane(pcost, 16);
+            else total += __builtin_amdgcn_readlane(pcost, 0) + __builtin_amdgcn_readlane(pcost, 32);      // 8x16: partitions on lanes 0.. and 32..
             if (total < best_cost) { best_cost = total; best_shape = shape; lmx = smx; lmy = smy; }
         }
     }

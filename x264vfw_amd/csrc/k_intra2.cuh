@@ -44,14 +44,6 @@ struct Intra2LdsT {
     int progress[160];
 };
 
-__device__ __forceinline__ unsigned row16_min_u32(unsigned v)      // min over a DPP row of quad-uniform values
-{
-    unsigned t;
-    t = (unsigned)dpp<DPP_ROW_HALF_MIRROR>((int)v); v = t < v ? t : v;
-    t = (unsigned)dpp<DPP_ROW_MIRROR>((int)v); v = t < v ? t : v;
-    return v;
-}
-
 // ---- phase A: neighbours of macroblock (mbx,mby) into the slot's LDS, Intra16x16 decision -------------------------
 __device__ __forceinline__ void i2_phase_a(const EncK &k, SlotLds &S, int lane, int s, int mbx, int mby)
 {
