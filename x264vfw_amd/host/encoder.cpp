@@ -11,6 +11,7 @@
 #include <stdlib.h>
 #include <string.h>
 #include <deque>
+#include <memory>
 #include <string>
 #include <thread>
 
@@ -52,7 +53,12 @@ struct x264_t {
     std::deque<Coded> ready;             // coded frames [emitted, emitted + ready.size())
     std::deque<int64_t> pts;             // pts of frames not yet emitted
     std::vector<Coded> slotbuf;          // G x keyint frames of the batch being coded (index slot * keyint + pos)
-    std::vector<uint8_t> slot_have;      // which of them are coded
+    std::vector<uint8_t> slot_have;      // which of them are coded AND joined (written by the calling thread only)
+    int pool_t = -1, pool_nslots = 0;    // position / slot count the running CAVLC threads are coding
+    std::vector<std::thread> pool;       // CAVLC threads of the position coded last: they overlap the GPU work of the next one
+    std::vector<x264gpu_mb> h_mb2;       // second download buffers (the pool reads one pair while the next position lands in the other)
+    std::vector<int16_t> h_lv2;
+    int dl = 0;                          // download buffer in use for the NEXT position
 };
 
 static void xlog(const x264_param_t *p, int level, const char *fmt, ...)
@@ -196,7 +202,12 @@ x264_t *x264_encoder_open(x264_param_t *param)
         return nullptr;
     }
     h->h_in.resize(insz); h->h_mb.resize((size_t)h->G * h->nmb); h->h_lv.resize((size_t)h->G * h->nmb * X264GPU_MB_LEVELS);
-    if (h->G > 1) { h->slotbuf.resize((size_t)h->G * h->keyint); h->slot_have.assign((size_t)h->G * h->keyint, 0); }
+    if (h->G > 1) {
+        const size_t n = (size_t)h->G * h->keyint;
+        h->slotbuf.resize(n);
+        h->slot_have.assign(n, 0);
+        h->h_mb2.resize(h->h_mb.size()); h->h_lv2.resize(h->h_lv.size());
+    }
     xlog(&p, X264_LOG_INFO, "MI355X hot path: %dx%d, %d MBs, CQP I:%d P:%d, keyint %d, level %d\n", p.i_width, p.i_height, h->nmb,
          h->qp_i, h->qp_p, h->keyint, h->level_idc);
     return h;
@@ -236,18 +247,35 @@ int x264_encoder_headers(x264_t *h, x264_nal_t **pp_nal, int *pi_nal)
 // Pictures are uploaded into a position-major device ring, so the G pictures of one position are contiguous = one
 // x264gpu_encode_frames call.  A position is coded when the batch's last GOP delivers it (or at flush with the slots that
 // exist); the G slices are entropy-coded by a thread each.  Frames leave in stream order, one per call.
+static void join_pool(x264_t *h)
+{
+    for (auto &th : h->pool) th.join();
+    h->pool.clear();
+    // only now do the frames of that position count as coded (the workers never touch the bookkeeping)
+    for (int s = 0; s < h->pool_nslots; s++) h->slot_have[(size_t)s * h->keyint + h->pool_t] = 1;
+    h->pool_nslots = 0;
+}
+
 static void code_position(x264_t *h, int batch, int t, int nslots_with_t)
 {
     const x264_param_t &p = h->param;
     const size_t insz = (size_t)p.i_width * p.i_height * 3 / 2;
     const int st = t == 0 ? X264GPU_SLICE_I : X264GPU_SLICE_P, G = h->G;
+    // GPU + download of this position run while the CAVLC threads of the previous position are still coding from the
+    // other buffer pair
+    x264gpu_mb *hmb = h->dl ? h->h_mb2.data() : h->h_mb.data();
+    int16_t *hlv = h->dl ? h->h_lv2.data() : h->h_lv.data();
+    h->dl ^= 1;
     if (x264gpu_encode_frames(h->gpu, h->d_ring + (size_t)t * G * insz, st, h->d_mb, h->d_lv, nullptr) != X264GPU_OK ||
-        x264gpu_memcpy_d2h(h->h_mb.data(), h->d_mb, (size_t)G * h->nmb * sizeof(x264gpu_mb), nullptr) != X264GPU_OK ||
-        x264gpu_memcpy_d2h(h->h_lv.data(), h->d_lv, (size_t)G * h->nmb * X264GPU_MB_LEVELS * sizeof(int16_t), nullptr) != X264GPU_OK) {
+        x264gpu_memcpy_d2h(hmb, h->d_mb, (size_t)G * h->nmb * sizeof(x264gpu_mb), nullptr) != X264GPU_OK ||
+        x264gpu_memcpy_d2h(hlv, h->d_lv, (size_t)G * h->nmb * X264GPU_MB_LEVELS * sizeof(int16_t), nullptr) != X264GPU_OK) {
         xlog(&p, X264_LOG_ERROR, "x264_encoder_encode: GPU hot path failed: %s\n", x264gpu_last_error());
         return;
     }
-    auto work = [&](int s) {
+    join_pool(h);
+    auto work = [h, batch, t, st, hmb, hlv](int s) {
+        const x264_param_t &p = h->param;
+        const int G = h->G;
         x264_t::Coded &c = h->slotbuf[(size_t)s * h->keyint + t];
         c.bytes.clear(); c.off.clear(); c.types.clear();
         c.idr = t == 0;
@@ -268,27 +296,24 @@ static void code_position(x264_t *h, int batch, int t, int nslots_with_t)
         sp.alpha_off_div2 = p.i_deblocking_filter_alphac0; sp.beta_off_div2 = p.i_deblocking_filter_beta;
         sp.transform8x8_mode = p.analyse.b_transform_8x8;
         c.off.push_back(c.bytes.size()); c.types.push_back(c.idr ? 5 : 1);
-        write_slice(c.bytes, sp, h->h_mb.data() + (size_t)s * h->nmb, h->h_lv.data() + (size_t)s * h->nmb * X264GPU_MB_LEVELS,
-                    p.b_annexb != 0, c.off.size() == 1, nullptr);
-        h->slot_have[(size_t)s * h->keyint + t] = 1;
+        write_slice(c.bytes, sp, hmb + (size_t)s * h->nmb, hlv + (size_t)s * h->nmb * X264GPU_MB_LEVELS, p.b_annexb != 0, c.off.size() == 1, nullptr);
     };
     const unsigned hw = std::thread::hardware_concurrency();
     const int nthr = (int)(hw ? (hw < (unsigned)nslots_with_t ? hw : (unsigned)nslots_with_t) : 1);
-    if (nthr <= 1) { for (int s = 0; s < nslots_with_t; s++) work(s); return; }
-    std::vector<std::thread> pool;
-    for (int th = 0; th < nthr; th++) pool.emplace_back([&, th]() { for (int s = th; s < nslots_with_t; s += nthr) work(s); });
-    for (auto &th : pool) th.join();
+    h->pool_t = t; h->pool_nslots = nslots_with_t;
+    for (int th = 0; th < nthr; th++)
+        h->pool.emplace_back([work, th, nthr, nslots_with_t]() { for (int s = th; s < nslots_with_t; s += nthr) work(s); });
 }
 
-// frames of the batch being gathered move to the ordered output queue once every earlier frame is there
-static void drain_batch(x264_t *h, long batch_first_frame, long frames_in_batch)
+// coded frames move to the ordered output queue once every earlier frame is there.  slotbuf is indexed inside a batch
+// (slot * keyint + position); an entry is reused by the next batch only long after it was drained.
+static void drain_coded(x264_t *h)
 {
-    const int K = h->keyint;
-    while ((long)(h->emitted + (long)h->ready.size()) < batch_first_frame + frames_in_batch) {
-        const long j = h->emitted + (long)h->ready.size() - batch_first_frame;     // index inside the batch
-        if (j < 0) break;
+    const long K = h->keyint, per_batch = (long)h->G * K;
+    for (long g = h->emitted + (long)h->ready.size(); g < h->submitted; g++) {
+        const long j = g % per_batch;
         const size_t idx = (size_t)(j / K) * K + (size_t)(j % K);
-        if (!h->slot_have[idx]) break;
+        if (!h->slot_have[idx]) break;                       // not coded yet (or its CAVLC threads have not been joined)
         h->ready.push_back(std::move(h->slotbuf[idx]));
         h->slot_have[idx] = 0;
     }
@@ -316,8 +341,8 @@ static int encode_gop_parallel(x264_t *h, x264_nal_t **pp_nal, int *pi_nal, x264
         if (s == G - 1) {                                      // the batch's last GOP delivers position t: every slot has it
             code_position(h, (int)b, t, G);
             h->next_pos = t + 1 == K ? 0 : t + 1;
-        }
-        drain_batch(h, b * per_batch, r + 1);
+        } else if (!h->pool.empty()) join_pool(h);             // gathering phase: the last position's CAVLC had a whole call to finish
+        drain_coded(h);
     } else {
         // flush: code what the partly gathered batch holds, position by position, with the slots that have that position
         const long i = h->submitted, b = i == 0 ? 0 : (i - 1) / per_batch, r = i - b * per_batch;    // r frames in the last batch
@@ -331,7 +356,8 @@ static int encode_gop_parallel(x264_t *h, x264_nal_t **pp_nal, int *pi_nal, x264
             h->next_pos = 0;
         }
         h->flushed = true;
-        drain_batch(h, b * per_batch, r);
+        join_pool(h);
+        drain_coded(h);
     }
     if (h->ready.empty()) return 0;
     // ---- emit frame h->emitted ----
@@ -423,6 +449,7 @@ int x264_encoder_delayed_frames(x264_t *h) { return h && h->G > 1 ? (int)(h->sub
 void x264_encoder_close(x264_t *h)
 {
     if (!h) return;
+    join_pool(h);
     if (h->gpu) x264gpu_encoder_destroy(h->gpu);
     if (h->d_in) x264gpu_free(h->d_in);
     if (h->d_mb) x264gpu_free(h->d_mb);
