@@ -145,6 +145,22 @@ __device__ void deblock_mb_wave(const EncK &k, DeblockLds &L, int wave, int lane
     __builtin_amdgcn_s_waitcnt(0xc07f);
 
     const x264gpu_mb *Q = &L.rec[wave][0];
+    // nothing to do when every edge segment of the macroblock has bS 0 (uniform motion, no coefficients): skip the
+    // eight edge steps and the write-back.  Lane = (dir, edge, segment).
+    {
+        bool any = false;
+        if (lane < 32) {
+            const int dir = lane >> 4, edge = (lane >> 2) & 3, seg = lane & 3;
+            const bool skip_edge = ((edge & 1) && Q->transform8x8) || (edge == 0 && (dir == 0 ? mbx == 0 : mby == 0));
+            if (!skip_edge) {
+                const x264gpu_mb *P = edge == 0 ? &L.rec[wave][dir == 0 ? 1 : 2] : Q;
+                const int qbx = dir == 0 ? edge : seg, qby = dir == 0 ? seg : edge;
+                const int pbx = dir == 0 ? (edge + 3) & 3 : seg, pby = dir == 0 ? seg : (edge + 3) & 3;
+                any = edge_bs(P, pbx, pby, Q, qbx, qby, edge == 0) != 0;
+            }
+        }
+        if (!__ballot(any)) return;
+    }
     const int qpq = Q->qp, qpcq = L.cqp[min(max(qpq + k.chroma_qp_offset, 0), 51)];
     for (int dir = 0; dir < 2; dir++)
         for (int edge = 0; edge < 4; edge++) {
