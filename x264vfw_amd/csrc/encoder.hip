@@ -231,7 +231,12 @@ int x264gpu_encode_frames(x264gpu_encoder *e, const uint8_t *d_i420, int slice_t
     else hipLaunchKernelGGL(k_intra2<I2_WAVES_FEW>, dim3(S), dim3(I2_WAVES_FEW * 64), 0, st, k);                  // few streams: all bands of a frame at once
     mask |= 8;
     STAGE_MARK(4);
-    if (e->cfg.deblock) { hipLaunchKernelGGL(k_deblock, dim3(S), dim3(DB_WAVES * 64), 0, st, k); mask |= 16; }
+    if (e->cfg.deblock) {
+        static const bool deblock_v1 = getenv("X264GPU_DEBLOCK_V1") != nullptr;      // one macroblock per wave (A/B runs)
+        if (deblock_v1) hipLaunchKernelGGL(k_deblock, dim3(S), dim3(DB_WAVES * 64), 0, st, k);
+        else hipLaunchKernelGGL(k_deblock2, dim3(S), dim3(1024), 0, st, k);
+        mask |= 16;
+    }
     STAGE_MARK(5);
     launch_hpel_filter(e->luma[e->cur], k.plane_bytes, k.rs, k.cw, k.ch, PAD, S, k.luma_bytes, st);
     hipLaunchKernelGGL(k_chroma_border, dim3((k.cw / 2 + 2 * CPAD + 255) / 256, k.ch / 2 + 2 * CPAD, S), dim3(256), 0, st, k);
