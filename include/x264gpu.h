@@ -159,6 +159,8 @@ typedef struct x264gpu_config {
                                * analyse.intra / analyse.inter masks) */
     int dct8x8;               /* --8x8dct: adaptive 8x8 luma transform (High profile) */
     int me_method;            /* --me: 0 dia (radius-1 diamond), 1 hex (hexagon + square refine); x264's X264_ME_DIA / X264_ME_HEX */
+    int chroma_me;            /* --chroma-me (x264 default on): sub-pel SATD costs of P macroblocks include the chroma planes; acts when subme >= 5,
+                               * as x264's h->mb.b_chroma_me ([x264-upstream] encoder/encoder.c, me.c COST_MV_SATD) */
 } x264gpu_config;
 
 int  x264gpu_encoder_create(x264gpu_encoder **enc, const x264gpu_config *cfg);

@@ -285,6 +285,18 @@ static const int8_t hex2[8][2] = { { -1, -2 }, { -2, 0 }, { -1, 2 }, { 1, 2 }, {
 static const int8_t square1[9][2] = { { 0, 0 }, { 0, -1 }, { 0, 1 }, { -1, 0 }, { 1, 0 }, { -1, -1 }, { -1, 1 }, { 1, -1 }, { 1, 1 } };
 static const int8_t mod6m1[8] = { 5, 0, 1, 2, 3, 4, 5, 0 };
 
+/* SATD of the two chroma planes of a w x h LUMA block at luma offset (ox,oy), predicted with quarter-pel vector (mvx,mvy):
+ * the chroma term of [x264-upstream] me.c COST_MV_SATD under b_chroma_me (mc_chroma + mbcmp[chromapix] on U and V) */
+static int chroma_me_satd(x264o_encoder *e, int mbx, int mby, int ox, int oy, int w, int h, int ref, int mvx, int mvy)
+{
+    pixel pu[64], pv[64], fu[64], fv[64];
+    const pixel *fuv = e->fenc_uv + (size_t)(mby * 8 + oy / 2) * e->fs + mbx * 16 + ox;
+    for (int y = 0; y < h / 2; y++)
+        for (int x = 0; x < w / 2; x++) { fu[y * 8 + x] = fuv[y * e->fs + 2 * x]; fv[y * 8 + x] = fuv[y * e->fs + 2 * x + 1]; }
+    x264o_mc_chroma(pu, pv, 8, chroma_plane(e, ref), e->rs, mbx * 8 + ox / 2, mby * 8 + oy / 2, mvx, mvy, w / 2, h / 2);
+    return x264o_satd(fu, 8, pu, 8, w / 2, h / 2) + x264o_satd(fv, 8, pv, 8, w / 2, h / 2);
+}
+
 /* Generic block search: w x h block at offset (ox,oy) inside macroblock (mbx,mby).  Start candidates are
  * tried in order (first-best wins), then hexagon + square full-pel search on SAD and the sub-pel diamonds
  * (half-pel on SAD, quarter-pel on SATD) — x264_me_search_ref + refine_subpel.  mvp = cost predictor. */
@@ -371,6 +383,10 @@ static me_result me_search_block(x264o_encoder *e, int mbx, int mby, int ox, int
         }
         x264o_mc_luma(pred, 16, planes, e->rs, mbx * 16 + ox, mby * 16 + oy, mx, my, w, h);
         bcost = x264o_satd(fenc, e->fs, pred, 16, w, h) + cmx[mx] + cmy[my];
+        /* b_chroma_me (subme >= 5, blocks of 8x8 and larger): every SATD cost that could become the best one also carries the
+         * chroma SATD; a candidate whose luma cost alone is not below bcost cannot win, so x264 skips its chroma */
+        const int chroma_me = e->cfg.chroma_me && sub >= 5;
+        if (chroma_me) bcost += chroma_me_satd(e, mbx, mby, ox, oy, w, h, ref, mx, my);
         /* early termination when examining several reference frames ([x264-upstream] me.c refine_subpel, p_halfpel_thresh):
          * a reference whose half-pel SATD cost is more than 8/7 of the best one so far skips the quarter-pel diamond */
         int skip_qpel = 0;
@@ -388,6 +404,7 @@ static me_result me_search_block(x264o_encoder *e, int mbx, int mby, int ox, int
                 int cx = omx + qd[k][0], cy = omy + qd[k][1];
                 x264o_mc_luma(pred, 16, planes, e->rs, mbx * 16 + ox, mby * 16 + oy, cx, cy, w, h);
                 int c = x264o_satd(fenc, e->fs, pred, 16, w, h) + cmx[cx] + cmy[cy];
+                if (chroma_me && c < bcost) c += chroma_me_satd(e, mbx, mby, ox, oy, w, h, ref, cx, cy);
                 if (c < bcost) { bcost = c; mx = cx; my = cy; bdir = k; }
             }
             if (mx == omx && my == omy) break;
@@ -426,6 +443,36 @@ static int intra16_estimate(x264o_encoder *e, int mbx, int mby, int lambda)
         int m = modes[i], sig = m > I_PRED_16x16_P ? I_PRED_16x16_DC : m;
         x264o_predict_16x16(pred, 16, fenc, e->fs, m);
         int c = x264o_satd(fenc, e->fs, pred, 16, 16, 16) + lambda * bs_size_ue(sig);
+        if (c < best) best = c;
+    }
+    return best;
+}
+
+/* chroma counterpart of intra16_estimate for b_chroma_me: x264 adds i_satd_chroma to the intra costs it compares with inter costs
+ * that carry chroma ([x264-upstream] analyse.c x264_macroblock_analyse, P slices).  Source neighbours, modes DC,H,V,P by availability. */
+static int intra_chroma_estimate(x264o_encoder *e, int mbx, int mby, int lambda)
+{
+    const pixel *fuv = e->fenc_uv + (size_t)mby * 8 * e->fs + mbx * 16;
+    pixel fu[64], fv[64], nu[9 * 9], nvv[9 * 9], pu[64], pv[64];
+    int left = mbx > 0, top = mby > 0, best = 1 << 28;
+    for (int y = 0; y < 8; y++) for (int x = 0; x < 8; x++) { fu[y * 8 + x] = fuv[y * e->fs + 2 * x]; fv[y * 8 + x] = fuv[y * e->fs + 2 * x + 1]; }
+    memset(nu, 128, sizeof(nu)); memset(nvv, 128, sizeof(nvv));
+    for (int y = -1; y < 8; y++)
+        for (int x = -1; x < 8; x++) {
+            if (y >= 0 && x >= 0) continue;
+            if ((y < 0 && !top) || (x < 0 && !left)) continue;
+            nu[(y + 1) * 9 + x + 1] = fuv[y * e->fs + 2 * x]; nvv[(y + 1) * 9 + x + 1] = fuv[y * e->fs + 2 * x + 1];
+        }
+    int cm[4], cn = 0;
+    if (left && top) { cm[cn++] = I_PRED_CHROMA_DC; cm[cn++] = I_PRED_CHROMA_H; cm[cn++] = I_PRED_CHROMA_V; cm[cn++] = I_PRED_CHROMA_P; }
+    else if (left) { cm[cn++] = I_PRED_CHROMA_DC_LEFT; cm[cn++] = I_PRED_CHROMA_H; }
+    else if (top) { cm[cn++] = I_PRED_CHROMA_DC_TOP; cm[cn++] = I_PRED_CHROMA_V; }
+    else cm[cn++] = I_PRED_CHROMA_DC_128;
+    for (int i = 0; i < cn; i++) {
+        int m = cm[i], sig = m > I_PRED_CHROMA_P ? I_PRED_CHROMA_DC : m;
+        x264o_predict_8x8c(pu, 8, nu + 10, 9, m);
+        x264o_predict_8x8c(pv, 8, nvv + 10, 9, m);
+        int c = x264o_satd(fu, 8, pu, 8, 8, 8) + x264o_satd(fv, 8, pv, 8, 8, 8) + lambda * bs_size_ue(sig);
         if (c < best) best = c;
     }
     return best;
@@ -475,6 +522,7 @@ static void analyse_p_mb(x264o_encoder *e, int mbx, int mby, x264gpu_mb *mb)
         }
     }
     int icost = intra16_estimate(e, mbx, mby, lambda);
+    if (e->cfg.chroma_me && e->cfg.subme >= 5) icost += intra_chroma_estimate(e, mbx, mby, lambda);
     memset(mb, 0, sizeof(*mb));
     mb->qp = (uint8_t)qp;
     mb->aux[0] = best_cost; mb->aux[1] = icost; mb->aux[2] = m.cost;

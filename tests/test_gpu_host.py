@@ -120,7 +120,7 @@ def test_bitstream_equals_oracle_path(gpu):
     stream, info, _ = encode_all(h_, w, h, frames)
     H.x264_encoder_close(h_)
     qp_i = max(1, int(qp - 6.0 * np.log2(1.4) + 0.5))
-    enc = O.OracleEncoder(O.default_config(w, h, qp_i=qp_i, qp_p=qp, partitions=7, refs=3, dct8x8=1))      # medium: p8x8 + i4x4 + i8x8, ref 3, 8x8dct
+    enc = O.OracleEncoder(O.default_config(w, h, qp_i=qp_i, qp_p=qp, partitions=7, refs=3, dct8x8=1, chroma_me=1))      # medium: p8x8 + i4x4 + i8x8, ref 3, 8x8dct, chroma-me
     ref = b""
     for i, f in enumerate(frames):
         mbs, lv = enc.encode(f, 2 if i == 0 else 0)

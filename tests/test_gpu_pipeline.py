@@ -58,6 +58,11 @@ def compare(tag, mbw, g_mb, o_mb, g_lv, o_lv, g_rec, o_rec):
     (208, 120, 3, dict(dct8x8=1, partitions=4, qp_i=14, qp_p=16)),
     (64, 48, 3, dict(dct8x8=1, partitions=7, qp_i=38, qp_p=40)),
     (352, 288, 4, dict(me_method=0, subme=0, partitions=0, deblock=0)),      # preset ultrafast: me dia, full-pel only, 16x16 only
+    (176, 144, 4, dict(chroma_me=1)),                                        # chroma in the sub-pel costs (subme 7)
+    (352, 288, 4, dict(chroma_me=1, dct8x8=1, partitions=7, refs=3, qp_i=28, qp_p=31)),   # medium toolset + chroma-ME
+    (208, 120, 4, dict(chroma_me=1, partitions=3, subme=5, refs=2, qp_i=18, qp_p=20)),
+    (176, 144, 4, dict(chroma_me=1, partitions=3, subme=9, me_method=0)),
+    (64, 48, 3, dict(chroma_me=1, subme=4, partitions=3)),                   # below subme 5 the flag is inert
     (176, 144, 4, dict(me_method=0, partitions=3, subme=5, refs=2)),         # diamond search in every partition
     (208, 120, 3, dict(me_method=0, subme=2, me_range=8)),
 ])

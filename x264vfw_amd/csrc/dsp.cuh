@@ -185,6 +185,17 @@ __device__ __forceinline__ s16x2 pk_bfly(s16x2 v, s16x2 sg)
     return v * sg + y;                                             // v_pk_mad_i16
 }
 // half share of sum|H4 (e - p) H4| for one 4x4 block: lane = one row (4 packed pixels), quad = block
+// da, db: the row's four pixel differences as two packed pairs, in any pairing (input-permutation invariance)
+__device__ __forceinline__ int satd4_half_diff(s16x2 da, s16x2 db, s16x2 sg1, s16x2 sg2)
+{
+    s16x2 u = da + db, v = da - db;                                // first horizontal stage
+    u = pk_bfly<DPP_XOR1>(u, sg1); v = pk_bfly<DPP_XOR1>(v, sg1);  // both vertical stages across the quad
+    u = pk_bfly<DPP_XOR2>(u, sg2); v = pk_bfly<DPP_XOR2>(v, sg2);
+    u = __builtin_elementwise_max(u, -u); v = __builtin_elementwise_max(v, -v);
+    const s16x2 m = __builtin_elementwise_max(u, as_s16x2(__builtin_amdgcn_alignbit(as_u32(u), as_u32(u), 16))) +
+                    __builtin_elementwise_max(v, as_s16x2(__builtin_amdgcn_alignbit(as_u32(v), as_u32(v), 16)));
+    return (int)(as_u32(m) & 0xffffu);
+}
 __device__ __forceinline__ int satd4_half_pk(s16x2 e_even, s16x2 e_odd, uint32_t p, s16x2 sg1, s16x2 sg2)
 {
     const s16x2 da = e_even - pk_even(p), db = e_odd - pk_odd(p);

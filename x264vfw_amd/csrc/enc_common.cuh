@@ -38,6 +38,7 @@ struct EncK {
     Q8 q8_intra, q8_inter;    // 8x8 luma transform (dct8x8)
     int dct8x8;
     int me_method;            // 0 dia, 1 hex
+    int chroma_me;            // sub-pel SATD costs carry chroma (subme >= 5)
     unsigned long long *dbg;  // optional diagnostics (NULL in production): per (stream, wave) cycle counters
 };
 

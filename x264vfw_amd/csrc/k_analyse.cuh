@@ -151,6 +151,41 @@ __device__ __forceinline__ int sub_sad_row16_hpel(const uint32_t *buf, int n, in
 }
 
 // ------------------------------------------------------------------------------------------------
+// Chroma term of the sub-pel SATD costs (oracle chroma_me_satd; x264 COST_MV_SATD under b_chroma_me).  A lane owns one row of
+// a 4x4 chroma block of BOTH planes (the NV12 bytes it loads serve U and V), a quad of lanes the block.  Bilinear 1/8-pel
+// prediction and Hadamard run on packed pairs: two neighbouring samples of a plane share a VGPR (weights <= 64, sums < 2^15).
+// Returns the lane's half share of SATD(U) + SATD(V); the sum over a candidate's lanes is the chroma cost of the candidate.
+// (cx, cy): chroma-sample position of the lane's four pixels; e0/e1: their 8 source bytes U0 V0 U1 V1 | U2 V2 U3 V3.
+// ------------------------------------------------------------------------------------------------
+typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ int chroma_me_half(const uint8_t *__restrict__ nv12, int rs, int cx, int cy, int mvx, int mvy, uint32_t e0, uint32_t e1,
+                                              s16x2 sg1, s16x2 sg2)
+{
+    const int dx = mvx & 7, dy = mvy & 7;
+    const uint32_t wA = (uint32_t)((8 - dx) * (8 - dy)) * 0x10001u, wB = (uint32_t)(dx * (8 - dy)) * 0x10001u;
+    const uint32_t wC = (uint32_t)((8 - dx) * dy) * 0x10001u, wD = (uint32_t)(dx * dy) * 0x10001u;
+    const uint8_t *s = nv12 + (long)(cy + (mvy >> 3)) * rs + 2 * (cx + (mvx >> 3));
+    const uint32_t a0 = load_u32_unaligned(s), a1 = load_u32_unaligned(s + 4), a2 = load_u32_unaligned(s + 8);
+    const uint32_t b0 = load_u32_unaligned(s + rs), b1 = load_u32_unaligned(s + rs + 4), b2 = load_u32_unaligned(s + rs + 8);
+    const uint32_t a01 = __builtin_amdgcn_alignbyte(a1, a0, 2), a12 = __builtin_amdgcn_alignbyte(a2, a1, 2);     // one sample to the right
+    const uint32_t b01 = __builtin_amdgcn_alignbyte(b1, b0, 2), b12 = __builtin_amdgcn_alignbyte(b2, b1, 2);
+    int acc = 0;
+#pragma unroll
+    for (int sh = 0; sh < 16; sh += 8) {
+#define CH(x) __builtin_bit_cast(u16x2, ((x) >> sh) & 0x00ff00ffu)
+#define W(x) __builtin_bit_cast(u16x2, x)
+        const u16x2 p01 = (W(wA) * CH(a0) + W(wB) * CH(a01) + W(wC) * CH(b0) + W(wD) * CH(b01) + W(0x00200020u)) >> 6;
+        const u16x2 p23 = (W(wA) * CH(a1) + W(wB) * CH(a12) + W(wC) * CH(b1) + W(wD) * CH(b12) + W(0x00200020u)) >> 6;
+        const s16x2 da = __builtin_bit_cast(s16x2, CH(e0)) - __builtin_bit_cast(s16x2, p01);
+        const s16x2 db = __builtin_bit_cast(s16x2, CH(e1)) - __builtin_bit_cast(s16x2, p23);
+#undef CH
+#undef W
+        acc += satd4_half_diff(da, db, sg1, sg2);
+    }
+    return acc;
+}
+
+// ------------------------------------------------------------------------------------------------
 // Sub-partition search (P16x8 / P8x16 / P8x8): every partition of a shape is searched at the same time, each on its own
 // lanes, with partition-private motion state and predicated updates, so the wave runs ONE instruction stream for 2 or 4
 // independent hexagon / square / half-pel / quarter-pel searches.  Restates oracle me_search_block for the partitions of a shape.
@@ -165,6 +200,7 @@ struct PartCtx {
     int me_range, me_method, hp_it, qp_it, lane;
     uint32_t *sub;                             // LDS sub-pel neighbourhood buffer (SUB_DWORDS)
     const uint8_t *fenc; int fs;               // source macroblock (for the candidate-parallel 8x8 search)
+    const uint8_t *cref, *fuv; int chroma_me;  // chroma-ME: NV12 reference plane (origin), source NV12 of this macroblock
 };
 __device__ __forceinline__ int pc_mvcost(const PartCtx &c, int qx, int qy) { return c.cx[qx - c.cbx + 96] + c.cy[qy - c.cby + 96]; }
 // ------------------------------------------------------------------------------------------------
@@ -228,6 +264,10 @@ __device__ int search_parts(const PartCtx &c, const int SHAPE, int c0x, int c0y,
     uint32_t e0[2], e1[2];
     { const uint2 a = *(const uint2 *)(c.fenc + (size_t)y0 * c.fs + ox), b = *(const uint2 *)(c.fenc + (size_t)y1 * c.fs + ox + x1);
       e0[0] = a.x; e0[1] = a.y; e1[0] = b.x; e1[1] = b.y; }
+    // chroma-ME: lane = row (sr & 3) of a 4x4 chroma block of the partition (16x8: blocks side by side, 8x16: stacked)
+    const int ccx = (ox >> 1) + (SHAPE == 1 ? (sr >> 2) * 4 : 0), ccy = (oy >> 1) + (SHAPE == 2 ? sr : sr & 3);
+    uint32_t ce0 = 0, ce1 = 0;
+    if (c.chroma_me) { const uint2 v = *(const uint2 *)(c.fuv + (size_t)ccy * c.fs + 2 * ccx); ce0 = v.x; ce1 = v.y; }
     const int wb0 = (c.py + y0 - c.wy0) * WIN_STRIDE + (c.px + ox - c.wx0), wb1 = (c.py + y1 - c.wy0) * WIN_STRIDE + (c.px + ox + x1 - c.wx0);
     auto gsum = [&](int v) { v = quad_sum(v); const int w = xor4(v); return GL == 8 ? v + w : v; };  // over the candidate's lanes
     auto cmin = [&](unsigned k) {                                                                        // over the four candidates of a partition
@@ -342,6 +382,7 @@ __device__ int search_parts(const PartCtx &c, const int SHAPE, int c0x, int c0y,
             sub_row8(sb, sn, rwl, sx0, sy0, X0, Y0, mx, my, p0);
             sub_row8(sb, sn, rwl, sx0, sy0, X1, Y1, mx, my, p1);
             bcost = satd_part(p0, p1) + pc_mvcost(c, mx, my);
+            if (c.chroma_me) bcost += gsum(chroma_me_half(c.cref, c.rs, (c.px >> 1) + ccx, (c.py >> 1) + ccy, mx, my, ce0, ce1, sg1, sg2));
         }
         int bdir = -1;
         bool qp_run = true;
@@ -352,7 +393,11 @@ __device__ int search_parts(const PartCtx &c, const int SHAPE, int c0x, int c0y,
             uint32_t p0[2], p1[2];
             sub_row8(sb, sn, rwl, sx0, sy0, X0, Y0, cx, cy, p0);
             sub_row8(sb, sn, rwl, sx0, sy0, X1, Y1, cx, cy, p1);
-            unsigned kk = ((unsigned)(satd_part(p0, p1) + pc_mvcost(c, cx, cy)) << 2) | (unsigned)cnd;
+            int cst = satd_part(p0, p1) + pc_mvcost(c, cx, cy);
+            // a candidate whose luma cost is not below the best cost cannot win; chroma only when some partition still can improve
+            if (c.chroma_me && __any(qp_run && cst < bcost && (cnd ^ 1) != bdir))
+                cst += gsum(chroma_me_half(c.cref, c.rs, (c.px >> 1) + ccx, (c.py >> 1) + ccy, cx, cy, ce0, ce1, sg1, sg2));
+            unsigned kk = ((unsigned)cst << 2) | (unsigned)cnd;
             if ((cnd ^ 1) == bdir) kk = 0xffffffffu;
             kk = cmin(kk);
             if (qp_run && (int)(kk >> 2) < bcost) {
@@ -395,6 +440,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(X264GPU_ANA
     { const uint4 v = *(const uint4 *)(fenc + (size_t)r * k.fs); cr[0] = v.x; cr[1] = v.y; cr[2] = v.z; cr[3] = v.w; }
     const int zx = z_x0(lane), zy = z_y(lane);      // Z mapping
     const uint32_t cz = *(const uint32_t *)(fenc + (size_t)zy * k.fs + zx);
+    // chroma-ME (subme >= 5): in the (candidate, row) mapping lane r owns row r & 3 of 4x4 chroma block r >> 2, both planes
+    const bool chroma_me = k.chroma_me && k.subme >= 5;
+    const uint8_t *fuv = k.fenc_uv + (size_t)s * k.fencuv_bytes + (size_t)mby * 8 * k.fs + px;
+    const int ccx = ((r >> 2) & 1) * 4, ccy = (r >> 3) * 4 + (r & 3);
+    uint32_t ce0 = 0, ce1 = 0;
+    if (chroma_me) { const uint2 v = *(const uint2 *)(fuv + (size_t)ccy * k.fs + 2 * ccx); ce0 = v.x; ce1 = v.y; }
 
     // ---- motion vector limits (oracle mv_limits) ----
     const int vrange = 512 * 4;
@@ -553,6 +604,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(X264GPU_ANA
             // SATD at the best half-pel position
             {
                 bcost = wave_sum(satd4_half(cz, sub_row4(sb, sn, rwl, sx0, sy0, px + zx, py + zy, mx, my), lane)) + MVC(mx, my);
+                if (chroma_me) bcost += row16_sum(chroma_me_half(ref_chroma00(k, s, r_), k.rs, (px >> 1) + ccx, (py >> 1) + ccy, mx, my, ce0, ce1,
+                                                                 pk_sign(lane & 1), pk_sign(lane & 2)));
             }
             // early termination when examining several references (x264 refine_subpel, p_halfpel_thresh): a reference whose
             // half-pel SATD cost exceeds 8/7 of the best so far skips its quarter-pel diamond
@@ -572,7 +625,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(X264GPU_ANA
                 const int cx = mx + (cnd == 2 ? -1 : cnd == 3 ? 1 : 0), cy = my + (cnd == 0 ? -1 : cnd == 1 ? 1 : 0);
                 uint32_t pr[4];
                 sub_row16(sb, sn, rwl, sx0, sy0, px, py + r, cx, cy, pr);
-                unsigned key = ((unsigned)(row16_sum(satd16x4_half_pk(cr, pr, sg1, sg2)) + MVC(cx, cy)) << 2) | (unsigned)cnd;
+                int cst = row16_sum(satd16x4_half_pk(cr, pr, sg1, sg2)) + MVC(cx, cy);
+                if (chroma_me && __any(cst < bcost && (cnd ^ 1) != bdir))
+                    cst += row16_sum(chroma_me_half(ref_chroma00(k, s, r_), k.rs, (px >> 1) + ccx, (py >> 1) + ccy, cx, cy, ce0, ce1, sg1, sg2));
+                unsigned key = ((unsigned)cst << 2) | (unsigned)cnd;
                 if ((cnd ^ 1) == bdir) key = 0xffffffffu;
                 key = wave_min_u32(key);
                 if ((int)(key >> 2) >= bcost) break;
@@ -615,6 +671,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(X264GPU_ANA
         pc.p00 = p00; pc.pb = k.plane_bytes; pc.rs = k.rs; pc.px = px; pc.py = py; pc.zx = zx; pc.zy = zy; pc.cz = cz;
         pc.fmin0 = fmin0; pc.fmax0 = fmax0; pc.fmin1 = fmin1; pc.fmax1 = fmax1; pc.smin0 = smin0; pc.smax0 = smax0; pc.smin1 = smin1; pc.smax1 = smax1;
         pc.me_range = k.me_range; pc.me_method = k.me_method; pc.lane = lane; pc.sub = s_sub[wave]; pc.fenc = fenc; pc.fs = k.fs;
+        pc.chroma_me = chroma_me; pc.cref = ref_chroma00(k, s, bref); pc.fuv = fuv;
         const int sub = min(k.subme, 11);
         pc.hp_it = sub < 2 ? 0 : sub < 6 ? 1 : sub < 8 ? 2 : 4;
         pc.qp_it = sub < 4 ? 0 : sub == 4 ? 1 : sub < 8 ? 2 : 10;
@@ -651,6 +708,39 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(X264GPU_ANA
             const int c = wave_sum(satd4_half(cz, pred16_row4(nb, pp, m, zx, zy), lane)) + k.lambda * bs_size_ue(sig);
             icost = min(icost, c);
         }
+    }
+
+    // ---- chroma intra estimate on source neighbours (oracle intra_chroma_estimate): lanes 0..31, plane = lane >> 4 ----
+    if (chroma_me) {
+        __builtin_amdgcn_wave_barrier();
+        const int c = (lane >> 4) & 1, ci = (lane >> 2) & 3, j = lane & 3, cx0 = (ci & 1) * 4, cyy = (ci >> 1) * 4 + j;
+        uint8_t *cnb = nb + c * CNB_SIZE;             // the luma neighbour array is free again (2 x 20 <= 48 bytes)
+        {
+            const int t = lane & 15, pl = (lane >> 4) & 1;
+            if (lane < 32) {
+                if (t < 9) { const int x = t - 1; nb[pl * CNB_SIZE + CNB_TOP + x] = (top && (x >= 0 || left)) ? fuv[-(long)k.fs + 2 * x + pl] : 128; }
+            } else if (lane < 48) {
+                const int y = t & 7, pl2 = (t >> 3) & 1;
+                nb[pl2 * CNB_SIZE + CNB_LEFT + y] = left ? fuv[(long)y * k.fs - 2 + pl2] : 128;
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_s_waitcnt(0xc07f);
+        const PredC pc = predc_setup(cnb);
+        const uint2 fe = *(const uint2 *)(fuv + (size_t)cyy * k.fs + 2 * cx0);
+        const uint32_t cenc = nv12_pick(fe.x, fe.y, c);
+        int modes[4], n;
+        if (left && top) { modes[0] = PREDC_DC; modes[1] = PREDC_H; modes[2] = PREDC_V; modes[3] = PREDC_P; n = 4; }
+        else if (left) { modes[0] = PREDC_DC_LEFT; modes[1] = PREDC_H; n = 2; }
+        else if (top) { modes[0] = PREDC_DC_TOP; modes[1] = PREDC_V; n = 2; }
+        else { modes[0] = PREDC_DC_128; n = 1; }
+        int bestc = 1 << 28;
+        for (int i = 0; i < n; i++) {
+            const int m = modes[i], sig = m > PREDC_P ? PREDC_DC : m;
+            const int hs = satd4_half(cenc, predc_row4(cnb, pc, m, ci, j), lane);
+            bestc = min(bestc, wave_sum(lane < 32 ? hs : 0) + k.lambda * bs_size_ue(sig));
+        }
+        icost += bestc;
     }
 
     // ---- record ----

@@ -152,6 +152,7 @@ x264_t *x264_encoder_open(x264_param_t *param)
     if (p.analyse.i_me_method > X264_ME_HEX) { xlog(&p, X264_LOG_WARNING, "me umh/esa/tesa are not implemented in the MI355X path yet: me hex\n"); p.analyse.i_me_method = X264_ME_HEX; }
     p.analyse.i_me_range = clampi(p.analyse.i_me_range, 4, 16);
     p.analyse.i_subpel_refine = clampi(p.analyse.i_subpel_refine, 0, 7);
+    p.analyse.b_chroma_me = p.analyse.b_chroma_me != 0;
     p.b_interlaced = 0; p.i_slice_count = 1;
     p.i_threads = clampi(p.i_threads, 1, 64);                  // --threads G: GOPs coded in lock-step (1 = no delay)
     if (p.i_keyint_max <= 0) p.i_keyint_max = 1;
@@ -191,6 +192,7 @@ x264_t *x264_encoder_open(x264_param_t *param)
                      0x100 | ((p.analyse.intra & X264_ANALYSE_I4x4) ? 0x200 : 0) | ((p.analyse.intra & X264_ANALYSE_I8x8) ? 0x400 : 0);
     cfg.dct8x8 = p.analyse.b_transform_8x8;
     cfg.me_method = p.analyse.i_me_method == X264_ME_DIA ? 0 : 1;
+    cfg.chroma_me = p.analyse.b_chroma_me && p.analyse.i_subpel_refine >= 5;     // x264: h->mb.b_chroma_me in P slices
     size_t insz = (size_t)p.i_width * p.i_height * 3 / 2;
     if (x264gpu_encoder_create(&h->gpu, &cfg) != X264GPU_OK ||
         x264gpu_malloc((void **)&h->d_in, insz) != X264GPU_OK ||
