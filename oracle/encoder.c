@@ -332,7 +332,83 @@ static me_result me_search_block(x264o_encoder *e, int mbx, int mby, int ox, int
             if (best < 0) break;
             bmx += dia1[best][0]; bmy += dia1[best][1];
         } while (--i && bmx >= fmin[0] && bmx <= fmax[0] && bmy >= fmin[1] && bmy <= fmax[1]);
-    } else
+    } else {
+    int range = e->cfg.me_range;
+    if (e->cfg.me_method == 2) {
+        /* X264_ME_UMH ([x264-upstream] encoder/me.c, "Uneven-cross Multi-Hexagon-grid Search"): predictor diamonds, early
+         * termination by SAD thresholds, uneven cross, 5x5 corners, 16-point hexagon grid rings with a search range adapted to
+         * the SAD level and to the disagreement of the predictors, then the hexagon + square refine below with that range.
+         * Every candidate update is x264's in-order "strictly better wins" (COPY3_IF_LT).
+         * mvc (x264: the neighbours' vectors, without mvp): here the start candidates after the predictor for 16x16 (zero,
+         * co-located), the 16x16 vector for sub-partitions. */
+        static const uint8_t range_mul[4][4] = { { 3, 3, 4, 4 }, { 3, 4, 4, 4 }, { 4, 4, 4, 5 }, { 4, 4, 5, 6 } };
+        static const int8_t hex4[16][2] = { { 0, -4 }, { 0, 4 }, { -2, -3 }, { 2, -3 }, { -4, -2 }, { 4, -2 }, { -4, -1 }, { 4, -1 },
+                                            { -4, 0 }, { 4, 0 }, { -4, 1 }, { 4, 1 }, { -4, 2 }, { 4, 2 }, { -2, 3 }, { 2, 3 } };
+        const int shift = (w == 16 ? 0 : 1) + (h == 16 ? 0 : 1);            /* pixel_size_shift: 16x16 0, 16x8 / 8x16 1, 8x8 2 */
+        const int pmx = clampi((mvp[0] + 2) >> 2, fmin[0], fmax[0]), pmy = clampi((mvp[1] + 2) >> 2, fmin[1], fmax[1]);
+        int omx, omy, c_, done = 0, cross_start = 1;
+#define INRANGE(mx, my) ((mx) >= fmin[0] && (mx) <= fmax[0] && (my) >= fmin[1] && (my) <= fmax[1])
+#define COST_MV(mx, my) do { c_ = FPEL_COST(mx, my); if (c_ < bcost) { bcost = c_; bmx = (mx); bmy = (my); } } while (0)
+#define COST_MV_X4(x0, y0, x1, y1, x2, y2, x3, y3) do { COST_MV(omx + (x0), omy + (y0)); COST_MV(omx + (x1), omy + (y1)); \
+                                                        COST_MV(omx + (x2), omy + (y2)); COST_MV(omx + (x3), omy + (y3)); } while (0)
+#define DIA1_ITER(mx, my) do { omx = (mx); omy = (my); COST_MV_X4(0, -1, 0, 1, -1, 0, 1, 0); } while (0)
+#define CROSS(start, x_max, y_max) do { \
+            for (int i_ = (start); i_ < (x_max); i_ += 2) { \
+                if (omx + i_ <= fmax[0]) COST_MV(omx + i_, omy); \
+                if (omx - i_ >= fmin[0]) COST_MV(omx - i_, omy); } \
+            for (int i_ = (start); i_ < (y_max); i_ += 2) { \
+                if (omy + i_ <= fmax[1]) COST_MV(omx, omy + i_); \
+                if (omy - i_ >= fmin[1]) COST_MV(omx, omy - i_); } } while (0)
+#define SAD_THRESH(v) (bcost < ((v) >> shift))
+        const int ucost1 = bcost;
+        DIA1_ITER(pmx, pmy);
+        if (pmx | pmy) DIA1_ITER(0, 0);
+        const int ucost2 = bcost;
+        if ((bmx | bmy) && ((bmx - pmx) | (bmy - pmy))) DIA1_ITER(bmx, bmy);
+        if (bcost == ucost2) cross_start = 3;
+        omx = bmx; omy = bmy;
+        if (bcost == ucost2 && SAD_THRESH(2000)) {
+            COST_MV_X4(0, -2, -1, -1, 1, -1, -2, 0);
+            COST_MV_X4(2, 0, -1, 1, 1, 1, 0, 2);
+            if (bcost == ucost1 && SAD_THRESH(500)) done = 1;
+            else if (bcost == ucost2) {
+                const int r1 = (range >> 1) | 1;
+                CROSS(3, r1, r1);
+                COST_MV_X4(-1, -2, 1, -2, -2, -1, 2, -1);
+                COST_MV_X4(-2, 1, 2, 1, -1, 2, 1, 2);
+                if (bcost == ucost2) done = 1;
+                cross_start = r1 + 2;
+            }
+        }
+        if (!done) {
+            /* adaptive search range: agreement of the predictors x SAD level */
+            int mvd;
+            if (w == 16 && h == 16) mvd = ncand <= 2 ? 25 : 4 * (abs(cand[1][0] - cand[2][0]) + abs(cand[1][1] - cand[2][1]));
+            else mvd = abs(mvp[0] - 4 * cand[0][0]) + abs(mvp[1] - 4 * cand[0][1]);
+            const int sad_ctx = SAD_THRESH(1000) ? 0 : SAD_THRESH(2000) ? 1 : SAD_THRESH(4000) ? 2 : 3;
+            const int mvd_ctx = mvd < 10 ? 0 : mvd < 20 ? 1 : mvd < 40 ? 2 : 3;
+            range = range * range_mul[mvd_ctx][sad_ctx] >> 2;
+            /* x264 keeps the cross centred where the small diamonds left it ("FIXME ... is this desirable?") */
+            CROSS(cross_start, range, range >> 1);
+            COST_MV_X4(-2, -2, -2, 2, 2, -2, 2, 2);
+            omx = bmx; omy = bmy;
+            int i = 1;
+            do {
+                for (int j = 0; j < 16; j++) {
+                    int mx = omx + hex4[j][0] * i, my = omy + hex4[j][1] * i;
+                    if (INRANGE(mx, my)) COST_MV(mx, my);
+                }
+            } while (++i <= range >> 2);
+            if (!INRANGE(bmx, bmy)) done = 1;
+        }
+#undef SAD_THRESH
+#undef CROSS
+#undef DIA1_ITER
+#undef COST_MV_X4
+#undef COST_MV
+#undef INRANGE
+        if (done) goto fullpel_done;
+    }
     /* hexagon search (radius 2), then 3x3 square refine; first-best wins ties, centre wins over all */
     {
         int key = bcost << 3;
@@ -343,7 +419,7 @@ static me_result me_search_block(x264o_encoder *e, int mbx, int mby, int ox, int
         if (key & 7) {
             int dir = (key & 7) - 2;
             bmx += hex2[dir + 1][0]; bmy += hex2[dir + 1][1];
-            for (int i = (e->cfg.me_range >> 1) - 1; i > 0 && bmx >= fmin[0] && bmx <= fmax[0] && bmy >= fmin[1] && bmy <= fmax[1]; i--) {
+            for (int i = (range >> 1) - 1; i > 0 && bmx >= fmin[0] && bmx <= fmax[0] && bmy >= fmin[1] && bmy <= fmax[1]; i--) {
                 key &= ~7;
                 for (int k = 0; k < 3; k++) {
                     int c = (FPEL_COST(bmx + hex2[dir + k][0], bmy + hex2[dir + k][1]) << 3) + k + 1;
@@ -363,6 +439,8 @@ static me_result me_search_block(x264o_encoder *e, int mbx, int mby, int ox, int
         }
         bmx += square1[bdir][0]; bmy += square1[bdir][1];
     }
+    }
+fullpel_done:;
 #undef FPEL_COST
     /* sub-pel refinement (subme>=2): half-pel diamond on SAD, then quarter-pel diamond on SATD */
     static const uint8_t iters[12][2] = { { 0, 0 }, { 0, 0 }, { 1, 0 }, { 1, 0 }, { 1, 1 }, { 1, 2 }, { 2, 2 }, { 2, 2 }, { 4, 10 }, { 4, 10 }, { 4, 10 }, { 4, 10 } };

@@ -72,8 +72,8 @@ int x264gpu_encoder_create(x264gpu_encoder **out, const x264gpu_config *cfg)
     ARG_TRY(out && cfg);
     ARG_TRY(cfg->width >= 16 && cfg->height >= 16 && !(cfg->width & 1) && !(cfg->height & 1) && cfg->streams >= 1);
     ARG_TRY(cfg->qp_i >= 0 && cfg->qp_i <= 51 && cfg->qp_p >= 0 && cfg->qp_p <= 51 && cfg->refs >= 1 && cfg->refs <= 4);
-    ARG_TRY(cfg->width <= 4096 && cfg->height <= 2304 && cfg->me_range >= 4 && cfg->me_range <= 16);
-    ARG_TRY(cfg->me_method == 0 || cfg->me_method == 1);
+    ARG_TRY(cfg->width <= 4096 && cfg->height <= 2304 && cfg->me_range >= 4 && cfg->me_range <= (cfg->me_method == 2 ? 64 : 16));
+    ARG_TRY(cfg->me_method >= 0 && cfg->me_method <= 2);
     x264gpu_encoder *e = new (std::nothrow) x264gpu_encoder();
     if (!e) return set_err(X264GPU_ENOMEM, "encoder", hipSuccess);
     e->cfg = *cfg;
@@ -213,8 +213,12 @@ int x264gpu_encode_frames(x264gpu_encoder *e, const uint8_t *d_i420, int slice_t
     if (slice_type == X264GPU_SLICE_P) {
         // sub-pel neighbourhood margin: 2 px reaches every step of subme <= 7, subme >= 8 needs 5 px
         const int me_blocks = (((k.nmb + 3) / 4 + 7) / 8) * 8;      // multiple of 8: XCD-contiguous mapping in the kernel
-        if (k.subme >= 8) hipLaunchKernelGGL(k_analyse_p<5>, dim3(me_blocks, S), dim3(256), 0, st, k);
-        else hipLaunchKernelGGL(k_analyse_p<2>, dim3(me_blocks, S), dim3(256), 0, st, k);
+        // sub-pel neighbourhood margin 2 (subme <= 7) or 5; UMH is its own instantiation so that the hexagon kernels keep their registers
+        if (k.me_method == 2) {
+            if (k.subme >= 8) hipLaunchKernelGGL((k_analyse_p<5, true>), dim3(me_blocks, S), dim3(256), 0, st, k);
+            else hipLaunchKernelGGL((k_analyse_p<2, true>), dim3(me_blocks, S), dim3(256), 0, st, k);
+        } else if (k.subme >= 8) hipLaunchKernelGGL((k_analyse_p<5, false>), dim3(me_blocks, S), dim3(256), 0, st, k);
+        else hipLaunchKernelGGL((k_analyse_p<2, false>), dim3(me_blocks, S), dim3(256), 0, st, k);
         STAGE_MARK(2);
         hipLaunchKernelGGL(k_encode_inter, dim3((k.nmb + 3) / 4, S), dim3(256), 0, st, k);
         mask |= 2 | 4;

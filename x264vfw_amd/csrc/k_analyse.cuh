@@ -201,8 +201,14 @@ struct PartCtx {
     uint32_t *sub;                             // LDS sub-pel neighbourhood buffer (SUB_DWORDS)
     const uint8_t *fenc; int fs;               // source macroblock (for the candidate-parallel 8x8 search)
     const uint8_t *cref, *fuv; int chroma_me;  // chroma-ME: NV12 reference plane (origin), source NV12 of this macroblock
+    const uint16_t *gcx, *gcy; int mvp0, mvp1; // UMH: mv-cost table in global memory (index = qpel mv), cost predictor
 };
-__device__ __forceinline__ int pc_mvcost(const PartCtx &c, int qx, int qy) { return c.cx[qx - c.cbx + 96] + c.cy[qy - c.cby + 96]; }
+template <bool UMH>
+__device__ __forceinline__ int pc_mvcost(const PartCtx &c, int qx, int qy)
+{
+    if (UMH) return c.gcx[qx] + c.gcy[qy];                         // UMH ends anywhere: no LDS slice around the start
+    return c.cx[qx - c.cbx + 96] + c.cy[qy - c.cby + 96];
+}
 // ------------------------------------------------------------------------------------------------
 // Candidate-parallel partition search: the lanes of a partition split into four groups that evaluate four CANDIDATE vectors at
 // once; a lane holds 16 pixels of its partition per candidate (as in the 16x16 search).  Per-partition search state is uniform
@@ -251,10 +257,148 @@ __device__ __forceinline__ int satd8x8_2rows_half(const uint32_t e0[2], const ui
     return (int)(as_u32(acc) & 0xffffu);
 }
 
+// ------------------------------------------------------------------------------------------------
+// X264_ME_UMH, full-pel part (oracle me_search_block, me_method 2; [x264-upstream] me.c "Uneven-cross Multi-Hexagon-grid").
+// The search roams up to ~70 pixels from its start, so it reads the reference plane and the mv-cost table from global memory
+// (L2-resident rows) instead of the LDS window of the hexagon search.  SHAPE 0 is the 16x16 block (16 lanes per candidate, a
+// lane = one row as two 8-pixel segments), 1..3 the sub-partition layouts of search_parts; all partitions of a shape run at
+// once with partition-private state and predicated updates.  Every update is x264's in-order "strictly better wins": four
+// candidates are costed side by side and the minimum of (cost << 2 | order) is compared with the running best.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ int sad8_global(const uint8_t *p, uint32_t e0, uint32_t e1)
+{
+    const unsigned sd = __builtin_amdgcn_sad_u8(load_u32_unaligned(p), e0, 0u);
+    return (int)__builtin_amdgcn_sad_u8(load_u32_unaligned(p + 4), e1, sd);
+}
+__device__ __forceinline__ int umh_hex4_dx(int j) { return (int)((0x6280808080806244ull >> (4 * j)) & 15) - 4; }
+__device__ __forceinline__ int umh_hex4_dy(int j) { return (int)((0x7766554433221180ull >> (4 * j)) & 15) - 4; }
+
+__device__ __forceinline__ void umh_fullpel(const PartCtx &c, const int SHAPE, const int mvd, int &bx, int &by, int &bcost)
+{
+    const int lane = c.lane, GL = SHAPE == 0 ? 16 : SHAPE == 3 ? 4 : 8;
+    const int part = SHAPE == 0 ? 0 : SHAPE == 3 ? lane >> 4 : lane >> 5, cnd = SHAPE == 0 ? lane >> 4 : SHAPE == 3 ? (lane >> 2) & 3 : (lane >> 3) & 3;
+    const int sr = lane & (GL - 1), pbase = lane - cnd * GL - sr;
+    const int ox = SHAPE == 3 ? (part & 1) * 8 : SHAPE == 2 ? part * 8 : 0, oy = SHAPE == 3 ? (part >> 1) * 8 : SHAPE == 1 ? part * 8 : 0;
+    const bool wide = SHAPE < 2;                     // 16-pixel rows: the two segments are the halves of one row
+    const int y0 = oy + (wide ? sr : 2 * sr), y1 = wide ? y0 : y0 + 1, x1 = wide ? 8 : 0;
+    uint32_t e00, e01, e10, e11;
+    { const uint2 a = *(const uint2 *)(c.fenc + (size_t)y0 * c.fs + ox), b = *(const uint2 *)(c.fenc + (size_t)y1 * c.fs + ox + x1);
+      e00 = a.x; e01 = a.y; e10 = b.x; e11 = b.y; }
+    const uint8_t *g0 = c.p00 + (long)(c.py + y0) * c.rs + c.px + ox, *g1 = c.p00 + (long)(c.py + y1) * c.rs + c.px + ox + x1;
+    auto gsum = [&](int v) { v = quad_sum(v); if (GL >= 8) v += xor4(v); if (GL == 16) v += dpp<DPP_ROW_MIRROR>(v); return v; };
+    auto cmin = [&](unsigned k) {
+        if (SHAPE == 0) return wave_min_u32(k);
+        if (SHAPE == 3) return row16_min_u32(k);
+        unsigned t = (unsigned)__builtin_amdgcn_update_dpp(0, (int)k, 0x128, 0xf, 0xf, true);
+        k = t < k ? t : k;
+        t = (unsigned)__shfl_xor((int)k, 16);
+        return t < k ? t : k;
+    };
+    auto inrange = [&](int mx, int my) { return mx >= c.fmin0 && mx <= c.fmax0 && my >= c.fmin1 && my <= c.fmax1; };
+    // cost this lane group's candidate (mx,my) if `valid`; the partition takes the best of its four groups when it beats bcost.
+    // Returns the winning group (0..3) or -1.
+    auto step = [&](int mx, int my, bool valid) {
+        mx = valid ? mx : bx; my = valid ? my : by;                 // keep the loads of masked candidates inside the padded plane
+        const long o = (long)my * c.rs + mx;
+        const int cst = gsum(sad8_global(g0 + o, e00, e01) + sad8_global(g1 + o, e10, e11)) + c.gcx[mx * 4] + c.gcy[my * 4];
+        unsigned kk = valid ? ((unsigned)cst << 2) | (unsigned)cnd : 0xffffffffu;
+        kk = cmin(kk);
+        const int wl = pbase + (int)(kk & 3) * GL;
+        const int wx = __shfl(mx, wl), wy = __shfl(my, wl);
+        if (kk != 0xffffffffu && (int)(kk >> 2) < bcost) { bcost = (int)(kk >> 2); bx = wx; by = wy; return (int)(kk & 3); }
+        return -1;
+    };
+    const int d1x = cnd == 2 ? -1 : cnd == 3 ? 1 : 0, d1y = cnd == 0 ? -1 : cnd == 1 ? 1 : 0;      // DIA1: (0,-1) (0,1) (-1,0) (1,0)
+    const int shift = SHAPE == 0 ? 0 : SHAPE == 3 ? 2 : 1;                                         // x264 pixel_size_shift
+#define UMH_TH(v) (bcost < ((v) >> shift))
+    const int pmx = clampi((c.mvp0 + 2) >> 2, c.fmin0, c.fmax0), pmy = clampi((c.mvp1 + 2) >> 2, c.fmin1, c.fmax1);
+    const int ucost1 = bcost;
+    step(pmx + d1x, pmy + d1y, true);
+    if (pmx | pmy) step(d1x, d1y, true);
+    const int ucost2 = bcost;
+    { const bool en = (bx | by) && ((bx - pmx) | (by - pmy)); if (__any(en)) step(bx + d1x, by + d1y, en); }
+    int cross_start = bcost == ucost2 ? 3 : 1;
+    const int omx = bx, omy = by;                       // x264 keeps the cross centred here
+    // uneven cross: +-i along x for i = start, start+2, .. < xmax, then along y; four candidates (+i, -i, +(i+2), -(i+2)) per pass
+    auto cross = [&](int start, int xmax, int ymax, bool en) {
+        for (int t = 0; __any(en && start + 4 * t < xmax); t++) {
+            const int i0 = start + 4 * t + 2 * (cnd >> 1), mx = omx + ((cnd & 1) ? -i0 : i0);
+            step(mx, omy, en && i0 < xmax && ((cnd & 1) ? mx >= c.fmin0 : mx <= c.fmax0));
+        }
+        for (int t = 0; __any(en && start + 4 * t < ymax); t++) {
+            const int i0 = start + 4 * t + 2 * (cnd >> 1), my = omy + ((cnd & 1) ? -i0 : i0);
+            step(omx, my, en && i0 < ymax && ((cnd & 1) ? my >= c.fmin1 : my <= c.fmax1));
+        }
+    };
+    bool done = false;
+    const bool et = bcost == ucost2 && UMH_TH(2000);
+    if (__any(et)) {                                    // early termination: small octagon
+        step(omx + (cnd == 0 ? 0 : cnd == 1 ? -1 : cnd == 2 ? 1 : -2), omy + (cnd == 0 ? -2 : cnd == 3 ? 0 : -1), et);     // (0,-2) (-1,-1) (1,-1) (-2,0)
+        step(omx + (cnd == 0 ? 2 : cnd == 1 ? -1 : cnd == 2 ? 1 : 0), omy + (cnd == 0 ? 0 : cnd == 3 ? 2 : 1), et);       // (2,0) (-1,1) (1,1) (0,2)
+        done = et && bcost == ucost1 && UMH_TH(500);
+        const bool et2 = et && !done && bcost == ucost2;
+        if (__any(et2)) {
+            const int r1 = (c.me_range >> 1) | 1;
+            cross(3, r1, r1, et2);
+            step(omx + (cnd == 0 ? -1 : cnd == 1 ? 1 : cnd == 2 ? -2 : 2), omy + (cnd < 2 ? -2 : -1), et2);                // (-1,-2) (1,-2) (-2,-1) (2,-1)
+            step(omx + (cnd == 0 ? -2 : cnd == 1 ? 2 : cnd == 2 ? -1 : 1), omy + (cnd < 2 ? 1 : 2), et2);                  // (-2,1) (2,1) (-1,2) (1,2)
+            done = done || (et2 && bcost == ucost2);
+            if (et2) cross_start = r1 + 2;
+        }
+    }
+    int range = c.me_range;
+    if (__any(!done)) {
+        const bool live = !done;
+        // adaptive search range: SAD level x disagreement of the predictors (x264 range_mul)
+        const int sad_ctx = UMH_TH(1000) ? 0 : UMH_TH(2000) ? 1 : UMH_TH(4000) ? 2 : 3;
+        const int mvd_ctx = mvd < 10 ? 0 : mvd < 20 ? 1 : mvd < 40 ? 2 : 3;
+        range = (range * (int)((0x6544544444434433ull >> (4 * (mvd_ctx * 4 + sad_ctx))) & 15)) >> 2;
+        cross(cross_start, range, range >> 1, live);
+        step(omx + ((cnd & 2) ? 2 : -2), omy + ((cnd & 1) ? 2 : -2), live);                                                  // (-2,-2) (-2,2) (2,-2) (2,2)
+        // 16-point hexagon grid rings around the best so far, radius 4*i
+        const int hx = bx, hy = by;
+        for (int i = 1; __any(live && (i == 1 || i <= (range >> 2))); i++) {          // do .. while (++i <= range >> 2)
+            const bool en = live && (i == 1 || i <= (range >> 2));
+            for (int ps = 0; ps < 4; ps++) {
+                const int j = 4 * ps + cnd, mx = hx + umh_hex4_dx(j) * i, my = hy + umh_hex4_dy(j) * i;
+                step(mx, my, en && inrange(mx, my));
+            }
+        }
+        done = done || !inrange(bx, by);
+    }
+#undef UMH_TH
+    // hexagon (radius 2, up to range/2 - 1 moves) + square refine of the partitions that are still searching (x264 me_hex2)
+    if (__any(!done)) {
+        bool running = !done;
+        int dir = 0;
+        {
+            const int cx0 = bx, cy0 = by;
+            const int q1 = step(cx0 + hex_dx(1 + cnd), cy0 + hex_dy(1 + cnd), running);
+            const int q2 = step(cx0 + hex_dx(5 + (cnd & 1)), cy0 + hex_dy(5 + (cnd & 1)), running && cnd < 2);
+            const int kw = q2 >= 0 ? 5 + q2 : q1 >= 0 ? 1 + q1 : 0;
+            running = running && kw != 0;
+            dir = kw - 1;
+        }
+        for (int n = 0; ; n++) {
+            running = running && n < (range >> 1) - 1 && inrange(bx, by);
+            if (!__any(running)) break;
+            const int cc = cnd < 3 ? cnd : 0, cx0 = bx, cy0 = by, d0 = running ? dir : 0;
+            const int q = step(cx0 + hex_dx(d0 + cc), cy0 + hex_dy(d0 + cc), running && cnd < 3);
+            if (running) {
+                if (q < 0) running = false;
+                else { dir += q - 1; dir = dir < 0 ? 5 : dir > 5 ? 0 : dir; }
+            }
+        }
+        const int cx0 = bx, cy0 = by;
+        step(cx0 + sq_dx(1 + cnd), cy0 + sq_dy(1 + cnd), !done);
+        step(cx0 + sq_dx(5 + cnd), cy0 + sq_dy(5 + cnd), !done);
+    }
+}
+
 // SHAPE 3: four 8x8 partitions (one per DPP row, four lanes per candidate); 1: two 16x8; 2: two 8x16 (32 lanes per partition,
 // eight lanes per candidate).  A lane holds two 8-pixel segments of its partition: rows (2s, 2s+1) for the 8-wide shapes,
 // the left and right half of row s for 16x8.
-template <int M>
+template <int M, bool UMH>
 __device__ int search_parts(const PartCtx &c, const int SHAPE, int c0x, int c0y, int &out_mx, int &out_my)
 {
     const int GL = SHAPE == 3 ? 4 : 8;             // SHAPE is wave-uniform: one copy of the code serves the three shapes
@@ -279,9 +423,16 @@ __device__ int search_parts(const PartCtx &c, const int SHAPE, int c0x, int c0y,
     };
     // candidate cost (uniform over the candidate's lanes): SAD of the partition at full-pel (fx,fy) + mv cost
 #define FPC(fx, fy) (gsum(sad8_lds(c.win, wb0 + (fy) * WIN_STRIDE + (fx), e0[0], e0[1]) + sad8_lds(c.win, wb1 + (fy) * WIN_STRIDE + (fx), e1[0], e1[1])) + \
-                     pc_mvcost(c, (fx) * 4, (fy) * 4))
+                     pc_mvcost<UMH>(c, (fx) * 4, (fy) * 4))
     int bx = c0x, by = c0y, bcost;
-    if (c.me_method == 0) {
+    if (UMH) {
+        {   // start candidate = the 16x16 vector (every group costs it)
+            const long o = (long)by * c.rs + bx;
+            const uint8_t *g0 = c.p00 + (long)(c.py + y0) * c.rs + c.px + ox, *g1 = c.p00 + (long)(c.py + y1) * c.rs + c.px + ox + x1;
+            bcost = gsum(sad8_global(g0 + o, e0[0], e0[1]) + sad8_global(g1 + o, e1[0], e1[1])) + pc_mvcost<UMH>(c, bx * 4, by * 4);
+        }
+        umh_fullpel(c, SHAPE, abs(c.mvp0 - 4 * c0x) + abs(c.mvp1 - 4 * c0y), bx, by, bcost);
+    } else if (c.me_method == 0) {
         bcost = FPC(bx, by);
         bool running = true;
         for (int it = c.me_range; it > 0; it--) {
@@ -370,7 +521,7 @@ __device__ int search_parts(const PartCtx &c, const int SHAPE, int c0x, int c0y,
             sub_row8(sb, sn, rwl, sx0, sy0, X1, Y1, cx, cy, p1);
             unsigned sd = __builtin_amdgcn_sad_u8(p0[0], e0[0], 0u);
             sd = __builtin_amdgcn_sad_u8(p0[1], e0[1], sd); sd = __builtin_amdgcn_sad_u8(p1[0], e1[0], sd); sd = __builtin_amdgcn_sad_u8(p1[1], e1[1], sd);
-            const unsigned kk = cmin(((unsigned)(gsum((int)sd) + pc_mvcost(c, cx, cy)) << 2) | (unsigned)cnd);
+            const unsigned kk = cmin(((unsigned)(gsum((int)sd) + pc_mvcost<UMH>(c, cx, cy)) << 2) | (unsigned)cnd);
             if (hp_run && (int)(kk >> 2) < bcost) {
                 const int b = kk & 3;
                 bcost = (int)(kk >> 2);
@@ -381,7 +532,7 @@ __device__ int search_parts(const PartCtx &c, const int SHAPE, int c0x, int c0y,
             uint32_t p0[2], p1[2];
             sub_row8(sb, sn, rwl, sx0, sy0, X0, Y0, mx, my, p0);
             sub_row8(sb, sn, rwl, sx0, sy0, X1, Y1, mx, my, p1);
-            bcost = satd_part(p0, p1) + pc_mvcost(c, mx, my);
+            bcost = satd_part(p0, p1) + pc_mvcost<UMH>(c, mx, my);
             if (c.chroma_me) bcost += gsum(chroma_me_half(c.cref, c.rs, (c.px >> 1) + ccx, (c.py >> 1) + ccy, mx, my, ce0, ce1, sg1, sg2));
         }
         int bdir = -1;
@@ -393,7 +544,7 @@ __device__ int search_parts(const PartCtx &c, const int SHAPE, int c0x, int c0y,
             uint32_t p0[2], p1[2];
             sub_row8(sb, sn, rwl, sx0, sy0, X0, Y0, cx, cy, p0);
             sub_row8(sb, sn, rwl, sx0, sy0, X1, Y1, cx, cy, p1);
-            int cst = satd_part(p0, p1) + pc_mvcost(c, cx, cy);
+            int cst = satd_part(p0, p1) + pc_mvcost<UMH>(c, cx, cy);
             // a candidate whose luma cost is not below the best cost cannot win; chroma only when some partition still can improve
             if (c.chroma_me && __any(qp_run && cst < bcost && (cnd ^ 1) != bdir))
                 cst += gsum(chroma_me_half(c.cref, c.rs, (c.px >> 1) + ccx, (c.py >> 1) + ccy, cx, cy, ce0, ce1, sg1, sg2));
@@ -414,7 +565,7 @@ __device__ int search_parts(const PartCtx &c, const int SHAPE, int c0x, int c0y,
     return bcost;
 }
 
-template <int M>
+template <int M, bool UMH>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(X264GPU_ANALYSE_WAVES, 8))) void k_analyse_p(EncK k)
 {
     __shared__ __attribute__((aligned(16))) uint8_t s_win[4][WIN_ROWS * WIN_STRIDE];
@@ -475,7 +626,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(X264GPU_ANA
     for (int r_ = 0; r_ < k.nref; r_++) {
         const uint8_t *p00 = ref_plane00(k, s, r_);
         // ---- start candidates: predictor, zero, co-located (lane groups 0..2 evaluate one each) ----
-        int bmx, bmy, bcost;
+        int bmx, bmy, bcost, umh_mvd16;
         {
             int cx[3], cy[3];
             cx[0] = clampi((mvp0 + 2) >> 2, fmin0, fmax0); cy[0] = clampi((mvp1 + 2) >> 2, fmin1, fmax1);
@@ -483,6 +634,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(X264GPU_ANA
             const bool has_col = rf[mbi] >= 0;
             cx[2] = has_col ? clampi((mvf[2 * mbi] + 2) >> 2, fmin0, fmax0) : 0;
             cy[2] = has_col ? clampi((mvf[2 * mbi + 1] + 2) >> 2, fmin1, fmax1) : 0;
+            umh_mvd16 = has_col ? 4 * (abs(cx[1] - cx[2]) + abs(cy[1] - cy[2])) : 25;
             const int c = cnd < 3 ? cnd : 0;
             const int mx = c == 0 ? cx[0] : c == 1 ? cx[1] : cx[2], my = c == 0 ? cy[0] : c == 1 ? cy[1] : cy[2];
             int sad = sad_row16_global(p00 + (long)(py + my + r) * k.rs + px + mx, cr);
@@ -500,6 +652,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(X264GPU_ANA
         int wx0 = (px + bmx - WIN_R) & ~7, wy0 = py + bmy - WIN_R;
         wx0 = clampi(wx0, -PAD, k.cw + PAD - WIN_COLS);
         wy0 = clampi(wy0, -PAD, k.ch + PAD - WIN_ROWS);
+        if (!UMH)
         for (int i = lane; i < WIN_ROWS * 8; i += 64) {
             const int row = i >> 3, col = (i & 7) * 8;
             const uint2 v = *(const uint2 *)(p00 + (long)(wy0 + row) * k.rs + wx0 + col);
@@ -515,13 +668,19 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(X264GPU_ANA
         }
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_s_waitcnt(0xc07f);
-    #define MVC(qx, qy) ((int)s_cost[wave][0][(qx) - cbx + 96] + (int)s_cost[wave][1][(qy) - cby + 96])
+    #define MVC(qx, qy) (UMH ? (int)cmx[qx] + (int)cmy[qy] : (int)s_cost[wave][0][(qx) - cbx + 96] + (int)s_cost[wave][1][(qy) - cby + 96])
 
         // cost of full-pel candidate (mx,my) for this lane's row; valid after row16_sum on the 16-lane group
     #define FPEL_KEY(mx, my, tag) \
         (((unsigned)(row16_sum(sad_row16_lds(win + (py + (my) + r - wy0) * WIN_STRIDE, px + (mx) - wx0, cr)) + MVC((mx) * 4, (my) * 4)) << 3) | (unsigned)(tag))
 
-        if (k.me_method == 0) {
+        if (UMH) {
+            // ---- X264_ME_UMH (global-memory search, see umh_fullpel); mvc = {zero, co-located} ----
+            PartCtx u;
+            u.p00 = p00; u.rs = k.rs; u.px = px; u.py = py; u.fenc = fenc; u.fs = k.fs; u.lane = lane; u.me_range = k.me_range; u.me_method = 2;
+            u.fmin0 = fmin0; u.fmax0 = fmax0; u.fmin1 = fmin1; u.fmax1 = fmax1; u.gcx = cmx; u.gcy = cmy; u.mvp0 = mvp0; u.mvp1 = mvp1;
+            umh_fullpel(u, 0, umh_mvd16, bmx, bmy, bcost);
+        } else if (k.me_method == 0) {
             // ---- X264_ME_DIA: the four neighbours are exactly the four lane groups; centre wins ties ----
             int it = k.me_range;
             do {
@@ -654,6 +813,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(X264GPU_ANA
         const int c0x = clampi((mx + 2) >> 2, fmin0, fmax0), c0y = clampi((my + 2) >> 2, fmin1, fmax1);
         int pwx0 = clampi((px + c0x - WIN_R) & ~7, -PAD, k.cw + PAD - WIN_COLS), pwy0 = clampi(py + c0y - WIN_R, -PAD, k.ch + PAD - WIN_ROWS);
         __builtin_amdgcn_wave_barrier();
+        if (!UMH)
         for (int i = lane; i < WIN_ROWS * 8; i += 64) {
             const int row = i >> 3, col = (i & 7) * 8;
             const uint2 v = *(const uint2 *)(p00 + (long)(pwy0 + row) * k.rs + pwx0 + col);
@@ -672,6 +832,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(X264GPU_ANA
         pc.fmin0 = fmin0; pc.fmax0 = fmax0; pc.fmin1 = fmin1; pc.fmax1 = fmax1; pc.smin0 = smin0; pc.smax0 = smax0; pc.smin1 = smin1; pc.smax1 = smax1;
         pc.me_range = k.me_range; pc.me_method = k.me_method; pc.lane = lane; pc.sub = s_sub[wave]; pc.fenc = fenc; pc.fs = k.fs;
         pc.chroma_me = chroma_me; pc.cref = ref_chroma00(k, s, bref); pc.fuv = fuv;
+        pc.gcx = cmx; pc.gcy = cmy; pc.mvp0 = mvp0; pc.mvp1 = mvp1;
         const int sub = min(k.subme, 11);
         pc.hp_it = sub < 2 ? 0 : sub < 6 ? 1 : sub < 8 ? 2 : 4;
         pc.qp_it = sub < 4 ? 0 : sub == 4 ? 1 : sub < 8 ? 2 : 10;
@@ -679,7 +840,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(X264GPU_ANA
             const int shape = oi == 0 ? 3 : oi;
             if (oi > 0 && best_shape == 0) break;
             int smx, smy;
-            const int pcost = search_parts<M>(pc, shape, c0x, c0y, smx, smy);
+            const int pcost = search_parts<M, UMH>(pc, shape, c0x, c0y, smx, smy);
             int total = k.lambda * ((shape == 3 ? 8 : 2) + (shape == 3 ? 4 : 2) * ref_bits(k.nref, bref));
             if (shape == 3) total += __builtin_amdgcn_readlane(pcost, 0) + __builtin_amdgcn_readlane(pcost, 16) + __builtin_amdgcn_readlane(pcost, 32) + __builtin_amdgcn_readlane(pcost, 48);
             else if (shape == 1) total += __builtin_amdgcn_readlane(pcost, 0) + __builtin_amdgcn_readlane(pcost, 32);
