@@ -186,6 +186,24 @@ int  x264gpu_encoder_profile_begin(x264gpu_encoder *enc, int max_calls);
  * wavefront kernels: {intra wait, work, MBs, total, deblock wait, work, MBs, total, 5 intra section sums, 3 spare} */
 int  x264gpu_encoder_set_debug(x264gpu_encoder *enc, void *d_counters);
 int  x264gpu_encoder_profile_end(x264gpu_encoder *enc, void *stream, double *ms_sum, int *launches);
+/* Quantisers of the following x264gpu_encode_frames calls (every stream of the call shares them): what x264_ratecontrol_start
+ * hands the slice ([x264-upstream] encoder/ratecontrol.c; CRF / scenecut sessions change it per picture). */
+int  x264gpu_encoder_set_qp(x264gpu_encoder *enc, int qp_i, int qp_p);
+
+/* ------------------------------------------------------------------------------------------------
+ * Lookahead frame cost: x264_slicetype_frame_cost of [x264-upstream]
+ * encoder/slicetype.c for the pair p0 = previous picture, b = p1 = new picture, on half-resolution planes
+ * (frame_init_lowres + 8x8 hexagon / sub-pel search + 8x8 intra SATD, lambda of qp 12).  Feeds the scenecut decision and
+ * the CRF complexity (x264_rc_analyse_slice) of the host encoder; independent of the encoder's DPB (source pictures only).
+ * d_i420: `streams` tightly packed I420 pictures.  reset != 0 forgets the previous picture (first picture / after an IDR
+ * decided elsewhere is NOT a reset: x264 keeps comparing consecutive source pictures).
+ * d_out [streams][4] int32: intra cost (i_cost_est[0][0]), P cost (i_cost_est[1][0]; = intra cost without a previous
+ * picture), blocks where intra won, blocks in the frame score.  d_blocks (optional) [streams][blocks][2]: intra, best cost.
+ * ------------------------------------------------------------------------------------------------ */
+typedef struct x264gpu_lookahead x264gpu_lookahead;
+int  x264gpu_lookahead_create(x264gpu_lookahead **la, int width, int height, int streams, int me_range, int subme);
+void x264gpu_lookahead_destroy(x264gpu_lookahead *la);
+int  x264gpu_lookahead_frame_cost(x264gpu_lookahead *la, const uint8_t *d_i420, int reset, int32_t *d_out, int32_t *d_blocks, void *stream);
 
 #ifdef __cplusplus
 }

@@ -113,6 +113,7 @@ void x264o_encoder_destroy(x264o_encoder *e)
 }
 
 int x264o_encoder_mb_count(const x264o_encoder *e) { return e->mbw * e->mbh; }
+void x264o_encoder_set_qp(x264o_encoder *e, int qp_i, int qp_p) { e->cfg.qp_i = qp_i; e->cfg.qp_p = qp_p; }
 
 static const uint16_t *cost_mv_for(x264o_encoder *e, int qp)
 {

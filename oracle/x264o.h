@@ -92,6 +92,13 @@ void x264o_predict_4x4(pixel *dst, int sd, const pixel *src, int ss, int mode, i
 void x264o_predict_8x8_filter(const pixel *src, int ss, pixel edge[33], int avail);
 void x264o_predict_8x8(pixel *dst, int sd, const pixel edge[33], int mode);
 
+/* ---- lookahead frame cost: encoder/slicetype.c (A12, next-row f2) — oracle/lookahead.c ---- */
+typedef struct x264o_lookahead x264o_lookahead;
+x264o_lookahead *x264o_lookahead_create(int width, int height, int me_range, int subme);
+void x264o_lookahead_destroy(x264o_lookahead *la);
+/* out[4] = { intra cost, P cost vs the previous picture, intra blocks, blocks in the frame score }; block_costs optional */
+int  x264o_lookahead_frame_cost(x264o_lookahead *la, const uint8_t *i420, int reset, int32_t out[4], int32_t *block_costs);
+
 /* ---- motion compensation / plane filters: common/mc.c, common/frame.c (A1/A4/A10) ---- */
 /* hpel planes: dsth/dstv/dstc (H, V, centre=HV) for an w x h region; src is read with
  * coordinates clamped to [0,w-1]x[0,h-1] by the caller-supplied clamp dims (planes are produced

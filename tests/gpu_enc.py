@@ -47,3 +47,36 @@ class GpuEncoder:
             self.close()
         except Exception:
             pass
+
+
+class GpuLookahead:
+    """Mirror of x264gpu_lookahead_* (include/x264gpu.h)."""
+
+    def __init__(self, w, h, streams=1, me_range=16, subme=7):
+        import torch
+        self.torch = torch
+        self.S = streams
+        self.nb = ((w + 15) // 16) * ((h + 15) // 16)
+        self.h = C.c_void_p()
+        lib.check(lib.x264gpu_lookahead_create(C.byref(self.h), w, h, streams, me_range, subme), "lookahead_create")
+        self.d_out = torch.zeros((streams, 4), dtype=torch.int32, device="cuda")
+        self.d_blocks = torch.zeros((streams, self.nb, 2), dtype=torch.int32, device="cuda")
+
+    def frame_cost(self, frames, reset=False):
+        t = self.torch
+        d_in = t.from_numpy(np.stack(frames)).cuda()
+        lib.check(lib.x264gpu_lookahead_frame_cost(self.h, d_in.data_ptr(), int(reset), self.d_out.data_ptr(),
+                                                   self.d_blocks.data_ptr(), None), "lookahead_frame_cost")
+        t.cuda.synchronize()
+        return self.d_out.cpu().numpy(), self.d_blocks.cpu().numpy()
+
+    def close(self):
+        if self.h:
+            lib.x264gpu_lookahead_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -138,6 +138,7 @@ from x264vfw_amd.lib import Config, MbRecord, MB_LEVELS  # noqa: E402  (plain ct
 _sig("x264o_encoder_create", C.c_void_p, [C.POINTER(Config)])
 _sig("x264o_encoder_destroy", None, [C.c_void_p])
 _sig("x264o_encoder_mb_count", _i, [C.c_void_p])
+_sig("x264o_encoder_set_qp", None, [C.c_void_p, _i, _i])
 _sig("x264o_encoder_encode", _i, [C.c_void_p, C.c_void_p, _i, C.c_void_p, C.c_void_p])
 _sig("x264o_encoder_get_recon", None, [C.c_void_p, C.c_void_p])
 _sig("x264o_encoder_ref_plane", C.c_void_p, [C.c_void_p, _i, C.POINTER(_i), C.POINTER(_i)])
@@ -172,6 +173,9 @@ class OracleEncoder:
         assert rc == 0
         return mbs, lv
 
+    def set_qp(self, qp_i, qp_p):
+        L.x264o_encoder_set_qp(self.h, qp_i, qp_p)
+
     def recon(self):
         w, h = self.cfg.width, self.cfg.height
         out = np.zeros(w * h * 3 // 2, np.uint8)
@@ -184,9 +188,38 @@ class OracleEncoder:
         return np.ctypeslib.as_array(C.cast(p, C.POINTER(C.c_uint8)), (r.value, s.value)).copy()
 
     def close(self):
-        if self.h:
+        if self.h and L is not None:
             L.x264o_encoder_destroy(self.h)
-            self.h = None
+        self.h = None
+
+    def __del__(self):
+        self.close()
+
+
+# ---- lookahead frame cost (oracle/lookahead.c) ----
+_sig("x264o_lookahead_create", C.c_void_p, [_i, _i, _i, _i])
+_sig("x264o_lookahead_destroy", None, [C.c_void_p])
+_sig("x264o_lookahead_frame_cost", _i, [C.c_void_p, C.c_void_p, _i, C.c_void_p, C.c_void_p])
+
+
+class OracleLookahead:
+    def __init__(self, w, h, me_range=16, subme=7):
+        self.w, self.h = w, h
+        self.nb = ((w + 15) // 16) * ((h + 15) // 16)
+        self.la = L.x264o_lookahead_create(w, h, me_range, subme)
+
+    def frame_cost(self, i420, reset=False):
+        """-> (out[4] = intra cost, P cost, intra blocks, scored blocks; per-block [intra cost, best cost])"""
+        out = np.zeros(4, np.int32)
+        blocks = np.zeros((self.nb, 2), np.int32)
+        i420 = np.ascontiguousarray(i420, np.uint8)
+        assert L.x264o_lookahead_frame_cost(self.la, ptr(i420), int(reset), ptr(out), ptr(blocks)) == 0
+        return out, blocks
+
+    def close(self):
+        if self.la and L is not None:
+            L.x264o_lookahead_destroy(self.la)
+        self.la = None
 
     def __del__(self):
         self.close()

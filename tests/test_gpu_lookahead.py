@@ -1,0 +1,70 @@
+"""-m gpu: lookahead frame cost (x264gpu_lookahead_frame_cost; [x264-upstream] slicetype.c x264_slicetype_frame_cost) vs
+oracle/lookahead.c, bit-exact: per-block intra / best costs and the frame sums, over consecutive pictures (the motion field of
+one picture predicts the next), scene changes and resets."""
+import numpy as np
+import pytest
+
+import oracle_lib as O
+from synth import synth_frames
+
+pytestmark = pytest.mark.gpu
+
+
+def run_case(w, h, frames, resets=(), me_range=16, subme=7):
+    from gpu_enc import GpuLookahead
+    ol, gl = O.OracleLookahead(w, h, me_range, subme), GpuLookahead(w, h, 1, me_range, subme)
+    mbw = (w + 15) // 16
+    for i, f in enumerate(frames):
+        rs = i == 0 or i in resets
+        o_out, o_blk = ol.frame_cost(f, rs)
+        g_out, g_blk = gl.frame_cost([f], rs)
+        if not np.array_equal(g_blk[0], o_blk):
+            bad = np.nonzero((g_blk[0] != o_blk).any(1))[0]
+            j = int(bad[0])
+            pytest.fail(f"{w}x{h} frame {i}: {len(bad)} blocks differ; first {j} (x={j % mbw}, y={j // mbw}) gpu={g_blk[0][j]} oracle={o_blk[j]}")
+        assert np.array_equal(g_out[0], o_out), f"{w}x{h} frame {i}: sums gpu={g_out[0]} oracle={o_out}"
+    ol.close(); gl.close()
+
+
+@pytest.mark.parametrize("w,h,n,kw", [
+    (176, 144, 5, {}),
+    (352, 288, 4, {}),
+    (208, 120, 4, {}),                       # odd number of block rows (8 macroblock rows -> 4 groups, 120 -> 8 rows) and ragged height
+    (80, 48, 4, {}),                         # 5 x 3 blocks: odd in both directions
+    (32, 32, 3, {}),                         # 2 x 2 blocks: every block counts for the frame score
+    (16, 16, 3, {}),
+    (352, 288, 3, dict(me_range=8, subme=1)),       # subme <= 1: DC/H/V only
+    (720, 304, 3, {}),
+])
+def test_lookahead_cost_bitexact(gpu, w, h, n, kw):
+    run_case(w, h, synth_frames(w, h, n, seed=w + h), **kw)
+
+
+def test_lookahead_scene_change_and_reset(gpu):
+    w, h = 352, 288
+    a, b = synth_frames(w, h, 4, seed=5), synth_frames(w, h, 3, seed=77)
+    run_case(w, h, a + b + a[:2], resets=(9,))
+
+
+def test_lookahead_streams_are_independent(gpu):
+    from gpu_enc import GpuLookahead
+    w, h, S = 176, 144, 3
+    seqs = [synth_frames(w, h, 4, seed=10 + s) for s in range(S)]
+    gl = GpuLookahead(w, h, S)
+    ols = [O.OracleLookahead(w, h) for _ in range(S)]
+    for i in range(4):
+        g_out, g_blk = gl.frame_cost([seqs[s][i] for s in range(S)], i == 0)
+        for s in range(S):
+            o_out, o_blk = ols[s].frame_cost(seqs[s][i], i == 0)
+            assert np.array_equal(g_out[s], o_out) and np.array_equal(g_blk[s], o_blk), f"stream {s} frame {i}"
+
+
+def test_scene_change_is_visible_in_the_costs(gpu):
+    """continuous content: P cost well below the intra cost; a hard cut: every block intra (what scenecut keys on)"""
+    from gpu_enc import GpuLookahead
+    w, h = 352, 288
+    a, b = synth_frames(w, h, 3, seed=5), synth_frames(w, h, 2, seed=77)
+    gl = GpuLookahead(w, h)
+    outs = [gl.frame_cost([f], i == 0)[0][0] for i, f in enumerate(a + b)]
+    assert outs[2][1] < 0.8 * outs[2][0]
+    assert outs[3][1] >= 0.95 * outs[3][0] and outs[3][2] > 0.8 * outs[3][3]

@@ -117,6 +117,15 @@ int x264gpu_encoder_create(x264gpu_encoder **out, const x264gpu_config *cfg)
     return X264GPU_OK;
 }
 
+int x264gpu_encoder_set_qp(x264gpu_encoder *e, int qp_i, int qp_p)
+{
+    ARG_TRY(e && qp_i >= 0 && qp_i <= 51 && qp_p >= 0 && qp_p <= 51);
+    const int rc = build_cost_mv(e, qp_p);
+    if (rc) return rc;
+    e->cfg.qp_i = qp_i; e->cfg.qp_p = qp_p;
+    return X264GPU_OK;
+}
+
 static void profile_free(x264gpu_encoder *e)
 {
     if (e->ev) {

@@ -202,6 +202,7 @@ struct PartCtx {
     const uint8_t *fenc; int fs;               // source macroblock (for the candidate-parallel 8x8 search)
     const uint8_t *cref, *fuv; int chroma_me;  // chroma-ME: NV12 reference plane (origin), source NV12 of this macroblock
     const uint16_t *gcx, *gcy; int mvp0, mvp1; // UMH: mv-cost table in global memory (index = qpel mv), cost predictor
+    int col_x, col_y; bool has_col, la_mode;   // lookahead: co-located start candidate (quarter-pel); la_mode selects its search
 };
 template <bool UMH>
 __device__ __forceinline__ int pc_mvcost(const PartCtx &c, int qx, int qy)
@@ -273,7 +274,9 @@ __device__ __forceinline__ int sad8_global(const uint8_t *p, uint32_t e0, uint32
 __device__ __forceinline__ int umh_hex4_dx(int j) { return (int)((0x6280808080806244ull >> (4 * j)) & 15) - 4; }
 __device__ __forceinline__ int umh_hex4_dy(int j) { return (int)((0x7766554433221180ull >> (4 * j)) & 15) - 4; }
 
-__device__ __forceinline__ void umh_fullpel(const PartCtx &c, const int SHAPE, const int mvd, int &bx, int &by, int &bcost)
+// MODE 0: UMH from the start (bx, by, bcost).  MODE 1: plain search on global memory — start candidates (predictor, zero,
+// co-located: c.col_*) in order, then hexagon + square with c.me_range (the lookahead's x264_me_search, oracle/lookahead.c la_search).
+__device__ __forceinline__ void umh_fullpel(const PartCtx &c, const int SHAPE, const int MODE, const int mvd, int &bx, int &by, int &bcost)
 {
     const int lane = c.lane, GL = SHAPE == 0 ? 16 : SHAPE == 3 ? 4 : 8;
     const int part = SHAPE == 0 ? 0 : SHAPE == 3 ? lane >> 4 : lane >> 5, cnd = SHAPE == 0 ? lane >> 4 : SHAPE == 3 ? (lane >> 2) & 3 : (lane >> 3) & 3;
@@ -312,6 +315,14 @@ __device__ __forceinline__ void umh_fullpel(const PartCtx &c, const int SHAPE, c
     const int shift = SHAPE == 0 ? 0 : SHAPE == 3 ? 2 : 1;                                         // x264 pixel_size_shift
 #define UMH_TH(v) (bcost < ((v) >> shift))
     const int pmx = clampi((c.mvp0 + 2) >> 2, c.fmin0, c.fmax0), pmy = clampi((c.mvp1 + 2) >> 2, c.fmin1, c.fmax1);
+    bool done = false;
+    int range = c.me_range;
+    if (MODE == 1) {
+        bx = 0; by = 0; bcost = 1 << 28;
+        const int sx = cnd == 0 ? pmx : cnd == 2 ? clampi((c.col_x + 2) >> 2, c.fmin0, c.fmax0) : clampi(0, c.fmin0, c.fmax0);
+        const int sy = cnd == 0 ? pmy : cnd == 2 ? clampi((c.col_y + 2) >> 2, c.fmin1, c.fmax1) : clampi(0, c.fmin1, c.fmax1);
+        step(sx, sy, cnd < 2 || (cnd == 2 && c.has_col));
+    } else {
     const int ucost1 = bcost;
     step(pmx + d1x, pmy + d1y, true);
     if (pmx | pmy) step(d1x, d1y, true);
@@ -330,7 +341,6 @@ __device__ __forceinline__ void umh_fullpel(const PartCtx &c, const int SHAPE, c
             step(omx, my, en && i0 < ymax && ((cnd & 1) ? my >= c.fmin1 : my <= c.fmax1));
         }
     };
-    bool done = false;
     const bool et = bcost == ucost2 && UMH_TH(2000);
     if (__any(et)) {                                    // early termination: small octagon
         step(omx + (cnd == 0 ? 0 : cnd == 1 ? -1 : cnd == 2 ? 1 : -2), omy + (cnd == 0 ? -2 : cnd == 3 ? 0 : -1), et);     // (0,-2) (-1,-1) (1,-1) (-2,0)
@@ -346,7 +356,6 @@ __device__ __forceinline__ void umh_fullpel(const PartCtx &c, const int SHAPE, c
             if (et2) cross_start = r1 + 2;
         }
     }
-    int range = c.me_range;
     if (__any(!done)) {
         const bool live = !done;
         // adaptive search range: SAD level x disagreement of the predictors (x264 range_mul)
@@ -365,6 +374,7 @@ __device__ __forceinline__ void umh_fullpel(const PartCtx &c, const int SHAPE, c
             }
         }
         done = done || !inrange(bx, by);
+    }
     }
 #undef UMH_TH
     // hexagon (radius 2, up to range/2 - 1 moves) + square refine of the partitions that are still searching (x264 me_hex2)
@@ -425,13 +435,16 @@ __device__ int search_parts(const PartCtx &c, const int SHAPE, int c0x, int c0y,
 #define FPC(fx, fy) (gsum(sad8_lds(c.win, wb0 + (fy) * WIN_STRIDE + (fx), e0[0], e0[1]) + sad8_lds(c.win, wb1 + (fy) * WIN_STRIDE + (fx), e1[0], e1[1])) + \
                      pc_mvcost<UMH>(c, (fx) * 4, (fy) * 4))
     int bx = c0x, by = c0y, bcost;
-    if (UMH) {
+    if (UMH && c.la_mode) {
+        bcost = 0;
+        umh_fullpel(c, SHAPE, 1, 0, bx, by, bcost);             // lookahead: own start candidates, hexagon + square
+    } else if (UMH) {
         {   // start candidate = the 16x16 vector (every group costs it)
             const long o = (long)by * c.rs + bx;
             const uint8_t *g0 = c.p00 + (long)(c.py + y0) * c.rs + c.px + ox, *g1 = c.p00 + (long)(c.py + y1) * c.rs + c.px + ox + x1;
             bcost = gsum(sad8_global(g0 + o, e0[0], e0[1]) + sad8_global(g1 + o, e1[0], e1[1])) + pc_mvcost<UMH>(c, bx * 4, by * 4);
         }
-        umh_fullpel(c, SHAPE, abs(c.mvp0 - 4 * c0x) + abs(c.mvp1 - 4 * c0y), bx, by, bcost);
+        umh_fullpel(c, SHAPE, 0, abs(c.mvp0 - 4 * c0x) + abs(c.mvp1 - 4 * c0y), bx, by, bcost);
     } else if (c.me_method == 0) {
         bcost = FPC(bx, by);
         bool running = true;
@@ -679,7 +692,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(X264GPU_ANA
             PartCtx u;
             u.p00 = p00; u.rs = k.rs; u.px = px; u.py = py; u.fenc = fenc; u.fs = k.fs; u.lane = lane; u.me_range = k.me_range; u.me_method = 2;
             u.fmin0 = fmin0; u.fmax0 = fmax0; u.fmin1 = fmin1; u.fmax1 = fmax1; u.gcx = cmx; u.gcy = cmy; u.mvp0 = mvp0; u.mvp1 = mvp1;
-            umh_fullpel(u, 0, umh_mvd16, bmx, bmy, bcost);
+            umh_fullpel(u, 0, 0, umh_mvd16, bmx, bmy, bcost);
         } else if (k.me_method == 0) {
             // ---- X264_ME_DIA: the four neighbours are exactly the four lane groups; centre wins ties ----
             int it = k.me_range;
@@ -832,7 +845,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(X264GPU_ANA
         pc.fmin0 = fmin0; pc.fmax0 = fmax0; pc.fmin1 = fmin1; pc.fmax1 = fmax1; pc.smin0 = smin0; pc.smax0 = smax0; pc.smin1 = smin1; pc.smax1 = smax1;
         pc.me_range = k.me_range; pc.me_method = k.me_method; pc.lane = lane; pc.sub = s_sub[wave]; pc.fenc = fenc; pc.fs = k.fs;
         pc.chroma_me = chroma_me; pc.cref = ref_chroma00(k, s, bref); pc.fuv = fuv;
-        pc.gcx = cmx; pc.gcy = cmy; pc.mvp0 = mvp0; pc.mvp1 = mvp1;
+        pc.gcx = cmx; pc.gcy = cmy; pc.mvp0 = mvp0; pc.mvp1 = mvp1; pc.la_mode = false;
         const int sub = min(k.subme, 11);
         pc.hp_it = sub < 2 ? 0 : sub < 6 ? 1 : sub < 8 ? 2 : 4;
         pc.qp_it = sub < 4 ? 0 : sub == 4 ? 1 : sub < 8 ? 2 : 10;
