@@ -24,6 +24,8 @@ int x264host_write_slice(int mbw, int mbh, int slice_type, int qp, int pic_init_
 /* SPS + PPS for a stream made of such slices */
 int x264host_write_headers(int width, int height, int level_idc, int log2_max_frame_num, int pic_init_qp, int chroma_qp_offset,
                            uint32_t num_units_in_tick, uint32_t time_scale, int num_ref, int transform8x8_mode, uint8_t *out, int cap);
+/* quantiser, scenecut flag and lookahead sums (x264gpu_lookahead_frame_cost) of the last coded picture */
+int x264host_last_decision(x264_t *h, int *qp, int *scenecut, int32_t costs[4]);
 /* reconstructed picture of the last encoded frame as I420 (host memory) */
 int x264host_get_recon(x264_t *h, uint8_t *i420_out);
 

@@ -90,6 +90,7 @@ _sig("x264_encoder_close", None, [C.c_void_p])
 _sig("x264host_write_slice", _i, [_i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, C.c_void_p, C.c_void_p, C.c_void_p, _i, C.POINTER(_i)])
 _sig("x264host_write_headers", _i, [_i, _i, _i, _i, _i, _i, C.c_uint32, C.c_uint32, _i, _i, C.c_void_p, _i])
 _sig("x264host_get_recon", _i, [C.c_void_p, C.c_void_p])
+_sig("x264host_last_decision", _i, [C.c_void_p, C.POINTER(_i), C.POINTER(_i), C.POINTER(C.c_int32)])
 LEVELS = (Level * 21).in_dll(H, "x264_levels")
 
 X264_CSP_I420, X264_RC_CQP, X264_RC_CRF = 1, 0, 1

@@ -57,11 +57,11 @@ def encode_all(h_, w, h, frames):
     return stream, info, recons
 
 
-@pytest.mark.parametrize("w,h,opts", [(176, 144, {"qp": 26, "keyint": 4}), (352, 288, {"qp": 30, "keyint": 250}),
-                                       (208, 120, {"qp": 22, "keyint": 3, "no-deblock": None}),
+@pytest.mark.parametrize("w,h,opts", [(176, 144, {"qp": 26, "keyint": 4, "no-scenecut": None}), (352, 288, {"qp": 30, "keyint": 250}),
+                                       (208, 120, {"qp": 22, "keyint": 3, "no-deblock": None, "no-scenecut": None}),
                                        (176, 144, {"qp": 28, "keyint": 250, "ref": 1, "partitions": "i4x4"}),
                                        (176, 144, {"qp": 24, "keyint": 250, "_profile": b"high"}),      # 8x8dct: High profile stream
-                                       (352, 288, {"qp": 27, "keyint": 5, "_profile": b"high"})])
+                                       (352, 288, {"qp": 27, "keyint": 5, "no-scenecut": None, "_profile": b"high"})])
 def test_encode_api_closed_loop(gpu, w, h, opts):
     nfr = 7
     frames = synth_frames(w, h, nfr, seed=w + 3 * h)
@@ -147,7 +147,7 @@ def test_gop_parallel_equals_serial(gpu, w, h, nfr, keyint, threads):
     """--threads G codes G closed GOPs in lock-step: the frames come out (G-1)*keyint (+1) calls late, in order, and the stream is
     byte-identical to the serial encode (fixed keyint + CQP make the GOPs independent); flush drains the rest."""
     frames = synth_frames(w, h, nfr, seed=31 * w + nfr)
-    opts = {"qp": 27, "keyint": keyint, "min-keyint": keyint}
+    opts = {"qp": 27, "keyint": keyint, "min-keyint": keyint, "no-scenecut": None}      # SURVEY config 5: fixed closed GOPs
     h1, _ = open_encoder(w, h, opts, b"high")
     serial, info1, _ = encode_all(h1, w, h, frames)
     H.x264_encoder_close(h1)
@@ -178,3 +178,81 @@ def test_gop_parallel_equals_serial(gpu, w, h, nfr, keyint, threads):
     assert pts_out == [100 + i for i in range(nfr)]
     assert stream == serial
     assert len(O.h264_decode(stream, nfr, w, h)) == nfr
+
+
+def encode_with_decisions(h_, w, h, frames):
+    """encode_all + the per-picture decisions (quantiser, scenecut flag, lookahead sums) the host took"""
+    pic, out = HL.Picture(), HL.Picture()
+    assert H.x264_picture_alloc(C.byref(pic), HL.X264_CSP_I420, w, h) == 0
+    stream, rows, recons = b"", [], []
+    for i, f in enumerate(frames):
+        C.memmove(pic.img.plane[0], f.ctypes.data, f.size)
+        pic.i_pts = i
+        nal, n = C.POINTER(HL.Nal)(), C.c_int()
+        size = H.x264_encoder_encode(h_, C.byref(nal), C.byref(n), C.byref(pic), C.byref(out))
+        assert size > 0
+        stream += C.string_at(nal[0].p_payload, size)
+        qp, sc, costs = C.c_int(), C.c_int(), (C.c_int32 * 4)()
+        assert H.x264host_last_decision(h_, C.byref(qp), C.byref(sc), costs) == 0
+        rows.append((int(out.b_keyframe), qp.value, sc.value, list(costs)))
+        rec = np.zeros(w * h * 3 // 2, np.uint8)
+        assert H.x264host_get_recon(h_, rec.ctypes.data) == 0
+        recons.append(rec)
+    H.x264_picture_clean(C.byref(pic))
+    return stream, rows, recons
+
+
+def test_scenecut_inserts_idr(gpu):
+    """--scenecut 40 (x264 default): a hard cut becomes an IDR picture (lookahead P cost ~ intra cost), continuous content does
+    not; the stream decodes to the encoder's reconstruction and equals the oracle pipeline driven by the same slice types."""
+    w, h = 176, 144
+    frames = synth_frames(w, h, 6, seed=5) + synth_frames(w, h, 5, seed=99)
+    h_, eff = open_encoder(w, h, {"qp": 27, "keyint": 250, "min-keyint": 2}, b"high")
+    assert eff.i_scenecut_threshold == 40 and eff.i_keyint_min == 2
+    stream, rows, recons = encode_with_decisions(h_, w, h, frames)
+    H.x264_encoder_close(h_)
+    assert [r[0] for r in rows] == [1, 0, 0, 0, 0, 0, 1, 0, 0, 0, 0]
+    assert rows[6][2] == 1 and rows[6][3][1] >= 0.9 * rows[6][3][0] and all(r[2] == 0 for i, r in enumerate(rows) if i != 6)
+    dec = O.h264_decode(stream, len(frames), w, h)
+    og = O.OracleEncoder(O.default_config(w, h, qp_i=24, qp_p=27, partitions=7, refs=3, dct8x8=1, chroma_me=1))
+    for i, f in enumerate(frames):
+        np.testing.assert_array_equal(dec[i], recons[i], err_msg=f"decoded picture {i}")
+        og.encode(f, 2 if rows[i][0] else 0)
+        np.testing.assert_array_equal(og.recon(), recons[i], err_msg=f"oracle pipeline picture {i}")
+
+
+def test_crf_follows_the_lookahead_complexity(gpu):
+    """--crf (the driver's default rate control, codec.c:1504-1507) without AQ / mbtree: one quantiser per picture from the
+    lookahead cost ([x264-upstream] ratecontrol.c rate_estimate_qscale, CRF branch, restated here).  The decoder reproduces the
+    reconstruction (slice_qp_delta carries the quantiser) and the oracle pipeline fed the same quantisers matches too."""
+    w, h, crf, qcomp, ipf = 176, 144, 26.0, 0.6, 1.4
+    frames = synth_frames(w, h, 5, seed=5) + synth_frames(w, h, 4, seed=99)
+    h_, eff = open_encoder(w, h, {"crf": crf, "keyint": 250, "min-keyint": 3}, b"high")
+    assert eff.rc.i_rc_method == HL.X264_RC_CRF
+    stream, rows, recons = encode_with_decisions(h_, w, h, frames)
+    H.x264_encoder_close(h_)
+    nmb = ((w + 15) // 16) * ((h + 15) // 16)
+    q2s, s2q = (lambda q: 0.85 * 2.0 ** ((q - 12.0) / 6.0)), (lambda s: 12.0 + 6.0 * np.log2(s / 0.85))
+    rfc = (nmb * 80.0) ** (1 - qcomp) / q2s(crf)
+    cs = cc = apq = apn = 0.0
+    last_i = True
+    qps = []
+    for i, (key, qp, sc, costs) in enumerate(rows):
+        satd = costs[0] if key else costs[1]
+        cs, cc = cs * 0.5 + satd, cc * 0.5 + 1
+        q = (cs / cc) ** (1 - qcomp) / rfc
+        if key and not last_i:
+            q = q2s(apq / apn) / ipf
+        qpf = float(np.clip(s2q(q), 1, 51))
+        apq, apn = apq * 0.95 + (qpf + 6 * np.log2(ipf) if key else qpf), apn * 0.95 + 1
+        last_i = bool(key)
+        qps.append(int(qpf + 0.5))
+    assert [r[1] for r in rows] == qps, (qps, rows)
+    assert len(set(qps)) > 1 and rows[5][0] == 1                     # the cut is an IDR and the quantiser moves with the content
+    dec = O.h264_decode(stream, len(frames), w, h)
+    og = O.OracleEncoder(O.default_config(w, h, partitions=7, refs=3, dct8x8=1, chroma_me=1))
+    for i, f in enumerate(frames):
+        np.testing.assert_array_equal(dec[i], recons[i], err_msg=f"decoded picture {i}")
+        og.set_qp(rows[i][1], rows[i][1])
+        og.encode(f, 2 if rows[i][0] else 0)
+        np.testing.assert_array_equal(og.recon(), recons[i], err_msg=f"oracle pipeline picture {i}")

@@ -13,7 +13,7 @@ pytestmark = pytest.mark.gpu
 D = V.H.DriverProc
 
 
-@pytest.mark.parametrize("four,cmdline", [(b"I420", b"--keyint 5 --profile baseline"), (b"YV12", b"--keyint 250 --no-deblock --subme 4")])
+@pytest.mark.parametrize("four,cmdline", [(b"I420", b"--keyint 5 --no-scenecut --profile baseline"), (b"YV12", b"--keyint 250 --no-deblock --subme 4")])
 def test_icm_compress_sequence(gpu, four, cmdline):
     w, h, nfr = 176, 144, 7
     frames = synth_frames(w, h, nfr, seed=1234)
@@ -181,9 +181,9 @@ def test_raw_file_output(gpu, tmp_path):
     # GOP-parallel coding (--threads 3): frames reach the file late and compress_end flushes the rest (codec.c:1842-1856);
     # the file is byte-identical to the serial one
     par_path = tmp_path / "par.h264"
-    run(b"--keyint 2 --min-keyint 2 --output " + str(path).encode())
+    run(b"--keyint 2 --min-keyint 2 --no-scenecut --output " + str(path).encode())
     serial_k2 = path.read_bytes()
-    to_file, sizes = run(b"--keyint 2 --min-keyint 2 --threads 3 --output " + str(par_path).encode())
+    to_file, sizes = run(b"--keyint 2 --min-keyint 2 --no-scenecut --threads 3 --output " + str(par_path).encode())
     assert to_file == b"" and par_path.read_bytes() == serial_k2
     # without a file the VfW buffer cannot take late frames: threads falls back to 1 (same stream, no delay)
     direct_t, sizes = run(b"--keyint 250 --threads 4")

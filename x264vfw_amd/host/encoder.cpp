@@ -41,6 +41,19 @@ struct x264_t {
     std::vector<x264_nal_t> nals;
     std::vector<size_t> nal_off;
     SliceStats last_stats = { 0 };
+    // ---- lookahead-driven decisions (threads 1 only): scenecut and CRF, both fed by x264gpu_lookahead_frame_cost ----
+    x264gpu_lookahead *la = nullptr;
+    int32_t *d_la = nullptr;             // device: the four sums of the last picture
+    int keyint_min = 25;
+    bool crf = false;
+    struct {                             // [x264-upstream] encoder/ratecontrol.c, the CRF branch of rate_estimate_qscale (restated from memory)
+        double rate_factor_constant = 1, qcompress = 0.6, ip_factor = 1.4, ip_offset = 0, dur_ratio = 1;
+        double cplxsum = 0, cplxcount = 0, accum_p_qp = 0, accum_p_norm = 0, lmin = 0, lmax = 0;
+        double last_qscale_for[2] = { 0, 0 };       // [0] I, [1] P
+        int last_non_b_is_i = 1;
+    } rc;
+    int last_qp = 0, last_scenecut = 0;  // diagnostics: quantiser and scenecut flag of the last coded picture
+    int32_t last_costs[4] = { 0, 0, 0, 0 };
     // ---- GOP-parallel mode (--threads G > 1): G closed GOPs of the one stream are coded in lock-step on G stream slots of the
     //      GPU encoder; frames come out in order, (G-1)*keyint calls late.  Fixed keyint + CQP make the GOPs independent, so
     //      the bytes equal the serial encode's (tests/test_gpu_host.py::test_gop_parallel_equals_serial).
@@ -148,7 +161,8 @@ x264_t *x264_encoder_open(x264_param_t *param)
     p.analyse.b_transform_8x8 = p.analyse.b_transform_8x8 != 0;
     p.analyse.inter &= X264_ANALYSE_I4x4 | X264_ANALYSE_I8x8 | X264_ANALYSE_PSUB16x16; p.analyse.intra &= X264_ANALYSE_I4x4 | X264_ANALYSE_I8x8;
     if (!p.analyse.b_transform_8x8) { p.analyse.inter &= ~X264_ANALYSE_I8x8; p.analyse.intra &= ~X264_ANALYSE_I8x8; }   // as x264 validate_parameters
-    p.analyse.i_trellis = 0; p.rc.b_mb_tree = 0; p.rc.i_aq_mode = X264_AQ_NONE; p.rc.i_lookahead = 0; p.i_scenecut_threshold = 0;
+    p.analyse.i_trellis = 0; p.rc.b_mb_tree = 0; p.rc.i_aq_mode = X264_AQ_NONE; p.rc.i_lookahead = 0;
+    p.i_scenecut_threshold = clampi(p.i_scenecut_threshold, 0, 100);
     if (p.analyse.i_me_method > X264_ME_UMH) { xlog(&p, X264_LOG_WARNING, "me esa/tesa are not implemented in the MI355X path yet: me umh\n"); p.analyse.i_me_method = X264_ME_UMH; }
     p.analyse.i_me_range = clampi(p.analyse.i_me_range, 4, p.analyse.i_me_method == X264_ME_UMH ? 64 : 16);     // x264 caps dia/hex at 16
     p.analyse.i_subpel_refine = clampi(p.analyse.i_subpel_refine, 0, 7);
@@ -157,14 +171,23 @@ x264_t *x264_encoder_open(x264_param_t *param)
     p.i_threads = clampi(p.i_threads, 1, 64);                  // --threads G: GOPs coded in lock-step (1 = no delay)
     if (p.i_keyint_max <= 0) p.i_keyint_max = 1;
     h->keyint = p.i_keyint_max;
-    // rate control: constant QP only (X264_RC_CQP, codec.c:1498-1502); CRF/ABR map to their nominal quantiser
+    // rate control: constant QP (X264_RC_CQP, codec.c:1498-1502) and single-pass CRF without AQ / mbtree (codec.c:1504-1507, the
+    // driver's default session) when one GOP is in flight; ABR and CRF under --threads > 1 map to their nominal quantiser
     int qp = p.rc.i_rc_method == X264_RC_CQP ? p.rc.i_qp_constant : p.rc.i_rc_method == X264_RC_CRF ? (int)(p.rc.f_rf_constant + 0.5f) : 26;
-    if (p.rc.i_rc_method != X264_RC_CQP) xlog(&p, X264_LOG_WARNING, "rate control other than CQP is not implemented yet: constant qp %d\n", qp);
+    h->crf = p.rc.i_rc_method == X264_RC_CRF && p.i_threads <= 1 && p.rc.f_rf_constant >= 1.0f;
+    if (p.rc.i_rc_method != X264_RC_CQP && !h->crf) xlog(&p, X264_LOG_WARNING, "this rate control mode is not implemented yet: constant qp %d\n", qp);
     if (qp < 1) { xlog(&p, X264_LOG_WARNING, "lossless is not supported: qp 1\n"); qp = 1; }
-    p.rc.i_rc_method = X264_RC_CQP; p.rc.i_qp_constant = clampi(qp, 1, 51);
+    if (!h->crf) p.rc.i_rc_method = X264_RC_CQP;
+    p.rc.i_qp_constant = clampi(qp, 1, 51);
+    p.rc.i_qp_min = clampi(p.rc.i_qp_min, 1, 51); p.rc.i_qp_max = clampi(p.rc.i_qp_max, p.rc.i_qp_min, 51);
+    if (p.i_threads > 1 && p.i_scenecut_threshold) { xlog(&p, X264_LOG_INFO, "scenecut needs threads 1 (GOPs in lock-step have a fixed structure): scenecut 0\n"); p.i_scenecut_threshold = 0; }
+    // x264 validate_parameters: min-keyint auto = min(keyint / 10, fps), then [1, keyint / 2 + 1]
+    if (p.i_keyint_min <= 0) { const int fps = (int)(p.i_fps_num / (p.i_fps_den ? p.i_fps_den : 1)); p.i_keyint_min = p.i_keyint_max / 10 < fps ? p.i_keyint_max / 10 : fps; }
+    p.i_keyint_min = clampi(p.i_keyint_min, 1, p.i_keyint_max / 2 + 1);
+    h->keyint_min = p.i_keyint_min;
     h->qp_p = p.rc.i_qp_constant;
     h->qp_i = clampi((int)(h->qp_p - 6.0 * log2(p.rc.f_ip_factor > 0 ? p.rc.f_ip_factor : 1.0) + 0.5), 1, 51);
-    h->pic_init_qp = clampi(h->qp_p, 0, 51);
+    h->pic_init_qp = h->crf ? 26 : clampi(h->qp_p, 0, 51);          // CRF moves the slice quantiser both ways: centre the +-26 range of slice_qp_delta
     h->profile_idc = p.analyse.b_transform_8x8 ? 100 : 66;        // High only for the 8x8 transform; everything else is Baseline-compatible
     h->level_idc = p.i_level_idc > 0 ? p.i_level_idc : pick_level(&p, h->nmb, p.i_frame_reference);
     p.i_level_idc = h->level_idc;
@@ -202,6 +225,26 @@ x264_t *x264_encoder_open(x264_param_t *param)
         xlog(&p, X264_LOG_ERROR, "GPU encoder setup failed: %s\n", x264gpu_last_error());
         x264_encoder_close(h);
         return nullptr;
+    }
+    if ((p.i_scenecut_threshold > 0 || h->crf) && h->G == 1) {
+        if (x264gpu_lookahead_create(&h->la, p.i_width, p.i_height, 1, p.analyse.i_me_range, p.analyse.i_subpel_refine) != X264GPU_OK ||
+            x264gpu_malloc((void **)&h->d_la, 4 * sizeof(int32_t)) != X264GPU_OK) {
+            xlog(&p, X264_LOG_ERROR, "GPU lookahead setup failed: %s\n", x264gpu_last_error());
+            x264_encoder_close(h);
+            return nullptr;
+        }
+    }
+    if (h->crf) {
+        // x264_ratecontrol_new: rate_factor_constant = base_cplx^(1 - qcomp) / qp2qscale(crf), base_cplx = mbs * (bframes ? 120 : 80)
+        auto qp2qscale = [](double q) { return 0.85 * pow(2.0, (q - 12.0) / 6.0); };
+        h->rc.qcompress = p.rc.f_qcompress; h->rc.ip_factor = fabs(p.rc.f_ip_factor) > 0 ? fabs(p.rc.f_ip_factor) : 1.0;
+        h->rc.ip_offset = 6.0 * log2(h->rc.ip_factor);
+        h->rc.rate_factor_constant = pow((double)h->nmb * 80.0, 1.0 - h->rc.qcompress) / qp2qscale(p.rc.f_rf_constant);
+        h->rc.last_qscale_for[0] = h->rc.last_qscale_for[1] = qp2qscale(p.rc.f_rf_constant);
+        h->rc.lmin = qp2qscale(p.rc.i_qp_min); h->rc.lmax = qp2qscale(p.rc.i_qp_max);
+        double dur = p.i_fps_num ? (double)p.i_fps_den / p.i_fps_num : 0.04;
+        dur = dur < 0.01 ? 0.01 : dur > 1.0 ? 1.0 : dur;              // CLIP_DURATION
+        h->rc.dur_ratio = dur / 0.04;                                  // BASE_FRAME_DURATION
     }
     h->h_in.resize(insz); h->h_mb.resize((size_t)h->G * h->nmb); h->h_lv.resize((size_t)h->G * h->nmb * X264GPU_MB_LEVELS);
     if (h->G > 1) {
@@ -403,10 +446,59 @@ int x264_encoder_encode(x264_t *h, x264_nal_t **pp_nal, int *pi_nal, x264_pictur
     }
     if (h->G > 1) return encode_gop_parallel(h, pp_nal, pi_nal, pic_in, pic_out, resident);
     bool idr = h->frames_since_idr == 0 || h->frames_since_idr >= h->keyint || pic_in->i_type == X264_TYPE_IDR || pic_in->i_type == X264_TYPE_KEYFRAME;
+    if (!resident && x264gpu_memcpy_h2d(h->d_in, h->h_in.data(), h->h_in.size(), nullptr) != X264GPU_OK) {
+        xlog(&p, X264_LOG_ERROR, "x264_encoder_encode: upload failed: %s\n", x264gpu_last_error());
+        return -1;
+    }
+    int qp_now = idr ? h->qp_i : h->qp_p;
+    h->last_scenecut = 0;
+    if (h->la) {
+        // ---- lookahead: cost of coding this picture intra / predicted from the previous SOURCE picture (slicetype.c) ----
+        int32_t c[4];
+        if (x264gpu_lookahead_frame_cost(h->la, h->d_in, h->frame_no == 0, h->d_la, nullptr, nullptr) != X264GPU_OK ||
+            x264gpu_memcpy_d2h(c, h->d_la, sizeof(c), nullptr) != X264GPU_OK) {
+            xlog(&p, X264_LOG_ERROR, "x264_encoder_encode: lookahead failed: %s\n", x264gpu_last_error());
+            return -1;
+        }
+        memcpy(h->last_costs, c, sizeof(c));
+        if (!idr && p.i_scenecut_threshold > 0 && h->frame_no > 0) {
+            // scenecut_internal: the bias grows with the distance from the last keyframe.  x264 codes a non-IDR I picture when the
+            // cut falls inside min-keyint; this pipeline's I slices are IDR, so such a picture stays P (its macroblocks go intra).
+            const int gop = h->frames_since_idr, kmin = h->keyint_min, kmax = h->keyint;
+            const double tmax = p.i_scenecut_threshold / 100.0, tmin = kmin == kmax ? tmax : tmax * 0.25;
+            double bias;
+            if (gop <= kmin / 4) bias = tmin / 4;
+            else if (gop <= kmin) bias = tmin * gop / kmin;
+            else bias = tmin + (tmax - tmin) * (gop - kmin) / (kmax - kmin);
+            h->last_scenecut = (double)c[1] >= (1.0 - bias) * (double)c[0];
+            if (h->last_scenecut && gop >= kmin) { idr = true; qp_now = h->qp_i; }
+        }
+        if (h->crf) {
+            // rate_estimate_qscale, CRF: q = blurred_complexity^(1 - qcomp) / rate_factor; an I picture after P pictures takes the
+            // running P quantiser / ipratio; the quantiser is qscale2qp(q) rounded, within [qpmin, qpmax]
+            auto qp2qscale = [](double q) { return 0.85 * pow(2.0, (q - 12.0) / 6.0); };
+            auto qscale2qp = [](double qs) { return 12.0 + 6.0 * log2(qs / 0.85); };
+            const double satd = idr ? c[0] : c[1];
+            h->rc.cplxsum = h->rc.cplxsum * 0.5 + satd / h->rc.dur_ratio;
+            h->rc.cplxcount = h->rc.cplxcount * 0.5 + 1.0;
+            double q = satd > 0 ? pow(h->rc.cplxsum / h->rc.cplxcount, 1.0 - h->rc.qcompress) / h->rc.rate_factor_constant : h->rc.last_qscale_for[idr ? 0 : 1];
+            if (idr && h->keyint > 1 && !h->rc.last_non_b_is_i) q = qp2qscale(h->rc.accum_p_qp / h->rc.accum_p_norm) / h->rc.ip_factor;
+            q = q < h->rc.lmin ? h->rc.lmin : q > h->rc.lmax ? h->rc.lmax : q;
+            h->rc.last_qscale_for[idr ? 0 : 1] = q;
+            if (h->frame_no == 0) h->rc.last_qscale_for[1] = q * h->rc.ip_factor;
+            double qpf = qscale2qp(q);
+            qpf = qpf < p.rc.i_qp_min ? p.rc.i_qp_min : qpf > p.rc.i_qp_max ? p.rc.i_qp_max : qpf;
+            qp_now = clampi((int)(qpf + 0.5), 1, 51);
+            h->rc.accum_p_qp = h->rc.accum_p_qp * 0.95 + (idr ? qpf + h->rc.ip_offset : qpf);      // accum_p_qp_update
+            h->rc.accum_p_norm = h->rc.accum_p_norm * 0.95 + 1.0;
+            h->rc.last_non_b_is_i = idr;
+            if (x264gpu_encoder_set_qp(h->gpu, qp_now, qp_now) != X264GPU_OK) return -1;
+        }
+    }
+    h->last_qp = qp_now;
     if (idr) { h->frames_since_idr = 0; h->frame_num = 0; }
     int st = idr ? X264GPU_SLICE_I : X264GPU_SLICE_P;
-    if ((!resident && x264gpu_memcpy_h2d(h->d_in, h->h_in.data(), h->h_in.size(), nullptr) != X264GPU_OK) ||
-        x264gpu_encode_frames(h->gpu, h->d_in, st, h->d_mb, h->d_lv, nullptr) != X264GPU_OK ||
+    if (x264gpu_encode_frames(h->gpu, h->d_in, st, h->d_mb, h->d_lv, nullptr) != X264GPU_OK ||
         x264gpu_memcpy_d2h(h->h_mb.data(), h->d_mb, h->h_mb.size() * sizeof(x264gpu_mb), nullptr) != X264GPU_OK ||
         x264gpu_memcpy_d2h(h->h_lv.data(), h->d_lv, h->h_lv.size() * sizeof(int16_t), nullptr) != X264GPU_OK) {
         xlog(&p, X264_LOG_ERROR, "x264_encoder_encode: GPU hot path failed: %s\n", x264gpu_last_error());
@@ -420,7 +512,7 @@ int x264_encoder_encode(x264_t *h, x264_nal_t **pp_nal, int *pi_nal, x264_pictur
         h->sei_sent = 1;
     }
     SliceParams sp = {};
-    sp.mbw = h->mbw; sp.mbh = h->mbh; sp.slice_type = st; sp.qp = idr ? h->qp_i : h->qp_p; sp.pic_init_qp = h->pic_init_qp;
+    sp.mbw = h->mbw; sp.mbh = h->mbh; sp.slice_type = st; sp.qp = qp_now; sp.pic_init_qp = h->pic_init_qp;
     sp.frame_num = h->frame_num; sp.log2_max_frame_num = h->log2_max_frame_num;
     sp.idr = idr; sp.idr_pic_id = h->idr_pic_id; sp.nal_ref_idc = idr ? 3 : 2; sp.pps_id = p.i_sps_id;
     sp.num_ref_default = p.i_frame_reference;
@@ -457,6 +549,8 @@ void x264_encoder_close(x264_t *h)
     if (h->d_mb) x264gpu_free(h->d_mb);
     if (h->d_lv) x264gpu_free(h->d_lv);
     if (h->d_ring) x264gpu_free(h->d_ring);
+    if (h->la) x264gpu_lookahead_destroy(h->la);
+    if (h->d_la) x264gpu_free(h->d_la);
     delete h;
 }
 
@@ -499,6 +593,15 @@ int x264host_write_headers(int width, int height, int level_idc, int log2_max_fr
 /* device pointer of the encoder's input staging buffer: a tight I420 picture (Y w*h, U, V).  A picture whose plane[0]
  * equals this pointer is encoded in place, without the host copy-in and upload (used by the VfW shell, vfw.cpp). */
 uint8_t *x264gpu_host_input_i420(x264_t *h) { return h ? h->d_in : nullptr; }
+
+int x264host_last_decision(x264_t *h, int *qp, int *scenecut, int32_t costs[4])
+{
+    if (!h) return -1;
+    if (qp) *qp = h->last_qp;
+    if (scenecut) *scenecut = h->last_scenecut;
+    if (costs) memcpy(costs, h->last_costs, sizeof(h->last_costs));
+    return 0;
+}
 
 int x264host_get_recon(x264_t *h, uint8_t *i420_out)
 {
