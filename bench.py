@@ -114,6 +114,34 @@ def csp_probe(torch, lib, dev, W, H, frames=64, iters=10):
             "achieved_GBps": round(gbs, 1), "frac_of_hbm_peak": round(gbs / HBM_PEAK_GBS, 4), "frames_per_s": round(frames / (ms * 1e-3), 1)}
 
 
+def lookahead_probe(torch, lib, dev, W, H, frames, iters=6):
+    """next-row f2 evidence (not part of `value`): lookahead frame cost (half-resolution planes + 8x8 search + intra SATD,
+    x264_slicetype_frame_cost) of `frames` 1080p pictures per launch pair, on a moving synthetic sequence."""
+    import numpy as np
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from synth import synth_frames
+    seq = synth_frames(W, H, 3, seed=0x264, scene_len=10 ** 9)
+    pics = [torch.from_numpy(np.stack([f] * frames)).to(dev) for f in seq]
+    la = C.c_void_p()
+    lib.check(lib.x264gpu_lookahead_create(C.byref(la), W, H, frames, 16, 7), "lookahead_create")
+    d_out = torch.zeros((frames, 4), dtype=torch.int32, device=dev)
+    cur = torch.cuda.current_stream(dev).cuda_stream
+    for i in range(2):
+        lib.check(lib.x264gpu_lookahead_frame_cost(la, pics[i].data_ptr(), int(i == 0), d_out.data_ptr(), None, cur), "lookahead")
+    torch.cuda.synchronize(dev)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for i in range(iters):
+        lib.check(lib.x264gpu_lookahead_frame_cost(la, pics[(i + 2) % 3].data_ptr(), 0, d_out.data_ptr(), None, cur), "lookahead")
+    e1.record()
+    torch.cuda.synchronize(dev)
+    ms = e0.elapsed_time(e1) / iters
+    o = d_out[0].cpu().numpy()
+    lib.x264gpu_lookahead_destroy(la)
+    return {"kernels": "k_la_lowres + k_la_cost", "frames_per_launch": frames, "avg_launch_ms": round(ms, 4),
+            "frames_per_s": round(frames / (ms * 1e-3), 1), "intra_cost": int(o[0]), "p_cost": int(o[1])}
+
+
 def cpu_baseline(w, h, nframes, keyint, tools):
     """oracle/ (CPU restatement, one core) on a bounded sample of the same workload — the checker timed as
     a baseline, never the product."""
@@ -251,6 +279,7 @@ def main():
         types = np.bincount(mbs[0].cpu().numpy()[:, :, 0].reshape(-1), minlength=7)
         out["config"]["mb_types_last_step"] = {"I4x4": int(types[0]), "I8x8": int(types[1]), "I16x16": int(types[2]), "P16x16/16x8/8x16": int(types[4]), "P8x8": int(types[5])}
         out["csp_ingest"] = csp_probe(torch, lib, dev, W, H)
+        out["lookahead"] = lookahead_probe(torch, lib, dev, W, H, min(S // G, 256))
         if args.cpu_frames > 0:
             cfps, cdt = cpu_baseline(W, H, args.cpu_frames, args.keyint, tools)
             out["cpu_baseline"] = {"value": round(cfps, 3), "unit": "frames/s", "cores": 1, "kind": "port",
