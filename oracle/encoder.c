@@ -236,6 +236,8 @@ static void encode_chroma(x264o_encoder *e, const pixel *fenc_uv, pixel *rec_uv,
         if (nzac && inter && e->cfg.dct_decimate && score < 7) nzac = 0;
         x264o_dct2x2dc(dc);
         int nzdc = x264o_quant_2x2_dc(dc, mf[0] >> 1, bias[0] << 1);
+        /* DC-only planes (no AC left): x264_mb_optimize_chroma_dc trims the DC levels that do not change the reconstruction */
+        if (nzdc && !nzac && !x264o_optimize_chroma_2x2_dc(dc, e->qt.dequant4_mf[qpc % 6][0] << (qpc / 6))) { nzdc = 0; dc[0] = dc[1] = dc[2] = dc[3] = 0; }
         for (int i = 0; i < 4; i++) lv[X264GPU_LV_CHROMA_DC + c * 4 + i] = dc[i];
         dctcoef dq[4] = { 0, 0, 0, 0 };
         if (nzdc) { x264o_dequant_2x2_dc(dq, dc, e->qt.dequant4_mf, qpc); mb->nnz |= 1u << (25 + c); any_dc = 1; }

@@ -131,6 +131,39 @@ void x264o_dequant_2x2_dc(dctcoef out[4], const dctcoef in[4], const int32_t dq[
     for (int i = 0; i < 4; i++) out[i] = (dctcoef)((f[i] * ls) >> 5);
 }
 
+/* optimize_chroma_2x2_dc ([x264-upstream] common/quant.c, used by x264_mb_encode_chroma_internal on the DC-only path): lower the
+ * magnitude of the quantised chroma DC levels as long as the reconstruction — ((idct2x2(level) * dmf) >> 5) + 32 >> 6 per 4x4
+ * block — does not change; highest frequency first.  d[] in this file's layout (0 sum, 1 horizontal, 2 vertical, 3 diagonal;
+ * x264 keeps 1 and 2 the other way round, hence the visiting order 3, 1, 2, 0).  Returns 0 when nothing remains to code. */
+static void idct_dequant_round_2x2(int out[4], const dctcoef d[4], int dmf)
+{
+    int d0 = d[0] + d[1], d1 = d[2] + d[3], d2 = d[0] - d[1], d3 = d[2] - d[3];
+    out[0] = ((d0 + d1) * dmf >> 5) + 32;
+    out[1] = ((d0 - d1) * dmf >> 5) + 32;
+    out[2] = ((d2 + d3) * dmf >> 5) + 32;
+    out[3] = ((d2 - d3) * dmf >> 5) + 32;
+}
+
+int x264o_optimize_chroma_2x2_dc(dctcoef d[4], int dmf)
+{
+    static const int order[4] = { 3, 1, 2, 0 };
+    int ref[4], out[4], sum = 0, nz = 0;
+    if (dmf > 32 * 64) return 1;                 /* x264_mb_optimize_chroma_dc: large quantisers are left alone */
+    idct_dequant_round_2x2(ref, d, dmf);
+    for (int i = 0; i < 4; i++) sum |= ref[i];
+    if (!(sum >> 6)) return 0;                   /* already rounds to nothing */
+    for (int k = 0; k < 4; k++) {
+        int c = order[k], level = d[c], sign = level >> 31 | 1;
+        while (level) {
+            d[c] = (dctcoef)(level - sign);
+            idct_dequant_round_2x2(out, d, dmf);
+            if (((ref[0] ^ out[0]) | (ref[1] ^ out[1]) | (ref[2] ^ out[2]) | (ref[3] ^ out[3])) >> 6) { nz = 1; d[c] = (dctcoef)level; break; }
+            level -= sign;
+        }
+    }
+    return nz;
+}
+
 int x264o_coeff_last(const dctcoef *l, int n)
 {
     int i = n - 1;

@@ -68,6 +68,7 @@ void x264o_dequant_4x4(dctcoef d[16], const int32_t dq[6][16], int qp);
 void x264o_dequant_8x8(dctcoef d[64], const int32_t dq[6][64], int qp);
 void x264o_dequant_4x4_dc(dctcoef d[16], const int32_t dq[6][16], int qp);
 void x264o_dequant_2x2_dc(dctcoef out[4], const dctcoef in[4], const int32_t dq[6][16], int qp);
+int  x264o_optimize_chroma_2x2_dc(dctcoef d[4], int dmf);   /* dmf = dequant4_mf[qp%6][0] << qp/6; 0 = nothing left to code */
 int  x264o_decimate_score(const dctcoef *scanned, int n); /* n = 15, 16 or 64; scanned order */
 int  x264o_coeff_last(const dctcoef *scanned, int n);
 extern const uint8_t x264o_chroma_qp[52];

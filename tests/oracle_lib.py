@@ -196,6 +196,9 @@ class OracleEncoder:
         self.close()
 
 
+_sig("x264o_optimize_chroma_2x2_dc", _i, [C.c_void_p, _i])
+
+
 # ---- lookahead frame cost (oracle/lookahead.c) ----
 _sig("x264o_lookahead_create", C.c_void_p, [_i, _i, _i, _i])
 _sig("x264o_lookahead_destroy", None, [C.c_void_p])

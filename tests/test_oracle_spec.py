@@ -228,3 +228,36 @@ def test_metric_definitions():
                 for x in range(0, w, 8):
                     raw += np.abs(H8 @ d[:, y:y + 8, x:x + 8] @ H8).sum((1, 2))
             np.testing.assert_array_equal(O.metric("sa8d", a, b), (raw + 2) >> 2)
+
+
+def test_optimize_chroma_2x2_dc_keeps_the_reconstruction():
+    """x264o_optimize_chroma_2x2_dc ([x264-upstream] quant.c optimize_chroma_2x2_dc): the trimmed DC levels must dequantise to
+    the same per-block DC contribution ((idct2x2 * dmf >> 5) + 32) >> 6 as the original ones, never grow, and return 0 exactly
+    when that contribution is zero everywhere."""
+    rnd = np.random.default_rng(7)
+    dq0 = [160, 176, 208, 224, 256, 288]                  # dequant4_mf[qp % 6][0], flat matrix
+
+    def contrib(d, dmf):
+        d = [int(v) for v in d]
+        a, b, c, e = d[0] + d[1], d[2] + d[3], d[0] - d[1], d[2] - d[3]
+        return [((x * dmf >> 5) + 32) >> 6 for x in (a + b, a - b, c + e, c - e)]
+    trimmed = 0
+    for _ in range(4000):
+        qp = int(rnd.integers(0, 40))
+        dmf = dq0[qp % 6] << (qp // 6)
+        d = rnd.integers(-6, 7, 4).astype(np.int16) if rnd.random() < 0.8 else rnd.integers(-40, 41, 4).astype(np.int16)
+        if not d.any():
+            continue
+        o = d.copy()
+        r = O.L.x264o_optimize_chroma_2x2_dc(O.ptr(o), dmf)
+        if dmf > 2048:
+            assert r == 1 and np.array_equal(o, d)
+            continue
+        before = contrib(d, dmf)
+        if r == 0:
+            assert not any(before), (d, dmf)
+        else:
+            assert contrib(o, dmf) == before, (d, o, dmf)
+            assert np.all(np.abs(o) <= np.abs(d)) and np.all(o * d >= 0)
+            trimmed += int(not np.array_equal(o, d))
+    assert trimmed > 50

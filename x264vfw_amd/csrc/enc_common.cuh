@@ -141,6 +141,33 @@ __device__ __forceinline__ uint32_t chroma_residual(uint32_t enc, uint32_t pred,
     int ldc[4], nzdc = 0;
 #pragma unroll
     for (int b = 0; b < 4; b++) { ldc[b] = quant_one(f[b], q.mf[0] >> 1, q.bias[0] << 1); nzdc |= ldc[b]; }
+    // DC-only planes: x264_mb_optimize_chroma_dc (oracle x264o_optimize_chroma_2x2_dc) lowers the DC levels while the
+    // reconstruction ((idct2x2(level) * dmf >> 5) + 32) >> 6 stays the same; visiting order 3, 1, 2, 0; quantisers whose
+    // dmf exceeds 2048 are left alone.  Every lane of the plane runs the same few iterations.
+    if (nzdc && !plane_ac) {
+        const int dmf = q.dq[0] << (q.qp / 6);
+        if (dmf <= 32 * 64) {
+            auto rnd = [&](int o[4]) {
+                const int d0 = ldc[0] + ldc[1], d1 = ldc[2] + ldc[3], d2 = ldc[0] - ldc[1], d3 = ldc[2] - ldc[3];
+                o[0] = ((d0 + d1) * dmf >> 5) + 32; o[1] = ((d0 - d1) * dmf >> 5) + 32;
+                o[2] = ((d2 + d3) * dmf >> 5) + 32; o[3] = ((d2 - d3) * dmf >> 5) + 32;
+            };
+            int ref[4], out[4];
+            rnd(ref);
+            if (!((ref[0] | ref[1] | ref[2] | ref[3]) >> 6)) { ldc[0] = ldc[1] = ldc[2] = ldc[3] = 0; nzdc = 0; }
+            else {
+                int left = 0;
+#define X264GPU_OPT_DC(C) { int level = ldc[C]; const int sign = level >> 31 | 1; \
+                    while (level) { ldc[C] = level - sign; rnd(out); \
+                        if (((ref[0] ^ out[0]) | (ref[1] ^ out[1]) | (ref[2] ^ out[2]) | (ref[3] ^ out[3])) >> 6) { left = 1; ldc[C] = level; break; } \
+                        level -= sign; } }
+                X264GPU_OPT_DC(3) X264GPU_OPT_DC(1) X264GPU_OPT_DC(2) X264GPU_OPT_DC(0)
+#undef X264GPU_OPT_DC
+                if (!left) { ldc[0] = ldc[1] = ldc[2] = ldc[3] = 0; nzdc = 0; }
+                else nzdc = 1;
+            }
+        }
+    }
     int dq[4] = { 0, 0, 0, 0 };
     if (nzdc) {
         int a = ldc[0] + ldc[1], b = ldc[0] - ldc[1], cc = ldc[2] + ldc[3], d = ldc[2] - ldc[3];

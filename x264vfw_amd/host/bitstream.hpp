@@ -9,32 +9,33 @@ namespace x264host {
 
 class BitWriter {
 public:
-    void reset() { buf_.clear(); cur_ = 0; nbits_ = 0; }
-    void put(uint32_t value, int n)          // n <= 32, MSB first
+    void reset() { buf_.clear(); acc_ = 0; nbits_ = 0; }
+    void put(uint32_t value, int n)          // n <= 32, MSB first; a 64-bit accumulator, whole bytes leave it at once
     {
-        for (int i = n - 1; i >= 0; i--) {
-            cur_ = (cur_ << 1) | ((value >> i) & 1);
-            if (++nbits_ == 8) { buf_.push_back((uint8_t)cur_); cur_ = 0; nbits_ = 0; }
-        }
+        if (n <= 0) return;
+        acc_ = (acc_ << n) | (uint64_t)(n == 32 ? value : value & ((1u << n) - 1u));
+        nbits_ += n;
+        while (nbits_ >= 8) { nbits_ -= 8; buf_.push_back((uint8_t)(acc_ >> nbits_)); }
     }
     void put1(int b) { put((uint32_t)b & 1, 1); }
     void ue(uint32_t v)                      // 9.1: codeNum v
     {
-        uint64_t x = (uint64_t)v + 1;
-        int len = 0;
-        while ((x >> (len + 1)) != 0) len++;
-        put(0, len);
-        put((uint32_t)x, len + 1);
+        const uint64_t x = (uint64_t)v + 1;
+        const int len = 63 - __builtin_clzll(x);
+        if (len) put(0, len);
+        if (len + 1 > 32) { put((uint32_t)(x >> 32), len + 1 - 32); put((uint32_t)x, 32); }
+        else put((uint32_t)x, len + 1);
     }
     void se(int v) { ue(v <= 0 ? (uint32_t)(-2 * (int64_t)v) : (uint32_t)(2 * (int64_t)v - 1)); }
     void te(int range, int v) { if (range == 1) put1(!v); else ue((uint32_t)v); }   // te(v) with cMax = range
-    void trailing() { put1(1); while (nbits_) put1(0); }                             // rbsp_trailing_bits
-    void align_zero() { while (nbits_) put1(0); }
+    void trailing() { put1(1); align_zero(); }                                       // rbsp_trailing_bits
+    void align_zero() { if (nbits_) put(0, 8 - nbits_); }
     size_t bits() const { return buf_.size() * 8 + nbits_; }
     const std::vector<uint8_t> &bytes() const { return buf_; }
+    void reserve(size_t n) { buf_.reserve(n); }
 private:
     std::vector<uint8_t> buf_;
-    uint32_t cur_ = 0;
+    uint64_t acc_ = 0;                       // only the low nbits_ (< 8 between calls) bits are pending
     int nbits_ = 0;
 };
 

@@ -14,6 +14,7 @@
 #include <memory>
 #include <string>
 #include <thread>
+#include <chrono>
 
 using namespace x264host;
 
@@ -52,6 +53,7 @@ struct x264_t {
         double last_qscale_for[2] = { 0, 0 };       // [0] I, [1] P
         int last_non_b_is_i = 1;
     } rc;
+    double t_phase[6] = { 0, 0, 0, 0, 0, 0 };   // X264GPU_HOST_TIMING=1: seconds in copy-in, upload + lookahead, GPU, download, entropy coding, calls
     int last_qp = 0, last_scenecut = 0;  // diagnostics: quantiser and scenecut flag of the last coded picture
     int32_t last_costs[4] = { 0, 0, 0, 0 };
     // ---- GOP-parallel mode (--threads G > 1): G closed GOPs of the one stream are coded in lock-step on G stream slots of the
@@ -437,6 +439,9 @@ int x264_encoder_encode(x264_t *h, x264_nal_t **pp_nal, int *pi_nal, x264_pictur
     // Zero-copy input (x264gpu_host_input_i420): the caller (the VfW shell after the device-side colourspace conversion)
     // already placed a tight I420 picture in the encoder's device staging buffer.
     const bool resident = pic_in->img.plane[0] == h->d_in;
+    auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    double t0 = now(), t1;
+#define PHASE(i) do { t1 = now(); h->t_phase[i] += t1 - t0; t0 = t1; } while (0)
     // ---- frame copy-in: three strided planes -> one tightly packed I420 buffer -> HBM (replaces x264_frame_copy_picture) ----
     uint8_t *dst = h->h_in.data();
     for (int pl = 0; pl < 3 && !resident; pl++) {
@@ -445,6 +450,7 @@ int x264_encoder_encode(x264_t *h, x264_nal_t **pp_nal, int *pi_nal, x264_pictur
         for (int y = 0; y < ph; y++, dst += pw, src += pic_in->img.i_stride[pl]) memcpy(dst, src, pw);
     }
     if (h->G > 1) return encode_gop_parallel(h, pp_nal, pi_nal, pic_in, pic_out, resident);
+    PHASE(0);
     bool idr = h->frames_since_idr == 0 || h->frames_since_idr >= h->keyint || pic_in->i_type == X264_TYPE_IDR || pic_in->i_type == X264_TYPE_KEYFRAME;
     if (!resident && x264gpu_memcpy_h2d(h->d_in, h->h_in.data(), h->h_in.size(), nullptr) != X264GPU_OK) {
         xlog(&p, X264_LOG_ERROR, "x264_encoder_encode: upload failed: %s\n", x264gpu_last_error());
@@ -498,12 +504,18 @@ int x264_encoder_encode(x264_t *h, x264_nal_t **pp_nal, int *pi_nal, x264_pictur
     h->last_qp = qp_now;
     if (idr) { h->frames_since_idr = 0; h->frame_num = 0; }
     int st = idr ? X264GPU_SLICE_I : X264GPU_SLICE_P;
-    if (x264gpu_encode_frames(h->gpu, h->d_in, st, h->d_mb, h->d_lv, nullptr) != X264GPU_OK ||
-        x264gpu_memcpy_d2h(h->h_mb.data(), h->d_mb, h->h_mb.size() * sizeof(x264gpu_mb), nullptr) != X264GPU_OK ||
+    PHASE(1);
+    if (x264gpu_encode_frames(h->gpu, h->d_in, st, h->d_mb, h->d_lv, nullptr) != X264GPU_OK || x264gpu_stream_sync(nullptr) != X264GPU_OK) {
+        xlog(&p, X264_LOG_ERROR, "x264_encoder_encode: GPU hot path failed: %s\n", x264gpu_last_error());
+        return -1;
+    }
+    PHASE(2);
+    if (x264gpu_memcpy_d2h(h->h_mb.data(), h->d_mb, h->h_mb.size() * sizeof(x264gpu_mb), nullptr) != X264GPU_OK ||
         x264gpu_memcpy_d2h(h->h_lv.data(), h->d_lv, h->h_lv.size() * sizeof(int16_t), nullptr) != X264GPU_OK) {
         xlog(&p, X264_LOG_ERROR, "x264_encoder_encode: GPU hot path failed: %s\n", x264gpu_last_error());
         return -1;
     }
+    PHASE(3);
     // ---- host: headers + entropy coding ----
     h->out.clear(); h->nal_off.clear();
     std::vector<int> types;
@@ -535,6 +547,9 @@ int x264_encoder_encode(x264_t *h, x264_nal_t **pp_nal, int *pi_nal, x264_pictur
     h->frame_num = (h->frame_num + 1) & ((1 << h->log2_max_frame_num) - 1);
     h->frames_since_idr++;
     h->frame_no++;
+    PHASE(4);
+    h->t_phase[5] += 1;
+#undef PHASE
     return (int)h->out.size();
 }
 
@@ -544,6 +559,9 @@ void x264_encoder_close(x264_t *h)
 {
     if (!h) return;
     join_pool(h);
+    if (getenv("X264GPU_HOST_TIMING") && h->t_phase[5] > 0)
+        fprintf(stderr, "x264gpu host timing, ms per call over %.0f calls: copy-in %.2f, upload+lookahead %.2f, GPU %.2f, download %.2f, entropy %.2f\n", h->t_phase[5],
+                1e3 * h->t_phase[0] / h->t_phase[5], 1e3 * h->t_phase[1] / h->t_phase[5], 1e3 * h->t_phase[2] / h->t_phase[5], 1e3 * h->t_phase[3] / h->t_phase[5], 1e3 * h->t_phase[4] / h->t_phase[5]);
     if (h->gpu) x264gpu_encoder_destroy(h->gpu);
     if (h->d_in) x264gpu_free(h->d_in);
     if (h->d_mb) x264gpu_free(h->d_mb);
