@@ -40,6 +40,7 @@ struct EncK {
     int me_method;            // 0 dia, 1 hex, 2 umh
     int chroma_me;            // sub-pel SATD costs carry chroma (subme >= 5)
     unsigned long long *dbg;  // optional diagnostics (NULL in production): per (stream, wave) cycle counters
+    int *wf_progress;         // [streams][2][WFG_ROWS]: row counters of the wavefront kernels when ONE stream spans several workgroups
 };
 
 __device__ __forceinline__ const uint8_t *ref_plane00(const EncK &k, int s, int r)
@@ -202,6 +203,32 @@ __device__ __forceinline__ uint32_t chroma_residual(uint32_t enc, uint32_t pred,
     nnz_bits |= bits;
     cbp_chroma = (bits & 0x00ff0000u) ? 2 : (bits & 0x06000000u) ? 1 : 0;
     return pack4_clip(v);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Row counters of the two wavefront kernels.  MWG = false: one workgroup owns the stream, counters live in LDS and hand-offs
+// are workgroup-scope (same CU, coherent L1).  MWG = true: the rows of ONE stream are dealt to several workgroups (few streams
+// in flight: single-stream latency), counters live in global memory, loads / stores are agent-scope atomics and the fences
+// make the reconstructed pixels and records of the row above visible across CUs.
+// ------------------------------------------------------------------------------------------------
+constexpr int WFG_ROWS = 160;
+template <bool MWG> __device__ __forceinline__ int wfp_load(const int *p)
+{
+    if (MWG) return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return *(const volatile int *)p;
+}
+template <bool MWG> __device__ __forceinline__ void wfp_store(int *p, int v)
+{
+    if (MWG) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    else *(volatile int *)p = v;
+}
+template <bool MWG> __device__ __forceinline__ void wfp_release()
+{
+    if (MWG) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent"); else __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+}
+template <bool MWG> __device__ __forceinline__ void wfp_acquire()
+{
+    if (MWG) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent"); else __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
 }
 
 }  // namespace x264gpu

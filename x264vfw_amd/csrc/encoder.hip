@@ -34,6 +34,7 @@ struct x264gpu_encoder {
     uint16_t *cost_mv[52] = {};
     int cur = 0;
     unsigned long long *dbg = nullptr;   // diagnostics buffer set by x264gpu_encoder_set_debug
+    int *wf_progress = nullptr;          // [streams][2][WFG_ROWS] row counters of the multi-workgroup wavefront kernels
     // optional per-stage profiling: (NSTAGE+1) events per armed call
     hipEvent_t *ev = nullptr;
     int *ev_mask = nullptr;       // per call: bit i = stage i ran
@@ -110,6 +111,7 @@ int x264gpu_encoder_create(x264gpu_encoder **out, const x264gpu_config *cfg)
         alloc((void **)&e->mvf[i], S * k.nmb * 2 * sizeof(int16_t), 0);
         alloc((void **)&e->reff[i], S * k.nmb, 0xff);
     }
+    alloc((void **)&e->wf_progress, S * 2 * WFG_ROWS * sizeof(int), 0);
     if (er != hipSuccess) { x264gpu_encoder_destroy(e); return set_err(er == hipErrorOutOfMemory ? X264GPU_ENOMEM : X264GPU_EHIP, "encoder buffers", er); }
     int rc = build_cost_mv(e, cfg->qp_p);
     if (rc) { x264gpu_encoder_destroy(e); return rc; }
@@ -173,6 +175,7 @@ void x264gpu_encoder_destroy(x264gpu_encoder *e)
     for (int i = 0; i < 5; i++) { (void)hipFree(e->luma[i]); (void)hipFree(e->chroma[i]); }
     for (int i = 0; i < 2; i++) { (void)hipFree(e->mvf[i]); (void)hipFree(e->reff[i]); }
     for (int q = 0; q < 52; q++) (void)hipFree(e->cost_mv[q]);
+    (void)hipFree(e->wf_progress);
     delete e;
 }
 
@@ -239,15 +242,26 @@ int x264gpu_encode_frames(x264gpu_encoder *e, const uint8_t *d_i420, int slice_t
     STAGE_MARK(3);
     // band kernel (four macroblock rows per wavefront); X264GPU_INTRA_V1=1 selects the row-per-wave predecessor for A/B runs
     static const bool intra_v1 = getenv("X264GPU_INTRA_V1") != nullptr;
+    // Few streams in flight (single-stream latency): the rows of ONE picture are dealt to several workgroups — a wave per band on
+    // its own SIMD instead of 16 waves sharing one CU — with row counters in global memory and agent-scope hand-offs.  All
+    // workgroups of a launch must be resident at once (they wait on each other): streams x workgroups <= 128.
+    static const bool mwg_off = getenv("X264GPU_WAVEFRONT_1WG") != nullptr;
+    const int nbands = (k.mbh + 3) / 4, npairs = (k.mbh + 1) / 2;
+    const int iwg = (nbands + I2_WAVES_MWG - 1) / I2_WAVES_MWG, dwg = (npairs + 3) / 4;
+    const bool mwg = !mwg_off && S * (iwg > dwg ? iwg : dwg) <= 128 && k.mbh > 4;
+    k.wf_progress = e->wf_progress;
+    if (mwg) HIP_TRY(hipMemsetAsync(e->wf_progress, 0, (size_t)S * 2 * WFG_ROWS * sizeof(int), st));
     if (intra_v1) hipLaunchKernelGGL(k_intra, dim3(S), dim3(1024), 0, st, k);
-    else if (S >= 128) hipLaunchKernelGGL(k_intra2<I2_WAVES>, dim3(S), dim3(I2_WAVES * 64), 0, st, k);        // CUs are full: small workgroups, two per CU
-    else hipLaunchKernelGGL(k_intra2<I2_WAVES_FEW>, dim3(S), dim3(I2_WAVES_FEW * 64), 0, st, k);                  // few streams: all bands of a frame at once
+    else if (mwg) hipLaunchKernelGGL((k_intra2<I2_WAVES_MWG, true>), dim3(S, iwg), dim3(I2_WAVES_MWG * 64), 0, st, k);
+    else if (S >= 128) hipLaunchKernelGGL((k_intra2<I2_WAVES, false>), dim3(S), dim3(I2_WAVES * 64), 0, st, k);        // CUs are full: small workgroups, two per CU
+    else hipLaunchKernelGGL((k_intra2<I2_WAVES_FEW, false>), dim3(S), dim3(I2_WAVES_FEW * 64), 0, st, k);                  // few streams: all bands of a frame at once
     mask |= 8;
     STAGE_MARK(4);
     if (e->cfg.deblock) {
         static const bool deblock_v1 = getenv("X264GPU_DEBLOCK_V1") != nullptr;      // one macroblock per wave (A/B runs)
         if (deblock_v1) hipLaunchKernelGGL(k_deblock, dim3(S), dim3(DB_WAVES * 64), 0, st, k);
-        else hipLaunchKernelGGL(k_deblock2, dim3(S), dim3(1024), 0, st, k);
+        else if (mwg) hipLaunchKernelGGL(k_deblock2<true>, dim3(S, dwg), dim3(256), 0, st, k);
+        else hipLaunchKernelGGL(k_deblock2<false>, dim3(S), dim3(1024), 0, st, k);
         mask |= 16;
     }
     STAGE_MARK(5);

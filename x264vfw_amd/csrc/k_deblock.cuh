@@ -398,29 +398,37 @@ __device__ void deblock_mb_pair(const EncK &k, Deblock2Lds &L, int wave, int lan
 }
 
 // One workgroup per stream; wave w owns the row pairs w, w + 16, ...; the pair at step x filters (x, r0) and (x - 2, r0 + 1)
+template <bool MWG>
 __global__ __launch_bounds__(1024) void k_deblock2(EncK k)
 {
     __shared__ __attribute__((aligned(16))) Deblock2Lds L;
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, s = blockIdx.x;
-    for (int i = threadIdx.x; i < WF_MAX_ROWS; i += 1024) L.progress[i] = 0;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, s = blockIdx.x, nw = blockDim.x >> 6;
+    const int gwave = MWG ? (int)blockIdx.y * nw + wave : wave, gstride = MWG ? (int)gridDim.y * nw : nw;
+    for (int i = threadIdx.x; i < WF_MAX_ROWS; i += blockDim.x) L.progress[i] = 0;
     if (threadIdx.x < 52) {
         const int i = threadIdx.x;
         L.alpha[i] = d_alpha_table[i]; L.beta[i] = d_beta_table[i]; L.cqp[i] = d_chroma_qp_table[i];
         L.tc0[i][0] = d_tc0_table[i][0]; L.tc0[i][1] = d_tc0_table[i][1]; L.tc0[i][2] = d_tc0_table[i][2]; L.tc0[i][3] = 0;
     }
     __syncthreads();
-    volatile int *progress = L.progress;
+    int *gprog = k.wf_progress + ((size_t)s * 2 + 1) * WFG_ROWS;     // MWG only
+    auto pload = [&](int r) { if (MWG) return wfp_load<true>(gprog + r); return ((volatile int *)L.progress)[r]; };
+    auto pstore = [&](int r, int v) { if (MWG) wfp_store<true>(gprog + r, v); else ((volatile int *)L.progress)[r] = v; };
     const int hf = lane >> 5;
-    for (int r0 = 2 * wave; r0 < k.mbh; r0 += 32) {
+    for (int r0 = 2 * gwave; r0 < k.mbh; r0 += 2 * gstride) {
         const bool row1 = r0 + 1 < k.mbh;
         for (int x = 0; x < k.mbw + 2; x++) {
-            if (x < k.mbw) wf_wait(progress, r0 - 1, min(x + 2, k.mbw));          // the upper row of the pair depends on the previous pair
+            if (x < k.mbw && r0 > 0) {                                             // the upper row of the pair depends on the previous pair
+                const int need = min(x + 2, k.mbw);
+                while (pload(r0 - 1) < need) __builtin_amdgcn_s_sleep(2);
+                wfp_acquire<MWG>();
+            }
             const int mx = hf ? x - 2 : x;
             const bool act = hf ? (row1 && x >= 2) : x < k.mbw;
             deblock_mb_pair(k, L, wave, lane, s, mx, r0 + hf, act);
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            wfp_release<MWG>();
             // the pair's lower row feeds the next pair's upper row; with an odd row count the upper row is the last one
-            if (lane == 0) { progress[r0] = min(x + 1, k.mbw); if (row1 && x >= 2) progress[r0 + 1] = x - 1; }
+            if (lane == 0) { pstore(r0, min(x + 1, k.mbw)); if (row1 && x >= 2) pstore(r0 + 1, x - 1); }
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");               // this wave's lower row reads what its upper row just wrote
         }
     }

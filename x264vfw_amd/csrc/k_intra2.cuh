@@ -21,6 +21,7 @@
 namespace x264gpu {
 
 constexpr int I2_WAVES = X264GPU_I2_WAVES;               // wavefronts per workgroup for many-stream launches
+constexpr int I2_WAVES_MWG = 4;                          // multi-workgroup mode: one wave per SIMD
 constexpr int I2_WAVES_FEW = 16;                         // ... and when few streams are in flight (latency over footprint)
 struct SlotLds {
     __attribute__((aligned(8))) uint8_t tile[IT_SIZE];
@@ -469,11 +470,13 @@ __device__ __forceinline__ int i2_next_intra(const EncK &k, const x264gpu_mb *mb
 #ifndef X264GPU_I2_OCC
 #define X264GPU_I2_OCC 4          // waves per SIMD the register allocator targets (2 -> up to 256 VGPRs, 4 -> 128)
 #endif
-template <int NW>
+template <int NW, bool MWG>
 __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(X264GPU_I2_OCC, 8))) void k_intra2(EncK kk)
 {
     __shared__ __attribute__((aligned(16))) Intra2LdsT<NW> L;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, s = blockIdx.x;
+    // MWG: gridDim.y workgroups share the bands of stream s (band = global wave index, then + all waves)
+    const int gwave = MWG ? (int)blockIdx.y * NW + wave : wave, gstride = MWG ? (int)gridDim.y * NW : NW;
     for (int i = threadIdx.x; i < 160; i += NW * 64) L.progress[i] = 0;
     if (threadIdx.x < 144) ((uint32_t *)L.pred8tab)[threadIdx.x] = ((const uint32_t *)c_pred8_table)[threadIdx.x];
     if (threadIdx.x < 36) ((uint32_t *)L.pred4tab)[threadIdx.x] = ((const uint32_t *)c_pred4_table.t)[threadIdx.x];
@@ -481,17 +484,19 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(X264GPU
     __syncthreads();
     const EncK &k = kk;
     const x264gpu_mb *mbs = k.mb + (size_t)s * k.nmb;
-    volatile int *progress = L.progress;
+    int *gprog = kk.wf_progress + (size_t)s * 2 * WFG_ROWS;          // MWG only; the LDS counters are addressed as LDS (no generic pointer)
+    auto pload = [&](int r) { if (MWG) return wfp_load<true>(gprog + r); return ((volatile int *)L.progress)[r]; };
+    auto pstore = [&](int r, int v) { if (MWG) wfp_store<true>(gprog + r, v); else ((volatile int *)L.progress)[r] = v; };
     SlotLds *slots = L.slot[wave];
     unsigned long long tA = 0, tB = 0, tC = 0, tW = 0, nstep = 0, nslot = 0, t_begin = k.dbg ? clock64() : 0;
     const int mbw = k.mbw, nbands = (k.mbh + 3) >> 2;
-    for (int band = wave; band < nbands; band += NW) {
+    for (int band = gwave; band < nbands; band += gstride) {
         const int r0 = band * 4;
         int x[4], cur[4];                      // next intra macroblock / macroblocks completed, per row of the band
 #pragma unroll
         for (int i = 0; i < 4; i++) { x[i] = r0 + i < k.mbh ? i2_next_intra(k, mbs, r0 + i, 0, lane) : mbw; cur[i] = x[i]; }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-        if (lane < 4 && r0 + lane < k.mbh) progress[r0 + lane] = lane == 0 ? cur[0] : lane == 1 ? cur[1] : lane == 2 ? cur[2] : cur[3];
+        wfp_release<MWG>();
+        if (lane < 4 && r0 + lane < k.mbh) pstore(r0 + lane, lane == 0 ? cur[0] : lane == 1 ? cur[1] : lane == 2 ? cur[2] : cur[3]);
         for (;;) {
             unsigned act = 0;
             bool all_done = true;
@@ -500,13 +505,13 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(X264GPU
                 if (x[i] >= mbw) continue;
                 all_done = false;
                 const int need = min(x[i] + 2, mbw);           // the row above must have passed the top-right neighbour
-                const int above = i == 0 ? (r0 == 0 ? mbw : progress[r0 - 1]) : cur[i - 1];
+                const int above = i == 0 ? (r0 == 0 ? mbw : pload(r0 - 1)) : cur[i - 1];
                 if (above >= need) act |= 1u << i;
             }
             if (all_done) break;
             if (!act) { const unsigned long long w0 = k.dbg ? clock64() : 0; __builtin_amdgcn_s_sleep(2); if (k.dbg) tW += clock64() - w0; continue; }
             const unsigned long long c0 = k.dbg ? clock64() : 0;
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+            wfp_acquire<MWG>();
 #pragma unroll 1
             for (int i = 0; i < 4; i++)            // one copy of the phase code (instruction-cache footprint), slot chosen at run time
                 if (act >> i & 1) { i2_phase_a(k, slots[i], lane, s, i == 0 ? x[0] : i == 1 ? x[1] : i == 2 ? x[2] : x[3], r0 + i); __builtin_amdgcn_sched_barrier(0); }
@@ -519,10 +524,10 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(X264GPU
             for (int i = 0; i < 4; i++)
                 if (act >> i & 1) { __builtin_amdgcn_sched_barrier(0); i2_phase_c(k, slots[i], lane, s, i == 0 ? x[0] : i == 1 ? x[1] : i == 2 ? x[2] : x[3], r0 + i); }
             if (k.dbg) { const unsigned long long c3 = clock64(); tA += c1 - c0; tB += c2 - c1; tC += c3 - c2; nstep++; nslot += __builtin_popcount(act); }
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            wfp_release<MWG>();
 #pragma unroll
             for (int i = 0; i < 4; i++) if (act >> i & 1) { x[i] = i2_next_intra(k, mbs, r0 + i, x[i] + 1, lane); cur[i] = x[i]; }
-            if (lane < 4 && r0 + lane < k.mbh) progress[r0 + lane] = lane == 0 ? cur[0] : lane == 1 ? cur[1] : lane == 2 ? cur[2] : cur[3];
+            if (lane < 4 && r0 + lane < k.mbh) pstore(r0 + lane, lane == 0 ? cur[0] : lane == 1 ? cur[1] : lane == 2 ? cur[2] : cur[3]);
         }
     }
     if (k.dbg && lane == 0) {
