@@ -234,3 +234,27 @@ def test_cavlc_closed_loop_random(seed):
         assert len(dec) == nfr, f"seed {seed} case {it}: {w}x{h} {kw}: decoder returned {len(dec)} pictures"
         for i in range(nfr):
             np.testing.assert_array_equal(dec[i], recons[i], err_msg=f"seed {seed} case {it}: {w}x{h} {kw} picture {i}")
+
+
+def test_row_band_parallel_cavlc_is_byte_identical(monkeypatch):
+    """write_slice codes row bands on several threads and stitches the bit strings (mb_skip_run carried across bands): the NAL
+    must not depend on the thread count — I and P slices, skip runs crossing band borders, ragged row counts."""
+    import random
+    rnd = random.Random(3)
+    for w, h, kw in [(352, 288, dict(qp_i=30, qp_p=38)), (176, 144, dict(qp_i=20, qp_p=23, partitions=7, dct8x8=1, refs=2)),
+                     (208, 120, dict(qp_i=45, qp_p=50)), (320, 368, dict(qp_i=26, qp_p=51, partitions=3))]:
+        mbw, mbh = (w + 15) // 16, (h + 15) // 16
+        enc = O.OracleEncoder(O.default_config(w, h, **kw))
+        frames = synth_frames(w, h, 3, seed=rnd.randint(0, 999))
+        frames.append(frames[-1].copy())                       # a repeated picture: long skip runs
+        for i, f in enumerate(frames):
+            st = 2 if i == 0 else 0
+            mbs, lv = enc.encode(f, st)
+            outs = []
+            for t in ("1", "2", "3", "7"):
+                monkeypatch.setenv("X264GPU_CAVLC_THREADS", t)
+                nal, skipped = HL.write_slice(mbw, mbh, st, kw["qp_i"] if st == 2 else kw["qp_p"], 26, i, 4, int(st == 2), 0, 0, mbs, lv,
+                                              num_ref=max(1, min(i, kw.get("refs", 1))), num_ref_default=kw.get("refs", 1), t8x8=kw.get("dct8x8", 0))
+                outs.append((nal, skipped))
+            assert all(o == outs[0] for o in outs), f"{w}x{h} frame {i}"
+        assert outs[0][1] > mbw                                # the repeated picture really is mostly skipped

@@ -33,6 +33,18 @@ public:
     size_t bits() const { return buf_.size() * 8 + nbits_; }
     const std::vector<uint8_t> &bytes() const { return buf_; }
     void reserve(size_t n) { buf_.reserve(n); }
+    void append(const BitWriter &o)          // every bit of `o`, in order, behind the bits written so far
+    {
+        const uint8_t *d = o.buf_.data();
+        const size_t nb = o.buf_.size();
+        if (nbits_ == 0) buf_.insert(buf_.end(), d, d + nb);
+        else {
+            size_t i = 0;
+            for (; i + 4 <= nb; i += 4) put((uint32_t)d[i] << 24 | (uint32_t)d[i + 1] << 16 | (uint32_t)d[i + 2] << 8 | d[i + 3], 32);
+            for (; i < nb; i++) put(d[i], 8);
+        }
+        if (o.nbits_) put((uint32_t)(o.acc_ & ((1u << o.nbits_) - 1u)), o.nbits_);
+    }
 private:
     std::vector<uint8_t> buf_;
     uint64_t acc_ = 0;                       // only the low nbits_ (< 8 between calls) bits are pending

@@ -54,6 +54,7 @@ struct x264_t {
         int last_non_b_is_i = 1;
     } rc;
     double t_phase[6] = { 0, 0, 0, 0, 0, 0 };   // X264GPU_HOST_TIMING=1: seconds in copy-in, upload + lookahead, GPU, download, entropy coding, calls
+    int cavlc_threads = 1;               // row bands of a slice coded in parallel (threads 1 sessions; GOP-parallel ones use a thread per GOP)
     int last_qp = 0, last_scenecut = 0;  // diagnostics: quantiser and scenecut flag of the last coded picture
     int32_t last_costs[4] = { 0, 0, 0, 0 };
     // ---- GOP-parallel mode (--threads G > 1): G closed GOPs of the one stream are coded in lock-step on G stream slots of the
@@ -86,6 +87,13 @@ static void xlog(const x264_param_t *p, int level, const char *fmt, ...)
 }
 
 static int clampi(int v, int lo, int hi) { return v < lo ? lo : v > hi ? hi : v; }
+
+// threads that entropy-code row bands of ONE slice (write_slice): X264GPU_CAVLC_THREADS overrides `dflt`
+static int cavlc_threads_default(int dflt)
+{
+    const char *e = getenv("X264GPU_CAVLC_THREADS");
+    return clampi(e ? atoi(e) : dflt, 1, 64);
+}
 
 static int pick_level(const x264_param_t *p, int mbs, int refs)
 {
@@ -248,6 +256,7 @@ x264_t *x264_encoder_open(x264_param_t *param)
         dur = dur < 0.01 ? 0.01 : dur > 1.0 ? 1.0 : dur;              // CLIP_DURATION
         h->rc.dur_ratio = dur / 0.04;                                  // BASE_FRAME_DURATION
     }
+    { const unsigned hw = std::thread::hardware_concurrency(); h->cavlc_threads = h->G > 1 ? 1 : cavlc_threads_default(hw >= 32 ? 16 : hw >= 16 ? 8 : hw >= 4 ? (int)hw / 2 : 1); }
     h->h_in.resize(insz); h->h_mb.resize((size_t)h->G * h->nmb); h->h_lv.resize((size_t)h->G * h->nmb * X264GPU_MB_LEVELS);
     if (h->G > 1) {
         const size_t n = (size_t)h->G * h->keyint;
@@ -534,7 +543,7 @@ int x264_encoder_encode(x264_t *h, x264_nal_t **pp_nal, int *pi_nal, x264_pictur
     sp.transform8x8_mode = p.analyse.b_transform_8x8;
     h->nal_off.push_back(h->out.size()); types.push_back(idr ? 5 : 1);
     h->last_stats.skip = 0;
-    write_slice(h->out, sp, h->h_mb.data(), h->h_lv.data(), p.b_annexb != 0, h->nal_off.size() == 1, &h->last_stats);
+    write_slice(h->out, sp, h->h_mb.data(), h->h_lv.data(), p.b_annexb != 0, h->nal_off.size() == 1, &h->last_stats, h->cavlc_threads);
     publish_nals(h, pp_nal, pi_nal, types);
     if (pic_out) {
         x264_picture_init(pic_out);
@@ -584,7 +593,7 @@ int x264host_write_slice(int mbw, int mbh, int slice_type, int qp, int pic_init_
     sp.disable_deblock_idc = disable_deblock_idc; sp.transform8x8_mode = transform8x8_mode;
     std::vector<uint8_t> v;
     SliceStats stt = { 0 };
-    write_slice(v, sp, mbs, levels, true, true, &stt);
+    write_slice(v, sp, mbs, levels, true, true, &stt, cavlc_threads_default(1));
     if (skipped) *skipped = stt.skip;
     if ((int)v.size() > cap) return -1;
     memcpy(out, v.data(), v.size());

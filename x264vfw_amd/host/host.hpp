@@ -36,6 +36,6 @@ void write_pps(std::vector<uint8_t> &out, const PpsParams &p, bool annexb);
 void write_sei_version(std::vector<uint8_t> &out, const char *text, bool annexb);
 void write_slice_header(BitWriter &bw, const SliceParams &p);
 void write_slice(std::vector<uint8_t> &out, const SliceParams &p, const x264gpu_mb *mbs, const int16_t *levels,
-                 bool annexb, bool long_startcode, SliceStats *stats);
+                 bool annexb, bool long_startcode, SliceStats *stats, int threads = 1);
 
 }  // namespace x264host

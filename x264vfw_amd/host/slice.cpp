@@ -6,6 +6,7 @@
 #include "host.hpp"
 #include "cavlc_tables.hpp"
 #include <stdlib.h>
+#include <thread>
 
 namespace x264host {
 
@@ -22,10 +23,13 @@ struct SliceCtx {
     const x264gpu_mb *mbs;
     const int16_t *levels;
     BitWriter &bw;
-    std::vector<uint8_t> tc;      // total_coeff per block: [mb][24] (16 luma by block index, 4 U, 4 V); skip/absent = 0
-    std::vector<uint8_t> coded;   // 1 once the macroblock has been written (availability inside the slice)
-    std::vector<uint8_t> skipped;
-    SliceStats *stats;
+    uint8_t *tc;                  // total_coeff per block: [mb][24] (16 luma by block index, 4 U, 4 V); skip/absent = 0.  Filled for the
+                                  // WHOLE picture before any row is coded (it depends on the macroblock's own levels only), so that
+                                  // bands of rows can be coded by different threads
+    int row0, row1;               // macroblock rows this context codes
+    // skip-run bookkeeping across bands (P slices): macroblocks skipped before the band's first coded macroblock / after its last
+    int lead_skip = 0, trail_skip = 0, nskip = 0;
+    bool has_coded = false;
 
     int mbw() const { return p.mbw; }
 
@@ -119,7 +123,7 @@ struct SliceCtx {
         if (gx < 0 || gy < 0 || gx >= 2 * p.mbw || gy >= 2 * p.mbh) return n;
         int i = (gy >> 1) * p.mbw + (gx >> 1), k = (gy & 1) * 2 + (gx & 1);
         if (i == cur_mb) { if (done8 >> k & 1) return cur8[k]; return n; }
-        if (!coded[i]) return n;
+        if (i > cur_mb) return n;                          // raster order: everything before the current macroblock is available
         n.avail = true;
         const x264gpu_mb &m = mbs[i];
         if (!is_intra(m)) { n.ref = m.ref[k]; n.mvx = m.mv[k][0]; n.mvy = m.mv[k][1]; }
@@ -172,7 +176,7 @@ struct SliceCtx {
 
     void write_residual(int mbx, int mby, const x264gpu_mb &m, const int16_t *lv)
     {
-        uint8_t *t = &tc[(size_t)(mby * p.mbw + mbx) * 24];
+        uint8_t *t = tc + (size_t)(mby * p.mbw + mbx) * 24;
         if (m.type == X264GPU_MB_I16x16) residual_block(lv + X264GPU_LV_LUMA_DC, 16, nc_luma(mbx, mby, 0));
         for (int i8 = 0; i8 < 4; i8++) {
             if (!(m.cbp_luma >> i8 & 1)) continue;
@@ -225,32 +229,48 @@ struct SliceCtx {
         write_residual(mbx, mby, m, lv);
     }
 
+    // total_coeff of every block of one macroblock (what residual_block will return for the blocks write_residual codes)
+    static void fill_tc(const x264gpu_mb &m, const int16_t *lv, uint8_t *t)
+    {
+        auto nzc = [](const int16_t *l, int n) { int c = 0; for (int i = 0; i < n; i++) c += l[i] != 0; return c; };
+        for (int b = 0; b < 24; b++) t[b] = 0;
+        const bool i16 = m.type == X264GPU_MB_I16x16;
+        for (int i8 = 0; i8 < 4; i8++)
+            if (m.cbp_luma >> i8 & 1)
+                for (int k = 0; k < 4; k++) { const int b = i8 * 4 + k; t[b] = (uint8_t)(i16 ? nzc(lv + b * 16 + 1, 15) : nzc(lv + b * 16, 16)); }
+        if (m.cbp_chroma == 2)
+            for (int c = 0; c < 8; c++) t[16 + c] = (uint8_t)nzc(lv + X264GPU_LV_CHROMA_AC + c * 16 + 1, 15);
+    }
+
+    // Codes rows [row0, row1).  In P slices the bits start at the first coded macroblock's mb_type: the mb_skip_run in front of it
+    // (lead_skip + whatever the previous band left pending) is written by the caller that stitches the bands together.
     void run()
     {
         int skip_run = 0;
-        for (int mby = 0; mby < p.mbh; mby++)
+        auto flush_run = [&] { if (!has_coded) { lead_skip = skip_run; has_coded = true; } else bw.ue(skip_run); skip_run = 0; };
+        for (int mby = row0; mby < row1; mby++)
             for (int mbx = 0; mbx < p.mbw; mbx++) {
                 int i = mby * p.mbw + mbx;
                 const x264gpu_mb &m = mbs[i];
                 const int16_t *lv = levels + (size_t)i * X264GPU_MB_LEVELS;
+                cur_mb = i; done8 = 0;
                 if (p.slice_type == X264GPU_SLICE_I) write_mb_intra(mbx, mby, m, lv, 0);
-                else if (is_intra(m)) { bw.ue(skip_run); skip_run = 0; write_mb_intra(mbx, mby, m, lv, 5); }
+                else if (is_intra(m)) { flush_run(); write_mb_intra(mbx, mby, m, lv, 5); }
                 else {
                     int px, py;
                     bool skip = false;
-                    cur_mb = i; done8 = 0;
                     if (m.partition == 0 && m.ref[0] == 0 && !m.cbp_luma && !m.cbp_chroma) {
                         pskip_mv(mbx, mby, px, py);
                         skip = px == m.mv[0][0] && py == m.mv[0][1];
                     }
-                    if (skip) { skip_run++; skipped[i] = 1; if (stats) stats->skip++; }
+                    if (skip) { skip_run++; nskip++; }
                     else {
                         // partition geometry in 8x8 units: {bx8, by8, w8, h8}
                         static const int8_t geom[4][4][4] = { { { 0, 0, 2, 2 } }, { { 0, 0, 2, 1 }, { 0, 1, 2, 1 } },
                                                               { { 0, 0, 1, 2 }, { 1, 0, 1, 2 } },
                                                               { { 0, 0, 1, 1 }, { 1, 0, 1, 1 }, { 0, 1, 1, 1 }, { 1, 1, 1, 1 } } };
                         const int nparts = m.partition == 0 ? 1 : m.partition == 3 ? 4 : 2;
-                        bw.ue(skip_run); skip_run = 0;
+                        flush_run();
                         bw.ue(m.partition);                                  // P_L0_16x16 / P_L0_L0_16x8 / P_L0_L0_8x16 / P_8x8
                         if (m.partition == 3) for (int k = 0; k < 4; k++) bw.ue(0);      // sub_mb_type P_L0_8x8
                         if (p.num_ref > 1)
@@ -272,9 +292,8 @@ struct SliceCtx {
                         write_residual(mbx, mby, m, lv);
                     }
                 }
-                coded[i] = 1;
             }
-        if (skip_run) bw.ue(skip_run);
+        if (has_coded) trail_skip = skip_run; else lead_skip = skip_run;
     }
 };
 
@@ -303,14 +322,46 @@ void write_slice_header(BitWriter &bw, const SliceParams &p)
     if (p.disable_deblock_idc != 1) { bw.se(p.alpha_off_div2); bw.se(p.beta_off_div2); }
 }
 
+// Row bands are entropy-coded by `threads` threads (CAVLC has no state that crosses macroblocks except mb_skip_run, which the
+// stitching below carries over; nC contexts come from the precomputed total_coeff table, predictors from the records), then
+// their bit strings are concatenated behind the slice header.  The bytes do not depend on the number of threads.
 void write_slice(std::vector<uint8_t> &out, const SliceParams &p, const x264gpu_mb *mbs, const int16_t *levels,
-                 bool annexb, bool long_startcode, SliceStats *stats)
+                 bool annexb, bool long_startcode, SliceStats *stats, int threads)
 {
     BitWriter bw;
     write_slice_header(bw, p);
-    size_t n = (size_t)p.mbw * p.mbh;
-    SliceCtx ctx{ p, mbs, levels, bw, std::vector<uint8_t>(n * 24, 0), std::vector<uint8_t>(n, 0), std::vector<uint8_t>(n, 0), stats };
-    ctx.run();
+    const size_t n = (size_t)p.mbw * p.mbh;
+    std::vector<uint8_t> tc(n * 24);
+    int T = threads < 1 ? 1 : threads;
+    if (T > p.mbh / 4) T = p.mbh / 4 > 0 ? p.mbh / 4 : 1;           // at least four rows per band
+    std::vector<BitWriter> bws((size_t)T);
+    std::vector<SliceCtx> ctx;
+    ctx.reserve((size_t)T);
+    for (int t = 0; t < T; t++) {
+        ctx.push_back(SliceCtx{ p, mbs, levels, bws[(size_t)t], tc.data(), (int)((long)p.mbh * t / T), (int)((long)p.mbh * (t + 1) / T) });
+        bws[(size_t)t].reserve(n * 48 / (size_t)T + 64);
+    }
+    auto fill = [&](int t) {
+        for (size_t i = (size_t)ctx[(size_t)t].row0 * p.mbw; i < (size_t)ctx[(size_t)t].row1 * p.mbw; i++)
+            SliceCtx::fill_tc(mbs[i], levels + i * X264GPU_MB_LEVELS, tc.data() + i * 24);
+    };
+    std::vector<std::thread> pool;
+    for (int t = 1; t < T; t++) pool.emplace_back(fill, t);          // pass 1: total_coeff of every block of the picture
+    fill(0);
+    for (auto &th : pool) th.join();
+    pool.clear();
+    for (int t = 1; t < T; t++) pool.emplace_back([&ctx, t] { ctx[(size_t)t].run(); });      // pass 2: the bands
+    ctx[0].run();
+    for (auto &th : pool) th.join();
+    int carry = 0;                                                   // skipped macroblocks not yet covered by an mb_skip_run
+    for (int t = 0; t < T; t++) {
+        const SliceCtx &c = ctx[(size_t)t];
+        if (p.slice_type == X264GPU_SLICE_I) { bw.append(bws[(size_t)t]); continue; }
+        if (c.has_coded) { bw.ue((uint32_t)(carry + c.lead_skip)); bw.append(bws[(size_t)t]); carry = c.trail_skip; }
+        else carry += c.lead_skip;
+    }
+    if (carry) bw.ue((uint32_t)carry);
+    if (stats) { stats->skip = 0; for (const SliceCtx &c : ctx) stats->skip += c.nskip; }
     bw.trailing();
     append_nal(out, p.nal_ref_idc, p.idr ? 5 : 1, bw.bytes(), annexb, long_startcode);
 }
