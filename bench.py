@@ -199,9 +199,9 @@ def main():
     qp_i, qp_p = max(0, args.qp - 3), args.qp      # CQP ladder: ipratio 1.4 ~ -3 (x264 CQP convention)
 
     # toolsets (config.c:1460-1498 preset deltas restricted to what the pipeline implements)
-    tools = {"medium": dict(refs=args.refs, subme=7, deblock=1, partitions=7, dct8x8=1, me_method=1, chroma_me=1),
-             "ultrafast": dict(refs=1, subme=0, deblock=0, partitions=0x100, dct8x8=0, me_method=0, chroma_me=0),
-             "slow": dict(refs=4, subme=9, deblock=1, partitions=7, dct8x8=1, me_method=2, chroma_me=1)}[args.preset]
+    tools = {"medium": dict(refs=args.refs, subme=7, deblock=1, partitions=7, dct8x8=1, me_method=1, chroma_me=1, mixed_refs=1),
+             "ultrafast": dict(refs=1, subme=0, deblock=0, partitions=0x100, dct8x8=0, me_method=0, chroma_me=0, mixed_refs=0),
+             "slow": dict(refs=4, subme=9, deblock=1, partitions=7, dct8x8=1, me_method=2, chroma_me=1, mixed_refs=1)}[args.preset]
     # ---- inputs resident in HBM: warmup frames + K timed frames per stream ----
     nfr = Wu + K
     data = [synth_batch(torch, per[g], nfr, W, H, shard.stream_seed(0x264, gids[sum(per[:g])]), dev) for g in range(G)]

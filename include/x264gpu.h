@@ -161,6 +161,8 @@ typedef struct x264gpu_config {
     int me_method;            /* --me: 0 dia (radius-1 diamond), 1 hex (hexagon + square refine), 2 umh (uneven multi-hexagon); X264_ME_DIA / _HEX / _UMH */
     int chroma_me;            /* --chroma-me (x264 default on): sub-pel SATD costs of P macroblocks include the chroma planes; acts when subme >= 5,
                                * as x264's h->mb.b_chroma_me ([x264-upstream] encoder/encoder.c, me.c COST_MV_SATD) */
+    int mixed_refs;           /* --mixed-refs (x264 default on): 8x8 blocks, and the 16x8 / 8x16 halves built on them, choose their reference
+                               * on their own ([x264-upstream] analyse.c x264_mb_analyse_inter_p8x8_mixed_ref); needs partitions bit0 and refs > 1 */
 } x264gpu_config;
 
 int  x264gpu_encoder_create(x264gpu_encoder **enc, const x264gpu_config *cfg);

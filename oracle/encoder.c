@@ -574,16 +574,66 @@ static void analyse_p_mb(x264o_encoder *e, int mbx, int mby, x264gpu_mb *mb)
 {
     int qp = e->cfg.qp_p, lambda = x264o_lambda(qp), mi = mby * e->mbw + mbx, mvp[2];
     /* 16x16 search in every usable reference (most recent first); lower index wins ties */
-    me_result m = { 0, 0, 1 << 28 };
+    me_result m = { 0, 0, 1 << 28 }, m16[4];
     int bref = 0;
     int halfpel_thresh = 1 << 28;          /* INT_MAX-like: shared by the references of this macroblock, only with more than one */
     for (int r = 0; r < e->nref; r++) {
         me_result t = me_search_16x16(e, mbx, mby, qp, r, mvp, e->nref > 1 ? &halfpel_thresh : NULL);
+        m16[r] = t;
         t.cost += lambda * ref_bits(e->nref, r);
         if (t.cost < m.cost) { m = t; bref = r; }
     }
     int best_cost = m.cost, best_shape = 0;
     int best_mv[4][2] = { { m.mvx, m.mvy }, { m.mvx, m.mvy }, { m.mvx, m.mvy }, { m.mvx, m.mvy } };
+    int best_ref[4] = { bref, bref, bref, bref };
+    if ((e->cfg.partitions & 1) && e->cfg.mixed_refs && e->nref > 1) {
+        /* --mixed-refs ([x264-upstream] analyse.c x264_mb_analyse_inter_p8x8_mixed_ref, _p16x8, _p8x16): every 8x8 block is
+         * searched in every reference, starting from that reference's 16x16 vector, and keeps the cheapest (cost + ref bits,
+         * lower index wins ties); 16x8 / 8x16 halves then try the references their two 8x8 blocks chose.  x264's early-out on
+         * the neighbours' references needs raster-order neighbours and is not used. */
+        int ref8[4], mv8[4][2], cost8[4], cost = lambda * part_extra_bits[3];
+        /* x264's early termination ("if 16x16 chose ref 0, then evaluate no refs older than those used by the neighbors"), with
+         * the PREVIOUS picture's field standing in for the raster-order neighbours as everywhere in this pipeline: left, top,
+         * top-left, top-right and co-located macroblocks; needs a left and a top neighbour */
+        int maxref = e->nref - 1;
+        if (bref == 0 && mbx > 0 && mby > 0) {
+            const int8_t *pr = e->reff[0];
+            maxref = 0;
+            const int nbs[5] = { mi - 1, mi - e->mbw, mi - e->mbw - 1, mbx + 1 < e->mbw ? mi - e->mbw + 1 : mi, mi };
+            for (int i = 0; i < 5; i++) if (pr[nbs[i]] > maxref) maxref = pr[nbs[i]];
+            if (maxref > e->nref - 1) maxref = e->nref - 1;
+        }
+        for (int p = 0; p < 4; p++) {
+            const int8_t *g = part_geom[3][p];
+            cost8[p] = 1 << 28;
+            for (int r = 0; r <= maxref; r++) {
+                int c0[1][2] = { { (m16[r].mvx + 2) >> 2, (m16[r].mvy + 2) >> 2 } };
+                me_result t = me_search_block(e, mbx, mby, g[0], g[1], g[2], g[3], qp, r, mvp, (const int (*)[2])c0, 1, NULL);
+                t.cost += lambda * ref_bits(e->nref, r);
+                if (t.cost < cost8[p]) { cost8[p] = t.cost; ref8[p] = r; mv8[p][0] = t.mvx; mv8[p][1] = t.mvy; }
+            }
+            cost += cost8[p];
+        }
+        if (cost < best_cost) { best_cost = cost; best_shape = 3; memcpy(best_mv, mv8, sizeof(mv8)); memcpy(best_ref, ref8, sizeof(ref8)); }
+        for (int shape = 1; shape <= 2 && best_shape != 0; shape++) {
+            int mv[4][2], rf[4];
+            cost = lambda * part_extra_bits[shape];
+            for (int p = 0; p < 2; p++) {
+                const int8_t *g = part_geom[shape][p];
+                const int cand_ref[2] = { ref8[g[4]], ref8[g[5]] };
+                int bc = 1 << 28;
+                for (int i = 0; i < (cand_ref[0] == cand_ref[1] ? 1 : 2); i++) {
+                    const int r = cand_ref[i];
+                    int c0[1][2] = { { (m16[r].mvx + 2) >> 2, (m16[r].mvy + 2) >> 2 } };
+                    me_result t = me_search_block(e, mbx, mby, g[0], g[1], g[2], g[3], qp, r, mvp, (const int (*)[2])c0, 1, NULL);
+                    t.cost += lambda * ref_bits(e->nref, r);
+                    if (t.cost < bc) { bc = t.cost; mv[g[4]][0] = mv[g[5]][0] = t.mvx; mv[g[4]][1] = mv[g[5]][1] = t.mvy; rf[g[4]] = rf[g[5]] = r; }
+                }
+                cost += bc;
+            }
+            if (cost < best_cost) { best_cost = cost; best_shape = shape; memcpy(best_mv, mv, sizeof(mv)); memcpy(best_ref, rf, sizeof(rf)); }
+        }
+    } else
     if (e->cfg.partitions & 1) {
         /* sub-partition searches start from the 16x16 vector, in the 16x16 winner's reference (no mixed refs);
          * 16x8 / 8x16 only when 8x8 beats 16x16 */
@@ -617,21 +667,24 @@ static void analyse_p_mb(x264o_encoder *e, int mbx, int mby, x264gpu_mb *mb)
         mb->type = best_shape == 3 ? X264GPU_MB_P_8x8 : X264GPU_MB_P_L0;
         mb->partition = (uint8_t)best_shape;
         mb->cost = best_cost;
-        for (int k = 0; k < 4; k++) { mb->mv[k][0] = (int16_t)best_mv[k][0]; mb->mv[k][1] = (int16_t)best_mv[k][1]; mb->ref[k] = (int8_t)bref; }
-        e->reff[1][mi] = 0; e->mvf[1][mi][0] = (int16_t)m.mvx; e->mvf[1][mi][1] = (int16_t)m.mvy;
+        for (int k = 0; k < 4; k++) { mb->mv[k][0] = (int16_t)best_mv[k][0]; mb->mv[k][1] = (int16_t)best_mv[k][1]; mb->ref[k] = (int8_t)best_ref[k]; }
+        /* the ref field keeps the oldest reference the macroblock uses (>= 0: inter); the vector field the 16x16 vector */
+        int oldest = best_ref[0];
+        for (int k = 1; k < 4; k++) if (best_ref[k] > oldest) oldest = best_ref[k];
+        e->reff[1][mi] = (int8_t)oldest; e->mvf[1][mi][0] = (int16_t)m.mvx; e->mvf[1][mi][1] = (int16_t)m.mvy;
     }
 }
 
 /* ---- stage 2: inter macroblock encode (x264_macroblock_encode, P_L0 16x16) ---- */
 static void encode_inter_mb(x264o_encoder *e, int mbx, int mby, x264gpu_mb *mb, int16_t *lv)
 {
-    int ref = ref_slot(e, mb->ref[0]), qp = mb->qp, qpc = x264o_chroma_qp[clampi(qp + e->cfg.chroma_qp_offset, 0, 51)];
-    pixel *planes[4] = { luma_plane(e, ref, 0), luma_plane(e, ref, 1), luma_plane(e, ref, 2), luma_plane(e, ref, 3) };
+    int qp = mb->qp, qpc = x264o_chroma_qp[clampi(qp + e->cfg.chroma_qp_offset, 0, 51)];
     pixel *rec = luma_plane(e, e->cur, 0) + (size_t)mby * 16 * e->rs + mbx * 16;
     pixel *rec_uv = chroma_plane(e, e->cur) + (size_t)mby * 8 * e->rs + mbx * 16;
     pixel pu[64], pv[64];
     for (int k = 0; k < 4; k++) {      /* motion compensation per 8x8 quadrant (covers 16x16 / 16x8 / 8x16 / 8x8) */
-        int ox = (k & 1) * 8, oy = (k >> 1) * 8;
+        int ox = (k & 1) * 8, oy = (k >> 1) * 8, ref = ref_slot(e, mb->ref[k]);       /* the reference is per 8x8 block (mixed refs) */
+        pixel *planes[4] = { luma_plane(e, ref, 0), luma_plane(e, ref, 1), luma_plane(e, ref, 2), luma_plane(e, ref, 3) };
         x264o_mc_luma(rec + oy * e->rs + ox, e->rs, planes, e->rs, mbx * 16 + ox, mby * 16 + oy, mb->mv[k][0], mb->mv[k][1], 8, 8);
         x264o_mc_chroma(pu + (oy / 2) * 8 + ox / 2, pv + (oy / 2) * 8 + ox / 2, 8, chroma_plane(e, ref), e->rs, mbx * 8 + ox / 2, mby * 8 + oy / 2,
                         mb->mv[k][0], mb->mv[k][1], 4, 4);

@@ -63,6 +63,11 @@ def compare(tag, mbw, g_mb, o_mb, g_lv, o_lv, g_rec, o_rec):
     (208, 120, 4, dict(chroma_me=1, partitions=3, subme=5, refs=2, qp_i=18, qp_p=20)),
     (176, 144, 4, dict(chroma_me=1, partitions=3, subme=9, me_method=0)),
     (64, 48, 3, dict(chroma_me=1, subme=4, partitions=3)),                   # below subme 5 the flag is inert
+    (176, 144, 6, dict(mixed_refs=1, refs=3, partitions=3)),                 # mixed refs: per-8x8 / per-half references
+    (352, 288, 6, dict(mixed_refs=1, refs=3, partitions=7, dct8x8=1, chroma_me=1, qp_i=28, qp_p=31)),   # x264 medium's ME toolset
+    (208, 120, 7, dict(mixed_refs=1, refs=4, partitions=1, subme=5, me_method=0)),
+    (352, 288, 5, dict(mixed_refs=1, refs=2, partitions=3, me_method=2, chroma_me=1)),
+    (64, 48, 4, dict(mixed_refs=1, refs=1, partitions=3)),                   # one reference: the flag is inert
     (176, 144, 4, dict(me_method=2)),                                        # --me umh, 16x16 only
     (352, 288, 4, dict(me_method=2, partitions=3, refs=2, chroma_me=1)),     # umh in every partition
     (352, 288, 3, dict(me_method=2, partitions=7, dct8x8=1, refs=4, subme=9, chroma_me=1, qp_i=26, qp_p=29)),   # preset slow-like (BASELINE config 4 toolset)

@@ -39,6 +39,7 @@ struct EncK {
     int dct8x8;
     int me_method;            // 0 dia, 1 hex, 2 umh
     int chroma_me;            // sub-pel SATD costs carry chroma (subme >= 5)
+    int mixed_refs;           // 8x8 blocks / 16x8, 8x16 halves pick their own reference
     unsigned long long *dbg;  // optional diagnostics (NULL in production): per (stream, wave) cycle counters
     int *wf_progress;         // [streams][2][WFG_ROWS]: row counters of the wavefront kernels when ONE stream spans several workgroups
 };

@@ -91,7 +91,7 @@ int x264gpu_encoder_create(x264gpu_encoder **out, const x264gpu_config *cfg)
     k.luma_bytes = 4 * k.plane_bytes;
     k.cplane_bytes = (size_t)k.rs * (k.ch / 2 + 2 * CPAD);
     k.me_range = cfg->me_range; k.subme = cfg->subme; k.dct_decimate = cfg->dct_decimate;
-    k.partitions = cfg->partitions; k.chroma_qp_offset = cfg->chroma_qp_offset; k.dct8x8 = cfg->dct8x8; k.me_method = cfg->me_method; k.chroma_me = cfg->chroma_me != 0;
+    k.partitions = cfg->partitions; k.chroma_qp_offset = cfg->chroma_qp_offset; k.dct8x8 = cfg->dct8x8; k.me_method = cfg->me_method; k.chroma_me = cfg->chroma_me != 0; k.mixed_refs = cfg->mixed_refs != 0;
     k.alpha_off = cfg->deblock_alpha * 2; k.beta_off = cfg->deblock_beta * 2;
     const size_t S = (size_t)cfg->streams;
     hipError_t er = hipSuccess;
@@ -225,12 +225,16 @@ int x264gpu_encode_frames(x264gpu_encoder *e, const uint8_t *d_i420, int slice_t
     if (slice_type == X264GPU_SLICE_P) {
         // sub-pel neighbourhood margin: 2 px reaches every step of subme <= 7, subme >= 8 needs 5 px
         const int me_blocks = (((k.nmb + 3) / 4 + 7) / 8) * 8;      // multiple of 8: XCD-contiguous mapping in the kernel
-        // sub-pel neighbourhood margin 2 (subme <= 7) or 5; UMH is its own instantiation so that the hexagon kernels keep their registers
-        if (k.me_method == 2) {
-            if (k.subme >= 8) hipLaunchKernelGGL((k_analyse_p<5, true>), dim3(me_blocks, S), dim3(256), 0, st, k);
-            else hipLaunchKernelGGL((k_analyse_p<2, true>), dim3(me_blocks, S), dim3(256), 0, st, k);
-        } else if (k.subme >= 8) hipLaunchKernelGGL((k_analyse_p<5, false>), dim3(me_blocks, S), dim3(256), 0, st, k);
-        else hipLaunchKernelGGL((k_analyse_p<2, false>), dim3(me_blocks, S), dim3(256), 0, st, k);
+        // sub-pel neighbourhood margin 2 (subme <= 7) or 5; UMH and mixed refs are their own instantiations so that the plain
+        // hexagon kernel keeps its registers
+        const bool big = k.subme >= 8, umh = k.me_method == 2, mixed = k.mixed_refs && (k.partitions & 1) && e->cfg.refs > 1;
+        const dim3 grid(me_blocks, S), blk(256);
+#define X264GPU_LAUNCH_ANALYSE(M, U, X) hipLaunchKernelGGL((k_analyse_p<M, U, X>), grid, blk, 0, st, k)
+        if (big) { if (umh) { if (mixed) X264GPU_LAUNCH_ANALYSE(5, true, true); else X264GPU_LAUNCH_ANALYSE(5, true, false); }
+                   else { if (mixed) X264GPU_LAUNCH_ANALYSE(5, false, true); else X264GPU_LAUNCH_ANALYSE(5, false, false); } }
+        else { if (umh) { if (mixed) X264GPU_LAUNCH_ANALYSE(2, true, true); else X264GPU_LAUNCH_ANALYSE(2, true, false); }
+               else { if (mixed) X264GPU_LAUNCH_ANALYSE(2, false, true); else X264GPU_LAUNCH_ANALYSE(2, false, false); } }
+#undef X264GPU_LAUNCH_ANALYSE
         STAGE_MARK(2);
         hipLaunchKernelGGL(k_encode_inter, dim3((k.nmb + 3) / 4, S), dim3(256), 0, st, k);
         mask |= 2 | 4;

@@ -578,7 +578,7 @@ __device__ int search_parts(const PartCtx &c, const int SHAPE, int c0x, int c0y,
     return bcost;
 }
 
-template <int M, bool UMH>
+template <int M, bool UMH, bool MIXED>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(X264GPU_ANALYSE_WAVES, 8))) void k_analyse_p(EncK k)
 {
     __shared__ __attribute__((aligned(16))) uint8_t s_win[4][WIN_ROWS * WIN_STRIDE];
@@ -636,6 +636,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(X264GPU_ANA
     // ---- 16x16 search in every usable reference (oracle analyse_p_mb); lower index wins ties ----
     const size_t pb = k.plane_bytes;
     int best_mx = 0, best_my = 0, best16 = 1 << 28, bref = 0, halfpel_thresh = 1 << 28;
+    int m16_0 = 0, m16_1 = 0, m16_2 = 0, m16_3 = 0;       // 16x16 vector found in each reference, packed (x | y << 16): start of the mixed-refs partition searches
     for (int r_ = 0; r_ < k.nref; r_++) {
         const uint8_t *p00 = ref_plane00(k, s, r_);
         // ---- start candidates: predictor, zero, co-located (lane groups 0..2 evaluate one each) ----
@@ -811,6 +812,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(X264GPU_ANA
         }
 
     #undef MVC
+        if (MIXED) { const int pk = (mx & 0xffff) | (my << 16); if (r_ == 0) m16_0 = pk; else if (r_ == 1) m16_1 = pk; else if (r_ == 2) m16_2 = pk; else m16_3 = pk; }
         bcost += k.lambda * ref_bits(k.nref, r_);
         if (bcost < best16) { best16 = bcost; best_mx = mx; best_my = my; bref = r_; }
         __builtin_amdgcn_wave_barrier();
@@ -819,10 +821,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(X264GPU_ANA
     int mx = best_mx, my = best_my, bcost = best16;
 
     // ---- sub-partitions (oracle analyse_p_mb): 8x8 first, 16x8 / 8x16 only if 8x8 beat 16x16 ----
+    // Without mixed refs every partition is searched in the 16x16 winner's reference.  With them (x264 --mixed-refs) each 8x8 block
+    // is searched in every reference from that reference's 16x16 vector and keeps the cheapest (cost + ref bits); the 16x8 / 8x16
+    // halves then try the references of their two 8x8 blocks, the first block's reference winning ties.  One search_parts call
+    // site serves all of it: the loop below walks (shape, reference) jobs.
     const int cost16 = bcost;
     int best_cost = bcost, best_shape = 0;
-    int lmx = mx, lmy = my;                         // this lane's 8x8 block's motion vector (lane>>4 = 8x8 index)
-    if (k.partitions & 1) {
+    int lmx = mx, lmy = my, lref = bref;            // this lane's 8x8 block's motion vector / reference (lane>>4 = 8x8 index)
+    if (!MIXED && (k.partitions & 1)) {
+        // plain path: every partition in the 16x16 winner's reference, one staging of the window
         const int c0x = clampi((mx + 2) >> 2, fmin0, fmax0), c0y = clampi((my + 2) >> 2, fmin1, fmax1);
         int pwx0 = clampi((px + c0x - WIN_R) & ~7, -PAD, k.cw + PAD - WIN_COLS), pwy0 = clampi(py + c0y - WIN_R, -PAD, k.ch + PAD - WIN_ROWS);
         __builtin_amdgcn_wave_barrier();
@@ -859,6 +866,83 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(X264GPU_ANA
             else if (shape == 1) total += __builtin_amdgcn_readlane(pcost, 0) + __builtin_amdgcn_readlane(pcost, 32);
             else total += __builtin_amdgcn_readlane(pcost, 0) + __builtin_amdgcn_readlane(pcost, 32);      // 8x16: partitions on lanes 0.. and 32..
             if (total < best_cost) { best_cost = total; best_shape = shape; lmx = smx; lmy = smy; }
+        }
+    }
+    if (MIXED && (k.partitions & 1)) {
+        const bool mixed = MIXED && k.nref > 1;         // MIXED is its own kernel instantiation: the plain one keeps its registers
+        PartCtx pc;
+        pc.win = win; pc.cx = s_cost[wave][0]; pc.cy = s_cost[wave][1];
+        pc.pb = k.plane_bytes; pc.rs = k.rs; pc.px = px; pc.py = py; pc.zx = zx; pc.zy = zy; pc.cz = cz;
+        pc.fmin0 = fmin0; pc.fmax0 = fmax0; pc.fmin1 = fmin1; pc.fmax1 = fmax1; pc.smin0 = smin0; pc.smax0 = smax0; pc.smin1 = smin1; pc.smax1 = smax1;
+        pc.me_range = k.me_range; pc.me_method = k.me_method; pc.lane = lane; pc.sub = s_sub[wave]; pc.fenc = fenc; pc.fs = k.fs;
+        pc.chroma_me = chroma_me; pc.fuv = fuv;
+        pc.gcx = cmx; pc.gcy = cmy; pc.mvp0 = mvp0; pc.mvp1 = mvp1; pc.la_mode = false;
+        const int sub = min(k.subme, 11);
+        pc.hp_it = sub < 2 ? 0 : sub < 6 ? 1 : sub < 8 ? 2 : 4;
+        pc.qp_it = sub < 4 ? 0 : sub == 4 ? 1 : sub < 8 ? 2 : 10;
+        int ref8 = bref;                            // reference chosen by this lane's 8x8 block (shape 3 pass)
+        // x264's early termination of the mixed-refs 8x8 pass (oracle analyse_p_mb): when 16x16 chose reference 0, no reference
+        // older than those of the previous picture's left / top / top-left / top-right / co-located macroblocks is tried
+        int maxref = k.nref - 1;
+        if (mixed && bref == 0 && mbx > 0 && mby > 0) {
+            int m0 = max((int)rf[mbi - 1], (int)rf[mbi - k.mbw]);
+            m0 = max(m0, max((int)rf[mbi - k.mbw - 1], (int)rf[mbx + 1 < k.mbw ? mbi - k.mbw + 1 : mbi]));
+            maxref = min(max(max(m0, (int)rf[mbi]), 0), k.nref - 1);
+        }
+        for (int ph = 0; ph < 3; ph++) {
+            const int shape = ph == 0 ? 3 : ph;
+            if (ph > 0 && best_shape == 0) break;
+            // candidate references of this lane's partition (mixed, 16x8 / 8x16): those of its two 8x8 blocks
+            int first_ref = bref, second_ref = bref;
+            if (mixed && ph > 0) {
+                const int p32 = lane >> 5;
+                first_ref = __shfl(ref8, shape == 1 ? p32 * 32 : p32 * 16);
+                second_ref = __shfl(ref8, shape == 1 ? p32 * 32 + 16 : p32 * 16 + 32);
+            }
+            unsigned pkey = 0xffffffffu;            // this lane's partition: best (cost << 1 | not-the-first-block's-reference)
+            int pmx = 0, pmy = 0, pref = 0;
+            for (int r = 0; r < k.nref; r++) {
+                const bool need = !mixed ? r == bref : ph == 0 ? r <= maxref : (r == first_ref || r == second_ref);
+                if (!__any(need)) continue;
+                // ---- stage the search window and the mv-cost slices around reference r's 16x16 vector ----
+                const int pk = mixed ? (r == 0 ? m16_0 : r == 1 ? m16_1 : r == 2 ? m16_2 : m16_3) : ((mx & 0xffff) | (my << 16));
+                const int qx = (int)(short)(pk & 0xffff), qy = pk >> 16;
+                const int c0x = clampi((qx + 2) >> 2, fmin0, fmax0), c0y = clampi((qy + 2) >> 2, fmin1, fmax1);
+                const uint8_t *pr = ref_plane00(k, s, r);
+                const int pwx0 = clampi((px + c0x - WIN_R) & ~7, -PAD, k.cw + PAD - WIN_COLS), pwy0 = clampi(py + c0y - WIN_R, -PAD, k.ch + PAD - WIN_ROWS);
+                __builtin_amdgcn_wave_barrier();
+                if (!UMH)
+                for (int i = lane; i < WIN_ROWS * 8; i += 64) {
+                    const int row = i >> 3, col = (i & 7) * 8;
+                    const uint2 v = *(const uint2 *)(pr + (long)(pwy0 + row) * k.rs + pwx0 + col);
+                    uint32_t *d = (uint32_t *)(win + row * WIN_STRIDE + col);
+                    d[0] = v.x; d[1] = v.y;
+                }
+                for (int i = lane; i < 192; i += 64) {
+                    s_cost[wave][0][i] = cmx[c0x * 4 + i - 96];
+                    s_cost[wave][1][i] = cmy[c0y * 4 + i - 96];
+                }
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_s_waitcnt(0xc07f);
+                pc.wx0 = pwx0; pc.wy0 = pwy0; pc.cbx = c0x * 4; pc.cby = c0y * 4; pc.p00 = pr; pc.cref = ref_chroma00(k, s, r);
+                int smx, smy;
+                const int pcost = search_parts<M, UMH>(pc, shape, c0x, c0y, smx, smy);
+                if (shape == 2) { smx = __shfl(smx, (lane >> 5) * 16); smy = __shfl(smy, (lane >> 5) * 16); }      // back to partition lanes
+                const unsigned key = ((unsigned)(pcost + (mixed ? k.lambda * ref_bits(k.nref, r) : 0)) << 1) | (mixed && ph > 0 && r != first_ref ? 1u : 0u);
+                if (need && key < pkey) { pkey = key; pmx = smx; pmy = smy; pref = r; }
+            }
+            const int pcst = (int)(pkey >> 1);
+            int total = k.lambda * ((shape == 3 ? 8 : 2) + (mixed ? 0 : (shape == 3 ? 4 : 2) * ref_bits(k.nref, bref)));
+            if (shape == 3) total += __builtin_amdgcn_readlane(pcst, 0) + __builtin_amdgcn_readlane(pcst, 16) + __builtin_amdgcn_readlane(pcst, 32) + __builtin_amdgcn_readlane(pcst, 48);
+            else total += __builtin_amdgcn_readlane(pcst, 0) + __builtin_amdgcn_readlane(pcst, 32);                  // two partitions, on lanes 0.. and 32..
+            if (ph == 0) ref8 = pref;
+            if (total < best_cost) {
+                best_cost = total; best_shape = shape;
+                if (shape == 2) {       // 8x16: partition k owns lanes 32k.., the record is indexed by 8x8 block (lane >> 4): blocks 1, 3 are partition 1
+                    const int src = ((lane >> 4) & 1) * 32;
+                    lmx = __shfl(pmx, src); lmy = __shfl(pmy, src); lref = __shfl(pref, src);
+                } else { lmx = pmx; lmy = pmy; lref = pref; }
+            }
         }
     }
     bcost = best_cost;
@@ -922,6 +1006,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(X264GPU_ANA
     const int m1x = __builtin_amdgcn_readlane(lmx, 16), m1y = __builtin_amdgcn_readlane(lmy, 16);
     const int m2x = __builtin_amdgcn_readlane(lmx, 32), m2y = __builtin_amdgcn_readlane(lmy, 32);
     const int m3x = __builtin_amdgcn_readlane(lmx, 48), m3y = __builtin_amdgcn_readlane(lmy, 48);
+    const int r0b = __builtin_amdgcn_readlane(lref, 0), r1b = __builtin_amdgcn_readlane(lref, 16), r2b = __builtin_amdgcn_readlane(lref, 32), r3b = __builtin_amdgcn_readlane(lref, 48);
     if (lane == 0) {
         x264gpu_mb *mb = k.mb + (size_t)s * k.nmb + mbi;
         x264gpu_mb rec;
@@ -940,8 +1025,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(X264GPU_ANA
             rec.cost = bcost;
             rec.mv[0][0] = (int16_t)m0x; rec.mv[0][1] = (int16_t)m0y; rec.mv[1][0] = (int16_t)m1x; rec.mv[1][1] = (int16_t)m1y;
             rec.mv[2][0] = (int16_t)m2x; rec.mv[2][1] = (int16_t)m2y; rec.mv[3][0] = (int16_t)m3x; rec.mv[3][1] = (int16_t)m3y;
-            for (int i = 0; i < 4; i++) rec.ref[i] = (int8_t)bref;
-            k.reff_cur[(size_t)s * k.nmb + mbi] = (int8_t)bref; mo[0] = (int16_t)mx; mo[1] = (int16_t)my;     // field carries the 16x16 vector
+            rec.ref[0] = (int8_t)r0b; rec.ref[1] = (int8_t)r1b; rec.ref[2] = (int8_t)r2b; rec.ref[3] = (int8_t)r3b;
+            k.reff_cur[(size_t)s * k.nmb + mbi] = (int8_t)max(max(r0b, r1b), max(r2b, r3b)); mo[0] = (int16_t)mx; mo[1] = (int16_t)my;     // fields: oldest reference used, 16x16 vector
         }
         *mb = rec;
     }

@@ -48,7 +48,7 @@ __global__ __launch_bounds__(256) void k_encode_inter(EncK k)
     const int j = lane & 3, blk = lane >> 2, zx = z_x0(lane), zy = z_y(lane);
 
     // ---- luma ----
-    const int refidx = mbp->ref[0];                 // one reference per macroblock (no mixed refs)
+    const int refidx = mbp->ref[lane >> 4];         // the reference is per 8x8 block (mixed refs)
     const uint32_t pred = mc_luma_row4(ref_plane00(k, s, refidx), k.plane_bytes, k.rs, px + zx, py + zy, mvx, mvy);
     const uint32_t enc = *(const uint32_t *)(fenc + (size_t)zy * k.fs + zx);
     unsigned nnz = 0;
@@ -153,7 +153,7 @@ __global__ __launch_bounds__(256) void k_encode_inter(EncK k)
     // ---- chroma (lanes 0..31: plane = lane>>4, block = (lane>>2)&3) ----
     const int c = (lane >> 4) & 1, ci = (lane >> 2) & 3, cx0 = (ci & 1) * 4, cyy = (ci >> 1) * 4 + j;
     uint32_t pu, pv;
-    mc_chroma_row4(ref_chroma00(k, s, refidx), k.rs, mbx * 8 + cx0, mby * 8 + cyy, mbp->mv[ci][0], mbp->mv[ci][1], pu, pv);   // chroma 4x4 block ci <-> luma 8x8 ci
+    mc_chroma_row4(ref_chroma00(k, s, mbp->ref[ci]), k.rs, mbx * 8 + cx0, mby * 8 + cyy, mbp->mv[ci][0], mbp->mv[ci][1], pu, pv);   // chroma 4x4 block ci <-> luma 8x8 ci
     const uint8_t *fuv = k.fenc_uv + (size_t)s * k.fencuv_bytes + (size_t)(mby * 8 + cyy) * k.fs + px + 2 * cx0;
     const uint2 fe = *(const uint2 *)fuv;
     const uint32_t cenc = nv12_pick(fe.x, fe.y, c), cpred = c ? pv : pu;

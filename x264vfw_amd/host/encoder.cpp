@@ -165,7 +165,7 @@ x264_t *x264_encoder_open(x264_param_t *param)
     if (p.i_bframe) { xlog(&p, X264_LOG_WARNING, "B-frames are not implemented in the MI355X path yet: bframes 0\n"); p.i_bframe = 0; }
     if (p.i_frame_reference > 4) { xlog(&p, X264_LOG_INFO, "ref %d -> 4 (DPB of the MI355X path holds up to 4 references)\n", p.i_frame_reference); p.i_frame_reference = 4; }
     if (p.i_frame_reference < 1) p.i_frame_reference = 1;
-    p.analyse.b_mixed_references = 0;
+    p.analyse.b_mixed_references = p.analyse.b_mixed_references && p.i_frame_reference > 1;      // x264 validate_parameters
     if (p.b_cabac) { xlog(&p, X264_LOG_WARNING, "CABAC is not implemented yet: using CAVLC\n"); p.b_cabac = 0; }
     p.analyse.i_weighted_pred = X264_WEIGHTP_NONE; p.analyse.b_weighted_bipred = 0;
     p.analyse.b_transform_8x8 = p.analyse.b_transform_8x8 != 0;
@@ -225,6 +225,7 @@ x264_t *x264_encoder_open(x264_param_t *param)
                      0x100 | ((p.analyse.intra & X264_ANALYSE_I4x4) ? 0x200 : 0) | ((p.analyse.intra & X264_ANALYSE_I8x8) ? 0x400 : 0);
     cfg.dct8x8 = p.analyse.b_transform_8x8;
     cfg.me_method = p.analyse.i_me_method == X264_ME_DIA ? 0 : p.analyse.i_me_method == X264_ME_HEX ? 1 : 2;
+    cfg.mixed_refs = p.analyse.b_mixed_references && (p.analyse.inter & X264_ANALYSE_PSUB16x16) != 0;
     cfg.chroma_me = p.analyse.b_chroma_me && p.analyse.i_subpel_refine >= 5;     // x264: h->mb.b_chroma_me in P slices
     size_t insz = (size_t)p.i_width * p.i_height * 3 / 2;
     if (x264gpu_encoder_create(&h->gpu, &cfg) != X264GPU_OK ||
