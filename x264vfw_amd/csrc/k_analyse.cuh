@@ -17,6 +17,9 @@ namespace x264gpu {
 #ifndef X264GPU_ANALYSE_WAVES
 #define X264GPU_ANALYSE_WAVES 4
 #endif
+#ifndef X264GPU_ANALYSE_WAVES_MIXED
+#define X264GPU_ANALYSE_WAVES_MIXED 3      // the mixed-refs instantiation carries more per-lane state: 3 waves/SIMD (170 VGPRs) beats spilling at 4
+#endif
 
 constexpr int WIN_ROWS = 50, WIN_COLS = 64, WIN_STRIDE = 68, WIN_R = 17;
 
@@ -579,7 +582,7 @@ __device__ int search_parts(const PartCtx &c, const int SHAPE, int c0x, int c0y,
 }
 
 template <int M, bool UMH, bool MIXED>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(X264GPU_ANALYSE_WAVES, 8))) void k_analyse_p(EncK k)
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MIXED ? X264GPU_ANALYSE_WAVES_MIXED : X264GPU_ANALYSE_WAVES, 8))) void k_analyse_p(EncK k)
 {
     __shared__ __attribute__((aligned(16))) uint8_t s_win[4][WIN_ROWS * WIN_STRIDE];
     __shared__ uint8_t s_nb[4][NB_SIZE];
