@@ -265,7 +265,10 @@ int x264gpu_encode_frames(x264gpu_encoder *e, const uint8_t *d_i420, int slice_t
         static const bool deblock_v1 = getenv("X264GPU_DEBLOCK_V1") != nullptr;      // one macroblock per wave (A/B runs)
         if (deblock_v1) hipLaunchKernelGGL(k_deblock, dim3(S), dim3(DB_WAVES * 64), 0, st, k);
         else if (mwg) hipLaunchKernelGGL(k_deblock2<true>, dim3(S, dwg), dim3(256), 0, st, k);
-        else hipLaunchKernelGGL(k_deblock2<false>, dim3(S), dim3(1024), 0, st, k);
+        else {
+            static const int db_waves = getenv("X264GPU_DEBLOCK_WAVES") ? atoi(getenv("X264GPU_DEBLOCK_WAVES")) : 16;     // A/B knob: 4, 8 or 16
+            hipLaunchKernelGGL(k_deblock2<false>, dim3(S), dim3((db_waves == 4 || db_waves == 8 ? db_waves : 16) * 64), 0, st, k);
+        }
         mask |= 16;
     }
     STAGE_MARK(5);
