@@ -161,15 +161,13 @@ __device__ __forceinline__ int sub_sad_row16_hpel(const uint32_t *buf, int n, in
 // (cx, cy): chroma-sample position of the lane's four pixels; e0/e1: their 8 source bytes U0 V0 U1 V1 | U2 V2 U3 V3.
 // ------------------------------------------------------------------------------------------------
 typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ int chroma_me_half(const uint8_t *__restrict__ nv12, int rs, int cx, int cy, int mvx, int mvy, uint32_t e0, uint32_t e1,
-                                              s16x2 sg1, s16x2 sg2)
+struct ChromaTaps { uint32_t a0, a1, a2, b0, b1, b2; };         // the six NV12 dwords one lane needs for one candidate
+__device__ __forceinline__ int chroma_me_cost(const ChromaTaps &t, int mvx, int mvy, uint32_t e0, uint32_t e1, s16x2 sg1, s16x2 sg2)
 {
     const int dx = mvx & 7, dy = mvy & 7;
     const uint32_t wA = (uint32_t)((8 - dx) * (8 - dy)) * 0x10001u, wB = (uint32_t)(dx * (8 - dy)) * 0x10001u;
     const uint32_t wC = (uint32_t)((8 - dx) * dy) * 0x10001u, wD = (uint32_t)(dx * dy) * 0x10001u;
-    const uint8_t *s = nv12 + (long)(cy + (mvy >> 3)) * rs + 2 * (cx + (mvx >> 3));
-    const uint32_t a0 = load_u32_unaligned(s), a1 = load_u32_unaligned(s + 4), a2 = load_u32_unaligned(s + 8);
-    const uint32_t b0 = load_u32_unaligned(s + rs), b1 = load_u32_unaligned(s + rs + 4), b2 = load_u32_unaligned(s + rs + 8);
+    const uint32_t a0 = t.a0, a1 = t.a1, a2 = t.a2, b0 = t.b0, b1 = t.b1, b2 = t.b2;
     const uint32_t a01 = __builtin_amdgcn_alignbyte(a1, a0, 2), a12 = __builtin_amdgcn_alignbyte(a2, a1, 2);     // one sample to the right
     const uint32_t b01 = __builtin_amdgcn_alignbyte(b1, b0, 2), b12 = __builtin_amdgcn_alignbyte(b2, b1, 2);
     int acc = 0;
@@ -186,6 +184,49 @@ __device__ __forceinline__ int chroma_me_half(const uint8_t *__restrict__ nv12, 
         acc += satd4_half_diff(da, db, sg1, sg2);
     }
     return acc;
+}
+__device__ __forceinline__ int chroma_me_half(const uint8_t *__restrict__ nv12, int rs, int cx, int cy, int mvx, int mvy, uint32_t e0, uint32_t e1,
+                                              s16x2 sg1, s16x2 sg2)
+{
+    const uint8_t *s = nv12 + (long)(cy + (mvy >> 3)) * rs + 2 * (cx + (mvx >> 3));
+    ChromaTaps t;
+    t.a0 = load_u32_unaligned(s); t.a1 = load_u32_unaligned(s + 4); t.a2 = load_u32_unaligned(s + 8);
+    t.b0 = load_u32_unaligned(s + rs); t.b1 = load_u32_unaligned(s + rs + 4); t.b2 = load_u32_unaligned(s + rs + 8);
+    return chroma_me_cost(t, mvx, mvy, e0, e1, sg1, sg2);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Chroma neighbourhood in LDS: like sub_stage for luma, the NV12 samples every sub-pel candidate of one block / partition can
+// touch are staged once after the full-pel search (one global-memory latency instead of one per candidate).  A candidate's
+// eighth-pel vector is 4 * full-pel winner + d with |d| <= 6 (M == 2) or 18 (M == 5) quarter-pels, so its integer chroma offset
+// lies in [(b >> 1) - MG, (b >> 1) + MG], MG = 1 or 3.  Rows hold ndw dwords (= 2 * ndw chroma samples of both planes),
+// starting at an even chroma sample x0c so that the global loads are aligned dwords.
+// ------------------------------------------------------------------------------------------------
+template <int M> struct CSubGeo {
+    static constexpr int MG = M == 2 ? 1 : 3;
+    static __device__ __forceinline__ int ndw(int wc) { return (wc + 2 * MG + 2 + 1) >> 1; }    // samples: wc + 2 MG + 1 tap + 1 alignment, two per dword
+    static __device__ __forceinline__ int rows(int hc) { return hc + 2 * MG + 1; }
+    static constexpr int DWORDS = M == 2 ? 128 : 288;              // four 8x8 partitions are the largest set: 4 x ndw(4) x rows(4), + slack
+};
+__device__ __forceinline__ void chroma_stage(uint32_t *cb, const uint8_t *__restrict__ nv12, int rs, int x0c, int y0c, int ndw, int nrows, int l, int L)
+{
+    for (int i = l; i < ndw * nrows; i += L) {
+        const int row = i / ndw, col = i - row * ndw;
+        cb[i] = *(const uint32_t *)(nv12 + (long)(y0c + row) * rs + 2 * x0c + 4 * col);
+    }
+}
+// chroma_me_half on the staged neighbourhood: (cx, cy) chroma position of the lane's four pixels
+__device__ __forceinline__ int chroma_me_lds(const uint32_t *cb, int ndw, int x0c, int y0c, int cx, int cy, int mvx, int mvy, uint32_t e0, uint32_t e1,
+                                             s16x2 sg1, s16x2 sg2)
+{
+    const int o = ((cy + (mvy >> 3) - y0c) * ndw << 2) + 2 * (cx + (mvx >> 3) - x0c), sh = o & 3;
+    const uint32_t *w = cb + (o >> 2), *v = w + ndw;
+    ChromaTaps t;
+    { const uint32_t d0 = w[0], d1 = w[1], d2 = w[2], d3 = w[3];
+      t.a0 = __builtin_amdgcn_alignbyte(d1, d0, sh); t.a1 = __builtin_amdgcn_alignbyte(d2, d1, sh); t.a2 = __builtin_amdgcn_alignbyte(d3, d2, sh); }
+    { const uint32_t d0 = v[0], d1 = v[1], d2 = v[2], d3 = v[3];
+      t.b0 = __builtin_amdgcn_alignbyte(d1, d0, sh); t.b1 = __builtin_amdgcn_alignbyte(d2, d1, sh); t.b2 = __builtin_amdgcn_alignbyte(d3, d2, sh); }
+    return chroma_me_cost(t, mvx, mvy, e0, e1, sg1, sg2);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -204,6 +245,7 @@ struct PartCtx {
     uint32_t *sub;                             // LDS sub-pel neighbourhood buffer (SUB_DWORDS)
     const uint8_t *fenc; int fs;               // source macroblock (for the candidate-parallel 8x8 search)
     const uint8_t *cref, *fuv; int chroma_me;  // chroma-ME: NV12 reference plane (origin), source NV12 of this macroblock
+    uint32_t *csub;                            // chroma-ME: LDS chroma neighbourhood buffer (CSubGeo<M>::DWORDS)
     const uint16_t *gcx, *gcy; int mvp0, mvp1; // UMH: mv-cost table in global memory (index = qpel mv), cost predictor
     int col_x, col_y; bool has_col, la_mode;   // lookahead: co-located start candidate (quarter-pel); la_mode selects its search
 };
@@ -517,6 +559,11 @@ __device__ int search_parts(const PartCtx &c, const int SHAPE, int c0x, int c0y,
         uint32_t *sb = c.sub + part * 4 * sn;
         __builtin_amdgcn_wave_barrier();
         sub_stage<M>(sb, c.p00, c.pb, c.rs, sx0, sy0, rwl, rh, ncol, lane & (L - 1), L);
+        // chroma neighbourhood of this partition (chroma-ME)
+        const int cwc = PW >> 1, chc = PH >> 1, cndw = CSubGeo<M>::ndw(cwc), cnr = CSubGeo<M>::rows(chc);
+        const int cx0c = ((c.px >> 1) + (ox >> 1) + (bx >> 1) - CSubGeo<M>::MG) & ~1, cy0c = (c.py >> 1) + (oy >> 1) + (by >> 1) - CSubGeo<M>::MG;
+        uint32_t *cb = c.csub + part * (cndw * cnr);
+        if (c.chroma_me) chroma_stage(cb, c.cref, c.rs, cx0c, cy0c, cndw, cnr, lane & (L - 1), L);
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_s_waitcnt(0xc07f);
         const int X0 = c.px + ox, Y0 = c.py + y0, X1 = X0 + x1, Y1 = c.py + y1;
@@ -549,7 +596,7 @@ __device__ int search_parts(const PartCtx &c, const int SHAPE, int c0x, int c0y,
             sub_row8(sb, sn, rwl, sx0, sy0, X0, Y0, mx, my, p0);
             sub_row8(sb, sn, rwl, sx0, sy0, X1, Y1, mx, my, p1);
             bcost = satd_part(p0, p1) + pc_mvcost<UMH>(c, mx, my);
-            if (c.chroma_me) bcost += gsum(chroma_me_half(c.cref, c.rs, (c.px >> 1) + ccx, (c.py >> 1) + ccy, mx, my, ce0, ce1, sg1, sg2));
+            if (c.chroma_me) bcost += gsum(chroma_me_lds(cb, cndw, cx0c, cy0c, (c.px >> 1) + ccx, (c.py >> 1) + ccy, mx, my, ce0, ce1, sg1, sg2));
         }
         int bdir = -1;
         bool qp_run = true;
@@ -563,7 +610,7 @@ __device__ int search_parts(const PartCtx &c, const int SHAPE, int c0x, int c0y,
             int cst = satd_part(p0, p1) + pc_mvcost<UMH>(c, cx, cy);
             // a candidate whose luma cost is not below the best cost cannot win; chroma only when some partition still can improve
             if (c.chroma_me && __any(qp_run && cst < bcost && (cnd ^ 1) != bdir))
-                cst += gsum(chroma_me_half(c.cref, c.rs, (c.px >> 1) + ccx, (c.py >> 1) + ccy, cx, cy, ce0, ce1, sg1, sg2));
+                cst += gsum(chroma_me_lds(cb, cndw, cx0c, cy0c, (c.px >> 1) + ccx, (c.py >> 1) + ccy, cx, cy, ce0, ce1, sg1, sg2));
             unsigned kk = ((unsigned)cst << 2) | (unsigned)cnd;
             if ((cnd ^ 1) == bdir) kk = 0xffffffffu;
             kk = cmin(kk);
@@ -588,6 +635,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MIXED ? X26
     __shared__ uint8_t s_nb[4][NB_SIZE];
     __shared__ uint16_t s_cost[4][2][192];
     __shared__ uint32_t s_sub[4][SubGeo<M>::DWORDS];
+    __shared__ uint32_t s_csub[4][CSubGeo<M>::DWORDS];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     // Workgroups are dealt round-robin to the 8 XCDs (each with its own L2): give every XCD one contiguous
     // eighth of the picture so the overlapping search windows of neighbouring macroblocks share an L2.
@@ -763,6 +811,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MIXED ? X26
             uint32_t *sb = s_sub[wave];
             const int sx0 = (px + bmx - M) & ~3, sy0 = py + bmy - M, rwl = 3, sn = SubGeo<M>::rh(16) << 3;
             sub_stage<M>(sb, p00, pb, k.rs, sx0, sy0, rwl, SubGeo<M>::rh(16), SubGeo<M>::ncol(16), lane, 64);
+            uint32_t *cb = s_csub[wave];
+            const int cndw = CSubGeo<M>::ndw(8), cnr = CSubGeo<M>::rows(8);
+            const int cx0c = ((px >> 1) + (bmx >> 1) - CSubGeo<M>::MG) & ~1, cy0c = (py >> 1) + (bmy >> 1) - CSubGeo<M>::MG;
+            if (chroma_me) chroma_stage(cb, ref_chroma00(k, s, r_), k.rs, cx0c, cy0c, cndw, cnr, lane, 64);
             __builtin_amdgcn_wave_barrier();
             __builtin_amdgcn_s_waitcnt(0xc07f);
             // half-pel diamond, SAD, lane = (candidate, row): (0,-2) (0,2) (-2,0) (2,0)
@@ -780,8 +832,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MIXED ? X26
             // SATD at the best half-pel position
             {
                 bcost = wave_sum(satd4_half(cz, sub_row4(sb, sn, rwl, sx0, sy0, px + zx, py + zy, mx, my), lane)) + MVC(mx, my);
-                if (chroma_me) bcost += row16_sum(chroma_me_half(ref_chroma00(k, s, r_), k.rs, (px >> 1) + ccx, (py >> 1) + ccy, mx, my, ce0, ce1,
-                                                                 pk_sign(lane & 1), pk_sign(lane & 2)));
+                if (chroma_me) bcost += row16_sum(chroma_me_lds(cb, cndw, cx0c, cy0c, (px >> 1) + ccx, (py >> 1) + ccy, mx, my, ce0, ce1,
+                                                                pk_sign(lane & 1), pk_sign(lane & 2)));
             }
             // early termination when examining several references (x264 refine_subpel, p_halfpel_thresh): a reference whose
             // half-pel SATD cost exceeds 8/7 of the best so far skips its quarter-pel diamond
@@ -803,7 +855,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MIXED ? X26
                 sub_row16(sb, sn, rwl, sx0, sy0, px, py + r, cx, cy, pr);
                 int cst = row16_sum(satd16x4_half_pk(cr, pr, sg1, sg2)) + MVC(cx, cy);
                 if (chroma_me && __any(cst < bcost && (cnd ^ 1) != bdir))
-                    cst += row16_sum(chroma_me_half(ref_chroma00(k, s, r_), k.rs, (px >> 1) + ccx, (py >> 1) + ccy, cx, cy, ce0, ce1, sg1, sg2));
+                    cst += row16_sum(chroma_me_lds(cb, cndw, cx0c, cy0c, (px >> 1) + ccx, (py >> 1) + ccy, cx, cy, ce0, ce1, sg1, sg2));
                 unsigned key = ((unsigned)cst << 2) | (unsigned)cnd;
                 if ((cnd ^ 1) == bdir) key = 0xffffffffu;
                 key = wave_min_u32(key);
@@ -854,7 +906,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MIXED ? X26
         pc.p00 = p00; pc.pb = k.plane_bytes; pc.rs = k.rs; pc.px = px; pc.py = py; pc.zx = zx; pc.zy = zy; pc.cz = cz;
         pc.fmin0 = fmin0; pc.fmax0 = fmax0; pc.fmin1 = fmin1; pc.fmax1 = fmax1; pc.smin0 = smin0; pc.smax0 = smax0; pc.smin1 = smin1; pc.smax1 = smax1;
         pc.me_range = k.me_range; pc.me_method = k.me_method; pc.lane = lane; pc.sub = s_sub[wave]; pc.fenc = fenc; pc.fs = k.fs;
-        pc.chroma_me = chroma_me; pc.cref = ref_chroma00(k, s, bref); pc.fuv = fuv;
+        pc.chroma_me = chroma_me; pc.cref = ref_chroma00(k, s, bref); pc.fuv = fuv; pc.csub = s_csub[wave];
         pc.gcx = cmx; pc.gcy = cmy; pc.mvp0 = mvp0; pc.mvp1 = mvp1; pc.la_mode = false;
         const int sub = min(k.subme, 11);
         pc.hp_it = sub < 2 ? 0 : sub < 6 ? 1 : sub < 8 ? 2 : 4;
@@ -878,7 +930,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MIXED ? X26
         pc.pb = k.plane_bytes; pc.rs = k.rs; pc.px = px; pc.py = py; pc.zx = zx; pc.zy = zy; pc.cz = cz;
         pc.fmin0 = fmin0; pc.fmax0 = fmax0; pc.fmin1 = fmin1; pc.fmax1 = fmax1; pc.smin0 = smin0; pc.smax0 = smax0; pc.smin1 = smin1; pc.smax1 = smax1;
         pc.me_range = k.me_range; pc.me_method = k.me_method; pc.lane = lane; pc.sub = s_sub[wave]; pc.fenc = fenc; pc.fs = k.fs;
-        pc.chroma_me = chroma_me; pc.fuv = fuv;
+        pc.chroma_me = chroma_me; pc.fuv = fuv; pc.csub = s_csub[wave];
         pc.gcx = cmx; pc.gcy = cmy; pc.mvp0 = mvp0; pc.mvp1 = mvp1; pc.la_mode = false;
         const int sub = min(k.subme, 11);
         pc.hp_it = sub < 2 ? 0 : sub < 6 ? 1 : sub < 8 ? 2 : 4;

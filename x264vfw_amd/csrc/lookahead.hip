@@ -105,7 +105,7 @@ __global__ __launch_bounds__(256) void k_la_cost(LaK k)
         pc.fmin0 = (pc.smin0 >> 2) + 6; pc.fmax0 = (pc.smax0 >> 2) - 6; pc.fmin1 = (pc.smin1 >> 2) + 6; pc.fmax1 = (pc.smax1 >> 2) - 6;
         pc.me_range = k.me_range; pc.me_method = 1; pc.hp_it = 1; pc.qp_it = 1; pc.lane = lane; pc.sub = s_sub[wave];
         pc.fenc = cur0 + (size_t)gy * 16 * k.ls + gx * 16; pc.fs = k.ls;
-        pc.cref = nullptr; pc.fuv = nullptr; pc.chroma_me = 0;
+        pc.cref = nullptr; pc.fuv = nullptr; pc.chroma_me = 0; pc.csub = nullptr;
         pc.gcx = k.cost_mv + MVCOST_HALF - mvp0; pc.gcy = k.cost_mv + MVCOST_HALF - mvp1; pc.mvp0 = mvp0; pc.mvp1 = mvp1;
         pc.col_x = pmv[2 * bi]; pc.col_y = pmv[2 * bi + 1]; pc.has_col = pin[bi] != 0; pc.la_mode = true;
         int smx, smy;
