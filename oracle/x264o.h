@@ -10,7 +10,9 @@
  * What IS pinned: every normative H.264 operation here (inverse transforms, dequant, intra predictors,
  * 6-tap/qpel/chroma interpolation, deblocking) is checked in tests/ against an independent numpy
  * restatement of ITU-T H.264 clauses 8.3-8.7 (tests/spec_ref.py), and the bitstream is closed-loop
- * checked by the decoder in oracle/h264dec.c.  Non-normative arithmetic (SAD/SATD/SA8D, forward
+ * checked by the decoder in oracle/h264dec.cpp; parameter sets and slice headers are additionally read back by L-SMASH's
+ * parser from the reference tree (oracle/_ref, built by the Makefile from /root/reference/output/L-SMASH + lsmash_shim.c).
+ * Non-normative arithmetic (SAD/SATD/SA8D, forward
  * transforms, deadzone quant, decimation, search order, cost tables) restates x264's published
  * algorithm from its public description.
  */

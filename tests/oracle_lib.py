@@ -228,6 +228,37 @@ class OracleLookahead:
         self.close()
 
 
+# ---- oracle/_ref: L-SMASH's H.264 header parser from the reference tree (oracle/lsmash_shim.c, built by oracle/Makefile) ----
+class LsSps(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in ("profile_idc", "constraint_set_flags", "level_idc", "sps_id", "chroma_format_idc", "log2_max_frame_num",
+                                         "pic_order_cnt_type", "max_num_ref_frames", "frame_mbs_only_flag", "cropped_width", "cropped_height",
+                                         "sar_width", "sar_height", "video_full_range_flag", "colour_primaries", "transfer_characteristics",
+                                         "matrix_coefficients", "fixed_frame_rate_flag")] + [("num_units_in_tick", C.c_uint32), ("time_scale", C.c_uint32)]
+
+
+class LsPps(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in ("pps_id", "sps_id", "entropy_coding_mode_flag", "num_ref_idx_l0_default_active_minus1", "weighted_pred_flag",
+                                         "weighted_bipred_idc", "deblocking_filter_control_present_flag", "redundant_pic_cnt_present_flag")]
+
+
+class LsSlice(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in ("nal_unit_type", "nal_ref_idc", "slice_type", "idr", "pps_id", "frame_num", "idr_pic_id")]
+
+
+LSMASH_REF = os.path.join(ROOT, "oracle", "_ref", "liblsmash_ref.so")
+
+
+def lsmash_parse(stream, max_slices=64):
+    """Annex-B bytes -> (sps, pps, [slice headers]) as read by L-SMASH (raises if oracle/_ref was never built)"""
+    lib = C.CDLL(LSMASH_REF)
+    lib.x264o_lsmash_parse_annexb.restype = _i
+    lib.x264o_lsmash_parse_annexb.argtypes = [C.c_char_p, C.c_size_t, C.POINTER(LsSps), C.POINTER(LsPps), C.POINTER(LsSlice), _i, C.POINTER(_i)]
+    sps, pps, sl, n = LsSps(), LsPps(), (LsSlice * max_slices)(), _i()
+    rc = lib.x264o_lsmash_parse_annexb(bytes(stream), len(stream), C.byref(sps), C.byref(pps), sl, max_slices, C.byref(n))
+    assert rc >= 0, f"L-SMASH refused the stream: error {rc}"
+    return sps, pps, [sl[i] for i in range(n.value)]
+
+
 # ---- bitstream checker (oracle/h264dec.cpp) ----
 _sig("x264o_h264_decode", _i, [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.POINTER(_i), C.POINTER(_i)])
 
