@@ -106,7 +106,8 @@ int x264gpu_csp_to_i420_batch(const uint8_t *const d_src[3], const int src_strid
  * ---------------------------------------------------------------------------------------------- */
 enum { X264GPU_MB_I4x4 = 0, X264GPU_MB_I8x8 = 1, X264GPU_MB_I16x16 = 2, X264GPU_MB_P_L0 = 4, X264GPU_MB_P_8x8 = 5,
        X264GPU_MB_P_SKIP = 6 };
-enum { X264GPU_SLICE_P = 0, X264GPU_SLICE_B = 1, X264GPU_SLICE_I = 2 };
+enum { X264GPU_SLICE_P = 0, X264GPU_SLICE_B = 1, X264GPU_SLICE_I = 2 /* IDR picture: empties the DPB */,
+       X264GPU_SLICE_I_NONIDR = 3 /* intra picture that keeps the DPB (x264's X264_TYPE_I, e.g. a scenecut inside min-keyint) */ };
 
 /* per-macroblock decision record written by the GPU, consumed by the host entropy coder (64 B) */
 typedef struct x264gpu_mb {
@@ -170,7 +171,7 @@ void x264gpu_encoder_destroy(x264gpu_encoder *enc);
 /* sizes of the per-frame outputs for ONE stream */
 int  x264gpu_encoder_mb_count(const x264gpu_encoder *enc);
 /* Encode one frame per stream.  d_i420: `streams` tightly packed I420 pictures (W*H*3/2 each) already
- * resident in HBM.  slice_type: X264GPU_SLICE_I (IDR, resets the DPB) or X264GPU_SLICE_P.
+ * resident in HBM.  slice_type: X264GPU_SLICE_I (IDR, resets the DPB), X264GPU_SLICE_I_NONIDR or X264GPU_SLICE_P.
  * Outputs stay on the device: d_mb [streams][mb_count] records, d_levels [streams][mb_count][416].
  * Replaces (for the slice types supported) x264_frame_copy_picture, x264_macroblock_analyse,
  * x264_macroblock_encode, x264_frame_deblock_row, x264_frame_filter of [x264-upstream]. */

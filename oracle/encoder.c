@@ -1029,8 +1029,9 @@ int x264o_encoder_encode(x264o_encoder *e, const uint8_t *i420, int slice_type, 
 {
     int n = e->mbw * e->mbh;
     if (slice_type == X264GPU_SLICE_P && !e->have_ref) return -1;
-    e->slice_type = slice_type;
     if (slice_type == X264GPU_SLICE_I) e->have_ref = 0;      /* IDR: the DPB is emptied */
+    if (slice_type == X264GPU_SLICE_I_NONIDR) slice_type = X264GPU_SLICE_I;      /* same coding tools, the references stay */
+    e->slice_type = slice_type;
     e->nref = e->have_ref < e->slots - 1 ? e->have_ref : e->slots - 1;
     ingest(e, i420);
     if (slice_type == X264GPU_SLICE_I) {

@@ -277,3 +277,20 @@ def test_stream_headers_read_back_by_lsmash(gpu):
     assert (pps.entropy_coding_mode_flag, pps.num_ref_idx_l0_default_active_minus1, pps.deblocking_filter_control_present_flag) == (0, 1, 1)
     assert [(s.nal_unit_type, s.slice_type, s.frame_num) for s in sl] == [(5, 2, 0) if i % 3 == 0 else (1, 0, i % 3) for i in range(nfr)]
     assert [s.idr_pic_id for s in sl if s.idr] == [0, 1, 2]
+
+
+def test_scenecut_inside_min_keyint_is_a_non_idr_i_picture(gpu):
+    """x264_slicetype_decide: a scenecut closer than min-keyint to the last IDR becomes an I picture that keeps the references
+    (nal_unit_type 1, slice_type I, frame_num keeps counting); decodes to the encoder's reconstruction"""
+    w, h = 176, 144
+    frames = synth_frames(w, h, 3, seed=5) + synth_frames(w, h, 3, seed=99)
+    h_, eff = open_encoder(w, h, {"qp": 27, "keyint": 250, "min-keyint": 25}, b"high")
+    stream, rows, recons = encode_with_decisions(h_, w, h, frames)
+    H.x264_encoder_close(h_)
+    assert [r[0] for r in rows] == [1, 0, 0, 0, 0, 0] and rows[3][2] == 1          # detected, but not a keyframe
+    if __import__("os").path.exists(O.LSMASH_REF):
+        _, _, sl = O.lsmash_parse(stream)
+        assert [(s.nal_unit_type, s.slice_type, s.frame_num) for s in sl] == [(5, 2, 0), (1, 0, 1), (1, 0, 2), (1, 2, 3), (1, 0, 4), (1, 0, 5)]
+    dec = O.h264_decode(stream, len(frames), w, h)
+    for i in range(len(frames)):
+        np.testing.assert_array_equal(dec[i], recons[i], err_msg=f"decoded picture {i}")

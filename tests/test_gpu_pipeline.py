@@ -165,3 +165,22 @@ def test_many_streams_long_gop_deterministic(gpu):
             o_mb, o_lv = og.encode(f, st)
             compare(f"frame {i}", mbw, mb[0], o_mb, lv[0], o_lv, r0, og.recon())
     gg.close(); og.close()
+
+
+def test_non_idr_intra_picture_keeps_the_references(gpu):
+    """X264GPU_SLICE_I_NONIDR: an intra picture that does not empty the DPB — the P picture after it may (and here does) predict
+    from pictures before it"""
+    from gpu_enc import GpuEncoder
+    w, h = 176, 144
+    a, b = synth_frames(w, h, 4, seed=5), synth_frames(w, h, 1, seed=99)
+    seq = [(a[0], 2), (a[1], 0), (a[2], 0), (b[0], 3), (a[3], 0), (a[2], 0)]            # the cut picture is followed by the old scene again
+    cfg = O.default_config(w, h, refs=3, partitions=3)
+    og, gg = O.OracleEncoder(cfg), GpuEncoder(cfg)
+    older = 0
+    for i, (f, st) in enumerate(seq):
+        o_mb, o_lv = og.encode(f, st)
+        g_mb, g_lv = gg.encode([f], st)
+        compare(f"non-IDR I sequence frame {i}", (w + 15) // 16, g_mb[0], o_mb, g_lv[0], o_lv, gg.recon(0), og.recon())
+        if i == 4:
+            older = int((o_mb["ref"][:, 0] >= 1).sum())
+    assert older > 20, "the picture after the non-IDR I picture should reach behind it"

@@ -188,14 +188,16 @@ int x264gpu_encode_frames(x264gpu_encoder *e, const uint8_t *d_i420, int slice_t
                           int16_t *d_levels, void *stream)
 {
     ARG_TRY(e && d_i420 && d_mb && d_levels);
-    ARG_TRY(slice_type == X264GPU_SLICE_I || slice_type == X264GPU_SLICE_P);
-    ARG_TRY(slice_type == X264GPU_SLICE_I || e->have > 0);
+    ARG_TRY(slice_type == X264GPU_SLICE_I || slice_type == X264GPU_SLICE_P || slice_type == X264GPU_SLICE_I_NONIDR);
+    ARG_TRY(slice_type != X264GPU_SLICE_P || e->have > 0);
+    const bool idr = slice_type == X264GPU_SLICE_I;
+    if (slice_type == X264GPU_SLICE_I_NONIDR) slice_type = X264GPU_SLICE_I;            // same kernels; only the DPB handling differs
     hipStream_t st = (hipStream_t)stream;
     const int S = e->cfg.streams;
     EncK k = e->k;
     const int qp = slice_type == X264GPU_SLICE_I ? e->cfg.qp_i : e->cfg.qp_p;
     k.i420 = d_i420; k.fenc_y = e->fenc_y; k.fenc_uv = e->fenc_uv;
-    if (slice_type == X264GPU_SLICE_I) e->have = 0;                      // IDR empties the DPB
+    if (idr) e->have = 0;                                                // IDR empties the DPB
     k.rec_luma = e->luma[e->cur]; k.rec_chroma = e->chroma[e->cur];
     k.nref = e->have < e->cfg.refs ? e->have : e->cfg.refs;
     for (int r = 0; r < 4; r++) {

@@ -467,6 +467,7 @@ int x264_encoder_encode(x264_t *h, x264_nal_t **pp_nal, int *pi_nal, x264_pictur
         return -1;
     }
     int qp_now = idr ? h->qp_i : h->qp_p;
+    bool intra_pic = false;              // I picture that is not IDR
     h->last_scenecut = 0;
     if (h->la) {
         // ---- lookahead: cost of coding this picture intra / predicted from the previous SOURCE picture (slicetype.c) ----
@@ -478,8 +479,8 @@ int x264_encoder_encode(x264_t *h, x264_nal_t **pp_nal, int *pi_nal, x264_pictur
         }
         memcpy(h->last_costs, c, sizeof(c));
         if (!idr && p.i_scenecut_threshold > 0 && h->frame_no > 0) {
-            // scenecut_internal: the bias grows with the distance from the last keyframe.  x264 codes a non-IDR I picture when the
-            // cut falls inside min-keyint; this pipeline's I slices are IDR, so such a picture stays P (its macroblocks go intra).
+            // scenecut_internal: the bias grows with the distance from the last keyframe.  A cut at or beyond min-keyint becomes
+            // an IDR picture, one inside min-keyint an I picture that keeps the references (x264_slicetype_decide).
             const int gop = h->frames_since_idr, kmin = h->keyint_min, kmax = h->keyint;
             const double tmax = p.i_scenecut_threshold / 100.0, tmin = kmin == kmax ? tmax : tmax * 0.25;
             double bias;
@@ -487,33 +488,34 @@ int x264_encoder_encode(x264_t *h, x264_nal_t **pp_nal, int *pi_nal, x264_pictur
             else if (gop <= kmin) bias = tmin * gop / kmin;
             else bias = tmin + (tmax - tmin) * (gop - kmin) / (kmax - kmin);
             h->last_scenecut = (double)c[1] >= (1.0 - bias) * (double)c[0];
-            if (h->last_scenecut && gop >= kmin) { idr = true; qp_now = h->qp_i; }
+            if (h->last_scenecut) { if (gop >= kmin) idr = true; else intra_pic = true; qp_now = h->qp_i; }
         }
         if (h->crf) {
             // rate_estimate_qscale, CRF: q = blurred_complexity^(1 - qcomp) / rate_factor; an I picture after P pictures takes the
             // running P quantiser / ipratio; the quantiser is qscale2qp(q) rounded, within [qpmin, qpmax]
             auto qp2qscale = [](double q) { return 0.85 * pow(2.0, (q - 12.0) / 6.0); };
             auto qscale2qp = [](double qs) { return 12.0 + 6.0 * log2(qs / 0.85); };
-            const double satd = idr ? c[0] : c[1];
+            const bool is_i = idr || intra_pic;
+            const double satd = is_i ? c[0] : c[1];
             h->rc.cplxsum = h->rc.cplxsum * 0.5 + satd / h->rc.dur_ratio;
             h->rc.cplxcount = h->rc.cplxcount * 0.5 + 1.0;
-            double q = satd > 0 ? pow(h->rc.cplxsum / h->rc.cplxcount, 1.0 - h->rc.qcompress) / h->rc.rate_factor_constant : h->rc.last_qscale_for[idr ? 0 : 1];
-            if (idr && h->keyint > 1 && !h->rc.last_non_b_is_i) q = qp2qscale(h->rc.accum_p_qp / h->rc.accum_p_norm) / h->rc.ip_factor;
+            double q = satd > 0 ? pow(h->rc.cplxsum / h->rc.cplxcount, 1.0 - h->rc.qcompress) / h->rc.rate_factor_constant : h->rc.last_qscale_for[is_i ? 0 : 1];
+            if (is_i && h->keyint > 1 && !h->rc.last_non_b_is_i) q = qp2qscale(h->rc.accum_p_qp / h->rc.accum_p_norm) / h->rc.ip_factor;
             q = q < h->rc.lmin ? h->rc.lmin : q > h->rc.lmax ? h->rc.lmax : q;
-            h->rc.last_qscale_for[idr ? 0 : 1] = q;
+            h->rc.last_qscale_for[is_i ? 0 : 1] = q;
             if (h->frame_no == 0) h->rc.last_qscale_for[1] = q * h->rc.ip_factor;
             double qpf = qscale2qp(q);
             qpf = qpf < p.rc.i_qp_min ? p.rc.i_qp_min : qpf > p.rc.i_qp_max ? p.rc.i_qp_max : qpf;
             qp_now = clampi((int)(qpf + 0.5), 1, 51);
-            h->rc.accum_p_qp = h->rc.accum_p_qp * 0.95 + (idr ? qpf + h->rc.ip_offset : qpf);      // accum_p_qp_update
+            h->rc.accum_p_qp = h->rc.accum_p_qp * 0.95 + (is_i ? qpf + h->rc.ip_offset : qpf);      // accum_p_qp_update
             h->rc.accum_p_norm = h->rc.accum_p_norm * 0.95 + 1.0;
-            h->rc.last_non_b_is_i = idr;
+            h->rc.last_non_b_is_i = is_i;
             if (x264gpu_encoder_set_qp(h->gpu, qp_now, qp_now) != X264GPU_OK) return -1;
         }
     }
     h->last_qp = qp_now;
     if (idr) { h->frames_since_idr = 0; h->frame_num = 0; }
-    int st = idr ? X264GPU_SLICE_I : X264GPU_SLICE_P;
+    int st = idr ? X264GPU_SLICE_I : intra_pic ? X264GPU_SLICE_I_NONIDR : X264GPU_SLICE_P;
     PHASE(1);
     if (x264gpu_encode_frames(h->gpu, h->d_in, st, h->d_mb, h->d_lv, nullptr) != X264GPU_OK || x264gpu_stream_sync(nullptr) != X264GPU_OK) {
         xlog(&p, X264_LOG_ERROR, "x264_encoder_encode: GPU hot path failed: %s\n", x264gpu_last_error());
@@ -534,7 +536,7 @@ int x264_encoder_encode(x264_t *h, x264_nal_t **pp_nal, int *pi_nal, x264_pictur
         h->sei_sent = 1;
     }
     SliceParams sp = {};
-    sp.mbw = h->mbw; sp.mbh = h->mbh; sp.slice_type = st; sp.qp = qp_now; sp.pic_init_qp = h->pic_init_qp;
+    sp.mbw = h->mbw; sp.mbh = h->mbh; sp.slice_type = st == X264GPU_SLICE_P ? X264GPU_SLICE_P : X264GPU_SLICE_I; sp.qp = qp_now; sp.pic_init_qp = h->pic_init_qp;
     sp.frame_num = h->frame_num; sp.log2_max_frame_num = h->log2_max_frame_num;
     sp.idr = idr; sp.idr_pic_id = h->idr_pic_id; sp.nal_ref_idc = idr ? 3 : 2; sp.pps_id = p.i_sps_id;
     sp.num_ref_default = p.i_frame_reference;
@@ -548,7 +550,7 @@ int x264_encoder_encode(x264_t *h, x264_nal_t **pp_nal, int *pi_nal, x264_pictur
     publish_nals(h, pp_nal, pi_nal, types);
     if (pic_out) {
         x264_picture_init(pic_out);
-        pic_out->i_type = idr ? X264_TYPE_IDR : X264_TYPE_P;
+        pic_out->i_type = idr ? X264_TYPE_IDR : intra_pic ? X264_TYPE_I : X264_TYPE_P;
         pic_out->b_keyframe = idr;
         pic_out->i_pts = pic_in->i_pts; pic_out->i_dts = pic_in->i_pts;
         pic_out->img = pic_in->img;
