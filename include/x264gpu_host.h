@@ -24,6 +24,13 @@ int x264host_write_slice(int mbw, int mbh, int slice_type, int qp, int pic_init_
 /* SPS + PPS for a stream made of such slices */
 int x264host_write_headers(int width, int height, int level_idc, int log2_max_frame_num, int pic_init_qp, int chroma_qp_offset,
                            uint32_t num_units_in_tick, uint32_t time_scale, int num_ref, int transform8x8_mode, uint8_t *out, int cap);
+/* the file muxers (`--output x.h264 | x.mkv | x.flv`, host/muxers.cpp; reference output/raw.c, matroska.c, flv.c) without an encoder */
+void *x264host_mux_open(const char *filename, const char *muxer /* "auto", "raw", "mkv", "flv" */, int *annexb);
+int x264host_mux_set_param(void *h, int width, int height, uint32_t fps_num, uint32_t fps_den, uint32_t timebase_num, uint32_t timebase_den,
+                           int sar_width, int sar_height, int vfr);
+int x264host_mux_write_headers(void *h, const uint8_t *sps, int sps_size, const uint8_t *pps, int pps_size, const uint8_t *sei, int sei_size);
+int x264host_mux_write_frame(void *h, const uint8_t *payload, int size, int64_t pts, int64_t dts, int keyframe, int type);
+int x264host_mux_close(void *h, int64_t largest_pts, int64_t second_largest_pts);
 /* quantiser, scenecut flag and lookahead sums (x264gpu_lookahead_frame_cost) of the last coded picture */
 int x264host_last_decision(x264_t *h, int *qp, int *scenecut, int32_t costs[4]);
 /* reconstructed picture of the last encoded frame as I420 (host memory) */

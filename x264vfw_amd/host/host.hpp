@@ -38,4 +38,16 @@ void write_slice_header(BitWriter &bw, const SliceParams &p);
 void write_slice(std::vector<uint8_t> &out, const SliceParams &p, const x264gpu_mb *mbs, const int16_t *levels,
                  bool annexb, bool long_startcode, SliceStats *stats, int threads = 1);
 
+// ---- file output (muxers.cpp): the reference's cli_output_t (output/output.h: open_file / set_param / write_headers / write_frame / close_file) ----
+class Muxer {
+public:
+    virtual ~Muxer() {}
+    virtual int set_param(const x264_param_t *p) = 0;
+    virtual int write_headers(const x264_nal_t *nal) = 0;                       // nal[0..2] = SPS, PPS, SEI of x264_encoder_headers
+    virtual int write_frame(const uint8_t *payload, int size, const x264_picture_t *pic) = 0;
+    virtual int close(int64_t largest_pts, int64_t second_largest_pts) = 0;
+};
+// muxer: "auto" (by extension), "raw", "mkv", "flv"; *annexb_out = how the encoder must frame NAL units for it.  NULL + *error on failure.
+Muxer *open_muxer(const char *filename, const char *muxer, int *annexb_out, const char **error);
+
 }  // namespace x264host

@@ -41,7 +41,8 @@ struct CODEC {                          /* x264vfw.h:187-252, compress-side memb
     int b_user_ref;
     uint8_t *d_raw; size_t raw_cap;     /* device copy of the caller's frame in its native colourspace */
     int colmatrix709, fullrange;        /* x264vfw_csp_init arguments (codec.c:1570-1577,1672) */
-    FILE *cli_hout; int b_cli_output, b_no_output;   /* file output instead of the VfW buffer (codec.c:1111-1164,1609-1663; output/raw.c) */
+    x264host::Muxer *cli_hout; int b_cli_output, b_no_output;   /* file output instead of the VfW buffer (codec.c:1111-1164,1609-1663; output/raw.c, matroska.c, flv.c) */
+    int64_t largest_pts, second_largest_pts;      /* for close_file (codec.c:1858-1866) */
     std::string log;
 };
 
@@ -147,7 +148,7 @@ LRESULT compress_end(CODEC *codec)
     x264_picture_clean(&codec->conv_pic);
     memset(&codec->conv_pic, 0, sizeof(codec->conv_pic));
     if (codec->d_raw) { x264gpu_free(codec->d_raw); codec->d_raw = nullptr; codec->raw_cap = 0; }
-    if (codec->cli_hout) { fclose(codec->cli_hout); codec->cli_hout = nullptr; }          /* raw_output.close_file (output/raw.c:60-66) */
+    if (codec->cli_hout) { codec->cli_hout->close(codec->largest_pts, codec->second_largest_pts); delete codec->cli_hout; codec->cli_hout = nullptr; }   /* cli_output.close_file */
     codec->b_cli_output = 0;
     codec->b_encoder_error = 0;
     return ICERR_OK;
@@ -286,22 +287,30 @@ LRESULT compress_begin(CODEC *codec, BITMAPINFO *in, BITMAPINFO *out)
         param.i_threads = 1;
     }
     if (out_file != "-") {                                                  /* select_output (codec.c:1111-1164) */
-        std::string ext = muxer;
-        if (muxer == "auto") { size_t dot = out_file.rfind('.'); ext = dot == std::string::npos ? "" : out_file.substr(dot + 1); }
-        for (char &ch : ext) ch = (char)tolower((unsigned char)ch);
-        if (ext == "mp4" || ext == "mkv" || ext == "flv" || ext == "avi") {
-            vlog(codec, X264_LOG_ERROR, "not compiled with %s output support (raw Annex-B only)\n", ext.c_str());
-            goto fail;
-        }
-        codec->b_cli_output = 1;                                            /* raw_output: Annex-B with in-band SPS/PPS */
-        if (!codec->b_no_output && !(codec->cli_hout = fopen(out_file.c_str(), "w+b"))) {
-            vlog(codec, X264_LOG_ERROR, "could not open output file: '%s'\n", out_file.c_str());
-            goto fail;
+        codec->b_cli_output = 1;
+        codec->largest_pts = codec->second_largest_pts = -1;
+        if (!codec->b_no_output) {
+            int annexb = 1;
+            const char *err = nullptr;
+            codec->cli_hout = x264host::open_muxer(out_file.c_str(), muxer.c_str(), &annexb, &err);
+            if (!codec->cli_hout) {
+                if (err && !strncmp(err, "not compiled", 12)) vlog(codec, X264_LOG_ERROR, "not compiled with this output support (raw, mkv and flv are built in)\n");
+                else vlog(codec, X264_LOG_ERROR, "could not open output file: '%s'\n", out_file.c_str());
+                goto fail;
+            }
+            param.b_annexb = annexb; param.b_repeat_headers = annexb;       /* containers: length-prefixed NALs, headers once (codec.c:1121-1143) */
         }
     }
     codec->h = x264_encoder_open(&param);
     if (!codec->h) { vlog(codec, X264_LOG_ERROR, "x264_encoder_open failed\n"); goto fail; }
     x264_encoder_parameters(codec->h, &param);
+    if (codec->cli_hout) {                                                  /* set_param + write_headers (codec.c:1632-1663) */
+        x264_nal_t *hn; int nh;
+        if (codec->cli_hout->set_param(&param) < 0 || x264_encoder_headers(codec->h, &hn, &nh) < 0 || (!param.b_repeat_headers && codec->cli_hout->write_headers(hn) < 0)) {
+            vlog(codec, X264_LOG_ERROR, "can't write headers to outfile\n");
+            goto fail;
+        }
+    }
     if (x264_picture_alloc(&codec->conv_pic, param.i_csp, param.i_width, param.i_height) < 0) {
         vlog(codec, X264_LOG_ERROR, "x264_picture_alloc failed\n");
         goto fail;
@@ -323,7 +332,11 @@ int encode_frame(CODEC *codec, x264_picture_t *pic, x264_picture_t *pic_out, uin
     if (size < 0) { vlog(codec, X264_LOG_ERROR, "x264_encoder_encode failed\n"); return -1; }
     if (size) {
         *got_picture = 1;
-        if (!codec->b_no_output && codec->b_cli_output && fwrite(nal[0].p_payload, size, 1, codec->cli_hout) != 1) {   /* raw_output.write_frame */
+        if (codec->b_cli_output && pic_out) {
+            if (pic_out->i_pts > codec->largest_pts) { codec->second_largest_pts = codec->largest_pts; codec->largest_pts = pic_out->i_pts; }
+            else if (pic_out->i_pts > codec->second_largest_pts) codec->second_largest_pts = pic_out->i_pts;
+        }
+        if (!codec->b_no_output && codec->b_cli_output && codec->cli_hout->write_frame(nal[0].p_payload, size, pic_out) < 0) {   /* cli_output.write_frame */
             vlog(codec, X264_LOG_ERROR, "can't write frame to outfile\n");
             return -1;
         }
