@@ -93,7 +93,7 @@ _sig("x264host_get_recon", _i, [C.c_void_p, C.c_void_p])
 _sig("x264host_last_decision", _i, [C.c_void_p, C.POINTER(_i), C.POINTER(_i), C.POINTER(C.c_int32)])
 LEVELS = (Level * 21).in_dll(H, "x264_levels")
 
-X264_CSP_I420, X264_RC_CQP, X264_RC_CRF = 1, 0, 1
+X264_CSP_I420, X264_RC_CQP, X264_RC_CRF, X264_RC_ABR = 1, 0, 1, 2
 X264_PARAM_BAD_NAME, X264_PARAM_BAD_VALUE = -1, -2
 
 

@@ -243,6 +243,8 @@ def test_crf_follows_the_lookahead_complexity(gpu):
         q = (cs / cc) ** (1 - qcomp) / rfc
         if key and not last_i:
             q = q2s(apq / apn) / ipf
+        elif i == 0:
+            q = q2s(crf) / ipf                                   # very first picture: ABR_INIT_QP / ipratio
         qpf = float(np.clip(s2q(q), 1, 51))
         apq, apn = apq * 0.95 + (qpf + 6 * np.log2(ipf) if key else qpf), apn * 0.95 + 1
         last_i = bool(key)
@@ -294,3 +296,24 @@ def test_scenecut_inside_min_keyint_is_a_non_idr_i_picture(gpu):
     dec = O.h264_decode(stream, len(frames), w, h)
     for i in range(len(frames)):
         np.testing.assert_array_equal(dec[i], recons[i], err_msg=f"decoded picture {i}")
+
+
+def test_abr_steers_towards_the_bitrate(gpu):
+    """--bitrate (single-pass ABR, no VBV; the 1-pass branch of x264's rate_estimate_qscale): the quantiser follows the rate
+    factor that would have met the target so far, so two targets a factor of four apart give clearly different quantisers and
+    sizes, each within a loose band of its target once the controller has settled; the stream stays decodable."""
+    w, h, nfr, fps = 352, 288, 50, 25
+    frames = synth_frames(w, h, nfr, seed=8, scene_len=10 ** 9)
+    res = {}
+    for kbps in (400, 1600):
+        h_, eff = open_encoder(w, h, {"bitrate": kbps, "keyint": 250, "no-scenecut": None}, b"high")
+        assert eff.rc.i_rc_method == HL.X264_RC_ABR and eff.rc.i_bitrate == kbps
+        stream, rows, recons = encode_with_decisions(h_, w, h, frames)
+        H.x264_encoder_close(h_)
+        dec = O.h264_decode(stream, nfr, w, h)
+        assert all(np.array_equal(d, r) for d, r in zip(dec, recons))
+        res[kbps] = (len(stream) * 8 / (nfr / fps) / 1000, [r[1] for r in rows])
+    lo, hi = res[400], res[1600]
+    assert 0.5 * 400 < lo[0] < 2.0 * 400 and 0.5 * 1600 < hi[0] < 2.0 * 1600, (lo[0], hi[0])
+    assert np.mean(lo[1][10:]) > np.mean(hi[1][10:]) + 4                        # ~4x the bits is ~12 quantiser steps in theory
+    assert len(set(lo[1])) > 2                                                  # it actually moves

@@ -52,7 +52,11 @@ struct x264_t {
         double cplxsum = 0, cplxcount = 0, accum_p_qp = 0, accum_p_norm = 0, lmin = 0, lmax = 0;
         double last_qscale_for[2] = { 0, 0 };       // [0] I, [1] P
         int last_non_b_is_i = 1;
+        // single-pass ABR (--bitrate): the 1-pass branch of rate_estimate_qscale + the bookkeeping of x264_ratecontrol_end
+        double bitrate = 0, fps = 25, cplxr_sum = 0, wanted_bits_window = 0, abr_buffer = 0, total_bits = 0, last_rceq = 1, lstep = 1.3195;
+        double qpa_last = 0;                        // quantiser of the picture whose size arrives next (ratecontrol_end)
     } rc;
+    bool abr = false;
     double t_phase[6] = { 0, 0, 0, 0, 0, 0 };   // X264GPU_HOST_TIMING=1: seconds in copy-in, upload + lookahead, GPU, download, entropy coding, calls
     int cavlc_threads = 1;               // row bands of a slice coded in parallel (threads 1 sessions; GOP-parallel ones use a thread per GOP)
     int last_qp = 0, last_scenecut = 0;  // diagnostics: quantiser and scenecut flag of the last coded picture
@@ -185,9 +189,11 @@ x264_t *x264_encoder_open(x264_param_t *param)
     // driver's default session) when one GOP is in flight; ABR and CRF under --threads > 1 map to their nominal quantiser
     int qp = p.rc.i_rc_method == X264_RC_CQP ? p.rc.i_qp_constant : p.rc.i_rc_method == X264_RC_CRF ? (int)(p.rc.f_rf_constant + 0.5f) : 26;
     h->crf = p.rc.i_rc_method == X264_RC_CRF && p.i_threads <= 1 && p.rc.f_rf_constant >= 1.0f;
-    if (p.rc.i_rc_method != X264_RC_CQP && !h->crf) xlog(&p, X264_LOG_WARNING, "this rate control mode is not implemented yet: constant qp %d\n", qp);
+    h->abr = p.rc.i_rc_method == X264_RC_ABR && p.i_threads <= 1 && p.rc.i_bitrate > 0 && !p.rc.b_stat_read;      // single pass, no VBV
+    if (p.rc.i_rc_method != X264_RC_CQP && !h->crf && !h->abr) xlog(&p, X264_LOG_WARNING, "this rate control mode is not implemented yet (2-pass, or CRF / ABR with --threads > 1): constant qp %d\n", qp);
     if (qp < 1) { xlog(&p, X264_LOG_WARNING, "lossless is not supported: qp 1\n"); qp = 1; }
-    if (!h->crf) p.rc.i_rc_method = X264_RC_CQP;
+    if (!h->crf && !h->abr) p.rc.i_rc_method = X264_RC_CQP;
+    p.rc.i_vbv_max_bitrate = 0; p.rc.i_vbv_buffer_size = 0;
     p.rc.i_qp_constant = clampi(qp, 1, 51);
     p.rc.i_qp_min = clampi(p.rc.i_qp_min, 1, 51); p.rc.i_qp_max = clampi(p.rc.i_qp_max, p.rc.i_qp_min, 51);
     if (p.i_threads > 1 && p.i_scenecut_threshold) { xlog(&p, X264_LOG_INFO, "scenecut needs threads 1 (GOPs in lock-step have a fixed structure): scenecut 0\n"); p.i_scenecut_threshold = 0; }
@@ -197,7 +203,7 @@ x264_t *x264_encoder_open(x264_param_t *param)
     h->keyint_min = p.i_keyint_min;
     h->qp_p = p.rc.i_qp_constant;
     h->qp_i = clampi((int)(h->qp_p - 6.0 * log2(p.rc.f_ip_factor > 0 ? p.rc.f_ip_factor : 1.0) + 0.5), 1, 51);
-    h->pic_init_qp = h->crf ? 26 : clampi(h->qp_p, 0, 51);          // CRF moves the slice quantiser both ways: centre the +-26 range of slice_qp_delta
+    h->pic_init_qp = h->crf || h->abr ? 26 : clampi(h->qp_p, 0, 51);          // CRF moves the slice quantiser both ways: centre the +-26 range of slice_qp_delta
     h->profile_idc = p.analyse.b_transform_8x8 ? 100 : 66;        // High only for the 8x8 transform; everything else is Baseline-compatible
     h->level_idc = p.i_level_idc > 0 ? p.i_level_idc : pick_level(&p, h->nmb, p.i_frame_reference);
     p.i_level_idc = h->level_idc;
@@ -237,7 +243,7 @@ x264_t *x264_encoder_open(x264_param_t *param)
         x264_encoder_close(h);
         return nullptr;
     }
-    if ((p.i_scenecut_threshold > 0 || h->crf) && h->G == 1) {
+    if ((p.i_scenecut_threshold > 0 || h->crf || h->abr) && h->G == 1) {
         if (x264gpu_lookahead_create(&h->la, p.i_width, p.i_height, 1, p.analyse.i_me_range, p.analyse.i_subpel_refine) != X264GPU_OK ||
             x264gpu_malloc((void **)&h->d_la, 4 * sizeof(int32_t)) != X264GPU_OK) {
             xlog(&p, X264_LOG_ERROR, "GPU lookahead setup failed: %s\n", x264gpu_last_error());
@@ -245,7 +251,7 @@ x264_t *x264_encoder_open(x264_param_t *param)
             return nullptr;
         }
     }
-    if (h->crf) {
+    if (h->crf || h->abr) {
         // x264_ratecontrol_new: rate_factor_constant = base_cplx^(1 - qcomp) / qp2qscale(crf), base_cplx = mbs * (bframes ? 120 : 80)
         auto qp2qscale = [](double q) { return 0.85 * pow(2.0, (q - 12.0) / 6.0); };
         h->rc.qcompress = p.rc.f_qcompress; h->rc.ip_factor = fabs(p.rc.f_ip_factor) > 0 ? fabs(p.rc.f_ip_factor) : 1.0;
@@ -256,6 +262,16 @@ x264_t *x264_encoder_open(x264_param_t *param)
         double dur = p.i_fps_num ? (double)p.i_fps_den / p.i_fps_num : 0.04;
         dur = dur < 0.01 ? 0.01 : dur > 1.0 ? 1.0 : dur;              // CLIP_DURATION
         h->rc.dur_ratio = dur / 0.04;                                  // BASE_FRAME_DURATION
+        if (h->abr) {
+            // x264_ratecontrol_new / x264_ratecontrol_init_reconfigurable, ABR without VBV
+            const double abr_init_qp = 24.0;
+            h->rc.bitrate = p.rc.i_bitrate * 1000.0; h->rc.fps = p.i_fps_num ? (double)p.i_fps_num / p.i_fps_den : 25.0;
+            h->rc.cplxr_sum = 0.01 * pow(7.0e5, h->rc.qcompress) * pow((double)h->nmb, 0.5);
+            h->rc.wanted_bits_window = h->rc.bitrate / h->rc.fps;
+            h->rc.abr_buffer = 2.0 * (p.rc.f_rate_tolerance > 0.01f ? p.rc.f_rate_tolerance : 0.01f) * h->rc.bitrate;
+            h->rc.lstep = pow(2.0, (p.rc.i_qp_step > 0 ? p.rc.i_qp_step : 4) / 6.0);
+            h->rc.last_qscale_for[0] = h->rc.last_qscale_for[1] = qp2qscale(abr_init_qp);
+        }
     }
     { const unsigned hw = std::thread::hardware_concurrency(); h->cavlc_threads = h->G > 1 ? 1 : cavlc_threads_default(hw >= 32 ? 16 : hw >= 16 ? 8 : hw >= 4 ? (int)hw / 2 : 1); }
     h->h_in.resize(insz); h->h_mb.resize((size_t)h->G * h->nmb); h->h_lv.resize((size_t)h->G * h->nmb * X264GPU_MB_LEVELS);
@@ -490,7 +506,7 @@ int x264_encoder_encode(x264_t *h, x264_nal_t **pp_nal, int *pi_nal, x264_pictur
             h->last_scenecut = (double)c[1] >= (1.0 - bias) * (double)c[0];
             if (h->last_scenecut) { if (gop >= kmin) idr = true; else intra_pic = true; qp_now = h->qp_i; }
         }
-        if (h->crf) {
+        if (h->crf || h->abr) {
             // rate_estimate_qscale, CRF: q = blurred_complexity^(1 - qcomp) / rate_factor; an I picture after P pictures takes the
             // running P quantiser / ipratio; the quantiser is qscale2qp(q) rounded, within [qpmin, qpmax]
             auto qp2qscale = [](double q) { return 0.85 * pow(2.0, (q - 12.0) / 6.0); };
@@ -499,8 +515,31 @@ int x264_encoder_encode(x264_t *h, x264_nal_t **pp_nal, int *pi_nal, x264_pictur
             const double satd = is_i ? c[0] : c[1];
             h->rc.cplxsum = h->rc.cplxsum * 0.5 + satd / h->rc.dur_ratio;
             h->rc.cplxcount = h->rc.cplxcount * 0.5 + 1.0;
-            double q = satd > 0 ? pow(h->rc.cplxsum / h->rc.cplxcount, 1.0 - h->rc.qcompress) / h->rc.rate_factor_constant : h->rc.last_qscale_for[is_i ? 0 : 1];
+            // get_qscale: rceq = blurred_complexity^(1 - qcomp), divided by the rate factor: the CRF constant, or under ABR the one
+            // that would have met the bitrate so far (wanted_bits_window / cplxr_sum)
+            double q, overflow = 1.0;
+            const double rate_factor = h->crf ? h->rc.rate_factor_constant : h->rc.wanted_bits_window / h->rc.cplxr_sum;
+            if (satd > 0) { h->rc.last_rceq = pow(h->rc.cplxsum / h->rc.cplxcount, 1.0 - h->rc.qcompress); q = h->rc.last_rceq / rate_factor; }
+            else q = h->rc.last_qscale_for[is_i ? 0 : 1];
+            if (h->abr && satd > 0) {
+                // pull towards the target: bits so far against time so far, within an abr_buffer that grows with sqrt(time)
+                const double time_done = h->frame_no / h->rc.fps, wanted_bits = time_done * h->rc.bitrate;
+                if (wanted_bits > 0) {
+                    const double buf = h->rc.abr_buffer * (time_done > 1.0 ? sqrt(time_done) : 1.0);
+                    overflow = 1.0 + (h->rc.total_bits - wanted_bits) / buf;
+                    overflow = overflow < 0.5 ? 0.5 : overflow > 2.0 ? 2.0 : overflow;
+                    q *= overflow;
+                }
+            }
             if (is_i && h->keyint > 1 && !h->rc.last_non_b_is_i) q = qp2qscale(h->rc.accum_p_qp / h->rc.accum_p_norm) / h->rc.ip_factor;
+            else if (h->frame_no > 0) {
+                if (h->abr) {       // asymmetric clipping against the last quantiser of the same picture type (qpstep)
+                    double lmin = h->rc.last_qscale_for[is_i ? 0 : 1] / h->rc.lstep, lmax = h->rc.last_qscale_for[is_i ? 0 : 1] * h->rc.lstep;
+                    if (overflow > 1.1 && h->frame_no > 3) lmax *= h->rc.lstep;
+                    else if (overflow < 0.9) lmin /= h->rc.lstep;
+                    q = q < lmin ? lmin : q > lmax ? lmax : q;
+                }
+            } else if (h->crf && h->rc.qcompress != 1.0) q = qp2qscale(p.rc.f_rf_constant) / h->rc.ip_factor;       // very first picture: ABR_INIT_QP / ipratio
             q = q < h->rc.lmin ? h->rc.lmin : q > h->rc.lmax ? h->rc.lmax : q;
             h->rc.last_qscale_for[is_i ? 0 : 1] = q;
             if (h->frame_no == 0) h->rc.last_qscale_for[1] = q * h->rc.ip_factor;
@@ -510,6 +549,7 @@ int x264_encoder_encode(x264_t *h, x264_nal_t **pp_nal, int *pi_nal, x264_pictur
             h->rc.accum_p_qp = h->rc.accum_p_qp * 0.95 + (is_i ? qpf + h->rc.ip_offset : qpf);      // accum_p_qp_update
             h->rc.accum_p_norm = h->rc.accum_p_norm * 0.95 + 1.0;
             h->rc.last_non_b_is_i = is_i;
+            h->rc.qpa_last = qpf;
             if (x264gpu_encoder_set_qp(h->gpu, qp_now, qp_now) != X264GPU_OK) return -1;
         }
     }
@@ -557,6 +597,13 @@ int x264_encoder_encode(x264_t *h, x264_nal_t **pp_nal, int *pi_nal, x264_pictur
     }
     if (idr) h->idr_pic_id = (h->idr_pic_id + 1) & 0xffff;
     h->frame_num = (h->frame_num + 1) & ((1 << h->log2_max_frame_num) - 1);
+    if (h->abr) {
+        // x264_ratecontrol_end: what this picture's bits say about the rate factor, and the bits the window now expects
+        const double bits = 8.0 * (double)h->out.size();
+        h->rc.total_bits += bits;
+        h->rc.cplxr_sum += bits * (0.85 * pow(2.0, (h->rc.qpa_last - 12.0) / 6.0)) / h->rc.last_rceq;
+        h->rc.wanted_bits_window += h->rc.bitrate / h->rc.fps;
+    }
     h->frames_since_idr++;
     h->frame_no++;
     PHASE(4);
