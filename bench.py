@@ -173,7 +173,7 @@ def main():
     ap.add_argument("--refs", type=int, default=3, help="reference frames (medium: 3)")
     ap.add_argument("--preset", default="medium", choices=["medium", "ultrafast", "slow"],
                     help="toolset of the other BASELINE.json configs (default medium = the headline); slow runs hex instead of umh")
-    ap.add_argument("--cpu-frames", type=int, default=12, help="frames of the CPU-baseline sample (0 = skip)")
+    ap.add_argument("--cpu-frames", type=int, default=24, help="frames of the CPU-baseline sample (0 = skip)")
     args = ap.parse_args()
 
     import torch

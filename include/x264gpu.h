@@ -164,6 +164,11 @@ typedef struct x264gpu_config {
                                * as x264's h->mb.b_chroma_me ([x264-upstream] encoder/encoder.c, me.c COST_MV_SATD) */
     int mixed_refs;           /* --mixed-refs (x264 default on): 8x8 blocks, and the 16x8 / 8x16 halves built on them, choose their reference
                                * on their own ([x264-upstream] analyse.c x264_mb_analyse_inter_p8x8_mixed_ref); needs partitions bit0 and refs > 1 */
+    int aq_mode;              /* --aq-mode: 0 off, 1 variance AQ (x264_adaptive_quant_frame, [x264-upstream] encoder/ratecontrol.c): every macroblock's
+                               * quantiser = slice quantiser + round(strength * (log2(max(energy, 1)) - 14.427)), energy = AC energy of its luma and
+                               * chroma source samples.  Restated in Q8 fixed point (table include/x264gpu_aq_lut.inc) so that host checker and device
+                               * agree to the bit.  x264 switches AQ off under constant QP; so does the host encoder. */
+    int aq_strength_q8;       /* --aq-strength * 1.0397 * 256, rounded (x264 default 1.0 -> 266) */
 } x264gpu_config;
 
 int  x264gpu_encoder_create(x264gpu_encoder **enc, const x264gpu_config *cfg);

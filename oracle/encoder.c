@@ -46,6 +46,7 @@ typedef struct x264o_encoder {
     x264o_quant_tables qt;
     int have_ref;
     int slice_type;              /* slice being encoded */
+    uint8_t *mbqp;               /* quantiser of every macroblock of the picture being coded (slice quantiser, + AQ offset) */
 } x264o_encoder;
 
 static int clampi(int v, int lo, int hi) { return v < lo ? lo : v > hi ? hi : v; }
@@ -99,6 +100,7 @@ x264o_encoder *x264o_encoder_create(const x264gpu_config *cfg)
         e->reff[s] = malloc((size_t)e->mbw * e->mbh);
         memset(e->reff[s], -1, (size_t)e->mbw * e->mbh);
     }
+    e->mbqp = malloc((size_t)e->mbw * e->mbh);
     x264o_quant_init(&e->qt, cfg->deadzone_inter, cfg->deadzone_intra);
     return e;
 }
@@ -109,7 +111,7 @@ void x264o_encoder_destroy(x264o_encoder *e)
     for (int s = 0; s < e->slots; s++) { free(e->luma[s]); free(e->chroma[s]); }
     for (int s = 0; s < 2; s++) { free(e->mvf[s]); free(e->reff[s]); }
     for (int q = 0; q < 52; q++) free(e->cost_mv[q]);
-    free(e->fenc_y); free(e->fenc_uv); free(e);
+    free(e->fenc_y); free(e->fenc_uv); free(e->mbqp); free(e);
 }
 
 int x264o_encoder_mb_count(const x264o_encoder *e) { return e->mbw * e->mbh; }
@@ -141,6 +143,48 @@ static void ingest(x264o_encoder *e, const uint8_t *i420)
 }
 
 /* ---- residual coding helpers ---- */
+/* ---- adaptive quantisation, mode 1 (x264_adaptive_quant_frame / x264_ac_energy_mb, [x264-upstream] encoder/ratecontrol.c):
+ * energy = var(16x16 luma) + var(8x8 U) + var(8x8 V) with var = ssd - (sum^2 >> log2 n); offset = strength * (log2(energy) - 14.427).
+ * Q8 fixed point: log2 = 256 * floor(log2 e) + table[next 7 bits]; the offset is rounded to an integer quantiser step. ---- */
+static const uint8_t aq_log2_lut[128] = {
+#include "x264gpu_aq_lut.inc"
+};
+static int aq_log2_q8(uint32_t x)
+{
+    int lz = 31 - __builtin_clz(x);
+    return lz * 256 + aq_log2_lut[((x << (31 - lz)) >> 24) & 0x7f];
+}
+static void compute_mb_qp(x264o_encoder *e, int slice_qp)
+{
+    const int n = e->mbw * e->mbh;
+    if (!e->cfg.aq_mode) { memset(e->mbqp, slice_qp, (size_t)n); return; }
+    for (int mby = 0; mby < e->mbh; mby++)
+        for (int mbx = 0; mbx < e->mbw; mbx++) {
+            const pixel *y = e->fenc_y + (size_t)mby * 16 * e->fs + mbx * 16, *uv = e->fenc_uv + (size_t)mby * 8 * e->fs + mbx * 16;
+            uint32_t sum = 0, sqr = 0, su = 0, squ = 0, sv = 0, sqv = 0;
+            for (int r = 0; r < 16; r++) for (int c = 0; c < 16; c++) { uint32_t p = y[r * e->fs + c]; sum += p; sqr += p * p; }
+            for (int r = 0; r < 8; r++) for (int c = 0; c < 8; c++) {
+                uint32_t u = uv[r * e->fs + 2 * c], v = uv[r * e->fs + 2 * c + 1];
+                su += u; squ += u * u; sv += v; sqv += v * v;
+            }
+            uint32_t energy = (sqr - (sum * sum >> 8)) + (squ - (su * su >> 6)) + (sqv - (sv * sv >> 6));
+            int adj_q8 = (e->cfg.aq_strength_q8 * (aq_log2_q8(energy ? energy : 1) - 3693)) >> 8;      /* 14.427 * 256 = 3693 */
+            e->mbqp[mby * e->mbw + mbx] = (uint8_t)clampi(slice_qp + ((adj_q8 + 128) >> 8), 1, 51);
+        }
+}
+
+/* QP_Y of a macroblock that sends no mb_qp_delta (no coefficients, not Intra16x16) is the previous macroblock's (7.4.5): the
+ * deblocking filter and the next delta use that value (x264_macroblock_cache_save does the same) */
+static void settle_mb_qp(x264o_encoder *e, x264gpu_mb *mbs, int slice_qp)
+{
+    int last = slice_qp;
+    for (int i = 0; i < e->mbw * e->mbh; i++) {
+        x264gpu_mb *m = &mbs[i];
+        if (m->type != X264GPU_MB_I16x16 && !m->cbp_luma && !m->cbp_chroma) m->qp = (uint8_t)last;
+        last = m->qp;
+    }
+}
+
 static void scan4(int16_t *dst, const dctcoef *src) { for (int k = 0; k < 16; k++) dst[k] = src[x264o_zigzag4[k]]; }
 
 static const uint8_t blk_x[16] = { 0, 1, 0, 1, 2, 3, 2, 3, 0, 1, 0, 1, 2, 3, 2, 3 };
@@ -572,7 +616,7 @@ static const int8_t part_extra_bits[4] = { 0, 2, 2, 8 };
 
 static void analyse_p_mb(x264o_encoder *e, int mbx, int mby, x264gpu_mb *mb)
 {
-    int qp = e->cfg.qp_p, lambda = x264o_lambda(qp), mi = mby * e->mbw + mbx, mvp[2];
+    int mi = mby * e->mbw + mbx, qp = e->mbqp[mi], lambda = x264o_lambda(qp), mvp[2];
     /* 16x16 search in every usable reference (most recent first); lower index wins ties */
     me_result m = { 0, 0, 1 << 28 }, m16[4];
     int bref = 0;
@@ -1034,11 +1078,13 @@ int x264o_encoder_encode(x264o_encoder *e, const uint8_t *i420, int slice_type, 
     e->slice_type = slice_type;
     e->nref = e->have_ref < e->slots - 1 ? e->have_ref : e->slots - 1;
     ingest(e, i420);
+    const int slice_qp = slice_type == X264GPU_SLICE_I ? e->cfg.qp_i : e->cfg.qp_p;
+    compute_mb_qp(e, slice_qp);
     if (slice_type == X264GPU_SLICE_I) {
         for (int i = 0; i < n; i++) { e->reff[1][i] = -1; e->mvf[1][i][0] = e->mvf[1][i][1] = 0; }
         for (int mby = 0; mby < e->mbh; mby++)
             for (int mbx = 0; mbx < e->mbw; mbx++)
-                intra_mb(e, mbx, mby, e->cfg.qp_i, mbs, levels + (size_t)(mby * e->mbw + mbx) * X264GPU_MB_LEVELS);
+                intra_mb(e, mbx, mby, e->mbqp[mby * e->mbw + mbx], mbs, levels + (size_t)(mby * e->mbw + mbx) * X264GPU_MB_LEVELS);
     } else {
         for (int mby = 0; mby < e->mbh; mby++)
             for (int mbx = 0; mbx < e->mbw; mbx++) analyse_p_mb(e, mbx, mby, &mbs[mby * e->mbw + mbx]);
@@ -1050,9 +1096,10 @@ int x264o_encoder_encode(x264o_encoder *e, const uint8_t *i420, int slice_type, 
         for (int mby = 0; mby < e->mbh; mby++)
             for (int mbx = 0; mbx < e->mbw; mbx++) {
                 x264gpu_mb *mb = &mbs[mby * e->mbw + mbx];
-                if (mb->type != X264GPU_MB_P_L0 && mb->type != X264GPU_MB_P_8x8) intra_mb(e, mbx, mby, e->cfg.qp_p, mbs, levels + (size_t)(mby * e->mbw + mbx) * X264GPU_MB_LEVELS);
+                if (mb->type != X264GPU_MB_P_L0 && mb->type != X264GPU_MB_P_8x8) intra_mb(e, mbx, mby, e->mbqp[mby * e->mbw + mbx], mbs, levels + (size_t)(mby * e->mbw + mbx) * X264GPU_MB_LEVELS);
             }
     }
+    if (e->cfg.aq_mode) settle_mb_qp(e, mbs, slice_qp);
     if (e->cfg.deblock) deblock_frame(e, mbs);
     filter_frame(e);
     /* rotate: the frame just built becomes the reference; its MV field becomes "previous" */

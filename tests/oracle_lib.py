@@ -153,7 +153,7 @@ assert MB_DTYPE.itemsize == 64 == C.sizeof(MbRecord)
 def default_config(width, height, streams=1, **kw):
     c = Config(width=width, height=height, streams=streams, refs=1, qp_i=20, qp_p=23, me_range=16, subme=7,
                deblock=1, deblock_alpha=0, deblock_beta=0, chroma_qp_offset=0, deadzone_inter=21,
-               deadzone_intra=11, dct_decimate=1, partitions=2, dct8x8=0, me_method=1, chroma_me=0, mixed_refs=0)
+               deadzone_intra=11, dct_decimate=1, partitions=2, dct8x8=0, me_method=1, chroma_me=0, mixed_refs=0, aq_mode=0, aq_strength_q8=266)
     for k, v in kw.items():
         setattr(c, k, v)
     return c

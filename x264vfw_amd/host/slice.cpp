@@ -33,6 +33,14 @@ struct SliceCtx {
 
     int mbw() const { return p.mbw; }
 
+    // mb_qp_delta (7.4.5): against QP_Y of the previous macroblock in decoding order — the records carry the settled quantisers
+    // (a macroblock that sends no delta has inherited its predecessor's), the first macroblock predicts from the slice quantiser
+    int qp_delta(const x264gpu_mb &m) const
+    {
+        const int i = (int)(&m - mbs);
+        return (int)m.qp - (i == 0 ? p.qp : (int)mbs[i - 1].qp);
+    }
+
     // ---- nC for coeff_token (9.2.1): average of left (A) and top (B) block totals ----
     int nc_luma(int mbx, int mby, int blk) const
     {
@@ -209,7 +217,7 @@ struct SliceCtx {
             }
             bw.ue(m.chroma_mode);
             bw.ue(cbp_to_golomb_intra[m.cbp_luma | (m.cbp_chroma << 4)]);
-            if (m.cbp_luma || m.cbp_chroma) bw.se(0);
+            if (m.cbp_luma || m.cbp_chroma) bw.se(qp_delta(m));
         } else if (m.type == X264GPU_MB_I4x4) {
             bw.ue(type_offset + 0);
             if (p.transform8x8_mode) bw.put1(0);                 // transform_size_8x8_flag
@@ -220,11 +228,11 @@ struct SliceCtx {
             }
             bw.ue(m.chroma_mode);
             bw.ue(cbp_to_golomb_intra[m.cbp_luma | (m.cbp_chroma << 4)]);
-            if (m.cbp_luma || m.cbp_chroma) bw.se(0);            // mb_qp_delta (constant QP)
+            if (m.cbp_luma || m.cbp_chroma) bw.se(qp_delta(m));  // mb_qp_delta
         } else {
             bw.ue(type_offset + 1 + m.i16_mode + 4 * m.cbp_chroma + (m.cbp_luma ? 12 : 0));
             bw.ue(m.chroma_mode);
-            bw.se(0);                                            // mb_qp_delta always present for Intra16x16
+            bw.se(qp_delta(m));                                  // mb_qp_delta always present for Intra16x16
         }
         write_residual(mbx, mby, m, lv);
     }
@@ -288,7 +296,7 @@ struct SliceCtx {
                         }
                         bw.ue(cbp_to_golomb_inter[m.cbp_luma | (m.cbp_chroma << 4)]);
                         if (p.transform8x8_mode && m.cbp_luma) bw.put1(m.transform8x8);      // every partition here is >= 8x8
-                        if (m.cbp_luma || m.cbp_chroma) bw.se(0);
+                        if (m.cbp_luma || m.cbp_chroma) bw.se(qp_delta(m));
                         write_residual(mbx, mby, m, lv);
                     }
                 }
