@@ -41,6 +41,13 @@ struct EncK {
     int chroma_me;            // sub-pel SATD costs carry chroma (subme >= 5)
     int mixed_refs;           // 8x8 blocks / 16x8, 8x16 halves pick their own reference
     unsigned long long *dbg;  // optional diagnostics (NULL in production): per (stream, wave) cycle counters
+    // adaptive quantisation (aq_mode 1): per-macroblock quantisers and the tables every quantiser-dependent value is read from
+    uint8_t *mbqp;            // [streams][nmb]; NULL = every macroblock uses the slice quantiser (the scalars above)
+    const Q4 *q4tab;          // [52][4]: luma intra, luma inter, chroma intra, chroma inter
+    const Q8 *q8tab;          // [52][2]: intra, inter
+    const int *lambda_tab;    // [52]
+    const uint16_t *cost_all; // [52][2 * MVCOST_HALF]
+    int aq_strength_q8;
     int *wf_progress;         // [streams][2][WFG_ROWS]: row counters of the wavefront kernels when ONE stream spans several workgroups
 };
 

@@ -14,6 +14,7 @@
 #include "k_intra2.cuh"
 #include "k_deblock.cuh"
 #include <math.h>
+#include <vector>
 #include <string.h>
 #include <new>
 
@@ -35,6 +36,9 @@ struct x264gpu_encoder {
     int cur = 0;
     unsigned long long *dbg = nullptr;   // diagnostics buffer set by x264gpu_encoder_set_debug
     int *wf_progress = nullptr;          // [streams][2][WFG_ROWS] row counters of the multi-workgroup wavefront kernels
+    // adaptive quantisation: per-macroblock quantisers and the per-quantiser tables (built when aq_mode != 0)
+    uint8_t *mbqp = nullptr;
+    Q4 *q4tab = nullptr; Q8 *q8tab = nullptr; int *lambda_tab = nullptr; uint16_t *cost_all = nullptr;
     // optional per-stage profiling: (NSTAGE+1) events per armed call
     hipEvent_t *ev = nullptr;
     int *ev_mask = nullptr;       // per call: bit i = stage i ran
@@ -63,6 +67,38 @@ static int build_cost_mv(x264gpu_encoder *e, int qp)
     if (er == hipSuccess) er = hipMemcpy(e->cost_mv[qp], h, 2 * MVCOST_HALF * sizeof(uint16_t), hipMemcpyHostToDevice);
     delete[] h;
     if (er != hipSuccess) return set_err(X264GPU_EHIP, "cost_mv upload", er);
+    return X264GPU_OK;
+}
+
+// every quantiser-dependent value for all 52 quantisers (adaptive quantisation reads them per macroblock)
+static int build_aq_tables(x264gpu_encoder *e)
+{
+    QuantCfg qc; qc.deadzone_inter = e->cfg.deadzone_inter; qc.deadzone_intra = e->cfg.deadzone_intra;
+    std::vector<Q4> q4(52 * 4); std::vector<Q8> q8(52 * 2); std::vector<int> lam(52);
+    std::vector<uint16_t> cost((size_t)52 * 2 * MVCOST_HALF);
+    for (int qp = 0; qp < 52; qp++) {
+        for (int l = 0; l < 4; l++) q4[qp * 4 + l] = make_q4(qp, l, qc);
+        for (int l = 0; l < 2; l++) q8[qp * 2 + l] = make_q8(qp, l, qc);
+        lam[qp] = lambda_of(qp);
+        uint16_t *h = cost.data() + (size_t)qp * 2 * MVCOST_HALF;
+        for (int i = 0; i < MVCOST_HALF; i++) {
+            float bits = log2f((float)(i + 1)) * 2.0f + 0.718f + (i ? 1.0f : 0.0f);
+            int c = (int)((float)lam[qp] * bits + 0.5f);
+            if (c > 65535) c = 65535;
+            h[MVCOST_HALF + i] = (uint16_t)c; h[MVCOST_HALF - i] = (uint16_t)c;
+        }
+        h[0] = h[1];
+    }
+    hipError_t er = hipMalloc((void **)&e->q4tab, q4.size() * sizeof(Q4));
+    if (er == hipSuccess) er = hipMalloc((void **)&e->q8tab, q8.size() * sizeof(Q8));
+    if (er == hipSuccess) er = hipMalloc((void **)&e->lambda_tab, lam.size() * sizeof(int));
+    if (er == hipSuccess) er = hipMalloc((void **)&e->cost_all, cost.size() * sizeof(uint16_t));
+    if (er == hipSuccess) er = hipMalloc((void **)&e->mbqp, (size_t)e->cfg.streams * e->k.nmb);
+    if (er == hipSuccess) er = hipMemcpy(e->q4tab, q4.data(), q4.size() * sizeof(Q4), hipMemcpyHostToDevice);
+    if (er == hipSuccess) er = hipMemcpy(e->q8tab, q8.data(), q8.size() * sizeof(Q8), hipMemcpyHostToDevice);
+    if (er == hipSuccess) er = hipMemcpy(e->lambda_tab, lam.data(), lam.size() * sizeof(int), hipMemcpyHostToDevice);
+    if (er == hipSuccess) er = hipMemcpy(e->cost_all, cost.data(), cost.size() * sizeof(uint16_t), hipMemcpyHostToDevice);
+    if (er != hipSuccess) return set_err(er == hipErrorOutOfMemory ? X264GPU_ENOMEM : X264GPU_EHIP, "aq tables", er);
     return X264GPU_OK;
 }
 
@@ -114,6 +150,7 @@ int x264gpu_encoder_create(x264gpu_encoder **out, const x264gpu_config *cfg)
     alloc((void **)&e->wf_progress, S * 2 * WFG_ROWS * sizeof(int), 0);
     if (er != hipSuccess) { x264gpu_encoder_destroy(e); return set_err(er == hipErrorOutOfMemory ? X264GPU_ENOMEM : X264GPU_EHIP, "encoder buffers", er); }
     int rc = build_cost_mv(e, cfg->qp_p);
+    if (!rc && cfg->aq_mode) rc = build_aq_tables(e);
     if (rc) { x264gpu_encoder_destroy(e); return rc; }
     *out = e;
     return X264GPU_OK;
@@ -176,6 +213,7 @@ void x264gpu_encoder_destroy(x264gpu_encoder *e)
     for (int i = 0; i < 2; i++) { (void)hipFree(e->mvf[i]); (void)hipFree(e->reff[i]); }
     for (int q = 0; q < 52; q++) (void)hipFree(e->cost_mv[q]);
     (void)hipFree(e->wf_progress);
+    (void)hipFree(e->mbqp); (void)hipFree(e->q4tab); (void)hipFree(e->q8tab); (void)hipFree(e->lambda_tab); (void)hipFree(e->cost_all);
     delete e;
 }
 
@@ -222,6 +260,11 @@ int x264gpu_encode_frames(x264gpu_encoder *e, const uint8_t *d_i420, int slice_t
 #define STAGE_MARK(i) do { if (ev) { HIP_TRY(hipEventRecord(ev[i], st)); } } while (0)
     STAGE_MARK(0);
     hipLaunchKernelGGL(k_ingest, dim3((k.cw / 4 + 255) / 256, k.ch, S), dim3(256), 0, st, k);
+    const bool aq = e->cfg.aq_mode != 0;
+    if (aq) {
+        k.mbqp = e->mbqp; k.q4tab = e->q4tab; k.q8tab = e->q8tab; k.lambda_tab = e->lambda_tab; k.cost_all = e->cost_all; k.aq_strength_q8 = e->cfg.aq_strength_q8;
+        hipLaunchKernelGGL(k_aq, dim3((k.nmb + 15) / 16, S), dim3(256), 0, st, k);
+    }
     mask |= 1;
     STAGE_MARK(1);
     if (slice_type == X264GPU_SLICE_P) {
@@ -257,10 +300,16 @@ int x264gpu_encode_frames(x264gpu_encoder *e, const uint8_t *d_i420, int slice_t
     const bool mwg = !mwg_off && S * (iwg > dwg ? iwg : dwg) <= 128 && k.mbh > 4;
     k.wf_progress = e->wf_progress;
     if (mwg) HIP_TRY(hipMemsetAsync(e->wf_progress, 0, (size_t)S * 2 * WFG_ROWS * sizeof(int), st));
-    if (intra_v1) hipLaunchKernelGGL(k_intra, dim3(S), dim3(1024), 0, st, k);
-    else if (mwg) hipLaunchKernelGGL((k_intra2<I2_WAVES_MWG, true>), dim3(S, iwg), dim3(I2_WAVES_MWG * 64), 0, st, k);
-    else if (S >= 128) hipLaunchKernelGGL((k_intra2<I2_WAVES, false>), dim3(S), dim3(I2_WAVES * 64), 0, st, k);        // CUs are full: small workgroups, two per CU
-    else hipLaunchKernelGGL((k_intra2<I2_WAVES_FEW, false>), dim3(S), dim3(I2_WAVES_FEW * 64), 0, st, k);                  // few streams: all bands of a frame at once
+    if (intra_v1 && !aq) hipLaunchKernelGGL(k_intra, dim3(S), dim3(1024), 0, st, k);
+    else if (aq) {      // per-macroblock quantisers: own instantiations (the slot carries its quantiser tables in LDS)
+        if (mwg) hipLaunchKernelGGL((k_intra2<I2_WAVES_MWG, true, true>), dim3(S, iwg), dim3(I2_WAVES_MWG * 64), 0, st, k);
+        else if (S >= 128) hipLaunchKernelGGL((k_intra2<I2_WAVES, false, true>), dim3(S), dim3(I2_WAVES * 64), 0, st, k);
+        else hipLaunchKernelGGL((k_intra2<I2_WAVES_FEW, false, true>), dim3(S), dim3(I2_WAVES_FEW * 64), 0, st, k);
+        hipLaunchKernelGGL(k_settle_qp, dim3(S), dim3(64), 0, st, k);      // QP_Y inheritance before the deblocking filter reads the records
+    }
+    else if (mwg) hipLaunchKernelGGL((k_intra2<I2_WAVES_MWG, true, false>), dim3(S, iwg), dim3(I2_WAVES_MWG * 64), 0, st, k);
+    else if (S >= 128) hipLaunchKernelGGL((k_intra2<I2_WAVES, false, false>), dim3(S), dim3(I2_WAVES * 64), 0, st, k);        // CUs are full: small workgroups, two per CU
+    else hipLaunchKernelGGL((k_intra2<I2_WAVES_FEW, false, false>), dim3(S), dim3(I2_WAVES_FEW * 64), 0, st, k);                  // few streams: all bands of a frame at once
     mask |= 8;
     STAGE_MARK(4);
     if (e->cfg.deblock) {

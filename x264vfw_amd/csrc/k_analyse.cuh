@@ -682,7 +682,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MIXED ? X26
         if (!ib && ia) { mvp0 = a0; mvp1 = a1; }
         else { mvp0 = median3(a0, b0, c0); mvp1 = median3(a1, b1, c1); }
     }
-    const uint16_t *cmx = k.cost_mv + MVCOST_HALF - mvp0, *cmy = k.cost_mv + MVCOST_HALF - mvp1;
+    // quantiser of this macroblock: the slice's, or its own under AQ (lambda and the mv-cost table follow it, as x264's a->i_qp)
+    const int mqp = k.mbqp ? (int)k.mbqp[(size_t)s * k.nmb + mbi] : k.qp, lambda = k.mbqp ? k.lambda_tab[mqp] : k.lambda;
+    const uint16_t *cost_base = k.mbqp ? k.cost_all + (size_t)mqp * 2 * MVCOST_HALF : k.cost_mv;
+    const uint16_t *cmx = cost_base + MVCOST_HALF - mvp0, *cmy = cost_base + MVCOST_HALF - mvp1;
 
     // ---- 16x16 search in every usable reference (oracle analyse_p_mb); lower index wins ties ----
     const size_t pb = k.plane_bytes;
@@ -868,7 +871,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MIXED ? X26
 
     #undef MVC
         if (MIXED) { const int pk = (mx & 0xffff) | (my << 16); if (r_ == 0) m16_0 = pk; else if (r_ == 1) m16_1 = pk; else if (r_ == 2) m16_2 = pk; else m16_3 = pk; }
-        bcost += k.lambda * ref_bits(k.nref, r_);
+        bcost += lambda * ref_bits(k.nref, r_);
         if (bcost < best16) { best16 = bcost; best_mx = mx; best_my = my; bref = r_; }
         __builtin_amdgcn_wave_barrier();
     }
@@ -916,7 +919,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MIXED ? X26
             if (oi > 0 && best_shape == 0) break;
             int smx, smy;
             const int pcost = search_parts<M, UMH>(pc, shape, c0x, c0y, smx, smy);
-            int total = k.lambda * ((shape == 3 ? 8 : 2) + (shape == 3 ? 4 : 2) * ref_bits(k.nref, bref));
+            int total = lambda * ((shape == 3 ? 8 : 2) + (shape == 3 ? 4 : 2) * ref_bits(k.nref, bref));
             if (shape == 3) total += __builtin_amdgcn_readlane(pcost, 0) + __builtin_amdgcn_readlane(pcost, 16) + __builtin_amdgcn_readlane(pcost, 32) + __builtin_amdgcn_readlane(pcost, 48);
             else if (shape == 1) total += __builtin_amdgcn_readlane(pcost, 0) + __builtin_amdgcn_readlane(pcost, 32);
             else total += __builtin_amdgcn_readlane(pcost, 0) + __builtin_amdgcn_readlane(pcost, 32);      // 8x16: partitions on lanes 0.. and 32..
@@ -983,11 +986,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MIXED ? X26
                 int smx, smy;
                 const int pcost = search_parts<M, UMH>(pc, shape, c0x, c0y, smx, smy);
                 if (shape == 2) { smx = __shfl(smx, (lane >> 5) * 16); smy = __shfl(smy, (lane >> 5) * 16); }      // back to partition lanes
-                const unsigned key = ((unsigned)(pcost + (mixed ? k.lambda * ref_bits(k.nref, r) : 0)) << 1) | (mixed && ph > 0 && r != first_ref ? 1u : 0u);
+                const unsigned key = ((unsigned)(pcost + (mixed ? lambda * ref_bits(k.nref, r) : 0)) << 1) | (mixed && ph > 0 && r != first_ref ? 1u : 0u);
                 if (need && key < pkey) { pkey = key; pmx = smx; pmy = smy; pref = r; }
             }
             const int pcst = (int)(pkey >> 1);
-            int total = k.lambda * ((shape == 3 ? 8 : 2) + (mixed ? 0 : (shape == 3 ? 4 : 2) * ref_bits(k.nref, bref)));
+            int total = lambda * ((shape == 3 ? 8 : 2) + (mixed ? 0 : (shape == 3 ? 4 : 2) * ref_bits(k.nref, bref)));
             if (shape == 3) total += __builtin_amdgcn_readlane(pcst, 0) + __builtin_amdgcn_readlane(pcst, 16) + __builtin_amdgcn_readlane(pcst, 32) + __builtin_amdgcn_readlane(pcst, 48);
             else total += __builtin_amdgcn_readlane(pcst, 0) + __builtin_amdgcn_readlane(pcst, 32);                  // two partitions, on lanes 0.. and 32..
             if (ph == 0) ref8 = pref;
@@ -1018,7 +1021,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MIXED ? X26
         else { modes[0] = PRED16_DC_128; n = 1; }
         for (int i = 0; i < n; i++) {
             const int m = modes[i], sig = m > PRED16_P ? PRED16_DC : m;
-            const int c = wave_sum(satd4_half(cz, pred16_row4(nb, pp, m, zx, zy), lane)) + k.lambda * bs_size_ue(sig);
+            const int c = wave_sum(satd4_half(cz, pred16_row4(nb, pp, m, zx, zy), lane)) + lambda * bs_size_ue(sig);
             icost = min(icost, c);
         }
     }
@@ -1051,7 +1054,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MIXED ? X26
         for (int i = 0; i < n; i++) {
             const int m = modes[i], sig = m > PREDC_P ? PREDC_DC : m;
             const int hs = satd4_half(cenc, predc_row4(cnb, pc, m, ci, j), lane);
-            bestc = min(bestc, wave_sum(lane < 32 ? hs : 0) + k.lambda * bs_size_ue(sig));
+            bestc = min(bestc, wave_sum(lane < 32 ? hs : 0) + lambda * bs_size_ue(sig));
         }
         icost += bestc;
     }
@@ -1066,7 +1069,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MIXED ? X26
         x264gpu_mb *mb = k.mb + (size_t)s * k.nmb + mbi;
         x264gpu_mb rec;
         __builtin_memset(&rec, 0, sizeof(rec));
-        rec.qp = (uint8_t)k.qp;
+        rec.qp = (uint8_t)mqp;
         rec.aux[0] = bcost; rec.aux[1] = icost; rec.aux[2] = cost16;
         int16_t *mo = k.mvf_cur + ((size_t)s * k.nmb + mbi) * 2;
         if (icost < bcost) {

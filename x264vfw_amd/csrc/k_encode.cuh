@@ -46,6 +46,10 @@ __global__ __launch_bounds__(256) void k_encode_inter(EncK k)
     int16_t *lv = k.levels + ((size_t)s * k.nmb + mbi) * X264GPU_MB_LEVELS;
     const uint8_t *fenc = k.fenc_y + (size_t)s * k.fency_bytes + (size_t)py * k.fs + px;
     const int j = lane & 3, blk = lane >> 2, zx = z_x0(lane), zy = z_y(lane);
+    // quantiser of this macroblock: the slice's, or its own under AQ (wave-uniform table reads)
+    const int mqp = k.mbqp ? mbp->qp : k.qp, mqpc = k.mbqp ? (int)d_chroma_qp_table[min(max(mqp + k.chroma_qp_offset, 0), 51)] : k.qpc;
+    const Q4 q_luma_inter = k.mbqp ? k.q4tab[mqp * 4 + 1] : k.q_luma_inter, q_chroma_inter = k.mbqp ? k.q4tab[mqpc * 4 + 3] : k.q_chroma_inter;
+    const Q8 q8_inter = k.mbqp ? k.q8tab[mqp * 2 + 1] : k.q8_inter;
 
     // ---- luma ----
     const int refidx = mbp->ref[lane >> 4];         // the reference is per 8x8 block (mixed refs)
@@ -71,7 +75,7 @@ __global__ __launch_bounds__(256) void k_encode_inter(EncK k)
         for (int i = 0; i < 8; i++) v[i] = e[i] - p[i];
         fwd8_1d(v); transpose8(v, lane); fwd8_1d(v); transpose8(v, lane);
         int mf[4], bs[4], dq[4];
-        q8_row(k.q8_inter, row, mf, bs, dq);
+        q8_row(q8_inter, row, mf, bs, dq);
         unsigned mlo = 0, mhi = 0, big = 0;
 #pragma unroll
         for (int i = 0; i < 8; i++) {
@@ -106,7 +110,7 @@ __global__ __launch_bounds__(256) void k_encode_inter(EncK k)
             nnz |= ng << (4 * g);
             cbp_luma |= ng ? 1 << g : 0;
         }
-        const int qb = k.q8_inter.qp / 6 - 6;
+        const int qb = q8_inter.qp / 6 - 6;
 #pragma unroll
         for (int i = 0; i < 8; i++) v[i] = keep ? dequant_one(v[i], dq[i & 3], qb) : 0;
         inv8_1d(v); transpose8(v, lane); inv8_1d(v); transpose8(v, lane);        // 8.5.13: rows first, then columns
@@ -123,7 +127,7 @@ __global__ __launch_bounds__(256) void k_encode_inter(EncK k)
 #pragma unroll
     for (int i = 0; i < 4; i++) v[i] = e[i] - p[i];
     dct4_quad(v, lane);
-    quant4_row(v, k.q_luma_inter, j);
+    quant4_row(v, q_luma_inter, j);
     const unsigned mask = (unsigned)quad_or((int)scan_mask(v, j));
     const bool nz = mask != 0;
     bool keep = nz;
@@ -138,7 +142,7 @@ __global__ __launch_bounds__(256) void k_encode_inter(EncK k)
     }
     { int z[4] = { 0, 0, 0, 0 }; store_levels_scan(lv + blk * 16, keep ? v : z, j); }
     if (!keep) v[0] = v[1] = v[2] = v[3] = 0;
-    dequant4_row(v, k.q_luma_inter, j);
+    dequant4_row(v, q_luma_inter, j);
     idct4_quad(v, lane);
 #pragma unroll
     for (int i = 0; i < 4; i++) v[i] += p[i];
@@ -158,7 +162,7 @@ __global__ __launch_bounds__(256) void k_encode_inter(EncK k)
     const uint2 fe = *(const uint2 *)fuv;
     const uint32_t cenc = nv12_pick(fe.x, fe.y, c), cpred = c ? pv : pu;
     int cbp_chroma = 0;
-    const uint32_t crec = chroma_residual(cenc, cpred, k.q_chroma_inter, true, k.dct_decimate != 0, lane, lv, nnz, cbp_chroma);
+    const uint32_t crec = chroma_residual(cenc, cpred, q_chroma_inter, true, k.dct_decimate != 0, lane, lv, nnz, cbp_chroma);
     // interleave U (lanes 0..15) with V (lanes 16..31) and store 8 NV12 bytes from the U lanes
     const uint32_t other = (uint32_t)__shfl_xor((int)crec, 16);
     if (lane < 16) {
@@ -175,6 +179,69 @@ __global__ __launch_bounds__(256) void k_encode_inter(EncK k)
         mbp->cbp_luma = (uint8_t)cbp_luma;
         mbp->transform8x8 = (uint8_t)(t8 && cbp_luma);     // not transmitted without luma coefficients
         mbp->cbp_chroma = (uint8_t)cbp_chroma;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Adaptive quantisation, mode 1 (oracle compute_mb_qp; x264_adaptive_quant_frame): one 16-lane row per macroblock — lane r sums row
+// r of the luma macroblock and, for r < 8, row r of both chroma planes; the AC energy -> log2 in Q8 (table) -> quantiser offset.
+// ------------------------------------------------------------------------------------------------
+static __constant__ uint8_t c_aq_log2_lut[128] = {
+#include "x264gpu_aq_lut.inc"
+};
+__global__ __launch_bounds__(256) void k_aq(EncK k)
+{
+    const int lane = threadIdx.x & 63, r = lane & 15, s = blockIdx.y;
+    const int mbi = (blockIdx.x * 4 + (threadIdx.x >> 6)) * 4 + (lane >> 4);
+    const bool valid = mbi < k.nmb;
+    const int mi = valid ? mbi : 0, mbx = mi % k.mbw, mby = mi / k.mbw;
+    const uint8_t *y = k.fenc_y + (size_t)s * k.fency_bytes + (size_t)(mby * 16 + r) * k.fs + mbx * 16;
+    unsigned sum = 0, sqr = 0, su = 0, squ = 0, sv = 0, sqv = 0;
+    const uint4 v = *(const uint4 *)y;
+    const uint32_t w[4] = { v.x, v.y, v.z, v.w };
+#pragma unroll
+    for (int i = 0; i < 4; i++)
+#pragma unroll
+        for (int b = 0; b < 4; b++) { const unsigned p = (w[i] >> (8 * b)) & 0xff; sum += p; sqr += p * p; }
+    if (r < 8) {
+        const uint8_t *uv = k.fenc_uv + (size_t)s * k.fencuv_bytes + (size_t)(mby * 8 + r) * k.fs + mbx * 16;
+        const uint4 c = *(const uint4 *)uv;
+        const uint32_t cw[4] = { c.x, c.y, c.z, c.w };
+#pragma unroll
+        for (int i = 0; i < 4; i++)
+#pragma unroll
+            for (int b = 0; b < 4; b++) { const unsigned p = (cw[i] >> (8 * b)) & 0xff; if (b & 1) { sv += p; sqv += p * p; } else { su += p; squ += p * p; } }
+    }
+    sum = (unsigned)row16_sum((int)sum); sqr = (unsigned)row16_sum((int)sqr);
+    su = (unsigned)row16_sum((int)su); squ = (unsigned)row16_sum((int)squ); sv = (unsigned)row16_sum((int)sv); sqv = (unsigned)row16_sum((int)sqv);
+    const unsigned energy = (sqr - (sum * sum >> 8)) + (squ - (su * su >> 6)) + (sqv - (sv * sv >> 6));
+    const unsigned e1 = energy ? energy : 1u;
+    const int lz = 31 - __builtin_clz(e1), lg = lz * 256 + c_aq_log2_lut[((e1 << (31 - lz)) >> 24) & 0x7f];
+    const int adj = (k.aq_strength_q8 * (lg - 3693)) >> 8;
+    if (valid && r == 0) k.mbqp[(size_t)s * k.nmb + mbi] = (uint8_t)min(max(k.qp + ((adj + 128) >> 8), 1), 51);
+}
+
+// QP_Y inheritance (oracle settle_mb_qp, 7.4.5): a macroblock that sends no mb_qp_delta takes its predecessor's quantiser; one wave per
+// stream walks the records 64 at a time (ballot of the macroblocks that keep their own value, highest one at or below each lane).
+__global__ __launch_bounds__(64) void k_settle_qp(EncK k)
+{
+    const int lane = threadIdx.x, s = blockIdx.x;
+    x264gpu_mb *mbs = k.mb + (size_t)s * k.nmb;
+    int carry = k.qp;
+    for (int base = 0; base < k.nmb; base += 64) {
+        const int i = base + lane;
+        const bool in = i < k.nmb;
+        int qp = 0;
+        bool own = false;
+        if (in) { const x264gpu_mb *m = mbs + i; qp = m->qp; own = m->type == X264GPU_MB_I16x16 || m->cbp_luma || m->cbp_chroma; }
+        const unsigned long long owners = __ballot(own);
+        const unsigned long long below = owners & (lane == 63 ? ~0ull : ((2ull << lane) - 1));
+        const int src = below ? 63 - __builtin_clzll(below) : -1;
+        const int from = __shfl(qp, src < 0 ? 0 : src);
+        const int settled = src < 0 ? carry : from;
+        if (in && !own) mbs[i].qp = (uint8_t)settled;
+        const int last = min(k.nmb - base, 64) - 1;
+        carry = __shfl(settled, last);
     }
 }
 

@@ -35,6 +35,8 @@ struct SlotLds {
     uint8_t cnb[2][CNB_SIZE];
     uint8_t modes[16], modes8[16], nmodes[8];
     int info[12];                                       // see enum below
+    // adaptive quantisation: this macroblock's quantiser-dependent values (filled per macroblock in phase A; unused otherwise)
+    struct { Q4 ql, qc; Q8 q8; int qp, lambda; } q;
 };
 enum { SI_BEST16 = 0, SI_MODE16, SI_COST8, SI_DONE8, SI_NNZ8, SI_CBP8, SI_COST4, SI_NNZ4, SI_MBX, SI_MBY };
 template <int NW>
@@ -46,6 +48,7 @@ struct Intra2LdsT {
 };
 
 // ---- phase A: neighbours of macroblock (mbx,mby) into the slot's LDS, Intra16x16 decision -------------------------
+template <bool AQ>
 __device__ __forceinline__ void i2_phase_a(const EncK &k, SlotLds &S, int lane, int s, int mbx, int mby)
 {
     uint8_t *tile = S.tile + IT_ORG, *tile8 = S.tile8 + IT_ORG, *nb = S.nb;
@@ -55,7 +58,21 @@ __device__ __forceinline__ void i2_phase_a(const EncK &k, SlotLds &S, int lane, 
     uint8_t *rec = rec_plane00(k, s) + (size_t)py * k.rs + px;
     const bool left = mbx > 0, top = mby > 0, topright = top && mbx + 1 < k.mbw;
     const int zx = z_x0(lane), zy = z_y(lane);
-    const int lambda = k.lambda;
+    if (AQ) {
+        // this macroblock's quantiser and everything derived from it, from the per-quantiser tables into the slot
+        const int qp = k.mbqp[(size_t)s * k.nmb + mbi], qpc = d_chroma_qp_table[min(max(qp + k.chroma_qp_offset, 0), 51)];
+        const int *a = (const int *)&k.q4tab[qp * 4 + 0], *b = (const int *)&k.q4tab[qpc * 4 + 2], *c = (const int *)&k.q8tab[qp * 2 + 0];
+        int *d = (int *)&S.q;
+        constexpr int N4 = sizeof(Q4) / 4, N8 = sizeof(Q8) / 4;
+        if (lane < N4) d[lane] = a[lane];
+        else if (lane < 2 * N4) d[lane] = b[lane - N4];
+        else if (lane < 2 * N4 + N8) d[lane] = c[lane - 2 * N4];
+        else if (lane == 2 * N4 + N8) d[lane] = qp;
+        else if (lane == 2 * N4 + N8 + 1) d[lane] = k.lambda_tab[qp];
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_s_waitcnt(0xc07f);
+    }
+    const int lambda = AQ ? S.q.lambda : k.lambda;
     // ---- neighbours: row -1 (x = -1..19) and column -1 into the tile; nb[] for the 16x16 predictors ----
         if (lane < 25) {                           // x = -1..23: the top-right 8 samples serve Intra_8x8 block 1
         const int x = lane - 1;
@@ -107,6 +124,7 @@ __device__ __forceinline__ void i2_phase_a(const EncK &k, SlotLds &S, int lane, 
 }
 
 // ---- phase C: final choice, record, Intra16x16 encode, chroma ---------------------------------------------------
+template <bool AQ>
 __device__ __forceinline__ void i2_phase_c(const EncK &k, SlotLds &S, int lane, int s, int mbx, int mby)
 {
     uint8_t *tile = S.tile + IT_ORG, *tile8 = S.tile8 + IT_ORG, *nb = S.nb;
@@ -116,7 +134,8 @@ __device__ __forceinline__ void i2_phase_c(const EncK &k, SlotLds &S, int lane, 
     uint8_t *rec = rec_plane00(k, s) + (size_t)py * k.rs + px;
     const bool left = mbx > 0, top = mby > 0;
     const int j = lane & 3, zx = z_x0(lane), zy = z_y(lane);
-    const int qp = k.qp, lambda = k.lambda;
+    const int qp = AQ ? S.q.qp : k.qp, lambda = AQ ? S.q.lambda : k.lambda;
+    const Q4 &q_luma_intra = AQ ? S.q.ql : k.q_luma_intra, &q_chroma_intra = AQ ? S.q.qc : k.q_chroma_intra;
     const uint32_t cz = *(const uint32_t *)(S.src + zy * 16 + zx);
     const Pred16 pp = pred16_setup(nb, lane);
     const int best16 = S.info[SI_BEST16], mode16 = S.info[SI_MODE16];
@@ -164,10 +183,10 @@ __device__ __forceinline__ void i2_phase_c(const EncK &k, SlotLds &S, int lane, 
         dct4_quad(v, lane);
         const int dcv = v[0];                      // meaningful on j == 0 lanes
         if (j == 0) v[0] = 0;
-        quant4_row(v, k.q_luma_intra, j);
+        quant4_row(v, q_luma_intra, j);
         const bool nz = quad_or((v[0] | v[1] | v[2] | v[3]) != 0 ? 1 : 0) != 0;
         store_levels_scan(lv + (lane >> 2) * 16, v, j);
-        dequant4_row(v, k.q_luma_intra, j);
+        dequant4_row(v, q_luma_intra, j);
         const unsigned long long bal = __ballot(nz && j == 0);
         unsigned acn = 0;
 #pragma unroll
@@ -178,12 +197,12 @@ __device__ __forceinline__ void i2_phase_c(const EncK &k, SlotLds &S, int lane, 
         for (int c = 0; c < 4; c++) dc[c] = __shfl(dcv, 4 * blkidx_of(c, j));
         had4x4_quad(dc, lane);
 #pragma unroll
-        for (int c = 0; c < 4; c++) dc[c] = quant_one((dc[c] + 1) >> 1, k.q_luma_intra.mf[0] >> 1, k.q_luma_intra.bias[0] << 1);
+        for (int c = 0; c < 4; c++) dc[c] = quant_one((dc[c] + 1) >> 1, q_luma_intra.mf[0] >> 1, q_luma_intra.bias[0] << 1);
         const bool nzdc = quad_or((dc[0] | dc[1] | dc[2] | dc[3]) != 0 ? 1 : 0) != 0;
         if (lane < 4) store_levels_scan(lv + X264GPU_LV_LUMA_DC, dc, j);
         had4x4_quad(dc, lane);
         {
-            const int ls = k.q_luma_intra.dq[0], qb = qp / 6 - 6;
+            const int ls = q_luma_intra.dq[0], qb = qp / 6 - 6;
 #pragma unroll
             for (int c = 0; c < 4; c++) dc[c] = dequant_one(dc[c], ls, qb);
         }
@@ -241,7 +260,7 @@ __device__ __forceinline__ void i2_phase_c(const EncK &k, SlotLds &S, int lane, 
         const uint32_t cpred = predc_row4(cnb, pc, bestm, ci, j);
         int cbp_chroma = 0;
         unsigned nn = recd.nnz;
-        const uint32_t crec = chroma_residual(cenc, cpred, k.q_chroma_intra, false, false, lane, lv, nn, cbp_chroma);
+        const uint32_t crec = chroma_residual(cenc, cpred, q_chroma_intra, false, false, lane, lv, nn, cbp_chroma);
         recd.nnz = nn;
         recd.cbp_chroma = (uint8_t)cbp_chroma;
         const uint32_t other = (uint32_t)__shfl_xor((int)crec, 16);
@@ -258,14 +277,16 @@ __device__ __forceinline__ void i2_phase_c(const EncK &k, SlotLds &S, int lane, 
 
 // ---- phase B: Intra8x8 then Intra4x4 of the four slots side by side -----------------------------------------------
 // lane = (slot, 16 lanes).  Values that are uniform inside a slot (costs, modes, availability) live in VGPRs here.
-template <class LDS>
+template <bool AQ, class LDS>
 __device__ __forceinline__ void i2_phase_b(const EncK &k, LDS &L, SlotLds *slots, int lane, int s, unsigned active)
 {
     const int sl = lane >> 4, l16 = lane & 15;
     SlotLds &S = slots[sl];
     const bool act = (active >> sl) & 1;
     const int mbx = S.info[SI_MBX], mby = S.info[SI_MBY], best16 = S.info[SI_BEST16];
-    const int lambda = k.lambda;
+    const int lambda = AQ ? S.q.lambda : k.lambda;
+    const Q4 &q_luma_intra = AQ ? S.q.ql : k.q_luma_intra;
+    const Q8 &q8_intra = AQ ? S.q.q8 : k.q8_intra;
     const bool left = mbx > 0, top = mby > 0, topright = top && mbx + 1 < k.mbw;
 
     // ================= Intra8x8: half h of the slot evaluates modes h, h+2, h+4, h+6 (+ mode 8 on half 0) =================
@@ -363,7 +384,7 @@ __device__ __forceinline__ void i2_phase_b(const EncK &k, LDS &L, SlotLds *slots
             for (int i = 0; i < 8; i++) v[i] = e[i] - p[i];
             fwd8_1d(v); transpose8(v, lane); fwd8_1d(v); transpose8(v, lane);
             int mf[4], bs[4], dq[4];
-            q8_row(k.q8_intra, r8, mf, bs, dq);
+            q8_row(q8_intra, r8, mf, bs, dq);
             unsigned mlo = 0, mhi = 0;
 #pragma unroll
             for (int i = 0; i < 8; i++) {
@@ -377,7 +398,7 @@ __device__ __forceinline__ void i2_phase_b(const EncK &k, LDS &L, SlotLds *slots
 #pragma unroll
             for (int q = 0; q < 4; q++) nnz8 |= (mask & (0x1111111111111111ull << q)) ? 1u << (i8 * 4 + q) : 0u;
             if (mask) cbp8 |= 1 << i8;
-            const int qb = k.q8_intra.qp / 6 - 6;
+            const int qb = q8_intra.qp / 6 - 6;
 #pragma unroll
             for (int i = 0; i < 8; i++) v[i] = dequant_one(v[i], dq[i & 3], qb);
             inv8_1d(v); transpose8(v, lane); inv8_1d(v); transpose8(v, lane);
@@ -429,10 +450,10 @@ __device__ __forceinline__ void i2_phase_b(const EncK &k, LDS &L, SlotLds *slots
 #pragma unroll
             for (int t = 0; t < 4; t++) v[t] = e[t] - p[t];
             dct4_quad(v, lane);
-            quant4_row(v, k.q_luma_intra, j);
+            quant4_row(v, q_luma_intra, j);
             const bool nz = quad_or((v[0] | v[1] | v[2] | v[3]) != 0 ? 1 : 0) != 0;
             if (act && q == 0) store_levels_scan(lvp + b * 16, v, j);
-            dequant4_row(v, k.q_luma_intra, j);
+            dequant4_row(v, q_luma_intra, j);
             idct4_quad(v, lane);
 #pragma unroll
             for (int t = 0; t < 4; t++) v[t] += p[t];
@@ -470,7 +491,7 @@ __device__ __forceinline__ int i2_next_intra(const EncK &k, const x264gpu_mb *mb
 #ifndef X264GPU_I2_OCC
 #define X264GPU_I2_OCC 4          // waves per SIMD the register allocator targets (2 -> up to 256 VGPRs, 4 -> 128)
 #endif
-template <int NW, bool MWG>
+template <int NW, bool MWG, bool AQ>
 __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(X264GPU_I2_OCC, 8))) void k_intra2(EncK kk)
 {
     __shared__ __attribute__((aligned(16))) Intra2LdsT<NW> L;
@@ -514,15 +535,15 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(X264GPU
             wfp_acquire<MWG>();
 #pragma unroll 1
             for (int i = 0; i < 4; i++)            // one copy of the phase code (instruction-cache footprint), slot chosen at run time
-                if (act >> i & 1) { i2_phase_a(k, slots[i], lane, s, i == 0 ? x[0] : i == 1 ? x[1] : i == 2 ? x[2] : x[3], r0 + i); __builtin_amdgcn_sched_barrier(0); }
+                if (act >> i & 1) { i2_phase_a<AQ>(k, slots[i], lane, s, i == 0 ? x[0] : i == 1 ? x[1] : i == 2 ? x[2] : x[3], r0 + i); __builtin_amdgcn_sched_barrier(0); }
             const unsigned long long c1 = k.dbg ? clock64() : 0;
             __builtin_amdgcn_sched_barrier(0);
-            i2_phase_b(k, L, slots, lane, s, act);
+            i2_phase_b<AQ>(k, L, slots, lane, s, act);
             __builtin_amdgcn_sched_barrier(0);
             const unsigned long long c2 = k.dbg ? clock64() : 0;
 #pragma unroll 1
             for (int i = 0; i < 4; i++)
-                if (act >> i & 1) { __builtin_amdgcn_sched_barrier(0); i2_phase_c(k, slots[i], lane, s, i == 0 ? x[0] : i == 1 ? x[1] : i == 2 ? x[2] : x[3], r0 + i); }
+                if (act >> i & 1) { __builtin_amdgcn_sched_barrier(0); i2_phase_c<AQ>(k, slots[i], lane, s, i == 0 ? x[0] : i == 1 ? x[1] : i == 2 ? x[2] : x[3], r0 + i); }
             if (k.dbg) { const unsigned long long c3 = clock64(); tA += c1 - c0; tB += c2 - c1; tC += c3 - c2; nstep++; nslot += __builtin_popcount(act); }
             wfp_release<MWG>();
 #pragma unroll
