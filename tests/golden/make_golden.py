@@ -25,7 +25,8 @@ CASES = [("p176x144", 176, 144, 5, {}), ("p208x120_q30", 208, 120, 3, dict(qp_i=
          ("p208x120_i8x8_only", 208, 120, 3, dict(partitions=4, dct8x8=1, qp_i=24, qp_p=27)),
          ("p176x144_medium_chroma_me", 176, 144, 5, dict(refs=3, partitions=7, dct8x8=1, chroma_me=1)),
          ("p176x144_lowqp_umh", 176, 144, 4, dict(qp_i=10, qp_p=13, refs=2, partitions=7, dct8x8=1, chroma_me=1, me_method=2)),
-         ("p176x144_x264_medium_me", 176, 144, 6, dict(refs=3, partitions=7, dct8x8=1, chroma_me=1, mixed_refs=1))]
+         ("p176x144_x264_medium_me", 176, 144, 6, dict(refs=3, partitions=7, dct8x8=1, chroma_me=1, mixed_refs=1)),
+         ("p176x144_aq", 176, 144, 4, dict(refs=2, partitions=7, dct8x8=1, chroma_me=1, aq_mode=1, aq_strength_q8=266, qp_i=23, qp_p=26))]
 
 
 def sha(a):

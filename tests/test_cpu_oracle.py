@@ -34,7 +34,7 @@ def test_prim_golden_vectors():
             np.testing.assert_array_equal(r, g[f"rec_q{qp}_l{lst}"])
 
 
-@pytest.mark.parametrize("case", ["p176x144", "p208x120_q30", "p64x48_nodeblock", "p176x144_medium", "p208x120_i8x8_only", "p176x144_medium_chroma_me", "p176x144_lowqp_umh", "p176x144_x264_medium_me"])
+@pytest.mark.parametrize("case", ["p176x144", "p208x120_q30", "p64x48_nodeblock", "p176x144_medium", "p208x120_i8x8_only", "p176x144_medium_chroma_me", "p176x144_lowqp_umh", "p176x144_x264_medium_me", "p176x144_aq"])
 def test_pipeline_golden(case):
     js = json.load(open(os.path.join(GOLD, "oracle_pipeline.json")))[case]
     w, h = js["w"], js["h"]

@@ -252,7 +252,8 @@ def test_crf_follows_the_lookahead_complexity(gpu):
     assert [r[1] for r in rows] == qps, (qps, rows)
     assert len(set(qps)) > 1 and rows[5][0] == 1                     # the cut is an IDR and the quantiser moves with the content
     dec = O.h264_decode(stream, len(frames), w, h)
-    og = O.OracleEncoder(O.default_config(w, h, partitions=7, refs=3, dct8x8=1, chroma_me=1, mixed_refs=1))
+    assert eff.rc.i_aq_mode == 1                                    # x264's default: variance AQ rides on CRF
+    og = O.OracleEncoder(O.default_config(w, h, partitions=7, refs=3, dct8x8=1, chroma_me=1, mixed_refs=1, aq_mode=1, aq_strength_q8=266))
     for i, f in enumerate(frames):
         np.testing.assert_array_equal(dec[i], recons[i], err_msg=f"decoded picture {i}")
         og.set_qp(rows[i][1], rows[i][1])

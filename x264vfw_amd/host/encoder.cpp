@@ -175,7 +175,7 @@ x264_t *x264_encoder_open(x264_param_t *param)
     p.analyse.b_transform_8x8 = p.analyse.b_transform_8x8 != 0;
     p.analyse.inter &= X264_ANALYSE_I4x4 | X264_ANALYSE_I8x8 | X264_ANALYSE_PSUB16x16; p.analyse.intra &= X264_ANALYSE_I4x4 | X264_ANALYSE_I8x8;
     if (!p.analyse.b_transform_8x8) { p.analyse.inter &= ~X264_ANALYSE_I8x8; p.analyse.intra &= ~X264_ANALYSE_I8x8; }   // as x264 validate_parameters
-    p.analyse.i_trellis = 0; p.rc.b_mb_tree = 0; p.rc.i_aq_mode = X264_AQ_NONE; p.rc.i_lookahead = 0;
+    p.analyse.i_trellis = 0; p.rc.b_mb_tree = 0; p.rc.i_lookahead = 0;
     p.i_scenecut_threshold = clampi(p.i_scenecut_threshold, 0, 100);
     if (p.analyse.i_me_method > X264_ME_UMH) { xlog(&p, X264_LOG_WARNING, "me esa/tesa are not implemented in the MI355X path yet: me umh\n"); p.analyse.i_me_method = X264_ME_UMH; }
     p.analyse.i_me_range = clampi(p.analyse.i_me_range, 4, p.analyse.i_me_method == X264_ME_UMH ? 64 : 16);     // x264 caps dia/hex at 16
@@ -194,6 +194,9 @@ x264_t *x264_encoder_open(x264_param_t *param)
     if (qp < 1) { xlog(&p, X264_LOG_WARNING, "lossless is not supported: qp 1\n"); qp = 1; }
     if (!h->crf && !h->abr) p.rc.i_rc_method = X264_RC_CQP;
     p.rc.i_vbv_max_bitrate = 0; p.rc.i_vbv_buffer_size = 0;
+    // adaptive quantisation: variance AQ (mode 1) under CRF / ABR; x264 itself switches AQ off under constant QP and at strength 0
+    if (p.rc.i_rc_method == X264_RC_CQP || p.rc.f_aq_strength <= 0) p.rc.i_aq_mode = X264_AQ_NONE;
+    if (p.rc.i_aq_mode > X264_AQ_VARIANCE) { xlog(&p, X264_LOG_WARNING, "aq-mode %d is not implemented yet: aq-mode 1\n", p.rc.i_aq_mode); p.rc.i_aq_mode = X264_AQ_VARIANCE; }
     p.rc.i_qp_constant = clampi(qp, 1, 51);
     p.rc.i_qp_min = clampi(p.rc.i_qp_min, 1, 51); p.rc.i_qp_max = clampi(p.rc.i_qp_max, p.rc.i_qp_min, 51);
     if (p.i_threads > 1 && p.i_scenecut_threshold) { xlog(&p, X264_LOG_INFO, "scenecut needs threads 1 (GOPs in lock-step have a fixed structure): scenecut 0\n"); p.i_scenecut_threshold = 0; }
@@ -231,6 +234,7 @@ x264_t *x264_encoder_open(x264_param_t *param)
                      0x100 | ((p.analyse.intra & X264_ANALYSE_I4x4) ? 0x200 : 0) | ((p.analyse.intra & X264_ANALYSE_I8x8) ? 0x400 : 0);
     cfg.dct8x8 = p.analyse.b_transform_8x8;
     cfg.me_method = p.analyse.i_me_method == X264_ME_DIA ? 0 : p.analyse.i_me_method == X264_ME_HEX ? 1 : 2;
+    cfg.aq_mode = p.rc.i_aq_mode == X264_AQ_VARIANCE; cfg.aq_strength_q8 = (int)(p.rc.f_aq_strength * 1.0397f * 256.0f + 0.5f);
     cfg.mixed_refs = p.analyse.b_mixed_references && (p.analyse.inter & X264_ANALYSE_PSUB16x16) != 0;
     cfg.chroma_me = p.analyse.b_chroma_me && p.analyse.i_subpel_refine >= 5;     // x264: h->mb.b_chroma_me in P slices
     size_t insz = (size_t)p.i_width * p.i_height * 3 / 2;
