@@ -46,6 +46,8 @@ int x264gpu_pixel_metric(int metric, const uint8_t *d_a, const uint8_t *d_b, int
                          int32_t *d_out, void *stream);
 /* pixel_var_{16x16,8x8}: out[i] = sum | (sqr << 32) */
 int x264gpu_pixel_var(const uint8_t *d_a, int n, int w, int h, uint64_t *d_out, void *stream);
+/* pixel_hadamard_ac_{16x16,16x8,8x16,8x8} (psy-RD energy, A3 / A11): out[i] = ((sum8 >> 2) << 32) | (sum4 >> 1), DC terms removed */
+int x264gpu_pixel_hadamard_ac(const uint8_t *d_a, int n, int w, int h, uint64_t *d_out, void *stream);
 
 /* A6/A7/A8: sub4x4_dct -> quant_4x4 -> (levels out) -> dequant_4x4 -> add4x4_idct, per 4x4 block
  * ([x264-upstream] common/dct.c, common/quant.c).  enc/pred: n blocks of 4x4 u8.  Outputs (any may be

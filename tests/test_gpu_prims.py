@@ -52,6 +52,21 @@ def test_pixel_var(gpu, w, h):
     np.testing.assert_array_equal(out.cpu().numpy().view(np.uint64), ref)
 
 
+@pytest.mark.parametrize("w,h", [(16, 16), (8, 8), (8, 16), (16, 8)])
+@pytest.mark.parametrize("kind", ["rand", "flat", "extreme"])
+def test_pixel_hadamard_ac(gpu, w, h, kind):
+    """pixel_hadamard_ac (psy-RD energy): AC sums of the 4x4 and 8x8 Hadamard transforms of source blocks, packed as x264 does"""
+    import torch
+    rng = np.random.default_rng(11)
+    n = 77
+    a = blocks(rng, n, h, w, kind)
+    out = torch.empty(n, dtype=torch.int64, device="cuda")
+    da = dev(a)
+    gpu.check(gpu.x264gpu_pixel_hadamard_ac(da.data_ptr(), n, w, h, out.data_ptr(), None))
+    ref = np.array([O.L.x264o_hadamard_ac(O.ptr(a, i * w * h), w, w, h) for i in range(n)], np.uint64)
+    np.testing.assert_array_equal(out.cpu().numpy().view(np.uint64), ref)
+
+
 @pytest.mark.parametrize("qp", [0, 5, 12, 23, 24, 26, 35, 36, 37, 51])
 @pytest.mark.parametrize("lst", [0, 1, 2, 3])
 def test_dctq4x4(gpu, qp, lst):

@@ -106,6 +106,31 @@ __global__ __launch_bounds__(256) void k_intra_predict(int kind, const uint8_t *
 
 }  // namespace
 
+// ------------------------------------------------------------------------------------------------
+// pixel_hadamard_ac ([x264-upstream] common/pixel.c; psy-RD's energy term): AC energy of the 4x4 and of the 8x8
+// Hadamard transforms of a SOURCE block.  R8 layout: lane = (8x8 sub-block, row), 8 pixels per lane; the packed-16 SATD / SA8D helpers
+// run on the pixels themselves (prediction = 0), both DC terms are the sub-block's pixel sum.  One wave per block (w x h in
+// {16x16, 8x16, 16x8, 8x8}); out = ((sum8 >> 2) << 32) | (sum4 >> 1) as x264 packs it.
+// ------------------------------------------------------------------------------------------------
+namespace {
+__global__ __launch_bounds__(256) void k_hadamard_ac(const uint8_t *__restrict__ a, int n, int w, int h, uint64_t *__restrict__ out)
+{
+    const int lane = threadIdx.x & 63, idx = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (idx >= n) return;
+    const int nsub = (w >> 3) * (h >> 3), sub = lane >> 3, row = lane & 7;
+    const bool act = sub < nsub;
+    const int sx = act ? (sub % (w >> 3)) * 8 : 0, sy = act ? (sub / (w >> 3)) * 8 : 0;
+    const uint2 v = act ? *(const uint2 *)(a + (size_t)idx * w * h + (size_t)(sy + row) * w + sx) : make_uint2(0, 0);
+    int p[8];
+    unpack8(v.x, v.y, p);
+    const int psum = p[0] + p[1] + p[2] + p[3] + p[4] + p[5] + p[6] + p[7];
+    const int h4 = satd4_half(v.x, 0u, lane) + satd4_half(v.y, 0u, lane), h8 = sa8d_r8_half(v.x, v.y, 0u, 0u, lane);
+    // per wave: sum over the active sub-blocks of (2 * shares - pixel sum)
+    const unsigned s4 = (unsigned)wave_sum(act ? 2 * h4 - psum : 0), s8 = (unsigned)wave_sum(act ? 2 * h8 - psum : 0);
+    if (lane == 0) out[idx] = ((uint64_t)(s8 >> 2) << 32) | (s4 >> 1);
+}
+}  // namespace
+
 extern "C" {
 
 int x264gpu_dctq8x8(const uint8_t *d_enc, const uint8_t *d_pred, int n, int qp, int list, int16_t *d_coef, int16_t *d_levels,
@@ -124,6 +149,15 @@ int x264gpu_intra_predict(int kind, const uint8_t *d_plane, int stride, const in
     ARG_TRY(kind >= 0 && kind <= 2 && d_plane && d_xy && d_mode && d_out && n >= 0 && (kind != 2 || d_avail));
     if (!n) return X264GPU_OK;
     hipLaunchKernelGGL(k_intra_predict, dim3((n + 3) / 4), dim3(256), 0, (hipStream_t)stream, kind, d_plane, stride, d_xy, d_mode, d_avail, n, d_out);
+    HIP_TRY(hipGetLastError());
+    return X264GPU_OK;
+}
+
+int x264gpu_pixel_hadamard_ac(const uint8_t *d_a, int n, int w, int h, uint64_t *d_out, void *stream)
+{
+    ARG_TRY(n >= 0 && d_a && d_out && (w == 8 || w == 16) && (h == 8 || h == 16));
+    if (!n) return X264GPU_OK;
+    hipLaunchKernelGGL(k_hadamard_ac, dim3((n + 3) / 4), dim3(256), 0, (hipStream_t)stream, d_a, n, w, h, d_out);
     HIP_TRY(hipGetLastError());
     return X264GPU_OK;
 }

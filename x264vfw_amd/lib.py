@@ -61,6 +61,7 @@ _SIGS = {
     "x264gpu_stream_sync": (_i, [_vp]),
     "x264gpu_pixel_metric": (_i, [_i, _vp, _vp, _i, _i, _i, _vp, _vp]),
     "x264gpu_pixel_var": (_i, [_vp, _i, _i, _i, _vp, _vp]),
+    "x264gpu_pixel_hadamard_ac": (_i, [_vp, _i, _i, _i, _vp, _vp]),
     "x264gpu_dctq4x4": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp]),
     "x264gpu_dctq8x8": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp]),
     "x264gpu_intra_predict": (_i, [_i, _vp, _i, _vp, _vp, _vp, _i, _vp, _vp]),
