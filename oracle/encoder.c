@@ -365,6 +365,21 @@ static me_result me_search_block(x264o_encoder *e, int mbx, int mby, int ox, int
         int c = FPEL_COST(cx, cy);
         if (c < bcost) { bcost = c; bmx = cx; bmy = cy; }
     }
+    if (e->cfg.me_method == 3) {
+        /* X264_ME_ESA ([x264-upstream] encoder/me.c): exhaustive search of the rectangle [bm - merange, bm + merange] clipped to the
+         * full-pel limits, its width rounded up to a multiple of 4 as x264's successive-elimination rows are; raster order, a strictly
+         * better candidate wins (the ADS / row-cost eliminations of x264 never drop a candidate that could win).  No hexagon / square
+         * refine afterwards. */
+        const int r = e->cfg.me_range;
+        const int min_x = bmx - r > fmin[0] ? bmx - r : fmin[0], min_y = bmy - r > fmin[1] ? bmy - r : fmin[1];
+        const int max_x = bmx + r < fmax[0] ? bmx + r : fmax[0], max_y = bmy + r < fmax[1] ? bmy + r : fmax[1];
+        const int width = (max_x - min_x + 3) & ~3;
+        for (int my = min_y; my <= max_y; my++)
+            for (int mx = min_x; mx < min_x + width; mx++) {
+                int c = FPEL_COST(mx, my);
+                if (c < bcost) { bcost = c; bmx = mx; bmy = my; }
+            }
+    } else
     if (e->cfg.me_method == 0) {
         /* X264_ME_DIA ([x264-upstream] encoder/me.c): radius-1 diamond, up to merange steps; order (0,-1) (0,1) (-1,0) (1,0),
          * strictly-better wins, the centre wins ties; no square refine afterwards */

@@ -72,6 +72,9 @@ def compare(tag, mbw, g_mb, o_mb, g_lv, o_lv, g_rec, o_rec):
     (352, 288, 5, dict(aq_mode=1, refs=3, partitions=7, dct8x8=1, chroma_me=1, mixed_refs=1, qp_i=24, qp_p=27)),
     (208, 120, 4, dict(aq_mode=1, aq_strength_q8=400, partitions=6, dct8x8=1, qp_i=40, qp_p=44)),       # strong AQ near the top of the range
     (96, 80, 4, dict(aq_mode=1, aq_strength_q8=133, partitions=3, qp_i=4, qp_p=6, deblock=0)),          # ... and near the bottom
+    (176, 144, 4, dict(me_method=3)),                                        # --me esa: exhaustive search, 16x16 only
+    (208, 120, 4, dict(me_method=3, partitions=3, refs=2, me_range=8, chroma_me=1)),      # ... in every partition
+    (96, 80, 4, dict(me_method=3, partitions=3, refs=3, mixed_refs=1, me_range=16, subme=5)),
     (176, 144, 4, dict(me_method=2)),                                        # --me umh, 16x16 only
     (352, 288, 4, dict(me_method=2, partitions=3, refs=2, chroma_me=1)),     # umh in every partition
     (352, 288, 3, dict(me_method=2, partitions=7, dct8x8=1, refs=4, subme=9, chroma_me=1, qp_i=26, qp_p=29)),   # preset slow-like (BASELINE config 4 toolset)

@@ -37,7 +37,7 @@ struct EncK {
     Q4 q_luma_intra, q_luma_inter, q_chroma_intra, q_chroma_inter;
     Q8 q8_intra, q8_inter;    // 8x8 luma transform (dct8x8)
     int dct8x8;
-    int me_method;            // 0 dia, 1 hex, 2 umh
+    int me_method;            // 0 dia, 1 hex, 2 umh, 3 esa
     int chroma_me;            // sub-pel SATD costs carry chroma (subme >= 5)
     int mixed_refs;           // 8x8 blocks / 16x8, 8x16 halves pick their own reference
     unsigned long long *dbg;  // optional diagnostics (NULL in production): per (stream, wave) cycle counters

@@ -490,6 +490,23 @@ __device__ int search_parts(const PartCtx &c, const int SHAPE, int c0x, int c0y,
             bcost = gsum(sad8_global(g0 + o, e0[0], e0[1]) + sad8_global(g1 + o, e1[0], e1[1])) + pc_mvcost<UMH>(c, bx * 4, by * 4);
         }
         umh_fullpel(c, SHAPE, 0, abs(c.mvp0 - 4 * c0x) + abs(c.mvp1 - 4 * c0y), bx, by, bcost);
+    } else if (c.me_method == 3) {
+        // exhaustive search (see the 16x16 path): the rectangle is the same for every partition (common start and limits)
+        bcost = FPC(bx, by);
+        const int rr = c.me_range;
+        const int min_x = max(bx - rr, c.fmin0), min_y = max(by - rr, c.fmin1), max_x = min(bx + rr, c.fmax0), max_y = min(by + rr, c.fmax1);
+        const int width = (max_x - min_x + 3) & ~3;
+        unsigned kmin = 0xffffffffu;
+        for (int my = min_y; my <= max_y; my++)
+            for (int x4 = 0; x4 < width; x4 += 4) {
+                const int mx = min_x + x4 + cnd;
+                kmin = min(kmin, ((unsigned)FPC(mx, my) << 11) | (unsigned)((my - min_y) * width + x4 + cnd));
+            }
+        kmin = cmin(kmin);
+        if (kmin != 0xffffffffu && (int)(kmin >> 11) < bcost) {
+            const int idx = (int)(kmin & 2047);
+            bcost = (int)(kmin >> 11); bx = min_x + idx % width; by = min_y + idx / width;
+        }
     } else if (c.me_method == 0) {
         bcost = FPC(bx, by);
         bool running = true;
@@ -748,6 +765,24 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MIXED ? X26
             u.p00 = p00; u.rs = k.rs; u.px = px; u.py = py; u.fenc = fenc; u.fs = k.fs; u.lane = lane; u.me_range = k.me_range; u.me_method = 2;
             u.fmin0 = fmin0; u.fmax0 = fmax0; u.fmin1 = fmin1; u.fmax1 = fmax1; u.gcx = cmx; u.gcy = cmy; u.mvp0 = mvp0; u.mvp1 = mvp1;
             umh_fullpel(u, 0, 0, umh_mvd16, bmx, bmy, bcost);
+        } else if (k.me_method == 3) {
+            // ---- X264_ME_ESA (oracle me_search_block, me_method 3): every position of the clipped +-merange rectangle, four per pass
+            // (one per lane group), raster order with "strictly better wins" = minimum of (cost << 11 | raster index) ----
+            const int rr = k.me_range;
+            const int min_x = max(bmx - rr, fmin0), min_y = max(bmy - rr, fmin1), max_x = min(bmx + rr, fmax0), max_y = min(bmy + rr, fmax1);
+            const int width = (max_x - min_x + 3) & ~3;
+            unsigned kmin = 0xffffffffu;
+            for (int my = min_y; my <= max_y; my++)
+                for (int x4 = 0; x4 < width; x4 += 4) {
+                    const int mx = min_x + x4 + cnd;
+                    const unsigned cst = (unsigned)(row16_sum(sad_row16_lds(win + (py + my + r - wy0) * WIN_STRIDE, px + mx - wx0, cr)) + MVC(mx * 4, my * 4));
+                    kmin = min(kmin, (cst << 11) | (unsigned)((my - min_y) * width + x4 + cnd));
+                }
+            kmin = wave_min_u32(kmin);
+            if (kmin != 0xffffffffu && (int)(kmin >> 11) < bcost) {
+                const int idx = (int)(kmin & 2047);
+                bcost = (int)(kmin >> 11); bmx = min_x + idx % width; bmy = min_y + idx / width;
+            }
         } else if (k.me_method == 0) {
             // ---- X264_ME_DIA: the four neighbours are exactly the four lane groups; centre wins ties ----
             int it = k.me_range;

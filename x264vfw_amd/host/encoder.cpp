@@ -177,8 +177,8 @@ x264_t *x264_encoder_open(x264_param_t *param)
     if (!p.analyse.b_transform_8x8) { p.analyse.inter &= ~X264_ANALYSE_I8x8; p.analyse.intra &= ~X264_ANALYSE_I8x8; }   // as x264 validate_parameters
     p.analyse.i_trellis = 0; p.rc.b_mb_tree = 0; p.rc.i_lookahead = 0;
     p.i_scenecut_threshold = clampi(p.i_scenecut_threshold, 0, 100);
-    if (p.analyse.i_me_method > X264_ME_UMH) { xlog(&p, X264_LOG_WARNING, "me esa/tesa are not implemented in the MI355X path yet: me umh\n"); p.analyse.i_me_method = X264_ME_UMH; }
-    p.analyse.i_me_range = clampi(p.analyse.i_me_range, 4, p.analyse.i_me_method == X264_ME_UMH ? 64 : 16);     // x264 caps dia/hex at 16
+    if (p.analyse.i_me_method > X264_ME_ESA) { xlog(&p, X264_LOG_WARNING, "me tesa is not implemented in the MI355X path yet: me esa\n"); p.analyse.i_me_method = X264_ME_ESA; }
+    p.analyse.i_me_range = clampi(p.analyse.i_me_range, 4, p.analyse.i_me_method == X264_ME_UMH ? 64 : 16);     // x264 caps dia/hex at 16; esa: the LDS search window
     p.analyse.i_subpel_refine = clampi(p.analyse.i_subpel_refine, 0, 7);
     p.analyse.b_chroma_me = p.analyse.b_chroma_me != 0;
     p.b_interlaced = 0; p.i_slice_count = 1;
@@ -233,7 +233,7 @@ x264_t *x264_encoder_open(x264_param_t *param)
     cfg.partitions = ((p.analyse.inter & X264_ANALYSE_PSUB16x16) ? 1 : 0) | ((p.analyse.inter & X264_ANALYSE_I4x4) ? 2 : 0) | ((p.analyse.inter & X264_ANALYSE_I8x8) ? 4 : 0) |
                      0x100 | ((p.analyse.intra & X264_ANALYSE_I4x4) ? 0x200 : 0) | ((p.analyse.intra & X264_ANALYSE_I8x8) ? 0x400 : 0);
     cfg.dct8x8 = p.analyse.b_transform_8x8;
-    cfg.me_method = p.analyse.i_me_method == X264_ME_DIA ? 0 : p.analyse.i_me_method == X264_ME_HEX ? 1 : 2;
+    cfg.me_method = p.analyse.i_me_method == X264_ME_DIA ? 0 : p.analyse.i_me_method == X264_ME_HEX ? 1 : p.analyse.i_me_method == X264_ME_UMH ? 2 : 3;
     cfg.aq_mode = p.rc.i_aq_mode == X264_AQ_VARIANCE; cfg.aq_strength_q8 = (int)(p.rc.f_aq_strength * 1.0397f * 256.0f + 0.5f);
     cfg.mixed_refs = p.analyse.b_mixed_references && (p.analyse.inter & X264_ANALYSE_PSUB16x16) != 0;
     cfg.chroma_me = p.analyse.b_chroma_me && p.analyse.i_subpel_refine >= 5;     // x264: h->mb.b_chroma_me in P slices
