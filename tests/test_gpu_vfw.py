@@ -206,3 +206,9 @@ def test_raw_file_output(gpu, tmp_path):
         assert slices == raw_slices, ext
         es = b"\0\0\0\1" + a["sps"] + b"\0\0\0\1" + a["pps"] + b"".join(b"\0\0\0\1" + n for n in slices)
         assert len(O.h264_decode(es, nfr, w, h)) == nfr
+    # GOP-parallel coding into a container: frames reach the muxer late but in order, with their own timestamps
+    run(b"--keyint 2 --min-keyint 2 --no-scenecut --output " + str(tmp_path / "s.mkv").encode())
+    run(b"--keyint 2 --min-keyint 2 --no-scenecut --threads 3 --output " + str(tmp_path / "p.mkv").encode())
+    ms, mp = CP.mkv_read((tmp_path / "s.mkv").read_bytes()), CP.mkv_read((tmp_path / "p.mkv").read_bytes())
+    assert [(f["timecode"], f["key"], f["data"]) for f in mp["frames"]] == [(f["timecode"], f["key"], f["data"]) for f in ms["frames"]]
+    assert [f["timecode"] for f in ms["frames"]] == sorted(f["timecode"] for f in ms["frames"]) and len(ms["frames"]) == nfr
