@@ -114,8 +114,12 @@ def test_pipeline_multistream(gpu):
 
 
 @pytest.mark.parametrize("w,h,nfr,kw", [
-    (1280, 720, 3, dict(dct8x8=1, partitions=7, refs=3)),        # BASELINE.json configs[1]: 720p, medium toolset, bit-exact
+    (1280, 720, 3, dict(dct8x8=1, partitions=7, refs=3)),        # BASELINE.json configs[1]: 720p, bit-exact
+    (1280, 720, 4, dict(dct8x8=1, partitions=7, refs=3, chroma_me=1, mixed_refs=1)),      # ... with the bench's full medium toolset
     (1920, 1080, 2, dict(dct8x8=1, partitions=7, refs=3)),       # configs[2] geometry: 1088 coded rows, cropped output
+    (1920, 1080, 3, dict(dct8x8=1, partitions=7, refs=3, chroma_me=1, mixed_refs=1)),     # the headline toolset (bench.py --preset medium)
+    (1920, 1080, 2, dict(dct8x8=1, partitions=7, refs=2, chroma_me=1, mixed_refs=1, aq_mode=1, qp_i=23, qp_p=26)),   # + variance AQ (CRF / ABR sessions)
+    (3840, 2160, 2, dict(dct8x8=1, partitions=7, refs=2, chroma_me=1, mixed_refs=1, me_method=2, subme=9)),          # configs[3] geometry and toolset (slow: umh, subme 9)
 ])
 def test_pipeline_bitexact_full_size(gpu, w, h, nfr, kw):
     """the headline geometries against the oracle (a few frames: the CPU oracle runs ~3 frames/s at 1080p)"""
