@@ -173,6 +173,7 @@ def main():
     ap.add_argument("--refs", type=int, default=3, help="reference frames (medium: 3)")
     ap.add_argument("--preset", default="medium", choices=["medium", "ultrafast", "slow"],
                     help="toolset of the other BASELINE.json configs (default medium = the headline); slow runs hex instead of umh")
+    ap.add_argument("--aq", action="store_true", help="variance AQ on (per-macroblock quantisers, the CRF / ABR path); the headline metric is CQP and leaves it off, as x264 does")
     ap.add_argument("--cpu-frames", type=int, default=24, help="frames of the CPU-baseline sample (0 = skip)")
     args = ap.parse_args()
 
@@ -202,6 +203,8 @@ def main():
     tools = {"medium": dict(refs=args.refs, subme=7, deblock=1, partitions=7, dct8x8=1, me_method=1, chroma_me=1, mixed_refs=1),
              "ultrafast": dict(refs=1, subme=0, deblock=0, partitions=0x100, dct8x8=0, me_method=0, chroma_me=0, mixed_refs=0),
              "slow": dict(refs=4, subme=9, deblock=1, partitions=7, dct8x8=1, me_method=2, chroma_me=1, mixed_refs=1)}[args.preset]
+    if args.aq:
+        tools = dict(tools, aq_mode=1, aq_strength_q8=266)
     # ---- inputs resident in HBM: warmup frames + K timed frames per stream ----
     nfr = Wu + K
     data = [synth_batch(torch, per[g], nfr, W, H, shard.stream_seed(0x264, gids[sum(per[:g])]), dev) for g in range(G)]
