@@ -208,12 +208,24 @@ int  x264gpu_encoder_set_qp(x264gpu_encoder *enc, int qp_i, int qp_p);
  * d_i420: `streams` tightly packed I420 pictures.  reset != 0 forgets the previous picture (first picture / after an IDR
  * decided elsewhere is NOT a reset: x264 keeps comparing consecutive source pictures).
  * d_out [streams][4] int32: intra cost (i_cost_est[0][0]), P cost (i_cost_est[1][0]; = intra cost without a previous
- * picture), blocks where intra won, blocks in the frame score.  d_blocks (optional) [streams][blocks][2]: intra, best cost.
+ * picture), blocks where intra won, blocks in the frame score.  d_blocks (optional) [streams][blocks][4]: intra cost, best cost, the
+ * block's vector (x & 0xffff | y << 16, quarter-pel of the half-resolution planes; 0 when intra won), 1 if inter won — the record
+ * x264gpu_lookahead_mbtree consumes.
  * ------------------------------------------------------------------------------------------------ */
 typedef struct x264gpu_lookahead x264gpu_lookahead;
 int  x264gpu_lookahead_create(x264gpu_lookahead **la, int width, int height, int streams, int me_range, int subme);
 void x264gpu_lookahead_destroy(x264gpu_lookahead *la);
 int  x264gpu_lookahead_frame_cost(x264gpu_lookahead *la, const uint8_t *d_i420, int reset, int32_t *d_out, int32_t *d_blocks, void *stream);
+/* Adaptive-quantisation offsets (Q8) of `streams` source pictures: strength * (log2(AC energy) - 14.427) per macroblock, as the lookahead
+ * of x264 computes them when a picture arrives (x264_adaptive_quant_frame); what aq_mode 1 of the encoder computes itself. */
+int  x264gpu_lookahead_aq_offsets(x264gpu_lookahead *la, const uint8_t *d_i420, int strength_q8, int16_t *d_out_q8, void *stream);
+/* Macroblock-tree ([x264-upstream] encoder/slicetype.c macroblock_tree / _propagate / _finish, common/mc.c mbtree_propagate_cost / _list)
+ * for an I/P-only stream at constant frame rate.  d_info[j], d_aq_q8[j] (host arrays of n device pointers): the per-block records
+ * (x264gpu_lookahead_frame_cost d_blocks) and AQ offsets of n consecutive pictures, j = 0 the one about to be coded; d_aq_q8 may be NULL.
+ * d_out_q8 [streams][blocks]: quantiser offsets of picture 0 = aq - strength * log2((intra + propagated) / intra), Q8;
+ * strength_q8 = 5 * (1 - qcomp) * 256.  Feed it to x264gpu_encoder_set_mb_qp_offsets. */
+int  x264gpu_lookahead_mbtree(x264gpu_lookahead *la, const int32_t *const *d_info, const int16_t *const *d_aq_q8, int n, int strength_q8,
+                              int16_t *d_out_q8, void *stream);
 
 #ifdef __cplusplus
 }

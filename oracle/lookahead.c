@@ -177,8 +177,9 @@ static int la_intra_cost(x264o_lookahead *la, int bx, int by)
 
 /* out[0] = intra cost of the picture (i_cost_est[0][0]), out[1] = P cost against the previous picture (i_cost_est[1][0];
  * equals out[0] when there is none), out[2] = blocks of the frame score where intra won, out[3] = blocks in the frame score.
- * block_costs (optional, bw*bh x 2 int32): per block intra cost, best cost.  reset: forget the previous picture (IDR). */
-int x264o_lookahead_frame_cost(x264o_lookahead *la, const uint8_t *i420, int reset, int32_t out[4], int32_t *block_costs)
+ * block_info (optional, bw*bh x 4 int32): per block intra cost, best cost, vector (x & 0xffff | y << 16, quarter-pel), 1 if inter won.
+ * reset: forget the previous picture (IDR). */
+int x264o_lookahead_frame_cost(x264o_lookahead *la, const uint8_t *i420, int reset, int32_t out[4], int32_t *block_info)
 {
     const int cw = la->bw * 16, ch = la->bh * 16;
     if (reset) la->have_prev = 0;
@@ -230,10 +231,94 @@ int x264o_lookahead_frame_cost(x264o_lookahead *la, const uint8_t *i420, int res
                 }
                 if (!(icost < pcost)) { bcost = pcost; intra = 0; cmv[bi][0] = (int16_t)mv[0]; cmv[bi][1] = (int16_t)mv[1]; cin[bi] = 1; }
             }
-            if (block_costs) { block_costs[2 * bi] = icost; block_costs[2 * bi + 1] = bcost; }
+            if (block_info) { block_info[4 * bi] = icost; block_info[4 * bi + 1] = bcost; block_info[4 * bi + 2] = (cmv[bi][0] & 0xffff) | (cmv[bi][1] << 16); block_info[4 * bi + 3] = !intra; }
             if (score) { isum += icost; psum += bcost; nintra += intra && la->have_prev; nscore++; }
         }
     out[0] = (int32_t)isum; out[1] = (int32_t)psum; out[2] = nintra; out[3] = nscore;
     la->have_prev = 1;
     return 0;
+}
+
+/* ---- adaptive-quantisation offsets of a source picture, Q8 (the lookahead computes them when the picture arrives, as
+ * x264_adaptive_quant_frame does; same arithmetic as encoder.c compute_mb_qp, on the mod-16 expanded picture) ---- */
+static const uint8_t la_log2_lut[128] = {
+#include "x264gpu_aq_lut.inc"
+};
+static int la_log2_q8(uint32_t x) { int lz = 31 - __builtin_clz(x); return lz * 256 + la_log2_lut[((x << (31 - lz)) >> 24) & 0x7f]; }
+
+void x264o_aq_offsets(const uint8_t *i420, int w, int h, int strength_q8, int16_t *out_q8)
+{
+    const int bw = (w + 15) / 16, bh = (h + 15) / 16;
+    const uint8_t *Y = i420, *U = i420 + (size_t)w * h, *V = U + (size_t)(w / 2) * (h / 2);
+    for (int by = 0; by < bh; by++)
+        for (int bx = 0; bx < bw; bx++) {
+            uint32_t sum = 0, sqr = 0, su = 0, squ = 0, sv = 0, sqv = 0;
+            for (int r = 0; r < 16; r++) for (int c = 0; c < 16; c++) { uint32_t p = Y[(size_t)clampi(by * 16 + r, 0, h - 1) * w + clampi(bx * 16 + c, 0, w - 1)]; sum += p; sqr += p * p; }
+            for (int r = 0; r < 8; r++) for (int c = 0; c < 8; c++) {
+                size_t o = (size_t)clampi(by * 8 + r, 0, h / 2 - 1) * (w / 2) + clampi(bx * 8 + c, 0, w / 2 - 1);
+                uint32_t u = U[o], v = V[o];
+                su += u; squ += u * u; sv += v; sqv += v * v;
+            }
+            uint32_t energy = (sqr - (sum * sum >> 8)) + (squ - (su * su >> 6)) + (sqv - (sv * sv >> 6));
+            out_q8[by * bw + bx] = (int16_t)((strength_q8 * (la_log2_q8(energy ? energy : 1) - 3693)) >> 8);
+        }
+}
+
+/* ---- macroblock-tree for an I/P-only stream ([x264-upstream] encoder/slicetype.c macroblock_tree, macroblock_tree_propagate,
+ * mbtree_propagate_cost / _list of common/mc.c, macroblock_tree_finish), constant frame rate.  info[j] / aq[j]: per-block records
+ * and AQ offsets of n consecutive pictures, j = 0 the one about to be coded.  Every picture hands the part of its cost that its
+ * reference explains back to the blocks its vectors point at (bilinear split over four blocks, 15-bit saturating sums); the
+ * oldest picture's blocks get  offset = aq - strength * log2((intra + propagated) / intra).  All integer arithmetic (x264's
+ * float expressions restated): amounts carry 9 fractional bits (fps_factor 1/512), inverse quantiser scales are x264_exp2fix8. ---- */
+static const uint16_t la_exp2_lut[64] = {
+#include "x264gpu_exp2_lut.inc"
+};
+static int la_inv_qscale(int aq_q8)
+{
+    int i = (-aq_q8 * 64 + 786432 + 768) / 1536;                       /* (int)(x * (-64 / 6) + 512.5), x = aq_q8 / 256 */
+    if (i < 0) return 0;
+    if (i > 1023) return 0xffff;
+    return (int)(((uint32_t)(la_exp2_lut[i & 63] + 256) << (i >> 6)) >> 8);
+}
+
+void x264o_mbtree(int bw, int bh, const int32_t *const *info, const int16_t *const *aq_q8, int n, int strength_q8, int16_t *out_q8)
+{
+    const int nb = bw * bh;
+    int32_t *prop = calloc((size_t)n * nb, sizeof(int32_t));           /* propagate cost of every picture's blocks */
+    for (int j = n - 1; j >= 1; j--) {
+        const int32_t *fi = info[j];
+        int32_t *ref = prop + (size_t)(j - 1) * nb;
+        for (int by = 0; by < bh; by++)
+            for (int bx = 0; bx < bw; bx++) {
+                const int i = by * bw + bx;
+                const int intra = fi[4 * i] > 16383 ? 16383 : fi[4 * i], best = fi[4 * i + 1] > 16383 ? 16383 : fi[4 * i + 1];   /* LOWRES_COST_MASK */
+                const int inter = best < intra ? best : intra, inv = la_inv_qscale(aq_q8 ? aq_q8[j][i] : 0);
+                int64_t amt512 = (int64_t)prop[(size_t)j * nb + i] * 512 + (int64_t)intra * inv;
+                int amount = intra ? (int)((amt512 * (intra - inter) + 256 * (int64_t)intra) / (512 * (int64_t)intra)) : 0;
+                if (amount > 32767) amount = 32767;
+                if (!fi[4 * i + 3]) continue;                           /* intra block: nothing is explained by the reference */
+                int x = (int16_t)(fi[4 * i + 2] & 0xffff), y = fi[4 * i + 2] >> 16;
+#define CLIP_ADD(idx, v) do { int t_ = ref[idx] + (v); ref[idx] = t_ > 32767 ? 32767 : t_; } while (0)
+                if (!(x | y)) { CLIP_ADD(i, amount); continue; }
+                const int mbx = (x >> 5) + bx, mby = (y >> 5) + by;
+                x &= 31; y &= 31;
+                const int w0 = ((32 - y) * (32 - x) * amount + 512) >> 10, w1 = ((32 - y) * x * amount + 512) >> 10;
+                const int w2 = (y * (32 - x) * amount + 512) >> 10, w3 = (y * x * amount + 512) >> 10;
+                if (mby >= 0 && mby < bh) { if (mbx >= 0 && mbx < bw) CLIP_ADD(mby * bw + mbx, w0); if (mbx + 1 >= 0 && mbx + 1 < bw) CLIP_ADD(mby * bw + mbx + 1, w1); }
+                if (mby + 1 >= 0 && mby + 1 < bh) { if (mbx >= 0 && mbx < bw) CLIP_ADD((mby + 1) * bw + mbx, w2); if (mbx + 1 >= 0 && mbx + 1 < bw) CLIP_ADD((mby + 1) * bw + mbx + 1, w3); }
+#undef CLIP_ADD
+            }
+    }
+    for (int i = 0; i < nb; i++) {
+        const int a = aq_q8 ? aq_q8[0][i] : 0;
+        const int icost = info[0][4 * i] > 16383 ? 16383 : info[0][4 * i];
+        const int intra = (icost * la_inv_qscale(a) + 128) >> 8;
+        int off = a;
+        if (intra) {
+            const int p2 = prop[i] * 2;                                 /* (propagate * 512 + 128) >> 8 */
+            off = a - ((strength_q8 * (la_log2_q8((uint32_t)(intra + p2)) - la_log2_q8((uint32_t)intra))) >> 8);
+        }
+        out_q8[i] = (int16_t)off;
+    }
+    free(prop);
 }

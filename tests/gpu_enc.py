@@ -60,7 +60,7 @@ class GpuLookahead:
         self.h = C.c_void_p()
         lib.check(lib.x264gpu_lookahead_create(C.byref(self.h), w, h, streams, me_range, subme), "lookahead_create")
         self.d_out = torch.zeros((streams, 4), dtype=torch.int32, device="cuda")
-        self.d_blocks = torch.zeros((streams, self.nb, 2), dtype=torch.int32, device="cuda")
+        self.d_blocks = torch.zeros((streams, self.nb, 4), dtype=torch.int32, device="cuda")
 
     def frame_cost(self, frames, reset=False):
         t = self.torch
@@ -69,6 +69,25 @@ class GpuLookahead:
                                                    self.d_blocks.data_ptr(), None), "lookahead_frame_cost")
         t.cuda.synchronize()
         return self.d_out.cpu().numpy(), self.d_blocks.cpu().numpy()
+
+    def aq_offsets(self, frames, strength_q8=266):
+        t = self.torch
+        d_in = t.from_numpy(np.stack(frames)).cuda()
+        out = t.zeros((self.S, self.nb), dtype=t.int16, device="cuda")
+        lib.check(lib.x264gpu_lookahead_aq_offsets(self.h, d_in.data_ptr(), strength_q8, out.data_ptr(), None), "lookahead_aq_offsets")
+        t.cuda.synchronize()
+        return out
+
+    def mbtree(self, d_infos, d_aqs, strength_q8=512):
+        """d_infos / d_aqs: lists of device tensors of consecutive pictures ([0] = the one about to be coded); d_aqs may be None"""
+        t = self.torch
+        n = len(d_infos)
+        ip = (C.c_void_p * n)(*[x.data_ptr() for x in d_infos])
+        ap = (C.c_void_p * n)(*[x.data_ptr() for x in d_aqs]) if d_aqs is not None else None
+        out = t.zeros((self.S, self.nb), dtype=t.int16, device="cuda")
+        lib.check(lib.x264gpu_lookahead_mbtree(self.h, ip, ap, n, strength_q8, out.data_ptr(), None), "lookahead_mbtree")
+        t.cuda.synchronize()
+        return out.cpu().numpy()
 
     def close(self):
         if self.h:

@@ -212,9 +212,9 @@ class OracleLookahead:
         self.la = L.x264o_lookahead_create(w, h, me_range, subme)
 
     def frame_cost(self, i420, reset=False):
-        """-> (out[4] = intra cost, P cost, intra blocks, scored blocks; per-block [intra cost, best cost])"""
+        """-> (out[4] = intra cost, P cost, intra blocks, scored blocks; per-block [intra cost, best cost, packed vector, inter])"""
         out = np.zeros(4, np.int32)
-        blocks = np.zeros((self.nb, 2), np.int32)
+        blocks = np.zeros((self.nb, 4), np.int32)
         i420 = np.ascontiguousarray(i420, np.uint8)
         assert L.x264o_lookahead_frame_cost(self.la, ptr(i420), int(reset), ptr(out), ptr(blocks)) == 0
         return out, blocks
@@ -226,6 +226,31 @@ class OracleLookahead:
 
     def __del__(self):
         self.close()
+
+
+_sig("x264o_aq_offsets", None, [C.c_void_p, _i, _i, _i, C.c_void_p])
+_sig("x264o_mbtree", None, [_i, _i, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), _i, _i, C.c_void_p])
+
+
+def aq_offsets(i420, w, h, strength_q8=266):
+    out = np.zeros(((w + 15) // 16) * ((h + 15) // 16), np.int16)
+    i420 = np.ascontiguousarray(i420, np.uint8)
+    L.x264o_aq_offsets(ptr(i420), w, h, strength_q8, ptr(out))
+    return out
+
+
+def mbtree(bw, bh, infos, aqs, strength_q8=512):
+    """infos: list of (blocks x 4) int32 arrays of consecutive pictures, [0] = the one about to be coded; aqs: list of int16 or None"""
+    n = len(infos)
+    infos = [np.ascontiguousarray(a, np.int32) for a in infos]
+    ip = (C.c_void_p * n)(*[a.ctypes.data for a in infos])
+    ap = None
+    if aqs is not None:
+        aqs = [np.ascontiguousarray(a, np.int16) for a in aqs]
+        ap = (C.c_void_p * n)(*[a.ctypes.data for a in aqs])
+    out = np.zeros(bw * bh, np.int16)
+    L.x264o_mbtree(bw, bh, ip, ap, n, strength_q8, ptr(out))
+    return out
 
 
 # ---- oracle/_ref: L-SMASH's H.264 header parser from the reference tree (oracle/lsmash_shim.c, built by oracle/Makefile) ----

@@ -68,3 +68,29 @@ def test_scene_change_is_visible_in_the_costs(gpu):
     outs = [gl.frame_cost([f], i == 0)[0][0] for i, f in enumerate(a + b)]
     assert outs[2][1] < 0.8 * outs[2][0]
     assert outs[3][1] >= 0.95 * outs[3][0] and outs[3][2] > 0.8 * outs[3][3]
+
+
+@pytest.mark.parametrize("w,h,n,strength,with_aq", [(352, 288, 7, 512, True), (208, 120, 5, 512, False), (80, 48, 4, 768, True), (720, 304, 4, 256, True), (16, 16, 3, 512, True)])
+def test_aq_offsets_and_mbtree_bitexact(gpu, w, h, n, strength, with_aq):
+    """x264gpu_lookahead_aq_offsets and x264gpu_lookahead_mbtree (macroblock_tree over n consecutive pictures) vs oracle/lookahead.c"""
+    import torch
+    from gpu_enc import GpuLookahead
+    frames = synth_frames(w, h, n, seed=3 * w + h)
+    ol, gl = O.OracleLookahead(w, h), GpuLookahead(w, h)
+    bw, bh = (w + 15) // 16, (h + 15) // 16
+    o_infos, g_infos, o_aqs, g_aqs = [], [], [], []
+    for i, f in enumerate(frames):
+        o_infos.append(ol.frame_cost(f, i == 0)[1])
+        g_infos.append(torch.from_numpy(gl.frame_cost([f], i == 0)[1].copy()).cuda())
+        o_aqs.append(O.aq_offsets(f, w, h, 266))
+        g_aqs.append(gl.aq_offsets([f], 266))
+        assert np.array_equal(g_aqs[-1].cpu().numpy()[0], o_aqs[-1]), f"aq offsets of picture {i}"
+        assert np.array_equal(g_infos[-1].cpu().numpy()[0], o_infos[-1]), f"block records of picture {i}"
+    for first in range(n):                                  # every suffix, as the queue drains at the end of a stream
+        want = O.mbtree(bw, bh, o_infos[first:], o_aqs[first:] if with_aq else None, strength)
+        got = gl.mbtree(g_infos[first:], g_aqs[first:] if with_aq else None, strength)[0]
+        assert np.array_equal(got, want), f"suffix {first}: {np.nonzero(got != want)[0][:5]}"
+    # the tree only ever lowers quantisers (more bits where later pictures keep looking), and a lone picture gets none of it
+    alone = O.mbtree(bw, bh, o_infos[-1:], o_aqs[-1:], strength)
+    assert np.array_equal(alone, o_aqs[-1])
+    assert (O.mbtree(bw, bh, o_infos[1:], o_aqs[1:], strength) <= o_aqs[1]).all()

@@ -26,7 +26,7 @@ struct LaK {
     int8_t *in_cur; const int8_t *in_prev;                  // S x bw*bh: 1 = vector valid
     const uint16_t *cost_mv;                                // 2*MVCOST_HALF entries, lambda of qp 12
     int me_range, subme, lambda, have_prev;
-    int32_t *out, *blocks;                                  // S x 4; optional S x bw*bh x 2
+    int32_t *out, *blocks;                                  // S x 4; optional S x bw*bh x 4 (intra cost, best cost, packed vector, inter)
 };
 
 __device__ __forceinline__ int la_avg4(int a, int b, int c, int d) { return (((a + b + 1) >> 1) + ((c + d + 1) >> 1) + 1) >> 1; }
@@ -165,7 +165,10 @@ __global__ __launch_bounds__(256) void k_la_cost(LaK k)
         int16_t *mo = k.mv_cur + ((size_t)s * nb + bi) * 2;
         mo[0] = intra ? 0 : (int16_t)mvx; mo[1] = intra ? 0 : (int16_t)mvy;
         k.in_cur[(size_t)s * nb + bi] = intra ? 0 : 1;
-        if (k.blocks) { k.blocks[((size_t)s * nb + bi) * 2] = icost; k.blocks[((size_t)s * nb + bi) * 2 + 1] = bcost; }
+        if (k.blocks) {
+            int32_t *bo = k.blocks + ((size_t)s * nb + bi) * 4;
+            bo[0] = icost; bo[1] = bcost; bo[2] = intra ? 0 : ((mvx & 0xffff) | (mvy << 16)); bo[3] = intra ? 0 : 1;
+        }
     }
     const bool cnt = bvalid && score;
     int v0 = cnt ? icost : 0, v1 = cnt ? bcost : 0, v2 = cnt && intra && k.have_prev ? 1 : 0, v3 = cnt ? 1 : 0;
@@ -176,6 +179,82 @@ __global__ __launch_bounds__(256) void k_la_cost(LaK k)
         int32_t *o = k.out + (size_t)s * 4;
         atomicAdd(o, v0); atomicAdd(o + 1, v1); atomicAdd(o + 2, v2); atomicAdd(o + 3, v3);
     }
+}
+
+// ---- AQ offsets of a source picture (oracle x264o_aq_offsets): as k_aq, on the tight I420 input with clamped coordinates ----
+static __constant__ uint8_t c_la_log2_lut[128] = {
+#include "x264gpu_aq_lut.inc"
+};
+static __constant__ uint16_t c_la_exp2_lut[64] = {
+#include "x264gpu_exp2_lut.inc"
+};
+__device__ __forceinline__ int la_log2_q8(unsigned x) { const int lz = 31 - __builtin_clz(x); return lz * 256 + c_la_log2_lut[((x << (31 - lz)) >> 24) & 0x7f]; }
+__device__ __forceinline__ int la_inv_qscale(int aq_q8)
+{
+    const int i = (-aq_q8 * 64 + 786432 + 768) / 1536;
+    if (i < 0) return 0;
+    if (i > 1023) return 0xffff;
+    return (int)(((unsigned)(c_la_exp2_lut[i & 63] + 256) << (i >> 6)) >> 8);
+}
+
+__global__ __launch_bounds__(256) void k_la_aq(const uint8_t *__restrict__ i420, size_t i420_bytes, int w, int h, int bw, int nb, int strength_q8, int16_t *__restrict__ out)
+{
+    const int lane = threadIdx.x & 63, r = lane & 15, s = blockIdx.y;
+    const int bi = (blockIdx.x * 4 + (threadIdx.x >> 6)) * 4 + (lane >> 4);
+    const bool valid = bi < nb;
+    const int b = valid ? bi : 0, bx = b % bw, by = b / bw;
+    const uint8_t *Y = i420 + (size_t)s * i420_bytes, *U = Y + (size_t)w * h, *V = U + (size_t)(w / 2) * (h / 2);
+    unsigned sum = 0, sqr = 0, su = 0, squ = 0, sv = 0, sqv = 0;
+    const uint8_t *yr = Y + (size_t)min(by * 16 + r, h - 1) * w;
+    for (int c = 0; c < 16; c++) { const unsigned p = yr[min(bx * 16 + c, w - 1)]; sum += p; sqr += p * p; }
+    if (r < 8) {
+        const size_t ro = (size_t)min(by * 8 + r, h / 2 - 1) * (w / 2);
+        for (int c = 0; c < 8; c++) { const int x = min(bx * 8 + c, w / 2 - 1); const unsigned u = U[ro + x], v = V[ro + x]; su += u; squ += u * u; sv += v; sqv += v * v; }
+    }
+    sum = (unsigned)row16_sum((int)sum); sqr = (unsigned)row16_sum((int)sqr);
+    su = (unsigned)row16_sum((int)su); squ = (unsigned)row16_sum((int)squ); sv = (unsigned)row16_sum((int)sv); sqv = (unsigned)row16_sum((int)sqv);
+    const unsigned energy = (sqr - (sum * sum >> 8)) + (squ - (su * su >> 6)) + (sqv - (sv * sv >> 6));
+    if (valid && r == 0) out[(size_t)s * nb + bi] = (int16_t)((strength_q8 * (la_log2_q8(energy ? energy : 1u) - 3693)) >> 8);
+}
+
+// ---- macroblock-tree (oracle x264o_mbtree): one launch per picture walks its blocks and scatters the explained cost into the
+// reference picture's accumulator (saturation is applied when an accumulator is read: the addends are non-negative) ----
+__global__ __launch_bounds__(256) void k_mbtree_propagate(const int32_t *__restrict__ info, const int16_t *__restrict__ aq, const int32_t *__restrict__ prop_in,
+                                                           int32_t *__restrict__ prop_ref, int bw, int bh)
+{
+    const int nb = bw * bh, i = blockIdx.x * 256 + threadIdx.x, s = blockIdx.y;
+    if (i >= nb) return;
+    const int32_t *fi = info + ((size_t)s * nb + i) * 4;
+    const int intra = min(fi[0], 16383), best = min(fi[1], 16383), inter = min(best, intra);
+    if (!fi[3] || !intra) return;
+    const int inv = la_inv_qscale(aq ? (int)aq[(size_t)s * nb + i] : 0);
+    const long long amt512 = (long long)min(prop_in[(size_t)s * nb + i], 32767) * 512 + (long long)intra * inv;
+    const int amount = (int)min((amt512 * (intra - inter) + 256ll * intra) / (512ll * intra), 32767ll);
+    int32_t *ref = prop_ref + (size_t)s * nb;
+    int x = (int)(short)(fi[2] & 0xffff), y = fi[2] >> 16;
+    const int bx = i % bw, by = i / bw;
+    if (!(x | y)) { atomicAdd(ref + i, amount); return; }
+    const int mbx = (x >> 5) + bx, mby = (y >> 5) + by;
+    x &= 31; y &= 31;
+    const int w0 = ((32 - y) * (32 - x) * amount + 512) >> 10, w1 = ((32 - y) * x * amount + 512) >> 10;
+    const int w2 = (y * (32 - x) * amount + 512) >> 10, w3 = (y * x * amount + 512) >> 10;
+    if (mby >= 0 && mby < bh) { if (mbx >= 0 && mbx < bw) atomicAdd(ref + mby * bw + mbx, w0); if (mbx + 1 >= 0 && mbx + 1 < bw) atomicAdd(ref + mby * bw + mbx + 1, w1); }
+    if (mby + 1 >= 0 && mby + 1 < bh) { if (mbx >= 0 && mbx < bw) atomicAdd(ref + (mby + 1) * bw + mbx, w2); if (mbx + 1 >= 0 && mbx + 1 < bw) atomicAdd(ref + (mby + 1) * bw + mbx + 1, w3); }
+}
+
+__global__ __launch_bounds__(256) void k_mbtree_finish(const int32_t *__restrict__ info, const int16_t *__restrict__ aq, const int32_t *__restrict__ prop,
+                                                        int nb, int strength_q8, int16_t *__restrict__ out)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x, s = blockIdx.y;
+    if (i >= nb) return;
+    const int a = aq ? (int)aq[(size_t)s * nb + i] : 0;
+    const int intra = (min(info[((size_t)s * nb + i) * 4], 16383) * la_inv_qscale(a) + 128) >> 8;
+    int off = a;
+    if (intra) {
+        const int p2 = min(prop[(size_t)s * nb + i], 32767) * 2;
+        off = a - ((strength_q8 * (la_log2_q8((unsigned)(intra + p2)) - la_log2_q8((unsigned)intra))) >> 8);
+    }
+    out[(size_t)s * nb + i] = (int16_t)off;
 }
 
 }  // namespace x264gpu
@@ -189,6 +268,7 @@ struct x264gpu_lookahead {
     int16_t *mv[2];
     int8_t *inter[2];
     uint16_t *cost_mv;
+    int32_t *prop; int prop_cap;     // macroblock-tree accumulators: prop_cap pictures x streams x blocks
     int cur, have_prev;
 };
 
@@ -240,7 +320,7 @@ void x264gpu_lookahead_destroy(x264gpu_lookahead *la)
 {
     if (!la) return;
     for (int i = 0; i < 2; i++) { (void)hipFree(la->planes[i]); (void)hipFree(la->mv[i]); (void)hipFree(la->inter[i]); }
-    (void)hipFree(la->cost_mv);
+    (void)hipFree(la->cost_mv); (void)hipFree(la->prop);
     delete la;
 }
 
@@ -265,6 +345,36 @@ int x264gpu_lookahead_frame_cost(x264gpu_lookahead *la, const uint8_t *d_i420, i
     hipLaunchKernelGGL(k_la_cost, dim3((groups + 3) / 4, S), dim3(256), 0, st, k);
     HIP_TRY(hipGetLastError());
     la->have_prev = 1;
+    return X264GPU_OK;
+}
+
+int x264gpu_lookahead_aq_offsets(x264gpu_lookahead *la, const uint8_t *d_i420, int strength_q8, int16_t *d_out_q8, void *stream)
+{
+    ARG_TRY(la && d_i420 && d_out_q8);
+    const int nb = la->bw * la->bh;
+    hipLaunchKernelGGL(k_la_aq, dim3((nb + 15) / 16, la->streams), dim3(256), 0, (hipStream_t)stream, d_i420, (size_t)la->w * la->h * 3 / 2, la->w, la->h, la->bw, nb,
+                       strength_q8, d_out_q8);
+    HIP_TRY(hipGetLastError());
+    return X264GPU_OK;
+}
+
+int x264gpu_lookahead_mbtree(x264gpu_lookahead *la, const int32_t *const *d_info, const int16_t *const *d_aq_q8, int n, int strength_q8, int16_t *d_out_q8, void *stream)
+{
+    ARG_TRY(la && d_info && n >= 1 && n <= 256 && d_out_q8);
+    hipStream_t st = (hipStream_t)stream;
+    const int nb = la->bw * la->bh, S = la->streams;
+    const size_t per = (size_t)S * nb;
+    if (la->prop_cap < n) {
+        (void)hipFree(la->prop); la->prop = nullptr; la->prop_cap = 0;
+        HIP_TRY(hipMalloc((void **)&la->prop, (size_t)n * per * sizeof(int32_t)));
+        la->prop_cap = n;
+    }
+    HIP_TRY(hipMemsetAsync(la->prop, 0, (size_t)n * per * sizeof(int32_t), st));
+    const dim3 grid((nb + 255) / 256, S);
+    for (int j = n - 1; j >= 1; j--)
+        hipLaunchKernelGGL(k_mbtree_propagate, grid, dim3(256), 0, st, d_info[j], d_aq_q8 ? d_aq_q8[j] : nullptr, la->prop + (size_t)j * per, la->prop + (size_t)(j - 1) * per, la->bw, la->bh);
+    hipLaunchKernelGGL(k_mbtree_finish, grid, dim3(256), 0, st, d_info[0], d_aq_q8 ? d_aq_q8[0] : nullptr, la->prop, nb, strength_q8, d_out_q8);
+    HIP_TRY(hipGetLastError());
     return X264GPU_OK;
 }
 
