@@ -199,6 +199,10 @@ int  x264gpu_encoder_profile_end(x264gpu_encoder *enc, void *stream, double *ms_
 /* Quantisers of the following x264gpu_encode_frames calls (every stream of the call shares them): what x264_ratecontrol_start
  * hands the slice ([x264-upstream] encoder/ratecontrol.c; CRF / scenecut sessions change it per picture). */
 int  x264gpu_encoder_set_qp(x264gpu_encoder *enc, int qp_i, int qp_p);
+/* Per-macroblock quantiser offsets (Q8, [streams][mb_count]) for the following pictures, as decided by the lookahead (x264: frame->f_qp_offset
+ * = AQ - macroblock-tree, applied by x264_ratecontrol_mb_qp): quantiser = slice quantiser + round(offset), clipped to 1..51.  The device array
+ * must stay valid until the encode that uses it has been issued; NULL returns to the encoder's own aq_mode. */
+int  x264gpu_encoder_set_mb_qp_offsets(x264gpu_encoder *enc, const int16_t *d_offsets_q8);
 
 /* ------------------------------------------------------------------------------------------------
  * Lookahead frame cost: x264_slicetype_frame_cost of [x264-upstream]

@@ -47,6 +47,7 @@ typedef struct x264o_encoder {
     int have_ref;
     int slice_type;              /* slice being encoded */
     uint8_t *mbqp;               /* quantiser of every macroblock of the picture being coded (slice quantiser, + AQ offset) */
+    const int16_t *ext_off_q8;   /* quantiser offsets handed in for the next picture (lookahead: AQ - macroblock-tree), or NULL */
 } x264o_encoder;
 
 static int clampi(int v, int lo, int hi) { return v < lo ? lo : v > hi ? hi : v; }
@@ -116,6 +117,8 @@ void x264o_encoder_destroy(x264o_encoder *e)
 
 int x264o_encoder_mb_count(const x264o_encoder *e) { return e->mbw * e->mbh; }
 void x264o_encoder_set_qp(x264o_encoder *e, int qp_i, int qp_p) { e->cfg.qp_i = qp_i; e->cfg.qp_p = qp_p; }
+/* per-macroblock quantiser offsets (Q8) for the following pictures; the array must stay valid; NULL = back to the encoder's own AQ */
+void x264o_encoder_set_mb_qp_offsets(x264o_encoder *e, const int16_t *off_q8) { e->ext_off_q8 = off_q8; }
 
 static const uint16_t *cost_mv_for(x264o_encoder *e, int qp)
 {
@@ -157,6 +160,10 @@ static int aq_log2_q8(uint32_t x)
 static void compute_mb_qp(x264o_encoder *e, int slice_qp)
 {
     const int n = e->mbw * e->mbh;
+    if (e->ext_off_q8) {        /* offsets decided by the lookahead (x264: frame->f_qp_offset, read by x264_ratecontrol_mb_qp) */
+        for (int i = 0; i < n; i++) e->mbqp[i] = (uint8_t)clampi(slice_qp + ((e->ext_off_q8[i] + 128) >> 8), 1, 51);
+        return;
+    }
     if (!e->cfg.aq_mode) { memset(e->mbqp, slice_qp, (size_t)n); return; }
     for (int mby = 0; mby < e->mbh; mby++)
         for (int mbx = 0; mbx < e->mbw; mbx++) {
@@ -1114,7 +1121,7 @@ int x264o_encoder_encode(x264o_encoder *e, const uint8_t *i420, int slice_type, 
                 if (mb->type != X264GPU_MB_P_L0 && mb->type != X264GPU_MB_P_8x8) intra_mb(e, mbx, mby, e->mbqp[mby * e->mbw + mbx], mbs, levels + (size_t)(mby * e->mbw + mbx) * X264GPU_MB_LEVELS);
             }
     }
-    if (e->cfg.aq_mode) settle_mb_qp(e, mbs, slice_qp);
+    if (e->cfg.aq_mode || e->ext_off_q8) settle_mb_qp(e, mbs, slice_qp);
     if (e->cfg.deblock) deblock_frame(e, mbs);
     filter_frame(e);
     /* rotate: the frame just built becomes the reference; its MV field becomes "previous" */

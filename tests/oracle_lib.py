@@ -139,6 +139,7 @@ _sig("x264o_encoder_create", C.c_void_p, [C.POINTER(Config)])
 _sig("x264o_encoder_destroy", None, [C.c_void_p])
 _sig("x264o_encoder_mb_count", _i, [C.c_void_p])
 _sig("x264o_encoder_set_qp", None, [C.c_void_p, _i, _i])
+_sig("x264o_encoder_set_mb_qp_offsets", None, [C.c_void_p, C.c_void_p])
 _sig("x264o_encoder_encode", _i, [C.c_void_p, C.c_void_p, _i, C.c_void_p, C.c_void_p])
 _sig("x264o_encoder_get_recon", None, [C.c_void_p, C.c_void_p])
 _sig("x264o_encoder_ref_plane", C.c_void_p, [C.c_void_p, _i, C.POINTER(_i), C.POINTER(_i)])
@@ -175,6 +176,10 @@ class OracleEncoder:
 
     def set_qp(self, qp_i, qp_p):
         L.x264o_encoder_set_qp(self.h, qp_i, qp_p)
+
+    def set_mb_qp_offsets(self, off_q8):
+        self._off = None if off_q8 is None else np.ascontiguousarray(off_q8, np.int16)      # keep alive
+        L.x264o_encoder_set_mb_qp_offsets(self.h, None if self._off is None else ptr(self._off))
 
     def recon(self):
         w, h = self.cfg.width, self.cfg.height

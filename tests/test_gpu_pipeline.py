@@ -195,3 +195,28 @@ def test_non_idr_intra_picture_keeps_the_references(gpu):
         if i == 4:
             older = int((o_mb["ref"][:, 0] >= 1).sum())
     assert older > 20, "the picture after the non-IDR I picture should reach behind it"
+
+
+def test_external_mb_qp_offsets(gpu):
+    """x264gpu_encoder_set_mb_qp_offsets: the lookahead's per-macroblock quantiser offsets (AQ - macroblock-tree, Q8) instead of
+    the encoder's own AQ; NULL returns to the configured mode"""
+    import torch
+    from gpu_enc import GpuEncoder
+    from x264vfw_amd import lib
+    w, h = 208, 120
+    frames = synth_frames(w, h, 4, seed=12)
+    cfg = O.default_config(w, h, refs=2, partitions=7, dct8x8=1, chroma_me=1, qp_i=25, qp_p=28)
+    og, gg = O.OracleEncoder(cfg), GpuEncoder(cfg)
+    rng = np.random.default_rng(5)
+    n = og.n
+    for i, f in enumerate(frames):
+        off = None if i == 3 else rng.integers(-1800, 1500, n).astype(np.int16)
+        og.set_mb_qp_offsets(off)
+        d_off = None if off is None else torch.from_numpy(off[None].copy()).cuda()
+        lib.check(lib.x264gpu_encoder_set_mb_qp_offsets(gg.h, None if d_off is None else d_off.data_ptr()), "set_mb_qp_offsets")
+        st = 2 if i == 0 else 0
+        o_mb, o_lv = og.encode(f, st)
+        g_mb, g_lv = gg.encode([f], st)
+        compare(f"external offsets frame {i}", (w + 15) // 16, g_mb[0], o_mb, g_lv[0], o_lv, gg.recon(0), og.recon())
+        if off is not None:
+            assert len(np.unique(o_mb["qp"])) > 4

@@ -38,6 +38,7 @@ struct x264gpu_encoder {
     int *wf_progress = nullptr;          // [streams][2][WFG_ROWS] row counters of the multi-workgroup wavefront kernels
     // adaptive quantisation: per-macroblock quantisers and the per-quantiser tables (built when aq_mode != 0)
     uint8_t *mbqp = nullptr;
+    const int16_t *ext_off = nullptr;    // quantiser offsets handed in by the caller (lookahead), [streams][nmb] Q8
     Q4 *q4tab = nullptr; Q8 *q8tab = nullptr; int *lambda_tab = nullptr; uint16_t *cost_all = nullptr;
     // optional per-stage profiling: (NSTAGE+1) events per armed call
     hipEvent_t *ev = nullptr;
@@ -165,6 +166,14 @@ int x264gpu_encoder_set_qp(x264gpu_encoder *e, int qp_i, int qp_p)
     return X264GPU_OK;
 }
 
+int x264gpu_encoder_set_mb_qp_offsets(x264gpu_encoder *e, const int16_t *d_offsets_q8)
+{
+    ARG_TRY(e);
+    if (d_offsets_q8 && !e->q4tab) { const int rc = build_aq_tables(e); if (rc) return rc; }
+    e->ext_off = d_offsets_q8;
+    return X264GPU_OK;
+}
+
 static void profile_free(x264gpu_encoder *e)
 {
     if (e->ev) {
@@ -260,10 +269,11 @@ int x264gpu_encode_frames(x264gpu_encoder *e, const uint8_t *d_i420, int slice_t
 #define STAGE_MARK(i) do { if (ev) { HIP_TRY(hipEventRecord(ev[i], st)); } } while (0)
     STAGE_MARK(0);
     hipLaunchKernelGGL(k_ingest, dim3((k.cw / 4 + 255) / 256, k.ch, S), dim3(256), 0, st, k);
-    const bool aq = e->cfg.aq_mode != 0;
+    const bool aq = e->cfg.aq_mode != 0 || e->ext_off != nullptr;
     if (aq) {
         k.mbqp = e->mbqp; k.q4tab = e->q4tab; k.q8tab = e->q8tab; k.lambda_tab = e->lambda_tab; k.cost_all = e->cost_all; k.aq_strength_q8 = e->cfg.aq_strength_q8;
-        hipLaunchKernelGGL(k_aq, dim3((k.nmb + 15) / 16, S), dim3(256), 0, st, k);
+        if (e->ext_off) hipLaunchKernelGGL(k_apply_qp_offsets, dim3((k.nmb + 255) / 256, S), dim3(256), 0, st, k, e->ext_off);
+        else hipLaunchKernelGGL(k_aq, dim3((k.nmb + 15) / 16, S), dim3(256), 0, st, k);
     }
     mask |= 1;
     STAGE_MARK(1);

@@ -221,6 +221,13 @@ __global__ __launch_bounds__(256) void k_aq(EncK k)
     if (valid && r == 0) k.mbqp[(size_t)s * k.nmb + mbi] = (uint8_t)min(max(k.qp + ((adj + 128) >> 8), 1), 51);
 }
 
+// quantiser offsets decided by the lookahead (AQ - macroblock-tree, Q8) -> per-macroblock quantisers (oracle compute_mb_qp, ext_off_q8)
+__global__ __launch_bounds__(256) void k_apply_qp_offsets(EncK k, const int16_t *__restrict__ off)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x, s = blockIdx.y;
+    if (i < k.nmb) k.mbqp[(size_t)s * k.nmb + i] = (uint8_t)min(max(k.qp + (((int)off[(size_t)s * k.nmb + i] + 128) >> 8), 1), 51);
+}
+
 // QP_Y inheritance (oracle settle_mb_qp, 7.4.5): a macroblock that sends no mb_qp_delta takes its predecessor's quantiser; one wave per
 // stream walks the records 64 at a time (ballot of the macroblocks that keep their own value, highest one at or below each lane).
 __global__ __launch_bounds__(64) void k_settle_qp(EncK k)
