@@ -181,23 +181,37 @@ def test_gop_parallel_equals_serial(gpu, w, h, nfr, keyint, threads):
 
 
 def encode_with_decisions(h_, w, h, frames):
-    """encode_all + the per-picture decisions (quantiser, scenecut flag, lookahead sums) the host took"""
+    """encode + flush (the lookahead may hold pictures back: x264_encoder_delayed_frames / encode(NULL), codec.c:1842-1856), with
+    the per-picture decisions (quantiser, scenecut flag, lookahead sums) the host took; rows are in output = input order"""
     pic, out = HL.Picture(), HL.Picture()
     assert H.x264_picture_alloc(C.byref(pic), HL.X264_CSP_I420, w, h) == 0
     stream, rows, recons = b"", [], []
+
+    def take(size, nal):
+        nonlocal stream
+        stream += C.string_at(nal[0].p_payload, size)
+        qp, sc, costs = C.c_int(), C.c_int(), (C.c_int32 * 4)()
+        assert H.x264host_last_decision(h_, C.byref(qp), C.byref(sc), costs) == 0
+        assert out.i_pts == len(rows)
+        rows.append((int(out.b_keyframe), qp.value, sc.value, list(costs), int(out.i_type)))
+        rec = np.zeros(w * h * 3 // 2, np.uint8)
+        assert H.x264host_get_recon(h_, rec.ctypes.data) == 0
+        recons.append(rec)
     for i, f in enumerate(frames):
         C.memmove(pic.img.plane[0], f.ctypes.data, f.size)
         pic.i_pts = i
         nal, n = C.POINTER(HL.Nal)(), C.c_int()
         size = H.x264_encoder_encode(h_, C.byref(nal), C.byref(n), C.byref(pic), C.byref(out))
+        assert size >= 0
+        if size:
+            take(size, nal)
+        assert H.x264_encoder_delayed_frames(h_) == i + 1 - len(rows)
+    while H.x264_encoder_delayed_frames(h_):
+        nal, n = C.POINTER(HL.Nal)(), C.c_int()
+        size = H.x264_encoder_encode(h_, C.byref(nal), C.byref(n), None, C.byref(out))
         assert size > 0
-        stream += C.string_at(nal[0].p_payload, size)
-        qp, sc, costs = C.c_int(), C.c_int(), (C.c_int32 * 4)()
-        assert H.x264host_last_decision(h_, C.byref(qp), C.byref(sc), costs) == 0
-        rows.append((int(out.b_keyframe), qp.value, sc.value, list(costs)))
-        rec = np.zeros(w * h * 3 // 2, np.uint8)
-        assert H.x264host_get_recon(h_, rec.ctypes.data) == 0
-        recons.append(rec)
+        take(size, nal)
+    assert len(rows) == len(frames)
     H.x264_picture_clean(C.byref(pic))
     return stream, rows, recons
 
@@ -227,8 +241,8 @@ def test_crf_follows_the_lookahead_complexity(gpu):
     reconstruction (slice_qp_delta carries the quantiser) and the oracle pipeline fed the same quantisers matches too."""
     w, h, crf, qcomp, ipf = 176, 144, 26.0, 0.6, 1.4
     frames = synth_frames(w, h, 5, seed=5) + synth_frames(w, h, 4, seed=99)
-    h_, eff = open_encoder(w, h, {"crf": crf, "keyint": 250, "min-keyint": 3}, b"high")
-    assert eff.rc.i_rc_method == HL.X264_RC_CRF
+    h_, eff = open_encoder(w, h, {"crf": crf, "keyint": 250, "min-keyint": 3, "no-mbtree": None}, b"high")
+    assert eff.rc.i_rc_method == HL.X264_RC_CRF and eff.rc.b_mb_tree == 0 and eff.rc.i_lookahead == 0
     stream, rows, recons = encode_with_decisions(h_, w, h, frames)
     H.x264_encoder_close(h_)
     nmb = ((w + 15) // 16) * ((h + 15) // 16)
@@ -237,7 +251,7 @@ def test_crf_follows_the_lookahead_complexity(gpu):
     cs = cc = apq = apn = 0.0
     last_i = True
     qps = []
-    for i, (key, qp, sc, costs) in enumerate(rows):
+    for i, (key, qp, sc, costs, _typ) in enumerate(rows):
         satd = costs[0] if key else costs[1]
         cs, cc = cs * 0.5 + satd, cc * 0.5 + 1
         q = (cs / cc) ** (1 - qcomp) / rfc
@@ -318,3 +332,40 @@ def test_abr_steers_towards_the_bitrate(gpu):
     assert 0.5 * 400 < lo[0] < 2.0 * 400 and 0.5 * 1600 < hi[0] < 2.0 * 1600, (lo[0], hi[0])
     assert np.mean(lo[1][10:]) > np.mean(hi[1][10:]) + 4                        # ~4x the bits is ~12 quantiser steps in theory
     assert len(set(lo[1])) > 2                                                  # it actually moves
+
+
+def test_crf_with_macroblock_tree(gpu):
+    """the driver's default rate control in full: CRF + variance AQ + macroblock-tree over rc-lookahead pictures held back in the
+    lookahead queue.  The frame quantiser is the constant crf + 13.5 (1 - qcomp) (the tree does the complexity weighting), the
+    macroblock offsets are AQ - tree; the whole chain is replayed with the CPU oracle (lookahead records -> x264o_mbtree -> oracle
+    pipeline with those offsets) and must reproduce the host encoder's reconstruction; the stream decodes to it as well."""
+    w, h, crf, look = 176, 144, 24.0, 4
+    frames = synth_frames(w, h, 7, seed=5) + synth_frames(w, h, 4, seed=99)
+    h_, eff = open_encoder(w, h, {"crf": crf, "keyint": 250, "min-keyint": 3, "rc-lookahead": look}, b"high")
+    assert (eff.rc.b_mb_tree, eff.rc.i_lookahead, eff.rc.i_aq_mode) == (1, look, 1)
+    stream, rows, recons = encode_with_decisions(h_, w, h, frames)
+    H.x264_encoder_close(h_)
+    n = len(frames)
+    types = [2 if r[0] else (1 if r[4] == 2 else 0) for r in rows]            # X264_TYPE_I == 2: I picture that is not IDR
+    assert types[0] == 2 and types[7] in (1, 2) and sum(1 for t in types if t) == 2
+    frame_qp = int(crf + 13.5 * (1 - 0.6) + 0.5)
+    assert all(r[1] == frame_qp for r, t in zip(rows, types) if t == 0)
+    dec = O.h264_decode(stream, n, w, h)
+    ol = O.OracleLookahead(w, h)
+    infos = [ol.frame_cost(f, i == 0)[1] for i, f in enumerate(frames)]
+    aqs = [O.aq_offsets(f, w, h, 266) for f in frames]
+    og = O.OracleEncoder(O.default_config(w, h, partitions=7, refs=3, dct8x8=1, chroma_me=1, mixed_refs=1, aq_mode=1, aq_strength_q8=266))
+    bw, bh = (w + 15) // 16, (h + 15) // 16
+    lowered = 0
+    for i, f in enumerate(frames):
+        np.testing.assert_array_equal(dec[i], recons[i], err_msg=f"decoded picture {i}")
+        last = i                                                            # the window: this picture + the P pictures queued behind it
+        while last + 1 < min(n, i + look + 1) and types[last + 1] == 0:
+            last += 1
+        off = O.mbtree(bw, bh, infos[i:last + 1], aqs[i:last + 1], int(1280 * (1 - 0.6) + 0.5))
+        lowered += int((off < aqs[i]).sum())
+        og.set_mb_qp_offsets(off)
+        og.set_qp(rows[i][1], rows[i][1])
+        og.encode(f, 2 if types[i] == 2 else 3 if types[i] == 1 else 0)
+        np.testing.assert_array_equal(og.recon(), recons[i], err_msg=f"oracle chain picture {i}")
+    assert lowered > 50

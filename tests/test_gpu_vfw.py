@@ -63,6 +63,11 @@ def test_small_output_buffer_is_an_error(gpu):
     f = synth_frames(w, h, 1, seed=2)[0]
     ico = V.ICOPEN(fccType=V.fourcc(b"vidc"))
     cid = D(0, None, V.DRV_OPEN, 0, V.addr(ico))
+    n = D(cid, None, V.ICM_GETSTATE, 0, 0)
+    cfg = V.VfwConfig()
+    D(cid, None, V.ICM_GETSTATE, V.addr(cfg), n)
+    cfg.b_zerolatency = 1                                                    # the first call has to produce a frame
+    assert D(cid, None, V.ICM_SETSTATE, V.addr(cfg), n) == n
     inb, outb = V.bmi(w, h, b"I420"), V.BITMAPINFO()
     D(cid, None, V.ICM_COMPRESS_GET_FORMAT, V.addr(inb), V.addr(outb))
     assert D(cid, None, V.ICM_COMPRESS_BEGIN, V.addr(inb), V.addr(outb)) == V.ICERR_OK
@@ -75,6 +80,62 @@ def test_small_output_buffer_is_an_error(gpu):
     assert b"output frame buffer too small" in V.H.x264vfw_shim_log(cid)
     assert D(cid, None, V.ICM_COMPRESS, V.addr(icc), 0) == V.ICERR_ERROR     # sticky b_encoder_error
     D(cid, None, V.DRV_CLOSE, 0, 0)
+
+
+def test_default_session_delays_output_by_the_lookahead(gpu, tmp_path):
+    """the driver's defaults (single pass CRF, preset medium: macroblock-tree over rc-lookahead 40): ICM_COMPRESS hands back empty
+    frames while the lookahead fills, warns once about the frames a VfW host will lose (codec.c:1798-1807), and with file output
+    compress_end flushes every picture (codec.c:1842-1856)."""
+    w, h, nfr, look = 96, 80, 9, 5
+    frames = synth_frames(w, h, nfr, seed=8)
+
+    def run(cmdline):
+        ico = V.ICOPEN(fccType=V.fourcc(b"vidc"))
+        cid = D(0, None, V.DRV_OPEN, 0, V.addr(ico))
+        n = D(cid, None, V.ICM_GETSTATE, 0, 0)
+        cfg = V.VfwConfig()
+        D(cid, None, V.ICM_GETSTATE, V.addr(cfg), n)
+        assert cfg.i_encoding_type == 2 and cfg.b_zerolatency == 0          # config.c defaults: single pass ratefactor-based (CRF)
+        cfg.extra_cmdline = cmdline
+        D(cid, None, V.ICM_SETSTATE, V.addr(cfg), n)
+        inb, outb = V.bmi(w, h, b"I420"), V.BITMAPINFO()
+        assert D(cid, None, V.ICM_COMPRESS_GET_FORMAT, V.addr(inb), V.addr(outb)) == V.ICERR_OK
+        assert D(cid, None, V.ICM_COMPRESS_BEGIN, V.addr(inb), V.addr(outb)) == V.ICERR_OK, V.H.x264vfw_shim_log(cid)
+        cap = outb.bmiHeader.biSizeImage
+        buf = C.create_string_buffer(cap)
+        stream, sizes, keys = b"", [], []
+        for f in frames:
+            flags = V.DWORD(0xdead)
+            outb.bmiHeader.biSizeImage = cap
+            icc = V.ICCOMPRESS(lpbiOutput=C.pointer(outb.bmiHeader), lpOutput=C.cast(buf, C.c_void_p), lpbiInput=C.pointer(inb.bmiHeader),
+                               lpInput=f.ctypes.data, lpdwFlags=C.pointer(flags))
+            assert D(cid, None, V.ICM_COMPRESS, V.addr(icc), C.sizeof(icc)) == V.ICERR_OK
+            sizes.append(outb.bmiHeader.biSizeImage)
+            keys.append(flags.value)
+            stream += buf.raw[:outb.bmiHeader.biSizeImage]
+        log = V.H.x264vfw_shim_log(cid)
+        assert D(cid, None, V.ICM_COMPRESS_END, 0, 0) == V.ICERR_OK
+        D(cid, None, V.DRV_CLOSE, 0, 0)
+        return stream, sizes, keys, log
+
+    opts = b"--rc-lookahead %d --keyint 250 " % look
+    stream, sizes, keys, log = run(opts)
+    assert sizes[:look] == [0] * look and all(s > 0 for s in sizes[look:])
+    assert keys[:look + 1] == [0] * look + [V.AVIIF_KEYFRAME] and log.count(b"Few frames probably would be lost") == 1
+    dec = O.h264_decode(stream, nfr - look, w, h)                            # the tail stays in the lookahead: the loss the log warns of
+    assert len(dec) == nfr - look
+    path = tmp_path / "d.h264"
+    to_file, sizes, keys, log = run(opts + b"--output " + str(path).encode())
+    assert to_file == b"" and b"Few frames" not in log
+    data = path.read_bytes()
+    assert data.startswith(stream)                                           # same pictures, then the flushed tail
+    from synth import psnr
+    full = O.h264_decode(data, nfr, w, h)
+    ps = [psnr(full[i][:w * h], frames[i][:w * h]) for i in range(len(full))]
+    assert len(full) == nfr and min(ps) > 30.0, ps
+    # zero latency (config.c / codec.c:1439 tune zerolatency): rc-lookahead 0, a frame per call
+    stream0, sizes0, _, _ = run(b"--tune zerolatency --keyint 250")
+    assert all(s > 0 for s in sizes0)
 
 
 @pytest.mark.parametrize("fmt", ["YUY2", "UYVY", "YV16", "YV24", "RGB24", "RGB32", "RGB32_topdown"])

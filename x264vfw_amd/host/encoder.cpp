@@ -58,6 +58,16 @@ struct x264_t {
     } rc;
     bool abr = false;
     double t_phase[6] = { 0, 0, 0, 0, 0, 0 };   // X264GPU_HOST_TIMING=1: seconds in copy-in, upload + lookahead, GPU, download, entropy coding, calls
+    // ---- lookahead queue (threads 1): pictures wait here rc-lookahead deep when the macroblock-tree needs to see what follows them ----
+    struct QEntry { int64_t pts; int slot; int type; int scenecut; int32_t costs[4]; x264_image_t img; };      // type: 0 P, 1 I, 2 IDR
+    std::deque<QEntry> queue;
+    int L = 0, Q = 1;                    // pictures held back; ring slots (L + 1)
+    std::vector<uint8_t *> q_raw;        // device: source pictures (slot 0 is d_in when nothing is held back: zero-copy input)
+    std::vector<int32_t *> q_info;       // device: lookahead block records per slot
+    std::vector<int16_t *> q_aq;         // device: AQ offsets per slot
+    int16_t *d_tree = nullptr;           // device: macroblock-tree quantiser offsets of the picture being coded
+    long la_count = 0; int la_gop = 0;   // pictures seen by the lookahead; distance from the last IDR at lookahead time
+    bool mbtree = false; int aq_strength_q8 = 0, tree_strength_q8 = 0;
     int cavlc_threads = 1;               // row bands of a slice coded in parallel (threads 1 sessions; GOP-parallel ones use a thread per GOP)
     int last_qp = 0, last_scenecut = 0;  // diagnostics: quantiser and scenecut flag of the last coded picture
     int32_t last_costs[4] = { 0, 0, 0, 0 };
@@ -175,7 +185,7 @@ x264_t *x264_encoder_open(x264_param_t *param)
     p.analyse.b_transform_8x8 = p.analyse.b_transform_8x8 != 0;
     p.analyse.inter &= X264_ANALYSE_I4x4 | X264_ANALYSE_I8x8 | X264_ANALYSE_PSUB16x16; p.analyse.intra &= X264_ANALYSE_I4x4 | X264_ANALYSE_I8x8;
     if (!p.analyse.b_transform_8x8) { p.analyse.inter &= ~X264_ANALYSE_I8x8; p.analyse.intra &= ~X264_ANALYSE_I8x8; }   // as x264 validate_parameters
-    p.analyse.i_trellis = 0; p.rc.b_mb_tree = 0; p.rc.i_lookahead = 0;
+    p.analyse.i_trellis = 0;
     p.i_scenecut_threshold = clampi(p.i_scenecut_threshold, 0, 100);
     if (p.analyse.i_me_method > X264_ME_ESA) { xlog(&p, X264_LOG_WARNING, "me tesa is not implemented in the MI355X path yet: me esa\n"); p.analyse.i_me_method = X264_ME_ESA; }
     p.analyse.i_me_range = clampi(p.analyse.i_me_range, 4, p.analyse.i_me_method == X264_ME_UMH ? 64 : 16);     // x264 caps dia/hex at 16; esa: the LDS search window
@@ -196,6 +206,10 @@ x264_t *x264_encoder_open(x264_param_t *param)
     p.rc.i_vbv_max_bitrate = 0; p.rc.i_vbv_buffer_size = 0;
     // adaptive quantisation: variance AQ (mode 1) under CRF / ABR; x264 itself switches AQ off under constant QP and at strength 0
     if (p.rc.i_rc_method == X264_RC_CQP || p.rc.f_aq_strength <= 0) p.rc.i_aq_mode = X264_AQ_NONE;
+    // macroblock-tree: needs a rate-controlled session and pictures held back (rc-lookahead); x264 switches it off under constant QP
+    if (p.rc.i_rc_method == X264_RC_CQP || p.rc.i_lookahead <= 0) p.rc.b_mb_tree = 0;
+    p.rc.b_mb_tree = p.rc.b_mb_tree != 0;
+    p.rc.i_lookahead = p.rc.b_mb_tree ? clampi(p.rc.i_lookahead, 1, p.i_keyint_max < 250 ? (p.i_keyint_max > 1 ? p.i_keyint_max : 1) : 250) : 0;
     if (p.rc.i_aq_mode > X264_AQ_VARIANCE) { xlog(&p, X264_LOG_WARNING, "aq-mode %d is not implemented yet: aq-mode 1\n", p.rc.i_aq_mode); p.rc.i_aq_mode = X264_AQ_VARIANCE; }
     p.rc.i_qp_constant = clampi(qp, 1, 51);
     p.rc.i_qp_min = clampi(p.rc.i_qp_min, 1, 51); p.rc.i_qp_max = clampi(p.rc.i_qp_max, p.rc.i_qp_min, 51);
@@ -255,12 +269,36 @@ x264_t *x264_encoder_open(x264_param_t *param)
             return nullptr;
         }
     }
+    // lookahead queue: rc-lookahead pictures are held back when the macroblock-tree is on (x264's sync lookahead), none otherwise
+    h->mbtree = p.rc.b_mb_tree && h->la != nullptr;
+    h->L = h->mbtree ? p.rc.i_lookahead : 0;
+    h->Q = h->L + 1;
+    h->aq_strength_q8 = cfg.aq_mode ? cfg.aq_strength_q8 : 0;
+    h->tree_strength_q8 = (int)(1280.0 * (1.0 - p.rc.f_qcompress) + 0.5);     // 5 * (1 - qcomp), Q8
+    h->q_raw.assign((size_t)h->Q, nullptr); h->q_info.assign((size_t)h->Q, nullptr); h->q_aq.assign((size_t)h->Q, nullptr);
+    if (h->Q == 1) h->q_raw[0] = h->d_in;            // no delay: the staging buffer is the one slot; with a delay the ring is separate,
+                                                     // because a zero-copy caller rewrites the staging buffer every call
+    {
+        bool ok = true;
+        for (int i = 0; i < h->Q && ok; i++) {
+            if (!h->q_raw[(size_t)i]) ok = x264gpu_malloc((void **)&h->q_raw[(size_t)i], insz) == X264GPU_OK;
+            if (ok && h->mbtree) ok = x264gpu_malloc((void **)&h->q_info[(size_t)i], (size_t)h->nmb * 4 * sizeof(int32_t)) == X264GPU_OK &&
+                                       x264gpu_malloc((void **)&h->q_aq[(size_t)i], (size_t)h->nmb * sizeof(int16_t)) == X264GPU_OK;
+        }
+        if (ok && h->mbtree) ok = x264gpu_malloc((void **)&h->d_tree, (size_t)h->nmb * sizeof(int16_t)) == X264GPU_OK;
+        if (!ok) {
+            xlog(&p, X264_LOG_ERROR, "GPU lookahead queue setup failed: %s\n", x264gpu_last_error());
+            x264_encoder_close(h);
+            return nullptr;
+        }
+    }
     if (h->crf || h->abr) {
         // x264_ratecontrol_new: rate_factor_constant = base_cplx^(1 - qcomp) / qp2qscale(crf), base_cplx = mbs * (bframes ? 120 : 80)
         auto qp2qscale = [](double q) { return 0.85 * pow(2.0, (q - 12.0) / 6.0); };
         h->rc.qcompress = p.rc.f_qcompress; h->rc.ip_factor = fabs(p.rc.f_ip_factor) > 0 ? fabs(p.rc.f_ip_factor) : 1.0;
         h->rc.ip_offset = 6.0 * log2(h->rc.ip_factor);
-        h->rc.rate_factor_constant = pow((double)h->nmb * 80.0, 1.0 - h->rc.qcompress) / qp2qscale(p.rc.f_rf_constant);
+        if (p.rc.b_mb_tree) h->rc.qcompress = 1.0;                     // x264_ratecontrol_new: the tree does the complexity weighting, CRF shifts by 13.5 (1 - qcomp)
+        h->rc.rate_factor_constant = pow((double)h->nmb * 80.0, 1.0 - h->rc.qcompress) / qp2qscale(p.rc.f_rf_constant + (p.rc.b_mb_tree ? (1.0 - p.rc.f_qcompress) * 13.5 : 0.0));
         h->rc.last_qscale_for[0] = h->rc.last_qscale_for[1] = qp2qscale(p.rc.f_rf_constant);
         h->rc.lmin = qp2qscale(p.rc.i_qp_min); h->rc.lmax = qp2qscale(p.rc.i_qp_max);
         double dur = p.i_fps_num ? (double)p.i_fps_den / p.i_fps_num : 0.04;
@@ -455,123 +493,86 @@ static int encode_gop_parallel(x264_t *h, x264_nal_t **pp_nal, int *pi_nal, x264
     return (int)h->out.size();
 }
 
-int x264_encoder_encode(x264_t *h, x264_nal_t **pp_nal, int *pi_nal, x264_picture_t *pic_in, x264_picture_t *pic_out)
+// Codes the oldest picture of the lookahead queue: macroblock-tree over the pictures queued behind it (up to the next intra picture),
+// rate control, the GPU hot path, entropy coding.  Returns the bytes of its NAL units.
+static int encode_queued(x264_t *h, x264_nal_t **pp_nal, int *pi_nal, x264_picture_t *pic_out)
 {
-    if (!h || !pp_nal || !pi_nal) return -1;
-    *pi_nal = 0; *pp_nal = nullptr;
-    if (!pic_in) return h->G > 1 ? encode_gop_parallel(h, pp_nal, pi_nal, nullptr, pic_out, false) : 0;   // flush
     const x264_param_t &p = h->param;
-    const int w = p.i_width, ht = p.i_height;
-    if ((pic_in->img.i_csp & X264_CSP_MASK) != X264_CSP_I420 || pic_in->img.i_plane < 3) {
-        xlog(&p, X264_LOG_ERROR, "x264_encoder_encode: input picture must be I420\n");
-        return -1;
-    }
-    // Zero-copy input (x264gpu_host_input_i420): the caller (the VfW shell after the device-side colourspace conversion)
-    // already placed a tight I420 picture in the encoder's device staging buffer.
-    const bool resident = pic_in->img.plane[0] == h->d_in;
-    auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
-    double t0 = now(), t1;
-#define PHASE(i) do { t1 = now(); h->t_phase[i] += t1 - t0; t0 = t1; } while (0)
-    // ---- frame copy-in: three strided planes -> one tightly packed I420 buffer -> HBM (replaces x264_frame_copy_picture) ----
-    uint8_t *dst = h->h_in.data();
-    for (int pl = 0; pl < 3 && !resident; pl++) {
-        int pw = pl ? w / 2 : w, ph = pl ? ht / 2 : ht;
-        const uint8_t *src = pic_in->img.plane[pl];
-        for (int y = 0; y < ph; y++, dst += pw, src += pic_in->img.i_stride[pl]) memcpy(dst, src, pw);
-    }
-    if (h->G > 1) return encode_gop_parallel(h, pp_nal, pi_nal, pic_in, pic_out, resident);
-    PHASE(0);
-    bool idr = h->frames_since_idr == 0 || h->frames_since_idr >= h->keyint || pic_in->i_type == X264_TYPE_IDR || pic_in->i_type == X264_TYPE_KEYFRAME;
-    if (!resident && x264gpu_memcpy_h2d(h->d_in, h->h_in.data(), h->h_in.size(), nullptr) != X264GPU_OK) {
-        xlog(&p, X264_LOG_ERROR, "x264_encoder_encode: upload failed: %s\n", x264gpu_last_error());
-        return -1;
-    }
-    int qp_now = idr ? h->qp_i : h->qp_p;
-    bool intra_pic = false;              // I picture that is not IDR
-    h->last_scenecut = 0;
-    if (h->la) {
-        // ---- lookahead: cost of coding this picture intra / predicted from the previous SOURCE picture (slicetype.c) ----
-        int32_t c[4];
-        if (x264gpu_lookahead_frame_cost(h->la, h->d_in, h->frame_no == 0, h->d_la, nullptr, nullptr) != X264GPU_OK ||
-            x264gpu_memcpy_d2h(c, h->d_la, sizeof(c), nullptr) != X264GPU_OK) {
-            xlog(&p, X264_LOG_ERROR, "x264_encoder_encode: lookahead failed: %s\n", x264gpu_last_error());
+    const x264_t::QEntry e = h->queue.front();
+    const bool idr = e.type == 2, intra_pic = e.type == 1, is_i = idr || intra_pic;
+    int qp_now = is_i ? h->qp_i : h->qp_p;
+    h->last_scenecut = e.scenecut;
+    memcpy(h->last_costs, e.costs, sizeof(e.costs));
+    if (h->mbtree) {
+        // macroblock_tree: this picture and the P pictures behind it that (transitively) reference it; an intra picture ends the chain
+        const int32_t *info[256]; const int16_t *aq[256];
+        int n = 0;
+        for (const x264_t::QEntry &q : h->queue) {
+            if (n > 0 && q.type != 0) break;
+            info[n] = h->q_info[(size_t)q.slot]; aq[n] = h->q_aq[(size_t)q.slot];
+            if (++n == 256) break;
+        }
+        if (x264gpu_lookahead_mbtree(h->la, info, h->aq_strength_q8 ? aq : nullptr, n, h->tree_strength_q8, h->d_tree, nullptr) != X264GPU_OK ||
+            x264gpu_encoder_set_mb_qp_offsets(h->gpu, h->d_tree) != X264GPU_OK) {
+            xlog(&p, X264_LOG_ERROR, "x264_encoder_encode: macroblock-tree failed: %s\n", x264gpu_last_error());
             return -1;
         }
-        memcpy(h->last_costs, c, sizeof(c));
-        if (!idr && p.i_scenecut_threshold > 0 && h->frame_no > 0) {
-            // scenecut_internal: the bias grows with the distance from the last keyframe.  A cut at or beyond min-keyint becomes
-            // an IDR picture, one inside min-keyint an I picture that keeps the references (x264_slicetype_decide).
-            const int gop = h->frames_since_idr, kmin = h->keyint_min, kmax = h->keyint;
-            const double tmax = p.i_scenecut_threshold / 100.0, tmin = kmin == kmax ? tmax : tmax * 0.25;
-            double bias;
-            if (gop <= kmin / 4) bias = tmin / 4;
-            else if (gop <= kmin) bias = tmin * gop / kmin;
-            else bias = tmin + (tmax - tmin) * (gop - kmin) / (kmax - kmin);
-            h->last_scenecut = (double)c[1] >= (1.0 - bias) * (double)c[0];
-            if (h->last_scenecut) { if (gop >= kmin) idr = true; else intra_pic = true; qp_now = h->qp_i; }
-        }
-        if (h->crf || h->abr) {
-            // rate_estimate_qscale, CRF: q = blurred_complexity^(1 - qcomp) / rate_factor; an I picture after P pictures takes the
-            // running P quantiser / ipratio; the quantiser is qscale2qp(q) rounded, within [qpmin, qpmax]
-            auto qp2qscale = [](double q) { return 0.85 * pow(2.0, (q - 12.0) / 6.0); };
-            auto qscale2qp = [](double qs) { return 12.0 + 6.0 * log2(qs / 0.85); };
-            const bool is_i = idr || intra_pic;
-            const double satd = is_i ? c[0] : c[1];
-            h->rc.cplxsum = h->rc.cplxsum * 0.5 + satd / h->rc.dur_ratio;
-            h->rc.cplxcount = h->rc.cplxcount * 0.5 + 1.0;
-            // get_qscale: rceq = blurred_complexity^(1 - qcomp), divided by the rate factor: the CRF constant, or under ABR the one
-            // that would have met the bitrate so far (wanted_bits_window / cplxr_sum)
-            double q, overflow = 1.0;
-            const double rate_factor = h->crf ? h->rc.rate_factor_constant : h->rc.wanted_bits_window / h->rc.cplxr_sum;
-            if (satd > 0) { h->rc.last_rceq = pow(h->rc.cplxsum / h->rc.cplxcount, 1.0 - h->rc.qcompress); q = h->rc.last_rceq / rate_factor; }
-            else q = h->rc.last_qscale_for[is_i ? 0 : 1];
-            if (h->abr && satd > 0) {
-                // pull towards the target: bits so far against time so far, within an abr_buffer that grows with sqrt(time)
-                const double time_done = h->frame_no / h->rc.fps, wanted_bits = time_done * h->rc.bitrate;
-                if (wanted_bits > 0) {
-                    const double buf = h->rc.abr_buffer * (time_done > 1.0 ? sqrt(time_done) : 1.0);
-                    overflow = 1.0 + (h->rc.total_bits - wanted_bits) / buf;
-                    overflow = overflow < 0.5 ? 0.5 : overflow > 2.0 ? 2.0 : overflow;
-                    q *= overflow;
-                }
+    }
+    if (h->crf || h->abr) {
+        // rate_estimate_qscale: q = rceq / rate_factor; rceq = blurred_complexity^(1 - qcomp), or under macroblock-tree (which does the
+        // complexity weighting itself) the frame-duration term alone; an I picture after P pictures takes the running P quantiser /
+        // ipratio; the quantiser is qscale2qp(q) rounded, within [qpmin, qpmax]
+        auto qp2qscale = [](double q) { return 0.85 * pow(2.0, (q - 12.0) / 6.0); };
+        auto qscale2qp = [](double qs) { return 12.0 + 6.0 * log2(qs / 0.85); };
+        const double satd = is_i ? e.costs[0] : e.costs[1];
+        h->rc.cplxsum = h->rc.cplxsum * 0.5 + satd / h->rc.dur_ratio;
+        h->rc.cplxcount = h->rc.cplxcount * 0.5 + 1.0;
+        double q, overflow = 1.0;
+        const double rate_factor = h->crf ? h->rc.rate_factor_constant : h->rc.wanted_bits_window / h->rc.cplxr_sum;
+        if (satd > 0) {
+            h->rc.last_rceq = h->mbtree ? pow(1.0 / h->rc.dur_ratio, 1.0 - p.rc.f_qcompress) : pow(h->rc.cplxsum / h->rc.cplxcount, 1.0 - h->rc.qcompress);
+            q = h->rc.last_rceq / rate_factor;
+        } else q = h->rc.last_qscale_for[is_i ? 0 : 1];
+        if (h->abr && satd > 0) {
+            // pull towards the target: bits so far against time so far, within an abr_buffer that grows with sqrt(time)
+            const double time_done = h->frame_no / h->rc.fps, wanted_bits = time_done * h->rc.bitrate;
+            if (wanted_bits > 0) {
+                const double buf = h->rc.abr_buffer * (time_done > 1.0 ? sqrt(time_done) : 1.0);
+                overflow = 1.0 + (h->rc.total_bits - wanted_bits) / buf;
+                overflow = overflow < 0.5 ? 0.5 : overflow > 2.0 ? 2.0 : overflow;
+                q *= overflow;
             }
-            if (is_i && h->keyint > 1 && !h->rc.last_non_b_is_i) q = qp2qscale(h->rc.accum_p_qp / h->rc.accum_p_norm) / h->rc.ip_factor;
-            else if (h->frame_no > 0) {
-                if (h->abr) {       // asymmetric clipping against the last quantiser of the same picture type (qpstep)
-                    double lmin = h->rc.last_qscale_for[is_i ? 0 : 1] / h->rc.lstep, lmax = h->rc.last_qscale_for[is_i ? 0 : 1] * h->rc.lstep;
-                    if (overflow > 1.1 && h->frame_no > 3) lmax *= h->rc.lstep;
-                    else if (overflow < 0.9) lmin /= h->rc.lstep;
-                    q = q < lmin ? lmin : q > lmax ? lmax : q;
-                }
-            } else if (h->crf && h->rc.qcompress != 1.0) q = qp2qscale(p.rc.f_rf_constant) / h->rc.ip_factor;       // very first picture: ABR_INIT_QP / ipratio
-            q = q < h->rc.lmin ? h->rc.lmin : q > h->rc.lmax ? h->rc.lmax : q;
-            h->rc.last_qscale_for[is_i ? 0 : 1] = q;
-            if (h->frame_no == 0) h->rc.last_qscale_for[1] = q * h->rc.ip_factor;
-            double qpf = qscale2qp(q);
-            qpf = qpf < p.rc.i_qp_min ? p.rc.i_qp_min : qpf > p.rc.i_qp_max ? p.rc.i_qp_max : qpf;
-            qp_now = clampi((int)(qpf + 0.5), 1, 51);
-            h->rc.accum_p_qp = h->rc.accum_p_qp * 0.95 + (is_i ? qpf + h->rc.ip_offset : qpf);      // accum_p_qp_update
-            h->rc.accum_p_norm = h->rc.accum_p_norm * 0.95 + 1.0;
-            h->rc.last_non_b_is_i = is_i;
-            h->rc.qpa_last = qpf;
-            if (x264gpu_encoder_set_qp(h->gpu, qp_now, qp_now) != X264GPU_OK) return -1;
         }
+        if (is_i && h->keyint > 1 && !h->rc.last_non_b_is_i) q = qp2qscale(h->rc.accum_p_qp / h->rc.accum_p_norm) / h->rc.ip_factor;
+        else if (h->frame_no > 0) {
+            if (h->abr) {       // asymmetric clipping against the last quantiser of the same picture type (qpstep)
+                double lmin = h->rc.last_qscale_for[is_i ? 0 : 1] / h->rc.lstep, lmax = h->rc.last_qscale_for[is_i ? 0 : 1] * h->rc.lstep;
+                if (overflow > 1.1 && h->frame_no > 3) lmax *= h->rc.lstep;
+                else if (overflow < 0.9) lmin /= h->rc.lstep;
+                q = q < lmin ? lmin : q > lmax ? lmax : q;
+            }
+        } else if (h->crf && h->rc.qcompress != 1.0) q = qp2qscale(p.rc.f_rf_constant) / h->rc.ip_factor;       // very first picture: ABR_INIT_QP / ipratio
+        q = q < h->rc.lmin ? h->rc.lmin : q > h->rc.lmax ? h->rc.lmax : q;
+        h->rc.last_qscale_for[is_i ? 0 : 1] = q;
+        if (h->frame_no == 0) h->rc.last_qscale_for[1] = q * h->rc.ip_factor;
+        double qpf = qscale2qp(q);
+        qpf = qpf < p.rc.i_qp_min ? p.rc.i_qp_min : qpf > p.rc.i_qp_max ? p.rc.i_qp_max : qpf;
+        qp_now = clampi((int)(qpf + 0.5), 1, 51);
+        h->rc.accum_p_qp = h->rc.accum_p_qp * 0.95 + (is_i ? qpf + h->rc.ip_offset : qpf);      // accum_p_qp_update
+        h->rc.accum_p_norm = h->rc.accum_p_norm * 0.95 + 1.0;
+        h->rc.last_non_b_is_i = is_i;
+        h->rc.qpa_last = qpf;
+        if (x264gpu_encoder_set_qp(h->gpu, qp_now, qp_now) != X264GPU_OK) return -1;
     }
     h->last_qp = qp_now;
     if (idr) { h->frames_since_idr = 0; h->frame_num = 0; }
-    int st = idr ? X264GPU_SLICE_I : intra_pic ? X264GPU_SLICE_I_NONIDR : X264GPU_SLICE_P;
-    PHASE(1);
-    if (x264gpu_encode_frames(h->gpu, h->d_in, st, h->d_mb, h->d_lv, nullptr) != X264GPU_OK || x264gpu_stream_sync(nullptr) != X264GPU_OK) {
-        xlog(&p, X264_LOG_ERROR, "x264_encoder_encode: GPU hot path failed: %s\n", x264gpu_last_error());
-        return -1;
-    }
-    PHASE(2);
-    if (x264gpu_memcpy_d2h(h->h_mb.data(), h->d_mb, h->h_mb.size() * sizeof(x264gpu_mb), nullptr) != X264GPU_OK ||
+    const int st = idr ? X264GPU_SLICE_I : intra_pic ? X264GPU_SLICE_I_NONIDR : X264GPU_SLICE_P;
+    if (x264gpu_encode_frames(h->gpu, h->q_raw[(size_t)e.slot], st, h->d_mb, h->d_lv, nullptr) != X264GPU_OK ||
+        x264gpu_memcpy_d2h(h->h_mb.data(), h->d_mb, h->h_mb.size() * sizeof(x264gpu_mb), nullptr) != X264GPU_OK ||
         x264gpu_memcpy_d2h(h->h_lv.data(), h->d_lv, h->h_lv.size() * sizeof(int16_t), nullptr) != X264GPU_OK) {
         xlog(&p, X264_LOG_ERROR, "x264_encoder_encode: GPU hot path failed: %s\n", x264gpu_last_error());
         return -1;
     }
-    PHASE(3);
     // ---- host: headers + entropy coding ----
     h->out.clear(); h->nal_off.clear();
     std::vector<int> types;
@@ -596,8 +597,8 @@ int x264_encoder_encode(x264_t *h, x264_nal_t **pp_nal, int *pi_nal, x264_pictur
         x264_picture_init(pic_out);
         pic_out->i_type = idr ? X264_TYPE_IDR : intra_pic ? X264_TYPE_I : X264_TYPE_P;
         pic_out->b_keyframe = idr;
-        pic_out->i_pts = pic_in->i_pts; pic_out->i_dts = pic_in->i_pts;
-        pic_out->img = pic_in->img;
+        pic_out->i_pts = e.pts; pic_out->i_dts = e.pts;
+        pic_out->img = e.img;
     }
     if (idr) h->idr_pic_id = (h->idr_pic_id + 1) & 0xffff;
     h->frame_num = (h->frame_num + 1) & ((1 << h->log2_max_frame_num) - 1);
@@ -610,13 +611,85 @@ int x264_encoder_encode(x264_t *h, x264_nal_t **pp_nal, int *pi_nal, x264_pictur
     }
     h->frames_since_idr++;
     h->frame_no++;
-    PHASE(4);
-    h->t_phase[5] += 1;
-#undef PHASE
+    h->queue.pop_front();
     return (int)h->out.size();
 }
 
-int x264_encoder_delayed_frames(x264_t *h) { return h && h->G > 1 ? (int)(h->submitted - h->emitted) : 0; }
+int x264_encoder_encode(x264_t *h, x264_nal_t **pp_nal, int *pi_nal, x264_picture_t *pic_in, x264_picture_t *pic_out)
+{
+    if (!h || !pp_nal || !pi_nal) return -1;
+    *pi_nal = 0; *pp_nal = nullptr;
+    if (!pic_in) {      // flush: GOP-parallel batches, or the pictures still waiting in the lookahead queue, one per call
+        if (h->G > 1) return encode_gop_parallel(h, pp_nal, pi_nal, nullptr, pic_out, false);
+        return h->queue.empty() ? 0 : encode_queued(h, pp_nal, pi_nal, pic_out);
+    }
+    const x264_param_t &p = h->param;
+    const int w = p.i_width, ht = p.i_height;
+    if ((pic_in->img.i_csp & X264_CSP_MASK) != X264_CSP_I420 || pic_in->img.i_plane < 3) {
+        xlog(&p, X264_LOG_ERROR, "x264_encoder_encode: input picture must be I420\n");
+        return -1;
+    }
+    // Zero-copy input (x264gpu_host_input_i420): the caller (the VfW shell after the device-side colourspace conversion)
+    // already placed a tight I420 picture in the encoder's device staging buffer.
+    const bool resident = pic_in->img.plane[0] == h->d_in;
+    auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    double t0 = now(), t1;
+#define PHASE(i) do { t1 = now(); h->t_phase[i] += t1 - t0; t0 = t1; } while (0)
+    // ---- frame copy-in: three strided planes -> one tightly packed I420 buffer -> HBM (replaces x264_frame_copy_picture) ----
+    uint8_t *dst = h->h_in.data();
+    for (int pl = 0; pl < 3 && !resident; pl++) {
+        int pw = pl ? w / 2 : w, ph = pl ? ht / 2 : ht;
+        const uint8_t *src = pic_in->img.plane[pl];
+        for (int y = 0; y < ph; y++, dst += pw, src += pic_in->img.i_stride[pl]) memcpy(dst, src, pw);
+    }
+    if (h->G > 1) return encode_gop_parallel(h, pp_nal, pi_nal, pic_in, pic_out, resident);
+    PHASE(0);
+    // ---- the picture enters the lookahead queue (x264_lookahead_put_frame): upload, frame cost against the previous source picture,
+    //      AQ offsets, slice-type decision (keyint / forced type / scenecut) — all causal, so they are taken on arrival ----
+    const int slot = (int)(h->la_count % h->Q);
+    uint8_t *d_raw = h->q_raw[(size_t)slot];
+    if ((!resident && x264gpu_memcpy_h2d(d_raw, h->h_in.data(), h->h_in.size(), nullptr) != X264GPU_OK) ||
+        (resident && d_raw != h->d_in && x264gpu_memcpy_d2d(d_raw, h->d_in, h->h_in.size(), nullptr) != X264GPU_OK)) {
+        xlog(&p, X264_LOG_ERROR, "x264_encoder_encode: upload failed: %s\n", x264gpu_last_error());
+        return -1;
+    }
+    x264_t::QEntry e = {};
+    e.pts = pic_in->i_pts; e.slot = slot; e.img = pic_in->img;
+    bool idr = h->la_count == 0 || h->la_gop >= h->keyint || pic_in->i_type == X264_TYPE_IDR || pic_in->i_type == X264_TYPE_KEYFRAME, intra_pic = false;
+    if (h->la) {
+        if (x264gpu_lookahead_frame_cost(h->la, d_raw, h->la_count == 0, h->d_la, h->mbtree ? h->q_info[(size_t)slot] : nullptr, nullptr) != X264GPU_OK ||
+            (h->mbtree && h->aq_strength_q8 && x264gpu_lookahead_aq_offsets(h->la, d_raw, h->aq_strength_q8, h->q_aq[(size_t)slot], nullptr) != X264GPU_OK) ||
+            x264gpu_memcpy_d2h(e.costs, h->d_la, sizeof(e.costs), nullptr) != X264GPU_OK) {
+            xlog(&p, X264_LOG_ERROR, "x264_encoder_encode: lookahead failed: %s\n", x264gpu_last_error());
+            return -1;
+        }
+        if (!idr && p.i_scenecut_threshold > 0 && h->la_count > 0) {
+            // scenecut_internal: the bias grows with the distance from the last keyframe.  A cut at or beyond min-keyint becomes
+            // an IDR picture, one inside min-keyint an I picture that keeps the references (x264_slicetype_decide).
+            const int gop = h->la_gop, kmin = h->keyint_min, kmax = h->keyint;
+            const double tmax = p.i_scenecut_threshold / 100.0, tmin = kmin == kmax ? tmax : tmax * 0.25;
+            double bias;
+            if (gop <= kmin / 4) bias = tmin / 4;
+            else if (gop <= kmin) bias = tmin * gop / kmin;
+            else bias = tmin + (tmax - tmin) * (gop - kmin) / (kmax - kmin);
+            e.scenecut = (double)e.costs[1] >= (1.0 - bias) * (double)e.costs[0];
+            if (e.scenecut) { if (gop >= kmin) idr = true; else intra_pic = true; }
+        }
+    }
+    e.type = idr ? 2 : intra_pic ? 1 : 0;
+    h->la_gop = idr ? 1 : h->la_gop + 1;
+    h->la_count++;
+    h->queue.push_back(e);
+    PHASE(1);
+    if ((int)h->queue.size() <= h->L) return 0;                        // still filling the lookahead: no picture yet (codec.c:1693, size 0)
+    const int size = encode_queued(h, pp_nal, pi_nal, pic_out);
+    PHASE(4);
+    h->t_phase[5] += 1;
+#undef PHASE
+    return size;
+}
+
+int x264_encoder_delayed_frames(x264_t *h) { return !h ? 0 : h->G > 1 ? (int)(h->submitted - h->emitted) : (int)h->queue.size(); }
 
 void x264_encoder_close(x264_t *h)
 {
@@ -630,6 +703,12 @@ void x264_encoder_close(x264_t *h)
     if (h->d_mb) x264gpu_free(h->d_mb);
     if (h->d_lv) x264gpu_free(h->d_lv);
     if (h->d_ring) x264gpu_free(h->d_ring);
+    for (size_t i = 0; i < h->q_raw.size(); i++) {
+        if (h->q_raw[i] && h->q_raw[i] != h->d_in) x264gpu_free(h->q_raw[i]);
+        if (h->q_info[i]) x264gpu_free(h->q_info[i]);
+        if (h->q_aq[i]) x264gpu_free(h->q_aq[i]);
+    }
+    if (h->d_tree) x264gpu_free(h->d_tree);
     if (h->la) x264gpu_lookahead_destroy(h->la);
     if (h->d_la) x264gpu_free(h->d_la);
     delete h;

@@ -35,6 +35,7 @@ struct CODEC {                          /* x264vfw.h:187-252, compress-side memb
     BITMAPINFOHEADER *prev_lpbiOutput;
     DWORD prev_output_biSizeImage;
     int b_check_size;
+    int b_warn_frame_loss;
     int i_frame_remain, i_frame_total;
     uint32_t i_fps_num, i_fps_den;
     x264_picture_t conv_pic;
@@ -304,6 +305,7 @@ LRESULT compress_begin(CODEC *codec, BITMAPINFO *in, BITMAPINFO *out)
     codec->h = x264_encoder_open(&param);
     if (!codec->h) { vlog(codec, X264_LOG_ERROR, "x264_encoder_open failed\n"); goto fail; }
     x264_encoder_parameters(codec->h, &param);
+    codec->b_warn_frame_loss = !codec->b_cli_output;                          /* codec.c:1667 */
     if (codec->cli_hout) {                                                  /* set_param + write_headers (codec.c:1632-1663) */
         x264_nal_t *hn; int nh;
         if (codec->cli_hout->set_param(&param) < 0 || x264_encoder_headers(codec->h, &hn, &nh) < 0 || (!param.b_repeat_headers && codec->cli_hout->write_headers(hn) < 0)) {
@@ -395,6 +397,12 @@ LRESULT compress(CODEC *codec, ICCOMPRESS *icc)
     } else
         i_out = encode_frame(codec, nullptr, &pic_out, (uint8_t *)icc->lpOutput, outhdr->biSizeImage, &got_picture);
     if (i_out < 0) { codec->b_encoder_error = 1; return ICERR_ERROR; }
+    if (!got_picture && codec->b_warn_frame_loss) {                          /* codec.c:1798-1807 */
+        codec->b_warn_frame_loss = 0;
+        vlog(codec, X264_LOG_WARNING, "Few frames probably would be lost. Ways to fix this:\n");
+        vlog(codec, X264_LOG_WARNING, " - you can enable 'File' output mode\n");
+        vlog(codec, X264_LOG_WARNING, " - you can enable 'Zero Latency' option\n");
+    }
     *icc->lpdwFlags = got_picture && pic_out.b_keyframe ? AVIIF_KEYFRAME : 0;
     outhdr->biSizeImage = i_out;
     return ICERR_OK;
