@@ -7,6 +7,9 @@
  * mounted or where a prebuilt copy travelled to).  It gives the bitstream headers this encoder emits an independent reader:
  * what x264_encoder_headers / the slice writer meant must be what L-SMASH parses (tests/test_lsmash_ref.py).
  * It does not look at macroblock data — slice_data() parity stays with oracle/h264dec.cpp.
+ * x264o_lsmash_read_mp4 is the same library as DEMUXER (its public reading API, lsmash.h): the mp4 files of the product's own
+ * muxer (x264vfw_amd/host/muxers.cpp) must read back, through the code the reference's mp4 output is built on, as the samples,
+ * timestamps, sync flags and parameter sets that went in (tests/test_muxers_cpu.py).
  */
 #include "common/internal.h" /* must be placed first (L-SMASH convention) */
 #include <string.h>
@@ -80,4 +83,85 @@ int x264o_lsmash_parse_annexb(const uint8_t *buf, size_t n, x264o_ls_sps *osps, 
     *nslices = ns;
     h264_cleanup_parser(&info);
     return nals;
+}
+
+
+/* ---- mp4 read-back through L-SMASH's demuxing API ---- */
+typedef struct {
+    uint32_t movie_timescale, media_timescale, n_samples, width, height, par_h, par_v, n_edits, avcc_size;
+    uint64_t movie_duration, media_duration, track_duration, edit_duration;
+    int64_t edit_start_time;
+    int32_t edit_rate, primaries, transfer, matrix, full_range;
+    uint32_t display_width, display_height;
+    uint8_t avcc[512];                         /* the avcC box L-SMASH rebuilds from what it parsed (unstructured form) */
+} x264o_mp4_info;
+typedef struct { uint64_t dts, cts, pos; uint32_t length, sync; } x264o_mp4_sample;
+
+/* Returns the number of samples (<= max_samples described; data of all of them concatenated into data_out up to data_cap), < 0 on error */
+int x264o_lsmash_read_mp4(const char *path, x264o_mp4_info *info, x264o_mp4_sample *samples, int max_samples, uint8_t *data_out, size_t data_cap)
+{
+    memset(info, 0, sizeof(*info));
+    lsmash_root_t *root = lsmash_create_root();
+    if (!root) return -1;
+    lsmash_file_parameters_t fp;
+    if (lsmash_open_file(path, 1, &fp) < 0) { lsmash_destroy_root(root); return -2; }
+    int ret = -3;
+    lsmash_file_t *file = lsmash_set_file(root, &fp);
+    if (!file || lsmash_read_file(file, &fp) < 0) goto done;
+    lsmash_movie_parameters_t mv;
+    lsmash_initialize_movie_parameters(&mv);
+    if (lsmash_get_movie_parameters(root, &mv) < 0) { ret = -4; goto done; }
+    info->movie_timescale = mv.timescale; info->movie_duration = mv.duration;
+    uint32_t track = lsmash_get_track_ID(root, 1);
+    if (!track) { ret = -5; goto done; }
+    lsmash_track_parameters_t tp;
+    lsmash_initialize_track_parameters(&tp);
+    if (lsmash_get_track_parameters(root, track, &tp) < 0) { ret = -6; goto done; }
+    info->track_duration = tp.duration; info->display_width = tp.display_width; info->display_height = tp.display_height;
+    lsmash_media_parameters_t md;
+    lsmash_initialize_media_parameters(&md);
+    if (lsmash_get_media_parameters(root, track, &md) < 0) { ret = -7; goto done; }
+    info->media_timescale = md.timescale; info->media_duration = md.duration;
+    info->n_edits = lsmash_count_explicit_timeline_map(root, track);
+    if (info->n_edits) {
+        lsmash_edit_t e;
+        if (lsmash_get_explicit_timeline_map(root, track, 1, &e) < 0) { ret = -8; goto done; }
+        info->edit_duration = e.duration; info->edit_start_time = e.start_time; info->edit_rate = e.rate;
+    }
+    lsmash_summary_t *sum = lsmash_get_summary(root, track, 1);
+    if (!sum) { ret = -9; goto done; }
+    if (sum->summary_type == LSMASH_SUMMARY_TYPE_VIDEO) {
+        lsmash_video_summary_t *v = (lsmash_video_summary_t *)sum;
+        info->width = v->width; info->height = v->height; info->par_h = v->par_h; info->par_v = v->par_v;
+        info->primaries = v->color.primaries_index; info->transfer = v->color.transfer_index; info->matrix = v->color.matrix_index;
+        info->full_range = v->color.full_range;
+    }
+    for (uint32_t i = 1; i <= lsmash_count_codec_specific_data(sum); i++) {
+        lsmash_codec_specific_t *cs = lsmash_get_codec_specific_data(sum, i);
+        if (!cs || cs->type != LSMASH_CODEC_SPECIFIC_DATA_TYPE_ISOM_VIDEO_H264) continue;
+        lsmash_codec_specific_t *u = cs->format == LSMASH_CODEC_SPECIFIC_FORMAT_UNSTRUCTURED ? cs : lsmash_convert_codec_specific_format(cs, LSMASH_CODEC_SPECIFIC_FORMAT_UNSTRUCTURED);
+        if (u && u->size <= sizeof(info->avcc)) { info->avcc_size = u->size; memcpy(info->avcc, u->data.unstructured, u->size); }
+        if (u && u != cs) lsmash_destroy_codec_specific_data(u);
+    }
+    lsmash_cleanup_summary(sum);
+    if (lsmash_construct_timeline(root, track) < 0) { ret = -10; goto done; }
+    info->n_samples = lsmash_get_sample_count_in_media_timeline(root, track);
+    size_t used = 0;
+    for (uint32_t i = 1; i <= info->n_samples; i++) {
+        lsmash_sample_t *sm = lsmash_get_sample_from_media_timeline(root, track, i);
+        if (!sm) { ret = -11; goto done; }
+        if ((int)i <= max_samples) {
+            x264o_mp4_sample *o = &samples[i - 1];
+            o->dts = sm->dts; o->cts = sm->cts; o->pos = sm->pos; o->length = sm->length;
+            o->sync = (sm->prop.ra_flags & ISOM_SAMPLE_RANDOM_ACCESS_FLAG_SYNC) != 0;
+        }
+        if (used + sm->length <= data_cap) { memcpy(data_out + used, sm->data, sm->length); used += sm->length; }
+        lsmash_delete_sample(sm);
+    }
+    lsmash_destruct_timeline(root, track);
+    ret = (int)info->n_samples;
+done:
+    lsmash_close_file(&fp);
+    lsmash_destroy_root(root);
+    return ret;
 }

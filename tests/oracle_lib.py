@@ -289,6 +289,33 @@ def lsmash_parse(stream, max_slices=64):
     return sps, pps, [sl[i] for i in range(n.value)]
 
 
+class LsMp4Info(C.Structure):
+    _fields_ = [(n, C.c_uint32) for n in ("movie_timescale", "media_timescale", "n_samples", "width", "height", "par_h", "par_v", "n_edits", "avcc_size")] + \
+               [(n, C.c_uint64) for n in ("movie_duration", "media_duration", "track_duration", "edit_duration")] + [("edit_start_time", C.c_int64)] + \
+               [(n, C.c_int32) for n in ("edit_rate", "primaries", "transfer", "matrix", "full_range")] + \
+               [("display_width", C.c_uint32), ("display_height", C.c_uint32), ("avcc", C.c_uint8 * 512)]
+
+
+class LsMp4Sample(C.Structure):
+    _fields_ = [("dts", C.c_uint64), ("cts", C.c_uint64), ("pos", C.c_uint64), ("length", C.c_uint32), ("sync", C.c_uint32)]
+
+
+def lsmash_read_mp4(path, max_samples=256):
+    """mp4 file -> (info, [samples], [sample bytes]) as demuxed by the reference tree's L-SMASH (oracle/_ref)"""
+    lib = C.CDLL(LSMASH_REF)
+    lib.x264o_lsmash_read_mp4.restype = _i
+    lib.x264o_lsmash_read_mp4.argtypes = [C.c_char_p, C.POINTER(LsMp4Info), C.POINTER(LsMp4Sample), _i, C.c_char_p, C.c_size_t]
+    info, sm = LsMp4Info(), (LsMp4Sample * max_samples)()
+    cap = os.path.getsize(path)
+    buf = C.create_string_buffer(cap)
+    n = lib.x264o_lsmash_read_mp4(str(path).encode(), C.byref(info), sm, max_samples, buf, cap)
+    assert n >= 0, f"L-SMASH refused the file: error {n}"
+    out, o = [], 0
+    for i in range(min(n, max_samples)):
+        out.append(buf.raw[o:o + sm[i].length]); o += sm[i].length
+    return info, [sm[i] for i in range(min(n, max_samples))], out
+
+
 # ---- bitstream checker (oracle/h264dec.cpp) ----
 _sig("x264o_h264_decode", _i, [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.POINTER(_i), C.POINTER(_i)])
 

@@ -249,19 +249,25 @@ def test_raw_file_output(gpu, tmp_path):
     # without a file the VfW buffer cannot take late frames: threads falls back to 1 (same stream, no delay)
     direct_t, sizes = run(b"--keyint 250 --threads 4")
     assert direct_t == direct and all(s > 0 for s in sizes)
-    none, log = run(b"--output " + str(tmp_path / "x.mp4").encode())
-    assert none is None and b"output support" in log                         # mp4 / avi need L-SMASH / libavformat: not built in
+    none, log = run(b"--output " + str(tmp_path / "x.avi").encode())
+    assert none is None and b"output support" in log                         # avi needs libavformat: not built in
     # containers (next-row f3): length-prefixed NALs, parameter sets once in the avcC record; same slices as the raw stream
     import container_parse as CP
     import oracle_lib as O
     raw_nals = [n for n in direct.split(b"\0\0\1")[1:]]
     raw_slices = [n.rstrip(b"\0") if i + 1 < len(raw_nals) else n for i, n in enumerate(raw_nals)]
     raw_slices = [n for n in raw_slices if (n[0] & 31) in (1, 5)]
-    for ext in ("mkv", "flv"):
+    for ext in ("mkv", "flv", "mp4"):
         cpath = tmp_path / ("c." + ext)
         to_file, sizes = run(b"--keyint 250 --output " + str(cpath).encode())
         assert to_file == b"" and sizes == [0] * nfr
-        c = CP.mkv_read(cpath.read_bytes()) if ext == "mkv" else CP.flv_read(cpath.read_bytes())
+        c = CP.mkv_read(cpath.read_bytes()) if ext == "mkv" else CP.flv_read(cpath.read_bytes()) if ext == "flv" else CP.mp4_read(cpath.read_bytes())
+        if ext == "mp4":
+            c["frames"] = c["samples"]
+            assert (c["media_timescale"], c["deltas"], [f["key"] for f in c["frames"]]) == (25, [1] * nfr, [True] + [False] * (nfr - 1))
+            if __import__("os").path.exists(O.LSMASH_REF):                   # and through the reference tree's L-SMASH
+                info, smp, data = O.lsmash_read_mp4(cpath)
+                assert info.n_samples == nfr and data == [f["data"] for f in c["frames"]] and [x.sync for x in smp] == [1] + [0] * (nfr - 1)
         a = CP.avcc_read(c["avcc"])
         slices = [CP.length_prefixed_nals(f["data"])[-1] for f in c["frames"]]
         assert slices == raw_slices, ext

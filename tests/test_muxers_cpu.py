@@ -126,5 +126,68 @@ def test_raw_and_unsupported(stream, tmp_path):
     es = (tmp_path / "a.h264").read_bytes()
     dec = O.h264_decode(es, len(recs), w, h)
     assert all(np.array_equal(d, r) for d, r in zip(dec, recs))
-    for name in ("x.mp4", "x.avi"):
-        assert not H.x264host_mux_open(str(tmp_path / name).encode(), b"auto", None)                  # need L-SMASH / libavformat: not built in
+    assert not H.x264host_mux_open(str(tmp_path / "x.avi").encode(), b"auto", None)                   # needs libavformat: not built in
+
+
+def check_mp4(path, w, h, sps, pps, frames, recs, sei, fps, sar):
+    """own box reader: structure, tables, timing (mp4_lsmash.c semantics); -> the parsed file"""
+    raw = path.read_bytes()
+    m = CP.mp4_read(raw)
+    n = len(frames)
+    assert m["order"] == ["ftyp", "mdat", "moov"] and (m["major"], m["minor"], m["brands"]) == (b"mp42", 0, [b"mp42", b"mp41", b"isom"])
+    assert (m["movie_timescale"], m["media_timescale"], m["handler"], m["tkhd_flags"], m["track_id"], m["next_track"]) == (600, fps[0], b"vide", 7, 1, 2)
+    assert (m["width"], m["height"], m["depth"]) == (w, h, 0x18)
+    dw, dh = w << 16, h << 16
+    if sar != (1, 1):
+        r = sar[0] / sar[1]
+        dw, dh = (int(dw * r), dh) if r > 1 else (dw, int(dh / r))
+    assert m["display"] == (dw, dh) and m.get("pasp", (1, 1)) == sar
+    assert m["ext"] == ["avcC", "colr", "pasp", "btrt"] and m["colr"] == (b"nclx", 2, 2, 2, 0)           # a 1:1 SAR is still a stated SAR (mp4_lsmash.c:245)
+    a = CP.avcc_read(m["avcc"])
+    assert (a["sps"], a["pps"], a["profile"], a["level"]) == (sps, pps, sps[1], sps[3])
+    # timing: dts = cts = i * timebase_num in a timescale of timebase_den; the last delta repeats the previous one
+    assert m["deltas"] == [fps[1]] * n and m["media_duration"] == n * fps[1]
+    assert [(x["dts"], x["cts"]) for x in m["samples"]] == [(i * fps[1], i * fps[1]) for i in range(n)]
+    pres = int(n * fps[1] / fps[0] * 600)
+    assert m["movie_duration"] == pres and m["track_duration"] == pres and m["edit"] == (pres, 0, 0x10000)
+    assert [x["key"] for x in m["samples"]] == [idr for _, idr in frames]
+    assert sum(m["chunks"]) == n and max(m["chunks"]) * fps[1] * 2 <= fps[0] + 2 * fps[1]                    # about half a second per chunk
+    nals = [CP.length_prefixed_nals(x["data"]) for x in m["samples"]]
+    assert nals[0][0] == sei and all(len(x) == 1 for x in nals[1:])                                         # the SEI rides with the first sample
+    total = sum(len(x["data"]) for x in m["samples"])
+    assert m["btrt"][0] == max(len(x["data"]) for x in m["samples"]) and abs(m["btrt"][2] - total * 8 * fps[0] / (n * fps[1])) < 1 and m["btrt"][1] >= m["btrt"][2] - 1
+    decode_check(w, h, sps, pps, [x[-1] for x in nals], recs)
+    return m
+
+
+@pytest.mark.parametrize("fps,sar", [((25, 1), (1, 1)), ((30000, 1001), (4, 3)), ((24, 1), (8, 9))])
+def test_mp4(stream, tmp_path, fps, sar):
+    w, h, sps, pps, frames, recs = stream
+    annexb, sei = mux(tmp_path / "a.mp4", b"auto", w, h, sps, pps, frames, fps=fps, sar=sar)
+    assert annexb == 0
+    check_mp4(tmp_path / "a.mp4", w, h, sps, pps, frames, recs, sei, fps, sar)
+
+
+@pytest.mark.skipif(not __import__("os").path.exists(O.LSMASH_REF), reason="oracle/_ref/liblsmash_ref.so not built (needs /root/reference)")
+@pytest.mark.parametrize("fps,sar", [((25, 1), (1, 1)), ((30000, 1001), (4, 3))])
+def test_mp4_reads_back_through_the_reference_lsmash(stream, tmp_path, fps, sar):
+    """the file demuxed by the L-SMASH of the reference tree (the library its mp4 output is built on, mp4_lsmash.c): every sample, its
+    timestamps and sync flag, the timescales / durations / edit, the sample entry and the avcC parameter sets are what went in"""
+    w, h, sps, pps, frames, recs = stream
+    path = tmp_path / "b.mp4"
+    annexb, sei = mux(path, b"mp4", w, h, sps, pps, frames, fps=fps, sar=sar)
+    info, samples, data = O.lsmash_read_mp4(path)
+    n = len(frames)
+    assert (info.movie_timescale, info.media_timescale, info.n_samples, info.width, info.height) == (600, fps[0], n, w, h)
+    assert (info.par_h, info.par_v) == sar
+    pres = int(n * fps[1] / fps[0] * 600)
+    assert (info.media_duration, info.movie_duration, info.track_duration) == (n * fps[1], pres, pres)
+    assert (info.n_edits, info.edit_duration, info.edit_start_time, info.edit_rate) == (1, pres, 0, 0x10000)
+    assert (info.primaries, info.transfer, info.matrix, info.full_range) == (2, 2, 2, 0)
+    avcc = bytes(info.avcc[:info.avcc_size])
+    assert sps in avcc and pps in avcc and avcc[4:8] == b"avcC"
+    assert [(s.dts, s.cts, s.sync) for s in samples] == [(i * fps[1], i * fps[1], int(idr)) for i, (_, idr) in enumerate(frames)]
+    expect = [(pref(sei) if i == 0 else b"") + pref(nal) for i, (nal, _) in enumerate(frames)]
+    assert data == expect
+    m = CP.mp4_read(path.read_bytes())
+    assert [s.pos for s in samples] == [x["pos"] for x in m["samples"]]

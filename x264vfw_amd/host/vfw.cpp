@@ -295,7 +295,7 @@ LRESULT compress_begin(CODEC *codec, BITMAPINFO *in, BITMAPINFO *out)
             const char *err = nullptr;
             codec->cli_hout = x264host::open_muxer(out_file.c_str(), muxer.c_str(), &annexb, &err);
             if (!codec->cli_hout) {
-                if (err && !strncmp(err, "not compiled", 12)) vlog(codec, X264_LOG_ERROR, "not compiled with this output support (raw, mkv and flv are built in)\n");
+                if (err && !strncmp(err, "not compiled", 12)) vlog(codec, X264_LOG_ERROR, "not compiled with this output support (raw, mkv, flv and mp4 are built in)\n");
                 else vlog(codec, X264_LOG_ERROR, "could not open output file: '%s'\n", out_file.c_str());
                 goto fail;
             }
