@@ -203,6 +203,11 @@ int  x264gpu_encoder_set_qp(x264gpu_encoder *enc, int qp_i, int qp_p);
  * = AQ - macroblock-tree, applied by x264_ratecontrol_mb_qp): quantiser = slice quantiser + round(offset), clipped to 1..51.  The device array
  * must stay valid until the encode that uses it has been issued; NULL returns to the encoder's own aq_mode. */
 int  x264gpu_encoder_set_mb_qp_offsets(x264gpu_encoder *enc, const int16_t *d_offsets_q8);
+/* One slice quantiser per stream (host array of `streams` values, 0..51) for the following pictures, instead of the shared one of
+ * x264gpu_encoder_set_qp: the streams of a call are then rate-controlled independently (GOP-parallel coding of one sequence under
+ * CRF: every GOP slot carries the quantiser x264_ratecontrol_start would have given that picture).  AQ / caller offsets add to it per
+ * macroblock.  NULL returns to the shared quantiser. */
+int  x264gpu_encoder_set_stream_qps(x264gpu_encoder *enc, const int8_t *qps);
 
 /* ------------------------------------------------------------------------------------------------
  * Lookahead frame cost: x264_slicetype_frame_cost of [x264-upstream]

@@ -220,3 +220,30 @@ def test_external_mb_qp_offsets(gpu):
         compare(f"external offsets frame {i}", (w + 15) // 16, g_mb[0], o_mb, g_lv[0], o_lv, gg.recon(0), og.recon())
         if off is not None:
             assert len(np.unique(o_mb["qp"])) > 4
+
+
+@pytest.mark.parametrize("aq", [0, 1])
+def test_per_stream_quantisers(gpu, aq):
+    """x264gpu_encoder_set_stream_qps: the streams of one call carry their own slice quantisers (GOP-parallel CRF); each stream must
+    equal an oracle encoder driven with that quantiser alone, with and without AQ on top; NULL returns to the shared quantiser"""
+    from gpu_enc import GpuEncoder
+    from x264vfw_amd import lib
+    w, h, S = 176, 144, 3
+    seqs = [synth_frames(w, h, 4, seed=20 + s) for s in range(S)]
+    cfg = O.default_config(w, h, refs=2, partitions=7, dct8x8=1, chroma_me=1, mixed_refs=1, qp_i=24, qp_p=27, aq_mode=aq)
+    gcfg = O.default_config(w, h, streams=S, refs=2, partitions=7, dct8x8=1, chroma_me=1, mixed_refs=1, qp_i=24, qp_p=27, aq_mode=aq)
+    ogs, gg = [O.OracleEncoder(cfg) for _ in range(S)], GpuEncoder(gcfg)
+    plan = [[20, 33, 27], [22, 38, 25], [30, 18, 44], None]                # per picture: a quantiser per stream, or back to the shared one
+    for i in range(4):
+        st = 2 if i == 0 else 0
+        qps = plan[i]
+        arr = None if qps is None else np.array(qps, np.int8)
+        lib.check(lib.x264gpu_encoder_set_stream_qps(gg.h, None if arr is None else arr.ctypes.data), "set_stream_qps")
+        g_mb, g_lv = gg.encode([seqs[s][i] for s in range(S)], st)
+        for s in range(S):
+            q = qps[s] if qps else (24 if st == 2 else 27)
+            ogs[s].set_qp(q, q)
+            o_mb, o_lv = ogs[s].encode(seqs[s][i], st)
+            compare(f"stream qp aq={aq} frame {i} stream {s}", (w + 15) // 16, g_mb[s], o_mb, g_lv[s], o_lv, gg.recon(s), ogs[s].recon())
+            if not aq:
+                assert set(np.unique(o_mb["qp"])) == {q}

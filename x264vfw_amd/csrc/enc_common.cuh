@@ -47,9 +47,13 @@ struct EncK {
     const Q8 *q8tab;          // [52][2]: intra, inter
     const int *lambda_tab;    // [52]
     const uint16_t *cost_all; // [52][2 * MVCOST_HALF]
+    const int8_t *stream_qp;  // optional [streams]: each stream's slice quantiser (x264gpu_encoder_set_stream_qps); k.qp otherwise
     int aq_strength_q8;
     int *wf_progress;         // [streams][2][WFG_ROWS]: row counters of the wavefront kernels when ONE stream spans several workgroups
 };
+// the slice quantiser of stream s
+__device__ __forceinline__ int slice_qp(const EncK &k, int s) { return k.stream_qp ? (int)k.stream_qp[s] : k.qp; }
+
 
 __device__ __forceinline__ const uint8_t *ref_plane00(const EncK &k, int s, int r)
 {

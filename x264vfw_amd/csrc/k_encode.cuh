@@ -218,14 +218,14 @@ __global__ __launch_bounds__(256) void k_aq(EncK k)
     const unsigned e1 = energy ? energy : 1u;
     const int lz = 31 - __builtin_clz(e1), lg = lz * 256 + c_aq_log2_lut[((e1 << (31 - lz)) >> 24) & 0x7f];
     const int adj = (k.aq_strength_q8 * (lg - 3693)) >> 8;
-    if (valid && r == 0) k.mbqp[(size_t)s * k.nmb + mbi] = (uint8_t)min(max(k.qp + ((adj + 128) >> 8), 1), 51);
+    if (valid && r == 0) k.mbqp[(size_t)s * k.nmb + mbi] = (uint8_t)min(max(slice_qp(k, s) + ((adj + 128) >> 8), 1), 51);
 }
 
 // quantiser offsets decided by the lookahead (AQ - macroblock-tree, Q8) -> per-macroblock quantisers (oracle compute_mb_qp, ext_off_q8)
 __global__ __launch_bounds__(256) void k_apply_qp_offsets(EncK k, const int16_t *__restrict__ off)
 {
     const int i = blockIdx.x * 256 + threadIdx.x, s = blockIdx.y;
-    if (i < k.nmb) k.mbqp[(size_t)s * k.nmb + i] = (uint8_t)min(max(k.qp + (((int)off[(size_t)s * k.nmb + i] + 128) >> 8), 1), 51);
+    if (i < k.nmb) k.mbqp[(size_t)s * k.nmb + i] = (uint8_t)min(max(slice_qp(k, s) + (off ? ((int)off[(size_t)s * k.nmb + i] + 128) >> 8 : 0), 1), 51);   // no offsets: per-stream quantisers only
 }
 
 // QP_Y inheritance (oracle settle_mb_qp, 7.4.5): a macroblock that sends no mb_qp_delta takes its predecessor's quantiser; one wave per
@@ -234,7 +234,7 @@ __global__ __launch_bounds__(64) void k_settle_qp(EncK k)
 {
     const int lane = threadIdx.x, s = blockIdx.x;
     x264gpu_mb *mbs = k.mb + (size_t)s * k.nmb;
-    int carry = k.qp;
+    int carry = slice_qp(k, s);
     for (int base = 0; base < k.nmb; base += 64) {
         const int i = base + lane;
         const bool in = i < k.nmb;
