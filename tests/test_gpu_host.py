@@ -142,17 +142,25 @@ def test_headers_call(gpu):
     H.x264_encoder_close(h_)
 
 
-@pytest.mark.parametrize("w,h,nfr,keyint,threads", [(176, 144, 23, 4, 3), (96, 80, 17, 5, 4), (176, 144, 12, 4, 3), (64, 48, 9, 3, 8), (64, 48, 2, 6, 2)])
-def test_gop_parallel_equals_serial(gpu, w, h, nfr, keyint, threads):
+@pytest.mark.parametrize("w,h,nfr,keyint,threads,rc", [(176, 144, 23, 4, 3, "qp"), (96, 80, 17, 5, 4, "qp"), (176, 144, 12, 4, 3, "qp"), (64, 48, 9, 3, 8, "qp"),
+                                                          (64, 48, 2, 6, 2, "qp"), (176, 144, 23, 4, 3, "crf"), (96, 80, 14, 5, 4, "crf-noaq"), (64, 48, 9, 3, 8, "crf")])
+def test_gop_parallel_equals_serial(gpu, w, h, nfr, keyint, threads, rc):
     """--threads G codes G closed GOPs in lock-step: the frames come out (G-1)*keyint (+1) calls late, in order, and the stream is
-    byte-identical to the serial encode (fixed keyint + CQP make the GOPs independent); flush drains the rest."""
+    byte-identical to the serial encode (fixed keyint makes the GOPs independent); flush drains the rest.  Under CRF every GOP slot
+    carries the quantiser the serial rate control gives that picture (it follows from the lookahead costs alone), with AQ on top."""
     frames = synth_frames(w, h, nfr, seed=31 * w + nfr)
-    opts = {"qp": 27, "keyint": keyint, "min-keyint": keyint, "no-scenecut": None}      # SURVEY config 5: fixed closed GOPs
-    h1, _ = open_encoder(w, h, opts, b"high")
+    if rc != "qp":                                                           # a sequence whose complexity moves, so the quantisers do
+        frames = [f if i % 5 else synth_frames(w, h, 1, seed=900 + i)[0] for i, f in enumerate(frames)]
+    opts = {"keyint": keyint, "min-keyint": keyint, "no-scenecut": None}      # SURVEY config 5: fixed closed GOPs
+    opts.update({"qp": 27} if rc == "qp" else {"crf": 25, "no-mbtree": None})
+    if rc == "crf-noaq":
+        opts["aq-mode"] = 0
+    h1, e1 = open_encoder(w, h, opts, b"high")
+    assert e1.rc.i_rc_method == (HL.X264_RC_CQP if rc == "qp" else HL.X264_RC_CRF)
     serial, info1, _ = encode_all(h1, w, h, frames)
     H.x264_encoder_close(h1)
     hg, eff = open_encoder(w, h, dict(opts, threads=threads), b"high")
-    assert eff.i_threads == threads
+    assert eff.i_threads == threads and eff.rc.i_rc_method == e1.rc.i_rc_method and eff.rc.i_aq_mode == e1.rc.i_aq_mode
     pic, out = HL.Picture(), HL.Picture()
     assert H.x264_picture_alloc(C.byref(pic), HL.X264_CSP_I420, w, h) == 0
     nal, n = C.POINTER(HL.Nal)(), C.c_int()
@@ -177,6 +185,11 @@ def test_gop_parallel_equals_serial(gpu, w, h, nfr, keyint, threads):
     H.x264_picture_clean(C.byref(pic))
     assert pts_out == [100 + i for i in range(nfr)]
     assert stream == serial
+    if rc != "qp":                                                           # and the serial session's quantisers did move
+        h2, _ = open_encoder(w, h, opts, b"high")
+        again, rows, _ = encode_with_decisions(h2, w, h, frames)
+        H.x264_encoder_close(h2)
+        assert again == serial and len({r[1] for r in rows if not r[0]}) > 1, [r[1] for r in rows]
     assert len(O.h264_decode(stream, nfr, w, h)) == nfr
 
 

@@ -69,6 +69,7 @@ struct x264_t {
     long la_count = 0; int la_gop = 0;   // pictures seen by the lookahead; distance from the last IDR at lookahead time
     bool mbtree = false; int aq_strength_q8 = 0, tree_strength_q8 = 0;
     int cavlc_threads = 1;               // row bands of a slice coded in parallel (threads 1 sessions; GOP-parallel ones use a thread per GOP)
+    std::vector<int8_t> gop_qp;          // GOP-parallel CRF: the quantiser of every ring picture (slot * keyint + position), decided on arrival
     int last_qp = 0, last_scenecut = 0;  // diagnostics: quantiser and scenecut flag of the last coded picture
     int32_t last_costs[4] = { 0, 0, 0, 0 };
     // ---- GOP-parallel mode (--threads G > 1): G closed GOPs of the one stream are coded in lock-step on G stream slots of the
@@ -198,9 +199,9 @@ x264_t *x264_encoder_open(x264_param_t *param)
     // rate control: constant QP (X264_RC_CQP, codec.c:1498-1502) and single-pass CRF without AQ / mbtree (codec.c:1504-1507, the
     // driver's default session) when one GOP is in flight; ABR and CRF under --threads > 1 map to their nominal quantiser
     int qp = p.rc.i_rc_method == X264_RC_CQP ? p.rc.i_qp_constant : p.rc.i_rc_method == X264_RC_CRF ? (int)(p.rc.f_rf_constant + 0.5f) : 26;
-    h->crf = p.rc.i_rc_method == X264_RC_CRF && p.i_threads <= 1 && p.rc.f_rf_constant >= 1.0f;
+    h->crf = p.rc.i_rc_method == X264_RC_CRF && p.rc.f_rf_constant >= 1.0f;       // also under --threads G: its quantisers follow from the lookahead costs alone
     h->abr = p.rc.i_rc_method == X264_RC_ABR && p.i_threads <= 1 && p.rc.i_bitrate > 0 && !p.rc.b_stat_read;      // single pass, no VBV
-    if (p.rc.i_rc_method != X264_RC_CQP && !h->crf && !h->abr) xlog(&p, X264_LOG_WARNING, "this rate control mode is not implemented yet (2-pass, or CRF / ABR with --threads > 1): constant qp %d\n", qp);
+    if (p.rc.i_rc_method != X264_RC_CQP && !h->crf && !h->abr) xlog(&p, X264_LOG_WARNING, "this rate control mode is not implemented yet (2-pass, or ABR with --threads > 1): constant qp %d\n", qp);
     if (qp < 1) { xlog(&p, X264_LOG_WARNING, "lossless is not supported: qp 1\n"); qp = 1; }
     if (!h->crf && !h->abr) p.rc.i_rc_method = X264_RC_CQP;
     p.rc.i_vbv_max_bitrate = 0; p.rc.i_vbv_buffer_size = 0;
@@ -208,6 +209,7 @@ x264_t *x264_encoder_open(x264_param_t *param)
     if (p.rc.i_rc_method == X264_RC_CQP || p.rc.f_aq_strength <= 0) p.rc.i_aq_mode = X264_AQ_NONE;
     // macroblock-tree: needs a rate-controlled session and pictures held back (rc-lookahead); x264 switches it off under constant QP
     if (p.rc.i_rc_method == X264_RC_CQP || p.rc.i_lookahead <= 0) p.rc.b_mb_tree = 0;
+    if (p.rc.b_mb_tree && p.i_threads > 1) { xlog(&p, X264_LOG_INFO, "mbtree needs threads 1 (GOPs in lock-step are coded before what follows them is seen): mbtree 0\n"); p.rc.b_mb_tree = 0; }
     p.rc.b_mb_tree = p.rc.b_mb_tree != 0;
     p.rc.i_lookahead = p.rc.b_mb_tree ? clampi(p.rc.i_lookahead, 1, p.i_keyint_max < 250 ? (p.i_keyint_max > 1 ? p.i_keyint_max : 1) : 250) : 0;
     if (p.rc.i_aq_mode > X264_AQ_VARIANCE) { xlog(&p, X264_LOG_WARNING, "aq-mode %d is not implemented yet: aq-mode 1\n", p.rc.i_aq_mode); p.rc.i_aq_mode = X264_AQ_VARIANCE; }
@@ -261,7 +263,7 @@ x264_t *x264_encoder_open(x264_param_t *param)
         x264_encoder_close(h);
         return nullptr;
     }
-    if ((p.i_scenecut_threshold > 0 || h->crf || h->abr) && h->G == 1) {
+    if (p.i_scenecut_threshold > 0 || h->crf || h->abr) {
         if (x264gpu_lookahead_create(&h->la, p.i_width, p.i_height, 1, p.analyse.i_me_range, p.analyse.i_subpel_refine) != X264GPU_OK ||
             x264gpu_malloc((void **)&h->d_la, 4 * sizeof(int32_t)) != X264GPU_OK) {
             xlog(&p, X264_LOG_ERROR, "GPU lookahead setup failed: %s\n", x264gpu_last_error());
@@ -319,6 +321,7 @@ x264_t *x264_encoder_open(x264_param_t *param)
     h->h_in.resize(insz); h->h_mb.resize((size_t)h->G * h->nmb); h->h_lv.resize((size_t)h->G * h->nmb * X264GPU_MB_LEVELS);
     if (h->G > 1) {
         const size_t n = (size_t)h->G * h->keyint;
+        h->gop_qp.assign(n, (int8_t)h->qp_p);
         h->slotbuf.resize(n);
         h->slot_have.assign(n, 0);
         h->h_mb2.resize(h->h_mb.size()); h->h_lv2.resize(h->h_lv.size());
@@ -371,6 +374,8 @@ static void join_pool(x264_t *h)
     h->pool_nslots = 0;
 }
 
+static int rc_pick_qp(x264_t *h, bool is_i, const int32_t costs[4], int frames_done);
+
 static void code_position(x264_t *h, int batch, int t, int nslots_with_t)
 {
     const x264_param_t &p = h->param;
@@ -381,6 +386,15 @@ static void code_position(x264_t *h, int batch, int t, int nslots_with_t)
     x264gpu_mb *hmb = h->dl ? h->h_mb2.data() : h->h_mb.data();
     int16_t *hlv = h->dl ? h->h_lv2.data() : h->h_lv.data();
     h->dl ^= 1;
+    std::vector<int8_t> qps;
+    if (h->crf) {
+        qps.assign((size_t)G, (int8_t)(t == 0 ? h->qp_i : h->qp_p));
+        for (int s = 0; s < nslots_with_t; s++) qps[(size_t)s] = h->gop_qp[(size_t)s * h->keyint + t];
+        if (x264gpu_encoder_set_stream_qps(h->gpu, qps.data()) != X264GPU_OK) {
+            xlog(&p, X264_LOG_ERROR, "x264_encoder_encode: GPU hot path failed: %s\n", x264gpu_last_error());
+            return;
+        }
+    }
     if (x264gpu_encode_frames(h->gpu, h->d_ring + (size_t)t * G * insz, st, h->d_mb, h->d_lv, nullptr) != X264GPU_OK ||
         x264gpu_memcpy_d2h(hmb, h->d_mb, (size_t)G * h->nmb * sizeof(x264gpu_mb), nullptr) != X264GPU_OK ||
         x264gpu_memcpy_d2h(hlv, h->d_lv, (size_t)G * h->nmb * X264GPU_MB_LEVELS * sizeof(int16_t), nullptr) != X264GPU_OK) {
@@ -388,7 +402,7 @@ static void code_position(x264_t *h, int batch, int t, int nslots_with_t)
         return;
     }
     join_pool(h);
-    auto work = [h, batch, t, st, hmb, hlv](int s) {
+    auto work = [h, batch, t, st, hmb, hlv, qps](int s) {
         const x264_param_t &p = h->param;
         const int G = h->G;
         x264_t::Coded &c = h->slotbuf[(size_t)s * h->keyint + t];
@@ -402,7 +416,7 @@ static void code_position(x264_t *h, int batch, int t, int nslots_with_t)
             if (gop == 0) { c.off.push_back(c.bytes.size()); c.types.push_back(6); write_sei_version(c.bytes, kSeiText, annexb); }
         }
         SliceParams sp = {};
-        sp.mbw = h->mbw; sp.mbh = h->mbh; sp.slice_type = st; sp.qp = c.idr ? h->qp_i : h->qp_p; sp.pic_init_qp = h->pic_init_qp;
+        sp.mbw = h->mbw; sp.mbh = h->mbh; sp.slice_type = st; sp.qp = !qps.empty() ? (int)qps[(size_t)s] : c.idr ? h->qp_i : h->qp_p; sp.pic_init_qp = h->pic_init_qp;
         sp.frame_num = t & ((1 << h->log2_max_frame_num) - 1); sp.log2_max_frame_num = h->log2_max_frame_num;
         sp.idr = c.idr; sp.idr_pic_id = (int)(gop & 0xffff); sp.nal_ref_idc = c.idr ? 3 : 2; sp.pps_id = p.i_sps_id;
         sp.num_ref_default = p.i_frame_reference;
@@ -451,6 +465,16 @@ static int encode_gop_parallel(x264_t *h, x264_nal_t **pp_nal, int *pi_nal, x264
             xlog(&p, X264_LOG_ERROR, "x264_encoder_encode: upload failed: %s\n", x264gpu_last_error());
             return -1;
         }
+        if (h->crf) {
+            // CRF: the picture's quantiser follows from the lookahead costs and the pictures before it, all known now (rc_pick_qp)
+            int32_t costs[4];
+            if (x264gpu_lookahead_frame_cost(h->la, dst, i == 0, h->d_la, nullptr, nullptr) != X264GPU_OK ||
+                x264gpu_memcpy_d2h(costs, h->d_la, sizeof(costs), nullptr) != X264GPU_OK) {
+                xlog(&p, X264_LOG_ERROR, "x264_encoder_encode: lookahead failed: %s\n", x264gpu_last_error());
+                return -1;
+            }
+            h->gop_qp[(size_t)s * K + t] = (int8_t)rc_pick_qp(h, t == 0, costs, (int)i);
+        }
         h->pts.push_back(pic_in->i_pts);
         h->submitted++;
         if (s == G - 1) {                                      // the batch's last GOP delivers position t: every slot has it
@@ -493,6 +517,58 @@ static int encode_gop_parallel(x264_t *h, x264_nal_t **pp_nal, int *pi_nal, x264
     return (int)h->out.size();
 }
 
+// rate_estimate_qscale for the picture about to be coded (single-pass CRF / ABR): a function of the lookahead costs, the picture type and
+// the running rate-control state only (ABR adds the coded sizes through x264_ratecontrol_end), so under CRF it can run when a picture
+// ARRIVES — which is what lets GOP-parallel sessions keep CRF's quantisers.  frames_done = pictures decided before this one.
+static int rc_pick_qp(x264_t *h, bool is_i, const int32_t costs[4], int frames_done)
+{
+    const x264_param_t &p = h->param;
+    // rate_estimate_qscale: q = rceq / rate_factor; rceq = blurred_complexity^(1 - qcomp), or under macroblock-tree (which does the
+    // complexity weighting itself) the frame-duration term alone; an I picture after P pictures takes the running P quantiser /
+    // ipratio; the quantiser is qscale2qp(q) rounded, within [qpmin, qpmax]
+    auto qp2qscale = [](double q) { return 0.85 * pow(2.0, (q - 12.0) / 6.0); };
+    auto qscale2qp = [](double qs) { return 12.0 + 6.0 * log2(qs / 0.85); };
+    const double satd = is_i ? costs[0] : costs[1];
+    h->rc.cplxsum = h->rc.cplxsum * 0.5 + satd / h->rc.dur_ratio;
+    h->rc.cplxcount = h->rc.cplxcount * 0.5 + 1.0;
+    double q, overflow = 1.0;
+    const double rate_factor = h->crf ? h->rc.rate_factor_constant : h->rc.wanted_bits_window / h->rc.cplxr_sum;
+    if (satd > 0) {
+        h->rc.last_rceq = h->mbtree ? pow(1.0 / h->rc.dur_ratio, 1.0 - p.rc.f_qcompress) : pow(h->rc.cplxsum / h->rc.cplxcount, 1.0 - h->rc.qcompress);
+        q = h->rc.last_rceq / rate_factor;
+    } else q = h->rc.last_qscale_for[is_i ? 0 : 1];
+    if (h->abr && satd > 0) {
+        // pull towards the target: bits so far against time so far, within an abr_buffer that grows with sqrt(time)
+        const double time_done = frames_done / h->rc.fps, wanted_bits = time_done * h->rc.bitrate;
+        if (wanted_bits > 0) {
+            const double buf = h->rc.abr_buffer * (time_done > 1.0 ? sqrt(time_done) : 1.0);
+            overflow = 1.0 + (h->rc.total_bits - wanted_bits) / buf;
+            overflow = overflow < 0.5 ? 0.5 : overflow > 2.0 ? 2.0 : overflow;
+            q *= overflow;
+        }
+    }
+    if (is_i && h->keyint > 1 && !h->rc.last_non_b_is_i) q = qp2qscale(h->rc.accum_p_qp / h->rc.accum_p_norm) / h->rc.ip_factor;
+    else if (frames_done > 0) {
+        if (h->abr) {       // asymmetric clipping against the last quantiser of the same picture type (qpstep)
+            double lmin = h->rc.last_qscale_for[is_i ? 0 : 1] / h->rc.lstep, lmax = h->rc.last_qscale_for[is_i ? 0 : 1] * h->rc.lstep;
+            if (overflow > 1.1 && frames_done > 3) lmax *= h->rc.lstep;
+            else if (overflow < 0.9) lmin /= h->rc.lstep;
+            q = q < lmin ? lmin : q > lmax ? lmax : q;
+        }
+    } else if (h->crf && h->rc.qcompress != 1.0) q = qp2qscale(p.rc.f_rf_constant) / h->rc.ip_factor;       // very first picture: ABR_INIT_QP / ipratio
+    q = q < h->rc.lmin ? h->rc.lmin : q > h->rc.lmax ? h->rc.lmax : q;
+    h->rc.last_qscale_for[is_i ? 0 : 1] = q;
+    if (frames_done == 0) h->rc.last_qscale_for[1] = q * h->rc.ip_factor;
+    double qpf = qscale2qp(q);
+    qpf = qpf < p.rc.i_qp_min ? p.rc.i_qp_min : qpf > p.rc.i_qp_max ? p.rc.i_qp_max : qpf;
+    const int qp_now = clampi((int)(qpf + 0.5), 1, 51);
+    h->rc.accum_p_qp = h->rc.accum_p_qp * 0.95 + (is_i ? qpf + h->rc.ip_offset : qpf);      // accum_p_qp_update
+    h->rc.accum_p_norm = h->rc.accum_p_norm * 0.95 + 1.0;
+    h->rc.last_non_b_is_i = is_i;
+    h->rc.qpa_last = qpf;
+    return qp_now;
+}
+
 // Codes the oldest picture of the lookahead queue: macroblock-tree over the pictures queued behind it (up to the next intra picture),
 // rate control, the GPU hot path, entropy coding.  Returns the bytes of its NAL units.
 static int encode_queued(x264_t *h, x264_nal_t **pp_nal, int *pi_nal, x264_picture_t *pic_out)
@@ -519,49 +595,7 @@ static int encode_queued(x264_t *h, x264_nal_t **pp_nal, int *pi_nal, x264_pictu
         }
     }
     if (h->crf || h->abr) {
-        // rate_estimate_qscale: q = rceq / rate_factor; rceq = blurred_complexity^(1 - qcomp), or under macroblock-tree (which does the
-        // complexity weighting itself) the frame-duration term alone; an I picture after P pictures takes the running P quantiser /
-        // ipratio; the quantiser is qscale2qp(q) rounded, within [qpmin, qpmax]
-        auto qp2qscale = [](double q) { return 0.85 * pow(2.0, (q - 12.0) / 6.0); };
-        auto qscale2qp = [](double qs) { return 12.0 + 6.0 * log2(qs / 0.85); };
-        const double satd = is_i ? e.costs[0] : e.costs[1];
-        h->rc.cplxsum = h->rc.cplxsum * 0.5 + satd / h->rc.dur_ratio;
-        h->rc.cplxcount = h->rc.cplxcount * 0.5 + 1.0;
-        double q, overflow = 1.0;
-        const double rate_factor = h->crf ? h->rc.rate_factor_constant : h->rc.wanted_bits_window / h->rc.cplxr_sum;
-        if (satd > 0) {
-            h->rc.last_rceq = h->mbtree ? pow(1.0 / h->rc.dur_ratio, 1.0 - p.rc.f_qcompress) : pow(h->rc.cplxsum / h->rc.cplxcount, 1.0 - h->rc.qcompress);
-            q = h->rc.last_rceq / rate_factor;
-        } else q = h->rc.last_qscale_for[is_i ? 0 : 1];
-        if (h->abr && satd > 0) {
-            // pull towards the target: bits so far against time so far, within an abr_buffer that grows with sqrt(time)
-            const double time_done = h->frame_no / h->rc.fps, wanted_bits = time_done * h->rc.bitrate;
-            if (wanted_bits > 0) {
-                const double buf = h->rc.abr_buffer * (time_done > 1.0 ? sqrt(time_done) : 1.0);
-                overflow = 1.0 + (h->rc.total_bits - wanted_bits) / buf;
-                overflow = overflow < 0.5 ? 0.5 : overflow > 2.0 ? 2.0 : overflow;
-                q *= overflow;
-            }
-        }
-        if (is_i && h->keyint > 1 && !h->rc.last_non_b_is_i) q = qp2qscale(h->rc.accum_p_qp / h->rc.accum_p_norm) / h->rc.ip_factor;
-        else if (h->frame_no > 0) {
-            if (h->abr) {       // asymmetric clipping against the last quantiser of the same picture type (qpstep)
-                double lmin = h->rc.last_qscale_for[is_i ? 0 : 1] / h->rc.lstep, lmax = h->rc.last_qscale_for[is_i ? 0 : 1] * h->rc.lstep;
-                if (overflow > 1.1 && h->frame_no > 3) lmax *= h->rc.lstep;
-                else if (overflow < 0.9) lmin /= h->rc.lstep;
-                q = q < lmin ? lmin : q > lmax ? lmax : q;
-            }
-        } else if (h->crf && h->rc.qcompress != 1.0) q = qp2qscale(p.rc.f_rf_constant) / h->rc.ip_factor;       // very first picture: ABR_INIT_QP / ipratio
-        q = q < h->rc.lmin ? h->rc.lmin : q > h->rc.lmax ? h->rc.lmax : q;
-        h->rc.last_qscale_for[is_i ? 0 : 1] = q;
-        if (h->frame_no == 0) h->rc.last_qscale_for[1] = q * h->rc.ip_factor;
-        double qpf = qscale2qp(q);
-        qpf = qpf < p.rc.i_qp_min ? p.rc.i_qp_min : qpf > p.rc.i_qp_max ? p.rc.i_qp_max : qpf;
-        qp_now = clampi((int)(qpf + 0.5), 1, 51);
-        h->rc.accum_p_qp = h->rc.accum_p_qp * 0.95 + (is_i ? qpf + h->rc.ip_offset : qpf);      // accum_p_qp_update
-        h->rc.accum_p_norm = h->rc.accum_p_norm * 0.95 + 1.0;
-        h->rc.last_non_b_is_i = is_i;
-        h->rc.qpa_last = qpf;
+        qp_now = rc_pick_qp(h, is_i, e.costs, h->frame_no);
         if (x264gpu_encoder_set_qp(h->gpu, qp_now, qp_now) != X264GPU_OK) return -1;
     }
     h->last_qp = qp_now;
