@@ -382,3 +382,71 @@ def test_crf_with_macroblock_tree(gpu):
         og.encode(f, 2 if types[i] == 2 else 3 if types[i] == 1 else 0)
         np.testing.assert_array_equal(og.recon(), recons[i], err_msg=f"oracle chain picture {i}")
     assert lowered > 50
+
+
+def test_random_option_mixes_stay_decodable(gpu):
+    """host-API stress: random picture sizes (ragged, tiny, wide) x random mixes of the options this round implements x every rate
+    control mode, serial and GOP-parallel; each session must return every picture exactly once, in order, and the stream must decode
+    to the reconstruction the encoder holds for the last picture (closed loop through the checker decoder)"""
+    rng = np.random.default_rng(20261002)
+    sizes = [(16, 16), (48, 32), (176, 144), (200, 104), (72, 136), (416, 64), (34, 50), (250, 18)]
+    for trial in range(int(__import__("os").environ.get("X264GPU_STRESS_TRIALS", "28"))):
+        w, h = sizes[int(rng.integers(len(sizes)))]
+        w, h = w & ~1, h & ~1
+        nfr = int(rng.integers(2, 12))
+        opts = {"keyint": int(rng.choice([1, 2, 3, 5, 250])), "ref": int(rng.integers(1, 5)), "subme": int(rng.integers(0, 8)),
+                "me": str(rng.choice(["dia", "hex", "umh", "esa"])), "merange": int(rng.choice([4, 8, 16]))}
+        if rng.random() < 0.5: opts["partitions"] = str(rng.choice(["none", "all", "p8x8,i4x4", "i8x8,i4x4", "p8x8"]))
+        if rng.random() < 0.3: opts["no-8x8dct"] = None
+        if rng.random() < 0.3: opts["no-deblock"] = None
+        elif rng.random() < 0.4: opts["deblock"] = f"{int(rng.integers(-3, 4))}:{int(rng.integers(-3, 4))}"
+        if rng.random() < 0.3: opts["no-chroma-me"] = None
+        if rng.random() < 0.3: opts["no-mixed-refs"] = None
+        if rng.random() < 0.3: opts["chroma-qp-offset"] = int(rng.integers(-6, 7))
+        if rng.random() < 0.3: opts["no-scenecut"] = None
+        mode = str(rng.choice(["qp", "crf", "crf-tree", "abr"]))
+        if mode == "qp": opts["qp"] = int(rng.integers(8, 48))
+        elif mode == "abr": opts["bitrate"] = int(rng.integers(50, 2000))
+        else:
+            opts["crf"] = int(rng.integers(12, 40))
+            if mode == "crf": opts["no-mbtree"] = None
+            else: opts["rc-lookahead"] = int(rng.integers(1, 7))
+        if rng.random() < 0.3: opts["aq-mode"] = int(rng.integers(0, 2))
+        threads = int(rng.choice([1, 1, 2, 3]))
+        if threads > 1:
+            opts["threads"] = threads
+            opts["keyint"] = min(opts["keyint"], 5)
+        opts["min-keyint"] = max(1, min(opts["keyint"], int(rng.integers(1, 4))))
+        frames = synth_frames(w, h, nfr, seed=1000 + trial)
+        if rng.random() < 0.5:                                               # a cut somewhere
+            frames[nfr // 2:] = synth_frames(w, h, nfr - nfr // 2, seed=5000 + trial)
+        tag = f"trial {trial}: {w}x{h} x{nfr} {opts}"
+        h_, eff = open_encoder(w, h, opts, None if rng.random() < 0.5 else b"high")
+        pic, out = HL.Picture(), HL.Picture()
+        assert H.x264_picture_alloc(C.byref(pic), HL.X264_CSP_I420, w, h) == 0
+        nal, n = C.POINTER(HL.Nal)(), C.c_int()
+        stream, pts = b"", []
+        for i, f in enumerate(frames):
+            C.memmove(pic.img.plane[0], f.ctypes.data, f.size)
+            pic.i_pts = 7 + 3 * i
+            size = H.x264_encoder_encode(h_, C.byref(nal), C.byref(n), C.byref(pic), C.byref(out))
+            assert size >= 0, tag
+            if size:
+                stream += C.string_at(nal[0].p_payload, size); pts.append(out.i_pts)
+            assert H.x264_encoder_delayed_frames(h_) == i + 1 - len(pts), tag
+        guard = 0
+        while H.x264_encoder_delayed_frames(h_):
+            size = H.x264_encoder_encode(h_, C.byref(nal), C.byref(n), None, C.byref(out))
+            assert size > 0, tag
+            stream += C.string_at(nal[0].p_payload, size); pts.append(out.i_pts)
+            guard += 1
+            assert guard <= nfr, tag
+        assert pts == [7 + 3 * i for i in range(nfr)], tag
+        rec = np.zeros(w * h * 3 // 2, np.uint8)
+        got_rec = eff.i_threads <= 1 and H.x264host_get_recon(h_, rec.ctypes.data) == 0
+        H.x264_encoder_close(h_)
+        H.x264_picture_clean(C.byref(pic))
+        dec = O.h264_decode(stream, nfr, w, h)
+        assert len(dec) == nfr, tag
+        if got_rec:
+            np.testing.assert_array_equal(dec[-1], rec, err_msg=tag)

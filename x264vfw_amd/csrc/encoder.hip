@@ -39,7 +39,8 @@ struct x264gpu_encoder {
     // adaptive quantisation: per-macroblock quantisers and the per-quantiser tables (built when aq_mode != 0)
     uint8_t *mbqp = nullptr;
     const int16_t *ext_off = nullptr;    // quantiser offsets handed in by the caller (lookahead), [streams][nmb] Q8
-    int8_t *stream_qp = nullptr;         // device copy of the per-stream slice quantisers (x264gpu_encoder_set_stream_qps)
+    int8_t *stream_qp = nullptr;         // device copies of the per-stream slice quantisers (x264gpu_encoder_set_stream_qps): two, used in turn,
+    int stream_qp_sel = 0;               // so that an encode still in flight on the caller's stream keeps reading the set it was issued with
     bool use_stream_qp = false;
     Q4 *q4tab = nullptr; Q8 *q8tab = nullptr; int *lambda_tab = nullptr; uint16_t *cost_all = nullptr;
     // optional per-stage profiling: (NSTAGE+1) events per armed call
@@ -182,8 +183,9 @@ int x264gpu_encoder_set_stream_qps(x264gpu_encoder *e, const int8_t *qps)
     if (!qps) { e->use_stream_qp = false; return X264GPU_OK; }
     for (int s = 0; s < e->cfg.streams; s++) ARG_TRY(qps[s] >= 0 && qps[s] <= 51);
     if (!e->q4tab) { const int rc = build_aq_tables(e); if (rc) return rc; }
-    if (!e->stream_qp) HIP_TRY(hipMalloc((void **)&e->stream_qp, (size_t)e->cfg.streams));
-    HIP_TRY(hipMemcpy(e->stream_qp, qps, (size_t)e->cfg.streams, hipMemcpyHostToDevice));
+    if (!e->stream_qp) HIP_TRY(hipMalloc((void **)&e->stream_qp, 2 * (size_t)e->cfg.streams));
+    e->stream_qp_sel ^= 1;
+    HIP_TRY(hipMemcpy(e->stream_qp + (size_t)e->stream_qp_sel * e->cfg.streams, qps, (size_t)e->cfg.streams, hipMemcpyHostToDevice));
     e->use_stream_qp = true;
     return X264GPU_OK;
 }
@@ -285,7 +287,7 @@ int x264gpu_encode_frames(x264gpu_encoder *e, const uint8_t *d_i420, int slice_t
     hipLaunchKernelGGL(k_ingest, dim3((k.cw / 4 + 255) / 256, k.ch, S), dim3(256), 0, st, k);
     const bool aq = e->cfg.aq_mode != 0 || e->ext_off != nullptr || e->use_stream_qp;
     if (aq) {
-        k.stream_qp = e->use_stream_qp ? e->stream_qp : nullptr;
+        k.stream_qp = e->use_stream_qp ? e->stream_qp + (size_t)e->stream_qp_sel * e->cfg.streams : nullptr;
         k.mbqp = e->mbqp; k.q4tab = e->q4tab; k.q8tab = e->q8tab; k.lambda_tab = e->lambda_tab; k.cost_all = e->cost_all; k.aq_strength_q8 = e->cfg.aq_strength_q8;
         if (e->ext_off || !e->cfg.aq_mode) hipLaunchKernelGGL(k_apply_qp_offsets, dim3((k.nmb + 255) / 256, S), dim3(256), 0, st, k, e->ext_off);
         else hipLaunchKernelGGL(k_aq, dim3((k.nmb + 15) / 16, S), dim3(256), 0, st, k);
