@@ -325,15 +325,21 @@ int x264gpu_encode_frames(x264gpu_encoder *e, const uint8_t *d_i420, int slice_t
     const int nbands = (k.mbh + 3) / 4, npairs = (k.mbh + 1) / 2;
     const int iwg = (nbands + I2_WAVES_MWG - 1) / I2_WAVES_MWG, dwg = (npairs + 3) / 4;
     const bool mwg = !mwg_off && S * (iwg > dwg ? iwg : dwg) <= 128 && k.mbh > 4;
+    // a lone picture (or a handful): one macroblock row per wavefront, four times the bands
+    const int iwg1 = (k.mbh + I2_WAVES_MWG - 1) / I2_WAVES_MWG;
+    static const bool rows1_off = getenv("X264GPU_INTRA_BAND4") != nullptr;
+    const bool rows1 = mwg && !rows1_off && S * iwg1 <= 128;
     k.wf_progress = e->wf_progress;
     if (mwg) HIP_TRY(hipMemsetAsync(e->wf_progress, 0, (size_t)S * 2 * WFG_ROWS * sizeof(int), st));
     if (intra_v1 && !aq) hipLaunchKernelGGL(k_intra, dim3(S), dim3(1024), 0, st, k);
     else if (aq) {      // per-macroblock quantisers: own instantiations (the slot carries its quantiser tables in LDS)
-        if (mwg) hipLaunchKernelGGL((k_intra2<I2_WAVES_MWG, true, true>), dim3(S, iwg), dim3(I2_WAVES_MWG * 64), 0, st, k);
+        if (rows1) hipLaunchKernelGGL((k_intra2<I2_WAVES_MWG, true, true, 1>), dim3(S, iwg1), dim3(I2_WAVES_MWG * 64), 0, st, k);
+        else if (mwg) hipLaunchKernelGGL((k_intra2<I2_WAVES_MWG, true, true>), dim3(S, iwg), dim3(I2_WAVES_MWG * 64), 0, st, k);
         else if (S >= 128) hipLaunchKernelGGL((k_intra2<I2_WAVES, false, true>), dim3(S), dim3(I2_WAVES * 64), 0, st, k);
         else hipLaunchKernelGGL((k_intra2<I2_WAVES_FEW, false, true>), dim3(S), dim3(I2_WAVES_FEW * 64), 0, st, k);
         hipLaunchKernelGGL(k_settle_qp, dim3(S), dim3(64), 0, st, k);      // QP_Y inheritance before the deblocking filter reads the records
     }
+    else if (rows1) hipLaunchKernelGGL((k_intra2<I2_WAVES_MWG, true, false, 1>), dim3(S, iwg1), dim3(I2_WAVES_MWG * 64), 0, st, k);
     else if (mwg) hipLaunchKernelGGL((k_intra2<I2_WAVES_MWG, true, false>), dim3(S, iwg), dim3(I2_WAVES_MWG * 64), 0, st, k);
     else if (S >= 128) hipLaunchKernelGGL((k_intra2<I2_WAVES, false, false>), dim3(S), dim3(I2_WAVES * 64), 0, st, k);        // CUs are full: small workgroups, two per CU
     else hipLaunchKernelGGL((k_intra2<I2_WAVES_FEW, false, false>), dim3(S), dim3(I2_WAVES_FEW * 64), 0, st, k);                  // few streams: all bands of a frame at once

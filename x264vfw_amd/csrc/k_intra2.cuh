@@ -491,7 +491,9 @@ __device__ __forceinline__ int i2_next_intra(const EncK &k, const x264gpu_mb *mb
 #ifndef X264GPU_I2_OCC
 #define X264GPU_I2_OCC 4          // waves per SIMD the register allocator targets (2 -> up to 256 VGPRs, 4 -> 128)
 #endif
-template <int NW, bool MWG, bool AQ>
+// ROWS = macroblock rows per band (slots in use): 4 fills the wave when many pictures are in flight; 1 gives every row of a lone
+// picture its own wavefront (single-stream latency: four times as many bands walk the picture at once)
+template <int NW, bool MWG, bool AQ, int ROWS = 4>
 __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(X264GPU_I2_OCC, 8))) void k_intra2(EncK kk)
 {
     __shared__ __attribute__((aligned(16))) Intra2LdsT<NW> L;
@@ -510,14 +512,14 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(X264GPU
     auto pstore = [&](int r, int v) { if (MWG) wfp_store<true>(gprog + r, v); else ((volatile int *)L.progress)[r] = v; };
     SlotLds *slots = L.slot[wave];
     unsigned long long tA = 0, tB = 0, tC = 0, tW = 0, nstep = 0, nslot = 0, t_begin = k.dbg ? clock64() : 0;
-    const int mbw = k.mbw, nbands = (k.mbh + 3) >> 2;
+    const int mbw = k.mbw, nbands = (k.mbh + ROWS - 1) / ROWS;
     for (int band = gwave; band < nbands; band += gstride) {
-        const int r0 = band * 4;
+        const int r0 = band * ROWS;
         int x[4], cur[4];                      // next intra macroblock / macroblocks completed, per row of the band
 #pragma unroll
-        for (int i = 0; i < 4; i++) { x[i] = r0 + i < k.mbh ? i2_next_intra(k, mbs, r0 + i, 0, lane) : mbw; cur[i] = x[i]; }
+        for (int i = 0; i < 4; i++) { x[i] = i < ROWS && r0 + i < k.mbh ? i2_next_intra(k, mbs, r0 + i, 0, lane) : mbw; cur[i] = x[i]; }
         wfp_release<MWG>();
-        if (lane < 4 && r0 + lane < k.mbh) pstore(r0 + lane, lane == 0 ? cur[0] : lane == 1 ? cur[1] : lane == 2 ? cur[2] : cur[3]);
+        if (lane < ROWS && r0 + lane < k.mbh) pstore(r0 + lane, lane == 0 ? cur[0] : lane == 1 ? cur[1] : lane == 2 ? cur[2] : cur[3]);
         for (;;) {
             unsigned act = 0;
             bool all_done = true;
@@ -534,7 +536,7 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(X264GPU
             const unsigned long long c0 = k.dbg ? clock64() : 0;
             wfp_acquire<MWG>();
 #pragma unroll 1
-            for (int i = 0; i < 4; i++)            // one copy of the phase code (instruction-cache footprint), slot chosen at run time
+            for (int i = 0; i < ROWS; i++)            // one copy of the phase code (instruction-cache footprint), slot chosen at run time
                 if (act >> i & 1) { i2_phase_a<AQ>(k, slots[i], lane, s, i == 0 ? x[0] : i == 1 ? x[1] : i == 2 ? x[2] : x[3], r0 + i); __builtin_amdgcn_sched_barrier(0); }
             const unsigned long long c1 = k.dbg ? clock64() : 0;
             __builtin_amdgcn_sched_barrier(0);
@@ -542,13 +544,13 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(X264GPU
             __builtin_amdgcn_sched_barrier(0);
             const unsigned long long c2 = k.dbg ? clock64() : 0;
 #pragma unroll 1
-            for (int i = 0; i < 4; i++)
+            for (int i = 0; i < ROWS; i++)
                 if (act >> i & 1) { __builtin_amdgcn_sched_barrier(0); i2_phase_c<AQ>(k, slots[i], lane, s, i == 0 ? x[0] : i == 1 ? x[1] : i == 2 ? x[2] : x[3], r0 + i); }
             if (k.dbg) { const unsigned long long c3 = clock64(); tA += c1 - c0; tB += c2 - c1; tC += c3 - c2; nstep++; nslot += __builtin_popcount(act); }
             wfp_release<MWG>();
 #pragma unroll
             for (int i = 0; i < 4; i++) if (act >> i & 1) { x[i] = i2_next_intra(k, mbs, r0 + i, x[i] + 1, lane); cur[i] = x[i]; }
-            if (lane < 4 && r0 + lane < k.mbh) pstore(r0 + lane, lane == 0 ? cur[0] : lane == 1 ? cur[1] : lane == 2 ? cur[2] : cur[3]);
+            if (lane < ROWS && r0 + lane < k.mbh) pstore(r0 + lane, lane == 0 ? cur[0] : lane == 1 ? cur[1] : lane == 2 ? cur[2] : cur[3]);
         }
     }
     if (k.dbg && lane == 0) {
