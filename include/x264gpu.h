@@ -26,6 +26,7 @@ enum { X264GPU_OK = 0, X264GPU_EINVAL = -1, X264GPU_EHIP = -2, X264GPU_ENOMEM = 
 int  x264gpu_abi_version(void);
 int  x264gpu_device_count(void);               /* 0 when no GPU is visible */
 int  x264gpu_set_device(int dev);
+int  x264gpu_get_device(int *dev);        /* the calling thread's device: a helper thread that issues work for an encoder selects it first */
 const char *x264gpu_last_error(void);
 int  x264gpu_malloc(void **d_ptr, size_t bytes);
 int  x264gpu_free(void *d_ptr);

@@ -347,17 +347,42 @@ def test_abr_steers_towards_the_bitrate(gpu):
     assert len(set(lo[1])) > 2                                                  # it actually moves
 
 
-def test_crf_with_macroblock_tree(gpu):
+def test_crf_with_macroblock_tree(gpu, monkeypatch):
     """the driver's default rate control in full: CRF + variance AQ + macroblock-tree over rc-lookahead pictures held back in the
     lookahead queue.  The frame quantiser is the constant crf + 13.5 (1 - qcomp) (the tree does the complexity weighting), the
     macroblock offsets are AQ - tree; the whole chain is replayed with the CPU oracle (lookahead records -> x264o_mbtree -> oracle
     pipeline with those offsets) and must reproduce the host encoder's reconstruction; the stream decodes to it as well."""
     w, h, crf, look = 176, 144, 24.0, 4
     frames = synth_frames(w, h, 7, seed=5) + synth_frames(w, h, 4, seed=99)
-    h_, eff = open_encoder(w, h, {"crf": crf, "keyint": 250, "min-keyint": 3, "rc-lookahead": look}, b"high")
+    opts = {"crf": crf, "keyint": 250, "min-keyint": 3, "rc-lookahead": look}
+    monkeypatch.setenv("X264GPU_HOST_PIPELINE", "0")                         # GPU stage and entropy coding in the same call: the reconstruction read
+    h_, eff = open_encoder(w, h, opts, b"high")                              # back after a call is that call's picture
     assert (eff.rc.b_mb_tree, eff.rc.i_lookahead, eff.rc.i_aq_mode) == (1, look, 1)
     stream, rows, recons = encode_with_decisions(h_, w, h, frames)
     H.x264_encoder_close(h_)
+    # the pipelined session (the default: the next picture's GPU stage runs behind this one's entropy coding) hands every picture
+    # back one call later and writes the same bytes
+    monkeypatch.delenv("X264GPU_HOST_PIPELINE")
+    hp, _ = open_encoder(w, h, opts, b"high")
+    pic, out = HL.Picture(), HL.Picture()
+    assert H.x264_picture_alloc(C.byref(pic), HL.X264_CSP_I420, w, h) == 0
+    nal, nn = C.POINTER(HL.Nal)(), C.c_int()
+    piped, first_out = b"", None
+    for i, f in enumerate(frames):
+        C.memmove(pic.img.plane[0], f.ctypes.data, f.size)
+        pic.i_pts = i
+        size = H.x264_encoder_encode(hp, C.byref(nal), C.byref(nn), C.byref(pic), C.byref(out))
+        assert size >= 0
+        if size:
+            first_out = i if first_out is None else first_out
+            piped += C.string_at(nal[0].p_payload, size)
+    while H.x264_encoder_delayed_frames(hp):
+        size = H.x264_encoder_encode(hp, C.byref(nal), C.byref(nn), None, C.byref(out))
+        assert size > 0
+        piped += C.string_at(nal[0].p_payload, size)
+    H.x264_encoder_close(hp)
+    H.x264_picture_clean(C.byref(pic))
+    assert first_out == look + 1 and piped == stream
     n = len(frames)
     types = [2 if r[0] else (1 if r[4] == 2 else 0) for r in rows]            # X264_TYPE_I == 2: I picture that is not IDR
     assert types[0] == 2 and types[7] in (1, 2) and sum(1 for t in types if t) == 2

@@ -21,12 +21,13 @@ def main():
     w, h, n = 1920, 1080, int(sys.argv[1]) if len(sys.argv) > 1 else 60
     threads = int(sys.argv[2]) if len(sys.argv) > 2 else 1              # --threads G: closed GOPs coded in lock-step
     keyint = int(sys.argv[3]) if len(sys.argv) > 3 else 60
+    rc = sys.argv[4] if len(sys.argv) > 4 else "qp"                     # "qp": constant quantiser; "crf": the driver's default session (CRF 23 + AQ + mbtree, rc-lookahead 40)
     frames = synth_frames(w, h, 8, seed=1)
     p = HL.Param()
     assert H.x264_param_default_preset(C.byref(p), b"medium", None) == 0
     p.i_width, p.i_height, p.i_csp = w, h, HL.X264_CSP_I420
     p.i_fps_num, p.i_fps_den, p.i_log_level = 25, 1, -1
-    for k, v in (("qp", "23"), ("keyint", str(keyint)), ("threads", str(threads))):
+    for k, v in ((("qp", "23") if rc == "qp" else ("crf", "23")), ("keyint", str(keyint)), ("threads", str(threads))):
         assert H.x264_param_parse(C.byref(p), k.encode(), v.encode()) == 0
     p.b_annexb, p.b_repeat_headers = 1, 1
     h_ = H.x264_encoder_open_157(C.byref(p))
@@ -55,7 +56,7 @@ def main():
     t_enc = time.perf_counter() - t_start
     H.x264_encoder_close(h_)
     assert got == n
-    print(f"B1 single stream 1080p medium toolset, threads {threads}, keyint {keyint}: {n / t_enc:.1f} frames/s ({1e3 * t_enc / n:.2f} ms/frame incl. "
+    print(f"B1 single stream 1080p medium toolset, {rc}, threads {threads}, keyint {keyint}: {n / t_enc:.1f} frames/s ({1e3 * t_enc / n:.2f} ms/frame incl. "
           f"host copy-in, upload, GPU, download, host CAVLC; {total / n / 1e3:.1f} kB/frame; {os.cpu_count()} host cores)")
 
 

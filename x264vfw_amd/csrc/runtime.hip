@@ -24,6 +24,7 @@ int x264gpu_device_count(void)
 }
 
 int x264gpu_set_device(int dev) { HIP_TRY(hipSetDevice(dev)); return X264GPU_OK; }
+int x264gpu_get_device(int *dev) { ARG_TRY(dev); HIP_TRY(hipGetDevice(dev)); return X264GPU_OK; }
 
 const char *x264gpu_last_error(void) { return g_err; }
 

@@ -59,7 +59,7 @@ struct x264_t {
     bool abr = false;
     double t_phase[6] = { 0, 0, 0, 0, 0, 0 };   // X264GPU_HOST_TIMING=1: seconds in copy-in, upload + lookahead, GPU, download, entropy coding, calls
     // ---- lookahead queue (threads 1): pictures wait here rc-lookahead deep when the macroblock-tree needs to see what follows them ----
-    struct QEntry { int64_t pts; int slot; int type; int scenecut; int32_t costs[4]; x264_image_t img; };      // type: 0 P, 1 I, 2 IDR
+    struct QEntry { int64_t pts; int slot; int type; int scenecut; int32_t costs[4]; x264_image_t img; int qp; int buf; bool launched; };      // type: 0 P, 1 I, 2 IDR; qp / buf / launched: set by gpu_stage
     std::deque<QEntry> queue;
     int L = 0, Q = 1;                    // pictures held back; ring slots (L + 1)
     std::vector<uint8_t *> q_raw;        // device: source pictures (slot 0 is d_in when nothing is held back: zero-copy input)
@@ -69,6 +69,13 @@ struct x264_t {
     long la_count = 0; int la_gop = 0;   // pictures seen by the lookahead; distance from the last IDR at lookahead time
     bool mbtree = false; int aq_strength_q8 = 0, tree_strength_q8 = 0;
     int cavlc_threads = 1;               // row bands of a slice coded in parallel (threads 1 sessions; GOP-parallel ones use a thread per GOP)
+    // ---- pipelined threads-1 sessions (CRF with pictures held back anyway): the GPU stage of picture n+1 runs in a helper thread while
+    //      the calling thread entropy-codes picture n; every picture is handed back one call later than without it ----
+    bool pipeline = false;
+    std::thread gpu_thread;
+    int gpu_rc = 0;                      // result of the GPU stage in flight
+    int rc_frames = 0;                   // pictures that went through rate control (frames_done of rc_pick_qp)
+    int device = 0;
     std::vector<int8_t> gop_qp;          // GOP-parallel CRF: the quantiser of every ring picture (slot * keyint + position), decided on arrival
     int last_qp = 0, last_scenecut = 0;  // diagnostics: quantiser and scenecut flag of the last coded picture
     int32_t last_costs[4] = { 0, 0, 0, 0 };
@@ -274,7 +281,11 @@ x264_t *x264_encoder_open(x264_param_t *param)
     // lookahead queue: rc-lookahead pictures are held back when the macroblock-tree is on (x264's sync lookahead), none otherwise
     h->mbtree = p.rc.b_mb_tree && h->la != nullptr;
     h->L = h->mbtree ? p.rc.i_lookahead : 0;
-    h->Q = h->L + 1;
+    // pictures are held back anyway and the quantisers do not depend on coded sizes: overlap the GPU stage of the next picture with
+    // the entropy coding of this one (one more picture of delay); X264GPU_HOST_PIPELINE=0 keeps the two stages in one call
+    { const char *pe = getenv("X264GPU_HOST_PIPELINE"); h->pipeline = h->G == 1 && h->L > 0 && h->crf && !(pe && pe[0] == '0'); }
+    (void)x264gpu_get_device(&h->device);
+    h->Q = h->L + 1 + (h->pipeline ? 1 : 0);
     h->aq_strength_q8 = cfg.aq_mode ? cfg.aq_strength_q8 : 0;
     h->tree_strength_q8 = (int)(1280.0 * (1.0 - p.rc.f_qcompress) + 0.5);     // 5 * (1 - qcomp), Q8
     h->q_raw.assign((size_t)h->Q, nullptr); h->q_info.assign((size_t)h->Q, nullptr); h->q_aq.assign((size_t)h->Q, nullptr);
@@ -319,6 +330,7 @@ x264_t *x264_encoder_open(x264_param_t *param)
     }
     { const unsigned hw = std::thread::hardware_concurrency(); h->cavlc_threads = h->G > 1 ? 1 : cavlc_threads_default(hw >= 32 ? 16 : hw >= 16 ? 8 : hw >= 4 ? (int)hw / 2 : 1); }
     h->h_in.resize(insz); h->h_mb.resize((size_t)h->G * h->nmb); h->h_lv.resize((size_t)h->G * h->nmb * X264GPU_MB_LEVELS);
+    if (h->pipeline) { h->h_mb2.resize(h->h_mb.size()); h->h_lv2.resize(h->h_lv.size()); }
     if (h->G > 1) {
         const size_t n = (size_t)h->G * h->keyint;
         h->gop_qp.assign(n, (int8_t)h->qp_p);
@@ -569,21 +581,22 @@ static int rc_pick_qp(x264_t *h, bool is_i, const int32_t costs[4], int frames_d
     return qp_now;
 }
 
-// Codes the oldest picture of the lookahead queue: macroblock-tree over the pictures queued behind it (up to the next intra picture),
-// rate control, the GPU hot path, entropy coding.  Returns the bytes of its NAL units.
-static int encode_queued(x264_t *h, x264_nal_t **pp_nal, int *pi_nal, x264_picture_t *pic_out)
+// GPU stage of queue[idx]: macroblock-tree over the pictures queued behind it (up to the next intra picture), rate control, the hot
+// path and the download of its records / levels into host buffer pair `buf` — in a helper thread when `async` (join_gpu waits).
+static void join_gpu(x264_t *h) { if (h->gpu_thread.joinable()) h->gpu_thread.join(); }
+
+static int gpu_stage(x264_t *h, size_t idx, int buf, bool async)
 {
     const x264_param_t &p = h->param;
-    const x264_t::QEntry e = h->queue.front();
+    x264_t::QEntry &e = h->queue[idx];
     const bool idr = e.type == 2, intra_pic = e.type == 1, is_i = idr || intra_pic;
     int qp_now = is_i ? h->qp_i : h->qp_p;
-    h->last_scenecut = e.scenecut;
-    memcpy(h->last_costs, e.costs, sizeof(e.costs));
     if (h->mbtree) {
         // macroblock_tree: this picture and the P pictures behind it that (transitively) reference it; an intra picture ends the chain
         const int32_t *info[256]; const int16_t *aq[256];
         int n = 0;
-        for (const x264_t::QEntry &q : h->queue) {
+        for (size_t j = idx; j < h->queue.size(); j++) {
+            const x264_t::QEntry &q = h->queue[j];
             if (n > 0 && q.type != 0) break;
             info[n] = h->q_info[(size_t)q.slot]; aq[n] = h->q_aq[(size_t)q.slot];
             if (++n == 256) break;
@@ -595,18 +608,48 @@ static int encode_queued(x264_t *h, x264_nal_t **pp_nal, int *pi_nal, x264_pictu
         }
     }
     if (h->crf || h->abr) {
-        qp_now = rc_pick_qp(h, is_i, e.costs, h->frame_no);
+        qp_now = rc_pick_qp(h, is_i, e.costs, h->rc_frames);
         if (x264gpu_encoder_set_qp(h->gpu, qp_now, qp_now) != X264GPU_OK) return -1;
     }
-    h->last_qp = qp_now;
-    if (idr) { h->frames_since_idr = 0; h->frame_num = 0; }
+    h->rc_frames++;
+    e.qp = qp_now; e.buf = buf; e.launched = true;
     const int st = idr ? X264GPU_SLICE_I : intra_pic ? X264GPU_SLICE_I_NONIDR : X264GPU_SLICE_P;
-    if (x264gpu_encode_frames(h->gpu, h->q_raw[(size_t)e.slot], st, h->d_mb, h->d_lv, nullptr) != X264GPU_OK ||
-        x264gpu_memcpy_d2h(h->h_mb.data(), h->d_mb, h->h_mb.size() * sizeof(x264gpu_mb), nullptr) != X264GPU_OK ||
-        x264gpu_memcpy_d2h(h->h_lv.data(), h->d_lv, h->h_lv.size() * sizeof(int16_t), nullptr) != X264GPU_OK) {
-        xlog(&p, X264_LOG_ERROR, "x264_encoder_encode: GPU hot path failed: %s\n", x264gpu_last_error());
-        return -1;
+    const uint8_t *src = h->q_raw[(size_t)e.slot];
+    x264gpu_mb *hmb = buf ? h->h_mb2.data() : h->h_mb.data();
+    int16_t *hlv = buf ? h->h_lv2.data() : h->h_lv.data();
+    auto run = [h, src, st, hmb, hlv]() {
+        h->gpu_rc = x264gpu_encode_frames(h->gpu, src, st, h->d_mb, h->d_lv, nullptr) != X264GPU_OK ||
+                    x264gpu_memcpy_d2h(hmb, h->d_mb, h->h_mb.size() * sizeof(x264gpu_mb), nullptr) != X264GPU_OK ||
+                    x264gpu_memcpy_d2h(hlv, h->d_lv, h->h_lv.size() * sizeof(int16_t), nullptr) != X264GPU_OK ? -1 : 0;
+    };
+    if (async) h->gpu_thread = std::thread([h, run]() { x264gpu_set_device(h->device); run(); });
+    else run();
+    return 0;
+}
+
+// Hands back the oldest picture of the lookahead queue: its GPU stage (unless a helper thread already ran it), then headers + entropy
+// coding.  Returns the bytes of its NAL units, 0 when the pipelined session only started a picture.
+static int encode_queued(x264_t *h, x264_nal_t **pp_nal, int *pi_nal, x264_picture_t *pic_out, bool flushing)
+{
+    const x264_param_t &p = h->param;
+    if (!h->queue.front().launched) {
+        if (gpu_stage(h, 0, 0, h->pipeline) < 0) return -1;
+        if (h->pipeline && !flushing) return 0;              // its results are collected by the next call
     }
+    join_gpu(h);
+    if (h->gpu_rc) { xlog(&p, X264_LOG_ERROR, "x264_encoder_encode: GPU hot path failed: %s\n", x264gpu_last_error()); return -1; }
+    // pipelined: the next picture has its whole lookahead window (or the input has ended): start its GPU stage behind this one's coding
+    if (h->pipeline && h->queue.size() >= 2 && (flushing || (int)h->queue.size() >= h->L + 2) &&
+        gpu_stage(h, 1, h->queue.front().buf ^ 1, true) < 0) return -1;
+    const x264_t::QEntry e = h->queue.front();
+    const bool idr = e.type == 2, intra_pic = e.type == 1;
+    const int qp_now = e.qp;
+    const int st = idr ? X264GPU_SLICE_I : intra_pic ? X264GPU_SLICE_I_NONIDR : X264GPU_SLICE_P;
+    const x264gpu_mb *hmb = e.buf ? h->h_mb2.data() : h->h_mb.data();
+    const int16_t *hlv = e.buf ? h->h_lv2.data() : h->h_lv.data();
+    h->last_scenecut = e.scenecut; h->last_qp = qp_now;
+    memcpy(h->last_costs, e.costs, sizeof(e.costs));
+    if (idr) { h->frames_since_idr = 0; h->frame_num = 0; }
     // ---- host: headers + entropy coding ----
     h->out.clear(); h->nal_off.clear();
     std::vector<int> types;
@@ -625,7 +668,7 @@ static int encode_queued(x264_t *h, x264_nal_t **pp_nal, int *pi_nal, x264_pictu
     sp.transform8x8_mode = p.analyse.b_transform_8x8;
     h->nal_off.push_back(h->out.size()); types.push_back(idr ? 5 : 1);
     h->last_stats.skip = 0;
-    write_slice(h->out, sp, h->h_mb.data(), h->h_lv.data(), p.b_annexb != 0, h->nal_off.size() == 1, &h->last_stats, h->cavlc_threads);
+    write_slice(h->out, sp, hmb, hlv, p.b_annexb != 0, h->nal_off.size() == 1, &h->last_stats, h->cavlc_threads);
     publish_nals(h, pp_nal, pi_nal, types);
     if (pic_out) {
         x264_picture_init(pic_out);
@@ -655,7 +698,7 @@ int x264_encoder_encode(x264_t *h, x264_nal_t **pp_nal, int *pi_nal, x264_pictur
     *pi_nal = 0; *pp_nal = nullptr;
     if (!pic_in) {      // flush: GOP-parallel batches, or the pictures still waiting in the lookahead queue, one per call
         if (h->G > 1) return encode_gop_parallel(h, pp_nal, pi_nal, nullptr, pic_out, false);
-        return h->queue.empty() ? 0 : encode_queued(h, pp_nal, pi_nal, pic_out);
+        return h->queue.empty() ? 0 : encode_queued(h, pp_nal, pi_nal, pic_out, true);
     }
     const x264_param_t &p = h->param;
     const int w = p.i_width, ht = p.i_height;
@@ -716,7 +759,7 @@ int x264_encoder_encode(x264_t *h, x264_nal_t **pp_nal, int *pi_nal, x264_pictur
     h->queue.push_back(e);
     PHASE(1);
     if ((int)h->queue.size() <= h->L) return 0;                        // still filling the lookahead: no picture yet (codec.c:1693, size 0)
-    const int size = encode_queued(h, pp_nal, pi_nal, pic_out);
+    const int size = encode_queued(h, pp_nal, pi_nal, pic_out, false);
     PHASE(4);
     h->t_phase[5] += 1;
 #undef PHASE
@@ -729,6 +772,7 @@ void x264_encoder_close(x264_t *h)
 {
     if (!h) return;
     join_pool(h);
+    join_gpu(h);
     if (getenv("X264GPU_HOST_TIMING") && h->t_phase[5] > 0)
         fprintf(stderr, "x264gpu host timing, ms per call over %.0f calls: copy-in %.2f, upload+lookahead %.2f, GPU %.2f, download %.2f, entropy %.2f\n", h->t_phase[5],
                 1e3 * h->t_phase[0] / h->t_phase[5], 1e3 * h->t_phase[1] / h->t_phase[5], 1e3 * h->t_phase[2] / h->t_phase[5], 1e3 * h->t_phase[3] / h->t_phase[5], 1e3 * h->t_phase[4] / h->t_phase[5]);
@@ -800,6 +844,7 @@ int x264host_last_decision(x264_t *h, int *qp, int *scenecut, int32_t costs[4])
 int x264host_get_recon(x264_t *h, uint8_t *i420_out)
 {
     if (!h || !h->gpu) return -1;
+    join_gpu(h);                             // a pipelined session: this is the picture whose GPU stage ran last, not the one handed back last
     size_t n = (size_t)h->param.i_width * h->param.i_height * 3 / 2;
     uint8_t *d = nullptr;
     if (x264gpu_malloc((void **)&d, n) != X264GPU_OK) return -1;
