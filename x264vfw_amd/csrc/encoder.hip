@@ -308,7 +308,8 @@ int x264gpu_encode_frames(x264gpu_encoder *e, const uint8_t *d_i420, int slice_t
                else { if (mixed) X264GPU_LAUNCH_ANALYSE(2, false, true); else X264GPU_LAUNCH_ANALYSE(2, false, false); } }
 #undef X264GPU_LAUNCH_ANALYSE
         STAGE_MARK(2);
-        hipLaunchKernelGGL(k_encode_inter, dim3((k.nmb + 3) / 4, S), dim3(256), 0, st, k);
+        if (aq) hipLaunchKernelGGL(k_encode_inter<true>, dim3((k.nmb + 3) / 4, S), dim3(256), 0, st, k);
+        else hipLaunchKernelGGL(k_encode_inter<false>, dim3((k.nmb + 3) / 4, S), dim3(256), 0, st, k);
         mask |= 2 | 4;
     } else {
         HIP_TRY(hipMemsetAsync(e->reff[1], 0xff, (size_t)S * k.nmb, st));

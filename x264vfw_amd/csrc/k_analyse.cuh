@@ -700,7 +700,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MIXED ? X26
         else { mvp0 = median3(a0, b0, c0); mvp1 = median3(a1, b1, c1); }
     }
     // quantiser of this macroblock: the slice's, or its own under AQ (lambda and the mv-cost table follow it, as x264's a->i_qp)
-    const int mqp = k.mbqp ? (int)k.mbqp[(size_t)s * k.nmb + mbi] : k.qp, lambda = k.mbqp ? k.lambda_tab[mqp] : k.lambda;
+    // (readfirstlane: the value is wave-uniform, and saying so keeps lambda and the cost-table base in scalar registers)
+    const int mqp = k.mbqp ? __builtin_amdgcn_readfirstlane((int)k.mbqp[(size_t)s * k.nmb + mbi]) : k.qp, lambda = k.mbqp ? k.lambda_tab[mqp] : k.lambda;
     const uint16_t *cost_base = k.mbqp ? k.cost_all + (size_t)mqp * 2 * MVCOST_HALF : k.cost_mv;
     const uint16_t *cmx = cost_base + MVCOST_HALF - mvp0, *cmy = cost_base + MVCOST_HALF - mvp1;
 

@@ -34,6 +34,9 @@ __global__ __launch_bounds__(256) void k_ingest(EncK k)
 // ------------------------------------------------------------------------------------------------
 // stage 2: inter macroblock encode, one wavefront per macroblock (Z layout)
 // ------------------------------------------------------------------------------------------------
+// AQ = per-macroblock quantisers (k.mbqp set): its own instantiation, so that constant-quantiser sessions keep reading the slice's
+// quantiser tables straight from the kernel arguments instead of through a run-time select of two structures
+template <bool AQ>
 __global__ __launch_bounds__(256) void k_encode_inter(EncK k)
 {
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -47,9 +50,9 @@ __global__ __launch_bounds__(256) void k_encode_inter(EncK k)
     const uint8_t *fenc = k.fenc_y + (size_t)s * k.fency_bytes + (size_t)py * k.fs + px;
     const int j = lane & 3, blk = lane >> 2, zx = z_x0(lane), zy = z_y(lane);
     // quantiser of this macroblock: the slice's, or its own under AQ (wave-uniform table reads)
-    const int mqp = k.mbqp ? mbp->qp : k.qp, mqpc = k.mbqp ? (int)d_chroma_qp_table[min(max(mqp + k.chroma_qp_offset, 0), 51)] : k.qpc;
-    const Q4 q_luma_inter = k.mbqp ? k.q4tab[mqp * 4 + 1] : k.q_luma_inter, q_chroma_inter = k.mbqp ? k.q4tab[mqpc * 4 + 3] : k.q_chroma_inter;
-    const Q8 q8_inter = k.mbqp ? k.q8tab[mqp * 2 + 1] : k.q8_inter;
+    const int mqp = AQ ? (int)mbp->qp : k.qp, mqpc = AQ ? (int)d_chroma_qp_table[min(max(mqp + k.chroma_qp_offset, 0), 51)] : k.qpc;
+    const Q4 &q_luma_inter = AQ ? k.q4tab[mqp * 4 + 1] : k.q_luma_inter, &q_chroma_inter = AQ ? k.q4tab[mqpc * 4 + 3] : k.q_chroma_inter;
+    const Q8 &q8_inter = AQ ? k.q8tab[mqp * 2 + 1] : k.q8_inter;
 
     // ---- luma ----
     const int refidx = mbp->ref[lane >> 4];         // the reference is per 8x8 block (mixed refs)
