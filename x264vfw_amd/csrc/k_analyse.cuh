@@ -653,7 +653,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MIXED ? X26
     __shared__ uint16_t s_cost[4][2][192];
     __shared__ uint32_t s_sub[4][SubGeo<M>::DWORDS];
     __shared__ uint32_t s_csub[4][CSubGeo<M>::DWORDS];
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    // the wave index is uniform across the wavefront: readfirstlane tells the compiler, so the macroblock position and every pointer
+    // derived from it live in scalar registers
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     // Workgroups are dealt round-robin to the 8 XCDs (each with its own L2): give every XCD one contiguous
     // eighth of the picture so the overlapping search windows of neighbouring macroblocks share an L2.
     const int per_xcd = gridDim.x >> 3;
@@ -698,6 +700,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MIXED ? X26
         else if (mby > 0 && mbx > 0) { int i = mbi - k.mbw - 1; if (rf[i] >= 0) { c0 = mvf[2 * i]; c1 = mvf[2 * i + 1]; } }
         if (!ib && ia) { mvp0 = a0; mvp1 = a1; }
         else { mvp0 = median3(a0, b0, c0); mvp1 = median3(a1, b1, c1); }
+        // wave-uniform by construction; saying so keeps the predictor and the cost-table pointers derived from it in scalar registers
+        mvp0 = __builtin_amdgcn_readfirstlane(mvp0); mvp1 = __builtin_amdgcn_readfirstlane(mvp1);
     }
     // quantiser of this macroblock: the slice's, or its own under AQ (lambda and the mv-cost table follow it, as x264's a->i_qp)
     // (readfirstlane: the value is wave-uniform, and saying so keeps lambda and the cost-table base in scalar registers)
@@ -730,8 +734,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MIXED ? X26
             key = wave_min_u32(key);
             const int best = key & 7;
             bcost = (int)(key >> 3);
-            bmx = best == 0 ? cx[0] : best == 1 ? cx[1] : cx[2];
-            bmy = best == 0 ? cy[0] : best == 1 ? cy[1] : cy[2];
+            bmx = __builtin_amdgcn_readfirstlane(best == 0 ? cx[0] : best == 1 ? cx[1] : cx[2]);        // uniform (see `wave`)
+            bmy = __builtin_amdgcn_readfirstlane(best == 0 ? cy[0] : best == 1 ? cy[1] : cy[2]);
         }
 
         // ---- stage the search window in LDS ----
@@ -981,7 +985,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MIXED ? X26
         if (mixed && bref == 0 && mbx > 0 && mby > 0) {
             int m0 = max((int)rf[mbi - 1], (int)rf[mbi - k.mbw]);
             m0 = max(m0, max((int)rf[mbi - k.mbw - 1], (int)rf[mbx + 1 < k.mbw ? mbi - k.mbw + 1 : mbi]));
-            maxref = min(max(max(m0, (int)rf[mbi]), 0), k.nref - 1);
+            maxref = __builtin_amdgcn_readfirstlane(min(max(max(m0, (int)rf[mbi]), 0), k.nref - 1));
         }
         for (int ph = 0; ph < 3; ph++) {
             const int shape = ph == 0 ? 3 : ph;

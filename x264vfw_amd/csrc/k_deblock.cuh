@@ -402,7 +402,7 @@ template <bool MWG>
 __global__ __launch_bounds__(1024) void k_deblock2(EncK k)
 {
     __shared__ __attribute__((aligned(16))) Deblock2Lds L;
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, s = blockIdx.x, nw = blockDim.x >> 6;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63, s = blockIdx.x, nw = blockDim.x >> 6;      // scalar wave index
     const int gwave = MWG ? (int)blockIdx.y * nw + wave : wave, gstride = MWG ? (int)gridDim.y * nw : nw;
     for (int i = threadIdx.x; i < WF_MAX_ROWS; i += blockDim.x) L.progress[i] = 0;
     if (threadIdx.x < 52) {

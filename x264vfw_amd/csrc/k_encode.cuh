@@ -39,7 +39,7 @@ __global__ __launch_bounds__(256) void k_ingest(EncK k)
 template <bool AQ>
 __global__ __launch_bounds__(256) void k_encode_inter(EncK k)
 {
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;       // scalar: see k_analyse_p
     const int mbi = blockIdx.x * 4 + wave, s = blockIdx.y;
     if (mbi >= k.nmb) return;
     x264gpu_mb *mbp = k.mb + (size_t)s * k.nmb + mbi;

@@ -497,7 +497,7 @@ template <int NW, bool MWG, bool AQ, int ROWS = 4>
 __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(X264GPU_I2_OCC, 8))) void k_intra2(EncK kk)
 {
     __shared__ __attribute__((aligned(16))) Intra2LdsT<NW> L;
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, s = blockIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63, s = blockIdx.x;      // scalar wave index: see k_analyse_p
     // MWG: gridDim.y workgroups share the bands of stream s (band = global wave index, then + all waves)
     const int gwave = MWG ? (int)blockIdx.y * NW + wave : wave, gstride = MWG ? (int)gridDim.y * NW : NW;
     for (int i = threadIdx.x; i < 160; i += NW * 64) L.progress[i] = 0;

@@ -60,7 +60,7 @@ __global__ __launch_bounds__(256) void k_la_cost(LaK k)
     __shared__ __attribute__((aligned(8))) uint8_t s_tab[9 * 64];
     __shared__ uint8_t s_cnb[4][4][CNB_SIZE];
     __shared__ uint8_t s_u8[4][4][U8_SIZE];
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, s = blockIdx.y;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63, s = blockIdx.y;      // scalar wave index
     for (int i = threadIdx.x; i < 9 * 64; i += 256) s_tab[i] = c_pred8_table[i];
     __syncthreads();
     const int gw = (k.bw + 1) >> 1, gh = (k.bh + 1) >> 1, g = blockIdx.x * 4 + wave;
