@@ -108,7 +108,7 @@ __device__ __forceinline__ unsigned scan_mask(const int v[4], int j)
 }
 __device__ __forceinline__ bool any_big(const int v[4])
 {
-    return (abs(v[0]) > 1) | (abs(v[1]) > 1) | (abs(v[2]) > 1) | (abs(v[3]) > 1);
+    return (int)(abs(v[0]) > 1) | (int)(abs(v[1]) > 1) | (int)(abs(v[2]) > 1) | (int)(abs(v[3]) > 1);      // branch-free on purpose
 }
 
 // gather 4 chroma samples of one plane (c = 0 U, 1 V) from 8 interleaved NV12 bytes
