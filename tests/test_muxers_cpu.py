@@ -191,3 +191,35 @@ def test_mp4_reads_back_through_the_reference_lsmash(stream, tmp_path, fps, sar)
     assert data == expect
     m = CP.mp4_read(path.read_bytes())
     assert [s.pos for s in samples] == [x["pos"] for x in m["samples"]]
+
+
+def test_mp4_composition_offsets_and_chunks(stream, tmp_path):
+    """timestamps that differ between decode and presentation order (what a stream with reordered pictures hands the muxer) go into a
+    ctts box, long sequences into several chunks; the start offset (first dts < 0, x264's B-frame convention) is folded into the edit
+    list's media_time — the container reader and the reference tree's L-SMASH agree on every sample"""
+    w, h, sps, pps, frames, recs = stream
+    path = tmp_path / "c.mp4"
+    annexb = C.c_int()
+    m = H.x264host_mux_open(str(path).encode(), b"mp4", C.byref(annexb))
+    assert m and H.x264host_mux_set_param(m, w, h, 25, 1, 1, 25, 1, 1, 0) == 0
+    sei = b"\x06\x05\x04test\x80"
+    hs, hp, he = pref(sps), pref(pps), pref(sei)
+    assert H.x264host_mux_write_headers(m, hs, len(hs), hp, len(hp), he, len(he)) > 0
+    n = 40
+    # decode order with dts starting one tick early, as x264 does for one B-frame of delay: pts pattern 0, 2, 1, 4, 3, ...
+    pts = [0] + [i + 1 if i % 2 else i - 1 for i in range(1, n)]
+    dts = [i - 1 for i in range(n)]
+    for i in range(n):
+        nal, idr = frames[i % len(frames)]
+        payload = pref(nal)
+        assert H.x264host_mux_write_frame(m, payload, len(payload), pts[i], dts[i], int(i % 8 == 0), 1) == len(payload)
+    assert H.x264host_mux_close(m, max(pts), sorted(pts)[-2]) == 0
+    r = CP.mp4_read(path.read_bytes())
+    assert [(x["dts"], x["cts"]) for x in r["samples"]] == [(dts[i] + 1, pts[i] + 1) for i in range(n)]     # + start offset 1
+    assert r["edit"][1] == 1 and [x["key"] for x in r["samples"]] == [i % 8 == 0 for i in range(n)]
+    assert len(r["chunks"]) >= 3 and sum(r["chunks"]) == n                                                  # 40 samples at 25 fps: half-second chunks
+    if __import__("os").path.exists(O.LSMASH_REF):
+        info, samples, data = O.lsmash_read_mp4(path)
+        assert info.n_samples == n and info.edit_start_time == 1
+        assert [(s.dts, s.cts, s.sync) for s in samples] == [(dts[i] + 1, pts[i] + 1, int(i % 8 == 0)) for i in range(n)]
+        assert data == [x["data"] for x in r["samples"]]
