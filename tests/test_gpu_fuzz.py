@@ -42,3 +42,47 @@ def test_random_configs_bitexact(gpu, seed):
             assert np.array_equal(g_lv[0], o_lv), tag + " levels"
             assert np.array_equal(gg.recon(0), og.recon()), tag + " reconstruction"
         og.close(); gg.close()
+
+
+@pytest.mark.parametrize("seed", [21, 22])
+def test_random_multi_stream_quantisers_bitexact(gpu, seed):
+    """several streams in lock-step, random toolsets, and per picture a random choice of quantiser source: the shared pair, one slice
+    quantiser per stream (x264gpu_encoder_set_stream_qps), per-macroblock offsets from the caller (set_mb_qp_offsets), or both at
+    once — every stream must equal its own oracle encoder"""
+    import torch
+    from gpu_enc import GpuEncoder
+    from x264vfw_amd import lib
+    rnd = random.Random(seed)
+    for it in range(12):
+        w, h, kw, nfr, fseed, _ = random_case(rnd)
+        S = rnd.randint(2, 4)
+        kw["qp_i"], kw["qp_p"] = rnd.randint(10, 44), rnd.randint(10, 44)
+        seqs = [synth_frames(w, h, nfr, seed=fseed + 17 * s) for s in range(S)]
+        ogs = [O.OracleEncoder(O.default_config(w, h, **kw)) for _ in range(S)]
+        gg = GpuEncoder(O.default_config(w, h, streams=S, **kw))
+        n = ogs[0].n
+        nprng = np.random.default_rng(fseed)
+        keep = []
+        for i in range(nfr):
+            st = 2 if i == 0 else 0
+            mode = rnd.choice(["shared", "stream", "offsets", "both"])
+            qps = [rnd.randint(8, 46) for _ in range(S)] if mode in ("stream", "both") else None
+            off = nprng.integers(-1500, 1500, (S, n)).astype(np.int16) if mode in ("offsets", "both") else None
+            arr = None if qps is None else np.array(qps, np.int8)
+            lib.check(lib.x264gpu_encoder_set_stream_qps(gg.h, None if arr is None else arr.ctypes.data), "set_stream_qps")
+            d_off = None if off is None else torch.from_numpy(off.copy()).cuda()
+            keep.append(d_off)
+            lib.check(lib.x264gpu_encoder_set_mb_qp_offsets(gg.h, None if d_off is None else d_off.data_ptr()), "set_mb_qp_offsets")
+            g_mb, g_lv = gg.encode([seqs[s][i] for s in range(S)], st)
+            for s in range(S):
+                q = qps[s] if qps else (kw["qp_i"] if st == 2 else kw["qp_p"])
+                ogs[s].set_qp(q, q)
+                ogs[s].set_mb_qp_offsets(None if off is None else off[s])
+                o_mb, o_lv = ogs[s].encode(seqs[s][i], st)
+                tag = f"seed {seed} case {it}: {w}x{h} S={S} {kw} frame {i} stream {s} mode {mode}"
+                assert np.array_equal(g_mb[s].view(np.uint8), o_mb.view(np.uint8)), tag + " records"
+                assert np.array_equal(g_lv[s], o_lv), tag + " levels"
+                assert np.array_equal(gg.recon(s), ogs[s].recon()), tag + " reconstruction"
+        for o in ogs:
+            o.close()
+        gg.close()
