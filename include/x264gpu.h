@@ -172,6 +172,8 @@ typedef struct x264gpu_config {
                                * chroma source samples.  Restated in Q8 fixed point (table include/x264gpu_aq_lut.inc) so that host checker and device
                                * agree to the bit.  x264 switches AQ off under constant QP; so does the host encoder. */
     int aq_strength_q8;       /* --aq-strength * 1.0397 * 256, rounded (x264 default 1.0 -> 266) */
+    int fast_pskip;           /* --no-fast-pskip clears it (x264 default on): P_Skip probed inside the analysis (x264_macroblock_probe_pskip) */
+    int mv_range;             /* --mvrange in luma samples, both directions; 0 = 512.  x264 takes it from the level (x264_levels[].mv_range) */
 } x264gpu_config;
 
 int  x264gpu_encoder_create(x264gpu_encoder **enc, const x264gpu_config *cfg);

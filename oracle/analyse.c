@@ -1,0 +1,1369 @@
+/* oracle/analyse.c — one macroblock of a slice: analysis and encode in x264's own structure (TEST INFRASTRUCTURE ONLY; see x264o.h).
+ *
+ * Restates, for I and P slices without RD (subme <= 5), the per-macroblock path behind x264_encoder_encode() (reference call site
+ * codec.c:1693): [x264-upstream] encoder/analyse.c x264_macroblock_analyse (x264_mb_analyse_init, _inter_p16x16, _inter_p8x8,
+ * _inter_p8x8_mixed_ref, _inter_p16x8, _inter_p8x16, _intra, _intra_chroma, _transform), encoder/me.c x264_me_search_ref /
+ * refine_subpel / x264_me_refine_qpel, common/mvpred.c x264_mb_predict_mv*, encoder/macroblock.c x264_macroblock_encode,
+ * x264_macroblock_probe_pskip, x264_mb_encode_i16x16 / _i4x4 / _i8x8 / _chroma.  libx264 is not in /root/reference: written from
+ * the published algorithm, "parity unpinned" (x264o.h).
+ *
+ * Everything a macroblock reads comes from macroblocks BEFORE it in raster order of the same slice — motion vector predictors and
+ * search candidates from the coded neighbours, intra prediction from their reconstruction, the fast-intra heuristic from the count
+ * of intra macroblocks so far — so the loop is raster-serial, as x264's is.
+ */
+#include "encoder_priv.h"
+#include <stdlib.h>
+#include <string.h>
+
+enum { D_16x16 = 0, D_16x8 = 1, D_8x16 = 2, D_8x8 = 3 };
+
+static const uint8_t blk_x[16] = { 0, 1, 0, 1, 2, 3, 2, 3, 0, 1, 0, 1, 2, 3, 2, 3 };
+static const uint8_t blk_y[16] = { 0, 0, 1, 1, 0, 0, 1, 1, 2, 2, 3, 3, 2, 2, 3, 3 };
+static const uint8_t idx_of[4][4] = { { 0, 1, 4, 5 }, { 2, 3, 6, 7 }, { 8, 9, 12, 13 }, { 10, 11, 14, 15 } };   /* [by][bx] */
+
+typedef struct {          /* x264_me_t */
+    int w, h, ox, oy;     /* block inside the macroblock */
+    int ref, ref_cost;
+    int mvp[2], mv[2];
+    int cost, cost_mv;
+} me_t;
+
+typedef struct { int ref; int mv[2]; } nb_t;      /* ref: -2 unavailable, -1 intra, >= 0 reference index */
+
+typedef struct {          /* x264_mb_analysis_t + the parts of h->mb the analysis uses */
+    x264o_encoder *e;
+    int mbx, mby, mi;
+    int qp, qpc, lambda;
+    const uint16_t *cost_mv;
+    int mv_min[2], mv_max[2], smin[2], smax[2], fmin[2], fmax[2];
+    int nref, subme, satd;                      /* satd: mbcmp is SATD (subme > 1), else SAD */
+    int chroma_me;
+    int type_left, type_top, type_tl, type_tr;  /* neighbour macroblock types, -1 = unavailable */
+    int partition;                              /* h->mb.i_partition: selects the directional predictor rules */
+    int cur_valid; nb_t cur8[4];                /* motion of this macroblock's 8x8 blocks decided so far (h->mb.cache) */
+    int pskip_mv[2];
+    int b_fast_intra, b_try_skip, b_early_terminate;
+    me_t me16, me8[4], me16x8[2], me8x16[2];
+    int mvc[X264O_MAX_REFS][5][2];              /* a->l0.mvc[ref][0] = 16x16 vector, [1..4] = 8x8 vectors */
+    int cost8x8, cost16x8, cost8x16;
+    int satd8x8[4], cost_est16x8_1, cost_est8x16_1;
+    int satd_i16, satd_i8, satd_i4, satd_chroma;
+    int pred16, pred8[4], pred4[16], predc;
+} actx;
+
+/* ---------------------------------------------------------------------------------------------------------------------------
+ * lambda tables (x264_lambda_tab / x264_lambda2_tab: round(2^(qp/6-2)), round(0.9 * 2^((qp-12)/3) * 256)) */
+static const uint8_t lambda_tab[52] = { 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 2, 2, 2, 2, 3, 3, 3, 4, 4, 4, 5, 6, 6, 7, 8, 9, 10, 11, 13, 14,
+                                        16, 18, 20, 23, 25, 29, 32, 36, 40, 45, 51, 57, 64, 72, 81, 91 };
+static const int lambda2_tab[52] = { 14, 18, 22, 28, 36, 45, 57, 72, 91, 115, 145, 182, 230, 290, 365, 460, 580, 731, 921, 1160, 1462, 1843, 2322, 2926,
+                                     3686, 4644, 5852, 7373, 9289, 11703, 14745, 18578, 23407, 29491, 37156, 46814, 58982, 74313, 93628, 117964,
+                                     148626, 187257, 235929, 297252, 374514, 471859, 594505, 749029, 943718, 1189010, 1498059, 1887436 };
+int x264o_lambda(int qp) { return lambda_tab[clampi(qp, 0, 51)]; }
+int x264o_lambda2(int qp) { return lambda2_tab[clampi(qp, 0, 51)]; }
+
+static int ref_cost(const actx *a, int r)       /* REF_COST(0, r): lambda * bs_size_te(nref - 1, r) */
+{
+    return a->nref <= 1 ? 0 : a->lambda * (a->nref == 2 ? 1 : bs_size_ue(r));
+}
+
+static int mbcmp(const actx *a, const pixel *p, int sp, const pixel *q, int sq, int w, int h)
+{
+    return a->satd ? x264o_satd(p, sp, q, sq, w, h) : x264o_sad(p, sp, q, sq, w, h);
+}
+
+/* ---------------------------------------------------------------------------------------------------------------------------
+ * motion vector prediction (common/mvpred.c) on an 8x8-granular motion cache (the smallest partition here is 8x8) */
+static int is_intra_type(int t) { return t >= 0 && t <= 3; }
+
+static nb_t nb8(const actx *a, int gx, int gy)
+{
+    nb_t n = { -2, { 0, 0 } };
+    const x264o_encoder *e = a->e;
+    if (gx < 0 || gy < 0 || gx >= 2 * e->mbw || gy >= 2 * e->mbh) return n;
+    const int i = (gy >> 1) * e->mbw + (gx >> 1), k = (gy & 1) * 2 + (gx & 1);
+    if (i == a->mi) { if (a->cur_valid >> k & 1) return a->cur8[k]; return n; }
+    if (i > a->mi) return n;
+    const x264gpu_mb *m = &e->mbs[i];
+    if (is_intra_type(m->type)) { n.ref = -1; return n; }
+    n.ref = m->ref[k]; n.mv[0] = m->mv[k][0]; n.mv[1] = m->mv[k][1];
+    return n;
+}
+
+static void median_mv(int mvp[2], const nb_t *A, const nb_t *B, const nb_t *C)
+{
+    mvp[0] = median3(A->mv[0], B->mv[0], C->mv[0]);
+    mvp[1] = median3(A->mv[1], B->mv[1], C->mv[1]);
+}
+
+/* x264_mb_predict_mv / _16x16: partition at 8x8 offset (bx8,by8), w8 blocks wide, of reference `ref` */
+static void predict_mv(const actx *a, int bx8, int by8, int w8, int ref, int mvp[2])
+{
+    const int gx = 2 * a->mbx + bx8, gy = 2 * a->mby + by8;
+    nb_t A = nb8(a, gx - 1, gy), B = nb8(a, gx, gy - 1), C = nb8(a, gx + w8, gy - 1);
+    if (C.ref == -2) C = nb8(a, gx - 1, gy - 1);
+    if (a->partition == D_16x8) {
+        if (by8 == 0) { if (B.ref == ref) { mvp[0] = B.mv[0]; mvp[1] = B.mv[1]; return; } }
+        else if (A.ref == ref) { mvp[0] = A.mv[0]; mvp[1] = A.mv[1]; return; }
+    } else if (a->partition == D_8x16) {
+        if (bx8 == 0) { if (A.ref == ref) { mvp[0] = A.mv[0]; mvp[1] = A.mv[1]; return; } }
+        else if (C.ref == ref) { mvp[0] = C.mv[0]; mvp[1] = C.mv[1]; return; }
+    }
+    const int cnt = (A.ref == ref) + (B.ref == ref) + (C.ref == ref);
+    if (cnt > 1) median_mv(mvp, &A, &B, &C);
+    else if (cnt == 1) {
+        const nb_t *s = A.ref == ref ? &A : B.ref == ref ? &B : &C;
+        mvp[0] = s->mv[0]; mvp[1] = s->mv[1];
+    } else if (B.ref == -2 && C.ref == -2 && A.ref != -2) { mvp[0] = A.mv[0]; mvp[1] = A.mv[1]; }
+    else median_mv(mvp, &A, &B, &C);
+}
+
+static void predict_mv_pskip(actx *a, int mv[2])
+{
+    const int gx = 2 * a->mbx, gy = 2 * a->mby, part = a->partition;
+    const nb_t A = nb8(a, gx - 1, gy), B = nb8(a, gx, gy - 1);
+    if (A.ref == -2 || B.ref == -2 || (A.ref == 0 && !A.mv[0] && !A.mv[1]) || (B.ref == 0 && !B.mv[0] && !B.mv[1])) { mv[0] = mv[1] = 0; return; }
+    a->partition = D_16x16;
+    predict_mv(a, 0, 0, 2, 0, mv);
+    a->partition = part;
+}
+
+/* x264_mb_predict_mv_ref16x16: search candidates of the 16x16 block in reference r */
+static int predict_mv_ref16x16(const actx *a, int r, int mvc[][2])
+{
+    const x264o_encoder *e = a->e;
+    int16_t (*mvr)[2] = r == 0 ? e->mv16[e->cur] : e->mvr[r];
+    int n = 0;
+    if (r == 0 && e->lowres_mv && e->lowres_mv[0] != 0x7fff) {          /* h->fenc->lowres_mvs[0][0]: one picture back */
+        mvc[n][0] = e->lowres_mv[2 * a->mi] * 2; mvc[n][1] = e->lowres_mv[2 * a->mi + 1] * 2; n++;
+    }
+    /* spatial: left, top, top-left, top-right 16x16 results in THIS reference; a missing neighbour reads the zero entry in front of the array */
+    const int nbi[4] = { a->type_left >= 0 ? a->mi - 1 : -1, a->type_top >= 0 ? a->mi - e->mbw : -1,
+                         a->type_tl >= 0 ? a->mi - e->mbw - 1 : -1, a->type_tr >= 0 ? a->mi - e->mbw + 1 : -1 };
+    for (int i = 0; i < 4; i++) {
+        mvc[n][0] = nbi[i] >= 0 ? mvr[nbi[i]][0] : 0; mvc[n][1] = nbi[i] >= 0 ? mvr[nbi[i]][1] : 0; n++;
+    }
+    /* temporal: the co-located macroblock of reference 0 and its right / lower neighbour, scaled by the POC distances */
+    const int s0 = ref_slot(e, 0);
+    if (e->slot_nref[s0] > 0) {
+        const int curpoc = e->poc, refpoc = e->slot_poc[ref_slot(e, r)];
+        const int delta = e->slot_poc[s0] - e->slot_ref0poc[s0];      /* l0's own distance to its reference 0 */
+        const int inv = (256 + delta / 2) / delta, scale = (curpoc - refpoc) * inv;
+        const int16_t (*l0)[2] = e->mv16[s0];
+        const int at[3] = { a->mi, a->mbx < e->mbw - 1 ? a->mi + 1 : -1, a->mby < e->mbh - 1 ? a->mi + e->mbw : -1 };
+        for (int i = 0; i < 3; i++)
+            if (at[i] >= 0) { mvc[n][0] = (l0[at[i]][0] * scale + 128) >> 8; mvc[n][1] = (l0[at[i]][1] * scale + 128) >> 8; n++; }
+    }
+    return n;
+}
+
+/* ---------------------------------------------------------------------------------------------------------------------------
+ * motion search (encoder/me.c) */
+typedef struct {
+    const actx *a; me_t *m;
+    const pixel *fenc; pixel *planes[4]; const pixel *full;
+    const uint16_t *cmx, *cmy;
+    int refslot;
+} sctx;
+
+static int cost_fpel(const sctx *s, int mx, int my)
+{
+    const x264o_encoder *e = s->a->e;
+    return x264o_sad(s->fenc, e->fs, s->full + my * e->rs + mx, e->rs, s->m->w, s->m->h) + s->cmx[mx * 4] + s->cmy[my * 4];
+}
+static void get_ref(const sctx *s, pixel *dst, int mx, int my)
+{
+    const actx *a = s->a;
+    x264o_mc_luma(dst, 16, s->planes, a->e->rs, a->mbx * 16 + s->m->ox, a->mby * 16 + s->m->oy, mx, my, s->m->w, s->m->h);
+}
+static int cost_qpel_sad(const sctx *s, int mx, int my)       /* COST_MV_HPEL / COST_MV_SAD */
+{
+    pixel pred[256];
+    get_ref(s, pred, mx, my);
+    return x264o_sad(s->fenc, s->a->e->fs, pred, 16, s->m->w, s->m->h) + s->cmx[mx] + s->cmy[my];
+}
+static int chroma_satd(const sctx *s, int mx, int my)
+{
+    const actx *a = s->a; const x264o_encoder *e = a->e; const me_t *m = s->m;
+    pixel pu[64], pv[64], fu[64], fv[64];
+    const pixel *fuv = e->fenc_uv + (size_t)(a->mby * 8 + m->oy / 2) * e->fs + a->mbx * 16 + m->ox;
+    for (int y = 0; y < m->h / 2; y++)
+        for (int x = 0; x < m->w / 2; x++) { fu[y * 8 + x] = fuv[y * e->fs + 2 * x]; fv[y * 8 + x] = fuv[y * e->fs + 2 * x + 1]; }
+    x264o_mc_chroma(pu, pv, 8, chroma_plane(e, s->refslot), e->rs, a->mbx * 8 + m->ox / 2, a->mby * 8 + m->oy / 2, mx, my, m->w / 2, m->h / 2);
+    return mbcmp(a, fu, 8, pu, 8, m->w / 2, m->h / 2) + mbcmp(a, fv, 8, pv, 8, m->w / 2, m->h / 2);
+}
+
+static const int8_t hex2[8][2] = { { -1, -2 }, { -2, 0 }, { -1, 2 }, { 1, 2 }, { 2, 0 }, { 1, -2 }, { -1, -2 }, { -2, 0 } };
+static const int8_t square1[9][2] = { { 0, 0 }, { 0, -1 }, { 0, 1 }, { -1, 0 }, { 1, 0 }, { -1, -1 }, { -1, 1 }, { 1, -1 }, { 1, 1 } };
+static const int8_t mod6m1[8] = { 5, 0, 1, 2, 3, 4, 5, 0 };
+static const uint8_t subpel_iterations[12][4] = { { 0, 0, 0, 0 }, { 1, 1, 0, 0 }, { 0, 1, 1, 0 }, { 0, 2, 1, 0 }, { 0, 2, 1, 1 }, { 0, 2, 1, 2 },
+                                                  { 0, 0, 2, 2 }, { 0, 0, 2, 2 }, { 0, 0, 4, 10 }, { 0, 0, 4, 10 }, { 0, 0, 4, 10 }, { 0, 0, 4, 10 } };
+
+static void refine_subpel(const sctx *s, int hpel_iters, int qpel_iters, int *p_halfpel_thresh, int b_refine_qpel)
+{
+    const actx *a = s->a; me_t *m = s->m;
+    const int b_chroma_me = a->chroma_me;               /* blocks here are 8x8 or larger */
+    int bmx = m->mv[0], bmy = m->mv[1], bcost = m->cost, odir = -1, bdir;
+    pixel pred[256];
+    const x264o_encoder *e = a->e;
+    if (hpel_iters) {
+        if (a->subme < 3) {     /* try the sub-pel component of the predicted vector */
+            const int mx = clampi(m->mvp[0], a->smin[0] + 2, a->smax[0] - 2), my = clampi(m->mvp[1], a->smin[1] + 2, a->smax[1] - 2);
+            if ((mx - bmx) | (my - bmy)) { const int c = cost_qpel_sad(s, mx, my); if (c < bcost) { bcost = c; bmx = mx; bmy = my; } }
+        }
+        static const int8_t dia[4][2] = { { 0, -2 }, { 0, 2 }, { -2, 0 }, { 2, 0 } };
+        for (int i = hpel_iters; i > 0; i--) {
+            const int omx = bmx, omy = bmy;
+            int best = -1;
+            for (int k = 0; k < 4; k++) {
+                const int c = cost_qpel_sad(s, omx + dia[k][0], omy + dia[k][1]);
+                if (c < bcost) { bcost = c; best = k; }
+            }
+            if (best < 0) break;
+            bmx = omx + dia[best][0]; bmy = omy + dia[best][1];
+        }
+    }
+#define COST_MV_SATD(mx, my, dir) \
+    if (b_refine_qpel || ((dir) ^ 1) != odir) { \
+        get_ref(s, pred, mx, my); \
+        int cost_ = mbcmp(a, s->fenc, e->fs, pred, 16, m->w, m->h) + s->cmx[mx] + s->cmy[my]; \
+        if (b_chroma_me && cost_ < bcost) cost_ += chroma_satd(s, mx, my); \
+        if (cost_ < bcost) { bcost = cost_; bmx = mx; bmy = my; bdir = dir; } \
+    }
+    if (!b_refine_qpel && (a->satd || b_chroma_me)) {
+        bcost = COST_MAX;
+        COST_MV_SATD(bmx, bmy, -1);
+    }
+    /* early termination when examining several reference frames */
+    if (p_halfpel_thresh) {
+        if ((bcost * 7) >> 3 > *p_halfpel_thresh) { m->cost = bcost; m->mv[0] = bmx; m->mv[1] = bmy; return; }
+        else if (bcost < *p_halfpel_thresh) *p_halfpel_thresh = bcost;
+    }
+    if (a->subme != 1) {
+        bdir = -1;
+        for (int i = qpel_iters; i > 0; i--) {
+            if (bmy <= a->smin[1] || bmy >= a->smax[1] || bmx <= a->smin[0] || bmx >= a->smax[0]) break;
+            odir = bdir;
+            const int omx = bmx, omy = bmy;
+            COST_MV_SATD(omx, omy - 1, 0);
+            COST_MV_SATD(omx, omy + 1, 1);
+            COST_MV_SATD(omx - 1, omy, 2);
+            COST_MV_SATD(omx + 1, omy, 3);
+            if (bmx == omx && bmy == omy) break;
+        }
+    } else if (bmy > a->smin[1] && bmy < a->smax[1] && bmx > a->smin[0] && bmx < a->smax[0]) {
+        /* subme 1: one quarter-pel step on SAD */
+        static const int8_t qd[4][2] = { { 0, -1 }, { 0, 1 }, { -1, 0 }, { 1, 0 } };
+        const int omx = bmx, omy = bmy;
+        for (int k = 0; k < 4; k++) {
+            const int c = cost_qpel_sad(s, omx + qd[k][0], omy + qd[k][1]);
+            if (c < bcost) { bcost = c; bmx = omx + qd[k][0]; bmy = omy + qd[k][1]; }
+        }
+    }
+#undef COST_MV_SATD
+    m->cost = bcost; m->mv[0] = bmx; m->mv[1] = bmy;
+    m->cost_mv = s->cmx[bmx] + s->cmy[bmy];
+}
+
+static void sctx_init(sctx *s, const actx *a, me_t *m)
+{
+    const x264o_encoder *e = a->e;
+    s->a = a; s->m = m;
+    s->fenc = e->fenc_y + (size_t)(a->mby * 16 + m->oy) * e->fs + a->mbx * 16 + m->ox;
+    s->refslot = ref_slot(e, m->ref);
+    for (int k = 0; k < 4; k++) s->planes[k] = luma_plane(e, s->refslot, k);
+    s->full = s->planes[0] + (size_t)(a->mby * 16 + m->oy) * e->rs + a->mbx * 16 + m->ox;
+    s->cmx = a->cost_mv - m->mvp[0]; s->cmy = a->cost_mv - m->mvp[1];
+}
+
+/* x264_me_search_ref: m->{w,h,ox,oy,ref,mvp} set by the caller */
+static void me_search_ref(const actx *a, me_t *m, int (*mvc)[2], int i_mvc, int *p_halfpel_thresh)
+{
+    const x264o_encoder *e = a->e;
+    sctx S, *s = &S;
+    sctx_init(s, a, m);
+    int i_me_range = e->cfg.me_range;
+    int bmx, bmy, bcost = COST_MAX, bpred_cost = COST_MAX, bpred_mx = 0, bpred_my = 0, pmx, pmy, pmv_nonzero, pmv_is_bpred_fullpel = 0;
+    const int *fmin = a->fmin, *fmax = a->fmax;
+    int cand[16][2];
+#define COST_MV(mx, my) do { const int c_ = cost_fpel(s, mx, my); if (c_ < bcost) { bcost = c_; bmx = (mx); bmy = (my); } } while (0)
+#define CHECK_MVRANGE(mx, my) ((mx) >= fmin[0] && (mx) <= fmax[0] && (my) >= fmin[1] && (my) <= fmax[1])
+    if (a->subme >= 3) {
+        /* the predictor and the candidates at sub-pel precision (SAD of the interpolated block) */
+        bpred_mx = clampi(m->mvp[0], fmin[0] * 4, fmax[0] * 4); bpred_my = clampi(m->mvp[1], fmin[1] * 4, fmax[1] * 4);
+        const int pmvx = bpred_mx, pmvy = bpred_my;
+        pmv_nonzero = (pmvx | pmvy) != 0;
+        pmx = (pmvx + 2) >> 2; pmy = (pmvy + 2) >> 2;
+        bpred_cost = cost_qpel_sad(s, bpred_mx, bpred_my);
+        const int pmv_cost = bpred_cost;
+        if (i_mvc > 0) {
+            /* x264_predictor_clip: drop candidates equal to zero or to pmv (before clipping), clip the rest */
+            int n = 0;
+            for (int i = 0; i < i_mvc; i++) {
+                const int mx = mvc[i][0], my = mvc[i][1];
+                if (!(mx | my) || (mx == pmvx && my == pmvy)) continue;
+                cand[n][0] = clampi(mx, fmin[0] * 4, fmax[0] * 4); cand[n][1] = clampi(my, fmin[1] * 4, fmax[1] * 4); n++;
+            }
+            for (int i = 0; i < n; i++) {            /* first strictly better candidate in order wins */
+                const int c = cost_qpel_sad(s, cand[i][0], cand[i][1]);
+                if (c < bpred_cost) { bpred_cost = c; bpred_mx = cand[i][0]; bpred_my = cand[i][1]; }
+            }
+        }
+        /* back to full-pel: the search starts at the rounded best predictor */
+        bmx = (bpred_mx + 2) >> 2; bmy = (bpred_my + 2) >> 2;
+        if ((bpred_mx & 3) | (bpred_my & 3)) { bcost = COST_MAX; COST_MV(bmx, bmy); }
+        else bcost = bpred_cost;
+        if (pmv_nonzero) { if (bmx | bmy) COST_MV(0, 0); }
+        else if (pmv_cost < bcost) { bcost = pmv_cost; bmx = 0; bmy = 0; }
+    } else {
+        /* full-pel predictor, costed without its vector bits */
+        bmx = pmx = clampi((m->mvp[0] + 2) >> 2, fmin[0], fmax[0]); bmy = pmy = clampi((m->mvp[1] + 2) >> 2, fmin[1], fmax[1]);
+        pmv_nonzero = (pmx | pmy) != 0;
+        bcost = x264o_sad(s->fenc, e->fs, s->full + bmy * e->rs + bmx, e->rs, m->w, m->h);
+        if (i_mvc > 0) {
+            /* x264_predictor_roundclip: round to full-pel, clip, drop zero and pmv */
+            int n = 0;
+            for (int i = 0; i < i_mvc; i++) {
+                const int mx = clampi((mvc[i][0] + 2) >> 2, fmin[0], fmax[0]), my = clampi((mvc[i][1] + 2) >> 2, fmin[1], fmax[1]);
+                if (!(mx | my) || (mx == pmx && my == pmy)) continue;
+                cand[n][0] = mx; cand[n][1] = my; n++;
+            }
+            for (int i = 0; i < n; i++) {
+                const int c = cost_fpel(s, cand[i][0], cand[i][1]);
+                if (c < bcost) { bcost = c; bmx = cand[i][0]; bmy = cand[i][1]; }
+            }
+        }
+        if (pmv_nonzero) COST_MV(0, 0);
+        pmv_is_bpred_fullpel = 1;
+    }
+
+    switch (e->cfg.me_method) {
+    case 0: {   /* X264_ME_DIA: radius-1 diamond, (0,-1) (0,1) (-1,0) (1,0); the centre wins ties */
+        static const int8_t dia1[4][2] = { { 0, -1 }, { 0, 1 }, { -1, 0 }, { 1, 0 } };
+        int i = i_me_range;
+        do {
+            int best = -1;
+            const int omx = bmx, omy = bmy;
+            for (int k = 0; k < 4; k++) { const int c = cost_fpel(s, omx + dia1[k][0], omy + dia1[k][1]); if (c < bcost) { bcost = c; best = k; } }
+            if (best < 0) break;
+            bmx = omx + dia1[best][0]; bmy = omy + dia1[best][1];
+        } while (--i && CHECK_MVRANGE(bmx, bmy));
+        break;
+    }
+    case 3: {   /* X264_ME_ESA: every position of the clipped +-merange rectangle (width rounded up to 4), raster order */
+        const int min_x = bmx - i_me_range > fmin[0] ? bmx - i_me_range : fmin[0], min_y = bmy - i_me_range > fmin[1] ? bmy - i_me_range : fmin[1];
+        const int max_x = bmx + i_me_range < fmax[0] ? bmx + i_me_range : fmax[0], max_y = bmy + i_me_range < fmax[1] ? bmy + i_me_range : fmax[1];
+        const int width = (max_x - min_x + 3) & ~3;
+        for (int my = min_y; my <= max_y; my++)
+            for (int mx = min_x; mx < min_x + width; mx++) COST_MV(mx, my);
+        break;
+    }
+    case 2: {   /* X264_ME_UMH */
+        static const uint8_t range_mul[4][4] = { { 3, 3, 4, 4 }, { 3, 4, 4, 4 }, { 4, 4, 4, 5 }, { 4, 4, 5, 6 } };
+        static const int8_t hex4[16][2] = { { 0, -4 }, { 0, 4 }, { -2, -3 }, { 2, -3 }, { -4, -2 }, { 4, -2 }, { -4, -1 }, { 4, -1 },
+                                            { -4, 0 }, { 4, 0 }, { -4, 1 }, { 4, 1 }, { -4, 2 }, { 4, 2 }, { -2, 3 }, { 2, 3 } };
+        const int shift = (m->w == 16 ? 0 : 1) + (m->h == 16 ? 0 : 1);          /* pixel_size_shift */
+        int omx, omy, cross_start = 1, done = 0;
+#define COST_MV_X4(x0, y0, x1, y1, x2, y2, x3, y3) do { COST_MV(omx + (x0), omy + (y0)); COST_MV(omx + (x1), omy + (y1)); \
+                                                        COST_MV(omx + (x2), omy + (y2)); COST_MV(omx + (x3), omy + (y3)); } while (0)
+#define DIA1_ITER(mx, my) do { omx = (mx); omy = (my); COST_MV_X4(0, -1, 0, 1, -1, 0, 1, 0); } while (0)
+#define CROSS(start, x_max, y_max) do { \
+            for (int i_ = (start); i_ < (x_max); i_ += 2) { \
+                if (omx + i_ <= fmax[0]) COST_MV(omx + i_, omy); \
+                if (omx - i_ >= fmin[0]) COST_MV(omx - i_, omy); } \
+            for (int i_ = (start); i_ < (y_max); i_ += 2) { \
+                if (omy + i_ <= fmax[1]) COST_MV(omx, omy + i_); \
+                if (omy - i_ >= fmin[1]) COST_MV(omx, omy - i_); } } while (0)
+#define SAD_THRESH(v) (bcost < ((v) >> shift))
+        const int ucost1 = bcost;
+        DIA1_ITER(pmx, pmy);
+        if (pmx | pmy) DIA1_ITER(0, 0);
+        const int ucost2 = bcost;
+        if ((bmx | bmy) && ((bmx - pmx) | (bmy - pmy))) DIA1_ITER(bmx, bmy);
+        if (bcost == ucost2) cross_start = 3;
+        omx = bmx; omy = bmy;
+        if (bcost == ucost2 && SAD_THRESH(2000)) {
+            COST_MV_X4(0, -2, -1, -1, 1, -1, -2, 0);
+            COST_MV_X4(2, 0, -1, 1, 1, 1, 0, 2);
+            if (bcost == ucost1 && SAD_THRESH(500)) done = 1;
+            else if (bcost == ucost2) {
+                const int r1 = (i_me_range >> 1) | 1;
+                CROSS(3, r1, r1);
+                COST_MV_X4(-1, -2, 1, -2, -2, -1, 2, -1);
+                COST_MV_X4(-2, 1, 2, 1, -1, 2, 1, 2);
+                if (bcost == ucost2) done = 1;
+                cross_start = r1 + 2;
+            }
+        }
+        if (done) goto fullpel_done;
+        if (i_mvc) {        /* adaptive search range: agreement of the predictors x SAD level */
+            int mvd, denom = 1;
+            if (i_mvc == 1) {
+                if (m->w == 16 && m->h == 16) mvd = 25;
+                else mvd = abs(m->mvp[0] - mvc[0][0]) + abs(m->mvp[1] - mvc[0][1]);
+            } else {
+                denom = i_mvc - 1; mvd = 0;
+                if (!(m->w == 16 && m->h == 16)) { mvd = abs(m->mvp[0] - mvc[0][0]) + abs(m->mvp[1] - mvc[0][1]); denom++; }
+                for (int i = 0; i < i_mvc - 1; i++) mvd += abs(mvc[i][0] - mvc[i + 1][0]) + abs(mvc[i][1] - mvc[i + 1][1]);      /* x264_predictor_difference */
+            }
+            const int sad_ctx = SAD_THRESH(1000) ? 0 : SAD_THRESH(2000) ? 1 : SAD_THRESH(4000) ? 2 : 3;
+            const int mvd_ctx = mvd < 10 * denom ? 0 : mvd < 20 * denom ? 1 : mvd < 40 * denom ? 2 : 3;
+            i_me_range = i_me_range * range_mul[mvd_ctx][sad_ctx] >> 2;
+        }
+        /* x264 keeps the cross centred where the small diamonds left it */
+        CROSS(cross_start, i_me_range, i_me_range >> 1);
+        COST_MV_X4(-2, -2, -2, 2, 2, -2, 2, 2);
+        omx = bmx; omy = bmy;
+        {
+            int i = 1;
+            do {
+                for (int j = 0; j < 16; j++) {
+                    const int mx = omx + hex4[j][0] * i, my = omy + hex4[j][1] * i;
+                    if (CHECK_MVRANGE(mx, my)) COST_MV(mx, my);
+                }
+            } while (++i <= i_me_range >> 2);
+        }
+        if (!CHECK_MVRANGE(bmx, bmy)) goto fullpel_done;
+#undef SAD_THRESH
+#undef CROSS
+#undef DIA1_ITER
+#undef COST_MV_X4
+    }   /* fall through: me_hex2 */
+    /* FALLTHROUGH */
+    default: {  /* X264_ME_HEX: hexagon (radius 2), then 3x3 square refine; first-best wins ties, the centre wins over all */
+        int key = bcost << 3;
+        for (int k = 1; k <= 6; k++) {
+            const int c = (cost_fpel(s, bmx + hex2[k][0], bmy + hex2[k][1]) << 3) + k + 1;
+            if (c < key) key = c;
+        }
+        if (key & 7) {
+            int dir = (key & 7) - 2;
+            bmx += hex2[dir + 1][0]; bmy += hex2[dir + 1][1];
+            for (int i = (i_me_range >> 1) - 1; i > 0 && CHECK_MVRANGE(bmx, bmy); i--) {
+                key &= ~7;
+                for (int k = 0; k < 3; k++) {
+                    const int c = (cost_fpel(s, bmx + hex2[dir + k][0], bmy + hex2[dir + k][1]) << 3) + k + 1;
+                    if (c < key) key = c;
+                }
+                if (!(key & 7)) break;
+                dir += (key & 7) - 2;
+                dir = mod6m1[dir + 1];
+                bmx += hex2[dir + 1][0]; bmy += hex2[dir + 1][1];
+            }
+        }
+        bcost = key >> 3;
+        int bdir = 0;
+        for (int k = 1; k <= 8; k++) {
+            const int c = cost_fpel(s, bmx + square1[k][0], bmy + square1[k][1]);
+            if (c < bcost) { bcost = c; bdir = k; }
+        }
+        bmx += square1[bdir][0]; bmy += square1[bdir][1];
+        break;
+    }
+    }
+fullpel_done:
+#undef COST_MV
+#undef CHECK_MVRANGE
+    /* -> quarter-pel vector */
+    if (a->subme < 3) {
+        m->cost_mv = s->cmx[bmx * 4] + s->cmy[bmy * 4];
+        m->cost = bcost;
+        if (pmv_is_bpred_fullpel && bmx == pmx && bmy == pmy) m->cost += m->cost_mv;        /* the real cost */
+        m->mv[0] = bmx * 4; m->mv[1] = bmy * 4;
+    } else {
+        if (bpred_cost < bcost) { m->mv[0] = bpred_mx; m->mv[1] = bpred_my; m->cost = bpred_cost; }
+        else { m->mv[0] = bmx * 4; m->mv[1] = bmy * 4; m->cost = bcost; }
+    }
+    m->cost_mv = s->cmx[m->mv[0]] + s->cmy[m->mv[1]];
+    if (a->subme >= 2) refine_subpel(s, subpel_iterations[a->subme][2], subpel_iterations[a->subme][3], p_halfpel_thresh, 0);
+}
+
+/* x264_me_refine_qpel: the extra sub-pel steps of the winning partition below subme 6 */
+static void me_refine_qpel(const actx *a, me_t *m)
+{
+    sctx S;
+    sctx_init(&S, a, m);
+    m->cost -= m->ref_cost;                   /* blocks of 8x8 and larger */
+    refine_subpel(&S, subpel_iterations[a->subme][0], subpel_iterations[a->subme][1], NULL, 1);
+}
+
+/* ---------------------------------------------------------------------------------------------------------------------------
+ * residual coding (encoder/macroblock.c) */
+static void scan4(int16_t *dst, const dctcoef *src) { for (int k = 0; k < 16; k++) dst[k] = src[x264o_zigzag4[k]]; }
+
+/* inter luma, 4x4 transform: prediction in rec; returns through mb: nnz, cbp_luma; levels in lv */
+static void encode_luma_inter(x264o_encoder *e, const pixel *fenc, pixel *rec, int qp, x264gpu_mb *mb, int16_t *lv)
+{
+    dctcoef d[16][16];
+    int nz[16], score8[4] = { 0, 0, 0, 0 };
+    const uint16_t *mf = e->qt.quant4_mf[X264O_CQM_4PY][qp], *bias = e->qt.quant4_bias[X264O_CQM_4PY][qp];
+    for (int b = 0; b < 16; b++) {
+        x264o_sub4x4_dct(d[b], fenc + blk_y[b] * 4 * e->fs + blk_x[b] * 4, e->fs, rec + blk_y[b] * 4 * e->rs + blk_x[b] * 4, e->rs);
+        nz[b] = x264o_quant_4x4(d[b], mf, bias);
+        scan4(lv + b * 16, d[b]);
+        if (nz[b] && e->cfg.dct_decimate) score8[b >> 2] += x264o_decimate_score(lv + b * 16, 16);
+    }
+    int mbscore = 0;
+    for (int i8 = 0; i8 < 4; i8++) {
+        int any = nz[i8 * 4] | nz[i8 * 4 + 1] | nz[i8 * 4 + 2] | nz[i8 * 4 + 3];
+        if (any) mbscore += e->cfg.dct_decimate ? score8[i8] : 6;      /* every coded 8x8 counts towards the macroblock score, kept or not */
+        if (any && e->cfg.dct_decimate && score8[i8] < 4) any = 0;
+        if (!any) for (int k = 0; k < 4; k++) nz[i8 * 4 + k] = 0;
+    }
+    if (mbscore < 6) for (int b = 0; b < 16; b++) nz[b] = 0;
+    for (int b = 0; b < 16; b++) {
+        if (!nz[b]) { memset(lv + b * 16, 0, 32); continue; }
+        x264o_dequant_4x4(d[b], e->qt.dequant4_mf, qp);
+        x264o_add4x4_idct(rec + blk_y[b] * 4 * e->rs + blk_x[b] * 4, e->rs, d[b]);
+        mb->nnz |= 1u << b;
+        mb->cbp_luma |= 1 << (b >> 2);
+    }
+}
+
+/* inter luma, 8x8 transform; levels leave in the CAVLC-interleaved 4x4 form (zigzag_interleave_8x8_cavlc) */
+static void encode_luma_inter8(x264o_encoder *e, const pixel *fenc, pixel *rec, int qp, x264gpu_mb *mb, int16_t *lv)
+{
+    dctcoef d[4][64];
+    int16_t scan[4][64];
+    int keep[4], mbscore = 0;
+    const uint16_t *mf = e->qt.quant8_mf[X264O_CQM_8PY][qp], *bias = e->qt.quant8_bias[X264O_CQM_8PY][qp];
+    for (int i8 = 0; i8 < 4; i8++) {
+        x264o_sub8x8_dct8(d[i8], fenc + (i8 >> 1) * 8 * e->fs + (i8 & 1) * 8, e->fs, rec + (i8 >> 1) * 8 * e->rs + (i8 & 1) * 8, e->rs);
+        keep[i8] = x264o_quant_8x8(d[i8], mf, bias);
+        for (int k = 0; k < 64; k++) scan[i8][k] = d[i8][x264o_zigzag8[k]];
+        if (keep[i8] && e->cfg.dct_decimate) {
+            const int sc = x264o_decimate_score(scan[i8], 64);
+            mbscore += sc;
+            if (sc < 4) keep[i8] = 0;
+        }
+    }
+    if (e->cfg.dct_decimate && mbscore < 6) keep[0] = keep[1] = keep[2] = keep[3] = 0;
+    for (int i8 = 0; i8 < 4; i8++) {
+        if (!keep[i8]) continue;
+        for (int k = 0; k < 64; k++) {
+            const int16_t v = scan[i8][k];
+            lv[(i8 * 4 + (k & 3)) * 16 + (k >> 2)] = v;
+            if (v) mb->nnz |= 1u << (i8 * 4 + (k & 3));
+        }
+        x264o_dequant_8x8(d[i8], e->qt.dequant8_mf, qp);
+        x264o_add8x8_idct8(rec + (i8 >> 1) * 8 * e->rs + (i8 & 1) * 8, e->rs, d[i8]);
+        mb->cbp_luma |= 1 << i8;
+    }
+}
+
+/* x264_mb_encode_chroma: prediction already in the NV12 reconstruction (rec_uv points at U of the 8x8) */
+static void encode_chroma(x264o_encoder *e, const pixel *fenc_uv, pixel *rec_uv, int qpc, int inter, x264gpu_mb *mb, int16_t *lv)
+{
+    const int list = inter ? X264O_CQM_4PC : X264O_CQM_4IC, b_decimate = inter && e->cfg.dct_decimate;
+    const uint16_t *mf = e->qt.quant4_mf[list][qpc], *bias = e->qt.quant4_bias[list][qpc];
+    const int dmf = e->qt.dequant4_mf[qpc % 6][0] << (qpc / 6);
+    pixel f[2][64], p[2][64];
+    int any_ac = 0, any_dc = 0;
+    for (int c = 0; c < 2; c++)
+        for (int y = 0; y < 8; y++)
+            for (int x = 0; x < 8; x++) { f[c][y * 8 + x] = fenc_uv[y * e->fs + 2 * x + c]; p[c][y * 8 + x] = rec_uv[y * e->rs + 2 * x + c]; }
+    memset(lv + X264GPU_LV_CHROMA_DC, 0, (8 + 128) * sizeof(int16_t));
+    /* early termination on the variance of the chroma residual (not at low quantisers): DC only, or nothing */
+    if (b_decimate && qpc >= 18) {
+        const int thresh = (x264o_lambda2(qpc) + 32) >> 6;
+        int ssd[2], score = 0;
+        for (int c = 0; c < 2; c++) {
+            int sum = 0, sqr = 0;
+            for (int i = 0; i < 64; i++) { const int dd = f[c][i] - p[c][i]; sum += dd; sqr += dd * dd; }
+            ssd[c] = sqr;
+            score += sqr - (int)(((int64_t)sum * sum) >> 6);
+        }
+        if (score < thresh * 4) {
+            for (int c = 0; c < 2; c++) {
+                if (ssd[c] <= thresh) continue;
+                dctcoef dc[4];
+                for (int i = 0; i < 4; i++) {           /* sub8x8_dct_dc: sums of the four 4x4 residual blocks, then the 2x2 Hadamard */
+                    int sm = 0;
+                    for (int y = 0; y < 4; y++) for (int x = 0; x < 4; x++) { const int o = ((i >> 1) * 4 + y) * 8 + (i & 1) * 4 + x; sm += f[c][o] - p[c][o]; }
+                    dc[i] = (dctcoef)sm;
+                }
+                x264o_dct2x2dc(dc);
+                if (!x264o_quant_2x2_dc(dc, mf[0] >> 1, bias[0] << 1)) continue;
+                if (!x264o_optimize_chroma_2x2_dc(dc, dmf)) continue;
+                for (int i = 0; i < 4; i++) lv[X264GPU_LV_CHROMA_DC + c * 4 + i] = dc[i];
+                dctcoef dq[4];
+                x264o_dequant_2x2_dc(dq, dc, e->qt.dequant4_mf, qpc);
+                for (int i = 0; i < 4; i++) x264o_add4x4_idct_dc(p[c] + (i >> 1) * 32 + (i & 1) * 4, 8, dq[i]);
+                mb->nnz |= 1u << (25 + c); any_dc = 1;
+            }
+            goto store;
+        }
+    }
+    for (int c = 0; c < 2; c++) {
+        dctcoef d[4][16], dc[4];
+        int nz[4], score = 0, nzac = 0;
+        for (int i = 0; i < 4; i++) {
+            const int o = (i >> 1) * 32 + (i & 1) * 4;
+            x264o_sub4x4_dct(d[i], f[c] + o, 8, p[c] + o, 8);
+            dc[i] = d[i][0]; d[i][0] = 0;
+            nz[i] = x264o_quant_4x4(d[i], mf, bias);
+            int16_t *l = lv + X264GPU_LV_CHROMA_AC + (c * 4 + i) * 16;
+            scan4(l, d[i]);
+            if (nz[i]) { nzac = 1; if (b_decimate) score += x264o_decimate_score(l + 1, 15); }
+        }
+        if (nzac && b_decimate && score < 7) nzac = 0;
+        x264o_dct2x2dc(dc);
+        int nzdc = x264o_quant_2x2_dc(dc, mf[0] >> 1, bias[0] << 1);
+        /* DC-only planes: x264_mb_optimize_chroma_dc trims the DC levels that do not change the reconstruction */
+        if (nzdc && !nzac && !x264o_optimize_chroma_2x2_dc(dc, dmf)) { nzdc = 0; dc[0] = dc[1] = dc[2] = dc[3] = 0; }
+        for (int i = 0; i < 4; i++) lv[X264GPU_LV_CHROMA_DC + c * 4 + i] = dc[i];
+        dctcoef dq[4] = { 0, 0, 0, 0 };
+        if (nzdc) { x264o_dequant_2x2_dc(dq, dc, e->qt.dequant4_mf, qpc); mb->nnz |= 1u << (25 + c); any_dc = 1; }
+        for (int i = 0; i < 4; i++) {
+            int16_t *l = lv + X264GPU_LV_CHROMA_AC + (c * 4 + i) * 16;
+            if (!nzac || !nz[i]) { memset(l, 0, 32); memset(d[i], 0, sizeof(d[i])); }
+            else { x264o_dequant_4x4(d[i], e->qt.dequant4_mf, qpc); mb->nnz |= 1u << (16 + c * 4 + i); any_ac = 1; }
+            d[i][0] = dq[i];
+            x264o_add4x4_idct(p[c] + (i >> 1) * 32 + (i & 1) * 4, 8, d[i]);
+        }
+    }
+store:
+    for (int c = 0; c < 2; c++)
+        for (int y = 0; y < 8; y++)
+            for (int x = 0; x < 8; x++) rec_uv[y * e->rs + 2 * x + c] = p[c][y * 8 + x];
+    mb->cbp_chroma = any_ac ? 2 : any_dc ? 1 : 0;
+}
+
+/* x264_mb_encode_i4x4 / _i8x8: prediction already in rec; returns non-zero when coefficients were coded */
+static int encode_i4x4(x264o_encoder *e, const pixel *f, pixel *r, int qp, int16_t *l)
+{
+    dctcoef d[16];
+    x264o_sub4x4_dct(d, f, e->fs, r, e->rs);
+    if (!x264o_quant_4x4(d, e->qt.quant4_mf[X264O_CQM_4IY][qp], e->qt.quant4_bias[X264O_CQM_4IY][qp])) { memset(l, 0, 32); return 0; }
+    scan4(l, d);
+    x264o_dequant_4x4(d, e->qt.dequant4_mf, qp);
+    x264o_add4x4_idct(r, e->rs, d);
+    return 1;
+}
+static int encode_i8x8(x264o_encoder *e, const pixel *f, pixel *r, int qp, int i8, int16_t *lv256, uint32_t *nnz)
+{
+    dctcoef d[64];
+    x264o_sub8x8_dct8(d, f, e->fs, r, e->rs);
+    if (!x264o_quant_8x8(d, e->qt.quant8_mf[X264O_CQM_8IY][qp], e->qt.quant8_bias[X264O_CQM_8IY][qp])) return 0;
+    for (int k = 0; k < 64; k++) {
+        const int16_t v = d[x264o_zigzag8[k]];
+        lv256[(i8 * 4 + (k & 3)) * 16 + (k >> 2)] = v;
+        if (v) *nnz |= 1u << (i8 * 4 + (k & 3));
+    }
+    x264o_dequant_8x8(d, e->qt.dequant8_mf, qp);
+    x264o_add8x8_idct8(r, e->rs, d);
+    return 1;
+}
+
+/* x264_mb_encode_i16x16: prediction of `mode` is written to rec first */
+static void encode_i16x16(x264o_encoder *e, const pixel *fenc, pixel *rec, int qp, int mode, x264gpu_mb *mb, int16_t *lv)
+{
+    pixel pred[256];
+    x264o_predict_16x16(pred, 16, rec, e->rs, mode);
+    for (int y = 0; y < 16; y++) memcpy(rec + y * e->rs, pred + y * 16, 16);
+    const uint16_t *mf = e->qt.quant4_mf[X264O_CQM_4IY][qp], *bias = e->qt.quant4_bias[X264O_CQM_4IY][qp];
+    const int b_decimate = e->slice_type != X264GPU_SLICE_I && e->cfg.dct_decimate;        /* h->mb.b_dct_decimate */
+    dctcoef d[16][16], dc[16];
+    int nz[16], any_ac = 0, score = b_decimate ? 0 : 9;
+    for (int b = 0; b < 16; b++) {
+        x264o_sub4x4_dct(d[b], fenc + blk_y[b] * 4 * e->fs + blk_x[b] * 4, e->fs, rec + blk_y[b] * 4 * e->rs + blk_x[b] * 4, e->rs);
+        dc[blk_y[b] * 4 + blk_x[b]] = d[b][0]; d[b][0] = 0;
+        nz[b] = x264o_quant_4x4(d[b], mf, bias);
+        scan4(lv + b * 16, d[b]);
+        if (nz[b]) { any_ac = 1; x264o_dequant_4x4(d[b], e->qt.dequant4_mf, qp); if (score < 6) score += x264o_decimate_score(lv + b * 16 + 1, 15); }
+    }
+    /* the 16 coded-block flags of an Intra16x16 macroblock are costly: decimate the AC part as a whole */
+    if (score < 6) any_ac = 0;
+    for (int b = 0; b < 16; b++) {
+        if (any_ac && nz[b]) mb->nnz |= 1u << b;
+        else { memset(lv + b * 16, 0, 32); memset(d[b], 0, sizeof(d[b])); }
+    }
+    mb->cbp_luma = any_ac ? 15 : 0;
+    x264o_dct4x4dc(dc);
+    const int nzdc = x264o_quant_4x4_dc(dc, mf[0] >> 1, bias[0] << 1);
+    scan4(lv + X264GPU_LV_LUMA_DC, dc);
+    if (nzdc) { mb->nnz |= 1u << 24; x264o_idct4x4dc(dc); x264o_dequant_4x4_dc(dc, e->qt.dequant4_mf, qp); }
+    for (int b = 0; b < 16; b++) {
+        d[b][0] = nzdc ? dc[blk_y[b] * 4 + blk_x[b]] : 0;
+        x264o_add4x4_idct(rec + blk_y[b] * 4 * e->rs + blk_x[b] * 4, e->rs, d[b]);
+    }
+}
+
+/* ---------------------------------------------------------------------------------------------------------------------------
+ * P_SKIP probe (x264_macroblock_probe_pskip): would the macroblock code to nothing at the skip vector? */
+static void mc_mb(x264o_encoder *e, int mbx, int mby, int bx, int by, int w, int h, int refslot, int mvx, int mvy, pixel *dy, int sy, pixel *du, pixel *dv, int sc)
+{
+    pixel *planes[4] = { luma_plane(e, refslot, 0), luma_plane(e, refslot, 1), luma_plane(e, refslot, 2), luma_plane(e, refslot, 3) };
+    x264o_mc_luma(dy + by * sy + bx, sy, planes, e->rs, mbx * 16 + bx, mby * 16 + by, mvx, mvy, w, h);
+    x264o_mc_chroma(du + (by / 2) * sc + bx / 2, dv + (by / 2) * sc + bx / 2, sc, chroma_plane(e, refslot), e->rs, mbx * 8 + bx / 2, mby * 8 + by / 2, mvx, mvy, w / 2, h / 2);
+}
+
+static int probe_pskip(const actx *a)
+{
+    x264o_encoder *e = a->e;
+    const int mvx = clampi(a->pskip_mv[0], a->mv_min[0], a->mv_max[0]), mvy = clampi(a->pskip_mv[1], a->mv_min[1], a->mv_max[1]);
+    pixel py[256], pu[64], pv[64];
+    mc_mb(e, a->mbx, a->mby, 0, 0, 16, 16, ref_slot(e, 0), mvx, mvy, py, 16, pu, pv, 8);
+    const pixel *fenc = e->fenc_y + (size_t)a->mby * 16 * e->fs + a->mbx * 16;
+    const uint16_t *mf = e->qt.quant4_mf[X264O_CQM_4PY][a->qp], *bias = e->qt.quant4_bias[X264O_CQM_4PY][a->qp];
+    int score = 0;
+    for (int b = 0; b < 16; b++) {
+        dctcoef d[16]; int16_t sc[16];
+        x264o_sub4x4_dct(d, fenc + blk_y[b] * 4 * e->fs + blk_x[b] * 4, e->fs, py + blk_y[b] * 64 + blk_x[b] * 4, 16);
+        if (!x264o_quant_4x4(d, mf, bias)) continue;
+        scan4(sc, d);
+        score += x264o_decimate_score(sc, 16);
+        if (score >= 6) return 0;
+    }
+    /* chroma: cheap SSD test first, then DC, then (rarely) the AC decimation score */
+    const int qpc = a->qpc, thresh = (x264o_lambda2(qpc) + 32) >> 6;
+    mf = e->qt.quant4_mf[X264O_CQM_4PC][qpc]; bias = e->qt.quant4_bias[X264O_CQM_4PC][qpc];
+    const pixel *fuv = e->fenc_uv + (size_t)a->mby * 8 * e->fs + a->mbx * 16;
+    for (int c = 0; c < 2; c++) {
+        pixel f[64];
+        const pixel *p = c ? pv : pu;
+        for (int y = 0; y < 8; y++) for (int x = 0; x < 8; x++) f[y * 8 + x] = fuv[y * e->fs + 2 * x + c];
+        const int ssd = x264o_ssd(p, 8, f, 8, 8, 8);
+        if (ssd < thresh) continue;
+        dctcoef dc[4];
+        for (int i = 0; i < 4; i++) {
+            int sm = 0;
+            for (int y = 0; y < 4; y++) for (int x = 0; x < 4; x++) { const int o = ((i >> 1) * 4 + y) * 8 + (i & 1) * 4 + x; sm += f[o] - p[o]; }
+            dc[i] = (dctcoef)sm;
+        }
+        x264o_dct2x2dc(dc);
+        if (x264o_quant_2x2_dc(dc, mf[0] >> 1, bias[0] << 1)) return 0;
+        if (ssd < thresh * 4) continue;
+        int cscore = 0;
+        for (int i = 0; i < 4; i++) {
+            dctcoef d[16]; int16_t sc[16];
+            const int o = (i >> 1) * 32 + (i & 1) * 4;
+            x264o_sub4x4_dct(d, f + o, 8, p + o, 8);
+            d[0] = 0;
+            if (!x264o_quant_4x4(d, mf, bias)) continue;
+            scan4(sc, d);
+            cscore += x264o_decimate_score(sc + 1, 15);
+            if (cscore >= 7) return 0;
+        }
+    }
+    return 1;
+}
+
+/* ---------------------------------------------------------------------------------------------------------------------------
+ * inter analysis (encoder/analyse.c) */
+static void cache_block(actx *a, int bx8, int by8, int w8, int h8, int ref, const int mv[2])
+{
+    for (int y = by8; y < by8 + h8; y++)
+        for (int x = bx8; x < bx8 + w8; x++) {
+            nb_t *n = &a->cur8[y * 2 + x];
+            n->ref = ref;
+            if (mv) { n->mv[0] = mv[0]; n->mv[1] = mv[1]; }
+            a->cur_valid |= 1 << (y * 2 + x);
+        }
+}
+
+/* returns 1 when the macroblock was settled as P_SKIP inside the 16x16 search */
+static int analyse_inter_p16x16(actx *a)
+{
+    x264o_encoder *e = a->e;
+    me_t m;
+    int mvc[8][2];
+    int i_halfpel_thresh = 0x7fffffff;
+    int *p_halfpel_thresh = (a->b_early_terminate && a->nref > 1) ? &i_halfpel_thresh : NULL;
+    m.w = m.h = 16; m.ox = m.oy = 0;
+    a->me16.cost = 0x7fffffff;
+    a->partition = D_16x16;
+    for (int r = 0; r < a->nref; r++) {
+        m.ref = r; m.ref_cost = ref_cost(a, r);
+        i_halfpel_thresh -= m.ref_cost;
+        a->cur_valid = 0;
+        predict_mv(a, 0, 0, 2, r, m.mvp);
+        const int i_mvc = predict_mv_ref16x16(a, r, mvc);
+        me_search_ref(a, &m, mvc, i_mvc, p_halfpel_thresh);
+        /* save the vector for predicting neighbours */
+        int16_t (*mvr)[2] = r == 0 ? e->mv16[e->cur] : e->mvr[r];
+        mvr[a->mi][0] = (int16_t)m.mv[0]; mvr[a->mi][1] = (int16_t)m.mv[1];
+        a->mvc[r][0][0] = m.mv[0]; a->mvc[r][0][1] = m.mv[1];
+        /* early termination: the skip vector is (almost) the search result and the residual would vanish */
+        if (r == 0 && a->b_try_skip && m.cost - m.cost_mv < 300 * a->lambda &&
+            abs(m.mv[0] - a->pskip_mv[0]) + abs(m.mv[1] - a->pskip_mv[1]) <= 1 && probe_pskip(a)) return 1;
+        m.cost += m.ref_cost;
+        i_halfpel_thresh += m.ref_cost;
+        if (m.cost < a->me16.cost) a->me16 = m;
+    }
+    cache_block(a, 0, 0, 2, 2, a->me16.ref, NULL);
+    return 0;
+}
+
+static void analyse_inter_p8x8_mixed_ref(actx *a)
+{
+    int i_maxref = a->nref - 1;
+    a->partition = D_8x8;
+    /* early termination: if 16x16 chose reference 0, evaluate no references older than those used by the neighbours
+     * (x264 tests the neighbour types with "> 0": unavailable and Intra4x4 neighbours both fail it) */
+    if (a->b_early_terminate && i_maxref > 0 && a->me16.ref == 0 && a->type_top > 0 && a->type_left > 0) {
+        const int gx = 2 * a->mbx, gy = 2 * a->mby;
+        const nb_t n[6] = { nb8(a, gx - 1, gy - 1), nb8(a, gx, gy - 1), nb8(a, gx + 1, gy - 1), nb8(a, gx + 2, gy - 1), nb8(a, gx - 1, gy), nb8(a, gx - 1, gy + 1) };
+        i_maxref = 0;
+        for (int i = 0; i < 6; i++) if (n[i].ref > i_maxref) i_maxref = n[i].ref;
+    }
+    for (int r = 0; r <= i_maxref; r++) {
+        const int16_t (*mvr)[2] = r == 0 ? a->e->mv16[a->e->cur] : a->e->mvr[r];
+        a->mvc[r][0][0] = mvr[a->mi][0]; a->mvc[r][0][1] = mvr[a->mi][1];
+    }
+    a->cur_valid = 0;
+    for (int i = 0; i < 4; i++) {
+        me_t *l0m = &a->me8[i], m;
+        const int x8 = i & 1, y8 = i >> 1;
+        m.w = m.h = 8; m.ox = 8 * x8; m.oy = 8 * y8;
+        l0m->cost = 0x7fffffff;
+        for (int r = 0; r <= i_maxref; r++) {
+            m.ref = r; m.ref_cost = ref_cost(a, r);
+            a->cur8[i].ref = r;             /* x264_macroblock_cache_ref before predicting (the block itself is not a neighbour) */
+            predict_mv(a, x8, y8, 1, r, m.mvp);
+            me_search_ref(a, &m, a->mvc[r], i + 1, NULL);
+            m.cost += m.ref_cost;
+            a->mvc[r][i + 1][0] = m.mv[0]; a->mvc[r][i + 1][1] = m.mv[1];
+            if (m.cost < l0m->cost) *l0m = m;
+        }
+        cache_block(a, x8, y8, 1, 1, l0m->ref, l0m->mv);
+        a->satd8x8[i] = l0m->cost - (l0m->cost_mv + l0m->ref_cost);
+        /* sub-macroblock type cost: CAVLC, or CABAC with sub-8x8 analysis (not the case here: CAVLC) */
+        l0m->cost += a->lambda * 1;
+    }
+    a->cost8x8 = a->me8[0].cost + a->me8[1].cost + a->me8[2].cost + a->me8[3].cost;
+    /* P_8x8ref0 has no reference cost (CAVLC) */
+    if (!(a->me8[0].ref | a->me8[1].ref | a->me8[2].ref | a->me8[3].ref)) a->cost8x8 -= ref_cost(a, 0) * 4;
+}
+
+static void analyse_inter_p8x8(actx *a)
+{
+    const int r = a->me16.ref;
+    const int i_ref_cost = r ? ref_cost(a, r) : 0;          /* CAVLC: reference 0 of P_8x8 costs nothing (P_8x8ref0) */
+    int i_mvc = 1;
+    a->partition = D_8x8;
+    a->mvc[r][0][0] = a->me16.mv[0]; a->mvc[r][0][1] = a->me16.mv[1];
+    a->cur_valid = 0;
+    for (int i = 0; i < 4; i++) {
+        me_t *m = &a->me8[i];
+        const int x8 = i & 1, y8 = i >> 1;
+        m->w = m->h = 8; m->ox = 8 * x8; m->oy = 8 * y8; m->ref = r; m->ref_cost = i_ref_cost;
+        predict_mv(a, x8, y8, 1, r, m->mvp);
+        me_search_ref(a, m, a->mvc[r], i_mvc, NULL);
+        cache_block(a, x8, y8, 1, 1, r, m->mv);
+        a->mvc[r][i_mvc][0] = m->mv[0]; a->mvc[r][i_mvc][1] = m->mv[1];
+        i_mvc++;
+        a->satd8x8[i] = m->cost - m->cost_mv;
+        m->cost += i_ref_cost;
+        m->cost += a->lambda * 1;
+    }
+    a->cost8x8 = a->me8[0].cost + a->me8[1].cost + a->me8[2].cost + a->me8[3].cost;
+}
+
+static void analyse_inter_p16x8(actx *a, int i_best_satd)
+{
+    int mvc[3][2];
+    a->partition = D_16x8;
+    a->cur_valid = 0;
+    for (int i = 0; i < 2; i++) {
+        me_t *l0m = &a->me16x8[i], m;
+        const int r0 = a->me8[2 * i].ref, r1 = a->me8[2 * i + 1].ref;
+        const int ref8[2] = { r0 < r1 ? r0 : r1, r0 < r1 ? r1 : r0 };
+        const int i_ref8s = ref8[0] == ref8[1] ? 1 : 2;
+        m.w = 16; m.h = 8; m.ox = 0; m.oy = 8 * i;
+        l0m->cost = 0x7fffffff;
+        for (int j = 0; j < i_ref8s; j++) {
+            const int r = ref8[j];
+            m.ref = r; m.ref_cost = ref_cost(a, r);
+            for (int k = 0; k < 2; k++) { mvc[0][k] = a->mvc[r][0][k]; mvc[1][k] = a->mvc[r][2 * i + 1][k]; mvc[2][k] = a->mvc[r][2 * i + 2][k]; }
+            a->cur8[2 * i].ref = a->cur8[2 * i + 1].ref = r;
+            predict_mv(a, 0, i, 2, r, m.mvp);
+            me_search_ref(a, &m, mvc, 3, NULL);
+            m.cost += m.ref_cost;
+            if (m.cost < l0m->cost) *l0m = m;
+        }
+        /* early termination on the first half plus the estimate of the second */
+        if (a->b_early_terminate && !i && l0m->cost + a->cost_est16x8_1 > i_best_satd) { a->cost16x8 = COST_MAX; return; }
+        cache_block(a, 0, i, 2, 1, l0m->ref, l0m->mv);
+    }
+    a->cost16x8 = a->me16x8[0].cost + a->me16x8[1].cost;
+}
+
+static void analyse_inter_p8x16(actx *a, int i_best_satd)
+{
+    int mvc[3][2];
+    a->partition = D_8x16;
+    a->cur_valid = 0;
+    for (int i = 0; i < 2; i++) {
+        me_t *l0m = &a->me8x16[i], m;
+        const int r0 = a->me8[i].ref, r1 = a->me8[i + 2].ref;
+        const int ref8[2] = { r0 < r1 ? r0 : r1, r0 < r1 ? r1 : r0 };
+        const int i_ref8s = ref8[0] == ref8[1] ? 1 : 2;
+        m.w = 8; m.h = 16; m.ox = 8 * i; m.oy = 0;
+        l0m->cost = 0x7fffffff;
+        for (int j = 0; j < i_ref8s; j++) {
+            const int r = ref8[j];
+            m.ref = r; m.ref_cost = ref_cost(a, r);
+            for (int k = 0; k < 2; k++) { mvc[0][k] = a->mvc[r][0][k]; mvc[1][k] = a->mvc[r][i + 1][k]; mvc[2][k] = a->mvc[r][i + 3][k]; }
+            a->cur8[i].ref = a->cur8[i + 2].ref = r;
+            predict_mv(a, i, 0, 1, r, m.mvp);
+            me_search_ref(a, &m, mvc, 3, NULL);
+            m.cost += m.ref_cost;
+            if (m.cost < l0m->cost) *l0m = m;
+        }
+        if (a->b_early_terminate && !i && l0m->cost + a->cost_est8x16_1 > i_best_satd) { a->cost8x16 = COST_MAX; return; }
+        cache_block(a, i, 0, 1, 2, l0m->ref, l0m->mv);
+    }
+    a->cost8x16 = a->me8x16[0].cost + a->me8x16[1].cost;
+}
+
+/* ---------------------------------------------------------------------------------------------------------------------------
+ * intra analysis (x264_mb_analyse_intra, x264_mb_analyse_intra_chroma) on the reconstruction of the coded neighbours.
+ * The block loops code each block as they go (the next block predicts from it); the luma reconstruction is restored afterwards:
+ * x264_macroblock_encode codes the chosen type again from scratch. */
+static int i4_pred_mode(const actx *a, int b, const uint8_t *cur_modes)
+{
+    /* 8.3.1.1 / x264_mb_predict_intra4x4_mode: min of the left / top block modes; DC when a neighbour is absent; neighbour macroblocks that are
+     * not I_NxN count as DC.  I8x8 macroblocks store each 8x8 mode replicated over their 4x4 entries. */
+    const x264o_encoder *e = a->e;
+    const int bx = blk_x[b], by = blk_y[b];
+    int ma, mb_;
+    if (bx > 0) ma = cur_modes[idx_of[by][bx - 1]];
+    else if (a->mbx > 0) { const x264gpu_mb *n = &e->mbs[a->mi - 1]; ma = (n->type == X264GPU_MB_I4x4 || n->type == X264GPU_MB_I8x8) ? n->i4_mode[idx_of[by][3]] : 2; }
+    else return 2;
+    if (by > 0) mb_ = cur_modes[idx_of[by - 1][bx]];
+    else if (a->mby > 0) { const x264gpu_mb *n = &e->mbs[a->mi - e->mbw]; mb_ = (n->type == X264GPU_MB_I4x4 || n->type == X264GPU_MB_I8x8) ? n->i4_mode[idx_of[3][bx]] : 2; }
+    else return 2;
+    return ma < mb_ ? ma : mb_;
+}
+static int i4_avail(const actx *a, int b)
+{
+    const int bx = blk_x[b], by = blk_y[b], mbx = a->mbx, mby = a->mby;
+    int av = 0;
+    if (bx > 0 || mbx > 0) av |= X264O_AVAIL_LEFT;
+    if (by > 0 || mby > 0) av |= X264O_AVAIL_TOP;
+    if ((bx > 0 || mbx > 0) && (by > 0 || mby > 0)) av |= X264O_AVAIL_TOPLEFT;
+    if (by == 0) { if (mby > 0 && (bx < 3 || mbx + 1 < a->e->mbw)) av |= X264O_AVAIL_TOPRIGHT; }
+    else if (bx < 3 && idx_of[by - 1][bx + 1] < b) av |= X264O_AVAIL_TOPRIGHT;
+    return av;
+}
+static int i8_avail(const actx *a, int i8)
+{
+    const int x8 = i8 & 1, y8 = i8 >> 1, left = a->mbx > 0, top = a->mby > 0;
+    int av = 0;
+    if (x8 || left) av |= X264O_AVAIL_LEFT;
+    if (y8 || top) av |= X264O_AVAIL_TOP;
+    if ((x8 || left) && (y8 || top)) av |= X264O_AVAIL_TOPLEFT;
+    if (i8 == 0 ? top : i8 == 1 ? (top && a->mbx + 1 < a->e->mbw) : i8 == 2) av |= X264O_AVAIL_TOPRIGHT;
+    return av;
+}
+static int real_mode4(int m, int avail)       /* DC variant by availability */
+{
+    if (m != I_PRED_4x4_DC) return m;
+    const int l = avail & X264O_AVAIL_LEFT, t = avail & X264O_AVAIL_TOP;
+    return l && t ? I_PRED_4x4_DC : l ? I_PRED_4x4_DC_LEFT : t ? I_PRED_4x4_DC_TOP : I_PRED_4x4_DC_128;
+}
+/* predict_4x4_mode_available / i4x4_mode_available: candidate list by neighbour availability */
+static const int8_t *mode4_available(int avail)
+{
+    static const int8_t tab[5][10] = {
+        { I_PRED_4x4_DC, -1, -1, -1, -1, -1, -1, -1, -1, -1 },
+        { I_PRED_4x4_DC, I_PRED_4x4_H, I_PRED_4x4_HU, -1, -1, -1, -1, -1, -1, -1 },
+        { I_PRED_4x4_DC, I_PRED_4x4_V, I_PRED_4x4_DDL, I_PRED_4x4_VL, -1, -1, -1, -1, -1, -1 },
+        { I_PRED_4x4_DC, I_PRED_4x4_H, I_PRED_4x4_V, I_PRED_4x4_DDL, I_PRED_4x4_VL, I_PRED_4x4_HU, -1, -1, -1, -1 },
+        { I_PRED_4x4_V, I_PRED_4x4_H, I_PRED_4x4_DC, I_PRED_4x4_DDL, I_PRED_4x4_DDR, I_PRED_4x4_VR, I_PRED_4x4_HD, I_PRED_4x4_VL, I_PRED_4x4_HU, -1 } };
+    const int all = X264O_AVAIL_LEFT | X264O_AVAIL_TOP | X264O_AVAIL_TOPLEFT;
+    return tab[(avail & all) == all ? 4 : avail & (X264O_AVAIL_LEFT | X264O_AVAIL_TOP)];
+}
+/* intra_analysis_shortcut[all nine available][favor_vertical]: directional modes still worth trying after V / H / DC */
+static const int8_t intra_analysis_shortcut[2][2][5] = {
+    { { I_PRED_4x4_HU, -1, -1, -1, -1 }, { I_PRED_4x4_DDL, I_PRED_4x4_VL, -1, -1, -1 } },
+    { { I_PRED_4x4_DDR, I_PRED_4x4_HD, I_PRED_4x4_HU, -1, -1 }, { I_PRED_4x4_DDL, I_PRED_4x4_DDR, I_PRED_4x4_VR, I_PRED_4x4_VL, -1 } } };
+
+static void analyse_intra_chroma(actx *a)
+{
+    if (a->satd_chroma < COST_MAX) return;
+    x264o_encoder *e = a->e;
+    const int left = a->mbx > 0, top = a->mby > 0;
+    const pixel *fuv = e->fenc_uv + (size_t)a->mby * 8 * e->fs + a->mbx * 16;
+    const pixel *ruv = chroma_plane(e, e->cur) + (size_t)a->mby * 8 * e->rs + a->mbx * 16;
+    pixel fu[64], fv[64], nu[9 * 9], nvv[9 * 9], pu[64], pv[64];
+    for (int y = 0; y < 8; y++) for (int x = 0; x < 8; x++) { fu[y * 8 + x] = fuv[y * e->fs + 2 * x]; fv[y * 8 + x] = fuv[y * e->fs + 2 * x + 1]; }
+    memset(nu, 128, sizeof(nu)); memset(nvv, 128, sizeof(nvv));
+    for (int y = -1; y < 8; y++)
+        for (int x = -1; x < 8; x++) {
+            if (y >= 0 && x >= 0) continue;
+            if ((y < 0 && !top) || (x < 0 && !left)) continue;
+            nu[(y + 1) * 9 + x + 1] = ruv[y * e->rs + 2 * x]; nvv[(y + 1) * 9 + x + 1] = ruv[y * e->rs + 2 * x + 1];
+        }
+    int cm[4], cn = 0;
+    if (left && top) { cm[cn++] = I_PRED_CHROMA_DC; cm[cn++] = I_PRED_CHROMA_H; cm[cn++] = I_PRED_CHROMA_V; cm[cn++] = I_PRED_CHROMA_P; }
+    else if (left) { cm[cn++] = I_PRED_CHROMA_DC_LEFT; cm[cn++] = I_PRED_CHROMA_H; }
+    else if (top) { cm[cn++] = I_PRED_CHROMA_DC_TOP; cm[cn++] = I_PRED_CHROMA_V; }
+    else cm[cn++] = I_PRED_CHROMA_DC_128;
+    for (int i = 0; i < cn; i++) {
+        const int m = cm[i], sig = m > I_PRED_CHROMA_P ? I_PRED_CHROMA_DC : m;
+        x264o_predict_8x8c(pu, 8, nu + 10, 9, m);
+        x264o_predict_8x8c(pv, 8, nvv + 10, 9, m);
+        const int c = mbcmp(a, pu, 8, fu, 8, 8, 8) + mbcmp(a, pv, 8, fv, 8, 8, 8) + a->lambda * bs_size_ue(sig);
+        if (c < a->satd_chroma) { a->satd_chroma = c; a->predc = m; }
+    }
+}
+
+static void analyse_intra(actx *a, int i_satd_inter)
+{
+    x264o_encoder *e = a->e;
+    const int lambda = a->lambda, qp = a->qp, left = a->mbx > 0, top = a->mby > 0;
+    const pixel *fenc = e->fenc_y + (size_t)a->mby * 16 * e->fs + a->mbx * 16;
+    pixel *rec = luma_plane(e, e->cur, 0) + (size_t)a->mby * 16 * e->rs + a->mbx * 16;
+    const int parts = (e->slice_type == X264GPU_SLICE_I && (e->cfg.partitions & 0x100)) ? (e->cfg.partitions >> 8) & 6 : e->cfg.partitions & 7;
+    pixel save[256], pred[256];
+    for (int y = 0; y < 16; y++) memcpy(save + y * 16, rec + y * e->rs, 16);
+    /* ---- 16x16: V, H, DC first; plane only if one of them was useful ---- */
+    {
+        static const uint8_t i16x16_thresh_lut[11] = { 2, 2, 2, 3, 3, 4, 4, 4, 4, 4, 4 };
+        const int i16x16_thresh = a->b_fast_intra ? (i16x16_thresh_lut[a->subme > 10 ? 10 : a->subme] * i_satd_inter) >> 1 : COST_MAX;
+        if (left && top) {
+            for (int m = 0; m < 3; m++) {       /* V, H, DC */
+                x264o_predict_16x16(pred, 16, rec, e->rs, m);
+                const int c = mbcmp(a, pred, 16, fenc, e->fs, 16, 16) + lambda * bs_size_ue(m);
+                if (c < a->satd_i16) { a->satd_i16 = c; a->pred16 = m; }
+            }
+            if (a->satd_i16 <= i16x16_thresh) {
+                x264o_predict_16x16(pred, 16, rec, e->rs, I_PRED_16x16_P);
+                const int c = mbcmp(a, pred, 16, fenc, e->fs, 16, 16) + lambda * bs_size_ue(3);
+                if (c < a->satd_i16) { a->satd_i16 = c; a->pred16 = I_PRED_16x16_P; }
+            }
+        } else {
+            int modes[2], n = 0;
+            if (left) { modes[n++] = I_PRED_16x16_DC_LEFT; modes[n++] = I_PRED_16x16_H; }
+            else if (top) { modes[n++] = I_PRED_16x16_DC_TOP; modes[n++] = I_PRED_16x16_V; }
+            else modes[n++] = I_PRED_16x16_DC_128;
+            for (int i = 0; i < n; i++) {
+                const int m = modes[i], sig = m > I_PRED_16x16_P ? I_PRED_16x16_DC : m;
+                x264o_predict_16x16(pred, 16, rec, e->rs, m);
+                const int c = mbcmp(a, pred, 16, fenc, e->fs, 16, 16) + lambda * bs_size_ue(sig);
+                if (c < a->satd_i16) { a->satd_i16 = c; a->pred16 = m; }
+            }
+        }
+        if (a->satd_i16 > i16x16_thresh) return;
+    }
+    /* ---- 8x8 ---- */
+    if ((parts & 4) && e->cfg.dct8x8) {
+        const int i_satd_thresh = i_satd_inter < a->satd_i16 ? i_satd_inter : a->satd_i16;
+        int i_cost = lambda * 4, idx;
+        uint8_t m8[16];
+        int16_t lvtmp[256]; uint32_t nnztmp = 0;
+        memset(m8, 2, sizeof(m8));
+        for (idx = 0;; idx++) {
+            const int x8 = idx & 1, y8 = idx >> 1, avail = i8_avail(a, idx);
+            const pixel *f = fenc + y8 * 8 * e->fs + x8 * 8;
+            pixel *r = rec + y8 * 8 * e->rs + x8 * 8;
+            const int i_pred_mode = i4_pred_mode(a, idx * 4, m8);
+            const int8_t *predict_mode = mode4_available(avail);
+            pixel edge[33], p8[64];
+            int i_best = COST_MAX, bestm = 2;
+            x264o_predict_8x8_filter(r, e->rs, edge, avail);
+            if (predict_mode[5] >= 0) {
+                int satd[9];
+                for (int m = 0; m < 3; m++) { x264o_predict_8x8(p8, 8, edge, m); satd[m] = a->satd ? x264o_sa8d(p8, 8, f, e->fs, 8, 8) : x264o_sad(p8, 8, f, e->fs, 8, 8); }
+                const int favor_vertical = satd[I_PRED_4x4_H] > satd[I_PRED_4x4_V];
+                if (i_pred_mode < 3) satd[i_pred_mode] -= 3 * lambda;
+                for (int i = 2; i >= 0; i--) if (satd[i] < i_best) { i_best = satd[i]; bestm = i; }
+                predict_mode = intra_analysis_shortcut[predict_mode[8] >= 0][favor_vertical];       /* i_mbrd == 0 */
+            }
+            for (; *predict_mode >= 0 && i_best >= 0; predict_mode++) {
+                const int m = *predict_mode;
+                x264o_predict_8x8(p8, 8, edge, real_mode4(m, avail));
+                int c = a->satd ? x264o_sa8d(p8, 8, f, e->fs, 8, 8) : x264o_sad(p8, 8, f, e->fs, 8, 8);
+                if (i_pred_mode == m) c -= 3 * lambda;
+                if (c < i_best) { i_best = c; bestm = m; }
+            }
+            i_cost += i_best + 3 * lambda;
+            a->pred8[idx] = bestm;
+            memset(m8 + idx * 4, bestm, 4);
+            if (idx == 3 || i_cost > i_satd_thresh) break;
+            /* code the block: the next ones predict from it */
+            x264o_predict_8x8(p8, 8, edge, real_mode4(bestm, avail));
+            for (int y = 0; y < 8; y++) memcpy(r + y * e->rs, p8 + y * 8, 8);
+            encode_i8x8(e, f, r, qp, idx, lvtmp, &nnztmp);
+        }
+        if (idx == 3) a->satd_i8 = i_cost;
+        else {
+            static const uint16_t cost_div_fix8[3] = { 1024, 512, 341 };
+            a->satd_i8 = COST_MAX;
+            i_cost = (i_cost * cost_div_fix8[idx]) >> 8;
+        }
+        for (int y = 0; y < 16; y++) memcpy(rec + y * e->rs, save + y * 16, 16);
+        static const uint8_t i8x8_thresh[11] = { 4, 4, 4, 5, 5, 5, 6, 6, 6, 6, 6 };
+        const int mn = i_cost < a->satd_i16 ? i_cost : a->satd_i16;
+        if (a->b_early_terminate && mn > (int)(((int64_t)i_satd_inter * i8x8_thresh[a->subme > 10 ? 10 : a->subme]) >> 2)) return;
+    }
+    /* ---- 4x4 ---- */
+    if (parts & 2) {
+        int i_cost = lambda * (24 + 16), idx;
+        int i_satd_thresh = COST_MAX;
+        if (a->b_early_terminate) { i_satd_thresh = i_satd_inter < a->satd_i16 ? i_satd_inter : a->satd_i16; if (a->satd_i8 < i_satd_thresh) i_satd_thresh = a->satd_i8; }
+        uint8_t m4[16];
+        int16_t l16[16];
+        memset(m4, 2, sizeof(m4));
+        for (idx = 0;; idx++) {
+            const pixel *f = fenc + blk_y[idx] * 4 * e->fs + blk_x[idx] * 4;
+            pixel *r = rec + blk_y[idx] * 4 * e->rs + blk_x[idx] * 4;
+            const int avail = i4_avail(a, idx), i_pred_mode = i4_pred_mode(a, idx, m4);
+            const int8_t *predict_mode = mode4_available(avail);
+            pixel p4[16];
+            int i_best = COST_MAX, bestm = 2;
+            if (predict_mode[5] >= 0) {
+                int satd[3];
+                for (int m = 0; m < 3; m++) { x264o_predict_4x4(p4, 4, r, e->rs, m, avail); satd[m] = mbcmp(a, p4, 4, f, e->fs, 4, 4); }
+                const int favor_vertical = satd[I_PRED_4x4_H] > satd[I_PRED_4x4_V];
+                if (i_pred_mode < 3) satd[i_pred_mode] -= 3 * lambda;
+                i_best = satd[I_PRED_4x4_DC]; bestm = I_PRED_4x4_DC;
+                if (satd[I_PRED_4x4_H] < i_best) { i_best = satd[I_PRED_4x4_H]; bestm = I_PRED_4x4_H; }
+                if (satd[I_PRED_4x4_V] < i_best) { i_best = satd[I_PRED_4x4_V]; bestm = I_PRED_4x4_V; }
+                predict_mode = intra_analysis_shortcut[predict_mode[8] >= 0][favor_vertical];
+            }
+            if (i_best > 0)
+                for (; *predict_mode >= 0; predict_mode++) {
+                    const int m = *predict_mode;
+                    x264o_predict_4x4(p4, 4, r, e->rs, real_mode4(m, avail), avail);
+                    int c = mbcmp(a, p4, 4, f, e->fs, 4, 4);
+                    if (i_pred_mode == m) {
+                        c -= lambda * 3;
+                        if (c <= 0) { i_best = c; bestm = m; break; }
+                    }
+                    if (c < i_best) { i_best = c; bestm = m; }
+                }
+            i_cost += i_best + 3 * lambda;
+            a->pred4[idx] = bestm;
+            m4[idx] = (uint8_t)bestm;
+            if (i_cost > i_satd_thresh || idx == 15) break;
+            x264o_predict_4x4(p4, 4, r, e->rs, real_mode4(bestm, avail), avail);
+            for (int y = 0; y < 4; y++) memcpy(r + y * e->rs, p4 + y * 4, 4);
+            encode_i4x4(e, f, r, qp, l16);
+        }
+        a->satd_i4 = idx == 15 ? i_cost : COST_MAX;
+        for (int y = 0; y < 16; y++) memcpy(rec + y * e->rs, save + y * 16, 16);
+    }
+}
+
+/* ---------------------------------------------------------------------------------------------------------------------------
+ * x264_macroblock_encode */
+static void encode_intra_chroma(actx *a, x264gpu_mb *mb, int16_t *lv)
+{
+    x264o_encoder *e = a->e;
+    const int left = a->mbx > 0, top = a->mby > 0;
+    const pixel *fuv = e->fenc_uv + (size_t)a->mby * 8 * e->fs + a->mbx * 16;
+    pixel *ruv = chroma_plane(e, e->cur) + (size_t)a->mby * 8 * e->rs + a->mbx * 16;
+    pixel nu[9 * 9], nvv[9 * 9], pu[64], pv[64];
+    memset(nu, 128, sizeof(nu)); memset(nvv, 128, sizeof(nvv));
+    for (int y = -1; y < 8; y++)
+        for (int x = -1; x < 8; x++) {
+            if (y >= 0 && x >= 0) continue;
+            if ((y < 0 && !top) || (x < 0 && !left)) continue;
+            nu[(y + 1) * 9 + x + 1] = ruv[y * e->rs + 2 * x]; nvv[(y + 1) * 9 + x + 1] = ruv[y * e->rs + 2 * x + 1];
+        }
+    x264o_predict_8x8c(pu, 8, nu + 10, 9, a->predc);
+    x264o_predict_8x8c(pv, 8, nvv + 10, 9, a->predc);
+    for (int y = 0; y < 8; y++) for (int x = 0; x < 8; x++) { ruv[y * e->rs + 2 * x] = pu[y * 8 + x]; ruv[y * e->rs + 2 * x + 1] = pv[y * 8 + x]; }
+    mb->chroma_mode = (uint8_t)(a->predc > I_PRED_CHROMA_P ? I_PRED_CHROMA_DC : a->predc);
+    encode_chroma(e, fuv, ruv, a->qpc, 0, mb, lv);
+}
+
+static void encode_intra_mb(actx *a, int type, x264gpu_mb *mb, int16_t *lv)
+{
+    x264o_encoder *e = a->e;
+    const pixel *fenc = e->fenc_y + (size_t)a->mby * 16 * e->fs + a->mbx * 16;
+    pixel *rec = luma_plane(e, e->cur, 0) + (size_t)a->mby * 16 * e->rs + a->mbx * 16;
+    mb->type = (uint8_t)type;
+    for (int k = 0; k < 4; k++) mb->ref[k] = -1;
+    if (type == X264GPU_MB_I16x16) {
+        mb->i16_mode = (uint8_t)(a->pred16 > I_PRED_16x16_P ? I_PRED_16x16_DC : a->pred16);
+        encode_i16x16(e, fenc, rec, a->qp, a->pred16, mb, lv);
+    } else if (type == X264GPU_MB_I8x8) {
+        mb->transform8x8 = 1;
+        for (int i8 = 0; i8 < 4; i8++) {
+            const pixel *f = fenc + (i8 >> 1) * 8 * e->fs + (i8 & 1) * 8;
+            pixel *r = rec + (i8 >> 1) * 8 * e->rs + (i8 & 1) * 8;
+            const int avail = i8_avail(a, i8);
+            pixel edge[33], p8[64];
+            memset(mb->i4_mode + i8 * 4, a->pred8[i8], 4);
+            x264o_predict_8x8_filter(r, e->rs, edge, avail);
+            x264o_predict_8x8(p8, 8, edge, real_mode4(a->pred8[i8], avail));
+            for (int y = 0; y < 8; y++) memcpy(r + y * e->rs, p8 + y * 8, 8);
+            if (encode_i8x8(e, f, r, a->qp, i8, lv, &mb->nnz)) mb->cbp_luma |= 1 << i8;
+        }
+    } else {
+        for (int b = 0; b < 16; b++) {
+            const pixel *f = fenc + blk_y[b] * 4 * e->fs + blk_x[b] * 4;
+            pixel *r = rec + blk_y[b] * 4 * e->rs + blk_x[b] * 4;
+            const int avail = i4_avail(a, b);
+            pixel p4[16];
+            mb->i4_mode[b] = (uint8_t)a->pred4[b];
+            x264o_predict_4x4(p4, 4, r, e->rs, real_mode4(a->pred4[b], avail), avail);
+            for (int y = 0; y < 4; y++) memcpy(r + y * e->rs, p4 + y * 4, 4);
+            if (encode_i4x4(e, f, r, a->qp, lv + b * 16)) { mb->nnz |= 1u << b; mb->cbp_luma |= 1 << (b >> 2); }
+        }
+    }
+    analyse_intra_chroma(a);          /* x264_analyse_update_cache: chroma mode of intra macroblocks, unless chroma-ME already did it */
+    encode_intra_chroma(a, mb, lv);
+}
+
+static void encode_inter_mb(actx *a, x264gpu_mb *mb, int16_t *lv)
+{
+    x264o_encoder *e = a->e;
+    const int mbx = a->mbx, mby = a->mby;
+    pixel *rec = luma_plane(e, e->cur, 0) + (size_t)mby * 16 * e->rs + mbx * 16;
+    pixel *rec_uv = chroma_plane(e, e->cur) + (size_t)mby * 8 * e->rs + mbx * 16;
+    const pixel *fenc = e->fenc_y + (size_t)mby * 16 * e->fs + mbx * 16;
+    pixel pu[64], pv[64];
+    for (int k = 0; k < 4; k++)       /* motion compensation per 8x8 quadrant (covers 16x16 / 16x8 / 8x16 / 8x8) */
+        mc_mb(e, mbx, mby, (k & 1) * 8, (k >> 1) * 8, 8, 8, ref_slot(e, mb->ref[k]), mb->mv[k][0], mb->mv[k][1], rec, e->rs, pu, pv, 8);
+    for (int y = 0; y < 8; y++)
+        for (int x = 0; x < 8; x++) { rec_uv[y * e->rs + 2 * x] = pu[y * 8 + x]; rec_uv[y * e->rs + 2 * x + 1] = pv[y * 8 + x]; }
+    if (mb->type == X264GPU_MB_P_SKIP) return;                /* x264_macroblock_encode_skip: the prediction is the reconstruction */
+    /* x264_mb_analyse_transform: SA8D vs SATD of the prediction error */
+    mb->transform8x8 = 0;
+    if (e->cfg.dct8x8) mb->transform8x8 = x264o_sa8d(fenc, e->fs, rec, e->rs, 16, 16) < x264o_satd(fenc, e->fs, rec, e->rs, 16, 16);
+    if (mb->transform8x8) encode_luma_inter8(e, fenc, rec, a->qp, mb, lv);
+    else encode_luma_inter(e, fenc, rec, a->qp, mb, lv);
+    if (!mb->cbp_luma) mb->transform8x8 = 0;      /* the flag is not transmitted without luma coefficients (macroblock_cache_save) */
+    encode_chroma(e, e->fenc_uv + (size_t)mby * 8 * e->fs + mbx * 16, rec_uv, a->qpc, 1, mb, lv);
+    /* P_L0 16x16, reference 0, skip vector, nothing coded: P_SKIP */
+    if (mb->type == X264GPU_MB_P_L0 && mb->partition == D_16x16 && !(mb->cbp_luma | mb->cbp_chroma) && mb->ref[0] == 0 &&
+        mb->mv[0][0] == a->pskip_mv[0] && mb->mv[0][1] == a->pskip_mv[1]) mb->type = X264GPU_MB_P_SKIP;
+}
+
+/* ---------------------------------------------------------------------------------------------------------------------------
+ * x264_macroblock_analyse + x264_macroblock_encode for macroblock (mbx,mby) */
+static int mb_type_at(const x264o_encoder *e, int mbx, int mby)
+{
+    if (mbx < 0 || mby < 0 || mbx >= e->mbw) return -1;
+    return e->mbs[mby * e->mbw + mbx].type;
+}
+
+void x264o_macroblock(x264o_encoder *e, int mbx, int mby)
+{
+    actx A, *a = &A;
+    memset(a, 0, sizeof(*a));
+    a->e = e; a->mbx = mbx; a->mby = mby; a->mi = mby * e->mbw + mbx;
+    x264gpu_mb *mb = &e->mbs[a->mi];
+    int16_t *lv = e->levels + (size_t)a->mi * X264GPU_MB_LEVELS;
+    memset(mb, 0, sizeof(*mb));
+    memset(lv, 0, X264GPU_MB_LEVELS * sizeof(int16_t));
+    a->qp = e->mbqp[a->mi]; a->qpc = x264o_chroma_qp[clampi(a->qp + e->cfg.chroma_qp_offset, 0, 51)];
+    a->lambda = x264o_lambda(a->qp);
+    a->subme = clampi(e->cfg.subme, 0, 11); a->satd = a->subme > 1;
+    a->nref = e->nref;
+    a->type_left = mb_type_at(e, mbx - 1, mby); a->type_top = mb_type_at(e, mbx, mby - 1);
+    a->type_tl = mb_type_at(e, mbx - 1, mby - 1); a->type_tr = mby > 0 ? mb_type_at(e, mbx + 1, mby - 1) : -1;
+    a->satd_i16 = a->satd_i8 = a->satd_i4 = a->satd_chroma = COST_MAX;
+    a->b_early_terminate = a->subme < 11;
+    mb->qp = (uint8_t)a->qp;
+
+    if (e->slice_type == X264GPU_SLICE_I) {
+        analyse_intra(a, COST_MAX);
+        int i_cost = a->satd_i16, type = X264GPU_MB_I16x16;
+        if (a->satd_i4 < i_cost) { i_cost = a->satd_i4; type = X264GPU_MB_I4x4; }
+        if (a->satd_i8 < i_cost) { i_cost = a->satd_i8; type = X264GPU_MB_I8x8; }
+        mb->cost = i_cost;
+        encode_intra_mb(a, type, mb, lv);
+        e->intra_count++;
+        return;
+    }
+
+    /* ---- P slice ---- */
+    a->cost_mv = x264o_cost_mv_for(e, a->qp);
+    a->chroma_me = e->cfg.chroma_me && a->subme >= 5;
+    {   /* motion vector limits (x264_analyse_init: mv_min / mv_max, _spel clipped to --mvrange, _fpel inside the padded picture) */
+        const int fr = 4 * (e->cfg.mv_range > 0 ? e->cfg.mv_range : 512);
+        a->mv_min[0] = 4 * (-16 * mbx - 24); a->mv_max[0] = 4 * (16 * (e->mbw - mbx - 1) + 24);
+        a->mv_min[1] = 4 * (-16 * mby - 24); a->mv_max[1] = 4 * (16 * (e->mbh - mby - 1) + 24);
+        for (int k = 0; k < 2; k++) {
+            a->smin[k] = clampi(a->mv_min[k], -fr, fr - 1); a->smax[k] = clampi(a->mv_max[k], -fr, fr - 1);
+            a->fmin[k] = (a->smin[k] >> 2) + 6; a->fmax[k] = (a->smax[k] >> 2) - 6;
+        }
+    }
+    /* fast intra decision: intra is unlikely unless a neighbour, the co-located macroblock of reference 0 or a third of the
+     * macroblocks coded so far are intra */
+    if (a->b_early_terminate && a->mi > 4) {
+        const int colo = e->mbtype[ref_slot(e, 0)][a->mi];
+        if (!(is_intra_type(a->type_left) || is_intra_type(a->type_top) || is_intra_type(a->type_tl) || is_intra_type(a->type_tr) ||
+              is_intra_type(colo) || a->mi < 3 * e->intra_count)) a->b_fast_intra = 1;
+    }
+    a->cur_valid = 0;
+    predict_mv_pskip(a, a->pskip_mv);
+    int b_skip = 0;
+    if (e->cfg.fast_pskip) {
+        if (a->subme >= 3) a->b_try_skip = 1;
+        else if (a->type_left == X264GPU_MB_P_SKIP || a->type_top == X264GPU_MB_P_SKIP || a->type_tl == X264GPU_MB_P_SKIP || a->type_tr == X264GPU_MB_P_SKIP)
+            b_skip = probe_pskip(a);
+    }
+    int16_t (*mvr0)[2] = e->mv16[e->cur];
+    if (b_skip) {
+        /* set up the vectors for future predictors */
+        mvr0[a->mi][0] = mvr0[a->mi][1] = 0;
+        for (int r = 1; r < a->nref; r++) e->mvr[r][a->mi][0] = e->mvr[r][a->mi][1] = 0;
+    } else if (analyse_inter_p16x16(a)) {
+        b_skip = 1;
+        for (int r = 1; r < a->nref; r++) e->mvr[r][a->mi][0] = e->mvr[r][a->mi][1] = 0;
+    }
+    if (b_skip) {
+        mb->type = X264GPU_MB_P_SKIP; mb->partition = D_16x16;
+        for (int k = 0; k < 4; k++) { mb->ref[k] = 0; mb->mv[k][0] = (int16_t)a->pskip_mv[0]; mb->mv[k][1] = (int16_t)a->pskip_mv[1]; }
+        /* the skip vector is motion-compensated clipped to the padded picture (same samples as the unclipped vector) */
+        x264gpu_mb t = *mb;
+        for (int k = 0; k < 4; k++) { t.mv[k][0] = (int16_t)clampi(a->pskip_mv[0], a->mv_min[0], a->mv_max[0]); t.mv[k][1] = (int16_t)clampi(a->pskip_mv[1], a->mv_min[1], a->mv_max[1]); }
+        encode_inter_mb(a, &t, lv);
+        return;
+    }
+
+    const int psub16 = e->cfg.partitions & 1;
+    if (psub16) { if (e->cfg.mixed_refs) analyse_inter_p8x8_mixed_ref(a); else analyse_inter_p8x8(a); }
+    /* best inter mode */
+    int i_type = X264GPU_MB_P_L0, i_partition = D_16x16, i_cost = a->me16.cost;
+    if (psub16 && (!a->b_early_terminate || a->cost8x8 < a->me16.cost)) { i_type = X264GPU_MB_P_8x8; i_partition = D_8x8; i_cost = a->cost8x8; }
+    {
+        const int i_thresh16x8 = psub16 ? a->me8[1].cost_mv + a->me8[2].cost_mv : 0;
+        if (psub16 && (!a->b_early_terminate || a->cost8x8 < a->me16.cost + i_thresh16x8)) {
+            int avg = (a->me8[2].cost_mv + a->me8[2].ref_cost + a->me8[3].cost_mv + a->me8[3].ref_cost + 1) >> 1;
+            a->cost_est16x8_1 = a->satd8x8[2] + a->satd8x8[3] + avg;
+            analyse_inter_p16x8(a, i_cost);
+            if (a->cost16x8 < i_cost) { i_type = X264GPU_MB_P_L0; i_partition = D_16x8; i_cost = a->cost16x8; }
+            avg = (a->me8[1].cost_mv + a->me8[1].ref_cost + a->me8[3].cost_mv + a->me8[3].ref_cost + 1) >> 1;
+            a->cost_est8x16_1 = a->satd8x8[1] + a->satd8x8[3] + avg;
+            analyse_inter_p8x16(a, i_cost);
+            if (a->cost8x16 < i_cost) { i_type = X264GPU_MB_P_L0; i_partition = D_8x16; i_cost = a->cost8x16; }
+        }
+    }
+    /* refine the winner's quarter-pel vectors (no RD: always, unless full-pel only) */
+    if (a->subme) {
+        if (i_partition == D_16x16) { a->partition = D_16x16; me_refine_qpel(a, &a->me16); i_cost = a->me16.cost; }
+        else if (i_partition == D_16x8) { me_refine_qpel(a, &a->me16x8[0]); me_refine_qpel(a, &a->me16x8[1]); i_cost = a->me16x8[0].cost + a->me16x8[1].cost; }
+        else if (i_partition == D_8x16) { me_refine_qpel(a, &a->me8x16[0]); me_refine_qpel(a, &a->me8x16[1]); i_cost = a->me8x16[0].cost + a->me8x16[1].cost; }
+        else { i_cost = 0; for (int i = 0; i < 4; i++) { me_refine_qpel(a, &a->me8[i]); i_cost += a->me8[i].cost; } }
+    }
+    if (a->chroma_me) {
+        analyse_intra_chroma(a);
+        analyse_intra(a, i_cost - a->satd_chroma);
+        a->satd_i16 += a->satd_chroma; a->satd_i8 += a->satd_chroma; a->satd_i4 += a->satd_chroma;
+    } else analyse_intra(a, i_cost);
+    mb->aux[0] = i_cost; mb->aux[2] = a->me16.cost;
+    { int mn = a->satd_i16 < a->satd_i8 ? a->satd_i16 : a->satd_i8; if (a->satd_i4 < mn) mn = a->satd_i4; mb->aux[1] = mn; }
+    if (a->satd_i16 < i_cost) { i_cost = a->satd_i16; i_type = X264GPU_MB_I16x16; }
+    if (a->satd_i8 < i_cost) { i_cost = a->satd_i8; i_type = X264GPU_MB_I8x8; }
+    if (a->satd_i4 < i_cost) { i_cost = a->satd_i4; i_type = X264GPU_MB_I4x4; }
+    mb->cost = i_cost;
+
+    if (is_intra_type(i_type)) {
+        encode_intra_mb(a, i_type, mb, lv);
+        e->intra_count++;
+        return;
+    }
+    mb->type = (uint8_t)i_type; mb->partition = (uint8_t)i_partition;
+    for (int k = 0; k < 4; k++) {
+        const me_t *m = i_partition == D_16x16 ? &a->me16 : i_partition == D_16x8 ? &a->me16x8[k >> 1] : i_partition == D_8x16 ? &a->me8x16[k & 1] : &a->me8[k];
+        mb->ref[k] = (int8_t)m->ref; mb->mv[k][0] = (int16_t)m->mv[0]; mb->mv[k][1] = (int16_t)m->mv[1];
+    }
+    encode_inter_mb(a, mb, lv);
+}

@@ -1,0 +1,66 @@
+/* oracle/encoder_priv.h — shared state of the CPU checker's frame encoder (TEST INFRASTRUCTURE ONLY; see x264o.h).
+ * encoder.c owns the frame-level stages (ingest, quantiser maps, deblocking, half-pel planes, DPB rotation); analyse.c owns the
+ * per-macroblock work of [x264-upstream] encoder/analyse.c + me.c + macroblock.c behind x264_encoder_encode (codec.c:1693). */
+#ifndef X264O_ENCODER_PRIV_H
+#define X264O_ENCODER_PRIV_H
+#include "x264o.h"
+#include "x264gpu.h"
+
+#define PAD 32          /* luma padding of reference planes */
+#define CPAD 16         /* chroma padding (samples) */
+#define MVCOST_HALF 32768
+#define X264O_MAX_REFS 5
+#define X264O_MAX_SLOTS (X264O_MAX_REFS + 1)     /* references + the picture being built */
+#define COST_MAX (1 << 28)
+
+typedef struct x264o_encoder x264o_encoder;
+
+struct x264o_encoder {
+    x264gpu_config cfg;
+    int mbw, mbh, cw, ch;
+    int fs;                      /* fenc stride (luma and NV12 chroma) */
+    pixel *fenc_y, *fenc_uv;
+    int rs;                      /* reference plane stride */
+    size_t plane_bytes, cplane_bytes;
+    pixel *luma[X264O_MAX_SLOTS];   /* DPB slots: 4 padded planes each (refs + the picture being built) */
+    pixel *chroma[X264O_MAX_SLOTS]; /* padded NV12 */
+    int slots;                   /* refs + 1 */
+    int nref;                    /* reference pictures usable by the current P slice */
+    int cur;                     /* DPB slot being reconstructed */
+    /* per-picture motion side data living with the DPB slot (x264_frame_t): mv16x16 (= h->mb.mvr[0][0], the 16x16 search result
+     * in reference 0 of every macroblock), mb_type, the number of references the picture was coded with, its POC */
+    int16_t (*mv16[X264O_MAX_SLOTS])[2];
+    uint8_t *mbtype[X264O_MAX_SLOTS];
+    int slot_nref[X264O_MAX_SLOTS], slot_poc[X264O_MAX_SLOTS], slot_ref0poc[X264O_MAX_SLOTS];   /* ..., POC of the picture's own reference 0 */
+    int16_t (*mvr[X264O_MAX_REFS])[2];   /* h->mb.mvr[0][r], r >= 1: 16x16 search results per reference index of the picture being coded */
+    int poc;                     /* POC of the picture being coded (2 x pictures since the IDR) */
+    uint16_t *cost_mv[52];       /* lambda-scaled mv bit costs per qp, centred at MVCOST_HALF */
+    x264o_quant_tables qt;
+    int have_ref;
+    int slice_type;              /* slice being encoded */
+    uint8_t *mbqp;               /* quantiser of every macroblock of the picture being coded (slice quantiser, + AQ offset) */
+    const int16_t *ext_off_q8;   /* quantiser offsets handed in for the next picture (lookahead: AQ - macroblock-tree), or NULL */
+    const int16_t *lowres_mv;    /* optional lookahead vectors of the next picture against its predecessor (x264 fenc->lowres_mvs[0][0]),
+                                  * [nmb][2] in lowres quarter-pels, first entry 0x7fff = absent */
+    /* state of the macroblock loop (x264: h->stat.frame, h->mb) */
+    x264gpu_mb *mbs;
+    int16_t *levels;
+    int intra_count;             /* intra macroblocks coded so far in this slice (h->stat.frame.i_mb_count[I_*]) */
+};
+
+static inline int clampi(int v, int lo, int hi) { return v < lo ? lo : v > hi ? hi : v; }
+static inline int median3(int a, int b, int c) { int mn = a < b ? a : b, mx = a < b ? b : a; return c < mn ? mn : c > mx ? mx : c; }
+static inline int bs_size_ue(int v) { int n = 0; v++; while (v >> (n + 1)) n++; return 2 * n + 1; }
+
+/* DPB slot of reference index r of the current P slice: r = 0 is the most recent picture */
+static inline int ref_slot(const x264o_encoder *e, int r) { return (e->cur - 1 - r + 2 * e->slots) % e->slots; }
+static inline pixel *luma_plane(const x264o_encoder *e, int slot, int k) { return e->luma[slot] + k * e->plane_bytes + (size_t)PAD * e->rs + PAD; }
+static inline pixel *chroma_plane(const x264o_encoder *e, int slot) { return e->chroma[slot] + (size_t)CPAD * e->rs + 2 * CPAD; }
+
+int x264o_lambda(int qp);
+int x264o_lambda2(int qp);
+const uint16_t *x264o_cost_mv_for(x264o_encoder *e, int qp);
+/* analyse.c: analysis + encode of macroblock (mbx,mby) of the slice being coded; fills e->mbs[], e->levels and the reconstruction */
+void x264o_macroblock(x264o_encoder *e, int mbx, int mby);
+
+#endif

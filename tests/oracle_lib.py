@@ -144,6 +144,7 @@ _sig("x264o_encoder_encode", _i, [C.c_void_p, C.c_void_p, _i, C.c_void_p, C.c_vo
 _sig("x264o_encoder_get_recon", None, [C.c_void_p, C.c_void_p])
 _sig("x264o_encoder_ref_plane", C.c_void_p, [C.c_void_p, _i, C.POINTER(_i), C.POINTER(_i)])
 _sig("x264o_lambda", _i, [_i])
+_sig("x264o_encoder_set_lowres_mvs", None, [C.c_void_p, C.c_void_p])
 
 MB_DTYPE = np.dtype([("type", "u1"), ("i16_mode", "u1"), ("chroma_mode", "u1"), ("qp", "u1"), ("cbp_luma", "u1"),
                      ("cbp_chroma", "u1"), ("partition", "u1"), ("ref", "i1", 4), ("i4_mode", "u1", 16),
@@ -154,7 +155,7 @@ assert MB_DTYPE.itemsize == 64 == C.sizeof(MbRecord)
 def default_config(width, height, streams=1, **kw):
     c = Config(width=width, height=height, streams=streams, refs=1, qp_i=20, qp_p=23, me_range=16, subme=7,
                deblock=1, deblock_alpha=0, deblock_beta=0, chroma_qp_offset=0, deadzone_inter=21,
-               deadzone_intra=11, dct_decimate=1, partitions=2, dct8x8=0, me_method=1, chroma_me=0, mixed_refs=0, aq_mode=0, aq_strength_q8=266)
+               deadzone_intra=11, dct_decimate=1, partitions=2, dct8x8=0, me_method=1, chroma_me=0, mixed_refs=0, aq_mode=0, aq_strength_q8=266, fast_pskip=1, mv_range=0)
     for k, v in kw.items():
         setattr(c, k, v)
     return c

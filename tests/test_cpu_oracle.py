@@ -84,7 +84,7 @@ def test_oracle_static_scene_goes_inter_zero_mv():
     enc.encode(f, 2)
     rec_i = enc.recon()
     mbs, lv = enc.encode(rec_i, 0)       # feed the reconstruction back: perfectly predictable
-    assert (mbs["type"] == 4).all() and (mbs["mv"] == 0).all() and not lv.any()
+    assert (mbs["type"] == 6).all() and (mbs["mv"] == 0).all() and not lv.any()      # P_Skip, found by the analysis itself
 
 
 def test_abi_exports_every_declared_symbol():
