@@ -149,10 +149,10 @@ typedef struct x264gpu_encoder x264gpu_encoder;  /* opaque: owns the device-resi
 typedef struct x264gpu_config {
     int width, height;        /* luma picture size (even) */
     int streams;              /* independent streams/closed GOPs encoded in lock-step */
-    int refs;                 /* reference frames for P (round 1: 1) */
+    int refs;                 /* reference frames for P slices, 1..4 */
     int qp_i, qp_p;           /* constant QPs (X264_RC_CQP path, codec.c:1498-1502) */
     int me_range;             /* --merange (16) */
-    int subme;                /* --subme level (round 1 honours 0..7 search depth) */
+    int subme;                /* --subme level: search depth 0..11; mode decision is SATD-based at every level (no RD yet: x264's subme <= 5 behaviour) */
     int deblock;              /* 1 = in-loop filter on */
     int deblock_alpha, deblock_beta; /* --deblock a:b offsets */
     int chroma_qp_offset;
@@ -162,7 +162,7 @@ typedef struct x264gpu_config {
                                * same bits 1-2 unless bit8 is set, then bit9 = i4x4 and bit10 = i8x8 (x264 keeps separate
                                * analyse.intra / analyse.inter masks) */
     int dct8x8;               /* --8x8dct: adaptive 8x8 luma transform (High profile) */
-    int me_method;            /* --me: 0 dia (radius-1 diamond), 1 hex (hexagon + square refine), 2 umh (uneven multi-hexagon), 3 esa (exhaustive); X264_ME_DIA / _HEX / _UMH / _ESA */
+    int me_method;            /* --me: 0 dia (radius-1 diamond), 1 hex (hexagon + square refine); X264_ME_DIA / _HEX (umh / esa: not in the device macroblock loop yet) */
     int chroma_me;            /* --chroma-me (x264 default on): sub-pel SATD costs of P macroblocks include the chroma planes; acts when subme >= 5,
                                * as x264's h->mb.b_chroma_me ([x264-upstream] encoder/encoder.c, me.c COST_MV_SATD) */
     int mixed_refs;           /* --mixed-refs (x264 default on): 8x8 blocks, and the 16x8 / 8x16 halves built on them, choose their reference
@@ -211,6 +211,10 @@ int  x264gpu_encoder_set_mb_qp_offsets(x264gpu_encoder *enc, const int16_t *d_of
  * CRF: every GOP slot carries the quantiser x264_ratecontrol_start would have given that picture).  AQ / caller offsets add to it per
  * macroblock.  NULL returns to the shared quantiser. */
 int  x264gpu_encoder_set_stream_qps(x264gpu_encoder *enc, const int8_t *qps);
+/* Lookahead vectors of the following pictures against their predecessors (x264: fenc->lowres_mvs[0][0], an extra start candidate of the
+ * 16x16 search in reference 0; x264_mb_predict_mv_ref16x16): device array [streams][mb_count][2] int16 in quarter-pels of the
+ * half-resolution planes, first entry 0x7fff = absent for that stream.  NULL (the default) = none. */
+int  x264gpu_encoder_set_lowres_mvs(x264gpu_encoder *enc, const int16_t *d_mvs);
 
 /* ------------------------------------------------------------------------------------------------
  * Lookahead frame cost: x264_slicetype_frame_cost of [x264-upstream]

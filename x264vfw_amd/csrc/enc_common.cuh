@@ -25,9 +25,6 @@ struct EncK {
     uint8_t *rec_luma, *rec_chroma;          // DPB slot being reconstructed
     const uint8_t *ref_luma[4], *ref_chroma[4];   // DPB slots of reference index 0..nref-1 (0 = most recent)
     int nref;                                // references usable by this P slice
-    const int16_t *mvf_prev; int16_t *mvf_cur;     // [streams][nmb][2]
-    const int8_t *reff_prev; int8_t *reff_cur;     // [streams][nmb]
-    const uint16_t *cost_mv;  // 2*MVCOST_HALF entries for the slice qp
     x264gpu_mb *mb;           // [streams][nmb]
     int16_t *levels;          // [streams][nmb][416]
     int qp, lambda, qpc;
@@ -50,6 +47,16 @@ struct EncK {
     const int8_t *stream_qp;  // optional [streams]: each stream's slice quantiser (x264gpu_encoder_set_stream_qps); k.qp otherwise
     int aq_strength_q8;
     int *wf_progress;         // [streams][2][WFG_ROWS]: row counters of the wavefront kernels when ONE stream spans several workgroups
+    // motion side data of the raster macroblock loop (k_mb.cuh; x264: h->mb.mvr, frame->mv16x16, frame->mb_type)
+    int16_t *mv16_cur;        // [streams][nmb][2]: 16x16 search result in reference 0 of the picture being coded (= mvr[0]); lives with the DPB slot
+    const int16_t *mv16_ref0; // the same array of reference 0 (temporal candidates)
+    int16_t *mvr[5];          // [r >= 1][streams][nmb][2]: 16x16 search results per reference index
+    uint8_t *mbtype_cur;      // [streams][nmb] macroblock types of the picture being coded; lives with the DPB slot
+    const uint8_t *mbtype_ref0;
+    int tscale[5];            // (POC distance to reference r) * inv_ref_poc of reference 0, for the temporal candidates
+    int temporal;             // reference 0 was itself a P picture: its 16x16 vectors are search candidates
+    const int16_t *lowres_mv; // optional [streams][nmb][2] lookahead vectors (x264 lowres_mvs[0][0]); first entry 0x7fff = absent
+    int fast_pskip, mv_range;
 };
 // the slice quantiser of stream s
 __device__ __forceinline__ int slice_qp(const EncK &k, int s) { return k.stream_qp ? (int)k.stream_qp[s] : k.qp; }

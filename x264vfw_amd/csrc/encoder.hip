@@ -3,15 +3,13 @@
 // codec.c:1693) for a lock-step batch of independent closed-GOP streams.
 //
 // Stage order per call (all on the caller's HIP stream, no host synchronisation, graph-capturable):
-//   ingest -> [P: analyse (ME) -> encode_inter] -> intra wavefront -> deblock wavefront ->
-//   half-pel planes + border expansion.   Device-resident DPB: two slots of {4 padded luma planes,
-//   padded NV12 chroma} per stream; the MV field of the previous frame feeds the next frame's ME.
+//   ingest -> per-macroblock quantisers -> macroblock loop (k_mb.cuh: analysis + encode of every macroblock in raster order,
+//   one wavefront per stream) -> QP_Y inheritance -> deblock wavefront -> half-pel planes + border expansion.
+//   Device-resident DPB: refs + 1 slots of {4 padded luma planes, padded NV12 chroma, 16x16 vectors, macroblock types} per stream.
 #include "enc_common.cuh"
-#include "k_analyse.cuh"
 #include "k_encode.cuh"
 #include <stdlib.h>
-#include "k_intra.cuh"
-#include "k_intra2.cuh"
+#include "k_mb.cuh"
 #include "k_deblock.cuh"
 #include <math.h>
 #include <vector>
@@ -30,9 +28,12 @@ struct x264gpu_encoder {
     uint8_t *fenc_y = nullptr, *fenc_uv = nullptr;
     uint8_t *luma[5] = {}, *chroma[5] = {};      // DPB slots: refs + the picture being reconstructed
     int slots = 2, have = 0;                     // have = pictures in the DPB since the last IDR
-    int16_t *mvf[2] = { nullptr, nullptr };
-    int8_t *reff[2] = { nullptr, nullptr };
-    uint16_t *cost_mv[52] = {};
+    int16_t *mv16[5] = {};                       // per DPB slot: 16x16 search results in reference 0 (x264 frame->mv16x16 = h->mb.mvr[0][0])
+    uint8_t *mbtype[5] = {};                     // per DPB slot: macroblock types (x264 frame->mb_type)
+    int16_t *mvr[5] = {};                        // per reference index >= 1: 16x16 search results of the picture being coded
+    int slot_nref[5] = {}, slot_poc[5] = {}, slot_ref0poc[5] = {};
+    int poc = 0;
+    const int16_t *lowres_mv = nullptr;
     int cur = 0;
     unsigned long long *dbg = nullptr;   // diagnostics buffer set by x264gpu_encoder_set_debug
     int *wf_progress = nullptr;          // [streams][2][WFG_ROWS] row counters of the multi-workgroup wavefront kernels
@@ -50,29 +51,7 @@ struct x264gpu_encoder {
 };
 enum { NSTAGE = 6 };
 
-static const char *const kStageNames[] = { "ingest", "analyse_p", "encode_inter", "intra", "deblock", "hpel_filter" };
-
-static int build_cost_mv(x264gpu_encoder *e, int qp)
-{
-    if (e->cost_mv[qp]) return X264GPU_OK;
-    // lambda * (2*log2(|mvd|+1) + 0.718 + (mvd != 0)) + 0.5 in float, saturated to u16 (x264's cost_mv)
-    uint16_t *h = new (std::nothrow) uint16_t[2 * MVCOST_HALF];
-    if (!h) return set_err(X264GPU_ENOMEM, "cost_mv host", hipSuccess);
-    const int lambda = lambda_of(qp);
-    for (int i = 0; i < MVCOST_HALF; i++) {
-        float bits = log2f((float)(i + 1)) * 2.0f + 0.718f + (i ? 1.0f : 0.0f);
-        int c = (int)((float)lambda * bits + 0.5f);
-        if (c > 65535) c = 65535;
-        h[MVCOST_HALF + i] = (uint16_t)c;
-        h[MVCOST_HALF - i] = (uint16_t)c;
-    }
-    h[0] = h[1];
-    hipError_t er = hipMalloc((void **)&e->cost_mv[qp], 2 * MVCOST_HALF * sizeof(uint16_t));
-    if (er == hipSuccess) er = hipMemcpy(e->cost_mv[qp], h, 2 * MVCOST_HALF * sizeof(uint16_t), hipMemcpyHostToDevice);
-    delete[] h;
-    if (er != hipSuccess) return set_err(X264GPU_EHIP, "cost_mv upload", er);
-    return X264GPU_OK;
-}
+static const char *const kStageNames[] = { "ingest", "macroblocks", "unused", "settle_qp", "deblock", "hpel_filter" };
 
 // every quantiser-dependent value for all 52 quantisers (adaptive quantisation reads them per macroblock)
 static int build_aq_tables(x264gpu_encoder *e)
@@ -86,8 +65,8 @@ static int build_aq_tables(x264gpu_encoder *e)
         lam[qp] = lambda_of(qp);
         uint16_t *h = cost.data() + (size_t)qp * 2 * MVCOST_HALF;
         for (int i = 0; i < MVCOST_HALF; i++) {
-            float bits = log2f((float)(i + 1)) * 2.0f + 0.718f + (i ? 1.0f : 0.0f);
-            int c = (int)((float)lam[qp] * bits + 0.5f);
+            const float logs = i ? log2f((float)(i + 1)) * 2.0f + 1.718f : 0.718f;      // x264_analyse_init_costs
+            int c = (int)((float)lam[qp] * logs + 0.5f);
             if (c > 65535) c = 65535;
             h[MVCOST_HALF + i] = (uint16_t)c; h[MVCOST_HALF - i] = (uint16_t)c;
         }
@@ -113,8 +92,8 @@ int x264gpu_encoder_create(x264gpu_encoder **out, const x264gpu_config *cfg)
     ARG_TRY(out && cfg);
     ARG_TRY(cfg->width >= 16 && cfg->height >= 16 && !(cfg->width & 1) && !(cfg->height & 1) && cfg->streams >= 1);
     ARG_TRY(cfg->qp_i >= 0 && cfg->qp_i <= 51 && cfg->qp_p >= 0 && cfg->qp_p <= 51 && cfg->refs >= 1 && cfg->refs <= 4);
-    ARG_TRY(cfg->width <= 4096 && cfg->height <= 2304 && cfg->me_range >= 4 && cfg->me_range <= (cfg->me_method == 2 ? 64 : 16));
-    ARG_TRY(cfg->me_method >= 0 && cfg->me_method <= 3);
+    ARG_TRY(cfg->width <= 4096 && cfg->height <= 2304 && cfg->me_range >= 4 && cfg->me_range <= 16);
+    ARG_TRY(cfg->me_method >= 0 && cfg->me_method <= 1);          // dia, hex (umh / esa: not in the raster macroblock loop yet)
     x264gpu_encoder *e = new (std::nothrow) x264gpu_encoder();
     if (!e) return set_err(X264GPU_ENOMEM, "encoder", hipSuccess);
     e->cfg = *cfg;
@@ -147,14 +126,14 @@ int x264gpu_encoder_create(x264gpu_encoder **out, const x264gpu_config *cfg)
         alloc((void **)&e->luma[i], S * k.luma_bytes, 0);
         alloc((void **)&e->chroma[i], S * k.cplane_bytes, 0);
     }
-    for (int i = 0; i < 2; i++) {
-        alloc((void **)&e->mvf[i], S * k.nmb * 2 * sizeof(int16_t), 0);
-        alloc((void **)&e->reff[i], S * k.nmb, 0xff);
+    for (int i = 0; i < e->slots; i++) {
+        alloc((void **)&e->mv16[i], S * k.nmb * 2 * sizeof(int16_t), 0);
+        alloc((void **)&e->mbtype[i], S * k.nmb, 0);
     }
+    for (int r = 1; r < cfg->refs; r++) alloc((void **)&e->mvr[r], S * k.nmb * 2 * sizeof(int16_t), 0);
     alloc((void **)&e->wf_progress, S * 2 * WFG_ROWS * sizeof(int), 0);
     if (er != hipSuccess) { x264gpu_encoder_destroy(e); return set_err(er == hipErrorOutOfMemory ? X264GPU_ENOMEM : X264GPU_EHIP, "encoder buffers", er); }
-    int rc = build_cost_mv(e, cfg->qp_p);
-    if (!rc && cfg->aq_mode) rc = build_aq_tables(e);
+    const int rc = build_aq_tables(e);       // the macroblock loop reads every quantiser-dependent value per macroblock
     if (rc) { x264gpu_encoder_destroy(e); return rc; }
     *out = e;
     return X264GPU_OK;
@@ -163,8 +142,6 @@ int x264gpu_encoder_create(x264gpu_encoder **out, const x264gpu_config *cfg)
 int x264gpu_encoder_set_qp(x264gpu_encoder *e, int qp_i, int qp_p)
 {
     ARG_TRY(e && qp_i >= 0 && qp_i <= 51 && qp_p >= 0 && qp_p <= 51);
-    const int rc = build_cost_mv(e, qp_p);
-    if (rc) return rc;
     e->cfg.qp_i = qp_i; e->cfg.qp_p = qp_p;
     return X264GPU_OK;
 }
@@ -172,7 +149,6 @@ int x264gpu_encoder_set_qp(x264gpu_encoder *e, int qp_i, int qp_p)
 int x264gpu_encoder_set_mb_qp_offsets(x264gpu_encoder *e, const int16_t *d_offsets_q8)
 {
     ARG_TRY(e);
-    if (d_offsets_q8 && !e->q4tab) { const int rc = build_aq_tables(e); if (rc) return rc; }
     e->ext_off = d_offsets_q8;
     return X264GPU_OK;
 }
@@ -182,7 +158,6 @@ int x264gpu_encoder_set_stream_qps(x264gpu_encoder *e, const int8_t *qps)
     ARG_TRY(e);
     if (!qps) { e->use_stream_qp = false; return X264GPU_OK; }
     for (int s = 0; s < e->cfg.streams; s++) ARG_TRY(qps[s] >= 0 && qps[s] <= 51);
-    if (!e->q4tab) { const int rc = build_aq_tables(e); if (rc) return rc; }
     if (!e->stream_qp) HIP_TRY(hipMalloc((void **)&e->stream_qp, 2 * (size_t)e->cfg.streams));
     e->stream_qp_sel ^= 1;
     HIP_TRY(hipMemcpy(e->stream_qp + (size_t)e->stream_qp_sel * e->cfg.streams, qps, (size_t)e->cfg.streams, hipMemcpyHostToDevice));
@@ -234,9 +209,7 @@ void x264gpu_encoder_destroy(x264gpu_encoder *e)
     if (!e) return;
     profile_free(e);
     (void)hipFree(e->fenc_y); (void)hipFree(e->fenc_uv);
-    for (int i = 0; i < 5; i++) { (void)hipFree(e->luma[i]); (void)hipFree(e->chroma[i]); }
-    for (int i = 0; i < 2; i++) { (void)hipFree(e->mvf[i]); (void)hipFree(e->reff[i]); }
-    for (int q = 0; q < 52; q++) (void)hipFree(e->cost_mv[q]);
+    for (int i = 0; i < 5; i++) { (void)hipFree(e->luma[i]); (void)hipFree(e->chroma[i]); (void)hipFree(e->mv16[i]); (void)hipFree(e->mbtype[i]); (void)hipFree(e->mvr[i]); }
     (void)hipFree(e->wf_progress);
     (void)hipFree(e->stream_qp); (void)hipFree(e->mbqp); (void)hipFree(e->q4tab); (void)hipFree(e->q8tab); (void)hipFree(e->lambda_tab); (void)hipFree(e->cost_all);
     delete e;
@@ -246,6 +219,8 @@ int x264gpu_encoder_mb_count(const x264gpu_encoder *e) { return e ? e->k.nmb : 0
 int x264gpu_encoder_set_debug(x264gpu_encoder *e, void *d_counters) { ARG_TRY(e); e->dbg = (unsigned long long *)d_counters; return X264GPU_OK; }
 int x264gpu_encoder_stage_count(void) { return (int)(sizeof(kStageNames) / sizeof(kStageNames[0])); }
 const char *x264gpu_encoder_stage_name(int i) { return i >= 0 && i < x264gpu_encoder_stage_count() ? kStageNames[i] : ""; }
+
+int x264gpu_encoder_set_lowres_mvs(x264gpu_encoder *e, const int16_t *d_mvs) { ARG_TRY(e); e->lowres_mv = d_mvs; return X264GPU_OK; }
 
 int x264gpu_encode_frames(x264gpu_encoder *e, const uint8_t *d_i420, int slice_type, x264gpu_mb *d_mb,
                           int16_t *d_levels, void *stream)
@@ -260,24 +235,31 @@ int x264gpu_encode_frames(x264gpu_encoder *e, const uint8_t *d_i420, int slice_t
     EncK k = e->k;
     const int qp = slice_type == X264GPU_SLICE_I ? e->cfg.qp_i : e->cfg.qp_p;
     k.i420 = d_i420; k.fenc_y = e->fenc_y; k.fenc_uv = e->fenc_uv;
-    if (idr) e->have = 0;                                                // IDR empties the DPB
+    if (idr) { e->have = 0; e->poc = 0; }                                // IDR empties the DPB
     k.rec_luma = e->luma[e->cur]; k.rec_chroma = e->chroma[e->cur];
-    k.nref = e->have < e->cfg.refs ? e->have : e->cfg.refs;
+    k.nref = slice_type == X264GPU_SLICE_I ? 0 : e->have < e->cfg.refs ? e->have : e->cfg.refs;
+    auto slot_of = [&](int r) { return (e->cur - 1 - r + 2 * e->slots) % e->slots; };
     for (int r = 0; r < 4; r++) {
-        const int slot = (e->cur - 1 - (r < k.nref ? r : 0) + 2 * e->slots) % e->slots;
+        const int slot = slot_of(r < k.nref ? r : 0);
         k.ref_luma[r] = e->luma[slot]; k.ref_chroma[r] = e->chroma[slot];
     }
-    k.mvf_prev = e->mvf[0]; k.mvf_cur = e->mvf[1]; k.reff_prev = e->reff[0]; k.reff_cur = e->reff[1];
-    k.cost_mv = e->cost_mv[e->cfg.qp_p];
+    // motion side data (x264: h->mb.mvr, fref[0][0]->mv16x16 / mb_type / i_ref, POC distances)
+    const int s0 = slot_of(0);
+    k.mv16_cur = e->mv16[e->cur]; k.mv16_ref0 = e->mv16[s0]; k.mbtype_cur = e->mbtype[e->cur]; k.mbtype_ref0 = e->mbtype[s0];
+    for (int r = 0; r < 5; r++) k.mvr[r] = e->mvr[r];
+    k.temporal = k.nref > 0 && e->slot_nref[s0] > 0;
+    for (int r = 0; r < 5; r++) k.tscale[r] = 0;
+    if (k.temporal) {
+        const int delta = e->slot_poc[s0] - e->slot_ref0poc[s0], inv = (256 + delta / 2) / delta;
+        for (int r = 0; r < k.nref; r++) k.tscale[r] = (e->poc - e->slot_poc[slot_of(r)]) * inv;
+    }
+    e->slot_nref[e->cur] = k.nref; e->slot_poc[e->cur] = e->poc; e->slot_ref0poc[e->cur] = k.nref ? e->slot_poc[s0] : 0;
+    k.lowres_mv = e->lowres_mv; k.fast_pskip = e->cfg.fast_pskip; k.mv_range = e->cfg.mv_range;
     k.mb = d_mb; k.levels = d_levels;
     k.qp = qp; k.lambda = lambda_of(qp); k.qpc = chroma_qp_of(qp, e->cfg.chroma_qp_offset);
     k.slice_type = slice_type;
     k.partitions = (slice_type == X264GPU_SLICE_I && (e->cfg.partitions & 0x100)) ? (e->cfg.partitions >> 8) & 6 : e->cfg.partitions & 7;
     k.dbg = e->dbg;
-    QuantCfg qc; qc.deadzone_inter = e->cfg.deadzone_inter; qc.deadzone_intra = e->cfg.deadzone_intra;
-    k.q_luma_intra = make_q4(qp, 0, qc); k.q_luma_inter = make_q4(qp, 1, qc);
-    k.q_chroma_intra = make_q4(k.qpc, 2, qc); k.q_chroma_inter = make_q4(k.qpc, 3, qc);
-    k.q8_intra = make_q8(qp, 0, qc); k.q8_inter = make_q8(qp, 1, qc);
 
     hipEvent_t *ev = nullptr;
     int mask = 0;
@@ -285,71 +267,31 @@ int x264gpu_encode_frames(x264gpu_encoder *e, const uint8_t *d_i420, int slice_t
 #define STAGE_MARK(i) do { if (ev) { HIP_TRY(hipEventRecord(ev[i], st)); } } while (0)
     STAGE_MARK(0);
     hipLaunchKernelGGL(k_ingest, dim3((k.cw / 4 + 255) / 256, k.ch, S), dim3(256), 0, st, k);
+    // per-macroblock quantisers: always materialised (the macroblock loop reads every quantiser-dependent value per macroblock)
     const bool aq = e->cfg.aq_mode != 0 || e->ext_off != nullptr || e->use_stream_qp;
-    if (aq) {
-        k.stream_qp = e->use_stream_qp ? e->stream_qp + (size_t)e->stream_qp_sel * e->cfg.streams : nullptr;
-        k.mbqp = e->mbqp; k.q4tab = e->q4tab; k.q8tab = e->q8tab; k.lambda_tab = e->lambda_tab; k.cost_all = e->cost_all; k.aq_strength_q8 = e->cfg.aq_strength_q8;
-        if (e->ext_off || !e->cfg.aq_mode) hipLaunchKernelGGL(k_apply_qp_offsets, dim3((k.nmb + 255) / 256, S), dim3(256), 0, st, k, e->ext_off);
-        else hipLaunchKernelGGL(k_aq, dim3((k.nmb + 15) / 16, S), dim3(256), 0, st, k);
-    }
+    k.stream_qp = e->use_stream_qp ? e->stream_qp + (size_t)e->stream_qp_sel * e->cfg.streams : nullptr;
+    k.mbqp = e->mbqp; k.q4tab = e->q4tab; k.q8tab = e->q8tab; k.lambda_tab = e->lambda_tab; k.cost_all = e->cost_all; k.aq_strength_q8 = e->cfg.aq_strength_q8;
+    if (e->ext_off || !e->cfg.aq_mode) hipLaunchKernelGGL(k_apply_qp_offsets, dim3((k.nmb + 255) / 256, S), dim3(256), 0, st, k, e->ext_off);
+    else hipLaunchKernelGGL(k_aq, dim3((k.nmb + 15) / 16, S), dim3(256), 0, st, k);
     mask |= 1;
     STAGE_MARK(1);
-    if (slice_type == X264GPU_SLICE_P) {
-        // sub-pel neighbourhood margin: 2 px reaches every step of subme <= 7, subme >= 8 needs 5 px
-        const int me_blocks = (((k.nmb + 3) / 4 + 7) / 8) * 8;      // multiple of 8: XCD-contiguous mapping in the kernel
-        // sub-pel neighbourhood margin 2 (subme <= 7) or 5; UMH and mixed refs are their own instantiations so that the plain
-        // hexagon kernel keeps its registers
-        const bool big = k.subme >= 8, umh = k.me_method == 2, mixed = k.mixed_refs && (k.partitions & 1) && e->cfg.refs > 1;
-        const dim3 grid(me_blocks, S), blk(256);
-#define X264GPU_LAUNCH_ANALYSE(M, U, X) hipLaunchKernelGGL((k_analyse_p<M, U, X>), grid, blk, 0, st, k)
-        if (big) { if (umh) { if (mixed) X264GPU_LAUNCH_ANALYSE(5, true, true); else X264GPU_LAUNCH_ANALYSE(5, true, false); }
-                   else { if (mixed) X264GPU_LAUNCH_ANALYSE(5, false, true); else X264GPU_LAUNCH_ANALYSE(5, false, false); } }
-        else { if (umh) { if (mixed) X264GPU_LAUNCH_ANALYSE(2, true, true); else X264GPU_LAUNCH_ANALYSE(2, true, false); }
-               else { if (mixed) X264GPU_LAUNCH_ANALYSE(2, false, true); else X264GPU_LAUNCH_ANALYSE(2, false, false); } }
-#undef X264GPU_LAUNCH_ANALYSE
-        STAGE_MARK(2);
-        if (aq) hipLaunchKernelGGL(k_encode_inter<true>, dim3((k.nmb + 3) / 4, S), dim3(256), 0, st, k);
-        else hipLaunchKernelGGL(k_encode_inter<false>, dim3((k.nmb + 3) / 4, S), dim3(256), 0, st, k);
-        mask |= 2 | 4;
-    } else {
-        HIP_TRY(hipMemsetAsync(e->reff[1], 0xff, (size_t)S * k.nmb, st));
-        HIP_TRY(hipMemsetAsync(e->mvf[1], 0, (size_t)S * k.nmb * 2 * sizeof(int16_t), st));
-        STAGE_MARK(2);
-    }
+    // the macroblock loop: one wavefront per stream, raster order (sub-pel neighbourhood margin 2 px up to subme 7, 5 px above)
+    if (k.subme >= 8) hipLaunchKernelGGL(k_mb_slice<5>, dim3(S), dim3(64), 0, st, k);
+    else hipLaunchKernelGGL(k_mb_slice<2>, dim3(S), dim3(64), 0, st, k);
+    mask |= 2;
+    STAGE_MARK(2);
     STAGE_MARK(3);
-    // band kernel (four macroblock rows per wavefront); X264GPU_INTRA_V1=1 selects the row-per-wave predecessor for A/B runs
-    static const bool intra_v1 = getenv("X264GPU_INTRA_V1") != nullptr;
-    // Few streams in flight (single-stream latency): the rows of ONE picture are dealt to several workgroups — a wave per band on
-    // its own SIMD instead of 16 waves sharing one CU — with row counters in global memory and agent-scope hand-offs.  All
-    // workgroups of a launch must be resident at once (they wait on each other): streams x workgroups <= 128.
+    if (aq) { hipLaunchKernelGGL(k_settle_qp, dim3(S), dim3(64), 0, st, k); mask |= 8; }      // QP_Y inheritance before the deblocking filter reads the records
+    STAGE_MARK(4);
+    // Few streams in flight (single-stream latency): the rows of ONE picture are dealt to several workgroups with row counters in global
+    // memory and agent-scope hand-offs.  All workgroups of a launch must be resident at once: streams x workgroups <= 128.
     static const bool mwg_off = getenv("X264GPU_WAVEFRONT_1WG") != nullptr;
-    const int nbands = (k.mbh + 3) / 4, npairs = (k.mbh + 1) / 2;
-    const int iwg = (nbands + I2_WAVES_MWG - 1) / I2_WAVES_MWG, dwg = (npairs + 3) / 4;
-    const bool mwg = !mwg_off && S * (iwg > dwg ? iwg : dwg) <= 128 && k.mbh > 4;
-    // a lone picture (or a handful): one macroblock row per wavefront, four times the bands
-    const int iwg1 = (k.mbh + I2_WAVES_MWG - 1) / I2_WAVES_MWG;
-    static const bool rows1_off = getenv("X264GPU_INTRA_BAND4") != nullptr;
-    const bool rows1 = mwg && !rows1_off && S * iwg1 <= 128;
+    const int npairs = (k.mbh + 1) / 2, dwg = (npairs + 3) / 4;
+    const bool mwg = !mwg_off && S * dwg <= 128 && k.mbh > 4;
     k.wf_progress = e->wf_progress;
     if (mwg) HIP_TRY(hipMemsetAsync(e->wf_progress, 0, (size_t)S * 2 * WFG_ROWS * sizeof(int), st));
-    if (intra_v1 && !aq) hipLaunchKernelGGL(k_intra, dim3(S), dim3(1024), 0, st, k);
-    else if (aq) {      // per-macroblock quantisers: own instantiations (the slot carries its quantiser tables in LDS)
-        if (rows1) hipLaunchKernelGGL((k_intra2<I2_WAVES_MWG, true, true, 1>), dim3(S, iwg1), dim3(I2_WAVES_MWG * 64), 0, st, k);
-        else if (mwg) hipLaunchKernelGGL((k_intra2<I2_WAVES_MWG, true, true>), dim3(S, iwg), dim3(I2_WAVES_MWG * 64), 0, st, k);
-        else if (S >= 128) hipLaunchKernelGGL((k_intra2<I2_WAVES, false, true>), dim3(S), dim3(I2_WAVES * 64), 0, st, k);
-        else hipLaunchKernelGGL((k_intra2<I2_WAVES_FEW, false, true>), dim3(S), dim3(I2_WAVES_FEW * 64), 0, st, k);
-        hipLaunchKernelGGL(k_settle_qp, dim3(S), dim3(64), 0, st, k);      // QP_Y inheritance before the deblocking filter reads the records
-    }
-    else if (rows1) hipLaunchKernelGGL((k_intra2<I2_WAVES_MWG, true, false, 1>), dim3(S, iwg1), dim3(I2_WAVES_MWG * 64), 0, st, k);
-    else if (mwg) hipLaunchKernelGGL((k_intra2<I2_WAVES_MWG, true, false>), dim3(S, iwg), dim3(I2_WAVES_MWG * 64), 0, st, k);
-    else if (S >= 128) hipLaunchKernelGGL((k_intra2<I2_WAVES, false, false>), dim3(S), dim3(I2_WAVES * 64), 0, st, k);        // CUs are full: small workgroups, two per CU
-    else hipLaunchKernelGGL((k_intra2<I2_WAVES_FEW, false, false>), dim3(S), dim3(I2_WAVES_FEW * 64), 0, st, k);                  // few streams: all bands of a frame at once
-    mask |= 8;
-    STAGE_MARK(4);
     if (e->cfg.deblock) {
-        static const bool deblock_v1 = getenv("X264GPU_DEBLOCK_V1") != nullptr;      // one macroblock per wave (A/B runs)
-        if (deblock_v1) hipLaunchKernelGGL(k_deblock, dim3(S), dim3(DB_WAVES * 64), 0, st, k);
-        else if (mwg) hipLaunchKernelGGL(k_deblock2<true>, dim3(S, dwg), dim3(256), 0, st, k);
+        if (mwg) hipLaunchKernelGGL(k_deblock2<true>, dim3(S, dwg), dim3(256), 0, st, k);
         else {
             static const int db_waves = getenv("X264GPU_DEBLOCK_WAVES") ? atoi(getenv("X264GPU_DEBLOCK_WAVES")) : 16;     // A/B knob: 4, 8 or 16
             hipLaunchKernelGGL(k_deblock2<false>, dim3(S), dim3((db_waves == 4 || db_waves == 8 ? db_waves : 16) * 64), 0, st, k);
@@ -365,9 +307,8 @@ int x264gpu_encode_frames(x264gpu_encoder *e, const uint8_t *d_i420, int slice_t
     if (ev) e->ev_mask[e->prof_calls++] = mask;
     HIP_TRY(hipGetLastError());
     e->cur = (e->cur + 1) % e->slots;
-    { int16_t *t = e->mvf[0]; e->mvf[0] = e->mvf[1]; e->mvf[1] = t; }
-    { int8_t *t = e->reff[0]; e->reff[0] = e->reff[1]; e->reff[1] = t; }
     e->have++;
+    e->poc += 2;
     return X264GPU_OK;
 }
 

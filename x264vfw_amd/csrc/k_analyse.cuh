@@ -1,5 +1,6 @@
-// k_analyse.cuh — P-frame macroblock analysis: motion estimation SAD/SATD pyramid (A2/A3) + the
-// intra-vs-inter estimate.  One wavefront per macroblock, four macroblocks per workgroup.
+// k_analyse.cuh — motion-estimation building blocks (A2/A3): LDS search window SADs, the staged sub-pel neighbourhood, the
+// chroma-ME term, and the candidate-parallel partition search the lookahead kernel uses.  The macroblock loop of the frame
+// pipeline is k_mb.cuh.
 //
 //   full-pel:  the reference search window (50 rows x 64 B, centred on the best start predictor) is
 //              staged in LDS with coalesced 8-byte loads; candidates are evaluated four at a time,
@@ -7,7 +8,6 @@
 //              reduction, then a packed (cost<<3|tag) wave min replaying x264's first-best tie-breaks.
 //   sub-pel:   half-pel diamond on SAD, quarter-pel diamond on SATD; the +-2 px neighbourhood of the full-pel
 //              winner in all four half-pel planes is staged in LDS once (sub_stage), SATD in the Z layout.
-// Restates oracle/encoder.c me_search_16x16 / intra16_estimate / analyse_p_mb bit-exactly.
 #pragma once
 #include "enc_common.cuh"
 
@@ -643,491 +643,6 @@ __device__ int search_parts(const PartCtx &c, const int SHAPE, int c0x, int c0y,
         out_mx = __shfl(mx, src); out_my = __shfl(my, src);
     } else { out_mx = mx; out_my = my; }
     return bcost;
-}
-
-template <int M, bool UMH, bool MIXED>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MIXED ? X264GPU_ANALYSE_WAVES_MIXED : X264GPU_ANALYSE_WAVES, 8))) void k_analyse_p(EncK k)
-{
-    __shared__ __attribute__((aligned(16))) uint8_t s_win[4][WIN_ROWS * WIN_STRIDE];
-    __shared__ uint8_t s_nb[4][NB_SIZE];
-    __shared__ uint16_t s_cost[4][2][192];
-    __shared__ uint32_t s_sub[4][SubGeo<M>::DWORDS];
-    __shared__ uint32_t s_csub[4][CSubGeo<M>::DWORDS];
-    // the wave index is uniform across the wavefront: readfirstlane tells the compiler, so the macroblock position and every pointer
-    // derived from it live in scalar registers
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
-    // Workgroups are dealt round-robin to the 8 XCDs (each with its own L2): give every XCD one contiguous
-    // eighth of the picture so the overlapping search windows of neighbouring macroblocks share an L2.
-    const int per_xcd = gridDim.x >> 3;
-    const int mbi = (((int)blockIdx.x & 7) * per_xcd + ((int)blockIdx.x >> 3)) * 4 + wave, s = blockIdx.y;
-    if (mbi >= k.nmb) return;                       // wave-uniform; no block-wide barriers below
-    const int mbx = mbi % k.mbw, mby = mbi / k.mbw;
-    uint8_t *win = s_win[wave];
-    uint8_t *nb = s_nb[wave];
-
-    const uint8_t *fenc = k.fenc_y + (size_t)s * k.fency_bytes + (size_t)mby * 16 * k.fs + mbx * 16;
-    const int px = mbx * 16, py = mby * 16;        // macroblock position in the picture
-
-    // current macroblock in both lane mappings
-    const int r = lane & 15, cnd = lane >> 4;       // (candidate, row) mapping
-    uint32_t cr[4];
-    { const uint4 v = *(const uint4 *)(fenc + (size_t)r * k.fs); cr[0] = v.x; cr[1] = v.y; cr[2] = v.z; cr[3] = v.w; }
-    const int zx = z_x0(lane), zy = z_y(lane);      // Z mapping
-    const uint32_t cz = *(const uint32_t *)(fenc + (size_t)zy * k.fs + zx);
-    // chroma-ME (subme >= 5): in the (candidate, row) mapping lane r owns row r & 3 of 4x4 chroma block r >> 2, both planes
-    const bool chroma_me = k.chroma_me && k.subme >= 5;
-    const uint8_t *fuv = k.fenc_uv + (size_t)s * k.fencuv_bytes + (size_t)mby * 8 * k.fs + px;
-    const int ccx = ((r >> 2) & 1) * 4, ccy = (r >> 3) * 4 + (r & 3);
-    uint32_t ce0 = 0, ce1 = 0;
-    if (chroma_me) { const uint2 v = *(const uint2 *)(fuv + (size_t)ccy * k.fs + 2 * ccx); ce0 = v.x; ce1 = v.y; }
-
-    // ---- motion vector limits (oracle mv_limits) ----
-    const int vrange = 512 * 4;
-    int smin0 = 4 * (-16 * mbx - 24), smax0 = 4 * (16 * (k.mbw - mbx - 1) + 24);
-    int smin1 = clampi(4 * (-16 * mby - 24), -vrange, vrange - 1), smax1 = clampi(4 * (16 * (k.mbh - mby - 1) + 24), -vrange, vrange - 1);
-    const int fmin0 = (smin0 >> 2) + 6, fmax0 = (smax0 >> 2) - 6, fmin1 = (smin1 >> 2) + 6, fmax1 = (smax1 >> 2) - 6;
-
-    // ---- predictor from the previous frame's MV field (oracle prev_mvp) ----
-    const int16_t *mvf = k.mvf_prev + (size_t)s * k.nmb * 2;
-    const int8_t *rf = k.reff_prev + (size_t)s * k.nmb;
-    int mvp0, mvp1;
-    {
-        int a0 = 0, a1 = 0, b0 = 0, b1 = 0, c0 = 0, c1 = 0;
-        const bool ia = mbx > 0, ib = mby > 0, ic = mby > 0 && mbx + 1 < k.mbw;
-        if (ia) { int i = mbi - 1; if (rf[i] >= 0) { a0 = mvf[2 * i]; a1 = mvf[2 * i + 1]; } }
-        if (ib) { int i = mbi - k.mbw; if (rf[i] >= 0) { b0 = mvf[2 * i]; b1 = mvf[2 * i + 1]; } }
-        if (ic) { int i = mbi - k.mbw + 1; if (rf[i] >= 0) { c0 = mvf[2 * i]; c1 = mvf[2 * i + 1]; } }
-        else if (mby > 0 && mbx > 0) { int i = mbi - k.mbw - 1; if (rf[i] >= 0) { c0 = mvf[2 * i]; c1 = mvf[2 * i + 1]; } }
-        if (!ib && ia) { mvp0 = a0; mvp1 = a1; }
-        else { mvp0 = median3(a0, b0, c0); mvp1 = median3(a1, b1, c1); }
-        // wave-uniform by construction; saying so keeps the predictor and the cost-table pointers derived from it in scalar registers
-        mvp0 = __builtin_amdgcn_readfirstlane(mvp0); mvp1 = __builtin_amdgcn_readfirstlane(mvp1);
-    }
-    // quantiser of this macroblock: the slice's, or its own under AQ (lambda and the mv-cost table follow it, as x264's a->i_qp)
-    // (readfirstlane: the value is wave-uniform, and saying so keeps lambda and the cost-table base in scalar registers)
-    const int mqp = k.mbqp ? __builtin_amdgcn_readfirstlane((int)k.mbqp[(size_t)s * k.nmb + mbi]) : k.qp, lambda = k.mbqp ? k.lambda_tab[mqp] : k.lambda;
-    const uint16_t *cost_base = k.mbqp ? k.cost_all + (size_t)mqp * 2 * MVCOST_HALF : k.cost_mv;
-    const uint16_t *cmx = cost_base + MVCOST_HALF - mvp0, *cmy = cost_base + MVCOST_HALF - mvp1;
-
-    // ---- 16x16 search in every usable reference (oracle analyse_p_mb); lower index wins ties ----
-    const size_t pb = k.plane_bytes;
-    int best_mx = 0, best_my = 0, best16 = 1 << 28, bref = 0, halfpel_thresh = 1 << 28;
-    int m16_0 = 0, m16_1 = 0, m16_2 = 0, m16_3 = 0;       // 16x16 vector found in each reference, packed (x | y << 16): start of the mixed-refs partition searches
-    for (int r_ = 0; r_ < k.nref; r_++) {
-        const uint8_t *p00 = ref_plane00(k, s, r_);
-        // ---- start candidates: predictor, zero, co-located (lane groups 0..2 evaluate one each) ----
-        int bmx, bmy, bcost, umh_mvd16;
-        {
-            int cx[3], cy[3];
-            cx[0] = clampi((mvp0 + 2) >> 2, fmin0, fmax0); cy[0] = clampi((mvp1 + 2) >> 2, fmin1, fmax1);
-            cx[1] = clampi(0, fmin0, fmax0); cy[1] = clampi(0, fmin1, fmax1);
-            const bool has_col = rf[mbi] >= 0;
-            cx[2] = has_col ? clampi((mvf[2 * mbi] + 2) >> 2, fmin0, fmax0) : 0;
-            cy[2] = has_col ? clampi((mvf[2 * mbi + 1] + 2) >> 2, fmin1, fmax1) : 0;
-            umh_mvd16 = has_col ? 4 * (abs(cx[1] - cx[2]) + abs(cy[1] - cy[2])) : 25;
-            const int c = cnd < 3 ? cnd : 0;
-            const int mx = c == 0 ? cx[0] : c == 1 ? cx[1] : cx[2], my = c == 0 ? cy[0] : c == 1 ? cy[1] : cy[2];
-            int sad = sad_row16_global(p00 + (long)(py + my + r) * k.rs + px + mx, cr);
-            sad = row16_sum(sad);
-            unsigned key = 0xffffffffu;
-            if (cnd < 2 || (cnd == 2 && has_col)) key = ((unsigned)(sad + cmx[mx * 4] + cmy[my * 4]) << 3) | (unsigned)cnd;
-            key = wave_min_u32(key);
-            const int best = key & 7;
-            bcost = (int)(key >> 3);
-            bmx = __builtin_amdgcn_readfirstlane(best == 0 ? cx[0] : best == 1 ? cx[1] : cx[2]);        // uniform (see `wave`)
-            bmy = __builtin_amdgcn_readfirstlane(best == 0 ? cy[0] : best == 1 ? cy[1] : cy[2]);
-        }
-
-        // ---- stage the search window in LDS ----
-        int wx0 = (px + bmx - WIN_R) & ~7, wy0 = py + bmy - WIN_R;
-        wx0 = clampi(wx0, -PAD, k.cw + PAD - WIN_COLS);
-        wy0 = clampi(wy0, -PAD, k.ch + PAD - WIN_ROWS);
-        if (!UMH)
-        for (int i = lane; i < WIN_ROWS * 8; i += 64) {
-            const int row = i >> 3, col = (i & 7) * 8;
-            const uint2 v = *(const uint2 *)(p00 + (long)(wy0 + row) * k.rs + wx0 + col);
-            uint32_t *d = (uint32_t *)(win + row * WIN_STRIDE + col);
-            d[0] = v.x; d[1] = v.y;
-        }
-        // mv-cost table slices around the start vector into LDS: every later cost lookup of this search is an
-        // LDS read instead of a dependent global load (hex moves <= 17 px, sub-pel <= 1 px: |delta| < 96 qpel)
-        const int cbx = bmx * 4, cby = bmy * 4;
-        for (int i = lane; i < 192; i += 64) {
-            s_cost[wave][0][i] = cmx[cbx + i - 96];
-            s_cost[wave][1][i] = cmy[cby + i - 96];
-        }
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_s_waitcnt(0xc07f);
-    #define MVC(qx, qy) (UMH ? (int)cmx[qx] + (int)cmy[qy] : (int)s_cost[wave][0][(qx) - cbx + 96] + (int)s_cost[wave][1][(qy) - cby + 96])
-
-        // cost of full-pel candidate (mx,my) for this lane's row; valid after row16_sum on the 16-lane group
-    #define FPEL_KEY(mx, my, tag) \
-        (((unsigned)(row16_sum(sad_row16_lds(win + (py + (my) + r - wy0) * WIN_STRIDE, px + (mx) - wx0, cr)) + MVC((mx) * 4, (my) * 4)) << 3) | (unsigned)(tag))
-
-        if (UMH) {
-            // ---- X264_ME_UMH (global-memory search, see umh_fullpel); mvc = {zero, co-located} ----
-            PartCtx u;
-            u.p00 = p00; u.rs = k.rs; u.px = px; u.py = py; u.fenc = fenc; u.fs = k.fs; u.lane = lane; u.me_range = k.me_range; u.me_method = 2;
-            u.fmin0 = fmin0; u.fmax0 = fmax0; u.fmin1 = fmin1; u.fmax1 = fmax1; u.gcx = cmx; u.gcy = cmy; u.mvp0 = mvp0; u.mvp1 = mvp1;
-            umh_fullpel(u, 0, 0, umh_mvd16, bmx, bmy, bcost);
-        } else if (k.me_method == 3) {
-            // ---- X264_ME_ESA (oracle me_search_block, me_method 3): every position of the clipped +-merange rectangle, four per pass
-            // (one per lane group), raster order with "strictly better wins" = minimum of (cost << 11 | raster index) ----
-            const int rr = k.me_range;
-            const int min_x = max(bmx - rr, fmin0), min_y = max(bmy - rr, fmin1), max_x = min(bmx + rr, fmax0), max_y = min(bmy + rr, fmax1);
-            const int width = (max_x - min_x + 3) & ~3;
-            unsigned kmin = 0xffffffffu;
-            for (int my = min_y; my <= max_y; my++)
-                for (int x4 = 0; x4 < width; x4 += 4) {
-                    const int mx = min_x + x4 + cnd;
-                    const unsigned cst = (unsigned)(row16_sum(sad_row16_lds(win + (py + my + r - wy0) * WIN_STRIDE, px + mx - wx0, cr)) + MVC(mx * 4, my * 4));
-                    kmin = min(kmin, (cst << 11) | (unsigned)((my - min_y) * width + x4 + cnd));
-                }
-            kmin = wave_min_u32(kmin);
-            if (kmin != 0xffffffffu && (int)(kmin >> 11) < bcost) {
-                const int idx = (int)(kmin & 2047);
-                bcost = (int)(kmin >> 11); bmx = min_x + idx % width; bmy = min_y + idx / width;
-            }
-        } else if (k.me_method == 0) {
-            // ---- X264_ME_DIA: the four neighbours are exactly the four lane groups; centre wins ties ----
-            int it = k.me_range;
-            do {
-                const unsigned kk = wave_min_u32(((FPEL_KEY(bmx + (cnd == 2 ? -1 : cnd == 3 ? 1 : 0), bmy + (cnd == 0 ? -1 : cnd == 1 ? 1 : 0), 0) >> 3) << 2) | (unsigned)cnd);
-                if ((int)(kk >> 2) >= bcost) break;
-                const int q = kk & 3;
-                bcost = (int)(kk >> 2);
-                bmx += q == 2 ? -1 : q == 3 ? 1 : 0; bmy += q == 0 ? -1 : q == 1 ? 1 : 0;
-            } while (--it && bmx >= fmin0 && bmx <= fmax0 && bmy >= fmin1 && bmy <= fmax1);
-        } else
-        // ---- hexagon search ----
-        {
-            unsigned key = (unsigned)bcost << 3;
-            // first ring: hex2[1..6], tags 2..7 (two passes of four lane groups)
-            {
-                int i = 1 + cnd;                                   // hex2 index 1..4
-                unsigned kk = FPEL_KEY(bmx + hex_dx(i), bmy + hex_dy(i), i + 1);
-                key = min(key, wave_min_u32(kk));
-                i = 5 + (cnd & 1);                                 // hex2 index 5..6
-                kk = FPEL_KEY(bmx + hex_dx(i), bmy + hex_dy(i), i + 1);
-                if (cnd >= 2) kk = 0xffffffffu;
-                key = min(key, wave_min_u32(kk));
-            }
-            if (key & 7) {
-                int dir = (int)(key & 7) - 2;
-                bmx += hex_dx(dir + 1); bmy += hex_dy(dir + 1);
-                for (int it = (k.me_range >> 1) - 1; it > 0 && bmx >= fmin0 && bmx <= fmax0 && bmy >= fmin1 && bmy <= fmax1; it--) {
-                    key &= ~7u;
-                    const int c = cnd < 3 ? cnd : 0;
-                    unsigned kk = FPEL_KEY(bmx + hex_dx(dir + c), bmy + hex_dy(dir + c), c + 1);
-                    if (cnd >= 3) kk = 0xffffffffu;
-                    key = min(key, wave_min_u32(kk));
-                    if (!(key & 7)) break;
-                    dir += (int)(key & 7) - 2;
-                    dir = dir < 0 ? 5 : dir > 5 ? 0 : dir;         // mod6m1
-                    bmx += hex_dx(dir + 1); bmy += hex_dy(dir + 1);
-                }
-            }
-            bcost = (int)(key >> 3);
-            // square refine: square1[1..8]; first strictly-better candidate in order wins
-            unsigned sk = ((unsigned)bcost << 4);
-            {
-                int q = 1 + cnd;
-                unsigned kk = (FPEL_KEY(bmx + sq_dx(q), bmy + sq_dy(q), 0) << 1) | (unsigned)q;
-                sk = min(sk, wave_min_u32(kk));
-                q = 5 + cnd;
-                kk = (FPEL_KEY(bmx + sq_dx(q), bmy + sq_dy(q), 0) << 1) | (unsigned)q;
-                sk = min(sk, wave_min_u32(kk));
-            }
-            const int bd = sk & 15;
-            bcost = (int)(sk >> 4);
-            if (bd) { bmx += sq_dx(bd); bmy += sq_dy(bd); }
-        }
-    #undef FPEL_KEY
-
-        // ---- sub-pel refinement ----
-        int mx = bmx * 4, my = bmy * 4;
-        if (k.subme >= 2) {
-            const int sub = min(k.subme, 11);
-            const int hp_it = sub < 6 ? 1 : sub < 8 ? 2 : 4;
-            const int qp_it = sub < 4 ? 0 : sub == 4 ? 1 : sub < 8 ? 2 : 10;
-            // the whole refinement reads the staged neighbourhood of the full-pel winner
-            uint32_t *sb = s_sub[wave];
-            const int sx0 = (px + bmx - M) & ~3, sy0 = py + bmy - M, rwl = 3, sn = SubGeo<M>::rh(16) << 3;
-            sub_stage<M>(sb, p00, pb, k.rs, sx0, sy0, rwl, SubGeo<M>::rh(16), SubGeo<M>::ncol(16), lane, 64);
-            uint32_t *cb = s_csub[wave];
-            const int cndw = CSubGeo<M>::ndw(8), cnr = CSubGeo<M>::rows(8);
-            const int cx0c = ((px >> 1) + (bmx >> 1) - CSubGeo<M>::MG) & ~1, cy0c = (py >> 1) + (bmy >> 1) - CSubGeo<M>::MG;
-            if (chroma_me) chroma_stage(cb, ref_chroma00(k, s, r_), k.rs, cx0c, cy0c, cndw, cnr, lane, 64);
-            __builtin_amdgcn_wave_barrier();
-            __builtin_amdgcn_s_waitcnt(0xc07f);
-            // half-pel diamond, SAD, lane = (candidate, row): (0,-2) (0,2) (-2,0) (2,0)
-            for (int it = hp_it; it > 0; it--) {
-                const int cx = mx + (cnd == 2 ? -2 : cnd == 3 ? 2 : 0), cy = my + (cnd == 0 ? -2 : cnd == 1 ? 2 : 0);
-                const int sd = sub_sad_row16_hpel(sb, sn, rwl, sx0, sy0, px, py + r, cx, cy, cr);
-                unsigned key = ((unsigned)(row16_sum(sd) + MVC(cx, cy)) << 2) | (unsigned)cnd;
-                key = wave_min_u32(key);
-                if ((int)(key >> 2) < bcost) {
-                    const int b = key & 3;
-                    bcost = (int)(key >> 2);
-                    mx += b == 2 ? -2 : b == 3 ? 2 : 0; my += b == 0 ? -2 : b == 1 ? 2 : 0;
-                } else break;
-            }
-            // SATD at the best half-pel position
-            {
-                bcost = wave_sum(satd4_half(cz, sub_row4(sb, sn, rwl, sx0, sy0, px + zx, py + zy, mx, my), lane)) + MVC(mx, my);
-                if (chroma_me) bcost += row16_sum(chroma_me_lds(cb, cndw, cx0c, cy0c, (px >> 1) + ccx, (py >> 1) + ccy, mx, my, ce0, ce1,
-                                                                pk_sign(lane & 1), pk_sign(lane & 2)));
-            }
-            // early termination when examining several references (x264 refine_subpel, p_halfpel_thresh): a reference whose
-            // half-pel SATD cost exceeds 8/7 of the best so far skips its quarter-pel diamond
-            bool skip_qpel = false;
-            if (k.nref > 1) {
-                if (((bcost * 7) >> 3) > halfpel_thresh) skip_qpel = true;
-                else if (bcost < halfpel_thresh) halfpel_thresh = bcost;
-            }
-            // quarter-pel diamond, SATD: (0,-1) (0,1) (-1,0) (1,0), never stepping straight back.  The four
-            // candidates are independent, so they run at once in the (candidate, row) mapping: a quad of
-            // lanes = 4 rows x 16 columns = four 4x4 blocks (packed-16 Hadamard), a DPP row = one candidate.
-            // min over (cost<<2 | q) == x264's in-order "first strictly better" update.
-            int bdir = -1;
-            const s16x2 sg1 = pk_sign(lane & 1), sg2 = pk_sign(lane & 2);
-            for (int it = skip_qpel ? 0 : qp_it; it > 0; it--) {
-                if (my <= smin1 || my >= smax1 || mx <= smin0 || mx >= smax0) break;
-                const int cx = mx + (cnd == 2 ? -1 : cnd == 3 ? 1 : 0), cy = my + (cnd == 0 ? -1 : cnd == 1 ? 1 : 0);
-                uint32_t pr[4];
-                sub_row16(sb, sn, rwl, sx0, sy0, px, py + r, cx, cy, pr);
-                int cst = row16_sum(satd16x4_half_pk(cr, pr, sg1, sg2)) + MVC(cx, cy);
-                if (chroma_me && __any(cst < bcost && (cnd ^ 1) != bdir))
-                    cst += row16_sum(chroma_me_lds(cb, cndw, cx0c, cy0c, (px >> 1) + ccx, (py >> 1) + ccy, cx, cy, ce0, ce1, sg1, sg2));
-                unsigned key = ((unsigned)cst << 2) | (unsigned)cnd;
-                if ((cnd ^ 1) == bdir) key = 0xffffffffu;
-                key = wave_min_u32(key);
-                if ((int)(key >> 2) >= bcost) break;
-                bcost = (int)(key >> 2);
-                bdir = key & 3;
-                mx += bdir == 2 ? -1 : bdir == 3 ? 1 : 0; my += bdir == 0 ? -1 : bdir == 1 ? 1 : 0;
-            }
-        }
-
-    #undef MVC
-        if (MIXED) { const int pk = (mx & 0xffff) | (my << 16); if (r_ == 0) m16_0 = pk; else if (r_ == 1) m16_1 = pk; else if (r_ == 2) m16_2 = pk; else m16_3 = pk; }
-        bcost += lambda * ref_bits(k.nref, r_);
-        if (bcost < best16) { best16 = bcost; best_mx = mx; best_my = my; bref = r_; }
-        __builtin_amdgcn_wave_barrier();
-    }
-    const uint8_t *p00 = ref_plane00(k, s, bref);
-    int mx = best_mx, my = best_my, bcost = best16;
-
-    // ---- sub-partitions (oracle analyse_p_mb): 8x8 first, 16x8 / 8x16 only if 8x8 beat 16x16 ----
-    // Without mixed refs every partition is searched in the 16x16 winner's reference.  With them (x264 --mixed-refs) each 8x8 block
-    // is searched in every reference from that reference's 16x16 vector and keeps the cheapest (cost + ref bits); the 16x8 / 8x16
-    // halves then try the references of their two 8x8 blocks, the first block's reference winning ties.  One search_parts call
-    // site serves all of it: the loop below walks (shape, reference) jobs.
-    const int cost16 = bcost;
-    int best_cost = bcost, best_shape = 0;
-    int lmx = mx, lmy = my, lref = bref;            // this lane's 8x8 block's motion vector / reference (lane>>4 = 8x8 index)
-    if (!MIXED && (k.partitions & 1)) {
-        // plain path: every partition in the 16x16 winner's reference, one staging of the window
-        const int c0x = clampi((mx + 2) >> 2, fmin0, fmax0), c0y = clampi((my + 2) >> 2, fmin1, fmax1);
-        int pwx0 = clampi((px + c0x - WIN_R) & ~7, -PAD, k.cw + PAD - WIN_COLS), pwy0 = clampi(py + c0y - WIN_R, -PAD, k.ch + PAD - WIN_ROWS);
-        __builtin_amdgcn_wave_barrier();
-        if (!UMH)
-        for (int i = lane; i < WIN_ROWS * 8; i += 64) {
-            const int row = i >> 3, col = (i & 7) * 8;
-            const uint2 v = *(const uint2 *)(p00 + (long)(pwy0 + row) * k.rs + pwx0 + col);
-            uint32_t *d = (uint32_t *)(win + row * WIN_STRIDE + col);
-            d[0] = v.x; d[1] = v.y;
-        }
-        for (int i = lane; i < 192; i += 64) {
-            s_cost[wave][0][i] = cmx[c0x * 4 + i - 96];
-            s_cost[wave][1][i] = cmy[c0y * 4 + i - 96];
-        }
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_s_waitcnt(0xc07f);
-        PartCtx pc;
-        pc.win = win; pc.wx0 = pwx0; pc.wy0 = pwy0; pc.cx = s_cost[wave][0]; pc.cy = s_cost[wave][1]; pc.cbx = c0x * 4; pc.cby = c0y * 4;
-        pc.p00 = p00; pc.pb = k.plane_bytes; pc.rs = k.rs; pc.px = px; pc.py = py; pc.zx = zx; pc.zy = zy; pc.cz = cz;
-        pc.fmin0 = fmin0; pc.fmax0 = fmax0; pc.fmin1 = fmin1; pc.fmax1 = fmax1; pc.smin0 = smin0; pc.smax0 = smax0; pc.smin1 = smin1; pc.smax1 = smax1;
-        pc.me_range = k.me_range; pc.me_method = k.me_method; pc.lane = lane; pc.sub = s_sub[wave]; pc.fenc = fenc; pc.fs = k.fs;
-        pc.chroma_me = chroma_me; pc.cref = ref_chroma00(k, s, bref); pc.fuv = fuv; pc.csub = s_csub[wave];
-        pc.gcx = cmx; pc.gcy = cmy; pc.mvp0 = mvp0; pc.mvp1 = mvp1; pc.la_mode = false;
-        const int sub = min(k.subme, 11);
-        pc.hp_it = sub < 2 ? 0 : sub < 6 ? 1 : sub < 8 ? 2 : 4;
-        pc.qp_it = sub < 4 ? 0 : sub == 4 ? 1 : sub < 8 ? 2 : 10;
-        for (int oi = 0; oi < 3; oi++) {
-            const int shape = oi == 0 ? 3 : oi;
-            if (oi > 0 && best_shape == 0) break;
-            int smx, smy;
-            const int pcost = search_parts<M, UMH>(pc, shape, c0x, c0y, smx, smy);
-            int total = lambda * ((shape == 3 ? 8 : 2) + (shape == 3 ? 4 : 2) * ref_bits(k.nref, bref));
-            if (shape == 3) total += __builtin_amdgcn_readlane(pcost, 0) + __builtin_amdgcn_readlane(pcost, 16) + __builtin_amdgcn_readlane(pcost, 32) + __builtin_amdgcn_readlane(pcost, 48);
-            else if (shape == 1) total += __builtin_amdgcn_readlane(pcost, 0) + __builtin_amdgcn_readlane(pcost, 32);
-            else total += __builtin_amdgcn_readlane(pcost, 0) + __builtin_amdgcn_readlane(pcost, 32);      // 8x16: partitions on lanes 0.. and 32..
-            if (total < best_cost) { best_cost = total; best_shape = shape; lmx = smx; lmy = smy; }
-        }
-    }
-    if (MIXED && (k.partitions & 1)) {
-        const bool mixed = MIXED && k.nref > 1;         // MIXED is its own kernel instantiation: the plain one keeps its registers
-        PartCtx pc;
-        pc.win = win; pc.cx = s_cost[wave][0]; pc.cy = s_cost[wave][1];
-        pc.pb = k.plane_bytes; pc.rs = k.rs; pc.px = px; pc.py = py; pc.zx = zx; pc.zy = zy; pc.cz = cz;
-        pc.fmin0 = fmin0; pc.fmax0 = fmax0; pc.fmin1 = fmin1; pc.fmax1 = fmax1; pc.smin0 = smin0; pc.smax0 = smax0; pc.smin1 = smin1; pc.smax1 = smax1;
-        pc.me_range = k.me_range; pc.me_method = k.me_method; pc.lane = lane; pc.sub = s_sub[wave]; pc.fenc = fenc; pc.fs = k.fs;
-        pc.chroma_me = chroma_me; pc.fuv = fuv; pc.csub = s_csub[wave];
-        pc.gcx = cmx; pc.gcy = cmy; pc.mvp0 = mvp0; pc.mvp1 = mvp1; pc.la_mode = false;
-        const int sub = min(k.subme, 11);
-        pc.hp_it = sub < 2 ? 0 : sub < 6 ? 1 : sub < 8 ? 2 : 4;
-        pc.qp_it = sub < 4 ? 0 : sub == 4 ? 1 : sub < 8 ? 2 : 10;
-        int ref8 = bref;                            // reference chosen by this lane's 8x8 block (shape 3 pass)
-        // x264's early termination of the mixed-refs 8x8 pass (oracle analyse_p_mb): when 16x16 chose reference 0, no reference
-        // older than those of the previous picture's left / top / top-left / top-right / co-located macroblocks is tried
-        int maxref = k.nref - 1;
-        if (mixed && bref == 0 && mbx > 0 && mby > 0) {
-            int m0 = max((int)rf[mbi - 1], (int)rf[mbi - k.mbw]);
-            m0 = max(m0, max((int)rf[mbi - k.mbw - 1], (int)rf[mbx + 1 < k.mbw ? mbi - k.mbw + 1 : mbi]));
-            maxref = __builtin_amdgcn_readfirstlane(min(max(max(m0, (int)rf[mbi]), 0), k.nref - 1));
-        }
-        for (int ph = 0; ph < 3; ph++) {
-            const int shape = ph == 0 ? 3 : ph;
-            if (ph > 0 && best_shape == 0) break;
-            // candidate references of this lane's partition (mixed, 16x8 / 8x16): those of its two 8x8 blocks
-            int first_ref = bref, second_ref = bref;
-            if (mixed && ph > 0) {
-                const int p32 = lane >> 5;
-                first_ref = __shfl(ref8, shape == 1 ? p32 * 32 : p32 * 16);
-                second_ref = __shfl(ref8, shape == 1 ? p32 * 32 + 16 : p32 * 16 + 32);
-            }
-            unsigned pkey = 0xffffffffu;            // this lane's partition: best (cost << 1 | not-the-first-block's-reference)
-            int pmx = 0, pmy = 0, pref = 0;
-            for (int r = 0; r < k.nref; r++) {
-                const bool need = !mixed ? r == bref : ph == 0 ? r <= maxref : (r == first_ref || r == second_ref);
-                if (!__any(need)) continue;
-                // ---- stage the search window and the mv-cost slices around reference r's 16x16 vector ----
-                const int pk = mixed ? (r == 0 ? m16_0 : r == 1 ? m16_1 : r == 2 ? m16_2 : m16_3) : ((mx & 0xffff) | (my << 16));
-                const int qx = (int)(short)(pk & 0xffff), qy = pk >> 16;
-                const int c0x = clampi((qx + 2) >> 2, fmin0, fmax0), c0y = clampi((qy + 2) >> 2, fmin1, fmax1);
-                const uint8_t *pr = ref_plane00(k, s, r);
-                const int pwx0 = clampi((px + c0x - WIN_R) & ~7, -PAD, k.cw + PAD - WIN_COLS), pwy0 = clampi(py + c0y - WIN_R, -PAD, k.ch + PAD - WIN_ROWS);
-                __builtin_amdgcn_wave_barrier();
-                if (!UMH)
-                for (int i = lane; i < WIN_ROWS * 8; i += 64) {
-                    const int row = i >> 3, col = (i & 7) * 8;
-                    const uint2 v = *(const uint2 *)(pr + (long)(pwy0 + row) * k.rs + pwx0 + col);
-                    uint32_t *d = (uint32_t *)(win + row * WIN_STRIDE + col);
-                    d[0] = v.x; d[1] = v.y;
-                }
-                for (int i = lane; i < 192; i += 64) {
-                    s_cost[wave][0][i] = cmx[c0x * 4 + i - 96];
-                    s_cost[wave][1][i] = cmy[c0y * 4 + i - 96];
-                }
-                __builtin_amdgcn_wave_barrier();
-                __builtin_amdgcn_s_waitcnt(0xc07f);
-                pc.wx0 = pwx0; pc.wy0 = pwy0; pc.cbx = c0x * 4; pc.cby = c0y * 4; pc.p00 = pr; pc.cref = ref_chroma00(k, s, r);
-                int smx, smy;
-                const int pcost = search_parts<M, UMH>(pc, shape, c0x, c0y, smx, smy);
-                if (shape == 2) { smx = __shfl(smx, (lane >> 5) * 16); smy = __shfl(smy, (lane >> 5) * 16); }      // back to partition lanes
-                const unsigned key = ((unsigned)(pcost + (mixed ? lambda * ref_bits(k.nref, r) : 0)) << 1) | (mixed && ph > 0 && r != first_ref ? 1u : 0u);
-                if (need && key < pkey) { pkey = key; pmx = smx; pmy = smy; pref = r; }
-            }
-            const int pcst = (int)(pkey >> 1);
-            int total = lambda * ((shape == 3 ? 8 : 2) + (mixed ? 0 : (shape == 3 ? 4 : 2) * ref_bits(k.nref, bref)));
-            if (shape == 3) total += __builtin_amdgcn_readlane(pcst, 0) + __builtin_amdgcn_readlane(pcst, 16) + __builtin_amdgcn_readlane(pcst, 32) + __builtin_amdgcn_readlane(pcst, 48);
-            else total += __builtin_amdgcn_readlane(pcst, 0) + __builtin_amdgcn_readlane(pcst, 32);                  // two partitions, on lanes 0.. and 32..
-            if (ph == 0) ref8 = pref;
-            if (total < best_cost) {
-                best_cost = total; best_shape = shape;
-                if (shape == 2) {       // 8x16: partition k owns lanes 32k.., the record is indexed by 8x8 block (lane >> 4): blocks 1, 3 are partition 1
-                    const int src = ((lane >> 4) & 1) * 32;
-                    lmx = __shfl(pmx, src); lmy = __shfl(pmy, src); lref = __shfl(pref, src);
-                } else { lmx = pmx; lmy = pmy; lref = pref; }
-            }
-        }
-    }
-    bcost = best_cost;
-
-    // ---- intra 16x16 estimate on source neighbours (oracle intra16_estimate) ----
-    const bool left = mbx > 0, top = mby > 0;
-    if (lane < 25) nb[NB_TOP - 1 + lane] = (top && (lane > 0 || left)) ? fenc[-(long)k.fs - 1 + lane] : 128;   // tl + top[0..23]
-    if (lane < 16) nb[NB_LEFT + lane] = left ? fenc[(long)lane * k.fs - 1] : 128;
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_s_waitcnt(0xc07f);
-    int icost = 1 << 28;
-    {
-        const Pred16 pp = pred16_setup(nb, lane);
-        int modes[4], n = 0;
-        if (left && top) { modes[0] = PRED16_V; modes[1] = PRED16_H; modes[2] = PRED16_DC; modes[3] = PRED16_P; n = 4; }
-        else if (left) { modes[0] = PRED16_H; modes[1] = PRED16_DC_LEFT; n = 2; }
-        else if (top) { modes[0] = PRED16_V; modes[1] = PRED16_DC_TOP; n = 2; }
-        else { modes[0] = PRED16_DC_128; n = 1; }
-        for (int i = 0; i < n; i++) {
-            const int m = modes[i], sig = m > PRED16_P ? PRED16_DC : m;
-            const int c = wave_sum(satd4_half(cz, pred16_row4(nb, pp, m, zx, zy), lane)) + lambda * bs_size_ue(sig);
-            icost = min(icost, c);
-        }
-    }
-
-    // ---- chroma intra estimate on source neighbours (oracle intra_chroma_estimate): lanes 0..31, plane = lane >> 4 ----
-    if (chroma_me) {
-        __builtin_amdgcn_wave_barrier();
-        const int c = (lane >> 4) & 1, ci = (lane >> 2) & 3, j = lane & 3, cx0 = (ci & 1) * 4, cyy = (ci >> 1) * 4 + j;
-        uint8_t *cnb = nb + c * CNB_SIZE;             // the luma neighbour array is free again (2 x 20 <= 48 bytes)
-        {
-            const int t = lane & 15, pl = (lane >> 4) & 1;
-            if (lane < 32) {
-                if (t < 9) { const int x = t - 1; nb[pl * CNB_SIZE + CNB_TOP + x] = (top && (x >= 0 || left)) ? fuv[-(long)k.fs + 2 * x + pl] : 128; }
-            } else if (lane < 48) {
-                const int y = t & 7, pl2 = (t >> 3) & 1;
-                nb[pl2 * CNB_SIZE + CNB_LEFT + y] = left ? fuv[(long)y * k.fs - 2 + pl2] : 128;
-            }
-        }
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_s_waitcnt(0xc07f);
-        const PredC pc = predc_setup(cnb);
-        const uint2 fe = *(const uint2 *)(fuv + (size_t)cyy * k.fs + 2 * cx0);
-        const uint32_t cenc = nv12_pick(fe.x, fe.y, c);
-        int modes[4], n;
-        if (left && top) { modes[0] = PREDC_DC; modes[1] = PREDC_H; modes[2] = PREDC_V; modes[3] = PREDC_P; n = 4; }
-        else if (left) { modes[0] = PREDC_DC_LEFT; modes[1] = PREDC_H; n = 2; }
-        else if (top) { modes[0] = PREDC_DC_TOP; modes[1] = PREDC_V; n = 2; }
-        else { modes[0] = PREDC_DC_128; n = 1; }
-        int bestc = 1 << 28;
-        for (int i = 0; i < n; i++) {
-            const int m = modes[i], sig = m > PREDC_P ? PREDC_DC : m;
-            const int hs = satd4_half(cenc, predc_row4(cnb, pc, m, ci, j), lane);
-            bestc = min(bestc, wave_sum(lane < 32 ? hs : 0) + lambda * bs_size_ue(sig));
-        }
-        icost += bestc;
-    }
-
-    // ---- record ----
-    const int m0x = __builtin_amdgcn_readlane(lmx, 0), m0y = __builtin_amdgcn_readlane(lmy, 0);
-    const int m1x = __builtin_amdgcn_readlane(lmx, 16), m1y = __builtin_amdgcn_readlane(lmy, 16);
-    const int m2x = __builtin_amdgcn_readlane(lmx, 32), m2y = __builtin_amdgcn_readlane(lmy, 32);
-    const int m3x = __builtin_amdgcn_readlane(lmx, 48), m3y = __builtin_amdgcn_readlane(lmy, 48);
-    const int r0b = __builtin_amdgcn_readlane(lref, 0), r1b = __builtin_amdgcn_readlane(lref, 16), r2b = __builtin_amdgcn_readlane(lref, 32), r3b = __builtin_amdgcn_readlane(lref, 48);
-    if (lane == 0) {
-        x264gpu_mb *mb = k.mb + (size_t)s * k.nmb + mbi;
-        x264gpu_mb rec;
-        __builtin_memset(&rec, 0, sizeof(rec));
-        rec.qp = (uint8_t)mqp;
-        rec.aux[0] = bcost; rec.aux[1] = icost; rec.aux[2] = cost16;
-        int16_t *mo = k.mvf_cur + ((size_t)s * k.nmb + mbi) * 2;
-        if (icost < bcost) {
-            rec.type = X264GPU_MB_I16x16;
-            rec.cost = icost;
-            for (int i = 0; i < 4; i++) rec.ref[i] = -1;
-            k.reff_cur[(size_t)s * k.nmb + mbi] = -1; mo[0] = 0; mo[1] = 0;
-        } else {
-            rec.type = best_shape == 3 ? X264GPU_MB_P_8x8 : X264GPU_MB_P_L0;
-            rec.partition = (uint8_t)best_shape;
-            rec.cost = bcost;
-            rec.mv[0][0] = (int16_t)m0x; rec.mv[0][1] = (int16_t)m0y; rec.mv[1][0] = (int16_t)m1x; rec.mv[1][1] = (int16_t)m1y;
-            rec.mv[2][0] = (int16_t)m2x; rec.mv[2][1] = (int16_t)m2y; rec.mv[3][0] = (int16_t)m3x; rec.mv[3][1] = (int16_t)m3y;
-            rec.ref[0] = (int8_t)r0b; rec.ref[1] = (int8_t)r1b; rec.ref[2] = (int8_t)r2b; rec.ref[3] = (int8_t)r3b;
-            k.reff_cur[(size_t)s * k.nmb + mbi] = (int8_t)max(max(r0b, r1b), max(r2b, r3b)); mo[0] = (int16_t)mx; mo[1] = (int16_t)my;     // fields: oldest reference used, 16x16 vector
-        }
-        *mb = rec;
-    }
 }
 
 }  // namespace x264gpu

@@ -1,7 +1,7 @@
 // k_deblock.cuh — in-loop deblocking filter (A9; H.264 8.7) as a 2-D wavefront.  The normative
-// macroblock order (left, top and top-right neighbours first) makes this a d = x + 2y wavefront; as in
-// k_intra one 1024-thread workgroup per stream walks the diagonals with workgroup barriers.  Each
-// wavefront stages its macroblock (+4 rows / 4 columns of neighbours) in LDS, runs the four vertical
+// macroblock order (left, top and top-right neighbours first) makes this a d = x + 2y wavefront: one
+// workgroup per stream (or several, few streams in flight), rows handed off through progress counters.  Each
+// wavefront stages its macroblocks (+4 rows / 4 columns of neighbours) in LDS, runs the four vertical
 // then four horizontal edges there (luma on lanes 0..15, chroma on lanes 16..31 in the same step), and
 // writes back only the samples the standard lets this macroblock modify.
 // Restates oracle/encoder.c deblock_frame + oracle/deblock.c bit-exactly.
@@ -32,14 +32,6 @@ constexpr int DC_STRIDE = 24;                  // chroma NV12 tile: rows -2..7, 
 constexpr int DC_ORG = 2 * DC_STRIDE + 4;
 constexpr int DC_SIZE = 10 * DC_STRIDE;
 constexpr int WF_MAX_ROWS = 160;               // macroblock rows supported by the wavefront kernels (2304/16 = 144)
-
-struct DeblockLds {
-    uint8_t lt[16][DL_SIZE];
-    uint8_t ct[16][DC_SIZE];
-    x264gpu_mb rec[16][3];                     // per wave: Q, left P, top P
-    int progress[WF_MAX_ROWS];                 // macroblocks completed per row (workgroup-local wavefront sync)
-    uint8_t alpha[52], beta[52], tc0[52][4], cqp[52];
-};
 
 __device__ __forceinline__ bool mb_is_intra(int type) { return type == X264GPU_MB_I4x4 || type == X264GPU_MB_I8x8 || type == X264GPU_MB_I16x16; }
 
@@ -103,165 +95,6 @@ __device__ __forceinline__ void filter_chroma_line(uint8_t *pix, int xs, int alp
     } else {
         pix[-xs] = (uint8_t)((2 * p1 + p0 + q1 + 2) >> 2);
         pix[0] = (uint8_t)((2 * q1 + q0 + p1 + 2) >> 2);
-    }
-}
-
-// ---- workgroup-local wavefront synchronisation (all waves of the workgroup live on one CU) ----
-__device__ __forceinline__ void wf_wait(volatile int *progress, int row, int need)
-{
-    if (row < 0) return;
-    while (progress[row] < need) __builtin_amdgcn_s_sleep(2);
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-}
-__device__ __forceinline__ void wf_signal(volatile int *progress, int row, int done, int lane)
-{
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");   // this wave's global stores are complete first
-    if (lane == 0) progress[row] = done;
-}
-
-__device__ void deblock_mb_wave(const EncK &k, DeblockLds &L, int wave, int lane, int s, int mbx, int mby)
-{
-    uint8_t *lt = L.lt[wave] + DL_ORG, *ct = L.ct[wave] + DC_ORG;
-    const x264gpu_mb *mbs = k.mb + (size_t)s * k.nmb;
-    const x264gpu_mb *gQ = mbs + mby * k.mbw + mbx;
-    uint8_t *Y = rec_plane00(k, s) + (size_t)(mby * 16) * k.rs + mbx * 16;
-    uint8_t *UV = rec_chroma00(k, s) + (size_t)(mby * 8) * k.rs + mbx * 16;
-
-    // ---- one round trip: pixel neighbourhood + the three macroblock records into LDS ----
-    for (int i = lane; i < 20 * 5; i += 64) {
-        const int r = i / 5 - 4, c = (i % 5) * 4 - 4;
-        *(uint32_t *)(lt + r * DL_STRIDE + c) = *(const uint32_t *)(Y + (long)r * k.rs + c);
-    }
-    if (lane < 50) {
-        const int r = lane / 5 - 2, c = (lane % 5) * 4 - 4;
-        *(uint32_t *)(ct + r * DC_STRIDE + c) = *(const uint32_t *)(UV + (long)r * k.rs + c);
-    }
-    if (lane < 48) {
-        const int which = lane >> 4, w = lane & 15;
-        const x264gpu_mb *src = which == 0 ? gQ : which == 1 ? (mbx > 0 ? gQ - 1 : gQ) : (mby > 0 ? gQ - k.mbw : gQ);
-        ((uint32_t *)&L.rec[wave][which])[w] = ((const uint32_t *)src)[w];
-    }
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_s_waitcnt(0xc07f);
-
-    const x264gpu_mb *Q = &L.rec[wave][0];
-    // nothing to do when every edge segment of the macroblock has bS 0 (uniform motion, no coefficients): skip the
-    // eight edge steps and the write-back.  Lane = (dir, edge, segment).
-    {
-        bool any = false;
-        if (lane < 32) {
-            const int dir = lane >> 4, edge = (lane >> 2) & 3, seg = lane & 3;
-            const bool skip_edge = ((edge & 1) && Q->transform8x8) || (edge == 0 && (dir == 0 ? mbx == 0 : mby == 0));
-            if (!skip_edge) {
-                const x264gpu_mb *P = edge == 0 ? &L.rec[wave][dir == 0 ? 1 : 2] : Q;
-                const int qbx = dir == 0 ? edge : seg, qby = dir == 0 ? seg : edge;
-                const int pbx = dir == 0 ? (edge + 3) & 3 : seg, pby = dir == 0 ? seg : (edge + 3) & 3;
-                any = edge_bs(P, pbx, pby, Q, qbx, qby, edge == 0) != 0;
-            }
-        }
-        if (!__ballot(any)) return;
-    }
-    const int qpq = Q->qp, qpcq = L.cqp[min(max(qpq + k.chroma_qp_offset, 0), 51)];
-    for (int dir = 0; dir < 2; dir++)
-        for (int edge = 0; edge < 4; edge++) {
-            const x264gpu_mb *P = Q;
-            if ((edge & 1) && Q->transform8x8) continue;       // no transform edge at 4-sample offsets
-            if (edge == 0) {
-                if (dir == 0) { if (mbx == 0) continue; P = &L.rec[wave][1]; }
-                else { if (mby == 0) continue; P = &L.rec[wave][2]; }
-            }
-            const int qpp = P->qp;
-            const int qpav = (qpp + qpq + 1) >> 1, qpcav = (L.cqp[min(max(qpp + k.chroma_qp_offset, 0), 51)] + qpcq + 1) >> 1;
-            const int ia = min(max(qpav + k.alpha_off, 0), 51), ib = min(max(qpav + k.beta_off, 0), 51);
-            const int ica = min(max(qpcav + k.alpha_off, 0), 51), icb = min(max(qpcav + k.beta_off, 0), 51);
-            if (lane < 16) {
-                const int seg = lane >> 2;
-                const int qbx = dir == 0 ? edge : seg, qby = dir == 0 ? seg : edge;
-                const int pbx = dir == 0 ? (edge + 3) & 3 : seg, pby = dir == 0 ? seg : (edge + 3) & 3;
-                const int bs = edge_bs(P, pbx, pby, Q, qbx, qby, edge == 0);
-                if (bs) {
-                    const int tc0 = bs < 4 ? L.tc0[ia][bs - 1] : 0;
-                    uint8_t *pix = dir == 0 ? lt + lane * DL_STRIDE + edge * 4 : lt + edge * 4 * DL_STRIDE + lane;
-                    filter_luma_line(pix, dir == 0 ? 1 : DL_STRIDE, L.alpha[ia], L.beta[ib], tc0, bs);
-                }
-            } else if (lane < 32 && !(edge & 1)) {
-                const int t = lane - 16;           // vertical edge: chroma row 0..7 (U and V); horizontal: byte column 0..15
-                if (dir == 0 && t < 8) {
-                    const int seg = t >> 1;
-                    const int bs = edge_bs(P, (edge + 3) & 3, seg, Q, edge, seg, edge == 0);
-                    if (bs) {
-                        const int tc0 = bs < 4 ? L.tc0[ica][bs - 1] : 0;
-                        uint8_t *pix = ct + t * DC_STRIDE + edge * 4;      // chroma x = edge*2 -> byte edge*4
-                        filter_chroma_line(pix, 2, L.alpha[ica], L.beta[icb], tc0, bs);
-                        filter_chroma_line(pix + 1, 2, L.alpha[ica], L.beta[icb], tc0, bs);
-                    }
-                } else if (dir == 1) {
-                    const int seg = t >> 2;
-                    const int bs = edge_bs(P, seg, (edge + 3) & 3, Q, seg, edge, edge == 0);
-                    if (bs) {
-                        const int tc0 = bs < 4 ? L.tc0[ica][bs - 1] : 0;
-                        uint8_t *pix = ct + (edge * 2) * DC_STRIDE + t;     // chroma y = edge*2
-                        filter_chroma_line(pix, DC_STRIDE, L.alpha[ica], L.beta[icb], tc0, bs);
-                    }
-                }
-            }
-            __builtin_amdgcn_wave_barrier();
-            __builtin_amdgcn_s_waitcnt(0xc07f);
-        }
-
-    // ---- write back exactly what this macroblock may have modified ----
-    {   // own luma 16x16: 64 dwords
-        const int r = lane >> 2, c = (lane & 3) * 4;
-        *(uint32_t *)(Y + (long)r * k.rs + c) = *(const uint32_t *)(lt + r * DL_STRIDE + c);
-    }
-    if (mbx > 0 && lane < 16) *(uint32_t *)(Y + (long)lane * k.rs - 4) = *(const uint32_t *)(lt + lane * DL_STRIDE - 4);
-    if (mby > 0 && lane >= 16 && lane < 28) {
-        const int i = lane - 16, r = -3 + i / 4, c = (i & 3) * 4;
-        *(uint32_t *)(Y + (long)r * k.rs + c) = *(const uint32_t *)(lt + r * DL_STRIDE + c);
-    }
-    if (lane >= 32) {   // own chroma 8 rows x 16 bytes: 32 dwords
-        const int i = lane - 32, r = i >> 2, c = (i & 3) * 4;
-        *(uint32_t *)(UV + (long)r * k.rs + c) = *(const uint32_t *)(ct + r * DC_STRIDE + c);
-    }
-    if (mbx > 0 && lane < 8) *(uint32_t *)(UV + (long)lane * k.rs - 4) = *(const uint32_t *)(ct + lane * DC_STRIDE - 4);
-    if (mby > 0 && lane >= 8 && lane < 16) {
-        const int i = lane - 8, r = -2 + (i >> 2), c = (i & 3) * 4;
-        *(uint32_t *)(UV + (long)r * k.rs + c) = *(const uint32_t *)(ct + r * DC_STRIDE + c);
-    }
-}
-
-// One workgroup per stream; wave w owns macroblock rows w, w+DB_WAVES, ...; row y may process macroblock x once
-// row y-1 has completed x+1 (top-right neighbour) — tracked with LDS counters, no block-wide barriers.
-#ifndef X264GPU_DB_WAVES
-#define X264GPU_DB_WAVES 16           // wavefronts per workgroup: wave w walks rows w, w + WAVES, ... (8 measured slower: 5.9k vs 6.4k fps)
-#endif
-constexpr int DB_WAVES = X264GPU_DB_WAVES;
-__global__ __launch_bounds__(DB_WAVES * 64) void k_deblock(EncK k)
-{
-    __shared__ __attribute__((aligned(16))) DeblockLds L;
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, s = blockIdx.x;
-    for (int i = threadIdx.x; i < WF_MAX_ROWS; i += DB_WAVES * 64) L.progress[i] = 0;
-    if (threadIdx.x < 52) {
-        const int i = threadIdx.x;
-        L.alpha[i] = d_alpha_table[i]; L.beta[i] = d_beta_table[i]; L.cqp[i] = d_chroma_qp_table[i];
-        L.tc0[i][0] = d_tc0_table[i][0]; L.tc0[i][1] = d_tc0_table[i][1]; L.tc0[i][2] = d_tc0_table[i][2]; L.tc0[i][3] = 0;
-    }
-    __syncthreads();
-    volatile int *progress = L.progress;
-    unsigned long long t_wait = 0, t_work = 0, n_mb = 0, t_begin = k.dbg ? clock64() : 0;
-    for (int row = wave; row < k.mbh; row += DB_WAVES) {
-        for (int x = 0; x < k.mbw; x++) {
-            const unsigned long long t0 = k.dbg ? clock64() : 0;
-            wf_wait(progress, row - 1, min(x + 2, k.mbw));
-            const unsigned long long t1 = k.dbg ? clock64() : 0;
-            deblock_mb_wave(k, L, wave, lane, s, x, row);
-            wf_signal(progress, row, x + 1, lane);
-            if (k.dbg) { const unsigned long long t2 = clock64(); t_wait += t1 - t0; t_work += t2 - t1; n_mb++; }
-        }
-    }
-    if (k.dbg && lane == 0) {
-        unsigned long long *d = k.dbg + ((size_t)s * 16 + wave) * 16 + 4;
-        d[0] = t_wait; d[1] = t_work; d[2] = n_mb; d[3] = clock64() - t_begin;
     }
 }
 

@@ -1,0 +1,1407 @@
+// k_mb.cuh — the macroblock loop of one slice in x264's own structure, raster-serial: x264_macroblock_analyse + x264_macroblock_encode
+// per macroblock ([x264-upstream] encoder/analyse.c, me.c, macroblock.c behind x264_encoder_encode, reference call site codec.c:1693).
+//
+// Why raster-serial: every decision of a macroblock reads macroblocks BEFORE it in raster order of the same slice — motion vector
+// predictors / search candidates / P_Skip vector from the coded neighbours, intra prediction from their reconstruction, the
+// fast-intra heuristic from the running count of intra macroblocks (and, once RD is in, the live CABAC state) — so the only exact
+// decomposition is: ONE wavefront per picture walks the macroblocks in order and spends its 64 lanes inside the macroblock
+// (candidates x rows in the searches, modes x rows in the intra analysis, 4x4 blocks x rows in the transforms); the chip is filled by
+// independent pictures (streams / closed GOPs) in flight.  Deblocking and the half-pel planes stay frame-level kernels behind it.
+//
+// Restates oracle/analyse.c bit-exactly (records, levels, reconstruction).
+#pragma once
+#include "enc_common.cuh"
+#include "k_analyse.cuh"
+#include "intra8.cuh"
+
+namespace x264gpu {
+
+constexpr int IT_STRIDE = 32;                 // luma tile stride (bytes)
+constexpr int IT_ORG = IT_STRIDE + 4;         // offset of sample (0,0): row -1 and columns -4..-1 precede it
+constexpr int IT_SIZE = 17 * IT_STRIDE + 8;
+constexpr int MB_COST_MAX = 1 << 28;
+enum { D_16x16 = 0, D_16x8 = 1, D_8x16 = 2, D_8x8 = 3 };
+enum { ME_16 = 0, ME_8 = 1, ME_16x8 = 5, ME_8x16 = 7, ME_COUNT = 9 };     // slots of the per-macroblock search results
+
+template <int M> struct MbLds {
+    __attribute__((aligned(16))) uint8_t win[WIN_ROWS * WIN_STRIDE];
+    uint32_t sub[SubGeo<M>::DWORDS];
+    uint32_t csub[CSubGeo<M>::DWORDS];
+    uint16_t cost[2][192];
+    __attribute__((aligned(8))) uint8_t tile[IT_SIZE];
+    __attribute__((aligned(8))) uint8_t tile8[IT_SIZE];
+    __attribute__((aligned(8))) int16_t lv8[256];
+    __attribute__((aligned(8))) int16_t lv4[256];
+    __attribute__((aligned(8))) uint8_t pred8tab[9 * 64];
+    uint8_t nb[NB_SIZE];
+    uint8_t cnb[2][CNB_SIZE];
+    uint8_t U[U_SIZE];
+    uint8_t U8[U8_SIZE];
+    uint8_t modes4[16], modes8[16], nmodes[8];
+    // motion cache (h->mb.cache.ref / .mv at 8x8 granularity): grid x = -1..2, y = -1..1 -> index (y + 1) * 4 + x + 1
+    int cref[12]; int cmvx[12], cmvy[12];
+    // search state
+    int16_t cand[16][2];                       // filtered start candidates of the search in progress
+    int16_t mvc[5][5][2];                      // a->l0.mvc[ref][0] = 16x16 vector, [1..4] = 8x8 vectors
+    int mvc_in[10][2];                         // raw candidates of the search in progress
+    int me_mvx[ME_COUNT], me_mvy[ME_COUNT], me_mvpx[ME_COUNT], me_mvpy[ME_COUNT], me_cost[ME_COUNT], me_costmv[ME_COUNT], me_ref[ME_COUNT], me_refcost[ME_COUNT];
+};
+
+struct MbCtx {
+    int s, lane, mbx, mby, mbi, px, py;
+    const uint8_t *fenc, *fuv;
+    int qp, qpc, lambda, subme;
+    bool satd, chroma_me;
+    const uint16_t *cost_base;
+    int mvmin0, mvmax0, mvmin1, mvmax1, smin0, smax0, smin1, smax1, fmin0, fmax0, fmin1, fmax1;
+    int nref;
+};
+
+__device__ __forceinline__ void lds_sync()
+{
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_s_waitcnt(0xc07f);
+}
+
+// ------------------------------------------------------------------------------------------------
+// motion vector prediction on the cache grid (oracle predict_mv / predict_mv_pskip)
+// ------------------------------------------------------------------------------------------------
+template <int M>
+__device__ __forceinline__ void mb_predict_mv(const MbLds<M> &L, int partition, int bx8, int by8, int w8, int ref, int &mvpx, int &mvpy)
+{
+    const int ia = (by8 + 1) * 4 + bx8, ib = by8 * 4 + bx8 + 1;
+    int ic = by8 * 4 + bx8 + w8 + 1;
+    if (L.cref[ic] == -2) ic = by8 * 4 + bx8;
+    const int ra = L.cref[ia], rb = L.cref[ib], rc = L.cref[ic];
+    const int ax = L.cmvx[ia], ay = L.cmvy[ia], bx = L.cmvx[ib], by = L.cmvy[ib], cx = L.cmvx[ic], cy = L.cmvy[ic];
+    if (partition == D_16x8) {
+        if (by8 == 0) { if (rb == ref) { mvpx = bx; mvpy = by; return; } }
+        else if (ra == ref) { mvpx = ax; mvpy = ay; return; }
+    } else if (partition == D_8x16) {
+        if (bx8 == 0) { if (ra == ref) { mvpx = ax; mvpy = ay; return; } }
+        else if (rc == ref) { mvpx = cx; mvpy = cy; return; }
+    }
+    const int cnt = (ra == ref) + (rb == ref) + (rc == ref);
+    if (cnt == 1) {
+        if (ra == ref) { mvpx = ax; mvpy = ay; } else if (rb == ref) { mvpx = bx; mvpy = by; } else { mvpx = cx; mvpy = cy; }
+    } else if (cnt == 0 && rb == -2 && rc == -2 && ra != -2) { mvpx = ax; mvpy = ay; }
+    else { mvpx = median3(ax, bx, cx); mvpy = median3(ay, by, cy); }
+}
+
+// ------------------------------------------------------------------------------------------------
+// One block search = x264_me_search_ref (oracle me_search_ref), or only the sub-pel refinement of an earlier result
+// (x264_me_refine_qpel).  Lane = (candidate = lane >> 4, row = lane & 15): four candidates are costed side by side, a lane holds
+// one row of the block (rows >= H idle).  Every update replays x264's in-order "first strictly better wins" as the minimum of
+// (cost << t | order).
+// ------------------------------------------------------------------------------------------------
+struct MeJob {
+    int W, H, ox, oy, ref;
+    int mvpx, mvpy;
+    int n_mvc;                 // raw candidates in L.mvc_in
+    bool search;               // false: refinement only (b_refine_qpel)
+    int hp_it, qp_it;
+    bool use_thresh;
+};
+
+// one row of W pixels at picture position (x, y) displaced by the quarter-pel vector, from global memory (mc.get_ref)
+__device__ __forceinline__ void mc_row_global(const uint8_t *__restrict__ p00, size_t pb, int rs, int x, int y, int mvx, int mvy, bool w16, uint32_t out[4])
+{
+    const int idx = ((mvy & 3) << 2) | (mvx & 3);
+    const long base = (long)(y + (mvy >> 2)) * rs + x + (mvx >> 2);
+    const int pl0 = (kQpelPlane0Packed >> (2 * idx)) & 3, pl1 = (kQpelPlane1Packed >> (2 * idx)) & 3;
+    const uint8_t *a = p00 + pl0 * pb + base + ((mvy & 3) == 3 ? rs : 0), *b = p00 + pl1 * pb + base + ((mvx & 3) == 3 ? 1 : 0);
+    const bool avg = (idx & 5) != 0;
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        out[i] = 0;
+        if (i < 2 || w16) {
+            const uint32_t va = load_u32_unaligned(a + 4 * i);
+            out[i] = avg ? avg4_u8(va, load_u32_unaligned(b + 4 * i)) : va;
+        }
+    }
+}
+
+template <int M>
+__device__ __forceinline__ void me_search(const EncK &k, MbLds<M> &L, const MbCtx &c, const MeJob &j, int &mvx, int &mvy, int &cost, int &cost_mv, int &halfpel_thresh)
+{
+    const int lane = c.lane, r = lane & 15, cnd = lane >> 4;
+    const bool w16 = j.W == 16, rowok = r < j.H;
+    const uint8_t *p00 = ref_plane00(k, c.s, j.ref);
+    const size_t pb = k.plane_bytes;
+    const int bx = c.px + j.ox, by = c.py + j.oy;
+    uint32_t e[4] = { 0, 0, 0, 0 };
+    if (rowok) {
+        const uint8_t *f = c.fenc + (size_t)(j.oy + r) * k.fs + j.ox;
+        const uint2 a = *(const uint2 *)f; e[0] = a.x; e[1] = a.y;
+        if (w16) { const uint2 b = *(const uint2 *)(f + 8); e[2] = b.x; e[3] = b.y; }
+    }
+    const uint16_t *cmx = c.cost_base + MVCOST_HALF - j.mvpx, *cmy = c.cost_base + MVCOST_HALF - j.mvpy;
+    // SAD of this lane's row at a quarter-pel vector, from global memory; summed over the candidate's 16 lanes
+    auto sad_global = [&](int qx, int qy) {
+        uint32_t p[4];
+        mc_row_global(p00, pb, k.rs, bx, by + r, qx, qy, w16, p);
+        unsigned sd = __builtin_amdgcn_sad_u8(p[0], e[0], 0u);
+        sd = __builtin_amdgcn_sad_u8(p[1], e[1], sd); sd = __builtin_amdgcn_sad_u8(p[2], e[2], sd); sd = __builtin_amdgcn_sad_u8(p[3], e[3], sd);
+        return row16_sum(rowok ? (int)sd : 0);
+    };
+    const int fmin0 = c.fmin0, fmax0 = c.fmax0, fmin1 = c.fmin1, fmax1 = c.fmax1;
+
+    if (j.search) {
+        int bmx, bmy, bcost, bpred_cost = MB_COST_MAX, bpred_mx = 0, bpred_my = 0, pmx, pmy;
+        const bool sub3 = c.subme >= 3;
+        // ---- predictor + candidates (L.cand[0] = the predictor, then the surviving candidates in order) ----
+        int pmvx, pmvy;
+        if (sub3) { pmvx = clampi(j.mvpx, fmin0 * 4, fmax0 * 4); pmvy = clampi(j.mvpy, fmin1 * 4, fmax1 * 4); pmx = (pmvx + 2) >> 2; pmy = (pmvy + 2) >> 2; }
+        else { pmx = clampi((j.mvpx + 2) >> 2, fmin0, fmax0); pmy = clampi((j.mvpy + 2) >> 2, fmin1, fmax1); pmvx = pmx * 4; pmvy = pmy * 4; }
+        int n = 1;
+        if (lane == 0) { L.cand[0][0] = (int16_t)pmvx; L.cand[0][1] = (int16_t)pmvy; }
+        for (int i = 0; i < j.n_mvc; i++) {
+            int mx = L.mvc_in[i][0], my = L.mvc_in[i][1];
+            bool drop;
+            if (sub3) { drop = !(mx | my) || (mx == pmvx && my == pmvy); mx = clampi(mx, fmin0 * 4, fmax0 * 4); my = clampi(my, fmin1 * 4, fmax1 * 4); }
+            else { mx = clampi((mx + 2) >> 2, fmin0, fmax0); my = clampi((my + 2) >> 2, fmin1, fmax1); drop = !(mx | my) || (mx == pmx && my == pmy); mx *= 4; my *= 4; }
+            if (!drop) { if (lane == 0) { L.cand[n][0] = (int16_t)mx; L.cand[n][1] = (int16_t)my; } n++; }
+        }
+        lds_sync();
+        unsigned key = 0xffffffffu;
+        int pmv_cost = 0;
+        for (int b0 = 0; b0 < n; b0 += 4) {
+            const int i = b0 + cnd, ii = i < n ? i : 0;
+            const int qx = L.cand[ii][0], qy = L.cand[ii][1];
+            int cst = sad_global(qx, qy);
+            if (sub3 || ii > 0) cst += cmx[qx] + cmy[qy];            // below subme 3 the rounded predictor is costed without its vector bits
+            const unsigned kk = i < n ? ((unsigned)cst << 4) | (unsigned)i : 0xffffffffu;
+            if (b0 == 0) pmv_cost = __builtin_amdgcn_readlane(cst, 0);
+            key = min(key, wave_min_u32(kk));
+        }
+        {
+            const int bi = key & 15;
+            bpred_cost = (int)(key >> 4); bpred_mx = L.cand[bi][0]; bpred_my = L.cand[bi][1];
+        }
+        const bool pmv_nonzero = (pmvx | pmvy) != 0;
+        bmx = (bpred_mx + 2) >> 2; bmy = (bpred_my + 2) >> 2;
+        {   // the rounded best predictor and the zero vector, both from global memory: groups 0 and 1
+            const int qx = cnd == 0 ? bmx * 4 : 0, qy = cnd == 0 ? bmy * 4 : 0;
+            const int cst = sad_global(qx, qy) + cmx[qx] + cmy[qy];
+            const int c_round = __builtin_amdgcn_readlane(cst, 0), c_zero = __builtin_amdgcn_readlane(cst, 16);
+            if (sub3) {
+                bcost = ((bpred_mx | bpred_my) & 3) ? c_round : bpred_cost;
+                if (pmv_nonzero) { if ((bmx | bmy) && c_zero < bcost) { bcost = c_zero; bmx = 0; bmy = 0; } }
+                else if (pmv_cost < bcost) { bcost = pmv_cost; bmx = 0; bmy = 0; }
+            } else {
+                bcost = bpred_cost;
+                if (pmv_nonzero && c_zero < bcost) { bcost = c_zero; bmx = 0; bmy = 0; }
+            }
+        }
+        bmx = __builtin_amdgcn_readfirstlane(bmx); bmy = __builtin_amdgcn_readfirstlane(bmy);
+
+        // ---- stage the search window and the mv-cost slices around the start ----
+        int wx0 = clampi((bx + bmx - WIN_R) & ~7, -PAD, k.cw + PAD - WIN_COLS), wy0 = clampi(by + bmy - WIN_R, -PAD, k.ch + PAD - WIN_ROWS);
+        for (int i = lane; i < WIN_ROWS * 8; i += 64) {
+            const int row = i >> 3, col = (i & 7) * 8;
+            const uint2 v = *(const uint2 *)(p00 + (long)(wy0 + row) * k.rs + wx0 + col);
+            uint32_t *d = (uint32_t *)(L.win + row * WIN_STRIDE + col);
+            d[0] = v.x; d[1] = v.y;
+        }
+        const int cbx = bmx * 4, cby = bmy * 4;
+        for (int i = lane; i < 192; i += 64) { L.cost[0][i] = cmx[cbx + i - 96]; L.cost[1][i] = cmy[cby + i - 96]; }
+        lds_sync();
+#define MVC(qx, qy) ((int)L.cost[0][(qx) - cbx + 96] + (int)L.cost[1][(qy) - cby + 96])
+        auto fpel = [&](int mx, int my) {       // full-pel candidate cost from the LDS window (valid after the row sum)
+            const uint8_t *wrow = L.win + (by + my + r - wy0) * WIN_STRIDE;
+            const int xo = bx + mx - wx0;
+            int sd = 0;
+            if (rowok) sd = w16 ? sad_row16_lds(wrow, xo, e) : sad8_lds(wrow, xo, e[0], e[1]);
+            return row16_sum(sd) + MVC(mx * 4, my * 4);
+        };
+        if (k.me_method == 0) {
+            // X264_ME_DIA: the four neighbours are the four lane groups; the centre wins ties
+            int it = k.me_range;
+            do {
+                const unsigned kk = wave_min_u32(((unsigned)fpel(bmx + (cnd == 2 ? -1 : cnd == 3 ? 1 : 0), bmy + (cnd == 0 ? -1 : cnd == 1 ? 1 : 0)) << 2) | (unsigned)cnd);
+                if ((int)(kk >> 2) >= bcost) break;
+                const int q = kk & 3;
+                bcost = (int)(kk >> 2);
+                bmx += q == 2 ? -1 : q == 3 ? 1 : 0; bmy += q == 0 ? -1 : q == 1 ? 1 : 0;
+            } while (--it && bmx >= fmin0 && bmx <= fmax0 && bmy >= fmin1 && bmy <= fmax1);
+        } else {
+            // X264_ME_HEX: hexagon, then square refine
+            unsigned hk = (unsigned)bcost << 3;
+            {
+                int i = 1 + cnd;
+                unsigned kk = ((unsigned)fpel(bmx + hex_dx(i), bmy + hex_dy(i)) << 3) | (unsigned)(i + 1);
+                hk = min(hk, wave_min_u32(kk));
+                i = 5 + (cnd & 1);
+                kk = ((unsigned)fpel(bmx + hex_dx(i), bmy + hex_dy(i)) << 3) | (unsigned)(i + 1);
+                if (cnd >= 2) kk = 0xffffffffu;
+                hk = min(hk, wave_min_u32(kk));
+            }
+            if (hk & 7) {
+                int dir = (int)(hk & 7) - 2;
+                bmx += hex_dx(dir + 1); bmy += hex_dy(dir + 1);
+                for (int it = (k.me_range >> 1) - 1; it > 0 && bmx >= fmin0 && bmx <= fmax0 && bmy >= fmin1 && bmy <= fmax1; it--) {
+                    hk &= ~7u;
+                    const int cc = cnd < 3 ? cnd : 0;
+                    unsigned kk = ((unsigned)fpel(bmx + hex_dx(dir + cc), bmy + hex_dy(dir + cc)) << 3) | (unsigned)(cc + 1);
+                    if (cnd >= 3) kk = 0xffffffffu;
+                    hk = min(hk, wave_min_u32(kk));
+                    if (!(hk & 7)) break;
+                    dir += (int)(hk & 7) - 2;
+                    dir = dir < 0 ? 5 : dir > 5 ? 0 : dir;
+                    bmx += hex_dx(dir + 1); bmy += hex_dy(dir + 1);
+                }
+            }
+            bcost = (int)(hk >> 3);
+            unsigned sk = (unsigned)bcost << 4;
+            {
+                int q = 1 + cnd;
+                sk = min(sk, wave_min_u32(((unsigned)fpel(bmx + sq_dx(q), bmy + sq_dy(q)) << 4) | (unsigned)q));
+                q = 5 + cnd;
+                sk = min(sk, wave_min_u32(((unsigned)fpel(bmx + sq_dx(q), bmy + sq_dy(q)) << 4) | (unsigned)q));
+            }
+            const int bd = sk & 15;
+            bcost = (int)(sk >> 4);
+            if (bd) { bmx += sq_dx(bd); bmy += sq_dy(bd); }
+        }
+        // ---- -> quarter-pel vector ----
+        if (!sub3) {
+            cost = bcost;
+            if (bmx == pmx && bmy == pmy) cost += MVC(bmx * 4, bmy * 4);        // the real cost of the predictor
+            mvx = bmx * 4; mvy = bmy * 4;
+        } else if (bpred_cost < bcost) { mvx = bpred_mx; mvy = bpred_my; cost = bpred_cost; }
+        else { mvx = bmx * 4; mvy = bmy * 4; cost = bcost; }
+#undef MVC
+        mvx = __builtin_amdgcn_readfirstlane(mvx); mvy = __builtin_amdgcn_readfirstlane(mvy);
+        cost_mv = cmx[mvx] + cmy[mvy];
+        if (c.subme < 2) return;
+    }
+
+    // ---- refine_subpel ----
+    const bool refq = !j.search;
+    int bmx = mvx, bmy = mvy, bcost = cost;
+    const bool chroma_me = c.chroma_me;
+    if (j.hp_it && c.subme < 3) {     // the sub-pel component of the predicted vector (anywhere: global memory)
+        const int mx = clampi(j.mvpx, c.smin0 + 2, c.smax0 - 2), my = clampi(j.mvpy, c.smin1 + 2, c.smax1 - 2);
+        if ((mx - bmx) | (my - bmy)) {
+            const int cst = __builtin_amdgcn_readlane(sad_global(mx, my), 0) + cmx[mx] + cmy[my];
+            if (cst < bcost) { bcost = cst; bmx = mx; bmy = my; }
+        }
+    }
+    // every sample the diamonds below can touch lies within M px of the rounded start: stage it (all four half-pel planes) in LDS
+    const int ctrx = (bmx + 2) >> 2, ctry = (bmy + 2) >> 2;
+    uint32_t *sb = L.sub;
+    const int rwl = SubGeo<M>::rwl(j.W), rh = SubGeo<M>::rh(j.H), ncol = SubGeo<M>::ncol(j.W), sn = rh << rwl;
+    const int sx0 = (bx + ctrx - M) & ~3, sy0 = by + ctry - M;
+    lds_sync();
+    sub_stage<M>(sb, p00, pb, k.rs, sx0, sy0, rwl, rh, ncol, lane, 64);
+    // chroma: lane r owns row (r & 3) of 4x4 chroma block r >> 2 of the partition, both planes
+    const int cbw = j.W >> 3, ncb = cbw * (j.H >> 3), cblk = r >> 2;
+    const bool cact = cblk < ncb;
+    const int ccx = (j.ox >> 1) + (cblk % cbw) * 4, ccy = (j.oy >> 1) + (cblk / cbw) * 4 + (r & 3);
+    uint32_t ce0 = 0, ce1 = 0;
+    uint32_t *cb = L.csub;
+    const int cndw = CSubGeo<M>::ndw(j.W >> 1), cnr = CSubGeo<M>::rows(j.H >> 1);
+    const int cx0c = ((bx >> 1) + (ctrx >> 1) - CSubGeo<M>::MG) & ~1, cy0c = (by >> 1) + (ctry >> 1) - CSubGeo<M>::MG;
+    if (chroma_me) {
+        if (cact) { const uint2 v = *(const uint2 *)(c.fuv + (size_t)ccy * k.fs + 2 * ccx); ce0 = v.x; ce1 = v.y; }
+        chroma_stage(cb, ref_chroma00(k, c.s, j.ref), k.rs, cx0c, cy0c, cndw, cnr, lane, 64);
+    }
+    lds_sync();
+    const s16x2 sg1 = pk_sign(lane & 1), sg2 = pk_sign(lane & 2);
+    auto fetch2 = [&](int qx, int qy, uint32_t p[4]) {
+        p[0] = p[1] = p[2] = p[3] = 0;
+        if (rowok) {
+            if (w16) sub_row16(sb, sn, rwl, sx0, sy0, bx, by + r, qx, qy, p);
+            else sub_row8(sb, sn, rwl, sx0, sy0, bx, by + r, qx, qy, p);
+        }
+    };
+    auto sad2 = [&](int qx, int qy) {
+        uint32_t p[4];
+        fetch2(qx, qy, p);
+        unsigned sd = __builtin_amdgcn_sad_u8(p[0], e[0], 0u);
+        sd = __builtin_amdgcn_sad_u8(p[1], e[1], sd); sd = __builtin_amdgcn_sad_u8(p[2], e[2], sd); sd = __builtin_amdgcn_sad_u8(p[3], e[3], sd);
+        return row16_sum(rowok ? (int)sd : 0) + cmx[qx] + cmy[qy];
+    };
+    auto cmp2 = [&](int qx, int qy) {           // mbcmp (SATD above subme 1) + vector bits, without chroma
+        if (!c.satd) return sad2(qx, qy);
+        uint32_t p[4];
+        fetch2(qx, qy, p);
+        return row16_sum(satd16x4_half_pk(e, p, sg1, sg2)) + cmx[qx] + cmy[qy];
+    };
+    auto chroma2 = [&](int qx, int qy) {
+        const int h = cact ? chroma_me_lds(cb, cndw, cx0c, cy0c, (c.px >> 1) + ccx, (c.py >> 1) + ccy, qx, qy, ce0, ce1, sg1, sg2) : 0;
+        return row16_sum(h);
+    };
+    // half-pel diamond on SAD: (0,-2) (0,2) (-2,0) (2,0)
+    for (int it = j.hp_it; it > 0; it--) {
+        const int cx = bmx + (cnd == 2 ? -2 : cnd == 3 ? 2 : 0), cy = bmy + (cnd == 0 ? -2 : cnd == 1 ? 2 : 0);
+        const unsigned kk = wave_min_u32(((unsigned)sad2(cx, cy) << 2) | (unsigned)cnd);
+        if ((int)(kk >> 2) >= bcost) break;
+        const int b = kk & 3;
+        bcost = (int)(kk >> 2);
+        bmx += b == 2 ? -2 : b == 3 ? 2 : 0; bmy += b == 0 ? -2 : b == 1 ? 2 : 0;
+    }
+    if (!refq && (c.satd || chroma_me)) {
+        bcost = __builtin_amdgcn_readlane(cmp2(bmx, bmy), 0);
+        if (chroma_me) bcost += __builtin_amdgcn_readlane(chroma2(bmx, bmy), 0);
+    }
+    if (j.use_thresh) {
+        if (((bcost * 7) >> 3) > halfpel_thresh) { mvx = bmx; mvy = bmy; cost = bcost; return; }
+        else if (bcost < halfpel_thresh) halfpel_thresh = bcost;
+    }
+    if (c.subme != 1) {
+        int bdir = -1;
+        for (int it = j.qp_it; it > 0; it--) {
+            if (bmy <= c.smin1 || bmy >= c.smax1 || bmx <= c.smin0 || bmx >= c.smax0) break;
+            const int cx = bmx + (cnd == 2 ? -1 : cnd == 3 ? 1 : 0), cy = bmy + (cnd == 0 ? -1 : cnd == 1 ? 1 : 0);
+            const bool skip = !refq && (cnd ^ 1) == bdir;             // do not step straight back
+            int cst = cmp2(cx, cy);
+            if (chroma_me && __any(cst < bcost && !skip)) cst += chroma2(cx, cy);
+            unsigned kk = skip ? 0xffffffffu : ((unsigned)cst << 2) | (unsigned)cnd;
+            kk = wave_min_u32(kk);
+            if ((int)(kk >> 2) >= bcost) break;
+            bcost = (int)(kk >> 2);
+            bdir = kk & 3;
+            bmx += bdir == 2 ? -1 : bdir == 3 ? 1 : 0; bmy += bdir == 0 ? -1 : bdir == 1 ? 1 : 0;
+        }
+    } else if (bmy > c.smin1 && bmy < c.smax1 && bmx > c.smin0 && bmx < c.smax0) {
+        const int cx = bmx + (cnd == 2 ? -1 : cnd == 3 ? 1 : 0), cy = bmy + (cnd == 0 ? -1 : cnd == 1 ? 1 : 0);
+        const unsigned kk = wave_min_u32(((unsigned)sad2(cx, cy) << 2) | (unsigned)cnd);
+        if ((int)(kk >> 2) < bcost) {
+            const int b = kk & 3;
+            bcost = (int)(kk >> 2);
+            bmx += b == 2 ? -1 : b == 3 ? 1 : 0; bmy += b == 0 ? -1 : b == 1 ? 1 : 0;
+        }
+    }
+    mvx = __builtin_amdgcn_readfirstlane(bmx); mvy = __builtin_amdgcn_readfirstlane(bmy); cost = bcost;
+    cost_mv = cmx[mvx] + cmy[mvy];
+}
+
+
+// ------------------------------------------------------------------------------------------------
+// intra analysis (oracle analyse_intra / analyse_intra_chroma; x264_mb_analyse_intra)
+// ------------------------------------------------------------------------------------------------
+static __constant__ int c_lambda2_tab[52] = { 14, 18, 22, 28, 36, 45, 57, 72, 91, 115, 145, 182, 230, 290, 365, 460, 580, 731, 921, 1160, 1462, 1843, 2322, 2926,
+                                              3686, 4644, 5852, 7373, 9289, 11703, 14745, 18578, 23407, 29491, 37156, 46814, 58982, 74313, 93628, 117964,
+                                              148626, 187257, 235929, 297252, 374514, 471859, 594505, 749029, 943718, 1189010, 1498059, 1887436 };
+
+__device__ __forceinline__ int blkidx_of(int bx, int by) { return ((by >> 1) * 2 + (bx >> 1)) * 4 + (by & 1) * 2 + (bx & 1); }
+
+// neighbour availability of 4x4 block b / 8x8 block i8 (oracle i4_avail / i8_avail)
+__device__ __forceinline__ int i4_avail(int mbx, int mby, int mbw, int b)
+{
+    const int bx = z_bx(b), by = z_by(b);
+    int a = 0;
+    if (bx > 0 || mbx > 0) a |= AVAIL_LEFT;
+    if (by > 0 || mby > 0) a |= AVAIL_TOP;
+    if ((bx > 0 || mbx > 0) && (by > 0 || mby > 0)) a |= AVAIL_TOPLEFT;
+    if (by == 0) { if (mby > 0 && (bx < 3 || mbx + 1 < mbw)) a |= AVAIL_TOPRIGHT; }
+    else if (bx < 3 && blkidx_of(bx + 1, by - 1) < b) a |= AVAIL_TOPRIGHT;
+    return a;
+}
+__device__ __forceinline__ int i8_avail(bool left, bool top, bool topright, int i8)
+{
+    const int x8 = i8 & 1, y8 = i8 >> 1;
+    int a = 0;
+    if (x8 || left) a |= AVAIL_LEFT;
+    if (y8 || top) a |= AVAIL_TOP;
+    if ((x8 || left) && (y8 || top)) a |= AVAIL_TOPLEFT;
+    if (i8 == 0 ? top : i8 == 1 ? topright : i8 == 2) a |= AVAIL_TOPRIGHT;
+    return a;
+}
+// predicted intra 4x4 mode (8.3.1.1; oracle i4_pred_mode): nm = edge modes of the left / top macroblocks
+__device__ __forceinline__ int i4_pred_mode(const uint8_t *nm, int mbx, int mby, int b, const uint8_t *cur)
+{
+    const int bx = z_bx(b), by = z_by(b);
+    int ma, mb_;
+    if (bx > 0) ma = cur[blkidx_of(bx - 1, by)];
+    else if (mbx > 0) ma = nm[by];
+    else return 2;
+    if (by > 0) mb_ = cur[blkidx_of(bx, by - 1)];
+    else if (mby > 0) mb_ = nm[4 + bx];
+    else return 2;
+    return min(ma, mb_);
+}
+
+__device__ __forceinline__ int sel9(const int v[9], int m)
+{
+    int r = v[0];
+#pragma unroll
+    for (int i = 1; i < 9; i++) r = m == i ? v[i] : r;
+    return r;
+}
+// x264's mode choice of one 4x4 / 8x8 block from the raw costs of the nine modes (oracle analyse_intra: V / H / DC first, then only the
+// directional modes near the favoured direction; list order and "first strictly better" decide ties).  Returns the cost incl. the
+// predicted-mode bonus; lists are nibble strings, 15 terminates.
+__device__ __forceinline__ int pick_intra_mode(const int raw[9], int avail, int pm, int lambda, bool is4, int &bestm)
+{
+    const int all3 = AVAIL_LEFT | AVAIL_TOP | AVAIL_TOPLEFT;
+    const int id = (avail & all3) == all3 ? 4 : avail & (AVAIL_LEFT | AVAIL_TOP);
+    unsigned long long rest;
+    int best = MB_COST_MAX;
+    bestm = 2;
+    if (id >= 3) {
+        int sv = raw[0], sh = raw[1], sdc = raw[2];
+        const bool fv = sh > sv;
+        if (pm == 0) sv -= 3 * lambda; else if (pm == 1) sh -= 3 * lambda; else if (pm == 2) sdc -= 3 * lambda;
+        best = sdc; bestm = 2;
+        if (sh < best) { best = sh; bestm = 1; }
+        if (sv < best) { best = sv; bestm = 0; }
+        rest = id == 4 ? (fv ? 0xF7543ull : 0xF864ull) : (fv ? 0xF73ull : 0xF8ull);
+    } else rest = id == 0 ? 0xF2ull : id == 1 ? 0xF812ull : 0xF7302ull;
+    if (is4) {
+        if (best > 0)
+            for (; (rest & 15) != 15; rest >>= 4) {
+                const int m = (int)(rest & 15);
+                int cst = sel9(raw, m);
+                if (pm == m) { cst -= 3 * lambda; if (cst <= 0) { best = cst; bestm = m; break; } }
+                if (cst < best) { best = cst; bestm = m; }
+            }
+    } else {
+        for (; (rest & 15) != 15 && best >= 0; rest >>= 4) {
+            const int m = (int)(rest & 15);
+            const int cst = sel9(raw, m) - (pm == m ? 3 * lambda : 0);
+            if (cst < best) { best = cst; bestm = m; }
+        }
+    }
+    return best;
+}
+
+struct IntraRes { int satd_i16, satd_i8, satd_i4, pred16; unsigned nnz4, nnz8; int cbp8; };
+
+// Needs the neighbour samples in L.tile / L.tile8 / L.nb and the neighbour macroblocks' edge modes in L.nmodes.
+template <int M>
+__device__ __forceinline__ void mb_analyse_intra(const EncK &k, MbLds<M> &L, const MbCtx &c, uint32_t cz, uint32_t t4, int parts, int i_satd_inter,
+                                                 bool fast_intra, bool early_term, const Q4 &q4, const Q8 &q8, IntraRes &R)
+{
+    const int lane = c.lane, j = lane & 3, zx = z_x0(lane), zy = z_y(lane), lambda = c.lambda;
+    const bool left = c.mbx > 0, top = c.mby > 0, topright = top && c.mbx + 1 < k.mbw;
+    const int sm = min(c.subme, 10);
+    uint8_t *tile = L.tile + IT_ORG, *tile8 = L.tile8 + IT_ORG;
+    R.satd_i16 = R.satd_i8 = R.satd_i4 = MB_COST_MAX; R.pred16 = 0; R.nnz4 = R.nnz8 = 0; R.cbp8 = 0;
+    // ---- 16x16 ----
+    {
+        const Pred16 pp = pred16_setup(L.nb, lane);
+        const int lut = sm < 3 ? 2 : sm < 5 ? 3 : 4;
+        const int thresh16 = fast_intra ? (lut * i_satd_inter) >> 1 : MB_COST_MAX;
+        auto cost16 = [&](int m) {
+            const uint32_t pr = pred16_row4(L.nb, pp, m, zx, zy);
+            const int sig = m > PRED16_P ? PRED16_DC : m;
+            return wave_sum(c.satd ? satd4_half(cz, pr, lane) : sad4(cz, pr)) + lambda * bs_size_ue(sig);
+        };
+        if (left && top) {
+            for (int m = 0; m < 3; m++) { const int cst = cost16(m); if (cst < R.satd_i16) { R.satd_i16 = cst; R.pred16 = m; } }
+            if (R.satd_i16 <= thresh16) { const int cst = cost16(PRED16_P); if (cst < R.satd_i16) { R.satd_i16 = cst; R.pred16 = PRED16_P; } }
+        } else {
+            const int m0 = left ? PRED16_DC_LEFT : top ? PRED16_DC_TOP : PRED16_DC_128, m1 = left ? PRED16_H : PRED16_V;
+            { const int cst = cost16(m0); if (cst < R.satd_i16) { R.satd_i16 = cst; R.pred16 = m0; } }
+            if (left || top) { const int cst = cost16(m1); if (cst < R.satd_i16) { R.satd_i16 = cst; R.pred16 = m1; } }
+        }
+        if (R.satd_i16 > thresh16) return;
+    }
+    // ---- 8x8: R8 layout, lane = (mode group, row); eight modes in one pass, the ninth in a second ----
+    if ((parts & 4) && k.dct8x8) {
+        const int thresh = min(i_satd_inter, R.satd_i16);
+        const int g = lane >> 3, r8 = lane & 7;
+        if (lane < 16) L.modes8[lane] = 2;
+        int i_cost = lambda * 4, idx;
+        for (idx = 0;; idx++) {
+            const int x8 = idx & 1, y8 = idx >> 1, avail = i8_avail(left, top, topright, idx);
+            lds_sync();
+            const int pm = i4_pred_mode(L.nmodes, c.mbx, c.mby, idx * 4, L.modes8);
+            uint8_t *bt = tile8 + y8 * 8 * IT_STRIDE + x8 * 8;
+            pred8_build_u(L.U8, bt, IT_STRIDE, avail, lane);
+            const int src = idx * 16 + (r8 >> 2) * 8 + (r8 & 3);
+            const uint32_t elo = (uint32_t)__shfl((int)cz, src), ehi = (uint32_t)__shfl((int)cz, src + 4);
+            uint32_t p1lo, p1hi, p2lo, p2hi;
+            auto cost8 = [&](uint32_t plo, uint32_t phi) {
+                int h;
+                if (c.satd) { h = sa8d_r8_half(elo, ehi, plo, phi, lane); h += dpp<DPP_XOR1>(h); h += dpp<DPP_XOR2>(h); h += xor4(h); return (2 * h + 2) >> 2; }
+                h = (int)__builtin_amdgcn_sad_u8(plo, elo, __builtin_amdgcn_sad_u8(phi, ehi, 0u));
+                h += dpp<DPP_XOR1>(h); h += dpp<DPP_XOR2>(h); h += xor4(h);
+                return h;
+            };
+            pred8_row8(L.U8, L.pred8tab, g, r8, p1lo, p1hi);
+            const int c1 = cost8(p1lo, p1hi);
+            pred8_row8(L.U8, L.pred8tab, 8, r8, p2lo, p2hi);
+            const int c2 = cost8(p2lo, p2hi);
+            int raw[9];
+#pragma unroll
+            for (int m = 0; m < 8; m++) raw[m] = __builtin_amdgcn_readlane(c1, m * 8);
+            raw[8] = __builtin_amdgcn_readlane(c2, 0);
+            int bm;
+            const int best = pick_intra_mode(raw, avail, pm, lambda, false, bm);
+            i_cost += best + 3 * lambda;
+            if (lane < 4) L.modes8[idx * 4 + lane] = (uint8_t)bm;
+            if (idx < 3 && i_cost > thresh) break;
+            // code the block (the next ones predict from it; the last one so that the result is complete if Intra8x8 wins)
+            const uint32_t plo = bm == 8 ? (uint32_t)__shfl((int)p2lo, r8) : (uint32_t)__shfl((int)p1lo, bm * 8 + r8);
+            const uint32_t phi = bm == 8 ? (uint32_t)__shfl((int)p2hi, r8) : (uint32_t)__shfl((int)p1hi, bm * 8 + r8);
+            int e[8], p[8], v[8];
+            unpack8(elo, ehi, e); unpack8(plo, phi, p);
+#pragma unroll
+            for (int i = 0; i < 8; i++) v[i] = e[i] - p[i];
+            fwd8_1d(v); transpose8(v, lane); fwd8_1d(v); transpose8(v, lane);
+            int mf[4], bs[4], dq[4];
+            q8_row(q8, r8, mf, bs, dq);
+            unsigned mlo = 0, mhi = 0;
+#pragma unroll
+            for (int i = 0; i < 8; i++) {
+                v[i] = quant_one(v[i], mf[i & 3], bs[i & 3]);
+                const int z = c_zigzag8_inv[r8 * 8 + i];
+                if (v[i]) { if (z < 32) mlo |= 1u << z; else mhi |= 1u << (z - 32); }
+                if (g == 0) L.lv8[(idx * 4 + (z & 3)) * 16 + (z >> 2)] = (int16_t)v[i];
+            }
+            mlo = group8_or(mlo); mhi = group8_or(mhi);
+            const unsigned long long mask = ((unsigned long long)mhi << 32) | mlo;
+#pragma unroll
+            for (int q = 0; q < 4; q++) R.nnz8 |= (mask & (0x1111111111111111ull << q)) ? 1u << (idx * 4 + q) : 0u;
+            if (mask) R.cbp8 |= 1 << idx;
+            const int qb = q8.qp / 6 - 6;
+#pragma unroll
+            for (int i = 0; i < 8; i++) v[i] = dequant_one(v[i], dq[i & 3], qb);
+            inv8_1d(v); transpose8(v, lane); inv8_1d(v); transpose8(v, lane);
+#pragma unroll
+            for (int i = 0; i < 8; i++) v[i] = ((v[i] + 32) >> 6) + p[i];
+            if (g == 0) {
+                *(uint32_t *)(bt + r8 * IT_STRIDE) = pack4_clip8lo(v);
+                *(uint32_t *)(bt + r8 * IT_STRIDE + 4) = pack4_clip8hi(v);
+            }
+            if (idx == 3) break;
+        }
+        lds_sync();
+        R.nnz8 = (unsigned)__builtin_amdgcn_readfirstlane((int)R.nnz8);
+        R.cbp8 = __builtin_amdgcn_readfirstlane(R.cbp8);
+        if (idx == 3) R.satd_i8 = i_cost;
+        else i_cost = (i_cost * (idx == 0 ? 1024 : idx == 1 ? 512 : 341)) >> 8;
+        const int thr8 = sm < 3 ? 4 : sm < 6 ? 5 : 6;
+        if (early_term && min(i_cost, R.satd_i16) > (int)(((long long)i_satd_inter * thr8) >> 2)) return;
+    }
+    // ---- 4x4: nine modes per block in parallel (one quad of lanes per mode), blocks in coding order ----
+    if (parts & 2) {
+        const int thresh = early_term ? min(min(i_satd_inter, R.satd_i16), R.satd_i8) : MB_COST_MAX;
+        if (lane < 16) L.modes4[lane] = 2;
+        int i_cost = lambda * (24 + 16), idx;
+        for (idx = 0;; idx++) {
+            const int bx = z_bx(idx), by = z_by(idx);
+            const int avail = i4_avail(c.mbx, c.mby, k.mbw, idx);
+            lds_sync();
+            const int pm = i4_pred_mode(L.nmodes, c.mbx, c.mby, idx, L.modes4);
+            uint8_t *bt = tile + by * 4 * IT_STRIDE + bx * 4;
+            pred4_build_u(L.U, bt, IT_STRIDE, avail, lane);
+            const uint32_t pr = pred4_row4(L.U, t4);
+            const uint32_t en = (uint32_t)__shfl((int)cz, idx * 4 + j);
+            const int sat = quad_sum(c.satd ? satd4_half(en, pr, lane) : sad4(en, pr));
+            int raw[9];
+#pragma unroll
+            for (int m = 0; m < 9; m++) raw[m] = __builtin_amdgcn_readlane(sat, m * 4);
+            int bm;
+            const int best = pick_intra_mode(raw, avail, pm, lambda, true, bm);
+            i_cost += best + 3 * lambda;
+            if (lane == 0) L.modes4[idx] = (uint8_t)bm;
+            if (idx < 15 && i_cost > thresh) break;
+            const uint32_t bp = (uint32_t)__shfl((int)pr, bm * 4 + j);
+            int e[4], p[4], v[4];
+            unpack4(en, e); unpack4(bp, p);
+#pragma unroll
+            for (int t = 0; t < 4; t++) v[t] = e[t] - p[t];
+            dct4_quad(v, lane);
+            quant4_row(v, q4, j);
+            const bool nz = quad_or((v[0] | v[1] | v[2] | v[3]) != 0 ? 1 : 0) != 0;
+            if (lane < 4) store_levels_scan(L.lv4 + idx * 16, v, j);
+            dequant4_row(v, q4, j);
+            idct4_quad(v, lane);
+#pragma unroll
+            for (int t = 0; t < 4; t++) v[t] += p[t];
+            if (lane < 4) *(uint32_t *)(bt + j * IT_STRIDE) = nz ? pack4_clip(v) : bp;
+            if (__builtin_amdgcn_readfirstlane((int)nz)) R.nnz4 |= 1u << idx;
+            if (idx == 15) break;
+        }
+        lds_sync();
+        if (idx == 15) R.satd_i4 = i_cost;
+    }
+}
+
+// chroma intra: mode decision (oracle analyse_intra_chroma).  Lanes 0..31 (plane = lane >> 4); needs L.cnb.
+template <int M>
+__device__ __forceinline__ int mb_intra_chroma_cost(const EncK &k, MbLds<M> &L, const MbCtx &c, int &predc)
+{
+    const int lane = c.lane, pl = (lane >> 4) & 1, ci = (lane >> 2) & 3, j = lane & 3, cx0 = (ci & 1) * 4, cyy = (ci >> 1) * 4 + j;
+    const bool left = c.mbx > 0, top = c.mby > 0;
+    const uint8_t *cnb = L.cnb[pl];
+    const PredC pc = predc_setup(cnb);
+    const uint2 fe = *(const uint2 *)(c.fuv + (size_t)cyy * k.fs + 2 * cx0);
+    const uint32_t cenc = nv12_pick(fe.x, fe.y, pl);
+    int modes[4], n;
+    if (left && top) { modes[0] = PREDC_DC; modes[1] = PREDC_H; modes[2] = PREDC_V; modes[3] = PREDC_P; n = 4; }
+    else if (left) { modes[0] = PREDC_DC_LEFT; modes[1] = PREDC_H; n = 2; }
+    else if (top) { modes[0] = PREDC_DC_TOP; modes[1] = PREDC_V; n = 2; }
+    else { modes[0] = PREDC_DC_128; n = 1; }
+    int bestc = MB_COST_MAX;
+    predc = modes[0];
+    for (int i = 0; i < n; i++) {
+        const int m = modes[i], sig = m > PREDC_P ? PREDC_DC : m;
+        const uint32_t pr = predc_row4(cnb, pc, m, ci, j);
+        const int hs = c.satd ? satd4_half(cenc, pr, lane) : sad4(cenc, pr);
+        const int cst = wave_sum(lane < 32 ? hs : 0) + c.lambda * bs_size_ue(sig);
+        if (cst < bestc) { bestc = cst; predc = m; }
+    }
+    return bestc;
+}
+
+// ------------------------------------------------------------------------------------------------
+// chroma residual with x264's variance early termination (oracle encode_chroma).  Lanes 0..31: plane = lane >> 4,
+// 4x4 block = (lane >> 2) & 3, row = lane & 3.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t mb_chroma_residual(uint32_t enc, uint32_t pred, const Q4 &q, bool inter, bool decimate, int lane, int16_t *lv,
+                                                       unsigned &nnz_bits, int &cbp_chroma)
+{
+    const int c = (lane >> 4) & 1, i = (lane >> 2) & 3, j = lane & 3;
+    const bool act = lane < 32;
+    int e[4], p[4], v[4];
+    unpack4(enc, e); unpack4(pred, p);
+#pragma unroll
+    for (int t = 0; t < 4; t++) v[t] = act ? e[t] - p[t] : 0;
+    // early termination (inter, dct-decimate, chroma quantiser >= 18): small residual variance -> DC only, or nothing
+    bool et = false, et_drop_dc = false;
+    if (inter && decimate && q.qp >= 18) {
+        const int thresh = (c_lambda2_tab[q.qp] + 32) >> 6;
+        const int sm = row16_sum(v[0] + v[1] + v[2] + v[3]), sq = row16_sum(v[0] * v[0] + v[1] * v[1] + v[2] * v[2] + v[3] * v[3]);
+        const int var = sq - (int)(((long long)sm * sm) >> 6);
+        const int score = __builtin_amdgcn_readlane(var, 0) + __builtin_amdgcn_readlane(var, 16);
+        et = score < thresh * 4;
+        et_drop_dc = sq <= thresh;
+    }
+    dct4_quad(v, lane);
+    int dcs[4];
+#pragma unroll
+    for (int b = 0; b < 4; b++) dcs[b] = __shfl(v[0], (lane & 48) + 4 * b);
+    if (j == 0) v[0] = 0;
+    quant4_row(v, q, j);
+    unsigned mask = quad_or((int)scan_mask(v, j));
+    int big = quad_or(any_big(v) ? 1 : 0);
+    bool nz = mask != 0;
+    int score = 0;
+    if (inter && decimate) {
+        int s = nz ? (big ? 9 : decimate_from_mask(mask, 1)) : 0;
+        score = row16_sum(j == 0 ? s : 0);
+    }
+    bool plane_ac = row16_or(nz ? 1 : 0) != 0;
+    if (plane_ac && inter && decimate && score < 7) plane_ac = false;
+    if (et) plane_ac = false;
+    int f[4];
+    { int a = dcs[0] + dcs[1], b = dcs[0] - dcs[1], cc = dcs[2] + dcs[3], d = dcs[2] - dcs[3];
+      f[0] = a + cc; f[1] = b + d; f[2] = a - cc; f[3] = b - d; }
+    int ldc[4], nzdc = 0;
+#pragma unroll
+    for (int b = 0; b < 4; b++) { ldc[b] = quant_one(f[b], q.mf[0] >> 1, q.bias[0] << 1); nzdc |= ldc[b]; }
+    if (et && et_drop_dc) { ldc[0] = ldc[1] = ldc[2] = ldc[3] = 0; nzdc = 0; }
+    if (nzdc && !plane_ac) {
+        const int dmf = q.dq[0] << (q.qp / 6);
+        if (dmf <= 32 * 64) {
+            auto rnd = [&](int o[4]) {
+                const int d0 = ldc[0] + ldc[1], d1 = ldc[2] + ldc[3], d2 = ldc[0] - ldc[1], d3 = ldc[2] - ldc[3];
+                o[0] = ((d0 + d1) * dmf >> 5) + 32; o[1] = ((d0 - d1) * dmf >> 5) + 32;
+                o[2] = ((d2 + d3) * dmf >> 5) + 32; o[3] = ((d2 - d3) * dmf >> 5) + 32;
+            };
+            int ref[4], out[4];
+            rnd(ref);
+            if (!((ref[0] | ref[1] | ref[2] | ref[3]) >> 6)) { ldc[0] = ldc[1] = ldc[2] = ldc[3] = 0; nzdc = 0; }
+            else {
+                int left = 0;
+#define X264GPU_OPT_DC(C) { int level = ldc[C]; const int sign = level >> 31 | 1; \
+                    while (level) { ldc[C] = level - sign; rnd(out); \
+                        if (((ref[0] ^ out[0]) | (ref[1] ^ out[1]) | (ref[2] ^ out[2]) | (ref[3] ^ out[3])) >> 6) { left = 1; ldc[C] = level; break; } \
+                        level -= sign; } }
+                X264GPU_OPT_DC(3) X264GPU_OPT_DC(1) X264GPU_OPT_DC(2) X264GPU_OPT_DC(0)
+#undef X264GPU_OPT_DC
+                if (!left) { ldc[0] = ldc[1] = ldc[2] = ldc[3] = 0; nzdc = 0; }
+                else nzdc = 1;
+            }
+        }
+    }
+    int dq[4] = { 0, 0, 0, 0 };
+    if (nzdc) {
+        int a = ldc[0] + ldc[1], b = ldc[0] - ldc[1], cc = ldc[2] + ldc[3], d = ldc[2] - ldc[3];
+        int g[4] = { a + cc, b + d, a - cc, b - d };
+        int ls = q.dq[0] << (q.qp / 6);
+#pragma unroll
+        for (int b2 = 0; b2 < 4; b2++) dq[b2] = (g[b2] * ls) >> 5;
+    }
+    const bool keep = plane_ac && nz;
+    if (act) {
+        int16_t *l = lv + X264GPU_LV_CHROMA_AC + (c * 4 + i) * 16;
+        int z[4] = { 0, 0, 0, 0 };
+        store_levels_scan(l, keep ? v : z, j);
+        if (i == 0 && j == 0)
+#pragma unroll
+            for (int b = 0; b < 4; b++) lv[X264GPU_LV_CHROMA_DC + c * 4 + b] = (int16_t)ldc[b];
+    }
+    if (keep) dequant4_row(v, q, j);
+    else { v[0] = v[1] = v[2] = v[3] = 0; }
+    if (j == 0) v[0] = dq[i];
+    idct4_quad(v, lane);
+#pragma unroll
+    for (int t = 0; t < 4; t++) v[t] += p[t];
+    unsigned long long bal = __ballot(act && keep && j == 0);
+    unsigned long long bdc = __ballot(act && nzdc != 0 && i == 0 && j == 0);
+    unsigned bits = 0;
+#pragma unroll
+    for (int b = 0; b < 8; b++) bits |= (unsigned)((bal >> (4 * b)) & 1) << (16 + b);
+    bits |= (unsigned)(bdc & 1) << 25;
+    bits |= (unsigned)((bdc >> 16) & 1) << 26;
+    nnz_bits |= bits;
+    cbp_chroma = (bits & 0x00ff0000u) ? 2 : (bits & 0x06000000u) ? 1 : 0;
+    return pack4_clip(v);
+}
+
+// store the reconstructed chroma rows of lanes 0..31 (U lanes 0..15, V lanes 16..31) as NV12
+__device__ __forceinline__ void mb_store_chroma(uint8_t *ruv, int rs, int lane, uint32_t crec)
+{
+    const int ci = (lane >> 2) & 3, j = lane & 3, cx0 = (ci & 1) * 4, cyy = (ci >> 1) * 4 + j;
+    const uint32_t other = (uint32_t)__shfl_xor((int)crec, 16);
+    if (lane < 16) {
+        const uint32_t u = crec, w = other;
+        uint2 o;
+        o.x = (u & 0xff) | ((w & 0xff) << 8) | ((u & 0xff00) << 8) | ((w & 0xff00) << 16);
+        o.y = ((u >> 16) & 0xff) | (((w >> 16) & 0xff) << 8) | ((u >> 24) << 16) | ((w >> 24) << 24);
+        *(uint2 *)(ruv + (size_t)cyy * rs + 2 * cx0) = o;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// x264_macroblock_probe_pskip (oracle probe_pskip): would the macroblock code to nothing at the skip vector?
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ bool mb_probe_pskip(const EncK &k, const MbCtx &c, uint32_t cz, int pmx, int pmy, const Q4 &ql, const Q4 &qc)
+{
+    const int lane = c.lane, j = lane & 3, zx = z_x0(lane), zy = z_y(lane);
+    const int mvx = clampi(pmx, c.mvmin0, c.mvmax0), mvy = clampi(pmy, c.mvmin1, c.mvmax1);
+    bool ok;
+    {
+        const uint32_t pred = mc_luma_row4(ref_plane00(k, c.s, 0), k.plane_bytes, k.rs, c.px + zx, c.py + zy, mvx, mvy);
+        int e[4], p[4], v[4];
+        unpack4(cz, e); unpack4(pred, p);
+#pragma unroll
+        for (int i = 0; i < 4; i++) v[i] = e[i] - p[i];
+        dct4_quad(v, lane);
+        quant4_row(v, ql, j);
+        const unsigned mask = (unsigned)quad_or((int)scan_mask(v, j));
+        const int big = quad_or(any_big(v) ? 1 : 0);
+        const int sc = mask ? (big ? 9 : decimate_from_mask(mask, 0)) : 0;
+        ok = wave_sum(j == 0 ? sc : 0) < 6;
+    }
+    {
+        const int pl = (lane >> 4) & 1, ci = (lane >> 2) & 3, cx0 = (ci & 1) * 4, cyy = (ci >> 1) * 4 + j;
+        const bool act = lane < 32;
+        uint32_t pu, pv;
+        mc_chroma_row4(ref_chroma00(k, c.s, 0), k.rs, c.mbx * 8 + cx0, c.mby * 8 + cyy, mvx, mvy, pu, pv);
+        const uint2 fe = *(const uint2 *)(c.fuv + (size_t)cyy * k.fs + 2 * cx0);
+        const uint32_t cenc = nv12_pick(fe.x, fe.y, pl), cpred = pl ? pv : pu;
+        int e[4], p[4], v[4];
+        unpack4(cenc, e); unpack4(cpred, p);
+#pragma unroll
+        for (int t = 0; t < 4; t++) v[t] = act ? e[t] - p[t] : 0;
+        const int thresh = (c_lambda2_tab[qc.qp] + 32) >> 6;
+        const int ssd = row16_sum(v[0] * v[0] + v[1] * v[1] + v[2] * v[2] + v[3] * v[3]);
+        dct4_quad(v, lane);
+        int dcs[4];
+#pragma unroll
+        for (int b = 0; b < 4; b++) dcs[b] = __shfl(v[0], (lane & 48) + 4 * b);
+        int f[4];
+        { int a = dcs[0] + dcs[1], b = dcs[0] - dcs[1], cc = dcs[2] + dcs[3], d = dcs[2] - dcs[3];
+          f[0] = a + cc; f[1] = b + d; f[2] = a - cc; f[3] = b - d; }
+        int nzdc = 0;
+#pragma unroll
+        for (int b = 0; b < 4; b++) nzdc |= quant_one(f[b], qc.mf[0] >> 1, qc.bias[0] << 1);
+        if (j == 0) v[0] = 0;
+        quant4_row(v, qc, j);
+        const unsigned mask = (unsigned)quad_or((int)scan_mask(v, j));
+        const int big = quad_or(any_big(v) ? 1 : 0);
+        const int sc = mask ? (big ? 9 : decimate_from_mask(mask, 1)) : 0;
+        const int score = row16_sum(j == 0 ? sc : 0);
+        const bool fail = ssd >= thresh && (nzdc != 0 || (ssd >= thresh * 4 && score >= 7));
+        ok = ok && !__builtin_amdgcn_readlane((int)fail, 0) && !__builtin_amdgcn_readlane((int)fail, 16);
+    }
+    return ok;
+}
+
+// ------------------------------------------------------------------------------------------------
+// The slice kernel: one wavefront per stream walks the macroblocks in raster order.
+// ------------------------------------------------------------------------------------------------
+template <int M>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 4))) void k_mb_slice(EncK k)
+{
+    __shared__ __attribute__((aligned(16))) MbLds<M> L;
+    const int lane = threadIdx.x, s = blockIdx.x;
+    const uint32_t t4 = (lane >> 2) < 9 ? ((const uint32_t *)c_pred4_table.t)[lane] : 0x01010101u * U_DC;
+    for (int i = lane; i < 144; i += 64) ((uint32_t *)L.pred8tab)[i] = ((const uint32_t *)c_pred8_table)[i];
+    lds_sync();
+    x264gpu_mb *mbs = k.mb + (size_t)s * k.nmb;
+    const bool pslice = k.slice_type == X264GPU_SLICE_P;
+    const int j4 = lane & 3, zx = z_x0(lane), zy = z_y(lane);
+    int intra_count = 0;
+    int16_t *mv16 = k.mv16_cur + (size_t)s * k.nmb * 2;
+    uint8_t *mbtype_cur = k.mbtype_cur + (size_t)s * k.nmb;
+
+    for (int mbi = 0; mbi < k.nmb; mbi++) {
+        MbCtx c;
+        c.s = s; c.lane = lane; c.mbi = mbi; c.mbx = mbi % k.mbw; c.mby = mbi / k.mbw; c.px = c.mbx * 16; c.py = c.mby * 16;
+        c.fenc = k.fenc_y + (size_t)s * k.fency_bytes + (size_t)c.py * k.fs + c.px;
+        c.fuv = k.fenc_uv + (size_t)s * k.fencuv_bytes + (size_t)c.mby * 8 * k.fs + c.px;
+        c.qp = __builtin_amdgcn_readfirstlane((int)k.mbqp[(size_t)s * k.nmb + mbi]);
+        c.qpc = (int)d_chroma_qp_table[min(max(c.qp + k.chroma_qp_offset, 0), 51)];
+        c.lambda = k.lambda_tab[c.qp];
+        c.subme = min(max(k.subme, 0), 11); c.satd = c.subme > 1; c.chroma_me = pslice && k.chroma_me && c.subme >= 5;
+        c.cost_base = k.cost_all + (size_t)c.qp * 2 * MVCOST_HALF;
+        c.nref = k.nref;
+        const Q4 &q_li = k.q4tab[c.qp * 4 + 0], &q_lp = k.q4tab[c.qp * 4 + 1], &q_ci = k.q4tab[c.qpc * 4 + 2], &q_cp = k.q4tab[c.qpc * 4 + 3];
+        const Q8 &q8i = k.q8tab[c.qp * 2 + 0], &q8p = k.q8tab[c.qp * 2 + 1];
+        const bool left = c.mbx > 0, top = c.mby > 0, topright = top && c.mbx + 1 < k.mbw, topleft = top && left;
+        const int mbx = c.mbx, mby = c.mby;
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        const int type_left = left ? (int)mbs[mbi - 1].type : -1, type_top = top ? (int)mbs[mbi - k.mbw].type : -1;
+        const int type_tl = topleft ? (int)mbs[mbi - k.mbw - 1].type : -1, type_tr = topright ? (int)mbs[mbi - k.mbw + 1].type : -1;
+        auto intra_t = [](int t) { return t >= 0 && t <= 3; };
+        uint8_t *rec = rec_plane00(k, s) + (size_t)c.py * k.rs + c.px;
+        uint8_t *ruv = rec_chroma00(k, s) + (size_t)(mby * 8) * k.rs + c.px;
+        int16_t *lv = k.levels + ((size_t)s * k.nmb + mbi) * X264GPU_MB_LEVELS;
+        uint8_t *tile = L.tile + IT_ORG, *tile8 = L.tile8 + IT_ORG;
+
+        // ---- neighbour samples (row -1, column -1 of the reconstruction), neighbour edge modes, chroma ring ----
+        lds_sync();
+        if (lane < 25) {
+            const int x = lane - 1;
+            const bool ok = top && (x >= 0 || left) && (x < 16 || topright);
+            const uint8_t v = ok ? rec[-(long)k.rs + x] : 128;
+            tile[-IT_STRIDE + x] = v; tile8[-IT_STRIDE + x] = v;
+            if (lane < 21) L.nb[NB_TOP + x] = v;
+        } else if (lane >= 32 && lane < 48) {
+            const int y = lane - 32;
+            const uint8_t v = left ? rec[(long)y * k.rs - 1] : 128;
+            tile[y * IT_STRIDE - 1] = v; tile8[y * IT_STRIDE - 1] = v; L.nb[NB_LEFT + y] = v;
+        } else if (lane >= 48 && lane < 56) {
+            const int i = lane - 48;
+            int m = 2;
+            if (i < 4 && left) { const x264gpu_mb *n = mbs + mbi - 1; if (n->type == X264GPU_MB_I4x4 || n->type == X264GPU_MB_I8x8) m = n->i4_mode[blkidx_of(3, i)]; }
+            if (i >= 4 && top) { const x264gpu_mb *n = mbs + mbi - k.mbw; if (n->type == X264GPU_MB_I4x4 || n->type == X264GPU_MB_I8x8) m = n->i4_mode[blkidx_of(i - 4, 3)]; }
+            L.nmodes[i] = (uint8_t)m;
+        }
+        {
+            const int t = lane & 15, pl = (lane >> 4) & 1;
+            if (lane < 32) {
+                if (t < 9) { const int x = t - 1; L.cnb[pl][CNB_TOP + x] = (top && (x >= 0 || left)) ? ruv[-(long)k.rs + 2 * x + pl] : 128; }
+            } else if (lane < 48) {
+                const int y = t & 7, pl2 = (t >> 3) & 1;
+                L.cnb[pl2][CNB_LEFT + y] = left ? ruv[(long)y * k.rs - 2 + pl2] : 128;
+            }
+        }
+        // ---- motion cache: neighbours' references / vectors at 8x8 granularity; this macroblock's blocks start unavailable ----
+        if (lane < 12) {
+            const int gx = (lane & 3) - 1, gy = (lane >> 2) - 1;
+            int ref = -2, vx = 0, vy = 0, nbi = -1, blk = 0;
+            if (gy < 0) {
+                if (gx < 0) { if (topleft) { nbi = mbi - k.mbw - 1; blk = 3; } }
+                else if (gx < 2) { if (top) { nbi = mbi - k.mbw; blk = 2 + gx; } }
+                else if (topright) { nbi = mbi - k.mbw + 1; blk = 2; }
+            } else if (gx < 0 && left) { nbi = mbi - 1; blk = 1 + 2 * gy; }
+            if (pslice && nbi >= 0) {
+                const x264gpu_mb *n = mbs + nbi;
+                if (n->type <= 3) ref = -1;
+                else { ref = n->ref[blk]; vx = n->mv[blk][0]; vy = n->mv[blk][1]; }
+            }
+            L.cref[lane] = ref; L.cmvx[lane] = vx; L.cmvy[lane] = vy;
+        }
+        const uint32_t cz = *(const uint32_t *)(c.fenc + (size_t)zy * k.fs + zx);
+        lds_sync();
+
+        x264gpu_mb recd;
+        __builtin_memset(&recd, 0, sizeof(recd));
+        recd.qp = (uint8_t)c.qp;
+        const int parts = k.partitions;
+        const bool early_term = c.subme < 11;
+        int mb_type = X264GPU_MB_I16x16, i_cost = 0, predc = 0, satd_chroma = MB_COST_MAX;
+        IntraRes IR;
+        bool pskip = false;
+        int pskx = 0, psky = 0, best_part = D_16x16;
+
+        if (pslice) {
+            // ---- limits ----
+            const int fr = 4 * (k.mv_range > 0 ? k.mv_range : 512);
+            c.mvmin0 = 4 * (-16 * mbx - 24); c.mvmax0 = 4 * (16 * (k.mbw - mbx - 1) + 24);
+            c.mvmin1 = 4 * (-16 * mby - 24); c.mvmax1 = 4 * (16 * (k.mbh - mby - 1) + 24);
+            c.smin0 = clampi(c.mvmin0, -fr, fr - 1); c.smax0 = clampi(c.mvmax0, -fr, fr - 1);
+            c.smin1 = clampi(c.mvmin1, -fr, fr - 1); c.smax1 = clampi(c.mvmax1, -fr, fr - 1);
+            c.fmin0 = (c.smin0 >> 2) + 6; c.fmax0 = (c.smax0 >> 2) - 6; c.fmin1 = (c.smin1 >> 2) + 6; c.fmax1 = (c.smax1 >> 2) - 6;
+            // ---- fast intra decision, skip vector, fast skip ----
+            bool fast_intra = false;
+            if (early_term && mbi > 4) {
+                const int colo = k.mbtype_ref0[(size_t)s * k.nmb + mbi];
+                fast_intra = !(intra_t(type_left) || intra_t(type_top) || intra_t(type_tl) || intra_t(type_tr) || intra_t(colo) || mbi < 3 * intra_count);
+            }
+            {
+                const int ra = L.cref[4], rb = L.cref[1];
+                if (ra == -2 || rb == -2 || (ra == 0 && !(L.cmvx[4] | L.cmvy[4])) || (rb == 0 && !(L.cmvx[1] | L.cmvy[1]))) pskx = psky = 0;
+                else mb_predict_mv(L, D_16x16, 0, 0, 2, 0, pskx, psky);
+            }
+            bool try_skip = false;
+            if (k.fast_pskip) {
+                if (c.subme >= 3) try_skip = true;
+                else if (type_left == X264GPU_MB_P_SKIP || type_top == X264GPU_MB_P_SKIP || type_tl == X264GPU_MB_P_SKIP || type_tr == X264GPU_MB_P_SKIP)
+                    pskip = mb_probe_pskip(k, c, cz, pskx, psky, q_lp, q_cp);
+            }
+            if (pskip) {
+                if (lane == 0) { mv16[2 * mbi] = 0; mv16[2 * mbi + 1] = 0; }
+                if (lane >= 1 && lane < c.nref) { int16_t *m = k.mvr[lane] + ((size_t)s * k.nmb + mbi) * 2; m[0] = 0; m[1] = 0; }
+            }
+            // ---- inter analysis: one search call site, walked by a small state machine (oracle analyse_inter_*) ----
+            const bool psub16 = (parts & 1) != 0, mixed = k.mixed_refs != 0;
+            int stage = 0, part = 0, kk = 0, nk = c.nref;
+            int halfpel_thresh = 0x7fffffff;
+            int i_maxref = c.nref - 1, ref_a = 0, ref_b = 0;      // 8x8: highest reference tried; 16x8 / 8x16: the two candidate references
+            int cost8x8 = 0, est1 = 0;
+            int sat8[4] = { 0, 0, 0, 0 };
+            bool done = pskip;
+            if (lane == 0) L.me_cost[ME_16] = 0x7fffffff;
+            i_cost = 0x7fffffff;
+            // a 16x8 / 8x16 half: candidate references = those of its two 8x8 blocks (lower index first); before the first half also the
+            // cost estimate of the second one and an empty cache for this macroblock's blocks
+            auto setup_half = [&](int st, int pt) {
+                lds_sync();
+                const int b0 = st == 2 ? 2 * pt : pt, b1 = st == 2 ? 2 * pt + 1 : pt + 2;
+                const int r0 = L.me_ref[ME_8 + b0], r1 = L.me_ref[ME_8 + b1];
+                ref_a = min(r0, r1); ref_b = max(r0, r1); nk = ref_a == ref_b ? 1 : 2;
+                if (pt == 0) {
+                    const int o0 = st == 2 ? 2 : 1;
+                    const int avg = (L.me_costmv[ME_8 + o0] + L.me_refcost[ME_8 + o0] + L.me_costmv[ME_8 + 3] + L.me_refcost[ME_8 + 3] + 1) >> 1;
+                    est1 = (st == 2 ? sat8[2] : sat8[1]) + sat8[3] + avg;
+                    if (lane == 5 || lane == 6 || lane == 9 || lane == 10) L.cref[lane] = -2;
+                }
+            };
+            while (!done) {
+                lds_sync();
+                MeJob jb;
+                int slot, r;
+                jb.search = stage < 4; jb.use_thresh = false; jb.n_mvc = 0;
+                if (stage == 0) {
+                    r = kk; slot = ME_16;
+                    jb.W = 16; jb.H = 16; jb.ox = 0; jb.oy = 0;
+                    mb_predict_mv(L, D_16x16, 0, 0, 2, r, jb.mvpx, jb.mvpy);
+                    // candidates (oracle predict_mv_ref16x16): lookahead vector, 16x16 results of the left / top / top-left / top-right macroblocks
+                    // in this reference, co-located vectors of reference 0 scaled by the POC distances
+                    if (lane == 0) {
+                        int n = 0;
+                        const int16_t *mvr = (r == 0 ? k.mv16_cur : k.mvr[r]) + (size_t)s * k.nmb * 2;
+                        if (r == 0 && k.lowres_mv) {
+                            const int16_t *lm = k.lowres_mv + (size_t)s * k.nmb * 2;
+                            if (lm[0] != 0x7fff) { L.mvc_in[n][0] = lm[2 * mbi] * 2; L.mvc_in[n][1] = lm[2 * mbi + 1] * 2; n++; }
+                        }
+                        const int nbi[4] = { left ? mbi - 1 : -1, top ? mbi - k.mbw : -1, topleft ? mbi - k.mbw - 1 : -1, topright ? mbi - k.mbw + 1 : -1 };
+                        for (int i = 0; i < 4; i++) { L.mvc_in[n][0] = nbi[i] >= 0 ? mvr[2 * nbi[i]] : 0; L.mvc_in[n][1] = nbi[i] >= 0 ? mvr[2 * nbi[i] + 1] : 0; n++; }
+                        if (k.temporal) {
+                            const int16_t *l0 = k.mv16_ref0 + (size_t)s * k.nmb * 2;
+                            const int scale = k.tscale[r];
+                            const int at[3] = { mbi, mbx < k.mbw - 1 ? mbi + 1 : -1, mby < k.mbh - 1 ? mbi + k.mbw : -1 };
+                            for (int i = 0; i < 3; i++)
+                                if (at[i] >= 0) { L.mvc_in[n][0] = (l0[2 * at[i]] * scale + 128) >> 8; L.mvc_in[n][1] = (l0[2 * at[i] + 1] * scale + 128) >> 8; n++; }
+                        }
+                        L.mvc_in[9][0] = n;
+                    }
+                    lds_sync();
+                    jb.n_mvc = L.mvc_in[9][0];
+                    jb.use_thresh = early_term && c.nref > 1;
+                    jb.hp_it = c.subme >= 2 ? (c.subme < 6 ? 1 : c.subme < 8 ? 2 : 4) : 0;
+                    jb.qp_it = c.subme < 4 ? 0 : c.subme == 4 ? 1 : c.subme < 8 ? 2 : 10;
+                } else if (stage == 1) {
+                    r = mixed ? kk : L.me_ref[ME_16]; slot = ME_8 + part;
+                    jb.W = 8; jb.H = 8; jb.ox = 8 * (part & 1); jb.oy = 8 * (part >> 1);
+                    mb_predict_mv(L, D_8x8, part & 1, part >> 1, 1, r, jb.mvpx, jb.mvpy);
+                    if (lane <= part) { L.mvc_in[lane][0] = L.mvc[r][lane][0]; L.mvc_in[lane][1] = L.mvc[r][lane][1]; }
+                    jb.n_mvc = part + 1;
+                } else if (stage == 2) {
+                    r = kk == 0 ? ref_a : ref_b; slot = ME_16x8 + part;
+                    jb.W = 16; jb.H = 8; jb.ox = 0; jb.oy = 8 * part;
+                    mb_predict_mv(L, D_16x8, 0, part, 2, r, jb.mvpx, jb.mvpy);
+                    if (lane < 3) { const int q = lane == 0 ? 0 : 2 * part + lane; L.mvc_in[lane][0] = L.mvc[r][q][0]; L.mvc_in[lane][1] = L.mvc[r][q][1]; }
+                    jb.n_mvc = 3;
+                } else if (stage == 3) {
+                    r = kk == 0 ? ref_a : ref_b; slot = ME_8x16 + part;
+                    jb.W = 8; jb.H = 16; jb.ox = 8 * part; jb.oy = 0;
+                    mb_predict_mv(L, D_8x16, part, 0, 1, r, jb.mvpx, jb.mvpy);
+                    if (lane < 3) { const int q = lane == 0 ? 0 : lane == 1 ? part + 1 : part + 3; L.mvc_in[lane][0] = L.mvc[r][q][0]; L.mvc_in[lane][1] = L.mvc[r][q][1]; }
+                    jb.n_mvc = 3;
+                } else {
+                    // x264_me_refine_qpel of the winner's blocks
+                    slot = best_part == D_16x16 ? ME_16 : best_part == D_16x8 ? ME_16x8 + part : best_part == D_8x16 ? ME_8x16 + part : ME_8 + part;
+                    r = L.me_ref[slot];
+                    jb.W = best_part == D_16x16 || best_part == D_16x8 ? 16 : 8; jb.H = best_part == D_16x16 || best_part == D_8x16 ? 16 : 8;
+                    jb.ox = best_part == D_8x16 ? 8 * part : best_part == D_8x8 ? 8 * (part & 1) : 0;
+                    jb.oy = best_part == D_16x8 ? 8 * part : best_part == D_8x8 ? 8 * (part >> 1) : 0;
+                    jb.mvpx = L.me_mvpx[slot]; jb.mvpy = L.me_mvpy[slot];
+                    jb.hp_it = c.subme == 1 ? 1 : 0;
+                    jb.qp_it = c.subme == 1 ? 1 : c.subme >= 2 && c.subme <= 5 ? (c.subme == 2 ? 1 : 2) : 0;
+                }
+                if (stage >= 1 && stage <= 3) {
+                    jb.hp_it = c.subme >= 2 ? (c.subme < 6 ? 1 : c.subme < 8 ? 2 : 4) : 0;
+                    jb.qp_it = c.subme < 4 ? 0 : c.subme == 4 ? 1 : c.subme < 8 ? 2 : 10;
+                }
+                jb.ref = r;
+                lds_sync();
+                const int rc = ref_bits(c.nref, r) * c.lambda;
+                int mvx = 0, mvy = 0, cost = 0, cost_mv = 0;
+                if (stage == 0) halfpel_thresh -= rc;
+                if (stage == 4) { mvx = L.me_mvx[slot]; mvy = L.me_mvy[slot]; cost = L.me_cost[slot] - L.me_refcost[slot]; cost_mv = L.me_costmv[slot]; }
+                me_search<M>(k, L, c, jb, mvx, mvy, cost, cost_mv, halfpel_thresh);
+                lds_sync();
+                // ---- merge / advance ----
+                if (stage == 0) {
+                    if (lane == 0) {
+                        int16_t *mo = (r == 0 ? k.mv16_cur : k.mvr[r]) + ((size_t)s * k.nmb + mbi) * 2;
+                        mo[0] = (int16_t)mvx; mo[1] = (int16_t)mvy;
+                        L.mvc[r][0][0] = (int16_t)mvx; L.mvc[r][0][1] = (int16_t)mvy;
+                    }
+                    if (r == 0 && try_skip && cost - cost_mv < 300 * c.lambda && abs(mvx - pskx) + abs(mvy - psky) <= 1 && mb_probe_pskip(k, c, cz, pskx, psky, q_lp, q_cp)) {
+                        pskip = true; done = true;
+                        if (lane >= 1 && lane < c.nref) { int16_t *m = k.mvr[lane] + ((size_t)s * k.nmb + mbi) * 2; m[0] = 0; m[1] = 0; }
+                        continue;
+                    }
+                    cost += rc; halfpel_thresh += rc;
+                    if (cost < L.me_cost[ME_16] && lane == 0) {
+                        L.me_mvx[ME_16] = mvx; L.me_mvy[ME_16] = mvy; L.me_cost[ME_16] = cost; L.me_costmv[ME_16] = cost_mv; L.me_ref[ME_16] = r; L.me_refcost[ME_16] = rc;
+                        L.me_mvpx[ME_16] = jb.mvpx; L.me_mvpy[ME_16] = jb.mvpy;
+                    }
+                    lds_sync();
+                    if (++kk < nk) continue;
+                    // 16x16 done
+                    i_cost = L.me_cost[ME_16]; best_part = D_16x16;
+                    if (!psub16) { stage = 4; part = 0; if (!c.subme) done = true; continue; }
+                    stage = 1; part = 0; kk = 0;
+                    i_maxref = c.nref - 1;
+                    if (mixed) {
+                        if (early_term && i_maxref > 0 && L.me_ref[ME_16] == 0 && type_top > 0 && type_left > 0) {
+                            i_maxref = max(max(max(L.cref[0], L.cref[1]), max(L.cref[2], L.cref[3])), max(max(L.cref[4], L.cref[8]), 0));
+                        }
+                        nk = i_maxref + 1;
+                    } else nk = 1;
+                    if (lane == 5 || lane == 6 || lane == 9 || lane == 10) L.cref[lane] = -2;      // this macroblock's blocks: not decided yet
+                    if (lane == 0) { L.me_cost[ME_8] = 0x7fffffff; }
+                    continue;
+                }
+                if (stage == 1) {
+                    const int rcost = mixed ? rc : (r ? rc : 0);
+                    cost += rcost;
+                    if (lane == 0) {
+                        L.mvc[r][part + 1][0] = (int16_t)mvx; L.mvc[r][part + 1][1] = (int16_t)mvy;
+                        if (kk == 0 || cost < L.me_cost[slot]) {
+                            L.me_mvx[slot] = mvx; L.me_mvy[slot] = mvy; L.me_cost[slot] = cost; L.me_costmv[slot] = cost_mv; L.me_ref[slot] = r; L.me_refcost[slot] = rcost;
+                            L.me_mvpx[slot] = jb.mvpx; L.me_mvpy[slot] = jb.mvpy;
+                        }
+                    }
+                    lds_sync();
+                    if (++kk < nk) continue;
+                    // block done: into the cache, cost bookkeeping
+                    {
+                        const int g = ((part >> 1) + 1) * 4 + (part & 1) + 1;
+                        if (lane == 0) { L.cref[g] = L.me_ref[slot]; L.cmvx[g] = L.me_mvx[slot]; L.cmvy[g] = L.me_mvy[slot]; }
+                        const int sv = L.me_cost[slot] - (L.me_costmv[slot] + L.me_refcost[slot]);
+                        if (part == 0) sat8[0] = sv; else if (part == 1) sat8[1] = sv; else if (part == 2) sat8[2] = sv; else sat8[3] = sv;
+                        lds_sync();
+                        if (lane == 0) L.me_cost[slot] += c.lambda;       // sub-macroblock type (CAVLC)
+                        lds_sync();
+                    }
+                    kk = 0;
+                    if (++part < 4) continue;
+                    cost8x8 = L.me_cost[ME_8] + L.me_cost[ME_8 + 1] + L.me_cost[ME_8 + 2] + L.me_cost[ME_8 + 3];
+                    if (mixed && !(L.me_ref[ME_8] | L.me_ref[ME_8 + 1] | L.me_ref[ME_8 + 2] | L.me_ref[ME_8 + 3])) cost8x8 -= ref_bits(c.nref, 0) * c.lambda * 4;
+                    const int c16 = L.me_cost[ME_16];
+                    if (!early_term || cost8x8 < c16) { best_part = D_8x8; i_cost = cost8x8; }
+                    const int th = L.me_costmv[ME_8 + 1] + L.me_costmv[ME_8 + 2];
+                    if (!early_term || cost8x8 < c16 + th) { stage = 2; part = 0; kk = 0; setup_half(2, 0); }
+                    else { stage = 4; part = 0; if (!c.subme) done = true; }
+                    continue;
+                }
+                if (stage == 2 || stage == 3) {
+                    cost += rc;
+                    if (lane == 0 && (kk == 0 || cost < L.me_cost[slot])) {
+                        L.me_mvx[slot] = mvx; L.me_mvy[slot] = mvy; L.me_cost[slot] = cost; L.me_costmv[slot] = cost_mv; L.me_ref[slot] = r; L.me_refcost[slot] = rc;
+                        L.me_mvpx[slot] = jb.mvpx; L.me_mvpy[slot] = jb.mvpy;
+                    }
+                    lds_sync();
+                    if (++kk < nk) continue;
+                    // this half is done; early termination on the first half plus the estimate of the second
+                    bool shape_done = part == 0 && early_term && L.me_cost[slot] + est1 > i_cost;
+                    if (!shape_done) {
+                        if (lane == 0) {
+                            const int g0 = stage == 2 ? (part + 1) * 4 + 1 : 5 + part, g1 = stage == 2 ? g0 + 1 : g0 + 4;
+                            L.cref[g0] = L.cref[g1] = L.me_ref[slot]; L.cmvx[g0] = L.cmvx[g1] = L.me_mvx[slot]; L.cmvy[g0] = L.cmvy[g1] = L.me_mvy[slot];
+                        }
+                        lds_sync();
+                        if (part == 0) { part = 1; kk = 0; setup_half(stage, 1); continue; }
+                        const int total = L.me_cost[slot - 1] + L.me_cost[slot];
+                        if (total < i_cost) { i_cost = total; best_part = stage == 2 ? D_16x8 : D_8x16; }
+                    }
+                    if (stage == 2) { stage = 3; part = 0; kk = 0; setup_half(3, 0); }
+                    else { stage = 4; part = 0; if (!c.subme) done = true; }
+                    continue;
+                }
+                // stage 4: refinement results
+                if (lane == 0) { L.me_mvx[slot] = mvx; L.me_mvy[slot] = mvy; L.me_cost[slot] = cost; L.me_costmv[slot] = cost_mv; }
+                lds_sync();
+                const int np = best_part == D_16x16 ? 1 : best_part == D_8x8 ? 4 : 2;
+                if (++part < np) continue;
+                i_cost = 0;
+                for (int i = 0; i < np; i++) i_cost += L.me_cost[(best_part == D_16x16 ? ME_16 : best_part == D_16x8 ? ME_16x8 : best_part == D_8x16 ? ME_8x16 : ME_8) + i];
+                done = true;
+            }
+            lds_sync();
+
+            if (!pskip) {
+                // ---- intra analysis against the inter cost ----
+                const int i_satd_inter = i_cost;
+                if (c.chroma_me) {
+                    satd_chroma = mb_intra_chroma_cost(k, L, c, predc);
+                    mb_analyse_intra(k, L, c, cz, t4, parts, i_cost - satd_chroma, fast_intra, early_term, q_li, q8i, IR);
+                    IR.satd_i16 += satd_chroma; IR.satd_i8 += satd_chroma; IR.satd_i4 += satd_chroma;
+                } else mb_analyse_intra(k, L, c, cz, t4, parts, i_cost, fast_intra, early_term, q_li, q8i, IR);
+                recd.aux[0] = i_satd_inter; recd.aux[1] = min(min(IR.satd_i16, IR.satd_i8), IR.satd_i4); recd.aux[2] = L.me_cost[ME_16];
+                mb_type = best_part == D_8x8 ? X264GPU_MB_P_8x8 : X264GPU_MB_P_L0;
+                if (IR.satd_i16 < i_cost) { i_cost = IR.satd_i16; mb_type = X264GPU_MB_I16x16; }
+                if (IR.satd_i8 < i_cost) { i_cost = IR.satd_i8; mb_type = X264GPU_MB_I8x8; }
+                if (IR.satd_i4 < i_cost) { i_cost = IR.satd_i4; mb_type = X264GPU_MB_I4x4; }
+            } else { mb_type = X264GPU_MB_P_SKIP; i_cost = 0; }
+        } else {
+            mb_analyse_intra(k, L, c, cz, t4, parts, MB_COST_MAX, false, early_term, q_li, q8i, IR);
+            i_cost = IR.satd_i16; mb_type = X264GPU_MB_I16x16;
+            if (IR.satd_i4 < i_cost) { i_cost = IR.satd_i4; mb_type = X264GPU_MB_I4x4; }
+            if (IR.satd_i8 < i_cost) { i_cost = IR.satd_i8; mb_type = X264GPU_MB_I8x8; }
+        }
+        recd.cost = i_cost;
+        recd.type = (uint8_t)mb_type;
+
+        // ---- x264_macroblock_encode ----
+        unsigned nnz = 0;
+        int cbp_luma = 0, cbp_chroma = 0;
+        if (mb_type >= X264GPU_MB_P_L0) {
+            // this lane's 8x8 block's motion (Z layout: lane >> 4)
+            const int b8 = lane >> 4;
+            int lmx, lmy, lref;
+            if (pskip) { lmx = clampi(pskx, c.mvmin0, c.mvmax0); lmy = clampi(psky, c.mvmin1, c.mvmax1); lref = 0; }
+            else {
+                const int slot = best_part == D_16x16 ? ME_16 : best_part == D_16x8 ? ME_16x8 + (b8 >> 1) : best_part == D_8x16 ? ME_8x16 + (b8 & 1) : ME_8 + b8;
+                lmx = L.me_mvx[slot]; lmy = L.me_mvy[slot]; lref = L.me_ref[slot];
+            }
+            const uint32_t pred = mc_luma_row4(ref_plane00(k, s, lref), k.plane_bytes, k.rs, c.px + zx, c.py + zy, lmx, lmy);
+            // chroma prediction: chroma 4x4 block ci <-> luma 8x8 ci
+            const int pl = (lane >> 4) & 1, ci = (lane >> 2) & 3, cx0 = (ci & 1) * 4, cyy = (ci >> 1) * 4 + j4;
+            const int cmvx = __shfl(lmx, ci * 16), cmvy = __shfl(lmy, ci * 16), cref = __shfl(lref, ci * 16);
+            uint32_t pu, pv;
+            mc_chroma_row4(ref_chroma00(k, s, cref), k.rs, mbx * 8 + cx0, mby * 8 + cyy, cmvx, cmvy, pu, pv);
+            const uint32_t cpred = pl ? pv : pu;
+            for (int b = 0; b < 4; b++) {
+                recd.mv[b][0] = (int16_t)(pskip ? pskx : __builtin_amdgcn_readlane(lmx, b * 16));
+                recd.mv[b][1] = (int16_t)(pskip ? psky : __builtin_amdgcn_readlane(lmy, b * 16));
+                recd.ref[b] = (int8_t)__builtin_amdgcn_readlane(lref, b * 16);
+            }
+            recd.partition = (uint8_t)(pskip ? 0 : best_part);
+            if (pskip) {
+                *(uint32_t *)(rec + (size_t)zy * k.rs + zx) = pred;
+                mb_store_chroma(ruv, k.rs, lane, cpred);
+                if (lane < 52) { uint4 z; z.x = z.y = z.z = z.w = 0; *(uint4 *)(lv + lane * 8) = z; }
+            } else {
+                const uint32_t enc = cz;
+                bool t8 = false;
+                uint32_t elo = 0, ehi = 0, plo = 0, phi = 0;
+                if (k.dct8x8) {
+                    z_to_r8(enc, lane, elo, ehi); z_to_r8(pred, lane, plo, phi);
+                    const int h8 = sa8d_r8_half(elo, ehi, plo, phi, lane);
+                    const int cost8 = (2 * wave_sum(lane < 32 ? h8 : 0) + 2) >> 2, cost4 = wave_sum(satd4_half(enc, pred, lane));
+                    t8 = cost8 < cost4;
+                }
+                if (t8) {
+                    const int row = lane & 7, i8 = (lane >> 3) & 3;
+                    int e[8], p[8], v[8];
+                    unpack8(elo, ehi, e); unpack8(plo, phi, p);
+#pragma unroll
+                    for (int i = 0; i < 8; i++) v[i] = e[i] - p[i];
+                    fwd8_1d(v); transpose8(v, lane); fwd8_1d(v); transpose8(v, lane);
+                    int mf[4], bs[4], dq[4];
+                    q8_row(q8p, row, mf, bs, dq);
+                    unsigned mlo = 0, mhi = 0, big = 0;
+#pragma unroll
+                    for (int i = 0; i < 8; i++) {
+                        v[i] = quant_one(v[i], mf[i & 3], bs[i & 3]);
+                        const int z = c_zigzag8_inv[row * 8 + i];
+                        if (v[i]) { if (z < 32) mlo |= 1u << z; else mhi |= 1u << (z - 32); }
+                        big |= abs(v[i]) > 1 ? 1u : 0u;
+                    }
+                    mlo = group8_or(mlo); mhi = group8_or(mhi); big = group8_or(big);
+                    const unsigned long long mask = ((unsigned long long)mhi << 32) | mlo;
+                    bool keep = mask != 0;
+                    if (k.dct_decimate) {
+                        const int sc = keep ? (big ? 9 : decimate64_from_mask(mask)) : 0;
+                        const int mbscore = __builtin_amdgcn_readlane(sc, 0) + __builtin_amdgcn_readlane(sc, 8) + __builtin_amdgcn_readlane(sc, 16) + __builtin_amdgcn_readlane(sc, 24);
+                        keep = keep && sc >= 4 && mbscore >= 6;
+                    }
+                    if (lane < 32) {
+#pragma unroll
+                        for (int i = 0; i < 8; i++) {
+                            const int z = c_zigzag8_inv[row * 8 + i];
+                            lv[(i8 * 4 + (z & 3)) * 16 + (z >> 2)] = (int16_t)(keep ? v[i] : 0);
+                        }
+                    }
+                    unsigned n4 = 0;
+#pragma unroll
+                    for (int q = 0; q < 4; q++) n4 |= (mask & (0x1111111111111111ull << q)) ? 1u << q : 0u;
+                    if (!keep) n4 = 0;
+#pragma unroll
+                    for (int g = 0; g < 4; g++) {
+                        const unsigned ng = (unsigned)__builtin_amdgcn_readlane((int)n4, g * 8);
+                        nnz |= ng << (4 * g);
+                        cbp_luma |= ng ? 1 << g : 0;
+                    }
+                    const int qb = q8p.qp / 6 - 6;
+#pragma unroll
+                    for (int i = 0; i < 8; i++) v[i] = keep ? dequant_one(v[i], dq[i & 3], qb) : 0;
+                    inv8_1d(v); transpose8(v, lane); inv8_1d(v); transpose8(v, lane);
+#pragma unroll
+                    for (int i = 0; i < 8; i++) v[i] = ((v[i] + 32) >> 6) + p[i];
+                    if (lane < 32) {
+                        uint2 o;
+                        o.x = pack4_clip8lo(v); o.y = pack4_clip8hi(v);
+                        *(uint2 *)(rec + (size_t)((i8 >> 1) * 8 + row) * k.rs + (i8 & 1) * 8) = o;
+                    }
+                } else {
+                    int e[4], p[4], v[4];
+                    unpack4(enc, e); unpack4(pred, p);
+#pragma unroll
+                    for (int i = 0; i < 4; i++) v[i] = e[i] - p[i];
+                    dct4_quad(v, lane);
+                    quant4_row(v, q_lp, j4);
+                    const unsigned mask = (unsigned)quad_or((int)scan_mask(v, j4));
+                    const bool nz = mask != 0;
+                    bool keep = nz;
+                    if (k.dct_decimate) {
+                        const int big = quad_or(any_big(v) ? 1 : 0);
+                        const int sc = nz ? (big ? 9 : decimate_from_mask(mask, 0)) : 0;
+                        const int score8 = row16_sum(j4 == 0 ? sc : 0);
+                        bool any8 = row16_or(nz ? 1 : 0) != 0;
+                        const int mbscore = wave_sum(((lane & 15) == 0 && any8) ? score8 : 0);
+                        if (any8 && score8 < 4) any8 = false;
+                        keep = nz && any8 && mbscore >= 6;
+                    }
+                    { int z[4] = { 0, 0, 0, 0 }; store_levels_scan(lv + (lane >> 2) * 16, keep ? v : z, j4); }
+                    if (!keep) v[0] = v[1] = v[2] = v[3] = 0;
+                    dequant4_row(v, q_lp, j4);
+                    idct4_quad(v, lane);
+#pragma unroll
+                    for (int i = 0; i < 4; i++) v[i] += p[i];
+                    *(uint32_t *)(rec + (size_t)zy * k.rs + zx) = pack4_clip(v);
+                    const unsigned long long bal = __ballot(keep && j4 == 0);
+#pragma unroll
+                    for (int b = 0; b < 16; b++) nnz |= (unsigned)((bal >> (4 * b)) & 1) << b;
+#pragma unroll
+                    for (int i8 = 0; i8 < 4; i8++) cbp_luma |= ((nnz >> (4 * i8)) & 15) ? 1 << i8 : 0;
+                }
+                const uint2 fe = *(const uint2 *)(c.fuv + (size_t)cyy * k.fs + 2 * cx0);
+                const uint32_t cenc = nv12_pick(fe.x, fe.y, pl);
+                const uint32_t crec = mb_chroma_residual(cenc, cpred, q_cp, true, k.dct_decimate != 0, lane, lv, nnz, cbp_chroma);
+                mb_store_chroma(ruv, k.rs, lane, crec);
+                if (lane >= 32 && lane < 40) lv[X264GPU_LV_LUMA_DC + (lane - 32) * 2] = 0, lv[X264GPU_LV_LUMA_DC + (lane - 32) * 2 + 1] = 0;
+                if (lane >= 40 && lane < 44) lv[408 + (lane - 40) * 2] = 0, lv[408 + (lane - 40) * 2 + 1] = 0;
+                recd.transform8x8 = (uint8_t)(t8 && cbp_luma);
+                // P_L0 16x16, reference 0, the skip vector, nothing coded: P_SKIP
+                if (mb_type == X264GPU_MB_P_L0 && best_part == D_16x16 && !(cbp_luma | cbp_chroma) && recd.ref[0] == 0 && recd.mv[0][0] == pskx && recd.mv[0][1] == psky)
+                    recd.type = X264GPU_MB_P_SKIP;
+            }
+        } else {
+            // ---- intra macroblock ----
+            for (int i = 0; i < 4; i++) recd.ref[i] = -1;
+            if (mb_type == X264GPU_MB_I8x8) {
+                recd.transform8x8 = 1;
+                for (int b = 0; b < 16; b++) recd.i4_mode[b] = L.modes8[b];
+                nnz = IR.nnz8; cbp_luma = IR.cbp8;
+                *(uint32_t *)(rec + (size_t)zy * k.rs + zx) = *(const uint32_t *)(tile8 + zy * IT_STRIDE + zx);
+                *(uint2 *)(lv + lane * 4) = *(const uint2 *)(L.lv8 + lane * 4);
+                if (lane < 16) lv[X264GPU_LV_LUMA_DC + lane] = 0;
+            } else if (mb_type == X264GPU_MB_I4x4) {
+                for (int b = 0; b < 16; b++) recd.i4_mode[b] = L.modes4[b];
+                nnz = IR.nnz4;
+                for (int i8 = 0; i8 < 4; i8++) if ((nnz >> (4 * i8)) & 15) cbp_luma |= 1 << i8;
+                *(uint32_t *)(rec + (size_t)zy * k.rs + zx) = *(const uint32_t *)(tile + zy * IT_STRIDE + zx);
+                *(uint2 *)(lv + lane * 4) = *(const uint2 *)(L.lv4 + lane * 4);
+                if (lane < 16) lv[X264GPU_LV_LUMA_DC + lane] = 0;
+            } else {
+                // x264_mb_encode_i16x16 (AC decimated as a whole in P slices)
+                const int mode16 = IR.pred16;
+                recd.i16_mode = (uint8_t)(mode16 > PRED16_P ? PRED16_DC : mode16);
+                const Pred16 pp = pred16_setup(L.nb, lane);
+                int e[4], p[4], v[4];
+                unpack4(cz, e); unpack4(pred16_row4(L.nb, pp, mode16, zx, zy), p);
+#pragma unroll
+                for (int t = 0; t < 4; t++) v[t] = e[t] - p[t];
+                dct4_quad(v, lane);
+                const int dcv = v[0];
+                if (j4 == 0) v[0] = 0;
+                quant4_row(v, q_li, j4);
+                const unsigned mask = (unsigned)quad_or((int)scan_mask(v, j4));
+                bool nz = mask != 0;
+                if (pslice && k.dct_decimate) {
+                    const int big = quad_or(any_big(v) ? 1 : 0);
+                    const int sc = nz ? (big ? 9 : decimate_from_mask(mask, 1)) : 0;
+                    if (wave_sum(j4 == 0 ? sc : 0) < 6) nz = false;
+                }
+                { int z[4] = { 0, 0, 0, 0 }; store_levels_scan(lv + (lane >> 2) * 16, nz ? v : z, j4); }
+                if (!nz) v[0] = v[1] = v[2] = v[3] = 0;
+                dequant4_row(v, q_li, j4);
+                const unsigned long long bal = __ballot(nz && j4 == 0);
+                unsigned acn = 0;
+#pragma unroll
+                for (int b = 0; b < 16; b++) acn |= (unsigned)((bal >> (4 * b)) & 1) << b;
+                int dc[4];
+#pragma unroll
+                for (int cc = 0; cc < 4; cc++) dc[cc] = __shfl(dcv, 4 * blkidx_of(cc, j4));
+                had4x4_quad(dc, lane);
+#pragma unroll
+                for (int cc = 0; cc < 4; cc++) dc[cc] = quant_one((dc[cc] + 1) >> 1, q_li.mf[0] >> 1, q_li.bias[0] << 1);
+                const bool nzdc = quad_or((dc[0] | dc[1] | dc[2] | dc[3]) != 0 ? 1 : 0) != 0;
+                if (lane < 4) store_levels_scan(lv + X264GPU_LV_LUMA_DC, dc, j4);
+                had4x4_quad(dc, lane);
+                {
+                    const int ls = q_li.dq[0], qb = c.qp / 6 - 6;
+#pragma unroll
+                    for (int cc = 0; cc < 4; cc++) dc[cc] = dequant_one(dc[cc], ls, qb);
+                }
+                {
+                    const int b = lane >> 2, bx = z_bx(b), by = z_by(b);
+                    int t0 = __shfl(dc[0], by), t1 = __shfl(dc[1], by), t2 = __shfl(dc[2], by), t3 = __shfl(dc[3], by);
+                    const int mine = bx == 0 ? t0 : bx == 1 ? t1 : bx == 2 ? t2 : t3;
+                    if (j4 == 0) v[0] = nzdc ? mine : 0;
+                }
+                idct4_quad(v, lane);
+#pragma unroll
+                for (int t = 0; t < 4; t++) v[t] += p[t];
+                *(uint32_t *)(rec + (size_t)zy * k.rs + zx) = pack4_clip(v);
+                nnz = acn | (nzdc ? 1u << 24 : 0);
+                cbp_luma = acn ? 15 : 0;
+            }
+            if (lane >= 16 && lane < 24) lv[408 + lane - 16] = 0;
+            // chroma: mode (unless chroma-ME already chose it), prediction, residual
+            if (satd_chroma >= MB_COST_MAX) satd_chroma = mb_intra_chroma_cost(k, L, c, predc);
+            {
+                const int pl = (lane >> 4) & 1, ci = (lane >> 2) & 3, cx0 = (ci & 1) * 4, cyy = (ci >> 1) * 4 + j4;
+                const PredC pc = predc_setup(L.cnb[pl]);
+                const uint2 fe = *(const uint2 *)(c.fuv + (size_t)cyy * k.fs + 2 * cx0);
+                const uint32_t cenc = nv12_pick(fe.x, fe.y, pl), cpred = predc_row4(L.cnb[pl], pc, predc, ci, j4);
+                recd.chroma_mode = (uint8_t)(predc > PREDC_P ? PREDC_DC : predc);
+                const uint32_t crec = mb_chroma_residual(cenc, cpred, q_ci, false, false, lane, lv, nnz, cbp_chroma);
+                mb_store_chroma(ruv, k.rs, lane, crec);
+            }
+            intra_count++;
+        }
+        recd.nnz = nnz; recd.cbp_luma = (uint8_t)cbp_luma; recd.cbp_chroma = (uint8_t)cbp_chroma;
+        if (lane == 0) { mbs[mbi] = recd; mbtype_cur[mbi] = recd.type; }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_s_waitcnt(0);
+    }
+}
+
+}  // namespace x264gpu

@@ -142,6 +142,7 @@ static SpsParams make_sps(const x264_t *h)
     s.overscan = p.vui.i_overscan; s.vidformat = p.vui.i_vidformat;
     s.num_units_in_tick = p.i_timebase_num; s.time_scale = p.i_timebase_den * 2;
     s.constraint_set0 = h->profile_idc == 66; s.constraint_set1 = h->profile_idc <= 77;
+    s.mv_range = h->param.analyse.i_mv_range;
     return s;
 }
 static PpsParams make_pps(const x264_t *h)
@@ -195,9 +196,12 @@ x264_t *x264_encoder_open(x264_param_t *param)
     if (!p.analyse.b_transform_8x8) { p.analyse.inter &= ~X264_ANALYSE_I8x8; p.analyse.intra &= ~X264_ANALYSE_I8x8; }   // as x264 validate_parameters
     p.analyse.i_trellis = 0;
     p.i_scenecut_threshold = clampi(p.i_scenecut_threshold, 0, 100);
-    if (p.analyse.i_me_method > X264_ME_ESA) { xlog(&p, X264_LOG_WARNING, "me tesa is not implemented in the MI355X path yet: me esa\n"); p.analyse.i_me_method = X264_ME_ESA; }
-    p.analyse.i_me_range = clampi(p.analyse.i_me_range, 4, p.analyse.i_me_method == X264_ME_UMH ? 64 : 16);     // x264 caps dia/hex at 16; esa: the LDS search window
-    p.analyse.i_subpel_refine = clampi(p.analyse.i_subpel_refine, 0, 7);
+    if (p.analyse.i_me_method > X264_ME_HEX) { xlog(&p, X264_LOG_WARNING, "me umh / esa / tesa are not implemented in the raster macroblock loop of the MI355X path yet: me hex\n"); p.analyse.i_me_method = X264_ME_HEX; }
+    p.analyse.i_me_range = clampi(p.analyse.i_me_range, 4, 16);     // x264 caps dia/hex at 16
+    // subme >= 6 means RD mode decision in x264 (i_mbrd >= 1): not implemented, so the highest level whose behaviour IS implemented is reported back
+    if (p.analyse.i_subpel_refine > 5) { xlog(&p, X264_LOG_WARNING, "subme %d needs RD mode decision, which is not implemented yet: subme 5\n", p.analyse.i_subpel_refine); p.analyse.i_subpel_refine = 5; }
+    p.analyse.i_subpel_refine = clampi(p.analyse.i_subpel_refine, 0, 5);
+    p.analyse.b_fast_pskip = p.analyse.b_fast_pskip != 0;
     p.analyse.b_chroma_me = p.analyse.b_chroma_me != 0;
     p.b_interlaced = 0; p.i_slice_count = 1;
     p.i_threads = clampi(p.i_threads, 1, 64);                  // --threads G: GOPs coded in lock-step (1 = no delay)
@@ -260,6 +264,14 @@ x264_t *x264_encoder_open(x264_param_t *param)
     cfg.aq_mode = p.rc.i_aq_mode == X264_AQ_VARIANCE; cfg.aq_strength_q8 = (int)(p.rc.f_aq_strength * 1.0397f * 256.0f + 0.5f);
     cfg.mixed_refs = p.analyse.b_mixed_references && (p.analyse.inter & X264_ANALYSE_PSUB16x16) != 0;
     cfg.chroma_me = p.analyse.b_chroma_me && p.analyse.i_subpel_refine >= 5;     // x264: h->mb.b_chroma_me in P slices
+    cfg.fast_pskip = p.analyse.b_fast_pskip;
+    // x264 validate_parameters: --mvrange defaults to the level's limit (x264_levels[].mv_range), never above 512 here
+    if (p.analyse.i_mv_range <= 0) {
+        p.analyse.i_mv_range = 512;
+        for (int i = 0; x264_levels[i].level_idc; i++) if (x264_levels[i].level_idc == h->level_idc) p.analyse.i_mv_range = x264_levels[i].mv_range;
+    }
+    p.analyse.i_mv_range = clampi(p.analyse.i_mv_range, 32, 512);
+    cfg.mv_range = p.analyse.i_mv_range;
     size_t insz = (size_t)p.i_width * p.i_height * 3 / 2;
     if (x264gpu_encoder_create(&h->gpu, &cfg) != X264GPU_OK ||
         x264gpu_malloc((void **)&h->d_in, insz) != X264GPU_OK ||

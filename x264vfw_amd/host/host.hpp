@@ -28,6 +28,7 @@ struct SpsParams {
     int sar_w, sar_h, fullrange, colorprim, transfer, colmatrix, overscan, vidformat;
     uint32_t num_units_in_tick, time_scale;
     int constraint_set0, constraint_set1;
+    int mv_range;            // --mvrange (luma samples): log2_max_mv_length_* = floor(log2(4 * mv_range - 1)) + 1, as x264's sps init
 };
 struct PpsParams { int pps_id, sps_id, cabac, num_ref, pic_init_qp, chroma_qp_offset, transform8x8_mode; };
 

@@ -66,7 +66,8 @@ void write_sps(std::vector<uint8_t> &out, const SpsParams &s, bool annexb)
         bw.put1(1);                             // bitstream_restriction_flag
         bw.put1(1);                             // motion_vectors_over_pic_boundaries_flag
         bw.ue(0); bw.ue(0);                     // max_bytes_per_pic_denom, max_bits_per_mb_denom
-        bw.ue(11); bw.ue(11);                   // log2_max_mv_length_horizontal / vertical (quarter pels: +-2048)
+        { int v = 4 * (s.mv_range > 0 ? s.mv_range : 512) - 1, l = 0; while (v >> (l + 1)) l++;      // x264: (int)log2f(max(1, mv_range * 4 - 1)) + 1
+          bw.ue((uint32_t)(l + 1)); bw.ue((uint32_t)(l + 1)); }   // log2_max_mv_length_horizontal / vertical
         bw.ue(0);                               // max_num_reorder_frames
         bw.ue(s.num_ref_frames);                // max_dec_frame_buffering
     }
