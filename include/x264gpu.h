@@ -162,7 +162,7 @@ typedef struct x264gpu_config {
                                * same bits 1-2 unless bit8 is set, then bit9 = i4x4 and bit10 = i8x8 (x264 keeps separate
                                * analyse.intra / analyse.inter masks) */
     int dct8x8;               /* --8x8dct: adaptive 8x8 luma transform (High profile) */
-    int me_method;            /* --me: 0 dia (radius-1 diamond), 1 hex (hexagon + square refine); X264_ME_DIA / _HEX (umh / esa: not in the device macroblock loop yet) */
+    int me_method;            /* --me: 0 dia (radius-1 diamond), 1 hex (hexagon + square refine), 2 umh (uneven multi-hexagon), 3 esa (exhaustive); X264_ME_DIA / _HEX / _UMH / _ESA */
     int chroma_me;            /* --chroma-me (x264 default on): sub-pel SATD costs of P macroblocks include the chroma planes; acts when subme >= 5,
                                * as x264's h->mb.b_chroma_me ([x264-upstream] encoder/encoder.c, me.c COST_MV_SATD) */
     int mixed_refs;           /* --mixed-refs (x264 default on): 8x8 blocks, and the 16x8 / 8x16 halves built on them, choose their reference

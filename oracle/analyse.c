@@ -354,7 +354,8 @@ static void me_search_ref(const actx *a, me_t *m, int (*mvc)[2], int i_mvc, int 
         const int max_x = bmx + i_me_range < fmax[0] ? bmx + i_me_range : fmax[0], max_y = bmy + i_me_range < fmax[1] ? bmy + i_me_range : fmax[1];
         const int width = (max_x - min_x + 3) & ~3;
         for (int my = min_y; my <= max_y; my++)
-            for (int mx = min_x; mx < min_x + width; mx++) COST_MV(mx, my);
+            for (int mx = min_x; mx < min_x + width && mx <= fmax[0]; mx++) COST_MV(mx, my);      /* x264 also costs the <= 3 positions of the
+                                                                                                    * rounded-up width beyond the limit; skipped here (they read past the picture padding) */
         break;
     }
     case 2: {   /* X264_ME_UMH */

@@ -34,6 +34,14 @@ CASES = [
     (176, 144, 4, dict(partitions=3, subme=9, refs=2)),
     (96, 80, 5, dict(partitions=7, dct8x8=1, refs=4, mixed_refs=1, subme=5, chroma_me=1, qp_i=36, qp_p=40)),
     (96, 80, 4, dict(partitions=7, dct8x8=1, qp_i=8, qp_p=10, dct_decimate=0)),
+    (176, 144, 4, dict(me_method=2)),
+    (352, 288, 4, dict(me_method=2, partitions=3, refs=2, chroma_me=1, subme=5)),
+    (208, 120, 4, dict(me_method=2, partitions=3, me_range=24, subme=5, mixed_refs=1, refs=3)),
+    (720, 304, 3, dict(me_method=2, partitions=3, me_range=32, qp_i=30, qp_p=33)),
+    (176, 144, 4, dict(me_method=3)),
+    (208, 120, 4, dict(me_method=3, partitions=3, refs=2, me_range=8, chroma_me=1, subme=5)),
+    (352, 288, 3, dict(me_method=2, partitions=7, dct8x8=1, refs=4, subme=9, chroma_me=1, mixed_refs=1, qp_i=26, qp_p=29)),
+    (1280, 720, 3, dict(partitions=7, refs=3, mixed_refs=1, dct8x8=1, chroma_me=1, subme=5)),
 ]
 
 

@@ -92,8 +92,8 @@ int x264gpu_encoder_create(x264gpu_encoder **out, const x264gpu_config *cfg)
     ARG_TRY(out && cfg);
     ARG_TRY(cfg->width >= 16 && cfg->height >= 16 && !(cfg->width & 1) && !(cfg->height & 1) && cfg->streams >= 1);
     ARG_TRY(cfg->qp_i >= 0 && cfg->qp_i <= 51 && cfg->qp_p >= 0 && cfg->qp_p <= 51 && cfg->refs >= 1 && cfg->refs <= 4);
-    ARG_TRY(cfg->width <= 4096 && cfg->height <= 2304 && cfg->me_range >= 4 && cfg->me_range <= 16);
-    ARG_TRY(cfg->me_method >= 0 && cfg->me_method <= 1);          // dia, hex (umh / esa: not in the raster macroblock loop yet)
+    ARG_TRY(cfg->width <= 4096 && cfg->height <= 2304 && cfg->me_range >= 4 && cfg->me_range <= (cfg->me_method == 2 ? 64 : 16));
+    ARG_TRY(cfg->me_method >= 0 && cfg->me_method <= 3);
     x264gpu_encoder *e = new (std::nothrow) x264gpu_encoder();
     if (!e) return set_err(X264GPU_ENOMEM, "encoder", hipSuccess);
     e->cfg = *cfg;

@@ -72,7 +72,7 @@ __global__ __launch_bounds__(256) void k_aq(EncK k)
 __global__ __launch_bounds__(256) void k_apply_qp_offsets(EncK k, const int16_t *__restrict__ off)
 {
     const int i = blockIdx.x * 256 + threadIdx.x, s = blockIdx.y;
-    if (i < k.nmb) k.mbqp[(size_t)s * k.nmb + i] = (uint8_t)min(max(slice_qp(k, s) + (off ? ((int)off[(size_t)s * k.nmb + i] + 128) >> 8 : 0), 1), 51);   // no offsets: per-stream quantisers only
+    if (i < k.nmb) k.mbqp[(size_t)s * k.nmb + i] = (uint8_t)(off ? min(max(slice_qp(k, s) + (((int)off[(size_t)s * k.nmb + i] + 128) >> 8), 1), 51) : slice_qp(k, s));   // no offsets: the slice's (or the stream's) quantiser as it is
 }
 
 // QP_Y inheritance (oracle settle_mb_qp, 7.4.5): a macroblock that sends no mb_qp_delta takes its predecessor's quantiser; one wave per

@@ -195,26 +195,128 @@ __device__ __forceinline__ void me_search(const EncK &k, MbLds<M> &L, const MbCt
         }
         bmx = __builtin_amdgcn_readfirstlane(bmx); bmy = __builtin_amdgcn_readfirstlane(bmy);
 
-        // ---- stage the search window and the mv-cost slices around the start ----
+        // ---- full-pel search.  dia / hex / esa stay within WIN_R of the start: LDS window + LDS slices of the mv-cost table.  umh roams up to
+        //      ~1.5 x merange from the start: reference rows and costs come from global memory (L2-resident) ----
+        const bool umh = k.me_method == 2;
+        int i_me_range = k.me_range;
         int wx0 = clampi((bx + bmx - WIN_R) & ~7, -PAD, k.cw + PAD - WIN_COLS), wy0 = clampi(by + bmy - WIN_R, -PAD, k.ch + PAD - WIN_ROWS);
-        for (int i = lane; i < WIN_ROWS * 8; i += 64) {
-            const int row = i >> 3, col = (i & 7) * 8;
-            const uint2 v = *(const uint2 *)(p00 + (long)(wy0 + row) * k.rs + wx0 + col);
-            uint32_t *d = (uint32_t *)(L.win + row * WIN_STRIDE + col);
-            d[0] = v.x; d[1] = v.y;
-        }
         const int cbx = bmx * 4, cby = bmy * 4;
-        for (int i = lane; i < 192; i += 64) { L.cost[0][i] = cmx[cbx + i - 96]; L.cost[1][i] = cmy[cby + i - 96]; }
+        if (!umh) {
+            for (int i = lane; i < WIN_ROWS * 8; i += 64) {
+                const int row = i >> 3, col = (i & 7) * 8;
+                const uint2 v = *(const uint2 *)(p00 + (long)(wy0 + row) * k.rs + wx0 + col);
+                uint32_t *d = (uint32_t *)(L.win + row * WIN_STRIDE + col);
+                d[0] = v.x; d[1] = v.y;
+            }
+            for (int i = lane; i < 192; i += 64) { L.cost[0][i] = cmx[cbx + i - 96]; L.cost[1][i] = cmy[cby + i - 96]; }
+        }
         lds_sync();
-#define MVC(qx, qy) ((int)L.cost[0][(qx) - cbx + 96] + (int)L.cost[1][(qy) - cby + 96])
-        auto fpel = [&](int mx, int my) {       // full-pel candidate cost from the LDS window (valid after the row sum)
+#define MVC(qx, qy) (umh ? (int)cmx[qx] + (int)cmy[qy] : (int)L.cost[0][(qx) - cbx + 96] + (int)L.cost[1][(qy) - cby + 96])
+        auto fpel = [&](int mx, int my) {       // full-pel candidate cost (valid after the row sum)
+            if (umh) return sad_global(mx * 4, my * 4) + (int)cmx[mx * 4] + (int)cmy[my * 4];
             const uint8_t *wrow = L.win + (by + my + r - wy0) * WIN_STRIDE;
             const int xo = bx + mx - wx0;
             int sd = 0;
             if (rowok) sd = w16 ? sad_row16_lds(wrow, xo, e) : sad8_lds(wrow, xo, e[0], e[1]);
             return row16_sum(sd) + MVC(mx * 4, my * 4);
         };
-        if (k.me_method == 0) {
+        bool hexrefine = true;
+        if (umh) {
+            // X264_ME_UMH (oracle me_search_ref case 2): four candidates per step, in-order "strictly better wins" = min of (cost << 2 | order)
+            auto inrange = [&](int mx, int my) { return mx >= fmin0 && mx <= fmax0 && my >= fmin1 && my <= fmax1; };
+            auto step = [&](int mx, int my, bool valid) {
+                const int sx = valid ? mx : bmx, sy = valid ? my : bmy;            // masked candidates stay inside the padded plane
+                const int cst = fpel(sx, sy);
+                unsigned kk = valid ? ((unsigned)cst << 2) | (unsigned)cnd : 0xffffffffu;
+                kk = wave_min_u32(kk);
+                if (kk != 0xffffffffu && (int)(kk >> 2) < bcost) {
+                    const int wl = (int)(kk & 3) * 16;
+                    bcost = (int)(kk >> 2); bmx = __shfl(sx, wl); bmy = __shfl(sy, wl);
+                }
+            };
+            const int d1x = cnd == 2 ? -1 : cnd == 3 ? 1 : 0, d1y = cnd == 0 ? -1 : cnd == 1 ? 1 : 0;       // DIA1: (0,-1) (0,1) (-1,0) (1,0)
+            const int shift = (w16 ? 0 : 1) + (j.H == 16 ? 0 : 1);
+#define UMH_TH(v) (bcost < ((v) >> shift))
+            const int ucost1 = bcost;
+            step(pmx + d1x, pmy + d1y, true);
+            if (pmx | pmy) step(d1x, d1y, true);
+            const int ucost2 = bcost;
+            if ((bmx | bmy) && ((bmx - pmx) | (bmy - pmy))) step(bmx + d1x, bmy + d1y, true);
+            int cross_start = bcost == ucost2 ? 3 : 1;
+            const int omx = bmx, omy = bmy;
+            auto cross = [&](int start, int xmax, int ymax) {
+                for (int i0 = start; i0 < xmax; i0 += 4) {
+                    const int i = i0 + 2 * (cnd >> 1), mx = omx + ((cnd & 1) ? -i : i);
+                    step(mx, omy, i < xmax && ((cnd & 1) ? mx >= fmin0 : mx <= fmax0));
+                }
+                for (int i0 = start; i0 < ymax; i0 += 4) {
+                    const int i = i0 + 2 * (cnd >> 1), my = omy + ((cnd & 1) ? -i : i);
+                    step(omx, my, i < ymax && ((cnd & 1) ? my >= fmin1 : my <= fmax1));
+                }
+            };
+            bool done = false;
+            if (bcost == ucost2 && UMH_TH(2000)) {
+                step(omx + (cnd == 0 ? 0 : cnd == 1 ? -1 : cnd == 2 ? 1 : -2), omy + (cnd == 0 ? -2 : cnd == 3 ? 0 : -1), true);     // (0,-2) (-1,-1) (1,-1) (-2,0)
+                step(omx + (cnd == 0 ? 2 : cnd == 1 ? -1 : cnd == 2 ? 1 : 0), omy + (cnd == 0 ? 0 : cnd == 3 ? 2 : 1), true);       // (2,0) (-1,1) (1,1) (0,2)
+                if (bcost == ucost1 && UMH_TH(500)) done = true;
+                else if (bcost == ucost2) {
+                    const int r1 = (i_me_range >> 1) | 1;
+                    cross(3, r1, r1);
+                    step(omx + (cnd == 0 ? -1 : cnd == 1 ? 1 : cnd == 2 ? -2 : 2), omy + (cnd < 2 ? -2 : -1), true);                // (-1,-2) (1,-2) (-2,-1) (2,-1)
+                    step(omx + (cnd == 0 ? -2 : cnd == 1 ? 2 : cnd == 2 ? -1 : 1), omy + (cnd < 2 ? 1 : 2), true);                  // (-2,1) (2,1) (-1,2) (1,2)
+                    if (bcost == ucost2) done = true;
+                    cross_start = r1 + 2;
+                }
+            }
+            if (!done) {
+                if (j.n_mvc) {      // adaptive search range: agreement of the predictors x SAD level
+                    int mvd, denom = 1;
+                    const bool is16 = w16 && j.H == 16;
+                    if (j.n_mvc == 1) mvd = is16 ? 25 : abs(j.mvpx - L.mvc_in[0][0]) + abs(j.mvpy - L.mvc_in[0][1]);
+                    else {
+                        denom = j.n_mvc - 1; mvd = 0;
+                        if (!is16) { mvd = abs(j.mvpx - L.mvc_in[0][0]) + abs(j.mvpy - L.mvc_in[0][1]); denom++; }
+                        for (int i = 0; i < j.n_mvc - 1; i++) mvd += abs(L.mvc_in[i][0] - L.mvc_in[i + 1][0]) + abs(L.mvc_in[i][1] - L.mvc_in[i + 1][1]);
+                    }
+                    const int sad_ctx = UMH_TH(1000) ? 0 : UMH_TH(2000) ? 1 : UMH_TH(4000) ? 2 : 3;
+                    const int mvd_ctx = mvd < 10 * denom ? 0 : mvd < 20 * denom ? 1 : mvd < 40 * denom ? 2 : 3;
+                    i_me_range = (i_me_range * (int)((0x6544544444434433ull >> (4 * (mvd_ctx * 4 + sad_ctx))) & 15)) >> 2;
+                }
+                cross(cross_start, i_me_range, i_me_range >> 1);
+                step(omx + ((cnd & 2) ? 2 : -2), omy + ((cnd & 1) ? 2 : -2), true);                                                 // (-2,-2) (-2,2) (2,-2) (2,2)
+                const int hx = bmx, hy = bmy;
+                int i = 1;
+                do {
+                    for (int ps = 0; ps < 4; ps++) {
+                        const int jj = 4 * ps + cnd, mx = hx + umh_hex4_dx(jj) * i, my = hy + umh_hex4_dy(jj) * i;
+                        step(mx, my, inrange(mx, my));
+                    }
+                } while (++i <= i_me_range >> 2);
+                if (!inrange(bmx, bmy)) done = true;
+            }
+            hexrefine = !done;
+#undef UMH_TH
+        }
+        if (k.me_method == 3) {
+            // X264_ME_ESA: every position of the clipped +-merange rectangle (width rounded up to 4, positions right of the full-pel limit
+            // skipped), raster order, strictly better wins = minimum of (cost << 11 | raster index)
+            const int rr = k.me_range;
+            const int min_x = max(bmx - rr, fmin0), min_y = max(bmy - rr, fmin1), max_x = min(bmx + rr, fmax0), max_y = min(bmy + rr, fmax1);
+            const int width = (max_x - min_x + 3) & ~3;
+            unsigned kmin = 0xffffffffu;
+            for (int my = min_y; my <= max_y; my++)
+                for (int x4 = 0; x4 < width; x4 += 4) {
+                    const int mx = min_x + x4 + cnd;
+                    const bool ok = mx <= fmax0;
+                    const unsigned cst = (unsigned)fpel(ok ? mx : min_x, my);
+                    if (ok) kmin = min(kmin, (cst << 11) | (unsigned)((my - min_y) * width + x4 + cnd));
+                }
+            kmin = wave_min_u32(kmin);
+            if (kmin != 0xffffffffu && (int)(kmin >> 11) < bcost) {
+                const int idx = (int)(kmin & 2047);
+                bcost = (int)(kmin >> 11); bmx = min_x + idx % width; bmy = min_y + idx / width;
+            }
+        } else if (k.me_method == 0) {
             // X264_ME_DIA: the four neighbours are the four lane groups; the centre wins ties
             int it = k.me_range;
             do {
@@ -224,8 +326,8 @@ __device__ __forceinline__ void me_search(const EncK &k, MbLds<M> &L, const MbCt
                 bcost = (int)(kk >> 2);
                 bmx += q == 2 ? -1 : q == 3 ? 1 : 0; bmy += q == 0 ? -1 : q == 1 ? 1 : 0;
             } while (--it && bmx >= fmin0 && bmx <= fmax0 && bmy >= fmin1 && bmy <= fmax1);
-        } else {
-            // X264_ME_HEX: hexagon, then square refine
+        } else if (hexrefine) {
+            // X264_ME_HEX (and the tail of umh): hexagon, then square refine
             unsigned hk = (unsigned)bcost << 3;
             {
                 int i = 1 + cnd;
@@ -239,7 +341,7 @@ __device__ __forceinline__ void me_search(const EncK &k, MbLds<M> &L, const MbCt
             if (hk & 7) {
                 int dir = (int)(hk & 7) - 2;
                 bmx += hex_dx(dir + 1); bmy += hex_dy(dir + 1);
-                for (int it = (k.me_range >> 1) - 1; it > 0 && bmx >= fmin0 && bmx <= fmax0 && bmy >= fmin1 && bmy <= fmax1; it--) {
+                for (int it = (i_me_range >> 1) - 1; it > 0 && bmx >= fmin0 && bmx <= fmax0 && bmy >= fmin1 && bmy <= fmax1; it--) {
                     hk &= ~7u;
                     const int cc = cnd < 3 ? cnd : 0;
                     unsigned kk = ((unsigned)fpel(bmx + hex_dx(dir + cc), bmy + hex_dy(dir + cc)) << 3) | (unsigned)(cc + 1);

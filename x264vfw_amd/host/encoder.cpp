@@ -87,6 +87,8 @@ struct x264_t {
     long submitted = 0, emitted = 0;     // frames in / out
     int next_pos = 0;                    // first position of the current batch not yet coded
     bool flushed = false;                // the partly gathered batch has been coded (flush calls only drain after that)
+    bool failed = false;                 // GOP-parallel mode: a GPU call failed; the session only returns errors from now on
+    std::string gpu_err;                 // threads 1, pipelined: the helper thread's x264gpu_last_error() text (that buffer is thread-local)
     struct Coded { std::vector<uint8_t> bytes; std::vector<size_t> off; std::vector<int> types; int idr; };
     std::deque<Coded> ready;             // coded frames [emitted, emitted + ready.size())
     std::deque<int64_t> pts;             // pts of frames not yet emitted
@@ -196,8 +198,8 @@ x264_t *x264_encoder_open(x264_param_t *param)
     if (!p.analyse.b_transform_8x8) { p.analyse.inter &= ~X264_ANALYSE_I8x8; p.analyse.intra &= ~X264_ANALYSE_I8x8; }   // as x264 validate_parameters
     p.analyse.i_trellis = 0;
     p.i_scenecut_threshold = clampi(p.i_scenecut_threshold, 0, 100);
-    if (p.analyse.i_me_method > X264_ME_HEX) { xlog(&p, X264_LOG_WARNING, "me umh / esa / tesa are not implemented in the raster macroblock loop of the MI355X path yet: me hex\n"); p.analyse.i_me_method = X264_ME_HEX; }
-    p.analyse.i_me_range = clampi(p.analyse.i_me_range, 4, 16);     // x264 caps dia/hex at 16
+    if (p.analyse.i_me_method > X264_ME_ESA) { xlog(&p, X264_LOG_WARNING, "me tesa is not implemented in the MI355X path yet: me esa\n"); p.analyse.i_me_method = X264_ME_ESA; }
+    p.analyse.i_me_range = clampi(p.analyse.i_me_range, 4, p.analyse.i_me_method == X264_ME_UMH ? 64 : 16);     // x264 caps dia/hex at 16; esa: the LDS search window
     // subme >= 6 means RD mode decision in x264 (i_mbrd >= 1): not implemented, so the highest level whose behaviour IS implemented is reported back
     if (p.analyse.i_subpel_refine > 5) { xlog(&p, X264_LOG_WARNING, "subme %d needs RD mode decision, which is not implemented yet: subme 5\n", p.analyse.i_subpel_refine); p.analyse.i_subpel_refine = 5; }
     p.analyse.i_subpel_refine = clampi(p.analyse.i_subpel_refine, 0, 5);
@@ -400,7 +402,9 @@ static void join_pool(x264_t *h)
 
 static int rc_pick_qp(x264_t *h, bool is_i, const int32_t costs[4], int frames_done);
 
-static void code_position(x264_t *h, int batch, int t, int nslots_with_t)
+// 0, or -1 after a GPU failure: the session is then dead (h->failed: every later call returns < 0 and nothing counts as delayed,
+// so the caller's flush loop — codec.c:1842-1856 — ends instead of spinning on frames that will never be coded)
+static int code_position(x264_t *h, int batch, int t, int nslots_with_t)
 {
     const x264_param_t &p = h->param;
     const size_t insz = (size_t)p.i_width * p.i_height * 3 / 2;
@@ -416,14 +420,16 @@ static void code_position(x264_t *h, int batch, int t, int nslots_with_t)
         for (int s = 0; s < nslots_with_t; s++) qps[(size_t)s] = h->gop_qp[(size_t)s * h->keyint + t];
         if (x264gpu_encoder_set_stream_qps(h->gpu, qps.data()) != X264GPU_OK) {
             xlog(&p, X264_LOG_ERROR, "x264_encoder_encode: GPU hot path failed: %s\n", x264gpu_last_error());
-            return;
+            join_pool(h); h->failed = true;
+            return -1;
         }
     }
     if (x264gpu_encode_frames(h->gpu, h->d_ring + (size_t)t * G * insz, st, h->d_mb, h->d_lv, nullptr) != X264GPU_OK ||
         x264gpu_memcpy_d2h(hmb, h->d_mb, (size_t)G * h->nmb * sizeof(x264gpu_mb), nullptr) != X264GPU_OK ||
         x264gpu_memcpy_d2h(hlv, h->d_lv, (size_t)G * h->nmb * X264GPU_MB_LEVELS * sizeof(int16_t), nullptr) != X264GPU_OK) {
         xlog(&p, X264_LOG_ERROR, "x264_encoder_encode: GPU hot path failed: %s\n", x264gpu_last_error());
-        return;
+        join_pool(h); h->failed = true;
+        return -1;
     }
     join_pool(h);
     auto work = [h, batch, t, st, hmb, hlv, qps](int s) {
@@ -456,6 +462,7 @@ static void code_position(x264_t *h, int batch, int t, int nslots_with_t)
     h->pool_t = t; h->pool_nslots = nslots_with_t;
     for (int th = 0; th < nthr; th++)
         h->pool.emplace_back([work, th, nthr, nslots_with_t]() { for (int s = th; s < nslots_with_t; s += nthr) work(s); });
+    return 0;
 }
 
 // coded frames move to the ordered output queue once every earlier frame is there.  slotbuf is indexed inside a batch
@@ -478,6 +485,7 @@ static int encode_gop_parallel(x264_t *h, x264_nal_t **pp_nal, int *pi_nal, x264
     const int G = h->G, K = h->keyint;
     const size_t insz = (size_t)p.i_width * p.i_height * 3 / 2;
     const long per_batch = (long)G * K;
+    if (h->failed) return -1;
     if (pic_in) {
         if (h->flushed) { xlog(&p, X264_LOG_ERROR, "x264_encoder_encode: pictures after a flush are not supported in GOP-parallel mode\n"); return -1; }
         const long i = h->submitted, b = i / per_batch, r = i % per_batch;
@@ -502,7 +510,7 @@ static int encode_gop_parallel(x264_t *h, x264_nal_t **pp_nal, int *pi_nal, x264
         h->pts.push_back(pic_in->i_pts);
         h->submitted++;
         if (s == G - 1) {                                      // the batch's last GOP delivers position t: every slot has it
-            code_position(h, (int)b, t, G);
+            if (code_position(h, (int)b, t, G) < 0) return -1;
             h->next_pos = t + 1 == K ? 0 : t + 1;
         } else if (!h->pool.empty()) join_pool(h);             // gathering phase: the last position's CAVLC had a whole call to finish
         drain_coded(h);
@@ -514,7 +522,7 @@ static int encode_gop_parallel(x264_t *h, x264_nal_t **pp_nal, int *pi_nal, x264
             for (int t = h->next_pos; t < K; t++) {
                 const int nslots = full + (t < part ? 1 : 0);
                 if (nslots <= 0) break;
-                code_position(h, (int)b, t, nslots);
+                if (code_position(h, (int)b, t, nslots) < 0) return -1;
             }
             h->next_pos = 0;
         }
@@ -633,6 +641,7 @@ static int gpu_stage(x264_t *h, size_t idx, int buf, bool async)
         h->gpu_rc = x264gpu_encode_frames(h->gpu, src, st, h->d_mb, h->d_lv, nullptr) != X264GPU_OK ||
                     x264gpu_memcpy_d2h(hmb, h->d_mb, h->h_mb.size() * sizeof(x264gpu_mb), nullptr) != X264GPU_OK ||
                     x264gpu_memcpy_d2h(hlv, h->d_lv, h->h_lv.size() * sizeof(int16_t), nullptr) != X264GPU_OK ? -1 : 0;
+        if (h->gpu_rc) h->gpu_err = x264gpu_last_error();          // the error text lives in this thread's buffer: keep it for the caller's log
     };
     if (async) h->gpu_thread = std::thread([h, run]() { x264gpu_set_device(h->device); run(); });
     else run();
@@ -649,7 +658,7 @@ static int encode_queued(x264_t *h, x264_nal_t **pp_nal, int *pi_nal, x264_pictu
         if (h->pipeline && !flushing) return 0;              // its results are collected by the next call
     }
     join_gpu(h);
-    if (h->gpu_rc) { xlog(&p, X264_LOG_ERROR, "x264_encoder_encode: GPU hot path failed: %s\n", x264gpu_last_error()); return -1; }
+    if (h->gpu_rc) { xlog(&p, X264_LOG_ERROR, "x264_encoder_encode: GPU hot path failed: %s\n", h->gpu_err.c_str()); return -1; }
     // pipelined: the next picture has its whole lookahead window (or the input has ended): start its GPU stage behind this one's coding
     if (h->pipeline && h->queue.size() >= 2 && (flushing || (int)h->queue.size() >= h->L + 2) &&
         gpu_stage(h, 1, h->queue.front().buf ^ 1, true) < 0) return -1;
@@ -778,7 +787,7 @@ int x264_encoder_encode(x264_t *h, x264_nal_t **pp_nal, int *pi_nal, x264_pictur
     return size;
 }
 
-int x264_encoder_delayed_frames(x264_t *h) { return !h ? 0 : h->G > 1 ? (int)(h->submitted - h->emitted) : (int)h->queue.size(); }
+int x264_encoder_delayed_frames(x264_t *h) { return !h || h->failed ? 0 : h->G > 1 ? (int)(h->submitted - h->emitted) : (int)h->queue.size(); }
 
 void x264_encoder_close(x264_t *h)
 {

@@ -1,8 +1,8 @@
 // slice.cpp — host-side entropy coding of one slice from the GPU's macroblock records + levels
 // (north star: "CABAC/entropy left on the host").  CAVLC (ITU-T H.264 7.3.4, 7.3.5, 9.2); plays the role
 // of [x264-upstream] encoder/cavlc.c + the slice header of encoder/encoder.c behind x264_encoder_encode
-// (reference call site codec.c:1693).  Motion-vector differences and P_Skip are derived here from the
-// true H.264 predictors (8.4.1.1, 8.4.1.3), because the GPU analysis ran without raster-order neighbours.
+// (reference call site codec.c:1693).  Motion-vector differences are formed here against the H.264 predictors
+// (8.4.1.3) of the records' vectors; macroblock types, P_Skip included, are the device analysis' decisions.
 #include "host.hpp"
 #include "cavlc_tables.hpp"
 #include <stdlib.h>
@@ -38,7 +38,10 @@ struct SliceCtx {
     int qp_delta(const x264gpu_mb &m) const
     {
         const int i = (int)(&m - mbs);
-        return (int)m.qp - (i == 0 ? p.qp : (int)mbs[i - 1].qp);
+        int d = (int)m.qp - (i == 0 ? p.qp : (int)mbs[i - 1].qp);
+        // mb_qp_delta lies in [-26, +25] (7.4.5); QP_Y is recovered modulo 52, so a larger step wraps (x264 cavlc.c does the same)
+        if (d < -26) d += 52; else if (d > 25) d -= 52;
+        return d;
     }
 
     // ---- nC for coeff_token (9.2.1): average of left (A) and top (B) block totals ----
@@ -266,11 +269,9 @@ struct SliceCtx {
                 else if (is_intra(m)) { flush_run(); write_mb_intra(mbx, mby, m, lv, 5); }
                 else {
                     int px, py;
-                    bool skip = false;
-                    if (m.partition == 0 && m.ref[0] == 0 && !m.cbp_luma && !m.cbp_chroma) {
-                        pskip_mv(mbx, mby, px, py);
-                        skip = px == m.mv[0][0] && py == m.mv[0][1];
-                    }
+                    // P_Skip is the analysis' decision (x264_macroblock_analyse / the conversion at the end of x264_macroblock_encode); its record
+                    // carries the skip vector, which the decoder re-derives (8.4.1.1) — the closed-loop tests compare the two
+                    const bool skip = m.type == X264GPU_MB_P_SKIP;
                     if (skip) { skip_run++; nskip++; }
                     else {
                         // partition geometry in 8x8 units: {bx8, by8, w8, h8}

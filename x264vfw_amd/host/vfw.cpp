@@ -226,7 +226,10 @@ LRESULT compress_begin(CODEC *codec, BITMAPINFO *in, BITMAPINFO *out)
     case 0: param.rc.i_rc_method = X264_RC_CQP; param.rc.i_qp_constant = 0; break;
     case 1: param.rc.i_rc_method = X264_RC_CQP; param.rc.i_qp_constant = cfg->i_qp; break;
     case 2: param.rc.i_rc_method = X264_RC_CRF; param.rc.f_rf_constant = (float)cfg->i_rf_constant * 0.1f; break;
-    case 3: case 4: param.rc.i_rc_method = X264_RC_ABR; param.rc.i_bitrate = cfg->i_passbitrate; break;
+    case 3: param.rc.i_rc_method = X264_RC_ABR; param.rc.i_bitrate = cfg->i_passbitrate; break;
+    case 4:     /* multipass (codec.c:1519-1533: pass 1 writes only the stats file, pass N reads it): no stats file support here */
+        vlog(codec, X264_LOG_WARNING, "multipass encoding is not implemented in the MI355X path: every pass is coded as single-pass ABR at %d kbit/s\n", cfg->i_passbitrate);
+        param.rc.i_rc_method = X264_RC_ABR; param.rc.i_bitrate = cfg->i_passbitrate; break;
     default: goto fail;
     }
     param.vui.i_sar_width = cfg->i_sar_width; param.vui.i_sar_height = cfg->i_sar_height;
