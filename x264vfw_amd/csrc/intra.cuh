@@ -172,7 +172,7 @@ __device__ __forceinline__ PredC predc_setup(const uint8_t *nb)
 }
 
 // 4 predicted chroma pixels of 4x4 block i (raster in the 8x8), row j
-__device__ __forceinline__ uint32_t predc_row4(const uint8_t *nb, const PredC &p, int mode, int i, int j)
+__device__ __forceinline__ uint32_t predc_row4(const uint8_t *nb, const PredC p, int mode, int i, int j)
 {
     const int x0 = (i & 1) * 4, y = (i >> 1) * 4 + j;
     switch (mode) {

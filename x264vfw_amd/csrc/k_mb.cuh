@@ -38,6 +38,7 @@ template <int M> struct MbLds {
     uint8_t U[U_SIZE];
     uint8_t U8[U8_SIZE];
     uint8_t modes4[16], modes8[16], nmodes[8];
+    __attribute__((aligned(16))) x264gpu_mb rec;   // the record being built (lane 0 fills it, 16 lanes store it)
     // motion cache (h->mb.cache.ref / .mv at 8x8 granularity): grid x = -1..2, y = -1..1 -> index (y + 1) * 4 + x + 1
     int cref[12]; int cmvx[12], cmvy[12];
     // search state
@@ -57,6 +58,9 @@ struct MbCtx {
     int nref;
 };
 
+// a wave-uniform value the compiler cannot prove uniform (it came through LDS or a vector load): say so, it then lives in an SGPR
+__device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
+
 __device__ __forceinline__ void lds_sync()
 {
     __builtin_amdgcn_wave_barrier();
@@ -72,8 +76,8 @@ __device__ __forceinline__ void mb_predict_mv(const MbLds<M> &L, int partition, 
     const int ia = (by8 + 1) * 4 + bx8, ib = by8 * 4 + bx8 + 1;
     int ic = by8 * 4 + bx8 + w8 + 1;
     if (L.cref[ic] == -2) ic = by8 * 4 + bx8;
-    const int ra = L.cref[ia], rb = L.cref[ib], rc = L.cref[ic];
-    const int ax = L.cmvx[ia], ay = L.cmvy[ia], bx = L.cmvx[ib], by = L.cmvy[ib], cx = L.cmvx[ic], cy = L.cmvy[ic];
+    const int ra = uni(L.cref[ia]), rb = uni(L.cref[ib]), rc = uni(L.cref[ic]);
+    const int ax = uni(L.cmvx[ia]), ay = uni(L.cmvy[ia]), bx = uni(L.cmvx[ib]), by = uni(L.cmvy[ib]), cx = uni(L.cmvx[ic]), cy = uni(L.cmvy[ic]);
     if (partition == D_16x8) {
         if (by8 == 0) { if (rb == ref) { mvpx = bx; mvpy = by; return; } }
         else if (ra == ref) { mvpx = ax; mvpy = ay; return; }
@@ -86,6 +90,7 @@ __device__ __forceinline__ void mb_predict_mv(const MbLds<M> &L, int partition, 
         if (ra == ref) { mvpx = ax; mvpy = ay; } else if (rb == ref) { mvpx = bx; mvpy = by; } else { mvpx = cx; mvpy = cy; }
     } else if (cnt == 0 && rb == -2 && rc == -2 && ra != -2) { mvpx = ax; mvpy = ay; }
     else { mvpx = median3(ax, bx, cx); mvpy = median3(ay, by, cy); }
+    mvpx = uni(mvpx); mvpy = uni(mvpy);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -121,7 +126,7 @@ __device__ __forceinline__ void mc_row_global(const uint8_t *__restrict__ p00, s
     }
 }
 
-template <int M>
+template <int M, int ME>
 __device__ __forceinline__ void me_search(const EncK &k, MbLds<M> &L, const MbCtx &c, const MeJob &j, int &mvx, int &mvy, int &cost, int &cost_mv, int &halfpel_thresh)
 {
     const int lane = c.lane, r = lane & 15, cnd = lane >> 4;
@@ -197,7 +202,7 @@ __device__ __forceinline__ void me_search(const EncK &k, MbLds<M> &L, const MbCt
 
         // ---- full-pel search.  dia / hex / esa stay within WIN_R of the start: LDS window + LDS slices of the mv-cost table.  umh roams up to
         //      ~1.5 x merange from the start: reference rows and costs come from global memory (L2-resident) ----
-        const bool umh = k.me_method == 2;
+        constexpr bool umh = ME == 2;
         int i_me_range = k.me_range;
         int wx0 = clampi((bx + bmx - WIN_R) & ~7, -PAD, k.cw + PAD - WIN_COLS), wy0 = clampi(by + bmy - WIN_R, -PAD, k.ch + PAD - WIN_ROWS);
         const int cbx = bmx * 4, cby = bmy * 4;
@@ -297,7 +302,7 @@ __device__ __forceinline__ void me_search(const EncK &k, MbLds<M> &L, const MbCt
             hexrefine = !done;
 #undef UMH_TH
         }
-        if (k.me_method == 3) {
+        if (ME == 3) {
             // X264_ME_ESA: every position of the clipped +-merange rectangle (width rounded up to 4, positions right of the full-pel limit
             // skipped), raster order, strictly better wins = minimum of (cost << 11 | raster index)
             const int rr = k.me_range;
@@ -316,7 +321,7 @@ __device__ __forceinline__ void me_search(const EncK &k, MbLds<M> &L, const MbCt
                 const int idx = (int)(kmin & 2047);
                 bcost = (int)(kmin >> 11); bmx = min_x + idx % width; bmy = min_y + idx / width;
             }
-        } else if (k.me_method == 0) {
+        } else if (ME == 0) {
             // X264_ME_DIA: the four neighbours are the four lane groups; the centre wins ties
             int it = k.me_range;
             do {
@@ -525,44 +530,38 @@ __device__ __forceinline__ int i4_pred_mode(const uint8_t *nm, int mbx, int mby,
     return min(ma, mb_);
 }
 
-__device__ __forceinline__ int sel9(const int v[9], int m)
-{
-    int r = v[0];
-#pragma unroll
-    for (int i = 1; i < 9; i++) r = m == i ? v[i] : r;
-    return r;
-}
 // x264's mode choice of one 4x4 / 8x8 block from the raw costs of the nine modes (oracle analyse_intra: V / H / DC first, then only the
-// directional modes near the favoured direction; list order and "first strictly better" decide ties).  Returns the cost incl. the
-// predicted-mode bonus; lists are nibble strings, 15 terminates.
-__device__ __forceinline__ int pick_intra_mode(const int raw[9], int avail, int pm, int lambda, bool is4, int &bestm)
+// directional modes near the favoured direction; list order and "first strictly better" decide ties).  raw(m) = cost of mode m (the
+// caller fetches it from the lanes that computed it).  Returns the cost incl. the predicted-mode bonus; lists are nibble strings, 15 ends one.
+template <class F>
+__device__ __forceinline__ int pick_intra_mode(F raw, int avail, int pm, int lambda, bool is4, int &bestm)
 {
     const int all3 = AVAIL_LEFT | AVAIL_TOP | AVAIL_TOPLEFT;
     const int id = (avail & all3) == all3 ? 4 : avail & (AVAIL_LEFT | AVAIL_TOP);
-    unsigned long long rest;
+    unsigned rest;
     int best = MB_COST_MAX;
     bestm = 2;
     if (id >= 3) {
-        int sv = raw[0], sh = raw[1], sdc = raw[2];
+        int sv = raw(0), sh = raw(1), sdc = raw(2);
         const bool fv = sh > sv;
         if (pm == 0) sv -= 3 * lambda; else if (pm == 1) sh -= 3 * lambda; else if (pm == 2) sdc -= 3 * lambda;
         best = sdc; bestm = 2;
         if (sh < best) { best = sh; bestm = 1; }
         if (sv < best) { best = sv; bestm = 0; }
-        rest = id == 4 ? (fv ? 0xF7543ull : 0xF864ull) : (fv ? 0xF73ull : 0xF8ull);
-    } else rest = id == 0 ? 0xF2ull : id == 1 ? 0xF812ull : 0xF7302ull;
+        rest = id == 4 ? (fv ? 0xF7543u : 0xF864u) : (fv ? 0xF73u : 0xF8u);
+    } else rest = id == 0 ? 0xF2u : id == 1 ? 0xF812u : 0xF7302u;
     if (is4) {
         if (best > 0)
             for (; (rest & 15) != 15; rest >>= 4) {
                 const int m = (int)(rest & 15);
-                int cst = sel9(raw, m);
+                int cst = raw(m);
                 if (pm == m) { cst -= 3 * lambda; if (cst <= 0) { best = cst; bestm = m; break; } }
                 if (cst < best) { best = cst; bestm = m; }
             }
     } else {
         for (; (rest & 15) != 15 && best >= 0; rest >>= 4) {
             const int m = (int)(rest & 15);
-            const int cst = sel9(raw, m) - (pm == m ? 3 * lambda : 0);
+            const int cst = raw(m) - (pm == m ? 3 * lambda : 0);
             if (cst < best) { best = cst; bestm = m; }
         }
     }
@@ -627,12 +626,8 @@ __device__ __forceinline__ void mb_analyse_intra(const EncK &k, MbLds<M> &L, con
             const int c1 = cost8(p1lo, p1hi);
             pred8_row8(L.U8, L.pred8tab, 8, r8, p2lo, p2hi);
             const int c2 = cost8(p2lo, p2hi);
-            int raw[9];
-#pragma unroll
-            for (int m = 0; m < 8; m++) raw[m] = __builtin_amdgcn_readlane(c1, m * 8);
-            raw[8] = __builtin_amdgcn_readlane(c2, 0);
             int bm;
-            const int best = pick_intra_mode(raw, avail, pm, lambda, false, bm);
+            const int best = pick_intra_mode([&](int m) { return uni(m < 8 ? __shfl(c1, m * 8) : __shfl(c2, 0)); }, avail, pm, lambda, false, bm);
             i_cost += best + 3 * lambda;
             if (lane < 4) L.modes8[idx * 4 + lane] = (uint8_t)bm;
             if (idx < 3 && i_cost > thresh) break;
@@ -694,11 +689,8 @@ __device__ __forceinline__ void mb_analyse_intra(const EncK &k, MbLds<M> &L, con
             const uint32_t pr = pred4_row4(L.U, t4);
             const uint32_t en = (uint32_t)__shfl((int)cz, idx * 4 + j);
             const int sat = quad_sum(c.satd ? satd4_half(en, pr, lane) : sad4(en, pr));
-            int raw[9];
-#pragma unroll
-            for (int m = 0; m < 9; m++) raw[m] = __builtin_amdgcn_readlane(sat, m * 4);
             int bm;
-            const int best = pick_intra_mode(raw, avail, pm, lambda, true, bm);
+            const int best = pick_intra_mode([&](int m) { return uni(__shfl(sat, m * 4)); }, avail, pm, lambda, true, bm);
             i_cost += best + 3 * lambda;
             if (lane == 0) L.modes4[idx] = (uint8_t)bm;
             if (idx < 15 && i_cost > thresh) break;
@@ -734,15 +726,13 @@ __device__ __forceinline__ int mb_intra_chroma_cost(const EncK &k, MbLds<M> &L, 
     const PredC pc = predc_setup(cnb);
     const uint2 fe = *(const uint2 *)(c.fuv + (size_t)cyy * k.fs + 2 * cx0);
     const uint32_t cenc = nv12_pick(fe.x, fe.y, pl);
-    int modes[4], n;
-    if (left && top) { modes[0] = PREDC_DC; modes[1] = PREDC_H; modes[2] = PREDC_V; modes[3] = PREDC_P; n = 4; }
-    else if (left) { modes[0] = PREDC_DC_LEFT; modes[1] = PREDC_H; n = 2; }
-    else if (top) { modes[0] = PREDC_DC_TOP; modes[1] = PREDC_V; n = 2; }
-    else { modes[0] = PREDC_DC_128; n = 1; }
+    // candidate list by availability, a nibble string: DC H V P | DC_LEFT H | DC_TOP V | DC_128
+    const unsigned lst = left && top ? 0x3210u : left ? 0x14u : top ? 0x25u : 0x6u;
+    const int n = left && top ? 4 : (left || top) ? 2 : 1;
     int bestc = MB_COST_MAX;
-    predc = modes[0];
+    predc = (int)(lst & 15);
     for (int i = 0; i < n; i++) {
-        const int m = modes[i], sig = m > PREDC_P ? PREDC_DC : m;
+        const int m = (int)((lst >> (4 * i)) & 15), sig = m > PREDC_P ? PREDC_DC : m;
         const uint32_t pr = predc_row4(cnb, pc, m, ci, j);
         const int hs = c.satd ? satd4_half(cenc, pr, lane) : sad4(cenc, pr);
         const int cst = wave_sum(lane < 32 ? hs : 0) + c.lambda * bs_size_ue(sig);
@@ -930,7 +920,9 @@ __device__ __forceinline__ bool mb_probe_pskip(const EncK &k, const MbCtx &c, ui
 // ------------------------------------------------------------------------------------------------
 // The slice kernel: one wavefront per stream walks the macroblocks in raster order.
 // ------------------------------------------------------------------------------------------------
-template <int M>
+// M: sub-pel neighbourhood margin (2 px up to subme 7, 5 above); ME: --me method (its own instantiation each: the roaming umh / esa code
+// costs the hexagon kernel registers otherwise)
+template <int M, int ME>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 4))) void k_mb_slice(EncK k)
 {
     __shared__ __attribute__((aligned(16))) MbLds<M> L;
@@ -961,8 +953,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 4))) void
         const bool left = c.mbx > 0, top = c.mby > 0, topright = top && c.mbx + 1 < k.mbw, topleft = top && left;
         const int mbx = c.mbx, mby = c.mby;
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-        const int type_left = left ? (int)mbs[mbi - 1].type : -1, type_top = top ? (int)mbs[mbi - k.mbw].type : -1;
-        const int type_tl = topleft ? (int)mbs[mbi - k.mbw - 1].type : -1, type_tr = topright ? (int)mbs[mbi - k.mbw + 1].type : -1;
+        const int type_left = uni(left ? (int)mbs[mbi - 1].type : -1), type_top = uni(top ? (int)mbs[mbi - k.mbw].type : -1);
+        const int type_tl = uni(topleft ? (int)mbs[mbi - k.mbw - 1].type : -1), type_tr = uni(topright ? (int)mbs[mbi - k.mbw + 1].type : -1);
         auto intra_t = [](int t) { return t >= 0 && t <= 3; };
         uint8_t *rec = rec_plane00(k, s) + (size_t)c.py * k.rs + c.px;
         uint8_t *ruv = rec_chroma00(k, s) + (size_t)(mby * 8) * k.rs + c.px;
@@ -1016,15 +1008,17 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 4))) void
         const uint32_t cz = *(const uint32_t *)(c.fenc + (size_t)zy * k.fs + zx);
         lds_sync();
 
-        x264gpu_mb recd;
-        __builtin_memset(&recd, 0, sizeof(recd));
-        recd.qp = (uint8_t)c.qp;
+        x264gpu_mb &recd = L.rec;
+        if (lane < 16) ((uint32_t *)&L.rec)[lane] = 0;
+        lds_sync();
+        if (lane == 0) recd.qp = (uint8_t)c.qp;
         const int parts = k.partitions;
         const bool early_term = c.subme < 11;
         int mb_type = X264GPU_MB_I16x16, i_cost = 0, predc = 0, satd_chroma = MB_COST_MAX;
         IntraRes IR;
         bool pskip = false;
         int pskx = 0, psky = 0, best_part = D_16x16;
+        bool fast_intra = false;
 
         if (pslice) {
             // ---- limits ----
@@ -1035,14 +1029,13 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 4))) void
             c.smin1 = clampi(c.mvmin1, -fr, fr - 1); c.smax1 = clampi(c.mvmax1, -fr, fr - 1);
             c.fmin0 = (c.smin0 >> 2) + 6; c.fmax0 = (c.smax0 >> 2) - 6; c.fmin1 = (c.smin1 >> 2) + 6; c.fmax1 = (c.smax1 >> 2) - 6;
             // ---- fast intra decision, skip vector, fast skip ----
-            bool fast_intra = false;
             if (early_term && mbi > 4) {
-                const int colo = k.mbtype_ref0[(size_t)s * k.nmb + mbi];
+                const int colo = uni((int)k.mbtype_ref0[(size_t)s * k.nmb + mbi]);
                 fast_intra = !(intra_t(type_left) || intra_t(type_top) || intra_t(type_tl) || intra_t(type_tr) || intra_t(colo) || mbi < 3 * intra_count);
             }
             {
-                const int ra = L.cref[4], rb = L.cref[1];
-                if (ra == -2 || rb == -2 || (ra == 0 && !(L.cmvx[4] | L.cmvy[4])) || (rb == 0 && !(L.cmvx[1] | L.cmvy[1]))) pskx = psky = 0;
+                const int ra = uni(L.cref[4]), rb = uni(L.cref[1]);
+                if (ra == -2 || rb == -2 || (ra == 0 && !uni(L.cmvx[4] | L.cmvy[4])) || (rb == 0 && !uni(L.cmvx[1] | L.cmvy[1]))) pskx = psky = 0;
                 else mb_predict_mv(L, D_16x16, 0, 0, 2, 0, pskx, psky);
             }
             bool try_skip = false;
@@ -1070,11 +1063,11 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 4))) void
             auto setup_half = [&](int st, int pt) {
                 lds_sync();
                 const int b0 = st == 2 ? 2 * pt : pt, b1 = st == 2 ? 2 * pt + 1 : pt + 2;
-                const int r0 = L.me_ref[ME_8 + b0], r1 = L.me_ref[ME_8 + b1];
+                const int r0 = uni(L.me_ref[ME_8 + b0]), r1 = uni(L.me_ref[ME_8 + b1]);
                 ref_a = min(r0, r1); ref_b = max(r0, r1); nk = ref_a == ref_b ? 1 : 2;
                 if (pt == 0) {
                     const int o0 = st == 2 ? 2 : 1;
-                    const int avg = (L.me_costmv[ME_8 + o0] + L.me_refcost[ME_8 + o0] + L.me_costmv[ME_8 + 3] + L.me_refcost[ME_8 + 3] + 1) >> 1;
+                    const int avg = (uni(L.me_costmv[ME_8 + o0]) + uni(L.me_refcost[ME_8 + o0]) + uni(L.me_costmv[ME_8 + 3]) + uni(L.me_refcost[ME_8 + 3]) + 1) >> 1;
                     est1 = (st == 2 ? sat8[2] : sat8[1]) + sat8[3] + avg;
                     if (lane == 5 || lane == 6 || lane == 9 || lane == 10) L.cref[lane] = -2;
                 }
@@ -1090,31 +1083,30 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 4))) void
                     mb_predict_mv(L, D_16x16, 0, 0, 2, r, jb.mvpx, jb.mvpy);
                     // candidates (oracle predict_mv_ref16x16): lookahead vector, 16x16 results of the left / top / top-left / top-right macroblocks
                     // in this reference, co-located vectors of reference 0 scaled by the POC distances
-                    if (lane == 0) {
-                        int n = 0;
+                    {
+                        // slot order: [lookahead] left top top-left top-right [co-located, its right neighbour, its lower neighbour]; lanes fetch in parallel
                         const int16_t *mvr = (r == 0 ? k.mv16_cur : k.mvr[r]) + (size_t)s * k.nmb * 2;
-                        if (r == 0 && k.lowres_mv) {
-                            const int16_t *lm = k.lowres_mv + (size_t)s * k.nmb * 2;
-                            if (lm[0] != 0x7fff) { L.mvc_in[n][0] = lm[2 * mbi] * 2; L.mvc_in[n][1] = lm[2 * mbi + 1] * 2; n++; }
-                        }
-                        const int nbi[4] = { left ? mbi - 1 : -1, top ? mbi - k.mbw : -1, topleft ? mbi - k.mbw - 1 : -1, topright ? mbi - k.mbw + 1 : -1 };
-                        for (int i = 0; i < 4; i++) { L.mvc_in[n][0] = nbi[i] >= 0 ? mvr[2 * nbi[i]] : 0; L.mvc_in[n][1] = nbi[i] >= 0 ? mvr[2 * nbi[i] + 1] : 0; n++; }
-                        if (k.temporal) {
+                        const bool has_lr = r == 0 && k.lowres_mv && (k.lowres_mv + (size_t)s * k.nmb * 2)[0] != 0x7fff;
+                        const int base = has_lr ? 1 : 0;
+                        const bool t1 = k.temporal && mbx < k.mbw - 1, t2 = k.temporal && mby < k.mbh - 1;
+                        if (lane == 0 && has_lr) { const int16_t *lm = k.lowres_mv + (size_t)s * k.nmb * 2; L.mvc_in[0][0] = lm[2 * mbi] * 2; L.mvc_in[0][1] = lm[2 * mbi + 1] * 2; }
+                        if (lane < 4) {
+                            const int nb = lane == 0 ? (left ? mbi - 1 : -1) : lane == 1 ? (top ? mbi - k.mbw : -1) : lane == 2 ? (topleft ? mbi - k.mbw - 1 : -1) : (topright ? mbi - k.mbw + 1 : -1);
+                            L.mvc_in[base + lane][0] = nb >= 0 ? mvr[2 * nb] : 0; L.mvc_in[base + lane][1] = nb >= 0 ? mvr[2 * nb + 1] : 0;
+                        } else if (lane < 7 && k.temporal) {
                             const int16_t *l0 = k.mv16_ref0 + (size_t)s * k.nmb * 2;
-                            const int scale = k.tscale[r];
-                            const int at[3] = { mbi, mbx < k.mbw - 1 ? mbi + 1 : -1, mby < k.mbh - 1 ? mbi + k.mbw : -1 };
-                            for (int i = 0; i < 3; i++)
-                                if (at[i] >= 0) { L.mvc_in[n][0] = (l0[2 * at[i]] * scale + 128) >> 8; L.mvc_in[n][1] = (l0[2 * at[i] + 1] * scale + 128) >> 8; n++; }
+                            const int scale = k.tscale[r], q = lane - 4;
+                            const int at = q == 0 ? mbi : q == 1 ? mbi + 1 : mbi + k.mbw, slot = base + 4 + (q == 0 ? 0 : q == 1 ? 1 : (t1 ? 2 : 1));
+                            if (q == 0 || (q == 1 && t1) || (q == 2 && t2)) { L.mvc_in[slot][0] = (l0[2 * at] * scale + 128) >> 8; L.mvc_in[slot][1] = (l0[2 * at + 1] * scale + 128) >> 8; }
                         }
-                        L.mvc_in[9][0] = n;
+                        jb.n_mvc = base + 4 + (k.temporal ? 1 + (t1 ? 1 : 0) + (t2 ? 1 : 0) : 0);
                     }
                     lds_sync();
-                    jb.n_mvc = L.mvc_in[9][0];
                     jb.use_thresh = early_term && c.nref > 1;
                     jb.hp_it = c.subme >= 2 ? (c.subme < 6 ? 1 : c.subme < 8 ? 2 : 4) : 0;
                     jb.qp_it = c.subme < 4 ? 0 : c.subme == 4 ? 1 : c.subme < 8 ? 2 : 10;
                 } else if (stage == 1) {
-                    r = mixed ? kk : L.me_ref[ME_16]; slot = ME_8 + part;
+                    r = mixed ? kk : uni(L.me_ref[ME_16]); slot = ME_8 + part;
                     jb.W = 8; jb.H = 8; jb.ox = 8 * (part & 1); jb.oy = 8 * (part >> 1);
                     mb_predict_mv(L, D_8x8, part & 1, part >> 1, 1, r, jb.mvpx, jb.mvpy);
                     if (lane <= part) { L.mvc_in[lane][0] = L.mvc[r][lane][0]; L.mvc_in[lane][1] = L.mvc[r][lane][1]; }
@@ -1134,11 +1126,11 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 4))) void
                 } else {
                     // x264_me_refine_qpel of the winner's blocks
                     slot = best_part == D_16x16 ? ME_16 : best_part == D_16x8 ? ME_16x8 + part : best_part == D_8x16 ? ME_8x16 + part : ME_8 + part;
-                    r = L.me_ref[slot];
+                    r = uni(L.me_ref[slot]);
                     jb.W = best_part == D_16x16 || best_part == D_16x8 ? 16 : 8; jb.H = best_part == D_16x16 || best_part == D_8x16 ? 16 : 8;
                     jb.ox = best_part == D_8x16 ? 8 * part : best_part == D_8x8 ? 8 * (part & 1) : 0;
                     jb.oy = best_part == D_16x8 ? 8 * part : best_part == D_8x8 ? 8 * (part >> 1) : 0;
-                    jb.mvpx = L.me_mvpx[slot]; jb.mvpy = L.me_mvpy[slot];
+                    jb.mvpx = uni(L.me_mvpx[slot]); jb.mvpy = uni(L.me_mvpy[slot]);
                     jb.hp_it = c.subme == 1 ? 1 : 0;
                     jb.qp_it = c.subme == 1 ? 1 : c.subme >= 2 && c.subme <= 5 ? (c.subme == 2 ? 1 : 2) : 0;
                 }
@@ -1151,8 +1143,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 4))) void
                 const int rc = ref_bits(c.nref, r) * c.lambda;
                 int mvx = 0, mvy = 0, cost = 0, cost_mv = 0;
                 if (stage == 0) halfpel_thresh -= rc;
-                if (stage == 4) { mvx = L.me_mvx[slot]; mvy = L.me_mvy[slot]; cost = L.me_cost[slot] - L.me_refcost[slot]; cost_mv = L.me_costmv[slot]; }
-                me_search<M>(k, L, c, jb, mvx, mvy, cost, cost_mv, halfpel_thresh);
+                if (stage == 4) { mvx = uni(L.me_mvx[slot]); mvy = uni(L.me_mvy[slot]); cost = uni(L.me_cost[slot]) - uni(L.me_refcost[slot]); cost_mv = uni(L.me_costmv[slot]); }
+                me_search<M, ME>(k, L, c, jb, mvx, mvy, cost, cost_mv, halfpel_thresh);
                 lds_sync();
                 // ---- merge / advance ----
                 if (stage == 0) {
@@ -1167,20 +1159,20 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 4))) void
                         continue;
                     }
                     cost += rc; halfpel_thresh += rc;
-                    if (cost < L.me_cost[ME_16] && lane == 0) {
+                    if (cost < uni(L.me_cost[ME_16]) && lane == 0) {
                         L.me_mvx[ME_16] = mvx; L.me_mvy[ME_16] = mvy; L.me_cost[ME_16] = cost; L.me_costmv[ME_16] = cost_mv; L.me_ref[ME_16] = r; L.me_refcost[ME_16] = rc;
                         L.me_mvpx[ME_16] = jb.mvpx; L.me_mvpy[ME_16] = jb.mvpy;
                     }
                     lds_sync();
                     if (++kk < nk) continue;
                     // 16x16 done
-                    i_cost = L.me_cost[ME_16]; best_part = D_16x16;
+                    i_cost = uni(L.me_cost[ME_16]); best_part = D_16x16;
                     if (!psub16) { stage = 4; part = 0; if (!c.subme) done = true; continue; }
                     stage = 1; part = 0; kk = 0;
                     i_maxref = c.nref - 1;
                     if (mixed) {
-                        if (early_term && i_maxref > 0 && L.me_ref[ME_16] == 0 && type_top > 0 && type_left > 0) {
-                            i_maxref = max(max(max(L.cref[0], L.cref[1]), max(L.cref[2], L.cref[3])), max(max(L.cref[4], L.cref[8]), 0));
+                        if (early_term && i_maxref > 0 && uni(L.me_ref[ME_16]) == 0 && type_top > 0 && type_left > 0) {
+                            i_maxref = max(max(max(uni(L.cref[0]), uni(L.cref[1])), max(uni(L.cref[2]), uni(L.cref[3]))), max(max(uni(L.cref[4]), uni(L.cref[8])), 0));
                         }
                         nk = i_maxref + 1;
                     } else nk = 1;
@@ -1193,7 +1185,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 4))) void
                     cost += rcost;
                     if (lane == 0) {
                         L.mvc[r][part + 1][0] = (int16_t)mvx; L.mvc[r][part + 1][1] = (int16_t)mvy;
-                        if (kk == 0 || cost < L.me_cost[slot]) {
+                        if (kk == 0 || cost < uni(L.me_cost[slot])) {
                             L.me_mvx[slot] = mvx; L.me_mvy[slot] = mvy; L.me_cost[slot] = cost; L.me_costmv[slot] = cost_mv; L.me_ref[slot] = r; L.me_refcost[slot] = rcost;
                             L.me_mvpx[slot] = jb.mvpx; L.me_mvpy[slot] = jb.mvpy;
                         }
@@ -1203,8 +1195,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 4))) void
                     // block done: into the cache, cost bookkeeping
                     {
                         const int g = ((part >> 1) + 1) * 4 + (part & 1) + 1;
-                        if (lane == 0) { L.cref[g] = L.me_ref[slot]; L.cmvx[g] = L.me_mvx[slot]; L.cmvy[g] = L.me_mvy[slot]; }
-                        const int sv = L.me_cost[slot] - (L.me_costmv[slot] + L.me_refcost[slot]);
+                        if (lane == 0) { L.cref[g] = uni(L.me_ref[slot]); L.cmvx[g] = uni(L.me_mvx[slot]); L.cmvy[g] = uni(L.me_mvy[slot]); }
+                        const int sv = uni(L.me_cost[slot]) - (uni(L.me_costmv[slot]) + uni(L.me_refcost[slot]));
                         if (part == 0) sat8[0] = sv; else if (part == 1) sat8[1] = sv; else if (part == 2) sat8[2] = sv; else sat8[3] = sv;
                         lds_sync();
                         if (lane == 0) L.me_cost[slot] += c.lambda;       // sub-macroblock type (CAVLC)
@@ -1212,33 +1204,33 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 4))) void
                     }
                     kk = 0;
                     if (++part < 4) continue;
-                    cost8x8 = L.me_cost[ME_8] + L.me_cost[ME_8 + 1] + L.me_cost[ME_8 + 2] + L.me_cost[ME_8 + 3];
-                    if (mixed && !(L.me_ref[ME_8] | L.me_ref[ME_8 + 1] | L.me_ref[ME_8 + 2] | L.me_ref[ME_8 + 3])) cost8x8 -= ref_bits(c.nref, 0) * c.lambda * 4;
-                    const int c16 = L.me_cost[ME_16];
+                    cost8x8 = uni(L.me_cost[ME_8]) + uni(L.me_cost[ME_8 + 1]) + uni(L.me_cost[ME_8 + 2]) + uni(L.me_cost[ME_8 + 3]);
+                    if (mixed && !(uni(L.me_ref[ME_8]) | uni(L.me_ref[ME_8 + 1]) | uni(L.me_ref[ME_8 + 2]) | uni(L.me_ref[ME_8 + 3]))) cost8x8 -= ref_bits(c.nref, 0) * c.lambda * 4;
+                    const int c16 = uni(L.me_cost[ME_16]);
                     if (!early_term || cost8x8 < c16) { best_part = D_8x8; i_cost = cost8x8; }
-                    const int th = L.me_costmv[ME_8 + 1] + L.me_costmv[ME_8 + 2];
+                    const int th = uni(L.me_costmv[ME_8 + 1]) + uni(L.me_costmv[ME_8 + 2]);
                     if (!early_term || cost8x8 < c16 + th) { stage = 2; part = 0; kk = 0; setup_half(2, 0); }
                     else { stage = 4; part = 0; if (!c.subme) done = true; }
                     continue;
                 }
                 if (stage == 2 || stage == 3) {
                     cost += rc;
-                    if (lane == 0 && (kk == 0 || cost < L.me_cost[slot])) {
+                    if (lane == 0 && (kk == 0 || cost < uni(L.me_cost[slot]))) {
                         L.me_mvx[slot] = mvx; L.me_mvy[slot] = mvy; L.me_cost[slot] = cost; L.me_costmv[slot] = cost_mv; L.me_ref[slot] = r; L.me_refcost[slot] = rc;
                         L.me_mvpx[slot] = jb.mvpx; L.me_mvpy[slot] = jb.mvpy;
                     }
                     lds_sync();
                     if (++kk < nk) continue;
                     // this half is done; early termination on the first half plus the estimate of the second
-                    bool shape_done = part == 0 && early_term && L.me_cost[slot] + est1 > i_cost;
+                    bool shape_done = part == 0 && early_term && uni(L.me_cost[slot]) + est1 > i_cost;
                     if (!shape_done) {
                         if (lane == 0) {
                             const int g0 = stage == 2 ? (part + 1) * 4 + 1 : 5 + part, g1 = stage == 2 ? g0 + 1 : g0 + 4;
-                            L.cref[g0] = L.cref[g1] = L.me_ref[slot]; L.cmvx[g0] = L.cmvx[g1] = L.me_mvx[slot]; L.cmvy[g0] = L.cmvy[g1] = L.me_mvy[slot];
+                            L.cref[g0] = L.cref[g1] = uni(L.me_ref[slot]); L.cmvx[g0] = L.cmvx[g1] = uni(L.me_mvx[slot]); L.cmvy[g0] = L.cmvy[g1] = uni(L.me_mvy[slot]);
                         }
                         lds_sync();
                         if (part == 0) { part = 1; kk = 0; setup_half(stage, 1); continue; }
-                        const int total = L.me_cost[slot - 1] + L.me_cost[slot];
+                        const int total = uni(L.me_cost[slot - 1]) + uni(L.me_cost[slot]);
                         if (total < i_cost) { i_cost = total; best_part = stage == 2 ? D_16x8 : D_8x16; }
                     }
                     if (stage == 2) { stage = 3; part = 0; kk = 0; setup_half(3, 0); }
@@ -1251,33 +1243,34 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 4))) void
                 const int np = best_part == D_16x16 ? 1 : best_part == D_8x8 ? 4 : 2;
                 if (++part < np) continue;
                 i_cost = 0;
-                for (int i = 0; i < np; i++) i_cost += L.me_cost[(best_part == D_16x16 ? ME_16 : best_part == D_16x8 ? ME_16x8 : best_part == D_8x16 ? ME_8x16 : ME_8) + i];
+                for (int i = 0; i < np; i++) i_cost += uni(L.me_cost[(best_part == D_16x16 ? ME_16 : best_part == D_16x8 ? ME_16x8 : best_part == D_8x16 ? ME_8x16 : ME_8) + i]);
                 done = true;
             }
             lds_sync();
 
-            if (!pskip) {
-                // ---- intra analysis against the inter cost ----
-                const int i_satd_inter = i_cost;
-                if (c.chroma_me) {
-                    satd_chroma = mb_intra_chroma_cost(k, L, c, predc);
-                    mb_analyse_intra(k, L, c, cz, t4, parts, i_cost - satd_chroma, fast_intra, early_term, q_li, q8i, IR);
-                    IR.satd_i16 += satd_chroma; IR.satd_i8 += satd_chroma; IR.satd_i4 += satd_chroma;
-                } else mb_analyse_intra(k, L, c, cz, t4, parts, i_cost, fast_intra, early_term, q_li, q8i, IR);
-                recd.aux[0] = i_satd_inter; recd.aux[1] = min(min(IR.satd_i16, IR.satd_i8), IR.satd_i4); recd.aux[2] = L.me_cost[ME_16];
+        }
+        // ---- intra analysis (P slices: against the inter cost; chroma-ME decides the chroma mode first and carries its cost) ----
+        if (!pskip) {
+            const int i_satd_inter = pslice ? i_cost : MB_COST_MAX;
+            // the chroma mode depends on the neighbours only: decided here for every macroblock that is analysed (x264 does it here under chroma-ME,
+            // otherwise only for macroblocks that end up intra — same mode either way); its cost enters the comparison under chroma-ME only
+            satd_chroma = mb_intra_chroma_cost(k, L, c, predc);
+            mb_analyse_intra(k, L, c, cz, t4, parts, c.chroma_me ? i_satd_inter - satd_chroma : i_satd_inter, fast_intra, early_term, q_li, q8i, IR);
+            if (c.chroma_me) { IR.satd_i16 += satd_chroma; IR.satd_i8 += satd_chroma; IR.satd_i4 += satd_chroma; }
+            if (pslice) {
+                if (lane == 0) { recd.aux[0] = i_satd_inter; recd.aux[1] = min(min(IR.satd_i16, IR.satd_i8), IR.satd_i4); recd.aux[2] = uni(L.me_cost[ME_16]); }
                 mb_type = best_part == D_8x8 ? X264GPU_MB_P_8x8 : X264GPU_MB_P_L0;
                 if (IR.satd_i16 < i_cost) { i_cost = IR.satd_i16; mb_type = X264GPU_MB_I16x16; }
                 if (IR.satd_i8 < i_cost) { i_cost = IR.satd_i8; mb_type = X264GPU_MB_I8x8; }
                 if (IR.satd_i4 < i_cost) { i_cost = IR.satd_i4; mb_type = X264GPU_MB_I4x4; }
-            } else { mb_type = X264GPU_MB_P_SKIP; i_cost = 0; }
-        } else {
-            mb_analyse_intra(k, L, c, cz, t4, parts, MB_COST_MAX, false, early_term, q_li, q8i, IR);
-            i_cost = IR.satd_i16; mb_type = X264GPU_MB_I16x16;
-            if (IR.satd_i4 < i_cost) { i_cost = IR.satd_i4; mb_type = X264GPU_MB_I4x4; }
-            if (IR.satd_i8 < i_cost) { i_cost = IR.satd_i8; mb_type = X264GPU_MB_I8x8; }
-        }
-        recd.cost = i_cost;
-        recd.type = (uint8_t)mb_type;
+            } else {
+                i_cost = IR.satd_i16; mb_type = X264GPU_MB_I16x16;
+                if (IR.satd_i4 < i_cost) { i_cost = IR.satd_i4; mb_type = X264GPU_MB_I4x4; }
+                if (IR.satd_i8 < i_cost) { i_cost = IR.satd_i8; mb_type = X264GPU_MB_I8x8; }
+            }
+        } else { mb_type = X264GPU_MB_P_SKIP; i_cost = 0; }
+        int rec_type = mb_type;
+        if (lane == 0) recd.cost = i_cost;
 
         // ---- x264_macroblock_encode ----
         unsigned nnz = 0;
@@ -1289,7 +1282,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 4))) void
             if (pskip) { lmx = clampi(pskx, c.mvmin0, c.mvmax0); lmy = clampi(psky, c.mvmin1, c.mvmax1); lref = 0; }
             else {
                 const int slot = best_part == D_16x16 ? ME_16 : best_part == D_16x8 ? ME_16x8 + (b8 >> 1) : best_part == D_8x16 ? ME_8x16 + (b8 & 1) : ME_8 + b8;
-                lmx = L.me_mvx[slot]; lmy = L.me_mvy[slot]; lref = L.me_ref[slot];
+                lmx = L.me_mvx[slot]; lmy = L.me_mvy[slot]; lref = L.me_ref[slot];      // slot varies with the lane (its 8x8 block)
             }
             const uint32_t pred = mc_luma_row4(ref_plane00(k, s, lref), k.plane_bytes, k.rs, c.px + zx, c.py + zy, lmx, lmy);
             // chroma prediction: chroma 4x4 block ci <-> luma 8x8 ci
@@ -1298,12 +1291,11 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 4))) void
             uint32_t pu, pv;
             mc_chroma_row4(ref_chroma00(k, s, cref), k.rs, mbx * 8 + cx0, mby * 8 + cyy, cmvx, cmvy, pu, pv);
             const uint32_t cpred = pl ? pv : pu;
-            for (int b = 0; b < 4; b++) {
-                recd.mv[b][0] = (int16_t)(pskip ? pskx : __builtin_amdgcn_readlane(lmx, b * 16));
-                recd.mv[b][1] = (int16_t)(pskip ? psky : __builtin_amdgcn_readlane(lmy, b * 16));
-                recd.ref[b] = (int8_t)__builtin_amdgcn_readlane(lref, b * 16);
+            const int mv0x = pskip ? pskx : __builtin_amdgcn_readlane(lmx, 0), mv0y = pskip ? psky : __builtin_amdgcn_readlane(lmy, 0), ref0 = __builtin_amdgcn_readlane(lref, 0);
+            if ((lane & 15) == 0) {      // one lane per 8x8 block writes that block's motion
+                recd.mv[lane >> 4][0] = (int16_t)(pskip ? pskx : lmx); recd.mv[lane >> 4][1] = (int16_t)(pskip ? psky : lmy); recd.ref[lane >> 4] = (int8_t)lref;
             }
-            recd.partition = (uint8_t)(pskip ? 0 : best_part);
+            if (lane == 0) recd.partition = (uint8_t)(pskip ? 0 : best_part);
             if (pskip) {
                 *(uint32_t *)(rec + (size_t)zy * k.rs + zx) = pred;
                 mb_store_chroma(ruv, k.rs, lane, cpred);
@@ -1409,23 +1401,23 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 4))) void
                 mb_store_chroma(ruv, k.rs, lane, crec);
                 if (lane >= 32 && lane < 40) lv[X264GPU_LV_LUMA_DC + (lane - 32) * 2] = 0, lv[X264GPU_LV_LUMA_DC + (lane - 32) * 2 + 1] = 0;
                 if (lane >= 40 && lane < 44) lv[408 + (lane - 40) * 2] = 0, lv[408 + (lane - 40) * 2 + 1] = 0;
-                recd.transform8x8 = (uint8_t)(t8 && cbp_luma);
+                if (lane == 0) recd.transform8x8 = (uint8_t)(t8 && cbp_luma);
                 // P_L0 16x16, reference 0, the skip vector, nothing coded: P_SKIP
-                if (mb_type == X264GPU_MB_P_L0 && best_part == D_16x16 && !(cbp_luma | cbp_chroma) && recd.ref[0] == 0 && recd.mv[0][0] == pskx && recd.mv[0][1] == psky)
-                    recd.type = X264GPU_MB_P_SKIP;
+                if (mb_type == X264GPU_MB_P_L0 && best_part == D_16x16 && !(cbp_luma | cbp_chroma) && ref0 == 0 && mv0x == pskx && mv0y == psky)
+                    rec_type = X264GPU_MB_P_SKIP;
             }
         } else {
             // ---- intra macroblock ----
-            for (int i = 0; i < 4; i++) recd.ref[i] = -1;
+            if (lane < 4) recd.ref[lane] = -1;
             if (mb_type == X264GPU_MB_I8x8) {
-                recd.transform8x8 = 1;
-                for (int b = 0; b < 16; b++) recd.i4_mode[b] = L.modes8[b];
+                if (lane == 0) recd.transform8x8 = 1;
+                if (lane < 16) recd.i4_mode[lane] = L.modes8[lane];
                 nnz = IR.nnz8; cbp_luma = IR.cbp8;
                 *(uint32_t *)(rec + (size_t)zy * k.rs + zx) = *(const uint32_t *)(tile8 + zy * IT_STRIDE + zx);
                 *(uint2 *)(lv + lane * 4) = *(const uint2 *)(L.lv8 + lane * 4);
                 if (lane < 16) lv[X264GPU_LV_LUMA_DC + lane] = 0;
             } else if (mb_type == X264GPU_MB_I4x4) {
-                for (int b = 0; b < 16; b++) recd.i4_mode[b] = L.modes4[b];
+                if (lane < 16) recd.i4_mode[lane] = L.modes4[lane];
                 nnz = IR.nnz4;
                 for (int i8 = 0; i8 < 4; i8++) if ((nnz >> (4 * i8)) & 15) cbp_luma |= 1 << i8;
                 *(uint32_t *)(rec + (size_t)zy * k.rs + zx) = *(const uint32_t *)(tile + zy * IT_STRIDE + zx);
@@ -1434,7 +1426,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 4))) void
             } else {
                 // x264_mb_encode_i16x16 (AC decimated as a whole in P slices)
                 const int mode16 = IR.pred16;
-                recd.i16_mode = (uint8_t)(mode16 > PRED16_P ? PRED16_DC : mode16);
+                if (lane == 0) recd.i16_mode = (uint8_t)(mode16 > PRED16_P ? PRED16_DC : mode16);
                 const Pred16 pp = pred16_setup(L.nb, lane);
                 int e[4], p[4], v[4];
                 unpack4(cz, e); unpack4(pred16_row4(L.nb, pp, mode16, zx, zy), p);
@@ -1486,21 +1478,21 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 4))) void
                 cbp_luma = acn ? 15 : 0;
             }
             if (lane >= 16 && lane < 24) lv[408 + lane - 16] = 0;
-            // chroma: mode (unless chroma-ME already chose it), prediction, residual
-            if (satd_chroma >= MB_COST_MAX) satd_chroma = mb_intra_chroma_cost(k, L, c, predc);
+            // chroma: prediction of the mode chosen above, residual
             {
                 const int pl = (lane >> 4) & 1, ci = (lane >> 2) & 3, cx0 = (ci & 1) * 4, cyy = (ci >> 1) * 4 + j4;
                 const PredC pc = predc_setup(L.cnb[pl]);
                 const uint2 fe = *(const uint2 *)(c.fuv + (size_t)cyy * k.fs + 2 * cx0);
                 const uint32_t cenc = nv12_pick(fe.x, fe.y, pl), cpred = predc_row4(L.cnb[pl], pc, predc, ci, j4);
-                recd.chroma_mode = (uint8_t)(predc > PREDC_P ? PREDC_DC : predc);
+                if (lane == 0) recd.chroma_mode = (uint8_t)(predc > PREDC_P ? PREDC_DC : predc);
                 const uint32_t crec = mb_chroma_residual(cenc, cpred, q_ci, false, false, lane, lv, nnz, cbp_chroma);
                 mb_store_chroma(ruv, k.rs, lane, crec);
             }
             intra_count++;
         }
-        recd.nnz = nnz; recd.cbp_luma = (uint8_t)cbp_luma; recd.cbp_chroma = (uint8_t)cbp_chroma;
-        if (lane == 0) { mbs[mbi] = recd; mbtype_cur[mbi] = recd.type; }
+        if (lane == 0) { recd.nnz = nnz; recd.cbp_luma = (uint8_t)cbp_luma; recd.cbp_chroma = (uint8_t)cbp_chroma; recd.type = (uint8_t)rec_type; mbtype_cur[mbi] = (uint8_t)rec_type; }
+        lds_sync();
+        if (lane < 16) ((uint32_t *)(mbs + mbi))[lane] = ((const uint32_t *)&L.rec)[lane];
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         __builtin_amdgcn_s_waitcnt(0);
     }

@@ -1,0 +1,11 @@
+// mb_slice_esa.hip — the macroblock-loop kernel (k_mb.cuh) instantiated for --me esa: one translation unit per search method so that
+// the four instantiation pairs build in parallel.
+#include "k_mb.cuh"
+
+namespace x264gpu {
+void launch_mb_slice_esa(const EncK &k, int streams, bool big_margin, hipStream_t st)
+{
+    if (big_margin) hipLaunchKernelGGL((k_mb_slice<5, 3>), dim3(streams), dim3(64), 0, st, k);
+    else hipLaunchKernelGGL((k_mb_slice<2, 3>), dim3(streams), dim3(64), 0, st, k);
+}
+}  // namespace x264gpu
