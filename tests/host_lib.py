@@ -4,10 +4,18 @@ import os
 
 import numpy as np
 
-from x264vfw_amd import lib as _gpu  # noqa: F401  (loads libx264gpu.so first; single HIP runtime)
-
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-H = C.CDLL(os.path.join(ROOT, "x264vfw_amd", "libx264gpu_host.so"))
+if os.environ.get("X264_HOST_STUB"):
+    # CPU tests of the host shell: the product's host sources linked against the stand-in device library (tests/stub/: the oracle behind
+    # the B3 ABI).  Only in a process that never loads the real libx264gpu.so (same soname).
+    _b = os.path.join(ROOT, "tests", "stub", "_build")
+    if not os.path.exists(os.path.join(_b, "libx264gpu_host.so")):
+        import subprocess
+        subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "tests", "stub")])
+    H = C.CDLL(os.path.join(_b, "libx264gpu_host.so"))
+else:
+    from x264vfw_amd import lib as _gpu  # noqa: F401  (loads libx264gpu.so first; single HIP runtime)
+    H = C.CDLL(os.path.join(ROOT, "x264vfw_amd", "libx264gpu_host.so"))
 _i = C.c_int
 
 

@@ -1,0 +1,119 @@
+/* tests/stub/x264gpu_stub.c — a CPU stand-in for the B3 device library (include/x264gpu.h), TEST INFRASTRUCTURE ONLY.
+ *
+ * Lets the CPU test suite drive the host shell (x264_* API, GOP-parallel scheduling, the dealing of GOP slots to several devices)
+ * without a GPU: "device memory" is malloc'ed, the frame pipeline is the CPU checker (oracle/, liboracle.so), the device count comes from
+ * X264GPU_STUB_DEVICES.  It is built into tests/stub/_build/ under the device library's soname together with a copy of the host
+ * library linked against it (tests/stub/Makefile); nothing under x264vfw_amd/ links or loads it, and bench.py never does. */
+#include "x264gpu.h"
+#include "x264o.h"
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+typedef struct x264o_encoder x264o_encoder;
+x264o_encoder *x264o_encoder_create(const x264gpu_config *cfg);
+void x264o_encoder_destroy(x264o_encoder *e);
+int x264o_encoder_mb_count(const x264o_encoder *e);
+void x264o_encoder_set_qp(x264o_encoder *e, int qp_i, int qp_p);
+void x264o_encoder_set_mb_qp_offsets(x264o_encoder *e, const int16_t *off_q8);
+int x264o_encoder_encode(x264o_encoder *e, const uint8_t *i420, int slice_type, x264gpu_mb *mbs, int16_t *levels);
+void x264o_encoder_get_recon(x264o_encoder *e, uint8_t *out);
+
+static __thread int t_dev = 0;
+static __thread char t_err[256] = "";
+static long g_calls[16];                       /* x264gpu_encode_frames calls per device */
+
+static int ndev(void) { const char *e = getenv("X264GPU_STUB_DEVICES"); int n = e ? atoi(e) : 2; return n < 1 ? 1 : n > 16 ? 16 : n; }
+static int fail(const char *what) { snprintf(t_err, sizeof(t_err), "stub: %s", what); return X264GPU_EINVAL; }
+
+int x264gpu_abi_version(void) { return X264GPU_ABI_VERSION; }
+int x264gpu_device_count(void) { return ndev(); }
+int x264gpu_set_device(int dev) { if (dev < 0 || dev >= ndev()) return fail("no such device"); t_dev = dev; return X264GPU_OK; }
+int x264gpu_get_device(int *dev) { *dev = t_dev; return X264GPU_OK; }
+const char *x264gpu_last_error(void) { return t_err; }
+int x264gpu_malloc(void **p, size_t n) { *p = calloc(1, n ? n : 1); return *p ? X264GPU_OK : X264GPU_ENOMEM; }
+int x264gpu_free(void *p) { free(p); return X264GPU_OK; }
+int x264gpu_memcpy_h2d(void *d, const void *s, size_t n, void *st) { memcpy(d, s, n); return X264GPU_OK; }
+int x264gpu_memcpy_d2h(void *d, const void *s, size_t n, void *st) { memcpy(d, s, n); return X264GPU_OK; }
+int x264gpu_memcpy_d2d(void *d, const void *s, size_t n, void *st) { memmove(d, s, n); return X264GPU_OK; }
+int x264gpu_memset(void *d, int v, size_t n, void *st) { memset(d, v, n); return X264GPU_OK; }
+int x264gpu_stream_sync(void *st) { return X264GPU_OK; }
+long x264gpu_stub_encode_calls(int dev) { return dev >= 0 && dev < 16 ? g_calls[dev] : -1; }
+
+struct x264gpu_encoder { x264gpu_config cfg; x264o_encoder **e; int dev, nmb; const int16_t *off; int8_t *sqp; };
+
+int x264gpu_encoder_create(x264gpu_encoder **out, const x264gpu_config *cfg)
+{
+    if (!out || !cfg || cfg->streams < 1) return fail("encoder_create arguments");
+    x264gpu_encoder *g = calloc(1, sizeof(*g));
+    g->cfg = *cfg; g->dev = t_dev;
+    g->e = calloc((size_t)cfg->streams, sizeof(*g->e));
+    x264gpu_config one = *cfg; one.streams = 1;
+    for (int s = 0; s < cfg->streams; s++) g->e[s] = x264o_encoder_create(&one);
+    g->nmb = x264o_encoder_mb_count(g->e[0]);
+    *out = g;
+    return X264GPU_OK;
+}
+void x264gpu_encoder_destroy(x264gpu_encoder *g)
+{
+    if (!g) return;
+    for (int s = 0; s < g->cfg.streams; s++) x264o_encoder_destroy(g->e[s]);
+    free(g->e); free(g->sqp); free(g);
+}
+int x264gpu_encoder_mb_count(const x264gpu_encoder *g) { return g ? g->nmb : 0; }
+int x264gpu_encoder_set_qp(x264gpu_encoder *g, int qp_i, int qp_p) { g->cfg.qp_i = qp_i; g->cfg.qp_p = qp_p; return X264GPU_OK; }
+int x264gpu_encoder_set_mb_qp_offsets(x264gpu_encoder *g, const int16_t *off) { g->off = off; return X264GPU_OK; }
+int x264gpu_encoder_set_stream_qps(x264gpu_encoder *g, const int8_t *qps)
+{
+    free(g->sqp); g->sqp = NULL;
+    if (qps) { g->sqp = malloc((size_t)g->cfg.streams); memcpy(g->sqp, qps, (size_t)g->cfg.streams); }
+    return X264GPU_OK;
+}
+int x264gpu_encoder_set_lowres_mvs(x264gpu_encoder *g, const int16_t *mv) { return mv ? fail("lowres vectors: not in the stub") : X264GPU_OK; }
+int x264gpu_encode_frames(x264gpu_encoder *g, const uint8_t *i420, int slice_type, x264gpu_mb *mb, int16_t *lv, void *st)
+{
+    if (g->dev != t_dev) return fail("encoder used from a thread bound to another device");
+    const size_t fsz = (size_t)g->cfg.width * g->cfg.height * 3 / 2;
+    g_calls[g->dev]++;
+    for (int s = 0; s < g->cfg.streams; s++) {
+        const int qi = g->sqp ? g->sqp[s] : g->cfg.qp_i, qp = g->sqp ? g->sqp[s] : g->cfg.qp_p;
+        x264o_encoder_set_qp(g->e[s], qi, qp);
+        x264o_encoder_set_mb_qp_offsets(g->e[s], g->off ? g->off + (size_t)s * g->nmb : NULL);
+        if (x264o_encoder_encode(g->e[s], i420 + s * fsz, slice_type, mb + (size_t)s * g->nmb, lv + (size_t)s * g->nmb * X264GPU_MB_LEVELS)) return fail("P picture without a reference");
+    }
+    return X264GPU_OK;
+}
+int x264gpu_encoder_get_recon(x264gpu_encoder *g, int s, uint8_t *out, void *st) { x264o_encoder_get_recon(g->e[s], out); return X264GPU_OK; }
+
+struct x264gpu_lookahead { x264o_lookahead *la; int w, h, nb; };
+int x264gpu_lookahead_create(x264gpu_lookahead **out, int w, int h, int streams, int me_range, int subme)
+{
+    if (streams != 1) return fail("stub lookahead: one stream");
+    x264gpu_lookahead *l = calloc(1, sizeof(*l));
+    l->la = x264o_lookahead_create(w, h, me_range, subme); l->w = w; l->h = h; l->nb = ((w + 15) / 16) * ((h + 15) / 16);
+    *out = l;
+    return X264GPU_OK;
+}
+void x264gpu_lookahead_destroy(x264gpu_lookahead *l) { if (l) { x264o_lookahead_destroy(l->la); free(l); } }
+int x264gpu_lookahead_frame_cost(x264gpu_lookahead *l, const uint8_t *i420, int reset, int32_t *out, int32_t *blocks, void *st)
+{
+    int32_t *tmp = blocks ? blocks : malloc((size_t)l->nb * 4 * sizeof(int32_t));
+    const int rc = x264o_lookahead_frame_cost(l->la, i420, reset, out, tmp);
+    if (!blocks) free(tmp);
+    return rc ? fail("lookahead") : X264GPU_OK;
+}
+int x264gpu_lookahead_aq_offsets(x264gpu_lookahead *l, const uint8_t *i420, int strength_q8, int16_t *out, void *st)
+{
+    x264o_aq_offsets(i420, l->w, l->h, strength_q8, out);
+    return X264GPU_OK;
+}
+int x264gpu_lookahead_mbtree(x264gpu_lookahead *l, const int32_t *const *info, const int16_t *const *aq, int n, int strength_q8, int16_t *out, void *st)
+{
+    x264o_mbtree((l->w + 15) / 16, (l->h + 15) / 16, info, aq, n, strength_q8, out);
+    return X264GPU_OK;
+}
+long x264gpu_csp_img_fill(int csp, int width, int height, long off[3], int stride[3]) { return x264o_csp_img_fill(csp, width, height, off, stride); }
+int x264gpu_csp_to_i420(const uint8_t *const src[3], const int ss[3], int csp, int w, int h, int m709, int full, uint8_t *const dst[3], const int ds[3], void *st)
+{
+    return x264o_csp_to_i420(dst, ds, src, ss, csp, w, h, m709, full) ? fail("csp") : X264GPU_OK;
+}

@@ -83,7 +83,16 @@ struct x264_t {
     //      GPU encoder; frames come out in order, (G-1)*keyint calls late.  Fixed keyint + CQP make the GOPs independent, so
     //      the bytes equal the serial encode's (tests/test_gpu_host.py::test_gop_parallel_equals_serial).
     int G = 1;
-    uint8_t *d_ring = nullptr;           // device: [keyint positions][G slots] tight I420 pictures of the batch being gathered
+    // The G slots are dealt to the visible devices (slot s -> device s % D, its local slot s / D): every device runs its slots in lock-step
+    // with its own encoder, ring and download buffers, issued by one host thread per device; closed GOPs are independent, so there is no
+    // exchange between devices and the frames still leave in stream order (north star: "frames of one stream shard one-per-GPU").
+    struct DevCtx {
+        int dev = 0, nsl = 0, base = 0;  // device ordinal; slots it owns; its first row in the host download buffers
+        x264gpu_encoder *gpu = nullptr;
+        uint8_t *d_ring = nullptr;       // [keyint positions][nsl slots] tight I420 pictures of the batch being gathered
+        x264gpu_mb *d_mb = nullptr; int16_t *d_lv = nullptr;
+    };
+    std::vector<DevCtx> devs;            // GOP-parallel mode only (threads 1 sessions use gpu / d_mb / d_lv below on the caller's device)
     long submitted = 0, emitted = 0;     // frames in / out
     int next_pos = 0;                    // first position of the current batch not yet coded
     bool flushed = false;                // the partly gathered batch has been coded (flush calls only drain after that)
@@ -275,11 +284,34 @@ x264_t *x264_encoder_open(x264_param_t *param)
     p.analyse.i_mv_range = clampi(p.analyse.i_mv_range, 32, 512);
     cfg.mv_range = p.analyse.i_mv_range;
     size_t insz = (size_t)p.i_width * p.i_height * 3 / 2;
-    if (x264gpu_encoder_create(&h->gpu, &cfg) != X264GPU_OK ||
-        x264gpu_malloc((void **)&h->d_in, insz) != X264GPU_OK ||
-        x264gpu_malloc((void **)&h->d_mb, (size_t)h->G * h->nmb * sizeof(x264gpu_mb)) != X264GPU_OK ||
-        x264gpu_malloc((void **)&h->d_lv, (size_t)h->G * h->nmb * X264GPU_MB_LEVELS * sizeof(int16_t)) != X264GPU_OK ||
-        (h->G > 1 && x264gpu_malloc((void **)&h->d_ring, (size_t)h->G * h->keyint * insz) != X264GPU_OK)) {
+    (void)x264gpu_get_device(&h->device);
+    bool ok_setup = x264gpu_malloc((void **)&h->d_in, insz) == X264GPU_OK;
+    if (ok_setup && h->G > 1) {
+        // GOP-parallel: the slots are dealt to the devices (X264GPU_DEVICES caps how many are used)
+        int D = x264gpu_device_count();
+        if (const char *de = getenv("X264GPU_DEVICES")) { const int v = atoi(de); if (v >= 1 && v < D) D = v; }
+        D = clampi(D, 1, h->G);
+        h->devs.resize((size_t)D);
+        int base = 0;
+        for (int d = 0; d < D && ok_setup; d++) {
+            x264_t::DevCtx &dc = h->devs[(size_t)d];
+            dc.dev = D == 1 ? h->device : d; dc.nsl = (h->G - d + D - 1) / D; dc.base = base; base += dc.nsl;
+            cfg.streams = dc.nsl;
+            ok_setup = x264gpu_set_device(dc.dev) == X264GPU_OK && x264gpu_encoder_create(&dc.gpu, &cfg) == X264GPU_OK &&
+                       x264gpu_malloc((void **)&dc.d_mb, (size_t)dc.nsl * h->nmb * sizeof(x264gpu_mb)) == X264GPU_OK &&
+                       x264gpu_malloc((void **)&dc.d_lv, (size_t)dc.nsl * h->nmb * X264GPU_MB_LEVELS * sizeof(int16_t)) == X264GPU_OK &&
+                       x264gpu_malloc((void **)&dc.d_ring, (size_t)dc.nsl * h->keyint * insz) == X264GPU_OK;
+        }
+        const std::string err = ok_setup ? "" : x264gpu_last_error();
+        (void)x264gpu_set_device(h->device);
+        if (!ok_setup) { xlog(&p, X264_LOG_ERROR, "GPU encoder setup failed: %s\n", err.c_str()); x264_encoder_close(h); return nullptr; }
+        if (D > 1) xlog(&p, X264_LOG_INFO, "GOP slots on %d devices (%d + ... per device)\n", D, h->devs[0].nsl);
+    } else if (ok_setup) {
+        ok_setup = x264gpu_encoder_create(&h->gpu, &cfg) == X264GPU_OK &&
+                   x264gpu_malloc((void **)&h->d_mb, (size_t)h->nmb * sizeof(x264gpu_mb)) == X264GPU_OK &&
+                   x264gpu_malloc((void **)&h->d_lv, (size_t)h->nmb * X264GPU_MB_LEVELS * sizeof(int16_t)) == X264GPU_OK;
+    }
+    if (!ok_setup) {
         xlog(&p, X264_LOG_ERROR, "GPU encoder setup failed: %s\n", x264gpu_last_error());
         x264_encoder_close(h);
         return nullptr;
@@ -298,7 +330,6 @@ x264_t *x264_encoder_open(x264_param_t *param)
     // pictures are held back anyway and the quantisers do not depend on coded sizes: overlap the GPU stage of the next picture with
     // the entropy coding of this one (one more picture of delay); X264GPU_HOST_PIPELINE=0 keeps the two stages in one call
     { const char *pe = getenv("X264GPU_HOST_PIPELINE"); h->pipeline = h->G == 1 && h->L > 0 && h->crf && !(pe && pe[0] == '0'); }
-    (void)x264gpu_get_device(&h->device);
     h->Q = h->L + 1 + (h->pipeline ? 1 : 0);
     h->aq_strength_q8 = cfg.aq_mode ? cfg.aq_strength_q8 : 0;
     h->tree_strength_q8 = (int)(1280.0 * (1.0 - p.rc.f_qcompress) + 0.5);     // 5 * (1 - qcomp), Q8
@@ -418,23 +449,40 @@ static int code_position(x264_t *h, int batch, int t, int nslots_with_t)
     if (h->crf) {
         qps.assign((size_t)G, (int8_t)(t == 0 ? h->qp_i : h->qp_p));
         for (int s = 0; s < nslots_with_t; s++) qps[(size_t)s] = h->gop_qp[(size_t)s * h->keyint + t];
-        if (x264gpu_encoder_set_stream_qps(h->gpu, qps.data()) != X264GPU_OK) {
-            xlog(&p, X264_LOG_ERROR, "x264_encoder_encode: GPU hot path failed: %s\n", x264gpu_last_error());
+    }
+    // every device codes position t of its slots; one host thread per device issues the work and collects the results
+    const int D = (int)h->devs.size();
+    std::vector<std::string> errs((size_t)D);
+    auto run_dev = [&](int d) {
+        x264_t::DevCtx &dc = h->devs[(size_t)d];
+        bool ok = D == 1 || x264gpu_set_device(dc.dev) == X264GPU_OK;
+        if (ok && h->crf) {
+            std::vector<int8_t> q((size_t)dc.nsl);
+            for (int l = 0; l < dc.nsl; l++) q[(size_t)l] = qps[(size_t)(l * D + d)];
+            ok = x264gpu_encoder_set_stream_qps(dc.gpu, q.data()) == X264GPU_OK;
+        }
+        ok = ok && x264gpu_encode_frames(dc.gpu, dc.d_ring + (size_t)t * dc.nsl * insz, st, dc.d_mb, dc.d_lv, nullptr) == X264GPU_OK &&
+             x264gpu_memcpy_d2h(hmb + (size_t)dc.base * h->nmb, dc.d_mb, (size_t)dc.nsl * h->nmb * sizeof(x264gpu_mb), nullptr) == X264GPU_OK &&
+             x264gpu_memcpy_d2h(hlv + (size_t)dc.base * h->nmb * X264GPU_MB_LEVELS, dc.d_lv, (size_t)dc.nsl * h->nmb * X264GPU_MB_LEVELS * sizeof(int16_t), nullptr) == X264GPU_OK;
+        if (!ok) errs[(size_t)d] = std::string("device ") + std::to_string(dc.dev) + ": " + x264gpu_last_error();      // the error text is per thread
+    };
+    if (D == 1) run_dev(0);
+    else {
+        std::vector<std::thread> ths;
+        for (int d = 0; d < D; d++) ths.emplace_back(run_dev, d);
+        for (auto &th : ths) th.join();
+    }
+    for (int d = 0; d < D; d++)
+        if (!errs[(size_t)d].empty()) {
+            xlog(&p, X264_LOG_ERROR, "x264_encoder_encode: GPU hot path failed: %s\n", errs[(size_t)d].c_str());
             join_pool(h); h->failed = true;
             return -1;
         }
-    }
-    if (x264gpu_encode_frames(h->gpu, h->d_ring + (size_t)t * G * insz, st, h->d_mb, h->d_lv, nullptr) != X264GPU_OK ||
-        x264gpu_memcpy_d2h(hmb, h->d_mb, (size_t)G * h->nmb * sizeof(x264gpu_mb), nullptr) != X264GPU_OK ||
-        x264gpu_memcpy_d2h(hlv, h->d_lv, (size_t)G * h->nmb * X264GPU_MB_LEVELS * sizeof(int16_t), nullptr) != X264GPU_OK) {
-        xlog(&p, X264_LOG_ERROR, "x264_encoder_encode: GPU hot path failed: %s\n", x264gpu_last_error());
-        join_pool(h); h->failed = true;
-        return -1;
-    }
     join_pool(h);
-    auto work = [h, batch, t, st, hmb, hlv, qps](int s) {
+    auto work = [h, batch, t, st, hmb, hlv, qps, D](int s) {
         const x264_param_t &p = h->param;
         const int G = h->G;
+        const size_t row = (size_t)h->devs[(size_t)(s % D)].base + (size_t)(s / D);       // where slot s landed in the download buffers
         x264_t::Coded &c = h->slotbuf[(size_t)s * h->keyint + t];
         c.bytes.clear(); c.off.clear(); c.types.clear();
         c.idr = t == 0;
@@ -455,7 +503,7 @@ static int code_position(x264_t *h, int batch, int t, int nslots_with_t)
         sp.alpha_off_div2 = p.i_deblocking_filter_alphac0; sp.beta_off_div2 = p.i_deblocking_filter_beta;
         sp.transform8x8_mode = p.analyse.b_transform_8x8;
         c.off.push_back(c.bytes.size()); c.types.push_back(c.idr ? 5 : 1);
-        write_slice(c.bytes, sp, hmb + (size_t)s * h->nmb, hlv + (size_t)s * h->nmb * X264GPU_MB_LEVELS, p.b_annexb != 0, c.off.size() == 1, nullptr);
+        write_slice(c.bytes, sp, hmb + row * h->nmb, hlv + row * h->nmb * X264GPU_MB_LEVELS, p.b_annexb != 0, c.off.size() == 1, nullptr);
     };
     const unsigned hw = std::thread::hardware_concurrency();
     const int nthr = (int)(hw ? (hw < (unsigned)nslots_with_t ? hw : (unsigned)nslots_with_t) : 1);
@@ -491,16 +539,24 @@ static int encode_gop_parallel(x264_t *h, x264_nal_t **pp_nal, int *pi_nal, x264
         const long i = h->submitted, b = i / per_batch, r = i % per_batch;
         const int s = (int)(r / K), t = (int)(r % K);
         // a new batch may only start gathering once the previous one is fully coded and drained into the output queue
-        uint8_t *dst = h->d_ring + ((size_t)t * G + s) * insz;
+        const int D = (int)h->devs.size();
+        x264_t::DevCtx &dc = h->devs[(size_t)(s % D)];
+        uint8_t *dst = dc.d_ring + ((size_t)t * dc.nsl + (size_t)(s / D)) * insz;
         const void *src = resident ? (const void *)h->d_in : (const void *)h->h_in.data();
         if ((resident ? x264gpu_memcpy_d2d(dst, src, insz, nullptr) : x264gpu_memcpy_h2d(dst, src, insz, nullptr)) != X264GPU_OK) {
             xlog(&p, X264_LOG_ERROR, "x264_encoder_encode: upload failed: %s\n", x264gpu_last_error());
             return -1;
         }
+        // the lookahead lives on the caller's device: with several devices the picture also goes to the staging buffer there
+        const uint8_t *la_src = dst;
+        if (h->crf && D > 1 && dc.dev != h->device) {
+            if (!resident && x264gpu_memcpy_h2d(h->d_in, src, insz, nullptr) != X264GPU_OK) { xlog(&p, X264_LOG_ERROR, "x264_encoder_encode: upload failed: %s\n", x264gpu_last_error()); return -1; }
+            la_src = h->d_in;
+        }
         if (h->crf) {
             // CRF: the picture's quantiser follows from the lookahead costs and the pictures before it, all known now (rc_pick_qp)
             int32_t costs[4];
-            if (x264gpu_lookahead_frame_cost(h->la, dst, i == 0, h->d_la, nullptr, nullptr) != X264GPU_OK ||
+            if (x264gpu_lookahead_frame_cost(h->la, la_src, i == 0, h->d_la, nullptr, nullptr) != X264GPU_OK ||
                 x264gpu_memcpy_d2h(costs, h->d_la, sizeof(costs), nullptr) != X264GPU_OK) {
                 xlog(&p, X264_LOG_ERROR, "x264_encoder_encode: lookahead failed: %s\n", x264gpu_last_error());
                 return -1;
@@ -801,7 +857,14 @@ void x264_encoder_close(x264_t *h)
     if (h->d_in) x264gpu_free(h->d_in);
     if (h->d_mb) x264gpu_free(h->d_mb);
     if (h->d_lv) x264gpu_free(h->d_lv);
-    if (h->d_ring) x264gpu_free(h->d_ring);
+    for (auto &dc : h->devs) {
+        if (h->devs.size() > 1) (void)x264gpu_set_device(dc.dev);
+        if (dc.gpu) x264gpu_encoder_destroy(dc.gpu);
+        if (dc.d_mb) x264gpu_free(dc.d_mb);
+        if (dc.d_lv) x264gpu_free(dc.d_lv);
+        if (dc.d_ring) x264gpu_free(dc.d_ring);
+    }
+    if (h->devs.size() > 1) (void)x264gpu_set_device(h->device);
     for (size_t i = 0; i < h->q_raw.size(); i++) {
         if (h->q_raw[i] && h->q_raw[i] != h->d_in) x264gpu_free(h->q_raw[i]);
         if (h->q_info[i]) x264gpu_free(h->q_info[i]);
