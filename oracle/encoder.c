@@ -137,6 +137,9 @@ static void settle_mb_qp(x264o_encoder *e, x264gpu_mb *mbs, int slice_qp)
     for (int i = 0; i < e->mbw * e->mbh; i++) {
         x264gpu_mb *m = &mbs[i];
         if (m->type != X264GPU_MB_I16x16 && !m->cbp_luma && !m->cbp_chroma) m->qp = (uint8_t)last;
+        /* x264's entropy coders (qp_delta writers): an I16x16 with nothing coded at all (no DC either) does not spend a delta on RAISING
+         * the quantiser — it takes the previous one, and that is the qp the loop filter then sees */
+        else if (m->type == X264GPU_MB_I16x16 && !m->cbp_luma && !m->cbp_chroma && !((m->nnz >> 24) & 1) && m->qp > last) m->qp = (uint8_t)last;
         last = m->qp;
     }
 }

@@ -3,10 +3,11 @@
 // reconstruction bit for bit, which checks the slice/macroblock syntax (7.3.3-7.3.5), CAVLC (9.2), motion
 // vector and intra-mode prediction (8.3.1.1, 8.4.1) and boundary strengths (8.7.2.1) independently of the
 // encoder-side code paths.  Sample reconstruction reuses the oracle's spec-pinned DSP (predict, dequant,
-// inverse transforms, interpolation, edge filters).  Subset: Baseline-style streams — CAVLC, frame MBs,
-// I (I4x4/I16x16) and P (P_L0_16x16, P_Skip, intra) slices, one slice per picture, poc type 2, one ref.
+// inverse transforms, interpolation, edge filters).  Subset: CAVLC or CABAC (cabac_dec.hpp; cabac_init_idc 0), frame MBs,
+// I (I4x4 / I8x8 / I16x16) and P (16x16 / 16x8 / 8x16 / 8x8, P_Skip, intra) slices, one slice per picture, poc type 2, up to 4 refs.
 #include "x264o.h"
 #include "../x264vfw_amd/host/cavlc_tables.hpp"
+#include "cabac_dec.hpp"
 #include <stdint.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -50,12 +51,16 @@ struct MbInfo {
     uint8_t i4mode[16];
     uint8_t tc[24];          // total_coeff per block (for nC)
     uint32_t nz;             // luma blocks with coefficients (deblock bS 2): bit per block idx
+    // CABAC context derivation (9.3.3.1.1): what the neighbours' syntax elements were
+    int cbp_luma, cbp_chroma, chroma_mode;
+    uint32_t cbf;            // coded_block_flag per block: bits 0..15 luma 4x4 (block index), 16..23 chroma AC (plane * 4 + block), 24 luma DC, 25 / 26 chroma DC
+    uint8_t amvd[4][2];      // |mvd| per 8x8 block and component
 };
 
 struct Decoder {
     int mbw = 0, mbh = 0, width = 0, height = 0, crop_r = 0, crop_b = 0;
     int log2_max_frame_num = 4, poc_type = 2;
-    int pic_init_qp = 26, chroma_qp_offset = 0, deblock_ctrl = 1, num_ref_default = 1, transform8x8_mode = 0;
+    int pic_init_qp = 26, chroma_qp_offset = 0, deblock_ctrl = 1, num_ref_default = 1, transform8x8_mode = 0, cabac = 0;
     int stride = 0, pad = 32, cpad = 16;
     size_t plane_bytes = 0, cplane_bytes = 0;
     std::vector<pixel> luma[5], chroma[5];   // DPB slots: up to 4 references + the picture being decoded
@@ -141,6 +146,187 @@ struct SliceDec {
     Decoder &d;
     BitReader &br;
     int slice_type, qp, disable_deblock, alpha_off, beta_off;
+    cabacdec::Engine cd;
+    int last_dqp = 0;                // mb_qp_delta of the previous macroblock in decoding order (ctxIdxInc of the first bin)
+
+    // ---- CABAC: binarisations + ctxIdxInc derivations (9.3.2, 9.3.3.1) ----
+    const MbInfo *nbA(int mbx, int mby) const { return mbx > 0 ? &d.mb[mby * d.mbw + mbx - 1] : nullptr; }
+    const MbInfo *nbB(int mbx, int mby) const { return mby > 0 ? &d.mb[(mby - 1) * d.mbw + mbx] : nullptr; }
+    static bool is_nxn(const MbInfo &m) { return m.intra && !m.i16; }
+    int ca_skip_flag(int mbx, int mby)
+    {
+        const MbInfo *a = nbA(mbx, mby), *b = nbB(mbx, mby);
+        return cd.decision(11 + (a && !a->skip) + (b && !b->skip));
+    }
+    // mb_type of an intra macroblock (I-slice numbering: 0 = I_NxN, 1..24 = I_16x16 variants); c[] = the six context indices
+    int ca_intra_type(int c0, int c1, int c2, int c3, int c4, int c5)
+    {
+        if (!cd.decision(c0)) return 0;
+        if (cd.terminate()) { cd.err = true; return 0; }          // I_PCM: not in the subset
+        const int luma = cd.decision(c1);
+        int chroma = 0;
+        if (cd.decision(c2)) chroma = cd.decision(c3) ? 2 : 1;
+        const int hi = cd.decision(c4), lo = cd.decision(c5);
+        return 1 + (hi * 2 + lo) + 4 * chroma + 12 * luma;
+    }
+    int ca_mb_type_i(int mbx, int mby)
+    {
+        const MbInfo *a = nbA(mbx, mby), *b = nbB(mbx, mby);
+        return ca_intra_type(3 + (a && !is_nxn(*a)) + (b && !is_nxn(*b)), 6, 7, 8, 9, 10);
+    }
+    // P slices: 0..3 = P_L0_16x16, P_L0_L0_16x8, P_L0_L0_8x16, P_8x8; 5 + n = intra type n
+    int ca_mb_type_p()
+    {
+        if (cd.decision(14)) return 5 + ca_intra_type(17, 18, 19, 19, 20, 20);
+        if (!cd.decision(15)) return cd.decision(16) ? 3 : 0;
+        return cd.decision(17) ? 1 : 2;
+    }
+    int ca_t8(int mbx, int mby)
+    {
+        const MbInfo *a = nbA(mbx, mby), *b = nbB(mbx, mby);
+        return cd.decision(399 + (a && a->t8) + (b && b->t8));
+    }
+    int ca_i4_mode(int pm)
+    {
+        if (cd.decision(68)) return pm;
+        int r = cd.decision(69); r |= cd.decision(69) << 1; r |= cd.decision(69) << 2;
+        return r < pm ? r : r + 1;
+    }
+    int ca_chroma_mode(int mbx, int mby)
+    {
+        const MbInfo *a = nbA(mbx, mby), *b = nbB(mbx, mby);
+        if (!cd.decision(64 + (a && a->intra && a->chroma_mode) + (b && b->intra && b->chroma_mode))) return 0;
+        if (!cd.decision(67)) return 1;
+        return cd.decision(67) ? 3 : 2;
+    }
+    int ca_cbp(int mbx, int mby)
+    {
+        const MbInfo *a = nbA(mbx, mby), *b = nbB(mbx, mby);
+        int luma = 0;
+        for (int b8 = 0; b8 < 4; b8++) {
+            // condTermFlagN: the neighbouring 8x8 block is available and its coded_block_pattern bit is 0 (9.3.3.1.1.4)
+            const int ca = (b8 & 1) ? !((luma >> (b8 - 1)) & 1) : a ? !((a->cbp_luma >> (b8 + 1)) & 1) : 0;
+            const int cb_ = (b8 & 2) ? !((luma >> (b8 - 2)) & 1) : b ? !((b->cbp_luma >> (b8 + 2)) & 1) : 0;
+            luma |= cd.decision(73 + ca + 2 * cb_) << b8;
+        }
+        int chroma = 0;
+        if (cd.decision(77 + (a && a->cbp_chroma) + 2 * (b && b->cbp_chroma)))
+            chroma = cd.decision(81 + (a && a->cbp_chroma == 2) + 2 * (b && b->cbp_chroma == 2)) ? 2 : 1;
+        return luma | chroma << 4;
+    }
+    int ca_dqp()
+    {
+        int ctx = 60 + (last_dqp != 0), k = 0;
+        while (cd.decision(ctx)) { ctx = k == 0 ? 62 : 63; if (++k > 104) { cd.err = true; break; } }
+        const int v = (k & 1) ? (k + 1) >> 1 : -(k >> 1);
+        last_dqp = v;
+        return v;
+    }
+    // reference index / mvd contexts look at the 8x8 blocks left of and above the partition's first block
+    int ref_gt0(int gx, int gy)
+    {
+        if (gx < 0 || gy < 0 || gx >= 2 * d.mbw || gy >= 2 * d.mbh) return 0;
+        const int i = (gy >> 1) * d.mbw + (gx >> 1), k = (gy & 1) * 2 + (gx & 1);
+        if (i > cur_idx) return 0;
+        if (i == cur_idx) return (refs_known >> k & 1) && cur_refs[k] > 0;
+        const MbInfo &m = d.mb[i];
+        return !m.intra && !m.skip && m.ref8[k] > 0;
+    }
+    int ca_ref(int gx, int gy)
+    {
+        int ctx = ref_gt0(gx - 1, gy) + 2 * ref_gt0(gx, gy - 1), r = 0;
+        while (cd.decision(54 + ctx)) { ctx = ctx < 4 ? 4 : 5; if (++r > 32) { cd.err = true; break; } }
+        return r;
+    }
+    int amvd_of(int gx, int gy, int comp)
+    {
+        if (gx < 0 || gy < 0 || gx >= 2 * d.mbw || gy >= 2 * d.mbh) return 0;
+        const int i = (gy >> 1) * d.mbw + (gx >> 1), k = (gy & 1) * 2 + (gx & 1);
+        if (i > cur_idx || (i == cur_idx && !(known8 >> k & 1))) return 0;
+        return d.mb[i].amvd[k][comp];
+    }
+    int ca_mvd(int gx, int gy, int comp)
+    {
+        const int sum = amvd_of(gx - 1, gy, comp) + amvd_of(gx, gy - 1, comp), base = comp ? 47 : 40;
+        if (!cd.decision(base + (sum > 2) + (sum > 32))) return 0;
+        int a = 1;
+        while (a < 9 && cd.decision(base + (a < 4 ? 2 + a : 6))) a++;
+        if (a == 9) a += cd.golomb_bypass(3);
+        return cd.bypass() ? -a : a;
+    }
+    // coded_block_flag neighbourhood (9.3.3.1.1.9): value of the flag of the neighbouring block, or the default for a missing one
+    static int luma_flag(const MbInfo &m, int bx, int by)
+    {
+        if (m.skip || !((m.cbp_luma >> ((by >> 1) * 2 + (bx >> 1))) & 1)) return 0;
+        return m.t8 ? 1 : (int)((m.cbf >> kIdxOf[by][bx]) & 1);
+    }
+    int cbf_ctx_luma(int mbx, int mby, const MbInfo &cur, int blk)
+    {
+        const int bx = kBlkX[blk], by = kBlkY[blk], missing = cur.intra ? 1 : 0;
+        const MbInfo *a = nbA(mbx, mby), *b = nbB(mbx, mby);
+        const int fa = bx ? luma_flag(cur, bx - 1, by) : a ? luma_flag(*a, 3, by) : missing;
+        const int fb = by ? luma_flag(cur, bx, by - 1) : b ? luma_flag(*b, bx, 3) : missing;
+        return fa + 2 * fb;
+    }
+    int cbf_ctx_dc(int mbx, int mby, const MbInfo &cur, int bit)
+    {
+        const int missing = cur.intra ? 1 : 0;
+        auto f = [&](const MbInfo *n) {
+            if (!n) return missing;
+            if (n->skip) return 0;
+            if (bit == 24) return n->i16 ? (int)((n->cbf >> 24) & 1) : 0;
+            return n->cbp_chroma ? (int)((n->cbf >> bit) & 1) : 0;
+        };
+        return f(nbA(mbx, mby)) + 2 * f(nbB(mbx, mby));
+    }
+    int cbf_ctx_chroma_ac(int mbx, int mby, const MbInfo &cur, int c, int i)
+    {
+        const int bx = i & 1, by = i >> 1, missing = cur.intra ? 1 : 0;
+        auto f = [&](const MbInfo &m, int x, int y) { return !m.skip && m.cbp_chroma == 2 ? (int)((m.cbf >> (16 + c * 4 + y * 2 + x)) & 1) : 0; };
+        const MbInfo *a = nbA(mbx, mby), *b = nbB(mbx, mby);
+        const int fa = bx ? f(cur, 0, by) : a ? f(*a, 1, by) : missing;
+        const int fb = by ? f(cur, bx, 0) : b ? f(*b, bx, 1) : missing;
+        return fa + 2 * fb;
+    }
+    // residual_block_cabac (7.3.5.3.3): cat = ctxBlockCat; out[0..n-1] in scan order; returns the number of non-zero levels
+    int ca_coeffs(int16_t *out, int n, int cat)
+    {
+        static const int sig0[6] = { 105, 120, 134, 149, 152, 402 }, last0[6] = { 166, 181, 195, 210, 213, 417 }, abs0[6] = { 227, 237, 247, 257, 266, 426 };
+        memset(out, 0, sizeof(int16_t) * (size_t)n);
+        int pos[64], np = 0;
+        for (int i = 0; i < n - 1; i++) {
+            const int si = cat == 5 ? cabacdec::kSigInc8[i] : cat == 3 ? (i < 2 ? i : 2) : i, li = cat == 5 ? cabacdec::kLastInc8[i] : cat == 3 ? (i < 2 ? i : 2) : i;
+            if (cd.decision(sig0[cat] + si)) {
+                pos[np++] = i;
+                if (cd.decision(last0[cat] + li)) goto levels;
+            }
+        }
+        pos[np++] = n - 1;                                         // reached the last position: it is significant by inference
+    levels:
+        int eq1 = 0, gt1 = 0;
+        for (int k = np - 1; k >= 0; k--) {
+            const int c0 = abs0[cat] + (gt1 ? 0 : (eq1 + 1 < 4 ? eq1 + 1 : 4));
+            int a = 1;
+            if (cd.decision(c0)) {
+                const int lim = cat == 3 ? 3 : 4, c1 = abs0[cat] + 5 + (gt1 < lim ? gt1 : lim);
+                a = 2;
+                while (a < 15 && cd.decision(c1)) a++;
+                if (a == 15) a += cd.golomb_bypass(0);
+                gt1++;
+            } else eq1++;
+            out[pos[k]] = (int16_t)(cd.bypass() ? -a : a);
+        }
+        return np;
+    }
+    // coded_block_flag + levels of one block; returns the number of non-zero levels (0 when the flag is 0)
+    int ca_block(int16_t *out, int n, int cat, int inc)
+    {
+        static const int cbf0[5] = { 85, 89, 93, 97, 101 };
+        memset(out, 0, sizeof(int16_t) * (size_t)n);
+        if (!cd.decision(cbf0[cat] + inc)) return 0;
+        return ca_coeffs(out, n, cat);
+    }
+    int cur_refs[4] = { 0, 0, 0, 0 }, refs_known = 0;
 
     int nc_luma(int mbx, int mby, int blk)
     {
@@ -216,10 +402,17 @@ struct SliceDec {
     {
         int16_t dc[2][4] = { { 0 } }, ac[2][4][16];
         memset(ac, 0, sizeof(ac));
+        if (d.cabac) {
+            if (cbp_chroma) for (int c = 0; c < 2; c++) if (ca_block(dc[c], 4, 3, cbf_ctx_dc(mbx, mby, m, 25 + c))) m.cbf |= 1u << (25 + c);
+            if (cbp_chroma == 2)
+                for (int c = 0; c < 2; c++)
+                    for (int i = 0; i < 4; i++) if (ca_block(ac[c][i] + 1, 15, 4, cbf_ctx_chroma_ac(mbx, mby, m, c, i))) m.cbf |= 1u << (16 + c * 4 + i);
+        } else {
         if (cbp_chroma) for (int c = 0; c < 2; c++) residual_block(br, dc[c], 4, -1);
         if (cbp_chroma == 2)
             for (int c = 0; c < 2; c++)
                 for (int i = 0; i < 4; i++) m.tc[16 + c * 4 + i] = (uint8_t)residual_block(br, ac[c][i] + 1, 15, nc_chroma(mbx, mby, c, i));
+        }
         pixel *uv = d.UV(d.cur) + (size_t)mby * 8 * d.stride + mbx * 16;
         for (int c = 0; c < 2; c++) {
             dctcoef dq[4];
@@ -244,7 +437,11 @@ struct SliceDec {
         dctcoef c8[64];
         memset(c8, 0, sizeof(c8));
         bool any = false;
-        if (coded)
+        if (coded && d.cabac) {
+            int16_t l8[64];
+            any = ca_coeffs(l8, 64, 5) != 0;                       // 4:2:0: no coded_block_flag for 8x8 blocks (inferred from the cbp bit)
+            for (int z = 0; z < 64; z++) c8[x264o_zigzag8[z]] = l8[z];
+        } else if (coded)
             for (int k = 0; k < 4; k++) {
                 int16_t l[16];
                 int b = i8 * 4 + k;
@@ -287,19 +484,21 @@ struct SliceDec {
         int cbp_luma = 0, cbp_chroma = 0, i16mode = 0;
         if (mbtype == 0) {
             m.i16 = 0;
-            m.t8 = d.transform8x8_mode ? br.get1() : 0;
+            m.t8 = d.transform8x8_mode ? (d.cabac ? ca_t8(mbx, mby) : br.get1()) : 0;
             if (m.t8) {
                 // Intra8x8PredMode (8.3.2.1): predicted from the neighbouring 4x4 entries; stored replicated
                 for (int i8 = 0; i8 < 4; i8++) {
                     int pm = pred_i4(mbx, mby, i8 * 4, m), mode;
-                    if (br.get1()) mode = pm;
+                    if (d.cabac) mode = ca_i4_mode(pm);
+                    else if (br.get1()) mode = pm;
                     else { int r = (int)br.get(3); mode = r < pm ? r : r + 1; }
                     memset(m.i4mode + i8 * 4, mode, 4);
                 }
             } else
             for (int b = 0; b < 16; b++) {
                 int pm = pred_i4(mbx, mby, b, m);
-                if (br.get1()) m.i4mode[b] = (uint8_t)pm;
+                if (d.cabac) m.i4mode[b] = (uint8_t)ca_i4_mode(pm);
+                else if (br.get1()) m.i4mode[b] = (uint8_t)pm;
                 else { int r = (int)br.get(3); m.i4mode[b] = (uint8_t)(r < pm ? r : r + 1); }
             }
         } else {
@@ -308,23 +507,35 @@ struct SliceDec {
             i16mode = t & 3; cbp_chroma = (t >> 2) % 3; cbp_luma = t >= 12 ? 15 : 0;
             memset(m.i4mode, 2, 16);
         }
-        int chroma_mode = (int)br.ue();
+        int chroma_mode = d.cabac ? ca_chroma_mode(mbx, mby) : (int)br.ue();
+        m.chroma_mode = chroma_mode;
         if (!m.i16) {
-            int code = (int)br.ue(), cbp = -1;
-            for (int i = 0; i < 48; i++) if (cbp_to_golomb_intra[i] == code) cbp = i;
+            int cbp = -1;
+            if (d.cabac) cbp = ca_cbp(mbx, mby);
+            else { int code = (int)br.ue(); for (int i = 0; i < 48; i++) if (cbp_to_golomb_intra[i] == code) cbp = i; }
             if (cbp < 0) { br.err = true; return; }
             cbp_luma = cbp & 15; cbp_chroma = cbp >> 4;
         }
-        if (m.i16 || cbp_luma || cbp_chroma) qp += br.se();
+        m.cbp_luma = cbp_luma; m.cbp_chroma = cbp_chroma;
+        if (m.i16 || cbp_luma || cbp_chroma) qp += d.cabac ? ca_dqp() : br.se();
+        else last_dqp = 0;
+        qp = (qp + 52) % 52;
         m.qp = qp;
         int qpc = x264o_chroma_qp[clampi(qp + d.chroma_qp_offset, 0, 51)];
         if (m.i16) {
             int16_t dcl[16], acl[16][16];
             memset(acl, 0, sizeof(acl));
+            if (d.cabac) {
+                if (ca_block(dcl, 16, 0, cbf_ctx_dc(mbx, mby, m, 24))) m.cbf |= 1u << 24;
+                for (int i8 = 0; i8 < 4; i8++)
+                    if (cbp_luma >> i8 & 1)
+                        for (int k = 0; k < 4; k++) { int b = i8 * 4 + k; if (ca_block(acl[b] + 1, 15, 1, cbf_ctx_luma(mbx, mby, m, b))) m.cbf |= 1u << b; }
+            } else {
             residual_block(br, dcl, 16, nc_luma(mbx, mby, 0));
             for (int i8 = 0; i8 < 4; i8++)
                 if (cbp_luma >> i8 & 1)
                     for (int k = 0; k < 4; k++) { int b = i8 * 4 + k; m.tc[b] = (uint8_t)residual_block(br, acl[b] + 1, 15, nc_luma(mbx, mby, b)); }
+            }
             int mode = i16mode;
             if (mode == I_PRED_16x16_DC) mode = left && top ? I_PRED_16x16_DC : left ? I_PRED_16x16_DC_LEFT : top ? I_PRED_16x16_DC_TOP : I_PRED_16x16_DC_128;
             pixel pred[256];
@@ -363,7 +574,10 @@ struct SliceDec {
             for (int b = 0; b < 16; b++) {
                 int16_t l[16];
                 memset(l, 0, sizeof(l));
-                if (cbp_luma >> (b >> 2) & 1) m.tc[b] = (uint8_t)residual_block(br, l, 16, nc_luma(mbx, mby, b));
+                if (cbp_luma >> (b >> 2) & 1) {
+                    if (d.cabac) { m.tc[b] = (uint8_t)ca_block(l, 16, 2, cbf_ctx_luma(mbx, mby, m, b)); if (m.tc[b]) m.cbf |= 1u << b; }
+                    else m.tc[b] = (uint8_t)residual_block(br, l, 16, nc_luma(mbx, mby, b));
+                }
                 int avail = i4_avail(mbx, mby, b), mode = m.i4mode[b];
                 if (mode == I_PRED_4x4_DC) {
                     int l_ = avail & X264O_AVAIL_LEFT, t_ = avail & X264O_AVAIL_TOP;
@@ -403,27 +617,40 @@ struct SliceDec {
                                               { { 0, 0, 1, 1 }, { 1, 0, 1, 1 }, { 0, 1, 1, 1 }, { 1, 1, 1, 1 } } };
         m.intra = 0; m.i16 = 0; memset(m.i4mode, 2, 16);
         int nparts = shape == 0 ? 1 : shape == 3 ? 4 : 2, refs[4] = { 0, 0, 0, 0 };
-        if (shape == 3) for (int k = 0; k < 4; k++) if (br.ue() != 0) { br.err = true; return; }     // only P_L0_8x8 sub-macroblocks
-        if (d.nref_active > 1) for (int k = 0; k < nparts; k++) refs[k] = d.nref_active == 2 ? !br.get1() : (int)br.ue();
+        m.cbf = 0; m.chroma_mode = 0;
+        refs_known = 0;
+        if (shape == 3) for (int k = 0; k < 4; k++) if (d.cabac ? !cd.decision(21) : br.ue() != 0) { br.err = true; return; }     // only P_L0_8x8 sub-macroblocks
+        if (d.nref_active > 1)
+            for (int k = 0; k < nparts; k++) {
+                const int8_t *g = geom[shape][k];
+                refs[k] = d.cabac ? ca_ref(2 * mbx + g[0], 2 * mby + g[1]) : d.nref_active == 2 ? !br.get1() : (int)br.ue();
+                for (int yy = g[1]; yy < g[1] + g[3]; yy++) for (int xx = g[0]; xx < g[0] + g[2]; xx++) { cur_refs[yy * 2 + xx] = refs[k]; refs_known |= 1 << (yy * 2 + xx); }
+            }
         for (int k = 0; k < nparts; k++) if (refs[k] >= d.nref_active) { br.err = true; return; }
         for (int k = 0; k < nparts; k++) {
             const int8_t *g = geom[shape][k];
             int px, py;
             mvp(2 * mbx + g[0], 2 * mby + g[1], g[2], shape, k, refs[k], px, py);
-            int mvx = px + br.se(), mvy = py + br.se();
+            const int dx = d.cabac ? ca_mvd(2 * mbx + g[0], 2 * mby + g[1], 0) : br.se(), dy = d.cabac ? ca_mvd(2 * mbx + g[0], 2 * mby + g[1], 1) : br.se();
+            int mvx = px + dx, mvy = py + dy;
             if (getenv("X264O_DEC_DEBUG")) fprintf(stderr, "mb %d,%d shape %d part %d mvp %d,%d mv %d,%d\n", mbx, mby, shape, k, px, py, mvx, mvy);
             for (int yy = g[1]; yy < g[1] + g[3]; yy++)
                 for (int xx = g[0]; xx < g[0] + g[2]; xx++) {
                     int b8 = yy * 2 + xx;
                     m.ref8[b8] = refs[k]; m.mv8[b8][0] = mvx; m.mv8[b8][1] = mvy;
+                    m.amvd[b8][0] = (uint8_t)(abs(dx) < 255 ? abs(dx) : 255); m.amvd[b8][1] = (uint8_t)(abs(dy) < 255 ? abs(dy) : 255);
                     known8 |= 1 << b8;
                 }
         }
-        int code = (int)br.ue(), cbp = -1;
-        for (int i = 0; i < 48; i++) if (cbp_to_golomb_inter[i] == code) cbp = i;
+        int cbp = -1;
+        if (d.cabac) cbp = ca_cbp(mbx, mby);
+        else { int code = (int)br.ue(); for (int i = 0; i < 48; i++) if (cbp_to_golomb_inter[i] == code) cbp = i; }
         if (cbp < 0) { br.err = true; return; }
-        m.t8 = (d.transform8x8_mode && (cbp & 15)) ? br.get1() : 0;      // all partitions are >= 8x8 in this subset
-        if (cbp) qp += br.se();
+        m.cbp_luma = cbp & 15; m.cbp_chroma = cbp >> 4;
+        m.t8 = (d.transform8x8_mode && (cbp & 15)) ? (d.cabac ? ca_t8(mbx, mby) : br.get1()) : 0;      // all partitions are >= 8x8 in this subset
+        if (cbp) qp += d.cabac ? ca_dqp() : br.se();
+        else last_dqp = 0;
+        qp = (qp + 52) % 52;
         m.qp = qp;
         inter_pred(mbx, mby, m);
         pixel *rec = d.Y(d.cur) + (size_t)mby * 16 * d.stride + mbx * 16;
@@ -434,7 +661,8 @@ struct SliceDec {
         for (int b = 0; b < 16; b++) {
             if (!(cbp >> (b >> 2) & 1)) continue;
             int16_t l[16];
-            m.tc[b] = (uint8_t)residual_block(br, l, 16, nc_luma(mbx, mby, b));
+            if (d.cabac) { m.tc[b] = (uint8_t)ca_block(l, 16, 2, cbf_ctx_luma(mbx, mby, m, b)); if (m.tc[b]) m.cbf |= 1u << b; }
+            else m.tc[b] = (uint8_t)residual_block(br, l, 16, nc_luma(mbx, mby, b));
             if (m.tc[b]) m.nz |= 1u << b;
             dctcoef blk[16];
             for (int k = 0; k < 16; k++) blk[x264o_zigzag4[k]] = l[k];
@@ -444,8 +672,40 @@ struct SliceDec {
         chroma_residual(mbx, mby, cbp >> 4, m, x264o_chroma_qp[clampi(qp + d.chroma_qp_offset, 0, 51)]);
     }
 
+    void skipped_mb(int i)
+    {
+        MbInfo &m = d.mb[i];
+        int mbx = i % d.mbw, mby = i / d.mbw, px, py;
+        cur_idx = i; known8 = 0;
+        skip_mv(mbx, mby, px, py);
+        m.intra = 0; m.skip = 1; m.qp = qp; memset(m.i4mode, 2, 16);
+        for (int k = 0; k < 4; k++) { m.ref8[k] = 0; m.mv8[k][0] = px; m.mv8[k][1] = py; }
+        inter_pred(mbx, mby, m);
+    }
+    void run_cabac()
+    {
+        const int n = d.mbw * d.mbh;
+        for (auto &m : d.mb) m = MbInfo();
+        while (br.pos & 7) if (!br.get1()) { br.err = true; return; }          // cabac_alignment_one_bit
+        cd.start(br.p, br.n, br.pos, slice_type == 0, qp);
+        for (int i = 0; i < n && !cd.err && !br.err; i++) {
+            const int mbx = i % d.mbw, mby = i / d.mbw;
+            cur_idx = i; known8 = 0;
+            if (slice_type == 0 && ca_skip_flag(mbx, mby)) { skipped_mb(i); last_dqp = 0; }
+            else {
+                MbInfo &m = d.mb[i];
+                const int t = slice_type == 0 ? ca_mb_type_p() : ca_mb_type_i(mbx, mby);
+                if (slice_type == 0 && t <= 3) inter_mb(mbx, mby, t, m);
+                else intra_mb(mbx, mby, slice_type == 0 ? t - 5 : t, m);
+            }
+            const int end = cd.terminate();
+            if (end != (i == n - 1)) { br.err = true; return; }                  // one slice per picture: the flag is set exactly at the last macroblock
+        }
+        if (cd.err) br.err = true;
+    }
     void run()
     {
+        if (d.cabac) { run_cabac(); return; }
         int n = d.mbw * d.mbh, i = 0;
         for (auto &m : d.mb) m = MbInfo();
         while (i < n && !br.err) {
@@ -580,7 +840,7 @@ bool decode_nal(Decoder &d, const uint8_t *nal, size_t n)
     }
     if (type == 8) {
         br.ue(); br.ue();
-        if (br.get1()) return false;                        // CABAC not supported by this checker
+        d.cabac = br.get1();                                // entropy_coding_mode_flag
         br.get1(); if (br.ue()) return false;
         d.num_ref_default = (int)br.ue() + 1; br.ue();
         if (br.get1() || br.get(2)) return false;           // weighted prediction
@@ -614,6 +874,7 @@ bool decode_nal(Decoder &d, const uint8_t *nal, size_t n)
             if (d.nref_active > d.have || d.nref_active > d.num_ref_frames) return false;   // refers to pictures not in the DPB
         }
         if ((nal[0] >> 5) & 3) { if (type == 5) { br.get1(); br.get1(); } else if (br.get1()) return false; }
+        if (d.cabac && st == 0 && br.ue() != 0) return false;   // cabac_init_idc: only the tables of 0 are in this checker
         int qp = d.pic_init_qp + br.se();
         int disable = 0, a = 0, b = 0;
         if (d.deblock_ctrl) { disable = (int)br.ue(); if (disable != 1) { a = 2 * br.se(); b = 2 * br.se(); } }

@@ -97,6 +97,8 @@ _sig("x264_encoder_delayed_frames", _i, [C.c_void_p])
 _sig("x264_encoder_close", None, [C.c_void_p])
 _sig("x264host_write_slice", _i, [_i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, C.c_void_p, C.c_void_p, C.c_void_p, _i, C.POINTER(_i)])
 _sig("x264host_write_headers", _i, [_i, _i, _i, _i, _i, _i, C.c_uint32, C.c_uint32, _i, _i, C.c_void_p, _i])
+_sig("x264host_write_slice_cabac", _i, [_i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, C.c_void_p, C.c_void_p, C.c_void_p, _i, C.POINTER(_i)])
+_sig("x264host_write_headers_cabac", _i, [_i, _i, _i, _i, _i, _i, C.c_uint32, C.c_uint32, _i, _i, _i, C.c_void_p, _i])
 _sig("x264host_get_recon", _i, [C.c_void_p, C.c_void_p])
 _sig("x264host_last_decision", _i, [C.c_void_p, C.POINTER(_i), C.POINTER(_i), C.POINTER(C.c_int32)])
 LEVELS = (Level * 21).in_dll(H, "x264_levels")
@@ -105,20 +107,20 @@ X264_CSP_I420, X264_RC_CQP, X264_RC_CRF, X264_RC_ABR = 1, 0, 1, 2
 X264_PARAM_BAD_NAME, X264_PARAM_BAD_VALUE = -1, -2
 
 
-def write_headers(w, h, level=40, log2_max_frame_num=8, pic_init_qp=23, cqo=0, tick=1, scale=50, num_ref=1, t8x8=0):
+def write_headers(w, h, level=40, log2_max_frame_num=8, pic_init_qp=23, cqo=0, tick=1, scale=50, num_ref=1, t8x8=0, cabac=0):
     buf = np.zeros(256, np.uint8)
-    n = H.x264host_write_headers(w, h, level, log2_max_frame_num, pic_init_qp, cqo, tick, scale, num_ref, t8x8, buf.ctypes.data, buf.size)
+    n = H.x264host_write_headers_cabac(w, h, level, log2_max_frame_num, pic_init_qp, cqo, tick, scale, num_ref, t8x8, cabac, buf.ctypes.data, buf.size)
     assert n > 0
     return bytes(buf[:n])
 
 
 def write_slice(mbw, mbh, slice_type, qp, pic_init_qp, frame_num, log2_max_frame_num, idr, idr_pic_id, disable_deblock, mbs, lv,
-                num_ref=1, num_ref_default=1, t8x8=0):
+                num_ref=1, num_ref_default=1, t8x8=0, cabac=0):
     buf = np.zeros(max(1 << 16, mbs.size * 1200), np.uint8)
     sk = _i()
     mbs = np.ascontiguousarray(mbs)
     lv = np.ascontiguousarray(lv)
-    n = H.x264host_write_slice(mbw, mbh, slice_type, qp, pic_init_qp, frame_num, log2_max_frame_num, idr, idr_pic_id,
+    n = (H.x264host_write_slice_cabac if cabac else H.x264host_write_slice)(mbw, mbh, slice_type, qp, pic_init_qp, frame_num, log2_max_frame_num, idr, idr_pic_id,
                                disable_deblock, num_ref, num_ref_default, t8x8, mbs.ctypes.data, lv.ctypes.data, buf.ctypes.data, buf.size,
                                C.byref(sk))
     assert n > 0

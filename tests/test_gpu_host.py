@@ -69,7 +69,7 @@ def test_encode_api_closed_loop(gpu, w, h, opts):
     profile = opts.pop("_profile", b"baseline")
     h_, eff = open_encoder(w, h, opts, profile)
     assert eff.analyse.b_transform_8x8 == int(profile == b"high")
-    assert (eff.i_bframe, eff.b_cabac, eff.rc.i_rc_method) == (0, 0, HL.X264_RC_CQP)   # effective params
+    assert (eff.i_bframe, eff.b_cabac, eff.rc.i_rc_method) == (0, int(profile == b"high"), HL.X264_RC_CQP)   # effective params: CABAC stays on above Baseline
     assert eff.i_frame_reference == int(opts.get("ref", 3))                         # medium: --ref 3
     stream, info, recons = encode_all(h_, w, h, frames)
     H.x264_encoder_close(h_)
@@ -125,7 +125,7 @@ def test_bitstream_equals_oracle_path(gpu):
     for i, f in enumerate(frames):
         mbs, lv = enc.encode(f, 2 if i == 0 else 0)
         ref += HL.write_slice(11, 9, 2 if i == 0 else 0, qp_i if i == 0 else qp, qp, i, 8, int(i == 0), 0, 0, mbs, lv,
-                              num_ref=max(1, min(3, i)), num_ref_default=3, t8x8=1)[0]
+                              num_ref=max(1, min(3, i)), num_ref_default=3, t8x8=1, cabac=1)[0]
     def slice_nals(b):
         import re
         return [n.rstrip(b"\x00") if False else n for n in re.split(b"\x00\x00\x00\x01|\x00\x00\x01", b) if n and (n[0] & 31) in (1, 5)]

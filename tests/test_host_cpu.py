@@ -116,20 +116,21 @@ def test_open_without_gpu_fails_loudly():
                                      (208, 120, dict(dct8x8=1, qp_i=12, qp_p=14, dct_decimate=0)),
                                      (176, 144, dict(dct8x8=1, partitions=6)), (352, 288, dict(dct8x8=1, partitions=7, refs=3, qp_i=28, qp_p=31)),
                                      (208, 120, dict(dct8x8=1, partitions=4, qp_i=14, qp_p=16)), (64, 48, dict(dct8x8=1, partitions=7, qp_i=38, qp_p=40))])
-def test_cavlc_closed_loop(w, h, kw):
-    """oracle records -> host CAVLC -> checker decoder == oracle reconstruction, I and P pictures"""
+@pytest.mark.parametrize("cabac", [0, 1])
+def test_entropy_closed_loop(w, h, kw, cabac):
+    """oracle records -> host CAVLC / CABAC -> checker decoder == oracle reconstruction, I and P pictures"""
     nfr = 7 if kw.get("refs", 1) > 1 else 4
     frames = synth_frames(w, h, nfr, seed=11 * w + h)
     cfg = O.default_config(w, h, **kw)
     enc = O.OracleEncoder(cfg)
     mbw, mbh = (w + 15) // 16, (h + 15) // 16
-    stream = HL.write_headers(w, h, pic_init_qp=cfg.qp_p, num_ref=cfg.refs, t8x8=cfg.dct8x8)
+    stream = HL.write_headers(w, h, pic_init_qp=cfg.qp_p, num_ref=cfg.refs, t8x8=cfg.dct8x8, cabac=cabac)
     recons, skipped = [], 0
     for i, f in enumerate(frames):
         idr = i == 0
         mbs, lv = enc.encode(f, 2 if idr else 0)
         s, sk = HL.write_slice(mbw, mbh, 2 if idr else 0, cfg.qp_i if idr else cfg.qp_p, cfg.qp_p, i, 8, int(idr), 0,
-                               0 if cfg.deblock else 1, mbs, lv, num_ref=max(1, min(cfg.refs, i)), num_ref_default=cfg.refs, t8x8=cfg.dct8x8)
+                               0 if cfg.deblock else 1, mbs, lv, num_ref=max(1, min(cfg.refs, i)), num_ref_default=cfg.refs, t8x8=cfg.dct8x8, cabac=cabac)
         if cfg.refs > 1 and i >= 2:
             assert (mbs["ref"][mbs["type"] >= 4] >= 0).all()
         stream += s
@@ -204,9 +205,10 @@ def test_host_abi_exports_every_declared_symbol():
     assert not missing, f"declared but not exported: {missing}"
 
 
+@pytest.mark.parametrize("cabac", [0, 1])
 @pytest.mark.parametrize("seed", [21, 22, 23])
-def test_cavlc_closed_loop_random(seed):
-    """randomised closed loop on the CPU: oracle records -> host CAVLC -> checker decoder == oracle reconstruction, over random
+def test_entropy_closed_loop_random(seed, cabac):
+    """randomised closed loop on the CPU: oracle records -> host CAVLC / CABAC -> checker decoder == oracle reconstruction, over random
     sizes, quantisers 0..51 and toolset combinations (partitions, refs, 8x8 transform, Intra_8x8, dia/hex, deblock offsets)"""
     import random
     rnd = random.Random(seed)
@@ -222,13 +224,13 @@ def test_cavlc_closed_loop_random(seed):
         cfg = O.default_config(w, h, **kw)
         enc = O.OracleEncoder(cfg)
         mbw, mbh = (w + 15) // 16, (h + 15) // 16
-        stream = HL.write_headers(w, h, pic_init_qp=cfg.qp_p, cqo=cfg.chroma_qp_offset, num_ref=cfg.refs, t8x8=cfg.dct8x8)
+        stream = HL.write_headers(w, h, pic_init_qp=cfg.qp_p, cqo=cfg.chroma_qp_offset, num_ref=cfg.refs, t8x8=cfg.dct8x8, cabac=cabac)
         recons = []
         for i, f in enumerate(frames):
             idr = i == 0
             mbs, lv = enc.encode(f, 2 if idr else 0)
             stream += HL.write_slice(mbw, mbh, 2 if idr else 0, cfg.qp_i if idr else cfg.qp_p, cfg.qp_p, i, 8, int(idr), 0,
-                                     0 if cfg.deblock else 1, mbs, lv, num_ref=max(1, min(cfg.refs, i)), num_ref_default=cfg.refs, t8x8=cfg.dct8x8)[0]
+                                     0 if cfg.deblock else 1, mbs, lv, num_ref=max(1, min(cfg.refs, i)), num_ref_default=cfg.refs, t8x8=cfg.dct8x8, cabac=cabac)[0]
             recons.append(enc.recon())
         dec = O.h264_decode(stream, nfr, w, h)
         assert len(dec) == nfr, f"seed {seed} case {it}: {w}x{h} {kw}: decoder returned {len(dec)} pictures"
@@ -258,3 +260,12 @@ def test_row_band_parallel_cavlc_is_byte_identical(monkeypatch):
                 outs.append((nal, skipped))
             assert all(o == outs[0] for o in outs), f"{w}x{h} frame {i}"
         assert outs[0][1] > mbw                                # the repeated picture really is mostly skipped
+
+
+def test_cabac_context_tables_typed_twice_agree():
+    """the (m, n) context initialisation values exist twice, typed separately: per context index in the product's encoder
+    (x264vfw_amd/host/cabac_tables.hpp) and per syntax element in the checker decoder (oracle/cabac_dec.hpp); every context a 4:2:0
+    I / P stream uses must carry the same pair in both (typing errors; neither copy could be checked against the standard's text here)"""
+    import ctypes as C
+    O.L.x264o_cabac_tables_mismatches.restype = C.c_int
+    assert O.L.x264o_cabac_tables_mismatches() == 0

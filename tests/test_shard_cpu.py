@@ -14,6 +14,7 @@ import pytest
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 RUN = os.path.join(HERE, "stub", "run_host.py")
+subprocess.check_call(["make", "-s", "-C", os.path.join(HERE, "stub")])    # once, here: the child processes only load what it built
 
 
 def run_host(w, h, n, seed, opts, devices):

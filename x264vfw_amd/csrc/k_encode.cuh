@@ -79,23 +79,31 @@ __global__ __launch_bounds__(256) void k_apply_qp_offsets(EncK k, const int16_t 
 // stream walks the records 64 at a time (ballot of the macroblocks that keep their own value, highest one at or below each lane).
 __global__ __launch_bounds__(64) void k_settle_qp(EncK k)
 {
+    // every macroblock is a function of the previous one's settled qp: "mine" (it codes a delta), "the previous" (nothing coded), or
+    // "min(mine, previous)" (an I16x16 with nothing coded, DC included, never RAISES the quantiser: x264's qp_delta writers).  Those
+    // compose — (is_const, v) with previous == min(255, .) — so a wave scan settles 64 macroblocks per step
     const int lane = threadIdx.x, s = blockIdx.x;
     x264gpu_mb *mbs = k.mb + (size_t)s * k.nmb;
     int carry = slice_qp(k, s);
     for (int base = 0; base < k.nmb; base += 64) {
         const int i = base + lane;
         const bool in = i < k.nmb;
-        int qp = 0;
-        bool own = false;
-        if (in) { const x264gpu_mb *m = mbs + i; qp = m->qp; own = m->type == X264GPU_MB_I16x16 || m->cbp_luma || m->cbp_chroma; }
-        const unsigned long long owners = __ballot(own);
-        const unsigned long long below = owners & (lane == 63 ? ~0ull : ((2ull << lane) - 1));
-        const int src = below ? 63 - __builtin_clzll(below) : -1;
-        const int from = __shfl(qp, src < 0 ? 0 : src);
-        const int settled = src < 0 ? carry : from;
-        if (in && !own) mbs[i].qp = (uint8_t)settled;
-        const int last = min(k.nmb - base, 64) - 1;
-        carry = __shfl(settled, last);
+        int v = 255;
+        bool cst = false;
+        if (in) {
+            const x264gpu_mb *m = mbs + i;
+            const bool coded = m->cbp_luma || m->cbp_chroma;
+            if (m->type == X264GPU_MB_I16x16) { v = m->qp; cst = coded || ((m->nnz >> 24) & 1); }
+            else if (coded) { v = m->qp; cst = true; }
+        }
+        for (int d = 1; d < 64; d <<= 1) {
+            const int pv = __shfl_up(v, d);
+            const int pc = __shfl_up((int)cst, d);
+            if (lane >= d && !cst) { v = min(v, pv); cst = pc != 0; }
+        }
+        const int settled = cst ? v : min(v, carry);
+        if (in) mbs[i].qp = (uint8_t)settled;
+        carry = __shfl(settled, min(k.nmb - base, 64) - 1);
     }
 }
 

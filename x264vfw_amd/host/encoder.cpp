@@ -158,7 +158,7 @@ static SpsParams make_sps(const x264_t *h)
 }
 static PpsParams make_pps(const x264_t *h)
 {
-    PpsParams pp = { h->param.i_sps_id, h->param.i_sps_id, 0, h->param.i_frame_reference, h->pic_init_qp, h->param.analyse.i_chroma_qp_offset,
+    PpsParams pp = { h->param.i_sps_id, h->param.i_sps_id, h->param.b_cabac, h->param.i_frame_reference, h->pic_init_qp, h->param.analyse.i_chroma_qp_offset,
                      h->param.analyse.b_transform_8x8 };
     return pp;
 }
@@ -200,7 +200,8 @@ x264_t *x264_encoder_open(x264_param_t *param)
     if (p.i_frame_reference > 4) { xlog(&p, X264_LOG_INFO, "ref %d -> 4 (DPB of the MI355X path holds up to 4 references)\n", p.i_frame_reference); p.i_frame_reference = 4; }
     if (p.i_frame_reference < 1) p.i_frame_reference = 1;
     p.analyse.b_mixed_references = p.analyse.b_mixed_references && p.i_frame_reference > 1;      // x264 validate_parameters
-    if (p.b_cabac) { xlog(&p, X264_LOG_WARNING, "CABAC is not implemented yet: using CAVLC\n"); p.b_cabac = 0; }
+    p.b_cabac = p.b_cabac != 0;
+    if (p.b_cabac && p.i_cabac_init_idc != 0) { xlog(&p, X264_LOG_WARNING, "cabac-idc %d: only the context tables of cabac_init_idc 0 (x264's default) are in the MI355X path: cabac-idc 0\n", p.i_cabac_init_idc); p.i_cabac_init_idc = 0; }
     p.analyse.i_weighted_pred = X264_WEIGHTP_NONE; p.analyse.b_weighted_bipred = 0;
     p.analyse.b_transform_8x8 = p.analyse.b_transform_8x8 != 0;
     p.analyse.inter &= X264_ANALYSE_I4x4 | X264_ANALYSE_I8x8 | X264_ANALYSE_PSUB16x16; p.analyse.intra &= X264_ANALYSE_I4x4 | X264_ANALYSE_I8x8;
@@ -245,7 +246,7 @@ x264_t *x264_encoder_open(x264_param_t *param)
     h->qp_p = p.rc.i_qp_constant;
     h->qp_i = clampi((int)(h->qp_p - 6.0 * log2(p.rc.f_ip_factor > 0 ? p.rc.f_ip_factor : 1.0) + 0.5), 1, 51);
     h->pic_init_qp = h->crf || h->abr ? 26 : clampi(h->qp_p, 0, 51);          // CRF moves the slice quantiser both ways: centre the +-26 range of slice_qp_delta
-    h->profile_idc = p.analyse.b_transform_8x8 ? 100 : 66;        // High only for the 8x8 transform; everything else is Baseline-compatible
+    h->profile_idc = p.analyse.b_transform_8x8 ? 100 : p.b_cabac ? 77 : 66;        // High for the 8x8 transform, Main for CABAC alone, else Baseline-compatible
     h->level_idc = p.i_level_idc > 0 ? p.i_level_idc : pick_level(&p, h->nmb, p.i_frame_reference);
     p.i_level_idc = h->level_idc;
     h->log2_max_frame_num = 4;
@@ -501,7 +502,7 @@ static int code_position(x264_t *h, int batch, int t, int nslots_with_t)
         sp.num_ref = t < p.i_frame_reference ? (t > 0 ? t : 1) : p.i_frame_reference;
         sp.disable_deblock_idc = p.b_deblocking_filter ? 0 : 1;
         sp.alpha_off_div2 = p.i_deblocking_filter_alphac0; sp.beta_off_div2 = p.i_deblocking_filter_beta;
-        sp.transform8x8_mode = p.analyse.b_transform_8x8;
+        sp.transform8x8_mode = p.analyse.b_transform_8x8; sp.cabac = p.b_cabac;
         c.off.push_back(c.bytes.size()); c.types.push_back(c.idr ? 5 : 1);
         write_slice(c.bytes, sp, hmb + row * h->nmb, hlv + row * h->nmb * X264GPU_MB_LEVELS, p.b_annexb != 0, c.off.size() == 1, nullptr);
     };
@@ -742,7 +743,7 @@ static int encode_queued(x264_t *h, x264_nal_t **pp_nal, int *pi_nal, x264_pictu
     sp.num_ref = h->frames_since_idr < p.i_frame_reference ? (h->frames_since_idr > 0 ? h->frames_since_idr : 1) : p.i_frame_reference;
     sp.disable_deblock_idc = p.b_deblocking_filter ? 0 : 1;
     sp.alpha_off_div2 = p.i_deblocking_filter_alphac0; sp.beta_off_div2 = p.i_deblocking_filter_beta;
-    sp.transform8x8_mode = p.analyse.b_transform_8x8;
+    sp.transform8x8_mode = p.analyse.b_transform_8x8; sp.cabac = p.b_cabac;
     h->nal_off.push_back(h->out.size()); types.push_back(idr ? 5 : 1);
     h->last_stats.skip = 0;
     write_slice(h->out, sp, hmb, hlv, p.b_annexb != 0, h->nal_off.size() == 1, &h->last_stats, h->cavlc_threads);
@@ -895,17 +896,43 @@ int x264host_write_slice(int mbw, int mbh, int slice_type, int qp, int pic_init_
     return (int)v.size();
 }
 
+// the same through the CABAC writer (tests: records from the CPU checker -> bytes -> checker decoder)
+int x264host_write_slice_cabac(int mbw, int mbh, int slice_type, int qp, int pic_init_qp, int frame_num, int log2_max_frame_num,
+                               int idr, int idr_pic_id, int disable_deblock_idc, int num_ref, int num_ref_default, int transform8x8_mode,
+                               const x264gpu_mb *mbs, const int16_t *levels, uint8_t *out, int cap, int *skipped)
+{
+    SliceParams sp = {};
+    sp.mbw = mbw; sp.mbh = mbh; sp.slice_type = slice_type; sp.qp = qp; sp.pic_init_qp = pic_init_qp; sp.frame_num = frame_num;
+    sp.log2_max_frame_num = log2_max_frame_num; sp.idr = idr; sp.idr_pic_id = idr_pic_id; sp.nal_ref_idc = idr ? 3 : 2;
+    sp.num_ref = num_ref; sp.num_ref_default = num_ref_default;
+    sp.disable_deblock_idc = disable_deblock_idc; sp.transform8x8_mode = transform8x8_mode; sp.cabac = 1;
+    std::vector<uint8_t> v;
+    SliceStats stt = { 0 };
+    write_slice(v, sp, mbs, levels, true, true, &stt, 1);
+    if (skipped) *skipped = stt.skip;
+    if ((int)v.size() > cap) return -1;
+    memcpy(out, v.data(), v.size());
+    return (int)v.size();
+}
+
+int x264host_write_headers_cabac(int width, int height, int level_idc, int log2_max_frame_num, int pic_init_qp, int chroma_qp_offset,
+                                 uint32_t num_units_in_tick, uint32_t time_scale, int num_ref, int transform8x8_mode, int cabac, uint8_t *out, int cap);
 int x264host_write_headers(int width, int height, int level_idc, int log2_max_frame_num, int pic_init_qp, int chroma_qp_offset,
                            uint32_t num_units_in_tick, uint32_t time_scale, int num_ref, int transform8x8_mode, uint8_t *out, int cap)
 {
+    return x264host_write_headers_cabac(width, height, level_idc, log2_max_frame_num, pic_init_qp, chroma_qp_offset, num_units_in_tick, time_scale, num_ref, transform8x8_mode, 0, out, cap);
+}
+int x264host_write_headers_cabac(int width, int height, int level_idc, int log2_max_frame_num, int pic_init_qp, int chroma_qp_offset,
+                                 uint32_t num_units_in_tick, uint32_t time_scale, int num_ref, int transform8x8_mode, int cabac, uint8_t *out, int cap)
+{
     SpsParams s = {};
-    s.profile_idc = transform8x8_mode ? 100 : 66; s.level_idc = level_idc; s.mbw = (width + 15) / 16; s.mbh = (height + 15) / 16;
+    s.profile_idc = transform8x8_mode ? 100 : cabac ? 77 : 66; s.level_idc = level_idc; s.mbw = (width + 15) / 16; s.mbh = (height + 15) / 16;
     s.crop_right = s.mbw * 16 - width; s.crop_bottom = s.mbh * 16 - height; s.num_ref_frames = num_ref; s.log2_max_frame_num = log2_max_frame_num;
     s.fullrange = 0; s.colorprim = 2; s.transfer = 2; s.colmatrix = 2; s.vidformat = 5;
-    s.num_units_in_tick = num_units_in_tick; s.time_scale = time_scale; s.constraint_set0 = !transform8x8_mode; s.constraint_set1 = !transform8x8_mode;
+    s.num_units_in_tick = num_units_in_tick; s.time_scale = time_scale; s.constraint_set0 = !transform8x8_mode && !cabac; s.constraint_set1 = !transform8x8_mode;
     std::vector<uint8_t> v;
     write_sps(v, s, true);
-    PpsParams pp = { 0, 0, 0, num_ref, pic_init_qp, chroma_qp_offset, transform8x8_mode };
+    PpsParams pp = { 0, 0, cabac, num_ref, pic_init_qp, chroma_qp_offset, transform8x8_mode };
     write_pps(v, pp, true);
     if ((int)v.size() > cap) return -1;
     memcpy(out, v.data(), v.size());

@@ -18,6 +18,7 @@ struct SliceParams {
     int num_ref_default;     // PPS num_ref_idx_l0_default_active
     int disable_deblock_idc, alpha_off_div2, beta_off_div2;
     int transform8x8_mode;   // PPS transform_8x8_mode_flag
+    int cabac;               // PPS entropy_coding_mode_flag: CABAC slice data (cabac_init_idc 0), else CAVLC
 };
 struct SliceStats { int skip; };
 
@@ -38,6 +39,9 @@ void write_sei_version(std::vector<uint8_t> &out, const char *text, bool annexb)
 void write_slice_header(BitWriter &bw, const SliceParams &p);
 void write_slice(std::vector<uint8_t> &out, const SliceParams &p, const x264gpu_mb *mbs, const int16_t *levels,
                  bool annexb, bool long_startcode, SliceStats *stats, int threads = 1);
+// cabac.cpp: the same slice with CABAC slice data (write_slice dispatches on p.cabac)
+void write_slice_cabac(std::vector<uint8_t> &out, const SliceParams &p, const x264gpu_mb *mbs, const int16_t *levels,
+                       bool annexb, bool long_startcode, SliceStats *stats);
 
 // ---- file output (muxers.cpp): the reference's cli_output_t (output/output.h: open_file / set_param / write_headers / write_frame / close_file) ----
 class Muxer {

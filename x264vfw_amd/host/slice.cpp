@@ -326,6 +326,7 @@ void write_slice_header(BitWriter &bw, const SliceParams &p)
         if (p.idr) { bw.put1(0); bw.put1(0); }                  // no_output_of_prior_pics, long_term_reference
         else bw.put1(0);                                        // adaptive_ref_pic_marking_mode_flag
     }
+    if (p.cabac && p.slice_type != X264GPU_SLICE_I) bw.ue(0);   // cabac_init_idc
     bw.se(p.qp - p.pic_init_qp);                                // slice_qp_delta
     bw.ue(p.disable_deblock_idc);
     if (p.disable_deblock_idc != 1) { bw.se(p.alpha_off_div2); bw.se(p.beta_off_div2); }
@@ -337,6 +338,7 @@ void write_slice_header(BitWriter &bw, const SliceParams &p)
 void write_slice(std::vector<uint8_t> &out, const SliceParams &p, const x264gpu_mb *mbs, const int16_t *levels,
                  bool annexb, bool long_startcode, SliceStats *stats, int threads)
 {
+    if (p.cabac) { write_slice_cabac(out, p, mbs, levels, annexb, long_startcode, stats); return; }      // one arithmetic code word per slice: no row bands
     BitWriter bw;
     write_slice_header(bw, p);
     const size_t n = (size_t)p.mbw * p.mbh;
