@@ -292,7 +292,7 @@ def test_crf_follows_the_lookahead_complexity(gpu):
 def test_stream_headers_read_back_by_lsmash(gpu):
     """the stream of x264_encoder_encode (VfW mode: SPS/PPS before every keyframe) as read by L-SMASH, the parser the reference's
     mp4 muxer relies on (oracle/_ref, built from /root/reference/output/L-SMASH): VUI (sar, range, colour description, timing),
-    cropping, reference count, CAVLC, and every slice header"""
+    cropping, reference count, CABAC (High profile), and every slice header (cabac_init_idc included: the fields after it must line up)"""
     w, h, nfr = 208, 120, 7
     frames = synth_frames(w, h, nfr, seed=4)
     h_, eff = open_encoder(w, h, {"qp": 26, "keyint": 3, "no-scenecut": None, "ref": 2, "sar": "4:3", "fullrange": "1", "colorprim": "bt709", "transfer": "bt709",
@@ -304,7 +304,7 @@ def test_stream_headers_read_back_by_lsmash(gpu):
     assert (sps.sar_width, sps.sar_height, sps.video_full_range_flag) == (4, 3, 1)
     assert (sps.colour_primaries, sps.transfer_characteristics, sps.matrix_coefficients) == (1, 1, 1)
     assert (sps.num_units_in_tick, sps.time_scale) == (1001, 60000)
-    assert (pps.entropy_coding_mode_flag, pps.num_ref_idx_l0_default_active_minus1, pps.deblocking_filter_control_present_flag) == (0, 1, 1)
+    assert (pps.entropy_coding_mode_flag, pps.num_ref_idx_l0_default_active_minus1, pps.deblocking_filter_control_present_flag) == (1, 1, 1)
     assert [(s.nal_unit_type, s.slice_type, s.frame_num) for s in sl] == [(5, 2, 0) if i % 3 == 0 else (1, 0, i % 3) for i in range(nfr)]
     assert [s.idr_pic_id for s in sl if s.idr] == [0, 1, 2]
 

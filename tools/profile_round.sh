@@ -12,13 +12,13 @@ out=$root/gpurun_out/prof_$tag
 mkdir -p "$out"
 export TMPDIR=/tmp
 cd /tmp
-K="--steps 12 --warmup 2 --cpu-frames 0"
-P="--steps 4 --warmup 2 --cpu-frames 0"
+K="--steps 8 --warmup 2 --cpu-frames 0 --e2e-frames 0"
+P="--steps 8 --warmup 0 --cpu-frames 0 --e2e-frames 0"
 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/p_kt -- python3 $root/bench.py $K "$@" > $out/bench_under_rocprof.json 2> /tmp/p_kt.err
 cp $(ls /tmp/p_kt/*/*kernel_stats.csv | head -1) $out/kernel_stats_full.csv
 rocprofv3 --pmc FETCH_SIZE --kernel-include-regex "x264gpu" --output-format csv -d /tmp/p_rd -- python3 $root/bench.py $P "$@" > /tmp/p_rd.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --kernel-include-regex "x264gpu" --output-format csv -d /tmp/p_wr -- python3 $root/bench.py $P "$@" > /tmp/p_wr.log 2>&1
 rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_SALU --kernel-include-regex "x264gpu" --output-format csv -d /tmp/p_sq -- python3 $root/bench.py $P "$@" > /tmp/p_sq.log 2>&1
 rocprofv3 --pmc SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SMEM SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS --kernel-include-regex "x264gpu" --output-format csv -d /tmp/p_sq2 -- python3 $root/bench.py $P "$@" > /tmp/p_sq2.log 2>&1
-python3 $root/tools/profile_summarise.py $out /tmp/p_rd /tmp/p_wr /tmp/p_sq /tmp/p_sq2
+python3 $root/tools/profile_summarise.py $out /tmp/p_kt /tmp/p_rd /tmp/p_wr /tmp/p_sq /tmp/p_sq2
 ls -la $out

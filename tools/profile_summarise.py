@@ -2,24 +2,60 @@
 import collections, csv, glob, json, os, sys
 
 
-def fold(d):
+def fold(d, skip, keep):
+    """per kernel: counters summed over its launches `skip` .. `skip + keep - 1` (the timed pictures of bench.py: warmup launches and the
+    IDR probe at the end are left out, so the averages are over the same launches as bench.py's own event timing)"""
     fs = glob.glob(os.path.join(d, "*", "*counter_collection.csv"))
     agg = collections.defaultdict(lambda: collections.defaultdict(float))
     disp = collections.defaultdict(set)
     if not fs:
         return agg, disp
-    for r in csv.DictReader(open(fs[0])):
+    rows = list(csv.DictReader(open(fs[0])))
+    order = collections.defaultdict(list)
+    for r in rows:
         k = r["Kernel_Name"].split("(")[0].replace("void ", "")
+        i = int(r["Dispatch_Id"])
+        if i not in order[k]:
+            order[k].append(i)
+    window = {k: set(sorted(v)[skip:skip + keep]) if "k_csp" not in k else set(v) for k, v in order.items()}
+    for r in rows:
+        k = r["Kernel_Name"].split("(")[0].replace("void ", "")
+        if int(r["Dispatch_Id"]) not in window[k]:
+            continue
         agg[k][r["Counter_Name"]] += float(r["Counter_Value"])
         disp[k].add(r["Dispatch_Id"])
     return agg, disp
 
 
+def trace_window(d, skip, keep):
+    """average duration per kernel over the same window of launches, from the --kernel-trace CSV"""
+    fs = glob.glob(os.path.join(d, "*", "*kernel_trace.csv"))
+    if not fs:
+        return {}
+    per = collections.defaultdict(list)
+    for r in csv.DictReader(open(fs[0])):
+        per[r["Kernel_Name"].split("(")[0].replace("void ", "")].append((int(r["Start_Timestamp"]), int(r["End_Timestamp"])))
+    out = {}
+    for k, v in per.items():
+        v.sort()
+        w = v[skip:skip + keep] if "x264gpu" in k and "k_csp" not in k else v
+        if w:
+            out[k] = {"launches": len(w), "avg_ms": sum(e - s for s, e in w) / len(w) / 1e6, "all_launches": len(v), "avg_ms_all_launches": sum(e - s for s, e in v) / len(v) / 1e6}
+    return out
+
+
 def main():
     out = sys.argv[1]
     table = collections.defaultdict(dict)
-    for d in sys.argv[2:]:
-        agg, disp = fold(d)
+    try:
+        bj = json.loads(open(os.path.join(out, "bench_under_rocprof.json")).read().strip().split("\n")[-1])
+        skip, keep = bj["warmup"], bj["steps"]
+    except Exception:  # noqa: BLE001
+        skip, keep = 0, 1 << 30
+    kt = trace_window(sys.argv[2], skip, keep)
+    json.dump(kt, open(os.path.join(out, "kernel_trace_timed_window.json"), "w"), indent=1, sort_keys=True)
+    for d in sys.argv[3:]:
+        agg, disp = fold(d, skip, keep)
         for k, v in agg.items():
             n = max(len(disp[k]), 1)
             table[k].setdefault("launches_profiled", {})
@@ -35,13 +71,16 @@ def main():
         if "SQ_INSTS_VALU" in v and "SQ_WAVES" in v and v["SQ_WAVES"]:
             v["valu_per_wave"] = v["SQ_INSTS_VALU"] / v["SQ_WAVES"]
             v["cycles_per_wave"] = v["SQ_WAVE_CYCLES"] / v["SQ_WAVES"]
-    # frames one launch covers in the profiled command (bench.py default: streams / groups), so bench.py only quotes these
+    # streams (= frames) one launch covers in the profiled command, so bench.py only quotes these
     # figures for the same workload
     try:
         b = json.loads(open(os.path.join(out, "bench_under_rocprof.json")).read().strip().split("\n")[-1])
-        table["_workload"] = {"frames_per_launch": b["config"]["streams_per_gpu"] // b["config"]["stream_groups"], "config": b["config"]["workload"]}
+        table["_workload"] = {"streams_per_launch": b["config"]["streams_per_gpu"], "config": b["config"]["workload"], "toolset": b["config"]["toolset"]}
+        for k, v in table.items():
+            if not k.startswith("_"):
+                v["macroblocks_per_launch"] = b["config"]["streams_per_gpu"] * b["config"]["mb_per_frame"]
     except Exception as e:  # noqa: BLE001
-        table["_workload"] = {"frames_per_launch": None, "error": str(e)}
+        table["_workload"] = {"streams_per_launch": None, "error": str(e)}
     json.dump(table, open(os.path.join(out, "pmc_per_launch.json"), "w"), indent=1, sort_keys=True)
     for k, v in sorted(table.items()):
         if k.startswith("_"):
