@@ -1,0 +1,61 @@
+"""Where the macroblock loop's cycles go: phase counters of k_mb_slice (a -DMB_PROF build of the device library).
+
+    make -C x264vfw_amd/csrc clean && make -C x264vfw_amd/csrc -j8 EXTRA=-DMB_PROF && python tools/mb_prof.py [streams] [frames]
+
+Prints, per picture, the average cycles per macroblock of every phase (s_memtime deltas summed by lane 0 of each stream's wavefront).
+The timers perturb scheduling a little; use the table for proportions, bench.py for absolute time."""
+import ctypes as C
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+import bench  # noqa: E402
+from x264vfw_amd import lib  # noqa: E402
+from x264vfw_amd.lib import Config, MB_LEVELS  # noqa: E402
+
+PH = ["setup", "me_pred", "me_win", "me_fpel", "me_substage", "me_subpel", "me_glue", "pskip", "intra_chroma", "intra", "enc_inter", "enc_intra", "store",
+      "n_search", "n_refine", "n_stage"]
+
+
+def main():
+    S = int(sys.argv[1]) if len(sys.argv) > 1 else 2048
+    F = int(sys.argv[2]) if len(sys.argv) > 2 else 4
+    W = int(sys.argv[3]) if len(sys.argv) > 3 else 1920
+    H = int(sys.argv[4]) if len(sys.argv) > 4 else 1080
+    dev = torch.device("cuda:0")
+    args = type("A", (), dict(refs=3, preset="medium", aq=False))()
+    tools = bench.toolset(args)
+    D = min(S, 64)
+    base = bench.synth_batch(torch, D, F, W, H, 0x264, dev)
+    data = base if D == S else base.repeat(1, (S + D - 1) // D, 1)[:, :S].contiguous()
+    cfg = Config(width=W, height=H, streams=S, qp_i=20, qp_p=23, me_range=16, deblock_alpha=0, deblock_beta=0, chroma_qp_offset=0, deadzone_inter=21,
+                 deadzone_intra=11, dct_decimate=1, **tools)
+    h = C.c_void_p()
+    lib.check(lib.x264gpu_encoder_create(C.byref(h), C.byref(cfg)), "create")
+    n = lib.x264gpu_encoder_mb_count(h)
+    mbs = torch.empty((S, n, 64), dtype=torch.uint8, device=dev)
+    lvs = torch.empty((S, n, MB_LEVELS), dtype=torch.int16, device=dev)
+    f = lib._lib.x264gpu_encoder_mb_prof
+    f.restype = C.c_int
+    f.argtypes = [C.c_void_p, C.c_void_p]
+    out = np.zeros((S, 16), dtype=np.uint64)
+    print("%-4s %10s " % ("pic", "cyc/MB") + " ".join("%9s" % p[:9] for p in PH[:16]))
+    for i in range(F):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        lib.check(lib.x264gpu_encode_frames(h, data[i].data_ptr(), 2 if i == 0 else 0, mbs.data_ptr(), lvs.data_ptr(), torch.cuda.current_stream().cuda_stream), "encode")
+        e1.record()
+        torch.cuda.synchronize()
+        lib.check(f(h, out.ctypes.data), "mb_prof (is this an MB_PROF build?)")
+        a = out.astype(np.float64).mean(axis=0) / n
+        tot = a[:13].sum()
+        print("%-4s %10.0f " % ("I" if i == 0 else "P", tot) + " ".join("%9.0f" % v for v in a[:13]) + " %9.2f %9.2f %9.2f" % (a[13], a[14], a[15]) + "   %.1f ms" % e0.elapsed_time(e1))
+        mx = out[:, :13].sum(axis=1).astype(np.float64)
+        print("     slowest/mean stream cycles: %.3f   share: " % (mx.max() / mx.mean()) + " ".join("%8.1f%%" % (100 * v / tot) for v in a[:13]))
+
+
+if __name__ == "__main__":
+    main()

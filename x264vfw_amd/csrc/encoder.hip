@@ -39,6 +39,7 @@ struct x264gpu_encoder {
     const int16_t *lowres_mv = nullptr;
     int cur = 0;
     unsigned long long *dbg = nullptr;   // diagnostics buffer set by x264gpu_encoder_set_debug
+    unsigned long long *prof = nullptr;  // MB_PROF builds: phase counters of the last macroblock-loop launch
     int *wf_progress = nullptr;          // [streams][2][WFG_ROWS] row counters of the multi-workgroup wavefront kernels
     // adaptive quantisation: per-macroblock quantisers and the per-quantiser tables (built when aq_mode != 0)
     uint8_t *mbqp = nullptr;
@@ -135,6 +136,9 @@ int x264gpu_encoder_create(x264gpu_encoder **out, const x264gpu_config *cfg)
     }
     for (int r = 1; r < cfg->refs; r++) alloc((void **)&e->mvr[r], S * k.nmb * 2 * sizeof(int16_t), 0);
     alloc((void **)&e->wf_progress, S * 2 * WFG_ROWS * sizeof(int), 0);
+#ifdef MB_PROF
+    alloc((void **)&e->prof, S * 16 * sizeof(unsigned long long), 0);
+#endif
     if (er != hipSuccess) { x264gpu_encoder_destroy(e); return set_err(er == hipErrorOutOfMemory ? X264GPU_ENOMEM : X264GPU_EHIP, "encoder buffers", er); }
     const int rc = build_aq_tables(e);       // the macroblock loop reads every quantiser-dependent value per macroblock
     if (rc) { x264gpu_encoder_destroy(e); return rc; }
@@ -214,6 +218,7 @@ void x264gpu_encoder_destroy(x264gpu_encoder *e)
     (void)hipFree(e->fenc_y); (void)hipFree(e->fenc_uv);
     for (int i = 0; i < 5; i++) { (void)hipFree(e->luma[i]); (void)hipFree(e->chroma[i]); (void)hipFree(e->mv16[i]); (void)hipFree(e->mbtype[i]); (void)hipFree(e->mvr[i]); }
     (void)hipFree(e->wf_progress);
+    (void)hipFree(e->prof);
     (void)hipFree(e->stream_qp); (void)hipFree(e->mbqp); (void)hipFree(e->q4tab); (void)hipFree(e->q8tab); (void)hipFree(e->lambda_tab); (void)hipFree(e->cost_all);
     delete e;
 }
@@ -222,6 +227,16 @@ int x264gpu_encoder_mb_count(const x264gpu_encoder *e) { return e ? e->k.nmb : 0
 int x264gpu_encoder_set_debug(x264gpu_encoder *e, void *d_counters) { ARG_TRY(e); e->dbg = (unsigned long long *)d_counters; return X264GPU_OK; }
 int x264gpu_encoder_stage_count(void) { return (int)(sizeof(kStageNames) / sizeof(kStageNames[0])); }
 const char *x264gpu_encoder_stage_name(int i) { return i >= 0 && i < x264gpu_encoder_stage_count() ? kStageNames[i] : ""; }
+
+// MB_PROF builds (tools/mb_prof.py): the phase counters of the last macroblock-loop launch, [streams][16] cycle counts; not part of the ABI
+int x264gpu_encoder_mb_prof(x264gpu_encoder *e, unsigned long long *out)
+{
+    ARG_TRY(e && out);
+    if (!e->prof) return X264GPU_EINVAL;
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpy(out, e->prof, (size_t)e->cfg.streams * 16 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    return X264GPU_OK;
+}
 
 int x264gpu_encoder_set_lowres_mvs(x264gpu_encoder *e, const int16_t *d_mvs) { ARG_TRY(e); e->lowres_mv = d_mvs; return X264GPU_OK; }
 
@@ -257,6 +272,7 @@ int x264gpu_encode_frames(x264gpu_encoder *e, const uint8_t *d_i420, int slice_t
         for (int r = 0; r < k.nref; r++) k.tscale[r] = (e->poc - e->slot_poc[slot_of(r)]) * inv;
     }
     e->slot_nref[e->cur] = k.nref; e->slot_poc[e->cur] = e->poc; e->slot_ref0poc[e->cur] = k.nref ? e->slot_poc[s0] : 0;
+    k.prof = e->prof;
     k.lowres_mv = e->lowres_mv; k.fast_pskip = e->cfg.fast_pskip; k.mv_range = e->cfg.mv_range;
     k.mb = d_mb; k.levels = d_levels;
     k.qp = qp; k.lambda = lambda_of(qp); k.qpc = chroma_qp_of(qp, e->cfg.chroma_qp_offset);

@@ -23,8 +23,18 @@ constexpr int MB_COST_MAX = 1 << 28;
 enum { D_16x16 = 0, D_16x8 = 1, D_8x16 = 2, D_8x8 = 3 };
 enum { ME_16 = 0, ME_8 = 1, ME_16x8 = 5, ME_8x16 = 7, ME_COUNT = 9 };     // slots of the per-macroblock search results
 
+// Full-pel window cache (dia / hex): one slot per reference (slot = ref % 3), WC_ROWS x WC_COLS samples around the macroblock displaced
+// by the start vector of the first search that needed it; later searches of the macroblock on the same reference (8x8 / 16x8 / 8x16
+// blocks, other starts) reuse it when the samples they touch lie inside, and re-centre it when they do not.  esa uses the same
+// bytes as ONE +-17 window (WIN_ROWS x WIN_STRIDE); umh roams global memory.
+#ifndef MB_WC_ROWS
+#define MB_WC_ROWS 40
+#endif
+constexpr int WC_ROWS = MB_WC_ROWS, WC_COLS = 48, WC_STRIDE = 52, WC_BYTES = WC_ROWS * WC_STRIDE, WC_MARGIN = 12;
+struct WinTags { int ref0, x00, y00, ref1, x01, y01, ref2, x02, y02; };
+
 template <int M> struct MbLds {
-    __attribute__((aligned(16))) uint8_t win[WIN_ROWS * WIN_STRIDE];
+    __attribute__((aligned(16))) uint8_t win[3 * WC_BYTES > WIN_ROWS * WIN_STRIDE ? 3 * WC_BYTES : WIN_ROWS * WIN_STRIDE];
     uint32_t sub[SubGeo<M>::DWORDS];
     uint32_t csub[CSubGeo<M>::DWORDS];
     uint16_t cost[2][192];
@@ -39,13 +49,8 @@ template <int M> struct MbLds {
     uint8_t U8[U8_SIZE];
     uint8_t modes4[16], modes8[16], nmodes[8];
     __attribute__((aligned(16))) x264gpu_mb rec;   // the record being built (lane 0 fills it, 16 lanes store it)
-    // motion cache (h->mb.cache.ref / .mv at 8x8 granularity): grid x = -1..2, y = -1..1 -> index (y + 1) * 4 + x + 1
-    int cref[12]; int cmvx[12], cmvy[12];
     // search state
     int16_t cand[16][2];                       // filtered start candidates of the search in progress
-    int16_t mvc[5][5][2];                      // a->l0.mvc[ref][0] = 16x16 vector, [1..4] = 8x8 vectors
-    int mvc_in[10][2];                         // raw candidates of the search in progress
-    int me_mvx[ME_COUNT], me_mvy[ME_COUNT], me_mvpx[ME_COUNT], me_mvpy[ME_COUNT], me_cost[ME_COUNT], me_costmv[ME_COUNT], me_ref[ME_COUNT], me_refcost[ME_COUNT];
 };
 
 struct MbCtx {
@@ -58,8 +63,42 @@ struct MbCtx {
     int nref;
 };
 
+// Phase timers of the macroblock loop (builds with -DMB_PROF only: tools/mb_prof.py); otherwise empty
+enum { PH_SETUP, PH_ME_PRED, PH_ME_WIN, PH_ME_FPEL, PH_ME_SUBSTAGE, PH_ME_SUBPEL, PH_ME_GLUE, PH_PSKIP, PH_INTRA_CHROMA, PH_INTRA, PH_ENC_INTER, PH_ENC_INTRA, PH_STORE, PH_COUNT };
+#ifdef MB_PROF
+struct Prof {
+    unsigned long long t, acc[16];
+    __device__ __forceinline__ void start() { for (int i = 0; i < 16; i++) acc[i] = 0; t = __builtin_readcyclecounter(); }
+    __device__ __forceinline__ void mark(int i) { const unsigned long long n = __builtin_readcyclecounter(); acc[i] += n - t; t = n; }
+    __device__ __forceinline__ void count(int i) { acc[i]++; }
+};
+#else
+struct Prof {
+    __device__ __forceinline__ void start() {}
+    __device__ __forceinline__ void mark(int) {}
+    __device__ __forceinline__ void count(int) {}
+};
+#endif
+
 // a wave-uniform value the compiler cannot prove uniform (it came through LDS or a vector load): say so, it then lives in an SGPR
 __device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
+
+// Per-macroblock search state held in registers, one table entry per lane (every value is wave-uniform): reading entry i is a
+// v_readlane, writing it a select -- no LDS round trip.
+struct MeState {
+    int mvx, mvy, mvpx, mvpy, cost, costmv, ref, refcost;   // lane = slot of the search result (ME_COUNT)
+    int cref, cmvx, cmvy;                                   // lane = motion cache grid index: (y + 1) * 4 + x + 1, x = -1..2, y = -1..1
+    int mvcx, mvcy;                                         // lane = ref * 5 + q: a->l0.mvc[ref][0] = 16x16 vector, [1..4] = 8x8 vectors
+    int inx, iny;                                           // lane = raw candidate i of the search in progress
+};
+__device__ __forceinline__ int rl(int v, int i) { return __builtin_amdgcn_readlane(v, i); }
+__device__ __forceinline__ void wl(int &v, int lane, int i, int x) { v = lane == i ? x : v; }
+__device__ __forceinline__ void me_store(MeState &S, int lane, int slot, int mvx, int mvy, int cost, int cost_mv, int ref, int refcost, int mvpx, int mvpy)
+{
+    const bool m = lane == slot;
+    S.mvx = m ? mvx : S.mvx; S.mvy = m ? mvy : S.mvy; S.cost = m ? cost : S.cost; S.costmv = m ? cost_mv : S.costmv;
+    S.ref = m ? ref : S.ref; S.refcost = m ? refcost : S.refcost; S.mvpx = m ? mvpx : S.mvpx; S.mvpy = m ? mvpy : S.mvpy;
+}
 
 __device__ __forceinline__ void lds_sync()
 {
@@ -70,14 +109,13 @@ __device__ __forceinline__ void lds_sync()
 // ------------------------------------------------------------------------------------------------
 // motion vector prediction on the cache grid (oracle predict_mv / predict_mv_pskip)
 // ------------------------------------------------------------------------------------------------
-template <int M>
-__device__ __forceinline__ void mb_predict_mv(const MbLds<M> &L, int partition, int bx8, int by8, int w8, int ref, int &mvpx, int &mvpy)
+__device__ __forceinline__ void mb_predict_mv(const MeState &S, int partition, int bx8, int by8, int w8, int ref, int &mvpx, int &mvpy)
 {
     const int ia = (by8 + 1) * 4 + bx8, ib = by8 * 4 + bx8 + 1;
     int ic = by8 * 4 + bx8 + w8 + 1;
-    if (L.cref[ic] == -2) ic = by8 * 4 + bx8;
-    const int ra = uni(L.cref[ia]), rb = uni(L.cref[ib]), rc = uni(L.cref[ic]);
-    const int ax = uni(L.cmvx[ia]), ay = uni(L.cmvy[ia]), bx = uni(L.cmvx[ib]), by = uni(L.cmvy[ib]), cx = uni(L.cmvx[ic]), cy = uni(L.cmvy[ic]);
+    if (rl(S.cref, ic) == -2) ic = by8 * 4 + bx8;
+    const int ra = rl(S.cref, ia), rb = rl(S.cref, ib), rc = rl(S.cref, ic);
+    const int ax = rl(S.cmvx, ia), ay = rl(S.cmvy, ia), bx = rl(S.cmvx, ib), by = rl(S.cmvy, ib), cx = rl(S.cmvx, ic), cy = rl(S.cmvy, ic);
     if (partition == D_16x8) {
         if (by8 == 0) { if (rb == ref) { mvpx = bx; mvpy = by; return; } }
         else if (ra == ref) { mvpx = ax; mvpy = ay; return; }
@@ -127,8 +165,9 @@ __device__ __forceinline__ void mc_row_global(const uint8_t *__restrict__ p00, s
 }
 
 template <int M, int ME>
-__device__ __forceinline__ void me_search(const EncK &k, MbLds<M> &L, const MbCtx &c, const MeJob &j, int &mvx, int &mvy, int &cost, int &cost_mv, int &halfpel_thresh)
+__device__ __forceinline__ void me_search(const EncK &k, MbLds<M> &L, const MbCtx &c, const MeJob &j, int &mvx, int &mvy, int &cost, int &cost_mv, int &halfpel_thresh, const MeState &S, WinTags &wt, Prof &pf)
 {
+    pf.mark(PH_ME_GLUE);
     const int lane = c.lane, r = lane & 15, cnd = lane >> 4;
     const bool w16 = j.W == 16, rowok = r < j.H;
     const uint8_t *p00 = ref_plane00(k, c.s, j.ref);
@@ -150,6 +189,8 @@ __device__ __forceinline__ void me_search(const EncK &k, MbLds<M> &L, const MbCt
         return row16_sum(rowok ? (int)sd : 0);
     };
     const int fmin0 = c.fmin0, fmax0 = c.fmax0, fmin1 = c.fmin1, fmax1 = c.fmax1;
+    constexpr bool umh = ME == 2, cached = ME == 0 || ME == 1;
+    int cbx = 0, cby = 0;                      // centre of the LDS slices of the mv-cost table (dia / hex / esa searches)
 
     if (j.search) {
         int bmx, bmy, bcost, bpred_cost = MB_COST_MAX, bpred_mx = 0, bpred_my = 0, pmx, pmy;
@@ -158,26 +199,118 @@ __device__ __forceinline__ void me_search(const EncK &k, MbLds<M> &L, const MbCt
         int pmvx, pmvy;
         if (sub3) { pmvx = clampi(j.mvpx, fmin0 * 4, fmax0 * 4); pmvy = clampi(j.mvpy, fmin1 * 4, fmax1 * 4); pmx = (pmvx + 2) >> 2; pmy = (pmvy + 2) >> 2; }
         else { pmx = clampi((j.mvpx + 2) >> 2, fmin0, fmax0); pmy = clampi((j.mvpy + 2) >> 2, fmin1, fmax1); pmvx = pmx * 4; pmvy = pmy * 4; }
-        int n = 1;
-        if (lane == 0) { L.cand[0][0] = (int16_t)pmvx; L.cand[0][1] = (int16_t)pmvy; }
-        for (int i = 0; i < j.n_mvc; i++) {
-            int mx = L.mvc_in[i][0], my = L.mvc_in[i][1];
-            bool drop;
-            if (sub3) { drop = !(mx | my) || (mx == pmvx && my == pmvy); mx = clampi(mx, fmin0 * 4, fmax0 * 4); my = clampi(my, fmin1 * 4, fmax1 * 4); }
-            else { mx = clampi((mx + 2) >> 2, fmin0, fmax0); my = clampi((my + 2) >> 2, fmin1, fmax1); drop = !(mx | my) || (mx == pmx && my == pmy); mx *= 4; my *= 4; }
-            if (!drop) { if (lane == 0) { L.cand[n][0] = (int16_t)mx; L.cand[n][1] = (int16_t)my; } n++; }
+        // lane i filters raw candidate i as x264 does (zero and the predictor itself are not tried again); a candidate equal to an earlier one
+        // (or, after clipping, to the predictor) cannot beat it under "first strictly better wins" and is not costed twice
+        int n;
+        {
+            int mx = 0, my = 0;
+            bool keep = false;
+            if (lane < j.n_mvc) {
+                mx = S.inx; my = S.iny;
+                if (sub3) { keep = (mx | my) && !(mx == pmvx && my == pmvy); mx = clampi(mx, fmin0 * 4, fmax0 * 4); my = clampi(my, fmin1 * 4, fmax1 * 4); }
+                else { mx = clampi((mx + 2) >> 2, fmin0, fmax0); my = clampi((my + 2) >> 2, fmin1, fmax1); keep = (mx | my) && !(mx == pmx && my == pmy); mx *= 4; my *= 4; }
+            }
+            const int pk = (mx << 16) | (my & 0xffff);
+            if (pk == ((pmvx << 16) | (pmvy & 0xffff))) keep = false;
+            const unsigned long long km0 = __ballot(keep);
+            for (int t = 0; t + 1 < j.n_mvc; t++)
+                if ((km0 >> t) & 1) { const int o = __builtin_amdgcn_readlane(pk, t); if (lane > t && pk == o) keep = false; }
+            const unsigned long long km = __ballot(keep);
+            const int rank = __builtin_popcountll(km & ((1ull << lane) - 1));
+            if (keep) { L.cand[1 + rank][0] = (int16_t)mx; L.cand[1 + rank][1] = (int16_t)my; }
+            if (lane == 0) { L.cand[0][0] = (int16_t)pmvx; L.cand[0][1] = (int16_t)pmvy; }
+            n = 1 + __builtin_popcountll(km);
         }
         lds_sync();
+        // ---- windows.  dia / hex: window cache + LDS slices of the mv-cost table; esa: one +-17 window around the start; umh roams up to
+        //      ~1.5 x merange from the start: reference rows and costs come from global memory ----
+        int i_me_range = k.me_range;
+        cbx = pmx * 4; cby = pmy * 4;
+        const int slot = j.ref >= 3 ? j.ref - 3 : j.ref;
+        uint8_t *wbase = L.win + (cached ? slot * WC_BYTES : 0);
+        const int wstride = cached ? WC_STRIDE : WIN_STRIDE;
+        int wx0 = 0, wy0 = 0;
+        bool whave = false;
+        if (cached) {
+            const int tr = slot == 0 ? wt.ref0 : slot == 1 ? wt.ref1 : wt.ref2;
+            wx0 = slot == 0 ? wt.x00 : slot == 1 ? wt.x01 : wt.x02; wy0 = slot == 0 ? wt.y00 : slot == 1 ? wt.y01 : wt.y02;
+            whave = tr == j.ref;
+        }
+        // are the samples of this block displaced by (mx +- rad, my +- rad) inside the window?
+        auto inside = [&](int mx, int my, int rad) {
+            return whave && bx + mx - rad >= wx0 && bx + mx + rad + j.W <= wx0 + WC_COLS && by + my - rad >= wy0 && by + my + rad + j.H <= wy0 + WC_ROWS;
+        };
+        // (re-)centre this reference's slot on the macroblock displaced by (mx, my): requests, then (after other work) the copy into LDS
+        auto win_issue = [&](int mx, int my, uint2 v[4]) {
+            wx0 = clampi((c.px + mx - WC_MARGIN) & ~7, -PAD, k.cw + PAD - WC_COLS); wy0 = clampi(c.py + my - WC_MARGIN, -PAD, k.ch + PAD - WC_ROWS);
+#pragma unroll
+            for (int t = 0; t < 4; t++) {
+                const int i = lane + 64 * t, row = (i * 171) >> 10, col = (i - row * 6) * 8;     // i / 6 for i < 256
+                v[t] = make_uint2(0u, 0u);
+                if (i < WC_ROWS * 6) v[t] = *(const uint2 *)(p00 + (long)(wy0 + row) * k.rs + wx0 + col);
+            }
+        };
+        auto win_commit = [&](const uint2 v[4]) {
+            lds_sync();
+#pragma unroll
+            for (int t = 0; t < 4; t++) {
+                const int i = lane + 64 * t, row = (i * 171) >> 10, col = (i - row * 6) * 8;
+                if (i < WC_ROWS * 6) { uint32_t *d = (uint32_t *)(wbase + row * WC_STRIDE + col); d[0] = v[t].x; d[1] = v[t].y; }
+            }
+            whave = true;
+            pf.count(15);
+            if (slot == 0) { wt.ref0 = j.ref; wt.x00 = wx0; wt.y00 = wy0; } else if (slot == 1) { wt.ref1 = j.ref; wt.x01 = wx0; wt.y01 = wy0; } else { wt.ref2 = j.ref; wt.x02 = wx0; wt.y02 = wy0; }
+            lds_sync();
+        };
+        auto stage_cached = [&](int mx, int my) { uint2 v[4]; win_issue(mx, my, v); win_commit(v); };
+        auto stage_costs = [&](int qx, int qy) {
+            cbx = qx; cby = qy;
+            lds_sync();
+            for (int i = lane; i < 192; i += 64) { L.cost[0][i] = cmx[cbx + i - 96]; L.cost[1][i] = cmy[cby + i - 96]; }
+            lds_sync();
+        };
+
+        // ---- the start candidates.  One trip to memory: the window around the predictor (if this reference's slot does not hold it yet), the
+        //      cost slices around the predictor, and the rows of up to 12 candidates are all requested before the first result is used ----
         unsigned key = 0xffffffffu;
         int pmv_cost = 0;
-        for (int b0 = 0; b0 < n; b0 += 4) {
-            const int i = b0 + cnd, ii = i < n ? i : 0;
-            const int qx = L.cand[ii][0], qy = L.cand[ii][1];
-            int cst = sad_global(qx, qy);
-            if (sub3 || ii > 0) cst += cmx[qx] + cmy[qy];            // below subme 3 the rounded predictor is costed without its vector bits
-            const unsigned kk = i < n ? ((unsigned)cst << 4) | (unsigned)i : 0xffffffffu;
-            if (b0 == 0) pmv_cost = __builtin_amdgcn_readlane(cst, 0);
-            key = min(key, wave_min_u32(kk));
+        {
+            const bool pre = cached && !inside(pmx, pmy, 2);
+            uint2 wv[4];
+            uint16_t cv[2][3];
+            if (pre) { whave = false; win_issue(pmx, pmy, wv); }
+            if (cached) {
+#pragma unroll
+                for (int t = 0; t < 3; t++) { cv[0][t] = cmx[cbx + lane + 64 * t - 96]; cv[1][t] = cmy[cby + lane + 64 * t - 96]; }
+            }
+            uint32_t pp[3][4];
+            int cm[3];
+#pragma unroll
+            for (int t = 0; t < 3; t++) {
+                pp[t][0] = pp[t][1] = pp[t][2] = pp[t][3] = 0; cm[t] = 0;
+                if (t * 4 < n) {
+                    const int i = t * 4 + cnd, ii = i < n ? i : 0;
+                    const int qx = L.cand[ii][0], qy = L.cand[ii][1];
+                    mc_row_global(p00, pb, k.rs, bx, by + r, qx, qy, w16, pp[t]);
+                    cm[t] = (sub3 || ii > 0) ? (int)cmx[qx] + (int)cmy[qy] : 0;       // below subme 3 the rounded predictor is costed without its vector bits
+                }
+            }
+#pragma unroll
+            for (int t = 0; t < 3; t++)
+                if (t * 4 < n) {
+                    const int i = t * 4 + cnd;
+                    unsigned sd = __builtin_amdgcn_sad_u8(pp[t][0], e[0], 0u);
+                    sd = __builtin_amdgcn_sad_u8(pp[t][1], e[1], sd); sd = __builtin_amdgcn_sad_u8(pp[t][2], e[2], sd); sd = __builtin_amdgcn_sad_u8(pp[t][3], e[3], sd);
+                    const int cst = row16_sum(rowok ? (int)sd : 0) + cm[t];
+                    const unsigned kk = i < n ? ((unsigned)cst << 4) | (unsigned)i : 0xffffffffu;
+                    if (t == 0) pmv_cost = __builtin_amdgcn_readlane(cst, 0);
+                    key = min(key, wave_min_u32(kk));
+                }
+            if (pre) win_commit(wv);
+            if (cached) {
+#pragma unroll
+                for (int t = 0; t < 3; t++) { L.cost[0][lane + 64 * t] = cv[0][t]; L.cost[1][lane + 64 * t] = cv[1][t]; }
+            }
         }
         {
             const int bi = key & 15;
@@ -185,10 +318,42 @@ __device__ __forceinline__ void me_search(const EncK &k, MbLds<M> &L, const MbCt
         }
         const bool pmv_nonzero = (pmvx | pmvy) != 0;
         bmx = (bpred_mx + 2) >> 2; bmy = (bpred_my + 2) >> 2;
-        {   // the rounded best predictor and the zero vector, both from global memory: groups 0 and 1
-            const int qx = cnd == 0 ? bmx * 4 : 0, qy = cnd == 0 ? bmy * 4 : 0;
-            const int cst = sad_global(qx, qy) + cmx[qx] + cmy[qy];
-            const int c_round = __builtin_amdgcn_readlane(cst, 0), c_zero = __builtin_amdgcn_readlane(cst, 16);
+        bmx = __builtin_amdgcn_readfirstlane(bmx); bmy = __builtin_amdgcn_readfirstlane(bmy);
+        lds_sync();
+        pf.mark(PH_ME_PRED);
+        if (cached) {
+            if (!inside(bmx, bmy, 2)) stage_cached(bmx, bmy);                                  // a far candidate won
+            if (abs(bmx * 4 - cbx) > 20 || abs(bmy * 4 - cby) > 20) stage_costs(bmx * 4, bmy * 4);
+        }
+        pf.mark(PH_ME_WIN);
+#define MVC(qx, qy) (umh ? (int)cmx[qx] + (int)cmy[qy] : (int)L.cost[0][(qx) - cbx + 96] + (int)L.cost[1][(qy) - cby + 96])
+        auto fpel = [&](int mx, int my) {       // full-pel candidate cost (valid after the row sum)
+            if (umh) return sad_global(mx * 4, my * 4) + (int)cmx[mx * 4] + (int)cmy[my * 4];
+            const uint8_t *wrow = wbase + (by + my + r - wy0) * wstride;
+            const int xo = bx + mx - wx0;
+            int sd = 0;
+            if (rowok) sd = w16 ? sad_row16_lds(wrow, xo, e) : sad8_lds(wrow, xo, e[0], e[1]);
+            return row16_sum(sd) + MVC(mx * 4, my * 4);
+        };
+        // the window follows a search that walks out of it (dia / hex; the cost slices reach +-24 around their centre: merange <= 16)
+        auto ensure = [&](int mx, int my, int rad) { if (cached && !inside(mx, my, rad)) stage_cached(mx, my); };
+        {   // the rounded best predictor and the zero vector: groups 0 and 1
+            int c_round, c_zero;
+            if (!cached) {
+                const int qx = cnd == 0 ? bmx * 4 : 0, qy = cnd == 0 ? bmy * 4 : 0;
+                const int cst = sad_global(qx, qy) + cmx[qx] + cmy[qy];
+                c_round = __builtin_amdgcn_readlane(cst, 0); c_zero = __builtin_amdgcn_readlane(cst, 16);
+            } else {
+                const bool zlds = inside(0, 0, 0) && abs(cbx) < 96 && abs(cby) < 96;
+                int cst;
+                if (zlds) cst = fpel(cnd == 0 ? bmx : 0, cnd == 0 ? bmy : 0);
+                else {
+                    cst = fpel(bmx, bmy);
+                    const int z = sad_global(0, 0) + cmx[0] + cmy[0];
+                    if (cnd == 1) cst = z;
+                }
+                c_round = __builtin_amdgcn_readlane(cst, 0); c_zero = __builtin_amdgcn_readlane(cst, 16);
+            }
             if (sub3) {
                 bcost = ((bpred_mx | bpred_my) & 3) ? c_round : bpred_cost;
                 if (pmv_nonzero) { if ((bmx | bmy) && c_zero < bcost) { bcost = c_zero; bmx = 0; bmy = 0; } }
@@ -199,32 +364,17 @@ __device__ __forceinline__ void me_search(const EncK &k, MbLds<M> &L, const MbCt
             }
         }
         bmx = __builtin_amdgcn_readfirstlane(bmx); bmy = __builtin_amdgcn_readfirstlane(bmy);
-
-        // ---- full-pel search.  dia / hex / esa stay within WIN_R of the start: LDS window + LDS slices of the mv-cost table.  umh roams up to
-        //      ~1.5 x merange from the start: reference rows and costs come from global memory (L2-resident) ----
-        constexpr bool umh = ME == 2;
-        int i_me_range = k.me_range;
-        int wx0 = clampi((bx + bmx - WIN_R) & ~7, -PAD, k.cw + PAD - WIN_COLS), wy0 = clampi(by + bmy - WIN_R, -PAD, k.ch + PAD - WIN_ROWS);
-        const int cbx = bmx * 4, cby = bmy * 4;
-        if (!umh) {
+        if (ME == 3) {      // esa: its window around the start
+            lds_sync();
+            wx0 = clampi((bx + bmx - WIN_R) & ~7, -PAD, k.cw + PAD - WIN_COLS); wy0 = clampi(by + bmy - WIN_R, -PAD, k.ch + PAD - WIN_ROWS);
             for (int i = lane; i < WIN_ROWS * 8; i += 64) {
                 const int row = i >> 3, col = (i & 7) * 8;
                 const uint2 v = *(const uint2 *)(p00 + (long)(wy0 + row) * k.rs + wx0 + col);
                 uint32_t *d = (uint32_t *)(L.win + row * WIN_STRIDE + col);
                 d[0] = v.x; d[1] = v.y;
             }
-            for (int i = lane; i < 192; i += 64) { L.cost[0][i] = cmx[cbx + i - 96]; L.cost[1][i] = cmy[cby + i - 96]; }
         }
-        lds_sync();
-#define MVC(qx, qy) (umh ? (int)cmx[qx] + (int)cmy[qy] : (int)L.cost[0][(qx) - cbx + 96] + (int)L.cost[1][(qy) - cby + 96])
-        auto fpel = [&](int mx, int my) {       // full-pel candidate cost (valid after the row sum)
-            if (umh) return sad_global(mx * 4, my * 4) + (int)cmx[mx * 4] + (int)cmy[my * 4];
-            const uint8_t *wrow = L.win + (by + my + r - wy0) * WIN_STRIDE;
-            const int xo = bx + mx - wx0;
-            int sd = 0;
-            if (rowok) sd = w16 ? sad_row16_lds(wrow, xo, e) : sad8_lds(wrow, xo, e[0], e[1]);
-            return row16_sum(sd) + MVC(mx * 4, my * 4);
-        };
+        if (ME == 3 || (cached && (abs(bmx * 4 - cbx) > 20 || abs(bmy * 4 - cby) > 20))) stage_costs(bmx * 4, bmy * 4);       // the zero vector won far away
         bool hexrefine = true;
         if (umh) {
             // X264_ME_UMH (oracle me_search_ref case 2): four candidates per step, in-order "strictly better wins" = min of (cost << 2 | order)
@@ -277,11 +427,11 @@ __device__ __forceinline__ void me_search(const EncK &k, MbLds<M> &L, const MbCt
                 if (j.n_mvc) {      // adaptive search range: agreement of the predictors x SAD level
                     int mvd, denom = 1;
                     const bool is16 = w16 && j.H == 16;
-                    if (j.n_mvc == 1) mvd = is16 ? 25 : abs(j.mvpx - L.mvc_in[0][0]) + abs(j.mvpy - L.mvc_in[0][1]);
+                    if (j.n_mvc == 1) mvd = is16 ? 25 : abs(j.mvpx - rl(S.inx, 0)) + abs(j.mvpy - rl(S.iny, 0));
                     else {
                         denom = j.n_mvc - 1; mvd = 0;
-                        if (!is16) { mvd = abs(j.mvpx - L.mvc_in[0][0]) + abs(j.mvpy - L.mvc_in[0][1]); denom++; }
-                        for (int i = 0; i < j.n_mvc - 1; i++) mvd += abs(L.mvc_in[i][0] - L.mvc_in[i + 1][0]) + abs(L.mvc_in[i][1] - L.mvc_in[i + 1][1]);
+                        if (!is16) { mvd = abs(j.mvpx - rl(S.inx, 0)) + abs(j.mvpy - rl(S.iny, 0)); denom++; }
+                        for (int i = 0; i < j.n_mvc - 1; i++) mvd += abs(rl(S.inx, i) - rl(S.inx, i + 1)) + abs(rl(S.iny, i) - rl(S.iny, i + 1));
                     }
                     const int sad_ctx = UMH_TH(1000) ? 0 : UMH_TH(2000) ? 1 : UMH_TH(4000) ? 2 : 3;
                     const int mvd_ctx = mvd < 10 * denom ? 0 : mvd < 20 * denom ? 1 : mvd < 40 * denom ? 2 : 3;
@@ -325,6 +475,7 @@ __device__ __forceinline__ void me_search(const EncK &k, MbLds<M> &L, const MbCt
             // X264_ME_DIA: the four neighbours are the four lane groups; the centre wins ties
             int it = k.me_range;
             do {
+                ensure(bmx, bmy, 1);
                 const unsigned kk = wave_min_u32(((unsigned)fpel(bmx + (cnd == 2 ? -1 : cnd == 3 ? 1 : 0), bmy + (cnd == 0 ? -1 : cnd == 1 ? 1 : 0)) << 2) | (unsigned)cnd);
                 if ((int)(kk >> 2) >= bcost) break;
                 const int q = kk & 3;
@@ -334,6 +485,7 @@ __device__ __forceinline__ void me_search(const EncK &k, MbLds<M> &L, const MbCt
         } else if (hexrefine) {
             // X264_ME_HEX (and the tail of umh): hexagon, then square refine
             unsigned hk = (unsigned)bcost << 3;
+            ensure(bmx, bmy, 2);
             {
                 int i = 1 + cnd;
                 unsigned kk = ((unsigned)fpel(bmx + hex_dx(i), bmy + hex_dy(i)) << 3) | (unsigned)(i + 1);
@@ -348,6 +500,7 @@ __device__ __forceinline__ void me_search(const EncK &k, MbLds<M> &L, const MbCt
                 bmx += hex_dx(dir + 1); bmy += hex_dy(dir + 1);
                 for (int it = (i_me_range >> 1) - 1; it > 0 && bmx >= fmin0 && bmx <= fmax0 && bmy >= fmin1 && bmy <= fmax1; it--) {
                     hk &= ~7u;
+                    ensure(bmx, bmy, 2);
                     const int cc = cnd < 3 ? cnd : 0;
                     unsigned kk = ((unsigned)fpel(bmx + hex_dx(dir + cc), bmy + hex_dy(dir + cc)) << 3) | (unsigned)(cc + 1);
                     if (cnd >= 3) kk = 0xffffffffu;
@@ -360,6 +513,7 @@ __device__ __forceinline__ void me_search(const EncK &k, MbLds<M> &L, const MbCt
             }
             bcost = (int)(hk >> 3);
             unsigned sk = (unsigned)bcost << 4;
+            ensure(bmx, bmy, 1);
             {
                 int q = 1 + cnd;
                 sk = min(sk, wave_min_u32(((unsigned)fpel(bmx + sq_dx(q), bmy + sq_dy(q)) << 4) | (unsigned)q));
@@ -375,11 +529,15 @@ __device__ __forceinline__ void me_search(const EncK &k, MbLds<M> &L, const MbCt
             cost = bcost;
             if (bmx == pmx && bmy == pmy) cost += MVC(bmx * 4, bmy * 4);        // the real cost of the predictor
             mvx = bmx * 4; mvy = bmy * 4;
-        } else if (bpred_cost < bcost) { mvx = bpred_mx; mvy = bpred_my; cost = bpred_cost; }
-        else { mvx = bmx * 4; mvy = bmy * 4; cost = bcost; }
-#undef MVC
+        } else if (bpred_cost < bcost) {
+            mvx = bpred_mx; mvy = bpred_my; cost = bpred_cost;
+            // the best predictor after a search that started at the zero vector far from it: the sub-pel steps need the costs around IT
+            if (!umh && (abs(mvx - cbx) > 64 || abs(mvy - cby) > 64)) stage_costs(((mvx + 2) >> 2) * 4, ((mvy + 2) >> 2) * 4);
+        } else { mvx = bmx * 4; mvy = bmy * 4; cost = bcost; }
         mvx = __builtin_amdgcn_readfirstlane(mvx); mvy = __builtin_amdgcn_readfirstlane(mvy);
-        cost_mv = cmx[mvx] + cmy[mvy];
+        cost_mv = MVC(mvx, mvy);
+#undef MVC
+        pf.mark(PH_ME_FPEL);
         if (c.subme < 2) return;
     }
 
@@ -414,7 +572,11 @@ __device__ __forceinline__ void me_search(const EncK &k, MbLds<M> &L, const MbCt
         chroma_stage(cb, ref_chroma00(k, c.s, j.ref), k.rs, cx0c, cy0c, cndw, cnr, lane, 64);
     }
     lds_sync();
+    pf.mark(PH_ME_SUBSTAGE);
     const s16x2 sg1 = pk_sign(lane & 1), sg2 = pk_sign(lane & 2);
+    // vector bits: the search's LDS slices reach every sub-pel position around its full-pel result; a refinement-only call reads the table
+    const bool lcost = !umh && j.search;
+    auto mvc2 = [&](int qx, int qy) { return lcost ? (int)L.cost[0][qx - cbx + 96] + (int)L.cost[1][qy - cby + 96] : (int)cmx[qx] + (int)cmy[qy]; };
     auto fetch2 = [&](int qx, int qy, uint32_t p[4]) {
         p[0] = p[1] = p[2] = p[3] = 0;
         if (rowok) {
@@ -427,13 +589,13 @@ __device__ __forceinline__ void me_search(const EncK &k, MbLds<M> &L, const MbCt
         fetch2(qx, qy, p);
         unsigned sd = __builtin_amdgcn_sad_u8(p[0], e[0], 0u);
         sd = __builtin_amdgcn_sad_u8(p[1], e[1], sd); sd = __builtin_amdgcn_sad_u8(p[2], e[2], sd); sd = __builtin_amdgcn_sad_u8(p[3], e[3], sd);
-        return row16_sum(rowok ? (int)sd : 0) + cmx[qx] + cmy[qy];
+        return row16_sum(rowok ? (int)sd : 0) + mvc2(qx, qy);
     };
     auto cmp2 = [&](int qx, int qy) {           // mbcmp (SATD above subme 1) + vector bits, without chroma
         if (!c.satd) return sad2(qx, qy);
         uint32_t p[4];
         fetch2(qx, qy, p);
-        return row16_sum(satd16x4_half_pk(e, p, sg1, sg2)) + cmx[qx] + cmy[qy];
+        return row16_sum(satd16x4_half_pk(e, p, sg1, sg2)) + mvc2(qx, qy);
     };
     auto chroma2 = [&](int qx, int qy) {
         const int h = cact ? chroma_me_lds(cb, cndw, cx0c, cy0c, (c.px >> 1) + ccx, (c.py >> 1) + ccy, qx, qy, ce0, ce1, sg1, sg2) : 0;
@@ -453,7 +615,7 @@ __device__ __forceinline__ void me_search(const EncK &k, MbLds<M> &L, const MbCt
         if (chroma_me) bcost += __builtin_amdgcn_readlane(chroma2(bmx, bmy), 0);
     }
     if (j.use_thresh) {
-        if (((bcost * 7) >> 3) > halfpel_thresh) { mvx = bmx; mvy = bmy; cost = bcost; return; }
+        if (((bcost * 7) >> 3) > halfpel_thresh) { mvx = bmx; mvy = bmy; cost = bcost; pf.mark(PH_ME_SUBPEL); return; }
         else if (bcost < halfpel_thresh) halfpel_thresh = bcost;
     }
     if (c.subme != 1) {
@@ -481,7 +643,8 @@ __device__ __forceinline__ void me_search(const EncK &k, MbLds<M> &L, const MbCt
         }
     }
     mvx = __builtin_amdgcn_readfirstlane(bmx); mvy = __builtin_amdgcn_readfirstlane(bmy); cost = bcost;
-    cost_mv = cmx[mvx] + cmy[mvy];
+    cost_mv = mvc2(mvx, mvy);
+    pf.mark(PH_ME_SUBPEL);
 }
 
 
@@ -627,7 +790,7 @@ __device__ __forceinline__ void mb_analyse_intra(const EncK &k, MbLds<M> &L, con
             pred8_row8(L.U8, L.pred8tab, 8, r8, p2lo, p2hi);
             const int c2 = cost8(p2lo, p2hi);
             int bm;
-            const int best = pick_intra_mode([&](int m) { return uni(m < 8 ? __shfl(c1, m * 8) : __shfl(c2, 0)); }, avail, pm, lambda, false, bm);
+            const int best = pick_intra_mode([&](int m) { return m < 8 ? rl(c1, m * 8) : rl(c2, 0); }, avail, pm, lambda, false, bm);
             i_cost += best + 3 * lambda;
             if (lane < 4) L.modes8[idx * 4 + lane] = (uint8_t)bm;
             if (idx < 3 && i_cost > thresh) break;
@@ -690,7 +853,7 @@ __device__ __forceinline__ void mb_analyse_intra(const EncK &k, MbLds<M> &L, con
             const uint32_t en = (uint32_t)__shfl((int)cz, idx * 4 + j);
             const int sat = quad_sum(c.satd ? satd4_half(en, pr, lane) : sad4(en, pr));
             int bm;
-            const int best = pick_intra_mode([&](int m) { return uni(__shfl(sat, m * 4)); }, avail, pm, lambda, true, bm);
+            const int best = pick_intra_mode([&](int m) { return rl(sat, m * 4); }, avail, pm, lambda, true, bm);
             i_cost += best + 3 * lambda;
             if (lane == 0) L.modes4[idx] = (uint8_t)bm;
             if (idx < 15 && i_cost > thresh) break;
@@ -922,8 +1085,11 @@ __device__ __forceinline__ bool mb_probe_pskip(const EncK &k, const MbCtx &c, ui
 // ------------------------------------------------------------------------------------------------
 // M: sub-pel neighbourhood margin (2 px up to subme 7, 5 above); ME: --me method (its own instantiation each: the roaming umh / esa code
 // costs the hexagon kernel registers otherwise)
+#ifndef MB_WAVES_PER_EU
+#define MB_WAVES_PER_EU 2
+#endif
 template <int M, int ME>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 4))) void k_mb_slice(EncK k)
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(MB_WAVES_PER_EU, 4))) void k_mb_slice(EncK k)
 {
     __shared__ __attribute__((aligned(16))) MbLds<M> L;
     const int lane = threadIdx.x, s = blockIdx.x;
@@ -934,6 +1100,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 4))) void
     const bool pslice = k.slice_type == X264GPU_SLICE_P;
     const int j4 = lane & 3, zx = z_x0(lane), zy = z_y(lane);
     int intra_count = 0;
+    Prof pf;
+    pf.start();
     int16_t *mv16 = k.mv16_cur + (size_t)s * k.nmb * 2;
     uint8_t *mbtype_cur = k.mbtype_cur + (size_t)s * k.nmb;
 
@@ -990,6 +1158,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 4))) void
             }
         }
         // ---- motion cache: neighbours' references / vectors at 8x8 granularity; this macroblock's blocks start unavailable ----
+        MeState S = {};
         if (lane < 12) {
             const int gx = (lane & 3) - 1, gy = (lane >> 2) - 1;
             int ref = -2, vx = 0, vy = 0, nbi = -1, blk = 0;
@@ -1003,7 +1172,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 4))) void
                 if (n->type <= 3) ref = -1;
                 else { ref = n->ref[blk]; vx = n->mv[blk][0]; vy = n->mv[blk][1]; }
             }
-            L.cref[lane] = ref; L.cmvx[lane] = vx; L.cmvy[lane] = vy;
+            S.cref = ref; S.cmvx = vx; S.cmvy = vy;
         }
         const uint32_t cz = *(const uint32_t *)(c.fenc + (size_t)zy * k.fs + zx);
         lds_sync();
@@ -1019,6 +1188,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 4))) void
         bool pskip = false;
         int pskx = 0, psky = 0, best_part = D_16x16;
         bool fast_intra = false;
+        pf.mark(PH_SETUP);
 
         if (pslice) {
             // ---- limits ----
@@ -1034,9 +1204,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 4))) void
                 fast_intra = !(intra_t(type_left) || intra_t(type_top) || intra_t(type_tl) || intra_t(type_tr) || intra_t(colo) || mbi < 3 * intra_count);
             }
             {
-                const int ra = uni(L.cref[4]), rb = uni(L.cref[1]);
-                if (ra == -2 || rb == -2 || (ra == 0 && !uni(L.cmvx[4] | L.cmvy[4])) || (rb == 0 && !uni(L.cmvx[1] | L.cmvy[1]))) pskx = psky = 0;
-                else mb_predict_mv(L, D_16x16, 0, 0, 2, 0, pskx, psky);
+                const int ra = rl(S.cref, 4), rb = rl(S.cref, 1);
+                if (ra == -2 || rb == -2 || (ra == 0 && !(rl(S.cmvx, 4) | rl(S.cmvy, 4))) || (rb == 0 && !(rl(S.cmvx, 1) | rl(S.cmvy, 1)))) pskx = psky = 0;
+                else mb_predict_mv(S, D_16x16, 0, 0, 2, 0, pskx, psky);
             }
             bool try_skip = false;
             if (k.fast_pskip) {
@@ -1044,6 +1214,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 4))) void
                 else if (type_left == X264GPU_MB_P_SKIP || type_top == X264GPU_MB_P_SKIP || type_tl == X264GPU_MB_P_SKIP || type_tr == X264GPU_MB_P_SKIP)
                     pskip = mb_probe_pskip(k, c, cz, pskx, psky, q_lp, q_cp);
             }
+            pf.mark(PH_PSKIP);
             if (pskip) {
                 if (lane == 0) { mv16[2 * mbi] = 0; mv16[2 * mbi + 1] = 0; }
                 if (lane >= 1 && lane < c.nref) { int16_t *m = k.mvr[lane] + ((size_t)s * k.nmb + mbi) * 2; m[0] = 0; m[1] = 0; }
@@ -1056,20 +1227,22 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 4))) void
             int cost8x8 = 0, est1 = 0;
             int sat8[4] = { 0, 0, 0, 0 };
             bool done = pskip;
-            if (lane == 0) L.me_cost[ME_16] = 0x7fffffff;
+            WinTags wt;
+            wt.ref0 = wt.ref1 = wt.ref2 = -1; wt.x00 = wt.x01 = wt.x02 = wt.y00 = wt.y01 = wt.y02 = 0;
+            wl(S.cost, lane, ME_16, 0x7fffffff);
             i_cost = 0x7fffffff;
             // a 16x8 / 8x16 half: candidate references = those of its two 8x8 blocks (lower index first); before the first half also the
             // cost estimate of the second one and an empty cache for this macroblock's blocks
             auto setup_half = [&](int st, int pt) {
                 lds_sync();
                 const int b0 = st == 2 ? 2 * pt : pt, b1 = st == 2 ? 2 * pt + 1 : pt + 2;
-                const int r0 = uni(L.me_ref[ME_8 + b0]), r1 = uni(L.me_ref[ME_8 + b1]);
+                const int r0 = rl(S.ref, ME_8 + b0), r1 = rl(S.ref, ME_8 + b1);
                 ref_a = min(r0, r1); ref_b = max(r0, r1); nk = ref_a == ref_b ? 1 : 2;
                 if (pt == 0) {
                     const int o0 = st == 2 ? 2 : 1;
-                    const int avg = (uni(L.me_costmv[ME_8 + o0]) + uni(L.me_refcost[ME_8 + o0]) + uni(L.me_costmv[ME_8 + 3]) + uni(L.me_refcost[ME_8 + 3]) + 1) >> 1;
+                    const int avg = (rl(S.costmv, ME_8 + o0) + rl(S.refcost, ME_8 + o0) + rl(S.costmv, ME_8 + 3) + rl(S.refcost, ME_8 + 3) + 1) >> 1;
                     est1 = (st == 2 ? sat8[2] : sat8[1]) + sat8[3] + avg;
-                    if (lane == 5 || lane == 6 || lane == 9 || lane == 10) L.cref[lane] = -2;
+                    if (lane == 5 || lane == 6 || lane == 9 || lane == 10) S.cref = -2;
                 }
             };
             while (!done) {
@@ -1080,7 +1253,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 4))) void
                 if (stage == 0) {
                     r = kk; slot = ME_16;
                     jb.W = 16; jb.H = 16; jb.ox = 0; jb.oy = 0;
-                    mb_predict_mv(L, D_16x16, 0, 0, 2, r, jb.mvpx, jb.mvpy);
+                    mb_predict_mv(S, D_16x16, 0, 0, 2, r, jb.mvpx, jb.mvpy);
                     // candidates (oracle predict_mv_ref16x16): lookahead vector, 16x16 results of the left / top / top-left / top-right macroblocks
                     // in this reference, co-located vectors of reference 0 scaled by the POC distances
                     {
@@ -1089,16 +1262,22 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 4))) void
                         const bool has_lr = r == 0 && k.lowres_mv && (k.lowres_mv + (size_t)s * k.nmb * 2)[0] != 0x7fff;
                         const int base = has_lr ? 1 : 0;
                         const bool t1 = k.temporal && mbx < k.mbw - 1, t2 = k.temporal && mby < k.mbh - 1;
-                        if (lane == 0 && has_lr) { const int16_t *lm = k.lowres_mv + (size_t)s * k.nmb * 2; L.mvc_in[0][0] = lm[2 * mbi] * 2; L.mvc_in[0][1] = lm[2 * mbi + 1] * 2; }
-                        if (lane < 4) {
-                            const int nb = lane == 0 ? (left ? mbi - 1 : -1) : lane == 1 ? (top ? mbi - k.mbw : -1) : lane == 2 ? (topleft ? mbi - k.mbw - 1 : -1) : (topright ? mbi - k.mbw + 1 : -1);
-                            L.mvc_in[base + lane][0] = nb >= 0 ? mvr[2 * nb] : 0; L.mvc_in[base + lane][1] = nb >= 0 ? mvr[2 * nb + 1] : 0;
-                        } else if (lane < 7 && k.temporal) {
+                        // lane i fetches raw candidate i
+                        const int q = lane - base;
+                        int vx = 0, vy = 0;
+                        if (has_lr && lane == 0) { const int16_t *lm = k.lowres_mv + (size_t)s * k.nmb * 2; vx = lm[2 * mbi] * 2; vy = lm[2 * mbi + 1] * 2; }
+                        else if (q >= 0 && q < 4) {
+                            const int nb = q == 0 ? (left ? mbi - 1 : -1) : q == 1 ? (top ? mbi - k.mbw : -1) : q == 2 ? (topleft ? mbi - k.mbw - 1 : -1) : (topright ? mbi - k.mbw + 1 : -1);
+                            if (nb >= 0) { vx = mvr[2 * nb]; vy = mvr[2 * nb + 1]; }
+                        } else if (q >= 4 && q < 7 && k.temporal) {
+                            // co-located; then its right neighbour (if there is one), then its lower neighbour (if there is one)
                             const int16_t *l0 = k.mv16_ref0 + (size_t)s * k.nmb * 2;
-                            const int scale = k.tscale[r], q = lane - 4;
-                            const int at = q == 0 ? mbi : q == 1 ? mbi + 1 : mbi + k.mbw, slot = base + 4 + (q == 0 ? 0 : q == 1 ? 1 : (t1 ? 2 : 1));
-                            if (q == 0 || (q == 1 && t1) || (q == 2 && t2)) { L.mvc_in[slot][0] = (l0[2 * at] * scale + 128) >> 8; L.mvc_in[slot][1] = (l0[2 * at + 1] * scale + 128) >> 8; }
+                            const int scale = k.tscale[r], jx = q - 4;
+                            const bool ok = jx == 0 || (jx == 1 && (t1 || t2)) || (jx == 2 && t1 && t2);
+                            const int at = jx == 0 ? mbi : (jx == 1 && t1) ? mbi + 1 : mbi + k.mbw;
+                            if (ok) { vx = (l0[2 * at] * scale + 128) >> 8; vy = (l0[2 * at + 1] * scale + 128) >> 8; }
                         }
+                        S.inx = vx; S.iny = vy;
                         jb.n_mvc = base + 4 + (k.temporal ? 1 + (t1 ? 1 : 0) + (t2 ? 1 : 0) : 0);
                     }
                     lds_sync();
@@ -1106,31 +1285,31 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 4))) void
                     jb.hp_it = c.subme >= 2 ? (c.subme < 6 ? 1 : c.subme < 8 ? 2 : 4) : 0;
                     jb.qp_it = c.subme < 4 ? 0 : c.subme == 4 ? 1 : c.subme < 8 ? 2 : 10;
                 } else if (stage == 1) {
-                    r = mixed ? kk : uni(L.me_ref[ME_16]); slot = ME_8 + part;
+                    r = mixed ? kk : rl(S.ref, ME_16); slot = ME_8 + part;
                     jb.W = 8; jb.H = 8; jb.ox = 8 * (part & 1); jb.oy = 8 * (part >> 1);
-                    mb_predict_mv(L, D_8x8, part & 1, part >> 1, 1, r, jb.mvpx, jb.mvpy);
-                    if (lane <= part) { L.mvc_in[lane][0] = L.mvc[r][lane][0]; L.mvc_in[lane][1] = L.mvc[r][lane][1]; }
+                    mb_predict_mv(S, D_8x8, part & 1, part >> 1, 1, r, jb.mvpx, jb.mvpy);
+                    { const int q = r * 5 + min(lane, 4); S.inx = __shfl(S.mvcx, q); S.iny = __shfl(S.mvcy, q); }        // lane i <- mvc[r][i], i <= part
                     jb.n_mvc = part + 1;
                 } else if (stage == 2) {
                     r = kk == 0 ? ref_a : ref_b; slot = ME_16x8 + part;
                     jb.W = 16; jb.H = 8; jb.ox = 0; jb.oy = 8 * part;
-                    mb_predict_mv(L, D_16x8, 0, part, 2, r, jb.mvpx, jb.mvpy);
-                    if (lane < 3) { const int q = lane == 0 ? 0 : 2 * part + lane; L.mvc_in[lane][0] = L.mvc[r][q][0]; L.mvc_in[lane][1] = L.mvc[r][q][1]; }
+                    mb_predict_mv(S, D_16x8, 0, part, 2, r, jb.mvpx, jb.mvpy);
+                    { const int q = r * 5 + (lane == 0 ? 0 : lane < 3 ? 2 * part + lane : 0); S.inx = __shfl(S.mvcx, q); S.iny = __shfl(S.mvcy, q); }
                     jb.n_mvc = 3;
                 } else if (stage == 3) {
                     r = kk == 0 ? ref_a : ref_b; slot = ME_8x16 + part;
                     jb.W = 8; jb.H = 16; jb.ox = 8 * part; jb.oy = 0;
-                    mb_predict_mv(L, D_8x16, part, 0, 1, r, jb.mvpx, jb.mvpy);
-                    if (lane < 3) { const int q = lane == 0 ? 0 : lane == 1 ? part + 1 : part + 3; L.mvc_in[lane][0] = L.mvc[r][q][0]; L.mvc_in[lane][1] = L.mvc[r][q][1]; }
+                    mb_predict_mv(S, D_8x16, part, 0, 1, r, jb.mvpx, jb.mvpy);
+                    { const int q = r * 5 + (lane == 0 ? 0 : lane == 1 ? part + 1 : lane == 2 ? part + 3 : 0); S.inx = __shfl(S.mvcx, q); S.iny = __shfl(S.mvcy, q); }
                     jb.n_mvc = 3;
                 } else {
                     // x264_me_refine_qpel of the winner's blocks
                     slot = best_part == D_16x16 ? ME_16 : best_part == D_16x8 ? ME_16x8 + part : best_part == D_8x16 ? ME_8x16 + part : ME_8 + part;
-                    r = uni(L.me_ref[slot]);
+                    r = rl(S.ref, slot);
                     jb.W = best_part == D_16x16 || best_part == D_16x8 ? 16 : 8; jb.H = best_part == D_16x16 || best_part == D_8x16 ? 16 : 8;
                     jb.ox = best_part == D_8x16 ? 8 * part : best_part == D_8x8 ? 8 * (part & 1) : 0;
                     jb.oy = best_part == D_16x8 ? 8 * part : best_part == D_8x8 ? 8 * (part >> 1) : 0;
-                    jb.mvpx = uni(L.me_mvpx[slot]); jb.mvpy = uni(L.me_mvpy[slot]);
+                    jb.mvpx = rl(S.mvpx, slot); jb.mvpy = rl(S.mvpy, slot);
                     jb.hp_it = c.subme == 1 ? 1 : 0;
                     jb.qp_it = c.subme == 1 ? 1 : c.subme >= 2 && c.subme <= 5 ? (c.subme == 2 ? 1 : 2) : 0;
                 }
@@ -1143,94 +1322,80 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 4))) void
                 const int rc = ref_bits(c.nref, r) * c.lambda;
                 int mvx = 0, mvy = 0, cost = 0, cost_mv = 0;
                 if (stage == 0) halfpel_thresh -= rc;
-                if (stage == 4) { mvx = uni(L.me_mvx[slot]); mvy = uni(L.me_mvy[slot]); cost = uni(L.me_cost[slot]) - uni(L.me_refcost[slot]); cost_mv = uni(L.me_costmv[slot]); }
-                me_search<M, ME>(k, L, c, jb, mvx, mvy, cost, cost_mv, halfpel_thresh);
+                if (stage == 4) { mvx = rl(S.mvx, slot); mvy = rl(S.mvy, slot); cost = rl(S.cost, slot) - rl(S.refcost, slot); cost_mv = rl(S.costmv, slot); }
+                me_search<M, ME>(k, L, c, jb, mvx, mvy, cost, cost_mv, halfpel_thresh, S, wt, pf);
+                pf.count(13 + (stage == 4));
                 lds_sync();
                 // ---- merge / advance ----
                 if (stage == 0) {
                     if (lane == 0) {
                         int16_t *mo = (r == 0 ? k.mv16_cur : k.mvr[r]) + ((size_t)s * k.nmb + mbi) * 2;
                         mo[0] = (int16_t)mvx; mo[1] = (int16_t)mvy;
-                        L.mvc[r][0][0] = (int16_t)mvx; L.mvc[r][0][1] = (int16_t)mvy;
                     }
+                    wl(S.mvcx, lane, r * 5, mvx); wl(S.mvcy, lane, r * 5, mvy);
                     if (r == 0 && try_skip && cost - cost_mv < 300 * c.lambda && abs(mvx - pskx) + abs(mvy - psky) <= 1 && mb_probe_pskip(k, c, cz, pskx, psky, q_lp, q_cp)) {
                         pskip = true; done = true;
                         if (lane >= 1 && lane < c.nref) { int16_t *m = k.mvr[lane] + ((size_t)s * k.nmb + mbi) * 2; m[0] = 0; m[1] = 0; }
                         continue;
                     }
                     cost += rc; halfpel_thresh += rc;
-                    if (cost < uni(L.me_cost[ME_16]) && lane == 0) {
-                        L.me_mvx[ME_16] = mvx; L.me_mvy[ME_16] = mvy; L.me_cost[ME_16] = cost; L.me_costmv[ME_16] = cost_mv; L.me_ref[ME_16] = r; L.me_refcost[ME_16] = rc;
-                        L.me_mvpx[ME_16] = jb.mvpx; L.me_mvpy[ME_16] = jb.mvpy;
-                    }
-                    lds_sync();
+                    if (cost < rl(S.cost, ME_16)) me_store(S, lane, ME_16, mvx, mvy, cost, cost_mv, r, rc, jb.mvpx, jb.mvpy);
                     if (++kk < nk) continue;
                     // 16x16 done
-                    i_cost = uni(L.me_cost[ME_16]); best_part = D_16x16;
+                    i_cost = rl(S.cost, ME_16); best_part = D_16x16;
                     if (!psub16) { stage = 4; part = 0; if (!c.subme) done = true; continue; }
                     stage = 1; part = 0; kk = 0;
                     i_maxref = c.nref - 1;
                     if (mixed) {
-                        if (early_term && i_maxref > 0 && uni(L.me_ref[ME_16]) == 0 && type_top > 0 && type_left > 0) {
-                            i_maxref = max(max(max(uni(L.cref[0]), uni(L.cref[1])), max(uni(L.cref[2]), uni(L.cref[3]))), max(max(uni(L.cref[4]), uni(L.cref[8])), 0));
+                        if (early_term && i_maxref > 0 && rl(S.ref, ME_16) == 0 && type_top > 0 && type_left > 0) {
+                            i_maxref = max(max(max(rl(S.cref, 0), rl(S.cref, 1)), max(rl(S.cref, 2), rl(S.cref, 3))), max(max(rl(S.cref, 4), rl(S.cref, 8)), 0));
                         }
                         nk = i_maxref + 1;
                     } else nk = 1;
-                    if (lane == 5 || lane == 6 || lane == 9 || lane == 10) L.cref[lane] = -2;      // this macroblock's blocks: not decided yet
-                    if (lane == 0) { L.me_cost[ME_8] = 0x7fffffff; }
+                    if (lane == 5 || lane == 6 || lane == 9 || lane == 10) S.cref = -2;      // this macroblock's blocks: not decided yet
+                    wl(S.cost, lane, ME_8, 0x7fffffff);
                     continue;
                 }
                 if (stage == 1) {
                     const int rcost = mixed ? rc : (r ? rc : 0);
                     cost += rcost;
-                    if (lane == 0) {
-                        L.mvc[r][part + 1][0] = (int16_t)mvx; L.mvc[r][part + 1][1] = (int16_t)mvy;
-                        if (kk == 0 || cost < uni(L.me_cost[slot])) {
-                            L.me_mvx[slot] = mvx; L.me_mvy[slot] = mvy; L.me_cost[slot] = cost; L.me_costmv[slot] = cost_mv; L.me_ref[slot] = r; L.me_refcost[slot] = rcost;
-                            L.me_mvpx[slot] = jb.mvpx; L.me_mvpy[slot] = jb.mvpy;
-                        }
-                    }
-                    lds_sync();
+                    wl(S.mvcx, lane, r * 5 + part + 1, mvx); wl(S.mvcy, lane, r * 5 + part + 1, mvy);
+                    if (kk == 0 || cost < rl(S.cost, slot)) me_store(S, lane, slot, mvx, mvy, cost, cost_mv, r, rcost, jb.mvpx, jb.mvpy);
                     if (++kk < nk) continue;
                     // block done: into the cache, cost bookkeeping
                     {
                         const int g = ((part >> 1) + 1) * 4 + (part & 1) + 1;
-                        if (lane == 0) { L.cref[g] = uni(L.me_ref[slot]); L.cmvx[g] = uni(L.me_mvx[slot]); L.cmvy[g] = uni(L.me_mvy[slot]); }
-                        const int sv = uni(L.me_cost[slot]) - (uni(L.me_costmv[slot]) + uni(L.me_refcost[slot]));
+                        wl(S.cref, lane, g, rl(S.ref, slot)); wl(S.cmvx, lane, g, rl(S.mvx, slot)); wl(S.cmvy, lane, g, rl(S.mvy, slot));
+                        const int sv = rl(S.cost, slot) - (rl(S.costmv, slot) + rl(S.refcost, slot));
                         if (part == 0) sat8[0] = sv; else if (part == 1) sat8[1] = sv; else if (part == 2) sat8[2] = sv; else sat8[3] = sv;
-                        lds_sync();
-                        if (lane == 0) L.me_cost[slot] += c.lambda;       // sub-macroblock type (CAVLC)
-                        lds_sync();
+                        S.cost += lane == slot ? c.lambda : 0;            // sub-macroblock type (CAVLC)
                     }
                     kk = 0;
                     if (++part < 4) continue;
-                    cost8x8 = uni(L.me_cost[ME_8]) + uni(L.me_cost[ME_8 + 1]) + uni(L.me_cost[ME_8 + 2]) + uni(L.me_cost[ME_8 + 3]);
-                    if (mixed && !(uni(L.me_ref[ME_8]) | uni(L.me_ref[ME_8 + 1]) | uni(L.me_ref[ME_8 + 2]) | uni(L.me_ref[ME_8 + 3]))) cost8x8 -= ref_bits(c.nref, 0) * c.lambda * 4;
-                    const int c16 = uni(L.me_cost[ME_16]);
+                    cost8x8 = rl(S.cost, ME_8) + rl(S.cost, ME_8 + 1) + rl(S.cost, ME_8 + 2) + rl(S.cost, ME_8 + 3);
+                    if (mixed && !(rl(S.ref, ME_8) | rl(S.ref, ME_8 + 1) | rl(S.ref, ME_8 + 2) | rl(S.ref, ME_8 + 3))) cost8x8 -= ref_bits(c.nref, 0) * c.lambda * 4;
+                    const int c16 = rl(S.cost, ME_16);
                     if (!early_term || cost8x8 < c16) { best_part = D_8x8; i_cost = cost8x8; }
-                    const int th = uni(L.me_costmv[ME_8 + 1]) + uni(L.me_costmv[ME_8 + 2]);
+                    const int th = rl(S.costmv, ME_8 + 1) + rl(S.costmv, ME_8 + 2);
                     if (!early_term || cost8x8 < c16 + th) { stage = 2; part = 0; kk = 0; setup_half(2, 0); }
                     else { stage = 4; part = 0; if (!c.subme) done = true; }
                     continue;
                 }
                 if (stage == 2 || stage == 3) {
                     cost += rc;
-                    if (lane == 0 && (kk == 0 || cost < uni(L.me_cost[slot]))) {
-                        L.me_mvx[slot] = mvx; L.me_mvy[slot] = mvy; L.me_cost[slot] = cost; L.me_costmv[slot] = cost_mv; L.me_ref[slot] = r; L.me_refcost[slot] = rc;
-                        L.me_mvpx[slot] = jb.mvpx; L.me_mvpy[slot] = jb.mvpy;
-                    }
-                    lds_sync();
+                    if (kk == 0 || cost < rl(S.cost, slot)) me_store(S, lane, slot, mvx, mvy, cost, cost_mv, r, rc, jb.mvpx, jb.mvpy);
                     if (++kk < nk) continue;
                     // this half is done; early termination on the first half plus the estimate of the second
-                    bool shape_done = part == 0 && early_term && uni(L.me_cost[slot]) + est1 > i_cost;
+                    bool shape_done = part == 0 && early_term && rl(S.cost, slot) + est1 > i_cost;
                     if (!shape_done) {
-                        if (lane == 0) {
+                        {
                             const int g0 = stage == 2 ? (part + 1) * 4 + 1 : 5 + part, g1 = stage == 2 ? g0 + 1 : g0 + 4;
-                            L.cref[g0] = L.cref[g1] = uni(L.me_ref[slot]); L.cmvx[g0] = L.cmvx[g1] = uni(L.me_mvx[slot]); L.cmvy[g0] = L.cmvy[g1] = uni(L.me_mvy[slot]);
+                            const bool m = lane == g0 || lane == g1;
+                            const int fr = rl(S.ref, slot), fx = rl(S.mvx, slot), fy = rl(S.mvy, slot);
+                            S.cref = m ? fr : S.cref; S.cmvx = m ? fx : S.cmvx; S.cmvy = m ? fy : S.cmvy;
                         }
-                        lds_sync();
                         if (part == 0) { part = 1; kk = 0; setup_half(stage, 1); continue; }
-                        const int total = uni(L.me_cost[slot - 1]) + uni(L.me_cost[slot]);
+                        const int total = rl(S.cost, slot - 1) + rl(S.cost, slot);
                         if (total < i_cost) { i_cost = total; best_part = stage == 2 ? D_16x8 : D_8x16; }
                     }
                     if (stage == 2) { stage = 3; part = 0; kk = 0; setup_half(3, 0); }
@@ -1238,16 +1403,15 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 4))) void
                     continue;
                 }
                 // stage 4: refinement results
-                if (lane == 0) { L.me_mvx[slot] = mvx; L.me_mvy[slot] = mvy; L.me_cost[slot] = cost; L.me_costmv[slot] = cost_mv; }
-                lds_sync();
+                wl(S.mvx, lane, slot, mvx); wl(S.mvy, lane, slot, mvy); wl(S.cost, lane, slot, cost); wl(S.costmv, lane, slot, cost_mv);
                 const int np = best_part == D_16x16 ? 1 : best_part == D_8x8 ? 4 : 2;
                 if (++part < np) continue;
                 i_cost = 0;
-                for (int i = 0; i < np; i++) i_cost += uni(L.me_cost[(best_part == D_16x16 ? ME_16 : best_part == D_16x8 ? ME_16x8 : best_part == D_8x16 ? ME_8x16 : ME_8) + i]);
+                for (int i = 0; i < np; i++) i_cost += rl(S.cost, (best_part == D_16x16 ? ME_16 : best_part == D_16x8 ? ME_16x8 : best_part == D_8x16 ? ME_8x16 : ME_8) + i);
                 done = true;
             }
             lds_sync();
-
+            pf.mark(PH_ME_GLUE);
         }
         // ---- intra analysis (P slices: against the inter cost; chroma-ME decides the chroma mode first and carries its cost) ----
         if (!pskip) {
@@ -1255,10 +1419,11 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 4))) void
             // the chroma mode depends on the neighbours only: decided here for every macroblock that is analysed (x264 does it here under chroma-ME,
             // otherwise only for macroblocks that end up intra — same mode either way); its cost enters the comparison under chroma-ME only
             satd_chroma = mb_intra_chroma_cost(k, L, c, predc);
+            pf.mark(PH_INTRA_CHROMA);
             mb_analyse_intra(k, L, c, cz, t4, parts, c.chroma_me ? i_satd_inter - satd_chroma : i_satd_inter, fast_intra, early_term, q_li, q8i, IR);
             if (c.chroma_me) { IR.satd_i16 += satd_chroma; IR.satd_i8 += satd_chroma; IR.satd_i4 += satd_chroma; }
             if (pslice) {
-                if (lane == 0) { recd.aux[0] = i_satd_inter; recd.aux[1] = min(min(IR.satd_i16, IR.satd_i8), IR.satd_i4); recd.aux[2] = uni(L.me_cost[ME_16]); }
+                if (lane == 0) { recd.aux[0] = i_satd_inter; recd.aux[1] = min(min(IR.satd_i16, IR.satd_i8), IR.satd_i4); recd.aux[2] = rl(S.cost, ME_16); }
                 mb_type = best_part == D_8x8 ? X264GPU_MB_P_8x8 : X264GPU_MB_P_L0;
                 if (IR.satd_i16 < i_cost) { i_cost = IR.satd_i16; mb_type = X264GPU_MB_I16x16; }
                 if (IR.satd_i8 < i_cost) { i_cost = IR.satd_i8; mb_type = X264GPU_MB_I8x8; }
@@ -1271,6 +1436,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 4))) void
         } else { mb_type = X264GPU_MB_P_SKIP; i_cost = 0; }
         int rec_type = mb_type;
         if (lane == 0) recd.cost = i_cost;
+        pf.mark(PH_INTRA);
 
         // ---- x264_macroblock_encode ----
         unsigned nnz = 0;
@@ -1282,7 +1448,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 4))) void
             if (pskip) { lmx = clampi(pskx, c.mvmin0, c.mvmax0); lmy = clampi(psky, c.mvmin1, c.mvmax1); lref = 0; }
             else {
                 const int slot = best_part == D_16x16 ? ME_16 : best_part == D_16x8 ? ME_16x8 + (b8 >> 1) : best_part == D_8x16 ? ME_8x16 + (b8 & 1) : ME_8 + b8;
-                lmx = L.me_mvx[slot]; lmy = L.me_mvy[slot]; lref = L.me_ref[slot];      // slot varies with the lane (its 8x8 block)
+                lmx = __shfl(S.mvx, slot); lmy = __shfl(S.mvy, slot); lref = __shfl(S.ref, slot);      // slot varies with the lane (its 8x8 block)
             }
             const uint32_t pred = mc_luma_row4(ref_plane00(k, s, lref), k.plane_bytes, k.rs, c.px + zx, c.py + zy, lmx, lmy);
             // chroma prediction: chroma 4x4 block ci <-> luma 8x8 ci
@@ -1406,6 +1572,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 4))) void
                 if (mb_type == X264GPU_MB_P_L0 && best_part == D_16x16 && !(cbp_luma | cbp_chroma) && ref0 == 0 && mv0x == pskx && mv0y == psky)
                     rec_type = X264GPU_MB_P_SKIP;
             }
+            pf.mark(PH_ENC_INTER);
         } else {
             // ---- intra macroblock ----
             if (lane < 4) recd.ref[lane] = -1;
@@ -1489,13 +1656,18 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 4))) void
                 mb_store_chroma(ruv, k.rs, lane, crec);
             }
             intra_count++;
+            pf.mark(PH_ENC_INTRA);
         }
         if (lane == 0) { recd.nnz = nnz; recd.cbp_luma = (uint8_t)cbp_luma; recd.cbp_chroma = (uint8_t)cbp_chroma; recd.type = (uint8_t)rec_type; mbtype_cur[mbi] = (uint8_t)rec_type; }
         lds_sync();
         if (lane < 16) ((uint32_t *)(mbs + mbi))[lane] = ((const uint32_t *)&L.rec)[lane];
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         __builtin_amdgcn_s_waitcnt(0);
+        pf.mark(PH_STORE);
     }
+#ifdef MB_PROF
+    if (lane == 0 && k.prof) for (int i = 0; i < 16; i++) k.prof[(size_t)s * 16 + i] = pf.acc[i];
+#endif
 }
 
 }  // namespace x264gpu
