@@ -103,6 +103,29 @@ __device__ __forceinline__ void sub_stage(uint32_t *buf, const uint8_t *__restri
         }
     }
 }
+// sub_stage<2> in two halves: the twelve requests, and (after other work has covered their latency) the copy into LDS
+__device__ __forceinline__ void sub_issue2(uint32_t v[12], const uint8_t *__restrict__ p00, size_t pb, int rs, int x0, int y0, int rwl, int rh, int ncol, int li)
+{
+    const int n = rh << rwl;
+#pragma unroll
+    for (int pl = 0; pl < 4; pl++)
+#pragma unroll
+        for (int t = 0; t < 3; t++) {
+            const int i = li + t * 64, row = i >> rwl, col = i & ((1 << rwl) - 1);
+            v[pl * 3 + t] = (i < n && col < ncol) ? *(const uint32_t *)(p00 + pl * pb + (long)(y0 + row) * rs + x0 + 4 * col) : 0u;
+        }
+}
+__device__ __forceinline__ void sub_commit2(uint32_t *buf, const uint32_t v[12], int rwl, int rh, int li)
+{
+    const int n = rh << rwl;
+#pragma unroll
+    for (int pl = 0; pl < 4; pl++)
+#pragma unroll
+        for (int t = 0; t < 3; t++) {
+            const int i = li + t * 64;
+            if (i < n) buf[pl * n + i] = v[pl * 3 + t];
+        }
+}
 __device__ __forceinline__ uint32_t lds_u32_at(const uint32_t *buf, int byte_off)
 {
     const uint32_t *w = buf + (byte_off >> 2);
@@ -214,6 +237,20 @@ __device__ __forceinline__ void chroma_stage(uint32_t *cb, const uint8_t *__rest
         const int row = i / ndw, col = i - row * ndw;
         cb[i] = *(const uint32_t *)(nv12 + (long)(y0c + row) * rs + 2 * x0c + 4 * col);
     }
+}
+// chroma_stage in two halves for M == 2 (at most 66 dwords: two per lane)
+__device__ __forceinline__ void chroma_issue2(uint32_t v[2], const uint8_t *__restrict__ nv12, int rs, int x0c, int y0c, int ndw, int nrows, int l)
+{
+#pragma unroll
+    for (int t = 0; t < 2; t++) {
+        const int i = l + 64 * t, row = i / ndw, col = i - row * ndw;
+        v[t] = i < ndw * nrows ? *(const uint32_t *)(nv12 + (long)(y0c + row) * rs + 2 * x0c + 4 * col) : 0u;
+    }
+}
+__device__ __forceinline__ void chroma_commit2(uint32_t *cb, const uint32_t v[2], int ndw, int nrows, int l)
+{
+#pragma unroll
+    for (int t = 0; t < 2; t++) { const int i = l + 64 * t; if (i < ndw * nrows) cb[i] = v[t]; }
 }
 // chroma_me_half on the staged neighbourhood: (cx, cy) chroma position of the lane's four pixels
 __device__ __forceinline__ int chroma_me_lds(const uint32_t *cb, int ndw, int x0c, int y0c, int cx, int cy, int mvx, int mvy, uint32_t e0, uint32_t e1,

@@ -191,6 +191,12 @@ __device__ __forceinline__ void me_search(const EncK &k, MbLds<M> &L, const MbCt
     const int fmin0 = c.fmin0, fmax0 = c.fmax0, fmin1 = c.fmin1, fmax1 = c.fmax1;
     constexpr bool umh = ME == 2, cached = ME == 0 || ME == 1;
     int cbx = 0, cby = 0;                      // centre of the LDS slices of the mv-cost table (dia / hex / esa searches)
+    // Most searches end where they start: the sub-pel neighbourhood of the START is requested before the full-pel search runs and is
+    // used if the search ends there (its latency then hides behind the search); otherwise it is fetched again around the result.
+    constexpr bool spec = (ME == 0 || ME == 1) && M == 2;
+    uint32_t spv[12], spc[2];
+    bool spec_on = false;
+    int spx = 0, spy = 0;
 
     if (j.search) {
         int bmx, bmy, bcost, bpred_cost = MB_COST_MAX, bpred_mx = 0, bpred_my = 0, pmx, pmy;
@@ -364,6 +370,13 @@ __device__ __forceinline__ void me_search(const EncK &k, MbLds<M> &L, const MbCt
             }
         }
         bmx = __builtin_amdgcn_readfirstlane(bmx); bmy = __builtin_amdgcn_readfirstlane(bmy);
+        if (spec && c.subme >= 2) {
+            spec_on = true; spx = bmx; spy = bmy;
+            sub_issue2(spv, p00, pb, k.rs, (bx + spx - M) & ~3, by + spy - M, SubGeo<M>::rwl(j.W), SubGeo<M>::rh(j.H), SubGeo<M>::ncol(j.W), lane);
+            if (c.chroma_me)
+                chroma_issue2(spc, ref_chroma00(k, c.s, j.ref), k.rs, ((bx >> 1) + (spx >> 1) - CSubGeo<M>::MG) & ~1, (by >> 1) + (spy >> 1) - CSubGeo<M>::MG,
+                              CSubGeo<M>::ndw(j.W >> 1), CSubGeo<M>::rows(j.H >> 1), lane);
+        }
         if (ME == 3) {      // esa: its window around the start
             lds_sync();
             wx0 = clampi((bx + bmx - WIN_R) & ~7, -PAD, k.cw + PAD - WIN_COLS); wy0 = clampi(by + bmy - WIN_R, -PAD, k.ch + PAD - WIN_ROWS);
@@ -558,7 +571,9 @@ __device__ __forceinline__ void me_search(const EncK &k, MbLds<M> &L, const MbCt
     const int rwl = SubGeo<M>::rwl(j.W), rh = SubGeo<M>::rh(j.H), ncol = SubGeo<M>::ncol(j.W), sn = rh << rwl;
     const int sx0 = (bx + ctrx - M) & ~3, sy0 = by + ctry - M;
     lds_sync();
-    sub_stage<M>(sb, p00, pb, k.rs, sx0, sy0, rwl, rh, ncol, lane, 64);
+    const bool spec_hit = spec && spec_on && ctrx == spx && ctry == spy;
+    if (spec_hit) sub_commit2(sb, spv, rwl, rh, lane);
+    else sub_stage<M>(sb, p00, pb, k.rs, sx0, sy0, rwl, rh, ncol, lane, 64);
     // chroma: lane r owns row (r & 3) of 4x4 chroma block r >> 2 of the partition, both planes
     const int cbw = j.W >> 3, ncb = cbw * (j.H >> 3), cblk = r >> 2;
     const bool cact = cblk < ncb;
@@ -569,7 +584,8 @@ __device__ __forceinline__ void me_search(const EncK &k, MbLds<M> &L, const MbCt
     const int cx0c = ((bx >> 1) + (ctrx >> 1) - CSubGeo<M>::MG) & ~1, cy0c = (by >> 1) + (ctry >> 1) - CSubGeo<M>::MG;
     if (chroma_me) {
         if (cact) { const uint2 v = *(const uint2 *)(c.fuv + (size_t)ccy * k.fs + 2 * ccx); ce0 = v.x; ce1 = v.y; }
-        chroma_stage(cb, ref_chroma00(k, c.s, j.ref), k.rs, cx0c, cy0c, cndw, cnr, lane, 64);
+        if (spec_hit) chroma_commit2(cb, spc, cndw, cnr, lane);
+        else chroma_stage(cb, ref_chroma00(k, c.s, j.ref), k.rs, cx0c, cy0c, cndw, cnr, lane, 64);
     }
     lds_sync();
     pf.mark(PH_ME_SUBSTAGE);
