@@ -81,6 +81,12 @@ int x264gpu_mc_luma(const uint8_t *d_planes00, size_t plane_bytes, int stride, c
                     const int32_t *d_mv, int n, int w, int h, uint8_t *d_out, void *stream);
 int x264gpu_mc_chroma(const uint8_t *d_nv12_00, int stride, const int32_t *d_xy, const int32_t *d_mv,
                       int n, int w, int h, uint8_t *d_out, void *stream);
+/* A10: the two sample combiners behind bi-prediction and --weightp ([x264-upstream] common/mc.c pixel_avg_wxh / pixel_avg_weight_wxh and
+ * mc_weight), on `bytes` already motion-compensated samples (a multiple of 4; any block shape, blocks contiguous):
+ * avg: weight1 == 32 -> (a + b + 1) >> 1, else clip((a * weight1 + b * (64 - weight1) + 32) >> 6);
+ * weight: clip(((src * scale + (1 << (denom - 1))) >> denom) + offset), denom 0: clip(src * scale + offset). */
+int x264gpu_mc_avg(const uint8_t *d_a, const uint8_t *d_b, size_t bytes, int weight1, uint8_t *d_out, void *stream);
+int x264gpu_mc_weight(const uint8_t *d_src, size_t bytes, int scale, int denom, int offset, uint8_t *d_out, void *stream);
 
 /* ---- input colourspace conversion to I420 -----------------------------------------
  * Replaces the x264vfw_csp_function_t table the driver installs for an I420 encoder (/root/reference/csp.c:436-487,
@@ -149,7 +155,7 @@ typedef struct x264gpu_encoder x264gpu_encoder;  /* opaque: owns the device-resi
 typedef struct x264gpu_config {
     int width, height;        /* luma picture size (even) */
     int streams;              /* independent streams/closed GOPs encoded in lock-step */
-    int refs;                 /* reference frames for P slices, 1..4 */
+    int refs;                 /* reference frames for P slices, 1..5 */
     int qp_i, qp_p;           /* constant QPs (X264_RC_CQP path, codec.c:1498-1502) */
     int me_range;             /* --merange (16) */
     int subme;                /* --subme level: search depth 0..11; mode decision is SATD-based at every level (no RD yet: x264's subme <= 5 behaviour) */

@@ -6,7 +6,7 @@
 // inverse transforms, interpolation, edge filters).  Subset: CAVLC or CABAC (cabac_dec.hpp; cabac_init_idc 0), frame MBs,
 // I (I4x4 / I8x8 / I16x16) and P (16x16 / 16x8 / 8x16 / 8x8, P_Skip, intra) slices, one slice per picture, poc type 2, up to 4 refs.
 #include "x264o.h"
-#include "../x264vfw_amd/host/cavlc_tables.hpp"
+#include "cavlc_dec.hpp"
 #include "cabac_dec.hpp"
 #include <stdint.h>
 #include <stdio.h>
@@ -14,7 +14,7 @@
 #include <string.h>
 #include <vector>
 
-using namespace x264host;
+
 
 namespace {
 
@@ -63,7 +63,7 @@ struct Decoder {
     int pic_init_qp = 26, chroma_qp_offset = 0, deblock_ctrl = 1, num_ref_default = 1, transform8x8_mode = 0, cabac = 0;
     int stride = 0, pad = 32, cpad = 16;
     size_t plane_bytes = 0, cplane_bytes = 0;
-    std::vector<pixel> luma[5], chroma[5];   // DPB slots: up to 4 references + the picture being decoded
+    std::vector<pixel> luma[6], chroma[6];   // DPB slots: up to 5 references + the picture being decoded
     int cur = 0, slots = 2, have = 0, num_ref_frames = 1, nref_active = 1;
     int ref_slot(int r) const { return (cur - 1 - r + 2 * slots) % slots; }
     std::vector<MbInfo> mb;
@@ -89,7 +89,7 @@ struct Decoder {
 int clampi(int v, int lo, int hi) { return v < lo ? lo : v > hi ? hi : v; }
 
 // ---- CAVLC parsing ----
-int read_vlc(BitReader &br, const uint8_t *len, const uint8_t *bits, int n)
+int read_vlc(BitReader &br, const uint8_t *len, const uint16_t *bits, int n)
 {
     // incremental prefix match (tables are prefix-free)
     uint32_t code = 0;
@@ -105,8 +105,9 @@ int read_vlc(BitReader &br, const uint8_t *len, const uint8_t *bits, int n)
 int residual_block(BitReader &br, int16_t *out, int maxn, int nC)
 {
     memset(out, 0, sizeof(int16_t) * maxn);
-    int tok = nC < 0 ? read_vlc(br, chroma_dc_coeff_token_len, chroma_dc_coeff_token_bits, 20)
-                     : read_vlc(br, coeff_token_len[nC < 2 ? 0 : nC < 4 ? 1 : nC < 8 ? 2 : 3], coeff_token_bits[nC < 2 ? 0 : nC < 4 ? 1 : nC < 8 ? 2 : 3], 68);
+    const cavlcdec::Tables &T = cavlcdec::tables();
+    int tok = nC < 0 ? read_vlc(br, T.chroma_dc_coeff_token_len, T.chroma_dc_coeff_token_bits, 20)
+                     : read_vlc(br, T.coeff_token_len[nC < 2 ? 0 : nC < 4 ? 1 : nC < 8 ? 2 : 3], T.coeff_token_bits[nC < 2 ? 0 : nC < 4 ? 1 : nC < 8 ? 2 : 3], 68);
     int total = tok >> 2, t1 = tok & 3;
     if (!total) return 0;
     int level[16];
@@ -126,8 +127,8 @@ int residual_block(BitReader &br, int16_t *out, int maxn, int nC)
     }
     int zeros = 0;
     if (total < maxn) {
-        if (nC < 0) zeros = read_vlc(br, chroma_dc_total_zeros_len[total - 1], chroma_dc_total_zeros_bits[total - 1], 4);
-        else zeros = read_vlc(br, total_zeros_len[total - 1], total_zeros_bits[total - 1], 16);
+        if (nC < 0) zeros = read_vlc(br, T.chroma_dc_total_zeros_len[total - 1], T.chroma_dc_total_zeros_bits[total - 1], 4);
+        else zeros = read_vlc(br, T.total_zeros_len[total - 1], T.total_zeros_bits[total - 1], 16);
     }
     int pos = total + zeros - 1;               // position of the highest-frequency coefficient
     int left = zeros;
@@ -135,7 +136,7 @@ int residual_block(BitReader &br, int16_t *out, int maxn, int nC)
         if (pos < 0 || pos >= maxn) { br.err = true; return total; }
         out[pos] = (int16_t)level[i];
         int run = 0;
-        if (i < total - 1 && left > 0) { int t = (left < 7 ? left : 7) - 1; run = read_vlc(br, run_before_len[t], run_before_bits[t], 16); left -= run; }
+        if (i < total - 1 && left > 0) { int t = (left < 7 ? left : 7) - 1; run = read_vlc(br, T.run_before_len[t], T.run_before_bits[t], 16); left -= run; }
         else if (i == total - 1) run = left;
         pos -= run + 1;
     }
@@ -512,7 +513,7 @@ struct SliceDec {
         if (!m.i16) {
             int cbp = -1;
             if (d.cabac) cbp = ca_cbp(mbx, mby);
-            else { int code = (int)br.ue(); for (int i = 0; i < 48; i++) if (cbp_to_golomb_intra[i] == code) cbp = i; }
+            else { int code = (int)br.ue(); if (code > 47) { br.err = true; return; } cbp = cavlcdec::kCbpOfCode[code][0]; }
             if (cbp < 0) { br.err = true; return; }
             cbp_luma = cbp & 15; cbp_chroma = cbp >> 4;
         }
@@ -644,7 +645,7 @@ struct SliceDec {
         }
         int cbp = -1;
         if (d.cabac) cbp = ca_cbp(mbx, mby);
-        else { int code = (int)br.ue(); for (int i = 0; i < 48; i++) if (cbp_to_golomb_inter[i] == code) cbp = i; }
+        else { int code = (int)br.ue(); if (code > 47) { br.err = true; return; } cbp = cavlcdec::kCbpOfCode[code][1]; }
         if (cbp < 0) { br.err = true; return; }
         m.cbp_luma = cbp & 15; m.cbp_chroma = cbp >> 4;
         m.t8 = (d.transform8x8_mode && (cbp & 15)) ? (d.cabac ? ca_t8(mbx, mby) : br.get1()) : 0;      // all partitions are >= 8x8 in this subset
@@ -827,7 +828,7 @@ bool decode_nal(Decoder &d, const uint8_t *nal, size_t n)
         d.poc_type = (int)br.ue();
         if (d.poc_type != 2) return false;
         d.num_ref_frames = (int)br.ue(); br.get1();
-        if (d.num_ref_frames < 1 || d.num_ref_frames > 4) return false;
+        if (d.num_ref_frames < 1 || d.num_ref_frames > 5) return false;
         d.mbw = (int)br.ue() + 1; d.mbh = (int)br.ue() + 1;
         if (!br.get1()) return false;                       // frame_mbs_only
         br.get1();

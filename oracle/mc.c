@@ -67,6 +67,30 @@ void x264o_pixel_avg(pixel *dst, int sd, const pixel *a, int sa, const pixel *b,
         for (int x = 0; x < w; x++) dst[y * sd + x] = (pixel)((a[y * sa + x] + b[y * sb + x] + 1) >> 1);
 }
 
+/* bi-prediction of two motion-compensated blocks ([x264-upstream] common/mc.c pixel_avg_wxh / pixel_avg_weight_wxh, the B-frame and
+ * weighted bi-pred path of A10): weight1 == 32 is the rounding average, otherwise (a * w1 + b * (64 - w1) + 32) >> 6, clipped */
+void x264o_pixel_avg_weight(pixel *dst, int sd, const pixel *a, int sa, const pixel *b, int sb, int w, int h, int weight1)
+{
+    if (weight1 == 32) { x264o_pixel_avg(dst, sd, a, sa, b, sb, w, h); return; }
+    int weight2 = 64 - weight1;
+    for (int y = 0; y < h; y++)
+        for (int x = 0; x < w; x++) {
+            int v = (a[y * sa + x] * weight1 + b[y * sb + x] * weight2 + 32) >> 6;
+            dst[y * sd + x] = (pixel)(v < 0 ? 0 : v > 255 ? 255 : v);
+        }
+}
+
+/* explicit weighted prediction of one reference ([x264-upstream] common/mc.c mc_weight; 8.4.2.3 with one direction):
+ * denom >= 1: ((src * scale + (1 << (denom - 1))) >> denom) + offset, else src * scale + offset; clipped */
+void x264o_mc_weight(pixel *dst, int sd, const pixel *src, int ss, int w, int h, int scale, int denom, int offset)
+{
+    for (int y = 0; y < h; y++)
+        for (int x = 0; x < w; x++) {
+            int v = denom >= 1 ? ((src[y * ss + x] * scale + (1 << (denom - 1))) >> denom) + offset : src[y * ss + x] * scale + offset;
+            dst[y * sd + x] = (pixel)(v < 0 ? 0 : v > 255 ? 255 : v);
+        }
+}
+
 /* which half-pel plane(s) realise each of the 16 quarter-sample positions (Figure 8-4 of the spec:
  * a,c,d,n,e,g,p,r,f,i,k,q are rounding averages of the two nearest integer/half samples) */
 static const uint8_t qpel_plane0[16] = { 0, 1, 1, 1, 0, 1, 1, 1, 2, 3, 3, 3, 0, 1, 1, 1 };

@@ -117,6 +117,8 @@ void x264o_frame_filter(pixel *plane[4], int stride, int w, int h, int pad);
 /* lowres: four half-resolution planes from luma (clamped reads); dst stride ds, size (w/2)x(h/2) */
 void x264o_frame_init_lowres(const pixel *src, int ss, int w, int h, pixel *dst[4], int ds);
 /* qpel luma fetch (normative 8.4.2.2.1 via hpel planes).  mv in quarter-pels relative to (0,0) of plane */
+void x264o_pixel_avg_weight(pixel *dst, int sd, const pixel *a, int sa, const pixel *b, int sb, int w, int h, int weight1);
+void x264o_mc_weight(pixel *dst, int sd, const pixel *src, int ss, int w, int h, int scale, int denom, int offset);
 void x264o_mc_luma(pixel *dst, int sd, pixel *const plane[4], int stride, int x, int y,
                    int mvx, int mvy, int w, int h);
 /* chroma 1/8-pel bilinear on an NV12 plane (normative 8.4.2.2.2): dstu/dstv w x h (chroma samples) */

@@ -60,6 +60,8 @@ _sig("x264o_predict_8x8_filter", None, [C.c_void_p, _i, C.c_void_p, _i])
 _sig("x264o_predict_8x8", None, [C.c_void_p, _i, C.c_void_p, _i])
 _sig("x264o_frame_filter", None, [C.POINTER(C.c_void_p), _i, _i, _i, _i])
 _sig("x264o_frame_init_lowres", None, [C.c_void_p, _i, _i, _i, C.POINTER(C.c_void_p), _i])
+_sig("x264o_pixel_avg_weight", None, [C.c_void_p, _i, C.c_void_p, _i, C.c_void_p, _i, _i, _i, _i])
+_sig("x264o_mc_weight", None, [C.c_void_p, _i, C.c_void_p, _i, _i, _i, _i, _i, _i])
 _sig("x264o_mc_luma", None, [C.c_void_p, _i, C.POINTER(C.c_void_p), _i, _i, _i, _i, _i, _i, _i])
 _sig("x264o_mc_chroma", None, [C.c_void_p, C.c_void_p, _i, C.c_void_p, _i, _i, _i, _i, _i, _i, _i])
 _sig("x264o_deblock_luma_edge", None, [C.c_void_p, _i, _i, _i, _i, _i, _i, _i])

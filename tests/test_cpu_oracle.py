@@ -114,3 +114,15 @@ def test_no_gpu_means_loud_failure():
     h = C.c_void_p()
     cfg = O.default_config(64, 48)
     assert lib.x264gpu_encoder_create(C.byref(h), C.byref(cfg)) != 0
+
+
+def test_pred8_table_comes_from_the_standards_equations():
+    """x264vfw_amd/csrc/pred8_table.inc (the product's Intra_8x8 lookup) is derived from tests/spec_ref.py's per-pixel equations of 8.3.2.2,
+    not from the oracle: regenerating it gives the committed file"""
+    import importlib.util
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("gen_pred8_table", os.path.join(root, "tools", "gen_pred8_table.py"))
+    g = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(g)
+    assert g.text(g.table()) == open(g.PATH).read()

@@ -1,6 +1,6 @@
 """-m gpu: randomised parity sweep — HIP frame pipeline == oracle (records, levels, reconstruction) over random picture sizes
 (including non-multiples of 16), quantisers 0..51, deblock / chroma-qp offsets and every toolset combination the config struct
-can express (refs 1..4, partitions, 8x8 transform + Intra_8x8, subme 0..9, me dia/hex, merange, decimate), with a second
+can express (refs 1..5, partitions, 8x8 transform + Intra_8x8, subme 0..9, me dia/hex, merange, decimate), with a second
 IDR inside some sequences.  Seeds are fixed so a failure names a reproducible case."""
 import random
 
@@ -17,7 +17,7 @@ def random_case(rnd):
     w = max(16, 16 * rnd.randint(1, 14) - rnd.choice([0, 0, 2, 6, 14]))
     h = max(16, 16 * rnd.randint(1, 10) - rnd.choice([0, 0, 2, 8, 12]))
     dct = rnd.randint(0, 1)
-    kw = dict(refs=rnd.randint(1, 4), partitions=rnd.choice([0, 1, 2, 3, 4, 5, 6, 7]) if dct else rnd.choice([0, 1, 2, 3]), dct8x8=dct,
+    kw = dict(refs=rnd.randint(1, 5), partitions=rnd.choice([0, 1, 2, 3, 4, 5, 6, 7]) if dct else rnd.choice([0, 1, 2, 3]), dct8x8=dct,
               subme=rnd.choice([0, 1, 2, 3, 4, 5, 6, 7, 8, 9]), me_method=rnd.choice([0, 1, 1, 2, 3]), chroma_me=rnd.randint(0, 1), mixed_refs=rnd.randint(0, 1), aq_mode=rnd.randint(0, 1), aq_strength_q8=rnd.choice([133, 266, 400]), me_range=rnd.choice([4, 8, 16]),
               qp_i=rnd.randint(0, 51), qp_p=rnd.randint(0, 51), deblock=rnd.randint(0, 1), dct_decimate=rnd.randint(0, 1),
               deblock_alpha=rnd.randint(-3, 3), deblock_beta=rnd.randint(-3, 3), chroma_qp_offset=rnd.randint(-6, 6))

@@ -66,6 +66,8 @@ def compare(tag, mbw, g_mb, o_mb, g_lv, o_lv, g_rec, o_rec):
     (176, 144, 6, dict(mixed_refs=1, refs=3, partitions=3)),                 # mixed refs: per-8x8 / per-half references
     (352, 288, 6, dict(mixed_refs=1, refs=3, partitions=7, dct8x8=1, chroma_me=1, qp_i=28, qp_p=31)),   # x264 medium's ME toolset
     (208, 120, 7, dict(mixed_refs=1, refs=4, partitions=1, subme=5, me_method=0)),
+    (176, 144, 8, dict(mixed_refs=1, refs=5, partitions=7, dct8x8=1, subme=5, chroma_me=1, qp_i=27, qp_p=30)),   # BASELINE config 4's ref 5
+    (96, 80, 8, dict(refs=5, partitions=0, subme=2, me_method=2)),
     (352, 288, 5, dict(mixed_refs=1, refs=2, partitions=3, me_method=2, chroma_me=1)),
     (64, 48, 4, dict(mixed_refs=1, refs=1, partitions=3)),                   # one reference: the flag is inert
     (176, 144, 4, dict(aq_mode=1)),                                          # variance AQ: a quantiser per macroblock

@@ -223,3 +223,29 @@ def test_intra_predictors(gpu):
             real = 2 if (a & 1 and a & 2) else 9 if a & 1 else 10 if a & 2 else 11
         O.L.x264o_predict_4x4(O.ptr(ref, i * 16), 4, O.ptr(plane, int(xy[i, 1]) * W + int(xy[i, 0])), W, real, a)
     np.testing.assert_array_equal(out.cpu().numpy(), ref)
+
+
+def test_mc_bipred_avg_and_weight(gpu):
+    """A10's sample combiners behind bi-prediction and --weightp: pixel_avg / pixel_avg_weight (implicit weights span -64..128) and
+    mc_weight over every denominator, on random sample blocks, vs oracle/mc.c"""
+    import torch
+    rng = np.random.default_rng(1234)
+    n = 16 * 16 * 40
+    a = rng.integers(0, 256, n, dtype=np.uint8)
+    b = rng.integers(0, 256, n, dtype=np.uint8)
+    a[:8] = [0, 255, 0, 255, 1, 254, 128, 127]
+    b[:8] = [0, 255, 255, 0, 254, 1, 127, 128]
+    da, db = dev(a), dev(b)
+    out = torch.empty(n, dtype=torch.uint8, device="cuda")
+    ref = np.empty(n, np.uint8)
+    for w1 in (32, 0, 64, 21, 43, -64, 128, -10, 90, 1, 63):
+        gpu.check(gpu.x264gpu_mc_avg(da.data_ptr(), db.data_ptr(), n, w1, out.data_ptr(), None))
+        O.L.x264o_pixel_avg_weight(O.ptr(ref), 16, O.ptr(a), 16, O.ptr(b), 16, 16, n // 16, w1)
+        np.testing.assert_array_equal(out.cpu().numpy(), ref, err_msg=f"avg weight {w1}")
+    for denom in range(8):
+        for scale, offset in ((1 << denom, 0), (1 << denom, -7), (0, 5), (255, -128), (37, 127), ((1 << denom) + 3, 9), (max(1, (1 << denom) - 1), -3)):
+            gpu.check(gpu.x264gpu_mc_weight(da.data_ptr(), n, scale, denom, offset, out.data_ptr(), None))
+            O.L.x264o_mc_weight(O.ptr(ref), 16, O.ptr(a), 16, 16, n // 16, scale, denom, offset)
+            np.testing.assert_array_equal(out.cpu().numpy(), ref, err_msg=f"weight scale {scale} denom {denom} offset {offset}")
+    assert gpu.x264gpu_mc_avg(da.data_ptr(), db.data_ptr(), 6, 32, out.data_ptr(), None) < 0          # not a multiple of four samples
+    assert gpu.x264gpu_mc_weight(da.data_ptr(), n, 1, 8, 0, out.data_ptr(), None) < 0                  # log2 denominator is 0..7

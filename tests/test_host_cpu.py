@@ -111,7 +111,7 @@ def test_open_without_gpu_fails_loudly():
                                      (96, 80, dict(qp_i=8, qp_p=10)), (64, 64, dict(partitions=0)),
                                      (176, 144, dict(partitions=3)), (352, 288, dict(partitions=3, qp_i=30, qp_p=33)),
                                      (208, 120, dict(partitions=1, subme=4)), (176, 144, dict(refs=3, partitions=3)),
-                                     (96, 80, dict(refs=2)), (208, 120, dict(refs=4, partitions=3, qp_i=30, qp_p=32)),
+                                     (96, 80, dict(refs=2)), (208, 120, dict(refs=4, partitions=3, qp_i=30, qp_p=32)), (96, 80, dict(refs=5, partitions=7, dct8x8=1, mixed_refs=1, qp_i=33, qp_p=36)),
                                      (176, 144, dict(dct8x8=1)), (352, 288, dict(dct8x8=1, partitions=3, refs=2, qp_i=26, qp_p=28)),
                                      (208, 120, dict(dct8x8=1, qp_i=12, qp_p=14, dct_decimate=0)),
                                      (176, 144, dict(dct8x8=1, partitions=6)), (352, 288, dict(dct8x8=1, partitions=7, refs=3, qp_i=28, qp_p=31)),
@@ -216,7 +216,7 @@ def test_entropy_closed_loop_random(seed, cabac):
         w = max(16, 16 * rnd.randint(1, 9) - rnd.choice([0, 0, 2, 6, 14]))
         h = max(16, 16 * rnd.randint(1, 7) - rnd.choice([0, 0, 2, 8, 12]))
         dct = rnd.randint(0, 1)
-        kw = dict(refs=rnd.randint(1, 4), partitions=rnd.choice([0, 1, 2, 3, 4, 5, 6, 7]) if dct else rnd.choice([0, 1, 2, 3]), dct8x8=dct,
+        kw = dict(refs=rnd.randint(1, 5), partitions=rnd.choice([0, 1, 2, 3, 4, 5, 6, 7]) if dct else rnd.choice([0, 1, 2, 3]), dct8x8=dct,
                   subme=rnd.choice([0, 2, 5, 7]), me_method=rnd.randint(0, 3), chroma_me=rnd.randint(0, 1), mixed_refs=rnd.randint(0, 1), aq_mode=rnd.randint(0, 1), aq_strength_q8=rnd.choice([133, 266, 400]), qp_i=rnd.randint(0, 51), qp_p=rnd.randint(0, 51),
                   deblock=rnd.randint(0, 1), dct_decimate=rnd.randint(0, 1), chroma_qp_offset=rnd.randint(-6, 6))
         nfr = rnd.randint(2, 6)
@@ -269,3 +269,13 @@ def test_cabac_context_tables_typed_twice_agree():
     import ctypes as C
     O.L.x264o_cabac_tables_mismatches.restype = C.c_int
     assert O.L.x264o_cabac_tables_mismatches() == 0
+
+
+def test_cavlc_tables_typed_twice_agree():
+    """the CAVLC code tables exist twice, typed separately: (length, value) arrays in the product's writer (x264vfw_amd/host/cavlc_tables.hpp)
+    and bit strings per symbol, as the standard prints them, in the checker decoder (oracle/cavlc_dec.hpp).  Every symbol must carry the same
+    code in both, and each of the decoder's tables must be a prefix code"""
+    import ctypes as C
+    for f in (O.L.x264o_cavlc_tables_mismatches, O.L.x264o_cavlc_tables_prefix_clashes):
+        f.restype = C.c_int
+        assert f() == 0

@@ -23,7 +23,7 @@ struct EncK {
     const uint8_t *i420;      // [streams] tightly packed input pictures
     uint8_t *fenc_y, *fenc_uv;
     uint8_t *rec_luma, *rec_chroma;          // DPB slot being reconstructed
-    const uint8_t *ref_luma[4], *ref_chroma[4];   // DPB slots of reference index 0..nref-1 (0 = most recent)
+    const uint8_t *ref_luma[5], *ref_chroma[5];   // DPB slots of reference index 0..nref-1 (0 = most recent)
     int nref;                                // references usable by this P slice
     x264gpu_mb *mb;           // [streams][nmb]
     int16_t *levels;          // [streams][nmb][416]

@@ -29,12 +29,12 @@ struct x264gpu_encoder {
     x264gpu_config cfg;
     EncK k;                       // template of the kernel argument block (pointers refreshed per call)
     uint8_t *fenc_y = nullptr, *fenc_uv = nullptr;
-    uint8_t *luma[5] = {}, *chroma[5] = {};      // DPB slots: refs + the picture being reconstructed
+    uint8_t *luma[6] = {}, *chroma[6] = {};      // DPB slots: refs + the picture being reconstructed
     int slots = 2, have = 0;                     // have = pictures in the DPB since the last IDR
-    int16_t *mv16[5] = {};                       // per DPB slot: 16x16 search results in reference 0 (x264 frame->mv16x16 = h->mb.mvr[0][0])
-    uint8_t *mbtype[5] = {};                     // per DPB slot: macroblock types (x264 frame->mb_type)
+    int16_t *mv16[6] = {};                       // per DPB slot: 16x16 search results in reference 0 (x264 frame->mv16x16 = h->mb.mvr[0][0])
+    uint8_t *mbtype[6] = {};                     // per DPB slot: macroblock types (x264 frame->mb_type)
     int16_t *mvr[5] = {};                        // per reference index >= 1: 16x16 search results of the picture being coded
-    int slot_nref[5] = {}, slot_poc[5] = {}, slot_ref0poc[5] = {};
+    int slot_nref[6] = {}, slot_poc[6] = {}, slot_ref0poc[6] = {};
     int poc = 0;
     const int16_t *lowres_mv = nullptr;
     int cur = 0;
@@ -95,7 +95,7 @@ int x264gpu_encoder_create(x264gpu_encoder **out, const x264gpu_config *cfg)
 {
     ARG_TRY(out && cfg);
     ARG_TRY(cfg->width >= 16 && cfg->height >= 16 && !(cfg->width & 1) && !(cfg->height & 1) && cfg->streams >= 1);
-    ARG_TRY(cfg->qp_i >= 0 && cfg->qp_i <= 51 && cfg->qp_p >= 0 && cfg->qp_p <= 51 && cfg->refs >= 1 && cfg->refs <= 4);
+    ARG_TRY(cfg->qp_i >= 0 && cfg->qp_i <= 51 && cfg->qp_p >= 0 && cfg->qp_p <= 51 && cfg->refs >= 1 && cfg->refs <= 5);
     ARG_TRY(cfg->width <= 4096 && cfg->height <= 2304 && cfg->me_range >= 4 && cfg->me_range <= (cfg->me_method == 2 ? 64 : 16));
     ARG_TRY(cfg->me_method >= 0 && cfg->me_method <= 3);
     x264gpu_encoder *e = new (std::nothrow) x264gpu_encoder();
@@ -216,7 +216,8 @@ void x264gpu_encoder_destroy(x264gpu_encoder *e)
     if (!e) return;
     profile_free(e);
     (void)hipFree(e->fenc_y); (void)hipFree(e->fenc_uv);
-    for (int i = 0; i < 5; i++) { (void)hipFree(e->luma[i]); (void)hipFree(e->chroma[i]); (void)hipFree(e->mv16[i]); (void)hipFree(e->mbtype[i]); (void)hipFree(e->mvr[i]); }
+    for (int i = 0; i < 6; i++) { (void)hipFree(e->luma[i]); (void)hipFree(e->chroma[i]); (void)hipFree(e->mv16[i]); (void)hipFree(e->mbtype[i]); }
+    for (int i = 0; i < 5; i++) (void)hipFree(e->mvr[i]);
     (void)hipFree(e->wf_progress);
     (void)hipFree(e->prof);
     (void)hipFree(e->stream_qp); (void)hipFree(e->mbqp); (void)hipFree(e->q4tab); (void)hipFree(e->q8tab); (void)hipFree(e->lambda_tab); (void)hipFree(e->cost_all);
@@ -257,7 +258,7 @@ int x264gpu_encode_frames(x264gpu_encoder *e, const uint8_t *d_i420, int slice_t
     k.rec_luma = e->luma[e->cur]; k.rec_chroma = e->chroma[e->cur];
     k.nref = slice_type == X264GPU_SLICE_I ? 0 : e->have < e->cfg.refs ? e->have : e->cfg.refs;
     auto slot_of = [&](int r) { return (e->cur - 1 - r + 2 * e->slots) % e->slots; };
-    for (int r = 0; r < 4; r++) {
+    for (int r = 0; r < 5; r++) {
         const int slot = slot_of(r < k.nref ? r : 0);
         k.ref_luma[r] = e->luma[slot]; k.ref_chroma[r] = e->chroma[slot];
     }

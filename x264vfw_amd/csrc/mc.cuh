@@ -57,4 +57,30 @@ __device__ __forceinline__ void mc_chroma_row4(const uint8_t *__restrict__ nv12,
     v = pack4(pv);
 }
 
+
+// bi-prediction of four packed samples (x264 pixel_avg_weight_wxh): weight1 == 32 is the rounding average
+__device__ __forceinline__ uint32_t avg_weight4_u8(uint32_t a, uint32_t b, int w1)
+{
+    if (w1 == 32) return avg4_u8(a, b);
+    uint32_t o = 0;
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        const int v = ((int)((a >> (8 * i)) & 255) * w1 + (int)((b >> (8 * i)) & 255) * (64 - w1) + 32) >> 6;
+        o |= (uint32_t)min(max(v, 0), 255) << (8 * i);
+    }
+    return o;
+}
+// explicit weighted prediction of four packed samples (x264 mc_weight)
+__device__ __forceinline__ uint32_t weight4_u8(uint32_t s, int scale, int denom, int offset)
+{
+    uint32_t o = 0;
+    const int rnd = denom >= 1 ? 1 << (denom - 1) : 0;
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        const int v = (((int)((s >> (8 * i)) & 255) * scale + rnd) >> denom) + offset;
+        o |= (uint32_t)min(max(v, 0), 255) << (8 * i);
+    }
+    return o;
+}
+
 }  // namespace x264gpu

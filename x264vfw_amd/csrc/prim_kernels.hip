@@ -119,6 +119,18 @@ __global__ __launch_bounds__(256) void k_mc_luma(const uint8_t *__restrict__ p00
     *(uint32_t *)(out + (size_t)idx * w * h + y * w + x0) = v;
 }
 
+// bi-prediction / explicit weighting of already motion-compensated samples, four per thread (any block shape: the blocks are contiguous)
+__global__ __launch_bounds__(256) void k_mc_avg(const uint32_t *__restrict__ a, const uint32_t *__restrict__ b, size_t n, int weight1, uint32_t *__restrict__ out)
+{
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) out[i] = avg_weight4_u8(a[i], b[i], weight1);
+}
+__global__ __launch_bounds__(256) void k_mc_weight(const uint32_t *__restrict__ src, size_t n, int scale, int denom, int offset, uint32_t *__restrict__ out)
+{
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) out[i] = weight4_u8(src[i], scale, denom, offset);
+}
+
 __global__ __launch_bounds__(256) void k_mc_chroma(const uint8_t *__restrict__ nv12, int stride,
                                                    const int32_t *__restrict__ xy, const int32_t *__restrict__ mv,
                                                    int n, int w, int h, uint8_t *__restrict__ out)
@@ -177,6 +189,24 @@ int x264gpu_mc_luma(const uint8_t *d_planes00, size_t plane_bytes, int stride, c
     ARG_TRY(n >= 0 && d_planes00 && d_xy && d_mv && d_out && (w == 4 || w == 8 || w == 16) && (h == 4 || h == 8 || h == 16));
     if (!n) return X264GPU_OK;
     hipLaunchKernelGGL(k_mc_luma, dim3((n + 3) / 4), dim3(256), 0, (hipStream_t)stream, d_planes00, plane_bytes, stride, d_xy, d_mv, n, w, h, d_out);
+    HIP_TRY(hipGetLastError());
+    return X264GPU_OK;
+}
+
+int x264gpu_mc_avg(const uint8_t *d_a, const uint8_t *d_b, size_t bytes, int weight1, uint8_t *d_out, void *stream)
+{
+    ARG_TRY(d_a && d_b && d_out && !(bytes & 3) && weight1 >= -64 && weight1 <= 128);
+    if (!bytes) return X264GPU_OK;
+    hipLaunchKernelGGL(k_mc_avg, dim3((unsigned)((bytes / 4 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (const uint32_t *)d_a, (const uint32_t *)d_b, bytes / 4, weight1, (uint32_t *)d_out);
+    HIP_TRY(hipGetLastError());
+    return X264GPU_OK;
+}
+
+int x264gpu_mc_weight(const uint8_t *d_src, size_t bytes, int scale, int denom, int offset, uint8_t *d_out, void *stream)
+{
+    ARG_TRY(d_src && d_out && !(bytes & 3) && denom >= 0 && denom <= 7 && scale >= 0 && scale <= 255 && offset >= -128 && offset <= 127);
+    if (!bytes) return X264GPU_OK;
+    hipLaunchKernelGGL(k_mc_weight, dim3((unsigned)((bytes / 4 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (const uint32_t *)d_src, bytes / 4, scale, denom, offset, (uint32_t *)d_out);
     HIP_TRY(hipGetLastError());
     return X264GPU_OK;
 }

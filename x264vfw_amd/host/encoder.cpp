@@ -197,7 +197,7 @@ x264_t *x264_encoder_open(x264_param_t *param)
 
     // ---- effective parameters: what this round's pipeline implements (reported back via encoder_parameters) ----
     if (p.i_bframe) { xlog(&p, X264_LOG_WARNING, "B-frames are not implemented in the MI355X path yet: bframes 0\n"); p.i_bframe = 0; }
-    if (p.i_frame_reference > 4) { xlog(&p, X264_LOG_INFO, "ref %d -> 4 (DPB of the MI355X path holds up to 4 references)\n", p.i_frame_reference); p.i_frame_reference = 4; }
+    if (p.i_frame_reference > 5) { xlog(&p, X264_LOG_INFO, "ref %d -> 5 (DPB of the MI355X path holds up to 5 references)\n", p.i_frame_reference); p.i_frame_reference = 5; }
     if (p.i_frame_reference < 1) p.i_frame_reference = 1;
     p.analyse.b_mixed_references = p.analyse.b_mixed_references && p.i_frame_reference > 1;      // x264 validate_parameters
     p.b_cabac = p.b_cabac != 0;

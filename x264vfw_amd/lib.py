@@ -68,6 +68,8 @@ _SIGS = {
     "x264gpu_hpel_filter": (_i, [_vp, _sz, _i, _i, _i, _i, _vp]),
     "x264gpu_lowres": (_i, [_vp, _i, _i, _i, _vp, _sz, _i, _vp]),
     "x264gpu_mc_luma": (_i, [_vp, _sz, _i, _vp, _vp, _i, _i, _i, _vp, _vp]),
+    "x264gpu_mc_avg": (_i, [_vp, _vp, _sz, _i, _vp, _vp]),
+    "x264gpu_mc_weight": (_i, [_vp, _sz, _i, _i, _i, _vp, _vp]),
     "x264gpu_mc_chroma": (_i, [_vp, _i, _vp, _vp, _i, _i, _i, _vp, _vp]),
     "x264gpu_csp_img_fill": (C.c_long, [_i, _i, _i, C.POINTER(C.c_long), C.POINTER(_i)]),
     "x264gpu_csp_to_i420": (_i, [C.POINTER(_vp), C.POINTER(_i), _i, _i, _i, _i, _i, C.POINTER(_vp), C.POINTER(_i), _vp]),
