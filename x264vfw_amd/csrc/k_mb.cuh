@@ -590,8 +590,9 @@ __device__ __forceinline__ void me_search(const EncK &k, MbLds<M> &L, const MbCt
     lds_sync();
     pf.mark(PH_ME_SUBSTAGE);
     const s16x2 sg1 = pk_sign(lane & 1), sg2 = pk_sign(lane & 2);
-    // vector bits: the search's LDS slices reach every sub-pel position around its full-pel result; a refinement-only call reads the table
-    const bool lcost = !umh && j.search;
+    // vector bits: the search's LDS slices reach every sub-pel position around its full-pel result (not when the predicted vector took over
+    // below subme 3 far from there); a refinement-only call reads the table
+    const bool lcost = !umh && j.search && abs(bmx - cbx) <= 72 && abs(bmy - cby) <= 72;
     auto mvc2 = [&](int qx, int qy) { return lcost ? (int)L.cost[0][qx - cbx + 96] + (int)L.cost[1][qy - cby + 96] : (int)cmx[qx] + (int)cmy[qy]; };
     auto fetch2 = [&](int qx, int qy, uint32_t p[4]) {
         p[0] = p[1] = p[2] = p[3] = 0;
