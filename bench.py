@@ -187,6 +187,7 @@ def pmc_evidence(kernel_substr, avg_launch_ms, streams_per_launch):
     tab = json.load(open(path))
     per = tab.get("_workload", {}).get("streams_per_launch")
     key = [k for k in tab if kernel_substr in k]
+    key = [k for k in key if "true>" in k] or key          # the macroblock loop has a P-slice and an I-slice instantiation: the timed pictures are P
     if not per or not key:
         return None, None
     t = tab[key[0]]

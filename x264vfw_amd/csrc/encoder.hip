@@ -20,6 +20,7 @@ void launch_mb_slice_dia(const EncK &k, int streams, bool big_margin, hipStream_
 void launch_mb_slice_hex(const EncK &k, int streams, bool big_margin, hipStream_t st);
 void launch_mb_slice_umh(const EncK &k, int streams, bool big_margin, hipStream_t st);
 void launch_mb_slice_esa(const EncK &k, int streams, bool big_margin, hipStream_t st);
+void launch_mb_slice_intra(const EncK &k, int streams, hipStream_t st);
 int launch_hpel_filter(uint8_t *planes, size_t plane_bytes, int stride, int w, int h, int pad, int batch,
                        size_t batch_bytes, hipStream_t st);
 }
@@ -296,7 +297,8 @@ int x264gpu_encode_frames(x264gpu_encoder *e, const uint8_t *d_i420, int slice_t
     mask |= 1;
     STAGE_MARK(1);
     // the macroblock loop: one wavefront per stream, raster order (sub-pel neighbourhood margin 2 px up to subme 7, 5 px above)
-    (k.me_method == 0 ? launch_mb_slice_dia : k.me_method == 2 ? launch_mb_slice_umh : k.me_method == 3 ? launch_mb_slice_esa : launch_mb_slice_hex)(k, S, k.subme >= 8, st);
+    if (slice_type == X264GPU_SLICE_I) launch_mb_slice_intra(k, S, st);
+    else (k.me_method == 0 ? launch_mb_slice_dia : k.me_method == 2 ? launch_mb_slice_umh : k.me_method == 3 ? launch_mb_slice_esa : launch_mb_slice_hex)(k, S, k.subme >= 8, st);
     mask |= 2;
     STAGE_MARK(2);
     STAGE_MARK(3);

@@ -1101,11 +1101,11 @@ __device__ __forceinline__ bool mb_probe_pskip(const EncK &k, const MbCtx &c, ui
 // The slice kernel: one wavefront per stream walks the macroblocks in raster order.
 // ------------------------------------------------------------------------------------------------
 // M: sub-pel neighbourhood margin (2 px up to subme 7, 5 above); ME: --me method (its own instantiation each: the roaming umh / esa code
-// costs the hexagon kernel registers otherwise)
+// costs the hexagon kernel registers otherwise); PS: P slice (I slices: k_mb_slice<2, 1, false>, mb_slice_intra.hip)
 #ifndef MB_WAVES_PER_EU
 #define MB_WAVES_PER_EU 2
 #endif
-template <int M, int ME>
+template <int M, int ME, bool PS>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(MB_WAVES_PER_EU, 4))) void k_mb_slice(EncK k)
 {
     __shared__ __attribute__((aligned(16))) MbLds<M> L;
@@ -1114,7 +1114,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(MB_WAVES_PER
     for (int i = lane; i < 144; i += 64) ((uint32_t *)L.pred8tab)[i] = ((const uint32_t *)c_pred8_table)[i];
     lds_sync();
     x264gpu_mb *mbs = k.mb + (size_t)s * k.nmb;
-    const bool pslice = k.slice_type == X264GPU_SLICE_P;
+    constexpr bool pslice = PS;                 // I slices run their own instantiation (no search code, a fraction of the registers)
     const int j4 = lane & 3, zx = z_x0(lane), zy = z_y(lane);
     int intra_count = 0;
     Prof pf;

@@ -1,0 +1,10 @@
+// mb_slice_intra.hip — the macroblock-loop kernel (k_mb.cuh) instantiated for I slices: no motion search, so one instantiation serves
+// every --me method and sub-pel margin.
+#include "k_mb.cuh"
+
+namespace x264gpu {
+void launch_mb_slice_intra(const EncK &k, int streams, hipStream_t st)
+{
+    hipLaunchKernelGGL((k_mb_slice<2, 1, false>), dim3(streams), dim3(64), 0, st, k);
+}
+}  // namespace x264gpu
