@@ -212,11 +212,12 @@ __device__ __forceinline__ int satd4_half(uint32_t e, uint32_t p, int lane)
     return satd4_half_pk(pk_even(e), pk_odd(e), p, pk_sign(lane & 1), pk_sign(lane & 2));
 }
 // lane = one 16-pixel row (4 dwords); the quad covers four 4x4 blocks side by side: half share of their SATDs
+template <int NB = 4>          // NB dwords of the row carry pixels (2: an 8-pixel row)
 __device__ __forceinline__ int satd16x4_half_pk(const uint32_t e[4], const uint32_t p[4], s16x2 sg1, s16x2 sg2)
 {
     s16x2 acc = as_s16x2(0u);
 #pragma unroll
-    for (int b = 0; b < 4; b++) {
+    for (int b = 0; b < NB; b++) {
         const s16x2 da = pk_even(e[b]) - pk_even(p[b]), db = pk_odd(e[b]) - pk_odd(p[b]);
         s16x2 u = da + db, v = da - db;
         u = pk_bfly<DPP_XOR1>(u, sg1); v = pk_bfly<DPP_XOR1>(v, sg1);

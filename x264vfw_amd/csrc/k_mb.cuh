@@ -612,7 +612,7 @@ __device__ __forceinline__ void me_search(const EncK &k, MbLds<M> &L, const MbCt
         if (!c.satd) return sad2(qx, qy);
         uint32_t p[4];
         fetch2(qx, qy, p);
-        return row16_sum(satd16x4_half_pk(e, p, sg1, sg2)) + mvc2(qx, qy);
+        return row16_sum(w16 ? satd16x4_half_pk<4>(e, p, sg1, sg2) : satd16x4_half_pk<2>(e, p, sg1, sg2)) + mvc2(qx, qy);       // 8-pixel rows: half the work
     };
     auto chroma2 = [&](int qx, int qy) {
         const int h = cact ? chroma_me_lds(cb, cndw, cx0c, cy0c, (c.px >> 1) + ccx, (c.py >> 1) + ccy, qx, qy, ce0, ce1, sg1, sg2) : 0;
