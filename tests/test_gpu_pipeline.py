@@ -85,6 +85,13 @@ def compare(tag, mbw, g_mb, o_mb, g_lv, o_lv, g_rec, o_rec):
     (96, 80, 4, dict(me_method=2, partitions=1, me_range=8, subme=2)),
     (176, 144, 4, dict(me_method=0, partitions=3, subme=5, refs=2)),         # diamond search in every partition
     (208, 120, 3, dict(me_method=0, subme=2, me_range=8)),
+    (176, 144, 4, dict(fast_pskip=0, partitions=3, refs=2)),                 # --no-fast-pskip: P_Skip only from empty 16x16 blocks
+    (176, 144, 4, dict(fast_pskip=0, subme=1)),
+    (352, 288, 4, dict(mv_range=32, partitions=3, refs=2, subme=5)),         # a low level's vector range: limits bite inside the picture
+    (208, 120, 4, dict(mv_range=64, me_method=2, me_range=32)),
+    (176, 144, 4, dict(subme=3, partitions=3, refs=2)),                      # subme 3 / 4: quarter-pel predictors, fewer refinement steps
+    (176, 144, 4, dict(subme=4, partitions=7, dct8x8=1, refs=3, mixed_refs=1)),
+    (96, 80, 5, dict(subme=0, partitions=3, refs=3, mixed_refs=1)),          # full-pel only with partitions
 ])
 def test_pipeline_bitexact(gpu, w, h, nfr, kw):
     from gpu_enc import GpuEncoder
@@ -249,3 +256,43 @@ def test_per_stream_quantisers(gpu, aq):
             compare(f"stream qp aq={aq} frame {i} stream {s}", (w + 15) // 16, g_mb[s], o_mb, g_lv[s], o_lv, gg.recon(s), ogs[s].recon())
             if not aq:
                 assert set(np.unique(o_mb["qp"])) == {q}
+
+
+def test_lookahead_vectors_enter_the_16x16_candidates(gpu):
+    """x264 hands the lookahead's vector of a macroblock (lowres_mvs[0][0], doubled) to the 16x16 search of reference 0 as its first
+    candidate: x264gpu_encoder_set_lowres_mvs.  Useful vectors (the true global motion), useless ones and the "absent" marker, against
+    the oracle fed the same arrays; the useful ones must actually change decisions somewhere"""
+    import torch
+    from gpu_enc import GpuEncoder
+    w, h, nfr = 176, 144, 4
+    base = synth_frames(w, h, 1, seed=31)[0]
+    Y = base[:w * h].reshape(h, w)
+    frames = []
+    for i in range(nfr):                                   # a pan of 6 px per picture: the neighbours' vectors lag behind at the left edge
+        yy = np.roll(Y, 6 * i, axis=1)
+        frames.append(np.concatenate([yy.reshape(-1), base[w * h:]]))
+    cfg = O.default_config(w, h, partitions=3, refs=2, subme=5, me_range=4)
+    nmb = ((w + 15) // 16) * ((h + 15) // 16)
+    rng = np.random.default_rng(5)
+    recs = {}
+    for name in ("none", "pan", "noise", "absent"):
+        og, gg = O.OracleEncoder(cfg), GpuEncoder(cfg)
+        mv = None
+        if name == "pan": mv = np.tile(np.array([-12, 0], np.int16), (nmb, 1))          # x 2 = quarter-pel: the content moved 6 px to the right
+        elif name == "noise": mv = rng.integers(-20, 21, (nmb, 2)).astype(np.int16)
+        elif name == "absent": mv = np.full((nmb, 2), 0x7fff, np.int16)
+        d_mv = torch.from_numpy(mv).cuda() if mv is not None else None
+        out = []
+        for i, f in enumerate(frames):
+            if mv is not None:
+                O.L.x264o_encoder_set_lowres_mvs(og.h, O.ptr(mv))
+                gpu.check(gpu.x264gpu_encoder_set_lowres_mvs(gg.h, d_mv.data_ptr()))
+            o_mb, o_lv = og.encode(f, 2 if i == 0 else 0)
+            g_mb, g_lv = gg.encode([f], 2 if i == 0 else 0)
+            compare(f"lowres mvs {name} frame {i}", (w + 15) // 16, g_mb[0], o_mb, g_lv[0], o_lv, gg.recon(0), og.recon())
+            out.append(o_mb.copy())
+        recs[name] = out
+        og.close(); gg.close()
+    same = lambda a, b: all(np.array_equal(x.view(np.uint8), y.view(np.uint8)) for x, y in zip(a, b))
+    assert same(recs["none"], recs["absent"])
+    assert not same(recs["none"], recs["pan"])
