@@ -193,6 +193,10 @@ int  x264gpu_encoder_mb_count(const x264gpu_encoder *enc);
  * x264_macroblock_encode, x264_frame_deblock_row, x264_frame_filter of [x264-upstream]. */
 int  x264gpu_encode_frames(x264gpu_encoder *enc, const uint8_t *d_i420, int slice_type,
                            x264gpu_mb *d_mb, int16_t *d_levels, void *stream);
+/* A9 as a primitive ([x264-upstream] common/deblock.c x264_frame_deblock_row over a whole picture): the in-loop filter alone on
+ * `streams` given pictures (d_i420: I420, width and height multiples of 16) with given macroblock records, through the kernel the
+ * frame pipeline launches; alpha / beta / chroma-qp offsets from the encoder's configuration.  d_out: the filtered pictures. */
+int x264gpu_encoder_deblock_pictures(x264gpu_encoder *e, const uint8_t *d_i420, const x264gpu_mb *d_mb, uint8_t *d_out, void *stream);
 /* copy the reconstructed (deblocked) picture of `stream_idx` out as I420 (for parity tests / PSNR) */
 int  x264gpu_encoder_get_recon(x264gpu_encoder *enc, int stream_idx, uint8_t *d_i420_out, void *stream);
 /* Per-stage device timing for bench.py (HIP events on the caller's stream, no host sync in the timed

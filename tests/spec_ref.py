@@ -422,3 +422,80 @@ def deblock_line(p, q, bs, index_a, index_b, chroma):
         else:
             nq[0] = (2 * q[1] + q[0] + p[1] + 2) >> 2
     return np_, nq
+
+
+# ---- deblocking of a whole picture (8.7, frame macroblocks, P / I slices, 4:2:0) ----
+QPC = list(range(30)) + [29, 30, 31, 32, 32, 33, 34, 34, 35, 35, 36, 36, 37, 37, 37, 38, 38, 38, 39, 39, 39, 39]     # Table 8-15
+_BLK = [[0, 1, 4, 5], [2, 3, 6, 7], [8, 9, 12, 13], [10, 11, 14, 15]]                                                # 4x4 block index of (by, bx)
+
+
+def deblock_picture(Y, U, V, mbs, mbw, mbh, alpha_off_div2, beta_off_div2, chroma_qp_index_offset):
+    """Y [16 mbh, 16 mbw], U / V half size (int arrays, modified in place); mbs: records with fields type (0..2 intra, 4 / 5 inter, 6 skip),
+    qp, nnz (bit per 4x4 luma block), cbp_luma, transform8x8, ref[4], mv[4][2] per 8x8.  Macroblocks in raster order; in each, the
+    vertical edges left to right, then the horizontal edges top to bottom (8.7), luma and both chroma planes."""
+    intra = lambda m: m["type"] <= 2
+
+    def coded(m, bx, by):
+        if m["type"] == 6:
+            return False
+        if m["transform8x8"]:
+            return bool((int(m["cbp_luma"]) >> ((by >> 1) * 2 + (bx >> 1))) & 1)
+        return bool((int(m["nnz"]) >> _BLK[by][bx]) & 1)
+
+    def bs_of(mp, pbx, pby, mq, qbx, qby, mb_edge):
+        if intra(mp) or intra(mq):
+            return 4 if mb_edge else 3
+        if coded(mp, pbx, pby) or coded(mq, qbx, qby):
+            return 2
+        pi, qi = (pby >> 1) * 2 + (pbx >> 1), (qby >> 1) * 2 + (qbx >> 1)
+        if int(mp["ref"][pi]) != int(mq["ref"][qi]):
+            return 1
+        if abs(int(mp["mv"][pi][0]) - int(mq["mv"][qi][0])) >= 4 or abs(int(mp["mv"][pi][1]) - int(mq["mv"][qi][1])) >= 4:
+            return 1
+        return 0
+
+    def filt(plane, x, y, dx, dy, bs, qp_p, qp_q, chroma):
+        """one line of samples across the edge at (x, y): p_i = plane[y - (i+1) dy, x - (i+1) dx], q_i = plane[y + i dy, x + i dx]"""
+        if chroma:
+            qp_p = QPC[min(51, max(0, qp_p + chroma_qp_index_offset))]
+            qp_q = QPC[min(51, max(0, qp_q + chroma_qp_index_offset))]
+        av = (qp_p + qp_q + 1) >> 1
+        ia, ib = min(51, max(0, av + 2 * alpha_off_div2)), min(51, max(0, av + 2 * beta_off_div2))
+        n = 2 if chroma else 4
+        p = [int(plane[y - (i + 1) * dy, x - (i + 1) * dx]) for i in range(n)]
+        q = [int(plane[y + i * dy, x + i * dx]) for i in range(n)]
+        if chroma:
+            p += [0, 0]
+            q += [0, 0]
+        p2, q2 = deblock_line(p, q, bs, ia, ib, chroma)
+        for i in range(n):
+            plane[y - (i + 1) * dy, x - (i + 1) * dx] = p2[i]
+            plane[y + i * dy, x + i * dx] = q2[i]
+
+    for mby in range(mbh):
+        for mbx in range(mbw):
+            m = mbs[mby * mbw + mbx]
+            for vertical in (True, False):
+                for e in range(4):
+                    if e == 0 and (mbx == 0 if vertical else mby == 0):
+                        continue                                    # picture edge
+                    if (e & 1) and m["transform8x8"]:
+                        continue                                    # no 4-sample transform edge inside an 8x8 transform block
+                    for k in range(16):                             # position along the edge
+                        if vertical:
+                            qbx, qby = e, k >> 2
+                            mp = mbs[mby * mbw + mbx - 1] if e == 0 else m
+                            pbx, pby = (3 if e == 0 else e - 1), qby
+                        else:
+                            qbx, qby = k >> 2, e
+                            mp = mbs[(mby - 1) * mbw + mbx] if e == 0 else m
+                            pbx, pby = qbx, (3 if e == 0 else e - 1)
+                        bs = bs_of(mp, pbx, pby, m, qbx, qby, e == 0)
+                        if not bs:
+                            continue
+                        x, y = (16 * mbx + 4 * e, 16 * mby + k) if vertical else (16 * mbx + k, 16 * mby + 4 * e)
+                        filt(Y, x, y, 1 if vertical else 0, 0 if vertical else 1, bs, int(mp["qp"]), int(m["qp"]), False)
+                        if not (e & 1) and not (k & 1):             # chroma: edges 0 and 2 of the luma grid, every second luma position
+                            cx, cy = (8 * mbx + 2 * e, 8 * mby + (k >> 1)) if vertical else (8 * mbx + (k >> 1), 8 * mby + 2 * e)
+                            for pl in (U, V):
+                                filt(pl, cx, cy, 1 if vertical else 0, 0 if vertical else 1, bs, int(mp["qp"]), int(m["qp"]), True)

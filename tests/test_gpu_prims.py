@@ -249,3 +249,55 @@ def test_mc_bipred_avg_and_weight(gpu):
             np.testing.assert_array_equal(out.cpu().numpy(), ref, err_msg=f"weight scale {scale} denom {denom} offset {offset}")
     assert gpu.x264gpu_mc_avg(da.data_ptr(), db.data_ptr(), 6, 32, out.data_ptr(), None) < 0          # not a multiple of four samples
     assert gpu.x264gpu_mc_weight(da.data_ptr(), n, 1, 8, 0, out.data_ptr(), None) < 0                  # log2 denominator is 0..7
+
+
+@pytest.mark.parametrize("alpha,beta,cqo", [(0, 0, 0), (2, -1, -3), (-3, 3, 5)])
+def test_deblock_primitive_vs_the_standard(gpu, alpha, beta, cqo):
+    """A9 on its own: the in-loop filter kernel of the frame pipeline on given pictures + random macroblock records (intra / inter / skip
+    mixes, per-macroblock quantisers, coded-block bits, 8x8 transform flags, two references, vectors around the 4-quarter-sample
+    threshold) against a per-sample restatement of 8.7 (tests/spec_ref.py deblock_picture: bS derivation, edge order, qp averaging,
+    chroma quantiser table — no oracle code involved)"""
+    import torch
+    import spec_ref as S
+    w, h, streams = 96, 64, 2
+    mbw, mbh = w // 16, h // 16
+    rng = np.random.default_rng(100 + alpha * 7 + beta)
+    cfg = O.default_config(w, h, streams=streams, deblock=1, deblock_alpha=alpha, deblock_beta=beta, chroma_qp_offset=cqo)
+    h_ = C.c_void_p()
+    gpu.check(gpu.x264gpu_encoder_create(C.byref(h_), C.byref(cfg)), "create")
+    pics, recs, want = [], [], []
+    for s in range(streams):
+        # blocky pictures: each 4x4 block has its own level near its neighbours' + a little noise, so that every filter branch is reached
+        lvl = np.cumsum(rng.integers(-6, 7, (h // 4, w // 4)), axis=1) + np.cumsum(rng.integers(-5, 6, (h // 4, 1)), axis=0) + 120
+        Y = np.clip(np.kron(lvl, np.ones((4, 4), np.int64)) + rng.integers(-2, 3, (h, w)), 0, 255)
+        U = np.clip(np.kron(lvl[::2, ::2] // 2 + 64, np.ones((4, 4), np.int64)) + rng.integers(-1, 2, (h // 2, w // 2)), 0, 255)
+        V = np.clip(255 - U + rng.integers(-3, 4, U.shape), 0, 255)
+        mbs = np.zeros(mbw * mbh, O.MB_DTYPE)
+        for m in mbs:
+            m["type"] = rng.choice([0, 1, 2, 4, 4, 4, 5, 5, 6, 6])
+            m["qp"] = rng.integers(8, 50)
+            m["transform8x8"] = 1 if m["type"] == 1 else (rng.integers(0, 2) if m["type"] in (4, 5) else 0)
+            m["nnz"] = rng.integers(0, 1 << 16) & rng.integers(0, 1 << 16)
+            m["cbp_luma"] = sum(1 << i for i in range(4) if (int(m["nnz"]) >> (4 * i)) & 15) if m["type"] != 6 else 0
+            if m["type"] >= 4:
+                m["ref"] = rng.integers(0, 2, 4) if m["type"] == 5 else [rng.integers(0, 2)] * 4
+                base = rng.integers(-9, 10, 2)
+                m["mv"] = base + (rng.integers(-4, 5, (4, 2)) if m["type"] == 5 else 0)
+            else:
+                m["ref"] = -1
+            if m["type"] == 6:
+                m["nnz"] = 0
+                m["ref"] = 0
+        pics.append(np.concatenate([Y.reshape(-1), U.reshape(-1), V.reshape(-1)]).astype(np.uint8))
+        recs.append(mbs)
+        S.deblock_picture(Y, U, V, mbs, mbw, mbh, alpha, beta, cqo)
+        want.append(np.concatenate([Y.reshape(-1), U.reshape(-1), V.reshape(-1)]).astype(np.uint8))
+    d_in = torch.from_numpy(np.stack(pics)).cuda()
+    d_mb = torch.from_numpy(np.stack(recs).view(np.uint8).reshape(streams, -1)).cuda()
+    d_out = torch.empty_like(d_in)
+    gpu.check(gpu.x264gpu_encoder_deblock_pictures(h_, d_in.data_ptr(), d_mb.data_ptr(), d_out.data_ptr(), None), "deblock_pictures")
+    got = d_out.cpu().numpy()
+    gpu.x264gpu_encoder_destroy(h_)
+    for s in range(streams):
+        assert not np.array_equal(want[s], pics[s])                  # the filter did something
+        np.testing.assert_array_equal(got[s], want[s], err_msg=f"stream {s}")

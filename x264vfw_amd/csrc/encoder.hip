@@ -349,6 +349,41 @@ __global__ __launch_bounds__(256) void k_get_recon(const uint8_t *__restrict__ l
     }
 }
 
+// I420 pictures -> the reconstruction planes of the slot being built (luma + NV12), one thread per luma sample pair row-wise
+__global__ void k_put_recon(uint8_t *luma00, uint8_t *chroma00, int rs, int w, int h, const uint8_t *__restrict__ in, size_t luma_bytes, size_t cplane_bytes)
+{
+    const int x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y, s = blockIdx.z;
+    const uint8_t *src = in + (size_t)s * (w * h * 3 / 2);
+    uint8_t *l = luma00 + (size_t)s * luma_bytes, *c = chroma00 + (size_t)s * cplane_bytes;
+    if (x < w) l[(size_t)y * rs + x] = src[(size_t)y * w + x];
+    if (y < h / 2 && x < w / 2) {
+        const uint8_t *u = src + (size_t)w * h, *v = u + (size_t)(w / 2) * (h / 2);
+        c[(size_t)y * rs + 2 * x] = u[(size_t)y * (w / 2) + x];
+        c[(size_t)y * rs + 2 * x + 1] = v[(size_t)y * (w / 2) + x];
+    }
+}
+
+// A9 as a primitive: the in-loop filter alone, on `streams` given pictures (I420, width and height multiples of 16) with given macroblock
+// records (types, quantisers, nnz / cbp / transform size, references, vectors), through the same kernel the frame pipeline launches.
+extern "C" int x264gpu_encoder_deblock_pictures(x264gpu_encoder *e, const uint8_t *d_i420, const x264gpu_mb *d_mb, uint8_t *d_out, void *stream)
+{
+    ARG_TRY(e && d_i420 && d_mb && d_out && !(e->cfg.width & 15) && !(e->cfg.height & 15));
+    hipStream_t st = (hipStream_t)stream;
+    const int S = e->cfg.streams;
+    EncK k = e->k;
+    k.rec_luma = e->luma[e->cur]; k.rec_chroma = e->chroma[e->cur];
+    k.mb = const_cast<x264gpu_mb *>(d_mb);
+    uint8_t *l00 = e->luma[e->cur] + (size_t)PAD * k.rs + PAD, *c00 = e->chroma[e->cur] + (size_t)CPAD * k.rs + 2 * CPAD;
+    hipLaunchKernelGGL(k_put_recon, dim3((k.w + 255) / 256, k.h, S), dim3(256), 0, st, l00, c00, k.rs, k.w, k.h, d_i420, k.luma_bytes, k.cplane_bytes);
+    k.wf_progress = e->wf_progress;
+    hipLaunchKernelGGL(k_deblock2<false>, dim3(S), dim3(16 * 64), 0, st, k);
+    for (int s = 0; s < S; s++)
+        hipLaunchKernelGGL(k_get_recon, dim3((k.w + 255) / 256, k.h), dim3(256), 0, st, l00 + (size_t)s * k.luma_bytes, c00 + (size_t)s * k.cplane_bytes, k.rs, k.w, k.h,
+                           d_out + (size_t)s * (k.w * k.h * 3 / 2));
+    HIP_TRY(hipGetLastError());
+    return X264GPU_OK;
+}
+
 extern "C" int x264gpu_encoder_get_recon(x264gpu_encoder *e, int stream_idx, uint8_t *d_out, void *stream)
 {
     ARG_TRY(e && d_out && stream_idx >= 0 && stream_idx < e->cfg.streams && e->have > 0);
