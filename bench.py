@@ -56,6 +56,8 @@ def parse_args():
     ap.add_argument("--cpu-frames", type=int, default=10, help="frames per core of the CPU-baseline sample (0 = skip)")
     ap.add_argument("--e2e-frames", type=int, default=10, help="frames of the single-stream threads-1 end-to-end sample (0 = skip e2e)")
     ap.add_argument("--cpu-frames-all", type=int, default=3, help="frames per core of the every-core leg of the CPU baseline (shorter: it runs one process per core)")
+    ap.add_argument("--content", default="noise", choices=["noise", "smooth"], help="synthetic content: 'noise' (default, the headline) = moving rectangles of per-pixel "
+                    "white noise + strong sensor noise, harder than camera material; 'smooth' = the same scene with band-limited textures and light noise")
     ap.add_argument("--cpu-worker", type=int, default=-1, help=argparse.SUPPRESS)
     return ap.parse_args()
 
@@ -144,7 +146,7 @@ def cpu_baseline(args):
 
 
 # ---------------------------------------------------------------------------------------------------------------------------
-def synth_batch(torch, streams, frames, w, h, seed, device):
+def synth_batch(torch, streams, frames, w, h, seed, device, smooth=False):
     """[frames, streams, w*h*3/2] uint8 I420 on the device: gradient + 3 moving textured rectangles +
     per-pixel noise, generated with torch ops (plumbing only)."""
     g = torch.Generator(device=device)
@@ -157,6 +159,14 @@ def synth_batch(torch, streams, frames, w, h, seed, device):
         base = 90 + 7 * (s % 8)
         grad = (base + xx * 60 // w + yy * 50 // h).to(torch.int16)
         tex = [torch.randint(0, 256, (h // 3, w // 3), generator=g, device=device, dtype=torch.int16) for _ in vel]
+        if smooth:       # band-limited textures: two 7x7 box blurs of the noise, contrast restored
+            F = torch.nn.functional
+            for i, t in enumerate(tex):
+                f = t.float()[None, None]
+                for _ in range(2):
+                    f = F.avg_pool2d(F.pad(f, (3, 3, 3, 3), mode="reflect"), 7, stride=1)
+                f = (f - f.mean()) * 6 + 128
+                tex[i] = f[0, 0].clamp(0, 255).to(torch.int16)
         pos = [(int(torch.randint(0, w, (1,), generator=g, device=device)), int(torch.randint(0, h, (1,), generator=g, device=device))) for _ in vel]
         for n in range(frames):
             y = grad.clone()
@@ -169,14 +179,15 @@ def synth_batch(torch, streams, frames, w, h, seed, device):
                 y[ys.view(-1, 1), xs.view(1, -1)] = 40 + t * 150 // 255
                 u[(ys[::2] // 2).view(-1, 1), (xs[::2] // 2).view(1, -1)] = 100 + t[::2, ::2] * 40 // 255
                 v[(ys[::2] // 2).view(-1, 1), (xs[::2] // 2).view(1, -1)] = 150 - t[::2, ::2] * 40 // 255
-            y = (y + torch.randint(-4, 5, y.shape, generator=g, device=device, dtype=torch.int16)).clamp_(16, 235)
+            na = 1 if smooth else 4
+            y = (y + torch.randint(-na, na + 1, y.shape, generator=g, device=device, dtype=torch.int16)).clamp_(16, 235)
             u = (u + torch.randint(-2, 3, u.shape, generator=g, device=device, dtype=torch.int16)).clamp_(16, 240)
             v = (v + torch.randint(-2, 3, v.shape, generator=g, device=device, dtype=torch.int16)).clamp_(16, 240)
             out[n, s] = torch.cat([y.reshape(-1), u.reshape(-1), v.reshape(-1)]).to(torch.uint8)
     return out
 
 
-def pmc_evidence(kernel_substr, avg_launch_ms, streams_per_launch):
+def pmc_evidence(kernel_substr, avg_launch_ms, streams_per_launch, content):
     """HBM bytes per launch of the dominant kernel and its VALU instruction count from the committed rocprofv3 --pmc passes of this
     command (tools/profile_round.sh -> profiles/r02_pmc_per_launch.json; FETCH_SIZE and WRITE_SIZE in separate passes, KB -> bytes,
     read side doubled as MI355X_MICROARCH.md prescribes for gfx950).  PMC counters cannot be read from inside an un-profiled run, so
@@ -186,6 +197,8 @@ def pmc_evidence(kernel_substr, avg_launch_ms, streams_per_launch):
         return None, None
     tab = json.load(open(path))
     per = tab.get("_workload", {}).get("streams_per_launch")
+    if tab.get("_workload", {}).get("content", "noise") != content:
+        return None, None                                     # counters of another workload say nothing about this one
     key = [k for k in tab if kernel_substr in k]
     key = [k for k in key if "true>" in k] or key          # the macroblock loop has a P-slice and an I-slice instantiation: the timed pictures are P
     if not per or not key:
@@ -328,7 +341,7 @@ def main():
 
     # ---- inputs resident in HBM: a clip of L frames per stream (D distinct sequences replicated over the streams) ----
     D = max(1, min(S, args.distinct))
-    base = synth_batch(torch, D, L, W, H, shard.stream_seed(0x264, gids[0]), dev)
+    base = synth_batch(torch, D, L, W, H, shard.stream_seed(0x264, gids[0]), dev, smooth=args.content == "smooth")
     data = base if D == S else base.repeat(1, (S + D - 1) // D, 1)[:, :S].contiguous()
     del base
 
@@ -383,7 +396,7 @@ def main():
     dom = max(range(nst), key=lambda i: ms[i])
     avg_ms = ms[dom] / max(cnt[dom], 1)
     achieved = alg[names[dom]] * S / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
-    traffic, valu = pmc_evidence("k_mb_slice" if names[dom] == "macroblocks" else names[dom], avg_ms, S)
+    traffic, valu = pmc_evidence("k_mb_slice" if names[dom] == "macroblocks" else names[dom], avg_ms, S, args.content)
     roof = {"bound": "hbm", "kernel": "k_mb_slice (macroblock loop)" if names[dom] == "macroblocks" else names[dom], "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic, "valu": valu,
             "note": "the path is bound by dependent-instruction latency inside a raster-serial macroblock loop, not by HBM: see valu.issue_util and DESIGN.md",
@@ -393,8 +406,8 @@ def main():
            "value": round(fps, 2), "unit": "frames/s", "n_gpus": world, "steps": K, "warmup": Wu,
            "ms_per_step": round(dt / K * 1e3, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
            "dtype": "u8", "data": "synthetic",
-           "config": {"workload": f"{W}x{H} yuv420p, {S} closed-GOP streams/GPU x {K} frames ({n_i} I + {K - n_i} P), CQP {qp_i}/{qp_p}, preset {args.preset} as implemented",
-                      "toolset": tools, "toolset_gaps": TOOLSET_GAPS, "streams_per_gpu": S, "distinct_sequences": D, "clip_frames": L, "frames_per_step": S * world,
+           "config": {"workload": f"{W}x{H} yuv420p, {S} closed-GOP streams/GPU x {K} frames ({n_i} I + {K - n_i} P), CQP {qp_i}/{qp_p}, preset {args.preset} as implemented, content '{args.content}'",
+                      "toolset": tools, "toolset_gaps": TOOLSET_GAPS, "streams_per_gpu": S, "distinct_sequences": D, "clip_frames": L, "content": args.content, "frames_per_step": S * world,
                       "mb_per_frame": ((W + 15) // 16) * ((H + 15) // 16)},
            "roofline": roof}
     if rank == 0:

@@ -1,0 +1,47 @@
+"""Longer randomised parity soak than tests/test_gpu_fuzz.py runs per round: python tools/fuzz_soak.py SEED0 SEED1 [cases per seed].
+Every random case (tests/test_gpu_fuzz.py random_case) is encoded by the HIP pipeline and the oracle; mismatches are listed, not fatal."""
+import os
+import random
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import numpy as np  # noqa: E402
+
+import oracle_lib as O  # noqa: E402
+from gpu_enc import GpuEncoder  # noqa: E402
+from synth import synth_frames  # noqa: E402
+from test_gpu_fuzz import random_case  # noqa: E402
+
+
+def main():
+    s0, s1 = int(sys.argv[1]), int(sys.argv[2])
+    per = int(sys.argv[3]) if len(sys.argv) > 3 else 40
+    bad = total = 0
+    t0 = time.time()
+    for seed in range(s0, s1):
+        rnd = random.Random(seed)
+        for it in range(per):
+            w, h, kw, nfr, fseed, second_idr = random_case(rnd)
+            frames = synth_frames(w, h, nfr, seed=fseed)
+            cfg = O.default_config(w, h, **kw)
+            og, gg = O.OracleEncoder(cfg), GpuEncoder(cfg)
+            total += 1
+            for i, f in enumerate(frames):
+                st = 2 if i == 0 or (i == 3 and second_idr) else 0
+                o_mb, o_lv = og.encode(f, st)
+                g_mb, g_lv = gg.encode([f], st)
+                ok = np.array_equal(g_mb[0].view(np.uint8), o_mb.view(np.uint8)) and np.array_equal(g_lv[0], o_lv) and np.array_equal(gg.recon(0), og.recon())
+                if not ok:
+                    bad += 1
+                    d = np.nonzero((g_mb[0].view(np.uint8).reshape(-1, 64) != o_mb.view(np.uint8).reshape(-1, 64)).any(axis=1))[0]
+                    print(f"MISMATCH seed {seed} case {it}: {w}x{h} {kw} frame {i}: {len(d)} records differ, first MB {d[:1]}", flush=True)
+                    break
+            og.close(); gg.close()
+    print(f"{total} cases, {bad} mismatching, {time.time() - t0:.0f} s")
+
+
+if __name__ == "__main__":
+    main()

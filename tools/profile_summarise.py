@@ -75,7 +75,7 @@ def main():
     # figures for the same workload
     try:
         b = json.loads(open(os.path.join(out, "bench_under_rocprof.json")).read().strip().split("\n")[-1])
-        table["_workload"] = {"streams_per_launch": b["config"]["streams_per_gpu"], "config": b["config"]["workload"], "toolset": b["config"]["toolset"]}
+        table["_workload"] = {"streams_per_launch": b["config"]["streams_per_gpu"], "config": b["config"]["workload"], "toolset": b["config"]["toolset"], "content": b["config"].get("content", "noise")}
         for k, v in table.items():
             if not k.startswith("_"):
                 v["macroblocks_per_launch"] = b["config"]["streams_per_gpu"] * b["config"]["mb_per_frame"]
