@@ -111,6 +111,7 @@ extern const x264_level_t x264_levels[];
 typedef struct x264_param_t {
     unsigned int cpu;                  /* codec.c:1560 ("no asm" -> 0); ignored by the GPU path */
     int i_threads;                     /* G > 1: G closed GOPs of the stream in lock-step (dealt to the visible devices); frames come back (G-1) x keyint calls late, byte-identical */
+    int b_sliced_threads;              /* x264 slice threads (--sliced-threads, --tune zerolatency): i_threads slices per picture, each analysed on its own */
     int b_deterministic;
     int i_width, i_height;             /* codec.c:1470-1471 */
     int i_csp;                         /* codec.c:1472 */

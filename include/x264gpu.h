@@ -180,6 +180,10 @@ typedef struct x264gpu_config {
     int aq_strength_q8;       /* --aq-strength * 1.0397 * 256, rounded (x264 default 1.0 -> 266) */
     int fast_pskip;           /* --no-fast-pskip clears it (x264 default on): P_Skip probed inside the analysis (x264_macroblock_probe_pskip) */
     int mv_range;             /* --mvrange in luma samples, both directions; 0 = 512.  x264 takes it from the level (x264_levels[].mv_range) */
+    int slices;               /* x264 --sliced-threads with --threads N: N slices per picture (0 / 1 = one), slice i = macroblock rows
+                               * [(mbh * i + N/2) / N, (mbh * (i+1) + N/2) / N); every slice is analysed on its own (no prediction across a slice
+                               * boundary, its own fast-intra statistics and quantiser chain) and the loop filter leaves slice boundaries alone
+                               * (disable_deblocking_filter_idc 2), as x264's slice threads do.  At most mbh / 4 ([x264-upstream] validate_parameters) */
 } x264gpu_config;
 
 int  x264gpu_encoder_create(x264gpu_encoder **enc, const x264gpu_config *cfg);

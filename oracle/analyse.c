@@ -79,7 +79,7 @@ static nb_t nb8(const actx *a, int gx, int gy)
 {
     nb_t n = { -2, { 0, 0 } };
     const x264o_encoder *e = a->e;
-    if (gx < 0 || gy < 0 || gx >= 2 * e->mbw || gy >= 2 * e->mbh) return n;
+    if (gx < 0 || gy < 2 * e->row0 || gx >= 2 * e->mbw || gy >= 2 * e->mbh) return n;      /* outside the picture or the slice */
     const int i = (gy >> 1) * e->mbw + (gx >> 1), k = (gy & 1) * 2 + (gx & 1);
     if (i == a->mi) { if (a->cur_valid >> k & 1) return a->cur8[k]; return n; }
     if (i > a->mi) return n;
@@ -932,13 +932,13 @@ static int i4_pred_mode(const actx *a, int b, const uint8_t *cur_modes)
     else if (a->mbx > 0) { const x264gpu_mb *n = &e->mbs[a->mi - 1]; ma = (n->type == X264GPU_MB_I4x4 || n->type == X264GPU_MB_I8x8) ? n->i4_mode[idx_of[by][3]] : 2; }
     else return 2;
     if (by > 0) mb_ = cur_modes[idx_of[by - 1][bx]];
-    else if (a->mby > 0) { const x264gpu_mb *n = &e->mbs[a->mi - e->mbw]; mb_ = (n->type == X264GPU_MB_I4x4 || n->type == X264GPU_MB_I8x8) ? n->i4_mode[idx_of[3][bx]] : 2; }
+    else if (a->mby > e->row0) { const x264gpu_mb *n = &e->mbs[a->mi - e->mbw]; mb_ = (n->type == X264GPU_MB_I4x4 || n->type == X264GPU_MB_I8x8) ? n->i4_mode[idx_of[3][bx]] : 2; }
     else return 2;
     return ma < mb_ ? ma : mb_;
 }
 static int i4_avail(const actx *a, int b)
 {
-    const int bx = blk_x[b], by = blk_y[b], mbx = a->mbx, mby = a->mby;
+    const int bx = blk_x[b], by = blk_y[b], mbx = a->mbx, mby = a->mby - a->e->row0;      /* row within the slice */
     int av = 0;
     if (bx > 0 || mbx > 0) av |= X264O_AVAIL_LEFT;
     if (by > 0 || mby > 0) av |= X264O_AVAIL_TOP;
@@ -949,7 +949,7 @@ static int i4_avail(const actx *a, int b)
 }
 static int i8_avail(const actx *a, int i8)
 {
-    const int x8 = i8 & 1, y8 = i8 >> 1, left = a->mbx > 0, top = a->mby > 0;
+    const int x8 = i8 & 1, y8 = i8 >> 1, left = a->mbx > 0, top = a->mby > a->e->row0;
     int av = 0;
     if (x8 || left) av |= X264O_AVAIL_LEFT;
     if (y8 || top) av |= X264O_AVAIL_TOP;
@@ -984,7 +984,7 @@ static void analyse_intra_chroma(actx *a)
 {
     if (a->satd_chroma < COST_MAX) return;
     x264o_encoder *e = a->e;
-    const int left = a->mbx > 0, top = a->mby > 0;
+    const int left = a->mbx > 0, top = a->mby > a->e->row0;
     const pixel *fuv = e->fenc_uv + (size_t)a->mby * 8 * e->fs + a->mbx * 16;
     const pixel *ruv = chroma_plane(e, e->cur) + (size_t)a->mby * 8 * e->rs + a->mbx * 16;
     pixel fu[64], fv[64], nu[9 * 9], nvv[9 * 9], pu[64], pv[64];
@@ -1013,7 +1013,7 @@ static void analyse_intra_chroma(actx *a)
 static void analyse_intra(actx *a, int i_satd_inter)
 {
     x264o_encoder *e = a->e;
-    const int lambda = a->lambda, qp = a->qp, left = a->mbx > 0, top = a->mby > 0;
+    const int lambda = a->lambda, qp = a->qp, left = a->mbx > 0, top = a->mby > a->e->row0;
     const pixel *fenc = e->fenc_y + (size_t)a->mby * 16 * e->fs + a->mbx * 16;
     pixel *rec = luma_plane(e, e->cur, 0) + (size_t)a->mby * 16 * e->rs + a->mbx * 16;
     const int parts = (e->slice_type == X264GPU_SLICE_I && (e->cfg.partitions & 0x100)) ? (e->cfg.partitions >> 8) & 6 : e->cfg.partitions & 7;
@@ -1153,7 +1153,7 @@ static void analyse_intra(actx *a, int i_satd_inter)
 static void encode_intra_chroma(actx *a, x264gpu_mb *mb, int16_t *lv)
 {
     x264o_encoder *e = a->e;
-    const int left = a->mbx > 0, top = a->mby > 0;
+    const int left = a->mbx > 0, top = a->mby > a->e->row0;
     const pixel *fuv = e->fenc_uv + (size_t)a->mby * 8 * e->fs + a->mbx * 16;
     pixel *ruv = chroma_plane(e, e->cur) + (size_t)a->mby * 8 * e->rs + a->mbx * 16;
     pixel nu[9 * 9], nvv[9 * 9], pu[64], pv[64];
@@ -1239,7 +1239,7 @@ static void encode_inter_mb(actx *a, x264gpu_mb *mb, int16_t *lv)
  * x264_macroblock_analyse + x264_macroblock_encode for macroblock (mbx,mby) */
 static int mb_type_at(const x264o_encoder *e, int mbx, int mby)
 {
-    if (mbx < 0 || mby < 0 || mbx >= e->mbw) return -1;
+    if (mbx < 0 || mby < e->row0 || mbx >= e->mbw) return -1;
     return e->mbs[mby * e->mbw + mbx].type;
 }
 
@@ -1257,7 +1257,7 @@ void x264o_macroblock(x264o_encoder *e, int mbx, int mby)
     a->subme = clampi(e->cfg.subme, 0, 11); a->satd = a->subme > 1;
     a->nref = e->nref;
     a->type_left = mb_type_at(e, mbx - 1, mby); a->type_top = mb_type_at(e, mbx, mby - 1);
-    a->type_tl = mb_type_at(e, mbx - 1, mby - 1); a->type_tr = mby > 0 ? mb_type_at(e, mbx + 1, mby - 1) : -1;
+    a->type_tl = mb_type_at(e, mbx - 1, mby - 1); a->type_tr = mby > e->row0 ? mb_type_at(e, mbx + 1, mby - 1) : -1;
     a->satd_i16 = a->satd_i8 = a->satd_i4 = a->satd_chroma = COST_MAX;
     a->b_early_terminate = a->subme < 11;
     mb->qp = (uint8_t)a->qp;
@@ -1287,10 +1287,11 @@ void x264o_macroblock(x264o_encoder *e, int mbx, int mby)
     }
     /* fast intra decision: intra is unlikely unless a neighbour, the co-located macroblock of reference 0 or a third of the
      * macroblocks coded so far are intra */
-    if (a->b_early_terminate && a->mi > 4) {
+    const int mi_in_slice = a->mi - e->row0 * e->mbw;            /* h->mb.i_mb_xy - h->sh.i_first_mb */
+    if (a->b_early_terminate && mi_in_slice > 4) {
         const int colo = e->mbtype[ref_slot(e, 0)][a->mi];
         if (!(is_intra_type(a->type_left) || is_intra_type(a->type_top) || is_intra_type(a->type_tl) || is_intra_type(a->type_tr) ||
-              is_intra_type(colo) || a->mi < 3 * e->intra_count)) a->b_fast_intra = 1;
+              is_intra_type(colo) || mi_in_slice < 3 * e->intra_count)) a->b_fast_intra = 1;
     }
     a->cur_valid = 0;
     predict_mv_pskip(a, a->pskip_mv);

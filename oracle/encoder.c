@@ -134,8 +134,10 @@ static void compute_mb_qp(x264o_encoder *e, int slice_qp)
 static void settle_mb_qp(x264o_encoder *e, x264gpu_mb *mbs, int slice_qp)
 {
     int last = slice_qp;
-    for (int i = 0; i < e->mbw * e->mbh; i++) {
+    const int ns = e->cfg.slices > 1 ? e->cfg.slices : 1;
+    for (int i = 0, sl = 0; i < e->mbw * e->mbh; i++) {
         x264gpu_mb *m = &mbs[i];
+        if (i == ((e->mbh * sl + ns / 2) / ns) * e->mbw) { last = slice_qp; sl++; }      /* a slice starts from the slice quantiser */
         if (m->type != X264GPU_MB_I16x16 && !m->cbp_luma && !m->cbp_chroma) m->qp = (uint8_t)last;
         /* x264's entropy coders (qp_delta writers): an I16x16 with nothing coded at all (no DC either) does not spend a delta on RAISING
          * the quantiser — it takes the previous one, and that is the qp the loop filter then sees */
@@ -164,6 +166,14 @@ static int edge_bs(const x264gpu_mb *p, int pbx, int pby, const x264gpu_mb *q, i
     return 0;
 }
 
+/* does a slice begin at macroblock row `mby` (x264 slice threads: rows split evenly, validate/threadslice arithmetic) */
+static int slice_starts_at_row(const x264o_encoder *e, int mby)
+{
+    const int ns = e->cfg.slices > 1 ? e->cfg.slices : 1;
+    for (int sl = 1; sl < ns; sl++) if ((e->mbh * sl + ns / 2) / ns == mby) return 1;
+    return 0;
+}
+
 static void deblock_frame(x264o_encoder *e, const x264gpu_mb *mbs)
 {
     int a_off = e->cfg.deblock_alpha * 2, b_off = e->cfg.deblock_beta * 2;   /* slice_alpha_c0_offset_div2 * 2 */
@@ -177,7 +187,7 @@ static void deblock_frame(x264o_encoder *e, const x264gpu_mb *mbs)
                     if ((edge & 1) && q->transform8x8) continue;     /* no transform edge at 4-sample offsets */
                     if (edge == 0) {
                         if (dir == 0) { if (mbx == 0) continue; p = &mbs[mby * e->mbw + mbx - 1]; }
-                        else { if (mby == 0) continue; p = &mbs[(mby - 1) * e->mbw + mbx]; }
+                        else { if (mby == 0 || slice_starts_at_row(e, mby)) continue; p = &mbs[(mby - 1) * e->mbw + mbx]; }      /* idc 2: not across slices */
                     }
                     int qpav = (p->qp + q->qp + 1) >> 1;
                     int qpc_p = x264o_chroma_qp[clampi(p->qp + e->cfg.chroma_qp_offset, 0, 51)];
@@ -236,11 +246,18 @@ int x264o_encoder_encode(x264o_encoder *e, const uint8_t *i420, int slice_type, 
     e->mbs = mbs; e->levels = levels; e->intra_count = 0;
     e->slot_nref[e->cur] = e->nref; e->slot_poc[e->cur] = e->poc; e->slot_ref0poc[e->cur] = e->nref ? e->slot_poc[ref_slot(e, 0)] : 0;
     /* the macroblock loop: raster order, every macroblock analysed AND coded before the next one starts (x264_slice_write) */
-    for (int mby = 0; mby < e->mbh; mby++)
-        for (int mbx = 0; mbx < e->mbw; mbx++) {
-            x264o_macroblock(e, mbx, mby);
-            e->mbtype[e->cur][mby * e->mbw + mbx] = mbs[mby * e->mbw + mbx].type;
-        }
+    const int ns = e->cfg.slices > 1 ? e->cfg.slices : 1;
+    for (int sl = 0; sl < ns; sl++) {
+        /* x264 slice threads: rows split evenly; each thread starts with empty frame statistics (h->stat.frame) */
+        e->row0 = (e->mbh * sl + ns / 2) / ns; e->row1 = (e->mbh * (sl + 1) + ns / 2) / ns;
+        e->intra_count = 0;
+        for (int mby = e->row0; mby < e->row1; mby++)
+            for (int mbx = 0; mbx < e->mbw; mbx++) {
+                x264o_macroblock(e, mbx, mby);
+                e->mbtype[e->cur][mby * e->mbw + mbx] = mbs[mby * e->mbw + mbx].type;
+            }
+    }
+    e->row0 = 0; e->row1 = e->mbh;
     if (e->cfg.aq_mode || e->ext_off_q8) settle_mb_qp(e, mbs, slice_qp);
     if (e->cfg.deblock) deblock_frame(e, mbs);
     filter_frame(e);

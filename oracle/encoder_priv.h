@@ -26,6 +26,7 @@ struct x264o_encoder {
     pixel *chroma[X264O_MAX_SLOTS]; /* padded NV12 */
     int slots;                   /* refs + 1 */
     int nref;                    /* reference pictures usable by the current P slice */
+    int row0, row1;              /* macroblock rows [row0, row1) of the slice being coded (x264 slice threads: cfg.slices per picture) */
     int cur;                     /* DPB slot being reconstructed */
     /* per-picture motion side data living with the DPB slot (x264_frame_t): mv16x16 (= h->mb.mvr[0][0], the 16x16 search result
      * in reference 0 of every macroblock), mb_type, the number of references the picture was coded with, its POC */

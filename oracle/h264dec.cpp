@@ -55,6 +55,7 @@ struct MbInfo {
     int cbp_luma, cbp_chroma, chroma_mode;
     uint32_t cbf;            // coded_block_flag per block: bits 0..15 luma 4x4 (block index), 16..23 chroma AC (plane * 4 + block), 24 luma DC, 25 / 26 chroma DC
     uint8_t amvd[4][2];      // |mvd| per 8x8 block and component
+    int slice;               // number of the slice the macroblock belongs to (availability 6.4.x, deblocking across slice edges)
 };
 
 struct Decoder {
@@ -65,6 +66,7 @@ struct Decoder {
     size_t plane_bytes = 0, cplane_bytes = 0;
     std::vector<pixel> luma[6], chroma[6];   // DPB slots: up to 5 references + the picture being decoded
     int cur = 0, slots = 2, have = 0, num_ref_frames = 1, nref_active = 1;
+    int next_mb = 0, slice_no = 0, pic_disable = 0, pic_a = 0, pic_b = 0;      // slices of the picture being decoded
     int ref_slot(int r) const { return (cur - 1 - r + 2 * slots) % slots; }
     std::vector<MbInfo> mb;
     bool have_sps = false, have_pps = false;
@@ -147,12 +149,14 @@ struct SliceDec {
     Decoder &d;
     BitReader &br;
     int slice_type, qp, disable_deblock, alpha_off, beta_off;
+    int first_mb = 0, slice_no = 0, end_mb = 0;      // first macroblock of this slice, its number in the picture, one past its last macroblock (set by run)
     cabacdec::Engine cd;
     int last_dqp = 0;                // mb_qp_delta of the previous macroblock in decoding order (ctxIdxInc of the first bin)
 
     // ---- CABAC: binarisations + ctxIdxInc derivations (9.3.2, 9.3.3.1) ----
     const MbInfo *nbA(int mbx, int mby) const { return mbx > 0 ? &d.mb[mby * d.mbw + mbx - 1] : nullptr; }
-    const MbInfo *nbB(int mbx, int mby) const { return mby > 0 ? &d.mb[(mby - 1) * d.mbw + mbx] : nullptr; }
+    bool top_ok(int mbx, int mby) const { return mby > 0 && (mby - 1) * d.mbw + mbx >= first_mb; }      // the macroblock above belongs to this slice
+    const MbInfo *nbB(int mbx, int mby) const { return top_ok(mbx, mby) ? &d.mb[(mby - 1) * d.mbw + mbx] : nullptr; }
     static bool is_nxn(const MbInfo &m) { return m.intra && !m.i16; }
     int ca_skip_flag(int mbx, int mby)
     {
@@ -228,7 +232,7 @@ struct SliceDec {
     {
         if (gx < 0 || gy < 0 || gx >= 2 * d.mbw || gy >= 2 * d.mbh) return 0;
         const int i = (gy >> 1) * d.mbw + (gx >> 1), k = (gy & 1) * 2 + (gx & 1);
-        if (i > cur_idx) return 0;
+        if (i > cur_idx || i < first_mb) return 0;                          // not decoded yet / another slice
         if (i == cur_idx) return (refs_known >> k & 1) && cur_refs[k] > 0;
         const MbInfo &m = d.mb[i];
         return !m.intra && !m.skip && m.ref8[k] > 0;
@@ -243,7 +247,7 @@ struct SliceDec {
     {
         if (gx < 0 || gy < 0 || gx >= 2 * d.mbw || gy >= 2 * d.mbh) return 0;
         const int i = (gy >> 1) * d.mbw + (gx >> 1), k = (gy & 1) * 2 + (gx & 1);
-        if (i > cur_idx || (i == cur_idx && !(known8 >> k & 1))) return 0;
+        if (i < first_mb || i > cur_idx || (i == cur_idx && !(known8 >> k & 1))) return 0;
         return d.mb[i].amvd[k][comp];
     }
     int ca_mvd(int gx, int gy, int comp)
@@ -335,7 +339,7 @@ struct SliceDec {
         if (bx > 0) na = d.mb[mby * d.mbw + mbx].tc[kIdxOf[by][bx - 1]];
         else if (mbx > 0) na = d.mb[mby * d.mbw + mbx - 1].tc[kIdxOf[by][3]];
         if (by > 0) nb = d.mb[mby * d.mbw + mbx].tc[kIdxOf[by - 1][bx]];
-        else if (mby > 0) nb = d.mb[(mby - 1) * d.mbw + mbx].tc[kIdxOf[3][bx]];
+        else if (top_ok(mbx, mby)) nb = d.mb[(mby - 1) * d.mbw + mbx].tc[kIdxOf[3][bx]];
         return na >= 0 && nb >= 0 ? (na + nb + 1) >> 1 : na >= 0 ? na : nb >= 0 ? nb : 0;
     }
     int nc_chroma(int mbx, int mby, int c, int i)
@@ -344,7 +348,7 @@ struct SliceDec {
         if (bx > 0) na = d.mb[mby * d.mbw + mbx].tc[base + by * 2];
         else if (mbx > 0) na = d.mb[mby * d.mbw + mbx - 1].tc[base + by * 2 + 1];
         if (by > 0) nb = d.mb[mby * d.mbw + mbx].tc[base + bx];
-        else if (mby > 0) nb = d.mb[(mby - 1) * d.mbw + mbx].tc[base + 2 + bx];
+        else if (top_ok(mbx, mby)) nb = d.mb[(mby - 1) * d.mbw + mbx].tc[base + 2 + bx];
         return na >= 0 && nb >= 0 ? (na + nb + 1) >> 1 : na >= 0 ? na : nb >= 0 ? nb : 0;
     }
 
@@ -355,7 +359,7 @@ struct SliceDec {
         Nb n = { false, -1, 0, 0 };
         if (gx < 0 || gy < 0 || gx >= 2 * d.mbw || gy >= 2 * d.mbh) return n;
         int i = (gy >> 1) * d.mbw + (gx >> 1), k = (gy & 1) * 2 + (gx & 1);
-        if (i > cur_idx || (i == cur_idx && !(known8 >> k & 1))) return n;
+        if (i < first_mb || i > cur_idx || (i == cur_idx && !(known8 >> k & 1))) return n;      // another slice, or not decoded yet
         n.avail = true;
         const MbInfo &m = d.mb[i];
         if (!m.intra) { n.ref = m.ref8[k]; n.mvx = m.mv8[k][0]; n.mvy = m.mv8[k][1]; }
@@ -458,10 +462,11 @@ struct SliceDec {
     int i4_avail(int mbx, int mby, int b)
     {
         int bx = kBlkX[b], by = kBlkY[b], a = 0;
+        const bool top = top_ok(mbx, mby), tl = mbx > 0 && top_ok(mbx - 1, mby), tr = mbx + 1 < d.mbw && top_ok(mbx + 1, mby);
         if (bx > 0 || mbx > 0) a |= X264O_AVAIL_LEFT;
-        if (by > 0 || mby > 0) a |= X264O_AVAIL_TOP;
-        if ((bx > 0 || mbx > 0) && (by > 0 || mby > 0)) a |= X264O_AVAIL_TOPLEFT;
-        if (by == 0) { if (mby > 0 && (bx < 3 || mbx + 1 < d.mbw)) a |= X264O_AVAIL_TOPRIGHT; }
+        if (by > 0 || top) a |= X264O_AVAIL_TOP;
+        if (bx > 0 ? (by > 0 || top) : by > 0 ? mbx > 0 : tl) a |= X264O_AVAIL_TOPLEFT;
+        if (by == 0) { if (bx < 3 ? top : tr) a |= X264O_AVAIL_TOPRIGHT; }
         else if (bx < 3 && kIdxOf[by - 1][bx + 1] < b) a |= X264O_AVAIL_TOPRIGHT;
         return a;
     }
@@ -472,7 +477,7 @@ struct SliceDec {
         else if (mbx > 0) { const MbInfo &n = d.mb[mby * d.mbw + mbx - 1]; ma = n.intra && !n.i16 ? n.i4mode[kIdxOf[by][3]] : 2; }
         else return 2;
         if (by > 0) mb_ = cur.i4mode[kIdxOf[by - 1][bx]];
-        else if (mby > 0) { const MbInfo &n = d.mb[(mby - 1) * d.mbw + mbx]; mb_ = n.intra && !n.i16 ? n.i4mode[kIdxOf[3][bx]] : 2; }
+        else if (top_ok(mbx, mby)) { const MbInfo &n = d.mb[(mby - 1) * d.mbw + mbx]; mb_ = n.intra && !n.i16 ? n.i4mode[kIdxOf[3][bx]] : 2; }
         else return 2;
         return ma < mb_ ? ma : mb_;
     }
@@ -480,7 +485,7 @@ struct SliceDec {
     void intra_mb(int mbx, int mby, int mbtype /* I-slice numbering */, MbInfo &m)
     {
         pixel *rec = d.Y(d.cur) + (size_t)mby * 16 * d.stride + mbx * 16;
-        int left = mbx > 0, top = mby > 0;
+        int left = mbx > 0, top = top_ok(mbx, mby);
         m.intra = 1; for (int k = 0; k < 4; k++) { m.ref8[k] = -1; m.mv8[k][0] = m.mv8[k][1] = 0; }
         int cbp_luma = 0, cbp_chroma = 0, i16mode = 0;
         if (mbtype == 0) {
@@ -686,12 +691,13 @@ struct SliceDec {
     void run_cabac()
     {
         const int n = d.mbw * d.mbh;
-        for (auto &m : d.mb) m = MbInfo();
         while (br.pos & 7) if (!br.get1()) { br.err = true; return; }          // cabac_alignment_one_bit
         cd.start(br.p, br.n, br.pos, slice_type == 0, qp);
-        for (int i = 0; i < n && !cd.err && !br.err; i++) {
+        end_mb = -1;
+        for (int i = first_mb; i < n && !cd.err && !br.err; i++) {
             const int mbx = i % d.mbw, mby = i / d.mbw;
             cur_idx = i; known8 = 0;
+            d.mb[i] = MbInfo(); d.mb[i].slice = slice_no;
             if (slice_type == 0 && ca_skip_flag(mbx, mby)) { skipped_mb(i); last_dqp = 0; }
             else {
                 MbInfo &m = d.mb[i];
@@ -699,21 +705,20 @@ struct SliceDec {
                 if (slice_type == 0 && t <= 3) inter_mb(mbx, mby, t, m);
                 else intra_mb(mbx, mby, slice_type == 0 ? t - 5 : t, m);
             }
-            const int end = cd.terminate();
-            if (end != (i == n - 1)) { br.err = true; return; }                  // one slice per picture: the flag is set exactly at the last macroblock
+            if (cd.terminate()) { end_mb = i + 1; break; }                       // end_of_slice_flag
         }
-        if (cd.err) br.err = true;
+        if (cd.err || end_mb < 0) br.err = true;                                 // the picture ended without the flag
     }
     void run()
     {
         if (d.cabac) { run_cabac(); return; }
-        int n = d.mbw * d.mbh, i = 0;
-        for (auto &m : d.mb) m = MbInfo();
+        int n = d.mbw * d.mbh, i = first_mb;
         while (i < n && !br.err) {
             if (slice_type == 0) {
                 int run = (int)br.ue();
                 while (run-- && i < n) {
                     MbInfo &m = d.mb[i];
+                    m = MbInfo(); m.slice = slice_no;
                     int mbx = i % d.mbw, mby = i / d.mbw, px, py;
                     cur_idx = i; known8 = 0;
                     skip_mv(mbx, mby, px, py);
@@ -725,13 +730,16 @@ struct SliceDec {
                 if (i >= n || !br.more_rbsp_data()) break;
             }
             MbInfo &m = d.mb[i];
+            m = MbInfo(); m.slice = slice_no;
             int mbx = i % d.mbw, mby = i / d.mbw;
             int t = (int)br.ue();
             cur_idx = i; known8 = 0;
             if (slice_type == 0) { if (t <= 3) inter_mb(mbx, mby, t, m); else if (t >= 5) intra_mb(mbx, mby, t - 5, m); else br.err = true; }
             else intra_mb(mbx, mby, t, m);
             i++;
+            if (!br.more_rbsp_data()) break;
         }
+        end_mb = i;
     }
 
     // ---- deblocking (8.7), written from the clause; filters come from oracle/deblock.c ----
@@ -757,6 +765,7 @@ struct SliceDec {
                         if (e == 0) {
                             if (vert) { if (!mbx) continue; p = &d.mb[mby * d.mbw + mbx - 1]; }
                             else { if (!mby) continue; p = &d.mb[(mby - 1) * d.mbw + mbx]; }
+                            if (disable_deblock == 2 && p->slice != q.slice) continue;      // not across slice boundaries
                         }
                         int qpav = (p->qp + q.qp + 1) >> 1;
                         int qpcav = (x264o_chroma_qp[clampi(p->qp + d.chroma_qp_offset, 0, 51)] + x264o_chroma_qp[clampi(q.qp + d.chroma_qp_offset, 0, 51)] + 1) >> 1;
@@ -861,13 +870,14 @@ bool decode_nal(Decoder &d, const uint8_t *nal, size_t n)
     }
     if (type == 1 || type == 5) {
         if (!d.have_sps || !d.have_pps) return false;
-        if (br.ue() != 0) return false;                     // first_mb_in_slice
+        const int first_mb = (int)br.ue();                  // first_mb_in_slice: slices arrive in order and tile the picture
+        if (first_mb != d.next_mb || first_mb >= d.mbw * d.mbh) return false;
         int st = (int)br.ue() % 5;
         if (st != 0 && st != 2) return false;
         br.ue();
         br.get(d.log2_max_frame_num);
         if (type == 5) br.ue();
-        if (type == 5) d.have = 0;                          // IDR empties the DPB
+        if (type == 5 && first_mb == 0) d.have = 0;         // IDR empties the DPB
         d.nref_active = d.num_ref_default;
         if (st == 0) {
             if (br.get1()) d.nref_active = (int)br.ue() + 1; // num_ref_idx_active_override_flag
@@ -880,10 +890,17 @@ bool decode_nal(Decoder &d, const uint8_t *nal, size_t n)
         int disable = 0, a = 0, b = 0;
         if (d.deblock_ctrl) { disable = (int)br.ue(); if (disable != 1) { a = 2 * br.se(); b = 2 * br.se(); } }
         SliceDec sd{ d, br, st, qp, disable, a, b };
+        sd.first_mb = first_mb; sd.slice_no = d.slice_no++;
+        if (first_mb) { if (disable != d.pic_disable || a != d.pic_a || b != d.pic_b) return false; }      // one filter setting per picture in this checker
+        else { d.pic_disable = disable; d.pic_a = a; d.pic_b = b; }
         sd.run();
-        if (br.err) return false;
-        sd.deblock();
-        finish_picture(d);
+        if (br.err || sd.end_mb <= first_mb) return false;
+        d.next_mb = sd.end_mb;
+        if (d.next_mb == d.mbw * d.mbh) {                   // the picture is complete
+            sd.deblock();
+            finish_picture(d);
+            d.next_mb = 0; d.slice_no = 0;
+        }
         return true;
     }
     return true;     // SEI, AUD, ... ignored

@@ -45,7 +45,7 @@ LOGFN = C.CFUNCTYPE(None, C.c_void_p, _i, C.c_char_p, C.c_void_p)
 
 
 class Param(C.Structure):
-    _fields_ = [("cpu", C.c_uint), ("i_threads", _i), ("b_deterministic", _i), ("i_width", _i), ("i_height", _i), ("i_csp", _i),
+    _fields_ = [("cpu", C.c_uint), ("i_threads", _i), ("b_sliced_threads", _i), ("b_deterministic", _i), ("i_width", _i), ("i_height", _i), ("i_csp", _i),
                 ("i_level_idc", _i), ("i_frame_total", _i), ("i_nal_hrd", _i), ("vui", Vui), ("i_frame_reference", _i),
                 ("i_keyint_max", _i), ("i_keyint_min", _i), ("i_scenecut_threshold", _i), ("b_intra_refresh", _i), ("i_bframe", _i),
                 ("i_bframe_adaptive", _i), ("i_bframe_bias", _i), ("i_bframe_pyramid", _i), ("b_open_gop", _i), ("b_bluray_compat", _i),
@@ -98,6 +98,7 @@ _sig("x264_encoder_close", None, [C.c_void_p])
 _sig("x264host_write_slice", _i, [_i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, C.c_void_p, C.c_void_p, C.c_void_p, _i, C.POINTER(_i)])
 _sig("x264host_write_headers", _i, [_i, _i, _i, _i, _i, _i, C.c_uint32, C.c_uint32, _i, _i, C.c_void_p, _i])
 _sig("x264host_write_slice_cabac", _i, [_i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, C.c_void_p, C.c_void_p, C.c_void_p, _i, C.POINTER(_i)])
+_sig("x264host_write_picture", _i, [_i] * 15 + [C.c_void_p, C.c_void_p, C.c_void_p, _i, C.POINTER(_i)])
 _sig("x264host_write_headers_cabac", _i, [_i, _i, _i, _i, _i, _i, C.c_uint32, C.c_uint32, _i, _i, _i, C.c_void_p, _i])
 _sig("x264host_get_recon", _i, [C.c_void_p, C.c_void_p])
 _sig("x264host_last_decision", _i, [C.c_void_p, C.POINTER(_i), C.POINTER(_i), C.POINTER(C.c_int32)])
@@ -115,11 +116,16 @@ def write_headers(w, h, level=40, log2_max_frame_num=8, pic_init_qp=23, cqo=0, t
 
 
 def write_slice(mbw, mbh, slice_type, qp, pic_init_qp, frame_num, log2_max_frame_num, idr, idr_pic_id, disable_deblock, mbs, lv,
-                num_ref=1, num_ref_default=1, t8x8=0, cabac=0):
+                num_ref=1, num_ref_default=1, t8x8=0, cabac=0, slices=1):
     buf = np.zeros(max(1 << 16, mbs.size * 1200), np.uint8)
     sk = _i()
     mbs = np.ascontiguousarray(mbs)
     lv = np.ascontiguousarray(lv)
+    if slices > 1:           # the picture as several slices (x264 slice threads), one NAL each
+        n = H.x264host_write_picture(mbw, mbh, slice_type, qp, pic_init_qp, frame_num, log2_max_frame_num, idr, idr_pic_id, disable_deblock, num_ref, num_ref_default,
+                                     t8x8, cabac, slices, mbs.ctypes.data, lv.ctypes.data, buf.ctypes.data, buf.size, C.byref(sk))
+        assert n > 0
+        return bytes(buf[:n]), sk.value
     n = (H.x264host_write_slice_cabac if cabac else H.x264host_write_slice)(mbw, mbh, slice_type, qp, pic_init_qp, frame_num, log2_max_frame_num, idr, idr_pic_id,
                                disable_deblock, num_ref, num_ref_default, t8x8, mbs.ctypes.data, lv.ctypes.data, buf.ctypes.data, buf.size,
                                C.byref(sk))

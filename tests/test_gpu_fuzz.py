@@ -22,6 +22,8 @@ def random_case(rnd):
               qp_i=rnd.randint(0, 51), qp_p=rnd.randint(0, 51), deblock=rnd.randint(0, 1), dct_decimate=rnd.randint(0, 1),
               deblock_alpha=rnd.randint(-3, 3), deblock_beta=rnd.randint(-3, 3), chroma_qp_offset=rnd.randint(-6, 6),
               fast_pskip=rnd.randint(0, 1), mv_range=rnd.choice([0, 0, 32, 64, 128, 512]))
+    if rnd.random() < 0.25 and (h + 15) // 16 >= 8:
+        kw["slices"] = rnd.randint(2, (h + 15) // 16 // 4)        # x264 slice threads
     return w, h, kw, rnd.randint(2, 6), rnd.randint(0, 10 ** 6), rnd.random() < 0.3
 
 

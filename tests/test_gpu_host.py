@@ -475,3 +475,46 @@ def test_random_option_mixes_stay_decodable(gpu):
         assert len(dec) == nfr, tag
         if got_rec:
             np.testing.assert_array_equal(dec[-1], rec, err_msg=tag)
+
+
+@pytest.mark.parametrize("w,h,opts,slices", [(176, 288, {"qp": 26, "keyint": 5, "no-scenecut": None, "sliced-threads": None, "threads": 3}, 3),
+                                            (96, 336, {"qp": 30, "keyint": 250, "no-scenecut": None, "tune-sliced": None}, 5),
+                                            (208, 144, {"qp": 24, "keyint": 4, "no-scenecut": None, "sliced-threads": None, "threads": 9}, 2)])
+def test_sliced_threads_through_the_api(gpu, w, h, opts, slices):
+    """x264's slice threads (--sliced-threads --threads N, what --tune zerolatency switches on): N slices per picture, every slice its own
+    wavefront on the device and its own NAL.  Zero delay; the stream decodes to the encoder's reconstruction; the oracle pipeline with the
+    same slice count gives the same pictures; more slices than one per four macroblock rows are cut back (x264 validate_parameters)"""
+    opts = dict(opts)
+    preset_tune = None
+    if "tune-sliced" in opts:          # sliced threads from the tune, slice count "auto" = as many as the picture allows
+        del opts["tune-sliced"]
+        preset_tune = b"zerolatency"
+    p = HL.Param()
+    assert H.x264_param_default_preset(C.byref(p), b"medium", preset_tune) == 0
+    p.i_width, p.i_height, p.i_csp = w, h, HL.X264_CSP_I420
+    p.i_fps_num, p.i_fps_den = 25, 1
+    p.i_log_level = -1
+    for k, v in opts.items():
+        assert H.x264_param_parse(C.byref(p), k.encode(), None if v is None else str(v).encode()) == 0, k
+    p.b_vfr_input = 0
+    p.b_annexb, p.b_repeat_headers = 1, 1
+    assert H.x264_param_apply_profile(C.byref(p), b"high") == 0
+    h_ = H.x264_encoder_open_157(C.byref(p))
+    assert h_
+    eff = HL.Param()
+    H.x264_encoder_parameters(h_, C.byref(eff))
+    assert eff.b_sliced_threads == 1
+    nfr = 6
+    frames = synth_frames(w, h, nfr, seed=77 + w)
+    stream, info, recons = encode_all(h_, w, h, frames)
+    H.x264_encoder_close(h_)
+    for i, (_, _, _, types) in enumerate(info):
+        assert sum(1 for t in types if t in (1, 5)) == slices, (i, types)      # one slice NAL per slice, every call returns its picture
+    dec = O.h264_decode(stream, nfr, w, h)
+    og = O.OracleEncoder(O.default_config(w, h, slices=slices, partitions=7, refs=3, dct8x8=1, chroma_me=1, mixed_refs=1, subme=5, qp_i=max(0, opts["qp"] - 3), qp_p=opts["qp"],
+                                          mv_range=eff.analyse.i_mv_range))
+    keyint = opts["keyint"]
+    for i, f in enumerate(frames):
+        np.testing.assert_array_equal(dec[i], recons[i], err_msg=f"decoded picture {i}")
+        og.encode(f, 2 if i % keyint == 0 else 0)
+        np.testing.assert_array_equal(og.recon(), recons[i], err_msg=f"oracle pipeline picture {i}")

@@ -92,6 +92,11 @@ def compare(tag, mbw, g_mb, o_mb, g_lv, o_lv, g_rec, o_rec):
     (176, 144, 4, dict(subme=3, partitions=3, refs=2)),                      # subme 3 / 4: quarter-pel predictors, fewer refinement steps
     (176, 144, 4, dict(subme=4, partitions=7, dct8x8=1, refs=3, mixed_refs=1)),
     (96, 80, 5, dict(subme=0, partitions=3, refs=3, mixed_refs=1)),          # full-pel only with partitions
+    (176, 144, 4, dict(slices=2, partitions=3, refs=2)),                     # x264 slice threads: slices analysed on their own, no filtering across them
+    (96, 208, 5, dict(slices=3, partitions=7, dct8x8=1, refs=3, mixed_refs=1, chroma_me=1, subme=5)),
+    (64, 272, 4, dict(slices=4, aq_mode=1, partitions=7, dct8x8=1, qp_i=30, qp_p=34)),
+    (352, 288, 4, dict(slices=4, me_method=2, partitions=3, refs=2)),
+    (48, 336, 4, dict(slices=5, partitions=3, refs=2, qp_i=12, qp_p=15, dct_decimate=0, me_method=3, me_range=8)),
 ])
 def test_pipeline_bitexact(gpu, w, h, nfr, kw):
     from gpu_enc import GpuEncoder

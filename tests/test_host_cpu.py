@@ -142,6 +142,38 @@ def test_entropy_closed_loop(w, h, kw, cabac):
         np.testing.assert_array_equal(dec[i], recons[i], err_msg=f"picture {i}")
 
 
+@pytest.mark.parametrize("cabac", [0, 1])
+@pytest.mark.parametrize("w,h,slices,kw", [(176, 144, 2, dict(partitions=3, refs=2)), (96, 208, 3, dict(partitions=7, dct8x8=1, refs=3, mixed_refs=1, chroma_me=1, subme=5)),
+                                          (64, 272, 4, dict(aq_mode=1, partitions=7, dct8x8=1, qp_i=30, qp_p=34)), (208, 128, 2, dict(deblock=0, subme=2)),
+                                          (48, 336, 5, dict(partitions=3, refs=2, qp_i=12, qp_p=15, dct_decimate=0))])
+def test_sliced_pictures_closed_loop(w, h, slices, kw, cabac):
+    """x264's slice threads: N slices per picture, each analysed on its own (nothing above the slice's first row is available, own fast-intra
+    statistics and quantiser chain) and written as its own NAL with disable_deblocking_filter_idc 2: oracle records -> host writers ->
+    checker decoder (slice-membership availability, no filtering across slice edges) == oracle reconstruction"""
+    nfr = 5
+    frames = synth_frames(w, h, nfr, seed=3 * w + h)
+    cfg = O.default_config(w, h, slices=slices, **kw)
+    enc, one = O.OracleEncoder(cfg), O.OracleEncoder(O.default_config(w, h, **kw))
+    mbw, mbh = (w + 15) // 16, (h + 15) // 16
+    stream = HL.write_headers(w, h, pic_init_qp=cfg.qp_p, num_ref=cfg.refs, t8x8=cfg.dct8x8, cabac=cabac)
+    recons, differs = [], False
+    for i, f in enumerate(frames):
+        idr = i == 0
+        mbs, lv = enc.encode(f, 2 if idr else 0)
+        m1, _ = one.encode(f, 2 if idr else 0)
+        differs |= not np.array_equal(mbs.view(np.uint8), m1.view(np.uint8))
+        s, _ = HL.write_slice(mbw, mbh, 2 if idr else 0, cfg.qp_i if idr else cfg.qp_p, cfg.qp_p, i, 8, int(idr), 0,
+                              0 if cfg.deblock else 1, mbs, lv, num_ref=max(1, min(cfg.refs, i)), num_ref_default=cfg.refs, t8x8=cfg.dct8x8, cabac=cabac, slices=slices)
+        assert s.count(b"\x00\x00\x01") >= slices                 # one NAL per slice
+        stream += s
+        recons.append(enc.recon())
+    assert differs                                                    # slicing changes decisions (it must: predictions stop at slice edges)
+    dec = O.h264_decode(stream, nfr, w, h)
+    assert len(dec) == nfr
+    for i in range(nfr):
+        np.testing.assert_array_equal(dec[i], recons[i], err_msg=f"picture {i}")
+
+
 def test_cavlc_static_sequence_uses_skip():
     w, h = 96, 64
     f = synth_frames(w, h, 1, seed=5)[0]

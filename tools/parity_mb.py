@@ -34,6 +34,7 @@ CASES = [
     (176, 144, 4, dict(partitions=3, subme=9, refs=2)),
     (96, 80, 5, dict(partitions=7, dct8x8=1, refs=4, mixed_refs=1, subme=5, chroma_me=1, qp_i=36, qp_p=40)),
     (176, 144, 8, dict(partitions=7, dct8x8=1, refs=5, mixed_refs=1, subme=5, chroma_me=1, qp_i=27, qp_p=30)),
+    (352, 288, 4, dict(slices=4, partitions=7, dct8x8=1, refs=3, mixed_refs=1, subme=5, chroma_me=1)),
     (96, 80, 4, dict(partitions=7, dct8x8=1, qp_i=8, qp_p=10, dct_decimate=0)),
     (176, 144, 4, dict(me_method=2)),
     (352, 288, 4, dict(me_method=2, partitions=3, refs=2, chroma_me=1, subme=5)),

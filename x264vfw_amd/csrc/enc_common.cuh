@@ -57,6 +57,7 @@ struct EncK {
     int temporal;             // reference 0 was itself a P picture: its 16x16 vectors are search candidates
     const int16_t *lowres_mv; // optional [streams][nmb][2] lookahead vectors (x264 lowres_mvs[0][0]); first entry 0x7fff = absent
     int fast_pskip, mv_range;
+    int slices;               // x264 slice threads: slices per picture (rows split evenly), 1 = one
     unsigned long long *prof; // MB_PROF builds only: [streams][16] cycle counters of the macroblock loop's phases (null otherwise)
 };
 // the slice quantiser of stream s
@@ -76,6 +77,12 @@ __device__ __forceinline__ const uint8_t *ref_chroma00(const EncK &k, int s, int
     return k.ref_chroma[r] + (size_t)s * k.cplane_bytes + (size_t)CPAD * k.rs + 2 * CPAD;
 }
 // bits of ref_idx te(v) with nref active references
+// x264 slice threads split the macroblock rows evenly: does a slice (other than the first) begin at row mby
+__device__ __forceinline__ bool slice_starts_at_row(const EncK &k, int mby)
+{
+    for (int sl = 1; sl < k.slices; sl++) if ((k.mbh * sl + k.slices / 2) / k.slices == mby) return true;
+    return false;
+}
 __device__ __forceinline__ int ref_bits(int nref, int r) { return nref <= 1 ? 0 : nref == 2 ? 1 : 2 * (31 - __builtin_clz(r + 1)) + 1; }
 __device__ __forceinline__ uint8_t *rec_chroma00(const EncK &k, int s)
 {

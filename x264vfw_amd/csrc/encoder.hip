@@ -97,6 +97,7 @@ int x264gpu_encoder_create(x264gpu_encoder **out, const x264gpu_config *cfg)
     ARG_TRY(out && cfg);
     ARG_TRY(cfg->width >= 16 && cfg->height >= 16 && !(cfg->width & 1) && !(cfg->height & 1) && cfg->streams >= 1);
     ARG_TRY(cfg->qp_i >= 0 && cfg->qp_i <= 51 && cfg->qp_p >= 0 && cfg->qp_p <= 51 && cfg->refs >= 1 && cfg->refs <= 5);
+    ARG_TRY(cfg->slices >= 0 && (cfg->slices <= 1 || cfg->slices <= (cfg->height + 15) / 16 / 4));      // x264 slice threads: at least four macroblock rows each
     ARG_TRY(cfg->width <= 4096 && cfg->height <= 2304 && cfg->me_range >= 4 && cfg->me_range <= (cfg->me_method == 2 ? 64 : 16));
     ARG_TRY(cfg->me_method >= 0 && cfg->me_method <= 3);
     x264gpu_encoder *e = new (std::nothrow) x264gpu_encoder();
@@ -115,6 +116,7 @@ int x264gpu_encoder_create(x264gpu_encoder **out, const x264gpu_config *cfg)
     k.luma_bytes = 4 * k.plane_bytes;
     k.cplane_bytes = (size_t)k.rs * (k.ch / 2 + 2 * CPAD);
     k.me_range = cfg->me_range; k.subme = cfg->subme; k.dct_decimate = cfg->dct_decimate;
+    k.slices = cfg->slices > 1 ? cfg->slices : 1;
     k.partitions = cfg->partitions; k.chroma_qp_offset = cfg->chroma_qp_offset; k.dct8x8 = cfg->dct8x8; k.me_method = cfg->me_method; k.chroma_me = cfg->chroma_me != 0; k.mixed_refs = cfg->mixed_refs != 0;
     k.alpha_off = cfg->deblock_alpha * 2; k.beta_off = cfg->deblock_beta * 2;
     const size_t S = (size_t)cfg->streams;
@@ -302,7 +304,7 @@ int x264gpu_encode_frames(x264gpu_encoder *e, const uint8_t *d_i420, int slice_t
     mask |= 2;
     STAGE_MARK(2);
     STAGE_MARK(3);
-    if (aq) { hipLaunchKernelGGL(k_settle_qp, dim3(S), dim3(64), 0, st, k); mask |= 8; }      // QP_Y inheritance before the deblocking filter reads the records
+    if (aq) { hipLaunchKernelGGL(k_settle_qp, dim3(S, k.slices > 1 ? k.slices : 1), dim3(64), 0, st, k); mask |= 8; }      // QP_Y inheritance before the deblocking filter reads the records
     STAGE_MARK(4);
     // Few streams in flight (single-stream latency): the rows of ONE picture are dealt to several workgroups with row counters in global
     // memory and agent-scope hand-offs.  All workgroups of a launch must be resident at once: streams x workgroups <= 128.

@@ -145,7 +145,8 @@ __device__ void deblock_mb_pair(const EncK &k, Deblock2Lds &L, int wave, int lan
     bool work = false;
     {
         const int dir = l32 >> 4, edge = (l32 >> 2) & 3, seg = l32 & 3;
-        const bool skip_edge = ((edge & 1) && Q->transform8x8) || (edge == 0 && (dir == 0 ? cmbx == 0 : cmby == 0));
+        // with several slices per picture the filter stops at slice boundaries (disable_deblocking_filter_idc 2, as x264's slice threads code it)
+        const bool skip_edge = ((edge & 1) && Q->transform8x8) || (edge == 0 && (dir == 0 ? cmbx == 0 : (cmby == 0 || slice_starts_at_row(k, cmby))));
         bool any = false;
         if (act && !skip_edge) {
             const x264gpu_mb *P = edge == 0 ? &L.rec[wave][hf][dir == 0 ? 1 : 2] : Q;

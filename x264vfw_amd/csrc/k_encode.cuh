@@ -83,11 +83,13 @@ __global__ __launch_bounds__(64) void k_settle_qp(EncK k)
     // "min(mine, previous)" (an I16x16 with nothing coded, DC included, never RAISES the quantiser: x264's qp_delta writers).  Those
     // compose — (is_const, v) with previous == min(255, .) — so a wave scan settles 64 macroblocks per step
     const int lane = threadIdx.x, s = blockIdx.x;
+    // one wave per (stream, slice): the chain starts from the slice quantiser at every slice
+    const int nsl = k.slices > 1 ? k.slices : 1, mb0 = ((k.mbh * (int)blockIdx.y + nsl / 2) / nsl) * k.mbw, mb1 = ((k.mbh * ((int)blockIdx.y + 1) + nsl / 2) / nsl) * k.mbw;
     x264gpu_mb *mbs = k.mb + (size_t)s * k.nmb;
     int carry = slice_qp(k, s);
-    for (int base = 0; base < k.nmb; base += 64) {
+    for (int base = mb0; base < mb1; base += 64) {
         const int i = base + lane;
-        const bool in = i < k.nmb;
+        const bool in = i < mb1;
         int v = 255;
         bool cst = false;
         if (in) {
@@ -103,7 +105,7 @@ __global__ __launch_bounds__(64) void k_settle_qp(EncK k)
         }
         const int settled = cst ? v : min(v, carry);
         if (in) mbs[i].qp = (uint8_t)settled;
-        carry = __shfl(settled, min(k.nmb - base, 64) - 1);
+        carry = __shfl(settled, min(mb1 - base, 64) - 1);
     }
 }
 

@@ -55,6 +55,7 @@ template <int M> struct MbLds {
 
 struct MbCtx {
     int s, lane, mbx, mby, mbi, px, py;
+    int sy;                       // macroblock row within the slice: nothing above row 0 of the slice is available
     const uint8_t *fenc, *fuv;
     int qp, qpc, lambda, subme;
     bool satd, chroma_me;
@@ -756,7 +757,7 @@ __device__ __forceinline__ void mb_analyse_intra(const EncK &k, MbLds<M> &L, con
                                                  bool fast_intra, bool early_term, const Q4 &q4, const Q8 &q8, IntraRes &R)
 {
     const int lane = c.lane, j = lane & 3, zx = z_x0(lane), zy = z_y(lane), lambda = c.lambda;
-    const bool left = c.mbx > 0, top = c.mby > 0, topright = top && c.mbx + 1 < k.mbw;
+    const bool left = c.mbx > 0, top = c.sy > 0, topright = top && c.mbx + 1 < k.mbw;
     const int sm = min(c.subme, 10);
     uint8_t *tile = L.tile + IT_ORG, *tile8 = L.tile8 + IT_ORG;
     R.satd_i16 = R.satd_i8 = R.satd_i4 = MB_COST_MAX; R.pred16 = 0; R.nnz4 = R.nnz8 = 0; R.cbp8 = 0;
@@ -789,7 +790,7 @@ __device__ __forceinline__ void mb_analyse_intra(const EncK &k, MbLds<M> &L, con
         for (idx = 0;; idx++) {
             const int x8 = idx & 1, y8 = idx >> 1, avail = i8_avail(left, top, topright, idx);
             lds_sync();
-            const int pm = i4_pred_mode(L.nmodes, c.mbx, c.mby, idx * 4, L.modes8);
+            const int pm = i4_pred_mode(L.nmodes, c.mbx, c.sy, idx * 4, L.modes8);
             uint8_t *bt = tile8 + y8 * 8 * IT_STRIDE + x8 * 8;
             pred8_build_u(L.U8, bt, IT_STRIDE, avail, lane);
             const int src = idx * 16 + (r8 >> 2) * 8 + (r8 & 3);
@@ -861,9 +862,9 @@ __device__ __forceinline__ void mb_analyse_intra(const EncK &k, MbLds<M> &L, con
         int i_cost = lambda * (24 + 16), idx;
         for (idx = 0;; idx++) {
             const int bx = z_bx(idx), by = z_by(idx);
-            const int avail = i4_avail(c.mbx, c.mby, k.mbw, idx);
+            const int avail = i4_avail(c.mbx, c.sy, k.mbw, idx);
             lds_sync();
-            const int pm = i4_pred_mode(L.nmodes, c.mbx, c.mby, idx, L.modes4);
+            const int pm = i4_pred_mode(L.nmodes, c.mbx, c.sy, idx, L.modes4);
             uint8_t *bt = tile + by * 4 * IT_STRIDE + bx * 4;
             pred4_build_u(L.U, bt, IT_STRIDE, avail, lane);
             const uint32_t pr = pred4_row4(L.U, t4);
@@ -901,7 +902,7 @@ template <int M>
 __device__ __forceinline__ int mb_intra_chroma_cost(const EncK &k, MbLds<M> &L, const MbCtx &c, int &predc)
 {
     const int lane = c.lane, pl = (lane >> 4) & 1, ci = (lane >> 2) & 3, j = lane & 3, cx0 = (ci & 1) * 4, cyy = (ci >> 1) * 4 + j;
-    const bool left = c.mbx > 0, top = c.mby > 0;
+    const bool left = c.mbx > 0, top = c.sy > 0;
     const uint8_t *cnb = L.cnb[pl];
     const PredC pc = predc_setup(cnb);
     const uint2 fe = *(const uint2 *)(c.fuv + (size_t)cyy * k.fs + 2 * cx0);
@@ -1110,6 +1111,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(MB_WAVES_PER
 {
     __shared__ __attribute__((aligned(16))) MbLds<M> L;
     const int lane = threadIdx.x, s = blockIdx.x;
+    // x264 slice threads: blockIdx.y = slice of the picture, macroblock rows [row0, row1) (k.slices == 1: the whole picture)
+    const int nsl = k.slices > 1 ? k.slices : 1, row0 = (k.mbh * (int)blockIdx.y + nsl / 2) / nsl, row1 = (k.mbh * ((int)blockIdx.y + 1) + nsl / 2) / nsl;
+    const int mb_first = row0 * k.mbw, mb_end = row1 * k.mbw;
     const uint32_t t4 = (lane >> 2) < 9 ? ((const uint32_t *)c_pred4_table.t)[lane] : 0x01010101u * U_DC;
     for (int i = lane; i < 144; i += 64) ((uint32_t *)L.pred8tab)[i] = ((const uint32_t *)c_pred8_table)[i];
     lds_sync();
@@ -1122,9 +1126,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(MB_WAVES_PER
     int16_t *mv16 = k.mv16_cur + (size_t)s * k.nmb * 2;
     uint8_t *mbtype_cur = k.mbtype_cur + (size_t)s * k.nmb;
 
-    for (int mbi = 0; mbi < k.nmb; mbi++) {
+    for (int mbi = mb_first; mbi < mb_end; mbi++) {
         MbCtx c;
-        c.s = s; c.lane = lane; c.mbi = mbi; c.mbx = mbi % k.mbw; c.mby = mbi / k.mbw; c.px = c.mbx * 16; c.py = c.mby * 16;
+        c.s = s; c.lane = lane; c.mbi = mbi; c.mbx = mbi % k.mbw; c.mby = mbi / k.mbw; c.sy = c.mby - row0; c.px = c.mbx * 16; c.py = c.mby * 16;
         c.fenc = k.fenc_y + (size_t)s * k.fency_bytes + (size_t)c.py * k.fs + c.px;
         c.fuv = k.fenc_uv + (size_t)s * k.fencuv_bytes + (size_t)c.mby * 8 * k.fs + c.px;
         c.qp = __builtin_amdgcn_readfirstlane((int)k.mbqp[(size_t)s * k.nmb + mbi]);
@@ -1135,7 +1139,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(MB_WAVES_PER
         c.nref = k.nref;
         const Q4 &q_li = k.q4tab[c.qp * 4 + 0], &q_lp = k.q4tab[c.qp * 4 + 1], &q_ci = k.q4tab[c.qpc * 4 + 2], &q_cp = k.q4tab[c.qpc * 4 + 3];
         const Q8 &q8i = k.q8tab[c.qp * 2 + 0], &q8p = k.q8tab[c.qp * 2 + 1];
-        const bool left = c.mbx > 0, top = c.mby > 0, topright = top && c.mbx + 1 < k.mbw, topleft = top && left;
+        const bool left = c.mbx > 0, top = c.sy > 0, topright = top && c.mbx + 1 < k.mbw, topleft = top && left;
         const int mbx = c.mbx, mby = c.mby;
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
         const int type_left = uni(left ? (int)mbs[mbi - 1].type : -1), type_top = uni(top ? (int)mbs[mbi - k.mbw].type : -1);
@@ -1216,9 +1220,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(MB_WAVES_PER
             c.smin1 = clampi(c.mvmin1, -fr, fr - 1); c.smax1 = clampi(c.mvmax1, -fr, fr - 1);
             c.fmin0 = (c.smin0 >> 2) + 6; c.fmax0 = (c.smax0 >> 2) - 6; c.fmin1 = (c.smin1 >> 2) + 6; c.fmax1 = (c.smax1 >> 2) - 6;
             // ---- fast intra decision, skip vector, fast skip ----
-            if (early_term && mbi > 4) {
+            if (early_term && mbi - mb_first > 4) {
                 const int colo = uni((int)k.mbtype_ref0[(size_t)s * k.nmb + mbi]);
-                fast_intra = !(intra_t(type_left) || intra_t(type_top) || intra_t(type_tl) || intra_t(type_tr) || intra_t(colo) || mbi < 3 * intra_count);
+                fast_intra = !(intra_t(type_left) || intra_t(type_top) || intra_t(type_tl) || intra_t(type_tr) || intra_t(colo) || mbi - mb_first < 3 * intra_count);
             }
             {
                 const int ra = rl(S.cref, 4), rb = rl(S.cref, 1);

@@ -104,7 +104,7 @@ struct CabacSlice {
     CabacSlice(const SliceParams &sp, const x264gpu_mb *m, const int16_t *l, Cabac &c) : p(sp), mbs(m), levels(l), cb(c), amvd((size_t)sp.mbw * sp.mbh * 8, 0), prev_coded_qp(sp.qp) {}
 
     const x264gpu_mb *left(int mbx, int mby) const { return mbx > 0 ? &mbs[mby * p.mbw + mbx - 1] : nullptr; }
-    const x264gpu_mb *top(int mbx, int mby) const { return mby > 0 ? &mbs[(mby - 1) * p.mbw + mbx] : nullptr; }
+    const x264gpu_mb *top(int mbx, int mby) const { return mby > p.first_row ? &mbs[(mby - 1) * p.mbw + mbx] : nullptr; }      // not across the slice boundary
 
     // ---- motion vector prediction (8.4.1.3), 8x8 granular: identical in role to the CAVLC writer's ----
     struct Nb { bool avail; int ref; int mvx, mvy; };
@@ -113,7 +113,7 @@ struct CabacSlice {
     Nb block8(int gx, int gy) const
     {
         Nb n = { false, -1, 0, 0 };
-        if (gx < 0 || gy < 0 || gx >= 2 * p.mbw || gy >= 2 * p.mbh) return n;
+        if (gx < 0 || gy < 2 * p.first_row || gx >= 2 * p.mbw || gy >= 2 * p.mbh) return n;
         const int i = (gy >> 1) * p.mbw + (gx >> 1), k = (gy & 1) * 2 + (gx & 1);
         if (i == cur_mb) { if (done8 >> k & 1) return cur8[k]; return n; }
         if (i > cur_mb) return n;
@@ -144,7 +144,7 @@ struct CabacSlice {
     // the current macroblock not yet coded
     int amvd_at(int gx, int gy, int comp) const
     {
-        if (gx < 0 || gy < 0 || gx >= 2 * p.mbw || gy >= 2 * p.mbh) return 0;
+        if (gx < 0 || gy < 2 * p.first_row || gx >= 2 * p.mbw || gy >= 2 * p.mbh) return 0;
         const int i = (gy >> 1) * p.mbw + (gx >> 1), k = (gy & 1) * 2 + (gx & 1);
         if (i > cur_mb || (i == cur_mb && !(done8 >> k & 1))) return 0;
         return amvd[((size_t)i * 4 + k) * 2 + comp];
@@ -166,7 +166,7 @@ struct CabacSlice {
         else if (mbx > 0) { const x264gpu_mb &n = mbs[mby * p.mbw + mbx - 1]; ma = (n.type == X264GPU_MB_I4x4 || n.type == X264GPU_MB_I8x8) ? n.i4_mode[kIdxOf[by][3]] : 2; }
         else return 2;
         if (by > 0) mb = cur.i4_mode[kIdxOf[by - 1][bx]];
-        else if (mby > 0) { const x264gpu_mb &n = mbs[(mby - 1) * p.mbw + mbx]; mb = (n.type == X264GPU_MB_I4x4 || n.type == X264GPU_MB_I8x8) ? n.i4_mode[kIdxOf[3][bx]] : 2; }
+        else if (mby > p.first_row) { const x264gpu_mb &n = mbs[(mby - 1) * p.mbw + mbx]; mb = (n.type == X264GPU_MB_I4x4 || n.type == X264GPU_MB_I8x8) ? n.i4_mode[kIdxOf[3][bx]] : 2; }
         else return 2;
         return ma < mb ? ma : mb;
     }
@@ -436,10 +436,10 @@ void write_slice_cabac(std::vector<uint8_t> &out, const SliceParams &p, const x2
     Cabac cb(bw);
     cb.init(p.slice_type == X264GPU_SLICE_I, p.qp);
     CabacSlice s(p, mbs, levels, cb);
-    const int n = p.mbw * p.mbh;
-    for (int i = 0; i < n; i++) {
+    const int i0 = p.first_row * p.mbw, i1 = (p.end_row > 0 ? p.end_row : p.mbh) * p.mbw;
+    for (int i = i0; i < i1; i++) {
         s.macroblock(i % p.mbw, i / p.mbw);
-        cb.terminate(i == n - 1);                           // end_of_slice_flag
+        cb.terminate(i == i1 - 1);                          // end_of_slice_flag
     }
     if (stats) stats->skip = s.nskip;
     bw.align_zero();                                        // the flush wrote the stop bit: pad the last byte with zeros

@@ -83,6 +83,7 @@ struct x264_t {
     //      GPU encoder; frames come out in order, (G-1)*keyint calls late.  Fixed keyint + CQP make the GOPs independent, so
     //      the bytes equal the serial encode's (tests/test_gpu_host.py::test_gop_parallel_equals_serial).
     int G = 1;
+    int slices = 1;               // x264 slice threads: slices per picture (own wavefront + own NAL each)
     // The G slots are dealt to the visible devices (slot s -> device s % D, its local slot s / D): every device runs its slots in lock-step
     // with its own encoder, ring and download buffers, issued by one host thread per device; closed GOPs are independent, so there is no
     // exchange between devices and the frames still leave in stream order (north star: "frames of one stream shard one-per-GPU").
@@ -216,6 +217,16 @@ x264_t *x264_encoder_open(x264_param_t *param)
     p.analyse.b_fast_pskip = p.analyse.b_fast_pskip != 0;
     p.analyse.b_chroma_me = p.analyse.b_chroma_me != 0;
     p.b_interlaced = 0; p.i_slice_count = 1;
+    // --sliced-threads / --tune zerolatency: i_threads is the number of slices per picture (x264 validate_parameters: at most one per four
+    // macroblock rows; auto = as many as that allows, where x264 would count host cores) and there is one GOP in flight
+    h->slices = 1;
+    if (p.b_sliced_threads) {
+        const int max_slices = (p.i_height + 15) / 16 / 4 > 1 ? (p.i_height + 15) / 16 / 4 : 1;
+        h->slices = p.i_threads <= 0 ? max_slices : p.i_threads < max_slices ? p.i_threads : max_slices;
+        if (p.i_threads > 0 && h->slices != p.i_threads) xlog(&p, X264_LOG_INFO, "sliced threads %d -> %d (four macroblock rows per slice)\n", p.i_threads, h->slices);
+        p.i_threads = 1;
+        if (h->slices < 2) p.b_sliced_threads = 0;
+    }
     p.i_threads = clampi(p.i_threads, 1, 64);                  // --threads G: GOPs coded in lock-step (1 = no delay)
     if (p.i_keyint_max <= 0) p.i_keyint_max = 1;
     h->keyint = p.i_keyint_max;
@@ -262,7 +273,7 @@ x264_t *x264_encoder_open(x264_param_t *param)
         if (h->G != p.i_threads) xlog(&p, X264_LOG_INFO, "threads %d -> %d (GOP ring of keyint %d pictures)\n", p.i_threads, h->G, h->keyint);
         p.i_threads = h->G;
     }
-    cfg.width = p.i_width; cfg.height = p.i_height; cfg.streams = h->G; cfg.refs = p.i_frame_reference;
+    cfg.width = p.i_width; cfg.height = p.i_height; cfg.streams = h->G; cfg.refs = p.i_frame_reference; cfg.slices = h->slices;
     cfg.qp_i = h->qp_i; cfg.qp_p = h->qp_p; cfg.me_range = p.analyse.i_me_range; cfg.subme = p.analyse.i_subpel_refine;
     cfg.deblock = p.b_deblocking_filter; cfg.deblock_alpha = p.i_deblocking_filter_alphac0; cfg.deblock_beta = p.i_deblocking_filter_beta;
     cfg.chroma_qp_offset = p.analyse.i_chroma_qp_offset;
@@ -503,8 +514,11 @@ static int code_position(x264_t *h, int batch, int t, int nslots_with_t)
         sp.disable_deblock_idc = p.b_deblocking_filter ? 0 : 1;
         sp.alpha_off_div2 = p.i_deblocking_filter_alphac0; sp.beta_off_div2 = p.i_deblocking_filter_beta;
         sp.transform8x8_mode = p.analyse.b_transform_8x8; sp.cabac = p.b_cabac;
-        c.off.push_back(c.bytes.size()); c.types.push_back(c.idr ? 5 : 1);
-        write_slice(c.bytes, sp, hmb + row * h->nmb, hlv + row * h->nmb * X264GPU_MB_LEVELS, p.b_annexb != 0, c.off.size() == 1, nullptr);
+        {
+            const size_t before = c.off.size();
+            write_picture(c.bytes, &c.off, sp, h->slices, hmb + row * h->nmb, hlv + row * h->nmb * X264GPU_MB_LEVELS, p.b_annexb != 0, before == 0, nullptr);
+            for (size_t i = before; i < c.off.size(); i++) c.types.push_back(c.idr ? 5 : 1);
+        }
     };
     const unsigned hw = std::thread::hardware_concurrency();
     const int nthr = (int)(hw ? (hw < (unsigned)nslots_with_t ? hw : (unsigned)nslots_with_t) : 1);
@@ -744,9 +758,12 @@ static int encode_queued(x264_t *h, x264_nal_t **pp_nal, int *pi_nal, x264_pictu
     sp.disable_deblock_idc = p.b_deblocking_filter ? 0 : 1;
     sp.alpha_off_div2 = p.i_deblocking_filter_alphac0; sp.beta_off_div2 = p.i_deblocking_filter_beta;
     sp.transform8x8_mode = p.analyse.b_transform_8x8; sp.cabac = p.b_cabac;
-    h->nal_off.push_back(h->out.size()); types.push_back(idr ? 5 : 1);
     h->last_stats.skip = 0;
-    write_slice(h->out, sp, hmb, hlv, p.b_annexb != 0, h->nal_off.size() == 1, &h->last_stats, h->cavlc_threads);
+    {
+        const size_t before = h->nal_off.size();
+        write_picture(h->out, &h->nal_off, sp, h->slices, hmb, hlv, p.b_annexb != 0, before == 0, &h->last_stats, h->cavlc_threads);
+        for (size_t i = before; i < h->nal_off.size(); i++) types.push_back(idr ? 5 : 1);
+    }
     publish_nals(h, pp_nal, pi_nal, types);
     if (pic_out) {
         x264_picture_init(pic_out);
@@ -890,6 +907,25 @@ int x264host_write_slice(int mbw, int mbh, int slice_type, int qp, int pic_init_
     std::vector<uint8_t> v;
     SliceStats stt = { 0 };
     write_slice(v, sp, mbs, levels, true, true, &stt, cavlc_threads_default(1));
+    if (skipped) *skipped = stt.skip;
+    if ((int)v.size() > cap) return -1;
+    memcpy(out, v.data(), v.size());
+    return (int)v.size();
+}
+
+// a whole picture of `slices` slices through either writer (tests: multi-slice pictures)
+int x264host_write_picture(int mbw, int mbh, int slice_type, int qp, int pic_init_qp, int frame_num, int log2_max_frame_num,
+                           int idr, int idr_pic_id, int disable_deblock_idc, int num_ref, int num_ref_default, int transform8x8_mode, int cabac, int slices,
+                           const x264gpu_mb *mbs, const int16_t *levels, uint8_t *out, int cap, int *skipped)
+{
+    SliceParams sp = {};
+    sp.mbw = mbw; sp.mbh = mbh; sp.slice_type = slice_type; sp.qp = qp; sp.pic_init_qp = pic_init_qp; sp.frame_num = frame_num;
+    sp.log2_max_frame_num = log2_max_frame_num; sp.idr = idr; sp.idr_pic_id = idr_pic_id; sp.nal_ref_idc = idr ? 3 : 2;
+    sp.num_ref = num_ref; sp.num_ref_default = num_ref_default;
+    sp.disable_deblock_idc = disable_deblock_idc; sp.transform8x8_mode = transform8x8_mode; sp.cabac = cabac;
+    std::vector<uint8_t> v;
+    SliceStats stt = { 0 };
+    write_picture(v, nullptr, sp, slices, mbs, levels, true, true, &stt, 4);
     if (skipped) *skipped = stt.skip;
     if ((int)v.size() > cap) return -1;
     memcpy(out, v.data(), v.size());

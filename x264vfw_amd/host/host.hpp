@@ -19,6 +19,8 @@ struct SliceParams {
     int disable_deblock_idc, alpha_off_div2, beta_off_div2;
     int transform8x8_mode;   // PPS transform_8x8_mode_flag
     int cabac;               // PPS entropy_coding_mode_flag: CABAC slice data (cabac_init_idc 0), else CAVLC
+    int first_row = 0, end_row = 0;   // macroblock rows [first_row, end_row) of this slice (end_row 0 = mbh: one slice per picture); nothing
+                             // above first_row is available to the slice's predictions (7.4.1.2.4 / 6.4.x availability)
 };
 struct SliceStats { int skip; };
 
@@ -39,6 +41,9 @@ void write_sei_version(std::vector<uint8_t> &out, const char *text, bool annexb)
 void write_slice_header(BitWriter &bw, const SliceParams &p);
 void write_slice(std::vector<uint8_t> &out, const SliceParams &p, const x264gpu_mb *mbs, const int16_t *levels,
                  bool annexb, bool long_startcode, SliceStats *stats, int threads = 1);
+int slice_first_row(int mbh, int i, int n);
+void write_picture(std::vector<uint8_t> &out, std::vector<size_t> *offs, const SliceParams &p, int slices, const x264gpu_mb *mbs, const int16_t *levels,
+                   bool annexb, bool long_startcode_first, SliceStats *stats, int threads = 1);
 // cabac.cpp: the same slice with CABAC slice data (write_slice dispatches on p.cabac)
 void write_slice_cabac(std::vector<uint8_t> &out, const SliceParams &p, const x264gpu_mb *mbs, const int16_t *levels,
                        bool annexb, bool long_startcode, SliceStats *stats);

@@ -141,7 +141,7 @@ static int apply_tune(x264_param_t *p, const char *tune)
         else if (!strncasecmp(s, "fastdecode", 10)) {
             psy = 0; p->b_deblocking_filter = 0; p->b_cabac = 0; p->analyse.b_weighted_bipred = 0; p->analyse.i_weighted_pred = X264_WEIGHTP_NONE;
         } else if (!strncasecmp(s, "zerolatency", 11)) {
-            psy = 0; p->rc.i_lookahead = 0; p->i_bframe = 0; p->b_vfr_input = 0; p->rc.b_mb_tree = 0;
+            psy = 0; p->rc.i_lookahead = 0; p->i_bframe = 0; p->b_vfr_input = 0; p->rc.b_mb_tree = 0; p->b_sliced_threads = 1;
         } else { rc = -1; break; }
         if (psy && psy_set++) rc = -1;          /* only one psy tuning at a time (config.c:1509) */
     }
@@ -241,7 +241,7 @@ int x264_param_parse(x264_param_t *p, const char *name, const char *value)
     OPT("asm") { int v = parse_bool(value, &err); p->cpu = v ? 1 : 0; }
     OPT("threads") { if (value && !strcasecmp(value, "auto")) p->i_threads = 0; else I(p->i_threads); }
     OPT("lookahead-threads") { if (!(value && !strcasecmp(value, "auto"))) (void)parse_int(value, &err); }
-    OPT("sliced-threads") (void)parse_bool(value, &err);
+    OPT("sliced-threads") B(p->b_sliced_threads);
     OPT("sync-lookahead") { if (!(value && !strcasecmp(value, "auto"))) (void)parse_int(value, &err); }
     OPT("deterministic") B(p->b_deterministic);
     OPT("non-deterministic") { p->b_deterministic = !parse_bool(value, &err); }

@@ -38,7 +38,7 @@ struct SliceCtx {
     int qp_delta(const x264gpu_mb &m) const
     {
         const int i = (int)(&m - mbs);
-        int d = (int)m.qp - (i == 0 ? p.qp : (int)mbs[i - 1].qp);
+        int d = (int)m.qp - (i == p.first_row * p.mbw ? p.qp : (int)mbs[i - 1].qp);
         // mb_qp_delta lies in [-26, +25] (7.4.5); QP_Y is recovered modulo 52, so a larger step wraps (x264 cavlc.c does the same)
         if (d < -26) d += 52; else if (d > 25) d -= 52;
         return d;
@@ -51,7 +51,7 @@ struct SliceCtx {
         if (bx > 0) na = tc[(size_t)(mby * mbw() + mbx) * 24 + kIdxOf[by][bx - 1]];
         else if (mbx > 0) na = tc[(size_t)(mby * mbw() + mbx - 1) * 24 + kIdxOf[by][3]];
         if (by > 0) nb = tc[(size_t)(mby * mbw() + mbx) * 24 + kIdxOf[by - 1][bx]];
-        else if (mby > 0) nb = tc[(size_t)((mby - 1) * mbw() + mbx) * 24 + kIdxOf[3][bx]];
+        else if (mby > p.first_row) nb = tc[(size_t)((mby - 1) * mbw() + mbx) * 24 + kIdxOf[3][bx]];
         if (na >= 0 && nb >= 0) return (na + nb + 1) >> 1;
         return na >= 0 ? na : nb >= 0 ? nb : 0;
     }
@@ -61,7 +61,7 @@ struct SliceCtx {
         if (bx > 0) na = tc[(size_t)(mby * mbw() + mbx) * 24 + base + by * 2];
         else if (mbx > 0) na = tc[(size_t)(mby * mbw() + mbx - 1) * 24 + base + by * 2 + 1];
         if (by > 0) nb = tc[(size_t)(mby * mbw() + mbx) * 24 + base + bx];
-        else if (mby > 0) nb = tc[(size_t)((mby - 1) * mbw() + mbx) * 24 + base + 2 + bx];
+        else if (mby > p.first_row) nb = tc[(size_t)((mby - 1) * mbw() + mbx) * 24 + base + 2 + bx];
         if (na >= 0 && nb >= 0) return (na + nb + 1) >> 1;
         return na >= 0 ? na : nb >= 0 ? nb : 0;
     }
@@ -131,7 +131,7 @@ struct SliceCtx {
     Nb block8(int gx, int gy) const
     {
         Nb n = { false, -1, 0, 0 };
-        if (gx < 0 || gy < 0 || gx >= 2 * p.mbw || gy >= 2 * p.mbh) return n;
+        if (gx < 0 || gy < 2 * p.first_row || gx >= 2 * p.mbw || gy >= 2 * p.mbh) return n;      // outside the picture or the slice
         int i = (gy >> 1) * p.mbw + (gx >> 1), k = (gy & 1) * 2 + (gx & 1);
         if (i == cur_mb) { if (done8 >> k & 1) return cur8[k]; return n; }
         if (i > cur_mb) return n;                          // raster order: everything before the current macroblock is available
@@ -180,7 +180,7 @@ struct SliceCtx {
         else if (mbx > 0) { const x264gpu_mb &n = mbs[mby * p.mbw + mbx - 1]; ma = (n.type == X264GPU_MB_I4x4 || n.type == X264GPU_MB_I8x8) ? n.i4_mode[kIdxOf[by][3]] : 2; }
         else return 2;
         if (by > 0) mb = cur.i4_mode[kIdxOf[by - 1][bx]];
-        else if (mby > 0) { const x264gpu_mb &n = mbs[(mby - 1) * p.mbw + mbx]; mb = (n.type == X264GPU_MB_I4x4 || n.type == X264GPU_MB_I8x8) ? n.i4_mode[kIdxOf[3][bx]] : 2; }
+        else if (mby > p.first_row) { const x264gpu_mb &n = mbs[(mby - 1) * p.mbw + mbx]; mb = (n.type == X264GPU_MB_I4x4 || n.type == X264GPU_MB_I8x8) ? n.i4_mode[kIdxOf[3][bx]] : 2; }
         else return 2;
         return ma < mb ? ma : mb;
     }
@@ -310,7 +310,7 @@ struct SliceCtx {
 
 void write_slice_header(BitWriter &bw, const SliceParams &p)
 {
-    bw.ue(0);                                                   // first_mb_in_slice
+    bw.ue((uint32_t)(p.first_row * p.mbw));                     // first_mb_in_slice
     bw.ue((p.slice_type == X264GPU_SLICE_I ? 2 : 0) + 5);       // slice_type (+5: all slices of the picture alike)
     bw.ue(p.pps_id);
     bw.put((uint32_t)p.frame_num & ((1u << p.log2_max_frame_num) - 1), p.log2_max_frame_num);
@@ -342,14 +342,15 @@ void write_slice(std::vector<uint8_t> &out, const SliceParams &p, const x264gpu_
     BitWriter bw;
     write_slice_header(bw, p);
     const size_t n = (size_t)p.mbw * p.mbh;
+    const int r0 = p.first_row, r1 = p.end_row > 0 ? p.end_row : p.mbh, rows = r1 - r0;
     std::vector<uint8_t> tc(n * 24);
     int T = threads < 1 ? 1 : threads;
-    if (T > p.mbh / 4) T = p.mbh / 4 > 0 ? p.mbh / 4 : 1;           // at least four rows per band
+    if (T > rows / 4) T = rows / 4 > 0 ? rows / 4 : 1;              // at least four rows per band
     std::vector<BitWriter> bws((size_t)T);
     std::vector<SliceCtx> ctx;
     ctx.reserve((size_t)T);
     for (int t = 0; t < T; t++) {
-        ctx.push_back(SliceCtx{ p, mbs, levels, bws[(size_t)t], tc.data(), (int)((long)p.mbh * t / T), (int)((long)p.mbh * (t + 1) / T) });
+        ctx.push_back(SliceCtx{ p, mbs, levels, bws[(size_t)t], tc.data(), r0 + (int)((long)rows * t / T), r0 + (int)((long)rows * (t + 1) / T) });
         bws[(size_t)t].reserve(n * 48 / (size_t)T + 64);
     }
     auto fill = [&](int t) {
@@ -375,6 +376,38 @@ void write_slice(std::vector<uint8_t> &out, const SliceParams &p, const x264gpu_
     if (stats) { stats->skip = 0; for (const SliceCtx &c : ctx) stats->skip += c.nskip; }
     bw.trailing();
     append_nal(out, p.nal_ref_idc, p.idr ? 5 : 1, bw.bytes(), annexb, long_startcode);
+}
+
+// first macroblock row of slice i of n (x264 slice threads split the rows evenly: threadslice start = (mb_height * i + n / 2) / n)
+int slice_first_row(int mbh, int i, int n) { return (mbh * i + n / 2) / n; }
+
+// One picture as `slices` slices, each its own NAL unit (offs gets the offset of each in `out`); slices share nothing, so they are coded by
+// up to `threads` threads.  With more than one slice the loop filter stops at slice boundaries (disable_deblocking_filter_idc 2), as under
+// x264's slice threads.
+void write_picture(std::vector<uint8_t> &out, std::vector<size_t> *offs, const SliceParams &p, int slices, const x264gpu_mb *mbs, const int16_t *levels,
+                   bool annexb, bool long_startcode_first, SliceStats *stats, int threads)
+{
+    const int n = slices > 1 ? slices : 1;
+    if (n == 1) { if (offs) offs->push_back(out.size()); write_slice(out, p, mbs, levels, annexb, long_startcode_first, stats, threads); return; }
+    std::vector<std::vector<uint8_t>> parts((size_t)n);
+    std::vector<SliceStats> st((size_t)n, SliceStats{ 0 });
+    auto one = [&](int i) {
+        SliceParams sp = p;
+        sp.first_row = slice_first_row(p.mbh, i, n); sp.end_row = slice_first_row(p.mbh, i + 1, n);
+        if (sp.disable_deblock_idc == 0) sp.disable_deblock_idc = 2;
+        write_slice(parts[(size_t)i], sp, mbs, levels, annexb, long_startcode_first && i == 0, &st[(size_t)i], 1);
+    };
+    int T = threads < 1 ? 1 : threads > n ? n : threads;
+    std::vector<std::thread> pool;
+    for (int t = 1; t < T; t++) pool.emplace_back([&, t] { for (int i = t; i < n; i += T) one(i); });
+    for (int i = 0; i < n; i += T) one(i);
+    for (auto &th : pool) th.join();
+    if (stats) stats->skip = 0;
+    for (int i = 0; i < n; i++) {
+        if (offs) offs->push_back(out.size());
+        out.insert(out.end(), parts[(size_t)i].begin(), parts[(size_t)i].end());
+        if (stats) stats->skip += st[(size_t)i].skip;
+    }
 }
 
 }  // namespace x264host
