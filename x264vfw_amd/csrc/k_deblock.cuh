@@ -165,7 +165,7 @@ __device__ void deblock_mb_pair(const EncK &k, Deblock2Lds &L, int wave, int lan
             bool go = work && !((edge & 1) && Q->transform8x8);
             if (edge == 0) {
                 if (dir == 0) { go = go && cmbx != 0; P = &L.rec[wave][hf][1]; }
-                else { go = go && cmby != 0; P = &L.rec[wave][hf][2]; }
+                else { go = go && cmby != 0 && !slice_starts_at_row(k, cmby); P = &L.rec[wave][hf][2]; }
             }
             if (__any(go)) {
                 const int qpp = P->qp;
