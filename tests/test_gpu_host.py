@@ -518,3 +518,28 @@ def test_sliced_threads_through_the_api(gpu, w, h, opts, slices):
         np.testing.assert_array_equal(dec[i], recons[i], err_msg=f"decoded picture {i}")
         og.encode(f, 2 if i % keyint == 0 else 0)
         np.testing.assert_array_equal(og.recon(), recons[i], err_msg=f"oracle pipeline picture {i}")
+
+
+@pytest.mark.parametrize("w,h,opts,okw", [
+    (1920, 1080, {"qp": 23, "keyint": 250, "no-scenecut": None}, dict(me_method=1)),                                              # BASELINE.json config 2 (headline size)
+    (1280, 720, {"qp": 23, "keyint": 250, "no-scenecut": None}, dict(me_method=1)),                                               # config 1
+    (3840, 2160, {"qp": 26, "keyint": 250, "no-scenecut": None, "me": "umh", "ref": 5, "sliced-threads": None}, dict(me_method=2, refs=5)),   # config 3's search (umh, ref 5) at its size
+])
+def test_full_size_round_trip(gpu, w, h, opts, okw):
+    """BASELINE.json's full sizes through the x264 API: the stream (High profile, CABAC) decodes to the encoder's own reconstruction, and the
+    oracle pipeline fed the same pictures reconstructs the same samples — at sizes where only a few pictures fit a test's time budget"""
+    nfr = 2 if w > 1920 else 3
+    h_, eff = open_encoder(w, h, opts, b"high")
+    frames = synth_frames(w, h, nfr, seed=w + h)
+    stream, info, recons = encode_all(h_, w, h, frames)
+    H.x264_encoder_close(h_)
+    assert eff.b_cabac == 1
+    dec = O.h264_decode(stream, nfr, w, h)
+    slices = (h + 15) // 16 // 4 if "sliced-threads" in opts else 1
+    kw = dict(slices=slices, partitions=7, refs=3, dct8x8=1, chroma_me=1, mixed_refs=1, subme=5, qp_i=opts["qp"] - 3, qp_p=opts["qp"], mv_range=eff.analyse.i_mv_range)
+    kw.update(okw)
+    og = O.OracleEncoder(O.default_config(w, h, **kw))
+    for i, f in enumerate(frames):
+        np.testing.assert_array_equal(dec[i], recons[i], err_msg=f"decoded picture {i}")
+        og.encode(f, 2 if i == 0 else 0)
+        np.testing.assert_array_equal(og.recon(), recons[i], err_msg=f"oracle pipeline picture {i}")
