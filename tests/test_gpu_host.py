@@ -543,3 +543,35 @@ def test_full_size_round_trip(gpu, w, h, opts, okw):
         np.testing.assert_array_equal(dec[i], recons[i], err_msg=f"decoded picture {i}")
         og.encode(f, 2 if i == 0 else 0)
         np.testing.assert_array_equal(og.recon(), recons[i], err_msg=f"oracle pipeline picture {i}")
+
+
+def test_slice_threads_with_gop_slots(gpu, monkeypatch):
+    """X264GPU_GOP_SLOTS=G on a slice-threads session: G closed GOPs in lock-step, every picture in slices (slices x G wavefronts of one
+    stream) — the bytes equal the zero-delay slice-threads session's, only the delay changes"""
+    w, h, nfr, keyint, G = 96, 272, 14, 3, 3
+    opts = {"qp": 27, "keyint": keyint, "min-keyint": keyint, "no-scenecut": None, "sliced-threads": None, "threads": 4}
+    frames = synth_frames(w, h, nfr, seed=4242)
+    h1, e1 = open_encoder(w, h, opts, b"high")
+    serial, info1, _ = encode_all(h1, w, h, frames)
+    H.x264_encoder_close(h1)
+    assert all(sum(1 for t in types if t in (1, 5)) == 4 for _, _, _, types in info1)
+    monkeypatch.setenv("X264GPU_GOP_SLOTS", str(G))
+    hg, eff = open_encoder(w, h, opts, b"high")
+    pic, out = HL.Picture(), HL.Picture()
+    assert H.x264_picture_alloc(C.byref(pic), HL.X264_CSP_I420, w, h) == 0
+    nal, n = C.POINTER(HL.Nal)(), C.c_int()
+    stream, got = b"", 0
+    for i, f in enumerate(frames):
+        C.memmove(pic.img.plane[0], f.ctypes.data, f.size)
+        pic.i_pts = i
+        size = H.x264_encoder_encode(hg, C.byref(nal), C.byref(n), C.byref(pic), C.byref(out))
+        assert size >= 0 and (size == 0 or i >= (G - 1) * keyint)
+        if size:
+            stream += C.string_at(nal[0].p_payload, size); got += 1
+    while H.x264_encoder_delayed_frames(hg):
+        size = H.x264_encoder_encode(hg, C.byref(nal), C.byref(n), None, C.byref(out))
+        assert size > 0
+        stream += C.string_at(nal[0].p_payload, size); got += 1
+    H.x264_encoder_close(hg)
+    H.x264_picture_clean(C.byref(pic))
+    assert got == nfr and stream == serial

@@ -226,6 +226,9 @@ x264_t *x264_encoder_open(x264_param_t *param)
         if (p.i_threads > 0 && h->slices != p.i_threads) xlog(&p, X264_LOG_INFO, "sliced threads %d -> %d (four macroblock rows per slice)\n", p.i_threads, h->slices);
         p.i_threads = 1;
         if (h->slices < 2) p.b_sliced_threads = 0;
+        // x264 has no word for "slice threads AND several GOPs in flight"; this library can do both (slices x GOP slots wavefronts per stream).
+        // X264GPU_GOP_SLOTS=G asks for it: the --threads G mode below (fixed keyint, delay (G-1) x keyint) with every picture in slices
+        if (const char *gs = getenv("X264GPU_GOP_SLOTS")) { const int g = atoi(gs); if (g > 1) p.i_threads = g; }
     }
     p.i_threads = clampi(p.i_threads, 1, 64);                  // --threads G: GOPs coded in lock-step (1 = no delay)
     if (p.i_keyint_max <= 0) p.i_keyint_max = 1;
