@@ -23,19 +23,17 @@ constexpr int MB_COST_MAX = 1 << 28;
 enum { D_16x16 = 0, D_16x8 = 1, D_8x16 = 2, D_8x8 = 3 };
 enum { ME_16 = 0, ME_8 = 1, ME_16x8 = 5, ME_8x16 = 7, ME_COUNT = 9 };     // slots of the per-macroblock search results
 
-// Full-pel window cache (dia / hex): one slot per reference (slot = ref % 3), WC_ROWS x WC_COLS samples around the macroblock displaced
-// by the start vector of the first search that needed it; later searches of the macroblock on the same reference (8x8 / 16x8 / 8x16
-// blocks, other starts) reuse it when the samples they touch lie inside, and re-centre it when they do not.  esa uses the same
-// bytes as ONE +-17 window (WIN_ROWS x WIN_STRIDE); umh roams global memory.
-#ifndef MB_WC_ROWS
-#define MB_WC_ROWS 40
-#endif
-constexpr int WC_ROWS = MB_WC_ROWS, WC_COLS = 48, WC_STRIDE = 52, WC_BYTES = WC_ROWS * WC_STRIDE, WC_MARGIN = 12;
+// Reference cache: one LDS slot per reference (slot = ref % 3) holding RC_ROWS x RC_COLS samples of ALL FOUR half-pel planes around the
+// macroblock displaced by the vector it was last centred on (the predictor of the first search that needed the reference).  Start
+// candidates, the full-pel search and the sub-pel refinement of every search of the macroblock on that reference read it when the samples
+// they touch lie inside, and re-centre it (one trip to memory for all four planes) when they do not: most searches of a macroblock then
+// cost no trip at all.  esa uses the same bytes as ONE +-17 full-pel window (WIN_ROWS x WIN_STRIDE); umh roams global memory for its
+// full-pel steps and uses the slot for the sub-pel ones.
+constexpr int RC_ROWS = 30, RC_PD = 10, RC_COLS = 4 * RC_PD, RC_PLANE_DW = RC_ROWS * RC_PD, RC_SLOT_DW = 4 * RC_PLANE_DW, RC_MX = 12, RC_MY = 7;
 struct WinTags { int ref0, x00, y00, ref1, x01, y01, ref2, x02, y02; };
 
 template <int M> struct MbLds {
-    __attribute__((aligned(16))) uint8_t win[3 * WC_BYTES > WIN_ROWS * WIN_STRIDE ? 3 * WC_BYTES : WIN_ROWS * WIN_STRIDE];
-    uint32_t sub[SubGeo<M>::DWORDS];
+    __attribute__((aligned(16))) uint32_t rc[3 * RC_SLOT_DW];        // >= WIN_ROWS * WIN_STRIDE bytes (esa)
     uint32_t csub[CSubGeo<M>::DWORDS];
     uint16_t cost[2][192];
     __attribute__((aligned(8))) uint8_t tile[IT_SIZE];
@@ -165,6 +163,26 @@ __device__ __forceinline__ void mc_row_global(const uint8_t *__restrict__ p00, s
     }
 }
 
+// this lane's row of W pixels at picture position (x, y) displaced by the quarter-pel vector, from a reference-cache slot whose sample
+// (0, 0) is picture position (X0, Y0) (mc.get_ref on the cached planes)
+__device__ __forceinline__ void rc_row(const uint32_t *slot, int X0, int Y0, int x, int y, int mvx, int mvy, bool w16, uint32_t out[4])
+{
+    const int idx = ((mvy & 3) << 2) | (mvx & 3);
+    const int pl0 = (kQpelPlane0Packed >> (2 * idx)) & 3, pl1 = (kQpelPlane1Packed >> (2 * idx)) & 3;
+    const int bx = x + (mvx >> 2) - X0, by = y + (mvy >> 2) - Y0;
+    const int o0 = (by + ((mvy & 3) == 3 ? 1 : 0)) * RC_COLS + bx, o1 = by * RC_COLS + bx + ((mvx & 3) == 3 ? 1 : 0);
+    const uint32_t *wa = slot + pl0 * RC_PLANE_DW + (o0 >> 2), *wb = slot + pl1 * RC_PLANE_DW + (o1 >> 2);
+    const bool avg = (idx & 5) != 0;
+    uint32_t a[5], b[5];
+#pragma unroll
+    for (int i = 0; i < 5; i++) { a[i] = (i < 3 || w16) ? wa[i] : 0u; b[i] = (i < 3 || w16) ? wb[i] : 0u; }
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        const uint32_t pa = __builtin_amdgcn_alignbyte(a[i + 1], a[i], o0 & 3), pb_ = __builtin_amdgcn_alignbyte(b[i + 1], b[i], o1 & 3);
+        out[i] = (i < 2 || w16) ? (avg ? avg4_u8(pa, pb_) : pa) : 0u;
+    }
+}
+
 template <int M, int ME>
 __device__ __forceinline__ void me_search(const EncK &k, MbLds<M> &L, const MbCtx &c, const MeJob &j, int &mvx, int &mvy, int &cost, int &cost_mv, int &halfpel_thresh, const MeState &S, WinTags &wt, Prof &pf)
 {
@@ -190,12 +208,46 @@ __device__ __forceinline__ void me_search(const EncK &k, MbLds<M> &L, const MbCt
         return row16_sum(rowok ? (int)sd : 0);
     };
     const int fmin0 = c.fmin0, fmax0 = c.fmax0, fmin1 = c.fmin1, fmax1 = c.fmax1;
-    constexpr bool umh = ME == 2, cached = ME == 0 || ME == 1;
+    constexpr bool umh = ME == 2, esa = ME == 3, cached = ME == 0 || ME == 1;      // cached: the full-pel steps read the reference-cache slot
     int cbx = 0, cby = 0;                      // centre of the LDS slices of the mv-cost table (dia / hex / esa searches)
-    // Most searches end where they start: the sub-pel neighbourhood of the START is requested before the full-pel search runs and is
-    // used if the search ends there (its latency then hides behind the search); otherwise it is fetched again around the result.
-    constexpr bool spec = (ME == 0 || ME == 1) && M == 2;
-    uint32_t spv[12], spc[2];
+    // ---- this reference's slot of the reference cache ----
+    const int slot = j.ref >= 3 ? j.ref - 3 : j.ref;
+    uint32_t *rslot = L.rc + slot * RC_SLOT_DW;
+    int X0 = slot == 0 ? wt.x00 : slot == 1 ? wt.x01 : wt.x02, Y0 = slot == 0 ? wt.y00 : slot == 1 ? wt.y01 : wt.y02;
+    bool rhave = (slot == 0 ? wt.ref0 : slot == 1 ? wt.ref1 : wt.ref2) == j.ref;
+    auto rc_inside = [&](int x0, int y0, int x1, int y1) { return rhave && x0 >= X0 && x1 <= X0 + RC_COLS && y0 >= Y0 && y1 <= Y0 + RC_ROWS; };
+    // the block displaced by full-pel (mx +- rad, my +- rad) / by the quarter-pel vector (qx, qy) / anywhere within M samples of full-pel (cx, cy)
+    auto in_fpel = [&](int mx, int my, int rad) { return rc_inside(bx + mx - rad, by + my - rad, bx + mx + rad + j.W, by + my + rad + j.H); };
+    auto in_qpel = [&](int qx, int qy) { return rc_inside(bx + (qx >> 2), by + (qy >> 2), bx + (qx >> 2) + j.W + 1, by + (qy >> 2) + j.H + 1); };
+    auto in_sub = [&](int cx, int cy) { return rc_inside(bx + cx - M, by + cy - M, bx + cx + j.W + M + 1, by + cy + j.H + M + 1); };
+    // (re-)centre the slot on the macroblock displaced by (cx, cy): twenty requests per lane, then (after other work) the copy into LDS
+    auto rc_issue = [&](int cx, int cy, uint32_t v[20]) {
+        X0 = clampi((c.px + cx - RC_MX) & ~3, -PAD, k.cw + PAD - RC_COLS); Y0 = clampi(c.py + cy - RC_MY, -PAD, k.ch + PAD - RC_ROWS);
+#pragma unroll
+        for (int t = 0; t < 5; t++) {
+            const int i = lane + 64 * t, row = (i * 205) >> 11, col = i - row * 10;        // i / 10 for i < 320
+            const long o = (long)(Y0 + row) * k.rs + X0 + 4 * col;
+#pragma unroll
+            for (int pl = 0; pl < 4; pl++) v[pl * 5 + t] = i < RC_PLANE_DW ? *(const uint32_t *)(p00 + pl * pb + o) : 0u;
+        }
+    };
+    auto rc_commit = [&](const uint32_t v[20]) {
+        lds_sync();
+#pragma unroll
+        for (int t = 0; t < 5; t++) {
+            const int i = lane + 64 * t;
+#pragma unroll
+            for (int pl = 0; pl < 4; pl++) if (i < RC_PLANE_DW) rslot[pl * RC_PLANE_DW + i] = v[pl * 5 + t];
+        }
+        rhave = true;
+        pf.count(15);
+        if (slot == 0) { wt.ref0 = j.ref; wt.x00 = X0; wt.y00 = Y0; } else if (slot == 1) { wt.ref1 = j.ref; wt.x01 = X0; wt.y01 = Y0; } else { wt.ref2 = j.ref; wt.x02 = X0; wt.y02 = Y0; }
+        lds_sync();
+    };
+    auto rc_stage = [&](int cx, int cy) { uint32_t v[20]; rc_issue(cx, cy, v); rc_commit(v); };
+    // the chroma taps of the search START are requested before the full-pel search runs and used if the search ends there
+    constexpr bool spec = cached && M == 2;
+    uint32_t spc[2];
     bool spec_on = false;
     int spx = 0, spy = 0;
 
@@ -229,83 +281,55 @@ __device__ __forceinline__ void me_search(const EncK &k, MbLds<M> &L, const MbCt
             n = 1 + __builtin_popcountll(km);
         }
         lds_sync();
-        // ---- windows.  dia / hex: window cache + LDS slices of the mv-cost table; esa: one +-17 window around the start; umh roams up to
-        //      ~1.5 x merange from the start: reference rows and costs come from global memory ----
+        // ---- the start candidates.  dia / hex: every full-pel step reads the reference-cache slot, with LDS slices of the mv-cost table; esa:
+        //      one +-17 full-pel window around the start; umh roams up to ~1.5 x merange from the start on global memory.
+        //      One trip to memory at most: the slot around the predictor (if it does not hold that area yet), the cost slices, and the rows of
+        //      those candidates the slot does not hold are all requested before the first result is used ----
         int i_me_range = k.me_range;
         cbx = pmx * 4; cby = pmy * 4;
-        const int slot = j.ref >= 3 ? j.ref - 3 : j.ref;
-        uint8_t *wbase = L.win + (cached ? slot * WC_BYTES : 0);
-        const int wstride = cached ? WC_STRIDE : WIN_STRIDE;
-        int wx0 = 0, wy0 = 0;
-        bool whave = false;
-        if (cached) {
-            const int tr = slot == 0 ? wt.ref0 : slot == 1 ? wt.ref1 : wt.ref2;
-            wx0 = slot == 0 ? wt.x00 : slot == 1 ? wt.x01 : wt.x02; wy0 = slot == 0 ? wt.y00 : slot == 1 ? wt.y01 : wt.y02;
-            whave = tr == j.ref;
-        }
-        // are the samples of this block displaced by (mx +- rad, my +- rad) inside the window?
-        auto inside = [&](int mx, int my, int rad) {
-            return whave && bx + mx - rad >= wx0 && bx + mx + rad + j.W <= wx0 + WC_COLS && by + my - rad >= wy0 && by + my + rad + j.H <= wy0 + WC_ROWS;
-        };
-        // (re-)centre this reference's slot on the macroblock displaced by (mx, my): requests, then (after other work) the copy into LDS
-        auto win_issue = [&](int mx, int my, uint2 v[4]) {
-            wx0 = clampi((c.px + mx - WC_MARGIN) & ~7, -PAD, k.cw + PAD - WC_COLS); wy0 = clampi(c.py + my - WC_MARGIN, -PAD, k.ch + PAD - WC_ROWS);
-#pragma unroll
-            for (int t = 0; t < 4; t++) {
-                const int i = lane + 64 * t, row = (i * 171) >> 10, col = (i - row * 6) * 8;     // i / 6 for i < 256
-                v[t] = make_uint2(0u, 0u);
-                if (i < WC_ROWS * 6) v[t] = *(const uint2 *)(p00 + (long)(wy0 + row) * k.rs + wx0 + col);
-            }
-        };
-        auto win_commit = [&](const uint2 v[4]) {
-            lds_sync();
-#pragma unroll
-            for (int t = 0; t < 4; t++) {
-                const int i = lane + 64 * t, row = (i * 171) >> 10, col = (i - row * 6) * 8;
-                if (i < WC_ROWS * 6) { uint32_t *d = (uint32_t *)(wbase + row * WC_STRIDE + col); d[0] = v[t].x; d[1] = v[t].y; }
-            }
-            whave = true;
-            pf.count(15);
-            if (slot == 0) { wt.ref0 = j.ref; wt.x00 = wx0; wt.y00 = wy0; } else if (slot == 1) { wt.ref1 = j.ref; wt.x01 = wx0; wt.y01 = wy0; } else { wt.ref2 = j.ref; wt.x02 = wx0; wt.y02 = wy0; }
-            lds_sync();
-        };
-        auto stage_cached = [&](int mx, int my) { uint2 v[4]; win_issue(mx, my, v); win_commit(v); };
         auto stage_costs = [&](int qx, int qy) {
             cbx = qx; cby = qy;
             lds_sync();
             for (int i = lane; i < 192; i += 64) { L.cost[0][i] = cmx[cbx + i - 96]; L.cost[1][i] = cmy[cby + i - 96]; }
             lds_sync();
         };
-
-        // ---- the start candidates.  One trip to memory: the window around the predictor (if this reference's slot does not hold it yet), the
-        //      cost slices around the predictor, and the rows of up to 12 candidates are all requested before the first result is used ----
         unsigned key = 0xffffffffu;
         int pmv_cost = 0;
         {
-            const bool pre = cached && !inside(pmx, pmy, 2);
-            uint2 wv[4];
+            const bool pre = cached && !in_fpel(pmx, pmy, 2);
+            uint32_t rv[20];
             uint16_t cv[2][3];
-            if (pre) { whave = false; win_issue(pmx, pmy, wv); }
-            if (cached) {
+            if (pre) { rhave = false; rc_issue(pmx, pmy, rv); rhave = true; }          // geometry known now, samples after rc_commit
+            if (!umh) {
 #pragma unroll
                 for (int t = 0; t < 3; t++) { cv[0][t] = cmx[cbx + lane + 64 * t - 96]; cv[1][t] = cmy[cby + lane + 64 * t - 96]; }
             }
             uint32_t pp[3][4];
-            int cm[3];
+            int cm[3], cqx[3], cqy[3];
+            bool inl[3];
 #pragma unroll
             for (int t = 0; t < 3; t++) {
-                pp[t][0] = pp[t][1] = pp[t][2] = pp[t][3] = 0; cm[t] = 0;
+                pp[t][0] = pp[t][1] = pp[t][2] = pp[t][3] = 0; cm[t] = 0; cqx[t] = cqy[t] = 0; inl[t] = false;
                 if (t * 4 < n) {
                     const int i = t * 4 + cnd, ii = i < n ? i : 0;
                     const int qx = L.cand[ii][0], qy = L.cand[ii][1];
-                    mc_row_global(p00, pb, k.rs, bx, by + r, qx, qy, w16, pp[t]);
+                    cqx[t] = qx; cqy[t] = qy;
+                    inl[t] = !esa && __all(in_qpel(qx, qy));                           // the whole group of four from the slot, or from memory
+                    if (!inl[t]) mc_row_global(p00, pb, k.rs, bx, by + r, qx, qy, w16, pp[t]);
                     cm[t] = (sub3 || ii > 0) ? (int)cmx[qx] + (int)cmy[qy] : 0;       // below subme 3 the rounded predictor is costed without its vector bits
                 }
+            }
+            if (pre) { rhave = false; rc_commit(rv); }
+            else lds_sync();
+            if (!umh) {
+#pragma unroll
+                for (int t = 0; t < 3; t++) { L.cost[0][lane + 64 * t] = cv[0][t]; L.cost[1][lane + 64 * t] = cv[1][t]; }
             }
 #pragma unroll
             for (int t = 0; t < 3; t++)
                 if (t * 4 < n) {
                     const int i = t * 4 + cnd;
+                    if (inl[t]) rc_row(rslot, X0, Y0, bx, by + r, cqx[t], cqy[t], w16, pp[t]);
                     unsigned sd = __builtin_amdgcn_sad_u8(pp[t][0], e[0], 0u);
                     sd = __builtin_amdgcn_sad_u8(pp[t][1], e[1], sd); sd = __builtin_amdgcn_sad_u8(pp[t][2], e[2], sd); sd = __builtin_amdgcn_sad_u8(pp[t][3], e[3], sd);
                     const int cst = row16_sum(rowok ? (int)sd : 0) + cm[t];
@@ -313,11 +337,6 @@ __device__ __forceinline__ void me_search(const EncK &k, MbLds<M> &L, const MbCt
                     if (t == 0) pmv_cost = __builtin_amdgcn_readlane(cst, 0);
                     key = min(key, wave_min_u32(kk));
                 }
-            if (pre) win_commit(wv);
-            if (cached) {
-#pragma unroll
-                for (int t = 0; t < 3; t++) { L.cost[0][lane + 64 * t] = cv[0][t]; L.cost[1][lane + 64 * t] = cv[1][t]; }
-            }
         }
         {
             const int bi = key & 15;
@@ -329,21 +348,23 @@ __device__ __forceinline__ void me_search(const EncK &k, MbLds<M> &L, const MbCt
         lds_sync();
         pf.mark(PH_ME_PRED);
         if (cached) {
-            if (!inside(bmx, bmy, 2)) stage_cached(bmx, bmy);                                  // a far candidate won
+            if (!in_fpel(bmx, bmy, 2)) rc_stage(bmx, bmy);                                     // a far candidate won
             if (abs(bmx * 4 - cbx) > 20 || abs(bmy * 4 - cby) > 20) stage_costs(bmx * 4, bmy * 4);
         }
         pf.mark(PH_ME_WIN);
+        // esa: its own window (aliases the slots: their tags are dropped when it is staged)
+        int wx0 = 0, wy0 = 0;
 #define MVC(qx, qy) (umh ? (int)cmx[qx] + (int)cmy[qy] : (int)L.cost[0][(qx) - cbx + 96] + (int)L.cost[1][(qy) - cby + 96])
         auto fpel = [&](int mx, int my) {       // full-pel candidate cost (valid after the row sum)
             if (umh) return sad_global(mx * 4, my * 4) + (int)cmx[mx * 4] + (int)cmy[my * 4];
-            const uint8_t *wrow = wbase + (by + my + r - wy0) * wstride;
-            const int xo = bx + mx - wx0;
+            const uint8_t *wrow = esa ? (const uint8_t *)L.rc + (by + my + r - wy0) * WIN_STRIDE : (const uint8_t *)rslot + (by + my + r - Y0) * RC_COLS;
+            const int xo = bx + mx - (esa ? wx0 : X0);
             int sd = 0;
             if (rowok) sd = w16 ? sad_row16_lds(wrow, xo, e) : sad8_lds(wrow, xo, e[0], e[1]);
             return row16_sum(sd) + MVC(mx * 4, my * 4);
         };
-        // the window follows a search that walks out of it (dia / hex; the cost slices reach +-24 around their centre: merange <= 16)
-        auto ensure = [&](int mx, int my, int rad) { if (cached && !inside(mx, my, rad)) stage_cached(mx, my); };
+        // the slot follows a search that walks out of it (dia / hex; the cost slices reach +-24 around their centre: merange <= 16)
+        auto ensure = [&](int mx, int my, int rad) { if (cached && !in_fpel(mx, my, rad)) rc_stage(mx, my); };
         {   // the rounded best predictor and the zero vector: groups 0 and 1
             int c_round, c_zero;
             if (!cached) {
@@ -351,7 +372,7 @@ __device__ __forceinline__ void me_search(const EncK &k, MbLds<M> &L, const MbCt
                 const int cst = sad_global(qx, qy) + cmx[qx] + cmy[qy];
                 c_round = __builtin_amdgcn_readlane(cst, 0); c_zero = __builtin_amdgcn_readlane(cst, 16);
             } else {
-                const bool zlds = inside(0, 0, 0) && abs(cbx) < 96 && abs(cby) < 96;
+                const bool zlds = in_fpel(0, 0, 0) && abs(cbx) < 96 && abs(cby) < 96;
                 int cst;
                 if (zlds) cst = fpel(cnd == 0 ? bmx : 0, cnd == 0 ? bmy : 0);
                 else {
@@ -371,24 +392,23 @@ __device__ __forceinline__ void me_search(const EncK &k, MbLds<M> &L, const MbCt
             }
         }
         bmx = __builtin_amdgcn_readfirstlane(bmx); bmy = __builtin_amdgcn_readfirstlane(bmy);
-        if (spec && c.subme >= 2) {
+        if (spec && c.subme >= 2 && c.chroma_me) {
             spec_on = true; spx = bmx; spy = bmy;
-            sub_issue2(spv, p00, pb, k.rs, (bx + spx - M) & ~3, by + spy - M, SubGeo<M>::rwl(j.W), SubGeo<M>::rh(j.H), SubGeo<M>::ncol(j.W), lane);
-            if (c.chroma_me)
-                chroma_issue2(spc, ref_chroma00(k, c.s, j.ref), k.rs, ((bx >> 1) + (spx >> 1) - CSubGeo<M>::MG) & ~1, (by >> 1) + (spy >> 1) - CSubGeo<M>::MG,
-                              CSubGeo<M>::ndw(j.W >> 1), CSubGeo<M>::rows(j.H >> 1), lane);
+            chroma_issue2(spc, ref_chroma00(k, c.s, j.ref), k.rs, ((bx >> 1) + (spx >> 1) - CSubGeo<M>::MG) & ~1, (by >> 1) + (spy >> 1) - CSubGeo<M>::MG,
+                          CSubGeo<M>::ndw(j.W >> 1), CSubGeo<M>::rows(j.H >> 1), lane);
         }
-        if (ME == 3) {      // esa: its window around the start
+        if (esa) {      // its window around the start
             lds_sync();
+            wt.ref0 = wt.ref1 = wt.ref2 = -1; rhave = false;
             wx0 = clampi((bx + bmx - WIN_R) & ~7, -PAD, k.cw + PAD - WIN_COLS); wy0 = clampi(by + bmy - WIN_R, -PAD, k.ch + PAD - WIN_ROWS);
             for (int i = lane; i < WIN_ROWS * 8; i += 64) {
                 const int row = i >> 3, col = (i & 7) * 8;
                 const uint2 v = *(const uint2 *)(p00 + (long)(wy0 + row) * k.rs + wx0 + col);
-                uint32_t *d = (uint32_t *)(L.win + row * WIN_STRIDE + col);
+                uint32_t *d = (uint32_t *)((uint8_t *)L.rc + row * WIN_STRIDE + col);
                 d[0] = v.x; d[1] = v.y;
             }
         }
-        if (ME == 3 || (cached && (abs(bmx * 4 - cbx) > 20 || abs(bmy * 4 - cby) > 20))) stage_costs(bmx * 4, bmy * 4);       // the zero vector won far away
+        if (esa || (cached && (abs(bmx * 4 - cbx) > 20 || abs(bmy * 4 - cby) > 20))) stage_costs(bmx * 4, bmy * 4);       // the zero vector won far away
         bool hexrefine = true;
         if (umh) {
             // X264_ME_UMH (oracle me_search_ref case 2): four candidates per step, in-order "strictly better wins" = min of (cost << 2 | order)
@@ -566,15 +586,11 @@ __device__ __forceinline__ void me_search(const EncK &k, MbLds<M> &L, const MbCt
             if (cst < bcost) { bcost = cst; bmx = mx; bmy = my; }
         }
     }
-    // every sample the diamonds below can touch lies within M px of the rounded start: stage it (all four half-pel planes) in LDS
+    // every sample the diamonds below can touch lies within M px of the rounded start: the reference-cache slot must hold that area
     const int ctrx = (bmx + 2) >> 2, ctry = (bmy + 2) >> 2;
-    uint32_t *sb = L.sub;
-    const int rwl = SubGeo<M>::rwl(j.W), rh = SubGeo<M>::rh(j.H), ncol = SubGeo<M>::ncol(j.W), sn = rh << rwl;
-    const int sx0 = (bx + ctrx - M) & ~3, sy0 = by + ctry - M;
     lds_sync();
+    if (!in_sub(ctrx, ctry)) rc_stage(ctrx, ctry);
     const bool spec_hit = spec && spec_on && ctrx == spx && ctry == spy;
-    if (spec_hit) sub_commit2(sb, spv, rwl, rh, lane);
-    else sub_stage<M>(sb, p00, pb, k.rs, sx0, sy0, rwl, rh, ncol, lane, 64);
     // chroma: lane r owns row (r & 3) of 4x4 chroma block r >> 2 of the partition, both planes
     const int cbw = j.W >> 3, ncb = cbw * (j.H >> 3), cblk = r >> 2;
     const bool cact = cblk < ncb;
@@ -597,10 +613,7 @@ __device__ __forceinline__ void me_search(const EncK &k, MbLds<M> &L, const MbCt
     auto mvc2 = [&](int qx, int qy) { return lcost ? (int)L.cost[0][qx - cbx + 96] + (int)L.cost[1][qy - cby + 96] : (int)cmx[qx] + (int)cmy[qy]; };
     auto fetch2 = [&](int qx, int qy, uint32_t p[4]) {
         p[0] = p[1] = p[2] = p[3] = 0;
-        if (rowok) {
-            if (w16) sub_row16(sb, sn, rwl, sx0, sy0, bx, by + r, qx, qy, p);
-            else sub_row8(sb, sn, rwl, sx0, sy0, bx, by + r, qx, qy, p);
-        }
+        if (rowok) rc_row(rslot, X0, Y0, bx, by + r, qx, qy, w16, p);
     };
     auto sad2 = [&](int qx, int qy) {
         uint32_t p[4];
