@@ -29,13 +29,16 @@ enum { ME_16 = 0, ME_8 = 1, ME_16x8 = 5, ME_8x16 = 7, ME_COUNT = 9 };     // slo
 // they touch lie inside, and re-centre it (one trip to memory for all four planes) when they do not: most searches of a macroblock then
 // cost no trip at all.  esa uses the same bytes as ONE +-17 full-pel window (WIN_ROWS x WIN_STRIDE); umh roams global memory for its
 // full-pel steps and uses the slot for the sub-pel ones.
+constexpr int MVC_N = 512;
 constexpr int RC_ROWS = 30, RC_PD = 10, RC_COLS = 4 * RC_PD, RC_PLANE_DW = RC_ROWS * RC_PD, RC_SLOT_DW = 4 * RC_PLANE_DW, RC_MX = 12, RC_MY = 7;
 struct WinTags { int ref0, x00, y00, ref1, x01, y01, ref2, x02, y02; };
 
 template <int M> struct MbLds {
     __attribute__((aligned(16))) uint32_t rc[3 * RC_SLOT_DW];        // >= WIN_ROWS * WIN_STRIDE bytes (esa)
     uint32_t csub[CSubGeo<M>::DWORDS];
-    uint16_t cost[2][192];
+    __attribute__((aligned(16))) uint8_t src[16 * 16];    // the source macroblock, row-major (the searches read rows of it)
+    __attribute__((aligned(16))) uint8_t csrc[8 * 16];    // its NV12 chroma rows
+    uint16_t mvcost[MVC_N];                    // mv-cost table of this macroblock's quantiser for |mv - mvp| < MVC_N quarter-samples (it is symmetric)
     __attribute__((aligned(8))) uint8_t tile[IT_SIZE];
     __attribute__((aligned(8))) uint8_t tile8[IT_SIZE];
     __attribute__((aligned(8))) int16_t lv8[256];
@@ -194,11 +197,17 @@ __device__ __forceinline__ void me_search(const EncK &k, MbLds<M> &L, const MbCt
     const int bx = c.px + j.ox, by = c.py + j.oy;
     uint32_t e[4] = { 0, 0, 0, 0 };
     if (rowok) {
-        const uint8_t *f = c.fenc + (size_t)(j.oy + r) * k.fs + j.ox;
+        const uint8_t *f = L.src + (j.oy + r) * 16 + j.ox;
         const uint2 a = *(const uint2 *)f; e[0] = a.x; e[1] = a.y;
         if (w16) { const uint2 b = *(const uint2 *)(f + 8); e[2] = b.x; e[3] = b.y; }
     }
     const uint16_t *cmx = c.cost_base + MVCOST_HALF - j.mvpx, *cmy = c.cost_base + MVCOST_HALF - j.mvpy;
+    // bits of a vector: both components from the LDS copy of the table; a component 128 samples or more from the predictor reads the table itself
+    auto mvc = [&](int qx, int qy) {
+        const int dx = abs(qx - j.mvpx), dy = abs(qy - j.mvpy);
+        if (__builtin_expect(__any(dx >= MVC_N || dy >= MVC_N), 0)) return (int)cmx[qx] + (int)cmy[qy];
+        return (int)L.mvcost[dx] + (int)L.mvcost[dy];
+    };
     // SAD of this lane's row at a quarter-pel vector, from global memory; summed over the candidate's 16 lanes
     auto sad_global = [&](int qx, int qy) {
         uint32_t p[4];
@@ -209,7 +218,6 @@ __device__ __forceinline__ void me_search(const EncK &k, MbLds<M> &L, const MbCt
     };
     const int fmin0 = c.fmin0, fmax0 = c.fmax0, fmin1 = c.fmin1, fmax1 = c.fmax1;
     constexpr bool umh = ME == 2, esa = ME == 3, cached = ME == 0 || ME == 1;      // cached: the full-pel steps read the reference-cache slot
-    int cbx = 0, cby = 0;                      // centre of the LDS slices of the mv-cost table (dia / hex / esa searches)
     // ---- this reference's slot of the reference cache ----
     const int slot = j.ref >= 3 ? j.ref - 3 : j.ref;
     uint32_t *rslot = L.rc + slot * RC_SLOT_DW;
@@ -286,24 +294,12 @@ __device__ __forceinline__ void me_search(const EncK &k, MbLds<M> &L, const MbCt
         //      One trip to memory at most: the slot around the predictor (if it does not hold that area yet), the cost slices, and the rows of
         //      those candidates the slot does not hold are all requested before the first result is used ----
         int i_me_range = k.me_range;
-        cbx = pmx * 4; cby = pmy * 4;
-        auto stage_costs = [&](int qx, int qy) {
-            cbx = qx; cby = qy;
-            lds_sync();
-            for (int i = lane; i < 192; i += 64) { L.cost[0][i] = cmx[cbx + i - 96]; L.cost[1][i] = cmy[cby + i - 96]; }
-            lds_sync();
-        };
         unsigned key = 0xffffffffu;
         int pmv_cost = 0;
         {
             const bool pre = cached && !in_fpel(pmx, pmy, 2);
             uint32_t rv[20];
-            uint16_t cv[2][3];
             if (pre) { rhave = false; rc_issue(pmx, pmy, rv); rhave = true; }          // geometry known now, samples after rc_commit
-            if (!umh) {
-#pragma unroll
-                for (int t = 0; t < 3; t++) { cv[0][t] = cmx[cbx + lane + 64 * t - 96]; cv[1][t] = cmy[cby + lane + 64 * t - 96]; }
-            }
             uint32_t pp[3][4];
             int cm[3], cqx[3], cqy[3];
             bool inl[3];
@@ -316,15 +312,11 @@ __device__ __forceinline__ void me_search(const EncK &k, MbLds<M> &L, const MbCt
                     cqx[t] = qx; cqy[t] = qy;
                     inl[t] = !esa && __all(in_qpel(qx, qy));                           // the whole group of four from the slot, or from memory
                     if (!inl[t]) mc_row_global(p00, pb, k.rs, bx, by + r, qx, qy, w16, pp[t]);
-                    cm[t] = (sub3 || ii > 0) ? (int)cmx[qx] + (int)cmy[qy] : 0;       // below subme 3 the rounded predictor is costed without its vector bits
+                    cm[t] = (sub3 || ii > 0) ? mvc(qx, qy) : 0;       // below subme 3 the rounded predictor is costed without its vector bits
                 }
             }
             if (pre) { rhave = false; rc_commit(rv); }
             else lds_sync();
-            if (!umh) {
-#pragma unroll
-                for (int t = 0; t < 3; t++) { L.cost[0][lane + 64 * t] = cv[0][t]; L.cost[1][lane + 64 * t] = cv[1][t]; }
-            }
 #pragma unroll
             for (int t = 0; t < 3; t++)
                 if (t * 4 < n) {
@@ -349,14 +341,13 @@ __device__ __forceinline__ void me_search(const EncK &k, MbLds<M> &L, const MbCt
         pf.mark(PH_ME_PRED);
         if (cached) {
             if (!in_fpel(bmx, bmy, 2)) rc_stage(bmx, bmy);                                     // a far candidate won
-            if (abs(bmx * 4 - cbx) > 20 || abs(bmy * 4 - cby) > 20) stage_costs(bmx * 4, bmy * 4);
         }
         pf.mark(PH_ME_WIN);
         // esa: its own window (aliases the slots: their tags are dropped when it is staged)
         int wx0 = 0, wy0 = 0;
-#define MVC(qx, qy) (umh ? (int)cmx[qx] + (int)cmy[qy] : (int)L.cost[0][(qx) - cbx + 96] + (int)L.cost[1][(qy) - cby + 96])
+#define MVC(qx, qy) mvc(qx, qy)
         auto fpel = [&](int mx, int my) {       // full-pel candidate cost (valid after the row sum)
-            if (umh) return sad_global(mx * 4, my * 4) + (int)cmx[mx * 4] + (int)cmy[my * 4];
+            if (umh) return sad_global(mx * 4, my * 4) + mvc(mx * 4, my * 4);
             const uint8_t *wrow = esa ? (const uint8_t *)L.rc + (by + my + r - wy0) * WIN_STRIDE : (const uint8_t *)rslot + (by + my + r - Y0) * RC_COLS;
             const int xo = bx + mx - (esa ? wx0 : X0);
             int sd = 0;
@@ -369,15 +360,15 @@ __device__ __forceinline__ void me_search(const EncK &k, MbLds<M> &L, const MbCt
             int c_round, c_zero;
             if (!cached) {
                 const int qx = cnd == 0 ? bmx * 4 : 0, qy = cnd == 0 ? bmy * 4 : 0;
-                const int cst = sad_global(qx, qy) + cmx[qx] + cmy[qy];
+                const int cst = sad_global(qx, qy) + mvc(qx, qy);
                 c_round = __builtin_amdgcn_readlane(cst, 0); c_zero = __builtin_amdgcn_readlane(cst, 16);
             } else {
-                const bool zlds = in_fpel(0, 0, 0) && abs(cbx) < 96 && abs(cby) < 96;
+                const bool zlds = in_fpel(0, 0, 0);
                 int cst;
                 if (zlds) cst = fpel(cnd == 0 ? bmx : 0, cnd == 0 ? bmy : 0);
                 else {
                     cst = fpel(bmx, bmy);
-                    const int z = sad_global(0, 0) + cmx[0] + cmy[0];
+                    const int z = sad_global(0, 0) + mvc(0, 0);
                     if (cnd == 1) cst = z;
                 }
                 c_round = __builtin_amdgcn_readlane(cst, 0); c_zero = __builtin_amdgcn_readlane(cst, 16);
@@ -408,7 +399,7 @@ __device__ __forceinline__ void me_search(const EncK &k, MbLds<M> &L, const MbCt
                 d[0] = v.x; d[1] = v.y;
             }
         }
-        if (esa || (cached && (abs(bmx * 4 - cbx) > 20 || abs(bmy * 4 - cby) > 20))) stage_costs(bmx * 4, bmy * 4);       // the zero vector won far away
+        if (esa) lds_sync();
         bool hexrefine = true;
         if (umh) {
             // X264_ME_UMH (oracle me_search_ref case 2): four candidates per step, in-order "strictly better wins" = min of (cost << 2 | order)
@@ -565,8 +556,6 @@ __device__ __forceinline__ void me_search(const EncK &k, MbLds<M> &L, const MbCt
             mvx = bmx * 4; mvy = bmy * 4;
         } else if (bpred_cost < bcost) {
             mvx = bpred_mx; mvy = bpred_my; cost = bpred_cost;
-            // the best predictor after a search that started at the zero vector far from it: the sub-pel steps need the costs around IT
-            if (!umh && (abs(mvx - cbx) > 64 || abs(mvy - cby) > 64)) stage_costs(((mvx + 2) >> 2) * 4, ((mvy + 2) >> 2) * 4);
         } else { mvx = bmx * 4; mvy = bmy * 4; cost = bcost; }
         mvx = __builtin_amdgcn_readfirstlane(mvx); mvy = __builtin_amdgcn_readfirstlane(mvy);
         cost_mv = MVC(mvx, mvy);
@@ -582,7 +571,7 @@ __device__ __forceinline__ void me_search(const EncK &k, MbLds<M> &L, const MbCt
     if (j.hp_it && c.subme < 3) {     // the sub-pel component of the predicted vector (anywhere: global memory)
         const int mx = clampi(j.mvpx, c.smin0 + 2, c.smax0 - 2), my = clampi(j.mvpy, c.smin1 + 2, c.smax1 - 2);
         if ((mx - bmx) | (my - bmy)) {
-            const int cst = __builtin_amdgcn_readlane(sad_global(mx, my), 0) + cmx[mx] + cmy[my];
+            const int cst = __builtin_amdgcn_readlane(sad_global(mx, my), 0) + mvc(mx, my);
             if (cst < bcost) { bcost = cst; bmx = mx; bmy = my; }
         }
     }
@@ -600,17 +589,14 @@ __device__ __forceinline__ void me_search(const EncK &k, MbLds<M> &L, const MbCt
     const int cndw = CSubGeo<M>::ndw(j.W >> 1), cnr = CSubGeo<M>::rows(j.H >> 1);
     const int cx0c = ((bx >> 1) + (ctrx >> 1) - CSubGeo<M>::MG) & ~1, cy0c = (by >> 1) + (ctry >> 1) - CSubGeo<M>::MG;
     if (chroma_me) {
-        if (cact) { const uint2 v = *(const uint2 *)(c.fuv + (size_t)ccy * k.fs + 2 * ccx); ce0 = v.x; ce1 = v.y; }
+        if (cact) { const uint2 v = *(const uint2 *)(L.csrc + ccy * 16 + 2 * ccx); ce0 = v.x; ce1 = v.y; }
         if (spec_hit) chroma_commit2(cb, spc, cndw, cnr, lane);
         else chroma_stage(cb, ref_chroma00(k, c.s, j.ref), k.rs, cx0c, cy0c, cndw, cnr, lane, 64);
     }
     lds_sync();
     pf.mark(PH_ME_SUBSTAGE);
     const s16x2 sg1 = pk_sign(lane & 1), sg2 = pk_sign(lane & 2);
-    // vector bits: the search's LDS slices reach every sub-pel position around its full-pel result (not when the predicted vector took over
-    // below subme 3 far from there); a refinement-only call reads the table
-    const bool lcost = !umh && j.search && abs(bmx - cbx) <= 72 && abs(bmy - cby) <= 72;
-    auto mvc2 = [&](int qx, int qy) { return lcost ? (int)L.cost[0][qx - cbx + 96] + (int)L.cost[1][qy - cby + 96] : (int)cmx[qx] + (int)cmy[qy]; };
+    auto mvc2 = [&](int qx, int qy) { return mvc(qx, qy); };
     auto fetch2 = [&](int qx, int qy, uint32_t p[4]) {
         p[0] = p[1] = p[2] = p[3] = 0;
         if (rowok) rc_row(rslot, X0, Y0, bx, by + r, qx, qy, w16, p);
@@ -918,7 +904,7 @@ __device__ __forceinline__ int mb_intra_chroma_cost(const EncK &k, MbLds<M> &L, 
     const bool left = c.mbx > 0, top = c.sy > 0;
     const uint8_t *cnb = L.cnb[pl];
     const PredC pc = predc_setup(cnb);
-    const uint2 fe = *(const uint2 *)(c.fuv + (size_t)cyy * k.fs + 2 * cx0);
+    const uint2 fe = *(const uint2 *)(L.csrc + cyy * 16 + 2 * cx0);
     const uint32_t cenc = nv12_pick(fe.x, fe.y, pl);
     // candidate list by availability, a nibble string: DC H V P | DC_LEFT H | DC_TOP V | DC_128
     const unsigned lst = left && top ? 0x3210u : left ? 0x14u : top ? 0x25u : 0x6u;
@@ -1133,7 +1119,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(MB_WAVES_PER
     x264gpu_mb *mbs = k.mb + (size_t)s * k.nmb;
     constexpr bool pslice = PS;                 // I slices run their own instantiation (no search code, a fraction of the registers)
     const int j4 = lane & 3, zx = z_x0(lane), zy = z_y(lane);
-    int intra_count = 0;
+    int intra_count = 0, cost_qp = -1;
     Prof pf;
     pf.start();
     int16_t *mv16 = k.mv16_cur + (size_t)s * k.nmb * 2;
@@ -1149,6 +1135,13 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(MB_WAVES_PER
         c.lambda = k.lambda_tab[c.qp];
         c.subme = min(max(k.subme, 0), 11); c.satd = c.subme > 1; c.chroma_me = pslice && k.chroma_me && c.subme >= 5;
         c.cost_base = k.cost_all + (size_t)c.qp * 2 * MVCOST_HALF;
+        if (pslice && c.qp != cost_qp) {          // the mv-cost table of this quantiser (symmetric: non-negative differences only) into LDS
+            cost_qp = c.qp;
+            lds_sync();
+            const uint32_t *src = (const uint32_t *)(c.cost_base + MVCOST_HALF);
+            for (int i = lane; i < MVC_N / 2; i += 64) ((uint32_t *)L.mvcost)[i] = src[i];
+            lds_sync();
+        }
         c.nref = k.nref;
         const Q4 &q_li = k.q4tab[c.qp * 4 + 0], &q_lp = k.q4tab[c.qp * 4 + 1], &q_ci = k.q4tab[c.qpc * 4 + 2], &q_cp = k.q4tab[c.qpc * 4 + 3];
         const Q8 &q8i = k.q8tab[c.qp * 2 + 0], &q8p = k.q8tab[c.qp * 2 + 1];
@@ -1209,6 +1202,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(MB_WAVES_PER
             S.cref = ref; S.cmvx = vx; S.cmvy = vy;
         }
         const uint32_t cz = *(const uint32_t *)(c.fenc + (size_t)zy * k.fs + zx);
+        *(uint32_t *)(L.src + zy * 16 + zx) = cz;
+        if (lane < 32) *(uint32_t *)(L.csrc + (lane >> 2) * 16 + (lane & 3) * 4) = *(const uint32_t *)(c.fuv + (size_t)(lane >> 2) * k.fs + (lane & 3) * 4);
         lds_sync();
 
         x264gpu_mb &recd = L.rec;
@@ -1595,7 +1590,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(MB_WAVES_PER
 #pragma unroll
                     for (int i8 = 0; i8 < 4; i8++) cbp_luma |= ((nnz >> (4 * i8)) & 15) ? 1 << i8 : 0;
                 }
-                const uint2 fe = *(const uint2 *)(c.fuv + (size_t)cyy * k.fs + 2 * cx0);
+                const uint2 fe = *(const uint2 *)(L.csrc + cyy * 16 + 2 * cx0);
                 const uint32_t cenc = nv12_pick(fe.x, fe.y, pl);
                 const uint32_t crec = mb_chroma_residual(cenc, cpred, q_cp, true, k.dct_decimate != 0, lane, lv, nnz, cbp_chroma);
                 mb_store_chroma(ruv, k.rs, lane, crec);
@@ -1683,7 +1678,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(MB_WAVES_PER
             {
                 const int pl = (lane >> 4) & 1, ci = (lane >> 2) & 3, cx0 = (ci & 1) * 4, cyy = (ci >> 1) * 4 + j4;
                 const PredC pc = predc_setup(L.cnb[pl]);
-                const uint2 fe = *(const uint2 *)(c.fuv + (size_t)cyy * k.fs + 2 * cx0);
+                const uint2 fe = *(const uint2 *)(L.csrc + cyy * 16 + 2 * cx0);
                 const uint32_t cenc = nv12_pick(fe.x, fe.y, pl), cpred = predc_row4(L.cnb[pl], pc, predc, ci, j4);
                 if (lane == 0) recd.chroma_mode = (uint8_t)(predc > PREDC_P ? PREDC_DC : predc);
                 const uint32_t crec = mb_chroma_residual(cenc, cpred, q_ci, false, false, lane, lv, nnz, cbp_chroma);
