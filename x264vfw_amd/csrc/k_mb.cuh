@@ -1248,6 +1248,32 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(MB_WAVES_PER
                 if (lane == 0) { mv16[2 * mbi] = 0; mv16[2 * mbi + 1] = 0; }
                 if (lane >= 1 && lane < c.nref) { int16_t *m = k.mvr[lane] + ((size_t)s * k.nmb + mbi) * 2; m[0] = 0; m[1] = 0; }
             }
+            // ---- 16x16 search candidates of every reference (oracle predict_mv_ref16x16): lookahead vector, 16x16 results of the left / top /
+            //      top-left / top-right macroblocks in that reference, co-located vectors of reference 0 scaled by the POC distances.
+            //      Slot order: [lookahead] left top top-left top-right [co-located, its right neighbour, its lower neighbour]; lane i of a
+            //      16-lane group fetches raw candidate i, groups 0..3 serve references 0..3 in ONE trip to memory ----
+            const bool has_lr = k.lowres_mv && (k.lowres_mv + (size_t)s * k.nmb * 2)[0] != 0x7fff;
+            const bool t1 = k.temporal && mbx < k.mbw - 1, t2 = k.temporal && mby < k.mbh - 1;
+            auto gather16 = [&](int r, int ln, int &vx, int &vy) {
+                const int i = ln & 15;
+                const int16_t *mvr = (r == 0 ? k.mv16_cur : r == 1 ? k.mvr[1] : r == 2 ? k.mvr[2] : r == 3 ? k.mvr[3] : k.mvr[4]) + (size_t)s * k.nmb * 2;
+                const int base = has_lr && r == 0 ? 1 : 0, q = i - base;
+                vx = 0; vy = 0;
+                if (base && i == 0) { const int16_t *lm = k.lowres_mv + (size_t)s * k.nmb * 2; vx = lm[2 * mbi] * 2; vy = lm[2 * mbi + 1] * 2; }
+                else if (q >= 0 && q < 4) {
+                    const int nb = q == 0 ? (left ? mbi - 1 : -1) : q == 1 ? (top ? mbi - k.mbw : -1) : q == 2 ? (topleft ? mbi - k.mbw - 1 : -1) : (topright ? mbi - k.mbw + 1 : -1);
+                    if (nb >= 0) { vx = mvr[2 * nb]; vy = mvr[2 * nb + 1]; }
+                } else if (q >= 4 && q < 7 && k.temporal) {
+                    // co-located; then its right neighbour (if there is one), then its lower neighbour (if there is one)
+                    const int16_t *l0 = k.mv16_ref0 + (size_t)s * k.nmb * 2;
+                    const int scale = r == 0 ? k.tscale[0] : r == 1 ? k.tscale[1] : r == 2 ? k.tscale[2] : r == 3 ? k.tscale[3] : k.tscale[4], jx = q - 4;
+                    const bool ok = jx == 0 || (jx == 1 && (t1 || t2)) || (jx == 2 && t1 && t2);
+                    const int at = jx == 0 ? mbi : (jx == 1 && t1) ? mbi + 1 : mbi + k.mbw;
+                    if (ok) { vx = (l0[2 * at] * scale + 128) >> 8; vy = (l0[2 * at + 1] * scale + 128) >> 8; }
+                }
+            };
+            int gvx = 0, gvy = 0;
+            if (!pskip && (lane >> 4) < c.nref) gather16(lane >> 4, lane, gvx, gvy);
             // ---- inter analysis: one search call site, walked by a small state machine (oracle analyse_inter_*) ----
             const bool psub16 = (parts & 1) != 0, mixed = k.mixed_refs != 0;
             int stage = 0, part = 0, kk = 0, nk = c.nref;
@@ -1286,27 +1312,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(MB_WAVES_PER
                     // candidates (oracle predict_mv_ref16x16): lookahead vector, 16x16 results of the left / top / top-left / top-right macroblocks
                     // in this reference, co-located vectors of reference 0 scaled by the POC distances
                     {
-                        // slot order: [lookahead] left top top-left top-right [co-located, its right neighbour, its lower neighbour]; lanes fetch in parallel
-                        const int16_t *mvr = (r == 0 ? k.mv16_cur : k.mvr[r]) + (size_t)s * k.nmb * 2;
-                        const bool has_lr = r == 0 && k.lowres_mv && (k.lowres_mv + (size_t)s * k.nmb * 2)[0] != 0x7fff;
-                        const int base = has_lr ? 1 : 0;
-                        const bool t1 = k.temporal && mbx < k.mbw - 1, t2 = k.temporal && mby < k.mbh - 1;
-                        // lane i fetches raw candidate i
-                        const int q = lane - base;
-                        int vx = 0, vy = 0;
-                        if (has_lr && lane == 0) { const int16_t *lm = k.lowres_mv + (size_t)s * k.nmb * 2; vx = lm[2 * mbi] * 2; vy = lm[2 * mbi + 1] * 2; }
-                        else if (q >= 0 && q < 4) {
-                            const int nb = q == 0 ? (left ? mbi - 1 : -1) : q == 1 ? (top ? mbi - k.mbw : -1) : q == 2 ? (topleft ? mbi - k.mbw - 1 : -1) : (topright ? mbi - k.mbw + 1 : -1);
-                            if (nb >= 0) { vx = mvr[2 * nb]; vy = mvr[2 * nb + 1]; }
-                        } else if (q >= 4 && q < 7 && k.temporal) {
-                            // co-located; then its right neighbour (if there is one), then its lower neighbour (if there is one)
-                            const int16_t *l0 = k.mv16_ref0 + (size_t)s * k.nmb * 2;
-                            const int scale = k.tscale[r], jx = q - 4;
-                            const bool ok = jx == 0 || (jx == 1 && (t1 || t2)) || (jx == 2 && t1 && t2);
-                            const int at = jx == 0 ? mbi : (jx == 1 && t1) ? mbi + 1 : mbi + k.mbw;
-                            if (ok) { vx = (l0[2 * at] * scale + 128) >> 8; vy = (l0[2 * at + 1] * scale + 128) >> 8; }
-                        }
-                        S.inx = vx; S.iny = vy;
+                        // raw candidate i of reference r: gathered for references 0..3 in one trip before the loop (gvx / gvy, lane = r * 16 + i)
+                        const int base = has_lr ? (r == 0 ? 1 : 0) : 0;
+                        if (r < 4) { S.inx = __shfl(gvx, r * 16 + (lane & 15)); S.iny = __shfl(gvy, r * 16 + (lane & 15)); }
+                        else { int vx, vy; gather16(4, lane, vx, vy); S.inx = vx; S.iny = vy; }
                         jb.n_mvc = base + 4 + (k.temporal ? 1 + (t1 ? 1 : 0) + (t2 ? 1 : 0) : 0);
                     }
                     lds_sync();
