@@ -139,7 +139,7 @@ __device__ __forceinline__ uint32_t load_u32_unaligned(const uint8_t *p)
 // rounding byte-wise average of 4 packed pixels: (a+b+1)>>1 per byte
 __device__ __forceinline__ uint32_t avg4_u8(uint32_t a, uint32_t b)
 {
-    return (a | b) - (((a ^ b) >> 1) & 0x7f7f7f7fu);
+    return __builtin_amdgcn_lerp(a, b, 0x01010101u);          // v_lerp_u8: (a + b + (c & 1)) >> 1 per byte
 }
 
 // ---------------------------------------------------------------------------------------------
