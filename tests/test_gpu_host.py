@@ -503,7 +503,7 @@ def test_sliced_threads_through_the_api(gpu, w, h, opts, slices):
     assert h_
     eff = HL.Param()
     H.x264_encoder_parameters(h_, C.byref(eff))
-    assert eff.b_sliced_threads == 1
+    assert eff.b_sliced_threads == 1 and eff.i_threads == slices
     nfr = 6
     frames = synth_frames(w, h, nfr, seed=77 + w)
     stream, info, recons = encode_all(h_, w, h, frames)

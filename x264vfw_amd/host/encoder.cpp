@@ -403,7 +403,12 @@ x264_t *x264_encoder_open(x264_param_t *param)
     return h;
 }
 
-void x264_encoder_parameters(x264_t *h, x264_param_t *param) { if (h && param) *param = h->param; }
+void x264_encoder_parameters(x264_t *h, x264_param_t *param)
+{
+    if (!h || !param) return;
+    *param = h->param;
+    if (h->slices > 1 && h->G <= 1) param->i_threads = h->slices;      // slice threads: i_threads is the slice count, as in x264
+}
 
 static void publish_nals(x264_t *h, x264_nal_t **pp_nal, int *pi_nal, const std::vector<int> &types)
 {
