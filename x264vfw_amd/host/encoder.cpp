@@ -230,7 +230,7 @@ x264_t *x264_encoder_open(x264_param_t *param)
         // X264GPU_GOP_SLOTS=G asks for it: the --threads G mode below (fixed keyint, delay (G-1) x keyint) with every picture in slices
         if (const char *gs = getenv("X264GPU_GOP_SLOTS")) { const int g = atoi(gs); if (g > 1) p.i_threads = g; }
     }
-    p.i_threads = clampi(p.i_threads, 1, 64);                  // --threads G: GOPs coded in lock-step (1 = no delay)
+    p.i_threads = clampi(p.i_threads, 1, 256);                 // --threads G: GOPs coded in lock-step (1 = no delay)
     if (p.i_keyint_max <= 0) p.i_keyint_max = 1;
     h->keyint = p.i_keyint_max;
     // rate control: constant QP (X264_RC_CQP, codec.c:1498-1502) and single-pass CRF without AQ / mbtree (codec.c:1504-1507, the
