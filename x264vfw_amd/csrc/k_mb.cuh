@@ -1148,62 +1148,76 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(MB_WAVES_PER
         const bool left = c.mbx > 0, top = c.sy > 0, topright = top && c.mbx + 1 < k.mbw, topleft = top && left;
         const int mbx = c.mbx, mby = c.mby;
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-        const int type_left = uni(left ? (int)mbs[mbi - 1].type : -1), type_top = uni(top ? (int)mbs[mbi - k.mbw].type : -1);
-        const int type_tl = uni(topleft ? (int)mbs[mbi - k.mbw - 1].type : -1), type_tr = uni(topright ? (int)mbs[mbi - k.mbw + 1].type : -1);
         auto intra_t = [](int t) { return t >= 0 && t <= 3; };
         uint8_t *rec = rec_plane00(k, s) + (size_t)c.py * k.rs + c.px;
         uint8_t *ruv = rec_chroma00(k, s) + (size_t)(mby * 8) * k.rs + c.px;
         int16_t *lv = k.levels + ((size_t)s * k.nmb + mbi) * X264GPU_MB_LEVELS;
         uint8_t *tile = L.tile + IT_ORG, *tile8 = L.tile8 + IT_ORG;
 
-        // ---- neighbour samples (row -1, column -1 of the reconstruction), neighbour edge modes, chroma ring ----
-        lds_sync();
+        // ---- everything the macroblock reads of its neighbours, in ONE trip to memory: all requests first (no load depends on another),
+        //      the LDS stores after.  Reconstruction row -1 / column -1, chroma ring, neighbour types, edge modes, motion of the 8x8 blocks
+        //      around the macroblock, the source samples ----
+        uint8_t v_y = 128, v_c = 128;
+        int n_type = -1, n_mode = 2, nb_type = -1, mc_type = -1, mc_ref = 0, mc_vx = 0, mc_vy = 0;
         if (lane < 25) {
             const int x = lane - 1;
-            const bool ok = top && (x >= 0 || left) && (x < 16 || topright);
-            const uint8_t v = ok ? rec[-(long)k.rs + x] : 128;
-            tile[-IT_STRIDE + x] = v; tile8[-IT_STRIDE + x] = v;
-            if (lane < 21) L.nb[NB_TOP + x] = v;
+            if (top && (x >= 0 || left) && (x < 16 || topright)) v_y = rec[-(long)k.rs + x];
         } else if (lane >= 32 && lane < 48) {
-            const int y = lane - 32;
-            const uint8_t v = left ? rec[(long)y * k.rs - 1] : 128;
-            tile[y * IT_STRIDE - 1] = v; tile8[y * IT_STRIDE - 1] = v; L.nb[NB_LEFT + y] = v;
-        } else if (lane >= 48 && lane < 56) {
+            if (left) v_y = rec[(long)(lane - 32) * k.rs - 1];
+        } else if (lane >= 48 && lane < 56) {          // edge modes of the left / top macroblocks
             const int i = lane - 48;
-            int m = 2;
-            if (i < 4 && left) { const x264gpu_mb *n = mbs + mbi - 1; if (n->type == X264GPU_MB_I4x4 || n->type == X264GPU_MB_I8x8) m = n->i4_mode[blkidx_of(3, i)]; }
-            if (i >= 4 && top) { const x264gpu_mb *n = mbs + mbi - k.mbw; if (n->type == X264GPU_MB_I4x4 || n->type == X264GPU_MB_I8x8) m = n->i4_mode[blkidx_of(i - 4, 3)]; }
-            L.nmodes[i] = (uint8_t)m;
+            const x264gpu_mb *n = i < 4 ? (left ? mbs + mbi - 1 : nullptr) : (top ? mbs + mbi - k.mbw : nullptr);
+            if (n) { n_type = n->type; n_mode = n->i4_mode[i < 4 ? blkidx_of(3, i) : blkidx_of(i - 4, 3)]; }
+        } else if (lane >= 56 && lane < 60) {          // types of the left / top / top-left / top-right macroblocks
+            const int q = lane - 56;
+            const int nbi = q == 0 ? (left ? mbi - 1 : -1) : q == 1 ? (top ? mbi - k.mbw : -1) : q == 2 ? (topleft ? mbi - k.mbw - 1 : -1) : (topright ? mbi - k.mbw + 1 : -1);
+            if (nbi >= 0) nb_type = mbs[nbi].type;
         }
         {
             const int t = lane & 15, pl = (lane >> 4) & 1;
-            if (lane < 32) {
-                if (t < 9) { const int x = t - 1; L.cnb[pl][CNB_TOP + x] = (top && (x >= 0 || left)) ? ruv[-(long)k.rs + 2 * x + pl] : 128; }
-            } else if (lane < 48) {
-                const int y = t & 7, pl2 = (t >> 3) & 1;
-                L.cnb[pl2][CNB_LEFT + y] = left ? ruv[(long)y * k.rs - 2 + pl2] : 128;
-            }
+            if (lane < 32) { if (t < 9) { const int x = t - 1; if (top && (x >= 0 || left)) v_c = ruv[-(long)k.rs + 2 * x + pl]; } }
+            else if (lane < 48) { if (left) v_c = ruv[(long)(t & 7) * k.rs - 2 + ((t >> 3) & 1)]; }
         }
-        // ---- motion cache: neighbours' references / vectors at 8x8 granularity; this macroblock's blocks start unavailable ----
-        MeState S = {};
-        if (lane < 12) {
+        if (lane < 12 && pslice) {                     // motion cache grid: x = -1..2, y = -1..1
             const int gx = (lane & 3) - 1, gy = (lane >> 2) - 1;
-            int ref = -2, vx = 0, vy = 0, nbi = -1, blk = 0;
+            int nbi = -1, blk = 0;
             if (gy < 0) {
                 if (gx < 0) { if (topleft) { nbi = mbi - k.mbw - 1; blk = 3; } }
                 else if (gx < 2) { if (top) { nbi = mbi - k.mbw; blk = 2 + gx; } }
                 else if (topright) { nbi = mbi - k.mbw + 1; blk = 2; }
             } else if (gx < 0 && left) { nbi = mbi - 1; blk = 1 + 2 * gy; }
-            if (pslice && nbi >= 0) {
-                const x264gpu_mb *n = mbs + nbi;
-                if (n->type <= 3) ref = -1;
-                else { ref = n->ref[blk]; vx = n->mv[blk][0]; vy = n->mv[blk][1]; }
-            }
-            S.cref = ref; S.cmvx = vx; S.cmvy = vy;
+            if (nbi >= 0) { const x264gpu_mb *n = mbs + nbi; mc_type = n->type; mc_ref = n->ref[blk]; mc_vx = n->mv[blk][0]; mc_vy = n->mv[blk][1]; }
         }
         const uint32_t cz = *(const uint32_t *)(c.fenc + (size_t)zy * k.fs + zx);
+        uint32_t csv = 0;
+        if (lane < 32) csv = *(const uint32_t *)(c.fuv + (size_t)(lane >> 2) * k.fs + (lane & 3) * 4);
+        // ---- ... into LDS / registers ----
+        lds_sync();
+        if (lane < 25) {
+            const int x = lane - 1;
+            tile[-IT_STRIDE + x] = v_y; tile8[-IT_STRIDE + x] = v_y;
+            if (lane < 21) L.nb[NB_TOP + x] = v_y;
+        } else if (lane >= 32 && lane < 48) {
+            const int y = lane - 32;
+            tile[y * IT_STRIDE - 1] = v_y; tile8[y * IT_STRIDE - 1] = v_y; L.nb[NB_LEFT + y] = v_y;
+        } else if (lane >= 48 && lane < 56) {
+            L.nmodes[lane - 48] = (uint8_t)((n_type == X264GPU_MB_I4x4 || n_type == X264GPU_MB_I8x8) ? n_mode : 2);
+        }
+        {
+            const int t = lane & 15, pl = (lane >> 4) & 1;
+            if (lane < 32) { if (t < 9) L.cnb[pl][CNB_TOP + t - 1] = v_c; }
+            else if (lane < 48) L.cnb[(t >> 3) & 1][CNB_LEFT + (t & 7)] = v_c;
+        }
+        const int type_left = rl(nb_type, 56), type_top = rl(nb_type, 57), type_tl = rl(nb_type, 58), type_tr = rl(nb_type, 59);
+        // motion cache: neighbours' references / vectors at 8x8 granularity; this macroblock's blocks start unavailable
+        MeState S = {};
+        if (lane < 12) {
+            int ref = -2, vx = 0, vy = 0;
+            if (mc_type >= 0) { if (mc_type <= 3) ref = -1; else { ref = mc_ref; vx = mc_vx; vy = mc_vy; } }
+            S.cref = ref; S.cmvx = vx; S.cmvy = vy;
+        }
         *(uint32_t *)(L.src + zy * 16 + zx) = cz;
-        if (lane < 32) *(uint32_t *)(L.csrc + (lane >> 2) * 16 + (lane & 3) * 4) = *(const uint32_t *)(c.fuv + (size_t)(lane >> 2) * k.fs + (lane & 3) * 4);
+        if (lane < 32) *(uint32_t *)(L.csrc + (lane >> 2) * 16 + (lane & 3) * 4) = csv;
         lds_sync();
 
         x264gpu_mb &recd = L.rec;
