@@ -575,3 +575,26 @@ def test_slice_threads_with_gop_slots(gpu, monkeypatch):
     H.x264_encoder_close(hg)
     H.x264_picture_clean(C.byref(pic))
     assert got == nfr and stream == serial
+
+
+def test_access_unit_delimiters(gpu):
+    """--aud: every access unit starts with a type-9 NAL whose primary_pic_type tells I from P (7.3.2.4); the rest of the stream is unchanged"""
+    w, h, nfr = 96, 80, 5
+    frames = synth_frames(w, h, nfr, seed=9)
+    opts = {"qp": 28, "keyint": 3, "no-scenecut": None}
+    h0, _ = open_encoder(w, h, opts, b"high")
+    plain, _, _ = encode_all(h0, w, h, frames)
+    H.x264_encoder_close(h0)
+    h1, eff = open_encoder(w, h, dict(opts, aud=None), b"high")
+    assert eff.b_aud == 1
+    stream, info, recons = encode_all(h1, w, h, frames)
+    H.x264_encoder_close(h1)
+    for i, (_, _, _, types) in enumerate(info):
+        assert types[0] == 9 and types.count(9) == 1, (i, types)
+    auds = [stream[k + 4:k + 6] for k in range(len(stream) - 6) if stream[k:k + 5] == b"\x00\x00\x00\x01\x09"]
+    assert [a[1] >> 5 for a in auds] == [0 if i % 3 == 0 else 1 for i in range(nfr)]          # primary_pic_type
+    short = lambda b: b.replace(b"\x00\x00\x00\x01", b"\x00\x00\x01")          # only the first NAL of an access unit has the long start code
+    assert short(stream).replace(b"\x00\x00\x01\x09\x10", b"").replace(b"\x00\x00\x01\x09\x30", b"") == short(plain)
+    dec = O.h264_decode(stream, nfr, w, h)
+    for i in range(nfr):
+        np.testing.assert_array_equal(dec[i], recons[i])

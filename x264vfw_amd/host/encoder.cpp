@@ -164,6 +164,15 @@ static PpsParams make_pps(const x264_t *h)
     return pp;
 }
 // appends SPS, PPS (and optionally the version SEI) to h->out, recording NAL offsets and types
+// access unit delimiter (--aud, 7.3.2.4): primary_pic_type 0 = I slices only, 1 = I and P; first NAL of the access unit (long start code)
+static void write_aud(std::vector<uint8_t> &out, bool intra_only, bool annexb)
+{
+    BitWriter bw;
+    bw.put(intra_only ? 0u : 1u, 3);
+    bw.trailing();
+    append_nal(out, 0, 9, bw.bytes(), annexb, true);
+}
+
 static void emit_sets(x264_t *h, std::vector<int> &types, bool sei)
 {
     const bool annexb = h->param.b_annexb != 0;
@@ -203,10 +212,12 @@ x264_t *x264_encoder_open(x264_param_t *param)
     p.analyse.b_mixed_references = p.analyse.b_mixed_references && p.i_frame_reference > 1;      // x264 validate_parameters
     p.b_cabac = p.b_cabac != 0;
     if (p.b_cabac && p.i_cabac_init_idc != 0) { xlog(&p, X264_LOG_WARNING, "cabac-idc %d: only the context tables of cabac_init_idc 0 (x264's default) are in the MI355X path: cabac-idc 0\n", p.i_cabac_init_idc); p.i_cabac_init_idc = 0; }
+    if (p.analyse.i_weighted_pred > X264_WEIGHTP_NONE) xlog(&p, X264_LOG_WARNING, "weightp %d is not implemented in the MI355X path yet: weightp 0\n", p.analyse.i_weighted_pred);
     p.analyse.i_weighted_pred = X264_WEIGHTP_NONE; p.analyse.b_weighted_bipred = 0;
     p.analyse.b_transform_8x8 = p.analyse.b_transform_8x8 != 0;
     p.analyse.inter &= X264_ANALYSE_I4x4 | X264_ANALYSE_I8x8 | X264_ANALYSE_PSUB16x16; p.analyse.intra &= X264_ANALYSE_I4x4 | X264_ANALYSE_I8x8;
     if (!p.analyse.b_transform_8x8) { p.analyse.inter &= ~X264_ANALYSE_I8x8; p.analyse.intra &= ~X264_ANALYSE_I8x8; }   // as x264 validate_parameters
+    if (p.analyse.i_trellis) xlog(&p, X264_LOG_WARNING, "trellis %d is not implemented in the MI355X path yet (it needs RD): trellis 0\n", p.analyse.i_trellis);
     p.analyse.i_trellis = 0;
     p.i_scenecut_threshold = clampi(p.i_scenecut_threshold, 0, 100);
     if (p.analyse.i_me_method > X264_ME_ESA) { xlog(&p, X264_LOG_WARNING, "me tesa is not implemented in the MI355X path yet: me esa\n"); p.analyse.i_me_method = X264_ME_ESA; }
@@ -216,7 +227,12 @@ x264_t *x264_encoder_open(x264_param_t *param)
     p.analyse.i_subpel_refine = clampi(p.analyse.i_subpel_refine, 0, 5);
     p.analyse.b_fast_pskip = p.analyse.b_fast_pskip != 0;
     p.analyse.b_chroma_me = p.analyse.b_chroma_me != 0;
-    p.b_interlaced = 0; p.i_slice_count = 1;
+    if (p.b_interlaced) { xlog(&p, X264_LOG_WARNING, "interlaced coding is not implemented in the MI355X path: progressive\n"); p.b_interlaced = 0; }
+    if (p.i_slice_count > 1) xlog(&p, X264_LOG_WARNING, "slices %d: only slice threads (--sliced-threads --threads N) split pictures in the MI355X path: slices 1\n", p.i_slice_count);
+    p.i_slice_count = 1;
+    if (p.b_constrained_intra) { xlog(&p, X264_LOG_WARNING, "constrained-intra is not implemented in the MI355X path: off\n"); p.b_constrained_intra = 0; }
+    if (p.b_intra_refresh) { xlog(&p, X264_LOG_WARNING, "intra-refresh is not implemented in the MI355X path: off\n"); p.b_intra_refresh = 0; }
+    if (p.i_nal_hrd) { xlog(&p, X264_LOG_WARNING, "nal-hrd needs VBV, which is not implemented in the MI355X path: none\n"); p.i_nal_hrd = 0; }
     // --sliced-threads / --tune zerolatency: i_threads is the number of slices per picture (x264 validate_parameters: at most one per four
     // macroblock rows; auto = as many as that allows, where x264 would count host cores) and there is one GOP in flight
     h->slices = 1;
@@ -507,6 +523,7 @@ static int code_position(x264_t *h, int batch, int t, int nslots_with_t)
         c.bytes.clear(); c.off.clear(); c.types.clear();
         c.idr = t == 0;
         const long gop = (long)batch * G + s;
+        if (p.b_aud) { c.off.push_back(c.bytes.size()); c.types.push_back(9); write_aud(c.bytes, t == 0, p.b_annexb != 0); }
         if (c.idr && p.b_repeat_headers) {
             const bool annexb = p.b_annexb != 0;
             c.off.push_back(c.bytes.size()); c.types.push_back(7); write_sps(c.bytes, make_sps(h), annexb);
@@ -753,6 +770,7 @@ static int encode_queued(x264_t *h, x264_nal_t **pp_nal, int *pi_nal, x264_pictu
     // ---- host: headers + entropy coding ----
     h->out.clear(); h->nal_off.clear();
     std::vector<int> types;
+    if (p.b_aud) { h->nal_off.push_back(h->out.size()); types.push_back(9); write_aud(h->out, st != X264GPU_SLICE_P, p.b_annexb != 0); }
     if (idr && p.b_repeat_headers) {
         emit_sets(h, types, !h->sei_sent);
         h->sei_sent = 1;
