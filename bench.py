@@ -67,7 +67,7 @@ def toolset(args):
     t = {"medium": dict(refs=args.refs, subme=5, deblock=1, partitions=7, dct8x8=1, me_method=1, chroma_me=1, mixed_refs=1),
          "ultrafast": dict(refs=1, subme=0, deblock=0, partitions=0x100, dct8x8=0, me_method=0, chroma_me=0, mixed_refs=0),
          "slow": dict(refs=4, subme=5, deblock=1, partitions=7, dct8x8=1, me_method=2, chroma_me=1, mixed_refs=1)}[args.preset]
-    t = dict(t, fast_pskip=1, mv_range=512)
+    t = dict(t, fast_pskip=1, mv_range=512, cabac=0 if args.preset == "ultrafast" else 1)          # medium's entropy coder (it runs on the host; the analysis costs know it)
     if args.aq:
         t = dict(t, aq_mode=1, aq_strength_q8=266)
     return t

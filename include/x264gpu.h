@@ -180,6 +180,9 @@ typedef struct x264gpu_config {
     int aq_strength_q8;       /* --aq-strength * 1.0397 * 256, rounded (x264 default 1.0 -> 266) */
     int fast_pskip;           /* --no-fast-pskip clears it (x264 default on): P_Skip probed inside the analysis (x264_macroblock_probe_pskip) */
     int mv_range;             /* --mvrange in luma samples, both directions; 0 = 512.  x264 takes it from the level (x264_levels[].mv_range) */
+    int cabac;                /* the session's entropy coder is CABAC (x264 b_cabac).  Entropy coding stays on the host, but x264's analysis knows the coder:
+                               * under CABAC the P8x8 sub-macroblock type costs nothing (no sub-8x8 analysis here) and reference 0 of a P8x8 macroblock is
+                               * costed like any other; under CAVLC P_8x8ref0 makes it free ([x264-upstream] analyse.c x264_mb_analyse_inter_p8x8*) */
     int slices;               /* x264 --sliced-threads with --threads N: N slices per picture (0 / 1 = one), slice i = macroblock rows
                                * [(mbh * i + N/2) / N, (mbh * (i+1) + N/2) / N); every slice is analysed on its own (no prediction across a slice
                                * boundary, its own fast-intra statistics and quantiser chain) and the loop filter leaves slice boundaries alone

@@ -828,18 +828,18 @@ static void analyse_inter_p8x8_mixed_ref(actx *a)
         }
         cache_block(a, x8, y8, 1, 1, l0m->ref, l0m->mv);
         a->satd8x8[i] = l0m->cost - (l0m->cost_mv + l0m->ref_cost);
-        /* sub-macroblock type cost: CAVLC, or CABAC with sub-8x8 analysis (not the case here: CAVLC) */
-        l0m->cost += a->lambda * 1;
+        /* sub-macroblock type cost: under CABAC without sub-8x8 analysis it is effectively zero */
+        if (!a->e->cfg.cabac) l0m->cost += a->lambda * 1;
     }
     a->cost8x8 = a->me8[0].cost + a->me8[1].cost + a->me8[2].cost + a->me8[3].cost;
     /* P_8x8ref0 has no reference cost (CAVLC) */
-    if (!(a->me8[0].ref | a->me8[1].ref | a->me8[2].ref | a->me8[3].ref)) a->cost8x8 -= ref_cost(a, 0) * 4;
+    if (!a->e->cfg.cabac && !(a->me8[0].ref | a->me8[1].ref | a->me8[2].ref | a->me8[3].ref)) a->cost8x8 -= ref_cost(a, 0) * 4;
 }
 
 static void analyse_inter_p8x8(actx *a)
 {
     const int r = a->me16.ref;
-    const int i_ref_cost = r ? ref_cost(a, r) : 0;          /* CAVLC: reference 0 of P_8x8 costs nothing (P_8x8ref0) */
+    const int i_ref_cost = (a->e->cfg.cabac || r) ? ref_cost(a, r) : 0;          /* CAVLC: reference 0 of P_8x8 costs nothing (P_8x8ref0) */
     int i_mvc = 1;
     a->partition = D_8x8;
     a->mvc[r][0][0] = a->me16.mv[0]; a->mvc[r][0][1] = a->me16.mv[1];
@@ -855,7 +855,7 @@ static void analyse_inter_p8x8(actx *a)
         i_mvc++;
         a->satd8x8[i] = m->cost - m->cost_mv;
         m->cost += i_ref_cost;
-        m->cost += a->lambda * 1;
+        if (!a->e->cfg.cabac) m->cost += a->lambda * 1;
     }
     a->cost8x8 = a->me8[0].cost + a->me8[1].cost + a->me8[2].cost + a->me8[3].cost;
 }

@@ -21,7 +21,7 @@ def random_case(rnd):
               subme=rnd.choice([0, 1, 2, 3, 4, 5, 6, 7, 8, 9]), me_method=rnd.choice([0, 1, 1, 2, 3]), chroma_me=rnd.randint(0, 1), mixed_refs=rnd.randint(0, 1), aq_mode=rnd.randint(0, 1), aq_strength_q8=rnd.choice([133, 266, 400]), me_range=rnd.choice([4, 8, 16]),
               qp_i=rnd.randint(0, 51), qp_p=rnd.randint(0, 51), deblock=rnd.randint(0, 1), dct_decimate=rnd.randint(0, 1),
               deblock_alpha=rnd.randint(-3, 3), deblock_beta=rnd.randint(-3, 3), chroma_qp_offset=rnd.randint(-6, 6),
-              fast_pskip=rnd.randint(0, 1), mv_range=rnd.choice([0, 0, 32, 64, 128, 512]))
+              fast_pskip=rnd.randint(0, 1), mv_range=rnd.choice([0, 0, 32, 64, 128, 512]), cabac=rnd.randint(0, 1))
     if rnd.random() < 0.25 and (h + 15) // 16 >= 8:
         kw["slices"] = rnd.randint(2, (h + 15) // 16 // 4)        # x264 slice threads
     return w, h, kw, rnd.randint(2, 6), rnd.randint(0, 10 ** 6), rnd.random() < 0.3

@@ -98,7 +98,7 @@ def test_preset_ultrafast_is_fully_covered(gpu):
     stream, info, recons = encode_all(h_, w, h, frames)
     H.x264_encoder_close(h_)
     qp_i = max(1, int(qp - 6.0 * np.log2(1.4) + 0.5))
-    enc = O.OracleEncoder(O.default_config(w, h, qp_i=qp_i, qp_p=qp, partitions=0x100, refs=1, me_method=0, subme=0, deblock=0, mv_range=eff.analyse.i_mv_range))
+    enc = O.OracleEncoder(O.default_config(w, h, qp_i=qp_i, qp_p=qp, partitions=0x100, refs=1, me_method=0, subme=0, deblock=0, mv_range=eff.analyse.i_mv_range, cabac=eff.b_cabac))
     ref = b""
     for i, f in enumerate(frames):
         mbs, lv = enc.encode(f, 2 if i == 0 else 0)
@@ -120,7 +120,7 @@ def test_bitstream_equals_oracle_path(gpu):
     stream, info, _ = encode_all(h_, w, h, frames)
     H.x264_encoder_close(h_)
     qp_i = max(1, int(qp - 6.0 * np.log2(1.4) + 0.5))
-    enc = O.OracleEncoder(O.default_config(w, h, qp_i=qp_i, qp_p=qp, partitions=7, refs=3, dct8x8=1, chroma_me=1, mixed_refs=1, subme=5, mv_range=eff.analyse.i_mv_range))      # medium: p8x8 + i4x4 + i8x8, ref 3, 8x8dct, chroma-me; subme 7 -> 5 (no RD yet)
+    enc = O.OracleEncoder(O.default_config(w, h, qp_i=qp_i, qp_p=qp, partitions=7, refs=3, dct8x8=1, chroma_me=1, mixed_refs=1, subme=5, mv_range=eff.analyse.i_mv_range, cabac=eff.b_cabac))      # medium: p8x8 + i4x4 + i8x8, ref 3, 8x8dct, chroma-me; subme 7 -> 5 (no RD yet)
     ref = b""
     for i, f in enumerate(frames):
         mbs, lv = enc.encode(f, 2 if i == 0 else 0)
@@ -241,7 +241,7 @@ def test_scenecut_inserts_idr(gpu):
     assert [r[0] for r in rows] == [1, 0, 0, 0, 0, 0, 1, 0, 0, 0, 0]
     assert rows[6][2] == 1 and rows[6][3][1] >= 0.9 * rows[6][3][0] and all(r[2] == 0 for i, r in enumerate(rows) if i != 6)
     dec = O.h264_decode(stream, len(frames), w, h)
-    og = O.OracleEncoder(O.default_config(w, h, qp_i=24, qp_p=27, partitions=7, refs=3, dct8x8=1, chroma_me=1, mixed_refs=1, subme=5, mv_range=eff.analyse.i_mv_range))
+    og = O.OracleEncoder(O.default_config(w, h, qp_i=24, qp_p=27, partitions=7, refs=3, dct8x8=1, chroma_me=1, mixed_refs=1, subme=5, mv_range=eff.analyse.i_mv_range, cabac=eff.b_cabac))
     for i, f in enumerate(frames):
         np.testing.assert_array_equal(dec[i], recons[i], err_msg=f"decoded picture {i}")
         og.encode(f, 2 if rows[i][0] else 0)
@@ -280,7 +280,7 @@ def test_crf_follows_the_lookahead_complexity(gpu):
     assert len(set(qps)) > 1 and rows[5][0] == 1                     # the cut is an IDR and the quantiser moves with the content
     dec = O.h264_decode(stream, len(frames), w, h)
     assert eff.rc.i_aq_mode == 1                                    # x264's default: variance AQ rides on CRF
-    og = O.OracleEncoder(O.default_config(w, h, partitions=7, refs=3, dct8x8=1, chroma_me=1, mixed_refs=1, aq_mode=1, aq_strength_q8=266, subme=5, mv_range=eff.analyse.i_mv_range))
+    og = O.OracleEncoder(O.default_config(w, h, partitions=7, refs=3, dct8x8=1, chroma_me=1, mixed_refs=1, aq_mode=1, aq_strength_q8=266, subme=5, mv_range=eff.analyse.i_mv_range, cabac=eff.b_cabac))
     for i, f in enumerate(frames):
         np.testing.assert_array_equal(dec[i], recons[i], err_msg=f"decoded picture {i}")
         og.set_qp(rows[i][1], rows[i][1])
@@ -392,7 +392,7 @@ def test_crf_with_macroblock_tree(gpu, monkeypatch):
     ol = O.OracleLookahead(w, h)
     infos = [ol.frame_cost(f, i == 0)[1] for i, f in enumerate(frames)]
     aqs = [O.aq_offsets(f, w, h, 266) for f in frames]
-    og = O.OracleEncoder(O.default_config(w, h, partitions=7, refs=3, dct8x8=1, chroma_me=1, mixed_refs=1, aq_mode=1, aq_strength_q8=266, subme=5, mv_range=eff.analyse.i_mv_range))
+    og = O.OracleEncoder(O.default_config(w, h, partitions=7, refs=3, dct8x8=1, chroma_me=1, mixed_refs=1, aq_mode=1, aq_strength_q8=266, subme=5, mv_range=eff.analyse.i_mv_range, cabac=eff.b_cabac))
     bw, bh = (w + 15) // 16, (h + 15) // 16
     lowered = 0
     for i, f in enumerate(frames):
@@ -512,7 +512,7 @@ def test_sliced_threads_through_the_api(gpu, w, h, opts, slices):
         assert sum(1 for t in types if t in (1, 5)) == slices, (i, types)      # one slice NAL per slice, every call returns its picture
     dec = O.h264_decode(stream, nfr, w, h)
     og = O.OracleEncoder(O.default_config(w, h, slices=slices, partitions=7, refs=3, dct8x8=1, chroma_me=1, mixed_refs=1, subme=5, qp_i=max(0, opts["qp"] - 3), qp_p=opts["qp"],
-                                          mv_range=eff.analyse.i_mv_range))
+                                          mv_range=eff.analyse.i_mv_range, cabac=eff.b_cabac))
     keyint = opts["keyint"]
     for i, f in enumerate(frames):
         np.testing.assert_array_equal(dec[i], recons[i], err_msg=f"decoded picture {i}")
@@ -536,7 +536,7 @@ def test_full_size_round_trip(gpu, w, h, opts, okw):
     assert eff.b_cabac == 1
     dec = O.h264_decode(stream, nfr, w, h)
     slices = (h + 15) // 16 // 4 if "sliced-threads" in opts else 1
-    kw = dict(slices=slices, partitions=7, refs=3, dct8x8=1, chroma_me=1, mixed_refs=1, subme=5, qp_i=opts["qp"] - 3, qp_p=opts["qp"], mv_range=eff.analyse.i_mv_range)
+    kw = dict(slices=slices, partitions=7, refs=3, dct8x8=1, chroma_me=1, mixed_refs=1, subme=5, qp_i=opts["qp"] - 3, qp_p=opts["qp"], mv_range=eff.analyse.i_mv_range, cabac=eff.b_cabac)
     kw.update(okw)
     og = O.OracleEncoder(O.default_config(w, h, **kw))
     for i, f in enumerate(frames):

@@ -92,6 +92,8 @@ def compare(tag, mbw, g_mb, o_mb, g_lv, o_lv, g_rec, o_rec):
     (176, 144, 4, dict(subme=3, partitions=3, refs=2)),                      # subme 3 / 4: quarter-pel predictors, fewer refinement steps
     (176, 144, 4, dict(subme=4, partitions=7, dct8x8=1, refs=3, mixed_refs=1)),
     (96, 80, 5, dict(subme=0, partitions=3, refs=3, mixed_refs=1)),          # full-pel only with partitions
+    (176, 144, 5, dict(cabac=1, partitions=3, refs=2)),                      # CABAC session: P8x8 costs without the CAVLC sub-type / P_8x8ref0 terms
+    (352, 288, 5, dict(cabac=1, partitions=7, dct8x8=1, refs=3, mixed_refs=1, chroma_me=1, subme=5)),
     (176, 144, 4, dict(slices=2, partitions=3, refs=2)),                     # x264 slice threads: slices analysed on their own, no filtering across them
     (96, 208, 5, dict(slices=3, partitions=7, dct8x8=1, refs=3, mixed_refs=1, chroma_me=1, subme=5)),
     (64, 272, 4, dict(slices=4, aq_mode=1, partitions=7, dct8x8=1, qp_i=30, qp_p=34)),

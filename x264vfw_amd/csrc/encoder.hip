@@ -116,7 +116,7 @@ int x264gpu_encoder_create(x264gpu_encoder **out, const x264gpu_config *cfg)
     k.luma_bytes = 4 * k.plane_bytes;
     k.cplane_bytes = (size_t)k.rs * (k.ch / 2 + 2 * CPAD);
     k.me_range = cfg->me_range; k.subme = cfg->subme; k.dct_decimate = cfg->dct_decimate;
-    k.slices = cfg->slices > 1 ? cfg->slices : 1;
+    k.slices = cfg->slices > 1 ? cfg->slices : 1; k.cabac = cfg->cabac != 0;
     k.partitions = cfg->partitions; k.chroma_qp_offset = cfg->chroma_qp_offset; k.dct8x8 = cfg->dct8x8; k.me_method = cfg->me_method; k.chroma_me = cfg->chroma_me != 0; k.mixed_refs = cfg->mixed_refs != 0;
     k.alpha_off = cfg->deblock_alpha * 2; k.beta_off = cfg->deblock_beta * 2;
     const size_t S = (size_t)cfg->streams;

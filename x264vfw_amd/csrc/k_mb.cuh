@@ -1409,7 +1409,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(MB_WAVES_PER
                     continue;
                 }
                 if (stage == 1) {
-                    const int rcost = mixed ? rc : (r ? rc : 0);
+                    const int rcost = mixed ? rc : ((r || k.cabac) ? rc : 0);        // CAVLC: reference 0 of P_8x8 costs nothing (P_8x8ref0)
                     cost += rcost;
                     wl(S.mvcx, lane, r * 5 + part + 1, mvx); wl(S.mvcy, lane, r * 5 + part + 1, mvy);
                     if (kk == 0 || cost < rl(S.cost, slot)) me_store(S, lane, slot, mvx, mvy, cost, cost_mv, r, rcost, jb.mvpx, jb.mvpy);
@@ -1420,12 +1420,12 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(MB_WAVES_PER
                         wl(S.cref, lane, g, rl(S.ref, slot)); wl(S.cmvx, lane, g, rl(S.mvx, slot)); wl(S.cmvy, lane, g, rl(S.mvy, slot));
                         const int sv = rl(S.cost, slot) - (rl(S.costmv, slot) + rl(S.refcost, slot));
                         if (part == 0) sat8[0] = sv; else if (part == 1) sat8[1] = sv; else if (part == 2) sat8[2] = sv; else sat8[3] = sv;
-                        S.cost += lane == slot ? c.lambda : 0;            // sub-macroblock type (CAVLC)
+                        S.cost += (lane == slot && !k.cabac) ? c.lambda : 0;        // sub-macroblock type: free under CABAC without sub-8x8 analysis
                     }
                     kk = 0;
                     if (++part < 4) continue;
                     cost8x8 = rl(S.cost, ME_8) + rl(S.cost, ME_8 + 1) + rl(S.cost, ME_8 + 2) + rl(S.cost, ME_8 + 3);
-                    if (mixed && !(rl(S.ref, ME_8) | rl(S.ref, ME_8 + 1) | rl(S.ref, ME_8 + 2) | rl(S.ref, ME_8 + 3))) cost8x8 -= ref_bits(c.nref, 0) * c.lambda * 4;
+                    if (mixed && !k.cabac && !(rl(S.ref, ME_8) | rl(S.ref, ME_8 + 1) | rl(S.ref, ME_8 + 2) | rl(S.ref, ME_8 + 3))) cost8x8 -= ref_bits(c.nref, 0) * c.lambda * 4;
                     const int c16 = rl(S.cost, ME_16);
                     if (!early_term || cost8x8 < c16) { best_part = D_8x8; i_cost = cost8x8; }
                     const int th = rl(S.costmv, ME_8 + 1) + rl(S.costmv, ME_8 + 2);

@@ -292,7 +292,7 @@ x264_t *x264_encoder_open(x264_param_t *param)
         if (h->G != p.i_threads) xlog(&p, X264_LOG_INFO, "threads %d -> %d (GOP ring of keyint %d pictures)\n", p.i_threads, h->G, h->keyint);
         p.i_threads = h->G;
     }
-    cfg.width = p.i_width; cfg.height = p.i_height; cfg.streams = h->G; cfg.refs = p.i_frame_reference; cfg.slices = h->slices;
+    cfg.width = p.i_width; cfg.height = p.i_height; cfg.streams = h->G; cfg.refs = p.i_frame_reference; cfg.slices = h->slices; cfg.cabac = p.b_cabac;
     cfg.qp_i = h->qp_i; cfg.qp_p = h->qp_p; cfg.me_range = p.analyse.i_me_range; cfg.subme = p.analyse.i_subpel_refine;
     cfg.deblock = p.b_deblocking_filter; cfg.deblock_alpha = p.i_deblocking_filter_alphac0; cfg.deblock_beta = p.i_deblocking_filter_beta;
     cfg.chroma_qp_offset = p.analyse.i_chroma_qp_offset;
