@@ -49,6 +49,8 @@ typedef struct {          /* x264_mb_analysis_t + the parts of h->mb the analysi
     int satd8x8[4], cost_est16x8_1, cost_est8x16_1;
     int satd_i16, satd_i8, satd_i4, satd_chroma;
     int pred16, pred8[4], pred4[16], predc;
+    /* RD mode decision (cfg.rd): x264_mb_analysis_t i_mbrd, l0.i_rd16x16, forced transform size of the candidate being costed */
+    int mbrd, rd16x16, force_t8, lambda2, chroma_lambda2_offset;
 } actx;
 
 /* ---------------------------------------------------------------------------------------------------------------------------
@@ -762,6 +764,8 @@ static void cache_block(actx *a, int bx8, int by8, int w8, int h8, int ref, cons
         }
 }
 
+static int rd_cost_inter(actx *a, int partition, int t8, x264gpu_mb *mb, int16_t *lv);
+
 /* returns 1 when the macroblock was settled as P_SKIP inside the 16x16 search */
 static int analyse_inter_p16x16(actx *a)
 {
@@ -792,6 +796,12 @@ static int analyse_inter_p16x16(actx *a)
         if (m.cost < a->me16.cost) a->me16 = m;
     }
     cache_block(a, 0, 0, 2, 2, a->me16.ref, NULL);
+    if (a->mbrd && a->me16.ref == 0 && a->me16.mv[0] == a->pskip_mv[0] && a->me16.mv[1] == a->pskip_mv[1]) {
+        /* RD: the 16x16 result IS the skip vector — cost it now; nothing coded means P_SKIP */
+        x264gpu_mb *mb = &e->mbs[a->mi];
+        a->rd16x16 = rd_cost_inter(a, D_16x16, 0, mb, e->levels + (size_t)a->mi * X264GPU_MB_LEVELS);
+        if (mb->type == X264GPU_MB_P_SKIP) return 1;
+    }
     return 0;
 }
 
@@ -1225,7 +1235,8 @@ static void encode_inter_mb(actx *a, x264gpu_mb *mb, int16_t *lv)
     if (mb->type == X264GPU_MB_P_SKIP) return;                /* x264_macroblock_encode_skip: the prediction is the reconstruction */
     /* x264_mb_analyse_transform: SA8D vs SATD of the prediction error */
     mb->transform8x8 = 0;
-    if (e->cfg.dct8x8) mb->transform8x8 = x264o_sa8d(fenc, e->fs, rec, e->rs, 16, 16) < x264o_satd(fenc, e->fs, rec, e->rs, 16, 16);
+    if (a->force_t8 >= 0) mb->transform8x8 = (uint8_t)a->force_t8;          /* RD: the transform size is a candidate property (x264_mb_analyse_transform_rd) */
+    else if (e->cfg.dct8x8) mb->transform8x8 = x264o_sa8d(fenc, e->fs, rec, e->rs, 16, 16) < x264o_satd(fenc, e->fs, rec, e->rs, 16, 16);
     if (mb->transform8x8) encode_luma_inter8(e, fenc, rec, a->qp, mb, lv);
     else encode_luma_inter(e, fenc, rec, a->qp, mb, lv);
     if (!mb->cbp_luma) mb->transform8x8 = 0;      /* the flag is not transmitted without luma coefficients (macroblock_cache_save) */
@@ -1237,15 +1248,189 @@ static void encode_inter_mb(actx *a, x264gpu_mb *mb, int16_t *lv)
 
 /* ---------------------------------------------------------------------------------------------------------------------------
  * x264_macroblock_analyse + x264_macroblock_encode for macroblock (mbx,mby) */
+
+/* ===========================================================================================================================
+ * Rate-distortion mode decision (cfg.rd: x264 subme 6 / 7, i_mbrd 1; [x264-upstream] encoder/rdo.c x264_rd_cost_mb, encoder/analyse.c
+ * x264_mb_analyse_p_rd / _transform_rd / x264_intra_rd), with the bit counts of a CAVLC session (x264_macroblock_size_cavlc: exactly the
+ * bits the macroblock layer would take, without the skip run).  Restated from memory like the rest of this file. */
+int x264o_cavlc_block_bits(const int16_t *l, int n, int nC, int *total_out);       /* rd.cpp */
+int x264o_cavlc_cbp_bits(int cbp, int inter);
+static int bs_size_se(int v) { return bs_size_ue(v <= 0 ? -2 * v : 2 * v - 1); }
+
+/* total_coeff of block b (0..15 luma, 16..23 chroma AC: plane * 4 + block) of a finished macroblock, as the nC derivation sees it */
+static int nb_total_coeff(const x264o_encoder *e, int mi, int b)
+{
+    const x264gpu_mb *m = &e->mbs[mi];
+    const int16_t *lv = e->levels + (size_t)mi * X264GPU_MB_LEVELS;
+    int c = 0;
+    if (m->type == X264GPU_MB_P_SKIP) return 0;
+    if (b < 16) {
+        if (!((m->cbp_luma >> (b >> 2)) & 1)) return 0;
+        for (int i = m->type == X264GPU_MB_I16x16; i < 16; i++) c += lv[b * 16 + i] != 0;
+    } else {
+        if (m->cbp_chroma != 2) return 0;
+        for (int i = 1; i < 16; i++) c += lv[X264GPU_LV_CHROMA_AC + (b - 16) * 16 + i] != 0;
+    }
+    return c;
+}
+
+/* bits of the macroblock layer of *mb (already coded into lv; neighbours from e->mbs) in a CAVLC slice */
+static int mb_bits_cavlc(actx *a, const x264gpu_mb *mb, const int16_t *lv)
+{
+    x264o_encoder *e = a->e;
+    const int pslice = e->slice_type == X264GPU_SLICE_P, left = a->mbx > 0, top = a->mby > e->row0, mi = a->mi;
+    const int intra = mb->type <= X264GPU_MB_I16x16;
+    int bits = 0, tc[24];
+    memset(tc, 0, sizeof(tc));
+    if (!intra) {
+        static const int8_t geom[4][4][4] = { { { 0, 0, 2, 2 } }, { { 0, 0, 2, 1 }, { 0, 1, 2, 1 } }, { { 0, 0, 1, 2 }, { 1, 0, 1, 2 } },
+                                              { { 0, 0, 1, 1 }, { 1, 0, 1, 1 }, { 0, 1, 1, 1 }, { 1, 1, 1, 1 } } };
+        const int nparts = mb->partition == D_16x16 ? 1 : mb->partition == D_8x8 ? 4 : 2;
+        const int part_bak = a->partition, valid_bak = a->cur_valid;
+        nb_t cur_bak[4];
+        memcpy(cur_bak, a->cur8, sizeof(cur_bak));
+        bits += bs_size_ue(mb->partition);
+        if (mb->partition == D_8x8) bits += 4;                                      /* four sub_mb_type ue(0) */
+        if (a->nref > 1) for (int k = 0; k < nparts; k++) { const int8_t *g = geom[mb->partition][k]; bits += a->nref == 2 ? 1 : bs_size_ue(mb->ref[g[1] * 2 + g[0]]); }
+        a->partition = mb->partition; a->cur_valid = 0;
+        for (int k = 0; k < nparts; k++) {
+            const int8_t *g = geom[mb->partition][k];
+            const int b8 = g[1] * 2 + g[0];
+            int mvp[2];
+            const int mv[2] = { mb->mv[b8][0], mb->mv[b8][1] };
+            for (int y = g[1]; y < g[1] + g[3]; y++) for (int x = g[0]; x < g[0] + g[2]; x++) a->cur8[y * 2 + x].ref = mb->ref[b8];   /* cache_ref before predicting */
+            predict_mv(a, g[0], g[1], g[2], mb->ref[b8], mvp);
+            bits += bs_size_se(mv[0] - mvp[0]) + bs_size_se(mv[1] - mvp[1]);
+            cache_block(a, g[0], g[1], g[2], g[3], mb->ref[b8], mv);
+        }
+        a->partition = part_bak; a->cur_valid = valid_bak; memcpy(a->cur8, cur_bak, sizeof(cur_bak));
+        bits += x264o_cavlc_cbp_bits(mb->cbp_luma | (mb->cbp_chroma << 4), 1);
+        if (e->cfg.dct8x8 && mb->cbp_luma) bits += 1;                               /* transform_size_8x8_flag */
+    } else {
+        const int off = pslice ? 5 : 0;
+        if (mb->type == X264GPU_MB_I16x16) bits += bs_size_ue(off + 1 + mb->i16_mode + 4 * mb->cbp_chroma + (mb->cbp_luma ? 12 : 0));
+        else {
+            bits += bs_size_ue(off);
+            if (e->cfg.dct8x8) bits += 1;
+            if (mb->type == X264GPU_MB_I8x8) { for (int i8 = 0; i8 < 4; i8++) bits += i4_pred_mode(a, i8 * 4, mb->i4_mode) == mb->i4_mode[i8 * 4] ? 1 : 4; }
+            else for (int b = 0; b < 16; b++) bits += i4_pred_mode(a, b, mb->i4_mode) == mb->i4_mode[b] ? 1 : 4;
+        }
+        bits += bs_size_ue(mb->chroma_mode);
+        if (mb->type != X264GPU_MB_I16x16) bits += x264o_cavlc_cbp_bits(mb->cbp_luma | (mb->cbp_chroma << 4), 0);
+    }
+    if (mb->cbp_luma || mb->cbp_chroma || mb->type == X264GPU_MB_I16x16) bits += bs_size_se((int)mb->qp - e->last_qp);
+#define NC_OF(na, nb) ((na) >= 0 && (nb) >= 0 ? ((na) + (nb) + 1) >> 1 : (na) >= 0 ? (na) : (nb) >= 0 ? (nb) : 0)
+    if (mb->type == X264GPU_MB_I16x16) {
+        const int na = left ? nb_total_coeff(e, mi - 1, idx_of[0][3]) : -1, nb = top ? nb_total_coeff(e, mi - e->mbw, idx_of[3][0]) : -1;
+        bits += x264o_cavlc_block_bits(lv + X264GPU_LV_LUMA_DC, 16, NC_OF(na, nb), NULL);
+    }
+    for (int b = 0; b < 16; b++) {
+        if (!((mb->cbp_luma >> (b >> 2)) & 1)) continue;
+        const int bx = blk_x[b], by = blk_y[b];
+        const int na = bx > 0 ? tc[idx_of[by][bx - 1]] : left ? nb_total_coeff(e, mi - 1, idx_of[by][3]) : -1;
+        const int nb = by > 0 ? tc[idx_of[by - 1][bx]] : top ? nb_total_coeff(e, mi - e->mbw, idx_of[3][bx]) : -1;
+        if (mb->type == X264GPU_MB_I16x16) bits += x264o_cavlc_block_bits(lv + b * 16 + 1, 15, NC_OF(na, nb), &tc[b]);
+        else bits += x264o_cavlc_block_bits(lv + b * 16, 16, NC_OF(na, nb), &tc[b]);
+    }
+    if (mb->cbp_chroma) {
+        for (int c = 0; c < 2; c++) bits += x264o_cavlc_block_bits(lv + X264GPU_LV_CHROMA_DC + c * 4, 4, -1, NULL);
+        if (mb->cbp_chroma == 2)
+            for (int c = 0; c < 2; c++)
+                for (int i = 0; i < 4; i++) {
+                    const int bx = i & 1, by = i >> 1, base = 16 + c * 4;
+                    const int na = bx > 0 ? tc[base + by * 2] : left ? nb_total_coeff(e, mi - 1, base + by * 2 + 1) : -1;
+                    const int nb = by > 0 ? tc[base + bx] : top ? nb_total_coeff(e, mi - e->mbw, base + 2 + bx) : -1;
+                    bits += x264o_cavlc_block_bits(lv + X264GPU_LV_CHROMA_AC + (c * 4 + i) * 16 + 1, 15, NC_OF(na, nb), &tc[base + i]);
+                }
+    }
+#undef NC_OF
+    return bits;
+}
+
+/* ssd_mb: luma SSD + the psy-rd energy term, chroma SSD scaled by the chroma lambda offset */
+static int rd_ssd_mb(const actx *a)
+{
+    const x264o_encoder *e = a->e;
+    static const pixel zero[16] = { 0 };
+    const pixel *fenc = e->fenc_y + (size_t)a->mby * 16 * e->fs + a->mbx * 16, *fuv = e->fenc_uv + (size_t)a->mby * 8 * e->fs + a->mbx * 16;
+    const pixel *rec = luma_plane((x264o_encoder *)e, e->cur, 0) + (size_t)a->mby * 16 * e->rs + a->mbx * 16;
+    const pixel *ruv = chroma_plane((x264o_encoder *)e, e->cur) + (size_t)a->mby * 8 * e->rs + a->mbx * 16;
+    int ssd = x264o_ssd(fenc, e->fs, rec, e->rs, 16, 16);
+    if (e->cfg.psy_rd_q8) {
+        /* sizes above 8x8: SATD against zero minus half the SAD against zero (the DC share), source vs reconstruction */
+        const int fdec_e = x264o_satd(rec, e->rs, zero, 0, 16, 16) - (x264o_sad(rec, e->rs, zero, 0, 16, 16) >> 1);
+        const int fenc_e = x264o_satd(fenc, e->fs, zero, 0, 16, 16) - (x264o_sad(fenc, e->fs, zero, 0, 16, 16) >> 1);
+        ssd += (abs(fdec_e - fenc_e) * e->cfg.psy_rd_q8 * a->lambda + 128) >> 8;
+    }
+    int cssd = 0;
+    for (int y = 0; y < 8; y++)
+        for (int x = 0; x < 16; x++) { const int d = fuv[y * e->fs + x] - ruv[y * e->rs + x]; cssd += d * d; }
+    return ssd + (int)(((int64_t)cssd * a->chroma_lambda2_offset + 128) >> 8);
+}
+
+static void rd_reset(const actx *a, x264gpu_mb *mb, int16_t *lv)
+{
+    memset(mb, 0, sizeof(*mb));
+    mb->qp = (uint8_t)a->qp;
+    memset(lv, 0, X264GPU_MB_LEVELS * sizeof(int16_t));
+}
+
+static int rd_finish(actx *a, x264gpu_mb *mb, int16_t *lv)
+{
+    const int ssd = rd_ssd_mb(a);
+    if (mb->type == X264GPU_MB_P_SKIP) return ssd + ((a->lambda2 + 128) >> 8);
+    return ssd + (int)(((int64_t)mb_bits_cavlc(a, mb, lv) * a->lambda2 + 128) >> 8);
+}
+
+/* x264_rd_cost_mb of an inter candidate: partition + the vectors of its search results, transform size t8 */
+static int rd_cost_inter(actx *a, int partition, int t8, x264gpu_mb *mb, int16_t *lv)
+{
+    rd_reset(a, mb, lv);
+    mb->type = partition == D_8x8 ? X264GPU_MB_P_8x8 : X264GPU_MB_P_L0; mb->partition = (uint8_t)partition;
+    for (int k = 0; k < 4; k++) {
+        const me_t *m = partition == D_16x16 ? &a->me16 : partition == D_16x8 ? &a->me16x8[k >> 1] : partition == D_8x16 ? &a->me8x16[k & 1] : &a->me8[k];
+        mb->ref[k] = (int8_t)m->ref; mb->mv[k][0] = (int16_t)m->mv[0]; mb->mv[k][1] = (int16_t)m->mv[1];
+    }
+    a->force_t8 = t8;
+    encode_inter_mb(a, mb, lv);
+    a->force_t8 = -1;
+    return rd_finish(a, mb, lv);
+}
+
+static int rd_cost_intra(actx *a, int type, x264gpu_mb *mb, int16_t *lv)
+{
+    rd_reset(a, mb, lv);
+    encode_intra_mb(a, type, mb, lv);
+    return rd_finish(a, mb, lv);
+}
+
+/* x264_intra_rd: the SATD costs of the intra types within reach become RD costs, the others drop out */
+static void intra_rd(actx *a, int thresh, x264gpu_mb *mb, int16_t *lv)
+{
+    if (!a->b_early_terminate) thresh = COST_MAX;
+    a->satd_i16 = a->satd_i16 < thresh ? rd_cost_intra(a, X264GPU_MB_I16x16, mb, lv) : COST_MAX;
+    a->satd_i4 = a->satd_i4 < thresh ? rd_cost_intra(a, X264GPU_MB_I4x4, mb, lv) : COST_MAX;
+    a->satd_i8 = a->satd_i8 < thresh ? rd_cost_intra(a, X264GPU_MB_I8x8, mb, lv) : COST_MAX;
+}
+
+/* x264_mb_analyse_p_rd */
+static void analyse_p_rd(actx *a, int i_satd, x264gpu_mb *mb, int16_t *lv)
+{
+    const int thresh = a->b_early_terminate ? i_satd * 5 / 4 + 1 : COST_MAX;
+    if (a->rd16x16 == COST_MAX && (!a->b_early_terminate || a->me16.cost <= i_satd * 3 / 2)) a->rd16x16 = rd_cost_inter(a, D_16x16, 0, mb, lv);
+    a->cost16x8 = a->cost16x8 < thresh ? rd_cost_inter(a, D_16x8, 0, mb, lv) : COST_MAX;
+    a->cost8x16 = a->cost8x16 < thresh ? rd_cost_inter(a, D_8x16, 0, mb, lv) : COST_MAX;
+    a->cost8x8 = a->cost8x8 < thresh ? rd_cost_inter(a, D_8x8, 0, mb, lv) : COST_MAX;
+}
+
 static int mb_type_at(const x264o_encoder *e, int mbx, int mby)
 {
     if (mbx < 0 || mby < e->row0 || mbx >= e->mbw) return -1;
     return e->mbs[mby * e->mbw + mbx].type;
 }
 
-void x264o_macroblock(x264o_encoder *e, int mbx, int mby)
+static void macroblock_body(x264o_encoder *e, int mbx, int mby, actx *a)
 {
-    actx A, *a = &A;
     memset(a, 0, sizeof(*a));
     a->e = e; a->mbx = mbx; a->mby = mby; a->mi = mby * e->mbw + mbx;
     x264gpu_mb *mb = &e->mbs[a->mi];
@@ -1261,12 +1446,22 @@ void x264o_macroblock(x264o_encoder *e, int mbx, int mby)
     a->satd_i16 = a->satd_i8 = a->satd_i4 = a->satd_chroma = COST_MAX;
     a->b_early_terminate = a->subme < 11;
     mb->qp = (uint8_t)a->qp;
+    a->mbrd = e->cfg.rd != 0; a->rd16x16 = COST_MAX; a->force_t8 = -1; a->cost8x8 = a->cost16x8 = a->cost8x16 = COST_MAX;
+    a->lambda2 = x264o_lambda2(a->qp);
+    {   /* h->mb.i_chroma_lambda2_offset: 256 * 2^((qp - chroma qp) / 3) under psy, else 256 */
+        static const uint16_t tab[37] = { 16, 20, 25, 32, 40, 50, 64, 80, 101, 128, 161, 203, 256, 322, 406, 512, 645, 812, 1024, 1290, 1625, 2048, 2580, 3250, 4096,
+                                          5160, 6501, 8192, 10321, 13003, 16384, 20642, 26007, 32768, 41285, 52015, 65535 };
+        const int idx = a->qp - a->qpc + 12;
+        a->chroma_lambda2_offset = e->cfg.psy ? tab[idx < 0 ? 0 : idx > 36 ? 36 : idx] : 256;
+    }
 
     if (e->slice_type == X264GPU_SLICE_I) {
         analyse_intra(a, COST_MAX);
+        if (a->mbrd) intra_rd(a, COST_MAX, mb, lv);
         int i_cost = a->satd_i16, type = X264GPU_MB_I16x16;
         if (a->satd_i4 < i_cost) { i_cost = a->satd_i4; type = X264GPU_MB_I4x4; }
         if (a->satd_i8 < i_cost) { i_cost = a->satd_i8; type = X264GPU_MB_I8x8; }
+        if (a->mbrd) rd_reset(a, mb, lv);
         mb->cost = i_cost;
         encode_intra_mb(a, type, mb, lv);
         e->intra_count++;
@@ -1338,8 +1533,8 @@ void x264o_macroblock(x264o_encoder *e, int mbx, int mby)
             if (a->cost8x16 < i_cost) { i_type = X264GPU_MB_P_L0; i_partition = D_8x16; i_cost = a->cost8x16; }
         }
     }
-    /* refine the winner's quarter-pel vectors (no RD: always, unless full-pel only) */
-    if (a->subme) {
+    /* refine the winner's quarter-pel vectors (no RD: always, unless full-pel only; with RD only the levels above 7 refine, by RD) */
+    if (a->subme && !a->mbrd) {
         if (i_partition == D_16x16) { a->partition = D_16x16; me_refine_qpel(a, &a->me16); i_cost = a->me16.cost; }
         else if (i_partition == D_16x8) { me_refine_qpel(a, &a->me16x8[0]); me_refine_qpel(a, &a->me16x8[1]); i_cost = a->me16x8[0].cost + a->me16x8[1].cost; }
         else if (i_partition == D_8x16) { me_refine_qpel(a, &a->me8x16[0]); me_refine_qpel(a, &a->me8x16[1]); i_cost = a->me8x16[0].cost + a->me8x16[1].cost; }
@@ -1352,9 +1547,26 @@ void x264o_macroblock(x264o_encoder *e, int mbx, int mby)
     } else analyse_intra(a, i_cost);
     mb->aux[0] = i_cost; mb->aux[2] = a->me16.cost;
     { int mn = a->satd_i16 < a->satd_i8 ? a->satd_i16 : a->satd_i8; if (a->satd_i4 < mn) mn = a->satd_i4; mb->aux[1] = mn; }
+    int t8 = -1;
+    if (a->mbrd) {
+        int i_satd_inter = i_cost, i_satd_intra = a->satd_i16 < a->satd_i8 ? a->satd_i16 : a->satd_i8;
+        if (a->satd_i4 < i_satd_intra) i_satd_intra = a->satd_i4;
+        analyse_p_rd(a, i_satd_inter < i_satd_intra ? i_satd_inter : i_satd_intra, mb, lv);
+        i_type = X264GPU_MB_P_L0; i_partition = D_16x16; i_cost = a->rd16x16;
+        if (a->cost16x8 < i_cost) { i_cost = a->cost16x8; i_partition = D_16x8; }
+        if (a->cost8x16 < i_cost) { i_cost = a->cost8x16; i_partition = D_8x16; }
+        if (a->cost8x8 < i_cost) { i_cost = a->cost8x8; i_partition = D_8x8; i_type = X264GPU_MB_P_8x8; }
+        t8 = 0;
+        if (i_cost < COST_MAX && e->cfg.dct8x8) {       /* x264_mb_analyse_transform_rd: the other transform size for the winner */
+            const int i_rd8 = rd_cost_inter(a, i_partition, 1, mb, lv);
+            if (i_cost >= i_rd8) { if (i_cost > 0) i_satd_inter = (int)((int64_t)i_satd_inter * i_rd8 / i_cost); i_cost = i_rd8; t8 = 1; }
+        }
+        intra_rd(a, i_satd_inter * 5 / 4 + 1, mb, lv);
+    }
     if (a->satd_i16 < i_cost) { i_cost = a->satd_i16; i_type = X264GPU_MB_I16x16; }
     if (a->satd_i8 < i_cost) { i_cost = a->satd_i8; i_type = X264GPU_MB_I8x8; }
     if (a->satd_i4 < i_cost) { i_cost = a->satd_i4; i_type = X264GPU_MB_I4x4; }
+    if (a->mbrd) { const int a0 = mb->aux[0], a1 = mb->aux[1], a2 = mb->aux[2]; rd_reset(a, mb, lv); mb->aux[0] = a0; mb->aux[1] = a1; mb->aux[2] = a2; }
     mb->cost = i_cost;
 
     if (is_intra_type(i_type)) {
@@ -1367,5 +1579,19 @@ void x264o_macroblock(x264o_encoder *e, int mbx, int mby)
         const me_t *m = i_partition == D_16x16 ? &a->me16 : i_partition == D_16x8 ? &a->me16x8[k >> 1] : i_partition == D_8x16 ? &a->me8x16[k & 1] : &a->me8[k];
         mb->ref[k] = (int8_t)m->ref; mb->mv[k][0] = (int16_t)m->mv[0]; mb->mv[k][1] = (int16_t)m->mv[1];
     }
+    a->force_t8 = t8;                 /* RD: the transform size chosen by transform_rd; else SA8D vs SATD */
     encode_inter_mb(a, mb, lv);
+}
+
+void x264o_macroblock(x264o_encoder *e, int mbx, int mby)
+{
+    actx A;
+    macroblock_body(e, mbx, mby, &A);
+    const x264gpu_mb *mb = &e->mbs[mby * e->mbw + mbx];
+    /* diagnostics for the tests: what mb_bits_cavlc says the macroblock layer of the final macroblock takes (0 for P_SKIP: it lives in a run) */
+    if (e->mb_bits) e->mb_bits[A.mi] = mb->type == X264GPU_MB_P_SKIP ? 0 : mb_bits_cavlc(&A, mb, e->levels + (size_t)A.mi * X264GPU_MB_LEVELS);
+    /* h->mb.i_last_qp for the mb_qp_delta bits of the RD costs: macroblocks that send a delta set it */
+    if (mb->type != X264GPU_MB_P_SKIP && (mb->cbp_luma || mb->cbp_chroma || mb->type == X264GPU_MB_I16x16)) {
+        if (!(mb->type == X264GPU_MB_I16x16 && !mb->cbp_luma && !mb->cbp_chroma && !((mb->nnz >> 24) & 1) && mb->qp > e->last_qp)) e->last_qp = mb->qp;
+    }
 }

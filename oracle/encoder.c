@@ -68,6 +68,8 @@ void x264o_encoder_set_mb_qp_offsets(x264o_encoder *e, const int16_t *off_q8) { 
 /* lookahead vectors of the NEXT picture against its predecessor ([nmb][2], lowres quarter-pels; first entry 0x7fff or NULL = none):
  * the extra 16x16 search candidate x264 takes from fenc->lowres_mvs[0][0] */
 void x264o_encoder_set_lowres_mvs(x264o_encoder *e, const int16_t *mv) { e->lowres_mv = mv; }
+/* tests: where to leave the predicted CAVLC bit count of every macroblock of the next pictures (NULL: off) */
+void x264o_encoder_set_mb_bits_out(x264o_encoder *e, int *bits) { e->mb_bits = bits; }
 
 const uint16_t *x264o_cost_mv_for(x264o_encoder *e, int qp)
 {
@@ -250,7 +252,7 @@ int x264o_encoder_encode(x264o_encoder *e, const uint8_t *i420, int slice_type, 
     for (int sl = 0; sl < ns; sl++) {
         /* x264 slice threads: rows split evenly; each thread starts with empty frame statistics (h->stat.frame) */
         e->row0 = (e->mbh * sl + ns / 2) / ns; e->row1 = (e->mbh * (sl + 1) + ns / 2) / ns;
-        e->intra_count = 0;
+        e->intra_count = 0; e->last_qp = slice_qp;
         for (int mby = e->row0; mby < e->row1; mby++)
             for (int mbx = 0; mbx < e->mbw; mbx++) {
                 x264o_macroblock(e, mbx, mby);

@@ -46,6 +46,8 @@ struct x264o_encoder {
     /* state of the macroblock loop (x264: h->stat.frame, h->mb) */
     x264gpu_mb *mbs;
     int16_t *levels;
+    int *mb_bits;                /* optional (tests): per macroblock, the CAVLC bit count the RD code predicts for the final macroblock */
+    int last_qp;                 /* QP_Y of the previous macroblock in coding order as the entropy coder sees it (h->mb.i_last_qp): mb_qp_delta bits of the RD costs */
     int intra_count;             /* intra macroblocks coded so far in this slice (h->stat.frame.i_mb_count[I_*]) */
 };
 

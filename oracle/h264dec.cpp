@@ -67,6 +67,7 @@ struct Decoder {
     std::vector<pixel> luma[6], chroma[6];   // DPB slots: up to 5 references + the picture being decoded
     int cur = 0, slots = 2, have = 0, num_ref_frames = 1, nref_active = 1;
     int next_mb = 0, slice_no = 0, pic_disable = 0, pic_a = 0, pic_b = 0;      // slices of the picture being decoded
+    std::vector<int> mb_bits;        // CAVLC: bits of the macroblock layer of every macroblock, picture after picture (0 for skipped ones)
     int ref_slot(int r) const { return (cur - 1 - r + 2 * slots) % slots; }
     std::vector<MbInfo> mb;
     bool have_sps = false, have_pps = false;
@@ -732,10 +733,12 @@ struct SliceDec {
             MbInfo &m = d.mb[i];
             m = MbInfo(); m.slice = slice_no;
             int mbx = i % d.mbw, mby = i / d.mbw;
+            const size_t pos0 = br.pos;
             int t = (int)br.ue();
             cur_idx = i; known8 = 0;
             if (slice_type == 0) { if (t <= 3) inter_mb(mbx, mby, t, m); else if (t >= 5) intra_mb(mbx, mby, t - 5, m); else br.err = true; }
             else intra_mb(mbx, mby, t, m);
+            d.mb_bits[d.mb_bits.size() - (size_t)(d.mbw * d.mbh) + (size_t)i] = (int)(br.pos - pos0);
             i++;
             if (!br.more_rbsp_data()) break;
         }
@@ -891,6 +894,7 @@ bool decode_nal(Decoder &d, const uint8_t *nal, size_t n)
         if (d.deblock_ctrl) { disable = (int)br.ue(); if (disable != 1) { a = 2 * br.se(); b = 2 * br.se(); } }
         SliceDec sd{ d, br, st, qp, disable, a, b };
         sd.first_mb = first_mb; sd.slice_no = d.slice_no++;
+        if (first_mb == 0) d.mb_bits.resize(d.mb_bits.size() + (size_t)(d.mbw * d.mbh), 0);
         if (first_mb) { if (disable != d.pic_disable || a != d.pic_a || b != d.pic_b) return false; }      // one filter setting per picture in this checker
         else { d.pic_disable = disable; d.pic_a = a; d.pic_b = b; }
         sd.run();
@@ -908,7 +912,17 @@ bool decode_nal(Decoder &d, const uint8_t *nal, size_t n)
 
 }  // namespace
 
+static std::vector<int> g_mb_bits;       // per-macroblock CAVLC bit counts of the last x264o_h264_decode call
+
 extern "C" {
+
+// after x264o_h264_decode of a CAVLC stream: bits the macroblock layer of every macroblock took (pictures back to back, 0 = skipped)
+int x264o_h264_last_mb_bits(int *out, int cap)
+{
+    const int n = (int)g_mb_bits.size();
+    for (int i = 0; i < n && i < cap; i++) out[i] = g_mb_bits[(size_t)i];
+    return n;
+}
 
 // Decodes an Annex-B stream.  Returns the number of pictures, or -1 on a syntax error / unsupported
 // feature.  Pictures are written back to back (cropped I420) into `out` if it is large enough.
@@ -928,6 +942,7 @@ int x264o_h264_decode(const uint8_t *data, size_t n, uint8_t *out, size_t out_ca
     }
     if (width) *width = d.width;
     if (height) *height = d.height;
+    g_mb_bits = d.mb_bits;
     size_t fsz = (size_t)d.width * d.height * 3 / 2, off = 0;
     for (auto &f : d.frames) { if (off + fsz <= out_cap) memcpy(out + off, f.data(), fsz); off += fsz; }
     return (int)d.frames.size();

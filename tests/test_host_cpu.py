@@ -112,6 +112,8 @@ def test_open_without_gpu_fails_loudly():
                                      (176, 144, dict(partitions=3)), (352, 288, dict(partitions=3, qp_i=30, qp_p=33)),
                                      (208, 120, dict(partitions=1, subme=4)), (176, 144, dict(refs=3, partitions=3)),
                                      (96, 80, dict(refs=2)), (208, 120, dict(refs=4, partitions=3, qp_i=30, qp_p=32)), (96, 80, dict(refs=5, partitions=7, dct8x8=1, mixed_refs=1, qp_i=33, qp_p=36)),
+                                     (176, 144, dict(rd=1, psy=1, psy_rd_q8=256, chroma_qp_offset=-2, subme=7, refs=3, partitions=7, dct8x8=1, mixed_refs=1, chroma_me=1)),
+                                     (96, 80, dict(rd=1, subme=6, refs=2, partitions=3, qp_i=30, qp_p=34)),
                                      (176, 144, dict(dct8x8=1)), (352, 288, dict(dct8x8=1, partitions=3, refs=2, qp_i=26, qp_p=28)),
                                      (208, 120, dict(dct8x8=1, qp_i=12, qp_p=14, dct_decimate=0)),
                                      (176, 144, dict(dct8x8=1, partitions=6)), (352, 288, dict(dct8x8=1, partitions=7, refs=3, qp_i=28, qp_p=31)),
@@ -124,7 +126,7 @@ def test_entropy_closed_loop(w, h, kw, cabac):
     cfg = O.default_config(w, h, **kw)
     enc = O.OracleEncoder(cfg)
     mbw, mbh = (w + 15) // 16, (h + 15) // 16
-    stream = HL.write_headers(w, h, pic_init_qp=cfg.qp_p, num_ref=cfg.refs, t8x8=cfg.dct8x8, cabac=cabac)
+    stream = HL.write_headers(w, h, pic_init_qp=cfg.qp_p, cqo=cfg.chroma_qp_offset, num_ref=cfg.refs, t8x8=cfg.dct8x8, cabac=cabac)
     recons, skipped = [], 0
     for i, f in enumerate(frames):
         idr = i == 0
@@ -311,3 +313,34 @@ def test_cavlc_tables_typed_twice_agree():
     for f in (O.L.x264o_cavlc_tables_mismatches, O.L.x264o_cavlc_tables_prefix_clashes):
         f.restype = C.c_int
         assert f() == 0
+
+
+@pytest.mark.parametrize("w,h,kw", [(176, 144, dict(partitions=7, dct8x8=1, refs=3, mixed_refs=1, chroma_me=1, subme=5)), (96, 80, dict(partitions=3, refs=2, qp_i=14, qp_p=16)),
+                                    (208, 120, dict(aq_mode=1, partitions=7, dct8x8=1, refs=2, qp_i=30, qp_p=33)), (64, 208, dict(slices=3, partitions=7, dct8x8=1, refs=2))])
+def test_rd_bit_counts_equal_the_bits_the_decoder_consumes(w, h, kw):
+    """the CAVLC bit count behind the RD costs (oracle mb_bits_cavlc: x264_macroblock_size_cavlc) of every final macroblock equals what the
+    checker decoder consumes for that macroblock's layer in the stream the host writer produced — mb_type, references, vector differences
+    (true predictors), intra modes, cbp, transform flag, mb_qp_delta (AQ case), every residual block with its nC"""
+    import ctypes as C
+    nfr = 4
+    frames = synth_frames(w, h, nfr, seed=w + 7 * h)
+    cfg = O.default_config(w, h, **kw)
+    enc = O.OracleEncoder(cfg)
+    mbw, mbh = (w + 15) // 16, (h + 15) // 16
+    pred = np.zeros(mbw * mbh, np.int32)
+    O.L.x264o_encoder_set_mb_bits_out.argtypes = [C.c_void_p, C.c_void_p]
+    O.L.x264o_encoder_set_mb_bits_out(enc.h, pred.ctypes.data)
+    stream = HL.write_headers(w, h, pic_init_qp=cfg.qp_p, num_ref=cfg.refs, t8x8=cfg.dct8x8, cabac=0)
+    want = []
+    for i, f in enumerate(frames):
+        idr = i == 0
+        mbs, lv = enc.encode(f, 2 if idr else 0)
+        want.append(pred.copy())
+        stream += HL.write_slice(mbw, mbh, 2 if idr else 0, cfg.qp_i if idr else cfg.qp_p, cfg.qp_p, i, 8, int(idr), 0, 0, mbs, lv,
+                                 num_ref=max(1, min(cfg.refs, i)), num_ref_default=cfg.refs, t8x8=cfg.dct8x8, cabac=0, slices=kw.get("slices", 1))[0]
+    dec = O.h264_decode(stream, nfr, w, h)
+    assert len(dec) == nfr
+    got = np.zeros(nfr * mbw * mbh, np.int32)
+    O.L.x264o_h264_last_mb_bits.restype = C.c_int
+    assert O.L.x264o_h264_last_mb_bits(got.ctypes.data_as(C.c_void_p), got.size) == got.size
+    np.testing.assert_array_equal(got.reshape(nfr, -1), np.stack(want))
