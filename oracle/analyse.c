@@ -1548,6 +1548,7 @@ static void macroblock_body(x264o_encoder *e, int mbx, int mby, actx *a)
     mb->aux[0] = i_cost; mb->aux[2] = a->me16.cost;
     { int mn = a->satd_i16 < a->satd_i8 ? a->satd_i16 : a->satd_i8; if (a->satd_i4 < mn) mn = a->satd_i4; mb->aux[1] = mn; }
     int t8 = -1;
+    const int aux0 = mb->aux[0], aux1 = mb->aux[1], aux2 = mb->aux[2];        /* the RD passes below reset the record */
     if (a->mbrd) {
         int i_satd_inter = i_cost, i_satd_intra = a->satd_i16 < a->satd_i8 ? a->satd_i16 : a->satd_i8;
         if (a->satd_i4 < i_satd_intra) i_satd_intra = a->satd_i4;
@@ -1566,7 +1567,7 @@ static void macroblock_body(x264o_encoder *e, int mbx, int mby, actx *a)
     if (a->satd_i16 < i_cost) { i_cost = a->satd_i16; i_type = X264GPU_MB_I16x16; }
     if (a->satd_i8 < i_cost) { i_cost = a->satd_i8; i_type = X264GPU_MB_I8x8; }
     if (a->satd_i4 < i_cost) { i_cost = a->satd_i4; i_type = X264GPU_MB_I4x4; }
-    if (a->mbrd) { const int a0 = mb->aux[0], a1 = mb->aux[1], a2 = mb->aux[2]; rd_reset(a, mb, lv); mb->aux[0] = a0; mb->aux[1] = a1; mb->aux[2] = a2; }
+    if (a->mbrd) { rd_reset(a, mb, lv); mb->aux[0] = aux0; mb->aux[1] = aux1; mb->aux[2] = aux2; }
     mb->cost = i_cost;
 
     if (is_intra_type(i_type)) {

@@ -47,6 +47,30 @@ def test_random_configs_bitexact(gpu, seed):
         og.close(); gg.close()
 
 
+@pytest.mark.parametrize("seed", [31, 32, 33])
+def test_random_rd_configs_bitexact(gpu, seed):
+    """the same sweep with RD mode decision on (x264 subme 6 / 7 in a CAVLC session: candidates coded and costed as SSD + psy + lambda2 x bits
+    on the device), psy-RD strengths from off to 2.0"""
+    from gpu_enc import GpuEncoder
+    rnd = random.Random(seed)
+    for it in range(30):
+        w, h, kw, nfr, fseed, second_idr = random_case(rnd)
+        psy = rnd.randint(0, 1)
+        kw.update(cabac=0, rd=1, subme=rnd.choice([6, 7]), psy=psy, psy_rd_q8=rnd.choice([26, 102, 256, 512]) if psy else 0)
+        frames = synth_frames(w, h, nfr, seed=fseed)
+        cfg = O.default_config(w, h, **kw)
+        og, gg = O.OracleEncoder(cfg), GpuEncoder(cfg)
+        for i, f in enumerate(frames):
+            st = 2 if i == 0 or (i == 3 and second_idr) else 0
+            o_mb, o_lv = og.encode(f, st)
+            g_mb, g_lv = gg.encode([f], st)
+            tag = f"seed {seed} case {it}: {w}x{h} {kw} frame {i}"
+            assert np.array_equal(g_mb[0].view(np.uint8), o_mb.view(np.uint8)), tag + " records"
+            assert np.array_equal(g_lv[0], o_lv), tag + " levels"
+            assert np.array_equal(gg.recon(0), og.recon()), tag + " reconstruction"
+        og.close(); gg.close()
+
+
 @pytest.mark.parametrize("seed", [21, 22])
 def test_random_multi_stream_quantisers_bitexact(gpu, seed):
     """several streams in lock-step, random toolsets, and per picture a random choice of quantiser source: the shared pair, one slice

@@ -32,6 +32,16 @@ def open_encoder(w, h, opts, profile=b"baseline", preset=b"medium"):
     return h_, eff
 
 
+def eff_kw(eff):
+    """the oracle's config fields that follow from the session's effective parameters (x264_encoder_parameters): sub-pel level, RD mode
+    decision + psy (subme 6 / 7 in --no-cabac sessions; the chroma quantiser offset the encoder reports already carries x264's psy
+    compensation), entropy coder, vector range"""
+    rd = int(eff.analyse.i_subpel_refine >= 6)
+    q8 = int(eff.analyse.f_psy_rd * 256.0 + 0.5) if rd and eff.analyse.b_psy else 0
+    return dict(subme=eff.analyse.i_subpel_refine, rd=rd, psy=int(q8 != 0), psy_rd_q8=q8, chroma_qp_offset=eff.analyse.i_chroma_qp_offset,
+                mv_range=eff.analyse.i_mv_range, cabac=eff.b_cabac)
+
+
 def encode_all(h_, w, h, frames):
     pic, out = HL.Picture(), HL.Picture()
     assert H.x264_picture_alloc(C.byref(pic), HL.X264_CSP_I420, w, h) == 0
@@ -86,6 +96,28 @@ def test_encode_api_closed_loop(gpu, w, h, opts):
         np.testing.assert_array_equal(dec[i], recons[i], err_msg=f"decoded picture {i} != encoder reconstruction")
 
 
+@pytest.mark.parametrize("opts,subme,cqo", [({}, 7, -2), ({"no-psy": None}, 7, 0), ({"psy-rd": "0.1:0", "subme": 6}, 6, -1), ({"subme": 9, "chroma-qp-offset": 3}, 7, 1)])
+def test_rd_session_equals_oracle_pipeline(gpu, opts, subme, cqo):
+    """preset medium without CABAC (Baseline profile): subme 7 = RD mode decision on the device with CAVLC bit counts and psy-RD; x264 lowers
+    the chroma quantiser offset to compensate psy (by 2, or 1 below psy-rd 0.25), and levels above 7 (RD refinement) come back as 7.  The
+    stream decodes to the encoder's reconstruction and the oracle pipeline (RD on) reconstructs the same samples"""
+    w, h, nfr, qp = 176, 144, 5, 27
+    frames = synth_frames(w, h, nfr, seed=606)
+    h_, eff = open_encoder(w, h, dict({"qp": qp, "keyint": 250}, **opts), b"baseline")
+    assert (eff.b_cabac, eff.analyse.i_subpel_refine, eff.analyse.i_chroma_qp_offset) == (0, subme, cqo)
+    stream, info, recons = encode_all(h_, w, h, frames)
+    H.x264_encoder_close(h_)
+    kw = eff_kw(eff)
+    assert kw["rd"] == 1 and kw["psy"] == int("no-psy" not in opts)
+    qp_i = max(1, int(qp - 6.0 * np.log2(1.4) + 0.5))
+    og = O.OracleEncoder(O.default_config(w, h, qp_i=qp_i, qp_p=qp, partitions=3, refs=3, chroma_me=1, mixed_refs=1, **kw))
+    dec = O.h264_decode(stream, nfr, w, h)
+    for i, f in enumerate(frames):
+        np.testing.assert_array_equal(dec[i], recons[i], err_msg=f"decoded picture {i}")
+        og.encode(f, 2 if i == 0 else 0)
+        np.testing.assert_array_equal(og.recon(), recons[i], err_msg=f"oracle pipeline picture {i}")
+
+
 def test_preset_ultrafast_is_fully_covered(gpu):
     """preset ultrafast (config.c:1460-1466): every tool x264 uses there exists in this path — me dia, subme 0, ref 1,
     no partitions, no 8x8dct, CAVLC, no deblock, no B-frames — so the effective parameters equal the requested ones and the
@@ -120,7 +152,7 @@ def test_bitstream_equals_oracle_path(gpu):
     stream, info, _ = encode_all(h_, w, h, frames)
     H.x264_encoder_close(h_)
     qp_i = max(1, int(qp - 6.0 * np.log2(1.4) + 0.5))
-    enc = O.OracleEncoder(O.default_config(w, h, qp_i=qp_i, qp_p=qp, partitions=7, refs=3, dct8x8=1, chroma_me=1, mixed_refs=1, subme=5, mv_range=eff.analyse.i_mv_range, cabac=eff.b_cabac))      # medium: p8x8 + i4x4 + i8x8, ref 3, 8x8dct, chroma-me; subme 7 -> 5 (no RD yet)
+    enc = O.OracleEncoder(O.default_config(w, h, qp_i=qp_i, qp_p=qp, partitions=7, refs=3, dct8x8=1, chroma_me=1, mixed_refs=1, **eff_kw(eff)))      # medium: p8x8 + i4x4 + i8x8, ref 3, 8x8dct, chroma-me; subme 7 -> 5 under CABAC
     ref = b""
     for i, f in enumerate(frames):
         mbs, lv = enc.encode(f, 2 if i == 0 else 0)
@@ -241,7 +273,7 @@ def test_scenecut_inserts_idr(gpu):
     assert [r[0] for r in rows] == [1, 0, 0, 0, 0, 0, 1, 0, 0, 0, 0]
     assert rows[6][2] == 1 and rows[6][3][1] >= 0.9 * rows[6][3][0] and all(r[2] == 0 for i, r in enumerate(rows) if i != 6)
     dec = O.h264_decode(stream, len(frames), w, h)
-    og = O.OracleEncoder(O.default_config(w, h, qp_i=24, qp_p=27, partitions=7, refs=3, dct8x8=1, chroma_me=1, mixed_refs=1, subme=5, mv_range=eff.analyse.i_mv_range, cabac=eff.b_cabac))
+    og = O.OracleEncoder(O.default_config(w, h, qp_i=24, qp_p=27, partitions=7, refs=3, dct8x8=1, chroma_me=1, mixed_refs=1, **eff_kw(eff)))
     for i, f in enumerate(frames):
         np.testing.assert_array_equal(dec[i], recons[i], err_msg=f"decoded picture {i}")
         og.encode(f, 2 if rows[i][0] else 0)
@@ -280,7 +312,7 @@ def test_crf_follows_the_lookahead_complexity(gpu):
     assert len(set(qps)) > 1 and rows[5][0] == 1                     # the cut is an IDR and the quantiser moves with the content
     dec = O.h264_decode(stream, len(frames), w, h)
     assert eff.rc.i_aq_mode == 1                                    # x264's default: variance AQ rides on CRF
-    og = O.OracleEncoder(O.default_config(w, h, partitions=7, refs=3, dct8x8=1, chroma_me=1, mixed_refs=1, aq_mode=1, aq_strength_q8=266, subme=5, mv_range=eff.analyse.i_mv_range, cabac=eff.b_cabac))
+    og = O.OracleEncoder(O.default_config(w, h, partitions=7, refs=3, dct8x8=1, chroma_me=1, mixed_refs=1, aq_mode=1, aq_strength_q8=266, **eff_kw(eff)))
     for i, f in enumerate(frames):
         np.testing.assert_array_equal(dec[i], recons[i], err_msg=f"decoded picture {i}")
         og.set_qp(rows[i][1], rows[i][1])
@@ -392,7 +424,7 @@ def test_crf_with_macroblock_tree(gpu, monkeypatch):
     ol = O.OracleLookahead(w, h)
     infos = [ol.frame_cost(f, i == 0)[1] for i, f in enumerate(frames)]
     aqs = [O.aq_offsets(f, w, h, 266) for f in frames]
-    og = O.OracleEncoder(O.default_config(w, h, partitions=7, refs=3, dct8x8=1, chroma_me=1, mixed_refs=1, aq_mode=1, aq_strength_q8=266, subme=5, mv_range=eff.analyse.i_mv_range, cabac=eff.b_cabac))
+    og = O.OracleEncoder(O.default_config(w, h, partitions=7, refs=3, dct8x8=1, chroma_me=1, mixed_refs=1, aq_mode=1, aq_strength_q8=266, **eff_kw(eff)))
     bw, bh = (w + 15) // 16, (h + 15) // 16
     lowered = 0
     for i, f in enumerate(frames):
@@ -511,8 +543,7 @@ def test_sliced_threads_through_the_api(gpu, w, h, opts, slices):
     for i, (_, _, _, types) in enumerate(info):
         assert sum(1 for t in types if t in (1, 5)) == slices, (i, types)      # one slice NAL per slice, every call returns its picture
     dec = O.h264_decode(stream, nfr, w, h)
-    og = O.OracleEncoder(O.default_config(w, h, slices=slices, partitions=7, refs=3, dct8x8=1, chroma_me=1, mixed_refs=1, subme=5, qp_i=max(0, opts["qp"] - 3), qp_p=opts["qp"],
-                                          mv_range=eff.analyse.i_mv_range, cabac=eff.b_cabac))
+    og = O.OracleEncoder(O.default_config(w, h, slices=slices, partitions=7, refs=3, dct8x8=1, chroma_me=1, mixed_refs=1, qp_i=max(0, opts["qp"] - 3), qp_p=opts["qp"], **eff_kw(eff)))
     keyint = opts["keyint"]
     for i, f in enumerate(frames):
         np.testing.assert_array_equal(dec[i], recons[i], err_msg=f"decoded picture {i}")
@@ -536,7 +567,7 @@ def test_full_size_round_trip(gpu, w, h, opts, okw):
     assert eff.b_cabac == 1
     dec = O.h264_decode(stream, nfr, w, h)
     slices = (h + 15) // 16 // 4 if "sliced-threads" in opts else 1
-    kw = dict(slices=slices, partitions=7, refs=3, dct8x8=1, chroma_me=1, mixed_refs=1, subme=5, qp_i=opts["qp"] - 3, qp_p=opts["qp"], mv_range=eff.analyse.i_mv_range, cabac=eff.b_cabac)
+    kw = dict(slices=slices, partitions=7, refs=3, dct8x8=1, chroma_me=1, mixed_refs=1, qp_i=opts["qp"] - 3, qp_p=opts["qp"], **eff_kw(eff))
     kw.update(okw)
     og = O.OracleEncoder(O.default_config(w, h, **kw))
     for i, f in enumerate(frames):

@@ -99,6 +99,15 @@ def compare(tag, mbw, g_mb, o_mb, g_lv, o_lv, g_rec, o_rec):
     (64, 272, 4, dict(slices=4, aq_mode=1, partitions=7, dct8x8=1, qp_i=30, qp_p=34)),
     (352, 288, 4, dict(slices=4, me_method=2, partitions=3, refs=2)),
     (48, 336, 4, dict(slices=5, partitions=3, refs=2, qp_i=12, qp_p=15, dct_decimate=0, me_method=3, me_range=8)),
+    (64, 48, 3, dict(rd=1, subme=6, partitions=0)),                          # RD mode decision (x264 subme 6 / 7, CAVLC bit counts): I16x16 / P16x16 / skip only
+    (176, 144, 4, dict(rd=1, subme=6, partitions=2)),                        # + Intra_4x4
+    (176, 144, 4, dict(rd=1, subme=6, partitions=1)),                        # + P16x8 / P8x16 / P8x8
+    (176, 144, 6, dict(rd=1, subme=7, partitions=3, refs=2, psy=1, psy_rd_q8=256, chroma_qp_offset=-2)),      # psy-RD at x264's default strength
+    (176, 144, 6, dict(rd=1, subme=7, partitions=7, dct8x8=1, refs=3, mixed_refs=1, chroma_me=1, psy=1, psy_rd_q8=256, chroma_qp_offset=-2)),   # preset medium --no-cabac
+    (352, 288, 4, dict(rd=1, subme=7, partitions=7, dct8x8=1, refs=3, mixed_refs=1, chroma_me=1, qp_i=30, qp_p=34, me_method=2)),
+    (96, 208, 4, dict(rd=1, subme=6, slices=3, partitions=7, dct8x8=1, refs=2, psy=1, psy_rd_q8=102, chroma_qp_offset=-1, aq_mode=1)),
+    (96, 80, 4, dict(rd=1, subme=6, partitions=7, dct8x8=1, qp_i=8, qp_p=10, dct_decimate=0, fast_pskip=0)),
+    (208, 120, 4, dict(rd=1, subme=6, partitions=7, dct8x8=1, qp_i=44, qp_p=47, psy=1, psy_rd_q8=512, me_method=3, me_range=8)),
 ])
 def test_pipeline_bitexact(gpu, w, h, nfr, kw):
     from gpu_enc import GpuEncoder

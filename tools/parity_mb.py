@@ -44,6 +44,15 @@ CASES = [
     (208, 120, 4, dict(me_method=3, partitions=3, refs=2, me_range=8, chroma_me=1, subme=5)),
     (352, 288, 3, dict(me_method=2, partitions=7, dct8x8=1, refs=4, subme=9, chroma_me=1, mixed_refs=1, qp_i=26, qp_p=29)),
     (1280, 720, 3, dict(partitions=7, refs=3, mixed_refs=1, dct8x8=1, chroma_me=1, subme=5)),
+    # RD mode decision (x264 subme 6 / 7, CAVLC bit counts): from the plainest candidate set up
+    (64, 48, 3, dict(rd=1, subme=6, partitions=0)),
+    (176, 144, 4, dict(rd=1, subme=6, partitions=2)),
+    (176, 144, 4, dict(rd=1, subme=6, partitions=1)),
+    (176, 144, 4, dict(rd=1, subme=7, partitions=3, refs=2, psy=1, psy_rd_q8=256, chroma_qp_offset=-2)),
+    (176, 144, 4, dict(rd=1, subme=7, partitions=7, dct8x8=1, refs=3, mixed_refs=1, chroma_me=1, psy=1, psy_rd_q8=256, chroma_qp_offset=-2)),
+    (352, 288, 4, dict(rd=1, subme=7, partitions=7, dct8x8=1, refs=3, mixed_refs=1, chroma_me=1, qp_i=30, qp_p=34, me_method=2)),
+    (96, 208, 4, dict(rd=1, subme=6, slices=3, partitions=7, dct8x8=1, refs=2, psy=1, psy_rd_q8=102, chroma_qp_offset=-1, aq_mode=1)),
+    (96, 80, 4, dict(rd=1, subme=6, partitions=7, dct8x8=1, qp_i=8, qp_p=10, dct_decimate=0, fast_pskip=0)),
 ]
 
 

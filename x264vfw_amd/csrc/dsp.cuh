@@ -146,6 +146,14 @@ __device__ __forceinline__ uint32_t avg4_u8(uint32_t a, uint32_t b)
 // metrics (oracle/pixel.c)
 // ---------------------------------------------------------------------------------------------
 __device__ __forceinline__ int sad4(uint32_t a, uint32_t b) { return (int)__builtin_amdgcn_sad_u8(a, b, 0u); }
+// sum of squared differences of four packed pixels
+__device__ __forceinline__ int ssd4_u8(uint32_t a, uint32_t b)
+{
+    int s = 0;
+#pragma unroll
+    for (int i = 0; i < 4; i++) { const int d = (int)((a >> (8 * i)) & 255) - (int)((b >> (8 * i)) & 255); s += d * d; }
+    return s;
+}
 
 // per-lane share of sum|H4 d H4| for the quad's 4x4 block (sum over the quad, then >>1, is SATD)
 __device__ __forceinline__ int satd_quad_partial(const int d[4], int lane)

@@ -40,6 +40,7 @@ struct x264gpu_encoder {
     const int16_t *lowres_mv = nullptr;
     int cur = 0;
     unsigned long long *dbg = nullptr;   // diagnostics buffer set by x264gpu_encoder_set_debug
+    uint8_t *tc = nullptr;               // RD: total_coeff of every block of the picture being coded
     unsigned long long *prof = nullptr;  // MB_PROF builds: phase counters of the last macroblock-loop launch
     int *wf_progress = nullptr;          // [streams][2][WFG_ROWS] row counters of the multi-workgroup wavefront kernels
     // adaptive quantisation: per-macroblock quantisers and the per-quantiser tables (built when aq_mode != 0)
@@ -97,6 +98,7 @@ int x264gpu_encoder_create(x264gpu_encoder **out, const x264gpu_config *cfg)
     ARG_TRY(out && cfg);
     ARG_TRY(cfg->width >= 16 && cfg->height >= 16 && !(cfg->width & 1) && !(cfg->height & 1) && cfg->streams >= 1);
     ARG_TRY(cfg->qp_i >= 0 && cfg->qp_i <= 51 && cfg->qp_p >= 0 && cfg->qp_p <= 51 && cfg->refs >= 1 && cfg->refs <= 5);
+    ARG_TRY(!cfg->rd || (!cfg->cabac && cfg->subme >= 6 && cfg->subme <= 7 && cfg->psy_rd_q8 >= 0 && cfg->psy_rd_q8 <= 2560));      // RD: CAVLC sessions, x264's i_mbrd 1
     ARG_TRY(cfg->slices >= 0 && (cfg->slices <= 1 || cfg->slices <= (cfg->height + 15) / 16 / 4));      // x264 slice threads: at least four macroblock rows each
     ARG_TRY(cfg->width <= 4096 && cfg->height <= 2304 && cfg->me_range >= 4 && cfg->me_range <= (cfg->me_method == 2 ? 64 : 16));
     ARG_TRY(cfg->me_method >= 0 && cfg->me_method <= 3);
@@ -117,6 +119,7 @@ int x264gpu_encoder_create(x264gpu_encoder **out, const x264gpu_config *cfg)
     k.cplane_bytes = (size_t)k.rs * (k.ch / 2 + 2 * CPAD);
     k.me_range = cfg->me_range; k.subme = cfg->subme; k.dct_decimate = cfg->dct_decimate;
     k.slices = cfg->slices > 1 ? cfg->slices : 1; k.cabac = cfg->cabac != 0;
+    k.rd = cfg->rd != 0; k.psy = cfg->psy != 0; k.psy_rd_q8 = cfg->psy_rd_q8;
     k.partitions = cfg->partitions; k.chroma_qp_offset = cfg->chroma_qp_offset; k.dct8x8 = cfg->dct8x8; k.me_method = cfg->me_method; k.chroma_me = cfg->chroma_me != 0; k.mixed_refs = cfg->mixed_refs != 0;
     k.alpha_off = cfg->deblock_alpha * 2; k.beta_off = cfg->deblock_beta * 2;
     const size_t S = (size_t)cfg->streams;
@@ -139,6 +142,7 @@ int x264gpu_encoder_create(x264gpu_encoder **out, const x264gpu_config *cfg)
     }
     for (int r = 1; r < cfg->refs; r++) alloc((void **)&e->mvr[r], S * k.nmb * 2 * sizeof(int16_t), 0);
     alloc((void **)&e->wf_progress, S * 2 * WFG_ROWS * sizeof(int), 0);
+    if (cfg->rd) alloc((void **)&e->tc, S * k.nmb * 24, 0);
 #ifdef MB_PROF
     alloc((void **)&e->prof, S * 16 * sizeof(unsigned long long), 0);
 #endif
@@ -222,6 +226,7 @@ void x264gpu_encoder_destroy(x264gpu_encoder *e)
     for (int i = 0; i < 6; i++) { (void)hipFree(e->luma[i]); (void)hipFree(e->chroma[i]); (void)hipFree(e->mv16[i]); (void)hipFree(e->mbtype[i]); }
     for (int i = 0; i < 5; i++) (void)hipFree(e->mvr[i]);
     (void)hipFree(e->wf_progress);
+    (void)hipFree(e->tc);
     (void)hipFree(e->prof);
     (void)hipFree(e->stream_qp); (void)hipFree(e->mbqp); (void)hipFree(e->q4tab); (void)hipFree(e->q8tab); (void)hipFree(e->lambda_tab); (void)hipFree(e->cost_all);
     delete e;
@@ -276,7 +281,7 @@ int x264gpu_encode_frames(x264gpu_encoder *e, const uint8_t *d_i420, int slice_t
         for (int r = 0; r < k.nref; r++) k.tscale[r] = (e->poc - e->slot_poc[slot_of(r)]) * inv;
     }
     e->slot_nref[e->cur] = k.nref; e->slot_poc[e->cur] = e->poc; e->slot_ref0poc[e->cur] = k.nref ? e->slot_poc[s0] : 0;
-    k.prof = e->prof;
+    k.prof = e->prof; k.tc = e->tc;
     k.lowres_mv = e->lowres_mv; k.fast_pskip = e->cfg.fast_pskip; k.mv_range = e->cfg.mv_range;
     k.mb = d_mb; k.levels = d_levels;
     k.qp = qp; k.lambda = lambda_of(qp); k.qpc = chroma_qp_of(qp, e->cfg.chroma_qp_offset);
@@ -299,7 +304,7 @@ int x264gpu_encode_frames(x264gpu_encoder *e, const uint8_t *d_i420, int slice_t
     mask |= 1;
     STAGE_MARK(1);
     // the macroblock loop: one wavefront per stream, raster order (sub-pel neighbourhood margin 2 px up to subme 7, 5 px above)
-    if (slice_type == X264GPU_SLICE_I) launch_mb_slice_intra(k, S, st);
+    if (slice_type == X264GPU_SLICE_I) launch_mb_slice_intra(k, S, st);        // (RD instantiations inside, chosen by k.rd)
     else (k.me_method == 0 ? launch_mb_slice_dia : k.me_method == 2 ? launch_mb_slice_umh : k.me_method == 3 ? launch_mb_slice_esa : launch_mb_slice_hex)(k, S, k.subme >= 8, st);
     mask |= 2;
     STAGE_MARK(2);

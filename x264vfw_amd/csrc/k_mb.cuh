@@ -13,6 +13,7 @@
 #include "enc_common.cuh"
 #include "k_analyse.cuh"
 #include "intra8.cuh"
+#include "rd.cuh"
 
 namespace x264gpu {
 
@@ -668,6 +669,9 @@ __device__ __forceinline__ void me_search(const EncK &k, MbLds<M> &L, const MbCt
 // ------------------------------------------------------------------------------------------------
 // intra analysis (oracle analyse_intra / analyse_intra_chroma; x264_mb_analyse_intra)
 // ------------------------------------------------------------------------------------------------
+// x264_chroma_lambda2_offset_tab: 256 * 2^((i - 12) / 3)
+static __constant__ uint16_t c_chroma_lambda2_offset[37] = { 16, 20, 25, 32, 40, 50, 64, 80, 101, 128, 161, 203, 256, 322, 406, 512, 645, 812, 1024, 1290, 1625, 2048, 2580, 3250, 4096,
+                                                             5160, 6501, 8192, 10321, 13003, 16384, 20642, 26007, 32768, 41285, 52015, 65535 };
 static __constant__ int c_lambda2_tab[52] = { 14, 18, 22, 28, 36, 45, 57, 72, 91, 115, 145, 182, 230, 290, 365, 460, 580, 731, 921, 1160, 1462, 1843, 2322, 2926,
                                               3686, 4644, 5852, 7373, 9289, 11703, 14745, 18578, 23407, 29491, 37156, 46814, 58982, 74313, 93628, 117964,
                                               148626, 187257, 235929, 297252, 374514, 471859, 594505, 749029, 943718, 1189010, 1498059, 1887436 };
@@ -1101,11 +1105,12 @@ __device__ __forceinline__ bool mb_probe_pskip(const EncK &k, const MbCtx &c, ui
 // The slice kernel: one wavefront per stream walks the macroblocks in raster order.
 // ------------------------------------------------------------------------------------------------
 // M: sub-pel neighbourhood margin (2 px up to subme 7, 5 above); ME: --me method (its own instantiation each: the roaming umh / esa code
-// costs the hexagon kernel registers otherwise); PS: P slice (I slices: k_mb_slice<2, 1, false>, mb_slice_intra.hip)
+// costs the hexagon kernel registers otherwise); PS: P slice (I slices: k_mb_slice<2, 1, false>, mb_slice_intra.hip); RD: x264's RD mode
+// decision of subme 6 / 7 with CAVLC bit counts (own instantiations: the candidate passes cost registers and code)
 #ifndef MB_WAVES_PER_EU
 #define MB_WAVES_PER_EU 2
 #endif
-template <int M, int ME, bool PS>
+template <int M, int ME, bool PS, bool RD = false>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(MB_WAVES_PER_EU, 4))) void k_mb_slice(EncK k)
 {
     __shared__ __attribute__((aligned(16))) MbLds<M> L;
@@ -1120,6 +1125,11 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(MB_WAVES_PER
     constexpr bool pslice = PS;                 // I slices run their own instantiation (no search code, a fraction of the registers)
     const int j4 = lane & 3, zx = z_x0(lane), zy = z_y(lane);
     int intra_count = 0, cost_qp = -1;
+    // RD instantiation: levels of the candidate being costed (and of the final macroblock, before they go out), total_coeff of the left / top
+    // macroblocks' blocks for the nC of the bit counts; the quantiser the previous coded macroblock left (mb_qp_delta bits)
+    __shared__ __attribute__((aligned(16))) int16_t rd_lvs[RD ? X264GPU_MB_LEVELS : 1];
+    __shared__ uint8_t rd_ntc[2][RD ? 24 : 1];
+    int last_qp = slice_qp(k, s);
     Prof pf;
     pf.start();
     int16_t *mv16 = k.mv16_cur + (size_t)s * k.nmb * 2;
@@ -1191,6 +1201,13 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(MB_WAVES_PER
         const uint32_t cz = *(const uint32_t *)(c.fenc + (size_t)zy * k.fs + zx);
         uint32_t csv = 0;
         if (lane < 32) csv = *(const uint32_t *)(c.fuv + (size_t)(lane >> 2) * k.fs + (lane & 3) * 4);
+        uint8_t ntcv = 0;            // RD: total_coeff of the left (lanes 0..23) / top (lanes 24..47) macroblock's blocks
+        if constexpr (RD) {
+            if (k.rd) {
+                if (lane < 24) { if (left) ntcv = k.tc[((size_t)s * k.nmb + mbi - 1) * 24 + lane]; }
+                else if (lane < 48) { if (top) ntcv = k.tc[((size_t)s * k.nmb + mbi - k.mbw) * 24 + lane - 24]; }
+            }
+        }
         // ---- ... into LDS / registers ----
         lds_sync();
         if (lane < 25) {
@@ -1217,6 +1234,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(MB_WAVES_PER
             S.cref = ref; S.cmvx = vx; S.cmvy = vy;
         }
         *(uint32_t *)(L.src + zy * 16 + zx) = cz;
+        if constexpr (RD) { if (lane < 48) rd_ntc[lane >= 24][lane >= 24 ? lane - 24 : lane] = ntcv; }
         if (lane < 32) *(uint32_t *)(L.csrc + (lane >> 2) * 16 + (lane & 3) * 4) = csv;
         lds_sync();
 
@@ -1229,6 +1247,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(MB_WAVES_PER
         int mb_type = X264GPU_MB_I16x16, i_cost = 0, predc = 0, satd_chroma = MB_COST_MAX;
         IntraRes IR;
         bool pskip = false;
+        int cost8x8 = MB_COST_MAX, satd16x8 = MB_COST_MAX, satd8x16 = MB_COST_MAX;      // SATD costs of the shapes (MB_COST_MAX: not analysed / terminated early)
+        const bool rdon = RD && k.rd != 0;
+        int i_inter_satd = MB_COST_MAX;            // best SATD cost of the inter analysis (the RD thresholds hang on it)
         int pskx = 0, psky = 0, best_part = D_16x16;
         bool fast_intra = false;
         pf.mark(PH_SETUP);
@@ -1293,7 +1314,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(MB_WAVES_PER
             int stage = 0, part = 0, kk = 0, nk = c.nref;
             int halfpel_thresh = 0x7fffffff;
             int i_maxref = c.nref - 1, ref_a = 0, ref_b = 0;      // 8x8: highest reference tried; 16x8 / 8x16: the two candidate references
-            int cost8x8 = 0, est1 = 0;
+            int est1 = 0;
             int sat8[4] = { 0, 0, 0, 0 };
             bool done = pskip;
             WinTags wt;
@@ -1395,7 +1416,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(MB_WAVES_PER
                     if (++kk < nk) continue;
                     // 16x16 done
                     i_cost = rl(S.cost, ME_16); best_part = D_16x16;
-                    if (!psub16) { stage = 4; part = 0; if (!c.subme) done = true; continue; }
+                    if (!psub16) { stage = 4; part = 0; if (!c.subme || rdon) done = true; continue; }
                     stage = 1; part = 0; kk = 0;
                     i_maxref = c.nref - 1;
                     if (mixed) {
@@ -1430,7 +1451,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(MB_WAVES_PER
                     if (!early_term || cost8x8 < c16) { best_part = D_8x8; i_cost = cost8x8; }
                     const int th = rl(S.costmv, ME_8 + 1) + rl(S.costmv, ME_8 + 2);
                     if (!early_term || cost8x8 < c16 + th) { stage = 2; part = 0; kk = 0; setup_half(2, 0); }
-                    else { stage = 4; part = 0; if (!c.subme) done = true; }
+                    else { stage = 4; part = 0; if (!c.subme || rdon) done = true; }
                     continue;
                 }
                 if (stage == 2 || stage == 3) {
@@ -1448,10 +1469,11 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(MB_WAVES_PER
                         }
                         if (part == 0) { part = 1; kk = 0; setup_half(stage, 1); continue; }
                         const int total = rl(S.cost, slot - 1) + rl(S.cost, slot);
+                        if (stage == 2) satd16x8 = total; else satd8x16 = total;
                         if (total < i_cost) { i_cost = total; best_part = stage == 2 ? D_16x8 : D_8x16; }
                     }
                     if (stage == 2) { stage = 3; part = 0; kk = 0; setup_half(3, 0); }
-                    else { stage = 4; part = 0; if (!c.subme) done = true; }
+                    else { stage = 4; part = 0; if (!c.subme || rdon) done = true; }
                     continue;
                 }
                 // stage 4: refinement results
@@ -1468,6 +1490,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(MB_WAVES_PER
         // ---- intra analysis (P slices: against the inter cost; chroma-ME decides the chroma mode first and carries its cost) ----
         if (!pskip) {
             const int i_satd_inter = pslice ? i_cost : MB_COST_MAX;
+            i_inter_satd = i_satd_inter;
             // the chroma mode depends on the neighbours only: decided here for every macroblock that is analysed (x264 does it here under chroma-ME,
             // otherwise only for macroblocks that end up intra — same mode either way); its cost enters the comparison under chroma-ME only
             satd_chroma = mb_intra_chroma_cost(k, L, c, predc);
@@ -1486,20 +1509,93 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(MB_WAVES_PER
                 if (IR.satd_i8 < i_cost) { i_cost = IR.satd_i8; mb_type = X264GPU_MB_I8x8; }
             }
         } else { mb_type = X264GPU_MB_P_SKIP; i_cost = 0; }
-        int rec_type = mb_type;
         if (lane == 0) recd.cost = i_cost;
         pf.mark(PH_INTRA);
 
-        // ---- x264_macroblock_encode ----
+        // ---- x264_macroblock_encode.  One pass of the code below codes the macroblock.  The RD instantiation first runs it for candidates
+        //      (e_type / e_part / e_t8, results kept on chip, nothing stored) and costs each with x264_rd_cost_mb: SSD + psy + lambda2 x bits ----
         unsigned nnz = 0;
         int cbp_luma = 0, cbp_chroma = 0;
-        if (mb_type >= X264GPU_MB_P_L0) {
+        int e_type = mb_type, e_part = best_part, e_t8 = -1;          // what this pass codes; e_t8: -1 = SA8D vs SATD decides, else the transform size
+        bool commit = true;
+        // RD bookkeeping (x264_mb_analysis_t l0.i_rd16x16 / i_cost16x8 / i_cost8x16 / i_cost8x8 turned into RD costs, the intra ones likewise)
+        int rd_ph = 0, rd16 = MB_COST_MAX, rd16x8 = MB_COST_MAX, rd8x16 = MB_COST_MAX, rd8x8 = MB_COST_MAX, rd_best = MB_COST_MAX, rd_part = D_16x16, rd_t8 = 0;
+        int rd_satd_inter = 0, rd_isatd = 0, rd_thresh = 0, rd_ithresh = 0, rd_i16 = MB_COST_MAX, rd_i4 = MB_COST_MAX, rd_i8 = MB_COST_MAX, fenc_energy = 0;
+        const int lambda2 = c_lambda2_tab[c.qp];
+        bool rd_run = false, rd_skip16 = false;
+        if constexpr (RD) {
+            rd_run = rdon && !pskip;
+            if (rd_run) {
+                commit = false;
+                const int i_satd_intra = min(min(IR.satd_i16, IR.satd_i8), IR.satd_i4);
+                rd_satd_inter = i_inter_satd;
+                rd_isatd = min(i_inter_satd, i_satd_intra);
+                rd_thresh = early_term ? rd_isatd * 5 / 4 + 1 : MB_COST_MAX;
+                if (k.psy_rd_q8) fenc_energy = wave_sum(satd4_half(cz, 0u, lane)) - (wave_sum((int)__builtin_amdgcn_sad_u8(cz, 0u, 0u)) >> 1);
+            }
+        }
+        int rec_type = mb_type, chroma_l2off = 256;
+        if constexpr (RD) { if (k.psy) chroma_l2off = c_chroma_lambda2_offset[min(max(c.qp - c.qpc + 12, 0), 36)]; }
+        for (;;) {
+        if constexpr (RD) {
+            if (rd_run && !commit) {
+                // next candidate in x264's order: P16x16, 16x8, 8x16, 8x8 (x264_mb_analyse_p_rd), the other transform size of the winner
+                // (x264_mb_analyse_transform_rd), I16x16, I4x4, I8x8 (x264_intra_rd); then the final pass
+                const int c16 = pslice ? rl(S.cost, ME_16) : MB_COST_MAX;
+                for (;; rd_ph++) {
+                    bool go = false;
+                    if (rd_ph == 0) { go = pslice && ((rl(S.ref, ME_16) == 0 && rl(S.mvx, ME_16) == pskx && rl(S.mvy, ME_16) == psky) || !early_term || c16 <= rd_isatd * 3 / 2); e_type = X264GPU_MB_P_L0; e_part = D_16x16; e_t8 = 0; }
+                    else if (rd_ph == 1) { go = pslice && satd16x8 < rd_thresh; e_type = X264GPU_MB_P_L0; e_part = D_16x8; e_t8 = 0; }
+                    else if (rd_ph == 2) { go = pslice && satd8x16 < rd_thresh; e_type = X264GPU_MB_P_L0; e_part = D_8x16; e_t8 = 0; }
+                    else if (rd_ph == 3) { go = pslice && cost8x8 < rd_thresh; e_type = X264GPU_MB_P_8x8; e_part = D_8x8; e_t8 = 0; }
+                    else if (rd_ph == 4) {
+                        rd_best = rd16; rd_part = D_16x16;
+                        if (rd16x8 < rd_best) { rd_best = rd16x8; rd_part = D_16x8; }
+                        if (rd8x16 < rd_best) { rd_best = rd8x16; rd_part = D_8x16; }
+                        if (rd8x8 < rd_best) { rd_best = rd8x8; rd_part = D_8x8; }
+                        go = pslice && rd_best < MB_COST_MAX && k.dct8x8; e_type = rd_part == D_8x8 ? X264GPU_MB_P_8x8 : X264GPU_MB_P_L0; e_part = rd_part; e_t8 = 1;
+                    } else if (rd_ph == 5) {
+                        rd_ithresh = !early_term || !pslice ? MB_COST_MAX : rd_satd_inter * 5 / 4 + 1;
+                        go = IR.satd_i16 < rd_ithresh; e_type = X264GPU_MB_I16x16;
+                    } else if (rd_ph == 6) { go = IR.satd_i4 < rd_ithresh; e_type = X264GPU_MB_I4x4; }
+                    else if (rd_ph == 7) { go = IR.satd_i8 < rd_ithresh; e_type = X264GPU_MB_I8x8; }
+                    else {
+                        // the decision on RD costs, then the real pass
+                        int best = pslice ? rd_best : MB_COST_MAX;
+                        e_type = rd_part == D_8x8 ? X264GPU_MB_P_8x8 : X264GPU_MB_P_L0; e_part = rd_part; e_t8 = rd_t8;
+                        if (pslice) {
+                            if (rd_i16 < best) { best = rd_i16; e_type = X264GPU_MB_I16x16; }
+                            if (rd_i8 < best) { best = rd_i8; e_type = X264GPU_MB_I8x8; }
+                            if (rd_i4 < best) { best = rd_i4; e_type = X264GPU_MB_I4x4; }
+                        } else {
+                            best = rd_i16; e_type = X264GPU_MB_I16x16;
+                            if (rd_i4 < best) { best = rd_i4; e_type = X264GPU_MB_I4x4; }
+                            if (rd_i8 < best) { best = rd_i8; e_type = X264GPU_MB_I8x8; }
+                        }
+                        i_cost = best; mb_type = e_type; best_part = e_part;
+                        if (rd_skip16) {           // as x264_macroblock_analyse leaves a P_SKIP found here: no cost, the other references' predictors zero
+                            i_cost = 0;
+                            if (lane == 0) { recd.aux[0] = 0; recd.aux[1] = 0; recd.aux[2] = 0; }
+                            if (lane >= 1 && lane < c.nref) { int16_t *m = k.mvr[lane] + ((size_t)s * k.nmb + mbi) * 2; m[0] = 0; m[1] = 0; }
+                        }
+                        if (lane == 0) recd.cost = i_cost;
+                        commit = true; go = true;
+                    }
+                    if (go) break;
+                }
+            }
+        }
+        nnz = 0; cbp_luma = 0; cbp_chroma = 0;
+        rec_type = e_type;
+        int16_t *lvw = RD ? (int16_t *)rd_lvs : lv;               // RD: levels stay on chip until the final pass has its bit counts' totals
+        int ssd_y = 0, ssd_c = 0, en_satd = 0, en_sad = 0;          // per-lane shares of the distortion terms of the candidate
+        if (e_type >= X264GPU_MB_P_L0) {
             // this lane's 8x8 block's motion (Z layout: lane >> 4)
             const int b8 = lane >> 4;
             int lmx, lmy, lref;
             if (pskip) { lmx = clampi(pskx, c.mvmin0, c.mvmax0); lmy = clampi(psky, c.mvmin1, c.mvmax1); lref = 0; }
             else {
-                const int slot = best_part == D_16x16 ? ME_16 : best_part == D_16x8 ? ME_16x8 + (b8 >> 1) : best_part == D_8x16 ? ME_8x16 + (b8 & 1) : ME_8 + b8;
+                const int slot = e_part == D_16x16 ? ME_16 : e_part == D_16x8 ? ME_16x8 + (b8 >> 1) : e_part == D_8x16 ? ME_8x16 + (b8 & 1) : ME_8 + b8;
                 lmx = __shfl(S.mvx, slot); lmy = __shfl(S.mvy, slot); lref = __shfl(S.ref, slot);      // slot varies with the lane (its 8x8 block)
             }
             const uint32_t pred = mc_luma_row4(ref_plane00(k, s, lref), k.plane_bytes, k.rs, c.px + zx, c.py + zy, lmx, lmy);
@@ -1510,23 +1606,26 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(MB_WAVES_PER
             mc_chroma_row4(ref_chroma00(k, s, cref), k.rs, mbx * 8 + cx0, mby * 8 + cyy, cmvx, cmvy, pu, pv);
             const uint32_t cpred = pl ? pv : pu;
             const int mv0x = pskip ? pskx : __builtin_amdgcn_readlane(lmx, 0), mv0y = pskip ? psky : __builtin_amdgcn_readlane(lmy, 0), ref0 = __builtin_amdgcn_readlane(lref, 0);
-            if ((lane & 15) == 0) {      // one lane per 8x8 block writes that block's motion
+            if (commit && (lane & 15) == 0) {      // one lane per 8x8 block writes that block's motion
                 recd.mv[lane >> 4][0] = (int16_t)(pskip ? pskx : lmx); recd.mv[lane >> 4][1] = (int16_t)(pskip ? psky : lmy); recd.ref[lane >> 4] = (int8_t)lref;
             }
-            if (lane == 0) recd.partition = (uint8_t)(pskip ? 0 : best_part);
+            if (commit && lane == 0) recd.partition = (uint8_t)(pskip ? 0 : e_part);
             if (pskip) {
                 *(uint32_t *)(rec + (size_t)zy * k.rs + zx) = pred;
                 mb_store_chroma(ruv, k.rs, lane, cpred);
-                if (lane < 52) { uint4 z; z.x = z.y = z.z = z.w = 0; *(uint4 *)(lv + lane * 8) = z; }
+                if (lane < 52) { uint4 z; z.x = z.y = z.z = z.w = 0; *(uint4 *)(lvw + lane * 8) = z; }
             } else {
                 const uint32_t enc = cz;
                 bool t8 = false;
                 uint32_t elo = 0, ehi = 0, plo = 0, phi = 0;
                 if (k.dct8x8) {
                     z_to_r8(enc, lane, elo, ehi); z_to_r8(pred, lane, plo, phi);
-                    const int h8 = sa8d_r8_half(elo, ehi, plo, phi, lane);
-                    const int cost8 = (2 * wave_sum(lane < 32 ? h8 : 0) + 2) >> 2, cost4 = wave_sum(satd4_half(enc, pred, lane));
-                    t8 = cost8 < cost4;
+                    if (e_t8 >= 0) t8 = e_t8 != 0;                  // RD: the transform size belongs to the candidate
+                    else {
+                        const int h8 = sa8d_r8_half(elo, ehi, plo, phi, lane);
+                        const int cost8 = (2 * wave_sum(lane < 32 ? h8 : 0) + 2) >> 2, cost4 = wave_sum(satd4_half(enc, pred, lane));
+                        t8 = cost8 < cost4;
+                    }
                 }
                 if (t8) {
                     const int row = lane & 7, i8 = (lane >> 3) & 3;
@@ -1557,7 +1656,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(MB_WAVES_PER
 #pragma unroll
                         for (int i = 0; i < 8; i++) {
                             const int z = c_zigzag8_inv[row * 8 + i];
-                            lv[(i8 * 4 + (z & 3)) * 16 + (z >> 2)] = (int16_t)(keep ? v[i] : 0);
+                            lvw[(i8 * 4 + (z & 3)) * 16 + (z >> 2)] = (int16_t)(keep ? v[i] : 0);
                         }
                     }
                     unsigned n4 = 0;
@@ -1579,7 +1678,12 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(MB_WAVES_PER
                     if (lane < 32) {
                         uint2 o;
                         o.x = pack4_clip8lo(v); o.y = pack4_clip8hi(v);
-                        *(uint2 *)(rec + (size_t)((i8 >> 1) * 8 + row) * k.rs + (i8 & 1) * 8) = o;
+                        if (commit) *(uint2 *)(rec + (size_t)((i8 >> 1) * 8 + row) * k.rs + (i8 & 1) * 8) = o;
+                        if constexpr (RD) {      // R8 layout: a quad of lanes is four rows of one 8x8 block, so both halves are 4x4 blocks for the SATD
+                            ssd_y = ssd4_u8(elo, o.x) + ssd4_u8(ehi, o.y);
+                            en_satd = satd4_half(o.x, 0u, lane) + satd4_half(o.y, 0u, lane);
+                            en_sad = (int)__builtin_amdgcn_sad_u8(o.x, 0u, __builtin_amdgcn_sad_u8(o.y, 0u, 0u));
+                        }
                     }
                 } else {
                     int e[4], p[4], v[4];
@@ -1600,13 +1704,17 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(MB_WAVES_PER
                         if (any8 && score8 < 4) any8 = false;
                         keep = nz && any8 && mbscore >= 6;
                     }
-                    { int z[4] = { 0, 0, 0, 0 }; store_levels_scan(lv + (lane >> 2) * 16, keep ? v : z, j4); }
+                    { int z[4] = { 0, 0, 0, 0 }; store_levels_scan(lvw + (lane >> 2) * 16, keep ? v : z, j4); }
                     if (!keep) v[0] = v[1] = v[2] = v[3] = 0;
                     dequant4_row(v, q_lp, j4);
                     idct4_quad(v, lane);
 #pragma unroll
                     for (int i = 0; i < 4; i++) v[i] += p[i];
-                    *(uint32_t *)(rec + (size_t)zy * k.rs + zx) = pack4_clip(v);
+                    {
+                        const uint32_t rz = pack4_clip(v);
+                        if (commit) *(uint32_t *)(rec + (size_t)zy * k.rs + zx) = rz;
+                        if constexpr (RD) { ssd_y = ssd4_u8(cz, rz); en_satd = satd4_half(rz, 0u, lane); en_sad = (int)__builtin_amdgcn_sad_u8(rz, 0u, 0u); }
+                    }
                     const unsigned long long bal = __ballot(keep && j4 == 0);
 #pragma unroll
                     for (int b = 0; b < 16; b++) nnz |= (unsigned)((bal >> (4 * b)) & 1) << b;
@@ -1615,37 +1723,46 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(MB_WAVES_PER
                 }
                 const uint2 fe = *(const uint2 *)(L.csrc + cyy * 16 + 2 * cx0);
                 const uint32_t cenc = nv12_pick(fe.x, fe.y, pl);
-                const uint32_t crec = mb_chroma_residual(cenc, cpred, q_cp, true, k.dct_decimate != 0, lane, lv, nnz, cbp_chroma);
-                mb_store_chroma(ruv, k.rs, lane, crec);
-                if (lane >= 32 && lane < 40) lv[X264GPU_LV_LUMA_DC + (lane - 32) * 2] = 0, lv[X264GPU_LV_LUMA_DC + (lane - 32) * 2 + 1] = 0;
-                if (lane >= 40 && lane < 44) lv[408 + (lane - 40) * 2] = 0, lv[408 + (lane - 40) * 2 + 1] = 0;
-                if (lane == 0) recd.transform8x8 = (uint8_t)(t8 && cbp_luma);
+                const uint32_t crec = mb_chroma_residual(cenc, cpred, q_cp, true, k.dct_decimate != 0, lane, lvw, nnz, cbp_chroma);
+                if (commit) mb_store_chroma(ruv, k.rs, lane, crec);
+                if constexpr (RD) { if (lane < 32) ssd_c = ssd4_u8(cenc, crec); }
+                if (lane >= 32 && lane < 40) lvw[X264GPU_LV_LUMA_DC + (lane - 32) * 2] = 0, lvw[X264GPU_LV_LUMA_DC + (lane - 32) * 2 + 1] = 0;
+                if (lane >= 40 && lane < 44) lvw[408 + (lane - 40) * 2] = 0, lvw[408 + (lane - 40) * 2 + 1] = 0;
+                if (commit && lane == 0) recd.transform8x8 = (uint8_t)(t8 && cbp_luma);
                 // P_L0 16x16, reference 0, the skip vector, nothing coded: P_SKIP
-                if (mb_type == X264GPU_MB_P_L0 && best_part == D_16x16 && !(cbp_luma | cbp_chroma) && ref0 == 0 && mv0x == pskx && mv0y == psky)
+                if (e_type == X264GPU_MB_P_L0 && e_part == D_16x16 && !(cbp_luma | cbp_chroma) && ref0 == 0 && mv0x == pskx && mv0y == psky)
                     rec_type = X264GPU_MB_P_SKIP;
             }
             pf.mark(PH_ENC_INTER);
         } else {
             // ---- intra macroblock ----
-            if (lane < 4) recd.ref[lane] = -1;
-            if (mb_type == X264GPU_MB_I8x8) {
-                if (lane == 0) recd.transform8x8 = 1;
-                if (lane < 16) recd.i4_mode[lane] = L.modes8[lane];
+            if (commit && lane < 4) recd.ref[lane] = -1;
+            if (e_type == X264GPU_MB_I8x8) {
+                if (commit && lane == 0) recd.transform8x8 = 1;
+                if (commit && lane < 16) recd.i4_mode[lane] = L.modes8[lane];
                 nnz = IR.nnz8; cbp_luma = IR.cbp8;
-                *(uint32_t *)(rec + (size_t)zy * k.rs + zx) = *(const uint32_t *)(tile8 + zy * IT_STRIDE + zx);
-                *(uint2 *)(lv + lane * 4) = *(const uint2 *)(L.lv8 + lane * 4);
-                if (lane < 16) lv[X264GPU_LV_LUMA_DC + lane] = 0;
-            } else if (mb_type == X264GPU_MB_I4x4) {
-                if (lane < 16) recd.i4_mode[lane] = L.modes4[lane];
+                {
+                    const uint32_t rz = *(const uint32_t *)(tile8 + zy * IT_STRIDE + zx);
+                    if (commit) *(uint32_t *)(rec + (size_t)zy * k.rs + zx) = rz;
+                    if constexpr (RD) { ssd_y = ssd4_u8(cz, rz); en_satd = satd4_half(rz, 0u, lane); en_sad = (int)__builtin_amdgcn_sad_u8(rz, 0u, 0u); }
+                }
+                *(uint2 *)(lvw + lane * 4) = *(const uint2 *)(L.lv8 + lane * 4);
+                if (lane < 16) lvw[X264GPU_LV_LUMA_DC + lane] = 0;
+            } else if (e_type == X264GPU_MB_I4x4) {
+                if (commit && lane < 16) recd.i4_mode[lane] = L.modes4[lane];
                 nnz = IR.nnz4;
                 for (int i8 = 0; i8 < 4; i8++) if ((nnz >> (4 * i8)) & 15) cbp_luma |= 1 << i8;
-                *(uint32_t *)(rec + (size_t)zy * k.rs + zx) = *(const uint32_t *)(tile + zy * IT_STRIDE + zx);
-                *(uint2 *)(lv + lane * 4) = *(const uint2 *)(L.lv4 + lane * 4);
-                if (lane < 16) lv[X264GPU_LV_LUMA_DC + lane] = 0;
+                {
+                    const uint32_t rz = *(const uint32_t *)(tile + zy * IT_STRIDE + zx);
+                    if (commit) *(uint32_t *)(rec + (size_t)zy * k.rs + zx) = rz;
+                    if constexpr (RD) { ssd_y = ssd4_u8(cz, rz); en_satd = satd4_half(rz, 0u, lane); en_sad = (int)__builtin_amdgcn_sad_u8(rz, 0u, 0u); }
+                }
+                *(uint2 *)(lvw + lane * 4) = *(const uint2 *)(L.lv4 + lane * 4);
+                if (lane < 16) lvw[X264GPU_LV_LUMA_DC + lane] = 0;
             } else {
                 // x264_mb_encode_i16x16 (AC decimated as a whole in P slices)
                 const int mode16 = IR.pred16;
-                if (lane == 0) recd.i16_mode = (uint8_t)(mode16 > PRED16_P ? PRED16_DC : mode16);
+                if (commit && lane == 0) recd.i16_mode = (uint8_t)(mode16 > PRED16_P ? PRED16_DC : mode16);
                 const Pred16 pp = pred16_setup(L.nb, lane);
                 int e[4], p[4], v[4];
                 unpack4(cz, e); unpack4(pred16_row4(L.nb, pp, mode16, zx, zy), p);
@@ -1662,7 +1779,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(MB_WAVES_PER
                     const int sc = nz ? (big ? 9 : decimate_from_mask(mask, 1)) : 0;
                     if (wave_sum(j4 == 0 ? sc : 0) < 6) nz = false;
                 }
-                { int z[4] = { 0, 0, 0, 0 }; store_levels_scan(lv + (lane >> 2) * 16, nz ? v : z, j4); }
+                { int z[4] = { 0, 0, 0, 0 }; store_levels_scan(lvw + (lane >> 2) * 16, nz ? v : z, j4); }
                 if (!nz) v[0] = v[1] = v[2] = v[3] = 0;
                 dequant4_row(v, q_li, j4);
                 const unsigned long long bal = __ballot(nz && j4 == 0);
@@ -1676,7 +1793,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(MB_WAVES_PER
 #pragma unroll
                 for (int cc = 0; cc < 4; cc++) dc[cc] = quant_one((dc[cc] + 1) >> 1, q_li.mf[0] >> 1, q_li.bias[0] << 1);
                 const bool nzdc = quad_or((dc[0] | dc[1] | dc[2] | dc[3]) != 0 ? 1 : 0) != 0;
-                if (lane < 4) store_levels_scan(lv + X264GPU_LV_LUMA_DC, dc, j4);
+                if (lane < 4) store_levels_scan(lvw + X264GPU_LV_LUMA_DC, dc, j4);
                 had4x4_quad(dc, lane);
                 {
                     const int ls = q_li.dq[0], qb = c.qp / 6 - 6;
@@ -1692,24 +1809,136 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(MB_WAVES_PER
                 idct4_quad(v, lane);
 #pragma unroll
                 for (int t = 0; t < 4; t++) v[t] += p[t];
-                *(uint32_t *)(rec + (size_t)zy * k.rs + zx) = pack4_clip(v);
+                {
+                    const uint32_t rz = pack4_clip(v);
+                    if (commit) *(uint32_t *)(rec + (size_t)zy * k.rs + zx) = rz;
+                    if constexpr (RD) { ssd_y = ssd4_u8(cz, rz); en_satd = satd4_half(rz, 0u, lane); en_sad = (int)__builtin_amdgcn_sad_u8(rz, 0u, 0u); }
+                }
                 nnz = acn | (nzdc ? 1u << 24 : 0);
                 cbp_luma = acn ? 15 : 0;
             }
-            if (lane >= 16 && lane < 24) lv[408 + lane - 16] = 0;
+            if (lane >= 16 && lane < 24) lvw[408 + lane - 16] = 0;
             // chroma: prediction of the mode chosen above, residual
             {
                 const int pl = (lane >> 4) & 1, ci = (lane >> 2) & 3, cx0 = (ci & 1) * 4, cyy = (ci >> 1) * 4 + j4;
                 const PredC pc = predc_setup(L.cnb[pl]);
                 const uint2 fe = *(const uint2 *)(L.csrc + cyy * 16 + 2 * cx0);
                 const uint32_t cenc = nv12_pick(fe.x, fe.y, pl), cpred = predc_row4(L.cnb[pl], pc, predc, ci, j4);
-                if (lane == 0) recd.chroma_mode = (uint8_t)(predc > PREDC_P ? PREDC_DC : predc);
-                const uint32_t crec = mb_chroma_residual(cenc, cpred, q_ci, false, false, lane, lv, nnz, cbp_chroma);
-                mb_store_chroma(ruv, k.rs, lane, crec);
+                if (commit && lane == 0) recd.chroma_mode = (uint8_t)(predc > PREDC_P ? PREDC_DC : predc);
+                const uint32_t crec = mb_chroma_residual(cenc, cpred, q_ci, false, false, lane, lvw, nnz, cbp_chroma);
+                if (commit) mb_store_chroma(ruv, k.rs, lane, crec);
+                if constexpr (RD) { if (lane < 32) ssd_c = ssd4_u8(cenc, crec); }
             }
-            intra_count++;
+            if (commit) intra_count++;
             pf.mark(PH_ENC_INTRA);
         }
+        if constexpr (RD) {
+            // ---- bits of the macroblock layer as CAVLC would write them (x264_macroblock_size_cavlc), and the blocks' total_coeff ----
+            int mb_bits = 0, my_tc = 0;
+            lds_sync();
+            if (rd_run || (rdon && commit)) {
+                const bool i16 = e_type == X264GPU_MB_I16x16, intra = e_type < X264GPU_MB_P_L0;
+                // residual: one lane per block — 0..15 luma (block order), 16..23 chroma AC (plane * 4 + block), 24 luma DC, 25 / 26 chroma DC
+                const int16_t *myl = rd_lvs;
+                int myn = 0;
+                bool coded = false;
+                if (lane < 16) { coded = (cbp_luma >> (lane >> 2)) & 1; myl = rd_lvs + lane * 16 + (i16 ? 1 : 0); myn = i16 ? 15 : 16; }
+                else if (lane < 24) { coded = cbp_chroma == 2; myl = rd_lvs + X264GPU_LV_CHROMA_AC + (lane - 16) * 16 + 1; myn = 15; }
+                else if (lane == 24) { coded = i16; myl = rd_lvs + X264GPU_LV_LUMA_DC; myn = 16; }
+                else if (lane < 27) { coded = cbp_chroma != 0; myl = rd_lvs + X264GPU_LV_CHROMA_DC + (lane - 25) * 4; myn = 4; }
+                if (rec_type == X264GPU_MB_P_SKIP) coded = false;
+                if (coded && lane < 24) for (int i = 0; i < myn; i++) my_tc += myl[i] != 0;
+                // nC: average of the left and upper blocks' totals where they exist (inside the macroblock: other lanes; outside: rd_ntc)
+                int na = -1, nb = -1;
+                {
+                    const bool chroma = lane >= 16 && lane < 24;
+                    const int b = lane == 24 ? 0 : lane & 15, ci = (lane - 16) & 3, cb = 16 + ((lane - 16) & 4);
+                    const int bx = chroma ? ci & 1 : z_bx(b), by = chroma ? ci >> 1 : z_by(b);
+                    const int l_in = chroma ? cb + by * 2 : blkidx_of(bx - 1, by), t_in = chroma ? cb + bx : blkidx_of(bx, by - 1);
+                    const int l_out = chroma ? cb + by * 2 + 1 : blkidx_of(3, by), t_out = chroma ? cb + 2 + bx : blkidx_of(bx, 3);
+                    const int tl = __shfl(my_tc, bx > 0 ? l_in : 0), tt = __shfl(my_tc, by > 0 ? t_in : 0);
+                    if (lane < 25) {
+                        if (bx > 0 && lane != 24) na = tl; else if (left) na = rd_ntc[0][l_out];
+                        if (by > 0 && lane != 24) nb = tt; else if (top) nb = rd_ntc[1][t_out];
+                    }
+                }
+                const int nC = lane >= 25 ? -1 : (na >= 0 && nb >= 0 ? (na + nb + 1) >> 1 : na >= 0 ? na : nb >= 0 ? nb : 0);
+                if (rd_run && !commit && rec_type != X264GPU_MB_P_SKIP) {
+                    mb_bits = wave_sum(coded ? cavlc_block_bits(myl, myn, nC) : 0);
+                    // header
+                    if (!intra) {
+                        const int np = e_part == D_16x16 ? 1 : e_part == D_8x8 ? 4 : 2;
+                        mb_bits += bs_size_ue_d(e_part) + (e_part == D_8x8 ? 4 : 0);
+                        const int sc0 = S.cref, sc1 = S.cmvx, sc2 = S.cmvy;
+                        if (lane == 5 || lane == 6 || lane == 9 || lane == 10) S.cref = -2;
+                        for (int kp = 0; kp < np; kp++) {
+                            const int x8 = e_part == D_8x16 ? kp : e_part == D_8x8 ? kp & 1 : 0, y8 = e_part == D_16x8 ? kp : e_part == D_8x8 ? kp >> 1 : 0;
+                            const int w8 = e_part == D_16x16 || e_part == D_16x8 ? 2 : 1, h8 = e_part == D_16x16 || e_part == D_8x16 ? 2 : 1;
+                            const int slot = e_part == D_16x16 ? ME_16 : e_part == D_16x8 ? ME_16x8 + kp : e_part == D_8x16 ? ME_8x16 + kp : ME_8 + kp;
+                            const int r = rl(S.ref, slot), vx = rl(S.mvx, slot), vy = rl(S.mvy, slot);
+                            if (c.nref > 1) mb_bits += c.nref == 2 ? 1 : bs_size_ue_d(r);
+                            const int g0 = (y8 + 1) * 4 + x8 + 1;
+                            const bool mine = lane == g0 || (w8 == 2 && lane == g0 + 1) || (h8 == 2 && lane == g0 + 4) || (w8 == 2 && h8 == 2 && lane == g0 + 5);
+                            S.cref = mine ? r : S.cref;                       // the partition's reference is cached before its vector is predicted
+                            int px, py;
+                            mb_predict_mv(S, e_part, x8, y8, w8, r, px, py);
+                            mb_bits += bs_size_se_d(vx - px) + bs_size_se_d(vy - py);
+                            S.cmvx = mine ? vx : S.cmvx; S.cmvy = mine ? vy : S.cmvy;
+                        }
+                        S.cref = sc0; S.cmvx = sc1; S.cmvy = sc2;
+                        mb_bits += cavlc_cbp_bits(cbp_luma | (cbp_chroma << 4), true);
+                        if (k.dct8x8 && cbp_luma) mb_bits += 1;
+                    } else {
+                        const int off = pslice ? 5 : 0;
+                        if (i16) { const int m16 = IR.pred16 > PRED16_P ? PRED16_DC : IR.pred16; mb_bits += bs_size_ue_d(off + 1 + m16 + 4 * cbp_chroma + (cbp_luma ? 12 : 0)); }
+                        else {
+                            mb_bits += bs_size_ue_d(off) + (k.dct8x8 ? 1 : 0);
+                            int fb = 0;
+                            if (e_type == X264GPU_MB_I4x4) { if (lane < 16) fb = i4_pred_mode(L.nmodes, c.mbx, c.sy, lane, L.modes4) == L.modes4[lane] ? 1 : 4; }
+                            else if (lane < 4) fb = i4_pred_mode(L.nmodes, c.mbx, c.sy, lane * 4, L.modes8) == L.modes8[lane * 4] ? 1 : 4;
+                            mb_bits += wave_sum(fb);
+                            mb_bits += cavlc_cbp_bits(cbp_luma | (cbp_chroma << 4), false);
+                        }
+                        mb_bits += bs_size_ue_d(predc > PREDC_P ? PREDC_DC : predc);
+                    }
+                    if (cbp_luma || cbp_chroma || i16) mb_bits += bs_size_se_d(c.qp - last_qp);
+                }
+            }
+            if (rd_run && !commit) {
+                // ---- x264_rd_cost_mb: SSD of luma (+ the psy-rd energy term) and chroma (scaled by the chroma lambda offset) + lambda2 x bits ----
+                int dist = wave_sum(ssd_y);
+                if (k.psy_rd_q8) {
+                    const int en = wave_sum(en_satd) - (wave_sum(en_sad) >> 1);
+                    dist += (abs(en - fenc_energy) * k.psy_rd_q8 * c.lambda + 128) >> 8;
+                }
+                dist += (int)(((long long)wave_sum(ssd_c) * chroma_l2off + 128) >> 8);
+                const int cost = rec_type == X264GPU_MB_P_SKIP ? dist + ((lambda2 + 128) >> 8) : dist + (int)(((long long)mb_bits * lambda2 + 128) >> 8);
+                if (rd_ph == 0) {
+                    rd16 = cost;
+                    if (rec_type == X264GPU_MB_P_SKIP) {          // the 16x16 result is the skip vector and nothing would be coded: P_SKIP, analysis over
+                        rd_best = cost; rd_part = D_16x16; rd_t8 = 0; rd_i16 = rd_i4 = rd_i8 = MB_COST_MAX; rd_ph = 8 - 1; rd_skip16 = true;
+                    }
+                } else if (rd_ph == 1) rd16x8 = cost;
+                else if (rd_ph == 2) rd8x16 = cost;
+                else if (rd_ph == 3) rd8x8 = cost;
+                else if (rd_ph == 4) { if (rd_best >= cost) { if (rd_best > 0) rd_satd_inter = (int)((long long)rd_satd_inter * cost / rd_best); rd_best = cost; rd_t8 = 1; } }
+                else if (rd_ph == 5) rd_i16 = cost;
+                else if (rd_ph == 6) rd_i4 = cost;
+                else if (rd_ph == 7) rd_i8 = cost;
+                rd_ph++;
+                continue;
+            }
+            // the final macroblock: its levels go out, its blocks' totals stay for the neighbours' nC
+            for (int i = lane; i < X264GPU_MB_LEVELS / 2; i += 64) ((uint32_t *)lv)[i] = ((const uint32_t *)rd_lvs)[i];
+            if (rdon && lane < 24) k.tc[((size_t)s * k.nmb + mbi) * 24 + lane] = (uint8_t)my_tc;
+        }
+        {   // h->mb.i_last_qp: a macroblock that sends mb_qp_delta sets it (an I16x16 with nothing coded never raises it)
+            const bool i16e = rec_type == X264GPU_MB_I16x16;
+            if (rec_type != X264GPU_MB_P_SKIP && (cbp_luma || cbp_chroma || i16e) && !(i16e && !cbp_luma && !cbp_chroma && !((nnz >> 24) & 1) && c.qp > last_qp)) last_qp = c.qp;
+        }
+        break;
+        }
+        // (rec_type / nnz / cbp of the final pass are needed below: they live outside the loop)
         if (lane == 0) { recd.nnz = nnz; recd.cbp_luma = (uint8_t)cbp_luma; recd.cbp_chroma = (uint8_t)cbp_chroma; recd.type = (uint8_t)rec_type; mbtype_cur[mbi] = (uint8_t)rec_type; }
         lds_sync();
         if (lane < 16) ((uint32_t *)(mbs + mbi))[lane] = ((const uint32_t *)&L.rec)[lane];

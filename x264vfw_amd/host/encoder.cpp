@@ -222,9 +222,21 @@ x264_t *x264_encoder_open(x264_param_t *param)
     p.i_scenecut_threshold = clampi(p.i_scenecut_threshold, 0, 100);
     if (p.analyse.i_me_method > X264_ME_ESA) { xlog(&p, X264_LOG_WARNING, "me tesa is not implemented in the MI355X path yet: me esa\n"); p.analyse.i_me_method = X264_ME_ESA; }
     p.analyse.i_me_range = clampi(p.analyse.i_me_range, 4, p.analyse.i_me_method == X264_ME_UMH ? 64 : 16);     // x264 caps dia/hex at 16; esa: the LDS search window
-    // subme >= 6 means RD mode decision in x264 (i_mbrd >= 1): not implemented, so the highest level whose behaviour IS implemented is reported back
-    if (p.analyse.i_subpel_refine > 5) { xlog(&p, X264_LOG_WARNING, "subme %d needs RD mode decision, which is not implemented yet: subme 5\n", p.analyse.i_subpel_refine); p.analyse.i_subpel_refine = 5; }
-    p.analyse.i_subpel_refine = clampi(p.analyse.i_subpel_refine, 0, 5);
+    // subme 6 / 7 = RD mode decision in P and I slices (x264's i_mbrd 1): on the device with CAVLC bit counts, so in --no-cabac sessions only
+    // (CABAC RD needs the context states at every macroblock); 8+ adds RD refinement of vectors and intra modes (i_mbrd 2, 3), not implemented.
+    // The highest level whose behaviour IS implemented is reported back
+    if (p.analyse.i_subpel_refine > 5 && p.b_cabac) { xlog(&p, X264_LOG_WARNING, "subme %d needs RD mode decision, implemented for --no-cabac sessions only: subme 5\n", p.analyse.i_subpel_refine); p.analyse.i_subpel_refine = 5; }
+    if (p.analyse.i_subpel_refine > 7) { xlog(&p, X264_LOG_WARNING, "subme %d needs RD refinement, which is not implemented yet: subme 7\n", p.analyse.i_subpel_refine); p.analyse.i_subpel_refine = 7; }
+    p.analyse.i_subpel_refine = clampi(p.analyse.i_subpel_refine, 0, 7);
+    p.analyse.b_psy = p.analyse.b_psy != 0;
+    if (!p.analyse.b_psy) { p.analyse.f_psy_rd = 0; p.analyse.f_psy_trellis = 0; }       // x264 validate_parameters
+    p.analyse.f_psy_rd = p.analyse.f_psy_rd < 0 ? 0 : p.analyse.f_psy_rd > 10 ? 10 : p.analyse.f_psy_rd;
+    const int psy_rd_q8 = p.analyse.i_subpel_refine >= 6 ? (int)(p.analyse.f_psy_rd * 256.0f + 0.5f) : 0;      // h->mb.i_psy_rd
+    // psy RD raises luma quality at chroma's cost, so x264 lowers the chroma quantiser offset to compensate (encoder.c, validate / mb init)
+    int eff_chroma_qp_offset = p.analyse.i_chroma_qp_offset;
+    if (psy_rd_q8) eff_chroma_qp_offset -= p.analyse.f_psy_rd < 0.25f ? 1 : 2;
+    eff_chroma_qp_offset = clampi(eff_chroma_qp_offset, -12, 12);
+    p.analyse.i_chroma_qp_offset = eff_chroma_qp_offset;          // x264 changes the parameter in place too: the PPS carries it
     p.analyse.b_fast_pskip = p.analyse.b_fast_pskip != 0;
     p.analyse.b_chroma_me = p.analyse.b_chroma_me != 0;
     if (p.b_interlaced) { xlog(&p, X264_LOG_WARNING, "interlaced coding is not implemented in the MI355X path: progressive\n"); p.b_interlaced = 0; }
@@ -295,7 +307,8 @@ x264_t *x264_encoder_open(x264_param_t *param)
     cfg.width = p.i_width; cfg.height = p.i_height; cfg.streams = h->G; cfg.refs = p.i_frame_reference; cfg.slices = h->slices; cfg.cabac = p.b_cabac;
     cfg.qp_i = h->qp_i; cfg.qp_p = h->qp_p; cfg.me_range = p.analyse.i_me_range; cfg.subme = p.analyse.i_subpel_refine;
     cfg.deblock = p.b_deblocking_filter; cfg.deblock_alpha = p.i_deblocking_filter_alphac0; cfg.deblock_beta = p.i_deblocking_filter_beta;
-    cfg.chroma_qp_offset = p.analyse.i_chroma_qp_offset;
+    cfg.chroma_qp_offset = eff_chroma_qp_offset;
+    cfg.rd = p.analyse.i_subpel_refine >= 6; cfg.psy = psy_rd_q8 != 0; cfg.psy_rd_q8 = psy_rd_q8;
     cfg.deadzone_inter = p.analyse.i_luma_deadzone[0]; cfg.deadzone_intra = p.analyse.i_luma_deadzone[1];
     cfg.dct_decimate = p.analyse.b_dct_decimate;
     // P slices follow analyse.inter, I slices analyse.intra (bit8 marks the separate I-slice set)
