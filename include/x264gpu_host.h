@@ -33,6 +33,8 @@ int x264host_write_slice_cabac(int mbw, int mbh, int slice_type, int qp, int pic
                                const x264gpu_mb *mbs, const int16_t *levels, uint8_t *out, int cap, int *skipped);
 int x264host_write_headers_cabac(int width, int height, int level_idc, int log2_max_frame_num, int pic_init_qp, int chroma_qp_offset,
                                  uint32_t num_units_in_tick, uint32_t time_scale, int num_ref, int transform8x8_mode, int cabac, uint8_t *out, int cap);
+/* (pStateIdx << 1) | valMPS of the 460 context variables after the last CABAC slice the calling thread wrote */
+void x264host_cabac_last_states(uint8_t *out460);
 /* the file muxers (`--output x.h264 | x.mkv | x.flv`, host/muxers.cpp; reference output/raw.c, matroska.c, flv.c) without an encoder */
 void *x264host_mux_open(const char *filename, const char *muxer /* "auto", "raw", "mkv", "flv" */, int *annexb);
 int x264host_mux_set_param(void *h, int width, int height, uint32_t fps_num, uint32_t fps_den, uint32_t timebase_num, uint32_t timebase_den,

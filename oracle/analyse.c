@@ -1368,6 +1368,14 @@ static int rd_ssd_mb(const actx *a)
     return ssd + (int)(((int64_t)cssd * a->chroma_lambda2_offset + 128) >> 8);
 }
 
+static void cabac_ctx_of(const actx *a, x264o_cabac_ctx *cc, uint8_t *state)
+{
+    x264o_encoder *e = a->e;
+    cc->mbs = e->mbs; cc->levels = e->levels; cc->mbw = e->mbw; cc->mbh = e->mbh; cc->first_row = e->row0;
+    cc->pslice = e->slice_type == X264GPU_SLICE_P; cc->num_ref = e->nref; cc->t8mode = e->cfg.dct8x8;
+    cc->amvd = e->amvd; cc->state = state; cc->last_dqp = e->last_dqp; cc->last_qp = e->last_qp;
+}
+
 static void rd_reset(const actx *a, x264gpu_mb *mb, int16_t *lv)
 {
     memset(mb, 0, sizeof(*mb));
@@ -1379,6 +1387,14 @@ static int rd_finish(actx *a, x264gpu_mb *mb, int16_t *lv)
 {
     const int ssd = rd_ssd_mb(a);
     if (mb->type == X264GPU_MB_P_SKIP) return ssd + ((a->lambda2 + 128) >> 8);
+    if (a->e->cfg.cabac) {
+        /* x264_rd_cost_mb under CABAC: the macroblock's syntax priced on a copy of the slice's context states, 1/256 bit units */
+        uint8_t st[460];
+        x264o_cabac_ctx cc;
+        memcpy(st, a->e->cabac_state, sizeof(st));
+        cabac_ctx_of(a, &cc, st);
+        return ssd + (int)(((uint64_t)x264o_cabac_mb(&cc, a->mbx, a->mby, 1) * (uint64_t)a->lambda2 + 32768) >> 16);
+    }
     return ssd + (int)(((int64_t)mb_bits_cavlc(a, mb, lv) * a->lambda2 + 128) >> 8);
 }
 
@@ -1590,7 +1606,20 @@ void x264o_macroblock(x264o_encoder *e, int mbx, int mby)
     macroblock_body(e, mbx, mby, &A);
     const x264gpu_mb *mb = &e->mbs[mby * e->mbw + mbx];
     /* diagnostics for the tests: what mb_bits_cavlc says the macroblock layer of the final macroblock takes (0 for P_SKIP: it lives in a run) */
-    if (e->mb_bits) e->mb_bits[A.mi] = mb->type == X264GPU_MB_P_SKIP ? 0 : mb_bits_cavlc(&A, mb, e->levels + (size_t)A.mi * X264GPU_MB_LEVELS);
+    if (e->mb_bits && !e->cfg.cabac) e->mb_bits[A.mi] = mb->type == X264GPU_MB_P_SKIP ? 0 : mb_bits_cavlc(&A, mb, e->levels + (size_t)A.mi * X264GPU_MB_LEVELS);
+    /* CABAC RD sessions: the finished macroblock moves the slice's context states on, as its entropy coding will */
+    if (e->cfg.cabac && e->cfg.rd) {
+        x264o_cabac_ctx cc;
+        if (e->mb_bits && mb->type != X264GPU_MB_P_SKIP) {          /* diagnostics: the size estimate of the final macroblock, 1/256 bits */
+            uint8_t st[460];
+            memcpy(st, e->cabac_state, sizeof(st));
+            cabac_ctx_of(&A, &cc, st);
+            e->mb_bits[A.mi] = (int)x264o_cabac_mb(&cc, mbx, mby, 1);
+        }
+        cabac_ctx_of(&A, &cc, e->cabac_state);
+        x264o_cabac_mb(&cc, mbx, mby, 0);
+        e->last_dqp = cc.last_dqp;
+    }
     /* h->mb.i_last_qp for the mb_qp_delta bits of the RD costs: macroblocks that send a delta set it */
     if (mb->type != X264GPU_MB_P_SKIP && (mb->cbp_luma || mb->cbp_chroma || mb->type == X264GPU_MB_I16x16)) {
         if (!(mb->type == X264GPU_MB_I16x16 && !mb->cbp_luma && !mb->cbp_chroma && !((mb->nnz >> 24) & 1) && mb->qp > e->last_qp)) e->last_qp = mb->qp;

@@ -48,6 +48,7 @@ x264o_encoder *x264o_encoder_create(const x264gpu_config *cfg)
     }
     for (int r = 1; r < X264O_MAX_REFS; r++) e->mvr[r] = calloc(n, sizeof(int16_t[2]));
     e->mbqp = malloc(n);
+    e->amvd = calloc((size_t)n, 8);
     x264o_quant_init(&e->qt, cfg->deadzone_inter, cfg->deadzone_intra);
     return e;
 }
@@ -58,7 +59,7 @@ void x264o_encoder_destroy(x264o_encoder *e)
     for (int s = 0; s < e->slots; s++) { free(e->luma[s]); free(e->chroma[s]); free(e->mv16[s]); free(e->mbtype[s]); }
     for (int r = 1; r < X264O_MAX_REFS; r++) free(e->mvr[r]);
     for (int q = 0; q < 52; q++) free(e->cost_mv[q]);
-    free(e->fenc_y); free(e->fenc_uv); free(e->mbqp); free(e);
+    free(e->fenc_y); free(e->fenc_uv); free(e->mbqp); free(e->amvd); free(e);
 }
 
 int x264o_encoder_mb_count(const x264o_encoder *e) { return e->mbw * e->mbh; }
@@ -70,6 +71,8 @@ void x264o_encoder_set_mb_qp_offsets(x264o_encoder *e, const int16_t *off_q8) { 
 void x264o_encoder_set_lowres_mvs(x264o_encoder *e, const int16_t *mv) { e->lowres_mv = mv; }
 /* tests: where to leave the predicted CAVLC bit count of every macroblock of the next pictures (NULL: off) */
 void x264o_encoder_set_mb_bits_out(x264o_encoder *e, int *bits) { e->mb_bits = bits; }
+/* tests: the CABAC context states (pStateIdx << 1 | valMPS) after the last slice coded — RD sessions with cabac only */
+void x264o_encoder_cabac_states(const x264o_encoder *e, uint8_t *out) { memcpy(out, e->cabac_state, 460); }
 
 const uint16_t *x264o_cost_mv_for(x264o_encoder *e, int qp)
 {
@@ -253,6 +256,7 @@ int x264o_encoder_encode(x264o_encoder *e, const uint8_t *i420, int slice_type, 
         /* x264 slice threads: rows split evenly; each thread starts with empty frame statistics (h->stat.frame) */
         e->row0 = (e->mbh * sl + ns / 2) / ns; e->row1 = (e->mbh * (sl + 1) + ns / 2) / ns;
         e->intra_count = 0; e->last_qp = slice_qp;
+        if (e->cfg.cabac && e->cfg.rd) { x264o_cabac_init_states(e->cabac_state, slice_type == X264GPU_SLICE_P, slice_qp); e->last_dqp = 0; }
         for (int mby = e->row0; mby < e->row1; mby++)
             for (int mbx = 0; mbx < e->mbw; mbx++) {
                 x264o_macroblock(e, mbx, mby);

@@ -49,7 +49,26 @@ struct x264o_encoder {
     int *mb_bits;                /* optional (tests): per macroblock, the CAVLC bit count the RD code predicts for the final macroblock */
     int last_qp;                 /* QP_Y of the previous macroblock in coding order as the entropy coder sees it (h->mb.i_last_qp): mb_qp_delta bits of the RD costs */
     int intra_count;             /* intra macroblocks coded so far in this slice (h->stat.frame.i_mb_count[I_*]) */
+    /* CABAC sessions with RD: the slice's context states as the entropy coding of the finished macroblocks leaves them (h->cabac), the
+     * previous macroblock's mb_qp_delta and every 8x8 block's |mvd| (cabac_rd.cpp) */
+    uint8_t cabac_state[460];
+    int last_dqp;
+    uint8_t *amvd;
 };
+
+/* cabac_rd.cpp */
+typedef struct x264o_cabac_ctx {
+    const x264gpu_mb *mbs;
+    const int16_t *levels;
+    int mbw, mbh, first_row;
+    int pslice, num_ref, t8mode;
+    uint8_t *amvd;
+    uint8_t *state;
+    int last_dqp, last_qp;
+} x264o_cabac_ctx;
+void x264o_cabac_init_states(uint8_t *state, int pslice, int qp);
+long x264o_cabac_mb(x264o_cabac_ctx *c, int mbx, int mby, int size_mode);
+const uint16_t *x264o_cabac_entropy(void);
 
 static inline int clampi(int v, int lo, int hi) { return v < lo ? lo : v > hi ? hi : v; }
 static inline int median3(int a, int b, int c) { int mn = a < b ? a : b, mx = a < b ? b : a; return c < mn ? mn : c > mx ? mx : c; }

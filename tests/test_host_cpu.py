@@ -344,3 +344,42 @@ def test_rd_bit_counts_equal_the_bits_the_decoder_consumes(w, h, kw):
     O.L.x264o_h264_last_mb_bits.restype = C.c_int
     assert O.L.x264o_h264_last_mb_bits(got.ctypes.data_as(C.c_void_p), got.size) == got.size
     np.testing.assert_array_equal(got.reshape(nfr, -1), np.stack(want))
+
+
+@pytest.mark.parametrize("w,h,kw", [(176, 144, dict(partitions=7, dct8x8=1, refs=3, mixed_refs=1, chroma_me=1, psy=1, psy_rd_q8=256, chroma_qp_offset=-2)),
+                                     (96, 80, dict(partitions=3, refs=2, qp_i=14, qp_p=16)), (96, 208, dict(slices=1, partitions=7, dct8x8=1, aq_mode=1, qp_i=30, qp_p=33)),
+                                     (64, 48, dict(partitions=0, qp_i=40, qp_p=44))])
+def test_cabac_rd_states_and_sizes_follow_the_real_coder(w, h, kw):
+    """CABAC RD (x264 subme 6 / 7 with cabac): (1) the context states the oracle's macroblock loop carries (cabac_rd.cpp "evolve": the
+    finished macroblocks' bins, states only) equal, after every picture, the states the product's arithmetic coder ends the slice with — the
+    states a decoder holds, which the checker decoder proves by decoding that slice; (2) the size estimates (entropy table, 1/256 bit)
+    summed over a picture stay within a few percent of the bytes the arithmetic coder really wrote"""
+    import ctypes as C
+    nfr = 4
+    frames = synth_frames(w, h, nfr, seed=3 * w + h)
+    cfg = O.default_config(w, h, cabac=1, rd=1, subme=7, **kw)
+    enc = O.OracleEncoder(cfg)
+    mbw, mbh = (w + 15) // 16, (h + 15) // 16
+    est = np.zeros(mbw * mbh, np.int32)
+    O.L.x264o_encoder_set_mb_bits_out.argtypes = [C.c_void_p, C.c_void_p]
+    O.L.x264o_encoder_set_mb_bits_out(enc.h, est.ctypes.data)
+    O.L.x264o_encoder_cabac_states.argtypes = [C.c_void_p, C.c_void_p]
+    stream = HL.write_headers(w, h, pic_init_qp=cfg.qp_p, num_ref=cfg.refs, t8x8=cfg.dct8x8, cabac=1, cqo=cfg.chroma_qp_offset)
+    total_est = total_real = 0
+    for i, f in enumerate(frames):
+        idr = i == 0
+        est[:] = 0
+        mbs, lv = enc.encode(f, 2 if idr else 0)
+        nal = HL.write_slice(mbw, mbh, 2 if idr else 0, cfg.qp_i if idr else cfg.qp_p, cfg.qp_p, i, 8, int(idr), 0, 0, mbs, lv,
+                             num_ref=max(1, min(cfg.refs, i)), num_ref_default=cfg.refs, t8x8=cfg.dct8x8, cabac=1)[0]
+        stream += nal
+        got, want = np.zeros(460, np.uint8), np.zeros(460, np.uint8)
+        O.L.x264o_encoder_cabac_states(enc.h, got.ctypes.data)
+        HL.H.x264host_cabac_last_states(want.ctypes.data_as(C.c_void_p))
+        # the contexts the slice type uses (the product seeds every table row, the checker only these)
+        used = list(range(3, 11)) + list(range(60, 70)) + list(range(73, 276)) + list(range(399, 436)) + ([] if idr else list(range(11, 24)) + list(range(40, 60)))
+        np.testing.assert_array_equal(got[used], want[used], err_msg=f"context states after picture {i}")
+        total_est += int(est.sum()) / 256.0
+        total_real += 8 * len(nal)
+    assert len(O.h264_decode(stream, nfr, w, h)) == nfr
+    assert abs(total_est - total_real) < 0.06 * total_real + 64 * nfr, (total_est, total_real)

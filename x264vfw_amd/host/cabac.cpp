@@ -425,7 +425,13 @@ struct CabacSlice {
     }
 };
 
+thread_local uint8_t g_last_states[460];     // diagnostics: the context variables the last slice written by this thread ended with
+
 }  // namespace
+
+// tests: (pStateIdx << 1) | valMPS of every context after the last CABAC slice this thread wrote — what a decoder holds at that point, and
+// what the device's RD bit counter must have arrived at (x264 prices candidates on the states the finished macroblocks left behind)
+extern "C" void x264host_cabac_last_states(uint8_t *out) { memcpy(out, g_last_states, sizeof(g_last_states)); }
 
 void write_slice_cabac(std::vector<uint8_t> &out, const SliceParams &p, const x264gpu_mb *mbs, const int16_t *levels,
                        bool annexb, bool long_startcode, SliceStats *stats)
@@ -442,6 +448,7 @@ void write_slice_cabac(std::vector<uint8_t> &out, const SliceParams &p, const x2
         cb.terminate(i == i1 - 1);                          // end_of_slice_flag
     }
     if (stats) stats->skip = s.nskip;
+    for (int i = 0; i < 460; i++) g_last_states[i] = (uint8_t)((cb.state[i] << 1) | cb.mps[i]);
     bw.align_zero();                                        // the flush wrote the stop bit: pad the last byte with zeros
     append_nal(out, p.nal_ref_idc, p.idr ? 5 : 1, bw.bytes(), annexb, long_startcode);
 }
