@@ -237,6 +237,9 @@ int  x264gpu_encoder_set_stream_qps(x264gpu_encoder *enc, const int8_t *qps);
  * 16x16 search in reference 0; x264_mb_predict_mv_ref16x16): device array [streams][mb_count][2] int16 in quarter-pels of the
  * half-resolution planes, first entry 0x7fff = absent for that stream.  NULL (the default) = none. */
 int  x264gpu_encoder_set_lowres_mvs(x264gpu_encoder *enc, const int16_t *d_mvs);
+/* tests: the 460 CABAC context variables ((pStateIdx << 1) | valMPS) the wavefront of (stream, slice) ended the last picture with (RD sessions
+ * with cabac: x264 prices candidates on the states the finished macroblocks left, [x264-upstream] encoder/rdo.c) */
+int  x264gpu_encoder_cabac_states(x264gpu_encoder *enc, int stream, int slice, uint8_t *out460);
 
 /* ------------------------------------------------------------------------------------------------
  * Lookahead frame cost: x264_slicetype_frame_cost of [x264-upstream]

@@ -37,6 +37,12 @@ class GpuEncoder:
         lib.check(lib.x264gpu_encoder_get_recon(self.h, s, out.data_ptr(), None), "get_recon")
         return out.cpu().numpy()
 
+    def cabac_states(self, s=0, sl=0):
+        """the 460 context variables the wavefront of (stream, slice) ended the last picture with (CABAC RD sessions)"""
+        out = np.zeros(460, np.uint8)
+        lib.check(lib.x264gpu_encoder_cabac_states(self.h, s, sl, out.ctypes.data), "cabac_states")
+        return out
+
     def close(self):
         if self.h:
             lib.x264gpu_encoder_destroy(self.h)

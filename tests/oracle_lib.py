@@ -177,6 +177,13 @@ class OracleEncoder:
         assert rc == 0
         return mbs, lv
 
+    def cabac_states(self):
+        """context variables after the last slice coded (CABAC RD sessions)"""
+        out = np.zeros(460, np.uint8)
+        L.x264o_encoder_cabac_states.argtypes = [C.c_void_p, C.c_void_p]
+        L.x264o_encoder_cabac_states(self.h, out.ctypes.data)
+        return out
+
     def set_qp(self, qp_i, qp_p):
         L.x264o_encoder_set_qp(self.h, qp_i, qp_p)
 

@@ -47,6 +47,33 @@ def test_random_configs_bitexact(gpu, seed):
         og.close(); gg.close()
 
 
+@pytest.mark.parametrize("seed", [41, 42, 43])
+def test_random_cabac_rd_configs_bitexact(gpu, seed):
+    """... and with RD in CABAC sessions (context variables carried on the device, size-only pricing); the context variables the last slice
+    ends with are compared too"""
+    from gpu_enc import GpuEncoder
+    from test_gpu_pipeline import CABAC_CTX_I, CABAC_CTX_P
+    rnd = random.Random(seed)
+    for it in range(30):
+        w, h, kw, nfr, fseed, second_idr = random_case(rnd)
+        psy = rnd.randint(0, 1)
+        kw.update(cabac=1, rd=1, subme=rnd.choice([6, 7]), psy=psy, psy_rd_q8=rnd.choice([26, 102, 256, 512]) if psy else 0)
+        frames = synth_frames(w, h, nfr, seed=fseed)
+        cfg = O.default_config(w, h, **kw)
+        og, gg = O.OracleEncoder(cfg), GpuEncoder(cfg)
+        for i, f in enumerate(frames):
+            st = 2 if i == 0 or (i == 3 and second_idr) else 0
+            o_mb, o_lv = og.encode(f, st)
+            g_mb, g_lv = gg.encode([f], st)
+            tag = f"seed {seed} case {it}: {w}x{h} {kw} frame {i}"
+            assert np.array_equal(g_mb[0].view(np.uint8), o_mb.view(np.uint8)), tag + " records"
+            assert np.array_equal(g_lv[0], o_lv), tag + " levels"
+            assert np.array_equal(gg.recon(0), og.recon()), tag + " reconstruction"
+            used = CABAC_CTX_I if st == 2 else CABAC_CTX_P
+            assert np.array_equal(gg.cabac_states(0, kw.get("slices", 1) - 1)[used], og.cabac_states()[used]), tag + " context variables"
+        og.close(); gg.close()
+
+
 @pytest.mark.parametrize("seed", [31, 32, 33])
 def test_random_rd_configs_bitexact(gpu, seed):
     """the same sweep with RD mode decision on (x264 subme 6 / 7 in a CAVLC session: candidates coded and costed as SSD + psy + lambda2 x bits

@@ -118,6 +118,28 @@ def test_rd_session_equals_oracle_pipeline(gpu, opts, subme, cqo):
         np.testing.assert_array_equal(og.recon(), recons[i], err_msg=f"oracle pipeline picture {i}")
 
 
+@pytest.mark.parametrize("opts", [{}, {"no-psy": None, "ref": 1}, {"sliced-threads": None, "threads": 2}])
+def test_medium_session_runs_rd_with_cabac(gpu, opts):
+    """preset medium as the reference's driver opens it (High profile, CABAC): subme 7 stays 7 — RD mode decision with CABAC sizes + psy-RD on
+    the device.  The stream decodes to the encoder's reconstruction and the oracle pipeline (cabac, rd) reconstructs the same samples"""
+    w, h, nfr, qp = 176, 144, 5, 26
+    frames = synth_frames(w, h, nfr, seed=707)
+    h_, eff = open_encoder(w, h, dict({"qp": qp, "keyint": 250}, **opts), b"high")
+    assert (eff.b_cabac, eff.analyse.i_subpel_refine) == (1, 7)
+    stream, info, recons = encode_all(h_, w, h, frames)
+    H.x264_encoder_close(h_)
+    kw = eff_kw(eff)
+    assert kw["rd"] == 1 and kw["cabac"] == 1 and kw["chroma_qp_offset"] == (0 if "no-psy" in opts else -2)
+    qp_i = max(1, int(qp - 6.0 * np.log2(1.4) + 0.5))
+    og = O.OracleEncoder(O.default_config(w, h, qp_i=qp_i, qp_p=qp, partitions=7, dct8x8=1, refs=eff.i_frame_reference, chroma_me=1, mixed_refs=int(eff.i_frame_reference > 1),
+                                          slices=2 if "sliced-threads" in opts else 1, **kw))
+    dec = O.h264_decode(stream, nfr, w, h)
+    for i, f in enumerate(frames):
+        np.testing.assert_array_equal(dec[i], recons[i], err_msg=f"decoded picture {i}")
+        og.encode(f, 2 if i == 0 else 0)
+        np.testing.assert_array_equal(og.recon(), recons[i], err_msg=f"oracle pipeline picture {i}")
+
+
 def test_preset_ultrafast_is_fully_covered(gpu):
     """preset ultrafast (config.c:1460-1466): every tool x264 uses there exists in this path — me dia, subme 0, ref 1,
     no partitions, no 8x8dct, CAVLC, no deblock, no B-frames — so the effective parameters equal the requested ones and the
@@ -152,7 +174,7 @@ def test_bitstream_equals_oracle_path(gpu):
     stream, info, _ = encode_all(h_, w, h, frames)
     H.x264_encoder_close(h_)
     qp_i = max(1, int(qp - 6.0 * np.log2(1.4) + 0.5))
-    enc = O.OracleEncoder(O.default_config(w, h, qp_i=qp_i, qp_p=qp, partitions=7, refs=3, dct8x8=1, chroma_me=1, mixed_refs=1, **eff_kw(eff)))      # medium: p8x8 + i4x4 + i8x8, ref 3, 8x8dct, chroma-me; subme 7 -> 5 under CABAC
+    enc = O.OracleEncoder(O.default_config(w, h, qp_i=qp_i, qp_p=qp, partitions=7, refs=3, dct8x8=1, chroma_me=1, mixed_refs=1, **eff_kw(eff)))      # medium: p8x8 + i4x4 + i8x8, ref 3, 8x8dct, chroma-me; subme 7: RD with CABAC sizes
     ref = b""
     for i, f in enumerate(frames):
         mbs, lv = enc.encode(f, 2 if i == 0 else 0)

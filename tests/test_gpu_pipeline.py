@@ -123,6 +123,41 @@ def test_pipeline_bitexact(gpu, w, h, nfr, kw):
     og.close(); gg.close()
 
 
+CABAC_CTX_I = list(range(3, 11)) + list(range(60, 70)) + list(range(73, 276)) + list(range(399, 436))        # contexts an I slice uses
+CABAC_CTX_P = CABAC_CTX_I + list(range(11, 24)) + list(range(40, 60))
+
+
+@pytest.mark.parametrize("w,h,nfr,kw", [
+    (64, 48, 3, dict(partitions=0, subme=6)),
+    (176, 144, 4, dict(partitions=2, subme=6)),
+    (176, 144, 4, dict(partitions=1, refs=2, subme=6)),
+    (176, 144, 4, dict(partitions=3, refs=3, mixed_refs=1, psy=1, psy_rd_q8=256, chroma_qp_offset=-2, subme=7)),
+    (176, 144, 4, dict(partitions=6, dct8x8=1, subme=7)),
+    (176, 144, 6, dict(partitions=7, dct8x8=1, refs=3, mixed_refs=1, chroma_me=1, psy=1, psy_rd_q8=256, chroma_qp_offset=-2, subme=7)),      # preset medium (I / P)
+    (352, 288, 4, dict(partitions=7, dct8x8=1, refs=3, mixed_refs=1, chroma_me=1, qp_i=30, qp_p=34, me_method=2, subme=7)),
+    (96, 208, 4, dict(slices=3, partitions=7, dct8x8=1, refs=2, psy=1, psy_rd_q8=102, chroma_qp_offset=-1, aq_mode=1, subme=6)),
+    (96, 80, 4, dict(partitions=7, dct8x8=1, qp_i=8, qp_p=10, dct_decimate=0, fast_pskip=0, subme=6)),
+    (208, 120, 4, dict(partitions=7, dct8x8=1, qp_i=44, qp_p=47, psy=1, psy_rd_q8=512, me_method=3, me_range=8, subme=6)),
+])
+def test_pipeline_cabac_rd_bitexact(gpu, w, h, nfr, kw):
+    """RD mode decision in a CABAC session (x264 subme 6 / 7 at preset medium's entropy coder): the device carries the slice's context
+    variables through the macroblock loop and prices every candidate with x264's size-only coder on a copy of them.  Records, levels and
+    reconstruction equal the oracle's, and so do the context variables the last slice ends every picture with"""
+    from gpu_enc import GpuEncoder
+    frames = synth_frames(w, h, nfr, seed=w * 5 + h)
+    cfg = O.default_config(w, h, cabac=1, rd=1, **kw)
+    og, gg = O.OracleEncoder(cfg), GpuEncoder(cfg)
+    ns = kw.get("slices", 1)
+    for i, f in enumerate(frames):
+        st = 2 if i == 0 else 0
+        o_mb, o_lv = og.encode(f, st)
+        g_mb, g_lv = gg.encode([f], st)
+        compare(f"{w}x{h} {kw} frame {i}", (w + 15) // 16, g_mb[0], o_mb, g_lv[0], o_lv, gg.recon(0), og.recon())
+        used = CABAC_CTX_I if st == 2 else CABAC_CTX_P
+        np.testing.assert_array_equal(gg.cabac_states(0, ns - 1)[used], og.cabac_states()[used], err_msg=f"context variables after picture {i}")
+    og.close(); gg.close()
+
+
 def test_pipeline_multistream(gpu):
     """streams are independent: a 3-stream lock-step batch equals three single-stream oracle encodes"""
     from gpu_enc import GpuEncoder

@@ -53,6 +53,16 @@ CASES = [
     (352, 288, 4, dict(rd=1, subme=7, partitions=7, dct8x8=1, refs=3, mixed_refs=1, chroma_me=1, qp_i=30, qp_p=34, me_method=2)),
     (96, 208, 4, dict(rd=1, subme=6, slices=3, partitions=7, dct8x8=1, refs=2, psy=1, psy_rd_q8=102, chroma_qp_offset=-1, aq_mode=1)),
     (96, 80, 4, dict(rd=1, subme=6, partitions=7, dct8x8=1, qp_i=8, qp_p=10, dct_decimate=0, fast_pskip=0)),
+    # ... with CABAC: context states carried through the macroblock loop, candidates priced by the size-only coder
+    (64, 48, 3, dict(cabac=1, rd=1, subme=6, partitions=0)),
+    (176, 144, 4, dict(cabac=1, rd=1, subme=6, partitions=2)),
+    (176, 144, 4, dict(cabac=1, rd=1, subme=6, partitions=1, refs=2)),
+    (176, 144, 4, dict(cabac=1, rd=1, subme=7, partitions=3, refs=3, mixed_refs=1, psy=1, psy_rd_q8=256, chroma_qp_offset=-2)),
+    (176, 144, 4, dict(cabac=1, rd=1, subme=7, partitions=6, dct8x8=1)),
+    (176, 144, 5, dict(cabac=1, rd=1, subme=7, partitions=7, dct8x8=1, refs=3, mixed_refs=1, chroma_me=1, psy=1, psy_rd_q8=256, chroma_qp_offset=-2)),
+    (352, 288, 4, dict(cabac=1, rd=1, subme=7, partitions=7, dct8x8=1, refs=3, mixed_refs=1, chroma_me=1, qp_i=30, qp_p=34, me_method=2)),
+    (96, 208, 4, dict(cabac=1, rd=1, subme=6, slices=3, partitions=7, dct8x8=1, refs=2, psy=1, psy_rd_q8=102, chroma_qp_offset=-1, aq_mode=1)),
+    (96, 80, 4, dict(cabac=1, rd=1, subme=6, partitions=7, dct8x8=1, qp_i=8, qp_p=10, dct_decimate=0, fast_pskip=0)),
 ]
 
 

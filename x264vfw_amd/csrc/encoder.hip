@@ -41,6 +41,8 @@ struct x264gpu_encoder {
     int cur = 0;
     unsigned long long *dbg = nullptr;   // diagnostics buffer set by x264gpu_encoder_set_debug
     uint8_t *tc = nullptr;               // RD: total_coeff of every block of the picture being coded
+    uint8_t *amvd = nullptr;             // CABAC RD: |mvd| of every 8x8 block of the picture being coded
+    uint32_t *cab_out = nullptr;         // ... and the context variables every slice's wavefront ended with: [stream][slice][2][64] (tests)
     unsigned long long *prof = nullptr;  // MB_PROF builds: phase counters of the last macroblock-loop launch
     int *wf_progress = nullptr;          // [streams][2][WFG_ROWS] row counters of the multi-workgroup wavefront kernels
     // adaptive quantisation: per-macroblock quantisers and the per-quantiser tables (built when aq_mode != 0)
@@ -98,7 +100,7 @@ int x264gpu_encoder_create(x264gpu_encoder **out, const x264gpu_config *cfg)
     ARG_TRY(out && cfg);
     ARG_TRY(cfg->width >= 16 && cfg->height >= 16 && !(cfg->width & 1) && !(cfg->height & 1) && cfg->streams >= 1);
     ARG_TRY(cfg->qp_i >= 0 && cfg->qp_i <= 51 && cfg->qp_p >= 0 && cfg->qp_p <= 51 && cfg->refs >= 1 && cfg->refs <= 5);
-    ARG_TRY(!cfg->rd || (!cfg->cabac && cfg->subme >= 6 && cfg->subme <= 7 && cfg->psy_rd_q8 >= 0 && cfg->psy_rd_q8 <= 2560));      // RD: CAVLC sessions, x264's i_mbrd 1
+    ARG_TRY(!cfg->rd || (cfg->subme >= 6 && cfg->subme <= 7 && cfg->psy_rd_q8 >= 0 && cfg->psy_rd_q8 <= 2560));      // RD: x264's i_mbrd 1 (bit counts of the session's entropy coder)
     ARG_TRY(cfg->slices >= 0 && (cfg->slices <= 1 || cfg->slices <= (cfg->height + 15) / 16 / 4));      // x264 slice threads: at least four macroblock rows each
     ARG_TRY(cfg->width <= 4096 && cfg->height <= 2304 && cfg->me_range >= 4 && cfg->me_range <= (cfg->me_method == 2 ? 64 : 16));
     ARG_TRY(cfg->me_method >= 0 && cfg->me_method <= 3);
@@ -142,7 +144,8 @@ int x264gpu_encoder_create(x264gpu_encoder **out, const x264gpu_config *cfg)
     }
     for (int r = 1; r < cfg->refs; r++) alloc((void **)&e->mvr[r], S * k.nmb * 2 * sizeof(int16_t), 0);
     alloc((void **)&e->wf_progress, S * 2 * WFG_ROWS * sizeof(int), 0);
-    if (cfg->rd) alloc((void **)&e->tc, S * k.nmb * 24, 0);
+    if (cfg->rd && !cfg->cabac) alloc((void **)&e->tc, S * k.nmb * 24, 0);
+    if (cfg->rd && cfg->cabac) { alloc((void **)&e->amvd, S * k.nmb * 8, 0); alloc((void **)&e->cab_out, S * (cfg->slices > 1 ? cfg->slices : 1) * 128 * sizeof(uint32_t), 0); }
 #ifdef MB_PROF
     alloc((void **)&e->prof, S * 16 * sizeof(unsigned long long), 0);
 #endif
@@ -227,6 +230,8 @@ void x264gpu_encoder_destroy(x264gpu_encoder *e)
     for (int i = 0; i < 5; i++) (void)hipFree(e->mvr[i]);
     (void)hipFree(e->wf_progress);
     (void)hipFree(e->tc);
+    (void)hipFree(e->amvd);
+    (void)hipFree(e->cab_out);
     (void)hipFree(e->prof);
     (void)hipFree(e->stream_qp); (void)hipFree(e->mbqp); (void)hipFree(e->q4tab); (void)hipFree(e->q8tab); (void)hipFree(e->lambda_tab); (void)hipFree(e->cost_all);
     delete e;
@@ -244,6 +249,19 @@ int x264gpu_encoder_mb_prof(x264gpu_encoder *e, unsigned long long *out)
     if (!e->prof) return X264GPU_EINVAL;
     HIP_TRY(hipDeviceSynchronize());
     HIP_TRY(hipMemcpy(out, e->prof, (size_t)e->cfg.streams * 16 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    return X264GPU_OK;
+}
+
+// tests: the CABAC context variables ((pStateIdx << 1) | valMPS, 460 of them) the wavefront of (stream, slice) ended the last picture with —
+// RD sessions with cabac only.  They must equal what the arithmetic coder of the host (and so a decoder) holds at the end of that slice.
+int x264gpu_encoder_cabac_states(x264gpu_encoder *e, int stream, int slice, uint8_t *out460)
+{
+    ARG_TRY(e && out460 && stream >= 0 && stream < e->cfg.streams && slice >= 0 && slice < (e->cfg.slices > 1 ? e->cfg.slices : 1));
+    if (!e->cab_out) return X264GPU_EINVAL;
+    uint32_t w[128];
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpy(w, e->cab_out + ((size_t)stream * (e->cfg.slices > 1 ? e->cfg.slices : 1) + slice) * 128, sizeof(w), hipMemcpyDeviceToHost));
+    for (int c = 0; c < 460; c++) out460[c] = (uint8_t)(w[(c >> 8) * 64 + ((c >> 2) & 63)] >> ((c & 3) * 8));
     return X264GPU_OK;
 }
 
@@ -281,7 +299,7 @@ int x264gpu_encode_frames(x264gpu_encoder *e, const uint8_t *d_i420, int slice_t
         for (int r = 0; r < k.nref; r++) k.tscale[r] = (e->poc - e->slot_poc[slot_of(r)]) * inv;
     }
     e->slot_nref[e->cur] = k.nref; e->slot_poc[e->cur] = e->poc; e->slot_ref0poc[e->cur] = k.nref ? e->slot_poc[s0] : 0;
-    k.prof = e->prof; k.tc = e->tc;
+    k.prof = e->prof; k.tc = e->tc; k.amvd = e->amvd; k.cab_out = e->cab_out;
     k.lowres_mv = e->lowres_mv; k.fast_pskip = e->cfg.fast_pskip; k.mv_range = e->cfg.mv_range;
     k.mb = d_mb; k.levels = d_levels;
     k.qp = qp; k.lambda = lambda_of(qp); k.qpc = chroma_qp_of(qp, e->cfg.chroma_qp_offset);

@@ -1110,7 +1110,12 @@ __device__ __forceinline__ bool mb_probe_pskip(const EncK &k, const MbCtx &c, ui
 #ifndef MB_WAVES_PER_EU
 #define MB_WAVES_PER_EU 2
 #endif
-template <int M, int ME, bool PS, bool RD = false>
+}  // namespace x264gpu
+#include "cabac_rd.cuh"          // needs the motion cache and the intra-mode helpers above
+namespace x264gpu {
+
+// RD: 0 = SATD decisions (subme <= 5); 1 = RD mode decision with CAVLC bit counts (rd.cuh); 2 = with CABAC context states and sizes (cabac_rd.cuh)
+template <int M, int ME, bool PS, int RD = 0>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(MB_WAVES_PER_EU, 4))) void k_mb_slice(EncK k)
 {
     __shared__ __attribute__((aligned(16))) MbLds<M> L;
@@ -1128,8 +1133,13 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(MB_WAVES_PER
     // RD instantiation: levels of the candidate being costed (and of the final macroblock, before they go out), total_coeff of the left / top
     // macroblocks' blocks for the nC of the bit counts; the quantiser the previous coded macroblock left (mb_qp_delta bits)
     __shared__ __attribute__((aligned(16))) int16_t rd_lvs[RD ? X264GPU_MB_LEVELS : 1];
-    __shared__ uint8_t rd_ntc[2][RD ? 24 : 1];
+    __shared__ uint8_t rd_ntc[2][RD == 1 ? 24 : 1];
     int last_qp = slice_qp(k, s);
+    // CABAC RD: the slice's context variables (two registers, see cabac_rd.cuh), the probability model, the previous macroblock's mb_qp_delta
+    Cab cab = { 0, 0, 0 };
+    uint32_t cab_modelv = 0;
+    int last_dqp = 0;
+    if constexpr (RD == 2) { cab_init(cab, lane, pslice, last_qp); cab_modelv = cab_model(lane); }
     Prof pf;
     pf.start();
     int16_t *mv16 = k.mv16_cur + (size_t)s * k.nmb * 2;
@@ -1202,7 +1212,13 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(MB_WAVES_PER
         uint32_t csv = 0;
         if (lane < 32) csv = *(const uint32_t *)(c.fuv + (size_t)(lane >> 2) * k.fs + (lane & 3) * 4);
         uint8_t ntcv = 0;            // RD: total_coeff of the left (lanes 0..23) / top (lanes 24..47) macroblock's blocks
-        if constexpr (RD) {
+        uint32_t cnbv = 0;           // CABAC RD: lanes 0..3 / 4..7 = dwords 0, 1, 6, 11 of the left / top record, lanes 8, 9 / 10, 11 = their |mvd| bytes
+        if constexpr (RD == 2) {
+            if (lane < 8) { const bool av = lane < 4 ? left : top; static_assert(sizeof(x264gpu_mb) == 64, "record"); const int dw = (lane & 3) == 0 ? 0 : (lane & 3) == 1 ? 1 : (lane & 3) == 2 ? 6 : 11;
+                            if (av) cnbv = ((const uint32_t *)(mbs + (lane < 4 ? mbi - 1 : mbi - k.mbw)))[dw]; }
+            else if (lane < 12) { const bool av = lane < 10 ? left : top; if (av) cnbv = ((const uint32_t *)(k.amvd + ((size_t)s * k.nmb + (lane < 10 ? mbi - 1 : mbi - k.mbw)) * 8))[lane & 1]; }
+        }
+        if constexpr (RD == 1) {
             if (k.rd) {
                 if (lane < 24) { if (left) ntcv = k.tc[((size_t)s * k.nmb + mbi - 1) * 24 + lane]; }
                 else if (lane < 48) { if (top) ntcv = k.tc[((size_t)s * k.nmb + mbi - k.mbw) * 24 + lane - 24]; }
@@ -1234,7 +1250,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(MB_WAVES_PER
             S.cref = ref; S.cmvx = vx; S.cmvy = vy;
         }
         *(uint32_t *)(L.src + zy * 16 + zx) = cz;
-        if constexpr (RD) { if (lane < 48) rd_ntc[lane >= 24][lane >= 24 ? lane - 24 : lane] = ntcv; }
+        if constexpr (RD == 1) { if (lane < 48) rd_ntc[lane >= 24][lane >= 24 ? lane - 24 : lane] = ntcv; }
         if (lane < 32) *(uint32_t *)(L.csrc + (lane >> 2) * 16 + (lane & 3) * 4) = csv;
         lds_sync();
 
@@ -1586,6 +1602,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(MB_WAVES_PER
             }
         }
         nnz = 0; cbp_luma = 0; cbp_chroma = 0;
+        int rd_t8cur = 0;                                         // transform_size_8x8_flag of what this pass codes
         rec_type = e_type;
         int16_t *lvw = RD ? (int16_t *)rd_lvs : lv;               // RD: levels stay on chip until the final pass has its bit counts' totals
         int ssd_y = 0, ssd_c = 0, en_satd = 0, en_sad = 0;          // per-lane shares of the distortion terms of the candidate
@@ -1728,6 +1745,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(MB_WAVES_PER
                 if constexpr (RD) { if (lane < 32) ssd_c = ssd4_u8(cenc, crec); }
                 if (lane >= 32 && lane < 40) lvw[X264GPU_LV_LUMA_DC + (lane - 32) * 2] = 0, lvw[X264GPU_LV_LUMA_DC + (lane - 32) * 2 + 1] = 0;
                 if (lane >= 40 && lane < 44) lvw[408 + (lane - 40) * 2] = 0, lvw[408 + (lane - 40) * 2 + 1] = 0;
+                rd_t8cur = t8 && cbp_luma;
                 if (commit && lane == 0) recd.transform8x8 = (uint8_t)(t8 && cbp_luma);
                 // P_L0 16x16, reference 0, the skip vector, nothing coded: P_SKIP
                 if (e_type == X264GPU_MB_P_L0 && e_part == D_16x16 && !(cbp_luma | cbp_chroma) && ref0 == 0 && mv0x == pskx && mv0y == psky)
@@ -1738,6 +1756,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(MB_WAVES_PER
             // ---- intra macroblock ----
             if (commit && lane < 4) recd.ref[lane] = -1;
             if (e_type == X264GPU_MB_I8x8) {
+                rd_t8cur = 1;
                 if (commit && lane == 0) recd.transform8x8 = 1;
                 if (commit && lane < 16) recd.i4_mode[lane] = L.modes8[lane];
                 nnz = IR.nnz8; cbp_luma = IR.cbp8;
@@ -1832,7 +1851,65 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(MB_WAVES_PER
             if (commit) intra_count++;
             pf.mark(PH_ENC_INTRA);
         }
-        if constexpr (RD) {
+        if constexpr (RD == 2) {
+            // ---- CABAC: the candidate priced on a copy of the slice's context variables; the finished macroblock moves them on ----
+            lds_sync();
+            CabIn ci;
+            ci.pslice = pslice; ci.left = left; ci.top = top; ci.nref = c.nref; ci.t8mode = k.dct8x8;
+            ci.type = rec_type; ci.part = e_part; ci.cbp_luma = cbp_luma; ci.cbp_chroma = cbp_chroma; ci.nnz = nnz;
+            ci.i16mode = IR.pred16 > PRED16_P ? PRED16_DC : IR.pred16; ci.cmode = predc > PREDC_P ? PREDC_DC : predc;
+            ci.qp = c.qp; ci.last_qp = last_qp; ci.last_dqp = last_dqp;
+            {
+                const uint32_t l0 = rl(cnbv, 0), l1 = rl(cnbv, 1), l6 = rl(cnbv, 2), l11 = rl(cnbv, 3), t0 = rl(cnbv, 4), t1 = rl(cnbv, 5), t6 = rl(cnbv, 6), t11 = rl(cnbv, 7);
+                ci.ltype = l0 & 255; ci.lcmode = (l0 >> 16) & 255; ci.lcbp_luma = l1 & 255; ci.lcbp_chroma = (l1 >> 8) & 255; ci.lt8 = l6 >> 24; ci.lnnz = l11;
+                ci.ttype = t0 & 255; ci.tcmode = (t0 >> 16) & 255; ci.tcbp_luma = t1 & 255; ci.tcbp_chroma = (t1 >> 8) & 255; ci.tt8 = t6 >> 24; ci.tnnz = t11;
+                ci.lamvd = (unsigned long long)rl(cnbv, 8) | ((unsigned long long)rl(cnbv, 9) << 32);
+                ci.tamvd = (unsigned long long)rl(cnbv, 10) | ((unsigned long long)rl(cnbv, 11) << 32);
+            }
+            ci.t8 = rd_t8cur;
+            if (rd_run && !commit) {
+                int cost;
+                int dist = wave_sum(ssd_y);
+                if (k.psy_rd_q8) {
+                    const int en = wave_sum(en_satd) - (wave_sum(en_sad) >> 1);
+                    dist += (abs(en - fenc_energy) * k.psy_rd_q8 * c.lambda + 128) >> 8;
+                }
+                dist += (int)(((long long)wave_sum(ssd_c) * chroma_l2off + 128) >> 8);
+                if (rec_type == X264GPU_MB_P_SKIP) cost = dist + ((lambda2 + 128) >> 8);
+                else {
+                    Cab tmp = cab;
+                    tmp.f8 = 0;
+                    int dq;
+                    ci.size = true;
+                    cab_mb(tmp, cab_modelv, lane, ci, S, rd_lvs, L.modes4, L.modes8, L.nmodes, c.mbx, c.sy, dq);
+                    cost = dist + (int)(((unsigned long long)tmp.f8 * (unsigned long long)lambda2 + 32768) >> 16);
+                }
+                if (rd_ph == 0) {
+                    rd16 = cost;
+                    if (rec_type == X264GPU_MB_P_SKIP) {          // the 16x16 result is the skip vector and nothing would be coded: P_SKIP, analysis over
+                        rd_best = cost; rd_part = D_16x16; rd_t8 = 0; rd_i16 = rd_i4 = rd_i8 = MB_COST_MAX; rd_ph = 8 - 1; rd_skip16 = true;
+                    }
+                } else if (rd_ph == 1) rd16x8 = cost;
+                else if (rd_ph == 2) rd8x16 = cost;
+                else if (rd_ph == 3) rd8x8 = cost;
+                else if (rd_ph == 4) { if (rd_best >= cost) { if (rd_best > 0) rd_satd_inter = (int)((long long)rd_satd_inter * cost / rd_best); rd_best = cost; rd_t8 = 1; } }
+                else if (rd_ph == 5) rd_i16 = cost;
+                else if (rd_ph == 6) rd_i4 = cost;
+                else if (rd_ph == 7) rd_i8 = cost;
+                rd_ph++;
+                continue;
+            }
+            // the final macroblock: its levels go out, its bins move the slice's context variables on, its |mvd| stay for the neighbours
+            for (int i = lane; i < X264GPU_MB_LEVELS / 2; i += 64) ((uint32_t *)lv)[i] = ((const uint32_t *)rd_lvs)[i];
+            if (rdon) {
+                int dq;
+                ci.size = false;
+                const unsigned long long av = cab_mb(cab, cab_modelv, lane, ci, S, rd_lvs, L.modes4, L.modes8, L.nmodes, c.mbx, c.sy, dq);
+                last_dqp = dq;
+                if (lane < 2) ((uint32_t *)(k.amvd + ((size_t)s * k.nmb + mbi) * 8))[lane] = (uint32_t)(av >> (32 * lane));
+            }
+        }
+        if constexpr (RD == 1) {
             // ---- bits of the macroblock layer as CAVLC would write them (x264_macroblock_size_cavlc), and the blocks' total_coeff ----
             int mb_bits = 0, my_tc = 0;
             lds_sync();
@@ -1945,6 +2022,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(MB_WAVES_PER
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         __builtin_amdgcn_s_waitcnt(0);
         pf.mark(PH_STORE);
+    }
+    if constexpr (RD == 2) {
+        if (k.cab_out) { uint32_t *o = k.cab_out + ((size_t)s * (k.slices > 1 ? k.slices : 1) + blockIdx.y) * 128; o[lane] = cab.a; o[64 + lane] = cab.b; }
     }
 #ifdef MB_PROF
     if (lane == 0 && k.prof) for (int i = 0; i < 16; i++) k.prof[(size_t)s * 16 + i] = pf.acc[i];

@@ -222,10 +222,9 @@ x264_t *x264_encoder_open(x264_param_t *param)
     p.i_scenecut_threshold = clampi(p.i_scenecut_threshold, 0, 100);
     if (p.analyse.i_me_method > X264_ME_ESA) { xlog(&p, X264_LOG_WARNING, "me tesa is not implemented in the MI355X path yet: me esa\n"); p.analyse.i_me_method = X264_ME_ESA; }
     p.analyse.i_me_range = clampi(p.analyse.i_me_range, 4, p.analyse.i_me_method == X264_ME_UMH ? 64 : 16);     // x264 caps dia/hex at 16; esa: the LDS search window
-    // subme 6 / 7 = RD mode decision in P and I slices (x264's i_mbrd 1): on the device with CAVLC bit counts, so in --no-cabac sessions only
-    // (CABAC RD needs the context states at every macroblock); 8+ adds RD refinement of vectors and intra modes (i_mbrd 2, 3), not implemented.
-    // The highest level whose behaviour IS implemented is reported back
-    if (p.analyse.i_subpel_refine > 5 && p.b_cabac) { xlog(&p, X264_LOG_WARNING, "subme %d needs RD mode decision, implemented for --no-cabac sessions only: subme 5\n", p.analyse.i_subpel_refine); p.analyse.i_subpel_refine = 5; }
+    // subme 6 / 7 = RD mode decision in P and I slices (x264's i_mbrd 1): on the device, with the bit counts of the session's entropy coder
+    // (CAVLC: exact; CABAC: x264's size-only coder on the slice's context states, which the device carries through the macroblock loop);
+    // 8+ adds RD refinement of vectors and intra modes (i_mbrd 2, 3), not implemented.  The highest level whose behaviour IS implemented is reported back
     if (p.analyse.i_subpel_refine > 7) { xlog(&p, X264_LOG_WARNING, "subme %d needs RD refinement, which is not implemented yet: subme 7\n", p.analyse.i_subpel_refine); p.analyse.i_subpel_refine = 7; }
     p.analyse.i_subpel_refine = clampi(p.analyse.i_subpel_refine, 0, 7);
     p.analyse.b_psy = p.analyse.b_psy != 0;
