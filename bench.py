@@ -13,9 +13,9 @@ deblock wavefront -> half-pel planes.  Inputs are resident in HBM before the tim
 forwards and backwards).  The timed K steps start on an IDR boundary.  Streams are independent (BASELINE.json config 5), so
 N GPUs shard streams one set per GPU with no collective in the data path ("scaling": "weak").
 
-WHAT IS MEASURED IS NOT x264's FULL preset=medium: the toolset is medium minus B-frames, RD mode decision + psy-RD (subme 7 -> 5 under
-CABAC: the device counts bits for CAVLC only), trellis and weightp — `config.toolset_gaps` says so in the JSON line.  `--rd` measures the
-other implemented variant instead: medium --no-cabac with subme 7 (RD mode decision, psy-rd 1.0) on the device.
+WHAT IS MEASURED IS NOT x264's FULL preset=medium: the toolset is medium (CABAC, subme 7 = RD mode decision with CABAC sizes, psy-rd 1.0)
+minus B-frames, trellis and weightp — `config.toolset_gaps` says so in the JSON line.  `--rd cavlc` measures medium --no-cabac (RD with
+CAVLC bit counts), `--rd off` the subme-5 toolset of the earlier rounds (SATD decisions), for comparison.
 
 Rank 0 prints ONE JSON line with `roofline` (the macroblock kernel, HIP-event timed inside the timed region, HBM fraction + VALU
 issue utilisation from the committed PMC profile), `cpu_baseline` (the oracle restatement on 1 and on all host cores, plus a
@@ -36,8 +36,8 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0   # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
-TOOLSET_GAPS = "x264 medium minus: B-frames (bframes 3 -> 0), RD mode decision + psy-rd (subme 7 -> 5; RD exists for CAVLC sessions: --rd), trellis 1, weightp 2; entropy coding (CABAC/CAVLC) runs on host threads and is outside `value` (inside `e2e`)"
-TOOLSET_GAPS_RD = "x264 medium --no-cabac minus: B-frames (bframes 3 -> 0), trellis 1, weightp 2; entropy coding (CAVLC) runs on host threads and is outside `value`"
+TOOLSET_GAPS = "x264 medium minus: B-frames (bframes 3 -> 0), trellis 1, weightp 2; entropy coding (CABAC/CAVLC bitstream writing) runs on host threads and is outside `value` (inside `e2e`)"
+TOOLSET_GAPS_NORD = "x264 medium minus: B-frames (bframes 3 -> 0), RD mode decision + psy-rd (subme 7 -> 5), trellis 1, weightp 2; entropy coding runs on host threads and is outside `value`"
 
 
 def parse_args():
@@ -54,7 +54,7 @@ def parse_args():
     ap.add_argument("--qp", type=int, default=23)
     ap.add_argument("--refs", type=int, default=3, help="reference frames (medium: 3)")
     ap.add_argument("--preset", default="medium", choices=["medium", "ultrafast", "slow"])
-    ap.add_argument("--rd", action="store_true", help="medium --no-cabac with subme 7: RD mode decision (CAVLC bit counts) + psy-rd 1.0 on the device; not the headline")
+    ap.add_argument("--rd", default="cabac", choices=["cabac", "cavlc", "off"], help="RD mode decision (subme 7, psy-rd 1.0) with the sizes of medium's CABAC (default, the headline), of CAVLC (medium --no-cabac), or off (subme 5: SATD decisions)")
     ap.add_argument("--aq", action="store_true", help="variance AQ on (per-macroblock quantisers, the CRF / ABR path); the headline metric is CQP and leaves it off, as x264 does")
     ap.add_argument("--cpu-frames", type=int, default=10, help="frames per core of the CPU-baseline sample (0 = skip)")
     ap.add_argument("--e2e-frames", type=int, default=10, help="frames of the single-stream threads-1 end-to-end sample (0 = skip e2e)")
@@ -71,8 +71,8 @@ def toolset(args):
          "ultrafast": dict(refs=1, subme=0, deblock=0, partitions=0x100, dct8x8=0, me_method=0, chroma_me=0, mixed_refs=0),
          "slow": dict(refs=4, subme=5, deblock=1, partitions=7, dct8x8=1, me_method=2, chroma_me=1, mixed_refs=1)}[args.preset]
     t = dict(t, fast_pskip=1, mv_range=512, cabac=0 if args.preset == "ultrafast" else 1)          # medium's entropy coder (it runs on the host; the analysis costs know it)
-    if args.rd:
-        t = dict(t, cabac=0, rd=1, subme=7, psy=1, psy_rd_q8=256, chroma_qp_offset=-2)            # x264 lowers the chroma offset by 2 under psy-rd >= 0.25
+    if args.rd != "off" and args.preset != "ultrafast":
+        t = dict(t, cabac=int(args.rd == "cabac"), rd=1, subme=7, psy=1, psy_rd_q8=256, chroma_qp_offset=-2)            # x264 lowers the chroma offset by 2 under psy-rd >= 0.25
     if args.aq:
         t = dict(t, aq_mode=1, aq_strength_q8=266)
     return t
@@ -133,7 +133,7 @@ def cpu_baseline(args):
     """the oracle (kind "port") on 1 core and on every host core (one stream per core), bounded sample"""
     ncpu = os.cpu_count() or 1
     base = [sys.executable, os.path.abspath(__file__), "--width", str(args.width), "--height", str(args.height), "--qp", str(args.qp),
-            "--keyint", str(args.keyint), "--refs", str(args.refs), "--preset", args.preset] + (["--aq"] if args.aq else []) + (["--rd"] if args.rd else [])
+            "--keyint", str(args.keyint), "--refs", str(args.refs), "--preset", args.preset] + (["--aq"] if args.aq else []) + ["--rd", args.rd]
     nall = max(2, min(args.cpu_frames, args.cpu_frames_all))
 
     def run(n, frames):
@@ -205,7 +205,7 @@ def pmc_evidence(kernel_substr, avg_launch_ms, streams_per_launch, content):
     if tab.get("_workload", {}).get("content", "noise") != content:
         return None, None                                     # counters of another workload say nothing about this one
     key = [k for k in tab if kernel_substr in k]
-    key = [k for k in key if "true>" in k] or key          # the macroblock loop has a P-slice and an I-slice instantiation: the timed pictures are P
+    key = [k for k in key if ", true" in k] or key          # the macroblock loop has a P-slice and an I-slice instantiation: the timed pictures are P
     if not per or not key:
         return None, None
     t = tab[key[0]]
@@ -413,8 +413,8 @@ def main():
     avg_ms = ms[dom] / max(cnt[dom], 1)
     achieved = alg[names[dom]] * S / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
     traffic, valu = pmc_evidence("k_mb_slice" if names[dom] == "macroblocks" else names[dom], avg_ms, S, args.content)
-    if args.rd:
-        traffic, valu = None, None                            # the committed counters are the headline kernel's, not the RD instantiation's
+    if args.rd != "cabac":
+        traffic, valu = None, None                            # the committed counters are the headline kernel's (RD with CABAC sizes)
     roof = {"bound": "hbm", "kernel": "k_mb_slice (macroblock loop)" if names[dom] == "macroblocks" else names[dom], "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic, "valu": valu,
             "note": "the path is bound by dependent-instruction latency inside a raster-serial macroblock loop, not by HBM: see valu.issue_util and DESIGN.md",
@@ -425,7 +425,7 @@ def main():
            "ms_per_step": round(dt / K * 1e3, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
            "dtype": "u8", "data": "synthetic",
            "config": {"workload": f"{W}x{H} yuv420p, {S} closed-GOP streams/GPU x {K} frames ({n_i} I + {K - n_i} P), CQP {qp_i}/{qp_p}, preset {args.preset} as implemented, content '{args.content}'",
-                      "toolset": tools, "toolset_gaps": TOOLSET_GAPS_RD if args.rd else TOOLSET_GAPS, "streams_per_gpu": S, "distinct_sequences": D, "clip_frames": L, "content": args.content, "frames_per_step": S * world,
+                      "toolset": tools, "toolset_gaps": TOOLSET_GAPS_NORD if args.rd == "off" or args.preset == "ultrafast" else TOOLSET_GAPS + (" [--rd cavlc: medium --no-cabac]" if args.rd == "cavlc" else ""), "streams_per_gpu": S, "distinct_sequences": D, "clip_frames": L, "content": args.content, "frames_per_step": S * world,
                       "mb_per_frame": ((W + 15) // 16) * ((H + 15) // 16)},
            "roofline": roof}
     if rank == 0:
