@@ -4,16 +4,20 @@
 // context variables per slice, moved on by the entropy coding of every finished macroblock, and prices a candidate by running the
 // macroblock's syntax over a COPY of them with the arithmetic coder replaced by a counter in 1/256 bit (entropy[state ^ bin], bypass
 // bin = 256, the I16x16 terminate bin = 7).  The bitstream itself is still written by the host (host/cabac.cpp); what lives here is
-//   * the 460 context variables of the slice a wavefront codes: ONE BYTE EACH, FOUR TO A DWORD, IN TWO VGPRs (context c sits in byte c & 3
-//     of lane (c >> 2) & 63 of register c >> 8) — copying them for a candidate is two moves, and the coder below, whose control flow is
-//     wave-uniform, reads and writes them with v_readlane / a lane select;
-//   * a third register with the probability model: lane s = cost of the MPS | cost of the LPS << 9 | state after an LPS << 20;
+//   * the context variables of the slice a wavefront codes, ONE BYTE EACH IN THREE VGPRs (cab_locate below) — copying them for a candidate
+//     is three moves.  The header syntax and the coded_block_flags are coded by wave-uniform code that reads and writes its register with
+//     v_readlane / a lane select; the residual contexts are laid out so that EVERY LANE OWNS ONE CONTEXT of the block category being
+//     coded: the significance map of a 4x4 block is one step of all lanes, and the serial part of a block is one step per non-zero
+//     coefficient (per-context bin order is all the arithmetic model cares about, and bits add);
+//   * a register with the probability model: lane s = cost of the MPS | cost of the LPS << 9 | state after an LPS << 20;
 //   * cab_mb(): the macroblock layer's bins, either in bitstream order ("evolve": what the finished macroblock leaves behind, skip flag
 //     included) or as x264_macroblock_size_cabac walks them ("size": no skip flag, residual blocks from the last coefficient down with
 //     flags and levels interleaved — the order matters for 8x8 blocks, whose positions share contexts).
 // Mirrors oracle/cabac_rd.cpp bin for bin; the initialisation values and state transitions are the host coder's tables.
 #pragma once
+#include <type_traits>
 #include "enc_common.cuh"
+#include "cabac_layout.cuh"
 #define CABAC_TABLE static __constant__ const
 #define CABAC_NAMESPACE x264gpu_cabac
 #include "../host/cabac_tables.hpp"
@@ -26,38 +30,59 @@ static __constant__ const uint16_t c_cabac_entropy[128] = {
 #include "cabac_entropy.inc"
 };
 
-struct Cab { uint32_t a, b; int f8; };
+struct Cab { uint32_t a, r, r8; int f8; int f8v; };       // f8: wave-uniform count, f8v: this lane's share of the parallel steps (1/256 bit)
 
 __device__ __forceinline__ uint32_t cab_model(int lane)
 {
     return (uint32_t)c_cabac_entropy[2 * lane] | ((uint32_t)c_cabac_entropy[2 * lane + 1] << 9) | ((uint32_t)x264gpu_cabac::cabac_trans_lps[lane] << 20);
 }
 
+__device__ __forceinline__ int cab_total(const Cab &cb) { return cb.f8 + wave_sum(cb.f8v); }
+
 // 9.3.1.1: context variables from the slice quantiser (cabac_init_idc 0)
 __device__ __forceinline__ void cab_init(Cab &cb, int lane, bool pslice, int qp)
 {
     namespace T = x264gpu_cabac;
     qp = min(max(qp, 0), 51);
-    uint32_t w[2] = { 0, 0 };
-    for (int r = 0; r < 2; r++)
-        for (int j = 0; j < 4; j++) {
-            const int ctx = r * 256 + lane * 4 + j;
-            int m = 0, n = 0;
-            if (ctx < 276) { const T::CabacInitRow row = T::cabac_init_0_275[ctx]; m = pslice ? row.mp : row.mi; n = pslice ? row.np : row.ni; }
-            else if (ctx >= 399 && ctx <= 435) { const T::CabacInitRow row = T::cabac_init_399_435[ctx - 399]; m = pslice ? row.mp : row.mi; n = pslice ? row.np : row.ni; }
-            const int pre = min(max(((m * qp) >> 4) + n, 1), 126);
-            const int st = pre <= 63 ? (63 - pre) << 1 : ((pre - 64) << 1) | 1;
-            w[r] |= (uint32_t)st << (8 * j);
+    uint32_t w[3] = { 0, 0, 0 };
+    auto seed = [&](int ctx) {
+        int m = 0, n = 0;
+        if (ctx < 276) { const T::CabacInitRow row = T::cabac_init_0_275[ctx]; m = pslice ? row.mp : row.mi; n = pslice ? row.np : row.ni; }
+        else { const T::CabacInitRow row = T::cabac_init_399_435[ctx - 399]; m = pslice ? row.mp : row.mi; n = pslice ? row.np : row.ni; }
+        const int pre = min(max(((m * qp) >> 4) + n, 1), 126);
+        return (uint32_t)(pre <= 63 ? (63 - pre) << 1 : ((pre - 64) << 1) | 1);
+    };
+    for (int j = 0; j < 4; j++) {
+        const int c = lane * 4 + j;
+        if (c < 105) w[0] |= seed(c) << (8 * j); else if (c < 108) w[0] |= seed(399 + c - 105) << (8 * j);
+    }
+    {
+        const int role = lane >> 4, i = lane & 15;
+        const int sig_off[5] = { 105, 120, 134, 149, 152 }, last_off[5] = { 166, 181, 195, 210, 213 }, abs_off[5] = { 227, 237, 247, 257, 266 }, n1[5] = { 15, 14, 15, 3, 14 };
+        const int cats[3] = { 2, 1, 4 };
+        for (int b = 0; b < 3; b++) {
+            const int cat = cats[b];
+            if (role == 0 && i < n1[cat]) w[1] |= seed(sig_off[cat] + i) << (8 * b);
+            else if (role == 1 && i < n1[cat]) w[1] |= seed(last_off[cat] + i) << (8 * b);
+            else if (role == 2 && i < 10) w[1] |= seed(abs_off[cat] + i) << (8 * b);
         }
-    cb.a = w[0]; cb.b = w[1]; cb.f8 = 0;
+        if (lane < 48) {
+            if (role == 0 && i < 15) w[1] |= seed(105 + i) << 24; else if (role == 1 && i < 15) w[1] |= seed(166 + i) << 24; else if (role == 2 && i < 10) w[1] |= seed(227 + i) << 24;
+        } else {
+            const int l = lane - 48;
+            if (l < 3) w[1] |= seed(149 + l) << 24; else if (l >= 4 && l < 7) w[1] |= seed(210 + l - 4) << 24; else if (l >= 7) w[1] |= seed(257 + l - 7) << 24;
+        }
+        if (role == 0 && i < 15) w[2] = seed(402 + i); else if (role == 1 && i < 9) w[2] = seed(417 + i); else if (role == 2 && i < 10) w[2] = seed(426 + i);
+    }
+    cb.a = w[0]; cb.r = w[1]; cb.r8 = w[2]; cb.f8 = 0; cb.f8v = 0;
 }
 
+// one bin of the header syntax / a coded_block_flag (contexts 0..104, 399..401): wave-uniform, context variables in register a
 __device__ __forceinline__ void cab_bin(Cab &cb, uint32_t model, int lane, int ctx, int bin)
 {
-    ctx = __builtin_amdgcn_readfirstlane(ctx); bin = __builtin_amdgcn_readfirstlane(bin);
-    const int li = (ctx >> 2) & 63, sh = (ctx & 3) * 8;
-    const bool hi = ctx >= 256;
-    const uint32_t w = hi ? __builtin_amdgcn_readlane(cb.b, li) : __builtin_amdgcn_readlane(cb.a, li);
+    ctx = __builtin_amdgcn_readfirstlane(ctx >= 399 ? ctx - 399 + 105 : ctx); bin = __builtin_amdgcn_readfirstlane(bin);
+    const int li = ctx >> 2, sh = (ctx & 3) * 8;
+    const uint32_t w = __builtin_amdgcn_readlane(cb.a, li);
     const int st = (w >> sh) & 255, sg = st >> 1, mps = st & 1;
     const uint32_t t = __builtin_amdgcn_readlane(model, sg);
     const bool lps = (mps ^ bin) != 0;
@@ -65,7 +90,7 @@ __device__ __forceinline__ void cab_bin(Cab &cb, uint32_t model, int lane, int c
     const int ns = lps ? (int)(t >> 20) : min(sg + 1, 62);
     const int nm = lps && sg == 0 ? mps ^ 1 : mps;
     const uint32_t nw = (w & ~(255u << sh)) | ((uint32_t)((ns << 1) | nm) << sh);
-    if (hi) cb.b = lane == li ? nw : cb.b; else cb.a = lane == li ? nw : cb.a;
+    cb.a = lane == li ? nw : cb.a;
 }
 __device__ __forceinline__ void cab_bypass(Cab &cb, int n = 1) { cb.f8 += 256 * n; }
 __device__ __forceinline__ void cab_ue_bypass(Cab &cb, int k, int v)
@@ -73,6 +98,77 @@ __device__ __forceinline__ void cab_ue_bypass(Cab &cb, int k, int v)
     int n = 0;
     while (v >= (1 << k)) { n++; v -= 1 << k; k++; }
     cb.f8 += 256 * (n + 1 + k);
+}
+
+// one bin in every lane that has one (mine): the lane's own context variable st, its share of the bits
+__device__ __forceinline__ void cab_step(int &st, int &f8v, uint32_t model, bool mine, int bin)
+{
+    const int sg = st >> 1, mps = st & 1;
+    const uint32_t t = (uint32_t)__builtin_amdgcn_ds_bpermute(sg << 2, (int)model);
+    const bool lps = (mps ^ bin) != 0;
+    const int cost = lps ? (t >> 9) & 0x7ff : t & 0x1ff;
+    const int ns = lps ? (int)(t >> 20) : min(sg + 1, 62);
+    const int nm = lps && sg == 0 ? mps ^ 1 : mps;
+    f8v += mine ? cost : 0;
+    st = mine ? (ns << 1) | nm : st;
+}
+
+// the levels of a block, last coefficient first: coefficient i in lane i of coef, mask = its non-zero positions; q = this lane's
+// coeff_abs_level_minus1 context (0..9), or anything else.  x264's node contexts: c1 = bin 0, cg = the bins after it.
+__device__ __forceinline__ void cab_levels(Cab &cb, int &st, uint32_t model, int coef, unsigned long long mask, int q)
+{
+    int node = 0;
+    while (mask) {
+        const int i = 63 - __builtin_clzll(mask);
+        mask ^= 1ull << i;
+        const int a = abs(__builtin_amdgcn_readlane(coef, i));
+        const int c1 = node < 4 ? node + 1 : 0, cg = node < 4 ? 5 : min(node + 2, 9);
+        const int ones = min(a, 15) - 2, nb = a > 1 ? (a < 15 ? a - 1 : 13) : 0;        // bins on cg: `ones` ones, then a zero unless the escape follows
+        cab_step(st, cb.f8v, model, q == c1 || (a > 1 && q == cg), q == c1 ? a > 1 : a > 2);
+        for (int kb = 1; kb < nb; kb++) cab_step(st, cb.f8v, model, q == cg, kb < ones);
+        cb.f8 += 256;                                                  // sign
+        if (a >= 15) cab_ue_bypass(cb, 0, a - 15);
+        node = a > 1 ? (node < 4 ? 4 : min(node + 1, 7)) : (node < 3 ? node + 1 : node);
+    }
+}
+
+// residual_block_cabac of a block of category CAT (0 luma DC, 1 luma AC, 2 luma 4x4, 3 chroma DC, 4 chroma AC): coefficient i (scan order)
+// in lane i of coef, zero elsewhere; the block holds a non-zero coefficient.  st = this lane's context variable of that category.
+template <int CAT>
+__device__ __forceinline__ void cab_block4(Cab &cb, int &st, uint32_t model, int lane, int coef)
+{
+    constexpr int n1 = CAT == 3 ? 3 : (CAT == 1 || CAT == 4) ? 14 : 15;
+    constexpr int sig0 = CAT == 3 ? 48 : 0, last0 = CAT == 3 ? 52 : 16, abs0 = CAT == 3 ? 55 : 32;
+    const unsigned long long mask = __ballot(coef != 0);
+    const int last = 63 - __builtin_clzll(mask);
+    const bool is_s = lane >= sig0 && lane < sig0 + n1, is_l = lane >= last0 && lane < last0 + n1;
+    const int p = is_s ? lane - sig0 : lane - last0;
+    const int nzp = (int)((mask >> (p & 63)) & 1);
+    cab_step(st, cb.f8v, model, (is_s && p <= last) || (is_l && nzp && p <= last), is_s ? nzp : p == last);
+    cab_levels(cb, st, model, coef, mask, lane - abs0);
+}
+
+static __constant__ const unsigned long long c_cabac_pos8[24] = {
+#include "cabac_masks8x8.inc"
+};
+
+// ... of an 8x8 luma block (64 coefficients, one per lane).  Positions share contexts here, so a lane walks the positions of ITS context:
+// downwards as x264's size-only coder does (flags interleaved with the levels from the last coefficient down), upwards in bitstream order.
+__device__ __forceinline__ void cab_block8(Cab &cb, int &st, uint32_t model, int lane, int coef, bool size)
+{
+    const unsigned long long mask = __ballot(coef != 0);
+    const int last = 63 - __builtin_clzll(mask);
+    const unsigned long long upto = last < 63 ? (2ull << last) - 1 : 0x7fffffffffffffffull;
+    unsigned long long mine = 0;
+    if (lane < 15) mine = c_cabac_pos8[lane] & upto;
+    else if (lane >= 16 && lane < 25) mine = c_cabac_pos8[15 + lane - 16] & upto & mask;
+    while (__ballot(mine != 0)) {
+        const bool have = mine != 0;
+        const int i = have ? (size ? 63 - __builtin_clzll(mine) : __builtin_ctzll(mine)) : 0;
+        cab_step(st, cb.f8v, model, have, lane < 15 ? (int)((mask >> i) & 1) : i == last);
+        mine &= ~(1ull << i);
+    }
+    cab_levels(cb, st, model, coef, mask, lane - 32);
 }
 
 // what the coder needs to know about the macroblock and its neighbours (all wave-uniform)
@@ -92,68 +188,6 @@ __device__ __forceinline__ int cab_luma_cbf_of(int type, int cbp_luma, int t8, u
     if (!((cbp_luma >> ((by >> 1) * 2 + (bx >> 1))) & 1)) return 0;
     if (t8) return 1;
     return (nnz >> blkidx_of(bx, by)) & 1;
-}
-
-// one level: coeff_abs_level_minus1 prefix / suffix + sign, x264's node contexts
-__device__ __forceinline__ void cab_level(Cab &cb, uint32_t model, int lane, int abs_off, int v, int &node)
-{
-    const int a = abs(v);
-    const int c1 = node < 4 ? node + 1 : 0, cg = node < 4 ? 5 : min(node + 2, 9);
-    if (a > 1) {
-        cab_bin(cb, model, lane, abs_off + c1, 1);
-        for (int i = min(a, 15) - 2; i > 0; i--) cab_bin(cb, model, lane, abs_off + cg, 1);
-        if (a < 15) cab_bin(cb, model, lane, abs_off + cg, 0); else cab_ue_bypass(cb, 0, a - 15);
-        node = node < 4 ? 4 : min(node + 1, 7);
-    } else { cab_bin(cb, model, lane, abs_off + c1, 0); node = node < 3 ? node + 1 : node == 3 ? 3 : node; }
-    cab_bypass(cb);
-}
-
-// residual_block_cabac of the block whose coefficient i (scan order) sits in lane i of coef (zero beyond the block).  cat: 0 luma DC,
-// 1 luma AC (15), 2 luma 4x4, 3 chroma DC (4), 4 chroma AC (15), 5 luma 8x8.  The block is known to hold a non-zero coefficient.
-__device__ __forceinline__ void cab_residual(Cab &cb, uint32_t model, int lane, int coef, int cat, bool size)
-{
-    namespace T = x264gpu_cabac;
-    const int sig_off = cat == 0 ? 105 : cat == 1 ? 120 : cat == 2 ? 134 : cat == 3 ? 149 : cat == 4 ? 152 : 402;
-    const int last_off = cat == 0 ? 166 : cat == 1 ? 181 : cat == 2 ? 195 : cat == 3 ? 210 : cat == 4 ? 213 : 417;
-    const int abs_off = cat == 0 ? 227 : cat == 1 ? 237 : cat == 2 ? 247 : cat == 3 ? 257 : cat == 4 ? 266 : 426;
-    const int n1 = cat == 3 ? 3 : cat == 5 ? 63 : (cat == 1 || cat == 4) ? 14 : 15;
-    const unsigned long long mask = __ballot(coef != 0);
-    const int last = 63 - __builtin_clzll(mask);
-    int node = 0;
-    if (size) {
-        if (last != n1) {
-            cab_bin(cb, model, lane, sig_off + (cat == 5 ? T::cabac_sig8x8[last] : last), 1);
-            cab_bin(cb, model, lane, last_off + (cat == 5 ? T::cabac_last8x8[last] : last), 1);
-        }
-        cab_level(cb, model, lane, abs_off, __builtin_amdgcn_readlane(coef, last), node);
-        for (int i = last - 1; i >= 0; i--) {
-            const int so = sig_off + (cat == 5 ? T::cabac_sig8x8[i] : i);
-            if ((mask >> i) & 1) {
-                cab_bin(cb, model, lane, so, 1);
-                cab_bin(cb, model, lane, last_off + (cat == 5 ? T::cabac_last8x8[i] : i), 0);
-                cab_level(cb, model, lane, abs_off, __builtin_amdgcn_readlane(coef, i), node);
-            } else cab_bin(cb, model, lane, so, 0);
-        }
-    } else {
-        for (int i = 0; i < last; i++) {
-            const int nz = (mask >> i) & 1;
-            cab_bin(cb, model, lane, sig_off + (cat == 5 ? T::cabac_sig8x8[i] : i), nz);
-            if (nz) cab_bin(cb, model, lane, last_off + (cat == 5 ? T::cabac_last8x8[i] : i), 0);
-        }
-        if (last != n1) {
-            cab_bin(cb, model, lane, sig_off + (cat == 5 ? T::cabac_sig8x8[last] : last), 1);
-            cab_bin(cb, model, lane, last_off + (cat == 5 ? T::cabac_last8x8[last] : last), 1);
-        }
-        for (int i = last; i >= 0; i--) if ((mask >> i) & 1) cab_level(cb, model, lane, abs_off, __builtin_amdgcn_readlane(coef, i), node);
-    }
-}
-
-// coded_block_flag + the block
-__device__ __forceinline__ void cab_block_cbf(Cab &cb, uint32_t model, int lane, int coef, int cat, int inc, bool size)
-{
-    const bool nz = __ballot(coef != 0) != 0;
-    cab_bin(cb, model, lane, 85 + cat * 4 + inc, nz);
-    if (nz) cab_residual(cb, model, lane, coef, cat, size);
 }
 
 __device__ __forceinline__ void cab_mb_type_intra(Cab &cb, uint32_t model, int lane, const CabIn &in, int c0, int c1, int c2, int c3, int c4, int c5)
@@ -310,20 +344,35 @@ __device__ __forceinline__ unsigned long long cab_mb(Cab &cb, uint32_t model, in
             const int b = by > 0 ? of(in.type, in.cbp_chroma, in.nnz, bx, 0) : tavail ? of(in.ttype, in.tcbp_chroma, in.tnnz, bx, 1) : un;
             return a + 2 * b;
         };
+        // residual: the category's context variables are this lane's byte of r (r8 for 8x8 blocks) for the duration of its blocks
+        auto blocks = [&](auto cat_tag, int shift, int nblk, auto coef_of, auto inc_of, auto coded) {
+            constexpr int CAT = decltype(cat_tag)::value;
+            int st = (cb.r >> shift) & 255;
+            for (int b = 0; b < nblk; b++) {
+                if (!coded(b)) continue;
+                const int coef = coef_of(b);
+                const bool nz = __ballot(coef != 0) != 0;
+                cab_bin(cb, model, lane, 85 + CAT * 4 + inc_of(b), nz);
+                if (nz) cab_block4<CAT>(cb, st, model, lane, coef);
+            }
+            cb.r = (cb.r & ~(255u << shift)) | ((uint32_t)st << shift);
+        };
+        auto always = [](int) { return true; };
         if (i16) {
-            cab_block_cbf(cb, model, lane, lane < 16 ? (int)lvs[X264GPU_LV_LUMA_DC + lane] : 0, 0, dc_inc(24), in.size);
-            if (in.cbp_luma) for (int b = 0; b < 16; b++) cab_block_cbf(cb, model, lane, lane < 15 ? (int)lvs[b * 16 + 1 + lane] : 0, 1, luma_inc(b), in.size);
+            blocks(std::integral_constant<int, 0>{}, 24, 1, [&](int) { return lane < 16 ? (int)lvs[X264GPU_LV_LUMA_DC + lane] : 0; }, [&](int) { return dc_inc(24); }, always);
+            if (in.cbp_luma) blocks(std::integral_constant<int, 1>{}, 8, 16, [&](int b) { return lane < 15 ? (int)lvs[b * 16 + 1 + lane] : 0; }, luma_inc, always);
         } else if (in.t8) {
+            int st = cb.r8 & 255;
             for (int i8 = 0; i8 < 4; i8++)
-                if ((in.cbp_luma >> i8) & 1) cab_residual(cb, model, lane, (int)lvs[(i8 * 4 + (lane & 3)) * 16 + (lane >> 2)], 5, in.size);
+                if ((in.cbp_luma >> i8) & 1) cab_block8(cb, st, model, lane, (int)lvs[(i8 * 4 + (lane & 3)) * 16 + (lane >> 2)], in.size);
+            cb.r8 = (uint32_t)st;
         } else {
-            for (int b = 0; b < 16; b++) if ((in.cbp_luma >> (b >> 2)) & 1) cab_block_cbf(cb, model, lane, lane < 16 ? (int)lvs[b * 16 + lane] : 0, 2, luma_inc(b), in.size);
+            blocks(std::integral_constant<int, 2>{}, 0, 16, [&](int b) { return lane < 16 ? (int)lvs[b * 16 + lane] : 0; }, luma_inc, [&](int b) { return ((in.cbp_luma >> (b >> 2)) & 1) != 0; });
         }
         if (in.cbp_chroma) {
-            for (int pl = 0; pl < 2; pl++) cab_block_cbf(cb, model, lane, lane < 4 ? (int)lvs[X264GPU_LV_CHROMA_DC + pl * 4 + lane] : 0, 3, dc_inc(25 + pl), in.size);
+            blocks(std::integral_constant<int, 3>{}, 24, 2, [&](int pl) { return lane < 4 ? (int)lvs[X264GPU_LV_CHROMA_DC + pl * 4 + lane] : 0; }, [&](int pl) { return dc_inc(25 + pl); }, always);
             if (in.cbp_chroma == 2)
-                for (int pl = 0; pl < 2; pl++)
-                    for (int i = 0; i < 4; i++) cab_block_cbf(cb, model, lane, lane < 15 ? (int)lvs[X264GPU_LV_CHROMA_AC + (pl * 4 + i) * 16 + 1 + lane] : 0, 4, ac_inc(pl, i), in.size);
+                blocks(std::integral_constant<int, 4>{}, 16, 8, [&](int k) { return lane < 15 ? (int)lvs[X264GPU_LV_CHROMA_AC + k * 16 + 1 + lane] : 0; }, [&](int k) { return ac_inc(k >> 2, k & 3); }, always);
         }
     }
     return amvd;

@@ -10,6 +10,7 @@
 #include "k_encode.cuh"
 #include <stdlib.h>
 #include "k_deblock.cuh"
+#include "cabac_layout.cuh"
 #include <math.h>
 #include <vector>
 #include <string.h>
@@ -42,7 +43,7 @@ struct x264gpu_encoder {
     unsigned long long *dbg = nullptr;   // diagnostics buffer set by x264gpu_encoder_set_debug
     uint8_t *tc = nullptr;               // RD: total_coeff of every block of the picture being coded
     uint8_t *amvd = nullptr;             // CABAC RD: |mvd| of every 8x8 block of the picture being coded
-    uint32_t *cab_out = nullptr;         // ... and the context variables every slice's wavefront ended with: [stream][slice][2][64] (tests)
+    uint32_t *cab_out = nullptr;         // ... and the context variables every slice's wavefront ended with: [stream][slice][3][64] (tests; layout: cabac_rd.cuh cab_locate)
     unsigned long long *prof = nullptr;  // MB_PROF builds: phase counters of the last macroblock-loop launch
     int *wf_progress = nullptr;          // [streams][2][WFG_ROWS] row counters of the multi-workgroup wavefront kernels
     // adaptive quantisation: per-macroblock quantisers and the per-quantiser tables (built when aq_mode != 0)
@@ -145,7 +146,7 @@ int x264gpu_encoder_create(x264gpu_encoder **out, const x264gpu_config *cfg)
     for (int r = 1; r < cfg->refs; r++) alloc((void **)&e->mvr[r], S * k.nmb * 2 * sizeof(int16_t), 0);
     alloc((void **)&e->wf_progress, S * 2 * WFG_ROWS * sizeof(int), 0);
     if (cfg->rd && !cfg->cabac) alloc((void **)&e->tc, S * k.nmb * 24, 0);
-    if (cfg->rd && cfg->cabac) { alloc((void **)&e->amvd, S * k.nmb * 8, 0); alloc((void **)&e->cab_out, S * (cfg->slices > 1 ? cfg->slices : 1) * 128 * sizeof(uint32_t), 0); }
+    if (cfg->rd && cfg->cabac) { alloc((void **)&e->amvd, S * k.nmb * 8, 0); alloc((void **)&e->cab_out, S * (cfg->slices > 1 ? cfg->slices : 1) * 192 * sizeof(uint32_t), 0); }
 #ifdef MB_PROF
     alloc((void **)&e->prof, S * 16 * sizeof(unsigned long long), 0);
 #endif
@@ -258,10 +259,13 @@ int x264gpu_encoder_cabac_states(x264gpu_encoder *e, int stream, int slice, uint
 {
     ARG_TRY(e && out460 && stream >= 0 && stream < e->cfg.streams && slice >= 0 && slice < (e->cfg.slices > 1 ? e->cfg.slices : 1));
     if (!e->cab_out) return X264GPU_EINVAL;
-    uint32_t w[128];
+    uint32_t w[192];
     HIP_TRY(hipDeviceSynchronize());
-    HIP_TRY(hipMemcpy(w, e->cab_out + ((size_t)stream * (e->cfg.slices > 1 ? e->cfg.slices : 1) + slice) * 128, sizeof(w), hipMemcpyDeviceToHost));
-    for (int c = 0; c < 460; c++) out460[c] = (uint8_t)(w[(c >> 8) * 64 + ((c >> 2) & 63)] >> ((c & 3) * 8));
+    HIP_TRY(hipMemcpy(w, e->cab_out + ((size_t)stream * (e->cfg.slices > 1 ? e->cfg.slices : 1) + slice) * 192, sizeof(w), hipMemcpyDeviceToHost));
+    for (int c = 0; c < 460; c++) {
+        int reg, lane, sh;
+        out460[c] = cab_locate(c, reg, lane, sh) ? (uint8_t)(w[reg * 64 + lane] >> sh) : 0;
+    }
     return X264GPU_OK;
 }
 

@@ -1136,7 +1136,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(MB_WAVES_PER
     __shared__ uint8_t rd_ntc[2][RD == 1 ? 24 : 1];
     int last_qp = slice_qp(k, s);
     // CABAC RD: the slice's context variables (two registers, see cabac_rd.cuh), the probability model, the previous macroblock's mb_qp_delta
-    Cab cab = { 0, 0, 0 };
+    Cab cab = { 0, 0, 0, 0, 0 };
     uint32_t cab_modelv = 0;
     int last_dqp = 0;
     if constexpr (RD == 2) { cab_init(cab, lane, pslice, last_qp); cab_modelv = cab_model(lane); }
@@ -1878,11 +1878,11 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(MB_WAVES_PER
                 if (rec_type == X264GPU_MB_P_SKIP) cost = dist + ((lambda2 + 128) >> 8);
                 else {
                     Cab tmp = cab;
-                    tmp.f8 = 0;
+                    tmp.f8 = 0; tmp.f8v = 0;
                     int dq;
                     ci.size = true;
                     cab_mb(tmp, cab_modelv, lane, ci, S, rd_lvs, L.modes4, L.modes8, L.nmodes, c.mbx, c.sy, dq);
-                    cost = dist + (int)(((unsigned long long)tmp.f8 * (unsigned long long)lambda2 + 32768) >> 16);
+                    cost = dist + (int)(((unsigned long long)cab_total(tmp) * (unsigned long long)lambda2 + 32768) >> 16);
                 }
                 if (rd_ph == 0) {
                     rd16 = cost;
@@ -2024,7 +2024,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(MB_WAVES_PER
         pf.mark(PH_STORE);
     }
     if constexpr (RD == 2) {
-        if (k.cab_out) { uint32_t *o = k.cab_out + ((size_t)s * (k.slices > 1 ? k.slices : 1) + blockIdx.y) * 128; o[lane] = cab.a; o[64 + lane] = cab.b; }
+        if (k.cab_out) { uint32_t *o = k.cab_out + ((size_t)s * (k.slices > 1 ? k.slices : 1) + blockIdx.y) * 192; o[lane] = cab.a; o[64 + lane] = cab.r; o[128 + lane] = cab.r8; }
     }
 #ifdef MB_PROF
     if (lane == 0 && k.prof) for (int i = 0; i < 16; i++) k.prof[(size_t)s * 16 + i] = pf.acc[i];
