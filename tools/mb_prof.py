@@ -26,13 +26,13 @@ def main():
     W = int(sys.argv[3]) if len(sys.argv) > 3 else 1920
     H = int(sys.argv[4]) if len(sys.argv) > 4 else 1080
     dev = torch.device("cuda:0")
-    args = type("A", (), dict(refs=3, preset="medium", aq=False))()
+    args = type("A", (), dict(refs=3, preset="medium", aq=False, rd=os.environ.get("MB_PROF_RD", "cabac")))()
     tools = bench.toolset(args)
     D = min(S, 64)
     base = bench.synth_batch(torch, D, F, W, H, 0x264, dev)
     data = base if D == S else base.repeat(1, (S + D - 1) // D, 1)[:, :S].contiguous()
-    cfg = Config(width=W, height=H, streams=S, qp_i=20, qp_p=23, me_range=16, deblock_alpha=0, deblock_beta=0, chroma_qp_offset=0, deadzone_inter=21,
-                 deadzone_intra=11, dct_decimate=1, **tools)
+    cfg = Config(**dict(dict(width=W, height=H, streams=S, qp_i=20, qp_p=23, me_range=16, deblock_alpha=0, deblock_beta=0, chroma_qp_offset=0, deadzone_inter=21,
+                             deadzone_intra=11, dct_decimate=1), **tools))
     h = C.c_void_p()
     lib.check(lib.x264gpu_encoder_create(C.byref(h), C.byref(cfg)), "create")
     n = lib.x264gpu_encoder_mb_count(h)
@@ -51,7 +51,7 @@ def main():
         torch.cuda.synchronize()
         lib.check(f(h, out.ctypes.data), "mb_prof (is this an MB_PROF build?)")
         a = out.astype(np.float64).mean(axis=0) / n
-        tot = a[:13].sum()
+        tot = a[:13].sum() + (a[15] if a[15] > 100 else 0)          # -DMB_PROF_RD builds: slot 15 = cycles of the CABAC pricing (RD sessions)
         print("%-4s %10.0f " % ("I" if i == 0 else "P", tot) + " ".join("%9.0f" % v for v in a[:13]) + " %9.2f %9.2f %9.2f" % (a[13], a[14], a[15]) + "   %.1f ms" % e0.elapsed_time(e1))
         mx = out[:, :13].sum(axis=1).astype(np.float64)
         print("     slowest/mean stream cycles: %.3f   share: " % (mx.max() / mx.mean()) + " ".join("%8.1f%%" % (100 * v / tot) for v in a[:13]))

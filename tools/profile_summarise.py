@@ -29,6 +29,14 @@ def fold(d, skip, keep):
             continue
         agg[k][r["Counter_Name"]] += float(r["Counter_Value"])
         disp[k].add(r["Dispatch_Id"])
+    for k in order:            # diagnostics for the round's log: which dispatches of the macroblock loop were folded
+        if "k_mb_slice" in k:
+            per = collections.defaultdict(dict)
+            for r in rows:
+                if r["Kernel_Name"].split("(")[0].replace("void ", "") == k:
+                    per[int(r["Dispatch_Id"])][r["Counter_Name"]] = per[int(r["Dispatch_Id"])].get(r["Counter_Name"], 0.0) + float(r["Counter_Value"])
+            print("fold", os.path.basename(d), k, "dispatches", sorted(per), "window", sorted(window[k]), "grid", sorted({r.get("Grid_Size", "?") for r in rows if r["Kernel_Name"].split("(")[0].replace("void ", "") == k}),
+                  {i: {c: "%.3g" % x for c, x in list(v.items())[:2]} for i, v in sorted(per.items())})
     return agg, disp
 
 
@@ -84,6 +92,14 @@ def main():
         for k, v in table.items():
             if not k.startswith("_"):
                 v["macroblocks_per_launch"] = b["config"]["streams_per_gpu"] * b["config"]["mb_per_frame"]
+            # the macroblock loop launches one wavefront per stream: if the counter rows of a pass fold two launches into one dispatch id the
+            # per-launch averages come out high by SQ_WAVES / streams — scale every counter of that kernel back (the factor is recorded)
+            if "k_mb_slice" in k and v.get("SQ_WAVES", 0) > 1.01 * b["config"]["streams_per_gpu"]:
+                f = v["SQ_WAVES"] / b["config"]["streams_per_gpu"]
+                for c in list(v):
+                    if isinstance(v[c], float) and c not in ("valu_per_wave", "cycles_per_wave"):
+                        v[c] = v[c] / f
+                v["launch_count_correction"] = f
     except Exception as e:  # noqa: BLE001
         table["_workload"] = {"streams_per_launch": None, "error": str(e)}
     json.dump(table, open(os.path.join(out, "pmc_per_launch.json"), "w"), indent=1, sort_keys=True)

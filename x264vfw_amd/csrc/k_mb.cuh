@@ -249,7 +249,9 @@ __device__ __forceinline__ void me_search(const EncK &k, MbLds<M> &L, const MbCt
             for (int pl = 0; pl < 4; pl++) if (i < RC_PLANE_DW) rslot[pl * RC_PLANE_DW + i] = v[pl * 5 + t];
         }
         rhave = true;
+#ifndef MB_PROF_RD
         pf.count(15);
+#endif
         if (slot == 0) { wt.ref0 = j.ref; wt.x00 = X0; wt.y00 = Y0; } else if (slot == 1) { wt.ref1 = j.ref; wt.x01 = X0; wt.y01 = Y0; } else { wt.ref2 = j.ref; wt.x02 = X0; wt.y02 = Y0; }
         lds_sync();
     };
@@ -1854,6 +1856,11 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(MB_WAVES_PER
         if constexpr (RD == 2) {
             // ---- CABAC: the candidate priced on a copy of the slice's context variables; the finished macroblock moves them on ----
             lds_sync();
+            struct RdMark { Prof &p; __device__ ~RdMark() {
+#ifdef MB_PROF_RD
+                p.mark(15);           // MB_PROF_RD builds: slot 15 = cycles of the CABAC pricing / evolution instead of the staging count
+#endif
+            } } rd_mark{ pf };
             CabIn ci;
             ci.pslice = pslice; ci.left = left; ci.top = top; ci.nref = c.nref; ci.t8mode = k.dct8x8;
             ci.type = rec_type; ci.part = e_part; ci.cbp_luma = cbp_luma; ci.cbp_chroma = cbp_chroma; ci.nnz = nnz;
