@@ -158,6 +158,30 @@ def test_pipeline_cabac_rd_bitexact(gpu, w, h, nfr, kw):
     og.close(); gg.close()
 
 
+@pytest.mark.parametrize("kw", [dict(cabac=1, rd=1, subme=7, partitions=7, dct8x8=1, refs=2, mixed_refs=1, psy=1, psy_rd_q8=256, chroma_qp_offset=-2),
+                                dict(cabac=0, rd=1, subme=6, partitions=3, refs=2), dict(cabac=1, rd=1, subme=7, slices=2, partitions=7, dct8x8=1, aq_mode=1)])
+def test_pipeline_rd_multistream(gpu, kw):
+    """RD sessions with several streams in lock-step: every stream (its own context variables, |mvd| and total_coeff side data) equals its own
+    single-stream oracle encode, context variables included"""
+    from gpu_enc import GpuEncoder
+    w, h, S, nfr = 96, 144, 4, 3
+    seqs = [synth_frames(w, h, nfr, seed=300 + 7 * s) for s in range(S)]
+    gg = GpuEncoder(O.default_config(w, h, streams=S, **kw))
+    ogs = [O.OracleEncoder(O.default_config(w, h, **kw)) for _ in range(S)]
+    for i in range(nfr):
+        st = 2 if i == 0 else 0
+        g_mb, g_lv = gg.encode([seqs[s][i] for s in range(S)], st)
+        for s in range(S):
+            o_mb, o_lv = ogs[s].encode(seqs[s][i], st)
+            compare(f"stream {s} frame {i}", (w + 15) // 16, g_mb[s], o_mb, g_lv[s], o_lv, gg.recon(s), ogs[s].recon())
+            if kw["cabac"]:
+                used = CABAC_CTX_I if st == 2 else CABAC_CTX_P
+                np.testing.assert_array_equal(gg.cabac_states(s, kw.get("slices", 1) - 1)[used], ogs[s].cabac_states()[used], err_msg=f"stream {s} picture {i}")
+    for o in ogs:
+        o.close()
+    gg.close()
+
+
 def test_pipeline_multistream(gpu):
     """streams are independent: a 3-stream lock-step batch equals three single-stream oracle encodes"""
     from gpu_enc import GpuEncoder
