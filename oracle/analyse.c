@@ -1060,7 +1060,8 @@ static void analyse_intra(actx *a, int i_satd_inter)
     }
     /* ---- 8x8 ---- */
     if ((parts & 4) && e->cfg.dct8x8) {
-        const int i_satd_thresh = i_satd_inter < a->satd_i16 ? i_satd_inter : a->satd_i16;
+        /* under RD every 8x8 block is analysed: the RD cost decides, not the running SATD sum */
+        const int i_satd_thresh = a->mbrd ? COST_MAX : i_satd_inter < a->satd_i16 ? i_satd_inter : a->satd_i16;
         int i_cost = lambda * 4, idx;
         uint8_t m8[16];
         int16_t lvtmp[256]; uint32_t nnztmp = 0;
@@ -1080,7 +1081,9 @@ static void analyse_intra(actx *a, int i_satd_inter)
                 const int favor_vertical = satd[I_PRED_4x4_H] > satd[I_PRED_4x4_V];
                 if (i_pred_mode < 3) satd[i_pred_mode] -= 3 * lambda;
                 for (int i = 2; i >= 0; i--) if (satd[i] < i_best) { i_best = satd[i]; bestm = i; }
-                predict_mode = intra_analysis_shortcut[predict_mode[8] >= 0][favor_vertical];       /* i_mbrd == 0 */
+                /* analysis shortcut: skip the modes far from the favoured direction — unless RD decides and fast-intra is off (i_mbrd < 1 + b_fast_intra) */
+                if (a->mbrd < 1 + a->b_fast_intra) predict_mode = intra_analysis_shortcut[predict_mode[8] >= 0][favor_vertical];
+                else predict_mode += 3;
             }
             for (; *predict_mode >= 0 && i_best >= 0; predict_mode++) {
                 const int m = *predict_mode;
@@ -1114,6 +1117,7 @@ static void analyse_intra(actx *a, int i_satd_inter)
         int i_cost = lambda * (24 + 16), idx;
         int i_satd_thresh = COST_MAX;
         if (a->b_early_terminate) { i_satd_thresh = i_satd_inter < a->satd_i16 ? i_satd_inter : a->satd_i16; if (a->satd_i8 < i_satd_thresh) i_satd_thresh = a->satd_i8; }
+        if (a->b_early_terminate && a->mbrd) i_satd_thresh = (int)((int64_t)i_satd_thresh * (10 - a->b_fast_intra) / 8);      /* RD: a little slack, the SATD order is not final */
         uint8_t m4[16];
         int16_t l16[16];
         memset(m4, 2, sizeof(m4));
@@ -1132,7 +1136,8 @@ static void analyse_intra(actx *a, int i_satd_inter)
                 i_best = satd[I_PRED_4x4_DC]; bestm = I_PRED_4x4_DC;
                 if (satd[I_PRED_4x4_H] < i_best) { i_best = satd[I_PRED_4x4_H]; bestm = I_PRED_4x4_H; }
                 if (satd[I_PRED_4x4_V] < i_best) { i_best = satd[I_PRED_4x4_V]; bestm = I_PRED_4x4_V; }
-                predict_mode = intra_analysis_shortcut[predict_mode[8] >= 0][favor_vertical];
+                if (a->mbrd < 1 + a->b_fast_intra) predict_mode = intra_analysis_shortcut[predict_mode[8] >= 0][favor_vertical];
+                else predict_mode += 3;
             }
             if (i_best > 0)
                 for (; *predict_mode >= 0; predict_mode++) {

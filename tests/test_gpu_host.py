@@ -38,7 +38,7 @@ def eff_kw(eff):
     compensation), entropy coder, vector range"""
     rd = int(eff.analyse.i_subpel_refine >= 6)
     q8 = int(eff.analyse.f_psy_rd * 256.0 + 0.5) if rd and eff.analyse.b_psy else 0
-    return dict(subme=eff.analyse.i_subpel_refine, rd=rd, psy=int(q8 != 0), psy_rd_q8=q8, chroma_qp_offset=eff.analyse.i_chroma_qp_offset,
+    return dict(subme=eff.analyse.i_subpel_refine, rd=rd, psy=int(rd and eff.analyse.b_psy), psy_rd_q8=q8, chroma_qp_offset=eff.analyse.i_chroma_qp_offset,
                 mv_range=eff.analyse.i_mv_range, cabac=eff.b_cabac)
 
 
@@ -96,7 +96,8 @@ def test_encode_api_closed_loop(gpu, w, h, opts):
         np.testing.assert_array_equal(dec[i], recons[i], err_msg=f"decoded picture {i} != encoder reconstruction")
 
 
-@pytest.mark.parametrize("opts,subme,cqo", [({}, 7, -2), ({"no-psy": None}, 7, 0), ({"psy-rd": "0.1:0", "subme": 6}, 6, -1), ({"subme": 9, "chroma-qp-offset": 3}, 7, 1)])
+@pytest.mark.parametrize("opts,subme,cqo", [({}, 7, -2), ({"no-psy": None}, 7, 0), ({"psy-rd": "0.1:0", "subme": 6}, 6, -1), ({"subme": 9, "chroma-qp-offset": 3}, 7, 1),
+                                            ({"psy-rd": "0:0"}, 7, 0)])       # psy on at strength 0: no energy term, no offset change, but the chroma lambda table applies
 def test_rd_session_equals_oracle_pipeline(gpu, opts, subme, cqo):
     """preset medium without CABAC (Baseline profile): subme 7 = RD mode decision on the device with CAVLC bit counts and psy-RD; x264 lowers
     the chroma quantiser offset to compensate psy (by 2, or 1 below psy-rd 0.25), and levels above 7 (RD refinement) come back as 7.  The

@@ -720,7 +720,7 @@ __device__ __forceinline__ int i4_pred_mode(const uint8_t *nm, int mbx, int mby,
 // directional modes near the favoured direction; list order and "first strictly better" decide ties).  raw(m) = cost of mode m (the
 // caller fetches it from the lanes that computed it).  Returns the cost incl. the predicted-mode bonus; lists are nibble strings, 15 ends one.
 template <class F>
-__device__ __forceinline__ int pick_intra_mode(F raw, int avail, int pm, int lambda, bool is4, int &bestm)
+__device__ __forceinline__ int pick_intra_mode(F raw, int avail, int pm, int lambda, bool is4, bool every_mode, int &bestm)
 {
     const int all3 = AVAIL_LEFT | AVAIL_TOP | AVAIL_TOPLEFT;
     const int id = (avail & all3) == all3 ? 4 : avail & (AVAIL_LEFT | AVAIL_TOP);
@@ -734,7 +734,8 @@ __device__ __forceinline__ int pick_intra_mode(F raw, int avail, int pm, int lam
         best = sdc; bestm = 2;
         if (sh < best) { best = sh; bestm = 1; }
         if (sv < best) { best = sv; bestm = 0; }
-        rest = id == 4 ? (fv ? 0xF7543u : 0xF864u) : (fv ? 0xF73u : 0xF8u);
+        // x264's analysis shortcut (modes near the favoured direction only) — or, when RD decides and fast-intra is off, every remaining mode
+        rest = every_mode ? (id == 4 ? 0xF876543u : 0xF873u) : id == 4 ? (fv ? 0xF7543u : 0xF864u) : (fv ? 0xF73u : 0xF8u);
     } else rest = id == 0 ? 0xF2u : id == 1 ? 0xF812u : 0xF7302u;
     if (is4) {
         if (best > 0)
@@ -759,8 +760,9 @@ struct IntraRes { int satd_i16, satd_i8, satd_i4, pred16; unsigned nnz4, nnz8; i
 // Needs the neighbour samples in L.tile / L.tile8 / L.nb and the neighbour macroblocks' edge modes in L.nmodes.
 template <int M>
 __device__ __forceinline__ void mb_analyse_intra(const EncK &k, MbLds<M> &L, const MbCtx &c, uint32_t cz, uint32_t t4, int parts, int i_satd_inter,
-                                                 bool fast_intra, bool early_term, const Q4 &q4, const Q8 &q8, IntraRes &R)
+                                                 bool fast_intra, bool early_term, bool mbrd, const Q4 &q4, const Q8 &q8, IntraRes &R)
 {
+    const bool every_mode = mbrd && !fast_intra;          // x264: i_mbrd >= 1 + b_fast_intra
     const int lane = c.lane, j = lane & 3, zx = z_x0(lane), zy = z_y(lane), lambda = c.lambda;
     const bool left = c.mbx > 0, top = c.sy > 0, topright = top && c.mbx + 1 < k.mbw;
     const int sm = min(c.subme, 10);
@@ -788,7 +790,7 @@ __device__ __forceinline__ void mb_analyse_intra(const EncK &k, MbLds<M> &L, con
     }
     // ---- 8x8: R8 layout, lane = (mode group, row); eight modes in one pass, the ninth in a second ----
     if ((parts & 4) && k.dct8x8) {
-        const int thresh = min(i_satd_inter, R.satd_i16);
+        const int thresh = mbrd ? MB_COST_MAX : min(i_satd_inter, R.satd_i16);       // RD: every block is analysed
         const int g = lane >> 3, r8 = lane & 7;
         if (lane < 16) L.modes8[lane] = 2;
         int i_cost = lambda * 4, idx;
@@ -813,7 +815,7 @@ __device__ __forceinline__ void mb_analyse_intra(const EncK &k, MbLds<M> &L, con
             pred8_row8(L.U8, L.pred8tab, 8, r8, p2lo, p2hi);
             const int c2 = cost8(p2lo, p2hi);
             int bm;
-            const int best = pick_intra_mode([&](int m) { return m < 8 ? rl(c1, m * 8) : rl(c2, 0); }, avail, pm, lambda, false, bm);
+            const int best = pick_intra_mode([&](int m) { return m < 8 ? rl(c1, m * 8) : rl(c2, 0); }, avail, pm, lambda, false, every_mode, bm);
             i_cost += best + 3 * lambda;
             if (lane < 4) L.modes8[idx * 4 + lane] = (uint8_t)bm;
             if (idx < 3 && i_cost > thresh) break;
@@ -862,7 +864,8 @@ __device__ __forceinline__ void mb_analyse_intra(const EncK &k, MbLds<M> &L, con
     }
     // ---- 4x4: nine modes per block in parallel (one quad of lanes per mode), blocks in coding order ----
     if (parts & 2) {
-        const int thresh = early_term ? min(min(i_satd_inter, R.satd_i16), R.satd_i8) : MB_COST_MAX;
+        int thresh = early_term ? min(min(i_satd_inter, R.satd_i16), R.satd_i8) : MB_COST_MAX;
+        if (early_term && mbrd) thresh = (int)((long long)thresh * (fast_intra ? 9 : 10) / 8);       // RD: a little slack, the SATD order is not final
         if (lane < 16) L.modes4[lane] = 2;
         int i_cost = lambda * (24 + 16), idx;
         for (idx = 0;; idx++) {
@@ -876,7 +879,7 @@ __device__ __forceinline__ void mb_analyse_intra(const EncK &k, MbLds<M> &L, con
             const uint32_t en = (uint32_t)__shfl((int)cz, idx * 4 + j);
             const int sat = quad_sum(c.satd ? satd4_half(en, pr, lane) : sad4(en, pr));
             int bm;
-            const int best = pick_intra_mode([&](int m) { return rl(sat, m * 4); }, avail, pm, lambda, true, bm);
+            const int best = pick_intra_mode([&](int m) { return rl(sat, m * 4); }, avail, pm, lambda, true, every_mode, bm);
             i_cost += best + 3 * lambda;
             if (lane == 0) L.modes4[idx] = (uint8_t)bm;
             if (idx < 15 && i_cost > thresh) break;
@@ -1513,7 +1516,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(MB_WAVES_PER
             // otherwise only for macroblocks that end up intra — same mode either way); its cost enters the comparison under chroma-ME only
             satd_chroma = mb_intra_chroma_cost(k, L, c, predc);
             pf.mark(PH_INTRA_CHROMA);
-            mb_analyse_intra(k, L, c, cz, t4, parts, c.chroma_me ? i_satd_inter - satd_chroma : i_satd_inter, fast_intra, early_term, q_li, q8i, IR);
+            mb_analyse_intra(k, L, c, cz, t4, parts, c.chroma_me ? i_satd_inter - satd_chroma : i_satd_inter, fast_intra, early_term, rdon, q_li, q8i, IR);
             if (c.chroma_me) { IR.satd_i16 += satd_chroma; IR.satd_i8 += satd_chroma; IR.satd_i4 += satd_chroma; }
             if (pslice) {
                 if (lane == 0) { recd.aux[0] = i_satd_inter; recd.aux[1] = min(min(IR.satd_i16, IR.satd_i8), IR.satd_i4); recd.aux[2] = rl(S.cost, ME_16); }

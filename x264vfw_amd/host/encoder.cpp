@@ -307,7 +307,8 @@ x264_t *x264_encoder_open(x264_param_t *param)
     cfg.qp_i = h->qp_i; cfg.qp_p = h->qp_p; cfg.me_range = p.analyse.i_me_range; cfg.subme = p.analyse.i_subpel_refine;
     cfg.deblock = p.b_deblocking_filter; cfg.deblock_alpha = p.i_deblocking_filter_alphac0; cfg.deblock_beta = p.i_deblocking_filter_beta;
     cfg.chroma_qp_offset = eff_chroma_qp_offset;
-    cfg.rd = p.analyse.i_subpel_refine >= 6; cfg.psy = psy_rd_q8 != 0; cfg.psy_rd_q8 = psy_rd_q8;
+    cfg.rd = p.analyse.i_subpel_refine >= 6; cfg.psy_rd_q8 = psy_rd_q8;
+    cfg.psy = cfg.rd && p.analyse.b_psy;           // x264: the chroma lambda offset table follows b_psy, whatever the psy-rd strength
     cfg.deadzone_inter = p.analyse.i_luma_deadzone[0]; cfg.deadzone_intra = p.analyse.i_luma_deadzone[1];
     cfg.dct_decimate = p.analyse.b_dct_decimate;
     // P slices follow analyse.inter, I slices analyse.intra (bit8 marks the separate I-slice set)
