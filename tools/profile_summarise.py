@@ -81,9 +81,8 @@ def main():
             # (MI355X_MICROARCH.md "HBM"): the read side is doubled, which is an upper bound for narrower accesses.
             v["hbm_bytes_per_launch_raw"] = (v["FETCH_SIZE"] + v["WRITE_SIZE"]) * 1024
             v["hbm_bytes_per_launch_corrected"] = (2 * v["FETCH_SIZE"] + v["WRITE_SIZE"]) * 1024
-        if "SQ_INSTS_VALU" in v and "SQ_WAVES" in v and v["SQ_WAVES"]:
-            v["valu_per_wave"] = v["SQ_INSTS_VALU"] / v["SQ_WAVES"]
-            v["cycles_per_wave"] = v["SQ_WAVE_CYCLES"] / v["SQ_WAVES"]
+        # (SQ_WAVES itself reads 8/7 of the launched wavefronts on this part — 2340.57 for 2048 one-wave workgroups, on every dispatch —
+        #  while the instruction and cycle counters add up for 2048: per-wave figures are not derived from it)
     # streams (= frames) one launch covers in the profiled command, so bench.py only quotes these
     # figures for the same workload
     try:
@@ -92,14 +91,6 @@ def main():
         for k, v in table.items():
             if not k.startswith("_"):
                 v["macroblocks_per_launch"] = b["config"]["streams_per_gpu"] * b["config"]["mb_per_frame"]
-            # the macroblock loop launches one wavefront per stream: if the counter rows of a pass fold two launches into one dispatch id the
-            # per-launch averages come out high by SQ_WAVES / streams — scale every counter of that kernel back (the factor is recorded)
-            if "k_mb_slice" in k and v.get("SQ_WAVES", 0) > 1.01 * b["config"]["streams_per_gpu"]:
-                f = v["SQ_WAVES"] / b["config"]["streams_per_gpu"]
-                for c in list(v):
-                    if isinstance(v[c], float) and c not in ("valu_per_wave", "cycles_per_wave"):
-                        v[c] = v[c] / f
-                v["launch_count_correction"] = f
     except Exception as e:  # noqa: BLE001
         table["_workload"] = {"streams_per_launch": None, "error": str(e)}
     json.dump(table, open(os.path.join(out, "pmc_per_launch.json"), "w"), indent=1, sort_keys=True)
