@@ -184,14 +184,16 @@ typedef struct x264gpu_config {
                                * under CABAC the P8x8 sub-macroblock type costs nothing (no sub-8x8 analysis here) and reference 0 of a P8x8 macroblock is
                                * costed like any other; under CAVLC P_8x8ref0 makes it free ([x264-upstream] analyse.c x264_mb_analyse_inter_p8x8*) */
     int rd;                   /* 1: x264's RD mode decision of subme 6 / 7 (i_mbrd 1: x264_rd_cost_mb = SSD + psy + lambda2 x bits over the candidate
-                               * macroblock types, transform-size RD, P_SKIP by RD; no final quarter-pel refinement), with CAVLC bit counts: requires
-                               * cabac == 0 (the CABAC counts need the coder's live context states on the device: not implemented) */
+                               * macroblock types, transform-size RD, P_SKIP by RD; no final quarter-pel refinement).  Bits: exact CAVLC counts
+                               * (cabac == 0), or x264's size-only CABAC on the slice's context variables, which the device carries (cabac == 1) */
     int psy;                  /* x264 analyse.b_psy (default on): chroma lambda offset of the RD costs */
     int psy_rd_q8;            /* x264 FIX8(--psy-rd strength) (medium: 256); enters the RD costs (subme >= 6) */
     int slices;               /* x264 --sliced-threads with --threads N: N slices per picture (0 / 1 = one), slice i = macroblock rows
                                * [(mbh * i + N/2) / N, (mbh * (i+1) + N/2) / N); every slice is analysed on its own (no prediction across a slice
                                * boundary, its own fast-intra statistics and quantiser chain) and the loop filter leaves slice boundaries alone
                                * (disable_deblocking_filter_idc 2), as x264's slice threads do.  At most mbh / 4 ([x264-upstream] validate_parameters) */
+    int trellis;              /* x264 --trellis 1 (the final encode of every macroblock quantised by the trellis search on the slice's CABAC state):
+                               * NOT IMPLEMENTED ON THE DEVICE YET — must be 0 (the checker restates it already: oracle/trellis.cpp, TRELLIS_NOTES.md) */
 } x264gpu_config;
 
 int  x264gpu_encoder_create(x264gpu_encoder **enc, const x264gpu_config *cfg);

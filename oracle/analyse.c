@@ -493,6 +493,27 @@ static void me_refine_qpel(const actx *a, me_t *m)
  * residual coding (encoder/macroblock.c) */
 static void scan4(int16_t *dst, const dctcoef *src) { for (int k = 0; k < 16; k++) dst[k] = src[x264o_zigzag4[k]]; }
 
+/* The quantiser calls of x264_macroblock_encode: the dead-zone quantiser, or — in the final encode of a macroblock of a trellis session
+ * (e->b_trellis; x264 h->mb.b_trellis under --trellis 1) — the trellis search of trellis.cpp on the slice's live context variables.
+ * cat = CABAC block category, qp = the block's quantiser (chroma: the chroma one) */
+int x264o_quant_trellis_cabac(dctcoef *dct, const uint16_t *mf, int qp, int cat, int intra, const uint8_t *state);
+static int quant_4x4(x264o_encoder *e, dctcoef *d, const uint16_t *mf, const uint16_t *bias, int qp, int cat, int intra)
+{
+    return e->b_trellis ? x264o_quant_trellis_cabac(d, mf, qp, cat, intra, e->cabac_state) : x264o_quant_4x4(d, mf, bias);
+}
+static int quant_8x8(x264o_encoder *e, dctcoef *d, const uint16_t *mf, const uint16_t *bias, int qp, int intra)
+{
+    return e->b_trellis ? x264o_quant_trellis_cabac(d, mf, qp, 5, intra, e->cabac_state) : x264o_quant_8x8(d, mf, bias);
+}
+static int quant_4x4_dc(x264o_encoder *e, dctcoef *d, const uint16_t *mf, const uint16_t *bias, int qp)
+{
+    return e->b_trellis ? x264o_quant_trellis_cabac(d, mf, qp, 0, 1, e->cabac_state) : x264o_quant_4x4_dc(d, mf[0] >> 1, bias[0] << 1);
+}
+static int quant_2x2_dc(x264o_encoder *e, dctcoef *d, const uint16_t *mf, const uint16_t *bias, int qp, int intra)
+{
+    return e->b_trellis ? x264o_quant_trellis_cabac(d, mf, qp, 3, intra, e->cabac_state) : x264o_quant_2x2_dc(d, mf[0] >> 1, bias[0] << 1);
+}
+
 /* inter luma, 4x4 transform: prediction in rec; returns through mb: nnz, cbp_luma; levels in lv */
 static void encode_luma_inter(x264o_encoder *e, const pixel *fenc, pixel *rec, int qp, x264gpu_mb *mb, int16_t *lv)
 {
@@ -501,7 +522,7 @@ static void encode_luma_inter(x264o_encoder *e, const pixel *fenc, pixel *rec, i
     const uint16_t *mf = e->qt.quant4_mf[X264O_CQM_4PY][qp], *bias = e->qt.quant4_bias[X264O_CQM_4PY][qp];
     for (int b = 0; b < 16; b++) {
         x264o_sub4x4_dct(d[b], fenc + blk_y[b] * 4 * e->fs + blk_x[b] * 4, e->fs, rec + blk_y[b] * 4 * e->rs + blk_x[b] * 4, e->rs);
-        nz[b] = x264o_quant_4x4(d[b], mf, bias);
+        nz[b] = quant_4x4(e, d[b], mf, bias, qp, 2, 0);
         scan4(lv + b * 16, d[b]);
         if (nz[b] && e->cfg.dct_decimate) score8[b >> 2] += x264o_decimate_score(lv + b * 16, 16);
     }
@@ -531,7 +552,7 @@ static void encode_luma_inter8(x264o_encoder *e, const pixel *fenc, pixel *rec, 
     const uint16_t *mf = e->qt.quant8_mf[X264O_CQM_8PY][qp], *bias = e->qt.quant8_bias[X264O_CQM_8PY][qp];
     for (int i8 = 0; i8 < 4; i8++) {
         x264o_sub8x8_dct8(d[i8], fenc + (i8 >> 1) * 8 * e->fs + (i8 & 1) * 8, e->fs, rec + (i8 >> 1) * 8 * e->rs + (i8 & 1) * 8, e->rs);
-        keep[i8] = x264o_quant_8x8(d[i8], mf, bias);
+        keep[i8] = quant_8x8(e, d[i8], mf, bias, qp, 0);
         for (int k = 0; k < 64; k++) scan[i8][k] = d[i8][x264o_zigzag8[k]];
         if (keep[i8] && e->cfg.dct_decimate) {
             const int sc = x264o_decimate_score(scan[i8], 64);
@@ -585,7 +606,7 @@ static void encode_chroma(x264o_encoder *e, const pixel *fenc_uv, pixel *rec_uv,
                     dc[i] = (dctcoef)sm;
                 }
                 x264o_dct2x2dc(dc);
-                if (!x264o_quant_2x2_dc(dc, mf[0] >> 1, bias[0] << 1)) continue;
+                if (!quant_2x2_dc(e, dc, mf, bias, qpc, !inter)) continue;
                 if (!x264o_optimize_chroma_2x2_dc(dc, dmf)) continue;
                 for (int i = 0; i < 4; i++) lv[X264GPU_LV_CHROMA_DC + c * 4 + i] = dc[i];
                 dctcoef dq[4];
@@ -603,14 +624,14 @@ static void encode_chroma(x264o_encoder *e, const pixel *fenc_uv, pixel *rec_uv,
             const int o = (i >> 1) * 32 + (i & 1) * 4;
             x264o_sub4x4_dct(d[i], f[c] + o, 8, p[c] + o, 8);
             dc[i] = d[i][0]; d[i][0] = 0;
-            nz[i] = x264o_quant_4x4(d[i], mf, bias);
+            nz[i] = quant_4x4(e, d[i], mf, bias, qpc, 4, !inter);
             int16_t *l = lv + X264GPU_LV_CHROMA_AC + (c * 4 + i) * 16;
             scan4(l, d[i]);
             if (nz[i]) { nzac = 1; if (b_decimate) score += x264o_decimate_score(l + 1, 15); }
         }
         if (nzac && b_decimate && score < 7) nzac = 0;
         x264o_dct2x2dc(dc);
-        int nzdc = x264o_quant_2x2_dc(dc, mf[0] >> 1, bias[0] << 1);
+        int nzdc = quant_2x2_dc(e, dc, mf, bias, qpc, !inter);
         /* DC-only planes: x264_mb_optimize_chroma_dc trims the DC levels that do not change the reconstruction */
         if (nzdc && !nzac && !x264o_optimize_chroma_2x2_dc(dc, dmf)) { nzdc = 0; dc[0] = dc[1] = dc[2] = dc[3] = 0; }
         for (int i = 0; i < 4; i++) lv[X264GPU_LV_CHROMA_DC + c * 4 + i] = dc[i];
@@ -636,7 +657,7 @@ static int encode_i4x4(x264o_encoder *e, const pixel *f, pixel *r, int qp, int16
 {
     dctcoef d[16];
     x264o_sub4x4_dct(d, f, e->fs, r, e->rs);
-    if (!x264o_quant_4x4(d, e->qt.quant4_mf[X264O_CQM_4IY][qp], e->qt.quant4_bias[X264O_CQM_4IY][qp])) { memset(l, 0, 32); return 0; }
+    if (!quant_4x4(e, d, e->qt.quant4_mf[X264O_CQM_4IY][qp], e->qt.quant4_bias[X264O_CQM_4IY][qp], qp, 2, 1)) { memset(l, 0, 32); return 0; }
     scan4(l, d);
     x264o_dequant_4x4(d, e->qt.dequant4_mf, qp);
     x264o_add4x4_idct(r, e->rs, d);
@@ -646,7 +667,7 @@ static int encode_i8x8(x264o_encoder *e, const pixel *f, pixel *r, int qp, int i
 {
     dctcoef d[64];
     x264o_sub8x8_dct8(d, f, e->fs, r, e->rs);
-    if (!x264o_quant_8x8(d, e->qt.quant8_mf[X264O_CQM_8IY][qp], e->qt.quant8_bias[X264O_CQM_8IY][qp])) return 0;
+    if (!quant_8x8(e, d, e->qt.quant8_mf[X264O_CQM_8IY][qp], e->qt.quant8_bias[X264O_CQM_8IY][qp], qp, 1)) return 0;
     for (int k = 0; k < 64; k++) {
         const int16_t v = d[x264o_zigzag8[k]];
         lv256[(i8 * 4 + (k & 3)) * 16 + (k >> 2)] = v;
@@ -670,7 +691,7 @@ static void encode_i16x16(x264o_encoder *e, const pixel *fenc, pixel *rec, int q
     for (int b = 0; b < 16; b++) {
         x264o_sub4x4_dct(d[b], fenc + blk_y[b] * 4 * e->fs + blk_x[b] * 4, e->fs, rec + blk_y[b] * 4 * e->rs + blk_x[b] * 4, e->rs);
         dc[blk_y[b] * 4 + blk_x[b]] = d[b][0]; d[b][0] = 0;
-        nz[b] = x264o_quant_4x4(d[b], mf, bias);
+        nz[b] = quant_4x4(e, d[b], mf, bias, qp, 1, 1);
         scan4(lv + b * 16, d[b]);
         if (nz[b]) { any_ac = 1; x264o_dequant_4x4(d[b], e->qt.dequant4_mf, qp); if (score < 6) score += x264o_decimate_score(lv + b * 16 + 1, 15); }
     }
@@ -682,7 +703,7 @@ static void encode_i16x16(x264o_encoder *e, const pixel *fenc, pixel *rec, int q
     }
     mb->cbp_luma = any_ac ? 15 : 0;
     x264o_dct4x4dc(dc);
-    const int nzdc = x264o_quant_4x4_dc(dc, mf[0] >> 1, bias[0] << 1);
+    const int nzdc = quant_4x4_dc(e, dc, mf, bias, qp);
     scan4(lv + X264GPU_LV_LUMA_DC, dc);
     if (nzdc) { mb->nnz |= 1u << 24; x264o_idct4x4dc(dc); x264o_dequant_4x4_dc(dc, e->qt.dequant4_mf, qp); }
     for (int b = 0; b < 16; b++) {
@@ -1484,7 +1505,9 @@ static void macroblock_body(x264o_encoder *e, int mbx, int mby, actx *a)
         if (a->satd_i8 < i_cost) { i_cost = a->satd_i8; type = X264GPU_MB_I8x8; }
         if (a->mbrd) rd_reset(a, mb, lv);
         mb->cost = i_cost;
+        e->b_trellis = e->cfg.trellis && e->cfg.cabac;          /* --trellis 1: the final encode only */
         encode_intra_mb(a, type, mb, lv);
+        e->b_trellis = 0;
         e->intra_count++;
         return;
     }
@@ -1592,7 +1615,9 @@ static void macroblock_body(x264o_encoder *e, int mbx, int mby, actx *a)
     mb->cost = i_cost;
 
     if (is_intra_type(i_type)) {
+        e->b_trellis = e->cfg.trellis && e->cfg.cabac;
         encode_intra_mb(a, i_type, mb, lv);
+        e->b_trellis = 0;
         e->intra_count++;
         return;
     }
@@ -1602,7 +1627,9 @@ static void macroblock_body(x264o_encoder *e, int mbx, int mby, actx *a)
         mb->ref[k] = (int8_t)m->ref; mb->mv[k][0] = (int16_t)m->mv[0]; mb->mv[k][1] = (int16_t)m->mv[1];
     }
     a->force_t8 = t8;                 /* RD: the transform size chosen by transform_rd; else SA8D vs SATD */
+    e->b_trellis = e->cfg.trellis && e->cfg.cabac;
     encode_inter_mb(a, mb, lv);
+    e->b_trellis = 0;
 }
 
 void x264o_macroblock(x264o_encoder *e, int mbx, int mby)
@@ -1613,7 +1640,7 @@ void x264o_macroblock(x264o_encoder *e, int mbx, int mby)
     /* diagnostics for the tests: what mb_bits_cavlc says the macroblock layer of the final macroblock takes (0 for P_SKIP: it lives in a run) */
     if (e->mb_bits && !e->cfg.cabac) e->mb_bits[A.mi] = mb->type == X264GPU_MB_P_SKIP ? 0 : mb_bits_cavlc(&A, mb, e->levels + (size_t)A.mi * X264GPU_MB_LEVELS);
     /* CABAC RD sessions: the finished macroblock moves the slice's context states on, as its entropy coding will */
-    if (e->cfg.cabac && e->cfg.rd) {
+    if (e->cfg.cabac && (e->cfg.rd || e->cfg.trellis)) {
         x264o_cabac_ctx cc;
         if (e->mb_bits && mb->type != X264GPU_MB_P_SKIP) {          /* diagnostics: the size estimate of the final macroblock, 1/256 bits */
             uint8_t st[460];

@@ -256,7 +256,7 @@ int x264o_encoder_encode(x264o_encoder *e, const uint8_t *i420, int slice_type, 
         /* x264 slice threads: rows split evenly; each thread starts with empty frame statistics (h->stat.frame) */
         e->row0 = (e->mbh * sl + ns / 2) / ns; e->row1 = (e->mbh * (sl + 1) + ns / 2) / ns;
         e->intra_count = 0; e->last_qp = slice_qp;
-        if (e->cfg.cabac && e->cfg.rd) { x264o_cabac_init_states(e->cabac_state, slice_type == X264GPU_SLICE_P, slice_qp); e->last_dqp = 0; }
+        if (e->cfg.cabac && (e->cfg.rd || e->cfg.trellis)) { x264o_cabac_init_states(e->cabac_state, slice_type == X264GPU_SLICE_P, slice_qp); e->last_dqp = 0; }
         for (int mby = e->row0; mby < e->row1; mby++)
             for (int mbx = 0; mbx < e->mbw; mbx++) {
                 x264o_macroblock(e, mbx, mby);

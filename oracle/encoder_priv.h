@@ -53,6 +53,7 @@ struct x264o_encoder {
      * previous macroblock's mb_qp_delta and every 8x8 block's |mvd| (cabac_rd.cpp) */
     uint8_t cabac_state[460];
     int last_dqp;
+    int b_trellis;               /* the macroblock's FINAL encode of a trellis session is running (h->mb.b_trellis under --trellis 1) */
     uint8_t *amvd;
 };
 

@@ -65,6 +65,10 @@ void x264o_quant_init(x264o_quant_tables *t, int deadzone_inter, int deadzone_in
     }
 }
 
+/* trellis: the direct inverse of the quantiser in the forward transform's scale (x264 unquant4_mf / unquant8_mf, flat matrices) */
+int x264o_unquant4(int qp, int pos) { return (int)((1ull << (qp / 6 + 15 + 8)) / quant4_scale[qp % 6][class4(pos)]); }
+int x264o_unquant8(int qp, int pos) { return (int)((1ull << (qp / 6 + 16 + 8)) / quant8_scale[qp % 6][class8(pos)]); }
+
 static inline int quant_one(int c, int mf, int bias)
 {
     return c > 0 ? ((bias + c) * mf) >> 16 : -(((bias - c) * mf) >> 16);

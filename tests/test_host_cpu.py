@@ -383,3 +383,41 @@ def test_cabac_rd_states_and_sizes_follow_the_real_coder(w, h, kw):
         total_real += 8 * len(nal)
     assert len(O.h264_decode(stream, nfr, w, h)) == nfr
     assert abs(total_est - total_real) < 0.06 * total_real + 64 * nfr, (total_est, total_real)
+
+
+@pytest.mark.parametrize("w,h,kw", [(176, 144, dict(partitions=7, dct8x8=1, refs=2, mixed_refs=1, chroma_me=1, rd=1, subme=7, psy=1, psy_rd_q8=256, chroma_qp_offset=-2)),
+                                     (176, 144, dict(partitions=7, dct8x8=1, refs=2, mixed_refs=1, chroma_me=1, rd=1, subme=7)),
+                                     (176, 144, dict(partitions=3, refs=1, subme=5)), (96, 80, dict(partitions=7, dct8x8=1, qp_i=12, qp_p=14, subme=5)),
+                                     (96, 80, dict(partitions=7, dct8x8=1, qp_i=40, qp_p=43, rd=1, subme=6))])
+def test_oracle_trellis_streams_decode_and_pay_off(w, h, kw):
+    """trellis quantisation in the checker (oracle/trellis.cpp, x264 --trellis 1; the device does not have it yet): the levels it picks are
+    ordinary levels — the stream written from them decodes to the encoder's own reconstruction — and the search pays off in rate-distortion
+    terms: PSNR gained plus the bits saved (at this content's ~3.3 dB per doubling of the rate) is positive.  With psy-RD on the mode
+    decision pulls the other way (it buys back the energy the trellis removed), so that case only checks the stream"""
+    nfr = 6
+    frames = synth_frames(w, h, nfr, seed=5 * w + h)
+    mbw, mbh = (w + 15) // 16, (h + 15) // 16
+    res = {}
+    for trellis in (0, 1):
+        cfg = O.default_config(w, h, cabac=1, trellis=trellis, **kw)
+        enc = O.OracleEncoder(cfg)
+        stream = HL.write_headers(w, h, pic_init_qp=cfg.qp_p, num_ref=cfg.refs, t8x8=cfg.dct8x8, cabac=1, cqo=cfg.chroma_qp_offset)
+        recs, bits = [], 0
+        for i, f in enumerate(frames):
+            idr = i == 0
+            mbs, lv = enc.encode(f, 2 if idr else 0)
+            nal = HL.write_slice(mbw, mbh, 2 if idr else 0, cfg.qp_i if idr else cfg.qp_p, cfg.qp_p, i, 8, int(idr), 0, 0, mbs, lv,
+                                 num_ref=max(1, min(cfg.refs, i)), num_ref_default=cfg.refs, t8x8=cfg.dct8x8, cabac=1)[0]
+            stream += nal; bits += 8 * len(nal)
+            recs.append(enc.recon().copy())
+        dec = O.h264_decode(stream, nfr, w, h)
+        assert len(dec) == nfr
+        sse = 0.0
+        for i in range(nfr):
+            np.testing.assert_array_equal(dec[i], recs[i], err_msg=f"trellis {trellis} picture {i}")
+            sse += float(((recs[i][:w * h].astype(np.int64) - frames[i][:w * h].astype(np.int64)) ** 2).sum())
+        res[trellis] = (bits, 10 * np.log10(255.0 ** 2 * w * h * nfr / max(sse, 1.0)))
+    (b0, p0), (b1, p1) = res[0], res[1]
+    assert b1 != b0, res
+    if not kw.get("psy"):
+        assert (p1 - p0) + 3.3 * np.log2(b0 / b1) > 0.05, res
