@@ -86,6 +86,11 @@ int x264gpu_mc_chroma(const uint8_t *d_nv12_00, int stride, const int32_t *d_xy,
  * avg: weight1 == 32 -> (a + b + 1) >> 1, else clip((a * weight1 + b * (64 - weight1) + 32) >> 6);
  * weight: clip(((src * scale + (1 << (denom - 1))) >> denom) + offset), denom 0: clip(src * scale + offset). */
 int x264gpu_mc_avg(const uint8_t *d_a, const uint8_t *d_b, size_t bytes, int weight1, uint8_t *d_out, void *stream);
+/* x264's CABAC trellis quantiser (--trellis 1; [x264-upstream] encoder/rdo.c quant_trellis_cabac) as a primitive: nblk blocks of block category
+ * cat (0 luma DC, 1 luma AC, 2 luma 4x4, 3 chroma DC, 4 chroma AC, 5 luma 8x8), coefficients in scan order (16 per block; 64 for cat 5, 4 for
+ * cat 3; AC blocks: entry 0 unused = 0), quantiser qp, inter / intra lambda, against the 460 context variables ((pStateIdx << 1) | valMPS) of a
+ * slice.  d_levels receives the levels in the same layout, d_nz one byte per block.  The macroblock loop does not use it yet (cfg.trellis). */
+int x264gpu_trellis_blocks(const int16_t *d_coefs, int nblk, int cat, int qp, int intra, const uint8_t *d_states460, int16_t *d_levels, uint8_t *d_nz, void *stream);
 int x264gpu_mc_weight(const uint8_t *d_src, size_t bytes, int scale, int denom, int offset, uint8_t *d_out, void *stream);
 
 /* ---- input colourspace conversion to I420 -----------------------------------------

@@ -69,6 +69,7 @@ int x264gpu_encoder_set_stream_qps(x264gpu_encoder *g, const int8_t *qps)
     if (qps) { g->sqp = malloc((size_t)g->cfg.streams); memcpy(g->sqp, qps, (size_t)g->cfg.streams); }
     return X264GPU_OK;
 }
+int x264gpu_trellis_blocks(const int16_t *c, int n, int cat, int qp, int intra, const uint8_t *s, int16_t *l, uint8_t *z, void *st) { return fail("trellis primitive: not in the stub"); }
 int x264gpu_encoder_cabac_states(x264gpu_encoder *g, int stream, int slice, uint8_t *out) { return fail("context states: not in the stub"); }
 int x264gpu_encoder_set_lowres_mvs(x264gpu_encoder *g, const int16_t *mv) { return mv ? fail("lowres vectors: not in the stub") : X264GPU_OK; }
 int x264gpu_encode_frames(x264gpu_encoder *g, const uint8_t *i420, int slice_type, x264gpu_mb *mb, int16_t *lv, void *st)

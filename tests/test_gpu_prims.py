@@ -301,3 +301,70 @@ def test_deblock_primitive_vs_the_standard(gpu, alpha, beta, cqo):
     for s in range(streams):
         assert not np.array_equal(want[s], pics[s])                  # the filter did something
         np.testing.assert_array_equal(got[s], want[s], err_msg=f"stream {s}")
+
+
+@pytest.mark.parametrize("cat", [0, 1, 2, 3, 4, 5])
+@pytest.mark.parametrize("qp,intra", [(23, 0), (20, 1), (8, 0), (37, 1), (51, 0), (30, 0)])
+def test_trellis_primitive_vs_oracle(gpu, cat, qp, intra):
+    """x264's CABAC trellis quantiser as a device primitive (csrc/trellis.cuh: eight lanes per block = the eight nodes of the search) against
+    the checker's restatement (oracle/trellis.cpp), block by block: random transform coefficients with a natural spectrum, random context
+    variables, every block category, quantisers from 8 to 51, inter and intra lambda.  The levels must be identical"""
+    import ctypes as C
+    import torch
+    from x264vfw_amd import lib
+    rng = np.random.default_rng(1000 * cat + qp + intra)
+    nc = 64 if cat == 5 else 4 if cat == 3 else 16
+    nblk = 203
+    zz4 = [0, 1, 4, 8, 5, 2, 3, 6, 9, 12, 13, 10, 7, 11, 14, 15]
+    zz8 = np.zeros(64, np.int64)
+    r, c_, up = 0, 0, True
+    for i in range(64):                       # frame zigzag of an 8x8 block
+        zz8[i] = r * 8 + c_
+        if up:
+            if c_ == 7: r += 1; up = False
+            elif r == 0: c_ += 1; up = False
+            else: r -= 1; c_ += 1
+        else:
+            if r == 7: c_ += 1; up = True
+            elif c_ == 0: r += 1; up = True
+            else: r += 1; c_ -= 1
+    zz = zz8 if cat == 5 else np.arange(4) if cat == 3 else np.array(zz4)
+    # quantiser rows as oracle/quant.c builds them (flat matrices)
+    s4 = [[13107, 8066, 5243], [11916, 7490, 4660], [10082, 6554, 4194], [9362, 5825, 3647], [8192, 5243, 3355], [7282, 4559, 2893]]
+    s8 = [[13107, 11428, 20972, 12222, 16777, 15481], [11916, 10826, 19174, 11058, 14980, 14290], [10082, 8943, 15978, 9675, 12710, 11985],
+          [9362, 8228, 14913, 8931, 11984, 11259], [8192, 7346, 13159, 7740, 10486, 9777], [7282, 6428, 11570, 6830, 9118, 8640]]
+    shr = lambda x, s: x << -s if s <= 0 else (x + (1 << (s - 1))) >> s
+    cls8 = [[0, 3, 4, 3], [3, 1, 5, 1], [4, 5, 2, 5], [3, 1, 5, 1]]
+    if cat == 5:
+        mf = np.array([shr(s8[qp % 6][cls8[(i >> 3) & 3][i & 3]], qp // 6) for i in range(64)], np.uint16)
+    else:
+        mf = np.array([shr(s4[qp % 6][(i & 1) + ((i >> 2) & 1)], qp // 6 - 1) for i in range(16)], np.uint16)
+    step = 65536.0 / float(mf[0])
+    # coefficients: Laplacian amplitudes falling with frequency, a share of blocks nearly empty, a few with big levels
+    scan_pos = np.arange(nc)
+    amp = step * (2.5 / (1.0 + 0.35 * scan_pos))
+    coefs_scan = (rng.laplace(0.0, 1.0, (nblk, nc)) * amp * rng.choice([0.15, 0.6, 1.0, 3.0, 12.0], (nblk, 1))).astype(np.int64)
+    coefs_scan = np.clip(coefs_scan, -30000, 30000).astype(np.int16)
+    if cat in (1, 4):
+        coefs_scan[:, 0] = 0
+    coefs_scan[0] = 0                                   # an empty block
+    coefs_scan[1] = 0; coefs_scan[1, 1 if cat in (1, 4) else 0] = int(step * 1.4)   # only the first coefficient
+    states = ((rng.integers(0, 63, 460) << 1) | rng.integers(0, 2, 460)).astype(np.uint8)
+    O.L.x264o_quant_trellis_cabac.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]
+    O.L.x264o_quant_trellis_cabac.restype = C.c_int
+    want = np.zeros_like(coefs_scan)
+    want_nz = np.zeros(nblk, np.uint8)
+    for b in range(nblk):
+        raster = np.zeros(nc, np.int16)
+        raster[zz] = coefs_scan[b]
+        want_nz[b] = O.L.x264o_quant_trellis_cabac(raster.ctypes.data, mf.ctypes.data, qp, cat, intra, states.ctypes.data) != 0
+        want[b] = raster[zz]
+    d_c, d_s = torch.from_numpy(coefs_scan.copy()).cuda(), torch.from_numpy(states).cuda()
+    d_l, d_z = torch.zeros_like(d_c), torch.zeros(nblk, dtype=torch.uint8, device="cuda")
+    lib.check(lib.x264gpu_trellis_blocks(d_c.data_ptr(), nblk, cat, qp, intra, d_s.data_ptr(), d_l.data_ptr(), d_z.data_ptr(), None), "trellis_blocks")
+    torch.cuda.synchronize()
+    got = d_l.cpu().numpy()
+    bad = np.nonzero((got != want).any(axis=1))[0]
+    assert len(bad) == 0, f"{len(bad)} of {nblk} blocks differ; first {bad[0]}: coefs {coefs_scan[bad[0]].tolist()} device {got[bad[0]].tolist()} oracle {want[bad[0]].tolist()}"
+    np.testing.assert_array_equal(d_z.cpu().numpy(), want_nz)
+    assert np.count_nonzero(want) > nblk          # the cases are not trivial

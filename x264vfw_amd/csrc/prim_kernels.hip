@@ -3,6 +3,10 @@
 // so each primitive is parity-tested against oracle/ with exactly the device code that ships.
 #include "common.cuh"
 #include "mc.cuh"
+#include "k_mb.cuh"          // the motion cache + intra helpers cabac_rd.cuh builds on
+#include "trellis.cuh"
+#include <math.h>
+#include <mutex>
 
 using namespace x264gpu;
 
@@ -217,6 +221,92 @@ int x264gpu_mc_chroma(const uint8_t *d_nv12_00, int stride, const int32_t *d_xy,
     ARG_TRY(n >= 0 && d_nv12_00 && d_xy && d_mv && d_out && (w == 4 || w == 8) && (h == 4 || h == 8));
     if (!n) return X264GPU_OK;
     hipLaunchKernelGGL(k_mc_chroma, dim3((n + 3) / 4), dim3(256), 0, (hipStream_t)stream, d_nv12_00, stride, d_xy, d_mv, n, w, h, d_out);
+    HIP_TRY(hipGetLastError());
+    return X264GPU_OK;
+}
+
+// ---- trellis quantiser primitive (trellis.cuh): blocks in, levels out, against caller-supplied context variables ----
+}  // extern "C"
+
+namespace x264gpu {
+
+// x264_rdo_init's unary tables and x264_trellis_lambda2_tab, built once per process and kept on the device
+static int trellis_tables(TrellisTab *out)
+{
+    static std::mutex mu;
+    static TrellisTab tt = { nullptr, nullptr, nullptr };
+    std::lock_guard<std::mutex> lock(mu);
+    if (!tt.size_unary) {
+        static const uint16_t ent[128] = {
+#include "cabac_entropy.inc"
+        };
+        static const uint8_t trans_lps[64] = { 0, 0, 1, 2, 2, 4, 4, 5, 6, 7, 8, 9, 9, 11, 11, 12, 13, 13, 15, 15, 16, 16, 18, 18, 19, 19, 21, 21, 22, 22, 23, 24,
+                                               24, 25, 26, 26, 27, 27, 28, 29, 29, 30, 30, 30, 31, 32, 32, 33, 33, 33, 34, 34, 35, 35, 35, 36, 36, 36, 37, 37, 37, 38, 38, 63 };
+        auto next = [&](int st, int b) { const int s = st >> 1, mps = st & 1; return (mps ^ b) ? (trans_lps[s] << 1) | (s == 0 ? mps ^ 1 : mps) : ((s < 62 ? s + 1 : 62) << 1) | mps; };
+        uint16_t su[15 * 128]; uint8_t tu[15 * 128]; int l2[104];
+        for (int prefix = 0; prefix < 15; prefix++)
+            for (int c0 = 0; c0 < 128; c0++) {
+                int bits = 0, ctx = c0;
+                for (int i = 1; i < prefix; i++) { bits += ent[ctx ^ 1]; ctx = next(ctx, 1); }
+                if (prefix > 0 && prefix < 14) { bits += ent[ctx]; ctx = next(ctx, 0); }
+                su[prefix * 128 + c0] = (uint16_t)(bits + 256); tu[prefix * 128 + c0] = (uint8_t)ctx;
+            }
+        for (int qp = 0; qp < 52; qp++) { l2[qp] = (int)(0.85 * 0.85 * pow(2.0, qp / 3.0 + 6.0) + 0.5); l2[52 + qp] = (int)(0.65 * 0.65 * pow(2.0, qp / 3.0 + 6.0) + 0.5); }
+        void *a = nullptr, *b = nullptr, *c = nullptr;
+        HIP_TRY(hipMalloc(&a, sizeof(su))); HIP_TRY(hipMalloc(&b, sizeof(tu))); HIP_TRY(hipMalloc(&c, sizeof(l2)));
+        HIP_TRY(hipMemcpy(a, su, sizeof(su), hipMemcpyHostToDevice)); HIP_TRY(hipMemcpy(b, tu, sizeof(tu), hipMemcpyHostToDevice)); HIP_TRY(hipMemcpy(c, l2, sizeof(l2), hipMemcpyHostToDevice));
+        tt.size_unary = (const uint16_t *)a; tt.trans_unary = (const uint8_t *)b; tt.lambda2 = (const int *)c;
+    }
+    *out = tt;
+    return X264GPU_OK;
+}
+
+template <int CAT>
+__global__ void __launch_bounds__(64) k_trellis_blocks(const int16_t *coefs, int nblk, int qp, int intra, const uint8_t *states, TrellisTab tt, int16_t *levels, uint8_t *nz)
+{
+    constexpr int NC = CAT == 5 ? 64 : CAT == 3 ? 4 : 16;
+    __shared__ int16_t buf[8 * 64];
+    __shared__ uint8_t st[460];
+    const int lane = threadIdx.x;
+    for (int i = lane; i < 460; i += 64) st[i] = states[i];
+    const uint32_t model = cab_model(lane);
+    __syncthreads();
+    const int sig_off = CAT == 0 ? 105 : CAT == 1 ? 120 : CAT == 2 ? 134 : CAT == 3 ? 149 : CAT == 4 ? 152 : 402;
+    const int last_off = CAT == 0 ? 166 : CAT == 1 ? 181 : CAT == 2 ? 195 : CAT == 3 ? 210 : CAT == 4 ? 213 : 417;
+    const int abs_off = CAT == 0 ? 227 : CAT == 1 ? 237 : CAT == 2 ? 247 : CAT == 3 ? 257 : CAT == 4 ? 266 : 426;
+    for (int b0 = 0; b0 < nblk; b0 += 8) {
+        const int nb = min(8, nblk - b0);
+        for (int i = lane; i < nb * NC; i += 64) buf[i] = coefs[(size_t)b0 * NC + i];
+        __syncthreads();
+        const unsigned m = trellis_blocks<CAT>(buf, NC, nb, qp, intra != 0, model, tt, lane,
+                                               [&](int i) { return (int)st[sig_off + i]; }, [&](int i) { return (int)st[last_off + i]; }, [&](int i) { return (int)st[abs_off + i]; });
+        __syncthreads();
+        for (int i = lane; i < nb * NC; i += 64) levels[(size_t)b0 * NC + i] = buf[i];
+        if (lane < nb) nz[b0 + lane] = (uint8_t)((m >> lane) & 1);
+        __syncthreads();
+    }
+}
+
+}  // namespace x264gpu
+
+extern "C" {
+
+int x264gpu_trellis_blocks(const int16_t *d_coefs, int nblk, int cat, int qp, int intra, const uint8_t *d_states460, int16_t *d_levels, uint8_t *d_nz, void *stream)
+{
+    ARG_TRY(d_coefs && d_states460 && d_levels && d_nz && nblk >= 0 && cat >= 0 && cat <= 5 && qp >= 0 && qp <= 51);
+    if (!nblk) return X264GPU_OK;
+    TrellisTab tt;
+    const int rc = trellis_tables(&tt);
+    if (rc != X264GPU_OK) return rc;
+    const hipStream_t st = (hipStream_t)stream;
+    switch (cat) {
+    case 0: hipLaunchKernelGGL(k_trellis_blocks<0>, dim3(1), dim3(64), 0, st, d_coefs, nblk, qp, intra, d_states460, tt, d_levels, d_nz); break;
+    case 1: hipLaunchKernelGGL(k_trellis_blocks<1>, dim3(1), dim3(64), 0, st, d_coefs, nblk, qp, intra, d_states460, tt, d_levels, d_nz); break;
+    case 2: hipLaunchKernelGGL(k_trellis_blocks<2>, dim3(1), dim3(64), 0, st, d_coefs, nblk, qp, intra, d_states460, tt, d_levels, d_nz); break;
+    case 3: hipLaunchKernelGGL(k_trellis_blocks<3>, dim3(1), dim3(64), 0, st, d_coefs, nblk, qp, intra, d_states460, tt, d_levels, d_nz); break;
+    case 4: hipLaunchKernelGGL(k_trellis_blocks<4>, dim3(1), dim3(64), 0, st, d_coefs, nblk, qp, intra, d_states460, tt, d_levels, d_nz); break;
+    default: hipLaunchKernelGGL(k_trellis_blocks<5>, dim3(1), dim3(64), 0, st, d_coefs, nblk, qp, intra, d_states460, tt, d_levels, d_nz); break;
+    }
     HIP_TRY(hipGetLastError());
     return X264GPU_OK;
 }

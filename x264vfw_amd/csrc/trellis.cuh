@@ -1,0 +1,231 @@
+// trellis.cuh — x264's CABAC trellis quantiser on the device ([x264-upstream] encoder/rdo.c quant_trellis_cabac; `--trellis 1`: the
+// final encode of a macroblock).  Mirrors oracle/trellis.cpp decision for decision; the algorithm is stated in oracle/TRELLIS_NOTES.md.
+//
+// EIGHT LANES PER BLOCK = THE EIGHT NODES of the search (the abs-level context states CABAC can be in), eight blocks per pass of a
+// wavefront.  The coefficients of the blocks sit in LDS in scan order; one step of the loop is one scan position for all eight blocks:
+//   * every lane, as a SOURCE node, prices its two candidate levels (the round-to-nearest guess q and q - 1) on its own copy of the
+//     four context variables a path can touch twice — no traffic between lanes;
+//   * every lane, as a DESTINATION node, takes the minimum over the sources that lead to it.  x264's "first strictly better wins" in its
+//     evaluation order (level q - 1 before q, sources ascending) is the minimum of (score << 4 | order);
+//   * the winner's context bytes and its path (two bits per position: 0 = level 0, 1 = q - 1, 2 = q) come over with one shuffle each.
+// The significance / last costs of a position are the same for all blocks (the slice's context variables are only read), so they are
+// computed once per step by wave-uniform code.  Status: a tested primitive (x264gpu_trellis_blocks, tests/test_gpu_prims.py); the
+// macroblock loop does not call it yet.
+#pragma once
+#include "cabac_rd.cuh"
+
+namespace x264gpu {
+
+// x264_cabac_size_unary / x264_cabac_transition_unary ([15][128], context variable = (pStateIdx << 1) | valMPS): built on the host from the
+// entropy table and the state transitions (trellis_tables() in prim_kernels.hip), read here through these pointers
+struct TrellisTab { const uint16_t *size_unary; const uint8_t *trans_unary; const int *lambda2; };      // lambda2[intra * 52 + qp]: x264_trellis_lambda2_tab
+
+static __constant__ const uint16_t c_quant4_scale[6][3] = { { 13107, 8066, 5243 }, { 11916, 7490, 4660 }, { 10082, 6554, 4194 },
+                                                            { 9362, 5825, 3647 },  { 8192, 5243, 3355 },  { 7282, 4559, 2893 } };
+static __constant__ const uint16_t c_quant8_scale[6][6] = { { 13107, 11428, 20972, 12222, 16777, 15481 }, { 11916, 10826, 19174, 11058, 14980, 14290 },
+                                                            { 10082, 8943, 15978, 9675, 12710, 11985 },   { 9362, 8228, 14913, 8931, 11984, 11259 },
+                                                            { 8192, 7346, 13159, 7740, 10486, 9777 },     { 7282, 6428, 11570, 6830, 9118, 8640 } };
+static __constant__ const uint8_t c_zigzag4_fwd[16] = { 0, 1, 4, 8, 5, 2, 3, 6, 9, 12, 13, 10, 7, 11, 14, 15 };
+static __constant__ const uint8_t c_zigzag8_fwd[64] = { 0, 1, 8, 16, 9, 2, 3, 10, 17, 24, 32, 25, 18, 11, 4, 5, 12, 19, 26, 33, 40, 48, 41, 34, 27, 20, 13, 6, 7, 14, 21, 28,
+                                                        35, 42, 49, 56, 57, 50, 43, 36, 29, 22, 15, 23, 30, 37, 44, 51, 58, 59, 52, 45, 38, 31, 39, 46, 53, 60, 61, 54, 47, 55, 62, 63 };
+static __constant__ const uint16_t c_trellis_w4[3] = { 800, 320, 128 };                       // FIX8(3.125), FIX8(1.25), FIX8(0.5)
+static __constant__ const uint16_t c_trellis_w8[6] = { 256, 201, 656, 227, 410, 363 };        // FIX8(1.00000, 0.78487, 2.56132, 0.88637, 1.60040, 1.41850)
+static __constant__ const uint8_t c_class8[16] = { 0, 3, 4, 3, 3, 1, 5, 1, 4, 5, 2, 5, 3, 1, 5, 1 };
+
+__device__ __forceinline__ int trellis_class(int cat, int i)       // quantiser / weight class of scan position i
+{
+    if (cat == 5) { const int pos = c_zigzag8_fwd[i]; return c_class8[((pos >> 3) & 3) * 4 + (pos & 3)]; }
+    const int pos = c_zigzag4_fwd[i];
+    return (pos & 1) + ((pos >> 2) & 1);
+}
+__device__ __forceinline__ int shift_round_d(int x, int s) { return s <= 0 ? x << -s : (x + (1 << (s - 1))) >> s; }
+
+// cost (1/256 bit) of bin b on context variable st, and the variable after it
+__device__ __forceinline__ int tr_ent(uint32_t model, int st, int b)
+{
+    const uint32_t t = (uint32_t)__builtin_amdgcn_ds_bpermute((st >> 1) << 2, (int)model);
+    return ((st & 1) ^ b) ? (t >> 9) & 0x7ff : t & 0x1ff;
+}
+__device__ __forceinline__ int tr_next(uint32_t model, int st, int b)
+{
+    const uint32_t t = (uint32_t)__builtin_amdgcn_ds_bpermute((st >> 1) << 2, (int)model);
+    const int s = st >> 1, mps = st & 1;
+    if (mps ^ b) return ((int)(t >> 20) << 1) | (s == 0 ? mps ^ 1 : mps);
+    return (min(s + 1, 62) << 1) | mps;
+}
+__device__ __forceinline__ int tr_size_ue_big(unsigned v) { return 2 * (31 - __builtin_clz(v + 1)) + 1; }
+
+// Up to eight blocks of category CAT (0 luma DC, 1 luma AC, 2 luma 4x4, 3 chroma DC, 4 chroma AC, 5 luma 8x8) whose coefficients lie in LDS
+// in scan order, block b at coefs + b * stride (AC blocks: 16 entries, entry 0 = 0); the levels replace them.  nblk <= 8.  lane & 7 = node,
+// lane >> 3 = block.  st_sig / st_last / st_abs: accessors of the slice's context variables of the category (wave-uniform arguments).
+// Returns the mask of blocks with a non-zero level (wave-uniform).
+template <int CAT, class FS, class FL, class FA>
+__device__ __forceinline__ unsigned trellis_blocks(int16_t *coefs, int stride, int nblk, int qp, bool intra, uint32_t model, const TrellisTab &tt,
+                                                   int lane, FS st_sig, FL st_last, FA st_abs)
+{
+    namespace T = x264gpu_cabac;
+    constexpr int NC = CAT == 5 ? 64 : CAT == 3 ? 4 : 16, B_AC = (CAT == 1 || CAT == 4) ? 1 : 0, PW = CAT == 5 ? 4 : 1;
+    constexpr bool DC = CAT == 0 || CAT == 3;
+    const int n = lane & 7, g = lane >> 3, base = lane & ~7;
+    const bool blk_on = g < nblk;
+    int16_t *mine = coefs + g * stride;
+    const int lambda2 = tt.lambda2[(intra ? 52 : 0) + qp];
+    const int sh4 = qp / 6 - 1, sh8 = qp / 6;
+    auto mf_of = [&](int i) {
+        if (DC) return shift_round_d(c_quant4_scale[qp % 6][0], sh4) >> 1;
+        return CAT == 5 ? shift_round_d(c_quant8_scale[qp % 6][trellis_class(CAT, i)], sh8) : shift_round_d(c_quant4_scale[qp % 6][trellis_class(CAT, i)], sh4);
+    };
+    auto guess = [&](int c, int i) {                 // |level| of the round-to-nearest quantiser (quant_bias0 = (1 << 15) / mf)
+        int m, bias;
+        if (DC) { const int m0 = shift_round_d(c_quant4_scale[qp % 6][0], sh4); m = m0 >> 1; bias = ((1 << 15) / m0) << 1; }
+        else { m = mf_of(i); bias = (1 << 15) / m; }
+        return ((bias + abs(c)) * m) >> 16;
+    };
+    auto unquant = [&](int i) {
+        if (DC) return (int)((1ull << (qp / 6 + 15 + 8)) / c_quant4_scale[qp % 6][0]) << 1;
+        return CAT == 5 ? (int)((1ull << (qp / 6 + 16 + 8)) / c_quant8_scale[qp % 6][trellis_class(CAT, i)])
+                        : (int)((1ull << (qp / 6 + 15 + 8)) / c_quant4_scale[qp % 6][trellis_class(CAT, i)]);
+    };
+    auto weight = [&](int i) { return DC ? 256 : CAT == 5 ? (int)c_trellis_w8[trellis_class(CAT, i)] : (int)c_trellis_w4[trellis_class(CAT, i)]; };
+
+    // the last position the guess leaves non-zero, per block
+    int last_nnz = -1;
+    for (int p = n; p < NC; p += 8) if (blk_on && p >= B_AC && guess(mine[p], p)) last_nnz = p;
+    last_nnz = max(last_nnz, __shfl_xor(last_nnz, 1)); last_nnz = max(last_nnz, __shfl_xor(last_nnz, 2)); last_nnz = max(last_nnz, __shfl_xor(last_nnz, 4));
+
+    // level_state: the ten abs-level context variables of the category (wave-uniform), packed four to a word
+    uint32_t ls[3] = { 0, 0, 0 };
+    for (int i = 0; i < 10; i++) ls[i >> 2] |= (uint32_t)st_abs(CAT == 3 && i > 8 ? 8 : i) << (8 * (i & 3));
+    auto level_state = [&](int i) { const uint32_t w = i < 4 ? ls[0] : i < 8 ? ls[1] : ls[2]; return (int)((w >> (8 * (i & 3))) & 255); };
+    const uint32_t init4 = (uint32_t)level_state(0) | ((uint32_t)level_state(4) << 8) | ((uint32_t)level_state(8) << 16) | ((uint32_t)level_state(9) << 24);
+    constexpr int LG_LAST = CAT == 3 ? 8 : 9;
+
+    const unsigned long long SMAX = ~0ull, BIAS = 1ull << 50;
+    unsigned long long score = n == 0 ? BIAS : SMAX;
+    uint32_t cs = 0, path[PW];
+    for (int w = 0; w < PW; w++) path[w] = 0;
+    bool ctx_hi = false;
+
+    for (int i = NC - 1; i >= B_AC; i--) {
+        const bool act = blk_on && i <= last_nnz;
+        if (!__ballot(act)) continue;
+        const int c = act ? (int)mine[i] : 0, q = guess(c, i), a = abs(c);
+        // costs of the position's significance / last flags (the same for every block): wave-uniform
+        const int sidx = CAT == 5 ? (int)T::cabac_sig8x8[min(i, 62)] : i - B_AC, lidx = CAT == 5 ? (int)T::cabac_last8x8[min(i, 62)] : i - B_AC;
+        int cost0 = 0, cost1 = 0, cost2 = 0;
+        if (i < NC - 1) {
+            const int ss = st_sig(sidx), sl = st_last(lidx);
+            const uint32_t ts = __builtin_amdgcn_readlane(model, ss >> 1), tl = __builtin_amdgcn_readlane(model, sl >> 1);
+            const int s0 = (ss & 1) ? (ts >> 9) & 0x7ff : ts & 0x1ff, s1 = (ss & 1) ? ts & 0x1ff : (ts >> 9) & 0x7ff;
+            const int l0 = (sl & 1) ? (tl >> 9) & 0x7ff : tl & 0x1ff, l1 = (sl & 1) ? tl & 0x1ff : (tl >> 9) & 0x7ff;
+            cost0 = s0; cost1 = s1 + l0; cost2 = s1 + l1;
+        }
+        const bool zero = act && q == 0, go = act && q != 0;
+        // ---- a zero of the guess: nothing to choose; the all-zero path of a block still in ctx_lo is spared the significance bit ----
+        if (zero && !ctx_hi && n == 0) score -= ((unsigned long long)cost0 * (unsigned long long)lambda2) >> 4;
+        // ---- every lane as a source node: its two candidate levels A = q - 1, B = q ----
+        const int un = unquant(i), wgt = weight(i);
+        unsigned long long ssd0[2], ssd1[2];
+        for (int kk = 0; kk < 2; kk++) {
+            const int lvl = q - 1 + kk, ua = (int)(((long long)un * lvl + 128) >> 8);
+            long long d = a - ua;
+            ssd1[kk] = (unsigned long long)(d * d) * (unsigned long long)wgt;
+            ssd0[kk] = ssd1[kk];
+            if (i == 0 && !DC && !ctx_hi) { d = c - (((c < 0 ? -ua : ua) + 8) & ~15); ssd0[kk] = (unsigned long long)(d * d) * (unsigned long long)wgt; }
+        }
+        const bool alive = (long long)score >= 0;
+        const bool src_ok = go && (ctx_hi ? (n >= 1 && alive) : (n <= 3 && (n == 0 || alive)));
+        // kinds of the two candidates: 0 = level 0 (a copy), 1 = level 1, 2 = level >= 2
+        const int kindA = q == 1 ? 0 : q == 2 ? 1 : 2, kindB = q == 1 ? 1 : 2;
+        if (q == 1) ssd1[0] += ((unsigned long long)cost0 * (unsigned long long)lambda2) >> 4;
+        unsigned long long candv[2];
+        uint32_t candcs[2];
+        // (the model lookups are ds_bpermutes: every lane must take part, whatever its block is doing — so nothing below is skipped, the
+        //  kinds only select)
+        const int l1ctx = n < 4 ? n + 1 : 0, lgctx = n < 4 ? 5 : n == 7 ? LG_LAST : n + 2;
+        const int l1state = n >= 3 ? (int)((cs >> (8 * (l1ctx >> 2))) & 255) : level_state(l1ctx);
+        const int lgstate = n >= 6 ? (int)((cs >> (8 * (lgctx - 6))) & 255) : level_state(lgctx);
+        const int ent_l1_0 = tr_ent(model, l1state, 0), ent_l1_1 = tr_ent(model, l1state, 1);
+        const int nxt_l1_0 = tr_next(model, l1state, 0), nxt_l1_1 = tr_next(model, l1state, 1);
+        for (int kk = 0; kk < 2; kk++) {
+            const int kind = kk ? kindB : kindA, lvl = q - 1 + kk;
+            unsigned long long v = SMAX;
+            uint32_t ncs = cs;
+            if (kind == 0) {
+                // trellis_coef0: node j -> node j; only node 0 pays a distortion difference (the others carry it in the baseline)
+                if (src_ok) v = score + (n == 0 ? ssd0[0] - ssd1[0] : 0ull);
+            } else {
+                const unsigned long long rel0 = q == 1 ? ssd0[kk] - ssd1[0] : ssd0[kk], rel1 = q == 1 ? ssd1[kk] - ssd1[0] : ssd1[kk];
+                const int node_ctx = kind == 1 ? (n < 3 ? n + 1 : n == 3 ? 3 : n) : (n < 4 ? 4 : min(n + 1, 7));
+                unsigned f8 = (unsigned)(n ? cost1 : cost2);
+                f8 += (unsigned)(kind == 2 ? ent_l1_1 : ent_l1_0);
+                const int prefix = max(min(lvl - 1, 14), 0);
+                if (kind == 2) f8 += tt.size_unary[prefix * 128 + lgstate] + (lvl >= 15 ? (unsigned)tr_size_ue_big((unsigned)(lvl - 15)) << 8 : 0u);
+                else f8 += 256;
+                if (src_ok) v = score + (n ? rel1 : rel0) + (((unsigned long long)f8 * (unsigned long long)lambda2) >> 4);
+                if (n == 2 || (n <= 3 && node_ctx == 4)) ncs = init4;
+                if (n >= 3) { const int sh = 8 * (l1ctx >> 2); ncs = (ncs & ~(255u << sh)) | ((uint32_t)(kind == 2 ? nxt_l1_1 : nxt_l1_0) << sh); }
+                if (kind == 2 && node_ctx == 7) { const int sh = 8 * (lgctx - 6); ncs = (ncs & ~(255u << sh)) | ((uint32_t)tt.trans_unary[prefix * 128 + lgstate] << sh); }
+            }
+            candv[kk] = v; candcs[kk] = ncs;
+        }
+        // ---- every lane as a destination node n: the sources that lead here, in x264's evaluation order ----
+        unsigned long long best = ~0ull;
+        for (int kk = 0; kk < 2; kk++) {
+            const int kind = kk ? kindB : kindA;
+            int lo, hi;
+            if (kind == 0) { lo = hi = n; }
+            else if (kind == 1) { lo = n == 0 ? 1 : n <= 2 ? n - 1 : n == 3 ? 2 : n; hi = n == 0 ? 0 : n == 3 ? 3 : lo; }
+            else { lo = n == 4 ? 0 : n >= 5 ? (n == 7 ? 6 : n - 1) : 1; hi = n == 4 ? 3 : n == 7 ? 7 : n >= 5 ? lo : 0; }
+            for (int t = 0; t < 4; t++) {
+                const int j = lo + t;
+                const unsigned lo32 = (unsigned)__shfl((int)(unsigned)candv[kk], base + (j & 7)), hi32 = (unsigned)__shfl((int)(unsigned)(candv[kk] >> 32), base + (j & 7));
+                const unsigned long long v = ((unsigned long long)hi32 << 32) | lo32;
+                if (j <= hi && v != SMAX) { const unsigned long long key = (v << 4) | (unsigned)(kk * 8 + j); best = key < best ? key : best; }
+            }
+        }
+        const bool won = best != ~0ull;
+        const int wj = (int)(best & 7), wk = (int)((best >> 3) & 1);
+        const uint32_t csA = (uint32_t)__shfl((int)candcs[0], base + wj), csB = (uint32_t)__shfl((int)candcs[1], base + wj);
+        uint32_t npath[PW];
+        for (int w = 0; w < PW; w++) npath[w] = (uint32_t)__shfl((int)path[w], base + wj);
+        if (go) {
+            score = won ? best >> 4 : SMAX;
+            cs = wk ? csB : csA;
+            const uint32_t choice = won ? (uint32_t)(wk + 1) : 0u;       // 1 = level q - 1, 2 = level q  (q - 1 == 0 codes as level 0 by value)
+            for (int w = 0; w < PW; w++) { path[w] = npath[w]; if (w == (i >> 4)) path[w] |= choice << (2 * (i & 15)); }
+            if (q >= 2) ctx_hi = true;
+        }
+    }
+    // ---- the best node of every block; node 0 = nothing left ----
+    const bool cand = ctx_hi ? n >= 1 : n <= 3;
+    unsigned long long key = cand && (long long)score >= 0 ? (score << 3) | (unsigned)n : ~0ull;
+    for (int m = 1; m < 8; m <<= 1) {
+        const unsigned lo32 = (unsigned)__shfl_xor((int)(unsigned)key, m), hi32 = (unsigned)__shfl_xor((int)(unsigned)(key >> 32), m);
+        const unsigned long long o = ((unsigned long long)hi32 << 32) | lo32;
+        key = o < key ? o : key;
+    }
+    const int bn = (int)(key & 7);
+    uint32_t bpath[PW];
+    for (int w = 0; w < PW; w++) bpath[w] = (uint32_t)__shfl((int)path[w], base + bn);
+    // ---- levels out: lane n writes positions n, n + 8, ... ----
+    int lv[NC / 8 > 0 ? NC / 8 : 1];
+    bool nz = false;
+    for (int t = 0, p = n; p < NC; p += 8, t++) {
+        const int c = blk_on ? (int)mine[p] : 0, q = guess(c, p);
+        const uint32_t choice = (bpath[CAT == 5 ? p >> 4 : 0] >> (2 * (p & 15))) & 3;
+        int l = 0;
+        if (blk_on && last_nnz >= 0 && bn != 0 && p >= B_AC && p <= last_nnz && choice) l = choice == 1 ? q - 1 : q;
+        lv[t] = c < 0 ? -l : l;
+        nz = nz || lv[t] != 0;
+    }
+    __builtin_amdgcn_wave_barrier();
+    if (CAT == 3) { if (blk_on && n < 4) mine[n] = (int16_t)lv[0]; }
+    else for (int t = 0, p = n; p < NC; p += 8, t++) if (blk_on) mine[p] = (int16_t)lv[t];
+    const unsigned long long nzm = __ballot(nz);
+    unsigned out = 0;
+    for (int b = 0; b < 8; b++) if ((nzm >> (8 * b)) & 0xff) out |= 1u << b;
+    return out;
+}
+
+}  // namespace x264gpu
