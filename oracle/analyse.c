@@ -497,21 +497,25 @@ static void scan4(int16_t *dst, const dctcoef *src) { for (int k = 0; k < 16; k+
  * (e->b_trellis; x264 h->mb.b_trellis under --trellis 1) — the trellis search of trellis.cpp on the slice's live context variables.
  * cat = CABAC block category, qp = the block's quantiser (chroma: the chroma one) */
 int x264o_quant_trellis_cabac(dctcoef *dct, const uint16_t *mf, int qp, int cat, int intra, const uint8_t *state);
+/* e->b_trellis: the sites of the final encode that use it, as a mask (cfg.trellis; x264's --trellis 1 = all of them = 63): 1 inter luma 4x4,
+ * 2 inter luma 8x8, 4 chroma, 8 Intra_16x16, 16 Intra_4x4, 32 Intra_8x8 — the device was brought up site by site against these masks */
+enum { TR_P4 = 1, TR_P8 = 2, TR_C = 4, TR_I16 = 8, TR_I4 = 16, TR_I8 = 32 };
 static int quant_4x4(x264o_encoder *e, dctcoef *d, const uint16_t *mf, const uint16_t *bias, int qp, int cat, int intra)
 {
-    return e->b_trellis ? x264o_quant_trellis_cabac(d, mf, qp, cat, intra, e->cabac_state) : x264o_quant_4x4(d, mf, bias);
+    const int site = cat == 4 ? TR_C : cat == 1 ? TR_I16 : intra ? TR_I4 : TR_P4;
+    return (e->b_trellis & site) ? x264o_quant_trellis_cabac(d, mf, qp, cat, intra, e->cabac_state) : x264o_quant_4x4(d, mf, bias);
 }
 static int quant_8x8(x264o_encoder *e, dctcoef *d, const uint16_t *mf, const uint16_t *bias, int qp, int intra)
 {
-    return e->b_trellis ? x264o_quant_trellis_cabac(d, mf, qp, 5, intra, e->cabac_state) : x264o_quant_8x8(d, mf, bias);
+    return (e->b_trellis & (intra ? TR_I8 : TR_P8)) ? x264o_quant_trellis_cabac(d, mf, qp, 5, intra, e->cabac_state) : x264o_quant_8x8(d, mf, bias);
 }
 static int quant_4x4_dc(x264o_encoder *e, dctcoef *d, const uint16_t *mf, const uint16_t *bias, int qp)
 {
-    return e->b_trellis ? x264o_quant_trellis_cabac(d, mf, qp, 0, 1, e->cabac_state) : x264o_quant_4x4_dc(d, mf[0] >> 1, bias[0] << 1);
+    return (e->b_trellis & TR_I16) ? x264o_quant_trellis_cabac(d, mf, qp, 0, 1, e->cabac_state) : x264o_quant_4x4_dc(d, mf[0] >> 1, bias[0] << 1);
 }
 static int quant_2x2_dc(x264o_encoder *e, dctcoef *d, const uint16_t *mf, const uint16_t *bias, int qp, int intra)
 {
-    return e->b_trellis ? x264o_quant_trellis_cabac(d, mf, qp, 3, intra, e->cabac_state) : x264o_quant_2x2_dc(d, mf[0] >> 1, bias[0] << 1);
+    return (e->b_trellis & TR_C) ? x264o_quant_trellis_cabac(d, mf, qp, 3, intra, e->cabac_state) : x264o_quant_2x2_dc(d, mf[0] >> 1, bias[0] << 1);
 }
 
 /* inter luma, 4x4 transform: prediction in rec; returns through mb: nnz, cbp_luma; levels in lv */
@@ -1505,7 +1509,7 @@ static void macroblock_body(x264o_encoder *e, int mbx, int mby, actx *a)
         if (a->satd_i8 < i_cost) { i_cost = a->satd_i8; type = X264GPU_MB_I8x8; }
         if (a->mbrd) rd_reset(a, mb, lv);
         mb->cost = i_cost;
-        e->b_trellis = e->cfg.trellis && e->cfg.cabac;          /* --trellis 1: the final encode only */
+        e->b_trellis = e->cfg.cabac ? e->cfg.trellis : 0;          /* --trellis 1: the final encode only */
         encode_intra_mb(a, type, mb, lv);
         e->b_trellis = 0;
         e->intra_count++;
@@ -1615,7 +1619,7 @@ static void macroblock_body(x264o_encoder *e, int mbx, int mby, actx *a)
     mb->cost = i_cost;
 
     if (is_intra_type(i_type)) {
-        e->b_trellis = e->cfg.trellis && e->cfg.cabac;
+        e->b_trellis = e->cfg.cabac ? e->cfg.trellis : 0;
         encode_intra_mb(a, i_type, mb, lv);
         e->b_trellis = 0;
         e->intra_count++;
@@ -1627,7 +1631,7 @@ static void macroblock_body(x264o_encoder *e, int mbx, int mby, actx *a)
         mb->ref[k] = (int8_t)m->ref; mb->mv[k][0] = (int16_t)m->mv[0]; mb->mv[k][1] = (int16_t)m->mv[1];
     }
     a->force_t8 = t8;                 /* RD: the transform size chosen by transform_rd; else SA8D vs SATD */
-    e->b_trellis = e->cfg.trellis && e->cfg.cabac;
+    e->b_trellis = e->cfg.cabac ? e->cfg.trellis : 0;
     encode_inter_mb(a, mb, lv);
     e->b_trellis = 0;
 }

@@ -63,6 +63,13 @@ CASES = [
     (352, 288, 4, dict(cabac=1, rd=1, subme=7, partitions=7, dct8x8=1, refs=3, mixed_refs=1, chroma_me=1, qp_i=30, qp_p=34, me_method=2)),
     (96, 208, 4, dict(cabac=1, rd=1, subme=6, slices=3, partitions=7, dct8x8=1, refs=2, psy=1, psy_rd_q8=102, chroma_qp_offset=-1, aq_mode=1)),
     (96, 80, 4, dict(cabac=1, rd=1, subme=6, partitions=7, dct8x8=1, qp_i=8, qp_p=10, dct_decimate=0, fast_pskip=0)),
+    # trellis quantisation of the final encode, site by site (mask: 1 inter 4x4, 2 inter 8x8, 4 chroma, 8 I16x16, 16 I4x4, 32 I8x8; x264 --trellis 1 = 63)
+    (176, 144, 4, dict(cabac=1, rd=1, subme=6, partitions=1, trellis=1)),
+    (176, 144, 4, dict(cabac=1, rd=1, subme=6, partitions=1, trellis=4)),
+    (176, 144, 4, dict(cabac=1, rd=1, subme=7, partitions=5, dct8x8=1, trellis=2)),
+    (176, 144, 4, dict(cabac=1, rd=1, subme=7, partitions=7, dct8x8=1, refs=2, trellis=7, psy=1, psy_rd_q8=256, chroma_qp_offset=-2)),
+    (96, 80, 4, dict(cabac=1, rd=1, subme=6, partitions=7, dct8x8=1, qp_i=8, qp_p=10, dct_decimate=0, trellis=7)),
+    (208, 120, 4, dict(cabac=1, rd=1, subme=6, partitions=7, dct8x8=1, qp_i=40, qp_p=44, trellis=7)),
 ]
 
 

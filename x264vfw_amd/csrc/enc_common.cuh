@@ -58,7 +58,8 @@ struct EncK {
     const int16_t *lowres_mv; // optional [streams][nmb][2] lookahead vectors (x264 lowres_mvs[0][0]); first entry 0x7fff = absent
     int fast_pskip, mv_range;
     int rd, psy, psy_rd_q8;   // RD mode decision (subme 6 / 7 of a CAVLC session), b_psy, FIX8(psy-rd strength)
-    uint8_t *tc, *amvd; uint32_t *cab_out;              // RD: [streams][nmb][24] total_coeff of every block of the picture being coded (nC of the bit counts)
+    uint8_t *tc, *amvd; uint32_t *cab_out;
+    int trellis; const uint16_t *tr_su; const uint8_t *tr_tu; const int *tr_l2;      // trellis sites of the final encode (mask) + x264_rdo_init's tables              // RD: [streams][nmb][24] total_coeff of every block of the picture being coded (nC of the bit counts)
     int cabac;                // the session's entropy coder is CABAC: P8x8 cost details of x264's analysis depend on it
     int slices;               // x264 slice threads: slices per picture (rows split evenly), 1 = one
     unsigned long long *prof; // MB_PROF builds only: [streams][16] cycle counters of the macroblock loop's phases (null otherwise)

@@ -22,6 +22,7 @@ void launch_mb_slice_hex(const EncK &k, int streams, bool big_margin, hipStream_
 void launch_mb_slice_umh(const EncK &k, int streams, bool big_margin, hipStream_t st);
 void launch_mb_slice_esa(const EncK &k, int streams, bool big_margin, hipStream_t st);
 void launch_mb_slice_intra(const EncK &k, int streams, hipStream_t st);
+int trellis_table_ptrs(const uint16_t **su, const uint8_t **tu, const int **l2);        // prim_kernels.hip
 int launch_hpel_filter(uint8_t *planes, size_t plane_bytes, int stride, int w, int h, int pad, int batch,
                        size_t batch_bytes, hipStream_t st);
 }
@@ -101,7 +102,7 @@ int x264gpu_encoder_create(x264gpu_encoder **out, const x264gpu_config *cfg)
     ARG_TRY(out && cfg);
     ARG_TRY(cfg->width >= 16 && cfg->height >= 16 && !(cfg->width & 1) && !(cfg->height & 1) && cfg->streams >= 1);
     ARG_TRY(cfg->qp_i >= 0 && cfg->qp_i <= 51 && cfg->qp_p >= 0 && cfg->qp_p <= 51 && cfg->refs >= 1 && cfg->refs <= 5);
-    ARG_TRY(cfg->trellis == 0);                  // trellis quantisation: not on the device yet
+    ARG_TRY(cfg->trellis == 0 || (cfg->trellis > 0 && cfg->trellis < 64 && cfg->rd && cfg->cabac));      // trellis sites (mask; x264 --trellis 1 = 63): RD sessions with CABAC
     ARG_TRY(!cfg->rd || (cfg->subme >= 6 && cfg->subme <= 7 && cfg->psy_rd_q8 >= 0 && cfg->psy_rd_q8 <= 2560));      // RD: x264's i_mbrd 1 (bit counts of the session's entropy coder)
     ARG_TRY(cfg->slices >= 0 && (cfg->slices <= 1 || cfg->slices <= (cfg->height + 15) / 16 / 4));      // x264 slice threads: at least four macroblock rows each
     ARG_TRY(cfg->width <= 4096 && cfg->height <= 2304 && cfg->me_range >= 4 && cfg->me_range <= (cfg->me_method == 2 ? 64 : 16));
@@ -305,6 +306,8 @@ int x264gpu_encode_frames(x264gpu_encoder *e, const uint8_t *d_i420, int slice_t
     }
     e->slot_nref[e->cur] = k.nref; e->slot_poc[e->cur] = e->poc; e->slot_ref0poc[e->cur] = k.nref ? e->slot_poc[s0] : 0;
     k.prof = e->prof; k.tc = e->tc; k.amvd = e->amvd; k.cab_out = e->cab_out;
+    k.trellis = e->cfg.trellis; k.tr_su = nullptr; k.tr_tu = nullptr; k.tr_l2 = nullptr;
+    if (k.trellis) { const int rc = trellis_table_ptrs(&k.tr_su, &k.tr_tu, &k.tr_l2); if (rc != X264GPU_OK) return rc; }
     k.lowres_mv = e->lowres_mv; k.fast_pskip = e->cfg.fast_pskip; k.mv_range = e->cfg.mv_range;
     k.mb = d_mb; k.levels = d_levels;
     k.qp = qp; k.lambda = lambda_of(qp); k.qpc = chroma_qp_of(qp, e->cfg.chroma_qp_offset);

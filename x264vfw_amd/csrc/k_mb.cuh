@@ -930,13 +930,44 @@ __device__ __forceinline__ int mb_intra_chroma_cost(const EncK &k, MbLds<M> &L, 
     return bestc;
 }
 
+}  // namespace x264gpu
+#include "cabac_rd.cuh"          // needs the motion cache and the intra-mode helpers above
+#include "trellis.cuh"
+namespace x264gpu {
+
+// The trellis sites of a macroblock's FINAL encode (x264 --trellis 1; k.trellis = the mask of sites, 63 = all): what they need to run the
+// search of trellis.cuh on the slice's live context variables (read only)
+enum { TR_P4 = 1, TR_P8 = 2, TR_C = 4, TR_I16 = 8, TR_I4 = 16, TR_I8 = 32 };
+struct TrCtx { int on; uint32_t r, r8, model; TrellisTab tt; };
+// nblk blocks of category CAT at coefs (scan order, `stride` entries apart), eight per pass; returns the mask of blocks left non-zero
+template <int CAT>
+__device__ __forceinline__ unsigned trellis_run(const TrCtx &tr, int16_t *coefs, int stride, int nblk, int qp, bool intra, int lane)
+{
+    constexpr int sh = CAT == 2 ? 0 : CAT == 1 ? 8 : CAT == 4 ? 16 : 24;
+    constexpr int sig0 = CAT == 3 ? 48 : 0, last0 = CAT == 3 ? 52 : 16, abs0 = CAT == 3 ? 55 : 32;
+    const uint32_t reg = CAT == 5 ? tr.r8 : tr.r;
+    auto st_sig = [&](int i) { return (int)((__builtin_amdgcn_readlane(reg, sig0 + i) >> (CAT == 5 ? 0 : sh)) & 255); };
+    auto st_last = [&](int i) { return (int)((__builtin_amdgcn_readlane(reg, last0 + i) >> (CAT == 5 ? 0 : sh)) & 255); };
+    auto st_abs = [&](int i) { return (int)((__builtin_amdgcn_readlane(reg, abs0 + i) >> (CAT == 5 ? 0 : sh)) & 255); };
+    unsigned out = 0;
+    for (int b0 = 0; b0 < nblk; b0 += 8) out |= trellis_blocks<CAT>(coefs + b0 * stride, stride, min(8, nblk - b0), qp, intra, tr.model, tr.tt, lane, st_sig, st_last, st_abs) << b0;
+    return out;
+}
+__device__ __forceinline__ void load_levels_scan(const int16_t *src, int v[4], int j)
+{
+    const unsigned z = scan_nibbles(j);
+    v[0] = src[z & 15]; v[1] = src[(z >> 4) & 15]; v[2] = src[(z >> 8) & 15]; v[3] = src[z >> 12];
+}
+
+
 // ------------------------------------------------------------------------------------------------
 // chroma residual with x264's variance early termination (oracle encode_chroma).  Lanes 0..31: plane = lane >> 4,
 // 4x4 block = (lane >> 2) & 3, row = lane & 3.
 // ------------------------------------------------------------------------------------------------
 __device__ __forceinline__ uint32_t mb_chroma_residual(uint32_t enc, uint32_t pred, const Q4 &q, bool inter, bool decimate, int lane, int16_t *lv,
-                                                       unsigned &nnz_bits, int &cbp_chroma)
+                                                       unsigned &nnz_bits, int &cbp_chroma, const TrCtx *tr = nullptr)
 {
+    const bool trellis = tr && (tr->on & TR_C);          // final encode of a trellis session: both quantisers below are the search (lv = LDS)
     const int c = (lane >> 4) & 1, i = (lane >> 2) & 3, j = lane & 3;
     const bool act = lane < 32;
     int e[4], p[4], v[4];
@@ -958,7 +989,13 @@ __device__ __forceinline__ uint32_t mb_chroma_residual(uint32_t enc, uint32_t pr
 #pragma unroll
     for (int b = 0; b < 4; b++) dcs[b] = __shfl(v[0], (lane & 48) + 4 * b);
     if (j == 0) v[0] = 0;
-    quant4_row(v, q, j);
+    if (trellis) {
+        if (act) store_levels_scan(lv + X264GPU_LV_CHROMA_AC + (c * 4 + i) * 16, v, j);
+        lds_sync();
+        trellis_run<4>(*tr, lv + X264GPU_LV_CHROMA_AC, 16, 8, q.qp, !inter, lane);
+        lds_sync();
+        if (act) load_levels_scan(lv + X264GPU_LV_CHROMA_AC + (c * 4 + i) * 16, v, j); else v[0] = v[1] = v[2] = v[3] = 0;
+    } else quant4_row(v, q, j);
     unsigned mask = quad_or((int)scan_mask(v, j));
     int big = quad_or(any_big(v) ? 1 : 0);
     bool nz = mask != 0;
@@ -976,6 +1013,19 @@ __device__ __forceinline__ uint32_t mb_chroma_residual(uint32_t enc, uint32_t pr
     int ldc[4], nzdc = 0;
 #pragma unroll
     for (int b = 0; b < 4; b++) { ldc[b] = quant_one(f[b], q.mf[0] >> 1, q.bias[0] << 1); nzdc |= ldc[b]; }
+    if (trellis) {
+        lds_sync();
+        if (act && i == 0 && j == 0)
+#pragma unroll
+            for (int b = 0; b < 4; b++) lv[X264GPU_LV_CHROMA_DC + c * 4 + b] = (int16_t)f[b];
+        lds_sync();
+        trellis_run<3>(*tr, lv + X264GPU_LV_CHROMA_DC, 4, 2, q.qp, !inter, lane);
+        lds_sync();
+        nzdc = 0;
+#pragma unroll
+        for (int b = 0; b < 4; b++) { ldc[b] = lv[X264GPU_LV_CHROMA_DC + c * 4 + b]; nzdc |= ldc[b]; }
+        lds_sync();
+    }
     if (et && et_drop_dc) { ldc[0] = ldc[1] = ldc[2] = ldc[3] = 0; nzdc = 0; }
     if (nzdc && !plane_ac) {
         const int dmf = q.dq[0] << (q.qp / 6);
@@ -1115,10 +1165,6 @@ __device__ __forceinline__ bool mb_probe_pskip(const EncK &k, const MbCtx &c, ui
 #ifndef MB_WAVES_PER_EU
 #define MB_WAVES_PER_EU 2
 #endif
-}  // namespace x264gpu
-#include "cabac_rd.cuh"          // needs the motion cache and the intra-mode helpers above
-namespace x264gpu {
-
 // RD: 0 = SATD decisions (subme <= 5); 1 = RD mode decision with CAVLC bit counts (rd.cuh); 2 = with CABAC context states and sizes (cabac_rd.cuh)
 template <int M, int ME, bool PS, int RD = 0>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(MB_WAVES_PER_EU, 4))) void k_mb_slice(EncK k)
@@ -1595,7 +1641,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(MB_WAVES_PER
                         }
                         i_cost = best; mb_type = e_type; best_part = e_part;
                         if (rd_skip16) {           // as x264_macroblock_analyse leaves a P_SKIP found here: no cost, the other references' predictors zero
-                            i_cost = 0;
+                            i_cost = 0; e_type = X264GPU_MB_P_SKIP; mb_type = e_type;          // and the final encode is x264_macroblock_encode_skip
                             if (lane == 0) { recd.aux[0] = 0; recd.aux[1] = 0; recd.aux[2] = 0; }
                             if (lane >= 1 && lane < c.nref) { int16_t *m = k.mvr[lane] + ((size_t)s * k.nmb + mbi) * 2; m[0] = 0; m[1] = 0; }
                         }
@@ -1607,6 +1653,11 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(MB_WAVES_PER
             }
         }
         nnz = 0; cbp_luma = 0; cbp_chroma = 0;
+        TrCtx trc;                                                // trellis: the final pass of RD sessions with CABAC (x264 --trellis 1)
+        trc.on = 0; trc.r = 0; trc.r8 = 0; trc.model = 0; trc.tt.size_unary = nullptr; trc.tt.trans_unary = nullptr; trc.tt.lambda2 = nullptr;
+        if constexpr (RD == 2) {
+            if (commit && k.trellis && rdon) { trc.on = k.trellis; trc.r = cab.r; trc.r8 = cab.r8; trc.model = cab_modelv; trc.tt.size_unary = k.tr_su; trc.tt.trans_unary = k.tr_tu; trc.tt.lambda2 = k.tr_l2; }
+        }
         int rd_t8cur = 0;                                         // transform_size_8x8_flag of what this pass codes
         rec_type = e_type;
         int16_t *lvw = RD ? (int16_t *)rd_lvs : lv;               // RD: levels stay on chip until the final pass has its bit counts' totals
@@ -1615,7 +1666,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(MB_WAVES_PER
             // this lane's 8x8 block's motion (Z layout: lane >> 4)
             const int b8 = lane >> 4;
             int lmx, lmy, lref;
-            if (pskip) { lmx = clampi(pskx, c.mvmin0, c.mvmax0); lmy = clampi(psky, c.mvmin1, c.mvmax1); lref = 0; }
+            const bool eskip = pskip || e_type == X264GPU_MB_P_SKIP;      // probed, or found by the RD test of the 16x16 result at the skip vector: no residual
+            if (eskip) { lmx = clampi(pskx, c.mvmin0, c.mvmax0); lmy = clampi(psky, c.mvmin1, c.mvmax1); lref = 0; }
             else {
                 const int slot = e_part == D_16x16 ? ME_16 : e_part == D_16x8 ? ME_16x8 + (b8 >> 1) : e_part == D_8x16 ? ME_8x16 + (b8 & 1) : ME_8 + b8;
                 lmx = __shfl(S.mvx, slot); lmy = __shfl(S.mvy, slot); lref = __shfl(S.ref, slot);      // slot varies with the lane (its 8x8 block)
@@ -1627,12 +1679,12 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(MB_WAVES_PER
             uint32_t pu, pv;
             mc_chroma_row4(ref_chroma00(k, s, cref), k.rs, mbx * 8 + cx0, mby * 8 + cyy, cmvx, cmvy, pu, pv);
             const uint32_t cpred = pl ? pv : pu;
-            const int mv0x = pskip ? pskx : __builtin_amdgcn_readlane(lmx, 0), mv0y = pskip ? psky : __builtin_amdgcn_readlane(lmy, 0), ref0 = __builtin_amdgcn_readlane(lref, 0);
+            const int mv0x = eskip ? pskx : __builtin_amdgcn_readlane(lmx, 0), mv0y = eskip ? psky : __builtin_amdgcn_readlane(lmy, 0), ref0 = __builtin_amdgcn_readlane(lref, 0);
             if (commit && (lane & 15) == 0) {      // one lane per 8x8 block writes that block's motion
-                recd.mv[lane >> 4][0] = (int16_t)(pskip ? pskx : lmx); recd.mv[lane >> 4][1] = (int16_t)(pskip ? psky : lmy); recd.ref[lane >> 4] = (int8_t)lref;
+                recd.mv[lane >> 4][0] = (int16_t)(eskip ? pskx : lmx); recd.mv[lane >> 4][1] = (int16_t)(eskip ? psky : lmy); recd.ref[lane >> 4] = (int8_t)lref;
             }
-            if (commit && lane == 0) recd.partition = (uint8_t)(pskip ? 0 : e_part);
-            if (pskip) {
+            if (commit && lane == 0) recd.partition = (uint8_t)(eskip ? 0 : e_part);
+            if (eskip) {
                 *(uint32_t *)(rec + (size_t)zy * k.rs + zx) = pred;
                 mb_store_chroma(ruv, k.rs, lane, cpred);
                 if (lane < 52) { uint4 z; z.x = z.y = z.z = z.w = 0; *(uint4 *)(lvw + lane * 8) = z; }
@@ -1659,9 +1711,21 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(MB_WAVES_PER
                     int mf[4], bs[4], dq[4];
                     q8_row(q8p, row, mf, bs, dq);
                     unsigned mlo = 0, mhi = 0, big = 0;
+                    const bool tr8 = (trc.on & TR_P8) != 0;
+                    if (tr8) {
+                        if (lane < 32)
+#pragma unroll
+                            for (int i = 0; i < 8; i++) lvw[i8 * 64 + c_zigzag8_inv[row * 8 + i]] = (int16_t)v[i];
+                        lds_sync();
+                        trellis_run<5>(trc, lvw, 64, 4, c.qp, false, lane);
+                        lds_sync();
+#pragma unroll
+                        for (int i = 0; i < 8; i++) v[i] = lvw[i8 * 64 + c_zigzag8_inv[row * 8 + i]];
+                        lds_sync();
+                    }
 #pragma unroll
                     for (int i = 0; i < 8; i++) {
-                        v[i] = quant_one(v[i], mf[i & 3], bs[i & 3]);
+                        if (!tr8) v[i] = quant_one(v[i], mf[i & 3], bs[i & 3]);
                         const int z = c_zigzag8_inv[row * 8 + i];
                         if (v[i]) { if (z < 32) mlo |= 1u << z; else mhi |= 1u << (z - 32); }
                         big |= abs(v[i]) > 1 ? 1u : 0u;
@@ -1713,7 +1777,14 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(MB_WAVES_PER
 #pragma unroll
                     for (int i = 0; i < 4; i++) v[i] = e[i] - p[i];
                     dct4_quad(v, lane);
-                    quant4_row(v, q_lp, j4);
+                    if (trc.on & TR_P4) {
+                        store_levels_scan(lvw + (lane >> 2) * 16, v, j4);
+                        lds_sync();
+                        trellis_run<2>(trc, lvw, 16, 16, c.qp, false, lane);
+                        lds_sync();
+                        load_levels_scan(lvw + (lane >> 2) * 16, v, j4);
+                        lds_sync();
+                    } else quant4_row(v, q_lp, j4);
                     const unsigned mask = (unsigned)quad_or((int)scan_mask(v, j4));
                     const bool nz = mask != 0;
                     bool keep = nz;
@@ -1745,7 +1816,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(MB_WAVES_PER
                 }
                 const uint2 fe = *(const uint2 *)(L.csrc + cyy * 16 + 2 * cx0);
                 const uint32_t cenc = nv12_pick(fe.x, fe.y, pl);
-                const uint32_t crec = mb_chroma_residual(cenc, cpred, q_cp, true, k.dct_decimate != 0, lane, lvw, nnz, cbp_chroma);
+                const uint32_t crec = mb_chroma_residual(cenc, cpred, q_cp, true, k.dct_decimate != 0, lane, lvw, nnz, cbp_chroma, &trc);
                 if (commit) mb_store_chroma(ruv, k.rs, lane, crec);
                 if constexpr (RD) { if (lane < 32) ssd_c = ssd4_u8(cenc, crec); }
                 if (lane >= 32 && lane < 40) lvw[X264GPU_LV_LUMA_DC + (lane - 32) * 2] = 0, lvw[X264GPU_LV_LUMA_DC + (lane - 32) * 2 + 1] = 0;
@@ -1849,7 +1920,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(MB_WAVES_PER
                 const uint2 fe = *(const uint2 *)(L.csrc + cyy * 16 + 2 * cx0);
                 const uint32_t cenc = nv12_pick(fe.x, fe.y, pl), cpred = predc_row4(L.cnb[pl], pc, predc, ci, j4);
                 if (commit && lane == 0) recd.chroma_mode = (uint8_t)(predc > PREDC_P ? PREDC_DC : predc);
-                const uint32_t crec = mb_chroma_residual(cenc, cpred, q_ci, false, false, lane, lvw, nnz, cbp_chroma);
+                const uint32_t crec = mb_chroma_residual(cenc, cpred, q_ci, false, false, lane, lvw, nnz, cbp_chroma, &trc);
                 if (commit) mb_store_chroma(ruv, k.rs, lane, crec);
                 if constexpr (RD) { if (lane < 32) ssd_c = ssd4_u8(cenc, crec); }
             }

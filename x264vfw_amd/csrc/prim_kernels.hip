@@ -261,6 +261,15 @@ static int trellis_tables(TrellisTab *out)
     return X264GPU_OK;
 }
 
+// the same tables for the macroblock loop (encoder.hip)
+int trellis_table_ptrs(const uint16_t **su, const uint8_t **tu, const int **l2)
+{
+    TrellisTab tt;
+    const int rc = trellis_tables(&tt);
+    if (rc == X264GPU_OK) { *su = tt.size_unary; *tu = tt.trans_unary; *l2 = tt.lambda2; }
+    return rc;
+}
+
 template <int CAT>
 __global__ void __launch_bounds__(64) k_trellis_blocks(const int16_t *coefs, int nblk, int qp, int intra, const uint8_t *states, TrellisTab tt, int16_t *levels, uint8_t *nz)
 {
