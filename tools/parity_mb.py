@@ -70,6 +70,14 @@ CASES = [
     (176, 144, 4, dict(cabac=1, rd=1, subme=7, partitions=7, dct8x8=1, refs=2, trellis=7, psy=1, psy_rd_q8=256, chroma_qp_offset=-2)),
     (96, 80, 4, dict(cabac=1, rd=1, subme=6, partitions=7, dct8x8=1, qp_i=8, qp_p=10, dct_decimate=0, trellis=7)),
     (208, 120, 4, dict(cabac=1, rd=1, subme=6, partitions=7, dct8x8=1, qp_i=40, qp_p=44, trellis=7)),
+    (64, 48, 3, dict(cabac=1, rd=1, subme=6, partitions=0, trellis=8)),
+    (176, 144, 4, dict(cabac=1, rd=1, subme=6, partitions=2, trellis=16)),
+    (176, 144, 4, dict(cabac=1, rd=1, subme=7, partitions=4, dct8x8=1, trellis=32)),
+    (176, 144, 5, dict(cabac=1, rd=1, subme=7, partitions=7, dct8x8=1, refs=3, mixed_refs=1, chroma_me=1, psy=1, psy_rd_q8=256, chroma_qp_offset=-2, trellis=63)),
+    (352, 288, 4, dict(cabac=1, rd=1, subme=7, partitions=7, dct8x8=1, refs=3, mixed_refs=1, chroma_me=1, qp_i=30, qp_p=34, me_method=2, trellis=63)),
+    (96, 208, 4, dict(cabac=1, rd=1, subme=6, slices=3, partitions=7, dct8x8=1, refs=2, aq_mode=1, trellis=63)),
+    (96, 80, 4, dict(cabac=1, rd=1, subme=6, partitions=7, dct8x8=1, qp_i=8, qp_p=10, dct_decimate=0, fast_pskip=0, trellis=63)),
+    (208, 120, 4, dict(cabac=1, rd=1, subme=6, partitions=7, dct8x8=1, qp_i=44, qp_p=47, trellis=63)),
 ]
 
 

@@ -960,6 +960,113 @@ __device__ __forceinline__ void load_levels_scan(const int16_t *src, int v[4], i
 }
 
 
+// Final encode of an Intra_4x4 / Intra_8x8 macroblock of a trellis session (x264: i_skip_intra is 0 under --trellis 1, so the blocks are coded
+// again): the modes of the analysis (L.modes4 / L.modes8), every block predicted from its re-coded neighbours in the tile, transformed,
+// quantised by the trellis search, reconstructed.  Levels go to lvw in their final layout; returns the non-zero flags (R.nnz4 / R.nnz8 form).
+template <int M>
+__device__ __forceinline__ unsigned mb_encode_i4x4_trellis(const EncK &k, MbLds<M> &L, const MbCtx &c, uint32_t cz, uint32_t t4, const Q4 &q4, const TrCtx &trc, int16_t *lvw)
+{
+    const int lane = c.lane, j = lane & 3;
+    uint8_t *tile = L.tile + IT_ORG;
+    unsigned nnz4 = 0;
+    for (int idx = 0; idx < 16; idx++) {
+        const int bx = z_bx(idx), by = z_by(idx);
+        const int avail = i4_avail(c.mbx, c.sy, k.mbw, idx);
+        lds_sync();
+        uint8_t *bt = tile + by * 4 * IT_STRIDE + bx * 4;
+        pred4_build_u(L.U, bt, IT_STRIDE, avail, lane);
+        const uint32_t pr = pred4_row4(L.U, t4);
+        const uint32_t en = (uint32_t)__shfl((int)cz, idx * 4 + j);
+        const int bm = L.modes4[idx];
+        const uint32_t bp = (uint32_t)__shfl((int)pr, bm * 4 + j);
+        int e[4], p[4], v[4];
+        unpack4(en, e); unpack4(bp, p);
+#pragma unroll
+        for (int t = 0; t < 4; t++) v[t] = e[t] - p[t];
+        dct4_quad(v, lane);
+        if (lane < 4) store_levels_scan(lvw + idx * 16, v, j);
+        lds_sync();
+        trellis_run<2>(trc, lvw + idx * 16, 16, 1, c.qp, true, lane);
+        lds_sync();
+        load_levels_scan(lvw + idx * 16, v, j);
+        const bool nz = quad_or((v[0] | v[1] | v[2] | v[3]) != 0 ? 1 : 0) != 0;
+        dequant4_row(v, q4, j);
+        idct4_quad(v, lane);
+#pragma unroll
+        for (int t = 0; t < 4; t++) v[t] += p[t];
+        if (lane < 4) *(uint32_t *)(bt + j * IT_STRIDE) = nz ? pack4_clip(v) : bp;
+        if (__builtin_amdgcn_readfirstlane((int)nz)) nnz4 |= 1u << idx;
+    }
+    lds_sync();
+    return nnz4;
+}
+template <int M>
+__device__ __forceinline__ unsigned mb_encode_i8x8_trellis(const EncK &k, MbLds<M> &L, const MbCtx &c, uint32_t cz, const Q8 &q8, const TrCtx &trc, int16_t *lvw, int &cbp8)
+{
+    const int lane = c.lane, g = lane >> 3, r8 = lane & 7;
+    const bool left = c.mbx > 0, top = c.sy > 0, topright = top && c.mbx + 1 < k.mbw;
+    uint8_t *tile8 = L.tile8 + IT_ORG;
+    unsigned nnz8 = 0;
+    cbp8 = 0;
+    for (int idx = 0; idx < 4; idx++) {
+        const int x8 = idx & 1, y8 = idx >> 1, avail = i8_avail(left, top, topright, idx);
+        lds_sync();
+        uint8_t *bt = tile8 + y8 * 8 * IT_STRIDE + x8 * 8;
+        pred8_build_u(L.U8, bt, IT_STRIDE, avail, lane);
+        const int src = idx * 16 + (r8 >> 2) * 8 + (r8 & 3);
+        const uint32_t elo = (uint32_t)__shfl((int)cz, src), ehi = (uint32_t)__shfl((int)cz, src + 4);
+        uint32_t p1lo, p1hi, p2lo, p2hi;
+        pred8_row8(L.U8, L.pred8tab, g, r8, p1lo, p1hi);
+        pred8_row8(L.U8, L.pred8tab, 8, r8, p2lo, p2hi);
+        const int bm = L.modes8[idx * 4];
+        const uint32_t plo = bm == 8 ? (uint32_t)__shfl((int)p2lo, r8) : (uint32_t)__shfl((int)p1lo, bm * 8 + r8);
+        const uint32_t phi = bm == 8 ? (uint32_t)__shfl((int)p2hi, r8) : (uint32_t)__shfl((int)p1hi, bm * 8 + r8);
+        int e[8], p[8], v[8];
+        unpack8(elo, ehi, e); unpack8(plo, phi, p);
+#pragma unroll
+        for (int i = 0; i < 8; i++) v[i] = e[i] - p[i];
+        fwd8_1d(v); transpose8(v, lane); fwd8_1d(v); transpose8(v, lane);
+        int mf[4], bs[4], dq[4];
+        q8_row(q8, r8, mf, bs, dq);
+        if (g == 0)
+#pragma unroll
+            for (int i = 0; i < 8; i++) lvw[idx * 64 + c_zigzag8_inv[r8 * 8 + i]] = (int16_t)v[i];
+        lds_sync();
+        trellis_run<5>(trc, lvw + idx * 64, 64, 1, c.qp, true, lane);
+        lds_sync();
+        unsigned mlo = 0, mhi = 0;
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+            const int z = c_zigzag8_inv[r8 * 8 + i];
+            v[i] = lvw[idx * 64 + z];
+            if (v[i]) { if (z < 32) mlo |= 1u << z; else mhi |= 1u << (z - 32); }
+        }
+        lds_sync();
+        if (g == 0)          // the levels leave in the interleaved form (level z of the zigzag at block 4 idx + (z & 3), entry z >> 2)
+#pragma unroll
+            for (int i = 0; i < 8; i++) { const int z = c_zigzag8_inv[r8 * 8 + i]; lvw[(idx * 4 + (z & 3)) * 16 + (z >> 2)] = (int16_t)v[i]; }
+        mlo = group8_or(mlo); mhi = group8_or(mhi);
+        const unsigned long long mask = ((unsigned long long)mhi << 32) | mlo;
+#pragma unroll
+        for (int q = 0; q < 4; q++) nnz8 |= (mask & (0x1111111111111111ull << q)) ? 1u << (idx * 4 + q) : 0u;
+        if (mask) cbp8 |= 1 << idx;
+        const int qb = q8.qp / 6 - 6;
+#pragma unroll
+        for (int i = 0; i < 8; i++) v[i] = dequant_one(v[i], dq[i & 3], qb);
+        inv8_1d(v); transpose8(v, lane); inv8_1d(v); transpose8(v, lane);
+#pragma unroll
+        for (int i = 0; i < 8; i++) v[i] = ((v[i] + 32) >> 6) + p[i];
+        if (g == 0) {
+            *(uint32_t *)(bt + r8 * IT_STRIDE) = pack4_clip8lo(v);
+            *(uint32_t *)(bt + r8 * IT_STRIDE + 4) = pack4_clip8hi(v);
+        }
+    }
+    lds_sync();
+    nnz8 = (unsigned)__builtin_amdgcn_readfirstlane((int)nnz8);
+    cbp8 = __builtin_amdgcn_readfirstlane(cbp8);
+    return nnz8;
+}
+
 // ------------------------------------------------------------------------------------------------
 // chroma residual with x264's variance early termination (oracle encode_chroma).  Lanes 0..31: plane = lane >> 4,
 // 4x4 block = (lane >> 2) & 3, row = lane & 3.
@@ -1836,23 +1943,27 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(MB_WAVES_PER
                 if (commit && lane == 0) recd.transform8x8 = 1;
                 if (commit && lane < 16) recd.i4_mode[lane] = L.modes8[lane];
                 nnz = IR.nnz8; cbp_luma = IR.cbp8;
+                const bool tri8 = (trc.on & TR_I8) != 0;
+                if (tri8) nnz = mb_encode_i8x8_trellis(k, L, c, cz, q8i, trc, lvw, cbp_luma);
                 {
                     const uint32_t rz = *(const uint32_t *)(tile8 + zy * IT_STRIDE + zx);
                     if (commit) *(uint32_t *)(rec + (size_t)zy * k.rs + zx) = rz;
                     if constexpr (RD) { ssd_y = ssd4_u8(cz, rz); en_satd = satd4_half(rz, 0u, lane); en_sad = (int)__builtin_amdgcn_sad_u8(rz, 0u, 0u); }
                 }
-                *(uint2 *)(lvw + lane * 4) = *(const uint2 *)(L.lv8 + lane * 4);
+                if (!tri8) *(uint2 *)(lvw + lane * 4) = *(const uint2 *)(L.lv8 + lane * 4);
                 if (lane < 16) lvw[X264GPU_LV_LUMA_DC + lane] = 0;
             } else if (e_type == X264GPU_MB_I4x4) {
                 if (commit && lane < 16) recd.i4_mode[lane] = L.modes4[lane];
                 nnz = IR.nnz4;
+                const bool tri4 = (trc.on & TR_I4) != 0;
+                if (tri4) nnz = mb_encode_i4x4_trellis(k, L, c, cz, t4, q_li, trc, lvw);
                 for (int i8 = 0; i8 < 4; i8++) if ((nnz >> (4 * i8)) & 15) cbp_luma |= 1 << i8;
                 {
                     const uint32_t rz = *(const uint32_t *)(tile + zy * IT_STRIDE + zx);
                     if (commit) *(uint32_t *)(rec + (size_t)zy * k.rs + zx) = rz;
                     if constexpr (RD) { ssd_y = ssd4_u8(cz, rz); en_satd = satd4_half(rz, 0u, lane); en_sad = (int)__builtin_amdgcn_sad_u8(rz, 0u, 0u); }
                 }
-                *(uint2 *)(lvw + lane * 4) = *(const uint2 *)(L.lv4 + lane * 4);
+                if (!tri4) *(uint2 *)(lvw + lane * 4) = *(const uint2 *)(L.lv4 + lane * 4);
                 if (lane < 16) lvw[X264GPU_LV_LUMA_DC + lane] = 0;
             } else {
                 // x264_mb_encode_i16x16 (AC decimated as a whole in P slices)
@@ -1866,7 +1977,14 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(MB_WAVES_PER
                 dct4_quad(v, lane);
                 const int dcv = v[0];
                 if (j4 == 0) v[0] = 0;
-                quant4_row(v, q_li, j4);
+                if (trc.on & TR_I16) {
+                    store_levels_scan(lvw + (lane >> 2) * 16, v, j4);
+                    lds_sync();
+                    trellis_run<1>(trc, lvw, 16, 16, c.qp, true, lane);
+                    lds_sync();
+                    load_levels_scan(lvw + (lane >> 2) * 16, v, j4);
+                    lds_sync();
+                } else quant4_row(v, q_li, j4);
                 const unsigned mask = (unsigned)quad_or((int)scan_mask(v, j4));
                 bool nz = mask != 0;
                 if (pslice && k.dct_decimate) {
@@ -1886,7 +2004,18 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(MB_WAVES_PER
                 for (int cc = 0; cc < 4; cc++) dc[cc] = __shfl(dcv, 4 * blkidx_of(cc, j4));
                 had4x4_quad(dc, lane);
 #pragma unroll
-                for (int cc = 0; cc < 4; cc++) dc[cc] = quant_one((dc[cc] + 1) >> 1, q_li.mf[0] >> 1, q_li.bias[0] << 1);
+                for (int cc = 0; cc < 4; cc++) dc[cc] = (dc[cc] + 1) >> 1;
+                if (trc.on & TR_I16) {
+                    lds_sync();
+                    if (lane < 4) store_levels_scan(lvw + X264GPU_LV_LUMA_DC, dc, j4);
+                    lds_sync();
+                    trellis_run<0>(trc, lvw + X264GPU_LV_LUMA_DC, 16, 1, c.qp, true, lane);
+                    lds_sync();
+                    load_levels_scan(lvw + X264GPU_LV_LUMA_DC, dc, j4);
+                    lds_sync();
+                } else
+#pragma unroll
+                    for (int cc = 0; cc < 4; cc++) dc[cc] = quant_one(dc[cc], q_li.mf[0] >> 1, q_li.bias[0] << 1);
                 const bool nzdc = quad_or((dc[0] | dc[1] | dc[2] | dc[3]) != 0 ? 1 : 0) != 0;
                 if (lane < 4) store_levels_scan(lvw + X264GPU_LV_LUMA_DC, dc, j4);
                 had4x4_quad(dc, lane);
