@@ -198,7 +198,7 @@ extern "C" int x264o_quant_trellis_cabac(dctcoef *dct, const uint16_t *mf, int q
         return dct[0] != 0;
     }
 
-    static Trellis T;                                   // (the oracle is single-threaded per process)
+    Trellis T;                                          // (on the stack: the stub device of tests/stub runs several oracle encoders on host threads)
     T.cur = T.nodes[0]; T.prev = T.nodes[1]; T.used = 1; T.lambda2 = lambda2;
     memset(T.nodes, 0, sizeof(T.nodes));
     for (int j = 1; j < 8; j++) T.cur[j].score = SCORE_MAX;

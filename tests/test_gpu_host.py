@@ -38,7 +38,7 @@ def eff_kw(eff):
     compensation), entropy coder, vector range"""
     rd = int(eff.analyse.i_subpel_refine >= 6)
     q8 = int(eff.analyse.f_psy_rd * 256.0 + 0.5) if rd and eff.analyse.b_psy else 0
-    return dict(subme=eff.analyse.i_subpel_refine, rd=rd, psy=int(rd and eff.analyse.b_psy), psy_rd_q8=q8, chroma_qp_offset=eff.analyse.i_chroma_qp_offset,
+    return dict(subme=eff.analyse.i_subpel_refine, rd=rd, psy=int(rd and eff.analyse.b_psy), psy_rd_q8=q8, trellis=63 if eff.analyse.i_trellis else 0, chroma_qp_offset=eff.analyse.i_chroma_qp_offset,
                 mv_range=eff.analyse.i_mv_range, cabac=eff.b_cabac)
 
 
@@ -105,7 +105,7 @@ def test_rd_session_equals_oracle_pipeline(gpu, opts, subme, cqo):
     w, h, nfr, qp = 176, 144, 5, 27
     frames = synth_frames(w, h, nfr, seed=606)
     h_, eff = open_encoder(w, h, dict({"qp": qp, "keyint": 250}, **opts), b"baseline")
-    assert (eff.b_cabac, eff.analyse.i_subpel_refine, eff.analyse.i_chroma_qp_offset) == (0, subme, cqo)
+    assert (eff.b_cabac, eff.analyse.i_subpel_refine, eff.analyse.i_chroma_qp_offset, eff.analyse.i_trellis) == (0, subme, cqo, 0)      # no CABAC: no trellis
     stream, info, recons = encode_all(h_, w, h, frames)
     H.x264_encoder_close(h_)
     kw = eff_kw(eff)
@@ -126,7 +126,7 @@ def test_medium_session_runs_rd_with_cabac(gpu, opts):
     w, h, nfr, qp = 176, 144, 5, 26
     frames = synth_frames(w, h, nfr, seed=707)
     h_, eff = open_encoder(w, h, dict({"qp": qp, "keyint": 250}, **opts), b"high")
-    assert (eff.b_cabac, eff.analyse.i_subpel_refine) == (1, 7)
+    assert (eff.b_cabac, eff.analyse.i_subpel_refine, eff.analyse.i_trellis) == (1, 7, 1)        # medium: trellis 1 on the device too
     stream, info, recons = encode_all(h_, w, h, frames)
     H.x264_encoder_close(h_)
     kw = eff_kw(eff)

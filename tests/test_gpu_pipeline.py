@@ -138,6 +138,19 @@ CABAC_CTX_P = CABAC_CTX_I + list(range(11, 24)) + list(range(40, 60))
     (96, 208, 4, dict(slices=3, partitions=7, dct8x8=1, refs=2, psy=1, psy_rd_q8=102, chroma_qp_offset=-1, aq_mode=1, subme=6)),
     (96, 80, 4, dict(partitions=7, dct8x8=1, qp_i=8, qp_p=10, dct_decimate=0, fast_pskip=0, subme=6)),
     (208, 120, 4, dict(partitions=7, dct8x8=1, qp_i=44, qp_p=47, psy=1, psy_rd_q8=512, me_method=3, me_range=8, subme=6)),
+    # trellis quantisation of the final encode (x264 --trellis 1 = every site = 63), and site by site: 1 inter 4x4, 2 inter 8x8, 4 chroma,
+    # 8 Intra_16x16, 16 Intra_4x4, 32 Intra_8x8
+    (176, 144, 4, dict(partitions=1, subme=6, trellis=1)),
+    (176, 144, 4, dict(partitions=5, dct8x8=1, subme=7, trellis=2)),
+    (176, 144, 4, dict(partitions=1, subme=6, trellis=4)),
+    (64, 48, 3, dict(partitions=0, subme=6, trellis=8)),
+    (176, 144, 4, dict(partitions=2, subme=6, trellis=16)),
+    (176, 144, 4, dict(partitions=4, dct8x8=1, subme=7, trellis=32)),
+    (176, 144, 6, dict(partitions=7, dct8x8=1, refs=3, mixed_refs=1, chroma_me=1, psy=1, psy_rd_q8=256, chroma_qp_offset=-2, subme=7, trellis=63)),       # preset medium (I / P)
+    (352, 288, 4, dict(partitions=7, dct8x8=1, refs=3, mixed_refs=1, chroma_me=1, qp_i=30, qp_p=34, me_method=2, subme=7, trellis=63)),
+    (96, 208, 4, dict(slices=3, partitions=7, dct8x8=1, refs=2, aq_mode=1, subme=6, trellis=63)),
+    (96, 80, 4, dict(partitions=7, dct8x8=1, qp_i=8, qp_p=10, dct_decimate=0, fast_pskip=0, subme=6, trellis=63)),
+    (208, 120, 4, dict(partitions=7, dct8x8=1, qp_i=44, qp_p=47, subme=6, trellis=63)),
 ])
 def test_pipeline_cabac_rd_bitexact(gpu, w, h, nfr, kw):
     """RD mode decision in a CABAC session (x264 subme 6 / 7 at preset medium's entropy coder): the device carries the slice's context

@@ -1,4 +1,4 @@
-"""Longer randomised parity soak than tests/test_gpu_fuzz.py runs per round: python tools/fuzz_soak.py SEED0 SEED1 [cases per seed] [rd | rdcabac].
+"""Longer randomised parity soak than tests/test_gpu_fuzz.py runs per round: python tools/fuzz_soak.py SEED0 SEED1 [cases per seed] [rd | rdcabac | trellis].
 With "rd" / "rdcabac" every case runs with RD mode decision on (CAVLC / CABAC session, subme 6 / 7, random psy-RD strength).
 Every random case (tests/test_gpu_fuzz.py random_case) is encoded by the HIP pipeline and the oracle; mismatches are listed, not fatal."""
 import os
@@ -20,8 +20,9 @@ from test_gpu_fuzz import random_case  # noqa: E402
 def main():
     s0, s1 = int(sys.argv[1]), int(sys.argv[2])
     per = int(sys.argv[3]) if len(sys.argv) > 3 else 40
-    rd = len(sys.argv) > 4 and sys.argv[4] in ("rd", "rdcabac")
-    rd_cabac = len(sys.argv) > 4 and sys.argv[4] == "rdcabac"
+    rd = len(sys.argv) > 4 and sys.argv[4] in ("rd", "rdcabac", "trellis")
+    rd_cabac = len(sys.argv) > 4 and sys.argv[4] in ("rdcabac", "trellis")
+    trellis = len(sys.argv) > 4 and sys.argv[4] == "trellis"
     bad = total = 0
     t0 = time.time()
     for seed in range(s0, s1):
@@ -30,6 +31,8 @@ def main():
             w, h, kw, nfr, fseed, second_idr = random_case(rnd)
             if rd:
                 psy = rnd.randint(0, 1)
+                if trellis:
+                    kw.update(trellis=rnd.choice([63, 63, rnd.randint(1, 62)]))
                 kw.update(cabac=int(rd_cabac), rd=1, subme=rnd.choice([6, 7]), psy=psy, psy_rd_q8=rnd.choice([26, 102, 256, 512]) if psy else 0)
             frames = synth_frames(w, h, nfr, seed=fseed)
             cfg = O.default_config(w, h, **kw)
