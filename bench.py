@@ -13,8 +13,8 @@ deblock wavefront -> half-pel planes.  Inputs are resident in HBM before the tim
 forwards and backwards).  The timed K steps start on an IDR boundary.  Streams are independent (BASELINE.json config 5), so
 N GPUs shard streams one set per GPU with no collective in the data path ("scaling": "weak").
 
-WHAT IS MEASURED IS NOT x264's FULL preset=medium: the toolset is medium (CABAC, subme 7 = RD mode decision with CABAC sizes, psy-rd 1.0)
-minus B-frames, trellis and weightp — `config.toolset_gaps` says so in the JSON line.  `--rd cavlc` measures medium --no-cabac (RD with
+WHAT IS MEASURED IS NOT x264's FULL preset=medium: the toolset is medium (CABAC, subme 7 = RD mode decision with CABAC sizes, psy-rd 1.0,
+trellis 1) minus B-frames and weightp — `config.toolset_gaps` says so in the JSON line.  `--rd cavlc` measures medium --no-cabac (RD with
 CAVLC bit counts), `--rd off` the subme-5 toolset of the earlier rounds (SATD decisions), for comparison.
 
 Rank 0 prints ONE JSON line with `roofline` (the macroblock kernel, HIP-event timed inside the timed region, HBM fraction + VALU
@@ -36,7 +36,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0   # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
-TOOLSET_GAPS = "x264 medium minus: B-frames (bframes 3 -> 0), trellis 1, weightp 2; entropy coding (CABAC/CAVLC bitstream writing) runs on host threads and is outside `value` (inside `e2e`)"
+TOOLSET_GAPS = "x264 medium minus: B-frames (bframes 3 -> 0), weightp 2; entropy coding (CABAC/CAVLC bitstream writing) runs on host threads and is outside `value` (inside `e2e`)"
 TOOLSET_GAPS_NORD = "x264 medium minus: B-frames (bframes 3 -> 0), RD mode decision + psy-rd (subme 7 -> 5), trellis 1, weightp 2; entropy coding runs on host threads and is outside `value`"
 
 
@@ -55,6 +55,7 @@ def parse_args():
     ap.add_argument("--refs", type=int, default=3, help="reference frames (medium: 3)")
     ap.add_argument("--preset", default="medium", choices=["medium", "ultrafast", "slow"])
     ap.add_argument("--rd", default="cabac", choices=["cabac", "cavlc", "off"], help="RD mode decision (subme 7, psy-rd 1.0) with the sizes of medium's CABAC (default, the headline), of CAVLC (medium --no-cabac), or off (subme 5: SATD decisions)")
+    ap.add_argument("--no-trellis", action="store_true", help="headline toolset without trellis 1 (for comparison)")
     ap.add_argument("--aq", action="store_true", help="variance AQ on (per-macroblock quantisers, the CRF / ABR path); the headline metric is CQP and leaves it off, as x264 does")
     ap.add_argument("--cpu-frames", type=int, default=10, help="frames per core of the CPU-baseline sample (0 = skip)")
     ap.add_argument("--e2e-frames", type=int, default=10, help="frames of the single-stream threads-1 end-to-end sample (0 = skip e2e)")
@@ -73,6 +74,8 @@ def toolset(args):
     t = dict(t, fast_pskip=1, mv_range=512, cabac=0 if args.preset == "ultrafast" else 1)          # medium's entropy coder (it runs on the host; the analysis costs know it)
     if args.rd != "off" and args.preset != "ultrafast":
         t = dict(t, cabac=int(args.rd == "cabac"), rd=1, subme=7, psy=1, psy_rd_q8=256, chroma_qp_offset=-2)            # x264 lowers the chroma offset by 2 under psy-rd >= 0.25
+        if args.rd == "cabac" and not args.no_trellis:
+            t = dict(t, trellis=63)                               # medium's --trellis 1: every quantiser call of the final encode
     if args.aq:
         t = dict(t, aq_mode=1, aq_strength_q8=266)
     return t
@@ -133,7 +136,7 @@ def cpu_baseline(args):
     """the oracle (kind "port") on 1 core and on every host core (one stream per core), bounded sample"""
     ncpu = os.cpu_count() or 1
     base = [sys.executable, os.path.abspath(__file__), "--width", str(args.width), "--height", str(args.height), "--qp", str(args.qp),
-            "--keyint", str(args.keyint), "--refs", str(args.refs), "--preset", args.preset] + (["--aq"] if args.aq else []) + ["--rd", args.rd]
+            "--keyint", str(args.keyint), "--refs", str(args.refs), "--preset", args.preset] + (["--aq"] if args.aq else []) + ["--rd", args.rd] + (["--no-trellis"] if args.no_trellis else [])
     nall = max(2, min(args.cpu_frames, args.cpu_frames_all))
 
     def run(n, frames):
@@ -413,7 +416,7 @@ def main():
     avg_ms = ms[dom] / max(cnt[dom], 1)
     achieved = alg[names[dom]] * S / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
     traffic, valu = pmc_evidence("k_mb_slice" if names[dom] == "macroblocks" else names[dom], avg_ms, S, args.content)
-    if args.rd != "cabac":
+    if args.rd != "cabac" or args.no_trellis:
         traffic, valu = None, None                            # the committed counters are the headline kernel's (RD with CABAC sizes)
     roof = {"bound": "hbm", "kernel": "k_mb_slice (macroblock loop)" if names[dom] == "macroblocks" else names[dom], "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic, "valu": valu,

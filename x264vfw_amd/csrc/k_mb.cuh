@@ -1272,7 +1272,8 @@ __device__ __forceinline__ bool mb_probe_pskip(const EncK &k, const MbCtx &c, ui
 #ifndef MB_WAVES_PER_EU
 #define MB_WAVES_PER_EU 2
 #endif
-// RD: 0 = SATD decisions (subme <= 5); 1 = RD mode decision with CAVLC bit counts (rd.cuh); 2 = with CABAC context states and sizes (cabac_rd.cuh)
+// RD: 0 = SATD decisions (subme <= 5); 1 = RD mode decision with CAVLC bit counts (rd.cuh); 2 = with CABAC context states and sizes (cabac_rd.cuh);
+// 3 = 2 + the trellis quantiser in the final encode (trellis.cuh) — an instantiation of its own: the search's registers would cost the others spills
 template <int M, int ME, bool PS, int RD = 0>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(MB_WAVES_PER_EU, 4))) void k_mb_slice(EncK k)
 {
@@ -1285,7 +1286,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(MB_WAVES_PER
     for (int i = lane; i < 144; i += 64) ((uint32_t *)L.pred8tab)[i] = ((const uint32_t *)c_pred8_table)[i];
     lds_sync();
     x264gpu_mb *mbs = k.mb + (size_t)s * k.nmb;
-    constexpr bool pslice = PS;                 // I slices run their own instantiation (no search code, a fraction of the registers)
+    constexpr bool pslice = PS;
+    constexpr bool TRL = RD == 3;               // trellis sites compiled in                 // I slices run their own instantiation (no search code, a fraction of the registers)
     const int j4 = lane & 3, zx = z_x0(lane), zy = z_y(lane);
     int intra_count = 0, cost_qp = -1;
     // RD instantiation: levels of the candidate being costed (and of the final macroblock, before they go out), total_coeff of the left / top
@@ -1297,7 +1299,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(MB_WAVES_PER
     Cab cab = { 0, 0, 0, 0, 0 };
     uint32_t cab_modelv = 0;
     int last_dqp = 0;
-    if constexpr (RD == 2) { cab_init(cab, lane, pslice, last_qp); cab_modelv = cab_model(lane); }
+    if constexpr (RD >= 2) { cab_init(cab, lane, pslice, last_qp); cab_modelv = cab_model(lane); }
     Prof pf;
     pf.start();
     int16_t *mv16 = k.mv16_cur + (size_t)s * k.nmb * 2;
@@ -1371,7 +1373,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(MB_WAVES_PER
         if (lane < 32) csv = *(const uint32_t *)(c.fuv + (size_t)(lane >> 2) * k.fs + (lane & 3) * 4);
         uint8_t ntcv = 0;            // RD: total_coeff of the left (lanes 0..23) / top (lanes 24..47) macroblock's blocks
         uint32_t cnbv = 0;           // CABAC RD: lanes 0..3 / 4..7 = dwords 0, 1, 6, 11 of the left / top record, lanes 8, 9 / 10, 11 = their |mvd| bytes
-        if constexpr (RD == 2) {
+        if constexpr (RD >= 2) {
             if (lane < 8) { const bool av = lane < 4 ? left : top; static_assert(sizeof(x264gpu_mb) == 64, "record"); const int dw = (lane & 3) == 0 ? 0 : (lane & 3) == 1 ? 1 : (lane & 3) == 2 ? 6 : 11;
                             if (av) cnbv = ((const uint32_t *)(mbs + (lane < 4 ? mbi - 1 : mbi - k.mbw)))[dw]; }
             else if (lane < 12) { const bool av = lane < 10 ? left : top; if (av) cnbv = ((const uint32_t *)(k.amvd + ((size_t)s * k.nmb + (lane < 10 ? mbi - 1 : mbi - k.mbw)) * 8))[lane & 1]; }
@@ -1762,7 +1764,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(MB_WAVES_PER
         nnz = 0; cbp_luma = 0; cbp_chroma = 0;
         TrCtx trc;                                                // trellis: the final pass of RD sessions with CABAC (x264 --trellis 1)
         trc.on = 0; trc.r = 0; trc.r8 = 0; trc.model = 0; trc.tt.size_unary = nullptr; trc.tt.trans_unary = nullptr; trc.tt.lambda2 = nullptr;
-        if constexpr (RD == 2) {
+        if constexpr (RD == 3) {
             if (commit && k.trellis && rdon) { trc.on = k.trellis; trc.r = cab.r; trc.r8 = cab.r8; trc.model = cab_modelv; trc.tt.size_unary = k.tr_su; trc.tt.trans_unary = k.tr_tu; trc.tt.lambda2 = k.tr_l2; }
         }
         int rd_t8cur = 0;                                         // transform_size_8x8_flag of what this pass codes
@@ -1818,7 +1820,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(MB_WAVES_PER
                     int mf[4], bs[4], dq[4];
                     q8_row(q8p, row, mf, bs, dq);
                     unsigned mlo = 0, mhi = 0, big = 0;
-                    const bool tr8 = (trc.on & TR_P8) != 0;
+                    const bool tr8 = TRL && (trc.on & TR_P8) != 0;
                     if (tr8) {
                         if (lane < 32)
 #pragma unroll
@@ -1884,7 +1886,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(MB_WAVES_PER
 #pragma unroll
                     for (int i = 0; i < 4; i++) v[i] = e[i] - p[i];
                     dct4_quad(v, lane);
-                    if (trc.on & TR_P4) {
+                    if (TRL && (trc.on & TR_P4)) {
                         store_levels_scan(lvw + (lane >> 2) * 16, v, j4);
                         lds_sync();
                         trellis_run<2>(trc, lvw, 16, 16, c.qp, false, lane);
@@ -1923,7 +1925,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(MB_WAVES_PER
                 }
                 const uint2 fe = *(const uint2 *)(L.csrc + cyy * 16 + 2 * cx0);
                 const uint32_t cenc = nv12_pick(fe.x, fe.y, pl);
-                const uint32_t crec = mb_chroma_residual(cenc, cpred, q_cp, true, k.dct_decimate != 0, lane, lvw, nnz, cbp_chroma, &trc);
+                const uint32_t crec = mb_chroma_residual(cenc, cpred, q_cp, true, k.dct_decimate != 0, lane, lvw, nnz, cbp_chroma, TRL ? &trc : nullptr);
                 if (commit) mb_store_chroma(ruv, k.rs, lane, crec);
                 if constexpr (RD) { if (lane < 32) ssd_c = ssd4_u8(cenc, crec); }
                 if (lane >= 32 && lane < 40) lvw[X264GPU_LV_LUMA_DC + (lane - 32) * 2] = 0, lvw[X264GPU_LV_LUMA_DC + (lane - 32) * 2 + 1] = 0;
@@ -1943,7 +1945,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(MB_WAVES_PER
                 if (commit && lane == 0) recd.transform8x8 = 1;
                 if (commit && lane < 16) recd.i4_mode[lane] = L.modes8[lane];
                 nnz = IR.nnz8; cbp_luma = IR.cbp8;
-                const bool tri8 = (trc.on & TR_I8) != 0;
+                const bool tri8 = TRL && (trc.on & TR_I8) != 0;
                 if (tri8) nnz = mb_encode_i8x8_trellis(k, L, c, cz, q8i, trc, lvw, cbp_luma);
                 {
                     const uint32_t rz = *(const uint32_t *)(tile8 + zy * IT_STRIDE + zx);
@@ -1955,7 +1957,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(MB_WAVES_PER
             } else if (e_type == X264GPU_MB_I4x4) {
                 if (commit && lane < 16) recd.i4_mode[lane] = L.modes4[lane];
                 nnz = IR.nnz4;
-                const bool tri4 = (trc.on & TR_I4) != 0;
+                const bool tri4 = TRL && (trc.on & TR_I4) != 0;
                 if (tri4) nnz = mb_encode_i4x4_trellis(k, L, c, cz, t4, q_li, trc, lvw);
                 for (int i8 = 0; i8 < 4; i8++) if ((nnz >> (4 * i8)) & 15) cbp_luma |= 1 << i8;
                 {
@@ -1977,7 +1979,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(MB_WAVES_PER
                 dct4_quad(v, lane);
                 const int dcv = v[0];
                 if (j4 == 0) v[0] = 0;
-                if (trc.on & TR_I16) {
+                if (TRL && (trc.on & TR_I16)) {
                     store_levels_scan(lvw + (lane >> 2) * 16, v, j4);
                     lds_sync();
                     trellis_run<1>(trc, lvw, 16, 16, c.qp, true, lane);
@@ -2005,7 +2007,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(MB_WAVES_PER
                 had4x4_quad(dc, lane);
 #pragma unroll
                 for (int cc = 0; cc < 4; cc++) dc[cc] = (dc[cc] + 1) >> 1;
-                if (trc.on & TR_I16) {
+                if (TRL && (trc.on & TR_I16)) {
                     lds_sync();
                     if (lane < 4) store_levels_scan(lvw + X264GPU_LV_LUMA_DC, dc, j4);
                     lds_sync();
@@ -2049,14 +2051,14 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(MB_WAVES_PER
                 const uint2 fe = *(const uint2 *)(L.csrc + cyy * 16 + 2 * cx0);
                 const uint32_t cenc = nv12_pick(fe.x, fe.y, pl), cpred = predc_row4(L.cnb[pl], pc, predc, ci, j4);
                 if (commit && lane == 0) recd.chroma_mode = (uint8_t)(predc > PREDC_P ? PREDC_DC : predc);
-                const uint32_t crec = mb_chroma_residual(cenc, cpred, q_ci, false, false, lane, lvw, nnz, cbp_chroma, &trc);
+                const uint32_t crec = mb_chroma_residual(cenc, cpred, q_ci, false, false, lane, lvw, nnz, cbp_chroma, TRL ? &trc : nullptr);
                 if (commit) mb_store_chroma(ruv, k.rs, lane, crec);
                 if constexpr (RD) { if (lane < 32) ssd_c = ssd4_u8(cenc, crec); }
             }
             if (commit) intra_count++;
             pf.mark(PH_ENC_INTRA);
         }
-        if constexpr (RD == 2) {
+        if constexpr (RD >= 2) {
             // ---- CABAC: the candidate priced on a copy of the slice's context variables; the finished macroblock moves them on ----
             lds_sync();
             struct RdMark { Prof &p; __device__ ~RdMark() {
@@ -2233,7 +2235,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(MB_WAVES_PER
         __builtin_amdgcn_s_waitcnt(0);
         pf.mark(PH_STORE);
     }
-    if constexpr (RD == 2) {
+    if constexpr (RD >= 2) {
         if (k.cab_out) { uint32_t *o = k.cab_out + ((size_t)s * (k.slices > 1 ? k.slices : 1) + blockIdx.y) * 192; o[lane] = cab.a; o[64 + lane] = cab.r; o[128 + lane] = cab.r8; }
     }
 #ifdef MB_PROF

@@ -70,23 +70,34 @@ __device__ __forceinline__ unsigned trellis_blocks(int16_t *coefs, int stride, i
     const bool blk_on = g < nblk;
     int16_t *mine = coefs + g * stride;
     const int lambda2 = tt.lambda2[(intra ? 52 : 0) + qp];
-    const int sh4 = qp / 6 - 1, sh8 = qp / 6;
-    auto mf_of = [&](int i) {
-        if (DC) return shift_round_d(c_quant4_scale[qp % 6][0], sh4) >> 1;
-        return CAT == 5 ? shift_round_d(c_quant8_scale[qp % 6][trellis_class(CAT, i)], sh8) : shift_round_d(c_quant4_scale[qp % 6][trellis_class(CAT, i)], sh4);
+    // quantiser, rounding offset, inverse and distortion weight of every coefficient class (three for 4x4 blocks, six for 8x8, one for DC
+    // blocks), worked out once: the divisions stay out of the loop
+    constexpr int NCLS = DC ? 1 : CAT == 5 ? 6 : 3;
+    int q_mf[NCLS], q_bias[NCLS], q_unq[NCLS], q_w[NCLS];
+#pragma unroll
+    for (int cl = 0; cl < NCLS; cl++) {
+        if (DC) {
+            const int m0 = shift_round_d(c_quant4_scale[qp % 6][0], qp / 6 - 1);
+            q_mf[cl] = m0 >> 1; q_bias[cl] = ((1 << 15) / m0) << 1;
+            q_unq[cl] = (int)((1ull << (qp / 6 + 15 + 8)) / c_quant4_scale[qp % 6][0]) << 1; q_w[cl] = 256;
+        } else if (CAT == 5) {
+            q_mf[cl] = shift_round_d(c_quant8_scale[qp % 6][cl], qp / 6); q_bias[cl] = (1 << 15) / q_mf[cl];
+            q_unq[cl] = (int)((1ull << (qp / 6 + 16 + 8)) / c_quant8_scale[qp % 6][cl]); q_w[cl] = c_trellis_w8[cl];
+        } else {
+            q_mf[cl] = shift_round_d(c_quant4_scale[qp % 6][cl], qp / 6 - 1); q_bias[cl] = (1 << 15) / q_mf[cl];
+            q_unq[cl] = (int)((1ull << (qp / 6 + 15 + 8)) / c_quant4_scale[qp % 6][cl]); q_w[cl] = c_trellis_w4[cl];
+        }
+    }
+    auto pick = [&](const int (&t)[NCLS], int cl) {
+        int r = t[0];
+#pragma unroll
+        for (int k2 = 1; k2 < NCLS; k2++) r = cl == k2 ? t[k2] : r;
+        return r;
     };
-    auto guess = [&](int c, int i) {                 // |level| of the round-to-nearest quantiser (quant_bias0 = (1 << 15) / mf)
-        int m, bias;
-        if (DC) { const int m0 = shift_round_d(c_quant4_scale[qp % 6][0], sh4); m = m0 >> 1; bias = ((1 << 15) / m0) << 1; }
-        else { m = mf_of(i); bias = (1 << 15) / m; }
-        return ((bias + abs(c)) * m) >> 16;
-    };
-    auto unquant = [&](int i) {
-        if (DC) return (int)((1ull << (qp / 6 + 15 + 8)) / c_quant4_scale[qp % 6][0]) << 1;
-        return CAT == 5 ? (int)((1ull << (qp / 6 + 16 + 8)) / c_quant8_scale[qp % 6][trellis_class(CAT, i)])
-                        : (int)((1ull << (qp / 6 + 15 + 8)) / c_quant4_scale[qp % 6][trellis_class(CAT, i)]);
-    };
-    auto weight = [&](int i) { return DC ? 256 : CAT == 5 ? (int)c_trellis_w8[trellis_class(CAT, i)] : (int)c_trellis_w4[trellis_class(CAT, i)]; };
+    auto cls_of = [&](int i) { return DC ? 0 : trellis_class(CAT, i); };
+    auto guess = [&](int c, int i) { const int cl = cls_of(i); return ((pick(q_bias, cl) + abs(c)) * pick(q_mf, cl)) >> 16; };      // |level| of the round-to-nearest quantiser
+    auto unquant = [&](int i) { return pick(q_unq, cls_of(i)); };
+    auto weight = [&](int i) { return pick(q_w, cls_of(i)); };
 
     // the last position the guess leaves non-zero, per block
     int last_nnz = -1;
@@ -145,8 +156,18 @@ __device__ __forceinline__ unsigned trellis_blocks(int16_t *coefs, int stride, i
         const int l1ctx = n < 4 ? n + 1 : 0, lgctx = n < 4 ? 5 : n == 7 ? LG_LAST : n + 2;
         const int l1state = n >= 3 ? (int)((cs >> (8 * (l1ctx >> 2))) & 255) : level_state(l1ctx);
         const int lgstate = n >= 6 ? (int)((cs >> (8 * (lgctx - 6))) & 255) : level_state(lgctx);
-        const int ent_l1_0 = tr_ent(model, l1state, 0), ent_l1_1 = tr_ent(model, l1state, 1);
-        const int nxt_l1_0 = tr_next(model, l1state, 0), nxt_l1_1 = tr_next(model, l1state, 1);
+        // one lookup of the model gives both bin costs and both successors of the level-1 context variable
+        const uint32_t tm = (uint32_t)__builtin_amdgcn_ds_bpermute((l1state >> 1) << 2, (int)model);
+        const int l1s = l1state >> 1, l1m = l1state & 1, c_mps = (int)(tm & 0x1ff), c_lps = (int)((tm >> 9) & 0x7ff);
+        const int s_mps = (min(l1s + 1, 62) << 1) | l1m, s_lps = ((int)(tm >> 20) << 1) | (l1s == 0 ? l1m ^ 1 : l1m);
+        const int ent_l1_0 = l1m ? c_lps : c_mps, ent_l1_1 = l1m ? c_mps : c_lps;
+        const int nxt_l1_0 = l1m ? s_lps : s_mps, nxt_l1_1 = l1m ? s_mps : s_lps;
+        // ... and the same for the greater-than-one context variable: cost of a zero, of a one, and of a zero after a one
+        const uint32_t tg = (uint32_t)__builtin_amdgcn_ds_bpermute((lgstate >> 1) << 2, (int)model);
+        const int lgs = lgstate >> 1, lgm = lgstate & 1;
+        const int lg_c0 = lgm ? (int)((tg >> 9) & 0x7ff) : (int)(tg & 0x1ff), lg_c1 = lgm ? (int)(tg & 0x1ff) : (int)((tg >> 9) & 0x7ff);
+        const int lg_after1 = lgm ? (min(lgs + 1, 62) << 1) | 1 : ((int)(tg >> 20) << 1) | (lgs == 0 ? 1 : 0);
+        const int lg_c10 = tr_ent(model, lg_after1, 0);
         for (int kk = 0; kk < 2; kk++) {
             const int kind = kk ? kindB : kindA, lvl = q - 1 + kk;
             unsigned long long v = SMAX;
@@ -160,7 +181,9 @@ __device__ __forceinline__ unsigned trellis_blocks(int16_t *coefs, int stride, i
                 unsigned f8 = (unsigned)(n ? cost1 : cost2);
                 f8 += (unsigned)(kind == 2 ? ent_l1_1 : ent_l1_0);
                 const int prefix = max(min(lvl - 1, 14), 0);
-                if (kind == 2) f8 += tt.size_unary[prefix * 128 + lgstate] + (lvl >= 15 ? (unsigned)tr_size_ue_big((unsigned)(lvl - 15)) << 8 : 0u);
+                // x264_cabac_size_unary[prefix][state]: prefix - 1 ones, a zero, the sign — from the model for the common small levels, the table beyond
+                if (kind == 2) f8 += (prefix == 1 ? (unsigned)(lg_c0 + 256) : prefix == 2 ? (unsigned)(lg_c1 + lg_c10 + 256) : (unsigned)tt.size_unary[prefix * 128 + lgstate])
+                                     + (lvl >= 15 ? (unsigned)tr_size_ue_big((unsigned)(lvl - 15)) << 8 : 0u);
                 else f8 += 256;
                 if (src_ok) v = score + (n ? rel1 : rel0) + (((unsigned long long)f8 * (unsigned long long)lambda2) >> 4);
                 if (n == 2 || (n <= 3 && node_ctx == 4)) ncs = init4;
@@ -177,7 +200,9 @@ __device__ __forceinline__ unsigned trellis_blocks(int16_t *coefs, int stride, i
             if (kind == 0) { lo = hi = n; }
             else if (kind == 1) { lo = n == 0 ? 1 : n <= 2 ? n - 1 : n == 3 ? 2 : n; hi = n == 0 ? 0 : n == 3 ? 3 : lo; }
             else { lo = n == 4 ? 0 : n >= 5 ? (n == 7 ? 6 : n - 1) : 1; hi = n == 4 ? 3 : n == 7 ? 7 : n >= 5 ? lo : 0; }
-            for (int t = 0; t < 4; t++) {
+            // (a block's eight lanes share `kind`, and a pull only reads lanes of the own block: the trip count may differ between blocks)
+            const int npull = kind == 0 ? 1 : kind == 1 ? 2 : 4;
+            for (int t = 0; t < npull; t++) {
                 const int j = lo + t;
                 const unsigned lo32 = (unsigned)__shfl((int)(unsigned)candv[kk], base + (j & 7)), hi32 = (unsigned)__shfl((int)(unsigned)(candv[kk] >> 32), base + (j & 7));
                 const unsigned long long v = ((unsigned long long)hi32 << 32) | lo32;
