@@ -943,14 +943,9 @@ struct TrCtx { int on; uint32_t r, r8, model; TrellisTab tt; };
 template <int CAT>
 __device__ __forceinline__ unsigned trellis_run(const TrCtx &tr, int16_t *coefs, int stride, int nblk, int qp, bool intra, int lane)
 {
-    constexpr int sh = CAT == 2 ? 0 : CAT == 1 ? 8 : CAT == 4 ? 16 : 24;
-    constexpr int sig0 = CAT == 3 ? 48 : 0, last0 = CAT == 3 ? 52 : 16, abs0 = CAT == 3 ? 55 : 32;
-    const uint32_t reg = CAT == 5 ? tr.r8 : tr.r;
-    auto st_sig = [&](int i) { return (int)((__builtin_amdgcn_readlane(reg, sig0 + i) >> (CAT == 5 ? 0 : sh)) & 255); };
-    auto st_last = [&](int i) { return (int)((__builtin_amdgcn_readlane(reg, last0 + i) >> (CAT == 5 ? 0 : sh)) & 255); };
-    auto st_abs = [&](int i) { return (int)((__builtin_amdgcn_readlane(reg, abs0 + i) >> (CAT == 5 ? 0 : sh)) & 255); };
     unsigned out = 0;
-    for (int b0 = 0; b0 < nblk; b0 += 8) out |= trellis_blocks<CAT>(coefs + b0 * stride, stride, min(8, nblk - b0), qp, intra, tr.model, tr.tt, lane, st_sig, st_last, st_abs) << b0;
+    for (int b0 = 0; b0 < nblk; b0 += 8)
+        out |= trellis_blocks<CAT>((lds_i16 *)(coefs + b0 * stride), stride, min(8, nblk - b0), qp, intra, tr.model, tr.tt, CAT == 5 ? tr.r8 : tr.r) << b0;
     return out;
 }
 __device__ __forceinline__ void load_levels_scan(const int16_t *src, int v[4], int j)

@@ -283,12 +283,19 @@ __global__ void __launch_bounds__(64) k_trellis_blocks(const int16_t *coefs, int
     const int sig_off = CAT == 0 ? 105 : CAT == 1 ? 120 : CAT == 2 ? 134 : CAT == 3 ? 149 : CAT == 4 ? 152 : 402;
     const int last_off = CAT == 0 ? 166 : CAT == 1 ? 181 : CAT == 2 ? 195 : CAT == 3 ? 210 : CAT == 4 ? 213 : 417;
     const int abs_off = CAT == 0 ? 227 : CAT == 1 ? 237 : CAT == 2 ? 247 : CAT == 3 ? 257 : CAT == 4 ? 266 : 426;
+    // the category's context variables in the role layout of cabac_rd.cuh (cab_locate): this lane's byte of r / r8
+    uint32_t reg = 0;
+    for (int ctx = 0; ctx < 460; ctx++) {
+        int rg, ln, sh;
+        if (!cab_locate(ctx, rg, ln, sh) || ln != lane) continue;
+        const bool mine = (ctx >= sig_off && ctx < sig_off + 16) || (ctx >= last_off && ctx < last_off + 16) || (ctx >= abs_off && ctx < abs_off + 10);
+        if (mine && rg == (CAT == 5 ? 2 : 1)) reg |= (uint32_t)st[ctx] << sh;
+    }
     for (int b0 = 0; b0 < nblk; b0 += 8) {
         const int nb = min(8, nblk - b0);
         for (int i = lane; i < nb * NC; i += 64) buf[i] = coefs[(size_t)b0 * NC + i];
         __syncthreads();
-        const unsigned m = trellis_blocks<CAT>(buf, NC, nb, qp, intra != 0, model, tt, lane,
-                                               [&](int i) { return (int)st[sig_off + i]; }, [&](int i) { return (int)st[last_off + i]; }, [&](int i) { return (int)st[abs_off + i]; });
+        const unsigned m = trellis_blocks<CAT>((lds_i16 *)buf, NC, nb, qp, intra != 0, model, tt, reg);
         __syncthreads();
         for (int i = lane; i < nb * NC; i += 64) levels[(size_t)b0 * NC + i] = buf[i];
         if (lane < nb) nz[b0 + lane] = (uint8_t)((m >> lane) & 1);

@@ -59,16 +59,25 @@ __device__ __forceinline__ int tr_size_ue_big(unsigned v) { return 2 * (31 - __b
 // in scan order, block b at coefs + b * stride (AC blocks: 16 entries, entry 0 = 0); the levels replace them.  nblk <= 8.  lane & 7 = node,
 // lane >> 3 = block.  st_sig / st_last / st_abs: accessors of the slice's context variables of the category (wave-uniform arguments).
 // Returns the mask of blocks with a non-zero level (wave-uniform).
-template <int CAT, class FS, class FL, class FA>
-__device__ __forceinline__ unsigned trellis_blocks(int16_t *coefs, int stride, int nblk, int qp, bool intra, uint32_t model, const TrellisTab &tt,
-                                                   int lane, FS st_sig, FL st_last, FA st_abs)
+// The context variables come in `reg`: the role-indexed register of the category (cabac_rd.cuh: r for categories 0..4 — this category's byte —,
+// r8 for 8x8 blocks).  ONE out-of-line copy per category serves every call site: inlined eight times the search cost the macroblock loop
+// twice the register spills.
+typedef __attribute__((address_space(3))) int16_t lds_i16;
+template <int CAT>
+__device__ __noinline__ unsigned trellis_blocks(lds_i16 *coefs, int stride, int nblk, int qp, bool intra, uint32_t model, TrellisTab tt, uint32_t reg)
 {
     namespace T = x264gpu_cabac;
+    const int lane = (int)threadIdx.x & 63;
+    constexpr int st_sh = CAT == 5 || CAT == 2 ? 0 : CAT == 1 ? 8 : CAT == 4 ? 16 : 24;
+    constexpr int sig0 = CAT == 3 ? 48 : 0, last0 = CAT == 3 ? 52 : 16, abs0 = CAT == 3 ? 55 : 32;
+    auto st_sig = [&](int i) { return (int)((__builtin_amdgcn_readlane(reg, sig0 + i) >> st_sh) & 255); };
+    auto st_last = [&](int i) { return (int)((__builtin_amdgcn_readlane(reg, last0 + i) >> st_sh) & 255); };
+    auto st_abs = [&](int i) { return (int)((__builtin_amdgcn_readlane(reg, abs0 + i) >> st_sh) & 255); };
     constexpr int NC = CAT == 5 ? 64 : CAT == 3 ? 4 : 16, B_AC = (CAT == 1 || CAT == 4) ? 1 : 0, PW = CAT == 5 ? 4 : 1;
     constexpr bool DC = CAT == 0 || CAT == 3;
     const int n = lane & 7, g = lane >> 3, base = lane & ~7;
     const bool blk_on = g < nblk;
-    int16_t *mine = coefs + g * stride;
+    lds_i16 *mine = coefs + g * stride;
     const int lambda2 = tt.lambda2[(intra ? 52 : 0) + qp];
     // quantiser, rounding offset, inverse and distortion weight of every coefficient class (three for 4x4 blocks, six for 8x8, one for DC
     // blocks), worked out once: the divisions stay out of the loop
