@@ -199,7 +199,8 @@ __device__ __noinline__ unsigned trellis_blocks(lds_i16 *coefs, int stride, int 
                 if (n >= 3) { const int sh = 8 * (l1ctx >> 2); ncs = (ncs & ~(255u << sh)) | ((uint32_t)(kind == 2 ? nxt_l1_1 : nxt_l1_0) << sh); }
                 if (kind == 2 && node_ctx == 7) { const int sh = 8 * (lgctx - 6); ncs = (ncs & ~(255u << sh)) | ((uint32_t)tt.trans_unary[prefix * 128 + lgstate] << sh); }
             }
-            candv[kk] = v; candcs[kk] = ncs;
+            // the key a destination compares: score, then x264's evaluation order (level q - 1 before q, sources ascending) as the tie-break
+            candv[kk] = v == SMAX ? ~0ull : (v << 4) | (unsigned)(kk * 8 + n); candcs[kk] = ncs;
         }
         // ---- every lane as a destination node n: the sources that lead here, in x264's evaluation order ----
         unsigned long long best = ~0ull;
@@ -213,16 +214,18 @@ __device__ __noinline__ unsigned trellis_blocks(lds_i16 *coefs, int stride, int 
             const int npull = kind == 0 ? 1 : kind == 1 ? 2 : 4;
             for (int t = 0; t < npull; t++) {
                 const int j = lo + t;
-                const unsigned lo32 = (unsigned)__shfl((int)(unsigned)candv[kk], base + (j & 7)), hi32 = (unsigned)__shfl((int)(unsigned)(candv[kk] >> 32), base + (j & 7));
-                const unsigned long long v = ((unsigned long long)hi32 << 32) | lo32;
-                if (j <= hi && v != SMAX) { const unsigned long long key = (v << 4) | (unsigned)(kk * 8 + j); best = key < best ? key : best; }
+                const int addr = (base + (j & 7)) << 2;
+                const unsigned lo32 = (unsigned)__builtin_amdgcn_ds_bpermute(addr, (int)(unsigned)candv[kk]), hi32 = (unsigned)__builtin_amdgcn_ds_bpermute(addr, (int)(unsigned)(candv[kk] >> 32));
+                const unsigned long long key = ((unsigned long long)hi32 << 32) | lo32;
+                if (j <= hi) best = key < best ? key : best;
             }
         }
         const bool won = best != ~0ull;
         const int wj = (int)(best & 7), wk = (int)((best >> 3) & 1);
-        const uint32_t csA = (uint32_t)__shfl((int)candcs[0], base + wj), csB = (uint32_t)__shfl((int)candcs[1], base + wj);
+        const int waddr = (base + wj) << 2;
+        const uint32_t csA = (uint32_t)__builtin_amdgcn_ds_bpermute(waddr, (int)candcs[0]), csB = (uint32_t)__builtin_amdgcn_ds_bpermute(waddr, (int)candcs[1]);
         uint32_t npath[PW];
-        for (int w = 0; w < PW; w++) npath[w] = (uint32_t)__shfl((int)path[w], base + wj);
+        for (int w = 0; w < PW; w++) npath[w] = (uint32_t)__builtin_amdgcn_ds_bpermute(waddr, (int)path[w]);
         if (go) {
             score = won ? best >> 4 : SMAX;
             cs = wk ? csB : csA;
