@@ -171,12 +171,17 @@ __device__ __noinline__ unsigned trellis_blocks(lds_i16 *coefs, int stride, int 
         const int s_mps = (min(l1s + 1, 62) << 1) | l1m, s_lps = ((int)(tm >> 20) << 1) | (l1s == 0 ? l1m ^ 1 : l1m);
         const int ent_l1_0 = l1m ? c_lps : c_mps, ent_l1_1 = l1m ? c_mps : c_lps;
         const int nxt_l1_0 = l1m ? s_lps : s_mps, nxt_l1_1 = l1m ? s_mps : s_lps;
-        // ... and the same for the greater-than-one context variable: cost of a zero, of a one, and of a zero after a one
-        const uint32_t tg = (uint32_t)__builtin_amdgcn_ds_bpermute((lgstate >> 1) << 2, (int)model);
-        const int lgs = lgstate >> 1, lgm = lgstate & 1;
-        const int lg_c0 = lgm ? (int)((tg >> 9) & 0x7ff) : (int)(tg & 0x1ff), lg_c1 = lgm ? (int)(tg & 0x1ff) : (int)((tg >> 9) & 0x7ff);
-        const int lg_after1 = lgm ? (min(lgs + 1, 62) << 1) | 1 : ((int)(tg >> 20) << 1) | (lgs == 0 ? 1 : 0);
-        const int lg_c10 = tr_ent(model, lg_after1, 0);
+        // ... and the same for the greater-than-one context variable: cost of a zero, of a one, and of a zero after a one — only on steps where
+        // some block tries a level of two or more (a wave-uniform branch: every lane takes part in the lookups or none does)
+        int lg_c0 = 0, lg_c1 = 0, lg_c10 = 0;
+        const bool any_big = __ballot(go && q >= 2) != 0;
+        if (any_big) {
+            const uint32_t tg = (uint32_t)__builtin_amdgcn_ds_bpermute((lgstate >> 1) << 2, (int)model);
+            const int lgs = lgstate >> 1, lgm = lgstate & 1;
+            lg_c0 = lgm ? (int)((tg >> 9) & 0x7ff) : (int)(tg & 0x1ff); lg_c1 = lgm ? (int)(tg & 0x1ff) : (int)((tg >> 9) & 0x7ff);
+            const int lg_after1 = lgm ? (min(lgs + 1, 62) << 1) | 1 : ((int)(tg >> 20) << 1) | (lgs == 0 ? 1 : 0);
+            lg_c10 = tr_ent(model, lg_after1, 0);
+        }
         for (int kk = 0; kk < 2; kk++) {
             const int kind = kk ? kindB : kindA, lvl = q - 1 + kk;
             unsigned long long v = SMAX;
@@ -202,22 +207,27 @@ __device__ __noinline__ unsigned trellis_blocks(lds_i16 *coefs, int stride, int 
             // the key a destination compares: score, then x264's evaluation order (level q - 1 before q, sources ascending) as the tie-break
             candv[kk] = v == SMAX ? ~0ull : (v << 4) | (unsigned)(kk * 8 + n); candcs[kk] = ncs;
         }
-        // ---- every lane as a destination node n: the sources that lead here, in x264's evaluation order ----
+        // ---- every lane as a destination node n: the sources that lead here, in x264's evaluation order.  They sit at n, n - 1, .. n - 4 of the
+        //      own block: DPP row shifts bring their keys over without a trip through LDS (a shift that crosses into the block before is never
+        //      a valid source) ----
         unsigned long long best = ~0ull;
+        auto shr = [&](unsigned long long key, auto tag) {
+            constexpr int CTRL = 0x110 + decltype(tag)::value;            // row_shr:N
+            const unsigned lo32 = (unsigned)__builtin_amdgcn_update_dpp(-1, (int)(unsigned)key, CTRL, 0xf, 0xf, false);
+            const unsigned hi32 = (unsigned)__builtin_amdgcn_update_dpp(-1, (int)(unsigned)(key >> 32), CTRL, 0xf, 0xf, false);
+            return ((unsigned long long)hi32 << 32) | lo32;
+        };
         for (int kk = 0; kk < 2; kk++) {
             const int kind = kk ? kindB : kindA;
-            int lo, hi;
-            if (kind == 0) { lo = hi = n; }
-            else if (kind == 1) { lo = n == 0 ? 1 : n <= 2 ? n - 1 : n == 3 ? 2 : n; hi = n == 0 ? 0 : n == 3 ? 3 : lo; }
-            else { lo = n == 4 ? 0 : n >= 5 ? (n == 7 ? 6 : n - 1) : 1; hi = n == 4 ? 3 : n == 7 ? 7 : n >= 5 ? lo : 0; }
-            // (a block's eight lanes share `kind`, and a pull only reads lanes of the own block: the trip count may differ between blocks)
-            const int npull = kind == 0 ? 1 : kind == 1 ? 2 : 4;
-            for (int t = 0; t < npull; t++) {
-                const int j = lo + t;
-                const int addr = (base + (j & 7)) << 2;
-                const unsigned lo32 = (unsigned)__builtin_amdgcn_ds_bpermute(addr, (int)(unsigned)candv[kk]), hi32 = (unsigned)__builtin_amdgcn_ds_bpermute(addr, (int)(unsigned)(candv[kk] >> 32));
-                const unsigned long long key = ((unsigned long long)hi32 << 32) | lo32;
-                if (j <= hi) best = key < best ? key : best;
+            const unsigned long long k0 = candv[kk], k1 = shr(candv[kk], std::integral_constant<int, 1>{});
+            // level 0: n <- n.  level 1: 1 <- 0, 2 <- 1, 3 <- 2 and 3, n >= 4 <- n.  levels >= 2: 4 <- 0..3, 5 <- 4, 6 <- 5, 7 <- 6 and 7
+            const bool self_ok = kind == 0 || (kind == 1 ? n >= 3 : n == 7);
+            const bool m1_ok = kind == 1 ? (n >= 1 && n <= 3) : kind == 2 && n >= 4;
+            if (m1_ok && k1 < best) best = k1;            // (the lower source first: its order value is lower anyway)
+            if (self_ok && k0 < best) best = k0;
+            if (any_big) {
+                const unsigned long long k2 = shr(candv[kk], std::integral_constant<int, 2>{}), k3 = shr(candv[kk], std::integral_constant<int, 3>{}), k4 = shr(candv[kk], std::integral_constant<int, 4>{});
+                if (kind == 2 && n == 4) { if (k2 < best) best = k2; if (k3 < best) best = k3; if (k4 < best) best = k4; }
             }
         }
         const bool won = best != ~0ull;
