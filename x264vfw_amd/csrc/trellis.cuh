@@ -173,39 +173,40 @@ __device__ __noinline__ unsigned trellis_blocks(lds_i16 *coefs, int stride, int 
         const int nxt_l1_0 = l1m ? s_lps : s_mps, nxt_l1_1 = l1m ? s_mps : s_lps;
         // ... and the same for the greater-than-one context variable: cost of a zero, of a one, and of a zero after a one — only on steps where
         // some block tries a level of two or more (a wave-uniform branch: every lane takes part in the lookups or none does)
-        int lg_c0 = 0, lg_c1 = 0, lg_c10 = 0;
+        int lg_c0 = 0, lg_c1 = 0, lg_c10 = 0, lg_n0 = 0, lg_n10 = 0;       // costs, and the variable after "0" / after "1 0"
         const bool any_big = __ballot(go && q >= 2) != 0;
         if (any_big) {
             const uint32_t tg = (uint32_t)__builtin_amdgcn_ds_bpermute((lgstate >> 1) << 2, (int)model);
             const int lgs = lgstate >> 1, lgm = lgstate & 1;
-            lg_c0 = lgm ? (int)((tg >> 9) & 0x7ff) : (int)(tg & 0x1ff); lg_c1 = lgm ? (int)(tg & 0x1ff) : (int)((tg >> 9) & 0x7ff);
-            const int lg_after1 = lgm ? (min(lgs + 1, 62) << 1) | 1 : ((int)(tg >> 20) << 1) | (lgs == 0 ? 1 : 0);
-            lg_c10 = tr_ent(model, lg_after1, 0);
+            const int cm = (int)(tg & 0x1ff), cl = (int)((tg >> 9) & 0x7ff), sm = (min(lgs + 1, 62) << 1) | lgm, sl = ((int)(tg >> 20) << 1) | (lgs == 0 ? lgm ^ 1 : lgm);
+            lg_c0 = lgm ? cl : cm; lg_c1 = lgm ? cm : cl; lg_n0 = lgm ? sl : sm;
+            const int after1 = lgm ? sm : sl;
+            const uint32_t t2 = (uint32_t)__builtin_amdgcn_ds_bpermute((after1 >> 1) << 2, (int)model);
+            const int a_s = after1 >> 1, a_m = after1 & 1;
+            lg_c10 = a_m ? (int)((t2 >> 9) & 0x7ff) : (int)(t2 & 0x1ff);
+            lg_n10 = a_m ? ((int)(t2 >> 20) << 1) | (a_s == 0 ? a_m ^ 1 : a_m) : (min(a_s + 1, 62) << 1) | a_m;
         }
+        // levels of four and more (prefix >= 3) read x264_rdo_init's tables; rare, so behind a wave-uniform test
+        const bool any_huge = __ballot(go && q >= 4) != 0;
         for (int kk = 0; kk < 2; kk++) {
             const int kind = kk ? kindB : kindA, lvl = q - 1 + kk;
-            unsigned long long v = SMAX;
-            uint32_t ncs = cs;
-            if (kind == 0) {
-                // trellis_coef0: node j -> node j; only node 0 pays a distortion difference (the others carry it in the baseline)
-                if (src_ok) v = score + (n == 0 ? ssd0[0] - ssd1[0] : 0ull);
-            } else {
-                const unsigned long long rel0 = q == 1 ? ssd0[kk] - ssd1[0] : ssd0[kk], rel1 = q == 1 ? ssd1[kk] - ssd1[0] : ssd1[kk];
-                const int node_ctx = kind == 1 ? (n < 3 ? n + 1 : n == 3 ? 3 : n) : (n < 4 ? 4 : min(n + 1, 7));
-                unsigned f8 = (unsigned)(n ? cost1 : cost2);
-                f8 += (unsigned)(kind == 2 ? ent_l1_1 : ent_l1_0);
-                const int prefix = max(min(lvl - 1, 14), 0);
-                // x264_cabac_size_unary[prefix][state]: prefix - 1 ones, a zero, the sign — from the model for the common small levels, the table beyond
-                if (kind == 2) f8 += (prefix == 1 ? (unsigned)(lg_c0 + 256) : prefix == 2 ? (unsigned)(lg_c1 + lg_c10 + 256) : (unsigned)tt.size_unary[prefix * 128 + lgstate])
-                                     + (lvl >= 15 ? (unsigned)tr_size_ue_big((unsigned)(lvl - 15)) << 8 : 0u);
-                else f8 += 256;
-                if (src_ok) v = score + (n ? rel1 : rel0) + (((unsigned long long)f8 * (unsigned long long)lambda2) >> 4);
-                if (n == 2 || (n <= 3 && node_ctx == 4)) ncs = init4;
-                if (n >= 3) { const int sh = 8 * (l1ctx >> 2); ncs = (ncs & ~(255u << sh)) | ((uint32_t)(kind == 2 ? nxt_l1_1 : nxt_l1_0) << sh); }
-                if (kind == 2 && node_ctx == 7) { const int sh = 8 * (lgctx - 6); ncs = (ncs & ~(255u << sh)) | ((uint32_t)tt.trans_unary[prefix * 128 + lgstate] << sh); }
-            }
+            const unsigned long long rel0 = q == 1 ? ssd0[kk] - ssd1[0] : ssd0[kk], rel1 = q == 1 ? ssd1[kk] - ssd1[0] : ssd1[kk];
+            const int node_ctx = kind == 1 ? (n < 3 ? n + 1 : n == 3 ? 3 : n) : (n < 4 ? 4 : min(n + 1, 7));
+            const int prefix = max(min(lvl - 1, 14), 0);
+            unsigned unary = prefix == 1 ? (unsigned)(lg_c0 + 256) : (unsigned)(lg_c1 + lg_c10 + 256);
+            int lg_next = prefix == 1 ? lg_n0 : lg_n10;
+            if (any_huge && prefix >= 3) { unary = tt.size_unary[prefix * 128 + lgstate]; lg_next = tt.trans_unary[prefix * 128 + lgstate]; }
+            const unsigned f8 = (unsigned)(n ? cost1 : cost2) + (unsigned)(kind == 2 ? ent_l1_1 : ent_l1_0)
+                                + (kind == 2 ? unary + (lvl >= 15 ? (unsigned)tr_size_ue_big((unsigned)(lvl - 15)) << 8 : 0u) : 256u);
+            // trellis_coef0 (level 0): node j -> node j, only node 0 pays a distortion difference (the others carry it in the baseline)
+            const unsigned long long v0 = score + (n == 0 ? ssd0[0] - ssd1[0] : 0ull);
+            const unsigned long long v12 = score + (n ? rel1 : rel0) + (((unsigned long long)f8 * (unsigned long long)lambda2) >> 4);
+            const unsigned long long v = kind == 0 ? v0 : v12;
+            uint32_t ncs = (n == 2 || (n <= 3 && node_ctx == 4)) ? init4 : cs;
+            if (n >= 3) { const int sh = 8 * (l1ctx >> 2); ncs = (ncs & ~(255u << sh)) | ((uint32_t)(kind == 2 ? nxt_l1_1 : nxt_l1_0) << sh); }
+            if (kind == 2 && node_ctx == 7) { const int sh = 8 * (lgctx - 6); ncs = (ncs & ~(255u << sh)) | ((uint32_t)lg_next << sh); }
             // the key a destination compares: score, then x264's evaluation order (level q - 1 before q, sources ascending) as the tie-break
-            candv[kk] = v == SMAX ? ~0ull : (v << 4) | (unsigned)(kk * 8 + n); candcs[kk] = ncs;
+            candv[kk] = src_ok ? (v << 4) | (unsigned)(kk * 8 + n) : ~0ull; candcs[kk] = kind == 0 ? cs : ncs;
         }
         // ---- every lane as a destination node n: the sources that lead here, in x264's evaluation order.  They sit at n, n - 1, .. n - 4 of the
         //      own block: DPP row shifts bring their keys over without a trip through LDS (a shift that crosses into the block before is never
