@@ -105,8 +105,6 @@ __device__ __noinline__ unsigned trellis_blocks(lds_i16 *coefs, int stride, int 
     };
     auto cls_of = [&](int i) { return DC ? 0 : trellis_class(CAT, i); };
     auto guess = [&](int c, int i) { const int cl = cls_of(i); return ((pick(q_bias, cl) + abs(c)) * pick(q_mf, cl)) >> 16; };      // |level| of the round-to-nearest quantiser
-    auto unquant = [&](int i) { return pick(q_unq, cls_of(i)); };
-    auto weight = [&](int i) { return pick(q_w, cls_of(i)); };
 
     // the last position the guess leaves non-zero, per block
     int last_nnz = -1;
@@ -120,6 +118,11 @@ __device__ __noinline__ unsigned trellis_blocks(lds_i16 *coefs, int stride, int 
     const uint32_t init4 = (uint32_t)level_state(0) | ((uint32_t)level_state(4) << 8) | ((uint32_t)level_state(8) << 16) | ((uint32_t)level_state(9) << 24);
     constexpr int LG_LAST = CAT == 3 ? 8 : 9;
 
+    // what depends on the node only (this lane's n), worked out before the loop: its level-1 / greater-than-one contexts, where their
+    // variables sit in the four bytes a path carries, the slice's values of those a path meets once
+    const int l1ctx = n < 4 ? n + 1 : 0, lgctx = n < 4 ? 5 : n == 7 ? LG_LAST : n + 2;
+    const int sh_l1 = 8 * (l1ctx >> 2), sh_lg = n >= 6 ? 8 * (lgctx - 6) : 0;
+    const int ls_l1 = level_state(l1ctx), ls_lg = level_state(lgctx);
     const unsigned long long SMAX = ~0ull, BIAS = 1ull << 50;
     unsigned long long score = n == 0 ? BIAS : SMAX;
     uint32_t cs = 0, path[PW];
@@ -129,7 +132,8 @@ __device__ __noinline__ unsigned trellis_blocks(lds_i16 *coefs, int stride, int 
     for (int i = NC - 1; i >= B_AC; i--) {
         const bool act = blk_on && i <= last_nnz;
         if (!__ballot(act)) continue;
-        const int c = act ? (int)mine[i] : 0, q = guess(c, i), a = abs(c);
+        const int cl = cls_of(i), un = pick(q_unq, cl), wgt = pick(q_w, cl);          // wave-uniform: the position's coefficient class
+        const int c = act ? (int)mine[i] : 0, a = abs(c), q = ((pick(q_bias, cl) + a) * pick(q_mf, cl)) >> 16;
         // costs of the position's significance / last flags (the same for every block): wave-uniform
         const int sidx = CAT == 5 ? (int)T::cabac_sig8x8[min(i, 62)] : i - B_AC, lidx = CAT == 5 ? (int)T::cabac_last8x8[min(i, 62)] : i - B_AC;
         int cost0 = 0, cost1 = 0, cost2 = 0;
@@ -144,14 +148,13 @@ __device__ __noinline__ unsigned trellis_blocks(lds_i16 *coefs, int stride, int 
         // ---- a zero of the guess: nothing to choose; the all-zero path of a block still in ctx_lo is spared the significance bit ----
         if (zero && !ctx_hi && n == 0) score -= ((unsigned long long)cost0 * (unsigned long long)lambda2) >> 4;
         // ---- every lane as a source node: its two candidate levels A = q - 1, B = q ----
-        const int un = unquant(i), wgt = weight(i);
         unsigned long long ssd0[2], ssd1[2];
         for (int kk = 0; kk < 2; kk++) {
             const int lvl = q - 1 + kk, ua = (int)(((long long)un * lvl + 128) >> 8);
-            long long d = a - ua;
-            ssd1[kk] = (unsigned long long)(d * d) * (unsigned long long)wgt;
+            int d = a - ua;                                                   // |d| < 2^15.5: the square fits 32 bits
+            ssd1[kk] = (unsigned long long)(unsigned)(d * d) * (unsigned)wgt;
             ssd0[kk] = ssd1[kk];
-            if (i == 0 && !DC && !ctx_hi) { d = c - (((c < 0 ? -ua : ua) + 8) & ~15); ssd0[kk] = (unsigned long long)(d * d) * (unsigned long long)wgt; }
+            if (i == 0 && !DC && !ctx_hi) { d = c - (((c < 0 ? -ua : ua) + 8) & ~15); ssd0[kk] = (unsigned long long)(unsigned)(d * d) * (unsigned)wgt; }
         }
         const bool alive = (long long)score >= 0;
         const bool src_ok = go && (ctx_hi ? (n >= 1 && alive) : (n <= 3 && (n == 0 || alive)));
@@ -162,9 +165,8 @@ __device__ __noinline__ unsigned trellis_blocks(lds_i16 *coefs, int stride, int 
         uint32_t candcs[2];
         // (the model lookups are ds_bpermutes: every lane must take part, whatever its block is doing — so nothing below is skipped, the
         //  kinds only select)
-        const int l1ctx = n < 4 ? n + 1 : 0, lgctx = n < 4 ? 5 : n == 7 ? LG_LAST : n + 2;
-        const int l1state = n >= 3 ? (int)((cs >> (8 * (l1ctx >> 2))) & 255) : level_state(l1ctx);
-        const int lgstate = n >= 6 ? (int)((cs >> (8 * (lgctx - 6))) & 255) : level_state(lgctx);
+        const int l1state = n >= 3 ? (int)((cs >> sh_l1) & 255) : ls_l1;
+        const int lgstate = n >= 6 ? (int)((cs >> sh_lg) & 255) : ls_lg;
         // one lookup of the model gives both bin costs and both successors of the level-1 context variable
         const uint32_t tm = (uint32_t)__builtin_amdgcn_ds_bpermute((l1state >> 1) << 2, (int)model);
         const int l1s = l1state >> 1, l1m = l1state & 1, c_mps = (int)(tm & 0x1ff), c_lps = (int)((tm >> 9) & 0x7ff);
@@ -203,8 +205,8 @@ __device__ __noinline__ unsigned trellis_blocks(lds_i16 *coefs, int stride, int 
             const unsigned long long v12 = score + (n ? rel1 : rel0) + (((unsigned long long)f8 * (unsigned long long)lambda2) >> 4);
             const unsigned long long v = kind == 0 ? v0 : v12;
             uint32_t ncs = (n == 2 || (n <= 3 && node_ctx == 4)) ? init4 : cs;
-            if (n >= 3) { const int sh = 8 * (l1ctx >> 2); ncs = (ncs & ~(255u << sh)) | ((uint32_t)(kind == 2 ? nxt_l1_1 : nxt_l1_0) << sh); }
-            if (kind == 2 && node_ctx == 7) { const int sh = 8 * (lgctx - 6); ncs = (ncs & ~(255u << sh)) | ((uint32_t)lg_next << sh); }
+            if (n >= 3) ncs = (ncs & ~(255u << sh_l1)) | ((uint32_t)(kind == 2 ? nxt_l1_1 : nxt_l1_0) << sh_l1);
+            if (kind == 2 && n >= 6) ncs = (ncs & ~(255u << sh_lg)) | ((uint32_t)lg_next << sh_lg);          // (node 7 is where nodes 6 and 7 go)
             // the key a destination compares: score, then x264's evaluation order (level q - 1 before q, sources ascending) as the tie-break
             candv[kk] = src_ok ? (v << 4) | (unsigned)(kk * 8 + n) : ~0ull; candcs[kk] = kind == 0 ? cs : ncs;
         }
