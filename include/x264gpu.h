@@ -197,8 +197,10 @@ typedef struct x264gpu_config {
                                * [(mbh * i + N/2) / N, (mbh * (i+1) + N/2) / N); every slice is analysed on its own (no prediction across a slice
                                * boundary, its own fast-intra statistics and quantiser chain) and the loop filter leaves slice boundaries alone
                                * (disable_deblocking_filter_idc 2), as x264's slice threads do.  At most mbh / 4 ([x264-upstream] validate_parameters) */
-    int trellis;              /* x264 --trellis 1 (the final encode of every macroblock quantised by the trellis search on the slice's CABAC state):
-                               * NOT IMPLEMENTED ON THE DEVICE YET — must be 0 (the checker restates it already: oracle/trellis.cpp, TRELLIS_NOTES.md) */
+    int trellis;              /* x264's trellis quantiser (quant_trellis_cabac: a search over the levels of a block on the slice's live CABAC state); needs cabac and
+                               * rd.  Bits 0..5 = the quantiser calls that use it (1 inter luma 4x4, 2 inter luma 8x8, 4 chroma, 8 Intra_16x16, 16 Intra_4x4,
+                               * 32 Intra_8x8): --trellis 1 = 63, in the final encode of every macroblock.  Bit 6 (64) = --trellis 2: also in the block encodes of
+                               * the intra analysis and in every RD candidate */
 } x264gpu_config;
 
 int  x264gpu_encoder_create(x264gpu_encoder **enc, const x264gpu_config *cfg);

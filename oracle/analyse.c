@@ -1509,7 +1509,7 @@ static void macroblock_body(x264o_encoder *e, int mbx, int mby, actx *a)
         if (a->satd_i8 < i_cost) { i_cost = a->satd_i8; type = X264GPU_MB_I8x8; }
         if (a->mbrd) rd_reset(a, mb, lv);
         mb->cost = i_cost;
-        e->b_trellis = e->cfg.cabac ? e->cfg.trellis : 0;          /* --trellis 1: the final encode only */
+        e->b_trellis = e->cfg.cabac ? e->cfg.trellis & 63 : 0;          /* --trellis 1: the final encode only */
         encode_intra_mb(a, type, mb, lv);
         e->b_trellis = 0;
         e->intra_count++;
@@ -1619,7 +1619,7 @@ static void macroblock_body(x264o_encoder *e, int mbx, int mby, actx *a)
     mb->cost = i_cost;
 
     if (is_intra_type(i_type)) {
-        e->b_trellis = e->cfg.cabac ? e->cfg.trellis : 0;
+        e->b_trellis = e->cfg.cabac ? e->cfg.trellis & 63 : 0;
         encode_intra_mb(a, i_type, mb, lv);
         e->b_trellis = 0;
         e->intra_count++;
@@ -1631,7 +1631,7 @@ static void macroblock_body(x264o_encoder *e, int mbx, int mby, actx *a)
         mb->ref[k] = (int8_t)m->ref; mb->mv[k][0] = (int16_t)m->mv[0]; mb->mv[k][1] = (int16_t)m->mv[1];
     }
     a->force_t8 = t8;                 /* RD: the transform size chosen by transform_rd; else SA8D vs SATD */
-    e->b_trellis = e->cfg.cabac ? e->cfg.trellis : 0;
+    e->b_trellis = e->cfg.cabac ? e->cfg.trellis & 63 : 0;
     encode_inter_mb(a, mb, lv);
     e->b_trellis = 0;
 }
@@ -1639,7 +1639,11 @@ static void macroblock_body(x264o_encoder *e, int mbx, int mby, actx *a)
 void x264o_macroblock(x264o_encoder *e, int mbx, int mby)
 {
     actx A;
+    /* --trellis 2 (cfg.trellis bit 6): h->mb.b_trellis is on for the whole analysis of RD sessions too — the block encodes inside the intra
+     * analysis and every RD candidate are quantised by the search (x264 mb_analyse_init: b_trellis = i_trellis > 1 && i_mbrd) */
+    e->b_trellis = (e->cfg.trellis & 64) && e->cfg.rd && e->cfg.cabac ? e->cfg.trellis & 63 : 0;
     macroblock_body(e, mbx, mby, &A);
+    e->b_trellis = 0;
     const x264gpu_mb *mb = &e->mbs[mby * e->mbw + mbx];
     /* diagnostics for the tests: what mb_bits_cavlc says the macroblock layer of the final macroblock takes (0 for P_SKIP: it lives in a run) */
     if (e->mb_bits && !e->cfg.cabac) e->mb_bits[A.mi] = mb->type == X264GPU_MB_P_SKIP ? 0 : mb_bits_cavlc(&A, mb, e->levels + (size_t)A.mi * X264GPU_MB_LEVELS);

@@ -58,7 +58,7 @@ def test_random_cabac_rd_configs_bitexact(gpu, seed):
         w, h, kw, nfr, fseed, second_idr = random_case(rnd)
         psy = rnd.randint(0, 1)
         kw.update(cabac=1, rd=1, subme=rnd.choice([6, 7]), psy=psy, psy_rd_q8=rnd.choice([26, 102, 256, 512]) if psy else 0,
-                  trellis=rnd.choice([0, 63, 63, rnd.randint(1, 62)]))          # x264 --trellis 1 is 63 (every site of the final encode)
+                  trellis=rnd.choice([0, 63, 63, 127, rnd.randint(1, 62), 64 + rnd.randint(1, 63)]))          # x264 --trellis 1 is 63 (every site of the final encode), --trellis 2 is 127
         frames = synth_frames(w, h, nfr, seed=fseed)
         cfg = O.default_config(w, h, **kw)
         og, gg = O.OracleEncoder(cfg), GpuEncoder(cfg)

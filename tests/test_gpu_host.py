@@ -38,7 +38,7 @@ def eff_kw(eff):
     compensation), entropy coder, vector range"""
     rd = int(eff.analyse.i_subpel_refine >= 6)
     q8 = int(eff.analyse.f_psy_rd * 256.0 + 0.5) if rd and eff.analyse.b_psy else 0
-    return dict(subme=eff.analyse.i_subpel_refine, rd=rd, psy=int(rd and eff.analyse.b_psy), psy_rd_q8=q8, trellis=63 if eff.analyse.i_trellis else 0, chroma_qp_offset=eff.analyse.i_chroma_qp_offset,
+    return dict(subme=eff.analyse.i_subpel_refine, rd=rd, psy=int(rd and eff.analyse.b_psy), psy_rd_q8=q8, trellis=(63 + 64 if eff.analyse.i_trellis == 2 else 63) if eff.analyse.i_trellis else 0, chroma_qp_offset=eff.analyse.i_chroma_qp_offset,
                 mv_range=eff.analyse.i_mv_range, cabac=eff.b_cabac)
 
 
@@ -119,21 +119,21 @@ def test_rd_session_equals_oracle_pipeline(gpu, opts, subme, cqo):
         np.testing.assert_array_equal(og.recon(), recons[i], err_msg=f"oracle pipeline picture {i}")
 
 
-@pytest.mark.parametrize("opts", [{}, {"no-psy": None, "ref": 1}, {"sliced-threads": None, "threads": 2}])
+@pytest.mark.parametrize("opts", [{}, {"no-psy": None, "ref": 1}, {"sliced-threads": None, "threads": 2}, {"trellis": 2, "me": "umh", "ref": 4}, {"trellis": 0}])
 def test_medium_session_runs_rd_with_cabac(gpu, opts):
     """preset medium as the reference's driver opens it (High profile, CABAC): subme 7 stays 7 — RD mode decision with CABAC sizes + psy-RD on
     the device.  The stream decodes to the encoder's reconstruction and the oracle pipeline (cabac, rd) reconstructs the same samples"""
     w, h, nfr, qp = 176, 144, 5, 26
     frames = synth_frames(w, h, nfr, seed=707)
     h_, eff = open_encoder(w, h, dict({"qp": qp, "keyint": 250}, **opts), b"high")
-    assert (eff.b_cabac, eff.analyse.i_subpel_refine, eff.analyse.i_trellis) == (1, 7, 1)        # medium: trellis 1 on the device too
+    assert (eff.b_cabac, eff.analyse.i_subpel_refine, eff.analyse.i_trellis) == (1, 7, opts.get("trellis", 1))        # medium: trellis 1 on the device too; 2 and 0 honoured
     stream, info, recons = encode_all(h_, w, h, frames)
     H.x264_encoder_close(h_)
     kw = eff_kw(eff)
     assert kw["rd"] == 1 and kw["cabac"] == 1 and kw["chroma_qp_offset"] == (0 if "no-psy" in opts else -2)
     qp_i = max(1, int(qp - 6.0 * np.log2(1.4) + 0.5))
     og = O.OracleEncoder(O.default_config(w, h, qp_i=qp_i, qp_p=qp, partitions=7, dct8x8=1, refs=eff.i_frame_reference, chroma_me=1, mixed_refs=int(eff.i_frame_reference > 1),
-                                          slices=2 if "sliced-threads" in opts else 1, **kw))
+                                          slices=2 if "sliced-threads" in opts else 1, me_method=2 if opts.get("me") == "umh" else 1, **kw))
     dec = O.h264_decode(stream, nfr, w, h)
     for i, f in enumerate(frames):
         np.testing.assert_array_equal(dec[i], recons[i], err_msg=f"decoded picture {i}")

@@ -151,6 +151,11 @@ CABAC_CTX_P = CABAC_CTX_I + list(range(11, 24)) + list(range(40, 60))
     (96, 208, 4, dict(slices=3, partitions=7, dct8x8=1, refs=2, aq_mode=1, subme=6, trellis=63)),
     (96, 80, 4, dict(partitions=7, dct8x8=1, qp_i=8, qp_p=10, dct_decimate=0, fast_pskip=0, subme=6, trellis=63)),
     (208, 120, 4, dict(partitions=7, dct8x8=1, qp_i=44, qp_p=47, subme=6, trellis=63)),
+    # --trellis 2 (+ 64): the search also inside the intra analysis' block encodes and in every RD candidate
+    (176, 144, 4, dict(partitions=2, subme=6, trellis=127)),
+    (176, 144, 5, dict(partitions=7, dct8x8=1, refs=3, mixed_refs=1, chroma_me=1, psy=1, psy_rd_q8=256, chroma_qp_offset=-2, subme=7, trellis=127)),
+    (96, 208, 4, dict(slices=3, partitions=7, dct8x8=1, refs=2, aq_mode=1, subme=6, trellis=127)),
+    (208, 120, 4, dict(partitions=7, dct8x8=1, qp_i=44, qp_p=47, me_method=2, subme=6, trellis=127)),
 ])
 def test_pipeline_cabac_rd_bitexact(gpu, w, h, nfr, kw):
     """RD mode decision in a CABAC session (x264 subme 6 / 7 at preset medium's entropy coder): the device carries the slice's context

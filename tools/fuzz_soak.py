@@ -32,7 +32,7 @@ def main():
             if rd:
                 psy = rnd.randint(0, 1)
                 if trellis:
-                    kw.update(trellis=rnd.choice([63, 63, rnd.randint(1, 62)]))
+                    kw.update(trellis=rnd.choice([63, 63, 127, rnd.randint(1, 62), 64 + rnd.randint(1, 63)]))
                 kw.update(cabac=int(rd_cabac), rd=1, subme=rnd.choice([6, 7]), psy=psy, psy_rd_q8=rnd.choice([26, 102, 256, 512]) if psy else 0)
             frames = synth_frames(w, h, nfr, seed=fseed)
             cfg = O.default_config(w, h, **kw)

@@ -78,6 +78,14 @@ CASES = [
     (96, 208, 4, dict(cabac=1, rd=1, subme=6, slices=3, partitions=7, dct8x8=1, refs=2, aq_mode=1, trellis=63)),
     (96, 80, 4, dict(cabac=1, rd=1, subme=6, partitions=7, dct8x8=1, qp_i=8, qp_p=10, dct_decimate=0, fast_pskip=0, trellis=63)),
     (208, 120, 4, dict(cabac=1, rd=1, subme=6, partitions=7, dct8x8=1, qp_i=44, qp_p=47, trellis=63)),
+    # --trellis 2 (bit 6): the search also in the intra analysis' block encodes and in every RD candidate
+    (64, 48, 3, dict(cabac=1, rd=1, subme=6, partitions=0, trellis=127)),
+    (176, 144, 4, dict(cabac=1, rd=1, subme=6, partitions=2, trellis=127)),
+    (176, 144, 4, dict(cabac=1, rd=1, subme=7, partitions=5, dct8x8=1, trellis=127)),
+    (176, 144, 5, dict(cabac=1, rd=1, subme=7, partitions=7, dct8x8=1, refs=3, mixed_refs=1, chroma_me=1, psy=1, psy_rd_q8=256, chroma_qp_offset=-2, trellis=127)),
+    (96, 208, 4, dict(cabac=1, rd=1, subme=6, slices=3, partitions=7, dct8x8=1, refs=2, aq_mode=1, trellis=127)),
+    (96, 80, 4, dict(cabac=1, rd=1, subme=6, partitions=7, dct8x8=1, qp_i=8, qp_p=10, dct_decimate=0, fast_pskip=0, trellis=127)),
+    (208, 120, 4, dict(cabac=1, rd=1, subme=6, partitions=7, dct8x8=1, qp_i=44, qp_p=47, me_method=2, trellis=127)),
 ]
 
 

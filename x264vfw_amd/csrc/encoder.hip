@@ -102,7 +102,7 @@ int x264gpu_encoder_create(x264gpu_encoder **out, const x264gpu_config *cfg)
     ARG_TRY(out && cfg);
     ARG_TRY(cfg->width >= 16 && cfg->height >= 16 && !(cfg->width & 1) && !(cfg->height & 1) && cfg->streams >= 1);
     ARG_TRY(cfg->qp_i >= 0 && cfg->qp_i <= 51 && cfg->qp_p >= 0 && cfg->qp_p <= 51 && cfg->refs >= 1 && cfg->refs <= 5);
-    ARG_TRY(cfg->trellis == 0 || (cfg->trellis > 0 && cfg->trellis < 64 && cfg->rd && cfg->cabac));      // trellis sites (mask; x264 --trellis 1 = 63): RD sessions with CABAC
+    ARG_TRY(cfg->trellis == 0 || (cfg->trellis > 0 && cfg->trellis < 128 && (cfg->trellis & 63) && cfg->rd && cfg->cabac));      // trellis sites (mask; x264 --trellis 1 = 63, --trellis 2 = 63 + 64): RD sessions with CABAC
     ARG_TRY(!cfg->rd || (cfg->subme >= 6 && cfg->subme <= 7 && cfg->psy_rd_q8 >= 0 && cfg->psy_rd_q8 <= 2560));      // RD: x264's i_mbrd 1 (bit counts of the session's entropy coder)
     ARG_TRY(cfg->slices >= 0 && (cfg->slices <= 1 || cfg->slices <= (cfg->height + 15) / 16 / 4));      // x264 slice threads: at least four macroblock rows each
     ARG_TRY(cfg->width <= 4096 && cfg->height <= 2304 && cfg->me_range >= 4 && cfg->me_range <= (cfg->me_method == 2 ? 64 : 16));

@@ -755,181 +755,6 @@ __device__ __forceinline__ int pick_intra_mode(F raw, int avail, int pm, int lam
     return best;
 }
 
-struct IntraRes { int satd_i16, satd_i8, satd_i4, pred16; unsigned nnz4, nnz8; int cbp8; };
-
-// Needs the neighbour samples in L.tile / L.tile8 / L.nb and the neighbour macroblocks' edge modes in L.nmodes.
-template <int M>
-__device__ __forceinline__ void mb_analyse_intra(const EncK &k, MbLds<M> &L, const MbCtx &c, uint32_t cz, uint32_t t4, int parts, int i_satd_inter,
-                                                 bool fast_intra, bool early_term, bool mbrd, const Q4 &q4, const Q8 &q8, IntraRes &R)
-{
-    const bool every_mode = mbrd && !fast_intra;          // x264: i_mbrd >= 1 + b_fast_intra
-    const int lane = c.lane, j = lane & 3, zx = z_x0(lane), zy = z_y(lane), lambda = c.lambda;
-    const bool left = c.mbx > 0, top = c.sy > 0, topright = top && c.mbx + 1 < k.mbw;
-    const int sm = min(c.subme, 10);
-    uint8_t *tile = L.tile + IT_ORG, *tile8 = L.tile8 + IT_ORG;
-    R.satd_i16 = R.satd_i8 = R.satd_i4 = MB_COST_MAX; R.pred16 = 0; R.nnz4 = R.nnz8 = 0; R.cbp8 = 0;
-    // ---- 16x16 ----
-    {
-        const Pred16 pp = pred16_setup(L.nb, lane);
-        const int lut = sm < 3 ? 2 : sm < 5 ? 3 : 4;
-        const int thresh16 = fast_intra ? (lut * i_satd_inter) >> 1 : MB_COST_MAX;
-        auto cost16 = [&](int m) {
-            const uint32_t pr = pred16_row4(L.nb, pp, m, zx, zy);
-            const int sig = m > PRED16_P ? PRED16_DC : m;
-            return wave_sum(c.satd ? satd4_half(cz, pr, lane) : sad4(cz, pr)) + lambda * bs_size_ue(sig);
-        };
-        if (left && top) {
-            for (int m = 0; m < 3; m++) { const int cst = cost16(m); if (cst < R.satd_i16) { R.satd_i16 = cst; R.pred16 = m; } }
-            if (R.satd_i16 <= thresh16) { const int cst = cost16(PRED16_P); if (cst < R.satd_i16) { R.satd_i16 = cst; R.pred16 = PRED16_P; } }
-        } else {
-            const int m0 = left ? PRED16_DC_LEFT : top ? PRED16_DC_TOP : PRED16_DC_128, m1 = left ? PRED16_H : PRED16_V;
-            { const int cst = cost16(m0); if (cst < R.satd_i16) { R.satd_i16 = cst; R.pred16 = m0; } }
-            if (left || top) { const int cst = cost16(m1); if (cst < R.satd_i16) { R.satd_i16 = cst; R.pred16 = m1; } }
-        }
-        if (R.satd_i16 > thresh16) return;
-    }
-    // ---- 8x8: R8 layout, lane = (mode group, row); eight modes in one pass, the ninth in a second ----
-    if ((parts & 4) && k.dct8x8) {
-        const int thresh = mbrd ? MB_COST_MAX : min(i_satd_inter, R.satd_i16);       // RD: every block is analysed
-        const int g = lane >> 3, r8 = lane & 7;
-        if (lane < 16) L.modes8[lane] = 2;
-        int i_cost = lambda * 4, idx;
-        for (idx = 0;; idx++) {
-            const int x8 = idx & 1, y8 = idx >> 1, avail = i8_avail(left, top, topright, idx);
-            lds_sync();
-            const int pm = i4_pred_mode(L.nmodes, c.mbx, c.sy, idx * 4, L.modes8);
-            uint8_t *bt = tile8 + y8 * 8 * IT_STRIDE + x8 * 8;
-            pred8_build_u(L.U8, bt, IT_STRIDE, avail, lane);
-            const int src = idx * 16 + (r8 >> 2) * 8 + (r8 & 3);
-            const uint32_t elo = (uint32_t)__shfl((int)cz, src), ehi = (uint32_t)__shfl((int)cz, src + 4);
-            uint32_t p1lo, p1hi, p2lo, p2hi;
-            auto cost8 = [&](uint32_t plo, uint32_t phi) {
-                int h;
-                if (c.satd) { h = sa8d_r8_half(elo, ehi, plo, phi, lane); h += dpp<DPP_XOR1>(h); h += dpp<DPP_XOR2>(h); h += xor4(h); return (2 * h + 2) >> 2; }
-                h = (int)__builtin_amdgcn_sad_u8(plo, elo, __builtin_amdgcn_sad_u8(phi, ehi, 0u));
-                h += dpp<DPP_XOR1>(h); h += dpp<DPP_XOR2>(h); h += xor4(h);
-                return h;
-            };
-            pred8_row8(L.U8, L.pred8tab, g, r8, p1lo, p1hi);
-            const int c1 = cost8(p1lo, p1hi);
-            pred8_row8(L.U8, L.pred8tab, 8, r8, p2lo, p2hi);
-            const int c2 = cost8(p2lo, p2hi);
-            int bm;
-            const int best = pick_intra_mode([&](int m) { return m < 8 ? rl(c1, m * 8) : rl(c2, 0); }, avail, pm, lambda, false, every_mode, bm);
-            i_cost += best + 3 * lambda;
-            if (lane < 4) L.modes8[idx * 4 + lane] = (uint8_t)bm;
-            if (idx < 3 && i_cost > thresh) break;
-            // code the block (the next ones predict from it; the last one so that the result is complete if Intra8x8 wins)
-            const uint32_t plo = bm == 8 ? (uint32_t)__shfl((int)p2lo, r8) : (uint32_t)__shfl((int)p1lo, bm * 8 + r8);
-            const uint32_t phi = bm == 8 ? (uint32_t)__shfl((int)p2hi, r8) : (uint32_t)__shfl((int)p1hi, bm * 8 + r8);
-            int e[8], p[8], v[8];
-            unpack8(elo, ehi, e); unpack8(plo, phi, p);
-#pragma unroll
-            for (int i = 0; i < 8; i++) v[i] = e[i] - p[i];
-            fwd8_1d(v); transpose8(v, lane); fwd8_1d(v); transpose8(v, lane);
-            int mf[4], bs[4], dq[4];
-            q8_row(q8, r8, mf, bs, dq);
-            unsigned mlo = 0, mhi = 0;
-#pragma unroll
-            for (int i = 0; i < 8; i++) {
-                v[i] = quant_one(v[i], mf[i & 3], bs[i & 3]);
-                const int z = c_zigzag8_inv[r8 * 8 + i];
-                if (v[i]) { if (z < 32) mlo |= 1u << z; else mhi |= 1u << (z - 32); }
-                if (g == 0) L.lv8[(idx * 4 + (z & 3)) * 16 + (z >> 2)] = (int16_t)v[i];
-            }
-            mlo = group8_or(mlo); mhi = group8_or(mhi);
-            const unsigned long long mask = ((unsigned long long)mhi << 32) | mlo;
-#pragma unroll
-            for (int q = 0; q < 4; q++) R.nnz8 |= (mask & (0x1111111111111111ull << q)) ? 1u << (idx * 4 + q) : 0u;
-            if (mask) R.cbp8 |= 1 << idx;
-            const int qb = q8.qp / 6 - 6;
-#pragma unroll
-            for (int i = 0; i < 8; i++) v[i] = dequant_one(v[i], dq[i & 3], qb);
-            inv8_1d(v); transpose8(v, lane); inv8_1d(v); transpose8(v, lane);
-#pragma unroll
-            for (int i = 0; i < 8; i++) v[i] = ((v[i] + 32) >> 6) + p[i];
-            if (g == 0) {
-                *(uint32_t *)(bt + r8 * IT_STRIDE) = pack4_clip8lo(v);
-                *(uint32_t *)(bt + r8 * IT_STRIDE + 4) = pack4_clip8hi(v);
-            }
-            if (idx == 3) break;
-        }
-        lds_sync();
-        R.nnz8 = (unsigned)__builtin_amdgcn_readfirstlane((int)R.nnz8);
-        R.cbp8 = __builtin_amdgcn_readfirstlane(R.cbp8);
-        if (idx == 3) R.satd_i8 = i_cost;
-        else i_cost = (i_cost * (idx == 0 ? 1024 : idx == 1 ? 512 : 341)) >> 8;
-        const int thr8 = sm < 3 ? 4 : sm < 6 ? 5 : 6;
-        if (early_term && min(i_cost, R.satd_i16) > (int)(((long long)i_satd_inter * thr8) >> 2)) return;
-    }
-    // ---- 4x4: nine modes per block in parallel (one quad of lanes per mode), blocks in coding order ----
-    if (parts & 2) {
-        int thresh = early_term ? min(min(i_satd_inter, R.satd_i16), R.satd_i8) : MB_COST_MAX;
-        if (early_term && mbrd) thresh = (int)((long long)thresh * (fast_intra ? 9 : 10) / 8);       // RD: a little slack, the SATD order is not final
-        if (lane < 16) L.modes4[lane] = 2;
-        int i_cost = lambda * (24 + 16), idx;
-        for (idx = 0;; idx++) {
-            const int bx = z_bx(idx), by = z_by(idx);
-            const int avail = i4_avail(c.mbx, c.sy, k.mbw, idx);
-            lds_sync();
-            const int pm = i4_pred_mode(L.nmodes, c.mbx, c.sy, idx, L.modes4);
-            uint8_t *bt = tile + by * 4 * IT_STRIDE + bx * 4;
-            pred4_build_u(L.U, bt, IT_STRIDE, avail, lane);
-            const uint32_t pr = pred4_row4(L.U, t4);
-            const uint32_t en = (uint32_t)__shfl((int)cz, idx * 4 + j);
-            const int sat = quad_sum(c.satd ? satd4_half(en, pr, lane) : sad4(en, pr));
-            int bm;
-            const int best = pick_intra_mode([&](int m) { return rl(sat, m * 4); }, avail, pm, lambda, true, every_mode, bm);
-            i_cost += best + 3 * lambda;
-            if (lane == 0) L.modes4[idx] = (uint8_t)bm;
-            if (idx < 15 && i_cost > thresh) break;
-            const uint32_t bp = (uint32_t)__shfl((int)pr, bm * 4 + j);
-            int e[4], p[4], v[4];
-            unpack4(en, e); unpack4(bp, p);
-#pragma unroll
-            for (int t = 0; t < 4; t++) v[t] = e[t] - p[t];
-            dct4_quad(v, lane);
-            quant4_row(v, q4, j);
-            const bool nz = quad_or((v[0] | v[1] | v[2] | v[3]) != 0 ? 1 : 0) != 0;
-            if (lane < 4) store_levels_scan(L.lv4 + idx * 16, v, j);
-            dequant4_row(v, q4, j);
-            idct4_quad(v, lane);
-#pragma unroll
-            for (int t = 0; t < 4; t++) v[t] += p[t];
-            if (lane < 4) *(uint32_t *)(bt + j * IT_STRIDE) = nz ? pack4_clip(v) : bp;
-            if (__builtin_amdgcn_readfirstlane((int)nz)) R.nnz4 |= 1u << idx;
-            if (idx == 15) break;
-        }
-        lds_sync();
-        if (idx == 15) R.satd_i4 = i_cost;
-    }
-}
-
-// chroma intra: mode decision (oracle analyse_intra_chroma).  Lanes 0..31 (plane = lane >> 4); needs L.cnb.
-template <int M>
-__device__ __forceinline__ int mb_intra_chroma_cost(const EncK &k, MbLds<M> &L, const MbCtx &c, int &predc)
-{
-    const int lane = c.lane, pl = (lane >> 4) & 1, ci = (lane >> 2) & 3, j = lane & 3, cx0 = (ci & 1) * 4, cyy = (ci >> 1) * 4 + j;
-    const bool left = c.mbx > 0, top = c.sy > 0;
-    const uint8_t *cnb = L.cnb[pl];
-    const PredC pc = predc_setup(cnb);
-    const uint2 fe = *(const uint2 *)(L.csrc + cyy * 16 + 2 * cx0);
-    const uint32_t cenc = nv12_pick(fe.x, fe.y, pl);
-    // candidate list by availability, a nibble string: DC H V P | DC_LEFT H | DC_TOP V | DC_128
-    const unsigned lst = left && top ? 0x3210u : left ? 0x14u : top ? 0x25u : 0x6u;
-    const int n = left && top ? 4 : (left || top) ? 2 : 1;
-    int bestc = MB_COST_MAX;
-    predc = (int)(lst & 15);
-    for (int i = 0; i < n; i++) {
-        const int m = (int)((lst >> (4 * i)) & 15), sig = m > PREDC_P ? PREDC_DC : m;
-        const uint32_t pr = predc_row4(cnb, pc, m, ci, j);
-        const int hs = c.satd ? satd4_half(cenc, pr, lane) : sad4(cenc, pr);
-        const int cst = wave_sum(lane < 32 ? hs : 0) + c.lambda * bs_size_ue(sig);
-        if (cst < bestc) { bestc = cst; predc = m; }
-    }
-    return bestc;
-}
-
 }  // namespace x264gpu
 #include "cabac_rd.cuh"          // needs the motion cache and the intra-mode helpers above
 #include "trellis.cuh"
@@ -1060,6 +885,200 @@ __device__ __forceinline__ unsigned mb_encode_i8x8_trellis(const EncK &k, MbLds<
     nnz8 = (unsigned)__builtin_amdgcn_readfirstlane((int)nnz8);
     cbp8 = __builtin_amdgcn_readfirstlane(cbp8);
     return nnz8;
+}
+
+struct IntraRes { int satd_i16, satd_i8, satd_i4, pred16; unsigned nnz4, nnz8; int cbp8; };
+
+// Needs the neighbour samples in L.tile / L.tile8 / L.nb and the neighbour macroblocks' edge modes in L.nmodes.
+template <int M>
+__device__ __forceinline__ void mb_analyse_intra(const EncK &k, MbLds<M> &L, const MbCtx &c, uint32_t cz, uint32_t t4, int parts, int i_satd_inter,
+                                                 bool fast_intra, bool early_term, bool mbrd, const Q4 &q4, const Q8 &q8, IntraRes &R, const TrCtx *tra = nullptr)
+{
+    const bool every_mode = mbrd && !fast_intra;          // x264: i_mbrd >= 1 + b_fast_intra
+    const int lane = c.lane, j = lane & 3, zx = z_x0(lane), zy = z_y(lane), lambda = c.lambda;
+    const bool left = c.mbx > 0, top = c.sy > 0, topright = top && c.mbx + 1 < k.mbw;
+    const int sm = min(c.subme, 10);
+    uint8_t *tile = L.tile + IT_ORG, *tile8 = L.tile8 + IT_ORG;
+    R.satd_i16 = R.satd_i8 = R.satd_i4 = MB_COST_MAX; R.pred16 = 0; R.nnz4 = R.nnz8 = 0; R.cbp8 = 0;
+    // ---- 16x16 ----
+    {
+        const Pred16 pp = pred16_setup(L.nb, lane);
+        const int lut = sm < 3 ? 2 : sm < 5 ? 3 : 4;
+        const int thresh16 = fast_intra ? (lut * i_satd_inter) >> 1 : MB_COST_MAX;
+        auto cost16 = [&](int m) {
+            const uint32_t pr = pred16_row4(L.nb, pp, m, zx, zy);
+            const int sig = m > PRED16_P ? PRED16_DC : m;
+            return wave_sum(c.satd ? satd4_half(cz, pr, lane) : sad4(cz, pr)) + lambda * bs_size_ue(sig);
+        };
+        if (left && top) {
+            for (int m = 0; m < 3; m++) { const int cst = cost16(m); if (cst < R.satd_i16) { R.satd_i16 = cst; R.pred16 = m; } }
+            if (R.satd_i16 <= thresh16) { const int cst = cost16(PRED16_P); if (cst < R.satd_i16) { R.satd_i16 = cst; R.pred16 = PRED16_P; } }
+        } else {
+            const int m0 = left ? PRED16_DC_LEFT : top ? PRED16_DC_TOP : PRED16_DC_128, m1 = left ? PRED16_H : PRED16_V;
+            { const int cst = cost16(m0); if (cst < R.satd_i16) { R.satd_i16 = cst; R.pred16 = m0; } }
+            if (left || top) { const int cst = cost16(m1); if (cst < R.satd_i16) { R.satd_i16 = cst; R.pred16 = m1; } }
+        }
+        if (R.satd_i16 > thresh16) return;
+    }
+    // ---- 8x8: R8 layout, lane = (mode group, row); eight modes in one pass, the ninth in a second ----
+    if ((parts & 4) && k.dct8x8) {
+        const int thresh = mbrd ? MB_COST_MAX : min(i_satd_inter, R.satd_i16);       // RD: every block is analysed
+        const int g = lane >> 3, r8 = lane & 7;
+        if (lane < 16) L.modes8[lane] = 2;
+        int i_cost = lambda * 4, idx;
+        for (idx = 0;; idx++) {
+            const int x8 = idx & 1, y8 = idx >> 1, avail = i8_avail(left, top, topright, idx);
+            lds_sync();
+            const int pm = i4_pred_mode(L.nmodes, c.mbx, c.sy, idx * 4, L.modes8);
+            uint8_t *bt = tile8 + y8 * 8 * IT_STRIDE + x8 * 8;
+            pred8_build_u(L.U8, bt, IT_STRIDE, avail, lane);
+            const int src = idx * 16 + (r8 >> 2) * 8 + (r8 & 3);
+            const uint32_t elo = (uint32_t)__shfl((int)cz, src), ehi = (uint32_t)__shfl((int)cz, src + 4);
+            uint32_t p1lo, p1hi, p2lo, p2hi;
+            auto cost8 = [&](uint32_t plo, uint32_t phi) {
+                int h;
+                if (c.satd) { h = sa8d_r8_half(elo, ehi, plo, phi, lane); h += dpp<DPP_XOR1>(h); h += dpp<DPP_XOR2>(h); h += xor4(h); return (2 * h + 2) >> 2; }
+                h = (int)__builtin_amdgcn_sad_u8(plo, elo, __builtin_amdgcn_sad_u8(phi, ehi, 0u));
+                h += dpp<DPP_XOR1>(h); h += dpp<DPP_XOR2>(h); h += xor4(h);
+                return h;
+            };
+            pred8_row8(L.U8, L.pred8tab, g, r8, p1lo, p1hi);
+            const int c1 = cost8(p1lo, p1hi);
+            pred8_row8(L.U8, L.pred8tab, 8, r8, p2lo, p2hi);
+            const int c2 = cost8(p2lo, p2hi);
+            int bm;
+            const int best = pick_intra_mode([&](int m) { return m < 8 ? rl(c1, m * 8) : rl(c2, 0); }, avail, pm, lambda, false, every_mode, bm);
+            i_cost += best + 3 * lambda;
+            if (lane < 4) L.modes8[idx * 4 + lane] = (uint8_t)bm;
+            if (idx < 3 && i_cost > thresh) break;
+            // code the block (the next ones predict from it; the last one so that the result is complete if Intra8x8 wins)
+            const uint32_t plo = bm == 8 ? (uint32_t)__shfl((int)p2lo, r8) : (uint32_t)__shfl((int)p1lo, bm * 8 + r8);
+            const uint32_t phi = bm == 8 ? (uint32_t)__shfl((int)p2hi, r8) : (uint32_t)__shfl((int)p1hi, bm * 8 + r8);
+            int e[8], p[8], v[8];
+            unpack8(elo, ehi, e); unpack8(plo, phi, p);
+#pragma unroll
+            for (int i = 0; i < 8; i++) v[i] = e[i] - p[i];
+            fwd8_1d(v); transpose8(v, lane); fwd8_1d(v); transpose8(v, lane);
+            int mf[4], bs[4], dq[4];
+            q8_row(q8, r8, mf, bs, dq);
+            unsigned mlo = 0, mhi = 0;
+            const bool tr8 = tra && (tra->on & TR_I8);         // --trellis 2: the block the following ones predict from is the searched one
+            if (tr8) {
+                if (g == 0)
+#pragma unroll
+                    for (int i = 0; i < 8; i++) L.lv8[idx * 64 + c_zigzag8_inv[r8 * 8 + i]] = (int16_t)v[i];
+                lds_sync();
+                trellis_run<5>(*tra, L.lv8 + idx * 64, 64, 1, c.qp, true, lane);
+                lds_sync();
+#pragma unroll
+                for (int i = 0; i < 8; i++) v[i] = L.lv8[idx * 64 + c_zigzag8_inv[r8 * 8 + i]];
+                lds_sync();
+            }
+#pragma unroll
+            for (int i = 0; i < 8; i++) {
+                if (!tr8) v[i] = quant_one(v[i], mf[i & 3], bs[i & 3]);
+                const int z = c_zigzag8_inv[r8 * 8 + i];
+                if (v[i]) { if (z < 32) mlo |= 1u << z; else mhi |= 1u << (z - 32); }
+                if (g == 0) L.lv8[(idx * 4 + (z & 3)) * 16 + (z >> 2)] = (int16_t)v[i];
+            }
+            mlo = group8_or(mlo); mhi = group8_or(mhi);
+            const unsigned long long mask = ((unsigned long long)mhi << 32) | mlo;
+#pragma unroll
+            for (int q = 0; q < 4; q++) R.nnz8 |= (mask & (0x1111111111111111ull << q)) ? 1u << (idx * 4 + q) : 0u;
+            if (mask) R.cbp8 |= 1 << idx;
+            const int qb = q8.qp / 6 - 6;
+#pragma unroll
+            for (int i = 0; i < 8; i++) v[i] = dequant_one(v[i], dq[i & 3], qb);
+            inv8_1d(v); transpose8(v, lane); inv8_1d(v); transpose8(v, lane);
+#pragma unroll
+            for (int i = 0; i < 8; i++) v[i] = ((v[i] + 32) >> 6) + p[i];
+            if (g == 0) {
+                *(uint32_t *)(bt + r8 * IT_STRIDE) = pack4_clip8lo(v);
+                *(uint32_t *)(bt + r8 * IT_STRIDE + 4) = pack4_clip8hi(v);
+            }
+            if (idx == 3) break;
+        }
+        lds_sync();
+        R.nnz8 = (unsigned)__builtin_amdgcn_readfirstlane((int)R.nnz8);
+        R.cbp8 = __builtin_amdgcn_readfirstlane(R.cbp8);
+        if (idx == 3) R.satd_i8 = i_cost;
+        else i_cost = (i_cost * (idx == 0 ? 1024 : idx == 1 ? 512 : 341)) >> 8;
+        const int thr8 = sm < 3 ? 4 : sm < 6 ? 5 : 6;
+        if (early_term && min(i_cost, R.satd_i16) > (int)(((long long)i_satd_inter * thr8) >> 2)) return;
+    }
+    // ---- 4x4: nine modes per block in parallel (one quad of lanes per mode), blocks in coding order ----
+    if (parts & 2) {
+        int thresh = early_term ? min(min(i_satd_inter, R.satd_i16), R.satd_i8) : MB_COST_MAX;
+        if (early_term && mbrd) thresh = (int)((long long)thresh * (fast_intra ? 9 : 10) / 8);       // RD: a little slack, the SATD order is not final
+        if (lane < 16) L.modes4[lane] = 2;
+        int i_cost = lambda * (24 + 16), idx;
+        for (idx = 0;; idx++) {
+            const int bx = z_bx(idx), by = z_by(idx);
+            const int avail = i4_avail(c.mbx, c.sy, k.mbw, idx);
+            lds_sync();
+            const int pm = i4_pred_mode(L.nmodes, c.mbx, c.sy, idx, L.modes4);
+            uint8_t *bt = tile + by * 4 * IT_STRIDE + bx * 4;
+            pred4_build_u(L.U, bt, IT_STRIDE, avail, lane);
+            const uint32_t pr = pred4_row4(L.U, t4);
+            const uint32_t en = (uint32_t)__shfl((int)cz, idx * 4 + j);
+            const int sat = quad_sum(c.satd ? satd4_half(en, pr, lane) : sad4(en, pr));
+            int bm;
+            const int best = pick_intra_mode([&](int m) { return rl(sat, m * 4); }, avail, pm, lambda, true, every_mode, bm);
+            i_cost += best + 3 * lambda;
+            if (lane == 0) L.modes4[idx] = (uint8_t)bm;
+            if (idx < 15 && i_cost > thresh) break;
+            const uint32_t bp = (uint32_t)__shfl((int)pr, bm * 4 + j);
+            int e[4], p[4], v[4];
+            unpack4(en, e); unpack4(bp, p);
+#pragma unroll
+            for (int t = 0; t < 4; t++) v[t] = e[t] - p[t];
+            dct4_quad(v, lane);
+            if (tra && (tra->on & TR_I4)) {
+                if (lane < 4) store_levels_scan(L.lv4 + idx * 16, v, j);
+                lds_sync();
+                trellis_run<2>(*tra, L.lv4 + idx * 16, 16, 1, c.qp, true, lane);
+                lds_sync();
+                load_levels_scan(L.lv4 + idx * 16, v, j);
+                lds_sync();
+            } else quant4_row(v, q4, j);
+            const bool nz = quad_or((v[0] | v[1] | v[2] | v[3]) != 0 ? 1 : 0) != 0;
+            if (lane < 4) store_levels_scan(L.lv4 + idx * 16, v, j);
+            dequant4_row(v, q4, j);
+            idct4_quad(v, lane);
+#pragma unroll
+            for (int t = 0; t < 4; t++) v[t] += p[t];
+            if (lane < 4) *(uint32_t *)(bt + j * IT_STRIDE) = nz ? pack4_clip(v) : bp;
+            if (__builtin_amdgcn_readfirstlane((int)nz)) R.nnz4 |= 1u << idx;
+            if (idx == 15) break;
+        }
+        lds_sync();
+        if (idx == 15) R.satd_i4 = i_cost;
+    }
+}
+
+// chroma intra: mode decision (oracle analyse_intra_chroma).  Lanes 0..31 (plane = lane >> 4); needs L.cnb.
+template <int M>
+__device__ __forceinline__ int mb_intra_chroma_cost(const EncK &k, MbLds<M> &L, const MbCtx &c, int &predc)
+{
+    const int lane = c.lane, pl = (lane >> 4) & 1, ci = (lane >> 2) & 3, j = lane & 3, cx0 = (ci & 1) * 4, cyy = (ci >> 1) * 4 + j;
+    const bool left = c.mbx > 0, top = c.sy > 0;
+    const uint8_t *cnb = L.cnb[pl];
+    const PredC pc = predc_setup(cnb);
+    const uint2 fe = *(const uint2 *)(L.csrc + cyy * 16 + 2 * cx0);
+    const uint32_t cenc = nv12_pick(fe.x, fe.y, pl);
+    // candidate list by availability, a nibble string: DC H V P | DC_LEFT H | DC_TOP V | DC_128
+    const unsigned lst = left && top ? 0x3210u : left ? 0x14u : top ? 0x25u : 0x6u;
+    const int n = left && top ? 4 : (left || top) ? 2 : 1;
+    int bestc = MB_COST_MAX;
+    predc = (int)(lst & 15);
+    for (int i = 0; i < n; i++) {
+        const int m = (int)((lst >> (4 * i)) & 15), sig = m > PREDC_P ? PREDC_DC : m;
+        const uint32_t pr = predc_row4(cnb, pc, m, ci, j);
+        const int hs = c.satd ? satd4_half(cenc, pr, lane) : sad4(cenc, pr);
+        const int cst = wave_sum(lane < 32 ? hs : 0) + c.lambda * bs_size_ue(sig);
+        if (cst < bestc) { bestc = cst; predc = m; }
+    }
+    return bestc;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1268,7 +1287,8 @@ __device__ __forceinline__ bool mb_probe_pskip(const EncK &k, const MbCtx &c, ui
 #define MB_WAVES_PER_EU 2
 #endif
 // RD: 0 = SATD decisions (subme <= 5); 1 = RD mode decision with CAVLC bit counts (rd.cuh); 2 = with CABAC context states and sizes (cabac_rd.cuh);
-// 3 = 2 + the trellis quantiser in the final encode (trellis.cuh) — an instantiation of its own: the search's registers would cost the others spills
+// 3 = 2 + the trellis quantiser in the final encode (trellis.cuh) — an instantiation of its own: the search's registers would cost the others spills;
+// 4 = 3 + the search in the intra analysis' block encodes and in every RD candidate (x264 --trellis 2)
 template <int M, int ME, bool PS, int RD = 0>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(MB_WAVES_PER_EU, 4))) void k_mb_slice(EncK k)
 {
@@ -1282,7 +1302,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(MB_WAVES_PER
     lds_sync();
     x264gpu_mb *mbs = k.mb + (size_t)s * k.nmb;
     constexpr bool pslice = PS;
-    constexpr bool TRL = RD == 3;               // trellis sites compiled in                 // I slices run their own instantiation (no search code, a fraction of the registers)
+    constexpr bool TRL = RD >= 3;               // trellis sites compiled in
+    constexpr bool TRL2 = RD == 4;              // --trellis 2: the search also inside the intra analysis and in every RD candidate                 // I slices run their own instantiation (no search code, a fraction of the registers)
     const int j4 = lane & 3, zx = z_x0(lane), zy = z_y(lane);
     int intra_count = 0, cost_qp = -1;
     // RD instantiation: levels of the candidate being costed (and of the final macroblock, before they go out), total_coeff of the left / top
@@ -1664,9 +1685,14 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(MB_WAVES_PER
             i_inter_satd = i_satd_inter;
             // the chroma mode depends on the neighbours only: decided here for every macroblock that is analysed (x264 does it here under chroma-ME,
             // otherwise only for macroblocks that end up intra — same mode either way); its cost enters the comparison under chroma-ME only
+            TrCtx tra_ctx;                   // --trellis 2: the analysis' block encodes run the search too
+            tra_ctx.on = 0; tra_ctx.r = 0; tra_ctx.r8 = 0; tra_ctx.model = 0; tra_ctx.tt.size_unary = nullptr; tra_ctx.tt.trans_unary = nullptr; tra_ctx.tt.lambda2 = nullptr;
+            if constexpr (RD == 4) {
+                if ((k.trellis & 64) && RD && k.rd) { tra_ctx.on = k.trellis & 63; tra_ctx.r = cab.r; tra_ctx.r8 = cab.r8; tra_ctx.model = cab_modelv; tra_ctx.tt.size_unary = k.tr_su; tra_ctx.tt.trans_unary = k.tr_tu; tra_ctx.tt.lambda2 = k.tr_l2; }
+            }
             satd_chroma = mb_intra_chroma_cost(k, L, c, predc);
             pf.mark(PH_INTRA_CHROMA);
-            mb_analyse_intra(k, L, c, cz, t4, parts, c.chroma_me ? i_satd_inter - satd_chroma : i_satd_inter, fast_intra, early_term, rdon, q_li, q8i, IR);
+            mb_analyse_intra(k, L, c, cz, t4, parts, c.chroma_me ? i_satd_inter - satd_chroma : i_satd_inter, fast_intra, early_term, rdon, q_li, q8i, IR, TRL2 && tra_ctx.on ? &tra_ctx : nullptr);
             if (c.chroma_me) { IR.satd_i16 += satd_chroma; IR.satd_i8 += satd_chroma; IR.satd_i4 += satd_chroma; }
             if (pslice) {
                 if (lane == 0) { recd.aux[0] = i_satd_inter; recd.aux[1] = min(min(IR.satd_i16, IR.satd_i8), IR.satd_i4); recd.aux[2] = rl(S.cost, ME_16); }
@@ -1759,8 +1785,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(MB_WAVES_PER
         nnz = 0; cbp_luma = 0; cbp_chroma = 0;
         TrCtx trc;                                                // trellis: the final pass of RD sessions with CABAC (x264 --trellis 1)
         trc.on = 0; trc.r = 0; trc.r8 = 0; trc.model = 0; trc.tt.size_unary = nullptr; trc.tt.trans_unary = nullptr; trc.tt.lambda2 = nullptr;
-        if constexpr (RD == 3) {
-            if (commit && k.trellis && rdon) { trc.on = k.trellis; trc.r = cab.r; trc.r8 = cab.r8; trc.model = cab_modelv; trc.tt.size_unary = k.tr_su; trc.tt.trans_unary = k.tr_tu; trc.tt.lambda2 = k.tr_l2; }
+        if constexpr (RD >= 3) {
+            if ((commit || TRL2) && (k.trellis & 63) && rdon) { trc.on = k.trellis & 63; trc.r = cab.r; trc.r8 = cab.r8; trc.model = cab_modelv; trc.tt.size_unary = k.tr_su; trc.tt.trans_unary = k.tr_tu; trc.tt.lambda2 = k.tr_l2; }
         }
         int rd_t8cur = 0;                                         // transform_size_8x8_flag of what this pass codes
         rec_type = e_type;
@@ -1940,7 +1966,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(MB_WAVES_PER
                 if (commit && lane == 0) recd.transform8x8 = 1;
                 if (commit && lane < 16) recd.i4_mode[lane] = L.modes8[lane];
                 nnz = IR.nnz8; cbp_luma = IR.cbp8;
-                const bool tri8 = TRL && (trc.on & TR_I8) != 0;
+                const bool tri8 = TRL && !TRL2 && (trc.on & TR_I8) != 0;         // (--trellis 2: the analysis' blocks were searched already, they are final)
                 if (tri8) nnz = mb_encode_i8x8_trellis(k, L, c, cz, q8i, trc, lvw, cbp_luma);
                 {
                     const uint32_t rz = *(const uint32_t *)(tile8 + zy * IT_STRIDE + zx);
@@ -1952,7 +1978,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(MB_WAVES_PER
             } else if (e_type == X264GPU_MB_I4x4) {
                 if (commit && lane < 16) recd.i4_mode[lane] = L.modes4[lane];
                 nnz = IR.nnz4;
-                const bool tri4 = TRL && (trc.on & TR_I4) != 0;
+                const bool tri4 = TRL && !TRL2 && (trc.on & TR_I4) != 0;
                 if (tri4) nnz = mb_encode_i4x4_trellis(k, L, c, cz, t4, q_li, trc, lvw);
                 for (int i8 = 0; i8 < 4; i8++) if ((nnz >> (4 * i8)) & 15) cbp_luma |= 1 << i8;
                 {

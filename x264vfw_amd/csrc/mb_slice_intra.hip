@@ -5,7 +5,8 @@
 namespace x264gpu {
 void launch_mb_slice_intra(const EncK &k, int streams, hipStream_t st)
 {
-    if (k.rd && k.cabac && k.trellis) hipLaunchKernelGGL((k_mb_slice<2, 1, false, 3>), dim3(streams, k.slices > 1 ? k.slices : 1), dim3(64), 0, st, k);
+    if (k.rd && k.cabac && (k.trellis & 64)) hipLaunchKernelGGL((k_mb_slice<2, 1, false, 4>), dim3(streams, k.slices > 1 ? k.slices : 1), dim3(64), 0, st, k);
+    else if (k.rd && k.cabac && k.trellis) hipLaunchKernelGGL((k_mb_slice<2, 1, false, 3>), dim3(streams, k.slices > 1 ? k.slices : 1), dim3(64), 0, st, k);
     else if (k.rd && k.cabac) hipLaunchKernelGGL((k_mb_slice<2, 1, false, 2>), dim3(streams, k.slices > 1 ? k.slices : 1), dim3(64), 0, st, k);
     else if (k.rd) hipLaunchKernelGGL((k_mb_slice<2, 1, false, 1>), dim3(streams, k.slices > 1 ? k.slices : 1), dim3(64), 0, st, k);
     else hipLaunchKernelGGL((k_mb_slice<2, 1, false>), dim3(streams, k.slices > 1 ? k.slices : 1), dim3(64), 0, st, k);

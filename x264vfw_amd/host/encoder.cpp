@@ -227,12 +227,11 @@ x264_t *x264_encoder_open(x264_param_t *param)
     if (p.analyse.i_subpel_refine > 7) { xlog(&p, X264_LOG_WARNING, "subme %d needs RD refinement, which is not implemented yet: subme 7\n", p.analyse.i_subpel_refine); p.analyse.i_subpel_refine = 7; }
     p.analyse.i_subpel_refine = clampi(p.analyse.i_subpel_refine, 0, 7);
     // trellis 1 = the final encode of every macroblock quantised by x264's trellis search on the slice's CABAC state: on the device where that state
-    // lives, i.e. in CABAC sessions with RD (subme >= 6); trellis 2 (every RD candidate too) is not implemented
+    // lives, i.e. in CABAC sessions with RD (subme >= 6); trellis 2 = also the block encodes of the intra analysis and every RD candidate
     if (p.analyse.i_trellis && (!p.b_cabac || p.analyse.i_subpel_refine < 6)) {
         xlog(&p, X264_LOG_WARNING, "trellis %d needs CABAC and subme >= 6 in the MI355X path (the search reads the CABAC state the device carries for RD): trellis 0\n", p.analyse.i_trellis);
         p.analyse.i_trellis = 0;
     }
-    if (p.analyse.i_trellis > 1) { xlog(&p, X264_LOG_WARNING, "trellis 2 (trellis on every RD candidate) is not implemented: trellis 1\n"); p.analyse.i_trellis = 1; }
     if (p.analyse.f_psy_trellis > 0) { xlog(&p, X264_LOG_WARNING, "psy-trellis is not implemented in the MI355X path: psy-trellis 0\n"); p.analyse.f_psy_trellis = 0; }
     p.analyse.b_psy = p.analyse.b_psy != 0;
     if (!p.analyse.b_psy) { p.analyse.f_psy_rd = 0; p.analyse.f_psy_trellis = 0; }       // x264 validate_parameters
@@ -315,7 +314,7 @@ x264_t *x264_encoder_open(x264_param_t *param)
     cfg.deblock = p.b_deblocking_filter; cfg.deblock_alpha = p.i_deblocking_filter_alphac0; cfg.deblock_beta = p.i_deblocking_filter_beta;
     cfg.chroma_qp_offset = eff_chroma_qp_offset;
     cfg.rd = p.analyse.i_subpel_refine >= 6; cfg.psy_rd_q8 = psy_rd_q8;
-    cfg.trellis = p.analyse.i_trellis ? 63 : 0;         // every quantiser call of the final encode
+    cfg.trellis = p.analyse.i_trellis == 2 ? 63 + 64 : p.analyse.i_trellis ? 63 : 0;         // every quantiser call of the final encode; + 64: of the analysis too
     cfg.psy = cfg.rd && p.analyse.b_psy;           // x264: the chroma lambda offset table follows b_psy, whatever the psy-rd strength
     cfg.deadzone_inter = p.analyse.i_luma_deadzone[0]; cfg.deadzone_intra = p.analyse.i_luma_deadzone[1];
     cfg.dct_decimate = p.analyse.b_dct_decimate;
