@@ -147,6 +147,7 @@ __device__ __noinline__ unsigned trellis_blocks(lds_i16 *coefs, int stride, int 
         const bool zero = act && q == 0, go = act && q != 0;
         // ---- a zero of the guess: nothing to choose; the all-zero path of a block still in ctx_lo is spared the significance bit ----
         if (zero && !ctx_hi && n == 0) score -= ((unsigned long long)cost0 * (unsigned long long)lambda2) >> 4;
+        if (!__ballot(go)) continue;                 // no block has anything to choose at this position (quantised spectra are sparse): done
         // ---- every lane as a source node: its two candidate levels A = q - 1, B = q ----
         unsigned long long ssd0[2], ssd1[2];
         for (int kk = 0; kk < 2; kk++) {
