@@ -110,6 +110,11 @@ __device__ __noinline__ unsigned trellis_blocks(lds_i16 *coefs, int stride, int 
     int last_nnz = -1;
     for (int p = n; p < NC; p += 8) if (blk_on && p >= B_AC && guess(mine[p], p)) last_nnz = p;
     last_nnz = max(last_nnz, __shfl_xor(last_nnz, 1)); last_nnz = max(last_nnz, __shfl_xor(last_nnz, 2)); last_nnz = max(last_nnz, __shfl_xor(last_nnz, 4));
+    if (!__ballot(last_nnz >= 0)) {                  // the guess leaves nothing in any block: all levels are zero, no search
+        if (CAT == 3) { if (blk_on && n < 4) mine[n] = 0; }
+        else for (int p = n; p < NC; p += 8) if (blk_on) mine[p] = 0;
+        return 0;
+    }
 
     // level_state: the ten abs-level context variables of the category (wave-uniform), packed four to a word
     uint32_t ls[3] = { 0, 0, 0 };
