@@ -70,8 +70,6 @@ __device__ __noinline__ unsigned trellis_blocks(lds_i16 *coefs, int stride, int 
     const int lane = (int)threadIdx.x & 63;
     constexpr int st_sh = CAT == 5 || CAT == 2 ? 0 : CAT == 1 ? 8 : CAT == 4 ? 16 : 24;
     constexpr int sig0 = CAT == 3 ? 48 : 0, last0 = CAT == 3 ? 52 : 16, abs0 = CAT == 3 ? 55 : 32;
-    auto st_sig = [&](int i) { return (int)((__builtin_amdgcn_readlane(reg, sig0 + i) >> st_sh) & 255); };
-    auto st_last = [&](int i) { return (int)((__builtin_amdgcn_readlane(reg, last0 + i) >> st_sh) & 255); };
     auto st_abs = [&](int i) { return (int)((__builtin_amdgcn_readlane(reg, abs0 + i) >> st_sh) & 255); };
     constexpr int NC = CAT == 5 ? 64 : CAT == 3 ? 4 : 16, B_AC = (CAT == 1 || CAT == 4) ? 1 : 0, PW = CAT == 5 ? 4 : 1;
     constexpr bool DC = CAT == 0 || CAT == 3;
@@ -106,14 +104,41 @@ __device__ __noinline__ unsigned trellis_blocks(lds_i16 *coefs, int stride, int 
     auto cls_of = [&](int i) { return DC ? 0 : trellis_class(CAT, i); };
     auto guess = [&](int c, int i) { const int cl = cls_of(i); return ((pick(q_bias, cl) + abs(c)) * pick(q_mf, cl)) >> 16; };      // |level| of the round-to-nearest quantiser
 
-    // the last position the guess leaves non-zero, per block
-    int last_nnz = -1;
-    for (int p = n; p < NC; p += 8) if (blk_on && p >= B_AC && guess(mine[p], p)) last_nnz = p;
-    last_nnz = max(last_nnz, __shfl_xor(last_nnz, 1)); last_nnz = max(last_nnz, __shfl_xor(last_nnz, 2)); last_nnz = max(last_nnz, __shfl_xor(last_nnz, 4));
-    if (!__ballot(last_nnz >= 0)) {                  // the guess leaves nothing in any block: all levels are zero, no search
+    // the positions the guess leaves non-zero, per block (the same mask in its eight lanes)
+    unsigned long long nzm = 0;
+    for (int p = n; p < NC; p += 8) if (blk_on && p >= B_AC && guess(mine[p], p)) nzm |= 1ull << p;
+    for (int m = 1; m < 8; m <<= 1) {
+        const unsigned lo32 = (unsigned)__shfl_xor((int)(unsigned)nzm, m), hi32 = CAT == 5 ? (unsigned)__shfl_xor((int)(unsigned)(nzm >> 32), m) : 0u;
+        nzm |= ((unsigned long long)hi32 << 32) | lo32;
+    }
+    const unsigned long long nzm0 = nzm;
+    if (!__ballot(nzm != 0)) {                       // the guess leaves nothing in any block: all levels are zero, no search
         if (CAT == 3) { if (blk_on && n < 4) mine[n] = 0; }
         else for (int p = n; p < NC; p += 8) if (blk_on) mine[p] = 0;
         return 0;
+    }
+    // What a scan position costs, once per call: lane p = position p holds the bits of its significance / last flags (the slice's context
+    // variables are only read, so every block sees the same), the class of its coefficient, and a running sum of the "significant = 0"
+    // costs — a block then steps from one of ITS non-zero positions to the next and settles the zeros in between with one subtraction
+    uint32_t pos_a = 0, pos_t0 = 0;
+    unsigned long long pos_z = 0;
+    {
+        const int p = lane;
+        const bool valid = p >= B_AC && p < NC - 1;
+        const int sidx = CAT == 5 ? (int)T::cabac_sig8x8[min(p, 62)] : max(p - B_AC, 0) & 15, lidx = CAT == 5 ? (int)T::cabac_last8x8[min(p, 62)] : max(p - B_AC, 0) & 15;
+        const int ss = (int)(((uint32_t)__builtin_amdgcn_ds_bpermute((sig0 + sidx) << 2, (int)reg) >> st_sh) & 255);
+        const int sl = (int)(((uint32_t)__builtin_amdgcn_ds_bpermute((last0 + (CAT == 3 ? min(lidx, 3) : lidx)) << 2, (int)reg) >> st_sh) & 255);
+        const uint32_t ts = (uint32_t)__builtin_amdgcn_ds_bpermute((ss >> 1) << 2, (int)model), tl = (uint32_t)__builtin_amdgcn_ds_bpermute((sl >> 1) << 2, (int)model);
+        const int s0 = (ss & 1) ? (ts >> 9) & 0x7ff : ts & 0x1ff, s1 = (ss & 1) ? ts & 0x1ff : (ts >> 9) & 0x7ff;
+        const int l0 = (sl & 1) ? (tl >> 9) & 0x7ff : tl & 0x1ff, l1 = (sl & 1) ? tl & 0x1ff : (tl >> 9) & 0x7ff;
+        const int cl = p < NC ? cls_of(min(p, NC - 1)) : 0;
+        if (valid) { pos_a = (uint32_t)(s1 + l0) | ((uint32_t)(s1 + l1) << 12); pos_t0 = (uint32_t)(((unsigned long long)s0 * (unsigned long long)lambda2) >> 4); }
+        pos_a |= (uint32_t)cl << 24;
+        pos_z = pos_t0;
+        for (int d = 1; d < 64; d <<= 1) {
+            const unsigned lo32 = (unsigned)__shfl_up((int)(unsigned)pos_z, d), hi32 = (unsigned)__shfl_up((int)(unsigned)(pos_z >> 32), d);
+            if (lane >= d) pos_z += ((unsigned long long)hi32 << 32) | lo32;
+        }
     }
 
     // level_state: the ten abs-level context variables of the category (wave-uniform), packed four to a word
@@ -134,25 +159,24 @@ __device__ __noinline__ unsigned trellis_blocks(lds_i16 *coefs, int stride, int 
     for (int w = 0; w < PW; w++) path[w] = 0;
     bool ctx_hi = false;
 
-    for (int i = NC - 1; i >= B_AC; i--) {
-        const bool act = blk_on && i <= last_nnz;
-        if (!__ballot(act)) continue;
-        const int cl = cls_of(i), un = pick(q_unq, cl), wgt = pick(q_w, cl);          // wave-uniform: the position's coefficient class
-        const int c = act ? (int)mine[i] : 0, a = abs(c), q = ((pick(q_bias, cl) + a) * pick(q_mf, cl)) >> 16;
-        // costs of the position's significance / last flags (the same for every block): wave-uniform
-        const int sidx = CAT == 5 ? (int)T::cabac_sig8x8[min(i, 62)] : i - B_AC, lidx = CAT == 5 ? (int)T::cabac_last8x8[min(i, 62)] : i - B_AC;
-        int cost0 = 0, cost1 = 0, cost2 = 0;
-        if (i < NC - 1) {
-            const int ss = st_sig(sidx), sl = st_last(lidx);
-            const uint32_t ts = __builtin_amdgcn_readlane(model, ss >> 1), tl = __builtin_amdgcn_readlane(model, sl >> 1);
-            const int s0 = (ss & 1) ? (ts >> 9) & 0x7ff : ts & 0x1ff, s1 = (ss & 1) ? ts & 0x1ff : (ts >> 9) & 0x7ff;
-            const int l0 = (sl & 1) ? (tl >> 9) & 0x7ff : tl & 0x1ff, l1 = (sl & 1) ? tl & 0x1ff : (tl >> 9) & 0x7ff;
-            cost0 = s0; cost1 = s1 + l0; cost2 = s1 + l1;
-        }
-        const bool zero = act && q == 0, go = act && q != 0;
-        // ---- a zero of the guess: nothing to choose; the all-zero path of a block still in ctx_lo is spared the significance bit ----
-        if (zero && !ctx_hi && n == 0) score -= ((unsigned long long)cost0 * (unsigned long long)lambda2) >> 4;
-        if (!__ballot(go)) continue;                 // no block has anything to choose at this position (quantised spectra are sparse): done
+    unsigned long long z_before = 0;                 // running sum of the zero costs below the block's previous non-zero position (exclusive)
+    bool started = false;
+    for (;;) {
+        const bool act = blk_on && nzm != 0, go = act;
+        if (!__ballot(act)) break;
+        const int i = act ? 63 - __builtin_clzll(nzm) : 0;          // this block's next non-zero position, from the top
+        nzm &= ~(1ull << i);
+        const int paddr = i << 2;
+        const uint32_t pa = (uint32_t)__builtin_amdgcn_ds_bpermute(paddr, (int)pos_a), t0i = (uint32_t)__builtin_amdgcn_ds_bpermute(paddr, (int)pos_t0);
+        const unsigned long long zi = ((unsigned long long)(uint32_t)__builtin_amdgcn_ds_bpermute(paddr, (int)(unsigned)(pos_z >> 32)) << 32) | (uint32_t)__builtin_amdgcn_ds_bpermute(paddr, (int)(unsigned)pos_z);
+        // the zeros between the previous non-zero position and this one: nothing to choose; the all-zero path of a block still in ctx_lo is
+        // spared their significance bits (subtracting from one node is adding to the rest)
+        if (act && started && !ctx_hi && n == 0) score -= z_before - zi;
+        if (act) { z_before = zi - t0i; started = true; }
+        const int cost1 = (int)(pa & 4095), cost2 = (int)((pa >> 12) & 4095), cl = (int)(pa >> 24);
+        const unsigned long long cost0_l = t0i;          // (bits of "significant = 0" x lambda2) >> 4 of this position
+        const int un = pick(q_unq, cl), wgt = pick(q_w, cl);
+        const int c = act ? (int)mine[i] : 0, a = abs(c), q = act ? ((pick(q_bias, cl) + a) * pick(q_mf, cl)) >> 16 : 1;
         // ---- every lane as a source node: its two candidate levels A = q - 1, B = q ----
         unsigned long long ssd0[2], ssd1[2];
         for (int kk = 0; kk < 2; kk++) {
@@ -166,7 +190,7 @@ __device__ __noinline__ unsigned trellis_blocks(lds_i16 *coefs, int stride, int 
         const bool src_ok = go && (ctx_hi ? (n >= 1 && alive) : (n <= 3 && (n == 0 || alive)));
         // kinds of the two candidates: 0 = level 0 (a copy), 1 = level 1, 2 = level >= 2
         const int kindA = q == 1 ? 0 : q == 2 ? 1 : 2, kindB = q == 1 ? 1 : 2;
-        if (q == 1) ssd1[0] += ((unsigned long long)cost0 * (unsigned long long)lambda2) >> 4;
+        if (q == 1) ssd1[0] += cost0_l;
         unsigned long long candv[2];
         uint32_t candcs[2];
         // (the model lookups are ds_bpermutes: every lane must take part, whatever its block is doing — so nothing below is skipped, the
@@ -253,6 +277,7 @@ __device__ __noinline__ unsigned trellis_blocks(lds_i16 *coefs, int stride, int 
             if (q >= 2) ctx_hi = true;
         }
     }
+    if (blk_on && started && !ctx_hi && n == 0) score -= z_before;          // the zeros below the lowest non-zero position
     // ---- the best node of every block; node 0 = nothing left ----
     const bool cand = ctx_hi ? n >= 1 : n <= 3;
     unsigned long long key = cand && (long long)score >= 0 ? (score << 3) | (unsigned)n : ~0ull;
@@ -271,16 +296,16 @@ __device__ __noinline__ unsigned trellis_blocks(lds_i16 *coefs, int stride, int 
         const int c = blk_on ? (int)mine[p] : 0, q = guess(c, p);
         const uint32_t choice = (bpath[CAT == 5 ? p >> 4 : 0] >> (2 * (p & 15))) & 3;
         int l = 0;
-        if (blk_on && last_nnz >= 0 && bn != 0 && p >= B_AC && p <= last_nnz && choice) l = choice == 1 ? q - 1 : q;
+        if (blk_on && bn != 0 && ((nzm0 >> p) & 1) && choice) l = choice == 1 ? q - 1 : q;
         lv[t] = c < 0 ? -l : l;
         nz = nz || lv[t] != 0;
     }
     __builtin_amdgcn_wave_barrier();
     if (CAT == 3) { if (blk_on && n < 4) mine[n] = (int16_t)lv[0]; }
     else for (int t = 0, p = n; p < NC; p += 8, t++) if (blk_on) mine[p] = (int16_t)lv[t];
-    const unsigned long long nzm = __ballot(nz);
+    const unsigned long long nzb = __ballot(nz);
     unsigned out = 0;
-    for (int b = 0; b < 8; b++) if ((nzm >> (8 * b)) & 0xff) out |= 1u << b;
+    for (int b = 0; b < 8; b++) if ((nzb >> (8 * b)) & 0xff) out |= 1u << b;
     return out;
 }
 
