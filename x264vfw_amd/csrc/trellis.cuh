@@ -2,15 +2,17 @@
 // final encode of a macroblock).  Mirrors oracle/trellis.cpp decision for decision; the algorithm is stated in oracle/TRELLIS_NOTES.md.
 //
 // EIGHT LANES PER BLOCK = THE EIGHT NODES of the search (the abs-level context states CABAC can be in), eight blocks per pass of a
-// wavefront.  The coefficients of the blocks sit in LDS in scan order; one step of the loop is one scan position for all eight blocks:
+// wavefront.  The coefficients of the blocks sit in LDS in scan order.  Quantised spectra are sparse, so a block does not visit every scan
+// position: one step of the loop takes every block from one of ITS non-zero positions (of the round-to-nearest guess) to the next — the
+// zeros in between only cost the all-zero node their "significant = 0" bits, one subtraction from a running sum prepared per call.  A step:
 //   * every lane, as a SOURCE node, prices its two candidate levels (the round-to-nearest guess q and q - 1) on its own copy of the
 //     four context variables a path can touch twice — no traffic between lanes;
 //   * every lane, as a DESTINATION node, takes the minimum over the sources that lead to it.  x264's "first strictly better wins" in its
 //     evaluation order (level q - 1 before q, sources ascending) is the minimum of (score << 4 | order);
 //   * the winner's context bytes and its path (two bits per position: 0 = level 0, 1 = q - 1, 2 = q) come over with one shuffle each.
-// The significance / last costs of a position are the same for all blocks (the slice's context variables are only read), so they are
-// computed once per step by wave-uniform code.  Status: a tested primitive (x264gpu_trellis_blocks, tests/test_gpu_prims.py); the
-// macroblock loop does not call it yet.
+// The significance / last costs of a position are the same for all blocks (the slice's context variables are only read): lane p works out
+// position p's once per call, a block fetches the ones of its current position with a ds_bpermute.  Used by the RD = 3 / 4 instantiations
+// of the macroblock loop (k_mb.cuh: trellis_run) and, as a primitive, by x264gpu_trellis_blocks (tests/test_gpu_prims.py).
 #pragma once
 #include "cabac_rd.cuh"
 
