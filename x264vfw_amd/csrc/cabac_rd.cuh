@@ -358,21 +358,57 @@ __device__ __forceinline__ unsigned long long cab_mb(Cab &cb, uint32_t model, in
             cb.r = (cb.r & ~(255u << shift)) | ((uint32_t)st << shift);
         };
         auto always = [](int) { return true; };
+        // The same for the many-block categories (luma 4x4, luma AC, chroma AC), faster: the coded_block_flags of the blocks are known up front
+        // (nzbits: the macroblock's non-zero flags), and they share FOUR contexts — lane j takes context increment j and walks the blocks
+        // that use it, in order, side by side with the other three; then only the blocks that hold coefficients are visited
+        auto blocks_many = [&](auto cat_tag, int shift, int nblk, unsigned codedmask, unsigned nzbits, auto coef_of, auto inc_of) {
+            constexpr int CAT = decltype(cat_tag)::value;
+            const int b_lane = lane & 15;
+            const bool mine_blk = lane < nblk && ((codedmask >> b_lane) & 1);
+            const int inc = inc_of(b_lane);
+            const unsigned long long nzm = (unsigned long long)(nzbits & codedmask);
+            unsigned long long seq = 0;
+#pragma unroll
+            for (int j = 0; j < 4; j++) { const unsigned long long m = __ballot(mine_blk && inc == j); seq = lane == j ? m : seq; }
+            const int cbase = 85 + CAT * 4;
+            int stc = 0;
+#pragma unroll
+            for (int j = 0; j < 4; j++) { const int c = cbase + j; const uint32_t w = __builtin_amdgcn_readlane(cb.a, c >> 2); stc = lane == j ? (int)((w >> ((c & 3) * 8)) & 255) : stc; }
+            while (__ballot(seq != 0)) {
+                const bool have = seq != 0;
+                const int b = have ? __builtin_ctzll(seq) : 0;
+                cab_step(stc, cb.f8v, model, have, (int)((nzm >> b) & 1));
+                seq &= seq - 1;
+            }
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const int c = cbase + j, li = c >> 2, sh = (c & 3) * 8;
+                const uint32_t v = (uint32_t)__builtin_amdgcn_readlane(stc, j);
+                cb.a = lane == li ? (cb.a & ~(255u << sh)) | (v << sh) : cb.a;
+            }
+            int st = (cb.r >> shift) & 255;
+            for (unsigned long long m = nzm; m; m &= m - 1) {
+                const int b = __builtin_ctzll(m);
+                cab_block4<CAT>(cb, st, model, lane, coef_of(b));
+            }
+            cb.r = (cb.r & ~(255u << shift)) | ((uint32_t)st << shift);
+        };
         if (i16) {
             blocks(std::integral_constant<int, 0>{}, 24, 1, [&](int) { return lane < 16 ? (int)lvs[X264GPU_LV_LUMA_DC + lane] : 0; }, [&](int) { return dc_inc(24); }, always);
-            if (in.cbp_luma) blocks(std::integral_constant<int, 1>{}, 8, 16, [&](int b) { return lane < 15 ? (int)lvs[b * 16 + 1 + lane] : 0; }, luma_inc, always);
+            if (in.cbp_luma) blocks_many(std::integral_constant<int, 1>{}, 8, 16, 0xffffu, in.nnz & 0xffffu, [&](int b) { return lane < 15 ? (int)lvs[b * 16 + 1 + lane] : 0; }, luma_inc);
         } else if (in.t8) {
             int st = cb.r8 & 255;
             for (int i8 = 0; i8 < 4; i8++)
                 if ((in.cbp_luma >> i8) & 1) cab_block8(cb, st, model, lane, (int)lvs[(i8 * 4 + (lane & 3)) * 16 + (lane >> 2)], in.size);
             cb.r8 = (uint32_t)st;
         } else {
-            blocks(std::integral_constant<int, 2>{}, 0, 16, [&](int b) { return lane < 16 ? (int)lvs[b * 16 + lane] : 0; }, luma_inc, [&](int b) { return ((in.cbp_luma >> (b >> 2)) & 1) != 0; });
+            const unsigned coded = ((in.cbp_luma & 1) ? 0x000fu : 0) | ((in.cbp_luma & 2) ? 0x00f0u : 0) | ((in.cbp_luma & 4) ? 0x0f00u : 0) | ((in.cbp_luma & 8) ? 0xf000u : 0);
+            blocks_many(std::integral_constant<int, 2>{}, 0, 16, coded, in.nnz & 0xffffu, [&](int b) { return lane < 16 ? (int)lvs[b * 16 + lane] : 0; }, luma_inc);
         }
         if (in.cbp_chroma) {
             blocks(std::integral_constant<int, 3>{}, 24, 2, [&](int pl) { return lane < 4 ? (int)lvs[X264GPU_LV_CHROMA_DC + pl * 4 + lane] : 0; }, [&](int pl) { return dc_inc(25 + pl); }, always);
             if (in.cbp_chroma == 2)
-                blocks(std::integral_constant<int, 4>{}, 16, 8, [&](int k) { return lane < 15 ? (int)lvs[X264GPU_LV_CHROMA_AC + k * 16 + 1 + lane] : 0; }, [&](int k) { return ac_inc(k >> 2, k & 3); }, always);
+                blocks_many(std::integral_constant<int, 4>{}, 16, 8, 0xffu, (in.nnz >> 16) & 0xffu, [&](int k) { return lane < 15 ? (int)lvs[X264GPU_LV_CHROMA_AC + k * 16 + 1 + lane] : 0; }, [&](int k) { return ac_inc((k >> 2) & 1, k & 3); });
         }
     }
     return amvd;
