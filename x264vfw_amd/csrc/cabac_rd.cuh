@@ -244,15 +244,21 @@ __device__ __forceinline__ unsigned long long cab_mb(Cab &cb, uint32_t model, in
             // every lane its block's mode and predicted mode; the bins go out block by block
             int mode = 0, pm = 0;
             if (lane < 16) { const uint8_t *cur = i8 ? modes8 : modes4; mode = cur[lane]; pm = i4_pred_mode(nmodes, mbx, sy, lane, cur); }
+            // prev_intra_pred_mode_flag (context 68) and the three rem_intra_pred_mode bins (context 69) are two chains: lane 0 and lane 1 walk
+            // them side by side, block after block (contexts 68 and 69 share a dword of register a with 70 and 71, which nothing uses)
+            const uint32_t w68 = __builtin_amdgcn_readlane(cb.a, 68 >> 2);
+            int stp = lane == 0 ? (int)(w68 & 255) : (int)((w68 >> 8) & 255);
             for (int b = 0; b < 16; b += i8 ? 4 : 1) {
                 int m = __builtin_amdgcn_readlane(mode, b);
                 const int p = __builtin_amdgcn_readlane(pm, b);
-                if (m == p) cab_bin(cb, model, lane, 68, 1);
-                else {
-                    cab_bin(cb, model, lane, 68, 0);
-                    if (m > p) m--;
-                    cab_bin(cb, model, lane, 69, m & 1); cab_bin(cb, model, lane, 69, (m >> 1) & 1); cab_bin(cb, model, lane, 69, m >> 2);
-                }
+                const bool same = m == p;
+                if (m > p) m--;
+                cab_step(stp, cb.f8v, model, lane == 0 || (lane == 1 && !same), lane == 0 ? same : m & 1);
+                if (!same) { cab_step(stp, cb.f8v, model, lane == 1, (m >> 1) & 1); cab_step(stp, cb.f8v, model, lane == 1, m >> 2); }
+            }
+            {
+                const uint32_t s68 = (uint32_t)__builtin_amdgcn_readlane(stp, 0), s69 = (uint32_t)__builtin_amdgcn_readlane(stp, 1);
+                cb.a = lane == (68 >> 2) ? (cb.a & ~0xffffu) | s68 | (s69 << 8) : cb.a;
             }
         }
         const int ctx = (lavail && in.ltype < X264GPU_MB_P_L0 && in.lcmode != 0) + (tavail && in.ttype < X264GPU_MB_P_L0 && in.tcmode != 0);
