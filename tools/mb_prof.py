@@ -26,7 +26,7 @@ def main():
     W = int(sys.argv[3]) if len(sys.argv) > 3 else 1920
     H = int(sys.argv[4]) if len(sys.argv) > 4 else 1080
     dev = torch.device("cuda:0")
-    args = type("A", (), dict(refs=3, preset="medium", aq=False, rd=os.environ.get("MB_PROF_RD", "cabac")))()
+    args = type("A", (), dict(refs=3, preset="medium", aq=False, rd=os.environ.get("MB_PROF_RD", "cabac"), no_trellis=bool(os.environ.get("MB_PROF_NO_TRELLIS"))))()
     tools = bench.toolset(args)
     D = min(S, 64)
     base = bench.synth_batch(torch, D, F, W, H, 0x264, dev)
