@@ -266,7 +266,7 @@ def e2e_probe(args):
     w, h = args.width, args.height
     planes = [(w * h, 0), (w * h // 4, w * h), (w * h // 4, w * h * 5 // 4)]
 
-    def run(n, threads, keyint, src, sliced=False, gop_slots=0):
+    def run(n, threads, keyint, src, sliced=False, gop_slots=0, slices=0):
         p = HL.Param()
         assert H.x264_param_default_preset(C.byref(p), b"medium", None) == 0
         p.i_width, p.i_height, p.i_csp = w, h, HL.X264_CSP_I420
@@ -275,6 +275,8 @@ def e2e_probe(args):
             assert H.x264_param_parse(C.byref(p), k.encode(), v.encode()) == 0
         if sliced:
             assert H.x264_param_parse(C.byref(p), b"sliced-threads", None) == 0
+        if slices:
+            assert H.x264_param_parse(C.byref(p), b"slices", str(slices).encode()) == 0
         os.environ.pop("X264GPU_GOP_SLOTS", None)
         if gop_slots:
             os.environ["X264GPU_GOP_SLOTS"] = str(gop_slots)
@@ -316,11 +318,14 @@ def e2e_probe(args):
     ns = (h + 15) // 16 // 4                        # x264 slice threads: at most one slice per four macroblock rows
     fs, kbs = run(max(n1, 24), ns, 250, src, sliced=True)
     fsg, kbsg = run(G * K * 2, ns, K, src, sliced=True, gop_slots=G)
+    nr = (h + 15) // 16                             # x264 --slices N: down to one macroblock row per slice (filtered across the boundaries)
+    fr, kbr = run(max(n1, 48), 1, 250, src, slices=nr)
     os.environ.pop("X264GPU_GOP_SLOTS", None)
     return {"what": "ONE 1920x1080 stream through x264_encoder_encode (host pictures in, Annex-B out: PCIe + host entropy coding included), CQP, preset medium as implemented",
             "threads1_fps": f1, "threads1_frames": n1, "threads1_kB_per_frame": kb1,
             "sliced_threads_fps": fs, "sliced_threads_slices": ns, "sliced_threads_delay_frames": 0, "sliced_threads_kB_per_frame": kbs,
             "sliced_threads_gop_slots32_fps": fsg, "sliced_threads_gop_slots32_delay_frames": (G - 1) * K + 1,
+            "slices_per_row_fps": fr, "slices_per_row_slices": nr, "slices_per_row_delay_frames": 0, "slices_per_row_kB_per_frame": kbr,
             "threads32_fps": fg, "threads32_frames": G * K, "threads32_keyint": K, "threads32_delay_frames": (G - 1) * K + 1, "threads32_kB_per_frame": kbg,
             "host_cores": os.cpu_count()}
 

@@ -196,11 +196,18 @@ typedef struct x264gpu_config {
     int slices;               /* x264 --sliced-threads with --threads N: N slices per picture (0 / 1 = one), slice i = macroblock rows
                                * [(mbh * i + N/2) / N, (mbh * (i+1) + N/2) / N); every slice is analysed on its own (no prediction across a slice
                                * boundary, its own fast-intra statistics and quantiser chain) and the loop filter leaves slice boundaries alone
-                               * (disable_deblocking_filter_idc 2), as x264's slice threads do.  At most mbh / 4 ([x264-upstream] validate_parameters) */
+                               * (disable_deblocking_filter_idc 2), as x264's slice threads do.  At most mbh / 4 ([x264-upstream] validate_parameters);
+                               * see slices_plain for --slices N */
     int trellis;              /* x264's trellis quantiser (quant_trellis_cabac: a search over the levels of a block on the slice's live CABAC state); needs cabac and
                                * rd.  Bits 0..5 = the quantiser calls that use it (1 inter luma 4x4, 2 inter luma 8x8, 4 chroma, 8 Intra_16x16, 16 Intra_4x4,
                                * 32 Intra_8x8): --trellis 1 = 63, in the final encode of every macroblock.  Bit 6 (64) = --trellis 2: also in the block encodes of
                                * the intra analysis and in every RD candidate */
+    int slices_plain;         /* 1: `slices` are x264's --slices N (i_slice_count) instead of its slice threads: same row split, no prediction across a
+                               * boundary, but (a) the loop filter runs ACROSS slice boundaries (disable_deblocking_filter_idc 0, [x264-upstream]
+                               * slice_header_init: 2 only under b_sliced_threads), (b) a slice may be a single macroblock row (at most mbh slices) and
+                               * (c) x264 codes these slices one after the other in one thread, so the frame statistics its fast-intra decision reads
+                               * (intra macroblocks so far) run on through the picture.  The slices still run side by side on the device: each on an
+                               * assumed count of the slices before it, and those whose decisions hang on a wrong assumption run again */
 } x264gpu_config;
 
 int  x264gpu_encoder_create(x264gpu_encoder **enc, const x264gpu_config *cfg);

@@ -24,7 +24,8 @@ int x264host_write_slice(int mbw, int mbh, int slice_type, int qp, int pic_init_
 /* SPS + PPS for a stream made of such slices */
 int x264host_write_headers(int width, int height, int level_idc, int log2_max_frame_num, int pic_init_qp, int chroma_qp_offset,
                            uint32_t num_units_in_tick, uint32_t time_scale, int num_ref, int transform8x8_mode, uint8_t *out, int cap);
-/* the same pair with CABAC slice data (PPS entropy_coding_mode_flag = 1; Main / High profile) */
+/* the same pair with CABAC slice data (PPS entropy_coding_mode_flag = 1; Main / High profile).  slices = N: N slices as x264's slice threads code
+ * them (disable_deblocking_filter_idc 2 where the caller passes 0); slices = -N: N slices as --slices N codes them (idc stays 0) */
 int x264host_write_picture(int mbw, int mbh, int slice_type, int qp, int pic_init_qp, int frame_num, int log2_max_frame_num,
                            int idr, int idr_pic_id, int disable_deblock_idc, int num_ref, int num_ref_default, int transform8x8_mode, int cabac, int slices,
                            const x264gpu_mb *mbs, const int16_t *levels, uint8_t *out, int cap, int *skipped);

@@ -192,7 +192,7 @@ static void deblock_frame(x264o_encoder *e, const x264gpu_mb *mbs)
                     if ((edge & 1) && q->transform8x8) continue;     /* no transform edge at 4-sample offsets */
                     if (edge == 0) {
                         if (dir == 0) { if (mbx == 0) continue; p = &mbs[mby * e->mbw + mbx - 1]; }
-                        else { if (mby == 0 || slice_starts_at_row(e, mby)) continue; p = &mbs[(mby - 1) * e->mbw + mbx]; }      /* idc 2: not across slices */
+                        else { if (mby == 0 || (!e->cfg.slices_plain && slice_starts_at_row(e, mby))) continue; p = &mbs[(mby - 1) * e->mbw + mbx]; }      /* slice threads (idc 2): not across slices; --slices N (idc 0): across */
                     }
                     int qpav = (p->qp + q->qp + 1) >> 1;
                     int qpc_p = x264o_chroma_qp[clampi(p->qp + e->cfg.chroma_qp_offset, 0, 51)];
@@ -253,9 +253,11 @@ int x264o_encoder_encode(x264o_encoder *e, const uint8_t *i420, int slice_type, 
     /* the macroblock loop: raster order, every macroblock analysed AND coded before the next one starts (x264_slice_write) */
     const int ns = e->cfg.slices > 1 ? e->cfg.slices : 1;
     for (int sl = 0; sl < ns; sl++) {
-        /* x264 slice threads: rows split evenly; each thread starts with empty frame statistics (h->stat.frame) */
+        /* x264 slice threads: rows split evenly; each thread starts with empty frame statistics (h->stat.frame).  Plain --slices N are coded one
+         * after the other by one thread: the statistics (the fast-intra decision reads the intra count) run on through the picture */
         e->row0 = (e->mbh * sl + ns / 2) / ns; e->row1 = (e->mbh * (sl + 1) + ns / 2) / ns;
-        e->intra_count = 0; e->last_qp = slice_qp;
+        if (!e->cfg.slices_plain) e->intra_count = 0;
+        e->last_qp = slice_qp;
         if (e->cfg.cabac && (e->cfg.rd || e->cfg.trellis)) { x264o_cabac_init_states(e->cabac_state, slice_type == X264GPU_SLICE_P, slice_qp); e->last_dqp = 0; }
         for (int mby = e->row0; mby < e->row1; mby++)
             for (int mbx = 0; mbx < e->mbw; mbx++) {

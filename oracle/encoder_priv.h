@@ -48,7 +48,7 @@ struct x264o_encoder {
     int16_t *levels;
     int *mb_bits;                /* optional (tests): per macroblock, the CAVLC bit count the RD code predicts for the final macroblock */
     int last_qp;                 /* QP_Y of the previous macroblock in coding order as the entropy coder sees it (h->mb.i_last_qp): mb_qp_delta bits of the RD costs */
-    int intra_count;             /* intra macroblocks coded so far in this slice (h->stat.frame.i_mb_count[I_*]) */
+    int intra_count;             /* intra macroblocks coded so far in this slice (slice threads) / picture (--slices N): h->stat.frame.i_mb_count[I_*] */
     /* CABAC sessions with RD: the slice's context states as the entropy coding of the finished macroblocks leaves them (h->cabac), the
      * previous macroblock's mb_qp_delta and every 8x8 block's |mvd| (cabac_rd.cpp) */
     uint8_t cabac_state[460];

@@ -121,7 +121,7 @@ def write_slice(mbw, mbh, slice_type, qp, pic_init_qp, frame_num, log2_max_frame
     sk = _i()
     mbs = np.ascontiguousarray(mbs)
     lv = np.ascontiguousarray(lv)
-    if slices > 1:           # the picture as several slices (x264 slice threads), one NAL each
+    if slices > 1 or slices < -1:           # the picture as several slices, one NAL each (N: x264 slice threads, -N: x264 --slices N)
         n = H.x264host_write_picture(mbw, mbh, slice_type, qp, pic_init_qp, frame_num, log2_max_frame_num, idr, idr_pic_id, disable_deblock, num_ref, num_ref_default,
                                      t8x8, cabac, slices, mbs.ctypes.data, lv.ctypes.data, buf.ctypes.data, buf.size, C.byref(sk))
         assert n > 0

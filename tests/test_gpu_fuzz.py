@@ -24,6 +24,8 @@ def random_case(rnd):
               fast_pskip=rnd.randint(0, 1), mv_range=rnd.choice([0, 0, 32, 64, 128, 512]), cabac=rnd.randint(0, 1))
     if rnd.random() < 0.25 and (h + 15) // 16 >= 8:
         kw["slices"] = rnd.randint(2, (h + 15) // 16 // 4)        # x264 slice threads
+    elif rnd.random() < 0.2 and h > 16:
+        kw["slices"] = rnd.randint(2, (h + 15) // 16); kw["slices_plain"] = 1          # x264 --slices N: down to one row each, filtered across
     return w, h, kw, rnd.randint(2, 6), rnd.randint(0, 10 ** 6), rnd.random() < 0.3
 
 

@@ -574,6 +574,43 @@ def test_sliced_threads_through_the_api(gpu, w, h, opts, slices):
         np.testing.assert_array_equal(og.recon(), recons[i], err_msg=f"oracle pipeline picture {i}")
 
 
+@pytest.mark.parametrize("w,h,opts,slices", [(176, 288, {"qp": 26, "keyint": 5, "no-scenecut": None, "slices": 18}, 18),
+                                            (96, 336, {"qp": 30, "keyint": 250, "no-scenecut": None, "slices": 4}, 4),
+                                            (208, 144, {"qp": 24, "keyint": 4, "no-scenecut": None, "slices": 40, "no-cabac": None}, 9)])
+def test_plain_slices_through_the_api(gpu, w, h, opts, slices):
+    """x264's --slices N: N slices per picture (at most one per macroblock row: validate_parameters clips), every slice its own wavefront on the
+    device and its own NAL, filtered across the boundaries (disable_deblocking_filter_idc 0).  Zero delay; the stream decodes to the
+    encoder's reconstruction; the oracle pipeline with slices_plain gives the same pictures"""
+    p = HL.Param()
+    assert H.x264_param_default_preset(C.byref(p), b"medium", None) == 0
+    p.i_width, p.i_height, p.i_csp = w, h, HL.X264_CSP_I420
+    p.i_fps_num, p.i_fps_den = 25, 1
+    p.i_log_level = -1
+    for k, v in opts.items():
+        assert H.x264_param_parse(C.byref(p), k.encode(), None if v is None else str(v).encode()) == 0, k
+    p.b_vfr_input = 0
+    p.b_annexb, p.b_repeat_headers = 1, 1
+    assert H.x264_param_apply_profile(C.byref(p), b"high") == 0
+    h_ = H.x264_encoder_open_157(C.byref(p))
+    assert h_
+    eff = HL.Param()
+    H.x264_encoder_parameters(h_, C.byref(eff))
+    assert eff.b_sliced_threads == 0 and eff.i_slice_count == slices and eff.i_threads == 1
+    nfr = 6
+    frames = synth_frames(w, h, nfr, seed=78 + w)
+    stream, info, recons = encode_all(h_, w, h, frames)
+    H.x264_encoder_close(h_)
+    for i, (_, _, _, types) in enumerate(info):
+        assert sum(1 for t in types if t in (1, 5)) == slices, (i, types)
+    dec = O.h264_decode(stream, nfr, w, h)
+    og = O.OracleEncoder(O.default_config(w, h, slices=slices, slices_plain=1, partitions=7, refs=3, dct8x8=1, chroma_me=1, mixed_refs=1, qp_i=max(0, opts["qp"] - 3), qp_p=opts["qp"], **eff_kw(eff)))
+    keyint = opts["keyint"]
+    for i, f in enumerate(frames):
+        np.testing.assert_array_equal(dec[i], recons[i], err_msg=f"decoded picture {i}")
+        og.encode(f, 2 if i % keyint == 0 else 0)
+        np.testing.assert_array_equal(og.recon(), recons[i], err_msg=f"oracle pipeline picture {i}")
+
+
 @pytest.mark.parametrize("w,h,opts,okw", [
     (1920, 1080, {"qp": 23, "keyint": 250, "no-scenecut": None}, dict(me_method=1)),                                              # BASELINE.json config 2 (headline size)
     (1280, 720, {"qp": 23, "keyint": 250, "no-scenecut": None}, dict(me_method=1)),                                               # config 1

@@ -32,6 +32,43 @@ def compare(tag, mbw, g_mb, o_mb, g_lv, o_lv, g_rec, o_rec):
         pytest.fail(f"{tag}: recon differs at {len(pos)} bytes, first offsets {pos[:8]}")
 
 
+@pytest.mark.parametrize("w,h,slices,kw", [
+    (352, 288, 18, dict(partitions=3, refs=2)),
+    (352, 288, 6, dict(partitions=7, dct8x8=1, refs=2, cabac=1, rd=1, subme=7, psy=1, psy_rd_q8=256, trellis=63)),
+    (640, 272, 17, dict(partitions=7, dct8x8=1, refs=3, mixed_refs=1, chroma_me=1, subme=5, cabac=1)),
+    (320, 400, 9, dict(rd=1, subme=6, partitions=3, qp_i=30, qp_p=33)),
+])
+def test_plain_slices_carry_the_intra_statistics(gpu, w, h, slices, kw):
+    """x264 codes the slices of --slices N one after the other and its fast-intra decision reads the picture's intra count so far; the device runs
+    the slices side by side on assumed counts and repeats those whose decisions hang on a wrong one.  Content with scene cuts and partial
+    changes puts intra macroblocks into P pictures, so that later slices do depend on earlier ones: same records as the serial oracle,
+    and the dependence is really there (the slice-threads oracle, which starts every slice's statistics at zero, decides differently)"""
+    from gpu_enc import GpuEncoder
+    nfr = 6
+    frames = synth_frames(w, h, nfr, seed=w + 3 * h, scene_len=2)
+    rng = np.random.default_rng(w * h)
+    for i in range(1, nfr):                                   # a few fresh patches per picture: intra macroblocks scattered over the slices
+        f = frames[i] = frames[i].copy()
+        Y = f[:w * h].reshape(h, w)
+        for _ in range(6):
+            y0, x0 = int(rng.integers(0, h - 32)), int(rng.integers(0, w - 48))
+            Y[y0:y0 + 32, x0:x0 + 48] = rng.integers(0, 256, (32, 48), dtype=np.uint8)
+    cfg = O.default_config(w, h, slices=slices, slices_plain=1, **kw)
+    og, gg = O.OracleEncoder(cfg), GpuEncoder(cfg)
+    other = O.OracleEncoder(O.default_config(w, h, slices=slices, **kw)) if slices <= (h + 15) // 16 // 4 else None
+    differs = False
+    for i, f in enumerate(frames):
+        st = 2 if i == 0 else 0
+        o_mb, o_lv = og.encode(f, st)
+        g_mb, g_lv = gg.encode([f], st)
+        compare(f"{w}x{h} {kw} frame {i}", (w + 15) // 16, g_mb[0], o_mb, g_lv[0], o_lv, gg.recon(0), og.recon())
+        if other is not None:
+            t_mb, _ = other.encode(f, st)
+            differs |= not np.array_equal(t_mb["type"], o_mb["type"])
+    assert other is None or differs
+    og.close(); gg.close()
+
+
 @pytest.mark.parametrize("w,h,nfr,kw", [
     (64, 48, 4, {}),
     (176, 144, 5, {}),
@@ -99,6 +136,9 @@ def compare(tag, mbw, g_mb, o_mb, g_lv, o_lv, g_rec, o_rec):
     (64, 272, 4, dict(slices=4, aq_mode=1, partitions=7, dct8x8=1, qp_i=30, qp_p=34)),
     (352, 288, 4, dict(slices=4, me_method=2, partitions=3, refs=2)),
     (48, 336, 4, dict(slices=5, partitions=3, refs=2, qp_i=12, qp_p=15, dct_decimate=0, me_method=3, me_range=8)),
+    (176, 144, 4, dict(slices=9, slices_plain=1, partitions=3, refs=2)),     # x264 --slices N: the same split down to one macroblock row, the loop filter crosses the boundaries
+    (96, 208, 5, dict(slices=5, slices_plain=1, partitions=7, dct8x8=1, refs=3, mixed_refs=1, chroma_me=1, subme=5, cabac=1)),
+    (64, 272, 4, dict(slices=17, slices_plain=1, aq_mode=1, partitions=7, dct8x8=1, qp_i=30, qp_p=34)),
     (64, 48, 3, dict(rd=1, subme=6, partitions=0)),                          # RD mode decision (x264 subme 6 / 7, CAVLC bit counts): I16x16 / P16x16 / skip only
     (176, 144, 4, dict(rd=1, subme=6, partitions=2)),                        # + Intra_4x4
     (176, 144, 4, dict(rd=1, subme=6, partitions=1)),                        # + P16x8 / P8x16 / P8x8
@@ -149,6 +189,7 @@ CABAC_CTX_P = CABAC_CTX_I + list(range(11, 24)) + list(range(40, 60))
     (176, 144, 6, dict(partitions=7, dct8x8=1, refs=3, mixed_refs=1, chroma_me=1, psy=1, psy_rd_q8=256, chroma_qp_offset=-2, subme=7, trellis=63)),       # preset medium (I / P)
     (352, 288, 4, dict(partitions=7, dct8x8=1, refs=3, mixed_refs=1, chroma_me=1, qp_i=30, qp_p=34, me_method=2, subme=7, trellis=63)),
     (96, 208, 4, dict(slices=3, partitions=7, dct8x8=1, refs=2, aq_mode=1, subme=6, trellis=63)),
+    (96, 208, 4, dict(slices=13, slices_plain=1, partitions=7, dct8x8=1, refs=2, aq_mode=1, subme=7, psy=1, psy_rd_q8=256, trellis=63)),       # --slices 13 (one row each)
     (96, 80, 4, dict(partitions=7, dct8x8=1, qp_i=8, qp_p=10, dct_decimate=0, fast_pskip=0, subme=6, trellis=63)),
     (208, 120, 4, dict(partitions=7, dct8x8=1, qp_i=44, qp_p=47, subme=6, trellis=63)),
     # --trellis 2 (+ 64): the search also inside the intra analysis' block encodes and in every RD candidate

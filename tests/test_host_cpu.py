@@ -176,6 +176,39 @@ def test_sliced_pictures_closed_loop(w, h, slices, kw, cabac):
         np.testing.assert_array_equal(dec[i], recons[i], err_msg=f"picture {i}")
 
 
+@pytest.mark.parametrize("cabac", [0, 1])
+@pytest.mark.parametrize("w,h,slices,kw", [(176, 144, 9, dict(partitions=3, refs=2)), (96, 208, 5, dict(partitions=7, dct8x8=1, refs=3, mixed_refs=1, chroma_me=1, subme=5)),
+                                          (64, 272, 17, dict(aq_mode=1, partitions=7, dct8x8=1, qp_i=30, qp_p=34)), (208, 128, 3, dict(qp_i=34, qp_p=38, subme=2))])
+def test_plain_slices_closed_loop(w, h, slices, kw, cabac):
+    """x264's --slices N (slices_plain): the split of slice threads, down to one macroblock row per slice, but the loop filter crosses the slice
+    boundaries (disable_deblocking_filter_idc 0) and the intra statistics run on through the picture: oracle records -> host writers ->
+    checker decoder == oracle reconstruction; an I picture differs from the slice-thread one exactly by that filtering"""
+    nfr = 4
+    frames = synth_frames(w, h, nfr, seed=5 * w + h)
+    cfg = O.default_config(w, h, slices=slices, slices_plain=1, **kw)
+    enc = O.OracleEncoder(cfg)
+    mbw, mbh = (w + 15) // 16, (h + 15) // 16
+    thr = O.OracleEncoder(O.default_config(w, h, slices=slices, **kw)) if slices <= mbh // 4 else None
+    stream = HL.write_headers(w, h, pic_init_qp=cfg.qp_p, num_ref=cfg.refs, t8x8=cfg.dct8x8, cabac=cabac)
+    recons = []
+    for i, f in enumerate(frames):
+        idr = i == 0
+        mbs, lv = enc.encode(f, 2 if idr else 0)
+        s, _ = HL.write_slice(mbw, mbh, 2 if idr else 0, cfg.qp_i if idr else cfg.qp_p, cfg.qp_p, i, 8, int(idr), 0,
+                              0, mbs, lv, num_ref=max(1, min(cfg.refs, i)), num_ref_default=cfg.refs, t8x8=cfg.dct8x8, cabac=cabac, slices=-slices)
+        assert s.count(b"\x00\x00\x01") >= slices
+        stream += s
+        recons.append(enc.recon())
+        if thr is not None and idr:
+            m2, _ = thr.encode(f, 2)
+            np.testing.assert_array_equal(mbs.view(np.uint8), m2.view(np.uint8))        # the first picture's decisions do not see the filter ...
+            assert not np.array_equal(thr.recon(), recons[0])                           # ... its reconstruction does
+    dec = O.h264_decode(stream, nfr, w, h)
+    assert len(dec) == nfr
+    for i in range(nfr):
+        np.testing.assert_array_equal(dec[i], recons[i], err_msg=f"picture {i}")
+
+
 def test_cavlc_static_sequence_uses_skip():
     w, h = 96, 64
     f = synth_frames(w, h, 1, seed=5)[0]

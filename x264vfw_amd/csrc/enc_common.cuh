@@ -59,9 +59,15 @@ struct EncK {
     int fast_pskip, mv_range;
     int rd, psy, psy_rd_q8;   // RD mode decision (subme 6 / 7 of a CAVLC session), b_psy, FIX8(psy-rd strength)
     uint8_t *tc, *amvd; uint32_t *cab_out;
+    // --slices N (slices_plain), P pictures: x264 codes the slices one after the other and its fast-intra decision reads the number of intra
+    // macroblocks of the picture so far.  The slices run side by side here on an ASSUMED count of the slices before them (sl_stat[..][3]) and
+    // report their own count plus the window of counts [hi, lo) for which every decision they took stays what it is ([0], [1], [2]); slices
+    // whose window misses the real sum run again (sl_rerun), until none does (k_slice_priors, encoder.hip)
+    int *sl_stat, *sl_rerun; int sl_pass;
     int trellis; const uint16_t *tr_su; const uint8_t *tr_tu; const int *tr_l2;      // trellis sites of the final encode (mask) + x264_rdo_init's tables              // RD: [streams][nmb][24] total_coeff of every block of the picture being coded (nC of the bit counts)
     int cabac;                // the session's entropy coder is CABAC: P8x8 cost details of x264's analysis depend on it
     int slices;               // x264 slice threads: slices per picture (rows split evenly), 1 = one
+    int slices_plain;         // x264 --slices N rather than slice threads: the loop filter crosses slice boundaries
     unsigned long long *prof; // MB_PROF builds only: [streams][16] cycle counters of the macroblock loop's phases (null otherwise)
 };
 // the slice quantiser of stream s
@@ -87,6 +93,8 @@ __device__ __forceinline__ bool slice_starts_at_row(const EncK &k, int mby)
     for (int sl = 1; sl < k.slices; sl++) if ((k.mbh * sl + k.slices / 2) / k.slices == mby) return true;
     return false;
 }
+// the loop filter leaves the top edge of row mby alone: slice threads code disable_deblocking_filter_idc 2, plain --slices N code 0
+__device__ __forceinline__ bool filter_stops_at_row(const EncK &k, int mby) { return !k.slices_plain && slice_starts_at_row(k, mby); }
 __device__ __forceinline__ int ref_bits(int nref, int r) { return nref <= 1 ? 0 : nref == 2 ? 1 : 2 * (31 - __builtin_clz(r + 1)) + 1; }
 __device__ __forceinline__ uint8_t *rec_chroma00(const EncK &k, int s)
 {

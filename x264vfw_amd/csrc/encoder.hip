@@ -45,6 +45,7 @@ struct x264gpu_encoder {
     uint8_t *tc = nullptr;               // RD: total_coeff of every block of the picture being coded
     uint8_t *amvd = nullptr;             // CABAC RD: |mvd| of every 8x8 block of the picture being coded
     uint32_t *cab_out = nullptr;         // ... and the context variables every slice's wavefront ended with: [stream][slice][3][64] (tests; layout: cabac_rd.cuh cab_locate)
+    int *sl_stat = nullptr, *sl_rerun = nullptr;     // --slices N: per (stream, slice) intra statistics of the speculative slice passes (EncK.sl_stat)
     unsigned long long *prof = nullptr;  // MB_PROF builds: phase counters of the last macroblock-loop launch
     int *wf_progress = nullptr;          // [streams][2][WFG_ROWS] row counters of the multi-workgroup wavefront kernels
     // adaptive quantisation: per-macroblock quantisers and the per-quantiser tables (built when aq_mode != 0)
@@ -104,7 +105,8 @@ int x264gpu_encoder_create(x264gpu_encoder **out, const x264gpu_config *cfg)
     ARG_TRY(cfg->qp_i >= 0 && cfg->qp_i <= 51 && cfg->qp_p >= 0 && cfg->qp_p <= 51 && cfg->refs >= 1 && cfg->refs <= 5);
     ARG_TRY(cfg->trellis == 0 || (cfg->trellis > 0 && cfg->trellis < 128 && (cfg->trellis & 63) && cfg->rd && cfg->cabac));      // trellis sites (mask; x264 --trellis 1 = 63, --trellis 2 = 63 + 64): RD sessions with CABAC
     ARG_TRY(!cfg->rd || (cfg->subme >= 6 && cfg->subme <= 7 && cfg->psy_rd_q8 >= 0 && cfg->psy_rd_q8 <= 2560));      // RD: x264's i_mbrd 1 (bit counts of the session's entropy coder)
-    ARG_TRY(cfg->slices >= 0 && (cfg->slices <= 1 || cfg->slices <= (cfg->height + 15) / 16 / 4));      // x264 slice threads: at least four macroblock rows each
+    ARG_TRY(cfg->slices >= 0 && (cfg->slices <= 1 || cfg->slices <= (cfg->height + 15) / 16 / (cfg->slices_plain ? 1 : 4)));      // x264 slice threads: at least four macroblock rows each; --slices N: one
+    ARG_TRY(cfg->slices_plain == 0 || cfg->slices_plain == 1);
     ARG_TRY(cfg->width <= 4096 && cfg->height <= 2304 && cfg->me_range >= 4 && cfg->me_range <= (cfg->me_method == 2 ? 64 : 16));
     ARG_TRY(cfg->me_method >= 0 && cfg->me_method <= 3);
     x264gpu_encoder *e = new (std::nothrow) x264gpu_encoder();
@@ -123,7 +125,7 @@ int x264gpu_encoder_create(x264gpu_encoder **out, const x264gpu_config *cfg)
     k.luma_bytes = 4 * k.plane_bytes;
     k.cplane_bytes = (size_t)k.rs * (k.ch / 2 + 2 * CPAD);
     k.me_range = cfg->me_range; k.subme = cfg->subme; k.dct_decimate = cfg->dct_decimate;
-    k.slices = cfg->slices > 1 ? cfg->slices : 1; k.cabac = cfg->cabac != 0;
+    k.slices = cfg->slices > 1 ? cfg->slices : 1; k.slices_plain = cfg->slices_plain != 0; k.cabac = cfg->cabac != 0;
     k.rd = cfg->rd != 0; k.psy = cfg->psy != 0; k.psy_rd_q8 = cfg->psy_rd_q8;
     k.partitions = cfg->partitions; k.chroma_qp_offset = cfg->chroma_qp_offset; k.dct8x8 = cfg->dct8x8; k.me_method = cfg->me_method; k.chroma_me = cfg->chroma_me != 0; k.mixed_refs = cfg->mixed_refs != 0;
     k.alpha_off = cfg->deblock_alpha * 2; k.beta_off = cfg->deblock_beta * 2;
@@ -149,6 +151,7 @@ int x264gpu_encoder_create(x264gpu_encoder **out, const x264gpu_config *cfg)
     alloc((void **)&e->wf_progress, S * 2 * WFG_ROWS * sizeof(int), 0);
     if (cfg->rd && !cfg->cabac) alloc((void **)&e->tc, S * k.nmb * 24, 0);
     if (cfg->rd && cfg->cabac) { alloc((void **)&e->amvd, S * k.nmb * 8, 0); alloc((void **)&e->cab_out, S * (cfg->slices > 1 ? cfg->slices : 1) * 192 * sizeof(uint32_t), 0); }
+    if (cfg->slices_plain && cfg->slices > 1) { alloc((void **)&e->sl_stat, S * cfg->slices * 4 * sizeof(int), 0); alloc((void **)&e->sl_rerun, S * cfg->slices * sizeof(int), 0); }
 #ifdef MB_PROF
     alloc((void **)&e->prof, S * 16 * sizeof(unsigned long long), 0);
 #endif
@@ -235,6 +238,7 @@ void x264gpu_encoder_destroy(x264gpu_encoder *e)
     (void)hipFree(e->tc);
     (void)hipFree(e->amvd);
     (void)hipFree(e->cab_out);
+    (void)hipFree(e->sl_stat); (void)hipFree(e->sl_rerun);
     (void)hipFree(e->prof);
     (void)hipFree(e->stream_qp); (void)hipFree(e->mbqp); (void)hipFree(e->q4tab); (void)hipFree(e->q8tab); (void)hipFree(e->lambda_tab); (void)hipFree(e->cost_all);
     delete e;
@@ -273,6 +277,24 @@ int x264gpu_encoder_cabac_states(x264gpu_encoder *e, int stream, int slice, uint
 
 int x264gpu_encoder_set_lowres_mvs(x264gpu_encoder *e, const int16_t *d_mvs) { ARG_TRY(e); e->lowres_mv = d_mvs; return X264GPU_OK; }
 
+// --slices N in P pictures (EncK.sl_stat): with the intra counts the slices reported, does every slice's window of harmless prior counts hold the
+// sum of the counts before it?  A slice whose window misses runs again on the sum as it stands now.  One thread per stream.
+// guess: before the first pass — the counts of the P picture before this one are the assumption (any assumption gives the same result;
+// a good one saves passes).
+__global__ void k_slice_priors(EncK k, int streams, int guess)
+{
+    const int s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= streams) return;
+    int sum = 0;
+    for (int sl = 0; sl < k.slices; sl++) {
+        int *st = k.sl_stat + ((size_t)s * k.slices + sl) * 4;
+        const bool again = guess || !(st[1] <= sum && sum < st[2]);
+        k.sl_rerun[(size_t)s * k.slices + sl] = again;
+        if (again) st[3] = sum;
+        sum += st[0];
+    }
+}
+
 int x264gpu_encode_frames(x264gpu_encoder *e, const uint8_t *d_i420, int slice_type, x264gpu_mb *d_mb,
                           int16_t *d_levels, void *stream)
 {
@@ -306,6 +328,7 @@ int x264gpu_encode_frames(x264gpu_encoder *e, const uint8_t *d_i420, int slice_t
     }
     e->slot_nref[e->cur] = k.nref; e->slot_poc[e->cur] = e->poc; e->slot_ref0poc[e->cur] = k.nref ? e->slot_poc[s0] : 0;
     k.prof = e->prof; k.tc = e->tc; k.amvd = e->amvd; k.cab_out = e->cab_out;
+    k.sl_stat = slice_type == X264GPU_SLICE_P ? e->sl_stat : nullptr; k.sl_rerun = e->sl_rerun; k.sl_pass = 0;
     k.trellis = e->cfg.trellis; k.tr_su = nullptr; k.tr_tu = nullptr; k.tr_l2 = nullptr;
     if (k.trellis) { const int rc = trellis_table_ptrs(&k.tr_su, &k.tr_tu, &k.tr_l2); if (rc != X264GPU_OK) return rc; }
     k.lowres_mv = e->lowres_mv; k.fast_pskip = e->cfg.fast_pskip; k.mv_range = e->cfg.mv_range;
@@ -331,7 +354,20 @@ int x264gpu_encode_frames(x264gpu_encoder *e, const uint8_t *d_i420, int slice_t
     STAGE_MARK(1);
     // the macroblock loop: one wavefront per stream, raster order (sub-pel neighbourhood margin 2 px up to subme 7, 5 px above)
     if (slice_type == X264GPU_SLICE_I) launch_mb_slice_intra(k, S, st);        // (RD instantiations inside, chosen by k.rd)
-    else (k.me_method == 0 ? launch_mb_slice_dia : k.me_method == 2 ? launch_mb_slice_umh : k.me_method == 3 ? launch_mb_slice_esa : launch_mb_slice_hex)(k, S, k.subme >= 8, st);
+    else {
+        const auto launch = k.me_method == 0 ? launch_mb_slice_dia : k.me_method == 2 ? launch_mb_slice_umh : k.me_method == 3 ? launch_mb_slice_esa : launch_mb_slice_hex;
+        if (k.sl_stat) hipLaunchKernelGGL(k_slice_priors, dim3((S + 63) / 64), dim3(64), 0, st, k, S, 1);
+        launch(k, S, k.subme >= 8, st);
+        // --slices N: slice i is final once slices 0..i-1 are, so slices - 1 rounds of "check the assumed counts, run the slices again whose
+        // decisions hang on a wrong one" always end at x264's serial result; a round in which nothing is flagged costs two empty launches
+        if (k.sl_stat)
+            for (int pass = 1; pass < k.slices; pass++) {
+                hipLaunchKernelGGL(k_slice_priors, dim3((S + 63) / 64), dim3(64), 0, st, k, S, 0);
+                k.sl_pass = pass;
+                launch(k, S, k.subme >= 8, st);
+            }
+        k.sl_pass = 0;
+    }
     mask |= 2;
     STAGE_MARK(2);
     STAGE_MARK(3);

@@ -145,8 +145,8 @@ __device__ void deblock_mb_pair(const EncK &k, Deblock2Lds &L, int wave, int lan
     bool work = false;
     {
         const int dir = l32 >> 4, edge = (l32 >> 2) & 3, seg = l32 & 3;
-        // with several slices per picture the filter stops at slice boundaries (disable_deblocking_filter_idc 2, as x264's slice threads code it)
-        const bool skip_edge = ((edge & 1) && Q->transform8x8) || (edge == 0 && (dir == 0 ? cmbx == 0 : (cmby == 0 || slice_starts_at_row(k, cmby))));
+        // under slice threads the filter stops at slice boundaries (disable_deblocking_filter_idc 2, as x264 codes them); plain --slices N: it does not
+        const bool skip_edge = ((edge & 1) && Q->transform8x8) || (edge == 0 && (dir == 0 ? cmbx == 0 : (cmby == 0 || filter_stops_at_row(k, cmby))));
         bool any = false;
         if (act && !skip_edge) {
             const x264gpu_mb *P = edge == 0 ? &L.rec[wave][hf][dir == 0 ? 1 : 2] : Q;
@@ -165,7 +165,7 @@ __device__ void deblock_mb_pair(const EncK &k, Deblock2Lds &L, int wave, int lan
             bool go = work && !((edge & 1) && Q->transform8x8);
             if (edge == 0) {
                 if (dir == 0) { go = go && cmbx != 0; P = &L.rec[wave][hf][1]; }
-                else { go = go && cmby != 0 && !slice_starts_at_row(k, cmby); P = &L.rec[wave][hf][2]; }
+                else { go = go && cmby != 0 && !filter_stops_at_row(k, cmby); P = &L.rec[wave][hf][2]; }
             }
             if (__any(go)) {
                 const int qpp = P->qp;

@@ -53,6 +53,7 @@ template <int M> struct MbLds {
     __attribute__((aligned(16))) x264gpu_mb rec;   // the record being built (lane 0 fills it, 16 lanes store it)
     // search state
     int16_t cand[16][2];                       // filtered start candidates of the search in progress
+    int slw[3];                                // --slices N in P pictures (EncK.sl_stat): window [0], [1]) of harmless prior intra counts, [2] the assumed one
 };
 
 struct MbCtx {
@@ -1297,6 +1298,15 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(MB_WAVES_PER
     // x264 slice threads: blockIdx.y = slice of the picture, macroblock rows [row0, row1) (k.slices == 1: the whole picture)
     const int nsl = k.slices > 1 ? k.slices : 1, row0 = (k.mbh * (int)blockIdx.y + nsl / 2) / nsl, row1 = (k.mbh * ((int)blockIdx.y + 1) + nsl / 2) / nsl;
     const int mb_first = row0 * k.mbw, mb_end = row1 * k.mbw;
+    // --slices N in P pictures: the intra count of the slices before this one as assumed for this pass, and the window of counts that leave
+    // every fast-intra decision of the slice as taken (EncK.sl_stat)
+    int intra_prior = 0;
+    if (PS && k.sl_stat) {
+        const size_t si = (size_t)s * nsl + blockIdx.y;
+        if (k.sl_pass && !k.sl_rerun[si]) return;
+        intra_prior = uni(k.sl_stat[si * 4 + 3]);
+        if (lane == 0) { L.slw[0] = 0; L.slw[1] = 0x7fffffff; L.slw[2] = intra_prior; }
+    }
     const uint32_t t4 = (lane >> 2) < 9 ? ((const uint32_t *)c_pred4_table.t)[lane] : 0x01010101u * U_DC;
     for (int i = lane; i < 144; i += 64) ((uint32_t *)L.pred8tab)[i] = ((const uint32_t *)c_pred8_table)[i];
     lds_sync();
@@ -1305,7 +1315,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(MB_WAVES_PER
     constexpr bool TRL = RD >= 3;               // trellis sites compiled in
     constexpr bool TRL2 = RD == 4;              // --trellis 2: the search also inside the intra analysis and in every RD candidate                 // I slices run their own instantiation (no search code, a fraction of the registers)
     const int j4 = lane & 3, zx = z_x0(lane), zy = z_y(lane);
-    int intra_count = 0, cost_qp = -1;
+    int intra_count = intra_prior, cost_qp = -1;          // intra macroblocks so far: of the slice (slice threads), of the picture (--slices N)
     // RD instantiation: levels of the candidate being costed (and of the final macroblock, before they go out), total_coeff of the left / top
     // macroblocks' blocks for the nC of the bit counts; the quantiser the previous coded macroblock left (mb_qp_delta bits)
     __shared__ __attribute__((aligned(16))) int16_t rd_lvs[RD ? X264GPU_MB_LEVELS : 1];
@@ -1457,7 +1467,12 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(MB_WAVES_PER
             // ---- fast intra decision, skip vector, fast skip ----
             if (early_term && mbi - mb_first > 4) {
                 const int colo = uni((int)k.mbtype_ref0[(size_t)s * k.nmb + mbi]);
-                fast_intra = !(intra_t(type_left) || intra_t(type_top) || intra_t(type_tl) || intra_t(type_tr) || intra_t(colo) || mbi - mb_first < 3 * intra_count);
+                const bool near_intra = intra_t(type_left) || intra_t(type_top) || intra_t(type_tl) || intra_t(type_tr) || intra_t(colo);
+                fast_intra = !(near_intra || mbi - mb_first < 3 * intra_count);
+                if (k.sl_stat && !near_intra && lane == 0) {
+                    const int prior = L.slw[2], need = (mbi - mb_first) / 3 + 1 - (intra_count - prior);      // the smallest prior count that makes "a third so far are intra" true
+                    if (prior >= need) L.slw[0] = max(L.slw[0], need); else L.slw[1] = min(L.slw[1], need);
+                }
             }
             {
                 const int ra = rl(S.cref, 4), rb = rl(S.cref, 1);
@@ -2256,6 +2271,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(MB_WAVES_PER
         __builtin_amdgcn_s_waitcnt(0);
         pf.mark(PH_STORE);
     }
+    if (PS && k.sl_stat && lane == 0) { int *st = k.sl_stat + ((size_t)s * nsl + blockIdx.y) * 4; st[0] = intra_count - L.slw[2]; st[1] = L.slw[0]; st[2] = L.slw[1]; }
     if constexpr (RD >= 2) {
         if (k.cab_out) { uint32_t *o = k.cab_out + ((size_t)s * (k.slices > 1 ? k.slices : 1) + blockIdx.y) * 192; o[lane] = cab.a; o[64 + lane] = cab.r; o[128 + lane] = cab.r8; }
     }

@@ -84,6 +84,7 @@ struct x264_t {
     //      the bytes equal the serial encode's (tests/test_gpu_host.py::test_gop_parallel_equals_serial).
     int G = 1;
     int slices = 1;               // x264 slice threads: slices per picture (own wavefront + own NAL each)
+    int slices_plain = 0;         // ... or x264 --slices N: the same split, filtered across the boundaries, up to one slice per macroblock row
     // The G slots are dealt to the visible devices (slot s -> device s % D, its local slot s / D): every device runs its slots in lock-step
     // with its own encoder, ring and download buffers, issued by one host thread per device; closed GOPs are independent, so there is no
     // exchange between devices and the frames still leave in stream order (north star: "frames of one stream shard one-per-GPU").
@@ -245,8 +246,6 @@ x264_t *x264_encoder_open(x264_param_t *param)
     p.analyse.b_fast_pskip = p.analyse.b_fast_pskip != 0;
     p.analyse.b_chroma_me = p.analyse.b_chroma_me != 0;
     if (p.b_interlaced) { xlog(&p, X264_LOG_WARNING, "interlaced coding is not implemented in the MI355X path: progressive\n"); p.b_interlaced = 0; }
-    if (p.i_slice_count > 1) xlog(&p, X264_LOG_WARNING, "slices %d: only slice threads (--sliced-threads --threads N) split pictures in the MI355X path: slices 1\n", p.i_slice_count);
-    p.i_slice_count = 1;
     if (p.b_constrained_intra) { xlog(&p, X264_LOG_WARNING, "constrained-intra is not implemented in the MI355X path: off\n"); p.b_constrained_intra = 0; }
     if (p.b_intra_refresh) { xlog(&p, X264_LOG_WARNING, "intra-refresh is not implemented in the MI355X path: off\n"); p.b_intra_refresh = 0; }
     if (p.i_nal_hrd) { xlog(&p, X264_LOG_WARNING, "nal-hrd needs VBV, which is not implemented in the MI355X path: none\n"); p.i_nal_hrd = 0; }
@@ -262,7 +261,17 @@ x264_t *x264_encoder_open(x264_param_t *param)
         // x264 has no word for "slice threads AND several GOPs in flight"; this library can do both (slices x GOP slots wavefronts per stream).
         // X264GPU_GOP_SLOTS=G asks for it: the --threads G mode below (fixed keyint, delay (G-1) x keyint) with every picture in slices
         if (const char *gs = getenv("X264GPU_GOP_SLOTS")) { const int g = atoi(gs); if (g > 1) p.i_threads = g; }
+        if (p.i_slice_count > 1) xlog(&p, X264_LOG_INFO, "slices %d ignored under slice threads (%d slices)\n", p.i_slice_count, h->slices);
+        if (h->slices > 1) p.i_slice_count = 0;
     }
+    // --slices N (x264 slices_write: slice i ends at macroblock row (mbh * (i + 1) + N / 2) / N, the split slice threads use too; validate_parameters
+    // clips N to the macroblock rows): every slice a wavefront of its own here, which is what makes one stream faster without any delay.
+    // Unlike slice threads the loop filter crosses the boundaries (disable_deblocking_filter_idc 0).
+    if (!p.b_sliced_threads && p.i_slice_count > 1) {
+        const int mbh = (p.i_height + 15) / 16;
+        p.i_slice_count = p.i_slice_count < mbh ? p.i_slice_count : mbh;
+        h->slices = p.i_slice_count; h->slices_plain = h->slices > 1;
+    } else if (!p.b_sliced_threads) p.i_slice_count = 0;
     p.i_threads = clampi(p.i_threads, 1, 256);                 // --threads G: GOPs coded in lock-step (1 = no delay)
     if (p.i_keyint_max <= 0) p.i_keyint_max = 1;
     h->keyint = p.i_keyint_max;
@@ -309,7 +318,7 @@ x264_t *x264_encoder_open(x264_param_t *param)
         if (h->G != p.i_threads) xlog(&p, X264_LOG_INFO, "threads %d -> %d (GOP ring of keyint %d pictures)\n", p.i_threads, h->G, h->keyint);
         p.i_threads = h->G;
     }
-    cfg.width = p.i_width; cfg.height = p.i_height; cfg.streams = h->G; cfg.refs = p.i_frame_reference; cfg.slices = h->slices; cfg.cabac = p.b_cabac;
+    cfg.width = p.i_width; cfg.height = p.i_height; cfg.streams = h->G; cfg.refs = p.i_frame_reference; cfg.slices = h->slices; cfg.slices_plain = h->slices_plain; cfg.cabac = p.b_cabac;
     cfg.qp_i = h->qp_i; cfg.qp_p = h->qp_p; cfg.me_range = p.analyse.i_me_range; cfg.subme = p.analyse.i_subpel_refine;
     cfg.deblock = p.b_deblocking_filter; cfg.deblock_alpha = p.i_deblocking_filter_alphac0; cfg.deblock_beta = p.i_deblocking_filter_beta;
     cfg.chroma_qp_offset = eff_chroma_qp_offset;
@@ -443,7 +452,7 @@ void x264_encoder_parameters(x264_t *h, x264_param_t *param)
 {
     if (!h || !param) return;
     *param = h->param;
-    if (h->slices > 1 && h->G <= 1) param->i_threads = h->slices;      // slice threads: i_threads is the slice count, as in x264
+    if (h->slices > 1 && !h->slices_plain && h->G <= 1) param->i_threads = h->slices;      // slice threads: i_threads is the slice count, as in x264
 }
 
 static void publish_nals(x264_t *h, x264_nal_t **pp_nal, int *pi_nal, const std::vector<int> &types)
@@ -556,7 +565,7 @@ static int code_position(x264_t *h, int batch, int t, int nslots_with_t)
         sp.idr = c.idr; sp.idr_pic_id = (int)(gop & 0xffff); sp.nal_ref_idc = c.idr ? 3 : 2; sp.pps_id = p.i_sps_id;
         sp.num_ref_default = p.i_frame_reference;
         sp.num_ref = t < p.i_frame_reference ? (t > 0 ? t : 1) : p.i_frame_reference;
-        sp.disable_deblock_idc = p.b_deblocking_filter ? 0 : 1;
+        sp.disable_deblock_idc = p.b_deblocking_filter ? 0 : 1; sp.slices_plain = h->slices_plain;
         sp.alpha_off_div2 = p.i_deblocking_filter_alphac0; sp.beta_off_div2 = p.i_deblocking_filter_beta;
         sp.transform8x8_mode = p.analyse.b_transform_8x8; sp.cabac = p.b_cabac;
         {
@@ -801,7 +810,7 @@ static int encode_queued(x264_t *h, x264_nal_t **pp_nal, int *pi_nal, x264_pictu
     sp.idr = idr; sp.idr_pic_id = h->idr_pic_id; sp.nal_ref_idc = idr ? 3 : 2; sp.pps_id = p.i_sps_id;
     sp.num_ref_default = p.i_frame_reference;
     sp.num_ref = h->frames_since_idr < p.i_frame_reference ? (h->frames_since_idr > 0 ? h->frames_since_idr : 1) : p.i_frame_reference;
-    sp.disable_deblock_idc = p.b_deblocking_filter ? 0 : 1;
+    sp.disable_deblock_idc = p.b_deblocking_filter ? 0 : 1; sp.slices_plain = h->slices_plain;
     sp.alpha_off_div2 = p.i_deblocking_filter_alphac0; sp.beta_off_div2 = p.i_deblocking_filter_beta;
     sp.transform8x8_mode = p.analyse.b_transform_8x8; sp.cabac = p.b_cabac;
     h->last_stats.skip = 0;
@@ -969,6 +978,8 @@ int x264host_write_picture(int mbw, int mbh, int slice_type, int qp, int pic_ini
     sp.log2_max_frame_num = log2_max_frame_num; sp.idr = idr; sp.idr_pic_id = idr_pic_id; sp.nal_ref_idc = idr ? 3 : 2;
     sp.num_ref = num_ref; sp.num_ref_default = num_ref_default;
     sp.disable_deblock_idc = disable_deblock_idc; sp.transform8x8_mode = transform8x8_mode; sp.cabac = cabac;
+    sp.slices_plain = slices < 0;                 // -N: N slices as x264's --slices N codes them (filtered across), N: as its slice threads do
+    if (slices < 0) slices = -slices;
     std::vector<uint8_t> v;
     SliceStats stt = { 0 };
     write_picture(v, nullptr, sp, slices, mbs, levels, true, true, &stt, 4);

@@ -19,6 +19,7 @@ struct SliceParams {
     int disable_deblock_idc, alpha_off_div2, beta_off_div2;
     int transform8x8_mode;   // PPS transform_8x8_mode_flag
     int cabac;               // PPS entropy_coding_mode_flag: CABAC slice data (cabac_init_idc 0), else CAVLC
+    int slices_plain = 0;    // several slices per picture are x264's --slices N (the loop filter crosses their boundaries: idc stays 0) rather than slice threads (idc 2)
     int first_row = 0, end_row = 0;   // macroblock rows [first_row, end_row) of this slice (end_row 0 = mbh: one slice per picture); nothing
                              // above first_row is available to the slice's predictions (7.4.1.2.4 / 6.4.x availability)
 };

@@ -383,7 +383,7 @@ int slice_first_row(int mbh, int i, int n) { return (mbh * i + n / 2) / n; }
 
 // One picture as `slices` slices, each its own NAL unit (offs gets the offset of each in `out`); slices share nothing, so they are coded by
 // up to `threads` threads.  With more than one slice the loop filter stops at slice boundaries (disable_deblocking_filter_idc 2), as under
-// x264's slice threads.
+// x264's slice threads — unless p.slices_plain says they are --slices N slices, which x264 filters across (idc 0).
 void write_picture(std::vector<uint8_t> &out, std::vector<size_t> *offs, const SliceParams &p, int slices, const x264gpu_mb *mbs, const int16_t *levels,
                    bool annexb, bool long_startcode_first, SliceStats *stats, int threads)
 {
@@ -394,7 +394,7 @@ void write_picture(std::vector<uint8_t> &out, std::vector<size_t> *offs, const S
     auto one = [&](int i) {
         SliceParams sp = p;
         sp.first_row = slice_first_row(p.mbh, i, n); sp.end_row = slice_first_row(p.mbh, i + 1, n);
-        if (sp.disable_deblock_idc == 0) sp.disable_deblock_idc = 2;
+        if (sp.disable_deblock_idc == 0 && !sp.slices_plain) sp.disable_deblock_idc = 2;
         write_slice(parts[(size_t)i], sp, mbs, levels, annexb, long_startcode_first && i == 0, &st[(size_t)i], 1);
     };
     int T = threads < 1 ? 1 : threads > n ? n : threads;

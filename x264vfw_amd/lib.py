@@ -42,7 +42,7 @@ class Config(C.Structure):
     _fields_ = [(n, C.c_int) for n in (
         "width", "height", "streams", "refs", "qp_i", "qp_p", "me_range", "subme", "deblock",
         "deblock_alpha", "deblock_beta", "chroma_qp_offset", "deadzone_inter", "deadzone_intra",
-        "dct_decimate", "partitions", "dct8x8", "me_method", "chroma_me", "mixed_refs", "aq_mode", "aq_strength_q8", "fast_pskip", "mv_range", "cabac", "rd", "psy", "psy_rd_q8", "slices", "trellis")]
+        "dct_decimate", "partitions", "dct8x8", "me_method", "chroma_me", "mixed_refs", "aq_mode", "aq_strength_q8", "fast_pskip", "mv_range", "cabac", "rd", "psy", "psy_rd_q8", "slices", "trellis", "slices_plain")]
 
 
 MB_LEVELS = 416
