@@ -320,12 +320,14 @@ def e2e_probe(args):
     fsg, kbsg = run(G * K * 2, ns, K, src, sliced=True, gop_slots=G)
     nr = (h + 15) // 16                             # x264 --slices N: down to one macroblock row per slice (filtered across the boundaries)
     fr, kbr = run(max(n1, 48), 1, 250, src, slices=nr)
+    frg, _ = run(G * K * 2, G, K, src, slices=nr)
     os.environ.pop("X264GPU_GOP_SLOTS", None)
     return {"what": "ONE 1920x1080 stream through x264_encoder_encode (host pictures in, Annex-B out: PCIe + host entropy coding included), CQP, preset medium as implemented",
             "threads1_fps": f1, "threads1_frames": n1, "threads1_kB_per_frame": kb1,
             "sliced_threads_fps": fs, "sliced_threads_slices": ns, "sliced_threads_delay_frames": 0, "sliced_threads_kB_per_frame": kbs,
             "sliced_threads_gop_slots32_fps": fsg, "sliced_threads_gop_slots32_delay_frames": (G - 1) * K + 1,
             "slices_per_row_fps": fr, "slices_per_row_slices": nr, "slices_per_row_delay_frames": 0, "slices_per_row_kB_per_frame": kbr,
+            "slices_per_row_threads32_fps": frg, "slices_per_row_threads32_delay_frames": (G - 1) * K + 1,
             "threads32_fps": fg, "threads32_frames": G * K, "threads32_keyint": K, "threads32_delay_frames": (G - 1) * K + 1, "threads32_kB_per_frame": kbg,
             "host_cores": os.cpu_count()}
 

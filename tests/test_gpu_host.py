@@ -668,6 +668,38 @@ def test_slice_threads_with_gop_slots(gpu, monkeypatch):
     assert got == nfr and stream == serial
 
 
+def test_plain_slices_with_gop_slots(gpu):
+    """--slices N --threads G: G closed GOPs in lock-step with every picture in N slices (N x G wavefronts of one stream; the slots keep their own
+    intra statistics for the repeated slice passes) — the bytes equal the --threads 1 session's, only the delay changes"""
+    w, h, nfr, keyint, G = 96, 272, 14, 3, 3
+    opts = {"qp": 27, "keyint": keyint, "min-keyint": keyint, "no-scenecut": None, "slices": 17}
+    frames = synth_frames(w, h, nfr, seed=4243, scene_len=3)
+    h1, e1 = open_encoder(w, h, opts, b"high")
+    serial, info1, _ = encode_all(h1, w, h, frames)
+    H.x264_encoder_close(h1)
+    assert all(sum(1 for t in types if t in (1, 5)) == 17 for _, _, _, types in info1)
+    hg, eff = open_encoder(w, h, dict(opts, threads=G), b"high")
+    assert eff.i_threads == G and eff.i_slice_count == 17 and eff.b_sliced_threads == 0
+    pic, out = HL.Picture(), HL.Picture()
+    assert H.x264_picture_alloc(C.byref(pic), HL.X264_CSP_I420, w, h) == 0
+    nal, n = C.POINTER(HL.Nal)(), C.c_int()
+    stream, got = b"", 0
+    for i, f in enumerate(frames):
+        C.memmove(pic.img.plane[0], f.ctypes.data, f.size)
+        pic.i_pts = i
+        size = H.x264_encoder_encode(hg, C.byref(nal), C.byref(n), C.byref(pic), C.byref(out))
+        assert size >= 0 and (size == 0 or i >= (G - 1) * keyint)
+        if size:
+            stream += C.string_at(nal[0].p_payload, size); got += 1
+    while H.x264_encoder_delayed_frames(hg):
+        size = H.x264_encoder_encode(hg, C.byref(nal), C.byref(n), None, C.byref(out))
+        assert size > 0
+        stream += C.string_at(nal[0].p_payload, size); got += 1
+    H.x264_encoder_close(hg)
+    H.x264_picture_clean(C.byref(pic))
+    assert got == nfr and stream == serial
+
+
 def test_access_unit_delimiters(gpu):
     """--aud: every access unit starts with a type-9 NAL whose primary_pic_type tells I from P (7.3.2.4); the rest of the stream is unchanged"""
     w, h, nfr = 96, 80, 5
