@@ -1,5 +1,7 @@
-"""Longer randomised parity soak than tests/test_gpu_fuzz.py runs per round: python tools/fuzz_soak.py SEED0 SEED1 [cases per seed] [rd | rdcabac | trellis].
+"""Longer randomised parity soak than tests/test_gpu_fuzz.py runs per round: python tools/fuzz_soak.py SEED0 SEED1 [cases per seed] [rd | rdcabac | trellis | slices].
 With "rd" / "rdcabac" every case runs with RD mode decision on (CAVLC / CABAC session, subme 6 / 7, random psy-RD strength).
+"slices": every case with x264 --slices N (slices_plain, 2 .. one per macroblock row) on content with scene cuts every few pictures, so that
+P pictures hold intra macroblocks and the repeated slice passes have work; a third of the cases with RD + CABAC + trellis.
 Every random case (tests/test_gpu_fuzz.py random_case) is encoded by the HIP pipeline and the oracle; mismatches are listed, not fatal."""
 import os
 import random
@@ -23,6 +25,7 @@ def main():
     rd = len(sys.argv) > 4 and sys.argv[4] in ("rd", "rdcabac", "trellis")
     rd_cabac = len(sys.argv) > 4 and sys.argv[4] in ("rdcabac", "trellis")
     trellis = len(sys.argv) > 4 and sys.argv[4] == "trellis"
+    plain = len(sys.argv) > 4 and sys.argv[4] == "slices"
     bad = total = 0
     t0 = time.time()
     for seed in range(s0, s1):
@@ -34,7 +37,15 @@ def main():
                 if trellis:
                     kw.update(trellis=rnd.choice([63, 63, 127, rnd.randint(1, 62), 64 + rnd.randint(1, 63)]))
                 kw.update(cabac=int(rd_cabac), rd=1, subme=rnd.choice([6, 7]), psy=psy, psy_rd_q8=rnd.choice([26, 102, 256, 512]) if psy else 0)
-            frames = synth_frames(w, h, nfr, seed=fseed)
+            scene_len = 97
+            if plain:
+                h = max(h, 32)
+                kw.update(slices=rnd.randint(2, (h + 15) // 16), slices_plain=1)
+                scene_len = rnd.choice([2, 3, 4, 97])
+                nfr = max(nfr, 4)
+                if rnd.random() < 0.33:
+                    kw.update(cabac=1, rd=1, subme=7, psy=1, psy_rd_q8=256, trellis=63)
+            frames = synth_frames(w, h, nfr, seed=fseed, scene_len=scene_len)
             cfg = O.default_config(w, h, **kw)
             og, gg = O.OracleEncoder(cfg), GpuEncoder(cfg)
             total += 1
