@@ -1,7 +1,5 @@
 set -u
-cd $GRAFT_REPO_ROOT
-make -s -C x264vfw_amd/csrc clean; make -s -C x264vfw_amd/csrc -j16 "EXTRA=-DMB_PROF" 2>&1 | grep -E "error" | head
-python tools/mb_prof.py 2048 4 2>&1 | tail -9 > gpurun_out/mb_prof.log
-make -s -C x264vfw_amd/csrc clean; make -s -C x264vfw_amd/csrc -j16 "EXTRA=-DMB_PROF -DMB_PROF_RD" 2>&1 | grep -E "error" | head
-python tools/mb_prof.py 2048 4 2>&1 | tail -9 >> gpurun_out/mb_prof.log
-cat gpurun_out/mb_prof.log
+cd /tmp; export TMPDIR=/tmp
+rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/p_b1 -- python3 $GRAFT_REPO_ROOT/tools/bench_b1.py 24 1 250 qp slices=68 > $GRAFT_REPO_ROOT/gpurun_out/b1_slices.log 2>&1
+tail -3 $GRAFT_REPO_ROOT/gpurun_out/b1_slices.log
+head -14 $(ls /tmp/p_b1/*/*kernel_stats.csv | head -1) | cut -c1-150

@@ -29,6 +29,9 @@ def main():
     p.i_fps_num, p.i_fps_den, p.i_log_level = 25, 1, -1
     for k, v in ((("qp", "23") if rc == "qp" else ("crf", "23")), ("keyint", str(keyint)), ("threads", str(threads))):
         assert H.x264_param_parse(C.byref(p), k.encode(), v.encode()) == 0
+    for kv in sys.argv[5:]:                                             # further x264 options: slices=68, sliced-threads, ...
+        k, _, v = kv.partition("=")
+        assert H.x264_param_parse(C.byref(p), k.encode(), v.encode() if v else None) == 0, kv
     p.b_annexb, p.b_repeat_headers = 1, 1
     h_ = H.x264_encoder_open_157(C.byref(p))
     assert h_
