@@ -358,6 +358,20 @@ __device__ __forceinline__ void me_search(const EncK &k, MbLds<M> &L, const MbCt
             if (rowok) sd = w16 ? sad_row16_lds(wrow, xo, e) : sad8_lds(wrow, xo, e[0], e[1]);
             return row16_sum(sd) + MVC(mx * 4, my * 4);
         };
+        // blocks of eight rows (8x8, 16x8): eight candidates a batch — lane = (candidate = lane >> 3, row = lane & 7); the source row comes from LDS
+        // again (it is not kept in registers beside e[])
+        const bool h8 = cached && j.H == 8;
+        auto fpel8 = [&](int mx, int my) {
+            const int r8 = lane & 7;
+            const uint8_t *f = L.src + (j.oy + r8) * 16 + j.ox;
+            const uint8_t *wrow = (const uint8_t *)rslot + (by + my + r8 - Y0) * RC_COLS;
+            const int xo = bx + mx - X0;
+            int sd;
+            if (w16) { const uint4 sv = *(const uint4 *)f; const uint32_t e8[4] = { sv.x, sv.y, sv.z, sv.w }; sd = sad_row16_lds(wrow, xo, e8); }
+            else { const uint2 sv = *(const uint2 *)f; sd = sad8_lds(wrow, xo, sv.x, sv.y); }
+            sd = quad_sum(sd); sd += dpp<DPP_ROW_HALF_MIRROR>(sd);
+            return sd + MVC(mx * 4, my * 4);
+        };
         // the slot follows a search that walks out of it (dia / hex; the cost slices reach +-24 around their centre: merange <= 16)
         auto ensure = [&](int mx, int my, int rad) { if (cached && !in_fpel(mx, my, rad)) rc_stage(mx, my); };
         {   // the rounded best predictor and the zero vector: groups 0 and 1
@@ -515,7 +529,12 @@ __device__ __forceinline__ void me_search(const EncK &k, MbLds<M> &L, const MbCt
             // X264_ME_HEX (and the tail of umh): hexagon, then square refine
             unsigned hk = (unsigned)bcost << 3;
             ensure(bmx, bmy, 2);
-            {
+            if (h8) {       // the six points in one batch
+                const int c8 = lane >> 3, i = 1 + (c8 < 6 ? c8 : 0);
+                unsigned kk = ((unsigned)fpel8(bmx + hex_dx(i), bmy + hex_dy(i)) << 3) | (unsigned)(i + 1);
+                if (c8 >= 6) kk = 0xffffffffu;
+                hk = min(hk, wave_min_u32(kk));
+            } else {
                 int i = 1 + cnd;
                 unsigned kk = ((unsigned)fpel(bmx + hex_dx(i), bmy + hex_dy(i)) << 3) | (unsigned)(i + 1);
                 hk = min(hk, wave_min_u32(kk));
@@ -543,7 +562,10 @@ __device__ __forceinline__ void me_search(const EncK &k, MbLds<M> &L, const MbCt
             bcost = (int)(hk >> 3);
             unsigned sk = (unsigned)bcost << 4;
             ensure(bmx, bmy, 1);
-            {
+            if (h8) {       // the eight points in one batch
+                const int q = 1 + (lane >> 3);
+                sk = min(sk, wave_min_u32(((unsigned)fpel8(bmx + sq_dx(q), bmy + sq_dy(q)) << 4) | (unsigned)q));
+            } else {
                 int q = 1 + cnd;
                 sk = min(sk, wave_min_u32(((unsigned)fpel(bmx + sq_dx(q), bmy + sq_dy(q)) << 4) | (unsigned)q));
                 q = 5 + cnd;
