@@ -84,6 +84,21 @@ __device__ __forceinline__ unsigned wave_min_u32(unsigned v)
     return a < c ? a : c;
 }
 
+// the same for a value that is already uniform within every DPP row of 16 lanes (one search candidate per row): four lanes tell it all
+__device__ __forceinline__ unsigned rows_min_u32(unsigned v)
+{
+    unsigned a = __builtin_amdgcn_readlane(v, 0), b = __builtin_amdgcn_readlane(v, 16);
+    unsigned c = __builtin_amdgcn_readlane(v, 32), d = __builtin_amdgcn_readlane(v, 48);
+    a = a < b ? a : b; c = c < d ? c : d;
+    return a < c ? a : c;
+}
+// ... uniform within every eight lanes (eight candidates of eight rows)
+__device__ __forceinline__ unsigned halfrows_min_u32(unsigned v)
+{
+    const unsigned t = (unsigned)dpp<DPP_ROW_MIRROR>((int)v);
+    return rows_min_u32(t < v ? t : v);
+}
+
 __device__ __forceinline__ unsigned row16_min_u32(unsigned v)      // min over a DPP row of quad-uniform values
 {
     unsigned t;

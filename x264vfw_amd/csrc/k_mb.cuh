@@ -331,7 +331,7 @@ __device__ __forceinline__ void me_search(const EncK &k, MbLds<M> &L, const MbCt
                     const int cst = row16_sum(rowok ? (int)sd : 0) + cm[t];
                     const unsigned kk = i < n ? ((unsigned)cst << 4) | (unsigned)i : 0xffffffffu;
                     if (t == 0) pmv_cost = __builtin_amdgcn_readlane(cst, 0);
-                    key = min(key, wave_min_u32(kk));
+                    key = min(key, rows_min_u32(kk));
                 }
         }
         {
@@ -426,7 +426,7 @@ __device__ __forceinline__ void me_search(const EncK &k, MbLds<M> &L, const MbCt
                 const int sx = valid ? mx : bmx, sy = valid ? my : bmy;            // masked candidates stay inside the padded plane
                 const int cst = fpel(sx, sy);
                 unsigned kk = valid ? ((unsigned)cst << 2) | (unsigned)cnd : 0xffffffffu;
-                kk = wave_min_u32(kk);
+                kk = rows_min_u32(kk);
                 if (kk != 0xffffffffu && (int)(kk >> 2) < bcost) {
                     const int wl = (int)(kk & 3) * 16;
                     bcost = (int)(kk >> 2); bmx = __shfl(sx, wl); bmy = __shfl(sy, wl);
@@ -519,7 +519,7 @@ __device__ __forceinline__ void me_search(const EncK &k, MbLds<M> &L, const MbCt
             int it = k.me_range;
             do {
                 ensure(bmx, bmy, 1);
-                const unsigned kk = wave_min_u32(((unsigned)fpel(bmx + (cnd == 2 ? -1 : cnd == 3 ? 1 : 0), bmy + (cnd == 0 ? -1 : cnd == 1 ? 1 : 0)) << 2) | (unsigned)cnd);
+                const unsigned kk = rows_min_u32(((unsigned)fpel(bmx + (cnd == 2 ? -1 : cnd == 3 ? 1 : 0), bmy + (cnd == 0 ? -1 : cnd == 1 ? 1 : 0)) << 2) | (unsigned)cnd);
                 if ((int)(kk >> 2) >= bcost) break;
                 const int q = kk & 3;
                 bcost = (int)(kk >> 2);
@@ -533,15 +533,15 @@ __device__ __forceinline__ void me_search(const EncK &k, MbLds<M> &L, const MbCt
                 const int c8 = lane >> 3, i = 1 + (c8 < 6 ? c8 : 0);
                 unsigned kk = ((unsigned)fpel8(bmx + hex_dx(i), bmy + hex_dy(i)) << 3) | (unsigned)(i + 1);
                 if (c8 >= 6) kk = 0xffffffffu;
-                hk = min(hk, wave_min_u32(kk));
+                hk = min(hk, halfrows_min_u32(kk));
             } else {
                 int i = 1 + cnd;
                 unsigned kk = ((unsigned)fpel(bmx + hex_dx(i), bmy + hex_dy(i)) << 3) | (unsigned)(i + 1);
-                hk = min(hk, wave_min_u32(kk));
+                hk = min(hk, rows_min_u32(kk));
                 i = 5 + (cnd & 1);
                 kk = ((unsigned)fpel(bmx + hex_dx(i), bmy + hex_dy(i)) << 3) | (unsigned)(i + 1);
                 if (cnd >= 2) kk = 0xffffffffu;
-                hk = min(hk, wave_min_u32(kk));
+                hk = min(hk, rows_min_u32(kk));
             }
             if (hk & 7) {
                 int dir = (int)(hk & 7) - 2;
@@ -552,7 +552,7 @@ __device__ __forceinline__ void me_search(const EncK &k, MbLds<M> &L, const MbCt
                     const int cc = cnd < 3 ? cnd : 0;
                     unsigned kk = ((unsigned)fpel(bmx + hex_dx(dir + cc), bmy + hex_dy(dir + cc)) << 3) | (unsigned)(cc + 1);
                     if (cnd >= 3) kk = 0xffffffffu;
-                    hk = min(hk, wave_min_u32(kk));
+                    hk = min(hk, rows_min_u32(kk));
                     if (!(hk & 7)) break;
                     dir += (int)(hk & 7) - 2;
                     dir = dir < 0 ? 5 : dir > 5 ? 0 : dir;
@@ -564,12 +564,12 @@ __device__ __forceinline__ void me_search(const EncK &k, MbLds<M> &L, const MbCt
             ensure(bmx, bmy, 1);
             if (h8) {       // the eight points in one batch
                 const int q = 1 + (lane >> 3);
-                sk = min(sk, wave_min_u32(((unsigned)fpel8(bmx + sq_dx(q), bmy + sq_dy(q)) << 4) | (unsigned)q));
+                sk = min(sk, halfrows_min_u32(((unsigned)fpel8(bmx + sq_dx(q), bmy + sq_dy(q)) << 4) | (unsigned)q));
             } else {
                 int q = 1 + cnd;
-                sk = min(sk, wave_min_u32(((unsigned)fpel(bmx + sq_dx(q), bmy + sq_dy(q)) << 4) | (unsigned)q));
+                sk = min(sk, rows_min_u32(((unsigned)fpel(bmx + sq_dx(q), bmy + sq_dy(q)) << 4) | (unsigned)q));
                 q = 5 + cnd;
-                sk = min(sk, wave_min_u32(((unsigned)fpel(bmx + sq_dx(q), bmy + sq_dy(q)) << 4) | (unsigned)q));
+                sk = min(sk, rows_min_u32(((unsigned)fpel(bmx + sq_dx(q), bmy + sq_dy(q)) << 4) | (unsigned)q));
             }
             const int bd = sk & 15;
             bcost = (int)(sk >> 4);
@@ -647,7 +647,7 @@ __device__ __forceinline__ void me_search(const EncK &k, MbLds<M> &L, const MbCt
     // half-pel diamond on SAD: (0,-2) (0,2) (-2,0) (2,0)
     for (int it = j.hp_it; it > 0; it--) {
         const int cx = bmx + (cnd == 2 ? -2 : cnd == 3 ? 2 : 0), cy = bmy + (cnd == 0 ? -2 : cnd == 1 ? 2 : 0);
-        const unsigned kk = wave_min_u32(((unsigned)sad2(cx, cy) << 2) | (unsigned)cnd);
+        const unsigned kk = rows_min_u32(((unsigned)sad2(cx, cy) << 2) | (unsigned)cnd);
         if ((int)(kk >> 2) >= bcost) break;
         const int b = kk & 3;
         bcost = (int)(kk >> 2);
@@ -670,7 +670,7 @@ __device__ __forceinline__ void me_search(const EncK &k, MbLds<M> &L, const MbCt
             int cst = cmp2(cx, cy);
             if (chroma_me && __any(cst < bcost && !skip)) cst += chroma2(cx, cy);
             unsigned kk = skip ? 0xffffffffu : ((unsigned)cst << 2) | (unsigned)cnd;
-            kk = wave_min_u32(kk);
+            kk = rows_min_u32(kk);
             if ((int)(kk >> 2) >= bcost) break;
             bcost = (int)(kk >> 2);
             bdir = kk & 3;
@@ -678,7 +678,7 @@ __device__ __forceinline__ void me_search(const EncK &k, MbLds<M> &L, const MbCt
         }
     } else if (bmy > c.smin1 && bmy < c.smax1 && bmx > c.smin0 && bmx < c.smax0) {
         const int cx = bmx + (cnd == 2 ? -1 : cnd == 3 ? 1 : 0), cy = bmy + (cnd == 0 ? -1 : cnd == 1 ? 1 : 0);
-        const unsigned kk = wave_min_u32(((unsigned)sad2(cx, cy) << 2) | (unsigned)cnd);
+        const unsigned kk = rows_min_u32(((unsigned)sad2(cx, cy) << 2) | (unsigned)cnd);
         if ((int)(kk >> 2) < bcost) {
             const int b = kk & 3;
             bcost = (int)(kk >> 2);
