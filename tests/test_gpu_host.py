@@ -668,6 +668,28 @@ def test_slice_threads_with_gop_slots(gpu, monkeypatch):
     assert got == nfr and stream == serial
 
 
+@pytest.mark.parametrize("extra", [{"slices": 9}, {"sliced-threads": None, "threads": 2}])
+def test_rate_controlled_session_in_slices(gpu, monkeypatch, extra):
+    """the driver's default rate control (CRF + variance AQ + macroblock-tree, pictures held back in the lookahead) on pictures coded in
+    slices — --slices N with its repeated slice passes, and slice threads: per-macroblock quantisers cross the slice boundaries (every
+    slice starts its delta chain at the slice quantiser), scene cuts put intra macroblocks into P pictures.  The stream decodes to the
+    encoder's reconstruction, picture by picture"""
+    w, h, look = 176, 144, 3
+    frames = synth_frames(w, h, 5, seed=15) + synth_frames(w, h, 4, seed=98)
+    monkeypatch.setenv("X264GPU_HOST_PIPELINE", "0")                         # the reconstruction read back after a call is that call's picture
+    h_, eff = open_encoder(w, h, dict({"crf": 25.0, "keyint": 250, "min-keyint": 3, "rc-lookahead": look}, **extra), b"high")
+    assert (eff.rc.b_mb_tree, eff.rc.i_aq_mode) == (1, 1)
+    ns = 9 if "slices" in extra else 2
+    stream, rows, recons = encode_with_decisions(h_, w, h, frames)
+    H.x264_encoder_close(h_)
+    assert len(recons) == len(frames)
+    nals = [n for n in stream.split(b"\x00\x00\x01") if n and (n[0] & 31) in (1, 5)]
+    assert len(nals) == ns * len(frames)
+    dec = O.h264_decode(stream, len(frames), w, h)
+    for i in range(len(frames)):
+        np.testing.assert_array_equal(dec[i], recons[i], err_msg=f"picture {i}")
+
+
 def test_plain_slices_with_gop_slots(gpu):
     """--slices N --threads G: G closed GOPs in lock-step with every picture in N slices (N x G wavefronts of one stream; the slots keep their own
     intra statistics for the repeated slice passes) — the bytes equal the --threads 1 session's, only the delay changes"""
