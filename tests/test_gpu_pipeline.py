@@ -264,6 +264,7 @@ def test_pipeline_multistream(gpu):
     (1280, 720, 3, dict(dct8x8=1, partitions=7, refs=3, chroma_me=1, mixed_refs=1, cabac=1, rd=1, subme=7, psy=1, psy_rd_q8=256, chroma_qp_offset=-2, trellis=63)),   # configs[1] with the headline toolset: RD + psy + trellis 1
     (1920, 1080, 3, dict(dct8x8=1, partitions=7, refs=3, chroma_me=1, mixed_refs=1, cabac=1, rd=1, subme=7, psy=1, psy_rd_q8=256, chroma_qp_offset=-2, trellis=63)),  # configs[2]: the bench's headline toolset
     (3840, 2160, 2, dict(dct8x8=1, partitions=7, refs=2, chroma_me=1, mixed_refs=1, me_method=2, cabac=1, rd=1, subme=7, psy=1, psy_rd_q8=256, chroma_qp_offset=-2, trellis=127, slices=33)),   # configs[3]: umh, --trellis 2 (slow's), slice threads
+    (1920, 1080, 3, dict(dct8x8=1, partitions=7, refs=3, chroma_me=1, mixed_refs=1, cabac=1, rd=1, subme=7, psy=1, psy_rd_q8=256, chroma_qp_offset=-2, trellis=63, slices=68, slices_plain=1)),  # configs[2], headline toolset, --slices 68 (one row each)
     (1920, 1080, 2, dict(dct8x8=1, partitions=7, refs=2, chroma_me=1, mixed_refs=1, aq_mode=1, qp_i=23, qp_p=26)),   # + variance AQ (CRF / ABR sessions)
     (3840, 2160, 2, dict(dct8x8=1, partitions=7, refs=2, chroma_me=1, mixed_refs=1, me_method=2, subme=9)),          # configs[3] geometry and toolset (slow: umh, subme 9)
 ])
