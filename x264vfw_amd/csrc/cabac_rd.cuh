@@ -125,7 +125,22 @@ __device__ __forceinline__ void cab_levels(Cab &cb, int &st, uint32_t model, int
         const int c1 = node < 4 ? node + 1 : 0, cg = node < 4 ? 5 : min(node + 2, 9);
         const int ones = min(a, 15) - 2, nb = a > 1 ? (a < 15 ? a - 1 : 13) : 0;        // bins on cg: `ones` ones, then a zero unless the escape follows
         cab_step(st, cb.f8v, model, q == c1 || (a > 1 && q == cg), q == c1 ? a > 1 : a > 2);
-        for (int kb = 1; kb < nb; kb++) cab_step(st, cb.f8v, model, q == cg, kb < ones);
+        if (ones >= 3) {
+            // a run of ones on cg.  While a one is that context's less probable symbol it is stepped; from then on every bin moves the state up
+            // by one (to 62 at most) and costs what the model says for the state it leaves: lane s of the model register IS state s, so the
+            // lanes of the states passed through add their own entry to their own share of the bits — no step per bin
+            int run = ones - 1;
+            const int owner = __builtin_ctzll(__ballot(q == cg));
+            int so = __builtin_amdgcn_readlane(st, owner);
+            while (run > 0 && !(so & 1)) { cab_step(st, cb.f8v, model, q == cg, 1); so = __builtin_amdgcn_readlane(st, owner); run--; }
+            if (run > 0) {
+                const int sg = so >> 1, hi = min(sg + run - 1, 62), extra = max(sg + run - 1 - 62, 0), ln = (int)__lane_id();
+                cb.f8v += ln >= sg && ln <= hi ? (int)(model & 0x1ff) * (ln == 62 ? 1 + extra : 1) : 0;
+                st = q == cg ? (min(sg + run, 62) << 1) | 1 : st;
+            }
+            if (a < 15) cab_step(st, cb.f8v, model, q == cg, 0);
+        } else
+            for (int kb = 1; kb < nb; kb++) cab_step(st, cb.f8v, model, q == cg, kb < ones);
         cb.f8 += 256;                                                  // sign
         if (a >= 15) cab_ue_bypass(cb, 0, a - 15);
         node = a > 1 ? (node < 4 ? 4 : min(node + 1, 7)) : (node < 3 ? node + 1 : node);
