@@ -88,7 +88,7 @@ def cpu_worker(args):
     import numpy as np
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import oracle_lib as O
-    from synth import synth_frames
+    from x264vfw_amd.synth import synth_frames
     frames = synth_frames(args.width, args.height, args.cpu_frames, seed=0x264 + args.cpu_worker, scene_len=97)
     enc = O.OracleEncoder(O.default_config(args.width, args.height, qp_i=max(0, args.qp - 3), qp_p=args.qp, **toolset(args)))
     t0 = time.perf_counter()
@@ -114,8 +114,7 @@ def x264_probe(args):
     if cli:
         try:
             import numpy as np
-            sys.path.insert(0, os.path.join(ROOT, "tests"))
-            from synth import synth_frames
+            from x264vfw_amd.synth import synth_frames
             n = 24
             raw = "/tmp/bench_x264_probe.yuv"
             with open(raw, "wb") as f:
@@ -259,9 +258,8 @@ def e2e_probe(args):
     SURVEY.md §8d), scene cut every 97 source frames.  threads 1: every call returns its picture; threads G: G closed GOPs in lock-step
     (delay (G - 1) x keyint + 1 pictures, byte-identical stream under CQP + fixed keyint)."""
     import numpy as np
-    sys.path.insert(0, os.path.join(ROOT, "tests"))
-    import host_lib as HL
-    from synth import synth_frames
+    from x264vfw_amd import host_api as HL
+    from x264vfw_amd.synth import synth_frames
     H = HL.H
     w, h = args.width, args.height
     planes = [(w * h, 0), (w * h // 4, w * h), (w * h // 4, w * h * 5 // 4)]

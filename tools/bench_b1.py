@@ -9,10 +9,9 @@ import time
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np  # noqa: E402
-import host_lib as HL  # noqa: E402
-from synth import synth_frames  # noqa: E402
+from x264vfw_amd import host_api as HL  # noqa: E402
+from x264vfw_amd.synth import synth_frames  # noqa: E402
 
 H = HL.H
 

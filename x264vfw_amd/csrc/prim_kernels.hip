@@ -7,6 +7,7 @@
 #include "trellis.cuh"
 #include <math.h>
 #include <mutex>
+#include <stddef.h>
 
 using namespace x264gpu;
 
@@ -230,34 +231,41 @@ int x264gpu_mc_chroma(const uint8_t *d_nv12_00, int stride, const int32_t *d_xy,
 
 namespace x264gpu {
 
-// x264_rdo_init's unary tables and x264_trellis_lambda2_tab, built once per process and kept on the device
+// x264_rdo_init's unary tables and x264_trellis_lambda2_tab, built once per DEVICE and kept there (GOP slots of one session live on
+// several devices, host/encoder.cpp: every device's macroblock loop must read its own copy).  One allocation holds the three tables.
 static int trellis_tables(TrellisTab *out)
 {
+    constexpr int MAXDEV = 64;
     static std::mutex mu;
-    static TrellisTab tt = { nullptr, nullptr, nullptr };
+    static TrellisTab tt[MAXDEV] = {};
+    int dev = 0;
+    HIP_TRY(hipGetDevice(&dev));
+    ARG_TRY(dev >= 0 && dev < MAXDEV);
     std::lock_guard<std::mutex> lock(mu);
-    if (!tt.size_unary) {
+    if (!tt[dev].size_unary) {
         static const uint16_t ent[128] = {
 #include "cabac_entropy.inc"
         };
         static const uint8_t trans_lps[64] = { 0, 0, 1, 2, 2, 4, 4, 5, 6, 7, 8, 9, 9, 11, 11, 12, 13, 13, 15, 15, 16, 16, 18, 18, 19, 19, 21, 21, 22, 22, 23, 24,
                                                24, 25, 26, 26, 27, 27, 28, 29, 29, 30, 30, 30, 31, 32, 32, 33, 33, 33, 34, 34, 35, 35, 35, 36, 36, 36, 37, 37, 37, 38, 38, 63 };
         auto next = [&](int st, int b) { const int s = st >> 1, mps = st & 1; return (mps ^ b) ? (trans_lps[s] << 1) | (s == 0 ? mps ^ 1 : mps) : ((s < 62 ? s + 1 : 62) << 1) | mps; };
-        uint16_t su[15 * 128]; uint8_t tu[15 * 128]; int l2[104];
+        struct Host { int l2[104]; uint16_t su[15 * 128]; uint8_t tu[15 * 128]; };
+        static Host hst;
         for (int prefix = 0; prefix < 15; prefix++)
             for (int c0 = 0; c0 < 128; c0++) {
                 int bits = 0, ctx = c0;
                 for (int i = 1; i < prefix; i++) { bits += ent[ctx ^ 1]; ctx = next(ctx, 1); }
                 if (prefix > 0 && prefix < 14) { bits += ent[ctx]; ctx = next(ctx, 0); }
-                su[prefix * 128 + c0] = (uint16_t)(bits + 256); tu[prefix * 128 + c0] = (uint8_t)ctx;
+                hst.su[prefix * 128 + c0] = (uint16_t)(bits + 256); hst.tu[prefix * 128 + c0] = (uint8_t)ctx;
             }
-        for (int qp = 0; qp < 52; qp++) { l2[qp] = (int)(0.85 * 0.85 * pow(2.0, qp / 3.0 + 6.0) + 0.5); l2[52 + qp] = (int)(0.65 * 0.65 * pow(2.0, qp / 3.0 + 6.0) + 0.5); }
-        void *a = nullptr, *b = nullptr, *c = nullptr;
-        HIP_TRY(hipMalloc(&a, sizeof(su))); HIP_TRY(hipMalloc(&b, sizeof(tu))); HIP_TRY(hipMalloc(&c, sizeof(l2)));
-        HIP_TRY(hipMemcpy(a, su, sizeof(su), hipMemcpyHostToDevice)); HIP_TRY(hipMemcpy(b, tu, sizeof(tu), hipMemcpyHostToDevice)); HIP_TRY(hipMemcpy(c, l2, sizeof(l2), hipMemcpyHostToDevice));
-        tt.size_unary = (const uint16_t *)a; tt.trans_unary = (const uint8_t *)b; tt.lambda2 = (const int *)c;
+        for (int qp = 0; qp < 52; qp++) { hst.l2[qp] = (int)(0.85 * 0.85 * pow(2.0, qp / 3.0 + 6.0) + 0.5); hst.l2[52 + qp] = (int)(0.65 * 0.65 * pow(2.0, qp / 3.0 + 6.0) + 0.5); }
+        char *a = nullptr;
+        HIP_TRY(hipMalloc((void **)&a, sizeof(Host)));
+        const hipError_t ce = hipMemcpy(a, &hst, sizeof(Host), hipMemcpyHostToDevice);
+        if (ce != hipSuccess) { (void)hipFree(a); HIP_TRY(ce); }
+        tt[dev].lambda2 = (const int *)(a + offsetof(Host, l2)); tt[dev].size_unary = (const uint16_t *)(a + offsetof(Host, su)); tt[dev].trans_unary = (const uint8_t *)(a + offsetof(Host, tu));
     }
-    *out = tt;
+    *out = tt[dev];
     return X264GPU_OK;
 }
 
