@@ -17,7 +17,7 @@
 extern "C" {
 #endif
 
-#define X264GPU_ABI_VERSION 1
+#define X264GPU_ABI_VERSION 2
 enum { X264GPU_OK = 0, X264GPU_EINVAL = -1, X264GPU_EHIP = -2, X264GPU_ENOMEM = -3, X264GPU_ENODEV = -4 };
 
 /* ------------------------------------------------------------------------------------------------
@@ -119,26 +119,41 @@ int x264gpu_csp_to_i420_batch(const uint8_t *const d_src[3], const int src_strid
  * closed-GOP streams (one launch covers `streams` frames of identical geometry).
  * ---------------------------------------------------------------------------------------------- */
 enum { X264GPU_MB_I4x4 = 0, X264GPU_MB_I8x8 = 1, X264GPU_MB_I16x16 = 2, X264GPU_MB_P_L0 = 4, X264GPU_MB_P_8x8 = 5,
-       X264GPU_MB_P_SKIP = 6 };
+       X264GPU_MB_P_SKIP = 6,
+       /* B slices.  B_DIRECT / B_SKIP: spatial direct prediction of the whole macroblock (with / without residual), the derived references
+        * and vectors of both lists are in the record.  B_INTER: partition 16x16 / 16x8 / 8x16, every partition predicted from list 0
+        * (ref[k] >= 0, ref1[k] < 0), list 1 (ref[k] < 0, ref1[k] >= 0) or both — x264's B_L0_L0 .. B_BI_BI.  B_8x8: partition 8x8, each
+        * 8x8 block L0 / L1 / BI by the same rule or direct (bit k of direct8) */
+       X264GPU_MB_B_DIRECT = 7, X264GPU_MB_B_SKIP = 8, X264GPU_MB_B_INTER = 9, X264GPU_MB_B_8x8 = 10 };
 enum { X264GPU_SLICE_P = 0, X264GPU_SLICE_B = 1, X264GPU_SLICE_I = 2 /* IDR picture: empties the DPB */,
-       X264GPU_SLICE_I_NONIDR = 3 /* intra picture that keeps the DPB (x264's X264_TYPE_I, e.g. a scenecut inside min-keyint) */ };
+       X264GPU_SLICE_I_NONIDR = 3 /* intra picture that keeps the DPB (x264's X264_TYPE_I, e.g. a scenecut inside min-keyint) */,
+       X264GPU_SLICE_NONE = -1 /* x264gpu_encode_pictures: the stream sits this call out */ };
 
 /* per-macroblock decision record written by the GPU, consumed by the host entropy coder (64 B) */
 typedef struct x264gpu_mb {
     uint8_t  type;          /* X264GPU_MB_* */
+    union {
     uint8_t  i16_mode;      /* intra 16x16 prediction mode (I_PRED_16x16_*, real modes 0..3) */
+    uint8_t  direct8;       /* B_8x8: bit k = 8x8 block k is a direct sub-macroblock (B_DIRECT / B_SKIP: 15) */
+    };
     uint8_t  chroma_mode;   /* intra chroma prediction mode 0..3 */
     uint8_t  qp;            /* luma qp used for this macroblock */
     uint8_t  cbp_luma;      /* bit i = 8x8 block i has coded coefficients */
     uint8_t  cbp_chroma;    /* 0 none, 1 DC only, 2 DC+AC */
     uint8_t  partition;     /* 0 16x16, 1 16x8, 2 8x16, 3 8x8 (P only) */
-    int8_t   ref[4];        /* reference index per 8x8 */
+    int8_t   ref[4];        /* reference index per 8x8 (list 0; -1 = the block does not use the list) */
+    union {
     uint8_t  i4_mode[16];   /* intra 4x4 modes, x264 block order (zigzag-of-8x8); I8x8: mode of 8x8 block i in [4i..4i+3] */
+    int16_t  mv1[4][2];     /* B macroblocks: list-1 vector per 8x8 */
+    };
     uint8_t  transform8x8;  /* transform_size_8x8_flag: luma residual uses the 8x8 transform (0 when cbp_luma == 0) */
-    int16_t  mv[4][2];      /* quarter-pel motion vector per 8x8 (x,y) */
+    int16_t  mv[4][2];      /* quarter-pel motion vector per 8x8 (x,y), list 0 */
     uint32_t nnz;           /* bit b (0..15 luma blk order [transform8x8: of the interleaved 4x4s], 16..19 U, 20..23 V, 24 lumaDC, 25 U DC, 26 V DC) */
     int32_t  cost;          /* analysis cost of the chosen mode (diagnostic) */
+    union {
     int32_t  aux[3];        /* diagnostics: [0] best inter cost, [1] intra-16x16 source estimate (P slices) */
+    struct { int32_t aux01[2]; int8_t ref1[4]; };      /* B macroblocks: list-1 reference index per 8x8 (-1 = unused) in place of aux[2] */
+    };
 } x264gpu_mb;
 
 /* quantised levels per macroblock, scan (zigzag) order, int16:

@@ -1381,16 +1381,17 @@ static int mb_bits_cavlc(actx *a, const x264gpu_mb *mb, const int16_t *lv)
 static int rd_ssd_mb(const actx *a)
 {
     const x264o_encoder *e = a->e;
-    static const pixel zero[16] = { 0 };
     const pixel *fenc = e->fenc_y + (size_t)a->mby * 16 * e->fs + a->mbx * 16, *fuv = e->fenc_uv + (size_t)a->mby * 8 * e->fs + a->mbx * 16;
     const pixel *rec = luma_plane((x264o_encoder *)e, e->cur, 0) + (size_t)a->mby * 16 * e->rs + a->mbx * 16;
     const pixel *ruv = chroma_plane((x264o_encoder *)e, e->cur) + (size_t)a->mby * 8 * e->rs + a->mbx * 16;
     int ssd = x264o_ssd(fenc, e->fs, rec, e->rs, 16, 16);
     if (e->cfg.psy_rd_q8) {
-        /* sizes above 8x8: SATD against zero minus half the SAD against zero (the DC share), source vs reconstruction */
-        const int fdec_e = x264o_satd(rec, e->rs, zero, 0, 16, 16) - (x264o_sad(rec, e->rs, zero, 0, 16, 16) >> 1);
-        const int fenc_e = x264o_satd(fenc, e->fs, zero, 0, 16, 16) - (x264o_sad(fenc, e->fs, zero, 0, 16, 16) >> 1);
-        ssd += (abs(fdec_e - fenc_e) * e->cfg.psy_rd_q8 * a->lambda + 128) >> 8;
+        /* ssd_plane: every size from 8x8 up (here the 16x16 luma) compares pixel_hadamard_ac of reconstruction and source — the AC sums of
+         * the 4x4 and of the 8x8 Hadamard transforms, (|d sum4| + |d sum8|) >> 1; only blocks smaller than 8x8 use SATD - SAD / 2
+         * (oracle/PSY_NOTES.md) */
+        const uint64_t fdec_acs = x264o_hadamard_ac(rec, e->rs, 16, 16), fenc_acs = x264o_hadamard_ac(fenc, e->fs, 16, 16);
+        const int satd = (abs((int32_t)fdec_acs - (int32_t)fenc_acs) + abs((int32_t)(fdec_acs >> 32) - (int32_t)(fenc_acs >> 32))) >> 1;
+        ssd += (satd * e->cfg.psy_rd_q8 * a->lambda + 128) >> 8;
     }
     int cssd = 0;
     for (int y = 0; y < 8; y++)

@@ -153,4 +153,22 @@ __device__ __forceinline__ int sa8d_r8_half(uint32_t elo, uint32_t ehi, uint32_t
     return (int)acc;
 }
 
+// pixel_hadamard_ac ([x264-upstream] common/pixel.c, psy-RD: ssd_plane uses it for every size from 8x8 up): this lane's share of
+// sum|H4 x H4| - sum(x) over the 4x4 blocks (e4) and of sum|H8 x H8| - sum(x) over the 8x8 blocks (e8) of a 16x16 block; the caller sums over
+// the wave and shifts by 1 / 2.  All 64 lanes must be active (DPP butterflies and the layout change).
+__device__ __forceinline__ void psy_energy_r8(uint32_t lo, uint32_t hi, int lane, int &e4, int &e8)      // R8 layout, lanes < 32 carry pixels
+{
+    const int pix = (int)__builtin_amdgcn_sad_u8(lo, 0u, __builtin_amdgcn_sad_u8(hi, 0u, 0u));
+    e4 = 2 * (satd4_half(lo, 0u, lane) + satd4_half(hi, 0u, lane)) - pix;
+    e8 = 2 * sa8d_r8_half(lo, hi, 0u, 0u, lane) - pix;
+}
+__device__ __forceinline__ void psy_energy_z(uint32_t z, int lane, int &e4, int &e8)                      // Z layout, 64 lanes x 4 pixels
+{
+    e4 = 2 * satd4_half(z, 0u, lane) - (int)__builtin_amdgcn_sad_u8(z, 0u, 0u);
+    uint32_t lo, hi;
+    z_to_r8(z, lane, lo, hi);
+    const int h8 = 2 * sa8d_r8_half(lo, hi, 0u, 0u, lane) - (int)__builtin_amdgcn_sad_u8(lo, 0u, __builtin_amdgcn_sad_u8(hi, 0u, 0u));
+    e8 = lane < 32 ? h8 : 0;
+}
+
 }  // namespace x264gpu

@@ -1754,7 +1754,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(MB_WAVES_PER
         bool commit = true;
         // RD bookkeeping (x264_mb_analysis_t l0.i_rd16x16 / i_cost16x8 / i_cost8x16 / i_cost8x8 turned into RD costs, the intra ones likewise)
         int rd_ph = 0, rd16 = MB_COST_MAX, rd16x8 = MB_COST_MAX, rd8x16 = MB_COST_MAX, rd8x8 = MB_COST_MAX, rd_best = MB_COST_MAX, rd_part = D_16x16, rd_t8 = 0;
-        int rd_satd_inter = 0, rd_isatd = 0, rd_thresh = 0, rd_ithresh = 0, rd_i16 = MB_COST_MAX, rd_i4 = MB_COST_MAX, rd_i8 = MB_COST_MAX, fenc_energy = 0;
+        int rd_satd_inter = 0, rd_isatd = 0, rd_thresh = 0, rd_ithresh = 0, rd_i16 = MB_COST_MAX, rd_i4 = MB_COST_MAX, rd_i8 = MB_COST_MAX, fenc_e4 = 0, fenc_e8 = 0;
         const int lambda2 = c_lambda2_tab[c.qp];
         bool rd_run = false, rd_skip16 = false;
         if constexpr (RD) {
@@ -1765,7 +1765,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(MB_WAVES_PER
                 rd_satd_inter = i_inter_satd;
                 rd_isatd = min(i_inter_satd, i_satd_intra);
                 rd_thresh = early_term ? rd_isatd * 5 / 4 + 1 : MB_COST_MAX;
-                if (k.psy_rd_q8) fenc_energy = wave_sum(satd4_half(cz, 0u, lane)) - (wave_sum((int)__builtin_amdgcn_sad_u8(cz, 0u, 0u)) >> 1);
+                if (k.psy_rd_q8) { int e4, e8; psy_energy_z(cz, lane, e4, e8); fenc_e4 = wave_sum(e4) >> 1; fenc_e8 = wave_sum(e8) >> 2; }      // fenc_hadamard_cache
             }
         }
         int rec_type = mb_type, chroma_l2off = 256;
@@ -1828,7 +1828,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(MB_WAVES_PER
         int rd_t8cur = 0;                                         // transform_size_8x8_flag of what this pass codes
         rec_type = e_type;
         int16_t *lvw = RD ? (int16_t *)rd_lvs : lv;               // RD: levels stay on chip until the final pass has its bit counts' totals
-        int ssd_y = 0, ssd_c = 0, en_satd = 0, en_sad = 0;          // per-lane shares of the distortion terms of the candidate
+        int ssd_y = 0, ssd_c = 0, en4 = 0, en8 = 0;          // per-lane shares of the distortion terms of the candidate
         if (e_type >= X264GPU_MB_P_L0) {
             // this lane's 8x8 block's motion (Z layout: lane >> 4)
             const int b8 = lane >> 4;
@@ -1934,8 +1934,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(MB_WAVES_PER
                         if (commit) *(uint2 *)(rec + (size_t)((i8 >> 1) * 8 + row) * k.rs + (i8 & 1) * 8) = o;
                         if constexpr (RD) {      // R8 layout: a quad of lanes is four rows of one 8x8 block, so both halves are 4x4 blocks for the SATD
                             ssd_y = ssd4_u8(elo, o.x) + ssd4_u8(ehi, o.y);
-                            en_satd = satd4_half(o.x, 0u, lane) + satd4_half(o.y, 0u, lane);
-                            en_sad = (int)__builtin_amdgcn_sad_u8(o.x, 0u, __builtin_amdgcn_sad_u8(o.y, 0u, 0u));
+                            psy_energy_r8(o.x, o.y, lane, en4, en8);
                         }
                     }
                 } else {
@@ -1973,7 +1972,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(MB_WAVES_PER
                     {
                         const uint32_t rz = pack4_clip(v);
                         if (commit) *(uint32_t *)(rec + (size_t)zy * k.rs + zx) = rz;
-                        if constexpr (RD) { ssd_y = ssd4_u8(cz, rz); en_satd = satd4_half(rz, 0u, lane); en_sad = (int)__builtin_amdgcn_sad_u8(rz, 0u, 0u); }
+                        if constexpr (RD) { ssd_y = ssd4_u8(cz, rz); psy_energy_z(rz, lane, en4, en8); }
                     }
                     const unsigned long long bal = __ballot(keep && j4 == 0);
 #pragma unroll
@@ -2008,7 +2007,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(MB_WAVES_PER
                 {
                     const uint32_t rz = *(const uint32_t *)(tile8 + zy * IT_STRIDE + zx);
                     if (commit) *(uint32_t *)(rec + (size_t)zy * k.rs + zx) = rz;
-                    if constexpr (RD) { ssd_y = ssd4_u8(cz, rz); en_satd = satd4_half(rz, 0u, lane); en_sad = (int)__builtin_amdgcn_sad_u8(rz, 0u, 0u); }
+                    if constexpr (RD) { ssd_y = ssd4_u8(cz, rz); psy_energy_z(rz, lane, en4, en8); }
                 }
                 if (!tri8) *(uint2 *)(lvw + lane * 4) = *(const uint2 *)(L.lv8 + lane * 4);
                 if (lane < 16) lvw[X264GPU_LV_LUMA_DC + lane] = 0;
@@ -2021,7 +2020,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(MB_WAVES_PER
                 {
                     const uint32_t rz = *(const uint32_t *)(tile + zy * IT_STRIDE + zx);
                     if (commit) *(uint32_t *)(rec + (size_t)zy * k.rs + zx) = rz;
-                    if constexpr (RD) { ssd_y = ssd4_u8(cz, rz); en_satd = satd4_half(rz, 0u, lane); en_sad = (int)__builtin_amdgcn_sad_u8(rz, 0u, 0u); }
+                    if constexpr (RD) { ssd_y = ssd4_u8(cz, rz); psy_energy_z(rz, lane, en4, en8); }
                 }
                 if (!tri4) *(uint2 *)(lvw + lane * 4) = *(const uint2 *)(L.lv4 + lane * 4);
                 if (lane < 16) lvw[X264GPU_LV_LUMA_DC + lane] = 0;
@@ -2096,7 +2095,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(MB_WAVES_PER
                 {
                     const uint32_t rz = pack4_clip(v);
                     if (commit) *(uint32_t *)(rec + (size_t)zy * k.rs + zx) = rz;
-                    if constexpr (RD) { ssd_y = ssd4_u8(cz, rz); en_satd = satd4_half(rz, 0u, lane); en_sad = (int)__builtin_amdgcn_sad_u8(rz, 0u, 0u); }
+                    if constexpr (RD) { ssd_y = ssd4_u8(cz, rz); psy_energy_z(rz, lane, en4, en8); }
                 }
                 nnz = acn | (nzdc ? 1u << 24 : 0);
                 cbp_luma = acn ? 15 : 0;
@@ -2141,8 +2140,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(MB_WAVES_PER
                 int cost;
                 int dist = wave_sum(ssd_y);
                 if (k.psy_rd_q8) {
-                    const int en = wave_sum(en_satd) - (wave_sum(en_sad) >> 1);
-                    dist += (abs(en - fenc_energy) * k.psy_rd_q8 * c.lambda + 128) >> 8;
+                    const int e4 = wave_sum(en4) >> 1, e8 = wave_sum(en8) >> 2;      // pixel_hadamard_ac_16x16 of the reconstruction
+                    dist += (((abs(e4 - fenc_e4) + abs(e8 - fenc_e8)) >> 1) * k.psy_rd_q8 * c.lambda + 128) >> 8;
                 }
                 dist += (int)(((long long)wave_sum(ssd_c) * chroma_l2off + 128) >> 8);
                 if (rec_type == X264GPU_MB_P_SKIP) cost = dist + ((lambda2 + 128) >> 8);
@@ -2255,8 +2254,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(MB_WAVES_PER
                 // ---- x264_rd_cost_mb: SSD of luma (+ the psy-rd energy term) and chroma (scaled by the chroma lambda offset) + lambda2 x bits ----
                 int dist = wave_sum(ssd_y);
                 if (k.psy_rd_q8) {
-                    const int en = wave_sum(en_satd) - (wave_sum(en_sad) >> 1);
-                    dist += (abs(en - fenc_energy) * k.psy_rd_q8 * c.lambda + 128) >> 8;
+                    const int e4 = wave_sum(en4) >> 1, e8 = wave_sum(en8) >> 2;      // pixel_hadamard_ac_16x16 of the reconstruction
+                    dist += (((abs(e4 - fenc_e4) + abs(e8 - fenc_e8)) >> 1) * k.psy_rd_q8 * c.lambda + 128) >> 8;
                 }
                 dist += (int)(((long long)wave_sum(ssd_c) * chroma_l2off + 128) >> 8);
                 const int cost = rec_type == X264GPU_MB_P_SKIP ? dist + ((lambda2 + 128) >> 8) : dist + (int)(((long long)mb_bits * lambda2 + 128) >> 8);
