@@ -144,15 +144,17 @@ typedef struct x264gpu_mb {
     int8_t   ref[4];        /* reference index per 8x8 (list 0; -1 = the block does not use the list) */
     union {
     uint8_t  i4_mode[16];   /* intra 4x4 modes, x264 block order (zigzag-of-8x8); I8x8: mode of 8x8 block i in [4i..4i+3] */
-    int16_t  mv1[4][2];     /* B macroblocks: list-1 vector per 8x8 */
+    int8_t   ref1[4];       /* inter macroblocks of B slices: list-1 reference index per 8x8 (-1 = the block does not use the list) */
     };
     uint8_t  transform8x8;  /* transform_size_8x8_flag: luma residual uses the 8x8 transform (0 when cbp_luma == 0) */
     int16_t  mv[4][2];      /* quarter-pel motion vector per 8x8 (x,y), list 0 */
     uint32_t nnz;           /* bit b (0..15 luma blk order [transform8x8: of the interleaved 4x4s], 16..19 U, 20..23 V, 24 lumaDC, 25 U DC, 26 V DC) */
-    int32_t  cost;          /* analysis cost of the chosen mode (diagnostic) */
     union {
+    struct {
+    int32_t  cost;          /* analysis cost of the chosen mode (diagnostic) */
     int32_t  aux[3];        /* diagnostics: [0] best inter cost, [1] intra-16x16 source estimate (P slices) */
-    struct { int32_t aux01[2]; int8_t ref1[4]; };      /* B macroblocks: list-1 reference index per 8x8 (-1 = unused) in place of aux[2] */
+    };
+    int16_t  mv1[4][2];     /* inter macroblocks of B slices: list-1 vector per 8x8, in place of the diagnostics */
     };
 } x264gpu_mb;
 
@@ -223,7 +225,24 @@ typedef struct x264gpu_config {
                                * (c) x264 codes these slices one after the other in one thread, so the frame statistics its fast-intra decision reads
                                * (intra macroblocks so far) run on through the picture.  The slices still run side by side on the device: each on an
                                * assumed count of the slices before it, and those whose decisions hang on a wrong assumption run again */
+    int dpb;                  /* reference pictures the DPB holds (x264 sps->i_num_ref_frames: max(refs, 4 under --b-pyramid, ...)); 0 = refs.  The encoder
+                               * owns dpb + 1 picture slots: x264gpu_encode_pictures names the slot every picture is reconstructed into */
+    int weightb;              /* x264 --weightb (default on): implicit weighted bi-prediction, weights from the POC distances (weighted_bipred_idc 2) */
 } x264gpu_config;
+
+/* One picture of one stream for x264gpu_encode_pictures: slice type, quantiser and the reference lists as DPB slots — what x264's
+ * x264_reference_build_list hands the slice ([x264-upstream] encoder/encoder.c): list 0 = pictures before it in display order, nearest
+ * first; list 1 (B) = pictures after it; the host keeps the DPB (sliding window, --b-pyramid, duplicates of --weightp) and names slots. */
+#define X264GPU_MAX_LIST 8
+typedef struct x264gpu_pic {
+    int slice_type;           /* X264GPU_SLICE_I (IDR) / _I_NONIDR / _P / _B; X264GPU_SLICE_NONE: nothing for this stream in this call */
+    int qp;                   /* slice quantiser */
+    int poc;                  /* picture order count: 2 x (display index since the IDR) */
+    int dst;                  /* DPB slot that receives the reconstruction (0 .. dpb) */
+    int keep;                 /* 1: the picture will be referenced (half-pel planes and borders are built); 0: a non-reference b */
+    int nref[2];              /* active references of list 0 / list 1 */
+    int8_t slot[2][X264GPU_MAX_LIST];      /* DPB slot of reference index i of list l */
+} x264gpu_pic;
 
 int  x264gpu_encoder_create(x264gpu_encoder **enc, const x264gpu_config *cfg);
 void x264gpu_encoder_destroy(x264gpu_encoder *enc);
@@ -236,12 +255,19 @@ int  x264gpu_encoder_mb_count(const x264gpu_encoder *enc);
  * x264_macroblock_encode, x264_frame_deblock_row, x264_frame_filter of [x264-upstream]. */
 int  x264gpu_encode_frames(x264gpu_encoder *enc, const uint8_t *d_i420, int slice_type,
                            x264gpu_mb *d_mb, int16_t *d_levels, void *stream);
+/* The same with explicit picture control, one entry of `pics` (host array) per stream: B pictures, b-pyramid, per-stream slice types and
+ * quantisers.  Streams of different slice types are batched per type behind this call.  B pictures need a CABAC session with RD (cfg.cabac,
+ * cfg.rd).  x264gpu_encode_frames is this call with the sliding-window DPB of an I / P stream. */
+int  x264gpu_encode_pictures(x264gpu_encoder *enc, const uint8_t *d_i420, const x264gpu_pic *pics,
+                             x264gpu_mb *d_mb, int16_t *d_levels, void *stream);
 /* A9 as a primitive ([x264-upstream] common/deblock.c x264_frame_deblock_row over a whole picture): the in-loop filter alone on
  * `streams` given pictures (d_i420: I420, width and height multiples of 16) with given macroblock records, through the kernel the
  * frame pipeline launches; alpha / beta / chroma-qp offsets from the encoder's configuration.  d_out: the filtered pictures. */
 int x264gpu_encoder_deblock_pictures(x264gpu_encoder *e, const uint8_t *d_i420, const x264gpu_mb *d_mb, uint8_t *d_out, void *stream);
 /* copy the reconstructed (deblocked) picture of `stream_idx` out as I420 (for parity tests / PSNR) */
 int  x264gpu_encoder_get_recon(x264gpu_encoder *enc, int stream_idx, uint8_t *d_i420_out, void *stream);
+/* the same for the picture in DPB slot `slot` (x264gpu_encode_pictures sessions) */
+int  x264gpu_encoder_get_recon_slot(x264gpu_encoder *enc, int stream_idx, int slot, uint8_t *d_i420_out, void *stream);
 /* Per-stage device timing for bench.py (HIP events on the caller's stream, no host sync in the timed
  * region): profile_begin arms up to max_calls encode_frames calls; profile_end synchronises the stream
  * and returns, per stage, the summed milliseconds and the number of launches that ran. */

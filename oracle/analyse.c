@@ -23,7 +23,7 @@ static const uint8_t idx_of[4][4] = { { 0, 1, 4, 5 }, { 2, 3, 6, 7 }, { 8, 9, 12
 
 typedef struct {          /* x264_me_t */
     int w, h, ox, oy;     /* block inside the macroblock */
-    int ref, ref_cost;
+    int list, ref, ref_cost;
     int mvp[2], mv[2];
     int cost, cost_mv;
 } me_t;
@@ -40,7 +40,8 @@ typedef struct {          /* x264_mb_analysis_t + the parts of h->mb the analysi
     int chroma_me;
     int type_left, type_top, type_tl, type_tr;  /* neighbour macroblock types, -1 = unavailable */
     int partition;                              /* h->mb.i_partition: selects the directional predictor rules */
-    int cur_valid; nb_t cur8[4];                /* motion of this macroblock's 8x8 blocks decided so far (h->mb.cache) */
+    int cur_valid; nb_t cur8[4];                /* motion of this macroblock's 8x8 blocks decided so far (h->mb.cache), list 0 */
+    int cur_valid1; nb_t cur8b[4];              /* ... list 1 (B slices) */
     int pskip_mv[2];
     int b_fast_intra, b_try_skip, b_early_terminate;
     me_t me16, me8[4], me16x8[2], me8x16[2];
@@ -51,6 +52,15 @@ typedef struct {          /* x264_mb_analysis_t + the parts of h->mb the analysi
     int pred16, pred8[4], pred4[16], predc;
     /* RD mode decision (cfg.rd): x264_mb_analysis_t i_mbrd, l0.i_rd16x16, forced transform size of the candidate being costed */
     int mbrd, rd16x16, force_t8, lambda2, chroma_lambda2_offset;
+    /* B slices (x264_mb_analysis_t l0 / l1 and the bi / direct costs) */
+    int nref_l[2];
+    me_t me16l[2], bi16[2], me8l[2][4], me16x8l[2][2], me8x16l[2][2];
+    int mvcl[2][X264O_MAX_REFS][5][2];
+    int direct_ref[2], direct_mv[2][4][2];
+    int cost16x16bi, cost16x16direct, cost8x8direct[4], cost8x8bi, cost16x8bi, cost8x16bi;
+    int satd8x8b[3][4], cost_est16x8[2], cost_est8x16[2];
+    int sub8[4], part16x8[2], part8x16[2];      /* per block / half: 0 list 0, 1 list 1, 2 both, 3 direct (8x8 only) */
+    int rd16l[2], rd16bi, rd16direct, rd8x8bi, rd16x8bi, rd8x16bi, bskip_cost;
 } actx;
 
 /* ---------------------------------------------------------------------------------------------------------------------------
@@ -67,6 +77,10 @@ static int ref_cost(const actx *a, int r)       /* REF_COST(0, r): lambda * bs_s
 {
     return a->nref <= 1 ? 0 : a->lambda * (a->nref == 2 ? 1 : bs_size_ue(r));
 }
+static int ref_cost_l(const actx *a, int l, int r)       /* REF_COST(l, r) */
+{
+    return a->nref_l[l] <= 1 ? 0 : a->lambda * (a->nref_l[l] == 2 ? 1 : bs_size_ue(r));
+}
 
 static int mbcmp(const actx *a, const pixel *p, int sp, const pixel *q, int sq, int w, int h)
 {
@@ -77,19 +91,22 @@ static int mbcmp(const actx *a, const pixel *p, int sp, const pixel *q, int sq, 
  * motion vector prediction (common/mvpred.c) on an 8x8-granular motion cache (the smallest partition here is 8x8) */
 static int is_intra_type(int t) { return t >= 0 && t <= 3; }
 
-static nb_t nb8(const actx *a, int gx, int gy)
+static nb_t nb8l(const actx *a, int l, int gx, int gy)
 {
     nb_t n = { -2, { 0, 0 } };
     const x264o_encoder *e = a->e;
     if (gx < 0 || gy < 2 * e->row0 || gx >= 2 * e->mbw || gy >= 2 * e->mbh) return n;      /* outside the picture or the slice */
     const int i = (gy >> 1) * e->mbw + (gx >> 1), k = (gy & 1) * 2 + (gx & 1);
-    if (i == a->mi) { if (a->cur_valid >> k & 1) return a->cur8[k]; return n; }
+    if (i == a->mi) { if ((l ? a->cur_valid1 : a->cur_valid) >> k & 1) return l ? a->cur8b[k] : a->cur8[k]; return n; }
     if (i > a->mi) return n;
     const x264gpu_mb *m = &e->mbs[i];
     if (is_intra_type(m->type)) { n.ref = -1; return n; }
-    n.ref = m->ref[k]; n.mv[0] = m->mv[k][0]; n.mv[1] = m->mv[k][1];
+    /* a block that does not use the list has reference -1 and a zero vector in x264's cache */
+    if (l) { n.ref = m->ref1[k]; if (n.ref >= 0) { n.mv[0] = m->mv1[k][0]; n.mv[1] = m->mv1[k][1]; } else n.ref = -1; }
+    else { n.ref = m->ref[k]; if (n.ref >= 0) { n.mv[0] = m->mv[k][0]; n.mv[1] = m->mv[k][1]; } else n.ref = -1; }
     return n;
 }
+static nb_t nb8(const actx *a, int gx, int gy) { return nb8l(a, 0, gx, gy); }
 
 static void median_mv(int mvp[2], const nb_t *A, const nb_t *B, const nb_t *C)
 {
@@ -98,11 +115,11 @@ static void median_mv(int mvp[2], const nb_t *A, const nb_t *B, const nb_t *C)
 }
 
 /* x264_mb_predict_mv / _16x16: partition at 8x8 offset (bx8,by8), w8 blocks wide, of reference `ref` */
-static void predict_mv(const actx *a, int bx8, int by8, int w8, int ref, int mvp[2])
+static void predict_mv_l(const actx *a, int l, int bx8, int by8, int w8, int ref, int mvp[2])
 {
     const int gx = 2 * a->mbx + bx8, gy = 2 * a->mby + by8;
-    nb_t A = nb8(a, gx - 1, gy), B = nb8(a, gx, gy - 1), C = nb8(a, gx + w8, gy - 1);
-    if (C.ref == -2) C = nb8(a, gx - 1, gy - 1);
+    nb_t A = nb8l(a, l, gx - 1, gy), B = nb8l(a, l, gx, gy - 1), C = nb8l(a, l, gx + w8, gy - 1);
+    if (C.ref == -2) C = nb8l(a, l, gx - 1, gy - 1);
     if (a->partition == D_16x8) {
         if (by8 == 0) { if (B.ref == ref) { mvp[0] = B.mv[0]; mvp[1] = B.mv[1]; return; } }
         else if (A.ref == ref) { mvp[0] = A.mv[0]; mvp[1] = A.mv[1]; return; }
@@ -119,6 +136,8 @@ static void predict_mv(const actx *a, int bx8, int by8, int w8, int ref, int mvp
     else median_mv(mvp, &A, &B, &C);
 }
 
+static void predict_mv(const actx *a, int bx8, int by8, int w8, int ref, int mvp[2]) { predict_mv_l(a, 0, bx8, by8, w8, ref, mvp); }
+
 static void predict_mv_pskip(actx *a, int mv[2])
 {
     const int gx = 2 * a->mbx, gy = 2 * a->mby, part = a->partition;
@@ -130,13 +149,18 @@ static void predict_mv_pskip(actx *a, int mv[2])
 }
 
 /* x264_mb_predict_mv_ref16x16: search candidates of the 16x16 block in reference r */
-static int predict_mv_ref16x16(const actx *a, int r, int mvc[][2])
+static int16_t (*mvr_of(const x264o_encoder *e, int l, int r))[2] { return l ? e->mvr1[r] : r == 0 ? e->mv16[e->cur] : e->mvr[r]; }
+
+static int predict_mv_ref16x16_l(const actx *a, int l, int r, int mvc[][2])
 {
     const x264o_encoder *e = a->e;
-    int16_t (*mvr)[2] = r == 0 ? e->mv16[e->cur] : e->mvr[r];
+    int16_t (*mvr)[2] = mvr_of(e, l, r);
     int n = 0;
-    if (r == 0 && e->lowres_mv && e->lowres_mv[0] != 0x7fff) {          /* h->fenc->lowres_mvs[0][0]: one picture back */
-        mvc[n][0] = e->lowres_mv[2 * a->mi] * 2; mvc[n][1] = e->lowres_mv[2 * a->mi + 1] * 2; n++;
+    /* B slices: the direct vector of the last 8x8 block when it points into this reference (h->mb.cache still holds the direct prediction) */
+    if (e->slice_type == X264GPU_SLICE_B && a->direct_ref[l] == r) { mvc[n][0] = a->direct_mv[l][3][0]; mvc[n][1] = a->direct_mv[l][3][1]; n++; }
+    const int16_t *lowres = l ? e->lowres_mv1 : e->lowres_mv;
+    if (r == 0 && lowres && lowres[0] != 0x7fff) {          /* h->fenc->lowres_mvs[l][distance - 1] */
+        mvc[n][0] = lowres[2 * a->mi] * 2; mvc[n][1] = lowres[2 * a->mi + 1] * 2; n++;
     }
     /* spatial: left, top, top-left, top-right 16x16 results in THIS reference; a missing neighbour reads the zero entry in front of the array */
     const int nbi[4] = { a->type_left >= 0 ? a->mi - 1 : -1, a->type_top >= 0 ? a->mi - e->mbw : -1,
@@ -147,7 +171,7 @@ static int predict_mv_ref16x16(const actx *a, int r, int mvc[][2])
     /* temporal: the co-located macroblock of reference 0 and its right / lower neighbour, scaled by the POC distances */
     const int s0 = ref_slot(e, 0);
     if (e->slot_nref[s0] > 0) {
-        const int curpoc = e->poc, refpoc = e->slot_poc[ref_slot(e, r)];
+        const int curpoc = e->poc, refpoc = e->slot_poc[ref_slot_l(e, l, r)];
         const int delta = e->slot_poc[s0] - e->slot_ref0poc[s0];      /* l0's own distance to its reference 0 */
         const int inv = (256 + delta / 2) / delta, scale = (curpoc - refpoc) * inv;
         const int16_t (*l0)[2] = e->mv16[s0];
@@ -157,6 +181,7 @@ static int predict_mv_ref16x16(const actx *a, int r, int mvc[][2])
     }
     return n;
 }
+static int predict_mv_ref16x16(const actx *a, int r, int mvc[][2]) { return predict_mv_ref16x16_l(a, 0, r, mvc); }
 
 /* ---------------------------------------------------------------------------------------------------------------------------
  * motion search (encoder/me.c) */
@@ -271,7 +296,7 @@ static void sctx_init(sctx *s, const actx *a, me_t *m)
     const x264o_encoder *e = a->e;
     s->a = a; s->m = m;
     s->fenc = e->fenc_y + (size_t)(a->mby * 16 + m->oy) * e->fs + a->mbx * 16 + m->ox;
-    s->refslot = ref_slot(e, m->ref);
+    s->refslot = ref_slot_l(e, m->list, m->ref);
     for (int k = 0; k < 4; k++) s->planes[k] = luma_plane(e, s->refslot, k);
     s->full = s->planes[0] + (size_t)(a->mby * 16 + m->oy) * e->rs + a->mbx * 16 + m->ox;
     s->cmx = a->cost_mv - m->mvp[0]; s->cmy = a->cost_mv - m->mvp[1];
@@ -725,6 +750,24 @@ static void mc_mb(x264o_encoder *e, int mbx, int mby, int bx, int by, int w, int
     x264o_mc_chroma(du + (by / 2) * sc + bx / 2, dv + (by / 2) * sc + bx / 2, sc, chroma_plane(e, refslot), e->rs, mbx * 8 + bx / 2, mby * 8 + by / 2, mvx, mvy, w / 2, h / 2);
 }
 
+/* x264_mb_mc of a B macroblock: per 8x8 block from list 0, list 1, or both averaged with the pair's implicit weight (mb_mc_01xywh) */
+static void mc_mb_b(x264o_encoder *e, int mbx, int mby, const x264gpu_mb *mb, pixel *dy, int sy, pixel *du, pixel *dv)
+{
+    for (int k = 0; k < 4; k++) {
+        const int bx = (k & 1) * 8, by = (k >> 1) * 8, r0 = mb->ref[k], r1 = mb->ref1[k];
+        if (r0 >= 0 && r1 >= 0) {
+            pixel y0[64], y1[64], u0[16], v0[16], u1[16], v1[16];
+            mc_mb(e, mbx, mby, bx, by, 8, 8, ref_slot_l(e, 0, r0), mb->mv[k][0], mb->mv[k][1], y0 - by * 8 - bx, 8, u0 - (by / 2) * 4 - bx / 2, v0 - (by / 2) * 4 - bx / 2, 4);
+            mc_mb(e, mbx, mby, bx, by, 8, 8, ref_slot_l(e, 1, r1), mb->mv1[k][0], mb->mv1[k][1], y1 - by * 8 - bx, 8, u1 - (by / 2) * 4 - bx / 2, v1 - (by / 2) * 4 - bx / 2, 4);
+            const int w = e->bipred_weight[r0][r1];
+            x264o_pixel_avg_weight(dy + by * sy + bx, sy, y0, 8, y1, 8, 8, 8, w);
+            x264o_pixel_avg_weight(du + (by / 2) * 8 + bx / 2, 8, u0, 4, u1, 4, 4, 4, w);
+            x264o_pixel_avg_weight(dv + (by / 2) * 8 + bx / 2, 8, v0, 4, v1, 4, 4, 4, w);
+        } else if (r0 >= 0) mc_mb(e, mbx, mby, bx, by, 8, 8, ref_slot_l(e, 0, r0), mb->mv[k][0], mb->mv[k][1], dy, sy, du, dv, 8);
+        else mc_mb(e, mbx, mby, bx, by, 8, 8, ref_slot_l(e, 1, r1), mb->mv1[k][0], mb->mv1[k][1], dy, sy, du, dv, 8);
+    }
+}
+
 static int probe_pskip(const actx *a)
 {
     x264o_encoder *e = a->e;
@@ -799,7 +842,7 @@ static int analyse_inter_p16x16(actx *a)
     int mvc[8][2];
     int i_halfpel_thresh = 0x7fffffff;
     int *p_halfpel_thresh = (a->b_early_terminate && a->nref > 1) ? &i_halfpel_thresh : NULL;
-    m.w = m.h = 16; m.ox = m.oy = 0;
+    m.w = m.h = 16; m.ox = m.oy = 0; m.list = 0;
     a->me16.cost = 0x7fffffff;
     a->partition = D_16x16;
     for (int r = 0; r < a->nref; r++) {
@@ -850,7 +893,7 @@ static void analyse_inter_p8x8_mixed_ref(actx *a)
     for (int i = 0; i < 4; i++) {
         me_t *l0m = &a->me8[i], m;
         const int x8 = i & 1, y8 = i >> 1;
-        m.w = m.h = 8; m.ox = 8 * x8; m.oy = 8 * y8;
+        m.w = m.h = 8; m.ox = 8 * x8; m.oy = 8 * y8; m.list = 0;
         l0m->cost = 0x7fffffff;
         for (int r = 0; r <= i_maxref; r++) {
             m.ref = r; m.ref_cost = ref_cost(a, r);
@@ -905,7 +948,7 @@ static void analyse_inter_p16x8(actx *a, int i_best_satd)
         const int r0 = a->me8[2 * i].ref, r1 = a->me8[2 * i + 1].ref;
         const int ref8[2] = { r0 < r1 ? r0 : r1, r0 < r1 ? r1 : r0 };
         const int i_ref8s = ref8[0] == ref8[1] ? 1 : 2;
-        m.w = 16; m.h = 8; m.ox = 0; m.oy = 8 * i;
+        m.w = 16; m.h = 8; m.ox = 0; m.oy = 8 * i; m.list = 0;
         l0m->cost = 0x7fffffff;
         for (int j = 0; j < i_ref8s; j++) {
             const int r = ref8[j];
@@ -934,7 +977,7 @@ static void analyse_inter_p8x16(actx *a, int i_best_satd)
         const int r0 = a->me8[i].ref, r1 = a->me8[i + 2].ref;
         const int ref8[2] = { r0 < r1 ? r0 : r1, r0 < r1 ? r1 : r0 };
         const int i_ref8s = ref8[0] == ref8[1] ? 1 : 2;
-        m.w = 8; m.h = 16; m.ox = 8 * i; m.oy = 0;
+        m.w = 8; m.h = 16; m.ox = 8 * i; m.oy = 0; m.list = 0;
         l0m->cost = 0x7fffffff;
         for (int j = 0; j < i_ref8s; j++) {
             const int r = ref8[j];
@@ -1258,11 +1301,13 @@ static void encode_inter_mb(actx *a, x264gpu_mb *mb, int16_t *lv)
     pixel *rec_uv = chroma_plane(e, e->cur) + (size_t)mby * 8 * e->rs + mbx * 16;
     const pixel *fenc = e->fenc_y + (size_t)mby * 16 * e->fs + mbx * 16;
     pixel pu[64], pv[64];
+    if (mb->type >= X264GPU_MB_B_DIRECT) mc_mb_b(e, mbx, mby, mb, rec, e->rs, pu, pv);
+    else
     for (int k = 0; k < 4; k++)       /* motion compensation per 8x8 quadrant (covers 16x16 / 16x8 / 8x16 / 8x8) */
         mc_mb(e, mbx, mby, (k & 1) * 8, (k >> 1) * 8, 8, 8, ref_slot(e, mb->ref[k]), mb->mv[k][0], mb->mv[k][1], rec, e->rs, pu, pv, 8);
     for (int y = 0; y < 8; y++)
         for (int x = 0; x < 8; x++) { rec_uv[y * e->rs + 2 * x] = pu[y * 8 + x]; rec_uv[y * e->rs + 2 * x + 1] = pv[y * 8 + x]; }
-    if (mb->type == X264GPU_MB_P_SKIP) return;                /* x264_macroblock_encode_skip: the prediction is the reconstruction */
+    if (mb->type == X264GPU_MB_P_SKIP || mb->type == X264GPU_MB_B_SKIP) return;                /* x264_macroblock_encode_skip: the prediction is the reconstruction */
     /* x264_mb_analyse_transform: SA8D vs SATD of the prediction error */
     mb->transform8x8 = 0;
     if (a->force_t8 >= 0) mb->transform8x8 = (uint8_t)a->force_t8;          /* RD: the transform size is a candidate property (x264_mb_analyse_transform_rd) */
@@ -1274,6 +1319,8 @@ static void encode_inter_mb(actx *a, x264gpu_mb *mb, int16_t *lv)
     /* P_L0 16x16, reference 0, skip vector, nothing coded: P_SKIP */
     if (mb->type == X264GPU_MB_P_L0 && mb->partition == D_16x16 && !(mb->cbp_luma | mb->cbp_chroma) && mb->ref[0] == 0 &&
         mb->mv[0][0] == a->pskip_mv[0] && mb->mv[0][1] == a->pskip_mv[1]) mb->type = X264GPU_MB_P_SKIP;
+    /* B_DIRECT with nothing coded: B_SKIP */
+    if (mb->type == X264GPU_MB_B_DIRECT && !(mb->cbp_luma | mb->cbp_chroma)) mb->type = X264GPU_MB_B_SKIP;
 }
 
 /* ---------------------------------------------------------------------------------------------------------------------------
@@ -1405,6 +1452,8 @@ static void cabac_ctx_of(const actx *a, x264o_cabac_ctx *cc, uint8_t *state)
     cc->mbs = e->mbs; cc->levels = e->levels; cc->mbw = e->mbw; cc->mbh = e->mbh; cc->first_row = e->row0;
     cc->pslice = e->slice_type == X264GPU_SLICE_P; cc->num_ref = e->nref; cc->t8mode = e->cfg.dct8x8;
     cc->amvd = e->amvd; cc->state = state; cc->last_dqp = e->last_dqp; cc->last_qp = e->last_qp;
+    cc->bslice = e->slice_type == X264GPU_SLICE_B; cc->num_ref1 = e->nref_l[1]; cc->amvd1 = e->amvd1;
+    if (cc->bslice) cc->pslice = 1;      /* an inter slice: the P / B context initialisation */
 }
 
 static void rd_reset(const actx *a, x264gpu_mb *mb, int16_t *lv)
@@ -1417,7 +1466,7 @@ static void rd_reset(const actx *a, x264gpu_mb *mb, int16_t *lv)
 static int rd_finish(actx *a, x264gpu_mb *mb, int16_t *lv)
 {
     const int ssd = rd_ssd_mb(a);
-    if (mb->type == X264GPU_MB_P_SKIP) return ssd + ((a->lambda2 + 128) >> 8);
+    if (mb->type == X264GPU_MB_P_SKIP || mb->type == X264GPU_MB_B_SKIP) return ssd + ((a->lambda2 + 128) >> 8);
     if (a->e->cfg.cabac) {
         /* x264_rd_cost_mb under CABAC: the macroblock's syntax priced on a copy of the slice's context states, 1/256 bit units */
         uint8_t st[460];
@@ -1470,6 +1519,540 @@ static void analyse_p_rd(actx *a, int i_satd, x264gpu_mb *mb, int16_t *lv)
     a->cost8x8 = a->cost8x8 < thresh ? rd_cost_inter(a, D_8x8, 0, mb, lv) : COST_MAX;
 }
 
+/* ===========================================================================================================================
+ * B slices ([x264-upstream] encoder/analyse.c x264_macroblock_analyse, SLICE_TYPE_B branch with i_mbrd 1: x264_mb_predict_mv_direct16x16
+ * (spatial), x264_mb_analyse_inter_direct / _b16x16 / _b8x8_mixed_ref / _b8x8 / _b16x8 / _b8x16, x264_mb_analyse_b_rd, x264_refine_bidir;
+ * encoder/me.c x264_me_refine_bidir_satd).  Restated from memory (oracle/BFRAME_NOTES.md): parity unpinned.  RD sessions only. */
+static const uint8_t mb_b_cost_direct = 1, mb_b_cost_l0 = 3, mb_b_cost_l1 = 3, mb_b_cost_bi = 5, mb_b_cost_8x8 = 9;      /* i_mb_b_cost_table */
+static const uint8_t sub_b_cost[4] = { 3, 3, 5, 1 };                          /* i_sub_mb_b_cost_table: L0_8x8, L1_8x8, BI_8x8, DIRECT_8x8 */
+/* i_mb_b16x8_cost_table[B_L0_L0 + 3 * first + second]: first / second half from list 0, list 1, both */
+static const uint8_t mb_b16x8_cost[9] = { 5, 7, 7, 7, 5, 7, 9, 9, 9 };
+
+static void cache_block_l(actx *a, int l, int bx8, int by8, int w8, int h8, int ref, const int mv[2])
+{
+    for (int y = by8; y < by8 + h8; y++)
+        for (int x = bx8; x < bx8 + w8; x++) {
+            nb_t *n = l ? &a->cur8b[y * 2 + x] : &a->cur8[y * 2 + x];
+            n->ref = ref;
+            if (mv) { n->mv[0] = mv[0]; n->mv[1] = mv[1]; } else if (ref < 0) n->mv[0] = n->mv[1] = 0;
+            if (l) a->cur_valid1 |= 1 << (y * 2 + x); else a->cur_valid |= 1 << (y * 2 + x);
+        }
+}
+
+/* x264_mb_predict_mv_direct16x16, spatial mode (8.4.1.2.2): a->direct_ref[], a->direct_mv[][8x8 block][] */
+static void predict_direct_spatial(actx *a)
+{
+    const x264o_encoder *e = a->e;
+    const int gx = 2 * a->mbx, gy = 2 * a->mby;
+    int ref[2], mv[2][2];
+    for (int l = 0; l < 2; l++) {
+        nb_t A = nb8l(a, l, gx - 1, gy), B = nb8l(a, l, gx, gy - 1), C = nb8l(a, l, gx + 2, gy - 1);
+        if (C.ref == -2) C = nb8l(a, l, gx - 1, gy - 1);
+        unsigned r = (unsigned)A.ref < (unsigned)B.ref ? (unsigned)A.ref : (unsigned)B.ref;      /* the smallest index in use: negatives are the largest */
+        if ((unsigned)C.ref < r) r = (unsigned)C.ref;
+        int i_ref = (int)r;
+        mv[l][0] = mv[l][1] = 0;
+        if (i_ref < 0) i_ref = -1;
+        else {
+            const int cnt = (A.ref == i_ref) + (B.ref == i_ref) + (C.ref == i_ref);
+            if (cnt > 1) median_mv(mv[l], &A, &B, &C);
+            else { const nb_t *s = A.ref == i_ref ? &A : B.ref == i_ref ? &B : &C; mv[l][0] = s->mv[0]; mv[l][1] = s->mv[1]; }
+        }
+        ref[l] = i_ref;
+    }
+    if (ref[0] < 0 && ref[1] < 0) ref[0] = ref[1] = 0;       /* nothing around: both lists, index 0, zero vectors */
+    for (int l = 0; l < 2; l++) { a->direct_ref[l] = ref[l]; for (int k = 0; k < 4; k++) { a->direct_mv[l][k][0] = mv[l][0]; a->direct_mv[l][k][1] = mv[l][1]; } }
+    if (!(mv[0][0] | mv[0][1] | mv[1][0] | mv[1][1]) || (ref[0] && ref[1])) return;
+    /* colZeroFlag per 8x8 block (direct_8x8_inference: its corner): the co-located block of list 1's first picture points into ITS reference 0
+     * with a vector within +-1 -> the vectors of the lists whose direct reference is 0 become zero */
+    const int cs = ref_slot_l(e, 1, 0);
+    for (int k = 0; k < 4; k++) {
+        if (e->colref[cs][a->mi][k] != 0) continue;
+        if (abs(e->colmv[cs][a->mi][k][0]) > 1 || abs(e->colmv[cs][a->mi][k][1]) > 1) continue;
+        for (int l = 0; l < 2; l++) if (ref[l] == 0) a->direct_mv[l][k][0] = a->direct_mv[l][k][1] = 0;
+    }
+}
+
+static void set_direct_record(const actx *a, x264gpu_mb *mb, int k)
+{
+    mb->ref[k] = (int8_t)a->direct_ref[0]; mb->ref1[k] = (int8_t)a->direct_ref[1];
+    mb->mv[k][0] = (int16_t)(a->direct_ref[0] < 0 ? 0 : a->direct_mv[0][k][0]); mb->mv[k][1] = (int16_t)(a->direct_ref[0] < 0 ? 0 : a->direct_mv[0][k][1]);
+    mb->mv1[k][0] = (int16_t)(a->direct_ref[1] < 0 ? 0 : a->direct_mv[1][k][0]); mb->mv1[k][1] = (int16_t)(a->direct_ref[1] < 0 ? 0 : a->direct_mv[1][k][1]);
+}
+
+/* the record of a B candidate: type / partition / per-block list use from the analysis state (x264_analyse_update_cache) */
+static void fill_b_record(const actx *a, int type, int partition, x264gpu_mb *mb)
+{
+    mb->type = (uint8_t)type; mb->partition = (uint8_t)partition; mb->direct8 = 0;
+    for (int k = 0; k < 4; k++) {
+        int use;      /* 0 list 0, 1 list 1, 2 both, 3 direct */
+        const me_t *m0, *m1;
+        if (type == X264GPU_MB_B_DIRECT || type == X264GPU_MB_B_SKIP) use = 3;
+        else if (partition == D_16x16) use = a->sub8[0];      /* fill_b16: sub8[0] carries L0 / L1 / BI of the 16x16 candidate */
+        else if (partition == D_16x8) use = a->part16x8[k >> 1];
+        else if (partition == D_8x16) use = a->part8x16[k & 1];
+        else use = a->sub8[k];
+        if (use == 3) { set_direct_record(a, mb, k); mb->direct8 |= (uint8_t)(1 << k); continue; }
+        if (partition == D_16x16) { m0 = use == 2 ? &a->bi16[0] : &a->me16l[0]; m1 = use == 2 ? &a->bi16[1] : &a->me16l[1]; }
+        else if (partition == D_16x8) { m0 = &a->me16x8l[0][k >> 1]; m1 = &a->me16x8l[1][k >> 1]; }
+        else if (partition == D_8x16) { m0 = &a->me8x16l[0][k & 1]; m1 = &a->me8x16l[1][k & 1]; }
+        else { m0 = &a->me8l[0][k]; m1 = &a->me8l[1][k]; }
+        mb->ref[k] = -1; mb->ref1[k] = -1; mb->mv[k][0] = mb->mv[k][1] = 0; mb->mv1[k][0] = mb->mv1[k][1] = 0;
+        if (use != 1) { mb->ref[k] = (int8_t)m0->ref; mb->mv[k][0] = (int16_t)m0->mv[0]; mb->mv[k][1] = (int16_t)m0->mv[1]; }
+        if (use != 0) { mb->ref1[k] = (int8_t)m1->ref; mb->mv1[k][0] = (int16_t)m1->mv[0]; mb->mv1[k][1] = (int16_t)m1->mv[1]; }
+    }
+}
+
+/* x264_rd_cost_mb of a B candidate (transform size t8) */
+static int rd_cost_b(actx *a, int type, int partition, int use16, int t8, x264gpu_mb *mb, int16_t *lv)
+{
+    rd_reset(a, mb, lv);
+    const int bak = a->sub8[0];
+    if (partition == D_16x16 && type == X264GPU_MB_B_INTER) a->sub8[0] = use16;
+    fill_b_record(a, type, partition, mb);
+    a->sub8[0] = bak;
+    a->force_t8 = t8;
+    encode_inter_mb(a, mb, lv);
+    a->force_t8 = -1;
+    return rd_finish(a, mb, lv);
+}
+
+/* the average of two motion-compensated blocks (get_ref x 2 + mc.avg) */
+static void bi_pred(const actx *a, const me_t *m0, const me_t *m1, pixel *dst /* stride 16 */)
+{
+    const x264o_encoder *e = a->e;
+    pixel p0[256], p1[256];
+    sctx S;
+    sctx_init(&S, a, (me_t *)m0); get_ref(&S, p0, m0->mv[0], m0->mv[1]);
+    sctx_init(&S, a, (me_t *)m1); get_ref(&S, p1, m1->mv[0], m1->mv[1]);
+    x264o_pixel_avg_weight(dst, 16, p0, 16, p1, 16, m0->w, m0->h, e->bipred_weight[m0->ref][m1->ref]);
+}
+/* analyse_bi_chroma: the chroma share of a bi-predicted block's SATD cost */
+static int bi_chroma(const actx *a, const me_t *m0, const me_t *m1)
+{
+    const x264o_encoder *e = a->e;
+    pixel u0[64], v0[64], u1[64], v1[64], bu[64], bv[64], fu[64], fv[64];
+    const int cw = m0->w / 2, ch = m0->h / 2;
+    const pixel *fuv = e->fenc_uv + (size_t)(a->mby * 8 + m0->oy / 2) * e->fs + a->mbx * 16 + m0->ox;
+    for (int y = 0; y < ch; y++) for (int x = 0; x < cw; x++) { fu[y * 8 + x] = fuv[y * e->fs + 2 * x]; fv[y * 8 + x] = fuv[y * e->fs + 2 * x + 1]; }
+    x264o_mc_chroma(u0, v0, 8, chroma_plane(e, ref_slot_l(e, 0, m0->ref)), e->rs, a->mbx * 8 + m0->ox / 2, a->mby * 8 + m0->oy / 2, m0->mv[0], m0->mv[1], cw, ch);
+    x264o_mc_chroma(u1, v1, 8, chroma_plane(e, ref_slot_l(e, 1, m1->ref)), e->rs, a->mbx * 8 + m1->ox / 2, a->mby * 8 + m1->oy / 2, m1->mv[0], m1->mv[1], cw, ch);
+    x264o_pixel_avg_weight(bu, 8, u0, 8, u1, 8, cw, ch, e->bipred_weight[m0->ref][m1->ref]);
+    x264o_pixel_avg_weight(bv, 8, v0, 8, v1, 8, cw, ch, e->bipred_weight[m0->ref][m1->ref]);
+    return mbcmp(a, fu, 8, bu, 8, cw, ch) + mbcmp(a, fv, 8, bv, 8, cw, ch);
+}
+
+/* x264_mb_analyse_inter_direct: the direct prediction is in the reconstruction buffers */
+static void analyse_inter_direct(actx *a)
+{
+    const x264o_encoder *e = a->e;
+    const pixel *fenc = e->fenc_y + (size_t)a->mby * 16 * e->fs + a->mbx * 16, *fuv = e->fenc_uv + (size_t)a->mby * 8 * e->fs + a->mbx * 16;
+    const pixel *rec = luma_plane((x264o_encoder *)e, e->cur, 0) + (size_t)a->mby * 16 * e->rs + a->mbx * 16;
+    const pixel *ruv = chroma_plane((x264o_encoder *)e, e->cur) + (size_t)a->mby * 8 * e->rs + a->mbx * 16;
+    a->cost16x16direct = a->lambda * mb_b_cost_direct;
+    if (e->cfg.partitions & 1) {
+        for (int i = 0; i < 4; i++) {
+            const int x = (i & 1) * 8, y = (i >> 1) * 8;
+            a->cost8x8direct[i] = mbcmp(a, fenc + y * e->fs + x, e->fs, rec + y * e->rs + x, e->rs, 8, 8);
+            if (a->chroma_me) {
+                pixel fu[16], fv[16], pu[16], pv[16];
+                for (int r = 0; r < 4; r++) for (int c = 0; c < 4; c++) {
+                    fu[r * 4 + c] = fuv[(y / 2 + r) * e->fs + 2 * (x / 2 + c)]; fv[r * 4 + c] = fuv[(y / 2 + r) * e->fs + 2 * (x / 2 + c) + 1];
+                    pu[r * 4 + c] = ruv[(y / 2 + r) * e->rs + 2 * (x / 2 + c)]; pv[r * 4 + c] = ruv[(y / 2 + r) * e->rs + 2 * (x / 2 + c) + 1];
+                }
+                a->cost8x8direct[i] += mbcmp(a, fu, 4, pu, 4, 4, 4) + mbcmp(a, fv, 4, pv, 4, 4, 4);
+            }
+            a->cost16x16direct += a->cost8x8direct[i];
+            a->cost8x8direct[i] += a->lambda * sub_b_cost[3];
+        }
+    } else {
+        a->cost16x16direct += mbcmp(a, fenc, e->fs, rec, e->rs, 16, 16);
+        if (a->chroma_me) {
+            pixel fu[64], fv[64], pu[64], pv[64];
+            for (int r = 0; r < 8; r++) for (int c = 0; c < 8; c++) {
+                fu[r * 8 + c] = fuv[r * e->fs + 2 * c]; fv[r * 8 + c] = fuv[r * e->fs + 2 * c + 1];
+                pu[r * 8 + c] = ruv[r * e->rs + 2 * c]; pv[r * 8 + c] = ruv[r * e->rs + 2 * c + 1];
+            }
+            a->cost16x16direct += mbcmp(a, fu, 8, pu, 8, 8, 8) + mbcmp(a, fv, 8, pv, 8, 8, 8);
+        }
+    }
+}
+
+/* x264_mb_analyse_inter_b16x16 (RD sessions: b_try_skip is off, so the lists are searched list 1 first, every reference) */
+static void analyse_inter_b16x16(actx *a)
+{
+    x264o_encoder *e = a->e;
+    int mvc[9][2];
+    a->partition = D_16x16;
+    a->me16l[0].cost = a->me16l[1].cost = 0x7fffffff;
+    for (int l = 1; l >= 0; l--) {
+        int i_halfpel_thresh = 0x7fffffff;
+        int *p_halfpel_thresh = (a->b_early_terminate && a->nref_l[l] > 1) ? &i_halfpel_thresh : NULL;
+        for (int r = 0; r < a->nref_l[l]; r++) {
+            me_t m;
+            memset(&m, 0, sizeof(m));
+            m.w = m.h = 16; m.list = l; m.ref = r; m.ref_cost = ref_cost_l(a, l, r);
+            a->cur_valid = a->cur_valid1 = 0;
+            predict_mv_l(a, l, 0, 0, 2, r, m.mvp);
+            const int i_mvc = predict_mv_ref16x16_l(a, l, r, mvc);
+            me_search_ref(a, &m, mvc, i_mvc, p_halfpel_thresh);
+            m.cost += m.ref_cost;
+            if (m.cost < a->me16l[l].cost) a->me16l[l] = m;
+            a->mvcl[l][r][0][0] = m.mv[0]; a->mvcl[l][r][0][1] = m.mv[1];
+            int16_t (*mvr)[2] = mvr_of(e, l, r);
+            mvr[a->mi][0] = (int16_t)m.mv[0]; mvr[a->mi][1] = (int16_t)m.mv[1];
+        }
+    }
+    /* the bi-predictive 16x16: both lists' winners averaged */
+    a->bi16[0] = a->me16l[0]; a->bi16[1] = a->me16l[1];
+    const pixel *fenc = e->fenc_y + (size_t)a->mby * 16 * e->fs + a->mbx * 16;
+    const int ref_costs = ref_cost_l(a, 0, a->bi16[0].ref) + ref_cost_l(a, 1, a->bi16[1].ref);
+    pixel pix[256];
+    bi_pred(a, &a->bi16[0], &a->bi16[1], pix);
+    a->cost16x16bi = mbcmp(a, fenc, e->fs, pix, 16, 16, 16) + ref_costs + a->bi16[0].cost_mv + a->bi16[1].cost_mv;
+    if (a->chroma_me) a->cost16x16bi += bi_chroma(a, &a->bi16[0], &a->bi16[1]);
+    /* always try the zero vectors */
+    if (a->bi16[0].mv[0] | a->bi16[0].mv[1] | a->bi16[1].mv[0] | a->bi16[1].mv[1]) {
+        const int l0_mv_cost = a->cost_mv[-a->bi16[0].mvp[0]] + a->cost_mv[-a->bi16[0].mvp[1]];
+        const int l1_mv_cost = a->cost_mv[-a->bi16[1].mvp[0]] + a->cost_mv[-a->bi16[1].mvp[1]];
+        me_t z0 = a->bi16[0], z1 = a->bi16[1];
+        z0.mv[0] = z0.mv[1] = z1.mv[0] = z1.mv[1] = 0;
+        bi_pred(a, &z0, &z1, pix);
+        int cost00 = mbcmp(a, fenc, e->fs, pix, 16, 16, 16) + ref_costs + l0_mv_cost + l1_mv_cost;
+        if (a->chroma_me && cost00 < a->cost16x16bi) cost00 += bi_chroma(a, &z0, &z1);
+        if (cost00 < a->cost16x16bi) {
+            a->bi16[0].mv[0] = a->bi16[0].mv[1] = a->bi16[1].mv[0] = a->bi16[1].mv[1] = 0;
+            a->bi16[0].cost_mv = l0_mv_cost; a->bi16[1].cost_mv = l1_mv_cost;
+            a->cost16x16bi = cost00;
+        }
+    }
+    a->cost16x16bi += a->lambda * mb_b_cost_bi;
+    a->me16l[0].cost += a->lambda * mb_b_cost_l0;
+    a->me16l[1].cost += a->lambda * mb_b_cost_l1;
+}
+
+/* mb_cache_mv_b8x8 / _b16x8 / _b8x16 without the mvd side: the block's part of both lists' motion cache */
+static void cache_b_block(actx *a, int bx8, int by8, int w8, int h8, int use, const me_t *m0, const me_t *m1, int k_direct)
+{
+    if (use == 3) {
+        for (int l = 0; l < 2; l++) cache_block_l(a, l, bx8, by8, w8, h8, a->direct_ref[l], a->direct_ref[l] < 0 ? NULL : a->direct_mv[l][k_direct]);
+        return;
+    }
+    if (use != 1) cache_block_l(a, 0, bx8, by8, w8, h8, m0->ref, m0->mv); else cache_block_l(a, 0, bx8, by8, w8, h8, -1, NULL);
+    if (use != 0) cache_block_l(a, 1, bx8, by8, w8, h8, m1->ref, m1->mv); else cache_block_l(a, 1, bx8, by8, w8, h8, -1, NULL);
+}
+
+/* x264_mb_analyse_inter_b8x8_mixed_ref / x264_mb_analyse_inter_b8x8 */
+static void analyse_inter_b8x8(actx *a)
+{
+    x264o_encoder *e = a->e;
+    const int mixed = e->cfg.mixed_refs;
+    int i_maxref[2] = { a->nref_l[0] - 1, a->nref_l[1] - 1 };
+    if (mixed)
+        for (int l = 0; l < 2; l++)
+            if (i_maxref[l] > 0 && a->me16l[l].ref == 0 && a->type_top > 0 && a->type_left > 0) {
+                const int gx = 2 * a->mbx, gy = 2 * a->mby;
+                const nb_t n[6] = { nb8l(a, l, gx - 1, gy - 1), nb8l(a, l, gx, gy - 1), nb8l(a, l, gx + 1, gy - 1), nb8l(a, l, gx + 2, gy - 1), nb8l(a, l, gx - 1, gy), nb8l(a, l, gx - 1, gy + 1) };
+                i_maxref[l] = 0;
+                for (int i = 0; i < 6; i++) if (n[i].ref > i_maxref[l]) i_maxref[l] = n[i].ref;
+            }
+    a->partition = D_8x8;
+    a->cost8x8bi = 0;
+    a->cur_valid = a->cur_valid1 = 0;
+    for (int i = 0; i < 4; i++) {
+        const int x8 = i & 1, y8 = i >> 1;
+        const pixel *fenc = e->fenc_y + (size_t)(a->mby * 16 + 8 * y8) * e->fs + a->mbx * 16 + 8 * x8;
+        for (int l = 0; l < 2; l++) {
+            me_t *lm = &a->me8l[l][i];
+            if (mixed) {
+                lm->cost = 0x7fffffff;
+                for (int r = 0; r <= i_maxref[l]; r++) {
+                    me_t m;
+                    memset(&m, 0, sizeof(m));
+                    m.w = m.h = 8; m.ox = 8 * x8; m.oy = 8 * y8; m.list = l; m.ref = r; m.ref_cost = ref_cost_l(a, l, r);
+                    (l ? a->cur8b : a->cur8)[i].ref = r;
+                    predict_mv_l(a, l, x8, y8, 1, r, m.mvp);
+                    me_search_ref(a, &m, a->mvcl[l][r], i + 1, NULL);
+                    m.cost += m.ref_cost;
+                    if (m.cost < lm->cost) { *lm = m; a->satd8x8b[l][i] = m.cost - (m.cost_mv + m.ref_cost); }
+                    a->mvcl[l][r][i + 1][0] = m.mv[0]; a->mvcl[l][r][i + 1][1] = m.mv[1];
+                }
+            } else {
+                const int r = a->me16l[l].ref;
+                int mvc1[1][2] = { { a->me16l[l].mv[0], a->me16l[l].mv[1] } };
+                memset(lm, 0, sizeof(*lm));
+                lm->w = lm->h = 8; lm->ox = 8 * x8; lm->oy = 8 * y8; lm->list = l; lm->ref = r; lm->ref_cost = ref_cost_l(a, l, r);
+                (l ? a->cur8b : a->cur8)[i].ref = r;
+                predict_mv_l(a, l, x8, y8, 1, r, lm->mvp);
+                me_search_ref(a, lm, mvc1, 1, NULL);
+                a->satd8x8b[l][i] = lm->cost - lm->cost_mv;
+                lm->cost += lm->ref_cost;
+                cache_block_l(a, l, x8, y8, 1, 1, r, lm->mv);
+                a->mvcl[l][r][i + 1][0] = lm->mv[0]; a->mvcl[l][r][i + 1][1] = lm->mv[1];
+            }
+        }
+        /* both lists */
+        pixel pix[256];
+        bi_pred(a, &a->me8l[0][i], &a->me8l[1][i], pix);
+        a->satd8x8b[2][i] = mbcmp(a, fenc, e->fs, pix, 16, 8, 8);
+        int i_part_cost_bi = a->satd8x8b[2][i] + a->me8l[0][i].cost_mv + a->me8l[1][i].cost_mv + a->me8l[0][i].ref_cost + a->me8l[1][i].ref_cost + a->lambda * sub_b_cost[2];
+        if (a->chroma_me) { const int cc = bi_chroma(a, &a->me8l[0][i], &a->me8l[1][i]); i_part_cost_bi += cc; a->satd8x8b[2][i] += cc; }
+        a->me8l[0][i].cost += a->lambda * sub_b_cost[0];
+        a->me8l[1][i].cost += a->lambda * sub_b_cost[1];
+        int i_part_cost = a->me8l[0][i].cost;
+        a->sub8[i] = 0;
+        if (a->me8l[1][i].cost < i_part_cost) { i_part_cost = a->me8l[1][i].cost; a->sub8[i] = 1; }
+        if (i_part_cost_bi < i_part_cost) { i_part_cost = i_part_cost_bi; a->sub8[i] = 2; }
+        if (a->cost8x8direct[i] < i_part_cost) { i_part_cost = a->cost8x8direct[i]; a->sub8[i] = 3; }
+        a->cost8x8bi += i_part_cost;
+        cache_b_block(a, x8, y8, 1, 1, a->sub8[i], &a->me8l[0][i], &a->me8l[1][i], i);
+    }
+    a->cost8x8bi += a->lambda * mb_b_cost_8x8;
+}
+
+/* x264_mb_analyse_inter_b16x8 (horizontal = 1) / _b8x16 (0) */
+static void analyse_inter_b_halves(actx *a, int horizontal, int i_best_satd)
+{
+    x264o_encoder *e = a->e;
+    int mvc[3][2];
+    int *p_cost = horizontal ? &a->cost16x8bi : &a->cost8x16bi, *part = horizontal ? a->part16x8 : a->part8x16;
+    const int *cost_est = horizontal ? a->cost_est16x8 : a->cost_est8x16;
+    a->partition = horizontal ? D_16x8 : D_8x16;
+    *p_cost = 0;
+    a->cur_valid = a->cur_valid1 = 0;
+    for (int i = 0; i < 2; i++) {
+        const int bx8 = horizontal ? 0 : i, by8 = horizontal ? i : 0, w8 = horizontal ? 2 : 1, h8 = horizontal ? 1 : 2;
+        const int ka = horizontal ? 2 * i : i, kb = horizontal ? 2 * i + 1 : i + 2;      /* the two 8x8 blocks the half covers */
+        const pixel *fenc = e->fenc_y + (size_t)(a->mby * 16 + 8 * by8) * e->fs + a->mbx * 16 + 8 * bx8;
+        me_t *lm[2];
+        for (int l = 0; l < 2; l++) {
+            lm[l] = horizontal ? &a->me16x8l[l][i] : &a->me8x16l[l][i];
+            const int ref8[2] = { a->me8l[l][ka].ref, a->me8l[l][kb].ref };
+            const int i_ref8s = ref8[0] == ref8[1] ? 1 : 2;
+            lm[l]->cost = 0x7fffffff;
+            for (int j = 0; j < i_ref8s; j++) {
+                const int r = ref8[j];
+                me_t m;
+                memset(&m, 0, sizeof(m));
+                m.w = 8 * w8; m.h = 8 * h8; m.ox = 8 * bx8; m.oy = 8 * by8; m.list = l; m.ref = r; m.ref_cost = ref_cost_l(a, l, r);
+                for (int k = 0; k < 2; k++) { mvc[0][k] = a->mvcl[l][r][0][k]; mvc[1][k] = a->mvcl[l][r][ka + 1][k]; mvc[2][k] = a->mvcl[l][r][kb + 1][k]; }
+                (l ? a->cur8b : a->cur8)[ka].ref = (l ? a->cur8b : a->cur8)[kb].ref = r;
+                predict_mv_l(a, l, bx8, by8, w8, r, m.mvp);
+                me_search_ref(a, &m, mvc, 3, NULL);
+                m.cost += m.ref_cost;
+                if (m.cost < lm[l]->cost) *lm[l] = m;
+            }
+        }
+        pixel pix[256];
+        bi_pred(a, lm[0], lm[1], pix);
+        int i_part_cost_bi = mbcmp(a, fenc, e->fs, pix, 16, 8 * w8, 8 * h8) + lm[0]->cost_mv + lm[1]->cost_mv + lm[0]->ref_cost + lm[1]->ref_cost;
+        if (a->chroma_me) i_part_cost_bi += bi_chroma(a, lm[0], lm[1]);
+        int i_part_cost = lm[0]->cost;
+        part[i] = 0;
+        if (lm[1]->cost < i_part_cost) { i_part_cost = lm[1]->cost; part[i] = 1; }
+        if (i_part_cost_bi + a->lambda * 1 < i_part_cost) { i_part_cost = i_part_cost_bi; part[i] = 2; }
+        *p_cost += i_part_cost;
+        /* early termination: the first half plus the estimate of the second */
+        if (a->b_early_terminate && !i && i_part_cost + cost_est[1] > i_best_satd) { *p_cost = COST_MAX; return; }
+        cache_b_block(a, bx8, by8, w8, h8, part[i], lm[0], lm[1], 0);
+    }
+    *p_cost += a->lambda * mb_b16x8_cost[part[0] * 3 + part[1]];
+}
+
+/* x264_me_refine_bidir_satd: both vectors of a bi-predicted block walk together, up to two components at a time */
+static void me_refine_bidir_satd(const actx *a, me_t *m0, me_t *m1, int i_weight)
+{
+    static const int8_t dia4d[33][4] = {
+        { 0, 0, 0, 0 },
+        { 0, 0, 0, 1 }, { 0, 0, 0, -1 }, { 0, 0, 1, 0 }, { 0, 0, -1, 0 }, { 0, 1, 0, 0 }, { 0, -1, 0, 0 }, { 1, 0, 0, 0 }, { -1, 0, 0, 0 },
+        { 0, 0, 1, 1 }, { 0, 0, -1, -1 }, { 0, 1, 1, 0 }, { 0, -1, -1, 0 }, { 1, 1, 0, 0 }, { -1, -1, 0, 0 }, { 1, 0, 0, 1 }, { -1, 0, 0, -1 },
+        { 0, 1, 0, 1 }, { 0, -1, 0, -1 }, { 1, 0, 1, 0 }, { -1, 0, -1, 0 }, { 0, 0, -1, 1 }, { 0, 0, 1, -1 }, { 0, -1, 1, 0 }, { 0, 1, -1, 0 },
+        { -1, 1, 0, 0 }, { 1, -1, 0, 0 }, { 1, 0, 0, -1 }, { -1, 0, 0, 1 }, { 0, -1, 0, 1 }, { 0, 1, 0, -1 }, { -1, 0, 1, 0 }, { 1, 0, -1, 0 } };
+    const x264o_encoder *e = a->e;
+    const int bw = m0->w, bh = m0->h;
+    int bm0x = m0->mv[0], bm0y = m0->mv[1], bm1x = m1->mv[0], bm1y = m1->mv[1], bcost = COST_MAX, mc_list0 = 1, mc_list1 = 1;
+    if (bm0y < a->smin[1] + 8 || bm1y < a->smin[1] + 8 || bm0y > a->smax[1] - 8 || bm1y > a->smax[1] - 8 ||
+        bm0x < a->smin[0] + 8 || bm1x < a->smin[0] + 8 || bm0x > a->smax[0] - 8 || bm1x > a->smax[0] - 8) return;
+    const uint16_t *cm0x = a->cost_mv - m0->mvp[0], *cm0y = a->cost_mv - m0->mvp[1], *cm1x = a->cost_mv - m1->mvp[0], *cm1y = a->cost_mv - m1->mvp[1];
+    const pixel *fenc = e->fenc_y + (size_t)(a->mby * 16 + m0->oy) * e->fs + a->mbx * 16 + m0->ox;
+    static pixel buf[2][9][256];
+    uint8_t visited[8][8][8];
+    memset(visited, 0, sizeof(visited));
+    sctx S0, S1;
+    sctx_init(&S0, a, m0); sctx_init(&S1, a, m1);
+    for (int pass = 0; pass < 8; pass++) {
+        int bestj = 0;
+        /* the nine sub-pel neighbours of each list's vector (square1 order; index 4 + 3 dx + dy) */
+        if (mc_list0) for (int j = 0; j < 9; j++) get_ref(&S0, buf[0][4 + 3 * square1[j][0] + square1[j][1]], bm0x + square1[j][0], bm0y + square1[j][1]);
+        if (mc_list1) for (int j = 0; j < 9; j++) get_ref(&S1, buf[1][4 + 3 * square1[j][0] + square1[j][1]], bm1x + square1[j][0], bm1y + square1[j][1]);
+        for (int j = !!pass; j < 33; j++) {
+            const int m0x = dia4d[j][0] + bm0x, m0y = dia4d[j][1] + bm0y, m1x = dia4d[j][2] + bm1x, m1y = dia4d[j][3] + bm1y;
+            if (!pass || !(visited[m0x & 7][m0y & 7][m1x & 7] & (1 << (m1y & 7)))) {
+                const int i0 = 4 + 3 * dia4d[j][0] + dia4d[j][1], i1 = 4 + 3 * dia4d[j][2] + dia4d[j][3];
+                pixel pix[256];
+                visited[m0x & 7][m0y & 7][m1x & 7] |= (uint8_t)(1 << (m1y & 7));
+                x264o_pixel_avg_weight(pix, 16, buf[0][i0], 16, buf[1][i1], 16, bw, bh, i_weight);
+                const int cost = mbcmp(a, fenc, e->fs, pix, 16, bw, bh) + cm0x[m0x] + cm0y[m0y] + cm1x[m1x] + cm1y[m1y];
+                if (cost < bcost) { bcost = cost; bestj = j; }
+            }
+        }
+        if (!bestj) break;
+        bm0x += dia4d[bestj][0]; bm0y += dia4d[bestj][1]; bm1x += dia4d[bestj][2]; bm1y += dia4d[bestj][3];
+        mc_list0 = dia4d[bestj][0] | dia4d[bestj][1]; mc_list1 = dia4d[bestj][2] | dia4d[bestj][3];
+    }
+    m0->mv[0] = bm0x; m0->mv[1] = bm0y; m1->mv[0] = bm1x; m1->mv[1] = bm1y;
+}
+
+/* x264_mb_analyse_b_rd */
+static void analyse_b_rd(actx *a, int i_satd_inter, x264gpu_mb *mb, int16_t *lv)
+{
+    const int thresh = a->b_early_terminate ? i_satd_inter * (17 + (a->e->cfg.psy_rd_q8 != 0)) / 16 + 1 : COST_MAX;
+    if (a->rd16direct == COST_MAX) a->rd16direct = rd_cost_b(a, X264GPU_MB_B_DIRECT, D_16x16, 0, 0, mb, lv);
+    if (a->me16l[0].cost < thresh && a->rd16l[0] == COST_MAX) a->rd16l[0] = rd_cost_b(a, X264GPU_MB_B_INTER, D_16x16, 0, 0, mb, lv);
+    if (a->me16l[1].cost < thresh && a->rd16l[1] == COST_MAX) a->rd16l[1] = rd_cost_b(a, X264GPU_MB_B_INTER, D_16x16, 1, 0, mb, lv);
+    if (a->cost16x16bi < thresh && a->rd16bi == COST_MAX) a->rd16bi = rd_cost_b(a, X264GPU_MB_B_INTER, D_16x16, 2, 0, mb, lv);
+    if (a->cost8x8bi < thresh && a->rd8x8bi == COST_MAX) a->rd8x8bi = rd_cost_b(a, X264GPU_MB_B_8x8, D_8x8, 0, 0, mb, lv);
+    if (a->cost16x8bi < thresh && a->rd16x8bi == COST_MAX) a->rd16x8bi = rd_cost_b(a, X264GPU_MB_B_INTER, D_16x8, 0, 0, mb, lv);
+    if (a->cost8x16bi < thresh && a->rd8x16bi == COST_MAX) a->rd8x16bi = rd_cost_b(a, X264GPU_MB_B_INTER, D_8x16, 0, 0, mb, lv);
+}
+
+static void intra_rd(actx *a, int thresh, x264gpu_mb *mb, int16_t *lv);
+
+/* the B branch of x264_macroblock_analyse + x264_macroblock_encode; the caller has set up qp / lambda / limits */
+static void macroblock_b(actx *a, x264gpu_mb *mb, int16_t *lv)
+{
+    x264o_encoder *e = a->e;
+    const int mi = a->mi;
+    pixel *rec = luma_plane(e, e->cur, 0) + (size_t)a->mby * 16 * e->rs + a->mbx * 16;
+    pixel *rec_uv = chroma_plane(e, e->cur) + (size_t)a->mby * 8 * e->rs + a->mbx * 16;
+    a->nref_l[0] = e->nref_l[0]; a->nref_l[1] = e->nref_l[1];
+    a->rd16l[0] = a->rd16l[1] = a->rd16bi = a->rd16direct = a->rd8x8bi = a->rd16x8bi = a->rd8x16bi = COST_MAX;
+    a->cost8x8bi = a->cost16x8bi = a->cost8x16bi = COST_MAX;
+    a->direct_ref[0] = a->direct_ref[1] = -1;
+    /* direct prediction, motion-compensated into the reconstruction; B_SKIP when its distortion alone is below the cheapest coded macroblock */
+    a->cur_valid = a->cur_valid1 = 0;
+    predict_direct_spatial(a);
+    {
+        x264gpu_mb t;
+        pixel pu[64], pv[64];
+        memset(&t, 0, sizeof(t));
+        fill_b_record(a, X264GPU_MB_B_SKIP, D_16x16, &t);
+        mc_mb_b(e, a->mbx, a->mby, &t, rec, e->rs, pu, pv);
+        for (int y = 0; y < 8; y++) for (int x = 0; x < 8; x++) { rec_uv[y * e->rs + 2 * x] = pu[y * 8 + x]; rec_uv[y * e->rs + 2 * x + 1] = pv[y * 8 + x]; }
+    }
+    a->bskip_cost = rd_ssd_mb(a);
+    if (a->bskip_cost <= ((6 * a->lambda2 + 128) >> 8)) {
+        for (int l = 0; l < 2; l++) for (int r = 0; r < a->nref_l[l]; r++) { int16_t (*mvr)[2] = mvr_of(e, l, r); mvr[mi][0] = mvr[mi][1] = 0; }
+        fill_b_record(a, X264GPU_MB_B_SKIP, D_16x16, mb);
+        return;                       /* the prediction is the reconstruction */
+    }
+    analyse_inter_direct(a);
+    analyse_inter_b16x16(a);
+    int use16 = 0, i_type = X264GPU_MB_B_INTER, i_partition = D_16x16, i_cost = a->me16l[0].cost;
+    if (a->me16l[1].cost < i_cost) { i_cost = a->me16l[1].cost; use16 = 1; }
+    if (a->cost16x16bi < i_cost) { i_cost = a->cost16x16bi; use16 = 2; }
+    if (a->cost16x16direct < i_cost) { i_cost = a->cost16x16direct; i_type = X264GPU_MB_B_DIRECT; }
+    if (a->b_early_terminate && a->cost16x16direct <= i_cost * 33 / 32) {
+        analyse_b_rd(a, i_cost, mb, lv);
+        if (a->bskip_cost < a->rd16direct && a->bskip_cost < a->rd16bi && a->bskip_cost < a->rd16l[0] && a->bskip_cost < a->rd16l[1]) {
+            rd_reset(a, mb, lv);
+            fill_b_record(a, X264GPU_MB_B_SKIP, D_16x16, mb);
+            encode_inter_mb(a, mb, lv);
+            return;
+        }
+    }
+    if (e->cfg.partitions & 1) {
+        analyse_inter_b8x8(a);
+        if (a->cost8x8bi < i_cost) { i_cost = a->cost8x8bi; i_type = X264GPU_MB_B_8x8; i_partition = D_8x8; }
+        /* estimates of the two-partition shapes from the SATD scores of the 8x8 blocks: the likelier one is analysed first */
+        int part_est16x8[2], part_est8x16[2];
+        for (int i = 0; i < 2; i++) {
+            for (int hor = 1; hor >= 0; hor--) {
+                const int ka = hor ? 2 * i : i, kb = hor ? 2 * i + 1 : i + 2;
+                const int l0_satd = a->satd8x8b[0][ka] + a->satd8x8b[0][kb], l1_satd = a->satd8x8b[1][ka] + a->satd8x8b[1][kb], bi_satd = a->satd8x8b[2][ka] + a->satd8x8b[2][kb];
+                const int avg_l0 = (a->me8l[0][ka].cost_mv + a->me8l[0][ka].ref_cost + a->me8l[0][kb].cost_mv + a->me8l[0][kb].ref_cost + 1) >> 1;
+                const int avg_l1 = (a->me8l[1][ka].cost_mv + a->me8l[1][ka].ref_cost + a->me8l[1][kb].cost_mv + a->me8l[1][kb].ref_cost + 1) >> 1;
+                int best = COST_MAX, *pe = hor ? part_est16x8 : part_est8x16;
+                if (l0_satd + avg_l0 < best) { best = l0_satd + avg_l0; pe[i] = 0; }
+                if (l1_satd + avg_l1 < best) { best = l1_satd + avg_l1; pe[i] = 1; }
+                if (bi_satd + avg_l0 + avg_l1 < best) { best = bi_satd + avg_l0 + avg_l1; pe[i] = 2; }
+                (hor ? a->cost_est16x8 : a->cost_est8x16)[i] = best;
+            }
+        }
+        a->cost_est16x8[1] += a->lambda * mb_b16x8_cost[part_est16x8[0] * 3 + part_est16x8[1]];
+        a->cost_est8x16[1] += a->lambda * mb_b16x8_cost[part_est8x16[0] * 3 + part_est8x16[1]];
+        const int est16x8 = a->cost_est16x8[0] + a->cost_est16x8[1], est8x16 = a->cost_est8x16[0] + a->cost_est8x16[1];
+        const int try_16x8_first = est16x8 < est8x16;
+        if (try_16x8_first && (!a->b_early_terminate || est16x8 < i_cost)) {
+            analyse_inter_b_halves(a, 1, i_cost);
+            if (a->cost16x8bi < i_cost) { i_cost = a->cost16x8bi; i_type = X264GPU_MB_B_INTER; i_partition = D_16x8; }
+        }
+        if (!a->b_early_terminate || est8x16 < i_cost) {
+            analyse_inter_b_halves(a, 0, i_cost);
+            if (a->cost8x16bi < i_cost) { i_cost = a->cost8x16bi; i_type = X264GPU_MB_B_INTER; i_partition = D_8x16; }
+        }
+        if (!try_16x8_first && (!a->b_early_terminate || est16x8 < i_cost)) {
+            analyse_inter_b_halves(a, 1, i_cost);
+            if (a->cost16x8bi < i_cost) { i_cost = a->cost16x8bi; i_type = X264GPU_MB_B_INTER; i_partition = D_16x8; }
+        }
+    }
+    int i_satd_inter = i_cost;
+    /* RD: every candidate within reach, B_SKIP included */
+    analyse_b_rd(a, i_satd_inter, mb, lv);
+    i_type = X264GPU_MB_B_SKIP; i_cost = a->bskip_cost; i_partition = D_16x16;
+    if (a->rd16l[0] < i_cost) { i_cost = a->rd16l[0]; i_type = X264GPU_MB_B_INTER; use16 = 0; }
+    if (a->rd16l[1] < i_cost) { i_cost = a->rd16l[1]; i_type = X264GPU_MB_B_INTER; use16 = 1; }
+    if (a->rd16bi < i_cost) { i_cost = a->rd16bi; i_type = X264GPU_MB_B_INTER; use16 = 2; }
+    if (a->rd16direct < i_cost) { i_cost = a->rd16direct; i_type = X264GPU_MB_B_DIRECT; }
+    if (a->rd16x8bi < i_cost) { i_cost = a->rd16x8bi; i_type = X264GPU_MB_B_INTER; i_partition = D_16x8; }
+    if (a->rd8x16bi < i_cost) { i_cost = a->rd8x16bi; i_type = X264GPU_MB_B_INTER; i_partition = D_8x16; }
+    if (a->rd8x8bi < i_cost) { i_cost = a->rd8x8bi; i_type = X264GPU_MB_B_8x8; i_partition = D_8x8; }
+    /* intra analysis against the inter SATD cost */
+    if (a->chroma_me) {
+        analyse_intra_chroma(a);
+        analyse_intra(a, i_satd_inter - a->satd_chroma);
+        a->satd_i16 += a->satd_chroma; a->satd_i8 += a->satd_chroma; a->satd_i4 += a->satd_chroma;
+    } else analyse_intra(a, i_satd_inter);
+    /* x264_mb_analyse_transform_rd: the other transform size for the winner (B_SKIP has no transform) */
+    int t8 = 0;
+    if (i_type != X264GPU_MB_B_SKIP && e->cfg.dct8x8) {
+        const int i_rd8 = rd_cost_b(a, i_type, i_partition, use16, 1, mb, lv);
+        if (i_cost >= i_rd8) { if (i_cost > 0) i_satd_inter = (int)((int64_t)i_satd_inter * i_rd8 / i_cost); i_cost = i_rd8; t8 = 1; }
+    }
+    intra_rd(a, i_satd_inter * 17 / 16 + 1, mb, lv);
+    int intra_type = -1;
+    if (a->satd_i16 < i_cost) { i_cost = a->satd_i16; intra_type = X264GPU_MB_I16x16; }
+    if (a->satd_i8 < i_cost) { i_cost = a->satd_i8; intra_type = X264GPU_MB_I8x8; }
+    if (a->satd_i4 < i_cost) { i_cost = a->satd_i4; intra_type = X264GPU_MB_I4x4; }
+    rd_reset(a, mb, lv);
+    if (intra_type >= 0) {
+        mb->cost = i_cost;
+        e->b_trellis = e->cfg.cabac ? e->cfg.trellis & 63 : 0;
+        encode_intra_mb(a, intra_type, mb, lv);
+        e->b_trellis = 0;
+        e->intra_count++;
+        return;
+    }
+    /* x264_refine_bidir (subme >= 5): the bi-predicted partitions of the winner refine both vectors together on SATD */
+    if (a->subme >= 5 && i_type != X264GPU_MB_B_SKIP && i_type != X264GPU_MB_B_DIRECT) {
+        if (i_partition == D_16x16) { if (use16 == 2) me_refine_bidir_satd(a, &a->bi16[0], &a->bi16[1], e->bipred_weight[a->bi16[0].ref][a->bi16[1].ref]); }
+        else if (i_partition == D_16x8) { for (int i = 0; i < 2; i++) if (a->part16x8[i] == 2) me_refine_bidir_satd(a, &a->me16x8l[0][i], &a->me16x8l[1][i], e->bipred_weight[a->me16x8l[0][i].ref][a->me16x8l[1][i].ref]); }
+        else if (i_partition == D_8x16) { for (int i = 0; i < 2; i++) if (a->part8x16[i] == 2) me_refine_bidir_satd(a, &a->me8x16l[0][i], &a->me8x16l[1][i], e->bipred_weight[a->me8x16l[0][i].ref][a->me8x16l[1][i].ref]); }
+        else for (int i = 0; i < 4; i++) if (a->sub8[i] == 2) me_refine_bidir_satd(a, &a->me8l[0][i], &a->me8l[1][i], e->bipred_weight[a->me8l[0][i].ref][a->me8l[1][i].ref]);
+    }
+    {
+        const int bak = a->sub8[0];
+        if (i_partition == D_16x16 && i_type == X264GPU_MB_B_INTER) a->sub8[0] = use16;
+        fill_b_record(a, i_type, i_partition, mb);
+        a->sub8[0] = bak;
+    }
+    a->force_t8 = t8;
+    e->b_trellis = e->cfg.cabac ? e->cfg.trellis & 63 : 0;
+    encode_inter_mb(a, mb, lv);
+    e->b_trellis = 0;
+    a->force_t8 = -1;
+}
+
 static int mb_type_at(const x264o_encoder *e, int mbx, int mby)
 {
     if (mbx < 0 || mby < e->row0 || mbx >= e->mbw) return -1;
@@ -1517,7 +2100,7 @@ static void macroblock_body(x264o_encoder *e, int mbx, int mby, actx *a)
         return;
     }
 
-    /* ---- P slice ---- */
+    /* ---- P / B slice ---- */
     a->cost_mv = x264o_cost_mv_for(e, a->qp);
     a->chroma_me = e->cfg.chroma_me && a->subme >= 5;
     {   /* motion vector limits (x264_analyse_init: mv_min / mv_max, _spel clipped to --mvrange, _fpel inside the padded picture) */
@@ -1533,10 +2116,11 @@ static void macroblock_body(x264o_encoder *e, int mbx, int mby, actx *a)
      * macroblocks coded so far are intra */
     const int mi_in_slice = a->mi - e->row0 * e->mbw;            /* h->mb.i_mb_xy - h->sh.i_first_mb */
     if (a->b_early_terminate && mi_in_slice > 4) {
-        const int colo = e->mbtype[ref_slot(e, 0)][a->mi];
+        const int colo = e->slice_type == X264GPU_SLICE_P ? e->mbtype[ref_slot(e, 0)][a->mi] : -1;      /* the co-located type counts in P slices only */
         if (!(is_intra_type(a->type_left) || is_intra_type(a->type_top) || is_intra_type(a->type_tl) || is_intra_type(a->type_tr) ||
               is_intra_type(colo) || mi_in_slice < 3 * e->intra_count)) a->b_fast_intra = 1;
     }
+    if (e->slice_type == X264GPU_SLICE_B) { macroblock_b(a, mb, lv); return; }
     a->cur_valid = 0;
     predict_mv_pskip(a, a->pskip_mv);
     int b_skip = 0;

@@ -4,10 +4,12 @@
 // copy of the context initialisation values, typed a second time and laid out per syntax element (Tables 9-12 .. 9-23) instead of per
 // context index; tests/test_host_cpu.py checks the two copies against each other.  Like the encoder's copy they were typed from memory
 // of the published tables — the standard's text is not in this container — so the pair pins typing errors, not recall errors.
-// Supported: I and P slices, frame macroblocks, 4:2:0, cabac_init_idc 0.
+// Supported: I, P and B slices, frame macroblocks, 4:2:0, cabac_init_idc 0.
 #pragma once
 #include <stdint.h>
 #include <string.h>
+#include <stdio.h>
+#include <stdlib.h>
 
 namespace cabacdec {
 
@@ -34,6 +36,10 @@ static const MN kMbTypeI[8] = { { 20, -15 }, { 2, 54 }, { 3, 74 }, { -28, 127 },
 static const MN kSkipP[3] = { { 23, 33 }, { 23, 2 }, { 21, 0 } };
 static const MN kMbTypeP[7] = { { 1, 9 }, { 0, 49 }, { -37, 118 }, { 5, 57 }, { -13, 78 }, { -11, 65 }, { 1, 62 } };
 static const MN kSubMbTypeP[3] = { { 12, 49 }, { -4, 73 }, { 17, 50 } };
+// B slices (cabac_init_idc 0): mb_skip_flag 24..26, mb_type 27..35, sub_mb_type 36..39
+static const MN kSkipB[3] = { { 18, 64 }, { 9, 43 }, { 29, 0 } };
+static const MN kMbTypeB[9] = { { 26, 67 }, { 16, 90 }, { 9, 104 }, { -46, 127 }, { -20, 104 }, { 1, 67 }, { -13, 78 }, { -11, 65 }, { 1, 62 } };
+static const MN kSubMbTypeB[4] = { { -6, 86 }, { -17, 95 }, { -6, 61 }, { 9, 45 } };
 // mvd_l0: horizontal 40..46, vertical 47..53; ref_idx 54..59
 static const MN kMvdX[7] = { { -3, 69 }, { -6, 81 }, { -11, 96 }, { 6, 55 }, { 7, 67 }, { -5, 86 }, { 2, 88 } };
 static const MN kMvdY[7] = { { 0, 58 }, { -3, 76 }, { -10, 94 }, { 5, 54 }, { 4, 69 }, { -3, 81 }, { 0, 88 } };
@@ -129,6 +135,9 @@ struct Engine {
             for (int i = 0; i < 3; i++) seed(11 + i, kSkipP[i], qp);
             for (int i = 0; i < 7; i++) seed(14 + i, kMbTypeP[i], qp);
             for (int i = 0; i < 3; i++) seed(21 + i, kSubMbTypeP[i], qp);
+            for (int i = 0; i < 3; i++) seed(24 + i, kSkipB[i], qp);
+            for (int i = 0; i < 9; i++) seed(27 + i, kMbTypeB[i], qp);
+            for (int i = 0; i < 4; i++) seed(36 + i, kSubMbTypeB[i], qp);
             for (int i = 0; i < 7; i++) { seed(40 + i, kMvdX[i], qp); seed(47 + i, kMvdY[i], qp); }
             for (int i = 0; i < 6; i++) seed(54 + i, kRefIdx[i], qp);
         }
@@ -145,7 +154,14 @@ struct Engine {
         range = 510; offset = 0;
         for (int i = 0; i < 9; i++) offset = (offset << 1) | (uint32_t)bit();
     }
+    int nbins = 0;
     int decision(int ctx)
+    {
+        const int r_ = decision_(ctx);
+        if (nbins++ < 24 && getenv("X264O_CABAC_DEBUG")) fprintf(stderr, "dec bin %d ctx %d -> %d\n", nbins - 1, ctx, r_);
+        return r_;
+    }
+    int decision_(int ctx)
     {
         const int s = st[ctx];
         const uint32_t lps = kRangeLps[s][(range >> 6) & 3];

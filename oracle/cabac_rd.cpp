@@ -40,6 +40,14 @@ struct Tables {
 const Tables &tables() { static const Tables t; return t; }
 
 inline bool intra_type(int t) { return t == X264GPU_MB_I4x4 || t == X264GPU_MB_I8x8 || t == X264GPU_MB_I16x16; }
+inline bool skip_type(int t) { return t == X264GPU_MB_P_SKIP || t == X264GPU_MB_B_SKIP; }
+inline bool b_type(int t) { return t >= X264GPU_MB_B_DIRECT && t <= X264GPU_MB_B_8x8; }
+// list use of 8x8 block k of a B macroblock: 0 list 0, 1 list 1, 2 both, 3 direct
+inline int b_use(const x264gpu_mb &m, int k)
+{
+    if (m.type == X264GPU_MB_B_DIRECT || m.type == X264GPU_MB_B_SKIP || (m.type == X264GPU_MB_B_8x8 && (m.direct8 >> k & 1))) return 3;
+    return m.ref[k] >= 0 ? (m.ref1[k] >= 0 ? 2 : 0) : 1;
+}
 
 }  // namespace
 
@@ -53,6 +61,8 @@ typedef struct x264o_cabac_ctx {
     uint8_t *amvd;                    /* [macroblock][8x8 block][x, y]: |mvd| capped as x264 keeps it */
     uint8_t *state;                   /* 460 context variables, (pStateIdx << 1) | valMPS */
     int last_dqp, last_qp;            /* mb_qp_delta of the previous macroblock in coding order; QP_Y the entropy coder predicts from */
+    int bslice, num_ref1;             /* B slice; active references of list 1 */
+    uint8_t *amvd1;                   /* list 1's |mvd| */
 } x264o_cabac_ctx;
 
 const uint16_t *x264o_cabac_entropy(void) { return tables().entropy; }
@@ -74,6 +84,7 @@ struct Coder {
     long f8 = 0;
     int cur = 0, done8 = 0;
     struct Nb { bool avail; int ref, mvx, mvy; } cur8[4];
+    int lst = 0;                      // the list the motion helpers below read (B slices: 0 / 1)
 
     Coder(x264o_cabac_ctx &ctx, bool size_mode) : c(ctx), rd(size_mode) {}
 
@@ -104,7 +115,10 @@ struct Coder {
         if (i > cur) return n;
         n.avail = true;
         const x264gpu_mb &m = c.mbs[i];
-        if (!intra_type(m.type)) { n.ref = m.ref[k]; n.mvx = m.mv[k][0]; n.mvy = m.mv[k][1]; }
+        if (!intra_type(m.type)) {
+            if (lst) { n.ref = m.ref1[k]; if (n.ref >= 0) { n.mvx = m.mv1[k][0]; n.mvy = m.mv1[k][1]; } else n.ref = -1; }
+            else { n.ref = m.ref[k]; if (n.ref >= 0) { n.mvx = m.mv[k][0]; n.mvy = m.mv[k][1]; } else n.ref = -1; }
+        }
         return n;
     }
     // 8.4.1.3 with the directional rules of the two-partition shapes
@@ -131,15 +145,18 @@ struct Coder {
         if (gx < 0 || gy < 2 * c.first_row || gx >= 2 * c.mbw || gy >= 2 * c.mbh) return 0;
         const int i = (gy >> 1) * c.mbw + (gx >> 1), k = (gy & 1) * 2 + (gx & 1);
         if (i > cur || (i == cur && !(done8 >> k & 1))) return 0;
-        return c.amvd[((size_t)i * 4 + k) * 2 + comp];
+        return (lst ? c.amvd1 : c.amvd)[((size_t)i * 4 + k) * 2 + comp];
     }
     int ref_gt0_at(int gx, int gy) const
     {
         const Nb n = block8(gx, gy);
         if (!n.avail || n.ref <= 0) return 0;
-        const int i = (gy >> 1) * c.mbw + (gx >> 1);
-        return i == cur || c.mbs[i].type != X264GPU_MB_P_SKIP;
+        const int i = (gy >> 1) * c.mbw + (gx >> 1), k = (gy & 1) * 2 + (gx & 1);
+        if (i == cur) return !(cur_direct >> k & 1);
+        if (b_type(c.mbs[i].type)) return b_use(c.mbs[i], k) != 3;      // predicted by direct inference: refIdxZeroFlag does not look at it
+        return c.mbs[i].type != X264GPU_MB_P_SKIP;
     }
+    int cur_direct = 0;               // direct 8x8 blocks of the macroblock being coded
     int pred_intra_mode(int mbx, int mby, int blk) const
     {
         const int bx = kBx[blk], by = kBy[blk];
@@ -266,7 +283,7 @@ struct Coder {
         }
         const uint8_t capped = (uint8_t)(a < 66 ? a : 66);
         for (int y = b8 >> 1; y < (b8 >> 1) + h8; y++)
-            for (int x = b8 & 1; x < (b8 & 1) + w8; x++) c.amvd[((size_t)cur * 4 + y * 2 + x) * 2 + comp] = capped;
+            for (int x = b8 & 1; x < (b8 & 1) + w8; x++) (lst ? c.amvd1 : c.amvd)[((size_t)cur * 4 + y * 2 + x) * 2 + comp] = capped;
     }
     void ref_idx(int mbx, int mby, int b8, int ref)
     {
@@ -276,19 +293,102 @@ struct Coder {
         decision(54 + ctx, 0);
     }
 
+    // mb_type of a B slice (Table 9-37 b; ctxIdx 27..35): the bin string of the value, context 27 + {0..2} for bin 0, 27 + 3 for bin 1,
+    // 27 + 5 - b1 for bin 2, 27 + 5 for the rest
+    void mb_type_b(int value, int ctx0)
+    {
+        static const char *const bins[24] = { "0", "100", "101", "110000", "110001", "110010", "110011", "110100", "110101", "110110", "110111", "111110",
+                                              "1110000", "1110001", "1110010", "1110011", "1110100", "1110101", "1110110", "1110111", "1111000", "1111001",
+                                              "111111", "111101" /* prefix of the intra types */ };
+        const char *b = bins[value];
+        for (int i = 0; b[i]; i++) decision(i == 0 ? 27 + ctx0 : i == 1 ? 27 + 3 : i == 2 ? 27 + 5 - (b[1] - '0') : 27 + 5, b[i] - '0');
+    }
+    void sub_mb_type_b(int use)          // 0 list 0, 1 list 1, 2 both, 3 direct (Table 9-37: B_Direct_8x8 "0", L0 "100", L1 "101", Bi "11000"; ctxIdx 36..39)
+    {
+        if (use == 3) { decision(36, 0); return; }
+        decision(36, 1);
+        if (use == 2) { decision(37, 1); decision(38, 0); decision(39, 0); decision(39, 0); return; }
+        decision(37, 0);
+        decision(39, use == 1);
+    }
+    void macroblock_b(int mbx, int mby, const x264gpu_mb &m)
+    {
+        static const int8_t geom[4][4][4] = { { { 0, 0, 2, 2 } }, { { 0, 0, 2, 1 }, { 0, 1, 2, 1 } }, { { 0, 0, 1, 2 }, { 1, 0, 1, 2 } },
+                                              { { 0, 0, 1, 1 }, { 1, 0, 1, 1 }, { 0, 1, 1, 1 }, { 1, 1, 1, 1 } } };
+        const x264gpu_mb *L = left(mbx, mby), *T = top(mbx, mby);
+        const int ctx0 = (L && L->type != X264GPU_MB_B_SKIP && L->type != X264GPU_MB_B_DIRECT) + (T && T->type != X264GPU_MB_B_SKIP && T->type != X264GPU_MB_B_DIRECT);
+        cur_direct = 0;
+        if (m.type == X264GPU_MB_B_DIRECT) { mb_type_b(0, ctx0); cur_direct = 15; return; }
+        const int part = m.partition & 3, nparts = part == 0 ? 1 : part == 3 ? 4 : 2;
+        int use[4];
+        for (int k = 0; k < nparts; k++) use[k] = b_use(m, geom[part][k][1] * 2 + geom[part][k][0]);
+        if (part == 3) {
+            mb_type_b(22, ctx0);
+            for (int k = 0; k < 4; k++) { sub_mb_type_b(use[k]); if (use[k] == 3) cur_direct |= 1 << k; }
+        } else if (part == 0) mb_type_b(1 + use[0], ctx0);
+        else {
+            // Table 7-14: 4 + 2 * pair + (8x16), pairs in the order L0_L0, L1_L1, L0_L1, L1_L0, L0_Bi, L1_Bi, Bi_L0, Bi_L1, Bi_Bi
+            static const int8_t pair_of[3][3] = { { 0, 2, 4 }, { 3, 1, 5 }, { 6, 7, 8 } };
+            mb_type_b(4 + 2 * pair_of[use[0]][use[1]] + (part == 2), ctx0);
+        }
+        for (lst = 0; lst < 2; lst++) {
+            if ((lst ? c.num_ref1 : c.num_ref) <= 1) continue;
+            done8 = 0;
+            for (int k = 0; k < nparts; k++) {
+                const int8_t *g = geom[part][k];
+                const int b8 = g[1] * 2 + g[0];
+                if (use[k] == 3 || use[k] == 1 - lst) {
+                    // the block does not send this list's index: for the neighbour rules it has none (direct: never "greater than 0")
+                    for (int y = g[1]; y < g[1] + g[3]; y++) for (int x = g[0]; x < g[0] + g[2]; x++) { cur8[y * 2 + x] = Nb{ true, use[k] == 3 ? (lst ? m.ref1[b8] : m.ref[b8]) : -1, 0, 0 }; done8 |= 1 << (y * 2 + x); }
+                    continue;
+                }
+                const int r = lst ? m.ref1[b8] : m.ref[b8];
+                ref_idx(mbx, mby, b8, r);
+                for (int y = g[1]; y < g[1] + g[3]; y++) for (int x = g[0]; x < g[0] + g[2]; x++) { cur8[y * 2 + x] = Nb{ true, r, 0, 0 }; done8 |= 1 << (y * 2 + x); }
+            }
+        }
+        for (lst = 0; lst < 2; lst++) {
+            done8 = 0;
+            for (int k = 0; k < nparts; k++) {
+                const int8_t *g = geom[part][k];
+                const int b8 = g[1] * 2 + g[0];
+                const int r = lst ? m.ref1[b8] : m.ref[b8], vx = lst ? m.mv1[b8][0] : m.mv[b8][0], vy = lst ? m.mv1[b8][1] : m.mv[b8][1];
+                if (!(use[k] == 3 || use[k] == 1 - lst)) {
+                    int px, py;
+                    predict(mbx, mby, g[0], g[1], g[2], part, k, r, px, py);
+                    mvd(mbx, mby, b8, g[2], g[3], 0, vx - px);
+                    mvd(mbx, mby, b8, g[2], g[3], 1, vy - py);
+                }
+                for (int y = g[1]; y < g[1] + g[3]; y++) for (int x = g[0]; x < g[0] + g[2]; x++) { cur8[y * 2 + x] = Nb{ true, r >= 0 ? r : -1, r >= 0 ? vx : 0, r >= 0 ? vy : 0 }; done8 |= 1 << (y * 2 + x); }
+            }
+        }
+        lst = 0;
+    }
+
     void macroblock(int mbx, int mby)
     {
-        cur = mby * c.mbw + mbx; done8 = 0;
+        cur = mby * c.mbw + mbx; done8 = 0; lst = 0; cur_direct = 0;
         const x264gpu_mb &m = c.mbs[cur];
         const int16_t *lv = c.levels + (size_t)cur * X264GPU_MB_LEVELS;
         const x264gpu_mb *L = left(mbx, mby), *T = top(mbx, mby);
         memset(c.amvd + (size_t)cur * 8, 0, 8);
-        if (c.pslice && !rd) {
+        if (c.bslice) memset(c.amvd1 + (size_t)cur * 8, 0, 8);
+        if (c.bslice && !rd) {
+            decision(24 + (L && !skip_type(L->type)) + (T && !skip_type(T->type)), m.type == X264GPU_MB_B_SKIP);
+            if (m.type == X264GPU_MB_B_SKIP) { c.last_dqp = 0; return; }
+        }
+        if (c.pslice && !c.bslice && !rd) {
             decision(11 + (L && L->type != X264GPU_MB_P_SKIP) + (T && T->type != X264GPU_MB_P_SKIP), m.type == X264GPU_MB_P_SKIP);
             if (m.type == X264GPU_MB_P_SKIP) { c.last_dqp = 0; return; }
         }
         const bool intra = intra_type(m.type);
-        if (!c.pslice) {
+        if (c.bslice) {
+            if (intra) {
+                const int ctx0 = (L && L->type != X264GPU_MB_B_SKIP && L->type != X264GPU_MB_B_DIRECT) + (T && T->type != X264GPU_MB_B_SKIP && T->type != X264GPU_MB_B_DIRECT);
+                mb_type_b(23, ctx0);
+                mb_type_intra(m, 32, 32 + 1, 32 + 2, 32 + 2, 32 + 3, 32 + 3);
+            } else macroblock_b(mbx, mby, m);
+        } else if (!c.pslice) {
             const int ctx = (L && L->type != X264GPU_MB_I4x4 && L->type != X264GPU_MB_I8x8) + (T && T->type != X264GPU_MB_I4x4 && T->type != X264GPU_MB_I8x8);
             mb_type_intra(m, 3 + ctx, 3 + 3, 3 + 4, 3 + 5, 3 + 6, 3 + 7);
         } else if (intra) { decision(14, 1); mb_type_intra(m, 17, 17 + 1, 17 + 2, 17 + 2, 17 + 3, 17 + 3); }
@@ -316,7 +416,7 @@ struct Coder {
             const int ctx = (L && intra_type(L->type) && L->chroma_mode != 0) + (T && intra_type(T->type) && T->chroma_mode != 0);
             if (!m.chroma_mode) decision(64 + ctx, 0);
             else { decision(64 + ctx, 1); decision(64 + 3, m.chroma_mode > 1); if (m.chroma_mode > 1) decision(64 + 3, m.chroma_mode > 2); }
-        } else {
+        } else if (!c.bslice) {
             static const int8_t geom[4][4][4] = { { { 0, 0, 2, 2 } }, { { 0, 0, 2, 1 }, { 0, 1, 2, 1 } }, { { 0, 0, 1, 2 }, { 1, 0, 1, 2 } },
                                                   { { 0, 0, 1, 1 }, { 1, 0, 1, 1 }, { 0, 1, 1, 1 }, { 1, 1, 1, 1 } } };
             const int nparts = m.partition == 0 ? 1 : m.partition == 3 ? 4 : 2;

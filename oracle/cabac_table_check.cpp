@@ -26,7 +26,9 @@ extern "C" int x264o_cabac_tables_mismatches(void)
         for (int i = 0; i < 9; i++) chk(417 + i, kLast8[t][i], t);
         for (int i = 0; i < 10; i++) chk(426 + i, kAbs8[t][i], t);
     }
-    for (int i = 0; i < 3; i++) { chk(11 + i, kSkipP[i], 1); chk(21 + i, kSubMbTypeP[i], 1); }
+    for (int i = 0; i < 3; i++) { chk(11 + i, kSkipP[i], 1); chk(21 + i, kSubMbTypeP[i], 1); chk(24 + i, kSkipB[i], 1); }
+    for (int i = 0; i < 9; i++) chk(27 + i, kMbTypeB[i], 1);
+    for (int i = 0; i < 4; i++) chk(36 + i, kSubMbTypeB[i], 1);
     for (int i = 0; i < 7; i++) { chk(14 + i, kMbTypeP[i], 1); chk(40 + i, kMvdX[i], 1); chk(47 + i, kMvdY[i], 1); }
     for (int i = 0; i < 6; i++) chk(54 + i, kRefIdx[i], 1);
     for (int i = 0; i < 63; i++) if (kSigInc8[i] != x264host::cabac_sig8x8[i] || kLastInc8[i] != x264host::cabac_last8x8[i]) bad++;

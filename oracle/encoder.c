@@ -38,17 +38,19 @@ x264o_encoder *x264o_encoder_create(const x264gpu_config *cfg)
     e->rs = (e->cw + 2 * PAD + 63) / 64 * 64;
     e->plane_bytes = (size_t)e->rs * (e->ch + 2 * PAD);
     e->cplane_bytes = (size_t)e->rs * (e->ch / 2 + 2 * CPAD);
-    e->slots = clampi(cfg->refs, 1, X264O_MAX_REFS) + 1;
+    e->slots = clampi(cfg->dpb > 0 ? cfg->dpb : cfg->refs, 1, X264O_MAX_SLOTS - 1) + 1;
     const size_t n = (size_t)e->mbw * e->mbh;
     for (int s = 0; s < e->slots; s++) {
         e->luma[s] = calloc(4, e->plane_bytes);
         e->chroma[s] = calloc(1, e->cplane_bytes);
         e->mv16[s] = calloc(n, sizeof(int16_t[2]));
         e->mbtype[s] = calloc(n, 1);
+        e->colref[s] = calloc(n, 4); e->colmv[s] = calloc(n, sizeof(int16_t[4][2]));
     }
     for (int r = 1; r < X264O_MAX_REFS; r++) e->mvr[r] = calloc(n, sizeof(int16_t[2]));
+    for (int r = 0; r < X264O_MAX_REFS; r++) e->mvr1[r] = calloc(n, sizeof(int16_t[2]));
     e->mbqp = malloc(n);
-    e->amvd = calloc((size_t)n, 8);
+    e->amvd = calloc((size_t)n, 8); e->amvd1 = calloc((size_t)n, 8);
     x264o_quant_init(&e->qt, cfg->deadzone_inter, cfg->deadzone_intra);
     return e;
 }
@@ -56,10 +58,11 @@ x264o_encoder *x264o_encoder_create(const x264gpu_config *cfg)
 void x264o_encoder_destroy(x264o_encoder *e)
 {
     if (!e) return;
-    for (int s = 0; s < e->slots; s++) { free(e->luma[s]); free(e->chroma[s]); free(e->mv16[s]); free(e->mbtype[s]); }
+    for (int s = 0; s < e->slots; s++) { free(e->luma[s]); free(e->chroma[s]); free(e->mv16[s]); free(e->mbtype[s]); free(e->colref[s]); free(e->colmv[s]); }
     for (int r = 1; r < X264O_MAX_REFS; r++) free(e->mvr[r]);
+    for (int r = 0; r < X264O_MAX_REFS; r++) free(e->mvr1[r]);
     for (int q = 0; q < 52; q++) free(e->cost_mv[q]);
-    free(e->fenc_y); free(e->fenc_uv); free(e->mbqp); free(e->amvd); free(e);
+    free(e->fenc_y); free(e->fenc_uv); free(e->mbqp); free(e->amvd); free(e->amvd1); free(e);
 }
 
 int x264o_encoder_mb_count(const x264o_encoder *e) { return e->mbw * e->mbh; }
@@ -69,6 +72,7 @@ void x264o_encoder_set_mb_qp_offsets(x264o_encoder *e, const int16_t *off_q8) { 
 /* lookahead vectors of the NEXT picture against its predecessor ([nmb][2], lowres quarter-pels; first entry 0x7fff or NULL = none):
  * the extra 16x16 search candidate x264 takes from fenc->lowres_mvs[0][0] */
 void x264o_encoder_set_lowres_mvs(x264o_encoder *e, const int16_t *mv) { e->lowres_mv = mv; }
+void x264o_encoder_set_lowres_mvs1(x264o_encoder *e, const int16_t *mv) { e->lowres_mv1 = mv; }
 /* tests: where to leave the predicted CAVLC bit count of every macroblock of the next pictures (NULL: off) */
 void x264o_encoder_set_mb_bits_out(x264o_encoder *e, int *bits) { e->mb_bits = bits; }
 /* tests: the CABAC context states (pStateIdx << 1 | valMPS) after the last slice coded — RD sessions with cabac only */
@@ -160,6 +164,7 @@ static int blk_nnz(const x264gpu_mb *m, int bx, int by)
     return (m->nnz >> idx_of[by][bx]) & 1;
 }
 static int is_intra(const x264gpu_mb *m) { return m->type == X264GPU_MB_I4x4 || m->type == X264GPU_MB_I8x8 || m->type == X264GPU_MB_I16x16; }
+static int is_b_inter(const x264gpu_mb *m) { return m->type >= X264GPU_MB_B_DIRECT && m->type <= X264GPU_MB_B_8x8; }
 
 static int edge_bs(const x264gpu_mb *p, int pbx, int pby, const x264gpu_mb *q, int qbx, int qby, int mb_edge)
 {
@@ -168,6 +173,14 @@ static int edge_bs(const x264gpu_mb *p, int pbx, int pby, const x264gpu_mb *q, i
     int pi = (pby >> 1) * 2 + (pbx >> 1), qi = (qby >> 1) * 2 + (qbx >> 1);
     if (p->ref[pi] != q->ref[qi]) return 1;
     if (abs(p->mv[pi][0] - q->mv[qi][0]) >= 4 || abs(p->mv[pi][1] - q->mv[qi][1]) >= 4) return 1;
+    /* B slices (deblock_strength_c with bframe): list 1 compared index by index as well — x264's lists never share a picture (list 0 holds
+     * earlier, list 1 later pictures), so comparing per list equals the standard's comparison of picture sets */
+    if (is_b_inter(p) && is_b_inter(q)) {
+        if (p->ref1[pi] != q->ref1[qi]) return 1;
+        const int px = p->ref1[pi] < 0 ? 0 : p->mv1[pi][0], py = p->ref1[pi] < 0 ? 0 : p->mv1[pi][1];
+        const int qx = q->ref1[qi] < 0 ? 0 : q->mv1[qi][0], qy = q->ref1[qi] < 0 ? 0 : q->mv1[qi][1];
+        if (abs(px - qx) >= 4 || abs(py - qy) >= 4) return 1;
+    }
     return 0;
 }
 
@@ -238,15 +251,41 @@ static void filter_frame(x264o_encoder *e)
             }
 }
 
-int x264o_encoder_encode(x264o_encoder *e, const uint8_t *i420, int slice_type, x264gpu_mb *mbs, int16_t *levels)
+/* h->mb.bipred_weight: implicit weights of 8.4.2.3.1 from the POC distances (x264_macroblock_bipred_init) */
+static void bipred_init(x264o_encoder *e)
 {
-    if (slice_type == X264GPU_SLICE_P && !e->have_ref) return -1;
-    if (slice_type == X264GPU_SLICE_I) { e->have_ref = 0; e->poc = 0; }      /* IDR: the DPB is emptied */
+    for (int r0 = 0; r0 < e->nref_l[0]; r0++)
+        for (int r1 = 0; r1 < e->nref_l[1]; r1++) {
+            const int poc0 = e->slot_poc[e->lslot[0][r0]], poc1 = e->slot_poc[e->lslot[1][r1]];
+            const int td = clampi(poc1 - poc0, -128, 127);
+            int dsf = 256;
+            if (td) { const int tb = clampi(e->poc - poc0, -128, 127), tx = (16384 + (abs(td) >> 1)) / td; dsf = clampi((tb * tx + 32) >> 6, -1024, 1023); }
+            dsf >>= 2;
+            e->bipred_weight[r0][r1] = (e->cfg.weightb && dsf >= -64 && dsf <= 128) ? 64 - dsf : 32;
+        }
+}
+
+/* One picture with explicit control (x264gpu_pic): slice type, quantiser, POC, destination slot, reference lists.  B pictures need cfg.rd
+ * and cfg.cabac. */
+int x264o_encoder_encode_pic(x264o_encoder *e, const uint8_t *i420, const x264gpu_pic *pic, x264gpu_mb *mbs, int16_t *levels)
+{
+    int slice_type = pic->slice_type;
     if (slice_type == X264GPU_SLICE_I_NONIDR) slice_type = X264GPU_SLICE_I;      /* same coding tools, the references stay */
+    if (slice_type == X264GPU_SLICE_B && !(e->cfg.rd && e->cfg.cabac)) return -1;
+    if (pic->dst < 0 || pic->dst >= e->slots) return -1;
     e->slice_type = slice_type;
-    e->nref = slice_type == X264GPU_SLICE_I ? 0 : e->have_ref < e->slots - 1 ? e->have_ref : e->slots - 1;
+    e->cur = pic->dst; e->poc = pic->poc; e->keep = pic->keep;
+    for (int l = 0; l < 2; l++) {
+        e->nref_l[l] = slice_type == X264GPU_SLICE_I ? 0 : l == 1 && slice_type != X264GPU_SLICE_B ? 0 : pic->nref[l];
+        if (e->nref_l[l] > X264O_MAX_REFS) return -1;
+        for (int r = 0; r < e->nref_l[l]; r++) { e->lslot[l][r] = pic->slot[l][r]; if (pic->slot[l][r] < 0 || pic->slot[l][r] >= e->slots || pic->slot[l][r] == pic->dst) return -1; }
+    }
+    if (slice_type != X264GPU_SLICE_I && !e->nref_l[0]) return -1;
+    if (slice_type == X264GPU_SLICE_B && !e->nref_l[1]) return -1;
+    e->nref = e->nref_l[0];
+    if (slice_type == X264GPU_SLICE_B) bipred_init(e);
     ingest(e, i420);
-    const int slice_qp = slice_type == X264GPU_SLICE_I ? e->cfg.qp_i : e->cfg.qp_p;
+    const int slice_qp = pic->qp;
     compute_mb_qp(e, slice_qp);
     e->mbs = mbs; e->levels = levels; e->intra_count = 0;
     e->slot_nref[e->cur] = e->nref; e->slot_poc[e->cur] = e->poc; e->slot_ref0poc[e->cur] = e->nref ? e->slot_poc[ref_slot(e, 0)] : 0;
@@ -258,28 +297,56 @@ int x264o_encoder_encode(x264o_encoder *e, const uint8_t *i420, int slice_type, 
         e->row0 = (e->mbh * sl + ns / 2) / ns; e->row1 = (e->mbh * (sl + 1) + ns / 2) / ns;
         if (!e->cfg.slices_plain) e->intra_count = 0;
         e->last_qp = slice_qp;
-        if (e->cfg.cabac && (e->cfg.rd || e->cfg.trellis)) { x264o_cabac_init_states(e->cabac_state, slice_type == X264GPU_SLICE_P, slice_qp); e->last_dqp = 0; }
+        if (e->cfg.cabac && (e->cfg.rd || e->cfg.trellis)) { x264o_cabac_init_states(e->cabac_state, slice_type != X264GPU_SLICE_I, slice_qp); e->last_dqp = 0; }
         for (int mby = e->row0; mby < e->row1; mby++)
             for (int mbx = 0; mbx < e->mbw; mbx++) {
+                const int mi = mby * e->mbw + mbx;
                 x264o_macroblock(e, mbx, mby);
-                e->mbtype[e->cur][mby * e->mbw + mbx] = mbs[mby * e->mbw + mbx].type;
+                const x264gpu_mb *m = &mbs[mi];
+                e->mbtype[e->cur][mi] = m->type;
+                /* the motion a later B picture's direct prediction reads when this picture heads its list 1 */
+                for (int k = 0; k < 4; k++) {
+                    const int intra = m->type <= X264GPU_MB_I16x16, b = m->type >= X264GPU_MB_B_DIRECT;
+                    const int use1 = !intra && b && m->ref[k] < 0;
+                    e->colref[e->cur][mi][k] = (int8_t)(intra ? -1 : use1 ? m->ref1[k] : m->ref[k]);
+                    e->colmv[e->cur][mi][k][0] = intra ? 0 : use1 ? m->mv1[k][0] : m->mv[k][0];
+                    e->colmv[e->cur][mi][k][1] = intra ? 0 : use1 ? m->mv1[k][1] : m->mv[k][1];
+                }
             }
     }
     e->row0 = 0; e->row1 = e->mbh;
     if (e->cfg.aq_mode || e->ext_off_q8) settle_mb_qp(e, mbs, slice_qp);
     if (e->cfg.deblock) deblock_frame(e, mbs);
-    filter_frame(e);
+    if (pic->keep) filter_frame(e);
+    return 0;
+}
+
+/* The I / P stream of the earlier rounds: sliding-window DPB, reference index r = the picture coded r + 1 pictures ago */
+int x264o_encoder_encode(x264o_encoder *e, const uint8_t *i420, int slice_type, x264gpu_mb *mbs, int16_t *levels)
+{
+    if (slice_type == X264GPU_SLICE_P && !e->have_ref) return -1;
+    if (slice_type == X264GPU_SLICE_B) return -1;
+    if (slice_type == X264GPU_SLICE_I) { e->have_ref = 0; e->ring_poc = 0; }      /* IDR: the DPB is emptied */
+    x264gpu_pic pic;
+    memset(&pic, 0, sizeof(pic));
+    const int ring = clampi(e->cfg.refs, 1, X264O_MAX_REFS) + 1;
+    pic.slice_type = slice_type; pic.qp = slice_type == X264GPU_SLICE_P ? e->cfg.qp_p : e->cfg.qp_i; pic.poc = e->ring_poc; pic.dst = e->ring_cur; pic.keep = 1;
+    pic.nref[0] = slice_type == X264GPU_SLICE_P ? (e->have_ref < ring - 1 ? e->have_ref : ring - 1) : 0;
+    for (int r = 0; r < pic.nref[0]; r++) pic.slot[0][r] = (int8_t)((e->ring_cur - 1 - r + 2 * ring) % ring);
+    const int rc = x264o_encoder_encode_pic(e, i420, &pic, mbs, levels);
+    if (rc) return rc;
     /* rotate: the frame just built becomes the reference */
-    e->cur = (e->cur + 1) % e->slots;
+    e->last_slot = e->ring_cur;
+    e->ring_cur = (e->ring_cur + 1) % ring;
     e->have_ref++;
-    e->poc += 2;
+    e->ring_poc += 2;
     return 0;
 }
 
 /* reconstructed (deblocked) picture of the most recent frame, cropped to width x height, I420 */
 void x264o_encoder_get_recon(x264o_encoder *e, uint8_t *out)
 {
-    int w = e->cfg.width, h = e->cfg.height, slot = (e->cur + e->slots - 1) % e->slots;
+    int w = e->cfg.width, h = e->cfg.height, slot = e->cur;
     const pixel *Y = luma_plane(e, slot, 0), *UV = chroma_plane(e, slot);
     for (int y = 0; y < h; y++) memcpy(out + (size_t)y * w, Y + (size_t)y * e->rs, w);
     uint8_t *u = out + (size_t)w * h, *v = u + (size_t)(w / 2) * (h / 2);
@@ -291,7 +358,7 @@ void x264o_encoder_get_recon(x264o_encoder *e, uint8_t *out)
 const uint8_t *x264o_encoder_ref_plane(x264o_encoder *e, int k, int *stride, int *rows)
 {
     *stride = e->rs;
-    int last = (e->cur + e->slots - 1) % e->slots;
+    int last = e->cur;
     if (k < 4) { *rows = e->ch + 2 * PAD; return e->luma[last] + k * e->plane_bytes; }
     *rows = e->ch / 2 + 2 * CPAD;
     return e->chroma[last];

@@ -10,7 +10,7 @@
 #define CPAD 16         /* chroma padding (samples) */
 #define MVCOST_HALF 32768
 #define X264O_MAX_REFS 5
-#define X264O_MAX_SLOTS (X264O_MAX_REFS + 1)     /* references + the picture being built */
+#define X264O_MAX_SLOTS 8                        /* reference pictures of the DPB (cfg.dpb or cfg.refs) + the picture being built */
 #define COST_MAX (1 << 28)
 
 typedef struct x264o_encoder x264o_encoder;
@@ -25,7 +25,12 @@ struct x264o_encoder {
     pixel *luma[X264O_MAX_SLOTS];   /* DPB slots: 4 padded planes each (refs + the picture being built) */
     pixel *chroma[X264O_MAX_SLOTS]; /* padded NV12 */
     int slots;                   /* refs + 1 */
-    int nref;                    /* reference pictures usable by the current P slice */
+    int nref;                    /* reference pictures usable by the current slice in list 0 (= nref_l[0]) */
+    /* the slice's reference lists as DPB slots (x264_reference_build_list; x264gpu_pic): list 0 = earlier pictures, nearest first; list 1 (B) = later
+     * ones; implicit bi-prediction weights of every (list-0, list-1) pair (h->mb.bipred_weight: the weight of the list-0 sample, of 64) */
+    int nref_l[2], lslot[2][X264GPU_MAX_LIST];
+    int bipred_weight[X264GPU_MAX_LIST][X264GPU_MAX_LIST];
+    int keep;                    /* the picture being coded will be a reference */
     int row0, row1;              /* macroblock rows [row0, row1) of the slice being coded (x264 slice threads: cfg.slices per picture) */
     int cur;                     /* DPB slot being reconstructed */
     /* per-picture motion side data living with the DPB slot (x264_frame_t): mv16x16 (= h->mb.mvr[0][0], the 16x16 search result
@@ -34,10 +39,16 @@ struct x264o_encoder {
     uint8_t *mbtype[X264O_MAX_SLOTS];
     int slot_nref[X264O_MAX_SLOTS], slot_poc[X264O_MAX_SLOTS], slot_ref0poc[X264O_MAX_SLOTS];   /* ..., POC of the picture's own reference 0 */
     int16_t (*mvr[X264O_MAX_REFS])[2];   /* h->mb.mvr[0][r], r >= 1: 16x16 search results per reference index of the picture being coded */
+    int16_t (*mvr1[X264O_MAX_REFS])[2];  /* h->mb.mvr[1][r] (B slices) */
+    /* what spatial direct prediction reads from the first picture of list 1 (x264_frame_t ref[] / mv[] of the co-located macroblock): per 8x8
+     * block the reference index the block used (list 0's, else list 1's; -1 intra) and that vector */
+    int8_t (*colref[X264O_MAX_SLOTS])[4];
+    int16_t (*colmv[X264O_MAX_SLOTS])[4][2];
+    const int16_t *lowres_mv1;   /* B: lookahead vectors towards the first picture of list 1 (lowres_mvs[1][d]) */
     int poc;                     /* POC of the picture being coded (2 x pictures since the IDR) */
     uint16_t *cost_mv[52];       /* lambda-scaled mv bit costs per qp, centred at MVCOST_HALF */
     x264o_quant_tables qt;
-    int have_ref;
+    int have_ref, ring_cur, ring_poc, last_slot;      /* x264o_encoder_encode's sliding window: pictures coded since the IDR, next slot, next POC */
     int slice_type;              /* slice being encoded */
     uint8_t *mbqp;               /* quantiser of every macroblock of the picture being coded (slice quantiser, + AQ offset) */
     const int16_t *ext_off_q8;   /* quantiser offsets handed in for the next picture (lookahead: AQ - macroblock-tree), or NULL */
@@ -54,7 +65,7 @@ struct x264o_encoder {
     uint8_t cabac_state[460];
     int last_dqp;
     int b_trellis;               /* the macroblock's FINAL encode of a trellis session is running (h->mb.b_trellis under --trellis 1) */
-    uint8_t *amvd;
+    uint8_t *amvd, *amvd1;
 };
 
 /* cabac_rd.cpp */
@@ -66,6 +77,8 @@ typedef struct x264o_cabac_ctx {
     uint8_t *amvd;
     uint8_t *state;
     int last_dqp, last_qp;
+    int bslice, num_ref1;        /* B slice: mb_skip / mb_type / sub_mb_type of B, both lists' ref_idx and mvd */
+    uint8_t *amvd1;              /* list 1's |mvd| */
 } x264o_cabac_ctx;
 void x264o_cabac_init_states(uint8_t *state, int pslice, int qp);
 long x264o_cabac_mb(x264o_cabac_ctx *c, int mbx, int mby, int size_mode);
@@ -75,8 +88,9 @@ static inline int clampi(int v, int lo, int hi) { return v < lo ? lo : v > hi ? 
 static inline int median3(int a, int b, int c) { int mn = a < b ? a : b, mx = a < b ? b : a; return c < mn ? mn : c > mx ? mx : c; }
 static inline int bs_size_ue(int v) { int n = 0; v++; while (v >> (n + 1)) n++; return 2 * n + 1; }
 
-/* DPB slot of reference index r of the current P slice: r = 0 is the most recent picture */
-static inline int ref_slot(const x264o_encoder *e, int r) { return (e->cur - 1 - r + 2 * e->slots) % e->slots; }
+/* DPB slot of reference index r of list l of the current slice (list 0 of a P slice: r = 0 is the most recent picture) */
+static inline int ref_slot_l(const x264o_encoder *e, int l, int r) { return e->lslot[l][r]; }
+static inline int ref_slot(const x264o_encoder *e, int r) { return e->lslot[0][r]; }
 static inline pixel *luma_plane(const x264o_encoder *e, int slot, int k) { return e->luma[slot] + k * e->plane_bytes + (size_t)PAD * e->rs + PAD; }
 static inline pixel *chroma_plane(const x264o_encoder *e, int slot) { return e->chroma[slot] + (size_t)CPAD * e->rs + 2 * CPAD; }
 

@@ -13,6 +13,7 @@
 #include <stdlib.h>
 #include <string.h>
 #include <vector>
+#include <algorithm>
 
 
 
@@ -46,7 +47,11 @@ const uint8_t kIdxOf[4][4] = { { 0, 1, 4, 5 }, { 2, 3, 6, 7 }, { 8, 9, 12, 13 },
 struct MbInfo {
     int intra, i16, skip;
     int t8;                  // transform_size_8x8_flag (luma residual / Intra_8x8)
-    int mv8[4][2], ref8[4];  // motion per 8x8 block; ref -1 for intra
+    int mv8[4][2], ref8[4];  // motion per 8x8 block, list 0; ref -1 for intra / list not used
+    int mv8b[4][2], ref8b[4]; // ... list 1 (B slices)
+    int bmb;                 // macroblock of a B slice (both lists' fields are meaningful)
+    int direct8;             // B: 8x8 blocks predicted by direct inference (B_Skip / B_Direct_16x16: 15)
+    int cbp_is_direct16;     // B_Skip or B_Direct_16x16 (the neighbour term of mb_type's first bin)
     int qp;
     uint8_t i4mode[16];
     uint8_t tc[24];          // total_coeff per block (for nC)
@@ -54,7 +59,8 @@ struct MbInfo {
     // CABAC context derivation (9.3.3.1.1): what the neighbours' syntax elements were
     int cbp_luma, cbp_chroma, chroma_mode;
     uint32_t cbf;            // coded_block_flag per block: bits 0..15 luma 4x4 (block index), 16..23 chroma AC (plane * 4 + block), 24 luma DC, 25 / 26 chroma DC
-    uint8_t amvd[4][2];      // |mvd| per 8x8 block and component
+    uint8_t amvd[4][2];      // |mvd| per 8x8 block and component, list 0
+    uint8_t amvdb[4][2];     // ... list 1
     int slice;               // number of the slice the macroblock belongs to (availability 6.4.x, deblocking across slice edges)
 };
 
@@ -64,11 +70,21 @@ struct Decoder {
     int pic_init_qp = 26, chroma_qp_offset = 0, deblock_ctrl = 1, num_ref_default = 1, transform8x8_mode = 0, cabac = 0;
     int stride = 0, pad = 32, cpad = 16;
     size_t plane_bytes = 0, cplane_bytes = 0;
-    std::vector<pixel> luma[6], chroma[6];   // DPB slots: up to 5 references + the picture being decoded
+    std::vector<pixel> luma[8], chroma[8];   // picture slots: the references + the picture being decoded
     int cur = 0, slots = 2, have = 0, num_ref_frames = 1, nref_active = 1;
+    // decoded picture buffer (8.2.4, 8.2.5): the short-term reference pictures in decoding order, the picture being decoded, the reference lists
+    struct Ref { int slot, frame_num, poc; };
+    std::vector<Ref> dpb;
+    int log2_max_poc_lsb = 4, prev_poc_msb = 0, prev_poc_lsb = 0, cur_poc = 0, cur_frame_num = 0, cur_is_ref = 1;
+    int weighted_bipred_idc = 0, num_ref1_default = 1, nref1_active = 0;
+    int list_slot[2][16], list_poc[2][16];
+    std::vector<int> pending_mmco;           // picture numbers to mark unused once the picture is complete
+    std::vector<MbInfo> slot_mb[8];          // motion of every kept picture (co-located blocks of direct prediction)
+    std::vector<int> frame_pocs;             // POC of every output picture (decoding order)
     int next_mb = 0, slice_no = 0, pic_disable = 0, pic_a = 0, pic_b = 0;      // slices of the picture being decoded
     std::vector<int> mb_bits;        // CAVLC: bits of the macroblock layer of every macroblock, picture after picture (0 for skipped ones)
-    int ref_slot(int r) const { return (cur - 1 - r + 2 * slots) % slots; }
+    int ref_slot(int r) const { return list_slot[0][r]; }
+    int ref_slot_l(int l, int r) const { return list_slot[l][r]; }
     std::vector<MbInfo> mb;
     bool have_sps = false, have_pps = false;
     std::vector<std::vector<uint8_t>> frames;
@@ -83,7 +99,8 @@ struct Decoder {
         plane_bytes = (size_t)stride * (mbh * 16 + 2 * pad);
         cplane_bytes = (size_t)stride * (mbh * 8 + 2 * cpad);
         slots = num_ref_frames + 1;
-        for (int s = 0; s < slots; s++) { luma[s].assign(4 * plane_bytes, 0); chroma[s].assign(cplane_bytes, 0); }
+        for (int s = 0; s < slots; s++) { luma[s].assign(4 * plane_bytes, 0); chroma[s].assign(cplane_bytes, 0); slot_mb[s].clear(); }
+        dpb.clear();
         mb.assign((size_t)mbw * mbh, MbInfo());
         x264o_quant_init(&qt, 21, 11);
     }
@@ -236,8 +253,10 @@ struct SliceDec {
         if (i > cur_idx || i < first_mb) return 0;                          // not decoded yet / another slice
         if (i == cur_idx) return (refs_known >> k & 1) && cur_refs[k] > 0;
         const MbInfo &m = d.mb[i];
-        return !m.intra && !m.skip && m.ref8[k] > 0;
+        // predicted by direct inference (B_Skip, B_Direct_16x16, direct sub-macroblocks): refIdxZeroFlag's condTerm is 0
+        return !m.intra && !m.skip && !(m.direct8 >> k & 1) && (lst ? m.ref8b[k] : m.ref8[k]) > 0;
     }
+    int lst = 0;                     // B slices: the list the motion helpers read
     int ca_ref(int gx, int gy)
     {
         int ctx = ref_gt0(gx - 1, gy) + 2 * ref_gt0(gx, gy - 1), r = 0;
@@ -249,7 +268,7 @@ struct SliceDec {
         if (gx < 0 || gy < 0 || gx >= 2 * d.mbw || gy >= 2 * d.mbh) return 0;
         const int i = (gy >> 1) * d.mbw + (gx >> 1), k = (gy & 1) * 2 + (gx & 1);
         if (i < first_mb || i > cur_idx || (i == cur_idx && !(known8 >> k & 1))) return 0;
-        return d.mb[i].amvd[k][comp];
+        return lst ? d.mb[i].amvdb[k][comp] : d.mb[i].amvd[k][comp];
     }
     int ca_mvd(int gx, int gy, int comp)
     {
@@ -363,7 +382,10 @@ struct SliceDec {
         if (i < first_mb || i > cur_idx || (i == cur_idx && !(known8 >> k & 1))) return n;      // another slice, or not decoded yet
         n.avail = true;
         const MbInfo &m = d.mb[i];
-        if (!m.intra) { n.ref = m.ref8[k]; n.mvx = m.mv8[k][0]; n.mvy = m.mv8[k][1]; }
+        if (!m.intra) {
+            if (lst) { n.ref = m.ref8b[k]; if (n.ref >= 0) { n.mvx = m.mv8b[k][0]; n.mvy = m.mv8b[k][1]; } else n.ref = -1; }
+            else { n.ref = m.ref8[k]; if (n.ref >= 0) { n.mvx = m.mv8[k][0]; n.mvy = m.mv8[k][1]; } else n.ref = -1; }
+        }
         return n;
     }
     // 8.4.1.3: gx,gy = first 8x8 block of the partition, w8 its width in 8x8 units; shape 1 = 16x8, 2 = 8x16
@@ -388,20 +410,216 @@ struct SliceDec {
         mvp(2 * mbx, 2 * mby, 2, 0, 0, 0, px, py);
     }
 
+    // implicit bi-prediction weights (8.4.2.3.1): w0 for the list-0 sample, of 64
+    int implicit_w0(int r0, int r1) const
+    {
+        if (d.weighted_bipred_idc != 2) return 32;
+        const int poc0 = d.list_poc[0][r0], poc1 = d.list_poc[1][r1];
+        const int tb = clampi(d.cur_poc - poc0, -128, 127), td = clampi(poc1 - poc0, -128, 127);
+        if (td == 0) return 32;
+        const int tx = (16384 + abs(td / 2)) / td, dsf = clampi((tb * tx + 32) >> 6, -1024, 1023);
+        if ((dsf >> 2) < -64 || (dsf >> 2) > 128) return 32;
+        return 64 - (dsf >> 2);
+    }
+    void pred_block(int mbx, int mby, int k, int l, int r, const int mv[2], pixel *y /* 8x8, stride 8 */, pixel *u, pixel *v /* 4x4, stride 4 */)
+    {
+        const int ref = d.ref_slot_l(l, r), ox = (k & 1) * 8, oy = (k >> 1) * 8;
+        pixel *planes[4] = { d.Y(ref, 0), d.Y(ref, 1), d.Y(ref, 2), d.Y(ref, 3) };
+        x264o_mc_luma(y, 8, planes, d.stride, mbx * 16 + ox, mby * 16 + oy, mv[0], mv[1], 8, 8);
+        x264o_mc_chroma(u, v, 4, d.UV(ref), d.stride, mbx * 8 + ox / 2, mby * 8 + oy / 2, mv[0], mv[1], 4, 4);
+    }
     void inter_pred(int mbx, int mby, const MbInfo &m)
     {
         pixel pu[64], pv[64];
+        pixel *rec = d.Y(d.cur) + (size_t)mby * 16 * d.stride + mbx * 16;
         for (int k = 0; k < 4; k++) {
-            int ref = d.ref_slot(m.ref8[k]);
-            pixel *planes[4] = { d.Y(ref, 0), d.Y(ref, 1), d.Y(ref, 2), d.Y(ref, 3) };
-            int ox = (k & 1) * 8, oy = (k >> 1) * 8;
-            x264o_mc_luma(d.Y(d.cur) + (size_t)(mby * 16 + oy) * d.stride + mbx * 16 + ox, d.stride, planes, d.stride, mbx * 16 + ox, mby * 16 + oy,
-                          m.mv8[k][0], m.mv8[k][1], 8, 8);
-            x264o_mc_chroma(pu + (oy / 2) * 8 + ox / 2, pv + (oy / 2) * 8 + ox / 2, 8, d.UV(ref), d.stride, mbx * 8 + ox / 2, mby * 8 + oy / 2,
-                            m.mv8[k][0], m.mv8[k][1], 4, 4);
+            const int ox = (k & 1) * 8, oy = (k >> 1) * 8;
+            pixel y0[64], u0[16], v0[16], y1[64], u1[16], v1[16];
+            const bool use0 = m.ref8[k] >= 0, use1 = m.bmb && m.ref8b[k] >= 0;
+            if (use0) pred_block(mbx, mby, k, 0, m.ref8[k], m.mv8[k], y0, u0, v0);
+            if (use1) pred_block(mbx, mby, k, 1, m.ref8b[k], m.mv8b[k], y1, u1, v1);
+            if (use0 && use1) {
+                // weighted sample prediction, implicit mode (8.4.2.3): logWD 5, no offsets
+                const int w0 = implicit_w0(m.ref8[k], m.ref8b[k]), w1 = 64 - w0;
+                for (int i = 0; i < 64; i++) y0[i] = (pixel)clampi((y0[i] * w0 + y1[i] * w1 + 32) >> 6, 0, 255);
+                for (int i = 0; i < 16; i++) { u0[i] = (pixel)clampi((u0[i] * w0 + u1[i] * w1 + 32) >> 6, 0, 255); v0[i] = (pixel)clampi((v0[i] * w0 + v1[i] * w1 + 32) >> 6, 0, 255); }
+            }
+            const pixel *sy = use0 ? y0 : y1, *su = use0 ? u0 : u1, *sv = use0 ? v0 : v1;
+            for (int yy = 0; yy < 8; yy++) memcpy(rec + (size_t)(oy + yy) * d.stride + ox, sy + yy * 8, 8);
+            for (int yy = 0; yy < 4; yy++) for (int xx = 0; xx < 4; xx++) { pu[(oy / 2 + yy) * 8 + ox / 2 + xx] = su[yy * 4 + xx]; pv[(oy / 2 + yy) * 8 + ox / 2 + xx] = sv[yy * 4 + xx]; }
         }
         pixel *uv = d.UV(d.cur) + (size_t)mby * 8 * d.stride + mbx * 16;
         for (int y = 0; y < 8; y++) for (int x = 0; x < 8; x++) { uv[y * d.stride + 2 * x] = pu[y * 8 + x]; uv[y * d.stride + 2 * x + 1] = pv[y * 8 + x]; }
+    }
+
+    // ---- B slices (CABAC): 7.3.5 with Tables 7-14 / 7-18, binarisations of 9.3.2.5, spatial direct prediction of 8.4.1.2.2 ----
+    int ca_skip_flag_b(int mbx, int mby)
+    {
+        const MbInfo *a = nbA(mbx, mby), *b = nbB(mbx, mby);
+        return cd.decision(24 + (a && !a->skip) + (b && !b->skip));
+    }
+    // mb_type of a B slice: 0 B_Direct_16x16, 1..21 the predicted types of Table 7-14, 22 B_8x8, 23 + n = intra type n
+    int ca_mb_type_b(int mbx, int mby)
+    {
+        const MbInfo *a = nbA(mbx, mby), *b = nbB(mbx, mby);
+        auto nd = [](const MbInfo *n) { return n && !(n->bmb && !n->intra && n->direct8 == 15 && n->cbp_is_direct16); };
+        if (!cd.decision(27 + nd(a) + nd(b))) return 0;
+        if (!cd.decision(27 + 3)) return 1 + cd.decision(27 + 5);
+        int v = cd.decision(27 + 4) << 3;
+        v |= cd.decision(27 + 5) << 2; v |= cd.decision(27 + 5) << 1; v |= cd.decision(27 + 5);
+        if (v < 8) return 3 + v;
+        if (v == 13) return 23 + ca_intra_type(32, 33, 34, 34, 35, 35);
+        if (v == 14) return 11;
+        if (v == 15) return 22;
+        const int b6 = cd.decision(27 + 5);
+        return v == 12 ? 20 + b6 : 12 + (((v & 3) << 1) | b6);
+    }
+    int ca_sub_mb_type_b()           // 0 direct, 1 list 0, 2 list 1, 3 both; anything smaller than 8x8 is outside the subset
+    {
+        if (!cd.decision(36)) return 0;
+        if (!cd.decision(37)) return 1 + cd.decision(39);
+        if (cd.decision(38)) { cd.err = true; return 0; }
+        if (cd.decision(39) || cd.decision(39)) { cd.err = true; return 0; }
+        return 3;
+    }
+    // spatial direct prediction of the whole macroblock (8.4.1.2.2, direct_8x8_inference): fills ref8 / mv8 of both lists for the blocks in mask
+    void direct_spatial(int mbx, int mby, MbInfo &m, int mask)
+    {
+        int ref[2], mv[2][2];
+        const int saved_known = known8;
+        known8 = 0;                                      // the neighbours of the MACROBLOCK: nothing inside it counts
+        for (int l = 0; l < 2; l++) {
+            lst = l;
+            const int gx = 2 * mbx, gy = 2 * mby;
+            Nb a = blk8(gx - 1, gy), b = blk8(gx, gy - 1), c = blk8(gx + 2, gy - 1);
+            if (!c.avail) c = blk8(gx - 1, gy - 1);
+            auto minpos = [](int x, int y) { return x >= 0 && y >= 0 ? (x < y ? x : y) : (x > y ? x : y); };
+            ref[l] = minpos(a.ref, minpos(b.ref, c.ref));
+            mv[l][0] = mv[l][1] = 0;
+            if (ref[l] >= 0) mvp(gx, gy, 2, 0, 0, ref[l], mv[l][0], mv[l][1]);
+        }
+        lst = 0;
+        known8 = saved_known;
+        const bool zero_pred = ref[0] < 0 && ref[1] < 0;
+        if (zero_pred) ref[0] = ref[1] = 0;
+        // the co-located macroblock in the first picture of list 1
+        const std::vector<MbInfo> &colpic = d.slot_mb[d.ref_slot_l(1, 0)];
+        const MbInfo *col = colpic.empty() ? nullptr : &colpic[(size_t)(mby * d.mbw + mbx)];
+        for (int k = 0; k < 4; k++) {
+            if (!(mask >> k & 1)) continue;
+            bool col_zero = false;
+            if (col && !col->intra) {
+                // the corner block of the co-located 8x8: its list-0 motion, or list 1's when list 0 is unused
+                const int rc = col->ref8[k] >= 0 ? col->ref8[k] : col->bmb ? col->ref8b[k] : -1;
+                const int *mc = col->ref8[k] >= 0 ? col->mv8[k] : col->mv8b[k];
+                col_zero = rc == 0 && mc[0] >= -1 && mc[0] <= 1 && mc[1] >= -1 && mc[1] <= 1;
+            }
+            for (int l = 0; l < 2; l++) {
+                int *dref = l ? m.ref8b : m.ref8; int (*dmv)[2] = l ? m.mv8b : m.mv8;
+                dref[k] = ref[l];
+                if (ref[l] < 0 || zero_pred || (ref[l] == 0 && col_zero)) { dmv[k][0] = dmv[k][1] = 0; }
+                else { dmv[k][0] = mv[l][0]; dmv[k][1] = mv[l][1]; }
+            }
+        }
+    }
+    void skipped_mb_b(int i)
+    {
+        MbInfo &m = d.mb[i];
+        const int mbx = i % d.mbw, mby = i / d.mbw;
+        cur_idx = i; known8 = 0;
+        m.intra = 0; m.skip = 1; m.bmb = 1; m.direct8 = 15; m.cbp_is_direct16 = 1; m.qp = qp; memset(m.i4mode, 2, 16);
+        direct_spatial(mbx, mby, m, 15);
+        inter_pred(mbx, mby, m);
+    }
+    // the residual of an inter macroblock, after its prediction: coded_block_pattern, transform_size_8x8_flag, mb_qp_delta, coefficients
+    void inter_residual(int mbx, int mby, MbInfo &m)
+    {
+        int cbp = -1;
+        if (d.cabac) cbp = ca_cbp(mbx, mby);
+        else { int code = (int)br.ue(); if (code > 47) { br.err = true; return; } cbp = cavlcdec::kCbpOfCode[code][1]; }
+        if (cbp < 0) { br.err = true; return; }
+        m.cbp_luma = cbp & 15; m.cbp_chroma = cbp >> 4;
+        m.t8 = (d.transform8x8_mode && (cbp & 15)) ? (d.cabac ? ca_t8(mbx, mby) : br.get1()) : 0;      // all partitions are >= 8x8 in this subset
+        if (cbp) qp += d.cabac ? ca_dqp() : br.se();
+        else last_dqp = 0;
+        qp = (qp + 52) % 52;
+        m.qp = qp;
+        pixel *rec = d.Y(d.cur) + (size_t)mby * 16 * d.stride + mbx * 16;
+        if (m.t8) {
+            for (int i8 = 0; i8 < 4; i8++)
+                if (cbp >> i8 & 1) luma8x8_residual(mbx, mby, i8, true, m, rec + (i8 >> 1) * 8 * d.stride + (i8 & 1) * 8);
+        } else
+        for (int b = 0; b < 16; b++) {
+            if (!(cbp >> (b >> 2) & 1)) continue;
+            int16_t l[16];
+            if (d.cabac) { m.tc[b] = (uint8_t)ca_block(l, 16, 2, cbf_ctx_luma(mbx, mby, m, b)); if (m.tc[b]) m.cbf |= 1u << b; }
+            else m.tc[b] = (uint8_t)residual_block(br, l, 16, nc_luma(mbx, mby, b));
+            if (m.tc[b]) m.nz |= 1u << b;
+            dctcoef blk[16];
+            for (int k = 0; k < 16; k++) blk[x264o_zigzag4[k]] = l[k];
+            x264o_dequant_4x4(blk, d.qt.dequant4_mf, qp);
+            x264o_add4x4_idct(rec + kBlkY[b] * 4 * d.stride + kBlkX[b] * 4, d.stride, blk);
+        }
+        chroma_residual(mbx, mby, cbp >> 4, m, x264o_chroma_qp[clampi(qp + d.chroma_qp_offset, 0, 51)]);
+    }
+
+    void inter_mb_b(int mbx, int mby, int value, MbInfo &m)
+    {
+        static const int8_t geom[4][4][4] = { { { 0, 0, 2, 2 } }, { { 0, 0, 2, 1 }, { 0, 1, 2, 1 } }, { { 0, 0, 1, 2 }, { 1, 0, 1, 2 } },
+                                              { { 0, 0, 1, 1 }, { 1, 0, 1, 1 }, { 0, 1, 1, 1 }, { 1, 1, 1, 1 } } };
+        // Table 7-14: prediction of the (at most two) partitions: 0 list 0, 1 list 1, 2 both
+        static const int8_t pair[9][2] = { { 0, 0 }, { 1, 1 }, { 0, 1 }, { 1, 0 }, { 0, 2 }, { 1, 2 }, { 2, 0 }, { 2, 1 }, { 2, 2 } };
+        m.intra = 0; m.i16 = 0; m.bmb = 1; m.direct8 = 0; m.cbp_is_direct16 = 0; memset(m.i4mode, 2, 16);
+        m.cbf = 0; m.chroma_mode = 0;
+        for (int k = 0; k < 4; k++) { m.ref8[k] = m.ref8b[k] = -1; m.mv8[k][0] = m.mv8[k][1] = m.mv8b[k][0] = m.mv8b[k][1] = 0; }
+        int shape, use[4] = { 0, 0, 0, 0 };       // 0 list 0, 1 list 1, 2 both, 3 direct
+        if (value == 0) { shape = 0; m.direct8 = 15; m.cbp_is_direct16 = 1; direct_spatial(mbx, mby, m, 15); known8 = 15; }
+        else {
+            if (value <= 3) { shape = 0; use[0] = value - 1; }
+            else if (value <= 21) { shape = 1 + ((value - 4) & 1); use[0] = pair[(value - 4) >> 1][0]; use[1] = pair[(value - 4) >> 1][1]; }
+            else {
+                shape = 3;
+                for (int k = 0; k < 4; k++) { const int t = ca_sub_mb_type_b(); use[k] = t == 0 ? 3 : t - 1; if (t == 0) m.direct8 |= 1 << k; }
+                if (m.direct8) direct_spatial(mbx, mby, m, m.direct8);
+            }
+            const int nparts = shape == 0 ? 1 : shape == 3 ? 4 : 2;
+            int refs[2][4] = { { 0, 0, 0, 0 }, { 0, 0, 0, 0 } };
+            for (lst = 0; lst < 2; lst++) {
+                refs_known = 0;
+                const int nact = lst ? d.nref1_active : d.nref_active;
+                for (int k = 0; k < nparts; k++) {
+                    const int8_t *g = geom[shape][k];
+                    const bool sends = use[k] == 2 || use[k] == lst;
+                    if (sends && nact > 1) { refs[lst][k] = ca_ref(2 * mbx + g[0], 2 * mby + g[1]); if (refs[lst][k] >= nact) { br.err = true; lst = 0; return; } }
+                    for (int yy = g[1]; yy < g[1] + g[3]; yy++) for (int xx = g[0]; xx < g[0] + g[2]; xx++) { cur_refs[yy * 2 + xx] = sends ? refs[lst][k] : 0; refs_known |= 1 << (yy * 2 + xx); }
+                }
+            }
+            for (lst = 0; lst < 2; lst++) {
+                known8 = 0;
+                for (int k = 0; k < nparts; k++) {
+                    const int8_t *g = geom[shape][k];
+                    const bool sends = use[k] == 2 || use[k] == lst;
+                    int *dref = lst ? m.ref8b : m.ref8; int (*dmv)[2] = lst ? m.mv8b : m.mv8; uint8_t (*da)[2] = lst ? m.amvdb : m.amvd;
+                    if (sends) {
+                        int px, py;
+                        // the partition's own blocks must not look like neighbours that use this reference yet: they are unknown until set below
+                        mvp(2 * mbx + g[0], 2 * mby + g[1], g[2], shape, k, refs[lst][k], px, py);
+                        const int dx = ca_mvd(2 * mbx + g[0], 2 * mby + g[1], 0), dy = ca_mvd(2 * mbx + g[0], 2 * mby + g[1], 1);
+                        for (int yy = g[1]; yy < g[1] + g[3]; yy++)
+                            for (int xx = g[0]; xx < g[0] + g[2]; xx++) {
+                                const int b8 = yy * 2 + xx;
+                                dref[b8] = refs[lst][k]; dmv[b8][0] = px + dx; dmv[b8][1] = py + dy;
+                                da[b8][0] = (uint8_t)(abs(dx) < 255 ? abs(dx) : 255); da[b8][1] = (uint8_t)(abs(dy) < 255 ? abs(dy) : 255);
+                            }
+                    }
+                    for (int yy = g[1]; yy < g[1] + g[3]; yy++) for (int xx = g[0]; xx < g[0] + g[2]; xx++) known8 |= 1 << (yy * 2 + xx);
+                }
+            }
+            lst = 0;
+            known8 = 15;
+        }
+        inter_pred(mbx, mby, m);
+        inter_residual(mbx, mby, m);
     }
 
     void chroma_residual(int mbx, int mby, int cbp_chroma, MbInfo &m, int qpc)
@@ -649,34 +867,8 @@ struct SliceDec {
                     known8 |= 1 << b8;
                 }
         }
-        int cbp = -1;
-        if (d.cabac) cbp = ca_cbp(mbx, mby);
-        else { int code = (int)br.ue(); if (code > 47) { br.err = true; return; } cbp = cavlcdec::kCbpOfCode[code][1]; }
-        if (cbp < 0) { br.err = true; return; }
-        m.cbp_luma = cbp & 15; m.cbp_chroma = cbp >> 4;
-        m.t8 = (d.transform8x8_mode && (cbp & 15)) ? (d.cabac ? ca_t8(mbx, mby) : br.get1()) : 0;      // all partitions are >= 8x8 in this subset
-        if (cbp) qp += d.cabac ? ca_dqp() : br.se();
-        else last_dqp = 0;
-        qp = (qp + 52) % 52;
-        m.qp = qp;
         inter_pred(mbx, mby, m);
-        pixel *rec = d.Y(d.cur) + (size_t)mby * 16 * d.stride + mbx * 16;
-        if (m.t8) {
-            for (int i8 = 0; i8 < 4; i8++)
-                if (cbp >> i8 & 1) luma8x8_residual(mbx, mby, i8, true, m, rec + (i8 >> 1) * 8 * d.stride + (i8 & 1) * 8);
-        } else
-        for (int b = 0; b < 16; b++) {
-            if (!(cbp >> (b >> 2) & 1)) continue;
-            int16_t l[16];
-            if (d.cabac) { m.tc[b] = (uint8_t)ca_block(l, 16, 2, cbf_ctx_luma(mbx, mby, m, b)); if (m.tc[b]) m.cbf |= 1u << b; }
-            else m.tc[b] = (uint8_t)residual_block(br, l, 16, nc_luma(mbx, mby, b));
-            if (m.tc[b]) m.nz |= 1u << b;
-            dctcoef blk[16];
-            for (int k = 0; k < 16; k++) blk[x264o_zigzag4[k]] = l[k];
-            x264o_dequant_4x4(blk, d.qt.dequant4_mf, qp);
-            x264o_add4x4_idct(rec + kBlkY[b] * 4 * d.stride + kBlkX[b] * 4, d.stride, blk);
-        }
-        chroma_residual(mbx, mby, cbp >> 4, m, x264o_chroma_qp[clampi(qp + d.chroma_qp_offset, 0, 51)]);
+        inter_residual(mbx, mby, m);
     }
 
     void skipped_mb(int i)
@@ -693,14 +885,21 @@ struct SliceDec {
     {
         const int n = d.mbw * d.mbh;
         while (br.pos & 7) if (!br.get1()) { br.err = true; return; }          // cabac_alignment_one_bit
-        cd.start(br.p, br.n, br.pos, slice_type == 0, qp);
+        cd.start(br.p, br.n, br.pos, slice_type != 2, qp);
         end_mb = -1;
         for (int i = first_mb; i < n && !cd.err && !br.err; i++) {
             const int mbx = i % d.mbw, mby = i / d.mbw;
             cur_idx = i; known8 = 0;
             d.mb[i] = MbInfo(); d.mb[i].slice = slice_no;
             if (slice_type == 0 && ca_skip_flag(mbx, mby)) { skipped_mb(i); last_dqp = 0; }
-            else {
+            else if (slice_type == 1 && ca_skip_flag_b(mbx, mby)) { if (getenv("X264O_DEC_DEBUG")) fprintf(stderr, "B mb %d,%d skip\n", mbx, mby); skipped_mb_b(i); last_dqp = 0; }
+            else if (slice_type == 1) {
+                MbInfo &m = d.mb[i];
+                const int t = ca_mb_type_b(mbx, mby);
+                if (getenv("X264O_DEC_DEBUG")) fprintf(stderr, "B mb %d,%d type %d\n", mbx, mby, t);
+                if (t <= 22) inter_mb_b(mbx, mby, t, m);
+                else intra_mb(mbx, mby, t - 23, m);
+            } else {
                 MbInfo &m = d.mb[i];
                 const int t = slice_type == 0 ? ca_mb_type_p() : ca_mb_type_i(mbx, mby);
                 if (slice_type == 0 && t <= 3) inter_mb(mbx, mby, t, m);
@@ -751,8 +950,24 @@ struct SliceDec {
         if (p.intra || q.intra) return mbedge ? 4 : 3;
         if ((p.nz >> pb & 1) || (q.nz >> qb & 1)) return 2;
         int p8 = pb >> 2, q8 = qb >> 2;           // block index / 4 = 8x8 quadrant in H.264 block order
-        if (p.ref8[p8] != q.ref8[q8]) return 1;
-        return abs(p.mv8[p8][0] - q.mv8[q8][0]) >= 4 || abs(p.mv8[p8][1] - q.mv8[q8][1]) >= 4;
+        if (!p.bmb && !q.bmb) {
+            if (p.ref8[p8] != q.ref8[q8]) return 1;
+            return abs(p.mv8[p8][0] - q.mv8[q8][0]) >= 4 || abs(p.mv8[p8][1] - q.mv8[q8][1]) >= 4;
+        }
+        // B slices (8.7.2.1): different reference PICTURES or a different number of vectors -> 1; else the vectors that point into the same picture
+        // are compared (both pairings when the two pictures of a block coincide)
+        int pp[2], qq[2]; const int *pm[2], *qm[2];
+        int np = 0, nq = 0;
+        if (p.ref8[p8] >= 0) { pp[np] = d.ref_slot_l(0, p.ref8[p8]); pm[np++] = p.mv8[p8]; }
+        if (p.bmb && p.ref8b[p8] >= 0) { pp[np] = d.ref_slot_l(1, p.ref8b[p8]); pm[np++] = p.mv8b[p8]; }
+        if (q.ref8[q8] >= 0) { qq[nq] = d.ref_slot_l(0, q.ref8[q8]); qm[nq++] = q.mv8[q8]; }
+        if (q.bmb && q.ref8b[q8] >= 0) { qq[nq] = d.ref_slot_l(1, q.ref8b[q8]); qm[nq++] = q.mv8b[q8]; }
+        auto far = [](const int *x, const int *y) { return abs(x[0] - y[0]) >= 4 || abs(x[1] - y[1]) >= 4; };
+        if (np != nq) return 1;
+        if (np == 1) return pp[0] != qq[0] || far(pm[0], qm[0]);
+        if (!((pp[0] == qq[0] && pp[1] == qq[1]) || (pp[0] == qq[1] && pp[1] == qq[0]))) return 1;
+        if (pp[0] != pp[1]) return pp[0] == qq[0] ? (far(pm[0], qm[0]) || far(pm[1], qm[1])) : (far(pm[0], qm[1]) || far(pm[1], qm[0]));
+        return (far(pm[0], qm[0]) || far(pm[1], qm[1])) && (far(pm[0], qm[1]) || far(pm[1], qm[0]));
     }
     void deblock()
     {
@@ -806,6 +1021,9 @@ void finish_picture(Decoder &d)
     const pixel *uv = d.UV(d.cur);
     for (int y = 0; y < h / 2; y++) for (int x = 0; x < w / 2; x++) { u[y * (w / 2) + x] = uv[(size_t)y * d.stride + 2 * x]; v[y * (w / 2) + x] = uv[(size_t)y * d.stride + 2 * x + 1]; }
     d.frames.push_back(std::move(f));
+    d.frame_pocs.push_back(d.cur_poc);
+    d.have++;
+    if (!d.cur_is_ref) return;                              // a non-reference picture leaves the DPB as it is
     pixel *planes[4] = { d.Y(d.cur, 0), d.Y(d.cur, 1), d.Y(d.cur, 2), d.Y(d.cur, 3) };
     x264o_frame_filter(planes, d.stride, d.mbw * 16, d.mbh * 16, d.pad);
     pixel *c = d.UV(d.cur);
@@ -817,9 +1035,23 @@ void finish_picture(Decoder &d)
                 c[(size_t)y * d.stride + 2 * x] = c[(size_t)sy * d.stride + 2 * sx];
                 c[(size_t)y * d.stride + 2 * x + 1] = c[(size_t)sy * d.stride + 2 * sx + 1];
             }
-    d.cur = (d.cur + 1) % d.slots;
-    d.have++;
+    d.slot_mb[d.cur] = d.mb;
+    // decoded reference picture marking (8.2.5): the slice's operations, else the sliding window
+    const int max_frame_num = 1 << d.log2_max_frame_num;
+    auto picnum = [&](const Decoder::Ref &r) { return r.frame_num > d.cur_frame_num ? r.frame_num - max_frame_num : r.frame_num; };
+    if (!d.pending_mmco.empty()) {
+        for (int pn : d.pending_mmco)
+            for (size_t i = 0; i < d.dpb.size(); i++) if (picnum(d.dpb[i]) == (pn > d.cur_frame_num ? pn - max_frame_num : pn)) { d.dpb.erase(d.dpb.begin() + (long)i); break; }
+    }
+    if ((int)d.dpb.size() >= d.num_ref_frames) {
+        size_t oldest = 0;
+        for (size_t i = 1; i < d.dpb.size(); i++) if (picnum(d.dpb[i]) < picnum(d.dpb[oldest])) oldest = i;
+        d.dpb.erase(d.dpb.begin() + (long)oldest);
+    }
+    d.dpb.push_back(Decoder::Ref{ d.cur, d.cur_frame_num, d.cur_poc });
 }
+
+static bool reject(int line) { if (getenv("X264O_DEC_DEBUG")) fprintf(stderr, "h264dec: rejected at line %d\n", line); return false; }
 
 bool decode_nal(Decoder &d, const uint8_t *nal, size_t n)
 {
@@ -834,15 +1066,16 @@ bool decode_nal(Decoder &d, const uint8_t *nal, size_t n)
     if (type == 7) {
         int profile = (int)br.get(8); br.get(8); br.get(8); br.ue();
         if (profile >= 100) {                               // High: 4:2:0, 8 bit, flat scaling lists only
-            if (br.ue() != 1 || br.ue() != 0 || br.ue() != 0 || br.get1() || br.get1()) return false;
+            if (br.ue() != 1 || br.ue() != 0 || br.ue() != 0 || br.get1() || br.get1()) return reject(__LINE__);
         }
         d.log2_max_frame_num = (int)br.ue() + 4;
         d.poc_type = (int)br.ue();
-        if (d.poc_type != 2) return false;
+        if (d.poc_type != 2 && d.poc_type != 0) return reject(__LINE__);
+        if (d.poc_type == 0) d.log2_max_poc_lsb = (int)br.ue() + 4;
         d.num_ref_frames = (int)br.ue(); br.get1();
-        if (d.num_ref_frames < 1 || d.num_ref_frames > 5) return false;
+        if (d.num_ref_frames < 1 || d.num_ref_frames > 6) return reject(__LINE__);
         d.mbw = (int)br.ue() + 1; d.mbh = (int)br.ue() + 1;
-        if (!br.get1()) return false;                       // frame_mbs_only
+        if (!br.get1()) return reject(__LINE__);                       // frame_mbs_only
         br.get1();
         d.crop_r = d.crop_b = 0;
         if (br.get1()) { br.ue(); d.crop_r = 2 * (int)br.ue(); br.ue(); d.crop_b = 2 * (int)br.ue(); }
@@ -854,51 +1087,134 @@ bool decode_nal(Decoder &d, const uint8_t *nal, size_t n)
     if (type == 8) {
         br.ue(); br.ue();
         d.cabac = br.get1();                                // entropy_coding_mode_flag
-        br.get1(); if (br.ue()) return false;
-        d.num_ref_default = (int)br.ue() + 1; br.ue();
-        if (br.get1() || br.get(2)) return false;           // weighted prediction
+        br.get1(); if (br.ue()) return reject(__LINE__);
+        d.num_ref_default = (int)br.ue() + 1; d.num_ref1_default = (int)br.ue() + 1;
+        if (br.get1()) return reject(__LINE__);                        // weighted_pred_flag: explicit weights are outside the subset
+        d.weighted_bipred_idc = (int)br.get(2);
+        if (d.weighted_bipred_idc == 1) return reject(__LINE__);
         d.pic_init_qp = 26 + br.se(); br.se();
         d.chroma_qp_offset = br.se();
         d.deblock_ctrl = br.get1();
-        if (br.get1()) return false;                        // constrained intra
+        if (br.get1()) return reject(__LINE__);                        // constrained intra
         br.get1();
         d.transform8x8_mode = 0;
         if (br.more_rbsp_data()) {
             d.transform8x8_mode = br.get1();
-            if (br.get1()) return false;                    // pic_scaling_matrix_present_flag
-            if (br.se() != d.chroma_qp_offset) return false; // second_chroma_qp_index_offset
+            if (br.get1()) return reject(__LINE__);                    // pic_scaling_matrix_present_flag
+            if (br.se() != d.chroma_qp_offset) return reject(__LINE__); // second_chroma_qp_index_offset
         }
         d.have_pps = !br.err;
         return d.have_pps;
     }
     if (type == 1 || type == 5) {
-        if (!d.have_sps || !d.have_pps) return false;
+        if (!d.have_sps || !d.have_pps) return reject(__LINE__);
         const int first_mb = (int)br.ue();                  // first_mb_in_slice: slices arrive in order and tile the picture
-        if (first_mb != d.next_mb || first_mb >= d.mbw * d.mbh) return false;
+        if (first_mb != d.next_mb || first_mb >= d.mbw * d.mbh) return reject(__LINE__);
         int st = (int)br.ue() % 5;
-        if (st != 0 && st != 2) return false;
+        if (st != 0 && st != 1 && st != 2) return reject(__LINE__);
+        if (st == 1 && !d.cabac) return reject(__LINE__);              // B slices: CABAC only in this checker
         br.ue();
-        br.get(d.log2_max_frame_num);
+        const int frame_num = (int)br.get(d.log2_max_frame_num), max_frame_num = 1 << d.log2_max_frame_num;
         if (type == 5) br.ue();
-        if (type == 5 && first_mb == 0) d.have = 0;         // IDR empties the DPB
-        d.nref_active = d.num_ref_default;
-        if (st == 0) {
-            if (br.get1()) d.nref_active = (int)br.ue() + 1; // num_ref_idx_active_override_flag
-            if (br.get1()) return false;                    // list modification
-            if (d.nref_active > d.have || d.nref_active > d.num_ref_frames) return false;   // refers to pictures not in the DPB
+        const int nal_ref_idc = (nal[0] >> 5) & 3;
+        int poc = 0;
+        if (d.poc_type == 0) {
+            // 8.2.1.1: PicOrderCntMsb from the previous REFERENCE picture's
+            const int lsb = (int)br.get(d.log2_max_poc_lsb), max_lsb = 1 << d.log2_max_poc_lsb;
+            if (type == 5) { d.prev_poc_msb = 0; d.prev_poc_lsb = 0; }
+            int msb = d.prev_poc_msb;
+            if (lsb < d.prev_poc_lsb && d.prev_poc_lsb - lsb >= max_lsb / 2) msb += max_lsb;
+            else if (lsb > d.prev_poc_lsb && lsb - d.prev_poc_lsb > max_lsb / 2) msb -= max_lsb;
+            poc = msb + lsb;
+            if (first_mb == 0 && nal_ref_idc) { d.prev_poc_msb = msb; d.prev_poc_lsb = lsb; }
+        } else poc = 2 * (type == 5 ? 0 : d.have);          // type 2: output order is decoding order (only used for bookkeeping here)
+        if (first_mb == 0) {
+            if (type == 5) { d.have = 0; d.dpb.clear(); }   // IDR empties the DPB
+            d.cur_poc = poc; d.cur_frame_num = frame_num; d.cur_is_ref = nal_ref_idc != 0;
+            // a free picture slot
+            for (int sl = 0; sl < d.slots; sl++) { bool used = false; for (auto &r : d.dpb) used |= r.slot == sl; if (!used) { d.cur = sl; break; } }
+            d.pending_mmco.clear();
         }
-        if ((nal[0] >> 5) & 3) { if (type == 5) { br.get1(); br.get1(); } else if (br.get1()) return false; }
-        if (d.cabac && st == 0 && br.ue() != 0) return false;   // cabac_init_idc: only the tables of 0 are in this checker
+        if (st == 1 && !br.get1()) return reject(__LINE__);            // direct_spatial_mv_pred_flag: temporal direct is outside the subset
+        d.nref_active = d.num_ref_default; d.nref1_active = st == 1 ? d.num_ref1_default : 0;
+        if (st != 2) {
+            if (br.get1()) { d.nref_active = (int)br.ue() + 1; if (st == 1) d.nref1_active = (int)br.ue() + 1; }   // num_ref_idx_active_override_flag
+            // ---- reference picture lists: initialisation (8.2.4.2) ----
+            auto picnum = [&](const Decoder::Ref &r) { return r.frame_num > frame_num ? r.frame_num - max_frame_num : r.frame_num; };
+            std::vector<Decoder::Ref> init[2];
+            if (st == 0) {
+                init[0] = d.dpb;
+                std::sort(init[0].begin(), init[0].end(), [&](const Decoder::Ref &x, const Decoder::Ref &y) { return picnum(x) > picnum(y); });
+            } else {
+                std::vector<Decoder::Ref> before, after;
+                for (auto &r : d.dpb) (r.poc < poc ? before : after).push_back(r);
+                std::sort(before.begin(), before.end(), [](const Decoder::Ref &x, const Decoder::Ref &y) { return x.poc > y.poc; });
+                std::sort(after.begin(), after.end(), [](const Decoder::Ref &x, const Decoder::Ref &y) { return x.poc < y.poc; });
+                init[0] = before; init[0].insert(init[0].end(), after.begin(), after.end());
+                init[1] = after; init[1].insert(init[1].end(), before.begin(), before.end());
+                if (init[1].size() > 1 && init[0].size() == init[1].size()) {
+                    bool same = true;
+                    for (size_t i = 0; i < init[0].size(); i++) same &= init[0][i].slot == init[1][i].slot;
+                    if (same) std::swap(init[1][0], init[1][1]);
+                }
+            }
+            for (int l = 0; l <= (st == 1 ? 1 : 0); l++) {
+                const int nact = l ? d.nref1_active : d.nref_active;
+                std::vector<Decoder::Ref> list = init[l];
+                if ((int)list.size() > nact) list.resize((size_t)nact);
+                // ---- modification (8.2.4.3.1): short-term pictures by picture number difference ----
+                if (br.get1()) {
+                    int pred = frame_num, idx = 0;
+                    for (;;) {
+                        const int idc = (int)br.ue();
+                        if (idc == 3) break;
+                        if (idc > 1 || br.err) return reject(__LINE__);
+                        const int absdiff = (int)br.ue() + 1;
+                        int nowrap = idc == 0 ? pred - absdiff : pred + absdiff;
+                        if (idc == 0 && nowrap < 0) nowrap += max_frame_num;
+                        if (idc == 1 && nowrap >= max_frame_num) nowrap -= max_frame_num;
+                        pred = nowrap;
+                        const int pn = nowrap > frame_num ? nowrap - max_frame_num : nowrap;
+                        const Decoder::Ref *pic = nullptr;
+                        for (auto &r : d.dpb) if (picnum(r) == pn) pic = &r;
+                        if (!pic) return reject(__LINE__);
+                        // insert at idx, drop the later duplicate
+                        const Decoder::Ref ins = *pic;
+                        list.insert(list.begin() + idx, ins);
+                        for (size_t j = (size_t)idx + 1; j < list.size(); j++) if (list[j].slot == ins.slot) { list.erase(list.begin() + (long)j); break; }
+                        if ((int)list.size() > nact) list.resize((size_t)nact);
+                        idx++;
+                    }
+                }
+                if ((int)list.size() < nact) return reject(__LINE__);  // refers to pictures not in the DPB
+                for (int i = 0; i < nact; i++) { d.list_slot[l][i] = list[(size_t)i].slot; d.list_poc[l][i] = list[(size_t)i].poc; }
+            }
+        }
+        if (nal_ref_idc) {
+            if (type == 5) { br.get1(); br.get1(); }
+            else if (br.get1()) {                           // adaptive_ref_pic_marking_mode_flag
+                for (;;) {
+                    const int op = (int)br.ue();
+                    if (op == 0) break;
+                    if (op != 1 || br.err) return reject(__LINE__);    // only "mark a short-term picture unused"
+                    const int pn = frame_num - ((int)br.ue() + 1);
+                    if (first_mb == 0) d.pending_mmco.push_back(pn);
+                }
+            }
+        }
+        if (d.cabac && st != 2 && br.ue() != 0) return reject(__LINE__);   // cabac_init_idc: only the tables of 0 are in this checker
         int qp = d.pic_init_qp + br.se();
         int disable = 0, a = 0, b = 0;
         if (d.deblock_ctrl) { disable = (int)br.ue(); if (disable != 1) { a = 2 * br.se(); b = 2 * br.se(); } }
+        if (getenv("X264O_DEC_DEBUG")) fprintf(stderr, "slice: type %d frame_num %d poc %d nref %d/%d qp %d disable %d bitpos %zu l0 %d,%d,%d l1 %d,%d\n", st, d.cur_frame_num, d.cur_poc, d.nref_active, d.nref1_active, qp, disable, br.pos,
+                                               d.list_poc[0][0], d.list_poc[0][1], d.list_poc[0][2], d.list_poc[1][0], d.list_poc[1][1]);
         SliceDec sd{ d, br, st, qp, disable, a, b };
         sd.first_mb = first_mb; sd.slice_no = d.slice_no++;
         if (first_mb == 0) d.mb_bits.resize(d.mb_bits.size() + (size_t)(d.mbw * d.mbh), 0);
-        if (first_mb) { if (disable != d.pic_disable || a != d.pic_a || b != d.pic_b) return false; }      // one filter setting per picture in this checker
+        if (first_mb) { if (disable != d.pic_disable || a != d.pic_a || b != d.pic_b) return reject(__LINE__); }      // one filter setting per picture in this checker
         else { d.pic_disable = disable; d.pic_a = a; d.pic_b = b; }
         sd.run();
-        if (br.err || sd.end_mb <= first_mb) return false;
+        if (br.err || sd.end_mb <= first_mb) return reject(__LINE__);
         d.next_mb = sd.end_mb;
         if (d.next_mb == d.mbw * d.mbh) {                   // the picture is complete
             sd.deblock();
@@ -924,6 +1240,15 @@ int x264o_h264_last_mb_bits(int *out, int cap)
     return n;
 }
 
+static std::vector<int> g_pocs;
+// POC of every picture of the last x264o_h264_decode call, in decoding order (the pictures are returned in that order)
+int x264o_h264_last_pocs(int *out, int cap)
+{
+    const int n = (int)g_pocs.size();
+    for (int i = 0; i < n && i < cap; i++) out[i] = g_pocs[(size_t)i];
+    return n;
+}
+
 // Decodes an Annex-B stream.  Returns the number of pictures, or -1 on a syntax error / unsupported
 // feature.  Pictures are written back to back (cropped I420) into `out` if it is large enough.
 int x264o_h264_decode(const uint8_t *data, size_t n, uint8_t *out, size_t out_cap, int *width, int *height)
@@ -942,7 +1267,7 @@ int x264o_h264_decode(const uint8_t *data, size_t n, uint8_t *out, size_t out_ca
     }
     if (width) *width = d.width;
     if (height) *height = d.height;
-    g_mb_bits = d.mb_bits;
+    g_mb_bits = d.mb_bits; g_pocs = d.frame_pocs;
     size_t fsz = (size_t)d.width * d.height * 3 / 2, off = 0;
     for (auto &f : d.frames) { if (off + fsz <= out_cap) memcpy(out + off, f.data(), fsz); off += fsz; }
     return (int)d.frames.size();

@@ -135,7 +135,7 @@ def plane_ptrs(planes, stride, pad):
 # ---- frame pipeline (oracle/encoder.c) ----
 import sys
 sys.path.insert(0, ROOT)
-from x264vfw_amd.lib import Config, MbRecord, MB_LEVELS  # noqa: E402  (plain ctypes structs, no GPU needed)
+from x264vfw_amd.lib import Config, MbRecord, MB_LEVELS, Pic, make_pic  # noqa: E402,F401  (plain ctypes structs, no GPU needed)
 
 _sig("x264o_encoder_create", C.c_void_p, [C.POINTER(Config)])
 _sig("x264o_encoder_destroy", None, [C.c_void_p])
@@ -143,6 +143,7 @@ _sig("x264o_encoder_mb_count", _i, [C.c_void_p])
 _sig("x264o_encoder_set_qp", None, [C.c_void_p, _i, _i])
 _sig("x264o_encoder_set_mb_qp_offsets", None, [C.c_void_p, C.c_void_p])
 _sig("x264o_encoder_encode", _i, [C.c_void_p, C.c_void_p, _i, C.c_void_p, C.c_void_p])
+_sig("x264o_encoder_encode_pic", _i, [C.c_void_p, C.c_void_p, C.POINTER(Pic), C.c_void_p, C.c_void_p])
 _sig("x264o_encoder_get_recon", None, [C.c_void_p, C.c_void_p])
 _sig("x264o_encoder_ref_plane", C.c_void_p, [C.c_void_p, _i, C.POINTER(_i), C.POINTER(_i)])
 _sig("x264o_lambda", _i, [_i])
@@ -152,6 +153,20 @@ MB_DTYPE = np.dtype([("type", "u1"), ("i16_mode", "u1"), ("chroma_mode", "u1"), 
                      ("cbp_chroma", "u1"), ("partition", "u1"), ("ref", "i1", 4), ("i4_mode", "u1", 16),
                      ("transform8x8", "u1"), ("mv", "<i2", (4, 2)), ("nnz", "<u4"), ("cost", "<i4"), ("aux", "<i4", 3)])
 assert MB_DTYPE.itemsize == 64 == C.sizeof(MbRecord)
+SLICE_P, SLICE_B, SLICE_I, SLICE_I_NONIDR = 0, 1, 2, 3
+MB_B_DIRECT, MB_B_SKIP, MB_B_INTER, MB_B_8x8 = 7, 8, 9, 10
+
+
+def mb_ref1(mbs):
+    """list-1 reference indices of B inter macroblocks (the first four i4_mode bytes)"""
+    return mbs["i4_mode"][..., :4].view(np.int8)
+
+
+def mb_mv1(mbs):
+    """list-1 vectors of B inter macroblocks (the cost / aux bytes)"""
+    raw = np.concatenate([mbs["cost"][..., None], mbs["aux"]], axis=-1).astype("<i4")
+    return raw.view("<i2").reshape(mbs.shape + (4, 2))
+
 
 
 def default_config(width, height, streams=1, **kw):
@@ -175,6 +190,15 @@ class OracleEncoder:
         i420 = np.ascontiguousarray(i420, np.uint8)
         rc = L.x264o_encoder_encode(self.h, ptr(i420), slice_type, ptr(mbs), ptr(lv))
         assert rc == 0
+        return mbs, lv
+
+    def encode_pic(self, i420, pic):
+        """one picture with explicit control (lib.make_pic): B pictures, explicit reference lists"""
+        mbs = np.zeros(self.n, MB_DTYPE)
+        lv = np.zeros((self.n, MB_LEVELS), np.int16)
+        i420 = np.ascontiguousarray(i420, np.uint8)
+        rc = L.x264o_encoder_encode_pic(self.h, ptr(i420), C.byref(pic), ptr(mbs), ptr(lv))
+        assert rc == 0, rc
         return mbs, lv
 
     def cabac_states(self):
@@ -328,6 +352,16 @@ def lsmash_read_mp4(path, max_samples=256):
 
 # ---- bitstream checker (oracle/h264dec.cpp) ----
 _sig("x264o_h264_decode", _i, [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.POINTER(_i), C.POINTER(_i)])
+
+
+_sig("x264o_h264_last_pocs", _i, [C.c_void_p, _i])
+
+
+def h264_last_pocs():
+    """picture order counts of the pictures the last h264_decode returned (decoding order)"""
+    out = np.zeros(4096, np.int32)
+    n = L.x264o_h264_last_pocs(ptr(out), out.size)
+    return out[:n].tolist()
 
 
 def h264_decode(stream, max_frames, w, h):

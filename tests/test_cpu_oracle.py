@@ -100,7 +100,7 @@ def test_abi_exports_every_declared_symbol():
     so = ctypes.CDLL(lib.LIB_PATH)
     for name in declared:
         assert hasattr(so, name), f"{name} not exported by libx264gpu.so"
-    assert lib.x264gpu_abi_version() == 1
+    assert lib.x264gpu_abi_version() == 2
 
 
 def test_no_gpu_means_loud_failure():

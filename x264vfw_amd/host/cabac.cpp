@@ -16,6 +16,14 @@ const uint8_t kBlkY[16] = { 0, 0, 1, 1, 0, 0, 1, 1, 2, 2, 3, 3, 2, 2, 3, 3 };
 const uint8_t kIdxOf[4][4] = { { 0, 1, 4, 5 }, { 2, 3, 6, 7 }, { 8, 9, 12, 13 }, { 10, 11, 14, 15 } };  // [by][bx]
 
 inline bool is_intra(const x264gpu_mb &m) { return m.type == X264GPU_MB_I4x4 || m.type == X264GPU_MB_I8x8 || m.type == X264GPU_MB_I16x16; }
+inline bool is_skip(const x264gpu_mb &m) { return m.type == X264GPU_MB_P_SKIP || m.type == X264GPU_MB_B_SKIP; }
+inline bool is_b(const x264gpu_mb &m) { return m.type >= X264GPU_MB_B_DIRECT && m.type <= X264GPU_MB_B_8x8; }
+// how 8x8 block k of a B macroblock is predicted: 0 list 0, 1 list 1, 2 both, 3 direct
+inline int b_use(const x264gpu_mb &m, int k)
+{
+    if (m.type == X264GPU_MB_B_DIRECT || m.type == X264GPU_MB_B_SKIP || (m.type == X264GPU_MB_B_8x8 && (m.direct8 >> k & 1))) return 3;
+    return m.ref[k] >= 0 ? (m.ref1[k] >= 0 ? 2 : 0) : 1;
+}
 
 struct Cabac {
     BitWriter &bw;
@@ -97,11 +105,14 @@ struct CabacSlice {
     const x264gpu_mb *mbs;
     const int16_t *levels;
     Cabac &cb;
-    std::vector<uint8_t> amvd;          // per macroblock and 8x8 block: |mvd| x, y (capped, x264 keeps 8 bits)
+    std::vector<uint8_t> amvd, amvd1;   // per macroblock and 8x8 block: |mvd| x, y (capped, x264 keeps 8 bits); list 0 / list 1
     int last_dqp = 0, prev_coded_qp;    // mb_qp_delta context: the previous macroblock's delta
     int nskip = 0;
+    int lst = 0;                        // B slices: the list the motion helpers read
+    int cur_direct = 0;                 // direct 8x8 blocks of the macroblock being coded
 
-    CabacSlice(const SliceParams &sp, const x264gpu_mb *m, const int16_t *l, Cabac &c) : p(sp), mbs(m), levels(l), cb(c), amvd((size_t)sp.mbw * sp.mbh * 8, 0), prev_coded_qp(sp.qp) {}
+    CabacSlice(const SliceParams &sp, const x264gpu_mb *m, const int16_t *l, Cabac &c) : p(sp), mbs(m), levels(l), cb(c), amvd((size_t)sp.mbw * sp.mbh * 8, 0),
+        amvd1(sp.slice_type == X264GPU_SLICE_B ? (size_t)sp.mbw * sp.mbh * 8 : 0, 0), prev_coded_qp(sp.qp) {}
 
     const x264gpu_mb *left(int mbx, int mby) const { return mbx > 0 ? &mbs[mby * p.mbw + mbx - 1] : nullptr; }
     const x264gpu_mb *top(int mbx, int mby) const { return mby > p.first_row ? &mbs[(mby - 1) * p.mbw + mbx] : nullptr; }      // not across the slice boundary
@@ -119,7 +130,11 @@ struct CabacSlice {
         if (i > cur_mb) return n;
         n.avail = true;
         const x264gpu_mb &m = mbs[i];
-        if (!is_intra(m)) { n.ref = m.ref[k]; n.mvx = m.mv[k][0]; n.mvy = m.mv[k][1]; }
+        if (!is_intra(m)) {
+            // a block that does not use the list: reference -1, zero vector (8.4.1.3.2: predFlagLX 0)
+            if (lst) { n.ref = m.ref1[k]; if (n.ref >= 0) { n.mvx = m.mv1[k][0]; n.mvy = m.mv1[k][1]; } else n.ref = -1; }
+            else { n.ref = m.ref[k]; if (n.ref >= 0) { n.mvx = m.mv[k][0]; n.mvy = m.mv[k][1]; } else n.ref = -1; }
+        }
         return n;
     }
     void mvp_part(int mbx, int mby, int bx8, int by8, int w8, int shape, int part, int ref, int &px, int &py) const
@@ -147,14 +162,16 @@ struct CabacSlice {
         if (gx < 0 || gy < 2 * p.first_row || gx >= 2 * p.mbw || gy >= 2 * p.mbh) return 0;
         const int i = (gy >> 1) * p.mbw + (gx >> 1), k = (gy & 1) * 2 + (gx & 1);
         if (i > cur_mb || (i == cur_mb && !(done8 >> k & 1))) return 0;
-        return amvd[((size_t)i * 4 + k) * 2 + comp];
+        return (lst ? amvd1 : amvd)[((size_t)i * 4 + k) * 2 + comp];
     }
     int ref_gt0_at(int gx, int gy) const
     {
         const Nb n = block8(gx, gy);
         if (!n.avail || n.ref <= 0) return 0;
-        const int i = (gy >> 1) * p.mbw + (gx >> 1);
-        return i == cur_mb || mbs[i].type != X264GPU_MB_P_SKIP;
+        const int i = (gy >> 1) * p.mbw + (gx >> 1), k = (gy & 1) * 2 + (gx & 1);
+        if (i == cur_mb) return !(cur_direct >> k & 1);
+        if (is_b(mbs[i])) return b_use(mbs[i], k) != 3;      // B_Skip / B_Direct_16x16 / direct sub-macroblocks: refIdxZeroFlag's condTerm is 0
+        return mbs[i].type != X264GPU_MB_P_SKIP;
     }
 
     int pred_i4_mode(int mbx, int mby, int blk) const
@@ -175,7 +192,7 @@ struct CabacSlice {
     // does luma 4x4 block (bx, by) of macroblock m carry coefficients, as the neighbour rule sees it
     static int luma_cbf_of(const x264gpu_mb &m, int bx, int by)
     {
-        if (m.type == X264GPU_MB_P_SKIP) return 0;
+        if (is_skip(m)) return 0;
         const int b8 = (by >> 1) * 2 + (bx >> 1);
         if (!(m.cbp_luma >> b8 & 1)) return 0;
         if (m.transform8x8) return 1;                       // 8x8 transform: the flag of the 8x8 block is inferred 1
@@ -194,7 +211,7 @@ struct CabacSlice {
         const int unavail = is_intra(cur) ? 1 : 0;
         auto of = [&](const x264gpu_mb *n) {
             if (!n) return unavail;
-            if (n->type == X264GPU_MB_P_SKIP) return 0;
+            if (is_skip(*n)) return 0;
             if (bit == 24) return n->type == X264GPU_MB_I16x16 ? (int)((n->nnz >> 24) & 1) : 0;
             return n->cbp_chroma ? (int)((n->nnz >> bit) & 1) : 0;
         };
@@ -203,7 +220,7 @@ struct CabacSlice {
     int cbf_inc_chroma_ac(int mbx, int mby, const x264gpu_mb &cur, int c, int i) const
     {
         const int bx = i & 1, by = i >> 1, unavail = is_intra(cur) ? 1 : 0;
-        auto of = [&](const x264gpu_mb &m, int x, int y) { return m.type != X264GPU_MB_P_SKIP && m.cbp_chroma == 2 ? (int)((m.nnz >> (16 + c * 4 + y * 2 + x)) & 1) : 0; };
+        auto of = [&](const x264gpu_mb &m, int x, int y) { return !is_skip(m) && m.cbp_chroma == 2 ? (int)((m.nnz >> (16 + c * 4 + y * 2 + x)) & 1) : 0; };
         int a, b;
         if (bx > 0) a = of(cur, 0, by); else { const x264gpu_mb *n = left(mbx, mby); a = n ? of(*n, 1, by) : unavail; }
         if (by > 0) b = of(cur, bx, 0); else { const x264gpu_mb *n = top(mbx, mby); b = n ? of(*n, bx, 1) : unavail; }
@@ -291,7 +308,7 @@ struct CabacSlice {
         }
         const uint8_t capped = (uint8_t)(a < 66 ? a : 66);
         for (int y = b8 >> 1; y < (b8 >> 1) + h8; y++)
-            for (int x = b8 & 1; x < (b8 & 1) + w8; x++) amvd[((size_t)cur_mb * 4 + y * 2 + x) * 2 + comp] = capped;
+            for (int x = b8 & 1; x < (b8 & 1) + w8; x++) (lst ? amvd1 : amvd)[((size_t)cur_mb * 4 + y * 2 + x) * 2 + comp] = capped;
     }
     void ref_idx(int mbx, int mby, int b8, int ref)
     {
@@ -301,14 +318,85 @@ struct CabacSlice {
         cb.decision(54 + ctx, 0);
     }
 
+    // mb_type of a B slice (Table 9-37 b): the value's bin string; bin 0: ctxIdx 27 + ctx0, bin 1: 27 + 3, bin 2: 27 + 5 - b1, later bins: 27 + 5
+    void mb_type_b(int value, int ctx0)
+    {
+        static const char *const bins[24] = { "0", "100", "101", "110000", "110001", "110010", "110011", "110100", "110101", "110110", "110111", "111110",
+                                              "1110000", "1110001", "1110010", "1110011", "1110100", "1110101", "1110110", "1110111", "1111000", "1111001",
+                                              "111111", "111101" /* the prefix of the intra types */ };
+        const char *b = bins[value];
+        for (int i = 0; b[i]; i++) cb.decision(i == 0 ? 27 + ctx0 : i == 1 ? 27 + 3 : i == 2 ? 27 + 5 - (b[1] - '0') : 27 + 5, b[i] - '0');
+    }
+    void sub_mb_type_b(int use)          // B_Direct_8x8 "0", B_L0_8x8 "100", B_L1_8x8 "101", B_Bi_8x8 "11000"; ctxIdx 36, 37, 38 | 39 (by b1), 39
+    {
+        if (use == 3) { cb.decision(36, 0); return; }
+        cb.decision(36, 1);
+        if (use == 2) { cb.decision(37, 1); cb.decision(38, 0); cb.decision(39, 0); cb.decision(39, 0); return; }
+        cb.decision(37, 0);
+        cb.decision(39, use == 1);
+    }
+    // mb_type, sub_mb_type, ref_idx_l0, ref_idx_l1, mvd_l0, mvd_l1 of an inter macroblock of a B slice (7.3.5.1 / 7.3.5.2)
+    void mb_pred_b(int mbx, int mby, const x264gpu_mb &m, int ctx0)
+    {
+        static const int8_t geom[4][4][4] = { { { 0, 0, 2, 2 } }, { { 0, 0, 2, 1 }, { 0, 1, 2, 1 } }, { { 0, 0, 1, 2 }, { 1, 0, 1, 2 } },
+                                              { { 0, 0, 1, 1 }, { 1, 0, 1, 1 }, { 0, 1, 1, 1 }, { 1, 1, 1, 1 } } };
+        cur_direct = 0;
+        if (m.type == X264GPU_MB_B_DIRECT) { mb_type_b(0, ctx0); cur_direct = 15; return; }
+        const int part = m.partition & 3, nparts = part == 0 ? 1 : part == 3 ? 4 : 2;
+        int use[4];
+        for (int k = 0; k < nparts; k++) use[k] = b_use(m, geom[part][k][1] * 2 + geom[part][k][0]);
+        if (part == 3) {
+            mb_type_b(22, ctx0);
+            for (int k = 0; k < 4; k++) { sub_mb_type_b(use[k]); if (use[k] == 3) cur_direct |= 1 << k; }
+        } else if (part == 0) mb_type_b(1 + use[0], ctx0);
+        else {
+            // Table 7-14: 4 + 2 * pair + (8x16); pairs ordered L0_L0, L1_L1, L0_L1, L1_L0, L0_Bi, L1_Bi, Bi_L0, Bi_L1, Bi_Bi
+            static const int8_t pair_of[3][3] = { { 0, 2, 4 }, { 3, 1, 5 }, { 6, 7, 8 } };
+            mb_type_b(4 + 2 * pair_of[use[0]][use[1]] + (part == 2), ctx0);
+        }
+        for (lst = 0; lst < 2; lst++) {
+            if ((lst ? p.num_ref1 : p.num_ref) <= 1) continue;
+            done8 = 0;
+            for (int k = 0; k < nparts; k++) {
+                const int8_t *g = geom[part][k];
+                const int b8 = g[1] * 2 + g[0];
+                const bool sends = !(use[k] == 3 || use[k] == 1 - lst);
+                const int r = lst ? m.ref1[b8] : m.ref[b8];
+                if (sends) ref_idx(mbx, mby, b8, r);
+                for (int yy = g[1]; yy < g[1] + g[3]; yy++) for (int xx = g[0]; xx < g[0] + g[2]; xx++) { cur8[yy * 2 + xx] = Nb{ true, sends || use[k] == 3 ? r : -1, 0, 0 }; done8 |= 1 << (yy * 2 + xx); }
+            }
+        }
+        for (lst = 0; lst < 2; lst++) {
+            done8 = 0;
+            for (int k = 0; k < nparts; k++) {
+                const int8_t *g = geom[part][k];
+                const int b8 = g[1] * 2 + g[0];
+                const int r = lst ? m.ref1[b8] : m.ref[b8], vx = lst ? m.mv1[b8][0] : m.mv[b8][0], vy = lst ? m.mv1[b8][1] : m.mv[b8][1];
+                if (!(use[k] == 3 || use[k] == 1 - lst)) {
+                    int px, py;
+                    mvp_part(mbx, mby, g[0], g[1], g[2], part, k, r, px, py);
+                    mvd(mbx, mby, b8, g[2], g[3], 0, vx - px);
+                    mvd(mbx, mby, b8, g[2], g[3], 1, vy - py);
+                }
+                for (int yy = g[1]; yy < g[1] + g[3]; yy++) for (int xx = g[0]; xx < g[0] + g[2]; xx++) { cur8[yy * 2 + xx] = Nb{ true, r >= 0 ? r : -1, r >= 0 ? vx : 0, r >= 0 ? vy : 0 }; done8 |= 1 << (yy * 2 + xx); }
+            }
+        }
+        lst = 0;
+    }
+
     void macroblock(int mbx, int mby)
     {
         const int i = mby * p.mbw + mbx;
         const x264gpu_mb &m = mbs[i];
         const int16_t *lv = levels + (size_t)i * X264GPU_MB_LEVELS;
         const x264gpu_mb *L = left(mbx, mby), *T = top(mbx, mby);
-        cur_mb = i; done8 = 0;
-        const bool pslice = p.slice_type != X264GPU_SLICE_I;
+        cur_mb = i; done8 = 0; lst = 0; cur_direct = 0;
+        const bool bslice = p.slice_type == X264GPU_SLICE_B;
+        const bool pslice = p.slice_type != X264GPU_SLICE_I && !bslice;
+        if (bslice) {
+            cb.decision(24 + (L && !is_skip(*L)) + (T && !is_skip(*T)), m.type == X264GPU_MB_B_SKIP);
+            if (m.type == X264GPU_MB_B_SKIP) { nskip++; last_dqp = 0; return; }
+        }
         if (pslice) {
             const int ctx = 11 + (L && L->type != X264GPU_MB_P_SKIP) + (T && T->type != X264GPU_MB_P_SKIP);
             cb.decision(ctx, m.type == X264GPU_MB_P_SKIP);
@@ -316,7 +404,11 @@ struct CabacSlice {
         }
         const bool intra = is_intra(m);
         // ---- mb_type ----
-        if (!pslice) {
+        if (bslice) {
+            const int ctx0 = (L && L->type != X264GPU_MB_B_SKIP && L->type != X264GPU_MB_B_DIRECT) + (T && T->type != X264GPU_MB_B_SKIP && T->type != X264GPU_MB_B_DIRECT);
+            if (intra) { mb_type_b(23, ctx0); mb_type_intra(m, 32, 32 + 1, 32 + 2, 32 + 2, 32 + 3, 32 + 3); }
+            else mb_pred_b(mbx, mby, m, ctx0);
+        } else if (!pslice) {
             const int ctx = (L && L->type != X264GPU_MB_I4x4 && L->type != X264GPU_MB_I8x8) + (T && T->type != X264GPU_MB_I4x4 && T->type != X264GPU_MB_I8x8);
             mb_type_intra(m, 3 + ctx, 3 + 3, 3 + 4, 3 + 5, 3 + 6, 3 + 7);
         } else if (intra) {
@@ -351,7 +443,7 @@ struct CabacSlice {
                 cb.decision(64 + 3, m.chroma_mode > 1);
                 if (m.chroma_mode > 1) cb.decision(64 + 3, m.chroma_mode > 2);
             }
-        } else {
+        } else if (!bslice) {
             static const int8_t geom[4][4][4] = { { { 0, 0, 2, 2 } }, { { 0, 0, 2, 1 }, { 0, 1, 2, 1 } }, { { 0, 0, 1, 2 }, { 1, 0, 1, 2 } },
                                                   { { 0, 0, 1, 1 }, { 1, 0, 1, 1 }, { 0, 1, 1, 1 }, { 1, 1, 1, 1 } } };
             const int nparts = m.partition == 0 ? 1 : m.partition == 3 ? 4 : 2;

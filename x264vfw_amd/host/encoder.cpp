@@ -6,6 +6,7 @@
 // call contiguous from nal[0].p_payload, buffers valid until the next call, param strings copied at open,
 // pic_out->{i_type,b_keyframe,i_pts,i_dts} filled.  No CPU fallback: open fails without a GPU.
 #include "host.hpp"
+#include "dpb.hpp"
 #include <math.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -1026,6 +1027,61 @@ int x264host_write_headers_cabac(int width, int height, int level_idc, int log2_
     std::vector<uint8_t> v;
     write_sps(v, s, true);
     PpsParams pp = { 0, 0, cabac, num_ref, pic_init_qp, chroma_qp_offset, transform8x8_mode };
+    write_pps(v, pp, true);
+    if ((int)v.size() > cap) return -1;
+    memcpy(out, v.data(), v.size());
+    return (int)v.size();
+}
+
+/* ---- tests: the DPB model (dpb.hpp) and a slice writer driven by it, for B-picture streams built from the CPU checker's records ---- */
+void *x264host_dpb_new(int frame_reference, int bframes, int b_pyramid, int log2_max_frame_num)
+{
+    Dpb *d = new Dpb();
+    d->configure(frame_reference, bframes, b_pyramid, log2_max_frame_num);
+    return d;
+}
+void x264host_dpb_free(void *h) { delete (Dpb *)h; }
+int x264host_dpb_info(void *h, int *max_dpb, int *num_reorder) { Dpb *d = (Dpb *)h; *max_dpb = d->max_dpb; *num_reorder = d->num_reorder; return d->slots(); }
+/* info[0..7] = frame_num, nal_ref_idc, n_mmco, reorder commands of list 0, of list 1, ... */
+int x264host_dpb_plan(void *h, int type, int frame, int n_follow, const int *follow_coded, const int *follow_frame, x264gpu_pic *pic_out, int *info)
+{
+    const DpbPlan &p = ((Dpb *)h)->plan(type, frame, n_follow, follow_coded, follow_frame);
+    *pic_out = p.pic;
+    if (info) { info[0] = p.frame_num; info[1] = p.nal_ref_idc; info[2] = p.n_mmco; info[3] = p.reorder[0].n; info[4] = p.reorder[1].n; }
+    return 0;
+}
+void x264host_dpb_commit(void *h) { ((Dpb *)h)->commit(); }
+int x264host_write_slice_dpb(void *h, int mbw, int mbh, int qp, int pic_init_qp, int log2_max_frame_num, int log2_max_poc_lsb, int idr_pic_id,
+                             int disable_deblock_idc, int num_ref_default, int transform8x8_mode, const x264gpu_mb *mbs, const int16_t *levels,
+                             uint8_t *out, int cap, int *skipped)
+{
+    SliceParams sp = {};
+    sp.mbw = mbw; sp.mbh = mbh; sp.qp = qp; sp.pic_init_qp = pic_init_qp; sp.log2_max_frame_num = log2_max_frame_num; sp.log2_max_poc_lsb = log2_max_poc_lsb;
+    sp.idr_pic_id = idr_pic_id; sp.num_ref_default = num_ref_default; sp.num_ref1_default = 1;
+    sp.disable_deblock_idc = disable_deblock_idc; sp.transform8x8_mode = transform8x8_mode; sp.cabac = 1;
+    ((Dpb *)h)->fill(sp);
+    std::vector<uint8_t> v;
+    SliceStats stt = { 0 };
+    write_slice(v, sp, mbs, levels, true, true, &stt, 1);
+    if (skipped) *skipped = stt.skip;
+    if ((int)v.size() > cap) return -1;
+    memcpy(out, v.data(), v.size());
+    return (int)v.size();
+}
+int x264host_write_headers_b(int width, int height, int level_idc, int log2_max_frame_num, int pic_init_qp, int chroma_qp_offset, uint32_t num_units_in_tick,
+                             uint32_t time_scale, int num_ref_default, int transform8x8_mode, int cabac, int num_ref_frames, int log2_max_poc_lsb, int num_reorder,
+                             int weighted_bipred_idc, uint8_t *out, int cap)
+{
+    SpsParams s = {};
+    s.profile_idc = transform8x8_mode ? 100 : 77; s.level_idc = level_idc; s.mbw = (width + 15) / 16; s.mbh = (height + 15) / 16;
+    s.crop_right = s.mbw * 16 - width; s.crop_bottom = s.mbh * 16 - height; s.num_ref_frames = num_ref_frames; s.log2_max_frame_num = log2_max_frame_num;
+    s.fullrange = 0; s.colorprim = 2; s.transfer = 2; s.colmatrix = 2; s.vidformat = 5;
+    s.num_units_in_tick = num_units_in_tick; s.time_scale = time_scale; s.constraint_set0 = 0; s.constraint_set1 = !transform8x8_mode;
+    s.log2_max_poc_lsb = log2_max_poc_lsb; s.num_reorder_frames = num_reorder;
+    std::vector<uint8_t> v;
+    write_sps(v, s, true);
+    PpsParams pp = { 0, 0, cabac, num_ref_default, pic_init_qp, chroma_qp_offset, transform8x8_mode };
+    pp.weighted_bipred_idc = weighted_bipred_idc;
     write_pps(v, pp, true);
     if ((int)v.size() > cap) return -1;
     memcpy(out, v.data(), v.size());

@@ -22,6 +22,16 @@ struct SliceParams {
     int slices_plain = 0;    // several slices per picture are x264's --slices N (the loop filter crosses their boundaries: idc stays 0) rather than slice threads (idc 2)
     int first_row = 0, end_row = 0;   // macroblock rows [first_row, end_row) of this slice (end_row 0 = mbh: one slice per picture); nothing
                              // above first_row is available to the slice's predictions (7.4.1.2.4 / 6.4.x availability)
+    // ---- sessions with B pictures (x264 slice_header_write with sps->i_poc_type 0) ----
+    int log2_max_poc_lsb = 0;    // > 0: pic_order_cnt_type 0, pic_order_cnt_lsb = poc mod 2^log2_max_poc_lsb is sent
+    int poc = 0;
+    int num_ref1 = 0, num_ref1_default = 1;      // B: active references of list 1, the PPS default
+    int direct_spatial = 1;      // direct_spatial_mv_pred_flag
+    // ref_pic_list_modification of list 0 / 1 (x264 b_ref_pic_list_reordering): the whole list as picture-number differences, when the encoder's
+    // order (nearest in display order first) is not the default initial order of 8.2.4.2
+    struct Reorder { int n = 0; struct { int idc, arg; } cmd[16]; } reorder[2];
+    // memory_management_control_operation 1 (mark a short-term picture unused) x n_mmco: difference_of_pic_nums (x264's b-pyramid bookkeeping)
+    int n_mmco = 0, mmco_diff[16] = { 0 };
 };
 struct SliceStats { int skip; };
 
@@ -33,8 +43,10 @@ struct SpsParams {
     uint32_t num_units_in_tick, time_scale;
     int constraint_set0, constraint_set1;
     int mv_range;            // --mvrange (luma samples): log2_max_mv_length_* = floor(log2(4 * mv_range - 1)) + 1, as x264's sps init
+    int log2_max_poc_lsb = 0;    // > 0: pic_order_cnt_type 0 (sessions with B pictures), else type 2
+    int num_reorder_frames = 0;  // x264: 2 with --b-pyramid, 1 with B pictures, else 0
 };
-struct PpsParams { int pps_id, sps_id, cabac, num_ref, pic_init_qp, chroma_qp_offset, transform8x8_mode; };
+struct PpsParams { int pps_id, sps_id, cabac, num_ref, pic_init_qp, chroma_qp_offset, transform8x8_mode; int weighted_bipred_idc = 0; };
 
 void write_sps(std::vector<uint8_t> &out, const SpsParams &s, bool annexb);
 void write_pps(std::vector<uint8_t> &out, const PpsParams &p, bool annexb);

@@ -20,7 +20,8 @@ void write_sps(std::vector<uint8_t> &out, const SpsParams &s, bool annexb)
         bw.put1(0);                             // seq_scaling_matrix_present_flag
     }
     bw.ue(s.log2_max_frame_num - 4);
-    bw.ue(2);                                   // pic_order_cnt_type 2: output order == decoding order (no B frames)
+    if (s.log2_max_poc_lsb > 0) { bw.ue(0); bw.ue(s.log2_max_poc_lsb - 4); }      // pic_order_cnt_type 0 (B pictures): log2_max_pic_order_cnt_lsb_minus4
+    else bw.ue(2);                              // pic_order_cnt_type 2: output order == decoding order (no B frames)
     bw.ue(s.num_ref_frames);
     bw.put1(0);                                 // gaps_in_frame_num_value_allowed_flag
     bw.ue(s.mbw - 1);
@@ -68,7 +69,7 @@ void write_sps(std::vector<uint8_t> &out, const SpsParams &s, bool annexb)
         bw.ue(0); bw.ue(0);                     // max_bytes_per_pic_denom, max_bits_per_mb_denom
         { int v = 4 * (s.mv_range > 0 ? s.mv_range : 512) - 1, l = 0; while (v >> (l + 1)) l++;      // x264: (int)log2f(max(1, mv_range * 4 - 1)) + 1
           bw.ue((uint32_t)(l + 1)); bw.ue((uint32_t)(l + 1)); }   // log2_max_mv_length_horizontal / vertical
-        bw.ue(0);                               // max_num_reorder_frames
+        bw.ue(s.num_reorder_frames);            // max_num_reorder_frames
         bw.ue(s.num_ref_frames);                // max_dec_frame_buffering
     }
     bw.trailing();
@@ -86,7 +87,7 @@ void write_pps(std::vector<uint8_t> &out, const PpsParams &p, bool annexb)
     bw.ue(p.num_ref - 1);                       // num_ref_idx_l0_default_active_minus1
     bw.ue(0);                                   // l1
     bw.put1(0);                                 // weighted_pred_flag
-    bw.put(0, 2);                               // weighted_bipred_idc
+    bw.put((uint32_t)p.weighted_bipred_idc, 2); // weighted_bipred_idc (2: implicit, x264 --weightb)
     bw.se(p.pic_init_qp - 26);
     bw.se(0);                                   // pic_init_qs_minus26
     bw.se(p.chroma_qp_offset);

@@ -310,23 +310,38 @@ struct SliceCtx {
 
 void write_slice_header(BitWriter &bw, const SliceParams &p)
 {
+    const bool islice = p.slice_type == X264GPU_SLICE_I, bslice = p.slice_type == X264GPU_SLICE_B;
     bw.ue((uint32_t)(p.first_row * p.mbw));                     // first_mb_in_slice
-    bw.ue((p.slice_type == X264GPU_SLICE_I ? 2 : 0) + 5);       // slice_type (+5: all slices of the picture alike)
+    bw.ue((islice ? 2 : bslice ? 1 : 0) + 5);                   // slice_type (+5: all slices of the picture alike)
     bw.ue(p.pps_id);
     bw.put((uint32_t)p.frame_num & ((1u << p.log2_max_frame_num) - 1), p.log2_max_frame_num);
     if (p.idr) bw.ue(p.idr_pic_id);
+    if (p.log2_max_poc_lsb > 0) bw.put((uint32_t)p.poc & ((1u << p.log2_max_poc_lsb) - 1), p.log2_max_poc_lsb);      // pic_order_cnt_lsb (type 0)
     // pic_order_cnt_type 2: nothing to send
-    if (p.slice_type != X264GPU_SLICE_I) {
-        const bool ovr = p.num_ref != p.num_ref_default;       // fewer pictures in the DPB than the PPS default
+    if (bslice) bw.put1(p.direct_spatial);                      // direct_spatial_mv_pred_flag
+    if (!islice) {
+        const bool ovr = p.num_ref != p.num_ref_default || (bslice && p.num_ref1 != p.num_ref1_default);       // fewer pictures in the DPB than the PPS default
         bw.put1(ovr);                                           // num_ref_idx_active_override_flag
-        if (ovr) bw.ue(p.num_ref - 1);
-        bw.put1(0);                                             // ref_pic_list_modification_flag_l0
+        if (ovr) { bw.ue(p.num_ref - 1); if (bslice) bw.ue(p.num_ref1 - 1); }
+        for (int l = 0; l <= (bslice ? 1 : 0); l++) {
+            bw.put1(p.reorder[l].n > 0);                        // ref_pic_list_modification_flag_lX
+            if (p.reorder[l].n > 0) {
+                for (int i = 0; i < p.reorder[l].n; i++) { bw.ue((uint32_t)p.reorder[l].cmd[i].idc); bw.ue((uint32_t)p.reorder[l].cmd[i].arg); }
+                bw.ue(3);
+            }
+        }
     }
     if (p.nal_ref_idc) {
         if (p.idr) { bw.put1(0); bw.put1(0); }                  // no_output_of_prior_pics, long_term_reference
-        else bw.put1(0);                                        // adaptive_ref_pic_marking_mode_flag
+        else {
+            bw.put1(p.n_mmco > 0);                              // adaptive_ref_pic_marking_mode_flag
+            if (p.n_mmco > 0) {
+                for (int i = 0; i < p.n_mmco; i++) { bw.ue(1); bw.ue((uint32_t)(p.mmco_diff[i] - 1)); }      // operation 1: difference_of_pic_nums_minus1
+                bw.ue(0);
+            }
+        }
     }
-    if (p.cabac && p.slice_type != X264GPU_SLICE_I) bw.ue(0);   // cabac_init_idc
+    if (p.cabac && !islice) bw.ue(0);                           // cabac_init_idc
     bw.se(p.qp - p.pic_init_qp);                                // slice_qp_delta
     bw.ue(p.disable_deblock_idc);
     if (p.disable_deblock_idc != 1) { bw.se(p.alpha_off_div2); bw.se(p.beta_off_div2); }

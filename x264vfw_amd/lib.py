@@ -42,7 +42,23 @@ class Config(C.Structure):
     _fields_ = [(n, C.c_int) for n in (
         "width", "height", "streams", "refs", "qp_i", "qp_p", "me_range", "subme", "deblock",
         "deblock_alpha", "deblock_beta", "chroma_qp_offset", "deadzone_inter", "deadzone_intra",
-        "dct_decimate", "partitions", "dct8x8", "me_method", "chroma_me", "mixed_refs", "aq_mode", "aq_strength_q8", "fast_pskip", "mv_range", "cabac", "rd", "psy", "psy_rd_q8", "slices", "trellis", "slices_plain")]
+        "dct_decimate", "partitions", "dct8x8", "me_method", "chroma_me", "mixed_refs", "aq_mode", "aq_strength_q8", "fast_pskip", "mv_range", "cabac", "rd", "psy", "psy_rd_q8", "slices", "trellis", "slices_plain", "dpb", "weightb")]
+
+
+class Pic(C.Structure):
+    """Mirror of struct x264gpu_pic (picture control of x264gpu_encode_pictures)."""
+    _fields_ = [("slice_type", C.c_int), ("qp", C.c_int), ("poc", C.c_int), ("dst", C.c_int), ("keep", C.c_int), ("nref", C.c_int * 2),
+                ("slot", (C.c_int8 * 8) * 2)]
+
+
+def make_pic(slice_type, qp, poc, dst, keep, l0=(), l1=()):
+    p = Pic(slice_type=slice_type, qp=qp, poc=poc, dst=dst, keep=keep)
+    p.nref[0], p.nref[1] = len(l0), len(l1)
+    for i, s in enumerate(l0):
+        p.slot[0][i] = s
+    for i, s in enumerate(l1):
+        p.slot[1][i] = s
+    return p
 
 
 MB_LEVELS = 416
