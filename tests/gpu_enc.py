@@ -30,6 +30,22 @@ class GpuEncoder:
         mb = self.d_mb.cpu().numpy().view(O.MB_DTYPE).reshape(self.S, self.n)
         return mb, self.d_lv.cpu().numpy()
 
+    def encode_pics(self, frames, pics):
+        """frames: one I420 array per stream; pics: one lib.Pic per stream (x264gpu_encode_pictures) -> (records [S,n], levels)"""
+        t = self.torch
+        d_in = t.from_numpy(np.stack(frames)).cuda()
+        arr = (lib.Pic * self.S)(*pics)
+        lib.check(lib.x264gpu_encode_pictures(self.h, d_in.data_ptr(), arr, self.d_mb.data_ptr(), self.d_lv.data_ptr(), None), "encode_pictures")
+        t.cuda.synchronize()
+        mb = self.d_mb.cpu().numpy().view(O.MB_DTYPE).reshape(self.S, self.n)
+        return mb, self.d_lv.cpu().numpy()
+
+    def encode_pic(self, frame, pic):
+        """single-stream form with the oracle's signature (tests/bgop.py)"""
+        assert self.S == 1
+        mb, lv = self.encode_pics([frame], [pic])
+        return mb[0], lv[0]
+
     def recon(self, s=0):
         t = self.torch
         w, h = self.cfg.width, self.cfg.height

@@ -1,0 +1,69 @@
+"""GPU: B pictures through the HIP macroblock loop (k_mb.cuh BS instantiations: spatial direct, both lists' searches, implicit weighted bi-prediction,
+x264's B RD decision, bidirectional refinement) — records, levels, reconstruction and CABAC context variables must equal the CPU checker's picture
+by picture, and the stream the host writer makes of the device's records must decode to the device's reconstruction."""
+import numpy as np
+import pytest
+
+import bgop
+import oracle_lib as O
+from synth import synth_frames
+
+pytestmark = pytest.mark.gpu
+
+MEDIUM = dict(refs=3, dpb=4, weightb=1, partitions=7, dct8x8=1, chroma_me=1, mixed_refs=1, cabac=1, rd=1, subme=7, psy=1, psy_rd_q8=256,
+              chroma_qp_offset=-2, trellis=63)
+USED_CTX = list(range(3, 11)) + list(range(11, 60)) + list(range(60, 70)) + list(range(73, 276)) + list(range(399, 436))
+
+
+def describe(mbs_g, mbs_o, i):
+    f = lambda m: dict(type=int(m["type"][i]), part=int(m["partition"][i]), d8=int(m["i16_mode"][i]), ref=m["ref"][i].tolist(), ref1=O.mb_ref1(m)[i].tolist(),
+                       mv=m["mv"][i].tolist(), mv1=O.mb_mv1(m)[i].tolist(), cbp=(int(m["cbp_luma"][i]), int(m["cbp_chroma"][i])), t8=int(m["transform8x8"][i]))
+    return f"\n gpu {f(mbs_g)}\n cpu {f(mbs_o)}"
+
+
+def run(gpu, w, h, types, seed, streams=1, bframes=3, pyramid=1, **over):
+    from gpu_enc import GpuEncoder
+    from x264vfw_amd import host_api as HL
+    kw = dict(MEDIUM, **over)
+    frames = synth_frames(w, h, len(types), seed=seed)
+    cfg = O.default_config(w, h, **kw)
+    og, gg = O.OracleEncoder(cfg), GpuEncoder(O.default_config(w, h, streams=streams, **kw))
+    dpb = bgop.HostDpb(HL, kw["refs"], bframes, pyramid)
+    stream = dpb.headers(w, h, 23, cfg.chroma_qp_offset, kw["refs"], cfg.dct8x8, cfg.weightb)
+    order = bgop.schedule(types, pyramid)
+    mbw, mbh = (w + 15) // 16, (h + 15) // 16
+    recons = []
+    for k, (disp, pt) in enumerate(order):
+        pic, _ = dpb.plan(pt, disp, bgop.follow_of(order, k))
+        pic.qp = 20 if pt <= 1 else 23 if pt == 2 else 25 if pt == 4 else 24
+        o_mb, o_lv = og.encode_pic(frames[disp], pic)
+        g_mb, g_lv = gg.encode_pics([frames[disp]] * streams, [pic] * streams)
+        for s in range(streams):
+            bad = np.nonzero(g_mb[s].view(np.uint8).reshape(-1, 64) != o_mb.view(np.uint8).reshape(-1, 64))[0]
+            assert bad.size == 0, f"picture {k} (display {disp}, type {pt}) stream {s}: record of macroblock {bad[0]} differs" + describe(g_mb[s], o_mb, bad[0])
+            assert np.array_equal(g_lv[s], o_lv), f"picture {k}: levels differ (macroblock {np.nonzero((g_lv[s] != o_lv).any(axis=1))[0][0]})"
+            assert np.array_equal(gg.recon(s), og.recon()), f"picture {k}: reconstruction differs"
+        assert np.array_equal(gg.cabac_states(0, 0)[USED_CTX], og.cabac_states()[USED_CTX]) or pt <= 1, f"picture {k}: CABAC context variables differ"
+        stream += dpb.slice(mbw, mbh, pic.qp, 23, 0, 0 if cfg.deblock else 1, kw["refs"], cfg.dct8x8, g_mb[0], g_lv[0])
+        recons.append(gg.recon(0))
+        dpb.commit()
+    dec = O.h264_decode(stream, len(order), w, h)
+    for k, (d, r) in enumerate(zip(dec, recons)):
+        assert np.array_equal(d, r), f"picture {k} of the device's stream decodes differently"
+
+
+@pytest.mark.parametrize("w,h,types,seed,over", [
+    (64, 48, "IBP", 1, dict(partitions=6)),                                         # 16x16 types only: direct / skip / L0 / L1 / BI
+    (176, 144, "IBBBP", 5, dict(partitions=6)),
+    (176, 144, "IBBBPBBBP", 5, {}),                                                 # medium: bframes 3, b-pyramid, ref 3, weightb
+    (96, 80, "IBPBBPBBBPP", 2, {}),
+    (208, 112, "IPBBBPBPBBP", 3, dict(weightb=0, mixed_refs=0)),
+    (176, 144, "IBBBPBBBPBBBP", 6, dict(refs=1, dct8x8=0, trellis=0)),
+    (128, 96, "IBBPBBP", 7, dict(refs=5, dpb=5, chroma_me=0, psy_rd_q8=0)),
+])
+def test_b_pictures_bitexact_and_decodable(gpu, w, h, types, seed, over):
+    run(gpu, w, h, types, seed, **over)
+
+
+def test_b_pictures_multistream(gpu):
+    run(gpu, 96, 80, "IBBBPBBP", 11, streams=3)

@@ -195,11 +195,22 @@ struct CabIn {
     int ltype, ttype, lcbp_luma, tcbp_luma, lcbp_chroma, tcbp_chroma, lcmode, tcmode, lt8, tt8;
     unsigned lnnz, tnnz;
     unsigned long long lamvd, tamvd;         // |mvd| of the neighbours' 8x8 blocks: byte (block * 2 + component)
+    // B slices: how the macroblock's 8x8 blocks are predicted (two bits each: 0 list 0, 1 list 1, 2 both, 3 direct), the motion of the lane's 8x8
+    // block (lane >> 4) in both lists (per-lane values: block b's are read from lane 16 b), list 1's |mvd| neighbours
+    bool bslice; int nref1; unsigned buse;
+    int b_r0, b_x0, b_y0, b_r1, b_x1, b_y1;
+    unsigned long long lamvd1, tamvd1;
 };
+
+// mb_type of a B slice (Table 9-37 b): bin strings, first bin in bit 0
+static __constant__ const uint8_t c_btype_len[24] = { 1, 3, 3, 6, 6, 6, 6, 6, 6, 6, 6, 6, 7, 7, 7, 7, 7, 7, 7, 7, 7, 7, 6, 6 };
+static __constant__ const uint8_t c_btype_bits[24] = { 0, 1, 5, 3, 35, 19, 51, 11, 43, 27, 59, 31, 7, 71, 39, 103, 23, 87, 55, 119, 15, 79, 63, 47 };
+__device__ __forceinline__ bool cab_is_skip(int t) { return t == X264GPU_MB_P_SKIP || t == X264GPU_MB_B_SKIP; }
+__device__ __forceinline__ bool cab_is_intra(int t) { return t < X264GPU_MB_P_L0; }
 
 __device__ __forceinline__ int cab_luma_cbf_of(int type, int cbp_luma, int t8, unsigned nnz, int bx, int by)
 {
-    if (type == X264GPU_MB_P_SKIP) return 0;
+    if (type == X264GPU_MB_P_SKIP || type == X264GPU_MB_B_SKIP) return 0;
     if (!((cbp_luma >> ((by >> 1) * 2 + (bx >> 1))) & 1)) return 0;
     if (t8) return 1;
     return (nnz >> blkidx_of(bx, by)) & 1;
@@ -231,17 +242,39 @@ __device__ __forceinline__ void cab_mvd(Cab &cb, uint32_t model, int lane, int b
 // restored before returning); lvs: the macroblock's levels (LDS); modes4 / modes8 / nmodes: intra modes (LDS).  Returns the |mvd| bytes of
 // the macroblock's 8x8 blocks (zero for intra / skip) and the mb_qp_delta it sent through dqp_out.
 __device__ __forceinline__ unsigned long long cab_mb(Cab &cb, uint32_t model, int lane, const CabIn &in, MeState &S, const int16_t *lvs,
-                                                     const uint8_t *modes4, const uint8_t *modes8, const uint8_t *nmodes, int mbx, int sy, int &dqp_out)
+                                                     const uint8_t *modes4, const uint8_t *modes8, const uint8_t *nmodes, int mbx, int sy, int &dqp_out,
+                                                     unsigned long long &amvd1_out)
 {
+    amvd1_out = 0;
     unsigned long long amvd = 0;
     dqp_out = 0;
     const bool lavail = in.left, tavail = in.top;
-    if (in.pslice && !in.size) {
+    if (in.bslice && !in.size) {
+        cab_bin(cb, model, lane, 24 + (lavail && !cab_is_skip(in.ltype)) + (tavail && !cab_is_skip(in.ttype)), in.type == X264GPU_MB_B_SKIP);
+        if (in.type == X264GPU_MB_B_SKIP) return 0;
+    }
+    if (in.pslice && !in.bslice && !in.size) {
         cab_bin(cb, model, lane, 11 + (lavail && in.ltype != X264GPU_MB_P_SKIP) + (tavail && in.ttype != X264GPU_MB_P_SKIP), in.type == X264GPU_MB_P_SKIP);
         if (in.type == X264GPU_MB_P_SKIP) return 0;
     }
     const bool intra = in.type < X264GPU_MB_P_L0;
-    if (!in.pslice) {
+    if (in.bslice) {
+        // mb_type: Table 7-14 value -> bins; contexts 27 + {0..2} (neighbours that are neither B_Skip nor B_Direct_16x16), 27 + 3, 27 + 5 - b1, 27 + 5 ...
+        const int ctx0 = (lavail && in.ltype != X264GPU_MB_B_SKIP && in.ltype != X264GPU_MB_B_DIRECT) + (tavail && in.ttype != X264GPU_MB_B_SKIP && in.ttype != X264GPU_MB_B_DIRECT);
+        int value;
+        if (intra) value = 23;
+        else if (in.type == X264GPU_MB_B_DIRECT) value = 0;
+        else if (in.part == D_8x8) value = 22;
+        else if (in.part == D_16x16) value = 1 + (int)(in.buse & 3);
+        else {
+            const int u0 = (int)(in.buse & 3), u1 = (int)((in.part == D_16x8 ? in.buse >> 4 : in.buse >> 2) & 3);      // first / second partition: blocks 0 and 2 | 0 and 1
+            const int pair = u0 == 0 ? (u1 == 0 ? 0 : u1 == 1 ? 2 : 4) : u0 == 1 ? (u1 == 0 ? 3 : u1 == 1 ? 1 : 5) : 6 + u1;
+            value = 4 + 2 * pair + (in.part == D_8x16);
+        }
+        const int len = c_btype_len[value], bits = c_btype_bits[value];
+        for (int i = 0; i < len; i++) cab_bin(cb, model, lane, i == 0 ? 27 + ctx0 : i == 1 ? 27 + 3 : i == 2 ? 27 + 5 - ((bits >> 1) & 1) : 27 + 5, (bits >> i) & 1);
+        if (intra) cab_mb_type_intra(cb, model, lane, in, 32, 32 + 1, 32 + 2, 32 + 2, 32 + 3, 32 + 3);
+    } else if (!in.pslice) {
         const int ctx = (lavail && in.ltype != X264GPU_MB_I4x4 && in.ltype != X264GPU_MB_I8x8) + (tavail && in.ttype != X264GPU_MB_I4x4 && in.ttype != X264GPU_MB_I8x8);
         cab_mb_type_intra(cb, model, lane, in, 3 + ctx, 3 + 3, 3 + 4, 3 + 5, 3 + 6, 3 + 7);
     } else if (intra) { cab_bin(cb, model, lane, 14, 1); cab_mb_type_intra(cb, model, lane, in, 17, 17 + 1, 17 + 2, 17 + 2, 17 + 3, 17 + 3); }
@@ -279,6 +312,71 @@ __device__ __forceinline__ unsigned long long cab_mb(Cab &cb, uint32_t model, in
         const int ctx = (lavail && in.ltype < X264GPU_MB_P_L0 && in.lcmode != 0) + (tavail && in.ttype < X264GPU_MB_P_L0 && in.tcmode != 0);
         if (!in.cmode) cab_bin(cb, model, lane, 64 + ctx, 0);
         else { cab_bin(cb, model, lane, 64 + ctx, 1); cab_bin(cb, model, lane, 64 + 3, in.cmode > 1); if (in.cmode > 1) cab_bin(cb, model, lane, 64 + 3, in.cmode > 2); }
+    } else if (in.bslice) {
+        // ---- B: sub_mb_type, then every list-0 reference index, every list-1 one, list 0's vector differences, list 1's (7.3.5.1 / 7.3.5.2) ----
+        if (in.type != X264GPU_MB_B_DIRECT) {
+            const int part = in.part, np = part == D_16x16 ? 1 : part == D_8x8 ? 4 : 2;
+            const int w8 = part == D_16x16 || part == D_16x8 ? 2 : 1, h8 = part == D_16x16 || part == D_8x16 ? 2 : 1;
+            auto use_of = [&](int kp) { const int b8 = part == D_16x8 ? 2 * kp : kp; return (int)((in.buse >> (2 * b8)) & 3); };
+            if (part == D_8x8)
+                for (int kp = 0; kp < 4; kp++) {
+                    const int u = use_of(kp);
+                    if (u == 3) { cab_bin(cb, model, lane, 36, 0); continue; }
+                    cab_bin(cb, model, lane, 36, 1);
+                    if (u == 2) { cab_bin(cb, model, lane, 37, 1); cab_bin(cb, model, lane, 38, 0); cab_bin(cb, model, lane, 39, 0); cab_bin(cb, model, lane, 39, 0); }
+                    else { cab_bin(cb, model, lane, 37, 0); cab_bin(cb, model, lane, 39, u == 1); }
+                }
+            const int sc0 = S.cref, sc1 = S.cmvx, sc2 = S.cmvy, sc3 = S.cdir;
+            for (int l = 0; l < 2; l++) {
+                const int go = 16 * l;
+                if ((l ? in.nref1 : in.nref) <= 1) continue;
+                if (lane == 5 + go || lane == 6 + go || lane == 9 + go || lane == 10 + go) S.cref = -2;
+                for (int kp = 0; kp < np; kp++) {
+                    const int x8 = part == D_8x16 ? kp : part == D_8x8 ? kp & 1 : 0, y8 = part == D_16x8 ? kp : part == D_8x8 ? kp >> 1 : 0;
+                    const int u = use_of(kp), b8 = y8 * 2 + x8, g0 = (y8 + 1) * 4 + x8 + 1 + go;
+                    const bool sends = u == 2 || u == l;
+                    const int r = rl(l ? in.b_r1 : in.b_r0, b8 * 16);
+                    if (sends) {
+                        int ctx = (rl(S.cref, g0 - 1) > 0 && !rl(S.cdir, g0 - 1)) + 2 * (rl(S.cref, g0 - 4) > 0 && !rl(S.cdir, g0 - 4));
+                        for (int q = r; q > 0; q--) { cab_bin(cb, model, lane, 54 + ctx, 1); ctx = (ctx >> 2) + 4; }
+                        cab_bin(cb, model, lane, 54 + ctx, 0);
+                    }
+                    const bool mine = lane == g0 || (w8 == 2 && lane == g0 + 1) || (h8 == 2 && lane == g0 + 4) || (w8 == 2 && h8 == 2 && lane == g0 + 5);
+                    S.cref = mine ? (sends ? r : u == 3 ? r : -1) : S.cref;
+                    S.cdir = mine ? (u == 3) : S.cdir;
+                }
+            }
+            unsigned long long amvd1 = 0;
+            for (int l = 0; l < 2; l++) {
+                const int go = 16 * l;
+                if (lane == 5 + go || lane == 6 + go || lane == 9 + go || lane == 10 + go) S.cref = -2;
+                unsigned long long am = 0;
+                const unsigned long long nl = l ? in.lamvd1 : in.lamvd, nt = l ? in.tamvd1 : in.tamvd;
+                for (int kp = 0; kp < np; kp++) {
+                    const int x8 = part == D_8x16 ? kp : part == D_8x8 ? kp & 1 : 0, y8 = part == D_16x8 ? kp : part == D_8x8 ? kp >> 1 : 0;
+                    const int u = use_of(kp), b8 = y8 * 2 + x8, g0 = (y8 + 1) * 4 + x8 + 1 + go;
+                    const bool sends = u == 2 || u == l;
+                    const int r = rl(l ? in.b_r1 : in.b_r0, b8 * 16), vx = rl(l ? in.b_x1 : in.b_x0, b8 * 16), vy = rl(l ? in.b_y1 : in.b_y0, b8 * 16);
+                    if (sends) {
+                        int px, py;
+                        mb_predict_mv(S, part, x8, y8, w8, r, px, py, go);
+                        for (int comp = 0; comp < 2; comp++) {
+                            const int la = x8 > 0 ? (int)((am >> (8 * ((y8 * 2 + x8 - 1) * 2 + comp))) & 255) : lavail ? (int)((nl >> (8 * ((y8 * 2 + 1) * 2 + comp))) & 255) : 0;
+                            const int ta = y8 > 0 ? (int)((am >> (8 * (((y8 - 1) * 2 + x8) * 2 + comp))) & 255) : tavail ? (int)((nt >> (8 * ((2 + x8) * 2 + comp))) & 255) : 0;
+                            const int d = comp ? vy - py : vx - px;
+                            cab_mvd(cb, model, lane, comp ? 47 : 40, la + ta, d);
+                            const unsigned long long capped = (unsigned long long)min(abs(d), 66);
+                            for (int yy = y8; yy < y8 + h8; yy++) for (int xx = x8; xx < x8 + w8; xx++) am |= capped << (8 * ((yy * 2 + xx) * 2 + comp));
+                        }
+                    }
+                    const bool mine = lane == g0 || (w8 == 2 && lane == g0 + 1) || (h8 == 2 && lane == g0 + 4) || (w8 == 2 && h8 == 2 && lane == g0 + 5);
+                    S.cref = mine ? (r >= 0 ? r : -1) : S.cref; S.cmvx = mine ? (r >= 0 ? vx : 0) : S.cmvx; S.cmvy = mine ? (r >= 0 ? vy : 0) : S.cmvy;
+                }
+                if (l) amvd1 = am; else amvd = am;
+            }
+            S.cref = sc0; S.cmvx = sc1; S.cmvy = sc2; S.cdir = sc3;
+            amvd1_out = amvd1;
+        }
     } else {
         const int part = in.part, np = part == D_16x16 ? 1 : part == D_8x8 ? 4 : 2;
         const int w8 = part == D_16x16 || part == D_16x8 ? 2 : 1, h8 = part == D_16x16 || part == D_8x16 ? 2 : 1;
@@ -352,7 +450,7 @@ __device__ __forceinline__ unsigned long long cab_mb(Cab &cb, uint32_t model, in
         auto dc_inc = [&](int bit) {
             auto of = [&](bool avail, int type, int cbp_chroma, unsigned nnz) {
                 if (!avail) return un;
-                if (type == X264GPU_MB_P_SKIP) return 0;
+                if (cab_is_skip(type)) return 0;
                 if (bit == 24) return type == X264GPU_MB_I16x16 ? (int)((nnz >> 24) & 1) : 0;
                 return cbp_chroma ? (int)((nnz >> bit) & 1) : 0;
             };
@@ -360,7 +458,7 @@ __device__ __forceinline__ unsigned long long cab_mb(Cab &cb, uint32_t model, in
         };
         auto ac_inc = [&](int pl, int i) {
             const int bx = i & 1, by = i >> 1;
-            auto of = [&](int type, int cbp_chroma, unsigned nnz, int x, int y) { return type != X264GPU_MB_P_SKIP && cbp_chroma == 2 ? (int)((nnz >> (16 + pl * 4 + y * 2 + x)) & 1) : 0; };
+            auto of = [&](int type, int cbp_chroma, unsigned nnz, int x, int y) { return !cab_is_skip(type) && cbp_chroma == 2 ? (int)((nnz >> (16 + pl * 4 + y * 2 + x)) & 1) : 0; };
             const int a = bx > 0 ? of(in.type, in.cbp_chroma, in.nnz, 0, by) : lavail ? of(in.ltype, in.lcbp_chroma, in.lnnz, 1, by) : un;
             const int b = by > 0 ? of(in.type, in.cbp_chroma, in.nnz, bx, 0) : tavail ? of(in.ttype, in.tcbp_chroma, in.tnnz, bx, 1) : un;
             return a + 2 * b;

@@ -23,8 +23,15 @@ struct EncK {
     const uint8_t *i420;      // [streams] tightly packed input pictures
     uint8_t *fenc_y, *fenc_uv;
     uint8_t *rec_luma, *rec_chroma;          // DPB slot being reconstructed
-    const uint8_t *ref_luma[5], *ref_chroma[5];   // DPB slots of reference index 0..nref-1 (0 = most recent)
-    int nref;                                // references usable by this P slice
+    // DPB slots of the slice's references, list 0 then list 1 in ONE index space: list 0 index r = entry r (0 = nearest), list 1 index r (B slices)
+    // = entry nref + r — motion search, reference cache and vector side data only ever see this combined index
+    const uint8_t *ref_luma[8], *ref_chroma[8];
+    int nref;                                // references of list 0 (all a P slice has)
+    int nref1;                               // references of list 1 (B slices)
+    uint8_t biw[5][4];                       // B: implicit bi-prediction weight of the list-0 sample for (list-0 index, list-1 index), of 64 (x264 bipred_weight)
+    const int8_t *colref; const int16_t *colmv;    // B: per 8x8 block of the first picture of list 1, the reference index it used (-1 intra) and that vector
+    int8_t *colref_cur; int16_t *colmv_cur;  // the same of the picture being coded, for the B pictures that will have it at the head of their list 1
+    const int16_t *lowres_mv1;               // B: lookahead vectors towards the first picture of list 1
     x264gpu_mb *mb;           // [streams][nmb]
     int16_t *levels;          // [streams][nmb][416]
     int qp, lambda, qpc;
@@ -50,10 +57,10 @@ struct EncK {
     // motion side data of the raster macroblock loop (k_mb.cuh; x264: h->mb.mvr, frame->mv16x16, frame->mb_type)
     int16_t *mv16_cur;        // [streams][nmb][2]: 16x16 search result in reference 0 of the picture being coded (= mvr[0]); lives with the DPB slot
     const int16_t *mv16_ref0; // the same array of reference 0 (temporal candidates)
-    int16_t *mvr[5];          // [r >= 1][streams][nmb][2]: 16x16 search results per reference index
+    int16_t *mvr[8];          // [combined index >= 1][streams][nmb][2]: 16x16 search results per reference (list 0 index 0 lives in mv16_cur)
     uint8_t *mbtype_cur;      // [streams][nmb] macroblock types of the picture being coded; lives with the DPB slot
     const uint8_t *mbtype_ref0;
-    int tscale[5];            // (POC distance to reference r) * inv_ref_poc of reference 0, for the temporal candidates
+    int tscale[8];            // (POC distance to reference r) * inv_ref_poc of reference 0, for the temporal candidates (combined index)
     int temporal;             // reference 0 was itself a P picture: its 16x16 vectors are search candidates
     const int16_t *lowres_mv; // optional [streams][nmb][2] lookahead vectors (x264 lowres_mvs[0][0]); first entry 0x7fff = absent
     int fast_pskip, mv_range;

@@ -22,6 +22,7 @@ void launch_mb_slice_hex(const EncK &k, int streams, bool big_margin, hipStream_
 void launch_mb_slice_umh(const EncK &k, int streams, bool big_margin, hipStream_t st);
 void launch_mb_slice_esa(const EncK &k, int streams, bool big_margin, hipStream_t st);
 void launch_mb_slice_intra(const EncK &k, int streams, hipStream_t st);
+void launch_mb_slice_b_hex(const EncK &k, int streams, hipStream_t st);       // B slices (mb_slice_b.hip): RD sessions with CABAC, --me hex
 int trellis_table_ptrs(const uint16_t **su, const uint8_t **tu, const int **l2);        // prim_kernels.hip
 int launch_hpel_filter(uint8_t *planes, size_t plane_bytes, int stride, int w, int h, int pad, int batch,
                        size_t batch_bytes, hipStream_t st);
@@ -32,15 +33,16 @@ struct x264gpu_encoder {
     x264gpu_config cfg;
     EncK k;                       // template of the kernel argument block (pointers refreshed per call)
     uint8_t *fenc_y = nullptr, *fenc_uv = nullptr;
-    uint8_t *luma[6] = {}, *chroma[6] = {};      // DPB slots: refs + the picture being reconstructed
-    int slots = 2, have = 0;                     // have = pictures in the DPB since the last IDR
-    int16_t *mv16[6] = {};                       // per DPB slot: 16x16 search results in reference 0 (x264 frame->mv16x16 = h->mb.mvr[0][0])
-    uint8_t *mbtype[6] = {};                     // per DPB slot: macroblock types (x264 frame->mb_type)
-    int16_t *mvr[5] = {};                        // per reference index >= 1: 16x16 search results of the picture being coded
-    int slot_nref[6] = {}, slot_poc[6] = {}, slot_ref0poc[6] = {};
-    int poc = 0;
-    const int16_t *lowres_mv = nullptr;
-    int cur = 0;
+    uint8_t *luma[8] = {}, *chroma[8] = {};      // picture slots: the DPB (cfg.dpb or cfg.refs pictures) + the picture being reconstructed
+    int slots = 2, have = 0;                     // have = pictures in the DPB since the last IDR (x264gpu_encode_frames' sliding window)
+    int16_t *mv16[8] = {};                       // per slot: 16x16 search results in reference 0 of list 0 (x264 frame->mv16x16 = h->mb.mvr[0][0])
+    uint8_t *mbtype[8] = {};                     // per slot: macroblock types (x264 frame->mb_type)
+    int8_t *colref[8] = {}; int16_t *colmv[8] = {};      // per slot (sessions with B pictures): what spatial direct prediction reads of a co-located picture
+    int16_t *mvr[8] = {};                        // per combined reference index >= 1: 16x16 search results of the picture being coded
+    int slot_nref[8] = {}, slot_poc[8] = {}, slot_ref0poc[8] = {};
+    int poc = 0, ring = 2;                       // the sliding window: next POC, slots in rotation (refs + 1)
+    const int16_t *lowres_mv = nullptr, *lowres_mv1 = nullptr;
+    int cur = 0, last = 0;                       // next slot of the sliding window; slot of the picture coded last
     unsigned long long *dbg = nullptr;   // diagnostics buffer set by x264gpu_encoder_set_debug
     uint8_t *tc = nullptr;               // RD: total_coeff of every block of the picture being coded
     uint8_t *amvd = nullptr;             // CABAC RD: |mvd| of every 8x8 block of the picture being coded
@@ -109,6 +111,7 @@ int x264gpu_encoder_create(x264gpu_encoder **out, const x264gpu_config *cfg)
     ARG_TRY(cfg->slices_plain == 0 || cfg->slices_plain == 1);
     ARG_TRY(cfg->width <= 4096 && cfg->height <= 2304 && cfg->me_range >= 4 && cfg->me_range <= (cfg->me_method == 2 ? 64 : 16));
     ARG_TRY(cfg->me_method >= 0 && cfg->me_method <= 3);
+    ARG_TRY(cfg->dpb == 0 || (cfg->dpb >= cfg->refs && cfg->dpb <= 7));
     x264gpu_encoder *e = new (std::nothrow) x264gpu_encoder();
     if (!e) return set_err(X264GPU_ENOMEM, "encoder", hipSuccess);
     e->cfg = *cfg;
@@ -138,7 +141,7 @@ int x264gpu_encoder_create(x264gpu_encoder **out, const x264gpu_config *cfg)
     };
     alloc((void **)&e->fenc_y, S * k.fency_bytes, 0);
     alloc((void **)&e->fenc_uv, S * k.fencuv_bytes, 0);
-    e->slots = cfg->refs + 1;
+    e->slots = (cfg->dpb > 0 ? cfg->dpb : cfg->refs) + 1; e->ring = cfg->refs + 1;
     for (int i = 0; i < e->slots; i++) {
         alloc((void **)&e->luma[i], S * k.luma_bytes, 0);
         alloc((void **)&e->chroma[i], S * k.cplane_bytes, 0);
@@ -146,11 +149,12 @@ int x264gpu_encoder_create(x264gpu_encoder **out, const x264gpu_config *cfg)
     for (int i = 0; i < e->slots; i++) {
         alloc((void **)&e->mv16[i], S * k.nmb * 2 * sizeof(int16_t), 0);
         alloc((void **)&e->mbtype[i], S * k.nmb, 0);
+        if (cfg->dpb > 0) { alloc((void **)&e->colref[i], S * k.nmb * 4, 0); alloc((void **)&e->colmv[i], S * k.nmb * 8 * sizeof(int16_t), 0); }
     }
-    for (int r = 1; r < cfg->refs; r++) alloc((void **)&e->mvr[r], S * k.nmb * 2 * sizeof(int16_t), 0);
+    for (int r = 1; r < (cfg->dpb > 0 ? 8 : cfg->refs); r++) alloc((void **)&e->mvr[r], S * k.nmb * 2 * sizeof(int16_t), 0);
     alloc((void **)&e->wf_progress, S * 2 * WFG_ROWS * sizeof(int), 0);
     if (cfg->rd && !cfg->cabac) alloc((void **)&e->tc, S * k.nmb * 24, 0);
-    if (cfg->rd && cfg->cabac) { alloc((void **)&e->amvd, S * k.nmb * 8, 0); alloc((void **)&e->cab_out, S * (cfg->slices > 1 ? cfg->slices : 1) * 192 * sizeof(uint32_t), 0); }
+    if (cfg->rd && cfg->cabac) { alloc((void **)&e->amvd, S * k.nmb * (cfg->dpb > 0 ? 16 : 8), 0); alloc((void **)&e->cab_out, S * (cfg->slices > 1 ? cfg->slices : 1) * 192 * sizeof(uint32_t), 0); }
     if (cfg->slices_plain && cfg->slices > 1) { alloc((void **)&e->sl_stat, S * cfg->slices * 4 * sizeof(int), 0); alloc((void **)&e->sl_rerun, S * cfg->slices * sizeof(int), 0); }
 #ifdef MB_PROF
     alloc((void **)&e->prof, S * 16 * sizeof(unsigned long long), 0);
@@ -232,8 +236,8 @@ void x264gpu_encoder_destroy(x264gpu_encoder *e)
     if (!e) return;
     profile_free(e);
     (void)hipFree(e->fenc_y); (void)hipFree(e->fenc_uv);
-    for (int i = 0; i < 6; i++) { (void)hipFree(e->luma[i]); (void)hipFree(e->chroma[i]); (void)hipFree(e->mv16[i]); (void)hipFree(e->mbtype[i]); }
-    for (int i = 0; i < 5; i++) (void)hipFree(e->mvr[i]);
+    for (int i = 0; i < 8; i++) { (void)hipFree(e->luma[i]); (void)hipFree(e->chroma[i]); (void)hipFree(e->mv16[i]); (void)hipFree(e->mbtype[i]); (void)hipFree(e->colref[i]); (void)hipFree(e->colmv[i]); }
+    for (int i = 0; i < 8; i++) (void)hipFree(e->mvr[i]);
     (void)hipFree(e->wf_progress);
     (void)hipFree(e->tc);
     (void)hipFree(e->amvd);
@@ -276,6 +280,7 @@ int x264gpu_encoder_cabac_states(x264gpu_encoder *e, int stream, int slice, uint
 }
 
 int x264gpu_encoder_set_lowres_mvs(x264gpu_encoder *e, const int16_t *d_mvs) { ARG_TRY(e); e->lowres_mv = d_mvs; return X264GPU_OK; }
+int x264gpu_encoder_set_lowres_mvs1(x264gpu_encoder *e, const int16_t *d_mvs) { ARG_TRY(e); e->lowres_mv1 = d_mvs; return X264GPU_OK; }
 
 // --slices N in P pictures (EncK.sl_stat): with the intra counts the slices reported, does every slice's window of harmless prior counts hold the
 // sum of the counts before it?  A slice whose window misses runs again on the sum as it stands now.  One thread per stream.
@@ -295,43 +300,85 @@ __global__ void k_slice_priors(EncK k, int streams, int guess)
     }
 }
 
-int x264gpu_encode_frames(x264gpu_encoder *e, const uint8_t *d_i420, int slice_type, x264gpu_mb *d_mb,
-                          int16_t *d_levels, void *stream)
+}  // extern "C"
+
+// what a later B picture's spatial direct prediction reads of this picture when it heads that picture's list 1 (x264 frame->ref[] / mv[] of the
+// co-located macroblock): per 8x8 block the reference index it used — list 0's, else list 1's, -1 for intra — and that vector
+__global__ void k_col_from_records(EncK k)
 {
-    ARG_TRY(e && d_i420 && d_mb && d_levels);
-    ARG_TRY(slice_type == X264GPU_SLICE_I || slice_type == X264GPU_SLICE_P || slice_type == X264GPU_SLICE_I_NONIDR);
-    ARG_TRY(slice_type != X264GPU_SLICE_P || e->have > 0);
-    const bool idr = slice_type == X264GPU_SLICE_I;
+    const int i = blockIdx.x * 256 + threadIdx.x, s = blockIdx.y;
+    if (i >= k.nmb * 4) return;
+    const int mbi = i >> 2, b8 = i & 3;
+    const x264gpu_mb *m = k.mb + (size_t)s * k.nmb + mbi;
+    const int t = m->type;
+    int r = -1, vx = 0, vy = 0;
+    if (t > X264GPU_MB_I16x16) {
+        const bool use1 = t >= X264GPU_MB_B_DIRECT && m->ref[b8] < 0;
+        r = use1 ? m->ref1[b8] : m->ref[b8]; vx = use1 ? m->mv1[b8][0] : m->mv[b8][0]; vy = use1 ? m->mv1[b8][1] : m->mv[b8][1];
+    }
+    k.colref_cur[((size_t)s * k.nmb + mbi) * 4 + b8] = (int8_t)r;
+    int16_t *o = k.colmv_cur + (((size_t)s * k.nmb + mbi) * 4 + b8) * 2;
+    o[0] = (int16_t)vx; o[1] = (int16_t)vy;
+}
+
+// One picture per stream, every stream with the SAME structure (slice type, destination slot, reference lists, POC); quantisers may differ
+// per stream (x264gpu_encoder_set_stream_qps) or be pic.qp for all
+static int encode_core(x264gpu_encoder *e, const uint8_t *d_i420, const x264gpu_pic &pic, x264gpu_mb *d_mb, int16_t *d_levels, hipStream_t st)
+{
+    int slice_type = pic.slice_type;
     if (slice_type == X264GPU_SLICE_I_NONIDR) slice_type = X264GPU_SLICE_I;            // same kernels; only the DPB handling differs
-    hipStream_t st = (hipStream_t)stream;
+    const bool bslice = slice_type == X264GPU_SLICE_B;
+    ARG_TRY(pic.dst >= 0 && pic.dst < e->slots && pic.qp >= 0 && pic.qp <= 51);
+    ARG_TRY(!bslice || (e->cfg.rd && e->cfg.cabac && e->cfg.dpb > 0 && e->cfg.me_method == 1 && (e->cfg.slices <= 1)));      // B pictures: RD sessions with CABAC, --me hex, one slice
+    const int n0 = slice_type == X264GPU_SLICE_I ? 0 : pic.nref[0], n1 = bslice ? pic.nref[1] : 0;
+    ARG_TRY(n0 >= 0 && n0 <= 5 && n1 >= 0 && n1 <= 3 && (slice_type == X264GPU_SLICE_I || n0 > 0) && (!bslice || n1 > 0));
+    for (int l = 0; l < 2; l++) for (int r = 0; r < (l ? n1 : n0); r++) ARG_TRY(pic.slot[l][r] >= 0 && pic.slot[l][r] < e->slots && pic.slot[l][r] != pic.dst);
     const int S = e->cfg.streams;
     EncK k = e->k;
-    const int qp = slice_type == X264GPU_SLICE_I ? e->cfg.qp_i : e->cfg.qp_p;
+    const int qp = pic.qp;
+    e->poc = pic.poc;
     k.i420 = d_i420; k.fenc_y = e->fenc_y; k.fenc_uv = e->fenc_uv;
-    if (idr) { e->have = 0; e->poc = 0; }                                // IDR empties the DPB
-    k.rec_luma = e->luma[e->cur]; k.rec_chroma = e->chroma[e->cur];
-    k.nref = slice_type == X264GPU_SLICE_I ? 0 : e->have < e->cfg.refs ? e->have : e->cfg.refs;
-    auto slot_of = [&](int r) { return (e->cur - 1 - r + 2 * e->slots) % e->slots; };
-    for (int r = 0; r < 5; r++) {
-        const int slot = slot_of(r < k.nref ? r : 0);
+    const int cur = pic.dst;
+    k.rec_luma = e->luma[cur]; k.rec_chroma = e->chroma[cur];
+    k.nref = n0; k.nref1 = n1;
+    auto slot_of = [&](int ri) { return (int)(ri < n0 ? pic.slot[0][ri] : pic.slot[1][ri - n0]); };      // combined index: list 0, then list 1
+    for (int r = 0; r < 8; r++) {
+        const int slot = n0 + n1 > 0 ? slot_of(r < n0 + n1 ? r : 0) : cur;
         k.ref_luma[r] = e->luma[slot]; k.ref_chroma[r] = e->chroma[slot];
     }
     // motion side data (x264: h->mb.mvr, fref[0][0]->mv16x16 / mb_type / i_ref, POC distances)
-    const int s0 = slot_of(0);
-    k.mv16_cur = e->mv16[e->cur]; k.mv16_ref0 = e->mv16[s0]; k.mbtype_cur = e->mbtype[e->cur]; k.mbtype_ref0 = e->mbtype[s0];
-    for (int r = 0; r < 5; r++) k.mvr[r] = e->mvr[r];
+    const int s0 = n0 ? slot_of(0) : cur;
+    k.mv16_cur = e->mv16[cur]; k.mv16_ref0 = e->mv16[s0]; k.mbtype_cur = e->mbtype[cur]; k.mbtype_ref0 = e->mbtype[s0];
+    for (int r = 0; r < 8; r++) k.mvr[r] = e->mvr[r];
     k.temporal = k.nref > 0 && e->slot_nref[s0] > 0;
-    for (int r = 0; r < 5; r++) k.tscale[r] = 0;
+    for (int r = 0; r < 8; r++) k.tscale[r] = 0;
     if (k.temporal) {
         const int delta = e->slot_poc[s0] - e->slot_ref0poc[s0], inv = (256 + delta / 2) / delta;
-        for (int r = 0; r < k.nref; r++) k.tscale[r] = (e->poc - e->slot_poc[slot_of(r)]) * inv;
+        for (int r = 0; r < n0 + n1; r++) k.tscale[r] = (e->poc - e->slot_poc[slot_of(r)]) * inv;
     }
-    e->slot_nref[e->cur] = k.nref; e->slot_poc[e->cur] = e->poc; e->slot_ref0poc[e->cur] = k.nref ? e->slot_poc[s0] : 0;
+    memset(k.biw, 32, sizeof(k.biw));
+    if (bslice) {
+        // x264_macroblock_bipred_init: implicit weights from the POC distances (8.4.2.3.1)
+        for (int r0 = 0; r0 < n0; r0++)
+            for (int r1 = 0; r1 < n1; r1++) {
+                const int poc0 = e->slot_poc[pic.slot[0][r0]], poc1 = e->slot_poc[pic.slot[1][r1]];
+                const int td = min(max(poc1 - poc0, -128), 127);
+                int dsf = 256;
+                if (td) { const int tb = min(max(e->poc - poc0, -128), 127), tx = (16384 + (abs(td) >> 1)) / td; dsf = min(max((tb * tx + 32) >> 6, -1024), 1023); }
+                dsf >>= 2;
+                const int w = (e->cfg.weightb && dsf >= -64 && dsf <= 128) ? 64 - dsf : 32;
+                ARG_TRY(w > 0 && w < 64);      // list 0 before, list 1 after the picture: always inside (the device averages in 16-bit lanes)
+                k.biw[r0][r1] = (uint8_t)w;
+            }
+        k.colref = e->colref[pic.slot[1][0]]; k.colmv = e->colmv[pic.slot[1][0]];
+    }
+    k.colref_cur = e->colref[cur]; k.colmv_cur = e->colmv[cur];
+    e->slot_nref[cur] = k.nref; e->slot_poc[cur] = e->poc; e->slot_ref0poc[cur] = k.nref ? e->slot_poc[s0] : 0;
     k.prof = e->prof; k.tc = e->tc; k.amvd = e->amvd; k.cab_out = e->cab_out;
     k.sl_stat = slice_type == X264GPU_SLICE_P ? e->sl_stat : nullptr; k.sl_rerun = e->sl_rerun; k.sl_pass = 0;
     k.trellis = e->cfg.trellis; k.tr_su = nullptr; k.tr_tu = nullptr; k.tr_l2 = nullptr;
     if (k.trellis) { const int rc = trellis_table_ptrs(&k.tr_su, &k.tr_tu, &k.tr_l2); if (rc != X264GPU_OK) return rc; }
-    k.lowres_mv = e->lowres_mv; k.fast_pskip = e->cfg.fast_pskip; k.mv_range = e->cfg.mv_range;
+    k.lowres_mv = e->lowres_mv; k.lowres_mv1 = e->lowres_mv1; k.fast_pskip = e->cfg.fast_pskip; k.mv_range = e->cfg.mv_range;
     k.mb = d_mb; k.levels = d_levels;
     k.qp = qp; k.lambda = lambda_of(qp); k.qpc = chroma_qp_of(qp, e->cfg.chroma_qp_offset);
     k.slice_type = slice_type;
@@ -354,6 +401,7 @@ int x264gpu_encode_frames(x264gpu_encoder *e, const uint8_t *d_i420, int slice_t
     STAGE_MARK(1);
     // the macroblock loop: one wavefront per stream, raster order (sub-pel neighbourhood margin 2 px up to subme 7, 5 px above)
     if (slice_type == X264GPU_SLICE_I) launch_mb_slice_intra(k, S, st);        // (RD instantiations inside, chosen by k.rd)
+    else if (bslice) launch_mb_slice_b_hex(k, S, st);
     else {
         const auto launch = k.me_method == 0 ? launch_mb_slice_dia : k.me_method == 2 ? launch_mb_slice_umh : k.me_method == 3 ? launch_mb_slice_esa : launch_mb_slice_hex;
         if (k.sl_stat) hipLaunchKernelGGL(k_slice_priors, dim3((S + 63) / 64), dim3(64), 0, st, k, S, 1);
@@ -368,6 +416,7 @@ int x264gpu_encode_frames(x264gpu_encoder *e, const uint8_t *d_i420, int slice_t
             }
         k.sl_pass = 0;
     }
+    if (e->cfg.dpb > 0 && pic.keep) hipLaunchKernelGGL(k_col_from_records, dim3((k.nmb * 4 + 255) / 256, S), dim3(256), 0, st, k);
     mask |= 2;
     STAGE_MARK(2);
     STAGE_MARK(3);
@@ -389,17 +438,62 @@ int x264gpu_encode_frames(x264gpu_encoder *e, const uint8_t *d_i420, int slice_t
         mask |= 16;
     }
     STAGE_MARK(5);
-    launch_hpel_filter(e->luma[e->cur], k.plane_bytes, k.rs, k.cw, k.ch, PAD, S, k.luma_bytes, st);
-    hipLaunchKernelGGL(k_chroma_border, dim3((k.cw / 2 + 2 * CPAD + 255) / 256, k.ch / 2 + 2 * CPAD, S), dim3(256), 0, st, k);
-    mask |= 32;
+    if (pic.keep) {       // only pictures that will be referenced need their half-pel planes and borders (x264: fdec->b_kept_as_ref)
+        launch_hpel_filter(e->luma[cur], k.plane_bytes, k.rs, k.cw, k.ch, PAD, S, k.luma_bytes, st);
+        hipLaunchKernelGGL(k_chroma_border, dim3((k.cw / 2 + 2 * CPAD + 255) / 256, k.ch / 2 + 2 * CPAD, S), dim3(256), 0, st, k);
+        mask |= 32;
+    }
     STAGE_MARK(6);
 #undef STAGE_MARK
     if (ev) e->ev_mask[e->prof_calls++] = mask;
     HIP_TRY(hipGetLastError());
-    e->cur = (e->cur + 1) % e->slots;
+    e->last = cur;
+    return X264GPU_OK;
+}
+
+extern "C" {
+
+int x264gpu_encode_frames(x264gpu_encoder *e, const uint8_t *d_i420, int slice_type, x264gpu_mb *d_mb,
+                          int16_t *d_levels, void *stream)
+{
+    ARG_TRY(e && d_i420 && d_mb && d_levels);
+    ARG_TRY(slice_type == X264GPU_SLICE_I || slice_type == X264GPU_SLICE_P || slice_type == X264GPU_SLICE_I_NONIDR);
+    ARG_TRY(slice_type != X264GPU_SLICE_P || e->have > 0);
+    if (slice_type == X264GPU_SLICE_I) { e->have = 0; e->poc = 0; }                    // IDR empties the DPB
+    x264gpu_pic pic;
+    memset(&pic, 0, sizeof(pic));
+    pic.slice_type = slice_type; pic.qp = slice_type == X264GPU_SLICE_P ? e->cfg.qp_p : e->cfg.qp_i; pic.poc = e->poc; pic.dst = e->cur; pic.keep = 1;
+    pic.nref[0] = slice_type == X264GPU_SLICE_P ? (e->have < e->cfg.refs ? e->have : e->cfg.refs) : 0;
+    for (int r = 0; r < pic.nref[0]; r++) pic.slot[0][r] = (int8_t)((e->cur - 1 - r + 2 * e->ring) % e->ring);
+    const int rc = encode_core(e, d_i420, pic, d_mb, d_levels, (hipStream_t)stream);
+    if (rc != X264GPU_OK) return rc;
+    e->cur = (e->cur + 1) % e->ring;
     e->have++;
     e->poc += 2;
     return X264GPU_OK;
+}
+
+int x264gpu_encode_pictures(x264gpu_encoder *e, const uint8_t *d_i420, const x264gpu_pic *pics, x264gpu_mb *d_mb, int16_t *d_levels, void *stream)
+{
+    ARG_TRY(e && d_i420 && pics && d_mb && d_levels);
+    // the streams of a call share the picture structure (lock-step GOPs); their quantisers may differ
+    const int S = e->cfg.streams;
+    bool same_qp = true;
+    for (int s = 1; s < S; s++) {
+        ARG_TRY(pics[s].slice_type == pics[0].slice_type && pics[s].poc == pics[0].poc && pics[s].dst == pics[0].dst && pics[s].keep == pics[0].keep &&
+                pics[s].nref[0] == pics[0].nref[0] && pics[s].nref[1] == pics[0].nref[1] && !memcmp(pics[s].slot, pics[0].slot, sizeof(pics[0].slot)));
+        same_qp = same_qp && pics[s].qp == pics[0].qp;
+    }
+    if (!same_qp) {
+        std::vector<int8_t> q((size_t)S);
+        for (int s = 0; s < S; s++) q[(size_t)s] = (int8_t)pics[s].qp;
+        const int rc = x264gpu_encoder_set_stream_qps(e, q.data());
+        if (rc != X264GPU_OK) return rc;
+    }
+    const int rc = encode_core(e, d_i420, pics[0], d_mb, d_levels, (hipStream_t)stream);
+    if (!same_qp) (void)x264gpu_encoder_set_stream_qps(e, nullptr);
+    if (rc == X264GPU_OK) e->have++;
+    return rc;
 }
 
 }  // extern "C"
@@ -457,7 +551,18 @@ extern "C" int x264gpu_encoder_get_recon(x264gpu_encoder *e, int stream_idx, uin
 {
     ARG_TRY(e && d_out && stream_idx >= 0 && stream_idx < e->cfg.streams && e->have > 0);
     const EncK &k = e->k;
-    const int slot = (e->cur + e->slots - 1) % e->slots;
+    const int slot = e->last;
+    const uint8_t *l = e->luma[slot] + (size_t)stream_idx * k.luma_bytes + (size_t)PAD * k.rs + PAD;
+    const uint8_t *c = e->chroma[slot] + (size_t)stream_idx * k.cplane_bytes + (size_t)CPAD * k.rs + 2 * CPAD;
+    hipLaunchKernelGGL(k_get_recon, dim3((k.w + 255) / 256, k.h), dim3(256), 0, (hipStream_t)stream, l, c, k.rs, k.w, k.h, d_out);
+    HIP_TRY(hipGetLastError());
+    return X264GPU_OK;
+}
+
+extern "C" int x264gpu_encoder_get_recon_slot(x264gpu_encoder *e, int stream_idx, int slot, uint8_t *d_out, void *stream)
+{
+    ARG_TRY(e && d_out && stream_idx >= 0 && stream_idx < e->cfg.streams && slot >= 0 && slot < e->slots);
+    const EncK &k = e->k;
     const uint8_t *l = e->luma[slot] + (size_t)stream_idx * k.luma_bytes + (size_t)PAD * k.rs + PAD;
     const uint8_t *c = e->chroma[slot] + (size_t)stream_idx * k.cplane_bytes + (size_t)CPAD * k.rs + 2 * CPAD;
     hipLaunchKernelGGL(k_get_recon, dim3((k.w + 255) / 256, k.h), dim3(256), 0, (hipStream_t)stream, l, c, k.rs, k.w, k.h, d_out);

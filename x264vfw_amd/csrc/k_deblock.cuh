@@ -48,6 +48,13 @@ __device__ __forceinline__ int edge_bs(const x264gpu_mb *P, int pbx, int pby, co
     const int pi = (pby >> 1) * 2 + (pbx >> 1), qi = (qby >> 1) * 2 + (qbx >> 1);
     if (P->ref[pi] != Q->ref[qi]) return 1;
     if (abs(P->mv[pi][0] - Q->mv[qi][0]) >= 4 || abs(P->mv[pi][1] - Q->mv[qi][1]) >= 4) return 1;
+    // B slices (x264 deblock_strength_c with bframe): list 1 index by index as well; the lists never share a picture
+    if (P->type >= X264GPU_MB_B_DIRECT && Q->type >= X264GPU_MB_B_DIRECT) {
+        if (P->ref1[pi] != Q->ref1[qi]) return 1;
+        const int px = P->ref1[pi] < 0 ? 0 : P->mv1[pi][0], py = P->ref1[pi] < 0 ? 0 : P->mv1[pi][1];
+        const int qx = Q->ref1[qi] < 0 ? 0 : Q->mv1[qi][0], qy = Q->ref1[qi] < 0 ? 0 : Q->mv1[qi][1];
+        if (abs(px - qx) >= 4 || abs(py - qy) >= 4) return 1;
+    }
     return 0;
 }
 

@@ -94,6 +94,9 @@ struct MeState {
     int cref, cmvx, cmvy;                                   // lane = motion cache grid index: (y + 1) * 4 + x + 1, x = -1..2, y = -1..1
     int mvcx, mvcy;                                         // lane = ref * 5 + q: a->l0.mvc[ref][0] = 16x16 vector, [1..4] = 8x8 vectors
     int inx, iny;                                           // lane = raw candidate i of the search in progress
+    int cdir;                                               // B slices: lane = motion cache grid index: the block is predicted by direct inference
+    // B slices keep list 1 sixteen lanes up in every table: result slots 16 + slot (the bi-predictive 16x16 pair lives in slots 32 / 48), cache grid
+    // 16 + index, mvc 32 + ref * 5 + q
 };
 __device__ __forceinline__ int rl(int v, int i) { return __builtin_amdgcn_readlane(v, i); }
 __device__ __forceinline__ void wl(int &v, int lane, int i, int x) { v = lane == i ? x : v; }
@@ -113,11 +116,11 @@ __device__ __forceinline__ void lds_sync()
 // ------------------------------------------------------------------------------------------------
 // motion vector prediction on the cache grid (oracle predict_mv / predict_mv_pskip)
 // ------------------------------------------------------------------------------------------------
-__device__ __forceinline__ void mb_predict_mv(const MeState &S, int partition, int bx8, int by8, int w8, int ref, int &mvpx, int &mvpy)
+__device__ __forceinline__ void mb_predict_mv(const MeState &S, int partition, int bx8, int by8, int w8, int ref, int &mvpx, int &mvpy, int go = 0)
 {
-    const int ia = (by8 + 1) * 4 + bx8, ib = by8 * 4 + bx8 + 1;
-    int ic = by8 * 4 + bx8 + w8 + 1;
-    if (rl(S.cref, ic) == -2) ic = by8 * 4 + bx8;
+    const int ia = (by8 + 1) * 4 + bx8 + go, ib = by8 * 4 + bx8 + 1 + go;      // go: 0 = list 0's cache, 16 = list 1's
+    int ic = by8 * 4 + bx8 + w8 + 1 + go;
+    if (rl(S.cref, ic) == -2) ic = by8 * 4 + bx8 + go;
     const int ra = rl(S.cref, ia), rb = rl(S.cref, ib), rc = rl(S.cref, ic);
     const int ax = rl(S.cmvx, ia), ay = rl(S.cmvy, ia), bx = rl(S.cmvx, ib), by = rl(S.cmvy, ib), cx = rl(S.cmvx, ic), cy = rl(S.cmvy, ic);
     if (partition == D_16x8) {
@@ -1301,6 +1304,46 @@ __device__ __forceinline__ bool mb_probe_pskip(const EncK &k, const MbCtx &c, ui
 }
 
 // ------------------------------------------------------------------------------------------------
+// B slices: how a macroblock is predicted, as per-lane values keyed by the lane's 8x8 block (lane >> 4 in the Z layout): reference index
+// and vector in list 0 and in list 1, reference -1 = the list is not used.  Block b's values are read from lane 16 b.
+// ------------------------------------------------------------------------------------------------
+struct BCfg { int r0, x0, y0, r1, x1, y1; };
+// x264_me_refine_bidir's dia4d: every offset in up to two of the four components (list-0 x, y, list-1 x, y), one byte each
+#define D4(a, b, c, d) ((uint32_t)(uint8_t)(int8_t)(a) | ((uint32_t)(uint8_t)(int8_t)(b) << 8) | ((uint32_t)(uint8_t)(int8_t)(c) << 16) | ((uint32_t)(uint8_t)(int8_t)(d) << 24))
+static __constant__ const uint32_t c_dia4d[33] = {
+    D4(0, 0, 0, 0),
+    D4(0, 0, 0, 1), D4(0, 0, 0, -1), D4(0, 0, 1, 0), D4(0, 0, -1, 0), D4(0, 1, 0, 0), D4(0, -1, 0, 0), D4(1, 0, 0, 0), D4(-1, 0, 0, 0),
+    D4(0, 0, 1, 1), D4(0, 0, -1, -1), D4(0, 1, 1, 0), D4(0, -1, -1, 0), D4(1, 1, 0, 0), D4(-1, -1, 0, 0), D4(1, 0, 0, 1), D4(-1, 0, 0, -1),
+    D4(0, 1, 0, 1), D4(0, -1, 0, -1), D4(1, 0, 1, 0), D4(-1, 0, -1, 0), D4(0, 0, -1, 1), D4(0, 0, 1, -1), D4(0, -1, 1, 0), D4(0, 1, -1, 0),
+    D4(-1, 1, 0, 0), D4(1, -1, 0, 0), D4(1, 0, 0, -1), D4(-1, 0, 0, 1), D4(0, -1, 0, 1), D4(0, 1, 0, -1), D4(-1, 0, 1, 0), D4(1, 0, -1, 0) };
+#undef D4
+
+// x264_mb_mc of a B macroblock for this lane's row of four luma samples (Z layout) and, in lanes 0..31, its row of the chroma 4x4 block
+// (lane >> 2) & 3 of plane (lane >> 4) & 1: from list 0, list 1, or both averaged with the pair's implicit weight (biwv: lane r0 * 4 + r1)
+__device__ __forceinline__ void b_predict(const EncK &k, const MbCtx &c, const BCfg &g, int biwv, uint32_t &pred, uint32_t &cpred)
+{
+    const int lane = c.lane, zx = z_x0(lane), zy = z_y(lane), j4 = lane & 3;
+    {
+        uint32_t p0 = 0, p1 = 0;
+        if (g.r0 >= 0) p0 = mc_luma_row4(ref_plane00(k, c.s, g.r0), k.plane_bytes, k.rs, c.px + zx, c.py + zy, g.x0, g.y0);
+        if (g.r1 >= 0) p1 = mc_luma_row4(ref_plane00(k, c.s, k.nref + g.r1), k.plane_bytes, k.rs, c.px + zx, c.py + zy, g.x1, g.y1);
+        const int w = __shfl(biwv, max(g.r0, 0) * 4 + max(g.r1, 0));
+        pred = g.r0 >= 0 ? (g.r1 >= 0 ? avg_weight4_u8(p0, p1, w) : p0) : p1;
+    }
+    {
+        const int pl = (lane >> 4) & 1, ci = (lane >> 2) & 3, cx0 = (ci & 1) * 4, cyy = (ci >> 1) * 4 + j4;
+        const int r0 = __shfl(g.r0, ci * 16), x0 = __shfl(g.x0, ci * 16), y0 = __shfl(g.y0, ci * 16);
+        const int r1 = __shfl(g.r1, ci * 16), x1 = __shfl(g.x1, ci * 16), y1 = __shfl(g.y1, ci * 16);
+        uint32_t u0 = 0, v0 = 0, u1 = 0, v1 = 0;
+        if (r0 >= 0) mc_chroma_row4(ref_chroma00(k, c.s, r0), k.rs, c.mbx * 8 + cx0, c.mby * 8 + cyy, x0, y0, u0, v0);
+        if (r1 >= 0) mc_chroma_row4(ref_chroma00(k, c.s, k.nref + r1), k.rs, c.mbx * 8 + cx0, c.mby * 8 + cyy, x1, y1, u1, v1);
+        const int w = __shfl(biwv, max(r0, 0) * 4 + max(r1, 0));
+        const uint32_t a = pl ? v0 : u0, b = pl ? v1 : u1;
+        cpred = r0 >= 0 ? (r1 >= 0 ? avg_weight4_u8(a, b, w) : a) : b;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // The slice kernel: one wavefront per stream walks the macroblocks in raster order.
 // ------------------------------------------------------------------------------------------------
 // M: sub-pel neighbourhood margin (2 px up to subme 7, 5 above); ME: --me method (its own instantiation each: the roaming umh / esa code
@@ -1312,9 +1355,12 @@ __device__ __forceinline__ bool mb_probe_pskip(const EncK &k, const MbCtx &c, ui
 // RD: 0 = SATD decisions (subme <= 5); 1 = RD mode decision with CAVLC bit counts (rd.cuh); 2 = with CABAC context states and sizes (cabac_rd.cuh);
 // 3 = 2 + the trellis quantiser in the final encode (trellis.cuh) — an instantiation of its own: the search's registers would cost the others spills;
 // 4 = 3 + the search in the intra analysis' block encodes and in every RD candidate (x264 --trellis 2)
-template <int M, int ME, bool PS, int RD = 0>
+// BS: B slice (PS is set as well: an inter slice) — RD instantiations with CABAC only; its own analysis and candidate order (k_mb_b.inc)
+template <int M, int ME, bool PS, int RD = 0, bool BS = false>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(MB_WAVES_PER_EU, 4))) void k_mb_slice(EncK k)
 {
+    static_assert(!BS || (PS && RD >= 2), "B slices: RD sessions with CABAC");
+    __shared__ uint32_t b_visited[BS ? 128 : 1];          // x264_me_refine_bidir: vector quadruples already costed
     __shared__ __attribute__((aligned(16))) MbLds<M> L;
     const int lane = threadIdx.x, s = blockIdx.x;
     // x264 slice threads: blockIdx.y = slice of the picture, macroblock rows [row0, row1) (k.slices == 1: the whole picture)
@@ -1350,6 +1396,13 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(MB_WAVES_PER
     if constexpr (RD >= 2) { cab_init(cab, lane, pslice, last_qp); cab_modelv = cab_model(lane); }
     Prof pf;
     pf.start();
+    int biwv = 32;                  // B: lane r0 * 4 + r1 = implicit weight of the list-0 sample of that reference pair
+    if constexpr (BS) {
+#pragma unroll
+        for (int r0 = 0; r0 < 5; r0++)
+#pragma unroll
+            for (int r1 = 0; r1 < 4; r1++) biwv = lane == r0 * 4 + r1 ? (int)k.biw[r0][r1] : biwv;
+    }
     int16_t *mv16 = k.mv16_cur + (size_t)s * k.nmb * 2;
     uint8_t *mbtype_cur = k.mbtype_cur + (size_t)s * k.nmb;
 
@@ -1406,15 +1459,21 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(MB_WAVES_PER
             if (lane < 32) { if (t < 9) { const int x = t - 1; if (top && (x >= 0 || left)) v_c = ruv[-(long)k.rs + 2 * x + pl]; } }
             else if (lane < 48) { if (left) v_c = ruv[(long)(t & 7) * k.rs - 2 + ((t >> 3) & 1)]; }
         }
-        if (lane < 12 && pslice) {                     // motion cache grid: x = -1..2, y = -1..1
-            const int gx = (lane & 3) - 1, gy = (lane >> 2) - 1;
+        int mc_dir = 0;
+        if (BS ? (lane < 32 && (lane & 15) < 12) : (lane < 12 && pslice)) {                     // motion cache grid: x = -1..2, y = -1..1 (B: list 1 sixteen lanes up)
+            const int gl = lane & 15, gx = (gl & 3) - 1, gy = (gl >> 2) - 1;
             int nbi = -1, blk = 0;
             if (gy < 0) {
                 if (gx < 0) { if (topleft) { nbi = mbi - k.mbw - 1; blk = 3; } }
                 else if (gx < 2) { if (top) { nbi = mbi - k.mbw; blk = 2 + gx; } }
                 else if (topright) { nbi = mbi - k.mbw + 1; blk = 2; }
             } else if (gx < 0 && left) { nbi = mbi - 1; blk = 1 + 2 * gy; }
-            if (nbi >= 0) { const x264gpu_mb *n = mbs + nbi; mc_type = n->type; mc_ref = n->ref[blk]; mc_vx = n->mv[blk][0]; mc_vy = n->mv[blk][1]; }
+            if (nbi >= 0) {
+                const x264gpu_mb *n = mbs + nbi; mc_type = n->type;
+                if (BS && lane >= 16) { mc_ref = n->ref1[blk]; mc_vx = n->mv1[blk][0]; mc_vy = n->mv1[blk][1]; }
+                else { mc_ref = n->ref[blk]; mc_vx = n->mv[blk][0]; mc_vy = n->mv[blk][1]; }
+                if constexpr (BS) mc_dir = mc_type == X264GPU_MB_B_DIRECT || mc_type == X264GPU_MB_B_SKIP || (mc_type == X264GPU_MB_B_8x8 && ((n->direct8 >> blk) & 1));
+            }
         }
         const uint32_t cz = *(const uint32_t *)(c.fenc + (size_t)zy * k.fs + zx);
         uint32_t csv = 0;
@@ -1424,7 +1483,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(MB_WAVES_PER
         if constexpr (RD >= 2) {
             if (lane < 8) { const bool av = lane < 4 ? left : top; static_assert(sizeof(x264gpu_mb) == 64, "record"); const int dw = (lane & 3) == 0 ? 0 : (lane & 3) == 1 ? 1 : (lane & 3) == 2 ? 6 : 11;
                             if (av) cnbv = ((const uint32_t *)(mbs + (lane < 4 ? mbi - 1 : mbi - k.mbw)))[dw]; }
-            else if (lane < 12) { const bool av = lane < 10 ? left : top; if (av) cnbv = ((const uint32_t *)(k.amvd + ((size_t)s * k.nmb + (lane < 10 ? mbi - 1 : mbi - k.mbw)) * 8))[lane & 1]; }
+            else if (lane < (BS ? 16 : 12)) {           // (B: 16 bytes a macroblock, list 1's |mvd| behind list 0's — lanes 12..15)
+                const bool lf = (lane & 3) < 2, av = lf ? left : top;
+                if (av) cnbv = ((const uint32_t *)(k.amvd + ((size_t)s * k.nmb + (lf ? mbi - 1 : mbi - k.mbw)) * (BS ? 16 : 8)))[(lane & 1) + (lane >= 12 ? 2 : 0)];
+            }
         }
         if constexpr (RD == 1) {
             if (k.rd) {
@@ -1452,10 +1514,11 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(MB_WAVES_PER
         const int type_left = rl(nb_type, 56), type_top = rl(nb_type, 57), type_tl = rl(nb_type, 58), type_tr = rl(nb_type, 59);
         // motion cache: neighbours' references / vectors at 8x8 granularity; this macroblock's blocks start unavailable
         MeState S = {};
-        if (lane < 12) {
+        if (BS ? (lane < 32 && (lane & 15) < 12) : lane < 12) {
             int ref = -2, vx = 0, vy = 0;
             if (mc_type >= 0) { if (mc_type <= 3) ref = -1; else { ref = mc_ref; vx = mc_vx; vy = mc_vy; } }
-            S.cref = ref; S.cmvx = vx; S.cmvy = vy;
+            if (BS && ref < 0) { vx = 0; vy = 0; if (ref != -2) ref = -1; }         // a list the block does not use: reference -1, zero vector
+            S.cref = ref; S.cmvx = vx; S.cmvy = vy; S.cdir = mc_dir;
         }
         *(uint32_t *)(L.src + zy * 16 + zx) = cz;
         if constexpr (RD == 1) { if (lane < 48) rd_ntc[lane >= 24][lane >= 24 ? lane - 24 : lane] = ntcv; }
@@ -1488,7 +1551,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(MB_WAVES_PER
             c.fmin0 = (c.smin0 >> 2) + 6; c.fmax0 = (c.smax0 >> 2) - 6; c.fmin1 = (c.smin1 >> 2) + 6; c.fmax1 = (c.smax1 >> 2) - 6;
             // ---- fast intra decision, skip vector, fast skip ----
             if (early_term && mbi - mb_first > 4) {
-                const int colo = uni((int)k.mbtype_ref0[(size_t)s * k.nmb + mbi]);
+                const int colo = BS ? -1 : uni((int)k.mbtype_ref0[(size_t)s * k.nmb + mbi]);      // the co-located type counts in P slices only
                 const bool near_intra = intra_t(type_left) || intra_t(type_top) || intra_t(type_tl) || intra_t(type_tr) || intra_t(colo);
                 fast_intra = !(near_intra || mbi - mb_first < 3 * intra_count);
                 if (k.sl_stat && !near_intra && lane == 0) {
@@ -1496,6 +1559,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(MB_WAVES_PER
                     if (prior >= need) L.slw[0] = max(L.slw[0], need); else L.slw[1] = min(L.slw[1], need);
                 }
             }
+            if constexpr (!BS) {
             {
                 const int ra = rl(S.cref, 4), rb = rl(S.cref, 1);
                 if (ra == -2 || rb == -2 || (ra == 0 && !(rl(S.cmvx, 4) | rl(S.cmvy, 4))) || (rb == 0 && !(rl(S.cmvx, 1) | rl(S.cmvy, 1)))) pskx = psky = 0;
@@ -1715,9 +1779,11 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(MB_WAVES_PER
             }
             lds_sync();
             pf.mark(PH_ME_GLUE);
+            }      // !BS
         }
         // ---- intra analysis (P slices: against the inter cost; chroma-ME decides the chroma mode first and carries its cost) ----
-        if (!pskip) {
+        if constexpr (BS) { /* B slices: after the inter RD decision (k_mb_b.inc) */ }
+        else if (!pskip) {
             const int i_satd_inter = pslice ? i_cost : MB_COST_MAX;
             i_inter_satd = i_satd_inter;
             // the chroma mode depends on the neighbours only: decided here for every macroblock that is analysed (x264 does it here under chroma-ME,
@@ -1770,8 +1836,30 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(MB_WAVES_PER
         }
         int rec_type = mb_type, chroma_l2off = 256;
         if constexpr (RD) { if (k.psy) chroma_l2off = c_chroma_lambda2_offset[min(max(c.qp - c.qpc + 12, 0), 36)]; }
+        // B slices: the direct prediction, the candidate being coded (ecfg; euse: two bits per 8x8 block, 0 list 0 / 1 list 1 / 2 both / 3 direct), the
+        // SATD and RD costs of x264_mb_analysis_t's B fields, the per-block / per-half list decisions
+        BCfg dcfg = { -1, 0, 0, -1, 0, 0 }, ecfg = { -1, 0, 0, -1, 0, 0 };
+        unsigned euse = 0;
+        int dref0 = -1, dref1 = -1, bskip_cost = MB_COST_MAX, cost16direct = MB_COST_MAX, cost8d_0 = 0, cost8d_1 = 0, cost8d_2 = 0, cost8d_3 = 0, cost16bi = MB_COST_MAX;
+        int cost8x8bi = MB_COST_MAX, cost16x8bi = MB_COST_MAX, cost8x16bi = MB_COST_MAX;
+        int rd_dir = MB_COST_MAX, rd_l0 = MB_COST_MAX, rd_l1 = MB_COST_MAX, rd_bi = MB_COST_MAX, rd_8x8 = MB_COST_MAX, rd_16x8 = MB_COST_MAX, rd_8x16 = MB_COST_MAX;
+        int sub8_0 = 0, sub8_1 = 0, sub8_2 = 0, sub8_3 = 0, p16x8_0 = 0, p16x8_1 = 0, p8x16_0 = 0, p8x16_1 = 0;
+        int b_type = X264GPU_MB_B_SKIP, b_part = D_16x16, b_use16 = 0;
+        uint32_t b_cenc = 0;             // this lane's chroma source row (lanes 0..31: plane (lane >> 4) & 1, 4x4 block (lane >> 2) & 3, row lane & 3)
+        WinTags wt;
+        wt.ref0 = wt.ref1 = wt.ref2 = -1; wt.x00 = wt.x01 = wt.x02 = wt.y00 = wt.y01 = wt.y02 = 0;
+        if constexpr (BS) {
+            rd_run = true; commit = false;
+            const int ci_ = (lane >> 2) & 3;
+            const uint2 fe = *(const uint2 *)(L.csrc + ((ci_ >> 1) * 4 + j4) * 16 + 2 * (ci_ & 1) * 4);
+            b_cenc = nv12_pick(fe.x, fe.y, (lane >> 4) & 1);
+        }
         for (;;) {
-        if constexpr (RD) {
+        if constexpr (BS) {
+            if (rd_run && !commit) {
+#include "k_mb_b.inc"
+            }
+        } else if constexpr (RD) {
             if (rd_run && !commit) {
                 // next candidate in x264's order: P16x16, 16x8, 8x16, 8x8 (x264_mb_analyse_p_rd), the other transform size of the winner
                 // (x264_mb_analyse_transform_rd), I16x16, I4x4, I8x8 (x264_intra_rd); then the final pass
@@ -1832,25 +1920,39 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(MB_WAVES_PER
         if (e_type >= X264GPU_MB_P_L0) {
             // this lane's 8x8 block's motion (Z layout: lane >> 4)
             const int b8 = lane >> 4;
-            int lmx, lmy, lref;
-            const bool eskip = pskip || e_type == X264GPU_MB_P_SKIP;      // probed, or found by the RD test of the 16x16 result at the skip vector: no residual
+            int lmx = 0, lmy = 0, lref = 0;
+            const bool eskip = BS ? e_type == X264GPU_MB_B_SKIP : (pskip || e_type == X264GPU_MB_P_SKIP);      // probed, or found by the RD test of the 16x16 result at the skip vector: no residual
+            const int pl = (lane >> 4) & 1, ci = (lane >> 2) & 3, cx0 = (ci & 1) * 4, cyy = (ci >> 1) * 4 + j4;
+            uint32_t pred, cpred;
+            int mv0x = 0, mv0y = 0, ref0 = 0;
+            if constexpr (BS) {
+                b_predict(k, c, ecfg, biwv, pred, cpred);
+                if (commit && (lane & 15) == 0) {      // one lane per 8x8 block writes that block's motion in both lists
+                    recd.ref[b8] = (int8_t)ecfg.r0; recd.mv[b8][0] = (int16_t)ecfg.x0; recd.mv[b8][1] = (int16_t)ecfg.y0;
+                    recd.ref1[b8] = (int8_t)ecfg.r1; recd.mv1[b8][0] = (int16_t)ecfg.x1; recd.mv1[b8][1] = (int16_t)ecfg.y1;
+                }
+                if (commit && lane == 0) {
+                    recd.partition = (uint8_t)e_part;
+                    recd.direct8 = (uint8_t)(((euse & 3) == 3 ? 1 : 0) | (((euse >> 2) & 3) == 3 ? 2 : 0) | (((euse >> 4) & 3) == 3 ? 4 : 0) | (((euse >> 6) & 3) == 3 ? 8 : 0));
+                }
+            } else {
             if (eskip) { lmx = clampi(pskx, c.mvmin0, c.mvmax0); lmy = clampi(psky, c.mvmin1, c.mvmax1); lref = 0; }
             else {
                 const int slot = e_part == D_16x16 ? ME_16 : e_part == D_16x8 ? ME_16x8 + (b8 >> 1) : e_part == D_8x16 ? ME_8x16 + (b8 & 1) : ME_8 + b8;
                 lmx = __shfl(S.mvx, slot); lmy = __shfl(S.mvy, slot); lref = __shfl(S.ref, slot);      // slot varies with the lane (its 8x8 block)
             }
-            const uint32_t pred = mc_luma_row4(ref_plane00(k, s, lref), k.plane_bytes, k.rs, c.px + zx, c.py + zy, lmx, lmy);
+            pred = mc_luma_row4(ref_plane00(k, s, lref), k.plane_bytes, k.rs, c.px + zx, c.py + zy, lmx, lmy);
             // chroma prediction: chroma 4x4 block ci <-> luma 8x8 ci
-            const int pl = (lane >> 4) & 1, ci = (lane >> 2) & 3, cx0 = (ci & 1) * 4, cyy = (ci >> 1) * 4 + j4;
             const int cmvx = __shfl(lmx, ci * 16), cmvy = __shfl(lmy, ci * 16), cref = __shfl(lref, ci * 16);
             uint32_t pu, pv;
             mc_chroma_row4(ref_chroma00(k, s, cref), k.rs, mbx * 8 + cx0, mby * 8 + cyy, cmvx, cmvy, pu, pv);
-            const uint32_t cpred = pl ? pv : pu;
-            const int mv0x = eskip ? pskx : __builtin_amdgcn_readlane(lmx, 0), mv0y = eskip ? psky : __builtin_amdgcn_readlane(lmy, 0), ref0 = __builtin_amdgcn_readlane(lref, 0);
+            cpred = pl ? pv : pu;
+            mv0x = eskip ? pskx : __builtin_amdgcn_readlane(lmx, 0); mv0y = eskip ? psky : __builtin_amdgcn_readlane(lmy, 0); ref0 = __builtin_amdgcn_readlane(lref, 0);
             if (commit && (lane & 15) == 0) {      // one lane per 8x8 block writes that block's motion
                 recd.mv[lane >> 4][0] = (int16_t)(eskip ? pskx : lmx); recd.mv[lane >> 4][1] = (int16_t)(eskip ? psky : lmy); recd.ref[lane >> 4] = (int8_t)lref;
             }
             if (commit && lane == 0) recd.partition = (uint8_t)(eskip ? 0 : e_part);
+            }
             if (eskip) {
                 *(uint32_t *)(rec + (size_t)zy * k.rs + zx) = pred;
                 mb_store_chroma(ruv, k.rs, lane, cpred);
@@ -1990,8 +2092,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(MB_WAVES_PER
                 rd_t8cur = t8 && cbp_luma;
                 if (commit && lane == 0) recd.transform8x8 = (uint8_t)(t8 && cbp_luma);
                 // P_L0 16x16, reference 0, the skip vector, nothing coded: P_SKIP
-                if (e_type == X264GPU_MB_P_L0 && e_part == D_16x16 && !(cbp_luma | cbp_chroma) && ref0 == 0 && mv0x == pskx && mv0y == psky)
+                if (!BS && e_type == X264GPU_MB_P_L0 && e_part == D_16x16 && !(cbp_luma | cbp_chroma) && ref0 == 0 && mv0x == pskx && mv0y == psky)
                     rec_type = X264GPU_MB_P_SKIP;
+                // B_DIRECT with nothing coded: B_SKIP
+                if (BS && e_type == X264GPU_MB_B_DIRECT && !(cbp_luma | cbp_chroma)) rec_type = X264GPU_MB_B_SKIP;
             }
             pf.mark(PH_ENC_INTER);
         } else {
@@ -2125,6 +2229,12 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(MB_WAVES_PER
             } } rd_mark{ pf };
             CabIn ci;
             ci.pslice = pslice; ci.left = left; ci.top = top; ci.nref = c.nref; ci.t8mode = k.dct8x8;
+            ci.bslice = BS; ci.nref1 = k.nref1; ci.buse = euse; ci.b_r0 = ecfg.r0; ci.b_x0 = ecfg.x0; ci.b_y0 = ecfg.y0; ci.b_r1 = ecfg.r1; ci.b_x1 = ecfg.x1; ci.b_y1 = ecfg.y1;
+            ci.lamvd1 = 0; ci.tamvd1 = 0;
+            if constexpr (BS) {
+                ci.lamvd1 = (unsigned long long)rl(cnbv, 12) | ((unsigned long long)rl(cnbv, 13) << 32);
+                ci.tamvd1 = (unsigned long long)rl(cnbv, 14) | ((unsigned long long)rl(cnbv, 15) << 32);
+            }
             ci.type = rec_type; ci.part = e_part; ci.cbp_luma = cbp_luma; ci.cbp_chroma = cbp_chroma; ci.nnz = nnz;
             ci.i16mode = IR.pred16 > PRED16_P ? PRED16_DC : IR.pred16; ci.cmode = predc > PREDC_P ? PREDC_DC : predc;
             ci.qp = c.qp; ci.last_qp = last_qp; ci.last_dqp = last_dqp;
@@ -2144,15 +2254,30 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(MB_WAVES_PER
                     dist += (((abs(e4 - fenc_e4) + abs(e8 - fenc_e8)) >> 1) * k.psy_rd_q8 * c.lambda + 128) >> 8;
                 }
                 dist += (int)(((long long)wave_sum(ssd_c) * chroma_l2off + 128) >> 8);
-                if (rec_type == X264GPU_MB_P_SKIP) cost = dist + ((lambda2 + 128) >> 8);
+                if (rec_type == X264GPU_MB_P_SKIP || rec_type == X264GPU_MB_B_SKIP) cost = dist + ((lambda2 + 128) >> 8);
                 else {
                     Cab tmp = cab;
                     tmp.f8 = 0; tmp.f8v = 0;
                     int dq;
+                    unsigned long long av1;
                     ci.size = true;
-                    cab_mb(tmp, cab_modelv, lane, ci, S, rd_lvs, L.modes4, L.modes8, L.nmodes, c.mbx, c.sy, dq);
+                    cab_mb(tmp, cab_modelv, lane, ci, S, rd_lvs, L.modes4, L.modes8, L.nmodes, c.mbx, c.sy, dq, av1);
                     cost = dist + (int)(((unsigned long long)cab_total(tmp) * (unsigned long long)lambda2 + 32768) >> 16);
                 }
+                if constexpr (BS) {
+                    // x264_mb_analyse_b_rd / _transform_rd / x264_intra_rd: where the candidate's cost goes
+                    if (rd_ph == 1 || rd_ph == 7) rd_dir = cost;
+                    else if (rd_ph == 2 || rd_ph == 8) rd_l0 = cost;
+                    else if (rd_ph == 3 || rd_ph == 9) rd_l1 = cost;
+                    else if (rd_ph == 4 || rd_ph == 10) rd_bi = cost;
+                    else if (rd_ph == 11) rd_8x8 = cost;
+                    else if (rd_ph == 12) rd_16x8 = cost;
+                    else if (rd_ph == 13) rd_8x16 = cost;
+                    else if (rd_ph == 14) { if (rd_best >= cost) { if (rd_best > 0) rd_satd_inter = (int)((long long)rd_satd_inter * cost / rd_best); rd_best = cost; rd_t8 = 1; } }
+                    else if (rd_ph == 15) rd_i16 = cost;
+                    else if (rd_ph == 16) rd_i4 = cost;
+                    else if (rd_ph == 17) rd_i8 = cost;
+                } else
                 if (rd_ph == 0) {
                     rd16 = cost;
                     if (rec_type == X264GPU_MB_P_SKIP) {          // the 16x16 result is the skip vector and nothing would be coded: P_SKIP, analysis over
@@ -2172,10 +2297,12 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(MB_WAVES_PER
             for (int i = lane; i < X264GPU_MB_LEVELS / 2; i += 64) ((uint32_t *)lv)[i] = ((const uint32_t *)rd_lvs)[i];
             if (rdon) {
                 int dq;
+                unsigned long long av1;
                 ci.size = false;
-                const unsigned long long av = cab_mb(cab, cab_modelv, lane, ci, S, rd_lvs, L.modes4, L.modes8, L.nmodes, c.mbx, c.sy, dq);
+                const unsigned long long av = cab_mb(cab, cab_modelv, lane, ci, S, rd_lvs, L.modes4, L.modes8, L.nmodes, c.mbx, c.sy, dq, av1);
                 last_dqp = dq;
-                if (lane < 2) ((uint32_t *)(k.amvd + ((size_t)s * k.nmb + mbi) * 8))[lane] = (uint32_t)(av >> (32 * lane));
+                if (lane < 2) ((uint32_t *)(k.amvd + ((size_t)s * k.nmb + mbi) * (BS ? 16 : 8)))[lane] = (uint32_t)(av >> (32 * lane));
+                if (BS && lane >= 2 && lane < 4) ((uint32_t *)(k.amvd + ((size_t)s * k.nmb + mbi) * 16))[lane] = (uint32_t)(av1 >> (32 * (lane - 2)));
             }
         }
         if constexpr (RD == 1) {

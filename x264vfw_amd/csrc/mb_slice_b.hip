@@ -1,0 +1,11 @@
+// mb_slice_b.hip — the macroblock-loop kernel (k_mb.cuh) instantiated for B slices (--me hex; RD sessions with CABAC, with and without the
+// trellis quantiser in the final encode): a translation unit of its own, like the per-method ones.
+#include "k_mb.cuh"
+
+namespace x264gpu {
+void launch_mb_slice_b_hex(const EncK &k, int streams, hipStream_t st)
+{
+    if (k.trellis) hipLaunchKernelGGL((k_mb_slice<2, 1, true, 3, true>), dim3(streams, 1), dim3(64), 0, st, k);
+    else hipLaunchKernelGGL((k_mb_slice<2, 1, true, 2, true>), dim3(streams, 1), dim3(64), 0, st, k);
+}
+}  // namespace x264gpu
