@@ -1,0 +1,64 @@
+#!/usr/bin/env python3
+"""A session with B pictures through x264_encoder_encode() of the STUB-backed host library: prints one JSON line with the picture types, pts / dts of
+the pictures as they leave, and writes the stream to the given file.  Usage: run_host_b.py OUT W H FRAMES SEED key=value ..."""
+import ctypes as C
+import json
+import os
+import sys
+
+os.environ["X264_HOST_STUB"] = "1"
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.dirname(HERE))
+sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+import host_lib as HL  # noqa: E402
+from synth import synth_frames  # noqa: E402
+
+
+def main():
+    out_path = sys.argv[1]
+    w, h, n, seed = (int(x) for x in sys.argv[2:6])
+    opts = {}
+    for a in sys.argv[6:]:
+        k, _, v = a.partition("=")
+        opts[k] = v if _ else None
+    H = HL.H
+    frames = synth_frames(w, h, n, seed=seed)
+    p = HL.Param()
+    assert H.x264_param_default_preset(C.byref(p), b"medium", None) == 0
+    p.i_width, p.i_height, p.i_csp = w, h, HL.X264_CSP_I420
+    p.i_fps_num, p.i_fps_den, p.i_log_level = 25, 1, -1
+    for k, v in opts.items():
+        assert H.x264_param_parse(C.byref(p), k.encode(), None if v is None else str(v).encode()) == 0, (k, v)
+    p.b_annexb, p.b_repeat_headers = 1, 1
+    h_ = H.x264_encoder_open_157(C.byref(p))
+    assert h_
+    eff = HL.Param()
+    H.x264_encoder_parameters(h_, C.byref(eff))
+    pic, out = HL.Picture(), HL.Picture()
+    assert H.x264_picture_alloc(C.byref(pic), HL.X264_CSP_I420, w, h) == 0
+    nal, nn = C.POINTER(HL.Nal)(), C.c_int()
+    planes = [(w * h, 0), (w * h // 4, w * h), (w * h // 4, w * h * 5 // 4)]
+    stream, recs = b"", []
+
+    def take(size):
+        nonlocal stream
+        if size > 0:
+            stream += C.string_at(nal[0].p_payload, size)
+            recs.append((out.i_type, out.i_pts, out.i_dts, out.b_keyframe, size))
+    for i, f in enumerate(frames):
+        for pl, (sz, off) in enumerate(planes):
+            C.memmove(pic.img.plane[pl], f[off:off + sz].ctypes.data, sz)
+        pic.i_pts = i
+        size = H.x264_encoder_encode(h_, C.byref(nal), C.byref(nn), C.byref(pic), C.byref(out))
+        assert size >= 0
+        take(size)
+    while H.x264_encoder_delayed_frames(h_):
+        size = H.x264_encoder_encode(h_, C.byref(nal), C.byref(nn), None, C.byref(out))
+        assert size > 0
+        take(size)
+    H.x264_encoder_close(h_)
+    open(out_path, "wb").write(stream)
+    print(json.dumps({"recs": recs, "bframes": eff.i_bframe, "pyramid": eff.i_bframe_pyramid, "badapt": eff.i_bframe_adaptive, "weightb": eff.analyse.b_weighted_bipred}))
+
+
+main()

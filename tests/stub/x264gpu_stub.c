@@ -85,7 +85,20 @@ int x264gpu_encode_frames(x264gpu_encoder *g, const uint8_t *i420, int slice_typ
     }
     return X264GPU_OK;
 }
+int x264o_encoder_encode_pic(x264o_encoder *e, const uint8_t *i420, const x264gpu_pic *pic, x264gpu_mb *mbs, int16_t *levels);
+int x264gpu_encode_pictures(x264gpu_encoder *g, const uint8_t *i420, const x264gpu_pic *pics, x264gpu_mb *mb, int16_t *lv, void *st)
+{
+    if (g->dev != t_dev) return fail("encoder used from a thread bound to another device");
+    const size_t fsz = (size_t)g->cfg.width * g->cfg.height * 3 / 2;
+    g_calls[g->dev]++;
+    for (int s = 0; s < g->cfg.streams; s++) {
+        x264o_encoder_set_mb_qp_offsets(g->e[s], g->off ? g->off + (size_t)s * g->nmb : NULL);
+        if (x264o_encoder_encode_pic(g->e[s], i420 + s * fsz, &pics[s], mb + (size_t)s * g->nmb, lv + (size_t)s * g->nmb * X264GPU_MB_LEVELS)) return fail("picture control rejected");
+    }
+    return X264GPU_OK;
+}
 int x264gpu_encoder_get_recon(x264gpu_encoder *g, int s, uint8_t *out, void *st) { x264o_encoder_get_recon(g->e[s], out); return X264GPU_OK; }
+int x264gpu_encoder_get_recon_slot(x264gpu_encoder *g, int s, int slot, uint8_t *out, void *st) { return fail("recon by slot: not in the stub"); }
 
 struct x264gpu_lookahead { x264o_lookahead *la; int w, h, nb; };
 int x264gpu_lookahead_create(x264gpu_lookahead **out, int w, int h, int streams, int me_range, int subme)

@@ -48,3 +48,55 @@ def test_without_pyramid_every_b_is_disposable():
 def test_schedule_is_x264s_coding_order():
     assert bgop.schedule("IBBBP") == [(0, 0), (4, 2), (2, 3), (1, 4), (3, 4)]
     assert bgop.schedule("IBBPBP") == [(0, 0), (3, 2), (1, 3), (2, 4), (5, 2), (4, 4)]
+
+
+def _host_b_session(tmp_path, n, opts, w=176, h=144, seed=3):
+    """x264_encoder_encode() of the product's host library over the stand-in device (tests/stub: the oracle behind the B3 ABI), in a child process"""
+    import json
+    import os
+    import subprocess
+    import sys
+    out = str(tmp_path / "b.h264")
+    here = os.path.dirname(os.path.abspath(__file__))
+    r = subprocess.run([sys.executable, os.path.join(here, "stub", "run_host_b.py"), out, str(w), str(h), str(n), str(seed)] + opts, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    return json.loads(r.stdout.strip().splitlines()[-1]), open(out, "rb").read()
+
+
+def test_host_session_with_b_pictures(tmp_path):
+    """preset medium at constant quantiser through x264_encoder_encode: B / BREF pictures leave in coding order with x264's types and a monotone
+    dts (consumers: output/matroska.c:199-202, codec.c:1822-1826), and the stream decodes to every source picture"""
+    import subprocess
+    subprocess.check_call(["make", "-s", "-C", __file__.rsplit("/", 1)[0] + "/stub"])
+    n, w, h = 14, 176, 144
+    info, stream = _host_b_session(tmp_path, n, ["qp=23", "keyint=30", "scenecut=0"])
+    assert (info["bframes"], info["pyramid"], info["badapt"], info["weightb"]) == (3, 2, 0, 1)      # b-adapt 1 is reported back as what runs: 0
+    recs = info["recs"]
+    assert len(recs) == n
+    TYPE = {1: "I", 3: "P", 4: "R", 5: "B"}
+    assert "".join(TYPE[r[0]] for r in recs) == "IPRBBPRBBPRBBP"
+    assert [r[1] for r in recs] == [0, 4, 2, 1, 3, 8, 6, 5, 7, 12, 10, 9, 11, 13]
+    dts = [r[2] for r in recs]
+    assert dts == sorted(dts) and len(set(dts)) == n and all(d <= p for _, p, d, _, _ in recs), "dts must be monotone and never after pts"
+    assert dts[:3] == [-2, -1, 0]
+    dec = O.h264_decode(stream, n, w, h)
+    pocs = O.h264_last_pocs()
+    assert [p // 2 for p in pocs] == [r[1] for r in recs]
+    frames = synth_frames(w, h, n, seed=3)
+    from synth import psnr
+    for d, p in zip(dec, pocs):
+        assert psnr(d[:w * h], frames[p // 2][:w * h]) > 34.0
+
+
+def test_host_session_crf_with_b_pictures_and_keyframes(tmp_path):
+    """CRF + a short keyint: runs cut short in front of keyframes, the picture before an IDR is never B, every picture decodes"""
+    n, w, h = 23, 128, 96
+    info, stream = _host_b_session(tmp_path, n, ["crf=24", "keyint=9", "min-keyint=9", "bframes=2", "scenecut=0"], w, h, seed=8)
+    recs = info["recs"]
+    assert len(recs) == n and info["bframes"] == 2
+    by_pts = sorted(recs, key=lambda r: r[1])
+    for a, b in zip(by_pts, by_pts[1:]):
+        assert not (b[0] == 1 and a[0] in (4, 5)), "a B picture in front of an IDR picture"
+    assert [r[0] for r in by_pts][::9] == [1, 1, 1]
+    dec = O.h264_decode(stream, n, w, h)
+    assert len(dec) == n

@@ -111,6 +111,20 @@ struct x264_t {
     std::vector<x264gpu_mb> h_mb2;       // second download buffers (the pool reads one pair while the next position lands in the other)
     std::vector<int16_t> h_lv2;
     int dl = 0;                          // download buffer in use for the NEXT position
+    // ---- sessions with B pictures (threads 1; x264 --bframes N --b-pyramid): pictures wait in display order until the mini-GOP they belong to
+    //      is closed by a P / I picture (x264_slicetype_decide with --b-adapt 0: N B pictures between non-B pictures, fewer in front of a keyframe
+    //      or at the end), then leave in coding order: the closing picture, the B-reference of the run, the other B pictures.  The DPB, the
+    //      reference lists and the slice header's share of them come from host/dpb.hpp ----
+    int bframes = 0, bpyramid = 0, log2_max_poc_lsb = 0;
+    Dpb dpb;
+    struct BEntry { int64_t pts; int frame; int slot; int forced; int scenecut; int32_t costs[4]; x264_image_t img; };      // forced: 0 auto, 1 I, 2 IDR
+    struct BPlanned { BEntry e; int type; };                                                                            // type: PIC_*
+    std::deque<BEntry> bq;
+    std::deque<BPlanned> bcoding;
+    std::vector<int64_t> all_pts;        // every pts seen, in display order (the dts delay line)
+    long coded_count = 0;
+    double slot_qp_rc[8] = { 0 };        // CRF: the quantiser (float) every kept picture was given, by DPB slot (x264 f_qp_avg_rc)
+    int slot_ptype[8] = { 0 };           // ... and its picture type
 };
 
 static void xlog(const x264_param_t *p, int level, const char *fmt, ...)
@@ -157,12 +171,14 @@ static SpsParams make_sps(const x264_t *h)
     s.num_units_in_tick = p.i_timebase_num; s.time_scale = p.i_timebase_den * 2;
     s.constraint_set0 = h->profile_idc == 66; s.constraint_set1 = h->profile_idc <= 77;
     s.mv_range = h->param.analyse.i_mv_range;
+    if (h->bframes) { s.num_ref_frames = h->dpb.max_dpb; s.log2_max_poc_lsb = h->log2_max_poc_lsb; s.num_reorder_frames = h->dpb.num_reorder; }
     return s;
 }
 static PpsParams make_pps(const x264_t *h)
 {
     PpsParams pp = { h->param.i_sps_id, h->param.i_sps_id, h->param.b_cabac, h->param.i_frame_reference, h->pic_init_qp, h->param.analyse.i_chroma_qp_offset,
                      h->param.analyse.b_transform_8x8 };
+    if (h->bframes && h->param.analyse.b_weighted_bipred) pp.weighted_bipred_idc = 2;
     return pp;
 }
 // appends SPS, PPS (and optionally the version SEI) to h->out, recording NAL offsets and types
@@ -208,14 +224,15 @@ x264_t *x264_encoder_open(x264_param_t *param)
     if (!p.i_timebase_num || !p.i_timebase_den) { p.i_timebase_num = p.i_fps_den; p.i_timebase_den = p.i_fps_num; }
 
     // ---- effective parameters: what this round's pipeline implements (reported back via encoder_parameters) ----
-    if (p.i_bframe) { xlog(&p, X264_LOG_WARNING, "B-frames are not implemented in the MI355X path yet: bframes 0\n"); p.i_bframe = 0; }
+    // B pictures: on the device in RD sessions with CABAC (subme >= 6), --me hex, one slice per picture, one GOP in flight (settled below, once those are known)
+    p.i_bframe = clampi(p.i_bframe, 0, 16);
     if (p.i_frame_reference > 5) { xlog(&p, X264_LOG_INFO, "ref %d -> 5 (DPB of the MI355X path holds up to 5 references)\n", p.i_frame_reference); p.i_frame_reference = 5; }
     if (p.i_frame_reference < 1) p.i_frame_reference = 1;
     p.analyse.b_mixed_references = p.analyse.b_mixed_references && p.i_frame_reference > 1;      // x264 validate_parameters
     p.b_cabac = p.b_cabac != 0;
     if (p.b_cabac && p.i_cabac_init_idc != 0) { xlog(&p, X264_LOG_WARNING, "cabac-idc %d: only the context tables of cabac_init_idc 0 (x264's default) are in the MI355X path: cabac-idc 0\n", p.i_cabac_init_idc); p.i_cabac_init_idc = 0; }
     if (p.analyse.i_weighted_pred > X264_WEIGHTP_NONE) xlog(&p, X264_LOG_WARNING, "weightp %d is not implemented in the MI355X path yet: weightp 0\n", p.analyse.i_weighted_pred);
-    p.analyse.i_weighted_pred = X264_WEIGHTP_NONE; p.analyse.b_weighted_bipred = 0;
+    p.analyse.i_weighted_pred = X264_WEIGHTP_NONE; p.analyse.b_weighted_bipred = p.analyse.b_weighted_bipred != 0;
     p.analyse.b_transform_8x8 = p.analyse.b_transform_8x8 != 0;
     p.analyse.inter &= X264_ANALYSE_I4x4 | X264_ANALYSE_I8x8 | X264_ANALYSE_PSUB16x16; p.analyse.intra &= X264_ANALYSE_I4x4 | X264_ANALYSE_I8x8;
     if (!p.analyse.b_transform_8x8) { p.analyse.inter &= ~X264_ANALYSE_I8x8; p.analyse.intra &= ~X264_ANALYSE_I8x8; }   // as x264 validate_parameters
@@ -274,6 +291,20 @@ x264_t *x264_encoder_open(x264_param_t *param)
         h->slices = p.i_slice_count; h->slices_plain = h->slices > 1;
     } else if (!p.b_sliced_threads) p.i_slice_count = 0;
     p.i_threads = clampi(p.i_threads, 1, 256);                 // --threads G: GOPs coded in lock-step (1 = no delay)
+    if (p.i_bframe) {
+        const char *why = !p.b_cabac ? "CABAC" : p.analyse.i_subpel_refine < 6 ? "subme >= 6" : p.analyse.i_me_method != X264_ME_HEX ? "me hex" : h->slices > 1 ? "one slice per picture" :
+                          p.i_threads > 1 ? "threads 1" : p.i_keyint_max < 2 ? "keyint > 1" : p.rc.i_rc_method == X264_RC_ABR ? "constant-quantiser or CRF rate control" : nullptr;
+        if (why) { xlog(&p, X264_LOG_WARNING, "B-frames need %s in the MI355X path: bframes 0\n", why); p.i_bframe = 0; }
+    }
+    if (p.i_bframe) {
+        if (p.i_bframe_adaptive) { xlog(&p, X264_LOG_WARNING, "b-adapt %d needs bidirectional lookahead costs, which are not implemented yet: b-adapt 0 (%d B pictures between references)\n", p.i_bframe_adaptive, p.i_bframe); p.i_bframe_adaptive = 0; }
+        if (p.i_bframe_pyramid == 1) { xlog(&p, X264_LOG_INFO, "b-pyramid strict -> normal\n"); p.i_bframe_pyramid = 2; }
+        if (p.i_bframe < 2) p.i_bframe_pyramid = 0;
+        if (p.b_open_gop) { xlog(&p, X264_LOG_WARNING, "open-gop is not implemented in the MI355X path: closed GOPs\n"); p.b_open_gop = 0; }
+        if (p.analyse.i_direct_mv_pred != 1) { xlog(&p, X264_LOG_INFO, "direct %d -> spatial (the one direct mode in the MI355X path)\n", p.analyse.i_direct_mv_pred); p.analyse.i_direct_mv_pred = 1; }
+        if (p.rc.b_mb_tree) { xlog(&p, X264_LOG_WARNING, "mbtree through B pictures is not implemented yet: mbtree 0\n"); p.rc.b_mb_tree = 0; }
+    } else { p.i_bframe_pyramid = 0; p.analyse.b_weighted_bipred = 0; }
+    h->bframes = p.i_bframe; h->bpyramid = p.i_bframe_pyramid ? 1 : 0;
     if (p.i_keyint_max <= 0) p.i_keyint_max = 1;
     h->keyint = p.i_keyint_max;
     // rate control: constant QP (X264_RC_CQP, codec.c:1498-1502) and single-pass CRF without AQ / mbtree (codec.c:1504-1507, the
@@ -308,6 +339,15 @@ x264_t *x264_encoder_open(x264_param_t *param)
     p.i_level_idc = h->level_idc;
     h->log2_max_frame_num = 4;
     while ((1 << h->log2_max_frame_num) <= (h->keyint < 65536 ? h->keyint : 65535) && h->log2_max_frame_num < 16) h->log2_max_frame_num++;
+    if (h->bframes) {
+        // x264 sps init: pic_order_cnt_type 0 with room for the largest POC distance of a mini-GOP; the DPB model owns frame_num / lists / marking
+        h->dpb.configure(p.i_frame_reference, h->bframes, h->bpyramid, h->log2_max_frame_num);
+        const int max_delta_poc = (h->bframes + 2) * (h->bpyramid + 1) * 2;
+        h->log2_max_poc_lsb = 4;
+        while ((1 << h->log2_max_poc_lsb) <= max_delta_poc * 2) h->log2_max_poc_lsb++;
+        h->level_idc = p.i_level_idc > 0 ? p.i_level_idc : pick_level(&p, h->nmb, h->dpb.max_dpb);
+        p.i_level_idc = h->level_idc;
+    }
 
     x264gpu_config cfg = {};
     // GOP-parallel factor: bounded by the device ring (keyint x G pictures) staying under 24 GB
@@ -344,6 +384,7 @@ x264_t *x264_encoder_open(x264_param_t *param)
     }
     p.analyse.i_mv_range = clampi(p.analyse.i_mv_range, 32, 512);
     cfg.mv_range = p.analyse.i_mv_range;
+    if (h->bframes) { cfg.dpb = h->dpb.max_dpb; cfg.weightb = p.analyse.b_weighted_bipred; }
     size_t insz = (size_t)p.i_width * p.i_height * 3 / 2;
     (void)x264gpu_get_device(&h->device);
     bool ok_setup = x264gpu_malloc((void **)&h->d_in, insz) == X264GPU_OK;
@@ -392,6 +433,7 @@ x264_t *x264_encoder_open(x264_param_t *param)
     // the entropy coding of this one (one more picture of delay); X264GPU_HOST_PIPELINE=0 keeps the two stages in one call
     { const char *pe = getenv("X264GPU_HOST_PIPELINE"); h->pipeline = h->G == 1 && h->L > 0 && h->crf && !(pe && pe[0] == '0'); }
     h->Q = h->L + 1 + (h->pipeline ? 1 : 0);
+    if (h->bframes) { h->pipeline = false; h->Q = 2 * (h->bframes + 1) + 2; }      // display-order queue + the mini-GOP being coded
     h->aq_strength_q8 = cfg.aq_mode ? cfg.aq_strength_q8 : 0;
     h->tree_strength_q8 = (int)(1280.0 * (1.0 - p.rc.f_qcompress) + 0.5);     // 5 * (1 - qcomp), Q8
     h->q_raw.assign((size_t)h->Q, nullptr); h->q_info.assign((size_t)h->Q, nullptr); h->q_aq.assign((size_t)h->Q, nullptr);
@@ -843,12 +885,139 @@ static int encode_queued(x264_t *h, x264_nal_t **pp_nal, int *pi_nal, x264_pictu
     return (int)h->out.size();
 }
 
+
+// ---- sessions with B pictures ---------------------------------------------------------------------------------------------------
+// x264_slicetype_decide with --b-adapt 0 over the display-order queue: the pictures up to the next non-B picture become one mini-GOP.
+// A forced I / IDR picture closes the run in front of it (the picture before an IDR becomes P: closed GOPs); otherwise the run is
+// `bframes` long, or what is left when the input ends (the last picture is never B).  Returns false while more input is needed.
+static bool bmode_decide(x264_t *h, bool flushing)
+{
+    if (!h->bcoding.empty() || h->bq.empty()) return !h->bcoding.empty();
+    const int n = (int)h->bq.size();
+    if (!flushing && n <= h->bframes) return false;          // the lookahead x264 keeps in front of the slice-type decision: a whole run and its closing picture
+    int j = -1;                                       // index of the closing picture
+    if (h->bq[0].forced) j = 0;
+    else {
+        for (int i = 0; i < n && i <= h->bframes; i++) {
+            if (h->bq[(size_t)i].forced == 2) { j = i > 0 ? i - 1 : 0; break; }        // IDR next: the picture before it closes the run as P
+            if (h->bq[(size_t)i].forced == 1) { j = i; break; }                        // I picture: B pictures in front of it may predict from it
+            if (i == h->bframes) { j = i; break; }
+        }
+        if (j < 0) { if (!flushing) return false; j = n - 1; }                      // end of input: the last picture closes the run
+    }
+    const int closing = h->bq[(size_t)j].forced == 2 ? PIC_IDR : h->bq[(size_t)j].forced == 1 ? PIC_I : PIC_P;
+    h->bcoding.push_back({ h->bq[(size_t)j], closing });
+    const int bref = h->bpyramid && j > 1 ? (j - 1) / 2 : -1;
+    if (bref >= 0) h->bcoding.push_back({ h->bq[(size_t)bref], PIC_BREF });
+    for (int i = 0; i < j; i++) if (i != bref) h->bcoding.push_back({ h->bq[(size_t)i], PIC_B });
+    h->bq.erase(h->bq.begin(), h->bq.begin() + j + 1);
+    return true;
+}
+
+// rate control of one picture of a B session: constant quantisers (x264 rc->qp_constant[] with --ipratio / --pbratio) or CRF (rate_estimate_qscale:
+// I / P as without B pictures; B pictures take the distance-weighted average of their nearest references' quantisers plus the pb offset)
+static int bmode_qp(x264_t *h, const x264_t::BPlanned &pl, const DpbPlan &plan, double *qp_float)
+{
+    const x264_param_t &p = h->param;
+    const double pb_offset = 6.0 * log2(fabs(p.rc.f_pb_factor) > 0 ? fabs(p.rc.f_pb_factor) : 1.0);
+    const bool is_i = pl.type == PIC_IDR || pl.type == PIC_I, is_b = pl.type == PIC_B || pl.type == PIC_BREF;
+    if (!h->crf) {
+        const int qb = clampi((int)(h->qp_p + pb_offset + 0.5), 0, 51);
+        const int q = is_i ? h->qp_i : !is_b ? h->qp_p : pl.type == PIC_BREF ? (qb + h->qp_p) / 2 : qb;
+        *qp_float = q;
+        return q;
+    }
+    if (!is_b) {
+        const int q = rc_pick_qp(h, is_i, pl.e.costs, h->rc_frames);
+        *qp_float = h->rc.qpa_last;
+        return q;
+    }
+    const int s0 = plan.pic.slot[0][0], s1 = plan.pic.slot[1][0];
+    const bool i0 = h->slot_ptype[s0] == PIC_IDR || h->slot_ptype[s0] == PIC_I, i1 = h->slot_ptype[s1] == PIC_IDR || h->slot_ptype[s1] == PIC_I;
+    const int dt0 = abs(plan.pic.poc - plan.list_poc[0][0]), dt1 = abs(plan.pic.poc - plan.list_poc[1][0]);
+    double q0 = h->slot_qp_rc[s0], q1 = h->slot_qp_rc[s1], q;
+    if (h->slot_ptype[s0] == PIC_BREF) q0 -= pb_offset / 2;
+    if (h->slot_ptype[s1] == PIC_BREF) q1 -= pb_offset / 2;
+    if (i0 && i1) q = (q0 + q1) / 2 + h->rc.ip_offset;
+    else if (i0) q = q1;
+    else if (i1) q = q0;
+    else q = (q0 * dt1 + q1 * dt0) / (dt0 + dt1);
+    q += pl.type == PIC_BREF ? pb_offset / 2 : pb_offset;
+    *qp_float = q;
+    return clampi((int)(q + 0.5), p.rc.i_qp_min, p.rc.i_qp_max);
+}
+
+// codes the next picture in coding order; returns the bytes of its NAL units, 0 when the queue still waits for input
+static int encode_bmode(x264_t *h, x264_nal_t **pp_nal, int *pi_nal, x264_picture_t *pic_out, bool flushing)
+{
+    const x264_param_t &p = h->param;
+    if (!bmode_decide(h, flushing)) return 0;
+    const x264_t::BPlanned pl = h->bcoding.front();
+    h->bcoding.pop_front();
+    // the disposable pictures coded right behind this one (x264_reference_hierarchy_reset looks at them)
+    int fc[16], ff[16], nf = 0;
+    for (size_t i = 0; i < h->bcoding.size() && nf < 16 && h->bcoding[i].type == PIC_B; i++) { fc[nf] = (int)(h->coded_count + 1 + (long)i); ff[nf] = h->bcoding[i].e.frame; nf++; }
+    const DpbPlan plan = h->dpb.plan(pl.type, pl.e.frame, nf, fc, ff);
+    x264gpu_pic pic = plan.pic;
+    double qpf = 0;
+    pic.qp = bmode_qp(h, pl, plan, &qpf);
+    h->rc_frames++;
+    if (x264gpu_encode_pictures(h->gpu, h->q_raw[(size_t)pl.e.slot], &pic, h->d_mb, h->d_lv, nullptr) != X264GPU_OK ||
+        x264gpu_memcpy_d2h(h->h_mb.data(), h->d_mb, h->h_mb.size() * sizeof(x264gpu_mb), nullptr) != X264GPU_OK ||
+        x264gpu_memcpy_d2h(h->h_lv.data(), h->d_lv, h->h_lv.size() * sizeof(int16_t), nullptr) != X264GPU_OK) {
+        xlog(&p, X264_LOG_ERROR, "x264_encoder_encode: GPU hot path failed: %s\n", x264gpu_last_error());
+        h->failed = true;
+        return -1;
+    }
+    if (plan.nal_ref_idc) { h->slot_qp_rc[pic.dst] = qpf; h->slot_ptype[pic.dst] = pl.type; }
+    h->last_scenecut = pl.e.scenecut; h->last_qp = pic.qp;
+    memcpy(h->last_costs, pl.e.costs, sizeof(pl.e.costs));
+    const bool idr = pl.type == PIC_IDR;
+    h->out.clear(); h->nal_off.clear();
+    std::vector<int> types;
+    if (p.b_aud) { h->nal_off.push_back(h->out.size()); types.push_back(9); write_aud(h->out, pl.type <= PIC_I, p.b_annexb != 0); }
+    if (idr && p.b_repeat_headers) { emit_sets(h, types, !h->sei_sent); h->sei_sent = 1; }
+    SliceParams sp = {};
+    sp.mbw = h->mbw; sp.mbh = h->mbh; sp.qp = pic.qp; sp.pic_init_qp = h->pic_init_qp; sp.log2_max_frame_num = h->log2_max_frame_num; sp.log2_max_poc_lsb = h->log2_max_poc_lsb;
+    sp.idr_pic_id = h->idr_pic_id; sp.pps_id = p.i_sps_id; sp.num_ref_default = p.i_frame_reference; sp.num_ref1_default = 1;
+    sp.disable_deblock_idc = p.b_deblocking_filter ? 0 : 1; sp.alpha_off_div2 = p.i_deblocking_filter_alphac0; sp.beta_off_div2 = p.i_deblocking_filter_beta;
+    sp.transform8x8_mode = p.analyse.b_transform_8x8; sp.cabac = p.b_cabac;
+    h->dpb.fill(sp);
+    h->last_stats.skip = 0;
+    {
+        const size_t before = h->nal_off.size();
+        write_picture(h->out, &h->nal_off, sp, 1, h->h_mb.data(), h->h_lv.data(), p.b_annexb != 0, before == 0, &h->last_stats, 1);
+        for (size_t i = before; i < h->nal_off.size(); i++) types.push_back(idr ? 5 : 1);
+    }
+    h->dpb.commit();
+    publish_nals(h, pp_nal, pi_nal, types);
+    for (size_t i = 0; i < h->nals.size(); i++) if (types[i] == 1 || types[i] == 5) h->nals[i].i_ref_idc = plan.nal_ref_idc;
+    if (pic_out) {
+        x264_picture_init(pic_out);
+        pic_out->i_type = idr ? X264_TYPE_IDR : pl.type == PIC_I ? X264_TYPE_I : pl.type == PIC_P ? X264_TYPE_P : pl.type == PIC_BREF ? X264_TYPE_BREF : X264_TYPE_B;
+        pic_out->b_keyframe = idr;
+        pic_out->i_pts = pl.e.pts;
+        // x264: the k-th coded picture's dts is the pts of display picture k - delay; the first `delay` ones are shifted back by the delay's duration
+        const long k = h->coded_count, delay = h->bpyramid ? 2 : 1;
+        const size_t np = h->all_pts.size();
+        if (k >= delay) pic_out->i_dts = h->all_pts[(size_t)(k - delay) < np ? (size_t)(k - delay) : np - 1];
+        else pic_out->i_dts = h->all_pts[(size_t)k < np ? (size_t)k : np - 1] - (h->all_pts[(size_t)delay < np ? (size_t)delay : np - 1] - h->all_pts[0]);
+        pic_out->img = pl.e.img;
+    }
+    if (idr) h->idr_pic_id = (h->idr_pic_id + 1) & 0xffff;
+    h->coded_count++;
+    h->frame_no++;
+    return (int)h->out.size();
+}
+
 int x264_encoder_encode(x264_t *h, x264_nal_t **pp_nal, int *pi_nal, x264_picture_t *pic_in, x264_picture_t *pic_out)
 {
     if (!h || !pp_nal || !pi_nal) return -1;
     *pi_nal = 0; *pp_nal = nullptr;
+    if (h->failed) return -1;
     if (!pic_in) {      // flush: GOP-parallel batches, or the pictures still waiting in the lookahead queue, one per call
         if (h->G > 1) return encode_gop_parallel(h, pp_nal, pi_nal, nullptr, pic_out, false);
+        if (h->bframes) return encode_bmode(h, pp_nal, pi_nal, pic_out, true);
         return h->queue.empty() ? 0 : encode_queued(h, pp_nal, pi_nal, pic_out, true);
     }
     const x264_param_t &p = h->param;
@@ -907,6 +1076,19 @@ int x264_encoder_encode(x264_t *h, x264_nal_t **pp_nal, int *pi_nal, x264_pictur
     e.type = idr ? 2 : intra_pic ? 1 : 0;
     h->la_gop = idr ? 1 : h->la_gop + 1;
     h->la_count++;
+    if (h->bframes) {
+        x264_t::BEntry be = {};
+        be.pts = e.pts; be.frame = (int)(h->la_count - 1); be.slot = slot; be.forced = e.type; be.scenecut = e.scenecut; be.img = e.img;
+        memcpy(be.costs, e.costs, sizeof(e.costs));
+        if (pic_in->i_type == X264_TYPE_I) be.forced = 1;
+        h->bq.push_back(be);
+        h->all_pts.push_back(e.pts);
+        PHASE(1);
+        const int size = encode_bmode(h, pp_nal, pi_nal, pic_out, false);
+        PHASE(4);
+        h->t_phase[5] += 1;
+        return size;
+    }
     h->queue.push_back(e);
     PHASE(1);
     if ((int)h->queue.size() <= h->L) return 0;                        // still filling the lookahead: no picture yet (codec.c:1693, size 0)
@@ -917,7 +1099,7 @@ int x264_encoder_encode(x264_t *h, x264_nal_t **pp_nal, int *pi_nal, x264_pictur
     return size;
 }
 
-int x264_encoder_delayed_frames(x264_t *h) { return !h || h->failed ? 0 : h->G > 1 ? (int)(h->submitted - h->emitted) : (int)h->queue.size(); }
+int x264_encoder_delayed_frames(x264_t *h) { return !h || h->failed ? 0 : h->G > 1 ? (int)(h->submitted - h->emitted) : h->bframes ? (int)(h->bq.size() + h->bcoding.size()) : (int)h->queue.size(); }
 
 void x264_encoder_close(x264_t *h)
 {
