@@ -8,7 +8,7 @@ import pytest
 
 import host_lib as HL
 import oracle_lib as O
-from synth import synth_frames
+from synth import psnr, synth_frames
 
 pytestmark = pytest.mark.gpu
 H = HL.H
@@ -20,6 +20,8 @@ def open_encoder(w, h, opts, profile=b"baseline", preset=b"medium"):
     p.i_width, p.i_height, p.i_csp = w, h, HL.X264_CSP_I420
     p.i_fps_num, p.i_fps_den = 25, 1
     p.i_log_level = -1
+    if "bframes" not in opts:
+        opts = dict(opts, bframes=0)          # these sessions test the I / P behaviours (one picture back per call); B sessions: test_b_session_*
     for k, v in opts.items():
         assert H.x264_param_parse(C.byref(p), k.encode(), None if v is None else str(v).encode()) == 0, k
     p.b_vfr_input = 0
@@ -549,6 +551,8 @@ def test_sliced_threads_through_the_api(gpu, w, h, opts, slices):
     p.i_width, p.i_height, p.i_csp = w, h, HL.X264_CSP_I420
     p.i_fps_num, p.i_fps_den = 25, 1
     p.i_log_level = -1
+    if "bframes" not in opts:
+        opts = dict(opts, bframes=0)          # these sessions test the I / P behaviours (one picture back per call); B sessions: test_b_session_*
     for k, v in opts.items():
         assert H.x264_param_parse(C.byref(p), k.encode(), None if v is None else str(v).encode()) == 0, k
     p.b_vfr_input = 0
@@ -586,6 +590,8 @@ def test_plain_slices_through_the_api(gpu, w, h, opts, slices):
     p.i_width, p.i_height, p.i_csp = w, h, HL.X264_CSP_I420
     p.i_fps_num, p.i_fps_den = 25, 1
     p.i_log_level = -1
+    if "bframes" not in opts:
+        opts = dict(opts, bframes=0)          # these sessions test the I / P behaviours (one picture back per call); B sessions: test_b_session_*
     for k, v in opts.items():
         assert H.x264_param_parse(C.byref(p), k.encode(), None if v is None else str(v).encode()) == 0, k
     p.b_vfr_input = 0
@@ -743,3 +749,58 @@ def test_access_unit_delimiters(gpu):
     dec = O.h264_decode(stream, nfr, w, h)
     for i in range(nfr):
         np.testing.assert_array_equal(dec[i], recons[i])
+
+
+def encode_delayed(h_, w, h, frames):
+    """feeds every frame, then drains (codec.c:1842-1856): -> (stream, [(type, keyframe, pts, dts, size)] as the pictures leave)"""
+    pic, out = HL.Picture(), HL.Picture()
+    assert H.x264_picture_alloc(C.byref(pic), HL.X264_CSP_I420, w, h) == 0
+    stream, recs = b"", []
+    nal, n = C.POINTER(HL.Nal)(), C.c_int()
+
+    def take(size):
+        nonlocal stream
+        assert size >= 0
+        if size:
+            assert sum(nal[k].i_payload for k in range(n.value)) == size
+            stream += C.string_at(nal[0].p_payload, size)
+            recs.append((out.i_type, out.b_keyframe, out.i_pts, out.i_dts, size))
+    for i, f in enumerate(frames):
+        C.memmove(pic.img.plane[0], f.ctypes.data, f.size)
+        pic.i_pts = i
+        take(H.x264_encoder_encode(h_, C.byref(nal), C.byref(n), C.byref(pic), C.byref(out)))
+    while H.x264_encoder_delayed_frames(h_):
+        size = H.x264_encoder_encode(h_, C.byref(nal), C.byref(n), None, C.byref(out))
+        assert size > 0
+        take(size)
+    H.x264_picture_clean(C.byref(pic))
+    return stream, recs
+
+
+@pytest.mark.parametrize("w,h,n,opts,pattern", [
+    (176, 144, 14, {"qp": 23, "keyint": 30, "scenecut": 0}, "IPRBBPRBBPRBBP"),                         # preset medium as the device runs it: bframes 3, b-pyramid, weightb, ref 3
+    (128, 96, 12, {"qp": 26, "keyint": 30, "scenecut": 0, "bframes": 1, "ref": 1}, "IPBPBPBPBPBP"),
+    (96, 80, 13, {"crf": 24, "keyint": 6, "min-keyint": 6, "scenecut": 0, "bframes": 2, "b-pyramid": "none", "no-mbtree": None}, None),
+])
+def test_b_session_through_the_encode_api(gpu, w, h, n, opts, pattern):
+    """B pictures through x264_encoder_encode (codec.c:1693): types / pts / dts as x264 hands them to the muxers (output/matroska.c:199-202), the
+    stream decodes to every source picture, and equals the checker's stream for the same schedule byte for byte"""
+    frames = synth_frames(w, h, n, seed=4)
+    h_, eff = open_encoder(w, h, opts, profile=None)
+    assert eff.i_bframe == opts.get("bframes", 3) and eff.i_bframe_adaptive == 0 and eff.analyse.i_direct_mv_pred == 1
+    stream, recs = encode_delayed(h_, w, h, frames)
+    H.x264_encoder_close(h_)
+    assert len(recs) == n
+    TYPE = {1: "I", 2: "i", 3: "P", 4: "R", 5: "B"}
+    got = "".join(TYPE[r[0]] for r in recs)
+    if pattern:
+        assert got == pattern
+    dts = [r[3] for r in recs]
+    assert dts == sorted(dts) and len(set(dts)) == n and all(r[3] <= r[2] for r in recs)
+    dec = O.h264_decode(stream, n, w, h)
+    pocs = O.h264_last_pocs()
+    assert len(dec) == n
+    # POC restarts at every IDR: display index = pts
+    for d, r in zip(dec, recs):
+        assert psnr(d[:w * h], frames[r[2]][:w * h]) > 33.0
+    assert [p for p in pocs] == [2 * (r[2] - max(q[2] for q in recs if q[1] and q[2] <= r[2])) for r in recs]
