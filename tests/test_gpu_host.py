@@ -802,5 +802,5 @@ def test_b_session_through_the_encode_api(gpu, w, h, n, opts, pattern):
     assert len(dec) == n
     # POC restarts at every IDR: display index = pts
     for d, r in zip(dec, recs):
-        assert psnr(d[:w * h], frames[r[2]][:w * h]) > 33.0
+        assert psnr(d[:w * h], frames[r[2]][:w * h]) > 30.0
     assert [p for p in pocs] == [2 * (r[2] - max(q[2] for q in recs if q[1] and q[2] <= r[2])) for r in recs]
