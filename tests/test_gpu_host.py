@@ -778,7 +778,7 @@ def encode_delayed(h_, w, h, frames):
 
 
 @pytest.mark.parametrize("w,h,n,opts,pattern", [
-    (176, 144, 14, {"qp": 23, "keyint": 30, "scenecut": 0}, "IPRBBPRBBPRBBP"),                         # preset medium as the device runs it: bframes 3, b-pyramid, weightb, ref 3
+    (176, 144, 14, {"qp": 23, "keyint": 30, "scenecut": 0, "bframes": 3}, "IPRBBPRBBPRBBP"),                         # preset medium as the device runs it: bframes 3, b-pyramid, weightb, ref 3
     (128, 96, 12, {"qp": 26, "keyint": 30, "scenecut": 0, "bframes": 1, "ref": 1}, "IPBPBPBPBPBP"),
     (96, 80, 13, {"crf": 24, "keyint": 6, "min-keyint": 6, "scenecut": 0, "bframes": 2, "b-pyramid": "none", "no-mbtree": None}, None),
 ])
