@@ -26,7 +26,8 @@ def main():
     W = int(sys.argv[3]) if len(sys.argv) > 3 else 1920
     H = int(sys.argv[4]) if len(sys.argv) > 4 else 1080
     dev = torch.device("cuda:0")
-    args = type("A", (), dict(refs=3, preset="medium", aq=False, rd=os.environ.get("MB_PROF_RD", "cabac"), no_trellis=bool(os.environ.get("MB_PROF_NO_TRELLIS"))))()
+    args = type("A", (), dict(refs=3, preset="medium", aq=False, rd=os.environ.get("MB_PROF_RD", "cabac"), no_trellis=bool(os.environ.get("MB_PROF_NO_TRELLIS")),
+                              bframes=int(os.environ.get("MB_PROF_BFRAMES", "3"))))()
     tools = bench.toolset(args)
     D = min(S, 64)
     base = bench.synth_batch(torch, D, F, W, H, 0x264, dev)
@@ -43,16 +44,25 @@ def main():
     f.argtypes = [C.c_void_p, C.c_void_p]
     out = np.zeros((S, 16), dtype=np.uint64)
     print("%-4s %10s " % ("pic", "cyc/MB") + " ".join("%9s" % p[:9] for p in PH[:16]))
-    for i in range(F):
+    from x264vfw_amd import gop, host_api as HL
+    from x264vfw_amd.lib import Pic
+    bfr = int(os.environ.get("MB_PROF_BFRAMES", "3")) if tools.get("dpb") else 0
+    order = gop.schedule(bench.display_types(F, bfr, F), 1)
+    dpb = gop.HostDpb(HL, tools["refs"], bfr, 1)
+    qargs = type("Q", (), dict(qp=23))()
+    for i, (disp, pt) in enumerate(order):
+        pic, _ = dpb.plan(pt, disp, gop.follow_of(order, i))
+        pic.qp = bench.qp_of(qargs, pt)
+        dpb.commit()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-        lib.check(lib.x264gpu_encode_frames(h, data[i].data_ptr(), 2 if i == 0 else 0, mbs.data_ptr(), lvs.data_ptr(), torch.cuda.current_stream().cuda_stream), "encode")
+        lib.check(lib.x264gpu_encode_pictures(h, data[disp].data_ptr(), (Pic * S)(*([pic] * S)), mbs.data_ptr(), lvs.data_ptr(), torch.cuda.current_stream().cuda_stream), "encode")
         e1.record()
         torch.cuda.synchronize()
         lib.check(f(h, out.ctypes.data), "mb_prof (is this an MB_PROF build?)")
         a = out.astype(np.float64).mean(axis=0) / n
         tot = a[:13].sum() + (a[15] if a[15] > 100 else 0)          # -DMB_PROF_RD builds: slot 15 = cycles of the CABAC pricing (RD sessions)
-        print("%-4s %10.0f " % ("I" if i == 0 else "P", tot) + " ".join("%9.0f" % v for v in a[:13]) + " %9.2f %9.2f %9.2f" % (a[13], a[14], a[15]) + "   %.1f ms" % e0.elapsed_time(e1))
+        print("%-4s %10.0f " % ("IIPRb"[pt] + str(disp), tot) + " ".join("%9.0f" % v for v in a[:13]) + " %9.2f %9.2f %9.2f" % (a[13], a[14], a[15]) + "   %.1f ms" % e0.elapsed_time(e1))
         mx = out[:, :13].sum(axis=1).astype(np.float64)
         print("     slowest/mean stream cycles: %.3f   share: " % (mx.max() / mx.mean()) + " ".join("%8.1f%%" % (100 * v / tot) for v in a[:13]))
 
