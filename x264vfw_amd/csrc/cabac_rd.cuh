@@ -113,25 +113,10 @@ __device__ __forceinline__ void cab_step(int &st, int &f8v, uint32_t model, bool
     st = mine ? (ns << 1) | nm : st;
 }
 
-// one bin on the context variable that lives in lane li of st (li wave-uniform): everything scalar — two lane reads, the update, a lane select.
-// The levels of a block touch two contexts per coefficient, one bin after the other: a dependent chain, so what counts is its latency, and
-// a v_readlane round trip is a fraction of the LDS shuffle cab_step pays to let every lane look its own state up
-__device__ __forceinline__ void cab_sbin(int &st, int &f8, uint32_t model, int lane, int li, int bin)
+// the levels of a block, last coefficient first: coefficient i in lane i of coef, mask = its non-zero positions; q = this lane's
+// coeff_abs_level_minus1 context (0..9), or anything else.  x264's node contexts: c1 = bin 0, cg = the bins after it.
+__device__ __forceinline__ void cab_levels(Cab &cb, int &st, uint32_t model, int coef, unsigned long long mask, int q)
 {
-    const int s = __builtin_amdgcn_readlane(st, li), sg = s >> 1, mps = s & 1;
-    const uint32_t t = (uint32_t)__builtin_amdgcn_readlane((int)model, sg);
-    const bool lps = (mps ^ bin) != 0;
-    f8 += lps ? (int)((t >> 9) & 0x7ff) : (int)(t & 0x1ff);
-    const int ns = lps ? (int)(t >> 20) : min(sg + 1, 62);
-    const int nm = lps && sg == 0 ? mps ^ 1 : mps;
-    st = lane == li ? (ns << 1) | nm : st;
-}
-
-// the levels of a block, last coefficient first: coefficient i in lane i of coef, mask = its non-zero positions; the category's ten
-// coeff_abs_level_minus1 context variables live in lanes abs0 .. abs0 + 9 of st.  x264's node contexts: c1 = bin 0, cg = the bins after it.
-__device__ __forceinline__ void cab_levels(Cab &cb, int &st, uint32_t model, int coef, unsigned long long mask, int abs0)
-{
-    const int lane = (int)__lane_id();
     int node = 0;
     while (mask) {
         const int i = 63 - __builtin_clzll(mask);
@@ -139,24 +124,23 @@ __device__ __forceinline__ void cab_levels(Cab &cb, int &st, uint32_t model, int
         const int a = abs(__builtin_amdgcn_readlane(coef, i));
         const int c1 = node < 4 ? node + 1 : 0, cg = node < 4 ? 5 : min(node + 2, 9);
         const int ones = min(a, 15) - 2, nb = a > 1 ? (a < 15 ? a - 1 : 13) : 0;        // bins on cg: `ones` ones, then a zero unless the escape follows
-        cab_sbin(st, cb.f8, model, lane, abs0 + c1, a > 1);
-        if (a > 1) {
-            if (ones >= 3) {
-                // a run of ones on cg.  While a one is that context's less probable symbol it is stepped; from then on every bin moves the state up
-                // by one (to 62 at most) and costs what the model says for the state it leaves: lane s of the model register IS state s, so the
-                // lanes of the states passed through add their own entry to their own share of the bits — no step per bin
-                int run = ones;
-                int so = __builtin_amdgcn_readlane(st, abs0 + cg);
-                while (run > 0 && !(so & 1)) { cab_sbin(st, cb.f8, model, lane, abs0 + cg, 1); so = __builtin_amdgcn_readlane(st, abs0 + cg); run--; }
-                if (run > 0) {
-                    const int sg = so >> 1, hi = min(sg + run - 1, 62), extra = max(sg + run - 1 - 62, 0);
-                    cb.f8v += lane >= sg && lane <= hi ? (int)(model & 0x1ff) * (lane == 62 ? 1 + extra : 1) : 0;
-                    st = lane == abs0 + cg ? (min(sg + run, 62) << 1) | 1 : st;
-                }
-                if (a < 15) cab_sbin(st, cb.f8, model, lane, abs0 + cg, 0);
-            } else
-                for (int kb = 0; kb < nb; kb++) cab_sbin(st, cb.f8, model, lane, abs0 + cg, kb < ones);
-        }
+        cab_step(st, cb.f8v, model, q == c1 || (a > 1 && q == cg), q == c1 ? a > 1 : a > 2);
+        if (ones >= 3) {
+            // a run of ones on cg.  While a one is that context's less probable symbol it is stepped; from then on every bin moves the state up
+            // by one (to 62 at most) and costs what the model says for the state it leaves: lane s of the model register IS state s, so the
+            // lanes of the states passed through add their own entry to their own share of the bits — no step per bin
+            int run = ones - 1;
+            const int owner = __builtin_ctzll(__ballot(q == cg));
+            int so = __builtin_amdgcn_readlane(st, owner);
+            while (run > 0 && !(so & 1)) { cab_step(st, cb.f8v, model, q == cg, 1); so = __builtin_amdgcn_readlane(st, owner); run--; }
+            if (run > 0) {
+                const int sg = so >> 1, hi = min(sg + run - 1, 62), extra = max(sg + run - 1 - 62, 0), ln = (int)__lane_id();
+                cb.f8v += ln >= sg && ln <= hi ? (int)(model & 0x1ff) * (ln == 62 ? 1 + extra : 1) : 0;
+                st = q == cg ? (min(sg + run, 62) << 1) | 1 : st;
+            }
+            if (a < 15) cab_step(st, cb.f8v, model, q == cg, 0);
+        } else
+            for (int kb = 1; kb < nb; kb++) cab_step(st, cb.f8v, model, q == cg, kb < ones);
         cb.f8 += 256;                                                  // sign
         if (a >= 15) cab_ue_bypass(cb, 0, a - 15);
         node = a > 1 ? (node < 4 ? 4 : min(node + 1, 7)) : (node < 3 ? node + 1 : node);
@@ -176,7 +160,7 @@ __device__ __forceinline__ void cab_block4(Cab &cb, int &st, uint32_t model, int
     const int p = is_s ? lane - sig0 : lane - last0;
     const int nzp = (int)((mask >> (p & 63)) & 1);
     cab_step(st, cb.f8v, model, (is_s && p <= last) || (is_l && nzp && p <= last), is_s ? nzp : p == last);
-    cab_levels(cb, st, model, coef, mask, abs0);
+    cab_levels(cb, st, model, coef, mask, lane - abs0);
 }
 
 static __constant__ const unsigned long long c_cabac_pos8[24] = {
@@ -199,7 +183,7 @@ __device__ __forceinline__ void cab_block8(Cab &cb, int &st, uint32_t model, int
         cab_step(st, cb.f8v, model, have, lane < 15 ? (int)((mask >> i) & 1) : i == last);
         mine &= ~(1ull << i);
     }
-    cab_levels(cb, st, model, coef, mask, 32);
+    cab_levels(cb, st, model, coef, mask, lane - 32);
 }
 
 // what the coder needs to know about the macroblock and its neighbours (all wave-uniform)
