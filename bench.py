@@ -234,21 +234,21 @@ def synth_batch(torch, streams, frames, w, h, seed, device, smooth=False, scene_
 
 def pmc_evidence(kernel_substr, avg_launch_ms, streams_per_launch, content):
     """HBM bytes per launch of the dominant kernel and its VALU instruction count from the committed rocprofv3 --pmc passes of this
-    command (tools/profile_round.sh -> profiles/r02_pmc_per_launch.json; FETCH_SIZE and WRITE_SIZE in separate passes, KB -> bytes,
-    read side doubled as MI355X_MICROARCH.md prescribes for gfx950).  PMC counters cannot be read from inside an un-profiled run, so
-    these are the profile's figures scaled per stream; null without a profile."""
-    path = os.path.join(ROOT, "profiles", "r02_pmc_per_launch.json")
+    command (tools/profile_round.sh -> profiles/r03_pmc_per_launch.json; FETCH_SIZE and WRITE_SIZE in separate passes, KB -> bytes,
+    read side doubled as MI355X_MICROARCH.md prescribes for gfx950).  The macroblock loop runs as three instantiations (I, P, B slices): the
+    profile's entry `_mb_loop_timed_window` is their average over the launches of the timed window, the same launches bench.py's own event
+    timing averages.  PMC counters cannot be read from inside an un-profiled run, so these are the profile's figures scaled per stream; null
+    without a profile of this workload."""
+    path = os.path.join(ROOT, "profiles", "r03_pmc_per_launch.json")
     if not os.path.exists(path):
         return None, None
     tab = json.load(open(path))
     per = tab.get("_workload", {}).get("streams_per_launch")
     if tab.get("_workload", {}).get("content", "noise") != content:
         return None, None                                     # counters of another workload say nothing about this one
-    key = [k for k in tab if kernel_substr in k]
-    key = [k for k in key if ", true" in k] or key          # the macroblock loop has a P-slice and an I-slice instantiation: the timed pictures are P
-    if not per or not key:
+    t = tab.get("_mb_loop_timed_window") if "k_mb_slice" in kernel_substr else next((tab[k] for k in tab if kernel_substr in k), None)
+    if not per or not t:
         return None, None
-    t = tab[key[0]]
     scale = streams_per_launch / per
     traffic = int(t["hbm_bytes_per_launch_corrected"] * scale) if "hbm_bytes_per_launch_corrected" in t else None
     valu = None
@@ -256,7 +256,7 @@ def pmc_evidence(kernel_substr, avg_launch_ms, streams_per_launch, content):
         simds, clk = 256 * 4, 2.4e9                      # a wave64 VALU op occupies its SIMD16 for 4 cycles
         insts = t["SQ_INSTS_VALU"] * scale
         valu = {"insts_per_launch": int(insts), "insts_per_macroblock": round(t["SQ_INSTS_VALU"] / t.get("macroblocks_per_launch", 1), 1) if t.get("macroblocks_per_launch") else None,
-                "issue_util": round(insts * 4 / (simds * clk * avg_launch_ms * 1e-3), 4), "source": "profiles/r02_pmc_per_launch.json"}
+                "issue_util": round(insts * 4 / (simds * clk * avg_launch_ms * 1e-3), 4), "source": "profiles/r03_pmc_per_launch.json"}
     return traffic, valu
 
 
@@ -469,6 +469,7 @@ def main():
     # algorithmic HBM bytes per frame and stage (DESIGN.md "kernels"): planes each stage must read / write once.  The macroblock loop reads the
     # source and one reference per list it predicts from and writes the reconstruction it keeps (I 2 S, P 3 S, B reference 4 S, b 3 S)
     tname = {0: "I", 1: "I", 2: "P", 3: "Bref", 4: "b"}
+    kind = {0: "I", 1: "I", 2: "P", 3: "B", 4: "B"}
     tcount = {"I": 0, "P": 0, "Bref": 0, "b": 0}
     tms = {"I": 0.0, "P": 0.0, "Bref": 0.0, "b": 0.0}
     for c in range(K):
@@ -504,7 +505,9 @@ def main():
                                   f"preset {args.preset}, content '{args.content}'",
                       "toolset": tools, "toolset_gaps": TOOLSET_GAPS_NORD if args.rd == "off" or args.preset == "ultrafast" else (TOOLSET_GAPS if args.bframes else TOOLSET_GAPS_NOB) + (" [--rd cavlc: medium --no-cabac]" if args.rd == "cavlc" else ""),
                       "streams_per_gpu": S, "distinct_sequences": D, "frames_per_sequence": L, "content": args.content, "frames_per_step": S * world, "keyint_for_proportions": args.keyint,
-                      "mb_per_frame": ((W + 15) // 16) * ((H + 15) // 16)},
+                      "mb_per_frame": ((W + 15) // 16) * ((H + 15) // 16),
+                      # launches of the three macroblock-loop instantiations before / inside the timed window (tools/profile_summarise.py folds the counters of the timed ones)
+                      "launch_plan": {t: {"warmup": sum(1 for _, pt in order[:Wu] if kind[pt] == t), "timed": sum(1 for _, pt in order[Wu:] if kind[pt] == t)} for t in ("I", "P", "B")}},
            "roofline": roof}
     if rank == 0:
         import numpy as np

@@ -2,6 +2,28 @@
 import collections, csv, glob, json, os, sys
 
 
+PLAN = {}          # bench.py config.launch_plan: launches of the macroblock loop's I / P / B instantiations before / inside the timed window
+
+
+def mb_kind(k):
+    """which instantiation of the macroblock loop a kernel name is: k_mb_slice<M, ME, PS, RD, BS>"""
+    if "k_mb_slice" not in k:
+        return None
+    args = [a.strip() for a in k[k.index("<") + 1:k.rindex(">")].split(",")] if "<" in k else []
+    if len(args) >= 5 and args[4] in ("true", "1"):
+        return "B"
+    return "P" if len(args) >= 3 and args[2] in ("true", "1") else "I"
+
+
+def window_of(k, v, skip, keep):
+    """the launches of kernel k (sorted dispatch ids / intervals v) that lie in bench.py's timed window"""
+    kind = mb_kind(k)
+    if kind and PLAN.get(kind):
+        w, t = PLAN[kind]["warmup"], PLAN[kind]["timed"]
+        return v[w:w + t]
+    return v[skip:skip + keep] if len(v) >= skip + keep else v[-keep:]
+
+
 def fold(d, skip, keep):
     """per kernel: counters summed over its launches `skip` .. `skip + keep - 1` (the timed pictures of bench.py: warmup launches and the
     IDR probe at the end are left out, so the averages are over the same launches as bench.py's own event timing)"""
@@ -19,10 +41,7 @@ def fold(d, skip, keep):
             order[k].append(i)
     # the macroblock loop has an I-slice and a P-slice instantiation: a kernel with fewer launches than warmup + timed ran only in part of the
     # pictures, and its timed launches are its last `keep` ones (the P instantiation: one warmup P picture, then the timed ones)
-    def win(v):
-        v = sorted(v)
-        return v[skip:skip + keep] if len(v) >= skip + keep else v[-keep:]
-    window = {k: set(win(v)) if "k_csp" not in k else set(v) for k, v in order.items()}
+    window = {k: set(window_of(k, sorted(v), skip, keep)) if "k_csp" not in k else set(v) for k, v in order.items()}
     for r in rows:
         k = r["Kernel_Name"].split("(")[0].replace("void ", "")
         if int(r["Dispatch_Id"]) not in window[k]:
@@ -51,7 +70,7 @@ def trace_window(d, skip, keep):
     out = {}
     for k, v in per.items():
         v.sort()
-        w = (v[skip:skip + keep] if len(v) >= skip + keep else v[-keep:]) if "x264gpu" in k and "k_csp" not in k else v
+        w = window_of(k, v, skip, keep) if "x264gpu" in k and "k_csp" not in k else v
         if w:
             out[k] = {"launches": len(w), "avg_ms": sum(e - s for s, e in w) / len(w) / 1e6, "all_launches": len(v), "avg_ms_all_launches": sum(e - s for s, e in v) / len(v) / 1e6}
     return out
@@ -63,6 +82,7 @@ def main():
     try:
         bj = json.loads(open(os.path.join(out, "bench_under_rocprof.json")).read().strip().split("\n")[-1])
         skip, keep = bj["warmup"], bj["steps"]
+        PLAN.update(bj["config"].get("launch_plan", {}))
     except Exception:  # noqa: BLE001
         skip, keep = 0, 1 << 30
     kt = trace_window(sys.argv[2], skip, keep)
@@ -75,6 +95,22 @@ def main():
             for c, x in v.items():
                 table[k][c] = x / n
                 table[k]["launches_profiled"][c] = n
+    # the macroblock loop as a whole: its instantiations' counters summed over the timed window, per launch of that window
+    mbk = [k for k in table if mb_kind(k)]
+    if mbk:
+        tot, n = collections.defaultdict(float), 0
+        for k in mbk:
+            nk = max(table[k]["launches_profiled"].values())
+            n += nk
+            for c, x in table[k].items():
+                if c != "launches_profiled":
+                    tot[c] += x * table[k]["launches_profiled"][c]
+        table["_mb_loop_timed_window"] = {c: x / n for c, x in tot.items()}
+        table["_mb_loop_timed_window"]["launches_profiled"] = {c: n for c in tot}
+        table["_mb_loop_timed_window"]["instantiations"] = {k: max(table[k]["launches_profiled"].values()) for k in mbk}
+        kts = {k: kt[k] for k in kt if mb_kind(k)}
+        if kts:
+            table["_mb_loop_timed_window"]["avg_ms_kernel_trace"] = sum(v["avg_ms"] * v["launches"] for v in kts.values()) / sum(v["launches"] for v in kts.values())
     for k, v in table.items():
         if "FETCH_SIZE" in v and "WRITE_SIZE" in v:
             # rocprofv3 reports KB; gfx950 FETCH_SIZE tallies 128-B requests at 64 B for wide coalesced reads
