@@ -242,6 +242,12 @@ typedef struct x264gpu_pic {
     int keep;                 /* 1: the picture will be referenced (half-pel planes and borders are built); 0: a non-reference b */
     int nref[2];              /* active references of list 0 / list 1 */
     int8_t slot[2][X264GPU_MAX_LIST];      /* DPB slot of reference index i of list l */
+    /* P pictures, x264 --weightp: explicit luma weight of list-0 index i (8.4.2.3.2): clip(((p * scale + (1 << (denom - 1))) >> denom) + offset),
+     * denom 0: clip(p * scale + offset); on == 0: the index is not weighted.  x264's --weightp 2 puts a DUPLICATE of reference 0 at index 1 with
+     * weight {scale 1, denom 0, offset -1} on every P picture that has at least two references (blind_dupe = that index, else -1): the host names
+     * the same slot twice in slot[0][], the analysis refines the duplicate from reference 0's vector instead of searching it */
+    struct { int8_t on, denom; int16_t scale, offset; } wl0[X264GPU_MAX_LIST];
+    int blind_dupe;
 } x264gpu_pic;
 
 int  x264gpu_encoder_create(x264gpu_encoder **enc, const x264gpu_config *cfg);

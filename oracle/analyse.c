@@ -190,17 +190,27 @@ typedef struct {
     const pixel *fenc; pixel *planes[4]; const pixel *full;
     const uint16_t *cmx, *cmy;
     int refslot;
+    int wt, wdenom, wscale, woffset;       /* m->weight[0]: the explicit luma weight of a P slice's list-0 index (--weightp) */
 } sctx;
 
+/* full-pel candidates read the weighted copy of the plane (x264: m->p_fref_w = h->fenc->weighted[ref], x264_weight_scale_plane of the padded
+ * plane — pointwise, so weighting the block read from the unweighted plane gives the same samples) */
 static int cost_fpel(const sctx *s, int mx, int my)
 {
     const x264o_encoder *e = s->a->e;
+    if (s->wt) {
+        pixel wb[256];
+        x264o_mc_weight(wb, 16, s->full + my * e->rs + mx, e->rs, s->m->w, s->m->h, s->wscale, s->wdenom, s->woffset);
+        return x264o_sad(s->fenc, e->fs, wb, 16, s->m->w, s->m->h) + s->cmx[mx * 4] + s->cmy[my * 4];
+    }
     return x264o_sad(s->fenc, e->fs, s->full + my * e->rs + mx, e->rs, s->m->w, s->m->h) + s->cmx[mx * 4] + s->cmy[my * 4];
 }
+/* mc.get_ref: interpolate, then weight (common/mc.c get_ref: mc_weight after pixel_avg / on the copied block) */
 static void get_ref(const sctx *s, pixel *dst, int mx, int my)
 {
     const actx *a = s->a;
     x264o_mc_luma(dst, 16, s->planes, a->e->rs, a->mbx * 16 + s->m->ox, a->mby * 16 + s->m->oy, mx, my, s->m->w, s->m->h);
+    if (s->wt) x264o_mc_weight(dst, 16, dst, 16, s->m->w, s->m->h, s->wscale, s->wdenom, s->woffset);
 }
 static int cost_qpel_sad(const sctx *s, int mx, int my)       /* COST_MV_HPEL / COST_MV_SAD */
 {
@@ -300,6 +310,8 @@ static void sctx_init(sctx *s, const actx *a, me_t *m)
     for (int k = 0; k < 4; k++) s->planes[k] = luma_plane(e, s->refslot, k);
     s->full = s->planes[0] + (size_t)(a->mby * 16 + m->oy) * e->rs + a->mbx * 16 + m->ox;
     s->cmx = a->cost_mv - m->mvp[0]; s->cmy = a->cost_mv - m->mvp[1];
+    s->wt = e->slice_type == X264GPU_SLICE_P && m->list == 0 && e->wl0[m->ref].on;
+    s->wdenom = e->wl0[m->ref].denom; s->wscale = e->wl0[m->ref].scale; s->woffset = e->wl0[m->ref].offset;
 }
 
 /* x264_me_search_ref: m->{w,h,ox,oy,ref,mvp} set by the caller */
@@ -345,7 +357,7 @@ static void me_search_ref(const actx *a, me_t *m, int (*mvc)[2], int i_mvc, int 
         /* full-pel predictor, costed without its vector bits */
         bmx = pmx = clampi((m->mvp[0] + 2) >> 2, fmin[0], fmax[0]); bmy = pmy = clampi((m->mvp[1] + 2) >> 2, fmin[1], fmax[1]);
         pmv_nonzero = (pmx | pmy) != 0;
-        bcost = x264o_sad(s->fenc, e->fs, s->full + bmy * e->rs + bmx, e->rs, m->w, m->h);
+        bcost = cost_fpel(s, bmx, bmy) - s->cmx[bmx * 4] - s->cmy[bmy * 4];
         if (i_mvc > 0) {
             /* x264_predictor_roundclip: round to full-pel, clip, drop zero and pmv */
             int n = 0;
@@ -506,6 +518,17 @@ fullpel_done:
 }
 
 /* x264_me_refine_qpel: the extra sub-pel steps of the winning partition below subme 6 */
+/* x264_me_refine_qpel_refdupe: the blind duplicate of reference 0 (--weightp 2) is never searched — its vector starts at reference 0's result
+ * (set by the caller) and takes at most two quarter-pel iterations.  m->cost is whatever the previous search left (it only matters below subme 2,
+ * where the starting cost is not recomputed — as in x264, whose x264_me_t is reused across the reference loop) */
+static void me_refine_qpel_refdupe(const actx *a, me_t *m, int *p_halfpel_thresh)
+{
+    sctx S;
+    sctx_init(&S, a, m);
+    const int q = subpel_iterations[a->subme][3];
+    refine_subpel(&S, 0, q < 2 ? q : 2, p_halfpel_thresh, 0);
+}
+
 static void me_refine_qpel(const actx *a, me_t *m)
 {
     sctx S;
@@ -768,12 +791,19 @@ static void mc_mb_b(x264o_encoder *e, int mbx, int mby, const x264gpu_mb *mb, pi
     }
 }
 
+/* x264_mb_mc_0xywh of a P slice: list-0 index r with its explicit luma weight (h->sh.weight[r][0]; chroma weights are not used here) */
+static void mc_mb_p(x264o_encoder *e, int mbx, int mby, int bx, int by, int w, int h, int r, int mvx, int mvy, pixel *dy, int sy, pixel *du, pixel *dv, int sc)
+{
+    mc_mb(e, mbx, mby, bx, by, w, h, ref_slot(e, r), mvx, mvy, dy, sy, du, dv, sc);
+    if (e->wl0[r].on) x264o_mc_weight(dy + by * sy + bx, sy, dy + by * sy + bx, sy, w, h, e->wl0[r].scale, e->wl0[r].denom, e->wl0[r].offset);
+}
+
 static int probe_pskip(const actx *a)
 {
     x264o_encoder *e = a->e;
     const int mvx = clampi(a->pskip_mv[0], a->mv_min[0], a->mv_max[0]), mvy = clampi(a->pskip_mv[1], a->mv_min[1], a->mv_max[1]);
     pixel py[256], pu[64], pv[64];
-    mc_mb(e, a->mbx, a->mby, 0, 0, 16, 16, ref_slot(e, 0), mvx, mvy, py, 16, pu, pv, 8);
+    mc_mb_p(e, a->mbx, a->mby, 0, 0, 16, 16, 0, mvx, mvy, py, 16, pu, pv, 8);
     const pixel *fenc = e->fenc_y + (size_t)a->mby * 16 * e->fs + a->mbx * 16;
     const uint16_t *mf = e->qt.quant4_mf[X264O_CQM_4PY][a->qp], *bias = e->qt.quant4_bias[X264O_CQM_4PY][a->qp];
     int score = 0;
@@ -850,8 +880,13 @@ static int analyse_inter_p16x16(actx *a)
         i_halfpel_thresh -= m.ref_cost;
         a->cur_valid = 0;
         predict_mv(a, 0, 0, 2, r, m.mvp);
-        const int i_mvc = predict_mv_ref16x16(a, r, mvc);
-        me_search_ref(a, &m, mvc, i_mvc, p_halfpel_thresh);
+        if (r == e->blind_dupe) {
+            m.mv[0] = a->mvc[0][0][0]; m.mv[1] = a->mvc[0][0][1];
+            me_refine_qpel_refdupe(a, &m, p_halfpel_thresh);
+        } else {
+            const int i_mvc = predict_mv_ref16x16(a, r, mvc);
+            me_search_ref(a, &m, mvc, i_mvc, p_halfpel_thresh);
+        }
         /* save the vector for predicting neighbours */
         int16_t (*mvr)[2] = r == 0 ? e->mv16[e->cur] : e->mvr[r];
         mvr[a->mi][0] = (int16_t)m.mv[0]; mvr[a->mi][1] = (int16_t)m.mv[1];
@@ -876,14 +911,15 @@ static int analyse_inter_p16x16(actx *a)
 static void analyse_inter_p8x8_mixed_ref(actx *a)
 {
     int i_maxref = a->nref - 1;
+    const int dupe = a->e->blind_dupe;
     a->partition = D_8x8;
     /* early termination: if 16x16 chose reference 0, evaluate no references older than those used by the neighbours
      * (x264 tests the neighbour types with "> 0": unavailable and Intra4x4 neighbours both fail it) */
-    if (a->b_early_terminate && i_maxref > 0 && a->me16.ref == 0 && a->type_top > 0 && a->type_left > 0) {
+    if (a->b_early_terminate && i_maxref > 0 && (a->me16.ref == 0 || a->me16.ref == dupe) && a->type_top > 0 && a->type_left > 0) {
         const int gx = 2 * a->mbx, gy = 2 * a->mby;
         const nb_t n[6] = { nb8(a, gx - 1, gy - 1), nb8(a, gx, gy - 1), nb8(a, gx + 1, gy - 1), nb8(a, gx + 2, gy - 1), nb8(a, gx - 1, gy), nb8(a, gx - 1, gy + 1) };
         i_maxref = 0;
-        for (int i = 0; i < 6; i++) if (n[i].ref > i_maxref) i_maxref = n[i].ref;
+        for (int i = 0; i < 6; i++) if (n[i].ref > i_maxref && n[i].ref != dupe) i_maxref = n[i].ref;
     }
     for (int r = 0; r <= i_maxref; r++) {
         const int16_t (*mvr)[2] = r == 0 ? a->e->mv16[a->e->cur] : a->e->mvr[r];
@@ -895,14 +931,19 @@ static void analyse_inter_p8x8_mixed_ref(actx *a)
         const int x8 = i & 1, y8 = i >> 1;
         m.w = m.h = 8; m.ox = 8 * x8; m.oy = 8 * y8; m.list = 0;
         l0m->cost = 0x7fffffff;
-        for (int r = 0; r <= i_maxref; r++) {
+        for (int r = 0; r <= i_maxref || r == dupe;) {
             m.ref = r; m.ref_cost = ref_cost(a, r);
             a->cur8[i].ref = r;             /* x264_macroblock_cache_ref before predicting (the block itself is not a neighbour) */
             predict_mv(a, x8, y8, 1, r, m.mvp);
-            me_search_ref(a, &m, a->mvc[r], i + 1, NULL);
+            if (r == dupe) {
+                m.mv[0] = a->mvc[0][i + 1][0]; m.mv[1] = a->mvc[0][i + 1][1];
+                me_refine_qpel_refdupe(a, &m, NULL);
+            } else me_search_ref(a, &m, a->mvc[r], i + 1, NULL);
             m.cost += m.ref_cost;
             a->mvc[r][i + 1][0] = m.mv[0]; a->mvc[r][i + 1][1] = m.mv[1];
             if (m.cost < l0m->cost) *l0m = m;
+            /* the duplicate is visited even when the early termination cut the loop short of it */
+            if (r == i_maxref && i_maxref < dupe) r = dupe; else r++;
         }
         cache_block(a, x8, y8, 1, 1, l0m->ref, l0m->mv);
         a->satd8x8[i] = l0m->cost - (l0m->cost_mv + l0m->ref_cost);
@@ -916,7 +957,8 @@ static void analyse_inter_p8x8_mixed_ref(actx *a)
 
 static void analyse_inter_p8x8(actx *a)
 {
-    const int r = a->me16.ref;
+    /* duplicates are rarely worth their reference bits in P_8x8: without mixed references they are not analysed (x264) */
+    const int r = a->me16.ref == a->e->blind_dupe ? 0 : a->me16.ref;
     const int i_ref_cost = (a->e->cfg.cabac || r) ? ref_cost(a, r) : 0;          /* CAVLC: reference 0 of P_8x8 costs nothing (P_8x8ref0) */
     int i_mvc = 1;
     a->partition = D_8x8;
@@ -956,7 +998,9 @@ static void analyse_inter_p16x8(actx *a, int i_best_satd)
             for (int k = 0; k < 2; k++) { mvc[0][k] = a->mvc[r][0][k]; mvc[1][k] = a->mvc[r][2 * i + 1][k]; mvc[2][k] = a->mvc[r][2 * i + 2][k]; }
             a->cur8[2 * i].ref = a->cur8[2 * i + 1].ref = r;
             predict_mv(a, 0, i, 2, r, m.mvp);
-            me_search_ref(a, &m, mvc, 3, NULL);
+            /* the duplicate right after a search of reference 0: keep that search's vector, refine only */
+            if (r == a->e->blind_dupe && !ref8[0]) me_refine_qpel_refdupe(a, &m, NULL);
+            else me_search_ref(a, &m, mvc, 3, NULL);
             m.cost += m.ref_cost;
             if (m.cost < l0m->cost) *l0m = m;
         }
@@ -985,7 +1029,8 @@ static void analyse_inter_p8x16(actx *a, int i_best_satd)
             for (int k = 0; k < 2; k++) { mvc[0][k] = a->mvc[r][0][k]; mvc[1][k] = a->mvc[r][i + 1][k]; mvc[2][k] = a->mvc[r][i + 3][k]; }
             a->cur8[i].ref = a->cur8[i + 2].ref = r;
             predict_mv(a, i, 0, 1, r, m.mvp);
-            me_search_ref(a, &m, mvc, 3, NULL);
+            if (r == a->e->blind_dupe && !ref8[0]) me_refine_qpel_refdupe(a, &m, NULL);
+            else me_search_ref(a, &m, mvc, 3, NULL);
             m.cost += m.ref_cost;
             if (m.cost < l0m->cost) *l0m = m;
         }
@@ -1304,7 +1349,7 @@ static void encode_inter_mb(actx *a, x264gpu_mb *mb, int16_t *lv)
     if (mb->type >= X264GPU_MB_B_DIRECT) mc_mb_b(e, mbx, mby, mb, rec, e->rs, pu, pv);
     else
     for (int k = 0; k < 4; k++)       /* motion compensation per 8x8 quadrant (covers 16x16 / 16x8 / 8x16 / 8x8) */
-        mc_mb(e, mbx, mby, (k & 1) * 8, (k >> 1) * 8, 8, 8, ref_slot(e, mb->ref[k]), mb->mv[k][0], mb->mv[k][1], rec, e->rs, pu, pv, 8);
+        mc_mb_p(e, mbx, mby, (k & 1) * 8, (k >> 1) * 8, 8, 8, mb->ref[k], mb->mv[k][0], mb->mv[k][1], rec, e->rs, pu, pv, 8);
     for (int y = 0; y < 8; y++)
         for (int x = 0; x < 8; x++) { rec_uv[y * e->rs + 2 * x] = pu[y * 8 + x]; rec_uv[y * e->rs + 2 * x + 1] = pv[y * 8 + x]; }
     if (mb->type == X264GPU_MB_P_SKIP || mb->type == X264GPU_MB_B_SKIP) return;                /* x264_macroblock_encode_skip: the prediction is the reconstruction */

@@ -166,12 +166,14 @@ static int blk_nnz(const x264gpu_mb *m, int bx, int by)
 static int is_intra(const x264gpu_mb *m) { return m->type == X264GPU_MB_I4x4 || m->type == X264GPU_MB_I8x8 || m->type == X264GPU_MB_I16x16; }
 static int is_b_inter(const x264gpu_mb *m) { return m->type >= X264GPU_MB_B_DIRECT && m->type <= X264GPU_MB_B_8x8; }
 
+static int g_ref_pic[X264GPU_MAX_LIST + 1];       /* deblock_frame: picture (DPB slot) behind list-0 index r at [r + 1]; [0] = no reference */
 static int edge_bs(const x264gpu_mb *p, int pbx, int pby, const x264gpu_mb *q, int qbx, int qby, int mb_edge)
 {
     if (is_intra(p) || is_intra(q)) return mb_edge ? 4 : 3;
     if (blk_nnz(p, pbx, pby) || blk_nnz(q, qbx, qby)) return 2;
     int pi = (pby >> 1) * 2 + (pbx >> 1), qi = (qby >> 1) * 2 + (qbx >> 1);
-    if (p->ref[pi] != q->ref[qi]) return 1;
+    /* x264 compares reference PICTURES (deblock_ref_table): an index and its --weightp duplicate are the same picture */
+    if (g_ref_pic[p->ref[pi] < 0 ? 0 : p->ref[pi] + 1] != g_ref_pic[q->ref[qi] < 0 ? 0 : q->ref[qi] + 1]) return 1;
     if (abs(p->mv[pi][0] - q->mv[qi][0]) >= 4 || abs(p->mv[pi][1] - q->mv[qi][1]) >= 4) return 1;
     /* B slices (deblock_strength_c with bframe): list 1 compared index by index as well — x264's lists never share a picture (list 0 holds
      * earlier, list 1 later pictures), so comparing per list equals the standard's comparison of picture sets */
@@ -196,6 +198,8 @@ static void deblock_frame(x264o_encoder *e, const x264gpu_mb *mbs)
 {
     int a_off = e->cfg.deblock_alpha * 2, b_off = e->cfg.deblock_beta * 2;   /* slice_alpha_c0_offset_div2 * 2 */
     pixel *Y = luma_plane(e, e->cur, 0), *UV = chroma_plane(e, e->cur);
+    g_ref_pic[0] = -1;
+    for (int r = 0; r < X264GPU_MAX_LIST; r++) g_ref_pic[r + 1] = e->slice_type == X264GPU_SLICE_P && r < e->nref_l[0] ? e->lslot[0][r] : 100 + r;      /* (B slices: list 0 holds no picture twice) */
     for (int mby = 0; mby < e->mbh; mby++)
         for (int mbx = 0; mbx < e->mbw; mbx++) {
             const x264gpu_mb *q = &mbs[mby * e->mbw + mbx];
@@ -283,6 +287,12 @@ int x264o_encoder_encode_pic(x264o_encoder *e, const uint8_t *i420, const x264gp
     if (slice_type != X264GPU_SLICE_I && !e->nref_l[0]) return -1;
     if (slice_type == X264GPU_SLICE_B && !e->nref_l[1]) return -1;
     e->nref = e->nref_l[0];
+    e->blind_dupe = -1;
+    for (int r = 0; r < X264GPU_MAX_LIST; r++) {
+        const int on = slice_type == X264GPU_SLICE_P && r < e->nref && pic->wl0[r].on;
+        e->wl0[r].on = on; e->wl0[r].denom = on ? pic->wl0[r].denom : 0; e->wl0[r].scale = on ? pic->wl0[r].scale : 1; e->wl0[r].offset = on ? pic->wl0[r].offset : 0;
+    }
+    if (slice_type == X264GPU_SLICE_P && pic->blind_dupe > 0 && pic->blind_dupe < e->nref) e->blind_dupe = pic->blind_dupe;
     if (slice_type == X264GPU_SLICE_B) bipred_init(e);
     ingest(e, i420);
     const int slice_qp = pic->qp;
@@ -329,8 +339,8 @@ int x264o_encoder_encode(x264o_encoder *e, const uint8_t *i420, int slice_type, 
     if (slice_type == X264GPU_SLICE_I) { e->have_ref = 0; e->ring_poc = 0; }      /* IDR: the DPB is emptied */
     x264gpu_pic pic;
     memset(&pic, 0, sizeof(pic));
-    const int ring = clampi(e->cfg.refs, 1, X264O_MAX_REFS) + 1;
-    pic.slice_type = slice_type; pic.qp = slice_type == X264GPU_SLICE_P ? e->cfg.qp_p : e->cfg.qp_i; pic.poc = e->ring_poc; pic.dst = e->ring_cur; pic.keep = 1;
+    const int ring = clampi(e->cfg.refs, 1, 5) + 1;
+    pic.slice_type = slice_type; pic.qp = slice_type == X264GPU_SLICE_P ? e->cfg.qp_p : e->cfg.qp_i; pic.poc = e->ring_poc; pic.dst = e->ring_cur; pic.keep = 1; pic.blind_dupe = -1;
     pic.nref[0] = slice_type == X264GPU_SLICE_P ? (e->have_ref < ring - 1 ? e->have_ref : ring - 1) : 0;
     for (int r = 0; r < pic.nref[0]; r++) pic.slot[0][r] = (int8_t)((e->ring_cur - 1 - r + 2 * ring) % ring);
     const int rc = x264o_encoder_encode_pic(e, i420, &pic, mbs, levels);

@@ -9,7 +9,7 @@
 #define PAD 32          /* luma padding of reference planes */
 #define CPAD 16         /* chroma padding (samples) */
 #define MVCOST_HALF 32768
-#define X264O_MAX_REFS 5
+#define X264O_MAX_REFS 8                         /* list 0 of a P slice: up to 5 pictures + the duplicates of --weightp 2 */
 #define X264O_MAX_SLOTS 8                        /* reference pictures of the DPB (cfg.dpb or cfg.refs) + the picture being built */
 #define COST_MAX (1 << 28)
 
@@ -31,6 +31,9 @@ struct x264o_encoder {
     int nref_l[2], lslot[2][X264GPU_MAX_LIST];
     int bipred_weight[X264GPU_MAX_LIST][X264GPU_MAX_LIST];
     int keep;                    /* the picture being coded will be a reference */
+    /* --weightp: explicit luma weights of list 0's indices and x264's blind duplicate of reference 0 (h->mb.ref_blind_dupe; -1 = none) */
+    struct { int on, denom, scale, offset; } wl0[X264GPU_MAX_LIST];
+    int blind_dupe;
     int row0, row1;              /* macroblock rows [row0, row1) of the slice being coded (x264 slice threads: cfg.slices per picture) */
     int cur;                     /* DPB slot being reconstructed */
     /* per-picture motion side data living with the DPB slot (x264_frame_t): mv16x16 (= h->mb.mvr[0][0], the 16x16 search result

@@ -77,6 +77,9 @@ struct Decoder {
     std::vector<Ref> dpb;
     int log2_max_poc_lsb = 4, prev_poc_msb = 0, prev_poc_lsb = 0, cur_poc = 0, cur_frame_num = 0, cur_is_ref = 1;
     int weighted_bipred_idc = 0, num_ref1_default = 1, nref1_active = 0;
+    // explicit weighted prediction of P slices (PPS weighted_pred_flag, pred_weight_table 7.3.3.2, samples 8.4.2.3.2)
+    int weighted_pred = 0, luma_logwd = 0, chroma_logwd = 0;
+    struct { int lw, lo, cw[2], co[2]; } wp[32];
     int list_slot[2][16], list_poc[2][16];
     std::vector<int> pending_mmco;           // picture numbers to mark unused once the picture is complete
     std::vector<MbInfo> slot_mb[8];          // motion of every kept picture (co-located blocks of direct prediction)
@@ -443,6 +446,15 @@ struct SliceDec {
                 const int w0 = implicit_w0(m.ref8[k], m.ref8b[k]), w1 = 64 - w0;
                 for (int i = 0; i < 64; i++) y0[i] = (pixel)clampi((y0[i] * w0 + y1[i] * w1 + 32) >> 6, 0, 255);
                 for (int i = 0; i < 16; i++) { u0[i] = (pixel)clampi((u0[i] * w0 + u1[i] * w1 + 32) >> 6, 0, 255); v0[i] = (pixel)clampi((v0[i] * w0 + v1[i] * w1 + 32) >> 6, 0, 255); }
+            }
+            if (d.weighted_pred && !m.bmb && use0) {
+                // explicit mode, one prediction (8.4.2.3.2): ((p * w + 2^(logWD - 1)) >> logWD) + o, or p * w + o when logWD is 0
+                const auto &w = d.wp[m.ref8[k]];
+                auto wt = [](pixel *p, int n, int lw, int lo, int logwd) {
+                    for (int i = 0; i < n; i++) p[i] = (pixel)clampi(logwd >= 1 ? ((p[i] * lw + (1 << (logwd - 1))) >> logwd) + lo : p[i] * lw + lo, 0, 255);
+                };
+                wt(y0, 64, w.lw, w.lo, d.luma_logwd);
+                wt(u0, 16, w.cw[0], w.co[0], d.chroma_logwd); wt(v0, 16, w.cw[1], w.co[1], d.chroma_logwd);
             }
             const pixel *sy = use0 ? y0 : y1, *su = use0 ? u0 : u1, *sv = use0 ? v0 : v1;
             for (int yy = 0; yy < 8; yy++) memcpy(rec + (size_t)(oy + yy) * d.stride + ox, sy + yy * 8, 8);
@@ -951,7 +963,7 @@ struct SliceDec {
         if ((p.nz >> pb & 1) || (q.nz >> qb & 1)) return 2;
         int p8 = pb >> 2, q8 = qb >> 2;           // block index / 4 = 8x8 quadrant in H.264 block order
         if (!p.bmb && !q.bmb) {
-            if (p.ref8[p8] != q.ref8[q8]) return 1;
+            if (d.ref_slot_l(0, p.ref8[p8]) != d.ref_slot_l(0, q.ref8[q8])) return 1;       // different reference PICTURES (an index may repeat a picture)
             return abs(p.mv8[p8][0] - q.mv8[q8][0]) >= 4 || abs(p.mv8[p8][1] - q.mv8[q8][1]) >= 4;
         }
         // B slices (8.7.2.1): different reference PICTURES or a different number of vectors -> 1; else the vectors that point into the same picture
@@ -1089,7 +1101,7 @@ bool decode_nal(Decoder &d, const uint8_t *nal, size_t n)
         d.cabac = br.get1();                                // entropy_coding_mode_flag
         br.get1(); if (br.ue()) return reject(__LINE__);
         d.num_ref_default = (int)br.ue() + 1; d.num_ref1_default = (int)br.ue() + 1;
-        if (br.get1()) return reject(__LINE__);                        // weighted_pred_flag: explicit weights are outside the subset
+        d.weighted_pred = (int)br.get1();                              // weighted_pred_flag
         d.weighted_bipred_idc = (int)br.get(2);
         if (d.weighted_bipred_idc == 1) return reject(__LINE__);
         d.pic_init_qp = 26 + br.se(); br.se();
@@ -1188,6 +1200,17 @@ bool decode_nal(Decoder &d, const uint8_t *nal, size_t n)
                 }
                 if ((int)list.size() < nact) return reject(__LINE__);  // refers to pictures not in the DPB
                 for (int i = 0; i < nact; i++) { d.list_slot[l][i] = list[(size_t)i].slot; d.list_poc[l][i] = list[(size_t)i].poc; }
+            }
+        }
+        if (d.weighted_pred && st == 0) {                   // pred_weight_table()
+            d.luma_logwd = (int)br.ue(); d.chroma_logwd = (int)br.ue();
+            if (d.luma_logwd > 7 || d.chroma_logwd > 7) return reject(__LINE__);
+            for (int i = 0; i < d.nref_active; i++) {
+                d.wp[i].lw = 1 << d.luma_logwd; d.wp[i].lo = 0;
+                d.wp[i].cw[0] = d.wp[i].cw[1] = 1 << d.chroma_logwd; d.wp[i].co[0] = d.wp[i].co[1] = 0;
+                if (br.get1()) { d.wp[i].lw = br.se(); d.wp[i].lo = br.se(); }
+                if (br.get1()) for (int c = 0; c < 2; c++) { d.wp[i].cw[c] = br.se(); d.wp[i].co[c] = br.se(); }
+                if (d.wp[i].lw < -128 || d.wp[i].lw > 127 || d.wp[i].lo < -128 || d.wp[i].lo > 127) return reject(__LINE__);
             }
         }
         if (nal_ref_idc) {

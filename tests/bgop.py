@@ -12,12 +12,12 @@ from x264vfw_amd.lib import Pic
 from x264vfw_amd.gop import HostDpb, follow_of, schedule  # noqa: E402,F401
 
 
-def encode_gop(HL, enc, frames, types, cfg, qp_i, qp_p, qp_b, refs, bframes=3, pyramid=1):
+def encode_gop(HL, enc, frames, types, cfg, qp_i, qp_p, qp_b, refs, bframes=3, pyramid=1, weightp=0, pics_out=None):
     """encodes `frames` (display order) with picture types `types` through `enc` (anything with encode_pic(i420, pic) -> mbs, lv and recon());
     returns (annex-B stream, [recon per coding position], coding order, pocs)"""
     w, h = cfg.width, cfg.height
     mbw, mbh = (w + 15) // 16, (h + 15) // 16
-    dpb = HostDpb(HL, refs, bframes, pyramid)
+    dpb = HostDpb(HL, refs, bframes, pyramid, weightp=weightp)
     stream = dpb.headers(w, h, qp_p, cfg.chroma_qp_offset, refs, cfg.dct8x8, cfg.weightb)
     order = schedule(types, pyramid)
     recons, pocs = [], []
@@ -26,6 +26,8 @@ def encode_gop(HL, enc, frames, types, cfg, qp_i, qp_p, qp_b, refs, bframes=3, p
         pic, info = dpb.plan(pt, disp, follow_of(order, k))
         pic.qp = qp_i if pt <= 1 else qp_p if pt == 2 else qp_b if pt == 4 else (qp_p + qp_b) // 2
         mbs, lv = enc.encode_pic(frames[disp], pic)
+        if pics_out is not None:
+            pics_out.append((pic, mbs))
         stream += dpb.slice(mbw, mbh, pic.qp, qp_p, idr_id, 0 if cfg.deblock else 1, refs, cfg.dct8x8, mbs, lv)
         recons.append(enc.recon())
         pocs.append(pic.poc)

@@ -155,6 +155,7 @@ MB_DTYPE = np.dtype([("type", "u1"), ("i16_mode", "u1"), ("chroma_mode", "u1"), 
 assert MB_DTYPE.itemsize == 64 == C.sizeof(MbRecord)
 SLICE_P, SLICE_B, SLICE_I, SLICE_I_NONIDR = 0, 1, 2, 3
 MB_B_DIRECT, MB_B_SKIP, MB_B_INTER, MB_B_8x8 = 7, 8, 9, 10
+MB_P_L0, MB_P_8x8, MB_P_SKIP = 4, 5, 6
 
 
 def mb_ref1(mbs):

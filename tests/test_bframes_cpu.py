@@ -15,12 +15,12 @@ MEDIUM = dict(refs=3, dpb=4, weightb=1, partitions=7, dct8x8=1, chroma_me=1, mix
               chroma_qp_offset=-2, trellis=63)
 
 
-def run(w, h, types, seed, bframes=3, pyramid=1, **over):
+def run(w, h, types, seed, bframes=3, pyramid=1, weightp=0, pics_out=None, **over):
     kw = dict(MEDIUM, **over)
     frames = synth_frames(w, h, len(types), seed=seed)
     cfg = O.default_config(w, h, **kw)
     enc = O.OracleEncoder(cfg)
-    stream, recons, order, pocs = bgop.encode_gop(HL, enc, frames, types, cfg, 20, 23, 25, kw["refs"], bframes, pyramid)
+    stream, recons, order, pocs = bgop.encode_gop(HL, enc, frames, types, cfg, 20, 23, 25, kw["refs"], bframes, pyramid, weightp, pics_out)
     dec = O.h264_decode(stream, len(order), w, h)
     assert len(dec) == len(order)
     assert O.h264_last_pocs() == pocs
@@ -38,6 +38,30 @@ def run(w, h, types, seed, bframes=3, pyramid=1, **over):
 ])
 def test_b_pictures_decode_to_the_encoders_reconstruction(w, h, types, seed, over):
     run(w, h, types, seed, **over)
+
+
+@pytest.mark.parametrize("w,h,types,seed,over", [
+    (176, 144, "IPPPPP", 4, {}),                                                  # P pictures only: lists of 1, then ref0 + duplicate + ...
+    (176, 144, "IBBBPBBBPBP", 5, {}),                                             # medium
+    (128, 96, "IPPBBPPP", 8, dict(refs=5, dpb=5, mixed_refs=0)),
+    (96, 80, "IPPPP", 2, dict(refs=2, rd=0, trellis=0, subme=5, psy=0, psy_rd_q8=0)),
+    (208, 112, "IPPPP", 3, dict(me_method=2, subme=6)),
+    (176, 144, "IPPP", 7, dict(rd=0, trellis=0, subme=4, psy=0, psy_rd_q8=0)),
+])
+def test_weightp_2_blind_duplicate_of_reference_0(w, h, types, seed, over):
+    """x264 --weightp 2 on content without fades: every P picture with two or more references carries a duplicate of reference 0 at index 1 with
+    the explicit luma weight {1, denom 0, offset -1} (pred_weight_table + list modification naming the picture twice); the decoder's explicit
+    weighted prediction (8.4.2.3.2) must land on the encoder's reconstruction, and the duplicate must actually get used"""
+    pics = []
+    _, order = run(w, h, types, seed, weightp=2, pics_out=pics, **over)
+    dupes = used = 0
+    for pic, mbs in pics:
+        if pic.blind_dupe > 0:
+            dupes += 1
+            assert pic.slot[0][0] == pic.slot[0][1] and pic.wl0[1].on and pic.wl0[1].offset == -1 and pic.wl0[1].scale == 1 and pic.wl0[1].denom == 0
+            inter = (mbs["type"] == O.MB_P_L0) | (mbs["type"] == O.MB_P_8x8)
+            used += int(((mbs["ref"] == 1) & inter[..., None]).sum())
+    assert dupes >= 2 and used > 0
 
 
 def test_without_pyramid_every_b_is_disposable():

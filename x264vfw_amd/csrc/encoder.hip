@@ -331,7 +331,7 @@ static int encode_core(x264gpu_encoder *e, const uint8_t *d_i420, const x264gpu_
     ARG_TRY(pic.dst >= 0 && pic.dst < e->slots && pic.qp >= 0 && pic.qp <= 51);
     ARG_TRY(!bslice || (e->cfg.rd && e->cfg.cabac && e->cfg.dpb > 0 && e->cfg.me_method == 1 && (e->cfg.slices <= 1)));      // B pictures: RD sessions with CABAC, --me hex, one slice
     const int n0 = slice_type == X264GPU_SLICE_I ? 0 : pic.nref[0], n1 = bslice ? pic.nref[1] : 0;
-    ARG_TRY(n0 >= 0 && n0 <= 5 && n1 >= 0 && n1 <= 3 && (slice_type == X264GPU_SLICE_I || n0 > 0) && (!bslice || n1 > 0));
+    ARG_TRY(n0 >= 0 && n0 <= 7 && n1 >= 0 && n1 <= 3 && n0 + n1 <= 8 && (slice_type == X264GPU_SLICE_I || n0 > 0) && (!bslice || n1 > 0));      // list 0: up to 5 pictures + --weightp duplicates
     for (int l = 0; l < 2; l++) for (int r = 0; r < (l ? n1 : n0); r++) ARG_TRY(pic.slot[l][r] >= 0 && pic.slot[l][r] < e->slots && pic.slot[l][r] != pic.dst);
     const int S = e->cfg.streams;
     EncK k = e->k;
@@ -341,6 +341,21 @@ static int encode_core(x264gpu_encoder *e, const uint8_t *d_i420, const x264gpu_
     const int cur = pic.dst;
     k.rec_luma = e->luma[cur]; k.rec_chroma = e->chroma[cur];
     k.nref = n0; k.nref1 = n1;
+    // --weightp: explicit luma weights of a P picture's list 0 and x264's blind duplicate of reference 0
+    k.blind_dupe = 0; k.wp_any = 0;
+    for (int r = 0; r < 8; r++) k.wl0[r] = 0;
+    if (slice_type == X264GPU_SLICE_P) {
+        for (int r = 0; r < n0; r++)
+            if (pic.wl0[r].on) {
+                ARG_TRY(pic.wl0[r].denom >= 0 && pic.wl0[r].denom <= 7 && pic.wl0[r].scale >= -128 && pic.wl0[r].scale <= 127 && pic.wl0[r].offset >= -128 && pic.wl0[r].offset <= 127);
+                k.wl0[r] = (int)(uint8_t)(int8_t)pic.wl0[r].offset | (int)(uint8_t)(int8_t)pic.wl0[r].scale << 8 | pic.wl0[r].denom << 16 | 1 << 24;
+                k.wp_any = 1;
+            }
+        if (pic.blind_dupe > 0) {
+            ARG_TRY(pic.blind_dupe == 1 && n0 >= 2 && pic.slot[0][1] == pic.slot[0][0]);      // x264 places it right behind reference 0
+            k.blind_dupe = 1; k.wp_any = 1;
+        }
+    }
     auto slot_of = [&](int ri) { return (int)(ri < n0 ? pic.slot[0][ri] : pic.slot[1][ri - n0]); };      // combined index: list 0, then list 1
     for (int r = 0; r < 8; r++) {
         const int slot = n0 + n1 > 0 ? slot_of(r < n0 + n1 ? r : 0) : cur;
@@ -481,7 +496,8 @@ int x264gpu_encode_pictures(x264gpu_encoder *e, const uint8_t *d_i420, const x26
     bool same_qp = true;
     for (int s = 1; s < S; s++) {
         ARG_TRY(pics[s].slice_type == pics[0].slice_type && pics[s].poc == pics[0].poc && pics[s].dst == pics[0].dst && pics[s].keep == pics[0].keep &&
-                pics[s].nref[0] == pics[0].nref[0] && pics[s].nref[1] == pics[0].nref[1] && !memcmp(pics[s].slot, pics[0].slot, sizeof(pics[0].slot)));
+                pics[s].nref[0] == pics[0].nref[0] && pics[s].nref[1] == pics[0].nref[1] && !memcmp(pics[s].slot, pics[0].slot, sizeof(pics[0].slot)) &&
+                pics[s].blind_dupe == pics[0].blind_dupe && !memcmp(pics[s].wl0, pics[0].wl0, sizeof(pics[0].wl0)));
         same_qp = same_qp && pics[s].qp == pics[0].qp;
     }
     if (!same_qp) {

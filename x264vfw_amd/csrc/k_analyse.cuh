@@ -43,6 +43,15 @@ __device__ __forceinline__ int sad_row16_lds(const uint8_t *wrow, int xoff, cons
     s = __builtin_amdgcn_sad_u8(__builtin_amdgcn_alignbyte(w4, w3, sh), cr[3], s);
     return (int)s;
 }
+// the 16 bytes at (row base `wrow`, byte offset xoff) in LDS
+__device__ __forceinline__ void row16_lds(const uint8_t *wrow, int xoff, uint32_t out[4])
+{
+    const uint32_t *w = (const uint32_t *)(wrow + (xoff & ~3));
+    const int sh = xoff & 3;
+    const uint32_t w0 = w[0], w1 = w[1], w2 = w[2], w3 = w[3], w4 = w[4];
+    out[0] = __builtin_amdgcn_alignbyte(w1, w0, sh); out[1] = __builtin_amdgcn_alignbyte(w2, w1, sh);
+    out[2] = __builtin_amdgcn_alignbyte(w3, w2, sh); out[3] = __builtin_amdgcn_alignbyte(w4, w3, sh);
+}
 __device__ __forceinline__ int sad_row16_global(const uint8_t *p, const uint32_t cr[4])
 {
     unsigned s = 0;

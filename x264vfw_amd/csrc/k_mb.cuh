@@ -149,6 +149,7 @@ struct MeJob {
     int mvpx, mvpy;
     int n_mvc;                 // raw candidates in L.mvc_in
     bool search;               // false: refinement only (b_refine_qpel)
+    bool qonly = false;        // x264_me_refine_qpel_refdupe: a search that starts at the given vector and skips the full-pel stage
     int hp_it, qp_it;
     bool use_thresh;
 };
@@ -192,7 +193,7 @@ __device__ __forceinline__ void rc_row(const uint32_t *slot, int X0, int Y0, int
 }
 
 template <int M, int ME>
-__device__ __forceinline__ void me_search(const EncK &k, MbLds<M> &L, const MbCtx &c, const MeJob &j, int &mvx, int &mvy, int &cost, int &cost_mv, int &halfpel_thresh, const MeState &S, WinTags &wt, Prof &pf)
+__device__ __forceinline__ void me_search(const EncK &k, MbLds<M> &L, const MbCtx &c, const MeJob &j, int &mvx, int &mvy, int &cost, int &cost_mv, int &halfpel_thresh, const MeState &S, WinTags &wtg, Prof &pf)
 {
     pf.mark(PH_ME_GLUE);
     const int lane = c.lane, r = lane & 15, cnd = lane >> 4;
@@ -200,6 +201,12 @@ __device__ __forceinline__ void me_search(const EncK &k, MbLds<M> &L, const MbCt
     const uint8_t *p00 = ref_plane00(k, c.s, j.ref);
     const size_t pb = k.plane_bytes;
     const int bx = c.px + j.ox, by = c.py + j.oy;
+    // explicit luma weight of this reference (P slices, --weightp): every sample fetched below goes through it after interpolation; the
+    // reference cache holds the unweighted planes under the PICTURE's tag, so an index and its duplicate share a slot
+    const int wpk = k.wp_any ? uni(k.wl0[j.ref]) : 0;
+    const bool wt = (wpk >> 24) != 0;
+    const int cref = k.wp_any ? ref_picture(k, j.ref) : j.ref;
+#define WP4X4(p) do { if (wt) { p[0] = wp4(p[0], wpk); p[1] = wp4(p[1], wpk); p[2] = wp4(p[2], wpk); p[3] = wp4(p[3], wpk); } } while (0)
     uint32_t e[4] = { 0, 0, 0, 0 };
     if (rowok) {
         const uint8_t *f = L.src + (j.oy + r) * 16 + j.ox;
@@ -217,6 +224,7 @@ __device__ __forceinline__ void me_search(const EncK &k, MbLds<M> &L, const MbCt
     auto sad_global = [&](int qx, int qy) {
         uint32_t p[4];
         mc_row_global(p00, pb, k.rs, bx, by + r, qx, qy, w16, p);
+        WP4X4(p);
         unsigned sd = __builtin_amdgcn_sad_u8(p[0], e[0], 0u);
         sd = __builtin_amdgcn_sad_u8(p[1], e[1], sd); sd = __builtin_amdgcn_sad_u8(p[2], e[2], sd); sd = __builtin_amdgcn_sad_u8(p[3], e[3], sd);
         return row16_sum(rowok ? (int)sd : 0);
@@ -224,10 +232,10 @@ __device__ __forceinline__ void me_search(const EncK &k, MbLds<M> &L, const MbCt
     const int fmin0 = c.fmin0, fmax0 = c.fmax0, fmin1 = c.fmin1, fmax1 = c.fmax1;
     constexpr bool umh = ME == 2, esa = ME == 3, cached = ME == 0 || ME == 1;      // cached: the full-pel steps read the reference-cache slot
     // ---- this reference's slot of the reference cache ----
-    const int slot = j.ref >= 3 ? j.ref - 3 : j.ref;
+    const int slot = cref >= 3 ? cref - 3 : cref;
     uint32_t *rslot = L.rc + slot * RC_SLOT_DW;
-    int X0 = slot == 0 ? wt.x00 : slot == 1 ? wt.x01 : wt.x02, Y0 = slot == 0 ? wt.y00 : slot == 1 ? wt.y01 : wt.y02;
-    bool rhave = (slot == 0 ? wt.ref0 : slot == 1 ? wt.ref1 : wt.ref2) == j.ref;
+    int X0 = slot == 0 ? wtg.x00 : slot == 1 ? wtg.x01 : wtg.x02, Y0 = slot == 0 ? wtg.y00 : slot == 1 ? wtg.y01 : wtg.y02;
+    bool rhave = (slot == 0 ? wtg.ref0 : slot == 1 ? wtg.ref1 : wtg.ref2) == cref;
     auto rc_inside = [&](int x0, int y0, int x1, int y1) { return rhave && x0 >= X0 && x1 <= X0 + RC_COLS && y0 >= Y0 && y1 <= Y0 + RC_ROWS; };
     // the block displaced by full-pel (mx +- rad, my +- rad) / by the quarter-pel vector (qx, qy) / anywhere within M samples of full-pel (cx, cy)
     auto in_fpel = [&](int mx, int my, int rad) { return rc_inside(bx + mx - rad, by + my - rad, bx + mx + rad + j.W, by + my + rad + j.H); };
@@ -256,7 +264,7 @@ __device__ __forceinline__ void me_search(const EncK &k, MbLds<M> &L, const MbCt
 #ifndef MB_PROF_RD
         pf.count(15);
 #endif
-        if (slot == 0) { wt.ref0 = j.ref; wt.x00 = X0; wt.y00 = Y0; } else if (slot == 1) { wt.ref1 = j.ref; wt.x01 = X0; wt.y01 = Y0; } else { wt.ref2 = j.ref; wt.x02 = X0; wt.y02 = Y0; }
+        if (slot == 0) { wtg.ref0 = cref; wtg.x00 = X0; wtg.y00 = Y0; } else if (slot == 1) { wtg.ref1 = cref; wtg.x01 = X0; wtg.y01 = Y0; } else { wtg.ref2 = cref; wtg.x02 = X0; wtg.y02 = Y0; }
         lds_sync();
     };
     auto rc_stage = [&](int cx, int cy) { uint32_t v[20]; rc_issue(cx, cy, v); rc_commit(v); };
@@ -266,7 +274,7 @@ __device__ __forceinline__ void me_search(const EncK &k, MbLds<M> &L, const MbCt
     bool spec_on = false;
     int spx = 0, spy = 0;
 
-    if (j.search) {
+    if (j.search && !j.qonly) {
         int bmx, bmy, bcost, bpred_cost = MB_COST_MAX, bpred_mx = 0, bpred_my = 0, pmx, pmy;
         const bool sub3 = c.subme >= 3;
         // ---- predictor + candidates (L.cand[0] = the predictor, then the surviving candidates in order) ----
@@ -318,7 +326,7 @@ __device__ __forceinline__ void me_search(const EncK &k, MbLds<M> &L, const MbCt
                     const int qx = L.cand[ii][0], qy = L.cand[ii][1];
                     cqx[t] = qx; cqy[t] = qy;
                     inl[t] = !esa && __all(in_qpel(qx, qy));                           // the whole group of four from the slot, or from memory
-                    if (!inl[t]) mc_row_global(p00, pb, k.rs, bx, by + r, qx, qy, w16, pp[t]);
+                    if (!inl[t]) { mc_row_global(p00, pb, k.rs, bx, by + r, qx, qy, w16, pp[t]); WP4X4(pp[t]); }
                     cm[t] = (sub3 || ii > 0) ? mvc(qx, qy) : 0;       // below subme 3 the rounded predictor is costed without its vector bits
                 }
             }
@@ -328,7 +336,7 @@ __device__ __forceinline__ void me_search(const EncK &k, MbLds<M> &L, const MbCt
             for (int t = 0; t < 3; t++)
                 if (t * 4 < n) {
                     const int i = t * 4 + cnd;
-                    if (inl[t]) rc_row(rslot, X0, Y0, bx, by + r, cqx[t], cqy[t], w16, pp[t]);
+                    if (inl[t]) { rc_row(rslot, X0, Y0, bx, by + r, cqx[t], cqy[t], w16, pp[t]); WP4X4(pp[t]); }
                     unsigned sd = __builtin_amdgcn_sad_u8(pp[t][0], e[0], 0u);
                     sd = __builtin_amdgcn_sad_u8(pp[t][1], e[1], sd); sd = __builtin_amdgcn_sad_u8(pp[t][2], e[2], sd); sd = __builtin_amdgcn_sad_u8(pp[t][3], e[3], sd);
                     const int cst = row16_sum(rowok ? (int)sd : 0) + cm[t];
@@ -358,6 +366,15 @@ __device__ __forceinline__ void me_search(const EncK &k, MbLds<M> &L, const MbCt
             const uint8_t *wrow = esa ? (const uint8_t *)L.rc + (by + my + r - wy0) * WIN_STRIDE : (const uint8_t *)rslot + (by + my + r - Y0) * RC_COLS;
             const int xo = bx + mx - (esa ? wx0 : X0);
             int sd = 0;
+            if (wt) {       // x264 searches the weighted copy of the plane (p_fref_w): pointwise, so weight the row read from the unweighted one
+                uint32_t p[4];
+                row16_lds(wrow, xo, p);
+                WP4X4(p);
+                unsigned s2 = __builtin_amdgcn_sad_u8(p[0], e[0], 0u);
+                s2 = __builtin_amdgcn_sad_u8(p[1], e[1], s2);
+                if (w16) { s2 = __builtin_amdgcn_sad_u8(p[2], e[2], s2); s2 = __builtin_amdgcn_sad_u8(p[3], e[3], s2); }
+                sd = rowok ? (int)s2 : 0;
+            } else
             if (rowok) sd = w16 ? sad_row16_lds(wrow, xo, e) : sad8_lds(wrow, xo, e[0], e[1]);
             return row16_sum(sd) + MVC(mx * 4, my * 4);
         };
@@ -370,6 +387,16 @@ __device__ __forceinline__ void me_search(const EncK &k, MbLds<M> &L, const MbCt
             const uint8_t *wrow = (const uint8_t *)rslot + (by + my + r8 - Y0) * RC_COLS;
             const int xo = bx + mx - X0;
             int sd;
+            if (wt) {
+                uint32_t p[4];
+                row16_lds(wrow, xo, p);
+                WP4X4(p);
+                const uint4 sv = *(const uint4 *)f;
+                unsigned s2 = __builtin_amdgcn_sad_u8(p[0], sv.x, 0u);
+                s2 = __builtin_amdgcn_sad_u8(p[1], sv.y, s2);
+                if (w16) { s2 = __builtin_amdgcn_sad_u8(p[2], sv.z, s2); s2 = __builtin_amdgcn_sad_u8(p[3], sv.w, s2); }
+                sd = (int)s2;
+            } else
             if (w16) { const uint4 sv = *(const uint4 *)f; const uint32_t e8[4] = { sv.x, sv.y, sv.z, sv.w }; sd = sad_row16_lds(wrow, xo, e8); }
             else { const uint2 sv = *(const uint2 *)f; sd = sad8_lds(wrow, xo, sv.x, sv.y); }
             sd = quad_sum(sd); sd += dpp<DPP_ROW_HALF_MIRROR>(sd);
@@ -411,7 +438,7 @@ __device__ __forceinline__ void me_search(const EncK &k, MbLds<M> &L, const MbCt
         }
         if (esa) {      // its window around the start
             lds_sync();
-            wt.ref0 = wt.ref1 = wt.ref2 = -1; rhave = false;
+            wtg.ref0 = wtg.ref1 = wtg.ref2 = -1; rhave = false;
             wx0 = clampi((bx + bmx - WIN_R) & ~7, -PAD, k.cw + PAD - WIN_COLS); wy0 = clampi(by + bmy - WIN_R, -PAD, k.ch + PAD - WIN_ROWS);
             for (int i = lane; i < WIN_ROWS * 8; i += 64) {
                 const int row = i >> 3, col = (i & 7) * 8;
@@ -628,7 +655,7 @@ __device__ __forceinline__ void me_search(const EncK &k, MbLds<M> &L, const MbCt
     auto mvc2 = [&](int qx, int qy) { return mvc(qx, qy); };
     auto fetch2 = [&](int qx, int qy, uint32_t p[4]) {
         p[0] = p[1] = p[2] = p[3] = 0;
-        if (rowok) rc_row(rslot, X0, Y0, bx, by + r, qx, qy, w16, p);
+        if (rowok) { rc_row(rslot, X0, Y0, bx, by + r, qx, qy, w16, p); WP4X4(p); }
     };
     auto sad2 = [&](int qx, int qy) {
         uint32_t p[4];
@@ -691,6 +718,7 @@ __device__ __forceinline__ void me_search(const EncK &k, MbLds<M> &L, const MbCt
     mvx = __builtin_amdgcn_readfirstlane(bmx); mvy = __builtin_amdgcn_readfirstlane(bmy); cost = bcost;
     cost_mv = mvc2(mvx, mvy);
     pf.mark(PH_ME_SUBPEL);
+#undef WP4X4
 }
 
 
@@ -1256,7 +1284,8 @@ __device__ __forceinline__ bool mb_probe_pskip(const EncK &k, const MbCtx &c, ui
     const int mvx = clampi(pmx, c.mvmin0, c.mvmax0), mvy = clampi(pmy, c.mvmin1, c.mvmax1);
     bool ok;
     {
-        const uint32_t pred = mc_luma_row4(ref_plane00(k, c.s, 0), k.plane_bytes, k.rs, c.px + zx, c.py + zy, mvx, mvy);
+        uint32_t pred = mc_luma_row4(ref_plane00(k, c.s, 0), k.plane_bytes, k.rs, c.px + zx, c.py + zy, mvx, mvy);
+        if (k.wp_any && (k.wl0[0] >> 24)) pred = wp4(pred, k.wl0[0]);
         int e[4], p[4], v[4];
         unpack4(cz, e); unpack4(pred, p);
 #pragma unroll
@@ -1584,7 +1613,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(MB_WAVES_PER
             const bool t1 = k.temporal && mbx < k.mbw - 1, t2 = k.temporal && mby < k.mbh - 1;
             auto gather16 = [&](int r, int ln, int &vx, int &vy) {
                 const int i = ln & 15;
-                const int16_t *mvr = (r == 0 ? k.mv16_cur : r == 1 ? k.mvr[1] : r == 2 ? k.mvr[2] : r == 3 ? k.mvr[3] : k.mvr[4]) + (size_t)s * k.nmb * 2;
+                const int16_t *mvr = (r == 0 ? k.mv16_cur : r == 1 ? k.mvr[1] : r == 2 ? k.mvr[2] : r == 3 ? k.mvr[3] : r == 4 ? k.mvr[4] : r == 5 ? k.mvr[5] : k.mvr[6]) + (size_t)s * k.nmb * 2;
                 const int base = has_lr && r == 0 ? 1 : 0, q = i - base;
                 vx = 0; vy = 0;
                 if (base && i == 0) { const int16_t *lm = k.lowres_mv + (size_t)s * k.nmb * 2; vx = lm[2 * mbi] * 2; vy = lm[2 * mbi + 1] * 2; }
@@ -1594,7 +1623,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(MB_WAVES_PER
                 } else if (q >= 4 && q < 7 && k.temporal) {
                     // co-located; then its right neighbour (if there is one), then its lower neighbour (if there is one)
                     const int16_t *l0 = k.mv16_ref0 + (size_t)s * k.nmb * 2;
-                    const int scale = r == 0 ? k.tscale[0] : r == 1 ? k.tscale[1] : r == 2 ? k.tscale[2] : r == 3 ? k.tscale[3] : k.tscale[4], jx = q - 4;
+                    const int scale = r == 0 ? k.tscale[0] : r == 1 ? k.tscale[1] : r == 2 ? k.tscale[2] : r == 3 ? k.tscale[3] : r == 4 ? k.tscale[4] : r == 5 ? k.tscale[5] : k.tscale[6], jx = q - 4;
                     const bool ok = jx == 0 || (jx == 1 && (t1 || t2)) || (jx == 2 && t1 && t2);
                     const int at = jx == 0 ? mbi : (jx == 1 && t1) ? mbi + 1 : mbi + k.mbw;
                     if (ok) { vx = (l0[2 * at] * scale + 128) >> 8; vy = (l0[2 * at + 1] * scale + 128) >> 8; }
@@ -1609,6 +1638,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(MB_WAVES_PER
             int i_maxref = c.nref - 1, ref_a = 0, ref_b = 0;      // 8x8: highest reference tried; 16x8 / 8x16: the two candidate references
             int est1 = 0;
             int sat8[4] = { 0, 0, 0, 0 };
+            // --weightp 2: the blind duplicate of reference 0 (always index 1) is never searched — it always follows a search of reference 0 on the
+            // same block and starts from that result (prev_*; x264_me_refine_qpel_refdupe).  0 = the slice has none
+            const int dupe = k.blind_dupe;
+            int prev_mvx = 0, prev_mvy = 0, prev_cost = 0;
             bool done = pskip;
             WinTags wt;
             wt.ref0 = wt.ref1 = wt.ref2 = -1; wt.x00 = wt.x01 = wt.x02 = wt.y00 = wt.y01 = wt.y02 = 0;
@@ -1632,7 +1665,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(MB_WAVES_PER
                 lds_sync();
                 MeJob jb;
                 int slot, r;
-                jb.search = stage < 4; jb.use_thresh = false; jb.n_mvc = 0;
+                jb.search = stage < 4; jb.use_thresh = false; jb.n_mvc = 0; jb.qonly = false;
                 if (stage == 0) {
                     r = kk; slot = ME_16;
                     jb.W = 16; jb.H = 16; jb.ox = 0; jb.oy = 0;
@@ -1643,7 +1676,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(MB_WAVES_PER
                         // raw candidate i of reference r: gathered for references 0..3 in one trip before the loop (gvx / gvy, lane = r * 16 + i)
                         const int base = has_lr ? (r == 0 ? 1 : 0) : 0;
                         if (r < 4) { S.inx = __shfl(gvx, r * 16 + (lane & 15)); S.iny = __shfl(gvy, r * 16 + (lane & 15)); }
-                        else { int vx, vy; gather16(4, lane, vx, vy); S.inx = vx; S.iny = vy; }
+                        else { int vx, vy; gather16(r, lane, vx, vy); S.inx = vx; S.iny = vy; }
                         jb.n_mvc = base + 4 + (k.temporal ? 1 + (t1 ? 1 : 0) + (t2 ? 1 : 0) : 0);
                     }
                     lds_sync();
@@ -1651,7 +1684,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(MB_WAVES_PER
                     jb.hp_it = c.subme >= 2 ? (c.subme < 6 ? 1 : c.subme < 8 ? 2 : 4) : 0;
                     jb.qp_it = c.subme < 4 ? 0 : c.subme == 4 ? 1 : c.subme < 8 ? 2 : 10;
                 } else if (stage == 1) {
-                    r = mixed ? kk : rl(S.ref, ME_16); slot = ME_8 + part;
+                    // mixed references: 0 .. i_maxref, then the duplicate if the early termination cut the loop short of it; else the 16x16 choice
+                    // (a duplicate stands for reference 0 there: its reference bits rarely pay in P_8x8)
+                    r = mixed ? (kk > i_maxref ? dupe : kk) : (dupe && rl(S.ref, ME_16) == dupe ? 0 : rl(S.ref, ME_16)); slot = ME_8 + part;
                     jb.W = 8; jb.H = 8; jb.ox = 8 * (part & 1); jb.oy = 8 * (part >> 1);
                     mb_predict_mv(S, D_8x8, part & 1, part >> 1, 1, r, jb.mvpx, jb.mvpy);
                     { const int q = r * 5 + min(lane, 4); S.inx = __shfl(S.mvcx, q); S.iny = __shfl(S.mvcy, q); }        // lane i <- mvc[r][i], i <= part
@@ -1684,13 +1719,18 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(MB_WAVES_PER
                     jb.qp_it = c.subme < 4 ? 0 : c.subme == 4 ? 1 : c.subme < 8 ? 2 : 10;
                 }
                 jb.ref = r;
+                if (dupe && r == dupe && (stage < 2 || (stage < 4 && kk == 1 && ref_a == 0))) {
+                    jb.qonly = true; jb.hp_it = 0; jb.qp_it = c.subme < 4 ? 0 : c.subme == 4 ? 1 : 2;      // min(2, subpel_iterations[subme][3])
+                }
                 lds_sync();
                 const int rc = ref_bits(c.nref, r) * c.lambda;
                 int mvx = 0, mvy = 0, cost = 0, cost_mv = 0;
+                if (jb.qonly) { mvx = prev_mvx; mvy = prev_mvy; cost = prev_cost; }
                 if (stage == 0) halfpel_thresh -= rc;
                 if (stage == 4) { mvx = rl(S.mvx, slot); mvy = rl(S.mvy, slot); cost = rl(S.cost, slot) - rl(S.refcost, slot); cost_mv = rl(S.costmv, slot); }
                 me_search<M, ME>(k, L, c, jb, mvx, mvy, cost, cost_mv, halfpel_thresh, S, wt, pf);
                 pf.count(13 + (stage == 4));
+                prev_mvx = mvx; prev_mvy = mvy; prev_cost = cost + rc;
                 lds_sync();
                 // ---- merge / advance ----
                 if (stage == 0) {
@@ -1713,11 +1753,15 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(MB_WAVES_PER
                     stage = 1; part = 0; kk = 0;
                     i_maxref = c.nref - 1;
                     if (mixed) {
-                        if (early_term && i_maxref > 0 && rl(S.ref, ME_16) == 0 && type_top > 0 && type_left > 0) {
-                            i_maxref = max(max(max(rl(S.cref, 0), rl(S.cref, 1)), max(rl(S.cref, 2), rl(S.cref, 3))), max(max(rl(S.cref, 4), rl(S.cref, 8)), 0));
+                        if (early_term && i_maxref > 0 && (rl(S.ref, ME_16) == 0 || (dupe && rl(S.ref, ME_16) == dupe)) && type_top > 0 && type_left > 0) {
+                            auto nbr = [&](int g) { const int v = rl(S.cref, g); return dupe && v == dupe ? 0 : v; };      // a neighbour's duplicate does not count
+                            i_maxref = max(max(max(nbr(0), nbr(1)), max(nbr(2), nbr(3))), max(max(nbr(4), nbr(8)), 0));
                         }
-                        nk = i_maxref + 1;
-                    } else nk = 1;
+                        nk = i_maxref + 1 + (dupe > i_maxref ? 1 : 0);
+                    } else {
+                        nk = 1;
+                        if (dupe && rl(S.ref, ME_16) == dupe) { wl(S.mvcx, lane, 0, rl(S.mvx, ME_16)); wl(S.mvcy, lane, 0, rl(S.mvy, ME_16)); }      // mvc[0] = the 16x16 winner's vector (x264 analyse_inter_p8x8)
+                    }
                     if (lane == 5 || lane == 6 || lane == 9 || lane == 10) S.cref = -2;      // this macroblock's blocks: not decided yet
                     wl(S.cost, lane, ME_8, 0x7fffffff);
                     continue;
@@ -1942,6 +1986,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(MB_WAVES_PER
                 lmx = __shfl(S.mvx, slot); lmy = __shfl(S.mvy, slot); lref = __shfl(S.ref, slot);      // slot varies with the lane (its 8x8 block)
             }
             pred = mc_luma_row4(ref_plane00(k, s, lref), k.plane_bytes, k.rs, c.px + zx, c.py + zy, lmx, lmy);
+            if (k.wp_any) { const int wpk = k.wl0[lref]; if (wpk >> 24) pred = wp4(pred, wpk); }      // lref varies with the lane's 8x8 block
             // chroma prediction: chroma 4x4 block ci <-> luma 8x8 ci
             const int cmvx = __shfl(lmx, ci * 16), cmvy = __shfl(lmy, ci * 16), cref = __shfl(lref, ci * 16);
             uint32_t pu, pv;

@@ -31,9 +31,10 @@ def schedule(types, pyramid=1):
 
 
 class HostDpb:
-    def __init__(self, HL, refs, bframes, pyramid, log2_max_frame_num=4):
+    def __init__(self, HL, refs, bframes, pyramid, log2_max_frame_num=4, weightp=0):
         self.HL, self.H = HL, HL.H
-        self.h = self.H.x264host_dpb_new(refs, bframes, pyramid, log2_max_frame_num)
+        self.weightp = weightp
+        self.h = self.H.x264host_dpb_new(refs, bframes, pyramid, log2_max_frame_num, weightp)
         a, b = C.c_int(), C.c_int()
         self.slots = self.H.x264host_dpb_info(self.h, C.byref(a), C.byref(b))
         self.max_dpb, self.num_reorder = a.value, b.value
@@ -58,7 +59,7 @@ class HostDpb:
     def headers(self, w, h, pic_init_qp, cqo, num_ref_default, t8x8, weightb):
         buf = np.zeros(256, np.uint8)
         n = self.H.x264host_write_headers_b(w, h, 40, self.log2_max_frame_num, pic_init_qp, cqo, 1, 50, num_ref_default, t8x8, 1, self.max_dpb,
-                                            self.log2_max_poc_lsb, self.num_reorder, 2 if weightb else 0, buf.ctypes.data, buf.size)
+                                            self.log2_max_poc_lsb, self.num_reorder, 2 if weightb else 0, 1 if self.weightp else 0, buf.ctypes.data, buf.size)
         assert n > 0
         return bytes(buf[:n])
 

@@ -6,7 +6,10 @@
 //     min(--ref, num_reorder_frames);
 //   * the default initial order of 8.2.4.2 is by picture number (P) / POC (B): where x264's order differs, the whole list is sent as modifications;
 //   * sliding window of sps num_ref_frames pictures; under --b-pyramid a B-reference whose mini-GOP holds a b displayed later than the reorder depth
-//     allows removes pictures from the END of list 0 by MMCO (x264: i_mmco_remove_from_end) so the delayed b's find room.
+//     allows removes pictures from the END of list 0 by MMCO (x264: i_mmco_remove_from_end) so the delayed b's find room;
+//   * --weightp 2: every P picture with at least two references gets a DUPLICATE of reference 0 at index 1 carrying the luma weight
+//     {scale 1, denom 0, offset -1} (x264 weighted_reference_duplicate, h->mb.ref_blind_dupe): the list grows by one, the whole list is sent as
+//     modifications (the duplicate is a picture-number difference of 0, coded as abs_diff_pic_num_minus1 = MaxFrameNum - 1).
 #pragma once
 #include "host.hpp"
 #include <stdlib.h>
@@ -32,14 +35,15 @@ struct DpbPlan {
 class Dpb {
 public:
     struct Ref { int slot, frame, frame_num, poc, type; };
-    int max_dpb = 1, max_ref0 = 1, max_ref1 = 0, pyramid = 0, num_reorder = 0, log2_max_frame_num = 4;
+    int max_dpb = 1, max_ref0 = 1, max_ref1 = 0, pyramid = 0, num_reorder = 0, log2_max_frame_num = 4, weightp = 0;
     std::vector<Ref> refs;       // h->frames.reference: kept pictures in coding order
     int frame_num = 0, last_idr = 0;
     DpbPlan last;
 
     // sps->i_num_ref_frames, vui.i_num_reorder_frames and the list limits of x264 for --ref / --bframes / --b-pyramid
-    void configure(int frame_reference, int bframes, int b_pyramid, int log2_max_fn)
+    void configure(int frame_reference, int bframes, int b_pyramid, int log2_max_fn, int weighted_pred = 0)
     {
+        weightp = weighted_pred;
         pyramid = bframes > 1 ? b_pyramid : 0;
         num_reorder = pyramid ? 2 : bframes ? 1 : 0;
         max_dpb = std::max(std::max(frame_reference, 1 + num_reorder), pyramid ? 4 : 1);
@@ -96,6 +100,13 @@ public:
         if ((int)l[1].size() > max_ref1) l[1].resize((size_t)max_ref1);
         if ((int)l[0].size() > max_ref0) l[0].resize((size_t)max_ref0);
         if (type == PIC_P) l[1].clear();
+        p.pic.blind_dupe = -1;
+        if (type == PIC_P && weightp == 2 && l[0].size() > 1) {       // the blind duplicate of reference 0
+            l[0].insert(l[0].begin() + 1, l[0][0]);
+            reorder[0] = true;
+            p.pic.blind_dupe = 1;
+            p.pic.wl0[1].on = 1; p.pic.wl0[1].denom = 0; p.pic.wl0[1].scale = 1; p.pic.wl0[1].offset = -1;
+        }
         for (int k = 0; k < 2; k++) {
             p.num_ref[k] = p.pic.nref[k] = (int)l[k].size();
             for (size_t i = 0; i < l[k].size(); i++) { p.pic.slot[k][i] = (int8_t)l[k][i].slot; p.list_poc[k][i] = l[k][i].poc; }
@@ -134,6 +145,8 @@ public:
         sp.reorder[0] = p.reorder[0]; sp.reorder[1] = p.reorder[1];
         sp.n_mmco = p.n_mmco;
         for (int i = 0; i < p.n_mmco; i++) sp.mmco_diff[i] = p.mmco_diff[i];
+        sp.weighted_pred = weightp > 0;
+        for (int i = 0; i < X264GPU_MAX_LIST; i++) { sp.wl0[i].on = p.pic.wl0[i].on; sp.wl0[i].denom = p.pic.wl0[i].denom; sp.wl0[i].scale = p.pic.wl0[i].scale; sp.wl0[i].offset = p.pic.wl0[i].offset; }
     }
 };
 

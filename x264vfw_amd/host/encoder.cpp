@@ -1216,10 +1216,10 @@ int x264host_write_headers_cabac(int width, int height, int level_idc, int log2_
 }
 
 /* ---- tests: the DPB model (dpb.hpp) and a slice writer driven by it, for B-picture streams built from the CPU checker's records ---- */
-void *x264host_dpb_new(int frame_reference, int bframes, int b_pyramid, int log2_max_frame_num)
+void *x264host_dpb_new(int frame_reference, int bframes, int b_pyramid, int log2_max_frame_num, int weightp)
 {
     Dpb *d = new Dpb();
-    d->configure(frame_reference, bframes, b_pyramid, log2_max_frame_num);
+    d->configure(frame_reference, bframes, b_pyramid, log2_max_frame_num, weightp);
     return d;
 }
 void x264host_dpb_free(void *h) { delete (Dpb *)h; }
@@ -1252,7 +1252,7 @@ int x264host_write_slice_dpb(void *h, int mbw, int mbh, int qp, int pic_init_qp,
 }
 int x264host_write_headers_b(int width, int height, int level_idc, int log2_max_frame_num, int pic_init_qp, int chroma_qp_offset, uint32_t num_units_in_tick,
                              uint32_t time_scale, int num_ref_default, int transform8x8_mode, int cabac, int num_ref_frames, int log2_max_poc_lsb, int num_reorder,
-                             int weighted_bipred_idc, uint8_t *out, int cap)
+                             int weighted_bipred_idc, int weighted_pred, uint8_t *out, int cap)
 {
     SpsParams s = {};
     s.profile_idc = transform8x8_mode ? 100 : 77; s.level_idc = level_idc; s.mbw = (width + 15) / 16; s.mbh = (height + 15) / 16;
@@ -1263,7 +1263,7 @@ int x264host_write_headers_b(int width, int height, int level_idc, int log2_max_
     std::vector<uint8_t> v;
     write_sps(v, s, true);
     PpsParams pp = { 0, 0, cabac, num_ref_default, pic_init_qp, chroma_qp_offset, transform8x8_mode };
-    pp.weighted_bipred_idc = weighted_bipred_idc;
+    pp.weighted_bipred_idc = weighted_bipred_idc; pp.weighted_pred = weighted_pred;
     write_pps(v, pp, true);
     if ((int)v.size() > cap) return -1;
     memcpy(out, v.data(), v.size());

@@ -32,6 +32,10 @@ struct SliceParams {
     struct Reorder { int n = 0; struct { int idc, arg; } cmd[16]; } reorder[2];
     // memory_management_control_operation 1 (mark a short-term picture unused) x n_mmco: difference_of_pic_nums (x264's b-pyramid bookkeeping)
     int n_mmco = 0, mmco_diff[16] = { 0 };
+    // pred_weight_table of P slices (x264 --weightp, PPS weighted_pred_flag): present whenever the PPS flag is set; luma weights only — the chroma
+    // flags are sent as 0.  luma_log2_weight_denom = the denominator of the first weighted index (x264: all weighted indices share it), else 0
+    int weighted_pred = 0;
+    struct { int on, denom, scale, offset; } wl0[X264GPU_MAX_LIST] = {};
 };
 struct SliceStats { int skip; };
 
@@ -46,7 +50,7 @@ struct SpsParams {
     int log2_max_poc_lsb = 0;    // > 0: pic_order_cnt_type 0 (sessions with B pictures), else type 2
     int num_reorder_frames = 0;  // x264: 2 with --b-pyramid, 1 with B pictures, else 0
 };
-struct PpsParams { int pps_id, sps_id, cabac, num_ref, pic_init_qp, chroma_qp_offset, transform8x8_mode; int weighted_bipred_idc = 0; };
+struct PpsParams { int pps_id, sps_id, cabac, num_ref, pic_init_qp, chroma_qp_offset, transform8x8_mode; int weighted_bipred_idc = 0; int weighted_pred = 0; };
 
 void write_sps(std::vector<uint8_t> &out, const SpsParams &s, bool annexb);
 void write_pps(std::vector<uint8_t> &out, const PpsParams &p, bool annexb);

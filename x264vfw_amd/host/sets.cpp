@@ -86,7 +86,7 @@ void write_pps(std::vector<uint8_t> &out, const PpsParams &p, bool annexb)
     bw.ue(0);                                   // num_slice_groups_minus1
     bw.ue(p.num_ref - 1);                       // num_ref_idx_l0_default_active_minus1
     bw.ue(0);                                   // l1
-    bw.put1(0);                                 // weighted_pred_flag
+    bw.put1(p.weighted_pred);                   // weighted_pred_flag (x264: --weightp > 0)
     bw.put((uint32_t)p.weighted_bipred_idc, 2); // weighted_bipred_idc (2: implicit, x264 --weightb)
     bw.se(p.pic_init_qp - 26);
     bw.se(0);                                   // pic_init_qs_minus26

@@ -331,6 +331,17 @@ void write_slice_header(BitWriter &bw, const SliceParams &p)
             }
         }
     }
+    if (p.weighted_pred && p.slice_type == X264GPU_SLICE_P) {   // pred_weight_table()
+        int denom = 0;
+        for (int i = p.num_ref - 1; i >= 0; i--) if (p.wl0[i].on) denom = p.wl0[i].denom;
+        bw.ue((uint32_t)denom);                                 // luma_log2_weight_denom
+        bw.ue(0);                                               // chroma_log2_weight_denom
+        for (int i = 0; i < p.num_ref; i++) {
+            bw.put1(p.wl0[i].on != 0);                          // luma_weight_l0_flag
+            if (p.wl0[i].on) { bw.se(p.wl0[i].scale); bw.se(p.wl0[i].offset); }
+            bw.put1(0);                                         // chroma_weight_l0_flag
+        }
+    }
     if (p.nal_ref_idc) {
         if (p.idr) { bw.put1(0); bw.put1(0); }                  // no_output_of_prior_pics, long_term_reference
         else {

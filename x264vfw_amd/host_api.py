@@ -97,13 +97,13 @@ _sig("x264host_write_picture", _i, [_i] * 15 + [C.c_void_p, C.c_void_p, C.c_void
 _sig("x264host_write_headers_cabac", _i, [_i, _i, _i, _i, _i, _i, C.c_uint32, C.c_uint32, _i, _i, _i, C.c_void_p, _i])
 _sig("x264host_get_recon", _i, [C.c_void_p, C.c_void_p])
 # tests: the DPB model of the host encoder (host/dpb.hpp) and a CABAC slice writer driven by it (streams with B pictures)
-_sig("x264host_dpb_new", C.c_void_p, [_i, _i, _i, _i])
+_sig("x264host_dpb_new", C.c_void_p, [_i, _i, _i, _i, _i])
 _sig("x264host_dpb_free", None, [C.c_void_p])
 _sig("x264host_dpb_info", _i, [C.c_void_p, C.POINTER(_i), C.POINTER(_i)])
 _sig("x264host_dpb_plan", _i, [C.c_void_p, _i, _i, _i, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p])
 _sig("x264host_dpb_commit", None, [C.c_void_p])
 _sig("x264host_write_slice_dpb", _i, [C.c_void_p] + [_i] * 10 + [C.c_void_p, C.c_void_p, C.c_void_p, _i, C.POINTER(_i)])
-_sig("x264host_write_headers_b", _i, [_i] * 6 + [C.c_uint32, C.c_uint32] + [_i] * 7 + [C.c_void_p, _i])
+_sig("x264host_write_headers_b", _i, [_i] * 6 + [C.c_uint32, C.c_uint32] + [_i] * 8 + [C.c_void_p, _i])
 PIC_IDR, PIC_I, PIC_P, PIC_BREF, PIC_B = range(5)
 _sig("x264host_last_decision", _i, [C.c_void_p, C.POINTER(_i), C.POINTER(_i), C.POINTER(C.c_int32)])
 LEVELS = (Level * 21).in_dll(H, "x264_levels")

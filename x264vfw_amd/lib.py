@@ -47,12 +47,14 @@ class Config(C.Structure):
 
 class Pic(C.Structure):
     """Mirror of struct x264gpu_pic (picture control of x264gpu_encode_pictures)."""
+    class W(C.Structure):
+        _fields_ = [("on", C.c_int8), ("denom", C.c_int8), ("scale", C.c_int16), ("offset", C.c_int16)]
     _fields_ = [("slice_type", C.c_int), ("qp", C.c_int), ("poc", C.c_int), ("dst", C.c_int), ("keep", C.c_int), ("nref", C.c_int * 2),
-                ("slot", (C.c_int8 * 8) * 2)]
+                ("slot", (C.c_int8 * 8) * 2), ("wl0", W * 8), ("blind_dupe", C.c_int)]
 
 
 def make_pic(slice_type, qp, poc, dst, keep, l0=(), l1=()):
-    p = Pic(slice_type=slice_type, qp=qp, poc=poc, dst=dst, keep=keep)
+    p = Pic(slice_type=slice_type, qp=qp, poc=poc, dst=dst, keep=keep, blind_dupe=-1)
     p.nref[0], p.nref[1] = len(l0), len(l1)
     for i, s in enumerate(l0):
         p.slot[0][i] = s
