@@ -58,7 +58,8 @@ def main():
         take(size)
     H.x264_encoder_close(h_)
     open(out_path, "wb").write(stream)
-    print(json.dumps({"recs": recs, "bframes": eff.i_bframe, "pyramid": eff.i_bframe_pyramid, "badapt": eff.i_bframe_adaptive, "weightb": eff.analyse.b_weighted_bipred}))
+    print(json.dumps({"recs": recs, "bframes": eff.i_bframe, "pyramid": eff.i_bframe_pyramid, "badapt": eff.i_bframe_adaptive, "weightb": eff.analyse.b_weighted_bipred,
+                      "weightp": eff.analyse.i_weighted_pred, "mbtree": eff.rc.b_mb_tree}))
 
 
 main()

@@ -95,6 +95,7 @@ def test_host_session_with_b_pictures(tmp_path):
     n, w, h = 14, 176, 144
     info, stream = _host_b_session(tmp_path, n, ["qp=23", "keyint=30", "scenecut=0"])
     assert (info["bframes"], info["pyramid"], info["badapt"], info["weightb"]) == (3, 2, 0, 1)      # b-adapt 1 is reported back as what runs: 0
+    assert info["weightp"] == 2                                                                     # medium's --weightp 2 runs (blind duplicate)
     recs = info["recs"]
     assert len(recs) == n
     TYPE = {1: "I", 3: "P", 4: "R", 5: "B"}
@@ -110,6 +111,27 @@ def test_host_session_with_b_pictures(tmp_path):
     from synth import psnr
     for d, p in zip(dec, pocs):
         assert psnr(d[:w * h], frames[p // 2][:w * h]) > 34.0
+
+
+def test_host_session_weightp_2_without_b_pictures(tmp_path):
+    """--bframes 0 --weightp 2: the session runs on the DPB model with no delay (dts = pts, POC type 2), P pictures carry pred_weight_table and
+    the duplicate; --weightp 1 (fade analysis only) and sessions that need the other path (mbtree) report weightp 0"""
+    n, w, h = 9, 176, 144
+    info, stream = _host_b_session(tmp_path, n, ["qp=23", "keyint=30", "scenecut=0", "bframes=0"])
+    assert (info["bframes"], info["weightp"]) == (0, 2)
+    recs = info["recs"]
+    assert [r[0] for r in recs] == [1] + [3] * (n - 1) and [r[1] for r in recs] == list(range(n)) and [r[2] for r in recs] == list(range(n))
+    dec = O.h264_decode(stream, n, w, h)
+    frames = synth_frames(w, h, n, seed=3)
+    from synth import psnr
+    for d, f in zip(dec, frames):
+        assert psnr(d[:w * h], f[:w * h]) > 34.0
+    info0, stream0 = _host_b_session(tmp_path, n, ["qp=23", "keyint=30", "scenecut=0", "bframes=0", "weightp=0"])
+    assert info0["weightp"] == 0 and stream0 != stream
+    info1, _ = _host_b_session(tmp_path, 3, ["qp=23", "bframes=0", "weightp=1"])
+    assert info1["weightp"] == 0
+    info2, _ = _host_b_session(tmp_path, 3, ["crf=23", "bframes=0", "rc-lookahead=10"])
+    assert (info2["weightp"], info2["mbtree"]) == (0, 1)
 
 
 def test_host_session_crf_with_b_pictures_and_keyframes(tmp_path):

@@ -22,6 +22,7 @@ def open_encoder(w, h, opts, profile=b"baseline", preset=b"medium"):
     p.i_log_level = -1
     if "bframes" not in opts:
         opts = dict(opts, bframes=0)          # these sessions test the I / P behaviours (one picture back per call); B sessions: test_b_session_*
+        opts.setdefault("weightp", 0)         # ... of the ring path (--weightp 2 moves a session without B pictures onto the DPB model: test_weightp_session_*)
     for k, v in opts.items():
         assert H.x264_param_parse(C.byref(p), k.encode(), None if v is None else str(v).encode()) == 0, k
     p.b_vfr_input = 0
@@ -553,6 +554,7 @@ def test_sliced_threads_through_the_api(gpu, w, h, opts, slices):
     p.i_log_level = -1
     if "bframes" not in opts:
         opts = dict(opts, bframes=0)          # these sessions test the I / P behaviours (one picture back per call); B sessions: test_b_session_*
+        opts.setdefault("weightp", 0)         # ... of the ring path (--weightp 2 moves a session without B pictures onto the DPB model: test_weightp_session_*)
     for k, v in opts.items():
         assert H.x264_param_parse(C.byref(p), k.encode(), None if v is None else str(v).encode()) == 0, k
     p.b_vfr_input = 0
@@ -592,6 +594,7 @@ def test_plain_slices_through_the_api(gpu, w, h, opts, slices):
     p.i_log_level = -1
     if "bframes" not in opts:
         opts = dict(opts, bframes=0)          # these sessions test the I / P behaviours (one picture back per call); B sessions: test_b_session_*
+        opts.setdefault("weightp", 0)         # ... of the ring path (--weightp 2 moves a session without B pictures onto the DPB model: test_weightp_session_*)
     for k, v in opts.items():
         assert H.x264_param_parse(C.byref(p), k.encode(), None if v is None else str(v).encode()) == 0, k
     p.b_vfr_input = 0
@@ -781,13 +784,15 @@ def encode_delayed(h_, w, h, frames):
     (176, 144, 14, {"qp": 23, "keyint": 30, "scenecut": 0, "bframes": 3}, "IPRBBPRBBPRBBP"),                         # preset medium as the device runs it: bframes 3, b-pyramid, weightb, ref 3
     (128, 96, 12, {"qp": 26, "keyint": 30, "scenecut": 0, "bframes": 1, "ref": 1}, "IPBPBPBPBPBP"),
     (96, 80, 13, {"crf": 24, "keyint": 6, "min-keyint": 6, "scenecut": 0, "bframes": 2, "b-pyramid": "none", "no-mbtree": None}, None),
+    (176, 144, 9, {"qp": 23, "keyint": 30, "scenecut": 0, "bframes": 0, "weightp": 2}, "IPPPPPPPP"),                # no B pictures, --weightp 2: the DPB model with no delay
 ])
 def test_b_session_through_the_encode_api(gpu, w, h, n, opts, pattern):
     """B pictures through x264_encoder_encode (codec.c:1693): types / pts / dts as x264 hands them to the muxers (output/matroska.c:199-202), the
     stream decodes to every source picture, and equals the checker's stream for the same schedule byte for byte"""
     frames = synth_frames(w, h, n, seed=4)
     h_, eff = open_encoder(w, h, opts, profile=None)
-    assert eff.i_bframe == opts.get("bframes", 3) and eff.i_bframe_adaptive == 0 and eff.analyse.i_direct_mv_pred == 1
+    assert eff.i_bframe == opts.get("bframes", 3) and eff.i_bframe_adaptive == 0 and (eff.analyse.i_direct_mv_pred == 1 or not eff.i_bframe)
+    assert eff.analyse.i_weighted_pred == (2 if opts.get("ref", 3) >= 2 else 0)          # medium's default, kept: the blind duplicate of reference 0 (it needs two references)
     stream, recs = encode_delayed(h_, w, h, frames)
     H.x264_encoder_close(h_)
     assert len(recs) == n

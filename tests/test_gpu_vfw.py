@@ -22,7 +22,7 @@ def test_icm_compress_sequence(gpu, four, cmdline):
     n = D(cid, None, V.ICM_GETSTATE, 0, 0)
     cfg = V.VfwConfig()
     D(cid, None, V.ICM_GETSTATE, V.addr(cfg), n)
-    cfg.i_encoding_type, cfg.i_qp, cfg.extra_cmdline = 1, 27, cmdline + b" --bframes 0"        # single pass CQP (codec.c:1498-1502)
+    cfg.i_encoding_type, cfg.i_qp, cfg.extra_cmdline = 1, 27, cmdline + b" --bframes 0 --weightp 0"        # single pass CQP (codec.c:1498-1502)
     assert D(cid, None, V.ICM_SETSTATE, V.addr(cfg), n) == n
     inb, outb = V.bmi(w, h, four), V.BITMAPINFO()
     icf = V.ICCOMPRESSFRAMES(lFrameCount=nfr, dwRate=25, dwScale=1)
@@ -96,7 +96,7 @@ def test_default_session_delays_output_by_the_lookahead(gpu, tmp_path):
         cfg = V.VfwConfig()
         D(cid, None, V.ICM_GETSTATE, V.addr(cfg), n)
         assert cfg.i_encoding_type == 2 and cfg.b_zerolatency == 0          # config.c defaults: single pass ratefactor-based (CRF)
-        cfg.extra_cmdline = cmdline + b" --bframes 0"          # (the macroblock-tree session: B sessions run without it so far)
+        cfg.extra_cmdline = cmdline + b" --bframes 0 --weightp 0"          # (the macroblock-tree session: B sessions run without it so far)
         D(cid, None, V.ICM_SETSTATE, V.addr(cfg), n)
         inb, outb = V.bmi(w, h, b"I420"), V.BITMAPINFO()
         assert D(cid, None, V.ICM_COMPRESS_GET_FORMAT, V.addr(inb), V.addr(outb)) == V.ICERR_OK
@@ -159,7 +159,7 @@ def test_icm_compress_native_colourspaces(gpu, fmt):
         n = D(cid, None, V.ICM_GETSTATE, 0, 0)
         cfg = V.VfwConfig()
         D(cid, None, V.ICM_GETSTATE, V.addr(cfg), n)
-        cfg.i_encoding_type, cfg.i_qp, cfg.extra_cmdline = 1, 30, b"--keyint 250 --colormatrix bt709 --range pc --bframes 0"
+        cfg.i_encoding_type, cfg.i_qp, cfg.extra_cmdline = 1, 30, b"--keyint 250 --colormatrix bt709 --range pc --bframes 0 --weightp 0"
         assert D(cid, None, V.ICM_SETSTATE, V.addr(cfg), n) == n
         inb, outb = V.bmi(w, hh, fourcc if fourcc else b"\x00\x00\x00\x00"), V.BITMAPINFO()
         inb.bmiHeader.biBitCount = bitcount
@@ -211,7 +211,7 @@ def test_raw_file_output(gpu, tmp_path):
         n = D(cid, None, V.ICM_GETSTATE, 0, 0)
         cfg = V.VfwConfig()
         D(cid, None, V.ICM_GETSTATE, V.addr(cfg), n)
-        cfg.i_encoding_type, cfg.i_qp, cfg.extra_cmdline = 1, 28, cmdline + b" --bframes 0"
+        cfg.i_encoding_type, cfg.i_qp, cfg.extra_cmdline = 1, 28, cmdline + b" --bframes 0 --weightp 0"
         D(cid, None, V.ICM_SETSTATE, V.addr(cfg), n)
         inb, outb = V.bmi(w, h, b"I420"), V.BITMAPINFO()
         assert D(cid, None, V.ICM_COMPRESS_GET_FORMAT, V.addr(inb), V.addr(outb)) == V.ICERR_OK

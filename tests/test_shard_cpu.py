@@ -29,7 +29,7 @@ def run_host(w, h, n, seed, opts, devices):
 @pytest.mark.parametrize("devices,threads", [(2, 4), (3, 5), (2, 2), (4, 3)])
 def test_gop_slots_dealt_to_devices_equal_the_serial_stream(devices, threads):
     w, h, n = 96, 80, 23
-    opts = {"qp": 27, "keyint": 4, "min-keyint": 4, "scenecut": 0, "ref": 2, "bframes": 0}      # (GOP slots carry I / P pictures only so far)
+    opts = {"qp": 27, "keyint": 4, "min-keyint": 4, "scenecut": 0, "ref": 2, "bframes": 0, "weightp": 0}      # (GOP slots carry I / P pictures only so far)
     serial = run_host(w, h, n, 7, dict(opts, threads=1), 1)
     par = run_host(w, h, n, 7, dict(opts, threads=threads), devices)
     assert par["frames"] == serial["frames"] == n

@@ -116,6 +116,9 @@ struct x264_t {
     //      or at the end), then leave in coding order: the closing picture, the B-reference of the run, the other B pictures.  The DPB, the
     //      reference lists and the slice header's share of them come from host/dpb.hpp ----
     int bframes = 0, bpyramid = 0, log2_max_poc_lsb = 0;
+    // dpbmode: the session runs on the DPB model (host/dpb.hpp) and x264gpu_encode_pictures — every session with B pictures, and sessions
+    // without them that use --weightp 2 (whose duplicate references need explicit lists); weightp: the effective --weightp (0 or 2)
+    bool dpbmode = false; int weightp = 0;
     Dpb dpb;
     struct BEntry { int64_t pts; int frame; int slot; int forced; int scenecut; int32_t costs[4]; x264_image_t img; };      // forced: 0 auto, 1 I, 2 IDR
     struct BPlanned { BEntry e; int type; };                                                                            // type: PIC_*
@@ -171,7 +174,7 @@ static SpsParams make_sps(const x264_t *h)
     s.num_units_in_tick = p.i_timebase_num; s.time_scale = p.i_timebase_den * 2;
     s.constraint_set0 = h->profile_idc == 66; s.constraint_set1 = h->profile_idc <= 77;
     s.mv_range = h->param.analyse.i_mv_range;
-    if (h->bframes) { s.num_ref_frames = h->dpb.max_dpb; s.log2_max_poc_lsb = h->log2_max_poc_lsb; s.num_reorder_frames = h->dpb.num_reorder; }
+    if (h->dpbmode) { s.num_ref_frames = h->dpb.max_dpb; s.log2_max_poc_lsb = h->log2_max_poc_lsb; s.num_reorder_frames = h->dpb.num_reorder; }
     return s;
 }
 static PpsParams make_pps(const x264_t *h)
@@ -179,6 +182,7 @@ static PpsParams make_pps(const x264_t *h)
     PpsParams pp = { h->param.i_sps_id, h->param.i_sps_id, h->param.b_cabac, h->param.i_frame_reference, h->pic_init_qp, h->param.analyse.i_chroma_qp_offset,
                      h->param.analyse.b_transform_8x8 };
     if (h->bframes && h->param.analyse.b_weighted_bipred) pp.weighted_bipred_idc = 2;
+    pp.weighted_pred = h->weightp > 0;
     return pp;
 }
 // appends SPS, PPS (and optionally the version SEI) to h->out, recording NAL offsets and types
@@ -231,8 +235,9 @@ x264_t *x264_encoder_open(x264_param_t *param)
     p.analyse.b_mixed_references = p.analyse.b_mixed_references && p.i_frame_reference > 1;      // x264 validate_parameters
     p.b_cabac = p.b_cabac != 0;
     if (p.b_cabac && p.i_cabac_init_idc != 0) { xlog(&p, X264_LOG_WARNING, "cabac-idc %d: only the context tables of cabac_init_idc 0 (x264's default) are in the MI355X path: cabac-idc 0\n", p.i_cabac_init_idc); p.i_cabac_init_idc = 0; }
-    if (p.analyse.i_weighted_pred > X264_WEIGHTP_NONE) xlog(&p, X264_LOG_WARNING, "weightp %d is not implemented in the MI355X path yet: weightp 0\n", p.analyse.i_weighted_pred);
-    p.analyse.i_weighted_pred = X264_WEIGHTP_NONE; p.analyse.b_weighted_bipred = p.analyse.b_weighted_bipred != 0;
+    // --weightp: settled below with the B-picture settings (2 = x264's blind duplicate of reference 0 in sessions that run on the DPB model;
+    // the fade analysis that produces other weights — x264_weights_analyse, all that --weightp 1 does — is not implemented)
+    p.analyse.i_weighted_pred = clampi(p.analyse.i_weighted_pred, X264_WEIGHTP_NONE, X264_WEIGHTP_SMART); p.analyse.b_weighted_bipred = p.analyse.b_weighted_bipred != 0;
     p.analyse.b_transform_8x8 = p.analyse.b_transform_8x8 != 0;
     p.analyse.inter &= X264_ANALYSE_I4x4 | X264_ANALYSE_I8x8 | X264_ANALYSE_PSUB16x16; p.analyse.intra &= X264_ANALYSE_I4x4 | X264_ANALYSE_I8x8;
     if (!p.analyse.b_transform_8x8) { p.analyse.inter &= ~X264_ANALYSE_I8x8; p.analyse.intra &= ~X264_ANALYSE_I8x8; }   // as x264 validate_parameters
@@ -306,6 +311,19 @@ x264_t *x264_encoder_open(x264_param_t *param)
     } else { p.i_bframe_pyramid = 0; p.analyse.b_weighted_bipred = 0; }
     h->bframes = p.i_bframe; h->bpyramid = p.i_bframe_pyramid ? 1 : 0;
     if (p.i_keyint_max <= 0) p.i_keyint_max = 1;
+    if (p.analyse.i_weighted_pred == X264_WEIGHTP_SIMPLE) { xlog(&p, X264_LOG_INFO, "weightp 1 is fade analysis only, which is not implemented in the MI355X path: weightp 0\n"); p.analyse.i_weighted_pred = X264_WEIGHTP_NONE; }
+    if (p.analyse.i_weighted_pred == X264_WEIGHTP_SMART && !h->bframes) {
+        // without B pictures the session can still run on the DPB model, if nothing of the other path is asked for
+        const bool tree = p.rc.b_mb_tree && p.rc.i_rc_method != X264_RC_CQP && p.rc.i_lookahead > 0;
+        const char *why = p.i_threads > 1 ? "threads 1" : h->slices > 1 ? "one slice per picture" : p.b_sliced_threads ? "no slice threads" : tree ? "no mbtree" :
+                          p.rc.i_rc_method == X264_RC_ABR ? "constant-quantiser or CRF rate control" : p.i_keyint_max < 2 ? "keyint > 1" : nullptr;
+        if (why) { xlog(&p, X264_LOG_WARNING, "weightp 2 without B-frames needs %s in the MI355X path: weightp 0\n", why); p.analyse.i_weighted_pred = X264_WEIGHTP_NONE; }
+    }
+    if (p.analyse.i_weighted_pred == X264_WEIGHTP_SMART && p.i_frame_reference < 2) p.analyse.i_weighted_pred = X264_WEIGHTP_NONE;      // a duplicate needs two references (x264: never placed)
+    h->weightp = p.analyse.i_weighted_pred;
+    h->dpbmode = h->bframes > 0 || h->weightp == X264_WEIGHTP_SMART;
+    if (h->dpbmode && !h->bframes) { p.rc.b_mb_tree = 0; }
+    if (h->weightp == X264_WEIGHTP_SMART) xlog(&p, X264_LOG_INFO, "weightp 2: the duplicate of reference 0 with luma offset -1 on every P picture (x264's fade analysis is not run)\n");
     h->keyint = p.i_keyint_max;
     // rate control: constant QP (X264_RC_CQP, codec.c:1498-1502) and single-pass CRF without AQ / mbtree (codec.c:1504-1507, the
     // driver's default session) when one GOP is in flight; ABR and CRF under --threads > 1 map to their nominal quantiser
@@ -339,12 +357,14 @@ x264_t *x264_encoder_open(x264_param_t *param)
     p.i_level_idc = h->level_idc;
     h->log2_max_frame_num = 4;
     while ((1 << h->log2_max_frame_num) <= (h->keyint < 65536 ? h->keyint : 65535) && h->log2_max_frame_num < 16) h->log2_max_frame_num++;
-    if (h->bframes) {
-        // x264 sps init: pic_order_cnt_type 0 with room for the largest POC distance of a mini-GOP; the DPB model owns frame_num / lists / marking
-        h->dpb.configure(p.i_frame_reference, h->bframes, h->bpyramid, h->log2_max_frame_num);
+    if (h->weightp && h->profile_idc == 66) h->profile_idc = 77;                  // explicit weighted prediction is a Main profile tool
+    if (h->dpbmode) {
+        // x264 sps init: pic_order_cnt_type 0 with room for the largest POC distance of a mini-GOP (type 2 without B pictures); the DPB model owns
+        // frame_num / lists / marking
+        h->dpb.configure(p.i_frame_reference, h->bframes, h->bpyramid, h->log2_max_frame_num, h->weightp);
         const int max_delta_poc = (h->bframes + 2) * (h->bpyramid + 1) * 2;
-        h->log2_max_poc_lsb = 4;
-        while ((1 << h->log2_max_poc_lsb) <= max_delta_poc * 2) h->log2_max_poc_lsb++;
+        h->log2_max_poc_lsb = h->bframes ? 4 : 0;
+        while (h->bframes && (1 << h->log2_max_poc_lsb) <= max_delta_poc * 2) h->log2_max_poc_lsb++;
         h->level_idc = p.i_level_idc > 0 ? p.i_level_idc : pick_level(&p, h->nmb, h->dpb.max_dpb);
         p.i_level_idc = h->level_idc;
     }
@@ -384,7 +404,7 @@ x264_t *x264_encoder_open(x264_param_t *param)
     }
     p.analyse.i_mv_range = clampi(p.analyse.i_mv_range, 32, 512);
     cfg.mv_range = p.analyse.i_mv_range;
-    if (h->bframes) { cfg.dpb = h->dpb.max_dpb; cfg.weightb = p.analyse.b_weighted_bipred; }
+    if (h->dpbmode) { cfg.dpb = h->dpb.max_dpb; cfg.weightb = p.analyse.b_weighted_bipred; }
     size_t insz = (size_t)p.i_width * p.i_height * 3 / 2;
     (void)x264gpu_get_device(&h->device);
     bool ok_setup = x264gpu_malloc((void **)&h->d_in, insz) == X264GPU_OK;
@@ -433,7 +453,7 @@ x264_t *x264_encoder_open(x264_param_t *param)
     // the entropy coding of this one (one more picture of delay); X264GPU_HOST_PIPELINE=0 keeps the two stages in one call
     { const char *pe = getenv("X264GPU_HOST_PIPELINE"); h->pipeline = h->G == 1 && h->L > 0 && h->crf && !(pe && pe[0] == '0'); }
     h->Q = h->L + 1 + (h->pipeline ? 1 : 0);
-    if (h->bframes) { h->pipeline = false; h->Q = 2 * (h->bframes + 1) + 2; }      // display-order queue + the mini-GOP being coded
+    if (h->dpbmode) { h->pipeline = false; h->Q = 2 * (h->bframes + 1) + 2; }      // display-order queue + the mini-GOP being coded
     h->aq_strength_q8 = cfg.aq_mode ? cfg.aq_strength_q8 : 0;
     h->tree_strength_q8 = (int)(1280.0 * (1.0 - p.rc.f_qcompress) + 0.5);     // 5 * (1 - qcomp), Q8
     h->q_raw.assign((size_t)h->Q, nullptr); h->q_info.assign((size_t)h->Q, nullptr); h->q_aq.assign((size_t)h->Q, nullptr);
@@ -998,7 +1018,7 @@ static int encode_bmode(x264_t *h, x264_nal_t **pp_nal, int *pi_nal, x264_pictur
         pic_out->b_keyframe = idr;
         pic_out->i_pts = pl.e.pts;
         // x264: the k-th coded picture's dts is the pts of display picture k - delay; the first `delay` ones are shifted back by the delay's duration
-        const long k = h->coded_count, delay = h->bpyramid ? 2 : 1;
+        const long k = h->coded_count, delay = !h->bframes ? 0 : h->bpyramid ? 2 : 1;
         const size_t np = h->all_pts.size();
         if (k >= delay) pic_out->i_dts = h->all_pts[(size_t)(k - delay) < np ? (size_t)(k - delay) : np - 1];
         else pic_out->i_dts = h->all_pts[(size_t)k < np ? (size_t)k : np - 1] - (h->all_pts[(size_t)delay < np ? (size_t)delay : np - 1] - h->all_pts[0]);
@@ -1017,7 +1037,7 @@ int x264_encoder_encode(x264_t *h, x264_nal_t **pp_nal, int *pi_nal, x264_pictur
     if (h->failed) return -1;
     if (!pic_in) {      // flush: GOP-parallel batches, or the pictures still waiting in the lookahead queue, one per call
         if (h->G > 1) return encode_gop_parallel(h, pp_nal, pi_nal, nullptr, pic_out, false);
-        if (h->bframes) return encode_bmode(h, pp_nal, pi_nal, pic_out, true);
+        if (h->dpbmode) return encode_bmode(h, pp_nal, pi_nal, pic_out, true);
         return h->queue.empty() ? 0 : encode_queued(h, pp_nal, pi_nal, pic_out, true);
     }
     const x264_param_t &p = h->param;
@@ -1076,7 +1096,7 @@ int x264_encoder_encode(x264_t *h, x264_nal_t **pp_nal, int *pi_nal, x264_pictur
     e.type = idr ? 2 : intra_pic ? 1 : 0;
     h->la_gop = idr ? 1 : h->la_gop + 1;
     h->la_count++;
-    if (h->bframes) {
+    if (h->dpbmode) {
         x264_t::BEntry be = {};
         be.pts = e.pts; be.frame = (int)(h->la_count - 1); be.slot = slot; be.forced = e.type; be.scenecut = e.scenecut; be.img = e.img;
         memcpy(be.costs, e.costs, sizeof(e.costs));
@@ -1099,7 +1119,7 @@ int x264_encoder_encode(x264_t *h, x264_nal_t **pp_nal, int *pi_nal, x264_pictur
     return size;
 }
 
-int x264_encoder_delayed_frames(x264_t *h) { return !h || h->failed ? 0 : h->G > 1 ? (int)(h->submitted - h->emitted) : h->bframes ? (int)(h->bq.size() + h->bcoding.size()) : (int)h->queue.size(); }
+int x264_encoder_delayed_frames(x264_t *h) { return !h || h->failed ? 0 : h->G > 1 ? (int)(h->submitted - h->emitted) : h->dpbmode ? (int)(h->bq.size() + h->bcoding.size()) : (int)h->queue.size(); }
 
 void x264_encoder_close(x264_t *h)
 {
