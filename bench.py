@@ -18,7 +18,7 @@ independent (BASELINE.json config 5), so N GPUs shard streams one set per GPU wi
 
 WHAT IS MEASURED IS x264's preset=medium TOOLSET AS THE DEVICE RUNS IT: CABAC, ref 3 + mixed refs, hex, subme 7 (RD mode decision with
 CABAC sizes, psy-rd 1.0), trellis 1, 8x8dct, all partitions, B pictures (spatial direct, weightb, b-pyramid) — `config.toolset_gaps`
-lists what still differs (weightp 2, b-adapt 1, the lookahead-driven tools).  `--bframes 0` measures the I / P stream of the earlier
+lists what still differs (weightp's fade analysis, b-adapt 1, the lookahead-driven tools).  `--bframes 0` measures the I / P stream of the earlier
 rounds, `--rd cavlc` medium --no-cabac, `--rd off` the subme-5 toolset, for comparison.
 
 Rank 0 prints ONE JSON line with `roofline` (the macroblock kernel, HIP-event timed inside the timed region, HBM fraction + VALU
@@ -40,9 +40,9 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0   # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
-TOOLSET_GAPS = "x264 medium minus: weightp 2, b-adapt 1 (every run is bframes long: b-adapt 0), rate control (constant quantisers: no AQ / mbtree / lookahead); entropy coding (CABAC bitstream writing) runs on host threads and is outside `value` (inside `e2e`)"
-TOOLSET_GAPS_NOB = "x264 medium minus: B-frames (bframes 3 -> 0), weightp 2; entropy coding (CABAC/CAVLC bitstream writing) runs on host threads and is outside `value` (inside `e2e`)"
-TOOLSET_GAPS_NORD = "x264 medium minus: B-frames (bframes 3 -> 0), RD mode decision + psy-rd (subme 7 -> 5), trellis 1, weightp 2; entropy coding runs on host threads and is outside `value`"
+TOOLSET_GAPS = "x264 medium minus: the fade analysis of weightp 2 (its duplicate reference with offset -1 on every P picture IS in), b-adapt 1 (every run is bframes long: b-adapt 0), rate control (constant quantisers: no AQ / mbtree / lookahead); entropy coding (CABAC bitstream writing) runs on host threads and is outside `value` (inside `e2e`)"
+TOOLSET_GAPS_NOB = "x264 medium minus: B-frames (bframes 3 -> 0), the fade analysis of weightp 2; entropy coding (CABAC/CAVLC bitstream writing) runs on host threads and is outside `value` (inside `e2e`)"
+TOOLSET_GAPS_NORD = "x264 medium minus: B-frames (bframes 3 -> 0), RD mode decision + psy-rd (subme 7 -> 5), trellis 1, the fade analysis of weightp 2; entropy coding runs on host threads and is outside `value`"
 
 
 def parse_args():
@@ -51,6 +51,7 @@ def parse_args():
     ap.add_argument("--steps", type=int, default=9)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--bframes", type=int, default=3, help="B pictures between references (medium: 3, with b-pyramid normal and weightb); 0 = the I / P stream of the earlier rounds")
+    ap.add_argument("--weightp", type=int, default=2, choices=[0, 2], help="2 (medium): x264's blind duplicate of reference 0 with luma offset -1 on every P picture with two or more references")
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--streams", type=int, default=2048, help="independent closed-GOP streams per GPU (lock-step batch; one wavefront each)")
@@ -105,7 +106,7 @@ def cpu_worker(args):
     tools = toolset(args)
     enc = O.OracleEncoder(O.default_config(args.width, args.height, qp_i=max(0, args.qp - 3), qp_p=args.qp, **tools))
     order = gop.schedule(display_types(args.cpu_frames, args.bframes, args.cpu_frames), 1)
-    dpb = gop.HostDpb(HL, tools["refs"], args.bframes, 1)
+    dpb = gop.HostDpb(HL, tools["refs"], args.bframes, 1, weightp=args.weightp)
     t0 = time.perf_counter()
     for k, (disp, pt) in enumerate(order):
         pic, _ = dpb.plan(pt, disp, gop.follow_of(order, k))
@@ -408,7 +409,7 @@ def main():
     types = display_types(Wu, args.bframes, Wu) + display_types(K, args.bframes, max(K, 1))
     order = gop.schedule(types, 1)                    # coding order: (display index, PIC_IDR / _I / _P / _BREF / _B)
     assert len(order) == Wu + K and order[Wu][1] == 0, "the timed region starts on an IDR picture"
-    dpb = gop.HostDpb(HL, tools["refs"], args.bframes, 1)
+    dpb = gop.HostDpb(HL, tools["refs"], args.bframes, 1, weightp=args.weightp)
 
     # ---- inputs resident in HBM: Wu + K distinct frames per stream (D distinct sequences replicated over the streams) ----
     D = max(1, min(S, args.distinct))
@@ -503,7 +504,7 @@ def main():
            "dtype": "u8", "data": "synthetic",
            "config": {"workload": f"{W}x{H} yuv420p, {S} closed-GOP streams/GPU x {K} coded pictures from an IDR on ({mix}; coding order of {types[Wu:]}), distinct frames, CQP {max(0, args.qp - 3)}/{args.qp}/{args.qp + 2}, "
                                   f"preset {args.preset}, content '{args.content}'",
-                      "toolset": tools, "toolset_gaps": TOOLSET_GAPS_NORD if args.rd == "off" or args.preset == "ultrafast" else (TOOLSET_GAPS if args.bframes else TOOLSET_GAPS_NOB) + (" [--rd cavlc: medium --no-cabac]" if args.rd == "cavlc" else ""),
+                      "toolset": tools, "weightp": args.weightp, "toolset_gaps": TOOLSET_GAPS_NORD if args.rd == "off" or args.preset == "ultrafast" else (TOOLSET_GAPS if args.bframes else TOOLSET_GAPS_NOB) + (" [--rd cavlc: medium --no-cabac]" if args.rd == "cavlc" else ""),
                       "streams_per_gpu": S, "distinct_sequences": D, "frames_per_sequence": L, "content": args.content, "frames_per_step": S * world, "keyint_for_proportions": args.keyint,
                       "mb_per_frame": ((W + 15) // 16) * ((H + 15) // 16),
                       # launches of the three macroblock-loop instantiations before / inside the timed window (tools/profile_summarise.py folds the counters of the timed ones)
