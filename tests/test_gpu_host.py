@@ -791,7 +791,7 @@ def test_b_session_through_the_encode_api(gpu, w, h, n, opts, pattern):
     stream decodes to every source picture, and equals the checker's stream for the same schedule byte for byte"""
     frames = synth_frames(w, h, n, seed=4)
     h_, eff = open_encoder(w, h, opts, profile=None)
-    assert eff.i_bframe == opts.get("bframes", 3) and eff.i_bframe_adaptive == 0 and (eff.analyse.i_direct_mv_pred == 1 or not eff.i_bframe)
+    assert eff.i_bframe == opts.get("bframes", 3) and (not eff.i_bframe or (eff.i_bframe_adaptive == 0 and eff.analyse.i_direct_mv_pred == 1))
     assert eff.analyse.i_weighted_pred == (2 if opts.get("ref", 3) >= 2 else 0)          # medium's default, kept: the blind duplicate of reference 0 (it needs two references)
     stream, recs = encode_delayed(h_, w, h, frames)
     H.x264_encoder_close(h_)
