@@ -300,9 +300,34 @@ int  x264gpu_encoder_set_stream_qps(x264gpu_encoder *enc, const int8_t *qps);
  * 16x16 search in reference 0; x264_mb_predict_mv_ref16x16): device array [streams][mb_count][2] int16 in quarter-pels of the
  * half-resolution planes, first entry 0x7fff = absent for that stream.  NULL (the default) = none. */
 int  x264gpu_encoder_set_lowres_mvs(x264gpu_encoder *enc, const int16_t *d_mvs);
+/* the same towards the first picture of list 1 of the next B picture (x264 lowres_mvs[1][distance - 1]) */
+int  x264gpu_encoder_set_lowres_mvs1(x264gpu_encoder *enc, const int16_t *d_mvs);
 /* tests: the 460 CABAC context variables ((pStateIdx << 1) | valMPS) the wavefront of (stream, slice) ended the last picture with (RD sessions
  * with cabac: x264 prices candidates on the states the finished macroblocks left, [x264-upstream] encoder/rdo.c) */
 int  x264gpu_encoder_cabac_states(x264gpu_encoder *enc, int stream, int slice, uint8_t *out460);
+
+/* ---- the lookahead's frame costs in x264's structure: x264_slicetype_frame_cost(p0, p1, b) for ANY triple of pictures held in the lookahead
+ * ([x264-upstream] encoder/slicetype.c slicetype_frame_cost / slicetype_slice_cost / slicetype_mb_cost, behind codec.c:1693) — I, P and B
+ * costs on the half-resolution planes, blocks visited in reverse raster order with the neighbours' vectors as predictors, each picture's
+ * searches cached per (list, distance) as x264's lowres_mvs / lowres_mv_costs, the intra cost computed once per picture.  What the host's
+ * x264_slicetype_analyse restatement (scenecut, --b-adapt 1) and the main encoder's search candidates (x264gpu_encoder_set_lowres_mvs) read.
+ * Pictures live in numbered slots; d0 = b - p0 and d1 = p1 - b are display distances (d0 = d1 = 0: the I cost; d1 = 0: a P cost). ---- */
+typedef struct x264gpu_slicetype x264gpu_slicetype;
+int  x264gpu_slicetype_create(x264gpu_slicetype **st, int width, int height, int streams, int slots, int bframes, int me_method, int subme, int me_range,
+                              int weightb, int mv_range, int do_edges /* x264: mbtree or VBV sessions also cost the picture's edge blocks */);
+void x264gpu_slicetype_destroy(x264gpu_slicetype *st);
+/* x264_frame_init_lowres of a new source picture ([streams] tight I420 pictures in device memory) into `slot`; forgets the slot's cached searches */
+int  x264gpu_slicetype_put_frame(x264gpu_slicetype *st, int slot, const uint8_t *d_i420, void *stream);
+/* the score of picture slot_b predicted from slot_p0 (and slot_p1): h_score[streams] (host memory; memoised per (slot_b, d0, d1)) */
+int  x264gpu_slicetype_frame_cost(x264gpu_slicetype *st, int slot_p0, int slot_p1, int slot_b, int d0, int d1, int32_t *h_score, void *stream);
+int  x264gpu_slicetype_intra_mbs(x264gpu_slicetype *st, int slot, int d0, int stream_idx);          /* frame->i_intra_mbs[d0] of the last P cost */
+int  x264gpu_slicetype_cost_est(x264gpu_slicetype *st, int slot, int d0, int d1, int stream_idx);   /* frame->i_cost_est[d0][d1], -1 = not computed */
+/* device pointers of a picture's cached results ([streams][blocks]): vectors ([2] each, quarter samples of the half-resolution planes) and costs of
+ * the search in `list` at distance `dist` (NULL: not searched), per-block intra costs, lowres_costs[d0][d1] (cost | list_used << 14) */
+const int16_t  *x264gpu_slicetype_lowres_mvs(x264gpu_slicetype *st, int slot, int list, int dist);
+const int      *x264gpu_slicetype_lowres_mv_costs(x264gpu_slicetype *st, int slot, int list, int dist);
+const int      *x264gpu_slicetype_intra_costs(x264gpu_slicetype *st, int slot);
+const uint16_t *x264gpu_slicetype_lowres_costs(x264gpu_slicetype *st, int slot, int d0, int d1);
 
 /* ------------------------------------------------------------------------------------------------
  * Lookahead frame cost: x264_slicetype_frame_cost of [x264-upstream]

@@ -2295,3 +2295,30 @@ void x264o_macroblock(x264o_encoder *e, int mbx, int mby)
         if (!(mb->type == X264GPU_MB_I16x16 && !mb->cbp_luma && !mb->cbp_chroma && !((mb->nnz >> 24) & 1) && mb->qp > e->last_qp)) e->last_qp = mb->qp;
     }
 }
+
+/* ---------------------------------------------------------------------------------------------------------------------------
+ * The lookahead's use of the same search (slicetype.c; x264 slicetype_mb_cost -> x264_me_search on an 8x8 block of the half-resolution
+ * planes, lowres_context_init: lambda of qp 12, me = min(hex, --me) and sub-pel level 4 when --subme > 1, else dia and level 2, no chroma).
+ * `lo` is an x264o_encoder shell whose DPB slots hold half-resolution plane sets and whose fenc is plane 0 of the picture being costed;
+ * (bx, by) = the 8x8 block, lim = { fmin x, fmax x, fmin y, fmax y, smin x, smax x, smin y, smax y } as slicetype_mb_cost sets them. */
+int x264o_lowres_me_search(x264o_encoder *lo, int slot, int bx, int by, const int mvp[2], int (*mvc)[2], int i_mvc, const int lim[8], int param_subme, int mv[2], int *cost_mv)
+{
+    actx A, *a = &A;
+    memset(a, 0, sizeof(*a));
+    a->e = lo; a->mbx = bx >> 1; a->mby = by >> 1;
+    a->qp = 12; a->lambda = x264o_lambda(12);
+    a->subme = param_subme > 1 ? 4 : 2; a->satd = param_subme > 1;
+    a->cost_mv = x264o_cost_mv_for(lo, 12);
+    a->fmin[0] = lim[0]; a->fmax[0] = lim[1]; a->fmin[1] = lim[2]; a->fmax[1] = lim[3];
+    a->smin[0] = lim[4]; a->smax[0] = lim[5]; a->smin[1] = lim[6]; a->smax[1] = lim[7];
+    a->nref = 1;
+    lo->lslot[0][0] = slot; lo->nref_l[0] = 1; lo->slice_type = X264GPU_SLICE_P;
+    me_t m;
+    memset(&m, 0, sizeof(m));
+    m.w = m.h = 8; m.ox = 8 * (bx & 1); m.oy = 8 * (by & 1);
+    m.mvp[0] = mvp[0]; m.mvp[1] = mvp[1];
+    me_search_ref(a, &m, mvc, i_mvc, NULL);
+    mv[0] = m.mv[0]; mv[1] = m.mv[1];
+    if (cost_mv) *cost_mv = m.cost_mv;
+    return m.cost;
+}

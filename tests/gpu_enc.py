@@ -121,3 +121,58 @@ class GpuLookahead:
             self.close()
         except Exception:
             pass
+
+
+class GpuSlicetype:
+    """Mirror of x264gpu_slicetype_* (include/x264gpu.h): slicetype_frame_cost(p0, p1, b) over pictures held in numbered slots"""
+
+    def __init__(self, w, h, streams=1, slots=8, bframes=3, me_method=1, subme=7, me_range=16, weightb=1, mv_range=512, do_edges=0):
+        import torch
+        self.torch = torch
+        self.S = streams
+        self.nb = ((w + 15) // 16) * ((h + 15) // 16)
+        self.h = C.c_void_p()
+        lib.check(lib.x264gpu_slicetype_create(C.byref(self.h), w, h, streams, slots, bframes, me_method, subme, me_range, weightb, mv_range, do_edges), "slicetype_create")
+        self.keep = {}
+
+    def put(self, slot, frames):
+        d_in = self.torch.from_numpy(np.stack(frames)).cuda()
+        self.keep[slot] = d_in
+        lib.check(lib.x264gpu_slicetype_put_frame(self.h, slot, d_in.data_ptr(), None), "slicetype_put_frame")
+
+    def cost(self, s0, s1, sb, d0, d1):
+        out = np.zeros(self.S, np.int32)
+        lib.check(lib.x264gpu_slicetype_frame_cost(self.h, s0, s1, sb, d0, d1, out.ctypes.data, None), "slicetype_frame_cost")
+        return out
+
+    def intra_mbs(self, slot, d0, s=0):
+        return lib.x264gpu_slicetype_intra_mbs(self.h, slot, d0, s)
+
+    def _dev(self, p, dtype, shape):
+        t = self.torch
+        assert p, "not computed"
+        n = int(np.prod(shape)) * np.dtype(dtype).itemsize
+        buf = np.zeros(n, np.uint8)
+        lib.check(lib.x264gpu_memcpy_d2h(buf.ctypes.data, p, n, None), "d2h")
+        t.cuda.synchronize()
+        return buf.view(dtype).reshape(shape)
+
+    def mvs(self, slot, lst, dist):
+        return self._dev(lib.x264gpu_slicetype_lowres_mvs(self.h, slot, lst, dist), np.int16, (self.S, self.nb, 2))
+
+    def mv_costs(self, slot, lst, dist):
+        return self._dev(lib.x264gpu_slicetype_lowres_mv_costs(self.h, slot, lst, dist), np.int32, (self.S, self.nb))
+
+    def intra_costs(self, slot):
+        return self._dev(lib.x264gpu_slicetype_intra_costs(self.h, slot), np.int32, (self.S, self.nb))
+
+    def lowres_costs(self, slot, d0, d1):
+        return self._dev(lib.x264gpu_slicetype_lowres_costs(self.h, slot, d0, d1), np.uint16, (self.S, self.nb))
+
+    def close(self):
+        if self.h:
+            lib.x264gpu_slicetype_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        self.close()

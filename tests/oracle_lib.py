@@ -268,6 +268,65 @@ class OracleLookahead:
         self.close()
 
 
+# ---- the lookahead's frame costs in x264's structure (oracle/slicetype.c) ----
+_sig("x264o_slicetype_create", C.c_void_p, [_i] * 10)
+_sig("x264o_slicetype_destroy", None, [C.c_void_p])
+_sig("x264o_slicetype_put_frame", _i, [C.c_void_p, _i, C.c_void_p])
+_sig("x264o_slicetype_frame_cost", _i, [C.c_void_p, _i, _i, _i, _i, _i])
+_sig("x264o_slicetype_intra_mbs", _i, [C.c_void_p, _i, _i])
+_sig("x264o_slicetype_cost_est", _i, [C.c_void_p, _i, _i, _i])
+_sig("x264o_slicetype_mvs", C.c_void_p, [C.c_void_p, _i, _i, _i])
+_sig("x264o_slicetype_mv_costs", C.c_void_p, [C.c_void_p, _i, _i, _i])
+_sig("x264o_slicetype_intra_costs", C.c_void_p, [C.c_void_p, _i])
+_sig("x264o_slicetype_lowres_costs", C.c_void_p, [C.c_void_p, _i, _i, _i])
+
+
+class OracleSlicetype:
+    """slicetype_frame_cost(p0, p1, b) over pictures held in numbered slots"""
+
+    def __init__(self, w, h, slots=8, bframes=3, me_method=1, subme=7, me_range=16, weightb=1, mv_range=512, do_edges=0):
+        self.w, self.h = w, h
+        self.nb = ((w + 15) // 16) * ((h + 15) // 16)
+        self.st = L.x264o_slicetype_create(w, h, slots, bframes, me_method, subme, me_range, weightb, mv_range, do_edges)
+
+    def put(self, slot, i420):
+        i420 = np.ascontiguousarray(i420, np.uint8)
+        assert L.x264o_slicetype_put_frame(self.st, slot, ptr(i420)) == 0
+
+    def cost(self, s0, s1, sb, d0, d1):
+        return L.x264o_slicetype_frame_cost(self.st, s0, s1, sb, d0, d1)
+
+    def intra_mbs(self, slot, d0):
+        return L.x264o_slicetype_intra_mbs(self.st, slot, d0)
+
+    def cost_est(self, slot, d0, d1):
+        return L.x264o_slicetype_cost_est(self.st, slot, d0, d1)
+
+    def _arr(self, p, dtype, shape):
+        n = int(np.prod(shape))
+        return np.frombuffer((C.c_char * (n * np.dtype(dtype).itemsize)).from_address(p), dtype=dtype).reshape(shape).copy()
+
+    def mvs(self, slot, lst, dist):
+        return self._arr(L.x264o_slicetype_mvs(self.st, slot, lst, dist), np.int16, (self.nb, 2))
+
+    def mv_costs(self, slot, lst, dist):
+        return self._arr(L.x264o_slicetype_mv_costs(self.st, slot, lst, dist), np.int32, (self.nb,))
+
+    def intra_costs(self, slot):
+        return self._arr(L.x264o_slicetype_intra_costs(self.st, slot), np.int32, (self.nb,))
+
+    def lowres_costs(self, slot, d0, d1):
+        return self._arr(L.x264o_slicetype_lowres_costs(self.st, slot, d0, d1), np.uint16, (self.nb,))
+
+    def close(self):
+        if self.st and L is not None:
+            L.x264o_slicetype_destroy(self.st)
+        self.st = None
+
+    def __del__(self):
+        self.close()
+
+
 _sig("x264o_aq_offsets", None, [C.c_void_p, _i, _i, _i, C.c_void_p])
 _sig("x264o_mbtree", None, [_i, _i, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), _i, _i, C.c_void_p])
 

@@ -22,7 +22,13 @@ def main():
         k, _, v = a.partition("=")
         opts[k] = v if _ else None
     H = HL.H
-    frames = synth_frames(w, h, n, seed=seed)
+    scene_len = int(opts.pop("scene_len", 0) or 0)
+    static = int(opts.pop("static", 0) or 0)
+    frames = synth_frames(w, h, n, seed=seed, **({"scene_len": scene_len} if scene_len else {}))
+    if static:          # the first picture again and again, with a little noise
+        import numpy as np
+        rng = np.random.default_rng(seed)
+        frames = [np.clip(frames[0].astype(np.int16) + rng.integers(-1, 2, frames[0].shape), 0, 255).astype(np.uint8) for _ in range(n)]
     p = HL.Param()
     assert H.x264_param_default_preset(C.byref(p), b"medium", None) == 0
     p.i_width, p.i_height, p.i_csp = w, h, HL.X264_CSP_I420

@@ -71,7 +71,52 @@ int x264gpu_encoder_set_stream_qps(x264gpu_encoder *g, const int8_t *qps)
 }
 int x264gpu_trellis_blocks(const int16_t *c, int n, int cat, int qp, int intra, const uint8_t *s, int16_t *l, uint8_t *z, void *st) { return fail("trellis primitive: not in the stub"); }
 int x264gpu_encoder_cabac_states(x264gpu_encoder *g, int stream, int slice, uint8_t *out) { return fail("context states: not in the stub"); }
-int x264gpu_encoder_set_lowres_mvs(x264gpu_encoder *g, const int16_t *mv) { return mv ? fail("lowres vectors: not in the stub") : X264GPU_OK; }
+void x264o_encoder_set_lowres_mvs(x264o_encoder *e, const int16_t *mv);
+void x264o_encoder_set_lowres_mvs1(x264o_encoder *e, const int16_t *mv);
+int x264gpu_encoder_set_lowres_mvs(x264gpu_encoder *g, const int16_t *mv) { if (g->cfg.streams != 1 && mv) return fail("lowres vectors: one stream in the stub"); x264o_encoder_set_lowres_mvs(g->e[0], mv); return X264GPU_OK; }
+int x264gpu_encoder_set_lowres_mvs1(x264gpu_encoder *g, const int16_t *mv) { if (g->cfg.streams != 1 && mv) return fail("lowres vectors: one stream in the stub"); x264o_encoder_set_lowres_mvs1(g->e[0], mv); return X264GPU_OK; }
+
+/* ---- the lookahead's frame costs in x264's structure: oracle/slicetype.c behind the x264gpu_slicetype_* ABI ("device" pointers are host pointers) ---- */
+typedef struct x264o_slicetype x264o_slicetype;
+x264o_slicetype *x264o_slicetype_create(int width, int height, int slots, int bframes, int me_method, int subme, int me_range, int weightb, int mv_range, int do_edges);
+void x264o_slicetype_destroy(x264o_slicetype *st);
+int x264o_slicetype_put_frame(x264o_slicetype *st, int slot, const uint8_t *i420);
+int x264o_slicetype_frame_cost(x264o_slicetype *st, int s0, int s1, int sb, int d0, int d1);
+int x264o_slicetype_intra_mbs(const x264o_slicetype *st, int slot, int d0);
+int x264o_slicetype_cost_est(const x264o_slicetype *st, int slot, int d0, int d1);
+const int16_t *x264o_slicetype_mvs(const x264o_slicetype *st, int slot, int list, int dist);
+const int *x264o_slicetype_mv_costs(const x264o_slicetype *st, int slot, int list, int dist);
+const int *x264o_slicetype_intra_costs(const x264o_slicetype *st, int slot);
+const uint16_t *x264o_slicetype_lowres_costs(const x264o_slicetype *st, int slot, int d0, int d1);
+struct x264gpu_slicetype { x264o_slicetype *st; };
+int x264gpu_slicetype_create(x264gpu_slicetype **out, int w, int h, int streams, int slots, int bframes, int me_method, int subme, int me_range, int weightb, int mv_range, int do_edges)
+{
+    if (streams != 1) return fail("stub slicetype: one stream");
+    if (slots > 24) return fail("stub slicetype: at most 24 slots");
+    x264gpu_slicetype *s = calloc(1, sizeof(*s));
+    s->st = x264o_slicetype_create(w, h, slots, bframes, me_method, subme, me_range, weightb, mv_range, do_edges);
+    *out = s;
+    return X264GPU_OK;
+}
+void x264gpu_slicetype_destroy(x264gpu_slicetype *s) { if (s) { x264o_slicetype_destroy(s->st); free(s); } }
+int x264gpu_slicetype_put_frame(x264gpu_slicetype *s, int slot, const uint8_t *i420, void *stream) { return x264o_slicetype_put_frame(s->st, slot, i420) ? fail("slicetype slot") : X264GPU_OK; }
+int x264gpu_slicetype_frame_cost(x264gpu_slicetype *s, int s0, int s1, int sb, int d0, int d1, int32_t *h_score, void *stream)
+{
+    const int c = x264o_slicetype_frame_cost(s->st, s0, s1, sb, d0, d1);
+    if (c < 0) return fail("slicetype triple");
+    h_score[0] = c;
+    return X264GPU_OK;
+}
+int x264gpu_slicetype_intra_mbs(x264gpu_slicetype *s, int slot, int d0, int idx) { return x264o_slicetype_intra_mbs(s->st, slot, d0); }
+int x264gpu_slicetype_cost_est(x264gpu_slicetype *s, int slot, int d0, int d1, int idx) { return x264o_slicetype_cost_est(s->st, slot, d0, d1); }
+const int16_t *x264gpu_slicetype_lowres_mvs(x264gpu_slicetype *s, int slot, int list, int dist)
+{
+    const int16_t *m = x264o_slicetype_mvs(s->st, slot, list, dist);
+    return m[0] == 0x7fff ? NULL : m;
+}
+const int *x264gpu_slicetype_lowres_mv_costs(x264gpu_slicetype *s, int slot, int list, int dist) { return x264o_slicetype_mv_costs(s->st, slot, list, dist); }
+const int *x264gpu_slicetype_intra_costs(x264gpu_slicetype *s, int slot) { return x264o_slicetype_intra_costs(s->st, slot); }
+const uint16_t *x264gpu_slicetype_lowres_costs(x264gpu_slicetype *s, int slot, int d0, int d1) { return x264o_slicetype_lowres_costs(s->st, slot, d0, d1); }
 int x264gpu_encode_frames(x264gpu_encoder *g, const uint8_t *i420, int slice_type, x264gpu_mb *mb, int16_t *lv, void *st)
 {
     if (g->dev != t_dev) return fail("encoder used from a thread bound to another device");

@@ -93,8 +93,8 @@ def test_host_session_with_b_pictures(tmp_path):
     import subprocess
     subprocess.check_call(["make", "-s", "-C", __file__.rsplit("/", 1)[0] + "/stub"])
     n, w, h = 14, 176, 144
-    info, stream = _host_b_session(tmp_path, n, ["qp=23", "keyint=30", "scenecut=0"])
-    assert (info["bframes"], info["pyramid"], info["badapt"], info["weightb"]) == (3, 2, 0, 1)      # b-adapt 1 is reported back as what runs: 0
+    info, stream = _host_b_session(tmp_path, n, ["qp=23", "keyint=30", "scenecut=0", "b-adapt=0"])
+    assert (info["bframes"], info["pyramid"], info["badapt"], info["weightb"]) == (3, 2, 0, 1)
     assert info["weightp"] == 2                                                                     # medium's --weightp 2 runs (blind duplicate)
     recs = info["recs"]
     assert len(recs) == n
@@ -137,7 +137,7 @@ def test_host_session_weightp_2_without_b_pictures(tmp_path):
 def test_host_session_crf_with_b_pictures_and_keyframes(tmp_path):
     """CRF + a short keyint: runs cut short in front of keyframes, the picture before an IDR is never B, every picture decodes"""
     n, w, h = 23, 128, 96
-    info, stream = _host_b_session(tmp_path, n, ["crf=24", "keyint=9", "min-keyint=9", "bframes=2", "scenecut=0"], w, h, seed=8)
+    info, stream = _host_b_session(tmp_path, n, ["crf=24", "keyint=9", "min-keyint=9", "bframes=2", "scenecut=0", "b-adapt=0"], w, h, seed=8)
     recs = info["recs"]
     assert len(recs) == n and info["bframes"] == 2
     by_pts = sorted(recs, key=lambda r: r[1])
@@ -146,3 +146,43 @@ def test_host_session_crf_with_b_pictures_and_keyframes(tmp_path):
     assert [r[0] for r in by_pts][::9] == [1, 1, 1]
     dec = O.h264_decode(stream, n, w, h)
     assert len(dec) == n
+
+
+def _types_by_display(recs):
+    TYPE = {1: "I", 2: "i", 3: "P", 4: "R", 5: "B"}
+    return "".join(TYPE[r[0]] for r in sorted(recs, key=lambda r: r[1]))
+
+
+def test_host_session_b_adapt_1_and_scenecut(tmp_path):
+    """medium's own lookahead settings (--b-adapt 1, --scenecut 40) through x264_encoder_encode: the slice types come from
+    x264_slicetype_analyse restated on the frame costs of (p0, p1, b) triples (oracle/slicetype.c behind the stub) — a scene cut becomes a
+    keyframe at the cut (I inside min-keyint, else IDR), the picture in front of it is never B, runs of B pictures are at most --bframes long,
+    and the stream decodes to every source picture"""
+    n, w, h = 20, 176, 144
+    frames = synth_frames(w, h, n, seed=5, scene_len=11)              # a scene cut at display pictures 11
+    info, stream = _host_b_session(tmp_path, n, ["qp=23", "keyint=60", "min-keyint=4", "scene_len=11"], w, h, seed=5)
+    assert (info["bframes"], info["badapt"], info["weightp"]) == (3, 1, 2)
+    recs = info["recs"]
+    assert len(recs) == n
+    t = _types_by_display(recs)
+    assert t[0] == "I" and t[11] == "I", t                               # the IDR at the start and the one at the cut (11 >= min-keyint)
+    assert t[10] in "PI" and t[-1] in "PI", t                            # never a B picture in front of a keyframe or last
+    assert "BBBB" not in t.replace("R", "B"), t
+    dec = O.h264_decode(stream, n, w, h)
+    pocs = O.h264_last_pocs()
+    from synth import psnr
+    by_coding = [r[1] for r in recs]
+    for d, disp in zip(dec, by_coding):
+        assert psnr(d[:w * h], frames[disp][:w * h]) > 33.0
+    assert len(pocs) == n
+
+
+def test_host_session_b_adapt_1_static_content_uses_b_pictures(tmp_path):
+    """on a nearly static clip b-adapt 1 keeps full runs of B pictures; on a clip that changes completely from picture to picture it codes P pictures"""
+    n, w, h = 13, 128, 96
+    info, _ = _host_b_session(tmp_path, n, ["qp=26", "keyint=60", "scenecut=0", "static=1"], w, h, seed=2)
+    t = _types_by_display(info["recs"])
+    assert t.replace("R", "B").count("B") >= 6, t
+    info2, _ = _host_b_session(tmp_path, n, ["qp=26", "keyint=60", "scenecut=0", "scene_len=1"], w, h, seed=2)
+    t2 = _types_by_display(info2["recs"])
+    assert t2.replace("R", "B").count("B") <= 2, t2

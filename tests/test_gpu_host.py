@@ -781,9 +781,10 @@ def encode_delayed(h_, w, h, frames):
 
 
 @pytest.mark.parametrize("w,h,n,opts,pattern", [
-    (176, 144, 14, {"qp": 23, "keyint": 30, "scenecut": 0, "bframes": 3}, "IPRBBPRBBPRBBP"),                         # preset medium as the device runs it: bframes 3, b-pyramid, weightb, ref 3
-    (128, 96, 12, {"qp": 26, "keyint": 30, "scenecut": 0, "bframes": 1, "ref": 1}, "IPBPBPBPBPBP"),
-    (96, 80, 13, {"crf": 24, "keyint": 6, "min-keyint": 6, "scenecut": 0, "bframes": 2, "b-pyramid": "none", "no-mbtree": None}, None),
+    (176, 144, 14, {"qp": 23, "keyint": 30, "scenecut": 0, "bframes": 3, "b-adapt": 0}, "IPRBBPRBBPRBBP"),                         # preset medium as the device runs it: bframes 3, b-pyramid, weightb, ref 3
+    (128, 96, 12, {"qp": 26, "keyint": 30, "scenecut": 0, "bframes": 1, "ref": 1, "b-adapt": 0}, "IPBPBPBPBPBP"),
+    (96, 80, 13, {"crf": 24, "keyint": 6, "min-keyint": 6, "scenecut": 0, "bframes": 2, "b-pyramid": "none", "no-mbtree": None, "b-adapt": 0}, None),
+    (176, 144, 16, {"qp": 23, "keyint": 30}, None),                                                                  # medium's lookahead: --b-adapt 1 --scenecut 40 on the device's (p0, p1, b) frame costs
     (176, 144, 9, {"qp": 23, "keyint": 30, "scenecut": 0, "bframes": 0, "weightp": 2}, "IPPPPPPPP"),                # no B pictures, --weightp 2: the DPB model with no delay
 ])
 def test_b_session_through_the_encode_api(gpu, w, h, n, opts, pattern):
@@ -791,7 +792,7 @@ def test_b_session_through_the_encode_api(gpu, w, h, n, opts, pattern):
     stream decodes to every source picture, and equals the checker's stream for the same schedule byte for byte"""
     frames = synth_frames(w, h, n, seed=4)
     h_, eff = open_encoder(w, h, opts, profile=None)
-    assert eff.i_bframe == opts.get("bframes", 3) and (not eff.i_bframe or (eff.i_bframe_adaptive == 0 and eff.analyse.i_direct_mv_pred == 1))
+    assert eff.i_bframe == opts.get("bframes", 3) and (not eff.i_bframe or (eff.i_bframe_adaptive == opts.get("b-adapt", 1) and eff.analyse.i_direct_mv_pred == 1))
     assert eff.analyse.i_weighted_pred == (2 if opts.get("ref", 3) >= 2 else 0)          # medium's default, kept: the blind duplicate of reference 0 (it needs two references)
     stream, recs = encode_delayed(h_, w, h, frames)
     H.x264_encoder_close(h_)

@@ -94,3 +94,57 @@ def test_aq_offsets_and_mbtree_bitexact(gpu, w, h, n, strength, with_aq):
     alone = O.mbtree(bw, bh, o_infos[-1:], o_aqs[-1:], strength)
     assert np.array_equal(alone, o_aqs[-1])
     assert (O.mbtree(bw, bh, o_infos[1:], o_aqs[1:], strength) <= o_aqs[1]).all()
+
+
+# ---- the lookahead in x264's structure: slicetype_frame_cost(p0, p1, b) for any triple (x264gpu_slicetype_* vs oracle/slicetype.c) ----
+def run_slicetype(w, h, n, seed, triples, streams=1, **kw):
+    from gpu_enc import GpuSlicetype
+    frames = synth_frames(w, h, n, seed=seed)
+    og, gg = O.OracleSlicetype(w, h, **kw), GpuSlicetype(w, h, streams=streams, **kw)
+    for i, f in enumerate(frames):
+        og.put(i, f)
+        gg.put(i, [f] * streams)
+    bw = (w + 15) // 16
+    for (p0, p1, b) in triples:
+        d0, d1 = b - p0, p1 - b
+        oc, gc = og.cost(p0, p1, b, d0, d1), gg.cost(p0, p1, b, d0, d1)
+        what = f"{w}x{h} cost(p0={p0}, p1={p1}, b={b})"
+        for l, d in ((0, d0), (1, d1)):
+            if d > 0:
+                om, gm = og.mvs(b, l, d), gg.mvs(b, l, d)
+                for s in range(streams):
+                    bad = np.nonzero((gm[s] != om).any(1))[0]
+                    assert bad.size == 0, f"{what}: list {l} vectors differ in {bad.size} blocks; first {bad[0]} (x={bad[0] % bw}, y={bad[0] // bw}) gpu={gm[s][bad[0]]} cpu={om[bad[0]]}"
+                    assert np.array_equal(gg.mv_costs(b, l, d)[s], og.mv_costs(b, l, d)), f"{what}: list {l} costs differ"
+        for s in range(streams):
+            assert np.array_equal(gg.intra_costs(b)[s], og.intra_costs(b)), f"{what}: intra costs differ"
+            ol, gl = og.lowres_costs(b, d0, d1), gg.lowres_costs(b, d0, d1)[s]
+            bad = np.nonzero(ol != gl)[0]
+            assert bad.size == 0, f"{what}: lowres_costs differ in {bad.size} blocks; first {bad[0]} gpu={gl[bad[0]]:#x} cpu={ol[bad[0]]:#x}"
+            assert gc[s] == oc, f"{what}: score gpu={gc[s]} cpu={oc}"
+        if d1 == 0 and d0 > 0:
+            assert gg.intra_mbs(b, d0) == og.intra_mbs(b, d0), f"{what}: intra block counts differ"
+    og.close(); gg.close()
+
+
+# what x264_slicetype_analyse asks for around one mini-GOP: scenecut (P against the previous picture), b-adapt 1's four costs, longer runs,
+# and the costs x264_rc_analyse_slice reads once the types are known; repeated triples come from the memo
+ADAPT = [(0, 1, 1), (0, 2, 2), (0, 2, 1), (1, 2, 2), (0, 3, 3), (0, 3, 1), (0, 3, 2), (0, 4, 4), (0, 4, 2), (0, 4, 1), (0, 4, 3), (2, 4, 3), (0, 2, 1), (4, 4, 4), (4, 5, 5)]
+
+
+@pytest.mark.parametrize("w,h,n,seed,triples,kw", [
+    (176, 144, 6, 3, ADAPT, {}),                                    # no mbtree: the picture's edge blocks are not costed
+    (176, 144, 6, 3, ADAPT, dict(do_edges=1)),                      # mbtree / VBV sessions: every block
+    (352, 288, 6, 5, ADAPT, dict(do_edges=1, weightb=0)),
+    (208, 120, 5, 7, ADAPT[:12], dict(me_range=8)),
+    (80, 48, 5, 9, ADAPT[:12], dict(do_edges=1)),
+    (32, 32, 4, 1, [(0, 1, 1), (0, 2, 2), (0, 2, 1), (0, 3, 3), (0, 3, 2)], {}),       # 2 x 2 blocks: edges always
+    (352, 288, 5, 2, ADAPT[:12], dict(subme=1, me_method=0)),        # subme <= 1: dia, SAD, level 2, half-pel bidirectional vectors
+    (720, 304, 4, 4, ADAPT[:7], dict(do_edges=1)),
+])
+def test_slicetype_costs_bitexact(gpu, w, h, n, seed, triples, kw):
+    run_slicetype(w, h, n, seed, triples, **kw)
+
+
+def test_slicetype_costs_multistream(gpu):
+    run_slicetype(176, 144, 5, 6, ADAPT[:10], streams=3, do_edges=1)

@@ -120,7 +120,15 @@ struct x264_t {
     // without them that use --weightp 2 (whose duplicate references need explicit lists); weightp: the effective --weightp (0 or 2)
     bool dpbmode = false; int weightp = 0;
     Dpb dpb;
-    struct BEntry { int64_t pts; int frame; int slot; int forced; int scenecut; int32_t costs[4]; x264_image_t img; };      // forced: 0 auto, 1 I, 2 IDR
+    struct BEntry { int64_t pts; int frame; int slot; int forced; int scenecut; int32_t costs[4]; x264_image_t img;      // forced: 0 auto, 1 I, 2 IDR
+                    int type = 0; int b_scenecut = 1; };      // slicetype analysis: the type decided so far (ST_*), "may still be a real scene cut"
+    // x264's lookahead in its own structure (x264_slicetype_analyse: scenecut against the last non-B picture with flash detection, --b-adapt 1)
+    // on the device's frame costs of arbitrary (p0, p1, b) triples; the half-resolution planes of a queued picture live in the slicetype object's
+    // slot of the same number as its raw picture
+    x264gpu_slicetype *st = nullptr;
+    bool have_last_nonb = false; BEntry last_nonb;
+    int last_keyframe = 0;                // display index of the last IDR picture decided (x264 h->lookahead->i_last_keyframe)
+    int badapt = 0;
     struct BPlanned { BEntry e; int type; };                                                                            // type: PIC_*
     std::deque<BEntry> bq;
     std::deque<BPlanned> bcoding;
@@ -302,7 +310,8 @@ x264_t *x264_encoder_open(x264_param_t *param)
         if (why) { xlog(&p, X264_LOG_WARNING, "B-frames need %s in the MI355X path: bframes 0\n", why); p.i_bframe = 0; }
     }
     if (p.i_bframe) {
-        if (p.i_bframe_adaptive) { xlog(&p, X264_LOG_WARNING, "b-adapt %d needs bidirectional lookahead costs, which are not implemented yet: b-adapt 0 (%d B pictures between references)\n", p.i_bframe_adaptive, p.i_bframe); p.i_bframe_adaptive = 0; }
+        if (p.i_bframe_adaptive > 1) { xlog(&p, X264_LOG_WARNING, "b-adapt 2 (the trellis over picture types) is not implemented in the MI355X path: b-adapt 1\n"); p.i_bframe_adaptive = 1; }
+        p.i_bframe_adaptive = p.i_bframe_adaptive != 0;
         if (p.i_bframe_pyramid == 1) { xlog(&p, X264_LOG_INFO, "b-pyramid strict -> normal\n"); p.i_bframe_pyramid = 2; }
         if (p.i_bframe < 2) p.i_bframe_pyramid = 0;
         if (p.b_open_gop) { xlog(&p, X264_LOG_WARNING, "open-gop is not implemented in the MI355X path: closed GOPs\n"); p.b_open_gop = 0; }
@@ -438,7 +447,7 @@ x264_t *x264_encoder_open(x264_param_t *param)
         x264_encoder_close(h);
         return nullptr;
     }
-    if (p.i_scenecut_threshold > 0 || h->crf || h->abr) {
+    if ((p.i_scenecut_threshold > 0 && !h->dpbmode) || h->crf || h->abr) {       // (sessions on the DPB model take scene cuts from x264's own analysis below)
         if (x264gpu_lookahead_create(&h->la, p.i_width, p.i_height, 1, p.analyse.i_me_range, p.analyse.i_subpel_refine) != X264GPU_OK ||
             x264gpu_malloc((void **)&h->d_la, 4 * sizeof(int32_t)) != X264GPU_OK) {
             xlog(&p, X264_LOG_ERROR, "GPU lookahead setup failed: %s\n", x264gpu_last_error());
@@ -454,6 +463,17 @@ x264_t *x264_encoder_open(x264_param_t *param)
     { const char *pe = getenv("X264GPU_HOST_PIPELINE"); h->pipeline = h->G == 1 && h->L > 0 && h->crf && !(pe && pe[0] == '0'); }
     h->Q = h->L + 1 + (h->pipeline ? 1 : 0);
     if (h->dpbmode) { h->pipeline = false; h->Q = 2 * (h->bframes + 1) + 2; }      // display-order queue + the mini-GOP being coded
+    h->last_keyframe = -p.i_keyint_max;
+    h->badapt = h->bframes ? p.i_bframe_adaptive : 0;
+    if (h->dpbmode && (h->badapt || p.i_scenecut_threshold > 0)) {
+        // x264's own lookahead structure: frame costs of (p0, p1, b) triples on the half-resolution planes (x264_slicetype_analyse)
+        if (x264gpu_slicetype_create(&h->st, p.i_width, p.i_height, 1, h->Q, h->bframes, p.analyse.i_me_method, p.analyse.i_subpel_refine, p.analyse.i_me_range,
+                                     p.analyse.b_weighted_bipred, p.analyse.i_mv_range, 0) != X264GPU_OK) {
+            xlog(&p, X264_LOG_ERROR, "GPU lookahead setup failed: %s\n", x264gpu_last_error());
+            x264_encoder_close(h);
+            return nullptr;
+        }
+    }
     h->aq_strength_q8 = cfg.aq_mode ? cfg.aq_strength_q8 : 0;
     h->tree_strength_q8 = (int)(1280.0 * (1.0 - p.rc.f_qcompress) + 0.5);     // 5 * (1 - qcomp), Q8
     h->q_raw.assign((size_t)h->Q, nullptr); h->q_info.assign((size_t)h->Q, nullptr); h->q_aq.assign((size_t)h->Q, nullptr);
@@ -910,12 +930,179 @@ static int encode_queued(x264_t *h, x264_nal_t **pp_nal, int *pi_nal, x264_pictu
 // x264_slicetype_decide with --b-adapt 0 over the display-order queue: the pictures up to the next non-B picture become one mini-GOP.
 // A forced I / IDR picture closes the run in front of it (the picture before an IDR becomes P: closed GOPs); otherwise the run is
 // `bframes` long, or what is left when the input ends (the last picture is never B).  Returns false while more input is needed.
+// ---- x264_slicetype_analyse / x264_slicetype_decide on the device's frame costs (sessions whose slicetype object exists: scenecut or
+//      --b-adapt 1).  frames[0] = the last non-B picture, frames[1..] = the pictures waiting in display order ----
+enum { ST_AUTO = 0, ST_IDR, ST_I, ST_P, ST_BREF, ST_B };
+struct StFrames { x264_t *h; std::vector<x264_t::BEntry *> f; };
+static int st_cost(StFrames &F, int p0, int p1, int b)
+{
+    int32_t sc = 0;
+    if (x264gpu_slicetype_frame_cost(F.h->st, F.f[(size_t)p0]->slot, F.f[(size_t)p1]->slot, F.f[(size_t)b]->slot, b - p0, p1 - b, &sc, nullptr) != X264GPU_OK) {
+        xlog(&F.h->param, X264_LOG_ERROR, "lookahead frame cost failed: %s\n", x264gpu_last_error());
+        F.h->failed = true;
+    }
+    return sc;
+}
+// scenecut_internal: P cost against I cost of frames[p1], the bias growing with the distance from the last keyframe
+static bool st_scenecut_internal(StFrames &F, int p0, int p1)
+{
+    x264_t *h = F.h;
+    const x264_param_t &p = h->param;
+    st_cost(F, p0, p1, p1);
+    const x264_t::BEntry *fr = F.f[(size_t)p1];
+    const int icost = x264gpu_slicetype_cost_est(h->st, fr->slot, 0, 0, 0), pcost = x264gpu_slicetype_cost_est(h->st, fr->slot, p1 - p0, 0, 0);
+    const int gop = fr->frame - h->last_keyframe;
+    const float tmax = (float)(p.i_scenecut_threshold / 100.0);
+    float tmin = (float)(tmax * 0.25), bias;
+    if (p.i_keyint_min == p.i_keyint_max) tmin = tmax;
+    if (gop <= p.i_keyint_min / 4) bias = tmin / 4;
+    else if (gop <= p.i_keyint_min) bias = tmin * gop / p.i_keyint_min;
+    else bias = tmin + (tmax - tmin) * (gop - p.i_keyint_min) / (p.i_keyint_max - p.i_keyint_min);
+    return pcost >= (1.0 - bias) * icost;
+}
+// scenecut: with B pictures a short flash between two scenes must not become a keyframe (x264 looks one picture past p1 under --b-adapt 1)
+static bool st_scenecut(StFrames &F, int p0, int p1, bool real, int num_frames, int i_max_search)
+{
+    x264_t *h = F.h;
+    if (real && h->bframes) {
+        const int origmaxp1 = p0 + 2, maxp1 = origmaxp1 < num_frames ? origmaxp1 : num_frames;
+        for (int curp1 = p1; curp1 <= maxp1; curp1++)
+            if (!st_scenecut_internal(F, p0, curp1))
+                for (int i = curp1; i > p0; i--) F.f[(size_t)i]->b_scenecut = 0;          // nothing between p0 and curp1 can be a real scene cut
+        for (int curp0 = p0; curp0 <= maxp1; curp0++)
+            if (origmaxp1 > i_max_search || (curp0 < maxp1 && st_scenecut_internal(F, curp0, maxp1)))
+                F.f[(size_t)curp0]->b_scenecut = 0;                                     // the p0 of a scene cut cannot be the p1 of one
+    }
+    if (!F.f[(size_t)p1]->b_scenecut) return false;
+    return st_scenecut_internal(F, p0, p1);
+}
+static void st_analyse(x264_t *h, StFrames &F, int framecnt)
+{
+    const x264_param_t &p = h->param;
+    auto type = [&](int i) -> int & { return F.f[(size_t)i]->type; };
+    auto forced = [&](int i) { const int f = F.f[(size_t)i]->forced; return f == 2 ? ST_IDR : f == 1 ? ST_I : ST_AUTO; };
+    auto auto_or_i = [](int t) { return t == ST_AUTO || t == ST_I || t == ST_IDR; };
+    const int i_max_search = framecnt;
+    if (!framecnt) return;
+    const int keyint_limit = p.i_keyint_max - F.f[0]->frame + h->last_keyframe - 1;
+    int num_frames = framecnt < keyint_limit ? framecnt : keyint_limit;
+    const int orig_num_frames = num_frames;
+    if (num_frames <= 0) { type(1) = ST_I; return; }
+    // a picture whose type the caller forced ends the window in front of it (x264 warns and overrides; here the analysis stops short)
+    for (int j = 2; j <= num_frames; j++) if (forced(j) != ST_AUTO) { num_frames = j - 1; break; }
+    if (auto_or_i(type(1)) && p.i_scenecut_threshold && st_scenecut(F, 0, 1, true, orig_num_frames, i_max_search)) {
+        if (type(1) == ST_AUTO) type(1) = ST_I;
+        return;
+    }
+    int num_bframes = 0, reset_start, num_analysed = num_frames;
+    if (h->bframes) {
+        if (h->badapt == 1) {
+            const int mbw = h->mbw, mbh = h->mbh, i_mb_count = mbw > 2 && mbh > 2 ? (mbw - 2) * (mbh - 2) : mbw * mbh;
+            for (int i = 0; i <= num_frames - 2;) {
+                const int cost2p1 = st_cost(F, i, i + 2, i + 2);
+                if (x264gpu_slicetype_intra_mbs(h->st, F.f[(size_t)i + 2]->slot, 2, 0) > i_mb_count / 2) { type(i + 1) = ST_P; type(i + 2) = ST_P; i += 2; continue; }
+                const int cost1b1 = st_cost(F, i, i + 2, i + 1), cost1p0 = st_cost(F, i, i + 1, i + 1), cost2p0 = st_cost(F, i + 1, i + 2, i + 2);
+                if (cost1p0 + cost2p0 < cost1b1 + cost2p1) { type(i + 1) = ST_P; i += 1; continue; }
+                type(i + 1) = ST_B;
+                int j;
+                for (j = i + 2; j <= (i + h->bframes < num_frames - 1 ? i + h->bframes : num_frames - 1); j++) {
+                    const int pthresh = 300 - (50 - p.i_bframe_bias) * (j - i - 1) > 30 ? 300 - (50 - p.i_bframe_bias) * (j - i - 1) : 30;
+                    const int pcost = st_cost(F, i, j + 1, j + 1);
+                    if (pcost > pthresh * i_mb_count || x264gpu_slicetype_intra_mbs(h->st, F.f[(size_t)j + 1]->slot, j - i + 1, 0) > i_mb_count / 3) break;
+                    type(j) = ST_B;
+                }
+                type(j) = ST_P;
+                i = j;
+            }
+            type(num_frames) = ST_P;
+            while (num_bframes < num_frames && type(num_bframes + 1) == ST_B) num_bframes++;
+        } else {
+            num_bframes = num_frames - 1 < h->bframes ? num_frames - 1 : h->bframes;
+            for (int j = 1; j < num_frames; j++) type(j) = (j % (num_bframes + 1)) ? ST_B : ST_P;
+            type(num_frames) = ST_P;
+        }
+        // scene cut inside the first mini-GOP: the picture in front of it closes the run
+        for (int j = 1; j < num_bframes + 1; j++)
+            if (forced(j) == ST_AUTO && auto_or_i(forced(j + 1)) && p.i_scenecut_threshold && st_scenecut(F, j, j + 1, false, orig_num_frames, i_max_search)) {
+                type(j) = ST_P;
+                num_analysed = j;
+                break;
+            }
+        reset_start = num_bframes + 2 < num_analysed + 1 ? num_bframes + 2 : num_analysed + 1;
+    } else {
+        for (int j = 1; j <= num_frames; j++) if (auto_or_i(forced(j))) type(j) = ST_P;
+        reset_start = 2;
+    }
+    // enforce the keyframe limit
+    {
+        int last_keyframe = h->last_keyframe, last_possible = 0;
+        for (int j = 1; j <= num_frames; j++) {
+            int kd = F.f[(size_t)j]->frame - last_keyframe;
+            if (auto_or_i(forced(j))) last_possible = j;
+            if (kd >= p.i_keyint_max) {
+                if (last_possible != 0 && last_possible != j) { j = last_possible; kd = F.f[(size_t)j]->frame - last_keyframe; }
+                last_possible = 0;
+                if (type(j) != ST_IDR) type(j) = ST_IDR;
+            }
+            if (type(j) == ST_I && kd >= p.i_keyint_min) type(j) = ST_IDR;
+            if (type(j) == ST_IDR) { last_keyframe = F.f[(size_t)j]->frame; if (j > 1 && (type(j - 1) == ST_B || type(j - 1) == ST_BREF)) type(j - 1) = ST_P; }
+        }
+    }
+    // the pictures behind the first mini-GOP are decided again when their turn comes
+    for (int j = reset_start; j <= framecnt; j++) type(j) = forced(j);
+}
+
+// x264_slicetype_decide: -> index of the picture that closes the first mini-GOP of the queue and its type (PIC_*)
+static bool st_decide(x264_t *h, bool flushing, int &j_out, int &closing_out)
+{
+    const x264_param_t &p = h->param;
+    const int n = (int)h->bq.size();
+    if (!flushing && n <= h->bframes) return false;
+    for (auto &e : h->bq) e.type = e.forced == 2 ? ST_IDR : e.forced == 1 ? ST_I : ST_AUTO;
+    if (h->have_last_nonb && ((h->bframes && h->badapt) || p.i_scenecut_threshold)) {
+        StFrames F;
+        F.h = h;
+        F.f.push_back(&h->last_nonb);
+        const int framecnt = n < h->bframes + 1 ? n : h->bframes + 1;          // what the lookahead holds for sure (deterministic mode), except at the end
+        for (int i = 0; i < framecnt; i++) F.f.push_back(&h->bq[(size_t)i]);
+        st_analyse(h, F, framecnt);
+        if (h->failed) return false;
+    }
+    int bfr;
+    for (bfr = 0;; bfr++) {
+        x264_t::BEntry &frm = h->bq[(size_t)bfr];
+        if (frm.frame - h->last_keyframe >= p.i_keyint_max) frm.type = ST_IDR;              // limit the GOP size
+        if (frm.type == ST_I && frm.frame - h->last_keyframe >= p.i_keyint_min) frm.type = ST_IDR;
+        if (frm.type == ST_IDR) {                                                          // close the GOP
+            h->last_keyframe = frm.frame;
+            if (bfr > 0) { bfr--; h->bq[(size_t)bfr].type = ST_P; }
+        }
+        if (bfr == h->bframes || bfr + 1 >= n) { if (frm.type == ST_AUTO || frm.type == ST_B || frm.type == ST_BREF) frm.type = ST_P; }
+        if (frm.type == ST_AUTO) frm.type = ST_B;
+        else if (frm.type != ST_B && frm.type != ST_BREF) break;
+    }
+    const int t = h->bq[(size_t)bfr].type;
+    j_out = bfr; closing_out = t == ST_IDR ? PIC_IDR : t == ST_I ? PIC_I : PIC_P;
+    return true;
+}
+
 static bool bmode_decide(x264_t *h, bool flushing)
 {
     if (!h->bcoding.empty() || h->bq.empty()) return !h->bcoding.empty();
     const int n = (int)h->bq.size();
     if (!flushing && n <= h->bframes) return false;          // the lookahead x264 keeps in front of the slice-type decision: a whole run and its closing picture
     int j = -1;                                       // index of the closing picture
+    if (h->st) {
+        int closing = PIC_P;
+        if (!st_decide(h, flushing, j, closing)) return false;
+        h->bcoding.push_back({ h->bq[(size_t)j], closing });
+        h->last_nonb = h->bq[(size_t)j]; h->have_last_nonb = true;
+        const int bref = h->bpyramid && j > 1 ? (j - 1) / 2 : -1;
+        if (bref >= 0) h->bcoding.push_back({ h->bq[(size_t)bref], PIC_BREF });
+        for (int i = 0; i < j; i++) if (i != bref) h->bcoding.push_back({ h->bq[(size_t)i], PIC_B });
+        h->bq.erase(h->bq.begin(), h->bq.begin() + j + 1);
+        return true;
+    }
     if (h->bq[0].forced) j = 0;
     else {
         for (int i = 0; i < n && i <= h->bframes; i++) {
@@ -982,6 +1169,15 @@ static int encode_bmode(x264_t *h, x264_nal_t **pp_nal, int *pi_nal, x264_pictur
     double qpf = 0;
     pic.qp = bmode_qp(h, pl, plan, &qpf);
     h->rc_frames++;
+    if (h->st) {
+        // x264_mb_predict_mv_ref16x16: the lookahead's vectors towards reference 0 of each list as search candidates, when that search ran
+        // (fenc->lowres_mvs[list][distance - 1], distances up to bframes + 1)
+        const int dist0 = pic.nref[0] ? (pic.poc - plan.list_poc[0][0]) / 2 : 0, dist1 = pic.nref[1] ? (plan.list_poc[1][0] - pic.poc) / 2 : 0;
+        const int16_t *m0 = dist0 >= 1 && dist0 <= h->bframes + 1 ? x264gpu_slicetype_lowres_mvs(h->st, pl.e.slot, 0, dist0) : nullptr;
+        const int16_t *m1 = dist1 >= 1 && dist1 <= h->bframes + 1 ? x264gpu_slicetype_lowres_mvs(h->st, pl.e.slot, 1, dist1) : nullptr;
+        x264gpu_encoder_set_lowres_mvs(h->gpu, m0);
+        x264gpu_encoder_set_lowres_mvs1(h->gpu, m1);
+    }
     if (x264gpu_encode_pictures(h->gpu, h->q_raw[(size_t)pl.e.slot], &pic, h->d_mb, h->d_lv, nullptr) != X264GPU_OK ||
         x264gpu_memcpy_d2h(h->h_mb.data(), h->d_mb, h->h_mb.size() * sizeof(x264gpu_mb), nullptr) != X264GPU_OK ||
         x264gpu_memcpy_d2h(h->h_lv.data(), h->d_lv, h->h_lv.size() * sizeof(int16_t), nullptr) != X264GPU_OK) {
@@ -1101,6 +1297,15 @@ int x264_encoder_encode(x264_t *h, x264_nal_t **pp_nal, int *pi_nal, x264_pictur
         be.pts = e.pts; be.frame = (int)(h->la_count - 1); be.slot = slot; be.forced = e.type; be.scenecut = e.scenecut; be.img = e.img;
         memcpy(be.costs, e.costs, sizeof(e.costs));
         if (pic_in->i_type == X264_TYPE_I) be.forced = 1;
+        if (h->st) {
+            // the slice-type analysis decides keyframes and scene cuts itself: only what the caller forced stays forced
+            be.forced = pic_in->i_type == X264_TYPE_IDR || pic_in->i_type == X264_TYPE_KEYFRAME ? 2 : pic_in->i_type == X264_TYPE_I ? 1 : 0;
+            be.scenecut = 0;
+            if (x264gpu_slicetype_put_frame(h->st, slot, d_raw, nullptr) != X264GPU_OK) {
+                xlog(&p, X264_LOG_ERROR, "x264_encoder_encode: lookahead failed: %s\n", x264gpu_last_error());
+                return -1;
+            }
+        }
         h->bq.push_back(be);
         h->all_pts.push_back(e.pts);
         PHASE(1);
@@ -1148,6 +1353,7 @@ void x264_encoder_close(x264_t *h)
     }
     if (h->d_tree) x264gpu_free(h->d_tree);
     if (h->la) x264gpu_lookahead_destroy(h->la);
+    if (h->st) x264gpu_slicetype_destroy(h->st);
     if (h->d_la) x264gpu_free(h->d_la);
     delete h;
 }

@@ -108,6 +108,7 @@ _SIGS = {
     "x264gpu_encoder_set_mb_qp_offsets": (_i, [_vp, _vp]),
     "x264gpu_encoder_set_stream_qps": (_i, [_vp, _vp]),
     "x264gpu_encoder_set_lowres_mvs": (_i, [_vp, _vp]),
+    "x264gpu_encoder_set_lowres_mvs1": (_i, [_vp, _vp]),
     "x264gpu_encoder_cabac_states": (_i, [_vp, _i, _i, _vp]),
     "x264gpu_trellis_blocks": (_i, [_vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp]),
     "x264gpu_encoder_deblock_pictures": (_i, [_vp, _vp, _vp, _vp, _vp]),
@@ -117,6 +118,16 @@ _SIGS = {
     "x264gpu_lookahead_frame_cost": (_i, [_vp, _vp, _i, _vp, _vp, _vp]),
     "x264gpu_lookahead_aq_offsets": (_i, [_vp, _vp, _i, _vp, _vp]),
     "x264gpu_lookahead_mbtree": (_i, [_vp, C.POINTER(_vp), C.POINTER(_vp), _i, _i, _vp, _vp]),
+    "x264gpu_slicetype_create": (_i, [C.POINTER(_vp)] + [_i] * 11),
+    "x264gpu_slicetype_destroy": (None, [_vp]),
+    "x264gpu_slicetype_put_frame": (_i, [_vp, _i, _vp, _vp]),
+    "x264gpu_slicetype_frame_cost": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _vp]),
+    "x264gpu_slicetype_intra_mbs": (_i, [_vp, _i, _i, _i]),
+    "x264gpu_slicetype_cost_est": (_i, [_vp, _i, _i, _i, _i]),
+    "x264gpu_slicetype_lowres_mvs": (_vp, [_vp, _i, _i, _i]),
+    "x264gpu_slicetype_lowres_mv_costs": (_vp, [_vp, _i, _i, _i]),
+    "x264gpu_slicetype_intra_costs": (_vp, [_vp, _i]),
+    "x264gpu_slicetype_lowres_costs": (_vp, [_vp, _i, _i, _i]),
 }
 
 EXPORTS = tuple(_SIGS)
