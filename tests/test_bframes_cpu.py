@@ -186,3 +186,16 @@ def test_host_session_b_adapt_1_static_content_uses_b_pictures(tmp_path):
     info2, _ = _host_b_session(tmp_path, n, ["qp=26", "keyint=60", "scenecut=0", "scene_len=1"], w, h, seed=2)
     t2 = _types_by_display(info2["recs"])
     assert t2.replace("R", "B").count("B") <= 2, t2
+
+
+def test_host_session_crf_on_the_lookaheads_costs(tmp_path):
+    """CRF with medium's lookahead (b-adapt 1, scenecut): the quantisers follow from the frame costs of the decided types (x264_rc_analyse_slice:
+    the I cost, or the P cost against the last non-B picture); quantisers move with the content and every picture decodes"""
+    n, w, h = 16, 176, 144
+    info, stream = _host_b_session(tmp_path, n, ["crf=24", "keyint=60", "no-mbtree"], w, h, seed=6)
+    assert (info["badapt"], info["mbtree"]) == (1, 0)
+    dec = O.h264_decode(stream, n, w, h)
+    frames = synth_frames(w, h, n, seed=6)
+    from synth import psnr
+    for d, r in zip(dec, info["recs"]):
+        assert psnr(d[:w * h], frames[r[1]][:w * h]) > 30.0

@@ -1095,6 +1095,17 @@ static bool bmode_decide(x264_t *h, bool flushing)
     if (h->st) {
         int closing = PIC_P;
         if (!st_decide(h, flushing, j, closing)) return false;
+        if (h->crf) {
+            // x264_rc_analyse_slice: the closing picture's complexity is its frame cost as the type it was given — the I cost, or the P cost
+            // against the last non-B picture (distance = run length + 1), from the lookahead that decided the types
+            x264_t::BEntry &c = h->bq[(size_t)j];
+            int32_t ic = 0, pc = 0;
+            bool ok = x264gpu_slicetype_frame_cost(h->st, c.slot, c.slot, c.slot, 0, 0, &ic, nullptr) == X264GPU_OK;
+            if (ok && closing == PIC_P && h->have_last_nonb) ok = x264gpu_slicetype_frame_cost(h->st, h->last_nonb.slot, c.slot, c.slot, j + 1, 0, &pc, nullptr) == X264GPU_OK;
+            else pc = ic;
+            if (!ok) { xlog(&h->param, X264_LOG_ERROR, "lookahead frame cost failed: %s\n", x264gpu_last_error()); h->failed = true; return false; }
+            c.costs[0] = ic; c.costs[1] = pc;
+        }
         h->bcoding.push_back({ h->bq[(size_t)j], closing });
         h->last_nonb = h->bq[(size_t)j]; h->have_last_nonb = true;
         const int bref = h->bpyramid && j > 1 ? (j - 1) / 2 : -1;
