@@ -234,8 +234,9 @@ __device__ __forceinline__ void me_search(const EncK &k, MbLds<M> &L, const MbCt
     // ---- this reference's slot of the reference cache ----
     const int slot = cref >= 3 ? cref - 3 : cref;
     uint32_t *rslot = L.rc + slot * RC_SLOT_DW;
-    int X0 = slot == 0 ? wtg.x00 : slot == 1 ? wtg.x01 : wtg.x02, Y0 = slot == 0 ? wtg.y00 : slot == 1 ? wtg.y01 : wtg.y02;
-    bool rhave = (slot == 0 ? wtg.ref0 : slot == 1 ? wtg.ref1 : wtg.ref2) == cref;
+    // (unary plus: a conditional over lvalues is a select of ADDRESSES, which keeps the tag structure in scratch memory; over values it is a select)
+    int X0 = slot == 0 ? +wtg.x00 : slot == 1 ? +wtg.x01 : +wtg.x02, Y0 = slot == 0 ? +wtg.y00 : slot == 1 ? +wtg.y01 : +wtg.y02;
+    bool rhave = (slot == 0 ? +wtg.ref0 : slot == 1 ? +wtg.ref1 : +wtg.ref2) == cref;
     auto rc_inside = [&](int x0, int y0, int x1, int y1) { return rhave && x0 >= X0 && x1 <= X0 + RC_COLS && y0 >= Y0 && y1 <= Y0 + RC_ROWS; };
     // the block displaced by full-pel (mx +- rad, my +- rad) / by the quarter-pel vector (qx, qy) / anywhere within M samples of full-pel (cx, cy)
     auto in_fpel = [&](int mx, int my, int rad) { return rc_inside(bx + mx - rad, by + my - rad, bx + mx + rad + j.W, by + my + rad + j.H); };
@@ -1389,8 +1390,12 @@ template <int M, int ME, bool PS, int RD = 0, bool BS = false>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(MB_WAVES_PER_EU, 4))) void k_mb_slice(EncK k)
 {
     static_assert(!BS || (PS && RD >= 2), "B slices: RD sessions with CABAC");
-    __shared__ uint32_t b_visited[BS ? 128 : 1];          // x264_me_refine_bidir: vector quadruples already costed
     __shared__ __attribute__((aligned(16))) MbLds<M> L;
+    // x264_me_refine_bidir: bit set of the vector quadruples already costed (4096 bits).  It lives in the chroma sub-pel staging area, which only
+    // holds data DURING a search: a buffer of its own made the B instantiations' LDS 20 992 B a wavefront — seven instead of eight wavefronts a CU,
+    // so the last 256 of 2048 streams ran as a second round
+    static_assert(!BS || CSubGeo<M>::DWORDS >= 128, "b_visited aliases L.csub");
+    uint32_t *const b_visited = L.csub;
     const int lane = threadIdx.x, s = blockIdx.x;
     // x264 slice threads: blockIdx.y = slice of the picture, macroblock rows [row0, row1) (k.slices == 1: the whole picture)
     const int nsl = k.slices > 1 ? k.slices : 1, row0 = (k.mbh * (int)blockIdx.y + nsl / 2) / nsl, row1 = (k.mbh * ((int)blockIdx.y + 1) + nsl / 2) / nsl;
