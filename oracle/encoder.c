@@ -285,6 +285,9 @@ int x264o_encoder_encode_pic(x264o_encoder *e, const uint8_t *i420, const x264gp
         for (int r = 0; r < e->nref_l[l]; r++) { e->lslot[l][r] = pic->slot[l][r]; if (pic->slot[l][r] < 0 || pic->slot[l][r] >= e->slots || pic->slot[l][r] == pic->dst) return -1; }
     }
     if (slice_type != X264GPU_SLICE_I && !e->nref_l[0]) return -1;
+    /* x264 slice init: h->mb.b_dct_decimate = B slice || (--dct-decimate && not an I slice): B slices decimate whatever the option says */
+    const int cfg_decimate = e->cfg.dct_decimate;
+    if (slice_type == X264GPU_SLICE_B) e->cfg.dct_decimate = 1;
     if (slice_type == X264GPU_SLICE_B && !e->nref_l[1]) return -1;
     e->nref = e->nref_l[0];
     e->blind_dupe = -1;
@@ -328,6 +331,7 @@ int x264o_encoder_encode_pic(x264o_encoder *e, const uint8_t *i420, const x264gp
     if (e->cfg.aq_mode || e->ext_off_q8) settle_mb_qp(e, mbs, slice_qp);
     if (e->cfg.deblock) deblock_frame(e, mbs);
     if (pic->keep) filter_frame(e);
+    e->cfg.dct_decimate = cfg_decimate;
     return 0;
 }
 

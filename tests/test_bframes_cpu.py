@@ -35,6 +35,7 @@ def run(w, h, types, seed, bframes=3, pyramid=1, weightp=0, pics_out=None, **ove
     (208, 112, "IPBBBPBPBBP", 3, dict(weightb=0, mixed_refs=0)),
     (176, 144, "IBBBPBBBPBBBP", 6, dict(refs=1, dct8x8=0, trellis=0)),            # ref 1: the DPB still holds 4 pictures under b-pyramid
     (128, 96, "IBBPBBP", 7, dict(refs=5, dpb=5, chroma_me=0, psy_rd_q8=0)),
+    (176, 144, "IBBPBP", 8, dict(dct_decimate=0)),
 ])
 def test_b_pictures_decode_to_the_encoders_reconstruction(w, h, types, seed, over):
     run(w, h, types, seed, **over)

@@ -64,6 +64,7 @@ def run(gpu, w, h, types, seed, streams=1, bframes=3, pyramid=1, weightp=0, **ov
     (208, 112, "IPBBBPBPBBP", 3, dict(weightb=0, mixed_refs=0)),
     (176, 144, "IBBBPBBBPBBBP", 6, dict(refs=1, dct8x8=0, trellis=0)),
     (128, 96, "IBBPBBP", 7, dict(refs=5, dpb=5, chroma_me=0, psy_rd_q8=0)),
+    (176, 144, "IBBPBP", 8, dict(dct_decimate=0)),                                  # --no-dct-decimate: B slices decimate all the same (x264 b_dct_decimate)
 ])
 def test_b_pictures_bitexact_and_decodable(gpu, w, h, types, seed, over):
     run(gpu, w, h, types, seed, **over)

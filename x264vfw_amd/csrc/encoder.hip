@@ -397,6 +397,7 @@ static int encode_core(x264gpu_encoder *e, const uint8_t *d_i420, const x264gpu_
     k.mb = d_mb; k.levels = d_levels;
     k.qp = qp; k.lambda = lambda_of(qp); k.qpc = chroma_qp_of(qp, e->cfg.chroma_qp_offset);
     k.slice_type = slice_type;
+    k.dct_decimate = e->cfg.dct_decimate || bslice;      // x264: B slices decimate whatever --no-dct-decimate says (h->mb.b_dct_decimate)
     k.partitions = (slice_type == X264GPU_SLICE_I && (e->cfg.partitions & 0x100)) ? (e->cfg.partitions >> 8) & 6 : e->cfg.partitions & 7;
     k.dbg = e->dbg;
 
