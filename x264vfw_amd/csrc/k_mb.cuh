@@ -32,7 +32,10 @@ enum { ME_16 = 0, ME_8 = 1, ME_16x8 = 5, ME_8x16 = 7, ME_COUNT = 9 };     // slo
 // full-pel steps and uses the slot for the sub-pel ones.
 constexpr int MVC_N = 512;
 constexpr int RC_ROWS = 30, RC_PD = 10, RC_COLS = 4 * RC_PD, RC_PLANE_DW = RC_ROWS * RC_PD, RC_SLOT_DW = 4 * RC_PLANE_DW, RC_MX = 12, RC_MY = 7;
-struct WinTags { int ref0, x00, y00, ref1, x01, y01, ref2, x02, y02; };
+// tags of the three reference-cache slots, as a lane-indexed register table like MeState (lane = slot): which picture the slot holds and where
+// its sample (0, 0) lies.  (As nine named fields selected by `slot` the structure stayed in scratch memory: a conditional over lvalues is a
+// select of addresses.)
+struct WinTags { int tref, tx, ty; };
 
 template <int M> struct MbLds {
     __attribute__((aligned(16))) uint32_t rc[3 * RC_SLOT_DW];        // >= WIN_ROWS * WIN_STRIDE bytes (esa)
@@ -234,9 +237,8 @@ __device__ __forceinline__ void me_search(const EncK &k, MbLds<M> &L, const MbCt
     // ---- this reference's slot of the reference cache ----
     const int slot = cref >= 3 ? cref - 3 : cref;
     uint32_t *rslot = L.rc + slot * RC_SLOT_DW;
-    // (unary plus: a conditional over lvalues is a select of ADDRESSES, which keeps the tag structure in scratch memory; over values it is a select)
-    int X0 = slot == 0 ? +wtg.x00 : slot == 1 ? +wtg.x01 : +wtg.x02, Y0 = slot == 0 ? +wtg.y00 : slot == 1 ? +wtg.y01 : +wtg.y02;
-    bool rhave = (slot == 0 ? +wtg.ref0 : slot == 1 ? +wtg.ref1 : +wtg.ref2) == cref;
+    int X0 = __builtin_amdgcn_readlane(wtg.tx, slot), Y0 = __builtin_amdgcn_readlane(wtg.ty, slot);
+    bool rhave = __builtin_amdgcn_readlane(wtg.tref, slot) == cref;
     auto rc_inside = [&](int x0, int y0, int x1, int y1) { return rhave && x0 >= X0 && x1 <= X0 + RC_COLS && y0 >= Y0 && y1 <= Y0 + RC_ROWS; };
     // the block displaced by full-pel (mx +- rad, my +- rad) / by the quarter-pel vector (qx, qy) / anywhere within M samples of full-pel (cx, cy)
     auto in_fpel = [&](int mx, int my, int rad) { return rc_inside(bx + mx - rad, by + my - rad, bx + mx + rad + j.W, by + my + rad + j.H); };
@@ -265,7 +267,7 @@ __device__ __forceinline__ void me_search(const EncK &k, MbLds<M> &L, const MbCt
 #ifndef MB_PROF_RD
         pf.count(15);
 #endif
-        if (slot == 0) { wtg.ref0 = cref; wtg.x00 = X0; wtg.y00 = Y0; } else if (slot == 1) { wtg.ref1 = cref; wtg.x01 = X0; wtg.y01 = Y0; } else { wtg.ref2 = cref; wtg.x02 = X0; wtg.y02 = Y0; }
+        { const bool m = lane == slot; wtg.tref = m ? cref : wtg.tref; wtg.tx = m ? X0 : wtg.tx; wtg.ty = m ? Y0 : wtg.ty; }
         lds_sync();
     };
     auto rc_stage = [&](int cx, int cy) { uint32_t v[20]; rc_issue(cx, cy, v); rc_commit(v); };
@@ -439,7 +441,7 @@ __device__ __forceinline__ void me_search(const EncK &k, MbLds<M> &L, const MbCt
         }
         if (esa) {      // its window around the start
             lds_sync();
-            wtg.ref0 = wtg.ref1 = wtg.ref2 = -1; rhave = false;
+            wtg.tref = -1; rhave = false;
             wx0 = clampi((bx + bmx - WIN_R) & ~7, -PAD, k.cw + PAD - WIN_COLS); wy0 = clampi(by + bmy - WIN_R, -PAD, k.ch + PAD - WIN_ROWS);
             for (int i = lane; i < WIN_ROWS * 8; i += 64) {
                 const int row = i >> 3, col = (i & 7) * 8;
@@ -1649,7 +1651,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(MB_WAVES_PER
             int prev_mvx = 0, prev_mvy = 0, prev_cost = 0;
             bool done = pskip;
             WinTags wt;
-            wt.ref0 = wt.ref1 = wt.ref2 = -1; wt.x00 = wt.x01 = wt.x02 = wt.y00 = wt.y01 = wt.y02 = 0;
+            wt.tref = -1; wt.tx = wt.ty = 0;
             wl(S.cost, lane, ME_16, 0x7fffffff);
             i_cost = 0x7fffffff;
             // a 16x8 / 8x16 half: candidate references = those of its two 8x8 blocks (lower index first); before the first half also the
@@ -1896,7 +1898,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(MB_WAVES_PER
         int b_type = X264GPU_MB_B_SKIP, b_part = D_16x16, b_use16 = 0;
         uint32_t b_cenc = 0;             // this lane's chroma source row (lanes 0..31: plane (lane >> 4) & 1, 4x4 block (lane >> 2) & 3, row lane & 3)
         WinTags wt;
-        wt.ref0 = wt.ref1 = wt.ref2 = -1; wt.x00 = wt.x01 = wt.x02 = wt.y00 = wt.y01 = wt.y02 = 0;
+        wt.tref = -1; wt.tx = wt.ty = 0;
         if constexpr (BS) {
             rd_run = true; commit = false;
             const int ci_ = (lane >> 2) & 3;

@@ -146,7 +146,7 @@ __global__ __launch_bounds__(64) void k_st_cost(StK k)
     MeState S;
     S.mvx = S.mvy = S.mvpx = S.mvpy = S.cost = S.costmv = S.ref = S.refcost = S.cref = S.cmvx = S.cmvy = S.mvcx = S.mvcy = S.inx = S.iny = S.cdir = 0;
     WinTags wtg;
-    wtg.ref0 = wtg.ref1 = wtg.ref2 = -1; wtg.x00 = wtg.x01 = wtg.x02 = wtg.y00 = wtg.y01 = wtg.y02 = 0;
+    wtg.tref = -1; wtg.tx = wtg.ty = 0;
     Prof pf;
     pf.start();
     const bool b_bidir = k.d1 > 0, satd = k.param_subme > 1;
