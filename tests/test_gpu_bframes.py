@@ -84,5 +84,12 @@ def test_weightp_2_blind_duplicate_bitexact_and_decodable(gpu, w, h, types, seed
     assert run(gpu, w, h, types, seed, weightp=2, **over) > 0
 
 
+def test_headline_size_b_pictures_and_weightp_bitexact(gpu):
+    """1920x1080 (BASELINE.json's headline geometry), the bench's toolset: one mini-GOP I B B B P plus a second P picture (so that a P picture has two
+    references and carries the --weightp 2 duplicate) — records, levels, reconstruction and context variables against the CPU checker, and the
+    device's stream through the checker decoder"""
+    assert run(gpu, 1920, 1080, "IBBBPP", 21, weightp=2) > 0
+
+
 def test_b_pictures_multistream(gpu):
     run(gpu, 96, 80, "IBBBPBBP", 11, streams=3)

@@ -146,5 +146,10 @@ def test_slicetype_costs_bitexact(gpu, w, h, n, seed, triples, kw):
     run_slicetype(w, h, n, seed, triples, **kw)
 
 
+def test_slicetype_costs_headline_size(gpu):
+    """1920x1080: 120 x 68 blocks, the row wavefront at its full depth"""
+    run_slicetype(1920, 1080, 4, 8, [(0, 1, 1), (0, 2, 2), (0, 2, 1), (1, 2, 2), (0, 3, 3), (0, 3, 1), (3, 3, 3)], do_edges=1)
+
+
 def test_slicetype_costs_multistream(gpu):
     run_slicetype(176, 144, 5, 6, ADAPT[:10], streams=3, do_edges=1)
