@@ -328,6 +328,15 @@ const int16_t  *x264gpu_slicetype_lowres_mvs(x264gpu_slicetype *st, int slot, in
 const int      *x264gpu_slicetype_lowres_mv_costs(x264gpu_slicetype *st, int slot, int list, int dist);
 const int      *x264gpu_slicetype_intra_costs(x264gpu_slicetype *st, int slot);
 const uint16_t *x264gpu_slicetype_lowres_costs(x264gpu_slicetype *st, int slot, int d0, int d1);
+/* macroblock-tree through B pictures: the building blocks of x264's macroblock_tree (the caller walks the pictures of the lookahead as x264 does:
+ * clear the propagate cost of a non-B picture, x264gpu_slicetype_frame_cost of a triple, _propagate it, ..., _finish the picture about to be coded).
+ * AQ offsets (x264_adaptive_quant_frame; x264gpu_lookahead_aq_offsets) weight the costs (i_inv_qscale_factor) and are the base of the result;
+ * the result is what x264gpu_encoder_set_mb_qp_offsets takes.  Propagate costs saturate at 32767 as x264's do (applied where a sum is read). */
+int  x264gpu_slicetype_set_aq(x264gpu_slicetype *st, int slot, const int16_t *d_aq_q8, void *stream);
+int  x264gpu_slicetype_clear_propagate(x264gpu_slicetype *st, int slot, void *stream);
+int  x264gpu_slicetype_propagate(x264gpu_slicetype *st, int slot_p0, int slot_p1, int slot_b, int d0, int d1, int referenced, void *stream);
+int  x264gpu_slicetype_finish(x264gpu_slicetype *st, int slot, int strength_q8, int16_t *d_out_q8, void *stream);
+const int32_t  *x264gpu_slicetype_propagate_cost(x264gpu_slicetype *st, int slot);
 
 /* ------------------------------------------------------------------------------------------------
  * Lookahead frame cost: x264_slicetype_frame_cost of [x264-upstream]

@@ -45,6 +45,7 @@ typedef struct x264o_slicetype {
     x264o_encoder lo;            /* shell over the half-resolution plane sets (see x264o_lowres_me_search) */
     st_frame *fr;
     pixel *tmp;
+    struct st_tree_s { int32_t *prop; int16_t *aq; } *tree;      /* per slot: macroblock-tree propagate costs, AQ offsets (Q8) */
 } x264o_slicetype;
 
 x264o_slicetype *x264o_slicetype_create(int width, int height, int slots, int bframes, int me_method, int subme, int me_range, int weightb, int mv_range, int do_edges)
@@ -70,6 +71,8 @@ x264o_slicetype *x264o_slicetype_create(int width, int height, int slots, int bf
         for (int i = 0; i <= st->bframes + 1; i++) for (int j = 0; j <= st->bframes + 1; j++) f->lowres_costs[i][j] = calloc((size_t)st->nb, sizeof(uint16_t));
     }
     st->tmp = malloc((size_t)st->bw * 16 * st->bh * 16);
+    st->tree = calloc((size_t)st->nslots, sizeof(*st->tree));
+    for (int s = 0; s < st->nslots; s++) { st->tree[s].prop = calloc((size_t)st->nb, sizeof(int32_t)); st->tree[s].aq = calloc((size_t)st->nb, sizeof(int16_t)); }
     return st;
 }
 
@@ -84,6 +87,8 @@ void x264o_slicetype_destroy(x264o_slicetype *st)
         for (int i = 0; i <= st->bframes + 1; i++) for (int j = 0; j <= st->bframes + 1; j++) free(f->lowres_costs[i][j]);
     }
     for (int q = 0; q < 52; q++) free(st->lo.cost_mv[q]);
+    for (int s = 0; s < st->nslots; s++) { free(st->tree[s].prop); free(st->tree[s].aq); }
+    free(st->tree);
     free(st->fr); free(st->tmp); free(st);
 }
 
@@ -108,6 +113,7 @@ int x264o_slicetype_put_frame(x264o_slicetype *st, int slot, const uint8_t *i420
     for (int i = 0; i <= st->bframes + 1; i++) for (int j = 0; j <= st->bframes + 1; j++) f->cost_est[i][j] = -1;
     memset(f->intra_mbs, 0, sizeof(f->intra_mbs));
     f->intra_calculated = 0;
+    memset(st->tree[slot].prop, 0, (size_t)st->nb * sizeof(int32_t)); memset(st->tree[slot].aq, 0, (size_t)st->nb * sizeof(int16_t));
     return 0;
 }
 
@@ -264,3 +270,93 @@ const int16_t *x264o_slicetype_mvs(const x264o_slicetype *st, int slot, int list
 const int *x264o_slicetype_mv_costs(const x264o_slicetype *st, int slot, int list, int dist) { return st->fr[slot].mv_costs[list][dist - 1]; }
 const int *x264o_slicetype_intra_costs(const x264o_slicetype *st, int slot) { return st->fr[slot].intra_cost; }
 const uint16_t *x264o_slicetype_lowres_costs(const x264o_slicetype *st, int slot, int d0, int d1) { return st->fr[slot].lowres_costs[d0][d1]; }
+
+/* ---------------------------------------------------------------------------------------------------------------------------
+ * macroblock-tree through B pictures ([x264-upstream] encoder/slicetype.c macroblock_tree_propagate, common/mc.c mbtree_propagate_cost /
+ * mbtree_propagate_list, macroblock_tree_finish), constant frame rate.  Every picture hands the part of its cost that its references explain
+ * back to the blocks its vectors point at: list 0 and list 1 as lowres_costs' list_used bits say, bi-predicted blocks split by the implicit
+ * weight, bilinear split over four blocks, 15-bit saturating sums.  Integer restatement of x264's float expressions as in oracle/lookahead.c
+ * x264o_mbtree: amounts carry 9 fractional bits (fps_factor 1 / 512), inverse quantiser scales are x264_exp2fix8 of the AQ offsets. */
+static const uint8_t st_log2_lut[128] = {
+#include "x264gpu_aq_lut.inc"
+};
+static const uint16_t st_exp2_lut[64] = {
+#include "x264gpu_exp2_lut.inc"
+};
+static int st_log2_q8(uint32_t x) { int lz = 31 - __builtin_clz(x); return lz * 256 + st_log2_lut[((x << (31 - lz)) >> 24) & 0x7f]; }
+static int st_inv_qscale(int aq_q8)
+{
+    int i = (-aq_q8 * 64 + 786432 + 768) / 1536;
+    if (i < 0) return 0;
+    if (i > 1023) return 0xffff;
+    return (int)(((uint32_t)(st_exp2_lut[i & 63] + 256) << (i >> 6)) >> 8);
+}
+typedef struct st_tree_s st_tree;
+static st_tree *st_tree_of(x264o_slicetype *st) { return st->tree; }
+/* x264_adaptive_quant_frame's offsets of the picture in `slot` (Q8; NULL = none): i_inv_qscale_factor follows from them */
+void x264o_slicetype_set_aq(x264o_slicetype *st, int slot, const int16_t *aq_q8)
+{
+    st_tree *t = st_tree_of(st);
+    if (aq_q8) memcpy(t[slot].aq, aq_q8, (size_t)st->nb * sizeof(int16_t)); else memset(t[slot].aq, 0, (size_t)st->nb * sizeof(int16_t));
+}
+void x264o_slicetype_clear_propagate(x264o_slicetype *st, int slot) { memset(st_tree_of(st)[slot].prop, 0, (size_t)st->nb * sizeof(int32_t)); }
+/* macroblock_tree_propagate(p0, p1, b, referenced): the costs of (p0, p1, b) must have been computed */
+int x264o_slicetype_propagate(x264o_slicetype *st, int s0, int s1, int sb, int d0, int d1, int referenced)
+{
+    st_tree *t = st_tree_of(st);
+    st_frame *f = &st->fr[sb];
+    if (d0 < 0 || d1 < 0 || d0 + d1 == 0 || f->cost_est[d0][d1] < 0) return -1;
+    const int bw = st->bw, bh = st->bh;
+    const int dsf = d1 > 0 ? ((d0 << 8) + ((d0 + d1) >> 1)) / (d0 + d1) : 256;
+    const int bipw = st->weightb && d1 > 0 ? 64 - (dsf >> 2) : 32, bw2[2] = { bipw, 64 - bipw };
+    const uint16_t *lc = f->lowres_costs[d0][d1];
+    int32_t *refs[2] = { t[s0].prop, t[s1].prop };
+    for (int by = 0; by < bh; by++)
+        for (int bx = 0; bx < bw; bx++) {
+            const int i = by * bw + bx;
+            const int intra = f->intra_cost[i] > LOWRES_COST_MASK ? LOWRES_COST_MASK : f->intra_cost[i];
+            const int best = lc[i] & LOWRES_COST_MASK, inter = best < intra ? best : intra, inv = st_inv_qscale(t[sb].aq[i]);
+            const int64_t amt512 = (int64_t)(referenced ? (t[sb].prop[i] > 32767 ? 32767 : t[sb].prop[i]) : 0) * 512 + (int64_t)intra * inv;
+            int amount = intra ? (int)((amt512 * (intra - inter) + 256 * (int64_t)intra) / (512 * (int64_t)intra)) : 0;
+            if (amount > 32767) amount = 32767;
+            const int used = lc[i] >> LOWRES_COST_SHIFT;
+            for (int l = 0; l < (d1 > 0 ? 2 : 1); l++) {
+                if (!(used & (1 << l))) continue;
+                int la = amount;
+                if (used == 3) la = (la * bw2[l] + 32) >> 6;
+                const int16_t (*mv)[2] = f->mvs[l][(l ? d1 : d0) - 1];
+                int x = mv[i][0], y = mv[i][1];
+                int32_t *ref = refs[l];
+#define CLIP_ADD(idx, v) do { int t_ = ref[idx] + (v); ref[idx] = t_ > 32767 ? 32767 : t_; } while (0)
+                if (!(x | y)) { CLIP_ADD(i, la); continue; }
+                const int mbx = (x >> 5) + bx, mby = (y >> 5) + by;
+                x &= 31; y &= 31;
+                const int w0 = ((32 - y) * (32 - x) * la + 512) >> 10, w1 = ((32 - y) * x * la + 512) >> 10;
+                const int w2 = (y * (32 - x) * la + 512) >> 10, w3 = (y * x * la + 512) >> 10;
+                if (mby >= 0 && mby < bh) { if (mbx >= 0 && mbx < bw) CLIP_ADD(mby * bw + mbx, w0); if (mbx + 1 >= 0 && mbx + 1 < bw) CLIP_ADD(mby * bw + mbx + 1, w1); }
+                if (mby + 1 >= 0 && mby + 1 < bh) { if (mbx >= 0 && mbx < bw) CLIP_ADD((mby + 1) * bw + mbx, w2); if (mbx + 1 >= 0 && mbx + 1 < bw) CLIP_ADD((mby + 1) * bw + mbx + 1, w3); }
+#undef CLIP_ADD
+            }
+        }
+    return 0;
+}
+/* macroblock_tree_finish: out = aq - strength * log2((intra + propagated) / intra), Q8 */
+int x264o_slicetype_finish(x264o_slicetype *st, int slot, int strength_q8, int16_t *out_q8)
+{
+    st_tree *t = st_tree_of(st);
+    const st_frame *f = &st->fr[slot];
+    if (f->cost_est[0][0] < 0) return -1;          /* the intra costs exist once any cost of the picture has been computed */
+    for (int i = 0; i < st->nb; i++) {
+        const int a = t[slot].aq[i];
+        const int icost = f->intra_cost[i] > LOWRES_COST_MASK ? LOWRES_COST_MASK : f->intra_cost[i];
+        const int intra = (icost * st_inv_qscale(a) + 128) >> 8;
+        int off = a;
+        if (intra) {
+            const int p2 = (t[slot].prop[i] > 32767 ? 32767 : t[slot].prop[i]) * 2;
+            off = a - ((strength_q8 * (st_log2_q8((uint32_t)(intra + p2)) - st_log2_q8((uint32_t)intra))) >> 8);
+        }
+        out_q8[i] = (int16_t)off;
+    }
+    return 0;
+}
+const int32_t *x264o_slicetype_propagate_cost(x264o_slicetype *st, int slot) { return st_tree_of(st)[slot].prop; }

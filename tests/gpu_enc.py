@@ -169,6 +169,30 @@ class GpuSlicetype:
     def lowres_costs(self, slot, d0, d1):
         return self._dev(lib.x264gpu_slicetype_lowres_costs(self.h, slot, d0, d1), np.uint16, (self.S, self.nb))
 
+    def set_aq(self, slot, aq_q8):
+        """aq_q8: [blocks] int16 (replicated over the streams) or None"""
+        if aq_q8 is None:
+            lib.check(lib.x264gpu_slicetype_set_aq(self.h, slot, None, None), "set_aq")
+            return
+        d = self.torch.from_numpy(np.ascontiguousarray(np.tile(np.asarray(aq_q8, np.int16), (self.S, 1)))).cuda()
+        lib.check(lib.x264gpu_slicetype_set_aq(self.h, slot, d.data_ptr(), None), "set_aq")
+        self.torch.cuda.synchronize()
+
+    def clear_propagate(self, slot):
+        lib.check(lib.x264gpu_slicetype_clear_propagate(self.h, slot, None), "clear_propagate")
+
+    def propagate(self, s0, s1, sb, d0, d1, referenced):
+        lib.check(lib.x264gpu_slicetype_propagate(self.h, s0, s1, sb, d0, d1, int(referenced), None), "propagate")
+
+    def finish(self, slot, strength_q8):
+        out = self.torch.zeros((self.S, self.nb), dtype=self.torch.int16, device="cuda")
+        lib.check(lib.x264gpu_slicetype_finish(self.h, slot, strength_q8, out.data_ptr(), None), "finish")
+        self.torch.cuda.synchronize()
+        return out.cpu().numpy()
+
+    def propagate_cost(self, slot):
+        return np.minimum(self._dev(lib.x264gpu_slicetype_propagate_cost(self.h, slot), np.int32, (self.S, self.nb)), 32767)
+
     def close(self):
         if self.h:
             lib.x264gpu_slicetype_destroy(self.h)

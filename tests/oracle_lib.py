@@ -279,6 +279,11 @@ _sig("x264o_slicetype_mvs", C.c_void_p, [C.c_void_p, _i, _i, _i])
 _sig("x264o_slicetype_mv_costs", C.c_void_p, [C.c_void_p, _i, _i, _i])
 _sig("x264o_slicetype_intra_costs", C.c_void_p, [C.c_void_p, _i])
 _sig("x264o_slicetype_lowres_costs", C.c_void_p, [C.c_void_p, _i, _i, _i])
+_sig("x264o_slicetype_set_aq", None, [C.c_void_p, _i, C.c_void_p])
+_sig("x264o_slicetype_clear_propagate", None, [C.c_void_p, _i])
+_sig("x264o_slicetype_propagate", _i, [C.c_void_p, _i, _i, _i, _i, _i, _i])
+_sig("x264o_slicetype_finish", _i, [C.c_void_p, _i, _i, C.c_void_p])
+_sig("x264o_slicetype_propagate_cost", C.c_void_p, [C.c_void_p, _i])
 
 
 class OracleSlicetype:
@@ -317,6 +322,24 @@ class OracleSlicetype:
 
     def lowres_costs(self, slot, d0, d1):
         return self._arr(L.x264o_slicetype_lowres_costs(self.st, slot, d0, d1), np.uint16, (self.nb,))
+
+    def set_aq(self, slot, aq_q8):
+        a = None if aq_q8 is None else np.ascontiguousarray(aq_q8, np.int16)
+        L.x264o_slicetype_set_aq(self.st, slot, None if a is None else ptr(a))
+
+    def clear_propagate(self, slot):
+        L.x264o_slicetype_clear_propagate(self.st, slot)
+
+    def propagate(self, s0, s1, sb, d0, d1, referenced):
+        assert L.x264o_slicetype_propagate(self.st, s0, s1, sb, d0, d1, int(referenced)) == 0
+
+    def finish(self, slot, strength_q8):
+        out = np.zeros(self.nb, np.int16)
+        assert L.x264o_slicetype_finish(self.st, slot, strength_q8, ptr(out)) == 0
+        return out
+
+    def propagate_cost(self, slot):
+        return np.minimum(self._arr(L.x264o_slicetype_propagate_cost(self.st, slot), np.int32, (self.nb,)), 32767)
 
     def close(self):
         if self.st and L is not None:

@@ -153,3 +153,34 @@ def test_slicetype_costs_headline_size(gpu):
 
 def test_slicetype_costs_multistream(gpu):
     run_slicetype(176, 144, 5, 6, ADAPT[:10], streams=3, do_edges=1)
+
+
+# ---- macroblock-tree through B pictures: x264's macroblock_tree walked over both implementations (tests/mbtree_walk.py) ----
+@pytest.mark.parametrize("w,h,types,pyramid,b_intra,aq,seed", [
+    (176, 144, "PBBBPBBPBP", True, False, True, 3),             # b-pyramid, runs of 3 / 2 / 1
+    (176, 144, "PBBBPBBPBP", False, False, True, 3),
+    (208, 120, "IPPBPBBBP", True, True, True, 5),               # the keyframe's own pass (b_intra): the tree reaches frames[0]
+    (352, 288, "PBBBPBBBPP", True, False, False, 7),            # without AQ
+    (80, 48, "PBPBBP", True, False, True, 9),
+])
+def test_mbtree_through_b_pictures_bitexact(gpu, w, h, types, pyramid, b_intra, aq, seed):
+    from gpu_enc import GpuSlicetype
+    from mbtree_walk import macroblock_tree
+    n = len(types)
+    frames = synth_frames(w, h, n, seed=seed)
+    og, gg = O.OracleSlicetype(w, h, slots=n + 1, do_edges=1), GpuSlicetype(w, h, slots=n + 1, do_edges=1)
+    for i, f in enumerate(frames):
+        og.put(i, f); gg.put(i, [f])
+        if aq:
+            a = O.aq_offsets(f, w, h)
+            og.set_aq(i, a); gg.set_aq(i, a)
+    slots = list(range(n))
+    oo = macroblock_tree(og, slots, types, n - 1, b_intra, pyramid, 512)
+    go = macroblock_tree(gg, slots, types, n - 1, b_intra, pyramid, 512)
+    assert sorted(oo) == sorted(go) and len(oo) >= 1
+    for i in range(n):
+        assert np.array_equal(gg.propagate_cost(i)[0], og.propagate_cost(i)), f"propagate cost of picture {i} differs"
+    for k in oo:
+        assert np.array_equal(go[k][0], oo[k]), f"offsets of picture {k} differ"
+        assert (oo[k] != (O.aq_offsets(frames[k], w, h) if aq else 0)).any(), "the tree moved nothing"
+    og.close(); gg.close()

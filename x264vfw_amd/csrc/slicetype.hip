@@ -283,6 +283,73 @@ __global__ __launch_bounds__(64) void k_st_cost(StK k)
     if (lane == 0) { atomicAdd(k.sums + (size_t)s * 4, sum_inter); atomicAdd(k.sums + (size_t)s * 4 + 2, sum_intra_mbs); }
 }
 
+// ---- macroblock-tree through B pictures (oracle/slicetype.c x264o_slicetype_propagate / _finish; x264 macroblock_tree_propagate,
+//      mbtree_propagate_cost / _list, macroblock_tree_finish).  Sums saturate at 32767 in x264; every addend is non-negative, so the
+//      accumulators here are plain 32-bit atomics and the saturation is applied where a sum is READ ----
+static __constant__ uint8_t c_st_log2_lut[128] = {
+#include "x264gpu_aq_lut.inc"
+};
+static __constant__ uint16_t c_st_exp2_lut[64] = {
+#include "x264gpu_exp2_lut.inc"
+};
+__device__ __forceinline__ int st_log2_q8(unsigned x) { const int lz = 31 - __builtin_clz(x); return lz * 256 + c_st_log2_lut[((x << (31 - lz)) >> 24) & 0x7f]; }
+__device__ __forceinline__ int st_inv_qscale(int aq_q8)
+{
+    const int i = (-aq_q8 * 64 + 786432 + 768) / 1536;
+    if (i < 0) return 0;
+    if (i > 1023) return 0xffff;
+    return (int)(((unsigned)(c_st_exp2_lut[i & 63] + 256) << (i >> 6)) >> 8);
+}
+struct StTreeK {
+    int bw, bh, nb, d0, d1, bipw0, bipw1, referenced, strength_q8;
+    const int *intra_cost; const uint16_t *lowres_costs; const int16_t *mv[2]; const int16_t *aq;
+    const int32_t *prop_b; int32_t *prop_ref[2];
+    int16_t *out;
+};
+__global__ __launch_bounds__(256) void k_st_propagate(StTreeK k)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x, s = blockIdx.y;
+    if (i >= k.nb) return;
+    const size_t o = (size_t)s * k.nb + i;
+    const int bx = i % k.bw, by = i / k.bw;
+    const int intra = min(k.intra_cost[o], LOWRES_COST_MASK), lc = k.lowres_costs[o];
+    const int best = lc & LOWRES_COST_MASK, inter = min(best, intra), inv = st_inv_qscale(k.aq ? k.aq[o] : 0);
+    const long long amt512 = (long long)(k.referenced ? min(k.prop_b[o], 32767) : 0) * 512 + (long long)intra * inv;
+    int amount = intra ? (int)((amt512 * (intra - inter) + 256 * (long long)intra) / (512 * (long long)intra)) : 0;
+    amount = min(amount, 32767);
+    const int used = lc >> LOWRES_COST_SHIFT;
+    for (int l = 0; l < (k.d1 > 0 ? 2 : 1); l++) {
+        if (!(used & (1 << l))) continue;
+        int la = amount;
+        if (used == 3) la = (la * (l ? k.bipw1 : k.bipw0) + 32) >> 6;
+        const int16_t *mv = k.mv[l] + o * 2;
+        int x = mv[0], y = mv[1];
+        int32_t *ref = k.prop_ref[l] + (size_t)s * k.nb;
+        if (!(x | y)) { atomicAdd(ref + i, la); continue; }
+        const int mbx = (x >> 5) + bx, mby = (y >> 5) + by;
+        x &= 31; y &= 31;
+        const int w0 = ((32 - y) * (32 - x) * la + 512) >> 10, w1 = ((32 - y) * x * la + 512) >> 10;
+        const int w2 = (y * (32 - x) * la + 512) >> 10, w3 = (y * x * la + 512) >> 10;
+        if (mby >= 0 && mby < k.bh) { if (mbx >= 0 && mbx < k.bw) atomicAdd(ref + mby * k.bw + mbx, w0); if (mbx + 1 >= 0 && mbx + 1 < k.bw) atomicAdd(ref + mby * k.bw + mbx + 1, w1); }
+        if (mby + 1 >= 0 && mby + 1 < k.bh) { if (mbx >= 0 && mbx < k.bw) atomicAdd(ref + (mby + 1) * k.bw + mbx, w2); if (mbx + 1 >= 0 && mbx + 1 < k.bw) atomicAdd(ref + (mby + 1) * k.bw + mbx + 1, w3); }
+    }
+}
+__global__ __launch_bounds__(256) void k_st_finish(StTreeK k)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x, s = blockIdx.y;
+    if (i >= k.nb) return;
+    const size_t o = (size_t)s * k.nb + i;
+    const int a = k.aq ? k.aq[o] : 0;
+    const int icost = min(k.intra_cost[o], LOWRES_COST_MASK);
+    const int intra = (icost * st_inv_qscale(a) + 128) >> 8;
+    int off = a;
+    if (intra) {
+        const int p2 = min(k.prop_b[o], 32767) * 2;
+        off = a - ((k.strength_q8 * (st_log2_q8((unsigned)(intra + p2)) - st_log2_q8((unsigned)intra))) >> 8);
+    }
+    k.out[o] = (int16_t)off;
+}
+
 }  // namespace x264gpu
 
 using namespace x264gpu;
@@ -300,6 +367,7 @@ struct x264gpu_slicetype {
     std::vector<int32_t> intra_mbs[ST_MAX_SLOTS];      // [d0 * S + s]
     uint16_t *cost_mv; int32_t *sums; int *progress;
     std::vector<int32_t> h_sums;
+    int32_t *prop[ST_MAX_SLOTS]; int16_t *aq[ST_MAX_SLOTS]; bool have_aq[ST_MAX_SLOTS];      // macroblock-tree: propagate costs, AQ offsets (Q8)
 };
 
 extern "C" {
@@ -308,7 +376,7 @@ void x264gpu_slicetype_destroy(x264gpu_slicetype *st)
 {
     if (!st) return;
     for (int i = 0; i < st->slots; i++) {
-        (void)hipFree(st->planes[i]); (void)hipFree(st->intra_cost[i]); (void)hipFree(st->lowres_costs[i]);
+        (void)hipFree(st->planes[i]); (void)hipFree(st->intra_cost[i]); (void)hipFree(st->lowres_costs[i]); (void)hipFree(st->prop[i]); (void)hipFree(st->aq[i]);
         for (int l = 0; l < 2; l++) for (int d = 0; d <= st->bframes; d++) { (void)hipFree(st->mvs[i][l][d]); (void)hipFree(st->mvcosts[i][l][d]); }
     }
     (void)hipFree(st->cost_mv); (void)hipFree(st->sums); (void)hipFree(st->progress);
@@ -338,6 +406,7 @@ int x264gpu_slicetype_create(x264gpu_slicetype **out, int width, int height, int
     for (int i = 0; i < slots; i++) {
         alloc((void **)&st->planes[i], S * st->lpic);
         alloc((void **)&st->intra_cost[i], S * nb * sizeof(int));
+        alloc((void **)&st->prop[i], S * nb * sizeof(int32_t)); alloc((void **)&st->aq[i], S * nb * sizeof(int16_t));
         alloc((void **)&st->lowres_costs[i], nd * S * nb * sizeof(uint16_t));
         for (int l = 0; l < 2; l++) for (int d = 0; d <= bframes; d++) { alloc((void **)&st->mvs[i][l][d], S * nb * 2 * sizeof(int16_t)); alloc((void **)&st->mvcosts[i][l][d], S * nb * sizeof(int)); }
         st->cost_est[i].assign(nd * S, -1); st->intra_mbs[i].assign((size_t)(bframes + 2) * S, 0);
@@ -391,6 +460,8 @@ int x264gpu_slicetype_put_frame(x264gpu_slicetype *st, int slot, const uint8_t *
             HIP_TRY(hipMemsetAsync(st->mvs[slot][l][d], 0, S * nb * 2 * sizeof(int16_t), s));
         }
     st->intra_calculated[slot] = false;
+    st->have_aq[slot] = false;
+    HIP_TRY(hipMemsetAsync(st->prop[slot], 0, S * nb * sizeof(int32_t), s));
     std::fill(st->cost_est[slot].begin(), st->cost_est[slot].end(), -1);
     std::fill(st->intra_mbs[slot].begin(), st->intra_mbs[slot].end(), 0);
     HIP_TRY(hipGetLastError());
@@ -457,6 +528,55 @@ int x264gpu_slicetype_frame_cost(x264gpu_slicetype *st, int s0, int s1, int sb, 
     memcpy(h_score, memo, S * sizeof(int32_t));
     return X264GPU_OK;
 }
+
+// ---- macroblock-tree (x264 macroblock_tree's building blocks; the host walks the pictures as x264 does) ----
+// x264_adaptive_quant_frame's offsets of the picture in `slot` ([streams][blocks] Q8, device memory; NULL = none)
+int x264gpu_slicetype_set_aq(x264gpu_slicetype *st, int slot, const int16_t *d_aq_q8, void *stream)
+{
+    ARG_TRY(st && slot >= 0 && slot < st->slots);
+    st->have_aq[slot] = d_aq_q8 != nullptr;
+    if (d_aq_q8) HIP_TRY(hipMemcpyAsync(st->aq[slot], d_aq_q8, (size_t)st->streams * st->nb * sizeof(int16_t), hipMemcpyDeviceToDevice, (hipStream_t)stream));
+    return X264GPU_OK;
+}
+int x264gpu_slicetype_clear_propagate(x264gpu_slicetype *st, int slot, void *stream)
+{
+    ARG_TRY(st && slot >= 0 && slot < st->slots);
+    HIP_TRY(hipMemsetAsync(st->prop[slot], 0, (size_t)st->streams * st->nb * sizeof(int32_t), (hipStream_t)stream));
+    return X264GPU_OK;
+}
+// macroblock_tree_propagate(p0, p1, b, referenced): picture b hands its explained cost to p0 (and p1); the costs of the triple must have been computed
+int x264gpu_slicetype_propagate(x264gpu_slicetype *st, int s0, int s1, int sb, int d0, int d1, int referenced, void *stream)
+{
+    ARG_TRY(st && s0 >= 0 && s0 < st->slots && s1 >= 0 && s1 < st->slots && sb >= 0 && sb < st->slots && d0 >= 1 && d1 >= 0 && d0 <= st->bframes + 1 && d1 <= st->bframes + 1);
+    const int nd = st->bframes + 2;
+    ARG_TRY(st->cost_est[sb][(size_t)(d0 * nd + d1) * st->streams] >= 0);
+    StTreeK k;
+    memset(&k, 0, sizeof(k));
+    k.bw = st->bw; k.bh = st->bh; k.nb = st->nb; k.d0 = d0; k.d1 = d1; k.referenced = referenced;
+    const int dsf = d1 > 0 ? ((d0 << 8) + ((d0 + d1) >> 1)) / (d0 + d1) : 256;
+    k.bipw0 = st->weightb && d1 > 0 ? 64 - (dsf >> 2) : 32; k.bipw1 = 64 - k.bipw0;
+    k.intra_cost = st->intra_cost[sb];
+    k.lowres_costs = st->lowres_costs[sb] + (size_t)(d0 * nd + d1) * st->streams * st->nb;
+    k.mv[0] = st->mvs[sb][0][d0 - 1]; k.mv[1] = d1 > 0 ? st->mvs[sb][1][d1 - 1] : nullptr;
+    k.aq = st->have_aq[sb] ? st->aq[sb] : nullptr;
+    k.prop_b = st->prop[sb]; k.prop_ref[0] = st->prop[s0]; k.prop_ref[1] = st->prop[s1];
+    hipLaunchKernelGGL(k_st_propagate, dim3((st->nb + 255) / 256, st->streams), dim3(256), 0, (hipStream_t)stream, k);
+    HIP_TRY(hipGetLastError());
+    return X264GPU_OK;
+}
+// macroblock_tree_finish: d_out_q8[streams][blocks] = aq - strength * log2((intra + propagated) / intra) of the picture in `slot`
+int x264gpu_slicetype_finish(x264gpu_slicetype *st, int slot, int strength_q8, int16_t *d_out_q8, void *stream)
+{
+    ARG_TRY(st && d_out_q8 && slot >= 0 && slot < st->slots && st->intra_calculated[slot]);
+    StTreeK k;
+    memset(&k, 0, sizeof(k));
+    k.bw = st->bw; k.bh = st->bh; k.nb = st->nb; k.strength_q8 = strength_q8;
+    k.intra_cost = st->intra_cost[slot]; k.aq = st->have_aq[slot] ? st->aq[slot] : nullptr; k.prop_b = st->prop[slot]; k.out = d_out_q8;
+    hipLaunchKernelGGL(k_st_finish, dim3((st->nb + 255) / 256, st->streams), dim3(256), 0, (hipStream_t)stream, k);
+    HIP_TRY(hipGetLastError());
+    return X264GPU_OK;
+}
+const int32_t *x264gpu_slicetype_propagate_cost(x264gpu_slicetype *st, int slot) { return st && slot >= 0 && slot < st->slots ? st->prop[slot] : nullptr; }
 
 int x264gpu_slicetype_intra_mbs(x264gpu_slicetype *st, int slot, int d0, int stream_idx)
 {
