@@ -45,6 +45,7 @@ def main():
     nal, nn = C.POINTER(HL.Nal)(), C.c_int()
     planes = [(w * h, 0), (w * h // 4, w * h), (w * h // 4, w * h * 5 // 4)]
     stream, recs = b"", []
+    first_out = None
 
     def take(size):
         nonlocal stream
@@ -57,6 +58,8 @@ def main():
         pic.i_pts = i
         size = H.x264_encoder_encode(h_, C.byref(nal), C.byref(nn), C.byref(pic), C.byref(out))
         assert size >= 0
+        if size > 0 and first_out is None:
+            first_out = i + 1
         take(size)
     while H.x264_encoder_delayed_frames(h_):
         size = H.x264_encoder_encode(h_, C.byref(nal), C.byref(nn), None, C.byref(out))
@@ -65,7 +68,7 @@ def main():
     H.x264_encoder_close(h_)
     open(out_path, "wb").write(stream)
     print(json.dumps({"recs": recs, "bframes": eff.i_bframe, "pyramid": eff.i_bframe_pyramid, "badapt": eff.i_bframe_adaptive, "weightb": eff.analyse.b_weighted_bipred,
-                      "weightp": eff.analyse.i_weighted_pred, "mbtree": eff.rc.b_mb_tree}))
+                      "weightp": eff.analyse.i_weighted_pred, "mbtree": eff.rc.b_mb_tree, "first_output_after": first_out}))
 
 
 main()

@@ -92,7 +92,7 @@ struct x264gpu_slicetype { x264o_slicetype *st; };
 int x264gpu_slicetype_create(x264gpu_slicetype **out, int w, int h, int streams, int slots, int bframes, int me_method, int subme, int me_range, int weightb, int mv_range, int do_edges)
 {
     if (streams != 1) return fail("stub slicetype: one stream");
-    if (slots > 24) return fail("stub slicetype: at most 24 slots");
+    if (slots > 80) return fail("stub slicetype: at most 80 slots");
     x264gpu_slicetype *s = calloc(1, sizeof(*s));
     s->st = x264o_slicetype_create(w, h, slots, bframes, me_method, subme, me_range, weightb, mv_range, do_edges);
     *out = s;
@@ -117,6 +117,16 @@ const int16_t *x264gpu_slicetype_lowres_mvs(x264gpu_slicetype *s, int slot, int 
 const int *x264gpu_slicetype_lowres_mv_costs(x264gpu_slicetype *s, int slot, int list, int dist) { return x264o_slicetype_mv_costs(s->st, slot, list, dist); }
 const int *x264gpu_slicetype_intra_costs(x264gpu_slicetype *s, int slot) { return x264o_slicetype_intra_costs(s->st, slot); }
 const uint16_t *x264gpu_slicetype_lowres_costs(x264gpu_slicetype *s, int slot, int d0, int d1) { return x264o_slicetype_lowres_costs(s->st, slot, d0, d1); }
+void x264o_slicetype_set_aq(x264o_slicetype *st, int slot, const int16_t *aq_q8);
+void x264o_slicetype_clear_propagate(x264o_slicetype *st, int slot);
+int x264o_slicetype_propagate(x264o_slicetype *st, int s0, int s1, int sb, int d0, int d1, int referenced);
+int x264o_slicetype_finish(x264o_slicetype *st, int slot, int strength_q8, int16_t *out_q8);
+const int32_t *x264o_slicetype_propagate_cost(x264o_slicetype *st, int slot);
+int x264gpu_slicetype_set_aq(x264gpu_slicetype *s, int slot, const int16_t *aq, void *stream) { x264o_slicetype_set_aq(s->st, slot, aq); return X264GPU_OK; }
+int x264gpu_slicetype_clear_propagate(x264gpu_slicetype *s, int slot, void *stream) { x264o_slicetype_clear_propagate(s->st, slot); return X264GPU_OK; }
+int x264gpu_slicetype_propagate(x264gpu_slicetype *s, int s0, int s1, int sb, int d0, int d1, int referenced, void *stream) { return x264o_slicetype_propagate(s->st, s0, s1, sb, d0, d1, referenced) ? fail("macroblock-tree: costs of the triple missing") : X264GPU_OK; }
+int x264gpu_slicetype_finish(x264gpu_slicetype *s, int slot, int strength_q8, int16_t *out, void *stream) { return x264o_slicetype_finish(s->st, slot, strength_q8, out) ? fail("macroblock-tree: no intra costs") : X264GPU_OK; }
+const int32_t *x264gpu_slicetype_propagate_cost(x264gpu_slicetype *s, int slot) { return x264o_slicetype_propagate_cost(s->st, slot); }
 int x264gpu_encode_frames(x264gpu_encoder *g, const uint8_t *i420, int slice_type, x264gpu_mb *mb, int16_t *lv, void *st)
 {
     if (g->dev != t_dev) return fail("encoder used from a thread bound to another device");

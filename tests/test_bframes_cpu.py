@@ -200,3 +200,20 @@ def test_host_session_crf_on_the_lookaheads_costs(tmp_path):
     from synth import psnr
     for d, r in zip(dec, info["recs"]):
         assert psnr(d[:w * h], frames[r[1]][:w * h]) > 30.0
+
+
+def test_host_session_mbtree_through_b_pictures(tmp_path):
+    """the driver's default rate control — CRF with macroblock-tree and AQ over rc-lookahead pictures — in a session with B pictures: the first
+    picture leaves after rc-lookahead + 1 pictures have arrived, the tree (x264 macroblock_tree over the decided types, through B pictures and
+    B-references) moves the quantisers of the P / I / B-reference pictures, and the stream decodes"""
+    n, w, h = 26, 176, 144
+    info, stream = _host_b_session(tmp_path, n, ["crf=24", "keyint=60", "rc-lookahead=10"], w, h, seed=4)
+    assert (info["mbtree"], info["badapt"], info["bframes"]) == (1, 1, 3)
+    assert info["first_output_after"] == 11
+    dec = O.h264_decode(stream, n, w, h)
+    frames = synth_frames(w, h, n, seed=4)
+    from synth import psnr
+    for d, r in zip(dec, info["recs"]):
+        assert psnr(d[:w * h], frames[r[1]][:w * h]) > 29.0
+    info0, stream0 = _host_b_session(tmp_path, n, ["crf=24", "keyint=60", "rc-lookahead=10", "no-mbtree"], w, h, seed=4)
+    assert info0["mbtree"] == 0 and stream0 != stream

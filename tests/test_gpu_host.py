@@ -784,6 +784,7 @@ def encode_delayed(h_, w, h, frames):
     (176, 144, 14, {"qp": 23, "keyint": 30, "scenecut": 0, "bframes": 3, "b-adapt": 0}, "IPRBBPRBBPRBBP"),                         # preset medium as the device runs it: bframes 3, b-pyramid, weightb, ref 3
     (128, 96, 12, {"qp": 26, "keyint": 30, "scenecut": 0, "bframes": 1, "ref": 1, "b-adapt": 0}, "IPBPBPBPBPBP"),
     (96, 80, 13, {"crf": 24, "keyint": 6, "min-keyint": 6, "scenecut": 0, "bframes": 2, "b-pyramid": "none", "no-mbtree": None, "b-adapt": 0}, None),
+    (176, 144, 20, {"crf": 24, "keyint": 30, "bframes": 3, "rc-lookahead": 8}, None),                               # the driver's default rate control: CRF + AQ + macroblock-tree through B pictures
     (176, 144, 16, {"qp": 23, "keyint": 30, "bframes": 3}, None),                                                                  # medium's lookahead: --b-adapt 1 --scenecut 40 on the device's (p0, p1, b) frame costs
     (176, 144, 9, {"qp": 23, "keyint": 30, "scenecut": 0, "bframes": 0, "weightp": 2}, "IPPPPPPPP"),                # no B pictures, --weightp 2: the DPB model with no delay
 ])

@@ -129,6 +129,8 @@ struct x264_t {
     bool have_last_nonb = false; BEntry last_nonb;
     int last_keyframe = 0;                // display index of the last IDR picture decided (x264 h->lookahead->i_last_keyframe)
     int badapt = 0;
+    std::vector<int16_t *> q_tree;       // device, per queue slot: the quantiser offsets the macroblock-tree left with the picture (AQ offsets until it ran)
+    int st_wait = 0;                     // pictures the lookahead holds before a decision (x264 i_slicetype_length: max(bframes, rc-lookahead under mbtree))
     struct BPlanned { BEntry e; int type; };                                                                            // type: PIC_*
     std::deque<BEntry> bq;
     std::deque<BPlanned> bcoding;
@@ -316,7 +318,6 @@ x264_t *x264_encoder_open(x264_param_t *param)
         if (p.i_bframe < 2) p.i_bframe_pyramid = 0;
         if (p.b_open_gop) { xlog(&p, X264_LOG_WARNING, "open-gop is not implemented in the MI355X path: closed GOPs\n"); p.b_open_gop = 0; }
         if (p.analyse.i_direct_mv_pred != 1) { xlog(&p, X264_LOG_INFO, "direct %d -> spatial (the one direct mode in the MI355X path)\n", p.analyse.i_direct_mv_pred); p.analyse.i_direct_mv_pred = 1; }
-        if (p.rc.b_mb_tree) { xlog(&p, X264_LOG_WARNING, "mbtree through B pictures is not implemented yet: mbtree 0\n"); p.rc.b_mb_tree = 0; }
     } else { p.i_bframe_pyramid = 0; p.analyse.b_weighted_bipred = 0; }
     h->bframes = p.i_bframe; h->bpyramid = p.i_bframe_pyramid ? 1 : 0;
     if (p.i_keyint_max <= 0) p.i_keyint_max = 1;
@@ -462,13 +463,17 @@ x264_t *x264_encoder_open(x264_param_t *param)
     // the entropy coding of this one (one more picture of delay); X264GPU_HOST_PIPELINE=0 keeps the two stages in one call
     { const char *pe = getenv("X264GPU_HOST_PIPELINE"); h->pipeline = h->G == 1 && h->L > 0 && h->crf && !(pe && pe[0] == '0'); }
     h->Q = h->L + 1 + (h->pipeline ? 1 : 0);
-    if (h->dpbmode) { h->pipeline = false; h->Q = 2 * (h->bframes + 1) + 2; }      // display-order queue + the mini-GOP being coded
+    if (h->dpbmode) {
+        if (h->L > 60) { xlog(&p, X264_LOG_INFO, "rc-lookahead %d -> 60 in sessions with B pictures (the lookahead keeps every queued picture's half-resolution planes and searches on the device)\n", h->L); h->L = 60; p.rc.i_lookahead = 60; }
+        h->pipeline = false; h->Q = h->L + 2 * (h->bframes + 1) + 2;      // the lookahead window + display-order queue + the mini-GOP being coded
+    }
+    h->st_wait = h->bframes > h->L ? h->bframes : h->L;
     h->last_keyframe = -p.i_keyint_max;
     h->badapt = h->bframes ? p.i_bframe_adaptive : 0;
-    if (h->dpbmode && (h->badapt || p.i_scenecut_threshold > 0)) {
+    if (h->dpbmode && (h->badapt || p.i_scenecut_threshold > 0 || h->mbtree)) {
         // x264's own lookahead structure: frame costs of (p0, p1, b) triples on the half-resolution planes (x264_slicetype_analyse)
         if (x264gpu_slicetype_create(&h->st, p.i_width, p.i_height, 1, h->Q, h->bframes, p.analyse.i_me_method, p.analyse.i_subpel_refine, p.analyse.i_me_range,
-                                     p.analyse.b_weighted_bipred, p.analyse.i_mv_range, 0) != X264GPU_OK) {
+                                     p.analyse.b_weighted_bipred, p.analyse.i_mv_range, h->mbtree ? 1 : 0) != X264GPU_OK) {
             xlog(&p, X264_LOG_ERROR, "GPU lookahead setup failed: %s\n", x264gpu_last_error());
             x264_encoder_close(h);
             return nullptr;
@@ -476,7 +481,7 @@ x264_t *x264_encoder_open(x264_param_t *param)
     }
     h->aq_strength_q8 = cfg.aq_mode ? cfg.aq_strength_q8 : 0;
     h->tree_strength_q8 = (int)(1280.0 * (1.0 - p.rc.f_qcompress) + 0.5);     // 5 * (1 - qcomp), Q8
-    h->q_raw.assign((size_t)h->Q, nullptr); h->q_info.assign((size_t)h->Q, nullptr); h->q_aq.assign((size_t)h->Q, nullptr);
+    h->q_raw.assign((size_t)h->Q, nullptr); h->q_info.assign((size_t)h->Q, nullptr); h->q_aq.assign((size_t)h->Q, nullptr); h->q_tree.assign((size_t)h->Q, nullptr);
     if (h->Q == 1) h->q_raw[0] = h->d_in;            // no delay: the staging buffer is the one slot; with a delay the ring is separate,
                                                      // because a zero-copy caller rewrites the staging buffer every call
     {
@@ -485,6 +490,7 @@ x264_t *x264_encoder_open(x264_param_t *param)
             if (!h->q_raw[(size_t)i]) ok = x264gpu_malloc((void **)&h->q_raw[(size_t)i], insz) == X264GPU_OK;
             if (ok && h->mbtree) ok = x264gpu_malloc((void **)&h->q_info[(size_t)i], (size_t)h->nmb * 4 * sizeof(int32_t)) == X264GPU_OK &&
                                        x264gpu_malloc((void **)&h->q_aq[(size_t)i], (size_t)h->nmb * sizeof(int16_t)) == X264GPU_OK;
+            if (ok && h->mbtree && h->dpbmode) ok = x264gpu_malloc((void **)&h->q_tree[(size_t)i], (size_t)h->nmb * sizeof(int16_t)) == X264GPU_OK;
         }
         if (ok && h->mbtree) ok = x264gpu_malloc((void **)&h->d_tree, (size_t)h->nmb * sizeof(int16_t)) == X264GPU_OK;
         if (!ok) {
@@ -976,7 +982,60 @@ static bool st_scenecut(StFrames &F, int p0, int p1, bool real, int num_frames, 
     if (!F.f[(size_t)p1]->b_scenecut) return false;
     return st_scenecut_internal(F, p0, p1);
 }
-static void st_analyse(x264_t *h, StFrames &F, int framecnt)
+// x264's macroblock_tree over frames[0 .. num_frames] with the types decided so far (tests/mbtree_walk.py is the same walk): every picture hands
+// the cost its references explain back to them, last picture first; the next picture to be coded (and the B-reference of its run) get their
+// quantiser offsets.  b_intra: the pass x264 runs for a keyframe after it was decided (frames[0] = that keyframe).
+static void st_macroblock_tree(x264_t *h, StFrames &F, int num_frames, bool b_intra)
+{
+    const int idx = b_intra ? 0 : 1;
+    auto isb = [&](int i) { return F.f[(size_t)i]->type == ST_B || F.f[(size_t)i]->type == ST_BREF; };
+    auto slot = [&](int i) { return F.f[(size_t)i]->slot; };
+    auto prop = [&](int p0, int p1, int b, int referenced) {
+        if (x264gpu_slicetype_propagate(h->st, slot(p0), slot(p1), slot(b), b - p0, p1 - b, referenced, nullptr) != X264GPU_OK) {
+            xlog(&h->param, X264_LOG_ERROR, "macroblock-tree failed: %s\n", x264gpu_last_error());
+            h->failed = true;
+        }
+    };
+    auto clear = [&](int i) { if (x264gpu_slicetype_clear_propagate(h->st, slot(i), nullptr) != X264GPU_OK) h->failed = true; };
+    auto finish = [&](int i) {
+        st_cost(F, i, i, i);          // (the intra costs the analysis left with the picture; a no-op when they exist)
+        if (x264gpu_slicetype_finish(h->st, slot(i), h->tree_strength_q8, h->q_tree[(size_t)slot(i)], nullptr) != X264GPU_OK) h->failed = true;
+    };
+    if (b_intra) st_cost(F, 0, 0, 0);
+    int i = num_frames;
+    while (i > 0 && isb(i)) i--;
+    int last_nonb = i, bframes = 0;
+    if (last_nonb < idx) return;
+    clear(last_nonb);
+    while (i-- > idx) {
+        int cur_nonb = i;
+        while (isb(cur_nonb) && cur_nonb > 0) cur_nonb--;
+        if (cur_nonb < idx) break;
+        // (distances beyond bframes + 1 cannot occur: the analysis never leaves longer runs)
+        st_cost(F, cur_nonb, last_nonb, last_nonb);
+        clear(cur_nonb);
+        bframes = last_nonb - cur_nonb - 1;
+        if (h->bpyramid && bframes > 1) {
+            const int middle = (bframes + 1) / 2 + cur_nonb;
+            st_cost(F, cur_nonb, last_nonb, middle);
+            clear(middle);
+            while (i > cur_nonb) {
+                const int p0 = i > middle ? middle : cur_nonb, p1 = i < middle ? middle : last_nonb;
+                if (i != middle) { st_cost(F, p0, p1, i); prop(p0, p1, i, 0); }
+                i--;
+            }
+            prop(cur_nonb, last_nonb, middle, 1);
+        } else
+            while (i > cur_nonb) { st_cost(F, cur_nonb, last_nonb, i); prop(cur_nonb, last_nonb, i, 0); i--; }
+        prop(cur_nonb, last_nonb, last_nonb, 1);
+        last_nonb = cur_nonb;
+        if (h->failed) return;
+    }
+    finish(last_nonb);
+    if (h->bpyramid && bframes > 1) finish(last_nonb + (bframes + 1) / 2);
+}
+
+static void st_analyse(x264_t *h, StFrames &F, int framecnt, bool keyframe = false)
 {
     const x264_param_t &p = h->param;
     auto type = [&](int i) -> int & { return F.f[(size_t)i]->type; };
@@ -987,10 +1046,11 @@ static void st_analyse(x264_t *h, StFrames &F, int framecnt)
     const int keyint_limit = p.i_keyint_max - F.f[0]->frame + h->last_keyframe - 1;
     int num_frames = framecnt < keyint_limit ? framecnt : keyint_limit;
     const int orig_num_frames = num_frames;
-    if (num_frames <= 0) { type(1) = ST_I; return; }
+    if (p.analyse.b_psy && h->mbtree) num_frames = framecnt;           // psy-wise the pictures before a keyframe must not lose their share of the tree
+    else if (num_frames <= 0) { type(1) = ST_I; return; }
     // a picture whose type the caller forced ends the window in front of it (x264 warns and overrides; here the analysis stops short)
     for (int j = 2; j <= num_frames; j++) if (forced(j) != ST_AUTO) { num_frames = j - 1; break; }
-    if (auto_or_i(type(1)) && p.i_scenecut_threshold && st_scenecut(F, 0, 1, true, orig_num_frames, i_max_search)) {
+    if (!keyframe && auto_or_i(type(1)) && p.i_scenecut_threshold && st_scenecut(F, 0, 1, true, orig_num_frames, i_max_search)) {
         if (type(1) == ST_AUTO) type(1) = ST_I;
         return;
     }
@@ -1028,11 +1088,14 @@ static void st_analyse(x264_t *h, StFrames &F, int framecnt)
                 num_analysed = j;
                 break;
             }
-        reset_start = num_bframes + 2 < num_analysed + 1 ? num_bframes + 2 : num_analysed + 1;
+        reset_start = keyframe ? 1 : num_bframes + 2 < num_analysed + 1 ? num_bframes + 2 : num_analysed + 1;
     } else {
         for (int j = 1; j <= num_frames; j++) if (auto_or_i(forced(j))) type(j) = ST_P;
-        reset_start = 2;
+        reset_start = keyframe ? 1 : 2;
     }
+    // the macroblock-tree over the window, no farther than a keyframe interval
+    if (h->mbtree) st_macroblock_tree(h, F, num_frames < p.i_keyint_max ? num_frames : p.i_keyint_max, keyframe);
+    if (h->failed) return;
     // enforce the keyframe limit
     {
         int last_keyframe = h->last_keyframe, last_possible = 0;
@@ -1057,13 +1120,13 @@ static bool st_decide(x264_t *h, bool flushing, int &j_out, int &closing_out)
 {
     const x264_param_t &p = h->param;
     const int n = (int)h->bq.size();
-    if (!flushing && n <= h->bframes) return false;
+    if (!flushing && n <= h->st_wait) return false;
     for (auto &e : h->bq) e.type = e.forced == 2 ? ST_IDR : e.forced == 1 ? ST_I : ST_AUTO;
-    if (h->have_last_nonb && ((h->bframes && h->badapt) || p.i_scenecut_threshold)) {
+    if (h->have_last_nonb && ((h->bframes && h->badapt) || p.i_scenecut_threshold || h->mbtree)) {
         StFrames F;
         F.h = h;
         F.f.push_back(&h->last_nonb);
-        const int framecnt = n < h->bframes + 1 ? n : h->bframes + 1;          // what the lookahead holds for sure (deterministic mode), except at the end
+        const int framecnt = n < h->st_wait + 1 ? n : h->st_wait + 1;          // what the lookahead holds for sure (deterministic mode), except at the end
         for (int i = 0; i < framecnt; i++) F.f.push_back(&h->bq[(size_t)i]);
         st_analyse(h, F, framecnt);
         if (h->failed) return false;
@@ -1090,7 +1153,7 @@ static bool bmode_decide(x264_t *h, bool flushing)
 {
     if (!h->bcoding.empty() || h->bq.empty()) return !h->bcoding.empty();
     const int n = (int)h->bq.size();
-    if (!flushing && n <= h->bframes) return false;          // the lookahead x264 keeps in front of the slice-type decision: a whole run and its closing picture
+    if (!flushing && n <= (h->st ? h->st_wait : h->bframes)) return false;          // the lookahead x264 keeps in front of the slice-type decision
     int j = -1;                                       // index of the closing picture
     if (h->st) {
         int closing = PIC_P;
@@ -1112,6 +1175,20 @@ static bool bmode_decide(x264_t *h, bool flushing)
         if (bref >= 0) h->bcoding.push_back({ h->bq[(size_t)bref], PIC_BREF });
         for (int i = 0; i < j; i++) if (i != bref) h->bcoding.push_back({ h->bq[(size_t)i], PIC_B });
         h->bq.erase(h->bq.begin(), h->bq.begin() + j + 1);
+        if (h->mbtree && (closing == PIC_IDR || closing == PIC_I)) {
+            // x264 lookahead_slicetype_decide: "for MB-tree, we have to perform propagation analysis on I-frames too" — the analysis again
+            // with the keyframe as frames[0]; it decides nothing, its tree reaches the keyframe itself
+            StFrames F;
+            F.h = h;
+            F.f.push_back(&h->last_nonb);
+            const int n2 = (int)h->bq.size(), framecnt = n2 < h->st_wait + 1 - (j + 1) ? n2 : (h->st_wait + 1 - (j + 1) > 0 ? h->st_wait + 1 - (j + 1) : 0);
+            for (auto &e : h->bq) e.type = e.forced == 2 ? ST_IDR : e.forced == 1 ? ST_I : ST_AUTO;
+            for (int i = 0; i < framecnt; i++) F.f.push_back(&h->bq[(size_t)i]);
+            h->last_nonb.type = closing == PIC_IDR ? ST_IDR : ST_I;
+            if (framecnt > 0) st_analyse(h, F, framecnt, true);
+            else st_macroblock_tree(h, F, 0, true);
+            if (h->failed) return false;
+        }
         return true;
     }
     if (h->bq[0].forced) j = 0;
@@ -1189,6 +1266,8 @@ static int encode_bmode(x264_t *h, x264_nal_t **pp_nal, int *pi_nal, x264_pictur
         x264gpu_encoder_set_lowres_mvs(h->gpu, m0);
         x264gpu_encoder_set_lowres_mvs1(h->gpu, m1);
     }
+    if (h->st && h->mbtree)          // P / I / B-reference pictures: what the tree left (AQ - tree); other B pictures: the AQ offsets alone (x264 f_qp_offset_aq)
+        x264gpu_encoder_set_mb_qp_offsets(h->gpu, pl.type == PIC_B ? h->q_aq[(size_t)pl.e.slot] : h->q_tree[(size_t)pl.e.slot]);
     if (x264gpu_encode_pictures(h->gpu, h->q_raw[(size_t)pl.e.slot], &pic, h->d_mb, h->d_lv, nullptr) != X264GPU_OK ||
         x264gpu_memcpy_d2h(h->h_mb.data(), h->d_mb, h->h_mb.size() * sizeof(x264gpu_mb), nullptr) != X264GPU_OK ||
         x264gpu_memcpy_d2h(h->h_lv.data(), h->d_lv, h->h_lv.size() * sizeof(int16_t), nullptr) != X264GPU_OK) {
@@ -1312,7 +1391,14 @@ int x264_encoder_encode(x264_t *h, x264_nal_t **pp_nal, int *pi_nal, x264_pictur
             // the slice-type analysis decides keyframes and scene cuts itself: only what the caller forced stays forced
             be.forced = pic_in->i_type == X264_TYPE_IDR || pic_in->i_type == X264_TYPE_KEYFRAME ? 2 : pic_in->i_type == X264_TYPE_I ? 1 : 0;
             be.scenecut = 0;
-            if (x264gpu_slicetype_put_frame(h->st, slot, d_raw, nullptr) != X264GPU_OK) {
+            bool ok = x264gpu_slicetype_put_frame(h->st, slot, d_raw, nullptr) == X264GPU_OK;
+            if (ok && h->mbtree) {
+                // x264_adaptive_quant_frame: the AQ offsets weight the lookahead's costs and are what the tree starts from (f_qp_offset = f_qp_offset_aq)
+                if (!h->aq_strength_q8) ok = x264gpu_memset(h->q_aq[(size_t)slot], 0, (size_t)h->nmb * sizeof(int16_t), nullptr) == X264GPU_OK;
+                ok = ok && x264gpu_slicetype_set_aq(h->st, slot, h->aq_strength_q8 ? h->q_aq[(size_t)slot] : nullptr, nullptr) == X264GPU_OK &&
+                     x264gpu_memcpy_d2d(h->q_tree[(size_t)slot], h->q_aq[(size_t)slot], (size_t)h->nmb * sizeof(int16_t), nullptr) == X264GPU_OK;
+            }
+            if (!ok) {
                 xlog(&p, X264_LOG_ERROR, "x264_encoder_encode: lookahead failed: %s\n", x264gpu_last_error());
                 return -1;
             }
@@ -1361,6 +1447,7 @@ void x264_encoder_close(x264_t *h)
         if (h->q_raw[i] && h->q_raw[i] != h->d_in) x264gpu_free(h->q_raw[i]);
         if (h->q_info[i]) x264gpu_free(h->q_info[i]);
         if (h->q_aq[i]) x264gpu_free(h->q_aq[i]);
+        if (i < h->q_tree.size() && h->q_tree[i]) x264gpu_free(h->q_tree[i]);
     }
     if (h->d_tree) x264gpu_free(h->d_tree);
     if (h->la) x264gpu_lookahead_destroy(h->la);
