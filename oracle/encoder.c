@@ -107,13 +107,11 @@ static void ingest(x264o_encoder *e, const uint8_t *i420)
 /* ---- adaptive quantisation, mode 1 (x264_adaptive_quant_frame / x264_ac_energy_mb, [x264-upstream] encoder/ratecontrol.c):
  * energy = var(16x16 luma) + var(8x8 U) + var(8x8 V) with var = ssd - (sum^2 >> log2 n); offset = strength * (log2(energy) - 14.427).
  * Q8 fixed point: log2 = 256 * floor(log2 e) + table[next 7 bits]; the offset is rounded to an integer quantiser step. ---- */
-static const uint8_t aq_log2_lut[128] = {
-#include "x264gpu_aq_lut.inc"
-};
+#include "fixlut.h"
 static int aq_log2_q8(uint32_t x)
 {
     int lz = 31 - __builtin_clz(x);
-    return lz * 256 + aq_log2_lut[((x << (31 - lz)) >> 24) & 0x7f];
+    return lz * 256 + x264o_log2_lut()[((x << (31 - lz)) >> 24) & 0x7f];
 }
 static void compute_mb_qp(x264o_encoder *e, int slice_qp)
 {
@@ -376,4 +374,11 @@ const uint8_t *x264o_encoder_ref_plane(x264o_encoder *e, int k, int *stride, int
     if (k < 4) { *rows = e->ch + 2 * PAD; return e->luma[last] + k * e->plane_bytes; }
     *rows = e->ch / 2 + 2 * CPAD;
     return e->chroma[last];
+}
+
+/* tests: the oracle's own derivation of the two fixed-point tables (fixlut.h), to be compared with the product's literals */
+void x264o_fixed_point_luts(uint8_t log2_lut[128], uint16_t exp2_lut[64])
+{
+    memcpy(log2_lut, x264o_log2_lut(), 128);
+    memcpy(exp2_lut, x264o_exp2_lut(), 64 * sizeof(uint16_t));
 }

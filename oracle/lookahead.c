@@ -241,10 +241,8 @@ int x264o_lookahead_frame_cost(x264o_lookahead *la, const uint8_t *i420, int res
 
 /* ---- adaptive-quantisation offsets of a source picture, Q8 (the lookahead computes them when the picture arrives, as
  * x264_adaptive_quant_frame does; same arithmetic as encoder.c compute_mb_qp, on the mod-16 expanded picture) ---- */
-static const uint8_t la_log2_lut[128] = {
-#include "x264gpu_aq_lut.inc"
-};
-static int la_log2_q8(uint32_t x) { int lz = 31 - __builtin_clz(x); return lz * 256 + la_log2_lut[((x << (31 - lz)) >> 24) & 0x7f]; }
+#include "fixlut.h"
+static int la_log2_q8(uint32_t x) { int lz = 31 - __builtin_clz(x); return lz * 256 + x264o_log2_lut()[((x << (31 - lz)) >> 24) & 0x7f]; }
 
 void x264o_aq_offsets(const uint8_t *i420, int w, int h, int strength_q8, int16_t *out_q8)
 {
@@ -270,15 +268,12 @@ void x264o_aq_offsets(const uint8_t *i420, int w, int h, int strength_q8, int16_
  * reference explains back to the blocks its vectors point at (bilinear split over four blocks, 15-bit saturating sums); the
  * oldest picture's blocks get  offset = aq - strength * log2((intra + propagated) / intra).  All integer arithmetic (x264's
  * float expressions restated): amounts carry 9 fractional bits (fps_factor 1/512), inverse quantiser scales are x264_exp2fix8. ---- */
-static const uint16_t la_exp2_lut[64] = {
-#include "x264gpu_exp2_lut.inc"
-};
 static int la_inv_qscale(int aq_q8)
 {
     int i = (-aq_q8 * 64 + 786432 + 768) / 1536;                       /* (int)(x * (-64 / 6) + 512.5), x = aq_q8 / 256 */
     if (i < 0) return 0;
     if (i > 1023) return 0xffff;
-    return (int)(((uint32_t)(la_exp2_lut[i & 63] + 256) << (i >> 6)) >> 8);
+    return (int)(((uint32_t)(x264o_exp2_lut()[i & 63] + 256) << (i >> 6)) >> 8);
 }
 
 void x264o_mbtree(int bw, int bh, const int32_t *const *info, const int16_t *const *aq_q8, int n, int strength_q8, int16_t *out_q8)

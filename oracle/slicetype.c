@@ -277,19 +277,14 @@ const uint16_t *x264o_slicetype_lowres_costs(const x264o_slicetype *st, int slot
  * back to the blocks its vectors point at: list 0 and list 1 as lowres_costs' list_used bits say, bi-predicted blocks split by the implicit
  * weight, bilinear split over four blocks, 15-bit saturating sums.  Integer restatement of x264's float expressions as in oracle/lookahead.c
  * x264o_mbtree: amounts carry 9 fractional bits (fps_factor 1 / 512), inverse quantiser scales are x264_exp2fix8 of the AQ offsets. */
-static const uint8_t st_log2_lut[128] = {
-#include "x264gpu_aq_lut.inc"
-};
-static const uint16_t st_exp2_lut[64] = {
-#include "x264gpu_exp2_lut.inc"
-};
-static int st_log2_q8(uint32_t x) { int lz = 31 - __builtin_clz(x); return lz * 256 + st_log2_lut[((x << (31 - lz)) >> 24) & 0x7f]; }
+#include "fixlut.h"
+static int st_log2_q8(uint32_t x) { int lz = 31 - __builtin_clz(x); return lz * 256 + x264o_log2_lut()[((x << (31 - lz)) >> 24) & 0x7f]; }
 static int st_inv_qscale(int aq_q8)
 {
     int i = (-aq_q8 * 64 + 786432 + 768) / 1536;
     if (i < 0) return 0;
     if (i > 1023) return 0xffff;
-    return (int)(((uint32_t)(st_exp2_lut[i & 63] + 256) << (i >> 6)) >> 8);
+    return (int)(((uint32_t)(x264o_exp2_lut()[i & 63] + 256) << (i >> 6)) >> 8);
 }
 typedef struct st_tree_s st_tree;
 static st_tree *st_tree_of(x264o_slicetype *st) { return st->tree; }

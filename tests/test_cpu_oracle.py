@@ -126,3 +126,21 @@ def test_pred8_table_comes_from_the_standards_equations():
     g = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(g)
     assert g.text(g.table()) == open(g.PATH).read()
+
+
+def test_fixed_point_tables_of_the_product_match_libm():
+    """the AQ / macroblock-tree tables the product carries as literals (include/x264gpu_aq_lut.inc, x264gpu_exp2_lut.inc) against the oracle's own
+    derivation with libm (oracle/fixlut.h) and against numpy: the oracle does not read the product's files"""
+    import ctypes as C
+    import os
+    import re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for f in os.listdir(os.path.join(root, "oracle")):
+        if f.endswith((".c", ".cpp", ".h", ".hpp")):
+            assert "_lut.inc" not in open(os.path.join(root, "oracle", f)).read().replace("x264gpu_aq_lut.inc, include/x264gpu_exp2_lut.inc", ""), f
+    lits = lambda name: [int(x) for x in re.findall(r"-?\d+", re.sub(r"/\*.*?\*/", "", open(os.path.join(root, "include", name)).read(), flags=re.S))]
+    lg, ex = np.zeros(128, np.uint8), np.zeros(64, np.uint16)
+    O.L.x264o_fixed_point_luts.argtypes = [C.c_void_p, C.c_void_p]
+    O.L.x264o_fixed_point_luts(lg.ctypes.data, ex.ctypes.data)
+    assert lits("x264gpu_aq_lut.inc") == lg.tolist() == np.rint(256 * np.log2(1 + np.arange(128) / 128)).astype(int).tolist()
+    assert lits("x264gpu_exp2_lut.inc") == ex.tolist() == np.rint(256 * (2 ** (np.arange(64) / 64) - 1)).astype(int).tolist()
