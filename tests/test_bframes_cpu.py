@@ -217,3 +217,29 @@ def test_host_session_mbtree_through_b_pictures(tmp_path):
         assert psnr(d[:w * h], frames[r[1]][:w * h]) > 29.0
     info0, stream0 = _host_b_session(tmp_path, n, ["crf=24", "keyint=60", "rc-lookahead=10", "no-mbtree"], w, h, seed=4)
     assert info0["mbtree"] == 0 and stream0 != stream
+
+
+def _batch(n, w, h, nf, opts, gpu=False, timeout=900):
+    import json
+    import os
+    import subprocess
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    env = dict(os.environ)
+    env.pop("X264GPU_BATCH", None)
+    r = subprocess.run([sys.executable, os.path.join(here, "stub", "run_host_batch.py"), str(n), str(w), str(h), str(nf)] + opts + (["--gpu"] if gpu else []),
+                       capture_output=True, text=True, timeout=timeout, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    return json.loads(r.stdout.strip().splitlines()[-1])
+
+
+@pytest.mark.parametrize("n,opts", [
+    (4, ["qp=23", "keyint=30", "scenecut=0", "b-adapt=0", "bframes=3"]),                     # medium's B structure, constant quantisers
+    (3, ["crf=24", "keyint=8", "min-keyint=8", "scenecut=0", "b-adapt=0", "bframes=2", "no-mbtree"]),      # CRF: every stream its own quantisers
+    (2, ["qp=26", "keyint=30", "scenecut=0", "bframes=0", "weightp=2"]),                      # no B pictures
+])
+def test_cross_session_batcher_is_byte_identical(n, opts):
+    """X264GPU_BATCH=N: N x264_encoder_open sessions driven from N host threads share one device encoder (N streams, one lock-step launch per
+    picture); every session's stream equals the one it writes on its own (driverproc.c:110-128: one CODEC per stream)"""
+    r = _batch(n, 176, 144, 11, opts)
+    assert r["equal"] == [True] * n and r["distinct"] == n, r

@@ -811,3 +811,11 @@ def test_b_session_through_the_encode_api(gpu, w, h, n, opts, pattern):
     for d, r in zip(dec, recs):
         assert psnr(d[:w * h], frames[r[2]][:w * h]) > 30.0
     assert [p for p in pocs] == [2 * (r[2] - max(q[2] for q in recs if q[1] and q[2] <= r[2])) for r in recs]
+
+
+def test_cross_session_batcher_on_the_device(gpu):
+    """X264GPU_BATCH=16: sixteen sessions from sixteen host threads, one lock-step launch per picture on the device; byte-identical to sixteen
+    sessions run one after the other"""
+    from test_bframes_cpu import _batch
+    r = _batch(16, 176, 144, 9, ["qp=23", "keyint=30", "scenecut=0", "b-adapt=0", "bframes=3"], gpu=True)
+    assert r["equal"] == [True] * 16 and r["distinct"] == 16, r

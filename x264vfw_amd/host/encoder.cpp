@@ -16,6 +16,8 @@
 #include <string>
 #include <thread>
 #include <chrono>
+#include <mutex>
+#include <condition_variable>
 
 using namespace x264host;
 
@@ -131,6 +133,9 @@ struct x264_t {
     int badapt = 0;
     std::vector<int16_t *> q_tree;       // device, per queue slot: the quantiser offsets the macroblock-tree left with the picture (AQ offsets until it ran)
     int st_wait = 0;                     // pictures the lookahead holds before a decision (x264 i_slicetype_length: max(bframes, rc-lookahead under mbtree))
+    // cross-session batcher (X264GPU_BATCH=N): N sessions of equal geometry and toolset share ONE device encoder with N streams; the pictures
+    // they submit are coded in one lock-step launch, every session entropy-codes its own stream on its caller's thread
+    struct BatchGroup *batch = nullptr; int batch_idx = -1, batch_n = 0;
     struct BPlanned { BEntry e; int type; };                                                                            // type: PIC_*
     std::deque<BEntry> bq;
     std::deque<BPlanned> bcoding;
@@ -139,6 +144,111 @@ struct x264_t {
     double slot_qp_rc[8] = { 0 };        // CRF: the quantiser (float) every kept picture was given, by DPB slot (x264 f_qp_avg_rc)
     int slot_ptype[8] = { 0 };           // ... and its picture type
 };
+
+// ---- cross-session batcher ------------------------------------------------------------------------------------------------------
+// The reference opens one CODEC / x264_t per stream (driverproc.c:110-128); the device is fast only when many streams are coded in lock-step
+// (x264gpu_config.streams).  With X264GPU_BATCH=N in the environment, the first N sessions opened with the same geometry and toolset (and
+// a fixed picture structure: no scenecut / b-adapt / mbtree, so that picture k has the same type in all of them) form a group around one
+// device encoder with N streams.  A session's x264_encoder_encode hands its picture to the group and waits; the call that completes the
+// round launches the hot path for all streams; every caller then downloads its own records and entropy-codes its own stream on its own
+// thread.  Each stream is coded exactly as a session of its own would code it (streams never interact): the bytes are the same.
+struct BatchGroup {
+    std::mutex m; std::condition_variable cv;
+    x264gpu_config cfg; int N = 0, device = 0;
+    x264gpu_encoder *gpu = nullptr; uint8_t *d_in = nullptr; x264gpu_mb *d_mb = nullptr; int16_t *d_lv = nullptr;
+    size_t insz = 0, nmb = 0;
+    std::vector<char> member, arrived; int joined = 0, active = 0, n_arrived = 0;
+    std::vector<x264gpu_pic> pics; long round = 0; int round_rc = 0; std::string err;
+};
+static std::mutex g_batch_mu;
+static std::vector<BatchGroup *> g_batch_groups;
+
+static void batch_destroy(BatchGroup *g)
+{
+    if (g->gpu) x264gpu_encoder_destroy(g->gpu);
+    if (g->d_in) x264gpu_free(g->d_in);
+    if (g->d_mb) x264gpu_free(g->d_mb);
+    if (g->d_lv) x264gpu_free(g->d_lv);
+    delete g;
+}
+// -> the group and the stream index of the caller, or nullptr (setup failed: last error set)
+static BatchGroup *batch_join(const x264gpu_config &cfg1, int N, size_t insz, size_t nmb, int *idx)
+{
+    std::lock_guard<std::mutex> lk(g_batch_mu);
+    int dev = 0;
+    (void)x264gpu_get_device(&dev);
+    for (BatchGroup *g : g_batch_groups) {
+        x264gpu_config a = g->cfg, b = cfg1;
+        a.streams = b.streams = 0;
+        if (g->N == N && g->device == dev && g->joined < N && !memcmp(&a, &b, sizeof(a))) {
+            std::lock_guard<std::mutex> lg(g->m);
+            *idx = g->joined++; g->active++; g->member[(size_t)*idx] = 1;
+            g->cv.notify_all();
+            return g;
+        }
+    }
+    BatchGroup *g = new BatchGroup();
+    g->cfg = cfg1; g->cfg.streams = N; g->N = N; g->device = dev; g->insz = insz; g->nmb = nmb;
+    g->member.assign((size_t)N, 0); g->arrived.assign((size_t)N, 0); g->pics.resize((size_t)N);
+    if (x264gpu_encoder_create(&g->gpu, &g->cfg) != X264GPU_OK ||
+        x264gpu_malloc((void **)&g->d_in, (size_t)N * insz) != X264GPU_OK ||
+        x264gpu_malloc((void **)&g->d_mb, (size_t)N * nmb * sizeof(x264gpu_mb)) != X264GPU_OK ||
+        x264gpu_malloc((void **)&g->d_lv, (size_t)N * nmb * X264GPU_MB_LEVELS * sizeof(int16_t)) != X264GPU_OK) { batch_destroy(g); return nullptr; }
+    g->joined = 1; g->active = 1; g->member[0] = 1; *idx = 0;
+    g_batch_groups.push_back(g);
+    return g;
+}
+// the launch of a complete round; g->m is held
+static void batch_run_round(BatchGroup *g)
+{
+    int first = -1;
+    for (int s = 0; s < g->N; s++) if (g->arrived[(size_t)s]) { first = s; break; }
+    g->round_rc = 0; g->err.clear();
+    if (first >= 0) {
+        for (int s = 0; s < g->N; s++) {
+            if (!g->arrived[(size_t)s]) { g->pics[(size_t)s] = g->pics[(size_t)first]; continue; }      // a stream whose session has gone: coded along, thrown away
+            const x264gpu_pic &a = g->pics[(size_t)s], &b = g->pics[(size_t)first];
+            if (a.slice_type != b.slice_type || a.poc != b.poc || a.dst != b.dst || a.keep != b.keep || a.nref[0] != b.nref[0] || a.nref[1] != b.nref[1] ||
+                memcmp(a.slot, b.slot, sizeof(a.slot)) || a.blind_dupe != b.blind_dupe) { g->round_rc = -1; g->err = "the sessions of a batch must submit pictures of the same structure (same picture count, keyint, bframes, forced types)"; }
+        }
+        if (!g->round_rc && x264gpu_encode_pictures(g->gpu, g->d_in, g->pics.data(), g->d_mb, g->d_lv, nullptr) != X264GPU_OK) { g->round_rc = -1; g->err = x264gpu_last_error(); }
+    }
+    g->round++; g->n_arrived = 0;
+    std::fill(g->arrived.begin(), g->arrived.end(), 0);
+    g->cv.notify_all();
+}
+static int batch_encode(BatchGroup *g, int s, const uint8_t *d_src, const x264gpu_pic &pic, x264gpu_mb *h_mb, int16_t *h_lv, std::string &err)
+{
+    if (x264gpu_memcpy_d2d(g->d_in + (size_t)s * g->insz, d_src, g->insz, nullptr) != X264GPU_OK) { err = x264gpu_last_error(); return -1; }
+    {
+        std::unique_lock<std::mutex> lk(g->m);
+        // every member must have been opened before the first picture is coded: a late joiner would be a picture behind for good
+        if (!g->cv.wait_for(lk, std::chrono::seconds(60), [&] { return g->joined == g->N; })) { err = "X264GPU_BATCH: fewer sessions were opened than the batch size"; return -1; }
+        g->pics[(size_t)s] = pic; g->arrived[(size_t)s] = 1; g->n_arrived++;
+        const long my_round = g->round;
+        if (g->n_arrived >= g->active) batch_run_round(g);
+        else g->cv.wait(lk, [&] { return g->round != my_round; });
+        if (g->round_rc) { err = g->err; return -1; }
+    }
+    if (x264gpu_memcpy_d2h(h_mb, g->d_mb + (size_t)s * g->nmb, g->nmb * sizeof(x264gpu_mb), nullptr) != X264GPU_OK ||
+        x264gpu_memcpy_d2h(h_lv, g->d_lv + (size_t)s * g->nmb * X264GPU_MB_LEVELS, g->nmb * X264GPU_MB_LEVELS * sizeof(int16_t), nullptr) != X264GPU_OK) { err = x264gpu_last_error(); return -1; }
+    return 0;
+}
+static void batch_leave(BatchGroup *g, int s)
+{
+    bool last;
+    {
+        std::unique_lock<std::mutex> lk(g->m);
+        g->member[(size_t)s] = 0; g->active--;
+        last = g->active == 0;
+        if (!last && g->n_arrived >= g->active && g->n_arrived > 0) batch_run_round(g);      // the others were only waiting for this session
+    }
+    if (last) {
+        std::lock_guard<std::mutex> lk(g_batch_mu);
+        for (size_t i = 0; i < g_batch_groups.size(); i++) if (g_batch_groups[i] == g) { g_batch_groups.erase(g_batch_groups.begin() + (long)i); break; }
+        batch_destroy(g);
+    }
+}
 
 static void xlog(const x264_param_t *p, int level, const char *fmt, ...)
 {
@@ -332,6 +442,17 @@ x264_t *x264_encoder_open(x264_param_t *param)
     if (p.analyse.i_weighted_pred == X264_WEIGHTP_SMART && p.i_frame_reference < 2) p.analyse.i_weighted_pred = X264_WEIGHTP_NONE;      // a duplicate needs two references (x264: never placed)
     h->weightp = p.analyse.i_weighted_pred;
     h->dpbmode = h->bframes > 0 || h->weightp == X264_WEIGHTP_SMART;
+    if (const char *be = getenv("X264GPU_BATCH")) {
+        // cross-session batcher: this session joins (or starts) a group of N sessions coded in lock-step, if its picture structure is fixed
+        const int bn = atoi(be);
+        if (bn >= 2) {
+            const bool tree = p.rc.b_mb_tree && p.rc.i_rc_method != X264_RC_CQP && p.rc.i_lookahead > 0;
+            const char *why = p.i_threads > 1 ? "threads 1" : h->slices > 1 || p.b_sliced_threads ? "one slice per picture" : p.i_scenecut_threshold > 0 ? "scenecut 0" :
+                              (h->bframes && p.i_bframe_adaptive) ? "b-adapt 0" : tree ? "no-mbtree" : p.rc.i_rc_method == X264_RC_ABR ? "constant-quantiser or CRF rate control" : nullptr;
+            if (why) xlog(&p, X264_LOG_WARNING, "X264GPU_BATCH needs %s (picture k must have the same type in every session of a batch): this session runs on its own\n", why);
+            else { h->batch_n = bn; h->dpbmode = true; }
+        }
+    }
     if (h->dpbmode && !h->bframes) { p.rc.b_mb_tree = 0; }
     if (h->weightp == X264_WEIGHTP_SMART) xlog(&p, X264_LOG_INFO, "weightp 2: the duplicate of reference 0 with luma offset -1 on every P picture (x264's fade analysis is not run)\n");
     h->keyint = p.i_keyint_max;
@@ -438,6 +559,10 @@ x264_t *x264_encoder_open(x264_param_t *param)
         (void)x264gpu_set_device(h->device);
         if (!ok_setup) { xlog(&p, X264_LOG_ERROR, "GPU encoder setup failed: %s\n", err.c_str()); x264_encoder_close(h); return nullptr; }
         if (D > 1) xlog(&p, X264_LOG_INFO, "GOP slots on %d devices (%d + ... per device)\n", D, h->devs[0].nsl);
+    } else if (ok_setup && h->batch_n) {
+        h->batch = batch_join(cfg, h->batch_n, insz, (size_t)h->nmb, &h->batch_idx);
+        ok_setup = h->batch != nullptr;
+        if (ok_setup) xlog(&p, X264_LOG_INFO, "X264GPU_BATCH: stream %d of a batch of %d sessions\n", h->batch_idx, h->batch_n);
     } else if (ok_setup) {
         ok_setup = x264gpu_encoder_create(&h->gpu, &cfg) == X264GPU_OK &&
                    x264gpu_malloc((void **)&h->d_mb, (size_t)h->nmb * sizeof(x264gpu_mb)) == X264GPU_OK &&
@@ -1268,6 +1393,14 @@ static int encode_bmode(x264_t *h, x264_nal_t **pp_nal, int *pi_nal, x264_pictur
     }
     if (h->st && h->mbtree)          // P / I / B-reference pictures: what the tree left (AQ - tree); other B pictures: the AQ offsets alone (x264 f_qp_offset_aq)
         x264gpu_encoder_set_mb_qp_offsets(h->gpu, pl.type == PIC_B ? h->q_aq[(size_t)pl.e.slot] : h->q_tree[(size_t)pl.e.slot]);
+    if (h->batch) {
+        std::string berr;
+        if (batch_encode(h->batch, h->batch_idx, h->q_raw[(size_t)pl.e.slot], pic, h->h_mb.data(), h->h_lv.data(), berr)) {
+            xlog(&p, X264_LOG_ERROR, "x264_encoder_encode: GPU hot path failed: %s\n", berr.c_str());
+            h->failed = true;
+            return -1;
+        }
+    } else
     if (x264gpu_encode_pictures(h->gpu, h->q_raw[(size_t)pl.e.slot], &pic, h->d_mb, h->d_lv, nullptr) != X264GPU_OK ||
         x264gpu_memcpy_d2h(h->h_mb.data(), h->d_mb, h->h_mb.size() * sizeof(x264gpu_mb), nullptr) != X264GPU_OK ||
         x264gpu_memcpy_d2h(h->h_lv.data(), h->d_lv, h->h_lv.size() * sizeof(int16_t), nullptr) != X264GPU_OK) {
@@ -1431,6 +1564,7 @@ void x264_encoder_close(x264_t *h)
     if (getenv("X264GPU_HOST_TIMING") && h->t_phase[5] > 0)
         fprintf(stderr, "x264gpu host timing, ms per call over %.0f calls: copy-in %.2f, upload+lookahead %.2f, GPU %.2f, download %.2f, entropy %.2f\n", h->t_phase[5],
                 1e3 * h->t_phase[0] / h->t_phase[5], 1e3 * h->t_phase[1] / h->t_phase[5], 1e3 * h->t_phase[2] / h->t_phase[5], 1e3 * h->t_phase[3] / h->t_phase[5], 1e3 * h->t_phase[4] / h->t_phase[5]);
+    if (h->batch) { batch_leave(h->batch, h->batch_idx); h->batch = nullptr; }
     if (h->gpu) x264gpu_encoder_destroy(h->gpu);
     if (h->d_in) x264gpu_free(h->d_in);
     if (h->d_mb) x264gpu_free(h->d_mb);
