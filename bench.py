@@ -65,6 +65,7 @@ def parse_args():
     ap.add_argument("--no-trellis", action="store_true", help="headline toolset without trellis 1 (for comparison)")
     ap.add_argument("--aq", action="store_true", help="variance AQ on (per-macroblock quantisers, the CRF / ABR path); the headline metric is CQP and leaves it off, as x264 does")
     ap.add_argument("--cpu-frames", type=int, default=10, help="frames per core of the CPU-baseline sample (0 = skip)")
+    ap.add_argument("--e2e-sessions", type=int, default=256, help="sessions of the multi-session end-to-end sample (cross-session batcher; 0 = skip)")
     ap.add_argument("--e2e-frames", type=int, default=10, help="frames of the single-stream threads-1 end-to-end sample (0 = skip e2e)")
     ap.add_argument("--cpu-frames-all", type=int, default=3, help="frames per core of the every-core leg of the CPU baseline (shorter: it runs one process per core)")
     ap.add_argument("--content", default="noise", choices=["noise", "smooth"], help="synthetic content: 'noise' (default, the headline) = moving rectangles of per-pixel "
@@ -347,9 +348,62 @@ def e2e_probe(args):
         assert got == n
         return round(n / dt, 2), round(total / n / 1e3, 1)
 
+    def run_sessions(ns, n, src):
+        """ns sessions on ns host threads through the cross-session batcher (X264GPU_BATCH): medium with a fixed picture structure (no scenecut, b-adapt 0,
+        constant quantisers), every thread feeds host pictures and entropy-codes its own stream; -> frames/s over all sessions, kB per frame"""
+        import threading
+        os.environ["X264GPU_BATCH"] = str(ns)
+        res, errs = [0] * ns, []
+
+        def one(idx):
+            try:
+                p = HL.Param()
+                assert H.x264_param_default_preset(C.byref(p), b"medium", None) == 0
+                p.i_width, p.i_height, p.i_csp = w, h, HL.X264_CSP_I420
+                p.i_fps_num, p.i_fps_den, p.i_log_level = 25, 1, -1
+                for k, v in (("qp", str(args.qp)), ("keyint", "250"), ("scenecut", "0"), ("b-adapt", "0"), ("threads", "1")):
+                    assert H.x264_param_parse(C.byref(p), k.encode(), v.encode()) == 0
+                p.b_annexb, p.b_repeat_headers = 1, 1
+                h_ = H.x264_encoder_open_157(C.byref(p))
+                assert h_
+                pic, out = HL.Picture(), HL.Picture()
+                assert H.x264_picture_alloc(C.byref(pic), HL.X264_CSP_I420, w, h) == 0
+                nal, nn = C.POINTER(HL.Nal)(), C.c_int()
+                got = total = 0
+                for i in range(n):
+                    f = src[(i + idx) % len(src)] if i else src[idx % len(src)]
+                    for pl, (sz, off) in enumerate(planes):
+                        C.memmove(pic.img.plane[pl], f[off:off + sz].ctypes.data, sz)
+                    pic.i_pts = i
+                    size = H.x264_encoder_encode(h_, C.byref(nal), C.byref(nn), C.byref(pic), C.byref(out))
+                    assert size >= 0
+                    got += size > 0
+                    total += size
+                while H.x264_encoder_delayed_frames(h_):
+                    size = H.x264_encoder_encode(h_, C.byref(nal), C.byref(nn), None, C.byref(out))
+                    assert size > 0
+                    got += 1
+                    total += size
+                H.x264_encoder_close(h_)
+                assert got == n
+                res[idx] = total
+            except Exception as e:  # noqa: BLE001
+                errs.append(repr(e))
+        ths = [threading.Thread(target=one, args=(i,)) for i in range(ns)]
+        t0 = time.perf_counter()
+        for t in ths:
+            t.start()
+        for t in ths:
+            t.join()
+        dt = time.perf_counter() - t0
+        os.environ.pop("X264GPU_BATCH", None)
+        assert not errs, errs[:3]
+        return round(ns * n / dt, 2), round(sum(res) / (ns * n) / 1e3, 1)
+
     n1 = args.e2e_frames
     src = synth_frames(w, h, max(n1, 16), seed=0x264, scene_len=97)
     f1, kb1 = run(n1, 1, 250, src)
+    fm, kbm = run_sessions(args.e2e_sessions, n1, src) if args.e2e_sessions > 1 else (None, None)
     G, K = 32, 4
     fg, kbg = run(G * K, G, K, src)
     ns = (h + 15) // 16 // 4                        # x264 slice threads: at most one slice per four macroblock rows
@@ -361,6 +415,8 @@ def e2e_probe(args):
     os.environ.pop("X264GPU_GOP_SLOTS", None)
     return {"what": "ONE 1920x1080 stream through x264_encoder_encode (host pictures in, Annex-B out: PCIe + host entropy coding included), CQP, preset medium as implemented",
             "threads1_fps": f1, "threads1_frames": n1, "threads1_kB_per_frame": kb1,
+            "multi_session_fps": fm, "multi_session_sessions": args.e2e_sessions, "multi_session_frames_each": n1, "multi_session_kB_per_frame": kbm,
+            "multi_session_what": "that many x264_encoder_open sessions on as many host threads through the cross-session batcher (X264GPU_BATCH): one lock-step device launch per picture, host pictures in, every thread entropy-codes its own stream; session setup and teardown inside the timed span",
             "sliced_threads_fps": fs, "sliced_threads_slices": ns, "sliced_threads_delay_frames": 0, "sliced_threads_kB_per_frame": kbs,
             "sliced_threads_gop_slots32_fps": fsg, "sliced_threads_gop_slots32_delay_frames": (G - 1) * K + 1,
             "slices_per_row_fps": fr, "slices_per_row_slices": nr, "slices_per_row_delay_frames": 0, "slices_per_row_kB_per_frame": kbr,
