@@ -65,6 +65,7 @@ def parse_args():
     ap.add_argument("--no-trellis", action="store_true", help="headline toolset without trellis 1 (for comparison)")
     ap.add_argument("--aq", action="store_true", help="variance AQ on (per-macroblock quantisers, the CRF / ABR path); the headline metric is CQP and leaves it off, as x264 does")
     ap.add_argument("--cpu-frames", type=int, default=10, help="frames per core of the CPU-baseline sample (0 = skip)")
+    ap.add_argument("--e2e-legs", default="all", choices=["all", "sessions"], help="'sessions': only the threads-1 and multi-session legs of the end-to-end sample")
     ap.add_argument("--e2e-sessions", type=int, default=256, help="sessions of the multi-session end-to-end sample (cross-session batcher; 0 = skip)")
     ap.add_argument("--e2e-frames", type=int, default=10, help="frames of the single-stream threads-1 end-to-end sample (0 = skip e2e)")
     ap.add_argument("--cpu-frames-all", type=int, default=3, help="frames per core of the every-core leg of the CPU baseline (shorter: it runs one process per core)")
@@ -404,6 +405,9 @@ def e2e_probe(args):
     src = synth_frames(w, h, max(n1, 16), seed=0x264, scene_len=97)
     f1, kb1 = run(n1, 1, 250, src)
     fm, kbm = run_sessions(args.e2e_sessions, n1, src) if args.e2e_sessions > 1 else (None, None)
+    if args.e2e_legs != "all":
+        return {"what": "x264_encoder_encode end to end, 1920x1080 (only the threads-1 and multi-session legs were asked for)", "threads1_fps": f1, "threads1_frames": n1,
+                "multi_session_fps": fm, "multi_session_sessions": args.e2e_sessions, "multi_session_frames_each": n1, "multi_session_kB_per_frame": kbm, "host_cores": os.cpu_count()}
     G, K = 32, 4
     fg, kbg = run(G * K, G, K, src)
     ns = (h + 15) // 16 // 4                        # x264 slice threads: at most one slice per four macroblock rows
