@@ -36,6 +36,9 @@ def run(w, h, types, seed, bframes=3, pyramid=1, weightp=0, pics_out=None, **ove
     (176, 144, "IBBBPBBBPBBBP", 6, dict(refs=1, dct8x8=0, trellis=0)),            # ref 1: the DPB still holds 4 pictures under b-pyramid
     (128, 96, "IBBPBBP", 7, dict(refs=5, dpb=5, chroma_me=0, psy_rd_q8=0)),
     (176, 144, "IBBPBP", 8, dict(dct_decimate=0)),
+    (176, 144, "IBBBPBBP", 9, dict(me_method=2)),
+    (128, 96, "IBPBBP", 12, dict(me_method=3, me_range=8)),
+    (176, 144, "IBBBPBP", 13, dict(trellis=63 + 64)),
 ])
 def test_b_pictures_decode_to_the_encoders_reconstruction(w, h, types, seed, over):
     run(w, h, types, seed, **over)

@@ -65,6 +65,12 @@ def run(gpu, w, h, types, seed, streams=1, bframes=3, pyramid=1, weightp=0, **ov
     (176, 144, "IBBBPBBBPBBBP", 6, dict(refs=1, dct8x8=0, trellis=0)),
     (128, 96, "IBBPBBP", 7, dict(refs=5, dpb=5, chroma_me=0, psy_rd_q8=0)),
     (176, 144, "IBBPBP", 8, dict(dct_decimate=0)),                                  # --no-dct-decimate: B slices decimate all the same (x264 b_dct_decimate)
+    (176, 144, "IBBBPBBP", 9, dict(me_method=2)),                                   # --me umh in B slices (presets slow and slower)
+    (208, 112, "IBBPBP", 10, dict(me_method=2, me_range=24, refs=4, dpb=4)),
+    (128, 96, "IBBPBBP", 11, dict(me_method=0)),                                    # dia
+    (128, 96, "IBPBBP", 12, dict(me_method=3, me_range=8)),                         # esa
+    (176, 144, "IBBBPBP", 13, dict(trellis=63 + 64)),                               # --trellis 2: the search in the analysis' block encodes and every RD candidate of B macroblocks too
+    (128, 96, "IBBPBP", 14, dict(trellis=63 + 64, me_method=2)),
 ])
 def test_b_pictures_bitexact_and_decodable(gpu, w, h, types, seed, over):
     run(gpu, w, h, types, seed, **over)

@@ -22,7 +22,10 @@ void launch_mb_slice_hex(const EncK &k, int streams, bool big_margin, hipStream_
 void launch_mb_slice_umh(const EncK &k, int streams, bool big_margin, hipStream_t st);
 void launch_mb_slice_esa(const EncK &k, int streams, bool big_margin, hipStream_t st);
 void launch_mb_slice_intra(const EncK &k, int streams, hipStream_t st);
-void launch_mb_slice_b_hex(const EncK &k, int streams, hipStream_t st);       // B slices (mb_slice_b.hip): RD sessions with CABAC, --me hex
+void launch_mb_slice_b_hex(const EncK &k, int streams, hipStream_t st);       // B slices (mb_slice_b*.hip): RD sessions with CABAC
+void launch_mb_slice_b_dia(const EncK &k, int streams, hipStream_t st);
+void launch_mb_slice_b_umh(const EncK &k, int streams, hipStream_t st);
+void launch_mb_slice_b_esa(const EncK &k, int streams, hipStream_t st);
 int trellis_table_ptrs(const uint16_t **su, const uint8_t **tu, const int **l2);        // prim_kernels.hip
 int launch_hpel_filter(uint8_t *planes, size_t plane_bytes, int stride, int w, int h, int pad, int batch,
                        size_t batch_bytes, hipStream_t st);
@@ -329,7 +332,7 @@ static int encode_core(x264gpu_encoder *e, const uint8_t *d_i420, const x264gpu_
     if (slice_type == X264GPU_SLICE_I_NONIDR) slice_type = X264GPU_SLICE_I;            // same kernels; only the DPB handling differs
     const bool bslice = slice_type == X264GPU_SLICE_B;
     ARG_TRY(pic.dst >= 0 && pic.dst < e->slots && pic.qp >= 0 && pic.qp <= 51);
-    ARG_TRY(!bslice || (e->cfg.rd && e->cfg.cabac && e->cfg.dpb > 0 && e->cfg.me_method == 1 && (e->cfg.slices <= 1)));      // B pictures: RD sessions with CABAC, --me hex, one slice
+    ARG_TRY(!bslice || (e->cfg.rd && e->cfg.cabac && e->cfg.dpb > 0 && (e->cfg.slices <= 1)));      // B pictures: RD sessions with CABAC, one slice
     const int n0 = slice_type == X264GPU_SLICE_I ? 0 : pic.nref[0], n1 = bslice ? pic.nref[1] : 0;
     ARG_TRY(n0 >= 0 && n0 <= 7 && n1 >= 0 && n1 <= 3 && n0 + n1 <= 8 && (slice_type == X264GPU_SLICE_I || n0 > 0) && (!bslice || n1 > 0));      // list 0: up to 5 pictures + --weightp duplicates
     for (int l = 0; l < 2; l++) for (int r = 0; r < (l ? n1 : n0); r++) ARG_TRY(pic.slot[l][r] >= 0 && pic.slot[l][r] < e->slots && pic.slot[l][r] != pic.dst);
@@ -417,7 +420,7 @@ static int encode_core(x264gpu_encoder *e, const uint8_t *d_i420, const x264gpu_
     STAGE_MARK(1);
     // the macroblock loop: one wavefront per stream, raster order (sub-pel neighbourhood margin 2 px up to subme 7, 5 px above)
     if (slice_type == X264GPU_SLICE_I) launch_mb_slice_intra(k, S, st);        // (RD instantiations inside, chosen by k.rd)
-    else if (bslice) launch_mb_slice_b_hex(k, S, st);
+    else if (bslice) (k.me_method == 0 ? launch_mb_slice_b_dia : k.me_method == 2 ? launch_mb_slice_b_umh : k.me_method == 3 ? launch_mb_slice_b_esa : launch_mb_slice_b_hex)(k, S, st);
     else {
         const auto launch = k.me_method == 0 ? launch_mb_slice_dia : k.me_method == 2 ? launch_mb_slice_umh : k.me_method == 3 ? launch_mb_slice_esa : launch_mb_slice_hex;
         if (k.sl_stat) hipLaunchKernelGGL(k_slice_priors, dim3((S + 63) / 64), dim3(64), 0, st, k, S, 1);

@@ -1397,7 +1397,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(MB_WAVES_PER
     // holds data DURING a search: a buffer of its own made the B instantiations' LDS 20 992 B a wavefront — seven instead of eight wavefronts a CU,
     // so the last 256 of 2048 streams ran as a second round
     static_assert(!BS || CSubGeo<M>::DWORDS >= 128, "b_visited aliases L.csub");
-    uint32_t *const b_visited = L.csub;
+#define b_visited L.csub      /* (not a pointer variable: a generic pointer into LDS trips an instruction-selection bug of this compiler in the umh instantiation) */
     const int lane = threadIdx.x, s = blockIdx.x;
     // x264 slice threads: blockIdx.y = slice of the picture, macroblock rows [row0, row1) (k.slices == 1: the whole picture)
     const int nsl = k.slices > 1 ? k.slices : 1, row0 = (k.mbh * (int)blockIdx.y + nsl / 2) / nsl, row1 = (k.mbh * ((int)blockIdx.y + 1) + nsl / 2) / nsl;

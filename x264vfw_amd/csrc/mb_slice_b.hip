@@ -1,11 +1,12 @@
-// mb_slice_b.hip — the macroblock-loop kernel (k_mb.cuh) instantiated for B slices (--me hex; RD sessions with CABAC, with and without the
-// trellis quantiser in the final encode): a translation unit of its own, like the per-method ones.
+// mb_slice_b.hip — the macroblock-loop kernel (k_mb.cuh) instantiated for B slices (--me hex; RD sessions with CABAC, without the trellis quantiser,
+// with it in the final encode, and with it in the analysis too): a translation unit of its own, like the per-method ones (mb_slice_b_dia / _umh / _esa.hip).
 #include "k_mb.cuh"
 
 namespace x264gpu {
 void launch_mb_slice_b_hex(const EncK &k, int streams, hipStream_t st)
 {
-    if (k.trellis) hipLaunchKernelGGL((k_mb_slice<2, 1, true, 3, true>), dim3(streams, 1), dim3(64), 0, st, k);
+    if (k.trellis & 64) hipLaunchKernelGGL((k_mb_slice<2, 1, true, 4, true>), dim3(streams, 1), dim3(64), 0, st, k);      // --trellis 2
+    else if (k.trellis) hipLaunchKernelGGL((k_mb_slice<2, 1, true, 3, true>), dim3(streams, 1), dim3(64), 0, st, k);
     else hipLaunchKernelGGL((k_mb_slice<2, 1, true, 2, true>), dim3(streams, 1), dim3(64), 0, st, k);
 }
 }  // namespace x264gpu

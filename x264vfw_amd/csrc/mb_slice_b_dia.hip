@@ -1,0 +1,12 @@
+// mb_slice_b_dia.hip — the macroblock-loop kernel (k_mb.cuh) instantiated for B slices under --me dia (RD sessions with CABAC; with and without
+// the trellis quantiser): a translation unit of its own so that the instantiations build in parallel.
+#include "k_mb.cuh"
+
+namespace x264gpu {
+void launch_mb_slice_b_dia(const EncK &k, int streams, hipStream_t st)
+{
+    if (k.trellis & 64) hipLaunchKernelGGL((k_mb_slice<2, 0, true, 4, true>), dim3(streams, 1), dim3(64), 0, st, k);      // --trellis 2
+    else if (k.trellis) hipLaunchKernelGGL((k_mb_slice<2, 0, true, 3, true>), dim3(streams, 1), dim3(64), 0, st, k);
+    else hipLaunchKernelGGL((k_mb_slice<2, 0, true, 2, true>), dim3(streams, 1), dim3(64), 0, st, k);
+}
+}  // namespace x264gpu

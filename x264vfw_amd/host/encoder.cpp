@@ -417,7 +417,7 @@ x264_t *x264_encoder_open(x264_param_t *param)
     } else if (!p.b_sliced_threads) p.i_slice_count = 0;
     p.i_threads = clampi(p.i_threads, 1, 256);                 // --threads G: GOPs coded in lock-step (1 = no delay)
     if (p.i_bframe) {
-        const char *why = !p.b_cabac ? "CABAC" : p.analyse.i_subpel_refine < 6 ? "subme >= 6" : p.analyse.i_me_method != X264_ME_HEX ? "me hex" : h->slices > 1 ? "one slice per picture" :
+        const char *why = !p.b_cabac ? "CABAC" : p.analyse.i_subpel_refine < 6 ? "subme >= 6" : h->slices > 1 ? "one slice per picture" :
                           p.i_threads > 1 ? "threads 1" : p.i_keyint_max < 2 ? "keyint > 1" : p.rc.i_rc_method == X264_RC_ABR ? "constant-quantiser or CRF rate control" : nullptr;
         if (why) { xlog(&p, X264_LOG_WARNING, "B-frames need %s in the MI355X path: bframes 0\n", why); p.i_bframe = 0; }
     }
