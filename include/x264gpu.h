@@ -320,6 +320,9 @@ void x264gpu_slicetype_destroy(x264gpu_slicetype *st);
 int  x264gpu_slicetype_put_frame(x264gpu_slicetype *st, int slot, const uint8_t *d_i420, void *stream);
 /* the score of picture slot_b predicted from slot_p0 (and slot_p1): h_score[streams] (host memory; memoised per (slot_b, d0, d1)) */
 int  x264gpu_slicetype_frame_cost(x264gpu_slicetype *st, int slot_p0, int slot_p1, int slot_b, int d0, int d1, int32_t *h_score, void *stream);
+/* ... of a P cost (d1 = 0) that is searched for the first time, on the reference weighted by the explicit luma weight the lookahead's
+ * x264_weights_analyse found (m[0].weight in slicetype_mb_cost) */
+int  x264gpu_slicetype_frame_cost_w(x264gpu_slicetype *st, int slot_p0, int slot_p1, int slot_b, int d0, int d1, int on, int scale, int denom, int offset, int32_t *h_score, void *stream);
 int  x264gpu_slicetype_intra_mbs(x264gpu_slicetype *st, int slot, int d0, int stream_idx);          /* frame->i_intra_mbs[d0] of the last P cost */
 int  x264gpu_slicetype_cost_est(x264gpu_slicetype *st, int slot, int d0, int d1, int stream_idx);   /* frame->i_cost_est[d0][d1], -1 = not computed */
 /* device pointers of a picture's cached results ([streams][blocks]): vectors ([2] each, quarter samples of the half-resolution planes) and costs of
@@ -328,6 +331,12 @@ const int16_t  *x264gpu_slicetype_lowres_mvs(x264gpu_slicetype *st, int slot, in
 const int      *x264gpu_slicetype_lowres_mv_costs(x264gpu_slicetype *st, int slot, int list, int dist);
 const int      *x264gpu_slicetype_intra_costs(x264gpu_slicetype *st, int slot);
 const uint16_t *x264gpu_slicetype_lowres_costs(x264gpu_slicetype *st, int slot, int d0, int d1);
+/* x264_weights_analyse's primitives (--weightp): the luma statistics of a source picture (x264_adaptive_quant_frame's i_pixel_sum / i_pixel_ssd over the
+ * mod-16 expanded picture: h_out[streams][2]) and weight_cost_luma — per 8x8 block min(mbcmp(weighted reference, source), intra cost) over the whole
+ * half-resolution picture + the slice-header bits of the weight; the reference motion-compensated by the picture's list-0 vectors of distance `dist`
+ * when that search has run.  The picture's intra costs must exist (any x264gpu_slicetype_frame_cost of it).  The analysis around them is the caller's. */
+int  x264gpu_slicetype_pixel_stats(x264gpu_slicetype *st, int slot, const uint8_t *d_i420, uint64_t *h_out, void *stream);
+int  x264gpu_slicetype_weight_cost(x264gpu_slicetype *st, int slot_fenc, int slot_ref, int dist, int on, int scale, int denom, int offset, int64_t *h_cost, void *stream);
 /* macroblock-tree through B pictures: the building blocks of x264's macroblock_tree (the caller walks the pictures of the lookahead as x264 does:
  * clear the propagate cost of a non-B picture, x264gpu_slicetype_frame_cost of a triple, _propagate it, ..., _finish the picture about to be coded).
  * AQ offsets (x264_adaptive_quant_frame; x264gpu_lookahead_aq_offsets) weight the costs (i_inv_qscale_factor) and are the base of the result;

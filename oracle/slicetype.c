@@ -113,6 +113,7 @@ int x264o_slicetype_put_frame(x264o_slicetype *st, int slot, const uint8_t *i420
     for (int i = 0; i <= st->bframes + 1; i++) for (int j = 0; j <= st->bframes + 1; j++) f->cost_est[i][j] = -1;
     memset(f->intra_mbs, 0, sizeof(f->intra_mbs));
     f->intra_calculated = 0;
+    for (int i = 0; i < st->nb; i++) f->intra_cost[i] = 0xffff;          /* x264_frame_new: memset( i_intra_cost, -1 ) — blocks never costed never win a minimum */
     memset(st->tree[slot].prop, 0, (size_t)st->nb * sizeof(int32_t)); memset(st->tree[slot].aq, 0, (size_t)st->nb * sizeof(int16_t));
     return 0;
 }
@@ -235,9 +236,14 @@ static void mb_cost(x264o_slicetype *st, int s0, int s1, int sb, int d0, int d1,
     fenc->lowres_costs[d0][d1][bi] = (uint16_t)((i_bcost < LOWRES_COST_MASK ? i_bcost : LOWRES_COST_MASK) + (list_used << LOWRES_COST_SHIFT));
 }
 
+int x264o_slicetype_frame_cost_w(x264o_slicetype *st, int s0, int s1, int sb, int d0, int d1, int on, int scale, int denom, int offset);
 /* slicetype_frame_cost(p0, p1, b): slots of the three pictures and the distances d0 = b - p0, d1 = p1 - b.  Returns the frame's score. */
-int x264o_slicetype_frame_cost(x264o_slicetype *st, int s0, int s1, int sb, int d0, int d1)
+int x264o_slicetype_frame_cost(x264o_slicetype *st, int s0, int s1, int sb, int d0, int d1) { return x264o_slicetype_frame_cost_w(st, s0, s1, sb, d0, d1, 0, 1, 0, 0); }
+/* ... with the explicit luma weight x264_weights_analyse( b_lookahead = 1 ) found for a P cost that is searched for the first time: the list-0 search
+ * runs on the weighted reference (m[0].weight / fenc->weighted[0]); the zero-vector shortcut reads the unweighted plane, as x264's does */
+int x264o_slicetype_frame_cost_w(x264o_slicetype *st, int s0, int s1, int sb, int d0, int d1, int on, int scale, int denom, int offset)
 {
+    st->lo.wl0[0].on = on && d1 == 0 && d0 > 0; st->lo.wl0[0].scale = scale; st->lo.wl0[0].denom = denom; st->lo.wl0[0].offset = offset;
     if (d0 < 0 || d1 < 0 || d0 > st->bframes + 1 || d1 > st->bframes + 1 || (d1 > 0 && d0 == 0)) return -1;
     st_frame *fenc = &st->fr[sb];
     if (fenc->cost_est[d0][d1] >= 0) return fenc->cost_est[d0][d1];
@@ -355,3 +361,49 @@ int x264o_slicetype_finish(x264o_slicetype *st, int slot, int strength_q8, int16
     return 0;
 }
 const int32_t *x264o_slicetype_propagate_cost(x264o_slicetype *st, int slot) { return st_tree_of(st)[slot].prop; }
+
+/* ---------------------------------------------------------------------------------------------------------------------------
+ * The primitives behind x264_weights_analyse ([x264-upstream] encoder/slicetype.c; --weightp): the pixel statistics of a source picture
+ * (x264_adaptive_quant_frame: i_pixel_sum / i_pixel_ssd of the mod-16 expanded luma) and weight_cost_luma — the cost of predicting the
+ * half-resolution picture from a reference under an explicit luma weight: per 8x8 block min(mbcmp(weighted reference block, source block),
+ * intra cost), every block of the picture, + the bits the weights cost in the slice header.  The reference is motion-compensated by the
+ * lookahead's vectors of (list 0, dist) when that search has run (weight_cost_init_luma), else taken in place.  The analysis itself — guessing
+ * scale and offset from the statistics, the candidates around the guess, the 0.2 % gain threshold — is the caller's (host/encoder.cpp). */
+void x264o_slicetype_pixel_stats(x264o_slicetype *st, int slot, const uint8_t *i420, uint64_t out[2])
+{
+    (void)slot;
+    const int cw = st->bw * 16, ch = st->bh * 16;
+    uint64_t sum = 0, sqr = 0;
+    for (int y = 0; y < ch; y++)
+        for (int x = 0; x < cw; x++) { const uint32_t p = i420[(size_t)clampi(y, 0, st->h - 1) * st->w + clampi(x, 0, st->w - 1)]; sum += p; sqr += p * p; }
+    const uint64_t n = (uint64_t)cw * ch;
+    out[0] = sum; out[1] = sqr - (sum * sum + n / 2) / n;
+}
+/* dist: > 0 and that list-0 search of `sf` has run: motion-compensated reference; else the reference in place.  on = 0: unweighted */
+long x264o_slicetype_weight_cost(x264o_slicetype *st, int sf, int sr, int dist, int on, int scale, int denom, int offset)
+{
+    x264o_encoder *lo = &st->lo;
+    st_frame *f = &st->fr[sf];
+    if (f->cost_est[0][0] < 0) return -1;
+    const int rs = lo->rs;
+    pixel *pl[4];
+    for (int k = 0; k < 4; k++) pl[k] = luma_plane(lo, sr, k);
+    const pixel *src = luma_plane(lo, sf, 0);
+    const int16_t (*mv)[2] = dist > 0 && dist <= st->bframes + 1 && f->mvs[0][dist - 1][0][0] != 0x7fff ? f->mvs[0][dist - 1] : NULL;
+    long cost = 0;
+    for (int by = 0; by < st->bh; by++)
+        for (int bx = 0; bx < st->bw; bx++) {
+            const int i = by * st->bw + bx;
+            pixel buf[64];
+            x264o_mc_luma(buf, 8, pl, rs, bx * 8, by * 8, mv ? mv[i][0] : 0, mv ? mv[i][1] : 0, 8, 8);
+            if (on) x264o_mc_weight(buf, 8, buf, 8, 8, 8, scale, denom, offset);
+            const pixel *s = src + (size_t)by * 8 * rs + bx * 8;
+            const int cmp = st->param_subme > 1 ? x264o_satd(buf, 8, s, rs, 8, 8) : x264o_sad(buf, 8, s, rs, 8, 8);
+            cost += cmp < f->intra_cost[i] ? cmp : f->intra_cost[i];
+        }
+    if (on) {       /* weight_slice_header_cost: lambda(12) x slices x (10 + 2 x denom bits + 2 x (scale bits + offset bits)) */
+        const int se_scale = bs_size_ue(scale > 0 ? 2 * scale - 1 : -2 * scale), se_off = bs_size_ue(offset > 0 ? 2 * offset - 1 : -2 * offset);
+        cost += x264o_lambda(12) * (10 + bs_size_ue(denom) * 2 + 2 * (se_scale + se_off));
+    }
+    return cost;
+}

@@ -140,9 +140,22 @@ class GpuSlicetype:
         self.keep[slot] = d_in
         lib.check(lib.x264gpu_slicetype_put_frame(self.h, slot, d_in.data_ptr(), None), "slicetype_put_frame")
 
-    def cost(self, s0, s1, sb, d0, d1):
+    def cost(self, s0, s1, sb, d0, d1, weight=None):
         out = np.zeros(self.S, np.int32)
-        lib.check(lib.x264gpu_slicetype_frame_cost(self.h, s0, s1, sb, d0, d1, out.ctypes.data, None), "slicetype_frame_cost")
+        if weight:
+            lib.check(lib.x264gpu_slicetype_frame_cost_w(self.h, s0, s1, sb, d0, d1, 1, *weight, out.ctypes.data, None), "slicetype_frame_cost_w")
+        else:
+            lib.check(lib.x264gpu_slicetype_frame_cost(self.h, s0, s1, sb, d0, d1, out.ctypes.data, None), "slicetype_frame_cost")
+        return out
+
+    def pixel_stats(self, slot):
+        out = np.zeros((self.S, 2), np.uint64)
+        lib.check(lib.x264gpu_slicetype_pixel_stats(self.h, slot, self.keep[slot].data_ptr(), out.ctypes.data, None), "pixel_stats")
+        return out
+
+    def weight_cost(self, sf, sr, dist, weight=None):
+        out = np.zeros(self.S, np.int64)
+        lib.check(lib.x264gpu_slicetype_weight_cost(self.h, sf, sr, dist, 1 if weight else 0, *(weight or (1, 0, 0)), out.ctypes.data, None), "weight_cost")
         return out
 
     def intra_mbs(self, slot, d0, s=0):

@@ -280,6 +280,9 @@ _sig("x264o_slicetype_mv_costs", C.c_void_p, [C.c_void_p, _i, _i, _i])
 _sig("x264o_slicetype_intra_costs", C.c_void_p, [C.c_void_p, _i])
 _sig("x264o_slicetype_lowres_costs", C.c_void_p, [C.c_void_p, _i, _i, _i])
 _sig("x264o_slicetype_set_aq", None, [C.c_void_p, _i, C.c_void_p])
+_sig("x264o_slicetype_frame_cost_w", _i, [C.c_void_p] + [_i] * 9)
+_sig("x264o_slicetype_pixel_stats", None, [C.c_void_p, _i, C.c_void_p, C.c_void_p])
+_sig("x264o_slicetype_weight_cost", C.c_long, [C.c_void_p] + [_i] * 7)
 _sig("x264o_slicetype_clear_propagate", None, [C.c_void_p, _i])
 _sig("x264o_slicetype_propagate", _i, [C.c_void_p, _i, _i, _i, _i, _i, _i])
 _sig("x264o_slicetype_finish", _i, [C.c_void_p, _i, _i, C.c_void_p])
@@ -298,8 +301,19 @@ class OracleSlicetype:
         i420 = np.ascontiguousarray(i420, np.uint8)
         assert L.x264o_slicetype_put_frame(self.st, slot, ptr(i420)) == 0
 
-    def cost(self, s0, s1, sb, d0, d1):
+    def cost(self, s0, s1, sb, d0, d1, weight=None):
+        if weight:
+            return L.x264o_slicetype_frame_cost_w(self.st, s0, s1, sb, d0, d1, 1, *weight)
         return L.x264o_slicetype_frame_cost(self.st, s0, s1, sb, d0, d1)
+
+    def pixel_stats(self, slot, i420):
+        out = np.zeros(2, np.uint64)
+        i420 = np.ascontiguousarray(i420, np.uint8)
+        L.x264o_slicetype_pixel_stats(self.st, slot, ptr(i420), ptr(out))
+        return out
+
+    def weight_cost(self, sf, sr, dist, weight=None):
+        return L.x264o_slicetype_weight_cost(self.st, sf, sr, dist, 1 if weight else 0, *(weight or (1, 0, 0)))
 
     def intra_mbs(self, slot, d0):
         return L.x264o_slicetype_intra_mbs(self.st, slot, d0)

@@ -184,3 +184,41 @@ def test_mbtree_through_b_pictures_bitexact(gpu, w, h, types, pyramid, b_intra, 
         assert np.array_equal(go[k][0], oo[k]), f"offsets of picture {k} differ"
         assert (oo[k] != (O.aq_offsets(frames[k], w, h) if aq else 0)).any(), "the tree moved nothing"
     og.close(); gg.close()
+
+
+def fade_frames(w, h, n, seed, step=6):
+    """a clip fading to black: picture i = picture of a moving scene scaled by (1 - i * step / 100), the chroma pulled towards 128"""
+    fr = synth_frames(w, h, n, seed=seed)
+    out = []
+    for i, f in enumerate(fr):
+        a = max(0.0, 1.0 - i * step / 100.0)
+        g = f.astype(np.float32)
+        g[:w * h] *= a
+        g[w * h:] = 128 + (g[w * h:] - 128) * a
+        out.append(np.clip(np.rint(g), 0, 255).astype(np.uint8))
+    return out
+
+
+@pytest.mark.parametrize("w,h,seed,kw", [(176, 144, 3, {}), (352, 288, 5, dict(do_edges=1)), (208, 120, 7, dict(subme=1, me_method=0))])
+def test_weight_analysis_primitives_bitexact(gpu, w, h, seed, kw):
+    """x264_weights_analyse's building blocks on a fade: luma statistics, the cost of predicting a picture from its predecessor under several explicit
+    weights (reference in place, and motion-compensated by the lookahead's vectors once that search has run), and the P cost searched on a weighted reference"""
+    from gpu_enc import GpuSlicetype
+    n = 4
+    frames = fade_frames(w, h, n, seed)
+    og, gg = O.OracleSlicetype(w, h, **kw), GpuSlicetype(w, h, **kw)
+    for i, f in enumerate(frames):
+        og.put(i, f); gg.put(i, [f])
+        assert np.array_equal(gg.pixel_stats(i)[0], og.pixel_stats(i, f)), f"statistics of picture {i}"
+    for i in range(1, n):
+        assert gg.cost(i, i, i, 0, 0)[0] == og.cost(i, i, i, 0, 0)
+    weights = [None, (60, 6, 0), (59, 6, 1), (117, 7, -2), (1, 0, -3), (127, 7, 0)]
+    for wgt in weights:
+        assert gg.weight_cost(2, 1, 1, wgt)[0] == og.weight_cost(2, 1, 1, wgt), f"weight {wgt}, reference in place"
+    # the P cost of picture 2 from picture 1, searched on the weighted reference (lookahead mode), then the costs on the compensated reference
+    assert gg.cost(1, 2, 2, 1, 0, weight=(60, 6, 0))[0] == og.cost(1, 2, 2, 1, 0, weight=(60, 6, 0))
+    assert np.array_equal(gg.mvs(2, 0, 1)[0], og.mvs(2, 0, 1))
+    for wgt in weights:
+        assert gg.weight_cost(2, 1, 1, wgt)[0] == og.weight_cost(2, 1, 1, wgt), f"weight {wgt}, compensated reference"
+    assert og.weight_cost(2, 1, 1, (60, 6, 0)) < og.weight_cost(2, 1, 1, None), "on a fade the right weight must pay"
+    og.close(); gg.close()

@@ -283,6 +283,50 @@ __global__ __launch_bounds__(64) void k_st_cost(StK k)
     if (lane == 0) { atomicAdd(k.sums + (size_t)s * 4, sum_inter); atomicAdd(k.sums + (size_t)s * 4 + 2, sum_intra_mbs); }
 }
 
+// ---- the primitives behind x264_weights_analyse (oracle/slicetype.c x264o_slicetype_pixel_stats / _weight_cost) ----
+struct StWeightK {
+    int bw, bh, nb, rs, satd, wpk;               // wpk: EncK::wl0 packing of the explicit luma weight, 0 = unweighted
+    size_t plane_bytes, luma_bytes, i420_bytes; int w, h, cw, ch;
+    const uint8_t *i420; const uint8_t *fenc, *ref; const int16_t *mv; const int *intra_cost;
+    unsigned long long *out;                     // [S][2]
+};
+__global__ __launch_bounds__(256) void k_st_pixel_stats(StWeightK k)
+{
+    const int s = blockIdx.y;
+    const uint8_t *src = k.i420 + (size_t)s * k.i420_bytes;
+    unsigned long long sum = 0, sqr = 0;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < k.cw * k.ch; i += gridDim.x * 256) {
+        const int y = i / k.cw, x = i - y * k.cw;
+        const unsigned p = src[(size_t)min(y, k.h - 1) * k.w + min(x, k.w - 1)];
+        sum += p; sqr += p * p;
+    }
+    for (int o = 32; o; o >>= 1) { sum += __shfl_xor(sum, o); sqr += __shfl_xor(sqr, o); }
+    if ((threadIdx.x & 63) == 0) { atomicAdd(k.out + (size_t)s * 2, sum); atomicAdd(k.out + (size_t)s * 2 + 1, sqr); }
+}
+// weight_cost_luma: lane = (block of the group of eight, row); every block of the picture
+__global__ __launch_bounds__(64) void k_st_weight_cost(StWeightK k)
+{
+    const int lane = threadIdx.x, s = blockIdx.y, row = lane & 7;
+    const int bi = blockIdx.x * 8 + (lane >> 3);
+    const bool valid = bi < k.nb;
+    const int b = valid ? bi : 0, bx = b % k.bw, by = b / k.bw;
+    const uint8_t *f0 = k.fenc + (size_t)s * k.luma_bytes + (size_t)PAD * k.rs + PAD;
+    const uint8_t *r0 = k.ref + (size_t)s * k.luma_bytes + (size_t)PAD * k.rs + PAD;
+    int mvx = 0, mvy = 0;
+    if (k.mv) { const int16_t *m = k.mv + ((size_t)s * k.nb + b) * 2; mvx = m[0]; mvy = m[1]; }
+    const uint2 e = *(const uint2 *)(f0 + (size_t)(by * 8 + row) * k.rs + bx * 8);
+    uint32_t p[4];
+    mc_row_global(r0, k.plane_bytes, k.rs, bx * 8, by * 8 + row, mvx, mvy, false, p);
+    if (k.wpk) { p[0] = wp4(p[0], k.wpk); p[1] = wp4(p[1], k.wpk); }
+    int h;
+    if (k.satd) { h = satd4_half(e.x, p[0], lane) + satd4_half(e.y, p[1], lane); h = quad_sum(h); h += xor4(h); }
+    else { h = (int)__builtin_amdgcn_sad_u8(p[1], e.y, __builtin_amdgcn_sad_u8(p[0], e.x, 0u)); h = quad_sum(h); h += xor4(h); }
+    const int cost = min(h, k.intra_cost[(size_t)s * k.nb + b]);
+    unsigned long long v = valid && row == 0 ? (unsigned long long)cost : 0ull;
+    for (int o = 32; o; o >>= 1) v += __shfl_xor(v, o);
+    if (lane == 0) atomicAdd(k.out + (size_t)s * 2, v);
+}
+
 // ---- macroblock-tree through B pictures (oracle/slicetype.c x264o_slicetype_propagate / _finish; x264 macroblock_tree_propagate,
 //      mbtree_propagate_cost / _list, macroblock_tree_finish).  Sums saturate at 32767 in x264; every addend is non-negative, so the
 //      accumulators here are plain 32-bit atomics and the saturation is applied where a sum is READ ----
@@ -368,6 +412,8 @@ struct x264gpu_slicetype {
     uint16_t *cost_mv; int32_t *sums; int *progress;
     std::vector<int32_t> h_sums;
     int32_t *prop[ST_MAX_SLOTS]; int16_t *aq[ST_MAX_SLOTS]; bool have_aq[ST_MAX_SLOTS];      // macroblock-tree: propagate costs, AQ offsets (Q8)
+    unsigned long long *d_acc;                                                                // [S][2] accumulators of the weight primitives
+    std::vector<unsigned long long> stats[ST_MAX_SLOTS];                                      // per slot [S][2]: i_pixel_sum, i_pixel_ssd of the luma
 };
 
 extern "C" {
@@ -379,7 +425,7 @@ void x264gpu_slicetype_destroy(x264gpu_slicetype *st)
         (void)hipFree(st->planes[i]); (void)hipFree(st->intra_cost[i]); (void)hipFree(st->lowres_costs[i]); (void)hipFree(st->prop[i]); (void)hipFree(st->aq[i]);
         for (int l = 0; l < 2; l++) for (int d = 0; d <= st->bframes; d++) { (void)hipFree(st->mvs[i][l][d]); (void)hipFree(st->mvcosts[i][l][d]); }
     }
-    (void)hipFree(st->cost_mv); (void)hipFree(st->sums); (void)hipFree(st->progress);
+    (void)hipFree(st->cost_mv); (void)hipFree(st->sums); (void)hipFree(st->progress); (void)hipFree(st->d_acc);
     delete st;
 }
 
@@ -412,6 +458,7 @@ int x264gpu_slicetype_create(x264gpu_slicetype **out, int width, int height, int
         st->cost_est[i].assign(nd * S, -1); st->intra_mbs[i].assign((size_t)(bframes + 2) * S, 0);
     }
     alloc((void **)&st->sums, S * 4 * sizeof(int32_t));
+    alloc((void **)&st->d_acc, S * 2 * sizeof(unsigned long long));
     alloc((void **)&st->progress, S * (size_t)st->bh * sizeof(int));
     alloc((void **)&st->cost_mv, 2 * MVCOST_HALF * sizeof(uint16_t));
     st->h_sums.resize(S * 4);
@@ -461,6 +508,8 @@ int x264gpu_slicetype_put_frame(x264gpu_slicetype *st, int slot, const uint8_t *
         }
     st->intra_calculated[slot] = false;
     st->have_aq[slot] = false;
+    st->stats[slot].clear();
+    HIP_TRY(hipMemsetD32Async((hipDeviceptr_t)st->intra_cost[slot], 0xffff, S * nb, s));          // x264_frame_new: memset( i_intra_cost, -1 )
     HIP_TRY(hipMemsetAsync(st->prop[slot], 0, S * nb * sizeof(int32_t), s));
     std::fill(st->cost_est[slot].begin(), st->cost_est[slot].end(), -1);
     std::fill(st->intra_mbs[slot].begin(), st->intra_mbs[slot].end(), 0);
@@ -470,8 +519,16 @@ int x264gpu_slicetype_put_frame(x264gpu_slicetype *st, int slot, const uint8_t *
 
 // slicetype_frame_cost(p0, p1, b): the slots of the three pictures and the distances d0 = b - p0, d1 = p1 - b; h_score[streams] receives the scores
 // (the call synchronises on the stream when it has to compute)
+int x264gpu_slicetype_frame_cost_w(x264gpu_slicetype *st, int s0, int s1, int sb, int d0, int d1, int on, int scale, int denom, int offset, int32_t *h_score, void *stream);
 int x264gpu_slicetype_frame_cost(x264gpu_slicetype *st, int s0, int s1, int sb, int d0, int d1, int32_t *h_score, void *stream)
 {
+    return x264gpu_slicetype_frame_cost_w(st, s0, s1, sb, d0, d1, 0, 1, 0, 0, h_score, stream);
+}
+// ... with the explicit luma weight x264_weights_analyse( b_lookahead = 1 ) found for a P cost whose search has not run yet: the list-0 search runs on
+// the weighted reference
+int x264gpu_slicetype_frame_cost_w(x264gpu_slicetype *st, int s0, int s1, int sb, int d0, int d1, int on, int scale, int denom, int offset, int32_t *h_score, void *stream)
+{
+    ARG_TRY(!on || (denom >= 0 && denom <= 7 && scale >= -128 && scale <= 127 && offset >= -128 && offset <= 127));
     ARG_TRY(st && h_score && s0 >= 0 && s0 < st->slots && s1 >= 0 && s1 < st->slots && sb >= 0 && sb < st->slots);
     ARG_TRY(d0 >= 0 && d1 >= 0 && d0 <= st->bframes + 1 && d1 <= st->bframes + 1 && !(d1 > 0 && d0 == 0));
     const size_t S = st->streams, nb = st->nb;
@@ -502,6 +559,7 @@ int x264gpu_slicetype_frame_cost(x264gpu_slicetype *st, int s0, int s1, int sb, 
         k.rmv = d1 > 0 && st->searched[s1][0][d0 + d1 - 1] ? st->mvs[s1][0][d0 + d1 - 1] : nullptr;
         k.lowres_costs = st->lowres_costs[sb] + (size_t)(d0 * nd + d1) * S * nb;
         k.ek.ref_luma[0] = st->planes[s0]; k.ek.ref_luma[1] = st->planes[s1];
+        if (on && d1 == 0) { k.ek.wp_any = 1; k.ek.wl0[0] = (int)(uint8_t)(int8_t)offset | (int)(uint8_t)(int8_t)scale << 8 | denom << 16 | 1 << 24; }
         for (int r = 2; r < 8; r++) k.ek.ref_luma[r] = st->planes[s0];
         HIP_TRY(hipMemsetAsync(st->progress, 0, S * (size_t)st->bh * sizeof(int), s));
         const int rows = k.start_y - k.end_y + 1;
@@ -526,6 +584,54 @@ int x264gpu_slicetype_frame_cost(x264gpu_slicetype *st, int s0, int s1, int sb, 
     }
     st->intra_calculated[sb] = true;
     memcpy(h_score, memo, S * sizeof(int32_t));
+    return X264GPU_OK;
+}
+
+// ---- x264_weights_analyse's primitives ----
+// i_pixel_sum / i_pixel_ssd of the luma of the picture last put into `slot` (d_i420: that picture again): h_out[streams][2]
+int x264gpu_slicetype_pixel_stats(x264gpu_slicetype *st, int slot, const uint8_t *d_i420, uint64_t *h_out, void *stream)
+{
+    ARG_TRY(st && d_i420 && h_out && slot >= 0 && slot < st->slots);
+    const size_t S = st->streams;
+    if (st->stats[slot].empty()) {
+        hipStream_t s = (hipStream_t)stream;
+        StWeightK k;
+        memset(&k, 0, sizeof(k));
+        k.w = st->w; k.h = st->h; k.cw = st->bw * 16; k.ch = st->bh * 16; k.i420 = d_i420; k.i420_bytes = (size_t)st->w * st->h * 3 / 2; k.out = st->d_acc;
+        HIP_TRY(hipMemsetAsync(st->d_acc, 0, S * 2 * sizeof(unsigned long long), s));
+        hipLaunchKernelGGL(k_st_pixel_stats, dim3(64, st->streams), dim3(256), 0, s, k);
+        st->stats[slot].resize(S * 2);
+        HIP_TRY(hipMemcpyAsync(st->stats[slot].data(), st->d_acc, S * 2 * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipStreamSynchronize(s));
+        const unsigned long long n = (unsigned long long)k.cw * k.ch;
+        for (size_t i = 0; i < S; i++) { const unsigned long long sum = st->stats[slot][2 * i], sqr = st->stats[slot][2 * i + 1]; st->stats[slot][2 * i + 1] = sqr - (sum * sum + n / 2) / n; }
+    }
+    memcpy(h_out, st->stats[slot].data(), S * 2 * sizeof(uint64_t));
+    return X264GPU_OK;
+}
+// weight_cost_luma of the picture in slot_fenc against the one in slot_ref under the explicit luma weight (on = 0: none); dist > 0: the reference
+// is motion-compensated by the picture's list-0 vectors of that distance when that search has run.  h_cost[streams]
+int x264gpu_slicetype_weight_cost(x264gpu_slicetype *st, int slot_fenc, int slot_ref, int dist, int on, int scale, int denom, int offset, int64_t *h_cost, void *stream)
+{
+    ARG_TRY(st && h_cost && slot_fenc >= 0 && slot_fenc < st->slots && slot_ref >= 0 && slot_ref < st->slots && st->intra_calculated[slot_fenc]);
+    ARG_TRY(!on || (denom >= 0 && denom <= 7 && scale >= -128 && scale <= 127 && offset >= -128 && offset <= 127));
+    hipStream_t s = (hipStream_t)stream;
+    const size_t S = st->streams;
+    StWeightK k;
+    memset(&k, 0, sizeof(k));
+    k.bw = st->bw; k.bh = st->bh; k.nb = st->nb; k.rs = st->ls; k.satd = st->param_subme > 1; k.plane_bytes = st->lplane; k.luma_bytes = st->lpic;
+    k.wpk = on ? ((int)(uint8_t)(int8_t)offset | (int)(uint8_t)(int8_t)scale << 8 | denom << 16 | 1 << 24) : 0;
+    k.fenc = st->planes[slot_fenc]; k.ref = st->planes[slot_ref];
+    k.mv = dist > 0 && dist <= st->bframes + 1 && st->searched[slot_fenc][0][dist - 1] ? st->mvs[slot_fenc][0][dist - 1] : nullptr;
+    k.intra_cost = st->intra_cost[slot_fenc]; k.out = st->d_acc;
+    HIP_TRY(hipMemsetAsync(st->d_acc, 0, S * 2 * sizeof(unsigned long long), s));
+    hipLaunchKernelGGL(k_st_weight_cost, dim3((st->nb + 7) / 8, st->streams), dim3(64), 0, s, k);
+    std::vector<unsigned long long> v(S * 2);
+    HIP_TRY(hipMemcpyAsync(v.data(), st->d_acc, S * 2 * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    auto size_ue = [](int x) { int n = 0; x++; while (x >> (n + 1)) n++; return 2 * n + 1; };
+    const int hdr = on ? st->lambda * (10 + size_ue(denom) * 2 + 2 * (size_ue(scale > 0 ? 2 * scale - 1 : -2 * scale) + size_ue(offset > 0 ? 2 * offset - 1 : -2 * offset))) : 0;
+    for (size_t i = 0; i < S; i++) h_cost[i] = (int64_t)v[2 * i] + hdr;
     return X264GPU_OK;
 }
 

@@ -128,6 +128,9 @@ _SIGS = {
     "x264gpu_slicetype_lowres_mv_costs": (_vp, [_vp, _i, _i, _i]),
     "x264gpu_slicetype_intra_costs": (_vp, [_vp, _i]),
     "x264gpu_slicetype_lowres_costs": (_vp, [_vp, _i, _i, _i]),
+    "x264gpu_slicetype_frame_cost_w": (_i, [_vp] + [_i] * 9 + [_vp, _vp]),
+    "x264gpu_slicetype_pixel_stats": (_i, [_vp, _i, _vp, _vp, _vp]),
+    "x264gpu_slicetype_weight_cost": (_i, [_vp, _i, _i, _i, _i, _i, _i, _i, _vp, _vp]),
     "x264gpu_slicetype_set_aq": (_i, [_vp, _i, _vp, _vp]),
     "x264gpu_slicetype_clear_propagate": (_i, [_vp, _i, _vp]),
     "x264gpu_slicetype_propagate": (_i, [_vp, _i, _i, _i, _i, _i, _i, _vp]),
