@@ -1208,9 +1208,11 @@ bool decode_nal(Decoder &d, const uint8_t *nal, size_t n)
             for (int i = 0; i < d.nref_active; i++) {
                 d.wp[i].lw = 1 << d.luma_logwd; d.wp[i].lo = 0;
                 d.wp[i].cw[0] = d.wp[i].cw[1] = 1 << d.chroma_logwd; d.wp[i].co[0] = d.wp[i].co[1] = 0;
-                if (br.get1()) { d.wp[i].lw = br.se(); d.wp[i].lo = br.se(); }
+                if (br.get1()) {
+                    d.wp[i].lw = br.se(); d.wp[i].lo = br.se();
+                    if (d.wp[i].lw < -128 || d.wp[i].lw > 127 || d.wp[i].lo < -128 || d.wp[i].lo > 127) return reject(__LINE__);      // (an inferred weight is 2^logWD: up to 128)
+                }
                 if (br.get1()) for (int c = 0; c < 2; c++) { d.wp[i].cw[c] = br.se(); d.wp[i].co[c] = br.se(); }
-                if (d.wp[i].lw < -128 || d.wp[i].lw > 127 || d.wp[i].lo < -128 || d.wp[i].lo > 127) return reject(__LINE__);
             }
         }
         if (nal_ref_idc) {

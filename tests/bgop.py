@@ -12,7 +12,7 @@ from x264vfw_amd.lib import Pic
 from x264vfw_amd.gop import HostDpb, follow_of, schedule  # noqa: E402,F401
 
 
-def encode_gop(HL, enc, frames, types, cfg, qp_i, qp_p, qp_b, refs, bframes=3, pyramid=1, weightp=0, pics_out=None):
+def encode_gop(HL, enc, frames, types, cfg, qp_i, qp_p, qp_b, refs, bframes=3, pyramid=1, weightp=0, pics_out=None, weights=None):
     """encodes `frames` (display order) with picture types `types` through `enc` (anything with encode_pic(i420, pic) -> mbs, lv and recon());
     returns (annex-B stream, [recon per coding position], coding order, pocs)"""
     w, h = cfg.width, cfg.height
@@ -23,7 +23,7 @@ def encode_gop(HL, enc, frames, types, cfg, qp_i, qp_p, qp_b, refs, bframes=3, p
     recons, pocs = [], []
     idr_id = 0
     for k, (disp, pt) in enumerate(order):
-        pic, info = dpb.plan(pt, disp, follow_of(order, k))
+        pic, info = dpb.plan(pt, disp, follow_of(order, k), weight=(weights or {}).get(disp) if pt == 2 else None)
         pic.qp = qp_i if pt <= 1 else qp_p if pt == 2 else qp_b if pt == 4 else (qp_p + qp_b) // 2
         mbs, lv = enc.encode_pic(frames[disp], pic)
         if pics_out is not None:

@@ -24,7 +24,16 @@ def main():
     H = HL.H
     scene_len = int(opts.pop("scene_len", 0) or 0)
     static = int(opts.pop("static", 0) or 0)
+    fade = int(opts.pop("fade", 0) or 0)
     frames = synth_frames(w, h, n, seed=seed, **({"scene_len": scene_len} if scene_len else {}))
+    if fade:            # fades to black by `fade` per cent a picture (tests/test_bframes_cpu.py fade_frames)
+        import numpy as np
+        for i, f in enumerate(frames):
+            a = max(0.0, 1.0 - i * fade / 100.0)
+            g = f.astype(np.float32)
+            g[:w * h] *= a
+            g[w * h:] = 128 + (g[w * h:] - 128) * a
+            frames[i] = np.clip(np.rint(g), 0, 255).astype(np.uint8)
     if static:          # the first picture again and again, with a little noise
         import numpy as np
         rng = np.random.default_rng(seed)

@@ -117,6 +117,24 @@ const int16_t *x264gpu_slicetype_lowres_mvs(x264gpu_slicetype *s, int slot, int 
 const int *x264gpu_slicetype_lowres_mv_costs(x264gpu_slicetype *s, int slot, int list, int dist) { return x264o_slicetype_mv_costs(s->st, slot, list, dist); }
 const int *x264gpu_slicetype_intra_costs(x264gpu_slicetype *s, int slot) { return x264o_slicetype_intra_costs(s->st, slot); }
 const uint16_t *x264gpu_slicetype_lowres_costs(x264gpu_slicetype *s, int slot, int d0, int d1) { return x264o_slicetype_lowres_costs(s->st, slot, d0, d1); }
+int x264o_slicetype_frame_cost_w(x264o_slicetype *st, int s0, int s1, int sb, int d0, int d1, int on, int scale, int denom, int offset);
+void x264o_slicetype_pixel_stats(x264o_slicetype *st, int slot, const uint8_t *i420, uint64_t out[2]);
+long x264o_slicetype_weight_cost(x264o_slicetype *st, int sf, int sr, int dist, int on, int scale, int denom, int offset);
+int x264gpu_slicetype_frame_cost_w(x264gpu_slicetype *s, int s0, int s1, int sb, int d0, int d1, int on, int scale, int denom, int offset, int32_t *h_score, void *stream)
+{
+    const int c = x264o_slicetype_frame_cost_w(s->st, s0, s1, sb, d0, d1, on, scale, denom, offset);
+    if (c < 0) return fail("slicetype triple");
+    h_score[0] = c;
+    return X264GPU_OK;
+}
+int x264gpu_slicetype_pixel_stats(x264gpu_slicetype *s, int slot, const uint8_t *i420, uint64_t *out, void *stream) { x264o_slicetype_pixel_stats(s->st, slot, i420, out); return X264GPU_OK; }
+int x264gpu_slicetype_weight_cost(x264gpu_slicetype *s, int sf, int sr, int dist, int on, int scale, int denom, int offset, int64_t *h_cost, void *stream)
+{
+    const long c = x264o_slicetype_weight_cost(s->st, sf, sr, dist, on, scale, denom, offset);
+    if (c < 0) return fail("weight cost: no intra costs");
+    h_cost[0] = c;
+    return X264GPU_OK;
+}
 void x264o_slicetype_set_aq(x264o_slicetype *st, int slot, const int16_t *aq_q8);
 void x264o_slicetype_clear_propagate(x264o_slicetype *st, int slot);
 int x264o_slicetype_propagate(x264o_slicetype *st, int s0, int s1, int sb, int d0, int d1, int referenced);

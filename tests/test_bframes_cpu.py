@@ -15,12 +15,12 @@ MEDIUM = dict(refs=3, dpb=4, weightb=1, partitions=7, dct8x8=1, chroma_me=1, mix
               chroma_qp_offset=-2, trellis=63)
 
 
-def run(w, h, types, seed, bframes=3, pyramid=1, weightp=0, pics_out=None, **over):
+def run(w, h, types, seed, bframes=3, pyramid=1, weightp=0, pics_out=None, weights=None, frames=None, **over):
     kw = dict(MEDIUM, **over)
-    frames = synth_frames(w, h, len(types), seed=seed)
+    frames = frames if frames is not None else synth_frames(w, h, len(types), seed=seed)
     cfg = O.default_config(w, h, **kw)
     enc = O.OracleEncoder(cfg)
-    stream, recons, order, pocs = bgop.encode_gop(HL, enc, frames, types, cfg, 20, 23, 25, kw["refs"], bframes, pyramid, weightp, pics_out)
+    stream, recons, order, pocs = bgop.encode_gop(HL, enc, frames, types, cfg, 20, 23, 25, kw["refs"], bframes, pyramid, weightp, pics_out, weights)
     dec = O.h264_decode(stream, len(order), w, h)
     assert len(dec) == len(order)
     assert O.h264_last_pocs() == pocs
@@ -246,3 +246,53 @@ def test_cross_session_batcher_is_byte_identical(n, opts):
     picture); every session's stream equals the one it writes on its own (driverproc.c:110-128: one CODEC per stream)"""
     r = _batch(n, 176, 144, 11, opts)
     assert r["equal"] == [True] * n and r["distinct"] == n, r
+
+
+def fade_frames(w, h, n, seed, step=6):
+    fr = synth_frames(w, h, n, seed=seed)
+    out = []
+    for i, f in enumerate(fr):
+        a = max(0.0, 1.0 - i * step / 100.0)
+        g = f.astype(np.float32)
+        g[:w * h] *= a
+        g[w * h:] = 128 + (g[w * h:] - 128) * a
+        out.append(np.clip(np.rint(g), 0, 255).astype(np.uint8))
+    return out
+
+
+@pytest.mark.parametrize("types,weights,weightp,over", [
+    ("IPPPP", {1: (60, 6, 0), 2: (59, 6, 1), 3: (15, 4, -2), 4: (1, 0, -3)}, 2, {}),              # weighted reference 0 + both duplicates
+    ("IBBPBBP", {3: (53, 6, 1), 6: (111, 7, 0)}, 2, {}),
+    ("IPPP", {1: (60, 6, 0), 2: (59, 6, 1), 3: (29, 5, 2)}, 1, {}),                               # --weightp 1: the weight alone
+    ("IPPP", {1: (1, 0, -128), 2: (60, 6, 0)}, 2, dict(refs=1)),                                  # offset -128 has no duplicate one step down; one reference: no duplicates at all
+])
+def test_explicit_luma_weights_of_reference_0(types, weights, weightp, over):
+    """the weights x264_weights_analyse gives a P picture of a fade: reference 0 carries {scale, denom, offset}; under --weightp 2 its duplicate one
+    offset step down and an unweighted duplicate follow (x264 weighted_reference_duplicate twice); pred_weight_table with a non-zero denominator,
+    explicit weighted prediction in the checker decoder, the loop filter seeing one picture behind three indices"""
+    w, h = 176, 144
+    pics = []
+    run(w, h, types, 3, weightp=weightp, pics_out=pics, weights=weights, frames=fade_frames(w, h, len(types), 3), **over)
+    seen = 0
+    for pic, mbs in pics:
+        if pic.wl0[0].on:
+            seen += 1
+            n0 = pic.nref[0]
+            if weightp == 2 and n0 >= 3:
+                assert pic.slot[0][0] == pic.slot[0][1] == pic.slot[0][2] or pic.wl0[0].offset == -128
+    assert seen == len(weights)
+
+
+def test_host_session_finds_the_weights_of_a_fade(tmp_path):
+    """a clip that fades to black through x264_encoder_encode with medium's lookahead: x264_weights_analyse restated on the lookahead's primitives
+    gives the P pictures luma weights (the stream shrinks against --weightp 0 and decodes to the source)"""
+    n, w, h = 14, 176, 144
+    info, stream = _host_b_session(tmp_path, n, ["qp=23", "keyint=60", "fade=6"], w, h, seed=3)
+    assert info["weightp"] == 2
+    info0, stream0 = _host_b_session(tmp_path, n, ["qp=23", "keyint=60", "fade=6", "weightp=0"], w, h, seed=3)
+    assert len(stream) < 0.97 * len(stream0), (len(stream), len(stream0))
+    dec = O.h264_decode(stream, n, w, h)
+    frames = fade_frames(w, h, n, 3)
+    from synth import psnr
+    for d, r in zip(dec, info["recs"]):
+        assert psnr(d[:w * h], frames[r[1]][:w * h]) > 33.0

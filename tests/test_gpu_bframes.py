@@ -21,11 +21,11 @@ def describe(mbs_g, mbs_o, i):
     return f"\n gpu {f(mbs_g)}\n cpu {f(mbs_o)}"
 
 
-def run(gpu, w, h, types, seed, streams=1, bframes=3, pyramid=1, weightp=0, **over):
+def run(gpu, w, h, types, seed, streams=1, bframes=3, pyramid=1, weightp=0, weights=None, frames=None, **over):
     from gpu_enc import GpuEncoder
     from x264vfw_amd import host_api as HL
     kw = dict(MEDIUM, **over)
-    frames = synth_frames(w, h, len(types), seed=seed)
+    frames = frames if frames is not None else synth_frames(w, h, len(types), seed=seed)
     cfg = O.default_config(w, h, **kw)
     og, gg = O.OracleEncoder(cfg), GpuEncoder(O.default_config(w, h, streams=streams, **kw))
     dpb = bgop.HostDpb(HL, kw["refs"], bframes, pyramid, weightp=weightp)
@@ -35,7 +35,7 @@ def run(gpu, w, h, types, seed, streams=1, bframes=3, pyramid=1, weightp=0, **ov
     mbw, mbh = (w + 15) // 16, (h + 15) // 16
     recons = []
     for k, (disp, pt) in enumerate(order):
-        pic, _ = dpb.plan(pt, disp, bgop.follow_of(order, k))
+        pic, _ = dpb.plan(pt, disp, bgop.follow_of(order, k), weight=(weights or {}).get(disp) if pt == 2 else None)
         pic.qp = 20 if pt <= 1 else 23 if pt == 2 else 25 if pt == 4 else 24
         o_mb, o_lv = og.encode_pic(frames[disp], pic)
         g_mb, g_lv = gg.encode_pics([frames[disp]] * streams, [pic] * streams)
@@ -95,6 +95,20 @@ def test_headline_size_b_pictures_and_weightp_bitexact(gpu):
     references and carries the --weightp 2 duplicate) — records, levels, reconstruction and context variables against the CPU checker, and the
     device's stream through the checker decoder"""
     assert run(gpu, 1920, 1080, "IBBBPP", 21, weightp=2) > 0
+
+
+@pytest.mark.parametrize("types,weights,weightp,over", [
+    ("IPPPP", {1: (60, 6, 0), 2: (59, 6, 1), 3: (15, 4, -2), 4: (1, 0, -3)}, 2, {}),              # weighted reference 0 + both duplicates (three indices, one picture)
+    ("IBBPBBP", {3: (53, 6, 1), 6: (111, 7, 0)}, 2, {}),
+    ("IPPP", {1: (60, 6, 0), 2: (59, 6, 1), 3: (29, 5, 2)}, 1, {}),                               # --weightp 1: the weight alone
+    ("IPPP", {1: (1, 0, -128), 2: (60, 6, 0)}, 2, dict(refs=1)),
+    ("IPPPP", {1: (60, 6, 0), 2: (59, 6, 1), 3: (58, 6, 0), 4: (57, 6, 1)}, 2, dict(refs=5, dpb=5, me_method=2)),      # seven list entries, umh
+])
+def test_explicit_luma_weights_bitexact_and_decodable(gpu, types, weights, weightp, over):
+    """a fade with the weights x264_weights_analyse would hand the P pictures: weighted reference 0 in the skip probe, every search and every
+    prediction, its two duplicates (x264 weighted_reference_duplicate twice), the reference cache and the loop filter seeing one picture behind three indices"""
+    from test_bframes_cpu import fade_frames
+    run(gpu, 176, 144, types, 3, weightp=weightp, weights=weights, frames=fade_frames(176, 144, len(types), 3), **over)
 
 
 def test_b_pictures_multistream(gpu):

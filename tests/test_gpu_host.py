@@ -819,3 +819,22 @@ def test_cross_session_batcher_on_the_device(gpu):
     from test_bframes_cpu import _batch
     r = _batch(16, 176, 144, 9, ["qp=23", "keyint=30", "scenecut=0", "b-adapt=0", "bframes=3"], gpu=True)
     assert r["equal"] == [True] * 16 and r["distinct"] == 16, r
+
+
+def test_fade_session_gets_luma_weights_on_the_device(gpu):
+    """a fade through x264_encoder_encode with medium's lookahead on the device: x264_weights_analyse's restatement (host) on the device's
+    statistics and weight costs gives the P pictures luma weights; the stream is smaller than with --weightp 0 and decodes to the source"""
+    from test_bframes_cpu import fade_frames
+    w, h, n = 176, 144, 14
+    frames = fade_frames(w, h, n, 3)
+    out = {}
+    for wp in (2, 0):
+        h_, eff = open_encoder(w, h, {"qp": 23, "keyint": 60, "bframes": 3, "weightp": wp}, profile=None)
+        assert eff.analyse.i_weighted_pred == wp
+        stream, recs = encode_delayed(h_, w, h, frames)
+        H.x264_encoder_close(h_)
+        out[wp] = (stream, recs)
+    assert len(out[2][0]) < 0.97 * len(out[0][0]), (len(out[2][0]), len(out[0][0]))
+    dec = O.h264_decode(out[2][0], n, w, h)
+    for d, r in zip(dec, out[2][1]):
+        assert psnr(d[:w * h], frames[r[2]][:w * h]) > 33.0

@@ -32,6 +32,7 @@ struct EncK {
     // (8.4.2.3.2; applied AFTER the quarter-pel interpolation, as mc.get_ref / mc_luma do) and the index of x264's blind duplicate of reference 0
     // (h->mb.ref_blind_dupe; 0 = none): the same picture as index 0, refined from index 0's vector instead of searched
     int wl0[8], blind_dupe, wp_any;
+    int refpic[8];                           // the picture behind list-0 index r as an index without duplicates (order of first appearance): reference cache tags, loop filter
     uint8_t biw[5][4];                       // B: implicit bi-prediction weight of the list-0 sample for (list-0 index, list-1 index), of 64 (x264 bipred_weight)
     const int8_t *colref; const int16_t *colmv;    // B: per 8x8 block of the first picture of list 1, the reference index it used (-1 intra) and that vector
     int8_t *colref_cur; int16_t *colmv_cur;  // the same of the picture being coded, for the B pictures that will have it at the head of their list 1
@@ -104,7 +105,7 @@ __device__ __forceinline__ uint32_t wp4(uint32_t p, int wpk)
     return (uint32_t)v[0] | ((uint32_t)v[1] << 8) | ((uint32_t)v[2] << 16) | ((uint32_t)v[3] << 24);
 }
 // the picture behind list-0 index r of a P slice, as an index without duplicates (reference cache tags, loop filter): the duplicate is picture 0
-__device__ __forceinline__ int ref_picture(const EncK &k, int r) { return k.blind_dupe > 0 && r >= k.blind_dupe ? (r == k.blind_dupe ? 0 : r - 1) : r; }
+__device__ __forceinline__ int ref_picture(const EncK &k, int r) { return k.refpic[r]; }
 __device__ __forceinline__ const uint8_t *ref_chroma00(const EncK &k, int s, int r)
 {
     return k.ref_chroma[r] + (size_t)s * k.cplane_bytes + (size_t)CPAD * k.rs + 2 * CPAD;

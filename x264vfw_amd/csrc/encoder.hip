@@ -346,7 +346,7 @@ static int encode_core(x264gpu_encoder *e, const uint8_t *d_i420, const x264gpu_
     k.nref = n0; k.nref1 = n1;
     // --weightp: explicit luma weights of a P picture's list 0 and x264's blind duplicate of reference 0
     k.blind_dupe = 0; k.wp_any = 0;
-    for (int r = 0; r < 8; r++) k.wl0[r] = 0;
+    for (int r = 0; r < 8; r++) { k.wl0[r] = 0; k.refpic[r] = r; }
     if (slice_type == X264GPU_SLICE_P) {
         for (int r = 0; r < n0; r++)
             if (pic.wl0[r].on) {
@@ -357,6 +357,14 @@ static int encode_core(x264gpu_encoder *e, const uint8_t *d_i420, const x264gpu_
         if (pic.blind_dupe > 0) {
             ARG_TRY(pic.blind_dupe == 1 && n0 >= 2 && pic.slot[0][1] == pic.slot[0][0]);      // x264 places it right behind reference 0
             k.blind_dupe = 1; k.wp_any = 1;
+        }
+        // duplicates (x264 places them right behind reference 0: the offset - 1 copy, and under a weighted reference 0 its unweighted copy)
+        int npics = 0;
+        for (int r = 0; r < n0; r++) {
+            int first = r;
+            for (int q = 0; q < r; q++) if (pic.slot[0][q] == pic.slot[0][r]) { first = q; break; }
+            k.refpic[r] = first == r ? npics++ : k.refpic[first];
+            if (first != r) k.wp_any = 1;
         }
     }
     auto slot_of = [&](int ri) { return (int)(ri < n0 ? pic.slot[0][ri] : pic.slot[1][ri - n0]); };      // combined index: list 0, then list 1

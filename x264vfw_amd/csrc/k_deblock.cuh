@@ -36,8 +36,8 @@ constexpr int WF_MAX_ROWS = 160;               // macroblock rows supported by t
 __device__ __forceinline__ bool mb_is_intra(int type) { return type == X264GPU_MB_I4x4 || type == X264GPU_MB_I8x8 || type == X264GPU_MB_I16x16; }
 
 // boundary strength between 4x4 block (pbx,pby) of P and (qbx,qby) of Q (oracle edge_bs)
-// dupe: list-0 index of the --weightp duplicate of reference 0 in this (P) picture, 0 = none — the filter compares reference PICTURES
-__device__ __forceinline__ int edge_bs(const x264gpu_mb *P, int pbx, int pby, const x264gpu_mb *Q, int qbx, int qby, bool mb_edge, int dupe)
+// k.refpic: P pictures under --weightp may hold a picture at several list-0 indices — the filter compares reference PICTURES
+__device__ __forceinline__ int edge_bs(const x264gpu_mb *P, int pbx, int pby, const x264gpu_mb *Q, int qbx, int qby, bool mb_edge, const EncK &k)
 {
     if (mb_is_intra(P->type) || mb_is_intra(Q->type)) return mb_edge ? 4 : 3;
     // transform8x8: "the 8x8 block containing the sample" has coefficients (8.7.2.1) = its cbp_luma bit
@@ -49,7 +49,7 @@ __device__ __forceinline__ int edge_bs(const x264gpu_mb *P, int pbx, int pby, co
     const int pi = (pby >> 1) * 2 + (pbx >> 1), qi = (qby >> 1) * 2 + (qbx >> 1);
     {
         int rp = P->ref[pi], rq = Q->ref[qi];
-        if (dupe) { rp = rp == dupe ? 0 : rp; rq = rq == dupe ? 0 : rq; }
+        if (k.wp_any) { rp = rp >= 0 ? k.refpic[rp & 7] : rp; rq = rq >= 0 ? k.refpic[rq & 7] : rq; }
         if (rp != rq) return 1;
     }
     if (abs(P->mv[pi][0] - Q->mv[qi][0]) >= 4 || abs(P->mv[pi][1] - Q->mv[qi][1]) >= 4) return 1;
@@ -164,7 +164,7 @@ __device__ void deblock_mb_pair(const EncK &k, Deblock2Lds &L, int wave, int lan
             const x264gpu_mb *P = edge == 0 ? &L.rec[wave][hf][dir == 0 ? 1 : 2] : Q;
             const int qbx = dir == 0 ? edge : seg, qby = dir == 0 ? seg : edge;
             const int pbx = dir == 0 ? (edge + 3) & 3 : seg, pby = dir == 0 ? seg : (edge + 3) & 3;
-            any = edge_bs(P, pbx, pby, Q, qbx, qby, edge == 0, k.blind_dupe) != 0;
+            any = edge_bs(P, pbx, pby, Q, qbx, qby, edge == 0, k) != 0;
         }
         const unsigned long long b = __ballot(any);
         work = hf ? (b >> 32) != 0 : (b & 0xffffffffull) != 0;
@@ -188,7 +188,7 @@ __device__ void deblock_mb_pair(const EncK &k, Deblock2Lds &L, int wave, int lan
                     const int seg = l32 >> 2;
                     const int qbx = dir == 0 ? edge : seg, qby = dir == 0 ? seg : edge;
                     const int pbx = dir == 0 ? (edge + 3) & 3 : seg, pby = dir == 0 ? seg : (edge + 3) & 3;
-                    const int bs = edge_bs(P, pbx, pby, Q, qbx, qby, edge == 0, k.blind_dupe);
+                    const int bs = edge_bs(P, pbx, pby, Q, qbx, qby, edge == 0, k);
                     if (bs) {
                         const int tc0 = bs < 4 ? L.tc0[ia][bs - 1] : 0;
                         uint8_t *pix = dir == 0 ? lt + l32 * DL_STRIDE + edge * 4 : lt + edge * 4 * DL_STRIDE + l32;
@@ -198,7 +198,7 @@ __device__ void deblock_mb_pair(const EncK &k, Deblock2Lds &L, int wave, int lan
                     const int t = l32 - 16;            // vertical edge: chroma row 0..7 (U and V); horizontal: byte column 0..15
                     if (dir == 0 && t < 8) {
                         const int seg = t >> 1;
-                        const int bs = edge_bs(P, (edge + 3) & 3, seg, Q, edge, seg, edge == 0, k.blind_dupe);
+                        const int bs = edge_bs(P, (edge + 3) & 3, seg, Q, edge, seg, edge == 0, k);
                         if (bs) {
                             const int tc0 = bs < 4 ? L.tc0[ica][bs - 1] : 0;
                             uint8_t *pix = ct + t * DC_STRIDE + edge * 4;
@@ -207,7 +207,7 @@ __device__ void deblock_mb_pair(const EncK &k, Deblock2Lds &L, int wave, int lan
                         }
                     } else if (dir == 1) {
                         const int seg = t >> 2;
-                        const int bs = edge_bs(P, seg, (edge + 3) & 3, Q, seg, edge, edge == 0, k.blind_dupe);
+                        const int bs = edge_bs(P, seg, (edge + 3) & 3, Q, seg, edge, edge == 0, k);
                         if (bs) {
                             const int tc0 = bs < 4 ? L.tc0[ica][bs - 1] : 0;
                             uint8_t *pix = ct + (edge * 2) * DC_STRIDE + t;

@@ -209,7 +209,8 @@ __device__ __forceinline__ void me_search(const EncK &k, MbLds<M> &L, const MbCt
     const int wpk = k.wp_any ? uni(k.wl0[j.ref]) : 0;
     const bool wt = (wpk >> 24) != 0;
     const int cref = k.wp_any ? ref_picture(k, j.ref) : j.ref;
-#define WP4X4(p) do { if (wt) { p[0] = wp4(p[0], wpk); p[1] = wp4(p[1], wpk); p[2] = wp4(p[2], wpk); p[3] = wp4(p[3], wpk); } } while (0)
+    // (the upper half of an 8-pixel row's registers stays zero: weighting it would turn it into the offset and into cost)
+#define WP4X4(p) do { if (wt) { p[0] = wp4(p[0], wpk); p[1] = wp4(p[1], wpk); if (w16) { p[2] = wp4(p[2], wpk); p[3] = wp4(p[3], wpk); } } } while (0)
     uint32_t e[4] = { 0, 0, 0, 0 };
     if (rowok) {
         const uint8_t *f = L.src + (j.oy + r) * 16 + j.ox;
@@ -394,10 +395,10 @@ __device__ __forceinline__ void me_search(const EncK &k, MbLds<M> &L, const MbCt
                 uint32_t p[4];
                 row16_lds(wrow, xo, p);
                 WP4X4(p);
-                const uint4 sv = *(const uint4 *)f;
-                unsigned s2 = __builtin_amdgcn_sad_u8(p[0], sv.x, 0u);
-                s2 = __builtin_amdgcn_sad_u8(p[1], sv.y, s2);
-                if (w16) { s2 = __builtin_amdgcn_sad_u8(p[2], sv.z, s2); s2 = __builtin_amdgcn_sad_u8(p[3], sv.w, s2); }
+                const uint2 sa = *(const uint2 *)f;                 // (an 8-pixel row at column 8 is only 8-byte aligned)
+                unsigned s2 = __builtin_amdgcn_sad_u8(p[0], sa.x, 0u);
+                s2 = __builtin_amdgcn_sad_u8(p[1], sa.y, s2);
+                if (w16) { const uint2 sb = *(const uint2 *)(f + 8); s2 = __builtin_amdgcn_sad_u8(p[2], sb.x, s2); s2 = __builtin_amdgcn_sad_u8(p[3], sb.y, s2); }
                 sd = (int)s2;
             } else
             if (w16) { const uint4 sv = *(const uint4 *)f; const uint32_t e8[4] = { sv.x, sv.y, sv.z, sv.w }; sd = sad_row16_lds(wrow, xo, e8); }

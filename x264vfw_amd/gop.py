@@ -44,13 +44,18 @@ class HostDpb:
         while (1 << self.log2_max_poc_lsb) <= d * 2:
             self.log2_max_poc_lsb += 1
 
-    def plan(self, ptype, frame, follow=()):
-        """follow: (coding index, display index) of the non-reference pictures coded right after this one"""
+    def plan(self, ptype, frame, follow=(), weight=None):
+        """follow: (coding index, display index) of the non-reference pictures coded right after this one; weight: (scale, denom, offset) of
+        reference 0 of a P picture (x264_weights_analyse's result), or None"""
         pic = Pic()
         info = (C.c_int * 8)()
         fc = (C.c_int * max(1, len(follow)))(*[c for c, _ in follow])
         ff = (C.c_int * max(1, len(follow)))(*[f for _, f in follow])
-        self.H.x264host_dpb_plan(self.h, ptype, frame, len(follow), fc, ff, C.byref(pic), info)
+        if weight is not None:
+            wv = (C.c_int * 3)(*weight)
+            self.H.x264host_dpb_plan_w(self.h, ptype, frame, len(follow), fc, ff, wv, C.byref(pic), info)
+        else:
+            self.H.x264host_dpb_plan(self.h, ptype, frame, len(follow), fc, ff, C.byref(pic), info)
         return pic, list(info)
 
     def commit(self):

@@ -9,7 +9,9 @@
 //     allows removes pictures from the END of list 0 by MMCO (x264: i_mmco_remove_from_end) so the delayed b's find room;
 //   * --weightp 2: every P picture with at least two references gets a DUPLICATE of reference 0 at index 1 carrying the luma weight
 //     {scale 1, denom 0, offset -1} (x264 weighted_reference_duplicate, h->mb.ref_blind_dupe): the list grows by one, the whole list is sent as
-//     modifications (the duplicate is a picture-number difference of 0, coded as abs_diff_pic_num_minus1 = MaxFrameNum - 1).
+//     modifications (the duplicate is a picture-number difference of 0, coded as abs_diff_pic_num_minus1 = MaxFrameNum - 1);
+//   * --weightp 1 / 2 with a luma weight from x264_weights_analyse (fades): reference 0 carries it; under --weightp 2 an UNWEIGHTED duplicate
+//     and (offset > -128) a duplicate with the same scale and offset - 1 follow it: [w ref0, w(offset - 1) dupe, unweighted dupe, ref1, ..].
 #pragma once
 #include "host.hpp"
 #include <stdlib.h>
@@ -57,7 +59,8 @@ public:
 
     // Plans the picture `frame` (display index) of type `type`.  follow_coded / follow_frame: coding index and display index of the disposable
     // pictures that follow it immediately in coding order (x264 reads them from h->frames.current); coded = this picture's coding index.
-    const DpbPlan &plan(int type, int frame, int n_follow = 0, const int *follow_coded = nullptr, const int *follow_frame = nullptr)
+    struct LumaWeight { int on = 0, scale = 1, denom = 0, offset = 0; };
+    const DpbPlan &plan(int type, int frame, int n_follow = 0, const int *follow_coded = nullptr, const int *follow_frame = nullptr, const LumaWeight *w0 = nullptr)
     {
         DpbPlan &p = last;
         p = DpbPlan();
@@ -101,7 +104,21 @@ public:
         if ((int)l[0].size() > max_ref0) l[0].resize((size_t)max_ref0);
         if (type == PIC_P) l[1].clear();
         p.pic.blind_dupe = -1;
-        if (type == PIC_P && weightp == 2 && l[0].size() > 1) {       // the blind duplicate of reference 0
+        if (type == PIC_P && weightp && w0 && w0->on && !l[0].empty()) {
+            // x264_reference_build_list with fenc->weight[0][0] set: a pure offset is sent with denominator 0
+            LumaWeight w = *w0;
+            if (w.scale == 1 << w.denom) { w.scale = 1; w.denom = 0; }
+            p.pic.wl0[0].on = 1; p.pic.wl0[0].denom = (int8_t)w.denom; p.pic.wl0[0].scale = (int16_t)w.scale; p.pic.wl0[0].offset = (int16_t)w.offset;
+            if (weightp == 2 && l[0].size() > 1) {
+                l[0].insert(l[0].begin() + 1, l[0][0]);             // the unweighted duplicate
+                reorder[0] = true;
+                if (w.offset > -128) {                              // ... and in front of it the duplicate one offset step down
+                    l[0].insert(l[0].begin() + 1, l[0][0]);
+                    p.pic.blind_dupe = 1;
+                    p.pic.wl0[1] = p.pic.wl0[0]; p.pic.wl0[1].offset = (int16_t)(w.offset - 1);
+                }
+            }
+        } else if (type == PIC_P && weightp == 2 && l[0].size() > 1) {       // the blind duplicate of reference 0
             l[0].insert(l[0].begin() + 1, l[0][0]);
             reorder[0] = true;
             p.pic.blind_dupe = 1;

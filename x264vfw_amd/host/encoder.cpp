@@ -123,7 +123,8 @@ struct x264_t {
     bool dpbmode = false; int weightp = 0;
     Dpb dpb;
     struct BEntry { int64_t pts; int frame; int slot; int forced; int scenecut; int32_t costs[4]; x264_image_t img;      // forced: 0 auto, 1 I, 2 IDR
-                    int type = 0; int b_scenecut = 1; };      // slicetype analysis: the type decided so far (ST_*), "may still be a real scene cut"
+                    int type = 0; int b_scenecut = 1;         // slicetype analysis: the type decided so far (ST_*), "may still be a real scene cut"
+                    Dpb::LumaWeight w; };                     // x264_weights_analyse's luma weight of reference 0 when the picture is coded as P (--weightp)
     // x264's lookahead in its own structure (x264_slicetype_analyse: scenecut against the last non-B picture with flash detection, --b-adapt 1)
     // on the device's frame costs of arbitrary (p0, p1, b) triples; the half-resolution planes of a queued picture live in the slicetype object's
     // slot of the same number as its raw picture
@@ -431,7 +432,7 @@ x264_t *x264_encoder_open(x264_param_t *param)
     } else { p.i_bframe_pyramid = 0; p.analyse.b_weighted_bipred = 0; }
     h->bframes = p.i_bframe; h->bpyramid = p.i_bframe_pyramid ? 1 : 0;
     if (p.i_keyint_max <= 0) p.i_keyint_max = 1;
-    if (p.analyse.i_weighted_pred == X264_WEIGHTP_SIMPLE) { xlog(&p, X264_LOG_INFO, "weightp 1 is fade analysis only, which is not implemented in the MI355X path: weightp 0\n"); p.analyse.i_weighted_pred = X264_WEIGHTP_NONE; }
+    if (p.analyse.i_weighted_pred == X264_WEIGHTP_SIMPLE && !h->bframes) { xlog(&p, X264_LOG_INFO, "weightp 1 (weights for fades, no duplicate references) runs in sessions with B pictures only: weightp 0\n"); p.analyse.i_weighted_pred = X264_WEIGHTP_NONE; }
     if (p.analyse.i_weighted_pred == X264_WEIGHTP_SMART && !h->bframes) {
         // without B pictures the session can still run on the DPB model, if nothing of the other path is asked for
         const bool tree = p.rc.b_mb_tree && p.rc.i_rc_method != X264_RC_CQP && p.rc.i_lookahead > 0;
@@ -454,7 +455,7 @@ x264_t *x264_encoder_open(x264_param_t *param)
         }
     }
     if (h->dpbmode && !h->bframes) { p.rc.b_mb_tree = 0; }
-    if (h->weightp == X264_WEIGHTP_SMART) xlog(&p, X264_LOG_INFO, "weightp 2: the duplicate of reference 0 with luma offset -1 on every P picture (x264's fade analysis is not run)\n");
+    if (h->weightp) xlog(&p, X264_LOG_INFO, "weightp %d: luma weights for fades from the lookahead (chroma planes are not weighted)%s\n", h->weightp, h->weightp == X264_WEIGHTP_SMART ? ", duplicates of reference 0 on every P picture" : "");
     h->keyint = p.i_keyint_max;
     // rate control: constant QP (X264_RC_CQP, codec.c:1498-1502) and single-pass CRF without AQ / mbtree (codec.c:1504-1507, the
     // driver's default session) when one GOP is in flight; ABR and CRF under --threads > 1 map to their nominal quantiser
@@ -595,6 +596,8 @@ x264_t *x264_encoder_open(x264_param_t *param)
     h->st_wait = h->bframes > h->L ? h->bframes : h->L;
     h->last_keyframe = -p.i_keyint_max;
     h->badapt = h->bframes ? p.i_bframe_adaptive : 0;
+    // (sessions with a fixed picture structure — no scenecut, b-adapt 0, no mbtree — run without the lookahead object: no fade weights and no
+    // lookahead vectors as search candidates there; that is also what makes the sessions of a batch equal to the same sessions run alone)
     if (h->dpbmode && (h->badapt || p.i_scenecut_threshold > 0 || h->mbtree)) {
         // x264's own lookahead structure: frame costs of (p0, p1, b) triples on the half-resolution planes (x264_slicetype_analyse)
         if (x264gpu_slicetype_create(&h->st, p.i_width, p.i_height, 1, h->Q, h->bframes, p.analyse.i_me_method, p.analyse.i_subpel_refine, p.analyse.i_me_range,
@@ -1065,10 +1068,69 @@ static int encode_queued(x264_t *h, x264_nal_t **pp_nal, int *pi_nal, x264_pictu
 //      --b-adapt 1).  frames[0] = the last non-B picture, frames[1..] = the pictures waiting in display order ----
 enum { ST_AUTO = 0, ST_IDR, ST_I, ST_P, ST_BREF, ST_B };
 struct StFrames { x264_t *h; std::vector<x264_t::BEntry *> f; };
+// x264_weights_analyse, luma plane: guess scale and offset from the two pictures' statistics, cost the candidates around the guess on the
+// half-resolution planes (b_lookahead: the guess alone, reference in place — called before a P cost is searched; else, for the P picture about
+// to be coded, +- the distances of the sub-pel level around it, reference motion-compensated by the lookahead's vectors), keep the weight if
+// it saves more than 0.2 %.  The chroma planes are not analysed (the device weights luma only).
+static Dpb::LumaWeight st_weights_analyse(x264_t *h, const x264_t::BEntry &fenc, const x264_t::BEntry &ref, int dist, bool b_lookahead)
+{
+    Dpb::LumaWeight none, w;
+    uint64_t sf[2], sr[2];
+    if (x264gpu_slicetype_pixel_stats(h->st, fenc.slot, h->q_raw[(size_t)fenc.slot], sf, nullptr) != X264GPU_OK ||
+        x264gpu_slicetype_pixel_stats(h->st, ref.slot, h->q_raw[(size_t)ref.slot], sr, nullptr) != X264GPU_OK) { h->failed = true; return none; }
+    const float epsilon = 1.f / 128.f;
+    const int zero_bias = !sr[1];
+    const float fenc_var = (float)(sf[1] + (uint64_t)zero_bias), ref_var = (float)(sr[1] + (uint64_t)zero_bias);
+    const float guess_scale = sqrtf(fenc_var / ref_var);
+    const float npix = (float)(h->mbw * 16) * (float)(h->mbh * 16);
+    const float fenc_mean = (float)(sf[0] + (uint64_t)zero_bias) / npix, ref_mean = (float)(sr[0] + (uint64_t)zero_bias) / npix;
+    if (fabsf(ref_mean - fenc_mean) < 0.5f && fabsf(1.f - guess_scale) < epsilon) return none;
+    // weight_get_h264( round( guess_scale * 128 ), 0 )
+    int mindenom = 7, minscale = (int)roundf(guess_scale * 128), minoff = 0;
+    while (mindenom > 0 && minscale > 127) { mindenom--; minscale >>= 1; }
+    if (minscale > 127) minscale = 127;
+    int32_t dummy = 0;
+    int64_t score = 0;
+    if (x264gpu_slicetype_frame_cost(h->st, fenc.slot, fenc.slot, fenc.slot, 0, 0, &dummy, nullptr) != X264GPU_OK ||       // the picture's intra costs
+        x264gpu_slicetype_weight_cost(h->st, fenc.slot, ref.slot, dist, 0, 1, 0, 0, &score, nullptr) != X264GPU_OK) { h->failed = true; return none; }
+    const unsigned origscore = (unsigned)score;
+    unsigned minscore = origscore;
+    if (!minscore) return none;
+    static const uint8_t check_distance[12][2] = { { 0, 0 }, { 0, 0 }, { 0, 1 }, { 0, 1 }, { 0, 1 }, { 0, 1 }, { 0, 1 }, { 1, 1 }, { 1, 1 }, { 2, 1 }, { 2, 1 }, { 4, 2 } };
+    const int sub = clampi(h->param.analyse.i_subpel_refine, 0, 11);
+    const int scale_dist = b_lookahead ? 0 : check_distance[sub][0], offset_dist = b_lookahead ? 0 : check_distance[sub][1];
+    const int start_scale = clampi(minscale - scale_dist, 0, 127), end_scale = clampi(minscale + scale_dist, 0, 127);      // (x264: up to 255; beyond 127 the syntax cannot carry it)
+    bool found = false;
+    for (int i_scale = start_scale; i_scale <= end_scale; i_scale++) {
+        int cur_scale = i_scale;
+        int cur_offset = (int)(fenc_mean - ref_mean * cur_scale / (1 << mindenom) + 0.5f * b_lookahead);
+        if (cur_offset < -128 || cur_offset > 127) {
+            cur_offset = clampi(cur_offset, -128, 127);
+            float cs = (1 << mindenom) * (fenc_mean - cur_offset) / ref_mean + 0.5f;
+            cur_scale = (int)(cs < 0 ? 0 : cs > 127 ? 127 : cs);
+        }
+        const int start_offset = clampi(cur_offset - offset_dist, -128, 127), end_offset = clampi(cur_offset + offset_dist, -128, 127);
+        for (int i_off = start_offset; i_off <= end_offset; i_off++) {
+            if (x264gpu_slicetype_weight_cost(h->st, fenc.slot, ref.slot, dist, 1, cur_scale, mindenom, i_off, &score, nullptr) != X264GPU_OK) { h->failed = true; return none; }
+            if ((unsigned)score < minscore) { minscore = (unsigned)score; minscale = cur_scale; minoff = i_off; found = true; }
+            if (minoff == start_offset && i_off != start_offset) break;          // the previous offset was better: no more
+        }
+    }
+    while (mindenom > 0 && !(minscale & 1)) { mindenom--; minscale >>= 1; }      // a smaller denominator if possible
+    if (!found || (minscale == 1 << mindenom && minoff == 0) || (float)minscore / origscore > 0.998f) return none;
+    w.on = 1; w.scale = minscale; w.denom = mindenom; w.offset = minoff;
+    return w;
+}
+
 static int st_cost(StFrames &F, int p0, int p1, int b)
 {
     int32_t sc = 0;
-    if (x264gpu_slicetype_frame_cost(F.h->st, F.f[(size_t)p0]->slot, F.f[(size_t)p1]->slot, F.f[(size_t)b]->slot, b - p0, p1 - b, &sc, nullptr) != X264GPU_OK) {
+    Dpb::LumaWeight w;
+    // slicetype_frame_cost: a P cost that is searched for the first time runs on the reference weighted by the lookahead's analysis
+    if (F.h->weightp && p1 == b && b != p0 && !x264gpu_slicetype_lowres_mvs(F.h->st, F.f[(size_t)b]->slot, 0, b - p0) &&
+        x264gpu_slicetype_cost_est(F.h->st, F.f[(size_t)b]->slot, b - p0, 0, 0) < 0)
+        w = st_weights_analyse(F.h, *F.f[(size_t)b], *F.f[(size_t)p0], b - p0, true);
+    if (x264gpu_slicetype_frame_cost_w(F.h->st, F.f[(size_t)p0]->slot, F.f[(size_t)p1]->slot, F.f[(size_t)b]->slot, b - p0, p1 - b, w.on, w.scale, w.denom, w.offset, &sc, nullptr) != X264GPU_OK) {
         xlog(&F.h->param, X264_LOG_ERROR, "lookahead frame cost failed: %s\n", x264gpu_last_error());
         F.h->failed = true;
     }
@@ -1283,6 +1345,11 @@ static bool bmode_decide(x264_t *h, bool flushing)
     if (h->st) {
         int closing = PIC_P;
         if (!st_decide(h, flushing, j, closing)) return false;
+        if (h->weightp && closing == PIC_P && h->have_last_nonb) {
+            // x264_slicetype_decide: "analyse for weighted P frames" — the picture about to be coded against the last non-B picture
+            h->bq[(size_t)j].w = st_weights_analyse(h, h->bq[(size_t)j], h->last_nonb, j + 1, false);
+            if (h->failed) return false;
+        }
         if (h->crf) {
             // x264_rc_analyse_slice: the closing picture's complexity is its frame cost as the type it was given — the I cost, or the P cost
             // against the last non-B picture (distance = run length + 1), from the lookahead that decided the types
@@ -1377,7 +1444,7 @@ static int encode_bmode(x264_t *h, x264_nal_t **pp_nal, int *pi_nal, x264_pictur
     // the disposable pictures coded right behind this one (x264_reference_hierarchy_reset looks at them)
     int fc[16], ff[16], nf = 0;
     for (size_t i = 0; i < h->bcoding.size() && nf < 16 && h->bcoding[i].type == PIC_B; i++) { fc[nf] = (int)(h->coded_count + 1 + (long)i); ff[nf] = h->bcoding[i].e.frame; nf++; }
-    const DpbPlan plan = h->dpb.plan(pl.type, pl.e.frame, nf, fc, ff);
+    const DpbPlan plan = h->dpb.plan(pl.type, pl.e.frame, nf, fc, ff, pl.type == PIC_P && pl.e.w.on ? &pl.e.w : nullptr);
     x264gpu_pic pic = plan.pic;
     double qpf = 0;
     pic.qp = bmode_qp(h, pl, plan, &qpf);
@@ -1525,6 +1592,7 @@ int x264_encoder_encode(x264_t *h, x264_nal_t **pp_nal, int *pi_nal, x264_pictur
             be.forced = pic_in->i_type == X264_TYPE_IDR || pic_in->i_type == X264_TYPE_KEYFRAME ? 2 : pic_in->i_type == X264_TYPE_I ? 1 : 0;
             be.scenecut = 0;
             bool ok = x264gpu_slicetype_put_frame(h->st, slot, d_raw, nullptr) == X264GPU_OK;
+            if (ok && h->weightp) { uint64_t stats[2]; ok = x264gpu_slicetype_pixel_stats(h->st, slot, d_raw, stats, nullptr) == X264GPU_OK; }      // x264_adaptive_quant_frame: i_pixel_sum / i_pixel_ssd
             if (ok && h->mbtree) {
                 // x264_adaptive_quant_frame: the AQ offsets weight the lookahead's costs and are what the tree starts from (f_qp_offset = f_qp_offset_aq)
                 if (!h->aq_strength_q8) ok = x264gpu_memset(h->q_aq[(size_t)slot], 0, (size_t)h->nmb * sizeof(int16_t), nullptr) == X264GPU_OK;
@@ -1686,6 +1754,16 @@ int x264host_dpb_info(void *h, int *max_dpb, int *num_reorder) { Dpb *d = (Dpb *
 int x264host_dpb_plan(void *h, int type, int frame, int n_follow, const int *follow_coded, const int *follow_frame, x264gpu_pic *pic_out, int *info)
 {
     const DpbPlan &p = ((Dpb *)h)->plan(type, frame, n_follow, follow_coded, follow_frame);
+    *pic_out = p.pic;
+    if (info) { info[0] = p.frame_num; info[1] = p.nal_ref_idc; info[2] = p.n_mmco; info[3] = p.reorder[0].n; info[4] = p.reorder[1].n; }
+    return 0;
+}
+/* ... with a luma weight for reference 0 (x264_weights_analyse's result): w = { scale, denom, offset } */
+int x264host_dpb_plan_w(void *h, int type, int frame, int n_follow, const int *follow_coded, const int *follow_frame, const int *w, x264gpu_pic *pic_out, int *info)
+{
+    Dpb::LumaWeight lw;
+    if (w) { lw.on = 1; lw.scale = w[0]; lw.denom = w[1]; lw.offset = w[2]; }
+    const DpbPlan &p = ((Dpb *)h)->plan(type, frame, n_follow, follow_coded, follow_frame, w ? &lw : nullptr);
     *pic_out = p.pic;
     if (info) { info[0] = p.frame_num; info[1] = p.nal_ref_idc; info[2] = p.n_mmco; info[3] = p.reorder[0].n; info[4] = p.reorder[1].n; }
     return 0;
