@@ -40,7 +40,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0   # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
-TOOLSET_GAPS = "x264 medium minus: the fade analysis of weightp 2 (its duplicate reference with offset -1 on every P picture IS in), b-adapt 1 (every run is bframes long: b-adapt 0), rate control (constant quantisers: no AQ / mbtree / lookahead); entropy coding (CABAC bitstream writing) runs on host threads and is outside `value` (inside `e2e`)"
+TOOLSET_GAPS = "x264 medium minus the lookahead's decisions, which sessions take and a lock-step batch cannot (every stream must code the same picture type): weightp's weights for fades (the duplicate reference with offset -1 on every P picture IS in), b-adapt 1 (every run is bframes long: b-adapt 0), rate control (constant quantisers: no AQ / mbtree / lookahead); entropy coding (CABAC bitstream writing) runs on host threads and is outside `value` (inside `e2e`)"
 TOOLSET_GAPS_NOB = "x264 medium minus: B-frames (bframes 3 -> 0), the fade analysis of weightp 2; entropy coding (CABAC/CAVLC bitstream writing) runs on host threads and is outside `value` (inside `e2e`)"
 TOOLSET_GAPS_NORD = "x264 medium minus: B-frames (bframes 3 -> 0), RD mode decision + psy-rd (subme 7 -> 5), trellis 1, the fade analysis of weightp 2; entropy coding runs on host threads and is outside `value`"
 
