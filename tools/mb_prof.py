@@ -48,7 +48,7 @@ def main():
     from x264vfw_amd.lib import Pic
     bfr = int(os.environ.get("MB_PROF_BFRAMES", "3")) if tools.get("dpb") else 0
     order = gop.schedule(bench.display_types(F, bfr, F), 1)
-    dpb = gop.HostDpb(HL, tools["refs"], bfr, 1)
+    dpb = gop.HostDpb(HL, tools["refs"], bfr, 1, weightp=2)
     qargs = type("Q", (), dict(qp=23))()
     for i, (disp, pt) in enumerate(order):
         pic, _ = dpb.plan(pt, disp, gop.follow_of(order, i))
