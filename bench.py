@@ -68,6 +68,7 @@ def parse_args():
     ap.add_argument("--e2e-legs", default="all", choices=["all", "sessions"], help="'sessions': only the threads-1 and multi-session legs of the end-to-end sample")
     ap.add_argument("--e2e-sessions", type=int, default=256, help="sessions of the multi-session end-to-end sample (cross-session batcher; 0 = skip)")
     ap.add_argument("--e2e-frames", type=int, default=10, help="frames of the single-stream threads-1 end-to-end sample (0 = skip e2e)")
+    ap.add_argument("--cpu-procs", type=int, default=64, help="processes of the many-core leg of the CPU baseline (cpu_baseline.cores reports what was used)")
     ap.add_argument("--cpu-frames-all", type=int, default=3, help="frames per core of the every-core leg of the CPU baseline (shorter: it runs one process per core)")
     ap.add_argument("--content", default="noise", choices=["noise", "smooth"], help="synthetic content: 'noise' (default, the headline) = moving rectangles of per-pixel "
                     "white noise + strong sensor noise, harder than camera material; 'smooth' = the same scene with band-limited textures and light noise")
@@ -169,7 +170,7 @@ def x264_probe(args):
 
 def cpu_baseline(args):
     """the oracle (kind "port") on 1 core and on every host core (one stream per core), bounded sample"""
-    ncpu = os.cpu_count() or 1
+    ncpu = min(os.cpu_count() or 1, max(1, args.cpu_procs))          # a bounded sample: the all-cores leg uses at most --cpu-procs processes
     base = [sys.executable, os.path.abspath(__file__), "--width", str(args.width), "--height", str(args.height), "--qp", str(args.qp),
             "--keyint", str(args.keyint), "--refs", str(args.refs), "--preset", args.preset, "--bframes", str(args.bframes)] + (["--aq"] if args.aq else []) + ["--rd", args.rd] + (["--no-trellis"] if args.no_trellis else [])
     nall = max(2, min(args.cpu_frames, args.cpu_frames_all))
@@ -183,7 +184,7 @@ def cpu_baseline(args):
     fn, wn = run(ncpu, nall) if ncpu > 1 else (f1, w1)
     return {"value": round(fn, 3), "unit": "frames/s", "cores": ncpu, "kind": "port",
             "value_1core": round(f1, 3),
-            "sample": f"{args.width}x{args.height}, one GOP in coding order ({display_types(args.cpu_frames, args.bframes, args.cpu_frames)}), oracle/analyse.c + encoder.c: one process alone on {args.cpu_frames} frames ({w1:.1f} s wall), then one process per core, "
+            "sample": f"{args.width}x{args.height}, one GOP in coding order ({display_types(args.cpu_frames, args.bframes, args.cpu_frames)}), oracle/analyse.c + encoder.c: one process alone on {args.cpu_frames} frames ({w1:.1f} s wall), then {ncpu} processes side by side (of {os.cpu_count()} hardware threads), "
                       f"{ncpu} streams at once, {nall} frames each ({wn:.1f} s wall) — the builder's own CPU restatement, NOT x264",
             "x264_probe": x264_probe(args)}
 
