@@ -838,3 +838,23 @@ def test_fade_session_gets_luma_weights_on_the_device(gpu):
     dec = O.h264_decode(out[2][0], n, w, h)
     for d, r in zip(dec, out[2][1]):
         assert psnr(d[:w * h], frames[r[2]][:w * h]) > 33.0
+
+
+def test_long_default_session_on_the_device(gpu):
+    """the driver's default session shape over several GOPs on the device: CRF + AQ + macroblock-tree over a 12-picture lookahead, b-adapt 1,
+    scene cuts, weightp 2, keyint 25 — every picture comes back once, dts is monotone, the stream decodes to the source (the queue rings, the DPB
+    and the lookahead's slots wrap many times)"""
+    w, h, n = 176, 144, 70
+    frames = synth_frames(w, h, n, seed=21, scene_len=19)
+    h_, eff = open_encoder(w, h, {"crf": 24, "keyint": 25, "min-keyint": 3, "bframes": 3, "rc-lookahead": 12}, profile=None)
+    assert (eff.i_bframe, eff.i_bframe_adaptive, eff.rc.b_mb_tree, eff.analyse.i_weighted_pred) == (3, 1, 1, 2)
+    stream, recs = encode_delayed(h_, w, h, frames)
+    H.x264_encoder_close(h_)
+    assert sorted(r[2] for r in recs) == list(range(n))
+    dts = [r[3] for r in recs]
+    assert dts == sorted(dts) and all(r[3] <= r[2] for r in recs)
+    dec = O.h264_decode(stream, n, w, h)
+    assert len(dec) == n
+    for d, r in zip(dec, recs):
+        assert psnr(d[:w * h], frames[r[2]][:w * h]) > 28.0
+    assert sum(1 for r in recs if r[1]) >= 3          # IDR pictures: keyint 25 and the scene cuts
