@@ -344,3 +344,48 @@ def test_every_config_dialog_choice_opens_a_session(gpu):
         rc, stream, sizes, log, frames = _session(lambda c: (setattr(c, "i_encoding_type", enc_type), setattr(c, "b_zerolatency", 1)))
         assert rc != V.ICERR_OK or (all(s > 0 for s in sizes) and len(O.h264_decode(stream, len(frames), 64, 48)) == len(frames)), (enc_type, log)
         assert rc == V.ICERR_OK or len(log) > 0
+
+
+def test_driver_defaults_with_b_pictures_to_a_file(gpu, tmp_path):
+    """the driver's own defaults untouched — single pass CRF, preset medium: bframes 3, b-adapt 1, b-pyramid, weightb, weightp 2, mbtree — through
+    DriverProc with file output: ICM_COMPRESS returns empty frames (the pictures leave in coding order into the file), ICM_COMPRESS_END flushes the
+    lookahead and the mini-GOP in flight (codec.c:1842-1856), the file holds every picture"""
+    w, h, nfr = 96, 80, 17
+    frames = synth_frames(w, h, nfr, seed=5)
+    path = tmp_path / "b.h264"
+    ico = V.ICOPEN(fccType=V.fourcc(b"vidc"))
+    cid = D(0, None, V.DRV_OPEN, 0, V.addr(ico))
+    n = D(cid, None, V.ICM_GETSTATE, 0, 0)
+    cfg = V.VfwConfig()
+    D(cid, None, V.ICM_GETSTATE, V.addr(cfg), n)
+    cfg.extra_cmdline = b"--rc-lookahead 6 --output " + str(path).encode()
+    D(cid, None, V.ICM_SETSTATE, V.addr(cfg), n)
+    inb, outb = V.bmi(w, h, b"I420"), V.BITMAPINFO()
+    assert D(cid, None, V.ICM_COMPRESS_GET_FORMAT, V.addr(inb), V.addr(outb)) == V.ICERR_OK
+    assert D(cid, None, V.ICM_COMPRESS_BEGIN, V.addr(inb), V.addr(outb)) == V.ICERR_OK, V.H.x264vfw_shim_log(cid)
+    cap = outb.bmiHeader.biSizeImage
+    buf = C.create_string_buffer(cap)
+    for f in frames:
+        flags = V.DWORD(0)
+        outb.bmiHeader.biSizeImage = cap
+        icc = V.ICCOMPRESS(lpbiOutput=C.pointer(outb.bmiHeader), lpOutput=C.cast(buf, C.c_void_p), lpbiInput=C.pointer(inb.bmiHeader),
+                           lpInput=f.ctypes.data, lpdwFlags=C.pointer(flags))
+        assert D(cid, None, V.ICM_COMPRESS, V.addr(icc), C.sizeof(icc)) == V.ICERR_OK, V.H.x264vfw_shim_log(cid)
+    log = V.H.x264vfw_shim_log(cid)
+    assert D(cid, None, V.ICM_COMPRESS_END, 0, 0) == V.ICERR_OK
+    D(cid, None, V.DRV_CLOSE, 0, 0)
+    assert b"bframes 0" not in log and b"mbtree 0" not in log, log
+    data = path.read_bytes()
+    dec = O.h264_decode(data, nfr, w, h)
+    pocs = O.h264_last_pocs()
+    assert len(dec) == nfr
+    from synth import psnr
+    # closed GOPs: POC restarts at IDR pictures; display index = pictures before the IDR + poc / 2
+    base, disp, last = 0, [], -1
+    for p in pocs:
+        if p == 0 and disp:
+            base = max(disp) + 1
+        disp.append(base + p // 2)
+    assert sorted(disp) == list(range(nfr))
+    for d, i in zip(dec, disp):
+        assert psnr(d[:w * h], frames[i][:w * h]) > 27.0
