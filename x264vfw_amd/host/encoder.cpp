@@ -228,7 +228,12 @@ static int batch_encode(BatchGroup *g, int s, const uint8_t *d_src, const x264gp
         g->pics[(size_t)s] = pic; g->arrived[(size_t)s] = 1; g->n_arrived++;
         const long my_round = g->round;
         if (g->n_arrived >= g->active) batch_run_round(g);
-        else g->cv.wait(lk, [&] { return g->round != my_round; });
+        else if (!g->cv.wait_for(lk, std::chrono::seconds(600), [&] { return g->round != my_round; })) {
+            // a member neither submitted its picture nor closed: give up on this session (the others keep waiting for it, or for its close)
+            g->arrived[(size_t)s] = 0; g->n_arrived--;
+            err = "X264GPU_BATCH: another session of the batch stopped submitting pictures";
+            return -1;
+        }
         if (g->round_rc) { err = g->err; return -1; }
     }
     if (x264gpu_memcpy_d2h(h_mb, g->d_mb + (size_t)s * g->nmb, g->nmb * sizeof(x264gpu_mb), nullptr) != X264GPU_OK ||
