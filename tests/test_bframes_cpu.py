@@ -283,6 +283,30 @@ def test_explicit_luma_weights_of_reference_0(types, weights, weightp, over):
     assert seen == len(weights)
 
 
+def test_host_session_single_pass_abr_with_b_pictures(tmp_path):
+    """--bitrate N (x264vfw's single-pass ABR page, config.c / codec.c:x264vfw 'Single pass - bitrate-based (ABR)') keeps B pictures, the
+    lookahead and macroblock-tree: the coded size of every picture, B pictures' divided by pbratio, steers the rate factor
+    (x264_ratecontrol_end), the stream lands near the target and decodes to the source"""
+    import subprocess
+    subprocess.check_call(["make", "-s", "-C", __file__.rsplit("/", 1)[0] + "/stub"])
+    n, w, h = 75, 176, 144
+    rates = {}
+    for kbps in (200, 600):
+        info, stream = _host_b_session(tmp_path, n, [f"bitrate={kbps}", "keyint=50"])
+        assert (info["bframes"], info["mbtree"], info["weightp"]) == (3, 1, 2)
+        recs = info["recs"]
+        assert len(recs) == n and any(r[0] in (4, 5) for r in recs)
+        rates[kbps] = sum(r[4] for r in recs) * 8 / n * 25 / 1000
+        assert abs(rates[kbps] - kbps) < 0.2 * kbps, rates
+        dec = O.h264_decode(stream, n, w, h)
+        assert len(dec) == n
+        frames = synth_frames(w, h, n, seed=3)
+        from synth import psnr
+        for d, r in zip(dec, recs):                                       # decode order = coding order; pts = source picture
+            assert psnr(d[:w * h], frames[r[1]][:w * h]) > (30.0 if kbps == 600 else 24.0)
+    assert rates[600] > 2 * rates[200]
+
+
 def test_host_session_finds_the_weights_of_a_fade(tmp_path):
     """a clip that fades to black through x264_encoder_encode with medium's lookahead: x264_weights_analyse restated on the lookahead's primitives
     gives the P pictures luma weights (the stream shrinks against --weightp 0 and decodes to the source)"""

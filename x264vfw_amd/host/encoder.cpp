@@ -424,7 +424,7 @@ x264_t *x264_encoder_open(x264_param_t *param)
     p.i_threads = clampi(p.i_threads, 1, 256);                 // --threads G: GOPs coded in lock-step (1 = no delay)
     if (p.i_bframe) {
         const char *why = !p.b_cabac ? "CABAC" : p.analyse.i_subpel_refine < 6 ? "subme >= 6" : h->slices > 1 ? "one slice per picture" :
-                          p.i_threads > 1 ? "threads 1" : p.i_keyint_max < 2 ? "keyint > 1" : p.rc.i_rc_method == X264_RC_ABR ? "constant-quantiser or CRF rate control" : nullptr;
+                          p.i_threads > 1 ? "threads 1" : p.i_keyint_max < 2 ? "keyint > 1" : (p.rc.i_rc_method == X264_RC_ABR && (p.rc.b_stat_read || p.rc.i_bitrate <= 0)) ? "constant-quantiser, CRF or single-pass ABR rate control" : nullptr;
         if (why) { xlog(&p, X264_LOG_WARNING, "B-frames need %s in the MI355X path: bframes 0\n", why); p.i_bframe = 0; }
     }
     if (p.i_bframe) {
@@ -442,7 +442,7 @@ x264_t *x264_encoder_open(x264_param_t *param)
         // without B pictures the session can still run on the DPB model, if nothing of the other path is asked for
         const bool tree = p.rc.b_mb_tree && p.rc.i_rc_method != X264_RC_CQP && p.rc.i_lookahead > 0;
         const char *why = p.i_threads > 1 ? "threads 1" : h->slices > 1 ? "one slice per picture" : p.b_sliced_threads ? "no slice threads" : tree ? "no mbtree" :
-                          p.rc.i_rc_method == X264_RC_ABR ? "constant-quantiser or CRF rate control" : p.i_keyint_max < 2 ? "keyint > 1" : nullptr;
+                          (p.rc.i_rc_method == X264_RC_ABR && (p.rc.b_stat_read || p.rc.i_bitrate <= 0)) ? "constant-quantiser, CRF or single-pass ABR rate control" : p.i_keyint_max < 2 ? "keyint > 1" : nullptr;
         if (why) { xlog(&p, X264_LOG_WARNING, "weightp 2 without B-frames needs %s in the MI355X path: weightp 0\n", why); p.analyse.i_weighted_pred = X264_WEIGHTP_NONE; }
     }
     if (p.analyse.i_weighted_pred == X264_WEIGHTP_SMART && p.i_frame_reference < 2) p.analyse.i_weighted_pred = X264_WEIGHTP_NONE;      // a duplicate needs two references (x264: never placed)
@@ -1355,7 +1355,7 @@ static bool bmode_decide(x264_t *h, bool flushing)
             h->bq[(size_t)j].w = st_weights_analyse(h, h->bq[(size_t)j], h->last_nonb, j + 1, false);
             if (h->failed) return false;
         }
-        if (h->crf) {
+        if (h->crf || h->abr) {
             // x264_rc_analyse_slice: the closing picture's complexity is its frame cost as the type it was given — the I cost, or the P cost
             // against the last non-B picture (distance = run length + 1), from the lookahead that decided the types
             x264_t::BEntry &c = h->bq[(size_t)j];
@@ -1413,7 +1413,7 @@ static int bmode_qp(x264_t *h, const x264_t::BPlanned &pl, const DpbPlan &plan, 
     const x264_param_t &p = h->param;
     const double pb_offset = 6.0 * log2(fabs(p.rc.f_pb_factor) > 0 ? fabs(p.rc.f_pb_factor) : 1.0);
     const bool is_i = pl.type == PIC_IDR || pl.type == PIC_I, is_b = pl.type == PIC_B || pl.type == PIC_BREF;
-    if (!h->crf) {
+    if (!h->crf && !h->abr) {
         const int qb = clampi((int)(h->qp_p + pb_offset + 0.5), 0, 51);
         const int q = is_i ? h->qp_i : !is_b ? h->qp_p : pl.type == PIC_BREF ? (qb + h->qp_p) / 2 : qb;
         *qp_float = q;
@@ -1514,6 +1514,15 @@ static int encode_bmode(x264_t *h, x264_nal_t **pp_nal, int *pi_nal, x264_pictur
         if (k >= delay) pic_out->i_dts = h->all_pts[(size_t)(k - delay) < np ? (size_t)(k - delay) : np - 1];
         else pic_out->i_dts = h->all_pts[(size_t)k < np ? (size_t)k : np - 1] - (h->all_pts[(size_t)delay < np ? (size_t)delay : np - 1] - h->all_pts[0]);
         pic_out->img = pl.e.img;
+    }
+    if (h->abr) {
+        // x264_ratecontrol_end: what the picture took moves the rate factor of the pictures to come (a B picture's quantiser is an offset of
+        // its neighbours': its bits count divided by pbratio)
+        const double bits = (double)h->out.size() * 8.0, pb = fabs(p.rc.f_pb_factor) > 0 ? fabs(p.rc.f_pb_factor) : 1.0;
+        const bool is_b = pl.type == PIC_B || pl.type == PIC_BREF;
+        h->rc.total_bits += bits;
+        h->rc.cplxr_sum += bits * (0.85 * pow(2.0, (qpf - 12.0) / 6.0)) / (h->rc.last_rceq * (is_b ? pb : 1.0));
+        h->rc.wanted_bits_window += h->rc.bitrate / h->rc.fps;
     }
     if (idr) h->idr_pic_id = (h->idr_pic_id + 1) & 0xffff;
     h->coded_count++;
