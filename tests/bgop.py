@@ -28,7 +28,8 @@ def encode_gop(HL, enc, frames, types, cfg, qp_i, qp_p, qp_b, refs, bframes=3, p
         mbs, lv = enc.encode_pic(frames[disp], pic)
         if pics_out is not None:
             pics_out.append((pic, mbs))
-        stream += dpb.slice(mbw, mbh, pic.qp, qp_p, idr_id, 0 if cfg.deblock else 1, refs, cfg.dct8x8, mbs, lv)
+        stream += dpb.slice(mbw, mbh, pic.qp, qp_p, idr_id, 0 if cfg.deblock else 1, refs, cfg.dct8x8, mbs, lv,
+                            slices=(-cfg.slices if cfg.slices_plain else cfg.slices) if cfg.slices > 1 else 1)
         recons.append(enc.recon())
         pocs.append(pic.poc)
         dpb.commit()

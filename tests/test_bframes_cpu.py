@@ -39,6 +39,9 @@ def run(w, h, types, seed, bframes=3, pyramid=1, weightp=0, pics_out=None, weigh
     (176, 144, "IBBBPBBP", 9, dict(me_method=2)),
     (128, 96, "IBPBBP", 12, dict(me_method=3, me_range=8)),
     (176, 144, "IBBBPBP", 13, dict(trellis=63 + 64)),
+    (176, 288, "IBBBPBBP", 14, dict(slices=3)),                                   # x264 slice threads: B pictures in three slices (not filtered across)
+    (176, 144, "IBBPBP", 15, dict(slices=9, slices_plain=1)),                     # --slices 9: one slice a macroblock row, filtered across
+    (96, 160, "IBPBBP", 16, dict(slices=4, slices_plain=1, refs=2)),
 ])
 def test_b_pictures_decode_to_the_encoders_reconstruction(w, h, types, seed, over):
     run(w, h, types, seed, **over)
@@ -281,6 +284,32 @@ def test_explicit_luma_weights_of_reference_0(types, weights, weightp, over):
             if weightp == 2 and n0 >= 3:
                 assert pic.slot[0][0] == pic.slot[0][1] == pic.slot[0][2] or pic.wl0[0].offset == -128
     assert seen == len(weights)
+
+
+@pytest.mark.parametrize("opts,per_pic", [(["slices=4"], 4), (["sliced-threads", "threads=2"], 2)])
+def test_host_session_b_pictures_in_slices(tmp_path, opts, per_pic):
+    """--slices N / x264's slice threads in a session with B pictures (the driver's default rate control: CRF + AQ + macroblock-tree): every picture,
+    B pictures too, leaves as `per_pic` slice NAL units; slice threads switch the loop filter off across slices (disable_deblocking_filter_idc 2);
+    the stream decodes to the source"""
+    import subprocess
+    subprocess.check_call(["make", "-s", "-C", __file__.rsplit("/", 1)[0] + "/stub"])
+    n, w, h = 16, 176, 144
+    info, stream = _host_b_session(tmp_path, n, ["crf=24", "keyint=12"] + opts)
+    assert (info["bframes"], info["mbtree"], info["weightp"]) == (3, 1, 2)
+    recs = info["recs"]
+    assert len(recs) == n and any(r[0] in (4, 5) for r in recs)
+    _, _, sl = O.lsmash_parse(stream, max_slices=256)
+    assert len(sl) == n * per_pic
+    k = 0
+    for r in recs:
+        want = {1: 2, 2: 2, 3: 0, 4: 1, 5: 1}[r[0]]
+        assert all(x.slice_type % 5 == want for x in sl[k:k + per_pic]), (r, [x.slice_type for x in sl[k:k + per_pic]])
+        k += per_pic
+    dec = O.h264_decode(stream, n, w, h)
+    frames = synth_frames(w, h, n, seed=3)
+    from synth import psnr
+    for d, r in zip(dec, recs):
+        assert psnr(d[:w * h], frames[r[1]][:w * h]) > 30.0
 
 
 def test_host_session_single_pass_abr_with_b_pictures(tmp_path):

@@ -44,8 +44,9 @@ def run(gpu, w, h, types, seed, streams=1, bframes=3, pyramid=1, weightp=0, weig
             assert bad.size == 0, f"picture {k} (display {disp}, type {pt}) stream {s}: record of macroblock {bad[0]} differs" + describe(g_mb[s], o_mb, bad[0])
             assert np.array_equal(g_lv[s], o_lv), f"picture {k}: levels differ (macroblock {np.nonzero((g_lv[s] != o_lv).any(axis=1))[0][0]})"
             assert np.array_equal(gg.recon(s), og.recon()), f"picture {k}: reconstruction differs"
-        assert not kw["rd"] or pt <= 1 or np.array_equal(gg.cabac_states(0, 0)[USED_CTX], og.cabac_states()[USED_CTX]), f"picture {k}: CABAC context variables differ"
-        stream += dpb.slice(mbw, mbh, pic.qp, 23, 0, 0 if cfg.deblock else 1, kw["refs"], cfg.dct8x8, g_mb[0], g_lv[0])
+        assert not kw["rd"] or pt <= 1 or np.array_equal(gg.cabac_states(0, max(kw.get('slices', 1), 1) - 1)[USED_CTX], og.cabac_states()[USED_CTX]), f"picture {k}: CABAC context variables differ"
+        stream += dpb.slice(mbw, mbh, pic.qp, 23, 0, 0 if cfg.deblock else 1, kw["refs"], cfg.dct8x8, g_mb[0], g_lv[0],
+                            slices=(-cfg.slices if cfg.slices_plain else cfg.slices) if cfg.slices > 1 else 1)
         recons.append(gg.recon(0))
         if pic.blind_dupe > 0:
             dupe_used += int(((g_mb[0]["ref"] == 1) & ((g_mb[0]["type"] == O.MB_P_L0) | (g_mb[0]["type"] == O.MB_P_8x8))[..., None]).sum())
@@ -71,6 +72,10 @@ def run(gpu, w, h, types, seed, streams=1, bframes=3, pyramid=1, weightp=0, weig
     (128, 96, "IBPBBP", 12, dict(me_method=3, me_range=8)),                         # esa
     (176, 144, "IBBBPBP", 13, dict(trellis=63 + 64)),                               # --trellis 2: the search in the analysis' block encodes and every RD candidate of B macroblocks too
     (128, 96, "IBBPBP", 14, dict(trellis=63 + 64, me_method=2)),
+    (176, 288, "IBBBPBBP", 15, dict(slices=3)),                                     # x264 slice threads: three wavefronts a B picture, each slice with its own neighbours, contexts and statistics
+    (176, 144, "IBBPBP", 16, dict(slices=9, slices_plain=1)),                       # --slices 9: the picture-wide intra count behind the fast-intra decision (speculative passes, EncK.sl_stat)
+    (96, 160, "IBPBBP", 17, dict(slices=4, slices_plain=1, refs=2)),
+    (176, 288, "IBBBP", 18, dict(slices=4, me_method=2)),
 ])
 def test_b_pictures_bitexact_and_decodable(gpu, w, h, types, seed, over):
     run(gpu, w, h, types, seed, **over)

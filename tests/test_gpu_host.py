@@ -787,6 +787,8 @@ def encode_delayed(h_, w, h, frames):
     (176, 144, 20, {"crf": 24, "keyint": 30, "bframes": 3, "rc-lookahead": 8}, None),                               # the driver's default rate control: CRF + AQ + macroblock-tree through B pictures
     (176, 144, 16, {"qp": 23, "keyint": 30, "bframes": 3}, None),                                                                  # medium's lookahead: --b-adapt 1 --scenecut 40 on the device's (p0, p1, b) frame costs
     (176, 144, 9, {"qp": 23, "keyint": 30, "scenecut": 0, "bframes": 0, "weightp": 2}, "IPPPPPPPP"),                # no B pictures, --weightp 2: the DPB model with no delay
+    (176, 288, 14, {"crf": 24, "keyint": 30, "bframes": 3, "rc-lookahead": 6, "slices": 6}, None),                  # B pictures in --slices 6
+    (176, 288, 14, {"crf": 24, "keyint": 30, "bframes": 3, "rc-lookahead": 6, "sliced-threads": None, "threads": 3}, None),      # ... and in x264's slice threads
     (176, 144, 30, {"bitrate": 600, "keyint": 30, "bframes": 3, "rc-lookahead": 10}, None),                          # single-pass ABR keeps B pictures, the lookahead and macroblock-tree
 ])
 def test_b_session_through_the_encode_api(gpu, w, h, n, opts, pattern):

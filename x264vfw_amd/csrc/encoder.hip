@@ -332,7 +332,7 @@ static int encode_core(x264gpu_encoder *e, const uint8_t *d_i420, const x264gpu_
     if (slice_type == X264GPU_SLICE_I_NONIDR) slice_type = X264GPU_SLICE_I;            // same kernels; only the DPB handling differs
     const bool bslice = slice_type == X264GPU_SLICE_B;
     ARG_TRY(pic.dst >= 0 && pic.dst < e->slots && pic.qp >= 0 && pic.qp <= 51);
-    ARG_TRY(!bslice || (e->cfg.rd && e->cfg.cabac && e->cfg.dpb > 0 && (e->cfg.slices <= 1)));      // B pictures: RD sessions with CABAC, one slice
+    ARG_TRY(!bslice || (e->cfg.rd && e->cfg.cabac && e->cfg.dpb > 0));      // B pictures: RD sessions with CABAC
     const int n0 = slice_type == X264GPU_SLICE_I ? 0 : pic.nref[0], n1 = bslice ? pic.nref[1] : 0;
     ARG_TRY(n0 >= 0 && n0 <= 7 && n1 >= 0 && n1 <= 3 && n0 + n1 <= 8 && (slice_type == X264GPU_SLICE_I || n0 > 0) && (!bslice || n1 > 0));      // list 0: up to 5 pictures + --weightp duplicates
     for (int l = 0; l < 2; l++) for (int r = 0; r < (l ? n1 : n0); r++) ARG_TRY(pic.slot[l][r] >= 0 && pic.slot[l][r] < e->slots && pic.slot[l][r] != pic.dst);
@@ -401,7 +401,7 @@ static int encode_core(x264gpu_encoder *e, const uint8_t *d_i420, const x264gpu_
     k.colref_cur = e->colref[cur]; k.colmv_cur = e->colmv[cur];
     e->slot_nref[cur] = k.nref; e->slot_poc[cur] = e->poc; e->slot_ref0poc[cur] = k.nref ? e->slot_poc[s0] : 0;
     k.prof = e->prof; k.tc = e->tc; k.amvd = e->amvd; k.cab_out = e->cab_out;
-    k.sl_stat = slice_type == X264GPU_SLICE_P ? e->sl_stat : nullptr; k.sl_rerun = e->sl_rerun; k.sl_pass = 0;
+    k.sl_stat = slice_type != X264GPU_SLICE_I ? e->sl_stat : nullptr; k.sl_rerun = e->sl_rerun; k.sl_pass = 0;
     k.trellis = e->cfg.trellis; k.tr_su = nullptr; k.tr_tu = nullptr; k.tr_l2 = nullptr;
     if (k.trellis) { const int rc = trellis_table_ptrs(&k.tr_su, &k.tr_tu, &k.tr_l2); if (rc != X264GPU_OK) return rc; }
     k.lowres_mv = e->lowres_mv; k.lowres_mv1 = e->lowres_mv1; k.fast_pskip = e->cfg.fast_pskip; k.mv_range = e->cfg.mv_range;
@@ -428,9 +428,10 @@ static int encode_core(x264gpu_encoder *e, const uint8_t *d_i420, const x264gpu_
     STAGE_MARK(1);
     // the macroblock loop: one wavefront per stream, raster order (sub-pel neighbourhood margin 2 px up to subme 7, 5 px above)
     if (slice_type == X264GPU_SLICE_I) launch_mb_slice_intra(k, S, st);        // (RD instantiations inside, chosen by k.rd)
-    else if (bslice) (k.me_method == 0 ? launch_mb_slice_b_dia : k.me_method == 2 ? launch_mb_slice_b_umh : k.me_method == 3 ? launch_mb_slice_b_esa : launch_mb_slice_b_hex)(k, S, st);
     else {
-        const auto launch = k.me_method == 0 ? launch_mb_slice_dia : k.me_method == 2 ? launch_mb_slice_umh : k.me_method == 3 ? launch_mb_slice_esa : launch_mb_slice_hex;
+        const auto launch_b = k.me_method == 0 ? launch_mb_slice_b_dia : k.me_method == 2 ? launch_mb_slice_b_umh : k.me_method == 3 ? launch_mb_slice_b_esa : launch_mb_slice_b_hex;
+        const auto launch_p = k.me_method == 0 ? launch_mb_slice_dia : k.me_method == 2 ? launch_mb_slice_umh : k.me_method == 3 ? launch_mb_slice_esa : launch_mb_slice_hex;
+        const auto launch = [&](const EncK &kk, int streams, bool big_margin, hipStream_t s_) { if (bslice) launch_b(kk, streams, s_); else launch_p(kk, streams, big_margin, s_); };
         if (k.sl_stat) hipLaunchKernelGGL(k_slice_priors, dim3((S + 63) / 64), dim3(64), 0, st, k, S, 1);
         launch(k, S, k.subme >= 8, st);
         // --slices N: slice i is final once slices 0..i-1 are, so slices - 1 rounds of "check the assumed counts, run the slices again whose

@@ -5,8 +5,8 @@
 namespace x264gpu {
 void launch_mb_slice_b_esa(const EncK &k, int streams, hipStream_t st)
 {
-    if (k.trellis & 64) hipLaunchKernelGGL((k_mb_slice<2, 3, true, 4, true>), dim3(streams, 1), dim3(64), 0, st, k);      // --trellis 2
-    else if (k.trellis) hipLaunchKernelGGL((k_mb_slice<2, 3, true, 3, true>), dim3(streams, 1), dim3(64), 0, st, k);
-    else hipLaunchKernelGGL((k_mb_slice<2, 3, true, 2, true>), dim3(streams, 1), dim3(64), 0, st, k);
+    if (k.trellis & 64) hipLaunchKernelGGL((k_mb_slice<2, 3, true, 4, true>), dim3(streams, k.slices > 1 ? k.slices : 1), dim3(64), 0, st, k);      // --trellis 2
+    else if (k.trellis) hipLaunchKernelGGL((k_mb_slice<2, 3, true, 3, true>), dim3(streams, k.slices > 1 ? k.slices : 1), dim3(64), 0, st, k);
+    else hipLaunchKernelGGL((k_mb_slice<2, 3, true, 2, true>), dim3(streams, k.slices > 1 ? k.slices : 1), dim3(64), 0, st, k);
 }
 }  // namespace x264gpu

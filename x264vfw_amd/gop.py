@@ -68,12 +68,12 @@ class HostDpb:
         assert n > 0
         return bytes(buf[:n])
 
-    def slice(self, mbw, mbh, qp, pic_init_qp, idr_pic_id, disable_deblock, num_ref_default, t8x8, mbs, lv):
+    def slice(self, mbw, mbh, qp, pic_init_qp, idr_pic_id, disable_deblock, num_ref_default, t8x8, mbs, lv, slices=1):
         buf = np.zeros(max(1 << 16, mbs.size * 1200), np.uint8)
         sk = C.c_int()
         mbs = np.ascontiguousarray(mbs); lv = np.ascontiguousarray(lv)
-        n = self.H.x264host_write_slice_dpb(self.h, mbw, mbh, qp, pic_init_qp, self.log2_max_frame_num, self.log2_max_poc_lsb, idr_pic_id, disable_deblock,
-                                            num_ref_default, t8x8, mbs.ctypes.data, lv.ctypes.data, buf.ctypes.data, buf.size, C.byref(sk))
+        n = self.H.x264host_write_picture_dpb(self.h, mbw, mbh, qp, pic_init_qp, self.log2_max_frame_num, self.log2_max_poc_lsb, idr_pic_id, disable_deblock,
+                                              num_ref_default, t8x8, slices, mbs.ctypes.data, lv.ctypes.data, buf.ctypes.data, buf.size, C.byref(sk))
         assert n > 0
         return bytes(buf[:n])
 

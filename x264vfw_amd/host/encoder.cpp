@@ -354,7 +354,7 @@ x264_t *x264_encoder_open(x264_param_t *param)
     if (!p.i_timebase_num || !p.i_timebase_den) { p.i_timebase_num = p.i_fps_den; p.i_timebase_den = p.i_fps_num; }
 
     // ---- effective parameters: what this round's pipeline implements (reported back via encoder_parameters) ----
-    // B pictures: on the device in RD sessions with CABAC (subme >= 6), --me hex, one slice per picture, one GOP in flight (settled below, once those are known)
+    // B pictures: on the device in RD sessions with CABAC (subme >= 6), one GOP in flight (settled below, once those are known)
     p.i_bframe = clampi(p.i_bframe, 0, 16);
     if (p.i_frame_reference > 5) { xlog(&p, X264_LOG_INFO, "ref %d -> 5 (DPB of the MI355X path holds up to 5 references)\n", p.i_frame_reference); p.i_frame_reference = 5; }
     if (p.i_frame_reference < 1) p.i_frame_reference = 1;
@@ -423,7 +423,7 @@ x264_t *x264_encoder_open(x264_param_t *param)
     } else if (!p.b_sliced_threads) p.i_slice_count = 0;
     p.i_threads = clampi(p.i_threads, 1, 256);                 // --threads G: GOPs coded in lock-step (1 = no delay)
     if (p.i_bframe) {
-        const char *why = !p.b_cabac ? "CABAC" : p.analyse.i_subpel_refine < 6 ? "subme >= 6" : h->slices > 1 ? "one slice per picture" :
+        const char *why = !p.b_cabac ? "CABAC" : p.analyse.i_subpel_refine < 6 ? "subme >= 6" :
                           p.i_threads > 1 ? "threads 1" : p.i_keyint_max < 2 ? "keyint > 1" : (p.rc.i_rc_method == X264_RC_ABR && (p.rc.b_stat_read || p.rc.i_bitrate <= 0)) ? "constant-quantiser, CRF or single-pass ABR rate control" : nullptr;
         if (why) { xlog(&p, X264_LOG_WARNING, "B-frames need %s in the MI355X path: bframes 0\n", why); p.i_bframe = 0; }
     }
@@ -441,7 +441,7 @@ x264_t *x264_encoder_open(x264_param_t *param)
     if (p.analyse.i_weighted_pred == X264_WEIGHTP_SMART && !h->bframes) {
         // without B pictures the session can still run on the DPB model, if nothing of the other path is asked for
         const bool tree = p.rc.b_mb_tree && p.rc.i_rc_method != X264_RC_CQP && p.rc.i_lookahead > 0;
-        const char *why = p.i_threads > 1 ? "threads 1" : h->slices > 1 ? "one slice per picture" : p.b_sliced_threads ? "no slice threads" : tree ? "no mbtree" :
+        const char *why = p.i_threads > 1 ? "threads 1" : tree ? "no mbtree" :
                           (p.rc.i_rc_method == X264_RC_ABR && (p.rc.b_stat_read || p.rc.i_bitrate <= 0)) ? "constant-quantiser, CRF or single-pass ABR rate control" : p.i_keyint_max < 2 ? "keyint > 1" : nullptr;
         if (why) { xlog(&p, X264_LOG_WARNING, "weightp 2 without B-frames needs %s in the MI355X path: weightp 0\n", why); p.analyse.i_weighted_pred = X264_WEIGHTP_NONE; }
     }
@@ -1492,12 +1492,12 @@ static int encode_bmode(x264_t *h, x264_nal_t **pp_nal, int *pi_nal, x264_pictur
     sp.mbw = h->mbw; sp.mbh = h->mbh; sp.qp = pic.qp; sp.pic_init_qp = h->pic_init_qp; sp.log2_max_frame_num = h->log2_max_frame_num; sp.log2_max_poc_lsb = h->log2_max_poc_lsb;
     sp.idr_pic_id = h->idr_pic_id; sp.pps_id = p.i_sps_id; sp.num_ref_default = p.i_frame_reference; sp.num_ref1_default = 1;
     sp.disable_deblock_idc = p.b_deblocking_filter ? 0 : 1; sp.alpha_off_div2 = p.i_deblocking_filter_alphac0; sp.beta_off_div2 = p.i_deblocking_filter_beta;
-    sp.transform8x8_mode = p.analyse.b_transform_8x8; sp.cabac = p.b_cabac;
+    sp.transform8x8_mode = p.analyse.b_transform_8x8; sp.cabac = p.b_cabac; sp.slices_plain = h->slices_plain;
     h->dpb.fill(sp);
     h->last_stats.skip = 0;
     {
         const size_t before = h->nal_off.size();
-        write_picture(h->out, &h->nal_off, sp, 1, h->h_mb.data(), h->h_lv.data(), p.b_annexb != 0, before == 0, &h->last_stats, 1);
+        write_picture(h->out, &h->nal_off, sp, h->slices, h->h_mb.data(), h->h_lv.data(), p.b_annexb != 0, before == 0, &h->last_stats, h->cavlc_threads);
         for (size_t i = before; i < h->nal_off.size(); i++) types.push_back(idr ? 5 : 1);
     }
     h->dpb.commit();
@@ -1795,6 +1795,26 @@ int x264host_write_slice_dpb(void *h, int mbw, int mbh, int qp, int pic_init_qp,
     std::vector<uint8_t> v;
     SliceStats stt = { 0 };
     write_slice(v, sp, mbs, levels, true, true, &stt, 1);
+    if (skipped) *skipped = stt.skip;
+    if ((int)v.size() > cap) return -1;
+    memcpy(out, v.data(), v.size());
+    return (int)v.size();
+}
+// the same picture in `slices` slices (N: as x264's slice threads cut it, -N: as --slices N does)
+int x264host_write_picture_dpb(void *h, int mbw, int mbh, int qp, int pic_init_qp, int log2_max_frame_num, int log2_max_poc_lsb, int idr_pic_id,
+                               int disable_deblock_idc, int num_ref_default, int transform8x8_mode, int slices, const x264gpu_mb *mbs, const int16_t *levels,
+                               uint8_t *out, int cap, int *skipped)
+{
+    SliceParams sp = {};
+    sp.mbw = mbw; sp.mbh = mbh; sp.qp = qp; sp.pic_init_qp = pic_init_qp; sp.log2_max_frame_num = log2_max_frame_num; sp.log2_max_poc_lsb = log2_max_poc_lsb;
+    sp.idr_pic_id = idr_pic_id; sp.num_ref_default = num_ref_default; sp.num_ref1_default = 1;
+    sp.disable_deblock_idc = disable_deblock_idc; sp.transform8x8_mode = transform8x8_mode; sp.cabac = 1;
+    sp.slices_plain = slices < 0;
+    if (slices < 0) slices = -slices;
+    ((Dpb *)h)->fill(sp);
+    std::vector<uint8_t> v;
+    SliceStats stt = { 0 };
+    write_picture(v, nullptr, sp, slices > 1 ? slices : 1, mbs, levels, true, true, &stt, 1);
     if (skipped) *skipped = stt.skip;
     if ((int)v.size() > cap) return -1;
     memcpy(out, v.data(), v.size());

@@ -104,6 +104,7 @@ _sig("x264host_dpb_info", _i, [C.c_void_p, C.POINTER(_i), C.POINTER(_i)])
 _sig("x264host_dpb_plan", _i, [C.c_void_p, _i, _i, _i, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p])
 _sig("x264host_dpb_commit", None, [C.c_void_p])
 _sig("x264host_write_slice_dpb", _i, [C.c_void_p] + [_i] * 10 + [C.c_void_p, C.c_void_p, C.c_void_p, _i, C.POINTER(_i)])
+_sig("x264host_write_picture_dpb", _i, [C.c_void_p] + [_i] * 11 + [C.c_void_p, C.c_void_p, C.c_void_p, _i, C.POINTER(_i)])
 _sig("x264host_write_headers_b", _i, [_i] * 6 + [C.c_uint32, C.c_uint32] + [_i] * 8 + [C.c_void_p, _i])
 PIC_IDR, PIC_I, PIC_P, PIC_BREF, PIC_B = range(5)
 _sig("x264host_last_decision", _i, [C.c_void_p, C.POINTER(_i), C.POINTER(_i), C.POINTER(C.c_int32)])
