@@ -195,6 +195,62 @@ def test_host_session_b_adapt_1_static_content_uses_b_pictures(tmp_path):
     assert t2.replace("R", "B").count("B") <= 2, t2
 
 
+@pytest.mark.parametrize("seed,extra", [(2, []), (7, ["scene_len=9"]), (4, ["static=1"])])
+def test_host_session_b_adapt_2_is_the_cheapest_path(tmp_path, seed, extra):
+    """--b-adapt 2 (presets slow and up): x264 slicetype_path, a Viterbi search over the lengths of the window, must find the cheapest way to
+    code the window in runs of at most --bframes B pictures — checked against an exhaustive enumeration of every such path on the same frame
+    costs (oracle/slicetype.c) for the first decision of the session; the stream decodes"""
+    n, w, h = 16, 128, 96
+    info, stream = _host_b_session(tmp_path, n, ["qp=26", "keyint=250", "scenecut=0", "b-adapt=2", "no-weightb", "weightp=0"] + extra, w, h, seed=seed)
+    assert (info["bframes"], info["badapt"]) == (3, 2)
+    assert info["first_output_after"] == 13                              # x264 h->frames.i_delay = max(bframes, 3) * 4 pictures ahead
+    t = _types_by_display(info["recs"]).replace("R", "B")
+    assert "BBBB" not in t and t[-1] == "P"
+    assert len(O.h264_decode(stream, n, w, h)) == n
+    # the window of the first decision: the I picture and the 13 pictures behind it
+    frames = synth_frames(w, h, n, seed=seed, **({"scene_len": 9} if extra == ["scene_len=9"] else {}))
+    if extra == ["static=1"]:
+        rng = np.random.default_rng(seed)
+        frames = [np.clip(frames[0].astype(np.int16) + rng.integers(-1, 2, frames[0].shape), 0, 255).astype(np.uint8) for _ in range(n)]
+    st = O.OracleSlicetype(w, h, slots=16, bframes=3, weightb=0)
+    for i in range(14):
+        st.put(i, frames[i])
+    memo = {}
+
+    def c(p0, p1, b):
+        if (p0, p1, b) not in memo:
+            memo[(p0, p1, b)] = st.cost(p0, p1, b, b - p0, p1 - b)
+        return memo[(p0, p1, b)]
+
+    def run_cost(a, b_):                                                 # pictures a+1 .. b_ coded as B ... B P behind the non-B picture a
+        cost = c(a, b_, b_)
+        if b_ - a > 2:
+            m = a + (b_ - a) // 2
+            cost += c(a, b_, m) + sum(c(a, m, i) for i in range(a + 1, m)) + sum(c(m, b_, i) for i in range(m + 1, b_))
+        else:
+            cost += sum(c(a, b_, i) for i in range(a + 1, b_))
+        return cost
+
+    def compositions(total):
+        if total == 0:
+            yield ()
+        for r in (1, 2, 3, 4):
+            if r <= total:
+                for rest in compositions(total - r):
+                    yield (r,) + rest
+
+    best = None
+    for runs in compositions(13):
+        pos, cost = 0, 0
+        for r in runs:
+            cost += run_cost(pos, pos + r)
+            pos += r
+        if best is None or cost < best[0]:
+            best = (cost, runs)
+    first_run = t[1:].index("P") + 1
+    assert first_run == best[1][0], (t, best)
+
+
 def test_host_session_crf_on_the_lookaheads_costs(tmp_path):
     """CRF with medium's lookahead (b-adapt 1, scenecut): the quantisers follow from the frame costs of the decided types (x264_rc_analyse_slice:
     the I cost, or the P cost against the last non-B picture); quantisers move with the content and every picture decodes"""

@@ -158,7 +158,7 @@ int x264gpu_encoder_create(x264gpu_encoder **out, const x264gpu_config *cfg)
     alloc((void **)&e->wf_progress, S * 2 * WFG_ROWS * sizeof(int), 0);
     if (cfg->rd && !cfg->cabac) alloc((void **)&e->tc, S * k.nmb * 24, 0);
     if (cfg->rd && cfg->cabac) { alloc((void **)&e->amvd, S * k.nmb * (cfg->dpb > 0 ? 16 : 8), 0); alloc((void **)&e->cab_out, S * (cfg->slices > 1 ? cfg->slices : 1) * 192 * sizeof(uint32_t), 0); }
-    if (cfg->slices_plain && cfg->slices > 1) { alloc((void **)&e->sl_stat, S * cfg->slices * 4 * sizeof(int), 0); alloc((void **)&e->sl_rerun, S * cfg->slices * sizeof(int), 0); }
+    if (cfg->slices_plain && cfg->slices > 1) { alloc((void **)&e->sl_stat, 3 * S * cfg->slices * 4 * sizeof(int), 0);      /* one history per picture kind: P, B reference, B */ alloc((void **)&e->sl_rerun, S * cfg->slices * sizeof(int), 0); }
 #ifdef MB_PROF
     alloc((void **)&e->prof, S * 16 * sizeof(unsigned long long), 0);
 #endif
@@ -401,7 +401,8 @@ static int encode_core(x264gpu_encoder *e, const uint8_t *d_i420, const x264gpu_
     k.colref_cur = e->colref[cur]; k.colmv_cur = e->colmv[cur];
     e->slot_nref[cur] = k.nref; e->slot_poc[cur] = e->poc; e->slot_ref0poc[cur] = k.nref ? e->slot_poc[s0] : 0;
     k.prof = e->prof; k.tc = e->tc; k.amvd = e->amvd; k.cab_out = e->cab_out;
-    k.sl_stat = slice_type != X264GPU_SLICE_I ? e->sl_stat : nullptr; k.sl_rerun = e->sl_rerun; k.sl_pass = 0;
+    k.sl_stat = slice_type != X264GPU_SLICE_I && e->sl_stat ? e->sl_stat + (size_t)(!bslice ? 0 : pic.keep ? 1 : 2) * S * (size_t)e->cfg.slices * 4 : nullptr;      // the first guess: the last picture of the same kind
+    k.sl_rerun = e->sl_rerun; k.sl_pass = 0;
     k.trellis = e->cfg.trellis; k.tr_su = nullptr; k.tr_tu = nullptr; k.tr_l2 = nullptr;
     if (k.trellis) { const int rc = trellis_table_ptrs(&k.tr_su, &k.tr_tu, &k.tr_l2); if (rc != X264GPU_OK) return rc; }
     k.lowres_mv = e->lowres_mv; k.lowres_mv1 = e->lowres_mv1; k.fast_pskip = e->cfg.fast_pskip; k.mv_range = e->cfg.mv_range;

@@ -60,6 +60,7 @@ struct x264_t {
         double qpa_last = 0;                        // quantiser of the picture whose size arrives next (ratecontrol_end)
     } rc;
     bool abr = false;
+    double t_b[5] = { 0, 0, 0, 0, 0 };          // ... sessions on the DPB model: slice-type analysis, GPU hot path, download, entropy coding, pictures
     double t_phase[6] = { 0, 0, 0, 0, 0, 0 };   // X264GPU_HOST_TIMING=1: seconds in copy-in, upload + lookahead, GPU, download, entropy coding, calls
     // ---- lookahead queue (threads 1): pictures wait here rc-lookahead deep when the macroblock-tree needs to see what follows them ----
     struct QEntry { int64_t pts; int slot; int type; int scenecut; int32_t costs[4]; x264_image_t img; int qp; int buf; bool launched; };      // type: 0 P, 1 I, 2 IDR; qp / buf / launched: set by gpu_stage
@@ -428,8 +429,7 @@ x264_t *x264_encoder_open(x264_param_t *param)
         if (why) { xlog(&p, X264_LOG_WARNING, "B-frames need %s in the MI355X path: bframes 0\n", why); p.i_bframe = 0; }
     }
     if (p.i_bframe) {
-        if (p.i_bframe_adaptive > 1) { xlog(&p, X264_LOG_WARNING, "b-adapt 2 (the trellis over picture types) is not implemented in the MI355X path: b-adapt 1\n"); p.i_bframe_adaptive = 1; }
-        p.i_bframe_adaptive = p.i_bframe_adaptive != 0;
+        p.i_bframe_adaptive = clampi(p.i_bframe_adaptive, 0, 2);
         if (p.i_bframe_pyramid == 1) { xlog(&p, X264_LOG_INFO, "b-pyramid strict -> normal\n"); p.i_bframe_pyramid = 2; }
         if (p.i_bframe < 2) p.i_bframe_pyramid = 0;
         if (p.b_open_gop) { xlog(&p, X264_LOG_WARNING, "open-gop is not implemented in the MI355X path: closed GOPs\n"); p.b_open_gop = 0; }
@@ -599,6 +599,8 @@ x264_t *x264_encoder_open(x264_param_t *param)
         h->pipeline = false; h->Q = h->L + 2 * (h->bframes + 1) + 2;      // the lookahead window + display-order queue + the mini-GOP being coded
     }
     h->st_wait = h->bframes > h->L ? h->bframes : h->L;
+    // x264 h->frames.i_delay: the trellis over picture types looks max(bframes, 3) * 4 pictures ahead
+    if (h->dpbmode && h->bframes && p.i_bframe_adaptive == 2) { const int d = (h->bframes > 3 ? h->bframes : 3) * 4; if (d > h->st_wait) h->st_wait = d; if (h->Q < h->st_wait + 2 * (h->bframes + 1) + 2) h->Q = h->st_wait + 2 * (h->bframes + 1) + 2; }
     h->last_keyframe = -p.i_keyint_max;
     h->badapt = h->bframes ? p.i_bframe_adaptive : 0;
     // (sessions with a fixed picture structure — no scenecut, b-adapt 0, no mbtree — run without the lookahead object: no fade weights and no
@@ -1163,7 +1165,7 @@ static bool st_scenecut(StFrames &F, int p0, int p1, bool real, int num_frames, 
 {
     x264_t *h = F.h;
     if (real && h->bframes) {
-        const int origmaxp1 = p0 + 2, maxp1 = origmaxp1 < num_frames ? origmaxp1 : num_frames;
+        const int origmaxp1 = p0 + 1 + (h->badapt == 2 ? h->bframes : 1), maxp1 = origmaxp1 < num_frames ? origmaxp1 : num_frames;      // the trellis may put bframes pictures between p0 and p1
         for (int curp1 = p1; curp1 <= maxp1; curp1++)
             if (!st_scenecut_internal(F, p0, curp1))
                 for (int i = curp1; i > p0; i--) F.f[(size_t)i]->b_scenecut = 0;          // nothing between p0 and curp1 can be a real scene cut
@@ -1227,6 +1229,68 @@ static void st_macroblock_tree(x264_t *h, StFrames &F, int num_frames, bool b_in
     if (h->bpyramid && bframes > 1) finish(last_nonb + (bframes + 1) / 2);
 }
 
+// x264 slicetype_path_cost: the cost of coding frames[1 ..] with the types in `path` ('P' / 'B' / 'I' per picture) — each non-B picture against the one
+// before it, the B pictures between them against both (through the middle one under b-pyramid); stops early beyond `threshold`
+static uint64_t st_path_cost(StFrames &F, const char *path0, uint64_t threshold)
+{
+    x264_t *h = F.h;
+    uint64_t cost = 0;
+    int loc = 1, cur_nonb = 0;
+    const char *path = path0 - 1;          // the first path element is the second frame
+    while (path[loc]) {
+        int next_nonb = loc;
+        while (path[next_nonb] == 'B') next_nonb++;
+        cost += path[next_nonb] == 'P' ? st_cost(F, cur_nonb, next_nonb, next_nonb) : st_cost(F, next_nonb, next_nonb, next_nonb);
+        if (cost > threshold || h->failed) break;
+        if (h->bpyramid && next_nonb - cur_nonb > 2) {
+            const int middle = cur_nonb + (next_nonb - cur_nonb) / 2;
+            cost += st_cost(F, cur_nonb, next_nonb, middle);
+            for (int next_b = loc; next_b < middle && cost < threshold; next_b++) cost += st_cost(F, cur_nonb, middle, next_b);
+            for (int next_b = middle + 1; next_b < next_nonb && cost < threshold; next_b++) cost += st_cost(F, middle, next_nonb, next_b);
+        } else
+            for (int next_b = loc; next_b < next_nonb && cost < threshold; next_b++) cost += st_cost(F, cur_nonb, next_nonb, next_b);
+        loc = next_nonb + 1;
+        cur_nonb = next_nonb;
+    }
+    return cost;
+}
+
+// x264 slicetype_path (--b-adapt 2): the best way to code the first `length` pictures ends in 0 .. bframes B pictures and a P picture behind the
+// best way to code the pictures in front of them (Viterbi over the lengths; best_paths is indexed by length modulo 17)
+constexpr int ST_PATH_MAX = 96;
+static void st_path(StFrames &F, int length, char (*best_paths)[ST_PATH_MAX + 1])
+{
+    x264_t *h = F.h;
+    char paths[2][ST_PATH_MAX + 1];
+    const int num_paths = h->bframes + 1 < length ? h->bframes + 1 : length;
+    uint64_t best_cost = ~0ull >> 1;
+    int best_possible = 0, idx = 0;
+    memset(paths, 0, sizeof(paths));
+    for (int path = 0; path < num_paths; path++) {
+        const int len = length - (path + 1);
+        memcpy(paths[idx], best_paths[len % 17], (size_t)len);
+        memset(paths[idx] + len, 'B', (size_t)path);
+        paths[idx][len + path] = 'P'; paths[idx][len + path + 1] = 0;
+        int possible = 1;
+        for (int i = 1; i <= length; i++) {
+            const int t = F.f[(size_t)i]->type;
+            if (t == ST_AUTO) continue;
+            if (t == ST_B || t == ST_BREF) possible = possible && (i < len || i == length || paths[idx][i - 1] == 'B');
+            else {
+                possible = possible && (i < len || paths[idx][i - 1] != 'B');
+                paths[idx][i - 1] = t == ST_I || t == ST_IDR ? 'I' : 'P';
+            }
+        }
+        if (possible || !best_possible) {
+            if (possible && !best_possible) best_cost = ~0ull >> 1;
+            const uint64_t cost = st_path_cost(F, paths[idx], best_cost);
+            if (cost < best_cost) { best_cost = cost; best_possible = possible; idx ^= 1; }
+        }
+    }
+    memcpy(best_paths[length % 17], paths[idx ^ 1], (size_t)length);
+    best_paths[length % 17][length] = 0;
+}
+
 static void st_analyse(x264_t *h, StFrames &F, int framecnt, bool keyframe = false)
 {
     const x264_param_t &p = h->param;
@@ -1248,7 +1312,23 @@ static void st_analyse(x264_t *h, StFrames &F, int framecnt, bool keyframe = fal
     }
     int num_bframes = 0, reset_start, num_analysed = num_frames;
     if (h->bframes) {
-        if (h->badapt == 1) {
+        if (h->badapt == 2) {
+            if (num_frames > ST_PATH_MAX) num_frames = ST_PATH_MAX;
+            if (num_frames > 1) {
+                static thread_local char best_paths[17][ST_PATH_MAX + 1];
+                memset(best_paths, 0, sizeof(best_paths));
+                best_paths[1][0] = 'P';
+                const int best_path_index = num_frames % 17;
+                for (int j = 2; j <= num_frames && !h->failed; j++) st_path(F, j, best_paths);
+                if (h->failed) return;
+                for (int j = 1; j < num_frames; j++) {
+                    if (best_paths[best_path_index][j - 1] != 'B') { if (type(j) == ST_AUTO || type(j) == ST_B || type(j) == ST_BREF) type(j) = ST_P; }
+                    else if (type(j) == ST_AUTO) type(j) = ST_B;
+                }
+            }
+            if (type(num_frames) == ST_AUTO || type(num_frames) == ST_B || type(num_frames) == ST_BREF) type(num_frames) = ST_P;
+            while (num_bframes < num_frames && type(num_bframes + 1) == ST_B) num_bframes++;
+        } else if (h->badapt == 1) {
             const int mbw = h->mbw, mbh = h->mbh, i_mb_count = mbw > 2 && mbh > 2 ? (mbw - 2) * (mbh - 2) : mbw * mbh;
             for (int i = 0; i <= num_frames - 2;) {
                 const int cost2p1 = st_cost(F, i, i + 2, i + 2);
@@ -1443,7 +1523,12 @@ static int bmode_qp(x264_t *h, const x264_t::BPlanned &pl, const DpbPlan &plan, 
 static int encode_bmode(x264_t *h, x264_nal_t **pp_nal, int *pi_nal, x264_picture_t *pic_out, bool flushing)
 {
     const x264_param_t &p = h->param;
-    if (!bmode_decide(h, flushing)) return 0;
+    auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    double tb0 = now(), tb1 = 0;
+    auto BPHASE = [&](int i) { tb1 = now(); h->t_b[i] += tb1 - tb0; tb0 = tb1; };
+    const bool decided = bmode_decide(h, flushing);
+    BPHASE(0);
+    if (!decided) return 0;
     const x264_t::BPlanned pl = h->bcoding.front();
     h->bcoding.pop_front();
     // the disposable pictures coded right behind this one (x264_reference_hierarchy_reset looks at them)
@@ -1473,13 +1558,14 @@ static int encode_bmode(x264_t *h, x264_nal_t **pp_nal, int *pi_nal, x264_pictur
             return -1;
         }
     } else
-    if (x264gpu_encode_pictures(h->gpu, h->q_raw[(size_t)pl.e.slot], &pic, h->d_mb, h->d_lv, nullptr) != X264GPU_OK ||
+    if (x264gpu_encode_pictures(h->gpu, h->q_raw[(size_t)pl.e.slot], &pic, h->d_mb, h->d_lv, nullptr) != X264GPU_OK || (getenv("X264GPU_HOST_TIMING") && (x264gpu_stream_sync(nullptr), BPHASE(1), false)) ||
         x264gpu_memcpy_d2h(h->h_mb.data(), h->d_mb, h->h_mb.size() * sizeof(x264gpu_mb), nullptr) != X264GPU_OK ||
         x264gpu_memcpy_d2h(h->h_lv.data(), h->d_lv, h->h_lv.size() * sizeof(int16_t), nullptr) != X264GPU_OK) {
         xlog(&p, X264_LOG_ERROR, "x264_encoder_encode: GPU hot path failed: %s\n", x264gpu_last_error());
         h->failed = true;
         return -1;
     }
+    BPHASE(2);
     if (plan.nal_ref_idc) { h->slot_qp_rc[pic.dst] = qpf; h->slot_ptype[pic.dst] = pl.type; }
     h->last_scenecut = pl.e.scenecut; h->last_qp = pic.qp;
     memcpy(h->last_costs, pl.e.costs, sizeof(pl.e.costs));
@@ -1524,6 +1610,8 @@ static int encode_bmode(x264_t *h, x264_nal_t **pp_nal, int *pi_nal, x264_pictur
         h->rc.cplxr_sum += bits * (0.85 * pow(2.0, (qpf - 12.0) / 6.0)) / (h->rc.last_rceq * (is_b ? pb : 1.0));
         h->rc.wanted_bits_window += h->rc.bitrate / h->rc.fps;
     }
+    BPHASE(3);
+    h->t_b[4] += 1;
     if (idr) h->idr_pic_id = (h->idr_pic_id + 1) & 0xffff;
     h->coded_count++;
     h->frame_no++;
@@ -1646,6 +1734,9 @@ void x264_encoder_close(x264_t *h)
     if (getenv("X264GPU_HOST_TIMING") && h->t_phase[5] > 0)
         fprintf(stderr, "x264gpu host timing, ms per call over %.0f calls: copy-in %.2f, upload+lookahead %.2f, GPU %.2f, download %.2f, entropy %.2f\n", h->t_phase[5],
                 1e3 * h->t_phase[0] / h->t_phase[5], 1e3 * h->t_phase[1] / h->t_phase[5], 1e3 * h->t_phase[2] / h->t_phase[5], 1e3 * h->t_phase[3] / h->t_phase[5], 1e3 * h->t_phase[4] / h->t_phase[5]);
+    if (getenv("X264GPU_HOST_TIMING") && h->t_b[4] > 0)
+        fprintf(stderr, "x264gpu host timing (DPB model), ms per picture over %.0f pictures: slice-type analysis %.2f, GPU hot path %.2f, download %.2f, entropy coding %.2f\n", h->t_b[4],
+                1e3 * h->t_b[0] / h->t_b[4], 1e3 * h->t_b[1] / h->t_b[4], 1e3 * h->t_b[2] / h->t_b[4], 1e3 * h->t_b[3] / h->t_b[4]);
     if (h->batch) { batch_leave(h->batch, h->batch_idx); h->batch = nullptr; }
     if (h->gpu) x264gpu_encoder_destroy(h->gpu);
     if (h->d_in) x264gpu_free(h->d_in);
