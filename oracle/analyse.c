@@ -2147,7 +2147,8 @@ static void macroblock_body(x264o_encoder *e, int mbx, int mby, actx *a)
 
     /* ---- P / B slice ---- */
     a->cost_mv = x264o_cost_mv_for(e, a->qp);
-    a->chroma_me = e->cfg.chroma_me && a->subme >= 5;
+    /* x264_macroblock_thread_init: b_chroma_me = --chroma-me && (P slice && subme >= 5 || B slice && subme >= 9) */
+    a->chroma_me = e->cfg.chroma_me && a->subme >= (e->slice_type == X264GPU_SLICE_B ? 9 : 5);
     {   /* motion vector limits (x264_analyse_init: mv_min / mv_max, _spel clipped to --mvrange, _fpel inside the padded picture) */
         const int fr = 4 * (e->cfg.mv_range > 0 ? e->cfg.mv_range : 512);
         a->mv_min[0] = 4 * (-16 * mbx - 24); a->mv_max[0] = 4 * (16 * (e->mbw - mbx - 1) + 24);

@@ -424,7 +424,7 @@ x264_t *x264_encoder_open(x264_param_t *param)
     } else if (!p.b_sliced_threads) p.i_slice_count = 0;
     p.i_threads = clampi(p.i_threads, 1, 256);                 // --threads G: GOPs coded in lock-step (1 = no delay)
     if (p.i_bframe) {
-        const char *why = !p.b_cabac ? "CABAC" : p.analyse.i_subpel_refine < 6 ? "subme >= 6" :
+        const char *why = !p.b_cabac ? "CABAC" : p.analyse.i_subpel_refine < 7 ? "subme >= 7 (x264 analyses B slices one sub-pel level down: at subme 6 without RD, which this path does not have for B slices)" :
                           p.i_threads > 1 ? "threads 1" : p.i_keyint_max < 2 ? "keyint > 1" : (p.rc.i_rc_method == X264_RC_ABR && (p.rc.b_stat_read || p.rc.i_bitrate <= 0)) ? "constant-quantiser, CRF or single-pass ABR rate control" : nullptr;
         if (why) { xlog(&p, X264_LOG_WARNING, "B-frames need %s in the MI355X path: bframes 0\n", why); p.i_bframe = 0; }
     }
