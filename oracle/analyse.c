@@ -2163,8 +2163,9 @@ static void macroblock_body(x264o_encoder *e, int mbx, int mby, actx *a)
     const int mi_in_slice = a->mi - e->row0 * e->mbw;            /* h->mb.i_mb_xy - h->sh.i_first_mb */
     if (a->b_early_terminate && mi_in_slice > 4) {
         const int colo = e->slice_type == X264GPU_SLICE_P ? e->mbtype[ref_slot(e, 0)][a->mi] : -1;      /* the co-located type counts in P slices only */
-        if (!(is_intra_type(a->type_left) || is_intra_type(a->type_top) || is_intra_type(a->type_tl) || is_intra_type(a->type_tr) ||
-              is_intra_type(colo) || mi_in_slice < 3 * e->intra_count)) a->b_fast_intra = 1;
+        /* (x264: "always run in fast-intra mode for subme < 3") */
+        if (!(a->subme > 2 && (is_intra_type(a->type_left) || is_intra_type(a->type_top) || is_intra_type(a->type_tl) || is_intra_type(a->type_tr) ||
+              is_intra_type(colo) || mi_in_slice < 3 * e->intra_count))) a->b_fast_intra = 1;
     }
     if (e->slice_type == X264GPU_SLICE_B) { macroblock_b(a, mb, lv); return; }
     a->cur_valid = 0;

@@ -1590,8 +1590,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(MB_WAVES_PER
             if (early_term && mbi - mb_first > 4) {
                 const int colo = BS ? -1 : uni((int)k.mbtype_ref0[(size_t)s * k.nmb + mbi]);      // the co-located type counts in P slices only
                 const bool near_intra = intra_t(type_left) || intra_t(type_top) || intra_t(type_tl) || intra_t(type_tr) || intra_t(colo);
-                fast_intra = !(near_intra || mbi - mb_first < 3 * intra_count);
-                if (k.sl_stat && !near_intra && lane == 0) {
+                fast_intra = !(c.subme > 2 && (near_intra || mbi - mb_first < 3 * intra_count));      // (x264: always fast-intra below subme 3)
+                if (k.sl_stat && c.subme > 2 && !near_intra && lane == 0) {
                     const int prior = L.slw[2], need = (mbi - mb_first) / 3 + 1 - (intra_count - prior);      // the smallest prior count that makes "a third so far are intra" true
                     if (prior >= need) L.slw[0] = max(L.slw[0], need); else L.slw[1] = min(L.slw[1], need);
                 }
