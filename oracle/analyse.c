@@ -1140,6 +1140,8 @@ static void analyse_intra(actx *a, int i_satd_inter)
     const pixel *fenc = e->fenc_y + (size_t)a->mby * 16 * e->fs + a->mbx * 16;
     pixel *rec = luma_plane(e, e->cur, 0) + (size_t)a->mby * 16 * e->rs + a->mbx * 16;
     const int parts = (e->slice_type == X264GPU_SLICE_I && (e->cfg.partitions & 0x100)) ? (e->cfg.partitions >> 8) & 6 : e->cfg.partitions & 7;
+    /* B slices: the macroblock type prefix of an intra type enters its SATD cost (x264 i_mb_b_cost_table[I_4x4 / I_8x8 / I_16x16] = 9) */
+    const int b_type_cost = e->slice_type == X264GPU_SLICE_B ? 9 * lambda : 0;
     pixel save[256], pred[256];
     for (int y = 0; y < 16; y++) memcpy(save + y * 16, rec + y * e->rs, 16);
     /* ---- 16x16: V, H, DC first; plane only if one of them was useful ---- */
@@ -1169,13 +1171,14 @@ static void analyse_intra(actx *a, int i_satd_inter)
                 if (c < a->satd_i16) { a->satd_i16 = c; a->pred16 = m; }
             }
         }
+        a->satd_i16 += b_type_cost;
         if (a->satd_i16 > i16x16_thresh) return;
     }
     /* ---- 8x8 ---- */
     if ((parts & 4) && e->cfg.dct8x8) {
         /* under RD every 8x8 block is analysed: the RD cost decides, not the running SATD sum */
         const int i_satd_thresh = a->mbrd ? COST_MAX : i_satd_inter < a->satd_i16 ? i_satd_inter : a->satd_i16;
-        int i_cost = lambda * 4, idx;
+        int i_cost = lambda * 4 + b_type_cost, idx;
         uint8_t m8[16];
         int16_t lvtmp[256]; uint32_t nnztmp = 0;
         memset(m8, 2, sizeof(m8));
@@ -1227,7 +1230,7 @@ static void analyse_intra(actx *a, int i_satd_inter)
     }
     /* ---- 4x4 ---- */
     if (parts & 2) {
-        int i_cost = lambda * (24 + 16), idx;
+        int i_cost = lambda * (24 + 16) + b_type_cost, idx;
         int i_satd_thresh = COST_MAX;
         if (a->b_early_terminate) { i_satd_thresh = i_satd_inter < a->satd_i16 ? i_satd_inter : a->satd_i16; if (a->satd_i8 < i_satd_thresh) i_satd_thresh = a->satd_i8; }
         if (a->b_early_terminate && a->mbrd) i_satd_thresh = (int)((int64_t)i_satd_thresh * (10 - a->b_fast_intra) / 8);      /* RD: a little slack, the SATD order is not final */

@@ -956,6 +956,7 @@ __device__ __forceinline__ void mb_analyse_intra(const EncK &k, MbLds<M> &L, con
     const int lane = c.lane, j = lane & 3, zx = z_x0(lane), zy = z_y(lane), lambda = c.lambda;
     const bool left = c.mbx > 0, top = c.sy > 0, topright = top && c.mbx + 1 < k.mbw;
     const int sm = min(c.subme, 10);
+    const int b_type_cost = k.slice_type == X264GPU_SLICE_B ? 9 * lambda : 0;      // B slices: the macroblock type prefix of an intra type (x264 i_mb_b_cost_table[I_*] = 9)
     uint8_t *tile = L.tile + IT_ORG, *tile8 = L.tile8 + IT_ORG;
     R.satd_i16 = R.satd_i8 = R.satd_i4 = MB_COST_MAX; R.pred16 = 0; R.nnz4 = R.nnz8 = 0; R.cbp8 = 0;
     // ---- 16x16 ----
@@ -976,6 +977,7 @@ __device__ __forceinline__ void mb_analyse_intra(const EncK &k, MbLds<M> &L, con
             { const int cst = cost16(m0); if (cst < R.satd_i16) { R.satd_i16 = cst; R.pred16 = m0; } }
             if (left || top) { const int cst = cost16(m1); if (cst < R.satd_i16) { R.satd_i16 = cst; R.pred16 = m1; } }
         }
+        R.satd_i16 += b_type_cost;
         if (R.satd_i16 > thresh16) return;
     }
     // ---- 8x8: R8 layout, lane = (mode group, row); eight modes in one pass, the ninth in a second ----
@@ -983,7 +985,7 @@ __device__ __forceinline__ void mb_analyse_intra(const EncK &k, MbLds<M> &L, con
         const int thresh = mbrd ? MB_COST_MAX : min(i_satd_inter, R.satd_i16);       // RD: every block is analysed
         const int g = lane >> 3, r8 = lane & 7;
         if (lane < 16) L.modes8[lane] = 2;
-        int i_cost = lambda * 4, idx;
+        int i_cost = lambda * 4 + b_type_cost, idx;
         for (idx = 0;; idx++) {
             const int x8 = idx & 1, y8 = idx >> 1, avail = i8_avail(left, top, topright, idx);
             lds_sync();
@@ -1069,7 +1071,7 @@ __device__ __forceinline__ void mb_analyse_intra(const EncK &k, MbLds<M> &L, con
         int thresh = early_term ? min(min(i_satd_inter, R.satd_i16), R.satd_i8) : MB_COST_MAX;
         if (early_term && mbrd) thresh = (int)((long long)thresh * (fast_intra ? 9 : 10) / 8);       // RD: a little slack, the SATD order is not final
         if (lane < 16) L.modes4[lane] = 2;
-        int i_cost = lambda * (24 + 16), idx;
+        int i_cost = lambda * (24 + 16) + b_type_cost, idx;
         for (idx = 0;; idx++) {
             const int bx = z_bx(idx), by = z_by(idx);
             const int avail = i4_avail(c.mbx, c.sy, k.mbw, idx);
