@@ -2115,7 +2115,11 @@ static void macroblock_body(x264o_encoder *e, int mbx, int mby, actx *a)
     int16_t *lv = e->levels + (size_t)a->mi * X264GPU_MB_LEVELS;
     memset(mb, 0, sizeof(*mb));
     memset(lv, 0, X264GPU_MB_LEVELS * sizeof(int16_t));
-    a->qp = e->mbqp[a->mi]; a->qpc = x264o_chroma_qp[clampi(a->qp + e->cfg.chroma_qp_offset, 0, 51)];
+    a->qp = e->mbqp[a->mi];
+    /* x264_macroblock_analyse: under AQ a quantiser within 1 of the previous macroblock's becomes that one (a cheaper mb_qp_delta); QPRD
+     * (subme >= 10, not built) would switch this off */
+    if (e->cfg.aq_mode && abs(a->qp - e->last_qp) == 1) a->qp = e->last_qp;
+    a->qpc = x264o_chroma_qp[clampi(a->qp + e->cfg.chroma_qp_offset, 0, 51)];
     a->lambda = x264o_lambda(a->qp);
     a->subme = clampi(e->cfg.subme, 0, 11); a->satd = a->subme > 1;
     a->nref = e->nref;

@@ -422,7 +422,7 @@ static int encode_core(x264gpu_encoder *e, const uint8_t *d_i420, const x264gpu_
     // per-macroblock quantisers: always materialised (the macroblock loop reads every quantiser-dependent value per macroblock)
     const bool aq = e->cfg.aq_mode != 0 || e->ext_off != nullptr || e->use_stream_qp;
     k.stream_qp = e->use_stream_qp ? e->stream_qp + (size_t)e->stream_qp_sel * e->cfg.streams : nullptr;
-    k.mbqp = e->mbqp; k.q4tab = e->q4tab; k.q8tab = e->q8tab; k.lambda_tab = e->lambda_tab; k.cost_all = e->cost_all; k.aq_strength_q8 = e->cfg.aq_strength_q8;
+    k.mbqp = e->mbqp; k.q4tab = e->q4tab; k.q8tab = e->q8tab; k.lambda_tab = e->lambda_tab; k.cost_all = e->cost_all; k.aq_strength_q8 = e->cfg.aq_strength_q8; k.qp_snap = e->cfg.aq_mode != 0;
     if (e->ext_off || !e->cfg.aq_mode) hipLaunchKernelGGL(k_apply_qp_offsets, dim3((k.nmb + 255) / 256, S), dim3(256), 0, st, k, e->ext_off);
     else hipLaunchKernelGGL(k_aq, dim3((k.nmb + 15) / 16, S), dim3(256), 0, st, k);
     mask |= 1;

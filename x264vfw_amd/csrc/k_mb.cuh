@@ -1451,6 +1451,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(MB_WAVES_PER
         c.fenc = k.fenc_y + (size_t)s * k.fency_bytes + (size_t)c.py * k.fs + c.px;
         c.fuv = k.fenc_uv + (size_t)s * k.fencuv_bytes + (size_t)c.mby * 8 * k.fs + c.px;
         c.qp = __builtin_amdgcn_readfirstlane((int)k.mbqp[(size_t)s * k.nmb + mbi]);
+        if (k.qp_snap && abs(c.qp - last_qp) == 1) c.qp = last_qp;      // x264_macroblock_analyse under AQ: within 1 of the previous macroblock's quantiser = that quantiser
         c.qpc = (int)d_chroma_qp_table[min(max(c.qp + k.chroma_qp_offset, 0), 51)];
         c.lambda = k.lambda_tab[c.qp];
         c.subme = min(max(k.subme, 0), 11); c.satd = c.subme > 1; c.chroma_me = !BS && pslice && k.chroma_me && c.subme >= 5;      // (x264_macroblock_thread_init: B slices carry chroma in the sub-pel costs from subme 9 up only: never here)
