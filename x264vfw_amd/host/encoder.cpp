@@ -640,7 +640,7 @@ x264_t *x264_encoder_open(x264_param_t *param)
         h->rc.qcompress = p.rc.f_qcompress; h->rc.ip_factor = fabs(p.rc.f_ip_factor) > 0 ? fabs(p.rc.f_ip_factor) : 1.0;
         h->rc.ip_offset = 6.0 * log2(h->rc.ip_factor);
         if (p.rc.b_mb_tree) h->rc.qcompress = 1.0;                     // x264_ratecontrol_new: the tree does the complexity weighting, CRF shifts by 13.5 (1 - qcomp)
-        h->rc.rate_factor_constant = pow((double)h->nmb * 80.0, 1.0 - h->rc.qcompress) / qp2qscale(p.rc.f_rf_constant + (p.rc.b_mb_tree ? (1.0 - p.rc.f_qcompress) * 13.5 : 0.0));
+        h->rc.rate_factor_constant = pow((double)h->nmb * (h->bframes ? 120.0 : 80.0), 1.0 - h->rc.qcompress) / qp2qscale(p.rc.f_rf_constant + (p.rc.b_mb_tree ? (1.0 - p.rc.f_qcompress) * 13.5 : 0.0));
         h->rc.last_qscale_for[0] = h->rc.last_qscale_for[1] = qp2qscale(p.rc.f_rf_constant);
         h->rc.lmin = qp2qscale(p.rc.i_qp_min); h->rc.lmax = qp2qscale(p.rc.i_qp_max);
         double dur = p.i_fps_num ? (double)p.i_fps_den / p.i_fps_num : 0.04;
