@@ -186,7 +186,8 @@ typedef struct x264gpu_config {
     int chroma_qp_offset;
     int deadzone_inter, deadzone_intra;
     int dct_decimate;
-    int partitions;           /* P slices: bit0 p8x8 (16x8/8x16/8x8), bit1 i4x4, bit2 i8x8 (needs dct8x8).  I slices use the
+    int partitions;           /* P slices: bit0 p8x8 (16x8/8x16/8x8), bit1 i4x4, bit2 i8x8 (needs dct8x8); with bit8 set B slices take their 8x8 / 16x8 / 8x16
+                               * analysis from bit11 (--partitions b8x8) instead of bit0.  I slices use the
                                * same bits 1-2 unless bit8 is set, then bit9 = i4x4 and bit10 = i8x8 (x264 keeps separate
                                * analyse.intra / analyse.inter masks) */
     int dct8x8;               /* --8x8dct: adaptive 8x8 luma transform (High profile) */

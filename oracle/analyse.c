@@ -1571,6 +1571,8 @@ static void analyse_p_rd(actx *a, int i_satd, x264gpu_mb *mb, int16_t *lv)
  * B slices ([x264-upstream] encoder/analyse.c x264_macroblock_analyse, SLICE_TYPE_B branch with i_mbrd 1: x264_mb_predict_mv_direct16x16
  * (spatial), x264_mb_analyse_inter_direct / _b16x16 / _b8x8_mixed_ref / _b8x8 / _b16x8 / _b8x16, x264_mb_analyse_b_rd, x264_refine_bidir;
  * encoder/me.c x264_me_refine_bidir_satd).  Restated from memory (oracle/BFRAME_NOTES.md): parity unpinned.  RD sessions only. */
+/* B slices: --partitions b8x8 (x264 X264_ANALYSE_BSUB16x16) is bit 11 of cfg.partitions when bit 8 marks the extended set; else as p8x8 */
+static int b_sub16x16(const x264o_encoder *e) { return (e->cfg.partitions & 0x100) ? (e->cfg.partitions >> 11) & 1 : e->cfg.partitions & 1; }
 static const uint8_t mb_b_cost_direct = 1, mb_b_cost_l0 = 3, mb_b_cost_l1 = 3, mb_b_cost_bi = 5, mb_b_cost_8x8 = 9;      /* i_mb_b_cost_table */
 static const uint8_t sub_b_cost[4] = { 3, 3, 5, 1 };                          /* i_sub_mb_b_cost_table: L0_8x8, L1_8x8, BI_8x8, DIRECT_8x8 */
 /* i_mb_b16x8_cost_table[B_L0_L0 + 3 * first + second]: first / second half from list 0, list 1, both */
@@ -1698,7 +1700,7 @@ static void analyse_inter_direct(actx *a)
     const pixel *rec = luma_plane((x264o_encoder *)e, e->cur, 0) + (size_t)a->mby * 16 * e->rs + a->mbx * 16;
     const pixel *ruv = chroma_plane((x264o_encoder *)e, e->cur) + (size_t)a->mby * 8 * e->rs + a->mbx * 16;
     a->cost16x16direct = a->lambda * mb_b_cost_direct;
-    if (e->cfg.partitions & 1) {
+    if (b_sub16x16(e)) {
         for (int i = 0; i < 4; i++) {
             const int x = (i & 1) * 8, y = (i >> 1) * 8;
             a->cost8x8direct[i] = mbcmp(a, fenc + y * e->fs + x, e->fs, rec + y * e->rs + x, e->rs, 8, 8);
@@ -2009,7 +2011,7 @@ static void macroblock_b(actx *a, x264gpu_mb *mb, int16_t *lv)
             return;
         }
     }
-    if (e->cfg.partitions & 1) {
+    if (b_sub16x16(e)) {
         analyse_inter_b8x8(a);
         if (a->cost8x8bi < i_cost) { i_cost = a->cost8x8bi; i_type = X264GPU_MB_B_8x8; i_partition = D_8x8; }
         /* estimates of the two-partition shapes from the SATD scores of the 8x8 blocks: the likelier one is analysed first */

@@ -42,6 +42,8 @@ def run(w, h, types, seed, bframes=3, pyramid=1, weightp=0, pics_out=None, weigh
     (176, 288, "IBBBPBBP", 14, dict(slices=3)),                                   # x264 slice threads: B pictures in three slices (not filtered across)
     (176, 144, "IBBPBP", 15, dict(slices=9, slices_plain=1)),                     # --slices 9: one slice a macroblock row, filtered across
     (96, 160, "IBPBBP", 16, dict(slices=4, slices_plain=1, refs=2)),
+    (176, 144, "IBBPBP", 19, dict(partitions=0x707)),                             # p8x8 without b8x8
+    (176, 144, "IBBP", 20, dict(partitions=0xf06)),                               # b8x8 without p8x8
 ])
 def test_b_pictures_decode_to_the_encoders_reconstruction(w, h, types, seed, over):
     run(w, h, types, seed, **over)

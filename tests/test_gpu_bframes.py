@@ -76,6 +76,8 @@ def run(gpu, w, h, types, seed, streams=1, bframes=3, pyramid=1, weightp=0, weig
     (176, 144, "IBBPBP", 16, dict(slices=9, slices_plain=1)),                       # --slices 9: the picture-wide intra count behind the fast-intra decision (speculative passes, EncK.sl_stat)
     (96, 160, "IBPBBP", 17, dict(slices=4, slices_plain=1, refs=2)),
     (176, 288, "IBBBP", 18, dict(slices=4, me_method=2)),
+    (176, 144, "IBBPBP", 19, dict(partitions=0x707)),                               # --partitions p8x8,i8x8,i4x4 without b8x8: P slices split, B slices stay 16x16
+    (176, 144, "IBBP", 20, dict(partitions=0xf06)),                                 # ... and b8x8 without p8x8
 ])
 def test_b_pictures_bitexact_and_decodable(gpu, w, h, types, seed, over):
     run(gpu, w, h, types, seed, **over)

@@ -411,6 +411,7 @@ static int encode_core(x264gpu_encoder *e, const uint8_t *d_i420, const x264gpu_
     k.slice_type = slice_type;
     k.dct_decimate = e->cfg.dct_decimate || bslice;      // x264: B slices decimate whatever --no-dct-decimate says (h->mb.b_dct_decimate)
     k.partitions = (slice_type == X264GPU_SLICE_I && (e->cfg.partitions & 0x100)) ? (e->cfg.partitions >> 8) & 6 : e->cfg.partitions & 7;
+    if (bslice && (e->cfg.partitions & 0x100)) k.partitions = (k.partitions & 6) | ((e->cfg.partitions >> 11) & 1);      // --partitions b8x8 (bit 11) instead of p8x8
     k.dbg = e->dbg;
 
     hipEvent_t *ev = nullptr;

@@ -527,7 +527,8 @@ x264_t *x264_encoder_open(x264_param_t *param)
     cfg.dct_decimate = p.analyse.b_dct_decimate;
     // P slices follow analyse.inter, I slices analyse.intra (bit8 marks the separate I-slice set)
     cfg.partitions = ((p.analyse.inter & X264_ANALYSE_PSUB16x16) ? 1 : 0) | ((p.analyse.inter & X264_ANALYSE_I4x4) ? 2 : 0) | ((p.analyse.inter & X264_ANALYSE_I8x8) ? 4 : 0) |
-                     0x100 | ((p.analyse.intra & X264_ANALYSE_I4x4) ? 0x200 : 0) | ((p.analyse.intra & X264_ANALYSE_I8x8) ? 0x400 : 0);
+                     0x100 | ((p.analyse.intra & X264_ANALYSE_I4x4) ? 0x200 : 0) | ((p.analyse.intra & X264_ANALYSE_I8x8) ? 0x400 : 0) |
+                     ((p.analyse.inter & X264_ANALYSE_BSUB16x16) ? 0x800 : 0);      // B slices: b8x8
     cfg.dct8x8 = p.analyse.b_transform_8x8;
     cfg.me_method = p.analyse.i_me_method == X264_ME_DIA ? 0 : p.analyse.i_me_method == X264_ME_HEX ? 1 : p.analyse.i_me_method == X264_ME_UMH ? 2 : 3;
     cfg.aq_mode = p.rc.i_aq_mode == X264_AQ_VARIANCE; cfg.aq_strength_q8 = (int)(p.rc.f_aq_strength * 1.0397f * 256.0f + 0.5f);
