@@ -1005,7 +1005,7 @@ static void analyse_inter_p16x8(actx *a, int i_best_satd)
             if (m.cost < l0m->cost) *l0m = m;
         }
         /* early termination on the first half plus the estimate of the second */
-        if (a->b_early_terminate && !i && l0m->cost + a->cost_est16x8_1 > i_best_satd) { a->cost16x8 = COST_MAX; return; }
+        if (a->b_early_terminate && !i && l0m->cost + a->cost_est16x8_1 > i_best_satd * (4 + !!a->mbrd) / 4) { a->cost16x8 = COST_MAX; return; }
         cache_block(a, 0, i, 2, 1, l0m->ref, l0m->mv);
     }
     a->cost16x8 = a->me16x8[0].cost + a->me16x8[1].cost;
@@ -1034,7 +1034,7 @@ static void analyse_inter_p8x16(actx *a, int i_best_satd)
             m.cost += m.ref_cost;
             if (m.cost < l0m->cost) *l0m = m;
         }
-        if (a->b_early_terminate && !i && l0m->cost + a->cost_est8x16_1 > i_best_satd) { a->cost8x16 = COST_MAX; return; }
+        if (a->b_early_terminate && !i && l0m->cost + a->cost_est8x16_1 > i_best_satd * (4 + !!a->mbrd) / 4) { a->cost8x16 = COST_MAX; return; }
         cache_block(a, i, 0, 1, 2, l0m->ref, l0m->mv);
     }
     a->cost8x16 = a->me8x16[0].cost + a->me8x16[1].cost;
@@ -1903,7 +1903,7 @@ static void analyse_inter_b_halves(actx *a, int horizontal, int i_best_satd)
         if (i_part_cost_bi + a->lambda * 1 < i_part_cost) { i_part_cost = i_part_cost_bi; part[i] = 2; }
         *p_cost += i_part_cost;
         /* early termination: the first half plus the estimate of the second */
-        if (a->b_early_terminate && !i && i_part_cost + cost_est[1] > i_best_satd) { *p_cost = COST_MAX; return; }
+        if (a->b_early_terminate && !i && i_part_cost + cost_est[1] > i_best_satd * (16 + !!a->mbrd + (a->mbrd && e->cfg.psy_rd_q8 != 0)) / 16) { *p_cost = COST_MAX; return; }
         cache_b_block(a, bx8, by8, w8, h8, part[i], lm[0], lm[1], 0);
     }
     *p_cost += a->lambda * mb_b16x8_cost[part[0] * 3 + part[1]];

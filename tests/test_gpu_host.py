@@ -817,6 +817,58 @@ def test_b_session_through_the_encode_api(gpu, w, h, n, opts, pattern):
     assert [p for p in pocs] == [2 * (r[2] - max(q[2] for q in recs if q[1] and q[2] <= r[2])) for r in recs]
 
 
+def test_random_b_session_mixes_stay_decodable(gpu):
+    """host-API stress for the sessions on the DPB model: random picture sizes x random mixes of B-picture structure (bframes, b-adapt 0 / 1 / 2,
+    b-pyramid, weightb, weightp 0 / 1 / 2), references, searches, partitions (p8x8 / b8x8 apart), trellis, slices / slice threads, scene cuts, short
+    GOPs and every rate control mode that runs there (CQP, CRF with and without macroblock-tree, single-pass ABR, AQ on / off).  Every picture must
+    come back exactly once with a monotone dts, the stream must decode to as many pictures, and every decoded picture must resemble its source"""
+    rng = np.random.default_rng(20261003)
+    sizes = [(64, 48), (176, 144), (200, 104), (72, 136), (128, 96), (96, 80), (160, 128)]
+    for trial in range(int(__import__("os").environ.get("X264GPU_STRESS_TRIALS", "24"))):
+        w, h = sizes[int(rng.integers(len(sizes)))]
+        nfr = int(rng.integers(3, 20))
+        opts = {"bframes": int(rng.integers(0, 4)), "b-adapt": int(rng.integers(0, 3)), "ref": int(rng.integers(1, 5)),
+                "me": str(rng.choice(["dia", "hex", "umh", "esa"])), "merange": int(rng.choice([4, 8, 16])), "subme": int(rng.choice([7, 7, 7, 8, 9, 6])),
+                "keyint": int(rng.choice([2, 4, 9, 250])), "weightp": int(rng.integers(0, 3))}
+        if rng.random() < 0.3: opts["b-pyramid"] = str(rng.choice(["none", "normal", "strict"]))
+        if rng.random() < 0.3: opts["no-weightb"] = None
+        if rng.random() < 0.4: opts["partitions"] = str(rng.choice(["none", "all", "p8x8,i4x4", "b8x8,i8x8,i4x4", "p8x8,b8x8", "i8x8,i4x4"]))
+        if rng.random() < 0.3: opts["no-8x8dct"] = None
+        if rng.random() < 0.3: opts["no-deblock"] = None
+        if rng.random() < 0.3: opts["no-mixed-refs"] = None
+        if rng.random() < 0.3: opts["trellis"] = int(rng.integers(0, 3))
+        if rng.random() < 0.3: opts["no-psy"] = None
+        if rng.random() < 0.3: opts["direct"] = str(rng.choice(["spatial", "auto", "temporal"]))
+        if rng.random() < 0.3: opts["scenecut"] = int(rng.choice([0, 40, 80]))
+        if rng.random() < 0.25: opts["slices"] = int(rng.integers(2, 6))
+        elif rng.random() < 0.2 and h >= 128: opts.update({"sliced-threads": None, "threads": 2})
+        mode = str(rng.choice(["qp", "crf", "crf-tree", "abr"]))
+        if mode == "qp": opts["qp"] = int(rng.integers(14, 40))
+        elif mode == "abr": opts["bitrate"] = int(rng.integers(100, 1500)); opts["rc-lookahead"] = int(rng.integers(0, 12))
+        else:
+            opts["crf"] = int(rng.integers(16, 36))
+            if mode == "crf": opts["no-mbtree"] = None
+            else: opts["rc-lookahead"] = int(rng.integers(1, 12))
+        if rng.random() < 0.3: opts["aq-mode"] = int(rng.integers(0, 2))
+        opts["min-keyint"] = max(1, min(opts["keyint"], int(rng.integers(1, 4))))
+        frames = synth_frames(w, h, nfr, seed=3000 + trial)
+        if rng.random() < 0.4:                                               # a cut somewhere
+            frames[nfr // 2:] = synth_frames(w, h, nfr - nfr // 2, seed=7000 + trial)
+        tag = f"trial {trial}: {w}x{h} x{nfr} {opts}"
+        h_, eff = open_encoder(w, h, opts, profile=None)
+        stream, recs = encode_delayed(h_, w, h, frames)
+        H.x264_encoder_close(h_)
+        assert sorted(r[2] for r in recs) == list(range(nfr)), tag
+        dts = [r[3] for r in recs]
+        assert dts == sorted(dts) and all(r[3] <= r[2] for r in recs), tag
+        if not eff.i_bframe:
+            assert [r[2] for r in recs] == list(range(nfr)), tag
+        dec = O.h264_decode(stream, nfr, w, h)
+        assert len(dec) == nfr, tag
+        for d, r in zip(dec, recs):
+            assert psnr(d[:w * h], frames[r[2]][:w * h]) > 16.0, (tag, r)          # (noise content at quantisers up to 40: a floor that only garbage falls under)
+
+
 def test_cross_session_batcher_on_the_device(gpu):
     """X264GPU_BATCH=16: sixteen sessions from sixteen host threads, one lock-step launch per picture on the device; byte-identical to sixteen
     sessions run one after the other"""

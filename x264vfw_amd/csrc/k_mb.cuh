@@ -1807,7 +1807,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(MB_WAVES_PER
                     if (kk == 0 || cost < rl(S.cost, slot)) me_store(S, lane, slot, mvx, mvy, cost, cost_mv, r, rc, jb.mvpx, jb.mvpy);
                     if (++kk < nk) continue;
                     // this half is done; early termination on the first half plus the estimate of the second
-                    bool shape_done = part == 0 && early_term && rl(S.cost, slot) + est1 > i_cost;
+                    bool shape_done = part == 0 && early_term && rl(S.cost, slot) + est1 > i_cost * (4 + (rdon ? 1 : 0)) / 4;      // (RD sessions keep shapes within a quarter above the best)
                     if (!shape_done) {
                         {
                             const int g0 = stage == 2 ? (part + 1) * 4 + 1 : 5 + part, g1 = stage == 2 ? g0 + 1 : g0 + 4;
