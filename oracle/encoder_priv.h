@@ -10,7 +10,7 @@
 #define CPAD 16         /* chroma padding (samples) */
 #define MVCOST_HALF 32768
 #define X264O_MAX_REFS 8                         /* list 0 of a P slice: up to 5 pictures + the duplicates of --weightp 2 */
-#define X264O_MAX_SLOTS 80                       /* reference pictures of the DPB (cfg.dpb or cfg.refs) + the picture being built */
+#define X264O_MAX_SLOTS 128                      /* reference pictures of the DPB (cfg.dpb or cfg.refs) + the picture being built */
 #define COST_MAX (1 << 28)
 
 typedef struct x264o_encoder x264o_encoder;

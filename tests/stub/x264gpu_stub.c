@@ -92,7 +92,7 @@ struct x264gpu_slicetype { x264o_slicetype *st; };
 int x264gpu_slicetype_create(x264gpu_slicetype **out, int w, int h, int streams, int slots, int bframes, int me_method, int subme, int me_range, int weightb, int mv_range, int do_edges)
 {
     if (streams != 1) return fail("stub slicetype: one stream");
-    if (slots > 80) return fail("stub slicetype: at most 80 slots");
+    if (slots > 128) return fail("stub slicetype: at most 128 slots");
     x264gpu_slicetype *s = calloc(1, sizeof(*s));
     s->st = x264o_slicetype_create(w, h, slots, bframes, me_method, subme, me_range, weightb, mv_range, do_edges);
     *out = s;

@@ -370,6 +370,21 @@ def test_host_session_b_pictures_in_slices(tmp_path, opts, per_pic):
         assert psnr(d[:w * h], frames[r[1]][:w * h]) > 30.0
 
 
+def test_host_session_b8x8_reaches_the_b_slices(tmp_path):
+    """--partitions b8x8 (medium has it) must reach the analysis of B slices through x264_encoder_open: the stream with it differs from the stream
+    without it, from the first B picture on"""
+    import subprocess
+    subprocess.check_call(["make", "-s", "-C", __file__.rsplit("/", 1)[0] + "/stub"])
+    n, w, h = 10, 176, 144
+    base = ["qp=24", "keyint=30", "scenecut=0", "b-adapt=0"]
+    a, sa = _host_b_session(tmp_path, n, base + ["partitions=p8x8,b8x8,i8x8,i4x4"], w, h, seed=9)
+    b, sb = _host_b_session(tmp_path, n, base + ["partitions=p8x8,i8x8,i4x4"], w, h, seed=9)
+    assert sa != sb
+    assert [r[:4] for r in a["recs"]] == [r[:4] for r in b["recs"]]
+    assert [r[4] for r in a["recs"][:2]] == [r[4] for r in b["recs"][:2]]          # the I and the first P picture are coded before any B picture
+    assert any(ra[4] != rb[4] for ra, rb in zip(a["recs"], b["recs"]) if ra[0] in (4, 5))
+
+
 def test_host_session_single_pass_abr_with_b_pictures(tmp_path):
     """--bitrate N (x264vfw's single-pass ABR page, config.c / codec.c:x264vfw 'Single pass - bitrate-based (ABR)') keeps B pictures, the
     lookahead and macroblock-tree: the coded size of every picture, B pictures' divided by pbratio, steers the rate factor

@@ -19,7 +19,7 @@
 
 namespace x264gpu {
 
-constexpr int ST_MAX_B = 16, ST_MAX_SLOTS = 80;
+constexpr int ST_MAX_B = 16, ST_MAX_SLOTS = 128;
 constexpr int LOWRES_COST_MASK = (1 << 14) - 1, LOWRES_COST_SHIFT = 14;
 
 struct StK {

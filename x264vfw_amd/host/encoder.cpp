@@ -366,7 +366,7 @@ x264_t *x264_encoder_open(x264_param_t *param)
     // the fade analysis that produces other weights — x264_weights_analyse, all that --weightp 1 does — is not implemented)
     p.analyse.i_weighted_pred = clampi(p.analyse.i_weighted_pred, X264_WEIGHTP_NONE, X264_WEIGHTP_SMART); p.analyse.b_weighted_bipred = p.analyse.b_weighted_bipred != 0;
     p.analyse.b_transform_8x8 = p.analyse.b_transform_8x8 != 0;
-    p.analyse.inter &= X264_ANALYSE_I4x4 | X264_ANALYSE_I8x8 | X264_ANALYSE_PSUB16x16; p.analyse.intra &= X264_ANALYSE_I4x4 | X264_ANALYSE_I8x8;
+    p.analyse.inter &= X264_ANALYSE_I4x4 | X264_ANALYSE_I8x8 | X264_ANALYSE_PSUB16x16 | X264_ANALYSE_BSUB16x16; p.analyse.intra &= X264_ANALYSE_I4x4 | X264_ANALYSE_I8x8;
     if (!p.analyse.b_transform_8x8) { p.analyse.inter &= ~X264_ANALYSE_I8x8; p.analyse.intra &= ~X264_ANALYSE_I8x8; }   // as x264 validate_parameters
     p.analyse.i_trellis = clampi(p.analyse.i_trellis, 0, 2);          // settled below, once the sub-pel level is known
     p.i_scenecut_threshold = clampi(p.i_scenecut_threshold, 0, 100);
@@ -602,6 +602,13 @@ x264_t *x264_encoder_open(x264_param_t *param)
     h->st_wait = h->bframes > h->L ? h->bframes : h->L;
     // x264 h->frames.i_delay: the trellis over picture types looks max(bframes, 3) * 4 pictures ahead
     if (h->dpbmode && h->bframes && p.i_bframe_adaptive == 2) { const int d = (h->bframes > 3 ? h->bframes : 3) * 4; if (d > h->st_wait) h->st_wait = d; if (h->Q < h->st_wait + 2 * (h->bframes + 1) + 2) h->Q = h->st_wait + 2 * (h->bframes + 1) + 2; }
+    if (h->dpbmode && h->Q > 128) {          // the lookahead object holds 128 pictures
+        const int over = h->Q - 128;
+        xlog(&p, X264_LOG_INFO, "lookahead window shortened by %d pictures (128 pictures are held at most)\n", over);
+        h->L = h->L > over ? h->L - over : 0; p.rc.i_lookahead = h->L;
+        if (h->st_wait > 128 - 2 * (h->bframes + 1) - 2) h->st_wait = 128 - 2 * (h->bframes + 1) - 2;
+        h->Q = 128;
+    }
     h->last_keyframe = -p.i_keyint_max;
     h->badapt = h->bframes ? p.i_bframe_adaptive : 0;
     // (sessions with a fixed picture structure — no scenecut, b-adapt 0, no mbtree — run without the lookahead object: no fade weights and no
