@@ -25,6 +25,7 @@ def main():
     scene_len = int(opts.pop("scene_len", 0) or 0)
     static = int(opts.pop("static", 0) or 0)
     fade = int(opts.pop("fade", 0) or 0)
+    preset = (opts.pop("preset", None) or "medium").encode()
     frames = synth_frames(w, h, n, seed=seed, **({"scene_len": scene_len} if scene_len else {}))
     if fade:            # fades to black by `fade` per cent a picture (tests/test_bframes_cpu.py fade_frames)
         import numpy as np
@@ -39,7 +40,7 @@ def main():
         rng = np.random.default_rng(seed)
         frames = [np.clip(frames[0].astype(np.int16) + rng.integers(-1, 2, frames[0].shape), 0, 255).astype(np.uint8) for _ in range(n)]
     p = HL.Param()
-    assert H.x264_param_default_preset(C.byref(p), b"medium", None) == 0
+    assert H.x264_param_default_preset(C.byref(p), preset, None) == 0
     p.i_width, p.i_height, p.i_csp = w, h, HL.X264_CSP_I420
     p.i_fps_num, p.i_fps_den, p.i_log_level = 25, 1, -1
     for k, v in opts.items():
