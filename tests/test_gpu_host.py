@@ -869,6 +869,28 @@ def test_random_b_session_mixes_stay_decodable(gpu):
             assert psnr(d[:w * h], frames[r[2]][:w * h]) > 16.0, (tag, r)          # (noise content at quantisers up to 40: a floor that only garbage falls under)
 
 
+@pytest.mark.parametrize("preset", ["ultrafast", "superfast", "veryfast", "faster", "fast", "medium", "slow", "slower", "veryslow", "placebo"])
+def test_every_preset_codes_a_decodable_stream(gpu, preset):
+    """x264_param_default_preset(name) as the driver calls it (codec.c:1463) for each of x264's ten presets, rate control left at the driver's default
+    (CRF 23): the session opens, reports what it runs (B pictures from medium up: x264 analyses B slices without RD below subme 7; bframes 8 / 16 and
+    --b-adapt 2 in veryslow / placebo), returns every picture once and the stream decodes to the source"""
+    w, h, n = 176, 144, 36
+    frames = synth_frames(w, h, n, seed=31, scene_len=23)
+    h_, eff = open_encoder(w, h, {"bframes": {"ultrafast": 0, "veryslow": 8, "placebo": 16}.get(preset, 3), "weightp": {"ultrafast": 0, "superfast": 1, "veryfast": 1, "faster": 1, "fast": 1}.get(preset, 2)},
+                           profile=None, preset=preset.encode())
+    if preset in ("medium", "slow", "slower", "veryslow", "placebo"):
+        assert eff.i_bframe == {"veryslow": 8, "placebo": 16}.get(preset, 3) and eff.i_bframe_adaptive == (1 if preset in ("medium", "slow") else 2)
+    else:
+        assert eff.i_bframe == 0
+    stream, recs = encode_delayed(h_, w, h, frames)
+    H.x264_encoder_close(h_)
+    assert sorted(r[2] for r in recs) == list(range(n))
+    dec = O.h264_decode(stream, n, w, h)
+    assert len(dec) == n
+    for d, r in zip(dec, recs):
+        assert psnr(d[:w * h], frames[r[2]][:w * h]) > 26.0, (preset, r)
+
+
 def test_cross_session_batcher_on_the_device(gpu):
     """X264GPU_BATCH=16: sixteen sessions from sixteen host threads, one lock-step launch per picture on the device; byte-identical to sixteen
     sessions run one after the other"""
