@@ -143,3 +143,21 @@ def test_random_multi_stream_quantisers_bitexact(gpu, seed):
         for o in ogs:
             o.close()
         gg.close()
+
+
+@pytest.mark.parametrize("seed", [3, 57])
+def test_random_b_picture_configs_bitexact(gpu, seed):
+    """randomised B-picture streams (tools/fuzz_soak_b.py random_b_case: sizes, runs of B pictures with and without b-pyramid, references, search
+    methods and ranges, p8x8 / b8x8 apart, weightb, trellis 0 / 1 / 2, psy strengths, slices, --weightp 2): device = CPU checker picture by picture,
+    and the device's stream decodes to its reconstruction.  Seed 57's first case is the one a 1 250-case soak of this round found: the B search
+    must not move the half-pel threshold by the reference cost (x264's P search does, its B search does not)"""
+    import os
+    import random
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    from fuzz_soak_b import random_b_case
+    from test_gpu_bframes import run
+    rnd = random.Random(seed)
+    for it in range(12):
+        w, h, types, fseed, bframes, pyramid, weightp, kw = random_b_case(rnd)
+        run(gpu, w, h, types, fseed, bframes=bframes, pyramid=pyramid, weightp=weightp, **kw)

@@ -1,0 +1,70 @@
+"""Randomised parity soak of the B-picture path (and --weightp 2): python tools/fuzz_soak_b.py SEED0 SEED1 [cases per seed].
+Every case draws a picture size, a string of picture types (runs of 0..3 B pictures, with and without b-pyramid), a toolset around preset medium
+(references, search method and range, partitions with p8x8 / b8x8 apart, 8x8 transform, mixed references, weightb, trellis 0 / 1 / 2, psy strength,
+deblocking, slices as x264's slice threads or --slices N, the blind duplicate of --weightp 2) and quantisers; tests/test_gpu_bframes.py run()
+codes it on the device and on the CPU checker (records, levels, reconstruction, context variables) and decodes the device's stream.  Mismatches
+are listed, not fatal."""
+import os
+import random
+import sys
+import time
+import traceback
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+
+def random_b_case(rnd):
+    w = rnd.choice([64, 96, 128, 176, 208, 200, 72])
+    h = rnd.choice([48, 80, 96, 144, 112, 104, 136])
+    bframes = rnd.randint(1, 3)
+    types = "I"
+    while len(types) < rnd.randint(4, 9):
+        types += "B" * rnd.randint(0, bframes) + "P"
+    refs = rnd.randint(1, 4)
+    pyramid = rnd.randint(0, 1) if bframes > 1 else 0
+    kw = dict(refs=refs, dpb=max(refs, 4 if pyramid else 2, 2), weightb=rnd.randint(0, 1), mixed_refs=rnd.randint(0, 1), dct8x8=rnd.randint(0, 1),
+              me_method=rnd.choice([0, 1, 1, 2, 3]), me_range=rnd.choice([4, 8, 16]), trellis=rnd.choice([0, 63, 63, 127]), deblock=rnd.randint(0, 1) or 1,
+              fast_pskip=rnd.randint(0, 1) or 1, dct_decimate=rnd.randint(0, 1) or 1)
+    kw["partitions"] = rnd.choice([7, 7, 6, 0x707, 0xf06, 0xf07, 3, 5])
+    if not kw["dct8x8"]:
+        kw["partitions"] &= ~0x404
+    psy = rnd.randint(0, 1)
+    kw.update(psy=psy, psy_rd_q8=rnd.choice([26, 102, 256, 512]) if psy else 0, chroma_qp_offset=rnd.choice([0, -2, -1, 3]) if psy else rnd.choice([0, 2]))
+    if rnd.random() < 0.3:
+        mbh = (h + 15) // 16
+        if rnd.random() < 0.5 and mbh >= 8:
+            kw.update(slices=rnd.randint(2, mbh // 4))
+        else:
+            kw.update(slices=rnd.randint(2, mbh), slices_plain=1)
+    weightp = rnd.choice([0, 0, 2]) if refs >= 2 else 0
+    return w, h, types, rnd.randint(1, 10 ** 6), bframes, pyramid, weightp, kw
+
+
+def main():
+    import pytest  # noqa: F401  (tests/conftest fixtures are not used: run() takes the gpu argument for show)
+    from test_gpu_bframes import run
+    s0, s1 = int(sys.argv[1]), int(sys.argv[2])
+    per = int(sys.argv[3]) if len(sys.argv) > 3 else 20
+    bad = total = 0
+    t0 = time.time()
+    for seed in range(s0, s1):
+        rnd = random.Random(seed)
+        for it in range(per):
+            w, h, types, fseed, bframes, pyramid, weightp, kw = random_b_case(rnd)
+            total += 1
+            try:
+                run(None, w, h, types, fseed, bframes=bframes, pyramid=pyramid, weightp=weightp, **kw)
+            except AssertionError as e:
+                bad += 1
+                print(f"MISMATCH seed {seed} case {it}: {w}x{h} {types} bframes {bframes} pyramid {pyramid} weightp {weightp} {kw}: {str(e)[:300]}", flush=True)
+            except Exception:
+                bad += 1
+                print(f"ERROR seed {seed} case {it}: {w}x{h} {types} bframes {bframes} pyramid {pyramid} weightp {weightp} {kw}", flush=True)
+                traceback.print_exc()
+    print(f"{total} cases, {bad} bad, {time.time() - t0:.0f} s")
+
+
+if __name__ == "__main__":
+    main()
