@@ -45,6 +45,7 @@ def main():
     p.i_fps_num, p.i_fps_den, p.i_log_level = 25, 1, -1
     for k, v in opts.items():
         assert H.x264_param_parse(C.byref(p), k.encode(), None if v is None else str(v).encode()) == 0, (k, v)
+    p.b_vfr_input = 0                                                  # the driver forces constant frame rate (codec.c:1476-1480)
     p.b_annexb, p.b_repeat_headers = 1, 1
     h_ = H.x264_encoder_open_157(C.byref(p))
     assert h_

@@ -891,6 +891,49 @@ def test_every_preset_codes_a_decodable_stream(gpu, preset):
         assert psnr(d[:w * h], frames[r[2]][:w * h]) > 26.0, (preset, r)
 
 
+def test_random_b_sessions_equal_the_checker_sessions(gpu, tmp_path):
+    """the same host code over the device and over the CPU checker (tests/stub: the oracle behind the device ABI, in a child process) must write
+    the same bytes for the same session: every device primitive a session touches — lookahead frame costs of (p0, p1, b) triples, weight analysis,
+    macroblock-tree propagation, AQ, the macroblock loop of I / P / B pictures — is compared through everything the host decides from it
+    (picture types, quantisers, weights).  Random option mixes around the driver's defaults"""
+    import json
+    import os
+    import subprocess
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    subprocess.check_call(["make", "-s", "-C", os.path.join(here, "stub")])
+    rng = np.random.default_rng(20261004)
+    for trial in range(int(os.environ.get("X264GPU_STRESS_TRIALS", "10"))):
+        w, h = [(176, 144), (128, 96), (96, 80), (208, 112)][int(rng.integers(4))]
+        nfr = int(rng.integers(8, 22))
+        opts = {"bframes": int(rng.integers(1, 4)), "b-adapt": int(rng.integers(0, 3)), "ref": int(rng.integers(1, 4)), "keyint": int(rng.choice([6, 12, 250])),
+                "weightp": int(rng.integers(0, 3)), "me": str(rng.choice(["dia", "hex", "umh"]))}
+        mode = str(rng.choice(["qp", "crf", "crf-tree", "abr"]))
+        if mode == "qp": opts["qp"] = int(rng.integers(18, 34))
+        elif mode == "abr": opts["bitrate"] = int(rng.integers(150, 900)); opts["rc-lookahead"] = int(rng.integers(2, 10))
+        else:
+            opts["crf"] = int(rng.integers(18, 32))
+            if mode == "crf": opts["no-mbtree"] = None
+            else: opts["rc-lookahead"] = int(rng.integers(2, 10))
+        if rng.random() < 0.3: opts["slices"] = int(rng.integers(2, 5))
+        if rng.random() < 0.3: opts["trellis"] = int(rng.integers(0, 3))
+        if rng.random() < 0.3: opts["scenecut"] = 0
+        seed = 400 + trial
+        scene = int(rng.choice([0, 7]))
+        frames = synth_frames(w, h, nfr, seed=seed, **({"scene_len": scene} if scene else {}))
+        tag = f"trial {trial}: {w}x{h} x{nfr} {opts} scene_len {scene}"
+        h_, eff = open_encoder(w, h, opts, profile=None)
+        stream, recs = encode_delayed(h_, w, h, frames)
+        H.x264_encoder_close(h_)
+        out = str(tmp_path / "chk.h264")
+        args = [f"{k}={v}" if v is not None else k for k, v in opts.items()] + ([f"scene_len={scene}"] if scene else [])
+        r = subprocess.run([sys.executable, os.path.join(here, "stub", "run_host_b.py"), out, str(w), str(h), str(nfr), str(seed)] + args, capture_output=True, text=True, timeout=900)
+        assert r.returncode == 0, (tag, r.stderr[-1500:])
+        info = json.loads(r.stdout.strip().splitlines()[-1])
+        assert [(x[0], x[1], x[2]) for x in info["recs"]] == [(t, pts, dts) for t, _, pts, dts, _ in recs], tag
+        assert open(out, "rb").read() == stream, tag
+
+
 def test_cross_session_batcher_on_the_device(gpu):
     """X264GPU_BATCH=16: sixteen sessions from sixteen host threads, one lock-step launch per picture on the device; byte-identical to sixteen
     sessions run one after the other"""
