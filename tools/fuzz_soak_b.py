@@ -39,6 +39,20 @@ def random_b_case(rnd):
         else:
             kw.update(slices=rnd.randint(2, mbh), slices_plain=1)
     weightp = rnd.choice([0, 0, 2]) if refs >= 2 else 0
+    if rnd.random() < 0.25:          # explicit luma weights on the P pictures (what x264_weights_analyse hands a fade): --weightp 1 or 2
+        weightp = rnd.choice([1, 2])
+        wts = {}
+        for i, t in enumerate(types):
+            if t == "P" and rnd.random() < 0.8:
+                denom = rnd.randint(0, 7)
+                scale = max(1, min(127, (1 << denom) + rnd.randint(-(1 << denom) // 4 - 1, (1 << denom) // 4 + 1))) if rnd.random() < 0.8 else rnd.randint(1, 127)
+                wts[i] = (scale, denom, rnd.randint(-12, 12) if rnd.random() < 0.8 else rnd.randint(-128, 127))
+        kw["_weights"] = wts
+    if rnd.random() < 0.15:          # sessions without RD (subme <= 5) run P pictures only on the DPB model: duplicates and weights there
+        types = types.replace("B", "P")
+        kw.update(rd=0, subme=rnd.randint(1, 5), trellis=0, psy=0, psy_rd_q8=0, chroma_qp_offset=rnd.choice([0, 2]), cabac=rnd.randint(0, 1))
+        if "_weights" in kw:
+            kw["_weights"] = {i: v for i, v in kw["_weights"].items() if types[i] == "P"}
     return w, h, types, rnd.randint(1, 10 ** 6), bframes, pyramid, weightp, kw
 
 
@@ -55,7 +69,7 @@ def main():
             w, h, types, fseed, bframes, pyramid, weightp, kw = random_b_case(rnd)
             total += 1
             try:
-                run(None, w, h, types, fseed, bframes=bframes, pyramid=pyramid, weightp=weightp, **kw)
+                run(None, w, h, types, fseed, bframes=bframes, pyramid=pyramid, weightp=weightp, weights=kw.pop("_weights", None), **kw)
             except AssertionError as e:
                 bad += 1
                 print(f"MISMATCH seed {seed} case {it}: {w}x{h} {types} bframes {bframes} pyramid {pyramid} weightp {weightp} {kw}: {str(e)[:300]}", flush=True)
