@@ -1,6 +1,8 @@
 """GPU: B pictures through the HIP macroblock loop (k_mb.cuh BS instantiations: spatial direct, both lists' searches, implicit weighted bi-prediction,
 x264's B RD decision, bidirectional refinement) — records, levels, reconstruction and CABAC context variables must equal the CPU checker's picture
 by picture, and the stream the host writer makes of the device's records must decode to the device's reconstruction."""
+import ctypes as C
+
 import numpy as np
 import pytest
 
@@ -95,6 +97,35 @@ def test_weightp_2_blind_duplicate_bitexact_and_decodable(gpu, w, h, types, seed
     """x264 --weightp 2: the duplicate of reference 0 with luma offset -1 (refined from reference 0's vector, searched in full only for 16x8 / 8x16
     halves whose 8x8 blocks both chose it), weighted fetches in the search / refinement / prediction, the loop filter comparing pictures"""
     assert run(gpu, w, h, types, seed, weightp=2, **over) > 0
+
+
+@pytest.mark.parametrize("streams,w,h,types,over", [(5, 176, 144, "IBBBPBBP", {}), (3, 128, 96, "IBPBBP", dict(me_method=2, trellis=127)), (4, 96, 208, "IBBPBP", dict(slices=3))])
+def test_b_pictures_lock_step_streams_with_distinct_content(gpu, streams, w, h, types, over):
+    """the lock-step batch as the bench and the cross-session batcher use it: every stream its own content and quantisers, one launch per picture;
+    each stream must equal the CPU checker's encode of that stream alone (records, levels, reconstruction)"""
+    from gpu_enc import GpuEncoder
+    from x264vfw_amd import host_api as HL
+    kw = dict(MEDIUM, **over)
+    seqs = [synth_frames(w, h, len(types), seed=50 + 7 * s) for s in range(streams)]
+    ogs = [O.OracleEncoder(O.default_config(w, h, **kw)) for _ in range(streams)]
+    gg = GpuEncoder(O.default_config(w, h, streams=streams, **kw))
+    dpb = bgop.HostDpb(HL, kw["refs"], 3, 1, weightp=2)
+    order = bgop.schedule(types, 1)
+    for k, (disp, pt) in enumerate(order):
+        pic, _ = dpb.plan(pt, disp, bgop.follow_of(order, k))
+        pics = []
+        for s in range(streams):
+            q = type(pic)()
+            C.memmove(C.byref(q), C.byref(pic), C.sizeof(pic))
+            q.qp = (20 if pt <= 1 else 23 if pt == 2 else 25 if pt == 4 else 24) + s
+            pics.append(q)
+        g_mb, g_lv = gg.encode_pics([seqs[s][disp] for s in range(streams)], pics)
+        for s in range(streams):
+            o_mb, o_lv = ogs[s].encode_pic(seqs[s][disp], pics[s])
+            bad = np.nonzero(g_mb[s].view(np.uint8).reshape(-1, 64) != o_mb.view(np.uint8).reshape(-1, 64))[0]
+            assert bad.size == 0, f"picture {k} (display {disp}, type {pt}) stream {s}: record of macroblock {bad[0]} differs" + describe(g_mb[s], o_mb, bad[0])
+            assert np.array_equal(g_lv[s], o_lv) and np.array_equal(gg.recon(s), ogs[s].recon()), f"picture {k} stream {s}"
+        dpb.commit()
 
 
 def test_headline_size_b_pictures_and_weightp_bitexact(gpu):
