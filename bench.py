@@ -330,6 +330,7 @@ def e2e_probe(args):
         assert H.x264_picture_alloc(C.byref(pic), HL.X264_CSP_I420, w, h) == 0
         nal, nn = C.POINTER(HL.Nal)(), C.c_int()
         got = total = 0
+        first = None
         t0 = time.perf_counter()
         for i in range(n):
             f = src[i % len(src)]
@@ -340,6 +341,8 @@ def e2e_probe(args):
             assert size >= 0
             got += size > 0
             total += size
+            if size > 0 and first is None:
+                first = i
         while H.x264_encoder_delayed_frames(h_):
             size = H.x264_encoder_encode(h_, C.byref(nal), C.byref(nn), None, C.byref(out))
             assert size > 0
@@ -348,6 +351,7 @@ def e2e_probe(args):
         dt = time.perf_counter() - t0
         H.x264_encoder_close(h_)
         assert got == n
+        delays.append(n if first is None else first)          # pictures handed in before the first one came back
         return round(n / dt, 2), round(total / n / 1e3, 1)
 
     def run_sessions(ns, n, src):
@@ -403,6 +407,7 @@ def e2e_probe(args):
         return round(ns * n / dt, 2), round(sum(res) / (ns * n) / 1e3, 1)
 
     n1 = args.e2e_frames
+    delays = []
     src = synth_frames(w, h, max(n1, 16), seed=0x264, scene_len=97)
     f1, kb1 = run(n1, 1, 250, src)
     fm, kbm = run_sessions(args.e2e_sessions, n1, src) if args.e2e_sessions > 1 else (None, None)
@@ -413,18 +418,20 @@ def e2e_probe(args):
     fg, kbg = run(G * K, G, K, src)
     ns = (h + 15) // 16 // 4                        # x264 slice threads: at most one slice per four macroblock rows
     fs, kbs = run(max(n1, 24), ns, 250, src, sliced=True)
+    d_sliced = delays[-1]
     fsg, kbsg = run(G * K * 2, ns, K, src, sliced=True, gop_slots=G)
     nr = (h + 15) // 16                             # x264 --slices N: down to one macroblock row per slice (filtered across the boundaries)
     fr, kbr = run(max(n1, 48), 1, 250, src, slices=nr)
+    d_rows = delays[-1]
     frg, _ = run(G * K * 2, G, K, src, slices=nr)
     os.environ.pop("X264GPU_GOP_SLOTS", None)
-    return {"what": "ONE 1920x1080 stream through x264_encoder_encode (host pictures in, Annex-B out: PCIe + host entropy coding included), CQP, preset medium as implemented",
+    return {"what": "ONE 1920x1080 stream through x264_encoder_encode (host pictures in, Annex-B out: PCIe + host entropy coding included), CQP, preset medium as implemented (the threads-1 and slice legs with B pictures, b-adapt 1 and scene cuts: delays as measured; the --threads G legs run without B pictures)",
             "threads1_fps": f1, "threads1_frames": n1, "threads1_kB_per_frame": kb1,
             "multi_session_fps": fm, "multi_session_sessions": args.e2e_sessions, "multi_session_frames_each": n1, "multi_session_kB_per_frame": kbm,
             "multi_session_what": "that many x264_encoder_open sessions on as many host threads through the cross-session batcher (X264GPU_BATCH): one lock-step device launch per picture, host pictures in, every thread entropy-codes its own stream; session setup and teardown inside the timed span",
-            "sliced_threads_fps": fs, "sliced_threads_slices": ns, "sliced_threads_delay_frames": 0, "sliced_threads_kB_per_frame": kbs,
+            "sliced_threads_fps": fs, "sliced_threads_slices": ns, "sliced_threads_delay_frames": d_sliced, "sliced_threads_kB_per_frame": kbs,
             "sliced_threads_gop_slots32_fps": fsg, "sliced_threads_gop_slots32_delay_frames": (G - 1) * K + 1,
-            "slices_per_row_fps": fr, "slices_per_row_slices": nr, "slices_per_row_delay_frames": 0, "slices_per_row_kB_per_frame": kbr,
+            "slices_per_row_fps": fr, "slices_per_row_slices": nr, "slices_per_row_delay_frames": d_rows, "slices_per_row_kB_per_frame": kbr,
             "slices_per_row_threads32_fps": frg, "slices_per_row_threads32_delay_frames": (G - 1) * K + 1,
             "threads32_fps": fg, "threads32_frames": G * K, "threads32_keyint": K, "threads32_delay_frames": (G - 1) * K + 1, "threads32_kB_per_frame": kbg,
             "host_cores": os.cpu_count()}
