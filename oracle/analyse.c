@@ -769,6 +769,10 @@ static void encode_i16x16(x264o_encoder *e, const pixel *fenc, pixel *rec, int q
 static void mc_mb(x264o_encoder *e, int mbx, int mby, int bx, int by, int w, int h, int refslot, int mvx, int mvy, pixel *dy, int sy, pixel *du, pixel *dv, int sc)
 {
     pixel *planes[4] = { luma_plane(e, refslot, 0), luma_plane(e, refslot, 1), luma_plane(e, refslot, 2), luma_plane(e, refslot, 3) };
+    /* x264 mb_mc_0xywh / _1xywh / _01xywh: the vector is clipped to the macroblock's mv_min / mv_max (24 pixels outside the picture) before the
+     * fetch.  Searched vectors are inside anyway; INFERRED ones (spatial direct takes a neighbour's vector as it is, the skip vector) can point
+     * farther than the padding reaches — inside the replicated border the clipped vector fetches the same samples */
+    mvx = clampi(mvx, 4 * (-16 * mbx - 24), 4 * (16 * (e->mbw - mbx - 1) + 24)); mvy = clampi(mvy, 4 * (-16 * mby - 24), 4 * (16 * (e->mbh - mby - 1) + 24));
     x264o_mc_luma(dy + by * sy + bx, sy, planes, e->rs, mbx * 16 + bx, mby * 16 + by, mvx, mvy, w, h);
     x264o_mc_chroma(du + (by / 2) * sc + bx / 2, dv + (by / 2) * sc + bx / 2, sc, chroma_plane(e, refslot), e->rs, mbx * 8 + bx / 2, mby * 8 + by / 2, mvx, mvy, w / 2, h / 2);
 }

@@ -428,8 +428,11 @@ struct SliceDec {
     {
         const int ref = d.ref_slot_l(l, r), ox = (k & 1) * 8, oy = (k >> 1) * 8;
         pixel *planes[4] = { d.Y(ref, 0), d.Y(ref, 1), d.Y(ref, 2), d.Y(ref, 3) };
-        x264o_mc_luma(y, 8, planes, d.stride, mbx * 16 + ox, mby * 16 + oy, mv[0], mv[1], 8, 8);
-        x264o_mc_chroma(u, v, 4, d.UV(ref), d.stride, mbx * 8 + ox / 2, mby * 8 + oy / 2, mv[0], mv[1], 4, 4);
+        // 8.4.2.2: samples outside the picture are the nearest edge samples.  The planes carry a finite replicated border, so a vector that points
+        // farther is pulled back to 24 samples outside the picture first: every sample the interpolation reads is an edge sample either way
+        const int mvx = clampi(mv[0], 4 * (-16 * mbx - 24), 4 * (16 * (d.mbw - mbx - 1) + 24)), mvy = clampi(mv[1], 4 * (-16 * mby - 24), 4 * (16 * (d.mbh - mby - 1) + 24));
+        x264o_mc_luma(y, 8, planes, d.stride, mbx * 16 + ox, mby * 16 + oy, mvx, mvy, 8, 8);
+        x264o_mc_chroma(u, v, 4, d.UV(ref), d.stride, mbx * 8 + ox / 2, mby * 8 + oy / 2, mvx, mvy, 4, 4);
     }
     void inter_pred(int mbx, int mby, const MbInfo &m)
     {

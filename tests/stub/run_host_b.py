@@ -14,6 +14,24 @@ import host_lib as HL  # noqa: E402
 from synth import synth_frames  # noqa: E402
 
 
+def make_frames(w, h, n, seed, scene_len=0, static=0, fade=0):
+    """the clips of the session tests: synthetic frames, optionally with scene cuts every scene_len frames, fading to black by `fade` per cent a
+    picture (tests/test_bframes_cpu.py fade_frames), or the first picture again and again with a little noise"""
+    import numpy as np
+    frames = synth_frames(w, h, n, seed=seed, **({"scene_len": scene_len} if scene_len else {}))
+    if fade:
+        for i, f in enumerate(frames):
+            a = max(0.0, 1.0 - i * fade / 100.0)
+            g = f.astype(np.float32)
+            g[:w * h] *= a
+            g[w * h:] = 128 + (g[w * h:] - 128) * a
+            frames[i] = np.clip(np.rint(g), 0, 255).astype(np.uint8)
+    if static:
+        rng = np.random.default_rng(seed)
+        frames = [np.clip(frames[0].astype(np.int16) + rng.integers(-1, 2, frames[0].shape), 0, 255).astype(np.uint8) for _ in range(n)]
+    return frames
+
+
 def main():
     out_path = sys.argv[1]
     w, h, n, seed = (int(x) for x in sys.argv[2:6])
@@ -26,19 +44,7 @@ def main():
     static = int(opts.pop("static", 0) or 0)
     fade = int(opts.pop("fade", 0) or 0)
     preset = (opts.pop("preset", None) or "medium").encode()
-    frames = synth_frames(w, h, n, seed=seed, **({"scene_len": scene_len} if scene_len else {}))
-    if fade:            # fades to black by `fade` per cent a picture (tests/test_bframes_cpu.py fade_frames)
-        import numpy as np
-        for i, f in enumerate(frames):
-            a = max(0.0, 1.0 - i * fade / 100.0)
-            g = f.astype(np.float32)
-            g[:w * h] *= a
-            g[w * h:] = 128 + (g[w * h:] - 128) * a
-            frames[i] = np.clip(np.rint(g), 0, 255).astype(np.uint8)
-    if static:          # the first picture again and again, with a little noise
-        import numpy as np
-        rng = np.random.default_rng(seed)
-        frames = [np.clip(frames[0].astype(np.int16) + rng.integers(-1, 2, frames[0].shape), 0, 255).astype(np.uint8) for _ in range(n)]
+    frames = make_frames(w, h, n, seed, scene_len, static, fade)
     p = HL.Param()
     assert H.x264_param_default_preset(C.byref(p), preset, None) == 0
     p.i_width, p.i_height, p.i_csp = w, h, HL.X264_CSP_I420
@@ -82,4 +88,5 @@ def main():
                       "weightp": eff.analyse.i_weighted_pred, "mbtree": eff.rc.b_mb_tree, "first_output_after": first_out}))
 
 
-main()
+if __name__ == "__main__":
+    main()

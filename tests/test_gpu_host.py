@@ -891,15 +891,36 @@ def test_every_preset_codes_a_decodable_stream(gpu, preset):
         assert psnr(d[:w * h], frames[r[2]][:w * h]) > 26.0, (preset, r)
 
 
-def test_random_b_sessions_equal_the_checker_sessions(gpu, tmp_path):
-    """the same host code over the device and over the CPU checker (tests/stub: the oracle behind the device ABI, in a child process) must write
-    the same bytes for the same session: every device primitive a session touches — lookahead frame costs of (p0, p1, b) triples, weight analysis,
-    macroblock-tree propagation, AQ, the macroblock loop of I / P / B pictures — is compared through everything the host decides from it
-    (picture types, quantisers, weights).  Random option mixes around the driver's defaults"""
+def _session_equals_checker(tmp_path, w, h, nfr, opts, seed, scene, kind):
+    """one session over the device (in process) and over the CPU checker (tests/stub, a child process): same picture types, pts, dts and bytes"""
     import json
     import os
     import subprocess
     import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    sys.path.insert(0, os.path.join(here, "stub"))
+    from run_host_b import make_frames
+    frames = make_frames(w, h, nfr, seed, scene_len=scene, static=int(kind == "static"), fade=4 if kind == "fade" else 0)
+    tag = f"{w}x{h} x{nfr} {opts} seed {seed} scene_len {scene} {kind}"
+    h_, eff = open_encoder(w, h, opts, profile=None)
+    stream, recs = encode_delayed(h_, w, h, frames)
+    H.x264_encoder_close(h_)
+    out = str(tmp_path / "chk.h264")
+    args = [f"{k}={v}" if v is not None else k for k, v in opts.items()] + ([f"scene_len={scene}"] if scene else []) + (["static=1"] if kind == "static" else ["fade=4"] if kind == "fade" else [])
+    r = subprocess.run([sys.executable, os.path.join(here, "stub", "run_host_b.py"), out, str(w), str(h), str(nfr), str(seed)] + args, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, (tag, r.stderr[-1500:])
+    info = json.loads(r.stdout.strip().splitlines()[-1])
+    assert [(x[0], x[1], x[2]) for x in info["recs"]] == [(t, pts, dts) for t, _, pts, dts, _ in recs], tag
+    assert open(out, "rb").read() == stream, tag
+
+
+def test_random_b_sessions_equal_the_checker_sessions(gpu, tmp_path):
+    """the same host code over the device and over the CPU checker (tests/stub: the oracle behind the device ABI, in a child process) must write
+    the same bytes for the same session: every device primitive a session touches — lookahead frame costs of (p0, p1, b) triples, weight analysis,
+    macroblock-tree propagation, AQ, the macroblock loop of I / P / B pictures — is compared through everything the host decides from it
+    (picture types, quantisers, weights).  Random option mixes around the driver's defaults, on plain, fading and static clips"""
+    import os
+    import subprocess
     here = os.path.dirname(os.path.abspath(__file__))
     subprocess.check_call(["make", "-s", "-C", os.path.join(here, "stub")])
     rng = np.random.default_rng(20261004)
@@ -920,18 +941,18 @@ def test_random_b_sessions_equal_the_checker_sessions(gpu, tmp_path):
         if rng.random() < 0.3: opts["scenecut"] = 0
         seed = 400 + trial
         scene = int(rng.choice([0, 7]))
-        frames = synth_frames(w, h, nfr, seed=seed, **({"scene_len": scene} if scene else {}))
-        tag = f"trial {trial}: {w}x{h} x{nfr} {opts} scene_len {scene}"
-        h_, eff = open_encoder(w, h, opts, profile=None)
-        stream, recs = encode_delayed(h_, w, h, frames)
-        H.x264_encoder_close(h_)
-        out = str(tmp_path / "chk.h264")
-        args = [f"{k}={v}" if v is not None else k for k, v in opts.items()] + ([f"scene_len={scene}"] if scene else [])
-        r = subprocess.run([sys.executable, os.path.join(here, "stub", "run_host_b.py"), out, str(w), str(h), str(nfr), str(seed)] + args, capture_output=True, text=True, timeout=900)
-        assert r.returncode == 0, (tag, r.stderr[-1500:])
-        info = json.loads(r.stdout.strip().splitlines()[-1])
-        assert [(x[0], x[1], x[2]) for x in info["recs"]] == [(t, pts, dts) for t, _, pts, dts, _ in recs], tag
-        assert open(out, "rb").read() == stream, tag
+        kind = str(rng.choice(["plain", "plain", "fade", "static"]))
+        _session_equals_checker(tmp_path, w, h, nfr, opts, seed, scene, kind)
+
+
+def test_direct_vector_beyond_the_padding_is_pulled_back(gpu, tmp_path):
+    """trial 291 of a 300-session soak: a spatial-direct vector is a neighbour's, taken as it is — in the bottom macroblock row it pointed 34 samples
+    below the picture, past the replicated border of the reference planes.  x264's mb_mc clips vectors to mv_min / mv_max before the fetch (same
+    samples inside the border); oracle, device and checker decoder now do too"""
+    import os
+    import subprocess
+    subprocess.check_call(["make", "-s", "-C", os.path.join(os.path.dirname(os.path.abspath(__file__)), "stub")])
+    _session_equals_checker(tmp_path, 96, 80, 10, {"bframes": 3, "b-adapt": 2, "ref": 1, "keyint": 6, "weightp": 2, "me": "hex", "bitrate": 554, "rc-lookahead": 3}, 691, 0, "fade")
 
 
 def test_cross_session_batcher_on_the_device(gpu):

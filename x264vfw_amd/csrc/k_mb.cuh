@@ -1355,9 +1355,13 @@ static __constant__ const uint32_t c_dia4d[33] = {
 
 // x264_mb_mc of a B macroblock for this lane's row of four luma samples (Z layout) and, in lanes 0..31, its row of the chroma 4x4 block
 // (lane >> 2) & 3 of plane (lane >> 4) & 1: from list 0, list 1, or both averaged with the pair's implicit weight (biwv: lane r0 * 4 + r1)
-__device__ __forceinline__ void b_predict(const EncK &k, const MbCtx &c, const BCfg &g, int biwv, uint32_t &pred, uint32_t &cpred)
+__device__ __forceinline__ void b_predict(const EncK &k, const MbCtx &c, const BCfg &g0, int biwv, uint32_t &pred, uint32_t &cpred)
 {
     const int lane = c.lane, zx = z_x0(lane), zy = z_y(lane), j4 = lane & 3;
+    // x264 mb_mc_*xywh: vectors are clipped to the macroblock's mv_min / mv_max before the fetch — a spatial-direct vector is a neighbour's, taken as it
+    // is, and can point farther than the padding reaches (same samples inside the replicated border)
+    BCfg g = g0;
+    g.x0 = clampi(g.x0, c.mvmin0, c.mvmax0); g.y0 = clampi(g.y0, c.mvmin1, c.mvmax1); g.x1 = clampi(g.x1, c.mvmin0, c.mvmax0); g.y1 = clampi(g.y1, c.mvmin1, c.mvmax1);
     {
         uint32_t p0 = 0, p1 = 0;
         if (g.r0 >= 0) p0 = mc_luma_row4(ref_plane00(k, c.s, g.r0), k.plane_bytes, k.rs, c.px + zx, c.py + zy, g.x0, g.y0);

@@ -1574,6 +1574,16 @@ static int encode_bmode(x264_t *h, x264_nal_t **pp_nal, int *pi_nal, x264_pictur
         return -1;
     }
     BPHASE(2);
+    if (const char *dd = getenv("X264GPU_DUMP_RECORDS")) {          // debugging aid: the records and levels of every coded picture, and what was asked of the device
+        char fn[512];
+        snprintf(fn, sizeof(fn), "%s/pic%04ld.bin", dd, h->coded_count);
+        if (FILE *f = fopen(fn, "wb")) {
+            fwrite(&pic, sizeof(pic), 1, f);
+            fwrite(h->h_mb.data(), sizeof(x264gpu_mb), h->h_mb.size(), f);
+            fwrite(h->h_lv.data(), sizeof(int16_t), h->h_lv.size(), f);
+            fclose(f);
+        }
+    }
     if (plan.nal_ref_idc) { h->slot_qp_rc[pic.dst] = qpf; h->slot_ptype[pic.dst] = pl.type; }
     h->last_scenecut = pl.e.scenecut; h->last_qp = pic.qp;
     memcpy(h->last_costs, pl.e.costs, sizeof(pl.e.costs));
