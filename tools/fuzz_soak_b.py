@@ -38,6 +38,8 @@ def random_b_case(rnd):
             kw.update(slices=rnd.randint(2, mbh // 4))
         else:
             kw.update(slices=rnd.randint(2, mbh), slices_plain=1)
+    if rnd.random() < 0.3:           # variance AQ: per-macroblock quantisers, the within-1 rule of x264_macroblock_analyse, mb_qp_delta in the RD costs
+        kw.update(aq_mode=1, aq_strength_q8=rnd.choice([133, 266, 400]))
     weightp = rnd.choice([0, 0, 2]) if refs >= 2 else 0
     if rnd.random() < 0.25:          # explicit luma weights on the P pictures (what x264_weights_analyse hands a fade): --weightp 1 or 2
         weightp = rnd.choice([1, 2])
@@ -56,6 +58,19 @@ def random_b_case(rnd):
     return w, h, types, rnd.randint(1, 10 ** 6), bframes, pyramid, weightp, kw
 
 
+def panned_frames(w, h, n, seed, dx, dy):
+    """a fast global pan (dx, dy pixels a picture) over one synthetic picture: long vectors, also across the picture borders"""
+    import numpy as np
+    from synth import synth_frames
+    base = synth_frames(w, h, 1, seed=seed)[0]
+    y = base[:w * h].reshape(h, w); u = base[w * h:w * h * 5 // 4].reshape(h // 2, w // 2); v = base[w * h * 5 // 4:].reshape(h // 2, w // 2)
+    out = []
+    for i in range(n):
+        sx, sy = (i * dx) // 2 * 2, (i * dy) // 2 * 2
+        out.append(np.concatenate([np.roll(y, (sy, sx), (0, 1)).ravel(), np.roll(u, (sy // 2, sx // 2), (0, 1)).ravel(), np.roll(v, (sy // 2, sx // 2), (0, 1)).ravel()]))
+    return out
+
+
 def main():
     import pytest  # noqa: F401  (tests/conftest fixtures are not used: run() takes the gpu argument for show)
     from test_gpu_bframes import run
@@ -69,7 +84,8 @@ def main():
             w, h, types, fseed, bframes, pyramid, weightp, kw = random_b_case(rnd)
             total += 1
             try:
-                run(None, w, h, types, fseed, bframes=bframes, pyramid=pyramid, weightp=weightp, weights=kw.pop("_weights", None), **kw)
+                frames = panned_frames(w, h, len(types), fseed, rnd.randint(-30, 30), rnd.randint(-30, 30)) if rnd.random() < 0.25 else None
+                run(None, w, h, types, fseed, bframes=bframes, pyramid=pyramid, weightp=weightp, weights=kw.pop("_weights", None), frames=frames, **kw)
             except AssertionError as e:
                 bad += 1
                 print(f"MISMATCH seed {seed} case {it}: {w}x{h} {types} bframes {bframes} pyramid {pyramid} weightp {weightp} {kw}: {str(e)[:300]}", flush=True)
