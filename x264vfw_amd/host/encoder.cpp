@@ -493,7 +493,10 @@ x264_t *x264_encoder_open(x264_param_t *param)
     h->level_idc = p.i_level_idc > 0 ? p.i_level_idc : pick_level(&p, h->nmb, p.i_frame_reference);
     p.i_level_idc = h->level_idc;
     h->log2_max_frame_num = 4;
-    while ((1 << h->log2_max_frame_num) <= (h->keyint < 65536 ? h->keyint : 65535) && h->log2_max_frame_num < 16) h->log2_max_frame_num++;
+    {   // x264 sps init: max_frame_num = keyint * (1 + b-pyramid) + 1
+        const long max_frame_num = (long)(h->keyint < 65536 ? h->keyint : 65535) * (h->bpyramid + 1) + 1;
+        while ((1L << h->log2_max_frame_num) <= max_frame_num && h->log2_max_frame_num < 16) h->log2_max_frame_num++;
+    }
     if (h->weightp && h->profile_idc == 66) h->profile_idc = 77;                  // explicit weighted prediction is a Main profile tool
     if (h->dpbmode) {
         // x264 sps init: pic_order_cnt_type 0 with room for the largest POC distance of a mini-GOP (type 2 without B pictures); the DPB model owns
