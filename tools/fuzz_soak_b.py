@@ -18,6 +18,8 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 def random_b_case(rnd):
     w = rnd.choice([64, 96, 128, 176, 208, 200, 72])
     h = rnd.choice([48, 80, 96, 144, 112, 104, 136])
+    if os.environ.get("FUZZ_BIG"):          # a slower soak on larger pictures
+        w, h = rnd.choice([(352, 288), (416, 240), (320, 192), (480, 272)])
     bframes = rnd.randint(1, 3)
     types = "I"
     while len(types) < rnd.randint(4, 9):
