@@ -389,3 +389,58 @@ def test_driver_defaults_with_b_pictures_to_a_file(gpu, tmp_path):
     assert sorted(disp) == list(range(nfr))
     for d, i in zip(dec, disp):
         assert psnr(d[:w * h], frames[i][:w * h]) > 27.0
+
+
+def test_virtualdub_hack_carries_b_pictures_through_the_vfw_buffer(gpu):
+    """--vd-hack (X264VFW_USE_VIRTUALDUB_HACK, codec.c:1809-1820): a call that hands in a frame while the lookahead / the mini-GOP hold the
+    pictures back answers with a one-byte 0x7f drop frame under the XVID fourcc; VirtualDub then keeps calling after the last frame
+    (ICM_COMPRESS_FRAMES_INFO told the driver the count: i_frame_remain, codec.c:1756-1790) until every picture has come back.  The real frames,
+    in the order they left, are the stream: B pictures survive VfW's one-in-one-out protocol"""
+    w, h, nfr = 96, 80, 15
+    frames = synth_frames(w, h, nfr, seed=6)
+    ico = V.ICOPEN(fccType=V.fourcc(b"vidc"))
+    cid = D(0, None, V.DRV_OPEN, 0, V.addr(ico))
+    n = D(cid, None, V.ICM_GETSTATE, 0, 0)
+    cfg = V.VfwConfig()
+    D(cid, None, V.ICM_GETSTATE, V.addr(cfg), n)
+    cfg.extra_cmdline = b"--rc-lookahead 5 --vd-hack"
+    D(cid, None, V.ICM_SETSTATE, V.addr(cfg), n)
+    inb, outb = V.bmi(w, h, b"I420"), V.BITMAPINFO()
+    assert D(cid, None, V.ICM_COMPRESS_GET_FORMAT, V.addr(inb), V.addr(outb)) == V.ICERR_OK
+    fi = V.ICCOMPRESSFRAMES(lFrameCount=nfr, dwRate=25, dwScale=1)
+    assert D(cid, None, V.ICM_COMPRESS_FRAMES_INFO, V.addr(fi), C.sizeof(fi)) == V.ICERR_OK
+    assert D(cid, None, V.ICM_COMPRESS_BEGIN, V.addr(inb), V.addr(outb)) == V.ICERR_OK, V.H.x264vfw_shim_log(cid)
+    fourcc = outb.bmiHeader.biCompression
+    cap = outb.bmiHeader.biSizeImage
+    buf = C.create_string_buffer(cap)
+    stream, drops, keyflags = b"", 0, []
+    calls = 0
+    while len(keyflags) < nfr and calls < 4 * nfr:
+        f = frames[min(calls, nfr - 1)]                         # after the last frame VirtualDub repeats its calls: the driver ignores the input then
+        flags = V.DWORD(0)
+        outb.bmiHeader.biSizeImage = cap
+        icc = V.ICCOMPRESS(lpbiOutput=C.pointer(outb.bmiHeader), lpOutput=C.cast(buf, C.c_void_p), lpbiInput=C.pointer(inb.bmiHeader),
+                           lpInput=f.ctypes.data, lpdwFlags=C.pointer(flags))
+        assert D(cid, None, V.ICM_COMPRESS, V.addr(icc), C.sizeof(icc)) == V.ICERR_OK, V.H.x264vfw_shim_log(cid)
+        calls += 1
+        size = outb.bmiHeader.biSizeImage
+        if size == 1 and buf.raw[0] == 0x7f:
+            assert outb.bmiHeader.biCompression == V.fourcc(b"XVID") and flags.value == 0
+            drops += 1
+        else:
+            assert size > 1 and outb.bmiHeader.biCompression == fourcc
+            stream += buf.raw[:size]
+            keyflags.append(flags.value)
+    log = V.H.x264vfw_shim_log(cid)
+    assert D(cid, None, V.ICM_COMPRESS_END, 0, 0) == V.ICERR_OK
+    D(cid, None, V.DRV_CLOSE, 0, 0)
+    assert len(keyflags) == nfr and drops == calls - nfr and drops >= 5, (calls, drops)
+    assert b"Few frames probably would be lost" not in log and b"bframes 0" not in log, log
+    assert keyflags[0] == V.AVIIF_KEYFRAME
+    dec = O.h264_decode(stream, nfr, w, h)
+    assert len(dec) == nfr
+    pocs = O.h264_last_pocs()
+    assert sorted(p // 2 for p in pocs) == list(range(nfr)) and [p // 2 for p in pocs] != list(range(nfr))        # B pictures: coding order != display order
+    from synth import psnr
+    for d, p in zip(dec, pocs):
+        assert psnr(d[:w * h], frames[p // 2][:w * h]) > 27.0

@@ -35,6 +35,7 @@ struct CODEC {                          /* x264vfw.h:187-252, compress-side memb
     BITMAPINFOHEADER *prev_lpbiOutput;
     DWORD prev_output_biSizeImage;
     int b_check_size;
+    int b_use_vd_hack; DWORD save_fourcc;      /* X264VFW_USE_VIRTUALDUB_HACK (x264vfw.h:199-202): delayed pictures answered with a one-byte XVID-style drop frame */
     int b_warn_frame_loss;
     int i_frame_remain, i_frame_total;
     uint32_t i_fps_num, i_fps_den;
@@ -194,6 +195,8 @@ LRESULT compress_begin(CODEC *codec, BITMAPINFO *in, BITMAPINFO *out)
         return ICERR_BADFORMAT;
     }
     codec->b_check_size = out->bmiHeader.biSizeImage != 0;
+    codec->b_use_vd_hack = 0;                                               /* (config.b_vd_hack is not part of this build's state blob: --vd-hack, codec.c:1313) */
+    codec->save_fourcc = out->bmiHeader.biCompression;                      /* codec.c:1411 */
     codec->b_user_ref = 0;
     codec->i_frame_remain = codec->i_frame_total ? codec->i_frame_total : -1;
 
@@ -258,7 +261,8 @@ LRESULT compress_begin(CODEC *codec, BITMAPINFO *in, BITMAPINFO *out)
         if (name == "output") { out_file = value; continue; }                /* OPT_OUTPUT (codec.c:1261-1263) */
         if (name == "muxer") { muxer = value; continue; }
         if (name == "no-output") { codec->b_no_output = 1; continue; }
-        if (name == "vd-hack" || name == "dts-compress") {
+        if (name == "vd-hack") { codec->b_use_vd_hack = 1; continue; }       /* OPT_VD_HACK (codec.c:1313-1315) */
+        if (name == "dts-compress") {
             vlog(codec, X264_LOG_WARNING, "not supported option: '%s'\n", a.c_str());
             continue;
         }
@@ -308,7 +312,8 @@ LRESULT compress_begin(CODEC *codec, BITMAPINFO *in, BITMAPINFO *out)
     codec->h = x264_encoder_open(&param);
     if (!codec->h) { vlog(codec, X264_LOG_ERROR, "x264_encoder_open failed\n"); goto fail; }
     x264_encoder_parameters(codec->h, &param);
-    codec->b_warn_frame_loss = !codec->b_cli_output;                          /* codec.c:1667 */
+    if (codec->b_cli_output) codec->b_use_vd_hack = 0;                        /* codec.c:1635 */
+    codec->b_warn_frame_loss = !(codec->b_use_vd_hack || codec->b_cli_output);  /* codec.c:1665 */
     if (codec->cli_hout) {                                                  /* set_param + write_headers (codec.c:1632-1663) */
         x264_nal_t *hn; int nh;
         if (codec->cli_hout->set_param(&param) < 0 || x264_encoder_headers(codec->h, &hn, &nh) < 0 || (!param.b_repeat_headers && codec->cli_hout->write_headers(hn) < 0)) {
@@ -403,11 +408,22 @@ LRESULT compress(CODEC *codec, ICCOMPRESS *icc)
     if (!got_picture && codec->b_warn_frame_loss) {                          /* codec.c:1798-1807 */
         codec->b_warn_frame_loss = 0;
         vlog(codec, X264_LOG_WARNING, "Few frames probably would be lost. Ways to fix this:\n");
+        vlog(codec, X264_LOG_WARNING, " - if you use VirtualDub or its fork than you can enable 'VirtualDub Hack' option\n");
         vlog(codec, X264_LOG_WARNING, " - you can enable 'File' output mode\n");
         vlog(codec, X264_LOG_WARNING, " - you can enable 'Zero Latency' option\n");
     }
-    *icc->lpdwFlags = got_picture && pic_out.b_keyframe ? AVIIF_KEYFRAME : 0;
-    outhdr->biSizeImage = i_out;
+    if (codec->b_use_vd_hack && !got_picture && (outhdr->biSizeImage > 0 || !codec->b_check_size)) {      /* codec.c:1809-1820 */
+        /* no picture came back (B pictures / the lookahead hold it): a one-byte drop frame under the XVID fourcc, which VirtualDub and its forks
+         * take as "delayed" and answer with as many extra calls at the end of the stream */
+        *icc->lpdwFlags = 0;
+        ((uint8_t *)icc->lpOutput)[0] = 0x7f;
+        outhdr->biSizeImage = 1;
+        outhdr->biCompression = mmioFOURCC('X', 'V', 'I', 'D');
+    } else {
+        *icc->lpdwFlags = got_picture && pic_out.b_keyframe ? AVIIF_KEYFRAME : 0;
+        outhdr->biSizeImage = i_out;
+        outhdr->biCompression = codec->save_fourcc;                          /* codec.c:1830 */
+    }
     return ICERR_OK;
 }
 
