@@ -444,3 +444,67 @@ def test_virtualdub_hack_carries_b_pictures_through_the_vfw_buffer(gpu):
     from synth import psnr
     for d, p in zip(dec, pocs):
         assert psnr(d[:w * h], frames[p // 2][:w * h]) > 27.0
+
+
+@pytest.mark.parametrize("ext", ["mp4", "mkv", "flv"])
+def test_b_pictures_into_the_containers(gpu, tmp_path, ext):
+    """the driver's default session (B pictures, b-pyramid) through DriverProc into the reference's container outputs (output/mp4_lsmash.c,
+    matroska.c, flv.c as restated in host/muxers.cpp): the samples lie in coding order with decode times that never run backwards, the presentation
+    times are a permutation of the frame times (mp4: composition offsets, read back by the reference tree's L-SMASH too; mkv: block timecodes,
+    B pictures that nothing references marked discardable, output/matroska.c:199-202; flv: CompositionTime), and the elementary stream decodes to
+    the source"""
+    import container_parse as CP
+    w, h, nfr = 96, 80, 13
+    frames = synth_frames(w, h, nfr, seed=8)
+    path = tmp_path / ("b." + ext)
+    ico = V.ICOPEN(fccType=V.fourcc(b"vidc"))
+    cid = D(0, None, V.DRV_OPEN, 0, V.addr(ico))
+    n = D(cid, None, V.ICM_GETSTATE, 0, 0)
+    cfg = V.VfwConfig()
+    D(cid, None, V.ICM_GETSTATE, V.addr(cfg), n)
+    cfg.extra_cmdline = b"--rc-lookahead 4 --b-adapt 0 --scenecut 0 --output " + str(path).encode()
+    D(cid, None, V.ICM_SETSTATE, V.addr(cfg), n)
+    inb, outb = V.bmi(w, h, b"I420"), V.BITMAPINFO()
+    assert D(cid, None, V.ICM_COMPRESS_GET_FORMAT, V.addr(inb), V.addr(outb)) == V.ICERR_OK
+    fi = V.ICCOMPRESSFRAMES(lFrameCount=nfr, dwRate=25, dwScale=1)
+    assert D(cid, None, V.ICM_COMPRESS_FRAMES_INFO, V.addr(fi), C.sizeof(fi)) == V.ICERR_OK
+    assert D(cid, None, V.ICM_COMPRESS_BEGIN, V.addr(inb), V.addr(outb)) == V.ICERR_OK, V.H.x264vfw_shim_log(cid)
+    cap = outb.bmiHeader.biSizeImage
+    buf = C.create_string_buffer(cap)
+    for f in frames:
+        flags = V.DWORD(0)
+        outb.bmiHeader.biSizeImage = cap
+        icc = V.ICCOMPRESS(lpbiOutput=C.pointer(outb.bmiHeader), lpOutput=C.cast(buf, C.c_void_p), lpbiInput=C.pointer(inb.bmiHeader),
+                           lpInput=f.ctypes.data, lpdwFlags=C.pointer(flags))
+        assert D(cid, None, V.ICM_COMPRESS, V.addr(icc), C.sizeof(icc)) == V.ICERR_OK, V.H.x264vfw_shim_log(cid)
+    assert D(cid, None, V.ICM_COMPRESS_END, 0, 0) == V.ICERR_OK
+    D(cid, None, V.DRV_CLOSE, 0, 0)
+    raw = path.read_bytes()
+    c = CP.mkv_read(raw) if ext == "mkv" else CP.flv_read(raw) if ext == "flv" else CP.mp4_read(raw)
+    fr = c["samples"] if ext == "mp4" else c["frames"]
+    assert len(fr) == nfr
+    a = CP.avcc_read(c["avcc"])
+    es = b"\0\0\0\1" + a["sps"] + b"\0\0\0\1" + a["pps"] + b"".join(b"\0\0\0\1" + nal for f in fr for nal in CP.length_prefixed_nals(f["data"]))
+    dec = O.h264_decode(es, nfr, w, h)
+    pocs = O.h264_last_pocs()
+    assert len(dec) == nfr and sorted(p // 2 for p in pocs) == list(range(nfr)) and [p // 2 for p in pocs] != list(range(nfr))
+    disp = [p // 2 for p in pocs]                                              # display index of every sample, in file (= coding) order
+    if ext == "mp4":
+        dts, cts = [x["dts"] for x in fr], [x["cts"] for x in fr]
+        assert dts == sorted(dts) and len(set(dts)) == nfr and all(ct >= dt for ct, dt in zip(cts, dts))
+        assert [ct - min(cts) for ct in cts] == [d * (cts[1] - cts[0]) // (disp[1] - disp[0]) for d in disp]        # presentation order = display order
+        if __import__("os").path.exists(O.LSMASH_REF):
+            info, smp, data = O.lsmash_read_mp4(path)
+            assert info.n_samples == nfr and [x.cts - x.dts for x in smp] == [ct - dt for ct, dt in zip(cts, dts)]
+    elif ext == "mkv":
+        tcs = [x["timecode"] for x in fr]
+        assert sorted(tcs) == [tcs[disp.index(i)] for i in range(nfr)] and len(set(tcs)) == nfr                 # block timecodes are presentation times
+        assert any(x["discardable"] for x in fr) and fr[0]["key"] and not fr[0]["discardable"]
+    else:
+        dts = [x["dts"] for x in fr]
+        assert dts == sorted(dts)
+        pts = [x["dts"] + x["cts_offset"] for x in fr]
+        assert sorted(pts) == [pts[disp.index(i)] for i in range(nfr)] and all(x["cts_offset"] >= 0 for x in fr)
+    from synth import psnr
+    for d, i in zip(dec, disp):
+        assert psnr(d[:w * h], frames[i][:w * h]) > 27.0
