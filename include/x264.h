@@ -173,6 +173,7 @@ typedef struct x264_param_t {
     uint32_t i_fps_num, i_fps_den, i_timebase_num, i_timebase_den;   /* codec.c:1476-1480,1568-1569 */
     int i_frame_packing;
     int b_stitchable;
+    int i_slice_max_size, i_slice_max_mbs, b_fake_interlaced, b_pic_struct;      /* accepted so that the session can say they are not implemented (no effect) */
     int i_slice_count;                          /* --slices N: N slices per picture (at most one per macroblock row), each its own wavefront; filtered across (idc 0) */
 } x264_param_t;
 

@@ -44,6 +44,7 @@ def main():
     static = int(opts.pop("static", 0) or 0)
     fade = int(opts.pop("fade", 0) or 0)
     preset = (opts.pop("preset", None) or "medium").encode()
+    want_log = int(opts.pop("log", 0) or 0)
     frames = make_frames(w, h, n, seed, scene_len, static, fade)
     p = HL.Param()
     assert H.x264_param_default_preset(C.byref(p), preset, None) == 0
@@ -51,6 +52,11 @@ def main():
     p.i_fps_num, p.i_fps_den, p.i_log_level = 25, 1, -1
     for k, v in opts.items():
         assert H.x264_param_parse(C.byref(p), k.encode(), None if v is None else str(v).encode()) == 0, (k, v)
+    log = []
+    cb = C.CFUNCTYPE(None, C.c_void_p, C.c_int, C.c_char_p, C.c_void_p)(lambda priv, lvl, fmt, va: log.append([lvl, fmt.decode(errors="replace").strip()]))
+    if want_log:          # the format strings of what the session reports through pf_log (codec.c:1274-1283 routes them to the driver's log window)
+        p.pf_log = C.cast(cb, C.c_void_p).value
+        p.i_log_level = 3
     p.b_vfr_input = 0                                                  # the driver forces constant frame rate (codec.c:1476-1480)
     p.b_annexb, p.b_repeat_headers = 1, 1
     h_ = H.x264_encoder_open_157(C.byref(p))
@@ -85,7 +91,7 @@ def main():
     H.x264_encoder_close(h_)
     open(out_path, "wb").write(stream)
     print(json.dumps({"recs": recs, "bframes": eff.i_bframe, "pyramid": eff.i_bframe_pyramid, "badapt": eff.i_bframe_adaptive, "weightb": eff.analyse.b_weighted_bipred,
-                      "weightp": eff.analyse.i_weighted_pred, "mbtree": eff.rc.b_mb_tree, "first_output_after": first_out}))
+                      "weightp": eff.analyse.i_weighted_pred, "mbtree": eff.rc.b_mb_tree, "first_output_after": first_out, "log": log}))
 
 
 if __name__ == "__main__":

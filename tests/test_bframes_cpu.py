@@ -385,6 +385,18 @@ def test_host_session_b8x8_reaches_the_b_slices(tmp_path):
     assert any(ra[4] != rb[4] for ra, rb in zip(a["recs"], b["recs"]) if ra[0] in (4, 5))
 
 
+def test_host_session_says_what_it_does_not_run(tmp_path):
+    """options for tools this path has not got are accepted (the driver passes the user's command line through x264_param_parse, codec.c:1349) and
+    reported through pf_log (the driver's log window, codec.c:1274-1283) with what runs instead — never dropped silently"""
+    import subprocess
+    subprocess.check_call(["make", "-s", "-C", __file__.rsplit("/", 1)[0] + "/stub"])
+    info, _ = _host_b_session(tmp_path, 3, ["log=1", "crf=24", "vbv-maxrate=2000", "vbv-bufsize=2000", "nr=200", "slice-max-size=1500", "fake-interlaced", "bluray-compat",
+                                            "direct=auto", "subme=9", "psy-rd=1.0:0.2", "aq-mode=2", "open-gop", "ref=9", "me=tesa"], 64, 48)
+    text = " | ".join(m for lvl, m in info["log"] if lvl <= 2)
+    for needle in ("VBV", "nr (noise reduction)", "slice-max-size", "fake-interlaced", "bluray-compat", "direct", "subme", "psy-trellis", "aq-mode", "open-gop", "ref %d -> 5", "tesa"):
+        assert needle in text, (needle, text)
+
+
 def test_host_session_single_pass_abr_with_b_pictures(tmp_path):
     """--bitrate N (x264vfw's single-pass ABR page, config.c / codec.c:x264vfw 'Single pass - bitrate-based (ABR)') keeps B pictures, the
     lookahead and macroblock-tree: the coded size of every picture, B pictures' divided by pbratio, steers the rate factor

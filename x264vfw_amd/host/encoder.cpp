@@ -470,7 +470,12 @@ x264_t *x264_encoder_open(x264_param_t *param)
     if (p.rc.i_rc_method != X264_RC_CQP && !h->crf && !h->abr) xlog(&p, X264_LOG_WARNING, "this rate control mode is not implemented yet (2-pass, or ABR with --threads > 1): constant qp %d\n", qp);
     if (qp < 1) { xlog(&p, X264_LOG_WARNING, "lossless is not supported: qp 1\n"); qp = 1; }
     if (!h->crf && !h->abr) p.rc.i_rc_method = X264_RC_CQP;
+    if (p.rc.i_vbv_max_bitrate > 0 || p.rc.i_vbv_buffer_size > 0) xlog(&p, X264_LOG_WARNING, "VBV (vbv-maxrate / vbv-bufsize) is not implemented in the MI355X path: unconstrained\n");
     p.rc.i_vbv_max_bitrate = 0; p.rc.i_vbv_buffer_size = 0;
+    if (p.analyse.i_noise_reduction) { xlog(&p, X264_LOG_WARNING, "nr (noise reduction) is not implemented in the MI355X path: nr 0\n"); p.analyse.i_noise_reduction = 0; }
+    if (p.i_slice_max_size > 0 || p.i_slice_max_mbs > 0) { xlog(&p, X264_LOG_WARNING, "slice-max-size / slice-max-mbs are not implemented in the MI355X path (slices are cut by --slices N or slice threads only)\n"); p.i_slice_max_size = p.i_slice_max_mbs = 0; }
+    if (p.b_fake_interlaced || p.b_pic_struct) { xlog(&p, X264_LOG_WARNING, "fake-interlaced / pic-struct are not implemented in the MI355X path: off\n"); p.b_fake_interlaced = p.b_pic_struct = 0; }
+    if (p.b_bluray_compat) { xlog(&p, X264_LOG_WARNING, "bluray-compat is not implemented in the MI355X path: off\n"); p.b_bluray_compat = 0; }
     // adaptive quantisation: variance AQ (mode 1) under CRF / ABR; x264 itself switches AQ off under constant QP and at strength 0
     if (p.rc.i_rc_method == X264_RC_CQP || p.rc.f_aq_strength <= 0) p.rc.i_aq_mode = X264_AQ_NONE;
     // macroblock-tree: needs a rate-controlled session and pictures held back (rc-lookahead); x264 switches it off under constant QP

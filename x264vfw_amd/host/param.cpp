@@ -282,8 +282,8 @@ int x264_param_parse(x264_param_t *p, const char *name, const char *value)
             int a = 0, b = 0, k = sscanf(value, "%d:%d", &a, &b); if (k < 1) k = sscanf(value, "%d,%d", &a, &b);
             if (k >= 1) { p->b_deblocking_filter = 1; p->i_deblocking_filter_alphac0 = a; p->i_deblocking_filter_beta = k == 2 ? b : a; } else err = 1; } }
     OPT("filter") { int a = 0, b = 0, k = value ? sscanf(value, "%d:%d", &a, &b) : 0; if (k >= 1) { p->b_deblocking_filter = 1; p->i_deblocking_filter_alphac0 = a; p->i_deblocking_filter_beta = k == 2 ? b : a; } else err = 1; }
-    OPT("slice-max-size") (void)parse_int(value, &err);
-    OPT("slice-max-mbs") (void)parse_int(value, &err);
+    OPT("slice-max-size") I(p->i_slice_max_size);
+    OPT("slice-max-mbs") I(p->i_slice_max_mbs);
     OPT("slice-min-mbs") (void)parse_int(value, &err);
     OPT("slices") I(p->i_slice_count);
     OPT("slices-max") (void)parse_int(value, &err);
@@ -292,7 +292,7 @@ int x264_param_parse(x264_param_t *p, const char *name, const char *value)
     OPT("interlaced") B(p->b_interlaced);
     OPT("tff") B(p->b_interlaced);
     OPT("bff") B(p->b_interlaced);
-    OPT("fake-interlaced") (void)parse_bool(value, &err);
+    OPT("fake-interlaced") B(p->b_fake_interlaced);
     OPT("constrained-intra") B(p->b_constrained_intra);
     OPT("cqm") { if (!value || (strcmp(value, "flat") && strcmp(value, "jvt"))) err = 1; else if (!strcmp(value, "jvt")) err = 1; /* flat only */ }
     OPT("cqmfile") err = 1;
@@ -374,7 +374,7 @@ int x264_param_parse(x264_param_t *p, const char *name, const char *value)
     OPT("force-cfr") { p->b_vfr_input = !parse_bool(value, &err); }
     OPT("nal-hrd") { static const char *const names[] = { "none", "vbr", "cbr", 0 }; err |= parse_enum(value, names, &p->i_nal_hrd) < 0; }
     OPT("filler") (void)parse_bool(value, &err);
-    OPT("pic-struct") (void)parse_bool(value, &err);
+    OPT("pic-struct") B(p->b_pic_struct);
     OPT("crop-rect") {}
     OPT("frame-packing") I(p->i_frame_packing);
     OPT("stitchable") B(p->b_stitchable);

@@ -49,7 +49,7 @@ class Param(C.Structure):
                 ("p_log_private", C.c_void_p), ("i_log_level", _i), ("analyse", Analyse), ("rc", Rc), ("b_aud", _i),
                 ("b_repeat_headers", _i), ("b_annexb", _i), ("i_sps_id", _i), ("b_vfr_input", _i), ("i_fps_num", C.c_uint32),
                 ("i_fps_den", C.c_uint32), ("i_timebase_num", C.c_uint32), ("i_timebase_den", C.c_uint32), ("i_frame_packing", _i),
-                ("b_stitchable", _i), ("i_slice_count", _i)]
+                ("b_stitchable", _i), ("i_slice_max_size", _i), ("i_slice_max_mbs", _i), ("b_fake_interlaced", _i), ("b_pic_struct", _i), ("i_slice_count", _i)]
 
 
 class Image(C.Structure):
