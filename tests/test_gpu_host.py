@@ -923,7 +923,7 @@ def test_random_b_sessions_equal_the_checker_sessions(gpu, tmp_path):
     import subprocess
     here = os.path.dirname(os.path.abspath(__file__))
     subprocess.check_call(["make", "-s", "-C", os.path.join(here, "stub")])
-    rng = np.random.default_rng(20261004)
+    rng = np.random.default_rng(int(os.environ.get("X264GPU_STRESS_SEED", "20261004")))
     for trial in range(int(os.environ.get("X264GPU_STRESS_TRIALS", "10"))):
         w, h = [(176, 144), (128, 96), (96, 80), (208, 112)][int(rng.integers(4))]
         nfr = int(rng.integers(8, 22))
@@ -942,6 +942,22 @@ def test_random_b_sessions_equal_the_checker_sessions(gpu, tmp_path):
         seed = 400 + trial
         scene = int(rng.choice([0, 7]))
         kind = str(rng.choice(["plain", "plain", "fade", "static"]))
+        if os.environ.get("X264GPU_STRESS_WIDE"):          # a wider mix for soaks (drawn after the draws above: the default trials stay what they were)
+            if rng.random() < 0.3: opts["partitions"] = str(rng.choice(["none", "p8x8,i4x4", "b8x8,i8x8,i4x4", "p8x8,b8x8", "i8x8,i4x4"]))
+            if rng.random() < 0.2: opts["no-8x8dct"] = None
+            if rng.random() < 0.2: opts["no-deblock"] = None
+            if rng.random() < 0.2: opts["no-mixed-refs"] = None
+            if rng.random() < 0.2: opts["no-weightb"] = None
+            if rng.random() < 0.2: opts["no-psy"] = None
+            if rng.random() < 0.2: opts["no-fast-pskip"] = None
+            if rng.random() < 0.2: opts["b-pyramid"] = "none"
+            if rng.random() < 0.2: opts["aq-mode"] = 0
+            if rng.random() < 0.2: opts["merange"] = int(rng.choice([4, 8, 24]))
+            if rng.random() < 0.2: opts["chroma-qp-offset"] = int(rng.integers(-4, 5))
+            if rng.random() < 0.2: opts["ref"] = int(rng.integers(4, 6))
+            if rng.random() < 0.15: opts["bframes"] = int(rng.integers(4, 7))
+            if rng.random() < 0.2: opts["min-keyint"] = int(rng.integers(1, 5))
+            if rng.random() < 0.15: opts.update({"sliced-threads": None, "threads": 2}); opts.pop("slices", None)
         _session_equals_checker(tmp_path, w, h, nfr, opts, seed, scene, kind)
 
 
