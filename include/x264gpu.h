@@ -343,6 +343,10 @@ int  x264gpu_slicetype_weight_cost(x264gpu_slicetype *st, int slot_fenc, int slo
  * AQ offsets (x264_adaptive_quant_frame; x264gpu_lookahead_aq_offsets) weight the costs (i_inv_qscale_factor) and are the base of the result;
  * the result is what x264gpu_encoder_set_mb_qp_offsets takes.  Propagate costs saturate at 32767 as x264's do (applied where a sum is read). */
 int  x264gpu_slicetype_set_aq(x264gpu_slicetype *st, int slot, const int16_t *d_aq_q8, void *stream);
+/* fenc->i_cost_est_aq[d0][d1] of a triple whose cost has been computed: the block costs weighted with the inverse quantiser scale of the picture's AQ
+ * offsets (set_aq), per stream into h_score[streams] — the complexity x264_rc_analyse_slice hands the rate control in AQ sessions without macroblock-tree
+ * ([x264-upstream] encoder/slicetype.c slicetype_mb_cost, ratecontrol.c x264_rc_analyse_slice) */
+int  x264gpu_slicetype_cost_aq(x264gpu_slicetype *st, int slot, int d0, int d1, int32_t *h_score, void *stream);
 int  x264gpu_slicetype_clear_propagate(x264gpu_slicetype *st, int slot, void *stream);
 int  x264gpu_slicetype_propagate(x264gpu_slicetype *st, int slot_p0, int slot_p1, int slot_b, int d0, int d1, int referenced, void *stream);
 int  x264gpu_slicetype_finish(x264gpu_slicetype *st, int slot, int strength_q8, int16_t *d_out_q8, void *stream);

@@ -300,6 +300,27 @@ void x264o_slicetype_set_aq(x264o_slicetype *st, int slot, const int16_t *aq_q8)
     st_tree *t = st_tree_of(st);
     if (aq_q8) memcpy(t[slot].aq, aq_q8, (size_t)st->nb * sizeof(int16_t)); else memset(t[slot].aq, 0, (size_t)st->nb * sizeof(int16_t));
 }
+/* fenc->i_cost_est_aq[b - p0][p1 - b]: the costs of the triple weighted block by block with the inverse quantiser scale of the picture's AQ offsets
+ * (x264 slicetype_mb_cost: i_mb_cost_aq = (cost * i_inv_qscale_factor + 128) >> 8, summed over the blocks that count for the frame score) — what
+ * x264_rc_analyse_slice hands the rate control in AQ sessions without macroblock-tree.  (The stored costs are capped at LOWRES_COST_MASK.) */
+int x264o_slicetype_cost_aq(x264o_slicetype *st, int slot, int d0, int d1)
+{
+    st_frame *f = &st->fr[slot];
+    if (d0 < 0 || d1 < 0 || d0 > st->bframes + 1 || d1 > st->bframes + 1 || f->cost_est[d0][d1] < 0) return -1;
+    const int16_t *aq = st_tree_of(st)[slot].aq;
+    const int is_i = d0 == 0 && d1 == 0, e = st->do_edges;
+    int sum = 0;
+    for (int by = 0; by < st->bh; by++)
+        for (int bx = 0; bx < st->bw; bx++) {
+            const int score = (bx > 0 && bx < st->bw - 1 && by > 0 && by < st->bh - 1) || st->bw <= 2 || st->bh <= 2;
+            if (!score) continue;
+            (void)e;
+            const int i = by * st->bw + bx;
+            const int c = is_i ? f->intra_cost[i] : f->lowres_costs[d0][d1][i] & LOWRES_COST_MASK;
+            sum += (c * st_inv_qscale(aq[i]) + 128) >> 8;
+        }
+    return sum;
+}
 void x264o_slicetype_clear_propagate(x264o_slicetype *st, int slot) { memset(st_tree_of(st)[slot].prop, 0, (size_t)st->nb * sizeof(int32_t)); }
 /* macroblock_tree_propagate(p0, p1, b, referenced): the costs of (p0, p1, b) must have been computed */
 int x264o_slicetype_propagate(x264o_slicetype *st, int s0, int s1, int sb, int d0, int d1, int referenced)

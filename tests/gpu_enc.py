@@ -182,6 +182,12 @@ class GpuSlicetype:
     def lowres_costs(self, slot, d0, d1):
         return self._dev(lib.x264gpu_slicetype_lowres_costs(self.h, slot, d0, d1), np.uint16, (self.S, self.nb))
 
+    def cost_aq(self, slot, d0, d1):
+        """i_cost_est_aq of a costed triple, per stream"""
+        out = (C.c_int32 * self.S)()
+        lib.check(lib.x264gpu_slicetype_cost_aq(self.h, slot, d0, d1, out, None), "cost_aq")
+        return list(out)
+
     def set_aq(self, slot, aq_q8):
         """aq_q8: [blocks] int16 (replicated over the streams) or None"""
         if aq_q8 is None:

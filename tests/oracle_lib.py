@@ -280,6 +280,7 @@ _sig("x264o_slicetype_mv_costs", C.c_void_p, [C.c_void_p, _i, _i, _i])
 _sig("x264o_slicetype_intra_costs", C.c_void_p, [C.c_void_p, _i])
 _sig("x264o_slicetype_lowres_costs", C.c_void_p, [C.c_void_p, _i, _i, _i])
 _sig("x264o_slicetype_set_aq", None, [C.c_void_p, _i, C.c_void_p])
+_sig("x264o_slicetype_cost_aq", _i, [C.c_void_p, _i, _i, _i])
 _sig("x264o_slicetype_frame_cost_w", _i, [C.c_void_p] + [_i] * 9)
 _sig("x264o_slicetype_pixel_stats", None, [C.c_void_p, _i, C.c_void_p, C.c_void_p])
 _sig("x264o_slicetype_weight_cost", C.c_long, [C.c_void_p] + [_i] * 7)
@@ -336,6 +337,9 @@ class OracleSlicetype:
 
     def lowres_costs(self, slot, d0, d1):
         return self._arr(L.x264o_slicetype_lowres_costs(self.st, slot, d0, d1), np.uint16, (self.nb,))
+
+    def cost_aq(self, slot, d0, d1):
+        return L.x264o_slicetype_cost_aq(self.st, slot, d0, d1)
 
     def set_aq(self, slot, aq_q8):
         a = None if aq_q8 is None else np.ascontiguousarray(aq_q8, np.int16)

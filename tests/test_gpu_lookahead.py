@@ -186,6 +186,33 @@ def test_mbtree_through_b_pictures_bitexact(gpu, w, h, types, pyramid, b_intra, 
     og.close(); gg.close()
 
 
+@pytest.mark.parametrize("w,h,seed,edges", [(176, 144, 3, 0), (352, 288, 5, 1), (48, 32, 7, 0)])
+def test_aq_weighted_frame_costs_bitexact(gpu, w, h, seed, edges):
+    """fenc->i_cost_est_aq: the I / P / B costs of a triple weighted block by block with the inverse quantiser scale of the picture's AQ offsets
+    (x264 slicetype_mb_cost) — the complexity x264_rc_analyse_slice uses in AQ sessions without macroblock-tree; with no offsets set it is the plain
+    sum of the (capped) block costs"""
+    from gpu_enc import GpuSlicetype
+    n = 4
+    frames = synth_frames(w, h, n, seed=seed)
+    og, gg = O.OracleSlicetype(w, h, slots=n + 1, do_edges=edges), GpuSlicetype(w, h, slots=n + 1, do_edges=edges)
+    for i, f in enumerate(frames):
+        og.put(i, f); gg.put(i, [f])
+    for (p0, p1, b) in [(0, 0, 0), (0, 1, 1), (0, 3, 3), (0, 3, 1), (1, 3, 2)]:
+        assert gg.cost(p0, p1, b, b - p0, p1 - b)[0] == og.cost(p0, p1, b, b - p0, p1 - b)
+        plain = og.cost_aq(b, b - p0, p1 - b)
+        assert gg.cost_aq(b, b - p0, p1 - b) == [plain]
+    for i, f in enumerate(frames):
+        a = O.aq_offsets(f, w, h)
+        og.set_aq(i, a); gg.set_aq(i, a)
+    moved = 0
+    for (p0, p1, b) in [(0, 0, 0), (0, 1, 1), (0, 3, 3), (0, 3, 1), (1, 3, 2)]:
+        c = og.cost_aq(b, b - p0, p1 - b)
+        assert gg.cost_aq(b, b - p0, p1 - b) == [c] and c > 0
+        moved += c != og.cost_est(b, b - p0, p1 - b)
+    assert moved >= 3
+    og.close(); gg.close()
+
+
 def fade_frames(w, h, n, seed, step=6):
     """a clip fading to black: picture i = picture of a moving scene scaled by (1 - i * step / 100), the chroma pulled towards 128"""
     fr = synth_frames(w, h, n, seed=seed)

@@ -644,6 +644,48 @@ int x264gpu_slicetype_set_aq(x264gpu_slicetype *st, int slot, const int16_t *d_a
     if (d_aq_q8) HIP_TRY(hipMemcpyAsync(st->aq[slot], d_aq_q8, (size_t)st->streams * st->nb * sizeof(int16_t), hipMemcpyDeviceToDevice, (hipStream_t)stream));
     return X264GPU_OK;
 }
+// fenc->i_cost_est_aq of a costed triple (x264 slicetype_mb_cost's i_mb_cost_aq summed over the blocks that count): per stream into h_score[streams]
+struct StAqK { int bw, bh, nb, is_i; const int *intra_cost; const uint16_t *lowres_costs; const int16_t *aq; int32_t *out; };
+__global__ __launch_bounds__(256) void k_st_cost_aq(StAqK k)
+{
+    const int s = blockIdx.x;
+    int sum = 0;
+    for (int i = threadIdx.x; i < k.nb; i += 256) {
+        const int bx = i % k.bw, by = i / k.bw;
+        const bool score = (bx > 0 && bx < k.bw - 1 && by > 0 && by < k.bh - 1) || k.bw <= 2 || k.bh <= 2;
+        if (!score) continue;
+        const size_t o = (size_t)s * k.nb + i;
+        const int c = k.is_i ? k.intra_cost[o] : k.lowres_costs[o] & LOWRES_COST_MASK;
+        sum += (c * st_inv_qscale(k.aq ? k.aq[o] : 0) + 128) >> 8;
+    }
+    __shared__ int red[256];
+    red[threadIdx.x] = sum;
+    __syncthreads();
+    for (int d = 128; d > 0; d >>= 1) { if ((int)threadIdx.x < d) red[threadIdx.x] += red[threadIdx.x + d]; __syncthreads(); }
+    if (threadIdx.x == 0) k.out[s] = red[0];
+}
+int x264gpu_slicetype_cost_aq(x264gpu_slicetype *st, int slot, int d0, int d1, int32_t *h_score, void *stream)
+{
+    ARG_TRY(st && h_score && slot >= 0 && slot < st->slots && d0 >= 0 && d1 >= 0 && d0 <= st->bframes + 1 && d1 <= st->bframes + 1);
+    const int nd = st->bframes + 2;
+    ARG_TRY(st->cost_est[slot][(size_t)(d0 * nd + d1) * st->streams] >= 0);
+    StAqK k;
+    memset(&k, 0, sizeof(k));
+    k.bw = st->bw; k.bh = st->bh; k.nb = st->nb; k.is_i = d0 == 0 && d1 == 0;
+    k.intra_cost = st->intra_cost[slot];
+    k.lowres_costs = st->lowres_costs[slot] + (size_t)(d0 * nd + d1) * st->streams * st->nb;
+    k.aq = st->have_aq[slot] ? st->aq[slot] : nullptr;
+    int32_t *d_out = nullptr;
+    HIP_TRY(hipMalloc((void **)&d_out, (size_t)st->streams * sizeof(int32_t)));
+    k.out = d_out;
+    hipLaunchKernelGGL(k_st_cost_aq, dim3(st->streams), dim3(256), 0, (hipStream_t)stream, k);
+    hipError_t e1 = hipGetLastError();
+    hipError_t e2 = e1 == hipSuccess ? hipMemcpyAsync(h_score, d_out, (size_t)st->streams * sizeof(int32_t), hipMemcpyDeviceToHost, (hipStream_t)stream) : e1;
+    hipError_t e3 = e2 == hipSuccess ? hipStreamSynchronize((hipStream_t)stream) : e2;
+    (void)hipFree(d_out);
+    HIP_TRY(e3);
+    return X264GPU_OK;
+}
 int x264gpu_slicetype_clear_propagate(x264gpu_slicetype *st, int slot, void *stream)
 {
     ARG_TRY(st && slot >= 0 && slot < st->slots);

@@ -134,6 +134,7 @@ struct x264_t {
     int last_keyframe = 0;                // display index of the last IDR picture decided (x264 h->lookahead->i_last_keyframe)
     int badapt = 0;
     std::vector<int16_t *> q_tree;       // device, per queue slot: the quantiser offsets the macroblock-tree left with the picture (AQ offsets until it ran)
+    bool st_aq_costs = false;            // AQ session without macroblock-tree on the DPB model: the rate control reads the AQ-weighted frame costs (i_cost_est_aq)
     int st_wait = 0;                     // pictures the lookahead holds before a decision (x264 i_slicetype_length: max(bframes, rc-lookahead under mbtree))
     // cross-session batcher (X264GPU_BATCH=N): N sessions of equal geometry and toolset share ONE device encoder with N streams; the pictures
     // they submit are coded in one lock-step launch, every session entropy-codes its own stream on its caller's thread
@@ -631,6 +632,7 @@ x264_t *x264_encoder_open(x264_param_t *param)
         }
     }
     h->aq_strength_q8 = cfg.aq_mode ? cfg.aq_strength_q8 : 0;
+    h->st_aq_costs = h->st && h->la && !h->mbtree && h->aq_strength_q8 && (h->crf || h->abr);
     h->tree_strength_q8 = (int)(1280.0 * (1.0 - p.rc.f_qcompress) + 0.5);     // 5 * (1 - qcomp), Q8
     h->q_raw.assign((size_t)h->Q, nullptr); h->q_info.assign((size_t)h->Q, nullptr); h->q_aq.assign((size_t)h->Q, nullptr); h->q_tree.assign((size_t)h->Q, nullptr);
     if (h->Q == 1) h->q_raw[0] = h->d_in;            // no delay: the staging buffer is the one slot; with a delay the ring is separate,
@@ -639,8 +641,8 @@ x264_t *x264_encoder_open(x264_param_t *param)
         bool ok = true;
         for (int i = 0; i < h->Q && ok; i++) {
             if (!h->q_raw[(size_t)i]) ok = x264gpu_malloc((void **)&h->q_raw[(size_t)i], insz) == X264GPU_OK;
-            if (ok && h->mbtree) ok = x264gpu_malloc((void **)&h->q_info[(size_t)i], (size_t)h->nmb * 4 * sizeof(int32_t)) == X264GPU_OK &&
-                                       x264gpu_malloc((void **)&h->q_aq[(size_t)i], (size_t)h->nmb * sizeof(int16_t)) == X264GPU_OK;
+            if (ok && h->mbtree) ok = x264gpu_malloc((void **)&h->q_info[(size_t)i], (size_t)h->nmb * 4 * sizeof(int32_t)) == X264GPU_OK;
+            if (ok && (h->mbtree || h->st_aq_costs)) ok = x264gpu_malloc((void **)&h->q_aq[(size_t)i], (size_t)h->nmb * sizeof(int16_t)) == X264GPU_OK;
             if (ok && h->mbtree && h->dpbmode) ok = x264gpu_malloc((void **)&h->q_tree[(size_t)i], (size_t)h->nmb * sizeof(int16_t)) == X264GPU_OK;
         }
         if (ok && h->mbtree) ok = x264gpu_malloc((void **)&h->d_tree, (size_t)h->nmb * sizeof(int16_t)) == X264GPU_OK;
@@ -1459,6 +1461,12 @@ static bool bmode_decide(x264_t *h, bool flushing)
             bool ok = x264gpu_slicetype_frame_cost(h->st, c.slot, c.slot, c.slot, 0, 0, &ic, nullptr) == X264GPU_OK;
             if (ok && closing == PIC_P && h->have_last_nonb) ok = x264gpu_slicetype_frame_cost(h->st, h->last_nonb.slot, c.slot, c.slot, j + 1, 0, &pc, nullptr) == X264GPU_OK;
             else pc = ic;
+            if (ok && h->st_aq_costs) {
+                // x264_rc_analyse_slice: "in AQ, use the weighted score instead" (without macroblock-tree; with it the rate factor does not read the cost)
+                const bool isp = closing == PIC_P && h->have_last_nonb;
+                ok = x264gpu_slicetype_cost_aq(h->st, c.slot, 0, 0, &ic, nullptr) == X264GPU_OK && (!isp || x264gpu_slicetype_cost_aq(h->st, c.slot, j + 1, 0, &pc, nullptr) == X264GPU_OK);
+                if (!isp) pc = ic;
+            }
             if (!ok) { xlog(&h->param, X264_LOG_ERROR, "lookahead frame cost failed: %s\n", x264gpu_last_error()); h->failed = true; return false; }
             c.costs[0] = ic; c.costs[1] = pc;
         }
@@ -1689,7 +1697,7 @@ int x264_encoder_encode(x264_t *h, x264_nal_t **pp_nal, int *pi_nal, x264_pictur
     bool idr = h->la_count == 0 || h->la_gop >= h->keyint || pic_in->i_type == X264_TYPE_IDR || pic_in->i_type == X264_TYPE_KEYFRAME, intra_pic = false;
     if (h->la) {
         if (x264gpu_lookahead_frame_cost(h->la, d_raw, h->la_count == 0, h->d_la, h->mbtree ? h->q_info[(size_t)slot] : nullptr, nullptr) != X264GPU_OK ||
-            (h->mbtree && h->aq_strength_q8 && x264gpu_lookahead_aq_offsets(h->la, d_raw, h->aq_strength_q8, h->q_aq[(size_t)slot], nullptr) != X264GPU_OK) ||
+            ((h->mbtree || h->st_aq_costs) && h->aq_strength_q8 && x264gpu_lookahead_aq_offsets(h->la, d_raw, h->aq_strength_q8, h->q_aq[(size_t)slot], nullptr) != X264GPU_OK) ||
             x264gpu_memcpy_d2h(e.costs, h->d_la, sizeof(e.costs), nullptr) != X264GPU_OK) {
             xlog(&p, X264_LOG_ERROR, "x264_encoder_encode: lookahead failed: %s\n", x264gpu_last_error());
             return -1;
@@ -1727,6 +1735,7 @@ int x264_encoder_encode(x264_t *h, x264_nal_t **pp_nal, int *pi_nal, x264_pictur
                 ok = ok && x264gpu_slicetype_set_aq(h->st, slot, h->aq_strength_q8 ? h->q_aq[(size_t)slot] : nullptr, nullptr) == X264GPU_OK &&
                      x264gpu_memcpy_d2d(h->q_tree[(size_t)slot], h->q_aq[(size_t)slot], (size_t)h->nmb * sizeof(int16_t), nullptr) == X264GPU_OK;
             }
+            if (ok && h->st_aq_costs) ok = x264gpu_slicetype_set_aq(h->st, slot, h->q_aq[(size_t)slot], nullptr) == X264GPU_OK;      // i_inv_qscale_factor for i_cost_est_aq
             if (!ok) {
                 xlog(&p, X264_LOG_ERROR, "x264_encoder_encode: lookahead failed: %s\n", x264gpu_last_error());
                 return -1;
