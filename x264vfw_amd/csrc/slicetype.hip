@@ -675,15 +675,11 @@ int x264gpu_slicetype_cost_aq(x264gpu_slicetype *st, int slot, int d0, int d1, i
     k.intra_cost = st->intra_cost[slot];
     k.lowres_costs = st->lowres_costs[slot] + (size_t)(d0 * nd + d1) * st->streams * st->nb;
     k.aq = st->have_aq[slot] ? st->aq[slot] : nullptr;
-    int32_t *d_out = nullptr;
-    HIP_TRY(hipMalloc((void **)&d_out, (size_t)st->streams * sizeof(int32_t)));
-    k.out = d_out;
+    k.out = st->sums;                          // (the frame-cost calls' scratch sums: every call reads its results back before it returns)
     hipLaunchKernelGGL(k_st_cost_aq, dim3(st->streams), dim3(256), 0, (hipStream_t)stream, k);
-    hipError_t e1 = hipGetLastError();
-    hipError_t e2 = e1 == hipSuccess ? hipMemcpyAsync(h_score, d_out, (size_t)st->streams * sizeof(int32_t), hipMemcpyDeviceToHost, (hipStream_t)stream) : e1;
-    hipError_t e3 = e2 == hipSuccess ? hipStreamSynchronize((hipStream_t)stream) : e2;
-    (void)hipFree(d_out);
-    HIP_TRY(e3);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(h_score, st->sums, (size_t)st->streams * sizeof(int32_t), hipMemcpyDeviceToHost, (hipStream_t)stream));
+    HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
     return X264GPU_OK;
 }
 int x264gpu_slicetype_clear_propagate(x264gpu_slicetype *st, int slot, void *stream)
