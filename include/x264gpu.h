@@ -343,6 +343,8 @@ int  x264gpu_slicetype_weight_cost(x264gpu_slicetype *st, int slot_fenc, int slo
  * AQ offsets (x264_adaptive_quant_frame; x264gpu_lookahead_aq_offsets) weight the costs (i_inv_qscale_factor) and are the base of the result;
  * the result is what x264gpu_encoder_set_mb_qp_offsets takes.  Propagate costs saturate at 32767 as x264's do (applied where a sum is read). */
 int  x264gpu_slicetype_set_aq(x264gpu_slicetype *st, int slot, const int16_t *d_aq_q8, void *stream);
+/* --b-bias (param.i_bframe_bias, -90 .. 100): slicetype_frame_cost scales B costs by 100 / (120 + bias); call once after create */
+int  x264gpu_slicetype_set_bframe_bias(x264gpu_slicetype *st, int bias);
 /* fenc->i_cost_est_aq[d0][d1] of a triple whose cost has been computed: the block costs weighted with the inverse quantiser scale of the picture's AQ
  * offsets (set_aq), per stream into h_score[streams] — the complexity x264_rc_analyse_slice hands the rate control in AQ sessions without macroblock-tree
  * ([x264-upstream] encoder/slicetype.c slicetype_mb_cost, ratecontrol.c x264_rc_analyse_slice) */

@@ -237,6 +237,8 @@ static void mb_cost(x264o_slicetype *st, int s0, int s1, int sb, int d0, int d1,
 }
 
 int x264o_slicetype_frame_cost_w(x264o_slicetype *st, int s0, int s1, int sb, int d0, int d1, int on, int scale, int denom, int offset);
+/* --b-bias: h->param.i_bframe_bias in the scaling of B costs (score * 100 / (120 + bias)) */
+void x264o_slicetype_set_bframe_bias(x264o_slicetype *st, int bias) { st->bframe_bias = bias < -90 ? -90 : bias > 100 ? 100 : bias; }
 /* slicetype_frame_cost(p0, p1, b): slots of the three pictures and the distances d0 = b - p0, d1 = p1 - b.  Returns the frame's score. */
 int x264o_slicetype_frame_cost(x264o_slicetype *st, int s0, int s1, int sb, int d0, int d1) { return x264o_slicetype_frame_cost_w(st, s0, s1, sb, d0, d1, 0, 1, 0, 0); }
 /* ... with the explicit luma weight x264_weights_analyse( b_lookahead = 1 ) found for a P cost that is searched for the first time: the list-0 search

@@ -281,6 +281,7 @@ _sig("x264o_slicetype_intra_costs", C.c_void_p, [C.c_void_p, _i])
 _sig("x264o_slicetype_lowres_costs", C.c_void_p, [C.c_void_p, _i, _i, _i])
 _sig("x264o_slicetype_set_aq", None, [C.c_void_p, _i, C.c_void_p])
 _sig("x264o_slicetype_cost_aq", _i, [C.c_void_p, _i, _i, _i])
+_sig("x264o_slicetype_set_bframe_bias", None, [C.c_void_p, _i])
 _sig("x264o_slicetype_frame_cost_w", _i, [C.c_void_p] + [_i] * 9)
 _sig("x264o_slicetype_pixel_stats", None, [C.c_void_p, _i, C.c_void_p, C.c_void_p])
 _sig("x264o_slicetype_weight_cost", C.c_long, [C.c_void_p] + [_i] * 7)

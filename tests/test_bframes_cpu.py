@@ -397,6 +397,18 @@ def test_host_session_says_what_it_does_not_run(tmp_path):
         assert needle in text, (needle, text)
 
 
+def test_host_session_b_bias_moves_the_b_decisions(tmp_path):
+    """--b-bias: x264's i_bframe_bias enters b-adapt 1's thresholds AND the scaling of every B cost in slicetype_frame_cost (100 / (120 + bias)):
+    a positive bias never gives fewer B pictures than a negative one"""
+    import subprocess
+    subprocess.check_call(["make", "-s", "-C", __file__.rsplit("/", 1)[0] + "/stub"])
+    counts = {}
+    for bias in (-50, 0, 60):
+        info, _ = _host_b_session(tmp_path, 14, ["qp=26", "keyint=60", "scenecut=0", f"b-bias={bias}"], 128, 96, seed=2)
+        counts[bias] = _types_by_display(info["recs"]).replace("R", "B").count("B")
+    assert counts[-50] <= counts[0] <= counts[60] and counts[-50] < counts[60], counts
+
+
 def test_host_session_single_pass_abr_with_b_pictures(tmp_path):
     """--bitrate N (x264vfw's single-pass ABR page, config.c / codec.c:x264vfw 'Single pass - bitrate-based (ABR)') keeps B pictures, the
     lookahead and macroblock-tree: the coded size of every picture, B pictures' divided by pbratio, steers the rate factor

@@ -682,6 +682,13 @@ int x264gpu_slicetype_cost_aq(x264gpu_slicetype *st, int slot, int d0, int d1, i
     HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
     return X264GPU_OK;
 }
+// --b-bias (x264 i_bframe_bias, -90 .. 100): B costs are scaled by 100 / (120 + bias); set once, before the first cost
+int x264gpu_slicetype_set_bframe_bias(x264gpu_slicetype *st, int bias)
+{
+    ARG_TRY(st && bias >= -90 && bias <= 100);
+    st->bframe_bias = bias;
+    return X264GPU_OK;
+}
 int x264gpu_slicetype_clear_propagate(x264gpu_slicetype *st, int slot, void *stream)
 {
     ARG_TRY(st && slot >= 0 && slot < st->slots);

@@ -630,6 +630,8 @@ x264_t *x264_encoder_open(x264_param_t *param)
             x264_encoder_close(h);
             return nullptr;
         }
+        p.i_bframe_bias = clampi(p.i_bframe_bias, -90, 100);
+        (void)x264gpu_slicetype_set_bframe_bias(h->st, p.i_bframe_bias);          // --b-bias also scales the B costs of slicetype_frame_cost
     }
     h->aq_strength_q8 = cfg.aq_mode ? cfg.aq_strength_q8 : 0;
     h->st_aq_costs = h->st && h->la && !h->mbtree && h->aq_strength_q8 && (h->crf || h->abr);
