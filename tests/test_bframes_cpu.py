@@ -199,7 +199,7 @@ def test_host_session_b_adapt_1_static_content_uses_b_pictures(tmp_path):
 
 @pytest.mark.parametrize("seed,extra", [(2, []), (7, ["scene_len=9"]), (4, ["static=1"])])
 def test_host_session_b_adapt_2_is_the_cheapest_path(tmp_path, seed, extra):
-    """--b-adapt 2 (presets slow and up): x264 slicetype_path, a Viterbi search over the lengths of the window, must find the cheapest way to
+    """--b-adapt 2 (presets slower and up): x264 slicetype_path, a Viterbi search over the lengths of the window, must find the cheapest way to
     code the window in runs of at most --bframes B pictures — checked against an exhaustive enumeration of every such path on the same frame
     costs (oracle/slicetype.c) for the first decision of the session; the stream decodes"""
     n, w, h = 16, 128, 96

@@ -790,7 +790,7 @@ def encode_delayed(h_, w, h, frames):
     (176, 288, 14, {"crf": 24, "keyint": 30, "bframes": 3, "rc-lookahead": 6, "slices": 6}, None),                  # B pictures in --slices 6
     (176, 288, 14, {"crf": 24, "keyint": 30, "bframes": 3, "rc-lookahead": 6, "sliced-threads": None, "threads": 3}, None),      # ... and in x264's slice threads
     (176, 144, 30, {"bitrate": 600, "keyint": 30, "bframes": 3, "rc-lookahead": 10}, None),
-    (176, 144, 22, {"crf": 24, "keyint": 60, "bframes": 3, "b-adapt": 2, "rc-lookahead": 14}, None),                # presets slow and up: the trellis over picture types on the device's frame costs                          # single-pass ABR keeps B pictures, the lookahead and macroblock-tree
+    (176, 144, 22, {"crf": 24, "keyint": 60, "bframes": 3, "b-adapt": 2, "rc-lookahead": 14}, None),                # presets slower and up: the trellis over picture types on the device's frame costs                          # single-pass ABR keeps B pictures, the lookahead and macroblock-tree
 ])
 def test_b_session_through_the_encode_api(gpu, w, h, n, opts, pattern):
     """B pictures through x264_encoder_encode (codec.c:1693): types / pts / dts as x264 hands them to the muxers (output/matroska.c:199-202), the
