@@ -1541,6 +1541,11 @@ static int bmode_qp(x264_t *h, const x264_t::BPlanned &pl, const DpbPlan &plan, 
     else if (i1) q = q0;
     else q = (q0 * dt1 + q1 * dt0) / (dt0 + dt1);
     q += pl.type == PIC_BREF ? pb_offset / 2 : pb_offset;
+    q = q < p.rc.i_qp_min ? p.rc.i_qp_min : q > p.rc.i_qp_max ? p.rc.i_qp_max : q;
+    // x264_ratecontrol_start: accum_p_qp_update runs for every picture type — a B picture's quantiser enters the running average an I picture
+    // after P pictures takes its quantiser from
+    h->rc.accum_p_qp = h->rc.accum_p_qp * 0.95 + q;
+    h->rc.accum_p_norm = h->rc.accum_p_norm * 0.95 + 1.0;
     *qp_float = q;
     return clampi((int)(q + 0.5), p.rc.i_qp_min, p.rc.i_qp_max);
 }
