@@ -144,7 +144,7 @@ static void settle_mb_qp(x264o_encoder *e, x264gpu_mb *mbs, int slice_qp)
     const int ns = e->cfg.slices > 1 ? e->cfg.slices : 1;
     for (int i = 0, sl = 0; i < e->mbw * e->mbh; i++) {
         x264gpu_mb *m = &mbs[i];
-        if (i == ((e->mbh * sl + ns / 2) / ns) * e->mbw) { last = slice_qp; sl++; }      /* a slice starts from the slice quantiser */
+        if (i == ((e->mbh * sl + ns / 2) / ns) * e->mbw) { last = e->mbqp[i]; sl++; }      /* a slice starts from the slice quantiser = its first macroblock's */
         if (m->type != X264GPU_MB_I16x16 && !m->cbp_luma && !m->cbp_chroma) m->qp = (uint8_t)last;
         /* x264's entropy coders (qp_delta writers): an I16x16 with nothing coded at all (no DC either) does not spend a delta on RAISING
          * the quantiser — it takes the previous one, and that is the qp the loop filter then sees */
@@ -307,8 +307,10 @@ int x264o_encoder_encode_pic(x264o_encoder *e, const uint8_t *i420, const x264gp
          * after the other by one thread: the statistics (the fast-intra decision reads the intra count) run on through the picture */
         e->row0 = (e->mbh * sl + ns / 2) / ns; e->row1 = (e->mbh * (sl + 1) + ns / 2) / ns;
         if (!e->cfg.slices_plain) e->intra_count = 0;
-        e->last_qp = slice_qp;
-        if (e->cfg.cabac && (e->cfg.rd || e->cfg.trellis)) { x264o_cabac_init_states(e->cabac_state, slice_type != X264GPU_SLICE_I, slice_qp); e->last_dqp = 0; }
+        /* x264_slice_write: the slice's quantiser — header, CABAC context initialisation, start of the mb_qp_delta chain — is its FIRST macroblock's */
+        const int sl_qp = e->mbqp[e->row0 * e->mbw];
+        e->last_qp = sl_qp;
+        if (e->cfg.cabac && (e->cfg.rd || e->cfg.trellis)) { x264o_cabac_init_states(e->cabac_state, slice_type != X264GPU_SLICE_I, sl_qp); e->last_dqp = 0; }
         for (int mby = e->row0; mby < e->row1; mby++)
             for (int mbx = 0; mbx < e->mbw; mbx++) {
                 const int mi = mby * e->mbw + mbx;

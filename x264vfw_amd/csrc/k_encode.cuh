@@ -86,7 +86,7 @@ __global__ __launch_bounds__(64) void k_settle_qp(EncK k)
     // one wave per (stream, slice): the chain starts from the slice quantiser at every slice
     const int nsl = k.slices > 1 ? k.slices : 1, mb0 = ((k.mbh * (int)blockIdx.y + nsl / 2) / nsl) * k.mbw, mb1 = ((k.mbh * ((int)blockIdx.y + 1) + nsl / 2) / nsl) * k.mbw;
     x264gpu_mb *mbs = k.mb + (size_t)s * k.nmb;
-    int carry = slice_qp(k, s);
+    int carry = k.mbqp[(size_t)s * k.nmb + mb0];          // the slice quantiser = the first macroblock's (x264_slice_write)
     for (int base = mb0; base < mb1; base += 64) {
         const int i = base + lane;
         const bool in = i < mb1;

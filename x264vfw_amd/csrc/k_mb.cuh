@@ -1431,7 +1431,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(MB_WAVES_PER
     // macroblocks' blocks for the nC of the bit counts; the quantiser the previous coded macroblock left (mb_qp_delta bits)
     __shared__ __attribute__((aligned(16))) int16_t rd_lvs[RD ? X264GPU_MB_LEVELS : 1];
     __shared__ uint8_t rd_ntc[2][RD == 1 ? 24 : 1];
-    int last_qp = slice_qp(k, s);
+    // x264_slice_write: the slice's quantiser (header, context initialisation, start of the mb_qp_delta chain) is its FIRST macroblock's
+    int last_qp = uni((int)k.mbqp[(size_t)s * k.nmb + mb_first]);
     // CABAC RD: the slice's context variables (two registers, see cabac_rd.cuh), the probability model, the previous macroblock's mb_qp_delta
     Cab cab = { 0, 0, 0, 0, 0 };
     uint32_t cab_modelv = 0;

@@ -361,9 +361,14 @@ void write_slice_header(BitWriter &bw, const SliceParams &p)
 // Row bands are entropy-coded by `threads` threads (CAVLC has no state that crosses macroblocks except mb_skip_run, which the
 // stitching below carries over; nC contexts come from the precomputed total_coeff table, predictors from the records), then
 // their bit strings are concatenated behind the slice header.  The bytes do not depend on the number of threads.
-void write_slice(std::vector<uint8_t> &out, const SliceParams &p, const x264gpu_mb *mbs, const int16_t *levels,
+void write_slice(std::vector<uint8_t> &out, const SliceParams &p_in, const x264gpu_mb *mbs, const int16_t *levels,
                  bool annexb, bool long_startcode, SliceStats *stats, int threads)
 {
+    // x264_slice_write: "set the QP equal to the first QP in the slice for more accurate CABAC initialization" — the slice header carries the first
+    // macroblock's quantiser (under AQ / macroblock-tree it differs from the picture's); the device started the slice's quantiser chain and its
+    // context variables from the same value, and a first macroblock that codes nothing inherits exactly it
+    SliceParams p = p_in;
+    p.qp = mbs[(size_t)p.first_row * p.mbw].qp;
     if (p.cabac) { write_slice_cabac(out, p, mbs, levels, annexb, long_startcode, stats); return; }      // one arithmetic code word per slice: no row bands
     BitWriter bw;
     write_slice_header(bw, p);
