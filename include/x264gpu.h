@@ -249,6 +249,8 @@ typedef struct x264gpu_pic {
      * the same slot twice in slot[0][], the analysis refines the duplicate from reference 0's vector instead of searching it */
     struct { int8_t on, denom; int16_t scale, offset; } wl0[X264GPU_MAX_LIST];
     int blind_dupe;
+    int qp_frac_q8;           /* rate-controlled sessions: the picture's quantiser is qp + qp_frac_q8 / 256 (x264 rc->qpm, a float); a macroblock's quantiser
+                               * under AQ / macroblock-tree is round(that + its offset) — one rounding, as x264_ratecontrol_mb_qp has it.  -128 .. 127, 0 otherwise */
 } x264gpu_pic;
 
 int  x264gpu_encoder_create(x264gpu_encoder **enc, const x264gpu_config *cfg);

@@ -113,11 +113,11 @@ static int aq_log2_q8(uint32_t x)
     int lz = 31 - __builtin_clz(x);
     return lz * 256 + x264o_log2_lut()[((x << (31 - lz)) >> 24) & 0x7f];
 }
-static void compute_mb_qp(x264o_encoder *e, int slice_qp)
-{
+static void compute_mb_qp(x264o_encoder *e, int slice_qp, int frac_q8)
+{          /* x264_ratecontrol_mb_qp: clip3(qpm + offset + 0.5): the picture's float quantiser (slice_qp + frac_q8 / 256) and the offset are rounded ONCE */
     const int n = e->mbw * e->mbh;
     if (e->ext_off_q8) {        /* offsets decided by the lookahead (x264: frame->f_qp_offset, read by x264_ratecontrol_mb_qp) */
-        for (int i = 0; i < n; i++) e->mbqp[i] = (uint8_t)clampi(slice_qp + ((e->ext_off_q8[i] + 128) >> 8), 1, 51);
+        for (int i = 0; i < n; i++) e->mbqp[i] = (uint8_t)clampi((slice_qp * 256 + frac_q8 + e->ext_off_q8[i] + 128) >> 8, 1, 51);
         return;
     }
     if (!e->cfg.aq_mode) { memset(e->mbqp, slice_qp, (size_t)n); return; }
@@ -132,7 +132,7 @@ static void compute_mb_qp(x264o_encoder *e, int slice_qp)
             }
             uint32_t energy = (sqr - (sum * sum >> 8)) + (squ - (su * su >> 6)) + (sqv - (sv * sv >> 6));
             int adj_q8 = (e->cfg.aq_strength_q8 * (aq_log2_q8(energy ? energy : 1) - 3693)) >> 8;      /* 14.427 * 256 = 3693 */
-            e->mbqp[mby * e->mbw + mbx] = (uint8_t)clampi(slice_qp + ((adj_q8 + 128) >> 8), 1, 51);
+            e->mbqp[mby * e->mbw + mbx] = (uint8_t)clampi((slice_qp * 256 + frac_q8 + adj_q8 + 128) >> 8, 1, 51);
         }
 }
 
@@ -297,7 +297,8 @@ int x264o_encoder_encode_pic(x264o_encoder *e, const uint8_t *i420, const x264gp
     if (slice_type == X264GPU_SLICE_B) bipred_init(e);
     ingest(e, i420);
     const int slice_qp = pic->qp;
-    compute_mb_qp(e, slice_qp);
+    if (pic->qp_frac_q8 < -128 || pic->qp_frac_q8 > 127) return -1;
+    compute_mb_qp(e, slice_qp, pic->qp_frac_q8);
     e->mbs = mbs; e->levels = levels; e->intra_count = 0;
     e->slot_nref[e->cur] = e->nref; e->slot_poc[e->cur] = e->poc; e->slot_ref0poc[e->cur] = e->nref ? e->slot_poc[ref_slot(e, 0)] : 0;
     /* the macroblock loop: raster order, every macroblock analysed AND coded before the next one starts (x264_slice_write) */

@@ -23,7 +23,7 @@ def describe(mbs_g, mbs_o, i):
     return f"\n gpu {f(mbs_g)}\n cpu {f(mbs_o)}"
 
 
-def run(gpu, w, h, types, seed, streams=1, bframes=3, pyramid=1, weightp=0, weights=None, frames=None, **over):
+def run(gpu, w, h, types, seed, streams=1, bframes=3, pyramid=1, weightp=0, weights=None, frames=None, qp_frac=None, **over):
     from gpu_enc import GpuEncoder
     from x264vfw_amd import host_api as HL
     kw = dict(MEDIUM, **over)
@@ -39,6 +39,8 @@ def run(gpu, w, h, types, seed, streams=1, bframes=3, pyramid=1, weightp=0, weig
     for k, (disp, pt) in enumerate(order):
         pic, _ = dpb.plan(pt, disp, bgop.follow_of(order, k), weight=(weights or {}).get(disp) if pt == 2 else None)
         pic.qp = 20 if pt <= 1 else 23 if pt == 2 else 25 if pt == 4 else 24
+        if qp_frac:          # a rate-controlled session's float quantiser: qp + frac / 256 (enters the AQ quantisers before the rounding)
+            pic.qp_frac_q8 = qp_frac[k % len(qp_frac)]
         o_mb, o_lv = og.encode_pic(frames[disp], pic)
         g_mb, g_lv = gg.encode_pics([frames[disp]] * streams, [pic] * streams)
         for s in range(streams):

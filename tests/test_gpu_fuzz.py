@@ -160,4 +160,4 @@ def test_random_b_picture_configs_bitexact(gpu, seed):
     rnd = random.Random(seed)
     for it in range(12):
         w, h, types, fseed, bframes, pyramid, weightp, kw = random_b_case(rnd)
-        run(gpu, w, h, types, fseed, bframes=bframes, pyramid=pyramid, weightp=weightp, weights=kw.pop("_weights", None), **kw)
+        run(gpu, w, h, types, fseed, bframes=bframes, pyramid=pyramid, weightp=weightp, weights=kw.pop("_weights", None), qp_frac=kw.pop("_qp_frac", None), **kw)

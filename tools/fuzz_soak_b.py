@@ -42,6 +42,8 @@ def random_b_case(rnd):
             kw.update(slices=rnd.randint(2, mbh), slices_plain=1)
     if rnd.random() < 0.3:           # variance AQ: per-macroblock quantisers, the within-1 rule of x264_macroblock_analyse, mb_qp_delta in the RD costs
         kw.update(aq_mode=1, aq_strength_q8=rnd.choice([133, 266, 400]))
+        if rnd.random() < 0.6:
+            kw["_qp_frac"] = [rnd.randint(-128, 127) for _ in range(4)]
     weightp = rnd.choice([0, 0, 2]) if refs >= 2 else 0
     if rnd.random() < 0.25:          # explicit luma weights on the P pictures (what x264_weights_analyse hands a fade): --weightp 1 or 2
         weightp = rnd.choice([1, 2])
@@ -87,7 +89,7 @@ def main():
             total += 1
             try:
                 frames = panned_frames(w, h, len(types), fseed, rnd.randint(-30, 30), rnd.randint(-30, 30)) if rnd.random() < 0.25 else None
-                run(None, w, h, types, fseed, bframes=bframes, pyramid=pyramid, weightp=weightp, weights=kw.pop("_weights", None), frames=frames, **kw)
+                run(None, w, h, types, fseed, bframes=bframes, pyramid=pyramid, weightp=weightp, weights=kw.pop("_weights", None), frames=frames, qp_frac=kw.pop("_qp_frac", None), **kw)
             except AssertionError as e:
                 bad += 1
                 print(f"MISMATCH seed {seed} case {it}: {w}x{h} {types} bframes {bframes} pyramid {pyramid} weightp {weightp} {kw}: {str(e)[:300]}", flush=True)

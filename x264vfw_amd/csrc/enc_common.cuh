@@ -58,6 +58,7 @@ struct EncK {
     const uint16_t *cost_all; // [52][2 * MVCOST_HALF]
     const int8_t *stream_qp;  // optional [streams]: each stream's slice quantiser (x264gpu_encoder_set_stream_qps); k.qp otherwise
     int aq_strength_q8;
+    int qp_frac_q8;           // the picture's quantiser is qp + qp_frac_q8 / 256 (x264gpu_pic.qp_frac_q8): enters the per-macroblock quantisers before the rounding
     int qp_snap;              // --aq-mode != 0: a macroblock quantiser within 1 of the previous macroblock's takes that one (x264_macroblock_analyse)
     int *wf_progress;         // [streams][2][WFG_ROWS]: row counters of the wavefront kernels when ONE stream spans several workgroups
     // motion side data of the raster macroblock loop (k_mb.cuh; x264: h->mb.mvr, frame->mv16x16, frame->mb_type)

@@ -334,6 +334,7 @@ static int encode_core(x264gpu_encoder *e, const uint8_t *d_i420, const x264gpu_
     ARG_TRY(pic.dst >= 0 && pic.dst < e->slots && pic.qp >= 0 && pic.qp <= 51);
     ARG_TRY(!bslice || (e->cfg.rd && e->cfg.cabac && e->cfg.dpb > 0 && e->cfg.subme >= 7));      // B pictures: RD sessions with CABAC; x264 analyses B slices without RD at subme 6
     const int n0 = slice_type == X264GPU_SLICE_I ? 0 : pic.nref[0], n1 = bslice ? pic.nref[1] : 0;
+    ARG_TRY(pic.qp_frac_q8 >= -128 && pic.qp_frac_q8 <= 127);
     ARG_TRY(n0 >= 0 && n0 <= 7 && n1 >= 0 && n1 <= 3 && n0 + n1 <= 8 && (slice_type == X264GPU_SLICE_I || n0 > 0) && (!bslice || n1 > 0));      // list 0: up to 5 pictures + --weightp duplicates
     for (int l = 0; l < 2; l++) for (int r = 0; r < (l ? n1 : n0); r++) ARG_TRY(pic.slot[l][r] >= 0 && pic.slot[l][r] < e->slots && pic.slot[l][r] != pic.dst);
     const int S = e->cfg.streams;
@@ -423,7 +424,7 @@ static int encode_core(x264gpu_encoder *e, const uint8_t *d_i420, const x264gpu_
     // per-macroblock quantisers: always materialised (the macroblock loop reads every quantiser-dependent value per macroblock)
     const bool aq = e->cfg.aq_mode != 0 || e->ext_off != nullptr || e->use_stream_qp;
     k.stream_qp = e->use_stream_qp ? e->stream_qp + (size_t)e->stream_qp_sel * e->cfg.streams : nullptr;
-    k.mbqp = e->mbqp; k.q4tab = e->q4tab; k.q8tab = e->q8tab; k.lambda_tab = e->lambda_tab; k.cost_all = e->cost_all; k.aq_strength_q8 = e->cfg.aq_strength_q8; k.qp_snap = e->cfg.aq_mode != 0;
+    k.mbqp = e->mbqp; k.q4tab = e->q4tab; k.q8tab = e->q8tab; k.lambda_tab = e->lambda_tab; k.cost_all = e->cost_all; k.aq_strength_q8 = e->cfg.aq_strength_q8; k.qp_snap = e->cfg.aq_mode != 0; k.qp_frac_q8 = pic.qp_frac_q8;
     if (e->ext_off || !e->cfg.aq_mode) hipLaunchKernelGGL(k_apply_qp_offsets, dim3((k.nmb + 255) / 256, S), dim3(256), 0, st, k, e->ext_off);
     else hipLaunchKernelGGL(k_aq, dim3((k.nmb + 15) / 16, S), dim3(256), 0, st, k);
     mask |= 1;
@@ -512,7 +513,7 @@ int x264gpu_encode_pictures(x264gpu_encoder *e, const uint8_t *d_i420, const x26
     for (int s = 1; s < S; s++) {
         ARG_TRY(pics[s].slice_type == pics[0].slice_type && pics[s].poc == pics[0].poc && pics[s].dst == pics[0].dst && pics[s].keep == pics[0].keep &&
                 pics[s].nref[0] == pics[0].nref[0] && pics[s].nref[1] == pics[0].nref[1] && !memcmp(pics[s].slot, pics[0].slot, sizeof(pics[0].slot)) &&
-                pics[s].blind_dupe == pics[0].blind_dupe && !memcmp(pics[s].wl0, pics[0].wl0, sizeof(pics[0].wl0)));
+                pics[s].blind_dupe == pics[0].blind_dupe && pics[s].qp_frac_q8 == pics[0].qp_frac_q8 && !memcmp(pics[s].wl0, pics[0].wl0, sizeof(pics[0].wl0)));
         same_qp = same_qp && pics[s].qp == pics[0].qp;
     }
     if (!same_qp) {

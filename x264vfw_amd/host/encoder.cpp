@@ -1569,6 +1569,8 @@ static int encode_bmode(x264_t *h, x264_nal_t **pp_nal, int *pi_nal, x264_pictur
     x264gpu_pic pic = plan.pic;
     double qpf = 0;
     pic.qp = bmode_qp(h, pl, plan, &qpf);
+    // x264_ratecontrol_mb_qp: a macroblock's quantiser is round(rc->qpm + its AQ / macroblock-tree offset) with qpm the picture's FLOAT quantiser
+    pic.qp_frac_q8 = clampi((int)lround((qpf - pic.qp) * 256.0), -128, 127);
     h->rc_frames++;
     if (h->st) {
         // x264_mb_predict_mv_ref16x16: the lookahead's vectors towards reference 0 of each list as search candidates, when that search ran
