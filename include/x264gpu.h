@@ -126,8 +126,7 @@ enum { X264GPU_MB_I4x4 = 0, X264GPU_MB_I8x8 = 1, X264GPU_MB_I16x16 = 2, X264GPU_
         * 8x8 block L0 / L1 / BI by the same rule or direct (bit k of direct8) */
        X264GPU_MB_B_DIRECT = 7, X264GPU_MB_B_SKIP = 8, X264GPU_MB_B_INTER = 9, X264GPU_MB_B_8x8 = 10 };
 enum { X264GPU_SLICE_P = 0, X264GPU_SLICE_B = 1, X264GPU_SLICE_I = 2 /* IDR picture: empties the DPB */,
-       X264GPU_SLICE_I_NONIDR = 3 /* intra picture that keeps the DPB (x264's X264_TYPE_I, e.g. a scenecut inside min-keyint) */,
-       X264GPU_SLICE_NONE = -1 /* x264gpu_encode_pictures: the stream sits this call out */ };
+       X264GPU_SLICE_I_NONIDR = 3 /* intra picture that keeps the DPB (x264's X264_TYPE_I, e.g. a scenecut inside min-keyint) */ };
 
 /* per-macroblock decision record written by the GPU, consumed by the host entropy coder (64 B) */
 typedef struct x264gpu_mb {
@@ -236,7 +235,7 @@ typedef struct x264gpu_config {
  * first; list 1 (B) = pictures after it; the host keeps the DPB (sliding window, --b-pyramid, duplicates of --weightp) and names slots. */
 #define X264GPU_MAX_LIST 8
 typedef struct x264gpu_pic {
-    int slice_type;           /* X264GPU_SLICE_I (IDR) / _I_NONIDR / _P / _B; X264GPU_SLICE_NONE: nothing for this stream in this call */
+    int slice_type;           /* X264GPU_SLICE_I (IDR) / _I_NONIDR / _P / _B — the same for every stream of a call */
     int qp;                   /* slice quantiser */
     int poc;                  /* picture order count: 2 x (display index since the IDR) */
     int dst;                  /* DPB slot that receives the reconstruction (0 .. dpb) */
@@ -264,9 +263,10 @@ int  x264gpu_encoder_mb_count(const x264gpu_encoder *enc);
  * x264_macroblock_encode, x264_frame_deblock_row, x264_frame_filter of [x264-upstream]. */
 int  x264gpu_encode_frames(x264gpu_encoder *enc, const uint8_t *d_i420, int slice_type,
                            x264gpu_mb *d_mb, int16_t *d_levels, void *stream);
-/* The same with explicit picture control, one entry of `pics` (host array) per stream: B pictures, b-pyramid, per-stream slice types and
- * quantisers.  Streams of different slice types are batched per type behind this call.  B pictures need a CABAC session with RD (cfg.cabac,
- * cfg.rd).  x264gpu_encode_frames is this call with the sliding-window DPB of an I / P stream. */
+/* The same with explicit picture control, one entry of `pics` (host array) per stream: B pictures, b-pyramid, per-stream quantisers.
+ * The streams of a call run in LOCK-STEP: slice type, POC, destination slot, keep flag, both reference lists, explicit weights and the
+ * blind duplicate must be the same in every entry (EINVAL otherwise); qp and qp_frac_q8 may differ per stream.  B pictures need a CABAC
+ * session with RD (cfg.cabac, cfg.rd).  x264gpu_encode_frames is this call with the sliding-window DPB of an I / P stream. */
 int  x264gpu_encode_pictures(x264gpu_encoder *enc, const uint8_t *d_i420, const x264gpu_pic *pics,
                              x264gpu_mb *d_mb, int16_t *d_levels, void *stream);
 /* A9 as a primitive ([x264-upstream] common/deblock.c x264_frame_deblock_row over a whole picture): the in-loop filter alone on

@@ -61,6 +61,11 @@ typedef struct {          /* x264_mb_analysis_t + the parts of h->mb the analysi
     int satd8x8b[3][4], cost_est16x8[2], cost_est8x16[2];
     int sub8[4], part16x8[2], part8x16[2];      /* per block / half: 0 list 0, 1 list 1, 2 both, 3 direct (8x8 only) */
     int rd16l[2], rd16bi, rd16direct, rd8x8bi, rd16x8bi, rd8x16bi, bskip_cost;
+    /* RD refinement (i_mbrd >= 2, subme >= 8): x264's h->mb.cache.non_zero_count of this macroblock as the LAST encode of any kind left it
+     * (0 / 1 flags under CABAC: luma blocks 0..15, chroma AC plane * 4 + block), the by-products of the intra analysis that intra_rd_refine
+     * reads (i_satd_i16x16_dir / i_satd_i8x8_dir / i_satd_chroma_dir, i_cbp_i8x8_luma), the chroma coded block pattern the refinement settled on */
+    uint8_t nnzc[24];
+    int satd_i16_dir[7], satd_i8_dir[4][12], satd_chroma_dir[7], cbp_i8;
 } actx;
 
 /* ---------------------------------------------------------------------------------------------------------------------------
@@ -1133,6 +1138,7 @@ static void analyse_intra_chroma(actx *a)
         x264o_predict_8x8c(pu, 8, nu + 10, 9, m);
         x264o_predict_8x8c(pv, 8, nvv + 10, 9, m);
         const int c = mbcmp(a, pu, 8, fu, 8, 8, 8) + mbcmp(a, pv, 8, fv, 8, 8, 8) + a->lambda * bs_size_ue(sig);
+        a->satd_chroma_dir[m] = c;
         if (c < a->satd_chroma) { a->satd_chroma = c; a->predc = m; }
     }
 }
@@ -1156,11 +1162,13 @@ static void analyse_intra(actx *a, int i_satd_inter)
             for (int m = 0; m < 3; m++) {       /* V, H, DC */
                 x264o_predict_16x16(pred, 16, rec, e->rs, m);
                 const int c = mbcmp(a, pred, 16, fenc, e->fs, 16, 16) + lambda * bs_size_ue(m);
+                a->satd_i16_dir[m] = c;
                 if (c < a->satd_i16) { a->satd_i16 = c; a->pred16 = m; }
             }
             if (a->satd_i16 <= i16x16_thresh) {
                 x264o_predict_16x16(pred, 16, rec, e->rs, I_PRED_16x16_P);
                 const int c = mbcmp(a, pred, 16, fenc, e->fs, 16, 16) + lambda * bs_size_ue(3);
+                a->satd_i16_dir[I_PRED_16x16_P] = c;
                 if (c < a->satd_i16) { a->satd_i16 = c; a->pred16 = I_PRED_16x16_P; }
             }
         } else {
@@ -1172,6 +1180,7 @@ static void analyse_intra(actx *a, int i_satd_inter)
                 const int m = modes[i], sig = m > I_PRED_16x16_P ? I_PRED_16x16_DC : m;
                 x264o_predict_16x16(pred, 16, rec, e->rs, m);
                 const int c = mbcmp(a, pred, 16, fenc, e->fs, 16, 16) + lambda * bs_size_ue(sig);
+                a->satd_i16_dir[m] = c;
                 if (c < a->satd_i16) { a->satd_i16 = c; a->pred16 = m; }
             }
         }
@@ -1200,17 +1209,18 @@ static void analyse_intra(actx *a, int i_satd_inter)
                 for (int m = 0; m < 3; m++) { x264o_predict_8x8(p8, 8, edge, m); satd[m] = a->satd ? x264o_sa8d(p8, 8, f, e->fs, 8, 8) : x264o_sad(p8, 8, f, e->fs, 8, 8); }
                 const int favor_vertical = satd[I_PRED_4x4_H] > satd[I_PRED_4x4_V];
                 if (i_pred_mode < 3) satd[i_pred_mode] -= 3 * lambda;
-                for (int i = 2; i >= 0; i--) if (satd[i] < i_best) { i_best = satd[i]; bestm = i; }
+                for (int i = 2; i >= 0; i--) { a->satd_i8_dir[idx][i] = satd[i] + 4 * lambda; if (satd[i] < i_best) { i_best = satd[i]; bestm = i; } }
                 /* analysis shortcut: skip the modes far from the favoured direction — unless RD decides and fast-intra is off (i_mbrd < 1 + b_fast_intra) */
                 if (a->mbrd < 1 + a->b_fast_intra) predict_mode = intra_analysis_shortcut[predict_mode[8] >= 0][favor_vertical];
                 else predict_mode += 3;
             }
-            for (; *predict_mode >= 0 && i_best >= 0; predict_mode++) {
+            for (; *predict_mode >= 0 && (i_best >= 0 || a->mbrd >= 2); predict_mode++) {       /* (RD refinement wants every mode's cost) */
                 const int m = *predict_mode;
                 x264o_predict_8x8(p8, 8, edge, real_mode4(m, avail));
                 int c = a->satd ? x264o_sa8d(p8, 8, f, e->fs, 8, 8) : x264o_sad(p8, 8, f, e->fs, 8, 8);
                 if (i_pred_mode == m) c -= 3 * lambda;
                 if (c < i_best) { i_best = c; bestm = m; }
+                a->satd_i8_dir[idx][m] = c + 4 * lambda;
             }
             i_cost += i_best + 3 * lambda;
             a->pred8[idx] = bestm;
@@ -1515,9 +1525,18 @@ static void rd_reset(const actx *a, x264gpu_mb *mb, int16_t *lv)
     memset(lv, 0, X264GPU_MB_LEVELS * sizeof(int16_t));
 }
 
+/* what a whole-macroblock encode leaves in x264's non_zero_count cache (CABAC: flags; an 8x8 transform block sets its four entries alike) */
+static void nnzc_sync(actx *a, const x264gpu_mb *mb)
+{
+    const int skip = mb->type == X264GPU_MB_P_SKIP || mb->type == X264GPU_MB_B_SKIP;
+    for (int b = 0; b < 16; b++) a->nnzc[b] = (uint8_t)(!skip && ((mb->cbp_luma >> (b >> 2)) & 1) ? (mb->transform8x8 ? 1 : (mb->nnz >> b) & 1) : 0);
+    for (int i = 0; i < 8; i++) a->nnzc[16 + i] = (uint8_t)(!skip && mb->cbp_chroma == 2 ? (mb->nnz >> (16 + i)) & 1 : 0);
+}
+
 static int rd_finish(actx *a, x264gpu_mb *mb, int16_t *lv)
 {
     const int ssd = rd_ssd_mb(a);
+    nnzc_sync(a, mb);
     if (mb->type == X264GPU_MB_P_SKIP || mb->type == X264GPU_MB_B_SKIP) return ssd + ((a->lambda2 + 128) >> 8);
     if (a->e->cfg.cabac) {
         /* x264_rd_cost_mb under CABAC: the macroblock's syntax priced on a copy of the slice's context states, 1/256 bit units */
@@ -1559,6 +1578,7 @@ static void intra_rd(actx *a, int thresh, x264gpu_mb *mb, int16_t *lv)
     a->satd_i16 = a->satd_i16 < thresh ? rd_cost_intra(a, X264GPU_MB_I16x16, mb, lv) : COST_MAX;
     a->satd_i4 = a->satd_i4 < thresh ? rd_cost_intra(a, X264GPU_MB_I4x4, mb, lv) : COST_MAX;
     a->satd_i8 = a->satd_i8 < thresh ? rd_cost_intra(a, X264GPU_MB_I8x8, mb, lv) : COST_MAX;
+    if (a->satd_i8 < COST_MAX) a->cbp_i8 = mb->cbp_luma;          /* a->i_cbp_i8x8_luma */
 }
 
 /* x264_mb_analyse_p_rd */
@@ -2107,6 +2127,409 @@ static void macroblock_b(actx *a, x264gpu_mb *mb, int16_t *lv)
     a->force_t8 = -1;
 }
 
+
+/* ===========================================================================================================================
+ * RD refinement (x264 --subme 8 and up, i_mbrd >= 2: [x264-upstream] encoder/me.c x264_me_refine_qpel_rd, encoder/rdo.c x264_rd_cost_part /
+ * rd_cost_i4x4 / rd_cost_i8x8 / rd_cost_chroma, encoder/analyse.c intra_rd_refine and the hooks in x264_macroblock_analyse;
+ * oracle/RDREFINE_NOTES.md).  CABAC sessions.  Restated from memory like the rest of this file: parity unpinned.
+ * Part costs carry 8 more bits than x264_rd_cost_mb's: (ssd << 8) + ((bits in 1/256 x lambda2 + 128) >> 8); they are only compared with each other. */
+long x264o_cabac_part(x264o_cabac_ctx *c, int mbx, int mby, int kind, int a, int b, int d, const uint8_t *nnzc);
+
+static int64_t part_bits(actx *a, int kind, int p0, int p1, int p2, int lambda2)
+{
+    uint8_t st[460];
+    x264o_cabac_ctx cc;
+    memcpy(st, a->e->cabac_state, sizeof(st));
+    cabac_ctx_of(a, &cc, st);
+    return ((int64_t)x264o_cabac_part(&cc, a->mbx, a->mby, kind, p0, p1, p2, a->nnzc) * lambda2 + 128) >> 8;
+}
+
+/* ssd_plane of the luma rectangle (x, y, w, h) of the macroblock: SSD + the psy-rd term (hadamard_ac from 8x8 up, SATD - SAD / 2 against zero below) */
+static int ssd_luma_part(const actx *a, int x, int y, int w, int h)
+{
+    const x264o_encoder *e = a->e;
+    const pixel *fenc = e->fenc_y + (size_t)(a->mby * 16 + y) * e->fs + a->mbx * 16 + x;
+    const pixel *rec = luma_plane((x264o_encoder *)e, e->cur, 0) + (size_t)(a->mby * 16 + y) * e->rs + a->mbx * 16 + x;
+    int ssd = x264o_ssd(fenc, e->fs, rec, e->rs, w, h);
+    if (e->cfg.psy_rd_q8) {
+        int satd;
+        if (w >= 8) {
+            const uint64_t fdec_acs = x264o_hadamard_ac(rec, e->rs, w, h), fenc_acs = x264o_hadamard_ac(fenc, e->fs, w, h);
+            satd = (abs((int32_t)fdec_acs - (int32_t)fenc_acs) + abs((int32_t)(fdec_acs >> 32) - (int32_t)(fenc_acs >> 32))) >> 1;
+        } else {
+            static const pixel zero[16] = { 0 };
+            const int dc = x264o_sad(rec, e->rs, zero, 0, w, h) >> 1, fe = x264o_satd(fenc, e->fs, zero, 0, w, h) - (x264o_sad(fenc, e->fs, zero, 0, w, h) >> 1);
+            satd = abs(x264o_satd(rec, e->rs, zero, 0, w, h) - dc - fe);
+        }
+        ssd += (satd * e->cfg.psy_rd_q8 * a->lambda + 128) >> 8;
+    }
+    return ssd;
+}
+static int ssd_chroma_part(const actx *a, int x, int y, int w, int h)      /* both planes of the NV12 rectangle, chroma samples */
+{
+    const x264o_encoder *e = a->e;
+    const pixel *fuv = e->fenc_uv + (size_t)(a->mby * 8 + y) * e->fs + a->mbx * 16 + 2 * x;
+    const pixel *ruv = chroma_plane((x264o_encoder *)e, e->cur) + (size_t)(a->mby * 8 + y) * e->rs + a->mbx * 16 + 2 * x;
+    int s = 0;
+    for (int j = 0; j < h; j++) for (int i = 0; i < 2 * w; i++) { const int d = fuv[j * e->fs + i] - ruv[j * e->rs + i]; s += d * d; }
+    return s;
+}
+
+/* x264_macroblock_encode_p8x8 with b_skip_mc: the prediction of 8x8 block i8 lies in the reconstruction; luma with the macroblock's transform
+ * size, the one chroma 4x4 block under it per plane without its DC */
+static void encode_p8x8(actx *a, int i8, x264gpu_mb *mb, int16_t *lv)
+{
+    x264o_encoder *e = a->e;
+    const int x8 = i8 & 1, y8 = i8 >> 1, qp = a->qp, qpc = a->qpc, b_decimate = e->cfg.dct_decimate || e->slice_type == X264GPU_SLICE_B;
+    const pixel *fenc = e->fenc_y + (size_t)(a->mby * 16 + 8 * y8) * e->fs + a->mbx * 16 + 8 * x8;
+    pixel *rec = luma_plane(e, e->cur, 0) + (size_t)(a->mby * 16 + 8 * y8) * e->rs + a->mbx * 16 + 8 * x8;
+    mb->cbp_luma &= (uint8_t)~(1 << i8);
+    mb->nnz &= ~(0xfu << (4 * i8));
+    for (int b = 4 * i8; b < 4 * i8 + 4; b++) { memset(lv + b * 16, 0, 32); a->nnzc[b] = 0; }
+    if (mb->transform8x8) {
+        dctcoef d[64];
+        int16_t scan[64];
+        x264o_sub8x8_dct8(d, fenc, e->fs, rec, e->rs);
+        int nz = quant_8x8(e, d, e->qt.quant8_mf[X264O_CQM_8PY][qp], e->qt.quant8_bias[X264O_CQM_8PY][qp], qp, 0);
+        if (nz) {
+            for (int k = 0; k < 64; k++) scan[k] = d[x264o_zigzag8[k]];
+            if (b_decimate) nz = x264o_decimate_score(scan, 64) >= 4;
+        }
+        if (nz) {
+            for (int k = 0; k < 64; k++) { lv[(i8 * 4 + (k & 3)) * 16 + (k >> 2)] = scan[k]; if (scan[k]) mb->nnz |= 1u << (i8 * 4 + (k & 3)); }
+            x264o_dequant_8x8(d, e->qt.dequant8_mf, qp);
+            x264o_add8x8_idct8(rec, e->rs, d);
+            mb->cbp_luma |= (uint8_t)(1 << i8);
+            for (int b = 4 * i8; b < 4 * i8 + 4; b++) a->nnzc[b] = 1;
+        }
+    } else {
+        dctcoef d[4][16];
+        int nz[4], any = 0, score = b_decimate ? 0 : 4;
+        for (int k = 0; k < 4; k++) {
+            const int b = 4 * i8 + k, ox = (k & 1) * 4, oy = (k >> 1) * 4;
+            x264o_sub4x4_dct(d[k], fenc + oy * e->fs + ox, e->fs, rec + oy * e->rs + ox, e->rs);
+            nz[k] = quant_4x4(e, d[k], e->qt.quant4_mf[X264O_CQM_4PY][qp], e->qt.quant4_bias[X264O_CQM_4PY][qp], qp, 2, 0);
+            a->nnzc[b] = (uint8_t)(nz[k] != 0);
+            if (nz[k]) {
+                scan4(lv + b * 16, d[k]);
+                x264o_dequant_4x4(d[k], e->qt.dequant4_mf, qp);
+                if (score < 4) score += x264o_decimate_score(lv + b * 16, 16);
+                any = 1;
+            }
+        }
+        if (any) {
+            if (score < 4) for (int b = 4 * i8; b < 4 * i8 + 4; b++) { a->nnzc[b] = 0; memset(lv + b * 16, 0, 32); }
+            else {
+                for (int k = 0; k < 4; k++) if (nz[k]) { x264o_add4x4_idct(rec + (k >> 1) * 4 * e->rs + (k & 1) * 4, e->rs, d[k]); mb->nnz |= 1u << (4 * i8 + k); }
+                mb->cbp_luma |= (uint8_t)(1 << i8);
+            }
+        }
+    }
+    const pixel *fuv = e->fenc_uv + (size_t)(a->mby * 8 + 4 * y8) * e->fs + a->mbx * 16 + 8 * x8;
+    pixel *ruv = chroma_plane(e, e->cur) + (size_t)(a->mby * 8 + 4 * y8) * e->rs + a->mbx * 16 + 8 * x8;
+    for (int c = 0; c < 2; c++) {
+        pixel f[16], p[16];
+        dctcoef d[16];
+        int16_t *l = lv + X264GPU_LV_CHROMA_AC + (c * 4 + i8) * 16;
+        for (int y = 0; y < 4; y++) for (int x = 0; x < 4; x++) { f[y * 4 + x] = fuv[y * e->fs + 2 * x + c]; p[y * 4 + x] = ruv[y * e->rs + 2 * x + c]; }
+        x264o_sub4x4_dct(d, f, 4, p, 4);
+        d[0] = 0;
+        const int nz = quant_4x4(e, d, e->qt.quant4_mf[X264O_CQM_4PC][qpc], e->qt.quant4_bias[X264O_CQM_4PC][qpc], qpc, 4, 0);
+        a->nnzc[16 + c * 4 + i8] = (uint8_t)(nz != 0);
+        mb->nnz &= ~(1u << (16 + c * 4 + i8));
+        memset(l, 0, 32);
+        if (nz) {
+            scan4(l, d);
+            x264o_dequant_4x4(d, e->qt.dequant4_mf, qpc);
+            x264o_add4x4_idct(p, 4, d);
+            for (int y = 0; y < 4; y++) for (int x = 0; x < 4; x++) ruv[y * e->rs + 2 * x + c] = p[y * 4 + x];
+            mb->nnz |= 1u << (16 + c * 4 + i8);
+        }
+    }
+    mb->cbp_chroma = 2;
+}
+
+/* x264_rd_cost_part of an inter part (pixel: 1 16x8, 2 8x16, 3 8x8) whose prediction lies in the reconstruction */
+static int64_t rd_cost_part(actx *a, int i8, int psize, int done, x264gpu_mb *mb, int16_t *lv)
+{
+    mb->cbp_luma = 0;
+    encode_p8x8(a, i8, mb, lv);
+    if (psize == 1) encode_p8x8(a, i8 + 1, mb, lv);
+    if (psize == 2) encode_p8x8(a, i8 + 2, mb, lv);
+    const int x = 8 * (i8 & 1), y = 8 * (i8 >> 1), w = psize == 1 ? 16 : 8, h = psize == 2 ? 16 : 8;
+    int64_t ssd = ssd_luma_part(a, x, y, w, h);
+    ssd += ((int64_t)ssd_chroma_part(a, x >> 1, y >> 1, w >> 1, h >> 1) * a->chroma_lambda2_offset + 128) >> 8;
+    return (ssd << 8) + part_bits(a, 0, i8, psize, done, a->lambda2);
+}
+
+/* x264_me_refine_qpel_rd of one part of the chosen P type: a sub-pel hexagon + square walk on RD cost, candidates gated by SATD.  mb holds
+ * the macroblock as decided so far (type, partition, transform size, the vectors of the parts refined before); *done = their 8x8 blocks */
+static void me_refine_qpel_rd(actx *a, me_t *m, int i8, int t8, int *done, x264gpu_mb *mb, int16_t *lv)
+{
+    x264o_encoder *e = a->e;
+    const int psize = m->w == 16 ? (m->h == 16 ? 0 : 1) : (m->h == 16 ? 2 : 3);
+    const int bx8 = i8 & 1, by8 = i8 >> 1, w8 = m->w >> 3, h8 = m->h >> 3;
+    pixel *rec = luma_plane(e, e->cur, 0) + (size_t)(a->mby * 16 + m->oy) * e->rs + a->mbx * 16 + m->ox;
+    pixel *ruv = chroma_plane(e, e->cur) + (size_t)(a->mby * 8 + m->oy / 2) * e->rs + a->mbx * 16 + m->ox;
+    const pixel *fenc = e->fenc_y + (size_t)(a->mby * 16 + m->oy) * e->fs + a->mbx * 16 + m->ox;
+    int64_t bcost = INT64_MAX;
+    const int mv0x = m->mv[0], mv0y = m->mv[1];          /* (for 16x16 the candidates pass through a->me16, which IS m) */
+    int bmx = mv0x, bmy = mv0y, omx, omy, pmx, pmy, satd, bsatd = COST_MAX, dir = -2;
+    int last_mvd[2] = { 0, 0 }, priced = 0;
+    if (psize != 0 && i8 != 0) predict_mv(a, bx8, by8, w8, m->ref, m->mvp);      /* the parts refined before moved */
+    pmx = m->mvp[0]; pmy = m->mvp[1];
+    sctx S;
+    sctx_init(&S, a, m);
+#define SATD_THRESH(c) ((c) + ((c) >> 4))
+#define COST_MV_SATD(mx, my, dst, avoid_mvp) do { \
+        if (!(avoid_mvp) || !((mx) == pmx && (my) == pmy)) { \
+            pixel pred_[256]; \
+            get_ref(&S, pred_, mx, my); \
+            for (int y_ = 0; y_ < m->h; y_++) memcpy(rec + y_ * e->rs, pred_ + y_ * 16, m->w); \
+            dst = mbcmp(a, fenc, e->fs, pred_, 16, m->w, m->h) + S.cmx[mx] + S.cmy[my]; \
+            if (dst < bsatd) bsatd = dst; \
+        } else dst = COST_MAX; } while (0)
+#define COST_MV_RD(mx, my, sat, do_dir, mdir) do { \
+        if ((sat) <= SATD_THRESH(bsatd)) { \
+            int64_t cost_; \
+            for (int k_ = 0; k_ < 4; k_++) if ((k_ & 1) >= bx8 && (k_ & 1) < bx8 + w8 && (k_ >> 1) >= by8 && (k_ >> 1) < by8 + h8) { mb->mv[k_][0] = (int16_t)(mx); mb->mv[k_][1] = (int16_t)(my); } \
+            if (psize == 0) { \
+                a->me16.mv[0] = (mx); a->me16.mv[1] = (my); \
+                cost_ = rd_cost_inter(a, D_16x16, t8, mb, lv); \
+            } else { \
+                pixel pu_[64], pv_[64]; \
+                x264o_mc_chroma(pu_, pv_, 8, chroma_plane(e, S.refslot), e->rs, a->mbx * 8 + m->ox / 2, a->mby * 8 + m->oy / 2, mx, my, m->w / 2, m->h / 2); \
+                for (int y_ = 0; y_ < m->h / 2; y_++) for (int x_ = 0; x_ < m->w / 2; x_++) { ruv[y_ * e->rs + 2 * x_] = pu_[y_ * 8 + x_]; ruv[y_ * e->rs + 2 * x_ + 1] = pv_[y_ * 8 + x_]; } \
+                cost_ = rd_cost_part(a, i8, psize, *done, mb, lv); \
+            } \
+            last_mvd[0] = abs((mx) - m->mvp[0]); last_mvd[1] = abs((my) - m->mvp[1]); priced = 1; \
+            if (cost_ < bcost) { bcost = cost_; bmx = (mx); bmy = (my); dir = (do_dir) ? (mdir) : dir; } \
+        } } while (0)
+    COST_MV_SATD(bmx, bmy, bsatd, 0);
+    if (psize != 0) COST_MV_RD(bmx, bmy, 0, 0, 0);
+    else bcost = m->cost;
+    /* the predicted vector */
+    if ((bmx != pmx || bmy != pmy) && pmx >= a->smin[0] && pmx <= a->smax[0] && pmy >= a->smin[1] && pmy <= a->smax[1]) {
+        COST_MV_SATD(pmx, pmy, satd, 0);
+        COST_MV_RD(pmx, pmy, satd, 0, 0);
+        /* the hexagon never repeats its centre: if the predictor won, the vector to avoid becomes the old one */
+        if (bmx == pmx && bmy == pmy) { pmx = mv0x; pmy = mv0y; }
+    }
+    if (bmy < a->smin[1] + 3 || bmy > a->smax[1] - 3 || bmx < a->smin[0] + 3 || bmx > a->smax[0] - 3) {
+        /* too close to the limits for the walk: the part keeps its vector; the |mvd| x264's size coder cached last stays (when it ran) */
+        m->mv[0] = mv0x; m->mv[1] = mv0y;
+        goto finish;
+    }
+    /* sub-pel hexagon, the pattern of the full-pel one */
+    dir = -2; omx = bmx; omy = bmy;
+    for (int j = 0; j < 6; j++) {
+        COST_MV_SATD(omx + hex2[j + 1][0], omy + hex2[j + 1][1], satd, 1);
+        COST_MV_RD(omx + hex2[j + 1][0], omy + hex2[j + 1][1], satd, 1, j);
+    }
+    if (dir != -2) {
+        /* half hexagons that do not overlap the previous one */
+        for (int i = 1; i < 10; i++) {
+            const int odir = mod6m1[dir + 1];
+            if (bmy < a->smin[1] + 3 || bmy > a->smax[1] - 3) break;
+            dir = -2; omx = bmx; omy = bmy;
+            for (int j = 0; j < 3; j++) {
+                COST_MV_SATD(omx + hex2[odir + j][0], omy + hex2[odir + j][1], satd, 1);
+                COST_MV_RD(omx + hex2[odir + j][0], omy + hex2[odir + j][1], satd, 1, odir - 1 + j);
+            }
+            if (dir == -2) break;
+        }
+    }
+    /* square refine */
+    omx = bmx; omy = bmy;
+    for (int i = 0; i < 8; i++) {
+        COST_MV_SATD(omx + square1[i + 1][0], omy + square1[i + 1][1], satd, 1);
+        COST_MV_RD(omx + square1[i + 1][0], omy + square1[i + 1][1], satd, 1, 0);
+    }
+    m->cost = bcost > COST_MAX ? COST_MAX : (int)bcost;
+    m->mv[0] = bmx; m->mv[1] = bmy;
+    last_mvd[0] = abs(bmx - m->mvp[0]); last_mvd[1] = abs(bmy - m->mvp[1]); priced = 1;
+finish:
+#undef COST_MV_SATD
+#undef COST_MV_RD
+#undef SATD_THRESH
+    /* x264_macroblock_cache_mv / _mvd of the part: what the parts after it predict from and count their mvd contexts on */
+    for (int k = 0; k < 4; k++)
+        if ((k & 1) >= bx8 && (k & 1) < bx8 + w8 && (k >> 1) >= by8 && (k >> 1) < by8 + h8) {
+            mb->mv[k][0] = (int16_t)m->mv[0]; mb->mv[k][1] = (int16_t)m->mv[1];
+            if (priced) { e->amvd[((size_t)a->mi * 4 + k) * 2] = (uint8_t)(last_mvd[0] < 66 ? last_mvd[0] : 66); e->amvd[((size_t)a->mi * 4 + k) * 2 + 1] = (uint8_t)(last_mvd[1] < 66 ? last_mvd[1] : 66); }
+            *done |= 1 << k;
+        }
+    cache_block(a, bx8, by8, w8, h8, m->ref, m->mv);
+}
+
+/* the hook of x264_macroblock_analyse for an inter P type chosen on RD cost; returns the partition (a pair of halves refined onto one vector is 16x16) */
+static int refine_inter_p_rd(actx *a, int i_partition, int t8, int i_cost, x264gpu_mb *mb, int16_t *lv)
+{
+    int done = 0;
+    rd_reset(a, mb, lv);
+    mb->type = i_partition == D_8x8 ? X264GPU_MB_P_8x8 : X264GPU_MB_P_L0; mb->partition = (uint8_t)i_partition; mb->transform8x8 = (uint8_t)t8;
+    for (int k = 0; k < 4; k++) {
+        const me_t *m = i_partition == D_16x16 ? &a->me16 : i_partition == D_16x8 ? &a->me16x8[k >> 1] : i_partition == D_8x16 ? &a->me8x16[k & 1] : &a->me8[k];
+        mb->ref[k] = (int8_t)m->ref; mb->mv[k][0] = (int16_t)m->mv[0]; mb->mv[k][1] = (int16_t)m->mv[1];
+    }
+    a->partition = i_partition; a->cur_valid = 0;
+    memset(a->e->amvd + (size_t)a->mi * 8, 0, 8);
+    if (i_partition == D_16x16) { a->me16.cost = i_cost; me_refine_qpel_rd(a, &a->me16, 0, t8, &done, mb, lv); }
+    else if (i_partition == D_16x8) { me_refine_qpel_rd(a, &a->me16x8[0], 0, t8, &done, mb, lv); me_refine_qpel_rd(a, &a->me16x8[1], 2, t8, &done, mb, lv); }
+    else if (i_partition == D_8x16) { me_refine_qpel_rd(a, &a->me8x16[0], 0, t8, &done, mb, lv); me_refine_qpel_rd(a, &a->me8x16[1], 1, t8, &done, mb, lv); }
+    else for (int i = 0; i < 4; i++) me_refine_qpel_rd(a, &a->me8[i], i, t8, &done, mb, lv);
+    /* "in rare cases we can end up qpel-RDing our way back to a larger partition size": the two halves on one vector and reference */
+    if (i_partition == D_16x8 || i_partition == D_8x16) {
+        const me_t *m0 = i_partition == D_16x8 ? &a->me16x8[0] : &a->me8x16[0], *m1 = i_partition == D_16x8 ? &a->me16x8[1] : &a->me8x16[1];
+        if (m0->mv[0] == m1->mv[0] && m0->mv[1] == m1->mv[1] && m0->ref == m1->ref) { a->me16 = *m0; a->me16.w = a->me16.h = 16; a->me16.ox = a->me16.oy = 0; i_partition = D_16x16; }
+    }
+    return i_partition;
+}
+
+static int64_t rd_cost_chroma(actx *a, int mode, int b_dct, x264gpu_mb *mb, int16_t *lv)
+{
+    x264o_encoder *e = a->e;
+    if (b_dct) {
+        mb->nnz &= ~0x06ff0000u; mb->cbp_chroma = 0;
+        encode_chroma(e, e->fenc_uv + (size_t)a->mby * 8 * e->fs + a->mbx * 16, chroma_plane(e, e->cur) + (size_t)a->mby * 8 * e->rs + a->mbx * 16, a->qpc, 0, mb, lv);
+        for (int i = 0; i < 8; i++) a->nnzc[16 + i] = (uint8_t)(mb->cbp_chroma == 2 ? (mb->nnz >> (16 + i)) & 1 : 0);
+    }
+    const int64_t ssd = ssd_chroma_part(a, 0, 0, 8, 8);
+    mb->chroma_mode = (uint8_t)(mode > I_PRED_CHROMA_P ? I_PRED_CHROMA_DC : mode);
+    return (ssd << 8) + part_bits(a, 3, 0, 0, 0, x264o_lambda2(a->qpc));
+}
+
+/* intra_rd_refine: the chosen intra type's modes once more, on RD cost.  mb / lv hold the last whole-macroblock encode of intra_rd */
+static void intra_rd_refine(actx *a, int type, x264gpu_mb *mb, int16_t *lv)
+{
+    x264o_encoder *e = a->e;
+    const int left = a->mbx > 0, top = a->mby > e->row0;
+    const pixel *fenc = e->fenc_y + (size_t)a->mby * 16 * e->fs + a->mbx * 16;
+    pixel *rec = luma_plane(e, e->cur, 0) + (size_t)a->mby * 16 * e->rs + a->mbx * 16;
+    if (type == X264GPU_MB_I16x16) {
+        const int old = a->pred16;
+        const int thresh = a->b_early_terminate ? a->satd_i16_dir[old] * 9 / 8 : COST_MAX;
+        int modes[4], n = 0, best = a->satd_i16, bestm = old;
+        if (left && top) { modes[n++] = I_PRED_16x16_V; modes[n++] = I_PRED_16x16_H; modes[n++] = I_PRED_16x16_DC; modes[n++] = I_PRED_16x16_P; }
+        else if (left) { modes[n++] = I_PRED_16x16_DC_LEFT; modes[n++] = I_PRED_16x16_H; }
+        else if (top) { modes[n++] = I_PRED_16x16_DC_TOP; modes[n++] = I_PRED_16x16_V; }
+        else modes[n++] = I_PRED_16x16_DC_128;
+        for (int i = 0; i < n; i++) {
+            const int m = modes[i];
+            if (m == old || a->satd_i16_dir[m] > thresh || a->satd_i16_dir[m] >= COST_MAX) continue;      /* (a mode the analysis never costed: x264 reads a stale value there) */
+            a->pred16 = m;
+            const int c = rd_cost_intra(a, X264GPU_MB_I16x16, mb, lv);
+            if (c < best) { best = c; bestm = m; }
+        }
+        a->pred16 = bestm;
+    }
+    /* the chroma mode (every intra type) */
+    {
+        int cm[4], cn = 0;
+        if (left && top) { cm[cn++] = I_PRED_CHROMA_DC; cm[cn++] = I_PRED_CHROMA_H; cm[cn++] = I_PRED_CHROMA_V; cm[cn++] = I_PRED_CHROMA_P; }
+        else if (left) { cm[cn++] = I_PRED_CHROMA_DC_LEFT; cm[cn++] = I_PRED_CHROMA_H; }
+        else if (top) { cm[cn++] = I_PRED_CHROMA_DC_TOP; cm[cn++] = I_PRED_CHROMA_V; }
+        if (cn > 1) {
+            const int thresh = a->b_early_terminate ? a->satd_chroma * 5 / 4 : COST_MAX;
+            int sorted[4], i_max = 0;
+            for (int i = 0; i < cn; i++) if (a->satd_chroma_dir[cm[i]] < thresh && cm[i] != a->predc) sorted[i_max++] = cm[i];
+            if (i_max > 0) {
+                /* the last thing coded was intra_rd's candidate: pixels and levels of the current chroma mode still lie there */
+                pixel *ruv = chroma_plane(e, e->cur) + (size_t)a->mby * 8 * e->rs + a->mbx * 16;
+                int64_t best = rd_cost_chroma(a, a->predc, 0, mb, lv);
+                pixel nu[9 * 9], nvv[9 * 9], pu[64], pv[64];
+                /* neighbours of the chroma block: the reconstruction around it (row -1, column -1) */
+                memset(nu, 128, sizeof(nu)); memset(nvv, 128, sizeof(nvv));
+                for (int y = -1; y < 8; y++)
+                    for (int x = -1; x < 8; x++) {
+                        if (y >= 0 && x >= 0) continue;
+                        if ((y < 0 && !top) || (x < 0 && !left)) continue;
+                        nu[(y + 1) * 9 + x + 1] = ruv[y * e->rs + 2 * x]; nvv[(y + 1) * 9 + x + 1] = ruv[y * e->rs + 2 * x + 1];
+                    }
+                for (int i = 0; i < i_max; i++) {
+                    const int m = sorted[i];
+                    x264o_predict_8x8c(pu, 8, nu + 10, 9, m);
+                    x264o_predict_8x8c(pv, 8, nvv + 10, 9, m);
+                    for (int y = 0; y < 8; y++) for (int x = 0; x < 8; x++) { ruv[y * e->rs + 2 * x] = pu[y * 8 + x]; ruv[y * e->rs + 2 * x + 1] = pv[y * 8 + x]; }
+                    /* once a mode without a residual has been found, the remaining ones are not transformed ("any mode with a residual will be worse") */
+                    const int64_t c = rd_cost_chroma(a, m, mb->cbp_chroma != 0, mb, lv);
+                    if (c < best) { best = c; a->predc = m; }
+                }
+            }
+        }
+    }
+    if (type == X264GPU_MB_I4x4) {
+        for (int k = 0; k < 16; k++) mb->i4_mode[k] = (uint8_t)a->pred4[k];
+        for (int idx = 0; idx < 16; idx++) {
+            const pixel *f = fenc + blk_y[idx] * 4 * e->fs + blk_x[idx] * 4;
+            pixel *r = rec + blk_y[idx] * 4 * e->rs + blk_x[idx] * 4;
+            const int avail = i4_avail(a, idx);
+            int64_t best = INT64_MAX;
+            pixel bestpix[16], p4[16];
+            int16_t bestlv[16];
+            int bestnz = 0, bestm = a->pred4[idx];
+            for (const int8_t *pm = mode4_available(avail); *pm >= 0; pm++) {
+                const int m = *pm;
+                x264o_predict_4x4(p4, 4, r, e->rs, real_mode4(m, avail), avail);
+                for (int y = 0; y < 4; y++) memcpy(r + y * e->rs, p4 + y * 4, 4);
+                const int nz = encode_i4x4(e, f, r, a->qp, lv + idx * 16);
+                a->nnzc[idx] = (uint8_t)nz;
+                mb->i4_mode[idx] = (uint8_t)m;
+                const int64_t c = ((int64_t)ssd_luma_part(a, blk_x[idx] * 4, blk_y[idx] * 4, 4, 4) << 8) + part_bits(a, 1, idx, 0, 0, a->lambda2);
+                if (best > c) {
+                    best = c; bestm = m; bestnz = nz;
+                    for (int y = 0; y < 4; y++) memcpy(bestpix + y * 4, r + y * e->rs, 4);
+                    memcpy(bestlv, lv + idx * 16, 32);
+                }
+            }
+            for (int y = 0; y < 4; y++) memcpy(r + y * e->rs, bestpix + y * 4, 4);
+            memcpy(lv + idx * 16, bestlv, 32);
+            a->nnzc[idx] = (uint8_t)bestnz;
+            a->pred4[idx] = bestm; mb->i4_mode[idx] = (uint8_t)bestm;
+        }
+    } else if (type == X264GPU_MB_I8x8) {
+        for (int k = 0; k < 4; k++) memset(mb->i4_mode + 4 * k, a->pred8[k], 4);
+        mb->transform8x8 = 1;
+        for (int idx = 0; idx < 4; idx++) {
+            const pixel *f = fenc + (idx >> 1) * 8 * e->fs + (idx & 1) * 8;
+            pixel *r = rec + (idx >> 1) * 8 * e->rs + (idx & 1) * 8;
+            const int avail = i8_avail(a, idx);
+            const int thresh = a->b_early_terminate ? a->satd_i8_dir[idx][a->pred8[idx]] * 11 / 8 : COST_MAX;
+            int64_t best = INT64_MAX;
+            pixel edge[33], p8[64], bestpix[64];
+            int16_t bestlv[64];
+            uint8_t bestnnz[4] = { 0, 0, 0, 0 };
+            int cbp_new = 0, bestm = a->pred8[idx];
+            uint32_t bestbits = 0;
+            x264o_predict_8x8_filter(r, e->rs, edge, avail);
+            for (const int8_t *pm = mode4_available(avail); *pm >= 0; pm++) {
+                const int m = *pm;
+                if (a->satd_i8_dir[idx][m] > thresh) continue;
+                mb->cbp_luma = (uint8_t)(a->cbp_i8 & ~(1 << idx));
+                mb->nnz &= ~(0xfu << (4 * idx));
+                for (int b = 4 * idx; b < 4 * idx + 4; b++) memset(lv + b * 16, 0, 32);
+                x264o_predict_8x8(p8, 8, edge, real_mode4(m, avail));
+                for (int y = 0; y < 8; y++) memcpy(r + y * e->rs, p8 + y * 8, 8);
+                const int nz = encode_i8x8(e, f, r, a->qp, idx, lv, &mb->nnz);
+                if (nz) mb->cbp_luma |= (uint8_t)(1 << idx);
+                for (int b = 4 * idx; b < 4 * idx + 4; b++) a->nnzc[b] = (uint8_t)nz;
+                memset(mb->i4_mode + 4 * idx, m, 4);
+                const int64_t c = ((int64_t)ssd_luma_part(a, (idx & 1) * 8, (idx >> 1) * 8, 8, 8) << 8) + part_bits(a, 2, idx, 0, 0, a->lambda2);
+                if (best > c) {
+                    best = c; bestm = m; cbp_new = mb->cbp_luma; bestbits = mb->nnz & (0xfu << (4 * idx));
+                    for (int y = 0; y < 8; y++) memcpy(bestpix + y * 8, r + y * e->rs, 8);
+                    for (int b = 0; b < 4; b++) { memcpy(bestlv + b * 16, lv + (4 * idx + b) * 16, 32); bestnnz[b] = a->nnzc[4 * idx + b]; }
+                }
+            }
+            a->cbp_i8 = cbp_new;
+            for (int y = 0; y < 8; y++) memcpy(r + y * e->rs, bestpix + y * 8, 8);
+            for (int b = 0; b < 4; b++) { memcpy(lv + (4 * idx + b) * 16, bestlv + b * 16, 32); a->nnzc[4 * idx + b] = bestnnz[b]; }
+            mb->nnz = (mb->nnz & ~(0xfu << (4 * idx))) | bestbits; mb->cbp_luma = (uint8_t)cbp_new;
+            a->pred8[idx] = bestm; memset(mb->i4_mode + 4 * idx, bestm, 4);
+        }
+    }
+}
+
 static int mb_type_at(const x264o_encoder *e, int mbx, int mby)
 {
     if (mbx < 0 || mby < e->row0 || mbx >= e->mbw) return -1;
@@ -2134,7 +2557,11 @@ static void macroblock_body(x264o_encoder *e, int mbx, int mby, actx *a)
     a->satd_i16 = a->satd_i8 = a->satd_i4 = a->satd_chroma = COST_MAX;
     a->b_early_terminate = a->subme < 11;
     mb->qp = (uint8_t)a->qp;
-    a->mbrd = e->cfg.rd != 0; a->rd16x16 = COST_MAX; a->force_t8 = -1; a->cost8x8 = a->cost16x8 = a->cost8x16 = COST_MAX;
+    /* x264_macroblock_thread_init / mb_analyse_init: B slices analyse one sub-pel level down (6 -> 5, 8 -> 7); i_mbrd = (subme >= 6) + (subme >= 8) */
+    if (e->slice_type == X264GPU_SLICE_B && (a->subme == 6 || a->subme == 8)) a->subme--;
+    a->mbrd = e->cfg.rd ? 1 + (e->cfg.cabac && a->subme >= 8) : 0; a->rd16x16 = COST_MAX; a->force_t8 = -1; a->cost8x8 = a->cost16x8 = a->cost8x16 = COST_MAX;
+    for (int i = 0; i < 7; i++) a->satd_i16_dir[i] = a->satd_chroma_dir[i] = COST_MAX;
+    for (int i = 0; i < 4; i++) for (int m = 0; m < 12; m++) a->satd_i8_dir[i][m] = COST_MAX;
     a->lambda2 = x264o_lambda2(a->qp);
     {   /* h->mb.i_chroma_lambda2_offset: 256 * 2^((qp - chroma qp) / 3) under psy, else 256 */
         static const uint16_t tab[37] = { 16, 20, 25, 32, 40, 50, 64, 80, 101, 128, 161, 203, 256, 322, 406, 512, 645, 812, 1024, 1290, 1625, 2048, 2580, 3250, 4096,
@@ -2149,6 +2576,7 @@ static void macroblock_body(x264o_encoder *e, int mbx, int mby, actx *a)
         int i_cost = a->satd_i16, type = X264GPU_MB_I16x16;
         if (a->satd_i4 < i_cost) { i_cost = a->satd_i4; type = X264GPU_MB_I4x4; }
         if (a->satd_i8 < i_cost) { i_cost = a->satd_i8; type = X264GPU_MB_I8x8; }
+        if (a->mbrd >= 2) intra_rd_refine(a, type, mb, lv);
         if (a->mbrd) rd_reset(a, mb, lv);
         mb->cost = i_cost;
         e->b_trellis = e->cfg.cabac ? e->cfg.trellis & 63 : 0;          /* --trellis 1: the final encode only */
@@ -2260,6 +2688,10 @@ static void macroblock_body(x264o_encoder *e, int mbx, int mby, actx *a)
     if (a->satd_i16 < i_cost) { i_cost = a->satd_i16; i_type = X264GPU_MB_I16x16; }
     if (a->satd_i8 < i_cost) { i_cost = a->satd_i8; i_type = X264GPU_MB_I8x8; }
     if (a->satd_i4 < i_cost) { i_cost = a->satd_i4; i_type = X264GPU_MB_I4x4; }
+    if (a->mbrd >= 2) {
+        if (is_intra_type(i_type)) intra_rd_refine(a, i_type, mb, lv);
+        else i_partition = refine_inter_p_rd(a, i_partition, t8, i_cost, mb, lv);
+    }
     if (a->mbrd) { rd_reset(a, mb, lv); mb->aux[0] = aux0; mb->aux[1] = aux1; mb->aux[2] = aux2; }
     mb->cost = i_cost;
 

@@ -179,12 +179,15 @@ struct Coder {
         if (m.transform8x8) return 1;
         return (m.nnz >> kIdx[by][bx]) & 1;
     }
+    // RD refinement (subme >= 8) prices PARTS of a macroblock: the blocks around a part inside the macroblock then read what x264's
+    // non_zero_count cache holds for them — whatever the last encode of any kind left there — and not the record being built
+    const uint8_t *nnz_over = nullptr;          // 24 flags: luma blocks 0..15, chroma AC plane * 4 + block
     int cbf_luma(int mbx, int mby, const x264gpu_mb &m, int blk) const
     {
         const int bx = kBx[blk], by = kBy[blk], un = intra_type(m.type) ? 1 : 0;
         int a, b;
-        if (bx > 0) a = luma_cbf_of(m, bx - 1, by); else { const x264gpu_mb *n = left(mbx, mby); a = n ? luma_cbf_of(*n, 3, by) : un; }
-        if (by > 0) b = luma_cbf_of(m, bx, by - 1); else { const x264gpu_mb *n = top(mbx, mby); b = n ? luma_cbf_of(*n, bx, 3) : un; }
+        if (bx > 0) a = nnz_over ? nnz_over[kIdx[by][bx - 1]] : luma_cbf_of(m, bx - 1, by); else { const x264gpu_mb *n = left(mbx, mby); a = n ? luma_cbf_of(*n, 3, by) : un; }
+        if (by > 0) b = nnz_over ? nnz_over[kIdx[by - 1][bx]] : luma_cbf_of(m, bx, by - 1); else { const x264gpu_mb *n = top(mbx, mby); b = n ? luma_cbf_of(*n, bx, 3) : un; }
         return a + 2 * b;
     }
     int cbf_dc(int mbx, int mby, const x264gpu_mb &m, int bit) const
@@ -203,8 +206,8 @@ struct Coder {
         const int bx = i & 1, by = i >> 1, un = intra_type(m.type) ? 1 : 0;
         auto of = [&](const x264gpu_mb &n, int x, int y) { return n.type != X264GPU_MB_P_SKIP && n.cbp_chroma == 2 ? (int)((n.nnz >> (16 + pl * 4 + y * 2 + x)) & 1) : 0; };
         int a, b;
-        if (bx > 0) a = of(m, 0, by); else { const x264gpu_mb *n = left(mbx, mby); a = n ? of(*n, 1, by) : un; }
-        if (by > 0) b = of(m, bx, 0); else { const x264gpu_mb *n = top(mbx, mby); b = n ? of(*n, bx, 1) : un; }
+        if (bx > 0) a = nnz_over ? nnz_over[16 + pl * 4 + by * 2] : of(m, 0, by); else { const x264gpu_mb *n = left(mbx, mby); a = n ? of(*n, 1, by) : un; }
+        if (by > 0) b = nnz_over ? nnz_over[16 + pl * 4 + bx] : of(m, bx, 0); else { const x264gpu_mb *n = top(mbx, mby); b = n ? of(*n, bx, 1) : un; }
         return a + 2 * b;
     }
 
@@ -483,9 +486,109 @@ struct Coder {
             }
         } else if (!rd) c.last_dqp = 0;
     }
+
+    // ---- the size functions of x264's RD refinement (encoder/rdo.c partition_size_cabac, partition_i4x4 / _i8x8_size_cabac,
+    //      chroma_size_cabac): parts of the macroblock that sits in the record, no macroblock type, reference index, cbp (inter) or qp bits ----
+    void intra_pred_mode_bins(int mbx, int mby, int b)
+    {
+        const x264gpu_mb &m = c.mbs[cur];
+        const int pm = pred_intra_mode(mbx, mby, b);
+        int mode = m.i4_mode[b];
+        if (mode == pm) decision(68, 1);
+        else {
+            decision(68, 0);
+            if (mode > pm) mode--;
+            decision(69, mode & 1); decision(69, (mode >> 1) & 1); decision(69, mode >> 2);
+        }
+    }
+    // P_L0 16x8 / 8x16 half or P_8x8 block i8 (pixel: 1 16x8, 2 8x16, 3 8x8); done = the 8x8 blocks of the macroblock refined before it
+    // (their final vectors in the record, their |mvd| in c.amvd)
+    void partition_p(int mbx, int mby, int i8, int pixel, int done)
+    {
+        cur = mby * c.mbw + mbx; done8 = done; lst = 0; cur_direct = 0;
+        const x264gpu_mb &m = c.mbs[cur];
+        const int16_t *lv = c.levels + (size_t)cur * X264GPU_MB_LEVELS;
+        for (int k = 0; k < 4; k++) cur8[k] = Nb{ true, m.ref[k], m.mv[k][0], m.mv[k][1] };
+        const int bx = i8 & 1, by = i8 >> 1, w8 = pixel == 1 ? 2 : 1, h8 = pixel == 2 ? 2 : 1;
+        int px, py;
+        predict(mbx, mby, bx, by, w8, pixel == 3 ? 3 : pixel, pixel == 1 ? by : bx, m.ref[i8], px, py);
+        mvd(mbx, mby, i8, w8, h8, 0, m.mv[i8][0] - px);
+        mvd(mbx, mby, i8, w8, h8, 1, m.mv[i8][1] - py);
+        if (pixel == 3) decision(21, 1);                       // sub_mb_type P_L0_8x8
+        for (int j = pixel < 3; j >= 0; j--) {
+            if ((m.cbp_luma >> i8) & 1) {
+                if (m.transform8x8) {
+                    int16_t l8[64];
+                    for (int z = 0; z < 64; z++) l8[z] = lv[(i8 * 4 + (z & 3)) * 16 + (z >> 2)];
+                    residual(l8, 5);
+                } else for (int b = i8 * 4; b < i8 * 4 + 4; b++) block_cbf(lv + b * 16, 16, 2, cbf_luma(mbx, mby, m, b));
+            }
+            if (m.cbp_chroma)
+                for (int pl = 0; pl < 2; pl++) block_cbf(lv + X264GPU_LV_CHROMA_AC + (pl * 4 + i8) * 16 + 1, 15, 4, cbf_chroma_ac(mbx, mby, m, pl, i8));
+            i8 += pixel == 1 ? 1 : 2;
+        }
+    }
+    void part_i4x4(int mbx, int mby, int idx)
+    {
+        cur = mby * c.mbw + mbx;
+        const x264gpu_mb &m = c.mbs[cur];
+        intra_pred_mode_bins(mbx, mby, idx);
+        block_cbf(c.levels + (size_t)cur * X264GPU_MB_LEVELS + idx * 16, 16, 2, cbf_luma(mbx, mby, m, idx));
+    }
+    void part_i8x8(int mbx, int mby, int i8)
+    {
+        cur = mby * c.mbw + mbx;
+        const x264gpu_mb &m = c.mbs[cur];
+        const int16_t *lv = c.levels + (size_t)cur * X264GPU_MB_LEVELS;
+        const x264gpu_mb *L = left(mbx, mby), *T = top(mbx, mby);
+        intra_pred_mode_bins(mbx, mby, i8 * 4);
+        for (int b8 = 0; b8 < 4; b8++) {                       // cabac_cbp_luma: all four bits
+            const int x = b8 & 1, y = b8 >> 1;
+            const int a = x ? !((m.cbp_luma >> (b8 - 1)) & 1) : L ? !((L->cbp_luma >> (b8 + 1)) & 1) : 0;
+            const int b = y ? !((m.cbp_luma >> (b8 - 2)) & 1) : T ? !((T->cbp_luma >> (b8 + 2)) & 1) : 0;
+            decision(73 + a + 2 * b, (m.cbp_luma >> b8) & 1);
+        }
+        if ((m.cbp_luma >> i8) & 1) {
+            int16_t l8[64];
+            for (int z = 0; z < 64; z++) l8[z] = lv[(i8 * 4 + (z & 3)) * 16 + (z >> 2)];
+            residual(l8, 5);
+        }
+    }
+    void chroma_part(int mbx, int mby)
+    {
+        cur = mby * c.mbw + mbx;
+        const x264gpu_mb &m = c.mbs[cur];
+        const int16_t *lv = c.levels + (size_t)cur * X264GPU_MB_LEVELS;
+        const x264gpu_mb *L = left(mbx, mby), *T = top(mbx, mby);
+        const int ctx = (L && intra_type(L->type) && L->chroma_mode != 0) + (T && intra_type(T->type) && T->chroma_mode != 0);
+        if (!m.chroma_mode) decision(64 + ctx, 0);
+        else { decision(64 + ctx, 1); decision(64 + 3, m.chroma_mode > 1); if (m.chroma_mode > 1) decision(64 + 3, m.chroma_mode > 2); }
+        decision(77 + (L && L->cbp_chroma) + 2 * (T && T->cbp_chroma), m.cbp_chroma != 0);
+        if (m.cbp_chroma) {
+            decision(77 + 4 + (L && L->cbp_chroma == 2) + 2 * (T && T->cbp_chroma == 2), m.cbp_chroma == 2);
+            for (int pl = 0; pl < 2; pl++) block_cbf(lv + X264GPU_LV_CHROMA_DC + pl * 4, 4, 3, cbf_dc(mbx, mby, m, 25 + pl));
+            if (m.cbp_chroma == 2)
+                for (int pl = 0; pl < 2; pl++)
+                    for (int k = 0; k < 4; k++) block_cbf(lv + X264GPU_LV_CHROMA_AC + (pl * 4 + k) * 16 + 1, 15, 4, cbf_chroma_ac(mbx, mby, m, pl, k));
+        }
+    }
 };
 
 }  // namespace
+
+// The part sizes of RD refinement (x264 subme >= 8), 1/256 bit; c->state is a scratch copy of the slice's context variables; nnzc = x264's
+// non_zero_count cache of the macroblock (24 flags) as the encodes before left it.  kind: 0 inter part (a = i8, b = pixel, d = done mask),
+// 1 Intra_4x4 block a, 2 Intra_8x8 block a, 3 the chroma of an intra macroblock
+extern "C" long x264o_cabac_part(x264o_cabac_ctx *c, int mbx, int mby, int kind, int a, int b, int d, const uint8_t *nnzc)
+{
+    Coder k(*c, true);
+    k.nnz_over = nnzc;
+    if (kind == 0) k.partition_p(mbx, mby, a, b, d);
+    else if (kind == 1) k.part_i4x4(mbx, mby, a);
+    else if (kind == 2) k.part_i8x8(mbx, mby, a);
+    else k.chroma_part(mbx, mby);
+    return k.f8;
+}
 
 // mode 0: move c->state (and last_dqp, the macroblock's |mvd| entries) past the finished macroblock; mode 1: price the candidate that sits
 // in the macroblock's record and levels — c->state must then be a scratch copy.  Returns the count in 1/256 bit units.

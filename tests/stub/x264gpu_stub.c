@@ -168,6 +168,13 @@ int x264gpu_encode_pictures(x264gpu_encoder *g, const uint8_t *i420, const x264g
     if (g->dev != t_dev) return fail("encoder used from a thread bound to another device");
     const size_t fsz = (size_t)g->cfg.width * g->cfg.height * 3 / 2;
     g_calls[g->dev]++;
+    /* the device's structural checks (csrc/encoder.hip x264gpu_encode_pictures): lock-step streams share everything but the quantiser and its fraction */
+    for (int s = 0; s < g->cfg.streams; s++) {
+        if (pics[s].qp_frac_q8 < -128 || pics[s].qp_frac_q8 > 127) return fail("qp_frac_q8 out of range");
+        if (s && !(pics[s].slice_type == pics[0].slice_type && pics[s].poc == pics[0].poc && pics[s].dst == pics[0].dst && pics[s].keep == pics[0].keep &&
+                   pics[s].nref[0] == pics[0].nref[0] && pics[s].nref[1] == pics[0].nref[1] && !memcmp(pics[s].slot, pics[0].slot, sizeof(pics[0].slot)) &&
+                   pics[s].blind_dupe == pics[0].blind_dupe && !memcmp(pics[s].wl0, pics[0].wl0, sizeof(pics[0].wl0)))) return fail("lock-step streams must share the picture structure");
+    }
     for (int s = 0; s < g->cfg.streams; s++) {
         x264o_encoder_set_mb_qp_offsets(g->e[s], g->off ? g->off + (size_t)s * g->nmb : NULL);
         if (x264o_encoder_encode_pic(g->e[s], i420 + s * fsz, &pics[s], mb + (size_t)s * g->nmb, lv + (size_t)s * g->nmb * X264GPU_MB_LEVELS)) return fail("picture control rejected");

@@ -117,13 +117,28 @@ __device__ __forceinline__ void cab_step(int &st, int &f8v, uint32_t model, bool
 // coeff_abs_level_minus1 context (0..9), or anything else.  x264's node contexts: c1 = bin 0, cg = the bins after it.
 __device__ __forceinline__ void cab_levels(Cab &cb, int &st, uint32_t model, int coef, unsigned long long mask, int q)
 {
-    int node = 0;
+    // What a coefficient's bins depend on besides the context variables — x264's node (how many ones / greater-than-ones were coded before it,
+    // i.e. at the higher scan positions) — is a function of the block alone: every lane works it out for ITS coefficient with two ballots and
+    // two population counts, adds the bypass bins (sign, escape suffix) to its own share of the bits, and packs what the serial walk needs;
+    // the walk itself is then one lane read and the context steps per non-zero coefficient.
+    int pkv;
+    {
+        const int ln = (int)__lane_id(), av = abs(coef);
+        const unsigned long long m1 = __ballot(av == 1), mg = __ballot(av > 1);
+        const unsigned long long above = ln < 63 ? ~((2ull << ln) - 1) : 0ull;
+        const int ngt = __builtin_popcountll(mg & above), n1 = __builtin_popcountll(m1 & above);
+        const int node = ngt == 0 ? min(n1, 3) : min(3 + ngt, 7);
+        const int c1 = node < 4 ? node + 1 : 0, cg = node < 4 ? 5 : node + 2;
+        // sign: one bypass bin; escape: Exp-Golomb order 0 of a - 15 = 2 floor(log2(a - 14)) + 1 bypass bins
+        cb.f8v += av ? 256 + (av >= 15 ? 256 * (2 * (31 - __builtin_clz(av - 14)) + 1) : 0) : 0;
+        pkv = c1 | (cg << 4) | (min(av, 15) << 8);
+    }
     while (mask) {
         const int i = 63 - __builtin_clzll(mask);
         mask ^= 1ull << i;
-        const int a = abs(__builtin_amdgcn_readlane(coef, i));
-        const int c1 = node < 4 ? node + 1 : 0, cg = node < 4 ? 5 : min(node + 2, 9);
-        const int ones = min(a, 15) - 2, nb = a > 1 ? (a < 15 ? a - 1 : 13) : 0;        // bins on cg: `ones` ones, then a zero unless the escape follows
+        const int pk = __builtin_amdgcn_readlane(pkv, i);
+        const int c1 = pk & 15, cg = (pk >> 4) & 15, a = pk >> 8;                       // a: min(|level|, 15)
+        const int ones = a - 2, nb = a > 1 ? (a < 15 ? a - 1 : 13) : 0;                 // bins on cg: `ones` ones, then a zero unless the escape follows
         cab_step(st, cb.f8v, model, q == c1 || (a > 1 && q == cg), q == c1 ? a > 1 : a > 2);
         if (ones >= 3) {
             // a run of ones on cg.  While a one is that context's less probable symbol it is stepped; from then on every bin moves the state up
@@ -141,9 +156,6 @@ __device__ __forceinline__ void cab_levels(Cab &cb, int &st, uint32_t model, int
             if (a < 15) cab_step(st, cb.f8v, model, q == cg, 0);
         } else
             for (int kb = 1; kb < nb; kb++) cab_step(st, cb.f8v, model, q == cg, kb < ones);
-        cb.f8 += 256;                                                  // sign
-        if (a >= 15) cab_ue_bypass(cb, 0, a - 15);
-        node = a > 1 ? (node < 4 ? 4 : min(node + 1, 7)) : (node < 3 ? node + 1 : node);
     }
 }
 

@@ -56,7 +56,9 @@ struct EncK {
     const Q8 *q8tab;          // [52][2]: intra, inter
     const int *lambda_tab;    // [52]
     const uint16_t *cost_all; // [52][2 * MVCOST_HALF]
-    const int8_t *stream_qp;  // optional [streams]: each stream's slice quantiser (x264gpu_encoder_set_stream_qps); k.qp otherwise
+    const int8_t *stream_qp;  // optional [2][streams]: each stream's slice quantiser (x264gpu_encoder_set_stream_qps) and, behind it, the fraction of its float
+                              // quantiser in 1/256 (x264gpu_pic.qp_frac_q8 of that stream); k.qp / k.qp_frac_q8 otherwise
+    int stream_qp_n;          // streams (the stride between the two halves of stream_qp)
     int aq_strength_q8;
     int qp_frac_q8;           // the picture's quantiser is qp + qp_frac_q8 / 256 (x264gpu_pic.qp_frac_q8): enters the per-macroblock quantisers before the rounding
     int qp_snap;              // --aq-mode != 0: a macroblock quantiser within 1 of the previous macroblock's takes that one (x264_macroblock_analyse)
@@ -86,6 +88,8 @@ struct EncK {
 };
 // the slice quantiser of stream s
 __device__ __forceinline__ int slice_qp(const EncK &k, int s) { return k.stream_qp ? (int)k.stream_qp[s] : k.qp; }
+// ... in 1/256, with the fraction of the stream's float quantiser (rate-controlled sessions; x264 rc->qpm)
+__device__ __forceinline__ int slice_qp_q8(const EncK &k, int s) { return k.stream_qp ? (int)k.stream_qp[s] * 256 + (int)k.stream_qp[k.stream_qp_n + s] : k.qp * 256 + k.qp_frac_q8; }
 
 
 __device__ __forceinline__ const uint8_t *ref_plane00(const EncK &k, int s, int r)

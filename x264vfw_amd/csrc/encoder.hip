@@ -183,16 +183,25 @@ int x264gpu_encoder_set_mb_qp_offsets(x264gpu_encoder *e, const int16_t *d_offse
     return X264GPU_OK;
 }
 
+// every stream its own slice quantiser and (fracs != NULL) the fraction of its float quantiser in 1/256: [quantisers][fractions] per set
+static int set_stream_qps_q8(x264gpu_encoder *e, const int8_t *qps, const int8_t *fracs)
+{
+    const size_t S = (size_t)e->cfg.streams;
+    for (size_t s = 0; s < S; s++) ARG_TRY(qps[s] >= 0 && qps[s] <= 51);
+    if (!e->stream_qp) HIP_TRY(hipMalloc((void **)&e->stream_qp, 4 * S));
+    e->stream_qp_sel ^= 1;
+    int8_t *dst = e->stream_qp + (size_t)e->stream_qp_sel * 2 * S;
+    HIP_TRY(hipMemcpy(dst, qps, S, hipMemcpyHostToDevice));
+    if (fracs) HIP_TRY(hipMemcpy(dst + S, fracs, S, hipMemcpyHostToDevice)); else HIP_TRY(hipMemset(dst + S, 0, S));
+    e->use_stream_qp = true;
+    return X264GPU_OK;
+}
+
 int x264gpu_encoder_set_stream_qps(x264gpu_encoder *e, const int8_t *qps)
 {
     ARG_TRY(e);
     if (!qps) { e->use_stream_qp = false; return X264GPU_OK; }
-    for (int s = 0; s < e->cfg.streams; s++) ARG_TRY(qps[s] >= 0 && qps[s] <= 51);
-    if (!e->stream_qp) HIP_TRY(hipMalloc((void **)&e->stream_qp, 2 * (size_t)e->cfg.streams));
-    e->stream_qp_sel ^= 1;
-    HIP_TRY(hipMemcpy(e->stream_qp + (size_t)e->stream_qp_sel * e->cfg.streams, qps, (size_t)e->cfg.streams, hipMemcpyHostToDevice));
-    e->use_stream_qp = true;
-    return X264GPU_OK;
+    return set_stream_qps_q8(e, qps, nullptr);
 }
 
 static void profile_free(x264gpu_encoder *e)
@@ -423,7 +432,7 @@ static int encode_core(x264gpu_encoder *e, const uint8_t *d_i420, const x264gpu_
     hipLaunchKernelGGL(k_ingest, dim3((k.cw / 4 + 255) / 256, k.ch, S), dim3(256), 0, st, k);
     // per-macroblock quantisers: always materialised (the macroblock loop reads every quantiser-dependent value per macroblock)
     const bool aq = e->cfg.aq_mode != 0 || e->ext_off != nullptr || e->use_stream_qp;
-    k.stream_qp = e->use_stream_qp ? e->stream_qp + (size_t)e->stream_qp_sel * e->cfg.streams : nullptr;
+    k.stream_qp = e->use_stream_qp ? e->stream_qp + (size_t)e->stream_qp_sel * 2 * e->cfg.streams : nullptr; k.stream_qp_n = e->cfg.streams;
     k.mbqp = e->mbqp; k.q4tab = e->q4tab; k.q8tab = e->q8tab; k.lambda_tab = e->lambda_tab; k.cost_all = e->cost_all; k.aq_strength_q8 = e->cfg.aq_strength_q8; k.qp_snap = e->cfg.aq_mode != 0; k.qp_frac_q8 = pic.qp_frac_q8;
     if (e->ext_off || !e->cfg.aq_mode) hipLaunchKernelGGL(k_apply_qp_offsets, dim3((k.nmb + 255) / 256, S), dim3(256), 0, st, k, e->ext_off);
     else hipLaunchKernelGGL(k_aq, dim3((k.nmb + 15) / 16, S), dim3(256), 0, st, k);
@@ -507,19 +516,21 @@ int x264gpu_encode_frames(x264gpu_encoder *e, const uint8_t *d_i420, int slice_t
 int x264gpu_encode_pictures(x264gpu_encoder *e, const uint8_t *d_i420, const x264gpu_pic *pics, x264gpu_mb *d_mb, int16_t *d_levels, void *stream)
 {
     ARG_TRY(e && d_i420 && pics && d_mb && d_levels);
-    // the streams of a call share the picture structure (lock-step GOPs); their quantisers may differ
+    // the streams of a call share the picture structure (lock-step GOPs: slice type, POC, DPB slots, lists, explicit weights); their quantisers —
+    // integer part and the fraction of a rate-controlled session's float quantiser — may differ
     const int S = e->cfg.streams;
     bool same_qp = true;
+    for (int s = 0; s < S; s++) ARG_TRY(pics[s].qp_frac_q8 >= -128 && pics[s].qp_frac_q8 <= 127);
     for (int s = 1; s < S; s++) {
         ARG_TRY(pics[s].slice_type == pics[0].slice_type && pics[s].poc == pics[0].poc && pics[s].dst == pics[0].dst && pics[s].keep == pics[0].keep &&
                 pics[s].nref[0] == pics[0].nref[0] && pics[s].nref[1] == pics[0].nref[1] && !memcmp(pics[s].slot, pics[0].slot, sizeof(pics[0].slot)) &&
-                pics[s].blind_dupe == pics[0].blind_dupe && pics[s].qp_frac_q8 == pics[0].qp_frac_q8 && !memcmp(pics[s].wl0, pics[0].wl0, sizeof(pics[0].wl0)));
-        same_qp = same_qp && pics[s].qp == pics[0].qp;
+                pics[s].blind_dupe == pics[0].blind_dupe && !memcmp(pics[s].wl0, pics[0].wl0, sizeof(pics[0].wl0)));
+        same_qp = same_qp && pics[s].qp == pics[0].qp && pics[s].qp_frac_q8 == pics[0].qp_frac_q8;
     }
     if (!same_qp) {
-        std::vector<int8_t> q((size_t)S);
-        for (int s = 0; s < S; s++) q[(size_t)s] = (int8_t)pics[s].qp;
-        const int rc = x264gpu_encoder_set_stream_qps(e, q.data());
+        std::vector<int8_t> q((size_t)S), f((size_t)S);
+        for (int s = 0; s < S; s++) { q[(size_t)s] = (int8_t)pics[s].qp; f[(size_t)s] = (int8_t)pics[s].qp_frac_q8; }
+        const int rc = set_stream_qps_q8(e, q.data(), f.data());
         if (rc != X264GPU_OK) return rc;
     }
     const int rc = encode_core(e, d_i420, pics[0], d_mb, d_levels, (hipStream_t)stream);

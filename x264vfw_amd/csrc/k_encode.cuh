@@ -65,14 +65,14 @@ __global__ __launch_bounds__(256) void k_aq(EncK k)
     const unsigned e1 = energy ? energy : 1u;
     const int lz = 31 - __builtin_clz(e1), lg = lz * 256 + c_aq_log2_lut[((e1 << (31 - lz)) >> 24) & 0x7f];
     const int adj = (k.aq_strength_q8 * (lg - 3693)) >> 8;
-    if (valid && r == 0) k.mbqp[(size_t)s * k.nmb + mbi] = (uint8_t)min(max((slice_qp(k, s) * 256 + k.qp_frac_q8 + adj + 128) >> 8, 1), 51);          // x264_ratecontrol_mb_qp: round(qpm + offset)
+    if (valid && r == 0) k.mbqp[(size_t)s * k.nmb + mbi] = (uint8_t)min(max((slice_qp_q8(k, s) + adj + 128) >> 8, 1), 51);          // x264_ratecontrol_mb_qp: round(qpm + offset)
 }
 
 // quantiser offsets decided by the lookahead (AQ - macroblock-tree, Q8) -> per-macroblock quantisers (oracle compute_mb_qp, ext_off_q8)
 __global__ __launch_bounds__(256) void k_apply_qp_offsets(EncK k, const int16_t *__restrict__ off)
 {
     const int i = blockIdx.x * 256 + threadIdx.x, s = blockIdx.y;
-    if (i < k.nmb) k.mbqp[(size_t)s * k.nmb + i] = (uint8_t)(off ? min(max((slice_qp(k, s) * 256 + k.qp_frac_q8 + (int)off[(size_t)s * k.nmb + i] + 128) >> 8, 1), 51) : slice_qp(k, s));   // no offsets: the slice's (or the stream's) quantiser as it is
+    if (i < k.nmb) k.mbqp[(size_t)s * k.nmb + i] = (uint8_t)(off ? min(max((slice_qp_q8(k, s) + (int)off[(size_t)s * k.nmb + i] + 128) >> 8, 1), 51) : slice_qp(k, s));   // no offsets: the slice's (or the stream's) quantiser as it is
 }
 
 // QP_Y inheritance (oracle settle_mb_qp, 7.4.5): a macroblock that sends no mb_qp_delta takes its predecessor's quantiser; one wave per

@@ -162,6 +162,7 @@ struct BatchGroup {
     size_t insz = 0, nmb = 0;
     std::vector<char> member, arrived; int joined = 0, active = 0, n_arrived = 0;
     std::vector<x264gpu_pic> pics; long round = 0; int round_rc = 0; std::string err;
+    bool closed = false;          // a member left: no more joiners (batch_leave)
 };
 static std::mutex g_batch_mu;
 static std::vector<BatchGroup *> g_batch_groups;
@@ -183,7 +184,7 @@ static BatchGroup *batch_join(const x264gpu_config &cfg1, int N, size_t insz, si
     for (BatchGroup *g : g_batch_groups) {
         x264gpu_config a = g->cfg, b = cfg1;
         a.streams = b.streams = 0;
-        if (g->N == N && g->device == dev && g->joined < N && !memcmp(&a, &b, sizeof(a))) {
+        if (g->N == N && g->device == dev && g->joined < N && !g->closed && !memcmp(&a, &b, sizeof(a))) {
             std::lock_guard<std::mutex> lg(g->m);
             *idx = g->joined++; g->active++; g->member[(size_t)*idx] = 1;
             g->cv.notify_all();
@@ -244,15 +245,17 @@ static int batch_encode(BatchGroup *g, int s, const uint8_t *d_src, const x264gp
 }
 static void batch_leave(BatchGroup *g, int s)
 {
+    // the registry lock first (the order batch_join takes them in): "last" is decided and the group unlisted under it, so that a joiner can
+    // never be handed a group that is about to be destroyed; a group that lost a member takes no more joiners (closed), its seats stay empty
+    std::lock_guard<std::mutex> reg(g_batch_mu);
     bool last;
     {
         std::unique_lock<std::mutex> lk(g->m);
-        g->member[(size_t)s] = 0; g->active--;
+        g->member[(size_t)s] = 0; g->active--; g->closed = true;
         last = g->active == 0;
         if (!last && g->n_arrived >= g->active && g->n_arrived > 0) batch_run_round(g);      // the others were only waiting for this session
     }
     if (last) {
-        std::lock_guard<std::mutex> lk(g_batch_mu);
         for (size_t i = 0; i < g_batch_groups.size(); i++) if (g_batch_groups[i] == g) { g_batch_groups.erase(g_batch_groups.begin() + (long)i); break; }
         batch_destroy(g);
     }
@@ -314,11 +317,12 @@ static PpsParams make_pps(const x264_t *h)
     return pp;
 }
 // appends SPS, PPS (and optionally the version SEI) to h->out, recording NAL offsets and types
-// access unit delimiter (--aud, 7.3.2.4): primary_pic_type 0 = I slices only, 1 = I and P; first NAL of the access unit (long start code)
-static void write_aud(std::vector<uint8_t> &out, bool intra_only, bool annexb)
+// access unit delimiter (--aud, 7.3.2.4, Table 7-5): primary_pic_type 0 = I slices only, 1 = I and P, 2 = I, P and B (what x264 writes for its three
+// slice types); first NAL of the access unit (long start code)
+static void write_aud(std::vector<uint8_t> &out, int pic_type /* 0 I, 1 P, 2 B */, bool annexb)
 {
     BitWriter bw;
-    bw.put(intra_only ? 0u : 1u, 3);
+    bw.put((unsigned)pic_type, 3);
     bw.trailing();
     append_nal(out, 0, 9, bw.bytes(), annexb, true);
 }
@@ -796,7 +800,7 @@ static int code_position(x264_t *h, int batch, int t, int nslots_with_t)
         c.bytes.clear(); c.off.clear(); c.types.clear();
         c.idr = t == 0;
         const long gop = (long)batch * G + s;
-        if (p.b_aud) { c.off.push_back(c.bytes.size()); c.types.push_back(9); write_aud(c.bytes, t == 0, p.b_annexb != 0); }
+        if (p.b_aud) { c.off.push_back(c.bytes.size()); c.types.push_back(9); write_aud(c.bytes, t == 0 ? 0 : 1, p.b_annexb != 0); }
         if (c.idr && p.b_repeat_headers) {
             const bool annexb = p.b_annexb != 0;
             c.off.push_back(c.bytes.size()); c.types.push_back(7); write_sps(c.bytes, make_sps(h), annexb);
@@ -1043,7 +1047,7 @@ static int encode_queued(x264_t *h, x264_nal_t **pp_nal, int *pi_nal, x264_pictu
     // ---- host: headers + entropy coding ----
     h->out.clear(); h->nal_off.clear();
     std::vector<int> types;
-    if (p.b_aud) { h->nal_off.push_back(h->out.size()); types.push_back(9); write_aud(h->out, st != X264GPU_SLICE_P, p.b_annexb != 0); }
+    if (p.b_aud) { h->nal_off.push_back(h->out.size()); types.push_back(9); write_aud(h->out, st != X264GPU_SLICE_P ? 0 : 1, p.b_annexb != 0); }
     if (idr && p.b_repeat_headers) {
         emit_sets(h, types, !h->sei_sent);
         h->sei_sent = 1;
@@ -1430,7 +1434,9 @@ static bool st_decide(x264_t *h, bool flushing, int &j_out, int &closing_out)
         if (frm.type == ST_I && frm.frame - h->last_keyframe >= p.i_keyint_min) frm.type = ST_IDR;
         if (frm.type == ST_IDR) {                                                          // close the GOP
             h->last_keyframe = frm.frame;
-            if (bfr > 0) { bfr--; h->bq[(size_t)bfr].type = ST_P; }
+            // x264 keeps i_type on the frame; here the queue's types are re-derived from `forced` on every call, so the decision is pinned
+            // there: the IDR stays an IDR when it is reached after the run in front of it (which closes as P) has been coded
+            if (bfr > 0) { frm.forced = 2; bfr--; h->bq[(size_t)bfr].type = ST_P; }
         }
         if (bfr == h->bframes || bfr + 1 >= n) { if (frm.type == ST_AUTO || frm.type == ST_B || frm.type == ST_BREF) frm.type = ST_P; }
         if (frm.type == ST_AUTO) frm.type = ST_B;
@@ -1615,7 +1621,7 @@ static int encode_bmode(x264_t *h, x264_nal_t **pp_nal, int *pi_nal, x264_pictur
     const bool idr = pl.type == PIC_IDR;
     h->out.clear(); h->nal_off.clear();
     std::vector<int> types;
-    if (p.b_aud) { h->nal_off.push_back(h->out.size()); types.push_back(9); write_aud(h->out, pl.type <= PIC_I, p.b_annexb != 0); }
+    if (p.b_aud) { h->nal_off.push_back(h->out.size()); types.push_back(9); write_aud(h->out, pl.type <= PIC_I ? 0 : pl.type == PIC_P ? 1 : 2, p.b_annexb != 0); }
     if (idr && p.b_repeat_headers) { emit_sets(h, types, !h->sei_sent); h->sei_sent = 1; }
     SliceParams sp = {};
     sp.mbw = h->mbw; sp.mbh = h->mbh; sp.qp = pic.qp; sp.pic_init_qp = h->pic_init_qp; sp.log2_max_frame_num = h->log2_max_frame_num; sp.log2_max_poc_lsb = h->log2_max_poc_lsb;

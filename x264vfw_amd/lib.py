@@ -3,7 +3,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libx264gpu.so")
+# X264GPU_LIB: an instrumented build of the same library (tools/mb_prof.py: -DMB_PROF), never a different implementation
+LIB_PATH = os.environ.get("X264GPU_LIB") or os.path.join(_HERE, "libx264gpu.so")
 
 
 class X264GpuError(RuntimeError):
