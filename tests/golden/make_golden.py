@@ -26,7 +26,18 @@ CASES = [("p176x144", 176, 144, 5, {}), ("p208x120_q30", 208, 120, 3, dict(qp_i=
          ("p176x144_medium_chroma_me", 176, 144, 5, dict(refs=3, partitions=7, dct8x8=1, chroma_me=1)),
          ("p176x144_lowqp_umh", 176, 144, 4, dict(qp_i=10, qp_p=13, refs=2, partitions=7, dct8x8=1, chroma_me=1, me_method=2)),
          ("p176x144_x264_medium_me", 176, 144, 6, dict(refs=3, partitions=7, dct8x8=1, chroma_me=1, mixed_refs=1)),
-         ("p176x144_aq", 176, 144, 4, dict(refs=2, partitions=7, dct8x8=1, chroma_me=1, aq_mode=1, aq_strength_q8=266, qp_i=23, qp_p=26))]
+         ("p176x144_aq", 176, 144, 4, dict(refs=2, partitions=7, dct8x8=1, chroma_me=1, aq_mode=1, aq_strength_q8=266, qp_i=23, qp_p=26)),
+         # round 4: the headline toolset — RD mode decision priced with CABAC sizes (subme 7), psy-rd, trellis 1 / 2 — and RD refinement (subme 8)
+         ("p176x144_medium_rd_cabac_trellis", 176, 144, 5, dict(refs=3, partitions=7, dct8x8=1, chroma_me=1, mixed_refs=1, cabac=1, rd=1, subme=7, psy=1, psy_rd_q8=256,
+                                                               chroma_qp_offset=-2, trellis=63)),
+         ("p176x144_rd_cavlc", 176, 144, 4, dict(refs=2, partitions=7, dct8x8=1, chroma_me=1, mixed_refs=1, rd=1, subme=7, psy=1, psy_rd_q8=256, chroma_qp_offset=-2)),
+         ("p128x96_trellis2_umh", 128, 96, 4, dict(refs=2, partitions=7, dct8x8=1, chroma_me=1, mixed_refs=1, cabac=1, rd=1, subme=7, psy=1, psy_rd_q8=256,
+                                                   chroma_qp_offset=-2, trellis=127, me_method=2)),
+         ("p176x144_subme8_rd_refine", 176, 144, 4, dict(refs=3, partitions=7, dct8x8=1, chroma_me=1, mixed_refs=1, cabac=1, rd=1, subme=8, psy=1, psy_rd_q8=256,
+                                                        chroma_qp_offset=-2, trellis=127))]
+MEDIUM_B = dict(refs=3, dpb=4, weightb=1, partitions=7, dct8x8=1, chroma_me=1, mixed_refs=1, cabac=1, rd=1, subme=7, psy=1, psy_rd_q8=256, chroma_qp_offset=-2, trellis=63)
+# (name, w, h, display-order types, seed, weightp, config overrides): mini-GOPs through the product's DPB model (host/dpb.hpp) and oracle encode_pic
+B_CASES = [("b176x144_medium_weightp2", 176, 144, "IBBBPBBBP", 5, 2, {}), ("b128x96_ref5_umh", 128, 96, "IBBPBP", 7, 0, dict(refs=5, dpb=5, me_method=2))]
 
 
 def sha(a):
@@ -41,6 +52,34 @@ def pipeline_case(w, h, n, kw):
         out.append({"mb": sha(mbs.view(np.uint8)), "levels": sha(lv), "recon": sha(enc.recon()),
                     "types": np.bincount(mbs["type"], minlength=7).tolist(), "nonzero_levels": int((lv != 0).sum())})
     enc.close()
+    return out
+
+
+def b_case(w, h, types, seed, weightp, over):
+    os.environ.setdefault("X264_HOST_STUB", "1")          # the DPB model is host code: linked against the stand-in device library on a CPU-only box
+    import bgop
+    import host_lib as HL
+    kw = dict(MEDIUM_B, **over)
+    cfg = O.default_config(w, h, **kw)
+    enc = O.OracleEncoder(cfg)
+    pics = []
+    stream, recons, order, pocs = bgop.encode_gop(HL, enc, synth_frames(w, h, len(types), seed=seed), types, cfg, 20, 23, 25, kw["refs"], 3, 1, weightp, pics)
+    return {"stream": sha(np.frombuffer(bytes(stream), dtype=np.uint8)), "bytes": len(stream), "order": [list(o) for o in order],
+            "per_picture": [{"mb": sha(m.view(np.uint8)), "recon": sha(r), "types": np.bincount(m["type"], minlength=11).tolist()} for (_, m), r in zip(pics, recons)]}
+
+
+def slicetype_case():
+    """frame costs of (p0, p1, b) triples on the half-resolution planes (oracle/slicetype.c): what the slice-type decisions and the macroblock-tree read"""
+    w, h = 176, 144
+    fr = synth_frames(w, h, 5, seed=33)
+    st = O.OracleSlicetype(w, h, slots=8, bframes=3)
+    for i, f in enumerate(fr):
+        st.put(i, f)
+    out = {"w": w, "h": h, "seed": 33, "costs": {}}
+    for (s0, s1, sb) in [(0, 0, 0), (0, 1, 1), (0, 2, 2), (0, 2, 1), (0, 4, 2), (1, 4, 3), (0, 3, 3)]:
+        out["costs"][f"{s0},{s1},{sb}"] = int(st.cost(s0, s1, sb, sb - s0, s1 - sb))
+    out["intra_costs_sha"] = sha(st.intra_costs(2)); out["mvs_sha"] = sha(st.mvs(2, 0, 2))
+    st.close()
     return out
 
 
@@ -82,5 +121,8 @@ if __name__ == "__main__":
     json.dump(csp_vectors(), open(os.path.join(HERE, "oracle_csp.json"), "w"), indent=1)
     js = {name: {"w": w, "h": h, "frames": n, "cfg": kw, "per_frame": pipeline_case(w, h, n, kw)} for name, w, h, n, kw in CASES}
     json.dump(js, open(os.path.join(HERE, "oracle_pipeline.json"), "w"), indent=1)
+    jb = {name: dict(w=w, h=h, types=t, seed=sd, weightp=wp, cfg=ov, **b_case(w, h, t, sd, wp, ov)) for name, w, h, t, sd, wp, ov in B_CASES}
+    json.dump(jb, open(os.path.join(HERE, "oracle_bframes.json"), "w"), indent=1)
+    json.dump(slicetype_case(), open(os.path.join(HERE, "oracle_slicetype.json"), "w"), indent=1)
     np.savez_compressed(os.path.join(HERE, "prim_vectors.npz"), **prim_vectors())
     print("golden fixtures written")

@@ -34,7 +34,8 @@ def test_prim_golden_vectors():
             np.testing.assert_array_equal(r, g[f"rec_q{qp}_l{lst}"])
 
 
-@pytest.mark.parametrize("case", ["p176x144", "p208x120_q30", "p64x48_nodeblock", "p176x144_medium", "p208x120_i8x8_only", "p176x144_medium_chroma_me", "p176x144_lowqp_umh", "p176x144_x264_medium_me", "p176x144_aq"])
+@pytest.mark.parametrize("case", ["p176x144", "p208x120_q30", "p64x48_nodeblock", "p176x144_medium", "p208x120_i8x8_only", "p176x144_medium_chroma_me", "p176x144_lowqp_umh", "p176x144_x264_medium_me", "p176x144_aq",
+                                  "p176x144_medium_rd_cabac_trellis", "p176x144_rd_cavlc", "p128x96_trellis2_umh", "p176x144_subme8_rd_refine"])
 def test_pipeline_golden(case):
     js = json.load(open(os.path.join(GOLD, "oracle_pipeline.json")))[case]
     w, h = js["w"], js["h"]
@@ -44,6 +45,32 @@ def test_pipeline_golden(case):
         assert sha(mbs.view(np.uint8)) == exp["mb"], f"frame {i} records"
         assert sha(lv) == exp["levels"], f"frame {i} levels"
         assert sha(enc.recon()) == exp["recon"], f"frame {i} recon"
+
+
+@pytest.mark.parametrize("case", ["b176x144_medium_weightp2", "b128x96_ref5_umh"])
+def test_bframes_golden(case):
+    """B mini-GOPs of the headline toolset (spatial direct, two-list searches, implicit weights, B RD decision, --weightp 2's duplicate) through the
+    product's DPB model and host CABAC writer: records, reconstruction and the written stream against the committed hashes"""
+    import subprocess
+    import sys
+    # (the DPB model is host code linked against the stand-in device library: its own process, as in test_bframes_cpu.py's sessions)
+    code = ("import os, sys, json; os.environ['X264_HOST_STUB'] = '1'; sys.path.insert(0, %r); sys.path.insert(0, %r);"
+            "import make_golden as G; js = json.load(open(os.path.join(%r, 'oracle_bframes.json')))[%r];"
+            "r = G.b_case(js['w'], js['h'], js['types'], js['seed'], js['weightp'], js['cfg']);"
+            "assert r['per_picture'] == js['per_picture'], 'records / reconstruction'; assert r['stream'] == js['stream'] and r['bytes'] == js['bytes'], 'stream'"
+            % (os.path.dirname(__file__), GOLD, GOLD, case))
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-1500:]
+
+
+def test_slicetype_golden():
+    """the lookahead's frame costs (oracle/slicetype.c) against the committed values"""
+    sys_path = os.path.join(GOLD)
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("make_golden", os.path.join(sys_path, "make_golden.py"))
+    G = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(G)
+    assert G.slicetype_case() == json.load(open(os.path.join(GOLD, "oracle_slicetype.json")))
 
 
 def test_csp_golden():

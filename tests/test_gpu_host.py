@@ -979,6 +979,14 @@ def test_cross_session_batcher_on_the_device(gpu):
     assert r["equal"] == [True] * 16 and r["distinct"] == 16, r
 
 
+def test_cross_session_batcher_with_crf_on_the_device(gpu):
+    """CRF sessions in one batch: every stream carries its own float quantiser (integer part + fraction, x264gpu_pic.qp / qp_frac_q8) through one
+    lock-step launch; byte-identical to the sessions run one by one (round-3 advisor finding: the device used to refuse differing fractions)"""
+    from test_bframes_cpu import _batch
+    r = _batch(6, 176, 144, 9, ["crf=24", "keyint=8", "min-keyint=8", "scenecut=0", "b-adapt=0", "bframes=2", "no-mbtree"], gpu=True)
+    assert r["equal"] == [True] * 6 and r["distinct"] == 6, r
+
+
 def test_fade_session_gets_luma_weights_on_the_device(gpu):
     """a fade through x264_encoder_encode with medium's lookahead on the device: x264_weights_analyse's restatement (host) on the device's
     statistics and weight costs gives the P pictures luma weights; the stream is smaller than with --weightp 0 and decodes to the source"""

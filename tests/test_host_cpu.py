@@ -454,3 +454,40 @@ def test_oracle_trellis_streams_decode_and_pay_off(w, h, kw):
     assert b1 != b0, res
     if not kw.get("psy"):
         assert (p1 - p0) + 3.3 * np.log2(b0 / b1) > 0.05, res
+
+
+@pytest.mark.parametrize("w,h,kw", [(176, 144, dict(partitions=7, dct8x8=1, refs=2, mixed_refs=1, chroma_me=1, rd=1)),
+                                     (176, 144, dict(partitions=7, dct8x8=1, refs=3, mixed_refs=1, chroma_me=1, rd=1, psy=1, psy_rd_q8=256, chroma_qp_offset=-2, trellis=63)),
+                                     (96, 80, dict(partitions=7, dct8x8=0, qp_i=34, qp_p=37, rd=1)),
+                                     (208, 120, dict(partitions=7, dct8x8=1, qp_i=14, qp_p=16, rd=1, refs=2, trellis=127))])
+def test_oracle_rd_refinement_streams_decode_and_pay_off(w, h, kw):
+    """RD refinement in the checker (x264 --subme 8: x264_me_refine_qpel_rd of the chosen P partitions, intra_rd_refine of the chosen intra type's
+    modes; oracle/analyse.c): the refined vectors and modes are ordinary ones — the stream written from them decodes to the encoder's own
+    reconstruction — and without psy-RD (which trades PSNR for energy on purpose) the refinement wins in rate-distortion terms over subme 7"""
+    nfr = 6
+    frames = synth_frames(w, h, nfr, seed=5 * w + h)
+    mbw, mbh = (w + 15) // 16, (h + 15) // 16
+    res = {}
+    for sub in (7, 8):
+        cfg = O.default_config(w, h, cabac=1, subme=sub, **kw)
+        enc = O.OracleEncoder(cfg)
+        stream = HL.write_headers(w, h, pic_init_qp=cfg.qp_p, num_ref=cfg.refs, t8x8=cfg.dct8x8, cabac=1, cqo=cfg.chroma_qp_offset)
+        recs, bits = [], 0
+        for i, f in enumerate(frames):
+            idr = i == 0
+            mbs, lv = enc.encode(f, 2 if idr else 0)
+            nal = HL.write_slice(mbw, mbh, 2 if idr else 0, cfg.qp_i if idr else cfg.qp_p, cfg.qp_p, i, 8, int(idr), 0, 0, mbs, lv,
+                                 num_ref=max(1, min(cfg.refs, i)), num_ref_default=cfg.refs, t8x8=cfg.dct8x8, cabac=1)[0]
+            stream += nal; bits += 8 * len(nal)
+            recs.append(enc.recon().copy())
+        dec = O.h264_decode(stream, nfr, w, h)
+        assert len(dec) == nfr
+        sse = 0.0
+        for i in range(nfr):
+            np.testing.assert_array_equal(dec[i], recs[i], err_msg=f"subme {sub} picture {i}")
+            sse += float(((recs[i][:w * h].astype(np.int64) - frames[i][:w * h].astype(np.int64)) ** 2).sum())
+        res[sub] = (bits, 10 * np.log10(255.0 ** 2 * w * h * nfr / max(sse, 1.0)))
+    (b0, p0), (b1, p1) = res[7], res[8]
+    assert b1 != b0, res
+    if not kw.get("psy"):
+        assert (p1 - p0) + 3.3 * np.log2(b0 / b1) > 0.0, res
