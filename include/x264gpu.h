@@ -207,7 +207,10 @@ typedef struct x264gpu_config {
                                * costed like any other; under CAVLC P_8x8ref0 makes it free ([x264-upstream] analyse.c x264_mb_analyse_inter_p8x8*) */
     int rd;                   /* 1: x264's RD mode decision of subme 6 / 7 (i_mbrd 1: x264_rd_cost_mb = SSD + psy + lambda2 x bits over the candidate
                                * macroblock types, transform-size RD, P_SKIP by RD; no final quarter-pel refinement).  Bits: exact CAVLC counts
-                               * (cabac == 0), or x264's size-only CABAC on the slice's context variables, which the device carries (cabac == 1) */
+                               * (cabac == 0), or x264's size-only CABAC on the slice's context variables, which the device carries (cabac == 1).
+                               * 1 | sites << 1 with subme 8 (CABAC sessions, --me hex / umh): RD refinement of the chosen type as well (x264 i_mbrd 2) —
+                               * sites: 1 the vectors of the P partitions (x264_me_refine_qpel_rd), 2 the Intra_16x16 mode, 4 the chroma mode, 8 the
+                               * Intra_4x4 modes, 16 the Intra_8x8 modes (intra_rd_refine); x264's --subme 8 is all of them: rd = 63 */
     int psy;                  /* x264 analyse.b_psy (default on): chroma lambda offset of the RD costs */
     int psy_rd_q8;            /* x264 FIX8(--psy-rd strength) (medium: 256); enters the RD costs (subme >= 6) */
     int slices;               /* x264 --sliced-threads with --threads N: N slices per picture (0 / 1 = one), slice i = macroblock rows

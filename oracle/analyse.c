@@ -607,17 +607,19 @@ static void encode_luma_inter8(x264o_encoder *e, const pixel *fenc, pixel *rec, 
     int16_t scan[4][64];
     int keep[4], mbscore = 0;
     const uint16_t *mf = e->qt.quant8_mf[X264O_CQM_8PY][qp], *bias = e->qt.quant8_bias[X264O_CQM_8PY][qp];
+    /* x264_macroblock_encode: "b_decimate &= !h->mb.b_trellis || !h->param.b_cabac; 8x8 trellis is inherently optimal decimation for CABAC" */
+    const int b_decimate = e->cfg.dct_decimate && !(e->b_trellis & TR_P8);
     for (int i8 = 0; i8 < 4; i8++) {
         x264o_sub8x8_dct8(d[i8], fenc + (i8 >> 1) * 8 * e->fs + (i8 & 1) * 8, e->fs, rec + (i8 >> 1) * 8 * e->rs + (i8 & 1) * 8, e->rs);
         keep[i8] = quant_8x8(e, d[i8], mf, bias, qp, 0);
         for (int k = 0; k < 64; k++) scan[i8][k] = d[i8][x264o_zigzag8[k]];
-        if (keep[i8] && e->cfg.dct_decimate) {
+        if (keep[i8] && b_decimate) {
             const int sc = x264o_decimate_score(scan[i8], 64);
             mbscore += sc;
             if (sc < 4) keep[i8] = 0;
         }
     }
-    if (e->cfg.dct_decimate && mbscore < 6) keep[0] = keep[1] = keep[2] = keep[3] = 0;
+    if (b_decimate && mbscore < 6) keep[0] = keep[1] = keep[2] = keep[3] = 0;
     for (int i8 = 0; i8 < 4; i8++) {
         if (!keep[i8]) continue;
         for (int k = 0; k < 64; k++) {
@@ -2193,7 +2195,7 @@ static void encode_p8x8(actx *a, int i8, x264gpu_mb *mb, int16_t *lv)
         int nz = quant_8x8(e, d, e->qt.quant8_mf[X264O_CQM_8PY][qp], e->qt.quant8_bias[X264O_CQM_8PY][qp], qp, 0);
         if (nz) {
             for (int k = 0; k < 64; k++) scan[k] = d[x264o_zigzag8[k]];
-            if (b_decimate) nz = x264o_decimate_score(scan, 64) >= 4;
+            if (b_decimate && !(e->b_trellis & TR_P8)) nz = x264o_decimate_score(scan, 64) >= 4;      /* (x264: b_decimate && !h->mb.b_trellis) */
         }
         if (nz) {
             for (int k = 0; k < 64; k++) { lv[(i8 * 4 + (k & 3)) * 16 + (k >> 2)] = scan[k]; if (scan[k]) mb->nnz |= 1u << (i8 * 4 + (k & 3)); }
@@ -2406,7 +2408,8 @@ static void intra_rd_refine(actx *a, int type, x264gpu_mb *mb, int16_t *lv)
     const int left = a->mbx > 0, top = a->mby > e->row0;
     const pixel *fenc = e->fenc_y + (size_t)a->mby * 16 * e->fs + a->mbx * 16;
     pixel *rec = luma_plane(e, e->cur, 0) + (size_t)a->mby * 16 * e->rs + a->mbx * 16;
-    if (type == X264GPU_MB_I16x16) {
+    const int sites = e->cfg.rd >> 1;
+    if (type == X264GPU_MB_I16x16 && (sites & 2)) {
         const int old = a->pred16;
         const int thresh = a->b_early_terminate ? a->satd_i16_dir[old] * 9 / 8 : COST_MAX;
         int modes[4], n = 0, best = a->satd_i16, bestm = old;
@@ -2424,7 +2427,7 @@ static void intra_rd_refine(actx *a, int type, x264gpu_mb *mb, int16_t *lv)
         a->pred16 = bestm;
     }
     /* the chroma mode (every intra type) */
-    {
+    if (sites & 4) {
         int cm[4], cn = 0;
         if (left && top) { cm[cn++] = I_PRED_CHROMA_DC; cm[cn++] = I_PRED_CHROMA_H; cm[cn++] = I_PRED_CHROMA_V; cm[cn++] = I_PRED_CHROMA_P; }
         else if (left) { cm[cn++] = I_PRED_CHROMA_DC_LEFT; cm[cn++] = I_PRED_CHROMA_H; }
@@ -2458,7 +2461,7 @@ static void intra_rd_refine(actx *a, int type, x264gpu_mb *mb, int16_t *lv)
             }
         }
     }
-    if (type == X264GPU_MB_I4x4) {
+    if (type == X264GPU_MB_I4x4 && (sites & 8)) {
         for (int k = 0; k < 16; k++) mb->i4_mode[k] = (uint8_t)a->pred4[k];
         for (int idx = 0; idx < 16; idx++) {
             const pixel *f = fenc + blk_y[idx] * 4 * e->fs + blk_x[idx] * 4;
@@ -2487,7 +2490,7 @@ static void intra_rd_refine(actx *a, int type, x264gpu_mb *mb, int16_t *lv)
             a->nnzc[idx] = (uint8_t)bestnz;
             a->pred4[idx] = bestm; mb->i4_mode[idx] = (uint8_t)bestm;
         }
-    } else if (type == X264GPU_MB_I8x8) {
+    } else if (type == X264GPU_MB_I8x8 && (sites & 16)) {
         for (int k = 0; k < 4; k++) memset(mb->i4_mode + 4 * k, a->pred8[k], 4);
         mb->transform8x8 = 1;
         for (int idx = 0; idx < 4; idx++) {
@@ -2559,7 +2562,8 @@ static void macroblock_body(x264o_encoder *e, int mbx, int mby, actx *a)
     mb->qp = (uint8_t)a->qp;
     /* x264_macroblock_thread_init / mb_analyse_init: B slices analyse one sub-pel level down (6 -> 5, 8 -> 7); i_mbrd = (subme >= 6) + (subme >= 8) */
     if (e->slice_type == X264GPU_SLICE_B && (a->subme == 6 || a->subme == 8)) a->subme--;
-    a->mbrd = e->cfg.rd ? 1 + (e->cfg.cabac && a->subme >= 8) : 0; a->rd16x16 = COST_MAX; a->force_t8 = -1; a->cost8x8 = a->cost16x8 = a->cost8x16 = COST_MAX;
+    /* cfg.rd: bit 0 = RD mode decision; bits 1..5 = the sites of the RD refinement (x264's subme 8 = all five) — brought up on the device site by site */
+    a->mbrd = e->cfg.rd ? 1 + (e->cfg.cabac && a->subme >= 8 && (e->cfg.rd >> 1)) : 0; a->rd16x16 = COST_MAX; a->force_t8 = -1; a->cost8x8 = a->cost16x8 = a->cost8x16 = COST_MAX;
     for (int i = 0; i < 7; i++) a->satd_i16_dir[i] = a->satd_chroma_dir[i] = COST_MAX;
     for (int i = 0; i < 4; i++) for (int m = 0; m < 12; m++) a->satd_i8_dir[i][m] = COST_MAX;
     a->lambda2 = x264o_lambda2(a->qp);
@@ -2576,7 +2580,7 @@ static void macroblock_body(x264o_encoder *e, int mbx, int mby, actx *a)
         int i_cost = a->satd_i16, type = X264GPU_MB_I16x16;
         if (a->satd_i4 < i_cost) { i_cost = a->satd_i4; type = X264GPU_MB_I4x4; }
         if (a->satd_i8 < i_cost) { i_cost = a->satd_i8; type = X264GPU_MB_I8x8; }
-        if (a->mbrd >= 2) intra_rd_refine(a, type, mb, lv);
+        if (a->mbrd >= 2 && ((e->cfg.rd >> 1) & 30)) intra_rd_refine(a, type, mb, lv);
         if (a->mbrd) rd_reset(a, mb, lv);
         mb->cost = i_cost;
         e->b_trellis = e->cfg.cabac ? e->cfg.trellis & 63 : 0;          /* --trellis 1: the final encode only */
@@ -2689,8 +2693,8 @@ static void macroblock_body(x264o_encoder *e, int mbx, int mby, actx *a)
     if (a->satd_i8 < i_cost) { i_cost = a->satd_i8; i_type = X264GPU_MB_I8x8; }
     if (a->satd_i4 < i_cost) { i_cost = a->satd_i4; i_type = X264GPU_MB_I4x4; }
     if (a->mbrd >= 2) {
-        if (is_intra_type(i_type)) intra_rd_refine(a, i_type, mb, lv);
-        else i_partition = refine_inter_p_rd(a, i_partition, t8, i_cost, mb, lv);
+        if (is_intra_type(i_type)) { if ((e->cfg.rd >> 1) & 30) intra_rd_refine(a, i_type, mb, lv); }
+        else if ((e->cfg.rd >> 1) & 1) i_partition = refine_inter_p_rd(a, i_partition, t8, i_cost, mb, lv);
     }
     if (a->mbrd) { rd_reset(a, mb, lv); mb->aux[0] = aux0; mb->aux[1] = aux1; mb->aux[2] = aux2; }
     mb->cost = i_cost;

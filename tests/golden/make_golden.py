@@ -33,7 +33,7 @@ CASES = [("p176x144", 176, 144, 5, {}), ("p208x120_q30", 208, 120, 3, dict(qp_i=
          ("p176x144_rd_cavlc", 176, 144, 4, dict(refs=2, partitions=7, dct8x8=1, chroma_me=1, mixed_refs=1, rd=1, subme=7, psy=1, psy_rd_q8=256, chroma_qp_offset=-2)),
          ("p128x96_trellis2_umh", 128, 96, 4, dict(refs=2, partitions=7, dct8x8=1, chroma_me=1, mixed_refs=1, cabac=1, rd=1, subme=7, psy=1, psy_rd_q8=256,
                                                    chroma_qp_offset=-2, trellis=127, me_method=2)),
-         ("p176x144_subme8_rd_refine", 176, 144, 4, dict(refs=3, partitions=7, dct8x8=1, chroma_me=1, mixed_refs=1, cabac=1, rd=1, subme=8, psy=1, psy_rd_q8=256,
+         ("p176x144_subme8_rd_refine", 176, 144, 4, dict(refs=3, partitions=7, dct8x8=1, chroma_me=1, mixed_refs=1, cabac=1, rd=63, subme=8, psy=1, psy_rd_q8=256,
                                                         chroma_qp_offset=-2, trellis=127))]
 MEDIUM_B = dict(refs=3, dpb=4, weightb=1, partitions=7, dct8x8=1, chroma_me=1, mixed_refs=1, cabac=1, rd=1, subme=7, psy=1, psy_rd_q8=256, chroma_qp_offset=-2, trellis=63)
 # (name, w, h, display-order types, seed, weightp, config overrides): mini-GOPs through the product's DPB model (host/dpb.hpp) and oracle encode_pic

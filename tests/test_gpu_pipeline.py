@@ -217,6 +217,32 @@ def test_pipeline_cabac_rd_bitexact(gpu, w, h, nfr, kw):
     og.close(); gg.close()
 
 
+@pytest.mark.parametrize("w,h,nfr,kw", [
+    # RD refinement (x264 --subme 8, i_mbrd 2), site by site (cfg.rd = 1 | sites << 1): 1 the vectors of the P partitions (x264_me_refine_qpel_rd),
+    # 2 the Intra_16x16 mode, 4 the chroma mode, 8 the Intra_4x4 modes, 16 the Intra_8x8 modes (intra_rd_refine); 63 = x264's subme 8
+    (176, 144, 4, dict(partitions=0, rd=3)),                                                              # 16x16 only: whole-macroblock candidates
+    (176, 144, 4, dict(partitions=1, refs=2, rd=3)),                                                       # P8x8 / 16x8 / 8x16 parts, 4x4 transform
+    (176, 144, 4, dict(partitions=7, dct8x8=1, refs=3, mixed_refs=1, chroma_me=1, psy=1, psy_rd_q8=256, chroma_qp_offset=-2, rd=3)),
+    (208, 120, 4, dict(partitions=7, dct8x8=1, refs=2, qp_i=30, qp_p=34, me_method=2, rd=3, trellis=63)),
+    (176, 144, 4, dict(partitions=7, dct8x8=1, refs=2, mixed_refs=1, psy=1, psy_rd_q8=256, chroma_qp_offset=-2, rd=3, trellis=127)),       # trellis 2: the search in the part encodes too
+])
+def test_pipeline_rd_refinement_bitexact(gpu, w, h, nfr, kw):
+    """RD refinement on the device (REF instantiations of the macroblock loop, k_mb_refine.inc) against oracle/analyse.c's restatement of
+    x264_me_refine_qpel_rd / intra_rd_refine: records, levels, reconstruction and context variables"""
+    from gpu_enc import GpuEncoder
+    frames = synth_frames(w, h, nfr, seed=w * 5 + h)
+    cfg = O.default_config(w, h, cabac=1, subme=8, **kw)
+    og, gg = O.OracleEncoder(cfg), GpuEncoder(cfg)
+    for i, f in enumerate(frames):
+        st = 2 if i == 0 else 0
+        o_mb, o_lv = og.encode(f, st)
+        g_mb, g_lv = gg.encode([f], st)
+        compare(f"{w}x{h} {kw} frame {i}", (w + 15) // 16, g_mb[0], o_mb, g_lv[0], o_lv, gg.recon(0), og.recon())
+        used = CABAC_CTX_I if st == 2 else CABAC_CTX_P
+        np.testing.assert_array_equal(gg.cabac_states(0, 0)[used], og.cabac_states()[used], err_msg=f"context variables after picture {i}")
+    og.close(); gg.close()
+
+
 @pytest.mark.parametrize("kw", [dict(cabac=1, rd=1, subme=7, partitions=7, dct8x8=1, refs=2, mixed_refs=1, psy=1, psy_rd_q8=256, chroma_qp_offset=-2),
                                 dict(cabac=0, rd=1, subme=6, partitions=3, refs=2), dict(cabac=1, rd=1, subme=7, slices=2, partitions=7, dct8x8=1, aq_mode=1)])
 def test_pipeline_rd_multistream(gpu, kw):

@@ -469,7 +469,7 @@ def test_oracle_rd_refinement_streams_decode_and_pay_off(w, h, kw):
     mbw, mbh = (w + 15) // 16, (h + 15) // 16
     res = {}
     for sub in (7, 8):
-        cfg = O.default_config(w, h, cabac=1, subme=sub, **kw)
+        cfg = O.default_config(w, h, cabac=1, subme=sub, **dict(kw, rd=63 if sub == 8 else 1))
         enc = O.OracleEncoder(cfg)
         stream = HL.write_headers(w, h, pic_init_qp=cfg.qp_p, num_ref=cfg.refs, t8x8=cfg.dct8x8, cabac=1, cqo=cfg.chroma_qp_offset)
         recs, bits = [], 0

@@ -212,6 +212,14 @@ struct CabIn {
     bool bslice; int nref1; unsigned buse;
     int b_r0, b_x0, b_y0, b_r1, b_x1, b_y1;
     unsigned long long lamvd1, tamvd1;
+    // RD refinement (x264 subme >= 8): the size of a PART of the macroblock (encoder/rdo.c partition_size_cabac, partition_i4x4 / _i8x8_size_cabac,
+    // chroma_size_cabac) instead of the macroblock layer.  pm: 0 = the macroblock; 1 = inter part (P_L0 16x8 / 8x16 half, P_8x8 block): its mvd
+    // (pm_dx, pm_dy against neighbours' |mvd| sums pm_sx, pm_sy), sub_mb_type for P_8x8, luma + chroma AC of its 8x8 blocks pm_b0 [, pm_b1];
+    // 2 = Intra_4x4 block pm_b0: mode + block; 3 = Intra_8x8 block pm_b0: mode + the four cbp_luma bits + block; 4 = chroma of an intra
+    // macroblock: mode + cbp_chroma + DC + AC.  Inside the macroblock the coded_block_flag neighbours read pm_nnzc — what x264's non_zero_count
+    // cache holds, i.e. what the LAST encode of any kind left there (24 flags: luma blocks, chroma AC plane * 4 + block)
+    int pm, pm_b0, pm_b1, pm_dx, pm_dy, pm_sx, pm_sy;
+    unsigned pm_nnzc;
 };
 
 // mb_type of a B slice (Table 9-37 b): bin strings, first bin in bit 0
@@ -261,6 +269,8 @@ __device__ __forceinline__ unsigned long long cab_mb(Cab &cb, uint32_t model, in
     unsigned long long amvd = 0;
     dqp_out = 0;
     const bool lavail = in.left, tavail = in.top;
+    const bool intra = in.type < X264GPU_MB_P_L0;
+    if (!in.pm) {
     if (in.bslice && !in.size) {
         cab_bin(cb, model, lane, 24 + (lavail && !cab_is_skip(in.ltype)) + (tavail && !cab_is_skip(in.ttype)), in.type == X264GPU_MB_B_SKIP);
         if (in.type == X264GPU_MB_B_SKIP) return 0;
@@ -269,7 +279,6 @@ __device__ __forceinline__ unsigned long long cab_mb(Cab &cb, uint32_t model, in
         cab_bin(cb, model, lane, 11 + (lavail && in.ltype != X264GPU_MB_P_SKIP) + (tavail && in.ttype != X264GPU_MB_P_SKIP), in.type == X264GPU_MB_P_SKIP);
         if (in.type == X264GPU_MB_P_SKIP) return 0;
     }
-    const bool intra = in.type < X264GPU_MB_P_L0;
     if (in.bslice) {
         // mb_type: Table 7-14 value -> bins; contexts 27 + {0..2} (neighbours that are neither B_Skip nor B_Direct_16x16), 27 + 3, 27 + 5 - b1, 27 + 5 ...
         const int ctx0 = (lavail && in.ltype != X264GPU_MB_B_SKIP && in.ltype != X264GPU_MB_B_DIRECT) + (tavail && in.ttype != X264GPU_MB_B_SKIP && in.ttype != X264GPU_MB_B_DIRECT);
@@ -296,11 +305,17 @@ __device__ __forceinline__ unsigned long long cab_mb(Cab &cb, uint32_t model, in
         if (in.part == D_16x16) { cab_bin(cb, model, lane, 15, 0); cab_bin(cb, model, lane, 16, 0); }
         else { cab_bin(cb, model, lane, 15, 1); cab_bin(cb, model, lane, 17, in.part == D_16x8); }
     }
+    }      // !in.pm
     const int t8ctx = 399 + (lavail && in.lt8) + (tavail && in.tt8);
-    if (intra) {
-        if (in.type != X264GPU_MB_I16x16) {
+    if (in.pm == 1) {
+        // partition_size_cabac of a P part: its vector difference, the sub-macroblock type of a P_8x8 block
+        cab_mvd(cb, model, lane, 40, in.pm_sx, in.pm_dx);
+        cab_mvd(cb, model, lane, 47, in.pm_sy, in.pm_dy);
+        if (in.part == D_8x8) cab_bin(cb, model, lane, 21, 1);
+    } else if (intra) {
+        if (in.type != X264GPU_MB_I16x16 && (!in.pm || in.pm == 2 || in.pm == 3)) {
             const bool i8 = in.type == X264GPU_MB_I8x8;
-            if (in.t8mode) cab_bin(cb, model, lane, t8ctx, i8);
+            if (in.t8mode && !in.pm) cab_bin(cb, model, lane, t8ctx, i8);
             // every lane its block's mode and predicted mode; the bins go out block by block
             int mode = 0, pm = 0;
             if (lane < 16) { const uint8_t *cur = i8 ? modes8 : modes4; mode = cur[lane]; pm = i4_pred_mode(nmodes, mbx, sy, lane, cur); }
@@ -309,6 +324,7 @@ __device__ __forceinline__ unsigned long long cab_mb(Cab &cb, uint32_t model, in
             const uint32_t w68 = __builtin_amdgcn_readlane(cb.a, 68 >> 2);
             int stp = lane == 0 ? (int)(w68 & 255) : (int)((w68 >> 8) & 255);
             for (int b = 0; b < 16; b += i8 ? 4 : 1) {
+                if (in.pm && b != (i8 ? 4 * in.pm_b0 : in.pm_b0)) continue;
                 int m = __builtin_amdgcn_readlane(mode, b);
                 const int p = __builtin_amdgcn_readlane(pm, b);
                 const bool same = m == p;
@@ -321,9 +337,11 @@ __device__ __forceinline__ unsigned long long cab_mb(Cab &cb, uint32_t model, in
                 cb.a = lane == (68 >> 2) ? (cb.a & ~0xffffu) | s68 | (s69 << 8) : cb.a;
             }
         }
+        if (!in.pm || in.pm == 4) {
         const int ctx = (lavail && in.ltype < X264GPU_MB_P_L0 && in.lcmode != 0) + (tavail && in.ttype < X264GPU_MB_P_L0 && in.tcmode != 0);
         if (!in.cmode) cab_bin(cb, model, lane, 64 + ctx, 0);
         else { cab_bin(cb, model, lane, 64 + ctx, 1); cab_bin(cb, model, lane, 64 + 3, in.cmode > 1); if (in.cmode > 1) cab_bin(cb, model, lane, 64 + 3, in.cmode > 2); }
+        }
     } else if (in.bslice) {
         // ---- B: sub_mb_type, then every list-0 reference index, every list-1 one, list 0's vector differences, list 1's (7.3.5.1 / 7.3.5.2) ----
         if (in.type != X264GPU_MB_B_DIRECT) {
@@ -427,22 +445,24 @@ __device__ __forceinline__ unsigned long long cab_mb(Cab &cb, uint32_t model, in
         }
         S.cref = sc0; S.cmvx = sc1; S.cmvy = sc2;
     }
-    if (in.type != X264GPU_MB_I16x16) {
+    if (in.pm ? in.pm == 3 : in.type != X264GPU_MB_I16x16)
         for (int b8 = 0; b8 < 4; b8++) {
             const int x = b8 & 1, y = b8 >> 1;
             const int a = x ? !((in.cbp_luma >> (b8 - 1)) & 1) : lavail ? !((in.lcbp_luma >> (b8 + 1)) & 1) : 0;
             const int b = y ? !((in.cbp_luma >> (b8 - 2)) & 1) : tavail ? !((in.tcbp_luma >> (b8 + 2)) & 1) : 0;
             cab_bin(cb, model, lane, 73 + a + 2 * b, (in.cbp_luma >> b8) & 1);
         }
+    if (in.pm ? in.pm == 4 : in.type != X264GPU_MB_I16x16) {
         cab_bin(cb, model, lane, 77 + (lavail && in.lcbp_chroma) + 2 * (tavail && in.tcbp_chroma), in.cbp_chroma != 0);
         if (in.cbp_chroma) cab_bin(cb, model, lane, 77 + 4 + (lavail && in.lcbp_chroma == 2) + 2 * (tavail && in.tcbp_chroma == 2), in.cbp_chroma == 2);
     }
-    if (!intra && in.t8mode && in.cbp_luma) cab_bin(cb, model, lane, t8ctx, in.t8);
-    if (in.cbp_luma || in.cbp_chroma || in.type == X264GPU_MB_I16x16) {
-        const bool i16 = in.type == X264GPU_MB_I16x16;
+    if (!in.pm && !intra && in.t8mode && in.cbp_luma) cab_bin(cb, model, lane, t8ctx, in.t8);
+    if (in.pm || in.cbp_luma || in.cbp_chroma || in.type == X264GPU_MB_I16x16) {
+        const bool i16 = !in.pm && in.type == X264GPU_MB_I16x16;
         int dqp = in.qp - in.last_qp;
         // an I16x16 with nothing coded, DC included, never raises the quantiser (x264's qp_delta writers): it is sent as "no change"
         if (i16 && !in.cbp_luma && !in.cbp_chroma && !((in.nnz >> 24) & 1) && dqp > 0) dqp = 0;
+        if (!in.pm) {
         int ctx = in.last_dqp != 0;
         if (dqp) {
             if (dqp < -26) dqp += 52; else if (dqp > 25) dqp -= 52;
@@ -451,12 +471,14 @@ __device__ __forceinline__ unsigned long long cab_mb(Cab &cb, uint32_t model, in
         }
         cab_bin(cb, model, lane, 60 + ctx, 0);
         dqp_out = dqp;
+        }
         const int un = intra ? 1 : 0;
         // neighbour terms of the coded_block_flag contexts
+        auto luma_in = [&](int bx, int by) { return in.pm ? (int)((in.pm_nnzc >> blkidx_of(bx, by)) & 1) : cab_luma_cbf_of(in.type, in.cbp_luma, in.t8, in.nnz, bx, by); };
         auto luma_inc = [&](int blk) {
             const int bx = z_bx(blk), by = z_by(blk);
-            const int a = bx > 0 ? cab_luma_cbf_of(in.type, in.cbp_luma, in.t8, in.nnz, bx - 1, by) : lavail ? cab_luma_cbf_of(in.ltype, in.lcbp_luma, in.lt8, in.lnnz, 3, by) : un;
-            const int b = by > 0 ? cab_luma_cbf_of(in.type, in.cbp_luma, in.t8, in.nnz, bx, by - 1) : tavail ? cab_luma_cbf_of(in.ttype, in.tcbp_luma, in.tt8, in.tnnz, bx, 3) : un;
+            const int a = bx > 0 ? luma_in(bx - 1, by) : lavail ? cab_luma_cbf_of(in.ltype, in.lcbp_luma, in.lt8, in.lnnz, 3, by) : un;
+            const int b = by > 0 ? luma_in(bx, by - 1) : tavail ? cab_luma_cbf_of(in.ttype, in.tcbp_luma, in.tt8, in.tnnz, bx, 3) : un;
             return a + 2 * b;
         };
         auto dc_inc = [&](int bit) {
@@ -471,8 +493,9 @@ __device__ __forceinline__ unsigned long long cab_mb(Cab &cb, uint32_t model, in
         auto ac_inc = [&](int pl, int i) {
             const int bx = i & 1, by = i >> 1;
             auto of = [&](int type, int cbp_chroma, unsigned nnz, int x, int y) { return !cab_is_skip(type) && cbp_chroma == 2 ? (int)((nnz >> (16 + pl * 4 + y * 2 + x)) & 1) : 0; };
-            const int a = bx > 0 ? of(in.type, in.cbp_chroma, in.nnz, 0, by) : lavail ? of(in.ltype, in.lcbp_chroma, in.lnnz, 1, by) : un;
-            const int b = by > 0 ? of(in.type, in.cbp_chroma, in.nnz, bx, 0) : tavail ? of(in.ttype, in.tcbp_chroma, in.tnnz, bx, 1) : un;
+            auto inside = [&](int x, int y) { return in.pm ? (int)((in.pm_nnzc >> (16 + pl * 4 + y * 2 + x)) & 1) : of(in.type, in.cbp_chroma, in.nnz, x, y); };
+            const int a = bx > 0 ? inside(0, by) : lavail ? of(in.ltype, in.lcbp_chroma, in.lnnz, 1, by) : un;
+            const int b = by > 0 ? inside(bx, 0) : tavail ? of(in.ttype, in.tcbp_chroma, in.tnnz, bx, 1) : un;
             return a + 2 * b;
         };
         // residual: the category's context variables are this lane's byte of r (r8 for 8x8 blocks) for the duration of its blocks
@@ -527,16 +550,28 @@ __device__ __forceinline__ unsigned long long cab_mb(Cab &cb, uint32_t model, in
         if (i16) {
             blocks(std::integral_constant<int, 0>{}, 24, 1, [&](int) { return lane < 16 ? (int)lvs[X264GPU_LV_LUMA_DC + lane] : 0; }, [&](int) { return dc_inc(24); }, always);
             if (in.cbp_luma) blocks_many(std::integral_constant<int, 1>{}, 8, 16, 0xffffu, in.nnz & 0xffffu, [&](int b) { return lane < 15 ? (int)lvs[b * 16 + 1 + lane] : 0; }, luma_inc);
+        } else if (in.pm == 4) {
         } else if (in.t8) {
+            // (part mode: only the part's 8x8 blocks — pm_b1 < 0: one block)
+            const int pmask = in.pm ? (1 << in.pm_b0) | (in.pm_b1 >= 0 ? 1 << in.pm_b1 : 0) : 15;
             int st = cb.r8 & 255;
             for (int i8 = 0; i8 < 4; i8++)
-                if ((in.cbp_luma >> i8) & 1) cab_block8(cb, st, model, lane, (int)lvs[(i8 * 4 + (lane & 3)) * 16 + (lane >> 2)], in.size);
+                if (((in.cbp_luma & pmask) >> i8) & 1) cab_block8(cb, st, model, lane, (int)lvs[(i8 * 4 + (lane & 3)) * 16 + (lane >> 2)], in.size);
             cb.r8 = (uint32_t)st;
         } else {
-            const unsigned coded = ((in.cbp_luma & 1) ? 0x000fu : 0) | ((in.cbp_luma & 2) ? 0x00f0u : 0) | ((in.cbp_luma & 4) ? 0x0f00u : 0) | ((in.cbp_luma & 8) ? 0xf000u : 0);
+            unsigned coded = ((in.cbp_luma & 1) ? 0x000fu : 0) | ((in.cbp_luma & 2) ? 0x00f0u : 0) | ((in.cbp_luma & 4) ? 0x0f00u : 0) | ((in.cbp_luma & 8) ? 0xf000u : 0);
+            if (in.pm == 1) coded &= (0xfu << (4 * in.pm_b0)) | (in.pm_b1 >= 0 ? 0xfu << (4 * in.pm_b1) : 0u);
+            if (in.pm == 2) coded = 1u << in.pm_b0;          // an Intra_4x4 block always sends its coded_block_flag
             blocks_many(std::integral_constant<int, 2>{}, 0, 16, coded, in.nnz & 0xffffu, [&](int b) { return lane < 16 ? (int)lvs[b * 16 + lane] : 0; }, luma_inc);
         }
-        if (in.cbp_chroma) {
+        if (in.pm == 1) {
+            // the chroma AC blocks under the part's 8x8 blocks, block by block (U then V of the first, then of the second)
+            for (int t = 0; t < 2; t++) {
+                const int b8 = t ? in.pm_b1 : in.pm_b0;
+                if (b8 < 0) continue;
+                blocks_many(std::integral_constant<int, 4>{}, 16, 8, (1u << b8) | (16u << b8), (in.nnz >> 16) & 0xffu, [&](int k) { return lane < 15 ? (int)lvs[X264GPU_LV_CHROMA_AC + k * 16 + 1 + lane] : 0; }, [&](int k) { return ac_inc((k >> 2) & 1, k & 3); });
+            }
+        } else if (in.cbp_chroma && (!in.pm || in.pm == 4)) {
             blocks(std::integral_constant<int, 3>{}, 24, 2, [&](int pl) { return lane < 4 ? (int)lvs[X264GPU_LV_CHROMA_DC + pl * 4 + lane] : 0; }, [&](int pl) { return dc_inc(25 + pl); }, always);
             if (in.cbp_chroma == 2)
                 blocks_many(std::integral_constant<int, 4>{}, 16, 8, 0xffu, (in.nnz >> 16) & 0xffu, [&](int k) { return lane < 15 ? (int)lvs[X264GPU_LV_CHROMA_AC + k * 16 + 1 + lane] : 0; }, [&](int k) { return ac_inc((k >> 2) & 1, k & 3); });

@@ -778,7 +778,7 @@ __device__ __forceinline__ int i4_pred_mode(const uint8_t *nm, int mbx, int mby,
 // directional modes near the favoured direction; list order and "first strictly better" decide ties).  raw(m) = cost of mode m (the
 // caller fetches it from the lanes that computed it).  Returns the cost incl. the predicted-mode bonus; lists are nibble strings, 15 ends one.
 template <class F>
-__device__ __forceinline__ int pick_intra_mode(F raw, int avail, int pm, int lambda, bool is4, bool every_mode, int &bestm)
+__device__ __forceinline__ int pick_intra_mode(F raw, int avail, int pm, int lambda, bool is4, bool every_mode, int &bestm, bool no_stop = false)
 {
     const int all3 = AVAIL_LEFT | AVAIL_TOP | AVAIL_TOPLEFT;
     const int id = (avail & all3) == all3 ? 4 : avail & (AVAIL_LEFT | AVAIL_TOP);
@@ -804,7 +804,7 @@ __device__ __forceinline__ int pick_intra_mode(F raw, int avail, int pm, int lam
                 if (cst < best) { best = cst; bestm = m; }
             }
     } else {
-        for (; (rest & 15) != 15 && best >= 0; rest >>= 4) {
+        for (; (rest & 15) != 15 && (best >= 0 || no_stop); rest >>= 4) {          // (no_stop: x264's i_mbrd >= 2 wants every 8x8 mode's cost for the refinement)
             const int m = (int)(rest & 15);
             const int cst = raw(m) - (pm == m ? 3 * lambda : 0);
             if (cst < best) { best = cst; bestm = m; }
@@ -952,7 +952,8 @@ template <int M>
 __device__ __forceinline__ void mb_analyse_intra(const EncK &k, MbLds<M> &L, const MbCtx &c, uint32_t cz, uint32_t t4, int parts, int i_satd_inter,
                                                  bool fast_intra, bool early_term, bool mbrd, const Q4 &q4, const Q8 &q8, IntraRes &R, const TrCtx *tra = nullptr)
 {
-    const bool every_mode = mbrd && !fast_intra;          // x264: i_mbrd >= 1 + b_fast_intra
+    const bool RF2 = mbrd && k.rd > 1;             // x264's i_mbrd >= 2 (RD refinement, subme >= 8)
+    const bool every_mode = RF2 || (mbrd && !fast_intra);          // x264: i_mbrd >= 1 + b_fast_intra
     const int lane = c.lane, j = lane & 3, zx = z_x0(lane), zy = z_y(lane), lambda = c.lambda;
     const bool left = c.mbx > 0, top = c.sy > 0, topright = top && c.mbx + 1 < k.mbw;
     const int sm = min(c.subme, 10);
@@ -1007,7 +1008,7 @@ __device__ __forceinline__ void mb_analyse_intra(const EncK &k, MbLds<M> &L, con
             pred8_row8(L.U8, L.pred8tab, 8, r8, p2lo, p2hi);
             const int c2 = cost8(p2lo, p2hi);
             int bm;
-            const int best = pick_intra_mode([&](int m) { return m < 8 ? rl(c1, m * 8) : rl(c2, 0); }, avail, pm, lambda, false, every_mode, bm);
+            const int best = pick_intra_mode([&](int m) { return m < 8 ? rl(c1, m * 8) : rl(c2, 0); }, avail, pm, lambda, false, every_mode, bm, RF2);
             i_cost += best + 3 * lambda;
             if (lane < 4) L.modes8[idx * 4 + lane] = (uint8_t)bm;
             if (idx < 3 && i_cost > thresh) break;
@@ -1393,7 +1394,8 @@ __device__ __forceinline__ void b_predict(const EncK &k, const MbCtx &c, const B
 #endif
 // RD: 0 = SATD decisions (subme <= 5); 1 = RD mode decision with CAVLC bit counts (rd.cuh); 2 = with CABAC context states and sizes (cabac_rd.cuh);
 // 3 = 2 + the trellis quantiser in the final encode (trellis.cuh) — an instantiation of its own: the search's registers would cost the others spills;
-// 4 = 3 + the search in the intra analysis' block encodes and in every RD candidate (x264 --trellis 2)
+// 4 = 3 + the search in the intra analysis' block encodes and in every RD candidate (x264 --trellis 2);
+// 5 / 6 = 3 / 4 + RD refinement of the chosen type's vectors and intra modes (x264 subme >= 8: k_mb_refine.inc)
 // BS: B slice (PS is set as well: an inter slice) — RD instantiations with CABAC only; its own analysis and candidate order (k_mb_b.inc)
 template <int M, int ME, bool PS, int RD = 0, bool BS = false>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(MB_WAVES_PER_EU, 4))) void k_mb_slice(EncK k)
@@ -1424,7 +1426,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(MB_WAVES_PER
     x264gpu_mb *mbs = k.mb + (size_t)s * k.nmb;
     constexpr bool pslice = PS;
     constexpr bool TRL = RD >= 3;               // trellis sites compiled in
-    constexpr bool TRL2 = RD == 4;              // --trellis 2: the search also inside the intra analysis and in every RD candidate                 // I slices run their own instantiation (no search code, a fraction of the registers)
+    constexpr bool TRL2 = RD == 4 || RD == 6;   // --trellis 2: the search also inside the intra analysis and in every RD candidate                 // I slices run their own instantiation (no search code, a fraction of the registers)
+    constexpr bool REF = RD >= 5;               // RD refinement of the chosen type (x264 subme >= 8, i_mbrd 2; k_mb_refine.inc): RD 5 = 3 + refinement, 6 = 4 + refinement
     const int j4 = lane & 3, zx = z_x0(lane), zy = z_y(lane);
     int intra_count = intra_prior, cost_qp = -1;          // intra macroblocks so far: of the slice (slice threads), of the picture (--slices N)
     // RD instantiation: levels of the candidate being costed (and of the final macroblock, before they go out), total_coeff of the left / top
@@ -1459,7 +1462,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(MB_WAVES_PER
         if (k.qp_snap && abs(c.qp - last_qp) == 1) c.qp = last_qp;      // x264_macroblock_analyse under AQ: within 1 of the previous macroblock's quantiser = that quantiser
         c.qpc = (int)d_chroma_qp_table[min(max(c.qp + k.chroma_qp_offset, 0), 51)];
         c.lambda = k.lambda_tab[c.qp];
-        c.subme = min(max(k.subme, 0), 11); c.satd = c.subme > 1; c.chroma_me = !BS && pslice && k.chroma_me && c.subme >= 5;      // (x264_macroblock_thread_init: B slices carry chroma in the sub-pel costs from subme 9 up only: never here)
+        c.subme = min(max(k.subme, 0), 11);
+        if (BS && (c.subme == 6 || c.subme == 8)) c.subme--;          // x264_macroblock_thread_init: B slices analyse one sub-pel level down (8 -> 7: no RD refinement there below subme 9)
+        c.satd = c.subme > 1; c.chroma_me = !BS && pslice && k.chroma_me && c.subme >= 5;      // (x264_macroblock_thread_init: B slices carry chroma in the sub-pel costs from subme 9 up only: never here)
         c.cost_base = k.cost_all + (size_t)c.qp * 2 * MVCOST_HALF;
         if (pslice && c.qp != cost_qp) {          // the mv-cost table of this quantiser (symmetric: non-negative differences only) into LDS
             cost_qp = c.qp;
@@ -1850,7 +1855,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(MB_WAVES_PER
             // otherwise only for macroblocks that end up intra — same mode either way); its cost enters the comparison under chroma-ME only
             TrCtx tra_ctx;                   // --trellis 2: the analysis' block encodes run the search too
             tra_ctx.on = 0; tra_ctx.r = 0; tra_ctx.r8 = 0; tra_ctx.model = 0; tra_ctx.tt.size_unary = nullptr; tra_ctx.tt.trans_unary = nullptr; tra_ctx.tt.lambda2 = nullptr;
-            if constexpr (RD == 4) {
+            if constexpr (TRL2) {
                 if ((k.trellis & 64) && RD && k.rd) { tra_ctx.on = k.trellis & 63; tra_ctx.r = cab.r; tra_ctx.r8 = cab.r8; tra_ctx.model = cab_modelv; tra_ctx.tt.size_unary = k.tr_su; tra_ctx.tt.trans_unary = k.tr_tu; tra_ctx.tt.lambda2 = k.tr_l2; }
             }
             satd_chroma = mb_intra_chroma_cost(k, L, c, predc);
@@ -1908,6 +1913,15 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(MB_WAVES_PER
         uint32_t b_cenc = 0;             // this lane's chroma source row (lanes 0..31: plane (lane >> 4) & 1, 4x4 block (lane >> 2) & 3, row lane & 3)
         WinTags wt;
         wt.tref = -1; wt.tx = wt.ty = 0;
+        // RD refinement (REF instantiations): the coroutine's state (k_mb_refine.inc) — what is being refined, where its walk stands, the candidate
+        // out for costing, x264's left-over caches (non_zero_count of this macroblock as the last encode left it, |mvd| of the parts done)
+        int rf_kind = 0, rf_pk = 0, rf_st = 0, rf_part = 0, rf_j = 0, rf_i = 0, rf_wait = 0;
+        int rf_bmx = 0, rf_bmy = 0, rf_omx = 0, rf_omy = 0, rf_pmx = 0, rf_pmy = 0, rf_dir = -2, rf_odir = 0, rf_bsatd = 0, rf_pmvchk = 0;
+        int rf_cx = 0, rf_cy = 0, rf_cdir = -99, rf_mvpx = 0, rf_mvpy = 0, rf_mv0x = 0, rf_mv0y = 0, rf_f4 = 0, rf_f8 = 0;
+        int rf_lmx = 0, rf_lmy = 0, rf_priced = 0, rf_done = 0, rf_ref = 0, rf_slot = 0, rf_pm8 = 0, rf_b0 = 0, rf_b1 = -1;
+        unsigned long long rf_bcost = 0, rf_cost = 0, rf_amvd = 0;
+        unsigned rf_nnzc = 0;
+        uint32_t rf_pred = 0;
         if constexpr (BS) {
             rd_run = true; commit = false;
             const int ci_ = (lane >> 2) & 3;
@@ -1941,7 +1955,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(MB_WAVES_PER
                         go = IR.satd_i16 < rd_ithresh; e_type = X264GPU_MB_I16x16;
                     } else if (rd_ph == 6) { go = IR.satd_i4 < rd_ithresh; e_type = X264GPU_MB_I4x4; }
                     else if (rd_ph == 7) { go = IR.satd_i8 < rd_ithresh; e_type = X264GPU_MB_I8x8; }
-                    else {
+                    else if (rd_ph == 8) {
                         // the decision on RD costs, then the real pass
                         int best = pslice ? rd_best : MB_COST_MAX;
                         e_type = rd_part == D_8x8 ? X264GPU_MB_P_8x8 : X264GPU_MB_P_L0; e_part = rd_part; e_t8 = rd_t8;
@@ -1962,6 +1976,21 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(MB_WAVES_PER
                         }
                         if (lane == 0) recd.cost = i_cost;
                         commit = true; go = true;
+                        if constexpr (REF) {
+                            // x264_macroblock_analyse: "if( analysis.i_mbrd >= 2 )" — the chosen type's vectors / intra modes once more on RD cost
+                            const int sites = k.rd >> 1;          // 1 inter vectors, 2 Intra_16x16 mode, 4 chroma mode, 8 Intra_4x4 modes, 16 Intra_8x8 modes
+                            const bool inter_w = e_type >= X264GPU_MB_P_L0;
+                            if (sites && !rd_skip16 && (inter_w ? (sites & 1) != 0 : (sites & 30) != 0)) {
+                                commit = false; go = false; rd_ph = 9;
+                                rf_kind = inter_w ? 0 : 1; rf_st = 0; rf_part = 0; rf_wait = 0; rf_done = 0; rf_amvd = 0; rf_pk = 0;
+                                if (lane == 5 || lane == 6 || lane == 9 || lane == 10) S.cref = -2;      // the motion cache of this macroblock's blocks starts empty
+                            }
+                        }
+                    }
+                    if constexpr (REF) {
+                        if (rd_ph == 9 && !commit) {
+#include "k_mb_refine.inc"
+                        }
                     }
                     if (go) break;
                 }
@@ -1977,6 +2006,170 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(MB_WAVES_PER
         rec_type = e_type;
         int16_t *lvw = RD ? (int16_t *)rd_lvs : lv;               // RD: levels stay on chip until the final pass has its bit counts' totals
         int ssd_y = 0, ssd_c = 0, en4 = 0, en8 = 0;          // per-lane shares of the distortion terms of the candidate
+        bool part_pass = false;
+        if constexpr (REF) part_pass = rf_pk != 0 && !commit;
+        if (part_pass) {
+            if constexpr (REF) {
+            if (rf_pk == 1) {
+                // ---- x264_rd_cost_part of an inter part: x264_macroblock_encode_p8x8 of its 8x8 blocks with the prediction as COST_MV_SATD left it
+                //      (rf_pred) — luma with the macroblock's transform size, per-8x8 decimation only, the chroma 4x4 block under each 8x8 without its DC ----
+                const unsigned pm8 = (unsigned)rf_pm8;
+                const bool t8 = e_t8 != 0;
+                const uint32_t pred = rf_pred;
+                rd_t8cur = t8;
+                if (t8) {
+                    uint32_t elo, ehi, plo, phi;
+                    z_to_r8(cz, lane, elo, ehi); z_to_r8(pred, lane, plo, phi);
+                    const int row = lane & 7, i8 = (lane >> 3) & 3;
+                    int e[8], p[8], v[8];
+                    unpack8(elo, ehi, e); unpack8(plo, phi, p);
+#pragma unroll
+                    for (int i = 0; i < 8; i++) v[i] = e[i] - p[i];
+                    fwd8_1d(v); transpose8(v, lane); fwd8_1d(v); transpose8(v, lane);
+                    int mf[4], bs[4], dq[4];
+                    q8_row(q8p, row, mf, bs, dq);
+                    unsigned mlo = 0, mhi = 0, big = 0;
+                    const bool tr8 = TRL2 && (trc.on & TR_P8) != 0;
+                    if (tr8) {
+                        if (lane < 32)
+#pragma unroll
+                            for (int i = 0; i < 8; i++) lvw[i8 * 64 + c_zigzag8_inv[row * 8 + i]] = (int16_t)v[i];
+                        lds_sync();
+                        trellis_run<5>(trc, lvw, 64, 4, c.qp, false, lane);
+                        lds_sync();
+#pragma unroll
+                        for (int i = 0; i < 8; i++) v[i] = lvw[i8 * 64 + c_zigzag8_inv[row * 8 + i]];
+                        lds_sync();
+                    }
+#pragma unroll
+                    for (int i = 0; i < 8; i++) {
+                        if (!tr8) v[i] = quant_one(v[i], mf[i & 3], bs[i & 3]);
+                        const int z = c_zigzag8_inv[row * 8 + i];
+                        if (v[i]) { if (z < 32) mlo |= 1u << z; else mhi |= 1u << (z - 32); }
+                        big |= abs(v[i]) > 1 ? 1u : 0u;
+                    }
+                    mlo = group8_or(mlo); mhi = group8_or(mhi); big = group8_or(big);
+                    const unsigned long long mask = ((unsigned long long)mhi << 32) | mlo;
+                    bool keep = mask != 0;
+                    if (k.dct_decimate && !tr8) keep = keep && (big || decimate64_from_mask(mask) >= 4);
+                    const bool inp = lane < 32 && ((pm8 >> i8) & 1);
+                    if (inp) {
+#pragma unroll
+                        for (int i = 0; i < 8; i++) {
+                            const int z = c_zigzag8_inv[row * 8 + i];
+                            lvw[(i8 * 4 + (z & 3)) * 16 + (z >> 2)] = (int16_t)(keep ? v[i] : 0);
+                        }
+                    }
+                    unsigned n4 = 0;
+#pragma unroll
+                    for (int q = 0; q < 4; q++) n4 |= (mask & (0x1111111111111111ull << q)) ? 1u << q : 0u;
+                    if (!keep) n4 = 0;
+#pragma unroll
+                    for (int g = 0; g < 4; g++) {
+                        const unsigned ng = (pm8 >> g) & 1 ? (unsigned)__builtin_amdgcn_readlane((int)n4, g * 8) : 0u;
+                        nnz |= ng << (4 * g);
+                        cbp_luma |= ng ? 1 << g : 0;
+                    }
+                    const int qb = q8p.qp / 6 - 6;
+#pragma unroll
+                    for (int i = 0; i < 8; i++) v[i] = keep ? dequant_one(v[i], dq[i & 3], qb) : 0;
+                    inv8_1d(v); transpose8(v, lane); inv8_1d(v); transpose8(v, lane);
+#pragma unroll
+                    for (int i = 0; i < 8; i++) v[i] = ((v[i] + 32) >> 6) + p[i];
+                    uint2 o;
+                    o.x = pack4_clip8lo(v); o.y = pack4_clip8hi(v);
+                    int e4 = 0, e8 = 0;
+                    psy_energy_r8(o.x, o.y, lane, e4, e8);
+                    if (inp) { ssd_y = ssd4_u8(elo, o.x) + ssd4_u8(ehi, o.y); en4 = e4; en8 = e8; }
+                } else {
+                    int e[4], p[4], v[4];
+                    unpack4(cz, e); unpack4(pred, p);
+#pragma unroll
+                    for (int i = 0; i < 4; i++) v[i] = e[i] - p[i];
+                    dct4_quad(v, lane);
+                    if (TRL2 && (trc.on & TR_P4)) {
+                        store_levels_scan(lvw + (lane >> 2) * 16, v, j4);
+                        lds_sync();
+                        trellis_run<2>(trc, lvw, 16, 16, c.qp, false, lane);
+                        lds_sync();
+                        load_levels_scan(lvw + (lane >> 2) * 16, v, j4);
+                        lds_sync();
+                    } else quant4_row(v, q_lp, j4);
+                    const unsigned mask = (unsigned)quad_or((int)scan_mask(v, j4));
+                    const bool nz = mask != 0;
+                    bool keep = nz;
+                    if (k.dct_decimate) {
+                        const int big = quad_or(any_big(v) ? 1 : 0);
+                        const int sc = nz ? (big ? 9 : decimate_from_mask(mask, 0)) : 0;
+                        const int score8 = row16_sum(j4 == 0 ? sc : 0);
+                        keep = nz && score8 >= 4;
+                    }
+                    const bool inp = ((pm8 >> (lane >> 4)) & 1) != 0;
+                    if (inp) { int z[4] = { 0, 0, 0, 0 }; store_levels_scan(lvw + (lane >> 2) * 16, keep ? v : z, j4); }
+                    if (!keep) v[0] = v[1] = v[2] = v[3] = 0;
+                    dequant4_row(v, q_lp, j4);
+                    idct4_quad(v, lane);
+#pragma unroll
+                    for (int i = 0; i < 4; i++) v[i] += p[i];
+                    const uint32_t rz = pack4_clip(v);
+                    int e4 = 0, e8 = 0;
+                    psy_energy_z(rz, lane, e4, e8);
+                    if (inp) { ssd_y = ssd4_u8(cz, rz); en4 = e4; }
+                    if (lane < 32 && ((pm8 >> (lane >> 3)) & 1)) en8 = e8;
+                    const unsigned long long bal = __ballot(keep && inp && j4 == 0);
+#pragma unroll
+                    for (int b = 0; b < 16; b++) nnz |= (unsigned)((bal >> (4 * b)) & 1) << b;
+#pragma unroll
+                    for (int i8 = 0; i8 < 4; i8++) cbp_luma |= ((nnz >> (4 * i8)) & 15) ? 1 << i8 : 0;
+                }
+                {
+                    // chroma: prediction at the candidate vector, the 4x4 block under each of the part's 8x8 blocks, AC only
+                    const int pl = (lane >> 4) & 1, ci = (lane >> 2) & 3, cx0 = (ci & 1) * 4, cyy = (ci >> 1) * 4 + j4;
+                    const bool act = lane < 32 && ((pm8 >> ci) & 1);
+                    uint32_t pu, pv;
+                    mc_chroma_row4(ref_chroma00(k, s, rf_ref), k.rs, mbx * 8 + cx0, mby * 8 + cyy, rf_cx, rf_cy, pu, pv);
+                    const uint32_t cpred = pl ? pv : pu;
+                    const uint2 fe = *(const uint2 *)(L.csrc + cyy * 16 + 2 * cx0);
+                    const uint32_t cenc = nv12_pick(fe.x, fe.y, pl);
+                    int e[4], p[4], v[4];
+                    unpack4(cenc, e); unpack4(cpred, p);
+#pragma unroll
+                    for (int t = 0; t < 4; t++) v[t] = act ? e[t] - p[t] : 0;
+                    dct4_quad(v, lane);
+                    if (j4 == 0) v[0] = 0;
+                    int16_t *l = lvw + X264GPU_LV_CHROMA_AC + (pl * 4 + ci) * 16;
+                    if (TRL2 && (trc.on & TR_C)) {
+                        if (lane < 32) store_levels_scan(l, v, j4);
+                        lds_sync();
+                        trellis_run<4>(trc, lvw + X264GPU_LV_CHROMA_AC, 16, 8, q_cp.qp, false, lane);
+                        lds_sync();
+                        if (lane < 32) load_levels_scan(l, v, j4); else v[0] = v[1] = v[2] = v[3] = 0;
+                        lds_sync();
+                    } else quant4_row(v, q_cp, j4);
+                    const bool nzc = quad_or((int)scan_mask(v, j4)) != 0 && act;
+                    if (act) { int z[4] = { 0, 0, 0, 0 }; store_levels_scan(l, nzc ? v : z, j4); }
+                    if (!nzc) v[0] = v[1] = v[2] = v[3] = 0;
+                    dequant4_row(v, q_cp, j4);
+                    idct4_quad(v, lane);
+#pragma unroll
+                    for (int t = 0; t < 4; t++) v[t] += p[t];
+                    const uint32_t crec = pack4_clip(v);
+                    if (act) ssd_c = ssd4_u8(cenc, crec);
+                    const unsigned long long bal = __ballot(nzc && j4 == 0);
+#pragma unroll
+                    for (int b = 0; b < 8; b++) nnz |= (unsigned)((bal >> (4 * b)) & 1) << (16 + b);
+                    cbp_chroma = 2;
+                }
+                // x264's non_zero_count cache after this encode: the part's entries are fresh, the rest stays what it was
+                {
+                    const unsigned lm = ((pm8 & 1) ? 0x000fu : 0) | ((pm8 & 2) ? 0x00f0u : 0) | ((pm8 & 4) ? 0x0f00u : 0) | ((pm8 & 8) ? 0xf000u : 0);
+                    const unsigned cm = (pm8 | (pm8 << 4)) << 16;
+                    const unsigned lfl = t8 ? ((cbp_luma & 1) ? 0x000fu : 0) | ((cbp_luma & 2) ? 0x00f0u : 0) | ((cbp_luma & 4) ? 0x0f00u : 0) | ((cbp_luma & 8) ? 0xf000u : 0) : nnz & 0xffffu;
+                    rf_nnzc = (rf_nnzc & ~(lm | cm)) | (lfl & lm) | (nnz & cm);
+                }
+            }
+            }
+        } else
         if (e_type >= X264GPU_MB_P_L0) {
             // this lane's 8x8 block's motion (Z layout: lane >> 4)
             const int b8 = lane >> 4;
@@ -2063,7 +2256,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(MB_WAVES_PER
                     mlo = group8_or(mlo); mhi = group8_or(mhi); big = group8_or(big);
                     const unsigned long long mask = ((unsigned long long)mhi << 32) | mlo;
                     bool keep = mask != 0;
-                    if (k.dct_decimate) {
+                    if (k.dct_decimate && !tr8) {          // (x264_macroblock_encode: the 8x8 trellis is its own decimation under CABAC)
                         const int sc = keep ? (big ? 9 : decimate64_from_mask(mask)) : 0;
                         const int mbscore = __builtin_amdgcn_readlane(sc, 0) + __builtin_amdgcn_readlane(sc, 8) + __builtin_amdgcn_readlane(sc, 16) + __builtin_amdgcn_readlane(sc, 24);
                         keep = keep && sc >= 4 && mbscore >= 6;
@@ -2307,23 +2500,50 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(MB_WAVES_PER
                 ci.tamvd = (unsigned long long)rl(cnbv, 10) | ((unsigned long long)rl(cnbv, 11) << 32);
             }
             ci.t8 = rd_t8cur;
+            ci.pm = 0; ci.pm_b0 = 0; ci.pm_b1 = -1; ci.pm_dx = ci.pm_dy = ci.pm_sx = ci.pm_sy = 0; ci.pm_nnzc = 0;
             if (rd_run && !commit) {
-                int cost;
+                int cost = 0;
+                unsigned long long cost64 = 0;          // part costs (RD refinement): 8 more bits than x264_rd_cost_mb's
                 int dist = wave_sum(ssd_y);
+                int src_e4 = fenc_e4, src_e8 = fenc_e8;
+                if constexpr (REF) { if (part_pass) { src_e4 = rf_f4; src_e8 = rf_f8; } }
                 if (k.psy_rd_q8) {
-                    const int e4 = wave_sum(en4) >> 1, e8 = wave_sum(en8) >> 2;      // pixel_hadamard_ac_16x16 of the reconstruction
-                    dist += (((abs(e4 - fenc_e4) + abs(e8 - fenc_e8)) >> 1) * k.psy_rd_q8 * c.lambda + 128) >> 8;
+                    const int e4 = wave_sum(en4) >> 1, e8 = wave_sum(en8) >> 2;      // pixel_hadamard_ac of the reconstruction (16x16, or the part)
+                    dist += (((abs(e4 - src_e4) + abs(e8 - src_e8)) >> 1) * k.psy_rd_q8 * c.lambda + 128) >> 8;
                 }
                 dist += (int)(((long long)wave_sum(ssd_c) * chroma_l2off + 128) >> 8);
-                if (rec_type == X264GPU_MB_P_SKIP || rec_type == X264GPU_MB_B_SKIP) cost = dist + ((lambda2 + 128) >> 8);
+                if (!part_pass && (rec_type == X264GPU_MB_P_SKIP || rec_type == X264GPU_MB_B_SKIP)) cost = dist + ((lambda2 + 128) >> 8);
                 else {
+                    if constexpr (REF) {
+                        if (part_pass && rf_pk == 1) {
+                            // partition_size_cabac: the part's vector difference against the |mvd| of the parts refined before / the neighbours
+                            const int x8 = rf_b0 & 1, y8 = rf_b0 >> 1;
+                            ci.pm = 1; ci.pm_b0 = rf_b0; ci.pm_b1 = rf_b1; ci.pm_nnzc = rf_nnzc; ci.t8 = e_t8 != 0;
+                            ci.pm_dx = rf_cx - rf_mvpx; ci.pm_dy = rf_cy - rf_mvpy;
+                            for (int comp = 0; comp < 2; comp++) {
+                                const int la = x8 > 0 ? (int)((rf_amvd >> (8 * ((y8 * 2 + x8 - 1) * 2 + comp))) & 255) : left ? (int)((ci.lamvd >> (8 * ((y8 * 2 + 1) * 2 + comp))) & 255) : 0;
+                                const int ta = y8 > 0 ? (int)((rf_amvd >> (8 * (((y8 - 1) * 2 + x8) * 2 + comp))) & 255) : top ? (int)((ci.tamvd >> (8 * ((2 + x8) * 2 + comp))) & 255) : 0;
+                                if (comp) ci.pm_sy = la + ta; else ci.pm_sx = la + ta;
+                            }
+                        }
+                    }
                     Cab tmp = cab;
                     tmp.f8 = 0; tmp.f8v = 0;
                     int dq;
                     unsigned long long av1;
                     ci.size = true;
                     cab_mb(tmp, cab_modelv, lane, ci, S, rd_lvs, L.modes4, L.modes8, L.nmodes, c.mbx, c.sy, dq, av1);
-                    cost = dist + (int)(((unsigned long long)cab_total(tmp) * (unsigned long long)lambda2 + 32768) >> 16);
+                    if (part_pass) cost64 = ((unsigned long long)(unsigned)dist << 8) + (((unsigned long long)cab_total(tmp) * (unsigned long long)lambda2 + 128) >> 8);
+                    else cost = dist + (int)(((unsigned long long)cab_total(tmp) * (unsigned long long)lambda2 + 32768) >> 16);
+                }
+                if constexpr (REF) {
+                    if (!part_pass) {
+                        // what this whole-macroblock encode leaves in x264's non_zero_count cache (flags; an 8x8 transform block sets its four entries alike)
+                        const unsigned ex = ((cbp_luma & 1) ? 0x000fu : 0) | ((cbp_luma & 2) ? 0x00f0u : 0) | ((cbp_luma & 4) ? 0x0f00u : 0) | ((cbp_luma & 8) ? 0xf000u : 0);
+                        const bool skc = rec_type == X264GPU_MB_P_SKIP || rec_type == X264GPU_MB_B_SKIP;
+                        rf_nnzc = skc ? 0u : (rd_t8cur ? ex : nnz & 0xffffu & ex) | (cbp_chroma == 2 ? nnz & 0x00ff0000u : 0u);
+                    }
+                    if (rd_ph == 9) { rf_cost = part_pass ? cost64 : (unsigned long long)(unsigned)cost; continue; }
                 }
                 if constexpr (BS) {
                     // x264_mb_analyse_b_rd / _transform_rd / x264_intra_rd: where the candidate's cost goes

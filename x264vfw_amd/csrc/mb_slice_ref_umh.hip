@@ -1,0 +1,11 @@
+// mb_slice_ref_umh.hip — the macroblock-loop kernel (k_mb.cuh) with RD refinement (x264 --subme 8: k_mb_refine.inc) for P slices under --me umh: the
+// +-5 sample sub-pel neighbourhood (4 half-pel + 10 quarter-pel iterations), trellis 0 / 1 (RD 5) and trellis 2 (RD 6); a translation unit of its own.
+#include "k_mb.cuh"
+
+namespace x264gpu {
+void launch_mb_slice_ref_umh(const EncK &k, int streams, hipStream_t st)
+{
+    if (k.trellis & 64) hipLaunchKernelGGL((k_mb_slice<5, 2, true, 6>), dim3(streams, k.slices > 1 ? k.slices : 1), dim3(64), 0, st, k);
+    else hipLaunchKernelGGL((k_mb_slice<5, 2, true, 5>), dim3(streams, k.slices > 1 ? k.slices : 1), dim3(64), 0, st, k);
+}
+}  // namespace x264gpu
