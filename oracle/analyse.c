@@ -12,6 +12,7 @@
  * of intra macroblocks so far — so the loop is raster-serial, as x264's is.
  */
 #include "encoder_priv.h"
+#include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 

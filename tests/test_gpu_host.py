@@ -882,6 +882,8 @@ def test_every_preset_codes_a_decodable_stream(gpu, preset):
         assert eff.i_bframe == {"veryslow": 8, "placebo": 16}.get(preset, 3) and eff.i_bframe_adaptive == (1 if preset in ("medium", "slow") else 2)
     else:
         assert eff.i_bframe == 0
+    # RD refinement (subme 8) runs from slow up (umh); placebo's tesa maps to esa, where it does not (subme 7)
+    assert eff.analyse.i_subpel_refine == {"ultrafast": 0, "superfast": 1, "veryfast": 2, "faster": 4, "fast": 6, "medium": 7, "placebo": 7}.get(preset, 8), preset
     stream, recs = encode_delayed(h_, w, h, frames)
     H.x264_encoder_close(h_)
     assert sorted(r[2] for r in recs) == list(range(n))
@@ -889,6 +891,19 @@ def test_every_preset_codes_a_decodable_stream(gpu, preset):
     assert len(dec) == n
     for d, r in zip(dec, recs):
         assert psnr(d[:w * h], frames[r[2]][:w * h]) > 26.0, (preset, r)
+
+
+@pytest.mark.parametrize("opts", [
+    {"subme": 8, "me": "umh", "trellis": 2, "ref": 5, "bframes": 3, "b-adapt": 2, "rc-lookahead": 10, "keyint": 12, "qp": 24},          # preset slow's toolset (direct stays spatial)
+    {"subme": 8, "me": "hex", "trellis": 1, "ref": 2, "bframes": 0, "keyint": 9, "crf": 25, "rc-lookahead": 4},
+])
+def test_rd_refinement_session_equals_the_checker(gpu, tmp_path, opts):
+    """a --subme 8 session (RD refinement of the P partitions' vectors and of the intra modes, B slices one level down) through x264_encoder_encode on
+    the device and over the CPU checker: same picture types, timestamps and bytes"""
+    import os
+    import subprocess
+    subprocess.check_call(["make", "-s", "-C", os.path.join(os.path.dirname(os.path.abspath(__file__)), "stub")])
+    _session_equals_checker(tmp_path, 176, 144, 14, opts, 77, 9, "moving")
 
 
 def _session_equals_checker(tmp_path, w, h, nfr, opts, seed, scene, kind):

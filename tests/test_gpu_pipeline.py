@@ -225,6 +225,13 @@ def test_pipeline_cabac_rd_bitexact(gpu, w, h, nfr, kw):
     (176, 144, 4, dict(partitions=7, dct8x8=1, refs=3, mixed_refs=1, chroma_me=1, psy=1, psy_rd_q8=256, chroma_qp_offset=-2, rd=3)),
     (208, 120, 4, dict(partitions=7, dct8x8=1, refs=2, qp_i=30, qp_p=34, me_method=2, rd=3, trellis=63)),
     (176, 144, 4, dict(partitions=7, dct8x8=1, refs=2, mixed_refs=1, psy=1, psy_rd_q8=256, chroma_qp_offset=-2, rd=3, trellis=127)),       # trellis 2: the search in the part encodes too
+    (176, 144, 3, dict(partitions=0, rd=1 | 2 << 1)),                                                      # Intra_16x16 modes
+    (176, 144, 3, dict(partitions=6, dct8x8=1, rd=1 | 4 << 1, psy=1, psy_rd_q8=256, chroma_qp_offset=-2)),   # chroma modes
+    (176, 144, 3, dict(partitions=2, rd=1 | 8 << 1, psy=1, psy_rd_q8=256, chroma_qp_offset=-2)),             # Intra_4x4 modes
+    (176, 144, 3, dict(partitions=4, dct8x8=1, rd=1 | 16 << 1, psy=1, psy_rd_q8=256, chroma_qp_offset=-2)),  # Intra_8x8 modes
+    (176, 144, 4, dict(partitions=7, dct8x8=1, refs=3, mixed_refs=1, chroma_me=1, psy=1, psy_rd_q8=256, chroma_qp_offset=-2, rd=63, trellis=63)),      # x264 --subme 8 on medium's toolset
+    (208, 120, 4, dict(partitions=7, dct8x8=1, refs=2, mixed_refs=1, chroma_me=1, qp_i=30, qp_p=34, me_method=2, rd=63, trellis=127)),                  # ... on slow's: umh, trellis 2
+    (96, 80, 3, dict(partitions=7, dct8x8=1, qp_i=10, qp_p=12, rd=63)),
 ])
 def test_pipeline_rd_refinement_bitexact(gpu, w, h, nfr, kw):
     """RD refinement on the device (REF instantiations of the macroblock loop, k_mb_refine.inc) against oracle/analyse.c's restatement of

@@ -945,7 +945,10 @@ __device__ __forceinline__ unsigned mb_encode_i8x8_trellis(const EncK &k, MbLds<
     return nnz8;
 }
 
-struct IntraRes { int satd_i16, satd_i8, satd_i4, pred16; unsigned nnz4, nnz8; int cbp8; };
+struct IntraRes { int satd_i16, satd_i8, satd_i4, pred16; unsigned nnz4, nnz8; int cbp8;
+                  // by-products intra_rd_refine reads (x264 i_satd_i16x16_dir / i_satd_i8x8_dir): the Intra_16x16 costs in the order of the mode list,
+                  // the Intra_8x8 costs (+ 4 lambda) as a lane-indexed table, lane = block * 9 + mode
+                  int dir16[4], dir8v; };
 
 // Needs the neighbour samples in L.tile / L.tile8 / L.nb and the neighbour macroblocks' edge modes in L.nmodes.
 template <int M>
@@ -960,6 +963,7 @@ __device__ __forceinline__ void mb_analyse_intra(const EncK &k, MbLds<M> &L, con
     const int b_type_cost = k.slice_type == X264GPU_SLICE_B ? 9 * lambda : 0;      // B slices: the macroblock type prefix of an intra type (x264 i_mb_b_cost_table[I_*] = 9)
     uint8_t *tile = L.tile + IT_ORG, *tile8 = L.tile8 + IT_ORG;
     R.satd_i16 = R.satd_i8 = R.satd_i4 = MB_COST_MAX; R.pred16 = 0; R.nnz4 = R.nnz8 = 0; R.cbp8 = 0;
+    R.dir16[0] = R.dir16[1] = R.dir16[2] = R.dir16[3] = MB_COST_MAX; R.dir8v = MB_COST_MAX;
     // ---- 16x16 ----
     {
         const Pred16 pp = pred16_setup(L.nb, lane);
@@ -971,12 +975,12 @@ __device__ __forceinline__ void mb_analyse_intra(const EncK &k, MbLds<M> &L, con
             return wave_sum(c.satd ? satd4_half(cz, pr, lane) : sad4(cz, pr)) + lambda * bs_size_ue(sig);
         };
         if (left && top) {
-            for (int m = 0; m < 3; m++) { const int cst = cost16(m); if (cst < R.satd_i16) { R.satd_i16 = cst; R.pred16 = m; } }
-            if (R.satd_i16 <= thresh16) { const int cst = cost16(PRED16_P); if (cst < R.satd_i16) { R.satd_i16 = cst; R.pred16 = PRED16_P; } }
+            for (int m = 0; m < 3; m++) { const int cst = cost16(m); R.dir16[m] = cst; if (cst < R.satd_i16) { R.satd_i16 = cst; R.pred16 = m; } }
+            if (R.satd_i16 <= thresh16) { const int cst = cost16(PRED16_P); R.dir16[3] = cst; if (cst < R.satd_i16) { R.satd_i16 = cst; R.pred16 = PRED16_P; } }
         } else {
             const int m0 = left ? PRED16_DC_LEFT : top ? PRED16_DC_TOP : PRED16_DC_128, m1 = left ? PRED16_H : PRED16_V;
-            { const int cst = cost16(m0); if (cst < R.satd_i16) { R.satd_i16 = cst; R.pred16 = m0; } }
-            if (left || top) { const int cst = cost16(m1); if (cst < R.satd_i16) { R.satd_i16 = cst; R.pred16 = m1; } }
+            { const int cst = cost16(m0); R.dir16[0] = cst; if (cst < R.satd_i16) { R.satd_i16 = cst; R.pred16 = m0; } }
+            if (left || top) { const int cst = cost16(m1); R.dir16[1] = cst; if (cst < R.satd_i16) { R.satd_i16 = cst; R.pred16 = m1; } }
         }
         R.satd_i16 += b_type_cost;
         if (R.satd_i16 > thresh16) return;
@@ -1011,6 +1015,13 @@ __device__ __forceinline__ void mb_analyse_intra(const EncK &k, MbLds<M> &L, con
             const int best = pick_intra_mode([&](int m) { return m < 8 ? rl(c1, m * 8) : rl(c2, 0); }, avail, pm, lambda, false, every_mode, bm, RF2);
             i_cost += best + 3 * lambda;
             if (lane < 4) L.modes8[idx * 4 + lane] = (uint8_t)bm;
+            if (RF2) {          // i_satd_i8x8_dir[idx][mode]: the mode's cost with the predicted-mode bonus, + 4 lambda
+                const int m = lane - idx * 9;
+                int raw = rl(c2, 0);
+#pragma unroll
+                for (int mm = 0; mm < 8; mm++) { const int v = rl(c1, mm * 8); raw = m == mm ? v : raw; }
+                if (m >= 0 && m < 9) R.dir8v = raw - (pm == m ? 3 * lambda : 0) + 4 * lambda;
+            }
             if (idx < 3 && i_cost > thresh) break;
             // code the block (the next ones predict from it; the last one so that the result is complete if Intra8x8 wins)
             const uint32_t plo = bm == 8 ? (uint32_t)__shfl((int)p2lo, r8) : (uint32_t)__shfl((int)p1lo, bm * 8 + r8);
@@ -1119,7 +1130,7 @@ __device__ __forceinline__ void mb_analyse_intra(const EncK &k, MbLds<M> &L, con
 
 // chroma intra: mode decision (oracle analyse_intra_chroma).  Lanes 0..31 (plane = lane >> 4); needs L.cnb.
 template <int M>
-__device__ __forceinline__ int mb_intra_chroma_cost(const EncK &k, MbLds<M> &L, const MbCtx &c, int &predc)
+__device__ __forceinline__ int mb_intra_chroma_cost(const EncK &k, MbLds<M> &L, const MbCtx &c, int &predc, int *dirc = nullptr /* [4]: the candidates' costs in list order */)
 {
     const int lane = c.lane, pl = (lane >> 4) & 1, ci = (lane >> 2) & 3, j = lane & 3, cx0 = (ci & 1) * 4, cyy = (ci >> 1) * 4 + j;
     const bool left = c.mbx > 0, top = c.sy > 0;
@@ -1137,6 +1148,7 @@ __device__ __forceinline__ int mb_intra_chroma_cost(const EncK &k, MbLds<M> &L, 
         const uint32_t pr = predc_row4(cnb, pc, m, ci, j);
         const int hs = c.satd ? satd4_half(cenc, pr, lane) : sad4(cenc, pr);
         const int cst = wave_sum(lane < 32 ? hs : 0) + c.lambda * bs_size_ue(sig);
+        if (dirc) dirc[i] = cst;
         if (cst < bestc) { bestc = cst; predc = m; }
     }
     return bestc;
@@ -1583,6 +1595,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(MB_WAVES_PER
         const bool early_term = c.subme < 11;
         int mb_type = X264GPU_MB_I16x16, i_cost = 0, predc = 0, satd_chroma = MB_COST_MAX;
         IntraRes IR;
+        int rf_dirc[4] = { MB_COST_MAX, MB_COST_MAX, MB_COST_MAX, MB_COST_MAX };          // i_satd_chroma_dir in list order (RD refinement)
         bool pskip = false;
         int cost8x8 = MB_COST_MAX, satd16x8 = MB_COST_MAX, satd8x16 = MB_COST_MAX;      // SATD costs of the shapes (MB_COST_MAX: not analysed / terminated early)
         const bool rdon = RD && k.rd != 0;
@@ -1858,7 +1871,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(MB_WAVES_PER
             if constexpr (TRL2) {
                 if ((k.trellis & 64) && RD && k.rd) { tra_ctx.on = k.trellis & 63; tra_ctx.r = cab.r; tra_ctx.r8 = cab.r8; tra_ctx.model = cab_modelv; tra_ctx.tt.size_unary = k.tr_su; tra_ctx.tt.trans_unary = k.tr_tu; tra_ctx.tt.lambda2 = k.tr_l2; }
             }
-            satd_chroma = mb_intra_chroma_cost(k, L, c, predc);
+            satd_chroma = mb_intra_chroma_cost(k, L, c, predc, rf_dirc);
             pf.mark(PH_INTRA_CHROMA);
             mb_analyse_intra(k, L, c, cz, t4, parts, c.chroma_me ? i_satd_inter - satd_chroma : i_satd_inter, fast_intra, early_term, rdon, q_li, q8i, IR, TRL2 && tra_ctx.on ? &tra_ctx : nullptr);
             if (c.chroma_me) { IR.satd_i16 += satd_chroma; IR.satd_i8 += satd_chroma; IR.satd_i4 += satd_chroma; }
@@ -1922,6 +1935,15 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(MB_WAVES_PER
         unsigned long long rf_bcost = 0, rf_cost = 0, rf_amvd = 0;
         unsigned rf_nnzc = 0;
         uint32_t rf_pred = 0;
+        // ... of the intra refinement: the mode out for costing (rf_cm), the best so far, the chroma pass' transform switch and last coded block pattern,
+        // i_cbp_i8x8_luma; an Intra_4x4 block's nine candidate encodes side by side (lane = mode * 4 + row: levels, reconstruction, distortion, non-zero)
+        int rf_cm = 0, rf_bm = 0, rf_bdct = 0, rf_cbpc = 0, rf_cbp_i8 = 0, rf_old = 0;
+        unsigned long long rf_list = 0;
+        int rf4_v0 = 0, rf4_v1 = 0, rf4_v2 = 0, rf4_v3 = 0, rf4_d = 0, rf4_nz = 0;
+        uint32_t rf4_rz = 0, rf8_blo = 0, rf8_bhi = 0;
+        int rf8_v[8] = { 0, 0, 0, 0, 0, 0, 0, 0 }, rf8c_v[8] = { 0, 0, 0, 0, 0, 0, 0, 0 }, rf8_cbp = 0;
+        uint32_t rf8c_lo = 0, rf8c_hi = 0;
+        unsigned rf8_n4 = 0;
         if constexpr (BS) {
             rd_run = true; commit = false;
             const int ci_ = (lane >> 2) & 3;
@@ -2167,6 +2189,80 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(MB_WAVES_PER
                     const unsigned lfl = t8 ? ((cbp_luma & 1) ? 0x000fu : 0) | ((cbp_luma & 2) ? 0x00f0u : 0) | ((cbp_luma & 4) ? 0x0f00u : 0) | ((cbp_luma & 8) ? 0xf000u : 0) : nnz & 0xffffu;
                     rf_nnzc = (rf_nnzc & ~(lm | cm)) | (lfl & lm) | (nnz & cm);
                 }
+            } else if (rf_pk == 2) {
+                // rd_cost_i4x4: the block's candidate encodes were done side by side by the coroutine; this mode's levels sit in the level buffer
+                const int idx = rf_i, bnz = rl(rf4_nz, rf_cm * 4);
+                nnz = (unsigned)bnz << idx;
+                rf_nnzc = (rf_nnzc & ~(1u << idx)) | ((unsigned)bnz << idx);
+                ssd_y = lane == 0 ? rl(rf4_d, rf_cm * 4) : 0;
+            } else if (rf_pk == 3) {
+                // rd_cost_i8x8: predict block rf_i with mode rf_cm from the refined neighbours in the tile, transform, quantise, reconstruct
+                const int idx = rf_i, x8 = idx & 1, y8 = idx >> 1, g = lane >> 3, r8 = lane & 7;
+                const int avail = i8_avail(left, top, topright, idx);
+                uint8_t *bt = tile8 + y8 * 8 * IT_STRIDE + x8 * 8;
+                lds_sync();
+                pred8_build_u(L.U8, bt, IT_STRIDE, avail, lane);
+                const int src = idx * 16 + (r8 >> 2) * 8 + (r8 & 3);
+                const uint32_t elo = (uint32_t)__shfl((int)cz, src), ehi = (uint32_t)__shfl((int)cz, src + 4);
+                uint32_t plo, phi;
+                pred8_row8(L.U8, L.pred8tab, rf_cm, r8, plo, phi);
+                int e[8], p[8], v[8];
+                unpack8(elo, ehi, e); unpack8(plo, phi, p);
+#pragma unroll
+                for (int i = 0; i < 8; i++) v[i] = e[i] - p[i];
+                fwd8_1d(v); transpose8(v, lane); fwd8_1d(v); transpose8(v, lane);
+                int mf[4], bs[4], dq[4];
+                q8_row(q8i, r8, mf, bs, dq);
+                unsigned mlo = 0, mhi = 0;
+                const bool tr8 = TRL2 && (trc.on & TR_I8) != 0;
+                if (tr8) {
+                    if (g == 0)
+#pragma unroll
+                        for (int i = 0; i < 8; i++) lvw[idx * 64 + c_zigzag8_inv[r8 * 8 + i]] = (int16_t)v[i];
+                    lds_sync();
+                    trellis_run<5>(trc, lvw + idx * 64, 64, 1, c.qp, true, lane);
+                    lds_sync();
+#pragma unroll
+                    for (int i = 0; i < 8; i++) v[i] = lvw[idx * 64 + c_zigzag8_inv[r8 * 8 + i]];
+                    lds_sync();
+                }
+#pragma unroll
+                for (int i = 0; i < 8; i++) {
+                    if (!tr8) v[i] = quant_one(v[i], mf[i & 3], bs[i & 3]);
+                    const int z = c_zigzag8_inv[r8 * 8 + i];
+                    if (v[i]) { if (z < 32) mlo |= 1u << z; else mhi |= 1u << (z - 32); }
+                    if (g == 0) lvw[(idx * 4 + (z & 3)) * 16 + (z >> 2)] = (int16_t)v[i];
+                    rf8c_v[i] = v[i];
+                }
+                mlo = group8_or(mlo); mhi = group8_or(mhi);
+                const unsigned long long mask = (unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)mlo) | ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)mhi) << 32);
+#pragma unroll
+                for (int q = 0; q < 4; q++) nnz |= (mask & (0x1111111111111111ull << q)) ? 1u << (idx * 4 + q) : 0u;
+                cbp_luma = (rf_cbp_i8 & ~(1 << idx)) | (mask ? 1 << idx : 0);
+                const int qb = q8i.qp / 6 - 6;
+#pragma unroll
+                for (int i = 0; i < 8; i++) v[i] = dequant_one(v[i], dq[i & 3], qb);
+                inv8_1d(v); transpose8(v, lane); inv8_1d(v); transpose8(v, lane);
+#pragma unroll
+                for (int i = 0; i < 8; i++) v[i] = ((v[i] + 32) >> 6) + p[i];
+                const uint32_t rlo = pack4_clip8lo(v), rhi = pack4_clip8hi(v);
+                rf8c_lo = rlo; rf8c_hi = rhi;
+                // ssd_plane( PIXEL_8x8 ): SSD + |hadamard_ac of the reconstruction - of the source| (lanes 0..7 = the block's rows; the others carry copies)
+                int e4, e8, f4, f8;
+                psy_energy_r8(rlo, rhi, lane, e4, e8);
+                psy_energy_r8(elo, ehi, lane, f4, f8);
+                if (g == 0) { ssd_y = ssd4_u8(elo, rlo) + ssd4_u8(ehi, rhi); en4 = e4; en8 = e8; }
+                rf_f4 = wave_sum(g == 0 ? f4 : 0) >> 1; rf_f8 = wave_sum(g == 0 ? f8 : 0) >> 2;
+                rd_t8cur = 1;
+            } else if (rf_pk == 4) {
+                // rd_cost_chroma: the chroma planes predicted with mode rf_cm, coded (unless a mode without residual was already seen), no luma
+                const int pl = (lane >> 4) & 1, ci = (lane >> 2) & 3, cx0 = (ci & 1) * 4, cyy = (ci >> 1) * 4 + j4;
+                const PredC pc = predc_setup(L.cnb[pl]);
+                const uint2 fe = *(const uint2 *)(L.csrc + cyy * 16 + 2 * cx0);
+                const uint32_t cenc = nv12_pick(fe.x, fe.y, pl), cpred = predc_row4(L.cnb[pl], pc, rf_cm, ci, j4);
+                uint32_t crec = cpred;
+                if (rf_bdct) crec = mb_chroma_residual(cenc, cpred, q_ci, false, false, lane, lvw, nnz, cbp_chroma, TRL ? &trc : nullptr);
+                if (lane < 32) ssd_c = ssd4_u8(cenc, crec);
             }
             }
         } else
@@ -2506,7 +2602,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(MB_WAVES_PER
                 unsigned long long cost64 = 0;          // part costs (RD refinement): 8 more bits than x264_rd_cost_mb's
                 int dist = wave_sum(ssd_y);
                 int src_e4 = fenc_e4, src_e8 = fenc_e8;
-                if constexpr (REF) { if (part_pass) { src_e4 = rf_f4; src_e8 = rf_f8; } }
+                if constexpr (REF) { if (part_pass) { src_e4 = rf_pk == 2 ? 0 : rf_f4; src_e8 = rf_pk == 2 ? 0 : rf_f8; } }      // (an Intra_4x4 block's psy term is in its distortion already)
                 if (k.psy_rd_q8) {
                     const int e4 = wave_sum(en4) >> 1, e8 = wave_sum(en8) >> 2;      // pixel_hadamard_ac of the reconstruction (16x16, or the part)
                     dist += (((abs(e4 - src_e4) + abs(e8 - src_e8)) >> 1) * k.psy_rd_q8 * c.lambda + 128) >> 8;
@@ -2526,6 +2622,13 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(MB_WAVES_PER
                                 if (comp) ci.pm_sy = la + ta; else ci.pm_sx = la + ta;
                             }
                         }
+                        if (part_pass && rf_pk >= 2) {
+                            // partition_i4x4_size_cabac / partition_i8x8_size_cabac / chroma_size_cabac
+                            ci.pm = rf_pk; ci.pm_b0 = rf_i; ci.pm_b1 = -1; ci.pm_nnzc = rf_nnzc;
+                            ci.type = rf_pk == 2 ? X264GPU_MB_I4x4 : rf_pk == 3 ? X264GPU_MB_I8x8 : e_type;
+                            if (rf_pk == 3) ci.t8 = 1;
+                            if (rf_pk == 4) ci.cmode = rf_cm > PREDC_P ? PREDC_DC : rf_cm;
+                        }
                     }
                     Cab tmp = cab;
                     tmp.f8 = 0; tmp.f8v = 0;
@@ -2533,7 +2636,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(MB_WAVES_PER
                     unsigned long long av1;
                     ci.size = true;
                     cab_mb(tmp, cab_modelv, lane, ci, S, rd_lvs, L.modes4, L.modes8, L.nmodes, c.mbx, c.sy, dq, av1);
-                    if (part_pass) cost64 = ((unsigned long long)(unsigned)dist << 8) + (((unsigned long long)cab_total(tmp) * (unsigned long long)lambda2 + 128) >> 8);
+                    if constexpr (REF) { if (part_pass && rf_pk == 4) dist = wave_sum(ssd_c); }          // rd_cost_chroma: the two planes' SSD as it is
+                    const int l2p = REF && part_pass && rf_pk == 4 ? c_lambda2_tab[c.qpc] : lambda2;
+                    if (part_pass) cost64 = ((unsigned long long)(unsigned)dist << 8) + (((unsigned long long)cab_total(tmp) * (unsigned long long)l2p + 128) >> 8);
                     else cost = dist + (int)(((unsigned long long)cab_total(tmp) * (unsigned long long)lambda2 + 32768) >> 16);
                 }
                 if constexpr (REF) {
@@ -2570,7 +2675,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(MB_WAVES_PER
                 else if (rd_ph == 4) { if (rd_best >= cost) { if (rd_best > 0) rd_satd_inter = (int)((long long)rd_satd_inter * cost / rd_best); rd_best = cost; rd_t8 = 1; } }
                 else if (rd_ph == 5) rd_i16 = cost;
                 else if (rd_ph == 6) rd_i4 = cost;
-                else if (rd_ph == 7) rd_i8 = cost;
+                else if (rd_ph == 7) { rd_i8 = cost; rf_cbp_i8 = cbp_luma; }
                 rd_ph++;
                 continue;
             }
