@@ -86,6 +86,12 @@ def toolset(args):
         t = dict(t, cabac=int(args.rd == "cabac"), rd=1, subme=7, psy=1, psy_rd_q8=256, chroma_qp_offset=-2)            # x264 lowers the chroma offset by 2 under psy-rd >= 0.25
         if args.rd == "cabac" and not args.no_trellis:
             t = dict(t, trellis=63)                               # medium's --trellis 1: every quantiser call of the final encode
+        if args.preset == "slow" and args.rd == "cabac":
+            # config.c:1482-1484: slow = --direct auto --rc-lookahead 50 --ref 5 --subme 8 --trellis 2 (+ --me umh above); subme 8 = RD refinement of the
+            # P partitions' vectors and of the intra modes (rd 63: every site); --direct auto stays spatial (config.toolset_gaps)
+            t = dict(t, refs=5, subme=8, rd=63)
+            if not args.no_trellis:
+                t = dict(t, trellis=127)
     if args.aq:
         t = dict(t, aq_mode=1, aq_strength_q8=266)
     if args.bframes and t.get("rd") and t.get("cabac") and args.preset != "ultrafast":

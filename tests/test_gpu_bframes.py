@@ -137,6 +137,13 @@ def test_headline_size_b_pictures_and_weightp_bitexact(gpu):
     assert run(gpu, 1920, 1080, "IBBBPP", 21, weightp=2) > 0
 
 
+def test_config4_size_slow_toolset_bitexact(gpu):
+    """3840x2160 (BASELINE.json configs[3]) with preset slow's toolset as it is built — --me umh, --subme 8 (RD refinement of the P partitions' vectors and of
+    the intra modes: cfg.rd 63), --ref 5, --trellis 2, bframes 3 + b-pyramid + weightb, --weightp 2's duplicate; --direct auto stays spatial and subme 9's
+    refinement of B slices / deblock-aware RD are not built — one mini-GOP I B P B plus a second P picture against the CPU checker"""
+    assert run(gpu, 3840, 2160, "IBPBP", 41, weightp=2, refs=5, dpb=5, me_method=2, subme=8, rd=63, trellis=127) >= 0
+
+
 @pytest.mark.parametrize("types,weights,weightp,over", [
     ("IPPPP", {1: (60, 6, 0), 2: (59, 6, 1), 3: (15, 4, -2), 4: (1, 0, -3)}, 2, {}),              # weighted reference 0 + both duplicates (three indices, one picture)
     ("IBBPBBP", {3: (53, 6, 1), 6: (111, 7, 0)}, 2, {}),

@@ -111,7 +111,7 @@ int x264gpu_encoder_create(x264gpu_encoder **out, const x264gpu_config *cfg)
     ARG_TRY(cfg->trellis == 0 || (cfg->trellis > 0 && cfg->trellis < 128 && (cfg->trellis & 63) && cfg->rd && cfg->cabac));      // trellis sites (mask; x264 --trellis 1 = 63, --trellis 2 = 63 + 64): RD sessions with CABAC
     ARG_TRY(!cfg->rd || (cfg->subme >= 6 && cfg->subme <= 8 && cfg->psy_rd_q8 >= 0 && cfg->psy_rd_q8 <= 2560));      // RD: x264's i_mbrd 1 (bit counts of the session's entropy coder)
     // rd > 1: RD refinement of the chosen type (x264 subme 8, i_mbrd 2): bit 0 on + a mask of refinement sites in bits 1..5 (x264 = all five: 63); CABAC, hex / umh
-    ARG_TRY(cfg->rd >= 0 && cfg->rd < 64 && (cfg->rd < 2 || ((cfg->rd & 1) && cfg->cabac && cfg->subme == 8 && (cfg->me_method == 1 || cfg->me_method == 2))) && (cfg->subme < 8 || cfg->rd > 1));
+    ARG_TRY(cfg->rd >= 0 && cfg->rd < 64 && (cfg->rd < 2 || ((cfg->rd & 1) && cfg->cabac && cfg->subme == 8 && (cfg->me_method == 1 || cfg->me_method == 2))));      // (rd 0 with subme >= 8: the sub-pel iteration table of those levels without RD, as before)
     ARG_TRY(cfg->slices >= 0 && (cfg->slices <= 1 || cfg->slices <= (cfg->height + 15) / 16 / (cfg->slices_plain ? 1 : 4)));      // x264 slice threads: at least four macroblock rows each; --slices N: one
     ARG_TRY(cfg->slices_plain == 0 || cfg->slices_plain == 1);
     ARG_TRY(cfg->width <= 4096 && cfg->height <= 2304 && cfg->me_range >= 4 && cfg->me_range <= (cfg->me_method == 2 ? 64 : 16));

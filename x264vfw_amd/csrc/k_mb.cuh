@@ -955,7 +955,7 @@ template <int M>
 __device__ __forceinline__ void mb_analyse_intra(const EncK &k, MbLds<M> &L, const MbCtx &c, uint32_t cz, uint32_t t4, int parts, int i_satd_inter,
                                                  bool fast_intra, bool early_term, bool mbrd, const Q4 &q4, const Q8 &q8, IntraRes &R, const TrCtx *tra = nullptr)
 {
-    const bool RF2 = mbrd && k.rd > 1;             // x264's i_mbrd >= 2 (RD refinement, subme >= 8)
+    const bool RF2 = mbrd && k.rd > 1 && k.slice_type != X264GPU_SLICE_B;      // x264's i_mbrd >= 2 (RD refinement, subme >= 8; a B slice analyses one level down)
     const bool every_mode = RF2 || (mbrd && !fast_intra);          // x264: i_mbrd >= 1 + b_fast_intra
     const int lane = c.lane, j = lane & 3, zx = z_x0(lane), zy = z_y(lane), lambda = c.lambda;
     const bool left = c.mbx > 0, top = c.sy > 0, topright = top && c.mbx + 1 < k.mbw;
@@ -2263,6 +2263,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(MB_WAVES_PER
                 uint32_t crec = cpred;
                 if (rf_bdct) crec = mb_chroma_residual(cenc, cpred, q_ci, false, false, lane, lvw, nnz, cbp_chroma, TRL ? &trc : nullptr);
                 if (lane < 32) ssd_c = ssd4_u8(cenc, crec);
+                if (rf_bdct) rf_nnzc = (rf_nnzc & 0xffffu) | (cbp_chroma == 2 ? nnz & 0x00ff0000u : 0u);      // (what x264_mb_encode_chroma leaves in the non_zero_count cache)
             }
             }
         } else
