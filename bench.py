@@ -70,8 +70,9 @@ def parse_args():
     ap.add_argument("--e2e-frames", type=int, default=10, help="frames of the single-stream threads-1 end-to-end sample (0 = skip e2e)")
     ap.add_argument("--cpu-procs", type=int, default=64, help="processes of the many-core leg of the CPU baseline (cpu_baseline.cores reports what was used)")
     ap.add_argument("--cpu-frames-all", type=int, default=3, help="frames per core of the every-core leg of the CPU baseline (shorter: it runs one process per core)")
-    ap.add_argument("--content", default="noise", choices=["noise", "smooth"], help="synthetic content: 'noise' (default, the headline) = moving rectangles of per-pixel "
-                    "white noise + strong sensor noise, harder than camera material; 'smooth' = the same scene with band-limited textures and light noise")
+    ap.add_argument("--content", default="noise", choices=["noise", "smooth", "survey"], help="synthetic content: 'noise' (default, the headline) = moving rectangles of per-pixel "
+                    "white noise + strong sensor noise, harder than camera material; 'smooth' = the same scene with band-limited textures and light noise; "
+                    "'survey' = SURVEY.md §8(d) read with natural textures: gradient + 3 moving band-limited rectangles + noise of +-4 on luma, +-2 on chroma")
     ap.add_argument("--cpu-worker", type=int, default=-1, help=argparse.SUPPRESS)
     return ap.parse_args()
 
@@ -196,7 +197,7 @@ def cpu_baseline(args):
 
 
 # ---------------------------------------------------------------------------------------------------------------------------
-def synth_batch(torch, streams, frames, w, h, seed, device, smooth=False, scene_len=0):
+def synth_batch(torch, streams, frames, w, h, seed, device, smooth=False, scene_len=0, luma_noise=None):
     """[frames, streams, w*h*3/2] uint8 I420 on the device: gradient + 3 moving textured rectangles +
     per-pixel noise, generated with torch ops (plumbing only)."""
     g = torch.Generator(device=device)
@@ -234,7 +235,7 @@ def synth_batch(torch, streams, frames, w, h, seed, device, smooth=False, scene_
                 y[ys.view(-1, 1), xs.view(1, -1)] = 40 + t * 150 // 255
                 u[(ys[::2] // 2).view(-1, 1), (xs[::2] // 2).view(1, -1)] = 100 + t[::2, ::2] * 40 // 255
                 v[(ys[::2] // 2).view(-1, 1), (xs[::2] // 2).view(1, -1)] = 150 - t[::2, ::2] * 40 // 255
-            na = 1 if smooth else 4
+            na = luma_noise if luma_noise is not None else 1 if smooth else 4
             y = (y + torch.randint(-na, na + 1, y.shape, generator=g, device=device, dtype=torch.int16)).clamp_(16, 235)
             u = (u + torch.randint(-2, 3, u.shape, generator=g, device=device, dtype=torch.int16)).clamp_(16, 240)
             v = (v + torch.randint(-2, 3, v.shape, generator=g, device=device, dtype=torch.int16)).clamp_(16, 240)
@@ -488,7 +489,7 @@ def main():
     # ---- inputs resident in HBM: Wu + K distinct frames per stream (D distinct sequences replicated over the streams) ----
     D = max(1, min(S, args.distinct))
     L = Wu + K
-    base = synth_batch(torch, D, L, W, H, shard.stream_seed(0x264, gids[0]), dev, smooth=args.content == "smooth", scene_len=97)
+    base = synth_batch(torch, D, L, W, H, shard.stream_seed(0x264, gids[0]), dev, smooth=args.content != "noise", scene_len=97, luma_noise=4 if args.content == "survey" else None)
     data = base if D == S else base.repeat(1, (S + D - 1) // D, 1)[:, :S].contiguous()
     del base
 

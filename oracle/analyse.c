@@ -810,12 +810,10 @@ static void mc_mb_p(x264o_encoder *e, int mbx, int mby, int bx, int by, int w, i
     if (e->wl0[r].on) x264o_mc_weight(dy + by * sy + bx, sy, dy + by * sy + bx, sy, w, h, e->wl0[r].scale, e->wl0[r].denom, e->wl0[r].offset);
 }
 
-static int probe_pskip(const actx *a)
+/* x264_macroblock_probe_skip_internal: would the residual of the prediction (py stride 16, pu / pv stride 8) code to nothing? */
+static int probe_skip_pred(const actx *a, const pixel *py, const pixel *pu, const pixel *pv)
 {
     x264o_encoder *e = a->e;
-    const int mvx = clampi(a->pskip_mv[0], a->mv_min[0], a->mv_max[0]), mvy = clampi(a->pskip_mv[1], a->mv_min[1], a->mv_max[1]);
-    pixel py[256], pu[64], pv[64];
-    mc_mb_p(e, a->mbx, a->mby, 0, 0, 16, 16, 0, mvx, mvy, py, 16, pu, pv, 8);
     const pixel *fenc = e->fenc_y + (size_t)a->mby * 16 * e->fs + a->mbx * 16;
     const uint16_t *mf = e->qt.quant4_mf[X264O_CQM_4PY][a->qp], *bias = e->qt.quant4_bias[X264O_CQM_4PY][a->qp];
     int score = 0;
@@ -859,6 +857,27 @@ static int probe_pskip(const actx *a)
         }
     }
     return 1;
+}
+
+static int probe_pskip(const actx *a)
+{
+    x264o_encoder *e = a->e;
+    const int mvx = clampi(a->pskip_mv[0], a->mv_min[0], a->mv_max[0]), mvy = clampi(a->pskip_mv[1], a->mv_min[1], a->mv_max[1]);
+    pixel py[256], pu[64], pv[64];
+    mc_mb_p(e, a->mbx, a->mby, 0, 0, 16, 16, 0, mvx, mvy, py, 16, pu, pv, 8);
+    return probe_skip_pred(a, py, pu, pv);
+}
+
+/* x264_macroblock_probe_bskip: the same test on the direct prediction, which x264_mb_mc left in the reconstruction */
+static int probe_bskip(const actx *a)
+{
+    x264o_encoder *e = a->e;
+    const pixel *rec = luma_plane(e, e->cur, 0) + (size_t)a->mby * 16 * e->rs + a->mbx * 16;
+    const pixel *ruv = chroma_plane(e, e->cur) + (size_t)a->mby * 8 * e->rs + a->mbx * 16;
+    pixel py[256], pu[64], pv[64];
+    for (int y = 0; y < 16; y++) memcpy(py + y * 16, rec + (size_t)y * e->rs, 16);
+    for (int y = 0; y < 8; y++) for (int x = 0; x < 8; x++) { pu[y * 8 + x] = ruv[y * e->rs + 2 * x]; pv[y * 8 + x] = ruv[y * e->rs + 2 * x + 1]; }
+    return probe_skip_pred(a, py, pu, pv);
 }
 
 /* ---------------------------------------------------------------------------------------------------------------------------
@@ -1755,17 +1774,22 @@ static void analyse_inter_direct(actx *a)
     }
 }
 
-/* x264_mb_analyse_inter_b16x16 (RD sessions: b_try_skip is off, so the lists are searched list 1 first, every reference) */
-static void analyse_inter_b16x16(actx *a)
+/* x264_mb_analyse_inter_b16x16.  The lists are searched list 1 first; with try_skip (analysis without RD, subme >= 3, the direct prediction
+ * probed clean) the order is list 1 reference 0, list 0 reference 0, "both within 1 of the direct vectors -> B_SKIP" (returns 1), the rest of
+ * list 0, the rest of list 1 */
+static int analyse_inter_b16x16(actx *a, int try_skip)
 {
     x264o_encoder *e = a->e;
     int mvc[9][2];
+    int list1_skipped = 0;
+    int i_halfpel_thresh[2] = { 0x7fffffff, 0x7fffffff };
     a->partition = D_16x16;
     a->me16l[0].cost = a->me16l[1].cost = 0x7fffffff;
-    for (int l = 1; l >= 0; l--) {
-        int i_halfpel_thresh = 0x7fffffff;
-        int *p_halfpel_thresh = (a->b_early_terminate && a->nref_l[l] > 1) ? &i_halfpel_thresh : NULL;
-        for (int r = 0; r < a->nref_l[l]; r++) {
+    for (int l = 1; l >= 0;) {
+        int *p_halfpel_thresh = (a->b_early_terminate && a->nref_l[l] > 1) ? &i_halfpel_thresh[l] : NULL;
+        int r;
+        for (r = (list1_skipped && l == 1) ? 1 : 0; r < a->nref_l[l]; r++) {
+            if (try_skip && l == 1 && r > 0) { list1_skipped = 1; break; }
             me_t m;
             memset(&m, 0, sizeof(m));
             m.w = m.h = 16; m.list = l; m.ref = r; m.ref_cost = ref_cost_l(a, l, r);
@@ -1778,7 +1802,14 @@ static void analyse_inter_b16x16(actx *a)
             a->mvcl[l][r][0][0] = m.mv[0]; a->mvcl[l][r][0][1] = m.mv[1];
             int16_t (*mvr)[2] = mvr_of(e, l, r);
             mvr[a->mi][0] = (int16_t)m.mv[0]; mvr[a->mi][1] = (int16_t)m.mv[1];
+            if (r == 0 && try_skip) {          /* fast skip detection against the direct vector of the first 8x8 block */
+                const int dx = a->direct_ref[l] < 0 ? 0 : a->direct_mv[l][0][0], dy = a->direct_ref[l] < 0 ? 0 : a->direct_mv[l][0][1];
+                if (abs(a->me16l[l].mv[0] - dx) + abs(a->me16l[l].mv[1] - dy) > 1) try_skip = 0;
+                else if (!l) return 1;         /* (the skip itself was tested before) */
+            }
         }
+        if (list1_skipped && l == 1 && r == a->nref_l[1]) break;
+        if (list1_skipped && l == 0) l = 1; else l--;
     }
     /* the bi-predictive 16x16: both lists' winners averaged */
     a->bi16[0] = a->me16l[0]; a->bi16[1] = a->me16l[1];
@@ -1806,6 +1837,7 @@ static void analyse_inter_b16x16(actx *a)
     a->cost16x16bi += a->lambda * mb_b_cost_bi;
     a->me16l[0].cost += a->lambda * mb_b_cost_l0;
     a->me16l[1].cost += a->lambda * mb_b_cost_l1;
+    return 0;
 }
 
 /* mb_cache_mv_b8x8 / _b16x8 / _b8x16 without the mvd side: the block's part of both lists' motion cache */
@@ -1930,7 +1962,7 @@ static void analyse_inter_b_halves(actx *a, int horizontal, int i_best_satd)
         if (i_part_cost_bi + a->lambda * 1 < i_part_cost) { i_part_cost = i_part_cost_bi; part[i] = 2; }
         *p_cost += i_part_cost;
         /* early termination: the first half plus the estimate of the second */
-        if (a->b_early_terminate && !i && i_part_cost + cost_est[1] > i_best_satd * (16 + !!a->mbrd + (a->mbrd && e->cfg.psy_rd_q8 != 0)) / 16) { *p_cost = COST_MAX; return; }
+        if (a->b_early_terminate && !i && i_part_cost + cost_est[1] > i_best_satd * (16 + !!a->mbrd + (e->cfg.psy_rd_q8 != 0)) / 16) { *p_cost = COST_MAX; return; }
         cache_b_block(a, bx8, by8, w8, h8, part[i], lm[0], lm[1], 0);
     }
     *p_cost += a->lambda * mb_b16x8_cost[part[0] * 3 + part[1]];
@@ -2017,19 +2049,29 @@ static void macroblock_b(actx *a, x264gpu_mb *mb, int16_t *lv)
         mc_mb_b(e, a->mbx, a->mby, &t, rec, e->rs, pu, pv);
         for (int y = 0; y < 8; y++) for (int x = 0; x < 8; x++) { rec_uv[y * e->rs + 2 * x] = pu[y * 8 + x]; rec_uv[y * e->rs + 2 * x + 1] = pv[y * 8 + x]; }
     }
-    a->bskip_cost = rd_ssd_mb(a);
-    if (a->bskip_cost <= ((6 * a->lambda2 + 128) >> 8)) {
+    int b_skip = 0, try_skip = 0;
+    if (a->mbrd) { a->bskip_cost = rd_ssd_mb(a); b_skip = a->bskip_cost <= ((6 * a->lambda2 + 128) >> 8); }
+    else {
+        /* without RD: x264_macroblock_probe_bskip; from subme 3 on the skip also wants both 16x16 searches to land on the direct vectors */
+        try_skip = probe_bskip(a);
+        if (a->subme < 3) b_skip = try_skip;
+    }
+    if (b_skip) {
         for (int l = 0; l < 2; l++) for (int r = 0; r < a->nref_l[l]; r++) { int16_t (*mvr)[2] = mvr_of(e, l, r); mvr[mi][0] = mvr[mi][1] = 0; }
         fill_b_record(a, X264GPU_MB_B_SKIP, D_16x16, mb);
         return;                       /* the prediction is the reconstruction */
     }
     analyse_inter_direct(a);
-    analyse_inter_b16x16(a);
+    if (analyse_inter_b16x16(a, try_skip)) {
+        for (int l = 0; l < 2; l++) for (int r = 1; r < a->nref_l[l]; r++) { int16_t (*mvr)[2] = mvr_of(e, l, r); mvr[mi][0] = mvr[mi][1] = 0; }
+        fill_b_record(a, X264GPU_MB_B_SKIP, D_16x16, mb);
+        return;                       /* (the direct prediction is still in the reconstruction) */
+    }
     int use16 = 0, i_type = X264GPU_MB_B_INTER, i_partition = D_16x16, i_cost = a->me16l[0].cost;
     if (a->me16l[1].cost < i_cost) { i_cost = a->me16l[1].cost; use16 = 1; }
     if (a->cost16x16bi < i_cost) { i_cost = a->cost16x16bi; use16 = 2; }
     if (a->cost16x16direct < i_cost) { i_cost = a->cost16x16direct; i_type = X264GPU_MB_B_DIRECT; }
-    if (a->b_early_terminate && a->cost16x16direct <= i_cost * 33 / 32) {
+    if (a->mbrd && a->b_early_terminate && a->cost16x16direct <= i_cost * 33 / 32) {
         analyse_b_rd(a, i_cost, mb, lv);
         if (a->bskip_cost < a->rd16direct && a->bskip_cost < a->rd16bi && a->bskip_cost < a->rd16l[0] && a->bskip_cost < a->rd16l[1]) {
             rd_reset(a, mb, lv);
@@ -2072,6 +2114,60 @@ static void macroblock_b(actx *a, x264gpu_mb *mb, int16_t *lv)
             analyse_inter_b_halves(a, 1, i_cost);
             if (a->cost16x8bi < i_cost) { i_cost = a->cost16x8bi; i_type = X264GPU_MB_B_INTER; i_partition = D_16x8; }
         }
+    }
+    if (!a->mbrd) {
+        /* ---- analysis without RD (x264 below subme 7 in B slices): quarter-pel refinement of the winner's vectors, intra on SATD cost ---- */
+        if (a->subme) {
+            if (i_partition == D_16x16 && i_type == X264GPU_MB_B_INTER) {
+                a->partition = D_16x16;
+                a->me16l[0].cost -= a->lambda * mb_b_cost_l0; a->me16l[1].cost -= a->lambda * mb_b_cost_l1;
+                if (use16 == 0) { me_refine_qpel(a, &a->me16l[0]); i_cost = a->me16l[0].cost + a->lambda * mb_b_cost_l0; }
+                else if (use16 == 1) { me_refine_qpel(a, &a->me16l[1]); i_cost = a->me16l[1].cost + a->lambda * mb_b_cost_l1; }
+                else { me_refine_qpel(a, &a->bi16[0]); me_refine_qpel(a, &a->bi16[1]); }
+            } else if (i_partition == D_16x8) {
+                for (int i = 0; i < 2; i++) { if (a->part16x8[i] != 1) me_refine_qpel(a, &a->me16x8l[0][i]); if (a->part16x8[i] != 0) me_refine_qpel(a, &a->me16x8l[1][i]); }
+            } else if (i_partition == D_8x16) {
+                for (int i = 0; i < 2; i++) { if (a->part8x16[i] != 1) me_refine_qpel(a, &a->me8x16l[0][i]); if (a->part8x16[i] != 0) me_refine_qpel(a, &a->me8x16l[1][i]); }
+            } else if (i_partition == D_8x8) {
+                /* (x264 refines the unused vectors of a direct block as well; nothing reads them afterwards) */
+                for (int i = 0; i < 4; i++) { if (a->sub8[i] == 0 || a->sub8[i] == 2) me_refine_qpel(a, &a->me8l[0][i]); if (a->sub8[i] == 1 || a->sub8[i] == 2) me_refine_qpel(a, &a->me8l[1][i]); }
+            }
+        }
+        const int i_satd_inter0 = i_cost;
+        if (a->chroma_me) {
+            analyse_intra_chroma(a);
+            analyse_intra(a, i_satd_inter0 - a->satd_chroma);
+            a->satd_i16 += a->satd_chroma; a->satd_i8 += a->satd_chroma; a->satd_i4 += a->satd_chroma;
+        } else analyse_intra(a, i_satd_inter0);
+        int intra_type = -1;
+        if (a->satd_i16 < i_cost) { i_cost = a->satd_i16; intra_type = X264GPU_MB_I16x16; }
+        if (a->satd_i8 < i_cost) { i_cost = a->satd_i8; intra_type = X264GPU_MB_I8x8; }
+        if (a->satd_i4 < i_cost) { i_cost = a->satd_i4; intra_type = X264GPU_MB_I4x4; }
+        if (intra_type >= 0) {
+            mb->cost = i_cost;
+            e->b_trellis = e->cfg.cabac ? e->cfg.trellis & 63 : 0;
+            encode_intra_mb(a, intra_type, mb, lv);
+            e->b_trellis = 0;
+            e->intra_count++;
+            return;
+        }
+        if (a->subme >= 5 && i_type != X264GPU_MB_B_DIRECT) {
+            if (i_partition == D_16x16) { if (use16 == 2) me_refine_bidir_satd(a, &a->bi16[0], &a->bi16[1], e->bipred_weight[a->bi16[0].ref][a->bi16[1].ref]); }
+            else if (i_partition == D_16x8) { for (int i = 0; i < 2; i++) if (a->part16x8[i] == 2) me_refine_bidir_satd(a, &a->me16x8l[0][i], &a->me16x8l[1][i], e->bipred_weight[a->me16x8l[0][i].ref][a->me16x8l[1][i].ref]); }
+            else if (i_partition == D_8x16) { for (int i = 0; i < 2; i++) if (a->part8x16[i] == 2) me_refine_bidir_satd(a, &a->me8x16l[0][i], &a->me8x16l[1][i], e->bipred_weight[a->me8x16l[0][i].ref][a->me8x16l[1][i].ref]); }
+            else for (int i = 0; i < 4; i++) if (a->sub8[i] == 2) me_refine_bidir_satd(a, &a->me8l[0][i], &a->me8l[1][i], e->bipred_weight[a->me8l[0][i].ref][a->me8l[1][i].ref]);
+        }
+        {
+            const int bak = a->sub8[0];
+            if (i_partition == D_16x16 && i_type == X264GPU_MB_B_INTER) a->sub8[0] = use16;
+            fill_b_record(a, i_type, i_partition, mb);
+            a->sub8[0] = bak;
+        }
+        a->force_t8 = -1;              /* x264_mb_analyse_transform: SA8D against SATD of the prediction error */
+        e->b_trellis = e->cfg.cabac ? e->cfg.trellis & 63 : 0;
+        encode_inter_mb(a, mb, lv);
+        e->b_trellis = 0;
+        return;
     }
     int i_satd_inter = i_cost;
     /* RD: every candidate within reach, B_SKIP included */
@@ -2564,7 +2660,9 @@ static void macroblock_body(x264o_encoder *e, int mbx, int mby, actx *a)
     /* x264_macroblock_thread_init / mb_analyse_init: B slices analyse one sub-pel level down (6 -> 5, 8 -> 7); i_mbrd = (subme >= 6) + (subme >= 8) */
     if (e->slice_type == X264GPU_SLICE_B && (a->subme == 6 || a->subme == 8)) a->subme--;
     /* cfg.rd: bit 0 = RD mode decision; bits 1..5 = the sites of the RD refinement (x264's subme 8 = all five) — brought up on the device site by site */
-    a->mbrd = e->cfg.rd ? 1 + (e->cfg.cabac && a->subme >= 8 && (e->cfg.rd >> 1)) : 0; a->rd16x16 = COST_MAX; a->force_t8 = -1; a->cost8x8 = a->cost16x8 = a->cost8x16 = COST_MAX;
+    a->mbrd = e->cfg.rd ? 1 + (e->cfg.cabac && a->subme >= 8 && (e->cfg.rd >> 1)) : 0;
+    if (e->slice_type == X264GPU_SLICE_B && a->subme < 6) a->mbrd = 0;         /* (x264: i_mbrd from subme - 1 in B slices: no RD below --subme 7) */
+    a->rd16x16 = COST_MAX; a->force_t8 = -1; a->cost8x8 = a->cost16x8 = a->cost8x16 = COST_MAX;
     for (int i = 0; i < 7; i++) a->satd_i16_dir[i] = a->satd_chroma_dir[i] = COST_MAX;
     for (int i = 0; i < 4; i++) for (int m = 0; m < 12; m++) a->satd_i8_dir[i][m] = COST_MAX;
     a->lambda2 = x264o_lambda2(a->qp);

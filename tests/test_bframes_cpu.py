@@ -44,6 +44,13 @@ def run(w, h, types, seed, bframes=3, pyramid=1, weightp=0, pics_out=None, weigh
     (96, 160, "IBPBBP", 16, dict(slices=4, slices_plain=1, refs=2)),
     (176, 144, "IBBPBP", 19, dict(partitions=0x707)),                             # p8x8 without b8x8
     (176, 144, "IBBP", 20, dict(partitions=0xf06)),                               # b8x8 without p8x8
+    # B analysis without RD (x264 below --subme 7: probe_bskip, the fast-skip search order, me_refine_qpel of the winner, SA8D/SATD transform choice)
+    (176, 144, "IBBBPBBP", 21, dict(rd=0, trellis=0, subme=5, psy_rd_q8=0)),      # preset fast's level minus one: subme 5
+    (176, 144, "IBBPBP", 22, dict(rd=1, subme=6)),                                # --subme 6: RD in I/P slices, B slices one level down without it
+    (128, 96, "IBBPBBP", 23, dict(rd=0, trellis=0, subme=2, psy_rd_q8=0, refs=1, partitions=0x303, mixed_refs=0, weightb=0)),      # veryfast: immediate skip on the probe
+    (176, 144, "IBBBP", 24, dict(rd=0, trellis=0, subme=4, psy_rd_q8=0, refs=2, mixed_refs=0)),                                   # faster
+    (96, 80, "IBPBBP", 25, dict(rd=0, trellis=0, subme=1, psy_rd_q8=0, refs=1, partitions=0x303, mixed_refs=0, weightb=0, dct8x8=0)),      # superfast
+    (176, 144, "IBBP", 26, dict(rd=0, trellis=0, subme=3, psy_rd_q8=0, me_method=2)),
 ])
 def test_b_pictures_decode_to_the_encoders_reconstruction(w, h, types, seed, over):
     run(w, h, types, seed, **over)

@@ -1295,16 +1295,14 @@ __device__ __forceinline__ void mb_store_chroma(uint8_t *ruv, int rs, int lane, 
 }
 
 // ------------------------------------------------------------------------------------------------
-// x264_macroblock_probe_pskip (oracle probe_pskip): would the macroblock code to nothing at the skip vector?
+// x264_macroblock_probe_skip_internal (oracle probe_skip_pred): would the residual of this prediction code to nothing?  pred: this lane's luma row
+// (Z layout); cenc / cpred: lanes 0..31 = chroma plane (lane >> 4) & 1, 4x4 block (lane >> 2) & 3, row lane & 3
 // ------------------------------------------------------------------------------------------------
-__device__ __forceinline__ bool mb_probe_pskip(const EncK &k, const MbCtx &c, uint32_t cz, int pmx, int pmy, const Q4 &ql, const Q4 &qc)
+__device__ __forceinline__ bool mb_probe_skip_pred(const MbCtx &c, uint32_t cz, uint32_t pred, uint32_t cenc, uint32_t cpred, const Q4 &ql, const Q4 &qc)
 {
-    const int lane = c.lane, j = lane & 3, zx = z_x0(lane), zy = z_y(lane);
-    const int mvx = clampi(pmx, c.mvmin0, c.mvmax0), mvy = clampi(pmy, c.mvmin1, c.mvmax1);
+    const int lane = c.lane, j = lane & 3;
     bool ok;
     {
-        uint32_t pred = mc_luma_row4(ref_plane00(k, c.s, 0), k.plane_bytes, k.rs, c.px + zx, c.py + zy, mvx, mvy);
-        if (k.wp_any && (k.wl0[0] >> 24)) pred = wp4(pred, k.wl0[0]);
         int e[4], p[4], v[4];
         unpack4(cz, e); unpack4(pred, p);
 #pragma unroll
@@ -1317,12 +1315,7 @@ __device__ __forceinline__ bool mb_probe_pskip(const EncK &k, const MbCtx &c, ui
         ok = wave_sum(j == 0 ? sc : 0) < 6;
     }
     {
-        const int pl = (lane >> 4) & 1, ci = (lane >> 2) & 3, cx0 = (ci & 1) * 4, cyy = (ci >> 1) * 4 + j;
         const bool act = lane < 32;
-        uint32_t pu, pv;
-        mc_chroma_row4(ref_chroma00(k, c.s, 0), k.rs, c.mbx * 8 + cx0, c.mby * 8 + cyy, mvx, mvy, pu, pv);
-        const uint2 fe = *(const uint2 *)(c.fuv + (size_t)cyy * k.fs + 2 * cx0);
-        const uint32_t cenc = nv12_pick(fe.x, fe.y, pl), cpred = pl ? pv : pu;
         int e[4], p[4], v[4];
         unpack4(cenc, e); unpack4(cpred, p);
 #pragma unroll
@@ -1349,6 +1342,20 @@ __device__ __forceinline__ bool mb_probe_pskip(const EncK &k, const MbCtx &c, ui
         ok = ok && !__builtin_amdgcn_readlane((int)fail, 0) && !__builtin_amdgcn_readlane((int)fail, 16);
     }
     return ok;
+}
+
+// x264_macroblock_probe_pskip (oracle probe_pskip): would the macroblock code to nothing at the skip vector?
+__device__ __forceinline__ bool mb_probe_pskip(const EncK &k, const MbCtx &c, uint32_t cz, int pmx, int pmy, const Q4 &ql, const Q4 &qc)
+{
+    const int lane = c.lane, j = lane & 3, zx = z_x0(lane), zy = z_y(lane);
+    const int mvx = clampi(pmx, c.mvmin0, c.mvmax0), mvy = clampi(pmy, c.mvmin1, c.mvmax1);
+    uint32_t pred = mc_luma_row4(ref_plane00(k, c.s, 0), k.plane_bytes, k.rs, c.px + zx, c.py + zy, mvx, mvy);
+    if (k.wp_any && (k.wl0[0] >> 24)) pred = wp4(pred, k.wl0[0]);
+    const int pl = (lane >> 4) & 1, ci = (lane >> 2) & 3, cx0 = (ci & 1) * 4, cyy = (ci >> 1) * 4 + j;
+    uint32_t pu, pv;
+    mc_chroma_row4(ref_chroma00(k, c.s, 0), k.rs, c.mbx * 8 + cx0, c.mby * 8 + cyy, mvx, mvy, pu, pv);
+    const uint2 fe = *(const uint2 *)(c.fuv + (size_t)cyy * k.fs + 2 * cx0);
+    return mb_probe_skip_pred(c, cz, pred, nv12_pick(fe.x, fe.y, pl), pl ? pv : pu, ql, qc);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1412,7 +1419,7 @@ __device__ __forceinline__ void b_predict(const EncK &k, const MbCtx &c, const B
 template <int M, int ME, bool PS, int RD = 0, bool BS = false>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(MB_WAVES_PER_EU, 4))) void k_mb_slice(EncK k)
 {
-    static_assert(!BS || (PS && RD >= 2), "B slices: RD sessions with CABAC");
+    static_assert(!BS || (PS && (RD >= 2 || RD == 0)), "B slices: RD sessions with CABAC, or the analysis without RD");
     __shared__ __attribute__((aligned(16))) MbLds<M> L;
     // x264_me_refine_bidir: bit set of the vector quadruples already costed (4096 bits).  It lives in the chroma sub-pel staging area, which only
     // holds data DURING a search: a buffer of its own made the B instantiations' LDS 20 992 B a wavefront — seven instead of eight wavefronts a CU,

@@ -1,0 +1,10 @@
+// mb_slice_b0_hex.hip — the macroblock-loop kernel (k_mb.cuh) instantiated for B slices analysed without RD (x264 below --subme 7 in B slices:
+// probe_bskip, SATD decisions, me_refine_qpel of the winner; k_mb_b.inc's RD == 0 branches), --me hex.
+#include "k_mb.cuh"
+
+namespace x264gpu {
+void launch_mb_slice_b0_hex(const EncK &k, int streams, hipStream_t st)
+{
+    hipLaunchKernelGGL((k_mb_slice<2, 1, true, 0, true>), dim3(streams, k.slices > 1 ? k.slices : 1), dim3(64), 0, st, k);
+}
+}  // namespace x264gpu
