@@ -2821,7 +2821,7 @@ void x264o_macroblock(x264o_encoder *e, int mbx, int mby)
     actx A;
     /* --trellis 2 (cfg.trellis bit 6): h->mb.b_trellis is on for the whole analysis of RD sessions too — the block encodes inside the intra
      * analysis and every RD candidate are quantised by the search (x264 mb_analyse_init: b_trellis = i_trellis > 1 && i_mbrd) */
-    e->b_trellis = (e->cfg.trellis & 64) && e->cfg.rd && e->cfg.cabac ? e->cfg.trellis & 63 : 0;
+    e->b_trellis = (e->cfg.trellis & 64) && e->cfg.rd && e->cfg.cabac && !(e->slice_type == X264GPU_SLICE_B && e->cfg.subme < 7) ? e->cfg.trellis & 63 : 0;      /* (B slices below --subme 7: i_mbrd 0) */
     macroblock_body(e, mbx, mby, &A);
     e->b_trellis = 0;
     const x264gpu_mb *mb = &e->mbs[mby * e->mbw + mbx];

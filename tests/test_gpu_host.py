@@ -872,14 +872,14 @@ def test_random_b_session_mixes_stay_decodable(gpu):
 @pytest.mark.parametrize("preset", ["ultrafast", "superfast", "veryfast", "faster", "fast", "medium", "slow", "slower", "veryslow", "placebo"])
 def test_every_preset_codes_a_decodable_stream(gpu, preset):
     """x264_param_default_preset(name) as the driver calls it (codec.c:1463) for each of x264's ten presets, rate control left at the driver's default
-    (CRF 23): the session opens, reports what it runs (B pictures from medium up: x264 analyses B slices without RD below subme 7; bframes 8 / 16 and
+    (CRF 23): the session opens, reports what it runs (B pictures from superfast up — below subme 7 their slices are analysed without RD; bframes 8 / 16 and
     --b-adapt 2 in veryslow / placebo), returns every picture once and the stream decodes to the source"""
     w, h, n = 176, 144, 36
     frames = synth_frames(w, h, n, seed=31, scene_len=23)
     h_, eff = open_encoder(w, h, {"bframes": {"ultrafast": 0, "veryslow": 8, "placebo": 16}.get(preset, 3), "weightp": {"ultrafast": 0, "superfast": 1, "veryfast": 1, "faster": 1, "fast": 1}.get(preset, 2)},
                            profile=None, preset=preset.encode())
-    if preset in ("medium", "slow", "slower", "veryslow", "placebo"):
-        assert eff.i_bframe == {"veryslow": 8, "placebo": 16}.get(preset, 3) and eff.i_bframe_adaptive == (1 if preset in ("medium", "slow") else 2)
+    if preset != "ultrafast":
+        assert eff.i_bframe == {"veryslow": 8, "placebo": 16}.get(preset, 3) and eff.i_bframe_adaptive == (2 if preset in ("slower", "veryslow", "placebo") else 1)
     else:
         assert eff.i_bframe == 0
     # RD refinement (subme 8) runs from slow up (umh); placebo's tesa maps to esa, where it does not (subme 7)
@@ -896,6 +896,9 @@ def test_every_preset_codes_a_decodable_stream(gpu, preset):
 @pytest.mark.parametrize("opts", [
     {"subme": 8, "me": "umh", "trellis": 2, "ref": 5, "bframes": 3, "b-adapt": 2, "rc-lookahead": 10, "keyint": 12, "qp": 24},          # preset slow's toolset (direct stays spatial)
     {"subme": 8, "me": "hex", "trellis": 1, "ref": 2, "bframes": 0, "keyint": 9, "crf": 25, "rc-lookahead": 4},
+    {"subme": 6, "me": "hex", "trellis": 1, "ref": 2, "bframes": 3, "b-adapt": 1, "rc-lookahead": 8, "keyint": 12, "crf": 24, "mixed-refs": 0},      # preset fast: B slices without RD, trellis in their final encode
+    {"subme": 4, "me": "hex", "trellis": 0, "ref": 2, "bframes": 3, "b-adapt": 1, "rc-lookahead": 6, "keyint": 12, "qp": 25, "mixed-refs": 0},       # preset faster
+    {"subme": 2, "me": "hex", "trellis": 0, "ref": 1, "bframes": 3, "b-adapt": 1, "rc-lookahead": 4, "keyint": 10, "qp": 26, "mixed-refs": 0},
 ])
 def test_rd_refinement_session_equals_the_checker(gpu, tmp_path, opts):
     """a --subme 8 session (RD refinement of the P partitions' vectors and of the intra modes, B slices one level down) through x264_encoder_encode on

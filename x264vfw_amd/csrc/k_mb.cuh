@@ -1420,6 +1420,7 @@ template <int M, int ME, bool PS, int RD = 0, bool BS = false>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(MB_WAVES_PER_EU, 4))) void k_mb_slice(EncK k)
 {
     static_assert(!BS || (PS && (RD >= 2 || RD == 0)), "B slices: RD sessions with CABAC, or the analysis without RD");
+    static_assert(RD != 7 || BS, "RD 7: B slices only");
     __shared__ __attribute__((aligned(16))) MbLds<M> L;
     // x264_me_refine_bidir: bit set of the vector quadruples already costed (4096 bits).  It lives in the chroma sub-pel staging area, which only
     // holds data DURING a search: a buffer of its own made the B instantiations' LDS 20 992 B a wavefront — seven instead of eight wavefronts a CU,
@@ -1446,7 +1447,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(MB_WAVES_PER
     constexpr bool pslice = PS;
     constexpr bool TRL = RD >= 3;               // trellis sites compiled in
     constexpr bool TRL2 = RD == 4 || RD == 6;   // --trellis 2: the search also inside the intra analysis and in every RD candidate                 // I slices run their own instantiation (no search code, a fraction of the registers)
-    constexpr bool REF = RD >= 5;               // RD refinement of the chosen type (x264 subme >= 8, i_mbrd 2; k_mb_refine.inc): RD 5 = 3 + refinement, 6 = 4 + refinement
+    constexpr bool NORD = RD == 0 || RD == 7;   // B slices analysed without RD (x264 below --subme 7); RD 7 = that + the slice's CABAC state and the trellis quantiser in the final encode (--subme 6 --trellis 1 / 2)
+    constexpr bool REF = RD == 5 || RD == 6;               // RD refinement of the chosen type (x264 subme >= 8, i_mbrd 2; k_mb_refine.inc): RD 5 = 3 + refinement, 6 = 4 + refinement
     const int j4 = lane & 3, zx = z_x0(lane), zy = z_y(lane);
     int intra_count = intra_prior, cost_qp = -1;          // intra macroblocks so far: of the slice (slice threads), of the picture (--slices N)
     // RD instantiation: levels of the candidate being costed (and of the final macroblock, before they go out), total_coeff of the left / top

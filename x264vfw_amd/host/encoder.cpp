@@ -360,7 +360,7 @@ x264_t *x264_encoder_open(x264_param_t *param)
     if (!p.i_timebase_num || !p.i_timebase_den) { p.i_timebase_num = p.i_fps_den; p.i_timebase_den = p.i_fps_num; }
 
     // ---- effective parameters: what this round's pipeline implements (reported back via encoder_parameters) ----
-    // B pictures: on the device in RD sessions with CABAC (subme >= 6), one GOP in flight (settled below, once those are known)
+    // B pictures: on the device in CABAC sessions, one GOP in flight (settled below, once those are known)
     p.i_bframe = clampi(p.i_bframe, 0, 16);
     if (p.i_frame_reference > 5) { xlog(&p, X264_LOG_INFO, "ref %d -> 5 (DPB of the MI355X path holds up to 5 references)\n", p.i_frame_reference); p.i_frame_reference = 5; }
     if (p.i_frame_reference < 1) p.i_frame_reference = 1;
@@ -434,7 +434,8 @@ x264_t *x264_encoder_open(x264_param_t *param)
     } else if (!p.b_sliced_threads) p.i_slice_count = 0;
     p.i_threads = clampi(p.i_threads, 1, 256);                 // --threads G: GOPs coded in lock-step (1 = no delay)
     if (p.i_bframe) {
-        const char *why = !p.b_cabac ? "CABAC" : p.analyse.i_subpel_refine < 7 ? "subme >= 7 (x264 analyses B slices one sub-pel level down: at subme 6 without RD, which this path does not have for B slices)" :
+        // (below --subme 7 x264 analyses B slices without RD: k_mb_b.inc's NORD flow)
+        const char *why = !p.b_cabac ? "CABAC" :
                           p.i_threads > 1 ? "threads 1" : p.i_keyint_max < 2 ? "keyint > 1" : (p.rc.i_rc_method == X264_RC_ABR && (p.rc.b_stat_read || p.rc.i_bitrate <= 0)) ? "constant-quantiser, CRF or single-pass ABR rate control" : nullptr;
         if (why) { xlog(&p, X264_LOG_WARNING, "B-frames need %s in the MI355X path: bframes 0\n", why); p.i_bframe = 0; }
     }
