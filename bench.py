@@ -245,12 +245,12 @@ def synth_batch(torch, streams, frames, w, h, seed, device, smooth=False, scene_
 
 def pmc_evidence(kernel_substr, avg_launch_ms, streams_per_launch, content):
     """HBM bytes per launch of the dominant kernel and its VALU instruction count from the committed rocprofv3 --pmc passes of this
-    command (tools/profile_round.sh -> profiles/r03_pmc_per_launch.json; FETCH_SIZE and WRITE_SIZE in separate passes, KB -> bytes,
+    command (tools/profile_round.sh -> profiles/r04_pmc_per_launch.json; FETCH_SIZE and WRITE_SIZE in separate passes, KB -> bytes,
     read side doubled as MI355X_MICROARCH.md prescribes for gfx950).  The macroblock loop runs as three instantiations (I, P, B slices): the
     profile's entry `_mb_loop_timed_window` is their average over the launches of the timed window, the same launches bench.py's own event
     timing averages.  PMC counters cannot be read from inside an un-profiled run, so these are the profile's figures scaled per stream; null
     without a profile of this workload."""
-    path = os.path.join(ROOT, "profiles", "r03_pmc_per_launch.json")
+    path = os.path.join(ROOT, "profiles", "r04_pmc_per_launch.json")
     if not os.path.exists(path):
         return None, None
     tab = json.load(open(path))
@@ -267,7 +267,7 @@ def pmc_evidence(kernel_substr, avg_launch_ms, streams_per_launch, content):
         simds, clk = 256 * 4, 2.4e9                      # a wave64 VALU op occupies its SIMD16 for 4 cycles
         insts = t["SQ_INSTS_VALU"] * scale
         valu = {"insts_per_launch": int(insts), "insts_per_macroblock": round(t["SQ_INSTS_VALU"] / t.get("macroblocks_per_launch", 1), 1) if t.get("macroblocks_per_launch") else None,
-                "issue_util": round(insts * 4 / (simds * clk * avg_launch_ms * 1e-3), 4), "source": "profiles/r03_pmc_per_launch.json"}
+                "issue_util": round(insts * 4 / (simds * clk * avg_launch_ms * 1e-3), 4), "source": "profiles/r04_pmc_per_launch.json"}
     return traffic, valu
 
 

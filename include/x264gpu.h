@@ -253,6 +253,9 @@ typedef struct x264gpu_pic {
     int blind_dupe;
     int qp_frac_q8;           /* rate-controlled sessions: the picture's quantiser is qp + qp_frac_q8 / 256 (x264 rc->qpm, a float); a macroblock's quantiser
                                * under AQ / macroblock-tree is round(that + its offset) — one rounding, as x264_ratecontrol_mb_qp has it.  -128 .. 127, 0 otherwise */
+    /* ... and the explicit chroma weights of list-0 index i (x264_weights_analyse weights the chroma planes of a fade once luma got a weight):
+     * plane 0 = Cb, 1 = Cr, one denominator for both (chroma_log2_weight_denom); same formula as luma */
+    struct { int8_t on[2], denom, pad; int16_t scale[2], offset[2]; } wc0[X264GPU_MAX_LIST];
 } x264gpu_pic;
 
 int  x264gpu_encoder_create(x264gpu_encoder **enc, const x264gpu_config *cfg);

@@ -232,6 +232,10 @@ static int chroma_satd(const sctx *s, int mx, int my)
     for (int y = 0; y < m->h / 2; y++)
         for (int x = 0; x < m->w / 2; x++) { fu[y * 8 + x] = fuv[y * e->fs + 2 * x]; fv[y * 8 + x] = fuv[y * e->fs + 2 * x + 1]; }
     x264o_mc_chroma(pu, pv, 8, chroma_plane(e, s->refslot), e->rs, a->mbx * 8 + m->ox / 2, a->mby * 8 + m->oy / 2, mx, my, m->w / 2, m->h / 2);
+    if (e->slice_type == X264GPU_SLICE_P && m->list == 0) {          /* m->weight[1] / [2] */
+        if (e->wc0[m->ref].on[0]) x264o_mc_weight(pu, 8, pu, 8, m->w / 2, m->h / 2, e->wc0[m->ref].scale[0], e->wc0[m->ref].denom, e->wc0[m->ref].offset[0]);
+        if (e->wc0[m->ref].on[1]) x264o_mc_weight(pv, 8, pv, 8, m->w / 2, m->h / 2, e->wc0[m->ref].scale[1], e->wc0[m->ref].denom, e->wc0[m->ref].offset[1]);
+    }
     return mbcmp(a, fu, 8, pu, 8, m->w / 2, m->h / 2) + mbcmp(a, fv, 8, pv, 8, m->w / 2, m->h / 2);
 }
 
@@ -803,11 +807,13 @@ static void mc_mb_b(x264o_encoder *e, int mbx, int mby, const x264gpu_mb *mb, pi
     }
 }
 
-/* x264_mb_mc_0xywh of a P slice: list-0 index r with its explicit luma weight (h->sh.weight[r][0]; chroma weights are not used here) */
+/* x264_mb_mc_0xywh of a P slice: list-0 index r with its explicit weights (h->sh.weight[r][0..2]) */
 static void mc_mb_p(x264o_encoder *e, int mbx, int mby, int bx, int by, int w, int h, int r, int mvx, int mvy, pixel *dy, int sy, pixel *du, pixel *dv, int sc)
 {
     mc_mb(e, mbx, mby, bx, by, w, h, ref_slot(e, r), mvx, mvy, dy, sy, du, dv, sc);
     if (e->wl0[r].on) x264o_mc_weight(dy + by * sy + bx, sy, dy + by * sy + bx, sy, w, h, e->wl0[r].scale, e->wl0[r].denom, e->wl0[r].offset);
+    if (e->wc0[r].on[0]) x264o_mc_weight(du + (by / 2) * sc + bx / 2, sc, du + (by / 2) * sc + bx / 2, sc, w / 2, h / 2, e->wc0[r].scale[0], e->wc0[r].denom, e->wc0[r].offset[0]);
+    if (e->wc0[r].on[1]) x264o_mc_weight(dv + (by / 2) * sc + bx / 2, sc, dv + (by / 2) * sc + bx / 2, sc, w / 2, h / 2, e->wc0[r].scale[1], e->wc0[r].denom, e->wc0[r].offset[1]);
 }
 
 /* x264_macroblock_probe_skip_internal: would the residual of the prediction (py stride 16, pu / pv stride 8) code to nothing? */
@@ -2398,6 +2404,8 @@ static void me_refine_qpel_rd(actx *a, me_t *m, int i8, int t8, int *done, x264g
             } else { \
                 pixel pu_[64], pv_[64]; \
                 x264o_mc_chroma(pu_, pv_, 8, chroma_plane(e, S.refslot), e->rs, a->mbx * 8 + m->ox / 2, a->mby * 8 + m->oy / 2, mx, my, m->w / 2, m->h / 2); \
+                if (e->wc0[m->ref].on[0]) x264o_mc_weight(pu_, 8, pu_, 8, m->w / 2, m->h / 2, e->wc0[m->ref].scale[0], e->wc0[m->ref].denom, e->wc0[m->ref].offset[0]); \
+                if (e->wc0[m->ref].on[1]) x264o_mc_weight(pv_, 8, pv_, 8, m->w / 2, m->h / 2, e->wc0[m->ref].scale[1], e->wc0[m->ref].denom, e->wc0[m->ref].offset[1]); \
                 for (int y_ = 0; y_ < m->h / 2; y_++) for (int x_ = 0; x_ < m->w / 2; x_++) { ruv[y_ * e->rs + 2 * x_] = pu_[y_ * 8 + x_]; ruv[y_ * e->rs + 2 * x_ + 1] = pv_[y_ * 8 + x_]; } \
                 cost_ = rd_cost_part(a, i8, psize, *done, mb, lv); \
             } \

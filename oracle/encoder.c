@@ -292,6 +292,11 @@ int x264o_encoder_encode_pic(x264o_encoder *e, const uint8_t *i420, const x264gp
     for (int r = 0; r < X264GPU_MAX_LIST; r++) {
         const int on = slice_type == X264GPU_SLICE_P && r < e->nref && pic->wl0[r].on;
         e->wl0[r].on = on; e->wl0[r].denom = on ? pic->wl0[r].denom : 0; e->wl0[r].scale = on ? pic->wl0[r].scale : 1; e->wl0[r].offset = on ? pic->wl0[r].offset : 0;
+        for (int c = 0; c < 2; c++) {
+            const int con = slice_type == X264GPU_SLICE_P && r < e->nref && pic->wc0[r].on[c];
+            e->wc0[r].on[c] = con; e->wc0[r].scale[c] = con ? pic->wc0[r].scale[c] : 1; e->wc0[r].offset[c] = con ? pic->wc0[r].offset[c] : 0;
+        }
+        e->wc0[r].denom = (e->wc0[r].on[0] || e->wc0[r].on[1]) ? pic->wc0[r].denom : 0;
     }
     if (slice_type == X264GPU_SLICE_P && pic->blind_dupe > 0 && pic->blind_dupe < e->nref) e->blind_dupe = pic->blind_dupe;
     if (slice_type == X264GPU_SLICE_B) bipred_init(e);

@@ -33,6 +33,7 @@ struct x264o_encoder {
     int keep;                    /* the picture being coded will be a reference */
     /* --weightp: explicit luma weights of list 0's indices and x264's blind duplicate of reference 0 (h->mb.ref_blind_dupe; -1 = none) */
     struct { int on, denom, scale, offset; } wl0[X264GPU_MAX_LIST];
+    struct { int on[2], denom, scale[2], offset[2]; } wc0[X264GPU_MAX_LIST];       /* ... and the chroma weights (Cb, Cr; one denominator) */
     int blind_dupe;
     int row0, row1;              /* macroblock rows [row0, row1) of the slice being coded (x264 slice threads: cfg.slices per picture) */
     int cur;                     /* DPB slot being reconstructed */

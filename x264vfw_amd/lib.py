@@ -50,8 +50,10 @@ class Pic(C.Structure):
     """Mirror of struct x264gpu_pic (picture control of x264gpu_encode_pictures)."""
     class W(C.Structure):
         _fields_ = [("on", C.c_int8), ("denom", C.c_int8), ("scale", C.c_int16), ("offset", C.c_int16)]
+    class WC(C.Structure):
+        _fields_ = [("on", C.c_int8 * 2), ("denom", C.c_int8), ("pad", C.c_int8), ("scale", C.c_int16 * 2), ("offset", C.c_int16 * 2)]
     _fields_ = [("slice_type", C.c_int), ("qp", C.c_int), ("poc", C.c_int), ("dst", C.c_int), ("keep", C.c_int), ("nref", C.c_int * 2),
-                ("slot", (C.c_int8 * 8) * 2), ("wl0", W * 8), ("blind_dupe", C.c_int), ("qp_frac_q8", C.c_int)]
+                ("slot", (C.c_int8 * 8) * 2), ("wl0", W * 8), ("blind_dupe", C.c_int), ("qp_frac_q8", C.c_int), ("wc0", WC * 8)]
 
 
 def make_pic(slice_type, qp, poc, dst, keep, l0=(), l1=()):
