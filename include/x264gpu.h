@@ -346,6 +346,15 @@ const uint16_t *x264gpu_slicetype_lowres_costs(x264gpu_slicetype *st, int slot, 
  * when that search has run.  The picture's intra costs must exist (any x264gpu_slicetype_frame_cost of it).  The analysis around them is the caller's. */
 int  x264gpu_slicetype_pixel_stats(x264gpu_slicetype *st, int slot, const uint8_t *d_i420, uint64_t *h_out, void *stream);
 int  x264gpu_slicetype_weight_cost(x264gpu_slicetype *st, int slot_fenc, int slot_ref, int dist, int on, int scale, int denom, int offset, int64_t *h_cost, void *stream);
+/* ... and the chroma planes' part of x264_weights_analyse (it weights them once luma got a weight): the statistics h_out[streams][4] = { sum Cb,
+ * ssd Cb, sum Cr, ssd Cr } over the mod-16 expanded picture's chroma, and weight_cost_chroma of plane 1 (Cb) / 2 (Cr) — the full-resolution chroma
+ * plane of the source picture d_i420_fenc against the reference picture's d_i420_ref (both raw I420, `streams` of them), the reference
+ * motion-compensated per 8x8 chroma block by the half-resolution vectors of (slot_fenc, list 0, dist) when that search has run, weighted
+ * (on = 0: not); per block |sum of differences| + the slice-header bits of the weight ([x264-upstream] encoder/slicetype.c weight_cost_init_chroma,
+ * weight_cost_chroma, pixel_asd8) */
+int  x264gpu_slicetype_chroma_stats(x264gpu_slicetype *st, int slot, const uint8_t *d_i420, uint64_t *h_out, void *stream);
+int  x264gpu_slicetype_weight_cost_chroma(x264gpu_slicetype *st, int slot_fenc, const uint8_t *d_i420_fenc, const uint8_t *d_i420_ref, int dist, int plane,
+                                          int on, int scale, int denom, int offset, int64_t *h_cost, void *stream);
 /* macroblock-tree through B pictures: the building blocks of x264's macroblock_tree (the caller walks the pictures of the lookahead as x264 does:
  * clear the propagate cost of a non-B picture, x264gpu_slicetype_frame_cost of a triple, _propagate it, ..., _finish the picture about to be coded).
  * AQ offsets (x264_adaptive_quant_frame; x264gpu_lookahead_aq_offsets) weight the costs (i_inv_qscale_factor) and are the base of the result;

@@ -84,6 +84,7 @@ struct Decoder {
     std::vector<int> pending_mmco;           // picture numbers to mark unused once the picture is complete
     std::vector<MbInfo> slot_mb[8];          // motion of every kept picture (co-located blocks of direct prediction)
     std::vector<int> frame_pocs;             // POC of every output picture (decoding order)
+    int weighted_slices[2] = { 0, 0 };       // diagnostics: P slices that carried an explicit luma weight / a chroma weight
     int next_mb = 0, slice_no = 0, pic_disable = 0, pic_a = 0, pic_b = 0;      // slices of the picture being decoded
     std::vector<int> mb_bits;        // CAVLC: bits of the macroblock layer of every macroblock, picture after picture (0 for skipped ones)
     int ref_slot(int r) const { return list_slot[0][r]; }
@@ -1208,15 +1209,17 @@ bool decode_nal(Decoder &d, const uint8_t *nal, size_t n)
         if (d.weighted_pred && st == 0) {                   // pred_weight_table()
             d.luma_logwd = (int)br.ue(); d.chroma_logwd = (int)br.ue();
             if (d.luma_logwd > 7 || d.chroma_logwd > 7) return reject(__LINE__);
+            bool any_l = false, any_c = false;
             for (int i = 0; i < d.nref_active; i++) {
                 d.wp[i].lw = 1 << d.luma_logwd; d.wp[i].lo = 0;
                 d.wp[i].cw[0] = d.wp[i].cw[1] = 1 << d.chroma_logwd; d.wp[i].co[0] = d.wp[i].co[1] = 0;
                 if (br.get1()) {
-                    d.wp[i].lw = br.se(); d.wp[i].lo = br.se();
+                    d.wp[i].lw = br.se(); d.wp[i].lo = br.se(); any_l = true;
                     if (d.wp[i].lw < -128 || d.wp[i].lw > 127 || d.wp[i].lo < -128 || d.wp[i].lo > 127) return reject(__LINE__);      // (an inferred weight is 2^logWD: up to 128)
                 }
-                if (br.get1()) for (int c = 0; c < 2; c++) { d.wp[i].cw[c] = br.se(); d.wp[i].co[c] = br.se(); }
+                if (br.get1()) { for (int c = 0; c < 2; c++) { d.wp[i].cw[c] = br.se(); d.wp[i].co[c] = br.se(); } any_c = true; }
             }
+            d.weighted_slices[0] += any_l; d.weighted_slices[1] += any_c;
         }
         if (nal_ref_idc) {
             if (type == 5) { br.get1(); br.get1(); }
@@ -1269,6 +1272,9 @@ int x264o_h264_last_mb_bits(int *out, int cap)
 }
 
 static std::vector<int> g_pocs;
+static int g_weighted[2];
+// P slices of the last x264o_h264_decode call that carried an explicit luma weight (out[0]) / chroma weights (out[1])
+extern "C" void x264o_h264_last_weighted(int *out) { out[0] = g_weighted[0]; out[1] = g_weighted[1]; }
 // POC of every picture of the last x264o_h264_decode call, in decoding order (the pictures are returned in that order)
 int x264o_h264_last_pocs(int *out, int cap)
 {
@@ -1295,7 +1301,7 @@ int x264o_h264_decode(const uint8_t *data, size_t n, uint8_t *out, size_t out_ca
     }
     if (width) *width = d.width;
     if (height) *height = d.height;
-    g_mb_bits = d.mb_bits; g_pocs = d.frame_pocs;
+    g_mb_bits = d.mb_bits; g_pocs = d.frame_pocs; g_weighted[0] = d.weighted_slices[0]; g_weighted[1] = d.weighted_slices[1];
     size_t fsz = (size_t)d.width * d.height * 3 / 2, off = 0;
     for (auto &f : d.frames) { if (off + fsz <= out_cap) memcpy(out + off, f.data(), fsz); off += fsz; }
     return (int)d.frames.size();

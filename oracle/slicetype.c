@@ -402,6 +402,53 @@ void x264o_slicetype_pixel_stats(x264o_slicetype *st, int slot, const uint8_t *i
     const uint64_t n = (uint64_t)cw * ch;
     out[0] = sum; out[1] = sqr - (sum * sum + n / 2) / n;
 }
+/* ... of the chroma planes: out = { sum Cb, ssd Cb, sum Cr, ssd Cr } (i_pixel_sum / i_pixel_ssd[1..2]) over the mod-16 expanded picture's chroma */
+void x264o_slicetype_chroma_stats(x264o_slicetype *st, int slot, const uint8_t *i420, uint64_t out[4])
+{
+    (void)slot;
+    const int cw = st->bw * 8, ch = st->bh * 8, pw = st->w / 2, ph = st->h / 2;
+    for (int c = 0; c < 2; c++) {
+        const uint8_t *pl = i420 + (size_t)st->w * st->h + (size_t)c * pw * ph;
+        uint64_t sum = 0, sqr = 0;
+        for (int y = 0; y < ch; y++)
+            for (int x = 0; x < cw; x++) { const uint32_t p = pl[(size_t)clampi(y, 0, ph - 1) * pw + clampi(x, 0, pw - 1)]; sum += p; sqr += p * p; }
+        const uint64_t n = (uint64_t)cw * ch;
+        out[2 * c] = sum; out[2 * c + 1] = sqr - (sum * sum + n / 2) / n;
+    }
+}
+/* weight_cost_chroma of plane 1 (Cb) / 2 (Cr): the full-resolution chroma plane of the SOURCE picture against the reference's, the reference
+ * motion-compensated 8x8 block by 8x8 block with the lookahead's vectors of (sf, list 0, dist) when that search has run (weight_cost_init_chroma:
+ * mc_chroma with the half-resolution quarter-sample vector as it is), weighted; per block |sum of differences| (pixf.asd8: "the DC coefficient is
+ * by far the most important part of the coding cost"), + the slice-header bits at four times luma's lambda.  i420_*: the raw pictures */
+long x264o_slicetype_weight_cost_chroma(x264o_slicetype *st, int sf, const uint8_t *i420_fenc, const uint8_t *i420_ref, int dist, int plane, int on, int scale, int denom, int offset)
+{
+    st_frame *f = &st->fr[sf];
+    const int pw = st->w / 2, ph = st->h / 2;
+    const uint8_t *src = i420_fenc + (size_t)st->w * st->h + (size_t)(plane - 1) * pw * ph;
+    const uint8_t *ref = i420_ref + (size_t)st->w * st->h + (size_t)(plane - 1) * pw * ph;
+    const int16_t (*mv)[2] = dist > 0 && dist <= st->bframes + 1 && f->mvs[0][dist - 1][0][0] != 0x7fff ? f->mvs[0][dist - 1] : NULL;
+    long cost = 0;
+    for (int by = 0; by < st->bh; by++)
+        for (int bx = 0; bx < st->bw; bx++) {
+            const int i = by * st->bw + bx, mvx = mv ? mv[i][0] : 0, mvy = mv ? mv[i][1] : 0;
+            const int d8x = mvx & 7, d8y = mvy & 7, cA = (8 - d8x) * (8 - d8y), cB = d8x * (8 - d8y), cC = (8 - d8x) * d8y, cD = d8x * d8y;
+            int sum = 0;
+            for (int y = 0; y < 8; y++)
+                for (int x = 0; x < 8; x++) {
+                    const int px = bx * 8 + x + (mvx >> 3), py = by * 8 + y + (mvy >> 3);
+                    const int x0 = clampi(px, 0, pw - 1), x1 = clampi(px + 1, 0, pw - 1), y0 = clampi(py, 0, ph - 1), y1 = clampi(py + 1, 0, ph - 1);
+                    int p = (cA * ref[(size_t)y0 * pw + x0] + cB * ref[(size_t)y0 * pw + x1] + cC * ref[(size_t)y1 * pw + x0] + cD * ref[(size_t)y1 * pw + x1] + 32) >> 6;
+                    if (on) { p = denom >= 1 ? ((p * scale + (1 << (denom - 1))) >> denom) + offset : p * scale + offset; p = p < 0 ? 0 : p > 255 ? 255 : p; }
+                    sum += p - src[(size_t)clampi(by * 8 + y, 0, ph - 1) * pw + clampi(bx * 8 + x, 0, pw - 1)];
+                }
+            cost += sum < 0 ? -sum : sum;
+        }
+    if (on) {       /* weight_slice_header_cost, chroma: 4 x lambda(12) x (10 + denom bits (shared by the two planes) + 2 x (scale bits + offset bits)) */
+        const int se_scale = bs_size_ue(scale > 0 ? 2 * scale - 1 : -2 * scale), se_off = bs_size_ue(offset > 0 ? 2 * offset - 1 : -2 * offset);
+        cost += 4 * x264o_lambda(12) * (10 + bs_size_ue(denom) + 2 * (se_scale + se_off));
+    }
+    return cost;
+}
 /* dist: > 0 and that list-0 search of `sf` has run: motion-compensated reference; else the reference in place.  on = 0: unweighted */
 long x264o_slicetype_weight_cost(x264o_slicetype *st, int sf, int sr, int dist, int on, int scale, int denom, int offset)
 {

@@ -158,6 +158,17 @@ class GpuSlicetype:
         lib.check(lib.x264gpu_slicetype_weight_cost(self.h, sf, sr, dist, 1 if weight else 0, *(weight or (1, 0, 0)), out.ctypes.data, None), "weight_cost")
         return out
 
+    def chroma_stats(self, slot):
+        out = np.zeros((self.S, 4), np.uint64)
+        lib.check(lib.x264gpu_slicetype_chroma_stats(self.h, slot, self.keep[slot].data_ptr(), out.ctypes.data, None), "chroma_stats")
+        return out
+
+    def weight_cost_chroma(self, sf, sr, dist, plane, weight=None):
+        out = np.zeros(self.S, np.int64)
+        lib.check(lib.x264gpu_slicetype_weight_cost_chroma(self.h, sf, self.keep[sf].data_ptr(), self.keep[sr].data_ptr(), dist, plane, 1 if weight else 0, *(weight or (1, 0, 0)),
+                                                           out.ctypes.data, None), "weight_cost_chroma")
+        return out
+
     def intra_mbs(self, slot, d0, s=0):
         return lib.x264gpu_slicetype_intra_mbs(self.h, slot, d0, s)
 

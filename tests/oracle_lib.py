@@ -285,6 +285,8 @@ _sig("x264o_slicetype_set_bframe_bias", None, [C.c_void_p, _i])
 _sig("x264o_slicetype_frame_cost_w", _i, [C.c_void_p] + [_i] * 9)
 _sig("x264o_slicetype_pixel_stats", None, [C.c_void_p, _i, C.c_void_p, C.c_void_p])
 _sig("x264o_slicetype_weight_cost", C.c_long, [C.c_void_p] + [_i] * 7)
+_sig("x264o_slicetype_chroma_stats", None, [C.c_void_p, _i, C.c_void_p, C.c_void_p])
+_sig("x264o_slicetype_weight_cost_chroma", C.c_long, [C.c_void_p, _i, C.c_void_p, C.c_void_p] + [_i] * 6)
 _sig("x264o_slicetype_clear_propagate", None, [C.c_void_p, _i])
 _sig("x264o_slicetype_propagate", _i, [C.c_void_p, _i, _i, _i, _i, _i, _i])
 _sig("x264o_slicetype_finish", _i, [C.c_void_p, _i, _i, C.c_void_p])
@@ -316,6 +318,16 @@ class OracleSlicetype:
 
     def weight_cost(self, sf, sr, dist, weight=None):
         return L.x264o_slicetype_weight_cost(self.st, sf, sr, dist, 1 if weight else 0, *(weight or (1, 0, 0)))
+
+    def chroma_stats(self, slot, i420):
+        out = np.zeros(4, np.uint64)
+        i420 = np.ascontiguousarray(i420, np.uint8)
+        L.x264o_slicetype_chroma_stats(self.st, slot, ptr(i420), ptr(out))
+        return out
+
+    def weight_cost_chroma(self, sf, fenc, ref, dist, plane, weight=None):
+        fenc = np.ascontiguousarray(fenc, np.uint8); ref = np.ascontiguousarray(ref, np.uint8)
+        return L.x264o_slicetype_weight_cost_chroma(self.st, sf, ptr(fenc), ptr(ref), dist, plane, 1 if weight else 0, *(weight or (1, 0, 0)))
 
     def intra_mbs(self, slot, d0):
         return L.x264o_slicetype_intra_mbs(self.st, slot, d0)
@@ -457,6 +469,14 @@ _sig("x264o_h264_decode", _i, [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C
 
 
 _sig("x264o_h264_last_pocs", _i, [C.c_void_p, _i])
+_sig("x264o_h264_last_weighted", None, [C.c_void_p])
+
+
+def h264_last_weighted():
+    """(P slices with an explicit luma weight, P slices with chroma weights) of the last h264_decode"""
+    out = np.zeros(2, np.int32)
+    L.x264o_h264_last_weighted(ptr(out))
+    return int(out[0]), int(out[1])
 
 
 def h264_last_pocs():

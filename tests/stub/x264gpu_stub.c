@@ -120,6 +120,8 @@ const uint16_t *x264gpu_slicetype_lowres_costs(x264gpu_slicetype *s, int slot, i
 int x264o_slicetype_frame_cost_w(x264o_slicetype *st, int s0, int s1, int sb, int d0, int d1, int on, int scale, int denom, int offset);
 void x264o_slicetype_pixel_stats(x264o_slicetype *st, int slot, const uint8_t *i420, uint64_t out[2]);
 long x264o_slicetype_weight_cost(x264o_slicetype *st, int sf, int sr, int dist, int on, int scale, int denom, int offset);
+void x264o_slicetype_chroma_stats(x264o_slicetype *st, int slot, const uint8_t *i420, uint64_t out[4]);
+long x264o_slicetype_weight_cost_chroma(x264o_slicetype *st, int sf, const uint8_t *i420_fenc, const uint8_t *i420_ref, int dist, int plane, int on, int scale, int denom, int offset);
 int x264gpu_slicetype_frame_cost_w(x264gpu_slicetype *s, int s0, int s1, int sb, int d0, int d1, int on, int scale, int denom, int offset, int32_t *h_score, void *stream)
 {
     const int c = x264o_slicetype_frame_cost_w(s->st, s0, s1, sb, d0, d1, on, scale, denom, offset);
@@ -128,6 +130,16 @@ int x264gpu_slicetype_frame_cost_w(x264gpu_slicetype *s, int s0, int s1, int sb,
     return X264GPU_OK;
 }
 int x264gpu_slicetype_pixel_stats(x264gpu_slicetype *s, int slot, const uint8_t *i420, uint64_t *out, void *stream) { x264o_slicetype_pixel_stats(s->st, slot, i420, out); return X264GPU_OK; }
+int x264gpu_slicetype_chroma_stats(x264gpu_slicetype *s, int slot, const uint8_t *i420, uint64_t *out, void *stream) { (void)stream; x264o_slicetype_chroma_stats(s->st, slot, i420, out); return X264GPU_OK; }
+int x264gpu_slicetype_weight_cost_chroma(x264gpu_slicetype *s, int sf, const uint8_t *i420_fenc, const uint8_t *i420_ref, int dist, int plane, int on, int scale, int denom, int offset, int64_t *h_cost, void *stream)
+{
+    (void)stream;
+    if (plane < 1 || plane > 2) return fail("weight_cost_chroma: plane 1 or 2");
+    const long c = x264o_slicetype_weight_cost_chroma(s->st, sf, i420_fenc, i420_ref, dist, plane, on, scale, denom, offset);
+    if (c < 0) return fail("weight_cost_chroma: the picture has no costs yet");
+    *h_cost = c;
+    return X264GPU_OK;
+}
 int x264gpu_slicetype_weight_cost(x264gpu_slicetype *s, int sf, int sr, int dist, int on, int scale, int denom, int offset, int64_t *h_cost, void *stream)
 {
     const long c = x264o_slicetype_weight_cost(s->st, sf, sr, dist, on, scale, denom, offset);

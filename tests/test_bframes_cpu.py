@@ -335,6 +335,11 @@ def fade_frames(w, h, n, seed, step=6):
     ("IBBPBBP", {3: (53, 6, 1), 6: (111, 7, 0)}, 2, {}),
     ("IPPP", {1: (60, 6, 0), 2: (59, 6, 1), 3: (29, 5, 2)}, 1, {}),                               # --weightp 1: the weight alone
     ("IPPP", {1: (1, 0, -128), 2: (60, 6, 0)}, 2, dict(refs=1)),                                  # offset -128 has no duplicate one step down; one reference: no duplicates at all
+    # ... with the chroma planes weighted beside luma (x264_weights_analyse once luma has a weight): (.., chroma denom, Cb on / scale / offset, Cr ...)
+    ("IPPP", {1: (58, 6, 3, 5, 1, 30, 4, 1, 29, 6)}, 2, {}),
+    ("IBPBP", {2: (60, 6, -2, 6, 1, 62, -3, 0, 1, 0), 4: (66, 6, 2, 5, 0, 1, 0, 1, 31, 2)}, 2, {}),   # one chroma plane alone: the other is sent as 1 << denom
+    ("IPP", {1: (60, 6, 1, 4, 1, 15, 0, 1, 17, -2), 2: (1, 0, 4, 6, 1, 60, 1, 1, 61, 0)}, 1, dict(rd=0, trellis=0, subme=5, psy_rd_q8=0)),
+    ("IPPP", {2: (62, 6, -1, 6, 1, 60, 2, 1, 66, -4)}, 2, dict(subme=8, rd=63, me_method=2)),          # RD refinement: the part costs' chroma predictions carry the weights
 ])
 def test_explicit_luma_weights_of_reference_0(types, weights, weightp, over):
     """the weights x264_weights_analyse gives a P picture of a fade: reference 0 carries {scale, denom, offset}; under --weightp 2 its duplicate one
@@ -451,7 +456,10 @@ def test_host_session_finds_the_weights_of_a_fade(tmp_path):
     info0, stream0 = _host_b_session(tmp_path, n, ["qp=23", "keyint=60", "fade=6", "weightp=0"], w, h, seed=3)
     assert len(stream) < 0.97 * len(stream0), (len(stream), len(stream0))
     dec = O.h264_decode(stream, n, w, h)
+    wl, wc = O.h264_last_weighted()
+    assert wl >= 3 and wc >= 2, (wl, wc)          # the fade scales the chroma planes towards grey: x264 weights them beside luma
     frames = fade_frames(w, h, n, 3)
     from synth import psnr
     for d, r in zip(dec, info["recs"]):
         assert psnr(d[:w * h], frames[r[1]][:w * h]) > 33.0
+        assert psnr(d[w * h:], frames[r[1]][w * h:]) > 33.0

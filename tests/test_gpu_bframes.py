@@ -175,6 +175,12 @@ def test_config4_size_slow_toolset_bitexact(gpu):
     ("IPPP", {1: (60, 6, 0), 2: (59, 6, 1), 3: (29, 5, 2)}, 1, {}),                               # --weightp 1: the weight alone
     ("IPPP", {1: (1, 0, -128), 2: (60, 6, 0)}, 2, dict(refs=1)),
     ("IPPPP", {1: (60, 6, 0), 2: (59, 6, 1), 3: (58, 6, 0), 4: (57, 6, 1)}, 2, dict(refs=5, dpb=5, me_method=2)),      # seven list entries, umh
+    # the chroma planes weighted beside luma: (.., chroma denom, Cb on / scale / offset, Cr on / scale / offset) — chroma-ME costs, skip probe, predictions
+    ("IPPP", {1: (58, 6, 3, 5, 1, 30, 4, 1, 29, 6), 2: (60, 6, 0, 6, 1, 61, -2, 1, 62, 1), 3: (59, 6, 1, 6, 1, 60, 0, 1, 66, -3)}, 2, {}),
+    ("IBPBP", {2: (60, 6, -2, 6, 1, 62, -3, 0, 1, 0), 4: (66, 6, 2, 5, 0, 1, 0, 1, 31, 2)}, 2, {}),
+    ("IPP", {1: (60, 6, 1, 4, 1, 15, 0, 1, 17, -2), 2: (1, 0, 4, 6, 1, 60, 1, 1, 61, 0)}, 1, dict(rd=0, trellis=0, subme=5, psy_rd_q8=0)),
+    ("IPPP", {1: (61, 6, 0, 6, 1, 60, 1, 1, 61, 0), 2: (62, 6, -1, 6, 1, 60, 2, 1, 66, -4)}, 2, dict(subme=8, rd=63, me_method=2, trellis=127)),      # RD refinement's part predictions
+    ("IPPP", {1: (58, 6, 3, 5, 1, 30, 4, 1, 29, 6), 2: (60, 6, 0, 6, 1, 61, -2, 1, 62, 1)}, 2, dict(me_method=0, refs=2, chroma_me=0)),
 ])
 def test_explicit_luma_weights_bitexact_and_decodable(gpu, types, weights, weightp, over):
     """a fade with the weights x264_weights_analyse would hand the P pictures: weighted reference 0 in the skip probe, every search and every

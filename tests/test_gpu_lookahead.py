@@ -237,6 +237,7 @@ def test_weight_analysis_primitives_bitexact(gpu, w, h, seed, kw):
     for i, f in enumerate(frames):
         og.put(i, f); gg.put(i, [f])
         assert np.array_equal(gg.pixel_stats(i)[0], og.pixel_stats(i, f)), f"statistics of picture {i}"
+        assert np.array_equal(gg.chroma_stats(i)[0], og.chroma_stats(i, f)), f"chroma statistics of picture {i}"
     for i in range(1, n):
         assert gg.cost(i, i, i, 0, 0)[0] == og.cost(i, i, i, 0, 0)
     weights = [None, (60, 6, 0), (59, 6, 1), (117, 7, -2), (1, 0, -3), (127, 7, 0)]
@@ -247,5 +248,9 @@ def test_weight_analysis_primitives_bitexact(gpu, w, h, seed, kw):
     assert np.array_equal(gg.mvs(2, 0, 1)[0], og.mvs(2, 0, 1))
     for wgt in weights:
         assert gg.weight_cost(2, 1, 1, wgt)[0] == og.weight_cost(2, 1, 1, wgt), f"weight {wgt}, compensated reference"
+    for wgt in weights:                      # (after the search: the chroma planes compensated by the half-resolution vectors)
+        for plane in (1, 2):
+            assert gg.weight_cost_chroma(2, 1, 1, plane, wgt)[0] == og.weight_cost_chroma(2, frames[2], frames[1], 1, plane, wgt), f"chroma plane {plane}, weight {wgt}"
+            assert gg.weight_cost_chroma(3, 1, 2, plane, wgt)[0] == og.weight_cost_chroma(3, frames[3], frames[1], 2, plane, wgt), f"chroma plane {plane}, weight {wgt}, reference in place"
     assert og.weight_cost(2, 1, 1, (60, 6, 0)) < og.weight_cost(2, 1, 1, None), "on a fade the right weight must pay"
     og.close(); gg.close()

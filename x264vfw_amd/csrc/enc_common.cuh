@@ -32,6 +32,7 @@ struct EncK {
     // (8.4.2.3.2; applied AFTER the quarter-pel interpolation, as mc.get_ref / mc_luma do) and the index of x264's blind duplicate of reference 0
     // (h->mb.ref_blind_dupe; 0 = none): the same picture as index 0, refined from index 0's vector instead of searched
     int wl0[8], blind_dupe, wp_any;
+    int wc0[16], wc_any;      // explicit chroma weights of list-0 index r: wc0[2 r] Cb, [2 r + 1] Cr, packed like wl0; wc_any: some index has one
     int refpic[8];                           // the picture behind list-0 index r as an index without duplicates (order of first appearance): reference cache tags, loop filter
     uint8_t biw[5][4];                       // B: implicit bi-prediction weight of the list-0 sample for (list-0 index, list-1 index), of 64 (x264 bipred_weight)
     const int8_t *colref; const int16_t *colmv;    // B: per 8x8 block of the first picture of list 1, the reference index it used (-1 intra) and that vector

@@ -358,7 +358,8 @@ static int encode_core(x264gpu_encoder *e, const uint8_t *d_i420, const x264gpu_
     k.nref = n0; k.nref1 = n1;
     // --weightp: explicit luma weights of a P picture's list 0 and x264's blind duplicate of reference 0
     k.blind_dupe = 0; k.wp_any = 0;
-    for (int r = 0; r < 8; r++) { k.wl0[r] = 0; k.refpic[r] = r; }
+    for (int r = 0; r < 8; r++) { k.wl0[r] = 0; k.refpic[r] = r; k.wc0[2 * r] = k.wc0[2 * r + 1] = 0; }
+    k.wc_any = 0;
     if (slice_type == X264GPU_SLICE_P) {
         for (int r = 0; r < n0; r++)
             if (pic.wl0[r].on) {
@@ -366,6 +367,13 @@ static int encode_core(x264gpu_encoder *e, const uint8_t *d_i420, const x264gpu_
                 k.wl0[r] = (int)(uint8_t)(int8_t)pic.wl0[r].offset | (int)(uint8_t)(int8_t)pic.wl0[r].scale << 8 | pic.wl0[r].denom << 16 | 1 << 24;
                 k.wp_any = 1;
             }
+        for (int r = 0; r < n0; r++)
+            for (int c = 0; c < 2; c++)
+                if (pic.wc0[r].on[c]) {
+                    ARG_TRY(pic.wc0[r].denom >= 0 && pic.wc0[r].denom <= 7 && pic.wc0[r].scale[c] >= -128 && pic.wc0[r].scale[c] <= 127 && pic.wc0[r].offset[c] >= -128 && pic.wc0[r].offset[c] <= 127);
+                    k.wc0[2 * r + c] = (int)(uint8_t)(int8_t)pic.wc0[r].offset[c] | (int)(uint8_t)(int8_t)pic.wc0[r].scale[c] << 8 | pic.wc0[r].denom << 16 | 1 << 24;
+                    k.wp_any = 1; k.wc_any = 1;
+                }
         if (pic.blind_dupe > 0) {
             ARG_TRY(pic.blind_dupe == 1 && n0 >= 2 && pic.slot[0][1] == pic.slot[0][0]);      // x264 places it right behind reference 0
             k.blind_dupe = 1; k.wp_any = 1;
@@ -526,7 +534,7 @@ int x264gpu_encode_pictures(x264gpu_encoder *e, const uint8_t *d_i420, const x26
     for (int s = 1; s < S; s++) {
         ARG_TRY(pics[s].slice_type == pics[0].slice_type && pics[s].poc == pics[0].poc && pics[s].dst == pics[0].dst && pics[s].keep == pics[0].keep &&
                 pics[s].nref[0] == pics[0].nref[0] && pics[s].nref[1] == pics[0].nref[1] && !memcmp(pics[s].slot, pics[0].slot, sizeof(pics[0].slot)) &&
-                pics[s].blind_dupe == pics[0].blind_dupe && !memcmp(pics[s].wl0, pics[0].wl0, sizeof(pics[0].wl0)));
+                pics[s].blind_dupe == pics[0].blind_dupe && !memcmp(pics[s].wl0, pics[0].wl0, sizeof(pics[0].wl0)) && !memcmp(pics[s].wc0, pics[0].wc0, sizeof(pics[0].wc0)));
         same_qp = same_qp && pics[s].qp == pics[0].qp && pics[s].qp_frac_q8 == pics[0].qp_frac_q8;
     }
     if (!same_qp) {

@@ -194,7 +194,18 @@ __device__ __forceinline__ int sub_sad_row16_hpel(const uint32_t *buf, int n, in
 // ------------------------------------------------------------------------------------------------
 typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
 struct ChromaTaps { uint32_t a0, a1, a2, b0, b1, b2; };         // the six NV12 dwords one lane needs for one candidate
-__device__ __forceinline__ int chroma_me_cost(const ChromaTaps &t, int mvx, int mvy, uint32_t e0, uint32_t e1, s16x2 sg1, s16x2 sg2)
+// explicit weighted prediction of two chroma samples held as 16-bit lanes (wpk = EncK::wc0 packing)
+__device__ __forceinline__ u16x2 wp2(u16x2 p, int wpk)
+{
+    const int offset = (int)(int8_t)(wpk & 0xff), scale = (int)(int8_t)((wpk >> 8) & 0xff), denom = (wpk >> 16) & 0xff;
+    const int rnd = denom ? 1 << (denom - 1) : 0;
+    int a = (((int)p.x * scale + rnd) >> denom) + offset, b = (((int)p.y * scale + rnd) >> denom) + offset;
+    a = a < 0 ? 0 : a > 255 ? 255 : a; b = b < 0 ? 0 : b > 255 ? 255 : b;
+    u16x2 r; r.x = (unsigned short)a; r.y = (unsigned short)b;
+    return r;
+}
+// wcu / wcv: the reference's explicit Cb / Cr weight (0 = none; wave-uniform)
+__device__ __forceinline__ int chroma_me_cost(const ChromaTaps &t, int mvx, int mvy, uint32_t e0, uint32_t e1, s16x2 sg1, s16x2 sg2, int wcu = 0, int wcv = 0)
 {
     const int dx = mvx & 7, dy = mvy & 7;
     const uint32_t wA = (uint32_t)((8 - dx) * (8 - dy)) * 0x10001u, wB = (uint32_t)(dx * (8 - dy)) * 0x10001u;
@@ -207,8 +218,9 @@ __device__ __forceinline__ int chroma_me_cost(const ChromaTaps &t, int mvx, int 
     for (int sh = 0; sh < 16; sh += 8) {
 #define CH(x) __builtin_bit_cast(u16x2, ((x) >> sh) & 0x00ff00ffu)
 #define W(x) __builtin_bit_cast(u16x2, x)
-        const u16x2 p01 = (W(wA) * CH(a0) + W(wB) * CH(a01) + W(wC) * CH(b0) + W(wD) * CH(b01) + W(0x00200020u)) >> 6;
-        const u16x2 p23 = (W(wA) * CH(a1) + W(wB) * CH(a12) + W(wC) * CH(b1) + W(wD) * CH(b12) + W(0x00200020u)) >> 6;
+        u16x2 p01 = (W(wA) * CH(a0) + W(wB) * CH(a01) + W(wC) * CH(b0) + W(wD) * CH(b01) + W(0x00200020u)) >> 6;
+        u16x2 p23 = (W(wA) * CH(a1) + W(wB) * CH(a12) + W(wC) * CH(b1) + W(wD) * CH(b12) + W(0x00200020u)) >> 6;
+        { const int wk = sh ? wcv : wcu; if (wk) { p01 = wp2(p01, wk); p23 = wp2(p23, wk); } }
         const s16x2 da = __builtin_bit_cast(s16x2, CH(e0)) - __builtin_bit_cast(s16x2, p01);
         const s16x2 db = __builtin_bit_cast(s16x2, CH(e1)) - __builtin_bit_cast(s16x2, p23);
 #undef CH
@@ -263,7 +275,7 @@ __device__ __forceinline__ void chroma_commit2(uint32_t *cb, const uint32_t v[2]
 }
 // chroma_me_half on the staged neighbourhood: (cx, cy) chroma position of the lane's four pixels
 __device__ __forceinline__ int chroma_me_lds(const uint32_t *cb, int ndw, int x0c, int y0c, int cx, int cy, int mvx, int mvy, uint32_t e0, uint32_t e1,
-                                             s16x2 sg1, s16x2 sg2)
+                                             s16x2 sg1, s16x2 sg2, int wcu = 0, int wcv = 0)
 {
     const int o = ((cy + (mvy >> 3) - y0c) * ndw << 2) + 2 * (cx + (mvx >> 3) - x0c), sh = o & 3;
     const uint32_t *w = cb + (o >> 2), *v = w + ndw;
@@ -272,7 +284,7 @@ __device__ __forceinline__ int chroma_me_lds(const uint32_t *cb, int ndw, int x0
       t.a0 = __builtin_amdgcn_alignbyte(d1, d0, sh); t.a1 = __builtin_amdgcn_alignbyte(d2, d1, sh); t.a2 = __builtin_amdgcn_alignbyte(d3, d2, sh); }
     { const uint32_t d0 = v[0], d1 = v[1], d2 = v[2], d3 = v[3];
       t.b0 = __builtin_amdgcn_alignbyte(d1, d0, sh); t.b1 = __builtin_amdgcn_alignbyte(d2, d1, sh); t.b2 = __builtin_amdgcn_alignbyte(d3, d2, sh); }
-    return chroma_me_cost(t, mvx, mvy, e0, e1, sg1, sg2);
+    return chroma_me_cost(t, mvx, mvy, e0, e1, sg1, sg2, wcu, wcv);
 }
 
 // ------------------------------------------------------------------------------------------------

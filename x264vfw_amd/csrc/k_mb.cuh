@@ -207,6 +207,7 @@ __device__ __forceinline__ void me_search(const EncK &k, MbLds<M> &L, const MbCt
     // explicit luma weight of this reference (P slices, --weightp): every sample fetched below goes through it after interpolation; the
     // reference cache holds the unweighted planes under the PICTURE's tag, so an index and its duplicate share a slot
     const int wpk = k.wp_any ? uni(k.wl0[j.ref]) : 0;
+    const int wcu = k.wc_any ? uni(k.wc0[2 * j.ref]) : 0, wcv = k.wc_any ? uni(k.wc0[2 * j.ref + 1]) : 0;          // (m->weight[1] / [2]: the chroma-ME costs)
     const bool wt = (wpk >> 24) != 0;
     const int cref = k.wp_any ? ref_picture(k, j.ref) : j.ref;
     // (the upper half of an 8-pixel row's registers stays zero: weighting it would turn it into the offset and into cost)
@@ -675,7 +676,7 @@ __device__ __forceinline__ void me_search(const EncK &k, MbLds<M> &L, const MbCt
         return row16_sum(w16 ? satd16x4_half_pk<4>(e, p, sg1, sg2) : satd16x4_half_pk<2>(e, p, sg1, sg2)) + mvc2(qx, qy);       // 8-pixel rows: half the work
     };
     auto chroma2 = [&](int qx, int qy) {
-        const int h = cact ? chroma_me_lds(cb, cndw, cx0c, cy0c, (c.px >> 1) + ccx, (c.py >> 1) + ccy, qx, qy, ce0, ce1, sg1, sg2) : 0;
+        const int h = cact ? chroma_me_lds(cb, cndw, cx0c, cy0c, (c.px >> 1) + ccx, (c.py >> 1) + ccy, qx, qy, ce0, ce1, sg1, sg2, wcu, wcv) : 0;
         return row16_sum(h);
     };
     // half-pel diamond on SAD: (0,-2) (0,2) (-2,0) (2,0)
@@ -1354,6 +1355,7 @@ __device__ __forceinline__ bool mb_probe_pskip(const EncK &k, const MbCtx &c, ui
     const int pl = (lane >> 4) & 1, ci = (lane >> 2) & 3, cx0 = (ci & 1) * 4, cyy = (ci >> 1) * 4 + j;
     uint32_t pu, pv;
     mc_chroma_row4(ref_chroma00(k, c.s, 0), k.rs, c.mbx * 8 + cx0, c.mby * 8 + cyy, mvx, mvy, pu, pv);
+    if (k.wc_any) { if (k.wc0[0] >> 24) pu = wp4(pu, k.wc0[0]); if (k.wc0[1] >> 24) pv = wp4(pv, k.wc0[1]); }
     const uint2 fe = *(const uint2 *)(c.fuv + (size_t)cyy * k.fs + 2 * cx0);
     return mb_probe_skip_pred(c, cz, pred, nv12_pick(fe.x, fe.y, pl), pl ? pv : pu, ql, qc);
 }
@@ -2159,6 +2161,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(MB_WAVES_PER
                     const bool act = lane < 32 && ((pm8 >> ci) & 1);
                     uint32_t pu, pv;
                     mc_chroma_row4(ref_chroma00(k, s, rf_ref), k.rs, mbx * 8 + cx0, mby * 8 + cyy, rf_cx, rf_cy, pu, pv);
+                    if (k.wc_any) { const int wu = uni(k.wc0[2 * rf_ref]), wv = uni(k.wc0[2 * rf_ref + 1]); if (wu >> 24) pu = wp4(pu, wu); if (wv >> 24) pv = wp4(pv, wv); }
                     const uint32_t cpred = pl ? pv : pu;
                     const uint2 fe = *(const uint2 *)(L.csrc + cyy * 16 + 2 * cx0);
                     const uint32_t cenc = nv12_pick(fe.x, fe.y, pl);
@@ -2307,6 +2310,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(MB_WAVES_PER
             uint32_t pu, pv;
             mc_chroma_row4(ref_chroma00(k, s, cref), k.rs, mbx * 8 + cx0, mby * 8 + cyy, cmvx, cmvy, pu, pv);
             cpred = pl ? pv : pu;
+            if (k.wc_any) { const int wck = k.wc0[2 * cref + pl]; if (wck >> 24) cpred = wp4(cpred, wck); }      // (cref varies with the lane's chroma block)
             mv0x = eskip ? pskx : __builtin_amdgcn_readlane(lmx, 0); mv0y = eskip ? psky : __builtin_amdgcn_readlane(lmy, 0); ref0 = __builtin_amdgcn_readlane(lref, 0);
             if (commit && (lane & 15) == 0) {      // one lane per 8x8 block writes that block's motion
                 recd.mv[lane >> 4][0] = (int16_t)(eskip ? pskx : lmx); recd.mv[lane >> 4][1] = (int16_t)(eskip ? psky : lmy); recd.ref[lane >> 4] = (int8_t)lref;

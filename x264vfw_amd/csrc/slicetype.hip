@@ -327,6 +327,45 @@ __global__ __launch_bounds__(64) void k_st_weight_cost(StWeightK k)
     if (lane == 0) atomicAdd(k.out + (size_t)s * 2, v);
 }
 
+// i_pixel_sum / i_pixel_ssd of the chroma planes (blockIdx.z = plane Cb / Cr): raw sums, the caller turns the squares into the ssd
+struct StChromaK {
+    int w, h, pw, ph, cw, ch, bw, nb, plane, on, scale, denom, offset;
+    size_t i420_bytes;
+    const uint8_t *i420, *ref; const int16_t *mv;
+    unsigned long long *out;                     // stats: [S][4]; cost: [S][2]
+};
+__global__ __launch_bounds__(256) void k_st_chroma_stats(StChromaK k)
+{
+    const int s = blockIdx.y, c = blockIdx.z;
+    const uint8_t *src = k.i420 + (size_t)s * k.i420_bytes + (size_t)k.w * k.h + (size_t)c * k.pw * k.ph;
+    unsigned long long sum = 0, sqr = 0;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < k.cw * k.ch; i += gridDim.x * 256) {
+        const int y = i / k.cw, x = i - y * k.cw;
+        const unsigned p = src[(size_t)min(y, k.ph - 1) * k.pw + min(x, k.pw - 1)];
+        sum += p; sqr += p * p;
+    }
+    for (int o = 32; o; o >>= 1) { sum += __shfl_xor(sum, o); sqr += __shfl_xor(sqr, o); }
+    if ((threadIdx.x & 63) == 0) { atomicAdd(k.out + (size_t)s * 4 + 2 * c, sum); atomicAdd(k.out + (size_t)s * 4 + 2 * c + 1, sqr); }
+}
+// weight_cost_chroma (oracle x264o_slicetype_weight_cost_chroma): one lane per sample of an 8x8 chroma block — mc_chroma with the block's
+// half-resolution vector, the weight, the difference to the source; |sum| per block (pixf.asd8).  Picture edges by clamping (the expanded border)
+__global__ __launch_bounds__(64) void k_st_weight_cost_chroma(StChromaK k)
+{
+    const int lane = threadIdx.x, s = blockIdx.y, b = blockIdx.x, bx = b % k.bw, by = b / k.bw, x = lane & 7, y = lane >> 3;
+    const uint8_t *src = k.i420 + (size_t)s * k.i420_bytes + (size_t)k.w * k.h + (size_t)(k.plane - 1) * k.pw * k.ph;
+    const uint8_t *ref = k.ref + (size_t)s * k.i420_bytes + (size_t)k.w * k.h + (size_t)(k.plane - 1) * k.pw * k.ph;
+    int mvx = 0, mvy = 0;
+    if (k.mv) { const int16_t *m = k.mv + ((size_t)s * k.nb + b) * 2; mvx = m[0]; mvy = m[1]; }
+    const int d8x = mvx & 7, d8y = mvy & 7, cA = (8 - d8x) * (8 - d8y), cB = d8x * (8 - d8y), cC = (8 - d8x) * d8y, cD = d8x * d8y;
+    const int px = bx * 8 + x + (mvx >> 3), py = by * 8 + y + (mvy >> 3);
+    const int x0 = min(max(px, 0), k.pw - 1), x1 = min(max(px + 1, 0), k.pw - 1), y0 = min(max(py, 0), k.ph - 1), y1 = min(max(py + 1, 0), k.ph - 1);
+    int p = (cA * ref[(size_t)y0 * k.pw + x0] + cB * ref[(size_t)y0 * k.pw + x1] + cC * ref[(size_t)y1 * k.pw + x0] + cD * ref[(size_t)y1 * k.pw + x1] + 32) >> 6;
+    if (k.on) { p = k.denom >= 1 ? ((p * k.scale + (1 << (k.denom - 1))) >> k.denom) + k.offset : p * k.scale + k.offset; p = min(max(p, 0), 255); }
+    int d = p - (int)src[(size_t)min(by * 8 + y, k.ph - 1) * k.pw + min(bx * 8 + x, k.pw - 1)];
+    for (int o = 32; o; o >>= 1) d += __shfl_xor(d, o);
+    if (lane == 0) atomicAdd(k.out + (size_t)s * 2, (unsigned long long)abs(d));
+}
+
 // ---- macroblock-tree through B pictures (oracle/slicetype.c x264o_slicetype_propagate / _finish; x264 macroblock_tree_propagate,
 //      mbtree_propagate_cost / _list, macroblock_tree_finish).  Sums saturate at 32767 in x264; every addend is non-negative, so the
 //      accumulators here are plain 32-bit atomics and the saturation is applied where a sum is READ ----
@@ -412,7 +451,8 @@ struct x264gpu_slicetype {
     uint16_t *cost_mv; int32_t *sums; int *progress;
     std::vector<int32_t> h_sums;
     int32_t *prop[ST_MAX_SLOTS]; int16_t *aq[ST_MAX_SLOTS]; bool have_aq[ST_MAX_SLOTS];      // macroblock-tree: propagate costs, AQ offsets (Q8)
-    unsigned long long *d_acc;                                                                // [S][2] accumulators of the weight primitives
+    unsigned long long *d_acc;                                                                // [S][4] accumulators of the weight primitives
+    std::vector<unsigned long long> cstats[ST_MAX_SLOTS];                                     // per slot [S][4]: i_pixel_sum, i_pixel_ssd of Cb, of Cr
     std::vector<unsigned long long> stats[ST_MAX_SLOTS];                                      // per slot [S][2]: i_pixel_sum, i_pixel_ssd of the luma
 };
 
@@ -458,7 +498,7 @@ int x264gpu_slicetype_create(x264gpu_slicetype **out, int width, int height, int
         st->cost_est[i].assign(nd * S, -1); st->intra_mbs[i].assign((size_t)(bframes + 2) * S, 0);
     }
     alloc((void **)&st->sums, S * 4 * sizeof(int32_t));
-    alloc((void **)&st->d_acc, S * 2 * sizeof(unsigned long long));
+    alloc((void **)&st->d_acc, S * 4 * sizeof(unsigned long long));
     alloc((void **)&st->progress, S * (size_t)st->bh * sizeof(int));
     alloc((void **)&st->cost_mv, 2 * MVCOST_HALF * sizeof(uint16_t));
     st->h_sums.resize(S * 4);
@@ -508,7 +548,7 @@ int x264gpu_slicetype_put_frame(x264gpu_slicetype *st, int slot, const uint8_t *
         }
     st->intra_calculated[slot] = false;
     st->have_aq[slot] = false;
-    st->stats[slot].clear();
+    st->stats[slot].clear(); st->cstats[slot].clear();
     HIP_TRY(hipMemsetD32Async((hipDeviceptr_t)st->intra_cost[slot], 0xffff, S * nb, s));          // x264_frame_new: memset( i_intra_cost, -1 )
     HIP_TRY(hipMemsetAsync(st->prop[slot], 0, S * nb * sizeof(int32_t), s));
     std::fill(st->cost_est[slot].begin(), st->cost_est[slot].end(), -1);
@@ -631,6 +671,52 @@ int x264gpu_slicetype_weight_cost(x264gpu_slicetype *st, int slot_fenc, int slot
     HIP_TRY(hipStreamSynchronize(s));
     auto size_ue = [](int x) { int n = 0; x++; while (x >> (n + 1)) n++; return 2 * n + 1; };
     const int hdr = on ? st->lambda * (10 + size_ue(denom) * 2 + 2 * (size_ue(scale > 0 ? 2 * scale - 1 : -2 * scale) + size_ue(offset > 0 ? 2 * offset - 1 : -2 * offset))) : 0;
+    for (size_t i = 0; i < S; i++) h_cost[i] = (int64_t)v[2 * i] + hdr;
+    return X264GPU_OK;
+}
+
+// ... of the chroma planes: h_out[streams][4] = { sum Cb, ssd Cb, sum Cr, ssd Cr }
+int x264gpu_slicetype_chroma_stats(x264gpu_slicetype *st, int slot, const uint8_t *d_i420, uint64_t *h_out, void *stream)
+{
+    ARG_TRY(st && d_i420 && h_out && slot >= 0 && slot < st->slots);
+    const size_t S = st->streams;
+    if (st->cstats[slot].empty()) {
+        hipStream_t s = (hipStream_t)stream;
+        StChromaK k;
+        memset(&k, 0, sizeof(k));
+        k.w = st->w; k.h = st->h; k.pw = st->w / 2; k.ph = st->h / 2; k.cw = st->bw * 8; k.ch = st->bh * 8; k.i420 = d_i420; k.i420_bytes = (size_t)st->w * st->h * 3 / 2; k.out = st->d_acc;
+        HIP_TRY(hipMemsetAsync(st->d_acc, 0, S * 4 * sizeof(unsigned long long), s));
+        hipLaunchKernelGGL(k_st_chroma_stats, dim3(32, st->streams, 2), dim3(256), 0, s, k);
+        st->cstats[slot].resize(S * 4);
+        HIP_TRY(hipMemcpyAsync(st->cstats[slot].data(), st->d_acc, S * 4 * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipStreamSynchronize(s));
+        const unsigned long long n = (unsigned long long)k.cw * k.ch;
+        for (size_t i = 0; i < S * 2; i++) { const unsigned long long sum = st->cstats[slot][2 * i], sqr = st->cstats[slot][2 * i + 1]; st->cstats[slot][2 * i + 1] = sqr - (sum * sum + n / 2) / n; }
+    }
+    memcpy(h_out, st->cstats[slot].data(), S * 4 * sizeof(uint64_t));
+    return X264GPU_OK;
+}
+// weight_cost_chroma of plane 1 (Cb) / 2 (Cr) of the raw picture d_i420_fenc (the one in slot_fenc) against the raw picture d_i420_ref.  h_cost[streams]
+int x264gpu_slicetype_weight_cost_chroma(x264gpu_slicetype *st, int slot_fenc, const uint8_t *d_i420_fenc, const uint8_t *d_i420_ref, int dist, int plane,
+                                         int on, int scale, int denom, int offset, int64_t *h_cost, void *stream)
+{
+    ARG_TRY(st && h_cost && d_i420_fenc && d_i420_ref && slot_fenc >= 0 && slot_fenc < st->slots && (plane == 1 || plane == 2));
+    ARG_TRY(!on || (denom >= 0 && denom <= 7 && scale >= -128 && scale <= 127 && offset >= -128 && offset <= 127));
+    hipStream_t s = (hipStream_t)stream;
+    const size_t S = st->streams;
+    StChromaK k;
+    memset(&k, 0, sizeof(k));
+    k.w = st->w; k.h = st->h; k.pw = st->w / 2; k.ph = st->h / 2; k.bw = st->bw; k.nb = st->nb; k.plane = plane; k.on = on; k.scale = scale; k.denom = denom; k.offset = offset;
+    k.i420 = d_i420_fenc; k.ref = d_i420_ref; k.i420_bytes = (size_t)st->w * st->h * 3 / 2; k.out = st->d_acc;
+    k.mv = dist > 0 && dist <= st->bframes + 1 && st->searched[slot_fenc][0][dist - 1] ? st->mvs[slot_fenc][0][dist - 1] : nullptr;
+    HIP_TRY(hipMemsetAsync(st->d_acc, 0, S * 2 * sizeof(unsigned long long), s));
+    hipLaunchKernelGGL(k_st_weight_cost_chroma, dim3(st->nb, st->streams), dim3(64), 0, s, k);
+    std::vector<unsigned long long> v(S * 2);
+    HIP_TRY(hipMemcpyAsync(v.data(), st->d_acc, S * 2 * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    auto size_ue = [](int x) { int n = 0; x++; while (x >> (n + 1)) n++; return 2 * n + 1; };
+    // weight_slice_header_cost, chroma: four times luma's lambda (full resolution), the denominator shared by the two planes
+    const int hdr = on ? 4 * st->lambda * (10 + size_ue(denom) + 2 * (size_ue(scale > 0 ? 2 * scale - 1 : -2 * scale) + size_ue(offset > 0 ? 2 * offset - 1 : -2 * offset))) : 0;
     for (size_t i = 0; i < S; i++) h_cost[i] = (int64_t)v[2 * i] + hdr;
     return X264GPU_OK;
 }

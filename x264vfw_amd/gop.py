@@ -51,7 +51,10 @@ class HostDpb:
         info = (C.c_int * 8)()
         fc = (C.c_int * max(1, len(follow)))(*[c for c, _ in follow])
         ff = (C.c_int * max(1, len(follow)))(*[f for _, f in follow])
-        if weight is not None:
+        if weight is not None and len(weight) == 10:          # + (chroma denom, Cb on, Cb scale, Cb offset, Cr on, Cr scale, Cr offset)
+            wv = (C.c_int * 10)(*weight)
+            self.H.x264host_dpb_plan_wc(self.h, ptype, frame, len(follow), fc, ff, wv, C.byref(pic), info)
+        elif weight is not None:
             wv = (C.c_int * 3)(*weight)
             self.H.x264host_dpb_plan_w(self.h, ptype, frame, len(follow), fc, ff, wv, C.byref(pic), info)
         else:

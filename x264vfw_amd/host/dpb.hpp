@@ -59,7 +59,8 @@ public:
 
     // Plans the picture `frame` (display index) of type `type`.  follow_coded / follow_frame: coding index and display index of the disposable
     // pictures that follow it immediately in coding order (x264 reads them from h->frames.current); coded = this picture's coding index.
-    struct LumaWeight { int on = 0, scale = 1, denom = 0, offset = 0; };
+    // x264_weights_analyse's result for reference 0: the luma weight and, once luma has one, the chroma planes' (Cb, Cr; one denominator)
+    struct LumaWeight { int on = 0, scale = 1, denom = 0, offset = 0; int con[2] = { 0, 0 }, cscale[2] = { 1, 1 }, cdenom = 0, coffset[2] = { 0, 0 }; };
     const DpbPlan &plan(int type, int frame, int n_follow = 0, const int *follow_coded = nullptr, const int *follow_frame = nullptr, const LumaWeight *w0 = nullptr)
     {
         DpbPlan &p = last;
@@ -109,6 +110,12 @@ public:
             LumaWeight w = *w0;
             if (w.scale == 1 << w.denom) { w.scale = 1; w.denom = 0; }
             p.pic.wl0[0].on = 1; p.pic.wl0[0].denom = (int8_t)w.denom; p.pic.wl0[0].scale = (int16_t)w.scale; p.pic.wl0[0].offset = (int16_t)w.offset;
+            // the chroma planes' weights ride on index 0 alone (x264's duplicates carry w[1].weightfn = w[2].weightfn = NULL); weighted_pred_init drops a
+            // weight that changes nothing
+            for (int c = 0; c < 2; c++)
+                if (w.con[c] && !(w.cscale[c] == 1 << w.cdenom && w.coffset[c] == 0)) {
+                    p.pic.wc0[0].on[c] = 1; p.pic.wc0[0].denom = (int8_t)w.cdenom; p.pic.wc0[0].scale[c] = (int16_t)w.cscale[c]; p.pic.wc0[0].offset[c] = (int16_t)w.coffset[c];
+                }
             if (weightp == 2 && l[0].size() > 1) {
                 l[0].insert(l[0].begin() + 1, l[0][0]);             // the unweighted duplicate
                 reorder[0] = true;
@@ -164,6 +171,8 @@ public:
         for (int i = 0; i < p.n_mmco; i++) sp.mmco_diff[i] = p.mmco_diff[i];
         sp.weighted_pred = weightp > 0;
         for (int i = 0; i < X264GPU_MAX_LIST; i++) { sp.wl0[i].on = p.pic.wl0[i].on; sp.wl0[i].denom = p.pic.wl0[i].denom; sp.wl0[i].scale = p.pic.wl0[i].scale; sp.wl0[i].offset = p.pic.wl0[i].offset; }
+        for (int i = 0; i < X264GPU_MAX_LIST; i++)
+            for (int c = 0; c < 2; c++) { sp.wc0[i].on[c] = p.pic.wc0[i].on[c]; sp.wc0[i].denom = p.pic.wc0[i].denom; sp.wc0[i].scale[c] = p.pic.wc0[i].scale[c]; sp.wc0[i].offset[c] = p.pic.wc0[i].offset[c]; }
     }
 };
 

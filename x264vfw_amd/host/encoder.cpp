@@ -471,7 +471,7 @@ x264_t *x264_encoder_open(x264_param_t *param)
         }
     }
     if (h->dpbmode && !h->bframes) { p.rc.b_mb_tree = 0; }
-    if (h->weightp) xlog(&p, X264_LOG_INFO, "weightp %d: luma weights for fades from the lookahead (chroma planes are not weighted)%s\n", h->weightp, h->weightp == X264_WEIGHTP_SMART ? ", duplicates of reference 0 on every P picture" : "");
+    if (h->weightp) xlog(&p, X264_LOG_INFO, "weightp %d: weights for fades from the lookahead (luma, and the chroma planes beside it)%s\n", h->weightp, h->weightp == X264_WEIGHTP_SMART ? ", duplicates of reference 0 on every P picture" : "");
     h->keyint = p.i_keyint_max;
     // rate control: constant QP (X264_RC_CQP, codec.c:1498-1502) and single-pass CRF without AQ / mbtree (codec.c:1504-1507, the
     // driver's default session) when one GOP is in flight; ABR and CRF under --threads > 1 map to their nominal quantiser
@@ -1105,57 +1105,100 @@ static int encode_queued(x264_t *h, x264_nal_t **pp_nal, int *pi_nal, x264_pictu
 //      --b-adapt 1).  frames[0] = the last non-B picture, frames[1..] = the pictures waiting in display order ----
 enum { ST_AUTO = 0, ST_IDR, ST_I, ST_P, ST_BREF, ST_B };
 struct StFrames { x264_t *h; std::vector<x264_t::BEntry *> f; };
-// x264_weights_analyse, luma plane: guess scale and offset from the two pictures' statistics, cost the candidates around the guess on the
-// half-resolution planes (b_lookahead: the guess alone, reference in place — called before a P cost is searched; else, for the P picture about
-// to be coded, +- the distances of the sub-pel level around it, reference motion-compensated by the lookahead's vectors), keep the weight if
-// it saves more than 0.2 %.  The chroma planes are not analysed (the device weights luma only).
+// x264_weights_analyse: guess scale and offset of each plane from the two pictures' statistics, cost the candidates around the guess — luma on the
+// half-resolution planes (per 8x8 block min(mbcmp, intra cost)), the chroma planes at full resolution on the blocks' DC differences — keep a weight
+// if it saves more than 0.2 %.  b_lookahead: luma alone, the guess alone, reference in place (called before a P cost is searched); else, for the P
+// picture about to be coded: +- the distances of the sub-pel level around the guess, the reference motion-compensated by the lookahead's vectors,
+// and the chroma planes once luma has a weight.
 static Dpb::LumaWeight st_weights_analyse(x264_t *h, const x264_t::BEntry &fenc, const x264_t::BEntry &ref, int dist, bool b_lookahead)
 {
     Dpb::LumaWeight none, w;
-    uint64_t sf[2], sr[2];
+    uint64_t sf[6], sr[6];
     if (x264gpu_slicetype_pixel_stats(h->st, fenc.slot, h->q_raw[(size_t)fenc.slot], sf, nullptr) != X264GPU_OK ||
         x264gpu_slicetype_pixel_stats(h->st, ref.slot, h->q_raw[(size_t)ref.slot], sr, nullptr) != X264GPU_OK) { h->failed = true; return none; }
+    const int nplanes = b_lookahead ? 1 : 3;
+    if (!b_lookahead && (x264gpu_slicetype_chroma_stats(h->st, fenc.slot, h->q_raw[(size_t)fenc.slot], sf + 2, nullptr) != X264GPU_OK ||
+                         x264gpu_slicetype_chroma_stats(h->st, ref.slot, h->q_raw[(size_t)ref.slot], sr + 2, nullptr) != X264GPU_OK)) { h->failed = true; return none; }
     const float epsilon = 1.f / 128.f;
-    const int zero_bias = !sr[1];
-    const float fenc_var = (float)(sf[1] + (uint64_t)zero_bias), ref_var = (float)(sr[1] + (uint64_t)zero_bias);
-    const float guess_scale = sqrtf(fenc_var / ref_var);
-    const float npix = (float)(h->mbw * 16) * (float)(h->mbh * 16);
-    const float fenc_mean = (float)(sf[0] + (uint64_t)zero_bias) / npix, ref_mean = (float)(sr[0] + (uint64_t)zero_bias) / npix;
-    if (fabsf(ref_mean - fenc_mean) < 0.5f && fabsf(1.f - guess_scale) < epsilon) return none;
-    // weight_get_h264( round( guess_scale * 128 ), 0 )
-    int mindenom = 7, minscale = (int)roundf(guess_scale * 128), minoff = 0;
-    while (mindenom > 0 && minscale > 127) { mindenom--; minscale >>= 1; }
-    if (minscale > 127) minscale = 127;
-    int32_t dummy = 0;
-    int64_t score = 0;
-    if (x264gpu_slicetype_frame_cost(h->st, fenc.slot, fenc.slot, fenc.slot, 0, 0, &dummy, nullptr) != X264GPU_OK ||       // the picture's intra costs
-        x264gpu_slicetype_weight_cost(h->st, fenc.slot, ref.slot, dist, 0, 1, 0, 0, &score, nullptr) != X264GPU_OK) { h->failed = true; return none; }
-    const unsigned origscore = (unsigned)score;
-    unsigned minscore = origscore;
-    if (!minscore) return none;
+    float guess_scale[3] = { 1, 1, 1 }, fenc_mean[3] = { 0, 0, 0 }, ref_mean[3] = { 0, 0, 0 };
+    for (int plane = 0; plane < nplanes; plane++) {
+        const int zero_bias = !sr[2 * plane + 1];
+        const float fenc_var = (float)(sf[2 * plane + 1] + (uint64_t)zero_bias), ref_var = (float)(sr[2 * plane + 1] + (uint64_t)zero_bias);
+        guess_scale[plane] = sqrtf(fenc_var / ref_var);
+        const float npix = plane ? (float)(h->mbw * 8) * (float)(h->mbh * 8) : (float)(h->mbw * 16) * (float)(h->mbh * 16);
+        fenc_mean[plane] = (float)(sf[2 * plane] + (uint64_t)zero_bias) / npix; ref_mean[plane] = (float)(sr[2 * plane] + (uint64_t)zero_bias) / npix;
+    }
+    int chroma_denom = 7;
+    if (!b_lookahead)          // make sure both chroma scale factors fit
+        while (chroma_denom > 0) {
+            const float thresh = 127.f / (1 << chroma_denom);
+            if (guess_scale[1] < thresh && guess_scale[2] < thresh) break;
+            chroma_denom--;
+        }
     static const uint8_t check_distance[12][2] = { { 0, 0 }, { 0, 0 }, { 0, 1 }, { 0, 1 }, { 0, 1 }, { 0, 1 }, { 0, 1 }, { 1, 1 }, { 1, 1 }, { 2, 1 }, { 2, 1 }, { 4, 2 } };
     const int sub = clampi(h->param.analyse.i_subpel_refine, 0, 11);
     const int scale_dist = b_lookahead ? 0 : check_distance[sub][0], offset_dist = b_lookahead ? 0 : check_distance[sub][1];
-    const int start_scale = clampi(minscale - scale_dist, 0, 127), end_scale = clampi(minscale + scale_dist, 0, 127);      // (x264: up to 255; beyond 127 the syntax cannot carry it)
-    bool found = false;
-    for (int i_scale = start_scale; i_scale <= end_scale; i_scale++) {
-        int cur_scale = i_scale;
-        int cur_offset = (int)(fenc_mean - ref_mean * cur_scale / (1 << mindenom) + 0.5f * b_lookahead);
-        if (cur_offset < -128 || cur_offset > 127) {
-            cur_offset = clampi(cur_offset, -128, 127);
-            float cs = (1 << mindenom) * (fenc_mean - cur_offset) / ref_mean + 0.5f;
-            cur_scale = (int)(cs < 0 ? 0 : cs > 127 ? 127 : cs);
+    bool planes_on[3] = { false, false, false };
+    int p_scale[3] = { 1, 1, 1 }, p_denom[3] = { 0, 0, 0 }, p_off[3] = { 0, 0, 0 };
+    // (the chroma planes are not checked in the lookahead, or if there was no luma weight)
+    for (int plane = 0; plane < nplanes && !(plane && !planes_on[0]); plane++) {
+        if (fabsf(ref_mean[plane] - fenc_mean[plane]) < 0.5f && fabsf(1.f - guess_scale[plane]) < epsilon) continue;      // early termination
+        int mindenom, minscale, minoff = 0;
+        if (plane) {
+            mindenom = chroma_denom;
+            minscale = clampi((int)roundf(guess_scale[plane] * (1 << chroma_denom)), 0, 255);
+            if (minscale > 127) { planes_on[1] = planes_on[2] = false; break; }
+        } else {
+            // weight_get_h264( round( guess_scale * 128 ), 0 )
+            mindenom = 7; minscale = (int)roundf(guess_scale[0] * 128);
+            while (mindenom > 0 && minscale > 127) { mindenom--; minscale >>= 1; }
+            if (minscale > 127) minscale = 127;
         }
-        const int start_offset = clampi(cur_offset - offset_dist, -128, 127), end_offset = clampi(cur_offset + offset_dist, -128, 127);
-        for (int i_off = start_offset; i_off <= end_offset; i_off++) {
-            if (x264gpu_slicetype_weight_cost(h->st, fenc.slot, ref.slot, dist, 1, cur_scale, mindenom, i_off, &score, nullptr) != X264GPU_OK) { h->failed = true; return none; }
-            if ((unsigned)score < minscore) { minscore = (unsigned)score; minscale = cur_scale; minoff = i_off; found = true; }
-            if (minoff == start_offset && i_off != start_offset) break;          // the previous offset was better: no more
+        auto cost_of = [&](int on, int scale, int denom, int offset, int64_t &score) {
+            if (!plane) return x264gpu_slicetype_weight_cost(h->st, fenc.slot, ref.slot, dist, on, scale, denom, offset, &score, nullptr) == X264GPU_OK;
+            return x264gpu_slicetype_weight_cost_chroma(h->st, fenc.slot, h->q_raw[(size_t)fenc.slot], h->q_raw[(size_t)ref.slot], dist, plane, on, scale, denom, offset, &score, nullptr) == X264GPU_OK;
+        };
+        int32_t dummy = 0;
+        int64_t score = 0;
+        if ((!plane && x264gpu_slicetype_frame_cost(h->st, fenc.slot, fenc.slot, fenc.slot, 0, 0, &dummy, nullptr) != X264GPU_OK) ||       // the picture's intra costs
+            !cost_of(0, 1, 0, 0, score)) { h->failed = true; return none; }
+        const unsigned origscore = (unsigned)score;
+        unsigned minscore = origscore;
+        if (!minscore) continue;
+        const int start_scale = clampi(minscale - scale_dist, 0, 127), end_scale = clampi(minscale + scale_dist, 0, 127);
+        bool found = false;
+        for (int i_scale = start_scale; i_scale <= end_scale; i_scale++) {
+            int cur_scale = i_scale;
+            int cur_offset = (int)(fenc_mean[plane] - ref_mean[plane] * cur_scale / (1 << mindenom) + 0.5f * b_lookahead);
+            if (cur_offset < -128 || cur_offset > 127) {
+                cur_offset = clampi(cur_offset, -128, 127);
+                float cs = (1 << mindenom) * (fenc_mean[plane] - cur_offset) / ref_mean[plane] + 0.5f;
+                cur_scale = (int)(cs < 0 ? 0 : cs > 127 ? 127 : cs);
+            }
+            const int start_offset = clampi(cur_offset - offset_dist, -128, 127), end_offset = clampi(cur_offset + offset_dist, -128, 127);
+            for (int i_off = start_offset; i_off <= end_offset; i_off++) {
+                if (!cost_of(1, cur_scale, mindenom, i_off, score)) { h->failed = true; return none; }
+                if ((unsigned)score < minscore) { minscore = (unsigned)score; minscale = cur_scale; minoff = i_off; found = true; }
+                if (minoff == start_offset && i_off != start_offset) break;          // the previous offset was better: no more
+            }
         }
+        if (!plane) while (mindenom > 0 && !(minscale & 1)) { mindenom--; minscale >>= 1; }      // a smaller denominator if possible
+        if (!found || (minscale == 1 << mindenom && minoff == 0) || (float)minscore / origscore > 0.998f) continue;
+        planes_on[plane] = true; p_scale[plane] = minscale; p_denom[plane] = mindenom; p_off[plane] = minoff;
     }
-    while (mindenom > 0 && !(minscale & 1)) { mindenom--; minscale >>= 1; }      // a smaller denominator if possible
-    if (!found || (minscale == 1 << mindenom && minoff == 0) || (float)minscore / origscore > 0.998f) return none;
-    w.on = 1; w.scale = minscale; w.denom = mindenom; w.offset = minoff;
+    if (!planes_on[0]) return none;           // (x264 keeps chroma weights only beside a luma weight: they are not even analysed without one)
+    w.on = 1; w.scale = p_scale[0]; w.denom = p_denom[0]; w.offset = p_off[0];
+    if (planes_on[1] || planes_on[2]) {
+        // optimise and unify the chroma denominator: a plane weighted alone leaves the other with the implicit scale 1 << denom, which 7 cannot carry
+        int denom = planes_on[1] ? p_denom[1] : p_denom[2];
+        const bool both = planes_on[1] && planes_on[2];
+        while ((!both && denom == 7) || (denom > 0 && !(planes_on[1] && (p_scale[1] & 1)) && !(planes_on[2] && (p_scale[2] & 1)))) {
+            denom--;
+            for (int i = 1; i <= 2; i++) if (planes_on[i]) { p_scale[i] >>= 1; p_denom[i] = denom; }
+        }
+        w.cdenom = denom;
+        for (int c = 0; c < 2; c++) if (planes_on[c + 1]) { w.con[c] = 1; w.cscale[c] = p_scale[c + 1]; w.coffset[c] = p_off[c + 1]; }
+    }
     return w;
 }
 
@@ -1925,6 +1968,17 @@ int x264host_dpb_plan_w(void *h, int type, int frame, int n_follow, const int *f
     Dpb::LumaWeight lw;
     if (w) { lw.on = 1; lw.scale = w[0]; lw.denom = w[1]; lw.offset = w[2]; }
     const DpbPlan &p = ((Dpb *)h)->plan(type, frame, n_follow, follow_coded, follow_frame, w ? &lw : nullptr);
+    *pic_out = p.pic;
+    if (info) { info[0] = p.frame_num; info[1] = p.nal_ref_idc; info[2] = p.n_mmco; info[3] = p.reorder[0].n; info[4] = p.reorder[1].n; }
+    return 0;
+}
+/* ... and chroma weights beside it: w = { scale, denom, offset, chroma denom, Cb on, Cb scale, Cb offset, Cr on, Cr scale, Cr offset } */
+int x264host_dpb_plan_wc(void *h, int type, int frame, int n_follow, const int *follow_coded, const int *follow_frame, const int *w, x264gpu_pic *pic_out, int *info)
+{
+    Dpb::LumaWeight lw;
+    lw.on = 1; lw.scale = w[0]; lw.denom = w[1]; lw.offset = w[2]; lw.cdenom = w[3];
+    for (int c = 0; c < 2; c++) { lw.con[c] = w[4 + 3 * c]; lw.cscale[c] = w[5 + 3 * c]; lw.coffset[c] = w[6 + 3 * c]; }
+    const DpbPlan &p = ((Dpb *)h)->plan(type, frame, n_follow, follow_coded, follow_frame, &lw);
     *pic_out = p.pic;
     if (info) { info[0] = p.frame_num; info[1] = p.nal_ref_idc; info[2] = p.n_mmco; info[3] = p.reorder[0].n; info[4] = p.reorder[1].n; }
     return 0;

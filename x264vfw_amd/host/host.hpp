@@ -32,10 +32,12 @@ struct SliceParams {
     struct Reorder { int n = 0; struct { int idc, arg; } cmd[16]; } reorder[2];
     // memory_management_control_operation 1 (mark a short-term picture unused) x n_mmco: difference_of_pic_nums (x264's b-pyramid bookkeeping)
     int n_mmco = 0, mmco_diff[16] = { 0 };
-    // pred_weight_table of P slices (x264 --weightp, PPS weighted_pred_flag): present whenever the PPS flag is set; luma weights only — the chroma
-    // flags are sent as 0.  luma_log2_weight_denom = the denominator of the first weighted index (x264: all weighted indices share it), else 0
+    // pred_weight_table of P slices (x264 --weightp, PPS weighted_pred_flag): present whenever the PPS flag is set.  luma_log2_weight_denom /
+    // chroma_log2_weight_denom = the denominator of the first weighted index (x264: all weighted indices share it), else 0; an index with one chroma
+    // plane weighted sends the other as { 1 << denom, 0 } (x264 weighted_pred_init)
     int weighted_pred = 0;
     struct { int on, denom, scale, offset; } wl0[X264GPU_MAX_LIST] = {};
+    struct { int on[2], denom, scale[2], offset[2]; } wc0[X264GPU_MAX_LIST] = {};
 };
 struct SliceStats { int skip; };
 

@@ -334,12 +334,16 @@ void write_slice_header(BitWriter &bw, const SliceParams &p)
     if (p.weighted_pred && p.slice_type == X264GPU_SLICE_P) {   // pred_weight_table()
         int denom = 0;
         for (int i = p.num_ref - 1; i >= 0; i--) if (p.wl0[i].on) denom = p.wl0[i].denom;
+        int cdenom = 0;
+        for (int i = p.num_ref - 1; i >= 0; i--) if (p.wc0[i].on[0] || p.wc0[i].on[1]) cdenom = p.wc0[i].denom;
         bw.ue((uint32_t)denom);                                 // luma_log2_weight_denom
-        bw.ue(0);                                               // chroma_log2_weight_denom
+        bw.ue((uint32_t)cdenom);                                // chroma_log2_weight_denom
         for (int i = 0; i < p.num_ref; i++) {
             bw.put1(p.wl0[i].on != 0);                          // luma_weight_l0_flag
             if (p.wl0[i].on) { bw.se(p.wl0[i].scale); bw.se(p.wl0[i].offset); }
-            bw.put1(0);                                         // chroma_weight_l0_flag
+            const bool cw = p.wc0[i].on[0] || p.wc0[i].on[1];
+            bw.put1(cw);                                        // chroma_weight_l0_flag
+            if (cw) for (int c = 0; c < 2; c++) { bw.se(p.wc0[i].on[c] ? p.wc0[i].scale[c] : 1 << cdenom); bw.se(p.wc0[i].on[c] ? p.wc0[i].offset[c] : 0); }
         }
     }
     if (p.nal_ref_idc) {
