@@ -256,8 +256,16 @@ typedef struct x264gpu_pic {
     /* ... and the explicit chroma weights of list-0 index i (x264_weights_analyse weights the chroma planes of a fade once luma got a weight):
      * plane 0 = Cb, 1 = Cr, one denominator for both (chroma_log2_weight_denom); same formula as luma */
     struct { int8_t on[2], denom, pad; int16_t scale[2], offset[2]; } wc0[X264GPU_MAX_LIST];
+    /* B pictures, x264 --direct: direct_temporal = 1: temporal direct prediction (8.4.1.2.3; direct_spatial_mv_pred_flag 0), 0: spatial.  This one
+     * field may differ between the streams of a call (each stream's --direct auto state decides it).  direct_auto = 1 (--direct auto, every
+     * stream alike): each macroblock also predicts with the OTHER mode and counts which of the two would let x264_macroblock_probe_bskip skip it
+     * (h->stat.frame.i_direct_score[]; x264gpu_encoder_direct_scores) — the host feeds the counts into the next B picture's choice */
+    int direct_temporal, direct_auto;
 } x264gpu_pic;
 
+/* --direct auto: h_scores[streams][2] = how many macroblocks of the last B picture coded with direct_auto the skip probe passed under temporal [0] /
+ * spatial [1] direct prediction (x264 h->stat.frame.i_direct_score) */
+int  x264gpu_encoder_direct_scores(x264gpu_encoder *enc, int *h_scores);
 int  x264gpu_encoder_create(x264gpu_encoder **enc, const x264gpu_config *cfg);
 void x264gpu_encoder_destroy(x264gpu_encoder *enc);
 /* sizes of the per-frame outputs for ONE stream */

@@ -57,7 +57,7 @@ typedef struct {          /* x264_mb_analysis_t + the parts of h->mb the analysi
     int nref_l[2];
     me_t me16l[2], bi16[2], me8l[2][4], me16x8l[2][2], me8x16l[2][2];
     int mvcl[2][X264O_MAX_REFS][5][2];
-    int direct_ref[2], direct_mv[2][4][2];
+    int direct_ref[2][4], direct_mv[2][4][2], b_direct_available;      /* per 8x8 block (temporal direct: the blocks' list-0 indices differ) */
     int cost16x16bi, cost16x16direct, cost8x8direct[4], cost8x8bi, cost16x8bi, cost8x16bi;
     int satd8x8b[3][4], cost_est16x8[2], cost_est8x16[2];
     int sub8[4], part16x8[2], part8x16[2];      /* per block / half: 0 list 0, 1 list 1, 2 both, 3 direct (8x8 only) */
@@ -163,7 +163,7 @@ static int predict_mv_ref16x16_l(const actx *a, int l, int r, int mvc[][2])
     int16_t (*mvr)[2] = mvr_of(e, l, r);
     int n = 0;
     /* B slices: the direct vector of the last 8x8 block when it points into this reference (h->mb.cache still holds the direct prediction) */
-    if (e->slice_type == X264GPU_SLICE_B && a->direct_ref[l] == r) { mvc[n][0] = a->direct_mv[l][3][0]; mvc[n][1] = a->direct_mv[l][3][1]; n++; }
+    if (e->slice_type == X264GPU_SLICE_B && a->b_direct_available && a->direct_ref[l][3] == r) { mvc[n][0] = a->direct_mv[l][3][0]; mvc[n][1] = a->direct_mv[l][3][1]; n++; }      /* (h->mb.cache.ref[l][scan8[12]]: the direct prediction's last block) */
     const int16_t *lowres = l ? e->lowres_mv1 : e->lowres_mv;
     if (r == 0 && lowres && lowres[0] != 0x7fff) {          /* h->fenc->lowres_mvs[l][distance - 1] */
         mvc[n][0] = lowres[2 * a->mi] * 2; mvc[n][1] = lowres[2 * a->mi + 1] * 2; n++;
@@ -1663,7 +1663,7 @@ static void predict_direct_spatial(actx *a)
         ref[l] = i_ref;
     }
     if (ref[0] < 0 && ref[1] < 0) ref[0] = ref[1] = 0;       /* nothing around: both lists, index 0, zero vectors */
-    for (int l = 0; l < 2; l++) { a->direct_ref[l] = ref[l]; for (int k = 0; k < 4; k++) { a->direct_mv[l][k][0] = mv[l][0]; a->direct_mv[l][k][1] = mv[l][1]; } }
+    for (int l = 0; l < 2; l++) for (int k = 0; k < 4; k++) { a->direct_ref[l][k] = ref[l]; a->direct_mv[l][k][0] = mv[l][0]; a->direct_mv[l][k][1] = mv[l][1]; }
     if (!(mv[0][0] | mv[0][1] | mv[1][0] | mv[1][1]) || (ref[0] && ref[1])) return;
     /* colZeroFlag per 8x8 block (direct_8x8_inference: its corner): the co-located block of list 1's first picture points into ITS reference 0
      * with a vector within +-1 -> the vectors of the lists whose direct reference is 0 become zero */
@@ -1675,11 +1675,35 @@ static void predict_direct_spatial(actx *a)
     }
 }
 
+/* x264_mb_predict_mv_direct16x16, temporal mode (mb_predict_mv_direct16x16_temporal; 8.4.1.2.3 with direct_8x8_inference): per 8x8 block the
+ * co-located block of list 1's first picture — its list-0 reference mapped into this picture's list 0, its vector scaled by the POC distances for
+ * list 0, the remainder for list 1 (index 0).  An intra co-located macroblock gives index 0 and zero vectors.  Returns 0 (no direct prediction for
+ * this macroblock) when a co-located block has no list-0 motion or its reference is not in this picture's list 0, as x264 does. */
+static int predict_direct_temporal(actx *a)
+{
+    const x264o_encoder *e = a->e;
+    const int cs = ref_slot_l(e, 1, 0);
+    const int intra_col = is_intra_type(e->mbtype[cs][a->mi]);
+    for (int k = 0; k < 4; k++) {
+        a->direct_ref[1][k] = 0;
+        if (intra_col) { a->direct_ref[0][k] = 0; a->direct_mv[0][k][0] = a->direct_mv[0][k][1] = a->direct_mv[1][k][0] = a->direct_mv[1][k][1] = 0; continue; }
+        const int rc = e->colref0[cs][a->mi][k];
+        const int i_ref = rc < 0 ? -1 : e->map_col_to_list0[rc];
+        if (i_ref < 0) return 0;
+        const int dsf = e->dist_scale[i_ref], cx = e->colmv[cs][a->mi][k][0], cy = e->colmv[cs][a->mi][k][1];
+        const int l0x = (dsf * cx + 128) >> 8, l0y = (dsf * cy + 128) >> 8;
+        a->direct_ref[0][k] = i_ref;
+        a->direct_mv[0][k][0] = (int16_t)l0x; a->direct_mv[0][k][1] = (int16_t)l0y;
+        a->direct_mv[1][k][0] = (int16_t)(l0x - cx); a->direct_mv[1][k][1] = (int16_t)(l0y - cy);
+    }
+    return 1;
+}
+
 static void set_direct_record(const actx *a, x264gpu_mb *mb, int k)
 {
-    mb->ref[k] = (int8_t)a->direct_ref[0]; mb->ref1[k] = (int8_t)a->direct_ref[1];
-    mb->mv[k][0] = (int16_t)(a->direct_ref[0] < 0 ? 0 : a->direct_mv[0][k][0]); mb->mv[k][1] = (int16_t)(a->direct_ref[0] < 0 ? 0 : a->direct_mv[0][k][1]);
-    mb->mv1[k][0] = (int16_t)(a->direct_ref[1] < 0 ? 0 : a->direct_mv[1][k][0]); mb->mv1[k][1] = (int16_t)(a->direct_ref[1] < 0 ? 0 : a->direct_mv[1][k][1]);
+    mb->ref[k] = (int8_t)a->direct_ref[0][k]; mb->ref1[k] = (int8_t)a->direct_ref[1][k];
+    mb->mv[k][0] = (int16_t)(a->direct_ref[0][k] < 0 ? 0 : a->direct_mv[0][k][0]); mb->mv[k][1] = (int16_t)(a->direct_ref[0][k] < 0 ? 0 : a->direct_mv[0][k][1]);
+    mb->mv1[k][0] = (int16_t)(a->direct_ref[1][k] < 0 ? 0 : a->direct_mv[1][k][0]); mb->mv1[k][1] = (int16_t)(a->direct_ref[1][k] < 0 ? 0 : a->direct_mv[1][k][1]);
 }
 
 /* the record of a B candidate: type / partition / per-block list use from the analysis state (x264_analyse_update_cache) */
@@ -1809,7 +1833,7 @@ static int analyse_inter_b16x16(actx *a, int try_skip)
             int16_t (*mvr)[2] = mvr_of(e, l, r);
             mvr[a->mi][0] = (int16_t)m.mv[0]; mvr[a->mi][1] = (int16_t)m.mv[1];
             if (r == 0 && try_skip) {          /* fast skip detection against the direct vector of the first 8x8 block */
-                const int dx = a->direct_ref[l] < 0 ? 0 : a->direct_mv[l][0][0], dy = a->direct_ref[l] < 0 ? 0 : a->direct_mv[l][0][1];
+                const int dx = a->direct_ref[l][0] < 0 ? 0 : a->direct_mv[l][0][0], dy = a->direct_ref[l][0] < 0 ? 0 : a->direct_mv[l][0][1];
                 if (abs(a->me16l[l].mv[0] - dx) + abs(a->me16l[l].mv[1] - dy) > 1) try_skip = 0;
                 else if (!l) return 1;         /* (the skip itself was tested before) */
             }
@@ -1850,7 +1874,7 @@ static int analyse_inter_b16x16(actx *a, int try_skip)
 static void cache_b_block(actx *a, int bx8, int by8, int w8, int h8, int use, const me_t *m0, const me_t *m1, int k_direct)
 {
     if (use == 3) {
-        for (int l = 0; l < 2; l++) cache_block_l(a, l, bx8, by8, w8, h8, a->direct_ref[l], a->direct_ref[l] < 0 ? NULL : a->direct_mv[l][k_direct]);
+        for (int l = 0; l < 2; l++) cache_block_l(a, l, bx8, by8, w8, h8, a->direct_ref[l][k_direct], a->direct_ref[l][k_direct] < 0 ? NULL : a->direct_mv[l][k_direct]);
         return;
     }
     if (use != 1) cache_block_l(a, 0, bx8, by8, w8, h8, m0->ref, m0->mv); else cache_block_l(a, 0, bx8, by8, w8, h8, -1, NULL);
@@ -2022,7 +2046,7 @@ static void me_refine_bidir_satd(const actx *a, me_t *m0, me_t *m1, int i_weight
 static void analyse_b_rd(actx *a, int i_satd_inter, x264gpu_mb *mb, int16_t *lv)
 {
     const int thresh = a->b_early_terminate ? i_satd_inter * (17 + (a->e->cfg.psy_rd_q8 != 0)) / 16 + 1 : COST_MAX;
-    if (a->rd16direct == COST_MAX) a->rd16direct = rd_cost_b(a, X264GPU_MB_B_DIRECT, D_16x16, 0, 0, mb, lv);
+    if (a->b_direct_available && a->rd16direct == COST_MAX) a->rd16direct = rd_cost_b(a, X264GPU_MB_B_DIRECT, D_16x16, 0, 0, mb, lv);
     if (a->me16l[0].cost < thresh && a->rd16l[0] == COST_MAX) a->rd16l[0] = rd_cost_b(a, X264GPU_MB_B_INTER, D_16x16, 0, 0, mb, lv);
     if (a->me16l[1].cost < thresh && a->rd16l[1] == COST_MAX) a->rd16l[1] = rd_cost_b(a, X264GPU_MB_B_INTER, D_16x16, 1, 0, mb, lv);
     if (a->cost16x16bi < thresh && a->rd16bi == COST_MAX) a->rd16bi = rd_cost_b(a, X264GPU_MB_B_INTER, D_16x16, 2, 0, mb, lv);
@@ -2043,30 +2067,42 @@ static void macroblock_b(actx *a, x264gpu_mb *mb, int16_t *lv)
     a->nref_l[0] = e->nref_l[0]; a->nref_l[1] = e->nref_l[1];
     a->rd16l[0] = a->rd16l[1] = a->rd16bi = a->rd16direct = a->rd8x8bi = a->rd16x8bi = a->rd8x16bi = COST_MAX;
     a->cost8x8bi = a->cost16x8bi = a->cost8x16bi = COST_MAX;
-    a->direct_ref[0] = a->direct_ref[1] = -1;
-    /* direct prediction, motion-compensated into the reconstruction; B_SKIP when its distortion alone is below the cheapest coded macroblock */
+    for (int k = 0; k < 4; k++) a->direct_ref[0][k] = a->direct_ref[1][k] = -1;
+    /* direct prediction (x264_mb_predict_mv_direct16x16 in the slice's mode), motion-compensated into the reconstruction; B_SKIP when its distortion
+     * alone is below the cheapest coded macroblock.  --direct auto (b_direct_auto_write): the other mode is predicted and probed first, then the
+     * slice's own — "prefer whichever mode allows more Skip macroblocks" (h->stat.frame.i_direct_score) */
     a->cur_valid = a->cur_valid1 = 0;
-    predict_direct_spatial(a);
-    {
+    a->bskip_cost = COST_MAX; a->cost16x16direct = COST_MAX;
+    for (int i = 0; i < 4; i++) a->cost8x8direct[i] = COST_MAX;
+    int probed = 0;
+    for (int pass = e->direct_auto ? 0 : 1; pass < 2; pass++) {
+        const int temporal = pass ? e->direct_temporal : !e->direct_temporal;
+        if (temporal) a->b_direct_available = predict_direct_temporal(a); else { predict_direct_spatial(a); a->b_direct_available = 1; }
+        probed = 0;
+        if (!a->b_direct_available) continue;
         x264gpu_mb t;
         pixel pu[64], pv[64];
         memset(&t, 0, sizeof(t));
         fill_b_record(a, X264GPU_MB_B_SKIP, D_16x16, &t);
         mc_mb_b(e, a->mbx, a->mby, &t, rec, e->rs, pu, pv);
         for (int y = 0; y < 8; y++) for (int x = 0; x < 8; x++) { rec_uv[y * e->rs + 2 * x] = pu[y * 8 + x]; rec_uv[y * e->rs + 2 * x + 1] = pv[y * 8 + x]; }
+        if (e->direct_auto) { probed = probe_bskip(a); e->direct_score[!temporal] += probed; }       /* (score[1] = spatial) */
     }
     int b_skip = 0, try_skip = 0;
-    if (a->mbrd) { a->bskip_cost = rd_ssd_mb(a); b_skip = a->bskip_cost <= ((6 * a->lambda2 + 128) >> 8); }
-    else {
-        /* without RD: x264_macroblock_probe_bskip; from subme 3 on the skip also wants both 16x16 searches to land on the direct vectors */
-        try_skip = probe_bskip(a);
-        if (a->subme < 3) b_skip = try_skip;
+    if (a->b_direct_available) {
+        if (a->mbrd) { a->bskip_cost = rd_ssd_mb(a); b_skip = a->bskip_cost <= ((6 * a->lambda2 + 128) >> 8); }
+        else if (!e->direct_auto) {
+            /* without RD: x264_macroblock_probe_bskip; from subme 3 on the skip also wants both 16x16 searches to land on the direct vectors */
+            try_skip = probe_bskip(a);
+            if (a->subme < 3) b_skip = try_skip;
+        } else b_skip = probed;          /* (--direct auto without RD: the probe of the slice's mode stands) */
     }
     if (b_skip) {
         for (int l = 0; l < 2; l++) for (int r = 0; r < a->nref_l[l]; r++) { int16_t (*mvr)[2] = mvr_of(e, l, r); mvr[mi][0] = mvr[mi][1] = 0; }
         fill_b_record(a, X264GPU_MB_B_SKIP, D_16x16, mb);
         return;                       /* the prediction is the reconstruction */
     }
+    if (a->b_direct_available)
     analyse_inter_direct(a);
     if (analyse_inter_b16x16(a, try_skip)) {
         for (int l = 0; l < 2; l++) for (int r = 1; r < a->nref_l[l]; r++) { int16_t (*mvr)[2] = mvr_of(e, l, r); mvr[mi][0] = mvr[mi][1] = 0; }

@@ -45,7 +45,7 @@ x264o_encoder *x264o_encoder_create(const x264gpu_config *cfg)
         e->chroma[s] = calloc(1, e->cplane_bytes);
         e->mv16[s] = calloc(n, sizeof(int16_t[2]));
         e->mbtype[s] = calloc(n, 1);
-        e->colref[s] = calloc(n, 4); e->colmv[s] = calloc(n, sizeof(int16_t[4][2]));
+        e->colref[s] = calloc(n, 4); e->colmv[s] = calloc(n, sizeof(int16_t[4][2])); e->colref0[s] = calloc(n, 4);
     }
     for (int r = 1; r < X264O_MAX_REFS; r++) e->mvr[r] = calloc(n, sizeof(int16_t[2]));
     for (int r = 0; r < X264O_MAX_REFS; r++) e->mvr1[r] = calloc(n, sizeof(int16_t[2]));
@@ -58,7 +58,7 @@ x264o_encoder *x264o_encoder_create(const x264gpu_config *cfg)
 void x264o_encoder_destroy(x264o_encoder *e)
 {
     if (!e) return;
-    for (int s = 0; s < e->slots; s++) { free(e->luma[s]); free(e->chroma[s]); free(e->mv16[s]); free(e->mbtype[s]); free(e->colref[s]); free(e->colmv[s]); }
+    for (int s = 0; s < e->slots; s++) { free(e->luma[s]); free(e->chroma[s]); free(e->mv16[s]); free(e->mbtype[s]); free(e->colref[s]); free(e->colmv[s]); free(e->colref0[s]); }
     for (int r = 1; r < X264O_MAX_REFS; r++) free(e->mvr[r]);
     for (int r = 0; r < X264O_MAX_REFS; r++) free(e->mvr1[r]);
     for (int q = 0; q < 52; q++) free(e->cost_mv[q]);
@@ -262,10 +262,14 @@ static void bipred_init(x264o_encoder *e)
             const int td = clampi(poc1 - poc0, -128, 127);
             int dsf = 256;
             if (td) { const int tb = clampi(e->poc - poc0, -128, 127), tx = (16384 + (abs(td) >> 1)) / td; dsf = clampi((tb * tx + 32) >> 6, -1024, 1023); }
+            if (r1 == 0) e->dist_scale[r0] = dsf;          /* h->mb.dist_scale_factor[r0][0]: temporal direct scales the co-located vector by it */
             dsf >>= 2;
             e->bipred_weight[r0][r1] = (e->cfg.weightb && dsf >= -64 && dsf <= 128) ? 64 - dsf : 32;
         }
 }
+
+/* --direct auto: the skip-probe counts of the last B picture coded with direct_auto (h->stat.frame.i_direct_score: [0] temporal, [1] spatial) */
+void x264o_encoder_direct_scores(const x264o_encoder *e, int out[2]) { out[0] = e->direct_score[0]; out[1] = e->direct_score[1]; }
 
 /* One picture with explicit control (x264gpu_pic): slice type, quantiser, POC, destination slot, reference lists.  B pictures need cfg.rd
  * and cfg.cabac. */
@@ -299,13 +303,26 @@ int x264o_encoder_encode_pic(x264o_encoder *e, const uint8_t *i420, const x264gp
         e->wc0[r].denom = (e->wc0[r].on[0] || e->wc0[r].on[1]) ? pic->wc0[r].denom : 0;
     }
     if (slice_type == X264GPU_SLICE_P && pic->blind_dupe > 0 && pic->blind_dupe < e->nref) e->blind_dupe = pic->blind_dupe;
-    if (slice_type == X264GPU_SLICE_B) bipred_init(e);
+    e->direct_temporal = 0; e->direct_auto = 0; e->direct_score[0] = e->direct_score[1] = 0;
+    if (slice_type == X264GPU_SLICE_B) {
+        bipred_init(e);
+        e->direct_temporal = pic->direct_temporal != 0; e->direct_auto = pic->direct_auto != 0;
+        /* x264_macroblock_slice_init: map_col_to_list0[i] = the list-0 index of this picture that shows the picture behind index i of the co-located
+         * picture's list 0 (-2: none) */
+        const int cs = e->lslot[1][0];
+        for (int i = 0; i < X264GPU_MAX_LIST; i++) {
+            e->map_col_to_list0[i] = -2;
+            if (i >= e->slot_nref[cs]) continue;
+            for (int j = 0; j < e->nref_l[0]; j++) if (e->slot_poc[e->lslot[0][j]] == e->slot_l0poc[cs][i]) { e->map_col_to_list0[i] = j; break; }
+        }
+    }
     ingest(e, i420);
     const int slice_qp = pic->qp;
     if (pic->qp_frac_q8 < -128 || pic->qp_frac_q8 > 127) return -1;
     compute_mb_qp(e, slice_qp, pic->qp_frac_q8);
     e->mbs = mbs; e->levels = levels; e->intra_count = 0;
     e->slot_nref[e->cur] = e->nref; e->slot_poc[e->cur] = e->poc; e->slot_ref0poc[e->cur] = e->nref ? e->slot_poc[ref_slot(e, 0)] : 0;
+    for (int r = 0; r < X264GPU_MAX_LIST; r++) e->slot_l0poc[e->cur][r] = r < e->nref ? e->slot_poc[ref_slot(e, r)] : 0;
     /* the macroblock loop: raster order, every macroblock analysed AND coded before the next one starts (x264_slice_write) */
     const int ns = e->cfg.slices > 1 ? e->cfg.slices : 1;
     for (int sl = 0; sl < ns; sl++) {
@@ -328,6 +345,7 @@ int x264o_encoder_encode_pic(x264o_encoder *e, const uint8_t *i420, const x264gp
                     const int intra = m->type <= X264GPU_MB_I16x16, b = m->type >= X264GPU_MB_B_DIRECT;
                     const int use1 = !intra && b && m->ref[k] < 0;
                     e->colref[e->cur][mi][k] = (int8_t)(intra ? -1 : use1 ? m->ref1[k] : m->ref[k]);
+                    e->colref0[e->cur][mi][k] = (int8_t)(intra ? -1 : m->ref[k]);
                     e->colmv[e->cur][mi][k][0] = intra ? 0 : use1 ? m->mv1[k][0] : m->mv[k][0];
                     e->colmv[e->cur][mi][k][1] = intra ? 0 : use1 ? m->mv1[k][1] : m->mv[k][1];
                 }

@@ -47,6 +47,12 @@ struct x264o_encoder {
     /* what spatial direct prediction reads from the first picture of list 1 (x264_frame_t ref[] / mv[] of the co-located macroblock): per 8x8
      * block the reference index the block used (list 0's, else list 1's; -1 intra) and that vector */
     int8_t (*colref[X264O_MAX_SLOTS])[4];
+    /* ... and what temporal direct prediction reads: the block's own LIST-0 index (-1: none / intra), the POCs behind the picture's list 0 when it was
+     * coded (x264_frame_t ref_poc[0]); of the B picture being coded: its mode, whether both modes are probed (--direct auto), the probe counts
+     * (h->stat.frame.i_direct_score), map_col_to_list0 and dist_scale_factor[r][0] */
+    int8_t (*colref0[X264O_MAX_SLOTS])[4];
+    int slot_l0poc[X264O_MAX_SLOTS][X264GPU_MAX_LIST];
+    int direct_temporal, direct_auto, direct_score[2], map_col_to_list0[X264GPU_MAX_LIST], dist_scale[X264GPU_MAX_LIST];
     int16_t (*colmv[X264O_MAX_SLOTS])[4][2];
     const int16_t *lowres_mv1;   /* B: lookahead vectors towards the first picture of list 1 (lowres_mvs[1][d]) */
     int poc;                     /* POC of the picture being coded (2 x pictures since the IDR) */

@@ -83,6 +83,8 @@ struct Decoder {
     int list_slot[2][16], list_poc[2][16];
     std::vector<int> pending_mmco;           // picture numbers to mark unused once the picture is complete
     std::vector<MbInfo> slot_mb[8];          // motion of every kept picture (co-located blocks of direct prediction)
+    int slot_lpoc[8][2][16];                 // ... and the POCs behind its reference lists when it was decoded (temporal direct: the picture a co-located block refers to)
+    int direct_spatial = 1;                  // direct_spatial_mv_pred_flag of the slice
     std::vector<int> frame_pocs;             // POC of every output picture (decoding order)
     int weighted_slices[2] = { 0, 0 };       // diagnostics: P slices that carried an explicit luma weight / a chroma weight
     int next_mb = 0, slice_no = 0, pic_disable = 0, pic_a = 0, pic_b = 0;      // slices of the picture being decoded
@@ -499,8 +501,38 @@ struct SliceDec {
         return 3;
     }
     // spatial direct prediction of the whole macroblock (8.4.1.2.2, direct_8x8_inference): fills ref8 / mv8 of both lists for the blocks in mask
+    // temporal direct prediction (8.4.1.2.3, direct_8x8_inference: the corner block of each co-located 8x8): list 0 = the picture the co-located block
+    // refers to (its list-0 motion, list 1's when list 0 is unused), found in this slice's list 0 by its POC; the co-located vector scaled by the
+    // POC distances for list 0, the remainder for list 1 index 0; an intra co-located macroblock gives index 0 and zero vectors
+    void direct_temporal(int mbx, int mby, MbInfo &m, int mask)
+    {
+        const int cs = d.ref_slot_l(1, 0);
+        const std::vector<MbInfo> &colpic = d.slot_mb[cs];
+        const MbInfo *col = colpic.empty() ? nullptr : &colpic[(size_t)(mby * d.mbw + mbx)];
+        for (int k = 0; k < 4; k++) {
+            if (!(mask >> k & 1)) continue;
+            m.ref8b[k] = 0;
+            if (!col || col->intra) { m.ref8[k] = 0; m.mv8[k][0] = m.mv8[k][1] = m.mv8b[k][0] = m.mv8b[k][1] = 0; continue; }
+            const int lc = col->ref8[k] >= 0 ? 0 : 1;
+            const int rc = lc ? col->ref8b[k] : col->ref8[k];
+            const int *mc = lc ? col->mv8b[k] : col->mv8[k];
+            if (rc < 0) { br.err = true; return; }
+            const int poc_ref = d.slot_lpoc[cs][lc][rc];
+            int r0 = -1;
+            for (int j = 0; j < d.nref_active; j++) if (d.list_poc[0][j] == poc_ref) { r0 = j; break; }
+            if (r0 < 0) { br.err = true; return; }          // (a conforming stream always finds it)
+            const int poc0 = d.list_poc[0][r0], poc1 = d.list_poc[1][0];
+            const int tb = clampi(d.cur_poc - poc0, -128, 127), td = clampi(poc1 - poc0, -128, 127);
+            m.ref8[k] = r0;
+            if (td == 0) { m.mv8[k][0] = mc[0]; m.mv8[k][1] = mc[1]; m.mv8b[k][0] = m.mv8b[k][1] = 0; continue; }
+            const int tx = (16384 + abs(td / 2)) / td, dsf = clampi((tb * tx + 32) >> 6, -1024, 1023);
+            m.mv8[k][0] = (dsf * mc[0] + 128) >> 8; m.mv8[k][1] = (dsf * mc[1] + 128) >> 8;
+            m.mv8b[k][0] = m.mv8[k][0] - mc[0]; m.mv8b[k][1] = m.mv8[k][1] - mc[1];
+        }
+    }
     void direct_spatial(int mbx, int mby, MbInfo &m, int mask)
     {
+        if (!d.direct_spatial) { direct_temporal(mbx, mby, m, mask); return; }
         int ref[2], mv[2][2];
         const int saved_known = known8;
         known8 = 0;                                      // the neighbours of the MACROBLOCK: nothing inside it counts
@@ -1052,6 +1084,7 @@ void finish_picture(Decoder &d)
                 c[(size_t)y * d.stride + 2 * x + 1] = c[(size_t)sy * d.stride + 2 * sx + 1];
             }
     d.slot_mb[d.cur] = d.mb;
+    for (int l = 0; l < 2; l++) for (int i = 0; i < 16; i++) d.slot_lpoc[d.cur][l][i] = d.list_poc[l][i];
     // decoded reference picture marking (8.2.5): the slice's operations, else the sliding window
     const int max_frame_num = 1 << d.log2_max_frame_num;
     auto picnum = [&](const Decoder::Ref &r) { return r.frame_num > d.cur_frame_num ? r.frame_num - max_frame_num : r.frame_num; };
@@ -1151,7 +1184,7 @@ bool decode_nal(Decoder &d, const uint8_t *nal, size_t n)
             for (int sl = 0; sl < d.slots; sl++) { bool used = false; for (auto &r : d.dpb) used |= r.slot == sl; if (!used) { d.cur = sl; break; } }
             d.pending_mmco.clear();
         }
-        if (st == 1 && !br.get1()) return reject(__LINE__);            // direct_spatial_mv_pred_flag: temporal direct is outside the subset
+        if (st == 1) d.direct_spatial = br.get1();                     // direct_spatial_mv_pred_flag
         d.nref_active = d.num_ref_default; d.nref1_active = st == 1 ? d.num_ref1_default : 0;
         if (st != 2) {
             if (br.get1()) { d.nref_active = (int)br.ue() + 1; if (st == 1) d.nref1_active = (int)br.ue() + 1; }   // num_ref_idx_active_override_flag

@@ -40,6 +40,12 @@ class GpuEncoder:
         mb = self.d_mb.cpu().numpy().view(O.MB_DTYPE).reshape(self.S, self.n)
         return mb, self.d_lv.cpu().numpy()
 
+    def direct_scores(self, s=None):
+        """--direct auto: (temporal, spatial) skip-probe counts of the last B picture coded with pic.direct_auto (stream s; None: stream 0)"""
+        out = np.zeros((self.S, 2), np.int32)
+        lib.check(lib.x264gpu_encoder_direct_scores(self.h, out.ctypes.data), "direct_scores")
+        return tuple(int(v) for v in out[s or 0])
+
     def encode_pic(self, frame, pic):
         """single-stream form with the oracle's signature (tests/bgop.py)"""
         assert self.S == 1

@@ -193,6 +193,12 @@ class OracleEncoder:
         assert rc == 0
         return mbs, lv
 
+    def direct_scores(self):
+        """--direct auto: (temporal, spatial) skip-probe counts of the last B picture coded with pic.direct_auto"""
+        out = np.zeros(2, np.int32)
+        L.x264o_encoder_direct_scores(self.h, ptr(out))
+        return int(out[0]), int(out[1])
+
     def encode_pic(self, i420, pic):
         """one picture with explicit control (lib.make_pic): B pictures, explicit reference lists"""
         mbs = np.zeros(self.n, MB_DTYPE)
@@ -468,6 +474,7 @@ def lsmash_read_mp4(path, max_samples=256):
 _sig("x264o_h264_decode", _i, [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.POINTER(_i), C.POINTER(_i)])
 
 
+_sig("x264o_encoder_direct_scores", None, [C.c_void_p, C.c_void_p])
 _sig("x264o_h264_last_pocs", _i, [C.c_void_p, _i])
 _sig("x264o_h264_last_weighted", None, [C.c_void_p])
 

@@ -185,7 +185,8 @@ int x264gpu_encode_pictures(x264gpu_encoder *g, const uint8_t *i420, const x264g
         if (pics[s].qp_frac_q8 < -128 || pics[s].qp_frac_q8 > 127) return fail("qp_frac_q8 out of range");
         if (s && !(pics[s].slice_type == pics[0].slice_type && pics[s].poc == pics[0].poc && pics[s].dst == pics[0].dst && pics[s].keep == pics[0].keep &&
                    pics[s].nref[0] == pics[0].nref[0] && pics[s].nref[1] == pics[0].nref[1] && !memcmp(pics[s].slot, pics[0].slot, sizeof(pics[0].slot)) &&
-                   pics[s].blind_dupe == pics[0].blind_dupe && !memcmp(pics[s].wl0, pics[0].wl0, sizeof(pics[0].wl0)))) return fail("lock-step streams must share the picture structure");
+                   pics[s].blind_dupe == pics[0].blind_dupe && !memcmp(pics[s].wl0, pics[0].wl0, sizeof(pics[0].wl0)) && !memcmp(pics[s].wc0, pics[0].wc0, sizeof(pics[0].wc0)) &&
+                   (pics[s].direct_auto != 0) == (pics[0].direct_auto != 0))) return fail("lock-step streams must share the picture structure");
     }
     for (int s = 0; s < g->cfg.streams; s++) {
         x264o_encoder_set_mb_qp_offsets(g->e[s], g->off ? g->off + (size_t)s * g->nmb : NULL);
@@ -193,6 +194,8 @@ int x264gpu_encode_pictures(x264gpu_encoder *g, const uint8_t *i420, const x264g
     }
     return X264GPU_OK;
 }
+void x264o_encoder_direct_scores(const x264o_encoder *e, int out[2]);
+int x264gpu_encoder_direct_scores(x264gpu_encoder *g, int *h_scores) { for (int s = 0; s < g->cfg.streams; s++) x264o_encoder_direct_scores(g->e[s], h_scores + 2 * s); return X264GPU_OK; }
 int x264gpu_encoder_get_recon(x264gpu_encoder *g, int s, uint8_t *out, void *st) { x264o_encoder_get_recon(g->e[s], out); return X264GPU_OK; }
 int x264gpu_encoder_get_recon_slot(x264gpu_encoder *g, int s, int slot, uint8_t *out, void *st) { return fail("recon by slot: not in the stub"); }
 

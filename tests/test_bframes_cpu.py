@@ -15,12 +15,12 @@ MEDIUM = dict(refs=3, dpb=4, weightb=1, partitions=7, dct8x8=1, chroma_me=1, mix
               chroma_qp_offset=-2, trellis=63)
 
 
-def run(w, h, types, seed, bframes=3, pyramid=1, weightp=0, pics_out=None, weights=None, frames=None, **over):
+def run(w, h, types, seed, bframes=3, pyramid=1, weightp=0, pics_out=None, weights=None, frames=None, direct="spatial", **over):
     kw = dict(MEDIUM, **over)
     frames = frames if frames is not None else synth_frames(w, h, len(types), seed=seed)
     cfg = O.default_config(w, h, **kw)
     enc = O.OracleEncoder(cfg)
-    stream, recons, order, pocs = bgop.encode_gop(HL, enc, frames, types, cfg, 20, 23, 25, kw["refs"], bframes, pyramid, weightp, pics_out, weights)
+    stream, recons, order, pocs = bgop.encode_gop(HL, enc, frames, types, cfg, 20, 23, 25, kw["refs"], bframes, pyramid, weightp, pics_out, weights, direct)
     dec = O.h264_decode(stream, len(order), w, h)
     assert len(dec) == len(order)
     assert O.h264_last_pocs() == pocs
@@ -56,6 +56,27 @@ def run(w, h, types, seed, bframes=3, pyramid=1, weightp=0, pics_out=None, weigh
 ])
 def test_b_pictures_decode_to_the_encoders_reconstruction(w, h, types, seed, over):
     run(w, h, types, seed, **over)
+
+
+@pytest.mark.parametrize("w,h,types,seed,direct,over", [
+    (176, 144, "IBBBPBBBP", 5, "temporal", {}),                                   # medium's structure: co-located pictures are P and B-ref pictures
+    (96, 80, "IBPBBPBBBPP", 2, "temporal", {}),
+    (176, 144, "IBBPBBP", 7, "temporal", dict(refs=5, dpb=5)),
+    (208, 112, "IBBBPBBP", 3, "temporal", dict(rd=0, trellis=0, subme=5, psy_rd_q8=0)),          # without RD: probe_bskip on the temporal prediction
+    (176, 144, "IBBBPBP", 9, "temporal", dict(me_method=2, partitions=0x707)),
+    (176, 144, "IBBBPBBBPBBP", 5, "auto", {}),                                    # --direct auto: both modes probed, the running score picks the next picture's
+    (176, 144, "IBBPBBPBBP", 8, "auto", dict(rd=0, trellis=0, subme=4, psy_rd_q8=0)),
+    (128, 96, "IBBBPBBBP", 11, "auto", dict(subme=8, rd=63, me_method=1)),
+])
+def test_temporal_direct_and_direct_auto_decode(w, h, types, seed, direct, over):
+    """x264 --direct temporal (mb_predict_mv_direct16x16_temporal: the co-located block's reference mapped into list 0, its vector scaled by the POC
+    distances; no direct prediction where the co-located block has no list-0 motion) and --direct auto (each macroblock probes the skip under both
+    modes, h->stat.i_direct_score picks the next B picture's mode): direct_spatial_mv_pred_flag, the checker decoder's 8.4.1.2.3"""
+    pics = []
+    run(w, h, types, seed, pics_out=pics, direct=direct, **over)
+    if direct == "auto":
+        marks = [p for p in pics if p[0] == "direct"]
+        assert marks and all(sum(m[2]) > 0 for m in marks), marks            # both modes were probed and something could be skipped
 
 
 @pytest.mark.parametrize("w,h,types,seed,over", [

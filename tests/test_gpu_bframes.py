@@ -23,7 +23,7 @@ def describe(mbs_g, mbs_o, i):
     return f"\n gpu {f(mbs_g)}\n cpu {f(mbs_o)}"
 
 
-def run(gpu, w, h, types, seed, streams=1, bframes=3, pyramid=1, weightp=0, weights=None, frames=None, qp_frac=None, **over):
+def run(gpu, w, h, types, seed, streams=1, bframes=3, pyramid=1, weightp=0, weights=None, frames=None, qp_frac=None, direct="spatial", **over):
     from gpu_enc import GpuEncoder
     from x264vfw_amd import host_api as HL
     kw = dict(MEDIUM, **over)
@@ -36,13 +36,24 @@ def run(gpu, w, h, types, seed, streams=1, bframes=3, pyramid=1, weightp=0, weig
     order = bgop.schedule(types, pyramid)
     mbw, mbh = (w + 15) // 16, (h + 15) // 16
     recons = []
+    dscore, modes = [0, 0], []
     for k, (disp, pt) in enumerate(order):
         pic, _ = dpb.plan(pt, disp, bgop.follow_of(order, k), weight=(weights or {}).get(disp) if pt == 2 else None)
         pic.qp = 20 if pt <= 1 else 23 if pt == 2 else 25 if pt == 4 else 24
         if qp_frac:          # a rate-controlled session's float quantiser: qp + frac / 256 (enters the AQ quantisers before the rounding)
             pic.qp_frac_q8 = qp_frac[k % len(qp_frac)]
+        if pt >= 3 and direct != "spatial":          # --direct temporal / auto (the running scores pick the mode as x264's slice_header_init does)
+            dpb.set_direct(pic, direct == "temporal" or (direct == "auto" and not dscore[1] > dscore[0]), direct == "auto")
         o_mb, o_lv = og.encode_pic(frames[disp], pic)
         g_mb, g_lv = gg.encode_pics([frames[disp]] * streams, [pic] * streams)
+        if pt >= 3 and direct == "auto":
+            fs = og.direct_scores()
+            for s in range(streams):
+                assert gg.direct_scores(s) == fs, f"picture {k}: skip-probe counts of the two direct modes differ ({gg.direct_scores(s)} vs {fs})"
+            if dscore[0] + dscore[1] > mbw * mbh:
+                dscore = [dscore[0] * 9 // 10, dscore[1] * 9 // 10]
+            dscore = [dscore[0] + fs[0], dscore[1] + fs[1]]
+            modes.append(int(pic.direct_temporal))
         for s in range(streams):
             bad = np.nonzero(g_mb[s].view(np.uint8).reshape(-1, 64) != o_mb.view(np.uint8).reshape(-1, 64))[0]
             assert bad.size == 0, f"picture {k} (display {disp}, type {pt}) stream {s}: record of macroblock {bad[0]} differs" + describe(g_mb[s], o_mb, bad[0])
@@ -137,6 +148,28 @@ def test_headline_size_b_pictures_and_weightp_bitexact(gpu):
     assert run(gpu, 1920, 1080, "IBBBPP", 21, weightp=2) > 0
 
 
+@pytest.mark.parametrize("w,h,types,seed,direct,over", [
+    (176, 144, "IBBBPBBBP", 5, "temporal", {}),                                   # medium's structure: co-located pictures are P and B-ref pictures
+    (96, 80, "IBPBBPBBBPP", 2, "temporal", {}),
+    (176, 144, "IBBPBBP", 7, "temporal", dict(refs=5, dpb=5)),
+    (208, 112, "IBBBPBBP", 3, "temporal", dict(rd=0, trellis=0, subme=5, psy_rd_q8=0)),
+    (176, 144, "IBBBPBP", 9, "temporal", dict(me_method=2, partitions=0x707)),
+    (176, 144, "IBBBPBBP", 13, "temporal", dict(trellis=127, weightb=0)),
+    (176, 144, "IBBBPBBBPBBP", 5, "auto", {}),
+    (176, 144, "IBBPBBPBBP", 8, "auto", dict(rd=0, trellis=0, subme=4, psy_rd_q8=0)),
+    (128, 96, "IBBBPBBBP", 11, "auto", dict(subme=8, rd=63, me_method=1)),
+    (176, 288, "IBBBPBBP", 14, "auto", dict(slices=3)),
+])
+def test_temporal_direct_and_direct_auto_bitexact(gpu, w, h, types, seed, direct, over):
+    """x264 --direct temporal (mb_predict_mv_direct16x16_temporal; no direct candidates where a co-located block's reference is out of reach) and
+    --direct auto (both modes predicted and probed per macroblock, the counts equal the checker's and pick the next picture's mode)"""
+    run(gpu, w, h, types, seed, direct=direct, **over)
+
+
+def test_direct_auto_multistream(gpu):
+    run(gpu, 96, 80, "IBBBPBBP", 11, streams=3, direct="auto")
+
+
 NORD = dict(rd=0, trellis=0, psy_rd_q8=0)
 
 
@@ -164,9 +197,9 @@ def test_b_pictures_without_rd_bitexact_and_decodable(gpu, w, h, types, seed, ov
 
 def test_config4_size_slow_toolset_bitexact(gpu):
     """3840x2160 (BASELINE.json configs[3]) with preset slow's toolset as it is built — --me umh, --subme 8 (RD refinement of the P partitions' vectors and of
-    the intra modes: cfg.rd 63), --ref 5, --trellis 2, bframes 3 + b-pyramid + weightb, --weightp 2's duplicate; --direct auto stays spatial and subme 9's
+    the intra modes: cfg.rd 63), --ref 5, --trellis 2, bframes 3 + b-pyramid + weightb, --weightp 2's duplicate, --direct auto; subme 9's
     refinement of B slices / deblock-aware RD are not built — one mini-GOP I B P B plus a second P picture against the CPU checker"""
-    assert run(gpu, 3840, 2160, "IBPBP", 41, weightp=2, refs=5, dpb=5, me_method=2, subme=8, rd=63, trellis=127) >= 0
+    assert run(gpu, 3840, 2160, "IBPBP", 41, weightp=2, refs=5, dpb=5, me_method=2, subme=8, rd=63, trellis=127, direct="auto") >= 0
 
 
 @pytest.mark.parametrize("types,weights,weightp,over", [

@@ -894,7 +894,8 @@ def test_every_preset_codes_a_decodable_stream(gpu, preset):
 
 
 @pytest.mark.parametrize("opts", [
-    {"subme": 8, "me": "umh", "trellis": 2, "ref": 5, "bframes": 3, "b-adapt": 2, "rc-lookahead": 10, "keyint": 12, "qp": 24},          # preset slow's toolset (direct stays spatial)
+    {"subme": 8, "me": "umh", "trellis": 2, "ref": 5, "bframes": 3, "b-adapt": 2, "rc-lookahead": 10, "keyint": 12, "qp": 24, "direct": "auto"},          # preset slow's toolset
+    {"subme": 7, "me": "hex", "trellis": 1, "ref": 3, "bframes": 3, "b-adapt": 0, "keyint": 16, "qp": 25, "direct": "temporal"},
     {"subme": 8, "me": "hex", "trellis": 1, "ref": 2, "bframes": 0, "keyint": 9, "crf": 25, "rc-lookahead": 4},
     {"subme": 6, "me": "hex", "trellis": 1, "ref": 2, "bframes": 3, "b-adapt": 1, "rc-lookahead": 8, "keyint": 12, "crf": 24, "mixed-refs": 0},      # preset fast: B slices without RD, trellis in their final encode
     {"subme": 4, "me": "hex", "trellis": 0, "ref": 2, "bframes": 3, "b-adapt": 1, "rc-lookahead": 6, "keyint": 12, "qp": 25, "mixed-refs": 0},       # preset faster

@@ -37,6 +37,12 @@ struct EncK {
     uint8_t biw[5][4];                       // B: implicit bi-prediction weight of the list-0 sample for (list-0 index, list-1 index), of 64 (x264 bipred_weight)
     const int8_t *colref; const int16_t *colmv;    // B: per 8x8 block of the first picture of list 1, the reference index it used (-1 intra) and that vector
     int8_t *colref_cur; int16_t *colmv_cur;  // the same of the picture being coded, for the B pictures that will have it at the head of their list 1
+    // --direct temporal / auto (B slices): the co-located picture's own list-0 index per 8x8 block (-1: none / intra) and its macroblock types, this
+    // picture's copy of the former; per stream 1 = temporal direct prediction (nullptr: spatial everywhere); direct_auto: both modes are probed and
+    // counted into dscore[streams][2] ([0] temporal, [1] spatial); x264's map_col_to_list0 and dist_scale_factor[r][0]
+    const int8_t *colref0; const uint8_t *coltype; int8_t *colref0_cur;
+    const uint8_t *direct_flags; int direct_auto; int *dscore;
+    int map_col[8], dist_scale[8];
     const int16_t *lowres_mv1;               // B: lookahead vectors towards the first picture of list 1
     x264gpu_mb *mb;           // [streams][nmb]
     int16_t *levels;          // [streams][nmb][416]

@@ -41,6 +41,9 @@ struct x264gpu_encoder {
     int16_t *mv16[8] = {};                       // per slot: 16x16 search results in reference 0 of list 0 (x264 frame->mv16x16 = h->mb.mvr[0][0])
     uint8_t *mbtype[8] = {};                     // per slot: macroblock types (x264 frame->mb_type)
     int8_t *colref[8] = {}; int16_t *colmv[8] = {};      // per slot (sessions with B pictures): what spatial direct prediction reads of a co-located picture
+    int8_t *colref0[8] = {};                             // ... and temporal direct prediction: the blocks' own list-0 indices; the POCs behind each slot's list 0
+    int slot_l0poc[8][8] = {};
+    uint8_t *direct_flags = nullptr; int *dscore = nullptr; bool use_direct_flags = false;      // --direct temporal / auto: per-stream modes of the B picture, the probe counts
     int16_t *mvr[8] = {};                        // per combined reference index >= 1: 16x16 search results of the picture being coded
     int slot_nref[8] = {}, slot_poc[8] = {}, slot_ref0poc[8] = {};
     int poc = 0, ring = 2;                       // the sliding window: next POC, slots in rotation (refs + 1)
@@ -154,7 +157,7 @@ int x264gpu_encoder_create(x264gpu_encoder **out, const x264gpu_config *cfg)
     for (int i = 0; i < e->slots; i++) {
         alloc((void **)&e->mv16[i], S * k.nmb * 2 * sizeof(int16_t), 0);
         alloc((void **)&e->mbtype[i], S * k.nmb, 0);
-        if (cfg->dpb > 0) { alloc((void **)&e->colref[i], S * k.nmb * 4, 0); alloc((void **)&e->colmv[i], S * k.nmb * 8 * sizeof(int16_t), 0); }
+        if (cfg->dpb > 0) { alloc((void **)&e->colref[i], S * k.nmb * 4, 0); alloc((void **)&e->colmv[i], S * k.nmb * 8 * sizeof(int16_t), 0); alloc((void **)&e->colref0[i], S * k.nmb * 4, 0xff); }
     }
     for (int r = 1; r < (cfg->dpb > 0 ? 8 : cfg->refs); r++) alloc((void **)&e->mvr[r], S * k.nmb * 2 * sizeof(int16_t), 0);
     alloc((void **)&e->wf_progress, S * 2 * WFG_ROWS * sizeof(int), 0);
@@ -250,7 +253,8 @@ void x264gpu_encoder_destroy(x264gpu_encoder *e)
     if (!e) return;
     profile_free(e);
     (void)hipFree(e->fenc_y); (void)hipFree(e->fenc_uv);
-    for (int i = 0; i < 8; i++) { (void)hipFree(e->luma[i]); (void)hipFree(e->chroma[i]); (void)hipFree(e->mv16[i]); (void)hipFree(e->mbtype[i]); (void)hipFree(e->colref[i]); (void)hipFree(e->colmv[i]); }
+    for (int i = 0; i < 8; i++) { (void)hipFree(e->luma[i]); (void)hipFree(e->chroma[i]); (void)hipFree(e->mv16[i]); (void)hipFree(e->mbtype[i]); (void)hipFree(e->colref[i]); (void)hipFree(e->colmv[i]); (void)hipFree(e->colref0[i]); }
+    (void)hipFree(e->direct_flags); (void)hipFree(e->dscore);
     for (int i = 0; i < 8; i++) (void)hipFree(e->mvr[i]);
     (void)hipFree(e->wf_progress);
     (void)hipFree(e->tc);
@@ -331,6 +335,7 @@ __global__ void k_col_from_records(EncK k)
         r = use1 ? m->ref1[b8] : m->ref[b8]; vx = use1 ? m->mv1[b8][0] : m->mv[b8][0]; vy = use1 ? m->mv1[b8][1] : m->mv[b8][1];
     }
     k.colref_cur[((size_t)s * k.nmb + mbi) * 4 + b8] = (int8_t)r;
+    k.colref0_cur[((size_t)s * k.nmb + mbi) * 4 + b8] = (int8_t)(t > X264GPU_MB_I16x16 ? m->ref[b8] : -1);
     int16_t *o = k.colmv_cur + (((size_t)s * k.nmb + mbi) * 4 + b8) * 2;
     o[0] = (int16_t)vx; o[1] = (int16_t)vy;
 }
@@ -417,9 +422,29 @@ static int encode_core(x264gpu_encoder *e, const uint8_t *d_i420, const x264gpu_
                 k.biw[r0][r1] = (uint8_t)w;
             }
         k.colref = e->colref[pic.slot[1][0]]; k.colmv = e->colmv[pic.slot[1][0]];
+        // --direct temporal / auto (x264_macroblock_slice_init: map_col_to_list0, dist_scale_factor[r][0])
+        const int cs = pic.slot[1][0];
+        k.colref0 = e->colref0[cs]; k.coltype = e->mbtype[cs];
+        k.direct_auto = pic.direct_auto != 0;
+        k.direct_flags = e->use_direct_flags ? e->direct_flags : nullptr;
+        for (int i = 0; i < 8; i++) {
+            k.map_col[i] = -2; k.dist_scale[i] = 256;
+            if (i < e->slot_nref[cs]) for (int j = 0; j < n0; j++) if (e->slot_poc[pic.slot[0][j]] == e->slot_l0poc[cs][i]) { k.map_col[i] = j; break; }
+            if (i < n0) {
+                const int poc0 = e->slot_poc[pic.slot[0][i]], poc1 = e->slot_poc[pic.slot[1][0]];
+                const int td = min(max(poc1 - poc0, -128), 127);
+                if (td) { const int tb = min(max(e->poc - poc0, -128), 127), tx = (16384 + (abs(td) >> 1)) / td; k.dist_scale[i] = min(max((tb * tx + 32) >> 6, -1024), 1023); }
+            }
+        }
+        if (k.direct_auto) {
+            if (!e->dscore) HIP_TRY(hipMalloc((void **)&e->dscore, (size_t)S * 2 * sizeof(int)));
+            HIP_TRY(hipMemsetAsync(e->dscore, 0, (size_t)S * 2 * sizeof(int), st));
+        }
+        k.dscore = e->dscore;
     }
-    k.colref_cur = e->colref[cur]; k.colmv_cur = e->colmv[cur];
+    k.colref_cur = e->colref[cur]; k.colmv_cur = e->colmv[cur]; k.colref0_cur = e->colref0[cur];
     e->slot_nref[cur] = k.nref; e->slot_poc[cur] = e->poc; e->slot_ref0poc[cur] = k.nref ? e->slot_poc[s0] : 0;
+    for (int r = 0; r < 8; r++) e->slot_l0poc[cur][r] = r < k.nref && slice_type != X264GPU_SLICE_I ? e->slot_poc[pic.slot[0][r]] : 0;
     k.prof = e->prof; k.tc = e->tc; k.amvd = e->amvd; k.cab_out = e->cab_out;
     k.sl_stat = slice_type != X264GPU_SLICE_I && e->sl_stat ? e->sl_stat + (size_t)(!bslice ? 0 : pic.keep ? 1 : 2) * S * (size_t)e->cfg.slices * 4 : nullptr;      // the first guess: the last picture of the same kind
     k.sl_rerun = e->sl_rerun; k.sl_pass = 0;
@@ -543,10 +568,33 @@ int x264gpu_encode_pictures(x264gpu_encoder *e, const uint8_t *d_i420, const x26
         const int rc = set_stream_qps_q8(e, q.data(), f.data());
         if (rc != X264GPU_OK) return rc;
     }
+    // --direct temporal / auto: each stream's own mode (the one field of the structure that may differ)
+    e->use_direct_flags = false;
+    if (pics[0].slice_type == X264GPU_SLICE_B) {
+        bool any = false;
+        for (int s = 0; s < S; s++) { any = any || pics[s].direct_temporal; ARG_TRY((pics[s].direct_auto != 0) == (pics[0].direct_auto != 0)); }
+        if (any) {
+            std::vector<uint8_t> f((size_t)S);
+            for (int s = 0; s < S; s++) f[(size_t)s] = pics[s].direct_temporal != 0;
+            if (!e->direct_flags) HIP_TRY(hipMalloc((void **)&e->direct_flags, (size_t)S));
+            HIP_TRY(hipMemcpy(e->direct_flags, f.data(), (size_t)S, hipMemcpyHostToDevice));
+            e->use_direct_flags = true;
+        }
+    }
     const int rc = encode_core(e, d_i420, pics[0], d_mb, d_levels, (hipStream_t)stream);
+    e->use_direct_flags = false;
     if (!same_qp) (void)x264gpu_encoder_set_stream_qps(e, nullptr);
     if (rc == X264GPU_OK) e->have++;
     return rc;
+}
+
+// --direct auto: the probe counts of the last B picture coded with direct_auto (synchronises with the device)
+int x264gpu_encoder_direct_scores(x264gpu_encoder *e, int *h_scores)
+{
+    ARG_TRY(e && h_scores && e->dscore);
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpy(h_scores, e->dscore, (size_t)e->cfg.streams * 2 * sizeof(int), hipMemcpyDeviceToHost));
+    return X264GPU_OK;
 }
 
 }  // extern "C"

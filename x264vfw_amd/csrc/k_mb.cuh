@@ -1929,7 +1929,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(MB_WAVES_PER
         // SATD and RD costs of x264_mb_analysis_t's B fields, the per-block / per-half list decisions
         BCfg dcfg = { -1, 0, 0, -1, 0, 0 }, ecfg = { -1, 0, 0, -1, 0, 0 };
         unsigned euse = 0;
-        int dref0 = -1, dref1 = -1, bskip_cost = MB_COST_MAX, cost16direct = MB_COST_MAX, cost8d_0 = 0, cost8d_1 = 0, cost8d_2 = 0, cost8d_3 = 0, cost16bi = MB_COST_MAX;
+        bool d_avail = true;             // the direct prediction exists (temporal direct: not when a co-located block's reference is out of reach)
+        int bskip_cost = MB_COST_MAX, cost16direct = MB_COST_MAX, cost8d_0 = MB_COST_MAX, cost8d_1 = MB_COST_MAX, cost8d_2 = MB_COST_MAX, cost8d_3 = MB_COST_MAX, cost16bi = MB_COST_MAX;
         int cost8x8bi = MB_COST_MAX, cost16x8bi = MB_COST_MAX, cost8x16bi = MB_COST_MAX;
         int rd_dir = MB_COST_MAX, rd_l0 = MB_COST_MAX, rd_l1 = MB_COST_MAX, rd_bi = MB_COST_MAX, rd_8x8 = MB_COST_MAX, rd_16x8 = MB_COST_MAX, rd_8x16 = MB_COST_MAX;
         int sub8_0 = 0, sub8_1 = 0, sub8_2 = 0, sub8_3 = 0, p16x8_0 = 0, p16x8_1 = 0, p8x16_0 = 0, p8x16_1 = 0;

@@ -61,6 +61,11 @@ class HostDpb:
             self.H.x264host_dpb_plan(self.h, ptype, frame, len(follow), fc, ff, C.byref(pic), info)
         return pic, list(info)
 
+    def set_direct(self, pic, temporal, auto=0):
+        """--direct temporal / auto for the B picture just planned: into the picture control and the slice header"""
+        pic.direct_temporal, pic.direct_auto = int(temporal), int(auto)
+        self.H.x264host_dpb_set_direct(self.h, int(temporal), int(auto))
+
     def commit(self):
         self.H.x264host_dpb_commit(self.h)
 

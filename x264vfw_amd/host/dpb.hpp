@@ -159,11 +159,14 @@ public:
         frame_num++;
     }
 
+    // --direct temporal / auto: the mode of the planned B picture (the caller's decision; plan() leaves spatial)
+    void set_direct(int temporal, int auto_write) { last.pic.direct_temporal = temporal; last.pic.direct_auto = auto_write; }
     // the slice header's share of a plan
     void fill(SliceParams &sp) const
     {
         const DpbPlan &p = last;
         sp.slice_type = p.pic.slice_type == X264GPU_SLICE_I_NONIDR ? X264GPU_SLICE_I : p.pic.slice_type;
+        sp.direct_spatial = !p.pic.direct_temporal;
         sp.frame_num = p.frame_num; sp.idr = p.idr; sp.nal_ref_idc = p.nal_ref_idc; sp.poc = p.pic.poc;
         sp.num_ref = p.num_ref[0]; sp.num_ref1 = p.num_ref[1];
         sp.reorder[0] = p.reorder[0]; sp.reorder[1] = p.reorder[1];

@@ -7,6 +7,7 @@
 // pic_out->{i_type,b_keyframe,i_pts,i_dts} filled.  No CPU fallback: open fails without a GPU.
 #include "host.hpp"
 #include "dpb.hpp"
+#include <limits.h>
 #include <math.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -146,6 +147,9 @@ struct x264_t {
     long coded_count = 0;
     double slot_qp_rc[8] = { 0 };        // CRF: the quantiser (float) every kept picture was given, by DPB slot (x264 f_qp_avg_rc)
     int slot_ptype[8] = { 0 };           // ... and its picture type
+    // --direct temporal / auto (x264 h->stat.i_direct_score, frame->i_poc_l0ref0): 1 spatial, 2 temporal, 3 auto; the running skip-probe counts of
+    // temporal [0] / spatial [1] prediction; the POC behind reference 0 of list 0 of every kept picture (INT_MIN: it had none)
+    int direct_mode = 1, direct_score[2] = { 0, 0 }, slot_l0ref0poc[8] = { 0 };
 };
 
 // ---- cross-session batcher ------------------------------------------------------------------------------------------------------
@@ -444,9 +448,11 @@ x264_t *x264_encoder_open(x264_param_t *param)
         if (p.i_bframe_pyramid == 1) { xlog(&p, X264_LOG_INFO, "b-pyramid strict -> normal\n"); p.i_bframe_pyramid = 2; }
         if (p.i_bframe < 2) p.i_bframe_pyramid = 0;
         if (p.b_open_gop) { xlog(&p, X264_LOG_WARNING, "open-gop is not implemented in the MI355X path: closed GOPs\n"); p.b_open_gop = 0; }
-        if (p.analyse.i_direct_mv_pred != 1) { xlog(&p, X264_LOG_INFO, "direct %d -> spatial (the one direct mode in the MI355X path)\n", p.analyse.i_direct_mv_pred); p.analyse.i_direct_mv_pred = 1; }
+        if (p.analyse.i_direct_mv_pred < 1 || p.analyse.i_direct_mv_pred > 3) { xlog(&p, X264_LOG_INFO, "direct %d -> spatial (B macroblocks without direct prediction are not in the MI355X path)\n", p.analyse.i_direct_mv_pred); p.analyse.i_direct_mv_pred = 1; }
+        if (p.analyse.i_direct_mv_pred != 1 && getenv("X264GPU_BATCH")) { xlog(&p, X264_LOG_INFO, "direct temporal / auto: not in cross-session batches: spatial\n"); p.analyse.i_direct_mv_pred = 1; }
     } else { p.i_bframe_pyramid = 0; p.analyse.b_weighted_bipred = 0; }
     h->bframes = p.i_bframe; h->bpyramid = p.i_bframe_pyramid ? 1 : 0;
+    h->direct_mode = p.i_bframe ? p.analyse.i_direct_mv_pred : 1;
     if (p.i_keyint_max <= 0) p.i_keyint_max = 1;
     if (p.analyse.i_weighted_pred == X264_WEIGHTP_SIMPLE && !h->bframes) { xlog(&p, X264_LOG_INFO, "weightp 1 (weights for fades, no duplicate references) runs in sessions with B pictures only: weightp 0\n"); p.analyse.i_weighted_pred = X264_WEIGHTP_NONE; }
     if (p.analyse.i_weighted_pred == X264_WEIGHTP_SMART && !h->bframes) {
@@ -1627,6 +1633,18 @@ static int encode_bmode(x264_t *h, x264_nal_t **pp_nal, int *pi_nal, x264_pictur
     // x264_ratecontrol_mb_qp: a macroblock's quantiser is round(rc->qpm + its AQ / macroblock-tree offset) with qpm the picture's FLOAT quantiser
     pic.qp_frac_q8 = clampi((int)lround((qpf - pic.qp) * 256.0), -128, 127);
     h->rc_frames++;
+    bool direct_auto_write = false;
+    if ((pl.type == PIC_B || pl.type == PIC_BREF) && h->direct_mode != 1) {
+        // x264 slice_header_init: temporal direct prediction is considered only when the co-located picture's reference 0 is this picture's reference 0;
+        // --direct auto: the mode whose skip probe passed more often so far (h->stat.i_direct_score), every macroblock probing both again
+        bool spatial = true;
+        if (pic.nref[0] && pic.nref[1] && h->slot_l0ref0poc[pic.slot[1][0]] == plan.list_poc[0][0]) {
+            direct_auto_write = h->direct_mode == 3;
+            spatial = direct_auto_write ? h->direct_score[1] > h->direct_score[0] : false;
+        }
+        pic.direct_temporal = !spatial; pic.direct_auto = direct_auto_write;
+        h->dpb.set_direct(pic.direct_temporal, pic.direct_auto);
+    }
     if (h->st) {
         // x264_mb_predict_mv_ref16x16: the lookahead's vectors towards reference 0 of each list as search candidates, when that search ran
         // (fenc->lowres_mvs[list][distance - 1], distances up to bframes + 1)
@@ -1665,6 +1683,14 @@ static int encode_bmode(x264_t *h, x264_nal_t **pp_nal, int *pi_nal, x264_pictur
         }
     }
     if (plan.nal_ref_idc) { h->slot_qp_rc[pic.dst] = qpf; h->slot_ptype[pic.dst] = pl.type; }
+    if (plan.nal_ref_idc) h->slot_l0ref0poc[pic.dst] = pic.nref[0] ? plan.list_poc[0][0] : INT_MIN;
+    if (direct_auto_write) {
+        // x264_encoder_frame_end ("somewhat arbitrary time constants"): the running counts decay once they exceed a picture's worth, then take this picture's
+        int sc[2] = { 0, 0 };
+        if (x264gpu_encoder_direct_scores(h->gpu, sc) != X264GPU_OK) { xlog(&p, X264_LOG_ERROR, "direct auto: %s\n", x264gpu_last_error()); h->failed = true; return -1; }
+        if (h->direct_score[0] + h->direct_score[1] > h->mbw * h->mbh) for (int i = 0; i < 2; i++) h->direct_score[i] = h->direct_score[i] * 9 / 10;
+        for (int i = 0; i < 2; i++) h->direct_score[i] += sc[i];
+    }
     h->last_scenecut = pl.e.scenecut; h->last_qp = pic.qp;
     memcpy(h->last_costs, pl.e.costs, sizeof(pl.e.costs));
     const bool idr = pl.type == PIC_IDR;
@@ -1984,6 +2010,7 @@ int x264host_dpb_plan_wc(void *h, int type, int frame, int n_follow, const int *
     return 0;
 }
 void x264host_dpb_commit(void *h) { ((Dpb *)h)->commit(); }
+void x264host_dpb_set_direct(void *h, int temporal, int auto_write) { ((Dpb *)h)->set_direct(temporal, auto_write); }
 int x264host_write_slice_dpb(void *h, int mbw, int mbh, int qp, int pic_init_qp, int log2_max_frame_num, int log2_max_poc_lsb, int idr_pic_id,
                              int disable_deblock_idc, int num_ref_default, int transform8x8_mode, const x264gpu_mb *mbs, const int16_t *levels,
                              uint8_t *out, int cap, int *skipped)

@@ -99,6 +99,7 @@ _sig("x264host_get_recon", _i, [C.c_void_p, C.c_void_p])
 # tests: the DPB model of the host encoder (host/dpb.hpp) and a CABAC slice writer driven by it (streams with B pictures)
 _sig("x264host_dpb_new", C.c_void_p, [_i, _i, _i, _i, _i])
 _sig("x264host_dpb_plan_w", _i, [C.c_void_p, _i, _i, _i, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p])
+_sig("x264host_dpb_set_direct", None, [C.c_void_p, _i, _i])
 _sig("x264host_dpb_plan_wc", _i, [C.c_void_p, _i, _i, _i, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p])
 _sig("x264host_dpb_free", None, [C.c_void_p])
 _sig("x264host_dpb_info", _i, [C.c_void_p, C.POINTER(_i), C.POINTER(_i)])

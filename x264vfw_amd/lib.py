@@ -53,7 +53,7 @@ class Pic(C.Structure):
     class WC(C.Structure):
         _fields_ = [("on", C.c_int8 * 2), ("denom", C.c_int8), ("pad", C.c_int8), ("scale", C.c_int16 * 2), ("offset", C.c_int16 * 2)]
     _fields_ = [("slice_type", C.c_int), ("qp", C.c_int), ("poc", C.c_int), ("dst", C.c_int), ("keep", C.c_int), ("nref", C.c_int * 2),
-                ("slot", (C.c_int8 * 8) * 2), ("wl0", W * 8), ("blind_dupe", C.c_int), ("qp_frac_q8", C.c_int), ("wc0", WC * 8)]
+                ("slot", (C.c_int8 * 8) * 2), ("wl0", W * 8), ("blind_dupe", C.c_int), ("qp_frac_q8", C.c_int), ("wc0", WC * 8), ("direct_temporal", C.c_int), ("direct_auto", C.c_int)]
 
 
 def make_pic(slice_type, qp, poc, dst, keep, l0=(), l1=()):
@@ -95,6 +95,7 @@ _SIGS = {
     "x264gpu_csp_img_fill": (C.c_long, [_i, _i, _i, C.POINTER(C.c_long), C.POINTER(_i)]),
     "x264gpu_csp_to_i420": (_i, [C.POINTER(_vp), C.POINTER(_i), _i, _i, _i, _i, _i, C.POINTER(_vp), C.POINTER(_i), _vp]),
     "x264gpu_csp_to_i420_batch": (_i, [C.POINTER(_vp), C.POINTER(_i), _sz, _i, _i, _i, _i, _i, C.POINTER(_vp), C.POINTER(_i), _sz, _i, _vp]),
+    "x264gpu_encoder_direct_scores": (_i, [_vp, _vp]),
     "x264gpu_encoder_create": (_i, [C.POINTER(_vp), C.POINTER(Config)]),
     "x264gpu_encoder_destroy": (None, [_vp]),
     "x264gpu_encoder_mb_count": (_i, [_vp]),
