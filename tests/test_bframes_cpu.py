@@ -484,3 +484,31 @@ def test_host_session_finds_the_weights_of_a_fade(tmp_path):
     for d, r in zip(dec, info["recs"]):
         assert psnr(d[:w * h], frames[r[1]][:w * h]) > 33.0
         assert psnr(d[w * h:], frames[r[1]][w * h:]) > 33.0
+
+
+def test_host_session_two_pass(tmp_path):
+    """x264's 2-pass rate control (the driver's encoding type 4, codec.c:1516-1541): pass 1 (ABR) writes one statistics line per coded picture — type,
+    quantiser, bits split into texture / vectors / the rest — and pass 2 plans every picture's quantiser from them (init_pass2 restated): it codes the
+    same picture types and lands within 5 % of the requested size; the stream decodes"""
+    import os
+    import subprocess
+    subprocess.check_call(["make", "-s", "-C", __file__.rsplit("/", 1)[0] + "/stub"])
+    n, w, h, kbps = 75, 176, 144, 260
+    st = str(tmp_path / "x264.stats")
+    common = ["scene_len=31", f"bitrate={kbps}", "keyint=40", "bframes=3", "subme=5", "trellis=0", "log=1", f"stats={st}"]
+    info1, _ = _host_b_session(tmp_path, n, common + ["pass=1"], w, h, seed=9)
+    lines = [ln for ln in open(st).read().splitlines() if not ln.startswith("#")]
+    assert len(lines) == n and all(ln.startswith("in:") and " tex:" in ln and " mv:" in ln and " misc:" in ln for ln in lines)
+    assert not os.path.exists(st + ".temp")
+    info2, stream = _host_b_session(tmp_path, n, common + ["pass=2"], w, h, seed=9)
+    assert any("planned from the first pass" in m for _, m in info2["log"])
+    assert [(r[0], r[1]) for r in info2["recs"]] == [(r[0], r[1]) for r in info1["recs"]]          # the first pass' picture types, in its coding order
+    rate = len(stream) * 8 / (n / 25.0) / 1000.0
+    assert abs(rate / kbps - 1.0) < 0.05, rate
+    dec = O.h264_decode(stream, n, w, h)
+    assert len(dec) == n
+    # a bitrate the headers alone exceed is refused the way x264 refuses it
+    import sys
+    r = subprocess.run([sys.executable, os.path.join(os.path.dirname(os.path.abspath(__file__)), "stub", "run_host_b.py"), str(tmp_path / "c.h264"), str(w), str(h), str(n), "9"] +
+                       ["scene_len=31", "bitrate=1", "keyint=40", "bframes=3", "pass=2", f"stats={st}"], capture_output=True, text=True, timeout=600)
+    assert r.returncode != 0

@@ -339,11 +339,17 @@ def test_every_config_dialog_choice_opens_a_session(gpu):
         def e(c):
             c.i_encoding_type, c.i_qp, c.i_rf_constant, c.i_passbitrate = enc_type, 26, 230, 400
         one(e, f"encoding type {enc_type}")
-    # lossless (qp 0 + transform bypass) and multipass need tools outside this round's subset: refused loudly or stepped down with a log line
-    for enc_type in (0, 4):
-        rc, stream, sizes, log, frames = _session(lambda c: (setattr(c, "i_encoding_type", enc_type), setattr(c, "b_zerolatency", 1)))
-        assert rc != V.ICERR_OK or (all(s > 0 for s in sizes) and len(O.h264_decode(stream, len(frames), 64, 48)) == len(frames)), (enc_type, log)
-        assert rc == V.ICERR_OK or len(log) > 0
+    # lossless (qp 0 + transform bypass) needs tools outside this subset: refused loudly or stepped down with a log line
+    rc, stream, sizes, log, frames = _session(lambda c: (setattr(c, "i_encoding_type", 0), setattr(c, "b_zerolatency", 1)))
+    assert rc != V.ICERR_OK or (all(s > 0 for s in sizes) and len(O.h264_decode(stream, len(frames), 64, 48)) == len(frames)), log
+    assert rc == V.ICERR_OK or len(log) > 0
+    # multipass, first pass (the dialog's default i_pass 1): the statistics file and no stream (codec.c:1519-1524 b_no_output); test_two_pass_through_the_driver
+    import os
+    import tempfile
+    with tempfile.TemporaryDirectory() as td:
+        st = os.path.join(td, "a.stats").encode()
+        rc, stream, sizes, log, frames = _session(lambda c: (setattr(c, "i_encoding_type", 4), setattr(c, "extra_cmdline", b"--stats " + st)))
+        assert rc == V.ICERR_OK and not any(sizes), (sizes, log)
 
 
 def test_driver_defaults_with_b_pictures_to_a_file(gpu, tmp_path):
@@ -508,3 +514,47 @@ def test_b_pictures_into_the_containers(gpu, tmp_path, ext):
     from synth import psnr
     for d, i in zip(dec, disp):
         assert psnr(d[:w * h], frames[i][:w * h]) > 27.0
+
+
+def test_two_pass_through_the_driver(gpu, tmp_path):
+    """encoding type 4 of the config dialog (codec.c:1516-1533): pass 1 returns no stream and writes the statistics file, pass 2 reads it and hits the
+    requested bitrate within 5 % (x264 ratecontrol.c init_pass2 restated in host/encoder.cpp)"""
+    w, h, nfr, kbps = 176, 144, 240, 300
+    frames = synth_frames(w, h, nfr, seed=11, scene_len=53)
+    stats = tmp_path / "vfw.stats"
+
+    def run(i_pass, out):
+        ico = V.ICOPEN(fccType=V.fourcc(b"vidc"))
+        cid = D(0, None, V.DRV_OPEN, 0, V.addr(ico))
+        n = D(cid, None, V.ICM_GETSTATE, 0, 0)
+        cfg = V.VfwConfig()
+        D(cid, None, V.ICM_GETSTATE, V.addr(cfg), n)
+        cfg.i_encoding_type, cfg.i_passbitrate, cfg.i_pass, cfg.i_log_level = 4, kbps, i_pass, 3
+        cfg.extra_cmdline = b"--keyint 40 --rc-lookahead 8 --stats " + str(stats).encode() + b" --output " + str(out).encode()
+        D(cid, None, V.ICM_SETSTATE, V.addr(cfg), n)
+        inb, outb = V.bmi(w, h, b"I420"), V.BITMAPINFO()
+        assert D(cid, None, V.ICM_COMPRESS_GET_FORMAT, V.addr(inb), V.addr(outb)) == V.ICERR_OK
+        assert D(cid, None, V.ICM_COMPRESS_BEGIN, V.addr(inb), V.addr(outb)) == V.ICERR_OK, V.H.x264vfw_shim_log(cid)
+        cap = outb.bmiHeader.biSizeImage
+        buf = C.create_string_buffer(cap)
+        for f in frames:
+            flags = V.DWORD(0)
+            outb.bmiHeader.biSizeImage = cap
+            icc = V.ICCOMPRESS(lpbiOutput=C.pointer(outb.bmiHeader), lpOutput=C.cast(buf, C.c_void_p), lpbiInput=C.pointer(inb.bmiHeader),
+                               lpInput=f.ctypes.data, lpdwFlags=C.pointer(flags))
+            assert D(cid, None, V.ICM_COMPRESS, V.addr(icc), C.sizeof(icc)) == V.ICERR_OK, V.H.x264vfw_shim_log(cid)
+        log = V.H.x264vfw_shim_log(cid)
+        assert D(cid, None, V.ICM_COMPRESS_END, 0, 0) == V.ICERR_OK
+        D(cid, None, V.DRV_CLOSE, 0, 0)
+        return log
+
+    run(1, tmp_path / "p1.h264")
+    assert stats.exists() and not (tmp_path / "p1.h264").exists()                    # pass 1: b_no_output
+    lines = [ln for ln in stats.read_text().splitlines() if not ln.startswith("#")]
+    assert len(lines) == nfr
+    log = run(2, tmp_path / "p2.h264")
+    assert b"planned from the first pass" in log, log
+    data = (tmp_path / "p2.h264").read_bytes()
+    rate = len(data) * 8 / (nfr / 25.0) / 1000.0
+    assert abs(rate / kbps - 1.0) < 0.05, rate
+    assert len(O.h264_decode(data, nfr, w, h)) == nfr

@@ -34,6 +34,7 @@ struct Cabac {
     long bins = 0;
 
     explicit Cabac(BitWriter &b) : bw(b) {}
+    long pos() const { return (long)bw.bits() + outstanding; }          // x264_cabac_pos: bits out, the outstanding ones included
     void init(bool islice, int qp)
     {
         memset(state, 0, sizeof(state)); memset(mps, 0, sizeof(mps));
@@ -108,6 +109,7 @@ struct CabacSlice {
     std::vector<uint8_t> amvd, amvd1;   // per macroblock and 8x8 block: |mvd| x, y (capped, x264 keeps 8 bits); list 0 / list 1
     int last_dqp = 0, prev_coded_qp;    // mb_qp_delta context: the previous macroblock's delta
     int nskip = 0;
+    long mv_bits = 0, tex_bits = 0, pos_start = 0;          // i_mv_bits / i_tex_bits of the slice
     int lst = 0;                        // B slices: the list the motion helpers read
     int cur_direct = 0;                 // direct 8x8 blocks of the macroblock being coded
 
@@ -402,6 +404,7 @@ struct CabacSlice {
             cb.decision(ctx, m.type == X264GPU_MB_P_SKIP);
             if (m.type == X264GPU_MB_P_SKIP) { nskip++; last_dqp = 0; return; }
         }
+        pos_start = cb.pos();
         const bool intra = is_intra(m);
         // ---- mb_type ----
         if (bslice) {
@@ -467,6 +470,9 @@ struct CabacSlice {
                 for (int yy = g[1]; yy < g[1] + g[3]; yy++) for (int xx = g[0]; xx < g[0] + g[2]; xx++) { cur8[yy * 2 + xx] = Nb{ true, m.ref[b8], m.mv[b8][0], m.mv[b8][1] }; done8 |= 1 << (yy * 2 + xx); }
             }
         }
+        const long pos_tex = cb.pos();
+        mv_bits += pos_tex - pos_start;
+        struct TexCount { CabacSlice &s; long t0; ~TexCount() { s.tex_bits += s.cb.pos() - t0; } } tex_count{ *this, pos_tex };
         // ---- coded_block_pattern ----
         if (m.type != X264GPU_MB_I16x16) {
             for (int b8 = 0; b8 < 4; b8++) {
@@ -539,7 +545,7 @@ void write_slice_cabac(std::vector<uint8_t> &out, const SliceParams &p, const x2
         s.macroblock(i % p.mbw, i / p.mbw);
         cb.terminate(i == i1 - 1);                          // end_of_slice_flag
     }
-    if (stats) stats->skip = s.nskip;
+    if (stats) { stats->skip = s.nskip; stats->mv_bits = s.mv_bits; stats->tex_bits = s.tex_bits; }
     for (int i = 0; i < 460; i++) g_last_states[i] = (uint8_t)((cb.state[i] << 1) | cb.mps[i]);
     bw.align_zero();                                        // the flush wrote the stop bit: pad the last byte with zeros
     append_nal(out, p.nal_ref_idc, p.idr ? 5 : 1, bw.bytes(), annexb, long_startcode);

@@ -150,6 +150,17 @@ struct x264_t {
     // --direct temporal / auto (x264 h->stat.i_direct_score, frame->i_poc_l0ref0): 1 spatial, 2 temporal, 3 auto; the running skip-probe counts of
     // temporal [0] / spatial [1] prediction; the POC behind reference 0 of list 0 of every kept picture (INT_MIN: it had none)
     int direct_mode = 1, direct_score[2] = { 0, 0 }, slot_l0ref0poc[8] = { 0 };
+    // 2-pass (x264 ratecontrol.c; the driver's encoding type 4, codec.c:1516-1541): pass 1 appends one line per coded picture to the statistics file;
+    // pass 2 reads them — picture types, bits split into texture / vectors / the rest, the quantiser they were coded at — and spreads the requested
+    // size over the pictures (init_pass2), then follows the plan with feedback (rate_estimate_qscale's 2-pass branch)
+    struct Pass2Entry { char type = 'P'; int in = 0, out = 0, icount = 0, kept_as_ref = 1; double qp = 0, qscale = 0, new_qscale = 0, blurred = 0, expected_bits = 0, dur = 1;
+                        long tex = 0, mv = 0, misc = 0; };
+    bool pass1 = false, pass2 = false;
+    FILE *stat_file = nullptr;
+    std::vector<Pass2Entry> p2;                       // by display index ("in:")
+    std::vector<int> p2_out;                          // coding order -> display index
+    double p2_expected_sum = 0, p2_total_bits = 0, p2_final_bits = 0, p2_abr_buffer = 0;
+    char last_direct_char = '-';
 };
 
 // ---- cross-session batcher ------------------------------------------------------------------------------------------------------
@@ -345,6 +356,8 @@ static void emit_sets(x264_t *h, std::vector<int> &types, bool sei)
 }
 
 extern "C" {
+static bool p2_load(x264_t *h, const char *path);
+static bool p2_init(x264_t *h);
 
 x264_t *x264_encoder_open(x264_param_t *param)
 {
@@ -440,7 +453,7 @@ x264_t *x264_encoder_open(x264_param_t *param)
     if (p.i_bframe) {
         // (below --subme 7 x264 analyses B slices without RD: k_mb_b.inc's NORD flow)
         const char *why = !p.b_cabac ? "CABAC" :
-                          p.i_threads > 1 ? "threads 1" : p.i_keyint_max < 2 ? "keyint > 1" : (p.rc.i_rc_method == X264_RC_ABR && (p.rc.b_stat_read || p.rc.i_bitrate <= 0)) ? "constant-quantiser, CRF or single-pass ABR rate control" : nullptr;
+                          p.i_threads > 1 ? "threads 1" : p.i_keyint_max < 2 ? "keyint > 1" : (p.rc.i_rc_method == X264_RC_ABR && p.rc.i_bitrate <= 0) ? "constant-quantiser, CRF or ABR rate control with a bitrate" : nullptr;
         if (why) { xlog(&p, X264_LOG_WARNING, "B-frames need %s in the MI355X path: bframes 0\n", why); p.i_bframe = 0; }
     }
     if (p.i_bframe) {
@@ -459,7 +472,7 @@ x264_t *x264_encoder_open(x264_param_t *param)
         // without B pictures the session can still run on the DPB model, if nothing of the other path is asked for
         const bool tree = p.rc.b_mb_tree && p.rc.i_rc_method != X264_RC_CQP && p.rc.i_lookahead > 0;
         const char *why = p.i_threads > 1 ? "threads 1" : tree ? "no mbtree" :
-                          (p.rc.i_rc_method == X264_RC_ABR && (p.rc.b_stat_read || p.rc.i_bitrate <= 0)) ? "constant-quantiser, CRF or single-pass ABR rate control" : p.i_keyint_max < 2 ? "keyint > 1" : nullptr;
+                          (p.rc.i_rc_method == X264_RC_ABR && p.rc.i_bitrate <= 0) ? "constant-quantiser, CRF or ABR rate control with a bitrate" : p.i_keyint_max < 2 ? "keyint > 1" : nullptr;
         if (why) { xlog(&p, X264_LOG_WARNING, "weightp 2 without B-frames needs %s in the MI355X path: weightp 0\n", why); p.analyse.i_weighted_pred = X264_WEIGHTP_NONE; }
     }
     if (p.analyse.i_weighted_pred == X264_WEIGHTP_SMART && p.i_frame_reference < 2) p.analyse.i_weighted_pred = X264_WEIGHTP_NONE;      // a duplicate needs two references (x264: never placed)
@@ -484,9 +497,16 @@ x264_t *x264_encoder_open(x264_param_t *param)
     int qp = p.rc.i_rc_method == X264_RC_CQP ? p.rc.i_qp_constant : p.rc.i_rc_method == X264_RC_CRF ? (int)(p.rc.f_rf_constant + 0.5f) : 26;
     h->crf = p.rc.i_rc_method == X264_RC_CRF && p.rc.f_rf_constant >= 1.0f;       // also under --threads G: its quantisers follow from the lookahead costs alone
     h->abr = p.rc.i_rc_method == X264_RC_ABR && p.i_threads <= 1 && p.rc.i_bitrate > 0 && !p.rc.b_stat_read;      // single pass, no VBV
-    if (p.rc.i_rc_method != X264_RC_CQP && !h->crf && !h->abr) xlog(&p, X264_LOG_WARNING, "this rate control mode is not implemented yet (2-pass, or ABR with --threads > 1): constant qp %d\n", qp);
+    // 2-pass: the second pass plans every picture's quantiser from the first pass' statistics; sessions on the DPB model (B pictures or --weightp 2)
+    h->pass2 = p.rc.b_stat_read && p.rc.i_rc_method == X264_RC_ABR && p.rc.i_bitrate > 0 && p.i_threads <= 1 && h->dpbmode && p.rc.psz_stat_in && !getenv("X264GPU_BATCH");
+    h->pass1 = p.rc.b_stat_write && !p.rc.b_stat_read && p.i_threads <= 1 && h->dpbmode && p.rc.psz_stat_out && !getenv("X264GPU_BATCH");
+    if ((p.rc.b_stat_read && !h->pass2) || (p.rc.b_stat_write && !p.rc.b_stat_read && !h->pass1))
+        xlog(&p, X264_LOG_WARNING, "2-pass statistics need threads 1 and B-frames or weightp 2 (the DPB-model path) in the MI355X path: this pass runs without them\n");
+    if (p.rc.b_stat_write && p.rc.b_stat_read) xlog(&p, X264_LOG_INFO, "updating the statistics in the second pass is not implemented: they stay as the first pass wrote them\n");
+    if (p.rc.i_rc_method != X264_RC_CQP && !h->crf && !h->abr && !h->pass2) xlog(&p, X264_LOG_WARNING, "this rate control mode is not implemented yet (ABR with --threads > 1): constant qp %d\n", qp);
     if (qp < 1) { xlog(&p, X264_LOG_WARNING, "lossless is not supported: qp 1\n"); qp = 1; }
-    if (!h->crf && !h->abr) p.rc.i_rc_method = X264_RC_CQP;
+    if (!h->crf && !h->abr && !h->pass2) p.rc.i_rc_method = X264_RC_CQP;
+    if ((h->pass1 || h->pass2) && p.rc.b_mb_tree) { xlog(&p, X264_LOG_INFO, "2-pass: the macroblock-tree statistics file is not implemented in the MI355X path: mbtree 0 in both passes\n"); p.rc.b_mb_tree = 0; }
     if (p.rc.i_vbv_max_bitrate > 0 || p.rc.i_vbv_buffer_size > 0) xlog(&p, X264_LOG_WARNING, "VBV (vbv-maxrate / vbv-bufsize) is not implemented in the MI355X path: unconstrained\n");
     p.rc.i_vbv_max_bitrate = 0; p.rc.i_vbv_buffer_size = 0;
     if (p.analyse.i_noise_reduction) { xlog(&p, X264_LOG_WARNING, "nr (noise reduction) is not implemented in the MI355X path: nr 0\n"); p.analyse.i_noise_reduction = 0; }
@@ -692,6 +712,19 @@ x264_t *x264_encoder_open(x264_param_t *param)
             h->rc.lstep = pow(2.0, (p.rc.i_qp_step > 0 ? p.rc.i_qp_step : 4) / 6.0);
             h->rc.last_qscale_for[0] = h->rc.last_qscale_for[1] = qp2qscale(abr_init_qp);
         }
+    }
+    h->rc.fps = p.i_fps_num ? (double)p.i_fps_num / p.i_fps_den : 25.0;
+    if (h->pass2) {
+        if (!p2_load(h, p.rc.psz_stat_in) || !p2_init(h)) { x264_encoder_close(h); return nullptr; }
+        xlog(&p, X264_LOG_INFO, "2-pass: %d pictures planned from the first pass' statistics, %.1f kbit expected\n", (int)h->p2.size(), h->p2_final_bits / 1000.0);
+    }
+    if (h->pass1) {
+        // x264 writes <stats>.temp and renames it when the encoder closes; the first line names the options the second pass must agree with
+        h->stat_file = fopen((std::string(p.rc.psz_stat_out) + ".temp").c_str(), "wb");
+        if (!h->stat_file) { xlog(&p, X264_LOG_ERROR, "ratecontrol_init: can't open stats file\n"); x264_encoder_close(h); return nullptr; }
+        fprintf(h->stat_file, "#options: %dx%d fps=%u/%u timebase=%u/%u bitdepth=8 cabac=%d ref=%d bframes=%d b_pyramid=%d b_adapt=%d weightp=%d keyint=%d rc=%s\n", p.i_width, p.i_height,
+                p.i_fps_num, p.i_fps_den, p.i_fps_den, p.i_fps_num, p.b_cabac, p.i_frame_reference, p.i_bframe, p.i_bframe_pyramid, p.i_bframe_adaptive, p.analyse.i_weighted_pred, p.i_keyint_max,
+                p.rc.i_rc_method == X264_RC_ABR ? "abr" : p.rc.i_rc_method == X264_RC_CRF ? "crf" : "cqp");
     }
     { const unsigned hw = std::thread::hardware_concurrency(); h->cavlc_threads = h->G > 1 ? 1 : cavlc_threads_default(hw >= 32 ? 16 : hw >= 16 ? 8 : hw >= 4 ? (int)hw / 2 : 1); }
     h->h_in.resize(insz); h->h_mb.resize((size_t)h->G * h->nmb); h->h_lv.resize((size_t)h->G * h->nmb * X264GPU_MB_LEVELS);
@@ -1473,6 +1506,15 @@ static bool st_decide(x264_t *h, bool flushing, int &j_out, int &closing_out)
     const int n = (int)h->bq.size();
     if (!flushing && n <= h->st_wait) return false;
     for (auto &e : h->bq) e.type = e.forced == 2 ? ST_IDR : e.forced == 1 ? ST_I : ST_AUTO;
+    if (h->pass2) {
+        // x264_ratecontrol_slice_type: the second pass codes every picture as the type the first pass gave it (the B-reference of a run is placed by
+        // the same rule in both passes)
+        for (auto &e : h->bq) {
+            if (e.frame >= (int)h->p2.size()) continue;
+            const char t = h->p2[(size_t)e.frame].type;
+            e.type = t == 'I' ? ST_IDR : t == 'i' ? ST_I : t == 'P' ? ST_P : ST_B;
+        }
+    } else
     if (h->have_last_nonb && ((h->bframes && h->badapt) || p.i_scenecut_threshold || h->mbtree)) {
         StFrames F;
         F.h = h;
@@ -1573,6 +1615,188 @@ static bool bmode_decide(x264_t *h, bool flushing)
     return true;
 }
 
+// ---- 2-pass rate control (x264 ratecontrol.c: x264_ratecontrol_new's statistics parser, init_pass2, get_qscale / get_diff_limited_q,
+//      qscale2bits; no VBV, no zones, no macroblock-tree file: the tree is off in these sessions) ----
+static double p2_qp2qscale(double q) { return 0.85 * pow(2.0, (q - 12.0) / 6.0); }
+static double p2_qscale2qp(double qs) { return 12.0 + 6.0 * log2(qs / 0.85); }
+static double p2_qscale2bits(const x264_t::Pass2Entry &e, double qscale)
+{
+    if (qscale < 0.1) qscale = 0.1;
+    return (e.tex + .1) * pow(e.qscale / qscale, 1.1) + e.mv * pow((e.qscale > 1 ? e.qscale : 1) / (qscale > 1 ? qscale : 1), 0.5) + e.misc;
+}
+static bool p2_load(x264_t *h, const char *path)
+{
+    FILE *f = fopen(path, "rb");
+    if (!f) { xlog(&h->param, X264_LOG_ERROR, "ratecontrol_init: can't open stats file\n"); return false; }
+    char line[2048];
+    std::vector<x264_t::Pass2Entry> raw;
+    while (fgets(line, sizeof(line), f)) {
+        if (line[0] == '#') continue;
+        x264_t::Pass2Entry e;
+        long long dur = 0, cpbdur = 0;
+        float q = 0, aq = 0;
+        int tex = 0, mv = 0, misc = 0, imb = 0, pmb = 0, smb = 0;
+        char d = '-';
+        if (sscanf(line, " in:%d out:%d type:%c dur:%lld cpbdur:%lld q:%f aq:%f tex:%d mv:%d misc:%d imb:%d pmb:%d smb:%d d:%c", &e.in, &e.out, &e.type, &dur, &cpbdur, &q, &aq,
+                   &tex, &mv, &misc, &imb, &pmb, &smb, &d) < 13) { fclose(f); xlog(&h->param, X264_LOG_ERROR, "statistics are damaged at line %d, parser out\n", (int)raw.size() + 1); return false; }
+        e.qp = q; e.qscale = p2_qp2qscale(q); e.tex = tex; e.mv = mv; e.misc = misc; e.icount = imb; e.dur = dur > 0 ? (double)dur : 1.0; e.kept_as_ref = e.type != 'b';
+        raw.push_back(e);
+    }
+    fclose(f);
+    if (raw.empty()) { xlog(&h->param, X264_LOG_ERROR, "empty stats file\n"); return false; }
+    h->p2.assign(raw.size(), x264_t::Pass2Entry()); h->p2_out.assign(raw.size(), 0);
+    for (const auto &e : raw) {
+        if (e.in < 0 || e.in >= (int)raw.size() || e.out < 0 || e.out >= (int)raw.size()) { xlog(&h->param, X264_LOG_ERROR, "bad frame number (%d) at stats line\n", e.in); return false; }
+        h->p2[(size_t)e.in] = e; h->p2_out[(size_t)e.out] = e.in;
+    }
+    return true;
+}
+// x264's slice type of a statistics character as the rate control groups them: 0 I, 1 P, 2 B
+static int p2_kind(char t) { return t == 'I' || t == 'i' ? 0 : t == 'P' ? 1 : 2; }
+static bool p2_init(x264_t *h)
+{
+    const x264_param_t &p = h->param;
+    std::vector<x264_t::Pass2Entry> &E = h->p2;
+    const int n = (int)E.size();
+    const double fps = h->rc.fps > 0 ? h->rc.fps : 25.0, nmb = h->nmb;
+    double duration = 0;
+    for (auto &e : E) duration += e.dur;
+    duration /= fps * E[0].dur;                               // (durations are in ticks of one picture here: constant frame rate, codec.c:1476-1480)
+    const double all_available_bits = p.rc.i_bitrate * 1000.0 * duration;
+    const double qblur = p.rc.f_qblur, cplxblur = p.rc.f_complexity_blur, qcompress = p.rc.f_qcompress;
+    const int filter_size = (int)(qblur * 4) | 1;
+    const double base_cplx = nmb * (p.i_bframe ? 120 : 80);
+    const double lstep = pow(2.0, p.rc.i_qp_step / 6.0), lmin = p2_qp2qscale(p.rc.i_qp_min), lmax = p2_qp2qscale(p.rc.i_qp_max);
+    const double ipf = fabs(p.rc.f_ip_factor) > 0 ? fabs(p.rc.f_ip_factor) : 1.0, pbf = fabs(p.rc.f_pb_factor) > 0 ? fabs(p.rc.f_pb_factor) : 1.0;
+    double all_const_bits = 0;
+    for (auto &e : E) all_const_bits += e.misc;
+    if (all_available_bits < all_const_bits) {
+        xlog(&p, X264_LOG_ERROR, "requested bitrate is too low. estimated minimum is %d kbps\n", (int)(all_const_bits * fps / (n * 1000.)));
+        return false;
+    }
+    // blur the complexities (not the quantisers: one very simple picture must not drag its neighbours down)
+    for (int i = 0; i < n; i++) {
+        double weight_sum = 0, cplx_sum = 0, weight = 1.0;
+        for (int j = 1; j < cplxblur * 2 && j < n - i; j++) {
+            const auto &r = E[(size_t)(i + j)];
+            weight *= 1 - pow((float)r.icount / nmb, 2);
+            if (weight < .0001) break;
+            const double g = weight * exp(-j * j / 200.0);
+            weight_sum += g; cplx_sum += g * (p2_qscale2bits(r, 1) - r.misc);
+        }
+        weight = 1.0;
+        for (int j = 0; j <= cplxblur * 2 && j <= i; j++) {
+            const auto &r = E[(size_t)(i - j)];
+            const double g = weight * exp(-j * j / 200.0);
+            weight_sum += g; cplx_sum += g * (p2_qscale2bits(r, 1) - r.misc);
+            weight *= 1 - pow((float)r.icount / nmb, 2);
+            if (weight < .0001) break;
+        }
+        E[(size_t)i].blurred = cplx_sum / weight_sum;
+    }
+    // the rate factor: multiplied into every picture's RCEQ value it makes the sizes add up to the request (no closed form: qscale2bits does not invert)
+    std::vector<double> qscale((size_t)n), blurred((size_t)n);
+    double last_q[3], accum_p_qp = 0, accum_p_norm = 0, last_accum_p_norm = 1;
+    int last_non_b = -1;
+    auto get_qscale = [&](const x264_t::Pass2Entry &e, double rate_factor) {
+        double q = pow(e.blurred, 1 - qcompress);
+        if (!std::isfinite(q) || e.tex + e.mv == 0) q = last_q[p2_kind(e.type)];
+        else q /= rate_factor;
+        return q;
+    };
+    auto diff_limited = [&](const x264_t::Pass2Entry &e, double q) {
+        const int kind = p2_kind(e.type);
+        const double last_p_q = last_q[1], last_non_b_q = last_non_b >= 0 ? last_q[last_non_b] : q;
+        if (kind == 0) {
+            const double iq = q, pq = accum_p_norm > 0 ? p2_qp2qscale(accum_p_qp / accum_p_norm) : q;
+            if (accum_p_norm <= 0) q = iq;
+            else if (p.rc.f_ip_factor < 0) q = iq / ipf;
+            else if (accum_p_norm >= 1) q = pq / ipf;
+            else q = accum_p_norm * pq / ipf + (1 - accum_p_norm) * iq;
+        } else if (kind == 2) {
+            if (p.rc.f_pb_factor > 0) q = last_non_b_q;
+            if (!e.kept_as_ref) q *= pbf;
+        } else if (last_non_b == 1 && e.tex == 0) q = last_p_q;
+        if (last_non_b == kind && (kind != 0 || last_accum_p_norm < 1)) {
+            const double lq = last_q[kind];
+            q = q > lq * lstep ? lq * lstep : q < lq / lstep ? lq / lstep : q;
+        }
+        last_q[kind] = q;
+        if (kind != 2) last_non_b = kind;
+        if (kind == 0) { last_accum_p_norm = accum_p_norm; accum_p_norm = 0; accum_p_qp = 0; }
+        if (kind == 1) { const double mask = 1 - pow((float)e.icount / nmb, 2); accum_p_qp = mask * (p2_qscale2qp(q) + accum_p_qp); accum_p_norm = mask * (1 + accum_p_norm); }
+        return q;
+    };
+    double expected_bits = 1;
+    last_q[0] = last_q[1] = last_q[2] = pow(base_cplx, 1 - qcompress);
+    for (int i = 0; i < n; i++) { const double q = get_qscale(E[(size_t)i], 1.0); expected_bits += p2_qscale2bits(E[(size_t)i], q); last_q[p2_kind(E[(size_t)i].type)] = q; }
+    const double step_mult = all_available_bits / expected_bits;
+    double rate_factor = 0;
+    for (double step = 1E4 * step_mult; step > 1E-7 * step_mult; step *= 0.5) {
+        expected_bits = 0;
+        rate_factor += step;
+        last_non_b = -1; last_accum_p_norm = 1; accum_p_norm = 0; accum_p_qp = 0;
+        last_q[0] = last_q[1] = last_q[2] = pow(base_cplx, 1 - qcompress) / rate_factor;
+        for (int i = 0; i < n; i++) { qscale[(size_t)i] = get_qscale(E[(size_t)i], rate_factor); last_q[p2_kind(E[(size_t)i].type)] = qscale[(size_t)i]; }
+        for (int i = n - 1; i >= 0; i--) qscale[(size_t)i] = diff_limited(E[(size_t)i], qscale[(size_t)i]);       // fixed I / B quantisers relative to P
+        if (filter_size > 1) {                                  // smooth the curve over pictures of the same kind
+            for (int i = 0; i < n; i++) {
+                double q = 0.0, sum = 0.0;
+                for (int j = 0; j < filter_size; j++) {
+                    const int idx = i + j - filter_size / 2;
+                    const double d = idx - i, coeff = qblur == 0 ? 1.0 : exp(-d * d / (qblur * qblur));
+                    if (idx < 0 || idx >= n) continue;
+                    if (p2_kind(E[(size_t)i].type) != p2_kind(E[(size_t)idx].type)) continue;
+                    q += qscale[(size_t)idx] * coeff; sum += coeff;
+                }
+                blurred[(size_t)i] = q / sum;
+            }
+        } else blurred = qscale;
+        for (int i = 0; i < n; i++) {
+            double q = blurred[(size_t)i];
+            q = q < lmin ? lmin : q > lmax ? lmax : q;          // clip_qscale without VBV
+            E[(size_t)i].new_qscale = q;
+            expected_bits += p2_qscale2bits(E[(size_t)i], q);
+        }
+        if (expected_bits > all_available_bits) rate_factor -= step;
+    }
+    // the plan in coding order: what should have been spent when each picture starts
+    expected_bits = 0;
+    for (int k = 0; k < n; k++) { auto &e = E[(size_t)h->p2_out[(size_t)k]]; e.expected_bits = expected_bits; expected_bits += p2_qscale2bits(e, e.new_qscale); }
+    h->p2_final_bits = expected_bits;
+    if (fabs(expected_bits / all_available_bits - 1.0) > 0.01) {
+        double avgq = 0;
+        for (auto &e : E) avgq += e.new_qscale;
+        avgq = p2_qscale2qp(avgq / n);
+        xlog(&p, X264_LOG_WARNING, "Error: 2pass curve failed to converge\n");
+        xlog(&p, X264_LOG_WARNING, "target: %.2f kbit/s, expected: %.2f kbit/s, avg QP: %.4f\n", (double)p.rc.i_bitrate, expected_bits / duration / 1000., avgq);
+    }
+    h->p2_abr_buffer = 2 * p.rc.f_rate_tolerance * p.rc.i_bitrate * 1000.0;
+    return true;
+}
+// rate_estimate_qscale, 2-pass branch: the planned quantiser of display picture `frame`, pulled by how far the coded size is from the plan
+static double p2_pick_qscale(x264_t *h, int frame, long coded_so_far)
+{
+    const x264_param_t &p = h->param;
+    const int n = (int)h->p2.size();
+    if (frame >= n) return h->p2[(size_t)(n - 1)].new_qscale;           // (x264: "2nd pass has more frames than 1st pass", then constant quantiser)
+    const x264_t::Pass2Entry &e = h->p2[(size_t)frame];
+    double abr_buffer = h->p2_abr_buffer;
+    if (n > coded_so_far) {           // adjust the buffer by the distance to the end of the video
+        const double video_pos = e.expected_bits / h->p2_final_bits, scale_factor = sqrt((1 - video_pos) * n);
+        abr_buffer *= 0.5 * (scale_factor > 0.5 ? scale_factor : 0.5);
+    }
+    const double diff = h->p2_total_bits - e.expected_bits;
+    double q = e.new_qscale, c = (abr_buffer - diff) / abr_buffer;
+    q /= c < .5 ? .5 : c > 2 ? 2 : c;
+    if (coded_so_far + 1 >= h->rc.fps && h->p2_expected_sum > 0) {
+        const double cur_time = (double)coded_so_far / n, w = cur_time * 100 < 0 ? 0 : cur_time * 100 > 1 ? 1 : cur_time * 100;
+        q *= pow(h->p2_total_bits / h->p2_expected_sum, w);
+    }
+    const double lmin = p2_qp2qscale(p.rc.i_qp_min), lmax = p2_qp2qscale(p.rc.i_qp_max);
+    return q < lmin ? lmin : q > lmax ? lmax : q;
+}
+
 // rate control of one picture of a B session: constant quantisers (x264 rc->qp_constant[] with --ipratio / --pbratio) or CRF (rate_estimate_qscale:
 // I / P as without B pictures; B pictures take the distance-weighted average of their nearest references' quantisers plus the pb offset)
 static int bmode_qp(x264_t *h, const x264_t::BPlanned &pl, const DpbPlan &plan, double *qp_float)
@@ -1580,6 +1804,12 @@ static int bmode_qp(x264_t *h, const x264_t::BPlanned &pl, const DpbPlan &plan, 
     const x264_param_t &p = h->param;
     const double pb_offset = 6.0 * log2(fabs(p.rc.f_pb_factor) > 0 ? fabs(p.rc.f_pb_factor) : 1.0);
     const bool is_i = pl.type == PIC_IDR || pl.type == PIC_I, is_b = pl.type == PIC_B || pl.type == PIC_BREF;
+    if (h->pass2) {
+        double q = p2_qscale2qp(p2_pick_qscale(h, pl.e.frame, h->coded_count));
+        q = q < p.rc.i_qp_min ? p.rc.i_qp_min : q > p.rc.i_qp_max ? p.rc.i_qp_max : q;
+        *qp_float = q;
+        return clampi((int)(q + 0.5), 1, 51);
+    }
     if (!h->crf && !h->abr) {
         const int qb = clampi((int)(h->qp_p + pb_offset + 0.5), 0, 51);
         const int q = is_i ? h->qp_i : !is_b ? h->qp_p : pl.type == PIC_BREF ? (qb + h->qp_p) / 2 : qb;
@@ -1684,6 +1914,7 @@ static int encode_bmode(x264_t *h, x264_nal_t **pp_nal, int *pi_nal, x264_pictur
     }
     if (plan.nal_ref_idc) { h->slot_qp_rc[pic.dst] = qpf; h->slot_ptype[pic.dst] = pl.type; }
     if (plan.nal_ref_idc) h->slot_l0ref0poc[pic.dst] = pic.nref[0] ? plan.list_poc[0][0] : INT_MIN;
+    h->last_direct_char = (pl.type == PIC_B || pl.type == PIC_BREF) ? (pic.direct_temporal ? 't' : 's') : '-';
     if (direct_auto_write) {
         // x264_encoder_frame_end ("somewhat arbitrary time constants"): the running counts decay once they exceed a picture's worth, then take this picture's
         int sc[2] = { 0, 0 };
@@ -1724,6 +1955,27 @@ static int encode_bmode(x264_t *h, x264_nal_t **pp_nal, int *pi_nal, x264_pictur
         if (k >= delay) pic_out->i_dts = h->all_pts[(size_t)(k - delay) < np ? (size_t)(k - delay) : np - 1];
         else pic_out->i_dts = h->all_pts[(size_t)k < np ? (size_t)k : np - 1] - (h->all_pts[(size_t)delay < np ? (size_t)delay : np - 1] - h->all_pts[0]);
         pic_out->img = pl.e.img;
+    }
+    if (h->pass1 || h->pass2) {
+        // x264_ratecontrol_end: the picture's line of the statistics file / the second pass' account of what was spent against the plan
+        const long total = (long)h->out.size() * 8;
+        long imb = 0, pmb = 0, smb = 0;
+        double aqsum = 0;
+        for (size_t i = 0; i < (size_t)h->nmb; i++) {
+            const x264gpu_mb &m = h->h_mb[i];
+            if (m.type <= X264GPU_MB_I16x16) imb++; else if (m.type == X264GPU_MB_P_SKIP || m.type == X264GPU_MB_B_SKIP) smb++; else pmb++;
+            aqsum += m.qp;
+        }
+        if (h->pass1 && h->stat_file) {
+            const char t = idr ? 'I' : pl.type == PIC_I ? 'i' : pl.type == PIC_P ? 'P' : pl.type == PIC_BREF ? 'B' : 'b';
+            const long mv = h->last_stats.mv_bits, tex = h->last_stats.tex_bits, misc = total - mv - tex;
+            fprintf(h->stat_file, "in:%d out:%ld type:%c dur:%d cpbdur:%d q:%.2f aq:%.2f tex:%ld mv:%ld misc:%ld imb:%ld pmb:%ld smb:%ld d:%c ref:;\n", pl.e.frame, h->coded_count, t, 1, 1, qpf,
+                    aqsum / h->nmb, tex, mv, misc, imb, pmb, smb, h->last_direct_char);
+        }
+        if (h->pass2) {
+            h->p2_total_bits += (double)total;
+            if (pl.e.frame < (int)h->p2.size()) h->p2_expected_sum += p2_qscale2bits(h->p2[(size_t)pl.e.frame], p2_qp2qscale(qpf));
+        }
     }
     if (h->abr) {
         // x264_ratecontrol_end: what the picture took moves the rate factor of the pictures to come (a B picture's quantiser is an offset of
@@ -1862,6 +2114,11 @@ void x264_encoder_close(x264_t *h)
     if (getenv("X264GPU_HOST_TIMING") && h->t_b[4] > 0)
         fprintf(stderr, "x264gpu host timing (DPB model), ms per picture over %.0f pictures: slice-type analysis %.2f, GPU hot path %.2f, download %.2f, entropy coding %.2f\n", h->t_b[4],
                 1e3 * h->t_b[0] / h->t_b[4], 1e3 * h->t_b[1] / h->t_b[4], 1e3 * h->t_b[2] / h->t_b[4], 1e3 * h->t_b[3] / h->t_b[4]);
+    if (h->stat_file) {
+        fclose(h->stat_file); h->stat_file = nullptr;
+        const std::string out = h->param.rc.psz_stat_out ? h->param.rc.psz_stat_out : "";
+        if (!out.empty() && rename((out + ".temp").c_str(), out.c_str())) xlog(&h->param, X264_LOG_ERROR, "failed to rename \"%s.temp\" to \"%s\"\n", out.c_str(), out.c_str());
+    }
     if (h->batch) { batch_leave(h->batch, h->batch_idx); h->batch = nullptr; }
     if (h->gpu) x264gpu_encoder_destroy(h->gpu);
     if (h->d_in) x264gpu_free(h->d_in);

@@ -39,7 +39,9 @@ struct SliceParams {
     struct { int on, denom, scale, offset; } wl0[X264GPU_MAX_LIST] = {};
     struct { int on[2], denom, scale[2], offset[2]; } wc0[X264GPU_MAX_LIST] = {};
 };
-struct SliceStats { int skip; };
+// what a slice took, split as x264's h->stat.frame does for the 2-pass statistics: the macroblock headers (types, prediction modes, references, vector
+// differences: i_mv_bits) and what follows them (coded block pattern, quantiser delta, residual: i_tex_bits); everything else is 'misc'
+struct SliceStats { int skip; long mv_bits = 0, tex_bits = 0; };
 
 struct SpsParams {
     int profile_idc, level_idc, sps_id;

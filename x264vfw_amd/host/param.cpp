@@ -358,7 +358,7 @@ int x264_param_parse(x264_param_t *p, const char *name, const char *value)
     OPT("aq-mode") I(p->rc.i_aq_mode);
     OPT("aq-strength") F(p->rc.f_aq_strength);
     OPT("pass") { int v = parse_int(value, &err); if (v < 0 || v > 3) err = 1; else { p->rc.b_stat_write = v & 1; p->rc.b_stat_read = v & 2; } }
-    OPT("stats") { /* the driver sets psz_stat_in/out itself (codec.c:1537-1541) */ }
+    OPT("stats") { p->rc.psz_stat_in = strdup(value); p->rc.psz_stat_out = strdup(value); }      /* (x264_param_parse; the driver sets both itself, codec.c:1537-1541) */
     OPT("qcomp") F(p->rc.f_qcompress);
     OPT("mbtree") B(p->rc.b_mb_tree);
     OPT("qblur") F(p->rc.f_qblur);

@@ -29,6 +29,7 @@ struct SliceCtx {
     int row0, row1;               // macroblock rows this context codes
     // skip-run bookkeeping across bands (P slices): macroblocks skipped before the band's first coded macroblock / after its last
     int lead_skip = 0, trail_skip = 0, nskip = 0;
+    long mv_bits = 0, tex_bits = 0;          // i_mv_bits / i_tex_bits (the skip runs are 'misc')
     bool has_coded = false;
 
     int mbw() const { return p.mbw; }
@@ -208,6 +209,8 @@ struct SliceCtx {
 
     void write_mb_intra(int mbx, int mby, const x264gpu_mb &m, const int16_t *lv, int type_offset)
     {
+        const long pos_start = (long)bw.bits();
+        long pos_tex = pos_start;
         if (m.type == X264GPU_MB_I8x8) {
             // I_NxN with transform_size_8x8_flag = 1: four Intra8x8PredMode (8.3.2.1); modes are stored replicated over
             // the 8x8's 4x4 entries, so the 4x4 predictor of its top-left block is exactly predIntra8x8PredMode
@@ -219,6 +222,7 @@ struct SliceCtx {
                 else { bw.put1(0); bw.put((uint32_t)(mode < pm ? mode : mode - 1), 3); }
             }
             bw.ue(m.chroma_mode);
+            pos_tex = (long)bw.bits();
             bw.ue(cbp_to_golomb_intra[m.cbp_luma | (m.cbp_chroma << 4)]);
             if (m.cbp_luma || m.cbp_chroma) bw.se(qp_delta(m));
         } else if (m.type == X264GPU_MB_I4x4) {
@@ -230,14 +234,17 @@ struct SliceCtx {
                 else { bw.put1(0); bw.put((uint32_t)(mode < pm ? mode : mode - 1), 3); }
             }
             bw.ue(m.chroma_mode);
+            pos_tex = (long)bw.bits();
             bw.ue(cbp_to_golomb_intra[m.cbp_luma | (m.cbp_chroma << 4)]);
             if (m.cbp_luma || m.cbp_chroma) bw.se(qp_delta(m));  // mb_qp_delta
         } else {
             bw.ue(type_offset + 1 + m.i16_mode + 4 * m.cbp_chroma + (m.cbp_luma ? 12 : 0));
             bw.ue(m.chroma_mode);
+            pos_tex = (long)bw.bits();
             bw.se(qp_delta(m));                                  // mb_qp_delta always present for Intra16x16
         }
         write_residual(mbx, mby, m, lv);
+        mv_bits += pos_tex - pos_start; tex_bits += (long)bw.bits() - pos_tex;
     }
 
     // total_coeff of every block of one macroblock (what residual_block will return for the blocks write_residual codes)
@@ -280,6 +287,7 @@ struct SliceCtx {
                                                               { { 0, 0, 1, 1 }, { 1, 0, 1, 1 }, { 0, 1, 1, 1 }, { 1, 1, 1, 1 } } };
                         const int nparts = m.partition == 0 ? 1 : m.partition == 3 ? 4 : 2;
                         flush_run();
+                        const long pos_start = (long)bw.bits();
                         bw.ue(m.partition);                                  // P_L0_16x16 / P_L0_L0_16x8 / P_L0_L0_8x16 / P_8x8
                         if (m.partition == 3) for (int k = 0; k < 4; k++) bw.ue(0);      // sub_mb_type P_L0_8x8
                         if (p.num_ref > 1)
@@ -295,10 +303,13 @@ struct SliceCtx {
                                     done8 |= 1 << (yy * 2 + xx);
                                 }
                         }
+                        const long pos_tex = (long)bw.bits();
+                        mv_bits += pos_tex - pos_start;
                         bw.ue(cbp_to_golomb_inter[m.cbp_luma | (m.cbp_chroma << 4)]);
                         if (p.transform8x8_mode && m.cbp_luma) bw.put1(m.transform8x8);      // every partition here is >= 8x8
                         if (m.cbp_luma || m.cbp_chroma) bw.se(qp_delta(m));
                         write_residual(mbx, mby, m, lv);
+                        tex_bits += (long)bw.bits() - pos_tex;
                     }
                 }
             }
@@ -408,7 +419,7 @@ void write_slice(std::vector<uint8_t> &out, const SliceParams &p_in, const x264g
         else carry += c.lead_skip;
     }
     if (carry) bw.ue((uint32_t)carry);
-    if (stats) { stats->skip = 0; for (const SliceCtx &c : ctx) stats->skip += c.nskip; }
+    if (stats) { stats->skip = 0; stats->mv_bits = stats->tex_bits = 0; for (const SliceCtx &c : ctx) { stats->skip += c.nskip; stats->mv_bits += c.mv_bits; stats->tex_bits += c.tex_bits; } }
     bw.trailing();
     append_nal(out, p.nal_ref_idc, p.idr ? 5 : 1, bw.bytes(), annexb, long_startcode);
 }
@@ -437,11 +448,11 @@ void write_picture(std::vector<uint8_t> &out, std::vector<size_t> *offs, const S
     for (int t = 1; t < T; t++) pool.emplace_back([&, t] { for (int i = t; i < n; i += T) one(i); });
     for (int i = 0; i < n; i += T) one(i);
     for (auto &th : pool) th.join();
-    if (stats) stats->skip = 0;
+    if (stats) { stats->skip = 0; stats->mv_bits = stats->tex_bits = 0; }
     for (int i = 0; i < n; i++) {
         if (offs) offs->push_back(out.size());
         out.insert(out.end(), parts[(size_t)i].begin(), parts[(size_t)i].end());
-        if (stats) stats->skip += st[(size_t)i].skip;
+        if (stats) { stats->skip += st[(size_t)i].skip; stats->mv_bits += st[(size_t)i].mv_bits; stats->tex_bits += st[(size_t)i].tex_bits; }
     }
 }
 

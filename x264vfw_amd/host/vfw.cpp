@@ -46,6 +46,7 @@ struct CODEC {                          /* x264vfw.h:187-252, compress-side memb
     x264host::Muxer *cli_hout; int b_cli_output, b_no_output;   /* file output instead of the VfW buffer (codec.c:1111-1164,1609-1663; output/raw.c, matroska.c, flv.c) */
     int64_t largest_pts, second_largest_pts;      /* for close_file (codec.c:1858-1866) */
     std::string log;
+    std::string stats_path;             /* the 2-pass statistics file (codec.c:1386,1447,1537-1541) */
 };
 
 void config_defaults(X264VFW_CONFIG *c)
@@ -208,6 +209,8 @@ LRESULT compress_begin(CODEC *codec, BITMAPINFO *in, BITMAPINFO *out)
     std::vector<std::string> argv = split_cmdline(cfg->extra_cmdline);
     std::string preset_s = preset ? preset : "", profile_s = profile ? profile : "";
     std::string out_file = "-", muxer = "auto";                                /* codec.c:1545-1546 */
+    std::string stats_path;
+    int fast1pass = 0;
     codec->b_no_output = 0; codec->b_cli_output = 0;
     for (size_t i = 0; i + 1 < argv.size(); i++) {                          /* presets first (parse_preset_tune, codec.c:1198-1223) */
         if (argv[i] == "--preset") preset_s = argv[i + 1];
@@ -230,9 +233,12 @@ LRESULT compress_begin(CODEC *codec, BITMAPINFO *in, BITMAPINFO *out)
     case 1: param.rc.i_rc_method = X264_RC_CQP; param.rc.i_qp_constant = cfg->i_qp; break;
     case 2: param.rc.i_rc_method = X264_RC_CRF; param.rc.f_rf_constant = (float)cfg->i_rf_constant * 0.1f; break;
     case 3: param.rc.i_rc_method = X264_RC_ABR; param.rc.i_bitrate = cfg->i_passbitrate; break;
-    case 4:     /* multipass (codec.c:1519-1533: pass 1 writes only the stats file, pass N reads it): no stats file support here */
-        vlog(codec, X264_LOG_WARNING, "multipass encoding is not implemented in the MI355X path: every pass is coded as single-pass ABR at %d kbit/s\n", cfg->i_passbitrate);
-        param.rc.i_rc_method = X264_RC_ABR; param.rc.i_bitrate = cfg->i_passbitrate; break;
+    case 4:     /* multipass (codec.c:1516-1533): pass 1 writes the statistics and returns no stream, pass N reads them; the file is --stats' (config.c:140:
+                 * ".\\x264.stats"); fast first pass only with --fast-firstpass (config.c:114 default 0) */
+        param.rc.i_rc_method = X264_RC_ABR; param.rc.i_bitrate = cfg->i_passbitrate;
+        if (cfg->i_pass <= 1) { codec->b_no_output = 1; param.rc.b_stat_write = 1; }
+        else { param.rc.b_stat_write = 1 /* config.c:116 updatestats default */; param.rc.b_stat_read = 1; }
+        break;
     default: goto fail;
     }
     param.vui.i_sar_width = cfg->i_sar_width; param.vui.i_sar_height = cfg->i_sar_height;
@@ -261,6 +267,9 @@ LRESULT compress_begin(CODEC *codec, BITMAPINFO *in, BITMAPINFO *out)
         if (name == "output") { out_file = value; continue; }                /* OPT_OUTPUT (codec.c:1261-1263) */
         if (name == "muxer") { muxer = value; continue; }
         if (name == "no-output") { codec->b_no_output = 1; continue; }
+        if (name == "fast-firstpass") { fast1pass = 1; continue; }               /* OPT_FASTFIRSTPASS / OPT_SLOWFIRSTPASS (codec.c:1296-1302) */
+        if (name == "slow-firstpass") { fast1pass = 0; continue; }
+        if (name == "stats") { stats_path = value; continue; }
         if (name == "vd-hack") { codec->b_use_vd_hack = 1; continue; }       /* OPT_VD_HACK (codec.c:1313-1315) */
         if (name == "dts-compress") {
             vlog(codec, X264_LOG_WARNING, "not supported option: '%s'\n", a.c_str());
@@ -270,6 +279,11 @@ LRESULT compress_begin(CODEC *codec, BITMAPINFO *in, BITMAPINFO *out)
         if (rc == X264_PARAM_BAD_NAME) { vlog(codec, X264_LOG_ERROR, "unknown option: '%s'\n", a.c_str()); goto fail; }
         if (rc == X264_PARAM_BAD_VALUE) { vlog(codec, X264_LOG_ERROR, "invalid argument: '%s' = '%s'\n", a.c_str(), value.c_str()); goto fail; }
     }
+    if (param.rc.b_stat_write || param.rc.b_stat_read) {                    /* codec.c:1537-1541 */
+        codec->stats_path = stats_path.empty() ? "./x264.stats" : stats_path;
+        param.rc.psz_stat_out = param.rc.psz_stat_in = &codec->stats_path[0];
+    }
+    if (fast1pass && param.rc.b_stat_write && !param.rc.b_stat_read) x264_param_apply_fastfirstpass(&param);      /* codec.c:1580-1581 */
     param.b_vfr_input = 0;                                                  /* VFW supports only CFR (codec.c:1567-1569) */
     param.i_timebase_num = param.i_fps_den; param.i_timebase_den = param.i_fps_num;
     param.vui.b_fullrange = param.vui.b_fullrange == 1;
