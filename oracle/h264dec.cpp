@@ -627,7 +627,7 @@ struct SliceDec {
             else if (value <= 21) { shape = 1 + ((value - 4) & 1); use[0] = pair[(value - 4) >> 1][0]; use[1] = pair[(value - 4) >> 1][1]; }
             else {
                 shape = 3;
-                for (int k = 0; k < 4; k++) { const int t = ca_sub_mb_type_b(); use[k] = t == 0 ? 3 : t - 1; if (t == 0) m.direct8 |= 1 << k; }
+                for (int k = 0; k < 4; k++) { const int t = d.cabac ? ca_sub_mb_type_b() : (int)br.ue(); if (t > 3) { br.err = true; return; } use[k] = t == 0 ? 3 : t - 1; if (t == 0) m.direct8 |= 1 << k; }
                 if (m.direct8) direct_spatial(mbx, mby, m, m.direct8);
             }
             const int nparts = shape == 0 ? 1 : shape == 3 ? 4 : 2;
@@ -638,7 +638,7 @@ struct SliceDec {
                 for (int k = 0; k < nparts; k++) {
                     const int8_t *g = geom[shape][k];
                     const bool sends = use[k] == 2 || use[k] == lst;
-                    if (sends && nact > 1) { refs[lst][k] = ca_ref(2 * mbx + g[0], 2 * mby + g[1]); if (refs[lst][k] >= nact) { br.err = true; lst = 0; return; } }
+                    if (sends && nact > 1) { refs[lst][k] = d.cabac ? ca_ref(2 * mbx + g[0], 2 * mby + g[1]) : nact == 2 ? !br.get1() : (int)br.ue(); if (refs[lst][k] >= nact) { br.err = true; lst = 0; return; } }
                     for (int yy = g[1]; yy < g[1] + g[3]; yy++) for (int xx = g[0]; xx < g[0] + g[2]; xx++) { cur_refs[yy * 2 + xx] = sends ? refs[lst][k] : 0; refs_known |= 1 << (yy * 2 + xx); }
                 }
             }
@@ -652,7 +652,7 @@ struct SliceDec {
                         int px, py;
                         // the partition's own blocks must not look like neighbours that use this reference yet: they are unknown until set below
                         mvp(2 * mbx + g[0], 2 * mby + g[1], g[2], shape, k, refs[lst][k], px, py);
-                        const int dx = ca_mvd(2 * mbx + g[0], 2 * mby + g[1], 0), dy = ca_mvd(2 * mbx + g[0], 2 * mby + g[1], 1);
+                        const int dx = d.cabac ? ca_mvd(2 * mbx + g[0], 2 * mby + g[1], 0) : br.se(), dy = d.cabac ? ca_mvd(2 * mbx + g[0], 2 * mby + g[1], 1) : br.se();
                         for (int yy = g[1]; yy < g[1] + g[3]; yy++)
                             for (int xx = g[0]; xx < g[0] + g[2]; xx++) {
                                 const int b8 = yy * 2 + xx;
@@ -962,6 +962,11 @@ struct SliceDec {
         if (d.cabac) { run_cabac(); return; }
         int n = d.mbw * d.mbh, i = first_mb;
         while (i < n && !br.err) {
+            if (slice_type == 1) {          // B slice: mb_skip_run of B_Skip macroblocks (direct prediction, nothing coded)
+                int run = (int)br.ue();
+                while (run-- && i < n) { d.mb[i] = MbInfo(); d.mb[i].slice = slice_no; skipped_mb_b(i); i++; }
+                if (i >= n || !br.more_rbsp_data()) break;
+            }
             if (slice_type == 0) {
                 int run = (int)br.ue();
                 while (run-- && i < n) {
@@ -984,6 +989,7 @@ struct SliceDec {
             int t = (int)br.ue();
             cur_idx = i; known8 = 0;
             if (slice_type == 0) { if (t <= 3) inter_mb(mbx, mby, t, m); else if (t >= 5) intra_mb(mbx, mby, t - 5, m); else br.err = true; }
+            else if (slice_type == 1) { if (t <= 22) inter_mb_b(mbx, mby, t, m); else intra_mb(mbx, mby, t - 23, m); }
             else intra_mb(mbx, mby, t, m);
             d.mb_bits[d.mb_bits.size() - (size_t)(d.mbw * d.mbh) + (size_t)i] = (int)(br.pos - pos0);
             i++;
@@ -1161,7 +1167,6 @@ bool decode_nal(Decoder &d, const uint8_t *nal, size_t n)
         if (first_mb != d.next_mb || first_mb >= d.mbw * d.mbh) return reject(__LINE__);
         int st = (int)br.ue() % 5;
         if (st != 0 && st != 1 && st != 2) return reject(__LINE__);
-        if (st == 1 && !d.cabac) return reject(__LINE__);              // B slices: CABAC only in this checker
         br.ue();
         const int frame_num = (int)br.get(d.log2_max_frame_num), max_frame_num = 1 << d.log2_max_frame_num;
         if (type == 5) br.ue();

@@ -51,6 +51,11 @@ def run(w, h, types, seed, bframes=3, pyramid=1, weightp=0, pics_out=None, weigh
     (176, 144, "IBBBP", 24, dict(rd=0, trellis=0, subme=4, psy_rd_q8=0, refs=2, mixed_refs=0)),                                   # faster
     (96, 80, "IBPBBP", 25, dict(rd=0, trellis=0, subme=1, psy_rd_q8=0, refs=1, partitions=0x303, mixed_refs=0, weightb=0, dct8x8=0)),      # superfast
     (176, 144, "IBBP", 26, dict(rd=0, trellis=0, subme=3, psy_rd_q8=0, me_method=2)),
+    # ... and with CAVLC (Main profile --no-cabac): mb_type ue(v) of Table 7-14, sub_mb_type, te(v) reference indices of both lists, B_Skip runs
+    (176, 144, "IBBBPBBP", 41, dict(rd=0, trellis=0, subme=5, psy_rd_q8=0, cabac=0)),
+    (96, 80, "IBPBBPBBBPP", 42, dict(rd=0, trellis=0, subme=4, psy_rd_q8=0, cabac=0, refs=2)),
+    (176, 144, "IBBPBP", 43, dict(rd=1, trellis=0, subme=6, cabac=0, partitions=0x707)),          # --subme 6: RD (CAVLC counts) in I / P slices only
+    (176, 288, "IBBBPBBP", 44, dict(rd=0, trellis=0, subme=5, psy_rd_q8=0, cabac=0, slices=3, dct8x8=0)),
     (176, 144, "IBBBPBBP", 31, dict(subme=6)),                                    # preset fast: subme 6 + trellis 1
     (176, 144, "IBBPBP", 32, dict(subme=6, trellis=127)),
 ])

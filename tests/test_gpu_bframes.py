@@ -184,6 +184,8 @@ NORD = dict(rd=0, trellis=0, psy_rd_q8=0)
     (128, 96, "IBBP", 28, dict(NORD, subme=4, me_method=3, me_range=8)),
     (176, 144, "IBBBPBBBP", 29, dict(NORD, subme=5, partitions=0x707)),              # no b8x8
     (176, 288, "IBBBPBBP", 30, dict(NORD, subme=5, slices=3)),
+    (176, 144, "IBBBPBBP", 41, dict(NORD, subme=5, cabac=0)),                        # CAVLC (Main profile --no-cabac): the host's B CAVLC writer, checker's CAVLC B parse
+    (96, 80, "IBPBBPBBBPP", 42, dict(NORD, subme=4, cabac=0, refs=2)),
     (176, 144, "IBBBPBBP", 31, dict(subme=6)),                                       # preset fast: --subme 6 --trellis 1: the final encode of the B macroblocks searches too (RD 7)
     (176, 144, "IBBPBP", 32, dict(subme=6, trellis=127)),                            # --trellis 2 at subme 6: off in the B slices' analysis (i_mbrd 0), on in their final encode
     (208, 112, "IBBPBP", 33, dict(subme=6, me_method=2, refs=2, dpb=4, mixed_refs=0)),

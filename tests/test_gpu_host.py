@@ -899,6 +899,7 @@ def test_every_preset_codes_a_decodable_stream(gpu, preset):
     {"subme": 8, "me": "hex", "trellis": 1, "ref": 2, "bframes": 0, "keyint": 9, "crf": 25, "rc-lookahead": 4},
     {"subme": 6, "me": "hex", "trellis": 1, "ref": 2, "bframes": 3, "b-adapt": 1, "rc-lookahead": 8, "keyint": 12, "crf": 24, "mixed-refs": 0},      # preset fast: B slices without RD, trellis in their final encode
     {"subme": 4, "me": "hex", "trellis": 0, "ref": 2, "bframes": 3, "b-adapt": 1, "rc-lookahead": 6, "keyint": 12, "qp": 25, "mixed-refs": 0},       # preset faster
+    {"subme": 5, "me": "hex", "trellis": 0, "ref": 2, "bframes": 3, "b-adapt": 1, "rc-lookahead": 6, "keyint": 12, "qp": 25, "no-cabac": None},      # Main profile CAVLC with B pictures
     {"subme": 2, "me": "hex", "trellis": 0, "ref": 1, "bframes": 3, "b-adapt": 1, "rc-lookahead": 4, "keyint": 10, "qp": 26, "mixed-refs": 0},
 ])
 def test_rd_refinement_session_equals_the_checker(gpu, tmp_path, opts):

@@ -129,6 +129,7 @@ struct SliceCtx {
     int cur_mb = 0;               // macroblock being coded
     int done8 = 0;                // 8x8 blocks of the current macroblock whose motion is already known
     Nb cur8[4];                   // motion of the current macroblock's 8x8 blocks (valid where done8 is set)
+    int lst = 0;                  // B slices: the list whose motion block8 / mvp_part look at
     Nb block8(int gx, int gy) const
     {
         Nb n = { false, -1, 0, 0 };
@@ -138,7 +139,10 @@ struct SliceCtx {
         if (i > cur_mb) return n;                          // raster order: everything before the current macroblock is available
         n.avail = true;
         const x264gpu_mb &m = mbs[i];
-        if (!is_intra(m)) { n.ref = m.ref[k]; n.mvx = m.mv[k][0]; n.mvy = m.mv[k][1]; }
+        if (!is_intra(m)) {
+            if (lst) { n.ref = m.ref1[k]; n.mvx = m.ref1[k] >= 0 ? m.mv1[k][0] : 0; n.mvy = m.ref1[k] >= 0 ? m.mv1[k][1] : 0; }
+            else { n.ref = m.ref[k]; n.mvx = m.ref[k] >= 0 ? m.mv[k][0] : 0; n.mvy = m.ref[k] >= 0 ? m.mv[k][1] : 0; }
+        }
         return n;
     }
     // partition = 8x8 blocks [bx8, bx8+w8) x [by8, by8+h8) of macroblock (mbx,mby); shape/part select the
@@ -260,6 +264,59 @@ struct SliceCtx {
             for (int c = 0; c < 8; c++) t[16 + c] = (uint8_t)nzc(lv + X264GPU_LV_CHROMA_AC + c * 16 + 1, 15);
     }
 
+    // an inter macroblock of a B slice (7.3.5 with Table 7-14 / 7-18): mb_type, sub_mb_type, ref_idx_l0 / _l1, mvd_l0 / _l1, then what every inter
+    // macroblock carries.  Direct blocks send nothing; their inferred motion (in the record) is what the other partitions' predictors see
+    void write_mb_b(int mbx, int mby, const x264gpu_mb &m, const int16_t *lv)
+    {
+        static const int8_t geom[4][4][4] = { { { 0, 0, 2, 2 } }, { { 0, 0, 2, 1 }, { 0, 1, 2, 1 } }, { { 0, 0, 1, 2 }, { 1, 0, 1, 2 } },
+                                              { { 0, 0, 1, 1 }, { 1, 0, 1, 1 }, { 0, 1, 1, 1 }, { 1, 1, 1, 1 } } };
+        auto use_of = [&](int k) { return (m.type == X264GPU_MB_B_DIRECT || (m.type == X264GPU_MB_B_8x8 && (m.direct8 >> k & 1))) ? 3 : m.ref[k] >= 0 ? (m.ref1[k] >= 0 ? 2 : 0) : 1; };
+        const long pos_start = (long)bw.bits();
+        if (m.type == X264GPU_MB_B_DIRECT) bw.ue(0);
+        else {
+            const int part = m.partition & 3, nparts = part == 0 ? 1 : part == 3 ? 4 : 2;
+            int use[4];
+            for (int k = 0; k < nparts; k++) use[k] = use_of(geom[part][k][1] * 2 + geom[part][k][0]);
+            if (part == 3) { bw.ue(22); for (int k = 0; k < 4; k++) bw.ue(use[k] == 3 ? 0 : (uint32_t)(use[k] + 1)); }
+            else if (part == 0) bw.ue((uint32_t)(1 + use[0]));
+            else {
+                static const int8_t pair_of[3][3] = { { 0, 2, 4 }, { 3, 1, 5 }, { 6, 7, 8 } };
+                bw.ue((uint32_t)(4 + 2 * pair_of[use[0]][use[1]] + (part == 2)));
+            }
+            for (int l = 0; l < 2; l++) {
+                const int nact = l ? p.num_ref1 : p.num_ref;
+                if (nact <= 1) continue;
+                for (int k = 0; k < nparts; k++) {
+                    const int b8 = geom[part][k][1] * 2 + geom[part][k][0];
+                    if (use[k] == 2 || use[k] == l) bw.te(nact - 1, l ? m.ref1[b8] : m.ref[b8]);
+                }
+            }
+            for (lst = 0; lst < 2; lst++) {
+                done8 = 0;
+                for (int k = 0; k < nparts; k++) {
+                    const int8_t *g = geom[part][k];
+                    const int b8 = g[1] * 2 + g[0];
+                    const int r = lst ? m.ref1[b8] : m.ref[b8], vx = lst ? m.mv1[b8][0] : m.mv[b8][0], vy = lst ? m.mv1[b8][1] : m.mv[b8][1];
+                    if (use[k] == 2 || use[k] == lst) {
+                        int px, py;
+                        mvp_part(mbx, mby, g[0], g[1], g[2], part, k, r, px, py);
+                        bw.se(vx - px); bw.se(vy - py);
+                    }
+                    for (int yy = g[1]; yy < g[1] + g[3]; yy++)
+                        for (int xx = g[0]; xx < g[0] + g[2]; xx++) { cur8[yy * 2 + xx] = Nb{ true, r >= 0 ? r : -1, r >= 0 ? vx : 0, r >= 0 ? vy : 0 }; done8 |= 1 << (yy * 2 + xx); }
+                }
+            }
+            lst = 0; done8 = 0;
+        }
+        const long pos_tex = (long)bw.bits();
+        mv_bits += pos_tex - pos_start;
+        bw.ue(cbp_to_golomb_inter[m.cbp_luma | (m.cbp_chroma << 4)]);
+        if (p.transform8x8_mode && m.cbp_luma) bw.put1(m.transform8x8);      // (direct_8x8_inference: every block here is 8x8 or larger)
+        if (m.cbp_luma || m.cbp_chroma) bw.se(qp_delta(m));
+        write_residual(mbx, mby, m, lv);
+        tex_bits += (long)bw.bits() - pos_tex;
+    }
+
     // Codes rows [row0, row1).  In P slices the bits start at the first coded macroblock's mb_type: the mb_skip_run in front of it
     // (lead_skip + whatever the previous band left pending) is written by the caller that stitches the bands together.
     void run()
@@ -273,7 +330,11 @@ struct SliceCtx {
                 const int16_t *lv = levels + (size_t)i * X264GPU_MB_LEVELS;
                 cur_mb = i; done8 = 0;
                 if (p.slice_type == X264GPU_SLICE_I) write_mb_intra(mbx, mby, m, lv, 0);
-                else if (is_intra(m)) { flush_run(); write_mb_intra(mbx, mby, m, lv, 5); }
+                else if (is_intra(m)) { flush_run(); write_mb_intra(mbx, mby, m, lv, p.slice_type == X264GPU_SLICE_B ? 23 : 5); }
+                else if (p.slice_type == X264GPU_SLICE_B) {
+                    if (m.type == X264GPU_MB_B_SKIP) { skip_run++; nskip++; }
+                    else { flush_run(); write_mb_b(mbx, mby, m, lv); }
+                }
                 else {
                     int px, py;
                     // P_Skip is the analysis' decision (x264_macroblock_analyse / the conversion at the end of x264_macroblock_encode); its record
