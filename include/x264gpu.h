@@ -398,6 +398,10 @@ int  x264gpu_lookahead_frame_cost(x264gpu_lookahead *la, const uint8_t *d_i420, 
 /* Adaptive-quantisation offsets (Q8) of `streams` source pictures: strength * (log2(AC energy) - 14.427) per macroblock, as the lookahead
  * of x264 computes them when a picture arrives (x264_adaptive_quant_frame); what aq_mode 1 of the encoder computes itself. */
 int  x264gpu_lookahead_aq_offsets(x264gpu_lookahead *la, const uint8_t *d_i420, int strength_q8, int16_t *d_out_q8, void *stream);
+/* ... with x264's --aq-mode: 1 = the call above; 2 (auto-variance) / 3 (auto-variance with a bias to dark scenes): x264_adaptive_quant_frame's float
+ * path — per macroblock (energy + 1)^(1/8), the picture's mean and mean square of them (summed in raster order), strength x (value - average)
+ * [+ aq-strength x (1 - 14 / value^2)]; strength_q8 = aq-strength x 256 here (mode 1: x 1.0397 x 256 as above).  The result is Q8 like every offset */
+int  x264gpu_lookahead_aq_offsets_mode(x264gpu_lookahead *la, const uint8_t *d_i420, int mode, int strength_q8, int16_t *d_out_q8, void *stream);
 /* Macroblock-tree ([x264-upstream] encoder/slicetype.c macroblock_tree / _propagate / _finish, common/mc.c mbtree_propagate_cost / _list)
  * for an I/P-only stream at constant frame rate.  d_info[j], d_aq_q8[j] (host arrays of n device pointers): the per-block records
  * (x264gpu_lookahead_frame_cost d_blocks) and AQ offsets of n consecutive pictures, j = 0 the one about to be coded; d_aq_q8 may be NULL.

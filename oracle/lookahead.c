@@ -262,6 +262,43 @@ void x264o_aq_offsets(const uint8_t *i420, int w, int h, int strength_q8, int16_
         }
 }
 
+/* ... --aq-mode 2 (auto-variance) and 3 (auto-variance with a bias to dark scenes), x264_adaptive_quant_frame's float path: every macroblock's
+ * qp_adj = (energy + 1)^(1/8), the picture's mean and mean square of them, strength = aq-strength x mean,
+ *   mode 2: strength x (qp_adj - avg)        mode 3: ... + aq-strength x (1 - 14 / qp_adj^2)        avg = mean - (mean square - 14) / (2 mean)
+ * in single floats, summed in raster order as x264 does; the eighth root is three IEEE square roots (x264 calls powf: may differ in the last place);
+ * the result is rounded to Q8 like every offset here.  strength_q8 = aq-strength x 256 (without mode 1's 1.0397). */
+#include <math.h>
+void x264o_aq_offsets_mode(const uint8_t *i420, int w, int h, int mode, int strength_q8, int16_t *out_q8)
+{
+    const int bw = (w + 15) / 16, bh = (h + 15) / 16, nb = bw * bh;
+    if (mode <= 1) { x264o_aq_offsets(i420, w, h, strength_q8, out_q8); return; }
+    const uint8_t *Y = i420, *U = i420 + (size_t)w * h, *V = U + (size_t)(w / 2) * (h / 2);
+    float *adj = malloc((size_t)nb * sizeof(float));
+    float avg_adj = 0.f, avg_adj_pow2 = 0.f;
+    for (int by = 0; by < bh; by++)
+        for (int bx = 0; bx < bw; bx++) {
+            uint32_t sum = 0, sqr = 0, su = 0, squ = 0, sv = 0, sqv = 0;
+            for (int r = 0; r < 16; r++) for (int c = 0; c < 16; c++) { uint32_t p = Y[(size_t)clampi(by * 16 + r, 0, h - 1) * w + clampi(bx * 16 + c, 0, w - 1)]; sum += p; sqr += p * p; }
+            for (int r = 0; r < 8; r++) for (int c = 0; c < 8; c++) {
+                size_t o = (size_t)clampi(by * 8 + r, 0, h / 2 - 1) * (w / 2) + clampi(bx * 8 + c, 0, w / 2 - 1);
+                uint32_t u = U[o], v = V[o];
+                su += u; squ += u * u; sv += v; sqv += v * v;
+            }
+            const uint32_t energy = (sqr - (sum * sum >> 8)) + (squ - (su * su >> 6)) + (sqv - (sv * sv >> 6));
+            const float q = sqrtf(sqrtf(sqrtf((float)energy + 1.f)));
+            adj[by * bw + bx] = q; avg_adj += q; avg_adj_pow2 += q * q;
+        }
+    avg_adj /= (float)nb; avg_adj_pow2 /= (float)nb;
+    const float aqs = (float)strength_q8 / 256.f, strength = aqs * avg_adj;
+    avg_adj = avg_adj - 0.5f * (avg_adj_pow2 - 14.f) / avg_adj;
+    for (int i = 0; i < nb; i++) {
+        float q = strength * (adj[i] - avg_adj);
+        if (mode == 3) q += aqs * (1.f - 14.f / (adj[i] * adj[i]));
+        out_q8[i] = (int16_t)lrintf(q * 256.f);
+    }
+    free(adj);
+}
+
 /* ---- macroblock-tree for an I/P-only stream ([x264-upstream] encoder/slicetype.c macroblock_tree, macroblock_tree_propagate,
  * mbtree_propagate_cost / _list of common/mc.c, macroblock_tree_finish), constant frame rate.  info[j] / aq[j]: per-block records
  * and AQ offsets of n consecutive pictures, j = 0 the one about to be coded.  Every picture hands the part of its cost that its

@@ -106,6 +106,14 @@ class GpuLookahead:
         t.cuda.synchronize()
         return out
 
+    def aq_offsets_mode(self, frames, mode, strength_q8=256):
+        t = self.torch
+        d_in = t.from_numpy(np.stack(frames)).cuda()
+        out = t.zeros((self.S, self.nb), dtype=t.int16, device="cuda")
+        lib.check(lib.x264gpu_lookahead_aq_offsets_mode(self.h, d_in.data_ptr(), mode, strength_q8, out.data_ptr(), None), "lookahead_aq_offsets_mode")
+        t.cuda.synchronize()
+        return out
+
     def mbtree(self, d_infos, d_aqs, strength_q8=512):
         """d_infos / d_aqs: lists of device tensors of consecutive pictures ([0] = the one about to be coded); d_aqs may be None"""
         t = self.torch

@@ -388,7 +388,15 @@ class OracleSlicetype:
 
 
 _sig("x264o_aq_offsets", None, [C.c_void_p, _i, _i, _i, C.c_void_p])
+_sig("x264o_aq_offsets_mode", None, [C.c_void_p, _i, _i, _i, _i, C.c_void_p])
 _sig("x264o_mbtree", None, [_i, _i, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), _i, _i, C.c_void_p])
+
+
+def aq_offsets_mode(i420, w, h, mode, strength_q8=256):
+    out = np.zeros(((w + 15) // 16) * ((h + 15) // 16), np.int16)
+    i420 = np.ascontiguousarray(i420, np.uint8)
+    L.x264o_aq_offsets_mode(ptr(i420), w, h, mode, strength_q8, ptr(out))
+    return out
 
 
 def aq_offsets(i420, w, h, strength_q8=266):

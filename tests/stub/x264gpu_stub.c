@@ -221,6 +221,15 @@ int x264gpu_lookahead_aq_offsets(x264gpu_lookahead *l, const uint8_t *i420, int 
     x264o_aq_offsets(i420, l->w, l->h, strength_q8, out);
     return X264GPU_OK;
 }
+
+void x264o_aq_offsets_mode(const uint8_t *i420, int w, int h, int mode, int strength_q8, int16_t *out_q8);
+int x264gpu_lookahead_aq_offsets_mode(x264gpu_lookahead *l, const uint8_t *i420, int mode, int strength_q8, int16_t *out, void *st)
+{
+    (void)st;
+    if (mode < 1 || mode > 3) return fail("aq mode 1..3");
+    x264o_aq_offsets_mode(i420, l->w, l->h, mode, strength_q8, out);
+    return X264GPU_OK;
+}
 int x264gpu_lookahead_mbtree(x264gpu_lookahead *l, const int32_t *const *info, const int16_t *const *aq, int n, int strength_q8, int16_t *out, void *st)
 {
     x264o_mbtree((l->w + 15) / 16, (l->h + 15) / 16, info, aq, n, strength_q8, out);

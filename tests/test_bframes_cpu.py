@@ -517,3 +517,18 @@ def test_host_session_two_pass(tmp_path):
     r = subprocess.run([sys.executable, os.path.join(os.path.dirname(os.path.abspath(__file__)), "stub", "run_host_b.py"), str(tmp_path / "c.h264"), str(w), str(h), str(n), "9"] +
                        ["scene_len=31", "bitrate=1", "keyint=40", "bframes=3", "pass=2", f"stats={st}"], capture_output=True, text=True, timeout=600)
     assert r.returncode != 0
+
+
+@pytest.mark.parametrize("mode", [2, 3])
+def test_host_session_aq_mode_2_and_3(tmp_path, mode):
+    """--aq-mode 2 / 3 (config.c:1610-1614 passes the user's choice through): the session computes x264_adaptive_quant_frame's auto-variance offsets
+    when a picture arrives and hands them to the encoder; the macroblock quantisers differ from mode 1's and the stream decodes"""
+    import subprocess
+    subprocess.check_call(["make", "-s", "-C", __file__.rsplit("/", 1)[0] + "/stub"])
+    n, w, h = 10, 176, 144
+    info, stream = _host_b_session(tmp_path, n, ["crf=24", "keyint=30", f"aq-mode={mode}", "log=1", "no-mbtree"], w, h, seed=6)
+    assert not any("aq-mode" in m and "aq-mode 1" in m for _, m in info["log"])
+    info1, stream1 = _host_b_session(tmp_path, n, ["crf=24", "keyint=30", "aq-mode=1", "no-mbtree"], w, h, seed=6)
+    assert stream != stream1
+    dec = O.h264_decode(stream, n, w, h)
+    assert len(dec) == n

@@ -254,3 +254,18 @@ def test_weight_analysis_primitives_bitexact(gpu, w, h, seed, kw):
             assert gg.weight_cost_chroma(3, 1, 2, plane, wgt)[0] == og.weight_cost_chroma(3, frames[3], frames[1], 2, plane, wgt), f"chroma plane {plane}, weight {wgt}, reference in place"
     assert og.weight_cost(2, 1, 1, (60, 6, 0)) < og.weight_cost(2, 1, 1, None), "on a fade the right weight must pay"
     og.close(); gg.close()
+
+
+@pytest.mark.parametrize("w,h,mode,strength", [(176, 144, 2, 256), (176, 144, 3, 256), (352, 288, 2, 205), (208, 120, 3, 333), (1920, 1080, 3, 256)])
+def test_aq_mode_2_and_3_bitexact(gpu, w, h, mode, strength):
+    """--aq-mode 2 (auto-variance) / 3 (auto-variance with a bias to dark scenes): x264_adaptive_quant_frame's float path — (energy + 1)^(1/8) per
+    macroblock, the picture's mean and mean square summed in raster order, the offsets — on the device equal to the CPU checker's, two streams"""
+    from gpu_enc import GpuLookahead
+    frames = synth_frames(w, h, 2, seed=w + mode)
+    gl = GpuLookahead(w, h, streams=2)
+    g = gl.aq_offsets_mode(frames, mode, strength).cpu().numpy()
+    for s in range(2):
+        o = O.aq_offsets_mode(frames[s], w, h, mode, strength)
+        assert np.array_equal(g[s], o), f"stream {s}: {np.nonzero(g[s] != o)[0][:5]}"
+    assert np.abs(g).max() > 64                       # (offsets of a quarter of a quantiser step and more: the mode does something)
+    gl.close()

@@ -197,7 +197,7 @@ __device__ __forceinline__ int la_inv_qscale(int aq_q8)
     return (int)(((unsigned)(c_la_exp2_lut[i & 63] + 256) << (i >> 6)) >> 8);
 }
 
-__global__ __launch_bounds__(256) void k_la_aq(const uint8_t *__restrict__ i420, size_t i420_bytes, int w, int h, int bw, int nb, int strength_q8, int16_t *__restrict__ out)
+__global__ __launch_bounds__(256) void k_la_aq(const uint8_t *__restrict__ i420, size_t i420_bytes, int w, int h, int bw, int nb, int strength_q8, int16_t *__restrict__ out, float *__restrict__ adj)
 {
     const int lane = threadIdx.x & 63, r = lane & 15, s = blockIdx.y;
     const int bi = (blockIdx.x * 4 + (threadIdx.x >> 6)) * 4 + (lane >> 4);
@@ -214,7 +214,31 @@ __global__ __launch_bounds__(256) void k_la_aq(const uint8_t *__restrict__ i420,
     sum = (unsigned)row16_sum((int)sum); sqr = (unsigned)row16_sum((int)sqr);
     su = (unsigned)row16_sum((int)su); squ = (unsigned)row16_sum((int)squ); sv = (unsigned)row16_sum((int)sv); sqv = (unsigned)row16_sum((int)sqv);
     const unsigned energy = (sqr - (sum * sum >> 8)) + (squ - (su * su >> 6)) + (sqv - (sv * sv >> 6));
-    if (valid && r == 0) out[(size_t)s * nb + bi] = (int16_t)((strength_q8 * (la_log2_q8(energy ? energy : 1u) - 3693)) >> 8);
+    if (valid && r == 0) {
+        if (adj) adj[(size_t)s * nb + bi] = sqrtf(sqrtf(sqrtf((float)energy + 1.f)));          // --aq-mode 2 / 3: (energy + 1)^(1/8), finished by k_la_aq_auto
+        else out[(size_t)s * nb + bi] = (int16_t)((strength_q8 * (la_log2_q8(energy ? energy : 1u) - 3693)) >> 8);
+    }
+}
+// --aq-mode 2 / 3 (oracle x264o_aq_offsets_mode): the picture's mean and mean square of the per-macroblock values, summed in raster order by one
+// thread a stream (x264's own order: float addition does not reassociate), then every macroblock's offset
+__global__ __launch_bounds__(256) void k_la_aq_auto(const float *__restrict__ adj, int nb, int mode, int strength_q8, int16_t *__restrict__ out)
+{
+    const int s = blockIdx.x;
+    __shared__ float sh[2];
+    const float *a = adj + (size_t)s * nb;
+    if (threadIdx.x == 0) {
+        float sum = 0.f, sq = 0.f;
+        for (int i = 0; i < nb; i++) { const float q = a[i]; sum += q; sq = __fadd_rn(sq, __fmul_rn(q, q)); }
+        sh[0] = sum / (float)nb; sh[1] = sq / (float)nb;
+    }
+    __syncthreads();
+    const float aqs = (float)strength_q8 / 256.f, mean = sh[0], strength = __fmul_rn(aqs, mean);
+    const float avg = __fsub_rn(mean, __fmul_rn(0.5f, __fsub_rn(sh[1], 14.f)) / mean);
+    for (int i = threadIdx.x; i < nb; i += 256) {
+        float q = __fmul_rn(strength, __fsub_rn(a[i], avg));
+        if (mode == 3) q = __fadd_rn(q, __fmul_rn(aqs, __fsub_rn(1.f, 14.f / __fmul_rn(a[i], a[i]))));
+        out[(size_t)s * nb + i] = (int16_t)lrintf(__fmul_rn(q, 256.f));
+    }
 }
 
 // ---- macroblock-tree (oracle x264o_mbtree): one launch per picture walks its blocks and scatters the explained cost into the
@@ -269,6 +293,7 @@ struct x264gpu_lookahead {
     int8_t *inter[2];
     uint16_t *cost_mv;
     int32_t *prop; int prop_cap;     // macroblock-tree accumulators: prop_cap pictures x streams x blocks
+    float *aq_adj;                   // --aq-mode 2 / 3: the per-macroblock (energy + 1)^(1/8) of the picture in work
     int cur, have_prev;
 };
 
@@ -320,7 +345,7 @@ void x264gpu_lookahead_destroy(x264gpu_lookahead *la)
 {
     if (!la) return;
     for (int i = 0; i < 2; i++) { (void)hipFree(la->planes[i]); (void)hipFree(la->mv[i]); (void)hipFree(la->inter[i]); }
-    (void)hipFree(la->cost_mv); (void)hipFree(la->prop);
+    (void)hipFree(la->cost_mv); (void)hipFree(la->prop); (void)hipFree(la->aq_adj);
     delete la;
 }
 
@@ -353,7 +378,19 @@ int x264gpu_lookahead_aq_offsets(x264gpu_lookahead *la, const uint8_t *d_i420, i
     ARG_TRY(la && d_i420 && d_out_q8);
     const int nb = la->bw * la->bh;
     hipLaunchKernelGGL(k_la_aq, dim3((nb + 15) / 16, la->streams), dim3(256), 0, (hipStream_t)stream, d_i420, (size_t)la->w * la->h * 3 / 2, la->w, la->h, la->bw, nb,
-                       strength_q8, d_out_q8);
+                       strength_q8, d_out_q8, (float *)nullptr);
+    HIP_TRY(hipGetLastError());
+    return X264GPU_OK;
+}
+int x264gpu_lookahead_aq_offsets_mode(x264gpu_lookahead *la, const uint8_t *d_i420, int mode, int strength_q8, int16_t *d_out_q8, void *stream)
+{
+    ARG_TRY(la && d_i420 && d_out_q8 && mode >= 1 && mode <= 3);
+    if (mode == 1) return x264gpu_lookahead_aq_offsets(la, d_i420, strength_q8, d_out_q8, stream);
+    const int nb = la->bw * la->bh;
+    if (!la->aq_adj) HIP_TRY(hipMalloc((void **)&la->aq_adj, (size_t)la->streams * nb * sizeof(float)));
+    hipLaunchKernelGGL(k_la_aq, dim3((nb + 15) / 16, la->streams), dim3(256), 0, (hipStream_t)stream, d_i420, (size_t)la->w * la->h * 3 / 2, la->w, la->h, la->bw, nb,
+                       strength_q8, d_out_q8, la->aq_adj);
+    hipLaunchKernelGGL(k_la_aq_auto, dim3(la->streams), dim3(256), 0, (hipStream_t)stream, la->aq_adj, nb, mode, strength_q8, d_out_q8);
     HIP_TRY(hipGetLastError());
     return X264GPU_OK;
 }

@@ -73,6 +73,7 @@ struct x264_t {
     int16_t *d_tree = nullptr;           // device: macroblock-tree quantiser offsets of the picture being coded
     long la_count = 0; int la_gop = 0;   // pictures seen by the lookahead; distance from the last IDR at lookahead time
     bool mbtree = false; int aq_strength_q8 = 0, tree_strength_q8 = 0;
+    int aq_mode = 0;                     // --aq-mode (1 variance, 2 auto-variance, 3 auto-variance biased); modes 2 / 3 always arrive as offsets computed when the picture comes in
     int cavlc_threads = 1;               // row bands of a slice coded in parallel (threads 1 sessions; GOP-parallel ones use a thread per GOP)
     // ---- pipelined threads-1 sessions (CRF with pictures held back anyway): the GPU stage of picture n+1 runs in a helper thread while
     //      the calling thread entropy-codes picture n; every picture is handed back one call later than without it ----
@@ -520,7 +521,10 @@ x264_t *x264_encoder_open(x264_param_t *param)
     if (p.rc.b_mb_tree && p.i_threads > 1) { xlog(&p, X264_LOG_INFO, "mbtree needs threads 1 (GOPs in lock-step are coded before what follows them is seen): mbtree 0\n"); p.rc.b_mb_tree = 0; }
     p.rc.b_mb_tree = p.rc.b_mb_tree != 0;
     p.rc.i_lookahead = p.rc.b_mb_tree ? clampi(p.rc.i_lookahead, 1, p.i_keyint_max < 250 ? (p.i_keyint_max > 1 ? p.i_keyint_max : 1) : 250) : 0;
-    if (p.rc.i_aq_mode > X264_AQ_VARIANCE) { xlog(&p, X264_LOG_WARNING, "aq-mode %d is not implemented yet: aq-mode 1\n", p.rc.i_aq_mode); p.rc.i_aq_mode = X264_AQ_VARIANCE; }
+    p.rc.i_aq_mode = clampi(p.rc.i_aq_mode, 0, 3);
+    if (p.rc.i_aq_mode > X264_AQ_VARIANCE && (!h->dpbmode || getenv("X264GPU_BATCH"))) {
+        xlog(&p, X264_LOG_WARNING, "aq-mode %d needs B-frames or weightp 2 (the DPB-model path, one session a device encoder) in the MI355X path: aq-mode 1\n", p.rc.i_aq_mode); p.rc.i_aq_mode = X264_AQ_VARIANCE;
+    }
     p.rc.i_qp_constant = clampi(qp, 1, 51);
     p.rc.i_qp_min = clampi(p.rc.i_qp_min, 1, 51); p.rc.i_qp_max = clampi(p.rc.i_qp_max, p.rc.i_qp_min, 51);
     if (p.i_threads > 1 && p.i_scenecut_threshold) { xlog(&p, X264_LOG_INFO, "scenecut needs threads 1 (GOPs in lock-step have a fixed structure): scenecut 0\n"); p.i_scenecut_threshold = 0; }
@@ -577,6 +581,7 @@ x264_t *x264_encoder_open(x264_param_t *param)
     cfg.dct8x8 = p.analyse.b_transform_8x8;
     cfg.me_method = p.analyse.i_me_method == X264_ME_DIA ? 0 : p.analyse.i_me_method == X264_ME_HEX ? 1 : p.analyse.i_me_method == X264_ME_UMH ? 2 : 3;
     cfg.aq_mode = p.rc.i_aq_mode == X264_AQ_VARIANCE; cfg.aq_strength_q8 = (int)(p.rc.f_aq_strength * 1.0397f * 256.0f + 0.5f);
+    h->aq_mode = p.rc.i_aq_mode;
     cfg.mixed_refs = p.analyse.b_mixed_references && (p.analyse.inter & X264_ANALYSE_PSUB16x16) != 0;
     cfg.chroma_me = p.analyse.b_chroma_me && p.analyse.i_subpel_refine >= 5;     // x264: h->mb.b_chroma_me in P slices
     cfg.fast_pskip = p.analyse.b_fast_pskip;
@@ -625,7 +630,7 @@ x264_t *x264_encoder_open(x264_param_t *param)
         x264_encoder_close(h);
         return nullptr;
     }
-    if ((p.i_scenecut_threshold > 0 && !h->dpbmode) || h->crf || h->abr) {       // (sessions on the DPB model take scene cuts from x264's own analysis below)
+    if ((p.i_scenecut_threshold > 0 && !h->dpbmode) || h->crf || h->abr || h->aq_mode >= 2) {       // (sessions on the DPB model take scene cuts from x264's own analysis below)
         if (x264gpu_lookahead_create(&h->la, p.i_width, p.i_height, 1, p.analyse.i_me_range, p.analyse.i_subpel_refine) != X264GPU_OK ||
             x264gpu_malloc((void **)&h->d_la, 4 * sizeof(int32_t)) != X264GPU_OK) {
             xlog(&p, X264_LOG_ERROR, "GPU lookahead setup failed: %s\n", x264gpu_last_error());
@@ -669,7 +674,7 @@ x264_t *x264_encoder_open(x264_param_t *param)
         p.i_bframe_bias = clampi(p.i_bframe_bias, -90, 100);
         (void)x264gpu_slicetype_set_bframe_bias(h->st, p.i_bframe_bias);          // --b-bias also scales the B costs of slicetype_frame_cost
     }
-    h->aq_strength_q8 = cfg.aq_mode ? cfg.aq_strength_q8 : 0;
+    h->aq_strength_q8 = cfg.aq_mode ? cfg.aq_strength_q8 : h->aq_mode >= 2 ? (int)(p.rc.f_aq_strength * 256.0f + 0.5f) : 0;      // (modes 2 / 3: the plain strength, x264_adaptive_quant_frame scales it by the picture's mean itself)
     h->st_aq_costs = h->st && h->la && !h->mbtree && h->aq_strength_q8 && (h->crf || h->abr);
     h->tree_strength_q8 = (int)(1280.0 * (1.0 - p.rc.f_qcompress) + 0.5);     // 5 * (1 - qcomp), Q8
     h->q_raw.assign((size_t)h->Q, nullptr); h->q_info.assign((size_t)h->Q, nullptr); h->q_aq.assign((size_t)h->Q, nullptr); h->q_tree.assign((size_t)h->Q, nullptr);
@@ -680,7 +685,7 @@ x264_t *x264_encoder_open(x264_param_t *param)
         for (int i = 0; i < h->Q && ok; i++) {
             if (!h->q_raw[(size_t)i]) ok = x264gpu_malloc((void **)&h->q_raw[(size_t)i], insz) == X264GPU_OK;
             if (ok && h->mbtree) ok = x264gpu_malloc((void **)&h->q_info[(size_t)i], (size_t)h->nmb * 4 * sizeof(int32_t)) == X264GPU_OK;
-            if (ok && (h->mbtree || h->st_aq_costs)) ok = x264gpu_malloc((void **)&h->q_aq[(size_t)i], (size_t)h->nmb * sizeof(int16_t)) == X264GPU_OK;
+            if (ok && (h->mbtree || h->st_aq_costs || h->aq_mode >= 2)) ok = x264gpu_malloc((void **)&h->q_aq[(size_t)i], (size_t)h->nmb * sizeof(int16_t)) == X264GPU_OK;
             if (ok && h->mbtree && h->dpbmode) ok = x264gpu_malloc((void **)&h->q_tree[(size_t)i], (size_t)h->nmb * sizeof(int16_t)) == X264GPU_OK;
         }
         if (ok && h->mbtree) ok = x264gpu_malloc((void **)&h->d_tree, (size_t)h->nmb * sizeof(int16_t)) == X264GPU_OK;
@@ -1886,6 +1891,7 @@ static int encode_bmode(x264_t *h, x264_nal_t **pp_nal, int *pi_nal, x264_pictur
     }
     if (h->st && h->mbtree)          // P / I / B-reference pictures: what the tree left (AQ - tree); other B pictures: the AQ offsets alone (x264 f_qp_offset_aq)
         x264gpu_encoder_set_mb_qp_offsets(h->gpu, pl.type == PIC_B ? h->q_aq[(size_t)pl.e.slot] : h->q_tree[(size_t)pl.e.slot]);
+    else if (h->aq_mode >= 2 && h->aq_strength_q8) x264gpu_encoder_set_mb_qp_offsets(h->gpu, h->q_aq[(size_t)pl.e.slot]);      // --aq-mode 2 / 3: the offsets computed when the picture arrived
     if (h->batch) {
         std::string berr;
         if (batch_encode(h->batch, h->batch_idx, h->q_raw[(size_t)pl.e.slot], pic, h->h_mb.data(), h->h_lv.data(), berr)) {
@@ -2039,7 +2045,7 @@ int x264_encoder_encode(x264_t *h, x264_nal_t **pp_nal, int *pi_nal, x264_pictur
     bool idr = h->la_count == 0 || h->la_gop >= h->keyint || pic_in->i_type == X264_TYPE_IDR || pic_in->i_type == X264_TYPE_KEYFRAME, intra_pic = false;
     if (h->la) {
         if (x264gpu_lookahead_frame_cost(h->la, d_raw, h->la_count == 0, h->d_la, h->mbtree ? h->q_info[(size_t)slot] : nullptr, nullptr) != X264GPU_OK ||
-            ((h->mbtree || h->st_aq_costs) && h->aq_strength_q8 && x264gpu_lookahead_aq_offsets(h->la, d_raw, h->aq_strength_q8, h->q_aq[(size_t)slot], nullptr) != X264GPU_OK) ||
+            ((h->mbtree || h->st_aq_costs || h->aq_mode >= 2) && h->aq_strength_q8 && x264gpu_lookahead_aq_offsets_mode(h->la, d_raw, h->aq_mode >= 2 ? h->aq_mode : 1, h->aq_strength_q8, h->q_aq[(size_t)slot], nullptr) != X264GPU_OK) ||
             x264gpu_memcpy_d2h(e.costs, h->d_la, sizeof(e.costs), nullptr) != X264GPU_OK) {
             xlog(&p, X264_LOG_ERROR, "x264_encoder_encode: lookahead failed: %s\n", x264gpu_last_error());
             return -1;

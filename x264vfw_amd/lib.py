@@ -121,6 +121,7 @@ _SIGS = {
     "x264gpu_lookahead_destroy": (None, [_vp]),
     "x264gpu_lookahead_frame_cost": (_i, [_vp, _vp, _i, _vp, _vp, _vp]),
     "x264gpu_lookahead_aq_offsets": (_i, [_vp, _vp, _i, _vp, _vp]),
+    "x264gpu_lookahead_aq_offsets_mode": (_i, [_vp, _vp, _i, _i, _vp, _vp]),
     "x264gpu_lookahead_mbtree": (_i, [_vp, C.POINTER(_vp), C.POINTER(_vp), _i, _i, _vp, _vp]),
     "x264gpu_slicetype_create": (_i, [C.POINTER(_vp)] + [_i] * 11),
     "x264gpu_slicetype_destroy": (None, [_vp]),
