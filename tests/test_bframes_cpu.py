@@ -431,9 +431,9 @@ def test_host_session_says_what_it_does_not_run(tmp_path):
     import subprocess
     subprocess.check_call(["make", "-s", "-C", __file__.rsplit("/", 1)[0] + "/stub"])
     info, _ = _host_b_session(tmp_path, 3, ["log=1", "crf=24", "vbv-maxrate=2000", "vbv-bufsize=2000", "nr=200", "slice-max-size=1500", "fake-interlaced", "bluray-compat",
-                                            "direct=none", "subme=9", "psy-rd=1.0:0.2", "aq-mode=2", "open-gop", "ref=9", "me=tesa"], 64, 48)
+                                            "direct=none", "subme=9", "psy-rd=1.0:0.2", "open-gop", "ref=9", "me=tesa"], 64, 48)
     text = " | ".join(m for lvl, m in info["log"] if lvl <= 2)
-    for needle in ("VBV", "nr (noise reduction)", "slice-max-size", "fake-interlaced", "bluray-compat", "direct", "subme", "psy-trellis", "aq-mode", "open-gop", "ref %d -> 5", "tesa"):
+    for needle in ("VBV", "nr (noise reduction)", "slice-max-size", "fake-interlaced", "bluray-compat", "direct", "subme", "psy-trellis", "open-gop", "ref %d -> 5", "tesa"):
         assert needle in text, (needle, text)
 
 
