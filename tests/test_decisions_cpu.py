@@ -1,0 +1,63 @@
+"""CPU: the session's DECISIONS — picture types (scenecut, --b-adapt 1, keyint / min-keyint, closed GOPs) and single-pass CRF quantisers (I / P from the
+frame costs, B from its nearest references) — as host/encoder.cpp takes them on the stand-in device, against oracle/decide.py, a second restatement of
+the same parts of libx264 written independently of the host code (numpy / plain python over the CPU checker's frame costs).  Reference consumers of
+these decisions: codec.c:1786 (every ICM_COMPRESS), config.c:1504-1514 (CRF / ABR rate control of the dialog)."""
+import ctypes as C
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+import oracle_lib as O
+from x264vfw_amd.lib import Pic
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(os.path.dirname(HERE), "oracle"))
+import decide as D  # noqa: E402
+
+
+def host_session(tmp_path, w, h, n, seed, opts):
+    subprocess.check_call(["make", "-s", "-C", os.path.join(HERE, "stub")])
+    dump = tmp_path / "dump"
+    dump.mkdir()
+    env = dict(os.environ, X264GPU_DUMP_RECORDS=str(dump))
+    r = subprocess.run([sys.executable, os.path.join(HERE, "stub", "run_host_b.py"), str(tmp_path / "s.h264"), str(w), str(h), str(n), str(seed)] + opts,
+                       capture_output=True, text=True, timeout=900, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    info = json.loads(r.stdout.strip().splitlines()[-1])
+    pics = []
+    for k in range(n):
+        raw = (dump / f"pic{k:04d}.bin").read_bytes()[:C.sizeof(Pic)]
+        pics.append(Pic.from_buffer_copy(raw))
+    return info, pics
+
+
+@pytest.mark.parametrize("w,h,n,seed,scene,kind,opts,kw", [
+    (176, 144, 40, 3, 13, "moving", ["crf=24", "keyint=30"], dict(crf=24.0, keyint=30)),                                   # scene cuts inside and beyond min-keyint
+    (176, 144, 36, 5, 0, "static", ["crf=22", "keyint=16", "b-adapt=1"], dict(crf=22.0, keyint=16)),                       # static content: runs of three B pictures, the keyint limit
+    (208, 112, 30, 7, 11, "moving", ["crf=26", "keyint=25", "b-adapt=0", "bframes=2"], dict(crf=26.0, keyint=25, b_adapt=0, bframes=2)),
+    (176, 144, 28, 9, 9, "moving", ["crf=23", "keyint=40", "bframes=0", "weightp=2", "ref=3"], dict(crf=23.0, keyint=40, bframes=0)),   # no B pictures: P and scene cuts only
+    (176, 144, 32, 11, 0, "static", ["crf=25", "keyint=250", "b-pyramid=none", "ipratio=1.6", "pbratio=1.5", "qcomp=0.7"],
+     dict(crf=25.0, keyint=250, b_pyramid=0, ip_factor=1.6, pb_factor=1.5, qcomp=0.7)),
+])
+def test_decisions_equal_the_twin(tmp_path, w, h, n, seed, scene, kind, opts, kw):
+    sys.path.insert(0, os.path.join(HERE, "stub"))
+    from run_host_b import make_frames
+    common = ["no-mbtree", "aq-mode=0", "weightp=0" if not any(o.startswith("weightp") for o in opts) else "subme=7", "rc-lookahead=0"]
+    info, pics = host_session(tmp_path, w, h, n, seed, opts + common + ([f"scene_len={scene}"] if scene else []) + (["static=1"] if kind == "static" else []))
+    frames = make_frames(w, h, n, seed, scene_len=scene, static=int(kind == "static"))
+    p = D.Params((w + 15) // 16, (h + 15) // 16, **kw)
+    slots = 64
+    st = O.OracleSlicetype(w, h, slots=slots, bframes=max(p.bframes, 1), subme=7)
+    twin = D.run_session(frames, p, st, slots)
+    st.close()
+    got = [(r[1], r[0]) for r in info["recs"]]                                   # (display index, x264 type) in coding order
+    want = [(f, t) for f, t, _, _ in twin]
+    assert got == want, f"picture types: session {got} twin {want}"
+    assert len({t for _, t in want}) >= 2
+    for k, ((f, t, qp, qpf), pic) in enumerate(zip(twin, pics)):
+        assert pic.qp == qp, f"coded picture {k} (display {f}, type {t}): quantiser {pic.qp} vs the twin's {qp} ({qpf:.3f})"
+        assert abs(pic.qp + pic.qp_frac_q8 / 256.0 - qpf) <= 1.0 / 256 + 1e-9, (k, pic.qp, pic.qp_frac_q8, qpf)
