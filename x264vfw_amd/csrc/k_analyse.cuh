@@ -205,6 +205,7 @@ __device__ __forceinline__ u16x2 wp2(u16x2 p, int wpk)
     return r;
 }
 // wcu / wcv: the reference's explicit Cb / Cr weight (0 = none; wave-uniform)
+template <bool WT = false>
 __device__ __forceinline__ int chroma_me_cost(const ChromaTaps &t, int mvx, int mvy, uint32_t e0, uint32_t e1, s16x2 sg1, s16x2 sg2, int wcu = 0, int wcv = 0)
 {
     const int dx = mvx & 7, dy = mvy & 7;
@@ -220,7 +221,7 @@ __device__ __forceinline__ int chroma_me_cost(const ChromaTaps &t, int mvx, int 
 #define W(x) __builtin_bit_cast(u16x2, x)
         u16x2 p01 = (W(wA) * CH(a0) + W(wB) * CH(a01) + W(wC) * CH(b0) + W(wD) * CH(b01) + W(0x00200020u)) >> 6;
         u16x2 p23 = (W(wA) * CH(a1) + W(wB) * CH(a12) + W(wC) * CH(b1) + W(wD) * CH(b12) + W(0x00200020u)) >> 6;
-        { const int wk = sh ? wcv : wcu; if (wk) { p01 = wp2(p01, wk); p23 = wp2(p23, wk); } }
+        if constexpr (WT) { const int wk = sh ? wcv : wcu; if (wk) { p01 = wp2(p01, wk); p23 = wp2(p23, wk); } }
         const s16x2 da = __builtin_bit_cast(s16x2, CH(e0)) - __builtin_bit_cast(s16x2, p01);
         const s16x2 db = __builtin_bit_cast(s16x2, CH(e1)) - __builtin_bit_cast(s16x2, p23);
 #undef CH
@@ -274,6 +275,7 @@ __device__ __forceinline__ void chroma_commit2(uint32_t *cb, const uint32_t v[2]
     for (int t = 0; t < 2; t++) { const int i = l + 64 * t; if (i < ndw * nrows) cb[i] = v[t]; }
 }
 // chroma_me_half on the staged neighbourhood: (cx, cy) chroma position of the lane's four pixels
+template <bool WT = false>
 __device__ __forceinline__ int chroma_me_lds(const uint32_t *cb, int ndw, int x0c, int y0c, int cx, int cy, int mvx, int mvy, uint32_t e0, uint32_t e1,
                                              s16x2 sg1, s16x2 sg2, int wcu = 0, int wcv = 0)
 {
@@ -284,7 +286,7 @@ __device__ __forceinline__ int chroma_me_lds(const uint32_t *cb, int ndw, int x0
       t.a0 = __builtin_amdgcn_alignbyte(d1, d0, sh); t.a1 = __builtin_amdgcn_alignbyte(d2, d1, sh); t.a2 = __builtin_amdgcn_alignbyte(d3, d2, sh); }
     { const uint32_t d0 = v[0], d1 = v[1], d2 = v[2], d3 = v[3];
       t.b0 = __builtin_amdgcn_alignbyte(d1, d0, sh); t.b1 = __builtin_amdgcn_alignbyte(d2, d1, sh); t.b2 = __builtin_amdgcn_alignbyte(d3, d2, sh); }
-    return chroma_me_cost(t, mvx, mvy, e0, e1, sg1, sg2, wcu, wcv);
+    return chroma_me_cost<WT>(t, mvx, mvy, e0, e1, sg1, sg2, wcu, wcv);
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -207,7 +207,7 @@ __device__ __forceinline__ void me_search(const EncK &k, MbLds<M> &L, const MbCt
     // explicit luma weight of this reference (P slices, --weightp): every sample fetched below goes through it after interpolation; the
     // reference cache holds the unweighted planes under the PICTURE's tag, so an index and its duplicate share a slot
     const int wpk = k.wp_any ? uni(k.wl0[j.ref]) : 0;
-    const int wcu = k.wc_any ? uni(k.wc0[2 * j.ref]) : 0, wcv = k.wc_any ? uni(k.wc0[2 * j.ref + 1]) : 0;          // (m->weight[1] / [2]: the chroma-ME costs)
+    const int wcu = k.wc_any ? uni(k.wc0[2 * j.ref]) : 0, wcv = k.wc_any ? uni(k.wc0[2 * j.ref + 1]) : 0;
     const bool wt = (wpk >> 24) != 0;
     const int cref = k.wp_any ? ref_picture(k, j.ref) : j.ref;
     // (the upper half of an 8-pixel row's registers stays zero: weighting it would turn it into the offset and into cost)
@@ -676,7 +676,10 @@ __device__ __forceinline__ void me_search(const EncK &k, MbLds<M> &L, const MbCt
         return row16_sum(w16 ? satd16x4_half_pk<4>(e, p, sg1, sg2) : satd16x4_half_pk<2>(e, p, sg1, sg2)) + mvc2(qx, qy);       // 8-pixel rows: half the work
     };
     auto chroma2 = [&](int qx, int qy) {
-        const int h = cact ? chroma_me_lds(cb, cndw, cx0c, cy0c, (c.px >> 1) + ccx, (c.py >> 1) + ccy, qx, qy, ce0, ce1, sg1, sg2, wcu, wcv) : 0;
+        // (explicit chroma weights are rare — a fade: their arithmetic lives in a second instantiation, the common one is the code without them)
+        int h = 0;
+        if (wcu | wcv) { if (cact) h = chroma_me_lds<true>(cb, cndw, cx0c, cy0c, (c.px >> 1) + ccx, (c.py >> 1) + ccy, qx, qy, ce0, ce1, sg1, sg2, wcu, wcv); }
+        else if (cact) h = chroma_me_lds<false>(cb, cndw, cx0c, cy0c, (c.px >> 1) + ccx, (c.py >> 1) + ccy, qx, qy, ce0, ce1, sg1, sg2);
         return row16_sum(h);
     };
     // half-pel diamond on SAD: (0,-2) (0,2) (-2,0) (2,0)
