@@ -1561,8 +1561,53 @@ static void nnzc_sync(actx *a, const x264gpu_mb *mb)
     for (int i = 0; i < 8; i++) a->nnzc[16 + i] = (uint8_t)(!skip && mb->cbp_chroma == 2 ? (mb->nnz >> (16 + i)) & 1 : 0);
 }
 
+/* x264_macroblock_deblock ([x264-upstream] encoder/macroblock.c; h->mb.b_deblock_rdo: --subme 9 and up, cfg.rd bit 6): before a whole-macroblock RD
+ * candidate's distortion is measured its luma is loop-filtered along the INTERNAL edges (what the real filter will do to them later; the macroblock's
+ * outer edges need the neighbours' final state and are left out): boundary strength 3 everywhere for intra, else from the coded flags / reference
+ * indices / vector differences of the 4x4 blocks on either side (deblock_strength: 2, 1 or 0; reference INDICES as they are, both lists in B slices);
+ * edges 1 and 3 only under the 4x4 transform; nothing for an uncoded 16x16 or at quantisers the filter does not touch */
+static void macroblock_deblock(actx *a, const x264gpu_mb *mb)
+{
+    x264o_encoder *e = a->e;
+    const int aoff = e->cfg.deblock_alpha * 2, boff = e->cfg.deblock_beta * 2;
+    const int qp_thresh = 15 - (aoff < boff ? aoff : boff) - (e->cfg.chroma_qp_offset > 0 ? e->cfg.chroma_qp_offset : 0);
+    const int intra = is_intra_type(mb->type), qp = a->qp;
+    if (!e->cfg.deblock) return;
+    if ((mb->partition == D_16x16 && !mb->cbp_luma && !intra) || qp <= qp_thresh) return;
+    const int ia = clampi(qp + aoff, 0, 51), ib = clampi(qp + boff, 0, 51);
+    const int alpha = x264o_alpha_table[ia], beta = x264o_beta_table[ib];
+    if (!alpha || !beta) return;
+    const int t8 = mb->transform8x8, bframe = e->slice_type == X264GPU_SLICE_B;
+    /* coded flag of the 4x4 block at (x, y): an 8x8-transform block flags all four (STORE_8x8_NNZ) */
+    int nz[4][4];
+    for (int y = 0; y < 4; y++) for (int x = 0; x < 4; x++) {
+        const int i8 = (y >> 1) * 2 + (x >> 1), blk = i8 * 4 + (y & 1) * 2 + (x & 1);
+        nz[y][x] = t8 ? (mb->cbp_luma >> i8) & 1 : (mb->nnz >> blk) & 1;
+    }
+    pixel *rec = luma_plane(e, e->cur, 0) + (size_t)a->mby * 16 * e->rs + a->mbx * 16;
+    for (int dir = 0; dir < 2; dir++)
+        for (int edge = 1; edge < 4; edge++) {
+            if (t8 && (edge & 1)) continue;
+            for (int i = 0; i < 4; i++) {
+                const int x = dir ? i : edge, y = dir ? edge : i, xn = dir ? x : x - 1, yn = dir ? y - 1 : y;
+                int bs;
+                if (intra) bs = 3;
+                else if (nz[y][x] || nz[yn][xn]) bs = 2;
+                else {
+                    const int k = (y >> 1) * 2 + (x >> 1), kn = (yn >> 1) * 2 + (xn >> 1);
+                    bs = mb->ref[k] != mb->ref[kn] || abs(mb->mv[k][0] - mb->mv[kn][0]) >= 4 || abs(mb->mv[k][1] - mb->mv[kn][1]) >= 4 ||
+                         (bframe && (mb->ref1[k] != mb->ref1[kn] || abs(mb->mv1[k][0] - mb->mv1[kn][0]) >= 4 || abs(mb->mv1[k][1] - mb->mv1[kn][1]) >= 4));
+                }
+                if (!bs) continue;
+                pixel *q0 = rec + (size_t)(4 * y) * e->rs + 4 * x;
+                x264o_deblock_luma_edge(q0, dir ? e->rs : 1, dir ? 1 : e->rs, 4, alpha, beta, x264o_tc0_table[ia][bs - 1], bs);
+            }
+        }
+}
+
 static int rd_finish(actx *a, x264gpu_mb *mb, int16_t *lv)
 {
+    if (a->e->cfg.rd & 64) macroblock_deblock(a, mb);
     const int ssd = rd_ssd_mb(a);
     nnzc_sync(a, mb);
     if (mb->type == X264GPU_MB_P_SKIP || mb->type == X264GPU_MB_B_SKIP) return ssd + ((a->lambda2 + 128) >> 8);
@@ -2704,7 +2749,7 @@ static void macroblock_body(x264o_encoder *e, int mbx, int mby, actx *a)
     /* x264_macroblock_thread_init / mb_analyse_init: B slices analyse one sub-pel level down (6 -> 5, 8 -> 7); i_mbrd = (subme >= 6) + (subme >= 8) */
     if (e->slice_type == X264GPU_SLICE_B && (a->subme == 6 || a->subme == 8)) a->subme--;
     /* cfg.rd: bit 0 = RD mode decision; bits 1..5 = the sites of the RD refinement (x264's subme 8 = all five) — brought up on the device site by site */
-    a->mbrd = e->cfg.rd ? 1 + (e->cfg.cabac && a->subme >= 8 && (e->cfg.rd >> 1)) : 0;
+    a->mbrd = e->cfg.rd ? 1 + (e->cfg.cabac && a->subme >= 8 && ((e->cfg.rd >> 1) & 31)) : 0;      /* (bit 6 of cfg.rd: deblock-aware RD, not a refinement site) */
     if (e->slice_type == X264GPU_SLICE_B && a->subme < 6) a->mbrd = 0;         /* (x264: i_mbrd from subme - 1 in B slices: no RD below --subme 7) */
     a->rd16x16 = COST_MAX; a->force_t8 = -1; a->cost8x8 = a->cost16x8 = a->cost8x16 = COST_MAX;
     for (int i = 0; i < 7; i++) a->satd_i16_dir[i] = a->satd_chroma_dir[i] = COST_MAX;

@@ -232,6 +232,12 @@ def test_pipeline_cabac_rd_bitexact(gpu, w, h, nfr, kw):
     (176, 144, 4, dict(partitions=7, dct8x8=1, refs=3, mixed_refs=1, chroma_me=1, psy=1, psy_rd_q8=256, chroma_qp_offset=-2, rd=63, trellis=63)),      # x264 --subme 8 on medium's toolset
     (208, 120, 4, dict(partitions=7, dct8x8=1, refs=2, mixed_refs=1, chroma_me=1, qp_i=30, qp_p=34, me_method=2, rd=63, trellis=127)),                  # ... on slow's: umh, trellis 2
     (96, 80, 3, dict(partitions=7, dct8x8=1, qp_i=10, qp_p=12, rd=63)),
+    # deblock-aware RD (x264 --subme 9, h->mb.b_deblock_rdo; cfg.rd bit 6): every whole-macroblock candidate is measured after x264_macroblock_deblock
+    (176, 144, 4, dict(partitions=7, dct8x8=0, refs=2, rd=1 | 64, qp_i=28, qp_p=30)),                                                            # 4x4 transform: all three internal edges
+    (176, 144, 4, dict(partitions=7, dct8x8=1, refs=3, mixed_refs=1, chroma_me=1, psy=1, psy_rd_q8=256, chroma_qp_offset=-2, rd=1 | 64, trellis=63)),
+    (208, 120, 4, dict(partitions=7, dct8x8=1, refs=2, mixed_refs=1, chroma_me=1, qp_i=30, qp_p=34, me_method=2, rd=63 | 64, trellis=127)),          # with the refinement: its whole-macroblock candidates too
+    (96, 80, 3, dict(partitions=7, dct8x8=1, qp_i=12, qp_p=14, rd=1 | 64)),                                                                        # quantisers at the filter's threshold
+    (176, 144, 3, dict(partitions=7, dct8x8=1, rd=63 | 64, psy=1, psy_rd_q8=256, deblock_alpha=-1, deblock_beta=2, qp_i=24, qp_p=27)),
 ])
 def test_pipeline_rd_refinement_bitexact(gpu, w, h, nfr, kw):
     """RD refinement on the device (REF instantiations of the macroblock loop, k_mb_refine.inc) against oracle/analyse.c's restatement of

@@ -50,6 +50,7 @@ struct EncK {
     int me_range, subme, dct_decimate, partitions, chroma_qp_offset;
     int slice_type;
     int alpha_off, beta_off;  // deblock offsets (already *2)
+    int deblock_rdo;          // x264 b_deblock_rdo (--subme 9 and up, cfg.rd bit 6, loop filter on): whole-macroblock RD candidates are measured after x264_macroblock_deblock
     Q4 q_luma_intra, q_luma_inter, q_chroma_intra, q_chroma_inter;
     Q8 q8_intra, q8_inter;    // 8x8 luma transform (dct8x8)
     int dct8x8;

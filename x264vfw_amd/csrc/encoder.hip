@@ -112,9 +112,9 @@ int x264gpu_encoder_create(x264gpu_encoder **out, const x264gpu_config *cfg)
     ARG_TRY(cfg->width >= 16 && cfg->height >= 16 && !(cfg->width & 1) && !(cfg->height & 1) && cfg->streams >= 1);
     ARG_TRY(cfg->qp_i >= 0 && cfg->qp_i <= 51 && cfg->qp_p >= 0 && cfg->qp_p <= 51 && cfg->refs >= 1 && cfg->refs <= 5);
     ARG_TRY(cfg->trellis == 0 || (cfg->trellis > 0 && cfg->trellis < 128 && (cfg->trellis & 63) && cfg->rd && cfg->cabac));      // trellis sites (mask; x264 --trellis 1 = 63, --trellis 2 = 63 + 64): RD sessions with CABAC
-    ARG_TRY(!cfg->rd || (cfg->subme >= 6 && cfg->subme <= 8 && cfg->psy_rd_q8 >= 0 && cfg->psy_rd_q8 <= 2560));      // RD: x264's i_mbrd 1 (bit counts of the session's entropy coder)
+    ARG_TRY(!cfg->rd || (cfg->subme >= 6 && cfg->subme <= 9 && cfg->psy_rd_q8 >= 0 && cfg->psy_rd_q8 <= 2560));      // RD: x264's i_mbrd 1 (bit counts of the session's entropy coder)
     // rd > 1: RD refinement of the chosen type (x264 subme 8, i_mbrd 2): bit 0 on + a mask of refinement sites in bits 1..5 (x264 = all five: 63); CABAC, hex / umh
-    ARG_TRY(cfg->rd >= 0 && cfg->rd < 64 && (cfg->rd < 2 || ((cfg->rd & 1) && cfg->cabac && cfg->subme == 8 && (cfg->me_method == 1 || cfg->me_method == 2))));      // (rd 0 with subme >= 8: the sub-pel iteration table of those levels without RD, as before)
+    ARG_TRY(cfg->rd >= 0 && cfg->rd < 128 && (cfg->rd < 2 || (cfg->rd & 1)) && (!(cfg->rd & 62) || (cfg->cabac && cfg->subme >= 8 && (cfg->me_method == 1 || cfg->me_method == 2))));      // bit 6: deblock-aware RD (x264 subme 9)      // (rd 0 with subme >= 8: the sub-pel iteration table of those levels without RD, as before)
     ARG_TRY(cfg->slices >= 0 && (cfg->slices <= 1 || cfg->slices <= (cfg->height + 15) / 16 / (cfg->slices_plain ? 1 : 4)));      // x264 slice threads: at least four macroblock rows each; --slices N: one
     ARG_TRY(cfg->slices_plain == 0 || cfg->slices_plain == 1);
     ARG_TRY(cfg->width <= 4096 && cfg->height <= 2304 && cfg->me_range >= 4 && cfg->me_range <= (cfg->me_method == 2 ? 64 : 16));
@@ -140,6 +140,7 @@ int x264gpu_encoder_create(x264gpu_encoder **out, const x264gpu_config *cfg)
     k.rd = cfg->rd; k.psy = cfg->psy != 0; k.psy_rd_q8 = cfg->psy_rd_q8;
     k.partitions = cfg->partitions; k.chroma_qp_offset = cfg->chroma_qp_offset; k.dct8x8 = cfg->dct8x8; k.me_method = cfg->me_method; k.chroma_me = cfg->chroma_me != 0; k.mixed_refs = cfg->mixed_refs != 0;
     k.alpha_off = cfg->deblock_alpha * 2; k.beta_off = cfg->deblock_beta * 2;
+    k.deblock_rdo = cfg->deblock && (cfg->rd & 64) ? 1 : 0;
     const size_t S = (size_t)cfg->streams;
     hipError_t er = hipSuccess;
     auto alloc = [&](void **p, size_t n, int fill) {

@@ -10,6 +10,7 @@
 //
 // Restates oracle/analyse.c bit-exactly (records, levels, reconstruction).
 #pragma once
+#include "deblock_line.cuh"
 #include "enc_common.cuh"
 #include "k_analyse.cuh"
 #include "intra8.cuh"
@@ -115,6 +116,32 @@ __device__ __forceinline__ void lds_sync()
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_s_waitcnt(0xc07f);
 }
+
+// x264_macroblock_deblock ([x264-upstream] encoder/macroblock.c; h->mb.b_deblock_rdo, --subme 9 and up; oracle macroblock_deblock): the INTERNAL luma edges
+// of a whole-macroblock RD candidate's reconstruction, held as a 16x16 byte tile in LDS (row stride 16), are loop-filtered before its distortion is
+// measured.  Lane r < 16 owns row r for the vertical edges, then column r for the horizontal ones (a row / column is touched by its owner alone, so only
+// the two directions need a barrier between them).  nz16: bit y * 4 + x = the 4x4 block at (x, y) is coded; mvm: bit dir * 2 + half = the two 8x8 blocks
+// either side of edge 2 in that half differ in a reference index or by a vector component of 4 quarter samples or more.
+__device__ __forceinline__ void mb_deblock_rdo(uint8_t *tile, int lane, bool intra, bool t8, unsigned nz16, unsigned mvm, int qp, int aoff, int boff)
+{
+    const int ia = min(max(qp + aoff, 0), 51), ib = min(max(qp + boff, 0), 51);
+    const int alpha = d_alpha_table[ia], beta = d_beta_table[ib];
+    if (!alpha || !beta) return;
+#pragma unroll
+    for (int dir = 0; dir < 2; dir++) {
+        if (lane < 16) {
+            const int i = lane >> 2;
+            for (int e = 1; e < 4; e++) {
+                if (t8 && (e & 1)) continue;
+                const int x = dir ? i : e, y = dir ? e : i, xn = dir ? x : x - 1, yn = dir ? y - 1 : y;
+                const int bs = intra ? 3 : (((nz16 >> (y * 4 + x)) | (nz16 >> (yn * 4 + xn))) & 1) ? 2 : (e == 2 && ((mvm >> (dir * 2 + (i >> 1))) & 1)) ? 1 : 0;
+                if (bs) filter_luma_line(tile + (dir ? 4 * e * 16 + lane : lane * 16 + 4 * e), dir ? 16 : 1, alpha, beta, d_tc0_table[ia][bs - 1], bs);
+            }
+        }
+        lds_sync();
+    }
+}
+
 
 // ------------------------------------------------------------------------------------------------
 // motion vector prediction on the cache grid (oracle predict_mv / predict_mv_pskip)
@@ -959,7 +986,7 @@ template <int M>
 __device__ __forceinline__ void mb_analyse_intra(const EncK &k, MbLds<M> &L, const MbCtx &c, uint32_t cz, uint32_t t4, int parts, int i_satd_inter,
                                                  bool fast_intra, bool early_term, bool mbrd, const Q4 &q4, const Q8 &q8, IntraRes &R, const TrCtx *tra = nullptr)
 {
-    const bool RF2 = mbrd && k.rd > 1 && k.slice_type != X264GPU_SLICE_B;      // x264's i_mbrd >= 2 (RD refinement, subme >= 8; a B slice analyses one level down)
+    const bool RF2 = mbrd && ((k.rd >> 1) & 31) && k.slice_type != X264GPU_SLICE_B;      // x264's i_mbrd >= 2 (RD refinement, subme >= 8; a B slice analyses one level down)
     const bool every_mode = RF2 || (mbrd && !fast_intra);          // x264: i_mbrd >= 1 + b_fast_intra
     const int lane = c.lane, j = lane & 3, zx = z_x0(lane), zy = z_y(lane), lambda = c.lambda;
     const bool left = c.mbx > 0, top = c.sy > 0, topright = top && c.mbx + 1 < k.mbw;
@@ -2015,7 +2042,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(MB_WAVES_PER
                         commit = true; go = true;
                         if constexpr (REF) {
                             // x264_macroblock_analyse: "if( analysis.i_mbrd >= 2 )" — the chosen type's vectors / intra modes once more on RD cost
-                            const int sites = k.rd >> 1;          // 1 inter vectors, 2 Intra_16x16 mode, 4 chroma mode, 8 Intra_4x4 modes, 16 Intra_8x8 modes
+                            const int sites = (k.rd >> 1) & 31;          // 1 inter vectors, 2 Intra_16x16 mode, 4 chroma mode, 8 Intra_4x4 modes, 16 Intra_8x8 modes
                             const bool inter_w = e_type >= X264GPU_MB_P_L0;
                             if (sites && !rd_skip16 && (inter_w ? (sites & 1) != 0 : (sites & 30) != 0)) {
                                 commit = false; go = false; rd_ph = 9;
@@ -2043,8 +2070,15 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(MB_WAVES_PER
         rec_type = e_type;
         int16_t *lvw = RD ? (int16_t *)rd_lvs : lv;               // RD: levels stay on chip until the final pass has its bit counts' totals
         int ssd_y = 0, ssd_c = 0, en4 = 0, en8 = 0;          // per-lane shares of the distortion terms of the candidate
+        // deblock-aware RD (x264 b_deblock_rdo): a whole-macroblock candidate's luma goes through a 16x16 tile in LDS (the chroma sub-pel staging area,
+        // idle during the encode passes), is loop-filtered along its internal edges there, and the distortion terms are taken from the result
+        uint8_t *const dtile = (uint8_t *)L.csub;
+        bool dbr = false;
+        unsigned db_mvm = 0;           // bit dir * 2 + half: the 8x8 blocks either side of edge 2 differ in motion (boundary strength 1)
+        if constexpr (RD) dbr = k.deblock_rdo && rd_run && !commit;
         bool part_pass = false;
         if constexpr (REF) part_pass = rf_pk != 0 && !commit;
+        dbr = dbr && !part_pass;          // (x264_rd_cost_part does not filter: whole-macroblock costs only)
         if (part_pass) {
             if constexpr (REF) {
             if (rf_pk == 1) {
@@ -2321,6 +2355,20 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(MB_WAVES_PER
             }
             if (commit && lane == 0) recd.partition = (uint8_t)(eskip ? 0 : e_part);
             }
+            if (dbr) {
+                // boundary strength 1 across edge 2: the 8x8 blocks on either side differ in a reference index or by four quarter samples in a vector
+                // component (deblock_strength on the motion cache: raw indices, both lists in B slices)
+                int r0v, x0v, y0v, r1v = 0, x1v = 0, y1v = 0;
+                if constexpr (BS) { r0v = ecfg.r0; x0v = ecfg.x0; y0v = ecfg.y0; r1v = ecfg.r1; x1v = ecfg.x1; y1v = ecfg.y1; }
+                else { r0v = lref; x0v = eskip ? pskx : lmx; y0v = eskip ? psky : lmy; }
+                auto differ = [&](int ka, int kb) __attribute__((always_inline)) {
+                    const int la = ka * 16, lb = kb * 16;
+                    bool d = rl(r0v, la) != rl(r0v, lb) || abs(rl(x0v, la) - rl(x0v, lb)) >= 4 || abs(rl(y0v, la) - rl(y0v, lb)) >= 4;
+                    if (BS) d = d || rl(r1v, la) != rl(r1v, lb) || abs(rl(x1v, la) - rl(x1v, lb)) >= 4 || abs(rl(y1v, la) - rl(y1v, lb)) >= 4;
+                    return d;
+                };
+                db_mvm = (differ(1, 0) ? 1u : 0u) | (differ(3, 2) ? 2u : 0u) | (differ(2, 0) ? 4u : 0u) | (differ(3, 1) ? 8u : 0u);
+            }
             if (eskip) {
                 *(uint32_t *)(rec + (size_t)zy * k.rs + zx) = pred;
                 mb_store_chroma(ruv, k.rs, lane, cpred);
@@ -2405,6 +2453,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(MB_WAVES_PER
                         if constexpr (RD) {      // R8 layout: a quad of lanes is four rows of one 8x8 block, so both halves are 4x4 blocks for the SATD
                             ssd_y = ssd4_u8(elo, o.x) + ssd4_u8(ehi, o.y);
                             psy_energy_r8(o.x, o.y, lane, en4, en8);
+                            if (dbr) *(uint2 *)(dtile + ((i8 >> 1) * 8 + row) * 16 + (i8 & 1) * 8) = o;
                         }
                     }
                 } else {
@@ -2442,7 +2491,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(MB_WAVES_PER
                     {
                         const uint32_t rz = pack4_clip(v);
                         if (commit) *(uint32_t *)(rec + (size_t)zy * k.rs + zx) = rz;
-                        if constexpr (RD) { ssd_y = ssd4_u8(cz, rz); psy_energy_z(rz, lane, en4, en8); }
+                        if constexpr (RD) { ssd_y = ssd4_u8(cz, rz); psy_energy_z(rz, lane, en4, en8); if (dbr) *(uint32_t *)(dtile + zy * 16 + zx) = rz; }
                     }
                     const unsigned long long bal = __ballot(keep && j4 == 0);
 #pragma unroll
@@ -2479,7 +2528,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(MB_WAVES_PER
                 {
                     const uint32_t rz = *(const uint32_t *)(tile8 + zy * IT_STRIDE + zx);
                     if (commit) *(uint32_t *)(rec + (size_t)zy * k.rs + zx) = rz;
-                    if constexpr (RD) { ssd_y = ssd4_u8(cz, rz); psy_energy_z(rz, lane, en4, en8); }
+                    if constexpr (RD) { ssd_y = ssd4_u8(cz, rz); psy_energy_z(rz, lane, en4, en8); if (dbr) *(uint32_t *)(dtile + zy * 16 + zx) = rz; }
                 }
                 if (!tri8) *(uint2 *)(lvw + lane * 4) = *(const uint2 *)(L.lv8 + lane * 4);
                 if (lane < 16) lvw[X264GPU_LV_LUMA_DC + lane] = 0;
@@ -2492,7 +2541,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(MB_WAVES_PER
                 {
                     const uint32_t rz = *(const uint32_t *)(tile + zy * IT_STRIDE + zx);
                     if (commit) *(uint32_t *)(rec + (size_t)zy * k.rs + zx) = rz;
-                    if constexpr (RD) { ssd_y = ssd4_u8(cz, rz); psy_energy_z(rz, lane, en4, en8); }
+                    if constexpr (RD) { ssd_y = ssd4_u8(cz, rz); psy_energy_z(rz, lane, en4, en8); if (dbr) *(uint32_t *)(dtile + zy * 16 + zx) = rz; }
                 }
                 if (!tri4) *(uint2 *)(lvw + lane * 4) = *(const uint2 *)(L.lv4 + lane * 4);
                 if (lane < 16) lvw[X264GPU_LV_LUMA_DC + lane] = 0;
@@ -2567,7 +2616,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(MB_WAVES_PER
                 {
                     const uint32_t rz = pack4_clip(v);
                     if (commit) *(uint32_t *)(rec + (size_t)zy * k.rs + zx) = rz;
-                    if constexpr (RD) { ssd_y = ssd4_u8(cz, rz); psy_energy_z(rz, lane, en4, en8); }
+                    if constexpr (RD) { ssd_y = ssd4_u8(cz, rz); psy_energy_z(rz, lane, en4, en8); if (dbr) *(uint32_t *)(dtile + zy * 16 + zx) = rz; }
                 }
                 nnz = acn | (nzdc ? 1u << 24 : 0);
                 cbp_luma = acn ? 15 : 0;
@@ -2586,6 +2635,26 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(MB_WAVES_PER
             }
             if (commit) intra_count++;
             pf.mark(PH_ENC_INTRA);
+        }
+        if constexpr (RD) {
+            if (dbr) {
+                // x264_rd_cost_mb with b_deblock_rdo: x264_macroblock_deblock between the encode and the distortion
+                const bool intra_c = e_type < X264GPU_MB_P_L0;
+                const bool skipc = rec_type == X264GPU_MB_P_SKIP || rec_type == X264GPU_MB_B_SKIP || e_type == X264GPU_MB_P_SKIP || e_type == X264GPU_MB_B_SKIP;
+                if (!skipc && !((e_part == D_16x16 && !cbp_luma && !intra_c) || c.qp <= 15 - min(k.alpha_off, k.beta_off) - max(k.chroma_qp_offset, 0))) {
+                    unsigned nz16 = 0;          // bit y * 4 + x: the 4x4 block at (x, y) is coded (an 8x8-transform block flags all four)
+#pragma unroll
+                    for (int b = 0; b < 16; b++) {
+                        const int x = (b & 1) + ((b >> 2) & 1) * 2, y = ((b >> 1) & 1) + (b >> 3) * 2;
+                        const unsigned f = rd_t8cur ? (unsigned)(cbp_luma >> (b >> 2)) & 1u : (nnz >> b) & 1u;
+                        nz16 |= f << (y * 4 + x);
+                    }
+                    lds_sync();
+                    mb_deblock_rdo(dtile, lane, intra_c, rd_t8cur != 0, nz16, db_mvm, c.qp, k.alpha_off, k.beta_off);
+                    const uint32_t rzf = *(const uint32_t *)(dtile + zy * 16 + zx);
+                    ssd_y = ssd4_u8(cz, rzf); psy_energy_z(rzf, lane, en4, en8);
+                }
+            }
         }
         if constexpr (RD >= 2) {
             // ---- CABAC: the candidate priced on a copy of the slice's context variables; the finished macroblock moves them on ----
