@@ -56,6 +56,8 @@ def run(w, h, types, seed, bframes=3, pyramid=1, weightp=0, pics_out=None, weigh
     (96, 80, "IBPBBPBBBPP", 42, dict(rd=0, trellis=0, subme=4, psy_rd_q8=0, cabac=0, refs=2)),
     (176, 144, "IBBPBP", 43, dict(rd=1, trellis=0, subme=6, cabac=0, partitions=0x707)),          # --subme 6: RD (CAVLC counts) in I / P slices only
     (176, 288, "IBBBPBBP", 44, dict(rd=0, trellis=0, subme=5, psy_rd_q8=0, cabac=0, slices=3, dct8x8=0)),
+    (176, 144, "IBBBPBBP", 18, dict(subme=9)),                                    # chroma-ME in B slices
+    (176, 144, "IBBPBP", 19, dict(subme=9, rd=1 | 64)),                           # + deblock-aware RD
     (176, 144, "IBBBPBBP", 31, dict(subme=6)),                                    # preset fast: subme 6 + trellis 1
     (176, 144, "IBBPBP", 32, dict(subme=6, trellis=127)),
 ])

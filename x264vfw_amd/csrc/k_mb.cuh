@@ -1517,7 +1517,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(MB_WAVES_PER
         c.lambda = k.lambda_tab[c.qp];
         c.subme = min(max(k.subme, 0), 11);
         if (BS && (c.subme == 6 || c.subme == 8)) c.subme--;          // x264_macroblock_thread_init: B slices analyse one sub-pel level down (8 -> 7: no RD refinement there below subme 9)
-        c.satd = c.subme > 1; c.chroma_me = !BS && pslice && k.chroma_me && c.subme >= 5;      // (x264_macroblock_thread_init: B slices carry chroma in the sub-pel costs from subme 9 up only: never here)
+        c.satd = c.subme > 1; c.chroma_me = pslice && k.chroma_me && c.subme >= (BS ? 9 : 5);      // (x264_macroblock_thread_init: B slices carry chroma in the sub-pel costs from subme 9 up)
         c.cost_base = k.cost_all + (size_t)c.qp * 2 * MVCOST_HALF;
         if (pslice && c.qp != cost_qp) {          // the mv-cost table of this quantiser (symmetric: non-negative differences only) into LDS
             cost_qp = c.qp;
