@@ -2101,6 +2101,7 @@ static void analyse_b_rd(actx *a, int i_satd_inter, x264gpu_mb *mb, int16_t *lv)
 }
 
 static void intra_rd(actx *a, int thresh, x264gpu_mb *mb, int16_t *lv);
+static void intra_rd_refine(actx *a, int type, x264gpu_mb *mb, int16_t *lv);
 
 /* the B branch of x264_macroblock_analyse + x264_macroblock_encode; the caller has set up qp / lambda / limits */
 static void macroblock_b(actx *a, x264gpu_mb *mb, int16_t *lv)
@@ -2284,6 +2285,8 @@ static void macroblock_b(actx *a, x264gpu_mb *mb, int16_t *lv)
     if (a->satd_i16 < i_cost) { i_cost = a->satd_i16; intra_type = X264GPU_MB_I16x16; }
     if (a->satd_i8 < i_cost) { i_cost = a->satd_i8; intra_type = X264GPU_MB_I8x8; }
     if (a->satd_i4 < i_cost) { i_cost = a->satd_i4; intra_type = X264GPU_MB_I4x4; }
+    /* --subme 9 (i_mbrd 2 in B slices): the chosen intra type's modes once more on RD cost */
+    if (intra_type >= 0 && a->mbrd >= 2 && ((e->cfg.rd >> 1) & 30)) intra_rd_refine(a, intra_type, mb, lv);
     rd_reset(a, mb, lv);
     if (intra_type >= 0) {
         mb->cost = i_cost;

@@ -87,6 +87,9 @@ def run(gpu, w, h, types, seed, streams=1, bframes=3, pyramid=1, weightp=0, weig
     (128, 96, "IBPBBP", 12, dict(me_method=3, me_range=8)),                         # esa
     (176, 144, "IBBBPBP", 13, dict(trellis=63 + 64)),                               # --trellis 2: the search in the analysis' block encodes and every RD candidate of B macroblocks too
     (128, 96, "IBBPBP", 14, dict(trellis=63 + 64, me_method=2)),
+    (176, 144, "IBBBPBBP", 20, dict(subme=9, rd=61)),                               # --subme 9, intra sites: intra_rd_refine of the intra macroblocks of B slices
+    (176, 144, "IBBPBP", 21, dict(subme=9, rd=61 | 64, trellis=127, me_method=2)),
+    (96, 80, "IBPBBP", 22, dict(subme=9, rd=61, qp_i=30)),
     (176, 144, "IBBBPBBP", 18, dict(subme=9)),                                      # --subme 9 without its refinement sites: chroma-ME in B slices, 4 + 10 sub-pel iterations
     (208, 112, "IBBPBP", 19, dict(subme=9, me_method=2, rd=1 | 64, refs=4, dpb=4)),
     (176, 144, "IBBBPBBP", 16, dict(rd=1 | 64)),                                    # deblock-aware RD (x264 b_deblock_rdo) in B macroblocks: both lists' motion in the boundary strengths

@@ -986,7 +986,7 @@ template <int M>
 __device__ __forceinline__ void mb_analyse_intra(const EncK &k, MbLds<M> &L, const MbCtx &c, uint32_t cz, uint32_t t4, int parts, int i_satd_inter,
                                                  bool fast_intra, bool early_term, bool mbrd, const Q4 &q4, const Q8 &q8, IntraRes &R, const TrCtx *tra = nullptr)
 {
-    const bool RF2 = mbrd && ((k.rd >> 1) & 31) && k.slice_type != X264GPU_SLICE_B;      // x264's i_mbrd >= 2 (RD refinement, subme >= 8; a B slice analyses one level down)
+    const bool RF2 = mbrd && ((k.rd >> 1) & 31) && (k.slice_type != X264GPU_SLICE_B || k.subme >= 9);      // x264's i_mbrd >= 2 (RD refinement, subme >= 8; a B slice analyses one level down)
     const bool every_mode = RF2 || (mbrd && !fast_intra);          // x264: i_mbrd >= 1 + b_fast_intra
     const int lane = c.lane, j = lane & 3, zx = z_x0(lane), zy = z_y(lane), lambda = c.lambda;
     const bool left = c.mbx > 0, top = c.sy > 0, topright = top && c.mbx + 1 < k.mbw;
@@ -1970,6 +1970,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(MB_WAVES_PER
         wt.tref = -1; wt.tx = wt.ty = 0;
         // RD refinement (REF instantiations): the coroutine's state (k_mb_refine.inc) — what is being refined, where its walk stands, the candidate
         // out for costing, x264's left-over caches (non_zero_count of this macroblock as the last encode left it, |mvd| of the parts done)
+        bool rf_on = false;              // the refinement coroutine owns the passes (P / I slices: rd_ph 9; B slices: after k_mb_b.inc's decision)
         int rf_kind = 0, rf_pk = 0, rf_st = 0, rf_part = 0, rf_j = 0, rf_i = 0, rf_wait = 0;
         int rf_bmx = 0, rf_bmy = 0, rf_omx = 0, rf_omy = 0, rf_pmx = 0, rf_pmy = 0, rf_dir = -2, rf_odir = 0, rf_bsatd = 0, rf_pmvchk = 0;
         int rf_cx = 0, rf_cy = 0, rf_cdir = -99, rf_mvpx = 0, rf_mvpy = 0, rf_mv0x = 0, rf_mv0y = 0, rf_f4 = 0, rf_f8 = 0;
@@ -1981,7 +1982,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(MB_WAVES_PER
         // i_cbp_i8x8_luma; an Intra_4x4 block's nine candidate encodes side by side (lane = mode * 4 + row: levels, reconstruction, distortion, non-zero)
         int rf_cm = 0, rf_bm = 0, rf_bdct = 0, rf_cbpc = 0, rf_cbp_i8 = 0, rf_old = 0;
         unsigned long long rf_list = 0;
-        int rf4_v0 = 0, rf4_v1 = 0, rf4_v2 = 0, rf4_v3 = 0, rf4_d = 0, rf4_nz = 0;
+        int rf4_v0 = 0, rf4_v1 = 0, rf4_v2 = 0, rf4_v3 = 0;
         uint32_t rf4_rz = 0, rf8_blo = 0, rf8_bhi = 0;
         int rf8_v[8] = { 0, 0, 0, 0, 0, 0, 0, 0 }, rf8c_v[8] = { 0, 0, 0, 0, 0, 0, 0, 0 }, rf8_cbp = 0;
         uint32_t rf8c_lo = 0, rf8c_hi = 0;
@@ -1995,7 +1996,17 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(MB_WAVES_PER
         for (;;) {
         if constexpr (BS) {
             if (rd_run && !commit) {
+                if (!rf_on) {
 #include "k_mb_b.inc"
+                }
+                if constexpr (REF) {
+                    // --subme 9: the decision's winner once more on RD cost (k_mb_b.inc switched rf_on on at its last phase)
+                    if (rf_on && !commit) {
+                        bool go = false;
+#include "k_mb_refine.inc"
+                        (void)go;
+                    }
+                }
             }
         } else if constexpr (RD) {
             if (rd_run && !commit) {
@@ -2045,7 +2056,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(MB_WAVES_PER
                             const int sites = (k.rd >> 1) & 31;          // 1 inter vectors, 2 Intra_16x16 mode, 4 chroma mode, 8 Intra_4x4 modes, 16 Intra_8x8 modes
                             const bool inter_w = e_type >= X264GPU_MB_P_L0;
                             if (sites && !rd_skip16 && (inter_w ? (sites & 1) != 0 : (sites & 30) != 0)) {
-                                commit = false; go = false; rd_ph = 9;
+                                commit = false; go = false; rd_ph = 9; rf_on = true;
                                 rf_kind = inter_w ? 0 : 1; rf_st = 0; rf_part = 0; rf_wait = 0; rf_done = 0; rf_amvd = 0; rf_pk = 0;
                                 if (lane == 5 || lane == 6 || lane == 9 || lane == 10) S.cref = -2;      // the motion cache of this macroblock's blocks starts empty
                             }
@@ -2241,10 +2252,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(MB_WAVES_PER
                 }
             } else if (rf_pk == 2) {
                 // rd_cost_i4x4: the block's candidate encodes were done side by side by the coroutine; this mode's levels sit in the level buffer
-                const int idx = rf_i, bnz = rl(rf4_nz, rf_cm * 4);
+                const int idx = rf_i, dn = ((const int *)L.cand)[rf_cm], bnz = dn & 1;
                 nnz = (unsigned)bnz << idx;
                 rf_nnzc = (rf_nnzc & ~(1u << idx)) | ((unsigned)bnz << idx);
-                ssd_y = lane == 0 ? rl(rf4_d, rf_cm * 4) : 0;
+                ssd_y = lane == 0 ? dn >> 1 : 0;
             } else if (rf_pk == 3) {
                 // rd_cost_i8x8: predict block rf_i with mode rf_cm from the refined neighbours in the tile, transform, quantise, reconstruct
                 const int idx = rf_i, x8 = idx & 1, y8 = idx >> 1, g = lane >> 3, r8 = lane & 7;
@@ -2735,7 +2746,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(MB_WAVES_PER
                         const bool skc = rec_type == X264GPU_MB_P_SKIP || rec_type == X264GPU_MB_B_SKIP;
                         rf_nnzc = skc ? 0u : (rd_t8cur ? ex : nnz & 0xffffu & ex) | (cbp_chroma == 2 ? nnz & 0x00ff0000u : 0u);
                     }
-                    if (rd_ph == 9) { rf_cost = part_pass ? cost64 : (unsigned long long)(unsigned)cost; continue; }
+                    if (rf_on) { rf_cost = part_pass ? cost64 : (unsigned long long)(unsigned)cost; continue; }
                 }
                 if constexpr (BS) {
                     // x264_mb_analyse_b_rd / _transform_rd / x264_intra_rd: where the candidate's cost goes
@@ -2749,7 +2760,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(MB_WAVES_PER
                     else if (rd_ph == 14) { if (rd_best >= cost) { if (rd_best > 0) rd_satd_inter = (int)((long long)rd_satd_inter * cost / rd_best); rd_best = cost; rd_t8 = 1; } }
                     else if (rd_ph == 15) rd_i16 = cost;
                     else if (rd_ph == 16) rd_i4 = cost;
-                    else if (rd_ph == 17) rd_i8 = cost;
+                    else if (rd_ph == 17) { rd_i8 = cost; rf_cbp_i8 = cbp_luma; }
                 } else
                 if (rd_ph == 0) {
                     rd16 = cost;
