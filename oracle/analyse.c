@@ -2102,6 +2102,7 @@ static void analyse_b_rd(actx *a, int i_satd_inter, x264gpu_mb *mb, int16_t *lv)
 
 static void intra_rd(actx *a, int thresh, x264gpu_mb *mb, int16_t *lv);
 static void intra_rd_refine(actx *a, int type, x264gpu_mb *mb, int16_t *lv);
+static void refine_inter_b_rd(actx *a, int i_type, int i_partition, int use16, int t8, int i_cost, x264gpu_mb *mb, int16_t *lv);
 
 /* the B branch of x264_macroblock_analyse + x264_macroblock_encode; the caller has set up qp / lambda / limits */
 static void macroblock_b(actx *a, x264gpu_mb *mb, int16_t *lv)
@@ -2303,6 +2304,11 @@ static void macroblock_b(actx *a, x264gpu_mb *mb, int16_t *lv)
         else if (i_partition == D_8x16) { for (int i = 0; i < 2; i++) if (a->part8x16[i] == 2) me_refine_bidir_satd(a, &a->me8x16l[0][i], &a->me8x16l[1][i], e->bipred_weight[a->me8x16l[0][i].ref][a->me8x16l[1][i].ref]); }
         else for (int i = 0; i < 4; i++) if (a->sub8[i] == 2) me_refine_bidir_satd(a, &a->me8l[0][i], &a->me8l[1][i], e->bipred_weight[a->me8l[0][i].ref][a->me8l[1][i].ref]);
     }
+    /* --subme 9 (i_mbrd 2 in B slices): the chosen inter type's vectors once more on RD cost */
+    if (a->mbrd >= 2 && ((e->cfg.rd >> 1) & 1) && (i_type == X264GPU_MB_B_INTER || i_type == X264GPU_MB_B_8x8)) {
+        refine_inter_b_rd(a, i_type, i_partition, use16, t8, i_cost, mb, lv);
+        rd_reset(a, mb, lv);
+    }
     {
         const int bak = a->sub8[0];
         if (i_partition == D_16x16 && i_type == X264GPU_MB_B_INTER) a->sub8[0] = use16;
@@ -2448,7 +2454,7 @@ static int64_t rd_cost_part(actx *a, int i8, int psize, int done, x264gpu_mb *mb
     const int x = 8 * (i8 & 1), y = 8 * (i8 >> 1), w = psize == 1 ? 16 : 8, h = psize == 2 ? 16 : 8;
     int64_t ssd = ssd_luma_part(a, x, y, w, h);
     ssd += ((int64_t)ssd_chroma_part(a, x >> 1, y >> 1, w >> 1, h >> 1) * a->chroma_lambda2_offset + 128) >> 8;
-    return (ssd << 8) + part_bits(a, 0, i8, psize, done, a->lambda2);
+    return (ssd << 8) + part_bits(a, a->e->slice_type == X264GPU_SLICE_B ? 4 : 0, i8, psize, done, a->lambda2);
 }
 
 /* x264_me_refine_qpel_rd of one part of the chosen P type: a sub-pel hexagon + square walk on RD cost, candidates gated by SATD.  mb holds
@@ -2465,7 +2471,10 @@ static void me_refine_qpel_rd(actx *a, me_t *m, int i8, int t8, int *done, x264g
     const int mv0x = m->mv[0], mv0y = m->mv[1];          /* (for 16x16 the candidates pass through a->me16, which IS m) */
     int bmx = mv0x, bmy = mv0y, omx, omy, pmx, pmy, satd, bsatd = COST_MAX, dir = -2;
     int last_mvd[2] = { 0, 0 }, priced = 0;
-    if (psize != 0 && i8 != 0) predict_mv(a, bx8, by8, w8, m->ref, m->mvp);      /* the parts refined before moved */
+    const int bsl = e->slice_type == X264GPU_SLICE_B, l = bsl ? m->list : 0;      /* B slices: the part's list (x264_me_refine_qpel_rd's i_list) */
+    int16_t (*rmv)[2] = l ? mb->mv1 : mb->mv;
+    uint8_t *amv = l ? e->amvd1 : e->amvd;
+    if (psize != 0 && i8 != 0) predict_mv_l(a, l, bx8, by8, w8, m->ref, m->mvp);      /* the parts refined before moved */
     pmx = m->mvp[0]; pmy = m->mvp[1];
     sctx S;
     sctx_init(&S, a, m);
@@ -2481,15 +2490,18 @@ static void me_refine_qpel_rd(actx *a, me_t *m, int i8, int t8, int *done, x264g
 #define COST_MV_RD(mx, my, sat, do_dir, mdir) do { \
         if ((sat) <= SATD_THRESH(bsatd)) { \
             int64_t cost_; \
-            for (int k_ = 0; k_ < 4; k_++) if ((k_ & 1) >= bx8 && (k_ & 1) < bx8 + w8 && (k_ >> 1) >= by8 && (k_ >> 1) < by8 + h8) { mb->mv[k_][0] = (int16_t)(mx); mb->mv[k_][1] = (int16_t)(my); } \
-            if (psize == 0) { \
+            for (int k_ = 0; k_ < 4; k_++) if ((k_ & 1) >= bx8 && (k_ & 1) < bx8 + w8 && (k_ >> 1) >= by8 && (k_ >> 1) < by8 + h8) { rmv[k_][0] = (int16_t)(mx); rmv[k_][1] = (int16_t)(my); } \
+            if (psize == 0 && bsl) { \
+                m->mv[0] = (mx); m->mv[1] = (my);          /* (m is a->me16l[l]: the candidate's record is filled from it) */ \
+                cost_ = rd_cost_b(a, X264GPU_MB_B_INTER, D_16x16, l, t8, mb, lv); \
+            } else if (psize == 0) { \
                 a->me16.mv[0] = (mx); a->me16.mv[1] = (my); \
                 cost_ = rd_cost_inter(a, D_16x16, t8, mb, lv); \
             } else { \
                 pixel pu_[64], pv_[64]; \
                 x264o_mc_chroma(pu_, pv_, 8, chroma_plane(e, S.refslot), e->rs, a->mbx * 8 + m->ox / 2, a->mby * 8 + m->oy / 2, mx, my, m->w / 2, m->h / 2); \
-                if (e->wc0[m->ref].on[0]) x264o_mc_weight(pu_, 8, pu_, 8, m->w / 2, m->h / 2, e->wc0[m->ref].scale[0], e->wc0[m->ref].denom, e->wc0[m->ref].offset[0]); \
-                if (e->wc0[m->ref].on[1]) x264o_mc_weight(pv_, 8, pv_, 8, m->w / 2, m->h / 2, e->wc0[m->ref].scale[1], e->wc0[m->ref].denom, e->wc0[m->ref].offset[1]); \
+                if (!bsl && e->wc0[m->ref].on[0]) x264o_mc_weight(pu_, 8, pu_, 8, m->w / 2, m->h / 2, e->wc0[m->ref].scale[0], e->wc0[m->ref].denom, e->wc0[m->ref].offset[0]); \
+                if (!bsl && e->wc0[m->ref].on[1]) x264o_mc_weight(pv_, 8, pv_, 8, m->w / 2, m->h / 2, e->wc0[m->ref].scale[1], e->wc0[m->ref].denom, e->wc0[m->ref].offset[1]); \
                 for (int y_ = 0; y_ < m->h / 2; y_++) for (int x_ = 0; x_ < m->w / 2; x_++) { ruv[y_ * e->rs + 2 * x_] = pu_[y_ * 8 + x_]; ruv[y_ * e->rs + 2 * x_ + 1] = pv_[y_ * 8 + x_]; } \
                 cost_ = rd_cost_part(a, i8, psize, *done, mb, lv); \
             } \
@@ -2546,11 +2558,138 @@ finish:
     /* x264_macroblock_cache_mv / _mvd of the part: what the parts after it predict from and count their mvd contexts on */
     for (int k = 0; k < 4; k++)
         if ((k & 1) >= bx8 && (k & 1) < bx8 + w8 && (k >> 1) >= by8 && (k >> 1) < by8 + h8) {
-            mb->mv[k][0] = (int16_t)m->mv[0]; mb->mv[k][1] = (int16_t)m->mv[1];
-            if (priced) { e->amvd[((size_t)a->mi * 4 + k) * 2] = (uint8_t)(last_mvd[0] < 66 ? last_mvd[0] : 66); e->amvd[((size_t)a->mi * 4 + k) * 2 + 1] = (uint8_t)(last_mvd[1] < 66 ? last_mvd[1] : 66); }
+            rmv[k][0] = (int16_t)m->mv[0]; rmv[k][1] = (int16_t)m->mv[1];
+            if (priced) { amv[((size_t)a->mi * 4 + k) * 2] = (uint8_t)(last_mvd[0] < 66 ? last_mvd[0] : 66); amv[((size_t)a->mi * 4 + k) * 2 + 1] = (uint8_t)(last_mvd[1] < 66 ? last_mvd[1] : 66); }
             *done |= 1 << k;
         }
-    cache_block(a, bx8, by8, w8, h8, m->ref, m->mv);
+    cache_block_l(a, l, bx8, by8, w8, h8, m->ref, m->mv);
+}
+
+/* x264_me_refine_bidir_rd ([x264-upstream] encoder/me.c me_refine_bidir with rd = 1): both vectors of a bi-predicted part walk together, up to two
+ * components at a time, up to eight rounds; a pair whose SATD cost is within 17/16 of the best SATD so far is priced on RD cost (the whole macroblock
+ * for 16x16, else the part), and the best RD cost moves the centre.  The part's final vectors and |mvd| (capped at 33 here) go into the caches. */
+static void me_refine_bidir_rd(actx *a, me_t *m0, me_t *m1, int i_weight, int i8, int t8, int *done, x264gpu_mb *mb, int16_t *lv)
+{
+    static const int8_t dia4d[33][4] = {
+        { 0, 0, 0, 0 },
+        { 0, 0, 0, 1 }, { 0, 0, 0, -1 }, { 0, 0, 1, 0 }, { 0, 0, -1, 0 }, { 0, 1, 0, 0 }, { 0, -1, 0, 0 }, { 1, 0, 0, 0 }, { -1, 0, 0, 0 },
+        { 0, 0, 1, 1 }, { 0, 0, -1, -1 }, { 0, 1, 1, 0 }, { 0, -1, -1, 0 }, { 1, 1, 0, 0 }, { -1, -1, 0, 0 }, { 1, 0, 0, 1 }, { -1, 0, 0, -1 },
+        { 0, 1, 0, 1 }, { 0, -1, 0, -1 }, { 1, 0, 1, 0 }, { -1, 0, -1, 0 }, { 0, 0, -1, 1 }, { 0, 0, 1, -1 }, { 0, -1, 1, 0 }, { 0, 1, -1, 0 },
+        { -1, 1, 0, 0 }, { 1, -1, 0, 0 }, { 1, 0, 0, -1 }, { -1, 0, 0, 1 }, { 0, -1, 0, 1 }, { 0, 1, 0, -1 }, { -1, 0, 1, 0 }, { 1, 0, -1, 0 } };
+    x264o_encoder *e = a->e;
+    const int bw = m0->w, bh = m0->h, psize = bw == 16 ? (bh == 16 ? 0 : 1) : (bh == 16 ? 2 : 3);
+    const int bx8 = i8 & 1, by8 = i8 >> 1, w8 = bw >> 3, h8 = bh >> 3;
+    int bm0x = m0->mv[0], bm0y = m0->mv[1], bm1x = m1->mv[0], bm1y = m1->mv[1], bcost = COST_MAX, mc_list0 = 1, mc_list1 = 1;
+    int64_t bcostrd = INT64_MAX;
+    if (bm0y < a->smin[1] + 8 || bm1y < a->smin[1] + 8 || bm0y > a->smax[1] - 8 || bm1y > a->smax[1] - 8 ||
+        bm0x < a->smin[0] + 8 || bm1x < a->smin[0] + 8 || bm0x > a->smax[0] - 8 || bm1x > a->smax[0] - 8) {
+        /* too close to the limits: the part keeps its vectors (and whatever |mvd| the caches held: zero here) */
+        for (int k = 0; k < 4; k++) if ((k & 1) >= bx8 && (k & 1) < bx8 + w8 && (k >> 1) >= by8 && (k >> 1) < by8 + h8) *done |= 1 << k;
+        cache_block_l(a, 0, bx8, by8, w8, h8, m0->ref, m0->mv); cache_block_l(a, 1, bx8, by8, w8, h8, m1->ref, m1->mv);
+        return;
+    }
+    if (psize != 0 && i8 != 0) { predict_mv_l(a, 0, bx8, by8, w8, m0->ref, m0->mvp); predict_mv_l(a, 1, bx8, by8, w8, m1->ref, m1->mvp); }
+    const uint16_t *cm0x = a->cost_mv - m0->mvp[0], *cm0y = a->cost_mv - m0->mvp[1], *cm1x = a->cost_mv - m1->mvp[0], *cm1y = a->cost_mv - m1->mvp[1];
+    const pixel *fenc = e->fenc_y + (size_t)(a->mby * 16 + m0->oy) * e->fs + a->mbx * 16 + m0->ox;
+    pixel *rec = luma_plane(e, e->cur, 0) + (size_t)(a->mby * 16 + m0->oy) * e->rs + a->mbx * 16 + m0->ox;
+    pixel *ruv = chroma_plane(e, e->cur) + (size_t)(a->mby * 8 + m0->oy / 2) * e->rs + a->mbx * 16 + m0->ox;
+    static pixel buf[2][9][256], bufu[2][9][64], bufv[2][9][64];
+    uint8_t visited[8][8][8];
+    memset(visited, 0, sizeof(visited));
+    sctx S0, S1;
+    sctx_init(&S0, a, m0); sctx_init(&S1, a, m1);
+    for (int pass = 0; pass < 8; pass++) {
+        int bestj = 0;
+        for (int li = 0; li < 2; li++) {
+            if (!(li ? mc_list1 : mc_list0)) continue;
+            const sctx *S = li ? &S1 : &S0;
+            const me_t *m = li ? m1 : m0;
+            for (int j = 0; j < 9; j++) {
+                const int q = 4 + 3 * square1[j][0] + square1[j][1], mx = (li ? bm1x : bm0x) + square1[j][0], my = (li ? bm1y : bm0y) + square1[j][1];
+                get_ref(S, buf[li][q], mx, my);
+                x264o_mc_chroma(bufu[li][q], bufv[li][q], 8, chroma_plane(e, S->refslot), e->rs, a->mbx * 8 + m->ox / 2, a->mby * 8 + m->oy / 2, mx, my, bw / 2, bh / 2);
+            }
+        }
+        for (int j = !!pass; j < 33; j++) {
+            const int m0x = dia4d[j][0] + bm0x, m0y = dia4d[j][1] + bm0y, m1x = dia4d[j][2] + bm1x, m1y = dia4d[j][3] + bm1y;
+            if (pass && (visited[m0x & 7][m0y & 7][m1x & 7] & (1 << (m1y & 7)))) continue;
+            const int i0 = 4 + 3 * dia4d[j][0] + dia4d[j][1], i1 = 4 + 3 * dia4d[j][2] + dia4d[j][3];
+            pixel pix[256];
+            visited[m0x & 7][m0y & 7][m1x & 7] |= (uint8_t)(1 << (m1y & 7));
+            x264o_pixel_avg_weight(pix, 16, buf[0][i0], 16, buf[1][i1], 16, bw, bh, i_weight);
+            const int cost = mbcmp(a, fenc, e->fs, pix, 16, bw, bh) + cm0x[m0x] + cm0y[m0y] + cm1x[m1x] + cm1y[m1y];
+            if (cost < bcost + (bcost >> 4)) {
+                int64_t costrd;
+                if (cost < bcost) bcost = cost;
+                for (int k = 0; k < 4; k++) if ((k & 1) >= bx8 && (k & 1) < bx8 + w8 && (k >> 1) >= by8 && (k >> 1) < by8 + h8) {
+                    mb->mv[k][0] = (int16_t)m0x; mb->mv[k][1] = (int16_t)m0y; mb->mv1[k][0] = (int16_t)m1x; mb->mv1[k][1] = (int16_t)m1y;
+                }
+                if (psize == 0) {
+                    const int s0x = m0->mv[0], s0y = m0->mv[1], s1x = m1->mv[0], s1y = m1->mv[1];
+                    m0->mv[0] = m0x; m0->mv[1] = m0y; m1->mv[0] = m1x; m1->mv[1] = m1y;          /* (m0 / m1 are a->bi16[]: the candidate's record is filled from them) */
+                    costrd = rd_cost_b(a, X264GPU_MB_B_INTER, D_16x16, 2, t8, mb, lv);
+                    m0->mv[0] = s0x; m0->mv[1] = s0y; m1->mv[0] = s1x; m1->mv[1] = s1y;
+                } else {
+                    pixel pu[64], pv[64];
+                    for (int y = 0; y < bh; y++) memcpy(rec + y * e->rs, pix + y * 16, bw);
+                    x264o_pixel_avg_weight(pu, 8, bufu[0][i0], 8, bufu[1][i1], 8, bw / 2, bh / 2, i_weight);
+                    x264o_pixel_avg_weight(pv, 8, bufv[0][i0], 8, bufv[1][i1], 8, bw / 2, bh / 2, i_weight);
+                    for (int y = 0; y < bh / 2; y++) for (int x = 0; x < bw / 2; x++) { ruv[y * e->rs + 2 * x] = pu[y * 8 + x]; ruv[y * e->rs + 2 * x + 1] = pv[y * 8 + x]; }
+                    costrd = rd_cost_part(a, i8, psize, *done, mb, lv);
+                }
+                if (costrd < bcostrd) { bcostrd = costrd; bestj = j; }
+            }
+        }
+        if (!bestj) break;
+        bm0x += dia4d[bestj][0]; bm0y += dia4d[bestj][1]; bm1x += dia4d[bestj][2]; bm1y += dia4d[bestj][3];
+        mc_list0 = dia4d[bestj][0] | dia4d[bestj][1]; mc_list1 = dia4d[bestj][2] | dia4d[bestj][3];
+    }
+    m0->mv[0] = bm0x; m0->mv[1] = bm0y; m1->mv[0] = bm1x; m1->mv[1] = bm1y;
+    for (int k = 0; k < 4; k++)
+        if ((k & 1) >= bx8 && (k & 1) < bx8 + w8 && (k >> 1) >= by8 && (k >> 1) < by8 + h8) {
+            const int d0x = abs(bm0x - m0->mvp[0]), d0y = abs(bm0y - m0->mvp[1]), d1x = abs(bm1x - m1->mvp[0]), d1y = abs(bm1y - m1->mvp[1]);
+            mb->mv[k][0] = (int16_t)bm0x; mb->mv[k][1] = (int16_t)bm0y; mb->mv1[k][0] = (int16_t)bm1x; mb->mv1[k][1] = (int16_t)bm1y;
+            e->amvd[((size_t)a->mi * 4 + k) * 2] = (uint8_t)(d0x < 33 ? d0x : 33); e->amvd[((size_t)a->mi * 4 + k) * 2 + 1] = (uint8_t)(d0y < 33 ? d0y : 33);
+            e->amvd1[((size_t)a->mi * 4 + k) * 2] = (uint8_t)(d1x < 33 ? d1x : 33); e->amvd1[((size_t)a->mi * 4 + k) * 2 + 1] = (uint8_t)(d1y < 33 ? d1y : 33);
+            *done |= 1 << k;
+        }
+    cache_block_l(a, 0, bx8, by8, w8, h8, m0->ref, m0->mv); cache_block_l(a, 1, bx8, by8, w8, h8, m1->ref, m1->mv);
+}
+
+/* the hook of x264_macroblock_analyse for a B inter type (B_L0_L0 .. B_8x8) chosen on RD cost at i_mbrd >= 2 (--subme 9 in B slices): every part
+ * that uses one list goes through x264_me_refine_qpel_rd in that list, every bi-predicted part through x264_me_refine_bidir_rd; direct 8x8 blocks stay */
+static void refine_inter_b_rd(actx *a, int i_type, int i_partition, int use16, int t8, int i_cost, x264gpu_mb *mb, int16_t *lv)
+{
+    x264o_encoder *e = a->e;
+    int done = 0;
+    rd_reset(a, mb, lv);
+    {
+        const int bak = a->sub8[0];
+        if (i_partition == D_16x16 && i_type == X264GPU_MB_B_INTER) a->sub8[0] = use16;
+        fill_b_record(a, i_type, i_partition, mb);
+        a->sub8[0] = bak;
+    }
+    mb->transform8x8 = (uint8_t)t8;
+    a->partition = i_partition; a->cur_valid = a->cur_valid1 = 0;
+    memset(e->amvd + (size_t)a->mi * 8, 0, 8); memset(e->amvd1 + (size_t)a->mi * 8, 0, 8);
+    const int np = i_partition == D_16x16 ? 1 : i_partition == D_8x8 ? 4 : 2;
+    for (int i = 0; i < np; i++) {
+        const int i8 = i_partition == D_16x8 ? 2 * i : i;
+        const int use = i_partition == D_16x16 ? use16 : i_partition == D_16x8 ? a->part16x8[i] : i_partition == D_8x16 ? a->part8x16[i] : a->sub8[i];
+        me_t *m0 = i_partition == D_16x16 ? (use == 2 ? &a->bi16[0] : &a->me16l[0]) : i_partition == D_16x8 ? &a->me16x8l[0][i] : i_partition == D_8x16 ? &a->me8x16l[0][i] : &a->me8l[0][i];
+        me_t *m1 = i_partition == D_16x16 ? (use == 2 ? &a->bi16[1] : &a->me16l[1]) : i_partition == D_16x8 ? &a->me16x8l[1][i] : i_partition == D_8x16 ? &a->me8x16l[1][i] : &a->me8l[1][i];
+        const int bx8 = i8 & 1, by8 = i8 >> 1, w8 = m0->w >> 3, h8 = m0->h >> 3;
+        if (use == 3) {          /* a direct 8x8 block: nothing to refine; the blocks after it predict from its direct motion */
+            cache_b_block(a, bx8, by8, 1, 1, 3, NULL, NULL, i8);
+            done |= 1 << i8;
+        } else if (use == 2) me_refine_bidir_rd(a, m0, m1, e->bipred_weight[m0->ref][m1->ref], i8, t8, &done, mb, lv);
+        else {
+            me_t *m = use ? m1 : m0;
+            if (i_partition == D_16x16) m->cost = i_cost;
+            me_refine_qpel_rd(a, m, i8, t8, &done, mb, lv);
+            cache_block_l(a, 1 - use, bx8, by8, w8, h8, -1, NULL);          /* the list the part does not use: no reference */
+        }
+    }
 }
 
 /* the hook of x264_macroblock_analyse for an inter P type chosen on RD cost; returns the partition (a pair of halves refined onto one vector is 16x16) */

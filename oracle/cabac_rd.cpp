@@ -528,6 +528,39 @@ struct Coder {
             i8 += pixel == 1 ? 1 : 2;
         }
     }
+    // a part of a B macroblock (x264_partition_size_cabac, B types): the vector differences of the lists the part uses — no sub_mb_type bins —
+    // then the residual of its 8x8 blocks.  The record holds the whole macroblock; done = the 8x8 blocks refined before this part
+    void partition_b(int mbx, int mby, int i8, int pixel, int done)
+    {
+        cur = mby * c.mbw + mbx; cur_direct = 0;
+        const x264gpu_mb &m = c.mbs[cur];
+        const int16_t *lv = c.levels + (size_t)cur * X264GPU_MB_LEVELS;
+        const int bx = i8 & 1, by = i8 >> 1, w8 = pixel == 1 ? 2 : 1, h8 = pixel == 2 ? 2 : 1;
+        const int use = b_use(m, i8);
+        for (lst = 0; lst < 2; lst++) {
+            if (use == 3 || use == 1 - lst) continue;
+            done8 = done;
+            for (int k = 0; k < 4; k++) { const int r = lst ? m.ref1[k] : m.ref[k]; cur8[k] = Nb{ true, r >= 0 ? r : -1, r >= 0 ? (lst ? m.mv1[k][0] : m.mv[k][0]) : 0, r >= 0 ? (lst ? m.mv1[k][1] : m.mv[k][1]) : 0 }; }
+            const int r = lst ? m.ref1[i8] : m.ref[i8], vx = lst ? m.mv1[i8][0] : m.mv[i8][0], vy = lst ? m.mv1[i8][1] : m.mv[i8][1];
+            int px, py;
+            predict(mbx, mby, bx, by, w8, pixel == 3 ? 3 : pixel, pixel == 1 ? by : bx, r, px, py);
+            mvd(mbx, mby, i8, w8, h8, 0, vx - px);
+            mvd(mbx, mby, i8, w8, h8, 1, vy - py);
+        }
+        lst = 0;
+        for (int j = pixel < 3; j >= 0; j--) {
+            if ((m.cbp_luma >> i8) & 1) {
+                if (m.transform8x8) {
+                    int16_t l8[64];
+                    for (int z = 0; z < 64; z++) l8[z] = lv[(i8 * 4 + (z & 3)) * 16 + (z >> 2)];
+                    residual(l8, 5);
+                } else for (int b = i8 * 4; b < i8 * 4 + 4; b++) block_cbf(lv + b * 16, 16, 2, cbf_luma(mbx, mby, m, b));
+            }
+            if (m.cbp_chroma)
+                for (int pl = 0; pl < 2; pl++) block_cbf(lv + X264GPU_LV_CHROMA_AC + (pl * 4 + i8) * 16 + 1, 15, 4, cbf_chroma_ac(mbx, mby, m, pl, i8));
+            i8 += pixel == 1 ? 1 : 2;
+        }
+    }
     void part_i4x4(int mbx, int mby, int idx)
     {
         cur = mby * c.mbw + mbx;
@@ -586,6 +619,7 @@ extern "C" long x264o_cabac_part(x264o_cabac_ctx *c, int mbx, int mby, int kind,
     if (kind == 0) k.partition_p(mbx, mby, a, b, d);
     else if (kind == 1) k.part_i4x4(mbx, mby, a);
     else if (kind == 2) k.part_i8x8(mbx, mby, a);
+    else if (kind == 4) k.partition_b(mbx, mby, a, b, d);
     else k.chroma_part(mbx, mby);
     return k.f8;
 }

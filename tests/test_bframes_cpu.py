@@ -58,6 +58,11 @@ def run(w, h, types, seed, bframes=3, pyramid=1, weightp=0, pics_out=None, weigh
     (176, 288, "IBBBPBBP", 44, dict(rd=0, trellis=0, subme=5, psy_rd_q8=0, cabac=0, slices=3, dct8x8=0)),
     (176, 144, "IBBBPBBP", 18, dict(subme=9)),                                    # chroma-ME in B slices
     (176, 144, "IBBPBP", 19, dict(subme=9, rd=1 | 64)),                           # + deblock-aware RD
+    # --subme 9 in full (i_mbrd 2 in B slices): intra_rd_refine, x264_me_refine_qpel_rd per list, x264_me_refine_bidir_rd of the bi-predicted parts
+    (176, 144, "IBBBPBBP", 33, dict(subme=9, rd=63 | 64)),
+    (96, 80, "IBPBBPBBBPP", 34, dict(subme=9, rd=63, partitions=0xf07)),
+    (176, 144, "IBBPBP", 35, dict(subme=9, rd=63 | 64, trellis=127, me_method=2)),
+    (128, 96, "IBBPBBP", 36, dict(subme=9, rd=3, refs=2, weightb=0)),               # the inter sites only
     (176, 144, "IBBBPBBP", 31, dict(subme=6)),                                    # preset fast: subme 6 + trellis 1
     (176, 144, "IBBPBP", 32, dict(subme=6, trellis=127)),
 ])
