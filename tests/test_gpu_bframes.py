@@ -90,6 +90,13 @@ def run(gpu, w, h, types, seed, streams=1, bframes=3, pyramid=1, weightp=0, weig
     (176, 144, "IBBBPBBP", 20, dict(subme=9, rd=61)),                               # --subme 9, intra sites: intra_rd_refine of the intra macroblocks of B slices
     (176, 144, "IBBPBP", 21, dict(subme=9, rd=61 | 64, trellis=127, me_method=2)),
     (96, 80, "IBPBBP", 22, dict(subme=9, rd=61, qp_i=30)),
+    # --subme 9 in full: the chosen B inter type's vectors on RD cost — x264_me_refine_qpel_rd per list, x264_me_refine_bidir_rd of the bi-predicted parts (k_mb_b_rdrefine.inc)
+    (176, 144, "IBBBP", 20, dict(subme=9, rd=3)),                                   # the inter site alone
+    (176, 144, "IBBBPBBP", 33, dict(subme=9, rd=63 | 64)),                          # x264's subme 9: every site + deblock-aware RD
+    (96, 80, "IBPBBPBBBPP", 34, dict(subme=9, rd=63, partitions=0xf07)),
+    (176, 144, "IBBPBP", 35, dict(subme=9, rd=63 | 64, trellis=127, me_method=2)),  # preset slower's analysis: umh, trellis 2
+    (128, 96, "IBBPBBP", 36, dict(subme=9, rd=3, refs=2, weightb=0)),
+    (208, 112, "IBBBPBP", 37, dict(subme=9, rd=63 | 64, refs=4, dpb=4, qp_i=20, qp_p=22)),
     (176, 144, "IBBBPBBP", 18, dict(subme=9)),                                      # --subme 9 without its refinement sites: chroma-ME in B slices, 4 + 10 sub-pel iterations
     (208, 112, "IBBPBP", 19, dict(subme=9, me_method=2, rd=1 | 64, refs=4, dpb=4)),
     (176, 144, "IBBBPBBP", 16, dict(rd=1 | 64)),                                    # deblock-aware RD (x264 b_deblock_rdo) in B macroblocks: both lists' motion in the boundary strengths
@@ -205,10 +212,10 @@ def test_b_pictures_without_rd_bitexact_and_decodable(gpu, w, h, types, seed, ov
 
 
 def test_config4_size_slow_toolset_bitexact(gpu):
-    """3840x2160 (BASELINE.json configs[3]) with preset slow's toolset as it is built — --me umh, --subme 8 (RD refinement of the P partitions' vectors and of
-    the intra modes: cfg.rd 63), --ref 5, --trellis 2, bframes 3 + b-pyramid + weightb, --weightp 2's duplicate, --direct auto; subme 9's
-    refinement of B slices / deblock-aware RD are not built — one mini-GOP I B P B plus a second P picture against the CPU checker"""
-    assert run(gpu, 3840, 2160, "IBPBP", 41, weightp=2, refs=5, dpb=5, me_method=2, subme=8, rd=63, trellis=127, direct="auto") >= 0
+    """3840x2160 (BASELINE.json configs[3]: slow + --me umh + --subme 9) with that toolset: RD refinement in I, P and B slices (cfg.rd 63: vectors per list,
+    bi-predicted pairs, intra modes), deblock-aware RD (bit 6), chroma in the B slices' sub-pel costs, --ref 5, --trellis 2, bframes 3 + b-pyramid + weightb,
+    --weightp 2's duplicate, --direct auto — one mini-GOP I B P B plus a second P picture against the CPU checker"""
+    assert run(gpu, 3840, 2160, "IBPBP", 41, weightp=2, refs=5, dpb=5, me_method=2, subme=9, rd=63 | 64, trellis=127, direct="auto") >= 0
 
 
 @pytest.mark.parametrize("types,weights,weightp,over", [

@@ -883,7 +883,7 @@ def test_every_preset_codes_a_decodable_stream(gpu, preset):
     else:
         assert eff.i_bframe == 0
     # RD refinement (subme 8) runs from slow up (umh); placebo's tesa maps to esa, where it does not (subme 7)
-    assert eff.analyse.i_subpel_refine == {"ultrafast": 0, "superfast": 1, "veryfast": 2, "faster": 4, "fast": 6, "medium": 7, "placebo": 7}.get(preset, 8), preset
+    assert eff.analyse.i_subpel_refine == {"ultrafast": 0, "superfast": 1, "veryfast": 2, "faster": 4, "fast": 6, "medium": 7, "slow": 8, "placebo": 7}.get(preset, 9), preset          # (slower 9; veryslow 10 -> 9; placebo's tesa -> esa keeps subme 7)
     stream, recs = encode_delayed(h_, w, h, frames)
     H.x264_encoder_close(h_)
     assert sorted(r[2] for r in recs) == list(range(n))

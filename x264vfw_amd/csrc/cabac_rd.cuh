@@ -219,6 +219,7 @@ struct CabIn {
     // macroblock: mode + cbp_chroma + DC + AC.  Inside the macroblock the coded_block_flag neighbours read pm_nnzc — what x264's non_zero_count
     // cache holds, i.e. what the LAST encode of any kind left there (24 flags: luma blocks, chroma AC plane * 4 + block)
     int pm, pm_b0, pm_b1, pm_dx, pm_dy, pm_sx, pm_sy;
+    int pm_lists, pm_dx1, pm_dy1, pm_sx1, pm_sy1;          // pm 1 in a B slice: the lists the part uses (bit 0 / 1), list 1's difference and sums
     unsigned pm_nnzc;
 };
 
@@ -309,9 +310,9 @@ __device__ __forceinline__ unsigned long long cab_mb(Cab &cb, uint32_t model, in
     const int t8ctx = 399 + (lavail && in.lt8) + (tavail && in.tt8);
     if (in.pm == 1) {
         // partition_size_cabac of a P part: its vector difference, the sub-macroblock type of a P_8x8 block
-        cab_mvd(cb, model, lane, 40, in.pm_sx, in.pm_dx);
-        cab_mvd(cb, model, lane, 47, in.pm_sy, in.pm_dy);
-        if (in.part == D_8x8) cab_bin(cb, model, lane, 21, 1);
+        if (in.pm_lists & 1) { cab_mvd(cb, model, lane, 40, in.pm_sx, in.pm_dx); cab_mvd(cb, model, lane, 47, in.pm_sy, in.pm_dy); }
+        if (in.pm_lists & 2) { cab_mvd(cb, model, lane, 40, in.pm_sx1, in.pm_dx1); cab_mvd(cb, model, lane, 47, in.pm_sy1, in.pm_dy1); }
+        if (in.part == D_8x8 && !in.bslice) cab_bin(cb, model, lane, 21, 1);
     } else if (intra) {
         if (in.type != X264GPU_MB_I16x16 && (!in.pm || in.pm == 2 || in.pm == 3)) {
             const bool i8 = in.type == X264GPU_MB_I8x8;

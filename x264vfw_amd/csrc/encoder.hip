@@ -115,6 +115,10 @@ int x264gpu_encoder_create(x264gpu_encoder **out, const x264gpu_config *cfg)
     ARG_TRY(!cfg->rd || (cfg->subme >= 6 && cfg->subme <= 9 && cfg->psy_rd_q8 >= 0 && cfg->psy_rd_q8 <= 2560));      // RD: x264's i_mbrd 1 (bit counts of the session's entropy coder)
     // rd > 1: RD refinement of the chosen type (x264 subme 8, i_mbrd 2): bit 0 on + a mask of refinement sites in bits 1..5 (x264 = all five: 63); CABAC, hex / umh
     ARG_TRY(cfg->rd >= 0 && cfg->rd < 128 && (cfg->rd < 2 || (cfg->rd & 1)) && (!(cfg->rd & 62) || (cfg->cabac && cfg->subme >= 8 && (cfg->me_method == 1 || cfg->me_method == 2))));      // bit 6: deblock-aware RD (x264 subme 9)      // (rd 0 with subme >= 8: the sub-pel iteration table of those levels without RD, as before)
+    // --subme 8 and up with RD: 4 half-pel + 10 quarter-pel iterations reach 4.5 samples from the full-pel vector — only the refinement instantiations stage
+    // that neighbourhood (CABAC, hex / umh); B slices search that far from subme 9 on (one level down)
+    ARG_TRY(!cfg->rd || cfg->subme < 8 || (cfg->cabac && (cfg->me_method == 1 || cfg->me_method == 2)));
+    ARG_TRY(cfg->dpb == 0 || cfg->subme < 9 || (cfg->rd && cfg->cabac && (cfg->me_method == 1 || cfg->me_method == 2)));
     ARG_TRY(cfg->slices >= 0 && (cfg->slices <= 1 || cfg->slices <= (cfg->height + 15) / 16 / (cfg->slices_plain ? 1 : 4)));      // x264 slice threads: at least four macroblock rows each; --slices N: one
     ARG_TRY(cfg->slices_plain == 0 || cfg->slices_plain == 1);
     ARG_TRY(cfg->width <= 4096 && cfg->height <= 2304 && cfg->me_range >= 4 && cfg->me_range <= (cfg->me_method == 2 ? 64 : 16));

@@ -1976,6 +1976,11 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(MB_WAVES_PER
         int rf_cx = 0, rf_cy = 0, rf_cdir = -99, rf_mvpx = 0, rf_mvpy = 0, rf_mv0x = 0, rf_mv0y = 0, rf_f4 = 0, rf_f8 = 0;
         int rf_lmx = 0, rf_lmy = 0, rf_priced = 0, rf_done = 0, rf_ref = 0, rf_slot = 0, rf_pm8 = 0, rf_b0 = 0, rf_b1 = -1;
         unsigned long long rf_bcost = 0, rf_cost = 0, rf_amvd = 0;
+        // ... of a B inter type (k_mb_b_rdrefine.inc, rf_kind 2): the part's list use (0 / 1 one list, 2 both), both lists' predicted vectors, list 1's
+        // candidate / best vector of a bi-predicted part, its |mvd| cache, the candidate's chroma prediction, the best pair of a round
+        int rf_l = 0, rf_mvp0x = 0, rf_mvp0y = 0, rf_mvp1x = 0, rf_mvp1y = 0, rf_bm1x = 0, rf_bm1y = 0, rf_c1x = 0, rf_c1y = 0, rf_bestj = 0;
+        unsigned long long rf_amvd1 = 0;
+        uint32_t rf_cpred = 0;
         unsigned rf_nnzc = 0;
         uint32_t rf_pred = 0;
         // ... of the intra refinement: the mode out for costing (rf_cm), the best so far, the chroma pass' transform switch and last coded block pattern,
@@ -1996,12 +2001,12 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(MB_WAVES_PER
         for (;;) {
         if constexpr (BS) {
             if (rd_run && !commit) {
-                if (!rf_on) {
+                if (!rf_on || rf_kind == 2) {          // (the refinement of an inter type runs inside k_mb_b.inc's last phase: k_mb_b_rdrefine.inc)
 #include "k_mb_b.inc"
                 }
                 if constexpr (REF) {
-                    // --subme 9: the decision's winner once more on RD cost (k_mb_b.inc switched rf_on on at its last phase)
-                    if (rf_on && !commit) {
+                    // --subme 9: the decision's intra winner once more on RD cost (k_mb_b.inc switched rf_on on at its last phase)
+                    if (rf_on && rf_kind != 2 && !commit) {
                         bool go = false;
 #include "k_mb_refine.inc"
                         (void)go;
@@ -2208,10 +2213,14 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(MB_WAVES_PER
                     // chroma: prediction at the candidate vector, the 4x4 block under each of the part's 8x8 blocks, AC only
                     const int pl = (lane >> 4) & 1, ci = (lane >> 2) & 3, cx0 = (ci & 1) * 4, cyy = (ci >> 1) * 4 + j4;
                     const bool act = lane < 32 && ((pm8 >> ci) & 1);
-                    uint32_t pu, pv;
-                    mc_chroma_row4(ref_chroma00(k, s, rf_ref), k.rs, mbx * 8 + cx0, mby * 8 + cyy, rf_cx, rf_cy, pu, pv);
-                    if (k.wc_any) { const int wu = uni(k.wc0[2 * rf_ref]), wv = uni(k.wc0[2 * rf_ref + 1]); if (wu >> 24) pu = wp4(pu, wu); if (wv >> 24) pv = wp4(pv, wv); }
-                    const uint32_t cpred = pl ? pv : pu;
+                    uint32_t cpred;
+                    if constexpr (BS) cpred = rf_cpred;          // (B: the coroutine's b_predict of the candidate — one list or both averaged)
+                    else {
+                        uint32_t pu, pv;
+                        mc_chroma_row4(ref_chroma00(k, s, rf_ref), k.rs, mbx * 8 + cx0, mby * 8 + cyy, rf_cx, rf_cy, pu, pv);
+                        if (k.wc_any) { const int wu = uni(k.wc0[2 * rf_ref]), wv = uni(k.wc0[2 * rf_ref + 1]); if (wu >> 24) pu = wp4(pu, wu); if (wv >> 24) pv = wp4(pv, wv); }
+                        cpred = pl ? pv : pu;
+                    }
                     const uint2 fe = *(const uint2 *)(L.csrc + cyy * 16 + 2 * cx0);
                     const uint32_t cenc = nv12_pick(fe.x, fe.y, pl);
                     int e[4], p[4], v[4];
@@ -2695,6 +2704,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(MB_WAVES_PER
             }
             ci.t8 = rd_t8cur;
             ci.pm = 0; ci.pm_b0 = 0; ci.pm_b1 = -1; ci.pm_dx = ci.pm_dy = ci.pm_sx = ci.pm_sy = 0; ci.pm_nnzc = 0;
+            ci.pm_lists = 1; ci.pm_dx1 = ci.pm_dy1 = ci.pm_sx1 = ci.pm_sy1 = 0;
             if (rd_run && !commit) {
                 int cost = 0;
                 unsigned long long cost64 = 0;          // part costs (RD refinement): 8 more bits than x264_rd_cost_mb's
@@ -2713,11 +2723,21 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(MB_WAVES_PER
                             // partition_size_cabac: the part's vector difference against the |mvd| of the parts refined before / the neighbours
                             const int x8 = rf_b0 & 1, y8 = rf_b0 >> 1;
                             ci.pm = 1; ci.pm_b0 = rf_b0; ci.pm_b1 = rf_b1; ci.pm_nnzc = rf_nnzc; ci.t8 = e_t8 != 0;
-                            ci.pm_dx = rf_cx - rf_mvpx; ci.pm_dy = rf_cy - rf_mvpy;
+                            ci.pm_lists = 1;
+                            if constexpr (BS) {
+                                // a B part: the vector difference(s) of the list(s) it uses (rf_l 0 / 1 / 2 both); no sub_mb_type bins
+                                ci.pm_lists = rf_l == 2 ? 3 : 1 << rf_l;
+                                ci.pm_dx = rf_cx - rf_mvp0x; ci.pm_dy = rf_cy - rf_mvp0y; ci.pm_dx1 = rf_c1x - rf_mvp1x; ci.pm_dy1 = rf_c1y - rf_mvp1y;
+                            } else { ci.pm_dx = rf_cx - rf_mvpx; ci.pm_dy = rf_cy - rf_mvpy; }
                             for (int comp = 0; comp < 2; comp++) {
                                 const int la = x8 > 0 ? (int)((rf_amvd >> (8 * ((y8 * 2 + x8 - 1) * 2 + comp))) & 255) : left ? (int)((ci.lamvd >> (8 * ((y8 * 2 + 1) * 2 + comp))) & 255) : 0;
                                 const int ta = y8 > 0 ? (int)((rf_amvd >> (8 * (((y8 - 1) * 2 + x8) * 2 + comp))) & 255) : top ? (int)((ci.tamvd >> (8 * ((2 + x8) * 2 + comp))) & 255) : 0;
                                 if (comp) ci.pm_sy = la + ta; else ci.pm_sx = la + ta;
+                                if constexpr (BS) {
+                                    const int la1 = x8 > 0 ? (int)((rf_amvd1 >> (8 * ((y8 * 2 + x8 - 1) * 2 + comp))) & 255) : left ? (int)((ci.lamvd1 >> (8 * ((y8 * 2 + 1) * 2 + comp))) & 255) : 0;
+                                    const int ta1 = y8 > 0 ? (int)((rf_amvd1 >> (8 * (((y8 - 1) * 2 + x8) * 2 + comp))) & 255) : top ? (int)((ci.tamvd1 >> (8 * ((2 + x8) * 2 + comp))) & 255) : 0;
+                                    if (comp) ci.pm_sy1 = la1 + ta1; else ci.pm_sx1 = la1 + ta1;
+                                }
                             }
                         }
                         if (part_pass && rf_pk >= 2) {

@@ -398,13 +398,14 @@ x264_t *x264_encoder_open(x264_param_t *param)
     // subme 6 / 7 = RD mode decision in P and I slices (x264's i_mbrd 1): on the device, with the bit counts of the session's entropy coder
     // (CAVLC: exact; CABAC: x264's size-only coder on the slice's context states, which the device carries through the macroblock loop);
     // 8 adds RD refinement of the chosen type's vectors and intra modes in I and P slices (i_mbrd 2: x264_me_refine_qpel_rd, intra_rd_refine; B slices
-    // analyse one level down, i.e. as at subme 7): on the device in CABAC sessions under --me hex / umh.  9 and up (RD refinement in B slices, deblock-aware
-    // RD, QP-RD) are not implemented.  The highest level whose behaviour IS implemented is reported back
-    if (p.analyse.i_subpel_refine > 8) { xlog(&p, X264_LOG_WARNING, "subme %d: RD refinement in B slices / deblock-aware RD / QP-RD are not implemented yet: subme 8\n", p.analyse.i_subpel_refine); p.analyse.i_subpel_refine = 8; }
-    if (p.analyse.i_subpel_refine == 8 && (!p.b_cabac || (p.analyse.i_me_method != X264_ME_HEX && p.analyse.i_me_method != X264_ME_UMH))) {
-        xlog(&p, X264_LOG_WARNING, "subme 8 (RD refinement) needs CABAC and me hex / umh in the MI355X path: subme 7\n"); p.analyse.i_subpel_refine = 7;
+    // analyse one level down, i.e. as at subme 7): on the device in CABAC sessions under --me hex / umh.  9 adds the refinement in B slices (per-list
+    // x264_me_refine_qpel_rd, x264_me_refine_bidir_rd, intra_rd_refine), chroma in their sub-pel costs and the deblock-aware RD costs.  10 and 11 (QP-RD,
+    // full-RD trellis) are not implemented.  The highest level whose behaviour IS implemented is reported back
+    if (p.analyse.i_subpel_refine > 9) { xlog(&p, X264_LOG_WARNING, "subme %d: QP-RD / full-RD trellis of the levels above 9 are not implemented yet: subme 9\n", p.analyse.i_subpel_refine); p.analyse.i_subpel_refine = 9; }
+    if (p.analyse.i_subpel_refine >= 8 && (!p.b_cabac || (p.analyse.i_me_method != X264_ME_HEX && p.analyse.i_me_method != X264_ME_UMH))) {
+        xlog(&p, X264_LOG_WARNING, "subme %d (RD refinement) needs CABAC and me hex / umh in the MI355X path: subme 7\n", p.analyse.i_subpel_refine); p.analyse.i_subpel_refine = 7;
     }
-    p.analyse.i_subpel_refine = clampi(p.analyse.i_subpel_refine, 0, 8);
+    p.analyse.i_subpel_refine = clampi(p.analyse.i_subpel_refine, 0, 9);
     // trellis 1 = the final encode of every macroblock quantised by x264's trellis search on the slice's CABAC state: on the device where that state
     // lives, i.e. in CABAC sessions with RD (subme >= 6); trellis 2 = also the block encodes of the intra analysis and every RD candidate
     if (p.analyse.i_trellis && (!p.b_cabac || p.analyse.i_subpel_refine < 6)) {
@@ -570,6 +571,7 @@ x264_t *x264_encoder_open(x264_param_t *param)
     cfg.deblock = p.b_deblocking_filter; cfg.deblock_alpha = p.i_deblocking_filter_alphac0; cfg.deblock_beta = p.i_deblocking_filter_beta;
     cfg.chroma_qp_offset = eff_chroma_qp_offset;
     cfg.rd = p.analyse.i_subpel_refine >= 8 ? 63 : p.analyse.i_subpel_refine >= 6; cfg.psy_rd_q8 = psy_rd_q8;      // 63: RD + every refinement site (x264's i_mbrd 2)
+    if (p.analyse.i_subpel_refine >= 9 && p.b_deblocking_filter) cfg.rd |= 64;          // h->mb.b_deblock_rdo: whole-macroblock RD costs measured after the loop filter
     cfg.trellis = p.analyse.i_trellis == 2 ? 63 + 64 : p.analyse.i_trellis ? 63 : 0;         // every quantiser call of the final encode; + 64: of the analysis too
     cfg.psy = cfg.rd && p.analyse.b_psy;           // x264: the chroma lambda offset table follows b_psy, whatever the psy-rd strength
     cfg.deadzone_inter = p.analyse.i_luma_deadzone[0]; cfg.deadzone_intra = p.analyse.i_luma_deadzone[1];
