@@ -61,6 +61,7 @@ def parse_args():
     ap.add_argument("--qp", type=int, default=23)
     ap.add_argument("--refs", type=int, default=3, help="reference frames (medium: 3)")
     ap.add_argument("--preset", default="medium", choices=["medium", "ultrafast", "slow"])
+    ap.add_argument("--subme", type=int, default=0, choices=[0, 8, 9], help="with --preset slow: 9 = BASELINE.json configs[3]'s level (RD refinement in B slices too, deblock-aware RD); default: the preset's own (slow: 8)")
     ap.add_argument("--rd", default="cabac", choices=["cabac", "cavlc", "off"], help="RD mode decision (subme 7, psy-rd 1.0) with the sizes of medium's CABAC (default, the headline), of CAVLC (medium --no-cabac), or off (subme 5: SATD decisions)")
     ap.add_argument("--no-trellis", action="store_true", help="headline toolset without trellis 1 (for comparison)")
     ap.add_argument("--aq", action="store_true", help="variance AQ on (per-macroblock quantisers, the CRF / ABR path); the headline metric is CQP and leaves it off, as x264 does")
@@ -89,8 +90,10 @@ def toolset(args):
             t = dict(t, trellis=63)                               # medium's --trellis 1: every quantiser call of the final encode
         if args.preset == "slow" and args.rd == "cabac":
             # config.c:1482-1484: slow = --direct auto --rc-lookahead 50 --ref 5 --subme 8 --trellis 2 (+ --me umh above); subme 8 = RD refinement of the
-            # P partitions' vectors and of the intra modes (rd 63: every site); --direct auto stays spatial (config.toolset_gaps)
+            # P partitions' vectors and of the intra modes (rd 63: every site); --direct auto stays spatial in the lock-step batch (sessions run it)
             t = dict(t, refs=5, subme=8, rd=63)
+            if args.subme == 9:          # configs[3]: slow + --me umh + --subme 9 — i_mbrd 2 in B slices as well, h->mb.b_deblock_rdo, chroma in the B slices' sub-pel costs
+                t = dict(t, subme=9, rd=63 | 64)
             if not args.no_trellis:
                 t = dict(t, trellis=127)
     if args.aq:

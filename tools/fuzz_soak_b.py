@@ -59,6 +59,23 @@ def random_b_case(rnd):
         kw.update(rd=0, subme=rnd.randint(1, 5), trellis=0, psy=0, psy_rd_q8=0, chroma_qp_offset=rnd.choice([0, 2]), cabac=rnd.randint(0, 1))
         if "_weights" in kw:
             kw["_weights"] = {i: v for i, v in kw["_weights"].items() if types[i] == "P"}
+    if os.environ.get("FUZZ_R04") and kw.get("rd", 1) and "B" in types:
+        # round 4's additions (drawn after the draws above: the committed seeds of tests/test_gpu_fuzz.py stay what they were): the levels of --subme in
+        # sessions with B pictures (B analysis without RD below 7, RD refinement 8 / 9 with its sites, deblock-aware RD), the three --direct modes
+        lvl = rnd.choice([9, 9, 9, 8, 8, 7, 6, 5, 4, 3, 2, 1])
+        if lvl >= 8:
+            if kw["me_method"] not in (1, 2):
+                kw["me_method"] = rnd.choice([1, 2])
+            kw.update(subme=lvl, rd=rnd.choice([63, 63, 63 | 64, 63 | 64, 3, 61, 1 | 64, 1, 17 | 64, 9, 37]))
+        elif lvl == 7:
+            kw.update(subme=7, rd=rnd.choice([1, 1 | 64]))
+        elif lvl == 6:
+            kw.update(subme=6, rd=1)
+        else:
+            kw.update(subme=lvl, rd=0, trellis=0, psy=0, psy_rd_q8=0, chroma_qp_offset=rnd.choice([0, 2]), cabac=rnd.randint(0, 1))
+        kw["direct"] = rnd.choice(["spatial", "spatial", "temporal", "auto", "auto"])
+        if os.environ.get("FUZZ_BIG"):
+            w, h = rnd.choice([(352, 288), (416, 240), (640, 360), (480, 272)])
     return w, h, types, rnd.randint(1, 10 ** 6), bframes, pyramid, weightp, kw
 
 
