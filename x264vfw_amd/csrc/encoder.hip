@@ -118,6 +118,7 @@ int x264gpu_encoder_create(x264gpu_encoder **out, const x264gpu_config *cfg)
     // --subme 8 and up with RD: 4 half-pel + 10 quarter-pel iterations reach 4.5 samples from the full-pel vector — only the refinement instantiations stage
     // that neighbourhood (CABAC, hex / umh); B slices search that far from subme 9 on (one level down)
     ARG_TRY(!cfg->rd || cfg->subme < 8 || (cfg->cabac && (cfg->me_method == 1 || cfg->me_method == 2)));
+    ARG_TRY(!(cfg->rd & 64) || (cfg->cabac && (cfg->me_method == 1 || cfg->me_method == 2)));          // deblock-aware RD: in the refinement instantiations
     ARG_TRY(cfg->dpb == 0 || cfg->subme < 9 || (cfg->rd && cfg->cabac && (cfg->me_method == 1 || cfg->me_method == 2)));
     ARG_TRY(cfg->slices >= 0 && (cfg->slices <= 1 || cfg->slices <= (cfg->height + 15) / 16 / (cfg->slices_plain ? 1 : 4)));      // x264 slice threads: at least four macroblock rows each; --slices N: one
     ARG_TRY(cfg->slices_plain == 0 || cfg->slices_plain == 1);

@@ -222,7 +222,8 @@ __device__ __forceinline__ void rc_row(const uint32_t *slot, int X0, int Y0, int
     }
 }
 
-template <int M, int ME>
+// WP: explicit weights can occur (P slices under --weightp); B slices instantiate without them
+template <int M, int ME, bool WP = true>
 __device__ __forceinline__ void me_search(const EncK &k, MbLds<M> &L, const MbCtx &c, const MeJob &j, int &mvx, int &mvy, int &cost, int &cost_mv, int &halfpel_thresh, const MeState &S, WinTags &wtg, Prof &pf)
 {
     pf.mark(PH_ME_GLUE);
@@ -233,10 +234,10 @@ __device__ __forceinline__ void me_search(const EncK &k, MbLds<M> &L, const MbCt
     const int bx = c.px + j.ox, by = c.py + j.oy;
     // explicit luma weight of this reference (P slices, --weightp): every sample fetched below goes through it after interpolation; the
     // reference cache holds the unweighted planes under the PICTURE's tag, so an index and its duplicate share a slot
-    const int wpk = k.wp_any ? uni(k.wl0[j.ref]) : 0;
-    const int wcu = k.wc_any ? uni(k.wc0[2 * j.ref]) : 0, wcv = k.wc_any ? uni(k.wc0[2 * j.ref + 1]) : 0;
-    const bool wt = (wpk >> 24) != 0;
-    const int cref = k.wp_any ? ref_picture(k, j.ref) : j.ref;
+    const int wpk = WP && k.wp_any ? uni(k.wl0[j.ref]) : 0;
+    const int wcu = WP && k.wc_any ? uni(k.wc0[2 * j.ref]) : 0, wcv = WP && k.wc_any ? uni(k.wc0[2 * j.ref + 1]) : 0;
+    const bool wt = WP && (wpk >> 24) != 0;
+    const int cref = WP && k.wp_any ? ref_picture(k, j.ref) : j.ref;
     // (the upper half of an 8-pixel row's registers stays zero: weighting it would turn it into the offset and into cost)
 #define WP4X4(p) do { if (wt) { p[0] = wp4(p[0], wpk); p[1] = wp4(p[1], wpk); if (w16) { p[2] = wp4(p[2], wpk); p[3] = wp4(p[3], wpk); } } } while (0)
     uint32_t e[4] = { 0, 0, 0, 0 };
@@ -1517,7 +1518,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(MB_WAVES_PER
         c.lambda = k.lambda_tab[c.qp];
         c.subme = min(max(k.subme, 0), 11);
         if (BS && (c.subme == 6 || c.subme == 8)) c.subme--;          // x264_macroblock_thread_init: B slices analyse one sub-pel level down (8 -> 7: no RD refinement there below subme 9)
-        c.satd = c.subme > 1; c.chroma_me = pslice && k.chroma_me && c.subme >= (BS ? 9 : 5);      // (x264_macroblock_thread_init: B slices carry chroma in the sub-pel costs from subme 9 up)
+        c.satd = c.subme > 1; c.chroma_me = pslice && k.chroma_me && (BS ? REF && c.subme >= 9 : c.subme >= 5);      // (x264_macroblock_thread_init: B slices carry chroma in the sub-pel costs from subme 9 up)
         c.cost_base = k.cost_all + (size_t)c.qp * 2 * MVCOST_HALF;
         if (pslice && c.qp != cost_qp) {          // the mv-cost table of this quantiser (symmetric: non-negative differences only) into LDS
             cost_qp = c.qp;
@@ -2091,7 +2092,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(MB_WAVES_PER
         uint8_t *const dtile = (uint8_t *)L.csub;
         bool dbr = false;
         unsigned db_mvm = 0;           // bit dir * 2 + half: the 8x8 blocks either side of edge 2 differ in motion (boundary strength 1)
-        if constexpr (RD) dbr = k.deblock_rdo && rd_run && !commit;
+        if constexpr (REF) dbr = k.deblock_rdo && rd_run && !commit;          // (the refinement instantiations only: launches with cfg.rd bit 6 go to them)
         bool part_pass = false;
         if constexpr (REF) part_pass = rf_pk != 0 && !commit;
         dbr = dbr && !part_pass;          // (x264_rd_cost_part does not filter: whole-macroblock costs only)

@@ -6,7 +6,7 @@ namespace x264gpu {
 void launch_mb_slice_ref_hex(const EncK &k, int streams, hipStream_t st);        // mb_slice_ref_hex.hip
 void launch_mb_slice_hex(const EncK &k, int streams, bool big_margin, hipStream_t st)
 {
-    if (k.rd && k.cabac && (((k.rd >> 1) & 31) || k.subme >= 8)) { launch_mb_slice_ref_hex(k, streams, st); return; }      // --subme 8 and up: the +-5 sample sub-pel neighbourhood, RD refinement of the sites cfg.rd names
+    if (k.rd && k.cabac && (((k.rd >> 1) & 63) || k.subme >= 8)) { launch_mb_slice_ref_hex(k, streams, st); return; }      // --subme 8 and up: the +-5 sample sub-pel neighbourhood, RD refinement of the sites cfg.rd names
     if (k.rd && k.cabac && (k.trellis & 64)) hipLaunchKernelGGL((k_mb_slice<2, 1, true, 4>), dim3(streams, k.slices > 1 ? k.slices : 1), dim3(64), 0, st, k);      // ... --trellis 2
     else if (k.rd && k.cabac && k.trellis) hipLaunchKernelGGL((k_mb_slice<2, 1, true, 3>), dim3(streams, k.slices > 1 ? k.slices : 1), dim3(64), 0, st, k);      // ... and trellis
     else if (k.rd && k.cabac) hipLaunchKernelGGL((k_mb_slice<2, 1, true, 2>), dim3(streams, k.slices > 1 ? k.slices : 1), dim3(64), 0, st, k);      // ... with CABAC sizes

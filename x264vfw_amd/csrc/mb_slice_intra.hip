@@ -6,7 +6,7 @@ namespace x264gpu {
 void launch_mb_slice_ref_intra(const EncK &k, int streams, hipStream_t st);        // mb_slice_ref_intra.hip
 void launch_mb_slice_intra(const EncK &k, int streams, hipStream_t st)
 {
-    if (((k.rd >> 1) & 31) && k.cabac) { launch_mb_slice_ref_intra(k, streams, st); return; }      // RD refinement (subme 8)
+    if (((k.rd >> 1) & 63) && k.cabac) { launch_mb_slice_ref_intra(k, streams, st); return; }      // RD refinement (subme 8)
     if (k.rd && k.cabac && (k.trellis & 64)) hipLaunchKernelGGL((k_mb_slice<2, 1, false, 4>), dim3(streams, k.slices > 1 ? k.slices : 1), dim3(64), 0, st, k);
     else if (k.rd && k.cabac && k.trellis) hipLaunchKernelGGL((k_mb_slice<2, 1, false, 3>), dim3(streams, k.slices > 1 ? k.slices : 1), dim3(64), 0, st, k);
     else if (k.rd && k.cabac) hipLaunchKernelGGL((k_mb_slice<2, 1, false, 2>), dim3(streams, k.slices > 1 ? k.slices : 1), dim3(64), 0, st, k);
