@@ -45,6 +45,10 @@ struct x264gpu_encoder { x264gpu_config cfg; x264o_encoder **e; int dev, nmb; co
 int x264gpu_encoder_create(x264gpu_encoder **out, const x264gpu_config *cfg)
 {
     if (!out || !cfg || cfg->streams < 1) return fail("encoder_create arguments");
+    /* the device's structural checks (csrc/encoder.hip): RD at subme >= 8, deblock-aware RD and B pictures at subme >= 9 run in the refinement instantiations only */
+    if (cfg->rd && cfg->subme >= 8 && !(cfg->cabac && (cfg->me_method == 1 || cfg->me_method == 2))) return fail("RD at subme >= 8 needs CABAC and me hex / umh");
+    if ((cfg->rd & 64) && !(cfg->cabac && (cfg->me_method == 1 || cfg->me_method == 2))) return fail("deblock-aware RD needs CABAC and me hex / umh");
+    if (cfg->dpb > 0 && cfg->subme >= 9 && !(cfg->rd && cfg->cabac && (cfg->me_method == 1 || cfg->me_method == 2))) return fail("B pictures at subme 9 need RD, CABAC and me hex / umh");
     x264gpu_encoder *g = calloc(1, sizeof(*g));
     g->cfg = *cfg; g->dev = t_dev;
     g->e = calloc((size_t)cfg->streams, sizeof(*g->e));

@@ -238,5 +238,29 @@ def test_explicit_luma_weights_bitexact_and_decodable(gpu, types, weights, weigh
     run(gpu, 176, 144, types, 3, weightp=weightp, weights=weights, frames=fade_frames(176, 144, len(types), 3), **over)
 
 
+@pytest.mark.parametrize("types,over", [
+    ("IBBP", dict(rd=0, trellis=0, subme=5, psy_rd_q8=0)),                                                # B analysis without RD (presets fast and below)
+    ("IBBP", dict(rd=0, trellis=0, subme=2, psy_rd_q8=0, cabac=0, refs=1, mixed_refs=0, weightb=0)),      # ... with CAVLC, veryfast's level
+    ("IBBP", dict(direct="temporal")),
+    ("IBBBP", dict(direct="auto", me_method=2)),
+    ("IBP", dict(subme=9, rd=63 | 64)),                                                                    # x264's subme 9 on medium's other tools
+    ("IBP", dict(subme=8, rd=63, refs=2, trellis=127)),
+    ("IBBP", dict(subme=7, rd=1, aq_mode=1, aq_strength_q8=266)),
+])
+def test_round4_paths_at_headline_size(gpu, types, over):
+    """1920x1080: the paths this round added, one mini-GOP each against the CPU checker — long vectors, the 4 + 10 sub-pel iterations of subme 8 / 9 and
+    the per-row structures only show at this size (the 5-sample sub-pel neighbourhood of the B kernels was found by a 2160p case, not by the small ones)"""
+    over = dict(over)
+    direct = over.pop("direct", "spatial")
+    run(gpu, 1920, 1080, types, 77, direct=direct, **over)
+
+
+def test_explicit_weights_at_headline_size(gpu):
+    """1920x1080 fade: luma + chroma weights on the P pictures of a session with B pictures"""
+    from test_bframes_cpu import fade_frames
+    types, weights = "IBPBP", {2: (60, 6, -2, 6, 1, 62, -3, 0, 1, 0), 4: (66, 6, 2, 5, 0, 1, 0, 1, 31, 2)}
+    run(gpu, 1920, 1080, types, 3, weightp=2, weights=weights, frames=fade_frames(1920, 1080, len(types), 3))
+
+
 def test_b_pictures_multistream(gpu):
     run(gpu, 96, 80, "IBBBPBBP", 11, streams=3)
