@@ -172,6 +172,8 @@ def test_headline_size_b_pictures_and_weightp_bitexact(gpu):
     (176, 144, "IBBBPBBBPBBP", 5, "auto", {}),
     (176, 144, "IBBPBBPBBP", 8, "auto", dict(rd=0, trellis=0, subme=4, psy_rd_q8=0)),
     (128, 96, "IBBBPBBBP", 11, "auto", dict(subme=8, rd=63, me_method=1)),
+    (208, 104, "IBBBPBP", 903, "auto", dict(refs=4, dpb=4, slices=3, slices_plain=1, rd=0, subme=4, trellis=0, psy_rd_q8=0)),      # --slices N: a repeated slice pass replaces its own probe counts (fuzz seed 903)
+    (200, 112, "IPBBBPBBBP", 911, "auto", dict(slices=5, slices_plain=1, subme=8, rd=63 | 64, trellis=127, dct8x8=0, partitions=3)),
     (176, 288, "IBBBPBBP", 14, "auto", dict(slices=3)),
 ])
 def test_temporal_direct_and_direct_auto_bitexact(gpu, w, h, types, seed, direct, over):

@@ -978,6 +978,11 @@ def test_random_b_sessions_equal_the_checker_sessions(gpu, tmp_path):
             if rng.random() < 0.15: opts["bframes"] = int(rng.integers(4, 7))
             if rng.random() < 0.2: opts["min-keyint"] = int(rng.integers(1, 5))
             if rng.random() < 0.15: opts.update({"sliced-threads": None, "threads": 2}); opts.pop("slices", None)
+            # round 4's options (drawn last)
+            if rng.random() < 0.5: opts["subme"] = int(rng.choice([1, 2, 4, 5, 6, 7, 8, 9, 9]))
+            if rng.random() < 0.4: opts["direct"] = str(rng.choice(["spatial", "temporal", "auto"]))
+            if rng.random() < 0.2 and opts.get("aq-mode", 1): opts["aq-mode"] = int(rng.choice([2, 3]))
+            if rng.random() < 0.15 and opts.get("subme", 7) < 7: opts["no-cabac"] = None
         _session_equals_checker(tmp_path, w, h, nfr, opts, seed, scene, kind)
 
 

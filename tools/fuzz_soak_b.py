@@ -68,7 +68,7 @@ def random_b_case(rnd):
                 kw["me_method"] = rnd.choice([1, 2])
             kw.update(subme=lvl, rd=rnd.choice([63, 63, 63 | 64, 63 | 64, 3, 61, 1 | 64, 1, 17 | 64, 9, 37]))
         elif lvl == 7:
-            kw.update(subme=7, rd=rnd.choice([1, 1 | 64]))
+            kw.update(subme=7, rd=rnd.choice([1, 1 | 64]) if kw["me_method"] in (1, 2) else 1)          # (deblock-aware RD lives in the refinement instantiations: hex / umh)
         elif lvl == 6:
             kw.update(subme=6, rd=1)
         else:

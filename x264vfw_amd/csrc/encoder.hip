@@ -443,8 +443,9 @@ static int encode_core(x264gpu_encoder *e, const uint8_t *d_i420, const x264gpu_
             }
         }
         if (k.direct_auto) {
-            if (!e->dscore) HIP_TRY(hipMalloc((void **)&e->dscore, (size_t)S * 2 * sizeof(int)));
-            HIP_TRY(hipMemsetAsync(e->dscore, 0, (size_t)S * 2 * sizeof(int), st));
+            const size_t nds = (size_t)S * (e->cfg.slices > 1 ? e->cfg.slices : 1) * 2;          // [stream][slice][temporal, spatial]: every slice's wavefront stores its own
+            if (!e->dscore) HIP_TRY(hipMalloc((void **)&e->dscore, nds * sizeof(int)));
+            HIP_TRY(hipMemsetAsync(e->dscore, 0, nds * sizeof(int), st));
         }
         k.dscore = e->dscore;
     }
@@ -599,7 +600,13 @@ int x264gpu_encoder_direct_scores(x264gpu_encoder *e, int *h_scores)
 {
     ARG_TRY(e && h_scores && e->dscore);
     HIP_TRY(hipDeviceSynchronize());
-    HIP_TRY(hipMemcpy(h_scores, e->dscore, (size_t)e->cfg.streams * 2 * sizeof(int), hipMemcpyDeviceToHost));
+    const int S = e->cfg.streams, nsl = e->cfg.slices > 1 ? e->cfg.slices : 1;
+    std::vector<int> tmp((size_t)S * nsl * 2);
+    HIP_TRY(hipMemcpy(tmp.data(), e->dscore, tmp.size() * sizeof(int), hipMemcpyDeviceToHost));
+    for (int s = 0; s < S; s++) {
+        h_scores[2 * s] = h_scores[2 * s + 1] = 0;
+        for (int sl = 0; sl < nsl; sl++) { h_scores[2 * s] += tmp[((size_t)s * nsl + sl) * 2]; h_scores[2 * s + 1] += tmp[((size_t)s * nsl + sl) * 2 + 1]; }
+    }
     return X264GPU_OK;
 }
 

@@ -1507,6 +1507,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(MB_WAVES_PER
     int16_t *mv16 = k.mv16_cur + (size_t)s * k.nmb * 2;
     uint8_t *mbtype_cur = k.mbtype_cur + (size_t)s * k.nmb;
 
+    int ds_t = 0, ds_s = 0;          // --direct auto: this slice's skip-probe counts of the temporal / spatial mode (stored, not added, at the slice's end: a repeated slice pass of --slices N replaces its own)
     for (int mbi = mb_first; mbi < mb_end; mbi++) {
         MbCtx c;
         c.s = s; c.lane = lane; c.mbi = mbi; c.mbx = mbi % k.mbw; c.mby = mbi / k.mbw; c.sy = c.mby - row0; c.px = c.mbx * 16; c.py = c.mby * 16;
@@ -2924,6 +2925,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(MB_WAVES_PER
         __builtin_amdgcn_s_waitcnt(0);
         pf.mark(PH_STORE);
     }
+    if (BS && k.dscore && k.direct_auto && lane == 0) { int *d = k.dscore + ((size_t)s * nsl + blockIdx.y) * 2; d[0] = ds_t; d[1] = ds_s; }
     if (PS && k.sl_stat && lane == 0) { int *st = k.sl_stat + ((size_t)s * nsl + blockIdx.y) * 4; st[0] = intra_count - L.slw[2]; st[1] = L.slw[0]; st[2] = L.slw[1]; }
     if constexpr (RD >= 2) {
         if (k.cab_out) { uint32_t *o = k.cab_out + ((size_t)s * (k.slices > 1 ? k.slices : 1) + blockIdx.y) * 192; o[lane] = cab.a; o[64 + lane] = cab.r; o[128 + lane] = cab.r8; }
