@@ -1442,6 +1442,7 @@ static int nb_total_coeff(const x264o_encoder *e, int mi, int b)
 }
 
 /* bits of the macroblock layer of *mb (already coded into lv; neighbours from e->mbs) in a CAVLC slice */
+static void cache_block_l(actx *a, int l, int bx8, int by8, int w8, int h8, int ref, const int mv[2]);
 static int mb_bits_cavlc(actx *a, const x264gpu_mb *mb, const int16_t *lv)
 {
     x264o_encoder *e = a->e;
@@ -1449,6 +1450,58 @@ static int mb_bits_cavlc(actx *a, const x264gpu_mb *mb, const int16_t *lv)
     const int intra = mb->type <= X264GPU_MB_I16x16;
     int bits = 0, tc[24];
     memset(tc, 0, sizeof(tc));
+    const int bsl = e->slice_type == X264GPU_SLICE_B;
+    if (!intra && bsl) {
+        /* cavlc_mb_header_b ([x264-upstream] encoder/cavlc.c) as a count: mb_type ue(v) of Table 7-14, the four sub_mb_type of B_8x8 (direct 0, L0 1, L1 2,
+         * Bi 3), te(v) reference indices of list 0 then list 1, vector differences of list 0 then list 1, each over the partitions that use the list */
+        static const int8_t geom[4][4][4] = { { { 0, 0, 2, 2 } }, { { 0, 0, 2, 1 }, { 0, 1, 2, 1 } }, { { 0, 0, 1, 2 }, { 1, 0, 1, 2 } },
+                                              { { 0, 0, 1, 1 }, { 1, 0, 1, 1 }, { 0, 1, 1, 1 }, { 1, 1, 1, 1 } } };
+        static const int8_t pair_of[3][3] = { { 0, 2, 4 }, { 3, 1, 5 }, { 6, 7, 8 } };
+        if (mb->type == X264GPU_MB_B_DIRECT) bits += bs_size_ue(0);
+        else {
+            const int part = mb->partition & 3, nparts = part == D_16x16 ? 1 : part == D_8x8 ? 4 : 2;
+            int use[4];
+            for (int k = 0; k < nparts; k++) {
+                const int b8 = geom[part][k][1] * 2 + geom[part][k][0];
+                use[k] = (mb->type == X264GPU_MB_B_8x8 && ((mb->direct8 >> b8) & 1)) ? 3 : mb->ref[b8] >= 0 ? (mb->ref1[b8] >= 0 ? 2 : 0) : 1;
+            }
+            if (part == D_8x8) { bits += bs_size_ue(22); for (int k = 0; k < 4; k++) bits += bs_size_ue(use[k] == 3 ? 0 : 1 + use[k]); }
+            else if (part == D_16x16) bits += bs_size_ue(1 + use[0]);
+            else bits += bs_size_ue(4 + 2 * pair_of[use[0]][use[1]] + (part == D_8x16));
+            for (int l = 0; l < 2; l++) {
+                if (a->nref_l[l] <= 1) continue;
+                for (int k = 0; k < nparts; k++) {
+                    if (use[k] == 3 || use[k] == 1 - l) continue;
+                    const int b8 = geom[part][k][1] * 2 + geom[part][k][0], r = l ? mb->ref1[b8] : mb->ref[b8];
+                    bits += a->nref_l[l] == 2 ? 1 : bs_size_ue(r);
+                }
+            }
+            const int part_bak = a->partition, valid_bak = a->cur_valid, valid1_bak = a->cur_valid1;
+            nb_t cur_bak[4], cur1_bak[4];
+            memcpy(cur_bak, a->cur8, sizeof(cur_bak)); memcpy(cur1_bak, a->cur8b, sizeof(cur1_bak));
+            a->partition = part;
+            for (int l = 0; l < 2; l++) {
+                if (l) a->cur_valid1 = 0; else a->cur_valid = 0;
+                for (int k = 0; k < nparts; k++) {
+                    const int8_t *g = geom[part][k];
+                    const int b8 = g[1] * 2 + g[0];
+                    const int r = l ? mb->ref1[b8] : mb->ref[b8];
+                    const int mv[2] = { l ? mb->mv1[b8][0] : mb->mv[b8][0], l ? mb->mv1[b8][1] : mb->mv[b8][1] };
+                    if (!(use[k] == 3 || use[k] == 1 - l)) {
+                        int mvp[2];
+                        nb_t *cur = l ? a->cur8b : a->cur8;
+                        for (int y = g[1]; y < g[1] + g[3]; y++) for (int x = g[0]; x < g[0] + g[2]; x++) cur[y * 2 + x].ref = r;          /* cache_ref before predicting */
+                        predict_mv_l(a, l, g[0], g[1], g[2], r, mvp);
+                        bits += bs_size_se(mv[0] - mvp[0]) + bs_size_se(mv[1] - mvp[1]);
+                    }
+                    cache_block_l(a, l, g[0], g[1], g[2], g[3], r >= 0 ? r : -1, r >= 0 ? mv : NULL);          /* (a direct block's motion is in the record) */
+                }
+            }
+            a->partition = part_bak; a->cur_valid = valid_bak; a->cur_valid1 = valid1_bak; memcpy(a->cur8, cur_bak, sizeof(cur_bak)); memcpy(a->cur8b, cur1_bak, sizeof(cur1_bak));
+        }
+        bits += x264o_cavlc_cbp_bits(mb->cbp_luma | (mb->cbp_chroma << 4), 1);
+        if (e->cfg.dct8x8 && mb->cbp_luma) bits += 1;                               /* transform_size_8x8_flag (direct_8x8_inference is on) */
+    } else
     if (!intra) {
         static const int8_t geom[4][4][4] = { { { 0, 0, 2, 2 } }, { { 0, 0, 2, 1 }, { 0, 1, 2, 1 } }, { { 0, 0, 1, 2 }, { 1, 0, 1, 2 } },
                                               { { 0, 0, 1, 1 }, { 1, 0, 1, 1 }, { 0, 1, 1, 1 }, { 1, 1, 1, 1 } } };
@@ -1474,7 +1527,7 @@ static int mb_bits_cavlc(actx *a, const x264gpu_mb *mb, const int16_t *lv)
         bits += x264o_cavlc_cbp_bits(mb->cbp_luma | (mb->cbp_chroma << 4), 1);
         if (e->cfg.dct8x8 && mb->cbp_luma) bits += 1;                               /* transform_size_8x8_flag */
     } else {
-        const int off = pslice ? 5 : 0;
+        const int off = bsl ? 23 : pslice ? 5 : 0;
         if (mb->type == X264GPU_MB_I16x16) bits += bs_size_ue(off + 1 + mb->i16_mode + 4 * mb->cbp_chroma + (mb->cbp_luma ? 12 : 0));
         else {
             bits += bs_size_ue(off);
@@ -3057,7 +3110,7 @@ void x264o_macroblock(x264o_encoder *e, int mbx, int mby)
     e->b_trellis = 0;
     const x264gpu_mb *mb = &e->mbs[mby * e->mbw + mbx];
     /* diagnostics for the tests: what mb_bits_cavlc says the macroblock layer of the final macroblock takes (0 for P_SKIP: it lives in a run) */
-    if (e->mb_bits && !e->cfg.cabac) e->mb_bits[A.mi] = mb->type == X264GPU_MB_P_SKIP ? 0 : mb_bits_cavlc(&A, mb, e->levels + (size_t)A.mi * X264GPU_MB_LEVELS);
+    if (e->mb_bits && !e->cfg.cabac) e->mb_bits[A.mi] = mb->type == X264GPU_MB_P_SKIP || mb->type == X264GPU_MB_B_SKIP ? 0 : mb_bits_cavlc(&A, mb, e->levels + (size_t)A.mi * X264GPU_MB_LEVELS);
     /* CABAC RD sessions: the finished macroblock moves the slice's context states on, as its entropy coding will */
     if (e->cfg.cabac && (e->cfg.rd || e->cfg.trellis)) {
         x264o_cabac_ctx cc;

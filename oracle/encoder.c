@@ -277,7 +277,6 @@ int x264o_encoder_encode_pic(x264o_encoder *e, const uint8_t *i420, const x264gp
 {
     int slice_type = pic->slice_type;
     if (slice_type == X264GPU_SLICE_I_NONIDR) slice_type = X264GPU_SLICE_I;      /* same coding tools, the references stay */
-    if (slice_type == X264GPU_SLICE_B && e->cfg.rd && e->cfg.subme >= 7 && !e->cfg.cabac) return -1;          /* (B slices with RD: CABAC sizes only) */
     if (pic->dst < 0 || pic->dst >= e->slots) return -1;
     e->slice_type = slice_type;
     e->cur = pic->dst; e->poc = pic->poc; e->keep = pic->keep;

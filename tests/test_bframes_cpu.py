@@ -56,6 +56,9 @@ def run(w, h, types, seed, bframes=3, pyramid=1, weightp=0, pics_out=None, weigh
     (96, 80, "IBPBBPBBBPP", 42, dict(rd=0, trellis=0, subme=4, psy_rd_q8=0, cabac=0, refs=2)),
     (176, 144, "IBBPBP", 43, dict(rd=1, trellis=0, subme=6, cabac=0, partitions=0x707)),          # --subme 6: RD (CAVLC counts) in I / P slices only
     (176, 288, "IBBBPBBP", 44, dict(rd=0, trellis=0, subme=5, psy_rd_q8=0, cabac=0, slices=3, dct8x8=0)),
+    # ... and RD decisions of B slices on CAVLC bit counts (--no-cabac at subme 7 and up)
+    (176, 144, "IBBBPBBP", 51, dict(cabac=0, trellis=0)),
+    (96, 80, "IBPBBPBBBPP", 52, dict(cabac=0, trellis=0, refs=1, weightb=0, partitions=0xf07)),
     (176, 144, "IBBBPBBP", 18, dict(subme=9)),                                    # chroma-ME in B slices
     (176, 144, "IBBPBP", 19, dict(subme=9, rd=1 | 64)),                           # + deblock-aware RD
     # --subme 9 in full (i_mbrd 2 in B slices): intra_rd_refine, x264_me_refine_qpel_rd per list, x264_me_refine_bidir_rd of the bi-predicted parts

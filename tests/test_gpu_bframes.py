@@ -59,7 +59,7 @@ def run(gpu, w, h, types, seed, streams=1, bframes=3, pyramid=1, weightp=0, weig
             assert bad.size == 0, f"picture {k} (display {disp}, type {pt}) stream {s}: record of macroblock {bad[0]} differs" + describe(g_mb[s], o_mb, bad[0])
             assert np.array_equal(g_lv[s], o_lv), f"picture {k}: levels differ (macroblock {np.nonzero((g_lv[s] != o_lv).any(axis=1))[0][0]})"
             assert np.array_equal(gg.recon(s), og.recon()), f"picture {k}: reconstruction differs"
-        assert not kw["rd"] or pt <= 1 or kw["subme"] < 7 or np.array_equal(gg.cabac_states(0, max(kw.get('slices', 1), 1) - 1)[USED_CTX], og.cabac_states()[USED_CTX]), f"picture {k}: CABAC context variables differ"
+        assert not kw["rd"] or not kw["cabac"] or pt <= 1 or kw["subme"] < 7 or np.array_equal(gg.cabac_states(0, max(kw.get('slices', 1), 1) - 1)[USED_CTX], og.cabac_states()[USED_CTX]), f"picture {k}: CABAC context variables differ"
         stream += dpb.slice(mbw, mbh, pic.qp, 23, 0, 0 if cfg.deblock else 1, kw["refs"], cfg.dct8x8, g_mb[0], g_lv[0],
                             slices=(-cfg.slices if cfg.slices_plain else cfg.slices) if cfg.slices > 1 else 1)
         recons.append(gg.recon(0))
@@ -90,6 +90,12 @@ def run(gpu, w, h, types, seed, streams=1, bframes=3, pyramid=1, weightp=0, weig
     (176, 144, "IBBBPBBP", 20, dict(subme=9, rd=61)),                               # --subme 9, intra sites: intra_rd_refine of the intra macroblocks of B slices
     (176, 144, "IBBPBP", 21, dict(subme=9, rd=61 | 64, trellis=127, me_method=2)),
     (96, 80, "IBPBBP", 22, dict(subme=9, rd=61, qp_i=30)),
+    # RD decisions of B slices priced with CAVLC bit counts (x264 --no-cabac at subme 7 and up: k_mb_slice<.., 1, true>)
+    (176, 144, "IBBBPBBP", 51, dict(cabac=0, trellis=0)),
+    (96, 80, "IBPBBPBBBPP", 52, dict(cabac=0, trellis=0, refs=1, weightb=0, partitions=0xf07)),
+    (176, 144, "IBBPBP", 53, dict(cabac=0, trellis=0, me_method=2, dct8x8=0, psy_rd_q8=0, chroma_qp_offset=0)),
+    (208, 112, "IBBBPBP", 54, dict(cabac=0, trellis=0, me_method=0, refs=4, dpb=4, slices=3, slices_plain=1)),
+    (128, 96, "IBBPBBP", 55, dict(cabac=0, trellis=0, me_method=3, me_range=8, aq_mode=1, aq_strength_q8=266)),
     # --subme 9 in full: the chosen B inter type's vectors on RD cost — x264_me_refine_qpel_rd per list, x264_me_refine_bidir_rd of the bi-predicted parts (k_mb_b_rdrefine.inc)
     (176, 144, "IBBBP", 20, dict(subme=9, rd=3)),                                   # the inter site alone
     (176, 144, "IBBBPBBP", 33, dict(subme=9, rd=63 | 64)),                          # x264's subme 9: every site + deblock-aware RD

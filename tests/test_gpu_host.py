@@ -901,6 +901,8 @@ def test_every_preset_codes_a_decodable_stream(gpu, preset):
     {"subme": 4, "me": "hex", "trellis": 0, "ref": 2, "bframes": 3, "b-adapt": 1, "rc-lookahead": 6, "keyint": 12, "qp": 25, "mixed-refs": 0},       # preset faster
     {"subme": 5, "me": "hex", "trellis": 0, "ref": 2, "bframes": 3, "b-adapt": 1, "rc-lookahead": 6, "keyint": 12, "qp": 25, "no-cabac": None},      # Main profile CAVLC with B pictures
     {"subme": 2, "me": "hex", "trellis": 0, "ref": 1, "bframes": 3, "b-adapt": 1, "rc-lookahead": 4, "keyint": 10, "qp": 26, "mixed-refs": 0},
+    {"subme": 7, "me": "hex", "ref": 3, "bframes": 3, "b-adapt": 1, "rc-lookahead": 6, "keyint": 12, "crf": 25, "no-cabac": None},      # medium --no-cabac keeps its B pictures: RD on CAVLC bit counts
+    {"subme": 9, "me": "umh", "trellis": 2, "ref": 4, "bframes": 3, "b-adapt": 2, "rc-lookahead": 8, "keyint": 12, "qp": 24, "direct": "auto"},          # preset slower's analysis: subme 9
 ])
 def test_rd_refinement_session_equals_the_checker(gpu, tmp_path, opts):
     """a --subme 8 session (RD refinement of the P partitions' vectors and of the intra modes, B slices one level down) through x264_encoder_encode on
@@ -982,7 +984,7 @@ def test_random_b_sessions_equal_the_checker_sessions(gpu, tmp_path):
             if rng.random() < 0.5: opts["subme"] = int(rng.choice([1, 2, 4, 5, 6, 7, 8, 9, 9]))
             if rng.random() < 0.4: opts["direct"] = str(rng.choice(["spatial", "temporal", "auto"]))
             if rng.random() < 0.2 and opts.get("aq-mode", 1): opts["aq-mode"] = int(rng.choice([2, 3]))
-            if rng.random() < 0.15 and opts.get("subme", 7) < 7: opts["no-cabac"] = None
+            if rng.random() < 0.15 and opts.get("subme", 7) < 8: opts["no-cabac"] = None
         _session_equals_checker(tmp_path, w, h, nfr, opts, seed, scene, kind)
 
 

@@ -67,6 +67,8 @@ def random_b_case(rnd):
             if kw["me_method"] not in (1, 2):
                 kw["me_method"] = rnd.choice([1, 2])
             kw.update(subme=lvl, rd=rnd.choice([63, 63, 63 | 64, 63 | 64, 3, 61, 1 | 64, 1, 17 | 64, 9, 37]))
+        elif lvl == 7 and rnd.random() < 0.3:          # --no-cabac at subme 7: the B decisions on CAVLC bit counts
+            kw.update(subme=7, rd=1, cabac=0, trellis=0)
         elif lvl == 7:
             kw.update(subme=7, rd=rnd.choice([1, 1 | 64]) if kw["me_method"] in (1, 2) else 1)          # (deblock-aware RD lives in the refinement instantiations: hex / umh)
         elif lvl == 6:

@@ -354,7 +354,7 @@ static int encode_core(x264gpu_encoder *e, const uint8_t *d_i420, const x264gpu_
     if (slice_type == X264GPU_SLICE_I_NONIDR) slice_type = X264GPU_SLICE_I;            // same kernels; only the DPB handling differs
     const bool bslice = slice_type == X264GPU_SLICE_B;
     ARG_TRY(pic.dst >= 0 && pic.dst < e->slots && pic.qp >= 0 && pic.qp <= 51);
-    ARG_TRY(!bslice || (e->cfg.dpb > 0 && (!e->cfg.rd || e->cfg.subme < 7 || e->cfg.cabac)));      // B pictures: with RD (subme >= 7) CABAC sizes only; below, x264 analyses B slices without RD
+    ARG_TRY(!bslice || e->cfg.dpb > 0);      // B pictures: with RD (subme >= 7) CABAC sizes only; below, x264 analyses B slices without RD
     const int n0 = slice_type == X264GPU_SLICE_I ? 0 : pic.nref[0], n1 = bslice ? pic.nref[1] : 0;
     ARG_TRY(pic.qp_frac_q8 >= -128 && pic.qp_frac_q8 <= 127);
     ARG_TRY(n0 >= 0 && n0 <= 7 && n1 >= 0 && n1 <= 3 && n0 + n1 <= 8 && (slice_type == X264GPU_SLICE_I || n0 > 0) && (!bslice || n1 > 0));      // list 0: up to 5 pictures + --weightp duplicates

@@ -1452,7 +1452,7 @@ __device__ __forceinline__ void b_predict(const EncK &k, const MbCtx &c, const B
 template <int M, int ME, bool PS, int RD = 0, bool BS = false>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(MB_WAVES_PER_EU, 4))) void k_mb_slice(EncK k)
 {
-    static_assert(!BS || (PS && (RD >= 2 || RD == 0)), "B slices: RD sessions with CABAC, or the analysis without RD");
+    static_assert(!BS || PS, "B slices are inter slices");
     static_assert(RD != 7 || BS, "RD 7: B slices only");
     __shared__ __attribute__((aligned(16))) MbLds<M> L;
     // x264_me_refine_bidir: bit set of the vector quadruples already costed (4096 bits).  It lives in the chroma sub-pel staging area, which only
@@ -2825,7 +2825,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(MB_WAVES_PER
                 else if (lane < 24) { coded = cbp_chroma == 2; myl = rd_lvs + X264GPU_LV_CHROMA_AC + (lane - 16) * 16 + 1; myn = 15; }
                 else if (lane == 24) { coded = i16; myl = rd_lvs + X264GPU_LV_LUMA_DC; myn = 16; }
                 else if (lane < 27) { coded = cbp_chroma != 0; myl = rd_lvs + X264GPU_LV_CHROMA_DC + (lane - 25) * 4; myn = 4; }
-                if (rec_type == X264GPU_MB_P_SKIP) coded = false;
+                const bool skp = rec_type == X264GPU_MB_P_SKIP || rec_type == X264GPU_MB_B_SKIP;
+                if (skp) coded = false;
                 if (coded && lane < 24) for (int i = 0; i < myn; i++) my_tc += myl[i] != 0;
                 // nC: average of the left and upper blocks' totals where they exist (inside the macroblock: other lanes; outside: rd_ntc)
                 int na = -1, nb = -1;
@@ -2842,9 +2843,51 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(MB_WAVES_PER
                     }
                 }
                 const int nC = lane >= 25 ? -1 : (na >= 0 && nb >= 0 ? (na + nb + 1) >> 1 : na >= 0 ? na : nb >= 0 ? nb : 0);
-                if (rd_run && !commit && rec_type != X264GPU_MB_P_SKIP) {
+                if (rd_run && !commit && !skp) {
                     mb_bits = wave_sum(coded ? cavlc_block_bits(myl, myn, nC) : 0);
                     // header
+                    if (BS && !intra) {
+                        // cavlc_mb_header_b as a count: mb_type of Table 7-14, the sub_mb_types of B_8x8 (direct 0, L0 1, L1 2, Bi 3), te(v) reference indices
+                        // of list 0 then list 1, vector differences of list 0 then list 1, each over the partitions that use the list
+                        if (e_type == X264GPU_MB_B_DIRECT) mb_bits += 1;
+                        else {
+                            const int np = e_part == D_16x16 ? 1 : e_part == D_8x8 ? 4 : 2;
+                            auto b8_of = [&](int kp) { return e_part == D_8x8 ? kp : e_part == D_16x8 ? 2 * kp : kp; };
+                            if (e_part == D_8x8) { mb_bits += bs_size_ue_d(22); for (int kp = 0; kp < 4; kp++) { const int u = (int)((euse >> (2 * kp)) & 3); mb_bits += bs_size_ue_d(u == 3 ? 0 : 1 + u); } }
+                            else if (e_part == D_16x16) mb_bits += bs_size_ue_d(1 + (int)(euse & 3));
+                            else {
+                                const int u0 = (int)(euse & 3), u1 = (int)((e_part == D_16x8 ? euse >> 4 : euse >> 2) & 3);
+                                const int pair = u0 == 0 ? (u1 == 0 ? 0 : u1 == 1 ? 2 : 4) : u0 == 1 ? (u1 == 0 ? 3 : u1 == 1 ? 1 : 5) : 6 + u1;
+                                mb_bits += bs_size_ue_d(4 + 2 * pair + (e_part == D_8x16 ? 1 : 0));
+                            }
+                            const int sc0 = S.cref, sc1 = S.cmvx, sc2 = S.cmvy;
+                            for (int l = 0; l < 2; l++) {
+                                const int nr = l ? k.nref1 : k.nref, go = 16 * l;
+                                for (int kp = 0; kp < np; kp++) {
+                                    const int b8 = b8_of(kp), u = (int)((euse >> (2 * b8)) & 3);
+                                    if (nr > 1 && !(u == 3 || u == 1 - l)) mb_bits += nr == 2 ? 1 : bs_size_ue_d(rl(l ? ecfg.r1 : ecfg.r0, b8 * 16));
+                                }
+                                if ((lane == 5 + go || lane == 6 + go || lane == 9 + go || lane == 10 + go)) S.cref = -2;
+                                for (int kp = 0; kp < np; kp++) {
+                                    const int b8 = b8_of(kp), u = (int)((euse >> (2 * b8)) & 3), x8 = b8 & 1, y8 = b8 >> 1;
+                                    const int w8 = e_part == D_16x16 || e_part == D_16x8 ? 2 : 1, h8 = e_part == D_16x16 || e_part == D_8x16 ? 2 : 1;
+                                    const int r = rl(l ? ecfg.r1 : ecfg.r0, b8 * 16), vx = rl(l ? ecfg.x1 : ecfg.x0, b8 * 16), vy = rl(l ? ecfg.y1 : ecfg.y0, b8 * 16);
+                                    const int g0 = (y8 + 1) * 4 + x8 + 1 + go;
+                                    const bool mine = lane == g0 || (w8 == 2 && lane == g0 + 1) || (h8 == 2 && lane == g0 + 4) || (w8 == 2 && h8 == 2 && lane == g0 + 5);
+                                    if (!(u == 3 || u == 1 - l)) {
+                                        S.cref = mine ? r : S.cref;
+                                        int px, py;
+                                        mb_predict_mv(S, e_part, x8, y8, w8, r, px, py, go);
+                                        mb_bits += bs_size_se_d(vx - px) + bs_size_se_d(vy - py);
+                                    }
+                                    S.cref = mine ? (r >= 0 ? r : -1) : S.cref; S.cmvx = mine ? (r >= 0 ? vx : 0) : S.cmvx; S.cmvy = mine ? (r >= 0 ? vy : 0) : S.cmvy;
+                                }
+                            }
+                            S.cref = sc0; S.cmvx = sc1; S.cmvy = sc2;
+                        }
+                        mb_bits += cavlc_cbp_bits(cbp_luma | (cbp_chroma << 4), true);
+                        if (k.dct8x8 && cbp_luma) mb_bits += 1;
+                    } else
                     if (!intra) {
                         const int np = e_part == D_16x16 ? 1 : e_part == D_8x8 ? 4 : 2;
                         mb_bits += bs_size_ue_d(e_part) + (e_part == D_8x8 ? 4 : 0);
@@ -2868,7 +2911,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(MB_WAVES_PER
                         mb_bits += cavlc_cbp_bits(cbp_luma | (cbp_chroma << 4), true);
                         if (k.dct8x8 && cbp_luma) mb_bits += 1;
                     } else {
-                        const int off = pslice ? 5 : 0;
+                        const int off = BS ? 23 : pslice ? 5 : 0;
                         if (i16) { const int m16 = IR.pred16 > PRED16_P ? PRED16_DC : IR.pred16; mb_bits += bs_size_ue_d(off + 1 + m16 + 4 * cbp_chroma + (cbp_luma ? 12 : 0)); }
                         else {
                             mb_bits += bs_size_ue_d(off) + (k.dct8x8 ? 1 : 0);
@@ -2891,7 +2934,21 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(MB_WAVES_PER
                     dist += (((abs(e4 - fenc_e4) + abs(e8 - fenc_e8)) >> 1) * k.psy_rd_q8 * c.lambda + 128) >> 8;
                 }
                 dist += (int)(((long long)wave_sum(ssd_c) * chroma_l2off + 128) >> 8);
-                const int cost = rec_type == X264GPU_MB_P_SKIP ? dist + ((lambda2 + 128) >> 8) : dist + (int)(((long long)mb_bits * lambda2 + 128) >> 8);
+                const int cost = rec_type == X264GPU_MB_P_SKIP || rec_type == X264GPU_MB_B_SKIP ? dist + ((lambda2 + 128) >> 8) : dist + (int)(((long long)mb_bits * lambda2 + 128) >> 8);
+                if constexpr (BS) {
+                    // x264_mb_analyse_b_rd / _transform_rd / x264_intra_rd: where the candidate's cost goes (as in the CABAC instantiations)
+                    if (rd_ph == 1 || rd_ph == 7) rd_dir = cost;
+                    else if (rd_ph == 2 || rd_ph == 8) rd_l0 = cost;
+                    else if (rd_ph == 3 || rd_ph == 9) rd_l1 = cost;
+                    else if (rd_ph == 4 || rd_ph == 10) rd_bi = cost;
+                    else if (rd_ph == 11) rd_8x8 = cost;
+                    else if (rd_ph == 12) rd_16x8 = cost;
+                    else if (rd_ph == 13) rd_8x16 = cost;
+                    else if (rd_ph == 14) { if (rd_best >= cost) { if (rd_best > 0) rd_satd_inter = (int)((long long)rd_satd_inter * cost / rd_best); rd_best = cost; rd_t8 = 1; } }
+                    else if (rd_ph == 15) rd_i16 = cost;
+                    else if (rd_ph == 16) rd_i4 = cost;
+                    else if (rd_ph == 17) rd_i8 = cost;
+                } else
                 if (rd_ph == 0) {
                     rd16 = cost;
                     if (rec_type == X264GPU_MB_P_SKIP) {          // the 16x16 result is the skip vector and nothing would be coded: P_SKIP, analysis over

@@ -4,10 +4,12 @@
 
 namespace x264gpu {
 void launch_mb_slice_ref_b_hex(const EncK &k, int streams, hipStream_t st);        // mb_slice_ref_b_hex.hip
+void launch_mb_slice_b1_hex(const EncK &k, int streams, hipStream_t st);        // mb_slice_b1_hex.hip
 void launch_mb_slice_b0_hex(const EncK &k, int streams, hipStream_t st);        // mb_slice_b0_hex.hip
 void launch_mb_slice_b_hex(const EncK &k, int streams, hipStream_t st)
 {
     if (!k.rd || k.subme < 7) { launch_mb_slice_b0_hex(k, streams, st); return; }
+    if (!k.cabac) { launch_mb_slice_b1_hex(k, streams, st); return; }      // RD with CAVLC bit counts
     if (k.cabac && (k.subme >= 9 || (k.rd & 64))) { launch_mb_slice_ref_b_hex(k, streams, st); return; }      // --subme 9: the +-5 sample sub-pel neighbourhood (4 + 10 iterations) and RD refinement of the sites cfg.rd names
     if (k.trellis & 64) hipLaunchKernelGGL((k_mb_slice<2, 1, true, 4, true>), dim3(streams, k.slices > 1 ? k.slices : 1), dim3(64), 0, st, k);      // --trellis 2
     else if (k.trellis) hipLaunchKernelGGL((k_mb_slice<2, 1, true, 3, true>), dim3(streams, k.slices > 1 ? k.slices : 1), dim3(64), 0, st, k);

@@ -1,0 +1,10 @@
+// mb_slice_b1_dia.hip — the macroblock-loop kernel (k_mb.cuh) instantiated for B slices of RD sessions WITHOUT CABAC (x264 --no-cabac at --subme 7 and
+// up: the B decisions priced with CAVLC bit counts, cavlc_mb_header_b as a count), --me dia; a translation unit of its own.
+#include "k_mb.cuh"
+
+namespace x264gpu {
+void launch_mb_slice_b1_dia(const EncK &k, int streams, hipStream_t st)
+{
+    hipLaunchKernelGGL((k_mb_slice<2, 0, true, 1, true>), dim3(streams, k.slices > 1 ? k.slices : 1), dim3(64), 0, st, k);
+}
+}  // namespace x264gpu

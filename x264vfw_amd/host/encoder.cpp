@@ -453,9 +453,8 @@ x264_t *x264_encoder_open(x264_param_t *param)
     } else if (!p.b_sliced_threads) p.i_slice_count = 0;
     p.i_threads = clampi(p.i_threads, 1, 256);                 // --threads G: GOPs coded in lock-step (1 = no delay)
     if (p.i_bframe) {
-        // (below --subme 7 x264 analyses B slices without RD: k_mb_b.inc's NORD flow)
-        const char *why = !p.b_cabac && p.analyse.i_subpel_refine >= 7 ? "CABAC at subme >= 7 (the RD decisions of B slices count CABAC sizes)" :
-                          p.i_threads > 1 ? "threads 1" : p.i_keyint_max < 2 ? "keyint > 1" : (p.rc.i_rc_method == X264_RC_ABR && p.rc.i_bitrate <= 0) ? "constant-quantiser, CRF or ABR rate control with a bitrate" : nullptr;
+        // (below --subme 7 x264 analyses B slices without RD: k_mb_b.inc's NORD flow; from 7 up their RD decisions count CABAC sizes or CAVLC bits)
+        const char *why = p.i_threads > 1 ? "threads 1" : p.i_keyint_max < 2 ? "keyint > 1" : (p.rc.i_rc_method == X264_RC_ABR && p.rc.i_bitrate <= 0) ? "constant-quantiser, CRF or ABR rate control with a bitrate" : nullptr;
         if (why) { xlog(&p, X264_LOG_WARNING, "B-frames need %s in the MI355X path: bframes 0\n", why); p.i_bframe = 0; }
     }
     if (p.i_bframe) {
