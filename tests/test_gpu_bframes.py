@@ -132,7 +132,11 @@ def test_weightp_2_blind_duplicate_bitexact_and_decodable(gpu, w, h, types, seed
     assert run(gpu, w, h, types, seed, weightp=2, **over) > 0
 
 
-@pytest.mark.parametrize("streams,w,h,types,over", [(5, 176, 144, "IBBBPBBP", {}), (3, 128, 96, "IBPBBP", dict(me_method=2, trellis=127)), (4, 96, 208, "IBBPBP", dict(slices=3))])
+@pytest.mark.parametrize("streams,w,h,types,over", [(5, 176, 144, "IBBBPBBP", {}), (3, 128, 96, "IBPBBP", dict(me_method=2, trellis=127)), (4, 96, 208, "IBBPBP", dict(slices=3)),
+                                                     (4, 176, 144, "IBBBPBP", dict(subme=9, rd=63 | 64)),                      # --subme 9: the refinement coroutines per stream
+                                                     (3, 128, 96, "IBBPBP", dict(subme=9, rd=63 | 64, me_method=2, trellis=127, slices=2, slices_plain=1)),
+                                                     (4, 176, 144, "IBBBPBP", dict(cabac=0, trellis=0)),                       # RD on CAVLC bit counts in B slices
+                                                     (3, 176, 144, "IBBPBP", dict(rd=0, trellis=0, subme=5, psy_rd_q8=0))])    # B analysis without RD
 def test_b_pictures_lock_step_streams_with_distinct_content(gpu, streams, w, h, types, over):
     """the lock-step batch as the bench and the cross-session batcher use it: every stream its own content and quantisers, one launch per picture;
     each stream must equal the CPU checker's encode of that stream alone (records, levels, reconstruction)"""
