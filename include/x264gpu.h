@@ -179,7 +179,9 @@ typedef struct x264gpu_config {
     int refs;                 /* reference frames for P slices, 1..5 */
     int qp_i, qp_p;           /* constant QPs (X264_RC_CQP path, codec.c:1498-1502) */
     int me_range;             /* --merange (16) */
-    int subme;                /* --subme level: search depth 0..11; mode decision is SATD-based at every level (no RD yet: x264's subme <= 5 behaviour) */
+    int subme;                /* --subme level 0..9: the sub-pel iteration table, SATD from 2 up, chroma-ME from 5 (B slices: 9), and with `rd` the RD levels
+                               * (6 / 7 mode decision, 8 / 9 refinement; B slices analyse one level down: without RD below 7).  With rd != 0, subme >= 8 needs
+                               * cabac and --me hex / umh (the 4 + 10 sub-pel iterations live in the refinement instantiations); with B pictures so does 9 */
     int deblock;              /* 1 = in-loop filter on */
     int deblock_alpha, deblock_beta; /* --deblock a:b offsets */
     int chroma_qp_offset;
@@ -210,7 +212,10 @@ typedef struct x264gpu_config {
                                * (cabac == 0), or x264's size-only CABAC on the slice's context variables, which the device carries (cabac == 1).
                                * 1 | sites << 1 with subme 8 (CABAC sessions, --me hex / umh): RD refinement of the chosen type as well (x264 i_mbrd 2) —
                                * sites: 1 the vectors of the P partitions (x264_me_refine_qpel_rd), 2 the Intra_16x16 mode, 4 the chroma mode, 8 the
-                               * Intra_4x4 modes, 16 the Intra_8x8 modes (intra_rd_refine); x264's --subme 8 is all of them: rd = 63 */
+                               * Intra_4x4 modes, 16 the Intra_8x8 modes (intra_rd_refine); x264's --subme 8 is all of them: rd = 63.  At subme 9 site 1 also
+                               * covers B slices (x264_me_refine_qpel_rd per list, x264_me_refine_bidir_rd) and the intra sites their intra macroblocks.
+                               * + 64: deblock-aware RD (x264 h->mb.b_deblock_rdo, --subme 9 with the loop filter on): whole-macroblock RD candidates are
+                               * measured after x264_macroblock_deblock; x264's --subme 9 = 63 | 64 (cabac, --me hex / umh) */
     int psy;                  /* x264 analyse.b_psy (default on): chroma lambda offset of the RD costs */
     int psy_rd_q8;            /* x264 FIX8(--psy-rd strength) (medium: 256); enters the RD costs (subme >= 6) */
     int slices;               /* x264 --sliced-threads with --threads N: N slices per picture (0 / 1 = one), slice i = macroblock rows
