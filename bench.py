@@ -42,7 +42,7 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0   # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 TOOLSET_GAPS = "x264 medium minus the lookahead's decisions, which sessions take and a lock-step batch cannot (every stream must code the same picture type): weightp's weights for fades (the duplicate reference with offset -1 on every P picture IS in), b-adapt 1 (every run is bframes long: b-adapt 0), rate control (constant quantisers: no AQ / mbtree / lookahead); entropy coding (CABAC bitstream writing) runs on host threads and is outside `value` (inside `e2e`)"
 TOOLSET_GAPS_NOB = "x264 medium minus: B-frames (bframes 3 -> 0), the fade analysis of weightp 2; entropy coding (CABAC/CAVLC bitstream writing) runs on host threads and is outside `value` (inside `e2e`)"
-TOOLSET_GAPS_NORD = "x264 medium minus: B-frames (bframes 3 -> 0), RD mode decision + psy-rd (subme 7 -> 5), trellis 1, the fade analysis of weightp 2; entropy coding runs on host threads and is outside `value`"
+TOOLSET_GAPS_NORD = "x264 medium minus: RD mode decision + psy-rd (subme 7 -> 5), trellis 1, the lookahead's decisions (b-adapt 1, fade weights, rate control); entropy coding runs on host threads and is outside `value`"
 
 
 def parse_args():
@@ -98,7 +98,8 @@ def toolset(args):
                 t = dict(t, trellis=127)
     if args.aq:
         t = dict(t, aq_mode=1, aq_strength_q8=266)
-    if args.bframes and t.get("rd") and t.get("cabac") and args.preset != "ultrafast":
+    if args.bframes and args.preset != "ultrafast":
+        # (B slices' RD decisions count CABAC sizes or CAVLC bits; with --rd off they are analysed without RD, as x264 does below subme 7)
         t = dict(t, dpb=max(t["refs"], 4 if args.bframes > 1 else 2), weightb=1)        # x264: sps num_ref_frames = max(ref, 4 under b-pyramid, 1 + reorder depth)
     else:
         args.bframes = 0

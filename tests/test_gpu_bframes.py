@@ -258,6 +258,7 @@ def test_explicit_luma_weights_bitexact_and_decodable(gpu, types, weights, weigh
     ("IBP", dict(subme=9, rd=63 | 64)),                                                                    # x264's subme 9 on medium's other tools
     ("IBP", dict(subme=8, rd=63, refs=2, trellis=127)),
     ("IBBP", dict(subme=7, rd=1, aq_mode=1, aq_strength_q8=266)),
+    ("IBBP", dict(cabac=0, trellis=0)),                                                                    # B decisions on CAVLC bit counts
 ])
 def test_round4_paths_at_headline_size(gpu, types, over):
     """1920x1080: the paths this round added, one mini-GOP each against the CPU checker — long vectors, the 4 + 10 sub-pel iterations of subme 8 / 9 and
