@@ -78,6 +78,9 @@ def random_b_case(rnd):
         kw["direct"] = rnd.choice(["spatial", "spatial", "temporal", "auto", "auto"])
         if os.environ.get("FUZZ_BIG"):
             w, h = rnd.choice([(352, 288), (416, 240), (640, 360), (480, 272)])
+            if "slices" in kw:          # (drawn for the first size)
+                mbh = (h + 15) // 16
+                kw["slices"] = max(2, min(kw["slices"], mbh if kw.get("slices_plain") else mbh // 4))
     return w, h, types, rnd.randint(1, 10 ** 6), bframes, pyramid, weightp, kw
 
 
