@@ -876,36 +876,50 @@ __device__ __forceinline__ void load_levels_scan(const int16_t *src, int v[4], i
 template <int M>
 __device__ __forceinline__ unsigned mb_encode_i4x4_trellis(const EncK &k, MbLds<M> &L, const MbCtx &c, uint32_t cz, uint32_t t4, const Q4 &q4, const TrCtx &trc, int16_t *lvw)
 {
-    const int lane = c.lane, j = lane & 3;
+    // The blocks in ten rounds along the anti-diagonals x + 2 y instead of sixteen steps in coding order: a block's neighbours (left, top, top left, and the
+    // top right one where the coding order makes it available) lie on earlier diagonals, the search of a block reads only the slice's context variables,
+    // so the two blocks of a round are independent and share ONE search call (it takes up to eight blocks at the latency of one) — same levels, same samples.
+    const int lane = c.lane, j = lane & 3, slot = (lane >> 2) & 1;          // lanes 0..3: the round's first block, 4..7: its second
     uint8_t *tile = L.tile + IT_ORG;
     unsigned nnz4 = 0;
-    for (int idx = 0; idx < 16; idx++) {
-        const int bx = z_bx(idx), by = z_by(idx);
-        const int avail = i4_avail(c.mbx, c.sy, k.mbw, idx);
-        lds_sync();
-        uint8_t *bt = tile + by * 4 * IT_STRIDE + bx * 4;
-        pred4_build_u(L.U, bt, IT_STRIDE, avail, lane);
-        const uint32_t pr = pred4_row4(L.U, t4);
-        const uint32_t en = (uint32_t)__shfl((int)cz, idx * 4 + j);
-        const int bm = L.modes4[idx];
-        const uint32_t bp = (uint32_t)__shfl((int)pr, bm * 4 + j);
-        int e[4], p[4], v[4];
-        unpack4(en, e); unpack4(bp, p);
+    for (int t = 0; t < 10; t++) {
+        // the blocks (bx, by) with bx + 2 by == t: by from max(0, ceil((t - 3) / 2)) to min(3, t / 2); at most two
+        const int by0 = t <= 3 ? 0 : (t - 2) >> 1, nb = min(3, t >> 1) - by0 + 1;
+        int e[4] = { 0, 0, 0, 0 }, p[4] = { 0, 0, 0, 0 }, v[4];
+        uint32_t bp = 0;
+        uint8_t *bt = tile;
+        int my_idx = 0;
+        int16_t *const pair = &L.cand[0][0];          // two blocks' coefficients side by side (the search's candidate list is idle during the encode passes)
+        for (int q = 0; q < nb; q++) {
+            const int by = by0 + q, bx = t - 2 * by, idx = blkidx_of(bx, by);
+            const int avail = i4_avail(c.mbx, c.sy, k.mbw, idx);
+            lds_sync();
+            uint8_t *bq = tile + by * 4 * IT_STRIDE + bx * 4;
+            pred4_build_u(L.U, bq, IT_STRIDE, avail, lane);
+            const uint32_t pr = pred4_row4(L.U, t4);
+            const uint32_t en = (uint32_t)__shfl((int)cz, idx * 4 + j);
+            const int bm = L.modes4[idx];
+            const uint32_t bpq = (uint32_t)__shfl((int)pr, bm * 4 + j);
+            if (slot == q) { unpack4(en, e); unpack4(bpq, p); bp = bpq; bt = bq; my_idx = idx; }
+        }
 #pragma unroll
-        for (int t = 0; t < 4; t++) v[t] = e[t] - p[t];
+        for (int i = 0; i < 4; i++) v[i] = e[i] - p[i];
         dct4_quad(v, lane);
-        if (lane < 4) store_levels_scan(lvw + idx * 16, v, j);
         lds_sync();
-        trellis_run<2>(trc, lvw + idx * 16, 16, 1, c.qp, true, lane);
+        if (lane < 4 * nb) store_levels_scan(pair + slot * 16, v, j);
         lds_sync();
-        load_levels_scan(lvw + idx * 16, v, j);
+        trellis_run<2>(trc, pair, 16, nb, c.qp, true, lane);
+        lds_sync();
+        load_levels_scan(pair + slot * 16, v, j);
+        if (lane < 4 * nb) store_levels_scan(lvw + my_idx * 16, v, j);
         const bool nz = quad_or((v[0] | v[1] | v[2] | v[3]) != 0 ? 1 : 0) != 0;
         dequant4_row(v, q4, j);
         idct4_quad(v, lane);
 #pragma unroll
-        for (int t = 0; t < 4; t++) v[t] += p[t];
-        if (lane < 4) *(uint32_t *)(bt + j * IT_STRIDE) = nz ? pack4_clip(v) : bp;
-        if (__builtin_amdgcn_readfirstlane((int)nz)) nnz4 |= 1u << idx;
+        for (int i = 0; i < 4; i++) v[i] += p[i];
+        if (lane < 4 * nb) *(uint32_t *)(bt + j * IT_STRIDE) = nz ? pack4_clip(v) : bp;
+        const unsigned long long bal = __ballot(nz && j == 0 && lane < 4 * nb);
+        for (int q = 0; q < nb; q++) if ((bal >> (4 * q)) & 1) { const int by = by0 + q; nnz4 |= 1u << blkidx_of(t - 2 * by, by); }
     }
     lds_sync();
     return nnz4;
