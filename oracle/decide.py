@@ -5,14 +5,15 @@ a second time, independently of that code, in plain Python over the CPU checker'
 tests/oracle_lib.OracleSlicetype), so that a session's decisions can be compared with something other than themselves:
 
   [x264-upstream] encoder/slicetype.c  x264_slicetype_decide (keyint / min-keyint, closed GOPs, the run of B pictures), x264_slicetype_analyse with
-                                       --b-adapt 0 / 1 (the cost comparisons and thresholds of the "fast" B decision), scenecut / scenecut_internal
+                                       --b-adapt 0 / 1 (the cost comparisons and thresholds of the "fast" B decision) / 2 (slicetype_path, slicetype_path_cost:
+                                       the Viterbi search over the lengths of the window, i_delay = max(bframes, 3) * 4), scenecut / scenecut_internal
                                        (the bias growing with the distance from the last keyframe, the flash test under B pictures)
   [x264-upstream] encoder/ratecontrol.c  rate_estimate_qscale for CRF (short-term complexity blur, get_qscale, the I picture after P pictures taking the
                                        running P quantiser / ipratio, the very first picture), the B quantiser from its nearest references (+ pbratio
                                        offsets, half for a B-reference), accum_p_qp_update, x264_ratecontrol_start's rounding
 
 Restated from memory of upstream like the rest of oracle/ (libx264 is not in the reference tree): parity unpinned.  Out of this twin's reach (not
-restated here): --b-adapt 2's trellis, macroblock-tree, weight analysis, AQ-weighted costs, ABR feedback, 2-pass.
+restated here): macroblock-tree, weight analysis, AQ-weighted costs, ABR feedback, 2-pass.
 """
 import math
 
@@ -142,6 +143,18 @@ class Lookahead:
                 fr[num_frames].type = P
                 while num_bframes < num_frames and fr[num_bframes + 1].type == B:
                     num_bframes += 1
+            elif p.b_adapt == 2:
+                # B_ADAPT_TRELLIS ([x264-upstream] encoder/slicetype.c slicetype_path / slicetype_path_cost): a Viterbi search over the lengths of the window —
+                # the best path of every length built from the best paths of the shorter ones + a run of 0 .. bframes B pictures closed by a P
+                if num_frames > 1:
+                    best_paths = {0: "", 1: "P"}
+                    for length in range(2, num_frames + 1):
+                        self.path(fr, length, best_paths)
+                    best = best_paths[num_frames % 17]
+                    num_bframes = len(best) - len(best.lstrip("B"))
+                    for j in range(1, num_frames):
+                        fr[j].type = B if best[j - 1] == "B" else P
+                fr[num_frames].type = P
             else:
                 num_bframes = min(num_frames - 1, p.bframes)
                 for j in range(1, num_frames):
@@ -178,6 +191,65 @@ class Lookahead:
         # the types beyond the first run are decided again when their turn comes
         for j in range(reset_start, framecnt + 1):
             fr[j].type = AUTO
+
+    def path_cost(self, fr, path, threshold):
+        """slicetype_path_cost: the frame costs of the pictures along a path ('P' / 'B' / 'I' for frames 1 ..), given up once above the best so far"""
+        p = self.p
+        cost, loc, cur_nonb, n = 0, 1, 0, len(path)
+        while loc <= n:
+            next_nonb = loc
+            while next_nonb <= n and path[next_nonb - 1] == "B":
+                next_nonb += 1
+            if next_nonb > n:
+                break
+            cost += self.cost(fr, cur_nonb, next_nonb, next_nonb) if path[next_nonb - 1] == "P" else self.cost(fr, next_nonb, next_nonb, next_nonb)
+            if cost > threshold:
+                break
+            if p.b_pyramid and next_nonb - cur_nonb > 2:
+                middle = cur_nonb + (next_nonb - cur_nonb) // 2
+                cost += self.cost(fr, cur_nonb, next_nonb, middle)
+                for nb in range(loc, middle):
+                    if cost >= threshold:
+                        break
+                    cost += self.cost(fr, cur_nonb, middle, nb)
+                for nb in range(middle + 1, next_nonb):
+                    if cost >= threshold:
+                        break
+                    cost += self.cost(fr, middle, next_nonb, nb)
+            else:
+                for nb in range(loc, next_nonb):
+                    if cost >= threshold:
+                        break
+                    cost += self.cost(fr, cur_nonb, next_nonb, nb)
+            loc = next_nonb + 1
+            cur_nonb = next_nonb
+        return cost
+
+    def path(self, fr, length, best_paths):
+        """slicetype_path: the cheapest way to code frames 1 .. length, ending in a run of 0 .. bframes B pictures and a P"""
+        p = self.p
+        best_cost, best_possible, best = 1 << 62, 0, None
+        for run in range(min(p.bframes + 1, length)):
+            ln = length - (run + 1)
+            cand = list(best_paths[ln % 17][:ln] + "B" * run + "P")
+            possible = 1
+            for i in range(1, length + 1):
+                t = fr[i].type
+                if t == AUTO:
+                    continue
+                if t in (B, BREF):
+                    possible = possible and (i < ln or i == length or cand[i - 1] == "B")
+                else:
+                    possible = possible and (i < ln or cand[i - 1] != "B")
+                    cand[i - 1] = "I" if t in (I, IDR) else "P"
+            cand = "".join(cand)
+            if possible or not best_possible:
+                if possible and not best_possible:
+                    best_cost = 1 << 62
+                c = self.path_cost(fr, cand, best_cost)
+                if c < best_cost:
+                    best_cost, best_possible, best = c, possible, cand
+        best_paths[length % 17] = best
 
     def decide(self, flushing, wait):
         """x264_slicetype_decide: -> (index of the picture closing the first run, its type) or None while more input is needed"""
@@ -291,6 +363,8 @@ def run_session(frames, params, costs, slots):
     p = params
     la, rc = Lookahead(p, costs), RateControl(p)
     wait = p.bframes                                    # h->frames.i_delay without macroblock-tree: the run length
+    if p.b_adapt == 2 and p.bframes:
+        wait = max(p.bframes, 3) * 4                    # ... B_ADAPT_TRELLIS: the window of its path search
     out = []
     kept = {}                                           # display index -> (type, float qp) of the pictures kept as references
 

@@ -40,6 +40,8 @@ def host_session(tmp_path, w, h, n, seed, opts):
     (176, 144, 36, 5, 0, "static", ["crf=22", "keyint=16", "b-adapt=1"], dict(crf=22.0, keyint=16)),                       # static content: runs of three B pictures, the keyint limit
     (208, 112, 30, 7, 11, "moving", ["crf=26", "keyint=25", "b-adapt=0", "bframes=2"], dict(crf=26.0, keyint=25, b_adapt=0, bframes=2)),
     (176, 144, 28, 9, 9, "moving", ["crf=23", "keyint=40", "bframes=0", "weightp=2", "ref=3"], dict(crf=23.0, keyint=40, bframes=0)),   # no B pictures: P and scene cuts only
+    (176, 144, 34, 13, 12, "moving", ["crf=24", "keyint=40", "b-adapt=2"], dict(crf=24.0, keyint=40, b_adapt=2)),                  # presets slower and up: the Viterbi search over the window
+    (176, 144, 30, 15, 0, "static", ["crf=23", "keyint=30", "b-adapt=2", "bframes=5", "b-pyramid=none"], dict(crf=23.0, keyint=30, b_adapt=2, bframes=5, b_pyramid=0)),
     (176, 144, 32, 11, 0, "static", ["crf=25", "keyint=250", "b-pyramid=none", "ipratio=1.6", "pbratio=1.5", "qcomp=0.7"],
      dict(crf=25.0, keyint=250, b_pyramid=0, ip_factor=1.6, pb_factor=1.5, qcomp=0.7)),
 ])
