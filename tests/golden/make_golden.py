@@ -37,7 +37,13 @@ CASES = [("p176x144", 176, 144, 5, {}), ("p208x120_q30", 208, 120, 3, dict(qp_i=
                                                         chroma_qp_offset=-2, trellis=127))]
 MEDIUM_B = dict(refs=3, dpb=4, weightb=1, partitions=7, dct8x8=1, chroma_me=1, mixed_refs=1, cabac=1, rd=1, subme=7, psy=1, psy_rd_q8=256, chroma_qp_offset=-2, trellis=63)
 # (name, w, h, display-order types, seed, weightp, config overrides): mini-GOPs through the product's DPB model (host/dpb.hpp) and oracle encode_pic
-B_CASES = [("b176x144_medium_weightp2", 176, 144, "IBBBPBBBP", 5, 2, {}), ("b128x96_ref5_umh", 128, 96, "IBBPBP", 7, 0, dict(refs=5, dpb=5, me_method=2))]
+B_CASES = [("b176x144_medium_weightp2", 176, 144, "IBBBPBBBP", 5, 2, {}), ("b128x96_ref5_umh", 128, 96, "IBBPBP", 7, 0, dict(refs=5, dpb=5, me_method=2)),
+           # round 4's paths: x264 --subme 9 (RD refinement in B slices, deblock-aware RD), B analysis without RD, RD on CAVLC counts, temporal direct / direct auto
+           ("b176x144_subme9_refine", 176, 144, "IBBBPBBP", 33, 0, dict(subme=9, rd=63 | 64)),
+           ("b176x144_subme5_without_rd", 176, 144, "IBBBPBBP", 21, 0, dict(rd=0, trellis=0, subme=5, psy_rd_q8=0)),
+           ("b176x144_rd_on_cavlc_counts", 176, 144, "IBBBPBBP", 51, 0, dict(cabac=0, trellis=0)),
+           ("b128x96_direct_temporal", 128, 96, "IBBBPBBBP", 11, 0, dict(_direct="temporal")),
+           ("b128x96_direct_auto_subme8", 128, 96, "IBBBPBBBP", 11, 0, dict(_direct="auto", subme=8, rd=63))]
 
 
 def sha(a):
@@ -60,12 +66,14 @@ def b_case(w, h, types, seed, weightp, over):
     import bgop
     import host_lib as HL
     kw = dict(MEDIUM_B, **over)
+    direct = kw.pop("_direct", "spatial")
     cfg = O.default_config(w, h, **kw)
     enc = O.OracleEncoder(cfg)
     pics = []
-    stream, recons, order, pocs = bgop.encode_gop(HL, enc, synth_frames(w, h, len(types), seed=seed), types, cfg, 20, 23, 25, kw["refs"], 3, 1, weightp, pics)
+    stream, recons, order, pocs = bgop.encode_gop(HL, enc, synth_frames(w, h, len(types), seed=seed), types, cfg, 20, 23, 25, kw["refs"], 3, 1, weightp, pics, None, direct)
     return {"stream": sha(np.frombuffer(bytes(stream), dtype=np.uint8)), "bytes": len(stream), "order": [list(o) for o in order],
-            "per_picture": [{"mb": sha(m.view(np.uint8)), "recon": sha(r), "types": np.bincount(m["type"], minlength=11).tolist()} for (_, m), r in zip(pics, recons)]}
+            "per_picture": [{"mb": sha(m.view(np.uint8)), "recon": sha(r), "types": np.bincount(m["type"], minlength=11).tolist()}
+                            for (_, m), r in zip([e for e in pics if len(e) == 2], recons)]}          # (--direct auto also logs its mode choices there)
 
 
 def slicetype_case():

@@ -47,7 +47,8 @@ def test_pipeline_golden(case):
         assert sha(enc.recon()) == exp["recon"], f"frame {i} recon"
 
 
-@pytest.mark.parametrize("case", ["b176x144_medium_weightp2", "b128x96_ref5_umh"])
+@pytest.mark.parametrize("case", ["b176x144_medium_weightp2", "b128x96_ref5_umh", "b176x144_subme9_refine", "b176x144_subme5_without_rd", "b176x144_rd_on_cavlc_counts",
+                                  "b128x96_direct_temporal", "b128x96_direct_auto_subme8"])
 def test_bframes_golden(case):
     """B mini-GOPs of the headline toolset (spatial direct, two-list searches, implicit weights, B RD decision, --weightp 2's duplicate) through the
     product's DPB model and host CABAC writer: records, reconstruction and the written stream against the committed hashes"""
