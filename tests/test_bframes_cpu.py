@@ -167,6 +167,30 @@ def test_host_session_with_b_pictures(tmp_path):
         assert psnr(d[:w * h], frames[p // 2][:w * h]) > 34.0
 
 
+@pytest.mark.parametrize("opts,expect", [
+    (["preset=slower", "qp=24", "keyint=20", "ref=4"], dict(subme=9, cabac=1, badapt=2, direct=3)),          # x264's slower: subme 9, b-adapt 2, direct auto, umh, trellis 2
+    (["no-cabac", "qp=24", "keyint=20", "b-adapt=1", "rc-lookahead=8"], dict(subme=7, cabac=0, badapt=1, direct=1)),      # medium --no-cabac keeps its B pictures (RD on CAVLC counts)
+])
+def test_host_session_levels_opened_this_round(tmp_path, opts, expect):
+    """sessions at the levels round 4 opened — preset slower as asked (--subme 9: RD refinement in B slices, deblock-aware RD) and medium without CABAC
+    with its B pictures — through x264_encoder_encode over the stand-in device: the effective parameters say so, B pictures are coded, and the
+    stream decodes to every source picture"""
+    import subprocess
+    subprocess.check_call(["make", "-s", "-C", __file__.rsplit("/", 1)[0] + "/stub"])
+    n, w, h = 14, 128, 96
+    info, stream = _host_b_session(tmp_path, n, opts, w, h, seed=6)
+    for k, v in expect.items():
+        assert info[k] == v, (k, info[k], v)
+    assert info["bframes"] == 3 and any(r[0] in (4, 5) for r in info["recs"]), "B pictures expected"
+    dec = O.h264_decode(stream, n, w, h)
+    assert len(dec) == n
+    frames = synth_frames(w, h, n, seed=6)
+    from synth import psnr
+    order = [r[1] for r in info["recs"]]
+    assert sorted(order) == list(range(n))
+    assert min(psnr(dec[k][:w * h], frames[order[k]][:w * h]) for k in range(n)) > 30.0
+
+
 def test_host_session_weightp_2_without_b_pictures(tmp_path):
     """--bframes 0 --weightp 2: the session runs on the DPB model with no delay (dts = pts, POC type 2), P pictures carry pred_weight_table and
     the duplicate; --weightp 1 (fade analysis only) and sessions that need the other path (mbtree) report weightp 0"""
