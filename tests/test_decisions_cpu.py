@@ -63,3 +63,33 @@ def test_decisions_equal_the_twin(tmp_path, w, h, n, seed, scene, kind, opts, kw
     for k, ((f, t, qp, qpf), pic) in enumerate(zip(twin, pics)):
         assert pic.qp == qp, f"coded picture {k} (display {f}, type {t}): quantiser {pic.qp} vs the twin's {qp} ({qpf:.3f})"
         assert abs(pic.qp + pic.qp_frac_q8 / 256.0 - qpf) <= 1.0 / 256 + 1e-9, (k, pic.qp, pic.qp_frac_q8, qpf)
+
+
+def test_fade_weights_are_the_fades_ratio(tmp_path):
+    """known answer for x264_weights_analyse as the host restates it: on a clip that fades to black by 5 % of the first picture's level a picture
+    (luma scaled, chroma scaled towards 128) a P picture's explicit weight of reference 0 must be the ratio of the two pictures' fade levels —
+    luma scale / 2^denom within 2 % and a small offset; chroma the same ratio with the offset that keeps 128 where it is"""
+    w, h, n, fade = 176, 144, 13, 5
+    info, pics = host_session(tmp_path, w, h, n, 3, ["qp=24", "keyint=60", f"fade={fade}", "bframes=3", "no-mbtree", "aq-mode=0", "weightp=2"])      # (medium's lookahead: b-adapt 1, scenecut)
+    level = lambda i: max(0.0, 1.0 - i * fade / 100.0)
+    checked = 0
+    for k, pic in enumerate(pics):
+        if pic.slice_type != 0 or not pic.nref[0]:          # P pictures (X264GPU_SLICE_P = 0)
+            continue
+        disp = info["recs"][k][1]
+        # reference 0 of a P picture: the I / P picture coded last before it
+        ref = [info["recs"][j][1] for j in range(k) if info["recs"][j][0] in (1, 2, 3)][-1]
+        want = level(disp) / level(ref)
+        wl = pic.wl0[0]
+        assert wl.on, f"picture {disp}: no luma weight on a {100 * (1 - want):.0f} % darker picture"
+        got = wl.scale / float(1 << wl.denom)
+        assert abs(got - want) < 0.02 * want and abs(wl.offset) <= 2, (disp, got, want, wl.offset)
+        wc = pic.wc0[0]
+        for c in range(2):
+            if wc.on[c]:
+                gc = wc.scale[c] / float(1 << wc.denom)
+                # (the chroma planes of this clip are nearly flat: the scale is a coarse estimate, the offset must still keep grey grey)
+                assert abs(gc - want) < 0.08 * want and abs(wc.offset[c] - 128 * (1 - gc)) <= 3, (disp, c, gc, want, wc.offset[c])
+        checked += 1
+    assert checked >= 2
+
