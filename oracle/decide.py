@@ -20,12 +20,20 @@ import math
 AUTO, IDR, I, P, BREF, B = 0, 1, 2, 3, 4, 5
 
 
+# [x264-upstream] encoder/ratecontrol.c qp2qscale / qscale2qp are single-float functions (powf / log2f): the C library's own, through ctypes
+import ctypes as _C
+_libm = _C.CDLL("libm.so.6")
+_libm.powf.restype = _C.c_float; _libm.powf.argtypes = [_C.c_float, _C.c_float]
+_libm.log2f.restype = _C.c_float; _libm.log2f.argtypes = [_C.c_float]
+_f = lambda x: _C.c_float(x).value
+
+
 def qp2qscale(qp):
-    return 0.85 * 2.0 ** ((qp - 12.0) / 6.0)
+    return _f(_f(0.85) * _libm.powf(2.0, _f(_f(_f(qp) - _f(12.0)) / _f(6.0))))
 
 
 def qscale2qp(qscale):
-    return 12.0 + 6.0 * math.log2(qscale / 0.85)
+    return _f(_f(12.0) + _f(_f(6.0) * _libm.log2f(_f(_f(qscale) / _f(0.85)))))
 
 
 class Params:

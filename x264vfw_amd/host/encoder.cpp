@@ -277,6 +277,10 @@ static void batch_leave(BatchGroup *g, int s)
     }
 }
 
+// [x264-upstream] encoder/ratecontrol.c qp2qscale / qscale2qp: single floats (powf / log2f), as x264 has them
+static inline double rc_qp2qscale(double qp) { return (double)(0.85f * powf(2.0f, ((float)qp - 12.0f) / 6.0f)); }
+static inline double rc_qscale2qp(double qscale) { return (double)(12.0f + 6.0f * log2f((float)qscale / 0.85f)); }
+
 static void xlog(const x264_param_t *p, int level, const char *fmt, ...)
 {
     if (!p->pf_log || level > p->i_log_level) return;
@@ -698,7 +702,7 @@ x264_t *x264_encoder_open(x264_param_t *param)
     }
     if (h->crf || h->abr) {
         // x264_ratecontrol_new: rate_factor_constant = base_cplx^(1 - qcomp) / qp2qscale(crf), base_cplx = mbs * (bframes ? 120 : 80)
-        auto qp2qscale = [](double q) { return 0.85 * pow(2.0, (q - 12.0) / 6.0); };
+        auto qp2qscale = [](double q) { return rc_qp2qscale(q); };
         h->rc.qcompress = p.rc.f_qcompress; h->rc.ip_factor = fabs(p.rc.f_ip_factor) > 0 ? fabs(p.rc.f_ip_factor) : 1.0;
         h->rc.ip_offset = 6.0 * log2(h->rc.ip_factor);
         if (p.rc.b_mb_tree) h->rc.qcompress = 1.0;                     // x264_ratecontrol_new: the tree does the complexity weighting, CRF shifts by 13.5 (1 - qcomp)
@@ -982,8 +986,8 @@ static int rc_pick_qp(x264_t *h, bool is_i, const int32_t costs[4], int frames_d
     // rate_estimate_qscale: q = rceq / rate_factor; rceq = blurred_complexity^(1 - qcomp), or under macroblock-tree (which does the
     // complexity weighting itself) the frame-duration term alone; an I picture after P pictures takes the running P quantiser /
     // ipratio; the quantiser is qscale2qp(q) rounded, within [qpmin, qpmax]
-    auto qp2qscale = [](double q) { return 0.85 * pow(2.0, (q - 12.0) / 6.0); };
-    auto qscale2qp = [](double qs) { return 12.0 + 6.0 * log2(qs / 0.85); };
+    auto qp2qscale = [](double q) { return rc_qp2qscale(q); };
+    auto qscale2qp = [](double qs) { return rc_qscale2qp(qs); };
     const double satd = is_i ? costs[0] : costs[1];
     h->rc.cplxsum = h->rc.cplxsum * 0.5 + satd / h->rc.dur_ratio;
     h->rc.cplxcount = h->rc.cplxcount * 0.5 + 1.0;
@@ -1132,7 +1136,7 @@ static int encode_queued(x264_t *h, x264_nal_t **pp_nal, int *pi_nal, x264_pictu
         // x264_ratecontrol_end: what this picture's bits say about the rate factor, and the bits the window now expects
         const double bits = 8.0 * (double)h->out.size();
         h->rc.total_bits += bits;
-        h->rc.cplxr_sum += bits * (0.85 * pow(2.0, (h->rc.qpa_last - 12.0) / 6.0)) / h->rc.last_rceq;
+        h->rc.cplxr_sum += bits * rc_qp2qscale(h->rc.qpa_last) / h->rc.last_rceq;
         h->rc.wanted_bits_window += h->rc.bitrate / h->rc.fps;
     }
     h->frames_since_idr++;
@@ -1623,8 +1627,8 @@ static bool bmode_decide(x264_t *h, bool flushing)
 
 // ---- 2-pass rate control (x264 ratecontrol.c: x264_ratecontrol_new's statistics parser, init_pass2, get_qscale / get_diff_limited_q,
 //      qscale2bits; no VBV, no zones, no macroblock-tree file: the tree is off in these sessions) ----
-static double p2_qp2qscale(double q) { return 0.85 * pow(2.0, (q - 12.0) / 6.0); }
-static double p2_qscale2qp(double qs) { return 12.0 + 6.0 * log2(qs / 0.85); }
+static double p2_qp2qscale(double q) { return rc_qp2qscale(q); }
+static double p2_qscale2qp(double qs) { return rc_qscale2qp(qs); }
 static double p2_qscale2bits(const x264_t::Pass2Entry &e, double qscale)
 {
     if (qscale < 0.1) qscale = 0.1;
@@ -1990,7 +1994,7 @@ static int encode_bmode(x264_t *h, x264_nal_t **pp_nal, int *pi_nal, x264_pictur
         const double bits = (double)h->out.size() * 8.0, pb = fabs(p.rc.f_pb_factor) > 0 ? fabs(p.rc.f_pb_factor) : 1.0;
         const bool is_b = pl.type == PIC_B || pl.type == PIC_BREF;
         h->rc.total_bits += bits;
-        h->rc.cplxr_sum += bits * (0.85 * pow(2.0, (qpf - 12.0) / 6.0)) / (h->rc.last_rceq * (is_b ? pb : 1.0));
+        h->rc.cplxr_sum += bits * rc_qp2qscale(qpf) / (h->rc.last_rceq * (is_b ? pb : 1.0));
         h->rc.wanted_bits_window += h->rc.bitrate / h->rc.fps;
     }
     BPHASE(3);
