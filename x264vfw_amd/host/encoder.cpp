@@ -393,6 +393,7 @@ x264_t *x264_encoder_open(x264_param_t *param)
     // the fade analysis that produces other weights — x264_weights_analyse, all that --weightp 1 does — is not implemented)
     p.analyse.i_weighted_pred = clampi(p.analyse.i_weighted_pred, X264_WEIGHTP_NONE, X264_WEIGHTP_SMART); p.analyse.b_weighted_bipred = p.analyse.b_weighted_bipred != 0;
     p.analyse.b_transform_8x8 = p.analyse.b_transform_8x8 != 0;
+    if (p.analyse.inter & X264_ANALYSE_PSUB8x8) xlog(&p, X264_LOG_WARNING, "partitions p4x4 (8x4 / 4x8 / 4x4 searches inside P_8x8) are not implemented in the MI355X path: p8x8 stays, p4x4 off\n");
     p.analyse.inter &= X264_ANALYSE_I4x4 | X264_ANALYSE_I8x8 | X264_ANALYSE_PSUB16x16 | X264_ANALYSE_BSUB16x16; p.analyse.intra &= X264_ANALYSE_I4x4 | X264_ANALYSE_I8x8;
     if (!p.analyse.b_transform_8x8) { p.analyse.inter &= ~X264_ANALYSE_I8x8; p.analyse.intra &= ~X264_ANALYSE_I8x8; }   // as x264 validate_parameters
     p.analyse.i_trellis = clampi(p.analyse.i_trellis, 0, 2);          // settled below, once the sub-pel level is known
@@ -501,12 +502,17 @@ x264_t *x264_encoder_open(x264_param_t *param)
     // driver's default session) when one GOP is in flight; ABR and CRF under --threads > 1 map to their nominal quantiser
     int qp = p.rc.i_rc_method == X264_RC_CQP ? p.rc.i_qp_constant : p.rc.i_rc_method == X264_RC_CRF ? (int)(p.rc.f_rf_constant + 0.5f) : 26;
     h->crf = p.rc.i_rc_method == X264_RC_CRF && p.rc.f_rf_constant >= 1.0f;       // also under --threads G: its quantisers follow from the lookahead costs alone
-    h->abr = p.rc.i_rc_method == X264_RC_ABR && p.i_threads <= 1 && p.rc.i_bitrate > 0 && !p.rc.b_stat_read;      // single pass, no VBV
     // 2-pass: the second pass plans every picture's quantiser from the first pass' statistics; sessions on the DPB model (B pictures or --weightp 2)
     h->pass2 = p.rc.b_stat_read && p.rc.i_rc_method == X264_RC_ABR && p.rc.i_bitrate > 0 && p.i_threads <= 1 && h->dpbmode && p.rc.psz_stat_in && !getenv("X264GPU_BATCH");
     h->pass1 = p.rc.b_stat_write && !p.rc.b_stat_read && p.i_threads <= 1 && h->dpbmode && p.rc.psz_stat_out && !getenv("X264GPU_BATCH");
-    if ((p.rc.b_stat_read && !h->pass2) || (p.rc.b_stat_write && !p.rc.b_stat_read && !h->pass1))
-        xlog(&p, X264_LOG_WARNING, "2-pass statistics need threads 1 and B-frames or weightp 2 (the DPB-model path) in the MI355X path: this pass runs without them\n");
+    if ((p.rc.b_stat_read && !h->pass2) || (p.rc.b_stat_write && !p.rc.b_stat_read && !h->pass1)) {
+        // a pass whose statistics cannot be honoured keeps its rate control: it runs as the single-pass session of the same method (ABR at i_bitrate
+        // for the driver's multipass encodes, codec.c:1509-1527), as every pass did before 2-pass existed here — not at a constant quantiser
+        xlog(&p, X264_LOG_WARNING, "2-pass statistics need threads 1 and B-frames or weightp 2 (the DPB-model path) in the MI355X path: this pass runs as a single pass without them\n");
+        if (!h->pass2) p.rc.b_stat_read = 0;
+        if (!h->pass1) p.rc.b_stat_write = 0;
+    }
+    h->abr = p.rc.i_rc_method == X264_RC_ABR && p.i_threads <= 1 && p.rc.i_bitrate > 0 && !p.rc.b_stat_read;      // single pass, no VBV
     if (p.rc.b_stat_write && p.rc.b_stat_read) xlog(&p, X264_LOG_INFO, "updating the statistics in the second pass is not implemented: they stay as the first pass wrote them\n");
     if (p.rc.i_rc_method != X264_RC_CQP && !h->crf && !h->abr && !h->pass2) xlog(&p, X264_LOG_WARNING, "this rate control mode is not implemented yet (ABR with --threads > 1): constant qp %d\n", qp);
     if (qp < 1) { xlog(&p, X264_LOG_WARNING, "lossless is not supported: qp 1\n"); qp = 1; }
