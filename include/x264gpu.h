@@ -92,6 +92,12 @@ int x264gpu_mc_avg(const uint8_t *d_a, const uint8_t *d_b, size_t bytes, int wei
  * slice.  d_levels receives the levels in the same layout, d_nz one byte per block.  The macroblock loop does not use it yet (cfg.trellis). */
 int x264gpu_trellis_blocks(const int16_t *d_coefs, int nblk, int cat, int qp, int intra, const uint8_t *d_states460, int16_t *d_levels, uint8_t *d_nz, void *stream);
 int x264gpu_mc_weight(const uint8_t *d_src, size_t bytes, int scale, int denom, int offset, uint8_t *d_out, void *stream);
+/* The level walk of the CABAC size pricing as a primitive ([x264-upstream] encoder/cabac.c coeff_abs_level_minus1 of residual_block_cabac, every block of a
+ * macroblock at once — csrc/cabac_rd.cuh cab_levels_all): n cases; d_levels the macroblocks' levels in x264gpu_mb layout (X264GPU_MB_LEVELS each);
+ * d_what five ints a case: luma category (2 = 4x4, 5 = 8x8, 1 = Intra_16x16 AC, -1 none), mask of luma blocks, of chroma AC blocks (plane * 4 + block), of
+ * chroma DC planes, luma DC flag; d_r / d_r8 the role-indexed context registers (64 lanes a case, csrc/cabac_layout.cuh) in, d_r_out / d_r8_out out;
+ * d_bits the bits in 1/256 (sign and escape bypass bins included).  tests/test_gpu_prims.py checks it against a serial restatement. */
+int x264gpu_cabac_level_walk(const int16_t *d_levels, const int32_t *d_what, int n, const uint32_t *d_r, const uint32_t *d_r8, uint32_t *d_r_out, uint32_t *d_r8_out, int32_t *d_bits, void *stream);
 
 /* ---- input colourspace conversion to I420 -----------------------------------------
  * Replaces the x264vfw_csp_function_t table the driver installs for an I420 encoder (/root/reference/csp.c:436-487,

@@ -277,3 +277,16 @@ def test_explicit_weights_at_headline_size(gpu):
 
 def test_b_pictures_multistream(gpu):
     run(gpu, 96, 80, "IBBBPBBP", 11, streams=3)
+
+
+@pytest.mark.parametrize("w,h,types,seed,over", [
+    (128, 96, "IBBPBP", 14, dict(trellis=63 + 64, me_method=2)),                    # umh + trellis 2 + B: the instantiation HISTORY.md §9 kept at -O2 through round 4
+    (128, 96, "IBBPBP", 14, dict(trellis=63, me_method=2, subme=9, rd=63 | 64)),    # ... and the refinement one
+    (176, 144, "IBBBP", 5, {}),                                                     # the headline instantiation
+])
+def test_every_simd_doubly_occupied_streams_stay_identical(gpu, w, h, types, seed, over):
+    """2304 streams of the SAME content in one launch: more wavefronts than the 1024 SIMDs of an MI355X, so that every SIMD holds two of them and the
+    macroblock loops run interleaved — the regime in which round 4 saw CABAC context variables go wrong after a chroma trellis call in an -O3 build
+    of the umh B instantiation (an occupancy-dependent result is the signature of a race or a hazard, not of the arithmetic).  Every stream must equal
+    the CPU checker, hence every other stream."""
+    run(gpu, w, h, types, seed, streams=2304, **over)

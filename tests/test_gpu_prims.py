@@ -368,3 +368,31 @@ def test_trellis_primitive_vs_oracle(gpu, cat, qp, intra):
     assert len(bad) == 0, f"{len(bad)} of {nblk} blocks differ; first {bad[0]}: coefs {coefs_scan[bad[0]].tolist()} device {got[bad[0]].tolist()} oracle {want[bad[0]].tolist()}"
     np.testing.assert_array_equal(d_z.cpu().numpy(), want_nz)
     assert np.count_nonzero(want) > nblk          # the cases are not trivial
+
+
+def test_cabac_level_walk_primitive_vs_serial_restatement(gpu):
+    """the level walk of the CABAC pricing (csrc/cabac_rd.cuh cab_levels_all: every block of a macroblock at once, one chain per context) against the
+    block-by-block, bin-by-bin restatement of x264's coder (tests/cabac_levels_ref.py): same bits, same context variables — every luma category,
+    chroma DC / AC, sparse and dense blocks, levels into the escape range, partial block masks"""
+    import torch
+    import cabac_levels_ref as R
+    lib = gpu
+    cases = R.random_cases(1500, 0xcab)
+    n = len(cases)
+    lv = np.array([c[0] for c in cases], np.int16)
+    what = np.array([[c[1]["cat0"], c[1]["nz0"], c[1]["nzac"], c[1]["nzdc"], c[1]["ldc"]] for c in cases], np.int32)
+    pack = lambda rows: np.array([[b[0] | (b[1] << 8) | (b[2] << 16) | (b[3] << 24) for b in r] for r in rows], np.uint32)
+    r_in, r8_in = pack([c[2] for c in cases]), np.array([c[3] for c in cases], np.uint32)
+    r_want, r8_want = pack([c[4] for c in cases]), np.array([c[5] for c in cases], np.uint32)
+    bits_want = np.array([c[6] for c in cases], np.int32)
+    d = lambda a: torch.from_numpy(a.copy()).cuda()
+    d_lv, d_w, d_r, d_r8 = d(lv), d(what), d(r_in.view(np.int32)), d(r8_in.view(np.int32))
+    d_ro, d_r8o, d_b = torch.zeros_like(d_r), torch.zeros_like(d_r8), torch.zeros(n, dtype=torch.int32, device="cuda")
+    lib.check(lib.x264gpu_cabac_level_walk(d_lv.data_ptr(), d_w.data_ptr(), n, d_r.data_ptr(), d_r8.data_ptr(), d_ro.data_ptr(), d_r8o.data_ptr(), d_b.data_ptr(), None), "cabac_level_walk")
+    torch.cuda.synchronize()
+    got_b, got_r, got_r8 = d_b.cpu().numpy(), d_ro.cpu().numpy().view(np.uint32), d_r8o.cpu().numpy().view(np.uint32)
+    bad = np.nonzero(got_b != bits_want)[0]
+    assert len(bad) == 0, f"bits differ in {len(bad)} of {n} cases; first {bad[0]}: what {what[bad[0]].tolist()} device {got_b[bad[0]]} serial {bits_want[bad[0]]}"
+    badr = np.nonzero((got_r != r_want).any(axis=1) | (got_r8 != r8_want).any(axis=1))[0]
+    assert len(badr) == 0, f"context variables differ in {len(badr)} of {n} cases; first {badr[0]}: what {what[badr[0]].tolist()}"
+    assert bits_want.max() > 100000 and (what[:, 0] == 5).sum() > 100

@@ -42,7 +42,7 @@ def main():
     f = lib._lib.x264gpu_encoder_mb_prof
     f.restype = C.c_int
     f.argtypes = [C.c_void_p, C.c_void_p]
-    out = np.zeros((S, 16), dtype=np.uint64)
+    out = np.zeros((S, 32), dtype=np.uint64)
     print("%-4s %10s " % ("pic", "cyc/MB") + " ".join("%9s" % p[:9] for p in PH[:16]))
     from x264vfw_amd import gop, host_api as HL
     from x264vfw_amd.lib import Pic
@@ -63,6 +63,10 @@ def main():
         a = out.astype(np.float64).mean(axis=0) / n
         tot = a[:13].sum() + (a[15] if a[15] > 100 else 0)          # -DMB_PROF_RD builds: slot 15 = cycles of the CABAC pricing (RD sessions)
         print("%-4s %10.0f " % ("IIPRb"[pt] + str(disp), tot) + " ".join("%9.0f" % v for v in a[:13]) + " %9.2f %9.2f %9.2f" % (a[13], a[14], a[15]) + "   %.1f ms" % e0.elapsed_time(e1))
+        if a[16] > 0:         # -DMB_PROF_RD: inside the CABAC pricing (cabac_rd.cuh), per macroblock
+            print("     cab_mb calls %.2f  header %.0f  cbf+sigmaps %.0f  levels: prep %.0f walk %.0f rest %.0f cycles;  walk steps %.1f  non-zero coefficients %.1f" % (a[16], a[17], a[18], a[22], a[23], a[19], a[20], a[21]))
+        if a[24] > 0:
+            print("     inter encode: prediction (b_predict) %.0f  luma transform / quantiser / reconstruction %.0f  chroma %.0f cycles" % (a[24], a[25], a[26]))
         mx = out[:, :13].sum(axis=1).astype(np.float64)
         print("     slowest/mean stream cycles: %.3f   share: " % (mx.max() / mx.mean()) + " ".join("%8.1f%%" % (100 * v / tot) for v in a[:13]))
 

@@ -113,66 +113,231 @@ __device__ __forceinline__ void cab_step(int &st, int &f8v, uint32_t model, bool
     st = mine ? (ns << 1) | nm : st;
 }
 
-// the levels of a block, last coefficient first: coefficient i in lane i of coef, mask = its non-zero positions; q = this lane's
-// coeff_abs_level_minus1 context (0..9), or anything else.  x264's node contexts: c1 = bin 0, cg = the bins after it.
-__device__ __forceinline__ void cab_levels(Cab &cb, int &st, uint32_t model, int coef, unsigned long long mask, int q)
+// ---- coeff_abs_level_minus1 of EVERY block of a macroblock (or part) in one walk ----
+// The bins a coefficient sends depend, besides the context variables, only on its own block: x264's node (how many ones / greater-than-ones were
+// coded before it, i.e. at the higher scan positions) picks the context c1 of its first bin and the context cg of the bins after it.  The arithmetic
+// model only cares about the order of bins WITHIN a context and bits add, so the walk goes CONTEXT BY CONTEXT instead of coefficient by coefficient,
+// and a context's chain is wave-uniform scalar code over ballot masks — no trip through the LDS crossbar per bin:
+//   * per word of 64 coefficient slots (four 4x4 blocks or one 8x8 block of luma, the blocks of one chroma plane, a DC block; slot order = coding
+//     order: blocks ascending, scan positions descending) every lane looks at its slot's coefficient and works out its node with two ballots;
+//   * a c1 context's bins are the "level > 1" flags of ITS coefficients (a ballot mask): the bins equal to the context's more probable symbol form runs
+//     that cost a difference of prefix sums over the states (lane s of the model register IS state s) and move the state up by their length — one
+//     step per LESS probable symbol, not per bin;
+//   * a cg context's bins are the unary strings of its coefficients above one: a run of ones on a context whose more probable symbol is one is the
+//     same closed form.
+// Measured before this form (tools/mb_prof.py, -DMB_PROF_RD): one step per coefficient through ds_bpermute cost 400 - 660 cycles a coefficient.
+struct CabLv {
+    int cat0;                // luma category of the blocks below: 2 (4x4), 5 (8x8), 1 (the AC blocks of an Intra_16x16), -1 none
+    unsigned nz0;            // luma blocks with coefficients (bit = block; 8x8: bit = 8x8 block)
+    unsigned nzac;           // chroma AC blocks with coefficients (bit = plane * 4 + block)
+    unsigned nzdc;           // chroma DC blocks with coefficients (bit = plane)
+    bool ldc;                // the luma DC block of an Intra_16x16 has coefficients
+};
+
+// inclusive prefix sum of v over the wavefront's 64 lanes (DPP: row_shr 1 / 2 / 4 / 8 inside each row of sixteen, then row_bcast:15 into rows 1 and 3 and
+// row_bcast:31 into rows 2 and 3; lanes without a source add the identity)
+__device__ __forceinline__ int wave_scan_add(int v)
 {
-    // What a coefficient's bins depend on besides the context variables — x264's node (how many ones / greater-than-ones were coded before it,
-    // i.e. at the higher scan positions) — is a function of the block alone: every lane works it out for ITS coefficient with two ballots and
-    // two population counts, adds the bypass bins (sign, escape suffix) to its own share of the bits, and packs what the serial walk needs;
-    // the walk itself is then one lane read and the context steps per non-zero coefficient.
-    int pkv;
-    {
-        const int ln = (int)__lane_id(), av = abs(coef);
-        const unsigned long long m1 = __ballot(av == 1), mg = __ballot(av > 1);
-        const unsigned long long above = ln < 63 ? ~((2ull << ln) - 1) : 0ull;
-        const int ngt = __builtin_popcountll(mg & above), n1 = __builtin_popcountll(m1 & above);
-        const int node = ngt == 0 ? min(n1, 3) : min(3 + ngt, 7);
-        const int c1 = node < 4 ? node + 1 : 0, cg = node < 4 ? 5 : node + 2;
-        // sign: one bypass bin; escape: Exp-Golomb order 0 of a - 15 = 2 floor(log2(a - 14)) + 1 bypass bins
-        cb.f8v += av ? 256 + (av >= 15 ? 256 * (2 * (31 - __builtin_clz(av - 14)) + 1) : 0) : 0;
-        pkv = c1 | (cg << 4) | (min(av, 15) << 8);
-    }
-    while (mask) {
-        const int i = 63 - __builtin_clzll(mask);
-        mask ^= 1ull << i;
-        const int pk = __builtin_amdgcn_readlane(pkv, i);
-        const int c1 = pk & 15, cg = (pk >> 4) & 15, a = pk >> 8;                       // a: min(|level|, 15)
-        const int ones = a - 2, nb = a > 1 ? (a < 15 ? a - 1 : 13) : 0;                 // bins on cg: `ones` ones, then a zero unless the escape follows
-        cab_step(st, cb.f8v, model, q == c1 || (a > 1 && q == cg), q == c1 ? a > 1 : a > 2);
-        if (ones >= 3) {
-            // a run of ones on cg.  While a one is that context's less probable symbol it is stepped; from then on every bin moves the state up
-            // by one (to 62 at most) and costs what the model says for the state it leaves: lane s of the model register IS state s, so the
-            // lanes of the states passed through add their own entry to their own share of the bits — no step per bin
-            int run = ones - 1;
-            const int owner = __builtin_ctzll(__ballot(q == cg));
-            int so = __builtin_amdgcn_readlane(st, owner);
-            while (run > 0 && !(so & 1)) { cab_step(st, cb.f8v, model, q == cg, 1); so = __builtin_amdgcn_readlane(st, owner); run--; }
-            if (run > 0) {
-                const int sg = so >> 1, hi = min(sg + run - 1, 62), extra = max(sg + run - 1 - 62, 0), ln = (int)__lane_id();
-                cb.f8v += ln >= sg && ln <= hi ? (int)(model & 0x1ff) * (ln == 62 ? 1 + extra : 1) : 0;
-                st = q == cg ? (min(sg + run, 62) << 1) | 1 : st;
-            }
-            if (a < 15) cab_step(st, cb.f8v, model, q == cg, 0);
-        } else
-            for (int kb = 1; kb < nb; kb++) cab_step(st, cb.f8v, model, q == cg, kb < ones);
-    }
+    v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, false);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, false);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, false);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, false);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, false);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, false);
+    return v;
+}
+__device__ __forceinline__ int cab_mbcnt(unsigned long long m) { return (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u)); }
+
+// The chain table (prim_kernels.hip cabac_chain_table): entry ((2^k - 1) + pattern) * 128 + variable = what k = 0..8 bins (first bin = bit 0 of the
+// pattern) leave of a context variable (bits 0..6) and what they cost (1/256 bit, above); k = 0: the variable itself, no cost
+#define CAB_CHAIN_ENTRIES (511 * 128)
+// v_writelane_b32: a wave-uniform value into ONE lane of a register.  This clang has no builtin for it; the lane is an inline constant (two scalar
+// registers in one VALU instruction would break the constant-bus limit).  gfx940+ needs two wait states between a VALU write of an SGPR / VCC (the
+// v_cmp behind a ballot) and a VALU read of it, and the compiler's hazard recogniser does not look inside inline assembly — measured on MI355X:
+// without the s_nop the lane receives what the register held BEFORE the compare (HISTORY.md §9)
+template <int LN>
+__device__ __forceinline__ void cab_writelane3(unsigned &lo, unsigned &hi, int &n, unsigned long long val, int nval)
+{
+    asm("s_nop 1\n\tv_writelane_b32 %0, %3, %6\n\tv_writelane_b32 %1, %4, %6\n\tv_writelane_b32 %2, %5, %6"
+        : "+v"(lo), "+v"(hi), "+v"(n) : "s"((unsigned)val), "s"((unsigned)(val >> 32)), "s"(nval), "n"(LN));
+}
+// one context's chain, wave-uniform: state index sg, more probable symbol mps, bits into f8
+struct CabChain { int sg, mps; };
+// n bins equal to the more probable symbol: every bin moves the state up by one (to 62 at most) and costs what the model says for the state it leaves
+__device__ __forceinline__ void cab_run_mps(CabChain &c, int &f8, int cumv, int m62, int n)
+{
+    const int hi = min(c.sg + n, 62);
+    f8 += __builtin_amdgcn_readlane(cumv, hi) - __builtin_amdgcn_readlane(cumv, c.sg) + (c.sg + n - hi) * m62;
+    c.sg = hi;
+}
+// one bin of the less probable symbol
+__device__ __forceinline__ void cab_one_lps(CabChain &c, int &f8, uint32_t model)
+{
+    const uint32_t t = (uint32_t)__builtin_amdgcn_readlane((int)model, c.sg);
+    f8 += (int)((t >> 9) & 0x7ff);
+    c.mps ^= c.sg == 0 ? 1 : 0;
+    c.sg = (int)(t >> 20);
 }
 
-// residual_block_cabac of a block of category CAT (0 luma DC, 1 luma AC, 2 luma 4x4, 3 chroma DC, 4 chroma AC): coefficient i (scan order)
-// in lane i of coef, zero elsewhere; the block holds a non-zero coefficient.  st = this lane's context variable of that category.
+// the "level > 1" flags of the coefficients whose node picks context 0 .. 4, each context's compacted into a bit string: every member pushes its flag
+// to the lane of its rank among the members (ds_permute; non-members push a zero to lane 63 — a member of rank 63 exists only when every lane is
+// one), a ballot reads the string off, and it goes into lane LANE0 + V.  The five pushes go out together (one trip's latency, not five)
+template <int LANE0, class PROF>
+__device__ __forceinline__ void cab_strings_c1(int a, int c1, unsigned &blo, unsigned &bhi, int &N, PROF &pf)
+{
+    unsigned long long cur[5];
+    int pushed[5];
+#pragma unroll
+    for (int v = 0; v < 5; v++) {
+        const bool member = a != 0 && c1 == v;
+        cur[v] = __ballot(member);
+        pushed[v] = __builtin_amdgcn_ds_permute((member ? cab_mbcnt(cur[v]) : 63) << 2, member && a > 1 ? 1 : 0);
+    }
+    if (cur[0]) { pf.count(20); cab_writelane3<LANE0 + 0>(blo, bhi, N, __ballot(pushed[0] != 0), __builtin_popcountll(cur[0])); }
+    if (cur[1]) { pf.count(20); cab_writelane3<LANE0 + 1>(blo, bhi, N, __ballot(pushed[1] != 0), __builtin_popcountll(cur[1])); }
+    if (cur[2]) { pf.count(20); cab_writelane3<LANE0 + 2>(blo, bhi, N, __ballot(pushed[2] != 0), __builtin_popcountll(cur[2])); }
+    if (cur[3]) { pf.count(20); cab_writelane3<LANE0 + 3>(blo, bhi, N, __ballot(pushed[3] != 0), __builtin_popcountll(cur[3])); }
+    if (cur[4]) { pf.count(20); cab_writelane3<LANE0 + 4>(blo, bhi, N, __ballot(pushed[4] != 0), __builtin_popcountll(cur[4])); }
+}
+// the unary strings of the coefficients above one on context V (.. 9), laid end to end: all ones but for the zero that ends the string of a level below
+// fifteen.  Where a string starts is a prefix sum of the lengths; every member with a closing zero pushes a flag to the lane of that zero's position
+// and a ballot gives the zeros — when the word's strings fit 63 bins (else: bit V - 5 of `serial`)
+template <int LANE0, int V, class PROF>
+__device__ __forceinline__ void cab_strings_cg(int a, int a15, int cg, unsigned &blo, unsigned &bhi, int &N, unsigned long long &serial, PROF &pf)
+{
+    const bool member = a > 1 && cg == V;
+    if (__ballot(member)) {
+        pf.count(20);
+        const int incl = wave_scan_add(member ? (a15 < 15 ? a15 - 1 : 13) : 0);
+        const int total = __builtin_amdgcn_readlane(incl, 63);
+        if (total <= 63) {
+            const bool closes = member && a15 < 15;
+            const int pushed = __builtin_amdgcn_ds_permute((closes ? incl - 1 : 63) << 2, closes ? 1 : 0);      // (the zero is the string's last bin)
+            cab_writelane3<LANE0 + V>(blo, bhi, N, ((1ull << total) - 1ull) & ~__ballot(pushed != 0), total);
+        } else serial |= 1ull << (V - 5);
+    }
+    if constexpr (V < 9 && LANE0 + V + 1 < 64) cab_strings_cg<LANE0, V + 1>(a, a15, cg, blo, bhi, N, serial, pf);
+}
+
+template <class PROF>
+__device__ __forceinline__ void cab_levels_all(Cab &cb, uint32_t model, int lane, const int16_t *lvs, const CabLv &W, const uint32_t *ctab, PROF &pf)
+{
+    if (W.cat0 < 0 && !W.nzac && !W.nzdc && !W.ldc) return;
+    const int cumv = wave_scan_add((int)(model & 0x1ff)) - (int)(model & 0x1ff);          // lane s: the more probable symbol's cost summed over the states below s
+    const int m62 = (int)(__builtin_amdgcn_readlane((int)model, 62) & 0x1ff);
+    int f8 = 0;
+    // one group of blocks that share their ten contexts: its words of 64 slots one after the other.  a_of(w): this lane's |level| in word w (0: no
+    // coefficient); gshift: log2 of the slots of a block; the contexts sit in lanes lane0 + q of register reg, byte sh
+    auto group = [&](auto a_of, int nwords, unsigned wordmask, int gshift, uint32_t &reg, int sh, auto lane0_tag, int bac, int ncm1, int sigbase, int lastbase) {
+        constexpr int LANE0 = decltype(lane0_tag)::value;
+        for (int w = 0; w < nwords; w++) {
+            if (!((wordmask >> w) & 1u)) continue;
+            const int a = a_of(w);
+            const unsigned long long nzm = __ballot(a != 0);
+            if (!nzm) continue;
+            const unsigned long long m1 = __ballot(a == 1), mg = nzm & ~m1;
+            int ngt, n1;                     // coded before this coefficient: the lower slots of its block
+            if (gshift == 6) { ngt = cab_mbcnt(mg); n1 = cab_mbcnt(m1); }
+            else {
+                const int base = lane & ~((1 << gshift) - 1);
+                const unsigned sel = (1u << (lane - base)) - 1u;
+                ngt = __builtin_popcount((unsigned)(mg >> base) & sel); n1 = __builtin_popcount((unsigned)(m1 >> base) & sel);
+            }
+            const int node = ngt == 0 ? min(n1, 3) : min(3 + ngt, 7);
+            const int c1 = node < 4 ? node + 1 : 0, cg = node < 4 ? 5 : node + 2;
+            // sign: one bypass bin; escape: Exp-Golomb order 0 of a - 15 = 2 floor(log2(a - 14)) + 1 bypass bins
+            cb.f8v += a ? 256 + (a >= 15 ? 256 * (2 * (31 - __builtin_clz(a - 14)) + 1) : 0) : 0;
+            const int a15 = min(a, 15);
+            pf.count(21, __builtin_popcountll(nzm));
+            // ---- the ten contexts' bin strings, each into the lane that holds the context (lane0 + q): B = the bins (first = bit 0), N = how many ----
+            unsigned blo = 0, bhi = 0; int N = 0;
+            cab_strings_c1<LANE0>(a, c1, blo, bhi, N, pf);
+            unsigned long long serial = 0;                   // the cg contexts (bit q - 5) whose strings do not fit a word: coded coefficient by coefficient below
+            if (mg) cab_strings_cg<LANE0, 5>(a, a15, cg, blo, bhi, N, serial, pf);
+            // ---- the significance map (4x4-type blocks; an 8x8 block's positions share contexts: cab_block8): position p of a block has its own
+            //      significant_coeff_flag context (lane sigbase + p) and last_significant_coeff_flag context (lane lastbase + p), so a context sees one
+            //      bin a block at most — every such lane appends ITS bin of each block of the word, straight from the word's non-zero mask ----
+            if (ncm1) {
+                const int nslots = 1 << gshift;
+                const bool is_s = lane >= sigbase && lane < sigbase + ncm1, is_l = lane >= lastbase && lane < lastbase + ncm1;
+                const int pp = is_s ? lane - sigbase : lane - lastbase;                      // the position (AC blocks: of the coefficients after the DC)
+                const int sbit = min(max(nslots - 1 - (pp + bac), 0), 31);                  // my coefficient's slot inside a block's field of the mask
+                for (int j = 0; j < (gshift == 4 ? 4 : gshift == 2 ? 2 : 1); j++) {
+                    const unsigned field = (unsigned)(nzm >> (j * nslots)) & ((1u << nslots) - 1u);
+                    if (!field) continue;
+                    const int lastp = nslots - 1 - __builtin_ctz(field) - bac;              // the block's last non-zero position
+                    const unsigned nzb = (field >> sbit) & 1u;
+                    const bool cond = is_s ? pp <= lastp : is_l && nzb && pp <= lastp;
+                    const unsigned bit = is_s ? nzb : (pp == lastp ? 1u : 0u);
+                    blo |= cond ? bit << N : 0u; N += cond ? 1 : 0;
+                }
+            }
+            // ---- every context lane walks ITS string through the chain table, eight bins a lookup; the lanes' lookups go out together ----
+            {
+                int st = (int)((reg >> sh) & 255u);
+                unsigned long long B = ((unsigned long long)bhi << 32) | blo;
+                while (__ballot(N > 0)) {
+                    const int k = min(N, 8);
+                    const uint32_t e = ctab[((((1 << k) - 1) + ((int)(unsigned)B & ((1 << k) - 1))) << 7) + st];
+                    st = (int)(e & 127u); cb.f8v += (int)(e >> 7);
+                    B >>= k; N -= k;
+                }
+                reg = (reg & ~(255u << sh)) | ((uint32_t)st << sh);
+            }
+            // ---- (rare) a cg context with more than 63 bins in one word: its coefficients one by one ----
+            for (int v = 5; serial && v < 10; v++) {
+                if (!((serial >> (v - 5)) & 1ull)) continue;
+                unsigned long long cur = __ballot(a > 1 && cg == v);
+                const int stv = (__builtin_amdgcn_readlane((int)reg, LANE0 + v) >> sh) & 255;
+                CabChain c = { stv >> 1, stv & 1 };
+                while (cur) {
+                    pf.count(20);
+                    const int f = __builtin_ctzll(cur);
+                    cur &= cur - 1ull;
+                    const int av = __builtin_amdgcn_readlane(a15, f);
+                    int ones = av - 2;                                   // (15 - 2 = the 13 ones of the escape)
+                    while (ones > 0) {
+                        if (c.mps) { cab_run_mps(c, f8, cumv, m62, ones); ones = 0; }
+                        else { cab_one_lps(c, f8, model); ones--; }
+                    }
+                    if (av != 15) { if (c.mps) cab_one_lps(c, f8, model); else cab_run_mps(c, f8, cumv, m62, 1); }
+                }
+                const uint32_t nst = (uint32_t)((c.sg << 1) | c.mps);
+                reg = lane == LANE0 + v ? (reg & ~(255u << sh)) | (nst << sh) : reg;
+            }
+        }
+    };
+    const int g = lane >> 4, q = lane & 15;
+    if (W.cat0 == 5)
+        group([&](int w) { const int pos = 63 - lane; return abs((int)lvs[(w * 4 + (pos & 3)) * 16 + (pos >> 2)]); }, 4, W.nz0 & 15u, 6, cb.r8, 0, std::integral_constant<int, 32>{}, 0, 0, 0, 0);
+    else if (W.cat0 >= 0) {
+        const bool ac = W.cat0 == 1;
+        const unsigned wm = ((W.nz0 & 0xfu) ? 1u : 0u) | ((W.nz0 & 0xf0u) ? 2u : 0u) | ((W.nz0 & 0xf00u) ? 4u : 0u) | ((W.nz0 & 0xf000u) ? 8u : 0u);
+        group([&](int w) { const int blk = 4 * w + g, pos = 15 - q; return ((W.nz0 >> blk) & 1u) && !(ac && pos == 0) ? abs((int)lvs[blk * 16 + pos]) : 0; }, 4, wm, 4, cb.r, ac ? 8 : 0, std::integral_constant<int, 32>{}, ac ? 1 : 0, ac ? 14 : 15, 0, 16);
+    }
+    if (W.ldc) group([&](int) { return lane < 16 ? abs((int)lvs[X264GPU_LV_LUMA_DC + 15 - lane]) : 0; }, 1, 1u, 4, cb.r, 24, std::integral_constant<int, 32>{}, 0, 15, 0, 16);
+    if (W.nzdc) group([&](int) { return lane < 8 && ((W.nzdc >> (lane >> 2)) & 1u) ? abs((int)lvs[X264GPU_LV_CHROMA_DC + (lane >> 2) * 4 + 3 - (lane & 3)]) : 0; }, 1, 1u, 2, cb.r, 24, std::integral_constant<int, 55>{}, 0, 3, 48, 52);
+    if (W.nzac) {
+        const unsigned wm = ((W.nzac & 0xfu) ? 1u : 0u) | ((W.nzac & 0xf0u) ? 2u : 0u);
+        group([&](int w) { const int blk = 4 * w + g, pos = 15 - q; return ((W.nzac >> blk) & 1u) && pos ? abs((int)lvs[X264GPU_LV_CHROMA_AC + blk * 16 + pos]) : 0; }, 2, wm, 4, cb.r, 16, std::integral_constant<int, 32>{}, 1, 14, 0, 16);
+    }
+    cb.f8 += f8;
+}
+
+// residual_block_cabac of a block of category CAT (0 luma DC, 1 luma AC, 2 luma 4x4, 3 chroma DC, 4 chroma AC) up to its levels (cab_levels_all
+// codes those for the whole macroblock): the significance map.  Coefficient i (scan order) in lane i of coef, zero elsewhere; the block holds a
+// non-zero coefficient.  st = this lane's context variable of that category.
 template <int CAT>
 __device__ __forceinline__ void cab_block4(Cab &cb, int &st, uint32_t model, int lane, int coef)
 {
     constexpr int n1 = CAT == 3 ? 3 : (CAT == 1 || CAT == 4) ? 14 : 15;
-    constexpr int sig0 = CAT == 3 ? 48 : 0, last0 = CAT == 3 ? 52 : 16, abs0 = CAT == 3 ? 55 : 32;
+    constexpr int sig0 = CAT == 3 ? 48 : 0, last0 = CAT == 3 ? 52 : 16;
     const unsigned long long mask = __ballot(coef != 0);
     const int last = 63 - __builtin_clzll(mask);
     const bool is_s = lane >= sig0 && lane < sig0 + n1, is_l = lane >= last0 && lane < last0 + n1;
     const int p = is_s ? lane - sig0 : lane - last0;
     const int nzp = (int)((mask >> (p & 63)) & 1);
     cab_step(st, cb.f8v, model, (is_s && p <= last) || (is_l && nzp && p <= last), is_s ? nzp : p == last);
-    cab_levels(cb, st, model, coef, mask, lane - abs0);
 }
 
 static __constant__ const unsigned long long c_cabac_pos8[24] = {
@@ -195,7 +360,6 @@ __device__ __forceinline__ void cab_block8(Cab &cb, int &st, uint32_t model, int
         cab_step(st, cb.f8v, model, have, lane < 15 ? (int)((mask >> i) & 1) : i == last);
         mine &= ~(1ull << i);
     }
-    cab_levels(cb, st, model, coef, mask, lane - 32);
 }
 
 // what the coder needs to know about the macroblock and its neighbours (all wave-uniform)
@@ -262,10 +426,12 @@ __device__ __forceinline__ void cab_mvd(Cab &cb, uint32_t model, int lane, int b
 // The macroblock layer.  S: the motion cache (neighbours + search results; partitions are cached into it as they are coded and it is
 // restored before returning); lvs: the macroblock's levels (LDS); modes4 / modes8 / nmodes: intra modes (LDS).  Returns the |mvd| bytes of
 // the macroblock's 8x8 blocks (zero for intra / skip) and the mb_qp_delta it sent through dqp_out.
+template <class PROF>
 __device__ __forceinline__ unsigned long long cab_mb(Cab &cb, uint32_t model, int lane, const CabIn &in, MeState &S, const int16_t *lvs,
                                                      const uint8_t *modes4, const uint8_t *modes8, const uint8_t *nmodes, int mbx, int sy, int &dqp_out,
-                                                     unsigned long long &amvd1_out)
+                                                     unsigned long long &amvd1_out, const uint32_t *ctab, PROF &pf)
 {
+    pf.begin2(); pf.count(16);
     amvd1_out = 0;
     unsigned long long amvd = 0;
     dqp_out = 0;
@@ -473,6 +639,7 @@ __device__ __forceinline__ unsigned long long cab_mb(Cab &cb, uint32_t model, in
         cab_bin(cb, model, lane, 60 + ctx, 0);
         dqp_out = dqp;
         }
+        pf.mark2(17);
         const int un = intra ? 1 : 0;
         // neighbour terms of the coded_block_flag contexts
         auto luma_in = [&](int bx, int by) { return in.pm ? (int)((in.pm_nnzc >> blkidx_of(bx, by)) & 1) : cab_luma_cbf_of(in.type, in.cbp_luma, in.t8, in.nnz, bx, by); };
@@ -500,17 +667,20 @@ __device__ __forceinline__ unsigned long long cab_mb(Cab &cb, uint32_t model, in
             return a + 2 * b;
         };
         // residual: the category's context variables are this lane's byte of r (r8 for 8x8 blocks) for the duration of its blocks
+        // (the levels of every block are coded at the end, all categories side by side: W collects which blocks hold coefficients)
+        CabLv W = { -1, 0u, 0u, 0u, false };
+        auto flush_levels = [&]() { pf.mark2(18); cab_levels_all(cb, model, lane, lvs, W, ctab, pf); pf.mark2(19); W.cat0 = -1; W.nz0 = 0; W.nzac = 0; W.nzdc = 0; W.ldc = false; };
         auto blocks = [&](auto cat_tag, int shift, int nblk, auto coef_of, auto inc_of, auto coded) {
             constexpr int CAT = decltype(cat_tag)::value;
-            int st = (cb.r >> shift) & 255;
+            static_assert(CAT == 0 || CAT == 3, "the DC categories");
+            (void)shift;
             for (int b = 0; b < nblk; b++) {
                 if (!coded(b)) continue;
                 const int coef = coef_of(b);
                 const bool nz = __ballot(coef != 0) != 0;
                 cab_bin(cb, model, lane, 85 + CAT * 4 + inc_of(b), nz);
-                if (nz) cab_block4<CAT>(cb, st, model, lane, coef);
+                if (nz) { if (CAT == 0) W.ldc = true; else W.nzdc |= 1u << b; }          // (the block itself: cab_levels_all)
             }
-            cb.r = (cb.r & ~(255u << shift)) | ((uint32_t)st << shift);
         };
         auto always = [](int) { return true; };
         // The same for the many-block categories (luma 4x4, luma AC, chroma AC), faster: the coded_block_flags of the blocks are known up front
@@ -541,12 +711,8 @@ __device__ __forceinline__ unsigned long long cab_mb(Cab &cb, uint32_t model, in
                 const uint32_t v = (uint32_t)__builtin_amdgcn_readlane(stc, j);
                 cb.a = lane == li ? (cb.a & ~(255u << sh)) | (v << sh) : cb.a;
             }
-            int st = (cb.r >> shift) & 255;
-            for (unsigned long long m = nzm; m; m &= m - 1) {
-                const int b = __builtin_ctzll(m);
-                cab_block4<CAT>(cb, st, model, lane, coef_of(b));
-            }
-            cb.r = (cb.r & ~(255u << shift)) | ((uint32_t)st << shift);
+            (void)coef_of; (void)shift;          // (the blocks themselves — significance maps and levels — are coded by cab_levels_all at the end)
+            if (CAT == 4) W.nzac |= (unsigned)nzm; else { W.cat0 = CAT; W.nz0 |= (unsigned)nzm; }
         };
         if (i16) {
             blocks(std::integral_constant<int, 0>{}, 24, 1, [&](int) { return lane < 16 ? (int)lvs[X264GPU_LV_LUMA_DC + lane] : 0; }, [&](int) { return dc_inc(24); }, always);
@@ -559,6 +725,7 @@ __device__ __forceinline__ unsigned long long cab_mb(Cab &cb, uint32_t model, in
             for (int i8 = 0; i8 < 4; i8++)
                 if (((in.cbp_luma & pmask) >> i8) & 1) cab_block8(cb, st, model, lane, (int)lvs[(i8 * 4 + (lane & 3)) * 16 + (lane >> 2)], in.size);
             cb.r8 = (uint32_t)st;
+            W.cat0 = 5; W.nz0 = (unsigned)(in.cbp_luma & pmask);
         } else {
             unsigned coded = ((in.cbp_luma & 1) ? 0x000fu : 0) | ((in.cbp_luma & 2) ? 0x00f0u : 0) | ((in.cbp_luma & 4) ? 0x0f00u : 0) | ((in.cbp_luma & 8) ? 0xf000u : 0);
             if (in.pm == 1) coded &= (0xfu << (4 * in.pm_b0)) | (in.pm_b1 >= 0 ? 0xfu << (4 * in.pm_b1) : 0u);
@@ -571,12 +738,14 @@ __device__ __forceinline__ unsigned long long cab_mb(Cab &cb, uint32_t model, in
                 const int b8 = t ? in.pm_b1 : in.pm_b0;
                 if (b8 < 0) continue;
                 blocks_many(std::integral_constant<int, 4>{}, 16, 8, (1u << b8) | (16u << b8), (in.nnz >> 16) & 0xffu, [&](int k) { return lane < 15 ? (int)lvs[X264GPU_LV_CHROMA_AC + k * 16 + 1 + lane] : 0; }, [&](int k) { return ac_inc((k >> 2) & 1, k & 3); });
+                flush_levels();          // (U then V of this 8x8 block before the next one's: the planes share their contexts, the walk goes plane by plane)
             }
         } else if (in.cbp_chroma && (!in.pm || in.pm == 4)) {
             blocks(std::integral_constant<int, 3>{}, 24, 2, [&](int pl) { return lane < 4 ? (int)lvs[X264GPU_LV_CHROMA_DC + pl * 4 + lane] : 0; }, [&](int pl) { return dc_inc(25 + pl); }, always);
             if (in.cbp_chroma == 2)
                 blocks_many(std::integral_constant<int, 4>{}, 16, 8, 0xffu, (in.nnz >> 16) & 0xffu, [&](int k) { return lane < 15 ? (int)lvs[X264GPU_LV_CHROMA_AC + k * 16 + 1 + lane] : 0; }, [&](int k) { return ac_inc((k >> 2) & 1, k & 3); });
         }
+        flush_levels();
     }
     return amvd;
 }

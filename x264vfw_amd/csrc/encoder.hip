@@ -27,6 +27,7 @@ void launch_mb_slice_b_dia(const EncK &k, int streams, hipStream_t st);
 void launch_mb_slice_b_umh(const EncK &k, int streams, hipStream_t st);
 void launch_mb_slice_b_esa(const EncK &k, int streams, hipStream_t st);
 int trellis_table_ptrs(const uint16_t **su, const uint8_t **tu, const int **l2);        // prim_kernels.hip
+int cabac_chain_table(const uint32_t **out);                                              // prim_kernels.hip
 int launch_hpel_filter(uint8_t *planes, size_t plane_bytes, int stride, int w, int h, int pad, int batch,
                        size_t batch_bytes, hipStream_t st);
 }
@@ -171,7 +172,7 @@ int x264gpu_encoder_create(x264gpu_encoder **out, const x264gpu_config *cfg)
     if (cfg->rd && cfg->cabac) { alloc((void **)&e->amvd, S * k.nmb * (cfg->dpb > 0 ? 16 : 8), 0); alloc((void **)&e->cab_out, S * (cfg->slices > 1 ? cfg->slices : 1) * 192 * sizeof(uint32_t), 0); }
     if (cfg->slices_plain && cfg->slices > 1) { alloc((void **)&e->sl_stat, 3 * S * cfg->slices * 4 * sizeof(int), 0);      /* one history per picture kind: P, B reference, B */ alloc((void **)&e->sl_rerun, S * cfg->slices * sizeof(int), 0); }
 #ifdef MB_PROF
-    alloc((void **)&e->prof, S * 16 * sizeof(unsigned long long), 0);
+    alloc((void **)&e->prof, S * 32 * sizeof(unsigned long long), 0);
 #endif
     if (er != hipSuccess) { x264gpu_encoder_destroy(e); return set_err(er == hipErrorOutOfMemory ? X264GPU_ENOMEM : X264GPU_EHIP, "encoder buffers", er); }
     const int rc = build_aq_tables(e);       // the macroblock loop reads every quantiser-dependent value per macroblock
@@ -277,13 +278,13 @@ int x264gpu_encoder_set_debug(x264gpu_encoder *e, void *d_counters) { ARG_TRY(e)
 int x264gpu_encoder_stage_count(void) { return (int)(sizeof(kStageNames) / sizeof(kStageNames[0])); }
 const char *x264gpu_encoder_stage_name(int i) { return i >= 0 && i < x264gpu_encoder_stage_count() ? kStageNames[i] : ""; }
 
-// MB_PROF builds (tools/mb_prof.py): the phase counters of the last macroblock-loop launch, [streams][16] cycle counts; not part of the ABI
+// MB_PROF builds (tools/mb_prof.py): the phase counters of the last macroblock-loop launch, [streams][32] cycle counts; not part of the ABI
 int x264gpu_encoder_mb_prof(x264gpu_encoder *e, unsigned long long *out)
 {
     ARG_TRY(e && out);
     if (!e->prof) return X264GPU_EINVAL;
     HIP_TRY(hipDeviceSynchronize());
-    HIP_TRY(hipMemcpy(out, e->prof, (size_t)e->cfg.streams * 16 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(out, e->prof, (size_t)e->cfg.streams * 32 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
     return X264GPU_OK;
 }
 
@@ -457,6 +458,8 @@ static int encode_core(x264gpu_encoder *e, const uint8_t *d_i420, const x264gpu_
     k.sl_rerun = e->sl_rerun; k.sl_pass = 0;
     k.trellis = e->cfg.trellis; k.tr_su = nullptr; k.tr_tu = nullptr; k.tr_l2 = nullptr;
     if (k.trellis) { const int rc = trellis_table_ptrs(&k.tr_su, &k.tr_tu, &k.tr_l2); if (rc != X264GPU_OK) return rc; }
+    k.ctab = nullptr;
+    if (k.rd && k.cabac) { const int rc = cabac_chain_table(&k.ctab); if (rc != X264GPU_OK) return rc; }
     k.lowres_mv = e->lowres_mv; k.lowres_mv1 = e->lowres_mv1; k.fast_pskip = e->cfg.fast_pskip; k.mv_range = e->cfg.mv_range;
     k.mb = d_mb; k.levels = d_levels;
     k.qp = qp; k.lambda = lambda_of(qp); k.qpc = chroma_qp_of(qp, e->cfg.chroma_qp_offset);

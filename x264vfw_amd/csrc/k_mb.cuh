@@ -75,16 +75,23 @@ struct MbCtx {
 enum { PH_SETUP, PH_ME_PRED, PH_ME_WIN, PH_ME_FPEL, PH_ME_SUBSTAGE, PH_ME_SUBPEL, PH_ME_GLUE, PH_PSKIP, PH_INTRA_CHROMA, PH_INTRA, PH_ENC_INTER, PH_ENC_INTRA, PH_STORE, PH_COUNT };
 #ifdef MB_PROF
 struct Prof {
-    unsigned long long t, acc[16];
-    __device__ __forceinline__ void start() { for (int i = 0; i < 16; i++) acc[i] = 0; t = __builtin_readcyclecounter(); }
+    unsigned long long t, acc[32], t2;          // 0..15: the phases / counts of the macroblock loop; 16..31: inside the CABAC pricing (cabac_rd.cuh, -DMB_PROF_RD)
+    __device__ __forceinline__ void start() { for (int i = 0; i < 32; i++) acc[i] = 0; t = __builtin_readcyclecounter(); t2 = t; }
     __device__ __forceinline__ void mark(int i) { const unsigned long long n = __builtin_readcyclecounter(); acc[i] += n - t; t = n; }
     __device__ __forceinline__ void count(int i) { acc[i]++; }
+    __device__ __forceinline__ void count(int i, int n) { acc[i] += (unsigned long long)n; }
+    // a second, nested clock (the phases' clock t keeps running): begin2 .. mark2
+    __device__ __forceinline__ void begin2() { t2 = __builtin_readcyclecounter(); }
+    __device__ __forceinline__ void mark2(int i) { const unsigned long long n = __builtin_readcyclecounter(); acc[i] += n - t2; t2 = n; }
 };
 #else
 struct Prof {
     __device__ __forceinline__ void start() {}
     __device__ __forceinline__ void mark(int) {}
     __device__ __forceinline__ void count(int) {}
+    __device__ __forceinline__ void count(int, int) {}
+    __device__ __forceinline__ void begin2() {}
+    __device__ __forceinline__ void mark2(int) {}
 };
 #endif
 
@@ -2362,7 +2369,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(MB_WAVES_PER
             uint32_t pred, cpred;
             int mv0x = 0, mv0y = 0, ref0 = 0;
             if constexpr (BS) {
+                pf.begin2();
                 b_predict(k, c, ecfg, biwv, pred, cpred);
+                { const int tch = wave_sum((int)(pred & 1) + (int)(cpred & 1)); if (tch == 12345678) pf.count(30); }      // (MB_PROF: the prediction has arrived)
+                pf.mark2(24);
                 if (commit && (lane & 15) == 0) {      // one lane per 8x8 block writes that block's motion in both lists
                     recd.ref[b8] = (int8_t)ecfg.r0; recd.mv[b8][0] = (int16_t)ecfg.x0; recd.mv[b8][1] = (int16_t)ecfg.y0;
                     recd.ref1[b8] = (int8_t)ecfg.r1; recd.mv1[b8][0] = (int16_t)ecfg.x1; recd.mv1[b8][1] = (int16_t)ecfg.y1;
@@ -2535,9 +2545,11 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(MB_WAVES_PER
 #pragma unroll
                     for (int i8 = 0; i8 < 4; i8++) cbp_luma |= ((nnz >> (4 * i8)) & 15) ? 1 << i8 : 0;
                 }
+                pf.mark2(25);
                 const uint2 fe = *(const uint2 *)(L.csrc + cyy * 16 + 2 * cx0);
                 const uint32_t cenc = nv12_pick(fe.x, fe.y, pl);
                 const uint32_t crec = mb_chroma_residual(cenc, cpred, q_cp, true, k.dct_decimate != 0, lane, lvw, nnz, cbp_chroma, TRL ? &trc : nullptr);
+                pf.mark2(26);
                 if (commit) mb_store_chroma(ruv, k.rs, lane, crec);
                 if constexpr (RD) { if (lane < 32) ssd_c = ssd4_u8(cenc, crec); }
                 if (lane >= 32 && lane < 40) lvw[X264GPU_LV_LUMA_DC + (lane - 32) * 2] = 0, lvw[X264GPU_LV_LUMA_DC + (lane - 32) * 2 + 1] = 0;
@@ -2769,7 +2781,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(MB_WAVES_PER
                     int dq;
                     unsigned long long av1;
                     ci.size = true;
-                    cab_mb(tmp, cab_modelv, lane, ci, S, rd_lvs, L.modes4, L.modes8, L.nmodes, c.mbx, c.sy, dq, av1);
+                    cab_mb(tmp, cab_modelv, lane, ci, S, rd_lvs, L.modes4, L.modes8, L.nmodes, c.mbx, c.sy, dq, av1, k.ctab, pf);
                     if constexpr (REF) { if (part_pass && rf_pk == 4) dist = wave_sum(ssd_c); }          // rd_cost_chroma: the two planes' SSD as it is
                     const int l2p = REF && part_pass && rf_pk == 4 ? c_lambda2_tab[c.qpc] : lambda2;
                     if (part_pass) cost64 = ((unsigned long long)(unsigned)dist << 8) + (((unsigned long long)cab_total(tmp) * (unsigned long long)l2p + 128) >> 8);
@@ -2819,7 +2831,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(MB_WAVES_PER
                 int dq;
                 unsigned long long av1;
                 ci.size = false;
-                const unsigned long long av = cab_mb(cab, cab_modelv, lane, ci, S, rd_lvs, L.modes4, L.modes8, L.nmodes, c.mbx, c.sy, dq, av1);
+                const unsigned long long av = cab_mb(cab, cab_modelv, lane, ci, S, rd_lvs, L.modes4, L.modes8, L.nmodes, c.mbx, c.sy, dq, av1, k.ctab, pf);
                 last_dqp = dq;
                 if (lane < 2) ((uint32_t *)(k.amvd + ((size_t)s * k.nmb + mbi) * (BS ? 16 : 8)))[lane] = (uint32_t)(av >> (32 * lane));
                 if (BS && lane >= 2 && lane < 4) ((uint32_t *)(k.amvd + ((size_t)s * k.nmb + mbi) * 16))[lane] = (uint32_t)(av1 >> (32 * (lane - 2)));
@@ -3002,7 +3014,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(MB_WAVES_PER
         if (k.cab_out) { uint32_t *o = k.cab_out + ((size_t)s * (k.slices > 1 ? k.slices : 1) + blockIdx.y) * 192; o[lane] = cab.a; o[64 + lane] = cab.r; o[128 + lane] = cab.r8; }
     }
 #ifdef MB_PROF
-    if (lane == 0 && k.prof) for (int i = 0; i < 16; i++) k.prof[(size_t)s * 16 + i] = pf.acc[i];
+    if (lane == 0 && k.prof) for (int i = 0; i < 32; i++) k.prof[(size_t)s * 32 + i] = pf.acc[i];
 #endif
 }
 

@@ -7,6 +7,7 @@
 #include "trellis.cuh"
 #include <math.h>
 #include <mutex>
+#include <vector>
 #include <stddef.h>
 
 using namespace x264gpu;
@@ -249,7 +250,7 @@ static int trellis_tables(TrellisTab *out)
         static const uint8_t trans_lps[64] = { 0, 0, 1, 2, 2, 4, 4, 5, 6, 7, 8, 9, 9, 11, 11, 12, 13, 13, 15, 15, 16, 16, 18, 18, 19, 19, 21, 21, 22, 22, 23, 24,
                                                24, 25, 26, 26, 27, 27, 28, 29, 29, 30, 30, 30, 31, 32, 32, 33, 33, 33, 34, 34, 35, 35, 35, 36, 36, 36, 37, 37, 37, 38, 38, 63 };
         auto next = [&](int st, int b) { const int s = st >> 1, mps = st & 1; return (mps ^ b) ? (trans_lps[s] << 1) | (s == 0 ? mps ^ 1 : mps) : ((s < 62 ? s + 1 : 62) << 1) | mps; };
-        struct Host { int l2[104]; uint16_t su[15 * 128]; uint8_t tu[15 * 128]; };
+        struct Host { int l2[104]; int qt[52 * TRELLIS_QT_ROW]; uint16_t su[15 * 128]; uint8_t tu[15 * 128]; };       // (qt directly behind l2: trellis.cuh finds it there)
         static Host hst;
         for (int prefix = 0; prefix < 15; prefix++)
             for (int c0 = 0; c0 < 128; c0++) {
@@ -259,6 +260,32 @@ static int trellis_tables(TrellisTab *out)
                 hst.su[prefix * 128 + c0] = (uint16_t)(bits + 256); hst.tu[prefix * 128 + c0] = (uint8_t)ctx;
             }
         for (int qp = 0; qp < 52; qp++) { hst.l2[qp] = (int)(0.85 * 0.85 * pow(2.0, qp / 3.0 + 6.0) + 0.5); hst.l2[52 + qp] = (int)(0.65 * 0.65 * pow(2.0, qp / 3.0 + 6.0) + 0.5); }
+        // quantiser, rounding offset, inverse and distortion weight of every coefficient class at every quantiser (trellis.cuh used to divide for
+        // them at the top of every call): classes 0..2 of 4x4 blocks, 3..8 of 8x8 blocks, 9 of DC blocks; { mf, bias, unq, w } each
+        {
+            static const int q4[6][3] = { { 13107, 8066, 5243 }, { 11916, 7490, 4660 }, { 10082, 6554, 4194 }, { 9362, 5825, 3647 }, { 8192, 5243, 3355 }, { 7282, 4559, 2893 } };
+            static const int q8[6][6] = { { 13107, 11428, 20972, 12222, 16777, 15481 }, { 11916, 10826, 19174, 11058, 14980, 14290 }, { 10082, 8943, 15978, 9675, 12710, 11985 },
+                                          { 9362, 8228, 14913, 8931, 11984, 11259 },    { 8192, 7346, 13159, 7740, 10486, 9777 },    { 7282, 6428, 11570, 6830, 9118, 8640 } };
+            static const int w4[3] = { 800, 320, 128 }, w8[6] = { 256, 201, 656, 227, 410, 363 };
+            auto srd = [](int x, int sh) { return sh <= 0 ? x << -sh : (x + (1 << (sh - 1))) >> sh; };
+            for (int qp = 0; qp < 52; qp++) {
+                int *row = hst.qt + qp * TRELLIS_QT_ROW;
+                for (int cl = 0; cl < 3; cl++) {
+                    const int mf = srd(q4[qp % 6][cl], qp / 6 - 1);
+                    row[cl * 4 + 0] = mf; row[cl * 4 + 1] = (1 << 15) / mf; row[cl * 4 + 2] = (int)((1ull << (qp / 6 + 15 + 8)) / (unsigned long long)q4[qp % 6][cl]); row[cl * 4 + 3] = w4[cl];
+                }
+                for (int cl = 0; cl < 6; cl++) {
+                    const int mf = srd(q8[qp % 6][cl], qp / 6);
+                    int *e = row + (3 + cl) * 4;
+                    e[0] = mf; e[1] = (1 << 15) / mf; e[2] = (int)((1ull << (qp / 6 + 16 + 8)) / (unsigned long long)q8[qp % 6][cl]); e[3] = w8[cl];
+                }
+                {
+                    const int m0 = srd(q4[qp % 6][0], qp / 6 - 1);
+                    int *e = row + 9 * 4;
+                    e[0] = m0 >> 1; e[1] = ((1 << 15) / m0) << 1; e[2] = (int)((1ull << (qp / 6 + 15 + 8)) / (unsigned long long)q4[qp % 6][0]) << 1; e[3] = 256;
+                }
+            }
+        }
         char *a = nullptr;
         HIP_TRY(hipMalloc((void **)&a, sizeof(Host)));
         const hipError_t ce = hipMemcpy(a, &hst, sizeof(Host), hipMemcpyHostToDevice);
@@ -266,6 +293,50 @@ static int trellis_tables(TrellisTab *out)
         tt[dev].lambda2 = (const int *)(a + offsetof(Host, l2)); tt[dev].size_unary = (const uint16_t *)(a + offsetof(Host, su)); tt[dev].trans_unary = (const uint8_t *)(a + offsetof(Host, tu));
     }
     *out = tt[dev];
+    return X264GPU_OK;
+}
+
+// The CABAC chain table (cabac_rd.cuh cab_chain): what k = 0..8 bins on ONE context variable leave behind — entry ((2^k - 1) + pattern) * 128 + variable
+// holds the variable after the bins (first bin = bit 0 of the pattern) in bits 0..6 and their cost (1/256 bit) above.  It turns the serial bin-by-bin
+// state machine of the size-only coder into one lookup per eight bins; 261 KB, built once per device, read through the scalar cache / L2.
+int cabac_chain_table(const uint32_t **out)
+{
+    constexpr int MAXDEV = 64;
+    static std::mutex mu;
+    static const uint32_t *tab[MAXDEV] = {};
+    int dev = 0;
+    HIP_TRY(hipGetDevice(&dev));
+    ARG_TRY(dev >= 0 && dev < MAXDEV);
+    std::lock_guard<std::mutex> lock(mu);
+    if (!tab[dev]) {
+        static const uint16_t ent[128] = {
+#include "cabac_entropy.inc"
+        };
+        static const uint8_t trans_lps[64] = { 0, 0, 1, 2, 2, 4, 4, 5, 6, 7, 8, 9, 9, 11, 11, 12, 13, 13, 15, 15, 16, 16, 18, 18, 19, 19, 21, 21, 22, 22, 23, 24,
+                                               24, 25, 26, 26, 27, 27, 28, 29, 29, 30, 30, 30, 31, 32, 32, 33, 33, 33, 34, 34, 35, 35, 35, 36, 36, 36, 37, 37, 37, 38, 38, 63 };
+        static std::vector<uint32_t> h;
+        if (h.empty()) {
+            h.assign((size_t)CAB_CHAIN_ENTRIES, 0u);
+            for (int k = 0; k <= 8; k++)
+                for (int pat = 0; pat < (1 << k); pat++)
+                    for (int st0 = 0; st0 < 128; st0++) {
+                        int st = st0, bits = 0;
+                        for (int i = 0; i < k; i++) {
+                            const int b = (pat >> i) & 1, sg = st >> 1, mps = st & 1;
+                            if (sg > 63) break;
+                            if (mps ^ b) { bits += ent[2 * sg + 1]; st = (trans_lps[sg] << 1) | (sg == 0 ? mps ^ 1 : mps); }
+                            else { bits += ent[2 * sg]; st = ((sg < 62 ? sg + 1 : 62) << 1) | mps; }
+                        }
+                        h[((size_t)((1 << k) - 1) + pat) * 128 + st0] = (uint32_t)(st & 127) | ((uint32_t)bits << 7);
+                    }
+        }
+        uint32_t *a = nullptr;
+        HIP_TRY(hipMalloc((void **)&a, h.size() * sizeof(uint32_t)));
+        const hipError_t ce = hipMemcpy(a, h.data(), h.size() * sizeof(uint32_t), hipMemcpyHostToDevice);
+        if (ce != hipSuccess) { (void)hipFree(a); HIP_TRY(ce); }
+        tab[dev] = a;
+    }
+    *out = tab[dev];
     return X264GPU_OK;
 }
 
@@ -335,4 +406,37 @@ int x264gpu_trellis_blocks(const int16_t *d_coefs, int nblk, int cat, int qp, in
     return X264GPU_OK;
 }
 
+
+/* the level walk of the CABAC pricing (cabac_rd.cuh cab_levels_all) as a primitive: n macroblocks' levels (x264gpu_mb layout, 416 each), what to cover
+ * per case (d_what[5 n]: luma category 2 / 5 / 1 / -1, luma block mask, chroma AC block mask, chroma DC plane mask, luma DC flag), the role-indexed
+ * context registers r / r8 in and out (64 lanes each), the bits (1/256) out */
+}  // extern "C"
+namespace x264gpu {
+__global__ void k_cab_level_walk(const int16_t *lv, const int *what, const uint32_t *r_in, const uint32_t *r8_in, uint32_t *r_out, uint32_t *r8_out, int *bits, const uint32_t *ctab)
+{
+    __shared__ int16_t l[X264GPU_MB_LEVELS];
+    const int i = blockIdx.x, lane = threadIdx.x;
+    for (int j = lane; j < X264GPU_MB_LEVELS; j += 64) l[j] = lv[(size_t)i * X264GPU_MB_LEVELS + j];
+    __syncthreads();
+    Cab cb; cb.a = 0; cb.r = r_in[i * 64 + lane]; cb.r8 = r8_in[i * 64 + lane]; cb.f8 = 0; cb.f8v = 0;
+    const uint32_t model = cab_model(lane);
+    CabLv W = { what[i * 5], (unsigned)what[i * 5 + 1], (unsigned)what[i * 5 + 2], (unsigned)what[i * 5 + 3], what[i * 5 + 4] != 0 };
+    Prof pf;
+    cab_levels_all(cb, model, lane, l, W, ctab, pf);
+    r_out[i * 64 + lane] = cb.r; r8_out[i * 64 + lane] = cb.r8;
+    const int t = cab_total(cb);
+    if (lane == 0) bits[i] = t;
+}
+}  // namespace x264gpu
+extern "C" {
+int x264gpu_cabac_level_walk(const int16_t *d_levels, const int32_t *d_what, int n, const uint32_t *d_r, const uint32_t *d_r8, uint32_t *d_r_out, uint32_t *d_r8_out, int32_t *d_bits, void *stream)
+{
+    ARG_TRY(d_levels && d_what && d_r && d_r8 && d_r_out && d_r8_out && d_bits && n >= 0);
+    if (!n) return X264GPU_OK;
+    const uint32_t *ctab = nullptr;
+    { const int rc = x264gpu::cabac_chain_table(&ctab); if (rc != X264GPU_OK) return rc; }
+    hipLaunchKernelGGL(x264gpu::k_cab_level_walk, dim3(n), dim3(64), 0, (hipStream_t)stream, d_levels, d_what, d_r, d_r8, d_r_out, d_r8_out, d_bits, ctab);
+    HIP_TRY(hipGetLastError());
+    return X264GPU_OK;
+}
 }  // extern "C"

@@ -21,6 +21,9 @@ namespace x264gpu {
 // x264_cabac_size_unary / x264_cabac_transition_unary ([15][128], context variable = (pStateIdx << 1) | valMPS): built on the host from the
 // entropy table and the state transitions (trellis_tables() in prim_kernels.hip), read here through these pointers
 struct TrellisTab { const uint16_t *size_unary; const uint8_t *trans_unary; const int *lambda2; };      // lambda2[intra * 52 + qp]: x264_trellis_lambda2_tab
+// ... and directly behind lambda2's 104 entries (one allocation, prim_kernels.hip trellis_tables): { mf, bias, unq, w } of every coefficient class at
+// every quantiser — row qp holds classes 0..2 of 4x4 blocks, 3..8 of 8x8 blocks, 9 of DC blocks
+#define TRELLIS_QT_ROW 40
 
 static __constant__ const uint16_t c_quant4_scale[6][3] = { { 13107, 8066, 5243 }, { 11916, 7490, 4660 }, { 10082, 6554, 4194 },
                                                             { 9362, 5825, 3647 },  { 8192, 5243, 3355 },  { 7282, 4559, 2893 } };
@@ -83,19 +86,11 @@ __device__ __noinline__ unsigned trellis_blocks(lds_i16 *coefs, int stride, int 
     // blocks), worked out once: the divisions stay out of the loop
     constexpr int NCLS = DC ? 1 : CAT == 5 ? 6 : 3;
     int q_mf[NCLS], q_bias[NCLS], q_unq[NCLS], q_w[NCLS];
+    {
+        // (from the per-quantiser table: the quantiser is wave-uniform, so these are scalar loads)
+        const int4 *row = (const int4 *)(tt.lambda2 + 104 + __builtin_amdgcn_readfirstlane(qp) * TRELLIS_QT_ROW) + (DC ? 9 : CAT == 5 ? 3 : 0);
 #pragma unroll
-    for (int cl = 0; cl < NCLS; cl++) {
-        if (DC) {
-            const int m0 = shift_round_d(c_quant4_scale[qp % 6][0], qp / 6 - 1);
-            q_mf[cl] = m0 >> 1; q_bias[cl] = ((1 << 15) / m0) << 1;
-            q_unq[cl] = (int)((1ull << (qp / 6 + 15 + 8)) / c_quant4_scale[qp % 6][0]) << 1; q_w[cl] = 256;
-        } else if (CAT == 5) {
-            q_mf[cl] = shift_round_d(c_quant8_scale[qp % 6][cl], qp / 6); q_bias[cl] = (1 << 15) / q_mf[cl];
-            q_unq[cl] = (int)((1ull << (qp / 6 + 16 + 8)) / c_quant8_scale[qp % 6][cl]); q_w[cl] = c_trellis_w8[cl];
-        } else {
-            q_mf[cl] = shift_round_d(c_quant4_scale[qp % 6][cl], qp / 6 - 1); q_bias[cl] = (1 << 15) / q_mf[cl];
-            q_unq[cl] = (int)((1ull << (qp / 6 + 15 + 8)) / c_quant4_scale[qp % 6][cl]); q_w[cl] = c_trellis_w4[cl];
-        }
+        for (int cl = 0; cl < NCLS; cl++) { const int4 e = row[cl]; q_mf[cl] = e.x; q_bias[cl] = e.y; q_unq[cl] = e.z; q_w[cl] = e.w; }
     }
     auto pick = [&](const int (&t)[NCLS], int cl) {
         int r = t[0];
@@ -136,11 +131,9 @@ __device__ __noinline__ unsigned trellis_blocks(lds_i16 *coefs, int stride, int 
         const int cl = p < NC ? cls_of(min(p, NC - 1)) : 0;
         if (valid) { pos_a = (uint32_t)(s1 + l0) | ((uint32_t)(s1 + l1) << 12); pos_t0 = (uint32_t)(((unsigned long long)s0 * (unsigned long long)lambda2) >> 4); }
         pos_a |= (uint32_t)cl << 24;
-        pos_z = pos_t0;
-        for (int d = 1; d < 64; d <<= 1) {
-            const unsigned lo32 = (unsigned)__shfl_up((int)(unsigned)pos_z, d), hi32 = (unsigned)__shfl_up((int)(unsigned)(pos_z >> 32), d);
-            if (lane >= d) pos_z += ((unsigned long long)hi32 << 32) | lo32;
-        }
+        // inclusive prefix sum over the positions: pos_t0 < 2^30, so its two 16-bit halves sum without overflow over 64 lanes — two 32-bit DPP
+        // scans (row shifts, then the row broadcasts) instead of six 64-bit shuffle rounds through the LDS crossbar
+        pos_z = ((unsigned long long)(unsigned)wave_scan_add((int)(pos_t0 >> 16)) << 16) + (unsigned long long)(unsigned)wave_scan_add((int)(pos_t0 & 0xffffu));
     }
 
     // level_state: the ten abs-level context variables of the category (wave-uniform), packed four to a word

@@ -115,6 +115,7 @@ _SIGS = {
     "x264gpu_encoder_set_lowres_mvs1": (_i, [_vp, _vp]),
     "x264gpu_encoder_cabac_states": (_i, [_vp, _i, _i, _vp]),
     "x264gpu_trellis_blocks": (_i, [_vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp]),
+    "x264gpu_cabac_level_walk": (_i, [_vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
     "x264gpu_encoder_deblock_pictures": (_i, [_vp, _vp, _vp, _vp, _vp]),
     "x264gpu_get_device": (_i, [_vp]),
     "x264gpu_lookahead_create": (_i, [C.POINTER(_vp), _i, _i, _i, _i, _i]),
