@@ -40,7 +40,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0   # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
-TOOLSET_GAPS = "x264 medium minus the lookahead's decisions, which sessions take and a lock-step batch cannot (every stream must code the same picture type): weightp's weights for fades (the duplicate reference with offset -1 on every P picture IS in), b-adapt 1 (every run is bframes long: b-adapt 0), rate control (constant quantisers: no AQ / mbtree / lookahead); entropy coding (CABAC bitstream writing) runs on host threads and is outside `value` (inside `e2e`)"
+TOOLSET_GAPS = "x264 medium with a fixed picture structure and constant quantisers: the lock-step batch codes the same picture type in every stream, so the lookahead's DECISIONS (b-adapt 1, scenecut, fade weights, AQ / mbtree / rate control) are not taken — its device work for the same streams is timed beside `value` (`lookahead`: lowres, AQ offsets, frame costs, macroblock-tree; `value_with_lookahead`); --weightp 2's duplicate reference with offset -1 on every P picture IS in; entropy coding (CABAC bitstream writing) runs on host threads and is outside `value` (inside `e2e`)"
 TOOLSET_GAPS_NOB = "x264 medium minus: B-frames (bframes 3 -> 0), the fade analysis of weightp 2; entropy coding (CABAC/CAVLC bitstream writing) runs on host threads and is outside `value` (inside `e2e`)"
 TOOLSET_GAPS_NORD = "x264 medium minus: RD mode decision + psy-rd (subme 7 -> 5), trellis 1, the lookahead's decisions (b-adapt 1, fade weights, rate control); entropy coding runs on host threads and is outside `value`"
 
@@ -71,6 +71,7 @@ def parse_args():
     ap.add_argument("--e2e-frames", type=int, default=10, help="frames of the single-stream threads-1 end-to-end sample (0 = skip e2e)")
     ap.add_argument("--cpu-procs", type=int, default=64, help="processes of the many-core leg of the CPU baseline (cpu_baseline.cores reports what was used)")
     ap.add_argument("--cpu-frames-all", type=int, default=3, help="frames per core of the every-core leg of the CPU baseline (shorter: it runs one process per core)")
+    ap.add_argument("--lookahead", type=int, default=1, help="1: also time the lookahead's device work (lowres, AQ, frame costs, macroblock-tree) for the same streams and report value_with_lookahead")
     ap.add_argument("--content", default="noise", choices=["noise", "smooth", "survey"], help="synthetic content: 'noise' (default, the headline) = moving rectangles of per-pixel "
                     "white noise + strong sensor noise, harder than camera material; 'smooth' = the same scene with band-limited textures and light noise; "
                     "'survey' = SURVEY.md §8(d) read with natural textures: gradient + 3 moving band-limited rectangles + noise of +-4 on luma, +-2 on chroma")
@@ -249,13 +250,13 @@ def synth_batch(torch, streams, frames, w, h, seed, device, smooth=False, scene_
 
 def pmc_evidence(kernel_substr, avg_launch_ms, streams_per_launch, content):
     """HBM bytes per launch of the dominant kernel and its VALU instruction count from the committed rocprofv3 --pmc passes of this
-    command (tools/profile_round.sh -> profiles/r04_pmc_per_launch.json; FETCH_SIZE and WRITE_SIZE in separate passes, KB -> bytes,
+    command (tools/profile_round.sh -> profiles/r05_pmc_per_launch.json; FETCH_SIZE and WRITE_SIZE in separate passes, KB -> bytes,
     read side doubled as MI355X_MICROARCH.md prescribes for gfx950).  The macroblock loop runs as three instantiations (I, P, B slices): the
     profile's entry `_mb_loop_timed_window` is their average over the launches of the timed window, the same launches bench.py's own event
     timing averages.  PMC counters cannot be read from inside an un-profiled run, so these are the profile's figures scaled per stream; null
     without a profile of this workload."""
-    path = os.path.join(ROOT, "profiles", "r04_pmc_per_launch.json")
-    if not os.path.exists(path):
+    path = next((q for q in (os.path.join(ROOT, "profiles", f"r0{r}_pmc_per_launch.json") for r in (5, 4)) if os.path.exists(q)), None)      # the newest round's profile
+    if not path:
         return None, None
     tab = json.load(open(path))
     per = tab.get("_workload", {}).get("streams_per_launch")
@@ -271,7 +272,7 @@ def pmc_evidence(kernel_substr, avg_launch_ms, streams_per_launch, content):
         simds, clk = 256 * 4, 2.4e9                      # a wave64 VALU op occupies its SIMD16 for 4 cycles
         insts = t["SQ_INSTS_VALU"] * scale
         valu = {"insts_per_launch": int(insts), "insts_per_macroblock": round(t["SQ_INSTS_VALU"] / t.get("macroblocks_per_launch", 1), 1) if t.get("macroblocks_per_launch") else None,
-                "issue_util": round(insts * 4 / (simds * clk * avg_launch_ms * 1e-3), 4), "source": "profiles/r04_pmc_per_launch.json"}
+                "issue_util": round(insts * 4 / (simds * clk * avg_launch_ms * 1e-3), 4), "source": "profiles/" + os.path.basename(path)}
     return traffic, valu
 
 
@@ -303,6 +304,85 @@ def csp_probe(torch, lib, dev, W, H, frames=64, iters=10):
     gbs = (n + osz) * frames / (ms * 1e-3) / 1e9
     return {"kernel": "k_csp_bgr<4> (BGRA -> I420)", "frames_per_launch": frames, "avg_launch_ms": round(ms, 4), "alg_bytes_per_frame": n + osz,
             "achieved_GBps": round(gbs, 1), "frac_of_hbm_peak": round(gbs / HBM_PEAK_GBS, 4), "frames_per_s": round(frames / (ms * 1e-3), 1)}
+
+
+def lookahead_probe(torch, lib, dev, args, data, first, K, S, W, H):
+    """The DEVICE work of x264's lookahead for the same streams and pictures as the timed window, run beside it (the lock-step batch codes a fixed
+    picture structure, so the decisions themselves are discarded): per display picture x264_frame_init_lowres + x264_adaptive_quant_frame, the two
+    slicetype_frame_cost calls --b-adapt 1 spends on a new picture (as a P picture on the last non-B one; its predecessor as a B picture between
+    them), and when a mini-GOP closes its path costs and macroblock_tree over it (clear / propagate / finish) — [x264-upstream] encoder/slicetype.c
+    x264_slicetype_analyse, macroblock_tree; csrc/slicetype.hip, csrc/lookahead.hip.  Returns the time per picture and the launches made."""
+    import numpy as np
+    nslots = args.bframes + 5
+    st, la = C.c_void_p(), C.c_void_p()
+    lib.check(lib.x264gpu_slicetype_create(C.byref(st), W, H, S, nslots, args.bframes, 1, 7, 16, 1, 512, 1), "slicetype_create")
+    lib.check(lib.x264gpu_lookahead_create(C.byref(la), W, H, S, 16, 7), "lookahead_create")
+    nb = ((W + 15) // 16) * ((H + 15) // 16)
+    aq = torch.empty((S, nb), dtype=torch.int16, device=dev)
+    offs = torch.empty((S, nb), dtype=torch.int16, device=dev)
+    score = np.zeros(S, np.int32)
+    calls = {"lowres": 0, "aq": 0, "frame_cost": 0, "propagate": 0, "finish": 0}
+    ms = {k_: 0.0 for k_ in calls}
+    sl = lambda i: i % nslots
+
+    class timed:          # wall time of one group of launches (synchronised: the calls are tens of milliseconds each at this batch size)
+        def __init__(self, key): self.key = key
+        def __enter__(self): self.t = time.perf_counter()
+        def __exit__(self, *a):
+            torch.cuda.synchronize(dev)
+            ms[self.key] += (time.perf_counter() - self.t) * 1e3
+            calls[self.key] += 1
+
+    def cost(p0, p1, b):
+        with timed("frame_cost"):
+            lib.check(lib.x264gpu_slicetype_frame_cost(st, sl(p0), sl(p1), sl(b), b - p0, p1 - b, score.ctypes.data, None), "slicetype_frame_cost")
+
+    def prop(p0, p1, b, ref):
+        with timed("propagate"):
+            lib.check(lib.x264gpu_slicetype_propagate(st, sl(p0), sl(p1), sl(b), b - p0, p1 - b, ref, None), "slicetype_propagate")
+
+    types = display_types(K, args.bframes, max(K, 1))
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    p0 = 0
+    for i in range(K):
+        with timed("lowres"):
+            lib.check(lib.x264gpu_slicetype_put_frame(st, sl(i), data[first + i].data_ptr(), None), "slicetype_put_frame")
+        with timed("aq"):
+            lib.check(lib.x264gpu_lookahead_aq_offsets(la, data[first + i].data_ptr(), 256, aq.data_ptr(), None), "aq_offsets")
+            lib.check(lib.x264gpu_slicetype_set_aq(st, sl(i), aq.data_ptr(), None), "set_aq")
+        if i == 0:
+            cost(0, 0, 0)
+            continue
+        cost(p0, i, i)
+        if i - p0 >= 2:
+            cost(p0, i, i - 1)
+        if types[i] != "B":
+            n = i - p0 - 1
+            lib.check(lib.x264gpu_slicetype_clear_propagate(st, sl(i), None), "clear_propagate")
+            lib.check(lib.x264gpu_slicetype_clear_propagate(st, sl(p0), None), "clear_propagate")
+            if n > 1:
+                mid = p0 + (n + 1) // 2
+                cost(p0, i, mid)
+                lib.check(lib.x264gpu_slicetype_clear_propagate(st, sl(mid), None), "clear_propagate")
+                for j in range(i - 1, p0, -1):
+                    if j != mid:
+                        a, b = (mid if j > mid else p0), (mid if j < mid else i)
+                        cost(a, b, j); prop(a, b, j, 0)
+                prop(p0, i, mid, 1)
+            else:
+                for j in range(i - 1, p0, -1):
+                    cost(p0, i, j); prop(p0, i, j, 0)
+            prop(p0, i, i, 1)
+            cost(p0, p0, p0)
+            with timed("finish"):
+                lib.check(lib.x264gpu_slicetype_finish(st, sl(p0), 512, offs.data_ptr(), None), "slicetype_finish")
+            p0 = i
+    torch.cuda.synchronize(dev)
+    dt = time.perf_counter() - t0
+    lib.x264gpu_slicetype_destroy(st)
+    lib.x264gpu_lookahead_destroy(la)
+    return dt, {k_: {"calls": calls[k_], "ms": round(ms[k_], 1)} for k_ in calls}
 
 
 def e2e_probe(args):
@@ -597,7 +677,17 @@ def main():
                                                                                           ("P8x8", mbt[5]), ("P_Skip", mbt[6]), ("B_Direct", mbt[7]), ("B_Skip", mbt[8]), ("B L0/L1/Bi", mbt[9]), ("B_8x8", mbt[10]))}
         out["csp_ingest"] = csp_probe(torch, lib, dev, W, H)
     lib.x264gpu_encoder_destroy(h)
-    del data, mbs, lvs
+    del mbs, lvs
+    torch.cuda.empty_cache()
+    if args.lookahead and args.bframes:
+        # ---- the lookahead's device work for the same streams and pictures, beside the headline ----
+        la_dt, la_calls = lookahead_probe(torch, lib, dev, args, data, Wu, K, S, W, H)
+        la_dt = shard.max_over_ranks(la_dt, dist, dev)
+        out["lookahead"] = {"what": "the device work of x264's lookahead for the same streams and pictures (lowres planes, AQ mode 1 offsets, --b-adapt 1's frame costs, path costs + "
+                                    "macroblock_tree per mini-GOP), run after the timed window; its decisions are discarded (the lock-step batch codes a fixed picture structure)",
+                            "ms_per_picture": round(la_dt / K * 1e3, 3), "launch_groups": la_calls,
+                            "value_with_lookahead": round(S * world * K / (dt + la_dt), 2), "share_of_step": round(la_dt / (dt + la_dt), 4)}
+    del data
     torch.cuda.empty_cache()
     if rank == 0:
         if cpu is not None:

@@ -381,6 +381,10 @@ int  x264gpu_slicetype_weight_cost_chroma(x264gpu_slicetype *st, int slot_fenc, 
 int  x264gpu_slicetype_set_aq(x264gpu_slicetype *st, int slot, const int16_t *d_aq_q8, void *stream);
 /* --b-bias (param.i_bframe_bias, -90 .. 100): slicetype_frame_cost scales B costs by 100 / (120 + bias); call once after create */
 int  x264gpu_slicetype_set_bframe_bias(x264gpu_slicetype *st, int bias);
+/* how x264gpu_slicetype_frame_cost walks a picture's block rows: 1 = one wavefront per stream walks every row itself (a batch of streams fills the chip
+ * without the per-stream row pipeline), 0 = one wavefront per row, chained bottom-up by progress counters (a lone stream's latency), -1 = auto
+ * (default: 1 from 512 streams on).  The costs are the same either way (tests/test_gpu_lookahead.py). */
+int  x264gpu_slicetype_set_row_mode(x264gpu_slicetype *st, int serial);
 /* fenc->i_cost_est_aq[d0][d1] of a triple whose cost has been computed: the block costs weighted with the inverse quantiser scale of the picture's AQ
  * offsets (set_aq), per stream into h_score[streams] — the complexity x264_rc_analyse_slice hands the rate control in AQ sessions without macroblock-tree
  * ([x264-upstream] encoder/slicetype.c slicetype_mb_cost, ratecontrol.c x264_rc_analyse_slice) */

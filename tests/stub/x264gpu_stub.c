@@ -158,6 +158,7 @@ int x264o_slicetype_finish(x264o_slicetype *st, int slot, int strength_q8, int16
 const int32_t *x264o_slicetype_propagate_cost(x264o_slicetype *st, int slot);
 void x264o_slicetype_set_bframe_bias(x264o_slicetype *st, int bias);
 int x264gpu_slicetype_set_bframe_bias(x264gpu_slicetype *s, int bias) { x264o_slicetype_set_bframe_bias(s->st, bias); return X264GPU_OK; }
+int x264gpu_slicetype_set_row_mode(x264gpu_slicetype *s, int serial) { (void)s; (void)serial; return X264GPU_OK; }          /* (a launch geometry: nothing to model) */
 int x264o_slicetype_cost_aq(x264o_slicetype *st, int slot, int d0, int d1);
 int x264gpu_slicetype_cost_aq(x264gpu_slicetype *s, int slot, int d0, int d1, int32_t *h_score, void *stream) { const int c = x264o_slicetype_cost_aq(s->st, slot, d0, d1); if (c < 0) return fail("slicetype cost_aq"); h_score[0] = c; return X264GPU_OK; }
 int x264gpu_slicetype_set_aq(x264gpu_slicetype *s, int slot, const int16_t *aq, void *stream) { x264o_slicetype_set_aq(s->st, slot, aq); return X264GPU_OK; }

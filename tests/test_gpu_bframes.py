@@ -290,3 +290,10 @@ def test_every_simd_doubly_occupied_streams_stay_identical(gpu, w, h, types, see
     of the umh B instantiation (an occupancy-dependent result is the signature of a race or a hazard, not of the arithmetic).  Every stream must equal
     the CPU checker, hence every other stream."""
     run(gpu, w, h, types, seed, streams=2304, **over)
+
+
+def test_config2_size_medium_toolset_bitexact(gpu):
+    """1280x720 (BASELINE.json configs[1]: preset medium, bit-exact vs the reference) as medium really is: bframes 3 + b-pyramid + weightb, --weightp 2's
+    duplicate, ref 3 + mixed refs, hex, subme 7 with RD on CABAC sizes + psy-rd, trellis 1, 8x8dct, all partitions — two mini-GOPs against the CPU checker,
+    the stream decoded back"""
+    assert run(gpu, 1280, 720, "IBBBPBBBP", 72, weightp=2) >= 0

@@ -97,10 +97,13 @@ def test_aq_offsets_and_mbtree_bitexact(gpu, w, h, n, strength, with_aq):
 
 
 # ---- the lookahead in x264's structure: slicetype_frame_cost(p0, p1, b) for any triple (x264gpu_slicetype_* vs oracle/slicetype.c) ----
-def run_slicetype(w, h, n, seed, triples, streams=1, **kw):
+def run_slicetype(w, h, n, seed, triples, streams=1, row_mode=-1, **kw):
     from gpu_enc import GpuSlicetype
     frames = synth_frames(w, h, n, seed=seed)
     og, gg = O.OracleSlicetype(w, h, **kw), GpuSlicetype(w, h, streams=streams, **kw)
+    if row_mode >= 0:
+        from x264vfw_amd import lib as gpu_lib
+        gpu_lib.check(gpu_lib.x264gpu_slicetype_set_row_mode(gg.h, row_mode), "set_row_mode")
     for i, f in enumerate(frames):
         og.put(i, f)
         gg.put(i, [f] * streams)
@@ -153,6 +156,13 @@ def test_slicetype_costs_headline_size(gpu):
 
 def test_slicetype_costs_multistream(gpu):
     run_slicetype(176, 144, 5, 6, ADAPT[:10], streams=3, do_edges=1)
+
+
+@pytest.mark.parametrize("w,h,kw", [(176, 144, dict(do_edges=1)), (352, 288, {}), (1920, 1080, dict(do_edges=1))])
+def test_slicetype_costs_one_wavefront_per_stream(gpu, w, h, kw):
+    """the batch geometry of x264gpu_slicetype_frame_cost (one wavefront walks every block row of its stream: x264gpu_slicetype_set_row_mode 1, the
+    default from 512 streams on) gives the same vectors, costs and scores as the row pipeline and the CPU checker"""
+    run_slicetype(w, h, 5, 11, ADAPT[:12] if w < 1000 else ADAPT[:6], streams=2, row_mode=1, **kw)
 
 
 # ---- macroblock-tree through B pictures: x264's macroblock_tree walked over both implementations (tests/mbtree_walk.py) ----

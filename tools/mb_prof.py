@@ -65,6 +65,8 @@ def main():
         print("%-4s %10.0f " % ("IIPRb"[pt] + str(disp), tot) + " ".join("%9.0f" % v for v in a[:13]) + " %9.2f %9.2f %9.2f" % (a[13], a[14], a[15]) + "   %.1f ms" % e0.elapsed_time(e1))
         if a[16] > 0:         # -DMB_PROF_RD: inside the CABAC pricing (cabac_rd.cuh), per macroblock
             print("     cab_mb calls %.2f  header %.0f  cbf+sigmaps %.0f  levels: prep %.0f walk %.0f rest %.0f cycles;  walk steps %.1f  non-zero coefficients %.1f" % (a[16], a[17], a[18], a[22], a[23], a[19], a[20], a[21]))
+        if a[27] > 0:
+            print("     around the pricing: candidate's distortion terms + header inputs %.0f  cost bookkeeping %.0f cycles" % (a[27], a[28]))
         if a[24] > 0:
             print("     inter encode: prediction (b_predict) %.0f  luma transform / quantiser / reconstruction %.0f  chroma %.0f cycles" % (a[24], a[25], a[26]))
         mx = out[:, :13].sum(axis=1).astype(np.float64)

@@ -89,6 +89,9 @@ struct EncK {
     // whose window misses the real sum run again (sl_rerun), until none does (k_slice_priors, encoder.hip)
     int *sl_stat, *sl_rerun; int sl_pass;
     int trellis; const uint16_t *tr_su; const uint8_t *tr_tu; const int *tr_l2;      // trellis sites of the final encode (mask) + x264_rdo_init's tables              // RD: [streams][nmb][24] total_coeff of every block of the picture being coded (nC of the bit counts)
+    // load balance of the lock-step batch (encoder.hip k_balance): perm[workgroup] = the stream it codes (null: identity), wtime[stream] = cycles its
+    // wavefront took (written by the macroblock loop, read for the next picture of the same kind)
+    const int *perm; unsigned *wtime;
     const uint32_t *ctab;     // CABAC sessions with RD: the chain table of the size-only coder (cabac_rd.cuh cab_chain; prim_kernels.hip cabac_chain_table)
     int cabac;                // the session's entropy coder is CABAC: P8x8 cost details of x264's analysis depend on it
     int slices;               // x264 slice threads: slices per picture (rows split evenly), 1 = one

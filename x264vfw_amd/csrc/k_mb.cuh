@@ -1437,9 +1437,10 @@ __device__ __forceinline__ void b_predict(const EncK &k, const MbCtx &c, const B
     BCfg g = g0;
     g.x0 = clampi(g.x0, c.mvmin0, c.mvmax0); g.y0 = clampi(g.y0, c.mvmin1, c.mvmax1); g.x1 = clampi(g.x1, c.mvmin0, c.mvmax0); g.y1 = clampi(g.y1, c.mvmin1, c.mvmax1);
     {
-        uint32_t p0 = 0, p1 = 0;
-        if (g.r0 >= 0) p0 = mc_luma_row4(ref_plane00(k, c.s, g.r0), k.plane_bytes, k.rs, c.px + zx, c.py + zy, g.x0, g.y0);
-        if (g.r1 >= 0) p1 = mc_luma_row4(ref_plane00(k, c.s, k.nref + g.r1), k.plane_bytes, k.rs, c.px + zx, c.py + zy, g.x1, g.y1);
+        // (both lists are fetched whether or not the block uses them — an unused list reads reference 0 at its clipped vector and is dropped: four
+        //  loads in flight together instead of two latencies one after the other behind per-lane branches)
+        const uint32_t p0 = mc_luma_row4(ref_plane00(k, c.s, max(g.r0, 0)), k.plane_bytes, k.rs, c.px + zx, c.py + zy, g.x0, g.y0);
+        const uint32_t p1 = mc_luma_row4(ref_plane00(k, c.s, k.nref + max(g.r1, 0)), k.plane_bytes, k.rs, c.px + zx, c.py + zy, g.x1, g.y1);
         const int w = __shfl(biwv, max(g.r0, 0) * 4 + max(g.r1, 0));
         pred = g.r0 >= 0 ? (g.r1 >= 0 ? avg_weight4_u8(p0, p1, w) : p0) : p1;
     }
@@ -1448,8 +1449,8 @@ __device__ __forceinline__ void b_predict(const EncK &k, const MbCtx &c, const B
         const int r0 = __shfl(g.r0, ci * 16), x0 = __shfl(g.x0, ci * 16), y0 = __shfl(g.y0, ci * 16);
         const int r1 = __shfl(g.r1, ci * 16), x1 = __shfl(g.x1, ci * 16), y1 = __shfl(g.y1, ci * 16);
         uint32_t u0 = 0, v0 = 0, u1 = 0, v1 = 0;
-        if (r0 >= 0) mc_chroma_row4(ref_chroma00(k, c.s, r0), k.rs, c.mbx * 8 + cx0, c.mby * 8 + cyy, x0, y0, u0, v0);
-        if (r1 >= 0) mc_chroma_row4(ref_chroma00(k, c.s, k.nref + r1), k.rs, c.mbx * 8 + cx0, c.mby * 8 + cyy, x1, y1, u1, v1);
+        mc_chroma_row4(ref_chroma00(k, c.s, max(r0, 0)), k.rs, c.mbx * 8 + cx0, c.mby * 8 + cyy, x0, y0, u0, v0);
+        mc_chroma_row4(ref_chroma00(k, c.s, k.nref + max(r1, 0)), k.rs, c.mbx * 8 + cx0, c.mby * 8 + cyy, x1, y1, u1, v1);
         const int w = __shfl(biwv, max(r0, 0) * 4 + max(r1, 0));
         const uint32_t a = pl ? v0 : u0, b = pl ? v1 : u1;
         cpred = r0 >= 0 ? (r1 >= 0 ? avg_weight4_u8(a, b, w) : a) : b;
@@ -1481,7 +1482,13 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(MB_WAVES_PER
     // so the last 256 of 2048 streams ran as a second round
     static_assert(!BS || CSubGeo<M>::DWORDS >= 128, "b_visited aliases L.csub");
 #define b_visited L.csub      /* (not a pointer variable: a generic pointer into LDS trips an instruction-selection bug of this compiler in the umh instantiation) */
-    const int lane = threadIdx.x, s = blockIdx.x;
+    const int lane = threadIdx.x, s = k.perm ? uni(k.perm[blockIdx.x]) : (int)blockIdx.x;
+    const unsigned long long wt0 = k.wtime ? __builtin_readcyclecounter() : 0ull;
+#ifdef X264GPU_POISON
+    // poison builds (tools/poison_check.sh): whatever the last wavefront left in LDS must not matter — start from a pattern that no test leaves there
+    for (int i = lane; i < (int)(sizeof(L) / 4); i += 64) ((uint32_t *)&L)[i] = 0xCDCDCDCDu;
+    __builtin_amdgcn_s_waitcnt(0); __builtin_amdgcn_wave_barrier();
+#endif
     // x264 slice threads: blockIdx.y = slice of the picture, macroblock rows [row0, row1) (k.slices == 1: the whole picture)
     const int nsl = k.slices > 1 ? k.slices : 1, row0 = (k.mbh * (int)blockIdx.y + nsl / 2) / nsl, row1 = (k.mbh * ((int)blockIdx.y + 1) + nsl / 2) / nsl;
     const int mb_first = row0 * k.mbw, mb_end = row1 * k.mbw;
@@ -1509,6 +1516,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(MB_WAVES_PER
     // macroblocks' blocks for the nC of the bit counts; the quantiser the previous coded macroblock left (mb_qp_delta bits)
     __shared__ __attribute__((aligned(16))) int16_t rd_lvs[RD ? X264GPU_MB_LEVELS : 1];
     __shared__ uint8_t rd_ntc[2][RD == 1 ? 24 : 1];
+#ifdef X264GPU_POISON
+    for (int i = lane; i < (RD ? X264GPU_MB_LEVELS : 1); i += 64) rd_lvs[i] = (int16_t)0xCDCD;
+    __builtin_amdgcn_s_waitcnt(0); __builtin_amdgcn_wave_barrier();
+#endif
     // x264_slice_write: the slice's quantiser (header, context initialisation, start of the mb_qp_delta chain) is its FIRST macroblock's
     int last_qp = uni((int)k.mbqp[(size_t)s * k.nmb + mb_first]);
     // CABAC RD: the slice's context variables (two registers, see cabac_rd.cuh), the probability model, the previous macroblock's mb_qp_delta
@@ -2423,7 +2434,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(MB_WAVES_PER
                 const uint32_t enc = cz;
                 bool t8 = false;
                 uint32_t elo = 0, ehi = 0, plo = 0, phi = 0;
-                if (k.dct8x8) {
+                if (k.dct8x8 && e_t8 != 0) {                        // (e_t8 == 0: a candidate with the 4x4 transform — no row layout needed)
                     z_to_r8(enc, lane, elo, ehi); z_to_r8(pred, lane, plo, phi);
                     if (e_t8 >= 0) t8 = e_t8 != 0;                  // RD: the transform size belongs to the candidate
                     else {
@@ -2712,6 +2723,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(MB_WAVES_PER
                 p.mark(15);           // MB_PROF_RD builds: slot 15 = cycles of the CABAC pricing / evolution instead of the staging count
 #endif
             } } rd_mark{ pf };
+            pf.begin2();
             CabIn ci;
             ci.pslice = pslice; ci.left = left; ci.top = top; ci.nref = c.nref; ci.t8mode = k.dct8x8;
             ci.bslice = BS; ci.nref1 = k.nref1; ci.buse = euse; ci.b_r0 = ecfg.r0; ci.b_x0 = ecfg.x0; ci.b_y0 = ecfg.y0; ci.b_r1 = ecfg.r1; ci.b_x1 = ecfg.x1; ci.b_y1 = ecfg.y1;
@@ -2781,7 +2793,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(MB_WAVES_PER
                     int dq;
                     unsigned long long av1;
                     ci.size = true;
+                    pf.mark2(27);
                     cab_mb(tmp, cab_modelv, lane, ci, S, rd_lvs, L.modes4, L.modes8, L.nmodes, c.mbx, c.sy, dq, av1, k.ctab, pf);
+                    pf.begin2();
                     if constexpr (REF) { if (part_pass && rf_pk == 4) dist = wave_sum(ssd_c); }          // rd_cost_chroma: the two planes' SSD as it is
                     const int l2p = REF && part_pass && rf_pk == 4 ? c_lambda2_tab[c.qpc] : lambda2;
                     if (part_pass) cost64 = ((unsigned long long)(unsigned)dist << 8) + (((unsigned long long)cab_total(tmp) * (unsigned long long)l2p + 128) >> 8);
@@ -2823,6 +2837,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(MB_WAVES_PER
                 else if (rd_ph == 6) rd_i4 = cost;
                 else if (rd_ph == 7) { rd_i8 = cost; rf_cbp_i8 = cbp_luma; }
                 rd_ph++;
+                pf.mark2(28);
                 continue;
             }
             // the final macroblock: its levels go out, its bins move the slice's context variables on, its |mvd| stay for the neighbours
@@ -3010,6 +3025,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(MB_WAVES_PER
     }
     if (BS && k.dscore && k.direct_auto && lane == 0) { int *d = k.dscore + ((size_t)s * nsl + blockIdx.y) * 2; d[0] = ds_t; d[1] = ds_s; }
     if (PS && k.sl_stat && lane == 0) { int *st = k.sl_stat + ((size_t)s * nsl + blockIdx.y) * 4; st[0] = intra_count - L.slw[2]; st[1] = L.slw[0]; st[2] = L.slw[1]; }
+    if (k.wtime && lane == 0 && blockIdx.y == 0) k.wtime[s] = (unsigned)min((unsigned long long)(__builtin_readcyclecounter() - wt0) >> 6, 0xffffffffull);
     if constexpr (RD >= 2) {
         if (k.cab_out) { uint32_t *o = k.cab_out + ((size_t)s * (k.slices > 1 ? k.slices : 1) + blockIdx.y) * 192; o[lane] = cab.a; o[64 + lane] = cab.r; o[128 + lane] = cab.r8; }
     }

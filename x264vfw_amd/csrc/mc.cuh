@@ -25,12 +25,11 @@ __device__ __forceinline__ uint32_t mc_luma_row4(const uint8_t *__restrict__ p00
     const int idx = ((mvy & 3) << 2) | (mvx & 3);
     const long base = (long)(y + (mvy >> 2)) * stride + x + (mvx >> 2);
     const int pl0 = (kQpelPlane0Packed >> (2 * idx)) & 3, pl1 = (kQpelPlane1Packed >> (2 * idx)) & 3;
-    uint32_t a = load_u32_unaligned(p00 + pl0 * plane_bytes + base + ((mvy & 3) == 3 ? stride : 0));
-    if (idx & 5) {
-        uint32_t b = load_u32_unaligned(p00 + pl1 * plane_bytes + base + ((mvx & 3) == 3 ? 1 : 0));
-        a = avg4_u8(a, b);
-    }
-    return a;
+    // (both loads go out together, whether or not the position needs the second plane: a load behind a per-lane branch waits for the first one's
+    //  latency before it is even issued; where it is not needed it reads a valid sample of a resident plane and is dropped)
+    const uint32_t a = load_u32_unaligned(p00 + pl0 * plane_bytes + base + ((mvy & 3) == 3 ? stride : 0));
+    const uint32_t b = load_u32_unaligned(p00 + pl1 * plane_bytes + base + ((mvx & 3) == 3 ? 1 : 0));
+    return (idx & 5) ? avg4_u8(a, b) : a;
 }
 
 // 4 chroma pixels (U and V) at chroma position (x..x+3, y) from a padded NV12 plane; mv in 1/8 chroma pel

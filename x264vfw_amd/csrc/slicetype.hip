@@ -35,6 +35,7 @@ struct StK {
     int *intra_cost; uint16_t *lowres_costs;  // [S][nb]
     int32_t *sums;                            // [S][4]: inter cost est, intra cost est, intra blocks, -
     int *progress;                            // [S][bh]
+    int serial_rows;                          // one wavefront walks every row of its stream (batches) instead of one wavefront a row
 };
 
 __device__ __forceinline__ int st_avg4(int a, int b, int c, int d) { return (((a + b + 1) >> 1) + ((c + d + 1) >> 1) + 1) >> 1; }
@@ -136,7 +137,9 @@ __global__ __launch_bounds__(64) void k_st_cost(StK k)
 {
     __shared__ __attribute__((aligned(16))) MbLds<2> L;
     const int lane = threadIdx.x, s = blockIdx.y, r = lane & 15;
-    const int by = k.start_y - (int)blockIdx.x;
+    // k.serial_rows: ONE wavefront walks all the rows of its stream, bottom-up (a batch of streams fills the chip by itself: no wavefront spins on the
+    // row below, no pipeline to fill per stream); else one wavefront per row, chained by the progress counters (a lone stream's latency)
+    const int row_first = k.serial_rows ? 0 : (int)blockIdx.x, row_last = k.serial_rows ? k.start_y - k.end_y : (int)blockIdx.x;
     const EncK &ek = k.ek;
     {
         const uint32_t *src = (const uint32_t *)(ek.cost_all + MVCOST_HALF);
@@ -159,11 +162,13 @@ __global__ __launch_bounds__(64) void k_st_cost(StK k)
     const int16_t *rmv = k.rmv ? k.rmv + (size_t)s * nb * 2 : nullptr;
     const int *icosts = k.intra_cost + (size_t)s * nb;
     uint16_t *lrc = k.lowres_costs + (size_t)s * nb;
-    int right_mv[2][2] = { { 0, 0 }, { 0, 0 } };          // this row's previous block (bx + 1): never re-read from memory
     int sum_inter = 0, sum_intra_mbs = 0;
     const s16x2 sg1 = pk_sign(lane & 1), sg2 = pk_sign(lane & 2);
     const int mvr = 2 * (ek.mv_range > 0 ? ek.mv_range : 512);
 
+    for (int row = row_first; row <= row_last; row++) {
+    const int by = k.start_y - row;
+    int right_mv[2][2] = { { 0, 0 }, { 0, 0 } };          // this row's previous block (bx + 1): never re-read from memory
     for (int bx = k.start_x; bx >= k.end_x; bx--) {
         if (by < k.start_y) {                              // the row below must have finished the block to the lower left
             const int need = min(k.start_x - (bx - 1) + 1, row_total);
@@ -279,6 +284,7 @@ __global__ __launch_bounds__(64) void k_st_cost(StK k)
         if (lane == 0) lrc[bi] = (uint16_t)(min(i_bcost, LOWRES_COST_MASK) + (list_used << LOWRES_COST_SHIFT));
         wfp_release<true>();
         if (lane == 0) wfp_store<true>(prog + by, k.start_x - bx + 1);
+    }
     }
     if (lane == 0) { atomicAdd(k.sums + (size_t)s * 4, sum_inter); atomicAdd(k.sums + (size_t)s * 4 + 2, sum_intra_mbs); }
 }
@@ -448,7 +454,7 @@ struct x264gpu_slicetype {
     uint16_t *lowres_costs[ST_MAX_SLOTS];     // [(d0 * (bframes + 2) + d1)][S][nb]
     std::vector<int32_t> cost_est[ST_MAX_SLOTS];       // [(d0 * (bframes + 2) + d1) * S + s], -1 = not computed
     std::vector<int32_t> intra_mbs[ST_MAX_SLOTS];      // [d0 * S + s]
-    uint16_t *cost_mv; int32_t *sums; int *progress;
+    uint16_t *cost_mv; int32_t *sums; int *progress; int serial_rows = -1;          // serial_rows: -1 auto (batches of >= 512 streams), 0 / 1 forced (tests)
     std::vector<int32_t> h_sums;
     int32_t *prop[ST_MAX_SLOTS]; int16_t *aq[ST_MAX_SLOTS]; bool have_aq[ST_MAX_SLOTS];      // macroblock-tree: propagate costs, AQ offsets (Q8)
     unsigned long long *d_acc;                                                                // [S][4] accumulators of the weight primitives
@@ -604,8 +610,11 @@ int x264gpu_slicetype_frame_cost_w(x264gpu_slicetype *st, int s0, int s1, int sb
         HIP_TRY(hipMemsetAsync(st->progress, 0, S * (size_t)st->bh * sizeof(int), s));
         const int rows = k.start_y - k.end_y + 1;
         if (rows > 0 && k.start_x >= k.end_x) {
-            if (st->me_method == 0) hipLaunchKernelGGL(k_st_cost<0>, dim3(rows, st->streams), dim3(64), 0, s, k);
-            else hipLaunchKernelGGL(k_st_cost<1>, dim3(rows, st->streams), dim3(64), 0, s, k);
+            // a batch of streams: one wavefront a stream walks its rows itself (every SIMD busy without the per-stream pipeline); few streams: a wavefront a row
+            k.serial_rows = st->serial_rows < 0 ? (st->streams >= 512 ? 1 : 0) : st->serial_rows;
+            const int gx = k.serial_rows ? 1 : rows;
+            if (st->me_method == 0) hipLaunchKernelGGL(k_st_cost<0>, dim3(gx, st->streams), dim3(64), 0, s, k);
+            else hipLaunchKernelGGL(k_st_cost<1>, dim3(gx, st->streams), dim3(64), 0, s, k);
         }
         st->searched[sb][0][d0 - 1] = true;
         if (d1 > 0) st->searched[sb][1][d1 - 1] = true;
@@ -769,6 +778,13 @@ int x264gpu_slicetype_cost_aq(x264gpu_slicetype *st, int slot, int d0, int d1, i
     return X264GPU_OK;
 }
 // --b-bias (x264 i_bframe_bias, -90 .. 100): B costs are scaled by 100 / (120 + bias); set once, before the first cost
+int x264gpu_slicetype_set_row_mode(x264gpu_slicetype *st, int serial)
+{
+    ARG_TRY(st && serial >= -1 && serial <= 1);
+    st->serial_rows = serial;
+    return X264GPU_OK;
+}
+
 int x264gpu_slicetype_set_bframe_bias(x264gpu_slicetype *st, int bias)
 {
     ARG_TRY(st && bias >= -90 && bias <= 100);

@@ -140,6 +140,7 @@ _SIGS = {
     "x264gpu_slicetype_chroma_stats": (_i, [_vp, _i, _vp, _vp, _vp]),
     "x264gpu_slicetype_weight_cost_chroma": (_i, [_vp, _i, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp]),
     "x264gpu_slicetype_set_aq": (_i, [_vp, _i, _vp, _vp]),
+    "x264gpu_slicetype_set_row_mode": (_i, [_vp, _i]),
     "x264gpu_slicetype_set_bframe_bias": (_i, [_vp, _i]),
     "x264gpu_slicetype_cost_aq": (_i, [_vp, _i, _i, _i, _vp, _vp]),
     "x264gpu_slicetype_clear_propagate": (_i, [_vp, _i, _vp]),
