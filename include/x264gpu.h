@@ -93,9 +93,9 @@ int x264gpu_mc_avg(const uint8_t *d_a, const uint8_t *d_b, size_t bytes, int wei
 int x264gpu_trellis_blocks(const int16_t *d_coefs, int nblk, int cat, int qp, int intra, const uint8_t *d_states460, int16_t *d_levels, uint8_t *d_nz, void *stream);
 int x264gpu_mc_weight(const uint8_t *d_src, size_t bytes, int scale, int denom, int offset, uint8_t *d_out, void *stream);
 /* The level walk of the CABAC size pricing as a primitive ([x264-upstream] encoder/cabac.c coeff_abs_level_minus1 of residual_block_cabac, every block of a
- * macroblock at once — csrc/cabac_rd.cuh cab_levels_all): n cases; d_levels the macroblocks' levels in x264gpu_mb layout (X264GPU_MB_LEVELS each);
+ * macroblock at once — csrc/cabac_rd.hip.h cab_levels_all): n cases; d_levels the macroblocks' levels in x264gpu_mb layout (X264GPU_MB_LEVELS each);
  * d_what five ints a case: luma category (2 = 4x4, 5 = 8x8, 1 = Intra_16x16 AC, -1 none), mask of luma blocks, of chroma AC blocks (plane * 4 + block), of
- * chroma DC planes, luma DC flag; d_r / d_r8 the role-indexed context registers (64 lanes a case, csrc/cabac_layout.cuh) in, d_r_out / d_r8_out out;
+ * chroma DC planes, luma DC flag; d_r / d_r8 the role-indexed context registers (64 lanes a case, csrc/cabac_layout.hip.h) in, d_r_out / d_r8_out out;
  * d_bits the bits in 1/256 (sign and escape bypass bins included).  tests/test_gpu_prims.py checks it against a serial restatement. */
 int x264gpu_cabac_level_walk(const int16_t *d_levels, const int32_t *d_what, int n, const uint32_t *d_r, const uint32_t *d_r8, uint32_t *d_r_out, uint32_t *d_r8_out, int32_t *d_bits, void *stream);
 
@@ -381,9 +381,9 @@ int  x264gpu_slicetype_weight_cost_chroma(x264gpu_slicetype *st, int slot_fenc, 
 int  x264gpu_slicetype_set_aq(x264gpu_slicetype *st, int slot, const int16_t *d_aq_q8, void *stream);
 /* --b-bias (param.i_bframe_bias, -90 .. 100): slicetype_frame_cost scales B costs by 100 / (120 + bias); call once after create */
 int  x264gpu_slicetype_set_bframe_bias(x264gpu_slicetype *st, int bias);
-/* how x264gpu_slicetype_frame_cost walks a picture's block rows: 1 = one wavefront per stream walks every row itself (a batch of streams fills the chip
- * without the per-stream row pipeline), 0 = one wavefront per row, chained bottom-up by progress counters (a lone stream's latency), -1 = auto
- * (default: 1 from 512 streams on).  The costs are the same either way (tests/test_gpu_lookahead.py). */
+/* how x264gpu_slicetype_frame_cost walks a picture's block rows: 0 = one wavefront per row, chained bottom-up by progress counters (default, and what -1 =
+ * auto picks: measured faster at 1 and at 2048 streams), 1 = one wavefront per stream walks every row itself.  The costs are the same either way
+ * (tests/test_gpu_lookahead.py). */
 int  x264gpu_slicetype_set_row_mode(x264gpu_slicetype *st, int serial);
 /* fenc->i_cost_est_aq[d0][d1] of a triple whose cost has been computed: the block costs weighted with the inverse quantiser scale of the picture's AQ
  * offsets (set_aq), per stream into h_score[streams] — the complexity x264_rc_analyse_slice hands the rate control in AQ sessions without macroblock-tree

@@ -1,6 +1,6 @@
 """Serial restatement of the residual coding (significance maps of 4x4-type blocks + coeff_abs_level_minus1) of a macroblock's blocks as x264's size-only CABAC coder prices it
 ([x264-upstream] encoder/cabac.c residual_block_cabac / encoder/rdo.c: coeff_abs_level1_ctx, coeff_abs_levelgt1_ctx, coeff_abs_level_transition), block
-after block and bin after bin — the checker of the device's all-blocks-at-once level walk (csrc/cabac_rd.cuh cab_levels_all, primitive
+after block and bin after bin — the checker of the device's all-blocks-at-once level walk (csrc/cabac_rd.hip.h cab_levels_all, primitive
 x264gpu_cabac_level_walk).  Test infrastructure: pure Python, the entropy table is the generated csrc/cabac_entropy.inc (tools/gen_cabac_entropy.py)."""
 import os
 import random

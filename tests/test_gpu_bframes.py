@@ -1,4 +1,4 @@
-"""GPU: B pictures through the HIP macroblock loop (k_mb.cuh BS instantiations: spatial direct, both lists' searches, implicit weighted bi-prediction,
+"""GPU: B pictures through the HIP macroblock loop (k_mb.hip.h BS instantiations: spatial direct, both lists' searches, implicit weighted bi-prediction,
 x264's B RD decision, bidirectional refinement) — records, levels, reconstruction and CABAC context variables must equal the CPU checker's picture
 by picture, and the stream the host writer makes of the device's records must decode to the device's reconstruction."""
 import ctypes as C

@@ -160,8 +160,8 @@ def test_slicetype_costs_multistream(gpu):
 
 @pytest.mark.parametrize("w,h,kw", [(176, 144, dict(do_edges=1)), (352, 288, {}), (1920, 1080, dict(do_edges=1))])
 def test_slicetype_costs_one_wavefront_per_stream(gpu, w, h, kw):
-    """the batch geometry of x264gpu_slicetype_frame_cost (one wavefront walks every block row of its stream: x264gpu_slicetype_set_row_mode 1, the
-    default from 512 streams on) gives the same vectors, costs and scores as the row pipeline and the CPU checker"""
+    """the other geometry of x264gpu_slicetype_frame_cost (one wavefront walks every block row of its stream: x264gpu_slicetype_set_row_mode 1) gives the
+    same vectors, costs and scores as the row pipeline and the CPU checker"""
     run_slicetype(w, h, 5, 11, ADAPT[:12] if w < 1000 else ADAPT[:6], streams=2, row_mode=1, **kw)
 
 

@@ -306,7 +306,7 @@ def test_deblock_primitive_vs_the_standard(gpu, alpha, beta, cqo):
 @pytest.mark.parametrize("cat", [0, 1, 2, 3, 4, 5])
 @pytest.mark.parametrize("qp,intra", [(23, 0), (20, 1), (8, 0), (37, 1), (51, 0), (30, 0)])
 def test_trellis_primitive_vs_oracle(gpu, cat, qp, intra):
-    """x264's CABAC trellis quantiser as a device primitive (csrc/trellis.cuh: eight lanes per block = the eight nodes of the search) against
+    """x264's CABAC trellis quantiser as a device primitive (csrc/trellis.hip.h: eight lanes per block = the eight nodes of the search) against
     the checker's restatement (oracle/trellis.cpp), block by block: random transform coefficients with a natural spectrum, random context
     variables, every block category, quantisers from 8 to 51, inter and intra lambda.  The levels must be identical"""
     import ctypes as C
@@ -371,7 +371,7 @@ def test_trellis_primitive_vs_oracle(gpu, cat, qp, intra):
 
 
 def test_cabac_level_walk_primitive_vs_serial_restatement(gpu):
-    """the level walk of the CABAC pricing (csrc/cabac_rd.cuh cab_levels_all: every block of a macroblock at once, one chain per context) against the
+    """the level walk of the CABAC pricing (csrc/cabac_rd.hip.h cab_levels_all: every block of a macroblock at once, one chain per context) against the
     block-by-block, bin-by-bin restatement of x264's coder (tests/cabac_levels_ref.py): same bits, same context variables — every luma category,
     chroma DC / AC, sparse and dense blocks, levels into the escape range, partial block masks"""
     import torch

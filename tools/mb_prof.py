@@ -63,7 +63,7 @@ def main():
         a = out.astype(np.float64).mean(axis=0) / n
         tot = a[:13].sum() + (a[15] if a[15] > 100 else 0)          # -DMB_PROF_RD builds: slot 15 = cycles of the CABAC pricing (RD sessions)
         print("%-4s %10.0f " % ("IIPRb"[pt] + str(disp), tot) + " ".join("%9.0f" % v for v in a[:13]) + " %9.2f %9.2f %9.2f" % (a[13], a[14], a[15]) + "   %.1f ms" % e0.elapsed_time(e1))
-        if a[16] > 0:         # -DMB_PROF_RD: inside the CABAC pricing (cabac_rd.cuh), per macroblock
+        if a[16] > 0:         # -DMB_PROF_RD: inside the CABAC pricing (cabac_rd.hip.h), per macroblock
             print("     cab_mb calls %.2f  header %.0f  cbf+sigmaps %.0f  levels: prep %.0f walk %.0f rest %.0f cycles;  walk steps %.1f  non-zero coefficients %.1f" % (a[16], a[17], a[18], a[22], a[23], a[19], a[20], a[21]))
         if a[27] > 0:
             print("     around the pricing: candidate's distortion terms + header inputs %.0f  cost bookkeeping %.0f cycles" % (a[27], a[28]))

@@ -1,4 +1,4 @@
-// cabac_layout.cuh — where the device keeps the CABAC context variables of a slice (cabac_rd.cuh codes with them, encoder.hip unpacks them
+// cabac_layout.hip.h — where the device keeps the CABAC context variables of a slice (cabac_rd.hip.h codes with them, encoder.hip unpacks them
 // for the tests).
 #pragma once
 

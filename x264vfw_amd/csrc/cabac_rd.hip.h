@@ -1,4 +1,4 @@
-// cabac_rd.cuh — CABAC as x264's rate-distortion code needs it on the device (k_mb.cuh, RD instantiations of CABAC sessions).
+// cabac_rd.hip.h — CABAC as x264's rate-distortion code needs it on the device (k_mb.hip.h, RD instantiations of CABAC sessions).
 //
 // x264 ([x264-upstream] encoder/cabac.c + encoder/rdo.c behind x264_encoder_encode, reference call site codec.c:1693) keeps one set of
 // context variables per slice, moved on by the entropy coding of every finished macroblock, and prices a candidate by running the
@@ -16,8 +16,8 @@
 // Mirrors oracle/cabac_rd.cpp bin for bin; the initialisation values and state transitions are the host coder's tables.
 #pragma once
 #include <type_traits>
-#include "enc_common.cuh"
-#include "cabac_layout.cuh"
+#include "enc_common.hip.h"
+#include "cabac_layout.hip.h"
 #define CABAC_TABLE static __constant__ const
 #define CABAC_NAMESPACE x264gpu_cabac
 #include "../host/cabac_tables.hpp"

@@ -1,11 +1,11 @@
-// common.cuh — shared host/device declarations for the x264gpu library (gfx950 only).
+// common.hip.h — shared host/device declarations for the x264gpu library (gfx950 only).
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
 #include "../../include/x264gpu.h"
-#include "dsp.cuh"
-#include "dsp8.cuh"
+#include "dsp.hip.h"
+#include "dsp8.hip.h"
 
 namespace x264gpu {
 

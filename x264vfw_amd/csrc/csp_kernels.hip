@@ -4,7 +4,7 @@
 // byte written once.  A thread owns an 8-pixel x 2-row cell (one 4:2:0 chroma row), so luma leaves as 8-byte
 // stores and chroma as 4-byte stores; ragged right edges (width % 8) take a scalar tail.  The vertical flip is a
 // negative source pitch, exactly as in the reference.  Restates oracle/csp.c bit-exactly.
-#include "common.cuh"
+#include "common.hip.h"
 
 using namespace x264gpu;
 

@@ -1,7 +1,7 @@
-// deblock_line.cuh — the edge filter of 8.7.2 for one line of luma samples and its tables (shared by the picture-level loop filter, k_deblock.cuh, and
-// the macroblock loop's deblock-aware RD, k_mb.cuh: x264_macroblock_deblock)
+// deblock_line.hip.h — the edge filter of 8.7.2 for one line of luma samples and its tables (shared by the picture-level loop filter, k_deblock.hip.h, and
+// the macroblock loop's deblock-aware RD, k_mb.hip.h: x264_macroblock_deblock)
 #pragma once
-#include "enc_common.cuh"
+#include "enc_common.hip.h"
 
 namespace x264gpu {
 

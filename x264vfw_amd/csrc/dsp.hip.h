@@ -1,4 +1,4 @@
-// dsp.cuh — wave64 device library for the H.264 encode hot path on gfx950 (CDNA4).
+// dsp.hip.h — wave64 device library for the H.264 encode hot path on gfx950 (CDNA4).
 //
 // Layout convention ("Z layout"): one wavefront owns one 16x16 luma macroblock.  Lane l holds one
 // 4-pixel row segment: blk = l>>2 is the 4x4 block in H.264/x264 block order (zigzag of 8x8s, so

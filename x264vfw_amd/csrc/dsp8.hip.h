@@ -1,4 +1,4 @@
-// dsp8.cuh — the 8x8 luma transform path (High profile, A6-A8: sub8x8_dct8, quant_8x8, scan_8x8,
+// dsp8.hip.h — the 8x8 luma transform path (High profile, A6-A8: sub8x8_dct8, quant_8x8, scan_8x8,
 // decimate_score64, dequant_8x8, add8x8_idct8) and SA8D for gfx950.
 //
 // "R8 layout": lane = (8x8 block, row) — 8 lanes own one 8x8 block, each lane holds one row of 8 samples in
@@ -7,7 +7,7 @@
 // lanes (DPP quad_perm for lane^1 / lane^2, a cross-lane shuffle for lane^4).  Quantiser tables have six
 // position classes (normAdjust8x8).  Restates oracle/dct.c + oracle/quant.c bit-exactly.
 #pragma once
-#include "dsp.cuh"
+#include "dsp.hip.h"
 
 namespace x264gpu {
 

@@ -1,8 +1,8 @@
-// enc_common.cuh — device-side view of one lock-step batch of streams (frame pipeline, Tier 2).
+// enc_common.hip.h — device-side view of one lock-step batch of streams (frame pipeline, Tier 2).
 #pragma once
-#include "common.cuh"
-#include "mc.cuh"
-#include "intra.cuh"
+#include "common.hip.h"
+#include "mc.hip.h"
+#include "intra.hip.h"
 
 namespace x264gpu {
 
@@ -71,7 +71,7 @@ struct EncK {
     int qp_frac_q8;           // the picture's quantiser is qp + qp_frac_q8 / 256 (x264gpu_pic.qp_frac_q8): enters the per-macroblock quantisers before the rounding
     int qp_snap;              // --aq-mode != 0: a macroblock quantiser within 1 of the previous macroblock's takes that one (x264_macroblock_analyse)
     int *wf_progress;         // [streams][2][WFG_ROWS]: row counters of the wavefront kernels when ONE stream spans several workgroups
-    // motion side data of the raster macroblock loop (k_mb.cuh; x264: h->mb.mvr, frame->mv16x16, frame->mb_type)
+    // motion side data of the raster macroblock loop (k_mb.hip.h; x264: h->mb.mvr, frame->mv16x16, frame->mb_type)
     int16_t *mv16_cur;        // [streams][nmb][2]: 16x16 search result in reference 0 of the picture being coded (= mvr[0]); lives with the DPB slot
     const int16_t *mv16_ref0; // the same array of reference 0 (temporal candidates)
     int16_t *mvr[8];          // [combined index >= 1][streams][nmb][2]: 16x16 search results per reference (list 0 index 0 lives in mv16_cur)
@@ -92,7 +92,7 @@ struct EncK {
     // load balance of the lock-step batch (encoder.hip k_balance): perm[workgroup] = the stream it codes (null: identity), wtime[stream] = cycles its
     // wavefront took (written by the macroblock loop, read for the next picture of the same kind)
     const int *perm; unsigned *wtime;
-    const uint32_t *ctab;     // CABAC sessions with RD: the chain table of the size-only coder (cabac_rd.cuh cab_chain; prim_kernels.hip cabac_chain_table)
+    const uint32_t *ctab;     // CABAC sessions with RD: the chain table of the size-only coder (cabac_rd.hip.h cab_chain; prim_kernels.hip cabac_chain_table)
     int cabac;                // the session's entropy coder is CABAC: P8x8 cost details of x264's analysis depend on it
     int slices;               // x264 slice threads: slices per picture (rows split evenly), 1 = one
     int slices_plain;         // x264 --slices N rather than slice threads: the loop filter crosses slice boundaries

@@ -3,14 +3,14 @@
 // codec.c:1693) for a lock-step batch of independent closed-GOP streams.
 //
 // Stage order per call (all on the caller's HIP stream, no host synchronisation, graph-capturable):
-//   ingest -> per-macroblock quantisers -> macroblock loop (k_mb.cuh: analysis + encode of every macroblock in raster order,
+//   ingest -> per-macroblock quantisers -> macroblock loop (k_mb.hip.h: analysis + encode of every macroblock in raster order,
 //   one wavefront per stream) -> QP_Y inheritance -> deblock wavefront -> half-pel planes + border expansion.
 //   Device-resident DPB: refs + 1 slots of {4 padded luma planes, padded NV12 chroma, 16x16 vectors, macroblock types} per stream.
-#include "enc_common.cuh"
-#include "k_encode.cuh"
+#include "enc_common.hip.h"
+#include "k_encode.hip.h"
 #include <stdlib.h>
-#include "k_deblock.cuh"
-#include "cabac_layout.cuh"
+#include "k_deblock.hip.h"
+#include "cabac_layout.hip.h"
 #include <math.h>
 #include <vector>
 #include <string.h>
@@ -44,7 +44,8 @@ struct x264gpu_encoder {
     int8_t *colref[8] = {}; int16_t *colmv[8] = {};      // per slot (sessions with B pictures): what spatial direct prediction reads of a co-located picture
     int8_t *colref0[8] = {};                             // ... and temporal direct prediction: the blocks' own list-0 indices; the POCs behind each slot's list 0
     int slot_l0poc[8][8] = {};
-    uint8_t *direct_flags = nullptr; int *dscore = nullptr; bool use_direct_flags = false;      // --direct temporal / auto: per-stream modes of the B picture, the probe counts
+    hipStream_t last_stream = nullptr;               // the stream of the last encode_core call (what a read-back of its results waits for)
+    uint8_t *direct_flags = nullptr, *direct_flags_base = nullptr; int direct_flags_sel = 0; int *dscore = nullptr; bool use_direct_flags = false;      // --direct temporal / auto: per-stream modes of the B picture, the probe counts
     int16_t *mvr[8] = {};                        // per combined reference index >= 1: 16x16 search results of the picture being coded
     int slot_nref[8] = {}, slot_poc[8] = {}, slot_ref0poc[8] = {};
     int poc = 0, ring = 2;                       // the sliding window: next POC, slots in rotation (refs + 1)
@@ -53,7 +54,7 @@ struct x264gpu_encoder {
     unsigned long long *dbg = nullptr;   // diagnostics buffer set by x264gpu_encoder_set_debug
     uint8_t *tc = nullptr;               // RD: total_coeff of every block of the picture being coded
     uint8_t *amvd = nullptr;             // CABAC RD: |mvd| of every 8x8 block of the picture being coded
-    uint32_t *cab_out = nullptr;         // ... and the context variables every slice's wavefront ended with: [stream][slice][3][64] (tests; layout: cabac_rd.cuh cab_locate)
+    uint32_t *cab_out = nullptr;         // ... and the context variables every slice's wavefront ended with: [stream][slice][3][64] (tests; layout: cabac_rd.hip.h cab_locate)
     int *perm = nullptr; unsigned *wtime = nullptr; bool wt_valid[4] = { false, false, false, false };      // load balance: EncK.perm / wtime, one history per picture kind (I, P, B reference, B)
     int *sl_stat = nullptr, *sl_rerun = nullptr;     // --slices N: per (stream, slice) intra statistics of the speculative slice passes (EncK.sl_stat)
     unsigned long long *prof = nullptr;  // MB_PROF builds: phase counters of the last macroblock-loop launch
@@ -263,7 +264,7 @@ void x264gpu_encoder_destroy(x264gpu_encoder *e)
     profile_free(e);
     (void)hipFree(e->fenc_y); (void)hipFree(e->fenc_uv);
     for (int i = 0; i < 8; i++) { (void)hipFree(e->luma[i]); (void)hipFree(e->chroma[i]); (void)hipFree(e->mv16[i]); (void)hipFree(e->mbtype[i]); (void)hipFree(e->colref[i]); (void)hipFree(e->colmv[i]); (void)hipFree(e->colref0[i]); }
-    (void)hipFree(e->direct_flags); (void)hipFree(e->dscore);
+    (void)hipFree(e->direct_flags_base); (void)hipFree(e->dscore);
     for (int i = 0; i < 8; i++) (void)hipFree(e->mvr[i]);
     (void)hipFree(e->wf_progress);
     (void)hipFree(e->tc);
@@ -372,6 +373,7 @@ __global__ void k_col_from_records(EncK k)
 static int encode_core(x264gpu_encoder *e, const uint8_t *d_i420, const x264gpu_pic &pic, x264gpu_mb *d_mb, int16_t *d_levels, hipStream_t st)
 {
     int slice_type = pic.slice_type;
+    e->last_stream = st;
     if (slice_type == X264GPU_SLICE_I_NONIDR) slice_type = X264GPU_SLICE_I;            // same kernels; only the DPB handling differs
     const bool bslice = slice_type == X264GPU_SLICE_B;
     ARG_TRY(pic.dst >= 0 && pic.dst < e->slots && pic.qp >= 0 && pic.qp <= 51);
@@ -613,7 +615,10 @@ int x264gpu_encode_pictures(x264gpu_encoder *e, const uint8_t *d_i420, const x26
         if (any) {
             std::vector<uint8_t> f((size_t)S);
             for (int s = 0; s < S; s++) f[(size_t)s] = pics[s].direct_temporal != 0;
-            if (!e->direct_flags) HIP_TRY(hipMalloc((void **)&e->direct_flags, (size_t)S));
+            // two halves used in turn (as stream_qp is): the B picture of the call before may still be reading the other one on the caller's stream
+            if (!e->direct_flags_base) HIP_TRY(hipMalloc((void **)&e->direct_flags_base, 2 * (size_t)S));
+            e->direct_flags_sel ^= 1;
+            e->direct_flags = e->direct_flags_base + (size_t)e->direct_flags_sel * (size_t)S;
             HIP_TRY(hipMemcpy(e->direct_flags, f.data(), (size_t)S, hipMemcpyHostToDevice));
             e->use_direct_flags = true;
         }
@@ -629,7 +634,7 @@ int x264gpu_encode_pictures(x264gpu_encoder *e, const uint8_t *d_i420, const x26
 int x264gpu_encoder_direct_scores(x264gpu_encoder *e, int *h_scores)
 {
     ARG_TRY(e && h_scores && e->dscore);
-    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipStreamSynchronize(e->last_stream));          // (the stream of the last picture: other sessions on the device are not stalled)
     const int S = e->cfg.streams, nsl = e->cfg.slices > 1 ? e->cfg.slices : 1;
     std::vector<int> tmp((size_t)S * nsl * 2);
     HIP_TRY(hipMemcpy(tmp.data(), e->dscore, tmp.size() * sizeof(int), hipMemcpyDeviceToHost));

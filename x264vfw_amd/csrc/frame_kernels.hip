@@ -1,6 +1,6 @@
 // frame_kernels.hip — whole-frame streaming kernels: half-pel plane filter + border expansion (A4)
 // and the lowres pyramid (A1).  HBM-bound streaming kernels.
-#include "common.cuh"
+#include "common.hip.h"
 
 using namespace x264gpu;
 

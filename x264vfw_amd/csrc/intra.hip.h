@@ -1,11 +1,11 @@
-// intra.cuh — H.264 intra predictors for wave64 (oracle/predict.c; normative 8.3.1-8.3.4).
+// intra.hip.h — H.264 intra predictors for wave64 (oracle/predict.c; normative 8.3.1-8.3.4).
 //
 // Neighbour samples live in small per-wave LDS arrays.  4x4 prediction is table driven: every
 // directional predictor is a 2- or 3-tap filter over the "edge line" e[] (left column bottom->top,
 // corner, top row left->right), so one LDS array U = { e, F2(e), F3(e), DC } plus a 9x16 index table
 // yields all nine modes without divergence — one quad of lanes per mode, nine modes per wavefront.
 #pragma once
-#include "dsp.cuh"
+#include "dsp.hip.h"
 
 namespace x264gpu {
 

@@ -1,6 +1,6 @@
-// k_analyse.cuh — motion-estimation building blocks (A2/A3): LDS search window SADs, the staged sub-pel neighbourhood, the
+// k_analyse.hip.h — motion-estimation building blocks (A2/A3): LDS search window SADs, the staged sub-pel neighbourhood, the
 // chroma-ME term, and the candidate-parallel partition search the lookahead kernel uses.  The macroblock loop of the frame
-// pipeline is k_mb.cuh.
+// pipeline is k_mb.hip.h.
 //
 //   full-pel:  the reference search window (50 rows x 64 B, centred on the best start predictor) is
 //              staged in LDS with coalesced 8-byte loads; candidates are evaluated four at a time,
@@ -9,7 +9,7 @@
 //   sub-pel:   half-pel diamond on SAD, quarter-pel diamond on SATD; the +-2 px neighbourhood of the full-pel
 //              winner in all four half-pel planes is staged in LDS once (sub_stage), SATD in the Z layout.
 #pragma once
-#include "enc_common.cuh"
+#include "enc_common.hip.h"
 
 namespace x264gpu {
 

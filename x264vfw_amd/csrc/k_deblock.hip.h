@@ -1,4 +1,4 @@
-// k_deblock.cuh — in-loop deblocking filter (A9; H.264 8.7) as a 2-D wavefront.  The normative
+// k_deblock.hip.h — in-loop deblocking filter (A9; H.264 8.7) as a 2-D wavefront.  The normative
 // macroblock order (left, top and top-right neighbours first) makes this a d = x + 2y wavefront: one
 // workgroup per stream (or several, few streams in flight), rows handed off through progress counters.  Each
 // wavefront stages its macroblocks (+4 rows / 4 columns of neighbours) in LDS, runs the four vertical
@@ -6,8 +6,8 @@
 // writes back only the samples the standard lets this macroblock modify.
 // Restates oracle/encoder.c deblock_frame + oracle/deblock.c bit-exactly.
 #pragma once
-#include "enc_common.cuh"
-#include "deblock_line.cuh"
+#include "enc_common.hip.h"
+#include "deblock_line.hip.h"
 
 namespace x264gpu {
 

@@ -1,7 +1,7 @@
-// k_encode.cuh — frame-level kernels around the macroblock loop (k_mb.cuh): ingest (A1), per-macroblock quantisers (AQ, caller
+// k_encode.hip.h — frame-level kernels around the macroblock loop (k_mb.hip.h): ingest (A1), per-macroblock quantisers (AQ, caller
 // offsets), QP_Y inheritance.  Restates oracle/encoder.c ingest / compute_mb_qp / settle_mb_qp bit-exactly.
 #pragma once
-#include "enc_common.cuh"
+#include "enc_common.hip.h"
 
 namespace x264gpu {
 

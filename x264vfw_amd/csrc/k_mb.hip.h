@@ -1,4 +1,4 @@
-// k_mb.cuh — the macroblock loop of one slice in x264's own structure, raster-serial: x264_macroblock_analyse + x264_macroblock_encode
+// k_mb.hip.h — the macroblock loop of one slice in x264's own structure, raster-serial: x264_macroblock_analyse + x264_macroblock_encode
 // per macroblock ([x264-upstream] encoder/analyse.c, me.c, macroblock.c behind x264_encoder_encode, reference call site codec.c:1693).
 //
 // Why raster-serial: every decision of a macroblock reads macroblocks BEFORE it in raster order of the same slice — motion vector
@@ -10,11 +10,11 @@
 //
 // Restates oracle/analyse.c bit-exactly (records, levels, reconstruction).
 #pragma once
-#include "deblock_line.cuh"
-#include "enc_common.cuh"
-#include "k_analyse.cuh"
-#include "intra8.cuh"
-#include "rd.cuh"
+#include "deblock_line.hip.h"
+#include "enc_common.hip.h"
+#include "k_analyse.hip.h"
+#include "intra8.hip.h"
+#include "rd.hip.h"
 
 namespace x264gpu {
 
@@ -75,7 +75,7 @@ struct MbCtx {
 enum { PH_SETUP, PH_ME_PRED, PH_ME_WIN, PH_ME_FPEL, PH_ME_SUBSTAGE, PH_ME_SUBPEL, PH_ME_GLUE, PH_PSKIP, PH_INTRA_CHROMA, PH_INTRA, PH_ENC_INTER, PH_ENC_INTRA, PH_STORE, PH_COUNT };
 #ifdef MB_PROF
 struct Prof {
-    unsigned long long t, acc[32], t2;          // 0..15: the phases / counts of the macroblock loop; 16..31: inside the CABAC pricing (cabac_rd.cuh, -DMB_PROF_RD)
+    unsigned long long t, acc[32], t2;          // 0..15: the phases / counts of the macroblock loop; 16..31: inside the CABAC pricing (cabac_rd.hip.h, -DMB_PROF_RD)
     __device__ __forceinline__ void start() { for (int i = 0; i < 32; i++) acc[i] = 0; t = __builtin_readcyclecounter(); t2 = t; }
     __device__ __forceinline__ void mark(int i) { const unsigned long long n = __builtin_readcyclecounter(); acc[i] += n - t; t = n; }
     __device__ __forceinline__ void count(int i) { acc[i]++; }
@@ -853,12 +853,12 @@ __device__ __forceinline__ int pick_intra_mode(F raw, int avail, int pm, int lam
 }
 
 }  // namespace x264gpu
-#include "cabac_rd.cuh"          // needs the motion cache and the intra-mode helpers above
-#include "trellis.cuh"
+#include "cabac_rd.hip.h"          // needs the motion cache and the intra-mode helpers above
+#include "trellis.hip.h"
 namespace x264gpu {
 
 // The trellis sites of a macroblock's FINAL encode (x264 --trellis 1; k.trellis = the mask of sites, 63 = all): what they need to run the
-// search of trellis.cuh on the slice's live context variables (read only)
+// search of trellis.hip.h on the slice's live context variables (read only)
 enum { TR_P4 = 1, TR_P8 = 2, TR_C = 4, TR_I16 = 8, TR_I4 = 16, TR_I8 = 32 };
 struct TrCtx { int on; uint32_t r, r8, model; TrellisTab tt; };
 // nblk blocks of category CAT at coefs (scan order, `stride` entries apart), eight per pass; returns the mask of blocks left non-zero
@@ -1466,8 +1466,8 @@ __device__ __forceinline__ void b_predict(const EncK &k, const MbCtx &c, const B
 #ifndef MB_WAVES_PER_EU
 #define MB_WAVES_PER_EU 2
 #endif
-// RD: 0 = SATD decisions (subme <= 5); 1 = RD mode decision with CAVLC bit counts (rd.cuh); 2 = with CABAC context states and sizes (cabac_rd.cuh);
-// 3 = 2 + the trellis quantiser in the final encode (trellis.cuh) — an instantiation of its own: the search's registers would cost the others spills;
+// RD: 0 = SATD decisions (subme <= 5); 1 = RD mode decision with CAVLC bit counts (rd.hip.h); 2 = with CABAC context states and sizes (cabac_rd.hip.h);
+// 3 = 2 + the trellis quantiser in the final encode (trellis.hip.h) — an instantiation of its own: the search's registers would cost the others spills;
 // 4 = 3 + the search in the intra analysis' block encodes and in every RD candidate (x264 --trellis 2);
 // 5 / 6 = 3 / 4 + RD refinement of the chosen type's vectors and intra modes (x264 subme >= 8: k_mb_refine.inc)
 // BS: B slice (PS is set as well: an inter slice) — RD instantiations with CABAC only; its own analysis and candidate order (k_mb_b.inc)
@@ -1522,7 +1522,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(MB_WAVES_PER
 #endif
     // x264_slice_write: the slice's quantiser (header, context initialisation, start of the mb_qp_delta chain) is its FIRST macroblock's
     int last_qp = uni((int)k.mbqp[(size_t)s * k.nmb + mb_first]);
-    // CABAC RD: the slice's context variables (two registers, see cabac_rd.cuh), the probability model, the previous macroblock's mb_qp_delta
+    // CABAC RD: the slice's context variables (two registers, see cabac_rd.hip.h), the probability model, the previous macroblock's mb_qp_delta
     Cab cab = { 0, 0, 0, 0, 0 };
     uint32_t cab_modelv = 0;
     int last_dqp = 0;

@@ -5,11 +5,11 @@
 //   k_la_lowres : the four half-resolution phase planes of the mod-16 expanded luma, written with their replicated borders in
 //                 one pass (HBM streaming: reads W*H, writes 4 * (W/2 + 64) * (H/2 + 64)).
 //   k_la_cost   : one wavefront per 2x2 group of 8x8 half-resolution blocks.  The four inter searches run side by side in the
-//                 candidate-parallel partition layout of k_analyse.cuh (search_parts, global-memory mode: per-block predictor and
+//                 candidate-parallel partition layout of k_analyse.hip.h (search_parts, global-memory mode: per-block predictor and
 //                 limits), the intra costs in the (block, 4x4, row) layout (8x8c DC/H/V/P) and in (mode pair, block, row) for the
 //                 filtered Intra_8x8 modes 3..8.  Frame sums are one atomicAdd per wave and counter.
-#include "k_analyse.cuh"
-#include "intra8.cuh"
+#include "k_analyse.hip.h"
+#include "intra8.hip.h"
 #include <new>
 #include <string.h>
 #include <math.h>

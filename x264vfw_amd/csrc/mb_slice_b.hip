@@ -1,6 +1,6 @@
-// mb_slice_b.hip — the macroblock-loop kernel (k_mb.cuh) instantiated for B slices (--me hex; RD sessions with CABAC, without the trellis quantiser,
+// mb_slice_b.hip — the macroblock-loop kernel (k_mb.hip.h) instantiated for B slices (--me hex; RD sessions with CABAC, without the trellis quantiser,
 // with it in the final encode, and with it in the analysis too): a translation unit of its own, like the per-method ones (mb_slice_b_dia / _umh / _esa.hip).
-#include "k_mb.cuh"
+#include "k_mb.hip.h"
 
 namespace x264gpu {
 void launch_mb_slice_ref_b_hex(const EncK &k, int streams, hipStream_t st);        // mb_slice_ref_b_hex.hip

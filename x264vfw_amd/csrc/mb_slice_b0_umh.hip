@@ -1,6 +1,6 @@
-// mb_slice_b0_umh.hip — the macroblock-loop kernel (k_mb.cuh) instantiated for B slices analysed without RD (x264 below --subme 7 in B slices:
+// mb_slice_b0_umh.hip — the macroblock-loop kernel (k_mb.hip.h) instantiated for B slices analysed without RD (x264 below --subme 7 in B slices:
 // probe_bskip, SATD decisions, me_refine_qpel of the winner; k_mb_b.inc's RD == 0 branches), --me umh.
-#include "k_mb.cuh"
+#include "k_mb.hip.h"
 
 namespace x264gpu {
 void launch_mb_slice_b0_umh(const EncK &k, int streams, hipStream_t st)

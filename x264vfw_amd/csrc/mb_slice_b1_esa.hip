@@ -1,6 +1,6 @@
-// mb_slice_b1_esa.hip — the macroblock-loop kernel (k_mb.cuh) instantiated for B slices of RD sessions WITHOUT CABAC (x264 --no-cabac at --subme 7 and
+// mb_slice_b1_esa.hip — the macroblock-loop kernel (k_mb.hip.h) instantiated for B slices of RD sessions WITHOUT CABAC (x264 --no-cabac at --subme 7 and
 // up: the B decisions priced with CAVLC bit counts, cavlc_mb_header_b as a count), --me esa; a translation unit of its own.
-#include "k_mb.cuh"
+#include "k_mb.hip.h"
 
 namespace x264gpu {
 void launch_mb_slice_b1_esa(const EncK &k, int streams, hipStream_t st)

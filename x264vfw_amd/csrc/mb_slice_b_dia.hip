@@ -1,6 +1,6 @@
-// mb_slice_b_dia.hip — the macroblock-loop kernel (k_mb.cuh) instantiated for B slices under --me dia (RD sessions with CABAC; with and without
+// mb_slice_b_dia.hip — the macroblock-loop kernel (k_mb.hip.h) instantiated for B slices under --me dia (RD sessions with CABAC; with and without
 // the trellis quantiser): a translation unit of its own so that the instantiations build in parallel.
-#include "k_mb.cuh"
+#include "k_mb.hip.h"
 
 namespace x264gpu {
 void launch_mb_slice_b1_dia(const EncK &k, int streams, hipStream_t st);        // mb_slice_b1_dia.hip

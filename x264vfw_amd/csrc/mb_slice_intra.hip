@@ -1,6 +1,6 @@
-// mb_slice_intra.hip — the macroblock-loop kernel (k_mb.cuh) instantiated for I slices: no motion search, so one instantiation serves
+// mb_slice_intra.hip — the macroblock-loop kernel (k_mb.hip.h) instantiated for I slices: no motion search, so one instantiation serves
 // every --me method and sub-pel margin.
-#include "k_mb.cuh"
+#include "k_mb.hip.h"
 
 namespace x264gpu {
 void launch_mb_slice_ref_intra(const EncK &k, int streams, hipStream_t st);        // mb_slice_ref_intra.hip

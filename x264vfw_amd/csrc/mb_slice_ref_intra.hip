@@ -1,6 +1,6 @@
-// mb_slice_ref_intra.hip — the macroblock-loop kernel (k_mb.cuh) for I slices with RD refinement of the intra modes (x264 --subme 8: intra_rd_refine,
+// mb_slice_ref_intra.hip — the macroblock-loop kernel (k_mb.hip.h) for I slices with RD refinement of the intra modes (x264 --subme 8: intra_rd_refine,
 // k_mb_refine.inc), trellis 0 / 1 (RD 5) and trellis 2 (RD 6).
-#include "k_mb.cuh"
+#include "k_mb.hip.h"
 
 namespace x264gpu {
 void launch_mb_slice_ref_intra(const EncK &k, int streams, hipStream_t st)

@@ -1,6 +1,6 @@
-// mb_slice_ref_umh.hip — the macroblock-loop kernel (k_mb.cuh) with RD refinement (x264 --subme 8: k_mb_refine.inc) for P slices under --me umh: the
+// mb_slice_ref_umh.hip — the macroblock-loop kernel (k_mb.hip.h) with RD refinement (x264 --subme 8: k_mb_refine.inc) for P slices under --me umh: the
 // +-5 sample sub-pel neighbourhood (4 half-pel + 10 quarter-pel iterations), trellis 0 / 1 (RD 5) and trellis 2 (RD 6); a translation unit of its own.
-#include "k_mb.cuh"
+#include "k_mb.hip.h"
 
 namespace x264gpu {
 void launch_mb_slice_ref_umh(const EncK &k, int streams, hipStream_t st)

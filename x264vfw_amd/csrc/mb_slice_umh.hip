@@ -1,6 +1,6 @@
-// mb_slice_umh.hip — the macroblock-loop kernel (k_mb.cuh) instantiated for --me umh: one translation unit per search method so that
+// mb_slice_umh.hip — the macroblock-loop kernel (k_mb.hip.h) instantiated for --me umh: one translation unit per search method so that
 // the four instantiation pairs build in parallel.
-#include "k_mb.cuh"
+#include "k_mb.hip.h"
 
 namespace x264gpu {
 void launch_mb_slice_ref_umh(const EncK &k, int streams, hipStream_t st);        // mb_slice_ref_umh.hip

@@ -1,8 +1,8 @@
-// mc.cuh — motion-compensated sample fetch for gfx950 (oracle/mc.c: x264o_mc_luma / x264o_mc_chroma;
+// mc.hip.h — motion-compensated sample fetch for gfx950 (oracle/mc.c: x264o_mc_luma / x264o_mc_chroma;
 // normative H.264 8.4.2.2).  Luma quarter-pel samples come from the four half-pel planes (full, H, V,
 // HV) resident in HBM: at most two unaligned dword loads + one packed rounding average per 4 pixels.
 #pragma once
-#include "dsp.cuh"
+#include "dsp.hip.h"
 
 namespace x264gpu {
 

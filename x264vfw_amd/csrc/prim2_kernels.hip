@@ -5,9 +5,9 @@
 // registers.  Row transforms are in-lane 8-point butterflies; column transforms run after an 8x8 transpose
 // across the 8 lanes (three exchange stages: DPP quad_perm for lane^1 / lane^2, a cross-lane shuffle for
 // lane^4).  Quantiser tables have six position classes (normAdjust8x8); each lane keeps the four it needs.
-#include "common.cuh"
-#include "intra.cuh"
-#include "dsp8.cuh"
+#include "common.hip.h"
+#include "intra.hip.h"
+#include "dsp8.hip.h"
 
 using namespace x264gpu;
 

@@ -1,10 +1,10 @@
 // prim_kernels.hip — Tier-1 batch primitives of include/x264gpu.h ("checkasm" surface).
-// Thin kernels around the wave-level device library (dsp.cuh, mc.cuh) that the frame pipeline uses,
+// Thin kernels around the wave-level device library (dsp.hip.h, mc.hip.h) that the frame pipeline uses,
 // so each primitive is parity-tested against oracle/ with exactly the device code that ships.
-#include "common.cuh"
-#include "mc.cuh"
-#include "k_mb.cuh"          // the motion cache + intra helpers cabac_rd.cuh builds on
-#include "trellis.cuh"
+#include "common.hip.h"
+#include "mc.hip.h"
+#include "k_mb.hip.h"          // the motion cache + intra helpers cabac_rd.hip.h builds on
+#include "trellis.hip.h"
 #include <math.h>
 #include <mutex>
 #include <vector>
@@ -227,7 +227,7 @@ int x264gpu_mc_chroma(const uint8_t *d_nv12_00, int stride, const int32_t *d_xy,
     return X264GPU_OK;
 }
 
-// ---- trellis quantiser primitive (trellis.cuh): blocks in, levels out, against caller-supplied context variables ----
+// ---- trellis quantiser primitive (trellis.hip.h): blocks in, levels out, against caller-supplied context variables ----
 }  // extern "C"
 
 namespace x264gpu {
@@ -250,7 +250,7 @@ static int trellis_tables(TrellisTab *out)
         static const uint8_t trans_lps[64] = { 0, 0, 1, 2, 2, 4, 4, 5, 6, 7, 8, 9, 9, 11, 11, 12, 13, 13, 15, 15, 16, 16, 18, 18, 19, 19, 21, 21, 22, 22, 23, 24,
                                                24, 25, 26, 26, 27, 27, 28, 29, 29, 30, 30, 30, 31, 32, 32, 33, 33, 33, 34, 34, 35, 35, 35, 36, 36, 36, 37, 37, 37, 38, 38, 63 };
         auto next = [&](int st, int b) { const int s = st >> 1, mps = st & 1; return (mps ^ b) ? (trans_lps[s] << 1) | (s == 0 ? mps ^ 1 : mps) : ((s < 62 ? s + 1 : 62) << 1) | mps; };
-        struct Host { int l2[104]; int qt[52 * TRELLIS_QT_ROW]; uint16_t su[15 * 128]; uint8_t tu[15 * 128]; };       // (qt directly behind l2: trellis.cuh finds it there)
+        struct Host { int l2[104]; int qt[52 * TRELLIS_QT_ROW]; uint16_t su[15 * 128]; uint8_t tu[15 * 128]; };       // (qt directly behind l2: trellis.hip.h finds it there)
         static Host hst;
         for (int prefix = 0; prefix < 15; prefix++)
             for (int c0 = 0; c0 < 128; c0++) {
@@ -260,7 +260,7 @@ static int trellis_tables(TrellisTab *out)
                 hst.su[prefix * 128 + c0] = (uint16_t)(bits + 256); hst.tu[prefix * 128 + c0] = (uint8_t)ctx;
             }
         for (int qp = 0; qp < 52; qp++) { hst.l2[qp] = (int)(0.85 * 0.85 * pow(2.0, qp / 3.0 + 6.0) + 0.5); hst.l2[52 + qp] = (int)(0.65 * 0.65 * pow(2.0, qp / 3.0 + 6.0) + 0.5); }
-        // quantiser, rounding offset, inverse and distortion weight of every coefficient class at every quantiser (trellis.cuh used to divide for
+        // quantiser, rounding offset, inverse and distortion weight of every coefficient class at every quantiser (trellis.hip.h used to divide for
         // them at the top of every call): classes 0..2 of 4x4 blocks, 3..8 of 8x8 blocks, 9 of DC blocks; { mf, bias, unq, w } each
         {
             static const int q4[6][3] = { { 13107, 8066, 5243 }, { 11916, 7490, 4660 }, { 10082, 6554, 4194 }, { 9362, 5825, 3647 }, { 8192, 5243, 3355 }, { 7282, 4559, 2893 } };
@@ -296,7 +296,7 @@ static int trellis_tables(TrellisTab *out)
     return X264GPU_OK;
 }
 
-// The CABAC chain table (cabac_rd.cuh cab_chain): what k = 0..8 bins on ONE context variable leave behind — entry ((2^k - 1) + pattern) * 128 + variable
+// The CABAC chain table (cabac_rd.hip.h cab_chain): what k = 0..8 bins on ONE context variable leave behind — entry ((2^k - 1) + pattern) * 128 + variable
 // holds the variable after the bins (first bin = bit 0 of the pattern) in bits 0..6 and their cost (1/256 bit) above.  It turns the serial bin-by-bin
 // state machine of the size-only coder into one lookup per eight bins; 261 KB, built once per device, read through the scalar cache / L2.
 int cabac_chain_table(const uint32_t **out)
@@ -362,7 +362,7 @@ __global__ void __launch_bounds__(64) k_trellis_blocks(const int16_t *coefs, int
     const int sig_off = CAT == 0 ? 105 : CAT == 1 ? 120 : CAT == 2 ? 134 : CAT == 3 ? 149 : CAT == 4 ? 152 : 402;
     const int last_off = CAT == 0 ? 166 : CAT == 1 ? 181 : CAT == 2 ? 195 : CAT == 3 ? 210 : CAT == 4 ? 213 : 417;
     const int abs_off = CAT == 0 ? 227 : CAT == 1 ? 237 : CAT == 2 ? 247 : CAT == 3 ? 257 : CAT == 4 ? 266 : 426;
-    // the category's context variables in the role layout of cabac_rd.cuh (cab_locate): this lane's byte of r / r8
+    // the category's context variables in the role layout of cabac_rd.hip.h (cab_locate): this lane's byte of r / r8
     uint32_t reg = 0;
     for (int ctx = 0; ctx < 460; ctx++) {
         int rg, ln, sh;
@@ -407,7 +407,7 @@ int x264gpu_trellis_blocks(const int16_t *d_coefs, int nblk, int cat, int qp, in
 }
 
 
-/* the level walk of the CABAC pricing (cabac_rd.cuh cab_levels_all) as a primitive: n macroblocks' levels (x264gpu_mb layout, 416 each), what to cover
+/* the level walk of the CABAC pricing (cabac_rd.hip.h cab_levels_all) as a primitive: n macroblocks' levels (x264gpu_mb layout, 416 each), what to cover
  * per case (d_what[5 n]: luma category 2 / 5 / 1 / -1, luma block mask, chroma AC block mask, chroma DC plane mask, luma DC flag), the role-indexed
  * context registers r / r8 in and out (64 lanes each), the bits (1/256) out */
 }  // extern "C"

@@ -1,8 +1,8 @@
-// rd.cuh — bit counts for the rate-distortion costs of the macroblock loop (k_mb.cuh, RD instantiations): x264_macroblock_size_cavlc
+// rd.hip.h — bit counts for the rate-distortion costs of the macroblock loop (k_mb.hip.h, RD instantiations): x264_macroblock_size_cavlc
 // ([x264-upstream] encoder/cavlc.c compiled with RDO_SKIP_BS) counts exactly the bits the macroblock layer takes in a CAVLC slice.
 // The code tables are the host writer's (host/cavlc_tables.hpp), placed in constant memory for the device.
 #pragma once
-#include "enc_common.cuh"
+#include "enc_common.hip.h"
 #define CAVLC_TABLE static __constant__ const
 #define CAVLC_NAMESPACE x264gpu_cavlc
 #include "../host/cavlc_tables.hpp"

@@ -1,5 +1,5 @@
 // runtime.hip — C-ABI runtime shims (device selection, memory, streams) of include/x264gpu.h.
-#include "common.cuh"
+#include "common.hip.h"
 #include <string.h>
 
 namespace x264gpu {

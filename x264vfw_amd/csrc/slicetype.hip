@@ -9,9 +9,9 @@
 //   k_st_cost   : the inter costs.  x264 walks the blocks in REVERSE raster order and predicts a block's vector from its right / lower /
 //                 lower-left / lower-right neighbours of the same search, so a block depends on the row below: one wavefront per block row,
 //                 rows chained bottom-up by progress counters in global memory (a 2:1 wavefront, as k_deblock2<true>); inside a block the
-//                 wavefront runs the main encoder's me_search (k_mb.cuh: 4 x 16 / 8 x 8 candidate-row lanes, reference cache in LDS) with the
+//                 wavefront runs the main encoder's me_search (k_mb.hip.h: 4 x 16 / 8 x 8 candidate-row lanes, reference cache in LDS) with the
 //                 lookahead's settings (qp 12, me <= hex, sub-pel level 4), then the bidirectional candidates of B costs.
-#include "k_mb.cuh"
+#include "k_mb.hip.h"
 #include <new>
 #include <string.h>
 #include <math.h>
@@ -454,7 +454,7 @@ struct x264gpu_slicetype {
     uint16_t *lowres_costs[ST_MAX_SLOTS];     // [(d0 * (bframes + 2) + d1)][S][nb]
     std::vector<int32_t> cost_est[ST_MAX_SLOTS];       // [(d0 * (bframes + 2) + d1) * S + s], -1 = not computed
     std::vector<int32_t> intra_mbs[ST_MAX_SLOTS];      // [d0 * S + s]
-    uint16_t *cost_mv; int32_t *sums; int *progress; int serial_rows = -1;          // serial_rows: -1 auto (batches of >= 512 streams), 0 / 1 forced (tests)
+    uint16_t *cost_mv; int32_t *sums; int *progress; int serial_rows = -1;          // serial_rows: -1 auto (= 0: measured faster at every batch size), 0 / 1 forced
     std::vector<int32_t> h_sums;
     int32_t *prop[ST_MAX_SLOTS]; int16_t *aq[ST_MAX_SLOTS]; bool have_aq[ST_MAX_SLOTS];      // macroblock-tree: propagate costs, AQ offsets (Q8)
     unsigned long long *d_acc;                                                                // [S][4] accumulators of the weight primitives
@@ -610,8 +610,10 @@ int x264gpu_slicetype_frame_cost_w(x264gpu_slicetype *st, int s0, int s1, int sb
         HIP_TRY(hipMemsetAsync(st->progress, 0, S * (size_t)st->bh * sizeof(int), s));
         const int rows = k.start_y - k.end_y + 1;
         if (rows > 0 && k.start_x >= k.end_x) {
-            // a batch of streams: one wavefront a stream walks its rows itself (every SIMD busy without the per-stream pipeline); few streams: a wavefront a row
-            k.serial_rows = st->serial_rows < 0 ? (st->streams >= 512 ? 1 : 0) : st->serial_rows;
+            // one wavefront a row, chained bottom-up (default), or — x264gpu_slicetype_set_row_mode(1) — one wavefront a stream walking its rows itself.
+            // Measured at 2048 streams of 1080p (bench.py `lookahead`): the single wavefront is 8 % SLOWER (17.8 s vs 16.5 s for 23 costs): the rows'
+            // pipeline was not what the costs wait for, the searches are; so auto = the row pipeline at every batch size
+            k.serial_rows = st->serial_rows < 0 ? 0 : st->serial_rows;
             const int gx = k.serial_rows ? 1 : rows;
             if (st->me_method == 0) hipLaunchKernelGGL(k_st_cost<0>, dim3(gx, st->streams), dim3(64), 0, s, k);
             else hipLaunchKernelGGL(k_st_cost<1>, dim3(gx, st->streams), dim3(64), 0, s, k);

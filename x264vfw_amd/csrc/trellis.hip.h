@@ -1,4 +1,4 @@
-// trellis.cuh — x264's CABAC trellis quantiser on the device ([x264-upstream] encoder/rdo.c quant_trellis_cabac; `--trellis 1`: the
+// trellis.hip.h — x264's CABAC trellis quantiser on the device ([x264-upstream] encoder/rdo.c quant_trellis_cabac; `--trellis 1`: the
 // final encode of a macroblock).  Mirrors oracle/trellis.cpp decision for decision; the algorithm is stated in oracle/TRELLIS_NOTES.md.
 //
 // EIGHT LANES PER BLOCK = THE EIGHT NODES of the search (the abs-level context states CABAC can be in), eight blocks per pass of a
@@ -12,9 +12,9 @@
 //   * the winner's context bytes and its path (two bits per position: 0 = level 0, 1 = q - 1, 2 = q) come over with one shuffle each.
 // The significance / last costs of a position are the same for all blocks (the slice's context variables are only read): lane p works out
 // position p's once per call, a block fetches the ones of its current position with a ds_bpermute.  Used by the RD = 3 / 4 instantiations
-// of the macroblock loop (k_mb.cuh: trellis_run) and, as a primitive, by x264gpu_trellis_blocks (tests/test_gpu_prims.py).
+// of the macroblock loop (k_mb.hip.h: trellis_run) and, as a primitive, by x264gpu_trellis_blocks (tests/test_gpu_prims.py).
 #pragma once
-#include "cabac_rd.cuh"
+#include "cabac_rd.hip.h"
 
 namespace x264gpu {
 
@@ -64,7 +64,7 @@ __device__ __forceinline__ int tr_size_ue_big(unsigned v) { return 2 * (31 - __b
 // in scan order, block b at coefs + b * stride (AC blocks: 16 entries, entry 0 = 0); the levels replace them.  nblk <= 8.  lane & 7 = node,
 // lane >> 3 = block.  st_sig / st_last / st_abs: accessors of the slice's context variables of the category (wave-uniform arguments).
 // Returns the mask of blocks with a non-zero level (wave-uniform).
-// The context variables come in `reg`: the role-indexed register of the category (cabac_rd.cuh: r for categories 0..4 — this category's byte —,
+// The context variables come in `reg`: the role-indexed register of the category (cabac_rd.hip.h: r for categories 0..4 — this category's byte —,
 // r8 for 8x8 blocks).  ONE out-of-line copy per category serves every call site: inlined eight times the search cost the macroblock loop
 // twice the register spills.
 typedef __attribute__((address_space(3))) int16_t lds_i16;

@@ -263,18 +263,24 @@ static void batch_leave(BatchGroup *g, int s)
 {
     // the registry lock first (the order batch_join takes them in): "last" is decided and the group unlisted under it, so that a joiner can
     // never be handed a group that is about to be destroyed; a group that lost a member takes no more joiners (closed), its seats stay empty
-    std::lock_guard<std::mutex> reg(g_batch_mu);
-    bool last;
+    // ... and ONLY that under it: the round the others were waiting for (a whole device launch plus downloads) runs after the registry lock is released,
+    // under the group's own lock — every x264_encoder_open / close that touches the batcher would otherwise wait for a GPU round
+    bool last, run = false;
     {
+        std::lock_guard<std::mutex> reg(g_batch_mu);
         std::unique_lock<std::mutex> lk(g->m);
         g->member[(size_t)s] = 0; g->active--; g->closed = true;
         last = g->active == 0;
-        if (!last && g->n_arrived >= g->active && g->n_arrived > 0) batch_run_round(g);      // the others were only waiting for this session
+        run = !last && g->n_arrived >= g->active && g->n_arrived > 0;      // the others were only waiting for this session
+        if (last)
+            for (size_t i = 0; i < g_batch_groups.size(); i++) if (g_batch_groups[i] == g) { g_batch_groups.erase(g_batch_groups.begin() + (long)i); break; }
     }
-    if (last) {
-        for (size_t i = 0; i < g_batch_groups.size(); i++) if (g_batch_groups[i] == g) { g_batch_groups.erase(g_batch_groups.begin() + (long)i); break; }
-        batch_destroy(g);
+    if (run) {
+        // (the group cannot go away meanwhile: its remaining members are blocked in batch_wait until this round is done)
+        std::unique_lock<std::mutex> lk(g->m);
+        if (g->active > 0 && g->n_arrived >= g->active && g->n_arrived > 0) batch_run_round(g);
     }
+    if (last) batch_destroy(g);
 }
 
 // [x264-upstream] encoder/ratecontrol.c qp2qscale / qscale2qp: single floats (powf / log2f), as x264 has them
@@ -732,7 +738,7 @@ x264_t *x264_encoder_open(x264_param_t *param)
     h->rc.fps = p.i_fps_num ? (double)p.i_fps_num / p.i_fps_den : 25.0;
     if (h->pass2) {
         if (!p2_load(h, p.rc.psz_stat_in) || !p2_init(h)) { x264_encoder_close(h); return nullptr; }
-        xlog(&p, X264_LOG_INFO, "2-pass: %d pictures planned from the first pass' statistics, %.1f kbit expected\n", (int)h->p2.size(), h->p2_final_bits / 1000.0);
+        xlog(&p, X264_LOG_INFO, "2-pass: %d pictures planned from the first pass' statistics, %.1f kbit expected before the last one\n", (int)h->p2.size(), h->p2_final_bits / 1000.0);
     }
     if (h->pass1) {
         // x264 writes <stats>.temp and renames it when the encoder closes; the first line names the options the second pass must agree with
@@ -1779,7 +1785,7 @@ static bool p2_init(x264_t *h)
     // the plan in coding order: what should have been spent when each picture starts
     expected_bits = 0;
     for (int k = 0; k < n; k++) { auto &e = E[(size_t)h->p2_out[(size_t)k]]; e.expected_bits = expected_bits; expected_bits += p2_qscale2bits(e, e.new_qscale); }
-    h->p2_final_bits = expected_bits;
+    h->p2_final_bits = n > 0 ? E[(size_t)h->p2_out[(size_t)(n - 1)]].expected_bits : 0;          // x264: entry_out[num_entries - 1]->expected_bits — what should have been spent BEFORE the last picture
     if (fabs(expected_bits / all_available_bits - 1.0) > 0.01) {
         double avgq = 0;
         for (auto &e : E) avgq += e.new_qscale;
@@ -1799,13 +1805,13 @@ static double p2_pick_qscale(x264_t *h, int frame, long coded_so_far)
     const x264_t::Pass2Entry &e = h->p2[(size_t)frame];
     double abr_buffer = h->p2_abr_buffer;
     if (n > coded_so_far) {           // adjust the buffer by the distance to the end of the video
-        const double video_pos = e.expected_bits / h->p2_final_bits, scale_factor = sqrt((1 - video_pos) * n);
+        const double video_pos = h->p2_final_bits > 0 ? e.expected_bits / h->p2_final_bits : 1.0, scale_factor = sqrt((1 - video_pos) * n);
         abr_buffer *= 0.5 * (scale_factor > 0.5 ? scale_factor : 0.5);
     }
     const double diff = h->p2_total_bits - e.expected_bits;
     double q = e.new_qscale, c = (abr_buffer - diff) / abr_buffer;
     q /= c < .5 ? .5 : c > 2 ? 2 : c;
-    if (coded_so_far + 1 >= h->rc.fps && h->p2_expected_sum > 0) {
+    if (coded_so_far >= h->rc.fps && h->p2_expected_sum >= 1) {          // x264: h->i_frame >= rcc->fps && rcc->expected_bits_sum >= 1
         const double cur_time = (double)coded_so_far / n, w = cur_time * 100 < 0 ? 0 : cur_time * 100 > 1 ? 1 : cur_time * 100;
         q *= pow(h->p2_total_bits / h->p2_expected_sum, w);
     }
