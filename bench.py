@@ -67,7 +67,7 @@ def parse_args():
     ap.add_argument("--aq", action="store_true", help="variance AQ on (per-macroblock quantisers, the CRF / ABR path); the headline metric is CQP and leaves it off, as x264 does")
     ap.add_argument("--cpu-frames", type=int, default=10, help="frames per core of the CPU-baseline sample (0 = skip)")
     ap.add_argument("--e2e-legs", default="all", choices=["all", "sessions"], help="'sessions': only the threads-1 and multi-session legs of the end-to-end sample")
-    ap.add_argument("--e2e-sessions", type=int, default=256, help="sessions of the multi-session end-to-end sample (cross-session batcher; 0 = skip)")
+    ap.add_argument("--e2e-sessions", type=int, default=2048, help="sessions of the multi-session end-to-end sample (cross-session batcher; 0 = skip)")
     ap.add_argument("--e2e-frames", type=int, default=10, help="frames of the single-stream threads-1 end-to-end sample (0 = skip e2e)")
     ap.add_argument("--cpu-procs", type=int, default=64, help="processes of the many-core leg of the CPU baseline (cpu_baseline.cores reports what was used)")
     ap.add_argument("--cpu-frames-all", type=int, default=3, help="frames per core of the every-core leg of the CPU baseline (shorter: it runs one process per core)")
