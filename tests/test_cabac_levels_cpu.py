@@ -1,6 +1,7 @@
-"""CPU: the serial restatement of the level coding the device's level walk is checked against (tests/cabac_levels_ref.py) agrees with the oracle's CABAC
-size coder (oracle/cabac_rd.cpp through liboracle) on whole blocks — so that the primitive test of x264gpu_cabac_level_walk stands on the same ground as
-the pipeline tests."""
+"""CPU: the serial restatement of the residual coding (tests/cabac_levels_ref.py) that the device's one-walk-per-macroblock pricing is checked against through the
+primitive x264gpu_cabac_level_walk: its state machine is 9.3.4.2's, its node walk x264's coeff_abs_level1_ctx / coeff_abs_levelgt1_ctx / coeff_abs_level_transition,
+its significance map 7.3.5.3.3's — known-answer cases typed by hand here.  (It is a second restatement beside oracle/cabac_rd.cpp, with its own control flow; the
+pipeline tests compare the device with that one, the primitive test with this one.)"""
 import random
 
 import cabac_levels_ref as R

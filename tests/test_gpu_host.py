@@ -884,6 +884,13 @@ def test_every_preset_codes_a_decodable_stream(gpu, preset):
         assert eff.i_bframe == 0
     # RD refinement (subme 8) runs from slow up (umh); placebo's tesa maps to esa, where it does not (subme 7)
     assert eff.analyse.i_subpel_refine == {"ultrafast": 0, "superfast": 1, "veryfast": 2, "faster": 4, "fast": 6, "medium": 7, "slow": 8, "placebo": 7}.get(preset, 9), preset          # (slower 9; veryslow 10 -> 9; placebo's tesa -> esa keeps subme 7)
+    # ... and the rest of the preset's list, or exactly the documented downgrade (tests/test_effective_params_cpu.py has the table and checks the log lines):
+    # ref > 5 -> 5, tesa -> esa, p4x4 off, trellis as the preset says wherever CABAC + subme >= 6 hold
+    X264_ANALYSE_PSUB8x8 = 0x0020
+    assert eff.i_frame_reference == {"ultrafast": 1, "superfast": 1, "veryfast": 1, "faster": 2, "fast": 2, "medium": 3}.get(preset, 5), preset
+    assert eff.analyse.i_me_method == {"ultrafast": 0, "superfast": 0, "slower": 2, "veryslow": 2, "placebo": 3}.get(preset, 1), preset          # dia / hex / umh / esa
+    assert eff.analyse.i_trellis == {"ultrafast": 0, "superfast": 0, "veryfast": 0, "faster": 0, "fast": 1, "medium": 1}.get(preset, 2), preset      # (faster: trellis 1 needs subme >= 6 here)
+    assert not (eff.analyse.inter & X264_ANALYSE_PSUB8x8), preset
     stream, recs = encode_delayed(h_, w, h, frames)
     H.x264_encoder_close(h_)
     assert sorted(r[2] for r in recs) == list(range(n))
