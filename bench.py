@@ -98,7 +98,7 @@ def toolset(args):
             if not args.no_trellis:
                 t = dict(t, trellis=127)
     if args.aq:
-        t = dict(t, aq_mode=1, aq_strength_q8=266)
+        t = dict(t, aq_mode=1, aq_strength=1.0397)
     if args.bframes and args.preset != "ultrafast":
         # (B slices' RD decisions count CABAC sizes or CAVLC bits; with --rd off they are analysed without RD, as x264 does below subme 7)
         t = dict(t, dpb=max(t["refs"], 4 if args.bframes > 1 else 2), weightb=1)        # x264: sps num_ref_frames = max(ref, 4 under b-pyramid, 1 + reorder depth)
@@ -318,8 +318,8 @@ def lookahead_probe(torch, lib, dev, args, data, first, K, S, W, H):
     lib.check(lib.x264gpu_slicetype_create(C.byref(st), W, H, S, nslots, args.bframes, 1, 7, 16, 1, 512, 1), "slicetype_create")
     lib.check(lib.x264gpu_lookahead_create(C.byref(la), W, H, S, 16, 7), "lookahead_create")
     nb = ((W + 15) // 16) * ((H + 15) // 16)
-    aq = torch.empty((S, nb), dtype=torch.int16, device=dev)
-    offs = torch.empty((S, nb), dtype=torch.int16, device=dev)
+    aq = torch.empty((S, nb), dtype=torch.float32, device=dev)          # x264's f_qp_offset_aq / f_qp_offset: single floats
+    offs = torch.empty((S, nb), dtype=torch.float32, device=dev)
     score = np.zeros(S, np.int32)
     calls = {"lowres": 0, "aq": 0, "frame_cost": 0, "propagate": 0, "finish": 0}
     ms = {k_: 0.0 for k_ in calls}
@@ -349,7 +349,7 @@ def lookahead_probe(torch, lib, dev, args, data, first, K, S, W, H):
         with timed("lowres"):
             lib.check(lib.x264gpu_slicetype_put_frame(st, sl(i), data[first + i].data_ptr(), None), "slicetype_put_frame")
         with timed("aq"):
-            lib.check(lib.x264gpu_lookahead_aq_offsets(la, data[first + i].data_ptr(), 256, aq.data_ptr(), None), "aq_offsets")
+            lib.check(lib.x264gpu_lookahead_aq_offsets(la, data[first + i].data_ptr(), 1.0397, aq.data_ptr(), None), "aq_offsets")
             lib.check(lib.x264gpu_slicetype_set_aq(st, sl(i), aq.data_ptr(), None), "set_aq")
         if i == 0:
             cost(0, 0, 0)
@@ -376,7 +376,7 @@ def lookahead_probe(torch, lib, dev, args, data, first, K, S, W, H):
             prop(p0, i, i, 1)
             cost(p0, p0, p0)
             with timed("finish"):
-                lib.check(lib.x264gpu_slicetype_finish(st, sl(p0), 512, offs.data_ptr(), None), "slicetype_finish")
+                lib.check(lib.x264gpu_slicetype_finish(st, sl(p0), 2.0, 0.0, offs.data_ptr(), None), "slicetype_finish")
             p0 = i
     torch.cuda.synchronize(dev)
     dt = time.perf_counter() - t0

@@ -204,10 +204,11 @@ typedef struct x264gpu_config {
     int mixed_refs;           /* --mixed-refs (x264 default on): 8x8 blocks, and the 16x8 / 8x16 halves built on them, choose their reference
                                * on their own ([x264-upstream] analyse.c x264_mb_analyse_inter_p8x8_mixed_ref); needs partitions bit0 and refs > 1 */
     int aq_mode;              /* --aq-mode: 0 off, 1 variance AQ (x264_adaptive_quant_frame, [x264-upstream] encoder/ratecontrol.c): every macroblock's
-                               * quantiser = slice quantiser + round(strength * (log2(max(energy, 1)) - 14.427)), energy = AC energy of its luma and
-                               * chroma source samples.  Restated in Q8 fixed point (table include/x264gpu_aq_lut.inc) so that host checker and device
-                               * agree to the bit.  x264 switches AQ off under constant QP; so does the host encoder. */
-    int aq_strength_q8;       /* --aq-strength * 1.0397 * 256, rounded (x264 default 1.0 -> 266) */
+                               * quantiser = clip3((int)(qpm + strength * (x264_log2(max(energy, 1)) - 14.427f) + 0.5f)), energy = AC energy of its luma
+                               * and chroma source samples, qpm the picture's float quantiser (x264gpu_pic.qpm) — x264's own single-float expressions
+                               * (x264_log2's table: include/x264gpu_log2f_lut.inc), evaluated without contraction on host checker and device alike.
+                               * x264 switches AQ off under constant QP; so does the host encoder. */
+    float aq_strength;        /* --aq-strength * 1.0397f (x264_adaptive_quant_frame's strength of mode 1; x264 default 1.0 -> 1.0397f) */
     int fast_pskip;           /* --no-fast-pskip clears it (x264 default on): P_Skip probed inside the analysis (x264_macroblock_probe_pskip) */
     int mv_range;             /* --mvrange in luma samples, both directions; 0 = 512.  x264 takes it from the level (x264_levels[].mv_range) */
     int cabac;                /* the session's entropy coder is CABAC (x264 b_cabac).  Entropy coding stays on the host, but x264's analysis knows the coder:
@@ -262,8 +263,8 @@ typedef struct x264gpu_pic {
      * the same slot twice in slot[0][], the analysis refines the duplicate from reference 0's vector instead of searching it */
     struct { int8_t on, denom; int16_t scale, offset; } wl0[X264GPU_MAX_LIST];
     int blind_dupe;
-    int qp_frac_q8;           /* rate-controlled sessions: the picture's quantiser is qp + qp_frac_q8 / 256 (x264 rc->qpm, a float); a macroblock's quantiser
-                               * under AQ / macroblock-tree is round(that + its offset) — one rounding, as x264_ratecontrol_mb_qp has it.  -128 .. 127, 0 otherwise */
+    float qpm;                /* rate-controlled sessions: the picture's FLOAT quantiser (x264 rc->qpm; qp is its rounding): a macroblock's quantiser under AQ /
+                               * macroblock-tree is clip3((int)(qpm + its offset + 0.5f)) as x264_ratecontrol_mb_qp has it.  0 = (float)qp */
     /* ... and the explicit chroma weights of list-0 index i (x264_weights_analyse weights the chroma planes of a fade once luma got a weight):
      * plane 0 = Cb, 1 = Cr, one denominator for both (chroma_log2_weight_denom); same formula as luma */
     struct { int8_t on[2], denom, pad; int16_t scale[2], offset[2]; } wc0[X264GPU_MAX_LIST];
@@ -290,7 +291,7 @@ int  x264gpu_encode_frames(x264gpu_encoder *enc, const uint8_t *d_i420, int slic
                            x264gpu_mb *d_mb, int16_t *d_levels, void *stream);
 /* The same with explicit picture control, one entry of `pics` (host array) per stream: B pictures, b-pyramid, per-stream quantisers.
  * The streams of a call run in LOCK-STEP: slice type, POC, destination slot, keep flag, both reference lists, explicit weights and the
- * blind duplicate must be the same in every entry (EINVAL otherwise); qp and qp_frac_q8 may differ per stream.  B pictures need a CABAC
+ * blind duplicate must be the same in every entry (EINVAL otherwise); qp and qpm may differ per stream.  B pictures need a CABAC
  * session with RD (cfg.cabac, cfg.rd).  x264gpu_encode_frames is this call with the sliding-window DPB of an I / P stream. */
 int  x264gpu_encode_pictures(x264gpu_encoder *enc, const uint8_t *d_i420, const x264gpu_pic *pics,
                              x264gpu_mb *d_mb, int16_t *d_levels, void *stream);
@@ -315,15 +316,20 @@ int  x264gpu_encoder_profile_end(x264gpu_encoder *enc, void *stream, double *ms_
 /* Quantisers of the following x264gpu_encode_frames calls (every stream of the call shares them): what x264_ratecontrol_start
  * hands the slice ([x264-upstream] encoder/ratecontrol.c; CRF / scenecut sessions change it per picture). */
 int  x264gpu_encoder_set_qp(x264gpu_encoder *enc, int qp_i, int qp_p);
-/* Per-macroblock quantiser offsets (Q8, [streams][mb_count]) for the following pictures, as decided by the lookahead (x264: frame->f_qp_offset
- * = AQ - macroblock-tree, applied by x264_ratecontrol_mb_qp): quantiser = slice quantiser + round(offset), clipped to 1..51.  The device array
+/* Per-macroblock quantiser offsets (single floats, [streams][mb_count]) for the following pictures, as decided by the lookahead (x264: frame->f_qp_offset
+ * = AQ - macroblock-tree, or f_qp_offset_aq; applied by x264_ratecontrol_mb_qp): quantiser = (int)(qpm + offset + 0.5f), clipped to 1..51.  The device array
  * must stay valid until the encode that uses it has been issued; NULL returns to the encoder's own aq_mode. */
-int  x264gpu_encoder_set_mb_qp_offsets(x264gpu_encoder *enc, const int16_t *d_offsets_q8);
+int  x264gpu_encoder_set_mb_qp_offsets(x264gpu_encoder *enc, const float *d_offsets);
 /* One slice quantiser per stream (host array of `streams` values, 0..51) for the following pictures, instead of the shared one of
  * x264gpu_encoder_set_qp: the streams of a call are then rate-controlled independently (GOP-parallel coding of one sequence under
  * CRF: every GOP slot carries the quantiser x264_ratecontrol_start would have given that picture).  AQ / caller offsets add to it per
  * macroblock.  NULL returns to the shared quantiser. */
 int  x264gpu_encoder_set_stream_qps(x264gpu_encoder *enc, const int8_t *qps);
+/* ... with every stream's FLOAT quantiser beside it (x264 rc->qpm; qps[s] is its rounding; qpms NULL or an entry 0: the integer one) */
+int  x264gpu_encoder_set_stream_qpms(x264gpu_encoder *enc, const int8_t *qps, const float *qpms);
+/* The float quantiser (x264 rc->qpm) of the following x264gpu_encode_frames pictures, every stream alike; the integer quantisers of x264gpu_encoder_set_qp
+ * must be its rounding.  0 (the default) = the integer quantiser as a float.  x264gpu_encode_pictures carries it in x264gpu_pic.qpm instead. */
+int  x264gpu_encoder_set_qpm(x264gpu_encoder *enc, float qpm);
 /* Lookahead vectors of the following pictures against their predecessors (x264: fenc->lowres_mvs[0][0], an extra start candidate of the
  * 16x16 search in reference 0; x264_mb_predict_mv_ref16x16): device array [streams][mb_count][2] int16 in quarter-pels of the
  * half-resolution planes, first entry 0x7fff = absent for that stream.  NULL (the default) = none. */
@@ -378,7 +384,7 @@ int  x264gpu_slicetype_weight_cost_chroma(x264gpu_slicetype *st, int slot_fenc, 
  * clear the propagate cost of a non-B picture, x264gpu_slicetype_frame_cost of a triple, _propagate it, ..., _finish the picture about to be coded).
  * AQ offsets (x264_adaptive_quant_frame; x264gpu_lookahead_aq_offsets) weight the costs (i_inv_qscale_factor) and are the base of the result;
  * the result is what x264gpu_encoder_set_mb_qp_offsets takes.  Propagate costs saturate at 32767 as x264's do (applied where a sum is read). */
-int  x264gpu_slicetype_set_aq(x264gpu_slicetype *st, int slot, const int16_t *d_aq_q8, void *stream);
+int  x264gpu_slicetype_set_aq(x264gpu_slicetype *st, int slot, const float *d_aq, void *stream);
 /* --b-bias (param.i_bframe_bias, -90 .. 100): slicetype_frame_cost scales B costs by 100 / (120 + bias); call once after create */
 int  x264gpu_slicetype_set_bframe_bias(x264gpu_slicetype *st, int bias);
 /* how x264gpu_slicetype_frame_cost walks a picture's block rows: 0 = one wavefront per row, chained bottom-up by progress counters (default, and what -1 =
@@ -391,7 +397,9 @@ int  x264gpu_slicetype_set_row_mode(x264gpu_slicetype *st, int serial);
 int  x264gpu_slicetype_cost_aq(x264gpu_slicetype *st, int slot, int d0, int d1, int32_t *h_score, void *stream);
 int  x264gpu_slicetype_clear_propagate(x264gpu_slicetype *st, int slot, void *stream);
 int  x264gpu_slicetype_propagate(x264gpu_slicetype *st, int slot_p0, int slot_p1, int slot_b, int d0, int d1, int referenced, void *stream);
-int  x264gpu_slicetype_finish(x264gpu_slicetype *st, int slot, int strength_q8, int16_t *d_out_q8, void *stream);
+/* macroblock_tree_finish: d_out = f_qp_offset_aq - strength * (x264_log2(intra + propagated) - x264_log2(intra) + weightdelta), strength = 5.0f * (1.0f - qcomp),
+ * weightdelta = 1 - f_weighted_cost_delta[distance to reference 0 - 1] when the lookahead's weight analysis found a weight for that distance, else 0 */
+int  x264gpu_slicetype_finish(x264gpu_slicetype *st, int slot, float strength, float weightdelta, float *d_out, void *stream);
 const int32_t  *x264gpu_slicetype_propagate_cost(x264gpu_slicetype *st, int slot);
 
 /* ------------------------------------------------------------------------------------------------
@@ -410,20 +418,21 @@ typedef struct x264gpu_lookahead x264gpu_lookahead;
 int  x264gpu_lookahead_create(x264gpu_lookahead **la, int width, int height, int streams, int me_range, int subme);
 void x264gpu_lookahead_destroy(x264gpu_lookahead *la);
 int  x264gpu_lookahead_frame_cost(x264gpu_lookahead *la, const uint8_t *d_i420, int reset, int32_t *d_out, int32_t *d_blocks, void *stream);
-/* Adaptive-quantisation offsets (Q8) of `streams` source pictures: strength * (log2(AC energy) - 14.427) per macroblock, as the lookahead
- * of x264 computes them when a picture arrives (x264_adaptive_quant_frame); what aq_mode 1 of the encoder computes itself. */
-int  x264gpu_lookahead_aq_offsets(x264gpu_lookahead *la, const uint8_t *d_i420, int strength_q8, int16_t *d_out_q8, void *stream);
+/* Adaptive-quantisation offsets (single floats) of `streams` source pictures: strength * (x264_log2(AC energy) - 14.427f) per macroblock, as the lookahead
+ * of x264 computes them when a picture arrives (x264_adaptive_quant_frame); what aq_mode 1 of the encoder computes itself.  strength = aq-strength * 1.0397f */
+int  x264gpu_lookahead_aq_offsets(x264gpu_lookahead *la, const uint8_t *d_i420, float strength, float *d_out, void *stream);
 /* ... with x264's --aq-mode: 1 = the call above; 2 (auto-variance) / 3 (auto-variance with a bias to dark scenes): x264_adaptive_quant_frame's float
- * path — per macroblock (energy + 1)^(1/8), the picture's mean and mean square of them (summed in raster order), strength x (value - average)
- * [+ aq-strength x (1 - 14 / value^2)]; strength_q8 = aq-strength x 256 here (mode 1: x 1.0397 x 256 as above).  The result is Q8 like every offset */
-int  x264gpu_lookahead_aq_offsets_mode(x264gpu_lookahead *la, const uint8_t *d_i420, int mode, int strength_q8, int16_t *d_out_q8, void *stream);
+ * path — per macroblock (energy + 1)^(1/8) (three IEEE square roots here; x264 calls powf, which may differ in the last place), the picture's mean and mean
+ * square of them (summed in raster order), strength x (value - average) [+ aq-strength x (1 - 14 / value^2)]; strength = the plain aq-strength for modes 2 / 3
+ * (mode 1: x 1.0397f as above) */
+int  x264gpu_lookahead_aq_offsets_mode(x264gpu_lookahead *la, const uint8_t *d_i420, int mode, float strength, float *d_out, void *stream);
 /* Macroblock-tree ([x264-upstream] encoder/slicetype.c macroblock_tree / _propagate / _finish, common/mc.c mbtree_propagate_cost / _list)
- * for an I/P-only stream at constant frame rate.  d_info[j], d_aq_q8[j] (host arrays of n device pointers): the per-block records
- * (x264gpu_lookahead_frame_cost d_blocks) and AQ offsets of n consecutive pictures, j = 0 the one about to be coded; d_aq_q8 may be NULL.
- * d_out_q8 [streams][blocks]: quantiser offsets of picture 0 = aq - strength * log2((intra + propagated) / intra), Q8;
- * strength_q8 = 5 * (1 - qcomp) * 256.  Feed it to x264gpu_encoder_set_mb_qp_offsets. */
-int  x264gpu_lookahead_mbtree(x264gpu_lookahead *la, const int32_t *const *d_info, const int16_t *const *d_aq_q8, int n, int strength_q8,
-                              int16_t *d_out_q8, void *stream);
+ * for an I/P-only stream at constant frame rate.  d_info[j], d_aq[j] (host arrays of n device pointers): the per-block records
+ * (x264gpu_lookahead_frame_cost d_blocks) and AQ offsets of n consecutive pictures, j = 0 the one about to be coded; d_aq may be NULL.
+ * d_out [streams][blocks]: quantiser offsets of picture 0 = aq - strength * (x264_log2(intra + propagated) - x264_log2(intra));
+ * strength = 5.0f * (1.0f - qcomp).  Feed it to x264gpu_encoder_set_mb_qp_offsets.  x264's C expressions in single floats throughout. */
+int  x264gpu_lookahead_mbtree(x264gpu_lookahead *la, const int32_t *const *d_info, const float *const *d_aq, int n, float strength,
+                              float *d_out, void *stream);
 
 #ifdef __cplusplus
 }

@@ -45,6 +45,8 @@ int x264host_mux_write_frame(void *h, const uint8_t *payload, int size, int64_t 
 int x264host_mux_close(void *h, int64_t largest_pts, int64_t second_largest_pts);
 /* quantiser, scenecut flag and lookahead sums (x264gpu_lookahead_frame_cost) of the last coded picture */
 int x264host_last_decision(x264_t *h, int *qp, int *scenecut, int32_t costs[4]);
+/* ... and the float quantiser (x264 rc->qpm) its macroblock quantisers were rounded from (0 = the integer quantiser) */
+float x264host_last_qpm(x264_t *h);
 /* reconstructed picture of the last encoded frame as I420 (host memory) */
 int x264host_get_recon(x264_t *h, uint8_t *i420_out);
 

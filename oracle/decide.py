@@ -44,7 +44,8 @@ class Params:
         if min_keyint <= 0:          # validate_parameters: auto = min(keyint / 10, fps), then [1, keyint / 2 + 1]
             min_keyint = min(keyint // 10, int(fps))
         self.min_keyint = max(1, min(min_keyint, keyint // 2 + 1))
-        self.crf, self.qcomp, self.ip_factor, self.pb_factor, self.qpmin, self.qpmax, self.fps = crf, qcomp, ip_factor, pb_factor, qpmin, qpmax, fps
+        # (x264_param_t carries these as single floats: the doubles of the rate control start from the float's value)
+        self.crf, self.qcomp, self.ip_factor, self.pb_factor, self.qpmin, self.qpmax, self.fps = _f(crf), _f(qcomp), _f(ip_factor), _f(pb_factor), qpmin, qpmax, fps
 
 
 class Frame:
@@ -306,8 +307,8 @@ class RateControl:
         dur = min(max(1.0 / p.fps, 0.01), 1.0)                      # CLIP_DURATION
         self.dur_ratio = dur / 0.04                                   # BASE_FRAME_DURATION
         self.rate_factor_constant = (p.mbw * p.mbh * (120.0 if p.bframes else 80.0)) ** (1.0 - p.qcomp) / qp2qscale(p.crf)
-        self.ip_offset = 6.0 * math.log2(p.ip_factor)
-        self.pb_offset = 6.0 * math.log2(p.pb_factor)
+        self.ip_offset = 6.0 * _libm.log2f(p.ip_factor)             # x264_ratecontrol_init_reconfigurable: 6.0 * log2f( f_ip_factor )
+        self.pb_offset = 6.0 * _libm.log2f(p.pb_factor)
         self.accum_p_qp = self.accum_p_norm = 0.0
         self.last_non_b_is_i = True                                   # x264_ratecontrol_new: last_non_b_pict_type = SLICE_TYPE_I
         self.last_qscale_for = [qp2qscale(p.crf)] * 2
@@ -323,14 +324,14 @@ class RateControl:
         self.cplxsum = self.cplxsum * 0.5 + satd / self.dur_ratio
         self.cplxcount = self.cplxcount * 0.5 + 1.0
         if satd > 0:
-            q = (self.cplxsum / self.cplxcount) ** (1.0 - p.qcomp) / self.rate_factor_constant
+            q = _f((self.cplxsum / self.cplxcount) ** (1.0 - p.qcomp) / self.rate_factor_constant)          # (rate_estimate_qscale's q is a float: every assignment rounds)
         else:
-            q = self.last_qscale_for[0 if is_i else 1]
+            q = _f(self.last_qscale_for[0 if is_i else 1])
         if is_i and p.keyint > 1 and not self.last_non_b_is_i:
-            q = qp2qscale(self.accum_p_qp / self.accum_p_norm) / p.ip_factor
+            q = _f(qp2qscale(self.accum_p_qp / self.accum_p_norm) / p.ip_factor)
         elif self.frames_done == 0 and p.qcomp != 1.0:
-            q = qp2qscale(p.crf) / p.ip_factor
-        q = min(max(q, qp2qscale(p.qpmin)), qp2qscale(p.qpmax))
+            q = _f(qp2qscale(p.crf) / p.ip_factor)
+        q = _f(min(max(q, qp2qscale(p.qpmin)), qp2qscale(p.qpmax)))
         self.last_qscale_for[0 if is_i else 1] = q
         if self.frames_done == 0:
             self.last_qscale_for[1] = q * p.ip_factor
@@ -340,25 +341,34 @@ class RateControl:
         self.frames_done += 1
         return min(max(int(qpf + 0.5), 1), 51), qpf
 
+    def qp_avg_rc(self, qpm):
+        """fdec->f_qp_avg_rc: rc->qpa_rc (a float) gathers qpm * mb_width row by row, x264_ratecontrol_end divides by the macroblock count"""
+        a = 0.0
+        for _ in range(self.p.mbh):
+            a = _f(a + _f(_f(qpm) * self.p.mbw))
+        return _f(a / (self.p.mbw * self.p.mbh))
+
     def b(self, poc, ref0, ref1, kept_as_ref):
         """a B picture's quantiser from its nearest references: ref = (poc, type, float quantiser)"""
         p = self.p
         i0, i1 = ref0[1] in (I, IDR), ref1[1] in (I, IDR)
         dt0, dt1 = abs(poc - ref0[0]), abs(poc - ref1[0])
-        q0, q1 = ref0[2], ref1[2]
+        # x264's own types: float q0, q1, q (the references' f_qp_avg_rc), double offsets; then qp2qscale and x264_ratecontrol_start's qscale2qp
+        q0, q1 = self.qp_avg_rc(ref0[2]), self.qp_avg_rc(ref1[2])
         if ref0[1] == BREF:
-            q0 -= self.pb_offset / 2
+            q0 = _f(q0 - self.pb_offset / 2)
         if ref1[1] == BREF:
-            q1 -= self.pb_offset / 2
+            q1 = _f(q1 - self.pb_offset / 2)
         if i0 and i1:
-            q = (q0 + q1) / 2 + self.ip_offset
+            q = _f(_f(_f(q0 + q1) / 2) + self.ip_offset)
         elif i0:
             q = q1
         elif i1:
             q = q0
         else:
-            q = (q0 * dt1 + q1 * dt0) / (dt0 + dt1)
-        q += self.pb_offset / 2 if kept_as_ref else self.pb_offset
+            q = _f(_f(_f(q0 * dt1) + _f(q1 * dt0)) / (dt0 + dt1))
+        q = _f(q + (self.pb_offset / 2 if kept_as_ref else self.pb_offset))
+        q = qscale2qp(qp2qscale(q))
         q = min(max(q, p.qpmin), p.qpmax)
         self._accum(q, False)
         self.frames_done += 1

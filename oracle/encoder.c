@@ -67,8 +67,10 @@ void x264o_encoder_destroy(x264o_encoder *e)
 
 int x264o_encoder_mb_count(const x264o_encoder *e) { return e->mbw * e->mbh; }
 void x264o_encoder_set_qp(x264o_encoder *e, int qp_i, int qp_p) { e->cfg.qp_i = qp_i; e->cfg.qp_p = qp_p; }
-/* per-macroblock quantiser offsets (Q8) for the following pictures; the array must stay valid; NULL = back to the encoder's own AQ */
-void x264o_encoder_set_mb_qp_offsets(x264o_encoder *e, const int16_t *off_q8) { e->ext_off_q8 = off_q8; }
+/* the float quantiser (rc->qpm) of x264o_encoder_encode's following pictures; 0 = the integer one */
+void x264o_encoder_set_qpm(x264o_encoder *e, float qpm) { e->qpm_next = qpm; }
+/* per-macroblock quantiser offsets (single floats) for the following pictures; the array must stay valid; NULL = back to the encoder's own AQ */
+void x264o_encoder_set_mb_qp_offsets(x264o_encoder *e, const float *off) { e->ext_off = off; }
 /* lookahead vectors of the NEXT picture against its predecessor ([nmb][2], lowres quarter-pels; first entry 0x7fff or NULL = none):
  * the extra 16x16 search candidate x264 takes from fenc->lowres_mvs[0][0] */
 void x264o_encoder_set_lowres_mvs(x264o_encoder *e, const int16_t *mv) { e->lowres_mv = mv; }
@@ -105,19 +107,16 @@ static void ingest(x264o_encoder *e, const uint8_t *i420)
 
 /* ---- residual coding helpers ---- */
 /* ---- adaptive quantisation, mode 1 (x264_adaptive_quant_frame / x264_ac_energy_mb, [x264-upstream] encoder/ratecontrol.c):
- * energy = var(16x16 luma) + var(8x8 U) + var(8x8 V) with var = ssd - (sum^2 >> log2 n); offset = strength * (log2(energy) - 14.427).
- * Q8 fixed point: log2 = 256 * floor(log2 e) + table[next 7 bits]; the offset is rounded to an integer quantiser step. ---- */
+ * energy = var(16x16 luma) + var(8x8 U) + var(8x8 V) with var = ssd - (sum^2 >> log2 n);
+ * qp_adj = strength * (x264_log2(max(energy, 1)) - 14.427f) in single floats, strength = --aq-strength * 1.0397f (cfg.aq_strength);
+ * x264_ratecontrol_mb_qp: the macroblock's quantiser = clip3((int)(rc->qpm + qp_adj + 0.5f)), qpm the picture's float quantiser. ---- */
 #include "fixlut.h"
-static int aq_log2_q8(uint32_t x)
+static void compute_mb_qp(x264o_encoder *e, int slice_qp, float qpm)
 {
-    int lz = 31 - __builtin_clz(x);
-    return lz * 256 + x264o_log2_lut()[((x << (31 - lz)) >> 24) & 0x7f];
-}
-static void compute_mb_qp(x264o_encoder *e, int slice_qp, int frac_q8)
-{          /* x264_ratecontrol_mb_qp: clip3(qpm + offset + 0.5): the picture's float quantiser (slice_qp + frac_q8 / 256) and the offset are rounded ONCE */
     const int n = e->mbw * e->mbh;
-    if (e->ext_off_q8) {        /* offsets decided by the lookahead (x264: frame->f_qp_offset, read by x264_ratecontrol_mb_qp) */
-        for (int i = 0; i < n; i++) e->mbqp[i] = (uint8_t)clampi((slice_qp * 256 + frac_q8 + e->ext_off_q8[i] + 128) >> 8, 1, 51);
+    if (qpm == 0.f) qpm = (float)slice_qp;          /* constant-quantiser sessions: rc->qpm = the slice's integer quantiser */
+    if (e->ext_off) {        /* offsets decided by the lookahead (x264: frame->f_qp_offset / f_qp_offset_aq, read by x264_ratecontrol_mb_qp) */
+        for (int i = 0; i < n; i++) e->mbqp[i] = (uint8_t)clampi(x264o_mb_qp(qpm, e->ext_off[i]), 1, 51);
         return;
     }
     if (!e->cfg.aq_mode) { memset(e->mbqp, slice_qp, (size_t)n); return; }
@@ -131,8 +130,8 @@ static void compute_mb_qp(x264o_encoder *e, int slice_qp, int frac_q8)
                 su += u; squ += u * u; sv += v; sqv += v * v;
             }
             uint32_t energy = (sqr - (sum * sum >> 8)) + (squ - (su * su >> 6)) + (sqv - (sv * sv >> 6));
-            int adj_q8 = (e->cfg.aq_strength_q8 * (aq_log2_q8(energy ? energy : 1) - 3693)) >> 8;      /* 14.427 * 256 = 3693 */
-            e->mbqp[mby * e->mbw + mbx] = (uint8_t)clampi((slice_qp * 256 + frac_q8 + adj_q8 + 128) >> 8, 1, 51);
+            const float qp_adj = e->cfg.aq_strength * (x264o_log2(energy ? energy : 1) - 14.427f);
+            e->mbqp[mby * e->mbw + mbx] = (uint8_t)clampi(x264o_mb_qp(qpm, qp_adj), 1, 51);
         }
 }
 
@@ -317,8 +316,8 @@ int x264o_encoder_encode_pic(x264o_encoder *e, const uint8_t *i420, const x264gp
     }
     ingest(e, i420);
     const int slice_qp = pic->qp;
-    if (pic->qp_frac_q8 < -128 || pic->qp_frac_q8 > 127) return -1;
-    compute_mb_qp(e, slice_qp, pic->qp_frac_q8);
+    if (pic->qpm != 0.f && !(pic->qpm > (float)slice_qp - 1.f && pic->qpm < (float)slice_qp + 1.f)) return -1;      /* qp is the rounding of qpm */
+    compute_mb_qp(e, slice_qp, pic->qpm);
     e->mbs = mbs; e->levels = levels; e->intra_count = 0;
     e->slot_nref[e->cur] = e->nref; e->slot_poc[e->cur] = e->poc; e->slot_ref0poc[e->cur] = e->nref ? e->slot_poc[ref_slot(e, 0)] : 0;
     for (int r = 0; r < X264GPU_MAX_LIST; r++) e->slot_l0poc[e->cur][r] = r < e->nref ? e->slot_poc[ref_slot(e, r)] : 0;
@@ -351,7 +350,7 @@ int x264o_encoder_encode_pic(x264o_encoder *e, const uint8_t *i420, const x264gp
             }
     }
     e->row0 = 0; e->row1 = e->mbh;
-    if (e->cfg.aq_mode || e->ext_off_q8) settle_mb_qp(e, mbs, slice_qp);
+    if (e->cfg.aq_mode || e->ext_off) settle_mb_qp(e, mbs, slice_qp);
     if (e->cfg.deblock) deblock_frame(e, mbs);
     if (pic->keep) filter_frame(e);
     e->cfg.dct_decimate = cfg_decimate;
@@ -367,7 +366,7 @@ int x264o_encoder_encode(x264o_encoder *e, const uint8_t *i420, int slice_type, 
     x264gpu_pic pic;
     memset(&pic, 0, sizeof(pic));
     const int ring = clampi(e->cfg.refs, 1, 5) + 1;
-    pic.slice_type = slice_type; pic.qp = slice_type == X264GPU_SLICE_P ? e->cfg.qp_p : e->cfg.qp_i; pic.poc = e->ring_poc; pic.dst = e->ring_cur; pic.keep = 1; pic.blind_dupe = -1;
+    pic.slice_type = slice_type; pic.qp = slice_type == X264GPU_SLICE_P ? e->cfg.qp_p : e->cfg.qp_i; pic.poc = e->ring_poc; pic.dst = e->ring_cur; pic.keep = 1; pic.blind_dupe = -1; pic.qpm = e->qpm_next;
     pic.nref[0] = slice_type == X264GPU_SLICE_P ? (e->have_ref < ring - 1 ? e->have_ref : ring - 1) : 0;
     for (int r = 0; r < pic.nref[0]; r++) pic.slot[0][r] = (int8_t)((e->ring_cur - 1 - r + 2 * ring) % ring);
     const int rc = x264o_encoder_encode_pic(e, i420, &pic, mbs, levels);
@@ -401,9 +400,13 @@ const uint8_t *x264o_encoder_ref_plane(x264o_encoder *e, int k, int *stride, int
     return e->chroma[last];
 }
 
-/* tests: the oracle's own derivation of the two fixed-point tables (fixlut.h), to be compared with the product's literals */
-void x264o_fixed_point_luts(uint8_t log2_lut[128], uint16_t exp2_lut[64])
+/* tests: the oracle's own derivation of the tables (fixlut.h), to be compared with the product's literals */
+void x264o_fixed_point_luts(float log2_lut[128], uint16_t exp2_lut[64])
 {
-    memcpy(log2_lut, x264o_log2_lut(), 128);
+    memcpy(log2_lut, x264o_log2f_lut(), 128 * sizeof(float));
     memcpy(exp2_lut, x264o_exp2_lut(), 64 * sizeof(uint16_t));
 }
+/* ... and the float primitives themselves, for known-answer tests */
+float x264o_log2_f(uint32_t x) { return x264o_log2(x); }
+int x264o_exp2fix8_f(float x) { return x264o_exp2fix8(x); }
+int x264o_mb_qp_f(float qpm, float off) { return x264o_mb_qp(qpm, off); }

@@ -61,7 +61,8 @@ struct x264o_encoder {
     int have_ref, ring_cur, ring_poc, last_slot;      /* x264o_encoder_encode's sliding window: pictures coded since the IDR, next slot, next POC */
     int slice_type;              /* slice being encoded */
     uint8_t *mbqp;               /* quantiser of every macroblock of the picture being coded (slice quantiser, + AQ offset) */
-    const int16_t *ext_off_q8;   /* quantiser offsets handed in for the next picture (lookahead: AQ - macroblock-tree), or NULL */
+    float qpm_next;              /* x264o_encoder_set_qpm */
+    const float *ext_off;        /* quantiser offsets handed in for the next picture (lookahead: AQ - macroblock-tree), or NULL */
     const int16_t *lowres_mv;    /* optional lookahead vectors of the next picture against its predecessor (x264 fenc->lowres_mvs[0][0]),
                                   * [nmb][2] in lowres quarter-pels, first entry 0x7fff = absent */
     /* state of the macroblock loop (x264: h->stat.frame, h->mb) */

@@ -239,62 +239,57 @@ int x264o_lookahead_frame_cost(x264o_lookahead *la, const uint8_t *i420, int res
     return 0;
 }
 
-/* ---- adaptive-quantisation offsets of a source picture, Q8 (the lookahead computes them when the picture arrives, as
- * x264_adaptive_quant_frame does; same arithmetic as encoder.c compute_mb_qp, on the mod-16 expanded picture) ---- */
+/* ---- adaptive-quantisation offsets of a source picture, single floats (the lookahead computes them when the picture arrives, as
+ * x264_adaptive_quant_frame does; same arithmetic as encoder.c compute_mb_qp, on the mod-16 expanded picture).  strength = aq-strength * 1.0397f ---- */
 #include "fixlut.h"
-static int la_log2_q8(uint32_t x) { int lz = 31 - __builtin_clz(x); return lz * 256 + x264o_log2_lut()[((x << (31 - lz)) >> 24) & 0x7f]; }
-
-void x264o_aq_offsets(const uint8_t *i420, int w, int h, int strength_q8, int16_t *out_q8)
+#include <math.h>
+static uint32_t la_ac_energy(const uint8_t *Y, const uint8_t *U, const uint8_t *V, int w, int h, int bx, int by)
+{
+    uint32_t sum = 0, sqr = 0, su = 0, squ = 0, sv = 0, sqv = 0;
+    for (int r = 0; r < 16; r++) for (int c = 0; c < 16; c++) { uint32_t p = Y[(size_t)clampi(by * 16 + r, 0, h - 1) * w + clampi(bx * 16 + c, 0, w - 1)]; sum += p; sqr += p * p; }
+    for (int r = 0; r < 8; r++) for (int c = 0; c < 8; c++) {
+        size_t o = (size_t)clampi(by * 8 + r, 0, h / 2 - 1) * (w / 2) + clampi(bx * 8 + c, 0, w / 2 - 1);
+        uint32_t u = U[o], v = V[o];
+        su += u; squ += u * u; sv += v; sqv += v * v;
+    }
+    return (sqr - (sum * sum >> 8)) + (squ - (su * su >> 6)) + (sqv - (sv * sv >> 6));
+}
+void x264o_aq_offsets(const uint8_t *i420, int w, int h, float strength, float *out)
 {
     const int bw = (w + 15) / 16, bh = (h + 15) / 16;
     const uint8_t *Y = i420, *U = i420 + (size_t)w * h, *V = U + (size_t)(w / 2) * (h / 2);
     for (int by = 0; by < bh; by++)
         for (int bx = 0; bx < bw; bx++) {
-            uint32_t sum = 0, sqr = 0, su = 0, squ = 0, sv = 0, sqv = 0;
-            for (int r = 0; r < 16; r++) for (int c = 0; c < 16; c++) { uint32_t p = Y[(size_t)clampi(by * 16 + r, 0, h - 1) * w + clampi(bx * 16 + c, 0, w - 1)]; sum += p; sqr += p * p; }
-            for (int r = 0; r < 8; r++) for (int c = 0; c < 8; c++) {
-                size_t o = (size_t)clampi(by * 8 + r, 0, h / 2 - 1) * (w / 2) + clampi(bx * 8 + c, 0, w / 2 - 1);
-                uint32_t u = U[o], v = V[o];
-                su += u; squ += u * u; sv += v; sqv += v * v;
-            }
-            uint32_t energy = (sqr - (sum * sum >> 8)) + (squ - (su * su >> 6)) + (sqv - (sv * sv >> 6));
-            out_q8[by * bw + bx] = (int16_t)((strength_q8 * (la_log2_q8(energy ? energy : 1) - 3693)) >> 8);
+            const uint32_t energy = la_ac_energy(Y, U, V, w, h, bx, by);
+            out[by * bw + bx] = strength * (x264o_log2(energy ? energy : 1) - 14.427f);
         }
 }
 
 /* ... --aq-mode 2 (auto-variance) and 3 (auto-variance with a bias to dark scenes), x264_adaptive_quant_frame's float path: every macroblock's
  * qp_adj = (energy + 1)^(1/8), the picture's mean and mean square of them, strength = aq-strength x mean,
  *   mode 2: strength x (qp_adj - avg)        mode 3: ... + aq-strength x (1 - 14 / qp_adj^2)        avg = mean - (mean square - 14) / (2 mean)
- * in single floats, summed in raster order as x264 does; the eighth root is three IEEE square roots (x264 calls powf: may differ in the last place);
- * the result is rounded to Q8 like every offset here.  strength_q8 = aq-strength x 256 (without mode 1's 1.0397). */
-#include <math.h>
-void x264o_aq_offsets_mode(const uint8_t *i420, int w, int h, int mode, int strength_q8, int16_t *out_q8)
+ * in single floats, summed in raster order as x264 does; the eighth root is three IEEE square roots (x264 calls powf: may differ in the last place).
+ * strength = the plain aq-strength (without mode 1's 1.0397). */
+void x264o_aq_offsets_mode(const uint8_t *i420, int w, int h, int mode, float aqs, float *out)
 {
     const int bw = (w + 15) / 16, bh = (h + 15) / 16, nb = bw * bh;
-    if (mode <= 1) { x264o_aq_offsets(i420, w, h, strength_q8, out_q8); return; }
+    if (mode <= 1) { x264o_aq_offsets(i420, w, h, aqs, out); return; }
     const uint8_t *Y = i420, *U = i420 + (size_t)w * h, *V = U + (size_t)(w / 2) * (h / 2);
     float *adj = malloc((size_t)nb * sizeof(float));
     float avg_adj = 0.f, avg_adj_pow2 = 0.f;
     for (int by = 0; by < bh; by++)
         for (int bx = 0; bx < bw; bx++) {
-            uint32_t sum = 0, sqr = 0, su = 0, squ = 0, sv = 0, sqv = 0;
-            for (int r = 0; r < 16; r++) for (int c = 0; c < 16; c++) { uint32_t p = Y[(size_t)clampi(by * 16 + r, 0, h - 1) * w + clampi(bx * 16 + c, 0, w - 1)]; sum += p; sqr += p * p; }
-            for (int r = 0; r < 8; r++) for (int c = 0; c < 8; c++) {
-                size_t o = (size_t)clampi(by * 8 + r, 0, h / 2 - 1) * (w / 2) + clampi(bx * 8 + c, 0, w / 2 - 1);
-                uint32_t u = U[o], v = V[o];
-                su += u; squ += u * u; sv += v; sqv += v * v;
-            }
-            const uint32_t energy = (sqr - (sum * sum >> 8)) + (squ - (su * su >> 6)) + (sqv - (sv * sv >> 6));
+            const uint32_t energy = la_ac_energy(Y, U, V, w, h, bx, by);
             const float q = sqrtf(sqrtf(sqrtf((float)energy + 1.f)));
             adj[by * bw + bx] = q; avg_adj += q; avg_adj_pow2 += q * q;
         }
     avg_adj /= (float)nb; avg_adj_pow2 /= (float)nb;
-    const float aqs = (float)strength_q8 / 256.f, strength = aqs * avg_adj;
+    const float strength = aqs * avg_adj;
     avg_adj = avg_adj - 0.5f * (avg_adj_pow2 - 14.f) / avg_adj;
     for (int i = 0; i < nb; i++) {
         float q = strength * (adj[i] - avg_adj);
-        if (mode == 3) q += aqs * (1.f - 14.f / (adj[i] * adj[i]));
-        out_q8[i] = (int16_t)lrintf(q * 256.f);
+        if (mode == 3) q = q + aqs * (1.f - 14.f / (adj[i] * adj[i]));
+        out[i] = q;
     }
     free(adj);
 }
@@ -303,17 +298,21 @@ void x264o_aq_offsets_mode(const uint8_t *i420, int w, int h, int mode, int stre
  * mbtree_propagate_cost / _list of common/mc.c, macroblock_tree_finish), constant frame rate.  info[j] / aq[j]: per-block records
  * and AQ offsets of n consecutive pictures, j = 0 the one about to be coded.  Every picture hands the part of its cost that its
  * reference explains back to the blocks its vectors point at (bilinear split over four blocks, 15-bit saturating sums); the
- * oldest picture's blocks get  offset = aq - strength * log2((intra + propagated) / intra).  All integer arithmetic (x264's
- * float expressions restated): amounts carry 9 fractional bits (fps_factor 1/512), inverse quantiser scales are x264_exp2fix8. ---- */
-static int la_inv_qscale(int aq_q8)
+ * oldest picture's blocks get  offset = aq - strength * (x264_log2(intra + propagated) - x264_log2(intra)).  x264's C expressions in single
+ * floats: fps_factor = 1 / 512 (MBTREE_PRECISION 0.5f, constant frame rate), inverse quantiser scales = x264_exp2fix8 of the AQ offsets. ---- */
+/* mbtree_propagate_cost (common/mc.c), one block */
+static int la_propagate_amount(int propagate_in, int intra_cost, int inter_cost, int inv_qscale)
 {
-    int i = (-aq_q8 * 64 + 786432 + 768) / 1536;                       /* (int)(x * (-64 / 6) + 512.5), x = aq_q8 / 256 */
-    if (i < 0) return 0;
-    if (i > 1023) return 0xffff;
-    return (int)(((uint32_t)(x264o_exp2_lut()[i & 63] + 256) << (i >> 6)) >> 8);
+    if (!intra_cost) return 0;          /* (0 / 0 in x264: the conversion of the NaN is 0 in the stored int16) */
+    const float fps = 1.f / 512.f;
+    float propagate_intra = (float)(intra_cost * inv_qscale);
+    float propagate_amount = (float)propagate_in + propagate_intra * fps;
+    float propagate_num = (float)(intra_cost - inter_cost);
+    float propagate_denom = (float)intra_cost;
+    const int v = (int)(propagate_amount * propagate_num / propagate_denom + 0.5f);
+    return v < 32767 ? v : 32767;
 }
-
-void x264o_mbtree(int bw, int bh, const int32_t *const *info, const int16_t *const *aq_q8, int n, int strength_q8, int16_t *out_q8)
+void x264o_mbtree(int bw, int bh, const int32_t *const *info, const float *const *aq, int n, float strength, float *out)
 {
     const int nb = bw * bh;
     int32_t *prop = calloc((size_t)n * nb, sizeof(int32_t));           /* propagate cost of every picture's blocks */
@@ -324,10 +323,8 @@ void x264o_mbtree(int bw, int bh, const int32_t *const *info, const int16_t *con
             for (int bx = 0; bx < bw; bx++) {
                 const int i = by * bw + bx;
                 const int intra = fi[4 * i] > 16383 ? 16383 : fi[4 * i], best = fi[4 * i + 1] > 16383 ? 16383 : fi[4 * i + 1];   /* LOWRES_COST_MASK */
-                const int inter = best < intra ? best : intra, inv = la_inv_qscale(aq_q8 ? aq_q8[j][i] : 0);
-                int64_t amt512 = (int64_t)prop[(size_t)j * nb + i] * 512 + (int64_t)intra * inv;
-                int amount = intra ? (int)((amt512 * (intra - inter) + 256 * (int64_t)intra) / (512 * (int64_t)intra)) : 0;
-                if (amount > 32767) amount = 32767;
+                const int inter = best < intra ? best : intra, inv = x264o_exp2fix8(aq ? aq[j][i] : 0.f);
+                const int amount = la_propagate_amount(prop[(size_t)j * nb + i], intra, inter, inv);
                 if (!fi[4 * i + 3]) continue;                           /* intra block: nothing is explained by the reference */
                 int x = (int16_t)(fi[4 * i + 2] & 0xffff), y = fi[4 * i + 2] >> 16;
 #define CLIP_ADD(idx, v) do { int t_ = ref[idx] + (v); ref[idx] = t_ > 32767 ? 32767 : t_; } while (0)
@@ -342,15 +339,16 @@ void x264o_mbtree(int bw, int bh, const int32_t *const *info, const int16_t *con
             }
     }
     for (int i = 0; i < nb; i++) {
-        const int a = aq_q8 ? aq_q8[0][i] : 0;
+        const float a = aq ? aq[0][i] : 0.f;
         const int icost = info[0][4 * i] > 16383 ? 16383 : info[0][4 * i];
-        const int intra = (icost * la_inv_qscale(a) + 128) >> 8;
-        int off = a;
+        const int intra = (icost * x264o_exp2fix8(a) + 128) >> 8;
+        float off = a;
         if (intra) {
-            const int p2 = prop[i] * 2;                                 /* (propagate * 512 + 128) >> 8 */
-            off = a - ((strength_q8 * (la_log2_q8((uint32_t)(intra + p2)) - la_log2_q8((uint32_t)intra))) >> 8);
+            const int p2 = prop[i] * 2;                                 /* (propagate * fps_factor + 128) >> 8, fps_factor = 512 */
+            const float log2_ratio = x264o_log2((uint32_t)(intra + p2)) - x264o_log2((uint32_t)intra) + 0.f;
+            off = a - strength * log2_ratio;
         }
-        out_q8[i] = (int16_t)off;
+        out[i] = off;
     }
     free(prop);
 }

@@ -45,7 +45,7 @@ typedef struct x264o_slicetype {
     x264o_encoder lo;            /* shell over the half-resolution plane sets (see x264o_lowres_me_search) */
     st_frame *fr;
     pixel *tmp;
-    struct st_tree_s { int32_t *prop; int16_t *aq; } *tree;      /* per slot: macroblock-tree propagate costs, AQ offsets (Q8) */
+    struct st_tree_s { int32_t *prop; float *aq; } *tree;        /* per slot: macroblock-tree propagate costs, AQ offsets (f_qp_offset_aq) */
 } x264o_slicetype;
 
 x264o_slicetype *x264o_slicetype_create(int width, int height, int slots, int bframes, int me_method, int subme, int me_range, int weightb, int mv_range, int do_edges)
@@ -72,7 +72,7 @@ x264o_slicetype *x264o_slicetype_create(int width, int height, int slots, int bf
     }
     st->tmp = malloc((size_t)st->bw * 16 * st->bh * 16);
     st->tree = calloc((size_t)st->nslots, sizeof(*st->tree));
-    for (int s = 0; s < st->nslots; s++) { st->tree[s].prop = calloc((size_t)st->nb, sizeof(int32_t)); st->tree[s].aq = calloc((size_t)st->nb, sizeof(int16_t)); }
+    for (int s = 0; s < st->nslots; s++) { st->tree[s].prop = calloc((size_t)st->nb, sizeof(int32_t)); st->tree[s].aq = calloc((size_t)st->nb, sizeof(float)); }
     return st;
 }
 
@@ -114,7 +114,7 @@ int x264o_slicetype_put_frame(x264o_slicetype *st, int slot, const uint8_t *i420
     memset(f->intra_mbs, 0, sizeof(f->intra_mbs));
     f->intra_calculated = 0;
     for (int i = 0; i < st->nb; i++) f->intra_cost[i] = 0xffff;          /* x264_frame_new: memset( i_intra_cost, -1 ) — blocks never costed never win a minimum */
-    memset(st->tree[slot].prop, 0, (size_t)st->nb * sizeof(int32_t)); memset(st->tree[slot].aq, 0, (size_t)st->nb * sizeof(int16_t));
+    memset(st->tree[slot].prop, 0, (size_t)st->nb * sizeof(int32_t)); memset(st->tree[slot].aq, 0, (size_t)st->nb * sizeof(float));
     return 0;
 }
 
@@ -283,24 +283,29 @@ const uint16_t *x264o_slicetype_lowres_costs(const x264o_slicetype *st, int slot
  * macroblock-tree through B pictures ([x264-upstream] encoder/slicetype.c macroblock_tree_propagate, common/mc.c mbtree_propagate_cost /
  * mbtree_propagate_list, macroblock_tree_finish), constant frame rate.  Every picture hands the part of its cost that its references explain
  * back to the blocks its vectors point at: list 0 and list 1 as lowres_costs' list_used bits say, bi-predicted blocks split by the implicit
- * weight, bilinear split over four blocks, 15-bit saturating sums.  Integer restatement of x264's float expressions as in oracle/lookahead.c
- * x264o_mbtree: amounts carry 9 fractional bits (fps_factor 1 / 512), inverse quantiser scales are x264_exp2fix8 of the AQ offsets. */
+ * weight, bilinear split over four blocks, 15-bit saturating sums.  x264's C expressions in single floats as in oracle/lookahead.c
+ * x264o_mbtree: fps_factor = 1 / 512 (MBTREE_PRECISION 0.5f at constant frame rate), inverse quantiser scales are x264_exp2fix8 of the AQ offsets. */
 #include "fixlut.h"
-static int st_log2_q8(uint32_t x) { int lz = 31 - __builtin_clz(x); return lz * 256 + x264o_log2_lut()[((x << (31 - lz)) >> 24) & 0x7f]; }
-static int st_inv_qscale(int aq_q8)
+static int st_inv_qscale(float aq) { return x264o_exp2fix8(aq); }
+/* mbtree_propagate_cost (common/mc.c), one block */
+static int st_propagate_amount(int propagate_in, int intra_cost, int inter_cost, int inv_qscale)
 {
-    int i = (-aq_q8 * 64 + 786432 + 768) / 1536;
-    if (i < 0) return 0;
-    if (i > 1023) return 0xffff;
-    return (int)(((uint32_t)(x264o_exp2_lut()[i & 63] + 256) << (i >> 6)) >> 8);
+    if (!intra_cost) return 0;          /* (0 / 0 in x264: the conversion of the NaN is 0 in the stored int16) */
+    const float fps = 1.f / 512.f;
+    float propagate_intra = (float)(intra_cost * inv_qscale);
+    float propagate_amount = (float)propagate_in + propagate_intra * fps;
+    float propagate_num = (float)(intra_cost - inter_cost);
+    float propagate_denom = (float)intra_cost;
+    const int v = (int)(propagate_amount * propagate_num / propagate_denom + 0.5f);
+    return v < 32767 ? v : 32767;
 }
 typedef struct st_tree_s st_tree;
 static st_tree *st_tree_of(x264o_slicetype *st) { return st->tree; }
-/* x264_adaptive_quant_frame's offsets of the picture in `slot` (Q8; NULL = none): i_inv_qscale_factor follows from them */
-void x264o_slicetype_set_aq(x264o_slicetype *st, int slot, const int16_t *aq_q8)
+/* x264_adaptive_quant_frame's offsets of the picture in `slot` (f_qp_offset_aq; NULL = none): i_inv_qscale_factor follows from them */
+void x264o_slicetype_set_aq(x264o_slicetype *st, int slot, const float *aq)
 {
     st_tree *t = st_tree_of(st);
-    if (aq_q8) memcpy(t[slot].aq, aq_q8, (size_t)st->nb * sizeof(int16_t)); else memset(t[slot].aq, 0, (size_t)st->nb * sizeof(int16_t));
+    if (aq) memcpy(t[slot].aq, aq, (size_t)st->nb * sizeof(float)); else memset(t[slot].aq, 0, (size_t)st->nb * sizeof(float));
 }
 /* fenc->i_cost_est_aq[b - p0][p1 - b]: the costs of the triple weighted block by block with the inverse quantiser scale of the picture's AQ offsets
  * (x264 slicetype_mb_cost: i_mb_cost_aq = (cost * i_inv_qscale_factor + 128) >> 8, summed over the blocks that count for the frame score) — what
@@ -309,7 +314,7 @@ int x264o_slicetype_cost_aq(x264o_slicetype *st, int slot, int d0, int d1)
 {
     st_frame *f = &st->fr[slot];
     if (d0 < 0 || d1 < 0 || d0 > st->bframes + 1 || d1 > st->bframes + 1 || f->cost_est[d0][d1] < 0) return -1;
-    const int16_t *aq = st_tree_of(st)[slot].aq;
+    const float *aq = st_tree_of(st)[slot].aq;
     const int is_i = d0 == 0 && d1 == 0, e = st->do_edges;
     int sum = 0;
     for (int by = 0; by < st->bh; by++)
@@ -340,9 +345,7 @@ int x264o_slicetype_propagate(x264o_slicetype *st, int s0, int s1, int sb, int d
             const int i = by * bw + bx;
             const int intra = f->intra_cost[i] > LOWRES_COST_MASK ? LOWRES_COST_MASK : f->intra_cost[i];
             const int best = lc[i] & LOWRES_COST_MASK, inter = best < intra ? best : intra, inv = st_inv_qscale(t[sb].aq[i]);
-            const int64_t amt512 = (int64_t)(referenced ? (t[sb].prop[i] > 32767 ? 32767 : t[sb].prop[i]) : 0) * 512 + (int64_t)intra * inv;
-            int amount = intra ? (int)((amt512 * (intra - inter) + 256 * (int64_t)intra) / (512 * (int64_t)intra)) : 0;
-            if (amount > 32767) amount = 32767;
+            const int amount = st_propagate_amount(referenced ? (t[sb].prop[i] > 32767 ? 32767 : t[sb].prop[i]) : 0, intra, inter, inv);
             const int used = lc[i] >> LOWRES_COST_SHIFT;
             for (int l = 0; l < (d1 > 0 ? 2 : 1); l++) {
                 if (!(used & (1 << l))) continue;
@@ -364,22 +367,24 @@ int x264o_slicetype_propagate(x264o_slicetype *st, int s0, int s1, int sb, int d
         }
     return 0;
 }
-/* macroblock_tree_finish: out = aq - strength * log2((intra + propagated) / intra), Q8 */
-int x264o_slicetype_finish(x264o_slicetype *st, int slot, int strength_q8, int16_t *out_q8)
+/* macroblock_tree_finish: out = f_qp_offset_aq - strength * (x264_log2(intra + propagated) - x264_log2(intra) + weightdelta), strength = 5.0f * (1.0f - qcomp),
+ * weightdelta = 1 - f_weighted_cost_delta[ref0_distance - 1] where the lookahead's weight analysis found a weight for that distance (else 0) */
+int x264o_slicetype_finish(x264o_slicetype *st, int slot, float strength, float weightdelta, float *out)
 {
     st_tree *t = st_tree_of(st);
     const st_frame *f = &st->fr[slot];
     if (f->cost_est[0][0] < 0) return -1;          /* the intra costs exist once any cost of the picture has been computed */
     for (int i = 0; i < st->nb; i++) {
-        const int a = t[slot].aq[i];
+        const float a = t[slot].aq[i];
         const int icost = f->intra_cost[i] > LOWRES_COST_MASK ? LOWRES_COST_MASK : f->intra_cost[i];
         const int intra = (icost * st_inv_qscale(a) + 128) >> 8;
-        int off = a;
+        float off = a;
         if (intra) {
-            const int p2 = (t[slot].prop[i] > 32767 ? 32767 : t[slot].prop[i]) * 2;
-            off = a - ((strength_q8 * (st_log2_q8((uint32_t)(intra + p2)) - st_log2_q8((uint32_t)intra))) >> 8);
+            const int p2 = (t[slot].prop[i] > 32767 ? 32767 : t[slot].prop[i]) * 2;          /* (propagate * fps_factor + 128) >> 8, fps_factor = 512 */
+            const float log2_ratio = x264o_log2((uint32_t)(intra + p2)) - x264o_log2((uint32_t)intra) + weightdelta;
+            off = a - strength * log2_ratio;
         }
-        out_q8[i] = (int16_t)off;
+        out[i] = off;
     }
     return 0;
 }

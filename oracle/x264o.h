@@ -101,9 +101,10 @@ x264o_lookahead *x264o_lookahead_create(int width, int height, int me_range, int
 void x264o_lookahead_destroy(x264o_lookahead *la);
 /* out[4] = { intra cost, P cost vs the previous picture, intra blocks, blocks in the frame score }; block_info (blocks x 4 int32) optional */
 int  x264o_lookahead_frame_cost(x264o_lookahead *la, const uint8_t *i420, int reset, int32_t out[4], int32_t *block_info);
-/* per-macroblock AQ offsets (Q8) of a source picture; macroblock-tree offsets (Q8) of picture 0 from n consecutive pictures' records */
-void x264o_aq_offsets(const uint8_t *i420, int w, int h, int strength_q8, int16_t *out_q8);
-void x264o_mbtree(int bw, int bh, const int32_t *const *info, const int16_t *const *aq_q8, int n, int strength_q8, int16_t *out_q8);
+/* per-macroblock AQ offsets (single floats) of a source picture; macroblock-tree offsets of picture 0 from n consecutive pictures' records */
+void x264o_aq_offsets(const uint8_t *i420, int w, int h, float strength, float *out);
+void x264o_aq_offsets_mode(const uint8_t *i420, int w, int h, int mode, float strength, float *out);
+void x264o_mbtree(int bw, int bh, const int32_t *const *info, const float *const *aq, int n, float strength, float *out);
 
 /* ---- motion compensation / plane filters: common/mc.c, common/frame.c (A1/A4/A10) ---- */
 /* hpel planes: dsth/dstv/dstc (H, V, centre=HV) for an w x h region; src is read with

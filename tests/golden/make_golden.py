@@ -26,7 +26,7 @@ CASES = [("p176x144", 176, 144, 5, {}), ("p208x120_q30", 208, 120, 3, dict(qp_i=
          ("p176x144_medium_chroma_me", 176, 144, 5, dict(refs=3, partitions=7, dct8x8=1, chroma_me=1)),
          ("p176x144_lowqp_umh", 176, 144, 4, dict(qp_i=10, qp_p=13, refs=2, partitions=7, dct8x8=1, chroma_me=1, me_method=2)),
          ("p176x144_x264_medium_me", 176, 144, 6, dict(refs=3, partitions=7, dct8x8=1, chroma_me=1, mixed_refs=1)),
-         ("p176x144_aq", 176, 144, 4, dict(refs=2, partitions=7, dct8x8=1, chroma_me=1, aq_mode=1, aq_strength_q8=266, qp_i=23, qp_p=26)),
+         ("p176x144_aq", 176, 144, 4, dict(refs=2, partitions=7, dct8x8=1, chroma_me=1, aq_mode=1, aq_strength=1.0397, qp_i=23, qp_p=26)),
          # round 4: the headline toolset — RD mode decision priced with CABAC sizes (subme 7), psy-rd, trellis 1 / 2 — and RD refinement (subme 8)
          ("p176x144_medium_rd_cabac_trellis", 176, 144, 5, dict(refs=3, partitions=7, dct8x8=1, chroma_me=1, mixed_refs=1, cabac=1, rd=1, subme=7, psy=1, psy_rd_q8=256,
                                                                chroma_qp_offset=-2, trellis=63)),

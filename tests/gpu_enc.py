@@ -98,30 +98,30 @@ class GpuLookahead:
         t.cuda.synchronize()
         return self.d_out.cpu().numpy(), self.d_blocks.cpu().numpy()
 
-    def aq_offsets(self, frames, strength_q8=266):
+    def aq_offsets(self, frames, strength=1.0397):
         t = self.torch
         d_in = t.from_numpy(np.stack(frames)).cuda()
-        out = t.zeros((self.S, self.nb), dtype=t.int16, device="cuda")
-        lib.check(lib.x264gpu_lookahead_aq_offsets(self.h, d_in.data_ptr(), strength_q8, out.data_ptr(), None), "lookahead_aq_offsets")
+        out = t.zeros((self.S, self.nb), dtype=t.float32, device="cuda")
+        lib.check(lib.x264gpu_lookahead_aq_offsets(self.h, d_in.data_ptr(), strength, out.data_ptr(), None), "lookahead_aq_offsets")
         t.cuda.synchronize()
         return out
 
-    def aq_offsets_mode(self, frames, mode, strength_q8=256):
+    def aq_offsets_mode(self, frames, mode, strength=1.0):
         t = self.torch
         d_in = t.from_numpy(np.stack(frames)).cuda()
-        out = t.zeros((self.S, self.nb), dtype=t.int16, device="cuda")
-        lib.check(lib.x264gpu_lookahead_aq_offsets_mode(self.h, d_in.data_ptr(), mode, strength_q8, out.data_ptr(), None), "lookahead_aq_offsets_mode")
+        out = t.zeros((self.S, self.nb), dtype=t.float32, device="cuda")
+        lib.check(lib.x264gpu_lookahead_aq_offsets_mode(self.h, d_in.data_ptr(), mode, strength, out.data_ptr(), None), "lookahead_aq_offsets_mode")
         t.cuda.synchronize()
         return out
 
-    def mbtree(self, d_infos, d_aqs, strength_q8=512):
+    def mbtree(self, d_infos, d_aqs, strength=2.0):
         """d_infos / d_aqs: lists of device tensors of consecutive pictures ([0] = the one about to be coded); d_aqs may be None"""
         t = self.torch
         n = len(d_infos)
         ip = (C.c_void_p * n)(*[x.data_ptr() for x in d_infos])
         ap = (C.c_void_p * n)(*[x.data_ptr() for x in d_aqs]) if d_aqs is not None else None
-        out = t.zeros((self.S, self.nb), dtype=t.int16, device="cuda")
-        lib.check(lib.x264gpu_lookahead_mbtree(self.h, ip, ap, n, strength_q8, out.data_ptr(), None), "lookahead_mbtree")
+        out = t.zeros((self.S, self.nb), dtype=t.float32, device="cuda")
+        lib.check(lib.x264gpu_lookahead_mbtree(self.h, ip, ap, n, strength, out.data_ptr(), None), "lookahead_mbtree")
         t.cuda.synchronize()
         return out.cpu().numpy()
 
@@ -213,12 +213,12 @@ class GpuSlicetype:
         lib.check(lib.x264gpu_slicetype_cost_aq(self.h, slot, d0, d1, out, None), "cost_aq")
         return list(out)
 
-    def set_aq(self, slot, aq_q8):
-        """aq_q8: [blocks] int16 (replicated over the streams) or None"""
-        if aq_q8 is None:
+    def set_aq(self, slot, aq):
+        """aq: [blocks] float32 (replicated over the streams) or None"""
+        if aq is None:
             lib.check(lib.x264gpu_slicetype_set_aq(self.h, slot, None, None), "set_aq")
             return
-        d = self.torch.from_numpy(np.ascontiguousarray(np.tile(np.asarray(aq_q8, np.int16), (self.S, 1)))).cuda()
+        d = self.torch.from_numpy(np.ascontiguousarray(np.tile(np.asarray(aq, np.float32), (self.S, 1)))).cuda()
         lib.check(lib.x264gpu_slicetype_set_aq(self.h, slot, d.data_ptr(), None), "set_aq")
         self.torch.cuda.synchronize()
 
@@ -228,9 +228,9 @@ class GpuSlicetype:
     def propagate(self, s0, s1, sb, d0, d1, referenced):
         lib.check(lib.x264gpu_slicetype_propagate(self.h, s0, s1, sb, d0, d1, int(referenced), None), "propagate")
 
-    def finish(self, slot, strength_q8):
-        out = self.torch.zeros((self.S, self.nb), dtype=self.torch.int16, device="cuda")
-        lib.check(lib.x264gpu_slicetype_finish(self.h, slot, strength_q8, out.data_ptr(), None), "finish")
+    def finish(self, slot, strength, weightdelta=0.0):
+        out = self.torch.zeros((self.S, self.nb), dtype=self.torch.float32, device="cuda")
+        lib.check(lib.x264gpu_slicetype_finish(self.h, slot, strength, weightdelta, out.data_ptr(), None), "finish")
         self.torch.cuda.synchronize()
         return out.cpu().numpy()
 

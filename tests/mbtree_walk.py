@@ -3,7 +3,7 @@ gpu_enc.GpuSlicetype: cost / clear_propagate / propagate / finish): frames[0] = 
 queued ones with their decided types ('I', 'P', 'B').  The product's host code (host/encoder.cpp st_macroblock_tree) is the same walk."""
 
 
-def macroblock_tree(st, slots, types, num_frames, b_intra, pyramid, strength_q8):
+def macroblock_tree(st, slots, types, num_frames, b_intra, pyramid, strength):
     """-> {frame index: offsets} of the pictures x264 finishes: the next non-B picture (index 1.. or 0 for b_intra) and its B-reference"""
     idx = 0 if b_intra else 1
     isb = lambda i: types[i] == 'B'
@@ -50,9 +50,9 @@ def macroblock_tree(st, slots, types, num_frames, b_intra, pyramid, strength_q8)
         last_nonb = cur_nonb
     # (x264 reads the intra costs the slice-type analysis left with these pictures; asking for the I cost is a no-op then)
     cost(last_nonb, last_nonb, last_nonb)
-    out = {last_nonb: st.finish(slots[last_nonb], strength_q8)}
+    out = {last_nonb: st.finish(slots[last_nonb], strength)}
     if pyramid and bframes > 1:
         m = last_nonb + (bframes + 1) // 2
         cost(m, m, m)
-        out[m] = st.finish(slots[m], strength_q8)
+        out[m] = st.finish(slots[m], strength)
     return out

@@ -142,6 +142,7 @@ _sig("x264o_encoder_destroy", None, [C.c_void_p])
 _sig("x264o_encoder_mb_count", _i, [C.c_void_p])
 _sig("x264o_encoder_set_qp", None, [C.c_void_p, _i, _i])
 _sig("x264o_encoder_set_mb_qp_offsets", None, [C.c_void_p, C.c_void_p])
+_sig("x264o_encoder_set_qpm", None, [C.c_void_p, C.c_float])
 _sig("x264o_encoder_encode", _i, [C.c_void_p, C.c_void_p, _i, C.c_void_p, C.c_void_p])
 _sig("x264o_encoder_encode_pic", _i, [C.c_void_p, C.c_void_p, C.POINTER(Pic), C.c_void_p, C.c_void_p])
 _sig("x264o_encoder_get_recon", None, [C.c_void_p, C.c_void_p])
@@ -173,7 +174,7 @@ def mb_mv1(mbs):
 def default_config(width, height, streams=1, **kw):
     c = Config(width=width, height=height, streams=streams, refs=1, qp_i=20, qp_p=23, me_range=16, subme=7,
                deblock=1, deblock_alpha=0, deblock_beta=0, chroma_qp_offset=0, deadzone_inter=21,
-               deadzone_intra=11, dct_decimate=1, partitions=2, dct8x8=0, me_method=1, chroma_me=0, mixed_refs=0, aq_mode=0, aq_strength_q8=266, fast_pskip=1, mv_range=0)
+               deadzone_intra=11, dct_decimate=1, partitions=2, dct8x8=0, me_method=1, chroma_me=0, mixed_refs=0, aq_mode=0, aq_strength=1.0397, fast_pskip=1, mv_range=0)
     for k, v in kw.items():
         setattr(c, k, v)
     return c
@@ -218,8 +219,12 @@ class OracleEncoder:
     def set_qp(self, qp_i, qp_p):
         L.x264o_encoder_set_qp(self.h, qp_i, qp_p)
 
-    def set_mb_qp_offsets(self, off_q8):
-        self._off = None if off_q8 is None else np.ascontiguousarray(off_q8, np.int16)      # keep alive
+    def set_qpm(self, qpm):
+        """the float quantiser (x264 rc->qpm) of encode()'s following pictures; 0 = the integer one"""
+        L.x264o_encoder_set_qpm(self.h, qpm)
+
+    def set_mb_qp_offsets(self, off):
+        self._off = None if off is None else np.ascontiguousarray(off, np.float32)      # keep alive
         L.x264o_encoder_set_mb_qp_offsets(self.h, None if self._off is None else ptr(self._off))
 
     def recon(self):
@@ -295,7 +300,7 @@ _sig("x264o_slicetype_chroma_stats", None, [C.c_void_p, _i, C.c_void_p, C.c_void
 _sig("x264o_slicetype_weight_cost_chroma", C.c_long, [C.c_void_p, _i, C.c_void_p, C.c_void_p] + [_i] * 6)
 _sig("x264o_slicetype_clear_propagate", None, [C.c_void_p, _i])
 _sig("x264o_slicetype_propagate", _i, [C.c_void_p, _i, _i, _i, _i, _i, _i])
-_sig("x264o_slicetype_finish", _i, [C.c_void_p, _i, _i, C.c_void_p])
+_sig("x264o_slicetype_finish", _i, [C.c_void_p, _i, C.c_float, C.c_float, C.c_void_p])
 _sig("x264o_slicetype_propagate_cost", C.c_void_p, [C.c_void_p, _i])
 
 
@@ -360,8 +365,8 @@ class OracleSlicetype:
     def cost_aq(self, slot, d0, d1):
         return L.x264o_slicetype_cost_aq(self.st, slot, d0, d1)
 
-    def set_aq(self, slot, aq_q8):
-        a = None if aq_q8 is None else np.ascontiguousarray(aq_q8, np.int16)
+    def set_aq(self, slot, aq):
+        a = None if aq is None else np.ascontiguousarray(aq, np.float32)
         L.x264o_slicetype_set_aq(self.st, slot, None if a is None else ptr(a))
 
     def clear_propagate(self, slot):
@@ -370,9 +375,9 @@ class OracleSlicetype:
     def propagate(self, s0, s1, sb, d0, d1, referenced):
         assert L.x264o_slicetype_propagate(self.st, s0, s1, sb, d0, d1, int(referenced)) == 0
 
-    def finish(self, slot, strength_q8):
-        out = np.zeros(self.nb, np.int16)
-        assert L.x264o_slicetype_finish(self.st, slot, strength_q8, ptr(out)) == 0
+    def finish(self, slot, strength, weightdelta=0.0):
+        out = np.zeros(self.nb, np.float32)
+        assert L.x264o_slicetype_finish(self.st, slot, strength, weightdelta, ptr(out)) == 0
         return out
 
     def propagate_cost(self, slot):
@@ -387,36 +392,40 @@ class OracleSlicetype:
         self.close()
 
 
-_sig("x264o_aq_offsets", None, [C.c_void_p, _i, _i, _i, C.c_void_p])
-_sig("x264o_aq_offsets_mode", None, [C.c_void_p, _i, _i, _i, _i, C.c_void_p])
-_sig("x264o_mbtree", None, [_i, _i, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), _i, _i, C.c_void_p])
+_sig("x264o_aq_offsets", None, [C.c_void_p, _i, _i, C.c_float, C.c_void_p])
+_sig("x264o_aq_offsets_mode", None, [C.c_void_p, _i, _i, _i, C.c_float, C.c_void_p])
+_sig("x264o_mbtree", None, [_i, _i, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), _i, C.c_float, C.c_void_p])
 
 
-def aq_offsets_mode(i420, w, h, mode, strength_q8=256):
-    out = np.zeros(((w + 15) // 16) * ((h + 15) // 16), np.int16)
+AQ1 = float(np.float32(1.0) * np.float32(1.0397))       # x264_adaptive_quant_frame's mode-1 strength at --aq-strength 1.0
+TREE = float(np.float32(5.0) * (np.float32(1.0) - np.float32(0.6)))       # macroblock_tree_finish's strength at --qcomp 0.6
+
+
+def aq_offsets_mode(i420, w, h, mode, strength=1.0):
+    out = np.zeros(((w + 15) // 16) * ((h + 15) // 16), np.float32)
     i420 = np.ascontiguousarray(i420, np.uint8)
-    L.x264o_aq_offsets_mode(ptr(i420), w, h, mode, strength_q8, ptr(out))
+    L.x264o_aq_offsets_mode(ptr(i420), w, h, mode, strength, ptr(out))
     return out
 
 
-def aq_offsets(i420, w, h, strength_q8=266):
-    out = np.zeros(((w + 15) // 16) * ((h + 15) // 16), np.int16)
+def aq_offsets(i420, w, h, strength=AQ1):
+    out = np.zeros(((w + 15) // 16) * ((h + 15) // 16), np.float32)
     i420 = np.ascontiguousarray(i420, np.uint8)
-    L.x264o_aq_offsets(ptr(i420), w, h, strength_q8, ptr(out))
+    L.x264o_aq_offsets(ptr(i420), w, h, strength, ptr(out))
     return out
 
 
-def mbtree(bw, bh, infos, aqs, strength_q8=512):
-    """infos: list of (blocks x 4) int32 arrays of consecutive pictures, [0] = the one about to be coded; aqs: list of int16 or None"""
+def mbtree(bw, bh, infos, aqs, strength=TREE):
+    """infos: list of (blocks x 4) int32 arrays of consecutive pictures, [0] = the one about to be coded; aqs: list of float32 or None"""
     n = len(infos)
     infos = [np.ascontiguousarray(a, np.int32) for a in infos]
     ip = (C.c_void_p * n)(*[a.ctypes.data for a in infos])
     ap = None
     if aqs is not None:
-        aqs = [np.ascontiguousarray(a, np.int16) for a in aqs]
+        aqs = [np.ascontiguousarray(a, np.float32) for a in aqs]
         ap = (C.c_void_p * n)(*[a.ctypes.data for a in aqs])
-    out = np.zeros(bw * bh, np.int16)
-    L.x264o_mbtree(bw, bh, ip, ap, n, strength_q8, ptr(out))
+    out = np.zeros(bw * bh, np.float32)
+    L.x264o_mbtree(bw, bh, ip, ap, n, strength, ptr(out))
     return out
 
 

@@ -15,7 +15,8 @@ x264o_encoder *x264o_encoder_create(const x264gpu_config *cfg);
 void x264o_encoder_destroy(x264o_encoder *e);
 int x264o_encoder_mb_count(const x264o_encoder *e);
 void x264o_encoder_set_qp(x264o_encoder *e, int qp_i, int qp_p);
-void x264o_encoder_set_mb_qp_offsets(x264o_encoder *e, const int16_t *off_q8);
+void x264o_encoder_set_qpm(x264o_encoder *e, float qpm);
+void x264o_encoder_set_mb_qp_offsets(x264o_encoder *e, const float *off);
 int x264o_encoder_encode(x264o_encoder *e, const uint8_t *i420, int slice_type, x264gpu_mb *mbs, int16_t *levels);
 void x264o_encoder_get_recon(x264o_encoder *e, uint8_t *out);
 
@@ -40,7 +41,7 @@ int x264gpu_memset(void *d, int v, size_t n, void *st) { memset(d, v, n); return
 int x264gpu_stream_sync(void *st) { return X264GPU_OK; }
 long x264gpu_stub_encode_calls(int dev) { return dev >= 0 && dev < 16 ? g_calls[dev] : -1; }
 
-struct x264gpu_encoder { x264gpu_config cfg; x264o_encoder **e; int dev, nmb; const int16_t *off; int8_t *sqp; };
+struct x264gpu_encoder { x264gpu_config cfg; x264o_encoder **e; int dev, nmb; const float *off; int8_t *sqp; float *sqpm; float qpm; };
 
 int x264gpu_encoder_create(x264gpu_encoder **out, const x264gpu_config *cfg)
 {
@@ -62,17 +63,23 @@ void x264gpu_encoder_destroy(x264gpu_encoder *g)
 {
     if (!g) return;
     for (int s = 0; s < g->cfg.streams; s++) x264o_encoder_destroy(g->e[s]);
-    free(g->e); free(g->sqp); free(g);
+    free(g->e); free(g->sqp); free(g->sqpm); free(g);
 }
 int x264gpu_encoder_mb_count(const x264gpu_encoder *g) { return g ? g->nmb : 0; }
 int x264gpu_encoder_set_qp(x264gpu_encoder *g, int qp_i, int qp_p) { g->cfg.qp_i = qp_i; g->cfg.qp_p = qp_p; return X264GPU_OK; }
-int x264gpu_encoder_set_mb_qp_offsets(x264gpu_encoder *g, const int16_t *off) { g->off = off; return X264GPU_OK; }
-int x264gpu_encoder_set_stream_qps(x264gpu_encoder *g, const int8_t *qps)
+int x264gpu_encoder_set_mb_qp_offsets(x264gpu_encoder *g, const float *off) { g->off = off; return X264GPU_OK; }
+int x264gpu_encoder_set_stream_qpms(x264gpu_encoder *g, const int8_t *qps, const float *qpms)
 {
-    free(g->sqp); g->sqp = NULL;
+    free(g->sqp); g->sqp = NULL; free(g->sqpm); g->sqpm = NULL;
     if (qps) { g->sqp = malloc((size_t)g->cfg.streams); memcpy(g->sqp, qps, (size_t)g->cfg.streams); }
+    if (qps && qpms) {
+        g->sqpm = malloc((size_t)g->cfg.streams * sizeof(float)); memcpy(g->sqpm, qpms, (size_t)g->cfg.streams * sizeof(float));
+        for (int s = 0; s < g->cfg.streams; s++) if (qpms[s] != 0.f && !(qpms[s] > (float)qps[s] - 1.f && qpms[s] < (float)qps[s] + 1.f)) return fail("qpm is not near qp");
+    }
     return X264GPU_OK;
 }
+int x264gpu_encoder_set_stream_qps(x264gpu_encoder *g, const int8_t *qps) { return x264gpu_encoder_set_stream_qpms(g, qps, NULL); }
+int x264gpu_encoder_set_qpm(x264gpu_encoder *g, float qpm) { if (!(qpm >= 0.f && qpm < 52.f)) return fail("qpm out of range"); g->qpm = qpm; return X264GPU_OK; }
 int x264gpu_trellis_blocks(const int16_t *c, int n, int cat, int qp, int intra, const uint8_t *s, int16_t *l, uint8_t *z, void *st) { return fail("trellis primitive: not in the stub"); }
 int x264gpu_encoder_cabac_states(x264gpu_encoder *g, int stream, int slice, uint8_t *out) { return fail("context states: not in the stub"); }
 void x264o_encoder_set_lowres_mvs(x264o_encoder *e, const int16_t *mv);
@@ -151,20 +158,20 @@ int x264gpu_slicetype_weight_cost(x264gpu_slicetype *s, int sf, int sr, int dist
     h_cost[0] = c;
     return X264GPU_OK;
 }
-void x264o_slicetype_set_aq(x264o_slicetype *st, int slot, const int16_t *aq_q8);
+void x264o_slicetype_set_aq(x264o_slicetype *st, int slot, const float *aq);
 void x264o_slicetype_clear_propagate(x264o_slicetype *st, int slot);
 int x264o_slicetype_propagate(x264o_slicetype *st, int s0, int s1, int sb, int d0, int d1, int referenced);
-int x264o_slicetype_finish(x264o_slicetype *st, int slot, int strength_q8, int16_t *out_q8);
+int x264o_slicetype_finish(x264o_slicetype *st, int slot, float strength, float weightdelta, float *out);
 const int32_t *x264o_slicetype_propagate_cost(x264o_slicetype *st, int slot);
 void x264o_slicetype_set_bframe_bias(x264o_slicetype *st, int bias);
 int x264gpu_slicetype_set_bframe_bias(x264gpu_slicetype *s, int bias) { x264o_slicetype_set_bframe_bias(s->st, bias); return X264GPU_OK; }
 int x264gpu_slicetype_set_row_mode(x264gpu_slicetype *s, int serial) { (void)s; (void)serial; return X264GPU_OK; }          /* (a launch geometry: nothing to model) */
 int x264o_slicetype_cost_aq(x264o_slicetype *st, int slot, int d0, int d1);
 int x264gpu_slicetype_cost_aq(x264gpu_slicetype *s, int slot, int d0, int d1, int32_t *h_score, void *stream) { const int c = x264o_slicetype_cost_aq(s->st, slot, d0, d1); if (c < 0) return fail("slicetype cost_aq"); h_score[0] = c; return X264GPU_OK; }
-int x264gpu_slicetype_set_aq(x264gpu_slicetype *s, int slot, const int16_t *aq, void *stream) { x264o_slicetype_set_aq(s->st, slot, aq); return X264GPU_OK; }
+int x264gpu_slicetype_set_aq(x264gpu_slicetype *s, int slot, const float *aq, void *stream) { x264o_slicetype_set_aq(s->st, slot, aq); return X264GPU_OK; }
 int x264gpu_slicetype_clear_propagate(x264gpu_slicetype *s, int slot, void *stream) { x264o_slicetype_clear_propagate(s->st, slot); return X264GPU_OK; }
 int x264gpu_slicetype_propagate(x264gpu_slicetype *s, int s0, int s1, int sb, int d0, int d1, int referenced, void *stream) { return x264o_slicetype_propagate(s->st, s0, s1, sb, d0, d1, referenced) ? fail("macroblock-tree: costs of the triple missing") : X264GPU_OK; }
-int x264gpu_slicetype_finish(x264gpu_slicetype *s, int slot, int strength_q8, int16_t *out, void *stream) { return x264o_slicetype_finish(s->st, slot, strength_q8, out) ? fail("macroblock-tree: no intra costs") : X264GPU_OK; }
+int x264gpu_slicetype_finish(x264gpu_slicetype *s, int slot, float strength, float weightdelta, float *out, void *stream) { return x264o_slicetype_finish(s->st, slot, strength, weightdelta, out) ? fail("macroblock-tree: no intra costs") : X264GPU_OK; }
 const int32_t *x264gpu_slicetype_propagate_cost(x264gpu_slicetype *s, int slot) { return x264o_slicetype_propagate_cost(s->st, slot); }
 int x264gpu_encode_frames(x264gpu_encoder *g, const uint8_t *i420, int slice_type, x264gpu_mb *mb, int16_t *lv, void *st)
 {
@@ -174,6 +181,7 @@ int x264gpu_encode_frames(x264gpu_encoder *g, const uint8_t *i420, int slice_typ
     for (int s = 0; s < g->cfg.streams; s++) {
         const int qi = g->sqp ? g->sqp[s] : g->cfg.qp_i, qp = g->sqp ? g->sqp[s] : g->cfg.qp_p;
         x264o_encoder_set_qp(g->e[s], qi, qp);
+        x264o_encoder_set_qpm(g->e[s], g->sqp ? (g->sqpm ? g->sqpm[s] : 0.f) : g->qpm);
         x264o_encoder_set_mb_qp_offsets(g->e[s], g->off ? g->off + (size_t)s * g->nmb : NULL);
         if (x264o_encoder_encode(g->e[s], i420 + s * fsz, slice_type, mb + (size_t)s * g->nmb, lv + (size_t)s * g->nmb * X264GPU_MB_LEVELS)) return fail("P picture without a reference");
     }
@@ -187,7 +195,7 @@ int x264gpu_encode_pictures(x264gpu_encoder *g, const uint8_t *i420, const x264g
     g_calls[g->dev]++;
     /* the device's structural checks (csrc/encoder.hip x264gpu_encode_pictures): lock-step streams share everything but the quantiser and its fraction */
     for (int s = 0; s < g->cfg.streams; s++) {
-        if (pics[s].qp_frac_q8 < -128 || pics[s].qp_frac_q8 > 127) return fail("qp_frac_q8 out of range");
+        if (pics[s].qpm != 0.f && !(pics[s].qpm > (float)pics[s].qp - 1.f && pics[s].qpm < (float)pics[s].qp + 1.f)) return fail("qpm is not near qp");
         if (s && !(pics[s].slice_type == pics[0].slice_type && pics[s].poc == pics[0].poc && pics[s].dst == pics[0].dst && pics[s].keep == pics[0].keep &&
                    pics[s].nref[0] == pics[0].nref[0] && pics[s].nref[1] == pics[0].nref[1] && !memcmp(pics[s].slot, pics[0].slot, sizeof(pics[0].slot)) &&
                    pics[s].blind_dupe == pics[0].blind_dupe && !memcmp(pics[s].wl0, pics[0].wl0, sizeof(pics[0].wl0)) && !memcmp(pics[s].wc0, pics[0].wc0, sizeof(pics[0].wc0)) &&
@@ -221,23 +229,22 @@ int x264gpu_lookahead_frame_cost(x264gpu_lookahead *l, const uint8_t *i420, int 
     if (!blocks) free(tmp);
     return rc ? fail("lookahead") : X264GPU_OK;
 }
-int x264gpu_lookahead_aq_offsets(x264gpu_lookahead *l, const uint8_t *i420, int strength_q8, int16_t *out, void *st)
+int x264gpu_lookahead_aq_offsets(x264gpu_lookahead *l, const uint8_t *i420, float strength, float *out, void *st)
 {
-    x264o_aq_offsets(i420, l->w, l->h, strength_q8, out);
+    x264o_aq_offsets(i420, l->w, l->h, strength, out);
     return X264GPU_OK;
 }
 
-void x264o_aq_offsets_mode(const uint8_t *i420, int w, int h, int mode, int strength_q8, int16_t *out_q8);
-int x264gpu_lookahead_aq_offsets_mode(x264gpu_lookahead *l, const uint8_t *i420, int mode, int strength_q8, int16_t *out, void *st)
+int x264gpu_lookahead_aq_offsets_mode(x264gpu_lookahead *l, const uint8_t *i420, int mode, float strength, float *out, void *st)
 {
     (void)st;
     if (mode < 1 || mode > 3) return fail("aq mode 1..3");
-    x264o_aq_offsets_mode(i420, l->w, l->h, mode, strength_q8, out);
+    x264o_aq_offsets_mode(i420, l->w, l->h, mode, strength, out);
     return X264GPU_OK;
 }
-int x264gpu_lookahead_mbtree(x264gpu_lookahead *l, const int32_t *const *info, const int16_t *const *aq, int n, int strength_q8, int16_t *out, void *st)
+int x264gpu_lookahead_mbtree(x264gpu_lookahead *l, const int32_t *const *info, const float *const *aq, int n, float strength, float *out, void *st)
 {
-    x264o_mbtree((l->w + 15) / 16, (l->h + 15) / 16, info, aq, n, strength_q8, out);
+    x264o_mbtree((l->w + 15) / 16, (l->h + 15) / 16, info, aq, n, strength, out);
     return X264GPU_OK;
 }
 long x264gpu_csp_img_fill(int csp, int width, int height, long off[3], int stride[3]) { return x264o_csp_img_fill(csp, width, height, off, stride); }

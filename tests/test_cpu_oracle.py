@@ -157,18 +157,49 @@ def test_pred8_table_comes_from_the_standards_equations():
 
 
 def test_fixed_point_tables_of_the_product_match_libm():
-    """the AQ / macroblock-tree tables the product carries as literals (include/x264gpu_aq_lut.inc, x264gpu_exp2_lut.inc) against the oracle's own
-    derivation with libm (oracle/fixlut.h) and against numpy: the oracle does not read the product's files"""
+    """the AQ / macroblock-tree tables the product carries as literals (include/x264gpu_log2f_lut.inc, x264gpu_exp2_lut.inc) against the oracle's own
+    derivation with libm (oracle/fixlut.h) and against numpy: the oracle does not read the product's files.  x264_log2_lut is written in x264 as
+    five-decimal literals (0.00000, 0.01123, 0.02237 ... 0.99435): a double literal stored in a float — the first row and the last entry from memory of
+    [x264-upstream] common/tables.c"""
     import ctypes as C
     import os
     import re
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     for f in os.listdir(os.path.join(root, "oracle")):
         if f.endswith((".c", ".cpp", ".h", ".hpp")):
-            assert "_lut.inc" not in open(os.path.join(root, "oracle", f)).read().replace("x264gpu_aq_lut.inc, include/x264gpu_exp2_lut.inc", ""), f
-    lits = lambda name: [int(x) for x in re.findall(r"-?\d+", re.sub(r"/\*.*?\*/", "", open(os.path.join(root, "include", name)).read(), flags=re.S))]
-    lg, ex = np.zeros(128, np.uint8), np.zeros(64, np.uint16)
+            assert "_lut.inc" not in open(os.path.join(root, "oracle", f)).read().replace("x264gpu_log2f_lut.inc, include/x264gpu_exp2_lut.inc", ""), f
+    text = lambda name: re.sub(r"/\*.*?\*/", "", open(os.path.join(root, "include", name)).read(), flags=re.S)
+    lg, ex = np.zeros(128, np.float32), np.zeros(64, np.uint16)
     O.L.x264o_fixed_point_luts.argtypes = [C.c_void_p, C.c_void_p]
     O.L.x264o_fixed_point_luts(lg.ctypes.data, ex.ctypes.data)
-    assert lits("x264gpu_aq_lut.inc") == lg.tolist() == np.rint(256 * np.log2(1 + np.arange(128) / 128)).astype(int).tolist()
-    assert lits("x264gpu_exp2_lut.inc") == ex.tolist() == np.rint(256 * (2 ** (np.arange(64) / 64) - 1)).astype(int).tolist()
+    lit = [np.float32(float(x)) for x in re.findall(r"(\d\.\d{5})f", text("x264gpu_log2f_lut.inc"))]
+    assert len(lit) == 128 and np.array(lit, np.float32).tobytes() == lg.tobytes()
+    assert lg.tobytes() == np.array([float("%.5f" % v) for v in np.log2(1 + np.arange(128) / 128)], np.float32).tobytes()
+    assert ["%.5f" % v for v in lg[:8]] == ["0.00000", "0.01123", "0.02237", "0.03342", "0.04439", "0.05528", "0.06609", "0.07682"] and "%.5f" % lg[127] == "0.99435"
+    assert [int(x) for x in re.findall(r"-?\d+", text("x264gpu_exp2_lut.inc"))] == ex.tolist() == np.rint(256 * (2 ** (np.arange(64) / 64) - 1)).astype(int).tolist()
+
+
+def test_float_primitives_of_aq_and_mbtree_known_answers():
+    """x264_log2 / x264_exp2fix8 / x264_ratecontrol_mb_qp as the oracle restates them (oracle/fixlut.h), against values worked out by hand from x264's
+    definitions and against the same expressions in numpy single floats"""
+    import ctypes as C
+    L = O.L
+    L.x264o_log2_f.restype = C.c_float; L.x264o_log2_f.argtypes = [C.c_uint32]
+    L.x264o_exp2fix8_f.restype = C.c_int; L.x264o_exp2fix8_f.argtypes = [C.c_float]
+    L.x264o_mb_qp_f.restype = C.c_int; L.x264o_mb_qp_f.argtypes = [C.c_float, C.c_float]
+    f32 = np.float32
+    # x264_log2: exact on powers of two, table + exponent elsewhere (the argument's top 7 bits below the leading one)
+    assert [L.x264o_log2_f(1 << k) for k in (0, 1, 10, 31)] == [0.0, 1.0, 10.0, 31.0]
+    assert L.x264o_log2_f(3) == f32(0.58496) + f32(1) and L.x264o_log2_f(0xffffffff) == f32(0.99435) + f32(31)
+    assert L.x264o_log2_f(22000) == f32(float("%.5f" % np.log2(1 + ((22000 << 17 >> 24) & 0x7f) / 128))) + f32(14)          # 22000 = 2^14 * 1.3427...
+    # x264_exp2fix8: 256 at 0, halves every 6 quantiser steps, saturates
+    assert [L.x264o_exp2fix8_f(x) for x in (0.0, 6.0, -6.0, 12.0, 3.0, 49.0, -48.1)] == [256, 128, 512, 64, 181, 0, 0xffff]
+    rnd = np.random.default_rng(1)
+    for x in rnd.uniform(-20, 20, 200).astype(np.float32):
+        i = int(f32(f32(x * f32(-64.0 / 6.0)) + f32(512.5)))
+        want = 0 if i < 0 else 0xffff if i > 1023 else ((int(np.rint(256 * (2 ** ((i & 63) / 64) - 1))) + 256) << (i >> 6)) >> 8
+        assert L.x264o_exp2fix8_f(float(x)) == want, x
+    # x264_ratecontrol_mb_qp: (int)(qpm + offset + 0.5f), two float additions
+    assert [L.x264o_mb_qp_f(28.4, o) for o in (0.0, 0.09, 0.11, -0.9, -0.91, 3.1)] == [28, 28, 29, 28, 27, 32]
+    for qpm, off in zip(rnd.uniform(10, 51, 200).astype(np.float32), rnd.uniform(-8, 8, 200).astype(np.float32)):
+        assert L.x264o_mb_qp_f(float(qpm), float(off)) == int(f32(f32(qpm + off) + f32(0.5)))

@@ -41,7 +41,7 @@ def run(gpu, w, h, types, seed, streams=1, bframes=3, pyramid=1, weightp=0, weig
         pic, _ = dpb.plan(pt, disp, bgop.follow_of(order, k), weight=(weights or {}).get(disp) if pt == 2 else None)
         pic.qp = 20 if pt <= 1 else 23 if pt == 2 else 25 if pt == 4 else 24
         if qp_frac:          # a rate-controlled session's float quantiser: qp + frac / 256 (enters the AQ quantisers before the rounding)
-            pic.qp_frac_q8 = qp_frac[k % len(qp_frac)]
+            pic.qpm = pic.qp + qp_frac[k % len(qp_frac)] / 256.0          # (exact in a single float)
         if pt >= 3 and direct != "spatial":          # --direct temporal / auto (the running scores pick the mode as x264's slice_header_init does)
             dpb.set_direct(pic, direct == "temporal" or (direct == "auto" and not dscore[1] > dscore[0]), direct == "auto")
         o_mb, o_lv = og.encode_pic(frames[disp], pic)
@@ -95,7 +95,7 @@ def run(gpu, w, h, types, seed, streams=1, bframes=3, pyramid=1, weightp=0, weig
     (96, 80, "IBPBBPBBBPP", 52, dict(cabac=0, trellis=0, refs=1, weightb=0, partitions=0xf07)),
     (176, 144, "IBBPBP", 53, dict(cabac=0, trellis=0, me_method=2, dct8x8=0, psy_rd_q8=0, chroma_qp_offset=0)),
     (208, 112, "IBBBPBP", 54, dict(cabac=0, trellis=0, me_method=0, refs=4, dpb=4, slices=3, slices_plain=1)),
-    (128, 96, "IBBPBBP", 55, dict(cabac=0, trellis=0, me_method=3, me_range=8, aq_mode=1, aq_strength_q8=266)),
+    (128, 96, "IBBPBBP", 55, dict(cabac=0, trellis=0, me_method=3, me_range=8, aq_mode=1, aq_strength=1.0397)),
     # --subme 9 in full: the chosen B inter type's vectors on RD cost — x264_me_refine_qpel_rd per list, x264_me_refine_bidir_rd of the bi-predicted parts (k_mb_b_rdrefine.inc)
     (176, 144, "IBBBP", 20, dict(subme=9, rd=3)),                                   # the inter site alone
     (176, 144, "IBBBPBBP", 33, dict(subme=9, rd=63 | 64)),                          # x264's subme 9: every site + deblock-aware RD
@@ -257,7 +257,7 @@ def test_explicit_luma_weights_bitexact_and_decodable(gpu, types, weights, weigh
     ("IBBBP", dict(direct="auto", me_method=2)),
     ("IBP", dict(subme=9, rd=63 | 64)),                                                                    # x264's subme 9 on medium's other tools
     ("IBP", dict(subme=8, rd=63, refs=2, trellis=127)),
-    ("IBBP", dict(subme=7, rd=1, aq_mode=1, aq_strength_q8=266)),
+    ("IBBP", dict(subme=7, rd=1, aq_mode=1, aq_strength=1.0397)),
     ("IBBP", dict(cabac=0, trellis=0)),                                                                    # B decisions on CAVLC bit counts
 ])
 def test_round4_paths_at_headline_size(gpu, types, over):

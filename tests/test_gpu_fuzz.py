@@ -18,7 +18,7 @@ def random_case(rnd):
     h = max(16, 16 * rnd.randint(1, 10) - rnd.choice([0, 0, 2, 8, 12]))
     dct = rnd.randint(0, 1)
     kw = dict(refs=rnd.randint(1, 5), partitions=rnd.choice([0, 1, 2, 3, 4, 5, 6, 7]) if dct else rnd.choice([0, 1, 2, 3]), dct8x8=dct,
-              subme=rnd.choice([0, 1, 2, 3, 4, 5, 6, 7, 8, 9]), me_method=rnd.choice([0, 1, 1, 2, 3]), chroma_me=rnd.randint(0, 1), mixed_refs=rnd.randint(0, 1), aq_mode=rnd.randint(0, 1), aq_strength_q8=rnd.choice([133, 266, 400]), me_range=rnd.choice([4, 8, 16]),
+              subme=rnd.choice([0, 1, 2, 3, 4, 5, 6, 7, 8, 9]), me_method=rnd.choice([0, 1, 1, 2, 3]), chroma_me=rnd.randint(0, 1), mixed_refs=rnd.randint(0, 1), aq_mode=rnd.randint(0, 1), aq_strength=rnd.choice([0.51985, 1.0397, 1.55955]), me_range=rnd.choice([4, 8, 16]),
               qp_i=rnd.randint(0, 51), qp_p=rnd.randint(0, 51), deblock=rnd.randint(0, 1), dct_decimate=rnd.randint(0, 1),
               deblock_alpha=rnd.randint(-3, 3), deblock_beta=rnd.randint(-3, 3), chroma_qp_offset=rnd.randint(-6, 6),
               fast_pskip=rnd.randint(0, 1), mv_range=rnd.choice([0, 0, 32, 64, 128, 512]), cabac=rnd.randint(0, 1))
@@ -124,7 +124,7 @@ def test_random_multi_stream_quantisers_bitexact(gpu, seed):
             st = 2 if i == 0 else 0
             mode = rnd.choice(["shared", "stream", "offsets", "both"])
             qps = [rnd.randint(8, 46) for _ in range(S)] if mode in ("stream", "both") else None
-            off = nprng.integers(-1500, 1500, (S, n)).astype(np.int16) if mode in ("offsets", "both") else None
+            off = (nprng.integers(-1500, 1500, (S, n)) / np.float32(256) + nprng.random((S, n), np.float32) / 64).astype(np.float32) if mode in ("offsets", "both") else None
             arr = None if qps is None else np.array(qps, np.int8)
             lib.check(lib.x264gpu_encoder_set_stream_qps(gg.h, None if arr is None else arr.ctypes.data), "set_stream_qps")
             d_off = None if off is None else torch.from_numpy(off.copy()).cuda()

@@ -264,7 +264,7 @@ def encode_with_decisions(h_, w, h, frames):
         qp, sc, costs = C.c_int(), C.c_int(), (C.c_int32 * 4)()
         assert H.x264host_last_decision(h_, C.byref(qp), C.byref(sc), costs) == 0
         assert out.i_pts == len(rows)
-        rows.append((int(out.b_keyframe), qp.value, sc.value, list(costs), int(out.i_type)))
+        rows.append((int(out.b_keyframe), qp.value, sc.value, list(costs), int(out.i_type), float(H.x264host_last_qpm(h_))))          # [5]: the float quantiser (x264 rc->qpm) handed to the device
         rec = np.zeros(w * h * 3 // 2, np.uint8)
         assert H.x264host_get_recon(h_, rec.ctypes.data) == 0
         recons.append(rec)
@@ -322,7 +322,7 @@ def test_crf_follows_the_lookahead_complexity(gpu):
     cs = cc = apq = apn = 0.0
     last_i = True
     qps = []
-    for i, (key, qp, sc, costs, _typ) in enumerate(rows):
+    for i, (key, qp, sc, costs, _typ, qpm) in enumerate(rows):
         satd = costs[0] if key else costs[1]
         cs, cc = cs * 0.5 + satd, cc * 0.5 + 1
         q = (cs / cc) ** (1 - qcomp) / rfc
@@ -335,13 +335,14 @@ def test_crf_follows_the_lookahead_complexity(gpu):
         last_i = bool(key)
         qps.append(int(qpf + 0.5))
     assert [r[1] for r in rows] == qps, (qps, rows)
+    assert all(abs(r[5] - r[1]) <= 0.5 + 1e-6 and r[5] != 0 for r in rows)          # ... each the rounding of the float quantiser the macroblock quantisers start from
     assert len(set(qps)) > 1 and rows[5][0] == 1                     # the cut is an IDR and the quantiser moves with the content
     dec = O.h264_decode(stream, len(frames), w, h)
     assert eff.rc.i_aq_mode == 1                                    # x264's default: variance AQ rides on CRF
-    og = O.OracleEncoder(O.default_config(w, h, partitions=7, refs=3, dct8x8=1, chroma_me=1, mixed_refs=1, aq_mode=1, aq_strength_q8=266, **eff_kw(eff)))
+    og = O.OracleEncoder(O.default_config(w, h, partitions=7, refs=3, dct8x8=1, chroma_me=1, mixed_refs=1, aq_mode=1, aq_strength=1.0397, **eff_kw(eff)))
     for i, f in enumerate(frames):
         np.testing.assert_array_equal(dec[i], recons[i], err_msg=f"decoded picture {i}")
-        og.set_qp(rows[i][1], rows[i][1])
+        og.set_qp(rows[i][1], rows[i][1]); og.set_qpm(rows[i][5])          # x264_ratecontrol_mb_qp: (int)(rc->qpm + the AQ offset + 0.5f)
         og.encode(f, 2 if rows[i][0] else 0)
         np.testing.assert_array_equal(og.recon(), recons[i], err_msg=f"oracle pipeline picture {i}")
 
@@ -449,8 +450,8 @@ def test_crf_with_macroblock_tree(gpu, monkeypatch):
     dec = O.h264_decode(stream, n, w, h)
     ol = O.OracleLookahead(w, h)
     infos = [ol.frame_cost(f, i == 0)[1] for i, f in enumerate(frames)]
-    aqs = [O.aq_offsets(f, w, h, 266) for f in frames]
-    og = O.OracleEncoder(O.default_config(w, h, partitions=7, refs=3, dct8x8=1, chroma_me=1, mixed_refs=1, aq_mode=1, aq_strength_q8=266, **eff_kw(eff)))
+    aqs = [O.aq_offsets(f, w, h, O.AQ1) for f in frames]
+    og = O.OracleEncoder(O.default_config(w, h, partitions=7, refs=3, dct8x8=1, chroma_me=1, mixed_refs=1, aq_mode=1, aq_strength=1.0397, **eff_kw(eff)))
     bw, bh = (w + 15) // 16, (h + 15) // 16
     lowered = 0
     for i, f in enumerate(frames):
@@ -458,10 +459,10 @@ def test_crf_with_macroblock_tree(gpu, monkeypatch):
         last = i                                                            # the window: this picture + the P pictures queued behind it
         while last + 1 < min(n, i + look + 1) and types[last + 1] == 0:
             last += 1
-        off = O.mbtree(bw, bh, infos[i:last + 1], aqs[i:last + 1], int(1280 * (1 - 0.6) + 0.5))
+        off = O.mbtree(bw, bh, infos[i:last + 1], aqs[i:last + 1], O.TREE)
         lowered += int((off < aqs[i]).sum())
         og.set_mb_qp_offsets(off)
-        og.set_qp(rows[i][1], rows[i][1])
+        og.set_qp(rows[i][1], rows[i][1]); og.set_qpm(rows[i][5])
         og.encode(f, 2 if types[i] == 2 else 3 if types[i] == 1 else 0)
         np.testing.assert_array_equal(og.recon(), recons[i], err_msg=f"oracle chain picture {i}")
     assert lowered > 50
@@ -1014,7 +1015,7 @@ def test_cross_session_batcher_on_the_device(gpu):
 
 
 def test_cross_session_batcher_with_crf_on_the_device(gpu):
-    """CRF sessions in one batch: every stream carries its own float quantiser (integer part + fraction, x264gpu_pic.qp / qp_frac_q8) through one
+    """CRF sessions in one batch: every stream carries its own float quantiser (x264gpu_pic.qp and its float quantiser qpm) through one
     lock-step launch; byte-identical to the sessions run one by one (round-3 advisor finding: the device used to refuse differing fractions)"""
     from test_bframes_cpu import _batch
     r = _batch(6, 176, 144, 9, ["crf=24", "keyint=8", "min-keyint=8", "scenecut=0", "b-adapt=0", "bframes=2", "no-mbtree"], gpu=True)

@@ -109,8 +109,8 @@ def test_plain_slices_carry_the_intra_statistics(gpu, w, h, slices, kw):
     (64, 48, 4, dict(mixed_refs=1, refs=1, partitions=3)),                   # one reference: the flag is inert
     (176, 144, 4, dict(aq_mode=1)),                                          # variance AQ: a quantiser per macroblock
     (352, 288, 5, dict(aq_mode=1, refs=3, partitions=7, dct8x8=1, chroma_me=1, mixed_refs=1, qp_i=24, qp_p=27)),
-    (208, 120, 4, dict(aq_mode=1, aq_strength_q8=400, partitions=6, dct8x8=1, qp_i=40, qp_p=44)),       # strong AQ near the top of the range
-    (96, 80, 4, dict(aq_mode=1, aq_strength_q8=133, partitions=3, qp_i=4, qp_p=6, deblock=0)),          # ... and near the bottom
+    (208, 120, 4, dict(aq_mode=1, aq_strength=1.55955, partitions=6, dct8x8=1, qp_i=40, qp_p=44)),       # strong AQ near the top of the range
+    (96, 80, 4, dict(aq_mode=1, aq_strength=0.51985, partitions=3, qp_i=4, qp_p=6, deblock=0)),          # ... and near the bottom
     (176, 144, 4, dict(me_method=3)),                                        # --me esa: exhaustive search, 16x16 only
     (208, 120, 4, dict(me_method=3, partitions=3, refs=2, me_range=8, chroma_me=1)),      # ... in every partition
     (96, 80, 4, dict(me_method=3, partitions=3, refs=3, mixed_refs=1, me_range=16, subme=5)),
@@ -384,7 +384,7 @@ def test_non_idr_intra_picture_keeps_the_references(gpu):
 
 
 def test_external_mb_qp_offsets(gpu):
-    """x264gpu_encoder_set_mb_qp_offsets: the lookahead's per-macroblock quantiser offsets (AQ - macroblock-tree, Q8) instead of
+    """x264gpu_encoder_set_mb_qp_offsets: the lookahead's per-macroblock quantiser offsets (AQ - macroblock-tree, single floats) instead of
     the encoder's own AQ; NULL returns to the configured mode"""
     import torch
     from gpu_enc import GpuEncoder
@@ -396,7 +396,7 @@ def test_external_mb_qp_offsets(gpu):
     rng = np.random.default_rng(5)
     n = og.n
     for i, f in enumerate(frames):
-        off = None if i == 3 else rng.integers(-1800, 1500, n).astype(np.int16)
+        off = None if i == 3 else (rng.integers(-1800, 1500, n) / np.float32(256) + rng.random(n, np.float32) / 64).astype(np.float32)
         og.set_mb_qp_offsets(off)
         d_off = None if off is None else torch.from_numpy(off[None].copy()).cuda()
         lib.check(lib.x264gpu_encoder_set_mb_qp_offsets(gg.h, None if d_off is None else d_off.data_ptr()), "set_mb_qp_offsets")

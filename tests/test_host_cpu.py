@@ -284,7 +284,7 @@ def test_entropy_closed_loop_random(seed, cabac):
         h = max(16, 16 * rnd.randint(1, 7) - rnd.choice([0, 0, 2, 8, 12]))
         dct = rnd.randint(0, 1)
         kw = dict(refs=rnd.randint(1, 5), partitions=rnd.choice([0, 1, 2, 3, 4, 5, 6, 7]) if dct else rnd.choice([0, 1, 2, 3]), dct8x8=dct,
-                  subme=rnd.choice([0, 2, 5, 7]), me_method=rnd.randint(0, 3), chroma_me=rnd.randint(0, 1), mixed_refs=rnd.randint(0, 1), aq_mode=rnd.randint(0, 1), aq_strength_q8=rnd.choice([133, 266, 400]), qp_i=rnd.randint(0, 51), qp_p=rnd.randint(0, 51),
+                  subme=rnd.choice([0, 2, 5, 7]), me_method=rnd.randint(0, 3), chroma_me=rnd.randint(0, 1), mixed_refs=rnd.randint(0, 1), aq_mode=rnd.randint(0, 1), aq_strength=rnd.choice([0.51985, 1.0397, 1.55955]), qp_i=rnd.randint(0, 51), qp_p=rnd.randint(0, 51),
                   deblock=rnd.randint(0, 1), dct_decimate=rnd.randint(0, 1), chroma_qp_offset=rnd.randint(-6, 6))
         nfr = rnd.randint(2, 6)
         frames = synth_frames(w, h, nfr, seed=rnd.randint(0, 10 ** 6))

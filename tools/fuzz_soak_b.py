@@ -41,7 +41,7 @@ def random_b_case(rnd):
         else:
             kw.update(slices=rnd.randint(2, mbh), slices_plain=1)
     if rnd.random() < 0.3:           # variance AQ: per-macroblock quantisers, the within-1 rule of x264_macroblock_analyse, mb_qp_delta in the RD costs
-        kw.update(aq_mode=1, aq_strength_q8=rnd.choice([133, 266, 400]))
+        kw.update(aq_mode=1, aq_strength=rnd.choice([0.51985, 1.0397, 1.55955]))
         if rnd.random() < 0.6:
             kw["_qp_frac"] = [rnd.randint(-128, 127) for _ in range(4)]
     weightp = rnd.choice([0, 0, 2]) if refs >= 2 else 0

@@ -64,11 +64,10 @@ struct EncK {
     const Q8 *q8tab;          // [52][2]: intra, inter
     const int *lambda_tab;    // [52]
     const uint16_t *cost_all; // [52][2 * MVCOST_HALF]
-    const int8_t *stream_qp;  // optional [2][streams]: each stream's slice quantiser (x264gpu_encoder_set_stream_qps) and, behind it, the fraction of its float
-                              // quantiser in 1/256 (x264gpu_pic.qp_frac_q8 of that stream); k.qp / k.qp_frac_q8 otherwise
-    int stream_qp_n;          // streams (the stride between the two halves of stream_qp)
-    int aq_strength_q8;
-    int qp_frac_q8;           // the picture's quantiser is qp + qp_frac_q8 / 256 (x264gpu_pic.qp_frac_q8): enters the per-macroblock quantisers before the rounding
+    const int8_t *stream_qp;  // optional [streams]: each stream's slice quantiser (x264gpu_encoder_set_stream_qps) and
+    const float *stream_qpm;  // ... [streams] its float quantiser (x264gpu_pic.qpm of that stream; never 0 here); k.qp / k.qpm otherwise
+    float aq_strength;        // x264_adaptive_quant_frame's strength of mode 1 (aq-strength * 1.0397f)
+    float qpm;                // the picture's float quantiser (x264 rc->qpm; (float)qp in constant-quantiser sessions): enters the per-macroblock quantisers before the rounding
     int qp_snap;              // --aq-mode != 0: a macroblock quantiser within 1 of the previous macroblock's takes that one (x264_macroblock_analyse)
     int *wf_progress;         // [streams][2][WFG_ROWS]: row counters of the wavefront kernels when ONE stream spans several workgroups
     // motion side data of the raster macroblock loop (k_mb.hip.h; x264: h->mb.mvr, frame->mv16x16, frame->mb_type)
@@ -100,8 +99,48 @@ struct EncK {
 };
 // the slice quantiser of stream s
 __device__ __forceinline__ int slice_qp(const EncK &k, int s) { return k.stream_qp ? (int)k.stream_qp[s] : k.qp; }
-// ... in 1/256, with the fraction of the stream's float quantiser (rate-controlled sessions; x264 rc->qpm)
-__device__ __forceinline__ int slice_qp_q8(const EncK &k, int s) { return k.stream_qp ? (int)k.stream_qp[s] * 256 + (int)k.stream_qp[k.stream_qp_n + s] : k.qp * 256 + k.qp_frac_q8; }
+// ... the stream's float quantiser (rate-controlled sessions; x264 rc->qpm)
+__device__ __forceinline__ float slice_qpm(const EncK &k, int s) { return k.stream_qp ? k.stream_qpm[s] : k.qpm; }
+// x264's single-float helpers (common/common.h x264_log2, x264_exp2fix8; ratecontrol.c x264_ratecontrol_mb_qp), evaluated as the C source reads: every
+// product and sum rounded on its own (no fused multiply-add), so that the host checker's -ffp-contract=off build and the device agree to the bit
+// (the compiler's __fmul_rn / __fadd_rn are plain operators that it may fuse; these carry no contraction flag into whatever they are inlined into)
+__device__ __forceinline__ float f_mul(float a, float b) {
+#pragma clang fp contract(off)
+    return a * b; }
+__device__ __forceinline__ float f_add(float a, float b) {
+#pragma clang fp contract(off)
+    return a + b; }
+__device__ __forceinline__ float f_sub(float a, float b) {
+#pragma clang fp contract(off)
+    return a - b; }
+__device__ __forceinline__ float f_div(float a, float b) {
+#pragma clang fp contract(off)
+    return a / b; }
+static __constant__ float c_x264_log2_lut[128] = {
+#include "x264gpu_log2f_lut.inc"
+};
+static __constant__ uint16_t c_x264_exp2_lut[64] = {
+#include "x264gpu_exp2_lut.inc"
+};
+__device__ __forceinline__ float x264_log2(unsigned x) { const int lz = __builtin_clz(x); return f_add(c_x264_log2_lut[((x << lz) >> 24) & 0x7f], (float)(31 - lz)); }
+__device__ __forceinline__ int x264_exp2fix8(float x)
+{
+    const int i = (int)f_add(f_mul(x, -64.f / 6.f), 512.5f);
+    if (i < 0) return 0;
+    if (i > 1023) return 0xffff;
+    return (int)(((unsigned)(c_x264_exp2_lut[i & 63] + 256) << (i >> 6)) >> 8);
+}
+// clip3((int)(qpm + offset + 0.5f), 1, 51)
+__device__ __forceinline__ int x264_mb_qp(float qpm, float offset) { return min(max((int)f_add(f_add(qpm, offset), 0.5f), 1), 51); }
+// mbtree_propagate_cost (common/mc.c), one block; fps_factor = 1 / 512 (constant frame rate, MBTREE_PRECISION 0.5f)
+__device__ __forceinline__ int x264_propagate_amount(int propagate_in, int intra_cost, int inter_cost, int inv_qscale)
+{
+    if (!intra_cost) return 0;
+    const float propagate_intra = (float)(intra_cost * inv_qscale);
+    const float propagate_amount = f_add((float)propagate_in, f_mul(propagate_intra, 1.f / 512.f));
+    const float propagate_num = (float)(intra_cost - inter_cost), propagate_denom = (float)intra_cost;
+    return min((int)f_add(f_div(f_mul(propagate_amount, propagate_num), propagate_denom), 0.5f), 32767);
+}
 
 
 __device__ __forceinline__ const uint8_t *ref_plane00(const EncK &k, int s, int r)

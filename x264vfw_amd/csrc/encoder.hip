@@ -61,10 +61,11 @@ struct x264gpu_encoder {
     int *wf_progress = nullptr;          // [streams][2][WFG_ROWS] row counters of the multi-workgroup wavefront kernels
     // adaptive quantisation: per-macroblock quantisers and the per-quantiser tables (built when aq_mode != 0)
     uint8_t *mbqp = nullptr;
-    const int16_t *ext_off = nullptr;    // quantiser offsets handed in by the caller (lookahead), [streams][nmb] Q8
-    int8_t *stream_qp = nullptr;         // device copies of the per-stream slice quantisers (x264gpu_encoder_set_stream_qps): two, used in turn,
+    const float *ext_off = nullptr;      // quantiser offsets handed in by the caller (lookahead), [streams][nmb] single floats
+    int8_t *stream_qp = nullptr; float *stream_qpm = nullptr;         // device copies of the per-stream slice quantisers (x264gpu_encoder_set_stream_qps): two, used in turn,
     int stream_qp_sel = 0;               // so that an encode still in flight on the caller's stream keeps reading the set it was issued with
     bool use_stream_qp = false;
+    float qpm_next = 0.f;                // x264gpu_encoder_set_qpm: the float quantiser of x264gpu_encode_frames' pictures (0 = the integer one)
     Q4 *q4tab = nullptr; Q8 *q8tab = nullptr; int *lambda_tab = nullptr; uint16_t *cost_all = nullptr;
     // optional per-stage profiling: (NSTAGE+1) events per armed call
     hipEvent_t *ev = nullptr;
@@ -191,23 +192,25 @@ int x264gpu_encoder_set_qp(x264gpu_encoder *e, int qp_i, int qp_p)
     return X264GPU_OK;
 }
 
-int x264gpu_encoder_set_mb_qp_offsets(x264gpu_encoder *e, const int16_t *d_offsets_q8)
+int x264gpu_encoder_set_mb_qp_offsets(x264gpu_encoder *e, const float *d_offsets)
 {
     ARG_TRY(e);
-    e->ext_off = d_offsets_q8;
+    e->ext_off = d_offsets;
     return X264GPU_OK;
 }
 
-// every stream its own slice quantiser and (fracs != NULL) the fraction of its float quantiser in 1/256: [quantisers][fractions] per set
-static int set_stream_qps_q8(x264gpu_encoder *e, const int8_t *qps, const int8_t *fracs)
+// every stream its own slice quantiser and its float quantiser (qpms == NULL: the integer one as a float): two sets, used in turn
+static int set_stream_qps_f(x264gpu_encoder *e, const int8_t *qps, const float *qpms)
 {
     const size_t S = (size_t)e->cfg.streams;
     for (size_t s = 0; s < S; s++) ARG_TRY(qps[s] >= 0 && qps[s] <= 51);
-    if (!e->stream_qp) HIP_TRY(hipMalloc((void **)&e->stream_qp, 4 * S));
+    if (!e->stream_qp) HIP_TRY(hipMalloc((void **)&e->stream_qp, 2 * S));
+    if (!e->stream_qpm) HIP_TRY(hipMalloc((void **)&e->stream_qpm, 2 * S * sizeof(float)));
     e->stream_qp_sel ^= 1;
-    int8_t *dst = e->stream_qp + (size_t)e->stream_qp_sel * 2 * S;
-    HIP_TRY(hipMemcpy(dst, qps, S, hipMemcpyHostToDevice));
-    if (fracs) HIP_TRY(hipMemcpy(dst + S, fracs, S, hipMemcpyHostToDevice)); else HIP_TRY(hipMemset(dst + S, 0, S));
+    std::vector<float> f(S);
+    for (size_t s = 0; s < S; s++) f[s] = qpms && qpms[s] != 0.f ? qpms[s] : (float)qps[s];
+    HIP_TRY(hipMemcpy(e->stream_qp + (size_t)e->stream_qp_sel * S, qps, S, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(e->stream_qpm + (size_t)e->stream_qp_sel * S, f.data(), S * sizeof(float), hipMemcpyHostToDevice));
     e->use_stream_qp = true;
     return X264GPU_OK;
 }
@@ -216,7 +219,20 @@ int x264gpu_encoder_set_stream_qps(x264gpu_encoder *e, const int8_t *qps)
 {
     ARG_TRY(e);
     if (!qps) { e->use_stream_qp = false; return X264GPU_OK; }
-    return set_stream_qps_q8(e, qps, nullptr);
+    return set_stream_qps_f(e, qps, nullptr);
+}
+int x264gpu_encoder_set_stream_qpms(x264gpu_encoder *e, const int8_t *qps, const float *qpms)
+{
+    ARG_TRY(e);
+    if (!qps) { e->use_stream_qp = false; return X264GPU_OK; }
+    if (qpms) for (int s = 0; s < e->cfg.streams; s++) ARG_TRY(qpms[s] == 0.f || (qpms[s] > (float)qps[s] - 1.f && qpms[s] < (float)qps[s] + 1.f));
+    return set_stream_qps_f(e, qps, qpms);
+}
+int x264gpu_encoder_set_qpm(x264gpu_encoder *e, float qpm)
+{
+    ARG_TRY(e && qpm >= 0.f && qpm < 52.f);
+    e->qpm_next = qpm;
+    return X264GPU_OK;
 }
 
 static void profile_free(x264gpu_encoder *e)
@@ -272,7 +288,7 @@ void x264gpu_encoder_destroy(x264gpu_encoder *e)
     (void)hipFree(e->cab_out);
     (void)hipFree(e->sl_stat); (void)hipFree(e->sl_rerun); (void)hipFree(e->perm); (void)hipFree(e->wtime);
     (void)hipFree(e->prof);
-    (void)hipFree(e->stream_qp); (void)hipFree(e->mbqp); (void)hipFree(e->q4tab); (void)hipFree(e->q8tab); (void)hipFree(e->lambda_tab); (void)hipFree(e->cost_all);
+    (void)hipFree(e->stream_qp); (void)hipFree(e->stream_qpm); (void)hipFree(e->mbqp); (void)hipFree(e->q4tab); (void)hipFree(e->q8tab); (void)hipFree(e->lambda_tab); (void)hipFree(e->cost_all);
     delete e;
 }
 
@@ -379,7 +395,7 @@ static int encode_core(x264gpu_encoder *e, const uint8_t *d_i420, const x264gpu_
     ARG_TRY(pic.dst >= 0 && pic.dst < e->slots && pic.qp >= 0 && pic.qp <= 51);
     ARG_TRY(!bslice || e->cfg.dpb > 0);      // B pictures: with RD (subme >= 7) CABAC sizes only; below, x264 analyses B slices without RD
     const int n0 = slice_type == X264GPU_SLICE_I ? 0 : pic.nref[0], n1 = bslice ? pic.nref[1] : 0;
-    ARG_TRY(pic.qp_frac_q8 >= -128 && pic.qp_frac_q8 <= 127);
+    ARG_TRY(pic.qpm == 0.f || (pic.qpm > (float)pic.qp - 1.f && pic.qpm < (float)pic.qp + 1.f));          // qp is the rounding of qpm
     ARG_TRY(n0 >= 0 && n0 <= 7 && n1 >= 0 && n1 <= 3 && n0 + n1 <= 8 && (slice_type == X264GPU_SLICE_I || n0 > 0) && (!bslice || n1 > 0));      // list 0: up to 5 pictures + --weightp duplicates
     for (int l = 0; l < 2; l++) for (int r = 0; r < (l ? n1 : n0); r++) ARG_TRY(pic.slot[l][r] >= 0 && pic.slot[l][r] < e->slots && pic.slot[l][r] != pic.dst);
     const int S = e->cfg.streams;
@@ -506,8 +522,8 @@ static int encode_core(x264gpu_encoder *e, const uint8_t *d_i420, const x264gpu_
     hipLaunchKernelGGL(k_ingest, dim3((k.cw / 4 + 255) / 256, k.ch, S), dim3(256), 0, st, k);
     // per-macroblock quantisers: always materialised (the macroblock loop reads every quantiser-dependent value per macroblock)
     const bool aq = e->cfg.aq_mode != 0 || e->ext_off != nullptr || e->use_stream_qp;
-    k.stream_qp = e->use_stream_qp ? e->stream_qp + (size_t)e->stream_qp_sel * 2 * e->cfg.streams : nullptr; k.stream_qp_n = e->cfg.streams;
-    k.mbqp = e->mbqp; k.q4tab = e->q4tab; k.q8tab = e->q8tab; k.lambda_tab = e->lambda_tab; k.cost_all = e->cost_all; k.aq_strength_q8 = e->cfg.aq_strength_q8; k.qp_snap = e->cfg.aq_mode != 0; k.qp_frac_q8 = pic.qp_frac_q8;
+    k.stream_qp = e->use_stream_qp ? e->stream_qp + (size_t)e->stream_qp_sel * e->cfg.streams : nullptr; k.stream_qpm = e->use_stream_qp ? e->stream_qpm + (size_t)e->stream_qp_sel * e->cfg.streams : nullptr;
+    k.mbqp = e->mbqp; k.q4tab = e->q4tab; k.q8tab = e->q8tab; k.lambda_tab = e->lambda_tab; k.cost_all = e->cost_all; k.aq_strength = e->cfg.aq_strength; k.qp_snap = e->cfg.aq_mode != 0; k.qpm = pic.qpm != 0.f ? pic.qpm : (float)pic.qp;
     if (e->ext_off || !e->cfg.aq_mode) hipLaunchKernelGGL(k_apply_qp_offsets, dim3((k.nmb + 255) / 256, S), dim3(256), 0, st, k, e->ext_off);
     else hipLaunchKernelGGL(k_aq, dim3((k.nmb + 15) / 16, S), dim3(256), 0, st, k);
     mask |= 1;
@@ -576,7 +592,7 @@ int x264gpu_encode_frames(x264gpu_encoder *e, const uint8_t *d_i420, int slice_t
     if (slice_type == X264GPU_SLICE_I) { e->have = 0; e->poc = 0; }                    // IDR empties the DPB
     x264gpu_pic pic;
     memset(&pic, 0, sizeof(pic));
-    pic.slice_type = slice_type; pic.qp = slice_type == X264GPU_SLICE_P ? e->cfg.qp_p : e->cfg.qp_i; pic.poc = e->poc; pic.dst = e->cur; pic.keep = 1;
+    pic.slice_type = slice_type; pic.qp = slice_type == X264GPU_SLICE_P ? e->cfg.qp_p : e->cfg.qp_i; pic.poc = e->poc; pic.dst = e->cur; pic.keep = 1; pic.qpm = e->qpm_next;
     pic.nref[0] = slice_type == X264GPU_SLICE_P ? (e->have < e->cfg.refs ? e->have : e->cfg.refs) : 0;
     for (int r = 0; r < pic.nref[0]; r++) pic.slot[0][r] = (int8_t)((e->cur - 1 - r + 2 * e->ring) % e->ring);
     const int rc = encode_core(e, d_i420, pic, d_mb, d_levels, (hipStream_t)stream);
@@ -594,17 +610,17 @@ int x264gpu_encode_pictures(x264gpu_encoder *e, const uint8_t *d_i420, const x26
     // integer part and the fraction of a rate-controlled session's float quantiser — may differ
     const int S = e->cfg.streams;
     bool same_qp = true;
-    for (int s = 0; s < S; s++) ARG_TRY(pics[s].qp_frac_q8 >= -128 && pics[s].qp_frac_q8 <= 127);
+    for (int s = 0; s < S; s++) ARG_TRY(pics[s].qpm == 0.f || (pics[s].qpm > (float)pics[s].qp - 1.f && pics[s].qpm < (float)pics[s].qp + 1.f));
     for (int s = 1; s < S; s++) {
         ARG_TRY(pics[s].slice_type == pics[0].slice_type && pics[s].poc == pics[0].poc && pics[s].dst == pics[0].dst && pics[s].keep == pics[0].keep &&
                 pics[s].nref[0] == pics[0].nref[0] && pics[s].nref[1] == pics[0].nref[1] && !memcmp(pics[s].slot, pics[0].slot, sizeof(pics[0].slot)) &&
                 pics[s].blind_dupe == pics[0].blind_dupe && !memcmp(pics[s].wl0, pics[0].wl0, sizeof(pics[0].wl0)) && !memcmp(pics[s].wc0, pics[0].wc0, sizeof(pics[0].wc0)));
-        same_qp = same_qp && pics[s].qp == pics[0].qp && pics[s].qp_frac_q8 == pics[0].qp_frac_q8;
+        same_qp = same_qp && pics[s].qp == pics[0].qp && pics[s].qpm == pics[0].qpm;
     }
     if (!same_qp) {
-        std::vector<int8_t> q((size_t)S), f((size_t)S);
-        for (int s = 0; s < S; s++) { q[(size_t)s] = (int8_t)pics[s].qp; f[(size_t)s] = (int8_t)pics[s].qp_frac_q8; }
-        const int rc = set_stream_qps_q8(e, q.data(), f.data());
+        std::vector<int8_t> q((size_t)S); std::vector<float> f((size_t)S);
+        for (int s = 0; s < S; s++) { q[(size_t)s] = (int8_t)pics[s].qp; f[(size_t)s] = pics[s].qpm; }
+        const int rc = set_stream_qps_f(e, q.data(), f.data());
         if (rc != X264GPU_OK) return rc;
     }
     // --direct temporal / auto: each stream's own mode (the one field of the structure that may differ)

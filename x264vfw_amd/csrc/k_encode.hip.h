@@ -31,11 +31,8 @@ __global__ __launch_bounds__(256) void k_ingest(EncK k)
 
 // ------------------------------------------------------------------------------------------------
 // Adaptive quantisation, mode 1 (oracle compute_mb_qp; x264_adaptive_quant_frame): one 16-lane row per macroblock — lane r sums row
-// r of the luma macroblock and, for r < 8, row r of both chroma planes; the AC energy -> log2 in Q8 (table) -> quantiser offset.
+// r of the luma macroblock and, for r < 8, row r of both chroma planes; the AC energy -> x264_log2 -> quantiser offset, in x264's single floats.
 // ------------------------------------------------------------------------------------------------
-static __constant__ uint8_t c_aq_log2_lut[128] = {
-#include "x264gpu_aq_lut.inc"
-};
 __global__ __launch_bounds__(256) void k_aq(EncK k)
 {
     const int lane = threadIdx.x & 63, r = lane & 15, s = blockIdx.y;
@@ -62,17 +59,15 @@ __global__ __launch_bounds__(256) void k_aq(EncK k)
     sum = (unsigned)row16_sum((int)sum); sqr = (unsigned)row16_sum((int)sqr);
     su = (unsigned)row16_sum((int)su); squ = (unsigned)row16_sum((int)squ); sv = (unsigned)row16_sum((int)sv); sqv = (unsigned)row16_sum((int)sqv);
     const unsigned energy = (sqr - (sum * sum >> 8)) + (squ - (su * su >> 6)) + (sqv - (sv * sv >> 6));
-    const unsigned e1 = energy ? energy : 1u;
-    const int lz = 31 - __builtin_clz(e1), lg = lz * 256 + c_aq_log2_lut[((e1 << (31 - lz)) >> 24) & 0x7f];
-    const int adj = (k.aq_strength_q8 * (lg - 3693)) >> 8;
-    if (valid && r == 0) k.mbqp[(size_t)s * k.nmb + mbi] = (uint8_t)min(max((slice_qp_q8(k, s) + adj + 128) >> 8, 1), 51);          // x264_ratecontrol_mb_qp: round(qpm + offset)
+    const float adj = f_mul(k.aq_strength, f_sub(x264_log2(energy ? energy : 1u), 14.427f));
+    if (valid && r == 0) k.mbqp[(size_t)s * k.nmb + mbi] = (uint8_t)x264_mb_qp(slice_qpm(k, s), adj);          // x264_ratecontrol_mb_qp: (int)(qpm + offset + 0.5f)
 }
 
-// quantiser offsets decided by the lookahead (AQ - macroblock-tree, Q8) -> per-macroblock quantisers (oracle compute_mb_qp, ext_off_q8)
-__global__ __launch_bounds__(256) void k_apply_qp_offsets(EncK k, const int16_t *__restrict__ off)
+// quantiser offsets decided by the lookahead (AQ - macroblock-tree, single floats) -> per-macroblock quantisers (oracle compute_mb_qp, ext_off)
+__global__ __launch_bounds__(256) void k_apply_qp_offsets(EncK k, const float *__restrict__ off)
 {
     const int i = blockIdx.x * 256 + threadIdx.x, s = blockIdx.y;
-    if (i < k.nmb) k.mbqp[(size_t)s * k.nmb + i] = (uint8_t)(off ? min(max((slice_qp_q8(k, s) + (int)off[(size_t)s * k.nmb + i] + 128) >> 8, 1), 51) : slice_qp(k, s));   // no offsets: the slice's (or the stream's) quantiser as it is
+    if (i < k.nmb) k.mbqp[(size_t)s * k.nmb + i] = (uint8_t)(off ? x264_mb_qp(slice_qpm(k, s), off[(size_t)s * k.nmb + i]) : slice_qp(k, s));   // no offsets: the slice's (or the stream's) quantiser as it is
 }
 
 // QP_Y inheritance (oracle settle_mb_qp, 7.4.5): a macroblock that sends no mb_qp_delta takes its predecessor's quantiser; one wave per

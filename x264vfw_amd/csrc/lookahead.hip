@@ -182,22 +182,7 @@ __global__ __launch_bounds__(256) void k_la_cost(LaK k)
 }
 
 // ---- AQ offsets of a source picture (oracle x264o_aq_offsets): as k_aq, on the tight I420 input with clamped coordinates ----
-static __constant__ uint8_t c_la_log2_lut[128] = {
-#include "x264gpu_aq_lut.inc"
-};
-static __constant__ uint16_t c_la_exp2_lut[64] = {
-#include "x264gpu_exp2_lut.inc"
-};
-__device__ __forceinline__ int la_log2_q8(unsigned x) { const int lz = 31 - __builtin_clz(x); return lz * 256 + c_la_log2_lut[((x << (31 - lz)) >> 24) & 0x7f]; }
-__device__ __forceinline__ int la_inv_qscale(int aq_q8)
-{
-    const int i = (-aq_q8 * 64 + 786432 + 768) / 1536;
-    if (i < 0) return 0;
-    if (i > 1023) return 0xffff;
-    return (int)(((unsigned)(c_la_exp2_lut[i & 63] + 256) << (i >> 6)) >> 8);
-}
-
-__global__ __launch_bounds__(256) void k_la_aq(const uint8_t *__restrict__ i420, size_t i420_bytes, int w, int h, int bw, int nb, int strength_q8, int16_t *__restrict__ out, float *__restrict__ adj)
+__global__ __launch_bounds__(256) void k_la_aq(const uint8_t *__restrict__ i420, size_t i420_bytes, int w, int h, int bw, int nb, float strength, float *__restrict__ out, float *__restrict__ adj)
 {
     const int lane = threadIdx.x & 63, r = lane & 15, s = blockIdx.y;
     const int bi = (blockIdx.x * 4 + (threadIdx.x >> 6)) * 4 + (lane >> 4);
@@ -216,34 +201,34 @@ __global__ __launch_bounds__(256) void k_la_aq(const uint8_t *__restrict__ i420,
     const unsigned energy = (sqr - (sum * sum >> 8)) + (squ - (su * su >> 6)) + (sqv - (sv * sv >> 6));
     if (valid && r == 0) {
         if (adj) adj[(size_t)s * nb + bi] = sqrtf(sqrtf(sqrtf((float)energy + 1.f)));          // --aq-mode 2 / 3: (energy + 1)^(1/8), finished by k_la_aq_auto
-        else out[(size_t)s * nb + bi] = (int16_t)((strength_q8 * (la_log2_q8(energy ? energy : 1u) - 3693)) >> 8);
+        else out[(size_t)s * nb + bi] = f_mul(strength, f_sub(x264_log2(energy ? energy : 1u), 14.427f));          // x264_adaptive_quant_frame, mode 1
     }
 }
 // --aq-mode 2 / 3 (oracle x264o_aq_offsets_mode): the picture's mean and mean square of the per-macroblock values, summed in raster order by one
 // thread a stream (x264's own order: float addition does not reassociate), then every macroblock's offset
-__global__ __launch_bounds__(256) void k_la_aq_auto(const float *__restrict__ adj, int nb, int mode, int strength_q8, int16_t *__restrict__ out)
+__global__ __launch_bounds__(256) void k_la_aq_auto(const float *__restrict__ adj, int nb, int mode, float aqs, float *__restrict__ out)
 {
     const int s = blockIdx.x;
     __shared__ float sh[2];
     const float *a = adj + (size_t)s * nb;
     if (threadIdx.x == 0) {
         float sum = 0.f, sq = 0.f;
-        for (int i = 0; i < nb; i++) { const float q = a[i]; sum += q; sq = __fadd_rn(sq, __fmul_rn(q, q)); }
-        sh[0] = sum / (float)nb; sh[1] = sq / (float)nb;
+        for (int i = 0; i < nb; i++) { const float q = a[i]; sum = f_add(sum, q); sq = f_add(sq, f_mul(q, q)); }
+        sh[0] = f_div(sum, (float)nb); sh[1] = f_div(sq, (float)nb);
     }
     __syncthreads();
-    const float aqs = (float)strength_q8 / 256.f, mean = sh[0], strength = __fmul_rn(aqs, mean);
-    const float avg = __fsub_rn(mean, __fmul_rn(0.5f, __fsub_rn(sh[1], 14.f)) / mean);
+    const float mean = sh[0], strength = f_mul(aqs, mean);
+    const float avg = f_sub(mean, f_div(f_mul(0.5f, f_sub(sh[1], 14.f)), mean));
     for (int i = threadIdx.x; i < nb; i += 256) {
-        float q = __fmul_rn(strength, __fsub_rn(a[i], avg));
-        if (mode == 3) q = __fadd_rn(q, __fmul_rn(aqs, __fsub_rn(1.f, 14.f / __fmul_rn(a[i], a[i]))));
-        out[(size_t)s * nb + i] = (int16_t)lrintf(__fmul_rn(q, 256.f));
+        float q = f_mul(strength, f_sub(a[i], avg));
+        if (mode == 3) q = f_add(q, f_mul(aqs, f_sub(1.f, f_div(14.f, f_mul(a[i], a[i])))));
+        out[(size_t)s * nb + i] = q;
     }
 }
 
 // ---- macroblock-tree (oracle x264o_mbtree): one launch per picture walks its blocks and scatters the explained cost into the
 // reference picture's accumulator (saturation is applied when an accumulator is read: the addends are non-negative) ----
-__global__ __launch_bounds__(256) void k_mbtree_propagate(const int32_t *__restrict__ info, const int16_t *__restrict__ aq, const int32_t *__restrict__ prop_in,
+__global__ __launch_bounds__(256) void k_mbtree_propagate(const int32_t *__restrict__ info, const float *__restrict__ aq, const int32_t *__restrict__ prop_in,
                                                            int32_t *__restrict__ prop_ref, int bw, int bh)
 {
     const int nb = bw * bh, i = blockIdx.x * 256 + threadIdx.x, s = blockIdx.y;
@@ -251,9 +236,8 @@ __global__ __launch_bounds__(256) void k_mbtree_propagate(const int32_t *__restr
     const int32_t *fi = info + ((size_t)s * nb + i) * 4;
     const int intra = min(fi[0], 16383), best = min(fi[1], 16383), inter = min(best, intra);
     if (!fi[3] || !intra) return;
-    const int inv = la_inv_qscale(aq ? (int)aq[(size_t)s * nb + i] : 0);
-    const long long amt512 = (long long)min(prop_in[(size_t)s * nb + i], 32767) * 512 + (long long)intra * inv;
-    const int amount = (int)min((amt512 * (intra - inter) + 256ll * intra) / (512ll * intra), 32767ll);
+    const int inv = x264_exp2fix8(aq ? aq[(size_t)s * nb + i] : 0.f);
+    const int amount = x264_propagate_amount(min(prop_in[(size_t)s * nb + i], 32767), intra, inter, inv);          // mbtree_propagate_cost
     int32_t *ref = prop_ref + (size_t)s * nb;
     int x = (int)(short)(fi[2] & 0xffff), y = fi[2] >> 16;
     const int bx = i % bw, by = i / bw;
@@ -266,19 +250,19 @@ __global__ __launch_bounds__(256) void k_mbtree_propagate(const int32_t *__restr
     if (mby + 1 >= 0 && mby + 1 < bh) { if (mbx >= 0 && mbx < bw) atomicAdd(ref + (mby + 1) * bw + mbx, w2); if (mbx + 1 >= 0 && mbx + 1 < bw) atomicAdd(ref + (mby + 1) * bw + mbx + 1, w3); }
 }
 
-__global__ __launch_bounds__(256) void k_mbtree_finish(const int32_t *__restrict__ info, const int16_t *__restrict__ aq, const int32_t *__restrict__ prop,
-                                                        int nb, int strength_q8, int16_t *__restrict__ out)
+__global__ __launch_bounds__(256) void k_mbtree_finish(const int32_t *__restrict__ info, const float *__restrict__ aq, const int32_t *__restrict__ prop,
+                                                        int nb, float strength, float *__restrict__ out)
 {
     const int i = blockIdx.x * 256 + threadIdx.x, s = blockIdx.y;
     if (i >= nb) return;
-    const int a = aq ? (int)aq[(size_t)s * nb + i] : 0;
-    const int intra = (min(info[((size_t)s * nb + i) * 4], 16383) * la_inv_qscale(a) + 128) >> 8;
-    int off = a;
+    const float a = aq ? aq[(size_t)s * nb + i] : 0.f;
+    const int intra = (min(info[((size_t)s * nb + i) * 4], 16383) * x264_exp2fix8(a) + 128) >> 8;
+    float off = a;
     if (intra) {
         const int p2 = min(prop[(size_t)s * nb + i], 32767) * 2;
-        off = a - ((strength_q8 * (la_log2_q8((unsigned)(intra + p2)) - la_log2_q8((unsigned)intra))) >> 8);
+        off = f_sub(a, f_mul(strength, f_add(f_sub(x264_log2((unsigned)(intra + p2)), x264_log2((unsigned)intra)), 0.f)));
     }
-    out[(size_t)s * nb + i] = (int16_t)off;
+    out[(size_t)s * nb + i] = off;
 }
 
 }  // namespace x264gpu
@@ -373,31 +357,31 @@ int x264gpu_lookahead_frame_cost(x264gpu_lookahead *la, const uint8_t *d_i420, i
     return X264GPU_OK;
 }
 
-int x264gpu_lookahead_aq_offsets(x264gpu_lookahead *la, const uint8_t *d_i420, int strength_q8, int16_t *d_out_q8, void *stream)
+int x264gpu_lookahead_aq_offsets(x264gpu_lookahead *la, const uint8_t *d_i420, float strength, float *d_out, void *stream)
 {
-    ARG_TRY(la && d_i420 && d_out_q8);
+    ARG_TRY(la && d_i420 && d_out);
     const int nb = la->bw * la->bh;
     hipLaunchKernelGGL(k_la_aq, dim3((nb + 15) / 16, la->streams), dim3(256), 0, (hipStream_t)stream, d_i420, (size_t)la->w * la->h * 3 / 2, la->w, la->h, la->bw, nb,
-                       strength_q8, d_out_q8, (float *)nullptr);
+                       strength, d_out, (float *)nullptr);
     HIP_TRY(hipGetLastError());
     return X264GPU_OK;
 }
-int x264gpu_lookahead_aq_offsets_mode(x264gpu_lookahead *la, const uint8_t *d_i420, int mode, int strength_q8, int16_t *d_out_q8, void *stream)
+int x264gpu_lookahead_aq_offsets_mode(x264gpu_lookahead *la, const uint8_t *d_i420, int mode, float strength, float *d_out, void *stream)
 {
-    ARG_TRY(la && d_i420 && d_out_q8 && mode >= 1 && mode <= 3);
-    if (mode == 1) return x264gpu_lookahead_aq_offsets(la, d_i420, strength_q8, d_out_q8, stream);
+    ARG_TRY(la && d_i420 && d_out && mode >= 1 && mode <= 3);
+    if (mode == 1) return x264gpu_lookahead_aq_offsets(la, d_i420, strength, d_out, stream);
     const int nb = la->bw * la->bh;
     if (!la->aq_adj) HIP_TRY(hipMalloc((void **)&la->aq_adj, (size_t)la->streams * nb * sizeof(float)));
     hipLaunchKernelGGL(k_la_aq, dim3((nb + 15) / 16, la->streams), dim3(256), 0, (hipStream_t)stream, d_i420, (size_t)la->w * la->h * 3 / 2, la->w, la->h, la->bw, nb,
-                       strength_q8, d_out_q8, la->aq_adj);
-    hipLaunchKernelGGL(k_la_aq_auto, dim3(la->streams), dim3(256), 0, (hipStream_t)stream, la->aq_adj, nb, mode, strength_q8, d_out_q8);
+                       strength, d_out, la->aq_adj);
+    hipLaunchKernelGGL(k_la_aq_auto, dim3(la->streams), dim3(256), 0, (hipStream_t)stream, la->aq_adj, nb, mode, strength, d_out);
     HIP_TRY(hipGetLastError());
     return X264GPU_OK;
 }
 
-int x264gpu_lookahead_mbtree(x264gpu_lookahead *la, const int32_t *const *d_info, const int16_t *const *d_aq_q8, int n, int strength_q8, int16_t *d_out_q8, void *stream)
+int x264gpu_lookahead_mbtree(x264gpu_lookahead *la, const int32_t *const *d_info, const float *const *d_aq, int n, float strength, float *d_out, void *stream)
 {
-    ARG_TRY(la && d_info && n >= 1 && n <= 256 && d_out_q8);
+    ARG_TRY(la && d_info && n >= 1 && n <= 256 && d_out);
     hipStream_t st = (hipStream_t)stream;
     const int nb = la->bw * la->bh, S = la->streams;
     const size_t per = (size_t)S * nb;
@@ -409,8 +393,8 @@ int x264gpu_lookahead_mbtree(x264gpu_lookahead *la, const int32_t *const *d_info
     HIP_TRY(hipMemsetAsync(la->prop, 0, (size_t)n * per * sizeof(int32_t), st));
     const dim3 grid((nb + 255) / 256, S);
     for (int j = n - 1; j >= 1; j--)
-        hipLaunchKernelGGL(k_mbtree_propagate, grid, dim3(256), 0, st, d_info[j], d_aq_q8 ? d_aq_q8[j] : nullptr, la->prop + (size_t)j * per, la->prop + (size_t)(j - 1) * per, la->bw, la->bh);
-    hipLaunchKernelGGL(k_mbtree_finish, grid, dim3(256), 0, st, d_info[0], d_aq_q8 ? d_aq_q8[0] : nullptr, la->prop, nb, strength_q8, d_out_q8);
+        hipLaunchKernelGGL(k_mbtree_propagate, grid, dim3(256), 0, st, d_info[j], d_aq ? d_aq[j] : nullptr, la->prop + (size_t)j * per, la->prop + (size_t)(j - 1) * per, la->bw, la->bh);
+    hipLaunchKernelGGL(k_mbtree_finish, grid, dim3(256), 0, st, d_info[0], d_aq ? d_aq[0] : nullptr, la->prop, nb, strength, d_out);
     HIP_TRY(hipGetLastError());
     return X264GPU_OK;
 }

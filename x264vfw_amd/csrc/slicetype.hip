@@ -375,25 +375,12 @@ __global__ __launch_bounds__(64) void k_st_weight_cost_chroma(StChromaK k)
 // ---- macroblock-tree through B pictures (oracle/slicetype.c x264o_slicetype_propagate / _finish; x264 macroblock_tree_propagate,
 //      mbtree_propagate_cost / _list, macroblock_tree_finish).  Sums saturate at 32767 in x264; every addend is non-negative, so the
 //      accumulators here are plain 32-bit atomics and the saturation is applied where a sum is READ ----
-static __constant__ uint8_t c_st_log2_lut[128] = {
-#include "x264gpu_aq_lut.inc"
-};
-static __constant__ uint16_t c_st_exp2_lut[64] = {
-#include "x264gpu_exp2_lut.inc"
-};
-__device__ __forceinline__ int st_log2_q8(unsigned x) { const int lz = 31 - __builtin_clz(x); return lz * 256 + c_st_log2_lut[((x << (31 - lz)) >> 24) & 0x7f]; }
-__device__ __forceinline__ int st_inv_qscale(int aq_q8)
-{
-    const int i = (-aq_q8 * 64 + 786432 + 768) / 1536;
-    if (i < 0) return 0;
-    if (i > 1023) return 0xffff;
-    return (int)(((unsigned)(c_st_exp2_lut[i & 63] + 256) << (i >> 6)) >> 8);
-}
+__device__ __forceinline__ int st_inv_qscale(float aq) { return x264_exp2fix8(aq); }          // frame->i_inv_qscale_factor
 struct StTreeK {
-    int bw, bh, nb, d0, d1, bipw0, bipw1, referenced, strength_q8;
-    const int *intra_cost; const uint16_t *lowres_costs; const int16_t *mv[2]; const int16_t *aq;
+    int bw, bh, nb, d0, d1, bipw0, bipw1, referenced; float strength, weightdelta;
+    const int *intra_cost; const uint16_t *lowres_costs; const int16_t *mv[2]; const float *aq;
     const int32_t *prop_b; int32_t *prop_ref[2];
-    int16_t *out;
+    float *out;
 };
 __global__ __launch_bounds__(256) void k_st_propagate(StTreeK k)
 {
@@ -402,10 +389,8 @@ __global__ __launch_bounds__(256) void k_st_propagate(StTreeK k)
     const size_t o = (size_t)s * k.nb + i;
     const int bx = i % k.bw, by = i / k.bw;
     const int intra = min(k.intra_cost[o], LOWRES_COST_MASK), lc = k.lowres_costs[o];
-    const int best = lc & LOWRES_COST_MASK, inter = min(best, intra), inv = st_inv_qscale(k.aq ? k.aq[o] : 0);
-    const long long amt512 = (long long)(k.referenced ? min(k.prop_b[o], 32767) : 0) * 512 + (long long)intra * inv;
-    int amount = intra ? (int)((amt512 * (intra - inter) + 256 * (long long)intra) / (512 * (long long)intra)) : 0;
-    amount = min(amount, 32767);
+    const int best = lc & LOWRES_COST_MASK, inter = min(best, intra), inv = st_inv_qscale(k.aq ? k.aq[o] : 0.f);
+    const int amount = x264_propagate_amount(k.referenced ? min(k.prop_b[o], 32767) : 0, intra, inter, inv);          // mbtree_propagate_cost
     const int used = lc >> LOWRES_COST_SHIFT;
     for (int l = 0; l < (k.d1 > 0 ? 2 : 1); l++) {
         if (!(used & (1 << l))) continue;
@@ -428,15 +413,16 @@ __global__ __launch_bounds__(256) void k_st_finish(StTreeK k)
     const int i = blockIdx.x * 256 + threadIdx.x, s = blockIdx.y;
     if (i >= k.nb) return;
     const size_t o = (size_t)s * k.nb + i;
-    const int a = k.aq ? k.aq[o] : 0;
+    const float a = k.aq ? k.aq[o] : 0.f;
     const int icost = min(k.intra_cost[o], LOWRES_COST_MASK);
     const int intra = (icost * st_inv_qscale(a) + 128) >> 8;
-    int off = a;
+    float off = a;
     if (intra) {
-        const int p2 = min(k.prop_b[o], 32767) * 2;
-        off = a - ((k.strength_q8 * (st_log2_q8((unsigned)(intra + p2)) - st_log2_q8((unsigned)intra))) >> 8);
+        const int p2 = min(k.prop_b[o], 32767) * 2;          // (propagate * fps_factor + 128) >> 8, fps_factor = 512
+        const float log2_ratio = f_add(f_sub(x264_log2((unsigned)(intra + p2)), x264_log2((unsigned)intra)), k.weightdelta);
+        off = f_sub(a, f_mul(k.strength, log2_ratio));
     }
-    k.out[o] = (int16_t)off;
+    k.out[o] = off;
 }
 
 }  // namespace x264gpu
@@ -456,7 +442,7 @@ struct x264gpu_slicetype {
     std::vector<int32_t> intra_mbs[ST_MAX_SLOTS];      // [d0 * S + s]
     uint16_t *cost_mv; int32_t *sums; int *progress; int serial_rows = -1;          // serial_rows: -1 auto (= 0: measured faster at every batch size), 0 / 1 forced
     std::vector<int32_t> h_sums;
-    int32_t *prop[ST_MAX_SLOTS]; int16_t *aq[ST_MAX_SLOTS]; bool have_aq[ST_MAX_SLOTS];      // macroblock-tree: propagate costs, AQ offsets (Q8)
+    int32_t *prop[ST_MAX_SLOTS]; float *aq[ST_MAX_SLOTS]; bool have_aq[ST_MAX_SLOTS];        // macroblock-tree: propagate costs, AQ offsets (f_qp_offset_aq)
     unsigned long long *d_acc;                                                                // [S][4] accumulators of the weight primitives
     std::vector<unsigned long long> cstats[ST_MAX_SLOTS];                                     // per slot [S][4]: i_pixel_sum, i_pixel_ssd of Cb, of Cr
     std::vector<unsigned long long> stats[ST_MAX_SLOTS];                                      // per slot [S][2]: i_pixel_sum, i_pixel_ssd of the luma
@@ -498,7 +484,7 @@ int x264gpu_slicetype_create(x264gpu_slicetype **out, int width, int height, int
     for (int i = 0; i < slots; i++) {
         alloc((void **)&st->planes[i], S * st->lpic);
         alloc((void **)&st->intra_cost[i], S * nb * sizeof(int));
-        alloc((void **)&st->prop[i], S * nb * sizeof(int32_t)); alloc((void **)&st->aq[i], S * nb * sizeof(int16_t));
+        alloc((void **)&st->prop[i], S * nb * sizeof(int32_t)); alloc((void **)&st->aq[i], S * nb * sizeof(float));
         alloc((void **)&st->lowres_costs[i], nd * S * nb * sizeof(uint16_t));
         for (int l = 0; l < 2; l++) for (int d = 0; d <= bframes; d++) { alloc((void **)&st->mvs[i][l][d], S * nb * 2 * sizeof(int16_t)); alloc((void **)&st->mvcosts[i][l][d], S * nb * sizeof(int)); }
         st->cost_est[i].assign(nd * S, -1); st->intra_mbs[i].assign((size_t)(bframes + 2) * S, 0);
@@ -733,16 +719,16 @@ int x264gpu_slicetype_weight_cost_chroma(x264gpu_slicetype *st, int slot_fenc, c
 }
 
 // ---- macroblock-tree (x264 macroblock_tree's building blocks; the host walks the pictures as x264 does) ----
-// x264_adaptive_quant_frame's offsets of the picture in `slot` ([streams][blocks] Q8, device memory; NULL = none)
-int x264gpu_slicetype_set_aq(x264gpu_slicetype *st, int slot, const int16_t *d_aq_q8, void *stream)
+// x264_adaptive_quant_frame's offsets of the picture in `slot` ([streams][blocks] single floats, device memory; NULL = none)
+int x264gpu_slicetype_set_aq(x264gpu_slicetype *st, int slot, const float *d_aq, void *stream)
 {
     ARG_TRY(st && slot >= 0 && slot < st->slots);
-    st->have_aq[slot] = d_aq_q8 != nullptr;
-    if (d_aq_q8) HIP_TRY(hipMemcpyAsync(st->aq[slot], d_aq_q8, (size_t)st->streams * st->nb * sizeof(int16_t), hipMemcpyDeviceToDevice, (hipStream_t)stream));
+    st->have_aq[slot] = d_aq != nullptr;
+    if (d_aq) HIP_TRY(hipMemcpyAsync(st->aq[slot], d_aq, (size_t)st->streams * st->nb * sizeof(float), hipMemcpyDeviceToDevice, (hipStream_t)stream));
     return X264GPU_OK;
 }
 // fenc->i_cost_est_aq of a costed triple (x264 slicetype_mb_cost's i_mb_cost_aq summed over the blocks that count): per stream into h_score[streams]
-struct StAqK { int bw, bh, nb, is_i; const int *intra_cost; const uint16_t *lowres_costs; const int16_t *aq; int32_t *out; };
+struct StAqK { int bw, bh, nb, is_i; const int *intra_cost; const uint16_t *lowres_costs; const float *aq; int32_t *out; };
 __global__ __launch_bounds__(256) void k_st_cost_aq(StAqK k)
 {
     const int s = blockIdx.x;
@@ -753,7 +739,7 @@ __global__ __launch_bounds__(256) void k_st_cost_aq(StAqK k)
         if (!score) continue;
         const size_t o = (size_t)s * k.nb + i;
         const int c = k.is_i ? k.intra_cost[o] : k.lowres_costs[o] & LOWRES_COST_MASK;
-        sum += (c * st_inv_qscale(k.aq ? k.aq[o] : 0) + 128) >> 8;
+        sum += (c * st_inv_qscale(k.aq ? k.aq[o] : 0.f) + 128) >> 8;
     }
     __shared__ int red[256];
     red[threadIdx.x] = sum;
@@ -819,14 +805,14 @@ int x264gpu_slicetype_propagate(x264gpu_slicetype *st, int s0, int s1, int sb, i
     HIP_TRY(hipGetLastError());
     return X264GPU_OK;
 }
-// macroblock_tree_finish: d_out_q8[streams][blocks] = aq - strength * log2((intra + propagated) / intra) of the picture in `slot`
-int x264gpu_slicetype_finish(x264gpu_slicetype *st, int slot, int strength_q8, int16_t *d_out_q8, void *stream)
+// macroblock_tree_finish: d_out[streams][blocks] = aq - strength * (x264_log2(intra + propagated) - x264_log2(intra) + weightdelta) of the picture in `slot`
+int x264gpu_slicetype_finish(x264gpu_slicetype *st, int slot, float strength, float weightdelta, float *d_out, void *stream)
 {
-    ARG_TRY(st && d_out_q8 && slot >= 0 && slot < st->slots && st->intra_calculated[slot]);
+    ARG_TRY(st && d_out && slot >= 0 && slot < st->slots && st->intra_calculated[slot]);
     StTreeK k;
     memset(&k, 0, sizeof(k));
-    k.bw = st->bw; k.bh = st->bh; k.nb = st->nb; k.strength_q8 = strength_q8;
-    k.intra_cost = st->intra_cost[slot]; k.aq = st->have_aq[slot] ? st->aq[slot] : nullptr; k.prop_b = st->prop[slot]; k.out = d_out_q8;
+    k.bw = st->bw; k.bh = st->bh; k.nb = st->nb; k.strength = strength; k.weightdelta = weightdelta;
+    k.intra_cost = st->intra_cost[slot]; k.aq = st->have_aq[slot] ? st->aq[slot] : nullptr; k.prop_b = st->prop[slot]; k.out = d_out;
     hipLaunchKernelGGL(k_st_finish, dim3((st->nb + 255) / 256, st->streams), dim3(256), 0, (hipStream_t)stream, k);
     HIP_TRY(hipGetLastError());
     return X264GPU_OK;

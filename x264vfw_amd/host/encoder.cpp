@@ -64,15 +64,15 @@ struct x264_t {
     double t_b[5] = { 0, 0, 0, 0, 0 };          // ... sessions on the DPB model: slice-type analysis, GPU hot path, download, entropy coding, pictures
     double t_phase[6] = { 0, 0, 0, 0, 0, 0 };   // X264GPU_HOST_TIMING=1: seconds in copy-in, upload + lookahead, GPU, download, entropy coding, calls
     // ---- lookahead queue (threads 1): pictures wait here rc-lookahead deep when the macroblock-tree needs to see what follows them ----
-    struct QEntry { int64_t pts; int slot; int type; int scenecut; int32_t costs[4]; x264_image_t img; int qp; int buf; bool launched; };      // type: 0 P, 1 I, 2 IDR; qp / buf / launched: set by gpu_stage
+    struct QEntry { int64_t pts; int slot; int type; int scenecut; int32_t costs[4]; x264_image_t img; int qp; int buf; bool launched; float qpm = 0.f; };      // type: 0 P, 1 I, 2 IDR; qpm: the float quantiser handed to the device (0: none); qp / buf / launched: set by gpu_stage
     std::deque<QEntry> queue;
     int L = 0, Q = 1;                    // pictures held back; ring slots (L + 1)
     std::vector<uint8_t *> q_raw;        // device: source pictures (slot 0 is d_in when nothing is held back: zero-copy input)
     std::vector<int32_t *> q_info;       // device: lookahead block records per slot
-    std::vector<int16_t *> q_aq;         // device: AQ offsets per slot
-    int16_t *d_tree = nullptr;           // device: macroblock-tree quantiser offsets of the picture being coded
+    std::vector<float *> q_aq;           // device: AQ offsets per slot (x264 f_qp_offset_aq, single floats)
+    float *d_tree = nullptr;             // device: macroblock-tree quantiser offsets of the picture being coded
     long la_count = 0; int la_gop = 0;   // pictures seen by the lookahead; distance from the last IDR at lookahead time
-    bool mbtree = false; int aq_strength_q8 = 0, tree_strength_q8 = 0;
+    bool mbtree = false; float aq_strength = 0.f, tree_strength = 0.f;      // x264_adaptive_quant_frame's strength (mode 1: aq-strength * 1.0397f; 2 / 3: aq-strength), macroblock_tree_finish's 5.0f * (1.0f - qcomp)
     int aq_mode = 0;                     // --aq-mode (1 variance, 2 auto-variance, 3 auto-variance biased); modes 2 / 3 always arrive as offsets computed when the picture comes in
     int cavlc_threads = 1;               // row bands of a slice coded in parallel (threads 1 sessions; GOP-parallel ones use a thread per GOP)
     // ---- pipelined threads-1 sessions (CRF with pictures held back anyway): the GPU stage of picture n+1 runs in a helper thread while
@@ -82,7 +82,9 @@ struct x264_t {
     int gpu_rc = 0;                      // result of the GPU stage in flight
     int rc_frames = 0;                   // pictures that went through rate control (frames_done of rc_pick_qp)
     int device = 0;
+    std::vector<float> gop_qpm;          // ... and its float quantiser (x264 rc->qpm)
     std::vector<int8_t> gop_qp;          // GOP-parallel CRF: the quantiser of every ring picture (slot * keyint + position), decided on arrival
+    float last_qpm = 0.f;                // ... and its float quantiser as the device got it (x264 rc->qpm; 0 = the integer one)
     int last_qp = 0, last_scenecut = 0;  // diagnostics: quantiser and scenecut flag of the last coded picture
     int32_t last_costs[4] = { 0, 0, 0, 0 };
     // ---- GOP-parallel mode (--threads G > 1): G closed GOPs of the one stream are coded in lock-step on G stream slots of the
@@ -124,10 +126,12 @@ struct x264_t {
     // dpbmode: the session runs on the DPB model (host/dpb.hpp) and x264gpu_encode_pictures — every session with B pictures, and sessions
     // without them that use --weightp 2 (whose duplicate references need explicit lists); weightp: the effective --weightp (0 or 2)
     bool dpbmode = false; int weightp = 0;
+    bool weightp_fake = false;           // x264 X264_WEIGHTP_FAKE: --weightp 0 with macroblock-tree and psy: the lookahead still looks for fades, for the tree's sake alone
     Dpb dpb;
     struct BEntry { int64_t pts; int frame; int slot; int forced; int scenecut; int32_t costs[4]; x264_image_t img;      // forced: 0 auto, 1 I, 2 IDR
                     int type = 0; int b_scenecut = 1;         // slicetype analysis: the type decided so far (ST_*), "may still be a real scene cut"
-                    Dpb::LumaWeight w; };                     // x264_weights_analyse's luma weight of reference 0 when the picture is coded as P (--weightp)
+                    Dpb::LumaWeight w;                        // x264_weights_analyse's luma weight of reference 0 when the picture is coded as P (--weightp)
+                    float weighted_cost_delta[18] = { 0 }; }; // f_weighted_cost_delta[distance - 1]: weighted / unweighted cost where the fake analysis found a luma weight
     // x264's lookahead in its own structure (x264_slicetype_analyse: scenecut against the last non-B picture with flash detection, --b-adapt 1)
     // on the device's frame costs of arbitrary (p0, p1, b) triples; the half-resolution planes of a queued picture live in the slicetype object's
     // slot of the same number as its raw picture
@@ -135,7 +139,7 @@ struct x264_t {
     bool have_last_nonb = false; BEntry last_nonb;
     int last_keyframe = 0;                // display index of the last IDR picture decided (x264 h->lookahead->i_last_keyframe)
     int badapt = 0;
-    std::vector<int16_t *> q_tree;       // device, per queue slot: the quantiser offsets the macroblock-tree left with the picture (AQ offsets until it ran)
+    std::vector<float *> q_tree;         // device, per queue slot: the quantiser offsets the macroblock-tree left with the picture (AQ offsets until it ran)
     bool st_aq_costs = false;            // AQ session without macroblock-tree on the DPB model: the rate control reads the AQ-weighted frame costs (i_cost_est_aq)
     int st_wait = 0;                     // pictures the lookahead holds before a decision (x264 i_slicetype_length: max(bframes, rc-lookahead under mbtree))
     // cross-session batcher (X264GPU_BATCH=N): N sessions of equal geometry and toolset share ONE device encoder with N streams; the pictures
@@ -286,6 +290,9 @@ static void batch_leave(BatchGroup *g, int s)
 // [x264-upstream] encoder/ratecontrol.c qp2qscale / qscale2qp: single floats (powf / log2f), as x264 has them
 static inline double rc_qp2qscale(double qp) { return (double)(0.85f * powf(2.0f, ((float)qp - 12.0f) / 6.0f)); }
 static inline double rc_qscale2qp(double qscale) { return (double)(12.0f + 6.0f * log2f((float)qscale / 0.85f)); }
+static inline double FL(double v) { return (double)(float)v; }          // an assignment to one of x264's float variables
+// fdec->f_qp_avg_rc as x264 arrives at it: rc->qpa_rc (a float) gathers qpm * mb_width row by row (x264_ratecontrol_mb), x264_ratecontrol_end divides by the macroblock count
+static inline double rc_qp_avg_rc(float qpm, int mbw, int mbh) { float a = 0.f; for (int y = 0; y < mbh; y++) a += qpm * mbw; return (double)(a / (float)(mbw * mbh)); }
 
 static void xlog(const x264_param_t *p, int level, const char *fmt, ...)
 {
@@ -597,7 +604,7 @@ x264_t *x264_encoder_open(x264_param_t *param)
                      ((p.analyse.inter & X264_ANALYSE_BSUB16x16) ? 0x800 : 0);      // B slices: b8x8
     cfg.dct8x8 = p.analyse.b_transform_8x8;
     cfg.me_method = p.analyse.i_me_method == X264_ME_DIA ? 0 : p.analyse.i_me_method == X264_ME_HEX ? 1 : p.analyse.i_me_method == X264_ME_UMH ? 2 : 3;
-    cfg.aq_mode = p.rc.i_aq_mode == X264_AQ_VARIANCE; cfg.aq_strength_q8 = (int)(p.rc.f_aq_strength * 1.0397f * 256.0f + 0.5f);
+    cfg.aq_mode = p.rc.i_aq_mode == X264_AQ_VARIANCE; cfg.aq_strength = p.rc.f_aq_strength * 1.0397f;
     h->aq_mode = p.rc.i_aq_mode;
     cfg.mixed_refs = p.analyse.b_mixed_references && (p.analyse.inter & X264_ANALYSE_PSUB16x16) != 0;
     cfg.chroma_me = p.analyse.b_chroma_me && p.analyse.i_subpel_refine >= 5;     // x264: h->mb.b_chroma_me in P slices
@@ -657,6 +664,7 @@ x264_t *x264_encoder_open(x264_param_t *param)
     }
     // lookahead queue: rc-lookahead pictures are held back when the macroblock-tree is on (x264's sync lookahead), none otherwise
     h->mbtree = p.rc.b_mb_tree && h->la != nullptr;
+    h->weightp_fake = !h->weightp && h->mbtree && p.analyse.b_psy && h->dpbmode;          // x264 validate_parameters: X264_WEIGHTP_FAKE (sessions on the DPB model: the others' tree has no weight analysis)
     h->L = h->mbtree ? p.rc.i_lookahead : 0;
     // pictures are held back anyway and the quantisers do not depend on coded sizes: overlap the GPU stage of the next picture with
     // the entropy coding of this one (one more picture of delay); X264GPU_HOST_PIPELINE=0 keeps the two stages in one call
@@ -691,9 +699,9 @@ x264_t *x264_encoder_open(x264_param_t *param)
         p.i_bframe_bias = clampi(p.i_bframe_bias, -90, 100);
         (void)x264gpu_slicetype_set_bframe_bias(h->st, p.i_bframe_bias);          // --b-bias also scales the B costs of slicetype_frame_cost
     }
-    h->aq_strength_q8 = cfg.aq_mode ? cfg.aq_strength_q8 : h->aq_mode >= 2 ? (int)(p.rc.f_aq_strength * 256.0f + 0.5f) : 0;      // (modes 2 / 3: the plain strength, x264_adaptive_quant_frame scales it by the picture's mean itself)
-    h->st_aq_costs = h->st && h->la && !h->mbtree && h->aq_strength_q8 && (h->crf || h->abr);
-    h->tree_strength_q8 = (int)(1280.0 * (1.0 - p.rc.f_qcompress) + 0.5);     // 5 * (1 - qcomp), Q8
+    h->aq_strength = cfg.aq_mode ? cfg.aq_strength : h->aq_mode >= 2 ? p.rc.f_aq_strength : 0.f;      // (modes 2 / 3: the plain strength, x264_adaptive_quant_frame scales it by the picture's mean itself)
+    h->st_aq_costs = h->st && h->la && !h->mbtree && h->aq_strength != 0.f && (h->crf || h->abr);
+    h->tree_strength = 5.0f * (1.0f - p.rc.f_qcompress);
     h->q_raw.assign((size_t)h->Q, nullptr); h->q_info.assign((size_t)h->Q, nullptr); h->q_aq.assign((size_t)h->Q, nullptr); h->q_tree.assign((size_t)h->Q, nullptr);
     if (h->Q == 1) h->q_raw[0] = h->d_in;            // no delay: the staging buffer is the one slot; with a delay the ring is separate,
                                                      // because a zero-copy caller rewrites the staging buffer every call
@@ -702,10 +710,10 @@ x264_t *x264_encoder_open(x264_param_t *param)
         for (int i = 0; i < h->Q && ok; i++) {
             if (!h->q_raw[(size_t)i]) ok = x264gpu_malloc((void **)&h->q_raw[(size_t)i], insz) == X264GPU_OK;
             if (ok && h->mbtree) ok = x264gpu_malloc((void **)&h->q_info[(size_t)i], (size_t)h->nmb * 4 * sizeof(int32_t)) == X264GPU_OK;
-            if (ok && (h->mbtree || h->st_aq_costs || h->aq_mode >= 2)) ok = x264gpu_malloc((void **)&h->q_aq[(size_t)i], (size_t)h->nmb * sizeof(int16_t)) == X264GPU_OK;
-            if (ok && h->mbtree && h->dpbmode) ok = x264gpu_malloc((void **)&h->q_tree[(size_t)i], (size_t)h->nmb * sizeof(int16_t)) == X264GPU_OK;
+            if (ok && (h->mbtree || h->st_aq_costs || h->aq_mode >= 2)) ok = x264gpu_malloc((void **)&h->q_aq[(size_t)i], (size_t)h->nmb * sizeof(float)) == X264GPU_OK;
+            if (ok && h->mbtree && h->dpbmode) ok = x264gpu_malloc((void **)&h->q_tree[(size_t)i], (size_t)h->nmb * sizeof(float)) == X264GPU_OK;
         }
-        if (ok && h->mbtree) ok = x264gpu_malloc((void **)&h->d_tree, (size_t)h->nmb * sizeof(int16_t)) == X264GPU_OK;
+        if (ok && h->mbtree) ok = x264gpu_malloc((void **)&h->d_tree, (size_t)h->nmb * sizeof(float)) == X264GPU_OK;
         if (!ok) {
             xlog(&p, X264_LOG_ERROR, "GPU lookahead queue setup failed: %s\n", x264gpu_last_error());
             x264_encoder_close(h);
@@ -716,7 +724,7 @@ x264_t *x264_encoder_open(x264_param_t *param)
         // x264_ratecontrol_new: rate_factor_constant = base_cplx^(1 - qcomp) / qp2qscale(crf), base_cplx = mbs * (bframes ? 120 : 80)
         auto qp2qscale = [](double q) { return rc_qp2qscale(q); };
         h->rc.qcompress = p.rc.f_qcompress; h->rc.ip_factor = fabs(p.rc.f_ip_factor) > 0 ? fabs(p.rc.f_ip_factor) : 1.0;
-        h->rc.ip_offset = 6.0 * log2(h->rc.ip_factor);
+        h->rc.ip_offset = 6.0 * log2f((float)h->rc.ip_factor);          // x264_ratecontrol_init_reconfigurable: 6.0 * log2f( f_ip_factor )
         if (p.rc.b_mb_tree) h->rc.qcompress = 1.0;                     // x264_ratecontrol_new: the tree does the complexity weighting, CRF shifts by 13.5 (1 - qcomp)
         h->rc.rate_factor_constant = pow((double)h->nmb * (h->bframes ? 120.0 : 80.0), 1.0 - h->rc.qcompress) / qp2qscale(p.rc.f_rf_constant + (p.rc.b_mb_tree ? (1.0 - p.rc.f_qcompress) * 13.5 : 0.0));
         h->rc.last_qscale_for[0] = h->rc.last_qscale_for[1] = qp2qscale(p.rc.f_rf_constant);
@@ -753,7 +761,7 @@ x264_t *x264_encoder_open(x264_param_t *param)
     if (h->pipeline) { h->h_mb2.resize(h->h_mb.size()); h->h_lv2.resize(h->h_lv.size()); }
     if (h->G > 1) {
         const size_t n = (size_t)h->G * h->keyint;
-        h->gop_qp.assign(n, (int8_t)h->qp_p);
+        h->gop_qp.assign(n, (int8_t)h->qp_p); h->gop_qpm.assign(n, 0.f);
         h->slotbuf.resize(n);
         h->slot_have.assign(n, 0);
         h->h_mb2.resize(h->h_mb.size()); h->h_lv2.resize(h->h_lv.size());
@@ -797,6 +805,8 @@ int x264_encoder_headers(x264_t *h, x264_nal_t **pp_nal, int *pi_nal)
     return (int)h->out.size();
 }
 
+// the float quantiser as the device takes it: beside its rounding (a quantiser clipped into 1..51 from outside has no fraction to carry: 0 = the integer one)
+static float near_qpm(double qpf, int qp) { const float f = (float)qpf; return f > (float)qp - 1.f && f < (float)qp + 1.f ? f : 0.f; }
 // ---- GOP-parallel mode ------------------------------------------------------------------------------------------------
 // Frame i of the stream belongs to GOP g = i / keyint at position t = i % keyint; GOP g runs on slot g % G of batch g / G.
 // Pictures are uploaded into a position-major device ring, so the G pictures of one position are contiguous = one
@@ -825,10 +835,10 @@ static int code_position(x264_t *h, int batch, int t, int nslots_with_t)
     x264gpu_mb *hmb = h->dl ? h->h_mb2.data() : h->h_mb.data();
     int16_t *hlv = h->dl ? h->h_lv2.data() : h->h_lv.data();
     h->dl ^= 1;
-    std::vector<int8_t> qps;
+    std::vector<int8_t> qps; std::vector<float> qpms;
     if (h->crf) {
-        qps.assign((size_t)G, (int8_t)(t == 0 ? h->qp_i : h->qp_p));
-        for (int s = 0; s < nslots_with_t; s++) qps[(size_t)s] = h->gop_qp[(size_t)s * h->keyint + t];
+        qps.assign((size_t)G, (int8_t)(t == 0 ? h->qp_i : h->qp_p)); qpms.assign((size_t)G, 0.f);
+        for (int s = 0; s < nslots_with_t; s++) { qps[(size_t)s] = h->gop_qp[(size_t)s * h->keyint + t]; qpms[(size_t)s] = h->gop_qpm[(size_t)s * h->keyint + t]; }
     }
     // every device codes position t of its slots; one host thread per device issues the work and collects the results
     const int D = (int)h->devs.size();
@@ -837,9 +847,9 @@ static int code_position(x264_t *h, int batch, int t, int nslots_with_t)
         x264_t::DevCtx &dc = h->devs[(size_t)d];
         bool ok = D == 1 || x264gpu_set_device(dc.dev) == X264GPU_OK;
         if (ok && h->crf) {
-            std::vector<int8_t> q((size_t)dc.nsl);
-            for (int l = 0; l < dc.nsl; l++) q[(size_t)l] = qps[(size_t)(l * D + d)];
-            ok = x264gpu_encoder_set_stream_qps(dc.gpu, q.data()) == X264GPU_OK;
+            std::vector<int8_t> q((size_t)dc.nsl); std::vector<float> qm((size_t)dc.nsl);
+            for (int l = 0; l < dc.nsl; l++) { q[(size_t)l] = qps[(size_t)(l * D + d)]; qm[(size_t)l] = qpms[(size_t)(l * D + d)]; }
+            ok = x264gpu_encoder_set_stream_qpms(dc.gpu, q.data(), qm.data()) == X264GPU_OK;
         }
         ok = ok && x264gpu_encode_frames(dc.gpu, dc.d_ring + (size_t)t * dc.nsl * insz, st, dc.d_mb, dc.d_lv, nullptr) == X264GPU_OK &&
              x264gpu_memcpy_d2h(hmb + (size_t)dc.base * h->nmb, dc.d_mb, (size_t)dc.nsl * h->nmb * sizeof(x264gpu_mb), nullptr) == X264GPU_OK &&
@@ -946,6 +956,7 @@ static int encode_gop_parallel(x264_t *h, x264_nal_t **pp_nal, int *pi_nal, x264
                 return -1;
             }
             h->gop_qp[(size_t)s * K + t] = (int8_t)rc_pick_qp(h, t == 0, costs, (int)i);
+            h->gop_qpm[(size_t)s * K + t] = near_qpm(h->rc.qpa_last, h->gop_qp[(size_t)s * K + t]);
         }
         h->pts.push_back(pic_in->i_pts);
         h->submitted++;
@@ -1007,8 +1018,8 @@ static int rc_pick_qp(x264_t *h, bool is_i, const int32_t costs[4], int frames_d
     const double rate_factor = h->crf ? h->rc.rate_factor_constant : h->rc.wanted_bits_window / h->rc.cplxr_sum;
     if (satd > 0) {
         h->rc.last_rceq = h->mbtree ? pow(1.0 / h->rc.dur_ratio, 1.0 - p.rc.f_qcompress) : pow(h->rc.cplxsum / h->rc.cplxcount, 1.0 - h->rc.qcompress);
-        q = h->rc.last_rceq / rate_factor;
-    } else q = h->rc.last_qscale_for[is_i ? 0 : 1];
+        q = FL(h->rc.last_rceq / rate_factor);          // (rate_estimate_qscale's q is a float: every assignment rounds)
+    } else q = FL(h->rc.last_qscale_for[is_i ? 0 : 1]);
     if (h->abr && satd > 0) {
         // pull towards the target: bits so far against time so far, within an abr_buffer that grows with sqrt(time)
         const double time_done = frames_done / h->rc.fps, wanted_bits = time_done * h->rc.bitrate;
@@ -1016,19 +1027,19 @@ static int rc_pick_qp(x264_t *h, bool is_i, const int32_t costs[4], int frames_d
             const double buf = h->rc.abr_buffer * (time_done > 1.0 ? sqrt(time_done) : 1.0);
             overflow = 1.0 + (h->rc.total_bits - wanted_bits) / buf;
             overflow = overflow < 0.5 ? 0.5 : overflow > 2.0 ? 2.0 : overflow;
-            q *= overflow;
+            q = FL(q * overflow);
         }
     }
-    if (is_i && h->keyint > 1 && !h->rc.last_non_b_is_i) q = qp2qscale(h->rc.accum_p_qp / h->rc.accum_p_norm) / h->rc.ip_factor;
+    if (is_i && h->keyint > 1 && !h->rc.last_non_b_is_i) q = FL(qp2qscale(h->rc.accum_p_qp / h->rc.accum_p_norm) / h->rc.ip_factor);
     else if (frames_done > 0) {
         if (h->abr) {       // asymmetric clipping against the last quantiser of the same picture type (qpstep)
             double lmin = h->rc.last_qscale_for[is_i ? 0 : 1] / h->rc.lstep, lmax = h->rc.last_qscale_for[is_i ? 0 : 1] * h->rc.lstep;
             if (overflow > 1.1 && frames_done > 3) lmax *= h->rc.lstep;
             else if (overflow < 0.9) lmin /= h->rc.lstep;
-            q = q < lmin ? lmin : q > lmax ? lmax : q;
+            q = FL(q < lmin ? lmin : q > lmax ? lmax : q);
         }
-    } else if (h->crf && h->rc.qcompress != 1.0) q = qp2qscale(p.rc.f_rf_constant) / h->rc.ip_factor;       // very first picture: ABR_INIT_QP / ipratio
-    q = q < h->rc.lmin ? h->rc.lmin : q > h->rc.lmax ? h->rc.lmax : q;
+    } else if (h->crf && h->rc.qcompress != 1.0) q = FL(qp2qscale(p.rc.f_rf_constant) / h->rc.ip_factor);       // very first picture: ABR_INIT_QP / ipratio
+    q = FL(q < h->rc.lmin ? h->rc.lmin : q > h->rc.lmax ? h->rc.lmax : q);
     h->rc.last_qscale_for[is_i ? 0 : 1] = q;
     if (frames_done == 0) h->rc.last_qscale_for[1] = q * h->rc.ip_factor;
     double qpf = qscale2qp(q);
@@ -1053,7 +1064,7 @@ static int gpu_stage(x264_t *h, size_t idx, int buf, bool async)
     int qp_now = is_i ? h->qp_i : h->qp_p;
     if (h->mbtree) {
         // macroblock_tree: this picture and the P pictures behind it that (transitively) reference it; an intra picture ends the chain
-        const int32_t *info[256]; const int16_t *aq[256];
+        const int32_t *info[256]; const float *aq[256];
         int n = 0;
         for (size_t j = idx; j < h->queue.size(); j++) {
             const x264_t::QEntry &q = h->queue[j];
@@ -1061,7 +1072,7 @@ static int gpu_stage(x264_t *h, size_t idx, int buf, bool async)
             info[n] = h->q_info[(size_t)q.slot]; aq[n] = h->q_aq[(size_t)q.slot];
             if (++n == 256) break;
         }
-        if (x264gpu_lookahead_mbtree(h->la, info, h->aq_strength_q8 ? aq : nullptr, n, h->tree_strength_q8, h->d_tree, nullptr) != X264GPU_OK ||
+        if (x264gpu_lookahead_mbtree(h->la, info, h->aq_strength != 0.f ? aq : nullptr, n, h->tree_strength, h->d_tree, nullptr) != X264GPU_OK ||
             x264gpu_encoder_set_mb_qp_offsets(h->gpu, h->d_tree) != X264GPU_OK) {
             xlog(&p, X264_LOG_ERROR, "x264_encoder_encode: macroblock-tree failed: %s\n", x264gpu_last_error());
             return -1;
@@ -1069,7 +1080,9 @@ static int gpu_stage(x264_t *h, size_t idx, int buf, bool async)
     }
     if (h->crf || h->abr) {
         qp_now = rc_pick_qp(h, is_i, e.costs, h->rc_frames);
-        if (x264gpu_encoder_set_qp(h->gpu, qp_now, qp_now) != X264GPU_OK) return -1;
+        // x264_ratecontrol_mb_qp adds the AQ / macroblock-tree offsets to the FLOAT quantiser (rc->qpm) before the one rounding
+        e.qpm = near_qpm(h->rc.qpa_last, qp_now);
+        if (x264gpu_encoder_set_qp(h->gpu, qp_now, qp_now) != X264GPU_OK || x264gpu_encoder_set_qpm(h->gpu, e.qpm) != X264GPU_OK) return -1;
     }
     h->rc_frames++;
     e.qp = qp_now; e.buf = buf; e.launched = true;
@@ -1108,7 +1121,7 @@ static int encode_queued(x264_t *h, x264_nal_t **pp_nal, int *pi_nal, x264_pictu
     const int st = idr ? X264GPU_SLICE_I : intra_pic ? X264GPU_SLICE_I_NONIDR : X264GPU_SLICE_P;
     const x264gpu_mb *hmb = e.buf ? h->h_mb2.data() : h->h_mb.data();
     const int16_t *hlv = e.buf ? h->h_lv2.data() : h->h_lv.data();
-    h->last_scenecut = e.scenecut; h->last_qp = qp_now;
+    h->last_scenecut = e.scenecut; h->last_qp = qp_now; h->last_qpm = e.qpm;
     memcpy(h->last_costs, e.costs, sizeof(e.costs));
     if (idr) { h->frames_since_idr = 0; h->frame_num = 0; }
     // ---- host: headers + entropy coding ----
@@ -1171,9 +1184,10 @@ struct StFrames { x264_t *h; std::vector<x264_t::BEntry *> f; };
 // if it saves more than 0.2 %.  b_lookahead: luma alone, the guess alone, reference in place (called before a P cost is searched); else, for the P
 // picture about to be coded: +- the distances of the sub-pel level around the guess, the reference motion-compensated by the lookahead's vectors,
 // and the chroma planes once luma has a weight.
-static Dpb::LumaWeight st_weights_analyse(x264_t *h, const x264_t::BEntry &fenc, const x264_t::BEntry &ref, int dist, bool b_lookahead)
+static Dpb::LumaWeight st_weights_analyse(x264_t *h, x264_t::BEntry &fenc, const x264_t::BEntry &ref, int dist, bool b_lookahead)
 {
     Dpb::LumaWeight none, w;
+    if (dist >= 1 && dist <= 18) fenc.weighted_cost_delta[dist - 1] = 0;
     uint64_t sf[6], sr[6];
     if (x264gpu_slicetype_pixel_stats(h->st, fenc.slot, h->q_raw[(size_t)fenc.slot], sf, nullptr) != X264GPU_OK ||
         x264gpu_slicetype_pixel_stats(h->st, ref.slot, h->q_raw[(size_t)ref.slot], sr, nullptr) != X264GPU_OK) { h->failed = true; return none; }
@@ -1246,6 +1260,7 @@ static Dpb::LumaWeight st_weights_analyse(x264_t *h, const x264_t::BEntry &fenc,
         if (!plane) while (mindenom > 0 && !(minscale & 1)) { mindenom--; minscale >>= 1; }      // a smaller denominator if possible
         if (!found || (minscale == 1 << mindenom && minoff == 0) || (float)minscore / origscore > 0.998f) continue;
         planes_on[plane] = true; p_scale[plane] = minscale; p_denom[plane] = mindenom; p_off[plane] = minoff;
+        if (h->weightp_fake && !plane && dist >= 1 && dist <= 18) fenc.weighted_cost_delta[dist - 1] = (float)minscore / origscore;
     }
     if (!planes_on[0]) return none;           // (x264 keeps chroma weights only beside a luma weight: they are not even analysed without one)
     w.on = 1; w.scale = p_scale[0]; w.denom = p_denom[0]; w.offset = p_off[0];
@@ -1268,7 +1283,7 @@ static int st_cost(StFrames &F, int p0, int p1, int b)
     int32_t sc = 0;
     Dpb::LumaWeight w;
     // slicetype_frame_cost: a P cost that is searched for the first time runs on the reference weighted by the lookahead's analysis
-    if (F.h->weightp && p1 == b && b != p0 && !x264gpu_slicetype_lowres_mvs(F.h->st, F.f[(size_t)b]->slot, 0, b - p0) &&
+    if ((F.h->weightp || F.h->weightp_fake) && p1 == b && b != p0 && !x264gpu_slicetype_lowres_mvs(F.h->st, F.f[(size_t)b]->slot, 0, b - p0) &&
         x264gpu_slicetype_cost_est(F.h->st, F.f[(size_t)b]->slot, b - p0, 0, 0) < 0)
         w = st_weights_analyse(F.h, *F.f[(size_t)b], *F.f[(size_t)p0], b - p0, true);
     if (x264gpu_slicetype_frame_cost_w(F.h->st, F.f[(size_t)p0]->slot, F.f[(size_t)p1]->slot, F.f[(size_t)b]->slot, b - p0, p1 - b, w.on, w.scale, w.denom, w.offset, &sc, nullptr) != X264GPU_OK) {
@@ -1325,9 +1340,12 @@ static void st_macroblock_tree(x264_t *h, StFrames &F, int num_frames, bool b_in
         }
     };
     auto clear = [&](int i) { if (x264gpu_slicetype_clear_propagate(h->st, slot(i), nullptr) != X264GPU_OK) h->failed = true; };
-    auto finish = [&](int i) {
+    auto finish = [&](int i, int ref0_distance) {
         st_cost(F, i, i, i);          // (the intra costs the analysis left with the picture; a no-op when they exist)
-        if (x264gpu_slicetype_finish(h->st, slot(i), h->tree_strength_q8, h->q_tree[(size_t)slot(i)], nullptr) != X264GPU_OK) h->failed = true;
+        // macroblock_tree_finish: a fade the (fake) weight analysis explained is not held against the picture
+        float weightdelta = 0.0;
+        if (ref0_distance >= 1 && ref0_distance <= 18 && F.f[(size_t)i]->weighted_cost_delta[ref0_distance - 1] > 0) weightdelta = (float)(1.0 - F.f[(size_t)i]->weighted_cost_delta[ref0_distance - 1]);
+        if (x264gpu_slicetype_finish(h->st, slot(i), h->tree_strength, weightdelta, h->q_tree[(size_t)slot(i)], nullptr) != X264GPU_OK) h->failed = true;
     };
     if (b_intra) st_cost(F, 0, 0, 0);
     int i = num_frames;
@@ -1359,8 +1377,8 @@ static void st_macroblock_tree(x264_t *h, StFrames &F, int num_frames, bool b_in
         last_nonb = cur_nonb;
         if (h->failed) return;
     }
-    finish(last_nonb);
-    if (h->bpyramid && bframes > 1) finish(last_nonb + (bframes + 1) / 2);
+    finish(last_nonb, last_nonb);
+    if (h->bpyramid && bframes > 1) finish(last_nonb + (bframes + 1) / 2, 0);
 }
 
 // x264 slicetype_path_cost: the cost of coding frames[1 ..] with the types in `path` ('P' / 'B' / 'I' per picture) — each non-B picture against the one
@@ -1824,7 +1842,7 @@ static double p2_pick_qscale(x264_t *h, int frame, long coded_so_far)
 static int bmode_qp(x264_t *h, const x264_t::BPlanned &pl, const DpbPlan &plan, double *qp_float)
 {
     const x264_param_t &p = h->param;
-    const double pb_offset = 6.0 * log2(fabs(p.rc.f_pb_factor) > 0 ? fabs(p.rc.f_pb_factor) : 1.0);
+    const double pb_offset = 6.0 * log2f(fabs(p.rc.f_pb_factor) > 0 ? fabsf(p.rc.f_pb_factor) : 1.0f);          // rc->pb_offset = 6.0 * log2f( f_pb_factor )
     const bool is_i = pl.type == PIC_IDR || pl.type == PIC_I, is_b = pl.type == PIC_B || pl.type == PIC_BREF;
     if (h->pass2) {
         double q = p2_qscale2qp(p2_pick_qscale(h, pl.e.frame, h->coded_count));
@@ -1846,14 +1864,17 @@ static int bmode_qp(x264_t *h, const x264_t::BPlanned &pl, const DpbPlan &plan, 
     const int s0 = plan.pic.slot[0][0], s1 = plan.pic.slot[1][0];
     const bool i0 = h->slot_ptype[s0] == PIC_IDR || h->slot_ptype[s0] == PIC_I, i1 = h->slot_ptype[s1] == PIC_IDR || h->slot_ptype[s1] == PIC_I;
     const int dt0 = abs(plan.pic.poc - plan.list_poc[0][0]), dt1 = abs(plan.pic.poc - plan.list_poc[1][0]);
-    double q0 = h->slot_qp_rc[s0], q1 = h->slot_qp_rc[s1], q;
-    if (h->slot_ptype[s0] == PIC_BREF) q0 -= pb_offset / 2;
-    if (h->slot_ptype[s1] == PIC_BREF) q1 -= pb_offset / 2;
-    if (i0 && i1) q = (q0 + q1) / 2 + h->rc.ip_offset;
-    else if (i0) q = q1;
-    else if (i1) q = q0;
-    else q = (q0 * dt1 + q1 * dt0) / (dt0 + dt1);
-    q += pl.type == PIC_BREF ? pb_offset / 2 : pb_offset;
+    // rate_estimate_qscale's B branch in x264's own types: float q0, q1, q (f_qp_avg_rc of the nearest references), double offsets; the result goes
+    // through qp2qscale and x264_ratecontrol_start's qscale2qp like every quantiser
+    float q0 = (float)h->slot_qp_rc[s0], q1 = (float)h->slot_qp_rc[s1], qf;
+    if (h->slot_ptype[s0] == PIC_BREF) q0 = (float)(q0 - pb_offset / 2);
+    if (h->slot_ptype[s1] == PIC_BREF) q1 = (float)(q1 - pb_offset / 2);
+    if (i0 && i1) qf = (float)((q0 + q1) / 2 + h->rc.ip_offset);
+    else if (i0) qf = q1;
+    else if (i1) qf = q0;
+    else qf = (q0 * dt1 + q1 * dt0) / (dt0 + dt1);
+    qf = (float)(qf + (pl.type == PIC_BREF ? pb_offset / 2 : pb_offset));
+    double q = rc_qscale2qp(rc_qp2qscale(qf));
     q = q < p.rc.i_qp_min ? p.rc.i_qp_min : q > p.rc.i_qp_max ? p.rc.i_qp_max : q;
     // x264_ratecontrol_start: accum_p_qp_update runs for every picture type — a B picture's quantiser enters the running average an I picture
     // after P pictures takes its quantiser from
@@ -1883,7 +1904,7 @@ static int encode_bmode(x264_t *h, x264_nal_t **pp_nal, int *pi_nal, x264_pictur
     double qpf = 0;
     pic.qp = bmode_qp(h, pl, plan, &qpf);
     // x264_ratecontrol_mb_qp: a macroblock's quantiser is round(rc->qpm + its AQ / macroblock-tree offset) with qpm the picture's FLOAT quantiser
-    pic.qp_frac_q8 = clampi((int)lround((qpf - pic.qp) * 256.0), -128, 127);
+    pic.qpm = near_qpm(qpf, pic.qp);
     h->rc_frames++;
     bool direct_auto_write = false;
     if ((pl.type == PIC_B || pl.type == PIC_BREF) && h->direct_mode != 1) {
@@ -1908,7 +1929,7 @@ static int encode_bmode(x264_t *h, x264_nal_t **pp_nal, int *pi_nal, x264_pictur
     }
     if (h->st && h->mbtree)          // P / I / B-reference pictures: what the tree left (AQ - tree); other B pictures: the AQ offsets alone (x264 f_qp_offset_aq)
         x264gpu_encoder_set_mb_qp_offsets(h->gpu, pl.type == PIC_B ? h->q_aq[(size_t)pl.e.slot] : h->q_tree[(size_t)pl.e.slot]);
-    else if (h->aq_mode >= 2 && h->aq_strength_q8) x264gpu_encoder_set_mb_qp_offsets(h->gpu, h->q_aq[(size_t)pl.e.slot]);      // --aq-mode 2 / 3: the offsets computed when the picture arrived
+    else if (h->aq_mode >= 2 && h->aq_strength != 0.f) x264gpu_encoder_set_mb_qp_offsets(h->gpu, h->q_aq[(size_t)pl.e.slot]);      // --aq-mode 2 / 3: the offsets computed when the picture arrived
     if (h->batch) {
         std::string berr;
         if (batch_encode(h->batch, h->batch_idx, h->q_raw[(size_t)pl.e.slot], pic, h->h_mb.data(), h->h_lv.data(), berr)) {
@@ -1935,7 +1956,7 @@ static int encode_bmode(x264_t *h, x264_nal_t **pp_nal, int *pi_nal, x264_pictur
             fclose(f);
         }
     }
-    if (plan.nal_ref_idc) { h->slot_qp_rc[pic.dst] = qpf; h->slot_ptype[pic.dst] = pl.type; }
+    if (plan.nal_ref_idc) { h->slot_qp_rc[pic.dst] = rc_qp_avg_rc((float)qpf, h->mbw, h->mbh); h->slot_ptype[pic.dst] = pl.type; }
     if (plan.nal_ref_idc) h->slot_l0ref0poc[pic.dst] = pic.nref[0] ? plan.list_poc[0][0] : INT_MIN;
     h->last_direct_char = (pl.type == PIC_B || pl.type == PIC_BREF) ? (pic.direct_temporal ? 't' : 's') : '-';
     if (direct_auto_write) {
@@ -1945,7 +1966,7 @@ static int encode_bmode(x264_t *h, x264_nal_t **pp_nal, int *pi_nal, x264_pictur
         if (h->direct_score[0] + h->direct_score[1] > h->mbw * h->mbh) for (int i = 0; i < 2; i++) h->direct_score[i] = h->direct_score[i] * 9 / 10;
         for (int i = 0; i < 2; i++) h->direct_score[i] += sc[i];
     }
-    h->last_scenecut = pl.e.scenecut; h->last_qp = pic.qp;
+    h->last_scenecut = pl.e.scenecut; h->last_qp = pic.qp; h->last_qpm = pic.qpm;
     memcpy(h->last_costs, pl.e.costs, sizeof(pl.e.costs));
     const bool idr = pl.type == PIC_IDR;
     h->out.clear(); h->nal_off.clear();
@@ -2062,7 +2083,7 @@ int x264_encoder_encode(x264_t *h, x264_nal_t **pp_nal, int *pi_nal, x264_pictur
     bool idr = h->la_count == 0 || h->la_gop >= h->keyint || pic_in->i_type == X264_TYPE_IDR || pic_in->i_type == X264_TYPE_KEYFRAME, intra_pic = false;
     if (h->la) {
         if (x264gpu_lookahead_frame_cost(h->la, d_raw, h->la_count == 0, h->d_la, h->mbtree ? h->q_info[(size_t)slot] : nullptr, nullptr) != X264GPU_OK ||
-            ((h->mbtree || h->st_aq_costs || h->aq_mode >= 2) && h->aq_strength_q8 && x264gpu_lookahead_aq_offsets_mode(h->la, d_raw, h->aq_mode >= 2 ? h->aq_mode : 1, h->aq_strength_q8, h->q_aq[(size_t)slot], nullptr) != X264GPU_OK) ||
+            ((h->mbtree || h->st_aq_costs || h->aq_mode >= 2) && h->aq_strength != 0.f && x264gpu_lookahead_aq_offsets_mode(h->la, d_raw, h->aq_mode >= 2 ? h->aq_mode : 1, h->aq_strength, h->q_aq[(size_t)slot], nullptr) != X264GPU_OK) ||
             x264gpu_memcpy_d2h(e.costs, h->d_la, sizeof(e.costs), nullptr) != X264GPU_OK) {
             xlog(&p, X264_LOG_ERROR, "x264_encoder_encode: lookahead failed: %s\n", x264gpu_last_error());
             return -1;
@@ -2096,9 +2117,9 @@ int x264_encoder_encode(x264_t *h, x264_nal_t **pp_nal, int *pi_nal, x264_pictur
             if (ok && h->weightp) { uint64_t stats[2]; ok = x264gpu_slicetype_pixel_stats(h->st, slot, d_raw, stats, nullptr) == X264GPU_OK; }      // x264_adaptive_quant_frame: i_pixel_sum / i_pixel_ssd
             if (ok && h->mbtree) {
                 // x264_adaptive_quant_frame: the AQ offsets weight the lookahead's costs and are what the tree starts from (f_qp_offset = f_qp_offset_aq)
-                if (!h->aq_strength_q8) ok = x264gpu_memset(h->q_aq[(size_t)slot], 0, (size_t)h->nmb * sizeof(int16_t), nullptr) == X264GPU_OK;
-                ok = ok && x264gpu_slicetype_set_aq(h->st, slot, h->aq_strength_q8 ? h->q_aq[(size_t)slot] : nullptr, nullptr) == X264GPU_OK &&
-                     x264gpu_memcpy_d2d(h->q_tree[(size_t)slot], h->q_aq[(size_t)slot], (size_t)h->nmb * sizeof(int16_t), nullptr) == X264GPU_OK;
+                if (h->aq_strength == 0.f) ok = x264gpu_memset(h->q_aq[(size_t)slot], 0, (size_t)h->nmb * sizeof(float), nullptr) == X264GPU_OK;
+                ok = ok && x264gpu_slicetype_set_aq(h->st, slot, h->aq_strength != 0.f ? h->q_aq[(size_t)slot] : nullptr, nullptr) == X264GPU_OK &&
+                     x264gpu_memcpy_d2d(h->q_tree[(size_t)slot], h->q_aq[(size_t)slot], (size_t)h->nmb * sizeof(float), nullptr) == X264GPU_OK;
             }
             if (ok && h->st_aq_costs) ok = x264gpu_slicetype_set_aq(h->st, slot, h->q_aq[(size_t)slot], nullptr) == X264GPU_OK;      // i_inv_qscale_factor for i_cost_est_aq
             if (!ok) {
@@ -2360,6 +2381,9 @@ int x264host_last_decision(x264_t *h, int *qp, int *scenecut, int32_t costs[4])
     if (costs) memcpy(costs, h->last_costs, sizeof(h->last_costs));
     return 0;
 }
+
+/* tests: the float quantiser (x264 rc->qpm) the last coded picture's macroblock quantisers were rounded from; 0 = its integer quantiser */
+float x264host_last_qpm(x264_t *h) { return h ? h->last_qpm : 0.f; }
 
 int x264host_get_recon(x264_t *h, uint8_t *i420_out)
 {

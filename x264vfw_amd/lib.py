@@ -40,10 +40,10 @@ class MbRecord(C.Structure):
 
 class Config(C.Structure):
     """Mirror of struct x264gpu_config."""
-    _fields_ = [(n, C.c_int) for n in (
+    _fields_ = [(n, C.c_float if n == "aq_strength" else C.c_int) for n in (
         "width", "height", "streams", "refs", "qp_i", "qp_p", "me_range", "subme", "deblock",
         "deblock_alpha", "deblock_beta", "chroma_qp_offset", "deadzone_inter", "deadzone_intra",
-        "dct_decimate", "partitions", "dct8x8", "me_method", "chroma_me", "mixed_refs", "aq_mode", "aq_strength_q8", "fast_pskip", "mv_range", "cabac", "rd", "psy", "psy_rd_q8", "slices", "trellis", "slices_plain", "dpb", "weightb")]
+        "dct_decimate", "partitions", "dct8x8", "me_method", "chroma_me", "mixed_refs", "aq_mode", "aq_strength", "fast_pskip", "mv_range", "cabac", "rd", "psy", "psy_rd_q8", "slices", "trellis", "slices_plain", "dpb", "weightb")]
 
 
 class Pic(C.Structure):
@@ -53,7 +53,7 @@ class Pic(C.Structure):
     class WC(C.Structure):
         _fields_ = [("on", C.c_int8 * 2), ("denom", C.c_int8), ("pad", C.c_int8), ("scale", C.c_int16 * 2), ("offset", C.c_int16 * 2)]
     _fields_ = [("slice_type", C.c_int), ("qp", C.c_int), ("poc", C.c_int), ("dst", C.c_int), ("keep", C.c_int), ("nref", C.c_int * 2),
-                ("slot", (C.c_int8 * 8) * 2), ("wl0", W * 8), ("blind_dupe", C.c_int), ("qp_frac_q8", C.c_int), ("wc0", WC * 8), ("direct_temporal", C.c_int), ("direct_auto", C.c_int)]
+                ("slot", (C.c_int8 * 8) * 2), ("wl0", W * 8), ("blind_dupe", C.c_int), ("qpm", C.c_float), ("wc0", WC * 8), ("direct_temporal", C.c_int), ("direct_auto", C.c_int)]
 
 
 def make_pic(slice_type, qp, poc, dst, keep, l0=(), l1=()):
@@ -110,6 +110,8 @@ _SIGS = {
     "x264gpu_encoder_profile_end": (_i, [_vp, _vp, C.POINTER(C.c_double), C.POINTER(_i)]),
     "x264gpu_encoder_set_qp": (_i, [_vp, _i, _i]),
     "x264gpu_encoder_set_mb_qp_offsets": (_i, [_vp, _vp]),
+    "x264gpu_encoder_set_stream_qpms": (_i, [_vp, _vp, _vp]),
+    "x264gpu_encoder_set_qpm": (_i, [_vp, C.c_float]),
     "x264gpu_encoder_set_stream_qps": (_i, [_vp, _vp]),
     "x264gpu_encoder_set_lowres_mvs": (_i, [_vp, _vp]),
     "x264gpu_encoder_set_lowres_mvs1": (_i, [_vp, _vp]),
@@ -121,9 +123,9 @@ _SIGS = {
     "x264gpu_lookahead_create": (_i, [C.POINTER(_vp), _i, _i, _i, _i, _i]),
     "x264gpu_lookahead_destroy": (None, [_vp]),
     "x264gpu_lookahead_frame_cost": (_i, [_vp, _vp, _i, _vp, _vp, _vp]),
-    "x264gpu_lookahead_aq_offsets": (_i, [_vp, _vp, _i, _vp, _vp]),
-    "x264gpu_lookahead_aq_offsets_mode": (_i, [_vp, _vp, _i, _i, _vp, _vp]),
-    "x264gpu_lookahead_mbtree": (_i, [_vp, C.POINTER(_vp), C.POINTER(_vp), _i, _i, _vp, _vp]),
+    "x264gpu_lookahead_aq_offsets": (_i, [_vp, _vp, C.c_float, _vp, _vp]),
+    "x264gpu_lookahead_aq_offsets_mode": (_i, [_vp, _vp, _i, C.c_float, _vp, _vp]),
+    "x264gpu_lookahead_mbtree": (_i, [_vp, C.POINTER(_vp), C.POINTER(_vp), _i, C.c_float, _vp, _vp]),
     "x264gpu_slicetype_create": (_i, [C.POINTER(_vp)] + [_i] * 11),
     "x264gpu_slicetype_destroy": (None, [_vp]),
     "x264gpu_slicetype_put_frame": (_i, [_vp, _i, _vp, _vp]),
@@ -145,7 +147,7 @@ _SIGS = {
     "x264gpu_slicetype_cost_aq": (_i, [_vp, _i, _i, _i, _vp, _vp]),
     "x264gpu_slicetype_clear_propagate": (_i, [_vp, _i, _vp]),
     "x264gpu_slicetype_propagate": (_i, [_vp, _i, _i, _i, _i, _i, _i, _vp]),
-    "x264gpu_slicetype_finish": (_i, [_vp, _i, _i, _vp, _vp]),
+    "x264gpu_slicetype_finish": (_i, [_vp, _i, C.c_float, C.c_float, _vp, _vp]),
     "x264gpu_slicetype_propagate_cost": (_vp, [_vp, _i]),
 }
 
