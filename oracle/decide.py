@@ -12,8 +12,15 @@ tests/oracle_lib.OracleSlicetype), so that a session's decisions can be compared
                                        running P quantiser / ipratio, the very first picture), the B quantiser from its nearest references (+ pbratio
                                        offsets, half for a B-reference), accum_p_qp_update, x264_ratecontrol_start's rounding
 
+  [x264-upstream] encoder/slicetype.c  the DEFAULT session's additions: macroblock_tree (the walk over the window with the types decided so far, the keyframe's own
+                                       pass: lookahead_slicetype_decide's second analysis), i_delay = max(run length, rc-lookahead), the whole window analysed
+                                       when psy and the tree are on, weights_analyse( b_lookahead = 1 ) in front of every P cost searched for the first time
+                                       (--weightp, or X264_WEIGHTP_FAKE for the tree's weightdelta), the AQ offsets every picture arrives with
+                                       (x264_adaptive_quant_frame, mode 1) as the tree's inverse quantiser scales and base
+  [x264-upstream] encoder/ratecontrol.c  get_qscale under macroblock-tree (the duration term alone, CRF shifted by 13.5 (1 - qcomp), qcompress 1)
+
 Restated from memory of upstream like the rest of oracle/ (libx264 is not in the reference tree): parity unpinned.  Out of this twin's reach (not
-restated here): macroblock-tree, weight analysis, AQ-weighted costs, ABR feedback, 2-pass.
+restated here): the final weight analysis of the picture about to be coded (its weights do not enter these decisions), ABR feedback, 2-pass, VBV.
 """
 import math
 
@@ -38,12 +45,16 @@ def qscale2qp(qscale):
 
 class Params:
     def __init__(self, mbw, mbh, keyint=250, min_keyint=0, scenecut=40, bframes=3, b_adapt=1, b_pyramid=1, b_bias=0, crf=23.0, qcomp=0.6, ip_factor=1.4,
-                 pb_factor=1.3, qpmin=0, qpmax=51, fps=25.0):
+                 pb_factor=1.3, qpmin=0, qpmax=51, fps=25.0, mbtree=False, aq_strength=0.0, weightp=0, rc_lookahead=0, psy=True):
         self.mbw, self.mbh = mbw, mbh
         self.keyint, self.scenecut, self.bframes, self.b_adapt, self.b_pyramid, self.b_bias = keyint, scenecut, bframes, b_adapt, b_pyramid, b_bias
         if min_keyint <= 0:          # validate_parameters: auto = min(keyint / 10, fps), then [1, keyint / 2 + 1]
             min_keyint = min(keyint // 10, int(fps))
         self.min_keyint = max(1, min(min_keyint, keyint // 2 + 1))
+        # the default session: macroblock-tree over rc_lookahead pictures, AQ mode 1 (aq_strength = --aq-strength x 1.0397f; 0 = off), --weightp
+        self.mbtree, self.aq_strength, self.weightp, self.rc_lookahead, self.psy = mbtree, _f(aq_strength), weightp, rc_lookahead, psy
+        self.weightp_fake = not weightp and mbtree and psy          # validate_parameters: X264_WEIGHTP_FAKE
+        self.tree_strength = _f(_f(5.0) * _f(_f(1.0) - _f(qcomp)))   # macroblock_tree_finish: 5.0f * (1.0f - f_qcompress)
         # (x264_param_t carries these as single floats: the doubles of the rate control start from the float's value)
         self.crf, self.qcomp, self.ip_factor, self.pb_factor, self.qpmin, self.qpmax, self.fps = _f(crf), _f(qcomp), _f(ip_factor), _f(pb_factor), qpmin, qpmax, fps
 
@@ -51,6 +62,10 @@ class Params:
 class Frame:
     def __init__(self, index, slot):
         self.frame, self.slot, self.type, self.b_scenecut = index, slot, AUTO, 1
+        self.raw = None                    # the source picture (weights_analyse reads its statistics)
+        self.aq = None                     # f_qp_offset_aq: the AQ offsets it arrived with
+        self.tree = None                   # f_qp_offset: what the last macroblock_tree pass over it left (starts as the AQ offsets)
+        self.weighted_cost_delta = {}      # f_weighted_cost_delta[distance]
 
 
 class Lookahead:
@@ -62,10 +77,113 @@ class Lookahead:
         self.next = []                 # display order
         self.last_nonb = None
         self.last_keyframe = -params.keyint
+        self.stats = {"lookahead_weights": 0, "weightdelta": 0}          # how often the analysis found a weight / a finished picture carried a weightdelta
 
     # slicetype_frame_cost of frames[b] predicted from frames[p0] (and frames[p1])
     def cost(self, fr, p0, p1, b):
-        return self.c.cost(fr[p0].slot, fr[p1].slot, fr[b].slot, b - p0, p1 - b)
+        w = None
+        # slicetype_frame_cost: a P cost searched for the first time runs on the reference weighted by the lookahead's analysis
+        if (self.p.weightp or self.p.weightp_fake) and p1 == b and b != p0 and self.c.cost_est(fr[b].slot, b - p0, 0) < 0 and self.c.mvs(fr[b].slot, 0, b - p0)[0][0] == 0x7fff:
+            w = self.weights_analyse(fr[b], fr[p0], b - p0)
+        return self.c.cost(fr[p0].slot, fr[p1].slot, fr[b].slot, b - p0, p1 - b, weight=w)
+
+    def weights_analyse(self, fenc, ref, dist):
+        """weights_analyse( b_lookahead = 1 ): luma alone, the guess alone, the reference in place -> (scale, denom, offset) or None"""
+        c = self.c
+        fenc.weighted_cost_delta[dist] = 0.0
+        sf, sr = c.pixel_stats(fenc.slot, fenc.raw), c.pixel_stats(ref.slot, ref.raw)
+        zero_bias = 0 if int(sr[1]) else 1
+        fenc_var, ref_var = _f(float(int(sf[1]) + zero_bias)), _f(float(int(sr[1]) + zero_bias))
+        guess_scale = _f(math.sqrt(_f(fenc_var / ref_var)))
+        npix = _f(_f(self.p.mbw * 16) * _f(self.p.mbh * 16))
+        fenc_mean, ref_mean = _f(_f(float(int(sf[0]) + zero_bias)) / npix), _f(_f(float(int(sr[0]) + zero_bias)) / npix)
+        if abs(_f(ref_mean - fenc_mean)) < 0.5 and abs(_f(1.0 - guess_scale)) < 1.0 / 128.0:
+            return None
+        roundf = lambda v: int(math.floor(abs(v) + 0.5)) * (1 if v >= 0 else -1)
+        mindenom, minscale, minoff = 7, roundf(_f(guess_scale * 128)), 0
+        while mindenom > 0 and minscale > 127:
+            mindenom -= 1
+            minscale >>= 1
+        minscale = min(minscale, 127)
+        c.cost(fenc.slot, fenc.slot, fenc.slot, 0, 0)                       # the picture's intra costs
+        origscore = c.weight_cost(fenc.slot, ref.slot, dist) & 0xffffffff
+        minscore = origscore
+        if not minscore:
+            return None
+        cur_scale = min(max(minscale, 0), 127)
+        cur_offset = int(_f(_f(fenc_mean - _f(_f(ref_mean * cur_scale) / (1 << mindenom))) + 0.5))
+        if cur_offset < -128 or cur_offset > 127:
+            cur_offset = min(max(cur_offset, -128), 127)
+            cs = _f(_f(_f((1 << mindenom) * _f(fenc_mean - cur_offset)) / ref_mean) + 0.5)
+            cur_scale = int(min(max(cs, 0), 127))
+        found = False
+        score = c.weight_cost(fenc.slot, ref.slot, dist, (cur_scale, mindenom, cur_offset)) & 0xffffffff
+        if score < minscore:
+            minscore, minscale, minoff, found = score, cur_scale, cur_offset, True
+        while mindenom > 0 and not (minscale & 1):                         # a smaller denominator if possible
+            mindenom -= 1
+            minscale >>= 1
+        if not found or (minscale == 1 << mindenom and minoff == 0) or _f(_f(float(minscore)) / _f(float(origscore))) > _f(0.998):
+            return None
+        self.stats["lookahead_weights"] += 1
+        if self.p.weightp_fake:
+            fenc.weighted_cost_delta[dist] = _f(_f(float(minscore)) / _f(float(origscore)))
+        return (minscale, mindenom, minoff)
+
+    def macroblock_tree(self, fr, num_frames, b_intra):
+        """x264's macroblock_tree over frames[0 .. num_frames] with the types decided so far; the next picture to be coded (and the B-reference of its run) get
+        their quantiser offsets (Frame.tree)"""
+        p, c = self.p, self.c
+        idx = 0 if b_intra else 1
+        isb = lambda i: fr[i].type in (B, BREF)
+        prop = lambda p0, p1, b, ref: c.propagate(fr[p0].slot, fr[p1].slot, fr[b].slot, b - p0, p1 - b, ref)
+
+        def finish(i, ref0_distance):
+            self.cost(fr, i, i, i)
+            d = fr[i].weighted_cost_delta.get(ref0_distance, 0.0) if ref0_distance else 0.0
+            weightdelta = _f(1.0 - d) if d > 0 else 0.0
+            self.stats["weightdelta"] += int(weightdelta != 0.0)
+            fr[i].tree = c.finish(fr[i].slot, p.tree_strength, weightdelta)
+        if b_intra:
+            self.cost(fr, 0, 0, 0)
+        i = num_frames
+        while i > 0 and isb(i):
+            i -= 1
+        last_nonb, bframes = i, 0
+        if last_nonb < idx:
+            return
+        c.clear_propagate(fr[last_nonb].slot)
+        while i > idx:
+            i -= 1
+            cur_nonb = i
+            while isb(cur_nonb) and cur_nonb > 0:
+                cur_nonb -= 1
+            if cur_nonb < idx:
+                break
+            self.cost(fr, cur_nonb, last_nonb, last_nonb)
+            c.clear_propagate(fr[cur_nonb].slot)
+            bframes = last_nonb - cur_nonb - 1
+            if p.b_pyramid and bframes > 1:
+                middle = (bframes + 1) // 2 + cur_nonb
+                self.cost(fr, cur_nonb, last_nonb, middle)
+                c.clear_propagate(fr[middle].slot)
+                while i > cur_nonb:
+                    p0, p1 = (middle if i > middle else cur_nonb), (middle if i < middle else last_nonb)
+                    if i != middle:
+                        self.cost(fr, p0, p1, i)
+                        prop(p0, p1, i, 0)
+                    i -= 1
+                prop(cur_nonb, last_nonb, middle, 1)
+            else:
+                while i > cur_nonb:
+                    self.cost(fr, cur_nonb, last_nonb, i)
+                    prop(cur_nonb, last_nonb, i, 0)
+                    i -= 1
+            prop(cur_nonb, last_nonb, last_nonb, 1)
+            last_nonb = cur_nonb
+        finish(last_nonb, last_nonb)
+        if p.b_pyramid and bframes > 1:
+            finish(last_nonb + (bframes + 1) // 2, 0)
 
     def scenecut_internal(self, fr, p0, p1):
         p = self.p
@@ -102,8 +220,9 @@ class Lookahead:
             return False
         return self.scenecut_internal(fr, p0, p1)
 
-    def analyse(self, framecnt):
-        """x264_slicetype_analyse over frames[0] = the last non-B picture and frames[1 ..] = the queue"""
+    def analyse(self, framecnt, keyframe=False):
+        """x264_slicetype_analyse over frames[0] = the last non-B picture and frames[1 ..] = the queue; keyframe: the pass over a keyframe just decided
+        (frames[0]): nothing is decided, its macroblock-tree reaches frames[0]"""
         p = self.p
         fr = [self.last_nonb] + self.next[:framecnt]
         i_max_search = framecnt
@@ -112,10 +231,12 @@ class Lookahead:
         keyint_limit = p.keyint - fr[0].frame + self.last_keyframe - 1
         num_frames = min(framecnt, keyint_limit)
         orig_num_frames = num_frames
-        if num_frames <= 0:
+        if p.psy and p.mbtree:
+            num_frames = framecnt              # psy-wise the pictures in front of a keyframe must not lose their share of the tree
+        elif num_frames <= 0:
             fr[1].type = I
             return
-        if fr[1].type in (AUTO, I, IDR) and p.scenecut and self.scenecut(fr, 0, 1, True, orig_num_frames, i_max_search):
+        if not keyframe and fr[1].type in (AUTO, I, IDR) and p.scenecut and self.scenecut(fr, 0, 1, True, orig_num_frames, i_max_search):
             if fr[1].type == AUTO:
                 fr[1].type = I
             return
@@ -175,11 +296,13 @@ class Lookahead:
                     fr[j].type = P
                     num_analysed = j
                     break
-            reset_start = min(num_bframes + 2, num_analysed + 1)
+            reset_start = 1 if keyframe else min(num_bframes + 2, num_analysed + 1)
         else:
             for j in range(1, num_frames + 1):
                 fr[j].type = P
-            reset_start = 2
+            reset_start = 1 if keyframe else 2
+        if p.mbtree:
+            self.macroblock_tree(fr, min(num_frames, p.keyint), keyframe)
         # enforce the keyframe limit
         last_keyframe, last_possible = self.last_keyframe, 0
         j = 1
@@ -271,7 +394,7 @@ class Lookahead:
             f.type = IDR if getattr(f, "pinned_idr", False) else AUTO
         if self.next[0].type == IDR:
             return 0, IDR
-        if self.last_nonb is not None and ((p.bframes and p.b_adapt) or p.scenecut):
+        if self.last_nonb is not None and ((p.bframes and p.b_adapt) or p.scenecut or p.mbtree):
             self.analyse(min(n, wait + 1))
         bfr = 0
         while True:
@@ -306,7 +429,9 @@ class RateControl:
         self.cplxsum = self.cplxcount = 0.0
         dur = min(max(1.0 / p.fps, 0.01), 1.0)                      # CLIP_DURATION
         self.dur_ratio = dur / 0.04                                   # BASE_FRAME_DURATION
-        self.rate_factor_constant = (p.mbw * p.mbh * (120.0 if p.bframes else 80.0)) ** (1.0 - p.qcomp) / qp2qscale(p.crf)
+        # x264_ratecontrol_new: under macroblock-tree qcompress = 1 (the tree does the complexity weighting) and CRF shifts by 13.5 (1 - qcomp)
+        self.qcompress = 1.0 if p.mbtree else p.qcomp
+        self.rate_factor_constant = (p.mbw * p.mbh * (120.0 if p.bframes else 80.0)) ** (1.0 - self.qcompress) / qp2qscale(p.crf + ((1.0 - p.qcomp) * 13.5 if p.mbtree else 0.0))
         self.ip_offset = 6.0 * _libm.log2f(p.ip_factor)             # x264_ratecontrol_init_reconfigurable: 6.0 * log2f( f_ip_factor )
         self.pb_offset = 6.0 * _libm.log2f(p.pb_factor)
         self.accum_p_qp = self.accum_p_norm = 0.0
@@ -324,12 +449,14 @@ class RateControl:
         self.cplxsum = self.cplxsum * 0.5 + satd / self.dur_ratio
         self.cplxcount = self.cplxcount * 0.5 + 1.0
         if satd > 0:
-            q = _f((self.cplxsum / self.cplxcount) ** (1.0 - p.qcomp) / self.rate_factor_constant)          # (rate_estimate_qscale's q is a float: every assignment rounds)
+            # get_qscale: under macroblock-tree the frame-duration term alone
+            rceq = (1.0 / self.dur_ratio) ** (1.0 - p.qcomp) if p.mbtree else (self.cplxsum / self.cplxcount) ** (1.0 - self.qcompress)
+            q = _f(rceq / self.rate_factor_constant)          # (rate_estimate_qscale's q is a float: every assignment rounds)
         else:
             q = _f(self.last_qscale_for[0 if is_i else 1])
         if is_i and p.keyint > 1 and not self.last_non_b_is_i:
             q = _f(qp2qscale(self.accum_p_qp / self.accum_p_norm) / p.ip_factor)
-        elif self.frames_done == 0 and p.qcomp != 1.0:
+        elif self.frames_done == 0 and self.qcompress != 1.0:
             q = _f(qp2qscale(p.crf) / p.ip_factor)
         q = _f(min(max(q, qp2qscale(p.qpmin)), qp2qscale(p.qpmax)))
         self.last_qscale_for[0 if is_i else 1] = q
@@ -375,14 +502,18 @@ class RateControl:
         return min(max(int(q + 0.5), p.qpmin), p.qpmax), q
 
 
-def run_session(frames, params, costs, slots):
-    """the pictures of `frames` (display order, I420 arrays) through the decisions: -> [(display index, type, qp, float qp)] in coding order.
-    costs: tests/oracle_lib.OracleSlicetype created with `slots` slots; the twin puts every picture into slot (index mod slots)"""
+def run_session(frames, params, costs, slots, aq_of=None):
+    """the pictures of `frames` (display order, I420 arrays) through the decisions: -> [(display index, type, qp, float qp, offsets)] in coding order;
+    offsets: the per-macroblock quantiser offsets the picture is coded with (float32 array; None when the session has neither tree nor AQ).
+    costs: tests/oracle_lib.OracleSlicetype created with `slots` slots (do_edges = 1 for a macroblock-tree session); the twin puts every picture into
+    slot (index mod slots).  aq_of(i420) -> the picture's AQ offsets (oracle_lib.aq_offsets with params.aq_strength) for sessions with AQ"""
     p = params
     la, rc = Lookahead(p, costs), RateControl(p)
     wait = p.bframes                                    # h->frames.i_delay without macroblock-tree: the run length
     if p.b_adapt == 2 and p.bframes:
         wait = max(p.bframes, 3) * 4                    # ... B_ADAPT_TRELLIS: the window of its path search
+    if p.mbtree:
+        wait = max(wait, p.rc_lookahead)                # ... and the tree's window
     out = []
     kept = {}                                           # display index -> (type, float qp) of the pictures kept as references
 
@@ -400,7 +531,7 @@ def run_session(frames, params, costs, slots):
             pcost = costs.cost(la.last_nonb.slot, closer.slot, closer.slot, closer.frame - la.last_nonb.frame, 0)
         is_i = closing in (I, IDR)
         qp, qpf = rc.nonb(is_i, icost if is_i else pcost)
-        out.append((closer.frame, closing, qp, qpf))
+        coded = [(closer, closing, qp, qpf)]
         kept[closer.frame] = (closing, qpf)
         la.last_nonb = closer
         bref = (j - 1) // 2 if p.b_pyramid and j > 1 else -1
@@ -409,17 +540,41 @@ def run_session(frames, params, costs, slots):
             t = BREF if i == bref else B
             before, after = max(k for k in kept if k < f.frame), min(k for k in kept if k > f.frame)        # nearest references in display order
             q, qf = rc.b(2 * f.frame, (2 * before,) + kept[before], (2 * after,) + kept[after], t == BREF)
-            out.append((f.frame, t, q, qf))
+            coded.append((f, t, q, qf))
             if t == BREF:
                 kept[f.frame] = (BREF, qf)
         del la.next[:j + 1]
+        if p.mbtree and is_i:
+            # lookahead_slicetype_decide: "for MB-tree, we have to perform propagation analysis on I-frames too" — the analysis again with the keyframe as frames[0]
+            for f in la.next:
+                f.type = IDR if getattr(f, "pinned_idr", False) else AUTO
+            closer.type = closing
+            framecnt = max(min(len(la.next), wait + 1 - (j + 1)), 0)
+            if framecnt > 0:
+                la.analyse(framecnt, True)
+            else:
+                la.macroblock_tree([closer], 0, True)
+        # x264_ratecontrol_mb_qp: kept pictures read f_qp_offset (what the tree left), the other B pictures f_qp_offset_aq
+        for f, t, q, qf in coded:
+            off = (f.aq if t == B else f.tree) if (p.mbtree or p.aq_strength) else None
+            out.append((f.frame, t, q, qf, off))
         return True
 
     for i, _ in enumerate(frames):
         costs.put(i % slots, frames[i])
-        la.next.append(Frame(i, i % slots))
+        fr = Frame(i, i % slots)
+        fr.raw = frames[i]
+        if p.mbtree or p.aq_strength:
+            fr.aq = aq_of(frames[i]) if p.aq_strength else None
+            if p.mbtree:
+                costs.set_aq(fr.slot, fr.aq)
+            import numpy as _np
+            fr.aq = fr.aq if fr.aq is not None else _np.zeros(p.mbw * p.mbh, _np.float32)
+            fr.tree = fr.aq
+        la.next.append(fr)
         while code_run(False):
             pass
     while la.next and code_run(True):
         pass
+    run_session.last_stats = la.stats
     return out

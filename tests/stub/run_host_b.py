@@ -93,7 +93,7 @@ def main():
     print(json.dumps({"recs": recs, "bframes": eff.i_bframe, "pyramid": eff.i_bframe_pyramid, "badapt": eff.i_bframe_adaptive, "weightb": eff.analyse.b_weighted_bipred,
                       "weightp": eff.analyse.i_weighted_pred, "mbtree": eff.rc.b_mb_tree, "subme": eff.analyse.i_subpel_refine, "cabac": eff.b_cabac, "direct": eff.analyse.i_direct_mv_pred, "first_output_after": first_out, "log": log,
                       "rc_method": eff.rc.i_rc_method, "stat_read": eff.rc.b_stat_read, "stat_write": eff.rc.b_stat_write, "inter": eff.analyse.inter, "refs": eff.i_frame_reference,
-                      "me": eff.analyse.i_me_method, "trellis": eff.analyse.i_trellis}))
+                      "me": eff.analyse.i_me_method, "trellis": eff.analyse.i_trellis, "mv_range": eff.analyse.i_mv_range, "me_range": eff.analyse.i_me_range}))
 
 
 if __name__ == "__main__":

@@ -19,7 +19,7 @@ sys.path.insert(0, os.path.join(os.path.dirname(HERE), "oracle"))
 import decide as D  # noqa: E402
 
 
-def host_session(tmp_path, w, h, n, seed, opts):
+def host_session(tmp_path, w, h, n, seed, opts, offsets=False):
     subprocess.check_call(["make", "-s", "-C", os.path.join(HERE, "stub")])
     dump = tmp_path / "dump"
     dump.mkdir()
@@ -28,11 +28,13 @@ def host_session(tmp_path, w, h, n, seed, opts):
                        capture_output=True, text=True, timeout=900, env=env)
     assert r.returncode == 0, r.stderr[-2000:]
     info = json.loads(r.stdout.strip().splitlines()[-1])
-    pics = []
+    pics, offs = [], []
+    nmb = ((w + 15) // 16) * ((h + 15) // 16)
     for k in range(n):
-        raw = (dump / f"pic{k:04d}.bin").read_bytes()[:C.sizeof(Pic)]
-        pics.append(Pic.from_buffer_copy(raw))
-    return info, pics
+        raw = (dump / f"pic{k:04d}.bin").read_bytes()
+        pics.append(Pic.from_buffer_copy(raw[:C.sizeof(Pic)]))
+        offs.append(np.frombuffer(raw[-4 * nmb:], np.float32))          # the per-macroblock quantiser offsets handed to the device (zeros: none)
+    return (info, pics, offs) if offsets else (info, pics)
 
 
 @pytest.mark.parametrize("w,h,n,seed,scene,kind,opts,kw", [
@@ -53,16 +55,58 @@ def test_decisions_equal_the_twin(tmp_path, w, h, n, seed, scene, kind, opts, kw
     frames = make_frames(w, h, n, seed, scene_len=scene, static=int(kind == "static"))
     p = D.Params((w + 15) // 16, (h + 15) // 16, **kw)
     slots = 64
-    st = O.OracleSlicetype(w, h, slots=slots, bframes=max(p.bframes, 1), subme=7)
+    st = O.OracleSlicetype(w, h, slots=slots, bframes=max(p.bframes, 1), me_method=info["me"], subme=info["subme"], me_range=info["me_range"], mv_range=info["mv_range"])
     twin = D.run_session(frames, p, st, slots)
     st.close()
     got = [(r[1], r[0]) for r in info["recs"]]                                   # (display index, x264 type) in coding order
-    want = [(f, t) for f, t, _, _ in twin]
+    want = [(f, t) for f, t, _, _, _ in twin]
     assert got == want, f"picture types: session {got} twin {want}"
     assert len({t for _, t in want}) >= 2
-    for k, ((f, t, qp, qpf), pic) in enumerate(zip(twin, pics)):
+    for k, ((f, t, qp, qpf, _off), pic) in enumerate(zip(twin, pics)):
         assert pic.qp == qp, f"coded picture {k} (display {f}, type {t}): quantiser {pic.qp} vs the twin's {qp} ({qpf:.3f})"
         assert pic.qpm == np.float32(qpf), (k, pic.qp, pic.qpm, qpf)          # the device gets x264's float quantiser (rc->qpm) as it is
+
+
+DEFAULT_CASES = [
+    # the driver's default session (codec.c:1504-1507, config.c:109-111): CRF + AQ mode 1 + macroblock-tree + b-adapt 1 + weightp 2, a short and the real rc-lookahead
+    (176, 144, 40, 3, 14, "moving", 0, ["crf=23", "keyint=250", "rc-lookahead=10"], dict(crf=23.0, keyint=250, rc_lookahead=10, weightp=2)),
+    (176, 144, 60, 5, 23, "moving", 0, ["crf=23", "keyint=250", "rc-lookahead=40"], dict(crf=23.0, keyint=250, rc_lookahead=40, weightp=2)),
+    (208, 112, 36, 7, 0, "moving", 4, ["crf=21", "keyint=30", "rc-lookahead=12"], dict(crf=21.0, keyint=30, rc_lookahead=12, weightp=2)),          # a fade: lookahead weights; the keyint limit
+    (176, 144, 30, 9, 11, "moving", 4, ["crf=24", "keyint=250", "rc-lookahead=8", "weightp=0"], dict(crf=24.0, keyint=250, rc_lookahead=8, weightp=0)),  # X264_WEIGHTP_FAKE: the fade's weightdelta
+    (176, 144, 30, 11, 0, "static", 0, ["crf=25", "keyint=250", "rc-lookahead=6", "b-pyramid=none", "qcomp=0.7", "aq-strength=0.8"],
+     dict(crf=25.0, keyint=250, rc_lookahead=6, weightp=2, b_pyramid=0, qcomp=0.7, aq=0.8)),
+]
+
+
+@pytest.mark.parametrize("w,h,n,seed,scene,kind,fade,opts,kw", DEFAULT_CASES)
+def test_default_session_equals_the_twin(tmp_path, w, h, n, seed, scene, kind, fade, opts, kw):
+    """the DEFAULT session against the twin: picture types, integer and float quantisers and the per-macroblock quantiser offsets (AQ - macroblock-tree for the
+    pictures kept as references, AQ for the others) of every coded picture, float for float"""
+    sys.path.insert(0, os.path.join(HERE, "stub"))
+    from run_host_b import make_frames
+    info, pics, offs = host_session(tmp_path, w, h, n, seed, opts + ([f"scene_len={scene}"] if scene else []) + (["static=1"] if kind == "static" else []) + ([f"fade={fade}"] if fade else []), offsets=True)
+    frames = make_frames(w, h, n, seed, scene_len=scene, static=int(kind == "static"), fade=fade)
+    aqs = kw.pop("aq", 1.0)
+    strength = float(np.float32(aqs) * np.float32(1.0397))
+    p = D.Params((w + 15) // 16, (h + 15) // 16, mbtree=True, aq_strength=strength, **kw)
+    slots = 128
+    # (the lookahead searches within the session's effective --mvrange: the level's limit at this picture size)
+    st = O.OracleSlicetype(w, h, slots=slots, bframes=max(p.bframes, 1), me_method=info["me"], subme=info["subme"], me_range=info["me_range"], mv_range=info["mv_range"], do_edges=1)
+    twin = D.run_session(frames, p, st, slots, aq_of=lambda f: O.aq_offsets(f, w, h, strength))
+    st.close()
+    got = [(r[1], r[0]) for r in info["recs"]]
+    want = [(f, t) for f, t, _, _, _ in twin]
+    assert got == want, f"picture types: session {got} twin {want}"
+    assert {3, 5} <= {t for _, t in want}          # P and B pictures at least
+    moved = 0
+    for k, ((f, t, qp, qpf, off), pic) in enumerate(zip(twin, pics)):
+        assert pic.qp == qp and pic.qpm == np.float32(qpf), f"coded picture {k} (display {f}, type {t}): quantiser {pic.qp} / {pic.qpm} vs the twin's {qp} / {qpf}"
+        assert offs[k].tobytes() == np.asarray(off, np.float32).tobytes(), f"coded picture {k} (display {f}, type {t}): offsets differ at {np.nonzero(offs[k] != off)[0][:6]}"
+        moved += int(t != 5 and (off != O.aq_offsets(frames[f], w, h, strength)).any())
+    assert moved >= 3, "the tree moved nothing"
+    if fade:          # the fade is seen by the lookahead's weight analysis; without --weightp it still enters the tree as the weightdelta (X264_WEIGHTP_FAKE)
+        assert D.run_session.last_stats["lookahead_weights"] >= 3, D.run_session.last_stats
+        assert (D.run_session.last_stats["weightdelta"] >= 2) == (kw["weightp"] == 0), D.run_session.last_stats
 
 
 def test_fade_weights_are_the_fades_ratio(tmp_path):

@@ -944,6 +944,22 @@ def _session_equals_checker(tmp_path, w, h, nfr, opts, seed, scene, kind):
     assert open(out, "rb").read() == stream, tag
 
 
+@pytest.mark.parametrize("w,h,nfr,seed,scene,kind,opts", [
+    # (bframes / weightp named because this file's open_encoder switches them off otherwise: they are medium's own values)
+    (176, 144, 60, 5, 23, "moving", {"crf": 23, "keyint": 250, "rc-lookahead": 40, "bframes": 3, "weightp": 2}),          # = tests/test_decisions_cpu.py DEFAULT_CASES[1]
+    (208, 112, 36, 7, 0, "fade", {"crf": 21, "keyint": 30, "rc-lookahead": 12, "bframes": 3, "weightp": 2}),               # ... [2]: lookahead weights on a fade, the keyint limit
+    (176, 144, 30, 9, 11, "fade", {"crf": 24, "keyint": 250, "rc-lookahead": 8, "bframes": 3, "weightp": 0}),            # ... [3]: X264_WEIGHTP_FAKE: the tree's weightdelta
+])
+def test_default_sessions_equal_the_checker_sessions(gpu, tmp_path, w, h, nfr, seed, scene, kind, opts):
+    """the driver's DEFAULT session (codec.c:1504-1507, config.c:109-111: CRF 23 + AQ mode 1 + macroblock-tree over rc-lookahead 40 + b-adapt 1 + weightp 2) on
+    the device against the same host code over the CPU checker: same picture types, timestamps and bytes — i.e. the same float quantisers and per-macroblock
+    quantisers, which tests/test_decisions_cpu.py test_default_session_equals_the_twin compares float for float with the decision twin on the same clips"""
+    import os
+    import subprocess
+    subprocess.check_call(["make", "-s", "-C", os.path.join(os.path.dirname(os.path.abspath(__file__)), "stub")])
+    _session_equals_checker(tmp_path, w, h, nfr, opts, seed, scene, kind)
+
+
 def test_random_b_sessions_equal_the_checker_sessions(gpu, tmp_path):
     """the same host code over the device and over the CPU checker (tests/stub: the oracle behind the device ABI, in a child process) must write
     the same bytes for the same session: every device primitive a session touches — lookahead frame costs of (p0, p1, b) triples, weight analysis,

@@ -1927,9 +1927,11 @@ static int encode_bmode(x264_t *h, x264_nal_t **pp_nal, int *pi_nal, x264_pictur
         x264gpu_encoder_set_lowres_mvs(h->gpu, m0);
         x264gpu_encoder_set_lowres_mvs1(h->gpu, m1);
     }
+    const float *d_offsets = nullptr;
     if (h->st && h->mbtree)          // P / I / B-reference pictures: what the tree left (AQ - tree); other B pictures: the AQ offsets alone (x264 f_qp_offset_aq)
-        x264gpu_encoder_set_mb_qp_offsets(h->gpu, pl.type == PIC_B ? h->q_aq[(size_t)pl.e.slot] : h->q_tree[(size_t)pl.e.slot]);
-    else if (h->aq_mode >= 2 && h->aq_strength != 0.f) x264gpu_encoder_set_mb_qp_offsets(h->gpu, h->q_aq[(size_t)pl.e.slot]);      // --aq-mode 2 / 3: the offsets computed when the picture arrived
+        d_offsets = pl.type == PIC_B ? h->q_aq[(size_t)pl.e.slot] : h->q_tree[(size_t)pl.e.slot];
+    else if (h->aq_mode >= 2 && h->aq_strength != 0.f) d_offsets = h->q_aq[(size_t)pl.e.slot];      // --aq-mode 2 / 3: the offsets computed when the picture arrived
+    if (d_offsets) x264gpu_encoder_set_mb_qp_offsets(h->gpu, d_offsets);
     if (h->batch) {
         std::string berr;
         if (batch_encode(h->batch, h->batch_idx, h->q_raw[(size_t)pl.e.slot], pic, h->h_mb.data(), h->h_lv.data(), berr)) {
@@ -1953,6 +1955,9 @@ static int encode_bmode(x264_t *h, x264_nal_t **pp_nal, int *pi_nal, x264_pictur
             fwrite(&pic, sizeof(pic), 1, f);
             fwrite(h->h_mb.data(), sizeof(x264gpu_mb), h->h_mb.size(), f);
             fwrite(h->h_lv.data(), sizeof(int16_t), h->h_lv.size(), f);
+            std::vector<float> off((size_t)h->nmb, 0.f);          // ... and the per-macroblock quantiser offsets it was coded with (zeros: none handed in)
+            if (d_offsets) x264gpu_memcpy_d2h(off.data(), d_offsets, off.size() * sizeof(float), nullptr);
+            fwrite(off.data(), sizeof(float), off.size(), f);
             fclose(f);
         }
     }
