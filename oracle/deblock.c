@@ -33,7 +33,7 @@ void x264o_deblock_luma_edge(pixel *pix, int xs, int ys, int lines, int alpha, i
         int ap = abs(p2 - p0), aq = abs(q2 - q0);
         if (bs < 4) {
             int tc = tc0 + (ap < beta) + (aq < beta);
-            int delta = clip3((((q0 - p0) << 2) + (p1 - q1) + 4) >> 3, -tc, tc);
+            int delta = clip3((((q0 - p0) * 4) + (p1 - q1) + 4) >> 3, -tc, tc);
             if (ap < beta) pix[-2 * xs] = (pixel)(p1 + clip3((p2 + ((p0 + q0 + 1) >> 1) - (p1 << 1)) >> 1, -tc0, tc0));
             if (aq < beta) pix[xs] = (pixel)(q1 + clip3((q2 + ((p0 + q0 + 1) >> 1) - (q1 << 1)) >> 1, -tc0, tc0));
             pix[-xs] = clip_pixel(p0 + delta);
@@ -66,7 +66,7 @@ void x264o_deblock_chroma_edge(pixel *pix, int xs, int ys, int lines, int alpha,
         if (abs(p0 - q0) >= alpha || abs(p1 - p0) >= beta || abs(q1 - q0) >= beta) continue;
         if (bs < 4) {
             int tc = tc0 + 1;
-            int delta = clip3((((q0 - p0) << 2) + (p1 - q1) + 4) >> 3, -tc, tc);
+            int delta = clip3((((q0 - p0) * 4) + (p1 - q1) + 4) >> 3, -tc, tc);
             pix[-xs] = clip_pixel(p0 + delta);
             pix[0] = clip_pixel(q0 - delta);
         } else {

@@ -231,7 +231,7 @@ int x264o_lookahead_frame_cost(x264o_lookahead *la, const uint8_t *i420, int res
                 }
                 if (!(icost < pcost)) { bcost = pcost; intra = 0; cmv[bi][0] = (int16_t)mv[0]; cmv[bi][1] = (int16_t)mv[1]; cin[bi] = 1; }
             }
-            if (block_info) { block_info[4 * bi] = icost; block_info[4 * bi + 1] = bcost; block_info[4 * bi + 2] = (cmv[bi][0] & 0xffff) | (cmv[bi][1] << 16); block_info[4 * bi + 3] = !intra; }
+            if (block_info) { block_info[4 * bi] = icost; block_info[4 * bi + 1] = bcost; block_info[4 * bi + 2] = (cmv[bi][0] & 0xffff) | (int32_t)((uint32_t)cmv[bi][1] << 16); block_info[4 * bi + 3] = !intra; }
             if (score) { isum += icost; psum += bcost; nintra += intra && la->have_prev; nscore++; }
         }
     out[0] = (int32_t)isum; out[1] = (int32_t)psum; out[2] = nintra; out[3] = nscore;

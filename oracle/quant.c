@@ -107,7 +107,7 @@ void x264o_dequant_4x4(dctcoef d[16], const int32_t dq[6][16], int qp)
 {
     int m = qp % 6, s = qp / 6 - 4;
     for (int i = 0; i < 16; i++)
-        d[i] = (dctcoef)(s >= 0 ? (d[i] * dq[m][i]) << s : (d[i] * dq[m][i] + (1 << (-s - 1))) >> -s);
+        d[i] = (dctcoef)(s >= 0 ? (d[i] * dq[m][i]) * (1 << s) : (d[i] * dq[m][i] + (1 << (-s - 1))) >> -s);
 }
 
 /* 8.5.13 scaling for 8x8 blocks */
@@ -115,7 +115,7 @@ void x264o_dequant_8x8(dctcoef d[64], const int32_t dq[6][64], int qp)
 {
     int m = qp % 6, s = qp / 6 - 6;
     for (int i = 0; i < 64; i++)
-        d[i] = (dctcoef)(s >= 0 ? (d[i] * dq[m][i]) << s : (d[i] * dq[m][i] + (1 << (-s - 1))) >> -s);
+        d[i] = (dctcoef)(s >= 0 ? (d[i] * dq[m][i]) * (1 << s) : (d[i] * dq[m][i] + (1 << (-s - 1))) >> -s);
 }
 
 /* 8.5.10: Intra16x16 luma DC scaling (input already inverse-Hadamard transformed) */
@@ -123,7 +123,7 @@ void x264o_dequant_4x4_dc(dctcoef d[16], const int32_t dq[6][16], int qp)
 {
     int ls = dq[qp % 6][0], s = qp / 6 - 6;
     for (int i = 0; i < 16; i++)
-        d[i] = (dctcoef)(s >= 0 ? (d[i] * ls) << s : (d[i] * ls + (1 << (-s - 1))) >> -s);
+        d[i] = (dctcoef)(s >= 0 ? (d[i] * ls) * (1 << s) : (d[i] * ls + (1 << (-s - 1))) >> -s);
 }
 
 /* 8.5.11.2 (4:2:0): f = H c H, dcC = ((f * LevelScale(qp%6,0,0)) << (qp/6)) >> 5 */
