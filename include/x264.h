@@ -166,6 +166,7 @@ typedef struct x264_param_t {
         int b_stat_read;
         char *psz_stat_in;
         float f_qcompress, f_qblur, f_complexity_blur;
+        char *psz_zones;               /* --zones <start>,<end>,q=<qp> | b=<bitrate factor> [ / ... ] (x264_param_parse; reaches the driver through its extra command line, codec.c:831-999) */
     } rc;
     int b_aud, b_repeat_headers, b_annexb;      /* codec.c:1611-1615 */
     int i_sps_id;

@@ -45,7 +45,7 @@ def qscale2qp(qscale):
 
 class Params:
     def __init__(self, mbw, mbh, keyint=250, min_keyint=0, scenecut=40, bframes=3, b_adapt=1, b_pyramid=1, b_bias=0, crf=23.0, qcomp=0.6, ip_factor=1.4,
-                 pb_factor=1.3, qpmin=0, qpmax=51, fps=25.0, mbtree=False, aq_strength=0.0, weightp=0, rc_lookahead=0, psy=True):
+                 pb_factor=1.3, qpmin=0, qpmax=51, fps=25.0, mbtree=False, aq_strength=0.0, weightp=0, rc_lookahead=0, psy=True, zones=()):
         self.mbw, self.mbh = mbw, mbh
         self.keyint, self.scenecut, self.bframes, self.b_adapt, self.b_pyramid, self.b_bias = keyint, scenecut, bframes, b_adapt, b_pyramid, b_bias
         if min_keyint <= 0:          # validate_parameters: auto = min(keyint / 10, fps), then [1, keyint / 2 + 1]
@@ -54,6 +54,7 @@ class Params:
         # the default session: macroblock-tree over rc_lookahead pictures, AQ mode 1 (aq_strength = --aq-strength x 1.0397f; 0 = off), --weightp
         self.mbtree, self.aq_strength, self.weightp, self.rc_lookahead, self.psy = mbtree, _f(aq_strength), weightp, rc_lookahead, psy
         self.weightp_fake = not weightp and mbtree and psy          # validate_parameters: X264_WEIGHTP_FAKE
+        self.zones = list(zones)           # --zones: (start, end, 'q', qp) or (start, end, 'b', bitrate factor), display indices; the last one that holds a picture wins
         self.tree_strength = _f(_f(5.0) * _f(_f(1.0) - _f(qcomp)))   # macroblock_tree_finish: 5.0f * (1.0f - f_qcompress)
         # (x264_param_t carries these as single floats: the doubles of the rate control start from the float's value)
         self.crf, self.qcomp, self.ip_factor, self.pb_factor, self.qpmin, self.qpmax, self.fps = _f(crf), _f(qcomp), _f(ip_factor), _f(pb_factor), qpmin, qpmax, fps
@@ -443,8 +444,8 @@ class RateControl:
         self.accum_p_qp = self.accum_p_qp * 0.95 + (qp + self.ip_offset if is_i else qp)
         self.accum_p_norm = self.accum_p_norm * 0.95 + 1.0
 
-    def nonb(self, is_i, satd):
-        """-> (integer quantiser, float quantiser) of an I or P picture whose frame cost is satd"""
+    def nonb(self, is_i, satd, frame=-1):
+        """-> (integer quantiser, float quantiser) of an I or P picture (display index `frame`) whose frame cost is satd"""
         p = self.p
         self.cplxsum = self.cplxsum * 0.5 + satd / self.dur_ratio
         self.cplxcount = self.cplxcount * 0.5 + 1.0
@@ -454,6 +455,11 @@ class RateControl:
             q = _f(rceq / self.rate_factor_constant)          # (rate_estimate_qscale's q is a float: every assignment rounds)
         else:
             q = _f(self.last_qscale_for[0 if is_i else 1])
+        # get_qscale: a zone forces its quantiser or scales the picture's bits
+        for z in reversed(p.zones):
+            if z[0] <= frame <= z[1]:
+                q = _f(qp2qscale(z[3]) if z[2] == 'q' else q / _f(z[3]))
+                break
         if is_i and p.keyint > 1 and not self.last_non_b_is_i:
             q = _f(qp2qscale(self.accum_p_qp / self.accum_p_norm) / p.ip_factor)
         elif self.frames_done == 0 and self.qcompress != 1.0:
@@ -530,7 +536,7 @@ def run_session(frames, params, costs, slots, aq_of=None):
         if closing == P and la.last_nonb is not None:
             pcost = costs.cost(la.last_nonb.slot, closer.slot, closer.slot, closer.frame - la.last_nonb.frame, 0)
         is_i = closing in (I, IDR)
-        qp, qpf = rc.nonb(is_i, icost if is_i else pcost)
+        qp, qpf = rc.nonb(is_i, icost if is_i else pcost, closer.frame)
         coded = [(closer, closing, qp, qpf)]
         kept[closer.frame] = (closing, qpf)
         la.last_nonb = closer

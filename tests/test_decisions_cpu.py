@@ -22,7 +22,7 @@ import decide as D  # noqa: E402
 def host_session(tmp_path, w, h, n, seed, opts, offsets=False):
     subprocess.check_call(["make", "-s", "-C", os.path.join(HERE, "stub")])
     dump = tmp_path / "dump"
-    dump.mkdir()
+    dump.mkdir(exist_ok=True)
     env = dict(os.environ, X264GPU_DUMP_RECORDS=str(dump))
     r = subprocess.run([sys.executable, os.path.join(HERE, "stub", "run_host_b.py"), str(tmp_path / "s.h264"), str(w), str(h), str(n), str(seed)] + opts,
                        capture_output=True, text=True, timeout=900, env=env)
@@ -107,6 +107,39 @@ def test_default_session_equals_the_twin(tmp_path, w, h, n, seed, scene, kind, f
     if fade:          # the fade is seen by the lookahead's weight analysis; without --weightp it still enters the tree as the weightdelta (X264_WEIGHTP_FAKE)
         assert D.run_session.last_stats["lookahead_weights"] >= 3, D.run_session.last_stats
         assert (D.run_session.last_stats["weightdelta"] >= 2) == (kw["weightp"] == 0), D.run_session.last_stats
+
+
+def test_zones_move_the_quantisers(tmp_path):
+    """--zones (x264 get_zone / get_qscale / the constant-quantiser branch of x264_ratecontrol_start; reaches the driver through its extra command line, codec.c:831-999):
+    under CRF the non-B pictures inside a zone take its quantiser (q=) or bitrate_factor times their bits (b=) — equal to the twin picture by picture, the B pictures
+    following from their references; under constant quantiser a zone shifts every picture type by (its qp - the P quantiser) or by -6 log2f(factor)"""
+    sys.path.insert(0, os.path.join(HERE, "stub"))
+    from run_host_b import make_frames
+    w, h, n, seed = 176, 144, 30, 21
+    opts = ["crf=24", "keyint=250", "no-mbtree", "aq-mode=0", "weightp=0", "rc-lookahead=0", "zones=4,9,q=31/14,22,b=0.4/20,22,q=18"]
+    info, pics = host_session(tmp_path, w, h, n, seed, opts)
+    frames = make_frames(w, h, n, seed)
+    p = D.Params((w + 15) // 16, (h + 15) // 16, crf=24.0, keyint=250, zones=[(4, 9, 'q', 31), (14, 22, 'b', 0.4), (20, 22, 'q', 18)])
+    st = O.OracleSlicetype(w, h, slots=64, bframes=3, me_method=info["me"], subme=info["subme"], me_range=info["me_range"], mv_range=info["mv_range"])
+    twin = D.run_session(frames, p, st, 64)
+    st.close()
+    assert [(r[1], r[0]) for r in info["recs"]] == [(f, t) for f, t, _, _, _ in twin]
+    seen = {"q31": 0, "q18": 0, "b": 0, "out": 0}
+    for (f, t, qp, qpf, _off), pic in zip(twin, pics):
+        assert pic.qp == qp and pic.qpm == np.float32(qpf), (f, t, pic.qp, pic.qpm, qp, qpf)
+        if t == 3:          # P pictures: the zone's own quantiser, or 0.4 times the bits = the quantiser scale / 0.4 = 7.9 quantiser steps up
+            if 4 <= f <= 9: assert qp == 31; seen["q31"] += 1
+            elif 20 <= f <= 22: assert qp == 18; seen["q18"] += 1
+            elif 14 <= f <= 19: assert qp >= 32; seen["b"] += 1
+            else: assert 25 <= qp <= 30; seen["out"] += 1
+    assert all(seen.values()), seen
+    # constant quantiser
+    info, pics = host_session(tmp_path, w, h, 16, seed, ["qp=26", "keyint=250", "bframes=2", "b-adapt=0", "b-pyramid=none", "scenecut=0", "zones=3,8,q=20/9,12,b=2"])
+    order = [r[1] for r in info["recs"]]
+    for f, t, pic in zip(order, [r[0] for r in info["recs"]], pics):
+        base = {1: 23, 3: 26, 5: 28}[t]          # ipratio 1.4 -> -3, pbratio 1.3 -> +2
+        want = base + (20 - 26) if 3 <= f <= 8 else int(np.float32(base) - np.float32(6.0) * np.float32(np.log2(np.float32(2.0))) + np.float32(0.5)) if 9 <= f <= 12 else base
+        assert pic.qp == want, (f, t, pic.qp, want)
 
 
 def test_fade_weights_are_the_fades_ratio(tmp_path):

@@ -84,6 +84,8 @@ struct x264_t {
     int device = 0;
     std::vector<float> gop_qpm;          // ... and its float quantiser (x264 rc->qpm)
     std::vector<int8_t> gop_qp;          // GOP-parallel CRF: the quantiser of every ring picture (slot * keyint + position), decided on arrival
+    struct Zone { int start, end; bool force_qp; int qp; float bitrate_factor; };      // x264_zone_t: pictures start..end (display order) at quantiser qp, or at bitrate_factor times their bits
+    std::vector<Zone> zones;
     float last_qpm = 0.f;                // ... and its float quantiser as the device got it (x264 rc->qpm; 0 = the integer one)
     int last_qp = 0, last_scenecut = 0;  // diagnostics: quantiser and scenecut flag of the last coded picture
     int32_t last_costs[4] = { 0, 0, 0, 0 };
@@ -304,6 +306,45 @@ static void xlog(const x264_param_t *p, int level, const char *fmt, ...)
 }
 
 static int clampi(int v, int lo, int hi) { return v < lo ? lo : v > hi ? hi : v; }
+// get_zone ([x264-upstream] encoder/ratecontrol.c): the LAST zone that holds the picture (display index) wins
+static const x264_t::Zone *get_zone(const x264_t *h, int frame)
+{
+    for (size_t i = h->zones.size(); i-- > 0;) if (frame >= h->zones[i].start && frame <= h->zones[i].end) return &h->zones[i];
+    return nullptr;
+}
+// parse_zones / parse_zone: "<start>,<end>,q=<int>" or "<start>,<end>,b=<float>", zones separated by '/'.  (x264 also lets a zone carry other options after
+// the first; those reconfigure the encoder for the zone's pictures and are not implemented: said in the log, the zone keeps its quantiser part)
+static void parse_zones(x264_t *h, const char *str)
+{
+    if (!str || !*str) return;
+    std::string all(str);
+    size_t pos = 0;
+    while (pos <= all.size()) {
+        const size_t e = all.find('/', pos);
+        const std::string z = all.substr(pos, e == std::string::npos ? std::string::npos : e - pos);
+        pos = e == std::string::npos ? all.size() + 1 : e + 1;
+        if (z.empty()) continue;
+        x264_t::Zone zn = { 0, 0, false, 0, 1.f };
+        int len = 0;
+        if (sscanf(z.c_str(), "%d,%d,q=%d%n", &zn.start, &zn.end, &zn.qp, &len) >= 3) zn.force_qp = true;
+        else if (sscanf(z.c_str(), "%d,%d,b=%f%n", &zn.start, &zn.end, &zn.bitrate_factor, &len) >= 3) zn.force_qp = false;
+        else if (sscanf(z.c_str(), "%d,%d%n", &zn.start, &zn.end, &len) >= 2) zn.bitrate_factor = 1.f;
+        else { xlog(&h->param, X264_LOG_ERROR, "invalid zone: \"%s\"\n", z.c_str()); continue; }
+        if (zn.start > zn.end) { xlog(&h->param, X264_LOG_ERROR, "invalid zone: start=%d end=%d\n", zn.start, zn.end); continue; }
+        if (!zn.force_qp && zn.bitrate_factor <= 0) { xlog(&h->param, X264_LOG_ERROR, "invalid zone: bitrate_factor=%f\n", zn.bitrate_factor); continue; }
+        if ((size_t)len < z.size()) xlog(&h->param, X264_LOG_WARNING, "zone %d,%d: per-zone encoder options (\"%s\") are not implemented in the MI355X path: the zone keeps its quantiser / bitrate part only\n", zn.start, zn.end, z.c_str() + len);
+        h->zones.push_back(zn);
+    }
+}
+// x264_ratecontrol_start, constant quantiser: a zone shifts the picture's quantiser by (its qp - the P quantiser), or by -6 log2f(bitrate factor)
+static int cqp_zone(const x264_t *h, const x264_t::Zone &z, int q)
+{
+    float qf = (float)q;
+    if (z.force_qp) qf += (float)(z.qp - h->qp_p); else qf -= 6.f * log2f(z.bitrate_factor);
+    const float lo = (float)h->param.rc.i_qp_min, hi = (float)(h->param.rc.i_qp_max < 51 ? h->param.rc.i_qp_max : 51);
+    qf = qf < lo ? lo : qf > hi ? hi : qf;
+    return clampi((int)(qf + 0.5f), 0, 51);
+}
 
 // threads that entropy-code row bands of ONE slice (write_slice): X264GPU_CAVLC_THREADS overrides `dflt`
 static int cavlc_threads_default(int dflt)
@@ -531,6 +572,8 @@ x264_t *x264_encoder_open(x264_param_t *param)
     if (qp < 1) { xlog(&p, X264_LOG_WARNING, "lossless is not supported: qp 1\n"); qp = 1; }
     if (!h->crf && !h->abr && !h->pass2) p.rc.i_rc_method = X264_RC_CQP;
     if ((h->pass1 || h->pass2) && p.rc.b_mb_tree) { xlog(&p, X264_LOG_INFO, "2-pass: the macroblock-tree statistics file is not implemented in the MI355X path: mbtree 0 in both passes\n"); p.rc.b_mb_tree = 0; }
+    parse_zones(h, p.rc.psz_zones);
+    if (!h->zones.empty()) xlog(&p, X264_LOG_INFO, "%d zone%s (quantiser / bitrate factor per range of pictures)\n", (int)h->zones.size(), h->zones.size() > 1 ? "s" : "");
     if (p.rc.i_vbv_max_bitrate > 0 || p.rc.i_vbv_buffer_size > 0) xlog(&p, X264_LOG_WARNING, "VBV (vbv-maxrate / vbv-bufsize) is not implemented in the MI355X path: unconstrained\n");
     p.rc.i_vbv_max_bitrate = 0; p.rc.i_vbv_buffer_size = 0;
     if (p.analyse.i_noise_reduction) { xlog(&p, X264_LOG_WARNING, "nr (noise reduction) is not implemented in the MI355X path: nr 0\n"); p.analyse.i_noise_reduction = 0; }
@@ -821,7 +864,7 @@ static void join_pool(x264_t *h)
     h->pool_nslots = 0;
 }
 
-static int rc_pick_qp(x264_t *h, bool is_i, const int32_t costs[4], int frames_done);
+static int rc_pick_qp(x264_t *h, bool is_i, const int32_t costs[4], int frames_done, int frame);
 
 // 0, or -1 after a GPU failure: the session is then dead (h->failed: every later call returns < 0 and nothing counts as delayed,
 // so the caller's flush loop — codec.c:1842-1856 — ends instead of spinning on frames that will never be coded)
@@ -839,6 +882,11 @@ static int code_position(x264_t *h, int batch, int t, int nslots_with_t)
     if (h->crf) {
         qps.assign((size_t)G, (int8_t)(t == 0 ? h->qp_i : h->qp_p)); qpms.assign((size_t)G, 0.f);
         for (int s = 0; s < nslots_with_t; s++) { qps[(size_t)s] = h->gop_qp[(size_t)s * h->keyint + t]; qpms[(size_t)s] = h->gop_qpm[(size_t)s * h->keyint + t]; }
+    } else if (!h->abr && !h->zones.empty()) {
+        // constant quantiser with zones: slot s of this batch holds picture (batch * G + s) * keyint + t of the stream
+        qps.assign((size_t)G, (int8_t)(t == 0 ? h->qp_i : h->qp_p)); qpms.assign((size_t)G, 0.f);
+        for (int s = 0; s < nslots_with_t; s++)
+            if (const x264_t::Zone *z = get_zone(h, (int)(((long)batch * G + s) * h->keyint + t))) qps[(size_t)s] = (int8_t)cqp_zone(h, *z, qps[(size_t)s]);
     }
     // every device codes position t of its slots; one host thread per device issues the work and collects the results
     const int D = (int)h->devs.size();
@@ -846,7 +894,7 @@ static int code_position(x264_t *h, int batch, int t, int nslots_with_t)
     auto run_dev = [&](int d) {
         x264_t::DevCtx &dc = h->devs[(size_t)d];
         bool ok = D == 1 || x264gpu_set_device(dc.dev) == X264GPU_OK;
-        if (ok && h->crf) {
+        if (ok && !qps.empty()) {
             std::vector<int8_t> q((size_t)dc.nsl); std::vector<float> qm((size_t)dc.nsl);
             for (int l = 0; l < dc.nsl; l++) { q[(size_t)l] = qps[(size_t)(l * D + d)]; qm[(size_t)l] = qpms[(size_t)(l * D + d)]; }
             ok = x264gpu_encoder_set_stream_qpms(dc.gpu, q.data(), qm.data()) == X264GPU_OK;
@@ -955,7 +1003,7 @@ static int encode_gop_parallel(x264_t *h, x264_nal_t **pp_nal, int *pi_nal, x264
                 xlog(&p, X264_LOG_ERROR, "x264_encoder_encode: lookahead failed: %s\n", x264gpu_last_error());
                 return -1;
             }
-            h->gop_qp[(size_t)s * K + t] = (int8_t)rc_pick_qp(h, t == 0, costs, (int)i);
+            h->gop_qp[(size_t)s * K + t] = (int8_t)rc_pick_qp(h, t == 0, costs, (int)i, (int)i);
             h->gop_qpm[(size_t)s * K + t] = near_qpm(h->rc.qpa_last, h->gop_qp[(size_t)s * K + t]);
         }
         h->pts.push_back(pic_in->i_pts);
@@ -1003,7 +1051,7 @@ static int encode_gop_parallel(x264_t *h, x264_nal_t **pp_nal, int *pi_nal, x264
 // rate_estimate_qscale for the picture about to be coded (single-pass CRF / ABR): a function of the lookahead costs, the picture type and
 // the running rate-control state only (ABR adds the coded sizes through x264_ratecontrol_end), so under CRF it can run when a picture
 // ARRIVES — which is what lets GOP-parallel sessions keep CRF's quantisers.  frames_done = pictures decided before this one.
-static int rc_pick_qp(x264_t *h, bool is_i, const int32_t costs[4], int frames_done)
+static int rc_pick_qp(x264_t *h, bool is_i, const int32_t costs[4], int frames_done, int frame)
 {
     const x264_param_t &p = h->param;
     // rate_estimate_qscale: q = rceq / rate_factor; rceq = blurred_complexity^(1 - qcomp), or under macroblock-tree (which does the
@@ -1020,6 +1068,8 @@ static int rc_pick_qp(x264_t *h, bool is_i, const int32_t costs[4], int frames_d
         h->rc.last_rceq = h->mbtree ? pow(1.0 / h->rc.dur_ratio, 1.0 - p.rc.f_qcompress) : pow(h->rc.cplxsum / h->rc.cplxcount, 1.0 - h->rc.qcompress);
         q = FL(h->rc.last_rceq / rate_factor);          // (rate_estimate_qscale's q is a float: every assignment rounds)
     } else q = FL(h->rc.last_qscale_for[is_i ? 0 : 1]);
+    // get_qscale: a zone forces its quantiser or scales the picture's bits (an I picture after P pictures still takes the running P quantiser below, as in x264)
+    if (const x264_t::Zone *z = get_zone(h, frame)) q = FL(z->force_qp ? qp2qscale(z->qp) : q / z->bitrate_factor);
     if (h->abr && satd > 0) {
         // pull towards the target: bits so far against time so far, within an abr_buffer that grows with sqrt(time)
         const double time_done = frames_done / h->rc.fps, wanted_bits = time_done * h->rc.bitrate;
@@ -1062,6 +1112,10 @@ static int gpu_stage(x264_t *h, size_t idx, int buf, bool async)
     x264_t::QEntry &e = h->queue[idx];
     const bool idr = e.type == 2, intra_pic = e.type == 1, is_i = idr || intra_pic;
     int qp_now = is_i ? h->qp_i : h->qp_p;
+    if (!h->crf && !h->abr && !h->zones.empty()) {          // constant quantiser with zones: every picture names its quantiser
+        if (const x264_t::Zone *z = get_zone(h, h->rc_frames)) qp_now = cqp_zone(h, *z, qp_now);
+        if (x264gpu_encoder_set_qp(h->gpu, qp_now, qp_now) != X264GPU_OK) return -1;
+    }
     if (h->mbtree) {
         // macroblock_tree: this picture and the P pictures behind it that (transitively) reference it; an intra picture ends the chain
         const int32_t *info[256]; const float *aq[256];
@@ -1079,7 +1133,7 @@ static int gpu_stage(x264_t *h, size_t idx, int buf, bool async)
         }
     }
     if (h->crf || h->abr) {
-        qp_now = rc_pick_qp(h, is_i, e.costs, h->rc_frames);
+        qp_now = rc_pick_qp(h, is_i, e.costs, h->rc_frames, h->rc_frames);
         // x264_ratecontrol_mb_qp adds the AQ / macroblock-tree offsets to the FLOAT quantiser (rc->qpm) before the one rounding
         e.qpm = near_qpm(h->rc.qpa_last, qp_now);
         if (x264gpu_encoder_set_qp(h->gpu, qp_now, qp_now) != X264GPU_OK || x264gpu_encoder_set_qpm(h->gpu, e.qpm) != X264GPU_OK) return -1;
@@ -1852,12 +1906,13 @@ static int bmode_qp(x264_t *h, const x264_t::BPlanned &pl, const DpbPlan &plan, 
     }
     if (!h->crf && !h->abr) {
         const int qb = clampi((int)(h->qp_p + pb_offset + 0.5), 0, 51);
-        const int q = is_i ? h->qp_i : !is_b ? h->qp_p : pl.type == PIC_BREF ? (qb + h->qp_p) / 2 : qb;
+        int q = is_i ? h->qp_i : !is_b ? h->qp_p : pl.type == PIC_BREF ? (qb + h->qp_p) / 2 : qb;
+        if (const x264_t::Zone *z = get_zone(h, pl.e.frame)) q = cqp_zone(h, *z, q);
         *qp_float = q;
         return q;
     }
     if (!is_b) {
-        const int q = rc_pick_qp(h, is_i, pl.e.costs, h->rc_frames);
+        const int q = rc_pick_qp(h, is_i, pl.e.costs, h->rc_frames, pl.e.frame);
         *qp_float = h->rc.qpa_last;
         return q;
     }

@@ -363,7 +363,7 @@ int x264_param_parse(x264_param_t *p, const char *name, const char *value)
     OPT("mbtree") B(p->rc.b_mb_tree);
     OPT("qblur") F(p->rc.f_qblur);
     OPT("cplxblur") F(p->rc.f_complexity_blur);
-    OPT("zones") {}
+    OPT("zones") { p->rc.psz_zones = value ? strdup(value) : nullptr; }
     OPT("psnr") B(p->analyse.b_psnr);
     OPT("ssim") B(p->analyse.b_ssim);
     OPT("aud") B(p->b_aud);

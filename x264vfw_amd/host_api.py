@@ -33,7 +33,7 @@ class Rc(C.Structure):
                 ("i_vbv_max_bitrate", _i), ("i_vbv_buffer_size", _i), ("f_vbv_buffer_init", C.c_float), ("f_ip_factor", C.c_float),
                 ("f_pb_factor", C.c_float), ("i_aq_mode", _i), ("f_aq_strength", C.c_float), ("b_mb_tree", _i), ("i_lookahead", _i),
                 ("b_stat_write", _i), ("psz_stat_out", C.c_char_p), ("b_stat_read", _i), ("psz_stat_in", C.c_char_p),
-                ("f_qcompress", C.c_float), ("f_qblur", C.c_float), ("f_complexity_blur", C.c_float)]
+                ("f_qcompress", C.c_float), ("f_qblur", C.c_float), ("f_complexity_blur", C.c_float), ("psz_zones", C.c_char_p)]
 
 
 LOGFN = C.CFUNCTYPE(None, C.c_void_p, _i, C.c_char_p, C.c_void_p)
