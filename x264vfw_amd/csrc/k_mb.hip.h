@@ -230,8 +230,9 @@ __device__ __forceinline__ void rc_row(const uint32_t *slot, int X0, int Y0, int
 }
 
 // WP: explicit weights can occur (P slices under --weightp); B slices instantiate without them
-template <int M, int ME, bool WP = true>
-__device__ __forceinline__ void me_search(const EncK &k, MbLds<M> &L, const MbCtx &c, const MeJob &j, int &mvx, int &mvy, int &cost, int &cost_mv, int &halfpel_thresh, const MeState &S, WinTags &wtg, Prof &pf)
+// (LDS: the macroblock loop's MbLds<M>, or the lookahead's own smaller layout with the members this function touches — csrc/slicetype.hip)
+template <int M, int ME, bool WP = true, typename LDS = MbLds<M>>
+__device__ __forceinline__ void me_search(const EncK &k, LDS &L, const MbCtx &c, const MeJob &j, int &mvx, int &mvy, int &cost, int &cost_mv, int &halfpel_thresh, const MeState &S, WinTags &wtg, Prof &pf)
 {
     pf.mark(PH_ME_GLUE);
     const int lane = c.lane, r = lane & 15, cnd = lane >> 4;

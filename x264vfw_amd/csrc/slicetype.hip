@@ -38,6 +38,17 @@ struct StK {
     int serial_rows;                          // one wavefront walks every row of its stream (batches) instead of one wavefront a row
 };
 
+// k_st_cost's LDS: 8x8 blocks of the half-resolution planes, me <= hex, at most two references, no chroma, no intra tiles, no record — only what me_search
+// touches, so that THREE wavefronts share a SIMD where the macroblock loop's layout (20 KB) allows two (12 x 11.4 KB of the CU's 160 KB)
+struct StLds {
+    __attribute__((aligned(16))) uint32_t rc[2 * RC_SLOT_DW];        // reference-cache slots of list 0 / list 1
+    uint32_t csub[CSubGeo<2>::DWORDS];
+    __attribute__((aligned(16))) uint8_t src[16 * 16];
+    __attribute__((aligned(16))) uint8_t csrc[8 * 16];               // (chroma rows: named by me_search's chroma-me branch, never taken here)
+    uint16_t mvcost[MVC_N];
+    int16_t cand[16][2];
+};
+
 __device__ __forceinline__ int st_avg4(int a, int b, int c, int d) { return (((a + b + 1) >> 1) + ((c + d + 1) >> 1) + 1) >> 1; }
 
 __global__ __launch_bounds__(256) void k_st_lowres(StK k)
@@ -133,9 +144,9 @@ __global__ __launch_bounds__(256) void k_st_intra(StK k)
 }
 
 template <int ME>
-__global__ __launch_bounds__(64) void k_st_cost(StK k)
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void k_st_cost(StK k)
 {
-    __shared__ __attribute__((aligned(16))) MbLds<2> L;
+    __shared__ __attribute__((aligned(16))) StLds L;
     const int lane = threadIdx.x, s = blockIdx.y, r = lane & 15;
     // k.serial_rows: ONE wavefront walks all the rows of its stream, bottom-up (a batch of streams fills the chip by itself: no wavefront spins on the
     // row below, no pipeline to fill per stream); else one wavefront per row, chained by the progress counters (a lone stream's latency)
@@ -261,7 +272,7 @@ __global__ __launch_bounds__(64) void k_st_cost(StK k)
                     jb.hp_it = 1; jb.qp_it = satd ? 1 : 0; jb.use_thresh = false;
                     int cost = 0, cost_mv = 0, thresh = 0x7fffffff;
                     lds_sync();
-                    me_search<2, ME>(ek, L, c, jb, mx, my, cost, cost_mv, thresh, S, wtg, pf);
+                    me_search<2, ME, true, StLds>(ek, L, c, jb, mx, my, cost, cost_mv, thresh, S, wtg, pf);
                     lds_sync();
                     mcost = cost - (int)ek.cost_all[MVCOST_HALF];         // "remove mvcost from skip mbs"
                     if (mx | my) mcost += 5 * k.lambda;
