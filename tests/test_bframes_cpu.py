@@ -546,6 +546,17 @@ def test_host_session_two_pass(tmp_path):
     assert abs(rate / kbps - 1.0) < 0.05, rate
     dec = O.h264_decode(stream, n, w, h)
     assert len(dec) == n
+    assert [ln for ln in open(st).read().splitlines() if not ln.startswith("#")] == lines          # pass 2 leaves the statistics alone ...
+    # ... the N-th pass (--pass 3: the driver's encoding type 4 past the first pass, codec.c:1519-1541 with its updatestats) reads them AND writes this pass' own
+    # lines in their place: same picture types, the quantisers and sizes of THIS pass, and a further pass plans from those
+    info3, stream3 = _host_b_session(tmp_path, n, common + ["pass=3"], w, h, seed=9)
+    assert stream3 == stream and not os.path.exists(st + ".temp")
+    lines3 = [ln for ln in open(st).read().splitlines() if not ln.startswith("#")]
+    field = lambda ln, k: ln.split(" " + k + ":")[1].split(" ")[0]
+    assert len(lines3) == n and [field(" " + ln, "type") for ln in lines3] == [field(" " + ln, "type") for ln in lines]
+    assert lines3 != lines and abs(sum(int(field(ln, "tex")) + int(field(ln, "mv")) + int(field(ln, "misc")) for ln in lines3) - len(stream) * 8) <= 8 * n
+    info4, stream4 = _host_b_session(tmp_path, n, common + ["pass=2"], w, h, seed=9)
+    assert abs(len(stream4) * 8 / (n / 25.0) / 1000.0 / kbps - 1.0) < 0.05
     # a bitrate the headers alone exceed is refused the way x264 refuses it
     import sys
     r = subprocess.run([sys.executable, os.path.join(os.path.dirname(os.path.abspath(__file__)), "stub", "run_host_b.py"), str(tmp_path / "c.h264"), str(w), str(h), str(n), "9"] +

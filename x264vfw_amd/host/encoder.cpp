@@ -567,7 +567,7 @@ x264_t *x264_encoder_open(x264_param_t *param)
         if (!h->pass1) p.rc.b_stat_write = 0;
     }
     h->abr = p.rc.i_rc_method == X264_RC_ABR && p.i_threads <= 1 && p.rc.i_bitrate > 0 && !p.rc.b_stat_read;      // single pass, no VBV
-    if (p.rc.b_stat_write && p.rc.b_stat_read) xlog(&p, X264_LOG_INFO, "updating the statistics in the second pass is not implemented: they stay as the first pass wrote them\n");
+    if (p.rc.b_stat_write && p.rc.b_stat_read && !h->pass2) xlog(&p, X264_LOG_INFO, "this pass runs without the statistics: they stay as the first pass wrote them\n");
     if (p.rc.i_rc_method != X264_RC_CQP && !h->crf && !h->abr && !h->pass2) xlog(&p, X264_LOG_WARNING, "this rate control mode is not implemented yet (ABR with --threads > 1): constant qp %d\n", qp);
     if (qp < 1) { xlog(&p, X264_LOG_WARNING, "lossless is not supported: qp 1\n"); qp = 1; }
     if (!h->crf && !h->abr && !h->pass2) p.rc.i_rc_method = X264_RC_CQP;
@@ -791,7 +791,9 @@ x264_t *x264_encoder_open(x264_param_t *param)
         if (!p2_load(h, p.rc.psz_stat_in) || !p2_init(h)) { x264_encoder_close(h); return nullptr; }
         xlog(&p, X264_LOG_INFO, "2-pass: %d pictures planned from the first pass' statistics, %.1f kbit expected before the last one\n", (int)h->p2.size(), h->p2_final_bits / 1000.0);
     }
-    if (h->pass1) {
+    // (the driver's N-th pass asks for both: statistics read AND written again — codec.c:1519-1541 with its fixed updatestats — so that a further pass plans from this one's pictures)
+    const bool stat_update = h->pass2 && p.rc.b_stat_write && p.rc.psz_stat_out;
+    if (h->pass1 || stat_update) {
         // x264 writes <stats>.temp and renames it when the encoder closes; the first line names the options the second pass must agree with
         h->stat_file = fopen((std::string(p.rc.psz_stat_out) + ".temp").c_str(), "wb");
         if (!h->stat_file) { xlog(&p, X264_LOG_ERROR, "ratecontrol_init: can't open stats file\n"); x264_encoder_close(h); return nullptr; }
@@ -2070,7 +2072,7 @@ static int encode_bmode(x264_t *h, x264_nal_t **pp_nal, int *pi_nal, x264_pictur
             if (m.type <= X264GPU_MB_I16x16) imb++; else if (m.type == X264GPU_MB_P_SKIP || m.type == X264GPU_MB_B_SKIP) smb++; else pmb++;
             aqsum += m.qp;
         }
-        if (h->pass1 && h->stat_file) {
+        if (h->stat_file) {
             const char t = idr ? 'I' : pl.type == PIC_I ? 'i' : pl.type == PIC_P ? 'P' : pl.type == PIC_BREF ? 'B' : 'b';
             const long mv = h->last_stats.mv_bits, tex = h->last_stats.tex_bits, misc = total - mv - tex;
             fprintf(h->stat_file, "in:%d out:%ld type:%c dur:%d cpbdur:%d q:%.2f aq:%.2f tex:%ld mv:%ld misc:%ld imb:%ld pmb:%ld smb:%ld d:%c ref:;\n", pl.e.frame, h->coded_count, t, 1, 1, qpf,
@@ -2221,7 +2223,9 @@ void x264_encoder_close(x264_t *h)
     if (h->stat_file) {
         fclose(h->stat_file); h->stat_file = nullptr;
         const std::string out = h->param.rc.psz_stat_out ? h->param.rc.psz_stat_out : "";
-        if (!out.empty() && rename((out + ".temp").c_str(), out.c_str())) xlog(&h->param, X264_LOG_ERROR, "failed to rename \"%s.temp\" to \"%s\"\n", out.c_str(), out.c_str());
+        // x264_ratecontrol_delete: a second pass that stopped short of the first one's pictures keeps the complete statistics it read
+        if (h->pass2 && h->coded_count < (long)h->p2.size()) { remove((out + ".temp").c_str()); xlog(&h->param, X264_LOG_INFO, "2-pass: %ld of %d pictures coded: the statistics file keeps the first pass' lines\n", h->coded_count, (int)h->p2.size()); }
+        else if (!out.empty() && rename((out + ".temp").c_str(), out.c_str())) xlog(&h->param, X264_LOG_ERROR, "failed to rename \"%s.temp\" to \"%s\"\n", out.c_str(), out.c_str());
     }
     if (h->batch) { batch_leave(h->batch, h->batch_idx); h->batch = nullptr; }
     if (h->gpu) x264gpu_encoder_destroy(h->gpu);
