@@ -134,6 +134,7 @@ typedef struct X264VFW_CONFIG {
     int b_fastdecode, b_zerolatency;
     int i_encoding_type;                               /* 0 lossless, 1 CQP, 2 CRF, 3 ABR, 4 2-pass (codec.c:1490-1533) */
     int i_qp, i_rf_constant, i_passbitrate, i_pass;    /* rf constant x10 (config.c:111) */
+    int b_fast1pass, b_createstats, b_updatestats;     /* x264vfw.h:138-140: fast first pass; statistics file in single-pass modes; pass N rewrites it (config.c:114-116: 0, 0, 1) */
     int i_fourcc;
     int i_log_level;
     int b_psnr, b_ssim, b_no_asm;

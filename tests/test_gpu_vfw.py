@@ -523,13 +523,16 @@ def test_two_pass_through_the_driver(gpu, tmp_path):
     frames = synth_frames(w, h, nfr, seed=11, scene_len=53)
     stats = tmp_path / "vfw.stats"
 
-    def run(i_pass, out):
+    def run(i_pass, out, enc_type=4, **fields):
         ico = V.ICOPEN(fccType=V.fourcc(b"vidc"))
         cid = D(0, None, V.DRV_OPEN, 0, V.addr(ico))
         n = D(cid, None, V.ICM_GETSTATE, 0, 0)
         cfg = V.VfwConfig()
         D(cid, None, V.ICM_GETSTATE, V.addr(cfg), n)
-        cfg.i_encoding_type, cfg.i_passbitrate, cfg.i_pass, cfg.i_log_level = 4, kbps, i_pass, 3
+        assert (cfg.b_fast1pass, cfg.b_createstats, cfg.b_updatestats) == (0, 0, 1)          # config.c:114-116
+        cfg.i_encoding_type, cfg.i_passbitrate, cfg.i_pass, cfg.i_log_level = enc_type, kbps, i_pass, 3
+        for k, v in fields.items():
+            setattr(cfg, k, v)
         cfg.extra_cmdline = b"--keyint 40 --rc-lookahead 8 --stats " + str(stats).encode() + b" --output " + str(out).encode()
         D(cid, None, V.ICM_SETSTATE, V.addr(cfg), n)
         inb, outb = V.bmi(w, h, b"I420"), V.BITMAPINFO()
@@ -558,3 +561,12 @@ def test_two_pass_through_the_driver(gpu, tmp_path):
     rate = len(data) * 8 / (nfr / 25.0) / 1000.0
     assert abs(rate / kbps - 1.0) < 0.05, rate
     assert len(O.h264_decode(data, nfr, w, h)) == nfr
+    # the dialog's "update stats" box (x264vfw.h:140, default on: codec.c:1527): pass N wrote its own lines over the first pass'; unticked, the file stays
+    lines2 = [ln for ln in stats.read_text().splitlines() if not ln.startswith("#")]
+    assert len(lines2) == nfr and lines2 != lines
+    run(2, tmp_path / "p3.h264", b_updatestats=0)
+    assert [ln for ln in stats.read_text().splitlines() if not ln.startswith("#")] == lines2
+    # "create stats" (x264vfw.h:139, codec.c:1495-1513): a single-pass session writes the file too — and returns its stream
+    stats.unlink()
+    run(1, tmp_path / "p4.h264", enc_type=2, b_createstats=1)
+    assert (tmp_path / "p4.h264").stat().st_size > 0 and len([ln for ln in stats.read_text().splitlines() if not ln.startswith("#")]) == nfr

@@ -57,6 +57,7 @@ void config_defaults(X264VFW_CONFIG *c)
     c->i_level = 0;                     /* auto */
     c->i_encoding_type = 2;             /* single pass CRF after the GordianKnot remap (config.c:205-228,256) */
     c->i_qp = 23; c->i_rf_constant = 230; c->i_passbitrate = 800; c->i_pass = 1;
+    c->b_fast1pass = 0; c->b_createstats = 0; c->b_updatestats = 1;      /* config.c:114-116 */
     c->i_log_level = 2;                 /* warning */
     c->i_sar_width = c->i_sar_height = 1;
 }
@@ -229,15 +230,16 @@ LRESULT compress_begin(CODEC *codec, BITMAPINFO *in, BITMAPINFO *out)
     param.i_level_idc = cfg->i_level >= 0 && cfg->i_level < (int)(sizeof(kLevels) / sizeof(kLevels[0])) ? kLevels[cfg->i_level] : -1;
     param.rc.b_stat_write = param.rc.b_stat_read = 0;
     switch (cfg->i_encoding_type) {                                         /* codec.c:1490-1533 */
-    case 0: param.rc.i_rc_method = X264_RC_CQP; param.rc.i_qp_constant = 0; break;
-    case 1: param.rc.i_rc_method = X264_RC_CQP; param.rc.i_qp_constant = cfg->i_qp; break;
-    case 2: param.rc.i_rc_method = X264_RC_CRF; param.rc.f_rf_constant = (float)cfg->i_rf_constant * 0.1f; break;
-    case 3: param.rc.i_rc_method = X264_RC_ABR; param.rc.i_bitrate = cfg->i_passbitrate; break;
+    /* (single-pass modes write the statistics file when the dialog's "create stats" box is ticked: codec.c:1495,1501,1507,1513) */
+    case 0: param.rc.i_rc_method = X264_RC_CQP; param.rc.i_qp_constant = 0; param.rc.b_stat_write = cfg->b_createstats != 0; break;
+    case 1: param.rc.i_rc_method = X264_RC_CQP; param.rc.i_qp_constant = cfg->i_qp; param.rc.b_stat_write = cfg->b_createstats != 0; break;
+    case 2: param.rc.i_rc_method = X264_RC_CRF; param.rc.f_rf_constant = (float)cfg->i_rf_constant * 0.1f; param.rc.b_stat_write = cfg->b_createstats != 0; break;
+    case 3: param.rc.i_rc_method = X264_RC_ABR; param.rc.i_bitrate = cfg->i_passbitrate; param.rc.b_stat_write = cfg->b_createstats != 0; break;
     case 4:     /* multipass (codec.c:1516-1533): pass 1 writes the statistics and returns no stream, pass N reads them; the file is --stats' (config.c:140:
                  * ".\\x264.stats"); fast first pass only with --fast-firstpass (config.c:114 default 0) */
         param.rc.i_rc_method = X264_RC_ABR; param.rc.i_bitrate = cfg->i_passbitrate;
-        if (cfg->i_pass <= 1) { codec->b_no_output = 1; param.rc.b_stat_write = 1; }
-        else { param.rc.b_stat_write = 1 /* config.c:116 updatestats default */; param.rc.b_stat_read = 1; }
+        if (cfg->i_pass <= 1) { codec->b_no_output = 1; fast1pass = cfg->b_fast1pass != 0; param.rc.b_stat_write = 1; }      /* codec.c:1519-1524 */
+        else { param.rc.b_stat_write = cfg->b_updatestats != 0; param.rc.b_stat_read = 1; }                                  /* codec.c:1525-1529 */
         break;
     default: goto fail;
     }

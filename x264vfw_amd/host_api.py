@@ -182,7 +182,7 @@ class ICCOMPRESSFRAMES(C.Structure):
 
 class VfwConfig(C.Structure):
     _fields_ = [(n, _i) for n in ("i_format_version", "i_preset", "i_tuning", "i_profile", "i_level", "b_fastdecode", "b_zerolatency",
-                                  "i_encoding_type", "i_qp", "i_rf_constant", "i_passbitrate", "i_pass", "i_fourcc", "i_log_level",
+                                  "i_encoding_type", "i_qp", "i_rf_constant", "i_passbitrate", "i_pass", "b_fast1pass", "b_createstats", "b_updatestats", "i_fourcc", "i_log_level",
                                   "b_psnr", "b_ssim", "b_no_asm", "i_sar_width", "i_sar_height")] + [("extra_cmdline", C.c_char * 4096)]
 
 
