@@ -125,20 +125,35 @@ typedef struct ICCOMPRESSFRAMES {       /* members used: codec.c:1881-1883 */
     void *GetData, *PutData;
 } ICCOMPRESSFRAMES;
 
-/* Driver configuration blob exchanged by ICM_GETSTATE / ICM_SETSTATE (x264vfw.h:121-167, version 4): the
- * subset of CONFIG that drives the encoder; strings are UTF-8 here (UTF-16 in the Windows build). */
+/* Driver configuration blob exchanged by ICM_GETSTATE / ICM_SETSTATE: the reference's CONFIG (x264vfw.h:121-167, format version 4), field for field and in its
+ * order; strings are UTF-8 here (UTF-16 in the Windows build).  Defaults: config.c:96-143. */
 #define X264VFW_FORMAT_VERSION 4
+#define X264VFW_MAX_PATH 260
 typedef struct X264VFW_CONFIG {
     int i_format_version;
+    /* Basic */
     int i_preset, i_tuning, i_profile, i_level;        /* indices into the tables of codec.c / config.c:96-104 */
+    int i_colorspace;                                  /* 0 = convert to YUV 4:2:0 (CSP_CONVERT_TO_I420), else keep the input's colourspace (codec.c:1472): this build codes
+                                                        * 4:2:0 only and says so in the log when asked to keep another one */
     int b_fastdecode, b_zerolatency;
+    /* Rate control */
     int i_encoding_type;                               /* 0 lossless, 1 CQP, 2 CRF, 3 ABR, 4 2-pass (codec.c:1490-1533) */
     int i_qp, i_rf_constant, i_passbitrate, i_pass;    /* rf constant x10 (config.c:111) */
     int b_fast1pass, b_createstats, b_updatestats;     /* x264vfw.h:138-140: fast first pass; statistics file in single-pass modes; pass N rewrites it (config.c:114-116: 0, 0, 1) */
+    char stats[X264VFW_MAX_PATH];                      /* the statistics file (config.c:140: ".\\x264.stats"); --stats on the extra command line overrides it */
+    /* Output */
+    int i_output_mode;                                 /* 0 = VFW (the caller's AVI), 1 = file: the stream also goes to output_file through the muxers (codec.c:1545) */
     int i_fourcc;
+    int b_vd_hack;                                     /* X264VFW_USE_VIRTUALDUB_HACK (codec.c:1410) */
+    char output_file[X264VFW_MAX_PATH];
+    /* Sample aspect ratio */
+    int i_sar_width, i_sar_height;
+    /* Debug */
     int i_log_level;
     int b_psnr, b_ssim, b_no_asm;
-    int i_sar_width, i_sar_height;
+    /* Decoder / AVI muxer (x264vfw.h:158-163; out of scope here: kept so that the blob has the reference's fields) */
+    int b_disable_decoder;
+    /* Extra command line */
     char extra_cmdline[4096];
 } X264VFW_CONFIG;
 

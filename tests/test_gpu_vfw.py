@@ -409,7 +409,8 @@ def test_virtualdub_hack_carries_b_pictures_through_the_vfw_buffer(gpu):
     n = D(cid, None, V.ICM_GETSTATE, 0, 0)
     cfg = V.VfwConfig()
     D(cid, None, V.ICM_GETSTATE, V.addr(cfg), n)
-    cfg.extra_cmdline = b"--rc-lookahead 5 --vd-hack"
+    cfg.b_vd_hack = 1                                                          # the dialog's box (codec.c:1410); --vd-hack on the command line does the same
+    cfg.extra_cmdline = b"--rc-lookahead 5"
     D(cid, None, V.ICM_SETSTATE, V.addr(cfg), n)
     inb, outb = V.bmi(w, h, b"I420"), V.BITMAPINFO()
     assert D(cid, None, V.ICM_COMPRESS_GET_FORMAT, V.addr(inb), V.addr(outb)) == V.ICERR_OK
@@ -533,7 +534,9 @@ def test_two_pass_through_the_driver(gpu, tmp_path):
         cfg.i_encoding_type, cfg.i_passbitrate, cfg.i_pass, cfg.i_log_level = enc_type, kbps, i_pass, 3
         for k, v in fields.items():
             setattr(cfg, k, v)
-        cfg.extra_cmdline = b"--keyint 40 --rc-lookahead 8 --stats " + str(stats).encode() + b" --output " + str(out).encode()
+        # (the statistics file and the output file as the dialog stores them: CONFIG.stats, CONFIG.i_output_mode / output_file — codec.c:1447,1537-1545)
+        cfg.stats, cfg.i_output_mode, cfg.output_file = str(stats).encode(), 1, str(out).encode()
+        cfg.extra_cmdline = b"--keyint 40 --rc-lookahead 8"
         D(cid, None, V.ICM_SETSTATE, V.addr(cfg), n)
         inb, outb = V.bmi(w, h, b"I420"), V.BITMAPINFO()
         assert D(cid, None, V.ICM_COMPRESS_GET_FORMAT, V.addr(inb), V.addr(outb)) == V.ICERR_OK

@@ -41,6 +41,9 @@ def test_state_blob():
     assert D(cid, None, V.ICM_GETSTATE, V.addr(cfg), n - 1) == V.ICERR_BADSIZE
     assert D(cid, None, V.ICM_GETSTATE, V.addr(cfg), n) == V.ICERR_OK
     assert (cfg.i_format_version, cfg.i_preset, cfg.i_encoding_type, cfg.i_rf_constant, cfg.i_qp) == (4, 5, 2, 230, 23)   # Appendix A defaults
+    # ... and the rest of the reference's CONFIG (x264vfw.h:121-167) with config.c:96-143's defaults: the blob carries every field the dialog edits
+    assert (cfg.i_colorspace, cfg.b_fast1pass, cfg.b_createstats, cfg.b_updatestats, cfg.i_output_mode, cfg.b_vd_hack, cfg.b_disable_decoder) == (0, 0, 0, 1, 0, 0, 0)
+    assert cfg.stats == b"./x264.stats" and cfg.output_file == b"" and (cfg.i_sar_width, cfg.i_sar_height, cfg.i_log_level) == (1, 1, 2)
     cfg.i_encoding_type, cfg.i_qp = 1, 30
     assert D(cid, None, V.ICM_SETSTATE, V.addr(cfg), n) == n
     cfg2 = V.VfwConfig()

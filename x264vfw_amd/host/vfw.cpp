@@ -58,6 +58,8 @@ void config_defaults(X264VFW_CONFIG *c)
     c->i_encoding_type = 2;             /* single pass CRF after the GordianKnot remap (config.c:205-228,256) */
     c->i_qp = 23; c->i_rf_constant = 230; c->i_passbitrate = 800; c->i_pass = 1;
     c->b_fast1pass = 0; c->b_createstats = 0; c->b_updatestats = 1;      /* config.c:114-116 */
+    snprintf(c->stats, sizeof(c->stats), "./x264.stats");               /* config.c:140 (".\\x264.stats") */
+    c->i_output_mode = 0; c->b_vd_hack = 0; c->output_file[0] = 0;      /* config.c:118,121,142 */
     c->i_log_level = 2;                 /* warning */
     c->i_sar_width = c->i_sar_height = 1;
 }
@@ -197,7 +199,7 @@ LRESULT compress_begin(CODEC *codec, BITMAPINFO *in, BITMAPINFO *out)
         return ICERR_BADFORMAT;
     }
     codec->b_check_size = out->bmiHeader.biSizeImage != 0;
-    codec->b_use_vd_hack = 0;                                               /* (config.b_vd_hack is not part of this build's state blob: --vd-hack, codec.c:1313) */
+    codec->b_use_vd_hack = cfg->b_vd_hack != 0;                             /* codec.c:1410; --vd-hack sets it too (codec.c:1313) */
     codec->save_fourcc = out->bmiHeader.biCompression;                      /* codec.c:1411 */
     codec->b_user_ref = 0;
     codec->i_frame_remain = codec->i_frame_total ? codec->i_frame_total : -1;
@@ -209,8 +211,9 @@ LRESULT compress_begin(CODEC *codec, BITMAPINFO *in, BITMAPINFO *out)
     if (cfg->b_zerolatency) tune += tune.empty() ? "zerolatency" : ",zerolatency";
     std::vector<std::string> argv = split_cmdline(cfg->extra_cmdline);
     std::string preset_s = preset ? preset : "", profile_s = profile ? profile : "";
-    std::string out_file = "-", muxer = "auto";                                /* codec.c:1545-1546 */
-    std::string stats_path;
+    cfg->stats[sizeof(cfg->stats) - 1] = 0; cfg->output_file[sizeof(cfg->output_file) - 1] = 0;
+    std::string out_file = cfg->i_output_mode == 1 ? cfg->output_file : "-", muxer = "auto";      /* codec.c:1545-1546 */
+    std::string stats_path = cfg->stats;                                   /* codec.c:1447,1537-1541 */
     int fast1pass = 0;
     codec->b_no_output = 0; codec->b_cli_output = 0;
     for (size_t i = 0; i + 1 < argv.size(); i++) {                          /* presets first (parse_preset_tune, codec.c:1198-1223) */
@@ -224,7 +227,8 @@ LRESULT compress_begin(CODEC *codec, BITMAPINFO *in, BITMAPINFO *out)
     }
     param.i_width = in->bmiHeader.biWidth;
     param.i_height = abs(in->bmiHeader.biHeight);
-    param.i_csp = X264_CSP_I420;
+    param.i_csp = X264_CSP_I420;                                           /* choose_output_csp (codec.c:269-300,1472) with b_keep_input_csp = 0 */
+    if (cfg->i_colorspace != 0) vlog(codec, X264_LOG_INFO, "colorspace %d (keep the input's colourspace): this build codes YUV 4:2:0 only — the input is converted\n", cfg->i_colorspace);
     param.i_frame_total = codec->i_frame_total;
     if (codec->i_fps_num > 0 && codec->i_fps_den > 0) { param.i_fps_num = codec->i_fps_num; param.i_fps_den = codec->i_fps_den; }
     param.i_level_idc = cfg->i_level >= 0 && cfg->i_level < (int)(sizeof(kLevels) / sizeof(kLevels[0])) ? kLevels[cfg->i_level] : -1;

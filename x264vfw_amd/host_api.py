@@ -181,9 +181,11 @@ class ICCOMPRESSFRAMES(C.Structure):
 
 
 class VfwConfig(C.Structure):
-    _fields_ = [(n, _i) for n in ("i_format_version", "i_preset", "i_tuning", "i_profile", "i_level", "b_fastdecode", "b_zerolatency",
-                                  "i_encoding_type", "i_qp", "i_rf_constant", "i_passbitrate", "i_pass", "b_fast1pass", "b_createstats", "b_updatestats", "i_fourcc", "i_log_level",
-                                  "b_psnr", "b_ssim", "b_no_asm", "i_sar_width", "i_sar_height")] + [("extra_cmdline", C.c_char * 4096)]
+    """Mirror of X264VFW_CONFIG (include/vfw_shim.h): the reference's CONFIG, field for field."""
+    _fields_ = ([(n, _i) for n in ("i_format_version", "i_preset", "i_tuning", "i_profile", "i_level", "i_colorspace", "b_fastdecode", "b_zerolatency",
+                                   "i_encoding_type", "i_qp", "i_rf_constant", "i_passbitrate", "i_pass", "b_fast1pass", "b_createstats", "b_updatestats")] +
+                [("stats", C.c_char * 260)] + [(n, _i) for n in ("i_output_mode", "i_fourcc", "b_vd_hack")] + [("output_file", C.c_char * 260)] +
+                [(n, _i) for n in ("i_sar_width", "i_sar_height", "i_log_level", "b_psnr", "b_ssim", "b_no_asm", "b_disable_decoder")] + [("extra_cmdline", C.c_char * 4096)])
 
 
 _sig("DriverProc", C.c_ssize_t, [C.c_size_t, C.c_void_p, C.c_uint, C.c_ssize_t, C.c_ssize_t])
