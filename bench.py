@@ -451,6 +451,7 @@ def e2e_probe(args):
         import threading
         os.environ["X264GPU_BATCH"] = str(ns)
         res, errs = [0] * ns, []
+        marks = {"opened": [0.0] * ns, "coded": [0.0] * ns}          # per session: every session open (the batch's first launch can start); its last picture out
 
         def one(idx):
             try:
@@ -465,6 +466,7 @@ def e2e_probe(args):
                 assert h_
                 pic, out = HL.Picture(), HL.Picture()
                 assert H.x264_picture_alloc(C.byref(pic), HL.X264_CSP_I420, w, h) == 0
+                marks["opened"][idx] = time.perf_counter()
                 nal, nn = C.POINTER(HL.Nal)(), C.c_int()
                 got = total = 0
                 for i in range(n):
@@ -481,6 +483,7 @@ def e2e_probe(args):
                     assert size > 0
                     got += 1
                     total += size
+                marks["coded"][idx] = time.perf_counter()
                 H.x264_encoder_close(h_)
                 assert got == n
                 res[idx] = total
@@ -495,6 +498,10 @@ def e2e_probe(args):
         dt = time.perf_counter() - t0
         os.environ.pop("X264GPU_BATCH", None)
         assert not errs, errs[:3]
+        # the same frames over the span from the last session's open (no picture can be coded before: the batch waits for its members) to the last picture out
+        steady = max(marks["coded"]) - max(marks["opened"])
+        run_sessions.detail = {"setup_s": round(max(marks["opened"]) - t0, 2), "coding_s": round(steady, 2), "teardown_s": round(t0 + dt - max(marks["coded"]), 2),
+                               "fps_coding_span": round(ns * n / steady, 2)}
         return round(ns * n / dt, 2), round(sum(res) / (ns * n) / 1e3, 1)
 
     n1 = args.e2e_frames
@@ -504,7 +511,7 @@ def e2e_probe(args):
     fm, kbm = run_sessions(args.e2e_sessions, n1, src) if args.e2e_sessions > 1 else (None, None)
     if args.e2e_legs != "all":
         return {"what": "x264_encoder_encode end to end, 1920x1080 (only the threads-1 and multi-session legs were asked for)", "threads1_fps": f1, "threads1_frames": n1,
-                "multi_session_fps": fm, "multi_session_sessions": args.e2e_sessions, "multi_session_frames_each": n1, "multi_session_kB_per_frame": kbm, "host_cores": os.cpu_count()}
+                "multi_session_fps": fm, "multi_session_sessions": args.e2e_sessions, "multi_session_frames_each": n1, "multi_session_kB_per_frame": kbm, "multi_session_spans": getattr(run_sessions, "detail", None), "host_cores": os.cpu_count()}
     G, K = 32, 4
     fg, kbg = run(G * K, G, K, src)
     ns = (h + 15) // 16 // 4                        # x264 slice threads: at most one slice per four macroblock rows
@@ -518,7 +525,7 @@ def e2e_probe(args):
     os.environ.pop("X264GPU_GOP_SLOTS", None)
     return {"what": "ONE 1920x1080 stream through x264_encoder_encode (host pictures in, Annex-B out: PCIe + host entropy coding included), CQP, preset medium as implemented (the threads-1 and slice legs with B pictures, b-adapt 1 and scene cuts: delays as measured; the --threads G legs run without B pictures)",
             "threads1_fps": f1, "threads1_frames": n1, "threads1_kB_per_frame": kb1,
-            "multi_session_fps": fm, "multi_session_sessions": args.e2e_sessions, "multi_session_frames_each": n1, "multi_session_kB_per_frame": kbm,
+            "multi_session_fps": fm, "multi_session_sessions": args.e2e_sessions, "multi_session_frames_each": n1, "multi_session_kB_per_frame": kbm, "multi_session_spans": getattr(run_sessions, "detail", None),
             "multi_session_what": "that many x264_encoder_open sessions on as many host threads through the cross-session batcher (X264GPU_BATCH): one lock-step device launch per picture, host pictures in, every thread entropy-codes its own stream; session setup and teardown inside the timed span",
             "sliced_threads_fps": fs, "sliced_threads_slices": ns, "sliced_threads_delay_frames": d_sliced, "sliced_threads_kB_per_frame": kbs,
             "sliced_threads_gop_slots32_fps": fsg, "sliced_threads_gop_slots32_delay_frames": (G - 1) * K + 1,

@@ -35,6 +35,10 @@ int  x264gpu_memcpy_d2h(void *h_dst, const void *d_src, size_t bytes, void *stre
 int  x264gpu_memcpy_d2d(void *d_dst, const void *d_src, size_t bytes, void *stream);   /* asynchronous on `stream` */
 int  x264gpu_memset(void *d_dst, int value, size_t bytes, void *stream);
 int  x264gpu_stream_sync(void *stream);
+/* A stream of the caller's own (it does not wait for the default stream, nor the default stream for it): what the `stream` arguments of this header take besides
+ * NULL.  The host encoder's batcher downloads one round's records on one while the next round runs on the default stream. */
+int  x264gpu_stream_create(void **stream);
+int  x264gpu_stream_destroy(void *stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Tier 1 — DSP primitives in batch form (the "checkasm" surface: same device code the frame

@@ -39,6 +39,8 @@ int x264gpu_memcpy_d2h(void *d, const void *s, size_t n, void *st) { memcpy(d, s
 int x264gpu_memcpy_d2d(void *d, const void *s, size_t n, void *st) { memmove(d, s, n); return X264GPU_OK; }
 int x264gpu_memset(void *d, int v, size_t n, void *st) { memset(d, v, n); return X264GPU_OK; }
 int x264gpu_stream_sync(void *st) { return X264GPU_OK; }
+int x264gpu_stream_create(void **st) { static int dummy; *st = &dummy; return X264GPU_OK; }
+int x264gpu_stream_destroy(void *st) { return st ? X264GPU_OK : fail("stream_destroy: null"); }
 long x264gpu_stub_encode_calls(int dev) { return dev >= 0 && dev < 16 ? g_calls[dev] : -1; }
 
 struct x264gpu_encoder { x264gpu_config cfg; x264o_encoder **e; int dev, nmb; const float *off; int8_t *sqp; float *sqpm; float qpm; };

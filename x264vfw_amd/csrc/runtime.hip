@@ -48,6 +48,20 @@ int x264gpu_memcpy_d2h(void *h, const void *d, size_t n, void *stream)
     HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
     return X264GPU_OK;
 }
+int x264gpu_stream_create(void **stream)
+{
+    ARG_TRY(stream);
+    hipStream_t st = nullptr;
+    HIP_TRY(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+    *stream = (void *)st;
+    return X264GPU_OK;
+}
+int x264gpu_stream_destroy(void *stream)
+{
+    ARG_TRY(stream);
+    HIP_TRY(hipStreamDestroy((hipStream_t)stream));
+    return X264GPU_OK;
+}
 int x264gpu_memcpy_d2d(void *dst, const void *src, size_t n, void *stream)
 {
     HIP_TRY(hipMemcpyAsync(dst, src, n, hipMemcpyDeviceToDevice, (hipStream_t)stream));

@@ -15,6 +15,7 @@
 #include <deque>
 #include <memory>
 #include <string>
+#include <atomic>
 #include <thread>
 #include <chrono>
 #include <mutex>
@@ -147,6 +148,12 @@ struct x264_t {
     // cross-session batcher (X264GPU_BATCH=N): N sessions of equal geometry and toolset share ONE device encoder with N streams; the pictures
     // they submit are coded in one lock-step launch, every session entropy-codes its own stream on its caller's thread
     struct BatchGroup *batch = nullptr; int batch_idx = -1, batch_n = 0;
+    // batch sessions with overlap (BatchGroup::overlap): the picture just submitted is downloaded and entropy-coded by a helper thread while the group's next round runs;
+    // its NAL units leave with the NEXT call (one picture of delay).  Two slots used in turn: the one being filled, the one waiting to be handed out
+    struct Deferred { std::thread th; bool valid = false; std::atomic<bool> hurry{ false }; std::string err; std::vector<uint8_t> out; std::vector<size_t> off; std::vector<int> types; int nal_ref_idc = 0;
+                      std::vector<x264gpu_mb> mb; std::vector<int16_t> lv; SliceStats stats = { 0 };
+                      int i_type = 0, b_keyframe = 0; int64_t pts = 0, dts = 0; x264_image_t img; };
+    Deferred defer[2]; int defer_cur = 0;
     struct BPlanned { BEntry e; int type; };                                                                            // type: PIC_*
     std::deque<BEntry> bq;
     std::deque<BPlanned> bcoding;
@@ -181,6 +188,12 @@ struct BatchGroup {
     std::mutex m; std::condition_variable cv;
     x264gpu_config cfg; int N = 0, device = 0;
     x264gpu_encoder *gpu = nullptr; uint8_t *d_in = nullptr; x264gpu_mb *d_mb = nullptr; int16_t *d_lv = nullptr;
+    // overlap: the records / levels of round k are downloaded and entropy-coded (by a helper thread of every session) WHILE round k + 1 runs: a second pair of
+    // output buffers used in turn, a stream of the group's own for the downloads; every session hands its pictures back one call later
+    bool overlap = false; x264gpu_mb *d_mb2 = nullptr; int16_t *d_lv2 = nullptr; void *dl_stream = nullptr;
+    long launched = 0;            // rounds whose kernels have been issued: the helper threads start entropy coding round k once round k + 1 is on the device (or when asked to hurry),
+                                  // so that the host cores are the callers' while the next pictures are uploaded and submitted
+    bool running = false;         // a round is being waited for with the group's lock released (overlap): nobody starts another
     size_t insz = 0, nmb = 0;
     std::vector<char> member, arrived; int joined = 0, active = 0, n_arrived = 0;
     std::vector<x264gpu_pic> pics; long round = 0; int round_rc = 0; std::string err;
@@ -195,6 +208,9 @@ static void batch_destroy(BatchGroup *g)
     if (g->d_in) x264gpu_free(g->d_in);
     if (g->d_mb) x264gpu_free(g->d_mb);
     if (g->d_lv) x264gpu_free(g->d_lv);
+    if (g->d_mb2) x264gpu_free(g->d_mb2);
+    if (g->d_lv2) x264gpu_free(g->d_lv2);
+    if (g->dl_stream) x264gpu_stream_destroy(g->dl_stream);
     delete g;
 }
 // -> the group and the stream index of the caller, or nullptr (setup failed: last error set)
@@ -220,12 +236,18 @@ static BatchGroup *batch_join(const x264gpu_config &cfg1, int N, size_t insz, si
         x264gpu_malloc((void **)&g->d_in, (size_t)N * insz) != X264GPU_OK ||
         x264gpu_malloc((void **)&g->d_mb, (size_t)N * nmb * sizeof(x264gpu_mb)) != X264GPU_OK ||
         x264gpu_malloc((void **)&g->d_lv, (size_t)N * nmb * X264GPU_MB_LEVELS * sizeof(int16_t)) != X264GPU_OK) { batch_destroy(g); return nullptr; }
+    {
+        const char *oe = getenv("X264GPU_BATCH_OVERLAP");
+        if (!(oe && oe[0] == '0') && !getenv("X264GPU_DUMP_RECORDS") &&
+            x264gpu_malloc((void **)&g->d_mb2, (size_t)N * nmb * sizeof(x264gpu_mb)) == X264GPU_OK &&
+            x264gpu_malloc((void **)&g->d_lv2, (size_t)N * nmb * X264GPU_MB_LEVELS * sizeof(int16_t)) == X264GPU_OK && x264gpu_stream_create(&g->dl_stream) == X264GPU_OK) g->overlap = true;
+    }
     g->joined = 1; g->active = 1; g->member[0] = 1; *idx = 0;
     g_batch_groups.push_back(g);
     return g;
 }
-// the launch of a complete round; g->m is held
-static void batch_run_round(BatchGroup *g)
+// the launch of a complete round; g->m is held through lk (released while an overlapping group waits for its kernels)
+static void batch_run_round(BatchGroup *g, std::unique_lock<std::mutex> &lk)
 {
     int first = -1;
     for (int s = 0; s < g->N; s++) if (g->arrived[(size_t)s]) { first = s; break; }
@@ -237,32 +259,51 @@ static void batch_run_round(BatchGroup *g)
             if (a.slice_type != b.slice_type || a.poc != b.poc || a.dst != b.dst || a.keep != b.keep || a.nref[0] != b.nref[0] || a.nref[1] != b.nref[1] ||
                 memcmp(a.slot, b.slot, sizeof(a.slot)) || a.blind_dupe != b.blind_dupe) { g->round_rc = -1; g->err = "the sessions of a batch must submit pictures of the same structure (same picture count, keyint, bframes, forced types)"; }
         }
-        if (!g->round_rc && x264gpu_encode_pictures(g->gpu, g->d_in, g->pics.data(), g->d_mb, g->d_lv, nullptr) != X264GPU_OK) { g->round_rc = -1; g->err = x264gpu_last_error(); }
+        const bool second = g->overlap && (g->round & 1);          // the output buffers of this round (the other pair may still be downloading)
+        if (!g->round_rc && x264gpu_encode_pictures(g->gpu, g->d_in, g->pics.data(), second ? g->d_mb2 : g->d_mb, second ? g->d_lv2 : g->d_lv, nullptr) != X264GPU_OK) { g->round_rc = -1; g->err = x264gpu_last_error(); }
+        // overlap: the downloads run on the group's own stream, which does not wait for the default one: the round must be complete before anyone is told
+        if (!g->round_rc && g->overlap) {
+            g->launched++; g->running = true;
+            g->cv.notify_all();          // the helper threads of the round before: the device is busy again, the host cores are theirs
+            lk.unlock();
+            const bool ok = x264gpu_stream_sync(nullptr) == X264GPU_OK;
+            std::string e = ok ? std::string() : std::string(x264gpu_last_error());
+            lk.lock();
+            g->running = false;
+            if (!ok) { g->round_rc = -1; g->err = e; }
+        }
     }
     g->round++; g->n_arrived = 0;
     std::fill(g->arrived.begin(), g->arrived.end(), 0);
     g->cv.notify_all();
 }
-static int batch_encode(BatchGroup *g, int s, const uint8_t *d_src, const x264gpu_pic &pic, x264gpu_mb *h_mb, int16_t *h_lv, std::string &err)
+// hands picture `pic` of stream s to the group and waits for the round that codes it; *buf = which pair of output buffers holds the round's results
+static int batch_submit(BatchGroup *g, int s, const uint8_t *d_src, const x264gpu_pic &pic, int *buf, std::string &err)
 {
     if (x264gpu_memcpy_d2d(g->d_in + (size_t)s * g->insz, d_src, g->insz, nullptr) != X264GPU_OK) { err = x264gpu_last_error(); return -1; }
-    {
-        std::unique_lock<std::mutex> lk(g->m);
-        // every member must have been opened before the first picture is coded: a late joiner would be a picture behind for good
-        if (!g->cv.wait_for(lk, std::chrono::seconds(60), [&] { return g->joined == g->N; })) { err = "X264GPU_BATCH: fewer sessions were opened than the batch size"; return -1; }
-        g->pics[(size_t)s] = pic; g->arrived[(size_t)s] = 1; g->n_arrived++;
-        const long my_round = g->round;
-        if (g->n_arrived >= g->active) batch_run_round(g);
-        else if (!g->cv.wait_for(lk, std::chrono::seconds(600), [&] { return g->round != my_round; })) {
-            // a member neither submitted its picture nor closed: give up on this session (the others keep waiting for it, or for its close)
-            g->arrived[(size_t)s] = 0; g->n_arrived--;
-            err = "X264GPU_BATCH: another session of the batch stopped submitting pictures";
-            return -1;
-        }
-        if (g->round_rc) { err = g->err; return -1; }
+    std::unique_lock<std::mutex> lk(g->m);
+    // every member must have been opened before the first picture is coded: a late joiner would be a picture behind for good
+    if (!g->cv.wait_for(lk, std::chrono::seconds(60), [&] { return g->joined == g->N; })) { err = "X264GPU_BATCH: fewer sessions were opened than the batch size"; return -1; }
+    g->pics[(size_t)s] = pic; g->arrived[(size_t)s] = 1; g->n_arrived++;
+    const long my_round = g->round;
+    *buf = g->overlap ? (int)(my_round & 1) : 0;
+    if (g->n_arrived >= g->active && !g->running) batch_run_round(g, lk);
+    else if (!g->cv.wait_for(lk, std::chrono::seconds(600), [&] { return g->round != my_round; })) {
+        // a member neither submitted its picture nor closed: give up on this session (the others keep waiting for it, or for its close)
+        g->arrived[(size_t)s] = 0; g->n_arrived--;
+        err = "X264GPU_BATCH: another session of the batch stopped submitting pictures";
+        return -1;
     }
-    if (x264gpu_memcpy_d2h(h_mb, g->d_mb + (size_t)s * g->nmb, g->nmb * sizeof(x264gpu_mb), nullptr) != X264GPU_OK ||
-        x264gpu_memcpy_d2h(h_lv, g->d_lv + (size_t)s * g->nmb * X264GPU_MB_LEVELS, g->nmb * X264GPU_MB_LEVELS * sizeof(int16_t), nullptr) != X264GPU_OK) { err = x264gpu_last_error(); return -1; }
+    if (g->round_rc) { err = g->err; return -1; }
+    return 0;
+}
+// stream s' records and levels of the round whose results lie in buffer pair `buf`
+static int batch_download(BatchGroup *g, int s, int buf, x264gpu_mb *h_mb, int16_t *h_lv, std::string &err)
+{
+    const x264gpu_mb *dm = buf ? g->d_mb2 : g->d_mb; const int16_t *dl = buf ? g->d_lv2 : g->d_lv;
+    void *st = g->overlap ? g->dl_stream : nullptr;
+    if (x264gpu_memcpy_d2h(h_mb, dm + (size_t)s * g->nmb, g->nmb * sizeof(x264gpu_mb), st) != X264GPU_OK ||
+        x264gpu_memcpy_d2h(h_lv, dl + (size_t)s * g->nmb * X264GPU_MB_LEVELS, g->nmb * X264GPU_MB_LEVELS * sizeof(int16_t), st) != X264GPU_OK) { err = x264gpu_last_error(); return -1; }
     return 0;
 }
 static void batch_leave(BatchGroup *g, int s)
@@ -284,7 +325,7 @@ static void batch_leave(BatchGroup *g, int s)
     if (run) {
         // (the group cannot go away meanwhile: its remaining members are blocked in batch_wait until this round is done)
         std::unique_lock<std::mutex> lk(g->m);
-        if (g->active > 0 && g->n_arrived >= g->active && g->n_arrived > 0) batch_run_round(g);
+        if (g->active > 0 && g->n_arrived >= g->active && g->n_arrived > 0 && !g->running) batch_run_round(g, lk);
     }
     if (last) batch_destroy(g);
 }
@@ -1941,6 +1982,27 @@ static int bmode_qp(x264_t *h, const x264_t::BPlanned &pl, const DpbPlan &plan, 
     return clampi((int)(q + 0.5), p.rc.i_qp_min, p.rc.i_qp_max);
 }
 
+// hands out a picture a helper thread finished (batch sessions with overlap): waits for the thread, publishes its NAL units; 0 when the slot is empty
+static int publish_deferred(x264_t *h, x264_t::Deferred &d, x264_nal_t **pp_nal, int *pi_nal, x264_picture_t *pic_out)
+{
+    if (!d.valid) return 0;
+    if (d.th.joinable()) {
+        d.hurry = true;
+        if (h->batch) { std::lock_guard<std::mutex> lg(h->batch->m); h->batch->cv.notify_all(); }
+        d.th.join();
+    }
+    d.valid = false;
+    if (!d.err.empty()) { xlog(&h->param, X264_LOG_ERROR, "x264_encoder_encode: download of a batched picture failed: %s\n", d.err.c_str()); h->failed = true; return -1; }
+    h->out.swap(d.out); h->nal_off = d.off; h->last_stats = d.stats;
+    publish_nals(h, pp_nal, pi_nal, d.types);
+    for (size_t i = 0; i < h->nals.size(); i++) if (d.types[i] == 1 || d.types[i] == 5) h->nals[i].i_ref_idc = d.nal_ref_idc;
+    if (pic_out) {
+        x264_picture_init(pic_out);
+        pic_out->i_type = d.i_type; pic_out->b_keyframe = d.b_keyframe; pic_out->i_pts = d.pts; pic_out->i_dts = d.dts; pic_out->img = d.img;
+    }
+    return (int)h->out.size();
+}
+
 // codes the next picture in coding order; returns the bytes of its NAL units, 0 when the queue still waits for input
 static int encode_bmode(x264_t *h, x264_nal_t **pp_nal, int *pi_nal, x264_picture_t *pic_out, bool flushing)
 {
@@ -1950,7 +2012,7 @@ static int encode_bmode(x264_t *h, x264_nal_t **pp_nal, int *pi_nal, x264_pictur
     auto BPHASE = [&](int i) { tb1 = now(); h->t_b[i] += tb1 - tb0; tb0 = tb1; };
     const bool decided = bmode_decide(h, flushing);
     BPHASE(0);
-    if (!decided) return 0;
+    if (!decided) return flushing ? publish_deferred(h, h->defer[h->defer_cur ^ 1].valid ? h->defer[h->defer_cur ^ 1] : h->defer[h->defer_cur], pp_nal, pi_nal, pic_out) : 0;
     const x264_t::BPlanned pl = h->bcoding.front();
     h->bcoding.pop_front();
     // the disposable pictures coded right behind this one (x264_reference_hierarchy_reset looks at them)
@@ -1989,9 +2051,13 @@ static int encode_bmode(x264_t *h, x264_nal_t **pp_nal, int *pi_nal, x264_pictur
         d_offsets = pl.type == PIC_B ? h->q_aq[(size_t)pl.e.slot] : h->q_tree[(size_t)pl.e.slot];
     else if (h->aq_mode >= 2 && h->aq_strength != 0.f) d_offsets = h->q_aq[(size_t)pl.e.slot];      // --aq-mode 2 / 3: the offsets computed when the picture arrived
     if (d_offsets) x264gpu_encoder_set_mb_qp_offsets(h->gpu, d_offsets);
+    int bbuf = 0;
+    bool deferred = false;
     if (h->batch) {
         std::string berr;
-        if (batch_encode(h->batch, h->batch_idx, h->q_raw[(size_t)pl.e.slot], pic, h->h_mb.data(), h->h_lv.data(), berr)) {
+        deferred = h->batch->overlap;          // the download and the entropy coding of this picture run beside the group's next round (below)
+        if (batch_submit(h->batch, h->batch_idx, h->q_raw[(size_t)pl.e.slot], pic, &bbuf, berr) ||
+            (!deferred && batch_download(h->batch, h->batch_idx, bbuf, h->h_mb.data(), h->h_lv.data(), berr))) {
             xlog(&p, X264_LOG_ERROR, "x264_encoder_encode: GPU hot path failed: %s\n", berr.c_str());
             h->failed = true;
             return -1;
@@ -2041,6 +2107,48 @@ static int encode_bmode(x264_t *h, x264_nal_t **pp_nal, int *pi_nal, x264_pictur
     sp.disable_deblock_idc = p.b_deblocking_filter ? 0 : 1; sp.alpha_off_div2 = p.i_deblocking_filter_alphac0; sp.beta_off_div2 = p.i_deblocking_filter_beta;
     sp.transform8x8_mode = p.analyse.b_transform_8x8; sp.cabac = p.b_cabac; sp.slices_plain = h->slices_plain;
     h->dpb.fill(sp);
+    if (deferred) {
+        // everything the slice writer needs is fixed now: the helper thread downloads this stream's records and levels (on the group's download stream) and writes the
+        // slices behind the header NAL units; the DPB moves on at once (the next picture's plan needs it), the NAL units leave with the next call
+        x264_t::Deferred &d = h->defer[h->defer_cur];
+        d.out = h->out; d.off = h->nal_off; d.types = types; d.err.clear(); d.nal_ref_idc = plan.nal_ref_idc; d.stats = SliceStats{ 0 };
+        d.mb.resize((size_t)h->nmb); d.lv.resize((size_t)h->nmb * X264GPU_MB_LEVELS);
+        d.i_type = idr ? X264_TYPE_IDR : pl.type == PIC_I ? X264_TYPE_I : pl.type == PIC_P ? X264_TYPE_P : pl.type == PIC_BREF ? X264_TYPE_BREF : X264_TYPE_B;
+        d.b_keyframe = idr; d.pts = pl.e.pts; d.img = pl.e.img;
+        {
+            const long k = h->coded_count, delay = !h->bframes ? 0 : h->bpyramid ? 2 : 1;
+            const size_t np = h->all_pts.size();
+            if (k >= delay) d.dts = h->all_pts[(size_t)(k - delay) < np ? (size_t)(k - delay) : np - 1];
+            else d.dts = h->all_pts[(size_t)k < np ? (size_t)k : np - 1] - (h->all_pts[(size_t)delay < np ? (size_t)delay : np - 1] - h->all_pts[0]);
+        }
+        BatchGroup *g = h->batch;
+        const int bidx = h->batch_idx, slices = h->slices, threads = h->cavlc_threads, dev = h->device;
+        const bool annexb = p.b_annexb != 0, first = d.off.empty();
+        long my_launched;
+        { std::lock_guard<std::mutex> lg(g->m); my_launched = g->launched; }
+        d.hurry = false;
+        d.th = std::thread([&d, g, bidx, bbuf, sp, slices, threads, annexb, first, idr, dev, my_launched]() {
+            x264gpu_set_device(dev);
+            if (batch_download(g, bidx, bbuf, d.mb.data(), d.lv.data(), d.err)) return;
+            {
+                // the slices are written once the group's next round is on the device (the callers need the cores to get it there), or when the picture is asked for
+                std::unique_lock<std::mutex> lk(g->m);
+                g->cv.wait_for(lk, std::chrono::seconds(30), [&] { return g->launched > my_launched || d.hurry.load() || g->closed; });
+            }
+            const size_t before = d.off.size();
+            write_picture(d.out, &d.off, sp, slices, d.mb.data(), d.lv.data(), annexb, first, &d.stats, threads);
+            for (size_t i = before; i < d.off.size(); i++) d.types.push_back(idr ? 5 : 1);
+        });
+        d.valid = true;
+        h->dpb.commit();
+        BPHASE(3);
+        h->t_b[4] += 1;
+        if (idr) h->idr_pic_id = (h->idr_pic_id + 1) & 0xffff;
+        h->coded_count++;
+        h->frame_no++;
+        h->defer_cur ^= 1;
+        return publish_deferred(h, h->defer[h->defer_cur], pp_nal, pi_nal, pic_out);          // the picture of the call before (0: none yet)
+    }
     h->last_stats.skip = 0;
     {
         const size_t before = h->nal_off.size();
@@ -2207,13 +2315,14 @@ int x264_encoder_encode(x264_t *h, x264_nal_t **pp_nal, int *pi_nal, x264_pictur
     return size;
 }
 
-int x264_encoder_delayed_frames(x264_t *h) { return !h || h->failed ? 0 : h->G > 1 ? (int)(h->submitted - h->emitted) : h->dpbmode ? (int)(h->bq.size() + h->bcoding.size()) : (int)h->queue.size(); }
+int x264_encoder_delayed_frames(x264_t *h) { return !h || h->failed ? 0 : h->G > 1 ? (int)(h->submitted - h->emitted) : h->dpbmode ? (int)(h->bq.size() + h->bcoding.size()) + (h->defer[0].valid ? 1 : 0) + (h->defer[1].valid ? 1 : 0) : (int)h->queue.size(); }
 
 void x264_encoder_close(x264_t *h)
 {
     if (!h) return;
     join_pool(h);
     join_gpu(h);
+    for (auto &d : h->defer) if (d.th.joinable()) { d.hurry = true; if (h->batch) { std::lock_guard<std::mutex> lg(h->batch->m); h->batch->cv.notify_all(); } d.th.join(); }
     if (getenv("X264GPU_HOST_TIMING") && h->t_phase[5] > 0)
         fprintf(stderr, "x264gpu host timing, ms per call over %.0f calls: copy-in %.2f, upload+lookahead %.2f, GPU %.2f, download %.2f, entropy %.2f\n", h->t_phase[5],
                 1e3 * h->t_phase[0] / h->t_phase[5], 1e3 * h->t_phase[1] / h->t_phase[5], 1e3 * h->t_phase[2] / h->t_phase[5], 1e3 * h->t_phase[3] / h->t_phase[5], 1e3 * h->t_phase[4] / h->t_phase[5]);

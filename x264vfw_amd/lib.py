@@ -80,6 +80,8 @@ _SIGS = {
     "x264gpu_memcpy_d2d": (_i, [_vp, _vp, _sz, _vp]),
     "x264gpu_memset": (_i, [_vp, _i, _sz, _vp]),
     "x264gpu_stream_sync": (_i, [_vp]),
+    "x264gpu_stream_create": (_i, [C.POINTER(_vp)]),
+    "x264gpu_stream_destroy": (_i, [_vp]),
     "x264gpu_pixel_metric": (_i, [_i, _vp, _vp, _i, _i, _i, _vp, _vp]),
     "x264gpu_pixel_var": (_i, [_vp, _i, _i, _i, _vp, _vp]),
     "x264gpu_pixel_hadamard_ac": (_i, [_vp, _i, _i, _i, _vp, _vp]),
