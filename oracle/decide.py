@@ -5,7 +5,7 @@ a second time, independently of that code, in plain Python over the CPU checker'
 tests/oracle_lib.OracleSlicetype), so that a session's decisions can be compared with something other than themselves:
 
   [x264-upstream] encoder/slicetype.c  x264_slicetype_decide (keyint / min-keyint, closed GOPs, the run of B pictures), x264_slicetype_analyse with
-                                       --b-adapt 0 / 1 (the cost comparisons and thresholds of the "fast" B decision) / 2 (slicetype_path, slicetype_path_cost:
+                                       --b-adapt 0 / 1 (the "fast" B decision: path cost of ..BP against ..PP) / 2 (slicetype_path, slicetype_path_cost:
                                        the Viterbi search over the lengths of the window, i_delay = max(bframes, 3) * 4), scenecut / scenecut_internal
                                        (the bias growing with the distance from the last keyframe, the flash test under B pictures)
   [x264-upstream] encoder/ratecontrol.c  rate_estimate_qscale for CRF (short-term complexity blur, get_qscale, the I picture after P pictures taking the
@@ -244,34 +244,30 @@ class Lookahead:
         num_bframes, num_analysed = 0, num_frames
         if p.bframes:
             if p.b_adapt == 1:
-                i_mb_count = (p.mbw - 2) * (p.mbh - 2) if p.mbw > 2 and p.mbh > 2 else p.mbw * p.mbh
-                i = 0
-                while i <= num_frames - 2:
-                    cost2p1 = self.cost(fr, i, i + 2, i + 2)
-                    if self.c.intra_mbs(fr[i + 2].slot, 2) > i_mb_count // 2:
-                        fr[i + 1].type = P
-                        fr[i + 2].type = P
-                        i += 2
+                # X264_B_ADAPT_FAST (the x264 generation whose lookahead knows forced types): picture j is a B picture when the path "..BP" from the last non-B
+                # picture costs less than "..PP" (slicetype_path_cost on both), runs no longer than --bframes
+                isb = lambda i: fr[i].type in (B, BREF)
+                last_nonb, num_bf = 0, p.bframes
+                for j in range(1, num_frames):
+                    if j - 1 > 0 and isb(j - 1):
+                        num_bf -= 1
+                    else:
+                        last_nonb, num_bf = j - 1, p.bframes
+                    if not num_bf:
+                        if fr[j].type == AUTO or isb(j):
+                            fr[j].type = P
                         continue
-                    cost1b1 = self.cost(fr, i, i + 2, i + 1)
-                    cost1p0 = self.cost(fr, i, i + 1, i + 1)
-                    cost2p0 = self.cost(fr, i + 1, i + 2, i + 2)
-                    if cost1p0 + cost2p0 < cost1b1 + cost2p1:
-                        fr[i + 1].type = P
-                        i += 1
+                    if fr[j].type != AUTO:
                         continue
-                    fr[i + 1].type = B
-                    j = i + 2
-                    while j <= min(i + p.bframes, num_frames - 1):
-                        pthresh = max(300 - (50 - p.b_bias) * (j - i - 1), 30)          # P_SENS_BIAS
-                        pcost = self.cost(fr, i, j + 1, j + 1)
-                        if pcost > pthresh * i_mb_count or self.c.intra_mbs(fr[j + 1].slot, j - i + 1) > i_mb_count // 3:
-                            break
-                        fr[j].type = B
-                        j += 1
-                    fr[j].type = P
-                    i = j
-                fr[num_frames].type = P
+                    if isb(j + 1):
+                        fr[j].type = P
+                        continue
+                    run = j - last_nonb - 1
+                    cost_p = self.path_cost(fr[last_nonb:], "B" * run + "PP", 1 << 62)
+                    cost_b = self.path_cost(fr[last_nonb:], "B" * run + "BP", cost_p)
+                    fr[j].type = B if cost_b < cost_p else P
+                if fr[num_frames].type in (AUTO, B, BREF):
+                    fr[num_frames].type = P
                 while num_bframes < num_frames and fr[num_bframes + 1].type == B:
                     num_bframes += 1
             elif p.b_adapt == 2:

@@ -1578,24 +1578,32 @@ static void st_analyse(x264_t *h, StFrames &F, int framecnt, bool keyframe = fal
             if (type(num_frames) == ST_AUTO || type(num_frames) == ST_B || type(num_frames) == ST_BREF) type(num_frames) = ST_P;
             while (num_bframes < num_frames && type(num_bframes + 1) == ST_B) num_bframes++;
         } else if (h->badapt == 1) {
-            const int mbw = h->mbw, mbh = h->mbh, i_mb_count = mbw > 2 && mbh > 2 ? (mbw - 2) * (mbh - 2) : mbw * mbh;
-            for (int i = 0; i <= num_frames - 2;) {
-                const int cost2p1 = st_cost(F, i, i + 2, i + 2);
-                if (x264gpu_slicetype_intra_mbs(h->st, F.f[(size_t)i + 2]->slot, 2, 0) > i_mb_count / 2) { type(i + 1) = ST_P; type(i + 2) = ST_P; i += 2; continue; }
-                const int cost1b1 = st_cost(F, i, i + 2, i + 1), cost1p0 = st_cost(F, i, i + 1, i + 1), cost2p0 = st_cost(F, i + 1, i + 2, i + 2);
-                if (cost1p0 + cost2p0 < cost1b1 + cost2p1) { type(i + 1) = ST_P; i += 1; continue; }
-                type(i + 1) = ST_B;
-                int j;
-                for (j = i + 2; j <= (i + h->bframes < num_frames - 1 ? i + h->bframes : num_frames - 1); j++) {
-                    const int pthresh = 300 - (50 - p.i_bframe_bias) * (j - i - 1) > 30 ? 300 - (50 - p.i_bframe_bias) * (j - i - 1) : 30;
-                    const int pcost = st_cost(F, i, j + 1, j + 1);
-                    if (pcost > pthresh * i_mb_count || x264gpu_slicetype_intra_mbs(h->st, F.f[(size_t)j + 1]->slot, j - i + 1, 0) > i_mb_count / 3) break;
-                    type(j) = ST_B;
-                }
-                type(j) = ST_P;
-                i = j;
+            // X264_B_ADAPT_FAST as the x264 generation this host restates has it (the one whose trellis loader and scene-cut loop know forced types): picture j becomes
+            // a B picture when the path "..BP" from the last non-B picture costs less than "..PP" (slicetype_path_cost on both), runs no longer than --bframes.
+            // (Older x264 compared pairwise frame costs against thresholds — INTER_THRESH / P_SENS_BIAS; which of the two the driver's core 157 carries cannot be
+            // checked here: DESIGN.md §0.)
+            auto isb = [&](int i) { return type(i) == ST_B || type(i) == ST_BREF; };
+            int last_nonb = 0, num_bf = h->bframes;
+            char path[ST_PATH_MAX + 4];
+            for (int j = 1; j < num_frames && !h->failed; j++) {
+                if (j - 1 > 0 && isb(j - 1)) num_bf--;
+                else { last_nonb = j - 1; num_bf = h->bframes; }
+                if (!num_bf) { if (type(j) == ST_AUTO || isb(j)) type(j) = ST_P; continue; }
+                if (type(j) != ST_AUTO) continue;
+                if (isb(j + 1)) { type(j) = ST_P; continue; }
+                const int bfr = j - last_nonb - 1;
+                StFrames sub;
+                sub.h = h;
+                sub.f.assign(F.f.begin() + last_nonb, F.f.end());
+                memset(path, 'B', (size_t)bfr);
+                strcpy(path + bfr, "PP");
+                const uint64_t cost_p = st_path_cost(sub, path, ~0ull >> 1);
+                strcpy(path + bfr, "BP");
+                const uint64_t cost_b = st_path_cost(sub, path, cost_p);
+                type(j) = cost_b < cost_p ? ST_B : ST_P;
             }
-            type(num_frames) = ST_P;
+            if (h->failed) return;
+            if (type(num_frames) == ST_AUTO || type(num_frames) == ST_B || type(num_frames) == ST_BREF) type(num_frames) = ST_P;
             while (num_bframes < num_frames && type(num_bframes + 1) == ST_B) num_bframes++;
         } else {
             num_bframes = num_frames - 1 < h->bframes ? num_frames - 1 : h->bframes;
