@@ -309,8 +309,8 @@ def csp_probe(torch, lib, dev, W, H, frames=64, iters=10):
 def lookahead_probe(torch, lib, dev, args, data, first, K, S, W, H):
     """The DEVICE work of x264's lookahead for the same streams and pictures as the timed window, run beside it (the lock-step batch codes a fixed
     picture structure, so the decisions themselves are discarded): per display picture x264_frame_init_lowres + x264_adaptive_quant_frame, the two
-    slicetype_frame_cost calls --b-adapt 1 spends on a new picture (as a P picture on the last non-B one; its predecessor as a B picture between
-    them), and when a mini-GOP closes its path costs and macroblock_tree over it (clear / propagate / finish) — [x264-upstream] encoder/slicetype.c
+    frame costs --b-adapt 1 spends on a new picture (x264's fast mode: the paths "..BP" and "..PP" from the last non-B picture through slicetype_path_cost),
+    and when a mini-GOP closes macroblock_tree over it (clear / propagate / finish) — [x264-upstream] encoder/slicetype.c
     x264_slicetype_analyse, macroblock_tree; csrc/slicetype.hip, csrc/lookahead.hip.  Returns the time per picture and the launches made."""
     import numpy as np
     nslots = args.bframes + 5
@@ -341,6 +341,27 @@ def lookahead_probe(torch, lib, dev, args, data, first, K, S, W, H):
         with timed("propagate"):
             lib.check(lib.x264gpu_slicetype_propagate(st, sl(p0), sl(p1), sl(b), b - p0, p1 - b, ref, None), "slicetype_propagate")
 
+    def path_cost(base, path):          # x264 slicetype_path_cost over pictures base + 1 .. base + len(path) (b-pyramid: through the middle B picture of a run)
+        loc, cur, n = 1, 0, len(path)
+        while loc <= n:
+            nxt = loc
+            while nxt <= n and path[nxt - 1] == "B":
+                nxt += 1
+            if nxt > n:
+                break
+            cost(base + cur, base + nxt, base + nxt)
+            if nxt - cur > 2:
+                mid = cur + (nxt - cur) // 2
+                cost(base + cur, base + nxt, base + mid)
+                for b_ in range(loc, mid):
+                    cost(base + cur, base + mid, base + b_)
+                for b_ in range(mid + 1, nxt):
+                    cost(base + mid, base + nxt, base + b_)
+            else:
+                for b_ in range(loc, nxt):
+                    cost(base + cur, base + nxt, base + b_)
+            loc, cur = nxt + 1, nxt
+
     types = display_types(K, args.bframes, max(K, 1))
     torch.cuda.synchronize(dev)
     t0 = time.perf_counter()
@@ -354,10 +375,17 @@ def lookahead_probe(torch, lib, dev, args, data, first, K, S, W, H):
         if i == 0:
             cost(0, 0, 0)
             continue
-        cost(p0, i, i)
-        if i - p0 >= 2:
-            cost(p0, i, i - 1)
+        # --b-adapt 1 (x264's fast mode: the path "..BP" against "..PP" from the last non-B picture, slicetype_path_cost on both) for picture j = i - 1, which needs
+        # picture i: the frame costs those two paths ask for (a cost computed once stays with its picture: repeated requests return at once)
+        j = i - 1
+        if j >= 1:
+            ln = max(q for q in range(j) if types[q] != "B")
+            run = j - ln - 1
+            if run < args.bframes:
+                path_cost(ln, "B" * run + "PP")
+                path_cost(ln, "B" * run + "BP")
         if types[i] != "B":
+            cost(p0, i, i)
             n = i - p0 - 1
             lib.check(lib.x264gpu_slicetype_clear_propagate(st, sl(i), None), "clear_propagate")
             lib.check(lib.x264gpu_slicetype_clear_propagate(st, sl(p0), None), "clear_propagate")
