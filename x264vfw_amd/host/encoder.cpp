@@ -2119,6 +2119,7 @@ static int encode_bmode(x264_t *h, x264_nal_t **pp_nal, int *pi_nal, x264_pictur
         // everything the slice writer needs is fixed now: the helper thread downloads this stream's records and levels (on the group's download stream) and writes the
         // slices behind the header NAL units; the DPB moves on at once (the next picture's plan needs it), the NAL units leave with the next call
         x264_t::Deferred &d = h->defer[h->defer_cur];
+        if (d.th.joinable()) d.th.join();          // (handed out two calls ago: long finished)
         d.out = h->out; d.off = h->nal_off; d.types = types; d.err.clear(); d.nal_ref_idc = plan.nal_ref_idc; d.stats = SliceStats{ 0 };
         d.mb.resize((size_t)h->nmb); d.lv.resize((size_t)h->nmb * X264GPU_MB_LEVELS);
         d.i_type = idr ? X264_TYPE_IDR : pl.type == PIC_I ? X264_TYPE_I : pl.type == PIC_P ? X264_TYPE_P : pl.type == PIC_BREF ? X264_TYPE_BREF : X264_TYPE_B;
