@@ -351,7 +351,7 @@ def test_host_session_mbtree_through_b_pictures(tmp_path):
     assert info0["mbtree"] == 0 and stream0 != stream
 
 
-def _batch(n, w, h, nf, opts, gpu=False, timeout=900):
+def _batch(n, w, h, nf, opts, gpu=False, timeout=900, overlap=True):
     import json
     import os
     import subprocess
@@ -359,6 +359,7 @@ def _batch(n, w, h, nf, opts, gpu=False, timeout=900):
     here = os.path.dirname(os.path.abspath(__file__))
     env = dict(os.environ)
     env.pop("X264GPU_BATCH", None)
+    env["X264GPU_BATCH_OVERLAP"] = "1" if overlap else "0"          # the host's entropy coding beside the device's next round (one picture of delay), or inside the call
     r = subprocess.run([sys.executable, os.path.join(here, "stub", "run_host_batch.py"), str(n), str(w), str(h), str(nf)] + opts + (["--gpu"] if gpu else []),
                        capture_output=True, text=True, timeout=timeout, env=env)
     assert r.returncode == 0, r.stderr[-2000:]
@@ -375,6 +376,8 @@ def test_cross_session_batcher_is_byte_identical(n, opts):
     picture); every session's stream equals the one it writes on its own (driverproc.c:110-128: one CODEC per stream)"""
     r = _batch(n, 176, 144, 11, opts)
     assert r["equal"] == [True] * n and r["distinct"] == n, r
+    r0 = _batch(n, 176, 144, 11, opts, overlap=False)          # ... with download and entropy coding inside the call: the same streams
+    assert r0["equal"] == [True] * n and r0["sizes"] == r["sizes"], (r0, r)
 
 
 def fade_frames(w, h, n, seed, step=6):
