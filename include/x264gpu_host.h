@@ -47,6 +47,8 @@ int x264host_mux_close(void *h, int64_t largest_pts, int64_t second_largest_pts)
 int x264host_last_decision(x264_t *h, int *qp, int *scenecut, int32_t costs[4]);
 /* ... and the float quantiser (x264 rc->qpm) its macroblock quantisers were rounded from (0 = the integer quantiser) */
 float x264host_last_qpm(x264_t *h);
+/* ... the second pass' plan (init_pass2): per picture of the statistics file, display order, the planned quantiser scale and the bits expected before it; returns the count */
+int x264host_pass2_plan(x264_t *h, double *new_qscale, double *expected_bits, int n);
 /* reconstructed picture of the last encoded frame as I420 (host memory) */
 int x264host_get_recon(x264_t *h, uint8_t *i420_out);
 

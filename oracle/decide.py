@@ -580,3 +580,147 @@ def run_session(frames, params, costs, slots, aq_of=None):
         pass
     run_session.last_stats = la.stats
     return out
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------------------------------------------
+# 2-pass: x264's init_pass2 ([x264-upstream] encoder/ratecontrol.c) over a statistics file — the complexity blur, get_qscale, get_diff_limited_q, the smoothing of the curve,
+# the search for the rate factor that makes qscale2bits add up to the requested size.  Doubles as in x264; `mask` of the P-quantiser accumulator is a float there.
+# No VBV, no zones, no macroblock-tree file (none of them is in the product's second pass).
+class StatEntry:
+    def __init__(self, line):
+        f = dict(kv.split(":", 1) for kv in line.split() if ":" in kv)
+        self.frame, self.out, self.type = int(f["in"]), int(f["out"]), f["type"]
+        self.qscale = qp2qscale(_f(float(f["q"])))
+        self.tex, self.mv, self.misc, self.icount = int(f["tex"]), int(f["mv"]), int(f["misc"]), int(f["imb"])
+        self.kind = 0 if self.type in "Ii" else 1 if self.type == "P" else 2          # SLICE_TYPE_I / _P / _B as the rate control groups them
+        self.kept_as_ref = self.type != "b"
+        self.blurred = self.new_qscale = self.expected_bits = 0.0
+
+
+def qscale2bits(e, qscale):
+    qscale = max(qscale, 0.1)
+    return (e.tex + .1) * (e.qscale / qscale) ** 1.1 + e.mv * (max(e.qscale, 1) / max(qscale, 1)) ** 0.5 + e.misc
+
+
+def init_pass2(stat_lines, nmb, bitrate_kbps, fps=25.0, bframes=3, qcomp=0.6, qblur=0.5, cplxblur=20.0, ip_factor=1.4, pb_factor=1.3, qpmin=0, qpmax=51, qpstep=4):
+    """-> the entries in display order with new_qscale (the plan) and expected_bits (what should have been spent when the picture starts, coding order)"""
+    ent = [StatEntry(ln) for ln in stat_lines if not ln.startswith("#")]
+    E = [None] * len(ent)
+    for e in ent:
+        E[e.frame] = e
+    n = len(E)
+    qcomp, qblur, cplxblur, ipf, pbf = _f(qcomp), _f(qblur), _f(cplxblur), abs(_f(ip_factor)), abs(_f(pb_factor))
+    frame_duration = min(max(1.0 / fps, 0.01), 1.0) / 0.04          # CLIP_DURATION / BASE_FRAME_DURATION, constant frame rate
+    all_available_bits = bitrate_kbps * 1000.0 * (n / fps)
+    filter_size = int(qblur * 4) | 1
+    base_cplx = nmb * (120 if bframes else 80)
+    lstep, lmin, lmax = 2.0 ** (qpstep / 6.0), qp2qscale(qpmin), qp2qscale(qpmax)
+    assert all_available_bits >= sum(e.misc for e in E), "requested bitrate is too low"
+    for i, e in enumerate(E):          # blur the complexities
+        weight_sum = cplx_sum = 0.0
+        weight, j = 1.0, 1
+        while j < cplxblur * 2 and j < n - i:
+            r = E[i + j]
+            weight *= 1 - _f(_f(r.icount) / _f(nmb)) ** 2
+            if weight < .0001:
+                break
+            g = weight * math.exp(-j * j / 200.0)
+            weight_sum += g
+            cplx_sum += g * (qscale2bits(r, 1) - r.misc) / frame_duration
+            j += 1
+        weight, j = 1.0, 0
+        while j <= cplxblur * 2 and j <= i:
+            r = E[i - j]
+            g = weight * math.exp(-j * j / 200.0)
+            weight_sum += g
+            cplx_sum += g * (qscale2bits(r, 1) - r.misc) / frame_duration
+            weight *= 1 - _f(_f(r.icount) / _f(nmb)) ** 2
+            if weight < .0001:
+                break
+            j += 1
+        e.blurred = cplx_sum / weight_sum
+    st = {"last_q": [0.0] * 3, "last_non_b": -1, "last_accum_p_norm": 1.0, "accum_p_norm": 0.0, "accum_p_qp": 0.0}
+
+    def get_qscale(e, rate_factor):
+        q = e.blurred ** (1 - qcomp)
+        return st["last_q"][e.kind] if not math.isfinite(q) or e.tex + e.mv == 0 else q / rate_factor
+
+    def get_diff_limited_q(e, q):
+        k = e.kind
+        last_p_q = st["last_q"][1]
+        last_non_b_q = st["last_q"][st["last_non_b"]] if st["last_non_b"] >= 0 else q          # (last_non_b_pict_type = -1 at the start: never read before it is set)
+        if k == 0:
+            iq = q
+            if st["accum_p_norm"] <= 0:
+                q = iq
+            elif ip_factor < 0:
+                q = iq / ipf
+            else:
+                pq = qp2qscale(st["accum_p_qp"] / st["accum_p_norm"])
+                q = pq / ipf if st["accum_p_norm"] >= 1 else st["accum_p_norm"] * pq / ipf + (1 - st["accum_p_norm"]) * iq
+        elif k == 2:
+            if pb_factor > 0:
+                q = last_non_b_q
+            if not e.kept_as_ref:
+                q *= pbf
+        elif st["last_non_b"] == 1 and e.tex == 0:
+            q = last_p_q
+        if st["last_non_b"] == k and (k != 0 or st["last_accum_p_norm"] < 1):
+            last_q = st["last_q"][k]
+            q = min(max(q, last_q / lstep), last_q * lstep)
+        st["last_q"][k] = q
+        if k != 2:
+            st["last_non_b"] = k
+        if k == 0:
+            st["last_accum_p_norm"], st["accum_p_norm"], st["accum_p_qp"] = st["accum_p_norm"], 0.0, 0.0
+        if k == 1:
+            mask = _f(1 - _f(_f(e.icount) / _f(nmb)) ** 2)          # (a float in x264)
+            st["accum_p_qp"] = mask * (qscale2qp(q) + st["accum_p_qp"])
+            st["accum_p_norm"] = mask * (1 + st["accum_p_norm"])
+        return q
+
+    expected_bits = 1.0
+    st["last_q"] = [base_cplx ** (1 - qcomp)] * 3
+    for e in E:
+        q = get_qscale(e, 1.0)
+        expected_bits += qscale2bits(e, q)
+        st["last_q"][e.kind] = q
+    step_mult = all_available_bits / expected_bits
+    rate_factor, step = 0.0, 1E4 * step_mult
+    while step > 1E-7 * step_mult:
+        expected_bits = 0.0
+        rate_factor += step
+        st.update(last_non_b=-1, last_accum_p_norm=1.0, accum_p_norm=0.0, accum_p_qp=0.0)
+        st["last_q"] = [base_cplx ** (1 - qcomp) / rate_factor] * 3
+        qs = []
+        for e in E:
+            qs.append(get_qscale(e, rate_factor))
+            st["last_q"][e.kind] = qs[-1]
+        for i in range(n - 1, -1, -1):          # fixed I / B quantisers relative to P
+            qs[i] = get_diff_limited_q(E[i], qs[i])
+        if filter_size > 1:                     # smooth the curve over pictures of one kind
+            bl = []
+            for i in range(n):
+                q = ssum = 0.0
+                for j in range(filter_size):
+                    idx = i + j - filter_size // 2
+                    d = idx - i
+                    coeff = 1.0 if qblur == 0 else math.exp(-d * d / (qblur * qblur))
+                    if idx < 0 or idx >= n or E[i].kind != E[idx].kind:
+                        continue
+                    q += qs[idx] * coeff
+                    ssum += coeff
+                bl.append(q / ssum)
+        else:
+            bl = qs
+        for e, q in zip(E, bl):
+            e.new_qscale = min(max(q, lmin), lmax)
+            expected_bits += qscale2bits(e, e.new_qscale)
+        if expected_bits > all_available_bits:
+            rate_factor -= step
+        step *= 0.5
+    acc = 0.0
+    for e in sorted(E, key=lambda x: x.out):
+        e.expected_bits = acc
+        acc += qscale2bits(e, e.new_qscale)
+    return E

@@ -45,6 +45,7 @@ def main():
     fade = int(opts.pop("fade", 0) or 0)
     preset = (opts.pop("preset", None) or "medium").encode()
     want_log = int(opts.pop("log", 0) or 0)
+    want_plan = int(opts.pop("plan", 0) or 0)          # a second pass: also print the quantiser scales init_pass2 planned (x264host_pass2_plan)
     frames = make_frames(w, h, n, seed, scene_len, static, fade)
     p = HL.Param()
     assert H.x264_param_default_preset(C.byref(p), preset, None) == 0
@@ -63,6 +64,11 @@ def main():
     assert h_
     eff = HL.Param()
     H.x264_encoder_parameters(h_, C.byref(eff))
+    plan = None
+    if want_plan:
+        qs, eb = (C.c_double * n)(), (C.c_double * n)()
+        cnt = H.x264host_pass2_plan(h_, qs, eb, n)
+        plan = {"count": cnt, "new_qscale": list(qs)[:cnt], "expected_bits": list(eb)[:cnt]}
     pic, out = HL.Picture(), HL.Picture()
     assert H.x264_picture_alloc(C.byref(pic), HL.X264_CSP_I420, w, h) == 0
     nal, nn = C.POINTER(HL.Nal)(), C.c_int()
@@ -93,7 +99,7 @@ def main():
     print(json.dumps({"recs": recs, "bframes": eff.i_bframe, "pyramid": eff.i_bframe_pyramid, "badapt": eff.i_bframe_adaptive, "weightb": eff.analyse.b_weighted_bipred,
                       "weightp": eff.analyse.i_weighted_pred, "mbtree": eff.rc.b_mb_tree, "subme": eff.analyse.i_subpel_refine, "cabac": eff.b_cabac, "direct": eff.analyse.i_direct_mv_pred, "first_output_after": first_out, "log": log,
                       "rc_method": eff.rc.i_rc_method, "stat_read": eff.rc.b_stat_read, "stat_write": eff.rc.b_stat_write, "inter": eff.analyse.inter, "refs": eff.i_frame_reference,
-                      "me": eff.analyse.i_me_method, "trellis": eff.analyse.i_trellis, "mv_range": eff.analyse.i_mv_range, "me_range": eff.analyse.i_me_range}))
+                      "me": eff.analyse.i_me_method, "trellis": eff.analyse.i_trellis, "mv_range": eff.analyse.i_mv_range, "me_range": eff.analyse.i_me_range, "plan": plan}))
 
 
 if __name__ == "__main__":

@@ -142,6 +142,29 @@ def test_zones_move_the_quantisers(tmp_path):
         assert pic.qp == want, (f, t, pic.qp, want)
 
 
+def test_second_pass_plan_equals_the_twin(tmp_path):
+    """x264's init_pass2 (the driver's encoding type 4, codec.c:1516-1541) twice: the host's plan — every picture's quantiser scale and the bits expected before it — against
+    oracle/decide.py init_pass2 over the statistics file the first pass wrote: equal to a part in 10^9 (the same double arithmetic in another language), on two bitrates"""
+    w, h, n = 176, 144, 60
+    st = str(tmp_path / "x264.stats")
+    common = ["scene_len=23", "keyint=40", "bframes=3", "subme=5", "trellis=0", f"stats={st}"]
+    host_session(tmp_path, w, h, n, 9, common + ["bitrate=260", "pass=1"])
+    lines = open(st).read().splitlines()
+    nmb = ((w + 15) // 16) * ((h + 15) // 16)
+    for kbps in (260, 120):
+        info, _pics = host_session(tmp_path, w, h, n, 9, common + [f"bitrate={kbps}", "pass=2", "plan=1"])
+        plan = info["plan"]
+        assert plan and plan["count"] == n
+        E = D.init_pass2(lines, nmb, kbps)
+        got_q, want_q = np.array(plan["new_qscale"]), np.array([e.new_qscale for e in E])
+        assert np.allclose(got_q, want_q, rtol=1e-9, atol=0), (kbps, np.abs(got_q / want_q - 1).max())
+        got_b, want_b = np.array(plan["expected_bits"]), np.array([e.expected_bits for e in E])
+        assert np.allclose(got_b, want_b, rtol=1e-9, atol=1e-6), (kbps, np.abs(got_b - want_b).max())
+        assert len({round(float(q), 6) for q in want_q}) > 10          # a curve, not a constant
+        total = want_b.max() + max(D.qscale2bits(e, e.new_qscale) for e in E if e.expected_bits == want_b.max())
+        assert abs(total / (kbps * 1000.0 * n / 25.0) - 1.0) < 0.01      # the plan adds up to the request
+
+
 def test_fade_weights_are_the_fades_ratio(tmp_path):
     """known answer for x264_weights_analyse as the host restates it: on a clip that fades to black by 5 % of the first picture's level a picture
     (luma scaled, chroma scaled towards 128) a P picture's explicit weight of reference 0 must be the ratio of the two pictures' fade levels —

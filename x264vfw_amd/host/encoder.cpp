@@ -615,6 +615,7 @@ x264_t *x264_encoder_open(x264_param_t *param)
     if ((h->pass1 || h->pass2) && p.rc.b_mb_tree) { xlog(&p, X264_LOG_INFO, "2-pass: the macroblock-tree statistics file is not implemented in the MI355X path: mbtree 0 in both passes\n"); p.rc.b_mb_tree = 0; }
     parse_zones(h, p.rc.psz_zones);
     if (!h->zones.empty()) xlog(&p, X264_LOG_INFO, "%d zone%s (quantiser / bitrate factor per range of pictures)\n", (int)h->zones.size(), h->zones.size() > 1 ? "s" : "");
+    if (!h->zones.empty() && h->pass2) xlog(&p, X264_LOG_WARNING, "zones are not applied to the second pass' plan in the MI355X path (the first pass and single-pass sessions honour them)\n");
     if (p.rc.i_vbv_max_bitrate > 0 || p.rc.i_vbv_buffer_size > 0) xlog(&p, X264_LOG_WARNING, "VBV (vbv-maxrate / vbv-bufsize) is not implemented in the MI355X path: unconstrained\n");
     p.rc.i_vbv_max_bitrate = 0; p.rc.i_vbv_buffer_size = 0;
     if (p.analyse.i_noise_reduction) { xlog(&p, X264_LOG_WARNING, "nr (noise reduction) is not implemented in the MI355X path: nr 0\n"); p.analyse.i_noise_reduction = 0; }
@@ -1819,22 +1820,23 @@ static bool p2_init(x264_t *h)
         xlog(&p, X264_LOG_ERROR, "requested bitrate is too low. estimated minimum is %d kbps\n", (int)(all_const_bits * fps / (n * 1000.)));
         return false;
     }
-    // blur the complexities (not the quantisers: one very simple picture must not drag its neighbours down)
+    // blur the complexities (not the quantisers: one very simple picture must not drag its neighbours down); per unit of BASE_FRAME_DURATION as x264 has it
+    const double frame_duration = (1.0 / fps < 0.01 ? 0.01 : 1.0 / fps > 1.0 ? 1.0 : 1.0 / fps) / 0.04;
     for (int i = 0; i < n; i++) {
         double weight_sum = 0, cplx_sum = 0, weight = 1.0;
         for (int j = 1; j < cplxblur * 2 && j < n - i; j++) {
             const auto &r = E[(size_t)(i + j)];
-            weight *= 1 - pow((float)r.icount / nmb, 2);
+            weight *= 1 - pow((float)r.icount / (float)h->nmb, 2);          // (x264: a float division — i_count and nmb are integers there)
             if (weight < .0001) break;
             const double g = weight * exp(-j * j / 200.0);
-            weight_sum += g; cplx_sum += g * (p2_qscale2bits(r, 1) - r.misc);
+            weight_sum += g; cplx_sum += g * (p2_qscale2bits(r, 1) - r.misc) / frame_duration;
         }
         weight = 1.0;
         for (int j = 0; j <= cplxblur * 2 && j <= i; j++) {
             const auto &r = E[(size_t)(i - j)];
             const double g = weight * exp(-j * j / 200.0);
-            weight_sum += g; cplx_sum += g * (p2_qscale2bits(r, 1) - r.misc);
-            weight *= 1 - pow((float)r.icount / nmb, 2);
+            weight_sum += g; cplx_sum += g * (p2_qscale2bits(r, 1) - r.misc) / frame_duration;
+            weight *= 1 - pow((float)r.icount / (float)h->nmb, 2);          // (x264: a float division — i_count and nmb are integers there)
             if (weight < .0001) break;
         }
         E[(size_t)i].blurred = cplx_sum / weight_sum;
@@ -1869,7 +1871,7 @@ static bool p2_init(x264_t *h)
         last_q[kind] = q;
         if (kind != 2) last_non_b = kind;
         if (kind == 0) { last_accum_p_norm = accum_p_norm; accum_p_norm = 0; accum_p_qp = 0; }
-        if (kind == 1) { const double mask = 1 - pow((float)e.icount / nmb, 2); accum_p_qp = mask * (p2_qscale2qp(q) + accum_p_qp); accum_p_norm = mask * (1 + accum_p_norm); }
+        if (kind == 1) { const float mask = (float)(1 - pow((float)e.icount / (float)h->nmb, 2)); accum_p_qp          /* (a float in x264) */ = mask * (p2_qscale2qp(q) + accum_p_qp); accum_p_norm = mask * (1 + accum_p_norm); }
         return q;
     };
     double expected_bits = 1;
@@ -2564,6 +2566,14 @@ int x264host_last_decision(x264_t *h, int *qp, int *scenecut, int32_t costs[4])
     return 0;
 }
 
+/* tests: the second pass' plan — the quantiser scale init_pass2 gave every picture of the statistics file (display order), and what should have been spent before each;
+ * returns the number of pictures planned (0: not a second pass) */
+int x264host_pass2_plan(x264_t *h, double *new_qscale, double *expected_bits, int n)
+{
+    if (!h || !h->pass2) return 0;
+    for (int i = 0; i < n && i < (int)h->p2.size(); i++) { if (new_qscale) new_qscale[i] = h->p2[(size_t)i].new_qscale; if (expected_bits) expected_bits[i] = h->p2[(size_t)i].expected_bits; }
+    return (int)h->p2.size();
+}
 /* tests: the float quantiser (x264 rc->qpm) the last coded picture's macroblock quantisers were rounded from; 0 = its integer quantiser */
 float x264host_last_qpm(x264_t *h) { return h ? h->last_qpm : 0.f; }
 
