@@ -20,7 +20,8 @@ tests/oracle_lib.OracleSlicetype), so that a session's decisions can be compared
   [x264-upstream] encoder/ratecontrol.c  get_qscale under macroblock-tree (the duration term alone, CRF shifted by 13.5 (1 - qcomp), qcompress 1)
 
 Restated from memory of upstream like the rest of oracle/ (libx264 is not in the reference tree): parity unpinned.  Out of this twin's reach (not
-restated here): the final weight analysis of the picture about to be coded (its weights do not enter these decisions), ABR feedback, 2-pass, VBV.
+restated here): the final weight analysis of the picture about to be coded (its weights do not enter these decisions), ABR feedback, the second pass' feedback
+(its PLAN has a twin at the end of this file: init_pass2), VBV.
 """
 import math
 
