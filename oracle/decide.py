@@ -432,7 +432,9 @@ class RateControl:
         self.rate_factor_constant = (p.mbw * p.mbh * (120.0 if p.bframes else 80.0)) ** (1.0 - self.qcompress) / qp2qscale(p.crf + ((1.0 - p.qcomp) * 13.5 if p.mbtree else 0.0))
         self.ip_offset = 6.0 * _libm.log2f(p.ip_factor)             # x264_ratecontrol_init_reconfigurable: 6.0 * log2f( f_ip_factor )
         self.pb_offset = 6.0 * _libm.log2f(p.pb_factor)
-        self.accum_p_qp = self.accum_p_norm = 0.0
+        # x264_ratecontrol_new: rc->accum_p_norm = .01; rc->accum_p_qp = ABR_INIT_QP * rc->accum_p_norm (ABR_INIT_QP = the rate factor under CRF)
+        self.accum_p_norm = .01
+        self.accum_p_qp = p.crf * self.accum_p_norm
         self.last_non_b_is_i = True                                   # x264_ratecontrol_new: last_non_b_pict_type = SLICE_TYPE_I
         self.last_qscale_for = [qp2qscale(p.crf)] * 2
         self.frames_done = 0

@@ -319,7 +319,8 @@ def test_crf_follows_the_lookahead_complexity(gpu):
     nmb = ((w + 15) // 16) * ((h + 15) // 16)
     q2s, s2q = (lambda q: 0.85 * 2.0 ** ((q - 12.0) / 6.0)), (lambda s: 12.0 + 6.0 * np.log2(s / 0.85))
     rfc = (nmb * 80.0) ** (1 - qcomp) / q2s(crf)
-    cs = cc = apq = apn = 0.0
+    cs = cc = 0.0
+    apn = 0.01; apq = crf * apn                                  # x264_ratecontrol_new: the running P quantiser starts with a hundredth of a picture at ABR_INIT_QP
     last_i = True
     qps = []
     for i, (key, qp, sc, costs, _typ, qpm) in enumerate(rows):

@@ -813,6 +813,8 @@ x264_t *x264_encoder_open(x264_param_t *param)
         if (p.rc.b_mb_tree) h->rc.qcompress = 1.0;                     // x264_ratecontrol_new: the tree does the complexity weighting, CRF shifts by 13.5 (1 - qcomp)
         h->rc.rate_factor_constant = pow((double)h->nmb * (h->bframes ? 120.0 : 80.0), 1.0 - h->rc.qcompress) / qp2qscale(p.rc.f_rf_constant + (p.rc.b_mb_tree ? (1.0 - p.rc.f_qcompress) * 13.5 : 0.0));
         h->rc.last_qscale_for[0] = h->rc.last_qscale_for[1] = qp2qscale(p.rc.f_rf_constant);
+        // x264_ratecontrol_new (b_abr = CRF and ABR alike): the running P quantiser starts with a hundredth of a picture at ABR_INIT_QP (CRF: the rate factor; ABR: 24)
+        h->rc.accum_p_norm = .01; h->rc.accum_p_qp = (h->crf ? (double)p.rc.f_rf_constant : 24.0) * h->rc.accum_p_norm;
         h->rc.lmin = qp2qscale(p.rc.i_qp_min); h->rc.lmax = qp2qscale(p.rc.i_qp_max);
         double dur = p.i_fps_num ? (double)p.i_fps_den / p.i_fps_num : 0.04;
         dur = dur < 0.01 ? 0.01 : dur > 1.0 ? 1.0 : dur;              // CLIP_DURATION
