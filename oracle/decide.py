@@ -17,10 +17,11 @@ tests/oracle_lib.OracleSlicetype), so that a session's decisions can be compared
                                        when psy and the tree are on, weights_analyse( b_lookahead = 1 ) in front of every P cost searched for the first time
                                        (--weightp, or X264_WEIGHTP_FAKE for the tree's weightdelta), the AQ offsets every picture arrives with
                                        (x264_adaptive_quant_frame, mode 1) as the tree's inverse quantiser scales and base
+  [x264-upstream] encoder/ratecontrol.c  single-pass ABR: the rate factor from the bits window, the overflow pull, the qpstep clip, x264_ratecontrol_end's feedback (fed the session's real sizes)
   [x264-upstream] encoder/ratecontrol.c  get_qscale under macroblock-tree (the duration term alone, CRF shifted by 13.5 (1 - qcomp), qcompress 1)
 
 Restated from memory of upstream like the rest of oracle/ (libx264 is not in the reference tree): parity unpinned.  Out of this twin's reach (not
-restated here): the final weight analysis of the picture about to be coded (its weights do not enter these decisions), ABR feedback, the second pass' feedback
+restated here): the final weight analysis of the picture about to be coded (its weights do not enter these decisions), the second pass' feedback
 (its PLAN has a twin at the end of this file: init_pass2), VBV.
 """
 import math
@@ -46,7 +47,7 @@ def qscale2qp(qscale):
 
 class Params:
     def __init__(self, mbw, mbh, keyint=250, min_keyint=0, scenecut=40, bframes=3, b_adapt=1, b_pyramid=1, b_bias=0, crf=23.0, qcomp=0.6, ip_factor=1.4,
-                 pb_factor=1.3, qpmin=0, qpmax=51, fps=25.0, mbtree=False, aq_strength=0.0, weightp=0, rc_lookahead=0, psy=True, zones=()):
+                 pb_factor=1.3, qpmin=0, qpmax=51, fps=25.0, mbtree=False, aq_strength=0.0, weightp=0, rc_lookahead=0, psy=True, zones=(), bitrate=0, rate_tolerance=1.0, qpstep=4):
         self.mbw, self.mbh = mbw, mbh
         self.keyint, self.scenecut, self.bframes, self.b_adapt, self.b_pyramid, self.b_bias = keyint, scenecut, bframes, b_adapt, b_pyramid, b_bias
         if min_keyint <= 0:          # validate_parameters: auto = min(keyint / 10, fps), then [1, keyint / 2 + 1]
@@ -55,6 +56,8 @@ class Params:
         # the default session: macroblock-tree over rc_lookahead pictures, AQ mode 1 (aq_strength = --aq-strength x 1.0397f; 0 = off), --weightp
         self.mbtree, self.aq_strength, self.weightp, self.rc_lookahead, self.psy = mbtree, _f(aq_strength), weightp, rc_lookahead, psy
         self.weightp_fake = not weightp and mbtree and psy          # validate_parameters: X264_WEIGHTP_FAKE
+        # single-pass ABR (--bitrate, kbit/s; 0 = CRF): rate_estimate_qscale's 1-pass branch with the feedback of x264_ratecontrol_end (the coded sizes come from the session)
+        self.bitrate, self.rate_tolerance, self.qpstep = bitrate * 1000.0, max(_f(rate_tolerance), 0.01), qpstep
         self.zones = list(zones)           # --zones: (start, end, 'q', qp) or (start, end, 'b', bitrate factor), display indices; the last one that holds a picture wins
         self.tree_strength = _f(_f(5.0) * _f(_f(1.0) - _f(qcomp)))   # macroblock_tree_finish: 5.0f * (1.0f - f_qcompress)
         # (x264_param_t carries these as single floats: the doubles of the rate control start from the float's value)
@@ -438,6 +441,14 @@ class RateControl:
         self.last_non_b_is_i = True                                   # x264_ratecontrol_new: last_non_b_pict_type = SLICE_TYPE_I
         self.last_qscale_for = [qp2qscale(p.crf)] * 2
         self.frames_done = 0
+        self.abr = p.bitrate > 0
+        if self.abr:          # x264_ratecontrol_new / x264_ratecontrol_init_reconfigurable without VBV (ABR_INIT_QP = 24 outside CRF)
+            self.accum_p_qp = 24.0 * self.accum_p_norm
+            self.cplxr_sum = .01 * 7.0e5 ** self.qcompress * (p.mbw * p.mbh) ** 0.5
+            self.wanted_bits_window = p.bitrate / p.fps
+            self.last_qscale_for = [qp2qscale(24.0)] * 2
+            self.lstep = 2.0 ** (p.qpstep / 6.0)
+            self.total_bits, self.last_rceq = 0.0, 1.0
 
     def _accum(self, qp, is_i):
         self.accum_p_qp = self.accum_p_qp * 0.95 + (qp + self.ip_offset if is_i else qp)
@@ -451,7 +462,8 @@ class RateControl:
         if satd > 0:
             # get_qscale: under macroblock-tree the frame-duration term alone
             rceq = (1.0 / self.dur_ratio) ** (1.0 - p.qcomp) if p.mbtree else (self.cplxsum / self.cplxcount) ** (1.0 - self.qcompress)
-            q = _f(rceq / self.rate_factor_constant)          # (rate_estimate_qscale's q is a float: every assignment rounds)
+            self.last_rceq = rceq
+            q = _f(rceq / (self.wanted_bits_window / self.cplxr_sum if self.abr else self.rate_factor_constant))          # (rate_estimate_qscale's q is a float: every assignment rounds)
         else:
             q = _f(self.last_qscale_for[0 if is_i else 1])
         # get_qscale: a zone forces its quantiser or scales the picture's bits
@@ -459,9 +471,24 @@ class RateControl:
             if z[0] <= frame <= z[1]:
                 q = _f(qp2qscale(z[3]) if z[2] == 'q' else q / _f(z[3]))
                 break
+        overflow = 1.0
+        if self.abr and satd > 0:          # pull towards the target: the bits so far against the time so far, within a buffer that grows with sqrt(time)
+            time_done = self.frames_done / p.fps
+            wanted_bits = time_done * p.bitrate
+            if wanted_bits > 0:
+                abr_buffer = 2 * p.rate_tolerance * p.bitrate * max(1.0, math.sqrt(time_done))
+                overflow = min(max(1.0 + (self.total_bits - wanted_bits) / abr_buffer, .5), 2.0)
+                q = _f(q * overflow)
         if is_i and p.keyint > 1 and not self.last_non_b_is_i:
             q = _f(qp2qscale(self.accum_p_qp / self.accum_p_norm) / p.ip_factor)
-        elif self.frames_done == 0 and self.qcompress != 1.0:
+        elif self.frames_done > 0 and self.abr:          # asymmetric clipping against the last quantiser of the picture type
+            lmin, lmax = self.last_qscale_for[0 if is_i else 1] / self.lstep, self.last_qscale_for[0 if is_i else 1] * self.lstep
+            if overflow > 1.1 and self.frames_done > 3:
+                lmax *= self.lstep
+            elif overflow < 0.9:
+                lmin /= self.lstep
+            q = _f(min(max(q, lmin), lmax))
+        elif self.frames_done == 0 and not self.abr and self.qcompress != 1.0:
             q = _f(qp2qscale(p.crf) / p.ip_factor)
         q = _f(min(max(q, qp2qscale(p.qpmin)), qp2qscale(p.qpmax)))
         self.last_qscale_for[0 if is_i else 1] = q
@@ -472,6 +499,15 @@ class RateControl:
         self.last_non_b_is_i = is_i
         self.frames_done += 1
         return min(max(int(qpf + 0.5), 1), 51), qpf
+
+    def end(self, bits, is_b, qpf):
+        """x264_ratecontrol_end of single-pass ABR: what the picture took moves the rate factor of the pictures to come (a B picture's quantiser is an offset of its
+        neighbours': its bits count divided by pbratio)"""
+        if not self.abr:
+            return
+        self.total_bits += bits
+        self.cplxr_sum += bits * qp2qscale(self.qp_avg_rc(qpf)) / (self.last_rceq * (abs(self.p.pb_factor) if is_b else 1.0))          # rc->qpa_rc: the float gathered row by row
+        self.wanted_bits_window += self.p.bitrate / self.p.fps
 
     def qp_avg_rc(self, qpm):
         """fdec->f_qp_avg_rc: rc->qpa_rc (a float) gathers qpm * mb_width row by row, x264_ratecontrol_end divides by the macroblock count"""
@@ -507,7 +543,7 @@ class RateControl:
         return min(max(int(q + 0.5), p.qpmin), p.qpmax), q
 
 
-def run_session(frames, params, costs, slots, aq_of=None):
+def run_session(frames, params, costs, slots, aq_of=None, sizes=None):
     """the pictures of `frames` (display order, I420 arrays) through the decisions: -> [(display index, type, qp, float qp, offsets)] in coding order;
     offsets: the per-macroblock quantiser offsets the picture is coded with (float32 array; None when the session has neither tree nor AQ).
     costs: tests/oracle_lib.OracleSlicetype created with `slots` slots (do_edges = 1 for a macroblock-tree session); the twin puts every picture into
@@ -521,6 +557,12 @@ def run_session(frames, params, costs, slots, aq_of=None):
         wait = max(wait, p.rc_lookahead)                # ... and the tree's window
     out = []
     kept = {}                                           # display index -> (type, float qp) of the pictures kept as references
+    nsize = [0]                                         # ABR: sizes (bytes) of the session's coded pictures, coding order, fed back as the session saw them
+
+    def spent(is_b, qf):
+        if sizes is not None:
+            rc.end(sizes[nsize[0]] * 8.0, is_b, qf)
+            nsize[0] += 1
 
     def code_run(flushing):
         r = la.decide(flushing, wait)
@@ -537,6 +579,7 @@ def run_session(frames, params, costs, slots, aq_of=None):
         is_i = closing in (I, IDR)
         qp, qpf = rc.nonb(is_i, icost if is_i else pcost, closer.frame)
         coded = [(closer, closing, qp, qpf)]
+        spent(False, qpf)
         kept[closer.frame] = (closing, qpf)
         la.last_nonb = closer
         bref = (j - 1) // 2 if p.b_pyramid and j > 1 else -1
@@ -546,6 +589,7 @@ def run_session(frames, params, costs, slots, aq_of=None):
             before, after = max(k for k in kept if k < f.frame), min(k for k in kept if k > f.frame)        # nearest references in display order
             q, qf = rc.b(2 * f.frame, (2 * before,) + kept[before], (2 * after,) + kept[after], t == BREF)
             coded.append((f, t, q, qf))
+            spent(True, qf)
             if t == BREF:
                 kept[f.frame] = (BREF, qf)
         del la.next[:j + 1]

@@ -142,6 +142,32 @@ def test_zones_move_the_quantisers(tmp_path):
         assert pic.qp == want, (f, t, pic.qp, want)
 
 
+@pytest.mark.parametrize("opts,kw", [
+    (["bitrate=300", "keyint=40", "no-mbtree", "aq-mode=0", "weightp=0", "rc-lookahead=0"], dict(bitrate=300, keyint=40)),
+    (["bitrate=150", "keyint=250", "rc-lookahead=10", "bframes=2", "qpstep=6", "ratetol=0.5"], dict(bitrate=150, keyint=250, bframes=2, rc_lookahead=10, weightp=2, mbtree=True, aq=1.0, qpstep=6, rate_tolerance=0.5)),
+])
+def test_single_pass_abr_equals_the_twin(tmp_path, opts, kw):
+    """single-pass ABR (the driver's encoding type 3 and the first pass of type 4, codec.c:1509-1524): rate_estimate_qscale's 1-pass branch — the rate factor from the bits window, the
+    overflow pull towards the target, the asymmetric qpstep clip — with x264_ratecontrol_end's feedback: the twin is fed the sizes the session's pictures really had and must arrive at
+    the same picture types and float quantisers, picture by picture"""
+    sys.path.insert(0, os.path.join(HERE, "stub"))
+    from run_host_b import make_frames
+    w, h, n, seed, scene = 176, 144, 48, 17, 19
+    kw = dict(kw)
+    info, pics = host_session(tmp_path, w, h, n, seed, opts + [f"scene_len={scene}"])
+    frames = make_frames(w, h, n, seed, scene_len=scene)
+    aqs = kw.pop("aq", 0.0)
+    strength = float(np.float32(aqs) * np.float32(1.0397)) if aqs else 0.0
+    p = D.Params((w + 15) // 16, (h + 15) // 16, aq_strength=strength, **kw)
+    st = O.OracleSlicetype(w, h, slots=128, bframes=max(p.bframes, 1), me_method=info["me"], subme=info["subme"], me_range=info["me_range"], mv_range=info["mv_range"], do_edges=int(p.mbtree))
+    twin = D.run_session(frames, p, st, 128, aq_of=(lambda f: O.aq_offsets(f, w, h, strength)) if strength else None, sizes=[r[4] for r in info["recs"]])
+    st.close()
+    assert [(r[1], r[0]) for r in info["recs"]] == [(f, t) for f, t, _, _, _ in twin]
+    for k, ((f, t, qp, qpf, _off), pic) in enumerate(zip(twin, pics)):
+        assert pic.qp == qp and pic.qpm == np.float32(qpf), f"coded picture {k} (display {f}, type {t}): quantiser {pic.qp} / {pic.qpm} vs the twin's {qp} / {qpf}"
+    assert len({pic.qp for pic in pics}) >= 4          # the rate control moves
+
+
 def test_second_pass_plan_equals_the_twin(tmp_path):
     """x264's init_pass2 (the driver's encoding type 4, codec.c:1516-1541) twice: the host's plan — every picture's quantiser scale and the bits expected before it — against
     oracle/decide.py init_pass2 over the statistics file the first pass wrote: equal to a part in 10^9 (the same double arithmetic in another language), on two bitrates"""

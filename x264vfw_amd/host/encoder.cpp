@@ -1261,7 +1261,7 @@ static int encode_queued(x264_t *h, x264_nal_t **pp_nal, int *pi_nal, x264_pictu
         // x264_ratecontrol_end: what this picture's bits say about the rate factor, and the bits the window now expects
         const double bits = 8.0 * (double)h->out.size();
         h->rc.total_bits += bits;
-        h->rc.cplxr_sum += bits * rc_qp2qscale(h->rc.qpa_last) / h->rc.last_rceq;
+        h->rc.cplxr_sum += bits * rc_qp2qscale(rc_qp_avg_rc((float)h->rc.qpa_last, h->mbw, h->mbh)) / h->rc.last_rceq;          // (rc->qpa_rc: the float gathered row by row)
         h->rc.wanted_bits_window += h->rc.bitrate / h->rc.fps;
     }
     h->frames_since_idr++;
@@ -2210,7 +2210,7 @@ static int encode_bmode(x264_t *h, x264_nal_t **pp_nal, int *pi_nal, x264_pictur
         const double bits = (double)h->out.size() * 8.0, pb = fabs(p.rc.f_pb_factor) > 0 ? fabs(p.rc.f_pb_factor) : 1.0;
         const bool is_b = pl.type == PIC_B || pl.type == PIC_BREF;
         h->rc.total_bits += bits;
-        h->rc.cplxr_sum += bits * rc_qp2qscale(qpf) / (h->rc.last_rceq * (is_b ? pb : 1.0));
+        h->rc.cplxr_sum += bits * rc_qp2qscale(rc_qp_avg_rc((float)qpf, h->mbw, h->mbh)) / (h->rc.last_rceq * (is_b ? pb : 1.0));
         h->rc.wanted_bits_window += h->rc.bitrate / h->rc.fps;
     }
     BPHASE(3);
