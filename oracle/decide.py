@@ -21,8 +21,8 @@ tests/oracle_lib.OracleSlicetype), so that a session's decisions can be compared
   [x264-upstream] encoder/ratecontrol.c  get_qscale under macroblock-tree (the duration term alone, CRF shifted by 13.5 (1 - qcomp), qcompress 1)
 
 Restated from memory of upstream like the rest of oracle/ (libx264 is not in the reference tree): parity unpinned.  Out of this twin's reach (not
-restated here): the final weight analysis of the picture about to be coded (its weights do not enter these decisions), the second pass' feedback
-(its PLAN has a twin at the end of this file: init_pass2), VBV.
+restated here): the final weight analysis of the picture about to be coded (its weights do not enter these decisions), VBV.  (The second pass has its twins at the end of this file: init_pass2 for the plan,
+pass2_quantisers for the feedback on top of it.)
 """
 import math
 
@@ -685,7 +685,7 @@ def init_pass2(stat_lines, nmb, bitrate_kbps, fps=25.0, bframes=3, qcomp=0.6, qb
             if weight < .0001:
                 break
             j += 1
-        e.blurred = cplx_sum / weight_sum
+        e.blurred = _f(cplx_sum / weight_sum)          # (ratecontrol_entry_t keeps blurred_complexity as a float)
     st = {"last_q": [0.0] * 3, "last_non_b": -1, "last_accum_p_norm": 1.0, "accum_p_norm": 0.0, "accum_p_qp": 0.0}
 
     def get_qscale(e, rate_factor):
@@ -771,3 +771,30 @@ def init_pass2(stat_lines, nmb, bitrate_kbps, fps=25.0, bframes=3, qcomp=0.6, qb
         e.expected_bits = acc
         acc += qscale2bits(e, e.new_qscale)
     return E
+
+
+def pass2_quantisers(E, sizes, bitrate_kbps, fps=25.0, rate_tolerance=1.0, qpmin=0, qpmax=51):
+    """rate_estimate_qscale's 2-pass branch over a plan of init_pass2, fed the sizes (bytes, coding order) the second pass' pictures really had:
+    -> [(display index, integer quantiser, float quantiser)] in coding order"""
+    n = len(E)
+    order = sorted(E, key=lambda e: e.out)
+    final_bits = order[-1].expected_bits          # entry_out[num_entries - 1]->expected_bits: what should have been spent BEFORE the last picture
+    lmin, lmax = qp2qscale(qpmin), qp2qscale(qpmax)
+    total_bits = expected_sum = 0.0
+    out = []
+    for k, e in enumerate(order):          # k = h->i_frame: pictures coded so far
+        abr_buffer = 2 * max(_f(rate_tolerance), 0.01) * bitrate_kbps * 1000.0
+        if n > k:          # the buffer shrinks towards the end of the video
+            video_pos = e.expected_bits / final_bits if final_bits > 0 else 1.0
+            abr_buffer *= 0.5 * max(math.sqrt((1 - video_pos) * n), 0.5)
+        diff = int(total_bits) - int(e.expected_bits)
+        q = e.new_qscale / min(max((abr_buffer - diff) / abr_buffer, .5), 2.0)
+        if k >= fps and expected_sum >= 1:          # the achieved against the expected bitrate so far
+            w = min(max(k / n * 100, 0.0), 1.0)
+            q *= (total_bits / expected_sum) ** w
+        q = min(max(q, lmin), lmax)
+        qpf = min(max(qscale2qp(q), qpmin), qpmax)
+        out.append((e.frame, min(max(int(qpf + 0.5), 1), 51), qpf))
+        total_bits += sizes[k] * 8.0
+        expected_sum += qscale2bits(e, qp2qscale(qpf))
+    return out

@@ -189,6 +189,11 @@ def test_second_pass_plan_equals_the_twin(tmp_path):
         assert len({round(float(q), 6) for q in want_q}) > 10          # a curve, not a constant
         total = want_b.max() + max(D.qscale2bits(e, e.new_qscale) for e in E if e.expected_bits == want_b.max())
         assert abs(total / (kbps * 1000.0 * n / 25.0) - 1.0) < 0.01      # the plan adds up to the request
+        # ... and the feedback on top of the plan (rate_estimate_qscale's 2-pass branch), fed the sizes this pass' pictures really had: the same quantisers picture by picture
+        fb = D.pass2_quantisers(E, [r[4] for r in info["recs"]], kbps)
+        assert [r[1] for r in info["recs"]] == [f for f, _, _ in fb]
+        for k, ((f, qp, qpf), pic) in enumerate(zip(fb, _pics)):
+            assert pic.qp == qp and pic.qpm == np.float32(qpf), (kbps, k, f, pic.qp, pic.qpm, qp, qpf)
 
 
 def test_fade_weights_are_the_fades_ratio(tmp_path):

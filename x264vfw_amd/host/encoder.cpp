@@ -1841,7 +1841,7 @@ static bool p2_init(x264_t *h)
             weight *= 1 - pow((float)r.icount / (float)h->nmb, 2);          // (x264: a float division — i_count and nmb are integers there)
             if (weight < .0001) break;
         }
-        E[(size_t)i].blurred = cplx_sum / weight_sum;
+        E[(size_t)i].blurred = (double)(float)(cplx_sum / weight_sum);          // (ratecontrol_entry_t keeps blurred_complexity as a float)
     }
     // the rate factor: multiplied into every picture's RCEQ value it makes the sizes add up to the request (no closed form: qscale2bits does not invert)
     std::vector<double> qscale((size_t)n), blurred((size_t)n);
@@ -1935,7 +1935,7 @@ static double p2_pick_qscale(x264_t *h, int frame, long coded_so_far)
         const double video_pos = h->p2_final_bits > 0 ? e.expected_bits / h->p2_final_bits : 1.0, scale_factor = sqrt((1 - video_pos) * n);
         abr_buffer *= 0.5 * (scale_factor > 0.5 ? scale_factor : 0.5);
     }
-    const double diff = h->p2_total_bits - e.expected_bits;
+    const double diff = (double)((long long)h->p2_total_bits - (long long)e.expected_bits);          // (x264: int64_t diff = predicted_bits - (int64_t)rce.expected_bits)
     double q = e.new_qscale, c = (abr_buffer - diff) / abr_buffer;
     q /= c < .5 ? .5 : c > 2 ? 2 : c;
     if (coded_so_far >= h->rc.fps && h->p2_expected_sum >= 1) {          // x264: h->i_frame >= rcc->fps && rcc->expected_bits_sum >= 1
