@@ -15,13 +15,14 @@ tests/oracle_lib.OracleSlicetype), so that a session's decisions can be compared
   [x264-upstream] encoder/slicetype.c  the DEFAULT session's additions: macroblock_tree (the walk over the window with the types decided so far, the keyframe's own
                                        pass: lookahead_slicetype_decide's second analysis), i_delay = max(run length, rc-lookahead), the whole window analysed
                                        when psy and the tree are on, weights_analyse( b_lookahead = 1 ) in front of every P cost searched for the first time
-                                       (--weightp, or X264_WEIGHTP_FAKE for the tree's weightdelta), the AQ offsets every picture arrives with
+                                       (--weightp, or X264_WEIGHTP_FAKE for the tree's weightdelta) and weights_analyse( b_lookahead = 0 ) of the P picture about to be coded
+                                       (scales / offsets around the guess, chroma planes, the unified chroma denominator), the AQ offsets every picture arrives with
                                        (x264_adaptive_quant_frame, mode 1) as the tree's inverse quantiser scales and base
   [x264-upstream] encoder/ratecontrol.c  single-pass ABR: the rate factor from the bits window, the overflow pull, the qpstep clip, x264_ratecontrol_end's feedback (fed the session's real sizes)
   [x264-upstream] encoder/ratecontrol.c  get_qscale under macroblock-tree (the duration term alone, CRF shifted by 13.5 (1 - qcomp), qcompress 1)
 
 Restated from memory of upstream like the rest of oracle/ (libx264 is not in the reference tree): parity unpinned.  Out of this twin's reach (not
-restated here): the final weight analysis of the picture about to be coded (its weights do not enter these decisions), VBV.  (The second pass has its twins at the end of this file: init_pass2 for the plan,
+restated here): VBV.  (The second pass has its twins at the end of this file: init_pass2 for the plan,
 pass2_quantisers for the feedback on top of it.)
 """
 import math
@@ -47,7 +48,7 @@ def qscale2qp(qscale):
 
 class Params:
     def __init__(self, mbw, mbh, keyint=250, min_keyint=0, scenecut=40, bframes=3, b_adapt=1, b_pyramid=1, b_bias=0, crf=23.0, qcomp=0.6, ip_factor=1.4,
-                 pb_factor=1.3, qpmin=0, qpmax=51, fps=25.0, mbtree=False, aq_strength=0.0, weightp=0, rc_lookahead=0, psy=True, zones=(), bitrate=0, rate_tolerance=1.0, qpstep=4):
+                 pb_factor=1.3, qpmin=0, qpmax=51, fps=25.0, mbtree=False, aq_strength=0.0, weightp=0, rc_lookahead=0, psy=True, zones=(), bitrate=0, rate_tolerance=1.0, qpstep=4, subme=7):
         self.mbw, self.mbh = mbw, mbh
         self.keyint, self.scenecut, self.bframes, self.b_adapt, self.b_pyramid, self.b_bias = keyint, scenecut, bframes, b_adapt, b_pyramid, b_bias
         if min_keyint <= 0:          # validate_parameters: auto = min(keyint / 10, fps), then [1, keyint / 2 + 1]
@@ -58,6 +59,7 @@ class Params:
         self.weightp_fake = not weightp and mbtree and psy          # validate_parameters: X264_WEIGHTP_FAKE
         # single-pass ABR (--bitrate, kbit/s; 0 = CRF): rate_estimate_qscale's 1-pass branch with the feedback of x264_ratecontrol_end (the coded sizes come from the session)
         self.bitrate, self.rate_tolerance, self.qpstep = bitrate * 1000.0, max(_f(rate_tolerance), 0.01), qpstep
+        self.subme = subme                 # the final weight analysis searches around its guess at the distances of the sub-pel level
         self.zones = list(zones)           # --zones: (start, end, 'q', qp) or (start, end, 'b', bitrate factor), display indices; the last one that holds a picture wins
         self.tree_strength = _f(_f(5.0) * _f(_f(1.0) - _f(qcomp)))   # macroblock_tree_finish: 5.0f * (1.0f - f_qcompress)
         # (x264_param_t carries these as single floats: the doubles of the rate control start from the float's value)
@@ -82,7 +84,7 @@ class Lookahead:
         self.next = []                 # display order
         self.last_nonb = None
         self.last_keyframe = -params.keyint
-        self.stats = {"lookahead_weights": 0, "weightdelta": 0}          # how often the analysis found a weight / a finished picture carried a weightdelta
+        self.stats = {"lookahead_weights": 0, "final_weights": 0, "weightdelta": 0}          # how often the analysis found a weight / a finished picture carried a weightdelta
 
     # slicetype_frame_cost of frames[b] predicted from frames[p0] (and frames[p1])
     def cost(self, fr, p0, p1, b):
@@ -92,48 +94,104 @@ class Lookahead:
             w = self.weights_analyse(fr[b], fr[p0], b - p0)
         return self.c.cost(fr[p0].slot, fr[p1].slot, fr[b].slot, b - p0, p1 - b, weight=w)
 
-    def weights_analyse(self, fenc, ref, dist):
-        """weights_analyse( b_lookahead = 1 ): luma alone, the guess alone, the reference in place -> (scale, denom, offset) or None"""
-        c = self.c
+    def weights_analyse(self, fenc, ref, dist, b_lookahead=True):
+        """x264's weights_analyse.  b_lookahead: luma alone, the guess alone, the reference in place (in front of a P cost searched for the first time) -> (scale, denom,
+        offset) or None.  Else (the P picture about to be coded against the last non-B picture): scales / offsets around the guess at the distances of the sub-pel level, the
+        reference motion-compensated by the lookahead's vectors, the chroma planes once luma has a weight, the chroma denominator unified
+        -> None or {"luma": (scale, denom, offset), "cdenom": d, "chroma": [None | (scale, offset), None | (scale, offset)]}"""
+        c, p = self.c, self.p
         fenc.weighted_cost_delta[dist] = 0.0
-        sf, sr = c.pixel_stats(fenc.slot, fenc.raw), c.pixel_stats(ref.slot, ref.raw)
-        zero_bias = 0 if int(sr[1]) else 1
-        fenc_var, ref_var = _f(float(int(sf[1]) + zero_bias)), _f(float(int(sr[1]) + zero_bias))
-        guess_scale = _f(math.sqrt(_f(fenc_var / ref_var)))
-        npix = _f(_f(self.p.mbw * 16) * _f(self.p.mbh * 16))
-        fenc_mean, ref_mean = _f(_f(float(int(sf[0]) + zero_bias)) / npix), _f(_f(float(int(sr[0]) + zero_bias)) / npix)
-        if abs(_f(ref_mean - fenc_mean)) < 0.5 and abs(_f(1.0 - guess_scale)) < 1.0 / 128.0:
-            return None
+        sf, sr = [int(v) for v in c.pixel_stats(fenc.slot, fenc.raw)], [int(v) for v in c.pixel_stats(ref.slot, ref.raw)]
+        nplanes = 1 if b_lookahead else 3
+        if not b_lookahead:
+            sf += [int(v) for v in c.chroma_stats(fenc.slot, fenc.raw)]
+            sr += [int(v) for v in c.chroma_stats(ref.slot, ref.raw)]
+        guess_scale, fenc_mean, ref_mean = [1.0] * 3, [0.0] * 3, [0.0] * 3
+        for pl in range(nplanes):
+            zero_bias = 0 if sr[2 * pl + 1] else 1
+            fenc_var, ref_var = _f(float(sf[2 * pl + 1] + zero_bias)), _f(float(sr[2 * pl + 1] + zero_bias))
+            guess_scale[pl] = _f(math.sqrt(_f(fenc_var / ref_var)))
+            npix = _f(_f(p.mbw * 8) * _f(p.mbh * 8)) if pl else _f(_f(p.mbw * 16) * _f(p.mbh * 16))
+            fenc_mean[pl], ref_mean[pl] = _f(_f(float(sf[2 * pl] + zero_bias)) / npix), _f(_f(float(sr[2 * pl] + zero_bias)) / npix)
+        chroma_denom = 7
+        if not b_lookahead:          # make sure both chroma scale factors fit
+            while chroma_denom > 0:
+                thresh = _f(127.0 / (1 << chroma_denom))
+                if guess_scale[1] < thresh and guess_scale[2] < thresh:
+                    break
+                chroma_denom -= 1
+        check_distance = [(0, 0), (0, 0), (0, 1), (0, 1), (0, 1), (0, 1), (0, 1), (1, 1), (1, 1), (2, 1), (2, 1), (4, 2)]
+        scale_dist, offset_dist = (0, 0) if b_lookahead else check_distance[min(max(p.subme, 0), 11)]
         roundf = lambda v: int(math.floor(abs(v) + 0.5)) * (1 if v >= 0 else -1)
-        mindenom, minscale, minoff = 7, roundf(_f(guess_scale * 128)), 0
-        while mindenom > 0 and minscale > 127:
-            mindenom -= 1
-            minscale >>= 1
-        minscale = min(minscale, 127)
-        c.cost(fenc.slot, fenc.slot, fenc.slot, 0, 0)                       # the picture's intra costs
-        origscore = c.weight_cost(fenc.slot, ref.slot, dist) & 0xffffffff
-        minscore = origscore
-        if not minscore:
+        on, w_scale, w_denom, w_off = [False] * 3, [1] * 3, [0] * 3, [0] * 3
+        for pl in range(nplanes):
+            if pl and not on[0]:
+                break          # (the chroma planes are not checked if there was no luma weight)
+            if abs(_f(ref_mean[pl] - fenc_mean[pl])) < 0.5 and abs(_f(1.0 - guess_scale[pl])) < 1.0 / 128.0:
+                continue
+            if pl:
+                mindenom = chroma_denom
+                minscale = min(max(roundf(_f(guess_scale[pl] * (1 << chroma_denom))), 0), 255)
+                if minscale > 127:
+                    on[1] = on[2] = False
+                    break
+            else:
+                mindenom, minscale = 7, roundf(_f(guess_scale[0] * 128))
+                while mindenom > 0 and minscale > 127:
+                    mindenom -= 1
+                    minscale >>= 1
+                minscale = min(minscale, 127)
+            minoff = 0
+            if pl:
+                cost_of = lambda w: c.weight_cost_chroma(fenc.slot, fenc.raw, ref.raw, dist, pl, w) & 0xffffffff
+            else:
+                c.cost(fenc.slot, fenc.slot, fenc.slot, 0, 0)                       # the picture's intra costs
+                cost_of = lambda w: c.weight_cost(fenc.slot, ref.slot, dist, w) & 0xffffffff
+            origscore = cost_of(None)
+            minscore = origscore
+            if not minscore:
+                continue
+            found = False
+            for i_scale in range(min(max(minscale - scale_dist, 0), 127), min(max(minscale + scale_dist, 0), 127) + 1):
+                cur_scale = i_scale
+                cur_offset = int(_f(_f(fenc_mean[pl] - _f(_f(ref_mean[pl] * cur_scale) / (1 << mindenom))) + (0.5 if b_lookahead else 0.0)))
+                if cur_offset < -128 or cur_offset > 127:
+                    cur_offset = min(max(cur_offset, -128), 127)
+                    cs = _f(_f(_f((1 << mindenom) * _f(fenc_mean[pl] - cur_offset)) / ref_mean[pl]) + 0.5)
+                    cur_scale = int(min(max(cs, 0), 127))
+                start_offset, end_offset = min(max(cur_offset - offset_dist, -128), 127), min(max(cur_offset + offset_dist, -128), 127)
+                for i_off in range(start_offset, end_offset + 1):
+                    score = cost_of((cur_scale, mindenom, i_off))
+                    if score < minscore:
+                        minscore, minscale, minoff, found = score, cur_scale, i_off, True
+                    if minoff == start_offset and i_off != start_offset:          # the previous offset was better: no more
+                        break
+            if not pl:
+                while mindenom > 0 and not (minscale & 1):                     # a smaller denominator if possible
+                    mindenom -= 1
+                    minscale >>= 1
+            if not found or (minscale == 1 << mindenom and minoff == 0) or _f(_f(float(minscore)) / _f(float(origscore))) > _f(0.998):
+                continue
+            on[pl], w_scale[pl], w_denom[pl], w_off[pl] = True, minscale, mindenom, minoff
+            if not pl:
+                self.stats["lookahead_weights" if b_lookahead else "final_weights"] = self.stats.get("lookahead_weights" if b_lookahead else "final_weights", 0) + 1
+                if p.weightp_fake:
+                    fenc.weighted_cost_delta[dist] = _f(_f(float(minscore)) / _f(float(origscore)))
+        if not on[0]:
             return None
-        cur_scale = min(max(minscale, 0), 127)
-        cur_offset = int(_f(_f(fenc_mean - _f(_f(ref_mean * cur_scale) / (1 << mindenom))) + 0.5))
-        if cur_offset < -128 or cur_offset > 127:
-            cur_offset = min(max(cur_offset, -128), 127)
-            cs = _f(_f(_f((1 << mindenom) * _f(fenc_mean - cur_offset)) / ref_mean) + 0.5)
-            cur_scale = int(min(max(cs, 0), 127))
-        found = False
-        score = c.weight_cost(fenc.slot, ref.slot, dist, (cur_scale, mindenom, cur_offset)) & 0xffffffff
-        if score < minscore:
-            minscore, minscale, minoff, found = score, cur_scale, cur_offset, True
-        while mindenom > 0 and not (minscale & 1):                         # a smaller denominator if possible
-            mindenom -= 1
-            minscale >>= 1
-        if not found or (minscale == 1 << mindenom and minoff == 0) or _f(_f(float(minscore)) / _f(float(origscore))) > _f(0.998):
-            return None
-        self.stats["lookahead_weights"] += 1
-        if self.p.weightp_fake:
-            fenc.weighted_cost_delta[dist] = _f(_f(float(minscore)) / _f(float(origscore)))
-        return (minscale, mindenom, minoff)
+        if b_lookahead:
+            return (w_scale[0], w_denom[0], w_off[0])
+        cdenom = 0
+        if on[1] or on[2]:
+            # unify the chroma denominator: a plane weighted alone leaves the other with the implicit scale 1 << denom, which 7 cannot carry
+            cdenom = w_denom[1] if on[1] else w_denom[2]
+            both = on[1] and on[2]
+            while (not both and cdenom == 7) or (cdenom > 0 and not (on[1] and (w_scale[1] & 1)) and not (on[2] and (w_scale[2] & 1))):
+                cdenom -= 1
+                for i in (1, 2):
+                    if on[i]:
+                        w_scale[i] >>= 1
+        return {"luma": (w_scale[0], w_denom[0], w_off[0]), "cdenom": cdenom, "chroma": [(w_scale[i], w_off[i]) if on[i] else None for i in (1, 2)]}
 
     def macroblock_tree(self, fr, num_frames, b_intra):
         """x264's macroblock_tree over frames[0 .. num_frames] with the types decided so far; the next picture to be coded (and the B-reference of its run) get
@@ -557,6 +615,7 @@ def run_session(frames, params, costs, slots, aq_of=None, sizes=None):
         wait = max(wait, p.rc_lookahead)                # ... and the tree's window
     out = []
     kept = {}                                           # display index -> (type, float qp) of the pictures kept as references
+    weights = {}                                        # display index of a P picture -> its explicit weights (weights_analyse, b_lookahead = 0) or None
     nsize = [0]                                         # ABR: sizes (bytes) of the session's coded pictures, coding order, fed back as the session saw them
 
     def spent(is_b, qf):
@@ -571,6 +630,9 @@ def run_session(frames, params, costs, slots, aq_of=None, sizes=None):
         j, closing = r
         run = la.next[:j + 1]
         closer = run[j]
+        if p.weightp and closing == P and la.last_nonb is not None:
+            # x264_slicetype_decide: "analyse for weighted P frames" — the picture about to be coded against the last non-B picture
+            weights[closer.frame] = la.weights_analyse(closer, la.last_nonb, closer.frame - la.last_nonb.frame, False)
         # x264_rc_analyse_slice: the closing picture's complexity is its frame cost as the type it got
         icost = costs.cost(closer.slot, closer.slot, closer.slot, 0, 0)
         pcost = icost
@@ -626,6 +688,7 @@ def run_session(frames, params, costs, slots, aq_of=None, sizes=None):
     while la.next and code_run(True):
         pass
     run_session.last_stats = la.stats
+    run_session.last_weights = weights
     return out
 
 

@@ -88,7 +88,7 @@ def test_default_session_equals_the_twin(tmp_path, w, h, n, seed, scene, kind, f
     frames = make_frames(w, h, n, seed, scene_len=scene, static=int(kind == "static"), fade=fade)
     aqs = kw.pop("aq", 1.0)
     strength = float(np.float32(aqs) * np.float32(1.0397))
-    p = D.Params((w + 15) // 16, (h + 15) // 16, mbtree=True, aq_strength=strength, **kw)
+    p = D.Params((w + 15) // 16, (h + 15) // 16, mbtree=True, aq_strength=strength, subme=info["subme"], **kw)
     slots = 128
     # (the lookahead searches within the session's effective --mvrange: the level's limit at this picture size)
     st = O.OracleSlicetype(w, h, slots=slots, bframes=max(p.bframes, 1), me_method=info["me"], subme=info["subme"], me_range=info["me_range"], mv_range=info["mv_range"], do_edges=1)
@@ -104,6 +104,25 @@ def test_default_session_equals_the_twin(tmp_path, w, h, n, seed, scene, kind, f
         assert offs[k].tobytes() == np.asarray(off, np.float32).tobytes(), f"coded picture {k} (display {f}, type {t}): offsets differ at {np.nonzero(offs[k] != off)[0][:6]}"
         moved += int(t != 5 and (off != O.aq_offsets(frames[f], w, h, strength)).any())
     assert moved >= 3, "the tree moved nothing"
+    # the explicit weights of every P picture (x264_weights_analyse of the picture about to be coded: scales / offsets around the guess, the chroma planes beside luma,
+    # the unified chroma denominator) equal the twin's
+    weighted = 0
+    for (f, t, _qp, _qpf, _off), pic in zip(twin, pics):
+        if t != 3 or not kw["weightp"] or f not in D.run_session.last_weights:
+            continue
+        wt, wl, wc = D.run_session.last_weights[f], pic.wl0[0], pic.wc0[0]
+        if wt is None:
+            assert not wl.on and not wc.on[0] and not wc.on[1], (f, wl.on, wl.scale, wl.denom, wl.offset)
+            continue
+        weighted += 1
+        assert (wl.on, wl.scale, wl.denom, wl.offset) == (1,) + wt["luma"], (f, (wl.scale, wl.denom, wl.offset), wt)
+        for ci in range(2):
+            if wt["chroma"][ci] is None:
+                assert not wc.on[ci], (f, ci, wt)
+            else:
+                assert (wc.on[ci], wc.scale[ci], wc.offset[ci], wc.denom) == (1,) + wt["chroma"][ci] + (wt["cdenom"],), (f, ci, (wc.scale[ci], wc.offset[ci], wc.denom), wt)
+    if fade and kw["weightp"]:
+        assert weighted >= 3, weighted
     if fade:          # the fade is seen by the lookahead's weight analysis; without --weightp it still enters the tree as the weightdelta (X264_WEIGHTP_FAKE)
         assert D.run_session.last_stats["lookahead_weights"] >= 3, D.run_session.last_stats
         assert (D.run_session.last_stats["weightdelta"] >= 2) == (kw["weightp"] == 0), D.run_session.last_stats
