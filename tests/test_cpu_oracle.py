@@ -203,3 +203,107 @@ def test_float_primitives_of_aq_and_mbtree_known_answers():
     assert [L.x264o_mb_qp_f(28.4, o) for o in (0.0, 0.09, 0.11, -0.9, -0.91, 3.1)] == [28, 28, 29, 28, 27, 32]
     for qpm, off in zip(rnd.uniform(10, 51, 200).astype(np.float32), rnd.uniform(-8, 8, 200).astype(np.float32)):
         assert L.x264o_mb_qp_f(float(qpm), float(off)) == int(f32(f32(qpm + off) + f32(0.5)))
+
+
+def test_mbtree_float_arithmetic_against_numpy():
+    """oracle/slicetype.c's macroblock-tree (mbtree_propagate_cost / mbtree_propagate_list / macroblock_tree_finish in x264's single floats) against the same expressions in numpy float32,
+    block by block, on the lookahead's own costs and vectors of a small clip: propagate amounts, the bilinear split with saturation, the finished offsets with a weightdelta"""
+    w, h, n = 176, 144, 5
+    frames = synth_frames(w, h, n, seed=31)
+    st = O.OracleSlicetype(w, h, slots=8, bframes=3, do_edges=1)
+    bw, bh = (w // 2 + 7) // 8, (h // 2 + 7) // 8
+    nb = bw * bh
+    aqs = []
+    for i, f in enumerate(frames):
+        st.put(i, f)
+        aqs.append(O.aq_offsets(f, w, h))
+        st.set_aq(i, aqs[-1])
+    f32 = np.float32
+    lut = np.array([float("%.5f" % v) for v in np.log2(1 + np.arange(128) / 128)], f32)
+    exp2 = np.rint(256 * (2 ** (np.arange(64) / 64) - 1)).astype(int)
+
+    def log2(x):
+        lz = 32 - int(x).bit_length()
+        return f32(lut[((int(x) << lz) >> 24) & 0x7f] + f32(31 - lz))
+
+    def exp2fix8(x):
+        i = int(f32(f32(f32(x) * f32(-64.0 / 6.0)) + f32(512.5)))
+        return 0 if i < 0 else 0xffff if i > 1023 else ((int(exp2[i & 63]) + 256) << (i >> 6)) >> 8
+
+    # the walk x264's macroblock_tree makes over I P B P P with the B picture between pictures 1 and 3: (p0, p1, b, referenced) in its order
+    st.cost(0, 0, 0, 0, 0)
+    steps = [(3, 4, 4, 1), (1, 3, 2, 0), (1, 3, 3, 1), (0, 1, 1, 1)]
+    prop = np.zeros((n, nb), np.int64)
+    for p0, p1, b, referenced in steps:
+        d0, d1 = b - p0, p1 - b
+        st.cost(p0, p1, b, d0, d1)
+        st.propagate(p0, p1, b, d0, d1, referenced)
+        intra = np.minimum(st.intra_costs(b), 16383)
+        lc = st.lowres_costs(b, d0, d1)
+        dsf = ((d0 << 8) + ((d0 + d1) >> 1)) // (d0 + d1) if d1 > 0 else 256
+        bipw = 64 - (dsf >> 2) if d1 > 0 else 32
+        mv = [st.mvs(b, 0, d0), st.mvs(b, 1, d1) if d1 > 0 else None]
+        refs = [p0, p1]
+        for i in range(nb):
+            ic, best, used = int(intra[i]), int(lc[i]) & 16383, int(lc[i]) >> 14
+            inter = min(best, ic)
+            amount = 0
+            if ic:
+                pin = f32(min(int(prop[b][i]), 32767) if referenced else 0)
+                amt = f32(pin + f32(f32(ic * exp2fix8(aqs[b][i])) * f32(1.0 / 512.0)))
+                amount = min(int(f32(f32(f32(amt * f32(ic - inter)) / f32(ic)) + f32(0.5))), 32767)
+            for l in range(2 if d1 > 0 else 1):
+                if not used & (1 << l):
+                    continue
+                la = (amount * (bipw if l == 0 else 64 - bipw) + 32) >> 6 if used == 3 else amount
+                x, y = int(mv[l][i][0]), int(mv[l][i][1])
+                tgt = prop[refs[l]]
+                bx, by = i % bw, i // bw
+
+                def add(xx, yy, v):
+                    if 0 <= xx < bw and 0 <= yy < bh:
+                        tgt[yy * bw + xx] = min(tgt[yy * bw + xx] + v, 32767)
+                if not (x | y):
+                    add(bx, by, la)
+                    continue
+                mbx, mby, x, y = (x >> 5) + bx, (y >> 5) + by, x & 31, y & 31
+                add(mbx, mby, ((32 - y) * (32 - x) * la + 512) >> 10); add(mbx + 1, mby, ((32 - y) * x * la + 512) >> 10)
+                add(mbx, mby + 1, (y * (32 - x) * la + 512) >> 10); add(mbx + 1, mby + 1, (y * x * la + 512) >> 10)
+        for k in range(n):
+            assert np.array_equal(st.propagate_cost(k), np.minimum(prop[k], 32767)), (p0, p1, b, k)
+    assert prop[0].sum() > 0 and prop[1].sum() > 0
+    for slot, strength, wd in ((1, 2.0, 0.0), (0, 1.5, 0.125)):
+        got = st.finish(slot, strength, wd)
+        intra = np.minimum(st.intra_costs(slot), 16383)
+        want = np.zeros(nb, f32)
+        for i in range(nb):
+            a = f32(aqs[slot][i])
+            ic = (int(intra[i]) * exp2fix8(a) + 128) >> 8
+            want[i] = a
+            if ic:
+                ratio = f32(f32(log2(ic + 2 * min(int(prop[slot][i]), 32767)) - log2(ic)) + f32(wd))
+                want[i] = f32(a - f32(f32(strength) * ratio))
+        assert got.tobytes() == want.tobytes(), (slot, np.nonzero(got != want)[0][:5])
+    st.close()
+
+
+def test_aq_mode_1_offsets_against_numpy():
+    """x264_adaptive_quant_frame, mode 1, as the oracle restates it (single floats) against numpy: AC energy of every 16x16 luma + two 8x8 chroma blocks, strength x (x264_log2(energy) - 14.427f)"""
+    w, h = 176, 144
+    f = synth_frames(w, h, 1, seed=7)[0]
+    f32 = np.float32
+    lut = np.array([float("%.5f" % v) for v in np.log2(1 + np.arange(128) / 128)], f32)
+    Y = f[:w * h].reshape(h, w).astype(np.int64)
+    U, V = f[w * h:w * h * 5 // 4].reshape(h // 2, w // 2).astype(np.int64), f[w * h * 5 // 4:].reshape(h // 2, w // 2).astype(np.int64)
+    strength = f32(f32(0.8) * f32(1.0397))
+    got = O.aq_offsets(f, w, h, float(strength))
+    want = np.zeros_like(got)
+    for by in range(h // 16):
+        for bx in range(w // 16):
+            y, u, v = Y[by * 16:by * 16 + 16, bx * 16:bx * 16 + 16], U[by * 8:by * 8 + 8, bx * 8:bx * 8 + 8], V[by * 8:by * 8 + 8, bx * 8:bx * 8 + 8]
+            var = lambda b_, sh: int((b_ * b_).sum()) - ((int(b_.sum()) ** 2) >> sh)
+            e = max((var(y, 8) + var(u, 6) + var(v, 6)) & 0xffffffff, 1)
+            lz = 32 - e.bit_length()
+            lg = f32(lut[((e << lz) >> 24) & 0x7f] + f32(31 - lz))
+            want[by * (w // 16) + bx] = f32(strength * f32(lg - f32(14.427)))
+    assert got.tobytes() == want.tobytes() and np.abs(got).max() > 0.5
