@@ -70,6 +70,7 @@ struct x264_t {
     int L = 0, Q = 1;                    // pictures held back; ring slots (L + 1)
     std::vector<uint8_t *> q_raw;        // device: source pictures (slot 0 is d_in when nothing is held back: zero-copy input)
     std::vector<int32_t *> q_info;       // device: lookahead block records per slot
+    void *q_block[4] = { nullptr, nullptr, nullptr, nullptr };      // device: the blocks the queue's per-slot arrays are cut from (raw pictures, block records, AQ offsets, tree offsets)
     std::vector<float *> q_aq;           // device: AQ offsets per slot (x264 f_qp_offset_aq, single floats)
     float *d_tree = nullptr;             // device: macroblock-tree quantiser offsets of the picture being coded
     long la_count = 0; int la_gop = 0;   // pictures seen by the lookahead; distance from the last IDR at lookahead time
@@ -791,12 +792,19 @@ x264_t *x264_encoder_open(x264_param_t *param)
     if (h->Q == 1) h->q_raw[0] = h->d_in;            // no delay: the staging buffer is the one slot; with a delay the ring is separate,
                                                      // because a zero-copy caller rewrites the staging buffer every call
     {
+        // one device block per array, cut into the queue's slots (an allocation and a release each cost a fraction of a millisecond: thousands of sessions open and close)
         bool ok = true;
-        for (int i = 0; i < h->Q && ok; i++) {
-            if (!h->q_raw[(size_t)i]) ok = x264gpu_malloc((void **)&h->q_raw[(size_t)i], insz) == X264GPU_OK;
-            if (ok && h->mbtree) ok = x264gpu_malloc((void **)&h->q_info[(size_t)i], (size_t)h->nmb * 4 * sizeof(int32_t)) == X264GPU_OK;
-            if (ok && (h->mbtree || h->st_aq_costs || h->aq_mode >= 2)) ok = x264gpu_malloc((void **)&h->q_aq[(size_t)i], (size_t)h->nmb * sizeof(float)) == X264GPU_OK;
-            if (ok && h->mbtree && h->dpbmode) ok = x264gpu_malloc((void **)&h->q_tree[(size_t)i], (size_t)h->nmb * sizeof(float)) == X264GPU_OK;
+        const size_t Q = (size_t)h->Q, insz_al = (insz + 255) & ~(size_t)255, nmbf = ((size_t)h->nmb * sizeof(float) + 255) & ~(size_t)255, ninfo = ((size_t)h->nmb * 4 * sizeof(int32_t) + 255) & ~(size_t)255;
+        const bool want_aq = h->mbtree || h->st_aq_costs || h->aq_mode >= 2, want_tree = h->mbtree && h->dpbmode;
+        if (!h->q_raw[0]) ok = x264gpu_malloc((void **)&h->q_block[0], Q * insz_al) == X264GPU_OK;
+        if (ok && h->mbtree) ok = x264gpu_malloc((void **)&h->q_block[1], Q * ninfo) == X264GPU_OK;
+        if (ok && want_aq) ok = x264gpu_malloc((void **)&h->q_block[2], Q * nmbf) == X264GPU_OK;
+        if (ok && want_tree) ok = x264gpu_malloc((void **)&h->q_block[3], Q * nmbf) == X264GPU_OK;
+        for (size_t i = 0; i < Q && ok; i++) {
+            if (!h->q_raw[i]) h->q_raw[i] = (uint8_t *)h->q_block[0] + i * insz_al;
+            if (h->mbtree) h->q_info[i] = (int32_t *)((uint8_t *)h->q_block[1] + i * ninfo);
+            if (want_aq) h->q_aq[i] = (float *)((uint8_t *)h->q_block[2] + i * nmbf);
+            if (want_tree) h->q_tree[i] = (float *)((uint8_t *)h->q_block[3] + i * nmbf);
         }
         if (ok && h->mbtree) ok = x264gpu_malloc((void **)&h->d_tree, (size_t)h->nmb * sizeof(float)) == X264GPU_OK;
         if (!ok) {
@@ -2362,12 +2370,7 @@ void x264_encoder_close(x264_t *h)
         if (dc.d_ring) x264gpu_free(dc.d_ring);
     }
     if (h->devs.size() > 1) (void)x264gpu_set_device(h->device);
-    for (size_t i = 0; i < h->q_raw.size(); i++) {
-        if (h->q_raw[i] && h->q_raw[i] != h->d_in) x264gpu_free(h->q_raw[i]);
-        if (h->q_info[i]) x264gpu_free(h->q_info[i]);
-        if (h->q_aq[i]) x264gpu_free(h->q_aq[i]);
-        if (i < h->q_tree.size() && h->q_tree[i]) x264gpu_free(h->q_tree[i]);
-    }
+    for (void *blk : h->q_block) if (blk) x264gpu_free(blk);          // the queue's slots (source pictures, lookahead records, AQ and tree offsets) are cuts of these
     if (h->d_tree) x264gpu_free(h->d_tree);
     if (h->la) x264gpu_lookahead_destroy(h->la);
     if (h->st) x264gpu_slicetype_destroy(h->st);
