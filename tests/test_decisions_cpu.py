@@ -75,6 +75,10 @@ DEFAULT_CASES = [
     (176, 144, 30, 9, 11, "moving", 4, ["crf=24", "keyint=250", "rc-lookahead=8", "weightp=0"], dict(crf=24.0, keyint=250, rc_lookahead=8, weightp=0)),  # X264_WEIGHTP_FAKE: the fade's weightdelta
     (176, 144, 30, 11, 0, "static", 0, ["crf=25", "keyint=250", "rc-lookahead=6", "b-pyramid=none", "qcomp=0.7", "aq-strength=0.8"],
      dict(crf=25.0, keyint=250, rc_lookahead=6, weightp=2, b_pyramid=0, qcomp=0.7, aq=0.8)),
+    # presets slower and up decide the B runs with the trellis (b-adapt 2) under the tree; one B picture a run; weightp 1 (fade weights without the duplicates); min-keyint keeps a scene cut an I picture
+    (176, 144, 34, 13, 15, "moving", 0, ["crf=23", "keyint=250", "rc-lookahead=14", "b-adapt=2"], dict(crf=23.0, keyint=250, rc_lookahead=14, weightp=2, b_adapt=2)),
+    (176, 144, 28, 15, 0, "moving", 4, ["crf=22", "keyint=250", "rc-lookahead=9", "bframes=1", "weightp=1"], dict(crf=22.0, keyint=250, rc_lookahead=9, weightp=1, bframes=1)),
+    (208, 112, 30, 19, 9, "moving", 0, ["crf=26", "keyint=60", "min-keyint=20", "rc-lookahead=7", "ipratio=1.2", "pbratio=1.5"], dict(crf=26.0, keyint=60, min_keyint=20, rc_lookahead=7, weightp=2, ip_factor=1.2, pb_factor=1.5)),
 ]
 
 
