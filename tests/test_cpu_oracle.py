@@ -307,3 +307,35 @@ def test_aq_mode_1_offsets_against_numpy():
             lg = f32(lut[((e << lz) >> 24) & 0x7f] + f32(31 - lz))
             want[by * (w // 16) + bx] = f32(strength * f32(lg - f32(14.427)))
     assert got.tobytes() == want.tobytes() and np.abs(got).max() > 0.5
+
+
+@pytest.mark.parametrize("mode", [2, 3])
+def test_aq_modes_2_and_3_against_numpy(mode):
+    """x264_adaptive_quant_frame, modes 2 / 3 (auto-variance, with the bias to dark scenes): (energy + 1)^(1/8) per macroblock — three IEEE square roots here —, the picture's mean and
+    mean square summed in raster order in single floats, strength x (value - average) [+ strength x (1 - 14 / value^2)]: the oracle against numpy float32, bit for bit"""
+    w, h = 176, 144
+    f = synth_frames(w, h, 1, seed=11)[0]
+    f32 = np.float32
+    Y = f[:w * h].reshape(h, w).astype(np.int64)
+    U, V = f[w * h:w * h * 5 // 4].reshape(h // 2, w // 2).astype(np.int64), f[w * h * 5 // 4:].reshape(h // 2, w // 2).astype(np.int64)
+    aqs = f32(1.2)
+    got = O.aq_offsets_mode(f, w, h, mode, float(aqs))
+    adj, s1, s2 = [], f32(0), f32(0)
+    var = lambda b_, sh: int((b_ * b_).sum()) - ((int(b_.sum()) ** 2) >> sh)
+    for by in range(h // 16):
+        for bx in range(w // 16):
+            y, u, v = Y[by * 16:by * 16 + 16, bx * 16:bx * 16 + 16], U[by * 8:by * 8 + 8, bx * 8:bx * 8 + 8], V[by * 8:by * 8 + 8, bx * 8:bx * 8 + 8]
+            e = (var(y, 8) + var(u, 6) + var(v, 6)) & 0xffffffff
+            q = np.sqrt(np.sqrt(np.sqrt(f32(f32(e) + f32(1)))))
+            adj.append(q); s1 = f32(s1 + q); s2 = f32(s2 + f32(q * q))
+    n = f32(len(adj))
+    mean, msq = f32(s1 / n), f32(s2 / n)
+    strength = f32(aqs * mean)
+    avg = f32(mean - f32(f32(f32(0.5) * f32(msq - f32(14))) / mean))
+    want = np.zeros(len(adj), f32)
+    for i, q in enumerate(adj):
+        o = f32(strength * f32(q - avg))
+        if mode == 3:
+            o = f32(o + f32(aqs * f32(f32(1) - f32(f32(14) / f32(q * q)))))
+        want[i] = o
+    assert got.tobytes() == want.tobytes() and np.abs(got).max() > 0.2
