@@ -339,3 +339,56 @@ def test_aq_modes_2_and_3_against_numpy(mode):
             o = f32(o + f32(aqs * f32(f32(1) - f32(f32(14) / f32(q * q)))))
         want[i] = o
     assert got.tobytes() == want.tobytes() and np.abs(got).max() > 0.2
+
+
+def test_ip_stream_mbtree_against_numpy():
+    """oracle/lookahead.c x264o_mbtree (the macroblock-tree of an I / P stream: every picture hands its explained cost to its predecessor) against numpy float32, bit for bit"""
+    w, h, n = 176, 144, 5
+    frames = synth_frames(w, h, n, seed=23)
+    ol = O.OracleLookahead(w, h)
+    infos = [ol.frame_cost(f, i == 0)[1] for i, f in enumerate(frames)]
+    aqs = [O.aq_offsets(f, w, h) for f in frames]
+    bw, bh = (w + 15) // 16, (h + 15) // 16
+    nb = bw * bh
+    f32 = np.float32
+    lut = np.array([float("%.5f" % v) for v in np.log2(1 + np.arange(128) / 128)], f32)
+    exp2 = np.rint(256 * (2 ** (np.arange(64) / 64) - 1)).astype(int)
+    log2 = lambda x: f32(lut[((int(x) << (32 - int(x).bit_length())) >> 24) & 0x7f] + f32(int(x).bit_length() - 1))
+
+    def exp2fix8(x):
+        i = int(f32(f32(f32(x) * f32(-64.0 / 6.0)) + f32(512.5)))
+        return 0 if i < 0 else 0xffff if i > 1023 else ((int(exp2[i & 63]) + 256) << (i >> 6)) >> 8
+    strength = f32(2.0)
+    got = O.mbtree(bw, bh, infos, aqs, float(strength))
+    prop = np.zeros((n, nb), np.int64)
+    for j in range(n - 1, 0, -1):
+        fi, ref = infos[j], prop[j - 1]
+        for i in range(nb):
+            intra, best = min(int(fi[i][0]), 16383), min(int(fi[i][1]), 16383)
+            inter = min(best, intra)
+            amount = 0
+            if intra:
+                amt = f32(f32(int(prop[j][i])) + f32(f32(intra * exp2fix8(aqs[j][i])) * f32(1.0 / 512.0)))
+                amount = min(int(f32(f32(f32(amt * f32(intra - inter)) / f32(intra)) + f32(0.5))), 32767)
+            if not fi[i][3]:
+                continue
+            v = int(fi[i][2])
+            x, y = ((v & 0xffff) ^ 0x8000) - 0x8000, v >> 16
+            bx, by = i % bw, i // bw
+
+            def add(xx, yy, val):
+                if 0 <= xx < bw and 0 <= yy < bh:
+                    ref[yy * bw + xx] = min(ref[yy * bw + xx] + val, 32767)
+            if not (x | y):
+                add(bx, by, amount)
+                continue
+            mbx, mby, x, y = (x >> 5) + bx, (y >> 5) + by, x & 31, y & 31
+            add(mbx, mby, ((32 - y) * (32 - x) * amount + 512) >> 10); add(mbx + 1, mby, ((32 - y) * x * amount + 512) >> 10)
+            add(mbx, mby + 1, (y * (32 - x) * amount + 512) >> 10); add(mbx + 1, mby + 1, (y * x * amount + 512) >> 10)
+    want = np.zeros(nb, f32)
+    for i in range(nb):
+        a = f32(aqs[0][i])
+        ic = (min(int(infos[0][i][0]), 16383) * exp2fix8(a) + 128) >> 8
+        want[i] = a if not ic else f32(a - f32(strength * f32(f32(log2(ic + 2 * int(prop[0][i])) - log2(ic)) + f32(0))))
+    assert got.tobytes() == want.tobytes(), np.nonzero(got != want)[0][:5]
+    assert (got < aqs[0]).sum() > nb // 4
