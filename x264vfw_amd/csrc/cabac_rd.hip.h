@@ -223,6 +223,7 @@ template <class PROF>
 __device__ __forceinline__ void cab_levels_all(Cab &cb, uint32_t model, int lane, const int16_t *lvs, const CabLv &W, const uint32_t *ctab, PROF &pf)
 {
     if (W.cat0 < 0 && !W.nzac && !W.nzdc && !W.ldc) return;
+    lane = relane(lane);
     const int cumv = wave_scan_add((int)(model & 0x1ff)) - (int)(model & 0x1ff);          // lane s: the more probable symbol's cost summed over the states below s
     const int m62 = (int)(__builtin_amdgcn_readlane((int)model, 62) & 0x1ff);
     int f8 = 0;
@@ -432,6 +433,7 @@ __device__ __forceinline__ unsigned long long cab_mb(Cab &cb, uint32_t model, in
                                                      unsigned long long &amvd1_out, const uint32_t *ctab, PROF &pf)
 {
     pf.begin2(); pf.count(16);
+    lane = relane(lane);
     amvd1_out = 0;
     unsigned long long amvd = 0;
     dqp_out = 0;

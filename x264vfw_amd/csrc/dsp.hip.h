@@ -13,6 +13,10 @@
 
 namespace x264gpu {
 
+// the lane index once more, as a value the compiler cannot trace back to the first one: whatever is derived from it (masks, LDS offsets, Z-layout
+// coordinates) is recomputed after this point instead of being hoisted out of the macroblock loop and kept alive — in scratch memory — across it
+__device__ __forceinline__ int relane(int lane0) { int l = lane0; asm volatile("" : "+v"(l)); __builtin_assume(l >= 0 && l < 64); return l; }
+
 // ---------------------------------------------------------------------------------------------
 // cross-lane helpers
 // ---------------------------------------------------------------------------------------------

@@ -383,7 +383,7 @@ __device__ __forceinline__ int umh_hex4_dy(int j) { return (int)((0x776655443322
 // co-located: c.col_*) in order, then hexagon + square with c.me_range (the lookahead's x264_me_search, oracle/lookahead.c la_search).
 __device__ __forceinline__ void umh_fullpel(const PartCtx &c, const int SHAPE, const int MODE, const int mvd, int &bx, int &by, int &bcost)
 {
-    const int lane = c.lane, GL = SHAPE == 0 ? 16 : SHAPE == 3 ? 4 : 8;
+    const int lane = relane(c.lane), GL = SHAPE == 0 ? 16 : SHAPE == 3 ? 4 : 8;
     const int part = SHAPE == 0 ? 0 : SHAPE == 3 ? lane >> 4 : lane >> 5, cnd = SHAPE == 0 ? lane >> 4 : SHAPE == 3 ? (lane >> 2) & 3 : (lane >> 3) & 3;
     const int sr = lane & (GL - 1), pbase = lane - cnd * GL - sr;
     const int ox = SHAPE == 3 ? (part & 1) * 8 : SHAPE == 2 ? part * 8 : 0, oy = SHAPE == 3 ? (part >> 1) * 8 : SHAPE == 1 ? part * 8 : 0;
@@ -517,7 +517,7 @@ template <int M, bool UMH>
 __device__ int search_parts(const PartCtx &c, const int SHAPE, int c0x, int c0y, int &out_mx, int &out_my)
 {
     const int GL = SHAPE == 3 ? 4 : 8;             // SHAPE is wave-uniform: one copy of the code serves the three shapes
-    const int lane = c.lane, part = SHAPE == 3 ? lane >> 4 : lane >> 5, cnd = SHAPE == 3 ? (lane >> 2) & 3 : (lane >> 3) & 3, sr = lane & (GL - 1);
+    const int lane = relane(c.lane), part = SHAPE == 3 ? lane >> 4 : lane >> 5, cnd = SHAPE == 3 ? (lane >> 2) & 3 : (lane >> 3) & 3, sr = lane & (GL - 1);
     const int ox = SHAPE == 3 ? (part & 1) * 8 : SHAPE == 2 ? part * 8 : 0, oy = SHAPE == 3 ? (part >> 1) * 8 : SHAPE == 1 ? part * 8 : 0;
     const int y0 = oy + (SHAPE == 1 ? sr : 2 * sr), y1 = SHAPE == 1 ? y0 : y0 + 1, x1 = SHAPE == 1 ? 8 : 0;
     uint32_t e0[2], e1[2];

@@ -235,7 +235,7 @@ template <int M, int ME, bool WP = true, typename LDS = MbLds<M>>
 __device__ __forceinline__ void me_search(const EncK &k, LDS &L, const MbCtx &c, const MeJob &j, int &mvx, int &mvy, int &cost, int &cost_mv, int &halfpel_thresh, const MeState &S, WinTags &wtg, Prof &pf)
 {
     pf.mark(PH_ME_GLUE);
-    const int lane = c.lane, r = lane & 15, cnd = lane >> 4;
+    const int lane = relane(c.lane), r = lane & 15, cnd = lane >> 4;
     const bool w16 = j.W == 16, rowok = r < j.H;
     const uint8_t *p00 = ref_plane00(k, c.s, j.ref);
     const size_t pb = k.plane_bytes;
@@ -887,7 +887,7 @@ __device__ __forceinline__ unsigned mb_encode_i4x4_trellis(const EncK &k, MbLds<
     // The blocks in ten rounds along the anti-diagonals x + 2 y instead of sixteen steps in coding order: a block's neighbours (left, top, top left, and the
     // top right one where the coding order makes it available) lie on earlier diagonals, the search of a block reads only the slice's context variables,
     // so the two blocks of a round are independent and share ONE search call (it takes up to eight blocks at the latency of one) — same levels, same samples.
-    const int lane = c.lane, j = lane & 3, slot = (lane >> 2) & 1;          // lanes 0..3: the round's first block, 4..7: its second
+    const int lane = relane(c.lane), j = lane & 3, slot = (lane >> 2) & 1;          // lanes 0..3: the round's first block, 4..7: its second
     uint8_t *tile = L.tile + IT_ORG;
     unsigned nnz4 = 0;
     for (int t = 0; t < 10; t++) {
@@ -935,7 +935,7 @@ __device__ __forceinline__ unsigned mb_encode_i4x4_trellis(const EncK &k, MbLds<
 template <int M>
 __device__ __forceinline__ unsigned mb_encode_i8x8_trellis(const EncK &k, MbLds<M> &L, const MbCtx &c, uint32_t cz, const Q8 &q8, const TrCtx &trc, int16_t *lvw, int &cbp8)
 {
-    const int lane = c.lane, g = lane >> 3, r8 = lane & 7;
+    const int lane = relane(c.lane), g = lane >> 3, r8 = lane & 7;
     const bool left = c.mbx > 0, top = c.sy > 0, topright = top && c.mbx + 1 < k.mbw;
     uint8_t *tile8 = L.tile8 + IT_ORG;
     unsigned nnz8 = 0;
@@ -1011,7 +1011,7 @@ __device__ __forceinline__ void mb_analyse_intra(const EncK &k, MbLds<M> &L, con
 {
     const bool RF2 = mbrd && ((k.rd >> 1) & 31) && (k.slice_type != X264GPU_SLICE_B || k.subme >= 9);      // x264's i_mbrd >= 2 (RD refinement, subme >= 8; a B slice analyses one level down)
     const bool every_mode = RF2 || (mbrd && !fast_intra);          // x264: i_mbrd >= 1 + b_fast_intra
-    const int lane = c.lane, j = lane & 3, zx = z_x0(lane), zy = z_y(lane), lambda = c.lambda;
+    const int lane = relane(c.lane), j = lane & 3, zx = z_x0(lane), zy = z_y(lane), lambda = c.lambda;
     const bool left = c.mbx > 0, top = c.sy > 0, topright = top && c.mbx + 1 < k.mbw;
     const int sm = min(c.subme, 10);
     const int b_type_cost = k.slice_type == X264GPU_SLICE_B ? 9 * lambda : 0;      // B slices: the macroblock type prefix of an intra type (x264 i_mb_b_cost_table[I_*] = 9)
@@ -1186,7 +1186,7 @@ __device__ __forceinline__ void mb_analyse_intra(const EncK &k, MbLds<M> &L, con
 template <int M>
 __device__ __forceinline__ int mb_intra_chroma_cost(const EncK &k, MbLds<M> &L, const MbCtx &c, int &predc, int *dirc = nullptr /* [4]: the candidates' costs in list order */)
 {
-    const int lane = c.lane, pl = (lane >> 4) & 1, ci = (lane >> 2) & 3, j = lane & 3, cx0 = (ci & 1) * 4, cyy = (ci >> 1) * 4 + j;
+    const int lane = relane(c.lane), pl = (lane >> 4) & 1, ci = (lane >> 2) & 3, j = lane & 3, cx0 = (ci & 1) * 4, cyy = (ci >> 1) * 4 + j;
     const bool left = c.mbx > 0, top = c.sy > 0;
     const uint8_t *cnb = L.cnb[pl];
     const PredC pc = predc_setup(cnb);
@@ -1216,6 +1216,7 @@ __device__ __forceinline__ uint32_t mb_chroma_residual(uint32_t enc, uint32_t pr
                                                        unsigned &nnz_bits, int &cbp_chroma, const TrCtx *tr = nullptr)
 {
     const bool trellis = tr && (tr->on & TR_C);          // final encode of a trellis session: both quantisers below are the search (lv = LDS)
+    lane = relane(lane);
     const int c = (lane >> 4) & 1, i = (lane >> 2) & 3, j = lane & 3;
     const bool act = lane < 32;
     int e[4], p[4], v[4];
@@ -1354,7 +1355,7 @@ __device__ __forceinline__ void mb_store_chroma(uint8_t *ruv, int rs, int lane, 
 // ------------------------------------------------------------------------------------------------
 __device__ __forceinline__ bool mb_probe_skip_pred(const MbCtx &c, uint32_t cz, uint32_t pred, uint32_t cenc, uint32_t cpred, const Q4 &ql, const Q4 &qc)
 {
-    const int lane = c.lane, j = lane & 3;
+    const int lane = relane(c.lane), j = lane & 3;
     bool ok;
     {
         int e[4], p[4], v[4];
@@ -1401,7 +1402,7 @@ __device__ __forceinline__ bool mb_probe_skip_pred(const MbCtx &c, uint32_t cz, 
 // x264_macroblock_probe_pskip (oracle probe_pskip): would the macroblock code to nothing at the skip vector?
 __device__ __forceinline__ bool mb_probe_pskip(const EncK &k, const MbCtx &c, uint32_t cz, int pmx, int pmy, const Q4 &ql, const Q4 &qc)
 {
-    const int lane = c.lane, j = lane & 3, zx = z_x0(lane), zy = z_y(lane);
+    const int lane = relane(c.lane), j = lane & 3, zx = z_x0(lane), zy = z_y(lane);
     const int mvx = clampi(pmx, c.mvmin0, c.mvmax0), mvy = clampi(pmy, c.mvmin1, c.mvmax1);
     uint32_t pred = mc_luma_row4(ref_plane00(k, c.s, 0), k.plane_bytes, k.rs, c.px + zx, c.py + zy, mvx, mvy);
     if (k.wp_any && (k.wl0[0] >> 24)) pred = wp4(pred, k.wl0[0]);
@@ -1432,7 +1433,7 @@ static __constant__ const uint32_t c_dia4d[33] = {
 // (lane >> 2) & 3 of plane (lane >> 4) & 1: from list 0, list 1, or both averaged with the pair's implicit weight (biwv: lane r0 * 4 + r1)
 __device__ __forceinline__ void b_predict(const EncK &k, const MbCtx &c, const BCfg &g0, int biwv, uint32_t &pred, uint32_t &cpred)
 {
-    const int lane = c.lane, zx = z_x0(lane), zy = z_y(lane), j4 = lane & 3;
+    const int lane = relane(c.lane), zx = z_x0(lane), zy = z_y(lane), j4 = lane & 3;
     // x264 mb_mc_*xywh: vectors are clipped to the macroblock's mv_min / mv_max before the fetch — a spatial-direct vector is a neighbour's, taken as it
     // is, and can point farther than the padding reaches (same samples inside the replicated border)
     BCfg g = g0;
@@ -1483,7 +1484,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(MB_WAVES_PER
     // so the last 256 of 2048 streams ran as a second round
     static_assert(!BS || CSubGeo<M>::DWORDS >= 128, "b_visited aliases L.csub");
 #define b_visited L.csub      /* (not a pointer variable: a generic pointer into LDS trips an instruction-selection bug of this compiler in the umh instantiation) */
-    const int lane = threadIdx.x, s = k.perm ? uni(k.perm[blockIdx.x]) : (int)blockIdx.x;
+    const int lane0 = threadIdx.x, s = k.perm ? uni(k.perm[blockIdx.x]) : (int)blockIdx.x;
+    int lane = lane0;
     const unsigned long long wt0 = k.wtime ? __builtin_readcyclecounter() : 0ull;
 #ifdef X264GPU_POISON
     // poison builds (tools/poison_check.sh): whatever the last wavefront left in LDS must not matter — start from a pattern that no test leaves there
@@ -1511,7 +1513,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(MB_WAVES_PER
     constexpr bool TRL2 = RD == 4 || RD == 6;   // --trellis 2: the search also inside the intra analysis and in every RD candidate                 // I slices run their own instantiation (no search code, a fraction of the registers)
     constexpr bool NORD = RD == 0 || RD == 7;   // B slices analysed without RD (x264 below --subme 7); RD 7 = that + the slice's CABAC state and the trellis quantiser in the final encode (--subme 6 --trellis 1 / 2)
     constexpr bool REF = RD == 5 || RD == 6;               // RD refinement of the chosen type (x264 subme >= 8, i_mbrd 2; k_mb_refine.inc): RD 5 = 3 + refinement, 6 = 4 + refinement
-    const int j4 = lane & 3, zx = z_x0(lane), zy = z_y(lane);
+    int j4 = lane & 3, zx = z_x0(lane), zy = z_y(lane);
+#define RELANE() do { lane = relane(lane0); c.lane = lane; j4 = lane & 3; zx = z_x0(lane); zy = z_y(lane); } while (0)
     int intra_count = intra_prior, cost_qp = -1;          // intra macroblocks so far: of the slice (slice threads), of the picture (--slices N)
     // RD instantiation: levels of the candidate being costed (and of the final macroblock, before they go out), total_coeff of the left / top
     // macroblocks' blocks for the nC of the bit counts; the quantiser the previous coded macroblock left (mb_qp_delta bits)
@@ -1543,7 +1546,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(MB_WAVES_PER
     int ds_t = 0, ds_s = 0;          // --direct auto: this slice's skip-probe counts of the temporal / spatial mode (stored, not added, at the slice's end: a repeated slice pass of --slices N replaces its own)
     for (int mbi = mb_first; mbi < mb_end; mbi++) {
         MbCtx c;
-        c.s = s; c.lane = lane; c.mbi = mbi; c.mbx = mbi % k.mbw; c.mby = mbi / k.mbw; c.sy = c.mby - row0; c.px = c.mbx * 16; c.py = c.mby * 16;
+        RELANE();
+        c.s = s; c.mbi = mbi; c.mbx = mbi % k.mbw; c.mby = mbi / k.mbw; c.sy = c.mby - row0; c.px = c.mbx * 16; c.py = c.mby * 16;
         c.fenc = k.fenc_y + (size_t)s * k.fency_bytes + (size_t)c.py * k.fs + c.px;
         c.fuv = k.fenc_uv + (size_t)s * k.fencuv_bytes + (size_t)c.mby * 8 * k.fs + c.px;
         c.qp = __builtin_amdgcn_readfirstlane((int)k.mbqp[(size_t)s * k.nmb + mbi]);
@@ -2034,6 +2038,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(MB_WAVES_PER
             b_cenc = nv12_pick(fe.x, fe.y, (lane >> 4) & 1);
         }
         for (;;) {
+        RELANE();
         if constexpr (BS) {
             if (rd_run && !commit) {
                 if (!rf_on || rf_kind == 2) {          // (the refinement of an inter type runs inside k_mb_b.inc's last phase: k_mb_b_rdrefine.inc)
