@@ -75,6 +75,7 @@ def parse_args():
     ap.add_argument("--content", default="noise", choices=["noise", "smooth", "survey"], help="synthetic content: 'noise' (default, the headline) = moving rectangles of per-pixel "
                     "white noise + strong sensor noise, harder than camera material; 'smooth' = the same scene with band-limited textures and light noise; "
                     "'survey' = SURVEY.md §8(d) read with natural textures: gradient + 3 moving band-limited rectangles + noise of +-4 on luma, +-2 on chroma")
+    ap.add_argument("--survey-leg", type=int, default=1, help="1 (default): time the same job on --content survey too and report it as value_survey_content in the same line; 0 = skip")
     ap.add_argument("--cpu-worker", type=int, default=-1, help=argparse.SUPPRESS)
     return ap.parse_args()
 
@@ -255,16 +256,16 @@ def pmc_evidence(kernel_substr, avg_launch_ms, streams_per_launch, content):
     profile's entry `_mb_loop_timed_window` is their average over the launches of the timed window, the same launches bench.py's own event
     timing averages.  PMC counters cannot be read from inside an un-profiled run, so these are the profile's figures scaled per stream; null
     without a profile of this workload."""
-    path = next((q for q in (os.path.join(ROOT, "profiles", f"r0{r}_pmc_per_launch.json") for r in (5, 4)) if os.path.exists(q)), None)      # the newest round's profile
+    path = next((q for q in (os.path.join(ROOT, "profiles", f"r0{r}_pmc_per_launch.json") for r in (6, 5, 4)) if os.path.exists(q)), None)      # the newest round's profile
     if not path:
-        return None, None
+        return None, None, None
     tab = json.load(open(path))
     per = tab.get("_workload", {}).get("streams_per_launch")
     if tab.get("_workload", {}).get("content", "noise") != content:
-        return None, None                                     # counters of another workload say nothing about this one
+        return None, None, None                               # counters of another workload say nothing about this one
     t = tab.get("_mb_loop_timed_window") if "k_mb_slice" in kernel_substr else next((tab[k] for k in tab if kernel_substr in k), None)
     if not per or not t:
-        return None, None
+        return None, None, None
     scale = streams_per_launch / per
     traffic = int(t["hbm_bytes_per_launch_corrected"] * scale) if "hbm_bytes_per_launch_corrected" in t else None
     valu = None
@@ -273,7 +274,21 @@ def pmc_evidence(kernel_substr, avg_launch_ms, streams_per_launch, content):
         insts = t["SQ_INSTS_VALU"] * scale
         valu = {"insts_per_launch": int(insts), "insts_per_macroblock": round(t["SQ_INSTS_VALU"] / t.get("macroblocks_per_launch", 1), 1) if t.get("macroblocks_per_launch") else None,
                 "issue_util": round(insts * 4 / (simds * clk * avg_launch_ms * 1e-3), 4), "source": "profiles/" + os.path.basename(path)}
-    return traffic, valu
+    return traffic, valu, "profiles/" + os.path.basename(path)
+
+
+def loaded_product_libraries():
+    """Real paths of the product libraries this process has mapped (/proc/self/maps), for the bench line: what was measured."""
+    found = {}
+    try:
+        for line in open("/proc/self/maps"):
+            path = line.split(None, 5)[5].strip() if len(line.split(None, 5)) == 6 else ""
+            base = os.path.basename(path)
+            if base.startswith("libx264gpu") and base.endswith(".so"):
+                found[base] = os.path.realpath(path)
+    except OSError:
+        pass
+    return found
 
 
 def csp_probe(torch, lib, dev, W, H, frames=64, iters=10):
@@ -540,8 +555,11 @@ def e2e_probe(args):
     if args.e2e_legs != "all":
         return {"what": "x264_encoder_encode end to end, 1920x1080 (only the threads-1 and multi-session legs were asked for)", "threads1_fps": f1, "threads1_frames": n1,
                 "multi_session_fps": fm, "multi_session_sessions": args.e2e_sessions, "multi_session_frames_each": n1, "multi_session_kB_per_frame": kbm, "multi_session_spans": getattr(run_sessions, "detail", None), "host_cores": os.cpu_count()}
-    G, K = 32, 4
+    # --threads G: 32 closed GOPs of the one stream in lock-step, medium's B pictures in every GOP (bframes 3, b-pyramid, weightb; b-adapt 0 and no scene cuts:
+    # a fixed structure).  keyint 12 keeps the leg within the bench's minutes (a slot is one wavefront: ~0.5 pictures/s; keyint 250 x 32 slots would be 8000 pictures)
+    G, K = 32, 12
     fg, kbg = run(G * K, G, K, src)
+    d_thr = delays[-1]
     ns = (h + 15) // 16 // 4                        # x264 slice threads: at most one slice per four macroblock rows
     fs, kbs = run(max(n1, 24), ns, 250, src, sliced=True)
     d_sliced = delays[-1]
@@ -551,7 +569,7 @@ def e2e_probe(args):
     d_rows = delays[-1]
     frg, _ = run(G * K * 2, G, K, src, slices=nr)
     os.environ.pop("X264GPU_GOP_SLOTS", None)
-    return {"what": "ONE 1920x1080 stream through x264_encoder_encode (host pictures in, Annex-B out: PCIe + host entropy coding included), CQP, preset medium as implemented (the threads-1 and slice legs with B pictures, b-adapt 1 and scene cuts: delays as measured; the --threads G legs run without B pictures)",
+    return {"what": "ONE 1920x1080 stream through x264_encoder_encode (host pictures in, Annex-B out: PCIe + host entropy coding included), CQP, preset medium as implemented (the threads-1 and slice legs with B pictures, b-adapt 1 and scene cuts: delays as measured; the --threads G legs with B pictures too: closed GOPs in lock-step on the DPB model, b-adapt 0, no scene cuts)",
             "threads1_fps": f1, "threads1_frames": n1, "threads1_kB_per_frame": kb1,
             "multi_session_fps": fm, "multi_session_sessions": args.e2e_sessions, "multi_session_frames_each": n1, "multi_session_kB_per_frame": kbm, "multi_session_spans": getattr(run_sessions, "detail", None),
             "multi_session_what": "that many x264_encoder_open sessions on as many host threads through the cross-session batcher (X264GPU_BATCH): one lock-step device launch per picture, host pictures in, every thread entropy-codes its own stream; session setup and teardown inside the timed span",
@@ -559,7 +577,7 @@ def e2e_probe(args):
             "sliced_threads_gop_slots32_fps": fsg, "sliced_threads_gop_slots32_delay_frames": (G - 1) * K + 1,
             "slices_per_row_fps": fr, "slices_per_row_slices": nr, "slices_per_row_delay_frames": d_rows, "slices_per_row_kB_per_frame": kbr,
             "slices_per_row_threads32_fps": frg, "slices_per_row_threads32_delay_frames": (G - 1) * K + 1,
-            "threads32_fps": fg, "threads32_frames": G * K, "threads32_keyint": K, "threads32_delay_frames": (G - 1) * K + 1, "threads32_kB_per_frame": kbg,
+            "threads32_fps": fg, "threads32_frames": G * K, "threads32_keyint": K, "threads32_bframes": 3, "threads32_delay_frames": d_thr, "threads32_kB_per_frame": kbg,
             "host_cores": os.cpu_count()}
 
 
@@ -574,6 +592,11 @@ def main():
                "--master-port", port, os.path.abspath(__file__)] + sys.argv[1:]
         sys.exit(subprocess.call(cmd))
     rank, local_rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
+    # the measured libraries are the product's own: an environment override (the hook tools/ and the stub tests use) would let any other
+    # library — the oracle behind the B3 ABI included — stand in for them, so the benchmark refuses to run under one
+    for var in ("X264GPU_LIB", "X264GPU_HOST_LIB"):
+        if os.environ.get(var):
+            raise SystemExit(f"bench.py: {var} is set ({os.environ[var]}): the benchmark measures x264vfw_amd/libx264gpu.so and libx264gpu_host.so only; unset it")
     cpu = cpu_baseline(args) if (rank == 0 and world == 1 and args.cpu_frames > 0) else None      # before the GPU is touched (child processes)
 
     import torch
@@ -603,62 +626,76 @@ def main():
     types = display_types(Wu, args.bframes, Wu) + display_types(K, args.bframes, max(K, 1))
     order = gop.schedule(types, 1)                    # coding order: (display index, PIC_IDR / _I / _P / _BREF / _B)
     assert len(order) == Wu + K and order[Wu][1] == 0, "the timed region starts on an IDR picture"
-    dpb = gop.HostDpb(HL, tools["refs"], args.bframes, 1, weightp=args.weightp)
-
-    # ---- inputs resident in HBM: Wu + K distinct frames per stream (D distinct sequences replicated over the streams) ----
     D = max(1, min(S, args.distinct))
     L = Wu + K
-    base = synth_batch(torch, D, L, W, H, shard.stream_seed(0x264, gids[0]), dev, smooth=args.content != "noise", scene_len=97, luma_noise=4 if args.content == "survey" else None)
-    data = base if D == S else base.repeat(1, (S + D - 1) // D, 1)[:, :S].contiguous()
-    del base
-
-    cfg = Config(**dict(dict(width=W, height=H, streams=S, qp_i=max(0, args.qp - 3), qp_p=args.qp, me_range=16, deblock_alpha=0, deblock_beta=0,
-                             chroma_qp_offset=0, deadzone_inter=21, deadzone_intra=11, dct_decimate=1), **tools))
-    h = C.c_void_p()
-    lib.check(lib.x264gpu_encoder_create(C.byref(h), C.byref(cfg)), "encoder_create")
-    n = lib.x264gpu_encoder_mb_count(h)
-    mbs = torch.empty((S, n, 64), dtype=torch.uint8, device=dev)
-    lvs = torch.empty((S, n, MB_LEVELS), dtype=torch.int16, device=dev)
-    stream = torch.cuda.Stream(device=dev)
-    # every stream has the same picture structure: the plans are made once, before anything is timed
-    plans = []
-    for k_, (disp, pt) in enumerate(order):
-        pic, _ = dpb.plan(pt, disp, gop.follow_of(order, k_))
-        pic.qp = qp_of(args, pt)
-        plans.append((disp, (Pic * S)(*([pic] * S))))
-        dpb.commit()
-
-    def step(c):
-        disp, arr = plans[c]
-        lib.check(lib.x264gpu_encode_pictures(h, data[disp].data_ptr(), arr, mbs.data_ptr(), lvs.data_ptr(), stream.cuda_stream), "encode_pictures")
 
     def sync():
         torch.cuda.synchronize(dev)
         if dist is not None:
             dist.barrier()
 
-    for c in range(Wu):
-        step(c)
-    sync()
-    lib.check(lib.x264gpu_encoder_profile_begin(h, K), "profile_begin")
-    evs = [torch.cuda.Event(enable_timing=True) for _ in range(K + 1)]
-    sync()
-    t0 = time.perf_counter()
-    evs[0].record(stream)
-    for c in range(K):
-        step(Wu + c)
-        evs[c + 1].record(stream)
-    sync()
-    dt = time.perf_counter() - t0
-    step_ms = [evs[c].elapsed_time(evs[c + 1]) for c in range(K)]
+    def timed_pass(content, keep_last=False):
+        """Wu untimed + K timed pictures of S lock-step streams on synthetic `content`, inputs resident in HBM before the clock starts."""
+        base = synth_batch(torch, D, L, W, H, shard.stream_seed(0x264, gids[0]), dev, smooth=content != "noise", scene_len=97, luma_noise=4 if content == "survey" else None)
+        data = base if D == S else base.repeat(1, (S + D - 1) // D, 1)[:, :S].contiguous()
+        del base
+        cfg = Config(**dict(dict(width=W, height=H, streams=S, qp_i=max(0, args.qp - 3), qp_p=args.qp, me_range=16, deblock_alpha=0, deblock_beta=0,
+                                 chroma_qp_offset=0, deadzone_inter=21, deadzone_intra=11, dct_decimate=1), **tools))
+        h = C.c_void_p()
+        lib.check(lib.x264gpu_encoder_create(C.byref(h), C.byref(cfg)), "encoder_create")
+        n = lib.x264gpu_encoder_mb_count(h)
+        mbs = torch.empty((S, n, 64), dtype=torch.uint8, device=dev)
+        lvs = torch.empty((S, n, MB_LEVELS), dtype=torch.int16, device=dev)
+        stream = torch.cuda.Stream(device=dev)
+        # every stream has the same picture structure: the plans are made once, before anything is timed
+        dpb = gop.HostDpb(HL, tools["refs"], args.bframes, 1, weightp=args.weightp)
+        plans = []
+        for k_, (disp, pt) in enumerate(order):
+            pic, _ = dpb.plan(pt, disp, gop.follow_of(order, k_))
+            pic.qp = qp_of(args, pt)
+            plans.append((disp, (Pic * S)(*([pic] * S))))
+            dpb.commit()
 
-    nst = lib.x264gpu_encoder_stage_count()
-    names = [lib.x264gpu_encoder_stage_name(i).decode() for i in range(nst)]
-    a, b = (C.c_double * nst)(), (C.c_int * nst)()
-    lib.check(lib.x264gpu_encoder_profile_end(h, stream.cuda_stream, a, b), "profile_end")
-    ms, cnt = list(a), list(b)
-    dt = shard.max_over_ranks(dt, dist, dev)
-    fps = shard.aggregate_fps(S, K, world, dt)
+        def step(c):
+            disp, arr = plans[c]
+            lib.check(lib.x264gpu_encode_pictures(h, data[disp].data_ptr(), arr, mbs.data_ptr(), lvs.data_ptr(), stream.cuda_stream), "encode_pictures")
+
+        for c in range(Wu):
+            step(c)
+        sync()
+        lib.check(lib.x264gpu_encoder_profile_begin(h, K), "profile_begin")
+        evs = [torch.cuda.Event(enable_timing=True) for _ in range(K + 1)]
+        sync()
+        t0 = time.perf_counter()
+        evs[0].record(stream)
+        for c in range(K):
+            step(Wu + c)
+            evs[c + 1].record(stream)
+        sync()
+        dt = time.perf_counter() - t0
+        step_ms = [evs[c].elapsed_time(evs[c + 1]) for c in range(K)]
+        nst = lib.x264gpu_encoder_stage_count()
+        names = [lib.x264gpu_encoder_stage_name(i).decode() for i in range(nst)]
+        a, b = (C.c_double * nst)(), (C.c_int * nst)()
+        lib.check(lib.x264gpu_encoder_profile_end(h, stream.cuda_stream, a, b), "profile_end")
+        dt = shard.max_over_ranks(dt, dist, dev)
+        res = {"dt": dt, "fps": shard.aggregate_fps(S, K, world, dt), "step_ms": step_ms, "names": names, "ms": list(a), "cnt": list(b), "nst": nst, "mbt": None}
+        if rank == 0 and keep_last:
+            import numpy as np
+            res["mbt"] = np.bincount(mbs[:min(S, 64)].cpu().numpy()[:, :, 0].reshape(-1), minlength=11)
+        lib.x264gpu_encoder_destroy(h)
+        del mbs, lvs
+        torch.cuda.empty_cache()
+        return res, data
+
+    # the same job on SURVEY.md 8(d)'s generator first (reported as value_survey_content beside the headline), then the headline's own content
+    survey = None
+    if args.survey_leg and args.content != "survey":
+        survey, sdata = timed_pass("survey")
+        del sdata
+        torch.cuda.empty_cache()
+    main_res, data = timed_pass(args.content, keep_last=True)
+    dt, fps, step_ms, names, ms, cnt, nst = (main_res[k_] for k_ in ("dt", "fps", "step_ms", "names", "ms", "cnt", "nst"))
     # ---- roofline of the dominant kernel: the macroblock loop (k_mb_slice) ----
     Sb = 1.5 * W * H
     # algorithmic HBM bytes per frame and stage (DESIGN.md "kernels"): planes each stage must read / write once.  The macroblock loop reads the
@@ -675,9 +712,9 @@ def main():
     dom = max(range(nst), key=lambda i: ms[i])
     avg_ms = ms[dom] / max(cnt[dom], 1)
     achieved = alg[names[dom]] * S / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
-    traffic, valu = pmc_evidence("k_mb_slice" if names[dom] == "macroblocks" else names[dom], avg_ms, S, args.content)
+    traffic, valu, pmc_src = pmc_evidence("k_mb_slice" if names[dom] == "macroblocks" else names[dom], avg_ms, S, args.content)
     if args.rd != "cabac" or args.no_trellis:
-        traffic, valu = None, None                            # the committed counters are the headline kernel's (RD with CABAC sizes)
+        traffic, valu, pmc_src = None, None, None                            # the committed counters are the headline kernel's (RD with CABAC sizes)
     per_type = {t: round(tms[t] / tcount[t], 2) for t in tms if tcount[t]}
     # the same per-type step times in the proportions of a --keyint GOP (1 I, then runs of bframes B pictures closed by P pictures)
     blended = None
@@ -688,6 +725,10 @@ def main():
         blended = round(S * world * len(go) / (tot * 1e-3), 2)
     roof = {"bound": "hbm", "binding_resource": "instruction issue of a raster-serial macroblock loop (neither HBM nor MFMA binds this integer path; the HBM fraction is reported because the contract asks for one of the two)", "kernel": "k_mb_slice (macroblock loop)" if names[dom] == "macroblocks" else names[dom], "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic, "valu": valu,
+            # traffic and valu.insts_* are the committed rocprofv3 --pmc passes' figures (counters cannot be read inside an un-profiled run), scaled to this
+            # run's streams; valu_issue_frac = those wave-level VALU instructions / (1024 SIMDs x 2.4 GHz / 4 cycles an instruction) / THIS run's kernel time
+            "traffic_from": pmc_src if traffic is not None else None, "valu_from": pmc_src if valu else None,
+            "valu_issue_frac": valu["issue_util"] if valu else None,
             "note": "I and P instantiations: two wavefronts per SIMD issue ~96 % of the time (fewer instructions per macroblock is the lever); see valu.issue_util, profiles/ and DESIGN.md 1d",
             "avg_launch_ms": round(avg_ms, 4), "step_ms_by_picture_type": per_type, "frames_per_s_in_keyint_proportions": blended,
             "stage_ms_per_step": {names[i]: round(ms[i] / K, 4) for i in range(nst) if names[i] != "unused"}}
@@ -704,16 +745,16 @@ def main():
                       # launches of the three macroblock-loop instantiations before / inside the timed window (tools/profile_summarise.py folds the counters of the timed ones)
                       "launch_plan": {t: {"warmup": sum(1 for _, pt in order[:Wu] if kind[pt] == t), "timed": sum(1 for _, pt in order[Wu:] if kind[pt] == t)} for t in ("I", "P", "B")}},
            "roofline": roof}
+    if survey is not None:
+        out["value_survey_content"] = round(survey["fps"], 2)
+        out["ms_per_step_survey_content"] = round(survey["dt"] / K * 1e3, 4)
     if rank == 0:
-        import numpy as np
-        mbt = np.bincount(mbs[:min(S, 64)].cpu().numpy()[:, :, 0].reshape(-1), minlength=11)
+        mbt = main_res["mbt"]
         tot = float(mbt.sum())
         out["config"]["mb_type_share_last_step"] = {k: round(int(v) / tot, 4) for k, v in (("I4x4", mbt[0]), ("I8x8", mbt[1]), ("I16x16", mbt[2]), ("P16x16/16x8/8x16", mbt[4]),
                                                                                           ("P8x8", mbt[5]), ("P_Skip", mbt[6]), ("B_Direct", mbt[7]), ("B_Skip", mbt[8]), ("B L0/L1/Bi", mbt[9]), ("B_8x8", mbt[10]))}
         out["csp_ingest"] = csp_probe(torch, lib, dev, W, H)
-    lib.x264gpu_encoder_destroy(h)
-    del mbs, lvs
-    torch.cuda.empty_cache()
+        out["config"]["product_libraries"] = loaded_product_libraries()
     if args.lookahead and args.bframes:
         # ---- the lookahead's device work for the same streams and pictures, beside the headline ----
         la_dt, la_calls = lookahead_probe(torch, lib, dev, args, data, Wu, K, S, W, H)
@@ -729,6 +770,12 @@ def main():
             out["cpu_baseline"] = cpu
         if world == 1 and args.e2e_frames > 0:
             out["e2e"] = e2e_probe(args)
+        if world == 1:
+            # a decoder nobody here wrote, if the box has one (tools/decoder_probe.py): the only independent check the entropy tables and the
+            # normative reconstruction can get while no libx264 exists to pin the oracle
+            sys.path.insert(0, os.path.join(ROOT, "tools"))
+            import decoder_probe
+            out["decoder_probe"] = decoder_probe.probe()
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.destroy_process_group()

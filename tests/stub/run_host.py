@@ -32,13 +32,14 @@ def encode(w, h, n, seed, opts, preset=b"medium"):
     assert H.x264_picture_alloc(C.byref(pic), HL.X264_CSP_I420, w, h) == 0
     nal, nn = C.POINTER(HL.Nal)(), C.c_int()
     planes = [(w * h, 0), (w * h // 4, w * h), (w * h // 4, w * h * 5 // 4)]
-    stream, sizes = b"", []
+    stream, sizes, meta = b"", [], []
 
     def take(size):
         nonlocal stream
         if size > 0:
             stream += C.string_at(nal[0].p_payload, size)
             sizes.append(size)
+            meta.append((int(out.i_type), int(out.b_keyframe), int(out.i_pts), int(out.i_dts), [(int(nal[k].i_type), int(nal[k].i_ref_idc)) for k in range(nn.value)]))
     for i, f in enumerate(frames):
         for pl, (sz, off) in enumerate(planes):
             C.memmove(pic.img.plane[pl], f[off:off + sz].ctypes.data, sz)
@@ -54,7 +55,8 @@ def encode(w, h, n, seed, opts, preset=b"medium"):
     stub = C.CDLL(os.path.join(HERE, "_build", "libx264gpu.so"))
     stub.x264gpu_stub_encode_calls.restype = C.c_long
     calls = [stub.x264gpu_stub_encode_calls(d) for d in range(int(os.environ.get("X264GPU_STUB_DEVICES", "2")))]
-    return {"sha": hashlib.sha256(stream).hexdigest(), "bytes": len(stream), "frames": len(sizes), "calls": calls}, stream
+    return {"sha": hashlib.sha256(stream).hexdigest(), "bytes": len(stream), "frames": len(sizes), "calls": calls,
+            "meta": hashlib.sha256(json.dumps(meta).encode()).hexdigest(), "pts": [m[2] for m in meta], "dts": [m[3] for m in meta]}, stream
 
 
 if __name__ == "__main__":

@@ -2,6 +2,7 @@
 x264_encoder_encode loop (the exact call sequence of codec.c:1463,1623,1693,1848-1857) on the MI355X path,
 bitstream checked by the decoder and against the bitstream the oracle's records produce."""
 import ctypes as C
+import os
 
 import numpy as np
 import pytest
@@ -1076,3 +1077,67 @@ def test_long_default_session_on_the_device(gpu):
     for d, r in zip(dec, recs):
         assert psnr(d[:w * h], frames[r[2]][:w * h]) > 28.0
     assert sum(1 for r in recs if r[1]) >= 3          # IDR pictures: keyint 25 and the scene cuts
+
+
+def test_third_party_decoder_agrees(gpu):
+    """a preset-medium stream (B pictures, CABAC, 8x8 transform) decoded by a decoder found on the box at run time equals the
+    encoder's own reconstruction picture for picture.  The harness itself (pts <-> reconstruction, display order) is checked against the
+    builder's decoder first, so that a mismatch reported by a third-party decoder means the stream; skips when the box has no such decoder."""
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import decoder_probe
+    w, h, nfr = 176, 144, 9
+    stream, recons = decoder_probe.encode_session(w, h, nfr)
+    dec = O.h264_decode(stream, nfr, w, h)                # (the builder's decoder returns pictures in decoding order = the order the calls returned them)
+    assert sorted(recons) == list(range(nfr)) and list(recons) != sorted(recons), "the session codes B pictures: output order differs from display order"
+    for i, pts in enumerate(recons):
+        np.testing.assert_array_equal(dec[i], recons[pts], err_msg=f"oracle/h264dec picture {i} (pts {pts})")
+    res = decoder_probe.probe(w, h, nfr)
+    assert set(res) >= {"found", "decoder", "equal", "pictures", "seen_not_driven"}
+    if not res["found"]:
+        pytest.skip("no third-party H.264 decoder on this box (ffmpeg / gst-launch-1.0 / rocDecode sample): nothing to compare with; seen: %r" % (res["seen_not_driven"],))
+    assert res["equal"] is True, res
+
+
+@pytest.mark.parametrize("w,h,nfr,keyint,threads,extra", [(176, 144, 23, 8, 3, {}), (96, 80, 21, 8, 2, {"weightp": 2, "b-pyramid": "none", "bframes": 2}), (64, 48, 5, 12, 2, {"direct": "temporal"})])
+def test_gop_slots_with_b_pictures_equal_serial(gpu, w, h, nfr, keyint, threads, extra):
+    """--threads G with medium's B pictures: closed GOPs of one stream in lock-step on the DPB model — the stream, the picture types and the
+    pts / dts of every output equal the threads-1 session's; the last, shorter GOP is coded alone at the flush.  (CPU twin on the stub over several
+    devices: tests/test_shard_cpu.py::test_gop_slots_with_b_pictures_equal_the_serial_stream.)"""
+    frames = synth_frames(w, h, nfr, seed=17 * w + nfr)
+    opts = dict({"qp": 26, "keyint": keyint, "min-keyint": keyint, "no-scenecut": None, "bframes": 3, "b-adapt": 0, "weightp": 0}, **extra)
+
+    def run(thr):
+        h_, eff = open_encoder(w, h, dict(opts, threads=thr), b"high")
+        assert eff.i_threads == thr and eff.i_bframe == opts["bframes"] and eff.i_bframe_adaptive == 0
+        pic, out = HL.Picture(), HL.Picture()
+        assert H.x264_picture_alloc(C.byref(pic), HL.X264_CSP_I420, w, h) == 0
+        nal, n = C.POINTER(HL.Nal)(), C.c_int()
+        stream, meta = b"", []
+
+        def take(size):
+            nonlocal stream
+            if size > 0:
+                stream += C.string_at(nal[0].p_payload, size)
+                meta.append((int(out.i_type), int(out.b_keyframe), int(out.i_pts), int(out.i_dts), [(int(nal[k].i_type), int(nal[k].i_ref_idc)) for k in range(n.value)]))
+        for i, f in enumerate(frames):
+            C.memmove(pic.img.plane[0], f.ctypes.data, f.size)
+            pic.i_pts = 10 + i
+            size = H.x264_encoder_encode(h_, C.byref(nal), C.byref(n), C.byref(pic), C.byref(out))
+            assert size >= 0
+            take(size)
+        while H.x264_encoder_delayed_frames(h_):
+            size = H.x264_encoder_encode(h_, C.byref(nal), C.byref(n), None, C.byref(out))
+            assert size > 0
+            take(size)
+        H.x264_encoder_close(h_)
+        H.x264_picture_clean(C.byref(pic))
+        return stream, meta
+
+    serial, m1 = run(1)
+    par, mg = run(threads)
+    assert len(m1) == len(mg) == nfr and [m[2] for m in m1] != sorted(m[2] for m in m1), "B pictures: output order differs from display order"
+    assert mg == m1
+    assert par == serial
+    dec = O.h264_decode(par, nfr, w, h)
+    assert len(dec) == nfr

@@ -29,7 +29,7 @@ def run_host(w, h, n, seed, opts, devices):
 @pytest.mark.parametrize("devices,threads", [(2, 4), (3, 5), (2, 2), (4, 3)])
 def test_gop_slots_dealt_to_devices_equal_the_serial_stream(devices, threads):
     w, h, n = 96, 80, 23
-    opts = {"qp": 27, "keyint": 4, "min-keyint": 4, "scenecut": 0, "ref": 2, "bframes": 0, "weightp": 0}      # (GOP slots carry I / P pictures only so far)
+    opts = {"qp": 27, "keyint": 4, "min-keyint": 4, "scenecut": 0, "ref": 2, "bframes": 0, "weightp": 0}      # (I / P pictures; B pictures: the test below)
     serial = run_host(w, h, n, 7, dict(opts, threads=1), 1)
     par = run_host(w, h, n, 7, dict(opts, threads=threads), devices)
     assert par["frames"] == serial["frames"] == n
@@ -37,6 +37,29 @@ def test_gop_slots_dealt_to_devices_equal_the_serial_stream(devices, threads):
     used = [c for c in par["calls"] if c > 0]
     assert len(used) == min(devices, threads), par["calls"]            # every device that owns a slot coded its positions
     assert serial["calls"][0] == n and sum(par["calls"]) < n * min(devices, threads)
+
+
+@pytest.mark.parametrize("devices,threads,n,keyint,extra", [
+    (2, 3, 23, 8, {}),                                            # two full GOPs + a last, shorter one (coded alone at the flush)
+    (3, 4, 27, 9, {"weightp": 2, "ref": 3}),                      # --weightp 2's duplicates on the P pictures; a last GOP of 0 pictures left over: 27 = 3 x 9
+    (2, 2, 21, 8, {"b-pyramid": "none", "bframes": 2}),           # the shorter GOP sits in the batch's LAST slot: the lock-step rounds had begun to code it
+    (4, 4, 14, 6, {"direct": "temporal", "bframes": 3}),          # two batches: 4 slots x 6 pictures would be 24 — one partly gathered batch only
+    (1, 2, 5, 12, {"bframes": 3}),                                # fewer pictures than one GOP
+    (2, 3, 41, 7, {"bframes": 1, "slices": 2}),                   # several batches (7 x 3 = 21 pictures each), slices
+])
+def test_gop_slots_with_b_pictures_equal_the_serial_stream(devices, threads, n, keyint, extra):
+    """north_star's own split at the real preset: closed GOPs of ONE stream, one per slot / device, WITH medium's B pictures (bframes 3, b-pyramid, weightb):
+    every slot runs the DPB model's plan in lock-step; bytes, picture types, pts / dts and nal_ref_idc equal the threads-1 session's
+    (codec.c:933 forwards --threads, :848 closed GOPs)."""
+    w, h = 96, 80
+    opts = dict({"qp": 27, "keyint": keyint, "min-keyint": keyint, "scenecut": 0, "ref": 2, "bframes": 3, "b-adapt": 0, "weightp": 0}, **extra)
+    serial = run_host(w, h, n, 11, dict(opts, threads=1), 1)
+    par = run_host(w, h, n, 11, dict(opts, threads=threads), devices)
+    assert par["frames"] == serial["frames"] == n
+    assert sorted(serial["pts"]) == list(range(n)) and serial["pts"] != sorted(serial["pts"]), "the serial session codes B pictures (output order differs from display order)"
+    assert par["sha"] == serial["sha"], "GOP slots with B pictures: the stream differs from the serial one"
+    assert par["meta"] == serial["meta"], (par["pts"], serial["pts"], par["dts"], serial["dts"])
+    assert sum(1 for c in par["calls"] if c > 0) == min(devices, threads, -(-n // keyint))
 
 
 def test_device_cap_env_and_crf_across_devices():

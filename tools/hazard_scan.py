@@ -94,7 +94,8 @@ def main():
     for p in args:
         q = p
         if bundle:
-            q = tempfile.mktemp(suffix=".co")
+            fd, q = tempfile.mkstemp(suffix=".co")
+            os.close(fd)
             subprocess.run([BUNDLER, "--unbundle", "--type=o", "--input=" + p, "--output=" + q, "--targets=hipv4-amdgcn-amd-amdhsa--gfx950"], check=True)
         hits = scan(q)
         if bundle: os.unlink(q)

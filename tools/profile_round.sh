@@ -12,8 +12,8 @@ out=$root/gpurun_out/prof_$tag
 mkdir -p "$out"
 export TMPDIR=/tmp
 cd /tmp
-K="--cpu-frames 0 --e2e-frames 0 --lookahead 0"
-P="--cpu-frames 0 --e2e-frames 0 --lookahead 0"
+K="--cpu-frames 0 --e2e-frames 0 --lookahead 0 --survey-leg 0"
+P="--cpu-frames 0 --e2e-frames 0 --lookahead 0 --survey-leg 0"
 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/p_kt -- python3 $root/bench.py $K "$@" > $out/bench_under_rocprof.json 2> /tmp/p_kt.err
 cp $(ls /tmp/p_kt/*/*kernel_stats.csv | head -1) $out/kernel_stats_full.csv
 rocprofv3 --pmc FETCH_SIZE --kernel-include-regex "x264gpu" --output-format csv -d /tmp/p_rd -- python3 $root/bench.py $P "$@" > /tmp/p_rd.log 2>&1

@@ -8,7 +8,8 @@ ROOT=$(cd "$(dirname "$0")/.." && pwd)
 S=${1:-/tmp/x264gpu_san}
 rm -rf "$S" && mkdir -p "$S/repo/x264vfw_amd"
 cp -r "$ROOT/oracle" "$ROOT/tests" "$ROOT/include" "$ROOT/tools" "$S/repo/"
-cp -r "$ROOT/x264vfw_amd/host" "$ROOT"/x264vfw_amd/*.py "$ROOT"/x264vfw_amd/*.so "$S/repo/x264vfw_amd/"
+cp -r "$ROOT/x264vfw_amd/host" "$ROOT"/x264vfw_amd/*.py "$S/repo/x264vfw_amd/"
+for f in "$ROOT"/x264vfw_amd/*.so; do [ -e "$f" ] && cp "$f" "$S/repo/x264vfw_amd/"; done      # (git-ignored: absent on a clean CPU-only checkout; the stub build makes its own)
 cd "$S/repo"
 rm -f oracle/*.o oracle/liboracle.so x264vfw_amd/host/*.o; rm -rf tests/stub/_build; mkdir -p tests/stub/_build
 SAN="-fsanitize=address,undefined -fno-omit-frame-pointer"

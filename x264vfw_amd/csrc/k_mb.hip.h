@@ -39,6 +39,8 @@ constexpr int RC_ROWS = 30, RC_PD = 10, RC_COLS = 4 * RC_PD, RC_PLANE_DW = RC_RO
 struct WinTags { int tref, tx, ty; };
 
 template <int M> struct MbLds {
+    // where a (re-)centred reference-cache slot lies around the block: rc_mx columns to its left, rc_my rows above it (a 16x16 macroblock sits in the middle)
+    static constexpr int rc_mx = RC_MX, rc_my = RC_MY;
     __attribute__((aligned(16))) uint32_t rc[3 * RC_SLOT_DW];        // >= WIN_ROWS * WIN_STRIDE bytes (esa)
     uint32_t csub[CSubGeo<M>::DWORDS];
     __attribute__((aligned(16))) uint8_t src[16 * 16];    // the source macroblock, row-major (the searches read rows of it)
@@ -97,6 +99,11 @@ struct Prof {
 
 // a wave-uniform value the compiler cannot prove uniform (it came through LDS or a vector load): say so, it then lives in an SGPR
 __device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
+__device__ __forceinline__ void uni_set(int &v) { v = __builtin_amdgcn_readfirstlane(v); }
+__device__ __forceinline__ void uni_set(unsigned &v) { v = (unsigned)__builtin_amdgcn_readfirstlane((int)v); }
+__device__ __forceinline__ void uni_set(bool &v) { v = __builtin_amdgcn_readfirstlane((int)v) != 0; }
+__device__ __forceinline__ void uni_set(unsigned long long &v) { v = (unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)v) | ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(v >> 32)) << 32); }
+template <class... T> __device__ __forceinline__ void uni_all(T &...v) { (uni_set(v), ...); }
 
 // Per-macroblock search state held in registers, one table entry per lane (every value is wave-uniform): reading entry i is a
 // v_readlane, writing it a select -- no LDS round trip.
@@ -284,7 +291,7 @@ __device__ __forceinline__ void me_search(const EncK &k, LDS &L, const MbCtx &c,
     auto in_sub = [&](int cx, int cy) { return rc_inside(bx + cx - M, by + cy - M, bx + cx + j.W + M + 1, by + cy + j.H + M + 1); };
     // (re-)centre the slot on the macroblock displaced by (cx, cy): twenty requests per lane, then (after other work) the copy into LDS
     auto rc_issue = [&](int cx, int cy, uint32_t v[20]) {
-        X0 = clampi((c.px + cx - RC_MX) & ~3, -PAD, k.cw + PAD - RC_COLS); Y0 = clampi(c.py + cy - RC_MY, -PAD, k.ch + PAD - RC_ROWS);
+        X0 = clampi((c.px + cx - LDS::rc_mx) & ~3, -PAD, k.cw + PAD - RC_COLS); Y0 = clampi(c.py + cy - LDS::rc_my, -PAD, k.ch + PAD - RC_ROWS);
 #pragma unroll
         for (int t = 0; t < 5; t++) {
             const int i = lane + 64 * t, row = (i * 205) >> 11, col = i - row * 10;        // i / 10 for i < 320
@@ -307,6 +314,7 @@ __device__ __forceinline__ void me_search(const EncK &k, LDS &L, const MbCtx &c,
 #endif
         { const bool m = lane == slot; wtg.tref = m ? cref : wtg.tref; wtg.tx = m ? X0 : wtg.tx; wtg.ty = m ? Y0 : wtg.ty; }
         lds_sync();
+        X0 = uni(X0); Y0 = uni(Y0);          // (wave-uniform; behind the lane-dependent stores above the compiler takes the window's origin for divergent otherwise)
     };
     auto rc_stage = [&](int cx, int cy) { uint32_t v[20]; rc_issue(cx, cy, v); rc_commit(v); };
     // the chroma taps of the search START are requested before the full-pel search runs and used if the search ends there
@@ -373,6 +381,7 @@ __device__ __forceinline__ void me_search(const EncK &k, LDS &L, const MbCtx &c,
             }
             if (pre) { rhave = false; rc_commit(rv); }
             else lds_sync();
+            uni_all(X0, Y0, rhave);
 #pragma unroll
             for (int t = 0; t < 3; t++)
                 if (t * 4 < n) {
@@ -397,6 +406,7 @@ __device__ __forceinline__ void me_search(const EncK &k, LDS &L, const MbCtx &c,
         pf.mark(PH_ME_PRED);
         if (cached) {
             if (!in_fpel(bmx, bmy, 2)) rc_stage(bmx, bmy);                                     // a far candidate won
+            uni_all(X0, Y0, rhave);
         }
         pf.mark(PH_ME_WIN);
         // esa: its own window (aliases the slots: their tags are dropped when it is staged)
@@ -444,7 +454,7 @@ __device__ __forceinline__ void me_search(const EncK &k, LDS &L, const MbCtx &c,
             return sd + MVC(mx * 4, my * 4);
         };
         // the slot follows a search that walks out of it (dia / hex; the cost slices reach +-24 around their centre: merange <= 16)
-        auto ensure = [&](int mx, int my, int rad) { if (cached && !in_fpel(mx, my, rad)) rc_stage(mx, my); };
+        auto ensure = [&](int mx, int my, int rad) { if (cached && !in_fpel(mx, my, rad)) rc_stage(mx, my); uni_all(X0, Y0, rhave); };
         {   // the rounded best predictor and the zero vector: groups 0 and 1
             int c_round, c_zero;
             if (!cached) {
@@ -676,6 +686,7 @@ __device__ __forceinline__ void me_search(const EncK &k, LDS &L, const MbCtx &c,
     const int ctrx = (bmx + 2) >> 2, ctry = (bmy + 2) >> 2;
     lds_sync();
     if (!in_sub(ctrx, ctry)) rc_stage(ctrx, ctry);
+    uni_all(X0, Y0, rhave);
     const bool spec_hit = spec && spec_on && ctrx == spx && ctry == spy;
     // chroma: lane r owns row (r & 3) of 4x4 chroma block r >> 2 of the partition, both planes
     const int cbw = j.W >> 3, ncb = cbw * (j.H >> 3), cblk = r >> 2;
@@ -1551,6 +1562,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(MB_WAVES_PER
         c.fenc = k.fenc_y + (size_t)s * k.fency_bytes + (size_t)c.py * k.fs + c.px;
         c.fuv = k.fenc_uv + (size_t)s * k.fencuv_bytes + (size_t)c.mby * 8 * k.fs + c.px;
         c.qp = __builtin_amdgcn_readfirstlane((int)k.mbqp[(size_t)s * k.nmb + mbi]);
+        // (the state carried from macroblock to macroblock is wave-uniform; said explicitly, because one value of it the compiler takes for divergent makes the
+        //  quantiser, lambda and with them every decision of the next macroblock a vector value and the state machine below divergent control flow)
+        last_qp = uni(last_qp); last_dqp = uni(last_dqp); intra_count = uni(intra_count); cost_qp = uni(cost_qp); ds_t = uni(ds_t); ds_s = uni(ds_s);
         if (k.qp_snap && abs(c.qp - last_qp) == 1) c.qp = last_qp;      // x264_macroblock_analyse under AQ: within 1 of the previous macroblock's quantiser = that quantiser
         c.qpc = (int)d_chroma_qp_table[min(max(c.qp + k.chroma_qp_offset, 0), 51)];
         c.lambda = k.lambda_tab[c.qp];
@@ -2037,8 +2051,27 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(MB_WAVES_PER
             const uint2 fe = *(const uint2 *)(L.csrc + ((ci_ >> 1) * 4 + j4) * 16 + 2 * (ci_ & 1) * 4);
             b_cenc = nv12_pick(fe.x, fe.y, (lane >> 4) & 1);
         }
+        // The state of the pass loop is wave-uniform, but the compiler cannot see it: wherever a lane-dependent `if` sits directly in front of a jump, its
+        // join block is the jump's target and every state variable merged there counts as divergent — from then on the state machine is vector code
+        // under exec masks (1395 s_and_saveexec in the B instantiation) with its state in vector registers.  STATE_UNIFORM() re-reads the state into
+        // scalar registers at the loop heads and stage boundaries.
+#define STATE_UNIFORM() do { \
+        uni_all(rd_ph, commit, rd_run, e_type, e_part, e_t8, mb_type, rec_type, best_part, i_cost, predc, satd_chroma, pskip, fast_intra, rd_skip16, nnz, cbp_luma, cbp_chroma); \
+        uni_all(rd16, rd16x8, rd8x16, rd8x8, rd_best, rd_part, rd_t8, rd_satd_inter, rd_isatd, rd_thresh, rd_ithresh, rd_i16, rd_i4, rd_i8, fenc_e4, fenc_e8, chroma_l2off); \
+        uni_all(IR.satd_i16, IR.satd_i8, IR.satd_i4, IR.pred16, IR.nnz4, IR.nnz8, IR.cbp8, cost8x8, satd16x8, satd8x16, i_inter_satd, pskx, psky); \
+        if constexpr (BS) { \
+            uni_all(euse, d_avail, bskip_cost, cost16direct, cost8d_0, cost8d_1, cost8d_2, cost8d_3, cost16bi, cost8x8bi, cost16x8bi, cost8x16bi); \
+            uni_all(rd_dir, rd_l0, rd_l1, rd_bi, rd_8x8, rd_16x8, rd_8x16, sub8_0, sub8_1, sub8_2, sub8_3, p16x8_0, p16x8_1, p8x16_0, p8x16_1, b_type, b_part, b_use16, ds_t, ds_s); \
+        } \
+        if constexpr (REF) { \
+            uni_all(rf_on, rf_kind, rf_pk, rf_st, rf_part, rf_j, rf_i, rf_wait, rf_bmx, rf_bmy, rf_omx, rf_omy, rf_pmx, rf_pmy, rf_dir, rf_odir, rf_bsatd, rf_pmvchk); \
+            uni_all(rf_cx, rf_cy, rf_cdir, rf_mvpx, rf_mvpy, rf_mv0x, rf_mv0y, rf_f4, rf_f8, rf_lmx, rf_lmy, rf_priced, rf_done, rf_ref, rf_slot, rf_pm8, rf_b0, rf_b1); \
+            uni_all(rf_bcost, rf_cost, rf_amvd, rf_l, rf_mvp0x, rf_mvp0y, rf_mvp1x, rf_mvp1y, rf_bm1x, rf_bm1y, rf_c1x, rf_c1y, rf_bestj, rf_amvd1, rf_nnzc); \
+            uni_all(rf_cm, rf_bm, rf_bdct, rf_cbpc, rf_cbp_i8, rf_old, rf_list, rf8_cbp, rf8_n4); \
+        } } while (0)
         for (;;) {
         RELANE();
+        STATE_UNIFORM();
         if constexpr (BS) {
             if (rd_run && !commit) {
                 if (!rf_on || rf_kind == 2) {          // (the refinement of an inter type runs inside k_mb_b.inc's last phase: k_mb_b_rdrefine.inc)
@@ -2116,6 +2149,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(MB_WAVES_PER
                 }
             }
         }
+        STATE_UNIFORM();
         nnz = 0; cbp_luma = 0; cbp_chroma = 0;
         TrCtx trc;                                                // trellis: the final pass of RD sessions with CABAC (x264 --trellis 1)
         trc.on = 0; trc.r = 0; trc.r8 = 0; trc.model = 0; trc.tt.size_unary = nullptr; trc.tt.trans_unary = nullptr; trc.tt.lambda2 = nullptr;
@@ -2723,6 +2757,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(MB_WAVES_PER
         }
         if constexpr (RD >= 2) {
             // ---- CABAC: the candidate priced on a copy of the slice's context variables; the finished macroblock moves them on ----
+            STATE_UNIFORM();
+            uni_all(rd_t8cur, db_mvm);
             lds_sync();
             struct RdMark { Prof &p; __device__ ~RdMark() {
 #ifdef MB_PROF_RD
@@ -2807,6 +2843,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(MB_WAVES_PER
                     if (part_pass) cost64 = ((unsigned long long)(unsigned)dist << 8) + (((unsigned long long)cab_total(tmp) * (unsigned long long)l2p + 128) >> 8);
                     else cost = dist + (int)(((unsigned long long)cab_total(tmp) * (unsigned long long)lambda2 + 32768) >> 16);
                 }
+                cost = uni(cost);          // (wave-uniform, but the bit count came through vector code: say so, or every RD cost of the macroblock lives in a vector register)
                 if constexpr (REF) {
                     if (!part_pass) {
                         // what this whole-macroblock encode leaves in x264's non_zero_count cache (flags; an 8x8 transform block sets its four entries alike)

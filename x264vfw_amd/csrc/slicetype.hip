@@ -41,6 +41,9 @@ struct StK {
 // k_st_cost's LDS: 8x8 blocks of the half-resolution planes, me <= hex, at most two references, no chroma, no intra tiles, no record — only what me_search
 // touches, so that THREE wavefronts share a SIMD where the macroblock loop's layout (20 KB) allows two (12 x 11.4 KB of the CU's 160 KB)
 struct StLds {
+    // the slot around an 8x8 block of a walk that runs RIGHT TO LEFT: 20 columns to the block's left, 12 to its right (the macroblock loop's 12 / 12 around
+    // 16 columns would leave 12 / 20: the wrong way round — every second block re-centred), 11 rows above and below (7 / 15 before)
+    static constexpr int rc_mx = 20, rc_my = 11;
     __attribute__((aligned(16))) uint32_t rc[2 * RC_SLOT_DW];        // reference-cache slots of list 0 / list 1
     uint32_t csub[CSubGeo<2>::DWORDS];
     __attribute__((aligned(16))) uint8_t src[16 * 16];
@@ -209,9 +212,15 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void
             sd = __builtin_amdgcn_sad_u8(p[1], e[1], sd);
             return row16_sum(r < 8 ? (int)sd : 0);
         };
+        // this lane group's rows of the block predicted at a quarter-sample vector: from the list's reference-cache slot when it holds them (the searches
+        // leave it around one of the last blocks of the row: the probe at the zero vector, the bidirectional candidates and the final pair mostly lie
+        // inside), else from memory — one latency of ~2 us a probe that the wavefront cannot hide
         auto fetch = [&](int ref, int qx, int qy, uint32_t p[4]) {
             p[0] = p[1] = p[2] = p[3] = 0;
-            if (r < 8) mc_row_global(ref_plane00(ek, s, ref), ek.plane_bytes, rs, c.px, c.py + r, qx, qy, false, p);
+            const int X0 = rl(wtg.tx, ref), Y0 = rl(wtg.ty, ref), x0 = c.px + (qx >> 2), y0 = c.py + (qy >> 2);
+            const bool inside = !ek.wp_any && rl(wtg.tref, ref) == ref && x0 >= X0 && x0 + 9 <= X0 + RC_COLS && y0 >= Y0 && y0 + 9 <= Y0 + RC_ROWS;
+            if (inside) { if (r < 8) rc_row(L.rc + ref * RC_SLOT_DW, X0, Y0, c.px, c.py + r, qx, qy, false, p); }
+            else if (r < 8) mc_row_global(ref_plane00(ek, s, ref), ek.plane_bytes, rs, c.px, c.py + r, qx, qy, false, p);
         };
         int i_bcost = MB_COST_MAX, list_used = 0;
         auto try_bidir = [&](int x0, int y0, int x1, int y1, int penalty) {

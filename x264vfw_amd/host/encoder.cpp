@@ -112,12 +112,20 @@ struct x264_t {
     bool flushed = false;                // the partly gathered batch has been coded (flush calls only drain after that)
     bool failed = false;                 // GOP-parallel mode: a GPU call failed; the session only returns errors from now on
     std::string gpu_err;                 // threads 1, pipelined: the helper thread's x264gpu_last_error() text (that buffer is thread-local)
-    struct Coded { std::vector<uint8_t> bytes; std::vector<size_t> off; std::vector<int> types; int idr; };
+    struct Coded { std::vector<uint8_t> bytes; std::vector<size_t> off; std::vector<int> types; int idr; int ref_idc = -1, i_type = 0, disp = -1; };      // (ref_idc / i_type / disp: GOP slots with B pictures — a slot index is a CODING position there)
     std::deque<Coded> ready;             // coded frames [emitted, emitted + ready.size())
     std::deque<int64_t> pts;             // pts of frames not yet emitted
     std::vector<Coded> slotbuf;          // G x keyint frames of the batch being coded (index slot * keyint + pos)
     std::vector<uint8_t> slot_have;      // which of them are coded AND joined (written by the calling thread only)
-    int pool_t = -1, pool_nslots = 0;    // position / slot count the running CAVLC threads are coding
+    int pool_t = -1, pool_nslots = 0, pool_slot0 = 0;    // position / slot count / first slot the running CAVLC threads are coding
+    // ---- GOP slots with B pictures (--threads G --bframes N under a constant quantiser): every slot is a closed GOP on the DPB model; the slots run the
+    //      same plan in lock-step (--b-adapt 0, no scenecut: picture c of the coding order has the same type, lists and marking in every GOP), a
+    //      mini-GOP is coded once the batch's last GOP has delivered its closing picture; the stream's last, shorter GOP is coded alone at the flush.
+    //      Frames leave in CODING order with x264's pts / dts, byte-identical to the threads-1 session (tests/test_shard_cpu.py).
+    bool gopb = false;
+    std::vector<std::pair<int, int>> gorder;      // coding order of a full GOP: (display index in the GOP, PIC_*)
+    int gb_next = 0;                              // next coding position of the batch being gathered
+    struct GopDpb { Dpb dpb; int l0ref0poc[8] = { 0 }; } gdpb;
     std::vector<std::thread> pool;       // CAVLC threads of the position coded last: they overlap the GPU work of the next one
     std::vector<x264gpu_mb> h_mb2;       // second download buffers (the pool reads one pair while the next position lands in the other)
     std::vector<int16_t> h_lv2;
@@ -153,7 +161,8 @@ struct x264_t {
     // its NAL units leave with the NEXT call (one picture of delay).  Two slots used in turn: the one being filled, the one waiting to be handed out
     struct Deferred { std::thread th; bool valid = false; std::atomic<bool> hurry{ false }; std::string err; std::vector<uint8_t> out; std::vector<size_t> off; std::vector<int> types; int nal_ref_idc = 0;
                       std::vector<x264gpu_mb> mb; std::vector<int16_t> lv; SliceStats stats = { 0 };
-                      int i_type = 0, b_keyframe = 0; int64_t pts = 0, dts = 0; x264_image_t img; };
+                      int i_type = 0, b_keyframe = 0; int64_t pts = 0, dts = 0; x264_image_t img;
+                      int qp = 0, scenecut = 0; float qpm = 0.f; int32_t costs[4] = { 0, 0, 0, 0 }; };      // the decision hooks' values of THIS picture (x264host_last_decision / _last_qpm)
     Deferred defer[2]; int defer_cur = 0;
     struct BPlanned { BEntry e; int type; };                                                                            // type: PIC_*
     std::deque<BEntry> bq;
@@ -195,6 +204,7 @@ struct BatchGroup {
     long launched = 0;            // rounds whose kernels have been issued: the helper threads start entropy coding round k once round k + 1 is on the device (or when asked to hurry),
                                   // so that the host cores are the callers' while the next pictures are uploaded and submitted
     bool running = false;         // a round is being waited for with the group's lock released (overlap): nobody starts another
+    int leaving = 0; bool orphaned = false;      // batch_leave: leavers between "decided to run the round" and "ran it"; the last member left meanwhile (the leaver destroys the group)
     size_t insz = 0, nmb = 0;
     std::vector<char> member, arrived; int joined = 0, active = 0, n_arrived = 0;
     std::vector<x264gpu_pic> pics; long round = 0; int round_rc = 0; std::string err;
@@ -320,13 +330,20 @@ static void batch_leave(BatchGroup *g, int s)
         g->member[(size_t)s] = 0; g->active--; g->closed = true;
         last = g->active == 0;
         run = !last && g->n_arrived >= g->active && g->n_arrived > 0;      // the others were only waiting for this session
+        if (run) g->leaving++;          // keeps the group alive across the gap below: a member that times out and closes meanwhile must not destroy it under this thread
         if (last)
             for (size_t i = 0; i < g_batch_groups.size(); i++) if (g_batch_groups[i] == g) { g_batch_groups.erase(g_batch_groups.begin() + (long)i); break; }
+        if (last && g->leaving > 0) { g->orphaned = true; last = false; }          // the leaver still inside destroys it when it is done
     }
     if (run) {
-        // (the group cannot go away meanwhile: its remaining members are blocked in batch_wait until this round is done)
-        std::unique_lock<std::mutex> lk(g->m);
-        if (g->active > 0 && g->n_arrived >= g->active && g->n_arrived > 0 && !g->running) batch_run_round(g, lk);
+        bool destroy = false;
+        {
+            std::unique_lock<std::mutex> lk(g->m);
+            if (g->active > 0 && g->n_arrived >= g->active && g->n_arrived > 0 && !g->running) batch_run_round(g, lk);
+            g->leaving--;
+            destroy = g->orphaned && g->leaving == 0;
+        }
+        if (destroy) batch_destroy(g);
     }
     if (last) batch_destroy(g);
 }
@@ -393,6 +410,25 @@ static int cavlc_threads_default(int dflt)
 {
     const char *e = getenv("X264GPU_CAVLC_THREADS");
     return clampi(e ? atoi(e) : dflt, 1, 64);
+}
+
+// Coding order of a closed GOP of n pictures under --b-adapt 0 (x264_slicetype_decide with a fixed pattern, as bmode_decide walks it for a session
+// without lookahead): an IDR picture, then runs of `bframes` B pictures closed by a P picture, the last picture always P; each closing picture first,
+// then under --b-pyramid the middle B of a run of two or more as a reference, then the other B pictures in display order.
+static std::vector<std::pair<int, int>> gop_coding_order(int n, int bframes, int bpyramid)
+{
+    std::vector<std::pair<int, int>> out;
+    std::vector<int> run;
+    for (int i = 0; i < n; i++) {
+        const bool closes = i == 0 || (int)run.size() == bframes || i == n - 1;
+        if (!closes) { run.push_back(i); continue; }
+        out.push_back({ i, i == 0 ? PIC_IDR : PIC_P });
+        const int j = (int)run.size(), bref = bpyramid && j > 1 ? (j - 1) / 2 : -1;
+        if (bref >= 0) out.push_back({ run[(size_t)bref], PIC_BREF });
+        for (int q = 0; q < j; q++) if (q != bref) out.push_back({ run[(size_t)q], PIC_B });
+        run.clear();
+    }
+    return out;
 }
 
 static int pick_level(const x264_param_t *p, int mbs, int refs)
@@ -555,8 +591,14 @@ x264_t *x264_encoder_open(x264_param_t *param)
     p.i_threads = clampi(p.i_threads, 1, 256);                 // --threads G: GOPs coded in lock-step (1 = no delay)
     if (p.i_bframe) {
         // (below --subme 7 x264 analyses B slices without RD: k_mb_b.inc's NORD flow; from 7 up their RD decisions count CABAC sizes or CAVLC bits)
-        const char *why = p.i_threads > 1 ? "threads 1" : p.i_keyint_max < 2 ? "keyint > 1" : (p.rc.i_rc_method == X264_RC_ABR && p.rc.i_bitrate <= 0) ? "constant-quantiser, CRF or ABR rate control with a bitrate" : nullptr;
+        // (--threads G: closed GOPs in lock-step carry B pictures when every GOP has the same picture structure and quantisers: constant quantiser)
+        const char *why = (p.i_threads > 1 && p.rc.i_rc_method != X264_RC_CQP) ? "threads 1, or a constant quantiser with --threads G" : p.i_keyint_max < 2 ? "keyint > 1" :
+                          (p.rc.i_rc_method == X264_RC_ABR && p.rc.i_bitrate <= 0) ? "constant-quantiser, CRF or ABR rate control with a bitrate" : nullptr;
         if (why) { xlog(&p, X264_LOG_WARNING, "B-frames need %s in the MI355X path: bframes 0\n", why); p.i_bframe = 0; }
+    }
+    if (p.i_bframe && p.i_threads > 1) {
+        if (p.i_bframe_adaptive) { xlog(&p, X264_LOG_INFO, "b-adapt needs threads 1 (GOPs in lock-step have a fixed structure): b-adapt 0\n"); p.i_bframe_adaptive = 0; }
+        if (p.analyse.i_direct_mv_pred == 3) { xlog(&p, X264_LOG_INFO, "direct auto needs threads 1 (its choice follows the pictures coded before, across GOPs): spatial\n"); p.analyse.i_direct_mv_pred = 1; }
     }
     if (p.i_bframe) {
         p.i_bframe_adaptive = clampi(p.i_bframe_adaptive, 0, 2);
@@ -862,6 +904,12 @@ x264_t *x264_encoder_open(x264_param_t *param)
         h->slotbuf.resize(n);
         h->slot_have.assign(n, 0);
         h->h_mb2.resize(h->h_mb.size()); h->h_lv2.resize(h->h_lv.size());
+        if (h->dpbmode) {
+            h->gopb = true;
+            h->gorder = gop_coding_order(h->keyint, h->bframes, h->bpyramid);
+            h->gdpb.dpb.configure(p.i_frame_reference, h->bframes, h->bpyramid, h->log2_max_frame_num, h->weightp);
+            xlog(&p, X264_LOG_INFO, "%d GOP slots in lock-step with B pictures (bframes %d, b-pyramid %d, constant quantiser): pictures leave in coding order, %d calls late\n", h->G, h->bframes, h->bpyramid, (h->G - 1) * h->keyint + h->bframes + 1);
+        }
     }
     xlog(&p, X264_LOG_INFO, "MI355X hot path: %dx%d, %d MBs, CQP I:%d P:%d, keyint %d, level %d\n", p.i_width, p.i_height, h->nmb,
          h->qp_i, h->qp_p, h->keyint, h->level_idc);
@@ -914,11 +962,108 @@ static void join_pool(x264_t *h)
     for (auto &th : h->pool) th.join();
     h->pool.clear();
     // only now do the frames of that position count as coded (the workers never touch the bookkeeping)
-    for (int s = 0; s < h->pool_nslots; s++) h->slot_have[(size_t)s * h->keyint + h->pool_t] = 1;
-    h->pool_nslots = 0;
+    for (int s = h->pool_slot0; s < h->pool_slot0 + h->pool_nslots; s++) h->slot_have[(size_t)s * h->keyint + h->pool_t] = 1;
+    h->pool_nslots = 0; h->pool_slot0 = 0;
 }
 
 static int rc_pick_qp(x264_t *h, bool is_i, const int32_t costs[4], int frames_done, int frame);
+
+// GOP slots with B pictures: coding position c of `order` for the slots [slot0, slot0 + nslots) of batch `batch` — the plan from the DPB model (the
+// same for every slot), one x264gpu_encode_pictures per device that owns one of the slots, the slices written by the pool while the next position runs.
+// 0, or -1 after a GPU failure (the session is then dead, as in code_position).
+static int code_position_b(x264_t *h, int batch, int c, int slot0, int nslots, const std::vector<std::pair<int, int>> &order, x264_t::GopDpb &gd)
+{
+    const x264_param_t &p = h->param;
+    const size_t insz = (size_t)p.i_width * p.i_height * 3 / 2;
+    const int G = h->G, K = h->keyint, disp = order[(size_t)c].first, type = order[(size_t)c].second;
+    x264gpu_mb *hmb = h->dl ? h->h_mb2.data() : h->h_mb.data();
+    int16_t *hlv = h->dl ? h->h_lv2.data() : h->h_lv.data();
+    h->dl ^= 1;
+    // the disposable pictures coded right behind this one (x264_reference_hierarchy_reset looks at them)
+    int fc[16], ff[16], nf = 0;
+    for (size_t i = (size_t)c + 1; i < order.size() && nf < 16 && order[i].second == PIC_B; i++) { fc[nf] = (int)i; ff[nf] = order[i].first; nf++; }
+    const DpbPlan plan = gd.dpb.plan(type, disp, nf, fc, ff, nullptr);
+    x264gpu_pic pic = plan.pic;
+    if ((type == PIC_B || type == PIC_BREF) && h->direct_mode == 2) {
+        // x264 slice_header_init: temporal direct prediction only when the co-located picture's reference 0 is this picture's reference 0
+        const bool temporal = pic.nref[0] && pic.nref[1] && gd.l0ref0poc[pic.slot[1][0]] == plan.list_poc[0][0];
+        pic.direct_temporal = temporal; pic.direct_auto = 0;
+        gd.dpb.set_direct(pic.direct_temporal, 0);
+    }
+    if (plan.nal_ref_idc) gd.l0ref0poc[pic.dst] = pic.nref[0] ? plan.list_poc[0][0] : INT_MIN;
+    // constant quantiser by picture type (x264_ratecontrol_start), a zone shifts it by the picture's display index in the stream
+    const double pb_offset = 6.0 * log2f(fabs(p.rc.f_pb_factor) > 0 ? fabsf(p.rc.f_pb_factor) : 1.0f);
+    const int qb = clampi((int)(h->qp_p + pb_offset + 0.5), 0, 51);
+    const int q_type = type <= PIC_I ? h->qp_i : type == PIC_P ? h->qp_p : type == PIC_BREF ? (qb + h->qp_p) / 2 : qb;
+    std::vector<int> qps((size_t)G, q_type);
+    if (!h->zones.empty())
+        for (int s = slot0; s < slot0 + nslots; s++)
+            if (const x264_t::Zone *z = get_zone(h, (int)(((long)batch * G + s) * K + disp))) qps[(size_t)s] = cqp_zone(h, *z, q_type);
+    SliceParams sp = {};
+    sp.mbw = h->mbw; sp.mbh = h->mbh; sp.pic_init_qp = h->pic_init_qp; sp.log2_max_frame_num = h->log2_max_frame_num; sp.log2_max_poc_lsb = h->log2_max_poc_lsb;
+    sp.pps_id = p.i_sps_id; sp.num_ref_default = p.i_frame_reference; sp.num_ref1_default = 1;
+    sp.disable_deblock_idc = p.b_deblocking_filter ? 0 : 1; sp.alpha_off_div2 = p.i_deblocking_filter_alphac0; sp.beta_off_div2 = p.i_deblocking_filter_beta;
+    sp.transform8x8_mode = p.analyse.b_transform_8x8; sp.cabac = p.b_cabac; sp.slices_plain = h->slices_plain;
+    gd.dpb.fill(sp);
+    gd.dpb.commit();
+    const int D = (int)h->devs.size();
+    std::vector<std::string> errs((size_t)D);
+    auto run_dev = [&](int d) {
+        x264_t::DevCtx &dc = h->devs[(size_t)d];
+        bool mine = false;
+        for (int s = slot0; s < slot0 + nslots; s++) mine |= s % D == d;
+        if (!mine) return;                                     // (the stream's last, shorter GOP is coded alone: only its device runs)
+        bool ok = D == 1 || x264gpu_set_device(dc.dev) == X264GPU_OK;
+        std::vector<x264gpu_pic> pics((size_t)dc.nsl, pic);
+        for (int l = 0; l < dc.nsl; l++) pics[(size_t)l].qp = qps[(size_t)(l * D + d)];
+        ok = ok && x264gpu_encode_pictures(dc.gpu, dc.d_ring + (size_t)disp * dc.nsl * insz, pics.data(), dc.d_mb, dc.d_lv, nullptr) == X264GPU_OK &&
+             x264gpu_memcpy_d2h(hmb + (size_t)dc.base * h->nmb, dc.d_mb, (size_t)dc.nsl * h->nmb * sizeof(x264gpu_mb), nullptr) == X264GPU_OK &&
+             x264gpu_memcpy_d2h(hlv + (size_t)dc.base * h->nmb * X264GPU_MB_LEVELS, dc.d_lv, (size_t)dc.nsl * h->nmb * X264GPU_MB_LEVELS * sizeof(int16_t), nullptr) == X264GPU_OK;
+        if (!ok) errs[(size_t)d] = std::string("device ") + std::to_string(dc.dev) + ": " + x264gpu_last_error();
+    };
+    if (D == 1) run_dev(0);
+    else {
+        std::vector<std::thread> ths;
+        for (int d = 0; d < D; d++) ths.emplace_back(run_dev, d);
+        for (auto &th : ths) th.join();
+    }
+    for (int d = 0; d < D; d++)
+        if (!errs[(size_t)d].empty()) {
+            xlog(&p, X264_LOG_ERROR, "x264_encoder_encode: GPU hot path failed: %s\n", errs[(size_t)d].c_str());
+            join_pool(h); h->failed = true;
+            return -1;
+        }
+    join_pool(h);
+    const int ref_idc = plan.nal_ref_idc;
+    auto work = [h, batch, c, disp, type, hmb, hlv, qps, D, sp, ref_idc](int s) {
+        const x264_param_t &p = h->param;
+        const int G = h->G;
+        const size_t row = (size_t)h->devs[(size_t)(s % D)].base + (size_t)(s / D);
+        x264_t::Coded &cd = h->slotbuf[(size_t)s * h->keyint + c];
+        cd.bytes.clear(); cd.off.clear(); cd.types.clear();
+        cd.idr = type == PIC_IDR; cd.ref_idc = ref_idc; cd.disp = disp;
+        cd.i_type = type == PIC_IDR ? X264_TYPE_IDR : type == PIC_I ? X264_TYPE_I : type == PIC_P ? X264_TYPE_P : type == PIC_BREF ? X264_TYPE_BREF : X264_TYPE_B;
+        const long gop = (long)batch * G + s;
+        const bool annexb = p.b_annexb != 0;
+        if (p.b_aud) { cd.off.push_back(cd.bytes.size()); cd.types.push_back(9); write_aud(cd.bytes, type <= PIC_I ? 0 : type == PIC_P ? 1 : 2, annexb); }
+        if (cd.idr && p.b_repeat_headers) {
+            cd.off.push_back(cd.bytes.size()); cd.types.push_back(7); write_sps(cd.bytes, make_sps(h), annexb);
+            cd.off.push_back(cd.bytes.size()); cd.types.push_back(8); write_pps(cd.bytes, make_pps(h), annexb);
+            if (gop == 0) { cd.off.push_back(cd.bytes.size()); cd.types.push_back(6); write_sei_version(cd.bytes, kSeiText, annexb); }
+        }
+        SliceParams sps = sp;
+        sps.qp = qps[(size_t)s]; sps.idr_pic_id = (int)(gop & 0xffff);
+        const size_t before = cd.off.size();
+        write_picture(cd.bytes, &cd.off, sps, h->slices, hmb + row * h->nmb, hlv + row * h->nmb * X264GPU_MB_LEVELS, annexb, before == 0, nullptr);
+        for (size_t i = before; i < cd.off.size(); i++) cd.types.push_back(cd.idr ? 5 : 1);
+    };
+    const unsigned hw = std::thread::hardware_concurrency();
+    const int nthr = (int)(hw ? (hw < (unsigned)nslots ? hw : (unsigned)nslots) : 1);
+    h->pool_t = c; h->pool_nslots = nslots; h->pool_slot0 = slot0;
+    for (int th = 0; th < nthr; th++)
+        h->pool.emplace_back([work, th, nthr, slot0, nslots]() { for (int s = slot0 + th; s < slot0 + nslots; s += nthr) work(s); });
+    return 0;
+}
 
 // 0, or -1 after a GPU failure: the session is then dead (h->failed: every later call returns < 0 and nothing counts as delayed,
 // so the caller's flush loop — codec.c:1842-1856 — ends instead of spinning on frames that will never be coded)
@@ -1061,7 +1206,18 @@ static int encode_gop_parallel(x264_t *h, x264_nal_t **pp_nal, int *pi_nal, x264
             h->gop_qpm[(size_t)s * K + t] = near_qpm(h->rc.qpa_last, h->gop_qp[(size_t)s * K + t]);
         }
         h->pts.push_back(pic_in->i_pts);
+        if (h->gopb) h->all_pts.push_back(pic_in->i_pts);
         h->submitted++;
+        if (s == G - 1 && h->gopb) {
+            // every slot holds display picture t now: the coding positions whose picture (and, being in coding order behind their closing picture,
+            // whose references) have arrived
+            if (t == 0) { h->gb_next = 0; }
+            while (h->gb_next < K && h->gorder[(size_t)h->gb_next].first <= t) {
+                if (code_position_b(h, (int)b, h->gb_next, 0, G, h->gorder, h->gdpb) < 0) return -1;
+                h->gb_next++;
+            }
+            h->next_pos = t + 1 == K ? 0 : t + 1;
+        } else
         if (s == G - 1) {                                      // the batch's last GOP delivers position t: every slot has it
             if (code_position(h, (int)b, t, G) < 0) return -1;
             h->next_pos = t + 1 == K ? 0 : t + 1;
@@ -1070,6 +1226,26 @@ static int encode_gop_parallel(x264_t *h, x264_nal_t **pp_nal, int *pi_nal, x264
     } else {
         // flush: code what the partly gathered batch holds, position by position, with the slots that have that position
         const long i = h->submitted, b = i == 0 ? 0 : (i - 1) / per_batch, r = i - b * per_batch;    // r frames in the last batch
+        if (h->gopb && !h->flushed && r > 0 && !(r == per_batch && h->next_pos == 0)) {
+            // the complete GOPs finish their plan in lock-step; then the stream's last, shorter GOP alone: its own coding order on a DPB model of its own,
+            // from its IDR picture on (what the lock-step rounds coded of it while it was the batch's last slot is coded again: its tail differs)
+            const int full = (int)(r / K), part = (int)(r % K);
+            const bool last_ran = full == G - 1 && part > 0;          // (the partial GOP sat in the last slot: the rounds so far included it)
+            if (!last_ran) h->gb_next = 0;                            // the last slot never delivered: nothing of this batch has been coded yet
+            if (full > 0)
+                for (int c = h->gb_next; c < K; c++)
+                    if (code_position_b(h, (int)b, c, 0, full, h->gorder, h->gdpb) < 0) return -1;
+            if (part > 0) {
+                join_pool(h);
+                x264_t::GopDpb gp;
+                gp.dpb.configure(p.i_frame_reference, h->bframes, h->bpyramid, h->log2_max_frame_num, h->weightp);
+                const std::vector<std::pair<int, int>> po = gop_coding_order(part, h->bframes, h->bpyramid);
+                for (int c = 0; c < part; c++) { h->slot_have[(size_t)full * K + c] = 0; }
+                for (int c = 0; c < part; c++)
+                    if (code_position_b(h, (int)b, c, full, 1, po, gp) < 0) return -1;
+            }
+            h->gb_next = 0; h->next_pos = 0;
+        } else
         if (!h->flushed && r > 0 && !(r == per_batch && h->next_pos == 0)) {
             const int full = (int)(r / K), part = (int)(r % K);            // `full` complete GOPs, then `part` frames
             for (int t = h->next_pos; t < K; t++) {
@@ -1090,6 +1266,18 @@ static int encode_gop_parallel(x264_t *h, x264_nal_t **pp_nal, int *pi_nal, x264
     h->out = std::move(c.bytes);
     h->nal_off = c.off;
     publish_nals(h, pp_nal, pi_nal, c.types);
+    if (h->gopb) for (size_t i = 0; i < h->nals.size(); i++) if (c.types[i] == 1 || c.types[i] == 5) h->nals[i].i_ref_idc = c.ref_idc;
+    if (pic_out && h->gopb) {
+        // coding order: the picture's own pts; x264's dts: the k-th coded picture takes the pts of display picture k - delay (the first ones shifted back)
+        x264_picture_init(pic_out);
+        pic_out->i_type = c.i_type; pic_out->b_keyframe = c.idr;
+        const long k = h->emitted, gop_base = k - k % K, delay = !h->bframes ? 0 : h->bpyramid ? 2 : 1;
+        const size_t np = h->all_pts.size();
+        const size_t di = (size_t)(gop_base + c.disp);
+        pic_out->i_pts = h->all_pts[di < np ? di : np - 1];
+        if (k >= delay) pic_out->i_dts = h->all_pts[(size_t)(k - delay) < np ? (size_t)(k - delay) : np - 1];
+        else pic_out->i_dts = h->all_pts[(size_t)k < np ? (size_t)k : np - 1] - (h->all_pts[(size_t)delay < np ? (size_t)delay : np - 1] - h->all_pts[0]);
+    } else
     if (pic_out) {
         x264_picture_init(pic_out);
         pic_out->i_type = c.idr ? X264_TYPE_IDR : X264_TYPE_P;
@@ -2014,6 +2202,8 @@ static int publish_deferred(x264_t *h, x264_t::Deferred &d, x264_nal_t **pp_nal,
     d.valid = false;
     if (!d.err.empty()) { xlog(&h->param, X264_LOG_ERROR, "x264_encoder_encode: download of a batched picture failed: %s\n", d.err.c_str()); h->failed = true; return -1; }
     h->out.swap(d.out); h->nal_off = d.off; h->last_stats = d.stats;
+    // the diagnostics hooks describe the picture whose NAL units this call returns, not the one submitted meanwhile
+    h->last_qp = d.qp; h->last_qpm = d.qpm; h->last_scenecut = d.scenecut; memcpy(h->last_costs, d.costs, sizeof(d.costs));
     publish_nals(h, pp_nal, pi_nal, d.types);
     for (size_t i = 0; i < h->nals.size(); i++) if (d.types[i] == 1 || d.types[i] == 5) h->nals[i].i_ref_idc = d.nal_ref_idc;
     if (pic_out) {
@@ -2136,6 +2326,10 @@ static int encode_bmode(x264_t *h, x264_nal_t **pp_nal, int *pi_nal, x264_pictur
         d.mb.resize((size_t)h->nmb); d.lv.resize((size_t)h->nmb * X264GPU_MB_LEVELS);
         d.i_type = idr ? X264_TYPE_IDR : pl.type == PIC_I ? X264_TYPE_I : pl.type == PIC_P ? X264_TYPE_P : pl.type == PIC_BREF ? X264_TYPE_BREF : X264_TYPE_B;
         d.b_keyframe = idr; d.pts = pl.e.pts; d.img = pl.e.img;
+        d.qp = pic.qp; d.qpm = pic.qpm; d.scenecut = pl.e.scenecut; memcpy(d.costs, pl.e.costs, sizeof(d.costs));
+        // (the deferred return skips x264_ratecontrol_end and the statistics line below: batched sessions are never ABR / 2-pass — x264_encoder_open admits
+        //  constant-quantiser and CRF sessions into a batch only)
+        if (h->abr || h->pass1 || h->pass2) { xlog(&p, X264_LOG_ERROR, "x264_encoder_encode: a batched session cannot run rate control that reads the coded sizes\n"); h->failed = true; return -1; }
         {
             const long k = h->coded_count, delay = !h->bframes ? 0 : h->bpyramid ? 2 : 1;
             const size_t np = h->all_pts.size();
