@@ -15,6 +15,19 @@ namespace x264gpu {
 
 // the lane index once more, as a value the compiler cannot trace back to the first one: whatever is derived from it (masks, LDS offsets, Z-layout
 // coordinates) is recomputed after this point instead of being hoisted out of the macroblock loop and kept alive — in scratch memory — across it
+// Orders this wavefront's LDS accesses: what one lane wrote before is what another lane reads after.  A workgroup here is ONE wavefront and the LDS
+// pipeline takes a wavefront's instructions in issue order, so the hardware needs nothing — the compiler must only keep the accesses in program order
+// (LDS_ORDER_WAIT: the earlier form, which also drained the LDS queue, i.e. stalled the wavefront for every store's round trip).
+__device__ __forceinline__ void lds_order()
+{
+#ifdef LDS_ORDER_WAIT
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_s_waitcnt(0xc07f);
+#else
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+#endif
+}
 __device__ __forceinline__ int relane(int lane0) { int l = lane0; asm volatile("" : "+v"(l)); __builtin_assume(l >= 0 && l < 64); return l; }
 
 // ---------------------------------------------------------------------------------------------

@@ -134,8 +134,7 @@ __device__ __forceinline__ void pred4_build_u(uint8_t *U, const uint8_t *blk, in
         U[U_F2 + lane - 1] = (uint8_t)((v + hi + 1) >> 1);
         U[U_F3 + lane - 1] = (uint8_t)((lo + 2 * v + hi + 2) >> 2);
     }
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_s_waitcnt(0xc07f);
+    lds_order();
 }
 
 // predicted row (4 pixels) from U[] given this lane's four table indices packed in t4

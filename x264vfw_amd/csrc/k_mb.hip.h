@@ -33,6 +33,12 @@ enum { ME_16 = 0, ME_8 = 1, ME_16x8 = 5, ME_8x16 = 7, ME_COUNT = 9 };     // slo
 // full-pel steps and uses the slot for the sub-pel ones.
 constexpr int MVC_N = 512;
 constexpr int RC_ROWS = 30, RC_PD = 10, RC_COLS = 4 * RC_PD, RC_PLANE_DW = RC_ROWS * RC_PD, RC_SLOT_DW = 4 * RC_PLANE_DW, RC_MX = 12, RC_MY = 7;
+// a slot's geometry as a type (the LDS layout names one: MbLds the macroblock loop's 30 x 40, the lookahead's StLds a wider, flatter one): PD dwords a row
+template <int PD_, int ROWS_> struct RcGeo {
+    static constexpr int PD = PD_, ROWS = ROWS_, COLS = 4 * PD_, PLANE_DW = ROWS_ * PD_, SLOT_DW = 4 * PLANE_DW, NT = (PLANE_DW + 63) / 64;      // NT: loads a lane issues per plane to fill a slot
+    static_assert(PD_ == 10 || PD_ == 16, "row length: 10 dwords (division by multiplication below) or 16");
+    static __device__ __forceinline__ int row_of(int i) { return PD_ == 16 ? i >> 4 : (i * 205) >> 11; }      // i / PD for i < 320 (PD 10)
+};
 // tags of the three reference-cache slots, as a lane-indexed register table like MeState (lane = slot): which picture the slot holds and where
 // its sample (0, 0) lies.  (As nine named fields selected by `slot` the structure stayed in scratch memory: a conditional over lvalues is a
 // select of addresses.)
@@ -41,6 +47,7 @@ struct WinTags { int tref, tx, ty; };
 template <int M> struct MbLds {
     // where a (re-)centred reference-cache slot lies around the block: rc_mx columns to its left, rc_my rows above it (a 16x16 macroblock sits in the middle)
     static constexpr int rc_mx = RC_MX, rc_my = RC_MY;
+    using rcg = RcGeo<RC_PD, RC_ROWS>;
     __attribute__((aligned(16))) uint32_t rc[3 * RC_SLOT_DW];        // >= WIN_ROWS * WIN_STRIDE bytes (esa)
     uint32_t csub[CSubGeo<M>::DWORDS];
     __attribute__((aligned(16))) uint8_t src[16 * 16];    // the source macroblock, row-major (the searches read rows of it)
@@ -125,11 +132,7 @@ __device__ __forceinline__ void me_store(MeState &S, int lane, int slot, int mvx
     S.ref = m ? ref : S.ref; S.refcost = m ? refcost : S.refcost; S.mvpx = m ? mvpx : S.mvpx; S.mvpy = m ? mvpy : S.mvpy;
 }
 
-__device__ __forceinline__ void lds_sync()
-{
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_s_waitcnt(0xc07f);
-}
+__device__ __forceinline__ void lds_sync() { lds_order(); }
 
 // x264_macroblock_deblock ([x264-upstream] encoder/macroblock.c; h->mb.b_deblock_rdo, --subme 9 and up; oracle macroblock_deblock): the INTERNAL luma edges
 // of a whole-macroblock RD candidate's reconstruction, held as a 16x16 byte tile in LDS (row stride 16), are loop-filtered before its distortion is
@@ -218,13 +221,14 @@ __device__ __forceinline__ void mc_row_global(const uint8_t *__restrict__ p00, s
 
 // this lane's row of W pixels at picture position (x, y) displaced by the quarter-pel vector, from a reference-cache slot whose sample
 // (0, 0) is picture position (X0, Y0) (mc.get_ref on the cached planes)
+template <class G = RcGeo<RC_PD, RC_ROWS>>
 __device__ __forceinline__ void rc_row(const uint32_t *slot, int X0, int Y0, int x, int y, int mvx, int mvy, bool w16, uint32_t out[4])
 {
     const int idx = ((mvy & 3) << 2) | (mvx & 3);
     const int pl0 = (kQpelPlane0Packed >> (2 * idx)) & 3, pl1 = (kQpelPlane1Packed >> (2 * idx)) & 3;
     const int bx = x + (mvx >> 2) - X0, by = y + (mvy >> 2) - Y0;
-    const int o0 = (by + ((mvy & 3) == 3 ? 1 : 0)) * RC_COLS + bx, o1 = by * RC_COLS + bx + ((mvx & 3) == 3 ? 1 : 0);
-    const uint32_t *wa = slot + pl0 * RC_PLANE_DW + (o0 >> 2), *wb = slot + pl1 * RC_PLANE_DW + (o1 >> 2);
+    const int o0 = (by + ((mvy & 3) == 3 ? 1 : 0)) * G::COLS + bx, o1 = by * G::COLS + bx + ((mvx & 3) == 3 ? 1 : 0);
+    const uint32_t *wa = slot + pl0 * G::PLANE_DW + (o0 >> 2), *wb = slot + pl1 * G::PLANE_DW + (o1 >> 2);
     const bool avg = (idx & 5) != 0;
     uint32_t a[5], b[5];
 #pragma unroll
@@ -281,32 +285,34 @@ __device__ __forceinline__ void me_search(const EncK &k, LDS &L, const MbCtx &c,
     constexpr bool umh = ME == 2, esa = ME == 3, cached = ME == 0 || ME == 1;      // cached: the full-pel steps read the reference-cache slot
     // ---- this reference's slot of the reference cache ----
     const int slot = cref >= 3 ? cref - 3 : cref;
-    uint32_t *rslot = L.rc + slot * RC_SLOT_DW;
+    using G = typename LDS::rcg;
+    uint32_t *rslot = L.rc + slot * G::SLOT_DW;
     int X0 = __builtin_amdgcn_readlane(wtg.tx, slot), Y0 = __builtin_amdgcn_readlane(wtg.ty, slot);
     bool rhave = __builtin_amdgcn_readlane(wtg.tref, slot) == cref;
-    auto rc_inside = [&](int x0, int y0, int x1, int y1) { return rhave && x0 >= X0 && x1 <= X0 + RC_COLS && y0 >= Y0 && y1 <= Y0 + RC_ROWS; };
+    auto rc_inside = [&](int x0, int y0, int x1, int y1) { return rhave && x0 >= X0 && x1 <= X0 + G::COLS && y0 >= Y0 && y1 <= Y0 + G::ROWS; };
     // the block displaced by full-pel (mx +- rad, my +- rad) / by the quarter-pel vector (qx, qy) / anywhere within M samples of full-pel (cx, cy)
     auto in_fpel = [&](int mx, int my, int rad) { return rc_inside(bx + mx - rad, by + my - rad, bx + mx + rad + j.W, by + my + rad + j.H); };
     auto in_qpel = [&](int qx, int qy) { return rc_inside(bx + (qx >> 2), by + (qy >> 2), bx + (qx >> 2) + j.W + 1, by + (qy >> 2) + j.H + 1); };
     auto in_sub = [&](int cx, int cy) { return rc_inside(bx + cx - M, by + cy - M, bx + cx + j.W + M + 1, by + cy + j.H + M + 1); };
     // (re-)centre the slot on the macroblock displaced by (cx, cy): twenty requests per lane, then (after other work) the copy into LDS
-    auto rc_issue = [&](int cx, int cy, uint32_t v[20]) {
-        X0 = clampi((c.px + cx - LDS::rc_mx) & ~3, -PAD, k.cw + PAD - RC_COLS); Y0 = clampi(c.py + cy - LDS::rc_my, -PAD, k.ch + PAD - RC_ROWS);
+    constexpr int NV = 4 * G::NT;
+    auto rc_issue = [&](int cx, int cy, uint32_t v[NV]) {
+        X0 = clampi((c.px + cx - LDS::rc_mx) & ~3, -PAD, k.cw + PAD - G::COLS); Y0 = clampi(c.py + cy - LDS::rc_my, -PAD, k.ch + PAD - G::ROWS);
 #pragma unroll
-        for (int t = 0; t < 5; t++) {
-            const int i = lane + 64 * t, row = (i * 205) >> 11, col = i - row * 10;        // i / 10 for i < 320
+        for (int t = 0; t < G::NT; t++) {
+            const int i = lane + 64 * t, row = G::row_of(i), col = i - row * G::PD;
             const long o = (long)(Y0 + row) * k.rs + X0 + 4 * col;
 #pragma unroll
-            for (int pl = 0; pl < 4; pl++) v[pl * 5 + t] = i < RC_PLANE_DW ? *(const uint32_t *)(p00 + pl * pb + o) : 0u;
+            for (int pl = 0; pl < 4; pl++) v[pl * G::NT + t] = i < G::PLANE_DW ? *(const uint32_t *)(p00 + pl * pb + o) : 0u;
         }
     };
-    auto rc_commit = [&](const uint32_t v[20]) {
+    auto rc_commit = [&](const uint32_t v[NV]) {
         lds_sync();
 #pragma unroll
-        for (int t = 0; t < 5; t++) {
+        for (int t = 0; t < G::NT; t++) {
             const int i = lane + 64 * t;
 #pragma unroll
-            for (int pl = 0; pl < 4; pl++) if (i < RC_PLANE_DW) rslot[pl * RC_PLANE_DW + i] = v[pl * 5 + t];
+            for (int pl = 0; pl < 4; pl++) if (i < G::PLANE_DW) rslot[pl * G::PLANE_DW + i] = v[pl * G::NT + t];
         }
         rhave = true;
 #ifndef MB_PROF_RD
@@ -316,7 +322,7 @@ __device__ __forceinline__ void me_search(const EncK &k, LDS &L, const MbCtx &c,
         lds_sync();
         X0 = uni(X0); Y0 = uni(Y0);          // (wave-uniform; behind the lane-dependent stores above the compiler takes the window's origin for divergent otherwise)
     };
-    auto rc_stage = [&](int cx, int cy) { uint32_t v[20]; rc_issue(cx, cy, v); rc_commit(v); };
+    auto rc_stage = [&](int cx, int cy) { uint32_t v[NV]; rc_issue(cx, cy, v); rc_commit(v); };
     // the chroma taps of the search START are requested before the full-pel search runs and used if the search ends there
     constexpr bool spec = cached && M == 2;
     uint32_t spc[2];
@@ -362,7 +368,7 @@ __device__ __forceinline__ void me_search(const EncK &k, LDS &L, const MbCtx &c,
         int pmv_cost = 0;
         {
             const bool pre = cached && !in_fpel(pmx, pmy, 2);
-            uint32_t rv[20];
+            uint32_t rv[NV];
             if (pre) { rhave = false; rc_issue(pmx, pmy, rv); rhave = true; }          // geometry known now, samples after rc_commit
             uint32_t pp[3][4];
             int cm[3], cqx[3], cqy[3];
@@ -386,7 +392,7 @@ __device__ __forceinline__ void me_search(const EncK &k, LDS &L, const MbCtx &c,
             for (int t = 0; t < 3; t++)
                 if (t * 4 < n) {
                     const int i = t * 4 + cnd;
-                    if (inl[t]) { rc_row(rslot, X0, Y0, bx, by + r, cqx[t], cqy[t], w16, pp[t]); WP4X4(pp[t]); }
+                    if (inl[t]) { rc_row<G>(rslot, X0, Y0, bx, by + r, cqx[t], cqy[t], w16, pp[t]); WP4X4(pp[t]); }
                     unsigned sd = __builtin_amdgcn_sad_u8(pp[t][0], e[0], 0u);
                     sd = __builtin_amdgcn_sad_u8(pp[t][1], e[1], sd); sd = __builtin_amdgcn_sad_u8(pp[t][2], e[2], sd); sd = __builtin_amdgcn_sad_u8(pp[t][3], e[3], sd);
                     const int cst = row16_sum(rowok ? (int)sd : 0) + cm[t];
@@ -414,7 +420,7 @@ __device__ __forceinline__ void me_search(const EncK &k, LDS &L, const MbCtx &c,
 #define MVC(qx, qy) mvc(qx, qy)
         auto fpel = [&](int mx, int my) {       // full-pel candidate cost (valid after the row sum)
             if (umh) return sad_global(mx * 4, my * 4) + mvc(mx * 4, my * 4);
-            const uint8_t *wrow = esa ? (const uint8_t *)L.rc + (by + my + r - wy0) * WIN_STRIDE : (const uint8_t *)rslot + (by + my + r - Y0) * RC_COLS;
+            const uint8_t *wrow = esa ? (const uint8_t *)L.rc + (by + my + r - wy0) * WIN_STRIDE : (const uint8_t *)rslot + (by + my + r - Y0) * G::COLS;
             const int xo = bx + mx - (esa ? wx0 : X0);
             int sd = 0;
             if (wt) {       // x264 searches the weighted copy of the plane (p_fref_w): pointwise, so weight the row read from the unweighted one
@@ -435,7 +441,7 @@ __device__ __forceinline__ void me_search(const EncK &k, LDS &L, const MbCtx &c,
         auto fpel8 = [&](int mx, int my) {
             const int r8 = lane & 7;
             const uint8_t *f = L.src + (j.oy + r8) * 16 + j.ox;
-            const uint8_t *wrow = (const uint8_t *)rslot + (by + my + r8 - Y0) * RC_COLS;
+            const uint8_t *wrow = (const uint8_t *)rslot + (by + my + r8 - Y0) * G::COLS;
             const int xo = bx + mx - X0;
             int sd;
             if (wt) {
@@ -707,7 +713,7 @@ __device__ __forceinline__ void me_search(const EncK &k, LDS &L, const MbCtx &c,
     auto mvc2 = [&](int qx, int qy) { return mvc(qx, qy); };
     auto fetch2 = [&](int qx, int qy, uint32_t p[4]) {
         p[0] = p[1] = p[2] = p[3] = 0;
-        if (rowok) { rc_row(rslot, X0, Y0, bx, by + r, qx, qy, w16, p); WP4X4(p); }
+        if (rowok) { rc_row<G>(rslot, X0, Y0, bx, by + r, qx, qy, w16, p); WP4X4(p); }
     };
     auto sad2 = [&](int qx, int qy) {
         uint32_t p[4];

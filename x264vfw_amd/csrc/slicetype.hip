@@ -41,10 +41,12 @@ struct StK {
 // k_st_cost's LDS: 8x8 blocks of the half-resolution planes, me <= hex, at most two references, no chroma, no intra tiles, no record — only what me_search
 // touches, so that THREE wavefronts share a SIMD where the macroblock loop's layout (20 KB) allows two (12 x 11.4 KB of the CU's 160 KB)
 struct StLds {
-    // the slot around an 8x8 block of a walk that runs RIGHT TO LEFT: 20 columns to the block's left, 12 to its right (the macroblock loop's 12 / 12 around
-    // 16 columns would leave 12 / 20: the wrong way round — every second block re-centred), 11 rows above and below (7 / 15 before)
-    static constexpr int rc_mx = 20, rc_my = 11;
-    __attribute__((aligned(16))) uint32_t rc[2 * RC_SLOT_DW];        // reference-cache slots of list 0 / list 1
+    // the slot around an 8x8 block of a walk that runs RIGHT TO LEFT: a row of 64 columns, 44 to the block's left and 12 to its right, so that the next four
+    // blocks of the row still lie inside with 12 columns to spare (the macroblock loop's 40-column slot, 12 / 20 around the block, was re-centred for nearly every
+    // block: every re-centre touches ROWS x 4 cache lines whatever the row length — the L2's line rate, not its bytes, bounds this kernel); 8 rows above and below
+    static constexpr int rc_mx = 44, rc_my = 8;
+    using rcg = RcGeo<16, 24>;                                       // 24 rows x 64 columns of the four planes: 6 KB a slot
+    __attribute__((aligned(16))) uint32_t rc[2 * RcGeo<16, 24>::SLOT_DW];        // reference-cache slots of list 0 / list 1
     uint32_t csub[CSubGeo<2>::DWORDS];
     __attribute__((aligned(16))) uint8_t src[16 * 16];
     __attribute__((aligned(16))) uint8_t csrc[8 * 16];               // (chroma rows: named by me_search's chroma-me branch, never taken here)
@@ -147,13 +149,15 @@ __global__ __launch_bounds__(256) void k_st_intra(StK k)
 }
 
 template <int ME>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void k_st_cost(StK k)
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 3))) void k_st_cost(StK k)
 {
     __shared__ __attribute__((aligned(16))) StLds L;
     const int lane = threadIdx.x, s = blockIdx.y, r = lane & 15;
     // k.serial_rows: ONE wavefront walks all the rows of its stream, bottom-up (a batch of streams fills the chip by itself: no wavefront spins on the
     // row below, no pipeline to fill per stream); else one wavefront per row, chained by the progress counters (a lone stream's latency)
-    const int row_first = k.serial_rows ? 0 : (int)blockIdx.x, row_last = k.serial_rows ? k.start_y - k.end_y : (int)blockIdx.x;
+    // in between (the default for batches): gridDim.x wavefronts a stream, wavefront w walking rows w, w + gridDim.x, ... — the same bottom-up chain with a
+    // shorter diagonal to fill and drain (a row trails the one below by two blocks: 68 wavefronts a stream idle for 136 of 256 block times at 1080p)
+    const int row_first = (int)blockIdx.x, row_last = k.start_y - k.end_y, row_step = (int)gridDim.x;
     const EncK &ek = k.ek;
     {
         const uint32_t *src = (const uint32_t *)(ek.cost_all + MVCOST_HALF);
@@ -180,14 +184,17 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void
     const s16x2 sg1 = pk_sign(lane & 1), sg2 = pk_sign(lane & 2);
     const int mvr = 2 * (ek.mv_range > 0 ? ek.mv_range : 512);
 
-    for (int row = row_first; row <= row_last; row++) {
+    for (int row = row_first; row <= row_last; row += row_step) {
     const int by = k.start_y - row;
-    int right_mv[2][2] = { { 0, 0 }, { 0, 0 } };          // this row's previous block (bx + 1): never re-read from memory
+    int rmv0x = 0, rmv0y = 0, rmv1x = 0, rmv1y = 0;          // this row's previous block (bx + 1) in list 0 / 1: never re-read from memory (scalars, not an array: an array
+                                                           // indexed by the list lives in scratch memory)
     for (int bx = k.start_x; bx >= k.end_x; bx--) {
         if (by < k.start_y) {                              // the row below must have finished the block to the lower left
+            // (no acquire fence: at agent scope that is a buffer_inv of the caches per block and, on the producer's side, a write-back of the whole L2
+            //  — measured: 95 % of the wave cycles waiting whatever the occupancy.  What the row below hands over are its vectors alone: the producer
+            //  writes them with agent-scope stores and waits for them before it moves its counter, this side reads them with agent-scope loads)
             const int need = min(k.start_x - (bx - 1) + 1, row_total);
             while (wfp_load<true>(prog + by + 1) < need) __builtin_amdgcn_s_sleep(2);
-            wfp_acquire<true>();
         }
         const int bi = by * bw + bx;
         const bool score = (bx > 0 && bx < bw - 1 && by > 0 && by < bh - 1) || bw <= 2 || bh <= 2;
@@ -218,8 +225,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void
         auto fetch = [&](int ref, int qx, int qy, uint32_t p[4]) {
             p[0] = p[1] = p[2] = p[3] = 0;
             const int X0 = rl(wtg.tx, ref), Y0 = rl(wtg.ty, ref), x0 = c.px + (qx >> 2), y0 = c.py + (qy >> 2);
-            const bool inside = !ek.wp_any && rl(wtg.tref, ref) == ref && x0 >= X0 && x0 + 9 <= X0 + RC_COLS && y0 >= Y0 && y0 + 9 <= Y0 + RC_ROWS;
-            if (inside) { if (r < 8) rc_row(L.rc + ref * RC_SLOT_DW, X0, Y0, c.px, c.py + r, qx, qy, false, p); }
+            const bool inside = !ek.wp_any && rl(wtg.tref, ref) == ref && x0 >= X0 && x0 + 9 <= X0 + StLds::rcg::COLS && y0 >= Y0 && y0 + 9 <= Y0 + StLds::rcg::ROWS;
+            if (inside) { if (r < 8) rc_row<StLds::rcg>(L.rc + ref * StLds::rcg::SLOT_DW, X0, Y0, c.px, c.py + r, qx, qy, false, p); }
             else if (r < 8) mc_row_global(ref_plane00(ek, s, ref), ek.plane_bytes, rs, c.px, c.py + r, qx, qy, false, p);
         };
         int i_bcost = MB_COST_MAX, list_used = 0;
@@ -245,24 +252,35 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void
             try_bidir(d00, d01, d10, d11, 0);
             if (d00 | d01 | d10 | d11) try_bidir(0, 0, 0, 0, 0);
         }
-        int mmv[2][2] = { { 0, 0 }, { 0, 0 } };
-        for (int l = 0; l < 1 + (b_bidir ? 1 : 0); l++) {
+        int mm0x = 0, mm0y = 0, mm1x = 0, mm1y = 0;          // the lists' vectors of this block
+#pragma unroll
+        for (int l = 0; l < 2; l++) {
+            if (l && !b_bidir) break;
             int mcost;
+            int16_t *mvl_l = l ? mvl[1] : mvl[0];
+            int *mcl_l = l ? mcl[1] : mcl[0];
             if (l ? k.do_search1 : k.do_search0) {
-                // reverse-order MV prediction: right, lower, lower-left, lower-right
-                int cx[4] = { 0, 0, 0, 0 }, cy[4] = { 0, 0, 0, 0 }, n = 0;
-                if (bx < bw - 1) { cx[n] = right_mv[l][0]; cy[n] = right_mv[l][1]; n++; }
+                // reverse-order MV prediction: right, lower, lower-left, lower-right — candidate i in lane i of cxv / cyv
+                int cxv = 0, cyv = 0, n = 0;
+                auto push = [&](int x, int y) { cxv = lane == n ? x : cxv; cyv = lane == n ? y : cyv; n++; };
+                if (bx < bw - 1) push(l ? rmv1x : rmv0x, l ? rmv1y : rmv0y);
                 if (by < bh - 1) {
-                    const int16_t *lo = mvl[l] + 2 * (bi + bw);
+                    const int16_t *lo = mvl_l + 2 * (bi + bw);
                     int vx = 0, vy = 0;
-                    if (lane < 3) { const int o = lane == 0 ? 0 : lane == 1 ? -1 : 1; if ((o < 0 && bx > 0) || o == 0 || (o > 0 && bx < bw - 1)) { vx = lo[2 * o]; vy = lo[2 * o + 1]; } }
-                    cx[n] = rl(vx, 0); cy[n] = rl(vy, 0); n++;
-                    if (bx > 0) { cx[n] = rl(vx, 1); cy[n] = rl(vy, 1); n++; }
-                    if (bx < bw - 1) { cx[n] = rl(vx, 2); cy[n] = rl(vy, 2); n++; }
+                    if (lane < 3) {
+                        const int o = lane == 0 ? 0 : lane == 1 ? -1 : 1;
+                        if ((o < 0 && bx > 0) || o == 0 || (o > 0 && bx < bw - 1)) {
+                            const int w = __hip_atomic_load((const int *)(lo + 2 * o), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // (another wavefront's, of this launch)
+                            vx = (int)(int16_t)(w & 0xffff); vy = (int)(int16_t)(w >> 16);
+                        }
+                    }
+                    push(rl(vx, 0), rl(vy, 0));
+                    if (bx > 0) push(rl(vx, 1), rl(vy, 1));
+                    if (bx < bw - 1) push(rl(vx, 2), rl(vy, 2));
                 }
                 int mvpx, mvpy;
-                if (n <= 1) { mvpx = cx[0]; mvpy = cy[0]; }
-                else { mvpx = median3(cx[0], cx[1], cx[2]); mvpy = median3(cy[0], cy[1], cy[2]); }
+                if (n <= 1) { mvpx = rl(cxv, 0); mvpy = rl(cyv, 0); }
+                else { mvpx = median3(rl(cxv, 0), rl(cxv, 1), rl(cxv, 2)); mvpy = median3(rl(cyv, 0), rl(cyv, 1), rl(cyv, 2)); }
                 mvpx = uni(mvpx); mvpy = uni(mvpy);
                 bool skip = false;
                 int mx = 0, my = 0;
@@ -274,8 +292,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void
                     skip = mcost < 64;
                 }
                 if (!skip) {
-                    S.inx = lane == 0 ? cx[0] : lane == 1 ? cx[1] : lane == 2 ? cx[2] : lane == 3 ? cx[3] : 0;
-                    S.iny = lane == 0 ? cy[0] : lane == 1 ? cy[1] : lane == 2 ? cy[2] : lane == 3 ? cy[3] : 0;
+                    S.inx = cxv; S.iny = cyv;
                     MeJob jb;
                     jb.W = 8; jb.H = 8; jb.ox = 0; jb.oy = 0; jb.ref = l; jb.mvpx = mvpx; jb.mvpy = mvpy; jb.n_mvc = n; jb.search = true; jb.qonly = false;
                     jb.hp_it = 1; jb.qp_it = satd ? 1 : 0; jb.use_thresh = false;
@@ -286,15 +303,16 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void
                     mcost = cost - (int)ek.cost_all[MVCOST_HALF];         // "remove mvcost from skip mbs"
                     if (mx | my) mcost += 5 * k.lambda;
                 }
-                mmv[l][0] = mx; mmv[l][1] = my;
-                if (lane == 0) { mvl[l][2 * bi] = (int16_t)mx; mvl[l][2 * bi + 1] = (int16_t)my; mcl[l][bi] = mcost; }
+                if (l) { mm1x = mx; mm1y = my; } else { mm0x = mx; mm0y = my; }
+                if (lane == 0) { __hip_atomic_store((int *)(mvl_l + 2 * bi), (int)(((unsigned)my << 16) | ((unsigned)mx & 0xffffu)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); mcl_l[bi] = mcost; }
             } else {
-                mmv[l][0] = uni((int)mvl[l][2 * bi]); mmv[l][1] = uni((int)mvl[l][2 * bi + 1]); mcost = uni(mcl[l][bi]);
+                const int mx = uni((int)mvl_l[2 * bi]), my = uni((int)mvl_l[2 * bi + 1]); mcost = uni(mcl_l[bi]);
+                if (l) { mm1x = mx; mm1y = my; } else { mm0x = mx; mm0y = my; }
             }
-            right_mv[l][0] = mmv[l][0]; right_mv[l][1] = mmv[l][1];
+            if (l) { rmv1x = mm1x; rmv1y = mm1y; } else { rmv0x = mm0x; rmv0y = mm0y; }
             if (mcost < i_bcost) { i_bcost = mcost; list_used = l + 1; }
         }
-        if (b_bidir && (mmv[0][0] | mmv[0][1] | mmv[1][0] | mmv[1][1])) try_bidir(mmv[0][0], mmv[0][1], mmv[1][0], mmv[1][1], 5);
+        if (b_bidir && (mm0x | mm0y | mm1x | mm1y)) try_bidir(mm0x, mm0y, mm1x, mm1y, 5);
         i_bcost += 4;                                      // lowres_penalty
         if (!b_bidir) {                                    // intra blocks are not considered in B pictures
             const int icost = uni(icosts[bi]);
@@ -302,7 +320,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void
         }
         if (score) sum_inter += i_bcost;
         if (lane == 0) lrc[bi] = (uint16_t)(min(i_bcost, LOWRES_COST_MASK) + (list_used << LOWRES_COST_SHIFT));
-        wfp_release<true>();
+        __builtin_amdgcn_s_waitcnt(0x0f70);                // vmcnt(0): the vectors have arrived where the row above reads them, before the counter says so
         if (lane == 0) wfp_store<true>(prog + by, k.start_x - bx + 1);
     }
     }
@@ -619,8 +637,11 @@ int x264gpu_slicetype_frame_cost_w(x264gpu_slicetype *st, int s0, int s1, int sb
             // one wavefront a row, chained bottom-up (default), or — x264gpu_slicetype_set_row_mode(1) — one wavefront a stream walking its rows itself.
             // Measured at 2048 streams of 1080p (bench.py `lookahead`): the single wavefront is 8 % SLOWER (17.8 s vs 16.5 s for 23 costs): the rows'
             // pipeline was not what the costs wait for, the searches are; so auto = the row pipeline at every batch size
+            // auto (round 6): as many wavefronts a stream as fill the chip about four times over — 2048 streams: 6 (the diagonal of 68 wavefronts a stream
+            // spent half its time filling and draining, polling the row below from memory all the while), one stream: a wavefront a row (its latency)
             k.serial_rows = st->serial_rows < 0 ? 0 : st->serial_rows;
-            const int gx = k.serial_rows ? 1 : rows;
+            const int fill = (4 * 3072 + st->streams - 1) / st->streams;
+            const int gx = k.serial_rows ? 1 : st->serial_rows == 0 ? rows : fill < 1 ? 1 : fill < rows ? fill : rows;
             if (st->me_method == 0) hipLaunchKernelGGL(k_st_cost<0>, dim3(gx, st->streams), dim3(64), 0, s, k);
             else hipLaunchKernelGGL(k_st_cost<1>, dim3(gx, st->streams), dim3(64), 0, s, k);
         }
