@@ -39,6 +39,13 @@ int  x264gpu_stream_sync(void *stream);
  * NULL.  The host encoder's batcher downloads one round's records on one while the next round runs on the default stream. */
 int  x264gpu_stream_create(void **stream);
 int  x264gpu_stream_destroy(void *stream);
+/* Events: "everything issued on `stream` before the record is done" as something a host thread can wait for WITHOUT waiting for what was issued after it
+ * (x264gpu_stream_sync waits for the whole stream).  The batcher records one behind every round: the round's downloads wait for theirs while the next round
+ * is already queued on the same stream. */
+int  x264gpu_event_create(void **event);
+int  x264gpu_event_destroy(void *event);
+int  x264gpu_event_record(void *event, void *stream);
+int  x264gpu_event_sync(void *event);
 
 /* ------------------------------------------------------------------------------------------------
  * Tier 1 — DSP primitives in batch form (the "checkasm" surface: same device code the frame

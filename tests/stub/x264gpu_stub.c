@@ -41,6 +41,11 @@ int x264gpu_memset(void *d, int v, size_t n, void *st) { memset(d, v, n); return
 int x264gpu_stream_sync(void *st) { return X264GPU_OK; }
 int x264gpu_stream_create(void **st) { static int dummy; *st = &dummy; return X264GPU_OK; }
 int x264gpu_stream_destroy(void *st) { return st ? X264GPU_OK : fail("stream_destroy: null"); }
+/* (the stand-in runs everything at call time: an event is always reached) */
+int x264gpu_event_create(void **ev) { static int dummy; *ev = &dummy; return X264GPU_OK; }
+int x264gpu_event_destroy(void *ev) { return ev ? X264GPU_OK : fail("event_destroy: null"); }
+int x264gpu_event_record(void *ev, void *st) { return ev ? X264GPU_OK : fail("event_record: null"); }
+int x264gpu_event_sync(void *ev) { return ev ? X264GPU_OK : fail("event_sync: null"); }
 long x264gpu_stub_encode_calls(int dev) { return dev >= 0 && dev < 16 ? g_calls[dev] : -1; }
 
 struct x264gpu_encoder { x264gpu_config cfg; x264o_encoder **e; int dev, nmb; const float *off; int8_t *sqp; float *sqpm; float qpm; };

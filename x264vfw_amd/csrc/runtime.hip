@@ -62,6 +62,17 @@ int x264gpu_stream_destroy(void *stream)
     HIP_TRY(hipStreamDestroy((hipStream_t)stream));
     return X264GPU_OK;
 }
+int x264gpu_event_create(void **event)
+{
+    ARG_TRY(event);
+    hipEvent_t ev = nullptr;
+    HIP_TRY(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+    *event = (void *)ev;
+    return X264GPU_OK;
+}
+int x264gpu_event_destroy(void *event) { ARG_TRY(event); HIP_TRY(hipEventDestroy((hipEvent_t)event)); return X264GPU_OK; }
+int x264gpu_event_record(void *event, void *stream) { ARG_TRY(event); HIP_TRY(hipEventRecord((hipEvent_t)event, (hipStream_t)stream)); return X264GPU_OK; }
+int x264gpu_event_sync(void *event) { ARG_TRY(event); HIP_TRY(hipEventSynchronize((hipEvent_t)event)); return X264GPU_OK; }
 int x264gpu_memcpy_d2d(void *dst, const void *src, size_t n, void *stream)
 {
     HIP_TRY(hipMemcpyAsync(dst, src, n, hipMemcpyDeviceToDevice, (hipStream_t)stream));

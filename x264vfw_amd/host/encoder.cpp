@@ -157,6 +157,7 @@ struct x264_t {
     // cross-session batcher (X264GPU_BATCH=N): N sessions of equal geometry and toolset share ONE device encoder with N streams; the pictures
     // they submit are coded in one lock-step launch, every session entropy-codes its own stream on its caller's thread
     struct BatchGroup *batch = nullptr; int batch_idx = -1, batch_n = 0;
+    void *up_stream = nullptr;           // a batch session's own upload stream (async groups): its pictures go up while the group's round runs on the compute stream
     // batch sessions with overlap (BatchGroup::overlap): the picture just submitted is downloaded and entropy-coded by a helper thread while the group's next round runs;
     // its NAL units leave with the NEXT call (one picture of delay).  Two slots used in turn: the one being filled, the one waiting to be handed out
     struct Deferred { std::thread th; bool valid = false; std::atomic<bool> hurry{ false }; std::string err; std::vector<uint8_t> out; std::vector<size_t> off; std::vector<int> types; int nal_ref_idc = 0;
@@ -201,6 +202,9 @@ struct BatchGroup {
     // overlap: the records / levels of round k are downloaded and entropy-coded (by a helper thread of every session) WHILE round k + 1 runs: a second pair of
     // output buffers used in turn, a stream of the group's own for the downloads; every session hands its pictures back one call later
     bool overlap = false; x264gpu_mb *d_mb2 = nullptr; int16_t *d_lv2 = nullptr; void *dl_stream = nullptr;
+    // ... and (async) the callers do not wait for the round either: it is QUEUED on the group's own compute stream behind the round before, an event behind it tells the
+    // download of its results when it is done; the callers go on to copy in and upload their next pictures (on upload streams of their own) while the device works
+    bool async = false; void *cs = nullptr, *ev[2] = { nullptr, nullptr };
     long launched = 0;            // rounds whose kernels have been issued: the helper threads start entropy coding round k once round k + 1 is on the device (or when asked to hurry),
                                   // so that the host cores are the callers' while the next pictures are uploaded and submitted
     bool running = false;         // a round is being waited for with the group's lock released (overlap): nobody starts another
@@ -221,7 +225,10 @@ static void batch_destroy(BatchGroup *g)
     if (g->d_lv) x264gpu_free(g->d_lv);
     if (g->d_mb2) x264gpu_free(g->d_mb2);
     if (g->d_lv2) x264gpu_free(g->d_lv2);
+    if (g->cs) x264gpu_stream_sync(g->cs);
     if (g->dl_stream) x264gpu_stream_destroy(g->dl_stream);
+    for (int i = 0; i < 2; i++) if (g->ev[i]) x264gpu_event_destroy(g->ev[i]);
+    if (g->cs) x264gpu_stream_destroy(g->cs);
     delete g;
 }
 // -> the group and the stream index of the caller, or nullptr (setup failed: last error set)
@@ -252,6 +259,8 @@ static BatchGroup *batch_join(const x264gpu_config &cfg1, int N, size_t insz, si
         if (!(oe && oe[0] == '0') && !getenv("X264GPU_DUMP_RECORDS") &&
             x264gpu_malloc((void **)&g->d_mb2, (size_t)N * nmb * sizeof(x264gpu_mb)) == X264GPU_OK &&
             x264gpu_malloc((void **)&g->d_lv2, (size_t)N * nmb * X264GPU_MB_LEVELS * sizeof(int16_t)) == X264GPU_OK && x264gpu_stream_create(&g->dl_stream) == X264GPU_OK) g->overlap = true;
+        const char *ae = getenv("X264GPU_BATCH_ASYNC");
+        if (g->overlap && !(ae && ae[0] == '0') && x264gpu_stream_create(&g->cs) == X264GPU_OK && x264gpu_event_create(&g->ev[0]) == X264GPU_OK && x264gpu_event_create(&g->ev[1]) == X264GPU_OK) g->async = true;
     }
     g->joined = 1; g->active = 1; g->member[0] = 1; *idx = 0;
     g_batch_groups.push_back(g);
@@ -271,7 +280,12 @@ static void batch_run_round(BatchGroup *g, std::unique_lock<std::mutex> &lk)
                 memcmp(a.slot, b.slot, sizeof(a.slot)) || a.blind_dupe != b.blind_dupe) { g->round_rc = -1; g->err = "the sessions of a batch must submit pictures of the same structure (same picture count, keyint, bframes, forced types)"; }
         }
         const bool second = g->overlap && (g->round & 1);          // the output buffers of this round (the other pair may still be downloading)
-        if (!g->round_rc && x264gpu_encode_pictures(g->gpu, g->d_in, g->pics.data(), second ? g->d_mb2 : g->d_mb, second ? g->d_lv2 : g->d_lv, nullptr) != X264GPU_OK) { g->round_rc = -1; g->err = x264gpu_last_error(); }
+        if (!g->round_rc && x264gpu_encode_pictures(g->gpu, g->d_in, g->pics.data(), second ? g->d_mb2 : g->d_mb, second ? g->d_lv2 : g->d_lv, g->async ? g->cs : nullptr) != X264GPU_OK) { g->round_rc = -1; g->err = x264gpu_last_error(); }
+        if (!g->round_rc && g->async) {
+            // queued, not awaited: the event behind the round is what its downloads wait for (batch_download)
+            if (x264gpu_event_record(g->ev[second ? 1 : 0], g->cs) != X264GPU_OK) { g->round_rc = -1; g->err = x264gpu_last_error(); }
+            g->launched++;
+        } else
         // overlap: the downloads run on the group's own stream, which does not wait for the default one: the round must be complete before anyone is told
         if (!g->round_rc && g->overlap) {
             g->launched++; g->running = true;
@@ -291,7 +305,8 @@ static void batch_run_round(BatchGroup *g, std::unique_lock<std::mutex> &lk)
 // hands picture `pic` of stream s to the group and waits for the round that codes it; *buf = which pair of output buffers holds the round's results
 static int batch_submit(BatchGroup *g, int s, const uint8_t *d_src, const x264gpu_pic &pic, int *buf, std::string &err)
 {
-    if (x264gpu_memcpy_d2d(g->d_in + (size_t)s * g->insz, d_src, g->insz, nullptr) != X264GPU_OK) { err = x264gpu_last_error(); return -1; }
+    // (async: on the group's compute stream, i.e. behind the round before — which may still be reading d_in — and in front of this round's launch)
+    if (x264gpu_memcpy_d2d(g->d_in + (size_t)s * g->insz, d_src, g->insz, g->async ? g->cs : nullptr) != X264GPU_OK) { err = x264gpu_last_error(); return -1; }
     std::unique_lock<std::mutex> lk(g->m);
     // every member must have been opened before the first picture is coded: a late joiner would be a picture behind for good
     if (!g->cv.wait_for(lk, std::chrono::seconds(60), [&] { return g->joined == g->N; })) { err = "X264GPU_BATCH: fewer sessions were opened than the batch size"; return -1; }
@@ -313,6 +328,7 @@ static int batch_download(BatchGroup *g, int s, int buf, x264gpu_mb *h_mb, int16
 {
     const x264gpu_mb *dm = buf ? g->d_mb2 : g->d_mb; const int16_t *dl = buf ? g->d_lv2 : g->d_lv;
     void *st = g->overlap ? g->dl_stream : nullptr;
+    if (g->async && x264gpu_event_sync(g->ev[buf ? 1 : 0]) != X264GPU_OK) { err = x264gpu_last_error(); return -1; }
     if (x264gpu_memcpy_d2h(h_mb, dm + (size_t)s * g->nmb, g->nmb * sizeof(x264gpu_mb), st) != X264GPU_OK ||
         x264gpu_memcpy_d2h(h_lv, dl + (size_t)s * g->nmb * X264GPU_MB_LEVELS, g->nmb * X264GPU_MB_LEVELS * sizeof(int16_t), st) != X264GPU_OK) { err = x264gpu_last_error(); return -1; }
     return 0;
@@ -771,7 +787,8 @@ x264_t *x264_encoder_open(x264_param_t *param)
     } else if (ok_setup && h->batch_n) {
         h->batch = batch_join(cfg, h->batch_n, insz, (size_t)h->nmb, &h->batch_idx);
         ok_setup = h->batch != nullptr;
-        if (ok_setup) xlog(&p, X264_LOG_INFO, "X264GPU_BATCH: stream %d of a batch of %d sessions\n", h->batch_idx, h->batch_n);
+        if (ok_setup && h->batch->async && x264gpu_stream_create(&h->up_stream) != X264GPU_OK) h->up_stream = nullptr;      // (without it the uploads wait on the default stream: slower, not wrong)
+        if (ok_setup) xlog(&p, X264_LOG_INFO, "X264GPU_BATCH: stream %d of a batch of %d sessions%s\n", h->batch_idx, h->batch_n, h->batch->async ? " (rounds queued: uploads overlap the device)" : "");
     } else if (ok_setup) {
         ok_setup = x264gpu_encoder_create(&h->gpu, &cfg) == X264GPU_OK &&
                    x264gpu_malloc((void **)&h->d_mb, (size_t)h->nmb * sizeof(x264gpu_mb)) == X264GPU_OK &&
@@ -2458,8 +2475,8 @@ int x264_encoder_encode(x264_t *h, x264_nal_t **pp_nal, int *pi_nal, x264_pictur
     //      AQ offsets, slice-type decision (keyint / forced type / scenecut) — all causal, so they are taken on arrival ----
     const int slot = (int)(h->la_count % h->Q);
     uint8_t *d_raw = h->q_raw[(size_t)slot];
-    if ((!resident && x264gpu_memcpy_h2d(d_raw, h->h_in.data(), h->h_in.size(), nullptr) != X264GPU_OK) ||
-        (resident && d_raw != h->d_in && x264gpu_memcpy_d2d(d_raw, h->d_in, h->h_in.size(), nullptr) != X264GPU_OK)) {
+    if ((!resident && x264gpu_memcpy_h2d(d_raw, h->h_in.data(), h->h_in.size(), h->up_stream) != X264GPU_OK) ||
+        (resident && d_raw != h->d_in && (x264gpu_memcpy_d2d(d_raw, h->d_in, h->h_in.size(), h->up_stream) != X264GPU_OK || (h->up_stream && x264gpu_stream_sync(h->up_stream) != X264GPU_OK)))) {
         xlog(&p, X264_LOG_ERROR, "x264_encoder_encode: upload failed: %s\n", x264gpu_last_error());
         return -1;
     }
@@ -2552,6 +2569,7 @@ void x264_encoder_close(x264_t *h)
         else if (!out.empty() && rename((out + ".temp").c_str(), out.c_str())) xlog(&h->param, X264_LOG_ERROR, "failed to rename \"%s.temp\" to \"%s\"\n", out.c_str(), out.c_str());
     }
     if (h->batch) { batch_leave(h->batch, h->batch_idx); h->batch = nullptr; }
+    if (h->up_stream) { x264gpu_stream_destroy(h->up_stream); h->up_stream = nullptr; }
     if (h->gpu) x264gpu_encoder_destroy(h->gpu);
     if (h->d_in) x264gpu_free(h->d_in);
     if (h->d_mb) x264gpu_free(h->d_mb);
