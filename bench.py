@@ -547,11 +547,44 @@ def e2e_probe(args):
                                "fps_coding_span": round(ns * n / steady, 2)}
         return round(ns * n / dt, 2), round(sum(res) / (ns * n) / 1e3, 1)
 
+    def run_sessions_native(ns, n, src):
+        """the same leg with a C++ caller (tools/multi_session.cpp, built on demand with g++): 2048 Python threads spend seconds a round handing the interpreter lock to each
+        other between the calls — the harness's time, not the library's.  None when the driver cannot be built (the Python leg then stands)."""
+        exe = os.path.join(ROOT, "tools", "_build", "multi_session")
+        try:
+            os.makedirs(os.path.dirname(exe), exist_ok=True)
+            srcf = os.path.join(ROOT, "tools", "multi_session.cpp")
+            if not os.path.exists(exe) or os.path.getmtime(exe) < os.path.getmtime(srcf):
+                subprocess.run(["g++", "-O2", "-std=c++17", "-pthread", "-I" + os.path.join(ROOT, "include"), "-o", exe, srcf, "-L" + os.path.join(ROOT, "x264vfw_amd"), "-lx264gpu_host",
+                                "-Wl,-rpath,$ORIGIN/../../x264vfw_amd"], check=True, capture_output=True, timeout=120)
+            raw = "/dev/shm/bench_multi_session_%d.yuv" % os.getpid()
+            with open(raw, "wb") as f:
+                for fr in src:
+                    f.write(np.ascontiguousarray(fr).tobytes())
+            try:
+                env = {k: v for k, v in os.environ.items() if k not in ("X264GPU_LIB", "X264GPU_HOST_LIB")}
+                out = subprocess.run([exe, raw, str(w), str(h), str(len(src)), str(ns), str(n), str(args.qp)], capture_output=True, timeout=1800, env=env)
+            finally:
+                os.remove(raw)
+            if out.returncode != 0:
+                return None
+            return json.loads(out.stdout.decode().strip().splitlines()[-1])
+        except Exception:
+            return None
+
     n1 = args.e2e_frames
     delays = []
     src = synth_frames(w, h, max(n1, 16), seed=0x264, scene_len=97)
     f1, kb1 = run(n1, 1, 250, src)
-    fm, kbm = run_sessions(args.e2e_sessions, n1, src) if args.e2e_sessions > 1 else (None, None)
+    fm, kbm = (None, None)
+    if args.e2e_sessions > 1:
+        nat = run_sessions_native(args.e2e_sessions, n1, src)
+        if nat and "fps" in nat:
+            fm, kbm = nat["fps"], nat["kB_per_frame"]
+            run_sessions.detail = {"setup_s": nat["setup_s"], "coding_s": nat["coding_s"], "teardown_s": nat["teardown_s"], "fps_coding_span": nat["fps_coding_span"], "driver": nat["driver"]}
+        else:
+            fm, kbm = run_sessions(args.e2e_sessions, n1, src)
+            run_sessions.detail["driver"] = "python threads (the C++ driver did not build or failed)"
     if args.e2e_legs != "all":
         return {"what": "x264_encoder_encode end to end, 1920x1080 (only the threads-1 and multi-session legs were asked for)", "threads1_fps": f1, "threads1_frames": n1,
                 "multi_session_fps": fm, "multi_session_sessions": args.e2e_sessions, "multi_session_frames_each": n1, "multi_session_kB_per_frame": kbm, "multi_session_spans": getattr(run_sessions, "detail", None), "host_cores": os.cpu_count()}

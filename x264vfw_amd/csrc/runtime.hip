@@ -66,7 +66,7 @@ int x264gpu_event_create(void **event)
 {
     ARG_TRY(event);
     hipEvent_t ev = nullptr;
-    HIP_TRY(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+    HIP_TRY(hipEventCreateWithFlags(&ev, hipEventDisableTiming | hipEventBlockingSync));      // a waiting host thread sleeps (the callers need the cores)
     *event = (void *)ev;
     return X264GPU_OK;
 }

@@ -205,6 +205,7 @@ struct BatchGroup {
     // ... and (async) the callers do not wait for the round either: it is QUEUED on the group's own compute stream behind the round before, an event behind it tells the
     // download of its results when it is done; the callers go on to copy in and upload their next pictures (on upload streams of their own) while the device works
     bool async = false; void *cs = nullptr, *ev[2] = { nullptr, nullptr };
+    long ev_round[2] = { 0, 0 }, ev_done[2] = { 0, 0 }; bool ev_waiting[2] = { false, false }; std::string ev_err;      // per buffer pair: the round recorded behind it (1-based), the last one known complete, a member is waiting for the event
     long launched = 0;            // rounds whose kernels have been issued: the helper threads start entropy coding round k once round k + 1 is on the device (or when asked to hurry),
                                   // so that the host cores are the callers' while the next pictures are uploaded and submitted
     bool running = false;         // a round is being waited for with the group's lock released (overlap): nobody starts another
@@ -285,6 +286,7 @@ static void batch_run_round(BatchGroup *g, std::unique_lock<std::mutex> &lk)
             // queued, not awaited: the event behind the round is what its downloads wait for (batch_download)
             if (x264gpu_event_record(g->ev[second ? 1 : 0], g->cs) != X264GPU_OK) { g->round_rc = -1; g->err = x264gpu_last_error(); }
             g->launched++;
+            g->ev_round[second ? 1 : 0] = g->round + 1;
         } else
         // overlap: the downloads run on the group's own stream, which does not wait for the default one: the round must be complete before anyone is told
         if (!g->round_rc && g->overlap) {
@@ -328,7 +330,26 @@ static int batch_download(BatchGroup *g, int s, int buf, x264gpu_mb *h_mb, int16
 {
     const x264gpu_mb *dm = buf ? g->d_mb2 : g->d_mb; const int16_t *dl = buf ? g->d_lv2 : g->d_lv;
     void *st = g->overlap ? g->dl_stream : nullptr;
-    if (g->async && x264gpu_event_sync(g->ev[buf ? 1 : 0]) != X264GPU_OK) { err = x264gpu_last_error(); return -1; }
+    if (g->async) {
+        // ONE thread waits for the round's event, the other members sleep on the group's condition variable (2048 helper threads in hipEventSynchronize would
+        // take the host's cores from the callers that are copying in and uploading the next pictures)
+        std::unique_lock<std::mutex> lk(g->m);
+        const long want = g->ev_round[buf ? 1 : 0];          // the round recorded behind this buffer pair (it cannot be re-recorded before every member has this round's results)
+        while (g->ev_done[buf ? 1 : 0] < want) {
+            if (!g->ev_waiting[buf ? 1 : 0]) {
+                g->ev_waiting[buf ? 1 : 0] = true;
+                lk.unlock();
+                const bool ok = x264gpu_event_sync(g->ev[buf ? 1 : 0]) == X264GPU_OK;
+                const std::string e = ok ? std::string() : std::string(x264gpu_last_error());
+                lk.lock();
+                g->ev_waiting[buf ? 1 : 0] = false;
+                if (!ok) { g->ev_err = e; g->ev_done[buf ? 1 : 0] = want; g->cv.notify_all(); err = e; return -1; }
+                g->ev_done[buf ? 1 : 0] = want;
+                g->cv.notify_all();
+            } else g->cv.wait(lk);
+        }
+        if (!g->ev_err.empty()) { err = g->ev_err; return -1; }
+    }
     if (x264gpu_memcpy_d2h(h_mb, dm + (size_t)s * g->nmb, g->nmb * sizeof(x264gpu_mb), st) != X264GPU_OK ||
         x264gpu_memcpy_d2h(h_lv, dl + (size_t)s * g->nmb * X264GPU_MB_LEVELS, g->nmb * X264GPU_MB_LEVELS * sizeof(int16_t), st) != X264GPU_OK) { err = x264gpu_last_error(); return -1; }
     return 0;
