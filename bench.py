@@ -762,7 +762,7 @@ def main():
             # run's streams; valu_issue_frac = those wave-level VALU instructions / (1024 SIMDs x 2.4 GHz / 4 cycles an instruction) / THIS run's kernel time
             "traffic_from": pmc_src if traffic is not None else None, "valu_from": pmc_src if valu else None,
             "valu_issue_frac": valu["issue_util"] if valu else None,
-            "note": "I and P instantiations: two wavefronts per SIMD issue ~96 % of the time (fewer instructions per macroblock is the lever); see valu.issue_util, profiles/ and DESIGN.md 1d",
+            "note": "two wavefronts per SIMD (256 VGPRs, 20 KB of LDS each); each waits 0.42 - 0.46 of its cycles (LDS / L2 round trips of a raster-serial loop), VALU issue 0.42 - 0.48 of the SIMDs' peak: profiles/r06_pmc_per_launch.json, DESIGN.md 5",
             "avg_launch_ms": round(avg_ms, 4), "step_ms_by_picture_type": per_type, "frames_per_s_in_keyint_proportions": blended,
             "stage_ms_per_step": {names[i]: round(ms[i] / K, 4) for i in range(nst) if names[i] != "unused"}}
     mix = " + ".join(f"{tcount[t]} {t}" for t in ("I", "P", "Bref", "b") if tcount[t])
