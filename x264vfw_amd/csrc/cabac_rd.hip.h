@@ -24,6 +24,9 @@
 #undef CABAC_TABLE
 #undef CABAC_NAMESPACE
 
+#ifndef CAB_WALK_BINS
+#define CAB_WALK_BINS 8          /* bins a chain-table lookup takes (the table holds 0..8): fewer = a smaller hot part of the table */
+#endif
 namespace x264gpu {
 
 static __constant__ const uint16_t c_cabac_entropy[128] = {
@@ -278,7 +281,7 @@ __device__ __forceinline__ void cab_levels_all(Cab &cb, uint32_t model, int lane
                 int st = (int)((reg >> sh) & 255u);
                 unsigned long long B = ((unsigned long long)bhi << 32) | blo;
                 while (__ballot(N > 0)) {
-                    const int k = min(N, 8);
+                    const int k = min(N, CAB_WALK_BINS);
                     const uint32_t e = ctab[((((1 << k) - 1) + ((int)(unsigned)B & ((1 << k) - 1))) << 7) + st];
                     st = (int)(e & 127u); cb.f8v += (int)(e >> 7);
                     B >>= k; N -= k;
