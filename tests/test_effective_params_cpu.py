@@ -78,3 +78,31 @@ def test_second_pass_without_statistics_support_keeps_its_rate_control(tmp_path)
     # ... and the first pass likewise
     info = _session(tmp_path, 3, ["log=1", "bitrate=300", "pass=1", "stats=" + st, "bframes=0", "weightp=0", "keyint=8", "scenecut=0", "rc-lookahead=0", "no-mbtree"])
     assert info["rc_method"] == X264_RC_ABR and info["stat_write"] == 0, info
+
+
+def test_bench_refuses_a_library_override():
+    """VERDICT r05 #5a: the benchmark measures the product's own libraries — with X264GPU_LIB / X264GPU_HOST_LIB in the environment (the hook the stub tests and
+    tools/ use to put another library behind the ABI) bench.py exits non-zero before anything is measured."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for var in ("X264GPU_LIB", "X264GPU_HOST_LIB"):
+        env = {k: v for k, v in os.environ.items() if k not in ("X264GPU_LIB", "X264GPU_HOST_LIB")}
+        env[var] = "/nonexistent/libstandin.so"
+        r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--cpu-frames", "0", "--e2e-frames", "0"], env=env, capture_output=True, timeout=120)
+        assert r.returncode != 0 and var.encode() in r.stderr, (var, r.returncode, r.stderr[-300:])
+
+
+def test_decoder_probe_reports_what_it_finds_without_a_gpu():
+    """tools/decoder_probe.py: with no third-party decoder CLI on the box the probe says so and claims nothing (no encode, no GPU needed); the keys bench.py prints are there"""
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import decoder_probe
+    found = decoder_probe.find_decoders()
+    assert set(found) == {"cli", "libraries"}
+    res = decoder_probe.probe()
+    assert set(res) >= {"found", "decoder", "equal", "pictures", "seen_not_driven", "what"}
+    if not found["cli"]:
+        assert res["found"] is False and res["equal"] is None and res["decoder"] is None

@@ -27,6 +27,11 @@ for o in "crf=23 rc-lookahead=10 scene_len=14" "crf=22 b-adapt=2 weightp=2 fade=
          "qp=24 bframes=3 direct=auto trellis=2 subme=9 me=umh ref=3" "crf=25 bframes=0 weightp=0 rc-lookahead=4"; do
     python tests/stub/run_host_b.py "$S/o.h264" 176 144 24 3 $o >> "$S/log.txt" 2>&1 || echo "session failed: $o"
 done
+# ... and the GOP slots (--threads G) with and without B pictures over several stand-in devices, incl. the stream's last, shorter GOP
+for t in 1 3; do
+    X264GPU_STUB_DEVICES=2 python tests/stub/run_host.py 96 80 23 7 qp=27 keyint=8 min-keyint=8 scenecut=0 ref=2 bframes=3 b-adapt=0 weightp=2 threads=$t >> "$S/log.txt" 2>&1 || echo "GOP-slot session failed: threads=$t"
+    X264GPU_STUB_DEVICES=2 python tests/stub/run_host.py 96 80 14 7 qp=27 keyint=4 min-keyint=4 scenecut=0 ref=2 bframes=0 weightp=0 threads=$t >> "$S/log.txt" 2>&1 || echo "GOP-slot session failed: threads=$t (I / P)"
+done
 tail -3 "$S/log.txt" | head -1
 echo "findings:"
 grep -h "runtime error\|ERROR: AddressSanitizer" "$S/log.txt" | sed 's/.*\/repo\///' | sort | uniq -c | sort -rn || true

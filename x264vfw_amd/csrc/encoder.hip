@@ -181,6 +181,10 @@ int x264gpu_encoder_create(x264gpu_encoder **out, const x264gpu_config *cfg)
     if (er != hipSuccess) { x264gpu_encoder_destroy(e); return set_err(er == hipErrorOutOfMemory ? X264GPU_ENOMEM : X264GPU_EHIP, "encoder buffers", er); }
     const int rc = build_aq_tables(e);       // the macroblock loop reads every quantiser-dependent value per macroblock
     if (rc) { x264gpu_encoder_destroy(e); return rc; }
+    // the device tables the macroblock loop reads (the chain table of the CABAC size pricing, the trellis quantiser's): built here, once per device, so that the
+    // encode path allocates and uploads nothing (no host synchronisation in it; they live as long as the library is loaded: one set per device, shared by every encoder)
+    if (cfg->rd && cfg->cabac) { const uint32_t *ct; const int r2 = cabac_chain_table(&ct); if (r2 != X264GPU_OK) { x264gpu_encoder_destroy(e); return r2; } }
+    if (cfg->trellis) { const uint16_t *a; const uint8_t *b; const int *c; const int r2 = trellis_table_ptrs(&a, &b, &c); if (r2 != X264GPU_OK) { x264gpu_encoder_destroy(e); return r2; } }
     *out = e;
     return X264GPU_OK;
 }
