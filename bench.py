@@ -440,7 +440,10 @@ def e2e_probe(args):
     w, h = args.width, args.height
     planes = [(w * h, 0), (w * h // 4, w * h), (w * h // 4, w * h * 5 // 4)]
 
-    def run(n, threads, keyint, src, sliced=False, gop_slots=0, slices=0):
+    def run(n, threads, keyint, src, sliced=False, gop_slots=0, slices=0, inflight=None):
+        os.environ.pop("X264GPU_INFLIGHT", None)
+        if inflight is not None:
+            os.environ["X264GPU_INFLIGHT"] = str(inflight)          # pictures of the session in flight (read at x264_encoder_open; 0: one picture a call)
         p = HL.Param()
         assert H.x264_param_default_preset(C.byref(p), b"medium", None) == 0
         p.i_width, p.i_height, p.i_csp = w, h, HL.X264_CSP_I420
@@ -575,7 +578,16 @@ def e2e_probe(args):
     n1 = args.e2e_frames
     delays = []
     src = synth_frames(w, h, max(n1, 16), seed=0x264, scene_len=97)
-    f1, kb1 = run(n1, 1, 250, src)
+    # one session, threads 1: the library's default keeps up to four pictures of the session in flight (launch contexts over the shared DPB; the stream is the serial
+    # one byte for byte: tests/test_gpu_host.py::test_pictures_in_flight_equal_serial); the same session one picture a call beside it
+    nf1 = max(n1, 24)
+    f1, kb1 = run(nf1, 1, 250, src)
+    d_f1 = delays[-1]
+    f1s, kb1s = run(n1, 1, 250, src, inflight=0)
+    d_f1s = delays[-1]
+    os.environ.pop("X264GPU_INFLIGHT", None)
+    one = {"threads1_fps": f1, "threads1_frames": nf1, "threads1_kB_per_frame": kb1, "threads1_pictures_in_flight": 4, "threads1_delay_frames": d_f1,
+           "threads1_serial_fps": f1s, "threads1_serial_frames": n1, "threads1_serial_delay_frames": d_f1s}
     fm, kbm = (None, None)
     if args.e2e_sessions > 1:
         nat = run_sessions_native(args.e2e_sessions, n1, src)
@@ -586,7 +598,7 @@ def e2e_probe(args):
             fm, kbm = run_sessions(args.e2e_sessions, n1, src)
             run_sessions.detail["driver"] = "python threads (the C++ driver did not build or failed)"
     if args.e2e_legs != "all":
-        return {"what": "x264_encoder_encode end to end, 1920x1080 (only the threads-1 and multi-session legs were asked for)", "threads1_fps": f1, "threads1_frames": n1,
+        return {"what": "x264_encoder_encode end to end, 1920x1080 (only the threads-1 and multi-session legs were asked for)", **one,
                 "multi_session_fps": fm, "multi_session_sessions": args.e2e_sessions, "multi_session_frames_each": n1, "multi_session_kB_per_frame": kbm, "multi_session_spans": getattr(run_sessions, "detail", None), "host_cores": os.cpu_count()}
     # --threads G: 32 closed GOPs of the one stream in lock-step, medium's B pictures in every GOP (bframes 3, b-pyramid, weightb; b-adapt 0 and no scene cuts:
     # a fixed structure).  keyint 12 keeps the leg within the bench's minutes (a slot is one wavefront: ~0.5 pictures/s; keyint 250 x 32 slots would be 8000 pictures)
@@ -603,7 +615,7 @@ def e2e_probe(args):
     frg, _ = run(G * K * 2, G, K, src, slices=nr)
     os.environ.pop("X264GPU_GOP_SLOTS", None)
     return {"what": "ONE 1920x1080 stream through x264_encoder_encode (host pictures in, Annex-B out: PCIe + host entropy coding included), CQP, preset medium as implemented (the threads-1 and slice legs with B pictures, b-adapt 1 and scene cuts: delays as measured; the --threads G legs with B pictures too: closed GOPs in lock-step on the DPB model, b-adapt 0, no scene cuts)",
-            "threads1_fps": f1, "threads1_frames": n1, "threads1_kB_per_frame": kb1,
+            **one,
             "multi_session_fps": fm, "multi_session_sessions": args.e2e_sessions, "multi_session_frames_each": n1, "multi_session_kB_per_frame": kbm, "multi_session_spans": getattr(run_sessions, "detail", None),
             "multi_session_what": "that many x264_encoder_open sessions on as many host threads through the cross-session batcher (X264GPU_BATCH): one lock-step device launch per picture, host pictures in, every thread entropy-codes its own stream; session setup and teardown inside the timed span",
             "sliced_threads_fps": fs, "sliced_threads_slices": ns, "sliced_threads_delay_frames": d_sliced, "sliced_threads_kB_per_frame": kbs,

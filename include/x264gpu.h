@@ -46,6 +46,7 @@ int  x264gpu_event_create(void **event);
 int  x264gpu_event_destroy(void *event);
 int  x264gpu_event_record(void *event, void *stream);
 int  x264gpu_event_sync(void *event);
+int  x264gpu_stream_wait_event(void *stream, void *event);   /* what is issued on `stream` after this call runs after the event (device side: the host does not wait) */
 
 /* ------------------------------------------------------------------------------------------------
  * Tier 1 — DSP primitives in batch form (the "checkasm" surface: same device code the frame
@@ -290,6 +291,12 @@ typedef struct x264gpu_pic {
  * spatial [1] direct prediction (x264 h->stat.frame.i_direct_score) */
 int  x264gpu_encoder_direct_scores(x264gpu_encoder *enc, int *h_scores);
 int  x264gpu_encoder_create(x264gpu_encoder **enc, const x264gpu_config *cfg);
+/* A second LAUNCH CONTEXT over `parent`'s DPB (x264gpu_encode_pictures sessions): the picture slots and their side data are the parent's, the per-launch scratch
+ * the view's own.  Pictures of one session that share only finished references — the b pictures of a mini-GOP, the next P picture, the B reference between two
+ * finished P pictures: x264's frame threads code them side by side too — can be issued through different contexts on different streams and run together; the
+ * CALLER orders them: a picture is issued after the events of the pictures it references (x264gpu_stream_wait_event) and into a slot no picture in flight reads
+ * or writes.  The results are what the same calls one after the other through `parent` give.  Destroy views before the parent. */
+int  x264gpu_encoder_create_view(x264gpu_encoder **enc, x264gpu_encoder *parent);
 void x264gpu_encoder_destroy(x264gpu_encoder *enc);
 /* sizes of the per-frame outputs for ONE stream */
 int  x264gpu_encoder_mb_count(const x264gpu_encoder *enc);

@@ -22,7 +22,7 @@ def encode(w, h, n, seed, opts, preset=b"medium"):
     p = HL.Param()
     assert H.x264_param_default_preset(C.byref(p), preset, None) == 0
     p.i_width, p.i_height, p.i_csp = w, h, HL.X264_CSP_I420
-    p.i_fps_num, p.i_fps_den, p.i_log_level = 25, 1, -1
+    p.i_fps_num, p.i_fps_den, p.i_log_level = 25, 1, int(os.environ.get("X264_HOST_LOG", "-1"))
     for k, v in opts.items():
         assert H.x264_param_parse(C.byref(p), k.encode(), None if v is None else str(v).encode()) == 0, (k, v)
     p.b_annexb, p.b_repeat_headers = 1, 1
@@ -55,7 +55,8 @@ def encode(w, h, n, seed, opts, preset=b"medium"):
     stub = C.CDLL(os.path.join(HERE, "_build", "libx264gpu.so"))
     stub.x264gpu_stub_encode_calls.restype = C.c_long
     calls = [stub.x264gpu_stub_encode_calls(d) for d in range(int(os.environ.get("X264GPU_STUB_DEVICES", "2")))]
-    return {"sha": hashlib.sha256(stream).hexdigest(), "bytes": len(stream), "frames": len(sizes), "calls": calls,
+    stub.x264gpu_stub_views.restype = C.c_long
+    return {"sha": hashlib.sha256(stream).hexdigest(), "bytes": len(stream), "frames": len(sizes), "calls": calls, "views": stub.x264gpu_stub_views(),
             "meta": hashlib.sha256(json.dumps(meta).encode()).hexdigest(), "pts": [m[2] for m in meta], "dts": [m[3] for m in meta]}, stream
 
 

@@ -46,9 +46,11 @@ int x264gpu_event_create(void **ev) { static int dummy; *ev = &dummy; return X26
 int x264gpu_event_destroy(void *ev) { return ev ? X264GPU_OK : fail("event_destroy: null"); }
 int x264gpu_event_record(void *ev, void *st) { return ev ? X264GPU_OK : fail("event_record: null"); }
 int x264gpu_event_sync(void *ev) { return ev ? X264GPU_OK : fail("event_sync: null"); }
+static long g_views;
+long x264gpu_stub_views(void) { return g_views; }          /* launch contexts created over a parent's DPB */
 long x264gpu_stub_encode_calls(int dev) { return dev >= 0 && dev < 16 ? g_calls[dev] : -1; }
 
-struct x264gpu_encoder { x264gpu_config cfg; x264o_encoder **e; int dev, nmb; const float *off; int8_t *sqp; float *sqpm; float qpm; };
+struct x264gpu_encoder { x264gpu_config cfg; x264o_encoder **e; int dev, nmb; const float *off; int8_t *sqp; float *sqpm; float qpm; struct x264gpu_encoder *view_of; };
 
 int x264gpu_encoder_create(x264gpu_encoder **out, const x264gpu_config *cfg)
 {
@@ -66,11 +68,23 @@ int x264gpu_encoder_create(x264gpu_encoder **out, const x264gpu_config *cfg)
     *out = g;
     return X264GPU_OK;
 }
+/* a view (a second launch context over the parent's DPB): the stand-in runs every call at call time, so the parent's checker encoders serve it — only the per-launch
+ * settings (quantiser offsets, per-stream quantisers) are its own */
+int x264gpu_encoder_create_view(x264gpu_encoder **out, x264gpu_encoder *parent)
+{
+    if (!out || !parent || parent->view_of || parent->cfg.dpb <= 0) return fail("encoder_create_view arguments");
+    x264gpu_encoder *g = calloc(1, sizeof(*g));
+    g->cfg = parent->cfg; g->dev = parent->dev; g->e = parent->e; g->nmb = parent->nmb; g->view_of = parent;
+    g_views++;
+    *out = g;
+    return X264GPU_OK;
+}
+int x264gpu_stream_wait_event(void *st, void *ev) { return ev ? X264GPU_OK : fail("stream_wait_event: null"); }
 void x264gpu_encoder_destroy(x264gpu_encoder *g)
 {
     if (!g) return;
-    for (int s = 0; s < g->cfg.streams; s++) x264o_encoder_destroy(g->e[s]);
-    free(g->e); free(g->sqp); free(g->sqpm); free(g);
+    if (!g->view_of) { for (int s = 0; s < g->cfg.streams; s++) x264o_encoder_destroy(g->e[s]); free(g->e); }
+    free(g->sqp); free(g->sqpm); free(g);
 }
 int x264gpu_encoder_mb_count(const x264gpu_encoder *g) { return g ? g->nmb : 0; }
 int x264gpu_encoder_set_qp(x264gpu_encoder *g, int qp_i, int qp_p) { g->cfg.qp_i = qp_i; g->cfg.qp_p = qp_p; return X264GPU_OK; }

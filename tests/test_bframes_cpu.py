@@ -128,7 +128,7 @@ def test_schedule_is_x264s_coding_order():
     assert bgop.schedule("IBBPBP") == [(0, 0), (3, 2), (1, 3), (2, 4), (5, 2), (4, 4)]
 
 
-def _host_b_session(tmp_path, n, opts, w=176, h=144, seed=3):
+def _host_b_session(tmp_path, n, opts, w=176, h=144, seed=3, inflight=None):
     """x264_encoder_encode() of the product's host library over the stand-in device (tests/stub: the oracle behind the B3 ABI), in a child process"""
     import json
     import os
@@ -136,7 +136,10 @@ def _host_b_session(tmp_path, n, opts, w=176, h=144, seed=3):
     import sys
     out = str(tmp_path / "b.h264")
     here = os.path.dirname(os.path.abspath(__file__))
-    r = subprocess.run([sys.executable, os.path.join(here, "stub", "run_host_b.py"), out, str(w), str(h), str(n), str(seed)] + opts, capture_output=True, text=True, timeout=600)
+    env = dict(os.environ)
+    env.pop("X264GPU_INFLIGHT", None)
+    if inflight is not None: env["X264GPU_INFLIGHT"] = str(inflight)          # pictures of the session in flight (0: one picture a call, x264's delay without frame threads)
+    r = subprocess.run([sys.executable, os.path.join(here, "stub", "run_host_b.py"), out, str(w), str(h), str(n), str(seed)] + opts, capture_output=True, text=True, timeout=600, env=env)
     assert r.returncode == 0, r.stderr[-2000:]
     return json.loads(r.stdout.strip().splitlines()[-1]), open(out, "rb").read()
 
@@ -271,9 +274,12 @@ def test_host_session_b_adapt_2_is_the_cheapest_path(tmp_path, seed, extra):
     code the window in runs of at most --bframes B pictures — checked against an exhaustive enumeration of every such path on the same frame
     costs (oracle/slicetype.c) for the first decision of the session; the stream decodes"""
     n, w, h = 16, 128, 96
-    info, stream = _host_b_session(tmp_path, n, ["qp=26", "keyint=250", "scenecut=0", "b-adapt=2", "no-weightb", "weightp=0"] + extra, w, h, seed=seed)
+    info, stream = _host_b_session(tmp_path, n, ["qp=26", "keyint=250", "scenecut=0", "b-adapt=2", "no-weightb", "weightp=0"] + extra, w, h, seed=seed, inflight=0)
     assert (info["bframes"], info["badapt"]) == (3, 2)
     assert info["first_output_after"] == 13                              # x264 h->frames.i_delay = max(bframes, 3) * 4 pictures ahead
+    # ... + up to i_thread_frames - 1 with pictures in flight (x264 encoder.c: i_delay counts the frame threads; here: until four pictures are out); the stream is the same
+    info4, stream4 = _host_b_session(tmp_path, n, ["qp=26", "keyint=250", "scenecut=0", "b-adapt=2", "no-weightb", "weightp=0"] + extra, w, h, seed=seed)
+    assert 13 < info4["first_output_after"] <= 13 + 3 and stream4 == stream and info4["recs"] == info["recs"]
     t = _types_by_display(info["recs"]).replace("R", "B")
     assert "BBBB" not in t and t[-1] == "P"
     assert len(O.h264_decode(stream, n, w, h)) == n
@@ -339,9 +345,11 @@ def test_host_session_mbtree_through_b_pictures(tmp_path):
     picture leaves after rc-lookahead + 1 pictures have arrived, the tree (x264 macroblock_tree over the decided types, through B pictures and
     B-references) moves the quantisers of the P / I / B-reference pictures, and the stream decodes"""
     n, w, h = 26, 176, 144
-    info, stream = _host_b_session(tmp_path, n, ["crf=24", "keyint=60", "rc-lookahead=10"], w, h, seed=4)
+    info, stream = _host_b_session(tmp_path, n, ["crf=24", "keyint=60", "rc-lookahead=10"], w, h, seed=4, inflight=0)
     assert (info["mbtree"], info["badapt"], info["bframes"]) == (1, 1, 3)
     assert info["first_output_after"] == 11
+    info4, stream4 = _host_b_session(tmp_path, n, ["crf=24", "keyint=60", "rc-lookahead=10"], w, h, seed=4)          # four pictures in flight: three more calls of delay
+    assert 11 < info4["first_output_after"] <= 11 + 3 and stream4 == stream and info4["recs"] == info["recs"]
     dec = O.h264_decode(stream, n, w, h)
     frames = synth_frames(w, h, n, seed=4)
     from synth import psnr

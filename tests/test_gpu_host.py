@@ -1141,3 +1141,62 @@ def test_gop_slots_with_b_pictures_equal_serial(gpu, w, h, nfr, keyint, threads,
     assert par == serial
     dec = O.h264_decode(par, nfr, w, h)
     assert len(dec) == nfr
+
+
+@pytest.mark.parametrize("w,h,nfr,opts", [
+    (352, 288, 26, {"qp": 26, "keyint": 12, "no-scenecut": None, "b-adapt": 0}),                                          # medium as it is: P, Bref, b, b of a mini-GOP + the next P in flight
+    (176, 144, 31, {"crf": 23, "rc-lookahead": 10}),                                                                  # the driver's default rate control: tree offsets per picture, read while later decisions run
+    (176, 144, 22, {"qp": 25, "bframes": 2, "b-pyramid": "none", "ref": 3, "direct": "temporal", "b-adapt": 0}),      # temporal direct: the co-located picture's vectors come from a picture in flight
+    (128, 96, 25, {"crf": 24, "b-adapt": 2, "weightp": 2, "rc-lookahead": 6, "slices": 2, "keyint": 9, "min-keyint": 3}),
+    (64, 48, 3, {"qp": 27}),                                                                                          # fewer pictures than launch contexts
+])
+def test_pictures_in_flight_equal_serial(gpu, w, h, nfr, opts):
+    """Several pictures of ONE session in flight: launch contexts over the shared DPB on streams of their own, each picture behind the events
+    of the pictures it references.  The stream, the picture types, pts / dts and nal_ref_idc equal those of the session that codes one picture a call (X264GPU_INFLIGHT=0),
+    and the reconstruction of the last picture handed back is the decoder's.  (CPU twin on the stub: tests/test_shard_cpu.py::test_pictures_in_flight_equal_the_serial_stream.)"""
+    frames = synth_frames(w, h, nfr, seed=3 * w + nfr)
+
+    def run(inflight):
+        old = os.environ.get("X264GPU_INFLIGHT")
+        os.environ["X264GPU_INFLIGHT"] = str(inflight)
+        try:
+            h_, eff = open_encoder(w, h, dict(opts, threads=1), b"high")
+        finally:
+            if old is None: os.environ.pop("X264GPU_INFLIGHT", None)
+            else: os.environ["X264GPU_INFLIGHT"] = old
+        pic, out = HL.Picture(), HL.Picture()
+        assert H.x264_picture_alloc(C.byref(pic), HL.X264_CSP_I420, w, h) == 0
+        nal, n = C.POINTER(HL.Nal)(), C.c_int()
+        stream, meta, first = b"", [], None
+
+        def take(size, i):
+            nonlocal stream, first
+            if size > 0:
+                if first is None: first = i
+                stream += C.string_at(nal[0].p_payload, size)
+                meta.append((int(out.i_type), int(out.b_keyframe), int(out.i_pts), int(out.i_dts), [(int(nal[k].i_type), int(nal[k].i_ref_idc)) for k in range(n.value)]))
+        for i, f in enumerate(frames):
+            C.memmove(pic.img.plane[0], f.ctypes.data, f.size)
+            pic.i_pts = i
+            size = H.x264_encoder_encode(h_, C.byref(nal), C.byref(n), C.byref(pic), C.byref(out))
+            assert size >= 0
+            take(size, i)
+        while H.x264_encoder_delayed_frames(h_):
+            size = H.x264_encoder_encode(h_, C.byref(nal), C.byref(n), None, C.byref(out))
+            assert size > 0
+            take(size, nfr)
+        rec = np.zeros(w * h * 3 // 2, np.uint8)
+        assert H.x264host_get_recon(h_, rec.ctypes.data) == 0
+        H.x264_encoder_close(h_)
+        H.x264_picture_clean(C.byref(pic))
+        return stream, meta, first, rec
+
+    serial, m1, first1, rec1 = run(0)
+    for k in (4, 2):
+        par, mk, firstk, reck = run(k)
+        assert len(m1) == len(mk) == nfr
+        assert mk == m1 and par == serial, "pictures in flight (%d): the stream differs from the serial one" % k
+        assert first1 <= firstk <= first1 + k - 1 or firstk == nfr          # at most k - 1 more calls of delay
+        assert np.array_equal(reck, rec1)
+    dec = O.h264_decode(serial, nfr, w, h)
+    assert len(dec) == nfr and np.array_equal(dec[-1], rec1)                # (the last picture in coding order is the one handed back last)

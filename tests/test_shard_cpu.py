@@ -17,9 +17,11 @@ RUN = os.path.join(HERE, "stub", "run_host.py")
 subprocess.check_call(["make", "-s", "-C", os.path.join(HERE, "stub")])    # once, here: the child processes only load what it built
 
 
-def run_host(w, h, n, seed, opts, devices):
+def run_host(w, h, n, seed, opts, devices, inflight=None):
     env = dict(os.environ, X264GPU_STUB_DEVICES=str(devices))
     env.pop("X264GPU_DEVICES", None)
+    env.pop("X264GPU_INFLIGHT", None)
+    if inflight is not None: env["X264GPU_INFLIGHT"] = str(inflight)
     args = [sys.executable, RUN, str(w), str(h), str(n), str(seed)] + [k if v is None else f"{k}={v}" for k, v in opts.items()]
     out = subprocess.run(args, env=env, capture_output=True, timeout=600)
     assert out.returncode == 0, out.stderr.decode()[-2000:]
@@ -60,6 +62,29 @@ def test_gop_slots_with_b_pictures_equal_the_serial_stream(devices, threads, n, 
     assert par["sha"] == serial["sha"], "GOP slots with B pictures: the stream differs from the serial one"
     assert par["meta"] == serial["meta"], (par["pts"], serial["pts"], par["dts"], serial["dts"])
     assert sum(1 for c in par["calls"] if c > 0) == min(devices, threads, -(-n // keyint))
+
+
+@pytest.mark.parametrize("n,opts", [
+    (23, {"qp": 27, "keyint": 12, "scenecut": 0, "ref": 2, "bframes": 3, "b-adapt": 0, "weightp": 2}),                 # medium's mini-GOP: P, Bref, b, b in flight together
+    (23, {"crf": 23, "rc-lookahead": 10, "bframes": 3, "b-adapt": 1}),                                                  # the tree's offsets and CRF quantisers, decided ahead of the coding
+    (19, {"qp": 25, "bframes": 2, "b-pyramid": "none", "ref": 3}),                                                     # no B reference: both b pictures behind the P picture only
+    (23, {"crf": 22, "b-adapt": 2, "weightp": 2, "rc-lookahead": 6, "bframes": 3, "direct": "temporal"}),               # temporal direct reads the co-located picture's side data: an event away
+    (3, {"qp": 27, "bframes": 3}),                                                                                     # fewer pictures than contexts: everything at the flush
+    (17, {"qp": 26, "bframes": 1, "ref": 1, "keyint": 5, "min-keyint": 5, "scenecut": 0}),                              # IDR pictures empty the DPB while pictures are in flight
+    (21, {"crf": 24, "bframes": 3, "ref": 4, "aud": None, "slices": 2, "aq-mode": 2, "no-mbtree": None}),
+])
+@pytest.mark.parametrize("inflight", [2, 4])
+def test_pictures_in_flight_equal_the_serial_stream(n, opts, inflight):
+    """Several pictures of ONE session in flight (x264_t::Inflight: launch contexts over the shared DPB, a picture behind the events of its references): bytes, picture types,
+    pts / dts and nal_ref_idc are those of the session that codes one picture a call (X264GPU_INFLIGHT=0) — what the reference's frame threads promise
+    ([x264-upstream] encoder/encoder.c x264_encoder_encode: i_thread_frames pictures in flight, the stream does not depend on the thread count beyond the lookahead's)."""
+    w, h = 96, 80
+    serial = run_host(w, h, n, 5, dict(opts, threads=1), 1, inflight=0)
+    fl = run_host(w, h, n, 5, dict(opts, threads=1), 1, inflight=inflight)
+    assert serial["views"] == 0 and fl["views"] == inflight - 1, (serial["views"], fl["views"])      # the launch contexts exist: the path under test ran
+    assert fl["frames"] == serial["frames"] == n
+    assert fl["sha"] == serial["sha"], "pictures in flight: the stream differs from the serial one"
+    assert fl["meta"] == serial["meta"], (fl["pts"], serial["pts"], fl["dts"], serial["dts"])
 
 
 def test_device_cap_env_and_crf_across_devices():

@@ -10,6 +10,7 @@ rm -rf "$S" && mkdir -p "$S/repo/x264vfw_amd"
 cp -r "$ROOT/oracle" "$ROOT/tests" "$ROOT/include" "$ROOT/tools" "$S/repo/"
 cp -r "$ROOT/x264vfw_amd/host" "$ROOT"/x264vfw_amd/*.py "$S/repo/x264vfw_amd/"
 for f in "$ROOT"/x264vfw_amd/*.so; do [ -e "$f" ] && cp "$f" "$S/repo/x264vfw_amd/"; done      # (git-ignored: absent on a clean CPU-only checkout; the stub build makes its own)
+mkdir -p "$S/repo/x264vfw_amd/csrc" && cp "$ROOT"/x264vfw_amd/csrc/*.inc "$S/repo/x264vfw_amd/csrc/"      # (generated tables a CPU test regenerates and compares)
 cd "$S/repo"
 rm -f oracle/*.o oracle/liboracle.so x264vfw_amd/host/*.o; rm -rf tests/stub/_build; mkdir -p tests/stub/_build
 SAN="-fsanitize=address,undefined -fno-omit-frame-pointer"
@@ -32,6 +33,8 @@ for t in 1 3; do
     X264GPU_STUB_DEVICES=2 python tests/stub/run_host.py 96 80 23 7 qp=27 keyint=8 min-keyint=8 scenecut=0 ref=2 bframes=3 b-adapt=0 weightp=2 threads=$t >> "$S/log.txt" 2>&1 || echo "GOP-slot session failed: threads=$t"
     X264GPU_STUB_DEVICES=2 python tests/stub/run_host.py 96 80 14 7 qp=27 keyint=4 min-keyint=4 scenecut=0 ref=2 bframes=0 weightp=0 threads=$t >> "$S/log.txt" 2>&1 || echo "GOP-slot session failed: threads=$t (I / P)"
 done
-tail -3 "$S/log.txt" | head -1
+# ... and a session that codes one picture a call beside the default (pictures in flight over launch contexts: the sessions above)
+X264GPU_INFLIGHT=0 python tests/stub/run_host_b.py "$S/o.h264" 176 144 24 3 crf=23 rc-lookahead=10 scene_len=14 >> "$S/log.txt" 2>&1 || echo "session failed: one picture a call"
+grep -h "passed\|failed" "$S/log.txt" | tail -1
 echo "findings:"
 grep -h "runtime error\|ERROR: AddressSanitizer" "$S/log.txt" | sed 's/.*\/repo\///' | sort | uniq -c | sort -rn || true

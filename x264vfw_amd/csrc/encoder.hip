@@ -43,11 +43,15 @@ struct x264gpu_encoder {
     uint8_t *mbtype[8] = {};                     // per slot: macroblock types (x264 frame->mb_type)
     int8_t *colref[8] = {}; int16_t *colmv[8] = {};      // per slot (sessions with B pictures): what spatial direct prediction reads of a co-located picture
     int8_t *colref0[8] = {};                             // ... and temporal direct prediction: the blocks' own list-0 indices; the POCs behind each slot's list 0
-    int slot_l0poc[8][8] = {};
+    // what the host knows about the pictures in the slots (set when a picture is issued): one block, so that the launch contexts of a session (views, below) share it
+    struct DpbMeta { int slot_l0poc[8][8] = {}; int slot_nref[8] = {}, slot_poc[8] = {}, slot_ref0poc[8] = {}; } meta_own, *meta = &meta_own;
+    // a VIEW (x264gpu_encoder_create_view): a second launch context over the parent's DPB — picture slots and their side data are the parent's (not freed here), the
+    // per-launch scratch (source planes, per-reference vector arrays, |mvd| / total_coeff, quantiser tables) its own: pictures of one session that share only FINISHED
+    // references can then be in flight together on different streams
+    x264gpu_encoder *view_of = nullptr;
     hipStream_t last_stream = nullptr;               // the stream of the last encode_core call (what a read-back of its results waits for)
     uint8_t *direct_flags = nullptr, *direct_flags_base = nullptr; int direct_flags_sel = 0; int *dscore = nullptr; bool use_direct_flags = false;      // --direct temporal / auto: per-stream modes of the B picture, the probe counts
     int16_t *mvr[8] = {};                        // per combined reference index >= 1: 16x16 search results of the picture being coded
-    int slot_nref[8] = {}, slot_poc[8] = {}, slot_ref0poc[8] = {};
     int poc = 0, ring = 2;                       // the sliding window: next POC, slots in rotation (refs + 1)
     const int16_t *lowres_mv = nullptr, *lowres_mv1 = nullptr;
     int cur = 0, last = 0;                       // next slot of the sliding window; slot of the picture coded last
@@ -110,7 +114,7 @@ static int build_aq_tables(x264gpu_encoder *e)
 
 extern "C" {
 
-int x264gpu_encoder_create(x264gpu_encoder **out, const x264gpu_config *cfg)
+static int encoder_create_impl(x264gpu_encoder **out, const x264gpu_config *cfg, x264gpu_encoder *parent)
 {
     ARG_TRY(out && cfg);
     ARG_TRY(cfg->width >= 16 && cfg->height >= 16 && !(cfg->width & 1) && !(cfg->height & 1) && cfg->streams >= 1);
@@ -160,6 +164,11 @@ int x264gpu_encoder_create(x264gpu_encoder **out, const x264gpu_config *cfg)
     alloc((void **)&e->fenc_y, S * k.fency_bytes, 0);
     alloc((void **)&e->fenc_uv, S * k.fencuv_bytes, 0);
     e->slots = (cfg->dpb > 0 ? cfg->dpb : cfg->refs) + 1; e->ring = cfg->refs + 1;
+    if (parent) {
+        e->view_of = parent; e->meta = &parent->meta_own;
+        for (int i = 0; i < 8; i++) { e->luma[i] = parent->luma[i]; e->chroma[i] = parent->chroma[i]; e->mv16[i] = parent->mv16[i]; e->mbtype[i] = parent->mbtype[i];
+                                      e->colref[i] = parent->colref[i]; e->colmv[i] = parent->colmv[i]; e->colref0[i] = parent->colref0[i]; }
+    } else {
     for (int i = 0; i < e->slots; i++) {
         alloc((void **)&e->luma[i], S * k.luma_bytes, 0);
         alloc((void **)&e->chroma[i], S * k.cplane_bytes, 0);
@@ -168,6 +177,7 @@ int x264gpu_encoder_create(x264gpu_encoder **out, const x264gpu_config *cfg)
         alloc((void **)&e->mv16[i], S * k.nmb * 2 * sizeof(int16_t), 0);
         alloc((void **)&e->mbtype[i], S * k.nmb, 0);
         if (cfg->dpb > 0) { alloc((void **)&e->colref[i], S * k.nmb * 4, 0); alloc((void **)&e->colmv[i], S * k.nmb * 8 * sizeof(int16_t), 0); alloc((void **)&e->colref0[i], S * k.nmb * 4, 0xff); }
+    }
     }
     for (int r = 1; r < (cfg->dpb > 0 ? 8 : cfg->refs); r++) alloc((void **)&e->mvr[r], S * k.nmb * 2 * sizeof(int16_t), 0);
     alloc((void **)&e->wf_progress, S * 2 * WFG_ROWS * sizeof(int), 0);
@@ -187,6 +197,12 @@ int x264gpu_encoder_create(x264gpu_encoder **out, const x264gpu_config *cfg)
     if (cfg->trellis) { const uint16_t *a; const uint8_t *b; const int *c; const int r2 = trellis_table_ptrs(&a, &b, &c); if (r2 != X264GPU_OK) { x264gpu_encoder_destroy(e); return r2; } }
     *out = e;
     return X264GPU_OK;
+}
+int x264gpu_encoder_create(x264gpu_encoder **out, const x264gpu_config *cfg) { return encoder_create_impl(out, cfg, nullptr); }
+int x264gpu_encoder_create_view(x264gpu_encoder **out, x264gpu_encoder *parent)
+{
+    ARG_TRY(out && parent && !parent->view_of && parent->cfg.dpb > 0);          // views of x264gpu_encode_pictures sessions (the DPB model names every slot)
+    return encoder_create_impl(out, &parent->cfg, parent);
 }
 
 int x264gpu_encoder_set_qp(x264gpu_encoder *e, int qp_i, int qp_p)
@@ -283,6 +299,7 @@ void x264gpu_encoder_destroy(x264gpu_encoder *e)
     if (!e) return;
     profile_free(e);
     (void)hipFree(e->fenc_y); (void)hipFree(e->fenc_uv);
+    if (!e->view_of)
     for (int i = 0; i < 8; i++) { (void)hipFree(e->luma[i]); (void)hipFree(e->chroma[i]); (void)hipFree(e->mv16[i]); (void)hipFree(e->mbtype[i]); (void)hipFree(e->colref[i]); (void)hipFree(e->colmv[i]); (void)hipFree(e->colref0[i]); }
     (void)hipFree(e->direct_flags_base); (void)hipFree(e->dscore);
     for (int i = 0; i < 8; i++) (void)hipFree(e->mvr[i]);
@@ -450,18 +467,18 @@ static int encode_core(x264gpu_encoder *e, const uint8_t *d_i420, const x264gpu_
     const int s0 = n0 ? slot_of(0) : cur;
     k.mv16_cur = e->mv16[cur]; k.mv16_ref0 = e->mv16[s0]; k.mbtype_cur = e->mbtype[cur]; k.mbtype_ref0 = e->mbtype[s0];
     for (int r = 0; r < 8; r++) k.mvr[r] = e->mvr[r];
-    k.temporal = k.nref > 0 && e->slot_nref[s0] > 0;
+    k.temporal = k.nref > 0 && e->meta->slot_nref[s0] > 0;
     for (int r = 0; r < 8; r++) k.tscale[r] = 0;
     if (k.temporal) {
-        const int delta = e->slot_poc[s0] - e->slot_ref0poc[s0], inv = (256 + delta / 2) / delta;
-        for (int r = 0; r < n0 + n1; r++) k.tscale[r] = (e->poc - e->slot_poc[slot_of(r)]) * inv;
+        const int delta = e->meta->slot_poc[s0] - e->meta->slot_ref0poc[s0], inv = (256 + delta / 2) / delta;
+        for (int r = 0; r < n0 + n1; r++) k.tscale[r] = (e->poc - e->meta->slot_poc[slot_of(r)]) * inv;
     }
     memset(k.biw, 32, sizeof(k.biw));
     if (bslice) {
         // x264_macroblock_bipred_init: implicit weights from the POC distances (8.4.2.3.1)
         for (int r0 = 0; r0 < n0; r0++)
             for (int r1 = 0; r1 < n1; r1++) {
-                const int poc0 = e->slot_poc[pic.slot[0][r0]], poc1 = e->slot_poc[pic.slot[1][r1]];
+                const int poc0 = e->meta->slot_poc[pic.slot[0][r0]], poc1 = e->meta->slot_poc[pic.slot[1][r1]];
                 const int td = min(max(poc1 - poc0, -128), 127);
                 int dsf = 256;
                 if (td) { const int tb = min(max(e->poc - poc0, -128), 127), tx = (16384 + (abs(td) >> 1)) / td; dsf = min(max((tb * tx + 32) >> 6, -1024), 1023); }
@@ -478,9 +495,9 @@ static int encode_core(x264gpu_encoder *e, const uint8_t *d_i420, const x264gpu_
         k.direct_flags = e->use_direct_flags ? e->direct_flags : nullptr;
         for (int i = 0; i < 8; i++) {
             k.map_col[i] = -2; k.dist_scale[i] = 256;
-            if (i < e->slot_nref[cs]) for (int j = 0; j < n0; j++) if (e->slot_poc[pic.slot[0][j]] == e->slot_l0poc[cs][i]) { k.map_col[i] = j; break; }
+            if (i < e->meta->slot_nref[cs]) for (int j = 0; j < n0; j++) if (e->meta->slot_poc[pic.slot[0][j]] == e->meta->slot_l0poc[cs][i]) { k.map_col[i] = j; break; }
             if (i < n0) {
-                const int poc0 = e->slot_poc[pic.slot[0][i]], poc1 = e->slot_poc[pic.slot[1][0]];
+                const int poc0 = e->meta->slot_poc[pic.slot[0][i]], poc1 = e->meta->slot_poc[pic.slot[1][0]];
                 const int td = min(max(poc1 - poc0, -128), 127);
                 if (td) { const int tb = min(max(e->poc - poc0, -128), 127), tx = (16384 + (abs(td) >> 1)) / td; k.dist_scale[i] = min(max((tb * tx + 32) >> 6, -1024), 1023); }
             }
@@ -493,8 +510,8 @@ static int encode_core(x264gpu_encoder *e, const uint8_t *d_i420, const x264gpu_
         k.dscore = e->dscore;
     }
     k.colref_cur = e->colref[cur]; k.colmv_cur = e->colmv[cur]; k.colref0_cur = e->colref0[cur];
-    e->slot_nref[cur] = k.nref; e->slot_poc[cur] = e->poc; e->slot_ref0poc[cur] = k.nref ? e->slot_poc[s0] : 0;
-    for (int r = 0; r < 8; r++) e->slot_l0poc[cur][r] = r < k.nref && slice_type != X264GPU_SLICE_I ? e->slot_poc[pic.slot[0][r]] : 0;
+    e->meta->slot_nref[cur] = k.nref; e->meta->slot_poc[cur] = e->poc; e->meta->slot_ref0poc[cur] = k.nref ? e->meta->slot_poc[s0] : 0;
+    for (int r = 0; r < 8; r++) e->meta->slot_l0poc[cur][r] = r < k.nref && slice_type != X264GPU_SLICE_I ? e->meta->slot_poc[pic.slot[0][r]] : 0;
     k.prof = e->prof; k.tc = e->tc; k.amvd = e->amvd; k.cab_out = e->cab_out;
     {
         // load balance: this picture's workgroup -> stream order from the times of the last picture of its kind; this picture's times replace them

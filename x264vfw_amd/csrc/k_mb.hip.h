@@ -3083,4 +3083,11 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(MB_WAVES_PER
 #endif
 }
 
+// The launch of the macroblock loop: one workgroup of one wavefront per stream and slice.  (The single workgroups of several streams' launches — a session's pictures
+// in flight — run side by side at a lone picture's rate, 1.0 - 1.1 s against 0.97 s: the dispatcher does not stack them on one SIMD; profiles/r06_inflight_kernel_timeline.txt)
+static inline void mb_launch(void (*kern)(EncK), const EncK &k, int streams, hipStream_t st)
+{
+    hipLaunchKernelGGL(kern, dim3(streams, k.slices > 1 ? k.slices : 1), dim3(64), 0, st, k);
+}
+
 }  // namespace x264gpu

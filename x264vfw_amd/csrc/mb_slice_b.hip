@@ -11,8 +11,8 @@ void launch_mb_slice_b_hex(const EncK &k, int streams, hipStream_t st)
     if (!k.rd || k.subme < 7) { launch_mb_slice_b0_hex(k, streams, st); return; }
     if (!k.cabac) { launch_mb_slice_b1_hex(k, streams, st); return; }      // RD with CAVLC bit counts
     if (k.cabac && (k.subme >= 9 || (k.rd & 64))) { launch_mb_slice_ref_b_hex(k, streams, st); return; }      // --subme 9: the +-5 sample sub-pel neighbourhood (4 + 10 iterations) and RD refinement of the sites cfg.rd names
-    if (k.trellis & 64) hipLaunchKernelGGL((k_mb_slice<2, 1, true, 4, true>), dim3(streams, k.slices > 1 ? k.slices : 1), dim3(64), 0, st, k);      // --trellis 2
-    else if (k.trellis) hipLaunchKernelGGL((k_mb_slice<2, 1, true, 3, true>), dim3(streams, k.slices > 1 ? k.slices : 1), dim3(64), 0, st, k);
-    else hipLaunchKernelGGL((k_mb_slice<2, 1, true, 2, true>), dim3(streams, k.slices > 1 ? k.slices : 1), dim3(64), 0, st, k);
+    if (k.trellis & 64) mb_launch(k_mb_slice<2, 1, true, 4, true>, k, streams, st);      // --trellis 2
+    else if (k.trellis) mb_launch(k_mb_slice<2, 1, true, 3, true>, k, streams, st);
+    else mb_launch(k_mb_slice<2, 1, true, 2, true>, k, streams, st);
 }
 }  // namespace x264gpu

@@ -6,7 +6,7 @@ namespace x264gpu {
 void launch_mb_slice_b0_umh(const EncK &k, int streams, hipStream_t st)
 {
     // (with the trellis quantiser the final encode reads the slice's CABAC state: the instantiation that carries it)
-    if (k.rd && k.cabac && k.trellis) hipLaunchKernelGGL((k_mb_slice<2, 2, true, 7, true>), dim3(streams, k.slices > 1 ? k.slices : 1), dim3(64), 0, st, k);
-    else hipLaunchKernelGGL((k_mb_slice<2, 2, true, 0, true>), dim3(streams, k.slices > 1 ? k.slices : 1), dim3(64), 0, st, k);
+    if (k.rd && k.cabac && k.trellis) mb_launch(k_mb_slice<2, 2, true, 7, true>, k, streams, st);
+    else mb_launch(k_mb_slice<2, 2, true, 0, true>, k, streams, st);
 }
 }  // namespace x264gpu

@@ -5,6 +5,6 @@
 namespace x264gpu {
 void launch_mb_slice_b1_umh(const EncK &k, int streams, hipStream_t st)
 {
-    hipLaunchKernelGGL((k_mb_slice<2, 2, true, 1, true>), dim3(streams, k.slices > 1 ? k.slices : 1), dim3(64), 0, st, k);
+    mb_launch(k_mb_slice<2, 2, true, 1, true>, k, streams, st);
 }
 }  // namespace x264gpu

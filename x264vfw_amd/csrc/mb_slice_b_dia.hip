@@ -9,8 +9,8 @@ void launch_mb_slice_b_dia(const EncK &k, int streams, hipStream_t st)
 {
     if (!k.rd || k.subme < 7) { launch_mb_slice_b0_dia(k, streams, st); return; }
     if (!k.cabac) { launch_mb_slice_b1_dia(k, streams, st); return; }      // RD with CAVLC bit counts      // B slices below --subme 7: analysis without RD
-    if (k.trellis & 64) hipLaunchKernelGGL((k_mb_slice<2, 0, true, 4, true>), dim3(streams, k.slices > 1 ? k.slices : 1), dim3(64), 0, st, k);      // --trellis 2
-    else if (k.trellis) hipLaunchKernelGGL((k_mb_slice<2, 0, true, 3, true>), dim3(streams, k.slices > 1 ? k.slices : 1), dim3(64), 0, st, k);
-    else hipLaunchKernelGGL((k_mb_slice<2, 0, true, 2, true>), dim3(streams, k.slices > 1 ? k.slices : 1), dim3(64), 0, st, k);
+    if (k.trellis & 64) mb_launch(k_mb_slice<2, 0, true, 4, true>, k, streams, st);      // --trellis 2
+    else if (k.trellis) mb_launch(k_mb_slice<2, 0, true, 3, true>, k, streams, st);
+    else mb_launch(k_mb_slice<2, 0, true, 2, true>, k, streams, st);
 }
 }  // namespace x264gpu

@@ -7,10 +7,10 @@ void launch_mb_slice_ref_intra(const EncK &k, int streams, hipStream_t st);     
 void launch_mb_slice_intra(const EncK &k, int streams, hipStream_t st)
 {
     if (((k.rd >> 1) & 63) && k.cabac) { launch_mb_slice_ref_intra(k, streams, st); return; }      // RD refinement (subme 8)
-    if (k.rd && k.cabac && (k.trellis & 64)) hipLaunchKernelGGL((k_mb_slice<2, 1, false, 4>), dim3(streams, k.slices > 1 ? k.slices : 1), dim3(64), 0, st, k);
-    else if (k.rd && k.cabac && k.trellis) hipLaunchKernelGGL((k_mb_slice<2, 1, false, 3>), dim3(streams, k.slices > 1 ? k.slices : 1), dim3(64), 0, st, k);
-    else if (k.rd && k.cabac) hipLaunchKernelGGL((k_mb_slice<2, 1, false, 2>), dim3(streams, k.slices > 1 ? k.slices : 1), dim3(64), 0, st, k);
-    else if (k.rd) hipLaunchKernelGGL((k_mb_slice<2, 1, false, 1>), dim3(streams, k.slices > 1 ? k.slices : 1), dim3(64), 0, st, k);
-    else hipLaunchKernelGGL((k_mb_slice<2, 1, false>), dim3(streams, k.slices > 1 ? k.slices : 1), dim3(64), 0, st, k);
+    if (k.rd && k.cabac && (k.trellis & 64)) mb_launch(k_mb_slice<2, 1, false, 4>, k, streams, st);
+    else if (k.rd && k.cabac && k.trellis) mb_launch(k_mb_slice<2, 1, false, 3>, k, streams, st);
+    else if (k.rd && k.cabac) mb_launch(k_mb_slice<2, 1, false, 2>, k, streams, st);
+    else if (k.rd) mb_launch(k_mb_slice<2, 1, false, 1>, k, streams, st);
+    else mb_launch(k_mb_slice<2, 1, false>, k, streams, st);
 }
 }  // namespace x264gpu

@@ -5,7 +5,7 @@
 namespace x264gpu {
 void launch_mb_slice_ref_hex(const EncK &k, int streams, hipStream_t st)
 {
-    if (k.trellis & 64) hipLaunchKernelGGL((k_mb_slice<5, 1, true, 6>), dim3(streams, k.slices > 1 ? k.slices : 1), dim3(64), 0, st, k);
-    else hipLaunchKernelGGL((k_mb_slice<5, 1, true, 5>), dim3(streams, k.slices > 1 ? k.slices : 1), dim3(64), 0, st, k);
+    if (k.trellis & 64) mb_launch(k_mb_slice<5, 1, true, 6>, k, streams, st);
+    else mb_launch(k_mb_slice<5, 1, true, 5>, k, streams, st);
 }
 }  // namespace x264gpu

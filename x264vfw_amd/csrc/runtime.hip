@@ -72,6 +72,7 @@ int x264gpu_event_create(void **event)
 }
 int x264gpu_event_destroy(void *event) { ARG_TRY(event); HIP_TRY(hipEventDestroy((hipEvent_t)event)); return X264GPU_OK; }
 int x264gpu_event_record(void *event, void *stream) { ARG_TRY(event); HIP_TRY(hipEventRecord((hipEvent_t)event, (hipStream_t)stream)); return X264GPU_OK; }
+int x264gpu_stream_wait_event(void *stream, void *event) { ARG_TRY(event); HIP_TRY(hipStreamWaitEvent((hipStream_t)stream, (hipEvent_t)event, 0)); return X264GPU_OK; }
 int x264gpu_event_sync(void *event) { ARG_TRY(event); HIP_TRY(hipEventSynchronize((hipEvent_t)event)); return X264GPU_OK; }
 int x264gpu_memcpy_d2d(void *dst, const void *src, size_t n, void *stream)
 {

@@ -55,7 +55,11 @@ public:
         log2_max_frame_num = log2_max_fn;
         refs.clear(); frame_num = 0; last_idr = 0;
     }
-    int slots() const { return max_dpb + 1; }
+    // extra_slots / avoid: a session with several pictures in flight (host/encoder.cpp: Inflight) owns more slots than the DPB holds pictures and keeps the
+    // slots its pictures in flight write or read out of the choice of a destination
+    int extra_slots = 0; unsigned avoid = 0;
+    int slots() const { return max_dpb + 1 + extra_slots; }
+    bool has_free_slot() const { for (int s = 0; s < slots(); s++) { bool used = (avoid >> s) & 1; for (const Ref &r : refs) used |= r.slot == s; if (!used) return true; } return false; }
 
     // Plans the picture `frame` (display index) of type `type`.  follow_coded / follow_frame: coding index and display index of the disposable
     // pictures that follow it immediately in coding order (x264 reads them from h->frames.current); coded = this picture's coding index.
@@ -74,7 +78,7 @@ public:
         p.pic.poc = 2 * (frame - last_idr);
         p.pic.keep = p.nal_ref_idc != 0;
         // a free slot: any not held by a kept picture
-        for (int s = 0; s < slots(); s++) { bool used = false; for (const Ref &r : refs) used |= r.slot == s; if (!used) { p.pic.dst = s; break; } }
+        for (int s = 0; s < slots(); s++) { bool used = (avoid >> s) & 1; for (const Ref &r : refs) used |= r.slot == s; if (!used) { p.pic.dst = s; break; } }
         // x264_reference_hierarchy_reset (I, P, BREF): room for the delayed b's of the mini-GOP
         int remove_from_end = 0;
         if (type == PIC_I || type == PIC_P || type == PIC_BREF) {

@@ -166,6 +166,14 @@ struct x264_t {
                       int qp = 0, scenecut = 0; float qpm = 0.f; int32_t costs[4] = { 0, 0, 0, 0 }; };      // the decision hooks' values of THIS picture (x264host_last_decision / _last_qpm)
     Deferred defer[2]; int defer_cur = 0;
     struct BPlanned { BEntry e; int type; };                                                                            // type: PIC_*
+    // ---- several pictures of ONE session in flight (threads-1 sessions on the DPB model; x264's frame threads overlap pictures too).  The b pictures of a mini-GOP, the
+    //      B reference between two finished P pictures and the next P picture share only FINISHED references: each is issued through a launch context of its own (the
+    //      encoder or a view of it: own scratch, the shared DPB) on a stream of its own, behind the events of the pictures it references, into a slot no picture in
+    //      flight reads or writes; pictures are planned, issued and handed back in coding order, so the stream is the serial session's byte for byte ----
+    struct LaunchCtx { x264gpu_encoder *gpu = nullptr; void *stream = nullptr, *ev = nullptr; x264gpu_mb *d_mb = nullptr; int16_t *d_lv = nullptr; bool busy = false; };
+    struct Inflight { BPlanned pl; x264gpu_pic pic; SliceParams sp; int ctx = 0, nal_ref_idc = 0; unsigned slots_used = 0; char direct_char = '-'; };
+    void *ev_la = nullptr;               // the default stream's position when a picture is issued: its upload, offsets and lowres vectors are complete behind it
+    std::vector<LaunchCtx> lctx; std::deque<Inflight> fl; int inflight = 1; int slot_writer[8] = { -1, -1, -1, -1, -1, -1, -1, -1 }; int last_retired_slot = -1;
     std::deque<BEntry> bq;
     std::deque<BPlanned> bcoding;
     std::vector<int64_t> all_pts;        // every pts seen, in display order (the dts delay line)
@@ -781,7 +789,16 @@ x264_t *x264_encoder_open(x264_param_t *param)
     }
     p.analyse.i_mv_range = clampi(p.analyse.i_mv_range, 32, 512);
     cfg.mv_range = p.analyse.i_mv_range;
-    if (h->dpbmode) { cfg.dpb = h->dpb.max_dpb; cfg.weightb = p.analyse.b_weighted_bipred; }
+    h->inflight = 1;
+    if (h->dpbmode && p.i_bframe > 0 && h->G == 1 && !h->batch_n && !h->pass1 && !h->pass2 && !h->abr && h->direct_mode != 3) {
+        // (--direct auto chooses a B picture's mode from the skip counts of the one before, ABR and 2-pass a picture's quantiser from the sizes of the ones before:
+        //  those sessions code one picture at a time)
+        const char *ie = getenv("X264GPU_INFLIGHT");
+        const int want = getenv("X264GPU_DUMP_RECORDS") ? 1 : ie ? atoi(ie) : 4,          // (the debugging dump follows the serial path)
+                  extra = want - 1 < 7 - h->dpb.max_dpb ? want - 1 : 7 - h->dpb.max_dpb;
+        if (extra >= 1) { h->inflight = extra + 1; h->dpb.extra_slots = extra; }
+    }
+    if (h->dpbmode) { cfg.dpb = h->dpb.max_dpb + h->dpb.extra_slots; cfg.weightb = p.analyse.b_weighted_bipred; }
     size_t insz = (size_t)p.i_width * p.i_height * 3 / 2;
     (void)x264gpu_get_device(&h->device);
     bool ok_setup = x264gpu_malloc((void **)&h->d_in, insz) == X264GPU_OK;
@@ -814,6 +831,19 @@ x264_t *x264_encoder_open(x264_param_t *param)
         ok_setup = x264gpu_encoder_create(&h->gpu, &cfg) == X264GPU_OK &&
                    x264gpu_malloc((void **)&h->d_mb, (size_t)h->nmb * sizeof(x264gpu_mb)) == X264GPU_OK &&
                    x264gpu_malloc((void **)&h->d_lv, (size_t)h->nmb * X264GPU_MB_LEVELS * sizeof(int16_t)) == X264GPU_OK;
+        if (ok_setup && h->inflight > 1) {
+            h->lctx.resize((size_t)h->inflight);
+            ok_setup = x264gpu_event_create(&h->ev_la) == X264GPU_OK;
+            for (int i = 0; i < h->inflight && ok_setup; i++) {
+                x264_t::LaunchCtx &c = h->lctx[(size_t)i];
+                if (i == 0) { c.gpu = h->gpu; c.d_mb = h->d_mb; c.d_lv = h->d_lv; }
+                else ok_setup = x264gpu_encoder_create_view(&c.gpu, h->gpu) == X264GPU_OK &&
+                                x264gpu_malloc((void **)&c.d_mb, (size_t)h->nmb * sizeof(x264gpu_mb)) == X264GPU_OK &&
+                                x264gpu_malloc((void **)&c.d_lv, (size_t)h->nmb * X264GPU_MB_LEVELS * sizeof(int16_t)) == X264GPU_OK;
+                ok_setup = ok_setup && x264gpu_stream_create(&c.stream) == X264GPU_OK && x264gpu_event_create(&c.ev) == X264GPU_OK;
+            }
+            if (ok_setup) xlog(&p, X264_LOG_INFO, "up to %d pictures of the session in flight (pictures that share only finished references; the stream is the serial one)\n", h->inflight);
+        }
     }
     if (!ok_setup) {
         xlog(&p, X264_LOG_ERROR, "GPU encoder setup failed: %s\n", x264gpu_last_error());
@@ -843,6 +873,7 @@ x264_t *x264_encoder_open(x264_param_t *param)
     h->st_wait = h->bframes > h->L ? h->bframes : h->L;
     // x264 h->frames.i_delay: the trellis over picture types looks max(bframes, 3) * 4 pictures ahead
     if (h->dpbmode && h->bframes && p.i_bframe_adaptive == 2) { const int d = (h->bframes > 3 ? h->bframes : 3) * 4; if (d > h->st_wait) h->st_wait = d; if (h->Q < h->st_wait + 2 * (h->bframes + 1) + 2) h->Q = h->st_wait + 2 * (h->bframes + 1) + 2; }
+    if (h->dpbmode && h->inflight > 1) h->Q += h->inflight + h->bframes + 1;           // ... + the pictures in flight (their source pictures and offsets are read when their kernels run)
     if (h->dpbmode && h->Q > 128) {          // the lookahead object holds 128 pictures
         const int over = h->Q - 128;
         xlog(&p, X264_LOG_INFO, "lookahead window shortened by %d pictures (128 pictures are held at most)\n", over);
@@ -2461,6 +2492,152 @@ static int encode_bmode(x264_t *h, x264_nal_t **pp_nal, int *pi_nal, x264_pictur
     return (int)h->out.size();
 }
 
+// ---- several pictures of the session in flight (x264_t::Inflight) ----
+// issues the next picture of the coding order through a free launch context; false: nothing could be issued (no picture decided, no free context, no free slot)
+static bool inflight_issue(x264_t *h, bool flushing)
+{
+    const x264_param_t &p = h->param;
+    int ci = -1;
+    for (int i = 0; i < (int)h->lctx.size(); i++) if (!h->lctx[(size_t)i].busy) { ci = i; break; }
+    if (ci < 0) return false;
+    if (h->bcoding.empty() && !bmode_decide(h, flushing)) return false;
+    if (h->failed) return false;
+    // the slots the pictures in flight write or read stay out of the choice of a destination
+    unsigned avoid = 0;
+    for (const x264_t::Inflight &f : h->fl) avoid |= f.slots_used;
+    h->dpb.avoid = avoid;
+    if (!h->dpb.has_free_slot()) return false;
+    const x264_t::BPlanned pl = h->bcoding.front();
+    h->bcoding.pop_front();
+    int fc[16], ff[16], nf = 0;
+    const long coded_index = h->coded_count + (long)h->fl.size();          // this picture's place in the coding order
+    for (size_t i = 0; i < h->bcoding.size() && nf < 16 && h->bcoding[i].type == PIC_B; i++) { fc[nf] = (int)(coded_index + 1 + (long)i); ff[nf] = h->bcoding[i].e.frame; nf++; }
+    const DpbPlan plan = h->dpb.plan(pl.type, pl.e.frame, nf, fc, ff, pl.type == PIC_P && pl.e.w.on ? &pl.e.w : nullptr);
+    x264_t::Inflight f;
+    f.pl = pl; f.ctx = ci; f.nal_ref_idc = plan.nal_ref_idc;
+    x264gpu_pic pic = plan.pic;
+    double qpf = 0;
+    pic.qp = bmode_qp(h, pl, plan, &qpf);
+    pic.qpm = near_qpm(qpf, pic.qp);
+    h->rc_frames++;
+    if ((pl.type == PIC_B || pl.type == PIC_BREF) && h->direct_mode != 1) {
+        // x264 slice_header_init: temporal direct prediction only when the co-located picture's reference 0 is this picture's reference 0 (--direct auto runs serially)
+        const bool temporal = pic.nref[0] && pic.nref[1] && h->slot_l0ref0poc[pic.slot[1][0]] == plan.list_poc[0][0];
+        pic.direct_temporal = temporal; pic.direct_auto = 0;
+        h->dpb.set_direct(pic.direct_temporal, 0);
+    }
+    x264_t::LaunchCtx &c = h->lctx[(size_t)ci];
+    if (h->st) {
+        const int dist0 = pic.nref[0] ? (pic.poc - plan.list_poc[0][0]) / 2 : 0, dist1 = pic.nref[1] ? (plan.list_poc[1][0] - pic.poc) / 2 : 0;
+        const int16_t *m0 = dist0 >= 1 && dist0 <= h->bframes + 1 ? x264gpu_slicetype_lowres_mvs(h->st, pl.e.slot, 0, dist0) : nullptr;
+        const int16_t *m1 = dist1 >= 1 && dist1 <= h->bframes + 1 ? x264gpu_slicetype_lowres_mvs(h->st, pl.e.slot, 1, dist1) : nullptr;
+        x264gpu_encoder_set_lowres_mvs(c.gpu, m0);
+        x264gpu_encoder_set_lowres_mvs1(c.gpu, m1);
+    }
+    const float *d_offsets = nullptr;
+    if (h->st && h->mbtree) d_offsets = pl.type == PIC_B ? h->q_aq[(size_t)pl.e.slot] : h->q_tree[(size_t)pl.e.slot];
+    else if (h->aq_mode >= 2 && h->aq_strength != 0.f) d_offsets = h->q_aq[(size_t)pl.e.slot];
+    x264gpu_encoder_set_mb_qp_offsets(c.gpu, d_offsets);
+    // behind the pictures in flight that write a slot this picture reads (its references; their side data lives with the slot)
+    f.slots_used = 1u << pic.dst;
+    bool ok = true;
+    for (int l = 0; l < 2 && ok; l++)
+        for (int r = 0; r < pic.nref[l] && ok; r++) {
+            const int sl = pic.slot[l][r];
+            f.slots_used |= 1u << sl;
+            const int w = h->slot_writer[sl];
+            if (w >= 0 && w != ci) ok = x264gpu_stream_wait_event(c.stream, h->lctx[(size_t)w].ev) == X264GPU_OK;
+        }
+    // ... and behind the default stream: this picture's upload, its quantiser offsets and the lookahead's vectors were produced there
+    ok = ok && x264gpu_event_record(h->ev_la, h->up_stream) == X264GPU_OK && x264gpu_stream_wait_event(c.stream, h->ev_la) == X264GPU_OK;
+    if (ok && h->up_stream) ok = x264gpu_event_record(h->ev_la, nullptr) == X264GPU_OK && x264gpu_stream_wait_event(c.stream, h->ev_la) == X264GPU_OK;
+    ok = ok && x264gpu_encode_pictures(c.gpu, h->q_raw[(size_t)pl.e.slot], &pic, c.d_mb, c.d_lv, c.stream) == X264GPU_OK && x264gpu_event_record(c.ev, c.stream) == X264GPU_OK;
+    if (!ok) { xlog(&p, X264_LOG_ERROR, "x264_encoder_encode: GPU hot path failed: %s\n", x264gpu_last_error()); h->failed = true; return false; }
+    c.busy = true;
+    h->slot_writer[pic.dst] = ci;
+    if (plan.nal_ref_idc) { h->slot_qp_rc[pic.dst] = rc_qp_avg_rc((float)qpf, h->mbw, h->mbh); h->slot_ptype[pic.dst] = pl.type; }
+    if (plan.nal_ref_idc) h->slot_l0ref0poc[pic.dst] = pic.nref[0] ? plan.list_poc[0][0] : INT_MIN;
+    f.direct_char = (pl.type == PIC_B || pl.type == PIC_BREF) ? (pic.direct_temporal ? 't' : 's') : '-';
+    f.pic = pic;
+    SliceParams sp = {};
+    sp.mbw = h->mbw; sp.mbh = h->mbh; sp.qp = pic.qp; sp.pic_init_qp = h->pic_init_qp; sp.log2_max_frame_num = h->log2_max_frame_num; sp.log2_max_poc_lsb = h->log2_max_poc_lsb;
+    sp.pps_id = p.i_sps_id; sp.num_ref_default = p.i_frame_reference; sp.num_ref1_default = 1;
+    sp.disable_deblock_idc = p.b_deblocking_filter ? 0 : 1; sp.alpha_off_div2 = p.i_deblocking_filter_alphac0; sp.beta_off_div2 = p.i_deblocking_filter_beta;
+    sp.transform8x8_mode = p.analyse.b_transform_8x8; sp.cabac = p.b_cabac; sp.slices_plain = h->slices_plain;
+    h->dpb.fill(sp);
+    h->dpb.commit();
+    f.sp = sp;
+    h->fl.push_back(f);
+    return true;
+}
+
+// hands back the oldest picture in flight: waits for its launch context, downloads its records, writes its NAL units
+static int inflight_retire(x264_t *h, x264_nal_t **pp_nal, int *pi_nal, x264_picture_t *pic_out)
+{
+    const x264_param_t &p = h->param;
+    x264_t::Inflight f = h->fl.front();
+    h->fl.pop_front();
+    x264_t::LaunchCtx &c = h->lctx[(size_t)f.ctx];
+    if (x264gpu_event_sync(c.ev) != X264GPU_OK ||
+        x264gpu_memcpy_d2h(h->h_mb.data(), c.d_mb, h->h_mb.size() * sizeof(x264gpu_mb), c.stream) != X264GPU_OK ||
+        x264gpu_memcpy_d2h(h->h_lv.data(), c.d_lv, h->h_lv.size() * sizeof(int16_t), c.stream) != X264GPU_OK) {
+        xlog(&p, X264_LOG_ERROR, "x264_encoder_encode: GPU hot path failed: %s\n", x264gpu_last_error());
+        h->failed = true;
+        return -1;
+    }
+    c.busy = false;
+    if (h->slot_writer[f.pic.dst] == f.ctx) h->slot_writer[f.pic.dst] = -1;
+    h->last_retired_slot = f.pic.dst;
+    const x264_t::BPlanned &pl = f.pl;
+    h->last_direct_char = f.direct_char;
+    h->last_scenecut = pl.e.scenecut; h->last_qp = f.pic.qp; h->last_qpm = f.pic.qpm;
+    memcpy(h->last_costs, pl.e.costs, sizeof(pl.e.costs));
+    const bool idr = pl.type == PIC_IDR;
+    h->out.clear(); h->nal_off.clear();
+    std::vector<int> types;
+    if (p.b_aud) { h->nal_off.push_back(h->out.size()); types.push_back(9); write_aud(h->out, pl.type <= PIC_I ? 0 : pl.type == PIC_P ? 1 : 2, p.b_annexb != 0); }
+    if (idr && p.b_repeat_headers) { emit_sets(h, types, !h->sei_sent); h->sei_sent = 1; }
+    SliceParams sp = f.sp;
+    sp.idr_pic_id = h->idr_pic_id;
+    h->last_stats.skip = 0;
+    {
+        const size_t before = h->nal_off.size();
+        write_picture(h->out, &h->nal_off, sp, h->slices, h->h_mb.data(), h->h_lv.data(), p.b_annexb != 0, before == 0, &h->last_stats, h->cavlc_threads);
+        for (size_t i = before; i < h->nal_off.size(); i++) types.push_back(idr ? 5 : 1);
+    }
+    publish_nals(h, pp_nal, pi_nal, types);
+    for (size_t i = 0; i < h->nals.size(); i++) if (types[i] == 1 || types[i] == 5) h->nals[i].i_ref_idc = f.nal_ref_idc;
+    if (pic_out) {
+        x264_picture_init(pic_out);
+        pic_out->i_type = idr ? X264_TYPE_IDR : pl.type == PIC_I ? X264_TYPE_I : pl.type == PIC_P ? X264_TYPE_P : pl.type == PIC_BREF ? X264_TYPE_BREF : X264_TYPE_B;
+        pic_out->b_keyframe = idr;
+        pic_out->i_pts = pl.e.pts;
+        const long k = h->coded_count, delay = !h->bframes ? 0 : h->bpyramid ? 2 : 1;
+        const size_t np = h->all_pts.size();
+        if (k >= delay) pic_out->i_dts = h->all_pts[(size_t)(k - delay) < np ? (size_t)(k - delay) : np - 1];
+        else pic_out->i_dts = h->all_pts[(size_t)k < np ? (size_t)k : np - 1] - (h->all_pts[(size_t)delay < np ? (size_t)delay : np - 1] - h->all_pts[0]);
+        pic_out->img = pl.e.img;
+    }
+    h->t_b[4] += 1;
+    if (idr) h->idr_pic_id = (h->idr_pic_id + 1) & 0xffff;
+    h->coded_count++;
+    h->frame_no++;
+    return (int)h->out.size();
+}
+
+static int encode_bmode_inflight(x264_t *h, x264_nal_t **pp_nal, int *pi_nal, x264_picture_t *pic_out, bool flushing)
+{
+    // issue what can be issued (a new picture's arrival may decide a mini-GOP: its closing picture, its B reference, its b pictures, as far as contexts and slots go) ...
+    while (inflight_issue(h, flushing)) ;
+    if (h->failed) return -1;
+    if (h->fl.empty()) return 0;
+    // ... and hand back the oldest picture once `inflight` pictures are out (x264's frame threads: i_thread_frames - 1 more calls of delay), when a decided picture
+    // waits for a context or a slot, or when the input has ended; else this call returns nothing (a delayed frame).  The pictures behind the oldest keep running:
+    // in the steady state a call issues one picture and waits for one that was issued inflight - 1 calls ago.
+    if (!(flushing || (int)h->fl.size() >= h->inflight || !h->bcoding.empty())) return 0;
+    return inflight_retire(h, pp_nal, pi_nal, pic_out);
+}
+
 int x264_encoder_encode(x264_t *h, x264_nal_t **pp_nal, int *pi_nal, x264_picture_t *pic_in, x264_picture_t *pic_out)
 {
     if (!h || !pp_nal || !pi_nal) return -1;
@@ -2468,7 +2645,7 @@ int x264_encoder_encode(x264_t *h, x264_nal_t **pp_nal, int *pi_nal, x264_pictur
     if (h->failed) return -1;
     if (!pic_in) {      // flush: GOP-parallel batches, or the pictures still waiting in the lookahead queue, one per call
         if (h->G > 1) return encode_gop_parallel(h, pp_nal, pi_nal, nullptr, pic_out, false);
-        if (h->dpbmode) return encode_bmode(h, pp_nal, pi_nal, pic_out, true);
+        if (h->dpbmode) return h->inflight > 1 ? encode_bmode_inflight(h, pp_nal, pi_nal, pic_out, true) : encode_bmode(h, pp_nal, pi_nal, pic_out, true);
         return h->queue.empty() ? 0 : encode_queued(h, pp_nal, pi_nal, pic_out, true);
     }
     const x264_param_t &p = h->param;
@@ -2553,7 +2730,7 @@ int x264_encoder_encode(x264_t *h, x264_nal_t **pp_nal, int *pi_nal, x264_pictur
         h->bq.push_back(be);
         h->all_pts.push_back(e.pts);
         PHASE(1);
-        const int size = encode_bmode(h, pp_nal, pi_nal, pic_out, false);
+        const int size = h->inflight > 1 ? encode_bmode_inflight(h, pp_nal, pi_nal, pic_out, false) : encode_bmode(h, pp_nal, pi_nal, pic_out, false);
         PHASE(4);
         h->t_phase[5] += 1;
         return size;
@@ -2568,7 +2745,7 @@ int x264_encoder_encode(x264_t *h, x264_nal_t **pp_nal, int *pi_nal, x264_pictur
     return size;
 }
 
-int x264_encoder_delayed_frames(x264_t *h) { return !h || h->failed ? 0 : h->G > 1 ? (int)(h->submitted - h->emitted) : h->dpbmode ? (int)(h->bq.size() + h->bcoding.size()) + (h->defer[0].valid ? 1 : 0) + (h->defer[1].valid ? 1 : 0) : (int)h->queue.size(); }
+int x264_encoder_delayed_frames(x264_t *h) { return !h || h->failed ? 0 : h->G > 1 ? (int)(h->submitted - h->emitted) : h->dpbmode ? (int)(h->bq.size() + h->bcoding.size() + h->fl.size()) + (h->defer[0].valid ? 1 : 0) + (h->defer[1].valid ? 1 : 0) : (int)h->queue.size(); }
 
 void x264_encoder_close(x264_t *h)
 {
@@ -2589,6 +2766,14 @@ void x264_encoder_close(x264_t *h)
         if (h->pass2 && h->coded_count < (long)h->p2.size()) { remove((out + ".temp").c_str()); xlog(&h->param, X264_LOG_INFO, "2-pass: %ld of %d pictures coded: the statistics file keeps the first pass' lines\n", h->coded_count, (int)h->p2.size()); }
         else if (!out.empty() && rename((out + ".temp").c_str(), out.c_str())) xlog(&h->param, X264_LOG_ERROR, "failed to rename \"%s.temp\" to \"%s\"\n", out.c_str(), out.c_str());
     }
+    for (size_t i = 0; i < h->lctx.size(); i++) {
+        x264_t::LaunchCtx &c = h->lctx[i];
+        if (c.stream) { x264gpu_stream_sync(c.stream); x264gpu_stream_destroy(c.stream); }
+        if (c.ev) x264gpu_event_destroy(c.ev);
+        if (i > 0) { if (c.gpu) x264gpu_encoder_destroy(c.gpu); if (c.d_mb) x264gpu_free(c.d_mb); if (c.d_lv) x264gpu_free(c.d_lv); }
+    }
+    h->lctx.clear();
+    if (h->ev_la) x264gpu_event_destroy(h->ev_la);
     if (h->batch) { batch_leave(h->batch, h->batch_idx); h->batch = nullptr; }
     if (h->up_stream) { x264gpu_stream_destroy(h->up_stream); h->up_stream = nullptr; }
     if (h->gpu) x264gpu_encoder_destroy(h->gpu);
@@ -2822,7 +3007,8 @@ int x264host_get_recon(x264_t *h, uint8_t *i420_out)
     size_t n = (size_t)h->param.i_width * h->param.i_height * 3 / 2;
     uint8_t *d = nullptr;
     if (x264gpu_malloc((void **)&d, n) != X264GPU_OK) return -1;
-    int rc = x264gpu_encoder_get_recon(h->gpu, 0, d, nullptr);
+    // (several pictures in flight: the picture handed back last — its slot is not reused before the next call issues a picture)
+    int rc = h->inflight > 1 && h->last_retired_slot >= 0 ? x264gpu_encoder_get_recon_slot(h->gpu, 0, h->last_retired_slot, d, nullptr) : x264gpu_encoder_get_recon(h->gpu, 0, d, nullptr);
     if (rc == X264GPU_OK) rc = x264gpu_memcpy_d2h(i420_out, d, n, nullptr);
     x264gpu_free(d);
     return rc;

@@ -86,6 +86,8 @@ _SIGS = {
     "x264gpu_event_destroy": (_i, [_vp]),
     "x264gpu_event_record": (_i, [_vp, _vp]),
     "x264gpu_event_sync": (_i, [_vp]),
+    "x264gpu_stream_wait_event": (_i, [_vp, _vp]),
+    "x264gpu_encoder_create_view": (_i, [C.POINTER(_vp), _vp]),
     "x264gpu_pixel_metric": (_i, [_i, _vp, _vp, _i, _i, _i, _vp, _vp]),
     "x264gpu_pixel_var": (_i, [_vp, _i, _i, _i, _vp, _vp]),
     "x264gpu_pixel_hadamard_ac": (_i, [_vp, _i, _i, _i, _vp, _vp]),
