@@ -9,6 +9,13 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <pthread.h>
+/* The checker behind this stand-in (oracle/) keeps scratch in file-scope variables: it is test infrastructure, written for one caller.  The host library calls the
+ * device ABI from several threads (one per device under --threads G, one per session in a batch): every entry point that computes takes this lock, so the threads'
+ * ORDER is still the host's business and the checker sees one call at a time. */
+static pthread_mutex_t g_oracle_mu = PTHREAD_MUTEX_INITIALIZER;
+static void oracle_unlock(int *held) { if (*held) pthread_mutex_unlock(&g_oracle_mu); }
+#define ORACLE_LOCK() int oracle_held_ __attribute__((cleanup(oracle_unlock))) = (pthread_mutex_lock(&g_oracle_mu), 1)
 
 typedef struct x264o_encoder x264o_encoder;
 x264o_encoder *x264o_encoder_create(const x264gpu_config *cfg);
@@ -53,7 +60,7 @@ long x264gpu_stub_encode_calls(int dev) { return dev >= 0 && dev < 16 ? g_calls[
 struct x264gpu_encoder { x264gpu_config cfg; x264o_encoder **e; int dev, nmb; const float *off; int8_t *sqp; float *sqpm; float qpm; struct x264gpu_encoder *view_of; };
 
 int x264gpu_encoder_create(x264gpu_encoder **out, const x264gpu_config *cfg)
-{
+{ ORACLE_LOCK();
     if (!out || !cfg || cfg->streams < 1) return fail("encoder_create arguments");
     /* the device's structural checks (csrc/encoder.hip): RD at subme >= 8, deblock-aware RD and B pictures at subme >= 9 run in the refinement instantiations only */
     if (cfg->rd && cfg->subme >= 8 && !(cfg->cabac && (cfg->me_method == 1 || cfg->me_method == 2))) return fail("RD at subme >= 8 needs CABAC and me hex / umh");
@@ -122,7 +129,7 @@ const int *x264o_slicetype_intra_costs(const x264o_slicetype *st, int slot);
 const uint16_t *x264o_slicetype_lowres_costs(const x264o_slicetype *st, int slot, int d0, int d1);
 struct x264gpu_slicetype { x264o_slicetype *st; };
 int x264gpu_slicetype_create(x264gpu_slicetype **out, int w, int h, int streams, int slots, int bframes, int me_method, int subme, int me_range, int weightb, int mv_range, int do_edges)
-{
+{ ORACLE_LOCK();
     if (streams != 1) return fail("stub slicetype: one stream");
     if (slots > 128) return fail("stub slicetype: at most 128 slots");
     x264gpu_slicetype *s = calloc(1, sizeof(*s));
@@ -131,9 +138,9 @@ int x264gpu_slicetype_create(x264gpu_slicetype **out, int w, int h, int streams,
     return X264GPU_OK;
 }
 void x264gpu_slicetype_destroy(x264gpu_slicetype *s) { if (s) { x264o_slicetype_destroy(s->st); free(s); } }
-int x264gpu_slicetype_put_frame(x264gpu_slicetype *s, int slot, const uint8_t *i420, void *stream) { return x264o_slicetype_put_frame(s->st, slot, i420) ? fail("slicetype slot") : X264GPU_OK; }
+int x264gpu_slicetype_put_frame(x264gpu_slicetype *s, int slot, const uint8_t *i420, void *stream) { ORACLE_LOCK(); return x264o_slicetype_put_frame(s->st, slot, i420) ? fail("slicetype slot") : X264GPU_OK; }
 int x264gpu_slicetype_frame_cost(x264gpu_slicetype *s, int s0, int s1, int sb, int d0, int d1, int32_t *h_score, void *stream)
-{
+{ ORACLE_LOCK();
     const int c = x264o_slicetype_frame_cost(s->st, s0, s1, sb, d0, d1);
     if (c < 0) return fail("slicetype triple");
     h_score[0] = c;
@@ -155,16 +162,16 @@ long x264o_slicetype_weight_cost(x264o_slicetype *st, int sf, int sr, int dist, 
 void x264o_slicetype_chroma_stats(x264o_slicetype *st, int slot, const uint8_t *i420, uint64_t out[4]);
 long x264o_slicetype_weight_cost_chroma(x264o_slicetype *st, int sf, const uint8_t *i420_fenc, const uint8_t *i420_ref, int dist, int plane, int on, int scale, int denom, int offset);
 int x264gpu_slicetype_frame_cost_w(x264gpu_slicetype *s, int s0, int s1, int sb, int d0, int d1, int on, int scale, int denom, int offset, int32_t *h_score, void *stream)
-{
+{ ORACLE_LOCK();
     const int c = x264o_slicetype_frame_cost_w(s->st, s0, s1, sb, d0, d1, on, scale, denom, offset);
     if (c < 0) return fail("slicetype triple");
     h_score[0] = c;
     return X264GPU_OK;
 }
-int x264gpu_slicetype_pixel_stats(x264gpu_slicetype *s, int slot, const uint8_t *i420, uint64_t *out, void *stream) { x264o_slicetype_pixel_stats(s->st, slot, i420, out); return X264GPU_OK; }
-int x264gpu_slicetype_chroma_stats(x264gpu_slicetype *s, int slot, const uint8_t *i420, uint64_t *out, void *stream) { (void)stream; x264o_slicetype_chroma_stats(s->st, slot, i420, out); return X264GPU_OK; }
+int x264gpu_slicetype_pixel_stats(x264gpu_slicetype *s, int slot, const uint8_t *i420, uint64_t *out, void *stream) { ORACLE_LOCK(); x264o_slicetype_pixel_stats(s->st, slot, i420, out); return X264GPU_OK; }
+int x264gpu_slicetype_chroma_stats(x264gpu_slicetype *s, int slot, const uint8_t *i420, uint64_t *out, void *stream) { ORACLE_LOCK(); (void)stream; x264o_slicetype_chroma_stats(s->st, slot, i420, out); return X264GPU_OK; }
 int x264gpu_slicetype_weight_cost_chroma(x264gpu_slicetype *s, int sf, const uint8_t *i420_fenc, const uint8_t *i420_ref, int dist, int plane, int on, int scale, int denom, int offset, int64_t *h_cost, void *stream)
-{
+{ ORACLE_LOCK();
     (void)stream;
     if (plane < 1 || plane > 2) return fail("weight_cost_chroma: plane 1 or 2");
     const long c = x264o_slicetype_weight_cost_chroma(s->st, sf, i420_fenc, i420_ref, dist, plane, on, scale, denom, offset);
@@ -173,7 +180,7 @@ int x264gpu_slicetype_weight_cost_chroma(x264gpu_slicetype *s, int sf, const uin
     return X264GPU_OK;
 }
 int x264gpu_slicetype_weight_cost(x264gpu_slicetype *s, int sf, int sr, int dist, int on, int scale, int denom, int offset, int64_t *h_cost, void *stream)
-{
+{ ORACLE_LOCK();
     const long c = x264o_slicetype_weight_cost(s->st, sf, sr, dist, on, scale, denom, offset);
     if (c < 0) return fail("weight cost: no intra costs");
     h_cost[0] = c;
@@ -188,14 +195,14 @@ void x264o_slicetype_set_bframe_bias(x264o_slicetype *st, int bias);
 int x264gpu_slicetype_set_bframe_bias(x264gpu_slicetype *s, int bias) { x264o_slicetype_set_bframe_bias(s->st, bias); return X264GPU_OK; }
 int x264gpu_slicetype_set_row_mode(x264gpu_slicetype *s, int serial) { (void)s; (void)serial; return X264GPU_OK; }          /* (a launch geometry: nothing to model) */
 int x264o_slicetype_cost_aq(x264o_slicetype *st, int slot, int d0, int d1);
-int x264gpu_slicetype_cost_aq(x264gpu_slicetype *s, int slot, int d0, int d1, int32_t *h_score, void *stream) { const int c = x264o_slicetype_cost_aq(s->st, slot, d0, d1); if (c < 0) return fail("slicetype cost_aq"); h_score[0] = c; return X264GPU_OK; }
+int x264gpu_slicetype_cost_aq(x264gpu_slicetype *s, int slot, int d0, int d1, int32_t *h_score, void *stream) { ORACLE_LOCK(); const int c = x264o_slicetype_cost_aq(s->st, slot, d0, d1); if (c < 0) return fail("slicetype cost_aq"); h_score[0] = c; return X264GPU_OK; }
 int x264gpu_slicetype_set_aq(x264gpu_slicetype *s, int slot, const float *aq, void *stream) { x264o_slicetype_set_aq(s->st, slot, aq); return X264GPU_OK; }
 int x264gpu_slicetype_clear_propagate(x264gpu_slicetype *s, int slot, void *stream) { x264o_slicetype_clear_propagate(s->st, slot); return X264GPU_OK; }
-int x264gpu_slicetype_propagate(x264gpu_slicetype *s, int s0, int s1, int sb, int d0, int d1, int referenced, void *stream) { return x264o_slicetype_propagate(s->st, s0, s1, sb, d0, d1, referenced) ? fail("macroblock-tree: costs of the triple missing") : X264GPU_OK; }
-int x264gpu_slicetype_finish(x264gpu_slicetype *s, int slot, float strength, float weightdelta, float *out, void *stream) { return x264o_slicetype_finish(s->st, slot, strength, weightdelta, out) ? fail("macroblock-tree: no intra costs") : X264GPU_OK; }
+int x264gpu_slicetype_propagate(x264gpu_slicetype *s, int s0, int s1, int sb, int d0, int d1, int referenced, void *stream) { ORACLE_LOCK(); return x264o_slicetype_propagate(s->st, s0, s1, sb, d0, d1, referenced) ? fail("macroblock-tree: costs of the triple missing") : X264GPU_OK; }
+int x264gpu_slicetype_finish(x264gpu_slicetype *s, int slot, float strength, float weightdelta, float *out, void *stream) { ORACLE_LOCK(); return x264o_slicetype_finish(s->st, slot, strength, weightdelta, out) ? fail("macroblock-tree: no intra costs") : X264GPU_OK; }
 const int32_t *x264gpu_slicetype_propagate_cost(x264gpu_slicetype *s, int slot) { return x264o_slicetype_propagate_cost(s->st, slot); }
 int x264gpu_encode_frames(x264gpu_encoder *g, const uint8_t *i420, int slice_type, x264gpu_mb *mb, int16_t *lv, void *st)
-{
+{ ORACLE_LOCK();
     if (g->dev != t_dev) return fail("encoder used from a thread bound to another device");
     const size_t fsz = (size_t)g->cfg.width * g->cfg.height * 3 / 2;
     g_calls[g->dev]++;
@@ -210,7 +217,7 @@ int x264gpu_encode_frames(x264gpu_encoder *g, const uint8_t *i420, int slice_typ
 }
 int x264o_encoder_encode_pic(x264o_encoder *e, const uint8_t *i420, const x264gpu_pic *pic, x264gpu_mb *mbs, int16_t *levels);
 int x264gpu_encode_pictures(x264gpu_encoder *g, const uint8_t *i420, const x264gpu_pic *pics, x264gpu_mb *mb, int16_t *lv, void *st)
-{
+{ ORACLE_LOCK();
     if (g->dev != t_dev) return fail("encoder used from a thread bound to another device");
     const size_t fsz = (size_t)g->cfg.width * g->cfg.height * 3 / 2;
     g_calls[g->dev]++;
@@ -235,7 +242,7 @@ int x264gpu_encoder_get_recon_slot(x264gpu_encoder *g, int s, int slot, uint8_t 
 
 struct x264gpu_lookahead { x264o_lookahead *la; int w, h, nb; };
 int x264gpu_lookahead_create(x264gpu_lookahead **out, int w, int h, int streams, int me_range, int subme)
-{
+{ ORACLE_LOCK();
     if (streams != 1) return fail("stub lookahead: one stream");
     x264gpu_lookahead *l = calloc(1, sizeof(*l));
     l->la = x264o_lookahead_create(w, h, me_range, subme); l->w = w; l->h = h; l->nb = ((w + 15) / 16) * ((h + 15) / 16);
@@ -244,32 +251,32 @@ int x264gpu_lookahead_create(x264gpu_lookahead **out, int w, int h, int streams,
 }
 void x264gpu_lookahead_destroy(x264gpu_lookahead *l) { if (l) { x264o_lookahead_destroy(l->la); free(l); } }
 int x264gpu_lookahead_frame_cost(x264gpu_lookahead *l, const uint8_t *i420, int reset, int32_t *out, int32_t *blocks, void *st)
-{
+{ ORACLE_LOCK();
     int32_t *tmp = blocks ? blocks : malloc((size_t)l->nb * 4 * sizeof(int32_t));
     const int rc = x264o_lookahead_frame_cost(l->la, i420, reset, out, tmp);
     if (!blocks) free(tmp);
     return rc ? fail("lookahead") : X264GPU_OK;
 }
 int x264gpu_lookahead_aq_offsets(x264gpu_lookahead *l, const uint8_t *i420, float strength, float *out, void *st)
-{
+{ ORACLE_LOCK();
     x264o_aq_offsets(i420, l->w, l->h, strength, out);
     return X264GPU_OK;
 }
 
 int x264gpu_lookahead_aq_offsets_mode(x264gpu_lookahead *l, const uint8_t *i420, int mode, float strength, float *out, void *st)
-{
+{ ORACLE_LOCK();
     (void)st;
     if (mode < 1 || mode > 3) return fail("aq mode 1..3");
     x264o_aq_offsets_mode(i420, l->w, l->h, mode, strength, out);
     return X264GPU_OK;
 }
 int x264gpu_lookahead_mbtree(x264gpu_lookahead *l, const int32_t *const *info, const float *const *aq, int n, float strength, float *out, void *st)
-{
+{ ORACLE_LOCK();
     x264o_mbtree((l->w + 15) / 16, (l->h + 15) / 16, info, aq, n, strength, out);
     return X264GPU_OK;
 }
 long x264gpu_csp_img_fill(int csp, int width, int height, long off[3], int stride[3]) { return x264o_csp_img_fill(csp, width, height, off, stride); }
 int x264gpu_csp_to_i420(const uint8_t *const src[3], const int ss[3], int csp, int w, int h, int m709, int full, uint8_t *const dst[3], const int ds[3], void *st)
-{
+{ ORACLE_LOCK();
     return x264o_csp_to_i420(dst, ds, src, ss, csp, w, h, m709, full) ? fail("csp") : X264GPU_OK;
 }

@@ -1149,6 +1149,7 @@ def test_gop_slots_with_b_pictures_equal_serial(gpu, w, h, nfr, keyint, threads,
     (176, 144, 22, {"qp": 25, "bframes": 2, "b-pyramid": "none", "ref": 3, "direct": "temporal", "b-adapt": 0}),      # temporal direct: the co-located picture's vectors come from a picture in flight
     (128, 96, 25, {"crf": 24, "b-adapt": 2, "weightp": 2, "rc-lookahead": 6, "slices": 2, "keyint": 9, "min-keyint": 3}),
     (64, 48, 3, {"qp": 27}),                                                                                          # fewer pictures than launch contexts
+    (1280, 720, 22, {"crf": 23}),                                                                                     # the driver's default session at a size where the pictures overlap for real (0.3 - 0.5 s each)
 ])
 def test_pictures_in_flight_equal_serial(gpu, w, h, nfr, opts):
     """Several pictures of ONE session in flight: launch contexts over the shared DPB on streams of their own, each picture behind the events

@@ -36,6 +36,9 @@ int main(int argc, char **argv)
     std::vector<double> opened((size_t)ns, 0.0), coded((size_t)ns, 0.0);
     std::vector<long> bytes((size_t)ns, 0);
     std::atomic<int> errors{ 0 };
+    // MULTI_SESSION_TRACE=1: when the LAST session came back from call k (seconds from the start), and the longest any session spent inside call k
+    const bool trace = getenv("MULTI_SESSION_TRACE") != nullptr;
+    std::vector<double> ret_at((size_t)ns * (size_t)(n + 8), 0.0), spent((size_t)ns * (size_t)(n + 8), 0.0);
     const double t0 = now();
     auto one = [&](int idx) {
         x264_param_t p;
@@ -60,7 +63,9 @@ int main(int argc, char **argv)
                 else for (int y = 0; y < ph; y++) memcpy(pic.img.plane[pl] + (size_t)y * pic.img.i_stride[pl], f + off[pl] + (size_t)y * pw, (size_t)pw);
             }
             pic.i_pts = i;
+            const double tc = trace ? now() : 0;
             const int size = x264_encoder_encode(e, &nal, &nn, &pic, &out);
+            if (trace) { ret_at[(size_t)idx * (size_t)(n + 8) + (size_t)i] = now(); spent[(size_t)idx * (size_t)(n + 8) + (size_t)i] = now() - tc; }
             if (size < 0) { errors++; break; }
             if (size > 0) { got++; total += size; }
         }
@@ -80,6 +85,12 @@ int main(int argc, char **argv)
     for (int i = 0; i < ns; i++) th.emplace_back(one, i);
     for (auto &t : th) t.join();
     const double t1 = now();
+    if (trace)
+        for (int i = 0; i < n; i++) {
+            double last = 0, longest = 0, first = 1e30;
+            for (int k = 0; k < ns; k++) { const double r = ret_at[(size_t)k * (size_t)(n + 8) + (size_t)i], d = spent[(size_t)k * (size_t)(n + 8) + (size_t)i]; if (r > last) last = r; if (r < first) first = r; if (d > longest) longest = d; }
+            fprintf(stderr, "call %d: first session back at %.2f s, last at %.2f s, longest call %.2f s\n", i, first - t0, last - t0, longest);
+        }
     if (errors) { printf("{\"error\": \"%d sessions failed\"}\n", errors.load()); return 1; }
     double last_open = 0, last_coded = 0; long tot = 0;
     for (int i = 0; i < ns; i++) { if (opened[(size_t)i] > last_open) last_open = opened[(size_t)i]; if (coded[(size_t)i] > last_coded) last_coded = coded[(size_t)i]; tot += bytes[(size_t)i]; }

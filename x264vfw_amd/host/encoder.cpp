@@ -222,12 +222,27 @@ struct BatchGroup {
     std::vector<char> member, arrived; int joined = 0, active = 0, n_arrived = 0;
     std::vector<x264gpu_pic> pics; long round = 0; int round_rc = 0; std::string err;
     bool closed = false;          // a member left: no more joiners (batch_leave)
+    // X264GPU_BATCH_TIMING=1: where the members' threads spent their time, summed over members (printed when the group goes): waiting for a round's event,
+    // downloading records / levels, waiting for the next round's launch before the slices are written, writing them, waiting in batch_submit for the round to fill
+    std::atomic<long> t_us[6] = {};
+    std::vector<long> tl_launch, tl_done, tl_host;          // ... and per round: issued, its event seen, its results on the host (microseconds; the first launch = 0)
+    bool timing = getenv("X264GPU_BATCH_TIMING") != nullptr;
 };
+static inline long us_now() { return (long)std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 static std::mutex g_batch_mu;
 static std::vector<BatchGroup *> g_batch_groups;
 
 static void batch_destroy(BatchGroup *g)
 {
+    if (g->timing)
+        fprintf(stderr, "x264gpu batch timing, seconds summed over %d members: event wait %.1f, download %.1f, wait for the next launch %.1f, slices %.1f, submit wait %.1f, join of the helper %.1f\n", g->N,
+                g->t_us[0] / 1e6, g->t_us[1] / 1e6, g->t_us[2] / 1e6, g->t_us[3] / 1e6, g->t_us[4] / 1e6, g->t_us[5] / 1e6);
+    if (g->timing && !g->tl_launch.empty()) {
+        fprintf(stderr, "x264gpu batch rounds (s from the first launch): issued / event seen / results on the host:");
+        for (size_t i = 0; i < g->tl_launch.size(); i++)
+            fprintf(stderr, "  %zu: %.2f / %.2f / %.2f", i, (g->tl_launch[i] - g->tl_launch[0]) / 1e6, i < g->tl_done.size() ? (g->tl_done[i] - g->tl_launch[0]) / 1e6 : -1., i < g->tl_host.size() ? (g->tl_host[i] - g->tl_launch[0]) / 1e6 : -1.);
+        fprintf(stderr, "\n");
+    }
     if (g->gpu) x264gpu_encoder_destroy(g->gpu);
     if (g->d_in) x264gpu_free(g->d_in);
     if (g->d_mb) x264gpu_free(g->d_mb);
@@ -294,6 +309,7 @@ static void batch_run_round(BatchGroup *g, std::unique_lock<std::mutex> &lk)
             // queued, not awaited: the event behind the round is what its downloads wait for (batch_download)
             if (x264gpu_event_record(g->ev[second ? 1 : 0], g->cs) != X264GPU_OK) { g->round_rc = -1; g->err = x264gpu_last_error(); }
             g->launched++;
+            if (g->timing) g->tl_launch.push_back(us_now());
             g->ev_round[second ? 1 : 0] = g->round + 1;
         } else
         // overlap: the downloads run on the group's own stream, which does not wait for the default one: the round must be complete before anyone is told
@@ -323,6 +339,8 @@ static int batch_submit(BatchGroup *g, int s, const uint8_t *d_src, const x264gp
     g->pics[(size_t)s] = pic; g->arrived[(size_t)s] = 1; g->n_arrived++;
     const long my_round = g->round;
     *buf = g->overlap ? (int)(my_round & 1) : 0;
+    const long t0 = g->timing ? us_now() : 0;
+    struct Acc { BatchGroup *g; long t0; ~Acc() { if (g->timing) g->t_us[4] += us_now() - t0; } } acc{ g, t0 };
     if (g->n_arrived >= g->active && !g->running) batch_run_round(g, lk);
     else if (!g->cv.wait_for(lk, std::chrono::seconds(600), [&] { return g->round != my_round; })) {
         // a member neither submitted its picture nor closed: give up on this session (the others keep waiting for it, or for its close)
@@ -338,6 +356,7 @@ static int batch_download(BatchGroup *g, int s, int buf, x264gpu_mb *h_mb, int16
 {
     const x264gpu_mb *dm = buf ? g->d_mb2 : g->d_mb; const int16_t *dl = buf ? g->d_lv2 : g->d_lv;
     void *st = g->overlap ? g->dl_stream : nullptr;
+    const long t0 = g->timing ? us_now() : 0;
     if (g->async) {
         // ONE thread waits for the round's event, the other members sleep on the group's condition variable (2048 helper threads in hipEventSynchronize would
         // take the host's cores from the callers that are copying in and uploading the next pictures)
@@ -348,8 +367,10 @@ static int batch_download(BatchGroup *g, int s, int buf, x264gpu_mb *h_mb, int16
                 g->ev_waiting[buf ? 1 : 0] = true;
                 lk.unlock();
                 const bool ok = x264gpu_event_sync(g->ev[buf ? 1 : 0]) == X264GPU_OK;
+                const long t_ev = g->timing ? us_now() : 0;
                 const std::string e = ok ? std::string() : std::string(x264gpu_last_error());
                 lk.lock();
+                if (g->timing) { g->tl_done.push_back(t_ev); g->tl_host.push_back(us_now()); }
                 g->ev_waiting[buf ? 1 : 0] = false;
                 if (!ok) { g->ev_err = e; g->ev_done[buf ? 1 : 0] = want; g->cv.notify_all(); err = e; return -1; }
                 g->ev_done[buf ? 1 : 0] = want;
@@ -358,6 +379,8 @@ static int batch_download(BatchGroup *g, int s, int buf, x264gpu_mb *h_mb, int16
         }
         if (!g->ev_err.empty()) { err = g->ev_err; return -1; }
     }
+    const long t1 = g->timing ? us_now() : 0;
+    struct Acc { BatchGroup *g; long t0, t1; ~Acc() { if (g->timing) { g->t_us[0] += t1 - t0; g->t_us[1] += us_now() - t1; } } } acc{ g, t0, t1 };
     if (x264gpu_memcpy_d2h(h_mb, dm + (size_t)s * g->nmb, g->nmb * sizeof(x264gpu_mb), st) != X264GPU_OK ||
         x264gpu_memcpy_d2h(h_lv, dl + (size_t)s * g->nmb * X264GPU_MB_LEVELS, g->nmb * X264GPU_MB_LEVELS * sizeof(int16_t), st) != X264GPU_OK) { err = x264gpu_last_error(); return -1; }
     return 0;
@@ -2266,7 +2289,9 @@ static int publish_deferred(x264_t *h, x264_t::Deferred &d, x264_nal_t **pp_nal,
     if (d.th.joinable()) {
         d.hurry = true;
         if (h->batch) { std::lock_guard<std::mutex> lg(h->batch->m); h->batch->cv.notify_all(); }
+        const long t0 = h->batch && h->batch->timing ? us_now() : 0;
         d.th.join();
+        if (h->batch && h->batch->timing) h->batch->t_us[5] += us_now() - t0;
     }
     d.valid = false;
     if (!d.err.empty()) { xlog(&h->param, X264_LOG_ERROR, "x264_encoder_encode: download of a batched picture failed: %s\n", d.err.c_str()); h->failed = true; return -1; }
@@ -2414,13 +2439,16 @@ static int encode_bmode(x264_t *h, x264_nal_t **pp_nal, int *pi_nal, x264_pictur
         d.th = std::thread([&d, g, bidx, bbuf, sp, slices, threads, annexb, first, idr, dev, my_launched]() {
             x264gpu_set_device(dev);
             if (batch_download(g, bidx, bbuf, d.mb.data(), d.lv.data(), d.err)) return;
+            const long t0 = g->timing ? us_now() : 0;
             {
                 // the slices are written once the group's next round is on the device (the callers need the cores to get it there), or when the picture is asked for
                 std::unique_lock<std::mutex> lk(g->m);
                 g->cv.wait_for(lk, std::chrono::seconds(30), [&] { return g->launched > my_launched || d.hurry.load() || g->closed; });
             }
+            const long t1 = g->timing ? us_now() : 0;
             const size_t before = d.off.size();
             write_picture(d.out, &d.off, sp, slices, d.mb.data(), d.lv.data(), annexb, first, &d.stats, threads);
+            if (g->timing) { g->t_us[2] += t1 - t0; g->t_us[3] += us_now() - t1; }
             for (size_t i = before; i < d.off.size(); i++) d.types.push_back(idr ? 5 : 1);
         });
         d.valid = true;
