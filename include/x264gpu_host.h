@@ -49,6 +49,8 @@ int x264host_last_decision(x264_t *h, int *qp, int *scenecut, int32_t costs[4]);
 float x264host_last_qpm(x264_t *h);
 /* ... the second pass' plan (init_pass2): per picture of the statistics file, display order, the planned quantiser scale and the bits expected before it; returns the count */
 int x264host_pass2_plan(x264_t *h, double *new_qscale, double *expected_bits, int n);
+/* how many pictures of the session may be in flight on the device at once (launch contexts over the shared DPB; 1: one picture a call) */
+int x264host_pictures_in_flight(x264_t *h);
 /* reconstructed picture of the last encoded frame as I420 (host memory) */
 int x264host_get_recon(x264_t *h, uint8_t *i420_out);
 

@@ -1144,12 +1144,12 @@ def test_gop_slots_with_b_pictures_equal_serial(gpu, w, h, nfr, keyint, threads,
 
 
 @pytest.mark.parametrize("w,h,nfr,opts", [
-    (352, 288, 26, {"qp": 26, "keyint": 12, "no-scenecut": None, "b-adapt": 0}),                                          # medium as it is: P, Bref, b, b of a mini-GOP + the next P in flight
-    (176, 144, 31, {"crf": 23, "rc-lookahead": 10}),                                                                  # the driver's default rate control: tree offsets per picture, read while later decisions run
+    (352, 288, 26, {"qp": 26, "bframes": 3, "keyint": 12, "no-scenecut": None, "b-adapt": 0}),                           # medium as it is: P, Bref, b, b of a mini-GOP + the next P in flight
+    (176, 144, 31, {"crf": 23, "bframes": 3, "rc-lookahead": 10}),                                                    # the driver's default rate control: tree offsets per picture, read while later decisions run
     (176, 144, 22, {"qp": 25, "bframes": 2, "b-pyramid": "none", "ref": 3, "direct": "temporal", "b-adapt": 0}),      # temporal direct: the co-located picture's vectors come from a picture in flight
-    (128, 96, 25, {"crf": 24, "b-adapt": 2, "weightp": 2, "rc-lookahead": 6, "slices": 2, "keyint": 9, "min-keyint": 3}),
-    (64, 48, 3, {"qp": 27}),                                                                                          # fewer pictures than launch contexts
-    (1280, 720, 22, {"crf": 23}),                                                                                     # the driver's default session at a size where the pictures overlap for real (0.3 - 0.5 s each)
+    (128, 96, 25, {"crf": 24, "bframes": 3, "b-adapt": 2, "weightp": 2, "rc-lookahead": 6, "slices": 2, "keyint": 9, "min-keyint": 3}),
+    (64, 48, 3, {"qp": 27, "bframes": 3}),                                                                            # fewer pictures than launch contexts
+    (1280, 720, 22, {"crf": 23, "bframes": 3}),                                                                       # the driver's default session at a size where the pictures overlap for real (0.3 - 0.5 s each)
 ])
 def test_pictures_in_flight_equal_serial(gpu, w, h, nfr, opts):
     """Several pictures of ONE session in flight: launch contexts over the shared DPB on streams of their own, each picture behind the events
@@ -1165,6 +1165,8 @@ def test_pictures_in_flight_equal_serial(gpu, w, h, nfr, opts):
         finally:
             if old is None: os.environ.pop("X264GPU_INFLIGHT", None)
             else: os.environ["X264GPU_INFLIGHT"] = old
+        assert eff.i_bframe == opts["bframes"]
+        assert H.x264host_pictures_in_flight(h_) == (inflight if inflight > 1 else 1), "the path under test: that many launch contexts"
         pic, out = HL.Picture(), HL.Picture()
         assert H.x264_picture_alloc(C.byref(pic), HL.X264_CSP_I420, w, h) == 0
         nal, n = C.POINTER(HL.Nal)(), C.c_int()

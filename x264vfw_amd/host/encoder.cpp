@@ -3028,6 +3028,8 @@ int x264host_pass2_plan(x264_t *h, double *new_qscale, double *expected_bits, in
 /* tests: the float quantiser (x264 rc->qpm) the last coded picture's macroblock quantisers were rounded from; 0 = its integer quantiser */
 float x264host_last_qpm(x264_t *h) { return h ? h->last_qpm : 0.f; }
 
+int x264host_pictures_in_flight(x264_t *h) { return h ? h->inflight : 0; }
+
 int x264host_get_recon(x264_t *h, uint8_t *i420_out)
 {
     if (!h || !h->gpu) return -1;

@@ -111,6 +111,7 @@ _sig("x264host_write_headers_b", _i, [_i] * 6 + [C.c_uint32, C.c_uint32] + [_i] 
 PIC_IDR, PIC_I, PIC_P, PIC_BREF, PIC_B = range(5)
 _sig("x264host_last_decision", _i, [C.c_void_p, C.POINTER(_i), C.POINTER(_i), C.POINTER(C.c_int32)])
 _sig("x264host_last_qpm", C.c_float, [C.c_void_p])
+_sig("x264host_pictures_in_flight", C.c_int, [C.c_void_p])
 _sig("x264host_pass2_plan", _i, [C.c_void_p, C.c_void_p, C.c_void_p, _i])
 LEVELS = (Level * 21).in_dll(H, "x264_levels")
 
