@@ -45,6 +45,16 @@ TOOLSET_GAPS_NOB = "x264 medium minus: B-frames (bframes 3 -> 0), the fade analy
 TOOLSET_GAPS_NORD = "x264 medium minus: RD mode decision + psy-rd (subme 7 -> 5), trellis 1, the lookahead's decisions (b-adapt 1, fade weights, rate control); entropy coding runs on host threads and is outside `value`"
 
 
+
+def cpu_quota():
+    """CPUs of time the control group grants this process (cpu.max "quota period"), None when uncapped: the pool's GPU boxes show 256 hardware threads and grant 16 —
+    what `cpu_baseline.cores` processes and the host side of the e2e legs really share"""
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        return None if q == "max" else round(int(q) / int(per), 2)
+    except Exception:
+        return None
+
 def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -195,7 +205,7 @@ def cpu_baseline(args):
         return n * frames / max(secs), time.perf_counter() - t0
     f1, w1 = run(1, args.cpu_frames)
     fn, wn = run(ncpu, nall) if ncpu > 1 else (f1, w1)
-    return {"value": round(fn, 3), "unit": "frames/s", "cores": ncpu, "kind": "port",
+    return {"value": round(fn, 3), "unit": "frames/s", "cores": ncpu, "cpu_quota": cpu_quota(), "kind": "port",
             "value_1core": round(f1, 3),
             "sample": f"{args.width}x{args.height}, one GOP in coding order ({display_types(args.cpu_frames, args.bframes, args.cpu_frames)}), oracle/analyse.c + encoder.c: one process alone on {args.cpu_frames} frames ({w1:.1f} s wall), then {ncpu} processes side by side (of {os.cpu_count()} hardware threads), "
                       f"{ncpu} streams at once, {nall} frames each ({wn:.1f} s wall) — the builder's own CPU restatement, NOT x264",
@@ -599,7 +609,7 @@ def e2e_probe(args):
             run_sessions.detail["driver"] = "python threads (the C++ driver did not build or failed)"
     if args.e2e_legs != "all":
         return {"what": "x264_encoder_encode end to end, 1920x1080 (only the threads-1 and multi-session legs were asked for)", **one,
-                "multi_session_fps": fm, "multi_session_sessions": args.e2e_sessions, "multi_session_frames_each": n1, "multi_session_kB_per_frame": kbm, "multi_session_spans": getattr(run_sessions, "detail", None), "host_cores": os.cpu_count()}
+                "multi_session_fps": fm, "multi_session_sessions": args.e2e_sessions, "multi_session_frames_each": n1, "multi_session_kB_per_frame": kbm, "multi_session_spans": getattr(run_sessions, "detail", None), "host_cores": os.cpu_count(), "host_cpu_quota": cpu_quota()}
     # --threads G: 32 closed GOPs of the one stream in lock-step, medium's B pictures in every GOP (bframes 3, b-pyramid, weightb; b-adapt 0 and no scene cuts:
     # a fixed structure).  keyint 12 keeps the leg within the bench's minutes (a slot is one wavefront: ~0.5 pictures/s; keyint 250 x 32 slots would be 8000 pictures)
     G, K = 32, 12
@@ -623,7 +633,7 @@ def e2e_probe(args):
             "slices_per_row_fps": fr, "slices_per_row_slices": nr, "slices_per_row_delay_frames": d_rows, "slices_per_row_kB_per_frame": kbr,
             "slices_per_row_threads32_fps": frg, "slices_per_row_threads32_delay_frames": (G - 1) * K + 1,
             "threads32_fps": fg, "threads32_frames": G * K, "threads32_keyint": K, "threads32_bframes": 3, "threads32_delay_frames": d_thr, "threads32_kB_per_frame": kbg,
-            "host_cores": os.cpu_count()}
+            "host_cores": os.cpu_count(), "host_cpu_quota": cpu_quota()}
 
 
 def main():

@@ -313,6 +313,14 @@ int  x264gpu_encode_frames(x264gpu_encoder *enc, const uint8_t *d_i420, int slic
  * session with RD (cfg.cabac, cfg.rd).  x264gpu_encode_frames is this call with the sliding-window DPB of an I / P stream. */
 int  x264gpu_encode_pictures(x264gpu_encoder *enc, const uint8_t *d_i420, const x264gpu_pic *pics,
                              x264gpu_mb *d_mb, int16_t *d_levels, void *stream);
+/* The levels of a call, packed IN PLACE for the trip to the host: of every macroblock's X264GPU_MB_LEVELS levels only the groups of 16 that hold a non-zero one stay,
+ * one behind the other from the start of the stream's array (a P picture at medium keeps ~10 % of the bytes, a B picture ~3 %, an I picture ~25 %).
+ * d_index[streams][mb_count] tells where: `at` = the macroblock's first kept group, counted in groups from the start of the stream's array; bit g of `groups` = levels
+ * [16 g, 16 g + 16) are kept (the kept groups follow each other in g order).  The bytes of stream s that matter are its first (at + popcount(groups)) x 32 of the
+ * last macroblock.  The host's slice writers take the pair (host/slice.cpp LevelSource).  x264_macroblock_write_* of [x264-upstream] reads h->dct the same way:
+ * what was not coded is not looked at. */
+typedef struct x264gpu_level_index { uint32_t at, groups; } x264gpu_level_index;
+int  x264gpu_pack_levels(int16_t *d_levels, int streams, int mb_count, x264gpu_level_index *d_index, uint32_t *d_kept /* [streams]: groups kept per stream, or NULL */, void *stream);
 /* A9 as a primitive ([x264-upstream] common/deblock.c x264_frame_deblock_row over a whole picture): the in-loop filter alone on
  * `streams` given pictures (d_i420: I420, width and height multiples of 16) with given macroblock records, through the kernel the
  * frame pipeline launches; alpha / beta / chroma-qp offsets from the encoder's configuration.  d_out: the filtered pictures. */

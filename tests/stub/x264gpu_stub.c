@@ -86,6 +86,25 @@ int x264gpu_encoder_create_view(x264gpu_encoder **out, x264gpu_encoder *parent)
     *out = g;
     return X264GPU_OK;
 }
+/* the levels packed in place (include/x264gpu.h): plain C, macroblock by macroblock */
+int x264gpu_pack_levels(int16_t *lv, int streams, int nmb, x264gpu_level_index *index, uint32_t *kept, void *st)
+{
+    if (!lv || !index || streams < 1 || nmb < 1) return fail("pack_levels arguments");
+    for (int s = 0; s < streams; s++) {
+        int16_t *base = lv + (size_t)s * nmb * X264GPU_MB_LEVELS;
+        uint32_t at = 0;
+        for (int i = 0; i < nmb; i++) {
+            int16_t mb[X264GPU_MB_LEVELS];
+            memcpy(mb, base + (size_t)i * X264GPU_MB_LEVELS, sizeof(mb));
+            uint32_t groups = 0;
+            for (int g = 0; g < X264GPU_MB_LEVELS / 16; g++) for (int k = 0; k < 16; k++) if (mb[g * 16 + k]) { groups |= 1u << g; break; }
+            index[(size_t)s * nmb + i].at = at; index[(size_t)s * nmb + i].groups = groups;
+            for (int g = 0; g < X264GPU_MB_LEVELS / 16; g++) if (groups >> g & 1) { memcpy(base + (size_t)at * 16, mb + g * 16, 32); at++; }
+        }
+        if (kept) kept[s] = at;
+    }
+    return X264GPU_OK;
+}
 int x264gpu_stream_wait_event(void *st, void *ev) { return ev ? X264GPU_OK : fail("stream_wait_event: null"); }
 void x264gpu_encoder_destroy(x264gpu_encoder *g)
 {

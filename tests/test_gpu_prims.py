@@ -396,3 +396,43 @@ def test_cabac_level_walk_primitive_vs_serial_restatement(gpu):
     badr = np.nonzero((got_r != r_want).any(axis=1) | (got_r8 != r8_want).any(axis=1))[0]
     assert len(badr) == 0, f"context variables differ in {len(badr)} of {n} cases; first {badr[0]}: what {what[badr[0]].tolist()}"
     assert bits_want.max() > 100000 and (what[:, 0] == 5).sum() > 100
+
+
+@pytest.mark.parametrize("streams,nmb,density", [(3, 396, 0.05), (2, 8160, 0.02), (5, 17, 0.0), (1, 99, 1.0), (4, 120, 0.5)])
+def test_pack_levels_in_place_vs_numpy(gpu, streams, nmb, density):
+    """x264gpu_pack_levels (one wavefront a stream, in place): the groups of 16 levels that hold a non-zero one, one behind the other in macroblock and group order,
+    and the index that finds them — against a numpy restatement; empty pictures, dense ones (nothing moves), 1080p's macroblock count; host/host.hpp mb_levels is the
+    inverse (tests/test_host_cpu.py packs through the stub and decodes the streams)"""
+    import torch
+    lib = gpu
+    L = 416
+    rng = np.random.default_rng(7 * streams + nmb)
+    lv = np.zeros((streams, nmb, L // 16, 16), np.int16)
+    on = rng.random((streams, nmb, L // 16)) < density
+    vals = rng.integers(-300, 300, lv.shape).astype(np.int16)
+    vals[vals == 0] = 1
+    sparse = rng.random(lv.shape) < 0.3          # a kept group holds a few non-zero levels, not sixteen
+    lv[on] = (vals * sparse)[on]
+    lv[on, 5] |= 1                                # ... at least one
+    want_ix = np.zeros((streams, nmb, 2), np.uint32)
+    want_lv = []
+    for s in range(streams):
+        at, out = 0, []
+        for i in range(nmb):
+            g = np.nonzero(lv[s, i].any(axis=1))[0]
+            want_ix[s, i] = (at, sum(1 << int(k) for k in g))
+            out += [lv[s, i, k] for k in g]
+            at += len(g)
+        want_lv.append(np.array(out, np.int16).reshape(-1))
+    d_lv = torch.from_numpy(lv.reshape(-1).copy()).cuda()
+    d_ix = torch.zeros(streams * nmb * 2, dtype=torch.int32, device="cuda")
+    d_kept = torch.zeros(streams, dtype=torch.int32, device="cuda")
+    lib.check(lib.x264gpu_pack_levels(d_lv.data_ptr(), streams, nmb, d_ix.data_ptr(), d_kept.data_ptr(), None), "pack_levels")
+    torch.cuda.synchronize()
+    assert d_kept.cpu().numpy().tolist() == [len(x) // 16 for x in want_lv]
+    got_ix = d_ix.cpu().numpy().view(np.uint32).reshape(streams, nmb, 2)
+    got_lv = d_lv.cpu().numpy().reshape(streams, -1)
+    assert np.array_equal(got_ix, want_ix)
+    for s in range(streams):
+        assert np.array_equal(got_lv[s, :len(want_lv[s])], want_lv[s]), s
+    assert density == 0.0 or sum(len(x) for x in want_lv) > 0

@@ -385,6 +385,37 @@ __global__ void k_slice_priors(EncK k, int streams, int guess)
 
 }  // extern "C"
 
+// x264gpu_pack_levels: one wavefront per stream walks its macroblocks in order; lane l < LEVELS / 8 holds 8 levels (16 bytes) of the macroblock, two lanes a group.
+// In place: the packed position of a group is never beyond its own, and a macroblock is read before anything is written at or beyond its start.
+__global__ __launch_bounds__(64) void k_pack_levels(int16_t *lv, x264gpu_level_index *index, uint32_t *kept, int nmb)
+{
+    constexpr int Q = X264GPU_MB_LEVELS / 8;          // 16-byte quads a macroblock (52)
+    static_assert(X264GPU_MB_LEVELS % 16 == 0 && Q <= 64, "two lanes a group of 16 levels");
+    const int s = blockIdx.x, lane = threadIdx.x;
+    uint4 *base = reinterpret_cast<uint4 *>(lv + (size_t)s * nmb * X264GPU_MB_LEVELS);
+    x264gpu_level_index *ix = index + (size_t)s * nmb;
+    unsigned at = 0;          // groups kept so far
+    uint4 nxt = lane < Q && nmb > 0 ? base[lane] : make_uint4(0, 0, 0, 0);
+    for (int i = 0; i < nmb; i++) {
+        const uint4 v = nxt;
+        if (i + 1 < nmb && lane < Q) nxt = base[(size_t)(i + 1) * Q + lane];          // (the next macroblock's quads are read before this one's are written: they may land there)
+        const unsigned long long nzq = __ballot((v.x | v.y | v.z | v.w) != 0);
+        const unsigned groups = (unsigned)__ballot(lane < Q / 2 && ((nzq >> (2 * lane)) & 3));
+        if (lane < Q && (groups >> (lane >> 1) & 1)) base[(size_t)(at + __popc(groups & ((1u << (lane >> 1)) - 1u))) * 2 + (lane & 1)] = v;
+        if (lane == 0) { ix[i].at = at; ix[i].groups = groups; }
+        at += __popc(groups);
+    }
+    if (kept && lane == 0) kept[s] = at;
+}
+
+extern "C" int x264gpu_pack_levels(int16_t *d_levels, int streams, int mb_count, x264gpu_level_index *d_index, uint32_t *d_kept, void *stream)
+{
+    if (!d_levels || !d_index || streams < 1 || mb_count < 1) return set_err(X264GPU_EINVAL, "x264gpu_pack_levels", hipSuccess);
+    hipLaunchKernelGGL(k_pack_levels, dim3(streams), dim3(64), 0, (hipStream_t)stream, d_levels, d_index, d_kept, mb_count);
+    HIP_TRY(hipGetLastError());
+    return X264GPU_OK;
+}
+
 // what a later B picture's spatial direct prediction reads of this picture when it heads that picture's list 1 (x264 frame->ref[] / mv[] of the
 // co-located macroblock): per 8x8 block the reference index it used — list 0's, else list 1's, -1 for intra — and that vector
 __global__ void k_col_from_records(EncK k)

@@ -157,11 +157,11 @@ struct x264_t {
     // cross-session batcher (X264GPU_BATCH=N): N sessions of equal geometry and toolset share ONE device encoder with N streams; the pictures
     // they submit are coded in one lock-step launch, every session entropy-codes its own stream on its caller's thread
     struct BatchGroup *batch = nullptr; int batch_idx = -1, batch_n = 0;
-    void *up_stream = nullptr;           // a batch session's own upload stream (async groups): its pictures go up while the group's round runs on the compute stream
+    void *up_stream = nullptr;           // a batch session's upload stream (one of the group's, async groups): its pictures go up while the group's round runs on the compute stream
     // batch sessions with overlap (BatchGroup::overlap): the picture just submitted is downloaded and entropy-coded by a helper thread while the group's next round runs;
     // its NAL units leave with the NEXT call (one picture of delay).  Two slots used in turn: the one being filled, the one waiting to be handed out
     struct Deferred { std::thread th; bool valid = false; std::atomic<bool> hurry{ false }; std::string err; std::vector<uint8_t> out; std::vector<size_t> off; std::vector<int> types; int nal_ref_idc = 0;
-                      std::vector<x264gpu_mb> mb; std::vector<int16_t> lv; SliceStats stats = { 0 };
+                      std::vector<x264gpu_mb> mb; std::vector<x264gpu_level_index> ix; std::unique_ptr<int16_t[]> lv; SliceStats stats = { 0 };      // (lv: never cleared — what is downloaded is what is read)
                       int i_type = 0, b_keyframe = 0; int64_t pts = 0, dts = 0; x264_image_t img;
                       int qp = 0, scenecut = 0; float qpm = 0.f; int32_t costs[4] = { 0, 0, 0, 0 }; };      // the decision hooks' values of THIS picture (x264host_last_decision / _last_qpm)
     Deferred defer[2]; int defer_cur = 0;
@@ -213,6 +213,10 @@ struct BatchGroup {
     // ... and (async) the callers do not wait for the round either: it is QUEUED on the group's own compute stream behind the round before, an event behind it tells the
     // download of its results when it is done; the callers go on to copy in and upload their next pictures (on upload streams of their own) while the device works
     bool async = false; void *cs = nullptr, *ev[2] = { nullptr, nullptr };
+    // the levels leave the device packed (x264gpu_pack_levels behind every round, in place): a member downloads its records, its index and the part of its levels that is kept
+    // (~10 % at medium; dense, 2048 members x 7 MB a round were what the first rounds waited for: fresh pages of the download buffers, 15 GB a round over the link)
+    bool pack = false; x264gpu_level_index *d_ix = nullptr, *d_ix2 = nullptr;
+    std::vector<void *> up_streams;          // the members' uploads: a handful of streams dealt round-robin (a stream per member was 0.7 ms to create and 0.6 ms to destroy, x 2048, serialised in the runtime)
     long ev_round[2] = { 0, 0 }, ev_done[2] = { 0, 0 }; bool ev_waiting[2] = { false, false }; std::string ev_err;      // per buffer pair: the round recorded behind it (1-based), the last one known complete, a member is waiting for the event
     long launched = 0;            // rounds whose kernels have been issued: the helper threads start entropy coding round k once round k + 1 is on the device (or when asked to hurry),
                                   // so that the host cores are the callers' while the next pictures are uploaded and submitted
@@ -225,6 +229,7 @@ struct BatchGroup {
     // X264GPU_BATCH_TIMING=1: where the members' threads spent their time, summed over members (printed when the group goes): waiting for a round's event,
     // downloading records / levels, waiting for the next round's launch before the slices are written, writing them, waiting in batch_submit for the round to fill
     std::atomic<long> t_us[6] = {};
+    std::atomic<long> r_dl[64] = {}, r_sl[64] = {}, r_dl_first[64] = {}, r_dl_last[64] = {};          // per round: download / slice seconds summed over the members; when the first / last download ended
     std::vector<long> tl_launch, tl_done, tl_host;          // ... and per round: issued, its event seen, its results on the host (microseconds; the first launch = 0)
     bool timing = getenv("X264GPU_BATCH_TIMING") != nullptr;
 };
@@ -242,6 +247,10 @@ static void batch_destroy(BatchGroup *g)
         for (size_t i = 0; i < g->tl_launch.size(); i++)
             fprintf(stderr, "  %zu: %.2f / %.2f / %.2f", i, (g->tl_launch[i] - g->tl_launch[0]) / 1e6, i < g->tl_done.size() ? (g->tl_done[i] - g->tl_launch[0]) / 1e6 : -1., i < g->tl_host.size() ? (g->tl_host[i] - g->tl_launch[0]) / 1e6 : -1.);
         fprintf(stderr, "\n");
+        fprintf(stderr, "x264gpu batch rounds: download s per member / slices s per member / first .. last download done (s from the first launch):");
+        for (size_t i = 0; i < g->tl_launch.size() && i < 64; i++)
+            fprintf(stderr, "  %zu: %.2f / %.2f / %.2f .. %.2f", i, g->r_dl[i] / 1e6 / g->N, g->r_sl[i] / 1e6 / g->N, (g->r_dl_first[i] - g->tl_launch[0]) / 1e6, (g->r_dl_last[i] - g->tl_launch[0]) / 1e6);
+        fprintf(stderr, "\n");
     }
     if (g->gpu) x264gpu_encoder_destroy(g->gpu);
     if (g->d_in) x264gpu_free(g->d_in);
@@ -249,8 +258,11 @@ static void batch_destroy(BatchGroup *g)
     if (g->d_lv) x264gpu_free(g->d_lv);
     if (g->d_mb2) x264gpu_free(g->d_mb2);
     if (g->d_lv2) x264gpu_free(g->d_lv2);
+    if (g->d_ix) x264gpu_free(g->d_ix);
+    if (g->d_ix2) x264gpu_free(g->d_ix2);
     if (g->cs) x264gpu_stream_sync(g->cs);
     if (g->dl_stream) x264gpu_stream_destroy(g->dl_stream);
+    for (void *st : g->up_streams) { x264gpu_stream_sync(st); x264gpu_stream_destroy(st); }
     for (int i = 0; i < 2; i++) if (g->ev[i]) x264gpu_event_destroy(g->ev[i]);
     if (g->cs) x264gpu_stream_destroy(g->cs);
     delete g;
@@ -285,6 +297,9 @@ static BatchGroup *batch_join(const x264gpu_config &cfg1, int N, size_t insz, si
             x264gpu_malloc((void **)&g->d_lv2, (size_t)N * nmb * X264GPU_MB_LEVELS * sizeof(int16_t)) == X264GPU_OK && x264gpu_stream_create(&g->dl_stream) == X264GPU_OK) g->overlap = true;
         const char *ae = getenv("X264GPU_BATCH_ASYNC");
         if (g->overlap && !(ae && ae[0] == '0') && x264gpu_stream_create(&g->cs) == X264GPU_OK && x264gpu_event_create(&g->ev[0]) == X264GPU_OK && x264gpu_event_create(&g->ev[1]) == X264GPU_OK) g->async = true;
+        if (g->async && !getenv("X264GPU_BATCH_DENSE") && x264gpu_malloc((void **)&g->d_ix, (size_t)N * nmb * sizeof(x264gpu_level_index)) == X264GPU_OK &&
+            x264gpu_malloc((void **)&g->d_ix2, (size_t)N * nmb * sizeof(x264gpu_level_index)) == X264GPU_OK) g->pack = true;
+        if (g->async) for (int i = 0; i < 16 && i < N; i++) { void *st = nullptr; if (x264gpu_stream_create(&st) == X264GPU_OK) g->up_streams.push_back(st); else break; }
     }
     g->joined = 1; g->active = 1; g->member[0] = 1; *idx = 0;
     g_batch_groups.push_back(g);
@@ -305,6 +320,7 @@ static void batch_run_round(BatchGroup *g, std::unique_lock<std::mutex> &lk)
         }
         const bool second = g->overlap && (g->round & 1);          // the output buffers of this round (the other pair may still be downloading)
         if (!g->round_rc && x264gpu_encode_pictures(g->gpu, g->d_in, g->pics.data(), second ? g->d_mb2 : g->d_mb, second ? g->d_lv2 : g->d_lv, g->async ? g->cs : nullptr) != X264GPU_OK) { g->round_rc = -1; g->err = x264gpu_last_error(); }
+        if (!g->round_rc && g->pack && x264gpu_pack_levels(second ? g->d_lv2 : g->d_lv, g->N, (int)g->nmb, second ? g->d_ix2 : g->d_ix, nullptr, g->cs) != X264GPU_OK) { g->round_rc = -1; g->err = x264gpu_last_error(); }
         if (!g->round_rc && g->async) {
             // queued, not awaited: the event behind the round is what its downloads wait for (batch_download)
             if (x264gpu_event_record(g->ev[second ? 1 : 0], g->cs) != X264GPU_OK) { g->round_rc = -1; g->err = x264gpu_last_error(); }
@@ -352,10 +368,12 @@ static int batch_submit(BatchGroup *g, int s, const uint8_t *d_src, const x264gp
     return 0;
 }
 // stream s' records and levels of the round whose results lie in buffer pair `buf`
-static int batch_download(BatchGroup *g, int s, int buf, x264gpu_mb *h_mb, int16_t *h_lv, std::string &err)
+// (h_ix: the group packs its levels — the member's index; h_lv then receives only the kept groups)
+static int batch_download(BatchGroup *g, int s, int buf, x264gpu_mb *h_mb, int16_t *h_lv, std::string &err, x264gpu_level_index *h_ix = nullptr)
 {
     const x264gpu_mb *dm = buf ? g->d_mb2 : g->d_mb; const int16_t *dl = buf ? g->d_lv2 : g->d_lv;
-    void *st = g->overlap ? g->dl_stream : nullptr;
+    // (async groups: the members' downloads are dealt to the group's upload / download streams — thousands of threads that copy and wait on ONE stream wake each other)
+    void *st = g->overlap ? (g->up_streams.empty() || getenv("X264GPU_BATCH_ONE_DL") ? g->dl_stream : g->up_streams[(size_t)s % g->up_streams.size()]) : nullptr;
     const long t0 = g->timing ? us_now() : 0;
     if (g->async) {
         // ONE thread waits for the round's event, the other members sleep on the group's condition variable (2048 helper threads in hipEventSynchronize would
@@ -380,7 +398,19 @@ static int batch_download(BatchGroup *g, int s, int buf, x264gpu_mb *h_mb, int16
         if (!g->ev_err.empty()) { err = g->ev_err; return -1; }
     }
     const long t1 = g->timing ? us_now() : 0;
-    struct Acc { BatchGroup *g; long t0, t1; ~Acc() { if (g->timing) { g->t_us[0] += t1 - t0; g->t_us[1] += us_now() - t1; } } } acc{ g, t0, t1 };
+    const long rnd = g->async ? g->ev_round[buf ? 1 : 0] - 1 : 0;
+    struct Acc { BatchGroup *g; long t0, t1, rnd; ~Acc() { if (g->timing) { const long t2 = us_now(); g->t_us[0] += t1 - t0; g->t_us[1] += t2 - t1;
+        if (rnd >= 0 && rnd < 64) { g->r_dl[rnd] += t2 - t1; long f = g->r_dl_first[rnd].load(); while ((f == 0 || t2 < f) && !g->r_dl_first[rnd].compare_exchange_weak(f, t2)) {} long l = g->r_dl_last[rnd].load(); while (t2 > l && !g->r_dl_last[rnd].compare_exchange_weak(l, t2)) {} } } } } acc{ g, t0, t1, rnd };
+    if (g->pack) {
+        if (!h_ix) { err = "X264GPU_BATCH: the group's levels are packed"; return -1; }
+        const x264gpu_level_index *di = (buf ? g->d_ix2 : g->d_ix) + (size_t)s * g->nmb;
+        if (x264gpu_memcpy_d2h(h_mb, dm + (size_t)s * g->nmb, g->nmb * sizeof(x264gpu_mb), st) != X264GPU_OK ||
+            x264gpu_memcpy_d2h(h_ix, di, g->nmb * sizeof(x264gpu_level_index), st) != X264GPU_OK) { err = x264gpu_last_error(); return -1; }
+        const size_t kept = ((size_t)h_ix[g->nmb - 1].at + (size_t)__builtin_popcount(h_ix[g->nmb - 1].groups)) * 16;          // levels
+        if (kept > g->nmb * (size_t)X264GPU_MB_LEVELS) { err = "X264GPU_BATCH: level index out of range"; return -1; }
+        if (kept && x264gpu_memcpy_d2h(h_lv, dl + (size_t)s * g->nmb * X264GPU_MB_LEVELS, kept * sizeof(int16_t), st) != X264GPU_OK) { err = x264gpu_last_error(); return -1; }
+        return 0;
+    }
     if (x264gpu_memcpy_d2h(h_mb, dm + (size_t)s * g->nmb, g->nmb * sizeof(x264gpu_mb), st) != X264GPU_OK ||
         x264gpu_memcpy_d2h(h_lv, dl + (size_t)s * g->nmb * X264GPU_MB_LEVELS, g->nmb * X264GPU_MB_LEVELS * sizeof(int16_t), st) != X264GPU_OK) { err = x264gpu_last_error(); return -1; }
     return 0;
@@ -848,7 +878,7 @@ x264_t *x264_encoder_open(x264_param_t *param)
     } else if (ok_setup && h->batch_n) {
         h->batch = batch_join(cfg, h->batch_n, insz, (size_t)h->nmb, &h->batch_idx);
         ok_setup = h->batch != nullptr;
-        if (ok_setup && h->batch->async && x264gpu_stream_create(&h->up_stream) != X264GPU_OK) h->up_stream = nullptr;      // (without it the uploads wait on the default stream: slower, not wrong)
+        if (ok_setup && h->batch->async && !h->batch->up_streams.empty()) h->up_stream = h->batch->up_streams[(size_t)h->batch_idx % h->batch->up_streams.size()];      // (the group's; without one the uploads wait on the default stream: slower, not wrong)
         if (ok_setup) xlog(&p, X264_LOG_INFO, "X264GPU_BATCH: stream %d of a batch of %d sessions%s\n", h->batch_idx, h->batch_n, h->batch->async ? " (rounds queued: uploads overlap the device)" : "");
     } else if (ok_setup) {
         ok_setup = x264gpu_encoder_create(&h->gpu, &cfg) == X264GPU_OK &&
@@ -988,7 +1018,9 @@ x264_t *x264_encoder_open(x264_param_t *param)
                 p.rc.i_rc_method == X264_RC_ABR ? "abr" : p.rc.i_rc_method == X264_RC_CRF ? "crf" : "cqp");
     }
     { const unsigned hw = std::thread::hardware_concurrency(); h->cavlc_threads = h->G > 1 ? 1 : cavlc_threads_default(hw >= 32 ? 16 : hw >= 16 ? 8 : hw >= 4 ? (int)hw / 2 : 1); }
-    h->h_in.resize(insz); h->h_mb.resize((size_t)h->G * h->nmb); h->h_lv.resize((size_t)h->G * h->nmb * X264GPU_MB_LEVELS);
+    h->h_in.resize(insz);
+    // (a batch session whose pictures are downloaded and coded by its helper threads keeps the records in the two deferred slots instead: 7 MB less to clear per open)
+    if (!(h->batch && h->batch->overlap)) { h->h_mb.resize((size_t)h->G * h->nmb); h->h_lv.resize((size_t)h->G * h->nmb * X264GPU_MB_LEVELS); }
     if (h->pipeline) { h->h_mb2.resize(h->h_mb.size()); h->h_lv2.resize(h->h_lv.size()); }
     if (h->G > 1) {
         const size_t n = (size_t)h->G * h->keyint;
@@ -2417,7 +2449,10 @@ static int encode_bmode(x264_t *h, x264_nal_t **pp_nal, int *pi_nal, x264_pictur
         x264_t::Deferred &d = h->defer[h->defer_cur];
         if (d.th.joinable()) d.th.join();          // (handed out two calls ago: long finished)
         d.out = h->out; d.off = h->nal_off; d.types = types; d.err.clear(); d.nal_ref_idc = plan.nal_ref_idc; d.stats = SliceStats{ 0 };
-        d.mb.resize((size_t)h->nmb); d.lv.resize((size_t)h->nmb * X264GPU_MB_LEVELS);
+        d.mb.resize((size_t)h->nmb);
+        if (h->batch->pack) d.ix.resize((size_t)h->nmb);
+        if (!d.lv) d.lv.reset(new (std::nothrow) int16_t[(size_t)h->nmb * X264GPU_MB_LEVELS]);
+        if (!d.lv) { xlog(&p, X264_LOG_ERROR, "x264_encoder_encode: out of memory (download buffers)\n"); h->failed = true; return -1; }
         d.i_type = idr ? X264_TYPE_IDR : pl.type == PIC_I ? X264_TYPE_I : pl.type == PIC_P ? X264_TYPE_P : pl.type == PIC_BREF ? X264_TYPE_BREF : X264_TYPE_B;
         d.b_keyframe = idr; d.pts = pl.e.pts; d.img = pl.e.img;
         d.qp = pic.qp; d.qpm = pic.qpm; d.scenecut = pl.e.scenecut; memcpy(d.costs, pl.e.costs, sizeof(d.costs));
@@ -2438,7 +2473,8 @@ static int encode_bmode(x264_t *h, x264_nal_t **pp_nal, int *pi_nal, x264_pictur
         d.hurry = false;
         d.th = std::thread([&d, g, bidx, bbuf, sp, slices, threads, annexb, first, idr, dev, my_launched]() {
             x264gpu_set_device(dev);
-            if (batch_download(g, bidx, bbuf, d.mb.data(), d.lv.data(), d.err)) return;
+            x264gpu_level_index *ix = d.ix.empty() ? nullptr : d.ix.data();
+            if (batch_download(g, bidx, bbuf, d.mb.data(), d.lv.get(), d.err, ix)) return;
             const long t0 = g->timing ? us_now() : 0;
             {
                 // the slices are written once the group's next round is on the device (the callers need the cores to get it there), or when the picture is asked for
@@ -2447,8 +2483,8 @@ static int encode_bmode(x264_t *h, x264_nal_t **pp_nal, int *pi_nal, x264_pictur
             }
             const long t1 = g->timing ? us_now() : 0;
             const size_t before = d.off.size();
-            write_picture(d.out, &d.off, sp, slices, d.mb.data(), d.lv.data(), annexb, first, &d.stats, threads);
-            if (g->timing) { g->t_us[2] += t1 - t0; g->t_us[3] += us_now() - t1; }
+            write_picture(d.out, &d.off, sp, slices, d.mb.data(), d.lv.get(), annexb, first, &d.stats, threads, ix);
+            if (g->timing) { const long t2 = us_now(); g->t_us[2] += t1 - t0; g->t_us[3] += t2 - t1; if (my_launched >= 1 && my_launched <= 64) g->r_sl[my_launched - 1] += t2 - t1; }
             for (size_t i = before; i < d.off.size(); i++) d.types.push_back(idr ? 5 : 1);
         });
         d.valid = true;
@@ -2803,7 +2839,7 @@ void x264_encoder_close(x264_t *h)
     h->lctx.clear();
     if (h->ev_la) x264gpu_event_destroy(h->ev_la);
     if (h->batch) { batch_leave(h->batch, h->batch_idx); h->batch = nullptr; }
-    if (h->up_stream) { x264gpu_stream_destroy(h->up_stream); h->up_stream = nullptr; }
+    h->up_stream = nullptr;          // (the batch group's)
     if (h->gpu) x264gpu_encoder_destroy(h->gpu);
     if (h->d_in) x264gpu_free(h->d_in);
     if (h->d_mb) x264gpu_free(h->d_mb);

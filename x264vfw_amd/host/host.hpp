@@ -3,6 +3,7 @@
 #include "../../include/x264.h"
 #include "../../include/x264gpu.h"
 #include "bitstream.hpp"
+#include <string.h>
 #include <vector>
 
 namespace x264host {
@@ -60,14 +61,24 @@ void write_sps(std::vector<uint8_t> &out, const SpsParams &s, bool annexb);
 void write_pps(std::vector<uint8_t> &out, const PpsParams &p, bool annexb);
 void write_sei_version(std::vector<uint8_t> &out, const char *text, bool annexb);
 void write_slice_header(BitWriter &bw, const SliceParams &p);
+// the levels of macroblock i: levels + i * X264GPU_MB_LEVELS, or — index != nullptr: the device packed them (x264gpu_pack_levels) — its kept groups of 16 spread out
+// into `scratch` (X264GPU_MB_LEVELS zeros first)
+inline const int16_t *mb_levels(const int16_t *levels, const x264gpu_level_index *index, size_t i, int16_t *scratch)
+{
+    if (!index) return levels + i * X264GPU_MB_LEVELS;
+    memset(scratch, 0, X264GPU_MB_LEVELS * sizeof(int16_t));
+    const int16_t *src = levels + (size_t)index[i].at * 16;
+    for (uint32_t g = index[i].groups; g; g &= g - 1, src += 16) memcpy(scratch + 16 * __builtin_ctz(g), src, 32);
+    return scratch;
+}
 void write_slice(std::vector<uint8_t> &out, const SliceParams &p, const x264gpu_mb *mbs, const int16_t *levels,
-                 bool annexb, bool long_startcode, SliceStats *stats, int threads = 1);
+                 bool annexb, bool long_startcode, SliceStats *stats, int threads = 1, const x264gpu_level_index *index = nullptr);
 int slice_first_row(int mbh, int i, int n);
 void write_picture(std::vector<uint8_t> &out, std::vector<size_t> *offs, const SliceParams &p, int slices, const x264gpu_mb *mbs, const int16_t *levels,
-                   bool annexb, bool long_startcode_first, SliceStats *stats, int threads = 1);
+                   bool annexb, bool long_startcode_first, SliceStats *stats, int threads = 1, const x264gpu_level_index *index = nullptr);
 // cabac.cpp: the same slice with CABAC slice data (write_slice dispatches on p.cabac)
 void write_slice_cabac(std::vector<uint8_t> &out, const SliceParams &p, const x264gpu_mb *mbs, const int16_t *levels,
-                       bool annexb, bool long_startcode, SliceStats *stats);
+                       bool annexb, bool long_startcode, SliceStats *stats, const x264gpu_level_index *index = nullptr);
 
 // ---- file output (muxers.cpp): the reference's cli_output_t (output/output.h: open_file / set_param / write_headers / write_frame / close_file) ----
 class Muxer {

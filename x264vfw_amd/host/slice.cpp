@@ -22,6 +22,7 @@ struct SliceCtx {
     const SliceParams &p;
     const x264gpu_mb *mbs;
     const int16_t *levels;
+    const x264gpu_level_index *index;          // the levels are packed (host.hpp mb_levels), or nullptr
     BitWriter &bw;
     uint8_t *tc;                  // total_coeff per block: [mb][24] (16 luma by block index, 4 U, 4 V); skip/absent = 0.  Filled for the
                                   // WHOLE picture before any row is coded (it depends on the macroblock's own levels only), so that
@@ -319,6 +320,7 @@ struct SliceCtx {
 
     // Codes rows [row0, row1).  In P slices the bits start at the first coded macroblock's mb_type: the mb_skip_run in front of it
     // (lead_skip + whatever the previous band left pending) is written by the caller that stitches the bands together.
+    int16_t lvbuf[X264GPU_MB_LEVELS];
     void run()
     {
         int skip_run = 0;
@@ -327,7 +329,7 @@ struct SliceCtx {
             for (int mbx = 0; mbx < p.mbw; mbx++) {
                 int i = mby * p.mbw + mbx;
                 const x264gpu_mb &m = mbs[i];
-                const int16_t *lv = levels + (size_t)i * X264GPU_MB_LEVELS;
+                const int16_t *lv = mb_levels(levels, index, (size_t)i, lvbuf);
                 cur_mb = i; done8 = 0;
                 if (p.slice_type == X264GPU_SLICE_I) write_mb_intra(mbx, mby, m, lv, 0);
                 else if (is_intra(m)) { flush_run(); write_mb_intra(mbx, mby, m, lv, p.slice_type == X264GPU_SLICE_B ? 23 : 5); }
@@ -438,14 +440,14 @@ void write_slice_header(BitWriter &bw, const SliceParams &p)
 // stitching below carries over; nC contexts come from the precomputed total_coeff table, predictors from the records), then
 // their bit strings are concatenated behind the slice header.  The bytes do not depend on the number of threads.
 void write_slice(std::vector<uint8_t> &out, const SliceParams &p_in, const x264gpu_mb *mbs, const int16_t *levels,
-                 bool annexb, bool long_startcode, SliceStats *stats, int threads)
+                 bool annexb, bool long_startcode, SliceStats *stats, int threads, const x264gpu_level_index *index)
 {
     // x264_slice_write: "set the QP equal to the first QP in the slice for more accurate CABAC initialization" — the slice header carries the first
     // macroblock's quantiser (under AQ / macroblock-tree it differs from the picture's); the device started the slice's quantiser chain and its
     // context variables from the same value, and a first macroblock that codes nothing inherits exactly it
     SliceParams p = p_in;
     p.qp = mbs[(size_t)p.first_row * p.mbw].qp;
-    if (p.cabac) { write_slice_cabac(out, p, mbs, levels, annexb, long_startcode, stats); return; }      // one arithmetic code word per slice: no row bands
+    if (p.cabac) { write_slice_cabac(out, p, mbs, levels, annexb, long_startcode, stats, index); return; }      // one arithmetic code word per slice: no row bands
     BitWriter bw;
     write_slice_header(bw, p);
     const size_t n = (size_t)p.mbw * p.mbh;
@@ -457,12 +459,13 @@ void write_slice(std::vector<uint8_t> &out, const SliceParams &p_in, const x264g
     std::vector<SliceCtx> ctx;
     ctx.reserve((size_t)T);
     for (int t = 0; t < T; t++) {
-        ctx.push_back(SliceCtx{ p, mbs, levels, bws[(size_t)t], tc.data(), r0 + (int)((long)rows * t / T), r0 + (int)((long)rows * (t + 1) / T) });
+        ctx.push_back(SliceCtx{ p, mbs, levels, index, bws[(size_t)t], tc.data(), r0 + (int)((long)rows * t / T), r0 + (int)((long)rows * (t + 1) / T) });
         bws[(size_t)t].reserve(n * 48 / (size_t)T + 64);
     }
     auto fill = [&](int t) {
+        int16_t scratch[X264GPU_MB_LEVELS];
         for (size_t i = (size_t)ctx[(size_t)t].row0 * p.mbw; i < (size_t)ctx[(size_t)t].row1 * p.mbw; i++)
-            SliceCtx::fill_tc(mbs[i], levels + i * X264GPU_MB_LEVELS, tc.data() + i * 24);
+            SliceCtx::fill_tc(mbs[i], mb_levels(levels, index, i, scratch), tc.data() + i * 24);
     };
     std::vector<std::thread> pool;
     for (int t = 1; t < T; t++) pool.emplace_back(fill, t);          // pass 1: total_coeff of every block of the picture
@@ -492,17 +495,17 @@ int slice_first_row(int mbh, int i, int n) { return (mbh * i + n / 2) / n; }
 // up to `threads` threads.  With more than one slice the loop filter stops at slice boundaries (disable_deblocking_filter_idc 2), as under
 // x264's slice threads — unless p.slices_plain says they are --slices N slices, which x264 filters across (idc 0).
 void write_picture(std::vector<uint8_t> &out, std::vector<size_t> *offs, const SliceParams &p, int slices, const x264gpu_mb *mbs, const int16_t *levels,
-                   bool annexb, bool long_startcode_first, SliceStats *stats, int threads)
+                   bool annexb, bool long_startcode_first, SliceStats *stats, int threads, const x264gpu_level_index *index)
 {
     const int n = slices > 1 ? slices : 1;
-    if (n == 1) { if (offs) offs->push_back(out.size()); write_slice(out, p, mbs, levels, annexb, long_startcode_first, stats, threads); return; }
+    if (n == 1) { if (offs) offs->push_back(out.size()); write_slice(out, p, mbs, levels, annexb, long_startcode_first, stats, threads, index); return; }
     std::vector<std::vector<uint8_t>> parts((size_t)n);
     std::vector<SliceStats> st((size_t)n, SliceStats{ 0 });
     auto one = [&](int i) {
         SliceParams sp = p;
         sp.first_row = slice_first_row(p.mbh, i, n); sp.end_row = slice_first_row(p.mbh, i + 1, n);
         if (sp.disable_deblock_idc == 0 && !sp.slices_plain) sp.disable_deblock_idc = 2;
-        write_slice(parts[(size_t)i], sp, mbs, levels, annexb, long_startcode_first && i == 0, &st[(size_t)i], 1);
+        write_slice(parts[(size_t)i], sp, mbs, levels, annexb, long_startcode_first && i == 0, &st[(size_t)i], 1, index);
     };
     int T = threads < 1 ? 1 : threads > n ? n : threads;
     std::vector<std::thread> pool;

@@ -110,6 +110,7 @@ _SIGS = {
     "x264gpu_encode_frames": (_i, [_vp, _vp, _i, _vp, _vp, _vp]),
     "x264gpu_encoder_get_recon": (_i, [_vp, _i, _vp, _vp]),
     "x264gpu_encode_pictures": (_i, [_vp, _vp, _vp, _vp, _vp, _vp]),
+    "x264gpu_pack_levels": (_i, [_vp, _i, _i, _vp, _vp, _vp]),
     "x264gpu_encoder_get_recon_slot": (_i, [_vp, _i, _i, _vp, _vp]),
     "x264gpu_encoder_stage_count": (_i, []),
     "x264gpu_encoder_stage_name": (C.c_char_p, [_i]),
