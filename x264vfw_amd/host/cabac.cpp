@@ -37,7 +37,6 @@ struct Cabac {
     long ff_run = 0;                   // bytes of 0xff held back
     long head_bits = 0;                // bits of the slice header in front (pos() counts from the start of the RBSP, as the bit writer did)
     uint8_t st[460];                   // (pStateIdx << 1) | valMPS per context
-    long bins = 0;
 
     long pos() const { return head_bits + 8 * ((long)buf.size() + ff_run) + queue + 8; }          // x264_cabac_pos: bits out, the pending ones included
     void init(bool islice, int qp)
@@ -52,7 +51,7 @@ struct Cabac {
         for (int i = 0; i < 276; i++) set(i, cabac_init_0_275[i]);
         for (int i = 0; i < 37; i++) set(399 + i, cabac_init_399_435[i]);
     }
-    inline void put_byte()
+    __attribute__((always_inline)) inline void put_byte()
     {
         if (queue < 0) return;
         const uint32_t o = (uint32_t)(low >> (queue + 10));          // carry (bit 8) + the byte
@@ -64,14 +63,14 @@ struct Cabac {
         for (; ff_run > 0; ff_run--) buf.push_back((uint8_t)(0xff + carry));
         buf.push_back((uint8_t)o);
     }
-    inline void renorm()
+    __attribute__((always_inline)) inline void renorm()
     {
         if (range >= 256) return;
         const int shift = __builtin_clz(range) - 23;
         range <<= shift; low <<= shift; queue += shift;
         put_byte();
     }
-    inline void decision(int ctx, int bin)
+    __attribute__((always_inline)) inline void decision(int ctx, int bin)
     {
         const int v = st[ctx], s = v >> 1, rlps = cabac_range_lps[s][(range >> 6) & 3];
         range -= rlps;
@@ -80,15 +79,13 @@ struct Cabac {
             st[ctx] = (uint8_t)((cabac_trans_lps[s] << 1) | ((v & 1) ^ (s == 0)));
         } else st[ctx] = (uint8_t)(v + (s < 62 ? 2 : 0));
         renorm();
-        bins++;
     }
-    inline void bypass(int bin)
+    __attribute__((always_inline)) inline void bypass(int bin)
     {
         low <<= 1;
         if (bin) low += range;
         queue++;
         put_byte();
-        bins++;
     }
     void ue_bypass(int k, int v)       // Exp-Golomb of order k, bypass bins (9.3.2.3 suffix)
     {
@@ -108,7 +105,6 @@ struct Cabac {
             if (queue > -8) { const int pad = -queue; low <<= pad; queue += pad; put_byte(); }      // what is left, zeros behind it up to the byte boundary
             for (; ff_run > 0; ff_run--) buf.push_back(0xff);
         } else renorm();
-        bins++;
     }
 };
 
