@@ -29,6 +29,21 @@ inline int b_use(const x264gpu_mb &m, int k)
 // the bits already shifted out but not yet written (`queue` + 8 of them; the first bit of the code word, which 9.3.4.2 drops, and a carry sit above those).  A byte leaves
 // when eight are there; a byte of 0xff is held back (`ff_run`) until the byte behind it shows whether a carry still comes — the outstanding bits of PutBit, byte-wise.
 // Same code words as the bit-by-bit formulation of the round before (tools/entropy_bench.cpp: same checksums on the device's records), ~4 x its speed.
+// (pStateIdx << 1 | valMPS) after a bin: [state byte << 1 | the bin was the less probable symbol]
+struct NextState {
+    uint8_t t[256];
+    NextState()
+    {
+        for (int v = 0; v < 128; v++) {
+            const int s = v >> 1, m = v & 1;
+            t[v << 1] = (uint8_t)(((s < 62 ? s + 1 : 62) << 1) | m);
+            t[(v << 1) | 1] = (uint8_t)((cabac_trans_lps[s] << 1) | (m ^ (s == 0)));
+        }
+    }
+};
+static const NextState kNextState;
+static const uint8_t *const kNext = kNextState.t;
+
 struct Cabac {
     std::vector<uint8_t> buf;          // the slice data's bytes so far (behind the slice header)
     uint64_t low = 0;
@@ -72,20 +87,62 @@ struct Cabac {
     }
     __attribute__((always_inline)) inline void decision(int ctx, int bin)
     {
-        const int v = st[ctx], s = v >> 1, rlps = cabac_range_lps[s][(range >> 6) & 3];
-        range -= rlps;
-        if (__builtin_expect(bin != (v & 1), 0)) {
-            low += range; range = rlps;
-            st[ctx] = (uint8_t)((cabac_trans_lps[s] << 1) | ((v & 1) ^ (s == 0)));
-        } else st[ctx] = (uint8_t)(v + (s < 62 ? 2 : 0));
-        renorm();
+        // without a branch on the bin (it is the one branch of the coder a predictor cannot learn): both outcomes computed, one selected
+        const uint32_t v = st[ctx], rlps = cabac_range_lps[v >> 1][(range >> 6) & 3];
+        const uint32_t lps = (uint32_t)bin ^ (v & 1), mask = 0u - lps;          // 1 / all ones: the less probable symbol
+        const uint32_t rmps = range - rlps;
+        low += rmps & mask;
+        range = rmps + ((rlps - rmps) & mask);
+        st[ctx] = kNext[(v << 1) | lps];
+        const int shift = __builtin_clz(range) - 23;                            // 0 when range >= 256
+        range <<= shift; low <<= shift; queue += shift;
+        put_byte();
     }
     __attribute__((always_inline)) inline void bypass(int bin)
     {
-        low <<= 1;
-        if (bin) low += range;
+        low = (low << 1) + (range & (0u - (uint32_t)(bin != 0)));
         queue++;
         put_byte();
+    }
+    // The same coder on a copy of its registers (the residual walk keeps them in machine registers: through `this` every store to a context byte — a uint8_t, which may alias
+    // anything — makes the compiler reload low / range / queue): regs() at the start of a block, set_regs() at its end.
+    struct R { uint64_t low; uint32_t range; int queue; };
+    R regs() const { return R{ low, range, queue }; }
+    void set_regs(const R &r) { low = r.low; range = r.range; queue = r.queue; }
+    __attribute__((always_inline)) inline void byte_out(R &r)
+    {
+        const uint32_t o = (uint32_t)(r.low >> (r.queue + 10));
+        r.low &= (0x400ull << r.queue) - 1;
+        r.queue -= 8;
+        if ((o & 0xff) == 0xff) { ff_run++; return; }
+        const uint32_t carry = o >> 8;
+        if (!buf.empty()) buf.back() = (uint8_t)(buf.back() + carry);
+        for (; ff_run > 0; ff_run--) buf.push_back((uint8_t)(0xff + carry));
+        buf.push_back((uint8_t)o);
+    }
+    __attribute__((always_inline)) inline void decision(R &r, int ctx, int bin)
+    {
+        const uint32_t v = st[ctx], rlps = cabac_range_lps[v >> 1][(r.range >> 6) & 3];
+        const uint32_t lps = (uint32_t)bin ^ (v & 1), mask = 0u - lps;
+        const uint32_t rmps = r.range - rlps;
+        r.low += rmps & mask;
+        r.range = rmps + ((rlps - rmps) & mask);
+        st[ctx] = kNext[(v << 1) | lps];
+        const int shift = __builtin_clz(r.range) - 23;
+        r.range <<= shift; r.low <<= shift; r.queue += shift;
+        if (r.queue >= 0) byte_out(r);
+    }
+    __attribute__((always_inline)) inline void bypass(R &r, int bin)
+    {
+        r.low = (r.low << 1) + (r.range & (0u - (uint32_t)(bin != 0)));
+        r.queue++;
+        if (r.queue >= 0) byte_out(r);
+    }
+    void ue_bypass(R &r, int k, int v)
+    {
+        while (v >= (1 << k)) { bypass(r, 1); v -= 1 << k; k++; }
+        bypass(r, 0);
+        while (k--) bypass(r, (v >> k) & 1);
     }
     void ue_bypass(int k, int v)       // Exp-Golomb of order k, bypass bins (9.3.2.3 suffix)
     {
@@ -252,14 +309,15 @@ struct CabacSlice {
         while (last > 0 && !l[last]) last--;
         int16_t coefs[64];
         int nc = 0;
+        Cabac::R r = cb.regs();
         for (int i = 0;; i++) {
             const int so = cat == 5 ? cabac_sig8x8[i] : cat == 3 ? (i < 2 ? i : 2) : i, lo = cat == 5 ? cabac_last8x8[i] : cat == 3 ? (i < 2 ? i : 2) : i;
             if (l[i]) {
                 coefs[nc++] = l[i];
-                cb.decision(sig_off[cat] + so, 1);
-                if (i == last) { cb.decision(last_off[cat] + lo, 1); break; }
-                cb.decision(last_off[cat] + lo, 0);
-            } else cb.decision(sig_off[cat] + so, 0);
+                cb.decision(r, sig_off[cat] + so, 1);
+                if (i == last) { cb.decision(r, last_off[cat] + lo, 1); break; }
+                cb.decision(r, last_off[cat] + lo, 0);
+            } else cb.decision(r, sig_off[cat] + so, 0);
             if (i + 1 == n1) { coefs[nc++] = l[n1]; break; }      // the last position needs no flags
         }
         // levels in reverse scan order; node = (coefficients equal to 1 seen, greater than 1 seen) folded into x264's node contexts
@@ -270,16 +328,17 @@ struct CabacSlice {
             const int v = coefs[k], a = v < 0 ? -v : v;
             const int ctx = abs_off[cat] + lvl1_ctx[node];
             if (a > 1) {
-                cb.decision(ctx, 1);
+                cb.decision(r, ctx, 1);
                 int g = gt1_ctx[node];
                 if (cat == 3 && g > 8) g = 8;               // chroma DC has one context less
                 const int c2 = abs_off[cat] + g;
-                for (int i = (a < 15 ? a : 15) - 2; i > 0; i--) cb.decision(c2, 1);
-                if (a < 15) cb.decision(c2, 0); else cb.ue_bypass(0, a - 15);
+                for (int i = (a < 15 ? a : 15) - 2; i > 0; i--) cb.decision(r, c2, 1);
+                if (a < 15) cb.decision(r, c2, 0); else cb.ue_bypass(r, 0, a - 15);
                 node = trans[1][node];
-            } else { cb.decision(ctx, 0); node = trans[0][node]; }
-            cb.bypass(v < 0);
+            } else { cb.decision(r, ctx, 0); node = trans[0][node]; }
+            cb.bypass(r, v < 0);
         }
+        cb.set_regs(r);
     }
     void block_cbf(const int16_t *l, int n, int cat, int inc)
     {
