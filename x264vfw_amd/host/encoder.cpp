@@ -372,8 +372,8 @@ static int batch_submit(BatchGroup *g, int s, const uint8_t *d_src, const x264gp
 static int batch_download(BatchGroup *g, int s, int buf, x264gpu_mb *h_mb, int16_t *h_lv, std::string &err, x264gpu_level_index *h_ix = nullptr)
 {
     const x264gpu_mb *dm = buf ? g->d_mb2 : g->d_mb; const int16_t *dl = buf ? g->d_lv2 : g->d_lv;
-    // (async groups: the members' downloads are dealt to the group's upload / download streams — thousands of threads that copy and wait on ONE stream wake each other)
-    void *st = g->overlap ? (g->up_streams.empty() || getenv("X264GPU_BATCH_ONE_DL") ? g->dl_stream : g->up_streams[(size_t)s % g->up_streams.size()]) : nullptr;
+    // (async groups: the members' downloads are dealt to the group's sixteen upload / download streams)
+    void *st = g->overlap ? (g->up_streams.empty() ? g->dl_stream : g->up_streams[(size_t)s % g->up_streams.size()]) : nullptr;
     const long t0 = g->timing ? us_now() : 0;
     if (g->async) {
         // ONE thread waits for the round's event, the other members sleep on the group's condition variable (2048 helper threads in hipEventSynchronize would
