@@ -607,6 +607,25 @@ def e2e_probe(args):
         else:
             fm, kbm = run_sessions(args.e2e_sessions, n1, src)
             run_sessions.detail["driver"] = "python threads (the C++ driver did not build or failed)"
+    # ... and the same leg on lighter content (the rectangles' per-pixel noise smoothed, a little sensor noise on top: ~58 kB a picture instead of ~171): how far the API path
+    # follows the device when the host — 16 CPUs on this pool's boxes, `host_cpu_quota` — has less to entropy-code
+    light = None
+    if args.e2e_sessions > 1 and fm is not None:
+        try:
+            from scipy.ndimage import uniform_filter
+            rng = np.random.default_rng(1)
+            lsrc = []
+            for fr in src[:16]:
+                fr = np.ascontiguousarray(fr).copy()
+                y = uniform_filter(fr[:w * h].reshape(h, w).astype(np.float32), 7) + rng.normal(0, 1.5, (h, w))
+                fr[:w * h] = np.clip(y + 0.5, 0, 255).astype(np.uint8).reshape(-1)
+                lsrc.append(fr)
+            nat = run_sessions_native(args.e2e_sessions, n1, lsrc)
+            if nat and "fps" in nat:
+                light = {"fps": nat["fps"], "kB_per_frame": nat["kB_per_frame"], "fps_coding_span": nat["fps_coding_span"], "setup_s": nat["setup_s"], "coding_s": nat["coding_s"], "teardown_s": nat["teardown_s"]}
+        except Exception:
+            light = None
+    one["multi_session_light_content"] = light
     if args.e2e_legs != "all":
         return {"what": "x264_encoder_encode end to end, 1920x1080 (only the threads-1 and multi-session legs were asked for)", **one,
                 "multi_session_fps": fm, "multi_session_sessions": args.e2e_sessions, "multi_session_frames_each": n1, "multi_session_kB_per_frame": kbm, "multi_session_spans": getattr(run_sessions, "detail", None), "host_cores": os.cpu_count(), "host_cpu_quota": cpu_quota()}
