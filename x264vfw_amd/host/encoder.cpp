@@ -239,6 +239,8 @@ static std::vector<BatchGroup *> g_batch_groups;
 
 static void batch_destroy(BatchGroup *g)
 {
+    const long t_destroy0 = g->timing ? us_now() : 0;
+    struct Tm { BatchGroup *g; long t0; bool on; ~Tm() { if (on) fprintf(stderr, "x264gpu batch: the group's device memory and streams took %.2f s to release\n", (us_now() - t0) / 1e6); } } tm{ g, t_destroy0, g->timing };
     if (g->timing)
         fprintf(stderr, "x264gpu batch timing, seconds summed over %d members: event wait %.1f, download %.1f, wait for the next launch %.1f, slices %.1f, submit wait %.1f, join of the helper %.1f\n", g->N,
                 g->t_us[0] / 1e6, g->t_us[1] / 1e6, g->t_us[2] / 1e6, g->t_us[3] / 1e6, g->t_us[4] / 1e6, g->t_us[5] / 1e6);
